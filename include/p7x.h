@@ -1,0 +1,207 @@
+/* p7x.h -- C ABI of libp7x, the MI355X-native replacement for the libhmmer calls that
+ * pyhmmer's plan7.Pipeline makes on its hot path.
+ *
+ * Every entry point cites the reference interface it replaces (paths relative to the
+ * pyhmmer tree, v0.12.3).  Plain pointers and sizes only: no torch types, no C++ types.
+ * All functions return an Easel-style status (include/libeasel/__init__.pxd:29-58):
+ *   P7X_OK 0, P7X_EINVAL 11 (-> MissingCutoffs, plan7.pyx:6424-6425), P7X_ERANGE 16
+ *   (-> OverflowError, plan7.pyx:6445-6446), anything else -> UnexpectedError (plan7.pyx:6447-6448).
+ * P7X_ENODEVICE is returned -- never a CPU fallback -- when a device entry point is called
+ * and no HIP device is usable.
+ *
+ * Ownership: inputs are borrowed for the duration of the call (as plan7.pyx:5116-5119);
+ * handles returned by *_create() are owned by the caller and released with *_destroy().
+ * Thread-safety: one p7x_pipeline per host thread (as hmmer/_base.py:324-325); profiles and
+ * sequence databases are immutable after creation and may be shared between pipelines
+ * (the per-target length model is computed inside the kernels instead of mutating the
+ * profile as p7_oprofile_ReconfigLength does, plan7.pyx:6438).
+ */
+#ifndef P7X_H
+#define P7X_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define P7X_ABI_VERSION 1
+
+enum {
+  P7X_OK = 0, P7X_EMEM = 5, P7X_EINVAL = 11, P7X_ERANGE = 16, P7X_ENORESULT = 19,
+  P7X_ENODEVICE = 100, P7X_EDEVICE = 101
+};
+
+enum { P7X_RNA = 1, P7X_DNA = 2, P7X_AMINO = 3 };                 /* libeasel/alphabet.pxd */
+enum { P7X_SEARCH_SEQS = 0, P7X_SCAN_MODELS = 1 };                /* p7_pipeline.pxd:26-28 */
+enum { P7X_ZSETBY_NTARGETS = 0, P7X_ZSETBY_OPTION = 1, P7X_ZSETBY_FILEINFO = 2 }; /* p7_pipeline.pxd:30-33 */
+enum { P7X_MMU = 0, P7X_MLAMBDA, P7X_VMU, P7X_VLAMBDA, P7X_FTAU, P7X_FLAMBDA };  /* libhmmer/__init__.pxd:30-37 */
+enum { P7X_GA1 = 0, P7X_GA2, P7X_TC1, P7X_TC2, P7X_NC1, P7X_NC2 };               /* libhmmer/__init__.pxd:39-46 */
+#define P7X_CUTOFF_UNSET (-99999.0f)
+#define P7X_EVPARAM_UNSET (-99999.0f)
+enum { P7X_IS_INCLUDED = 1, P7X_IS_REPORTED = 2, P7X_IS_NEW = 4, P7X_IS_DROPPED = 8, P7X_IS_DUPLICATE = 16 }; /* p7_tophits.pxd:13-18 */
+enum { P7X_BITCUT_NONE = 0, P7X_BITCUT_GA = 1, P7X_BITCUT_NC = 2, P7X_BITCUT_TC = 3 }; /* p7_pipeline.pxd p7_pipemodes */
+
+/* ------------------------------------------------------------------ host utilities */
+
+int p7x_abi_version(void);
+
+/* expf(-v) exactly as upstream read_asc30hmm parses an HMMER3/f ASCII save file
+ * ('*' is passed as +inf and yields 0).  Replaces the C parser behind HMMFile (plan7.pyx:3656-4050). */
+void p7x_expf_neg(const double *in, float *out, size_t n);
+
+/* ------------------------------------------------------------------ profiles
+ * p7x_hmm_view mirrors the P7_HMM fields the path needs (include/libhmmer/p7_hmm.pxd:48-78). */
+typedef struct p7x_hmm_view {
+  int32_t M;
+  int32_t abc_type;            /* P7X_AMINO | P7X_DNA | P7X_RNA */
+  const float *t;              /* [(M+1)*7] MM,MI,MD,IM,II,DM,DD probabilities */
+  const float *mat;            /* [(M+1)*K] */
+  const float *ins;            /* [(M+1)*K] */
+  const float *compo;          /* [K] or NULL (model had no COMPO line) */
+  float evparam[6];
+  float cutoff[6];
+  int32_t max_length;
+  const char *name;            /* required */
+  const char *acc;             /* or NULL */
+  const char *desc;            /* or NULL */
+  const char *consensus;       /* [M+2] as P7_HMM.consensus, or NULL */
+  const char *rf, *mm, *cs;    /* optional annotation lines [M+2], or NULL */
+} p7x_hmm_view;
+
+typedef struct p7x_oprofile p7x_oprofile;   /* opaque: replaces P7_PROFILE + P7_OPROFILE */
+
+/* p7_ProfileConfig (modelconfig.pxd:7-10; plan7.pyx:8082) followed by p7_oprofile_Convert
+ * (impl_sse/p7_oprofile.pxd:121; plan7.pyx:4961), local multihit mode, length model L.
+ * bg_f is P7_BG.f (p7_bg.pxd:10-30); K floats. */
+int  p7x_oprofile_create(const p7x_hmm_view *hmm, const float *bg_f, int32_t L, p7x_oprofile **out);
+void p7x_oprofile_destroy(p7x_oprofile *om);
+
+typedef struct p7x_oprofile_info {          /* scalars of P7_OPROFILE (impl_sse/p7_oprofile.pxd:52-108) */
+  int32_t M, K, Kp, abc_type, L, max_length, mode;
+  int32_t Q16, Q8, Q4;                       /* p7O_NQB/NQW/NQF (p7_oprofile.pxd:24-26) */
+  uint8_t tbm_b, tec_b, tjb_b, base_b, bias_b;
+  float   scale_b;
+  int16_t xw[4][2];                          /* [E,N,J,C][MOVE,LOOP] */
+  float   scale_w; int16_t base_w, ddbound_w; float ncj_roundoff;
+  float   xf[4][2];
+  float   evparam[6], cutoff[6], compo[20];
+  float   nj;
+} p7x_oprofile_info;
+int p7x_oprofile_get_info(const p7x_oprofile *om, p7x_oprofile_info *info);
+
+/* Striped (Farrar) views exactly as impl_sse stores them, for the OptimizedProfile properties
+ * rbv/sbv/rwv/twv/rfv/tfv (plan7.pyx:4623-4813) and for checking against pressed .h3f/.h3p files.
+ * which: 0 rbv u8 [Kp][Q16*16]; 1 sbv i8 [Kp][(Q16+17)*16]; 2 rwv i16 [Kp][Q8*8]; 3 twv i16 [8*Q8*8];
+ *        4 rfv f32 [Kp][Q4*4]; 5 tfv f32 [8*Q4*4].  Returns bytes written, or -1. */
+int64_t p7x_oprofile_striped(const p7x_oprofile *om, int which, void *out, size_t out_bytes);
+
+/* ------------------------------------------------------------------ devices */
+int p7x_device_count(void);                       /* 0 when no HIP device is usable */
+int p7x_device_name(int device, char *buf, size_t n);
+
+/* ------------------------------------------------------------------ sequence database (device resident)
+ * Replaces the `const ESL_SQ**` array of a DigitalSequenceBlock handed to _search_loop
+ * (plan7.pyx:6393-6398; easel.pyx:8168-8192).  dsq holds the residues of target t at
+ * dsq[offsets[t] .. offsets[t]+lengths[t]-1], digital codes 0..Kp-1.  Packed once, searched
+ * by any number of profiles. */
+typedef struct p7x_seqdb p7x_seqdb;
+int  p7x_seqdb_create(int device, int32_t abc_type, const uint8_t *dsq, const int64_t *offsets,
+                      const int32_t *lengths, size_t n, p7x_seqdb **out);
+void p7x_seqdb_destroy(p7x_seqdb *db);
+int64_t p7x_seqdb_ntargets(const p7x_seqdb *db);
+int64_t p7x_seqdb_nresidues(const p7x_seqdb *db);
+
+/* ------------------------------------------------------------------ single-stage entry points (unit-test seam)
+ * Mirror OptimizedProfile.msv_filter / ssv_filter (plan7.pyx:4969-5070): one digital sequence,
+ * score in nats; P7X_ERANGE + *sc=+inf on overflow.  dsq[0..L-1] are the residues (no sentinels). */
+int p7x_msv_filter(const p7x_oprofile *om, int device, const uint8_t *dsq, int32_t L, float *sc);
+int p7x_vit_filter(const p7x_oprofile *om, int device, const uint8_t *dsq, int32_t L, float *sc);
+int p7x_fwd_parser(const p7x_oprofile *om, int device, const uint8_t *dsq, int32_t L, float *sc);
+int p7x_bck_parser(const p7x_oprofile *om, int device, const uint8_t *dsq, int32_t L, float *sc);
+
+/* Batched raw filter outputs over a whole database (parity tests and bench).
+ * xJ[t]  : integer MSV end state (p7_MSVFilter's xJ), -1 on overflow.
+ * xC[t]  : integer Viterbi end state (p7_ViterbiFilter's xC), 32767 on overflow.
+ * fwd[t] : Forward score in nats (p7_ForwardParser). Any output pointer may be NULL. */
+int p7x_filters_batch(const p7x_oprofile *om, const p7x_seqdb *db, int32_t *xJ, int32_t *xC,
+                      float *fwd, float *bias_filtersc);
+
+/* ------------------------------------------------------------------ the pipeline
+ * p7x_pipeline_cfg mirrors the P7_PIPELINE fields reachable through the Python property
+ * setters (p7_pipeline.pxd:58-107; plan7.pyx:5635-5950). */
+typedef struct p7x_pipeline_cfg {
+  int32_t by_E; double E, T; int32_t dom_by_E; double domE, domT; int32_t use_bit_cutoffs;
+  int32_t inc_by_E; double incE, incT; int32_t incdom_by_E; double incdomE, incdomT;
+  double  Z, domZ; int32_t Z_setby, domZ_setby;
+  double  F1, F2, F3;
+  int32_t do_max, do_biasfilter, do_null2;
+  uint32_t seed;             /* do_reseeding = (seed != 0), plan7.pyx:5684-5688 */
+  int32_t mode;              /* P7X_SEARCH_SEQS | P7X_SCAN_MODELS */
+  int32_t host_threads;      /* workers for host-side domain definition; 0 = hardware_concurrency */
+} p7x_pipeline_cfg;
+void p7x_pipeline_cfg_default(p7x_pipeline_cfg *cfg);   /* p7_pipeline_Create(NULL,...) defaults, plan7.pyx:5413-5421 */
+
+typedef struct p7x_counters {   /* accounting, p7_pipeline.pxd:88-101 */
+  uint64_t nmodels, nseqs, nres, nnodes;
+  uint64_t n_past_msv, n_past_bias, n_past_vit, n_past_fwd;
+  uint64_t n_output, pos_past_msv, pos_past_bias, pos_past_vit, pos_past_fwd, pos_output;
+} p7x_counters;
+
+typedef struct p7x_domain {     /* P7_DOMAIN, p7_domain.pxd:10-26 */
+  int64_t ienv, jenv, iali, jali, iorf, jorf;
+  float envsc, domcorrection, dombias, oasc, bitscore;
+  double lnP;
+  int32_t is_reported, is_included;
+  /* alignment display, P7_ALIDISPLAY p7_alidisplay.pxd:26-53 (strings owned by the tophits handle) */
+  int32_t N, hmmfrom, hmmto, M;
+  int64_t sqfrom, sqto, L;
+  const char *model, *mline, *aseq, *ppline, *rfline, *mmline, *csline;
+  const char *hmmname, *hmmacc, *hmmdesc, *sqname, *sqacc, *sqdesc;
+} p7x_domain;
+
+typedef struct p7x_hit {        /* P7_HIT, p7_hit.pxd:27-58 */
+  const char *name, *acc, *desc;
+  int64_t seqidx;               /* index of the target in the searched block */
+  int32_t window_length;
+  double sortkey;
+  float score, pre_score, sum_score;
+  double lnP, pre_lnP, sum_lnP;
+  float nexpected;
+  int32_t nregions, nclustered, noverlaps, nenvelopes, ndom;
+  uint32_t flags;
+  int32_t nreported, nincluded, best_domain;
+} p7x_hit;
+
+typedef struct p7x_tophits p7x_tophits;   /* opaque: replaces P7_TOPHITS + the copied P7_PIPELINE (plan7.pyx:8813-8817) */
+
+/* Pipeline._search_loop (plan7.pyx:6393-6453): p7_pli_NewModel once, then for every target
+ * p7_pli_NewSeq / p7_bg_SetLength / p7_oprofile_ReconfigLength / p7_Pipeline / p7_pipeline_Reuse;
+ * followed by p7_tophits_SortBySortkey + p7_tophits_Threshold (plan7.pyx:6255-6256).
+ * targets' names/accessions/descriptions are NUL-separated string tables indexed by target
+ * (may be NULL: hits then carry only seqidx). */
+int p7x_search_block(const p7x_pipeline_cfg *cfg, const p7x_oprofile *om, const float *bg_f,
+                     const p7x_seqdb *db, const char *const *names, const char *const *accs,
+                     const char *const *descs, p7x_tophits **out);
+
+void     p7x_tophits_destroy(p7x_tophits *th);
+int64_t  p7x_tophits_nhits(const p7x_tophits *th);
+int      p7x_tophits_get_counters(const p7x_tophits *th, p7x_counters *c);
+int      p7x_tophits_get_cfg(const p7x_tophits *th, p7x_pipeline_cfg *cfg);   /* Z/domZ as finally set */
+int      p7x_tophits_get_hit(const p7x_tophits *th, int64_t i, p7x_hit *hit);
+int      p7x_tophits_get_domain(const p7x_tophits *th, int64_t i, int32_t d, p7x_domain *dom);
+/* p7_tophits_Merge + p7_pipeline_Merge + re-threshold (plan7.pyx:9172-9276): merges src into dst. */
+int      p7x_tophits_merge(p7x_tophits *dst, const p7x_tophits *src);
+int      p7x_tophits_sort_by_key(p7x_tophits *th);       /* p7_tophits_SortBySortkey, plan7.pyx:8820-8824 */
+int      p7x_tophits_threshold(p7x_tophits *th);         /* p7_tophits_Threshold, plan7.pyx:8804-8818 */
+/* per-stage device timings of the search that produced th, milliseconds (HIP events):
+ * [0] msv [1] bias [2] viterbi [3] forward [4] backward [5] host domain definition [6] total */
+int      p7x_tophits_get_timings(const p7x_tophits *th, double *ms, int n);
+
+const char *p7x_last_error(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* P7X_H */

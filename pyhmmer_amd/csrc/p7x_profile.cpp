@@ -1,0 +1,412 @@
+// p7x_profile.cpp -- host side of libp7x: alphabets, query preparation and small statistics.
+//
+// Replaces, for the search path only, what pyhmmer reaches through
+//   Profile.configure      -> p7_ProfileConfig      (reference plan7.pyx:8082, modelconfig.pxd:7-10)
+//   Profile.to_optimized   -> p7_oprofile_Convert   (reference plan7.pyx:4961, impl_sse/p7_oprofile.pxd:121)
+// The numbers produced are the reference's (they are checked bit-for-bit against the pressed
+// .h3f/.h3p fixtures in tests/), but the storage is un-striped: node k lives at index k.  Farrar
+// striping is an SSE artefact; the device kernels build their own layouts from these arrays, and
+// p7x_oprofile_striped() re-creates the impl_sse views on demand for API parity.
+#include "p7x_internal.hpp"
+#include <cmath>
+#include <cstring>
+#include <mutex>
+
+namespace p7x {
+
+static thread_local std::string g_err;
+void set_error(const std::string &msg) { g_err = msg; }
+
+// ---------------------------------------------------------------- alphabets (easel.pyx:313-347)
+static Alphabet make_alphabet(int type)
+{
+  Alphabet a{};
+  a.type = type;
+  std::memset(a.degen, 0, sizeof(a.degen));
+  if (type == P7X_AMINO) {
+    a.K = 20; a.Kp = 29; a.sym = "ACDEFGHIKLMNPQRSTVWY-BJZOUX*~";
+    struct { int x; const char *set; } d[] = { {21, "ND"}, {22, "IL"}, {23, "QE"}, {24, "K"}, {25, "C"} };
+    for (auto &e : d) for (const char *c = e.set; *c; ++c) a.degen[e.x][std::strchr(a.sym, *c) - a.sym] = 1;
+    for (int y = 0; y < 20; ++y) a.degen[26][y] = 1;
+  } else {
+    a.K = 4; a.Kp = 18; a.sym = (type == P7X_RNA) ? "ACGU-RYMKSWHBVDN*~" : "ACGT-RYMKSWHBVDN*~";
+    const char *ref = "ACGT";
+    struct { int x; const char *set; } d[] = { {5, "AG"}, {6, "CT"}, {7, "AC"}, {8, "GT"}, {9, "CG"}, {10, "AT"},
+                                               {11, "ACT"}, {12, "CGT"}, {13, "ACG"}, {14, "AGT"}, {15, "ACGT"} };
+    for (auto &e : d) for (const char *c = e.set; *c; ++c) a.degen[e.x][std::strchr(ref, *c) - ref] = 1;
+  }
+  for (int x = 0; x < a.K; ++x) a.degen[x][x] = 1;
+  return a;
+}
+
+const Alphabet &Alphabet::get(int type)
+{
+  static const Alphabet amino = make_alphabet(P7X_AMINO), dna = make_alphabet(P7X_DNA), rna = make_alphabet(P7X_RNA);
+  return type == P7X_AMINO ? amino : (type == P7X_RNA ? rna : dna);
+}
+
+// ---------------------------------------------------------------- Easel's vector expf, one lane
+// (esl_sse_expf; fb_conversion applies it to every emission/transition score.)
+float sse_expf(float x)
+{
+  static const float P0 = 1.9875691500E-4f, P1 = 1.3981999507E-3f, P2 = 8.3334519073E-3f,
+                     P3 = 4.1665795894E-2f, P4 = 1.6666665459E-1f, P5 = 5.0000001201E-1f;
+  static const float C1 = 0.693359375f, C2 = -2.12194440e-4f;
+  const bool over = x > 88.72283905206835f, under = x <= -103.27892990343185f;
+  if (std::isnan(x)) return x;
+  if (over)  return INFINITY;
+  if (under) return 0.0f;
+  volatile float fx = x * (float) kLog2R;   // volatile: one IEEE rounding per operation, no contraction
+  fx = fx + 0.5f;
+  volatile float fl = (float) (int) fx;
+  if (fl > fx) fl = fl - 1.0f;
+  const int k = (int) fl;
+  volatile float r = x;
+  volatile float t1 = fl * C1, t2 = fl * C2;
+  r = r - t1;
+  r = r - t2;
+  volatile float z = r * r;
+  volatile float y = P0;
+  y = y * r; y = y + P1;
+  y = y * r; y = y + P2;
+  y = y * r; y = y + P3;
+  y = y * r; y = y + P4;
+  y = y * r; y = y + P5;
+  y = y * z;
+  y = y + r;
+  y = y + 1.0f;
+  union { int32_t i; float f; } two_k;
+  two_k.i = (int32_t) ((uint32_t) (k + 127) << 23);
+  y = y * two_k.f;
+  return y;
+}
+
+uint8_t unbiased_byteify(float scale_b, float sc)
+{
+  sc = -1.0f * roundf(scale_b * sc);
+  return (sc > 255.) ? 255 : (uint8_t) (int) sc;
+}
+static uint8_t biased_byteify(float scale_b, int bias_b, float sc)
+{
+  sc = -1.0f * roundf(scale_b * sc);
+  return (sc > 255 - bias_b) ? 255 : (uint8_t) ((int) sc + bias_b);
+}
+int16_t wordify(float scale_w, float sc)
+{
+  sc = roundf(scale_w * sc);
+  if (sc >= 32767.0) return 32767;
+  if (sc <= -32768.0) return -32768;
+  return (int16_t) sc;
+}
+
+// ---------------------------------------------------------------- statistics (Easel gumbel / exponential)
+double gumbel_surv(double x, double mu, double lambda)
+{
+  const double y = lambda * (x - mu), ey = -std::exp(-y);
+  return (std::fabs(ey) < 5e-9) ? -ey : 1 - std::exp(ey);
+}
+double exp_surv(double x, double mu, double lambda)    { return x < mu ? 1.0 : std::exp(-lambda * (x - mu)); }
+double exp_logsurv(double x, double mu, double lambda) { return x < mu ? 0.0 : -lambda * (x - mu); }
+
+float null1_score(int L)
+{ // p7_bg_SetLength + p7_bg_NullOne (p7_bg.pxd:10-30; plan7.pyx:6435)
+  const float p1 = (float) L / (float) (L + 1);
+  return (float) L * std::log(p1) + std::log(1. - p1);
+}
+
+static float g_flogsum[16000];
+static std::once_flag g_flogsum_once;
+void flogsum_init()
+{
+  std::call_once(g_flogsum_once, [] {
+    for (int i = 0; i < 16000; ++i) g_flogsum[i] = std::log(1. + std::exp((double) -i / 1000.0));
+  });
+}
+float flogsum(float a, float b)
+{ // upstream logsum.c p7_FLogsum: table lookup, 1/1000 nat resolution
+  const float mx = a > b ? a : b, mn = a > b ? b : a;
+  return (mn == -INFINITY || (mx - mn) >= 15.7f) ? mx : mx + g_flogsum[(int) ((mx - mn) * 1000.0f)];
+}
+
+// ---------------------------------------------------------------- query preparation
+static void configure_generic(Profile &p, const p7x_hmm_view &h)
+{
+  const Alphabet &abc = Alphabet::get(p.abc_type);
+  const int M = p.M, K = p.K, Kp = p.Kp;
+  const float *t = h.t;
+  p.tsc.assign((size_t) (M + 1) * 8, -INFINITY);
+  p.msc.assign((size_t) Kp * (M + 1), -INFINITY);
+  // local entry: occ[k] / sum_j occ[j] (M-j+1)   (p7_hmm_CalculateOccupancy + p7_ProfileConfig)
+  std::vector<float> occ(M + 1);
+  occ[0] = 0.f;
+  occ[1] = t[0 * 7 + 1] + t[0 * 7 + 0];
+  for (int k = 2; k <= M; ++k)
+    occ[k] = occ[k - 1] * (t[(k - 1) * 7 + 0] + t[(k - 1) * 7 + 1]) + (1.0 - occ[k - 1]) * t[(k - 1) * 7 + 5];
+  float Z = 0.f;
+  for (int k = 1; k <= M; ++k) Z += occ[k] * (float) (M - k + 1);
+  for (int k = 1; k <= M; ++k) p.tsc[(size_t) (k - 1) * 8 + gBM] = std::log(occ[k] / Z);
+  // multihit: E->J = E->C = 1/2
+  p.xsc[XE][MOVE] = -kLog2;
+  p.xsc[XE][LOOP] = -kLog2;
+  p.nj = 1.0f;
+  for (int k = 1; k < M; ++k) {
+    float *g = &p.tsc[(size_t) k * 8];
+    const float *tk = t + (size_t) k * 7;   // MM,MI,MD,IM,II,DM,DD
+    g[gMM] = std::log(tk[0]); g[gMI] = std::log(tk[1]); g[gMD] = std::log(tk[2]);
+    g[gIM] = std::log(tk[3]); g[gII] = std::log(tk[4]);
+    g[gDM] = std::log(tk[5]); g[gDD] = std::log(tk[6]);
+  }
+  for (int k = 1; k <= M; ++k) {
+    float sc[MAXKP];
+    for (int x = 0; x < K; ++x) sc[x] = std::log((double) h.mat[(size_t) k * K + x] / p.bgf[x]);
+    sc[K] = sc[Kp - 2] = sc[Kp - 1] = -INFINITY;
+    for (int x = K + 1; x <= Kp - 3; ++x) {   // esl_abc_FExpectScVec
+      float num = 0.f, den = 0.f;
+      for (int y = 0; y < K; ++y) if (abc.degen[x][y]) { num += sc[y] * p.bgf[y]; den += p.bgf[y]; }
+      sc[x] = num / den;
+    }
+    for (int x = 0; x < Kp; ++x) p.msc[(size_t) x * (M + 1) + k] = sc[x];
+  }
+  // length model (p7_ReconfigLength)
+  const float pmove = (2.0f + p.nj) / ((float) p.L + 2.0f + p.nj), ploop = 1.0f - pmove;
+  p.xsc[XN][LOOP] = p.xsc[XC][LOOP] = p.xsc[XJ][LOOP] = std::log(ploop);
+  p.xsc[XN][MOVE] = p.xsc[XC][MOVE] = p.xsc[XJ][MOVE] = std::log(pmove);
+}
+
+static void convert_msv(Profile &p)
+{
+  const int M = p.M;
+  float mx = 0.0f;   // rsc also holds the insert scores (0), so the maximum is never negative
+  for (int x = 0; x < p.K; ++x)
+    for (int k = 1; k <= M; ++k) mx = std::fmax(mx, p.msc[(size_t) x * (M + 1) + k]);
+  p.scale_b = 3.0 / kLog2;
+  p.base_b = 190;
+  p.bias_b = unbiased_byteify(p.scale_b, -1.0 * mx);
+  p.rb.assign((size_t) p.Kp * (M + 1), 255);
+  for (int x = 0; x < p.Kp; ++x)
+    for (int k = 1; k <= M; ++k)
+      p.rb[(size_t) x * (M + 1) + k] = biased_byteify(p.scale_b, p.bias_b, p.msc[(size_t) x * (M + 1) + k]);
+  p.tbm_b = unbiased_byteify(p.scale_b, logf(2.0f / ((float) M * (float) (M + 1))));
+  p.tec_b = unbiased_byteify(p.scale_b, logf(0.5f));
+  p.tjb_b = unbiased_byteify(p.scale_b, logf(3.0f / (float) (p.L + 3)));
+}
+
+static void convert_viterbi(Profile &p)
+{
+  const int M = p.M;
+  p.scale_w = 500.0 / kLog2;
+  p.base_w = 12000;
+  p.rw.assign((size_t) p.Kp * (M + 1), -32768);
+  for (int x = 0; x < p.Kp; ++x)
+    for (int k = 1; k <= M; ++k) p.rw[(size_t) x * (M + 1) + k] = wordify(p.scale_w, p.msc[(size_t) x * (M + 1) + k]);
+  p.tw.assign((size_t) NTRANS * (M + 1), -32768);
+  auto W = [&](int t, int k) -> int16_t & { return p.tw[(size_t) t * (M + 1) + k]; };
+  auto cap = [](int16_t v, int16_t maxval) { return v <= maxval ? v : maxval; };
+  for (int k = 1; k <= M; ++k) {
+    // entering node k: generic node k-1 (tsc[0] carries only B->M1)
+    W(tBM, k) = cap(wordify(p.scale_w, p.tsc[(size_t) (k - 1) * 8 + gBM]), 0);
+    W(tMM, k) = cap(wordify(p.scale_w, p.tsc[(size_t) (k - 1) * 8 + gMM]), 0);
+    W(tIM, k) = cap(wordify(p.scale_w, p.tsc[(size_t) (k - 1) * 8 + gIM]), 0);
+    W(tDM, k) = cap(wordify(p.scale_w, p.tsc[(size_t) (k - 1) * 8 + gDM]), 0);
+    if (k < M) {   // leaving node k
+      W(tMD, k) = cap(wordify(p.scale_w, p.tsc[(size_t) k * 8 + gMD]), 0);
+      W(tMI, k) = cap(wordify(p.scale_w, p.tsc[(size_t) k * 8 + gMI]), 0);
+      W(tII, k) = cap(wordify(p.scale_w, p.tsc[(size_t) k * 8 + gII]), -1);   // never a zero-cost I->I
+      W(tDD, k) = wordify(p.scale_w, p.tsc[(size_t) k * 8 + gDD]);
+    }
+  }
+  p.xw[XE][LOOP] = wordify(p.scale_w, p.xsc[XE][LOOP]);
+  p.xw[XE][MOVE] = wordify(p.scale_w, p.xsc[XE][MOVE]);
+  for (int s : {XN, XC, XJ}) { p.xw[s][MOVE] = wordify(p.scale_w, p.xsc[s][MOVE]); p.xw[s][LOOP] = 0; }
+  p.ncj_roundoff = 0.0f;
+  int bound = -32768;
+  for (int k = 2; k < M - 1; ++k) {
+    int dd = (int) wordify(p.scale_w, p.tsc[(size_t) k * 8 + gDD]);
+    dd += (int) wordify(p.scale_w, p.tsc[(size_t) (k + 1) * 8 + gDM]);
+    dd -= (int) wordify(p.scale_w, p.tsc[(size_t) (k + 1) * 8 + gBM]);
+    if (dd > bound) bound = dd;
+  }
+  p.ddbound_w = (int16_t) bound;
+}
+
+static void convert_forward(Profile &p)
+{
+  const int M = p.M;
+  p.rf_.assign((size_t) p.Kp * (M + 1), 0.0f);
+  for (int x = 0; x < p.Kp; ++x)
+    for (int k = 1; k <= M; ++k) p.rf_[(size_t) x * (M + 1) + k] = sse_expf(p.msc[(size_t) x * (M + 1) + k]);
+  p.tf.assign((size_t) NTRANS * (M + 1), 0.0f);
+  auto F = [&](int t, int k) -> float & { return p.tf[(size_t) t * (M + 1) + k]; };
+  for (int k = 1; k <= M; ++k) {
+    F(tBM, k) = sse_expf(p.tsc[(size_t) (k - 1) * 8 + gBM]);
+    F(tMM, k) = sse_expf(p.tsc[(size_t) (k - 1) * 8 + gMM]);
+    F(tIM, k) = sse_expf(p.tsc[(size_t) (k - 1) * 8 + gIM]);
+    F(tDM, k) = sse_expf(p.tsc[(size_t) (k - 1) * 8 + gDM]);
+    if (k < M) {
+      F(tMD, k) = sse_expf(p.tsc[(size_t) k * 8 + gMD]);
+      F(tMI, k) = sse_expf(p.tsc[(size_t) k * 8 + gMI]);
+      F(tII, k) = sse_expf(p.tsc[(size_t) k * 8 + gII]);
+      F(tDD, k) = sse_expf(p.tsc[(size_t) k * 8 + gDD]);
+    }
+  }
+  for (int s = 0; s < 4; ++s) for (int m = 0; m < 2; ++m) p.xf[s][m] = expf(p.xsc[s][m]);
+}
+
+} // namespace p7x
+
+using namespace p7x;
+
+extern "C" {
+
+int p7x_abi_version(void) { return P7X_ABI_VERSION; }
+
+const char *p7x_last_error(void) { return g_err.c_str(); }
+
+void p7x_expf_neg(const double *in, float *out, size_t n)
+{
+  for (size_t i = 0; i < n; ++i) out[i] = std::isinf(in[i]) ? 0.0f : expf((float) (-1.0 * in[i]));
+}
+
+int p7x_oprofile_create(const p7x_hmm_view *h, const float *bg_f, int32_t L, p7x_oprofile **out)
+{
+  if (!h || !bg_f || !out || h->M < 1 || !h->t || !h->mat || !h->name) { set_error("p7x_oprofile_create: bad arguments"); return P7X_EINVAL; }
+  if (h->abc_type != P7X_AMINO && h->abc_type != P7X_DNA && h->abc_type != P7X_RNA) { set_error("unknown alphabet"); return P7X_EINVAL; }
+  flogsum_init();
+  auto *om = new p7x_oprofile();
+  Profile &p = om->p;
+  const Alphabet &abc = Alphabet::get(h->abc_type);
+  p.M = h->M; p.K = abc.K; p.Kp = abc.Kp; p.abc_type = h->abc_type; p.L = L; p.max_length = h->max_length;
+  p.name = h->name;
+  if (h->acc)  { p.acc = h->acc;   p.has_acc = true; }
+  if (h->desc) { p.desc = h->desc; p.has_desc = true; }
+  if (h->consensus) p.consensus = h->consensus;
+  if (h->rf) p.rf = h->rf;
+  if (h->mm) p.mm = h->mm;
+  if (h->cs) p.cs = h->cs;
+  std::memcpy(p.evparam, h->evparam, sizeof(p.evparam));
+  std::memcpy(p.cutoff, h->cutoff, sizeof(p.cutoff));
+  std::memset(p.compo, 0, sizeof(p.compo));
+  if (h->compo) std::memcpy(p.compo, h->compo, sizeof(float) * p.K);
+  std::memset(p.bgf, 0, sizeof(p.bgf));
+  std::memcpy(p.bgf, bg_f, sizeof(float) * p.K);
+  configure_generic(p, *h);
+  convert_msv(p);
+  convert_viterbi(p);
+  convert_forward(p);
+  *out = om;
+  return P7X_OK;
+}
+
+int p7x_oprofile_get_info(const p7x_oprofile *om, p7x_oprofile_info *o)
+{
+  if (!om || !o) return P7X_EINVAL;
+  const Profile &p = om->p;
+  std::memset(o, 0, sizeof(*o));
+  o->M = p.M; o->K = p.K; o->Kp = p.Kp; o->abc_type = p.abc_type; o->L = p.L; o->max_length = p.max_length; o->mode = p.mode;
+  o->Q16 = p.Q16(); o->Q8 = p.Q8(); o->Q4 = p.Q4();
+  o->tbm_b = p.tbm_b; o->tec_b = p.tec_b; o->tjb_b = p.tjb_b; o->base_b = p.base_b; o->bias_b = p.bias_b; o->scale_b = p.scale_b;
+  std::memcpy(o->xw, p.xw, sizeof(p.xw));
+  o->scale_w = p.scale_w; o->base_w = p.base_w; o->ddbound_w = p.ddbound_w; o->ncj_roundoff = p.ncj_roundoff;
+  std::memcpy(o->xf, p.xf, sizeof(p.xf));
+  std::memcpy(o->evparam, p.evparam, sizeof(p.evparam));
+  std::memcpy(o->cutoff, p.cutoff, sizeof(p.cutoff));
+  std::memcpy(o->compo, p.compo, sizeof(p.compo));
+  o->nj = p.nj;
+  return P7X_OK;
+}
+
+// Farrar striping: lane z of vector q holds node k = q + 1 + z*Q.
+int64_t p7x_oprofile_striped(const p7x_oprofile *om, int which, void *out, size_t out_bytes)
+{
+  if (!om || !out) return -1;
+  const Profile &p = om->p;
+  const int M = p.M, Kp = p.Kp;
+  auto node = [](int q, int z, int Q) { return q + 1 + z * Q; };
+  switch (which) {
+  case 0: {  // rbv
+    const int Q = p.Q16(); const size_t need = (size_t) Kp * Q * 16;
+    if (out_bytes < need) return -1;
+    auto *o = (uint8_t *) out;
+    for (int x = 0; x < Kp; ++x) for (int q = 0; q < Q; ++q) for (int z = 0; z < 16; ++z) {
+      const int k = node(q, z, Q);
+      o[((size_t) x * Q + q) * 16 + z] = k <= M ? p.rb[(size_t) x * (M + 1) + k] : 255;
+    }
+    return (int64_t) need;
+  }
+  case 1: {  // sbv = signed (rbv - bias), saturating; 17 extra wrap-around vectors
+    const int Q = p.Q16(), QS = Q + 17; const size_t need = (size_t) Kp * QS * 16;
+    if (out_bytes < need) return -1;
+    auto *o = (int8_t *) out;
+    const uint8_t top = (uint8_t) (p.bias_b + 127);
+    for (int x = 0; x < Kp; ++x) for (int q = 0; q < QS; ++q) for (int z = 0; z < 16; ++z) {
+      const int k = node(q % Q, z, Q);
+      const uint8_t r = k <= M ? p.rb[(size_t) x * (M + 1) + k] : 255;
+      const uint8_t d = top > r ? (uint8_t) (top - r) : 0;
+      o[((size_t) x * QS + q) * 16 + z] = (int8_t) (d ^ 127);
+    }
+    return (int64_t) need;
+  }
+  case 2: {  // rwv
+    const int Q = p.Q8(); const size_t need = (size_t) Kp * Q * 8 * 2;
+    if (out_bytes < need) return -1;
+    auto *o = (int16_t *) out;
+    for (int x = 0; x < Kp; ++x) for (int q = 0; q < Q; ++q) for (int z = 0; z < 8; ++z) {
+      const int k = node(q, z, Q);
+      o[((size_t) x * Q + q) * 8 + z] = k <= M ? p.rw[(size_t) x * (M + 1) + k] : -32768;
+    }
+    return (int64_t) need;
+  }
+  case 3: {  // twv: per q the 7 vectors BM,MM,IM,DM,MD,MI,II; then all DD vectors
+    const int Q = p.Q8(); const size_t need = (size_t) 8 * Q * 8 * 2;
+    if (out_bytes < need) return -1;
+    auto *o = (int16_t *) out;
+    for (int q = 0; q < Q; ++q) for (int z = 0; z < 8; ++z) {
+      const int k = node(q, z, Q);
+      for (int t = tBM; t <= tII; ++t) {
+        int16_t v = k <= M ? p.tw[(size_t) t * (M + 1) + k] : -32768;
+        if (k > M) v = (t == tII) ? -32768 : -32768;
+        o[((size_t) q * 7 + t) * 8 + z] = v;
+      }
+      o[((size_t) 7 * Q + q) * 8 + z] = k <= M ? p.tw[(size_t) tDD * (M + 1) + k] : -32768;
+    }
+    return (int64_t) need;
+  }
+  case 4: {  // rfv
+    const int Q = p.Q4(); const size_t need = (size_t) Kp * Q * 4 * 4;
+    if (out_bytes < need) return -1;
+    auto *o = (float *) out;
+    for (int x = 0; x < Kp; ++x) for (int q = 0; q < Q; ++q) for (int z = 0; z < 4; ++z) {
+      const int k = node(q, z, Q);
+      o[((size_t) x * Q + q) * 4 + z] = k <= M ? p.rf_[(size_t) x * (M + 1) + k] : 0.0f;
+    }
+    return (int64_t) need;
+  }
+  case 5: {  // tfv
+    const int Q = p.Q4(); const size_t need = (size_t) 8 * Q * 4 * 4;
+    if (out_bytes < need) return -1;
+    auto *o = (float *) out;
+    for (int q = 0; q < Q; ++q) for (int z = 0; z < 4; ++z) {
+      const int k = node(q, z, Q);
+      for (int t = tBM; t <= tII; ++t) o[((size_t) q * 7 + t) * 4 + z] = k <= M ? p.tf[(size_t) t * (M + 1) + k] : 0.0f;
+      o[((size_t) 7 * Q + q) * 4 + z] = k <= M ? p.tf[(size_t) tDD * (M + 1) + k] : 0.0f;
+    }
+    return (int64_t) need;
+  }
+  default: return -1;
+  }
+}
+
+void p7x_oprofile_destroy(p7x_oprofile *om);   // defined in p7x_device.hip (releases the device cache)
+
+void p7x_pipeline_cfg_default(p7x_pipeline_cfg *c)
+{ // p7_pipeline_Create(NULL, ...) defaults; pyhmmer plan7.pyx:5413-5421
+  std::memset(c, 0, sizeof(*c));
+  c->by_E = 1; c->E = 10.0; c->T = 0.0; c->dom_by_E = 1; c->domE = 10.0; c->domT = 0.0; c->use_bit_cutoffs = 0;
+  c->inc_by_E = 1; c->incE = 0.01; c->incT = 0.0; c->incdom_by_E = 1; c->incdomE = 0.01; c->incdomT = 0.0;
+  c->Z = 0.0; c->domZ = 0.0; c->Z_setby = P7X_ZSETBY_NTARGETS; c->domZ_setby = P7X_ZSETBY_NTARGETS;
+  c->F1 = 0.02; c->F2 = 1e-3; c->F3 = 1e-5;
+  c->do_max = 0; c->do_biasfilter = 1; c->do_null2 = 1;
+  c->seed = 42; c->mode = P7X_SEARCH_SEQS; c->host_threads = 0;
+}
+
+} // extern "C"

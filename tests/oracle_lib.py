@@ -1,0 +1,159 @@
+"""ctypes binding of the CPU oracle (oracle/_build/libp7oracle.so).  TEST INFRASTRUCTURE ONLY:
+imported by tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg, never by pyhmmer_amd."""
+import ctypes as C
+import subprocess
+from pathlib import Path
+
+import numpy as np
+
+ROOT = Path(__file__).resolve().parent.parent
+ORACLE_DIR = ROOT / "oracle"
+LIB = ORACLE_DIR / "_build" / "libp7oracle.so"
+
+
+class Profile(C.Structure):
+    _fields_ = [
+        ("M", C.c_int), ("K", C.c_int), ("Kp", C.c_int), ("Q16", C.c_int), ("Q8", C.c_int), ("Q4", C.c_int),
+        ("L", C.c_int), ("nj", C.c_float),
+        ("tsc", C.POINTER(C.c_float)), ("msc", C.POINTER(C.c_float)), ("xsc", (C.c_float * 2) * 4),
+        ("rbv", C.POINTER(C.c_uint8)), ("sbv", C.POINTER(C.c_int8)),
+        ("tbm_b", C.c_uint8), ("tec_b", C.c_uint8), ("tjb_b", C.c_uint8), ("base_b", C.c_uint8), ("bias_b", C.c_uint8),
+        ("scale_b", C.c_float),
+        ("rwv", C.POINTER(C.c_int16)), ("twv", C.POINTER(C.c_int16)), ("xw", (C.c_int16 * 2) * 4),
+        ("scale_w", C.c_float), ("base_w", C.c_int16), ("ddbound_w", C.c_int16), ("ncj_roundoff", C.c_float),
+        ("rfv", C.POINTER(C.c_float)), ("tfv", C.POINTER(C.c_float)), ("xf", (C.c_float * 2) * 4),
+        ("evparam", C.c_float * 6), ("compo", C.c_float * 20), ("bgf", C.c_float * 20),
+    ]
+
+
+class Record(C.Structure):
+    _fields_ = [
+        ("usc", C.c_float), ("filtersc", C.c_float), ("nullsc", C.c_float), ("vfsc", C.c_float), ("fwdsc", C.c_float),
+        ("P_msv", C.c_double), ("P_bias", C.c_double), ("P_vit", C.c_double), ("P_fwd", C.c_double),
+        ("xJ_msv", C.c_int32), ("xC_vit", C.c_int32), ("stage", C.c_int32), ("ran_vit", C.c_int32),
+    ]
+
+
+class Counters(C.Structure):
+    _fields_ = [(n, C.c_uint64) for n in ("nseqs", "nres", "n_past_msv", "n_past_bias", "n_past_vit", "n_past_fwd")]
+
+
+_lib = None
+
+
+def build():
+    subprocess.run(["make", "-C", str(ORACLE_DIR)], check=True, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+    return LIB
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not LIB.exists():
+            build()
+        l = C.CDLL(str(LIB))
+        PP = C.POINTER(Profile)
+        l.p7o_profile_build.restype = PP
+        l.p7o_profile_build.argtypes = [C.c_int, C.c_int] + [C.c_void_p] * 5 + [C.c_int]
+        l.p7o_profile_free.argtypes = [PP]
+        l.p7o_reconfig_length.argtypes = [PP, C.c_int]
+        for fn in ("p7o_msv", "p7o_msv_scalar", "p7o_vit", "p7o_vit_scalar"):
+            getattr(l, fn).argtypes = [PP, C.c_void_p, C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_int)]
+        l.p7o_fwd.argtypes = [PP, C.c_void_p, C.c_int, C.c_void_p, C.POINTER(C.c_float)]
+        l.p7o_bck.argtypes = [PP, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.POINTER(C.c_float)]
+        l.p7o_null1.restype = C.c_float
+        l.p7o_null1.argtypes = [C.c_int]
+        l.p7o_bias_filter.restype = C.c_float
+        l.p7o_bias_filter.argtypes = [PP, C.c_void_p, C.c_int]
+        l.p7o_cascade.argtypes = [PP, C.c_void_p, C.c_int, C.c_double, C.c_double, C.c_double, C.c_int, C.POINTER(Record)]
+        l.p7o_cascade_block.argtypes = [PP, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_double, C.c_double,
+                                        C.c_double, C.c_int, C.c_void_p, C.POINTER(Counters)]
+        l.p7o_msv_block.argtypes = [PP, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
+        l.p7o_expf_neg.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
+        l.p7o_sse_expf_scalar.restype = C.c_float
+        l.p7o_sse_expf_scalar.argtypes = [C.c_float]
+        for fn in ("p7o_gumbel_surv", "p7o_exp_surv", "p7o_exp_logsurv"):
+            getattr(l, fn).restype = C.c_double
+            getattr(l, fn).argtypes = [C.c_double] * 3
+        _lib = l
+    return _lib
+
+
+class OracleProfile:
+    """Owns a P7O_PROFILE built from a pyhmmer_amd.plan7.HMM (host-side parser) + background."""
+
+    def __init__(self, hmm, bg, L=400):
+        l = lib()
+        t = np.ascontiguousarray(hmm.transition_probabilities, dtype=np.float32)
+        mat = np.ascontiguousarray(hmm.match_emissions, dtype=np.float32)
+        bgf = np.ascontiguousarray(bg.residue_frequencies, dtype=np.float32)
+        compo = None if hmm.composition is None else np.ascontiguousarray(hmm.composition, dtype=np.float32)
+        ev = np.ascontiguousarray(hmm._evparam, dtype=np.float32)
+        self.ptr = l.p7o_profile_build(hmm.M, hmm.alphabet.K, t.ctypes.data, mat.ctypes.data, bgf.ctypes.data,
+                                       None if compo is None else compo.ctypes.data, ev.ctypes.data, L)
+        self.p = self.ptr.contents
+        self.hmm = hmm
+
+    def __del__(self):
+        if getattr(self, "ptr", None):
+            lib().p7o_profile_free(self.ptr)
+            self.ptr = None
+
+    def arr(self, name):
+        p = self.p
+        shapes = {
+            "rbv": (p.Kp, p.Q16 * 16), "sbv": (p.Kp, (p.Q16 + 17) * 16), "rwv": (p.Kp, p.Q8 * 8),
+            "twv": (8 * p.Q8, 8), "rfv": (p.Kp, p.Q4 * 4), "tfv": (8 * p.Q4, 4),
+        }
+        return np.ctypeslib.as_array(getattr(p, name), shape=shapes[name]).copy()
+
+    @staticmethod
+    def _dsq(seq):
+        a = np.empty(len(seq) + 2, dtype=np.uint8)
+        a[0] = a[-1] = 255
+        a[1:-1] = seq
+        return a
+
+    def msv(self, seq, scalar=False):
+        d = self._dsq(seq); sc = C.c_float(); xj = C.c_int()
+        lib().p7o_reconfig_length(self.ptr, len(seq))
+        st = (lib().p7o_msv_scalar if scalar else lib().p7o_msv)(self.ptr, d.ctypes.data, len(seq), C.byref(sc), C.byref(xj))
+        return st, sc.value, xj.value
+
+    def vit(self, seq, scalar=False):
+        d = self._dsq(seq); sc = C.c_float(); xc = C.c_int()
+        lib().p7o_reconfig_length(self.ptr, len(seq))
+        st = (lib().p7o_vit_scalar if scalar else lib().p7o_vit)(self.ptr, d.ctypes.data, len(seq), C.byref(sc), C.byref(xc))
+        return st, sc.value, xc.value
+
+    def fwd(self, seq, want_xmx=False):
+        d = self._dsq(seq); sc = C.c_float()
+        lib().p7o_reconfig_length(self.ptr, len(seq))
+        xmx = np.zeros((len(seq) + 1, 6), dtype=np.float32) if want_xmx else None
+        st = lib().p7o_fwd(self.ptr, d.ctypes.data, len(seq), None if xmx is None else xmx.ctypes.data, C.byref(sc))
+        return (st, sc.value, xmx) if want_xmx else (st, sc.value)
+
+    def bck(self, seq):
+        st, fsc, fx = self.fwd(seq, want_xmx=True)
+        d = self._dsq(seq); sc = C.c_float()
+        bx = np.zeros_like(fx)
+        st = lib().p7o_bck(self.ptr, d.ctypes.data, len(seq), fx.ctypes.data, bx.ctypes.data, C.byref(sc))
+        return st, sc.value, fx, bx
+
+    def bias(self, seq):
+        d = self._dsq(seq)
+        return lib().p7o_bias_filter(self.ptr, d.ctypes.data, len(seq))
+
+    def cascade_block(self, packed, F1=0.02, F2=1e-3, F3=1e-5, do_bias=True, want_records=True):
+        n = packed.n
+        recs = (Record * n)() if want_records else None
+        ctr = Counters()
+        lib().p7o_cascade_block(self.ptr, packed.dsq.ctypes.data, packed.offsets.ctypes.data, packed.lengths.ctypes.data,
+                                n, F1, F2, F3, int(do_bias), recs, C.byref(ctr))
+        return recs, ctr
+
+    def msv_block(self, packed):
+        out = np.empty(packed.n, dtype=np.int32)
+        lib().p7o_msv_block(self.ptr, packed.dsq.ctypes.data, packed.offsets.ctypes.data, packed.lengths.ctypes.data,
+                            packed.n, out.ctypes.data)
+        return out
