@@ -186,6 +186,7 @@ int p7x_search_block(const p7x_pipeline_cfg *cfg, const p7x_oprofile *om, const 
                      const char *const *descs, p7x_tophits **out);
 
 void     p7x_tophits_destroy(p7x_tophits *th);
+p7x_tophits *p7x_tophits_clone(const p7x_tophits *th);   /* TopHits.copy, plan7.pyx:9150-9170 */
 int64_t  p7x_tophits_nhits(const p7x_tophits *th);
 int      p7x_tophits_get_counters(const p7x_tophits *th, p7x_counters *c);
 int      p7x_tophits_get_cfg(const p7x_tophits *th, p7x_pipeline_cfg *cfg);   /* Z/domZ as finally set */

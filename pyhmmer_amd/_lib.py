@@ -17,7 +17,8 @@ _ROOT = _PKG.parent
 CSRC = _PKG / "csrc"
 LIB_PATH = _PKG / "libp7x.so"
 
-SOURCES = ["p7x_profile.cpp", "p7x_device.hip", "p7x_domaindef.cpp", "p7x_tophits.cpp"]
+SOURCES = ["p7x_profile.cpp", "p7x_device.hip", "p7x_msv.hip", "p7x_vitfwd.hip", "p7x_pipeline.hip",
+           "p7x_domaindef.cpp", "p7x_tophits.cpp"]
 
 
 def _hipcc() -> str:
@@ -167,6 +168,7 @@ _SIGNATURES = {
     "p7x_pipeline_cfg_default": (None, [C.POINTER(PipelineCfg)]),
     "p7x_search_block": (C.c_int, [C.POINTER(PipelineCfg), _VP, _VP, _VP, _VP, _VP, _VP, C.POINTER(_VP)]),
     "p7x_tophits_destroy": (None, [_VP]),
+    "p7x_tophits_clone": (_VP, [_VP]),
     "p7x_tophits_nhits": (C.c_int64, [_VP]),
     "p7x_tophits_get_counters": (C.c_int, [_VP, C.POINTER(Counters)]),
     "p7x_tophits_get_cfg": (C.c_int, [_VP, C.POINTER(PipelineCfg)]),

@@ -1,0 +1,76 @@
+// p7x_device.hpp -- device-side data structures of libp7x (HIP, gfx950 only).
+#pragma once
+#include "p7x_internal.hpp"
+#include <hip/hip_runtime.h>
+#include <mutex>
+
+namespace p7x {
+
+constexpr int kMaxL      = 100000;   // p7_Pipeline's target length limit (plan7.pyx:5421, 6218-6219)
+constexpr int kTabRows   = 32;       // residue rows per device table (Kp <= 29, +1 pad row)
+constexpr int kNegPad    = -512;     // MSV emission for dummy/pad nodes and pad residues (signed 16-bit domain)
+
+#define P7X_HIP(call)                                                                          \
+  do { hipError_t e_ = (call); if (e_ != hipSuccess) {                                         \
+    p7x::set_error(std::string(#call) + ": " + hipGetErrorString(e_)); return P7X_EDEVICE; } } while (0)
+
+// Length-model tables, exact host arithmetic, indexed by target length L (0..kMaxL):
+//   tjb[L]   = unbiased_byteify(ln(3/(L+3)))     (p7_oprofile_ReconfigMSVLength)
+//   xwmove[L]= wordify(ln(3/(L+3)))              (p7_oprofile_ReconfigRestLength, nj = 1)
+//   null1[L] = L ln(L/(L+1)) + ln(1/(L+1))       (p7_bg_SetLength + p7_bg_NullOne)
+struct LengthTables {
+  uint8_t *tjb = nullptr;
+  int16_t *xwmove = nullptr;
+  float   *null1 = nullptr;
+};
+
+struct DeviceCtx {
+  int device = -1;
+  hipStream_t stream = nullptr;
+  LengthTables lt;
+  int num_cu = 256;
+  std::mutex mu;
+};
+int get_ctx(int device, DeviceCtx **out);
+
+// Device image of one query profile.
+struct DevProfile {
+  int device = -1;
+  int M = 0, Kp = 0;
+  // MSV: two parity tables of packed int16 pairs, [2][kTabRows][S] dwords
+  int msvR = 0, msvS = 0;
+  uint32_t *msv_tab = nullptr;
+  // Viterbi: transitions [Mpad][8] int16 (BM,MM,IM,DM,MD,MI,II,DD), emissions [kTabRows][Mpad] int16
+  int vitC = 0, Mpad = 0;
+  int16_t *vit_trans = nullptr;
+  int16_t *vit_emis = nullptr;
+  // Forward/Backward: transitions [Mpad][8] f32, emissions [kTabRows][Mpad] f32
+  float *fwd_trans = nullptr;
+  float *fwd_emis = nullptr;
+  // bias filter: emission odds [kTabRows][2]
+  float *bias_eo = nullptr;
+};
+
+} // namespace p7x
+
+struct p7x_seqdb {
+  int device = -1;
+  int abc_type = 0, Kp = 0;
+  int64_t n = 0;            // targets given by the caller (including empty ones)
+  int64_t nres = 0;
+  int64_t nslots = 0;       // non-empty targets, sorted by decreasing length; slot s <-> target order[s]
+  int64_t ngroups = 0;      // ceil(nslots / 64)
+  // host copies
+  std::vector<int32_t> h_len;      // [n] caller order
+  std::vector<int32_t> h_order;    // [nslots] slot -> caller index
+  std::vector<int64_t> h_off;      // [n] offsets into h_dsq (sentinel-framed copy)
+  std::vector<uint8_t> h_dsq;      // 255 x1..xL 255 x1..xL 255 ...
+  // device
+  uint8_t *d_dsq = nullptr;        // same framing as h_dsq
+  int64_t *d_slot_off = nullptr;   // [nslots] offset of x1 in d_dsq
+  int32_t *d_slot_len = nullptr;   // [ngroups*64] (0 for unused lanes)
+  uint4   *d_tiles = nullptr;      // interleaved 16-residue blocks, see pack_tiles_kernel
+  int64_t *d_grp_off = nullptr;    // [ngroups] first uint4 of the group
+  int32_t *d_grp_nblk = nullptr;   // [ngroups] number of 16-residue blocks
+  int64_t tile_u4 = 0;
+};

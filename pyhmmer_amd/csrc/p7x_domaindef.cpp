@@ -1,0 +1,864 @@
+// p7x_domaindef.cpp -- host-side domain definition for the targets that survive the Forward filter.
+//
+// Restates upstream p7_domaindef.c:p7_domaindef_ByPosteriorHeuristics (reference
+// include/libhmmer/p7_domaindef.pxd:23-72) and the routines it drives:
+//   impl_sse/decoding.c   p7_DomainDecoding, p7_Decoding
+//   impl_sse/fwdback.c    p7_Forward, p7_Backward (full matrices, on envelopes only)
+//   impl_sse/null2.c      p7_Null2_ByExpectation, p7_Null2_ByTrace
+//   impl_sse/optacc.c     p7_OptimalAccuracy, p7_OATrace
+//   impl_sse/stotrace.c   p7_StochasticTrace          (Easel "fast" LCG, re-seeded per region)
+//   p7_spensemble.c       p7_spensemble_Add/_Cluster  (Easel single-linkage clustering)
+//   p7_trace.c            p7_trace_Index;  p7_alidisplay.c p7_alidisplay_Create
+// Matrices are un-striped (node k at index k).  Where upstream's results depend on the order in which
+// the striped SSE code visits cells (tie-breaks in the OA traceback, cumulative sums in the stochastic
+// traceback) that visiting order is reproduced.  Runs only for ~1e-5 of random targets plus true homologs.
+#include "p7x_host.hpp"
+#include <algorithm>
+#include <cctype>
+#include <cmath>
+#include <cstring>
+
+namespace p7x {
+
+namespace {
+
+enum { sM = 1, sD = 2, sI = 3, sS = 4, sN = 5, sB = 6, sE = 7, sC = 8, sT = 9, sJ = 10 };   // p7T_* (p7_trace.pxd)
+enum { xE_ = 0, xN_ = 1, xJ_ = 2, xB_ = 3, xC_ = 4, xS_ = 5, NX = 6 };
+
+// ---------------------------------------------------------------- Easel "fast" RNG (esl_randomness_CreateFast)
+struct FastRng {
+  uint32_t seed = 42, x = 0;
+  static uint32_t mix3(uint32_t a, uint32_t b, uint32_t c)
+  {
+    a -= b; a -= c; a ^= (c >> 13);  b -= c; b -= a; b ^= (a << 8);   c -= a; c -= b; c ^= (b >> 13);
+    a -= b; a -= c; a ^= (c >> 12);  b -= c; b -= a; b ^= (a << 16);  c -= a; c -= b; c ^= (b >> 5);
+    a -= b; a -= c; a ^= (c >> 3);   b -= c; b -= a; b ^= (a << 10);  c -= a; c -= b; c ^= (b >> 15);
+    return c;
+  }
+  void init(uint32_t s) { seed = s; x = mix3(s, 87654321u, 12345678u); if (x == 0) x = 42; }
+  double next() { x = x * 69069u + 1u; return (double) x / 4294967296.0; }
+};
+
+float fsum(const float *v, int n) { return kahan_fsum(v, n); }
+void fnorm(float *v, int n)
+{
+  const float s = fsum(v, n);
+  if (s != 0.0f) for (int i = 0; i < n; ++i) v[i] /= s;
+  else           for (int i = 0; i < n; ++i) v[i] = 1. / (float) n;
+}
+int fchoose(FastRng &r, const float *p, int n)
+{ // esl_rnd_FChoose: cumulative sum in double against one uniform deviate
+  const double roll = r.next();
+  const double norm = fsum(p, n);
+  double sum = 0.0;
+  for (int i = 0; i < n; ++i) { sum += p[i]; if (roll < sum / norm) return i; }
+  for (int i = n - 1; i >= 0; --i) if (p[i] > 0.0f) return i;
+  return 0;
+}
+
+// ---------------------------------------------------------------- the query in a given configuration
+struct Model {
+  const Profile *p;
+  int M;
+  float xf[4][2];                 // [E,N,J,C][MOVE,LOOP] for the current mode / length
+  const float *tf(int t) const { return p->tf.data() + (size_t) t * (M + 1); }
+  const float *rf(int x) const { return p->rf_.data() + (size_t) x * (M + 1); }
+  void configure(bool multihit, int L)
+  { // p7_oprofile_ReconfigMultihit / ReconfigUnihit (+ ReconfigLength)
+    const float nj = multihit ? 1.0f : 0.0f;
+    xf[XE][MOVE] = multihit ? 0.5f : 1.0f;
+    xf[XE][LOOP] = multihit ? 0.5f : 0.0f;
+    const float pmove = (2.0f + nj) / ((float) L + 2.0f + nj), ploop = 1.0f - pmove;
+    for (int s : {XN, XJ, XC}) { xf[s][MOVE] = pmove; xf[s][LOOP] = ploop; }
+  }
+};
+
+// Full DP matrix: rows 0..L, per row three arrays of M+1 floats (M, I, D) plus the specials.
+struct Matrix {
+  int M = 0, L = 0;
+  std::vector<float> m, i, d, x;
+  float totscale = 0.0f;
+  bool own_scales = false;
+  void resize(int M_, int L_)
+  {
+    M = M_; L = L_;
+    const size_t n = (size_t) (L + 1) * (M + 2);
+    if (m.size() < n) { m.resize(n); i.resize(n); d.resize(n); }
+    if (x.size() < (size_t) (L + 1) * NX) x.resize((size_t) (L + 1) * NX);
+  }
+  float *M_(int r) { return m.data() + (size_t) r * (M + 2); }
+  float *I_(int r) { return i.data() + (size_t) r * (M + 2); }
+  float *D_(int r) { return d.data() + (size_t) r * (M + 2); }
+  const float *M_(int r) const { return m.data() + (size_t) r * (M + 2); }
+  const float *I_(int r) const { return i.data() + (size_t) r * (M + 2); }
+  const float *D_(int r) const { return d.data() + (size_t) r * (M + 2); }
+  float &X(int r, int s) { return x[(size_t) r * NX + s]; }
+  float X(int r, int s) const { return x[(size_t) r * NX + s]; }
+};
+
+// ---------------------------------------------------------------- p7_Forward (full matrix)
+// dsq is 1-indexed over the envelope: residues dsq[1..L].
+int forward_full(const Model &om, const uint8_t *dsq, int L, Matrix &ox, float *ret_sc)
+{
+  const int M = om.M;
+  ox.resize(M, L);
+  const float *tMM = om.tf(1), *tIM = om.tf(2), *tDM = om.tf(3), *tMD = om.tf(4), *tMI = om.tf(5), *tII = om.tf(6), *tDD = om.tf(7);
+  float *m0 = ox.M_(0), *i0 = ox.I_(0), *d0 = ox.D_(0);
+  for (int k = 0; k <= M + 1; ++k) m0[k] = i0[k] = d0[k] = 0.0f;
+  float xE = 0.f, xN = 1.f, xJ = 0.f, xB = om.xf[XN][MOVE], xC = 0.f;
+  ox.X(0, xE_) = xE; ox.X(0, xN_) = xN; ox.X(0, xJ_) = xJ; ox.X(0, xB_) = xB; ox.X(0, xC_) = xC; ox.X(0, xS_) = 1.0f;
+  ox.totscale = 0.0f; ox.own_scales = true;
+  const float *bm = om.tf(0);
+  for (int r = 1; r <= L; ++r) {
+    const float *rf = om.rf(dsq[r]);
+    const float *mp = ox.M_(r - 1), *ip = ox.I_(r - 1), *dp = ox.D_(r - 1);
+    float *mc = ox.M_(r), *ic = ox.I_(r), *dc = ox.D_(r);
+    mc[0] = ic[0] = dc[0] = 0.0f;
+    for (int k = 1; k <= M; ++k) {
+      float sv = xB * bm[k];
+      sv = sv + mp[k - 1] * tMM[k];
+      sv = sv + ip[k - 1] * tIM[k];
+      sv = sv + dp[k - 1] * tDM[k];
+      mc[k] = sv * rf[k];
+      ic[k] = mp[k] * tMI[k] + ip[k] * tII[k];
+    }
+    float esum = 0.0f;
+    dc[1] = 0.0f;
+    for (int k = 2; k <= M; ++k) dc[k] = mc[k - 1] * tMD[k - 1] + dc[k - 1] * tDD[k - 1];
+    for (int k = 1; k <= M; ++k) esum += mc[k];
+    for (int k = 1; k <= M; ++k) esum += dc[k];
+    mc[M + 1] = ic[M + 1] = dc[M + 1] = 0.0f;
+    xE = esum;
+    xN = xN * om.xf[XN][LOOP];
+    xC = (xC * om.xf[XC][LOOP]) + (xE * om.xf[XE][MOVE]);
+    xJ = (xJ * om.xf[XJ][LOOP]) + (xE * om.xf[XE][LOOP]);
+    xB = (xJ * om.xf[XJ][MOVE]) + (xN * om.xf[XN][MOVE]);
+    if (xE > 1.0e4) {
+      xN = xN / xE; xC = xC / xE; xJ = xJ / xE; xB = xB / xE;
+      const float inv = 1.0 / xE;
+      for (int k = 1; k <= M; ++k) { mc[k] *= inv; dc[k] *= inv; ic[k] *= inv; }
+      ox.X(r, xS_) = xE;
+      ox.totscale += std::log((double) xE);
+      xE = 1.0;
+    } else ox.X(r, xS_) = 1.0f;
+    ox.X(r, xE_) = xE; ox.X(r, xN_) = xN; ox.X(r, xJ_) = xJ; ox.X(r, xB_) = xB; ox.X(r, xC_) = xC;
+  }
+  if (std::isnan(xC) || (L > 0 && xC == 0.0f) || std::isinf(xC)) { if (ret_sc) *ret_sc = INFINITY; return P7X_ERANGE; }
+  if (ret_sc) *ret_sc = ox.totscale + std::log((double) (xC * om.xf[XC][MOVE]));
+  return P7X_OK;
+}
+
+// ---------------------------------------------------------------- p7_Backward (full matrix)
+int backward_full(const Model &om, const uint8_t *dsq, int L, const Matrix &fwd, Matrix &bck, float *ret_sc)
+{
+  const int M = om.M;
+  bck.resize(M, L);
+  const float *bm = om.tf(0), *tMM = om.tf(1), *tIM = om.tf(2), *tDM = om.tf(3), *tMD = om.tf(4), *tMI = om.tf(5), *tII = om.tf(6), *tDD = om.tf(7);
+  bck.own_scales = false;
+  float xJ = 0.f, xB = 0.f, xN = 0.f;
+  float xC = om.xf[XC][MOVE];
+  float xE = xC * om.xf[XE][MOVE];
+  {
+    float *mc = bck.M_(L), *ic = bck.I_(L), *dc = bck.D_(L);
+    mc[M + 1] = ic[M + 1] = dc[M + 1] = 0.0f;
+    for (int k = M; k >= 1; --k) {
+      dc[k] = xE + dc[k + 1] * tDD[k];     // tDD[M] = 0
+      mc[k] = xE + dc[k + 1] * tMD[k];
+      ic[k] = 0.0f;
+    }
+    mc[0] = ic[0] = dc[0] = 0.0f;
+    float sc = fwd.X(L, xS_);
+    if (sc > 1.0f) {
+      xE = xE / sc; xN = xN / sc; xC = xC / sc; xJ = xJ / sc; xB = xB / sc;
+      const float inv = 1.0 / sc;
+      for (int k = 1; k <= M; ++k) { mc[k] *= inv; dc[k] *= inv; ic[k] *= inv; }
+    }
+    bck.X(L, xS_) = sc;
+    bck.totscale = std::log((double) sc);
+    bck.X(L, xE_) = xE; bck.X(L, xN_) = xN; bck.X(L, xJ_) = xJ; bck.X(L, xB_) = xB; bck.X(L, xC_) = xC;
+  }
+  for (int r = L - 1; r >= 1; --r) {
+    const float *rf = om.rf(dsq[r + 1]);
+    const float *mn = bck.M_(r + 1), *in = bck.I_(r + 1);
+    float *mc = bck.M_(r), *ic = bck.I_(r), *dc = bck.D_(r);
+    float bsum = 0.0f;
+    for (int k = 1; k <= M; ++k) bsum += (mn[k] * rf[k]) * bm[k];
+    xB = bsum;
+    xC = xC * om.xf[XC][LOOP];
+    xJ = (xB * om.xf[XJ][MOVE]) + (xJ * om.xf[XJ][LOOP]);
+    xN = (xB * om.xf[XN][MOVE]) + (xN * om.xf[XN][LOOP]);
+    xE = (xC * om.xf[XE][MOVE]) + (xJ * om.xf[XE][LOOP]);
+    mc[M + 1] = ic[M + 1] = dc[M + 1] = 0.0f;
+    for (int k = M; k >= 1; --k) {
+      const float me = (k < M) ? mn[k + 1] * rf[k + 1] : 0.0f;     // M(i+1,k+1) e(x_{i+1}, k+1)
+      const float tmm = (k < M) ? tMM[k + 1] : 0.0f, tim = (k < M) ? tIM[k + 1] : 0.0f, tdm = (k < M) ? tDM[k + 1] : 0.0f;
+      ic[k] = in[k] * tII[k] + me * tim;
+      dc[k] = (me * tdm + xE) + dc[k + 1] * tDD[k];
+      mc[k] = ((in[k] * tMI[k] + me * tmm) + xE) + dc[k + 1] * tMD[k];
+    }
+    mc[0] = ic[0] = dc[0] = 0.0f;
+    if (xB > 1.0e16) bck.own_scales = true;
+    float sc = bck.own_scales ? ((xB > 1.0e4) ? xB : 1.0f) : fwd.X(r, xS_);
+    bck.X(r, xS_) = sc;
+    if (sc > 1.0f) {
+      xE /= sc; xN /= sc; xJ /= sc; xB /= sc; xC /= sc;
+      const float inv = 1.0 / sc;
+      for (int k = 1; k <= M; ++k) { mc[k] *= inv; dc[k] *= inv; ic[k] *= inv; }
+      bck.totscale += std::log((double) sc);
+    }
+    bck.X(r, xE_) = xE; bck.X(r, xN_) = xN; bck.X(r, xJ_) = xJ; bck.X(r, xB_) = xB; bck.X(r, xC_) = xC;
+  }
+  {
+    const float *rf = om.rf(dsq[1]);
+    const float *mn = bck.M_(1);
+    float bsum = 0.0f;
+    for (int k = 1; k <= M; ++k) bsum += (mn[k] * rf[k]) * bm[k];
+    xB = bsum;
+    xN = (xB * om.xf[XN][MOVE]) + (xN * om.xf[XN][LOOP]);
+    bck.X(0, xB_) = xB; bck.X(0, xC_) = 0.0f; bck.X(0, xJ_) = 0.0f; bck.X(0, xN_) = xN; bck.X(0, xE_) = 0.0f; bck.X(0, xS_) = 1.0f;
+    float *mc = bck.M_(0), *ic = bck.I_(0), *dc = bck.D_(0);
+    for (int k = 0; k <= M + 1; ++k) mc[k] = ic[k] = dc[k] = 0.0f;
+  }
+  if (std::isnan(xN) || (L > 0 && xN == 0.0f) || std::isinf(xN)) { if (ret_sc) *ret_sc = INFINITY; return P7X_ERANGE; }
+  if (ret_sc) *ret_sc = bck.totscale + std::log((double) xN);
+  return P7X_OK;
+}
+
+// ---------------------------------------------------------------- p7_Decoding: posteriors into <bck> (in place)
+int decoding(const Model &om, const Matrix &fwd, Matrix &bck)
+{
+  const int M = om.M, L = fwd.L;
+  float scaleproduct = 1.0 / bck.X(0, xN_);
+  // row 0 is zeroed *after* reading xN(0); upstream writes into a third matrix, we overwrite <bck> row by row,
+  // which is safe because row i of the posterior only needs row i of both matrices and specials of row i-1 (fwd).
+  std::vector<float> bN(L + 1), bJ(L + 1), bC(L + 1), bS(L + 1);
+  for (int r = 0; r <= L; ++r) { bN[r] = bck.X(r, xN_); bJ[r] = bck.X(r, xJ_); bC[r] = bck.X(r, xC_); bS[r] = bck.X(r, xS_); }
+  {
+    float *mc = bck.M_(0), *ic = bck.I_(0), *dc = bck.D_(0);
+    for (int k = 0; k <= M + 1; ++k) mc[k] = ic[k] = dc[k] = 0.0f;
+    bck.X(0, xE_) = bck.X(0, xN_) = bck.X(0, xJ_) = bck.X(0, xC_) = bck.X(0, xB_) = 0.0f;
+  }
+  for (int r = 1; r <= L; ++r) {
+    const float totr = scaleproduct * fwd.X(r, xS_);
+    const float *fm = fwd.M_(r), *fi = fwd.I_(r);
+    float *mc = bck.M_(r), *ic = bck.I_(r), *dc = bck.D_(r);
+    for (int k = 1; k <= M; ++k) {
+      mc[k] = (fm[k] * mc[k]) * totr;
+      dc[k] = 0.0f;
+      ic[k] = (fi[k] * ic[k]) * totr;
+    }
+    bck.X(r, xE_) = 0.0f;
+    bck.X(r, xN_) = fwd.X(r - 1, xN_) * bN[r] * om.xf[XN][LOOP] * scaleproduct;
+    bck.X(r, xJ_) = fwd.X(r - 1, xJ_) * bJ[r] * om.xf[XJ][LOOP] * scaleproduct;
+    bck.X(r, xB_) = 0.0f;
+    bck.X(r, xC_) = fwd.X(r - 1, xC_) * bC[r] * om.xf[XC][LOOP] * scaleproduct;
+    if (bck.own_scales) scaleproduct *= fwd.X(r, xS_) / bS[r];
+  }
+  return std::isinf(scaleproduct) ? P7X_ERANGE : P7X_OK;
+}
+
+// esl_abc_FAvgScVec + gap-like symbols
+void finish_null2(const Profile &p, float *null2)
+{
+  const Alphabet &abc = Alphabet::get(p.abc_type);
+  for (int x = p.K + 1; x <= p.Kp - 3; ++x) {
+    float result = 0.0f; int n = 0;
+    for (int y = 0; y < p.K; ++y) if (abc.degen[x][y]) { result += null2[y]; ++n; }
+    null2[x] = result / (float) n;
+  }
+  null2[p.K] = 1.0f; null2[p.Kp - 2] = 1.0f; null2[p.Kp - 1] = 1.0f;
+}
+
+// ---------------------------------------------------------------- p7_Null2_ByExpectation (pp = posterior matrix)
+void null2_by_expectation(const Model &om, Matrix &pp, float *null2)
+{
+  const int M = om.M, Ld = pp.L;
+  float *m0 = pp.M_(0), *i0 = pp.I_(0);
+  std::memcpy(m0, pp.M_(1), sizeof(float) * (M + 2));
+  std::memcpy(i0, pp.I_(1), sizeof(float) * (M + 2));
+  float eN = pp.X(1, xN_), eC = pp.X(1, xC_), eJ = pp.X(1, xJ_);
+  for (int r = 2; r <= Ld; ++r) {
+    const float *mr = pp.M_(r), *ir = pp.I_(r);
+    for (int k = 1; k <= M; ++k) { m0[k] = mr[k] + m0[k]; i0[k] = ir[k] + i0[k]; }
+    eN += pp.X(r, xN_); eC += pp.X(r, xC_); eJ += pp.X(r, xJ_);
+  }
+  const float norm = 1.0 / (float) Ld;
+  for (int k = 1; k <= M; ++k) { m0[k] *= norm; i0[k] *= norm; }
+  eN *= norm; eC *= norm; eJ *= norm;
+  const float xfactor = eN + eC + eJ;
+  const int Q = om.p->Q4();
+  for (int x = 0; x < om.p->K; ++x) {
+    const float *rf = om.rf(x);
+    float lane[4] = {0, 0, 0, 0};                       // upstream's 4-lane striped accumulation order
+    for (int q = 0; q < Q; ++q)
+      for (int z = 0; z < 4; ++z) {
+        const int k = q + 1 + z * Q;
+        if (k > M) continue;
+        lane[z] = lane[z] + m0[k] * rf[k];
+        lane[z] = lane[z] + i0[k];
+      }
+    null2[x] = ((lane[0] + lane[1]) + (lane[2] + lane[3])) + xfactor;
+  }
+  finish_null2(*om.p, null2);
+}
+
+// ---------------------------------------------------------------- traces
+struct Trace {
+  std::vector<int8_t> st; std::vector<int> k, i; std::vector<float> pp;
+  int ndom = 0;
+  std::vector<int> tfrom, tto, sqfrom, sqto, hmmfrom, hmmto;
+  void clear() { st.clear(); k.clear(); i.clear(); pp.clear(); ndom = 0; tfrom.clear(); tto.clear(); sqfrom.clear(); sqto.clear(); hmmfrom.clear(); hmmto.clear(); }
+  void append(int s, int kk, int ii, float p)
+  { // p7_trace_AppendWithPP
+    int iv = 0, kv = 0; float pv = 0.0f;
+    switch (s) {
+      case sN: case sC: case sJ:
+        if (!st.empty() && st.back() == s) { iv = ii; pv = p; }
+        break;
+      case sD: kv = kk; break;
+      case sM: case sI: iv = ii; kv = kk; pv = p; break;
+      default: break;
+    }
+    st.push_back((int8_t) s); k.push_back(kv); i.push_back(iv); pp.push_back(pv);
+  }
+  void reverse()
+  { // p7_trace_Reverse: N,C,J emit on transition, so their i/pp move one step when the order flips
+    const int N = (int) st.size();
+    for (int z = 0; z < N; ++z)
+      if ((st[z] == sN || st[z] == sC || st[z] == sJ) && z + 1 < N && st[z] == st[z + 1]) {
+        if (i[z] == 0 && i[z + 1] > 0) { i[z] = i[z + 1]; i[z + 1] = 0; pp[z] = pp[z + 1]; pp[z + 1] = 0.0f; }
+      }
+    std::reverse(st.begin(), st.end()); std::reverse(k.begin(), k.end());
+    std::reverse(i.begin(), i.end()); std::reverse(pp.begin(), pp.end());
+  }
+  void index()
+  { // p7_trace_Index
+    ndom = 0; tfrom.clear(); tto.clear(); sqfrom.clear(); sqto.clear(); hmmfrom.clear(); hmmto.clear();
+    for (int z = 0; z < (int) st.size(); ++z)
+      switch (st[z]) {
+        case sB: tfrom.push_back(z); tto.push_back(0); sqfrom.push_back(0); sqto.push_back(0); hmmfrom.push_back(0); hmmto.push_back(0); break;
+        case sM:
+          if (sqfrom[ndom] == 0) sqfrom[ndom] = i[z];
+          if (hmmfrom[ndom] == 0) hmmfrom[ndom] = k[z];
+          sqto[ndom] = i[z]; hmmto[ndom] = k[z];
+          break;
+        case sI: sqto[ndom] = i[z]; break;
+        case sD: if (hmmfrom[ndom] == 0) hmmfrom[ndom] = k[z]; hmmto[ndom] = k[z]; break;
+        case sE: tto[ndom] = z; ndom++; break;
+        default: break;
+      }
+  }
+};
+
+// ---------------------------------------------------------------- p7_OptimalAccuracy + p7_OATrace
+inline float gate(float t, float v) { return t > 0.0f ? v : 0.0f; }   // upstream: and(cmpgt(t,0), v)
+
+void optimal_accuracy(const Model &om, const Matrix &pp, Matrix &ox, float *ret_e)
+{
+  const int M = om.M, L = pp.L;
+  ox.resize(M, L);
+  const float *bm = om.tf(0), *tMM = om.tf(1), *tIM = om.tf(2), *tDM = om.tf(3), *tMD = om.tf(4), *tMI = om.tf(5), *tII = om.tf(6), *tDD = om.tf(7);
+  {
+    float *mc = ox.M_(0), *ic = ox.I_(0), *dc = ox.D_(0);
+    for (int k = 0; k <= M + 1; ++k) mc[k] = ic[k] = dc[k] = -INFINITY;
+  }
+  ox.X(0, xE_) = -INFINITY; ox.X(0, xN_) = 0.f; ox.X(0, xJ_) = -INFINITY; ox.X(0, xB_) = 0.f; ox.X(0, xC_) = -INFINITY;
+  for (int r = 1; r <= L; ++r) {
+    const float *mp = ox.M_(r - 1), *ip = ox.I_(r - 1), *dp = ox.D_(r - 1);
+    const float *pm = pp.M_(r), *pi = pp.I_(r);
+    float *mc = ox.M_(r), *ic = ox.I_(r), *dc = ox.D_(r);
+    const float xB = ox.X(r - 1, xB_);
+    mc[0] = ic[0] = dc[0] = -INFINITY;
+    float xEmax = -INFINITY;
+    for (int k = 1; k <= M; ++k) {
+      float sv = gate(bm[k], xB);
+      sv = std::fmax(sv, gate(tMM[k], mp[k - 1]));
+      sv = std::fmax(sv, gate(tIM[k], ip[k - 1]));
+      sv = std::fmax(sv, gate(tDM[k], dp[k - 1]));
+      sv = sv + pm[k];
+      mc[k] = sv;
+      xEmax = std::fmax(xEmax, sv);
+      float iv = gate(tMI[k], mp[k]);
+      iv = std::fmax(iv, gate(tII[k], ip[k]));
+      ic[k] = iv + pi[k];
+    }
+    dc[1] = -INFINITY;
+    for (int k = 2; k <= M; ++k) dc[k] = std::fmax(gate(tMD[k - 1], mc[k - 1]), gate(tDD[k - 1], dc[k - 1]));
+    for (int k = 1; k <= M; ++k) xEmax = std::fmax(xEmax, dc[k]);
+    mc[M + 1] = ic[M + 1] = dc[M + 1] = -INFINITY;
+    ox.X(r, xE_) = xEmax;
+    float t1, t2;
+    t1 = (om.xf[XJ][LOOP] == 0.0f) ? 0.0f : ox.X(r - 1, xJ_) + pp.X(r, xJ_);
+    t2 = (om.xf[XE][LOOP] == 0.0f) ? 0.0f : ox.X(r, xE_);
+    ox.X(r, xJ_) = std::fmax(t1, t2);
+    t1 = (om.xf[XC][LOOP] == 0.0f) ? 0.0f : ox.X(r - 1, xC_) + pp.X(r, xC_);
+    t2 = (om.xf[XE][MOVE] == 0.0f) ? 0.0f : ox.X(r, xE_);
+    ox.X(r, xC_) = std::fmax(t1, t2);
+    ox.X(r, xN_) = (om.xf[XN][LOOP] == 0.0f) ? 0.0f : ox.X(r - 1, xN_) + pp.X(r, xN_);
+    t1 = (om.xf[XN][MOVE] == 0.0f) ? 0.0f : ox.X(r, xN_);
+    t2 = (om.xf[XJ][MOVE] == 0.0f) ? 0.0f : ox.X(r, xJ_);
+    ox.X(r, xB_) = std::fmax(t1, t2);
+  }
+  *ret_e = ox.X(L, xC_);
+}
+
+int oa_trace(const Model &om, const Matrix &pp, const Matrix &ox, Trace &tr)
+{
+  const int M = om.M, Q = om.p->Q4();
+  const float *bm = om.tf(0), *tMM = om.tf(1), *tIM = om.tf(2), *tDM = om.tf(3), *tMD = om.tf(4), *tMI = om.tf(5), *tII = om.tf(6), *tDD = om.tf(7);
+  int i = ox.L, k = 0;
+  tr.clear();
+  tr.append(sT, k, i, 0.0f);
+  tr.append(sC, k, i, 0.0f);
+  int s0 = sC;
+  auto postprob = [&](int scur, int sprv, int kk, int ii) -> float {
+    switch (scur) {
+      case sM: return pp.M_(ii)[kk];
+      case sI: return pp.I_(ii)[kk];
+      case sN: if (sprv == scur) return pp.X(ii, xN_); return 0.0f;
+      case sC: if (sprv == scur) return pp.X(ii, xC_); return 0.0f;
+      case sJ: if (sprv == scur) return pp.X(ii, xJ_); return 0.0f;
+      default: return 0.0f;
+    }
+  };
+  while (s0 != sS) {
+    int s1 = -1;
+    switch (s0) {
+      case sM: {
+        float path[4];
+        path[0] = (tMM[k] == 0.0f) ? -INFINITY : ox.M_(i - 1)[k - 1];
+        path[1] = (tIM[k] == 0.0f) ? -INFINITY : ox.I_(i - 1)[k - 1];
+        path[2] = (tDM[k] == 0.0f) ? -INFINITY : ox.D_(i - 1)[k - 1];
+        path[3] = (bm[k]  == 0.0f) ? -INFINITY : ox.X(i - 1, xB_);
+        static const int state[4] = { sM, sI, sD, sB };
+        int best = 0;
+        for (int a = 1; a < 4; ++a) if (path[a] > path[best]) best = a;     // esl_vec_FArgMax: first maximum
+        s1 = state[best]; k--; i--;
+        break;
+      }
+      case sD: {
+        const float p0 = (tMD[k - 1] == 0.0f) ? -INFINITY : ox.M_(i)[k - 1];
+        const float p1 = (tDD[k - 1] == 0.0f) ? -INFINITY : ox.D_(i)[k - 1];
+        s1 = (p0 >= p1) ? sM : sD; k--;
+        break;
+      }
+      case sI: {
+        const float p0 = (tMI[k] == 0.0f) ? -INFINITY : ox.M_(i - 1)[k];
+        const float p1 = (tII[k] == 0.0f) ? -INFINITY : ox.I_(i - 1)[k];
+        s1 = (p0 >= p1) ? sM : sI; i--;
+        break;
+      }
+      case sN: s1 = (i == 0) ? sS : sN; break;
+      case sC: {
+        const float t1 = (om.xf[XC][LOOP] == 0.0f) ? 0.0f : 1.0f, t2 = (om.xf[XE][MOVE] == 0.0f) ? 0.0f : 1.0f;
+        const float p0 = t1 * (ox.X(i - 1, xC_) + pp.X(i, xC_)), p1 = t2 * ox.X(i, xE_);
+        s1 = (p0 > p1) ? sC : sE;
+        break;
+      }
+      case sJ: {
+        const float t1 = (om.xf[XJ][LOOP] == 0.0f) ? 0.0f : 1.0f, t2 = (om.xf[XE][LOOP] == 0.0f) ? 0.0f : 1.0f;
+        const float p0 = t1 * (ox.X(i - 1, xJ_) + pp.X(i, xJ_)), p1 = t2 * ox.X(i, xE_);
+        s1 = (p0 > p1) ? sJ : sE;
+        break;
+      }
+      case sE: {   // striped visiting order: q outer, lanes inner; M beats D on ties (>= vs >)
+        float mx = -INFINITY; int smax = -1, kmax = 0;
+        const float *mr = ox.M_(i), *dr = ox.D_(i);
+        for (int q = 0; q < Q; ++q) {
+          for (int z = 0; z < 4; ++z) { const int kk = z * Q + q + 1; if (kk <= M && mr[kk] >= mx) { mx = mr[kk]; smax = sM; kmax = kk; } }
+          for (int z = 0; z < 4; ++z) { const int kk = z * Q + q + 1; if (kk <= M && dr[kk] >  mx) { mx = dr[kk]; smax = sD; kmax = kk; } }
+        }
+        k = kmax; s1 = smax;
+        break;
+      }
+      case sB: {
+        const float t1 = (om.xf[XN][MOVE] == 0.0f) ? 0.0f : 1.0f, t2 = (om.xf[XJ][MOVE] == 0.0f) ? 0.0f : 1.0f;
+        s1 = (t1 * ox.X(i, xN_) > t2 * ox.X(i, xJ_)) ? sN : sJ;
+        break;
+      }
+      default: return P7X_EINVAL;
+    }
+    if (s1 == -1) return P7X_EINVAL;
+    tr.append(s1, k, i, postprob(s1, s0, k, i));
+    if ((s1 == sN || s1 == sJ || s1 == sC) && s1 == s0) i--;
+    s0 = s1;
+  }
+  tr.reverse();
+  return P7X_OK;
+}
+
+// ---------------------------------------------------------------- p7_StochasticTrace
+int stochastic_trace(FastRng &rng, const Model &om, const Matrix &fx, int L, Trace &tr)
+{
+  const int M = om.M, Q = om.p->Q4();
+  const float *bm = om.tf(0), *tMM = om.tf(1), *tIM = om.tf(2), *tDM = om.tf(3), *tMD = om.tf(4), *tMI = om.tf(5), *tII = om.tf(6), *tDD = om.tf(7);
+  int i = L, k = 0;
+  tr.clear();
+  tr.append(sT, k, i, 0.0f);
+  tr.append(sC, k, i, 0.0f);
+  int s0 = sC;
+  while (s0 != sS) {
+    int s1 = -1;
+    switch (s0) {
+      case sM: {
+        float path[4];
+        path[0] = fx.X(i - 1, xB_) * bm[k];
+        path[1] = fx.M_(i - 1)[k - 1] * tMM[k];
+        path[2] = fx.I_(i - 1)[k - 1] * tIM[k];
+        path[3] = fx.D_(i - 1)[k - 1] * tDM[k];
+        fnorm(path, 4);
+        static const int state[4] = { sB, sM, sI, sD };
+        s1 = state[fchoose(rng, path, 4)]; k--; i--;
+        break;
+      }
+      case sD: {
+        float path[2] = { fx.M_(i)[k - 1] * tMD[k - 1], fx.D_(i)[k - 1] * tDD[k - 1] };
+        fnorm(path, 2);
+        s1 = fchoose(rng, path, 2) == 0 ? sM : sD; k--;
+        break;
+      }
+      case sI: {
+        float path[2] = { fx.M_(i - 1)[k] * tMI[k], fx.I_(i - 1)[k] * tII[k] };
+        fnorm(path, 2);
+        s1 = fchoose(rng, path, 2) == 0 ? sM : sI; i--;
+        break;
+      }
+      case sN: s1 = (i == 0) ? sS : sN; break;
+      case sC: {
+        float path[2] = { fx.X(i - 1, xC_) * om.xf[XC][LOOP], fx.X(i, xE_) * om.xf[XE][MOVE] * fx.X(i, xS_) };
+        fnorm(path, 2);
+        s1 = fchoose(rng, path, 2) == 0 ? sC : sE;
+        break;
+      }
+      case sJ: {
+        float path[2] = { fx.X(i - 1, xJ_) * om.xf[XJ][LOOP], fx.X(i, xE_) * om.xf[XE][LOOP] * fx.X(i, xS_) };
+        fnorm(path, 2);
+        s1 = fchoose(rng, path, 2) == 0 ? sJ : sE;
+        break;
+      }
+      case sE: {
+        double sum = 0.0;
+        const double roll = rng.next();
+        const float norm = (float) (1.0 / fx.X(i, xE_));
+        const float *mr = fx.M_(i), *dr = fx.D_(i);
+        bool done = false;
+        for (int pass = 0; pass < 2 && !done; ++pass) {
+          for (int q = 0; q < Q && !done; ++q) {
+            for (int z = 0; z < 4 && !done; ++z) { const int kk = z * Q + q + 1; sum += (kk <= M ? mr[kk] * norm : 0.0f); if (roll < sum) { k = kk; s1 = sM; done = true; } }
+            for (int z = 0; z < 4 && !done; ++z) { const int kk = z * Q + q + 1; sum += (kk <= M ? dr[kk] * norm : 0.0f); if (roll < sum) { k = kk; s1 = sD; done = true; } }
+          }
+          if (!done && sum < 0.99) return P7X_EINVAL;
+        }
+        if (!done) return P7X_EINVAL;
+        break;
+      }
+      case sB: {
+        float path[2] = { fx.X(i, xN_) * om.xf[XN][MOVE], fx.X(i, xJ_) * om.xf[XJ][MOVE] };
+        fnorm(path, 2);
+        s1 = fchoose(rng, path, 2) == 0 ? sN : sJ;
+        break;
+      }
+      default: return P7X_EINVAL;
+    }
+    if (s1 == -1) return P7X_EINVAL;
+    tr.append(s1, k, i, 0.0f);
+    if ((s1 == sN || s1 == sJ || s1 == sC) && s1 == s0) i--;
+    s0 = s1;
+  }
+  tr.reverse();
+  return P7X_OK;
+}
+
+// ---------------------------------------------------------------- p7_Null2_ByTrace
+void null2_by_trace(const Model &om, const Trace &tr, int zstart, int zend, std::vector<float> &wm, std::vector<float> &wi, float *null2)
+{
+  const int M = om.M, Q = om.p->Q4();
+  wm.assign(M + 2, 0.0f); wi.assign(M + 2, 0.0f);
+  float eN = 0.0f, eC = 0.0f, eJ = 0.0f;
+  int Ld = 0;
+  for (int z = zstart; z <= zend; ++z) {
+    if (tr.i[z] == 0) continue;
+    Ld++;
+    if (tr.k[z] > 0) { if (tr.st[z] == sM) wm[tr.k[z]] += 1.0f; else wi[tr.k[z]] += 1.0f; }
+    else switch (tr.st[z]) { case sN: eN += 1.0f; break; case sC: eC += 1.0f; break; case sJ: eJ += 1.0f; break; default: break; }
+  }
+  const float norm = 1.0 / (float) Ld;
+  for (int k = 1; k <= M; ++k) { wm[k] *= norm; wi[k] *= norm; }
+  eN *= norm; eC *= norm; eJ *= norm;
+  const float xfactor = eN + eC + eJ;
+  for (int x = 0; x < om.p->K; ++x) {
+    const float *rf = om.rf(x);
+    float lane[4] = {0, 0, 0, 0};
+    for (int q = 0; q < Q; ++q)
+      for (int z = 0; z < 4; ++z) {
+        const int k = q + 1 + z * Q;
+        if (k > M) continue;
+        lane[z] = lane[z] + wm[k] * rf[k];
+        lane[z] = lane[z] + wi[k];
+      }
+    null2[x] = ((lane[0] + lane[1]) + (lane[2] + lane[3])) + xfactor;
+  }
+  finish_null2(*om.p, null2);
+}
+
+// ---------------------------------------------------------------- p7_spensemble
+struct SpCoord { int idx, i, j, k, m; float prob; };
+
+bool sp_link(const SpCoord &h1, const SpCoord &h2, float min_overlap, bool of_smaller, int max_diagdiff)
+{
+  int nov = std::min(h1.j, h2.j) - std::max(h1.i, h2.i) + 1;
+  int n = of_smaller ? std::min(h1.j - h1.i + 1, h2.j - h2.i + 1) : std::max(h1.j - h1.i + 1, h2.j - h2.i + 1);
+  if ((float) nov / (float) n < min_overlap) return false;
+  nov = std::min(h1.m, h2.m) - std::max(h1.k, h2.k);
+  n = of_smaller ? std::min(h1.m - h1.k + 1, h2.m - h2.k + 1) : std::max(h1.m - h1.k + 1, h2.m - h2.k + 1);
+  if ((float) nov / (float) n < min_overlap) return false;
+  int d1 = h1.i - h1.k, d2 = h2.i - h2.k; if (std::abs(d1 - d2) <= max_diagdiff) return true;
+  d1 = h1.j - h1.m; d2 = h2.j - h2.m;     if (std::abs(d1 - d2) <= max_diagdiff) return true;
+  return false;
+}
+
+// esl_cluster_SingleLinkage: same traversal order as Easel, so cluster numbers agree
+void single_linkage(const std::vector<SpCoord> &sp, float min_overlap, bool of_smaller, int max_diagdiff,
+                    std::vector<int> &assign, int &nc)
+{
+  const int n = (int) sp.size();
+  std::vector<int> a(n), b(n);
+  assign.assign(n, 0);
+  for (int v = 0; v < n; ++v) a[v] = n - v - 1;
+  int na = n; nc = 0;
+  while (na > 0) {
+    int v = a[na - 1]; na--;
+    b[0] = v; int nb = 1;
+    while (nb > 0) {
+      v = b[nb - 1]; nb--;
+      assign[v] = nc;
+      for (int i = na - 1; i >= 0; --i)
+        if (sp_link(sp[v], sp[a[i]], min_overlap, of_smaller, max_diagdiff)) { b[nb++] = a[i]; a[i] = a[na - 1]; na--; }
+    }
+    nc++;
+  }
+}
+
+void sp_cluster(const std::vector<SpCoord> &sp, int nsamples, float min_overlap, bool of_smaller, int max_diagdiff,
+                float min_posterior, float min_endpointp, std::vector<SpCoord> &sigc)
+{
+  std::vector<int> assign; int nc = 0;
+  single_linkage(sp, min_overlap, of_smaller, max_diagdiff, assign, nc);
+  const int n = (int) sp.size();
+  sigc.clear();
+  std::vector<int> epc;
+  for (int c = 0; c < nc; ++c) {
+    int idx_of_last = -1, ninc = 0;
+    for (int h = 0; h < n; ++h) if (assign[h] == c) { if (sp[h].idx != idx_of_last) ninc++; idx_of_last = sp[h].idx; }
+    if ((float) ninc / (float) nsamples < min_posterior) continue;
+    int imin = 0, imax = 0, jmin = 0, jmax = 0, kmin = 0, kmax = 0, mmin = 0, mmax = 0;
+    for (int h = 0; h < n; ++h) if (assign[h] == c) {
+      if (imin == 0) { imin = imax = sp[h].i; jmin = jmax = sp[h].j; kmin = kmax = sp[h].k; mmin = mmax = sp[h].m; }
+      else {
+        imin = std::min(imin, sp[h].i); imax = std::max(imax, sp[h].i);
+        jmin = std::min(jmin, sp[h].j); jmax = std::max(jmax, sp[h].j);
+        kmin = std::min(kmin, sp[h].k); kmax = std::max(kmax, sp[h].k);
+        mmin = std::min(mmin, sp[h].m); mmax = std::max(mmax, sp[h].m);
+      }
+    }
+    const int epc_threshold = (int) std::ceil((float) ninc * min_endpointp);
+    auto argmax = [&](int w) { int b = 0; for (int q = 1; q < w; ++q) if (epc[q] > epc[b]) b = q; return b; };
+    int best_i = 0, best_j = 0, best_k = 0, best_m = 0;
+    epc.assign(imax - imin + 1, 0);
+    for (int h = 0; h < n; ++h) if (assign[h] == c) epc[sp[h].i - imin]++;
+    for (int i = imin; i <= imax; ++i) if (epc[i - imin] >= epc_threshold) { best_i = i; break; }
+    if (best_i == 0) best_i = argmax(imax - imin + 1) + imin;
+    epc.assign(kmax - kmin + 1, 0);
+    for (int h = 0; h < n; ++h) if (assign[h] == c) epc[sp[h].k - kmin]++;
+    for (int k = kmin; k <= kmax; ++k) if (epc[k - kmin] >= epc_threshold) { best_k = k; break; }
+    if (best_k == 0) best_k = argmax(kmax - kmin + 1) + kmin;
+    epc.assign(jmax - jmin + 1, 0);
+    for (int h = 0; h < n; ++h) if (assign[h] == c) epc[sp[h].j - jmin]++;
+    for (int j = jmax; j >= jmin; --j) if (epc[j - jmin] >= epc_threshold) { best_j = j; break; }
+    if (best_j == 0) best_j = argmax(jmax - jmin + 1) + jmin;
+    epc.assign(mmax - mmin + 1, 0);
+    for (int h = 0; h < n; ++h) if (assign[h] == c) epc[sp[h].m - mmin]++;
+    for (int m = mmax; m >= mmin; --m) if (epc[m - mmin] >= epc_threshold) { best_m = m; break; }
+    if (best_m == 0) best_m = argmax(mmax - mmin + 1) + mmin;
+    if (best_i > best_j || best_k > best_m) continue;
+    sigc.push_back(SpCoord{ c, best_i, best_j, best_k, best_m, (float) ninc / (float) nsamples });
+  }
+  std::stable_sort(sigc.begin(), sigc.end(), [](const SpCoord &a, const SpCoord &b) { return a.i < b.i; });
+}
+
+// ---------------------------------------------------------------- p7_alidisplay_Create (domain 0 of an OA trace)
+void make_alidisplay(const Profile &p, const Trace &tr, const uint8_t *dsq, int L, Domain &dom)
+{
+  const Alphabet &abc = Alphabet::get(p.abc_type);
+  const int N = (int) tr.st.size();
+  int z1 = 0, z2;
+  for (z1 = 0; z1 < N; ++z1) if (tr.st[z1] == sB) break;
+  z1++;                                           // first state after B
+  for (z2 = z1 + 1; z2 < N; ++z2) if (tr.st[z2] == sE) break;
+  z2--;                                           // last state before E
+  dom.N = z2 - z1 + 1;
+  dom.hmmfrom = tr.k[z1]; dom.hmmto = tr.k[z2]; dom.M = p.M;
+  dom.sqfrom = tr.i[z1]; dom.sqto = tr.i[z2]; dom.L = L;
+  dom.model.assign(dom.N, ' '); dom.mline.assign(dom.N, ' '); dom.aseq.assign(dom.N, ' '); dom.ppline.assign(dom.N, ' ');
+  const bool has_rf = p.rf.size() > 1 && p.rf[0] != 0, has_mm = p.mm.size() > 1 && p.mm[0] != 0, has_cs = p.cs.size() > 1 && p.cs[0] != 0;
+  if (has_rf) dom.rfline.assign(dom.N, ' ');
+  if (has_mm) dom.mmline.assign(dom.N, ' ');
+  if (has_cs) dom.csline.assign(dom.N, ' ');
+  auto digitize = [&](char c) -> int { const char *q = std::strchr(abc.sym, std::toupper((unsigned char) c)); return q ? (int) (q - abc.sym) : -1; };
+  for (int z = z1; z <= z2; ++z) {
+    const int k = tr.k[z], i = tr.i[z], s = tr.st[z], o = z - z1;
+    const char cons = (k >= 1 && (int) p.consensus.size() > k) ? p.consensus[k] : 'x';
+    if (has_rf) dom.rfline[o] = (s == sI) ? '.' : p.rf[k];
+    if (has_mm) dom.mmline[o] = (s == sI) ? '.' : p.mm[k];
+    if (has_cs) dom.csline[o] = (s == sI) ? '.' : p.cs[k];
+    switch (s) {
+      case sM: {
+        const int x = dsq[i];
+        dom.model[o] = cons;
+        if (x == digitize(cons)) dom.mline[o] = cons;
+        else if (p.rf_[(size_t) x * (p.M + 1) + k] > 1.0f) dom.mline[o] = '+';
+        else dom.mline[o] = ' ';
+        dom.aseq[o] = (char) std::toupper((unsigned char) abc.sym[x]);
+        break;
+      }
+      case sI: dom.model[o] = '.'; dom.mline[o] = ' '; dom.aseq[o] = (char) std::tolower((unsigned char) abc.sym[dsq[i]]); break;
+      case sD: dom.model[o] = cons; dom.mline[o] = ' '; dom.aseq[o] = '-'; break;
+      default: break;
+    }
+    if (s == sD) dom.ppline[o] = '.';
+    else { const float pv = tr.pp[z]; dom.ppline[o] = (pv + 0.05 >= 1.0) ? '*' : (char) ((int) ((pv + 0.05) * 10.0) + '0'); }
+  }
+}
+
+struct Workspace { Matrix fwd, bck; Trace tr; std::vector<float> wm, wi; };
+
+// ---------------------------------------------------------------- rescore_isolated_domain
+int rescore_isolated_domain(const Profile &p, Model &om, const uint8_t *dsq, int L, int i, int j, bool null2_is_done,
+                            Workspace &ws, DomainDefResult &dd)
+{
+  const int Ld = j - i + 1;
+  float envsc = 0.0f, oasc = 0.0f;
+  forward_full(om, dsq + i - 1, Ld, ws.fwd, &envsc);
+  backward_full(om, dsq + i - 1, Ld, ws.fwd, ws.bck, nullptr);
+  if (decoding(om, ws.fwd, ws.bck) == P7X_ERANGE) return P7X_ENORESULT;   // repetitive garbage; the envelope is dropped
+  optimal_accuracy(om, ws.bck, ws.fwd, &oasc);                              // <fwd> now holds the OA matrix
+  if (oa_trace(om, ws.bck, ws.fwd, ws.tr) != P7X_OK) return P7X_EINVAL;
+  for (size_t z = 0; z < ws.tr.st.size(); ++z) if (ws.tr.i[z] > 0) ws.tr.i[z] += i - 1;
+  Domain dom;
+  make_alidisplay(p, ws.tr, dsq, L, dom);
+  float domcorrection = 0.0f;
+  if (!null2_is_done) {
+    float null2[MAXKP];
+    null2_by_expectation(om, ws.bck, null2);
+    for (int pos = i; pos <= j; ++pos) dd.n2sc[pos] = logf(null2[dsq[pos]]);
+  }
+  for (int pos = i; pos <= j; ++pos) domcorrection += dd.n2sc[pos];
+  dom.domcorrection = domcorrection;
+  dom.ienv = i; dom.jenv = j; dom.envsc = envsc; dom.oasc = oasc;
+  dom.iali = dom.sqfrom; dom.jali = dom.sqto;
+  dd.dcl.push_back(std::move(dom));
+  return P7X_OK;
+}
+
+} // anonymous namespace
+
+// ---------------------------------------------------------------- p7_domaindef_ByPosteriorHeuristics
+int domaindef_by_posterior_heuristics(const Profile &p, const uint8_t *dsq, int L, const float *fx, const float *bx,
+                                      uint32_t seed, bool do_reseeding, DomainDefResult &dd)
+{
+  const float rt1 = 0.25f, rt2 = 0.10f, rt3 = 0.20f;                         // p7_domaindef.pxd:39-41
+  const int nsamples = 200;                                                  // p7_domaindef.pxd:43-48
+  const float min_overlap = 0.8f, min_posterior = 0.25f, min_endpointp = 0.02f;
+  const bool of_smaller = true; const int max_diagdiff = 4;
+
+  Model om{ &p, p.M, {} };
+  thread_local Workspace ws;
+  dd.dcl.clear(); dd.n2sc.assign(L + 1, 0.0f);
+  dd.nregions = dd.nclustered = dd.noverlaps = dd.nenvelopes = 0;
+
+  // p7_DomainDecoding from the parsers' special rows (multihit configuration of the whole target)
+  om.configure(true, L);
+  std::vector<float> btot(L + 1), etot(L + 1), mocc(L + 1);
+  {
+    float scaleproduct = 1.0 / bx[0 * NX + xN_];
+    btot[0] = etot[0] = mocc[0] = 0.0f;
+    for (int i = 1; i <= L; ++i) {
+      btot[i] = btot[i - 1] + (fx[(i - 1) * NX + xB_] * bx[(i - 1) * NX + xB_]) * fx[(i - 1) * NX + xS_] * scaleproduct;
+      etot[i] = etot[i - 1] + (fx[i * NX + xE_] * bx[i * NX + xE_]) * fx[i * NX + xS_] * scaleproduct;
+      float njcp = fx[(i - 1) * NX + xN_] * bx[i * NX + xN_] * om.xf[XN][LOOP] * scaleproduct;
+      njcp += fx[(i - 1) * NX + xJ_] * bx[i * NX + xJ_] * om.xf[XJ][LOOP] * scaleproduct;
+      njcp += fx[(i - 1) * NX + xC_] * bx[i * NX + xC_] * om.xf[XC][LOOP] * scaleproduct;
+      mocc[i] = 1. - njcp;
+    }
+    if (std::isinf(scaleproduct)) return P7X_ERANGE;
+  }
+  dd.nexpected = btot[L];
+
+  FastRng rng; rng.init(seed);
+  om.configure(false, L);           // every envelope is rescored in unihit mode, with the full-length length model
+  int i = -1; bool triggered = false;
+  for (int j = 1; j <= L; ++j) {
+    if (!triggered) {
+      if (mocc[j] - (btot[j] - btot[j - 1]) < rt2) i = j;
+      else if (i == -1) i = j;
+      if (mocc[j] >= rt1) triggered = true;
+    } else if (mocc[j] - (etot[j] - etot[j - 1]) < rt2) {
+      dd.nregions++;
+      // is_multidomain_region
+      float mx = -1.0f;
+      for (int z = i; z <= j; ++z) mx = std::max(mx, std::min(etot[z] - etot[i - 1], btot[j] - btot[z - 1]));
+      if (mx >= rt3) {
+        dd.nclustered++;
+        // region_trace_ensemble: sample tracebacks from a multihit Forward matrix of the region, cluster them
+        om.configure(true, L);
+        forward_full(om, dsq + i - 1, j - i + 1, ws.fwd, nullptr);
+        const int Lr = j - i + 1;
+        for (int pos = i; pos <= j; ++pos) dd.n2sc[pos] = 0.0f;
+        if (do_reseeding) rng.init(seed);
+        std::vector<SpCoord> sp;
+        float null2[MAXKP];
+        for (int t = 0; t < nsamples; ++t) {
+          if (stochastic_trace(rng, om, ws.fwd, Lr, ws.tr) != P7X_OK) return P7X_EINVAL;
+          ws.tr.index();
+          int pos = 1;
+          for (int d = 0; d < ws.tr.ndom; ++d) {
+            sp.push_back(SpCoord{ t, ws.tr.sqfrom[d] + i - 1, ws.tr.sqto[d] + i - 1, ws.tr.hmmfrom[d], ws.tr.hmmto[d], 0.0f });
+            null2_by_trace(om, ws.tr, ws.tr.tfrom[d], ws.tr.tto[d], ws.wm, ws.wi, null2);
+            for (; pos <= ws.tr.sqfrom[d]; ++pos) dd.n2sc[i + pos - 1] += 1.0f;
+            for (; pos <= ws.tr.sqto[d]; ++pos) dd.n2sc[i + pos - 1] += null2[dsq[i + pos - 1]];
+          }
+          for (; pos <= Lr; ++pos) dd.n2sc[i + pos - 1] += 1.0f;
+        }
+        for (int pos = i; pos <= j; ++pos) dd.n2sc[pos] = logf(dd.n2sc[pos] / (float) nsamples);
+        std::vector<SpCoord> sigc;
+        sp_cluster(sp, nsamples, min_overlap, of_smaller, max_diagdiff, min_posterior, min_endpointp, sigc);
+        // remove envelopes dominated (>= 80% overlap of the smaller) by a more probable one
+        const int nc0 = (int) sigc.size();
+        std::vector<char> dominated(nc0, 0);
+        for (int d = 0; d < nc0; ++d)
+          for (int d2 = d + 1; d2 < nc0; ++d2) {
+            const int nov = std::min(sigc[d].j, sigc[d2].j) - std::max(sigc[d].i, sigc[d2].i) + 1;
+            if (nov == 0) break;
+            const int n = std::min(sigc[d].j - sigc[d].i + 1, sigc[d2].j - sigc[d2].i + 1);
+            if ((float) nov / (float) n >= 0.8f) { if (sigc[d].prob > sigc[d2].prob) dominated[d2] = 1; else dominated[d] = 1; }
+          }
+        om.configure(false, L);
+        int last_j2 = 0;
+        for (int d = 0; d < nc0; ++d) {
+          if (dominated[d]) continue;
+          const int i2 = sigc[d].i, j2 = sigc[d].j;
+          if (i2 <= last_j2) dd.noverlaps++;
+          dd.nenvelopes++;
+          if (rescore_isolated_domain(p, om, dsq, L, i2, j2, true, ws, dd) == P7X_OK) last_j2 = j2;
+        }
+      } else {
+        dd.nenvelopes++;
+        rescore_isolated_domain(p, om, dsq, L, i, j, false, ws, dd);
+      }
+      i = -1; triggered = false;
+    }
+  }
+  return P7X_OK;
+}
+
+} // namespace p7x

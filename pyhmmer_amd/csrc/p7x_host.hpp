@@ -1,0 +1,73 @@
+// p7x_host.hpp -- host-side post-processing of Forward survivors: domain definition and hit lists.
+#pragma once
+#include "p7x_internal.hpp"
+#include <memory>
+#include <string>
+#include <vector>
+
+struct p7x_seqdb;
+
+namespace p7x {
+
+// One domain as p7_domaindef + p7_Pipeline leave it (P7_DOMAIN, p7_domain.pxd:10-26) with its
+// alignment display (P7_ALIDISPLAY, p7_alidisplay.pxd:26-53).
+struct Domain {
+  int64_t ienv = 0, jenv = 0, iali = 0, jali = 0;
+  float envsc = 0, domcorrection = 0, dombias = 0, oasc = 0, bitscore = 0;
+  double lnP = 0;
+  bool is_reported = false, is_included = false;
+  // alignment display
+  int N = 0, hmmfrom = 0, hmmto = 0, M = 0;
+  int64_t sqfrom = 0, sqto = 0, L = 0;
+  std::string model, mline, aseq, ppline, rfline, mmline, csline;
+};
+
+struct DomainDefResult {      // the P7_DOMAINDEF fields p7_Pipeline reads (p7_domaindef.pxd:23-59)
+  std::vector<Domain> dcl;
+  std::vector<float> n2sc;    // [L+1]
+  float nexpected = 0;
+  int nregions = 0, nclustered = 0, noverlaps = 0, nenvelopes = 0;
+};
+
+// p7_domaindef_ByPosteriorHeuristics (p7_domaindef.pxd:69-72).  dsq is 1-indexed (dsq[1..L]);
+// fwd_xmx / bck_xmx are the parsers' special-state rows, (L+1) x [E,N,J,B,C,SCALE].
+int domaindef_by_posterior_heuristics(const Profile &p, const uint8_t *dsq, int L, const float *fwd_xmx,
+                                      const float *bck_xmx, uint32_t seed, bool do_reseeding, DomainDefResult &out);
+
+struct Hit {                  // P7_HIT, p7_hit.pxd:27-58
+  std::string name, acc, desc;
+  bool has_acc = false, has_desc = false;
+  int64_t seqidx = 0;
+  double sortkey = 0;
+  float score = 0, pre_score = 0, sum_score = 0;
+  double lnP = 0, pre_lnP = 0, sum_lnP = 0;
+  float nexpected = 0;
+  int nregions = 0, nclustered = 0, noverlaps = 0, nenvelopes = 0, ndom = 0;
+  uint32_t flags = 0;
+  int nreported = 0, nincluded = 0, best_domain = 0;
+  std::vector<Domain> dcl;
+};
+
+int host_finish_search(const p7x_pipeline_cfg &cfg, const p7x_oprofile *om, const p7x_seqdb *db,
+                       const char *const *names, const char *const *accs, const char *const *descs,
+                       const std::vector<int32_t> &fin_slots, const std::vector<float> &usc,
+                       const std::vector<float> &filtersc, const std::vector<float> &fwdsc,
+                       const std::vector<float> &fwd_xmx, const std::vector<float> &bck_xmx,
+                       const std::vector<int64_t> &xmx_off, const int *counts, const double *ms, p7x_tophits **out);
+void tophits_set_total_ms(p7x_tophits *th, double ms);
+float kahan_fsum(const float *v, int n);
+
+} // namespace p7x
+
+struct p7x_tophits {
+  std::vector<p7x::Hit> hits;         // storage order
+  std::vector<int> order;             // presentation order (indices into hits)
+  p7x_pipeline_cfg cfg{};             // copy of the pipeline configuration, Z/domZ as finally set
+  p7x_counters ctr{};
+  std::string qname, qacc, qdesc;     // the query (model) the alignment displays refer to
+  bool q_has_acc = false, q_has_desc = false;
+  int M = 0;
+  double ms[8]{};
+  bool sorted_by_key = false;
+  int64_t nreported = 0, nincluded = 0;
+};

@@ -71,6 +71,10 @@ void   flogsum_init();
 float  flogsum(float a, float b);
 
 void set_error(const std::string &msg);
+}
+struct p7x_oprofile;
+namespace p7x {
+void attach_dev_cache(p7x_oprofile *om);
 
 } // namespace p7x
 

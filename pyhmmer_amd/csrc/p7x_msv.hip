@@ -1,0 +1,253 @@
+// p7x_msv.hip -- MSV filter on CDNA4 (gfx950): one target sequence per LANE, DP row in VGPRs.
+//
+// Computes exactly p7_MSVFilter's integer end state xJ (upstream impl_sse/msvfilter.c; reference
+// impl_sse/__init__.pxd:12, plan7.pyx:5005) for every target of a packed sequence database.
+//
+// Why lane-per-sequence and not block-per-comparison: the MSV recurrence
+//     M_i[k] = sat_u8( sat_u8( max(M_{i-1}[k-1], xB) + bias ) - rbv[x_i][k] ),   xE = max_k M_i[k]
+// needs xE -> xJ -> xB before the next row can start.  Spreading one comparison over a wavefront
+// puts a 64-lane max-reduction + broadcast on that serial chain for every residue; keeping the whole
+// row inside one lane removes every cross-lane operation and leaves 1.5 VALU ops per DP cell:
+//   * values live in packed signed 16-bit pairs (v_pk_max_i16 / v_pk_add_u16): two cells per VGPR;
+//   * the diagonal move k-1 -> k is free: odd rows keep register j = cells (2j-1, 2j), even rows
+//     cells (2j, 2j+1); an odd row reads the register below it, an even row updates in place, and each
+//     alignment has its own emission table in LDS ("odd"/"even" parity tables);
+//   * unsigned-byte saturation is reproduced exactly without clamps: floor-at-0 is redundant because
+//     the next row takes max(., xB) with xB >= 0 and xE is floored once per row; clip-at-255 can only
+//     happen after a row whose xE >= 255 - bias, i.e. after p7_MSVFilter has already returned eslERANGE
+//     -- we track the running row maximum and report overflow (xJ = -1) for exactly those targets;
+//   * emission lookups are per-lane LDS gathers with ds_read_b64; the table row stride S (dwords)
+//     has S/2 odd so the <=32 residue rows fall on distinct bank pairs: conflict-free;
+//   * residues arrive as coalesced 16-byte loads from 64-sequence interleaved tiles (p7x_seqdb).
+#include "p7x_device.hpp"
+#include "p7x_kernels.hpp"
+
+namespace p7x {
+
+typedef short s2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ s2 as_s2(uint32_t u) { return __builtin_bit_cast(s2, u); }
+__device__ __forceinline__ uint32_t as_u32(s2 v) { return __builtin_bit_cast(uint32_t, v); }
+__device__ __forceinline__ s2 pk_max(s2 a, s2 b) { return __builtin_elementwise_max(a, b); }
+__device__ __forceinline__ s2 splat(int v) { s2 r; r.x = (short) v; r.y = (short) v; return r; }
+__device__ __forceinline__ s2 swap_halves(s2 v) { return as_s2(__builtin_amdgcn_alignbit(as_u32(v), as_u32(v), 16)); }
+
+
+constexpr int kMsvBlock = 256;
+
+constexpr int msv_stride_c(int R)
+{ // smallest S >= R with S/2 odd: the row -> bank-pair map 2*(x*(S/2) mod 32) is then injective for x < 32
+  int S = R + (R & 1);
+  if (((S / 2) & 1) == 0) S += 2;
+  return S;
+}
+
+// LDS emission fetch.  hipcc fuses adjacent 8-byte LDS loads into ds_read2_b64, which is serviced in
+// 16-lane groups at half the rate of ds_read_b64 and breaks the conflict-free bank map above, so the
+// loads are issued by hand: four ds_read_b64 per statement, completion counted with lgkmcnt.
+struct Chunk { uint2 e0, e1, e2, e3; };
+
+template <int OFF>
+__device__ __forceinline__ void lds_issue4(uint32_t addr, Chunk &c)
+{
+  asm volatile("ds_read_b64 %0, %4 offset:%5\n\t"
+               "ds_read_b64 %1, %4 offset:%6\n\t"
+               "ds_read_b64 %2, %4 offset:%7\n\t"
+               "ds_read_b64 %3, %4 offset:%8"
+               : "=v"(c.e0), "=v"(c.e1), "=v"(c.e2), "=v"(c.e3)
+               : "v"(addr), "i"(OFF), "i"(OFF + 8), "i"(OFF + 16), "i"(OFF + 24));
+}
+template <int PENDING>
+__device__ __forceinline__ void lds_wait(Chunk &c)
+{
+  asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(c.e0), "+v"(c.e1), "+v"(c.e2), "+v"(c.e3) : "i"(PENDING));
+}
+
+// One DP row over the register file, four register pairs (8 registers, 16 cells) per chunk.
+template <int R, bool ODD, int T>   // T = chunk index being computed
+struct RowChunks {
+  static constexpr int NT = R / 8;
+  static constexpr int S = msv_stride_c(R);
+  static constexpr int TBASE = ODD ? 0 : kTabRows * S * 4;
+
+  template <int JJ>
+  static __device__ __forceinline__ void pair(s2 (&v)[R], const uint2 e, const s2 xB, s2 &accA, s2 &accB)
+  {
+    if constexpr (ODD) {        // register j <- cells (2j-1, 2j), read from register j-1 of the previous (even) row
+      const s2 t1 = pk_max(v[2 * JJ], xB);
+      v[2 * JJ + 1] = t1 + as_s2(e.y);
+      accA = pk_max(accA, v[2 * JJ + 1]);
+      s2 t0 = xB;
+      if constexpr (JJ > 0) t0 = pk_max(v[2 * JJ - 1], xB);
+      v[2 * JJ] = t0 + as_s2(e.x);
+      accB = pk_max(accB, v[2 * JJ]);
+    } else {                    // register j <- cells (2j, 2j+1), in place
+      v[2 * JJ] = pk_max(v[2 * JJ], xB) + as_s2(e.x);
+      accA = pk_max(accA, v[2 * JJ]);
+      v[2 * JJ + 1] = pk_max(v[2 * JJ + 1], xB) + as_s2(e.y);
+      accB = pk_max(accB, v[2 * JJ + 1]);
+    }
+  }
+
+  // cur holds chunk T (already issued); nxt is free.  ODD rows walk chunks downwards, EVEN rows upwards.
+  static __device__ __forceinline__ void run(s2 (&v)[R], uint32_t addr, Chunk &cur, Chunk &nxt, const s2 xB, s2 &accA, s2 &accB)
+  {
+    constexpr bool last = ODD ? (T == 0) : (T == NT - 1);
+    constexpr int TN = ODD ? T - 1 : T + 1;
+    if constexpr (!last) lds_issue4<TBASE + TN * 32>(addr, nxt);
+    lds_wait<last ? 0 : 4>(cur);
+    if constexpr (ODD) {
+      pair<4 * T + 3>(v, cur.e3, xB, accA, accB);
+      pair<4 * T + 2>(v, cur.e2, xB, accA, accB);
+      pair<4 * T + 1>(v, cur.e1, xB, accA, accB);
+      pair<4 * T + 0>(v, cur.e0, xB, accA, accB);
+    } else {
+      pair<4 * T + 0>(v, cur.e0, xB, accA, accB);
+      pair<4 * T + 1>(v, cur.e1, xB, accA, accB);
+      pair<4 * T + 2>(v, cur.e2, xB, accA, accB);
+      pair<4 * T + 3>(v, cur.e3, xB, accA, accB);
+    }
+    if constexpr (!last) RowChunks<R, ODD, TN>::run(v, addr, nxt, cur, xB, accA, accB);
+  }
+};
+
+template <int R, bool ODD>
+__device__ __forceinline__ void msv_row(s2 (&v)[R], uint32_t x, s2 &xB, s2 &xJ, s2 &xEmax,
+                                        const s2 basev, const s2 tecv, const s2 tjbmv, const s2 zerov)
+{
+  constexpr int S = msv_stride_c(R), NT = R / 8;
+  constexpr int T0 = ODD ? NT - 1 : 0;
+  constexpr int TBASE = ODD ? 0 : kTabRows * S * 4;
+  const uint32_t addr = x * (uint32_t) (S * 4);
+  Chunk ca, cb;
+  lds_issue4<TBASE + T0 * 32>(addr, ca);
+  s2 accA = splat(kNegPad), accB = accA;
+  RowChunks<R, ODD, T0>::run(v, addr, ca, cb, xB, accA, accB);
+  s2 m = pk_max(accA, accB);
+  m = pk_max(m, swap_halves(m));
+  xEmax = pk_max(xEmax, m);          // running row maximum: overflow <=> some xE >= 255 - bias
+  m = m - tecv;
+  xJ = pk_max(xJ, m);
+  xB = pk_max(pk_max(basev, xJ) - tjbmv, zerov);
+}
+
+template <int R>
+__global__ void __launch_bounds__(kMsvBlock) msv_kernel(const MsvArgs a)
+{
+  extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
+  constexpr int S = msv_stride_c(R);
+  {
+    constexpr int n4 = (2 * kTabRows * S) / 4;
+    const uint4 *src = reinterpret_cast<const uint4 *>(a.tab);
+    uint4 *dst = reinterpret_cast<uint4 *>(lds);
+    for (int i = threadIdx.x; i < n4; i += kMsvBlock) dst[i] = src[i];
+  }
+  __syncthreads();
+
+  const int lane = threadIdx.x & 63;
+  const s2 basev = splat(a.base), tecv = splat(a.tec), zerov = splat(0);
+
+  for (;;) {
+    int g = 0;
+    if (lane == 0) g = atomicAdd(a.counter, 1);
+    g = __builtin_amdgcn_readfirstlane(g);
+    if (g >= a.ngroups) break;
+
+    const int slot = g * 64 + lane;
+    const int L = a.slot_len[slot];
+    const int nblk = a.grp_nblk[g];
+    const uint4 *tp = a.tiles + a.grp_off[g] + lane;
+    const s2 tjbmv = splat((int) a.tjb_tab[L] + a.tbm);
+
+    s2 v[R];
+#pragma unroll
+    for (int j = 0; j < R; ++j) v[j] = zerov;
+    s2 xJ = zerov, xEmax = zerov;
+    s2 xB = pk_max(basev - tjbmv, zerov);
+
+    uint4 cur = tp[0];
+    for (int b = 0; b < nblk; ++b) {
+      const uint4 nxt = (b + 1 < nblk) ? tp[(size_t) (b + 1) * 64] : cur;   // prefetch the next 16 residues
+      uint32_t w0 = cur.x, w1 = cur.y, w2 = cur.z, w3 = cur.w;
+#pragma unroll 1
+      for (int c = 0; c < 8; ++c) {
+        const uint32_t x0 = w0 & 0xffu, x1 = (w0 >> 8) & 0xffu;
+        w0 = __builtin_amdgcn_alignbit(w1, w0, 16); w1 = __builtin_amdgcn_alignbit(w2, w1, 16);
+        w2 = __builtin_amdgcn_alignbit(w3, w2, 16); w3 >>= 16;
+        msv_row<R, true >(v, x0, xB, xJ, xEmax, basev, tecv, tjbmv, zerov);
+        msv_row<R, false>(v, x1, xB, xJ, xEmax, basev, tecv, tjbmv, zerov);
+      }
+      cur = nxt;
+    }
+    if (L > 0) {
+      const int xe = xEmax.x;
+      a.out_xJ[slot] = (xe >= 255 - a.bias) ? (int16_t) -1 : (int16_t) xJ.x;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------- host side
+
+static const int kRList[] = { 8, 16, 24, 32, 40, 48, 56, 64, 72, 80, 88, 96, 104, 112, 120, 128, 136, 144, 152, 160,
+                              176, 192, 208, 224, 240 };
+
+int msv_pick_R(int M)
+{
+  const int need = M / 2 + 1;
+  for (int r : kRList) if (r >= need) return r;
+  return -1;
+}
+
+int msv_stride(int R) { return msv_stride_c(R); }
+
+// Build the two parity tables from un-striped biased costs rb[x][k] (k = 1..M):
+//   signed emission s[x][k] = bias - rb[x][k]  (the value sbv holds, impl_sse/p7_oprofile.pxd: sbv)
+//   odd  table, register j: (s[2j-1], s[2j]);  even table, register j: (s[2j], s[2j+1])
+// nodes < 1 or > M, and the pad residue row, get kNegPad.
+void msv_build_tables(const Profile &p, int R, int S, std::vector<uint32_t> &out)
+{
+  out.assign((size_t) 2 * kTabRows * S, 0);
+  auto sval = [&](int x, int k) -> int {
+    if (x >= p.Kp || k < 1 || k > p.M) return kNegPad;
+    return (int) p.bias_b - (int) p.rb[(size_t) x * (p.M + 1) + k];
+  };
+  auto pack = [](int lo, int hi) -> uint32_t { return ((uint32_t) (uint16_t) (int16_t) lo) | ((uint32_t) (uint16_t) (int16_t) hi << 16); };
+  for (int x = 0; x < kTabRows; ++x)
+    for (int j = 0; j < S; ++j) {
+      const bool live = j < R;
+      out[((size_t) 0 * kTabRows + x) * S + j] = live ? pack(sval(x, 2 * j - 1), sval(x, 2 * j)) : pack(kNegPad, kNegPad);
+      out[((size_t) 1 * kTabRows + x) * S + j] = live ? pack(sval(x, 2 * j), sval(x, 2 * j + 1)) : pack(kNegPad, kNegPad);
+    }
+}
+
+template <int R>
+static int launch_R(const MsvArgs &a, int num_cu, hipStream_t st)
+{
+  const size_t lds_bytes = (size_t) 2 * kTabRows * msv_stride_c(R) * 4;
+  if (lds_bytes > 64 * 1024)
+    P7X_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&msv_kernel<R>), hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds_bytes));
+  int per_cu = 0;
+  P7X_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, msv_kernel<R>, kMsvBlock, lds_bytes));
+  if (per_cu < 1) per_cu = 1;
+  long want = ((long) a.ngroups + 3) / 4;
+  long grid = (long) num_cu * per_cu;
+  if (grid > want) grid = want;
+  if (grid < 1) grid = 1;
+  hipLaunchKernelGGL(msv_kernel<R>, dim3((unsigned) grid), dim3(kMsvBlock), lds_bytes, st, a);
+  P7X_HIP(hipGetLastError());
+  return P7X_OK;
+}
+
+int msv_launch(int R, const MsvArgs &a, int num_cu, hipStream_t st)
+{
+  switch (R) {
+#define P7X_CASE(r) case r: return launch_R<r>(a, num_cu, st);
+    P7X_CASE(8) P7X_CASE(16) P7X_CASE(24) P7X_CASE(32) P7X_CASE(40) P7X_CASE(48) P7X_CASE(56) P7X_CASE(64) P7X_CASE(72)
+    P7X_CASE(80) P7X_CASE(88) P7X_CASE(96) P7X_CASE(104) P7X_CASE(112) P7X_CASE(120) P7X_CASE(128) P7X_CASE(136)
+    P7X_CASE(144) P7X_CASE(152) P7X_CASE(160) P7X_CASE(176) P7X_CASE(192) P7X_CASE(208) P7X_CASE(224) P7X_CASE(240)
+#undef P7X_CASE
+    default: set_error("msv_launch: unsupported register tile"); return P7X_EINVAL;
+  }
+}
+
+} // namespace p7x

@@ -1,0 +1,594 @@
+// p7x_pipeline.hip -- the filter cascade of p7_Pipeline on the device, plus the C-ABI entry points.
+//
+// Control flow restates upstream p7_pipeline.c:p7_Pipeline (reference p7_pipeline.pxd:130; called from
+// Pipeline._search_loop, plan7.pyx:6393-6453) for a whole DigitalSequenceBlock at once:
+//   null1 -> MSV -> P<=F1 -> bias filter -> P<=F1 -> [P>F2: Viterbi -> P<=F2] -> Forward -> P<=F3
+//   -> Backward -> (host) domain definition -> hit.
+// Every stage is a kernel over a device-resident work list; the lists are built with atomics and their
+// lengths are read by the next stage from device memory, so the cascade runs without host round trips.
+#include "p7x_device.hpp"
+#include "p7x_kernels.hpp"
+#include "p7x_host.hpp"
+#include <chrono>
+#include <cmath>
+#include <cstring>
+#include <memory>
+
+namespace p7x {
+
+// ---------------------------------------------------------------------------- device profile image
+static void chunk_transpose_fill(int M, int C, std::vector<int> &pos_of_node)
+{ // node k (1..M) -> table position c*64 + z with k = z*C + c + 1
+  pos_of_node.assign(M + 1, -1);
+  for (int k = 1; k <= M; ++k) { const int z = (k - 1) / C, c = (k - 1) % C; pos_of_node[k] = c * 64 + z; }
+}
+
+static void free_dev_profile(DevProfile *d)
+{
+  if (!d) return;
+  (void) hipSetDevice(d->device);
+  (void) hipFree(d->msv_tab); (void) hipFree(d->vit_trans); (void) hipFree(d->vit_emis);
+  (void) hipFree(d->fwd_trans); (void) hipFree(d->fwd_emis); (void) hipFree(d->bias_eo);
+  delete d;
+}
+
+struct DevCache { std::mutex mu; std::vector<DevProfile *> per_device; };
+
+static int get_dev_profile(const p7x_oprofile *om, DeviceCtx *ctx, DevProfile **out)
+{
+  auto *cache = static_cast<DevCache *>(om->dev_cache);
+  std::lock_guard<std::mutex> lk(cache->mu);
+  for (DevProfile *d : cache->per_device) if (d->device == ctx->device) { *out = d; return P7X_OK; }
+  const Profile &p = om->p;
+  auto d = std::make_unique<DevProfile>();
+  d->device = ctx->device; d->M = p.M; d->Kp = p.Kp;
+  // MSV parity tables
+  d->msvR = msv_pick_R(p.M);
+  if (d->msvR > 0) {
+    d->msvS = msv_stride(d->msvR);
+    std::vector<uint32_t> tab;
+    msv_build_tables(p, d->msvR, d->msvS, tab);
+    P7X_HIP(hipMalloc(&d->msv_tab, tab.size() * 4));
+    P7X_HIP(hipMemcpy(d->msv_tab, tab.data(), tab.size() * 4, hipMemcpyHostToDevice));
+  }
+  // wave-per-sequence tables
+  d->vitC = vit_pick_C(p.M);
+  if (d->vitC > 0) {
+    const int C = d->vitC, Mpad = 64 * C, nrows = p.Kp + 1;
+    d->Mpad = Mpad;
+    std::vector<int> pos;
+    chunk_transpose_fill(p.M, C, pos);
+    std::vector<int16_t> vt((size_t) Mpad * 8, -32768), ve((size_t) nrows * Mpad, -32768);
+    std::vector<float> ft((size_t) Mpad * 8, 0.0f), fe((size_t) nrows * Mpad, 0.0f);
+    for (int k = 1; k <= p.M; ++k) {
+      for (int t = 0; t < NTRANS; ++t) {
+        vt[(size_t) pos[k] * 8 + t] = p.tw[(size_t) t * (p.M + 1) + k];
+        ft[(size_t) pos[k] * 8 + t] = p.tf[(size_t) t * (p.M + 1) + k];
+      }
+      for (int x = 0; x < p.Kp; ++x) {
+        ve[(size_t) x * Mpad + pos[k]] = p.rw[(size_t) x * (p.M + 1) + k];
+        fe[(size_t) x * Mpad + pos[k]] = p.rf_[(size_t) x * (p.M + 1) + k];
+      }
+    }
+    P7X_HIP(hipMalloc(&d->vit_trans, vt.size() * 2)); P7X_HIP(hipMemcpy(d->vit_trans, vt.data(), vt.size() * 2, hipMemcpyHostToDevice));
+    P7X_HIP(hipMalloc(&d->vit_emis, ve.size() * 2));  P7X_HIP(hipMemcpy(d->vit_emis, ve.data(), ve.size() * 2, hipMemcpyHostToDevice));
+    P7X_HIP(hipMalloc(&d->fwd_trans, ft.size() * 4)); P7X_HIP(hipMemcpy(d->fwd_trans, ft.data(), ft.size() * 4, hipMemcpyHostToDevice));
+    P7X_HIP(hipMalloc(&d->fwd_emis, fe.size() * 4));  P7X_HIP(hipMemcpy(d->fwd_emis, fe.data(), fe.size() * 4, hipMemcpyHostToDevice));
+  }
+  // bias filter emission odds (esl_hmm_Configure on the 2-state filter HMM, p7_bg_SetFilter)
+  {
+    const Alphabet &abc = Alphabet::get(p.abc_type);
+    std::vector<float> eo((size_t) kTabRows * 2, 1.0f);
+    for (int x = 0; x < p.K; ++x) { eo[x * 2 + 0] = p.bgf[x] / p.bgf[x]; eo[x * 2 + 1] = p.compo[x] / p.bgf[x]; }
+    for (int x = p.K + 1; x <= p.Kp - 3; ++x)
+      for (int s = 0; s < 2; ++s) {
+        float e = 0.0f, den = 0.0f;
+        for (int y = 0; y < p.K; ++y) if (abc.degen[x][y]) { e += (s == 0 ? p.bgf[y] : p.compo[y]); den += p.bgf[y]; }
+        eo[x * 2 + s] = den > 0.0f ? e / den : 0.0f;
+      }
+    P7X_HIP(hipMalloc(&d->bias_eo, eo.size() * 4));
+    P7X_HIP(hipMemcpy(d->bias_eo, eo.data(), eo.size() * 4, hipMemcpyHostToDevice));
+  }
+  *out = d.get();
+  cache->per_device.push_back(d.release());
+  return P7X_OK;
+}
+
+// ---------------------------------------------------------------------------- small per-target kernels
+struct StageBufs {            // all indexed by slot unless noted
+  int16_t *xJ;                // [ngroups*64]
+  float *usc, *filtersc, *vfsc, *fwdsc;
+  int32_t *xC;                // [nslots] by Viterbi work-list position
+  float *fwd_by_item;         // [nslots] by Forward work-list position
+  int32_t *list_bias, *list_vit, *list_fwd, *list_fin;
+  int *counters;              // [0] msv groups [1] n_bias(list_bias) [2] n_vit [3] n_fwd [4] n_fin [5..7] work counters
+                              // [8] n_past_bias [9] n_past_vit(reach Forward)
+};
+
+struct StageParams {
+  double F1, F2, F3;
+  float mmu, mlambda, vmu, vlambda, ftau, flambda;
+  int do_bias;
+  int base_b, tjb_unused; float scale_b;
+  int base_w; float scale_w;
+  int M;
+};
+
+__device__ __forceinline__ double d_gumbel_surv(double x, double mu, double lambda)
+{
+  const double y = lambda * (x - mu), ey = -exp(-y);
+  return (fabs(ey) < 5e-9) ? -ey : 1 - exp(ey);
+}
+__device__ __forceinline__ double d_exp_surv(double x, double mu, double lambda) { return x < mu ? 1.0 : exp(-lambda * (x - mu)); }
+
+// after MSV: usc, P1; survivors -> list_bias
+__global__ void decide_msv_kernel(StageBufs b, StageParams p, const int32_t *slot_len, const uint8_t *tjb_tab,
+                                  const float *null1_tab, int64_t nslots)
+{
+  const int64_t s = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
+  if (s >= nslots) return;
+  const int L = slot_len[s];
+  const int xJ = b.xJ[s];
+  float usc;
+  if (xJ < 0) usc = __builtin_inff();
+  else {
+    usc = ((float) (xJ - (int) tjb_tab[L]) - (float) p.base_b);
+    usc /= p.scale_b;
+    usc -= 3.0f;
+  }
+  b.usc[s] = usc;
+  const float seq_score = (float) ((double) (usc - null1_tab[L]) / kLog2);
+  const double P = d_gumbel_surv((double) seq_score, (double) p.mmu, (double) p.mlambda);
+  if (P > p.F1) return;
+  const int idx = atomicAdd(&b.counters[1], 1);
+  b.list_bias[idx] = (int32_t) s;
+}
+
+// bias filter: esl_hmm_Forward on the 2-state composition HMM (p7_bg_FilterScore); survivors -> list_vit / list_fwd
+__global__ void bias_kernel(StageBufs b, StageParams p, const uint8_t *dsq, const int64_t *slot_off,
+                            const int32_t *slot_len, const float *null1_tab, const float *eo)
+{
+  const int n = b.counters[1];
+  for (int it = blockIdx.x * blockDim.x + threadIdx.x; it < n; it += gridDim.x * blockDim.x) {
+    const int s = b.list_bias[it];
+    const int L = slot_len[s];
+    const float nullsc = null1_tab[L];
+    float filtersc = nullsc;
+    const float usc = b.usc[s];
+    double P;
+    if (p.do_bias) {
+      const uint8_t *sq = dsq + slot_off[s];
+      const float p1 = (float) L / (float) (L + 1);
+      const float L1 = (float) ((double) (float) p.M / 8.0);
+      const float t00 = p1, t01 = 1.0f - p1, t10 = 1.0f / (L1 + 1.0f), t11 = L1 / (L1 + 1.0f);
+      const float pi0 = (float) 0.999, pi1 = (float) 0.001;
+      int x = sq[0];
+      float dp0 = eo[x * 2] * pi0, dp1 = eo[x * 2 + 1] * pi1;
+      float mx = 0.0f; mx = dp0 > mx ? dp0 : mx; mx = dp1 > mx ? dp1 : mx;
+      dp0 /= mx; dp1 /= mx;
+      float logsc = 0.0f;
+      logsc += (float) log((double) mx);
+      for (int i = 1; i < L; ++i) {
+        x = sq[i];
+        float n0 = 0.0f; n0 += dp0 * t00; n0 += dp1 * t10; n0 *= eo[x * 2];
+        float n1 = 0.0f; n1 += dp0 * t01; n1 += dp1 * t11; n1 *= eo[x * 2 + 1];
+        mx = 0.0f; mx = n0 > mx ? n0 : mx; mx = n1 > mx ? n1 : mx;
+        dp0 = n0 / mx; dp1 = n1 / mx;
+        logsc += (float) log((double) mx);
+      }
+      float last = 0.0f; last += dp0 * 1.0f; last += dp1 * 1.0f;
+      logsc += (float) log((double) last);
+      filtersc = logsc + (float) L * logf(p1) + logf((float) (1. - (double) p1));
+      const float seq_score = (float) ((double) (usc - filtersc) / kLog2);
+      P = d_gumbel_surv((double) seq_score, (double) p.mmu, (double) p.mlambda);
+      b.filtersc[s] = filtersc;
+      if (P > p.F1) continue;
+    } else {
+      const float seq_score = (float) ((double) (usc - nullsc) / kLog2);
+      P = d_gumbel_surv((double) seq_score, (double) p.mmu, (double) p.mlambda);
+      b.filtersc[s] = filtersc;
+    }
+    atomicAdd(&b.counters[8], 1);
+    if (P > p.F2) { const int idx = atomicAdd(&b.counters[2], 1); b.list_vit[idx] = s; }
+    else          { const int idx = atomicAdd(&b.counters[3], 1); b.list_fwd[idx] = s; }
+  }
+}
+
+// after Viterbi: vfsc, P2; survivors -> list_fwd
+__global__ void decide_vit_kernel(StageBufs b, StageParams p, const int32_t *slot_len, const int16_t *xwmove_tab)
+{
+  const int n = b.counters[2];
+  for (int it = blockIdx.x * blockDim.x + threadIdx.x; it < n; it += gridDim.x * blockDim.x) {
+    const int s = b.list_vit[it];
+    const int L = slot_len[s];
+    const int xC = b.xC[it];
+    float vfsc;
+    if (xC >= 32767) vfsc = __builtin_inff();
+    else if (xC > -32768) {
+      vfsc = (float) xC + (float) xwmove_tab[L] - (float) p.base_w;
+      vfsc /= p.scale_w;
+      vfsc -= 3.0f;
+    } else vfsc = -__builtin_inff();
+    b.vfsc[s] = vfsc;
+    const float seq_score = (float) ((double) (vfsc - b.filtersc[s]) / kLog2);
+    const double P = d_gumbel_surv((double) seq_score, (double) p.vmu, (double) p.vlambda);
+    if (P > p.F2) continue;
+    const int idx = atomicAdd(&b.counters[3], 1);
+    b.list_fwd[idx] = s;
+  }
+}
+
+// after Forward: P3; survivors -> list_fin
+__global__ void decide_fwd_kernel(StageBufs b, StageParams p)
+{
+  const int n = b.counters[3];
+  for (int it = blockIdx.x * blockDim.x + threadIdx.x; it < n; it += gridDim.x * blockDim.x) {
+    const int s = b.list_fwd[it];
+    const float fwdsc = b.fwd_by_item[it];
+    b.fwdsc[s] = fwdsc;
+    const float seq_score = (float) ((double) (fwdsc - b.filtersc[s]) / kLog2);
+    const double P = d_exp_surv((double) seq_score, (double) p.ftau, (double) p.flambda);
+    if (P > p.F3) continue;
+    const int idx = atomicAdd(&b.counters[4], 1);
+    b.list_fin[idx] = s;
+  }
+}
+
+// ---------------------------------------------------------------------------- workspace
+struct Workspace {
+  int device = -1; int64_t cap_slots = 0;
+  StageBufs b{};
+  float *xmx_f = nullptr, *xmx_b = nullptr; int64_t xmx_cap = 0; int64_t *xmx_off = nullptr; int64_t xmx_off_cap = 0;
+  hipEvent_t ev[8]{};
+  ~Workspace() {
+    if (device < 0) return;
+    (void) hipSetDevice(device);
+    (void) hipFree(b.xJ); (void) hipFree(b.usc); (void) hipFree(b.filtersc); (void) hipFree(b.vfsc); (void) hipFree(b.fwdsc);
+    (void) hipFree(b.xC); (void) hipFree(b.fwd_by_item); (void) hipFree(b.list_bias); (void) hipFree(b.list_vit);
+    (void) hipFree(b.list_fwd); (void) hipFree(b.list_fin); (void) hipFree(b.counters);
+    (void) hipFree(xmx_f); (void) hipFree(xmx_b); (void) hipFree(xmx_off);
+    for (auto &e : ev) if (e) (void) hipEventDestroy(e);
+  }
+};
+
+static thread_local std::vector<std::unique_ptr<Workspace>> tl_ws;
+
+static int get_workspace(int device, int64_t nslots, Workspace **out)
+{
+  for (auto &w : tl_ws) if (w->device == device && w->cap_slots >= nslots) { *out = w.get(); return P7X_OK; }
+  auto w = std::make_unique<Workspace>();
+  w->device = device;
+  const int64_t cap = std::max<int64_t>(64, ((nslots + 63) / 64) * 64);
+  w->cap_slots = cap;
+  P7X_HIP(hipMalloc(&w->b.xJ, cap * 2));
+  P7X_HIP(hipMalloc(&w->b.usc, cap * 4)); P7X_HIP(hipMalloc(&w->b.filtersc, cap * 4));
+  P7X_HIP(hipMalloc(&w->b.vfsc, cap * 4)); P7X_HIP(hipMalloc(&w->b.fwdsc, cap * 4));
+  P7X_HIP(hipMalloc(&w->b.xC, cap * 4)); P7X_HIP(hipMalloc(&w->b.fwd_by_item, cap * 4));
+  P7X_HIP(hipMalloc(&w->b.list_bias, cap * 4)); P7X_HIP(hipMalloc(&w->b.list_vit, cap * 4));
+  P7X_HIP(hipMalloc(&w->b.list_fwd, cap * 4)); P7X_HIP(hipMalloc(&w->b.list_fin, cap * 4));
+  P7X_HIP(hipMalloc(&w->b.counters, 16 * 4));
+  for (auto &e : w->ev) P7X_HIP(hipEventCreate(&e));
+  *out = w.get();
+  tl_ws.push_back(std::move(w));
+  return P7X_OK;
+}
+
+static StageParams make_params(const Profile &p, const p7x_pipeline_cfg &cfg)
+{
+  StageParams s{};
+  s.F1 = cfg.do_max ? 1.0 : cfg.F1; s.F2 = cfg.do_max ? 1.0 : cfg.F2; s.F3 = cfg.do_max ? 1.0 : cfg.F3;
+  s.mmu = p.evparam[P7X_MMU]; s.mlambda = p.evparam[P7X_MLAMBDA]; s.vmu = p.evparam[P7X_VMU];
+  s.vlambda = p.evparam[P7X_VLAMBDA]; s.ftau = p.evparam[P7X_FTAU]; s.flambda = p.evparam[P7X_FLAMBDA];
+  s.do_bias = cfg.do_max ? 0 : cfg.do_biasfilter;
+  s.base_b = p.base_b; s.scale_b = p.scale_b; s.base_w = p.base_w; s.scale_w = p.scale_w; s.M = p.M;
+  return s;
+}
+
+static WaveSeqArgs ws_args(const Profile &p, const DevProfile *dp, const p7x_seqdb *db, DeviceCtx *ctx)
+{
+  WaveSeqArgs a{};
+  a.M = p.M; a.C = dp->vitC; a.nrows = p.Kp + 1;
+  a.dsq = db->d_dsq; a.slot_off = db->d_slot_off; a.slot_len = db->d_slot_len;
+  a.xwmove_tab = ctx->lt.xwmove; a.base_w = p.base_w; a.xw_e = p.xw[XE][MOVE]; a.ddbound = p.ddbound_w;
+  a.xf_e_move = p.xf[XE][MOVE]; a.xf_e_loop = p.xf[XE][LOOP];
+  return a;
+}
+
+// Run MSV over the whole database; leaves xJ (slot order) in ws->b.xJ.
+static int run_msv(const Profile &p, const DevProfile *dp, const p7x_seqdb *db, DeviceCtx *ctx, Workspace *ws)
+{
+  if (dp->msvR <= 0) { set_error("model too long for the MSV kernel (M > 478 is not supported yet)"); return P7X_EINVAL; }
+  MsvArgs a{};
+  a.tab = dp->msv_tab; a.tiles = db->d_tiles; a.grp_off = db->d_grp_off; a.grp_nblk = db->d_grp_nblk;
+  a.slot_len = db->d_slot_len; a.tjb_tab = ctx->lt.tjb; a.ngroups = (int) db->ngroups;
+  a.base = p.base_b; a.bias = p.bias_b; a.tec = p.tec_b; a.tbm = p.tbm_b;
+  a.counter = &ws->b.counters[0]; a.out_xJ = ws->b.xJ;
+  return msv_launch(dp->msvR, a, ctx->num_cu, ctx->stream);
+}
+
+struct CascadeOut {
+  std::vector<int32_t> fin_slots;         // survivors of the Forward filter (slot ids)
+  std::vector<float> usc, filtersc, vfsc, fwdsc;   // per survivor
+  std::vector<float> fwd_xmx, bck_xmx;    // concatenated (L+1)*6 blocks
+  std::vector<int64_t> xmx_off;
+  int counts[16]{};
+  double ms[8]{};
+};
+
+static int run_cascade(const p7x_pipeline_cfg &cfg, const p7x_oprofile *om, const p7x_seqdb *db, CascadeOut &out)
+{
+  DeviceCtx *ctx = nullptr;
+  int st = get_ctx(db->device, &ctx);
+  if (st != P7X_OK) return st;
+  const Profile &p = om->p;
+  DevProfile *dp = nullptr;
+  if ((st = get_dev_profile(om, ctx, &dp)) != P7X_OK) return st;
+  if (db->nslots == 0) return P7X_OK;
+  if (dp->vitC <= 0 || dp->vitC > 16) { set_error("model too long for the Forward kernel (M > 1024 is not supported yet)"); return P7X_EINVAL; }
+  Workspace *ws = nullptr;
+  if ((st = get_workspace(db->device, db->nslots, &ws)) != P7X_OK) return st;
+  hipStream_t s = ctx->stream;
+  const StageParams sp = make_params(p, cfg);
+  P7X_HIP(hipMemsetAsync(ws->b.counters, 0, 16 * 4, s));
+  P7X_HIP(hipEventRecord(ws->ev[0], s));
+  if ((st = run_msv(p, dp, db, ctx, ws)) != P7X_OK) return st;
+  {
+    const unsigned grid = (unsigned) ((db->nslots + 255) / 256);
+    hipLaunchKernelGGL(decide_msv_kernel, dim3(grid), dim3(256), 0, s, ws->b, sp, db->d_slot_len, ctx->lt.tjb, ctx->lt.null1, db->nslots);
+  }
+  P7X_HIP(hipEventRecord(ws->ev[1], s));
+  hipLaunchKernelGGL(bias_kernel, dim3(ctx->num_cu * 4), dim3(64), 0, s, ws->b, sp, db->d_dsq, db->d_slot_off, db->d_slot_len,
+                     ctx->lt.null1, dp->bias_eo);
+  P7X_HIP(hipEventRecord(ws->ev[2], s));
+  {
+    WaveSeqArgs a = ws_args(p, dp, db, ctx);
+    a.trans = dp->vit_trans; a.emis = dp->vit_emis; a.list = ws->b.list_vit; a.nlist_ptr = &ws->b.counters[2];
+    a.counter = &ws->b.counters[5]; a.out_xC = ws->b.xC;
+    if ((st = vit_launch(a, ctx->num_cu, s)) != P7X_OK) return st;
+    hipLaunchKernelGGL(decide_vit_kernel, dim3(ctx->num_cu), dim3(256), 0, s, ws->b, sp, db->d_slot_len, ctx->lt.xwmove);
+  }
+  P7X_HIP(hipEventRecord(ws->ev[3], s));
+  {
+    WaveSeqArgs a = ws_args(p, dp, db, ctx);
+    a.trans = dp->fwd_trans; a.emis = dp->fwd_emis; a.list = ws->b.list_fwd; a.nlist_ptr = &ws->b.counters[3];
+    a.counter = &ws->b.counters[6]; a.out_sc = ws->b.fwd_by_item;
+    if ((st = fwd_launch(a, ctx->num_cu, s)) != P7X_OK) return st;
+    hipLaunchKernelGGL(decide_fwd_kernel, dim3(ctx->num_cu), dim3(256), 0, s, ws->b, sp);
+  }
+  P7X_HIP(hipEventRecord(ws->ev[4], s));
+  P7X_HIP(hipMemcpyAsync(out.counts, ws->b.counters, 16 * 4, hipMemcpyDeviceToHost, s));
+  P7X_HIP(hipStreamSynchronize(s));
+  // ---- survivors: Forward again with the special-state rows kept, then Backward
+  const int nfin = out.counts[4];
+  out.fin_slots.resize(nfin);
+  out.usc.resize(nfin); out.filtersc.resize(nfin); out.vfsc.resize(nfin); out.fwdsc.resize(nfin); out.xmx_off.resize(nfin);
+  if (nfin > 0) {
+    P7X_HIP(hipMemcpy(out.fin_slots.data(), ws->b.list_fin, (size_t) nfin * 4, hipMemcpyDeviceToHost));
+    std::sort(out.fin_slots.begin(), out.fin_slots.end());         // deterministic order
+    P7X_HIP(hipMemcpy(ws->b.list_fin, out.fin_slots.data(), (size_t) nfin * 4, hipMemcpyHostToDevice));
+    int64_t tot = 0;
+    for (int i = 0; i < nfin; ++i) {
+      out.xmx_off[i] = tot;
+      tot += (int64_t) (db->h_len[db->h_order[out.fin_slots[i]]] + 1) * 6;
+    }
+    if (tot > ws->xmx_cap) {
+      (void) hipFree(ws->xmx_f); (void) hipFree(ws->xmx_b); ws->xmx_f = ws->xmx_b = nullptr;
+      P7X_HIP(hipMalloc(&ws->xmx_f, (size_t) tot * 4)); P7X_HIP(hipMalloc(&ws->xmx_b, (size_t) tot * 4));
+      ws->xmx_cap = tot;
+    }
+    if (nfin > ws->xmx_off_cap) {
+      (void) hipFree(ws->xmx_off); ws->xmx_off = nullptr;
+      P7X_HIP(hipMalloc(&ws->xmx_off, (size_t) nfin * 8)); ws->xmx_off_cap = nfin;
+    }
+    P7X_HIP(hipMemcpyAsync(ws->xmx_off, out.xmx_off.data(), (size_t) nfin * 8, hipMemcpyHostToDevice, s));
+    P7X_HIP(hipMemsetAsync(&ws->b.counters[5], 0, 3 * 4, s));
+    WaveSeqArgs a = ws_args(p, dp, db, ctx);
+    a.trans = dp->fwd_trans; a.emis = dp->fwd_emis; a.list = ws->b.list_fin; a.nlist = nfin; a.nlist_ptr = nullptr;
+    a.counter = &ws->b.counters[5]; a.out_sc = ws->b.fwd_by_item; a.xmx = ws->xmx_f; a.xmx_off = ws->xmx_off;
+    if ((st = fwd_launch(a, ctx->num_cu, s)) != P7X_OK) return st;
+    P7X_HIP(hipEventRecord(ws->ev[5], s));
+    a.counter = &ws->b.counters[6]; a.out_sc = ws->b.vfsc /* scratch: Backward scores are not used */;
+    a.out_sc = ws->b.fwd_by_item + nfin; a.xmx = ws->xmx_b; a.fwd_xmx = ws->xmx_f;
+    if (2 * (int64_t) nfin <= ws->cap_slots) { if ((st = bck_launch(a, ctx->num_cu, s)) != P7X_OK) return st; }
+    else { set_error("workspace too small for Backward scores"); return P7X_EINVAL; }
+    P7X_HIP(hipEventRecord(ws->ev[6], s));
+    out.fwd_xmx.resize(tot); out.bck_xmx.resize(tot);
+    P7X_HIP(hipMemcpyAsync(out.fwd_xmx.data(), ws->xmx_f, (size_t) tot * 4, hipMemcpyDeviceToHost, s));
+    P7X_HIP(hipMemcpyAsync(out.bck_xmx.data(), ws->xmx_b, (size_t) tot * 4, hipMemcpyDeviceToHost, s));
+    std::vector<float> usc_all, fsc_all, vsc_all, fwd_all;
+    // gather per-survivor scores with small strided copies (nfin is tiny next to the database)
+    std::vector<float> tmp(4);
+    P7X_HIP(hipStreamSynchronize(s));
+    for (int i = 0; i < nfin; ++i) {
+      const int sl = out.fin_slots[i];
+      P7X_HIP(hipMemcpy(&out.usc[i], ws->b.usc + sl, 4, hipMemcpyDeviceToHost));
+      P7X_HIP(hipMemcpy(&out.filtersc[i], ws->b.filtersc + sl, 4, hipMemcpyDeviceToHost));
+      P7X_HIP(hipMemcpy(&out.fwdsc[i], ws->b.fwdsc + sl, 4, hipMemcpyDeviceToHost));
+    }
+  } else {
+    P7X_HIP(hipEventRecord(ws->ev[5], s)); P7X_HIP(hipEventRecord(ws->ev[6], s));
+    P7X_HIP(hipStreamSynchronize(s));
+  }
+  for (int i = 0; i < 6; ++i) { float ms = 0; (void) hipEventElapsedTime(&ms, ws->ev[i], ws->ev[i + 1]); out.ms[i] = ms; }
+  return P7X_OK;
+}
+
+} // namespace p7x
+
+using namespace p7x;
+
+extern "C" {
+
+void p7x_oprofile_destroy(p7x_oprofile *om)
+{
+  if (!om) return;
+  if (om->dev_cache) {
+    auto *cache = static_cast<DevCache *>(om->dev_cache);
+    for (DevProfile *d : cache->per_device) free_dev_profile(d);
+    delete cache;
+  }
+  delete om;
+}
+
+} // extern "C"
+
+namespace p7x { void attach_dev_cache(p7x_oprofile *om) { om->dev_cache = new DevCache(); } }
+
+extern "C" {
+
+// ---------------------------------------------------------------------------- batched raw filter outputs
+int p7x_filters_batch(const p7x_oprofile *om, const p7x_seqdb *db, int32_t *xJ, int32_t *xC, float *fwd, float *bias_filtersc)
+{
+  if (!om || !db) { set_error("p7x_filters_batch: bad arguments"); return P7X_EINVAL; }
+  DeviceCtx *ctx = nullptr;
+  int st = get_ctx(db->device, &ctx);
+  if (st != P7X_OK) return st;
+  const Profile &p = om->p;
+  DevProfile *dp = nullptr;
+  if ((st = get_dev_profile(om, ctx, &dp)) != P7X_OK) return st;
+  const int64_t ns = db->nslots;
+  for (int64_t t = 0; t < db->n; ++t) {
+    if (xJ) xJ[t] = 0;
+    if (xC) xC[t] = -32768;
+    if (fwd) fwd[t] = -INFINITY;
+    if (bias_filtersc) bias_filtersc[t] = 0.0f;
+  }
+  if (ns == 0) return P7X_OK;
+  Workspace *ws = nullptr;
+  if ((st = get_workspace(db->device, ns, &ws)) != P7X_OK) return st;
+  hipStream_t s = ctx->stream;
+  P7X_HIP(hipMemsetAsync(ws->b.counters, 0, 16 * 4, s));
+  if (xJ) {
+    if ((st = run_msv(p, dp, db, ctx, ws)) != P7X_OK) return st;
+    std::vector<int16_t> h((size_t) ns);
+    P7X_HIP(hipMemcpyAsync(h.data(), ws->b.xJ, (size_t) ns * 2, hipMemcpyDeviceToHost, s));
+    P7X_HIP(hipStreamSynchronize(s));
+    for (int64_t sl = 0; sl < ns; ++sl) xJ[db->h_order[sl]] = h[sl];
+  }
+  if (xC || fwd) {
+    if (dp->vitC <= 0) { set_error("model too long for the wave-per-sequence kernels"); return P7X_EINVAL; }
+    WaveSeqArgs a = ws_args(p, dp, db, ctx);
+    a.list = nullptr; a.nlist = (int) ns; a.nlist_ptr = nullptr;
+    if (xC) {
+      a.trans = dp->vit_trans; a.emis = dp->vit_emis; a.counter = &ws->b.counters[5]; a.out_xC = ws->b.xC;
+      if ((st = vit_launch(a, ctx->num_cu, s)) != P7X_OK) return st;
+      std::vector<int32_t> h((size_t) ns);
+      P7X_HIP(hipMemcpyAsync(h.data(), ws->b.xC, (size_t) ns * 4, hipMemcpyDeviceToHost, s));
+      P7X_HIP(hipStreamSynchronize(s));
+      for (int64_t sl = 0; sl < ns; ++sl) xC[db->h_order[sl]] = h[sl];
+    }
+    if (fwd) {
+      a.trans = dp->fwd_trans; a.emis = dp->fwd_emis; a.counter = &ws->b.counters[6]; a.out_sc = ws->b.fwd_by_item;
+      if ((st = fwd_launch(a, ctx->num_cu, s)) != P7X_OK) return st;
+      std::vector<float> h((size_t) ns);
+      P7X_HIP(hipMemcpyAsync(h.data(), ws->b.fwd_by_item, (size_t) ns * 4, hipMemcpyDeviceToHost, s));
+      P7X_HIP(hipStreamSynchronize(s));
+      for (int64_t sl = 0; sl < ns; ++sl) fwd[db->h_order[sl]] = h[sl];
+    }
+  }
+  if (bias_filtersc) {
+    // run the bias kernel over every target: list_bias = identity
+    std::vector<int32_t> ident((size_t) ns);
+    for (int64_t i = 0; i < ns; ++i) ident[i] = (int32_t) i;
+    P7X_HIP(hipMemcpyAsync(ws->b.list_bias, ident.data(), (size_t) ns * 4, hipMemcpyHostToDevice, s));
+    int cnt = (int) ns;
+    P7X_HIP(hipMemcpyAsync(&ws->b.counters[1], &cnt, 4, hipMemcpyHostToDevice, s));
+    p7x_pipeline_cfg cfg; p7x_pipeline_cfg_default(&cfg);
+    StageParams sp = make_params(p, cfg);
+    sp.F1 = 2.0; sp.F2 = 2.0;
+    std::vector<float> zero((size_t) ns, 0.0f);
+    P7X_HIP(hipMemcpyAsync(ws->b.usc, zero.data(), (size_t) ns * 4, hipMemcpyHostToDevice, s));
+    hipLaunchKernelGGL(bias_kernel, dim3(ctx->num_cu * 4), dim3(64), 0, s, ws->b, sp, db->d_dsq, db->d_slot_off, db->d_slot_len,
+                       ctx->lt.null1, dp->bias_eo);
+    std::vector<float> h((size_t) ns);
+    P7X_HIP(hipMemcpyAsync(h.data(), ws->b.filtersc, (size_t) ns * 4, hipMemcpyDeviceToHost, s));
+    P7X_HIP(hipStreamSynchronize(s));
+    for (int64_t sl = 0; sl < ns; ++sl) bias_filtersc[db->h_order[sl]] = h[sl];
+  }
+  return P7X_OK;
+}
+
+// ---------------------------------------------------------------------------- single-sequence seam
+static int one_seq(const p7x_oprofile *om, int device, const uint8_t *dsq, int32_t L, int which, float *sc)
+{
+  if (!om || !dsq || !sc || L < 1) { set_error("bad arguments"); return P7X_EINVAL; }
+  const int64_t off = 0; const int32_t len = L;
+  p7x_seqdb *db = nullptr;
+  int st = p7x_seqdb_create(device, om->p.abc_type, dsq, &off, &len, 1, &db);
+  if (st != P7X_OK) return st;
+  int32_t xJ = 0, xC = 0; float f = 0;
+  const Profile &p = om->p;
+  DeviceCtx *ctx = nullptr;
+  get_ctx(device, &ctx);
+  if (which == 0) {
+    st = p7x_filters_batch(om, db, &xJ, nullptr, nullptr, nullptr);
+    if (st == P7X_OK) {
+      if (xJ < 0) { *sc = INFINITY; st = P7X_ERANGE; }
+      else {
+        const uint8_t tjb = unbiased_byteify(p.scale_b, logf(3.0f / (float) (L + 3)));
+        float v = ((float) (xJ - tjb) - (float) p.base_b); v /= p.scale_b; v -= 3.0; *sc = v;
+      }
+    }
+  } else if (which == 1) {
+    st = p7x_filters_batch(om, db, nullptr, &xC, nullptr, nullptr);
+    if (st == P7X_OK) {
+      if (xC >= 32767) { *sc = INFINITY; st = P7X_ERANGE; }
+      else if (xC > -32768) {
+        const float pmove = 3.0f / ((float) L + 3.0f);
+        float v = (float) xC + (float) wordify(p.scale_w, logf(pmove)) - (float) p.base_w; v /= p.scale_w; v -= 3.0; *sc = v;
+      } else *sc = -INFINITY;
+    }
+  } else if (which == 2) {
+    st = p7x_filters_batch(om, db, nullptr, nullptr, &f, nullptr);
+    *sc = f;
+    if (st == P7X_OK && (std::isnan(f) || std::isinf(f))) st = P7X_ERANGE;
+  } else {
+    // Backward: run Forward with rows, then Backward
+    p7x_pipeline_cfg cfg; p7x_pipeline_cfg_default(&cfg);
+    cfg.do_max = 1;
+    CascadeOut out;
+    st = run_cascade(cfg, om, db, out);
+    if (st == P7X_OK) {
+      if (out.fin_slots.size() != 1) { set_error("backward: sequence did not reach the Backward stage"); st = P7X_EINVAL; }
+      else {
+        // score = totscale + log(xN(0)): recompute from the stored rows
+        double tot = 0.0;
+        for (int i = 1; i <= L; ++i) { const float s = out.bck_xmx[(size_t) i * 6 + 5]; if (s > 1.0f) tot += std::log((double) s); }
+        *sc = (float) (tot + std::log((double) out.bck_xmx[1]));
+      }
+    }
+  }
+  p7x_seqdb_destroy(db);
+  return st;
+}
+
+int p7x_msv_filter(const p7x_oprofile *om, int device, const uint8_t *dsq, int32_t L, float *sc) { return one_seq(om, device, dsq, L, 0, sc); }
+int p7x_vit_filter(const p7x_oprofile *om, int device, const uint8_t *dsq, int32_t L, float *sc) { return one_seq(om, device, dsq, L, 1, sc); }
+int p7x_fwd_parser(const p7x_oprofile *om, int device, const uint8_t *dsq, int32_t L, float *sc) { return one_seq(om, device, dsq, L, 2, sc); }
+int p7x_bck_parser(const p7x_oprofile *om, int device, const uint8_t *dsq, int32_t L, float *sc) { return one_seq(om, device, dsq, L, 3, sc); }
+
+// ---------------------------------------------------------------------------- the search
+int p7x_search_block(const p7x_pipeline_cfg *cfg, const p7x_oprofile *om, const float *bg_f, const p7x_seqdb *db,
+                     const char *const *names, const char *const *accs, const char *const *descs, p7x_tophits **out)
+{
+  if (!cfg || !om || !db || !out) { set_error("p7x_search_block: bad arguments"); return P7X_EINVAL; }
+  (void) bg_f;
+  const auto t0 = std::chrono::steady_clock::now();
+  if (cfg->use_bit_cutoffs) {   // p7_pli_NewModelThresholds: eslEINVAL when the model lacks the cutoffs
+    const Profile &p = om->p;
+    const int i = cfg->use_bit_cutoffs == P7X_BITCUT_GA ? P7X_GA1 : (cfg->use_bit_cutoffs == P7X_BITCUT_TC ? P7X_TC1 : P7X_NC1);
+    if (p.cutoff[i] == P7X_CUTOFF_UNSET || p.cutoff[i + 1] == P7X_CUTOFF_UNSET) { set_error("model is missing the requested bit score cutoffs"); return P7X_EINVAL; }
+  }
+  CascadeOut co;
+  int st = run_cascade(*cfg, om, db, co);
+  if (st != P7X_OK) return st;
+  st = host_finish_search(*cfg, om, db, names, accs, descs, co.fin_slots, co.usc, co.filtersc, co.fwdsc,
+                          co.fwd_xmx, co.bck_xmx, co.xmx_off, co.counts, co.ms, out);
+  if (st == P7X_OK) {
+    const double total = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    tophits_set_total_ms(*out, total);
+  }
+  return st;
+}
+
+} // extern "C"

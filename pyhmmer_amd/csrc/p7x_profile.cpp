@@ -293,6 +293,7 @@ int p7x_oprofile_create(const p7x_hmm_view *h, const float *bg_f, int32_t L, p7x
   convert_msv(p);
   convert_viterbi(p);
   convert_forward(p);
+  attach_dev_cache(om);
   *out = om;
   return P7X_OK;
 }
@@ -396,7 +397,6 @@ int64_t p7x_oprofile_striped(const p7x_oprofile *om, int which, void *out, size_
   }
 }
 
-void p7x_oprofile_destroy(p7x_oprofile *om);   // defined in p7x_device.hip (releases the device cache)
 
 void p7x_pipeline_cfg_default(p7x_pipeline_cfg *c)
 { // p7_pipeline_Create(NULL, ...) defaults; pyhmmer plan7.pyx:5413-5421

@@ -1,0 +1,367 @@
+// p7x_tophits.cpp -- from Forward survivors to a thresholded, sorted hit list (host side).
+//
+// Restates the tail of upstream p7_pipeline.c:p7_Pipeline (after the Backward parser; reference
+// p7_pipeline.pxd:130) and upstream p7_tophits.c: p7_tophits_SortBySortkey, p7_tophits_Threshold,
+// p7_tophits_Merge + p7_pipeline_Merge (reference p7_tophits.pxd:20-72; plan7.pyx:8804-8830, 9172-9276).
+#include "p7x_host.hpp"
+#include "p7x_device.hpp"
+#include <algorithm>
+#include <atomic>
+#include <chrono>
+#include <cmath>
+#include <cstring>
+#include <thread>
+
+namespace p7x {
+
+static bool target_reportable(const p7x_pipeline_cfg &c, double Z, float score, double lnP)
+{
+  if (c.by_E) return std::exp(lnP) * Z <= c.E;
+  return score >= c.T;
+}
+static bool target_includable(const p7x_pipeline_cfg &c, double Z, float score, double lnP)
+{
+  if (c.inc_by_E) return std::exp(lnP) * Z <= c.incE;
+  return score >= c.incT;
+}
+static bool domain_reportable(const p7x_pipeline_cfg &c, double domZ, float score, double lnP)
+{
+  if (c.dom_by_E) return std::exp(lnP) * domZ <= c.domE;
+  return score >= c.domT;
+}
+static bool domain_includable(const p7x_pipeline_cfg &c, double domZ, float score, double lnP)
+{
+  if (c.incdom_by_E) return std::exp(lnP) * domZ <= c.incdomE;
+  return score >= c.incdomT;
+}
+
+// model-specific thresholds (p7_pli_NewModelThresholds): T/domT/incT/incdomT from GA/TC/NC
+static void apply_bit_cutoffs(p7x_pipeline_cfg &c, const Profile &p)
+{
+  if (!c.use_bit_cutoffs) return;
+  const int i = c.use_bit_cutoffs == P7X_BITCUT_GA ? P7X_GA1 : (c.use_bit_cutoffs == P7X_BITCUT_TC ? P7X_TC1 : P7X_NC1);
+  c.T = c.incT = p.cutoff[i];
+  c.domT = c.incdomT = p.cutoff[i + 1];
+  c.by_E = c.dom_by_E = c.inc_by_E = c.incdom_by_E = 0;
+}
+
+struct Pending { bool have = false; Hit hit; };
+
+float kahan_fsum(const float *v, int n)
+{ // Easel esl_vec_FSum: Kahan compensated summation
+  float sum = 0.0f, c = 0.0f;
+  for (int i = 0; i < n; ++i) { volatile float y = v[i] - c; volatile float t = sum + y; c = (t - sum) - y; sum = t; }
+  return sum;
+}
+
+
+// Everything p7_Pipeline does after p7_domaindef_ByPosteriorHeuristics, for one target.
+static void finish_one(const p7x_pipeline_cfg &cfg, const Profile &p, int L, float fwdsc, double Z_running,
+                       DomainDefResult &dd, Pending &out)
+{
+  if (dd.nregions == 0 || dd.nenvelopes == 0 || dd.dcl.empty()) return;
+  const float nullsc = null1_score(L);
+  const float omega = 1.0f / 256.0f;
+  float seqbias;
+  if (cfg.do_null2) {
+    seqbias = kahan_fsum(dd.n2sc.data(), L + 1);                      // esl_vec_FSum (compensated)
+    seqbias = flogsum(0.0f, std::log((double) omega) + seqbias);
+  } else seqbias = 0.0f;
+  float pre_score = (fwdsc - nullsc) / kLog2;
+  float seq_score = (fwdsc - (nullsc + seqbias)) / kLog2;
+  // reconstruction score: sum of the domains that stay significant after their null2 correction
+  float sum_score = 0.0f;
+  int Ld = 0;
+  seqbias = 0.0f;
+  if (cfg.do_null2) {
+    for (const Domain &d : dd.dcl)
+      if (d.envsc - d.domcorrection > 0.0) { sum_score += d.envsc; Ld += (int) (d.jenv - d.ienv + 1); seqbias += d.domcorrection; }
+    seqbias = flogsum(0.0f, std::log((double) omega) + seqbias);
+  } else {
+    for (const Domain &d : dd.dcl)
+      if (d.envsc > 0.0) { sum_score += d.envsc; Ld += (int) (d.jenv - d.ienv + 1); }
+    seqbias = 0.0f;
+  }
+  sum_score += (L - Ld) * std::log((double) ((float) L / (float) (L + 3)));
+  const float pre2_score = (sum_score - nullsc) / kLog2;
+  sum_score = (sum_score - (nullsc + seqbias)) / kLog2;
+  if (Ld > 0 && sum_score > seq_score) { seq_score = sum_score; pre_score = pre2_score; }
+
+  const double lnP = exp_logsurv(seq_score, p.evparam[P7X_FTAU], p.evparam[P7X_FLAMBDA]);
+  if (!target_reportable(cfg, Z_running, seq_score, lnP)) return;
+
+  Hit &h = out.hit;
+  out.have = true;
+  h.ndom = (int) dd.dcl.size();
+  h.nexpected = dd.nexpected; h.nregions = dd.nregions; h.nclustered = dd.nclustered;
+  h.noverlaps = dd.noverlaps; h.nenvelopes = dd.nenvelopes;
+  h.pre_score = pre_score; h.pre_lnP = exp_logsurv(pre_score, p.evparam[P7X_FTAU], p.evparam[P7X_FLAMBDA]);
+  h.score = seq_score; h.lnP = lnP;
+  h.sortkey = cfg.inc_by_E ? -lnP : seq_score;
+  h.sum_score = sum_score; h.sum_lnP = exp_logsurv(sum_score, p.evparam[P7X_FTAU], p.evparam[P7X_FLAMBDA]);
+  h.dcl = std::move(dd.dcl);
+  h.best_domain = 0;
+  for (int d = 0; d < h.ndom; ++d) {
+    Domain &dm = h.dcl[d];
+    const int Ldd = (int) (dm.jenv - dm.ienv + 1);
+    dm.bitscore = dm.envsc + (L - Ldd) * std::log((double) ((float) L / (float) (L + 3)));
+    dm.dombias = cfg.do_null2 ? flogsum(0.0f, std::log((double) omega) + dm.domcorrection) : 0.0f;
+    dm.bitscore = (dm.bitscore - (nullsc + dm.dombias)) / kLog2;
+    dm.lnP = exp_logsurv(dm.bitscore, p.evparam[P7X_FTAU], p.evparam[P7X_FLAMBDA]);
+    if (dm.bitscore > h.dcl[h.best_domain].bitscore) h.best_domain = d;
+  }
+  if (cfg.use_bit_cutoffs) {
+    if (target_reportable(cfg, Z_running, h.score, h.lnP)) {
+      h.flags |= P7X_IS_REPORTED;
+      if (target_includable(cfg, Z_running, h.score, h.lnP)) h.flags |= P7X_IS_INCLUDED;
+    }
+    for (Domain &dm : h.dcl)
+      if (domain_reportable(cfg, cfg.domZ, dm.bitscore, dm.lnP)) {
+        dm.is_reported = true;
+        if (domain_includable(cfg, cfg.domZ, dm.bitscore, dm.lnP)) dm.is_included = true;
+      }
+  }
+}
+
+static void sort_by_key(p7x_tophits &th)
+{
+  th.order.resize(th.hits.size());
+  for (size_t i = 0; i < th.order.size(); ++i) th.order[i] = (int) i;
+  std::stable_sort(th.order.begin(), th.order.end(), [&](int a, int b) {
+    const Hit &h1 = th.hits[a], &h2 = th.hits[b];
+    if (h1.sortkey != h2.sortkey) return h1.sortkey > h2.sortkey;
+    const int c = std::strcmp(h1.name.c_str(), h2.name.c_str());
+    if (c != 0) return c < 0;
+    const int dir1 = h1.dcl[0].iali < h1.dcl[0].jali ? 1 : -1, dir2 = h2.dcl[0].iali < h2.dcl[0].jali ? 1 : -1;
+    if (dir1 != dir2) return dir2 < 0;
+    return h1.dcl[0].iali < h2.dcl[0].iali;
+  });
+  th.sorted_by_key = true;
+}
+
+static void threshold(p7x_tophits &th)
+{
+  p7x_pipeline_cfg &c = th.cfg;
+  if (!c.use_bit_cutoffs) {
+    for (Hit &h : th.hits) {
+      h.flags &= ~(uint32_t) (P7X_IS_REPORTED | P7X_IS_INCLUDED);
+      if (!(h.flags & P7X_IS_DUPLICATE) && target_reportable(c, c.Z, h.score, h.lnP)) {
+        h.flags |= P7X_IS_REPORTED;
+        if (target_includable(c, c.Z, h.score, h.lnP)) h.flags |= P7X_IS_INCLUDED;
+      }
+    }
+  }
+  th.nreported = th.nincluded = 0;
+  for (const Hit &h : th.hits) { if (h.flags & P7X_IS_REPORTED) th.nreported++; if (h.flags & P7X_IS_INCLUDED) th.nincluded++; }
+  if (c.domZ_setby == P7X_ZSETBY_NTARGETS) c.domZ = (double) th.nreported;
+  if (!c.use_bit_cutoffs) {
+    for (Hit &h : th.hits) {
+      for (Domain &d : h.dcl) d.is_reported = d.is_included = false;
+      if (h.flags & P7X_IS_REPORTED)
+        for (Domain &d : h.dcl) {
+          if (domain_reportable(c, c.domZ, d.bitscore, d.lnP)) d.is_reported = true;
+          if ((h.flags & P7X_IS_INCLUDED) && domain_includable(c, c.domZ, d.bitscore, d.lnP)) d.is_included = true;
+        }
+    }
+  }
+  for (Hit &h : th.hits) {
+    h.nreported = h.nincluded = 0;
+    for (const Domain &d : h.dcl) { if (d.is_reported) h.nreported++; if (d.is_included) h.nincluded++; }
+  }
+  // upstream workaround_bug_h74: hide all but one of several envelopes that produced the same alignment
+  for (Hit &h : th.hits)
+    if (h.noverlaps)
+      for (int d1 = 0; d1 < h.ndom; ++d1)
+        for (int d2 = d1 + 1; d2 < h.ndom; ++d2)
+          if (h.dcl[d1].iali == h.dcl[d2].iali && h.dcl[d1].jali == h.dcl[d2].jali) {
+            const int rm = (h.dcl[d1].bitscore >= h.dcl[d2].bitscore) ? d2 : d1;
+            if (h.dcl[rm].is_reported) { h.dcl[rm].is_reported = false; h.nreported--; }
+            if (h.dcl[rm].is_included) { h.dcl[rm].is_included = false; h.nincluded--; }
+          }
+}
+
+int host_finish_search(const p7x_pipeline_cfg &cfg_in, const p7x_oprofile *om, const p7x_seqdb *db,
+                       const char *const *names, const char *const *accs, const char *const *descs,
+                       const std::vector<int32_t> &fin_slots, const std::vector<float> &usc,
+                       const std::vector<float> &filtersc, const std::vector<float> &fwdsc,
+                       const std::vector<float> &fwd_xmx, const std::vector<float> &bck_xmx,
+                       const std::vector<int64_t> &xmx_off, const int *counts, const double *ms, p7x_tophits **out)
+{
+  (void) usc; (void) filtersc;
+  const Profile &p = om->p;
+  auto th = std::make_unique<p7x_tophits>();
+  th->cfg = cfg_in;
+  p7x_pipeline_cfg &cfg = th->cfg;
+  apply_bit_cutoffs(cfg, p);
+  th->qname = p.name; th->qacc = p.acc; th->qdesc = p.desc; th->q_has_acc = p.has_acc; th->q_has_desc = p.has_desc;
+  th->M = p.M;
+  th->ctr.nmodels = 1; th->ctr.nnodes = (uint64_t) p.M;
+  th->ctr.nseqs = (uint64_t) db->n; th->ctr.nres = (uint64_t) db->nres;
+  th->ctr.n_past_msv = (uint64_t) counts[1]; th->ctr.n_past_bias = (uint64_t) counts[8];
+  th->ctr.n_past_vit = (uint64_t) counts[3]; th->ctr.n_past_fwd = (uint64_t) counts[4];
+  for (int i = 0; i < 7; ++i) th->ms[i] = ms[i];
+
+  const auto t0 = std::chrono::steady_clock::now();
+  const int n = (int) fin_slots.size();
+  std::vector<Pending> pend((size_t) n);
+  std::vector<int> tgt((size_t) n);
+  for (int i = 0; i < n; ++i) tgt[i] = db->h_order[fin_slots[i]];
+  std::atomic<int> next{0};
+  std::atomic<int> failed{0};
+  auto worker = [&]() {
+    flogsum_init();
+    for (;;) {
+      const int i = next.fetch_add(1);
+      if (i >= n) break;
+      const int t = tgt[i];
+      const int L = db->h_len[t];
+      const uint8_t *dsq = db->h_dsq.data() + db->h_off[t] - 1;
+      DomainDefResult dd;
+      const int st = domaindef_by_posterior_heuristics(p, dsq, L, fwd_xmx.data() + xmx_off[i], bck_xmx.data() + xmx_off[i],
+                                                       cfg.seed, cfg.seed != 0, dd);
+      if (st != P7X_OK) { failed.store(st); continue; }
+      const double Zrun = (cfg.Z_setby == P7X_ZSETBY_NTARGETS) ? (double) (t + 1) : cfg.Z;
+      finish_one(cfg, p, L, fwdsc[i], Zrun, dd, pend[i]);
+      if (pend[i].have) pend[i].hit.seqidx = t;
+    }
+  };
+  int nthreads = cfg.host_threads > 0 ? cfg.host_threads : (int) std::thread::hardware_concurrency();
+  if (nthreads < 1) nthreads = 1;
+  if (nthreads > n) nthreads = n > 0 ? n : 1;
+  if (nthreads <= 1) worker();
+  else {
+    std::vector<std::thread> pool;
+    for (int i = 0; i < nthreads; ++i) pool.emplace_back(worker);
+    for (auto &t : pool) t.join();
+  }
+  if (failed.load() != 0) { set_error("domain definition workflow failure"); return failed.load(); }
+  // hits in target order, as the reference's sequential loop would have appended them
+  std::vector<int> idx((size_t) n);
+  for (int i = 0; i < n; ++i) idx[i] = i;
+  std::sort(idx.begin(), idx.end(), [&](int a, int b) { return tgt[a] < tgt[b]; });
+  for (int i : idx) {
+    if (!pend[i].have) continue;
+    Hit &h = pend[i].hit;
+    const int t = tgt[i];
+    if (names && names[t]) h.name = names[t];
+    if (accs && accs[t] && accs[t][0]) { h.acc = accs[t]; h.has_acc = true; }
+    if (descs && descs[t] && descs[t][0]) { h.desc = descs[t]; h.has_desc = true; }
+    th->hits.push_back(std::move(h));
+  }
+  th->ms[5] = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+  // Z for E-values: number of targets seen (p7_pli_NewSeq), unless set by the caller
+  if (cfg.Z_setby == P7X_ZSETBY_NTARGETS) cfg.Z = (double) db->n;
+  sort_by_key(*th);
+  threshold(*th);
+  *out = th.release();
+  return P7X_OK;
+}
+
+void tophits_set_total_ms(p7x_tophits *th, double ms) { th->ms[6] = ms; }
+
+} // namespace p7x
+
+using namespace p7x;
+
+extern "C" {
+
+void p7x_tophits_destroy(p7x_tophits *th) { delete th; }
+p7x_tophits *p7x_tophits_clone(const p7x_tophits *th) { return th ? new p7x_tophits(*th) : nullptr; }
+int64_t p7x_tophits_nhits(const p7x_tophits *th) { return th ? (int64_t) th->hits.size() : -1; }
+
+int p7x_tophits_get_counters(const p7x_tophits *th, p7x_counters *c)
+{
+  if (!th || !c) return P7X_EINVAL;
+  *c = th->ctr;
+  c->n_output = 0; c->pos_output = 0;
+  return P7X_OK;
+}
+int p7x_tophits_get_cfg(const p7x_tophits *th, p7x_pipeline_cfg *cfg)
+{
+  if (!th || !cfg) return P7X_EINVAL;
+  *cfg = th->cfg;
+  return P7X_OK;
+}
+
+static const Hit *hit_at(const p7x_tophits *th, int64_t i)
+{
+  if (!th || i < 0 || i >= (int64_t) th->hits.size()) return nullptr;
+  return &th->hits[th->order.size() == th->hits.size() ? th->order[i] : (int) i];
+}
+
+int p7x_tophits_get_hit(const p7x_tophits *th, int64_t i, p7x_hit *o)
+{
+  const Hit *h = hit_at(th, i);
+  if (!h || !o) return P7X_EINVAL;
+  std::memset(o, 0, sizeof(*o));
+  o->name = h->name.c_str(); o->acc = h->has_acc ? h->acc.c_str() : nullptr; o->desc = h->has_desc ? h->desc.c_str() : nullptr;
+  o->seqidx = h->seqidx; o->sortkey = h->sortkey; o->score = h->score; o->pre_score = h->pre_score; o->sum_score = h->sum_score;
+  o->lnP = h->lnP; o->pre_lnP = h->pre_lnP; o->sum_lnP = h->sum_lnP; o->nexpected = h->nexpected;
+  o->nregions = h->nregions; o->nclustered = h->nclustered; o->noverlaps = h->noverlaps; o->nenvelopes = h->nenvelopes;
+  o->ndom = h->ndom; o->flags = h->flags; o->nreported = h->nreported; o->nincluded = h->nincluded; o->best_domain = h->best_domain;
+  return P7X_OK;
+}
+
+int p7x_tophits_get_domain(const p7x_tophits *th, int64_t i, int32_t d, p7x_domain *o)
+{
+  const Hit *h = hit_at(th, i);
+  if (!h || !o || d < 0 || d >= h->ndom) return P7X_EINVAL;
+  const Domain &m = h->dcl[d];
+  std::memset(o, 0, sizeof(*o));
+  o->ienv = m.ienv; o->jenv = m.jenv; o->iali = m.iali; o->jali = m.jali;
+  o->envsc = m.envsc; o->domcorrection = m.domcorrection; o->dombias = m.dombias; o->oasc = m.oasc; o->bitscore = m.bitscore;
+  o->lnP = m.lnP; o->is_reported = m.is_reported; o->is_included = m.is_included;
+  o->N = m.N; o->hmmfrom = m.hmmfrom; o->hmmto = m.hmmto; o->M = m.M; o->sqfrom = m.sqfrom; o->sqto = m.sqto; o->L = m.L;
+  o->model = m.model.c_str(); o->mline = m.mline.c_str(); o->aseq = m.aseq.c_str(); o->ppline = m.ppline.c_str();
+  o->rfline = m.rfline.empty() ? nullptr : m.rfline.c_str();
+  o->mmline = m.mmline.empty() ? nullptr : m.mmline.c_str();
+  o->csline = m.csline.empty() ? nullptr : m.csline.c_str();
+  o->hmmname = th->qname.c_str(); o->hmmacc = th->q_has_acc ? th->qacc.c_str() : nullptr; o->hmmdesc = th->q_has_desc ? th->qdesc.c_str() : nullptr;
+  o->sqname = h->name.c_str(); o->sqacc = h->has_acc ? h->acc.c_str() : nullptr; o->sqdesc = h->has_desc ? h->desc.c_str() : nullptr;
+  return P7X_OK;
+}
+
+int p7x_tophits_sort_by_key(p7x_tophits *th) { if (!th) return P7X_EINVAL; sort_by_key(*th); return P7X_OK; }
+int p7x_tophits_threshold(p7x_tophits *th)   { if (!th) return P7X_EINVAL; threshold(*th); return P7X_OK; }
+
+// TopHits.merge (plan7.pyx:9172-9276): p7_tophits_Merge (concatenate, re-sort), p7_pipeline_Merge (add the
+// accounting; Z too when it counts targets), clear REPORTED/INCLUDED unless bit cutoffs, re-threshold.
+int p7x_tophits_merge(p7x_tophits *dst, const p7x_tophits *src)
+{
+  if (!dst || !src) return P7X_EINVAL;
+  if (dst->qname != src->qname) { set_error("Trying to merge `TopHits` obtained from different queries"); return P7X_EINVAL; }
+  const p7x_pipeline_cfg &a = dst->cfg, &b = src->cfg;
+  if (a.by_E != b.by_E || a.dom_by_E != b.dom_by_E || a.inc_by_E != b.inc_by_E || a.incdom_by_E != b.incdom_by_E ||
+      a.use_bit_cutoffs != b.use_bit_cutoffs || a.Z_setby != b.Z_setby || a.domZ_setby != b.domZ_setby ||
+      (a.by_E ? a.E != b.E : a.T != b.T) || (a.dom_by_E ? a.domE != b.domE : a.domT != b.domT) ||
+      (a.inc_by_E ? a.incE != b.incE : a.incT != b.incT) || (a.incdom_by_E ? a.incdomE != b.incdomE : a.incdomT != b.incdomT) ||
+      (a.Z_setby != P7X_ZSETBY_NTARGETS && a.Z != b.Z) || (a.domZ_setby != P7X_ZSETBY_NTARGETS && a.domZ != b.domZ)) {
+    set_error("Trying to merge `TopHits` obtained from pipelines configured with different parameters");
+    return P7X_EINVAL;
+  }
+  for (const Hit &h : src->hits) dst->hits.push_back(h);
+  dst->ctr.nseqs += src->ctr.nseqs; dst->ctr.nres += src->ctr.nres;
+  dst->ctr.nmodels = std::max(dst->ctr.nmodels, src->ctr.nmodels); dst->ctr.nnodes = std::max(dst->ctr.nnodes, src->ctr.nnodes);
+  dst->ctr.n_past_msv += src->ctr.n_past_msv; dst->ctr.n_past_bias += src->ctr.n_past_bias;
+  dst->ctr.n_past_vit += src->ctr.n_past_vit; dst->ctr.n_past_fwd += src->ctr.n_past_fwd;
+  if (dst->cfg.Z_setby == P7X_ZSETBY_NTARGETS) dst->cfg.Z += src->cfg.Z;
+  for (int i = 0; i < 7; ++i) dst->ms[i] += src->ms[i];
+  if (!dst->cfg.use_bit_cutoffs)
+    for (Hit &h : dst->hits) {
+      h.flags &= ~(uint32_t) (P7X_IS_REPORTED | P7X_IS_INCLUDED);
+      h.nreported = h.nincluded = 0;
+      for (Domain &d : h.dcl) d.is_reported = d.is_included = false;
+    }
+  sort_by_key(*dst);
+  threshold(*dst);
+  return P7X_OK;
+}
+
+int p7x_tophits_get_timings(const p7x_tophits *th, double *ms, int n)
+{
+  if (!th || !ms) return P7X_EINVAL;
+  for (int i = 0; i < n && i < 7; ++i) ms[i] = th->ms[i];
+  return P7X_OK;
+}
+
+} // extern "C"

@@ -1,0 +1,490 @@
+// p7x_vitfwd.hip -- Viterbi filter, Forward parser and Backward parser on CDNA4: one target per WAVEFRONT.
+//
+// These stages only see the survivors of the MSV filter (~2% / ~0.1% of the targets), too few to fill the
+// chip with one sequence per lane, so a wavefront shares one (profile, sequence) comparison: lane z owns
+// the C consecutive nodes k = z*C+1 .. z*C+C (this is Farrar striping with 64 stripes: the k-1 neighbour is
+// the previous register, except at chunk boundaries where one DPP wave_shr moves it across lanes).
+//   * transitions: one ds_read_b128 per node per row (8 x int16) or two (8 x f32), stored [c*64 + lane];
+//   * emissions:   [residue][c*64 + lane];
+//   * xE (row maximum / row sum) and the special states: DPP row_shr/row_bcast reduction -> SGPR scalars;
+//   * D->D: serial inside the lane; across lanes the Viterbi filter uses HMMER's lazy-F test
+//     (Dmax + ddbound_w > xB) and then relaxes chunk carries until no lane improves -- a fixed point of
+//     max-plus, hence bit-identical to the serial evaluation; Forward/Backward use a 6-step affine scan.
+// Integer semantics follow upstream impl_sse/vitfilter.c exactly (signed saturating 16-bit adds via
+// v_add_i16 clamp); float semantics follow impl_sse/fwdback.c up to the association order of sums.
+#include "p7x_device.hpp"
+#include "p7x_kernels.hpp"
+
+namespace p7x {
+
+constexpr int kWsBlock = 256;     // 4 wavefronts per workgroup, each walking its own targets
+
+__device__ __forceinline__ int   dpp_shr1(int v, int fill)   { return __builtin_amdgcn_update_dpp(fill, v, 0x138, 0xf, 0xf, false); }
+__device__ __forceinline__ int   dpp_shl1(int v, int fill)   { return __builtin_amdgcn_update_dpp(fill, v, 0x130, 0xf, 0xf, false); }
+__device__ __forceinline__ float dpp_shr1f(float v, float fill) { return __builtin_bit_cast(float, dpp_shr1(__builtin_bit_cast(int, v), __builtin_bit_cast(int, fill))); }
+__device__ __forceinline__ float dpp_shl1f(float v, float fill) { return __builtin_bit_cast(float, dpp_shl1(__builtin_bit_cast(int, v), __builtin_bit_cast(int, fill))); }
+
+#define P7X_DPP_STEP_I(v, ident, ctrl, rmask) __builtin_amdgcn_update_dpp((ident), (v), (ctrl), (rmask), 0xf, false)
+
+__device__ __forceinline__ int wave_max_i32(int v)
+{
+  const int id = INT_MIN;
+  v = max(v, P7X_DPP_STEP_I(v, id, 0x111, 0xf));
+  v = max(v, P7X_DPP_STEP_I(v, id, 0x112, 0xf));
+  v = max(v, P7X_DPP_STEP_I(v, id, 0x114, 0xf));
+  v = max(v, P7X_DPP_STEP_I(v, id, 0x118, 0xf));
+  v = max(v, P7X_DPP_STEP_I(v, id, 0x142, 0xa));
+  v = max(v, P7X_DPP_STEP_I(v, id, 0x143, 0xc));
+  return __builtin_amdgcn_readlane(v, 63);
+}
+#define P7X_DPP_STEP_F(v, ctrl, rmask) __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, (v)), (ctrl), (rmask), 0xf, false))
+__device__ __forceinline__ float wave_sum_f32(float v)
+{
+  v = v + P7X_DPP_STEP_F(v, 0x111, 0xf);
+  v = v + P7X_DPP_STEP_F(v, 0x112, 0xf);
+  v = v + P7X_DPP_STEP_F(v, 0x114, 0xf);
+  v = v + P7X_DPP_STEP_F(v, 0x118, 0xf);
+  v = v + P7X_DPP_STEP_F(v, 0x142, 0xa);
+  v = v + P7X_DPP_STEP_F(v, 0x143, 0xc);
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
+}
+
+__device__ __forceinline__ short adds16(short a, short b) { return __builtin_elementwise_add_sat(a, b); }
+__device__ __forceinline__ short max16(short a, short b) { return a > b ? a : b; }
+__device__ __forceinline__ short lo16(uint32_t w) { return (short) (w & 0xffffu); }
+__device__ __forceinline__ short hi16(uint32_t w) { return (short) (w >> 16); }
+
+// Each wave pulls targets from a shared counter; returns -1 when the list is exhausted.
+__device__ __forceinline__ int next_item(int *counter, int n, int lane)
+{
+  int it = 0;
+  if (lane == 0) it = atomicAdd(counter, 1);
+  it = __builtin_amdgcn_readfirstlane(it);
+  return it < n ? it : -1;
+}
+
+// ======================================================================================= Viterbi filter
+template <int C>
+__global__ void __launch_bounds__(kWsBlock) vit_kernel(const WaveSeqArgs a)
+{
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  constexpr int Mpad = 64 * C;
+  uint4 *tr = reinterpret_cast<uint4 *>(smem);                       // [Mpad]
+  short *em = reinterpret_cast<short *>(smem + (size_t) Mpad * 16);  // [kTabRows][Mpad]
+  {
+    const uint4 *gt = reinterpret_cast<const uint4 *>(a.trans);
+    for (int i = threadIdx.x; i < Mpad; i += kWsBlock) tr[i] = gt[i];
+    const uint4 *ge = reinterpret_cast<const uint4 *>(a.emis);
+    uint4 *le = reinterpret_cast<uint4 *>(em);
+    for (int i = threadIdx.x; i < a.nrows * Mpad / 8; i += kWsBlock) le[i] = ge[i];
+  }
+  __syncthreads();
+  const int lane = threadIdx.x & 63;
+  const short NEG = (short) -32768;
+  const int nlist = a.nlist_ptr ? *a.nlist_ptr : a.nlist;
+
+  for (;;) {
+    const int it = next_item(a.counter, nlist, lane);
+    if (it < 0) break;
+    const int slot = a.list ? a.list[it] : it;
+    const int L = a.slot_len[slot];
+    const uint8_t *sq = a.dsq + a.slot_off[slot];
+    const int xwm = a.xwmove_tab[L];
+
+    short mm[C], im[C], dm[C], tdd[C];
+#pragma unroll
+    for (int c = 0; c < C; ++c) { mm[c] = im[c] = dm[c] = NEG; tdd[c] = NEG; }
+    int xN = a.base_w, xB = xN + xwm, xJ = -32768, xC = -32768;
+    bool overflow = false;
+    uint32_t resid = 0;
+
+    for (int i = 0; i < L; ++i) {
+      if ((i & 63) == 0) resid = (i + lane < L) ? sq[i + lane] : 0;
+      const int x = __builtin_amdgcn_readlane((int) resid, i & 63);
+      const short *er = em + x * Mpad + lane;
+      const short xBs = (short) xB;
+      short mp = (short) dpp_shr1(mm[C - 1], NEG);
+      short ip = (short) dpp_shr1(im[C - 1], NEG);
+      short dp = (short) dpp_shr1(dm[C - 1], NEG);
+      short rowmax = NEG, dmax = NEG, dcarry = NEG;
+#pragma unroll
+      for (int c = 0; c < C; ++c) {
+        const uint4 t = tr[c * 64 + lane];
+        short sv = adds16(xBs, lo16(t.x));
+        sv = max16(sv, adds16(mp, hi16(t.x)));
+        sv = max16(sv, adds16(ip, lo16(t.y)));
+        sv = max16(sv, adds16(dp, hi16(t.y)));
+        sv = adds16(sv, er[c * 64]);
+        rowmax = max16(rowmax, sv);
+        mp = mm[c]; ip = im[c]; dp = dm[c];
+        im[c] = max16(adds16(mp, hi16(t.z)), adds16(ip, lo16(t.w)));
+        mm[c] = sv;
+        dm[c] = dcarry;                       // M(i,k-1) -> D(i,k); node c=0 is patched below
+        dcarry = adds16(sv, lo16(t.z));
+        dmax = max16(dmax, dcarry);
+        tdd[c] = hi16(t.w);
+      }
+      dm[0] = (short) dpp_shr1(dcarry, NEG);
+
+      const int xE = wave_max_i32((int) rowmax);
+      if (xE >= 32767) { overflow = true; break; }
+      xC = max(xC, xE + a.xw_e);              // xw[C][LOOP] = xw[J][LOOP] = xw[N][LOOP] = 0
+      xJ = max(xJ, xE + a.xw_e);
+      xB = max(xJ + xwm, xN + xwm);
+
+      const int Dmax = wave_max_i32((int) dmax);
+      if (Dmax + a.ddbound > xB) {            // lazy F: only now can a D->D path beat B->M on the next row
+#pragma unroll
+        for (int c = 1; c < C; ++c) dm[c] = max16(dm[c], adds16(dm[c - 1], tdd[c - 1]));
+        for (;;) {
+          const short ddout = adds16(dm[C - 1], tdd[C - 1]);
+          const short cand = (short) dpp_shr1(ddout, NEG);
+          if (!__any(cand > dm[0])) break;
+          dm[0] = max16(dm[0], cand);
+#pragma unroll
+          for (int c = 1; c < C; ++c) dm[c] = max16(dm[c], adds16(dm[c - 1], tdd[c - 1]));
+        }
+      }
+    }
+    if (lane == 0) a.out_xC[it] = overflow ? 32767 : xC;
+  }
+}
+
+// ======================================================================================= Forward parser
+struct F8 { float bm, mm, im, dm, md, mi, ii, dd; };
+__device__ __forceinline__ F8 load_f8(const float4 *t, int idx)
+{
+  const float4 a = t[2 * idx], b = t[2 * idx + 1];
+  return F8{ a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w };
+}
+
+template <int C>
+__global__ void __launch_bounds__(kWsBlock) fwd_kernel(const WaveSeqArgs a)
+{
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  constexpr int Mpad = 64 * C;
+  float4 *tr = reinterpret_cast<float4 *>(smem);                         // [2*Mpad]
+  float *em = reinterpret_cast<float *>(smem + (size_t) Mpad * 32);      // [kTabRows][Mpad]
+  {
+    const float4 *gt = reinterpret_cast<const float4 *>(a.trans);
+    for (int i = threadIdx.x; i < 2 * Mpad; i += kWsBlock) tr[i] = gt[i];
+    const float4 *ge = reinterpret_cast<const float4 *>(a.emis);
+    float4 *le = reinterpret_cast<float4 *>(em);
+    for (int i = threadIdx.x; i < a.nrows * Mpad / 4; i += kWsBlock) le[i] = ge[i];
+  }
+  __syncthreads();
+  const int lane = threadIdx.x & 63;
+  const int nlist = a.nlist_ptr ? *a.nlist_ptr : a.nlist;
+
+  for (;;) {
+    const int it = next_item(a.counter, nlist, lane);
+    if (it < 0) break;
+    const int slot = a.list ? a.list[it] : it;
+    const int L = a.slot_len[slot];
+    const uint8_t *sq = a.dsq + a.slot_off[slot];
+    float *xo = a.xmx ? a.xmx + a.xmx_off[it] : nullptr;
+    const float pmove = (2.0f + 1.0f) / ((float) L + 2.0f + 1.0f), ploop = 1.0f - pmove;
+
+    float mm[C], im[C], dm[C];
+#pragma unroll
+    for (int c = 0; c < C; ++c) mm[c] = im[c] = dm[c] = 0.0f;
+    // product of this lane's D->D probabilities: the multiplier of an incoming D carry
+    float ddprod = 1.0f;
+#pragma unroll
+    for (int c = 0; c < C; ++c) ddprod *= tr[2 * (c * 64 + lane) + 1].w;
+
+    float xN = 1.0f, xB = pmove, xJ = 0.0f, xC = 0.0f, xE = 0.0f, totscale = 0.0f;
+    if (xo && lane == 0) { xo[0] = 0.0f; xo[1] = 1.0f; xo[2] = 0.0f; xo[3] = xB; xo[4] = 0.0f; xo[5] = 1.0f; }
+    uint32_t resid = 0;
+
+    for (int i = 0; i < L; ++i) {
+      if ((i & 63) == 0) resid = (i + lane < L) ? sq[i + lane] : 0;
+      const int x = __builtin_amdgcn_readlane((int) resid, i & 63);
+      const float *er = em + x * Mpad + lane;
+      float mp = dpp_shr1f(mm[C - 1], 0.0f), ip = dpp_shr1f(im[C - 1], 0.0f), dp = dpp_shr1f(dm[C - 1], 0.0f);
+      float esum = 0.0f, dcarry = 0.0f;
+      float tdd[C], tmd[C];
+#pragma unroll
+      for (int c = 0; c < C; ++c) {
+        const F8 t = load_f8(tr, c * 64 + lane);
+        float sv = xB * t.bm;
+        sv = sv + mp * t.mm;
+        sv = sv + ip * t.im;
+        sv = sv + dp * t.dm;
+        sv = sv * er[c * 64];
+        esum = esum + sv;
+        mp = mm[c]; ip = im[c]; dp = dm[c];
+        im[c] = mp * t.mi + ip * t.ii;
+        mm[c] = sv;
+        tdd[c] = t.dd; tmd[c] = t.md;
+      }
+      // D(i,k) = M(i,k-1) tMD(k-1) + D(i,k-1) tDD(k-1): serial inside the lane, affine scan across lanes
+      float A = 0.0f;                                   // this lane's outgoing carry for a zero incoming carry
+#pragma unroll
+      for (int c = 0; c < C; ++c) { dm[c] = A; A = mm[c] * tmd[c] + A * tdd[c]; }
+      float sa = A, sp = ddprod;                        // inclusive scan of (carry, multiplier)
+#pragma unroll
+      for (int s = 1; s < 64; s <<= 1) {
+        const float pa = __shfl_up(sa, s), pp = __shfl_up(sp, s);
+        if (lane >= s) { sa = sa + pa * sp; sp = sp * pp; }
+      }
+      dcarry = dpp_shr1f(sa, 0.0f);                     // exclusive: the carry entering this lane
+      {
+        float w = dcarry;
+#pragma unroll
+        for (int c = 0; c < C; ++c) { dm[c] = dm[c] + w; esum = esum + dm[c]; w = w * tdd[c]; }
+      }
+      xE = wave_sum_f32(esum);
+      xN = xN * ploop;
+      xC = (xC * ploop) + (xE * a.xf_e_move);
+      xJ = (xJ * ploop) + (xE * a.xf_e_loop);
+      xB = (xJ * pmove) + (xN * pmove);
+      float scale = 1.0f;
+      if (xE > 1.0e4f) {
+        xN = xN / xE; xC = xC / xE; xJ = xJ / xE; xB = xB / xE;
+        const float inv = (float) (1.0 / (double) xE);
+#pragma unroll
+        for (int c = 0; c < C; ++c) { mm[c] *= inv; dm[c] *= inv; im[c] *= inv; }
+        scale = xE;
+        totscale += (float) log((double) xE);
+        xE = 1.0f;
+      }
+      if (xo && lane == 0) {
+        float *r = xo + (size_t) (i + 1) * 6;
+        r[0] = xE; r[1] = xN; r[2] = xJ; r[3] = xB; r[4] = xC; r[5] = scale;
+      }
+    }
+    if (lane == 0) {
+      float sc;
+      if (xC != xC) sc = __builtin_nanf("");
+      else if ((L > 0 && xC == 0.0f) || __builtin_isinf(xC)) sc = __builtin_inff();
+      else sc = (float) ((double) totscale + log((double) (xC * pmove)));
+      a.out_sc[it] = sc;
+    }
+  }
+}
+
+// ======================================================================================= Backward parser
+// Mirror of the Forward parser, re-using Forward's per-row scale factors (upstream backward_engine).
+template <int C>
+__global__ void __launch_bounds__(kWsBlock) bck_kernel(const WaveSeqArgs a)
+{
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  constexpr int Mpad = 64 * C;
+  float4 *tr = reinterpret_cast<float4 *>(smem);
+  float *em = reinterpret_cast<float *>(smem + (size_t) Mpad * 32);
+  {
+    const float4 *gt = reinterpret_cast<const float4 *>(a.trans);
+    for (int i = threadIdx.x; i < 2 * Mpad; i += kWsBlock) tr[i] = gt[i];
+    const float4 *ge = reinterpret_cast<const float4 *>(a.emis);
+    float4 *le = reinterpret_cast<float4 *>(em);
+    for (int i = threadIdx.x; i < a.nrows * Mpad / 4; i += kWsBlock) le[i] = ge[i];
+  }
+  __syncthreads();
+  const int lane = threadIdx.x & 63;
+  const int nlist = a.nlist_ptr ? *a.nlist_ptr : a.nlist;
+
+  for (;;) {
+    const int it = next_item(a.counter, nlist, lane);
+    if (it < 0) break;
+    const int slot = a.list ? a.list[it] : it;
+    const int L = a.slot_len[slot];
+    const uint8_t *sq = a.dsq + a.slot_off[slot];
+    const float *fx = a.fwd_xmx + a.xmx_off[it];
+    float *xo = a.xmx + a.xmx_off[it];
+    const float pmove = (2.0f + 1.0f) / ((float) L + 2.0f + 1.0f), ploop = 1.0f - pmove;
+
+    // per-lane constants: transitions leaving node (c) and entering node (c+1) [next node]
+    float tmd[C], tdd[C], tmi[C], tii[C];       // leaving node k
+    float nmm[C], nim[C], ndm[C];               // entering node k+1 (B->M uses node k itself: bm[c])
+    float bm[C];
+    float ddprod = 1.0f;
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+      const F8 t = load_f8(tr, c * 64 + lane);
+      tmd[c] = t.md; tdd[c] = t.dd; tmi[c] = t.mi; tii[c] = t.ii; bm[c] = t.bm;
+      ddprod *= t.dd;
+    }
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+      float mmn, imn, dmn;
+      if (c + 1 < C) { const F8 t = load_f8(tr, (c + 1) * 64 + lane); mmn = t.mm; imn = t.im; dmn = t.dm; }
+      else {
+        const F8 t = load_f8(tr, 0 * 64 + lane);              // first node of the next lane
+        mmn = dpp_shl1f(t.mm, 0.0f); imn = dpp_shl1f(t.im, 0.0f); dmn = dpp_shl1f(t.dm, 0.0f);
+      }
+      nmm[c] = mmn; nim[c] = imn; ndm[c] = dmn;
+    }
+
+    float mm[C], im[C], dm[C];
+    float xJ = 0.0f, xB = 0.0f, xN = 0.0f;
+    float xC = pmove;
+    float xE = xC * a.xf_e_move;
+    float totscale = 0.0f;
+    bool own_scales = false;
+
+    // D chain helper: D(k) = base(k) + D(k+1) tDD(k), running from the last node to the first; affine scan
+    // across lanes in reverse lane order.  On entry dm[c] holds base(k); on exit the full D(i,k).
+    auto d_chain = [&](float (&d)[C]) {
+      float A = 0.0f;                                   // outgoing carry (towards lower k) for zero incoming
+#pragma unroll
+      for (int c = C - 1; c >= 0; --c) { A = d[c] + A * tdd[c]; }
+      float sa = A, sp = ddprod;
+#pragma unroll
+      for (int s = 1; s < 64; s <<= 1) {
+        const float pa = __shfl_down(sa, s), pp = __shfl_down(sp, s);
+        if (lane + s < 64) { sa = sa + pa * sp; sp = sp * pp; }
+      }
+      float w = dpp_shl1f(sa, 0.0f);                    // D of the first node of the next lane
+#pragma unroll
+      for (int c = C - 1; c >= 0; --c) { d[c] = d[c] + w * tdd[c]; w = d[c]; }
+    };
+
+    // row L
+#pragma unroll
+    for (int c = 0; c < C; ++c) { mm[c] = xE; dm[c] = xE; im[c] = 0.0f; }
+    d_chain(dm);
+    {
+      float dn = dpp_shl1f(dm[0], 0.0f);
+#pragma unroll
+      for (int c = C - 1; c >= 0; --c) { mm[c] = mm[c] + dn * tmd[c]; dn = dm[c]; }
+    }
+    float sc = fx[(size_t) L * 6 + 5];
+    if (sc > 1.0f) {
+      xE = xE / sc; xN = xN / sc; xC = xC / sc; xJ = xJ / sc; xB = xB / sc;
+      const float inv = (float) (1.0 / (double) sc);
+#pragma unroll
+      for (int c = 0; c < C; ++c) { mm[c] *= inv; dm[c] *= inv; im[c] *= inv; }
+    }
+    totscale = (float) log((double) sc);
+    if (lane == 0) { float *r = xo + (size_t) L * 6; r[0] = xE; r[1] = xN; r[2] = xJ; r[3] = xB; r[4] = xC; r[5] = sc; }
+
+    for (int i = L - 1; i >= 1; --i) {
+      const int x = sq[i];                                  // residue x_{i+1} (0-based index i)
+      const float *er = em + x * Mpad + lane;
+      // mp(k) = M(i+1,k+1) e(x_{i+1},k+1): value of the NEXT node
+      float me[C];
+#pragma unroll
+      for (int c = 0; c < C; ++c) me[c] = mm[c] * er[c * 64];
+      float bsum = 0.0f;
+#pragma unroll
+      for (int c = 0; c < C; ++c) bsum = bsum + me[c] * bm[c];
+      const float me_next0 = dpp_shl1f(me[0], 0.0f);
+#pragma unroll
+      for (int c = 0; c < C; ++c) {
+        const float mp = (c + 1 < C) ? me[c + 1] : me_next0;
+        const float ipv = im[c];
+        im[c] = ipv * tii[c] + mp * nim[c];
+        dm[c] = mp * ndm[c];
+        mm[c] = ipv * tmi[c] + mp * nmm[c];
+      }
+      xB = wave_sum_f32(bsum);
+      xC = xC * ploop;
+      xJ = (xB * pmove) + (xJ * ploop);
+      xN = (xB * pmove) + (xN * ploop);
+      xE = (xC * a.xf_e_move) + (xJ * a.xf_e_loop);
+#pragma unroll
+      for (int c = 0; c < C; ++c) { dm[c] = dm[c] + xE; mm[c] = mm[c] + xE; }
+      d_chain(dm);
+      {
+        float dn = dpp_shl1f(dm[0], 0.0f);
+#pragma unroll
+        for (int c = C - 1; c >= 0; --c) { mm[c] = mm[c] + dn * tmd[c]; dn = dm[c]; }
+      }
+      if (xB > 1.0e16f) own_scales = true;
+      sc = own_scales ? ((xB > 1.0e4f) ? xB : 1.0f) : fx[(size_t) i * 6 + 5];
+      if (sc > 1.0f) {
+        xE /= sc; xN /= sc; xJ /= sc; xB /= sc; xC /= sc;
+        const float inv = (float) (1.0 / (double) sc);
+#pragma unroll
+        for (int c = 0; c < C; ++c) { mm[c] *= inv; dm[c] *= inv; im[c] *= inv; }
+        totscale += (float) log((double) sc);
+      }
+      if (lane == 0) { float *r = xo + (size_t) i * 6; r[0] = xE; r[1] = xN; r[2] = xJ; r[3] = xB; r[4] = xC; r[5] = sc; }
+    }
+    // row 0
+    {
+      const int x = sq[0];
+      const float *er = em + x * Mpad + lane;
+      float bsum = 0.0f;
+#pragma unroll
+      for (int c = 0; c < C; ++c) bsum = bsum + (mm[c] * er[c * 64]) * bm[c];
+      xB = wave_sum_f32(bsum);
+      xN = (xB * pmove) + (xN * ploop);
+      if (lane == 0) {
+        float *r = xo; r[0] = 0.0f; r[1] = xN; r[2] = 0.0f; r[3] = xB; r[4] = 0.0f; r[5] = 1.0f;
+        float scv;
+        if (xN != xN || (L > 0 && xN == 0.0f) || __builtin_isinf(xN)) scv = __builtin_inff();
+        else scv = (float) ((double) totscale + log((double) xN));
+        a.out_sc[it] = scv;
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------- host side
+static const int kCList[] = { 1, 2, 3, 4, 5, 6, 8, 10, 12, 16, 20, 24, 32, 40 };
+
+int vit_pick_C(int M)
+{
+  const int need = (M + 63) / 64;
+  for (int c : kCList) if (c >= need) return c;
+  return -1;
+}
+
+template <typename K>
+static int launch_ws(K kernel, const WaveSeqArgs &a, size_t lds_bytes, int num_cu, hipStream_t st)
+{
+  if (!a.nlist_ptr && a.nlist <= 0) return P7X_OK;
+  if (lds_bytes > 64 * 1024)
+    P7X_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds_bytes));
+  int per_cu = 0;
+  P7X_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, kWsBlock, lds_bytes));
+  if (per_cu < 1) per_cu = 1;
+  long grid = (long) num_cu * per_cu, want = ((long) a.nlist + 3) / 4;
+  if (!a.nlist_ptr && grid > want) grid = want;
+  if (grid < 1) grid = 1;
+  hipLaunchKernelGGL(kernel, dim3((unsigned) grid), dim3(kWsBlock), lds_bytes, st, a);
+  P7X_HIP(hipGetLastError());
+  return P7X_OK;
+}
+
+#define P7X_C_SWITCH(KERNEL, BYTES_PER_NODE, EBYTES)                                                        \
+  switch (a.C) {                                                                                            \
+    case 1:  return launch_ws(KERNEL<1>,  a, (size_t) 64 * 1  * (BYTES_PER_NODE + a.nrows * EBYTES), num_cu, st); \
+    case 2:  return launch_ws(KERNEL<2>,  a, (size_t) 64 * 2  * (BYTES_PER_NODE + a.nrows * EBYTES), num_cu, st); \
+    case 3:  return launch_ws(KERNEL<3>,  a, (size_t) 64 * 3  * (BYTES_PER_NODE + a.nrows * EBYTES), num_cu, st); \
+    case 4:  return launch_ws(KERNEL<4>,  a, (size_t) 64 * 4  * (BYTES_PER_NODE + a.nrows * EBYTES), num_cu, st); \
+    case 5:  return launch_ws(KERNEL<5>,  a, (size_t) 64 * 5  * (BYTES_PER_NODE + a.nrows * EBYTES), num_cu, st); \
+    case 6:  return launch_ws(KERNEL<6>,  a, (size_t) 64 * 6  * (BYTES_PER_NODE + a.nrows * EBYTES), num_cu, st); \
+    case 8:  return launch_ws(KERNEL<8>,  a, (size_t) 64 * 8  * (BYTES_PER_NODE + a.nrows * EBYTES), num_cu, st); \
+    case 10: return launch_ws(KERNEL<10>, a, (size_t) 64 * 10 * (BYTES_PER_NODE + a.nrows * EBYTES), num_cu, st); \
+    case 12: return launch_ws(KERNEL<12>, a, (size_t) 64 * 12 * (BYTES_PER_NODE + a.nrows * EBYTES), num_cu, st); \
+    case 16: return launch_ws(KERNEL<16>, a, (size_t) 64 * 16 * (BYTES_PER_NODE + a.nrows * EBYTES), num_cu, st); \
+    case 20: return launch_ws(KERNEL<20>, a, (size_t) 64 * 20 * (BYTES_PER_NODE + a.nrows * EBYTES), num_cu, st); \
+    case 24: return launch_ws(KERNEL<24>, a, (size_t) 64 * 24 * (BYTES_PER_NODE + a.nrows * EBYTES), num_cu, st); \
+    case 32: return launch_ws(KERNEL<32>, a, (size_t) 64 * 32 * (BYTES_PER_NODE + a.nrows * EBYTES), num_cu, st); \
+    default: set_error("model too long for the wave-per-sequence kernels"); return P7X_EINVAL;             \
+  }
+
+int vit_launch(const WaveSeqArgs &a, int num_cu, hipStream_t st) { P7X_C_SWITCH(vit_kernel, 16, 2) }
+
+#define P7X_CF_SWITCH(KERNEL)                                                                               \
+  switch (a.C) {                                                                                            \
+    case 1:  return launch_ws(KERNEL<1>,  a, (size_t) 64 * 1  * (32 + a.nrows * 4), num_cu, st);           \
+    case 2:  return launch_ws(KERNEL<2>,  a, (size_t) 64 * 2  * (32 + a.nrows * 4), num_cu, st);           \
+    case 3:  return launch_ws(KERNEL<3>,  a, (size_t) 64 * 3  * (32 + a.nrows * 4), num_cu, st);           \
+    case 4:  return launch_ws(KERNEL<4>,  a, (size_t) 64 * 4  * (32 + a.nrows * 4), num_cu, st);           \
+    case 5:  return launch_ws(KERNEL<5>,  a, (size_t) 64 * 5  * (32 + a.nrows * 4), num_cu, st);           \
+    case 6:  return launch_ws(KERNEL<6>,  a, (size_t) 64 * 6  * (32 + a.nrows * 4), num_cu, st);           \
+    case 8:  return launch_ws(KERNEL<8>,  a, (size_t) 64 * 8  * (32 + a.nrows * 4), num_cu, st);           \
+    case 10: return launch_ws(KERNEL<10>, a, (size_t) 64 * 10 * (32 + a.nrows * 4), num_cu, st);           \
+    case 12: return launch_ws(KERNEL<12>, a, (size_t) 64 * 12 * (32 + a.nrows * 4), num_cu, st);           \
+    case 16: return launch_ws(KERNEL<16>, a, (size_t) 64 * 16 * (32 + a.nrows * 4), num_cu, st);           \
+    default: set_error("model too long for the Forward/Backward kernels"); return P7X_EINVAL;               \
+  }
+
+int fwd_launch(const WaveSeqArgs &a, int num_cu, hipStream_t st) { P7X_CF_SWITCH(fwd_kernel) }
+int bck_launch(const WaveSeqArgs &a, int num_cu, hipStream_t st) { P7X_CF_SWITCH(bck_kernel) }
+
+} // namespace p7x

@@ -22,7 +22,7 @@ from .errors import (AlphabetMismatch, AllocationError, InvalidParameter, Missin
 
 __all__ = [
     "HMM", "HMMFile", "Background", "Profile", "OptimizedProfile", "EvalueParameters", "Cutoffs",
-    "Pipeline", "TopHits", "Hit", "Domain", "Domains", "Alignment",
+    "Pipeline", "SequenceDatabase", "TopHits", "Hit", "Domain", "Domains", "Alignment",
 ]
 
 CUTOFF_UNSET = -99999.0
@@ -546,3 +546,509 @@ class Profile:
         if self._hmm is None:
             raise ValueError("profile is not configured")
         return OptimizedProfile(self._hmm, self._bg, self.L)
+
+
+# --------------------------------------------------------------------------- results
+
+def _s(b: Optional[bytes]) -> Optional[str]:
+    return None if b is None else b.decode()
+
+
+class Alignment:
+    """An alignment of a target domain to the query (reference ``plan7.pyx:229-426``; ``P7_ALIDISPLAY``)."""
+
+    def __init__(self, domain: "Domain"):
+        self.domain = domain
+        r = domain._rec
+        self.hmm_from, self.hmm_to, self.hmm_length = r.hmmfrom, r.hmmto, r.M
+        self.hmm_name, self.hmm_accession = _s(r.hmmname), _s(r.hmmacc)
+        self.hmm_sequence = _s(r.model)
+        self.identity_sequence = _s(r.mline)
+        self.target_from, self.target_to, self.target_length = r.sqfrom, r.sqto, r.L
+        self.target_name = _s(r.sqname)
+        self.target_sequence = _s(r.aseq)
+        self.posterior_probabilities = _s(r.ppline)
+
+    def __len__(self) -> int:
+        return self.domain._rec.N
+
+    def __str__(self) -> str:
+        w = max(len(self.hmm_name or ""), len(self.target_name or ""))
+        return "\n".join([
+            f"{self.hmm_name:>{w}} {self.hmm_from:6d} {self.hmm_sequence} {self.hmm_to:<6d}",
+            f"{'':>{w}} {'':6} {self.identity_sequence}",
+            f"{self.target_name:>{w}} {self.target_from:6d} {self.target_sequence} {self.target_to:<6d}",
+            f"{'':>{w}} {'':6} {self.posterior_probabilities} PP",
+        ])
+
+
+class Domain:
+    """A single domain of a hit (reference ``plan7.pyx:1441-1688``; ``P7_DOMAIN`` in ``p7_domain.pxd:10-26``)."""
+
+    def __init__(self, hit: "Hit", index: int):
+        self.hit = hit
+        self._index = index
+        self._rec = _lib.DomainRec()
+        st = _lib.lib().p7x_tophits_get_domain(hit.hits._handle, hit._index, index, C.byref(self._rec))
+        if st != 0:
+            raise IndexError("domain index out of range")
+        self.alignment = Alignment(self)
+
+    @property
+    def env_from(self) -> int:
+        return self._rec.ienv
+
+    @property
+    def env_to(self) -> int:
+        return self._rec.jenv
+
+    @property
+    def score(self) -> float:
+        return self._rec.bitscore
+
+    @property
+    def bias(self) -> float:
+        return self._rec.dombias / math.log(2.0)           # plan7.pyx:1536-1554: nats / ln 2
+
+    @property
+    def correction(self) -> float:
+        return self._rec.domcorrection / math.log(2.0)
+
+    @property
+    def envelope_score(self) -> float:
+        return self._rec.envsc / math.log(2.0)
+
+    @property
+    def pvalue(self) -> float:
+        return math.exp(self._rec.lnP)
+
+    @property
+    def c_evalue(self) -> float:
+        return math.exp(self._rec.lnP) * self.hit.hits.domZ      # plan7.pyx:1557-1574
+
+    @property
+    def i_evalue(self) -> float:
+        return math.exp(self._rec.lnP) * self.hit.hits.Z
+
+    @property
+    def reported(self) -> bool:
+        return bool(self._rec.is_reported)
+
+    @property
+    def included(self) -> bool:
+        return bool(self._rec.is_included)
+
+    @property
+    def accuracy(self) -> float:
+        return self._rec.oasc / (1.0 + abs(self._rec.jenv - self._rec.ienv))
+
+
+class Domains:
+    """Read-only view over the domains of a hit (reference ``plan7.pyx:1850-1935``)."""
+
+    def __init__(self, hit: "Hit"):
+        self.hit = hit
+
+    def __len__(self) -> int:
+        return self.hit._rec.ndom
+
+    def __getitem__(self, index: int) -> Domain:
+        n = len(self)
+        if index < 0:
+            index += n
+        if index < 0 or index >= n:
+            raise IndexError("list index out of range")
+        return Domain(self.hit, index)
+
+    def __iter__(self):
+        return (Domain(self.hit, i) for i in range(len(self)))
+
+    @property
+    def reported(self):
+        return [d for d in self if d.reported]
+
+    @property
+    def included(self):
+        return [d for d in self if d.included]
+
+
+class Hit:
+    """A high-scoring target (reference ``plan7.pyx:1936-2235``; ``P7_HIT`` in ``p7_hit.pxd:27-58``)."""
+
+    def __init__(self, hits: "TopHits", index: int):
+        self.hits = hits
+        self._index = index
+        self._rec = _lib.HitRec()
+        st = _lib.lib().p7x_tophits_get_hit(hits._handle, index, C.byref(self._rec))
+        if st != 0:
+            raise IndexError("list index out of range")
+
+    @property
+    def name(self) -> str:
+        return self._rec.name.decode()
+
+    @property
+    def accession(self) -> Optional[str]:
+        return _s(self._rec.acc)
+
+    @property
+    def description(self) -> Optional[str]:
+        return _s(self._rec.desc)
+
+    @property
+    def score(self) -> float:
+        return self._rec.score
+
+    @property
+    def pre_score(self) -> float:
+        return self._rec.pre_score
+
+    @property
+    def sum_score(self) -> float:
+        return self._rec.sum_score
+
+    @property
+    def bias(self) -> float:
+        return self._rec.pre_score - self._rec.score             # plan7.pyx:2080-2084
+
+    @property
+    def pvalue(self) -> float:
+        return math.exp(self._rec.lnP)
+
+    @property
+    def evalue(self) -> float:
+        return math.exp(self._rec.lnP) * self.hits.Z              # plan7.pyx:2104-2111
+
+    @property
+    def domains(self) -> Domains:
+        return Domains(self)
+
+    @property
+    def best_domain(self) -> Domain:
+        return Domain(self, self._rec.best_domain)
+
+    @property
+    def reported(self) -> bool:
+        return bool(self._rec.flags & 2)
+
+    @property
+    def included(self) -> bool:
+        return bool(self._rec.flags & 1)
+
+    @property
+    def dropped(self) -> bool:
+        return bool(self._rec.flags & 8)
+
+    @property
+    def duplicate(self) -> bool:
+        return bool(self._rec.flags & 16)
+
+    @property
+    def length(self) -> int:
+        return Domain(self, 0)._rec.L
+
+    # domain number estimation columns of the tabular output (p7_hit.pxd:42-51)
+    @property
+    def nexpected(self) -> float:
+        return self._rec.nexpected
+
+    @property
+    def nregions(self) -> int:
+        return self._rec.nregions
+
+    @property
+    def nclustered(self) -> int:
+        return self._rec.nclustered
+
+    @property
+    def noverlaps(self) -> int:
+        return self._rec.noverlaps
+
+    @property
+    def nenvelopes(self) -> int:
+        return self._rec.nenvelopes
+
+
+class TopHits:
+    """An ordered list of hits with the pipeline accounting that produced it
+    (reference ``plan7.pyx:8312-9276``; ``P7_TOPHITS`` + copied ``P7_PIPELINE``)."""
+
+    def __init__(self, query=None, _handle=None):
+        self.query = query
+        self._handle = _handle
+
+    def __del__(self):
+        if getattr(self, "_handle", None):
+            try:
+                _lib.lib().p7x_tophits_destroy(self._handle)
+            except Exception:
+                pass
+            self._handle = None
+
+    def _cfg(self) -> "_lib.PipelineCfg":
+        cfg = _lib.PipelineCfg()
+        _lib.lib().p7x_tophits_get_cfg(self._handle, C.byref(cfg))
+        return cfg
+
+    def _ctr(self) -> "_lib.Counters":
+        c = _lib.Counters()
+        _lib.lib().p7x_tophits_get_counters(self._handle, C.byref(c))
+        return c
+
+    def __len__(self) -> int:
+        return int(_lib.lib().p7x_tophits_nhits(self._handle))
+
+    def __bool__(self) -> bool:
+        return len(self) > 0
+
+    def __getitem__(self, index: int) -> Hit:
+        n = len(self)
+        if index < 0:
+            index += n
+        if index < 0 or index >= n:
+            raise IndexError("list index out of range")
+        return Hit(self, index)
+
+    def __iter__(self):
+        return (Hit(self, i) for i in range(len(self)))
+
+    @property
+    def Z(self) -> float:
+        return self._cfg().Z
+
+    @property
+    def domZ(self) -> float:
+        return self._cfg().domZ
+
+    @property
+    def E(self) -> float:
+        return self._cfg().E
+
+    @property
+    def searched_models(self) -> int:
+        return self._ctr().nmodels
+
+    @property
+    def searched_nodes(self) -> int:
+        return self._ctr().nnodes
+
+    @property
+    def searched_sequences(self) -> int:
+        return self._ctr().nseqs
+
+    @property
+    def searched_residues(self) -> int:
+        return self._ctr().nres
+
+    @property
+    def stage_counts(self) -> dict:
+        """n_past_{msv,bias,vit,fwd} (``p7_pipeline.pxd:88-101``; pickled by the reference at ``plan7.pyx:8457-8460``)."""
+        c = self._ctr()
+        return dict(msv=c.n_past_msv, bias=c.n_past_bias, vit=c.n_past_vit, fwd=c.n_past_fwd)
+
+    @property
+    def timings_ms(self) -> dict:
+        buf = (C.c_double * 7)()
+        _lib.lib().p7x_tophits_get_timings(self._handle, buf, 7)
+        return dict(zip(("msv", "bias", "viterbi", "forward", "fwd_rows", "host_domaindef_or_bck", "total"), buf))
+
+    @property
+    def reported(self):
+        return [h for h in self if h.reported]
+
+    @property
+    def included(self):
+        return [h for h in self if h.included]
+
+    def sort(self, by: str = "key") -> None:
+        if by != "key":
+            raise InvalidParameter("by", by, choices=["key"])
+        _lib.lib().p7x_tophits_sort_by_key(self._handle)
+
+    def is_sorted(self, by: str = "key") -> bool:
+        return True
+
+    def copy(self) -> "TopHits":
+        h = _lib.lib().p7x_tophits_clone(self._handle)
+        return TopHits(self.query, C.c_void_p(h))
+
+    def merge(self, *others: "TopHits") -> "TopHits":
+        """Reference ``plan7.pyx:9172-9276``: concatenate, sum the accounting, re-threshold with the global Z."""
+        merged = self.copy()
+        for o in others:
+            st = _lib.lib().p7x_tophits_merge(merged._handle, o._handle)
+            if st != 0:
+                raise ValueError(_lib.last_error())
+        return merged
+
+    def __add__(self, other: "TopHits") -> "TopHits":
+        return self.merge(other)
+
+
+# --------------------------------------------------------------------------- Pipeline
+
+class Pipeline:
+    """An accelerated sequence/profile comparison pipeline (reference ``plan7.pyx:5423-6906``).
+
+    Same constructor keywords and defaults as the reference (``plan7.pyx:5413-5421``).  ``search_hmm`` runs
+    ``Pipeline._search_loop`` (``plan7.pyx:6393-6453``) for a whole ``DigitalSequenceBlock`` on one MI355X.
+    """
+
+    M_HINT = 100
+    L_HINT = 100
+    _BIT_CUTOFFS = {"gathering": 1, "noise": 2, "trusted": 3}
+
+    def __init__(self, alphabet: Alphabet, background: Optional[Background] = None, *, bias_filter: bool = True,
+                 null2: bool = True, seed: int = 42, Z=None, domZ=None, F1: float = 0.02, F2: float = 1e-3,
+                 F3: float = 1e-5, E: float = 10.0, T=None, domE: float = 10.0, domT=None, incE: float = 0.01,
+                 incT=None, incdomE: float = 0.01, incdomT=None, bit_cutoffs: Optional[str] = None,
+                 device: int = 0, host_threads: int = 0):
+        self.alphabet = alphabet
+        if background is None:
+            self.background = Background(alphabet)
+        elif background.alphabet != alphabet:
+            raise AlphabetMismatch(alphabet, background.alphabet)
+        else:
+            self.background = background.copy()
+        for name, v in (("F1", F1), ("F2", F2), ("F3", F3)):
+            if not (0.0 <= v <= 1.0) and v != 1.0:
+                raise InvalidParameter(name, v, hint="real number between 0 and 1")
+        for name, v in (("E", E), ("domE", domE), ("incE", incE), ("incdomE", incdomE)):
+            if v < 0:
+                raise InvalidParameter(name, v, hint="positive real number")
+        if bit_cutoffs is not None and bit_cutoffs not in self._BIT_CUTOFFS:
+            raise InvalidParameter("bit_cutoffs", bit_cutoffs, choices=list(self._BIT_CUTOFFS) + [None])
+        self.bias_filter, self.null2, self.seed = bias_filter, null2, seed
+        self.Z, self.domZ = Z, domZ
+        self.F1, self.F2, self.F3 = F1, F2, F3
+        self.E, self.T, self.domE, self.domT = E, T, domE, domT
+        self.incE, self.incT, self.incdomE, self.incdomT = incE, incT, incdomE, incdomT
+        self.bit_cutoffs = bit_cutoffs
+        self.device = device
+        self.host_threads = host_threads
+        self._db_cache = None           # (id(block), packed n, device) -> SequenceDatabase
+
+    def clear(self) -> None:
+        """Reference ``plan7.pyx:6113-6154``: reset accounting between queries (stateless here)."""
+
+    def _cfg(self) -> "_lib.PipelineCfg":
+        c = _lib.PipelineCfg()
+        _lib.lib().p7x_pipeline_cfg_default(C.byref(c))
+        c.do_biasfilter, c.do_null2, c.seed = int(self.bias_filter), int(self.null2), int(self.seed or 0)
+        c.F1, c.F2, c.F3 = self.F1, self.F2, self.F3
+        c.E, c.domE, c.incE, c.incdomE = self.E, self.domE, self.incE, self.incdomE
+        if self.T is not None:
+            c.T, c.by_E = float(self.T), 0
+        if self.domT is not None:
+            c.domT, c.dom_by_E = float(self.domT), 0
+        if self.incT is not None:
+            c.incT, c.inc_by_E = float(self.incT), 0
+        if self.incdomT is not None:
+            c.incdomT, c.incdom_by_E = float(self.incdomT), 0
+        if self.Z is not None:
+            c.Z, c.Z_setby = float(self.Z), 1
+        if self.domZ is not None:
+            c.domZ, c.domZ_setby = float(self.domZ), 1
+        c.use_bit_cutoffs = 0 if self.bit_cutoffs is None else self._BIT_CUTOFFS[self.bit_cutoffs]
+        c.host_threads = int(self.host_threads)
+        return c
+
+    def _get_om_from_query(self, query, L: int = L_HINT) -> OptimizedProfile:
+        """Reference ``plan7.pyx:5979-6013``."""
+        if isinstance(query, OptimizedProfile):
+            return query
+        if isinstance(query, Profile):
+            return query.to_optimized()
+        if isinstance(query, HMM):
+            return OptimizedProfile(query, self.background, L)
+        raise TypeError(f"Expected HMM, Profile or OptimizedProfile, found {type(query).__name__}")
+
+    def search_hmm(self, query, sequences, database: Optional["SequenceDatabase"] = None) -> TopHits:
+        """Run the pipeline with ``query`` against every target of ``sequences``
+        (reference ``plan7.pyx:6156-6262``)."""
+        if query.alphabet != self.alphabet:
+            raise AlphabetMismatch(self.alphabet, query.alphabet)
+        if isinstance(sequences, SequenceFile):
+            if not sequences.digital:
+                raise ValueError("target sequences file is not in digital mode")
+            sequences = sequences.read_block()
+        if isinstance(sequences, SequenceDatabase):
+            database, sequences = sequences, sequences.block
+        if not isinstance(sequences, DigitalSequenceBlock):
+            raise TypeError(f"Expected DigitalSequenceBlock or SequenceFile, found {type(sequences).__name__}")
+        if sequences.alphabet != self.alphabet:
+            raise AlphabetMismatch(self.alphabet, sequences.alphabet)
+        L = len(sequences[0]) if len(sequences) else self.L_HINT
+        om = self._get_om_from_query(query, L)
+        if database is None:
+            key = (id(sequences), len(sequences), self.device)
+            if self._db_cache is None or self._db_cache[0] != key:
+                self._db_cache = (key, SequenceDatabase(sequences, device=self.device))
+            database = self._db_cache[1]
+        cfg = self._cfg()
+        out = C.c_void_p()
+        bgf = np.ascontiguousarray(self.background.residue_frequencies, dtype=np.float32)
+        st = _lib.lib().p7x_search_block(C.byref(cfg), om._handle, bgf.ctypes.data, database._handle,
+                                         database._names, database._accs, database._descs, C.byref(out))
+        if st == 11 and self.bit_cutoffs is not None:
+            raise MissingCutoffs(om.name, self.bit_cutoffs)       # plan7.pyx:6424-6425
+        if st != 0:
+            raise status_to_exception(st, "p7x_search_block", _lib.last_error())
+        return TopHits(query, out)
+
+
+class SequenceDatabase:
+    """A ``DigitalSequenceBlock`` packed once and resident in the HBM of one device (``p7x_seqdb``);
+    any number of queries can then be searched against it without re-uploading the targets."""
+
+    def __init__(self, block: DigitalSequenceBlock, device: int = 0):
+        self.block = block
+        self.device = device
+        limit = 100000                                            # plan7.pyx:5421, 6218-6219
+        for s in block:
+            if len(s) > limit:
+                raise ValueError(f"sequence length over comparison pipeline limit ({limit})")
+        pk = block.packed()
+        self._handle = C.c_void_p()
+        st = _lib.lib().p7x_seqdb_create(device, block.alphabet.type_code, pk.dsq.ctypes.data, pk.offsets.ctypes.data,
+                                         pk.lengths.ctypes.data, pk.n, C.byref(self._handle))
+        if st != 0:
+            raise status_to_exception(st, "p7x_seqdb_create", _lib.last_error())
+        n = pk.n
+        self._names = (C.c_char_p * max(n, 1))(*[s.name.encode() for s in block])
+        self._accs = (C.c_char_p * max(n, 1))(*[(s.accession or "").encode() for s in block])
+        self._descs = (C.c_char_p * max(n, 1))(*[(s.description or "").encode() for s in block])
+
+    def __len__(self) -> int:
+        return len(self.block)
+
+    def __del__(self):
+        if getattr(self, "_handle", None):
+            try:
+                _lib.lib().p7x_seqdb_destroy(self._handle)
+            except Exception:
+                pass
+            self._handle = None
+
+    def filters(self, om: OptimizedProfile, msv=True, viterbi=False, forward=False, bias=False):
+        """Raw per-target filter outputs (``p7x_filters_batch``): dict of numpy arrays in target order."""
+        n = len(self.block)
+        out = {}
+        xj = np.zeros(n, dtype=np.int32) if msv else None
+        xc = np.zeros(n, dtype=np.int32) if viterbi else None
+        fw = np.zeros(n, dtype=np.float32) if forward else None
+        bs = np.zeros(n, dtype=np.float32) if bias else None
+        st = _lib.lib().p7x_filters_batch(om._handle, self._handle,
+                                          None if xj is None else xj.ctypes.data, None if xc is None else xc.ctypes.data,
+                                          None if fw is None else fw.ctypes.data, None if bs is None else bs.ctypes.data)
+        if st != 0:
+            raise status_to_exception(st, "p7x_filters_batch", _lib.last_error())
+        if msv:
+            out["xJ"] = xj
+        if viterbi:
+            out["xC"] = xc
+        if forward:
+            out["fwd"] = fw
+        if bias:
+            out["filtersc"] = bs
+        return out

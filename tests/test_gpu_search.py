@@ -1,0 +1,150 @@
+"""End-to-end parity of Pipeline.search_hmm / hmmsearch with the reference's golden tables
+(real HMMER output: tests/golden/tables, reference tests/test_hmmer.py:51-238) and with the oracle's cascade."""
+import itertools
+
+import numpy as np
+import pytest
+
+from conftest import golden_table, synthetic_block
+from pyhmmer_amd import easel, errors, hmmer, plan7
+from test_oracle_golden import STAGE_COUNTS
+
+pytestmark = pytest.mark.gpu
+
+
+def _check_tbl(hits, rows):
+    reported = [h for h in hits if h.reported]
+    assert len(reported) == len(rows)
+    for row, hit in itertools.zip_longest(rows, reported):
+        assert hit.name == row[0]
+        assert hit.accession is None if row[1] == "-" else hit.accession == row[1]
+        assert hit.score == pytest.approx(float(row[5]), abs=0.1)
+        assert hit.bias == pytest.approx(float(row[6]), abs=0.1)
+        assert f"{hit.evalue:9.2g}" == f"{float(row[4]):9.2g}" or hit.evalue == pytest.approx(float(row[4]), rel=0.12)
+        # best-domain and domain-number-estimation columns
+        assert hit.best_domain.score == pytest.approx(float(row[8]), abs=0.1)
+        assert hit.nexpected == pytest.approx(float(row[10]), abs=0.1)
+        assert (hit.nregions, hit.nclustered, hit.noverlaps, hit.nenvelopes) == tuple(int(v) for v in row[11:15])
+        assert len(hit.domains) == int(row[15])
+        assert len(hit.domains.reported) == int(row[16]) and len(hit.domains.included) == int(row[17])
+
+
+def _check_domtbl(hits, rows):
+    doms = [d for h in hits if h.reported for d in h.domains if d.reported]
+    assert len(doms) == len(rows)
+    for row, d in itertools.zip_longest(rows, doms):
+        assert d.hit.name == row[0]
+        assert d.score == pytest.approx(float(row[13]), abs=0.1)
+        assert d.bias == pytest.approx(float(row[14]), abs=0.1)
+        assert f"{d.c_evalue:9.2g}" == f"{float(row[11]):9.2g}" or d.c_evalue == pytest.approx(float(row[11]), rel=0.12)
+        assert f"{d.i_evalue:9.2g}" == f"{float(row[12]):9.2g}" or d.i_evalue == pytest.approx(float(row[12]), rel=0.12)
+        assert (d.alignment.hmm_from, d.alignment.hmm_to) == (int(row[15]), int(row[16]))
+        assert (d.alignment.target_from, d.alignment.target_to) == (int(row[17]), int(row[18]))
+        assert (d.env_from, d.env_to) == (int(row[19]), int(row[20]))
+        assert d.accuracy == pytest.approx(float(row[21]), abs=0.01)
+
+
+def test_pf02826_hits_and_domains_match_hmmer(models, proteome):
+    hmm = models["PF02826"][0]
+    hits = plan7.Pipeline(hmm.alphabet).search_hmm(hmm, proteome)
+    assert len(hits) == 22                                   # reference test_hmmer.py:114
+    assert hits.Z == len(proteome) and hits.searched_residues == proteome.total_length()
+    assert tuple(hits.stage_counts.values()) == STAGE_COUNTS[hmm.name]
+    _check_tbl(hits, golden_table("PF02826.tbl"))
+    _check_domtbl(hits, golden_table("PF02826.domtbl", kind="domtbl"))
+
+
+def test_thioesterase_inline_known_answer(models, proteome):
+    """reference test_hmmer.py:51-106."""
+    hmm = models["Thioesterase"][0]
+    hits = plan7.Pipeline(hmm.alphabet).search_hmm(hmm, proteome)
+    assert len(hits) == 1
+    hit = hits[0]
+    assert hit.name == "938293.PRJEB85.HG003687_113"
+    assert hit.score == pytest.approx(8.6, abs=0.1) and hit.bias == pytest.approx(1.5, abs=0.1)
+    assert hit.evalue == pytest.approx(0.096, abs=0.01)
+    assert len(hit.domains) == 1
+    d = hit.domains[0]
+    assert d.score == pytest.approx(8.1, abs=0.1) and d.bias == pytest.approx(1.5, abs=0.1)
+    assert d.i_evalue == pytest.approx(0.14, abs=0.005) and d.c_evalue == pytest.approx(6.5e-05, abs=0.005)
+    assert (d.alignment.target_from, d.alignment.target_to, d.alignment.target_length) == (115, 129, 261)
+    assert (d.alignment.hmm_from, d.alignment.hmm_to, d.alignment.hmm_length) == (79, 93, 243)
+    assert (d.env_from, d.env_to) == (115, 129)
+    assert d.alignment.hmm_sequence == "GWSfGGvlAyEmArq"
+    assert d.alignment.identity_sequence == "G+S+GG +A ++A++"
+    assert d.alignment.target_sequence == "GHSMGGSVAVAIAHE"
+    assert d.alignment.posterior_probabilities == "9************96"
+    tophits_T5 = plan7.Pipeline(hmm.alphabet, T=5).search_hmm(hmm, proteome)     # reference _hmmsearch.py:365-367
+    assert tophits_T5[0].score == pytest.approx(8.601, abs=0.02)
+
+
+def test_rrefam_hits_and_domains_match_hmmer(models, proteome):
+    """reference test_hmmer.py:161-198 (bias filter with a non-zero composition vector)."""
+    db = plan7.SequenceDatabase(proteome)
+    pli = plan7.Pipeline(proteome.alphabet)
+    all_hits = [pli.search_hmm(hmm, db) for hmm in models["RREFam"]]
+    for hmm, hits in zip(models["RREFam"], all_hits):
+        assert tuple(hits.stage_counts.values()) == STAGE_COUNTS[hmm.name]
+        _check_tbl(hits, golden_table("RREFam.tbl", hmm.name))
+        _check_domtbl(hits, golden_table("RREFam.domtbl", hmm.name, kind="domtbl"))
+        for h in hits:
+            assert h.hits.Z == len(proteome)
+
+
+def test_cascade_decisions_match_oracle_on_synthetic_block(models, oracle):
+    hmm = models["KR"][0]
+    bg = plan7.Background(hmm.alphabet)
+    blk = synthetic_block(30000, 300, seed=5)
+    hits = plan7.Pipeline(hmm.alphabet).search_hmm(hmm, blk)
+    recs, ctr = oracle.OracleProfile(hmm, bg, 400).cascade_block(blk.packed(), want_records=False)
+    assert tuple(hits.stage_counts.values()) == (ctr.n_past_msv, ctr.n_past_bias, ctr.n_past_vit, ctr.n_past_fwd)
+
+
+def test_shard_merge_equals_whole(models, proteome):
+    """reference tests/test_plan7/test_tophits.py:191-224: merged shards == one search, field by field."""
+    hmm = models["PF02826"][0]
+    pli = plan7.Pipeline(hmm.alphabet)
+    whole = pli.search_hmm(hmm, proteome)
+    parts = [pli.search_hmm(hmm, proteome[a:b]) for a, b in ((0, 1000), (1000, 2000), (2000, 2100))]
+    merged = parts[0].merge(*parts[1:])
+    assert merged.Z == whole.Z == 2100 and merged.domZ == whole.domZ
+    assert merged.stage_counts == whole.stage_counts and merged.searched_residues == whole.searched_residues
+    assert len(merged) == len(whole)
+    for a, b in zip(merged, whole):
+        assert (a.name, a.score, a.pre_score, a.sum_score, a.evalue, a.reported, a.included) == \
+               (b.name, b.score, b.pre_score, b.sum_score, b.evalue, b.reported, b.included)
+        for da, dbb in itertools.zip_longest(a.domains, b.domains):
+            assert (da.env_from, da.env_to, da.score, da.c_evalue, da.i_evalue, da.reported, da.included) == \
+                   (dbb.env_from, dbb.env_to, dbb.score, dbb.c_evalue, dbb.i_evalue, dbb.reported, dbb.included)
+            assert da.alignment.target_sequence == dbb.alignment.target_sequence
+    # through the public entry point, sharded "over devices" (same device listed twice)
+    via = list(hmmer.hmmsearch(hmm, proteome, devices=[0, 0]))[0]
+    assert [h.name for h in via] == [h.name for h in whole] and via.Z == 2100
+
+
+def test_hmm_vs_optimized_profile_query(models, proteome):
+    """reference test_hmmer.py:201-237: HMM query == OptimizedProfile query, exact equality."""
+    hmm = models["PF02826"][0]
+    bg = plan7.Background(hmm.alphabet)
+    prof = plan7.Profile(hmm.M, hmm.alphabet)
+    prof.configure(hmm, bg, 100)
+    pli = plan7.Pipeline(hmm.alphabet)
+    a = pli.search_hmm(hmm, proteome)
+    b = pli.search_hmm(prof.to_optimized(), proteome)
+    assert len(a) == len(b) == 22
+    for x, y in zip(a, b):
+        assert (x.name, x.score, x.pre_score, x.sum_score, x.evalue) == (y.name, y.score, y.pre_score, y.sum_score, y.evalue)
+
+
+def test_z_and_bit_cutoffs(models, proteome):
+    """reference test_pipeline.py:151-195."""
+    hmm = models["PF02826"][0]
+    hits = plan7.Pipeline(hmm.alphabet, Z=25).search_hmm(hmm, proteome)
+    assert hits.Z == 25
+    ga = plan7.Pipeline(hmm.alphabet, bit_cutoffs="gathering").search_hmm(hmm, proteome)
+    assert all(h.score >= 25.1 for h in ga.reported) and len(ga.reported) == 6
+    thio = models["Thioesterase"][0]
+    with pytest.raises(errors.MissingCutoffs):
+        plan7.Pipeline(thio.alphabet, bit_cutoffs="gathering").search_hmm(thio, proteome)
+    with pytest.raises(errors.AlphabetMismatch):
+        plan7.Pipeline(easel.Alphabet.dna()).search_hmm(hmm, proteome)

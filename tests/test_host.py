@@ -1,0 +1,115 @@
+"""Host logic of the product (no GPU): file parsing, profile conversion, packing, ABI surface, error behaviour."""
+import ctypes as C
+import re
+
+import numpy as np
+import pytest
+
+import h3_reader
+from conftest import GOLDEN, ROOT, synthetic_block
+from pyhmmer_amd import _lib, easel, errors, hmmer, plan7
+
+
+def test_abi_exports_every_declared_symbol(libp7x):
+    header = (ROOT / "include" / "p7x.h").read_text()
+    declared = set(re.findall(r"\b(p7x_[a-z0-9_]+)\s*\(", header))
+    assert declared, "no prototypes found in include/p7x.h"
+    raw = C.CDLL(str(_lib.LIB_PATH))
+    for name in sorted(declared):
+        assert hasattr(raw, name), f"libp7x.so does not export {name}"
+    assert declared == set(_lib.declared_symbols()), declared ^ set(_lib.declared_symbols())
+    assert libp7x.p7x_abi_version() == 1
+
+
+@pytest.mark.parametrize("name", ["PF02826", "Thioesterase", "RREFam"])
+def test_product_conversion_bit_exact_vs_pressed(name, models):
+    f = h3_reader.read_h3f(GOLDEN / "db" / f"{name}.hmm.h3f")
+    p = h3_reader.read_h3p(GOLDEN / "db" / f"{name}.hmm.h3p")
+    for hmm, ff, pp in zip(models[name], f, p):
+        om = plan7.OptimizedProfile(hmm, plan7.Background(hmm.alphabet), 400)
+        assert np.array_equal(om.rbv, ff["rbv"]) and np.array_equal(om.sbv, ff["sbv"])
+        assert np.array_equal(om.rwv, pp["rwv"]) and np.array_equal(om.twv, pp["twv"])
+        assert np.array_equal(om.rfv.view(np.uint32), pp["rfv"].view(np.uint32))
+        assert np.array_equal(om.tfv.view(np.uint32), pp["tfv"].view(np.uint32))
+        assert (om.tbm, om.tec, om.tjb, om.base, om.bias) == (ff["tbm"], ff["tec"], ff["tjb"], ff["base"], ff["bias"])
+        assert np.array_equal(om.xw, pp["xw"]) and om.ddbound_w == pp["ddbound_w"]
+        assert np.array_equal(om.xf.view(np.uint32), pp["xf"].view(np.uint32))
+        assert np.allclose(om.compositions, ff["compo"][: hmm.alphabet.K])
+        assert np.allclose(om.evalue_parameters.as_vector(), ff["evparam"])
+        assert om.M == ff["M"] and hmm.name == ff["name"] == pp["name"]
+
+
+def test_hmm_parser_fields(models):
+    hmm = models["PF02826"][0]
+    assert (hmm.name, hmm.accession, hmm.M) == ("2-Hacid_dh_C", "PF02826.20", 178)
+    assert hmm.cutoffs.gathering == (pytest.approx(25.1), pytest.approx(25.1))
+    assert hmm.evalue_parameters.m_mu == pytest.approx(-10.2529)
+    assert hmm.composition is None                       # no COMPO line
+    assert len(hmm.consensus) == hmm.M
+    assert np.allclose(hmm.match_emissions[1:].sum(axis=1), 1.0, atol=1e-4)
+    assert np.allclose(hmm.transition_probabilities[1:-1, :3].sum(axis=1), 1.0, atol=1e-4)
+    rre = models["RREFam"][0]
+    assert rre.composition is not None and abs(float(rre.composition.sum()) - 1.0) < 1e-3
+    assert len(models["RREFam"]) == 10
+
+
+def test_alphabet_and_packing(proteome):
+    abc = easel.Alphabet.amino()
+    assert (abc.K, abc.Kp, abc.symbols) == (20, 29, "ACDEFGHIKLMNPQRSTVWY-BJZOUX*~")
+    assert abc.decode(abc.encode("ACDXZ*")) == "ACDXZ*"
+    with pytest.raises(ValueError):
+        abc.encode("AC1")
+    assert len(proteome) == 2100 and proteome.total_length() == 682583      # fixture facts, SURVEY.md Appendix A
+    pk = proteome.packed()
+    assert pk.dsq[0] == 255 and pk.dsq[-1] == 255
+    for t in (0, 1, 17, 2099):
+        s = proteome[t]
+        o, L = int(pk.offsets[t]), int(pk.lengths[t])
+        assert L == len(s) and np.array_equal(pk.dsq[o:o + L], s.sequence)
+        assert pk.dsq[o - 1] == 255 and pk.dsq[o + L] == 255
+
+
+def test_make_chunks_balanced_by_residues(proteome):
+    chunks = hmmer.make_chunks(proteome, 8)
+    assert sum(len(c) for c in chunks) == len(proteome)
+    names = [s.name for c in chunks for s in c]
+    assert names == [s.name for s in proteome]              # contiguous, order preserving
+    res = [c.total_length() for c in chunks]
+    assert max(res) - min(res) < 2 * max(len(s) for s in proteome)
+
+
+def test_pipeline_argument_validation():
+    abc = easel.Alphabet.amino()
+    with pytest.raises(errors.InvalidParameter):
+        plan7.Pipeline(abc, bit_cutoffs="nope")
+    with pytest.raises(errors.InvalidParameter):
+        plan7.Pipeline(abc, F1=1.5)
+    with pytest.raises(errors.AlphabetMismatch):
+        plan7.Pipeline(abc, background=plan7.Background(easel.Alphabet.dna()))
+    p = plan7.Pipeline(abc, Z=100, T=5.0)
+    c = p._cfg()
+    assert (c.Z, c.Z_setby, c.by_E, c.T) == (100.0, 1, 0, 5.0)
+    d = plan7.Pipeline(abc)._cfg()
+    assert (d.F1, d.F2, d.F3, d.E, d.incE, d.seed) == (0.02, 1e-3, 1e-5, 10.0, 0.01, 42)   # plan7.pyx:5413-5421
+
+
+def test_no_cpu_fallback_without_a_device(libp7x, models):
+    """On a box without a GPU every device entry point must fail loudly (never compute on the CPU)."""
+    if libp7x.p7x_device_count() > 0:
+        pytest.skip("a HIP device is present")
+    hmm = models["PF02826"][0]
+    om = plan7.OptimizedProfile(hmm, plan7.Background(hmm.alphabet), 100)
+    blk = synthetic_block(4, 50, 1)
+    with pytest.raises(errors.DeviceUnavailable):
+        om.msv_filter(blk[0])
+    with pytest.raises(errors.DeviceUnavailable):
+        plan7.Pipeline(hmm.alphabet).search_hmm(hmm, blk)
+    with pytest.raises(errors.DeviceUnavailable):
+        list(hmmer.hmmsearch(hmm, blk))
+
+
+def test_sequence_length_limit(libp7x):
+    abc = easel.Alphabet.amino()
+    big = easel.DigitalSequence(abc, name="big", sequence=np.zeros(100001, dtype=np.uint8))
+    with pytest.raises(ValueError):
+        plan7.SequenceDatabase(easel.DigitalSequenceBlock(abc, [big]))
