@@ -185,6 +185,18 @@ int p7x_search_block(const p7x_pipeline_cfg *cfg, const p7x_oprofile *om, const 
                      const p7x_seqdb *db, const char *const *names, const char *const *accs,
                      const char *const *descs, p7x_tophits **out);
 
+/* Host half of p7_Pipeline for targets that already passed the Forward filter: Backward-derived domain
+ * definition (p7_domaindef_ByPosteriorHeuristics, p7_domaindef.pxd:69-72), per-sequence / per-domain scores,
+ * reporting thresholds, sort.  p7x_search_block calls this internally with the device parsers' output; it is
+ * exported so the host logic can be tested without a GPU from any Forward/Backward parser rows.
+ * surv[i] = target index; fwdsc[i] nats; fwd_xmx / bck_xmx + xmx_off[i] = (L+1) x [E,N,J,B,C,SCALE] rows
+ * (impl_sse/p7_omx.pxd:16-38).  offsets[t] >= 1.  stage_counts = n_past_{msv,bias,vit,fwd} or NULL. */
+int p7x_postprocess_targets(const p7x_pipeline_cfg *cfg, const p7x_oprofile *om, const uint8_t *dsq,
+                            const int64_t *offsets, const int32_t *lengths, size_t n, const int32_t *surv,
+                            size_t nsurv, const float *fwdsc, const float *fwd_xmx, const float *bck_xmx,
+                            const int64_t *xmx_off, const uint64_t *stage_counts, const char *const *names,
+                            const char *const *accs, const char *const *descs, p7x_tophits **out);
+
 void     p7x_tophits_destroy(p7x_tophits *th);
 p7x_tophits *p7x_tophits_clone(const p7x_tophits *th);   /* TopHits.copy, plan7.pyx:9150-9170 */
 int64_t  p7x_tophits_nhits(const p7x_tophits *th);
@@ -194,10 +206,15 @@ int      p7x_tophits_get_hit(const p7x_tophits *th, int64_t i, p7x_hit *hit);
 int      p7x_tophits_get_domain(const p7x_tophits *th, int64_t i, int32_t d, p7x_domain *dom);
 /* p7_tophits_Merge + p7_pipeline_Merge + re-threshold (plan7.pyx:9172-9276): merges src into dst. */
 int      p7x_tophits_merge(p7x_tophits *dst, const p7x_tophits *src);
+/* Flat byte image of a hit list (the reference pickles TopHits through p7_hit_Serialize, plan7.pyx:8394-8572);
+ * used to move per-device / per-process results to the merging host.  serialize returns the size needed. */
+int64_t  p7x_tophits_serialize(const p7x_tophits *th, void *buf, size_t cap);
+p7x_tophits *p7x_tophits_deserialize(const void *buf, size_t n);
 int      p7x_tophits_sort_by_key(p7x_tophits *th);       /* p7_tophits_SortBySortkey, plan7.pyx:8820-8824 */
 int      p7x_tophits_threshold(p7x_tophits *th);         /* p7_tophits_Threshold, plan7.pyx:8804-8818 */
 /* per-stage device timings of the search that produced th, milliseconds (HIP events):
- * [0] msv [1] bias [2] viterbi [3] forward [4] backward [5] host domain definition [6] total */
+ * [0] msv + P-value pass [1] bias filter [2] viterbi [3] forward [4] forward rows for survivors [5] backward, then
+ * overwritten by host domain definition wall time [6] whole call wall time [7] the MSV kernel alone */
 int      p7x_tophits_get_timings(const p7x_tophits *th, double *ms, int n);
 
 const char *p7x_last_error(void);

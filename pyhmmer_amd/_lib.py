@@ -167,6 +167,8 @@ _SIGNATURES = {
     "p7x_filters_batch": (C.c_int, [_VP, _VP, _VP, _VP, _VP, _VP]),
     "p7x_pipeline_cfg_default": (None, [C.POINTER(PipelineCfg)]),
     "p7x_search_block": (C.c_int, [C.POINTER(PipelineCfg), _VP, _VP, _VP, _VP, _VP, _VP, C.POINTER(_VP)]),
+    "p7x_postprocess_targets": (C.c_int, [C.POINTER(PipelineCfg), _VP, _VP, _VP, _VP, C.c_size_t, _VP, C.c_size_t, _VP, _VP, _VP,
+                                          _VP, _VP, _VP, _VP, _VP, C.POINTER(_VP)]),
     "p7x_tophits_destroy": (None, [_VP]),
     "p7x_tophits_clone": (_VP, [_VP]),
     "p7x_tophits_nhits": (C.c_int64, [_VP]),
@@ -175,6 +177,8 @@ _SIGNATURES = {
     "p7x_tophits_get_hit": (C.c_int, [_VP, C.c_int64, C.POINTER(HitRec)]),
     "p7x_tophits_get_domain": (C.c_int, [_VP, C.c_int64, C.c_int32, C.POINTER(DomainRec)]),
     "p7x_tophits_merge": (C.c_int, [_VP, _VP]),
+    "p7x_tophits_serialize": (C.c_int64, [_VP, _VP, C.c_size_t]),
+    "p7x_tophits_deserialize": (_VP, [_VP, C.c_size_t]),
     "p7x_tophits_sort_by_key": (C.c_int, [_VP]),
     "p7x_tophits_threshold": (C.c_int, [_VP]),
     "p7x_tophits_get_timings": (C.c_int, [_VP, C.POINTER(C.c_double), C.c_int]),

@@ -35,6 +35,7 @@ struct FastRng {
     a -= b; a -= c; a ^= (c >> 3);   b -= c; b -= a; b ^= (a << 10);  c -= a; c -= b; c ^= (b >> 15);
     return c;
   }
+  // esl_randomness_Init for the LCG type: the seed is dispersed with Jenkins' mix3, never zero
   void init(uint32_t s) { seed = s; x = mix3(s, 87654321u, 12345678u); if (x == 0) x = 42; }
   double next() { x = x * 69069u + 1u; return (double) x / 4294967296.0; }
 };
@@ -824,7 +825,7 @@ int domaindef_by_posterior_heuristics(const Profile &p, const uint8_t *dsq, int 
           for (int d = 0; d < ws.tr.ndom; ++d) {
             sp.push_back(SpCoord{ t, ws.tr.sqfrom[d] + i - 1, ws.tr.sqto[d] + i - 1, ws.tr.hmmfrom[d], ws.tr.hmmto[d], 0.0f });
             null2_by_trace(om, ws.tr, ws.tr.tfrom[d], ws.tr.tto[d], ws.wm, ws.wi, null2);
-            for (; pos <= ws.tr.sqfrom[d]; ++pos) dd.n2sc[i + pos - 1] += 1.0f;
+            for (; pos <= ws.tr.sqfrom[d]; ++pos) dd.n2sc[i + pos - 1] += 1.0f;   // sic: the first domain residue counts as "outside"
             for (; pos <= ws.tr.sqto[d]; ++pos) dd.n2sc[i + pos - 1] += null2[dsq[i + pos - 1]];
           }
           for (; pos <= Lr; ++pos) dd.n2sc[i + pos - 1] += 1.0f;

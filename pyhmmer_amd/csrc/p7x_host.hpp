@@ -48,12 +48,15 @@ struct Hit {                  // P7_HIT, p7_hit.pxd:27-58
   std::vector<Domain> dcl;
 };
 
-int host_finish_search(const p7x_pipeline_cfg &cfg, const p7x_oprofile *om, const p7x_seqdb *db,
+// The searched block as the host sees it: residues of target t are dsq[off[t] .. off[t]+len[t]-1], off[t] >= 1.
+struct HostTargets { int64_t n = 0, nres = 0; const int32_t *len = nullptr; const int64_t *off = nullptr; const uint8_t *dsq = nullptr; };
+
+// counts[4] = n_past_{msv,bias,vit,fwd}; targets[] = indices of the Forward survivors; fwdsc / xmx blocks per survivor.
+int host_finish_search(const p7x_pipeline_cfg &cfg, const p7x_oprofile *om, const HostTargets &tg,
                        const char *const *names, const char *const *accs, const char *const *descs,
-                       const std::vector<int32_t> &fin_slots, const std::vector<float> &usc,
-                       const std::vector<float> &filtersc, const std::vector<float> &fwdsc,
-                       const std::vector<float> &fwd_xmx, const std::vector<float> &bck_xmx,
-                       const std::vector<int64_t> &xmx_off, const int *counts, const double *ms, p7x_tophits **out);
+                       const std::vector<int32_t> &targets, const float *fwdsc,
+                       const float *fwd_xmx, const float *bck_xmx, const int64_t *xmx_off,
+                       const uint64_t *counts, const double *ms, p7x_tophits **out);
 void tophits_set_total_ms(p7x_tophits *th, double ms);
 float kahan_fsum(const float *v, int n);
 

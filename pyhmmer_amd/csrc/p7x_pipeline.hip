@@ -332,6 +332,7 @@ static int run_cascade(const p7x_pipeline_cfg &cfg, const p7x_oprofile *om, cons
   P7X_HIP(hipMemsetAsync(ws->b.counters, 0, 16 * 4, s));
   P7X_HIP(hipEventRecord(ws->ev[0], s));
   if ((st = run_msv(p, dp, db, ctx, ws)) != P7X_OK) return st;
+  P7X_HIP(hipEventRecord(ws->ev[7], s));
   {
     const unsigned grid = (unsigned) ((db->nslots + 255) / 256);
     hipLaunchKernelGGL(decide_msv_kernel, dim3(grid), dim3(256), 0, s, ws->b, sp, db->d_slot_len, ctx->lt.tjb, ctx->lt.null1, db->nslots);
@@ -410,6 +411,7 @@ static int run_cascade(const p7x_pipeline_cfg &cfg, const p7x_oprofile *om, cons
     P7X_HIP(hipStreamSynchronize(s));
   }
   for (int i = 0; i < 6; ++i) { float ms = 0; (void) hipEventElapsedTime(&ms, ws->ev[i], ws->ev[i + 1]); out.ms[i] = ms; }
+  { float ms = 0; (void) hipEventElapsedTime(&ms, ws->ev[0], ws->ev[7]); out.ms[7] = ms; }
   return P7X_OK;
 }
 
@@ -582,8 +584,13 @@ int p7x_search_block(const p7x_pipeline_cfg *cfg, const p7x_oprofile *om, const 
   CascadeOut co;
   int st = run_cascade(*cfg, om, db, co);
   if (st != P7X_OK) return st;
-  st = host_finish_search(*cfg, om, db, names, accs, descs, co.fin_slots, co.usc, co.filtersc, co.fwdsc,
-                          co.fwd_xmx, co.bck_xmx, co.xmx_off, co.counts, co.ms, out);
+  HostTargets tg;
+  tg.n = db->n; tg.nres = db->nres; tg.len = db->h_len.data(); tg.off = db->h_off.data(); tg.dsq = db->h_dsq.data();
+  std::vector<int32_t> targets(co.fin_slots.size());
+  for (size_t i = 0; i < targets.size(); ++i) targets[i] = db->h_order[co.fin_slots[i]];
+  const uint64_t counts[4] = { (uint64_t) co.counts[1], (uint64_t) co.counts[8], (uint64_t) co.counts[3], (uint64_t) co.counts[4] };
+  st = host_finish_search(*cfg, om, tg, names, accs, descs, targets, co.fwdsc.data(), co.fwd_xmx.data(), co.bck_xmx.data(),
+                          co.xmx_off.data(), counts, co.ms, out);
   if (st == P7X_OK) {
     const double total = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     tophits_set_total_ms(*out, total);

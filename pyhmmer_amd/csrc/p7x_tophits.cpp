@@ -4,7 +4,6 @@
 // p7_pipeline.pxd:130) and upstream p7_tophits.c: p7_tophits_SortBySortkey, p7_tophits_Threshold,
 // p7_tophits_Merge + p7_pipeline_Merge (reference p7_tophits.pxd:20-72; plan7.pyx:8804-8830, 9172-9276).
 #include "p7x_host.hpp"
-#include "p7x_device.hpp"
 #include <algorithm>
 #include <atomic>
 #include <chrono>
@@ -180,14 +179,12 @@ static void threshold(p7x_tophits &th)
           }
 }
 
-int host_finish_search(const p7x_pipeline_cfg &cfg_in, const p7x_oprofile *om, const p7x_seqdb *db,
+int host_finish_search(const p7x_pipeline_cfg &cfg_in, const p7x_oprofile *om, const HostTargets &tg,
                        const char *const *names, const char *const *accs, const char *const *descs,
-                       const std::vector<int32_t> &fin_slots, const std::vector<float> &usc,
-                       const std::vector<float> &filtersc, const std::vector<float> &fwdsc,
-                       const std::vector<float> &fwd_xmx, const std::vector<float> &bck_xmx,
-                       const std::vector<int64_t> &xmx_off, const int *counts, const double *ms, p7x_tophits **out)
+                       const std::vector<int32_t> &tgt, const float *fwdsc,
+                       const float *fwd_xmx, const float *bck_xmx, const int64_t *xmx_off,
+                       const uint64_t *counts, const double *ms, p7x_tophits **out)
 {
-  (void) usc; (void) filtersc;
   const Profile &p = om->p;
   auto th = std::make_unique<p7x_tophits>();
   th->cfg = cfg_in;
@@ -196,16 +193,14 @@ int host_finish_search(const p7x_pipeline_cfg &cfg_in, const p7x_oprofile *om, c
   th->qname = p.name; th->qacc = p.acc; th->qdesc = p.desc; th->q_has_acc = p.has_acc; th->q_has_desc = p.has_desc;
   th->M = p.M;
   th->ctr.nmodels = 1; th->ctr.nnodes = (uint64_t) p.M;
-  th->ctr.nseqs = (uint64_t) db->n; th->ctr.nres = (uint64_t) db->nres;
-  th->ctr.n_past_msv = (uint64_t) counts[1]; th->ctr.n_past_bias = (uint64_t) counts[8];
-  th->ctr.n_past_vit = (uint64_t) counts[3]; th->ctr.n_past_fwd = (uint64_t) counts[4];
-  for (int i = 0; i < 7; ++i) th->ms[i] = ms[i];
+  th->ctr.nseqs = (uint64_t) tg.n; th->ctr.nres = (uint64_t) tg.nres;
+  th->ctr.n_past_msv = counts[0]; th->ctr.n_past_bias = counts[1];
+  th->ctr.n_past_vit = counts[2]; th->ctr.n_past_fwd = counts[3];
+  if (ms) for (int i = 0; i < 8; ++i) th->ms[i] = ms[i];
 
   const auto t0 = std::chrono::steady_clock::now();
-  const int n = (int) fin_slots.size();
+  const int n = (int) tgt.size();
   std::vector<Pending> pend((size_t) n);
-  std::vector<int> tgt((size_t) n);
-  for (int i = 0; i < n; ++i) tgt[i] = db->h_order[fin_slots[i]];
   std::atomic<int> next{0};
   std::atomic<int> failed{0};
   auto worker = [&]() {
@@ -214,10 +209,10 @@ int host_finish_search(const p7x_pipeline_cfg &cfg_in, const p7x_oprofile *om, c
       const int i = next.fetch_add(1);
       if (i >= n) break;
       const int t = tgt[i];
-      const int L = db->h_len[t];
-      const uint8_t *dsq = db->h_dsq.data() + db->h_off[t] - 1;
+      const int L = tg.len[t];
+      const uint8_t *dsq = tg.dsq + tg.off[t] - 1;
       DomainDefResult dd;
-      const int st = domaindef_by_posterior_heuristics(p, dsq, L, fwd_xmx.data() + xmx_off[i], bck_xmx.data() + xmx_off[i],
+      const int st = domaindef_by_posterior_heuristics(p, dsq, L, fwd_xmx + xmx_off[i], bck_xmx + xmx_off[i],
                                                        cfg.seed, cfg.seed != 0, dd);
       if (st != P7X_OK) { failed.store(st); continue; }
       const double Zrun = (cfg.Z_setby == P7X_ZSETBY_NTARGETS) ? (double) (t + 1) : cfg.Z;
@@ -250,7 +245,7 @@ int host_finish_search(const p7x_pipeline_cfg &cfg_in, const p7x_oprofile *om, c
   }
   th->ms[5] = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
   // Z for E-values: number of targets seen (p7_pli_NewSeq), unless set by the caller
-  if (cfg.Z_setby == P7X_ZSETBY_NTARGETS) cfg.Z = (double) db->n;
+  if (cfg.Z_setby == P7X_ZSETBY_NTARGETS) cfg.Z = (double) tg.n;
   sort_by_key(*th);
   threshold(*th);
   *out = th.release();
@@ -264,6 +259,24 @@ void tophits_set_total_ms(p7x_tophits *th, double ms) { th->ms[6] = ms; }
 using namespace p7x;
 
 extern "C" {
+
+int p7x_postprocess_targets(const p7x_pipeline_cfg *cfg, const p7x_oprofile *om, const uint8_t *dsq, const int64_t *offsets,
+                            const int32_t *lengths, size_t n, const int32_t *surv, size_t nsurv, const float *fwdsc,
+                            const float *fwd_xmx, const float *bck_xmx, const int64_t *xmx_off, const uint64_t *stage_counts,
+                            const char *const *names, const char *const *accs, const char *const *descs, p7x_tophits **out)
+{
+  if (!cfg || !om || !out || (n && (!dsq || !offsets || !lengths)) || (nsurv && (!surv || !fwdsc || !fwd_xmx || !bck_xmx || !xmx_off))) {
+    set_error("p7x_postprocess_targets: bad arguments"); return P7X_EINVAL;
+  }
+  flogsum_init();
+  HostTargets tg;
+  tg.n = (int64_t) n; tg.len = lengths; tg.off = offsets; tg.dsq = dsq;
+  for (size_t t = 0; t < n; ++t) tg.nres += lengths[t];
+  std::vector<int32_t> targets(surv, surv + nsurv);
+  const uint64_t zero[4] = {0, 0, 0, 0};
+  return host_finish_search(*cfg, om, tg, names, accs, descs, targets, fwdsc, fwd_xmx, bck_xmx, xmx_off,
+                            stage_counts ? stage_counts : zero, nullptr, out);
+}
 
 void p7x_tophits_destroy(p7x_tophits *th) { delete th; }
 p7x_tophits *p7x_tophits_clone(const p7x_tophits *th) { return th ? new p7x_tophits(*th) : nullptr; }
@@ -345,7 +358,7 @@ int p7x_tophits_merge(p7x_tophits *dst, const p7x_tophits *src)
   dst->ctr.n_past_msv += src->ctr.n_past_msv; dst->ctr.n_past_bias += src->ctr.n_past_bias;
   dst->ctr.n_past_vit += src->ctr.n_past_vit; dst->ctr.n_past_fwd += src->ctr.n_past_fwd;
   if (dst->cfg.Z_setby == P7X_ZSETBY_NTARGETS) dst->cfg.Z += src->cfg.Z;
-  for (int i = 0; i < 7; ++i) dst->ms[i] += src->ms[i];
+  for (int i = 0; i < 8; ++i) dst->ms[i] += src->ms[i];
   if (!dst->cfg.use_bit_cutoffs)
     for (Hit &h : dst->hits) {
       h.flags &= ~(uint32_t) (P7X_IS_REPORTED | P7X_IS_INCLUDED);
@@ -357,10 +370,87 @@ int p7x_tophits_merge(p7x_tophits *dst, const p7x_tophits *src)
   return P7X_OK;
 }
 
+} // extern "C"
+
+// ---------------------------------------------------------------- serialisation (TopHits pickling, plan7.pyx:8394-8572)
+namespace {
+struct Writer {
+  std::vector<uint8_t> b;
+  template <class T> void pod(const T &v) { const uint8_t *q = reinterpret_cast<const uint8_t *>(&v); b.insert(b.end(), q, q + sizeof(T)); }
+  void str(const std::string &s) { const uint32_t n = (uint32_t) s.size(); pod(n); b.insert(b.end(), s.begin(), s.end()); }
+};
+struct Reader {
+  const uint8_t *p, *e; bool ok = true;
+  template <class T> void pod(T &v) { if (p + sizeof(T) > e) { ok = false; return; } std::memcpy(&v, p, sizeof(T)); p += sizeof(T); }
+  void str(std::string &s) { uint32_t n = 0; pod(n); if (!ok || p + n > e) { ok = false; return; } s.assign((const char *) p, n); p += n; }
+};
+constexpr uint32_t kMagic = 0x70377874u;   // "p7xt"
+
+template <class IO> void io_domain(IO &io, Domain &d)
+{
+  io.pod(d.ienv); io.pod(d.jenv); io.pod(d.iali); io.pod(d.jali); io.pod(d.envsc); io.pod(d.domcorrection); io.pod(d.dombias);
+  io.pod(d.oasc); io.pod(d.bitscore); io.pod(d.lnP); io.pod(d.is_reported); io.pod(d.is_included);
+  io.pod(d.N); io.pod(d.hmmfrom); io.pod(d.hmmto); io.pod(d.M); io.pod(d.sqfrom); io.pod(d.sqto); io.pod(d.L);
+  io.str(d.model); io.str(d.mline); io.str(d.aseq); io.str(d.ppline); io.str(d.rfline); io.str(d.mmline); io.str(d.csline);
+}
+template <class IO> void io_hit(IO &io, Hit &h)
+{
+  io.str(h.name); io.str(h.acc); io.str(h.desc); io.pod(h.has_acc); io.pod(h.has_desc); io.pod(h.seqidx); io.pod(h.sortkey);
+  io.pod(h.score); io.pod(h.pre_score); io.pod(h.sum_score); io.pod(h.lnP); io.pod(h.pre_lnP); io.pod(h.sum_lnP);
+  io.pod(h.nexpected); io.pod(h.nregions); io.pod(h.nclustered); io.pod(h.noverlaps); io.pod(h.nenvelopes); io.pod(h.ndom);
+  io.pod(h.flags); io.pod(h.nreported); io.pod(h.nincluded); io.pod(h.best_domain);
+}
+} // namespace
+
+extern "C" {
+
+int64_t p7x_tophits_serialize(const p7x_tophits *th, void *buf, size_t cap)
+{
+  if (!th) return -1;
+  Writer w;
+  uint32_t magic = kMagic; w.pod(magic);
+  w.pod(th->cfg); w.pod(th->ctr);
+  w.str(th->qname); w.str(th->qacc); w.str(th->qdesc); w.pod(th->q_has_acc); w.pod(th->q_has_desc); w.pod(th->M);
+  for (int i = 0; i < 8; ++i) w.pod(th->ms[i]);
+  const uint64_t n = th->hits.size(); w.pod(n);
+  for (const Hit &hc : th->hits) {
+    Hit &h = const_cast<Hit &>(hc);
+    io_hit(w, h);
+    for (Domain &d : h.dcl) io_domain(w, d);
+  }
+  if (buf && cap >= w.b.size()) std::memcpy(buf, w.b.data(), w.b.size());
+  return (int64_t) w.b.size();
+}
+
+p7x_tophits *p7x_tophits_deserialize(const void *buf, size_t n)
+{
+  if (!buf) return nullptr;
+  Reader r{ (const uint8_t *) buf, (const uint8_t *) buf + n };
+  uint32_t magic = 0; r.pod(magic);
+  if (!r.ok || magic != kMagic) { set_error("not a serialised TopHits"); return nullptr; }
+  auto th = std::make_unique<p7x_tophits>();
+  r.pod(th->cfg); r.pod(th->ctr);
+  r.str(th->qname); r.str(th->qacc); r.str(th->qdesc); r.pod(th->q_has_acc); r.pod(th->q_has_desc); r.pod(th->M);
+  for (int i = 0; i < 8; ++i) r.pod(th->ms[i]);
+  uint64_t nh = 0; r.pod(nh);
+  if (!r.ok) return nullptr;
+  th->hits.resize(nh);
+  for (Hit &h : th->hits) {
+    io_hit(r, h);
+    if (!r.ok || h.ndom < 0 || h.ndom > 100000) { set_error("corrupt serialised TopHits"); return nullptr; }
+    h.dcl.resize(h.ndom);
+    for (Domain &d : h.dcl) io_domain(r, d);
+  }
+  if (!r.ok) { set_error("truncated serialised TopHits"); return nullptr; }
+  sort_by_key(*th);
+  threshold(*th);
+  return th.release();
+}
+
 int p7x_tophits_get_timings(const p7x_tophits *th, double *ms, int n)
 {
   if (!th || !ms) return P7X_EINVAL;
-  for (int i = 0; i < n && i < 7; ++i) ms[i] = th->ms[i];
+  for (int i = 0; i < n && i < 8; ++i) ms[i] = th->ms[i];
   return P7X_OK;
 }
 

@@ -54,14 +54,28 @@ __device__ __forceinline__ short max16(short a, short b) { return a > b ? a : b;
 __device__ __forceinline__ short lo16(uint32_t w) { return (short) (w & 0xffffu); }
 __device__ __forceinline__ short hi16(uint32_t w) { return (short) (w >> 16); }
 
-// Each wave pulls targets from a shared counter; returns -1 when the list is exhausted.
-__device__ __forceinline__ int next_item(int *counter, int n, int lane)
+// Work distribution: wave w of the grid takes items w, w + nwaves, ...  Everything that steers control flow
+// (item index, slot, length, residue pointer) is forced into SGPRs with readfirstlane so that the row loops are
+// plain scalar loops: the DPP / readlane steps below must never run under a partial EXEC mask.
+struct Item { int slot, L; const uint8_t *sq; };
+
+__device__ __forceinline__ int rfl(int v) { return __builtin_amdgcn_readfirstlane(v); }
+
+__device__ __forceinline__ Item load_item(const WaveSeqArgs &a, int it)
 {
-  int it = 0;
-  if (lane == 0) it = atomicAdd(counter, 1);
-  it = __builtin_amdgcn_readfirstlane(it);
-  return it < n ? it : -1;
+  Item o;
+  o.slot = rfl(a.list ? a.list[it] : it);
+  o.L = rfl(a.slot_len[o.slot]);
+  const unsigned long long off = (unsigned long long) a.slot_off[o.slot];
+  const unsigned lo = (unsigned) rfl((int) (unsigned) off), hi = (unsigned) rfl((int) (unsigned) (off >> 32));
+  o.sq = a.dsq + (((unsigned long long) hi << 32) | lo);
+  return o;
 }
+
+#define P7X_WAVE_ITEMS(it)                                                                                   \
+  const int wave0_ = rfl((int) (blockIdx.x * (kWsBlock / 64) + (threadIdx.x >> 6)));                        \
+  const int nwaves_ = (int) (gridDim.x * (kWsBlock / 64));                                                  \
+  for (int it = wave0_; it < nlist; it += nwaves_)
 
 // ======================================================================================= Viterbi filter
 template <int C>
@@ -83,66 +97,67 @@ __global__ void __launch_bounds__(kWsBlock) vit_kernel(const WaveSeqArgs a)
   const short NEG = (short) -32768;
   const int nlist = a.nlist_ptr ? *a.nlist_ptr : a.nlist;
 
-  for (;;) {
-    const int it = next_item(a.counter, nlist, lane);
-    if (it < 0) break;
-    const int slot = a.list ? a.list[it] : it;
-    const int L = a.slot_len[slot];
-    const uint8_t *sq = a.dsq + a.slot_off[slot];
-    const int xwm = a.xwmove_tab[L];
+  P7X_WAVE_ITEMS(it) {
+    const Item item = load_item(a, it);
+    const int L = item.L;
+    const uint8_t *sq = item.sq;
+    const int xwm = rfl((int) a.xwmove_tab[L]);
 
     short mm[C], im[C], dm[C], tdd[C];
 #pragma unroll
     for (int c = 0; c < C; ++c) { mm[c] = im[c] = dm[c] = NEG; tdd[c] = NEG; }
     int xN = a.base_w, xB = xN + xwm, xJ = -32768, xC = -32768;
     bool overflow = false;
-    uint32_t resid = 0;
 
-    for (int i = 0; i < L; ++i) {
-      if ((i & 63) == 0) resid = (i + lane < L) ? sq[i + lane] : 0;
-      const int x = __builtin_amdgcn_readlane((int) resid, i & 63);
-      const short *er = em + x * Mpad + lane;
-      const short xBs = (short) xB;
-      short mp = (short) dpp_shr1(mm[C - 1], NEG);
-      short ip = (short) dpp_shr1(im[C - 1], NEG);
-      short dp = (short) dpp_shr1(dm[C - 1], NEG);
-      short rowmax = NEG, dmax = NEG, dcarry = NEG;
+    for (int i0 = 0; i0 < L && !overflow; i0 += 64) {
+      const int nrow = min(64, L - i0);
+      const uint32_t resid = (lane < nrow) ? sq[i0 + lane] : 0;
+      for (int r = 0; r < nrow && !overflow; ++r) {
+        const int x = __builtin_amdgcn_readlane((int) resid, r);
+        const short *er = em + x * Mpad + lane;
+        const short xBs = (short) xB;
+        short mp = (short) dpp_shr1(mm[C - 1], NEG);
+        short ip = (short) dpp_shr1(im[C - 1], NEG);
+        short dp = (short) dpp_shr1(dm[C - 1], NEG);
+        short rowmax = NEG, dmax = NEG, dcarry = NEG;
 #pragma unroll
-      for (int c = 0; c < C; ++c) {
-        const uint4 t = tr[c * 64 + lane];
-        short sv = adds16(xBs, lo16(t.x));
-        sv = max16(sv, adds16(mp, hi16(t.x)));
-        sv = max16(sv, adds16(ip, lo16(t.y)));
-        sv = max16(sv, adds16(dp, hi16(t.y)));
-        sv = adds16(sv, er[c * 64]);
-        rowmax = max16(rowmax, sv);
-        mp = mm[c]; ip = im[c]; dp = dm[c];
-        im[c] = max16(adds16(mp, hi16(t.z)), adds16(ip, lo16(t.w)));
-        mm[c] = sv;
-        dm[c] = dcarry;                       // M(i,k-1) -> D(i,k); node c=0 is patched below
-        dcarry = adds16(sv, lo16(t.z));
-        dmax = max16(dmax, dcarry);
-        tdd[c] = hi16(t.w);
-      }
-      dm[0] = (short) dpp_shr1(dcarry, NEG);
+        for (int c = 0; c < C; ++c) {
+          const uint4 t = tr[c * 64 + lane];
+          short sv = adds16(xBs, lo16(t.x));
+          sv = max16(sv, adds16(mp, hi16(t.x)));
+          sv = max16(sv, adds16(ip, lo16(t.y)));
+          sv = max16(sv, adds16(dp, hi16(t.y)));
+          sv = adds16(sv, er[c * 64]);
+          rowmax = max16(rowmax, sv);
+          mp = mm[c]; ip = im[c]; dp = dm[c];
+          im[c] = max16(adds16(mp, hi16(t.z)), adds16(ip, lo16(t.w)));
+          mm[c] = sv;
+          dm[c] = dcarry;                       // M(i,k-1) -> D(i,k); node c=0 is patched below
+          dcarry = adds16(sv, lo16(t.z));
+          dmax = max16(dmax, dcarry);
+          tdd[c] = hi16(t.w);
+        }
+        dm[0] = (short) dpp_shr1(dcarry, NEG);
 
-      const int xE = wave_max_i32((int) rowmax);
-      if (xE >= 32767) { overflow = true; break; }
-      xC = max(xC, xE + a.xw_e);              // xw[C][LOOP] = xw[J][LOOP] = xw[N][LOOP] = 0
-      xJ = max(xJ, xE + a.xw_e);
-      xB = max(xJ + xwm, xN + xwm);
+        const int xE = wave_max_i32((int) rowmax);
+        if (xE >= 32767) overflow = true;
+        xC = max(xC, xE + a.xw_e);              // xw[C][LOOP] = xw[J][LOOP] = xw[N][LOOP] = 0
+        xJ = max(xJ, xE + a.xw_e);
+        xB = max(xJ + xwm, xN + xwm);
 
-      const int Dmax = wave_max_i32((int) dmax);
-      if (Dmax + a.ddbound > xB) {            // lazy F: only now can a D->D path beat B->M on the next row
-#pragma unroll
-        for (int c = 1; c < C; ++c) dm[c] = max16(dm[c], adds16(dm[c - 1], tdd[c - 1]));
-        for (;;) {
-          const short ddout = adds16(dm[C - 1], tdd[C - 1]);
-          const short cand = (short) dpp_shr1(ddout, NEG);
-          if (!__any(cand > dm[0])) break;
-          dm[0] = max16(dm[0], cand);
+        const int Dmax = wave_max_i32((int) dmax);
+        if (Dmax + a.ddbound > xB) {            // lazy F: only now can a D->D path beat B->M on the next row
 #pragma unroll
           for (int c = 1; c < C; ++c) dm[c] = max16(dm[c], adds16(dm[c - 1], tdd[c - 1]));
+          for (int pass = 0; pass < 64; ++pass) { // a carry can cross at most 63 lane boundaries
+            const short ddout = adds16(dm[C - 1], tdd[C - 1]);
+            const short cand = (short) dpp_shr1(ddout, NEG);
+            const int improved = wave_max_i32((cand > dm[0]) ? 1 : 0);
+            if (improved == 0) break;
+            dm[0] = max16(dm[0], cand);
+#pragma unroll
+            for (int c = 1; c < C; ++c) dm[c] = max16(dm[c], adds16(dm[c - 1], tdd[c - 1]));
+          }
         }
       }
     }
@@ -176,12 +191,10 @@ __global__ void __launch_bounds__(kWsBlock) fwd_kernel(const WaveSeqArgs a)
   const int lane = threadIdx.x & 63;
   const int nlist = a.nlist_ptr ? *a.nlist_ptr : a.nlist;
 
-  for (;;) {
-    const int it = next_item(a.counter, nlist, lane);
-    if (it < 0) break;
-    const int slot = a.list ? a.list[it] : it;
-    const int L = a.slot_len[slot];
-    const uint8_t *sq = a.dsq + a.slot_off[slot];
+  P7X_WAVE_ITEMS(it) {
+    const Item item = load_item(a, it);
+    const int L = item.L;
+    const uint8_t *sq = item.sq;
     float *xo = a.xmx ? a.xmx + a.xmx_off[it] : nullptr;
     const float pmove = (2.0f + 1.0f) / ((float) L + 2.0f + 1.0f), ploop = 1.0f - pmove;
 
@@ -195,11 +208,12 @@ __global__ void __launch_bounds__(kWsBlock) fwd_kernel(const WaveSeqArgs a)
 
     float xN = 1.0f, xB = pmove, xJ = 0.0f, xC = 0.0f, xE = 0.0f, totscale = 0.0f;
     if (xo && lane == 0) { xo[0] = 0.0f; xo[1] = 1.0f; xo[2] = 0.0f; xo[3] = xB; xo[4] = 0.0f; xo[5] = 1.0f; }
-    uint32_t resid = 0;
-
-    for (int i = 0; i < L; ++i) {
-      if ((i & 63) == 0) resid = (i + lane < L) ? sq[i + lane] : 0;
-      const int x = __builtin_amdgcn_readlane((int) resid, i & 63);
+    for (int i0 = 0; i0 < L; i0 += 64) {
+     const int nrow = min(64, L - i0);
+     const uint32_t resid = (lane < nrow) ? sq[i0 + lane] : 0;
+     for (int r = 0; r < nrow; ++r) {
+      const int i = i0 + r;
+      const int x = __builtin_amdgcn_readlane((int) resid, r);
       const float *er = em + x * Mpad + lane;
       float mp = dpp_shr1f(mm[C - 1], 0.0f), ip = dpp_shr1f(im[C - 1], 0.0f), dp = dpp_shr1f(dm[C - 1], 0.0f);
       float esum = 0.0f, dcarry = 0.0f;
@@ -250,9 +264,10 @@ __global__ void __launch_bounds__(kWsBlock) fwd_kernel(const WaveSeqArgs a)
         xE = 1.0f;
       }
       if (xo && lane == 0) {
-        float *r = xo + (size_t) (i + 1) * 6;
-        r[0] = xE; r[1] = xN; r[2] = xJ; r[3] = xB; r[4] = xC; r[5] = scale;
+        float *row = xo + (size_t) (i + 1) * 6;
+        row[0] = xE; row[1] = xN; row[2] = xJ; row[3] = xB; row[4] = xC; row[5] = scale;
       }
+     }
     }
     if (lane == 0) {
       float sc;
@@ -284,12 +299,10 @@ __global__ void __launch_bounds__(kWsBlock) bck_kernel(const WaveSeqArgs a)
   const int lane = threadIdx.x & 63;
   const int nlist = a.nlist_ptr ? *a.nlist_ptr : a.nlist;
 
-  for (;;) {
-    const int it = next_item(a.counter, nlist, lane);
-    if (it < 0) break;
-    const int slot = a.list ? a.list[it] : it;
-    const int L = a.slot_len[slot];
-    const uint8_t *sq = a.dsq + a.slot_off[slot];
+  P7X_WAVE_ITEMS(it) {
+    const Item item = load_item(a, it);
+    const int L = item.L;
+    const uint8_t *sq = item.sq;
     const float *fx = a.fwd_xmx + a.xmx_off[it];
     float *xo = a.xmx + a.xmx_off[it];
     const float pmove = (2.0f + 1.0f) / ((float) L + 2.0f + 1.0f), ploop = 1.0f - pmove;
@@ -349,7 +362,7 @@ __global__ void __launch_bounds__(kWsBlock) bck_kernel(const WaveSeqArgs a)
 #pragma unroll
       for (int c = C - 1; c >= 0; --c) { mm[c] = mm[c] + dn * tmd[c]; dn = dm[c]; }
     }
-    float sc = fx[(size_t) L * 6 + 5];
+    float sc = __builtin_bit_cast(float, rfl(__builtin_bit_cast(int, fx[(size_t) L * 6 + 5])));
     if (sc > 1.0f) {
       xE = xE / sc; xN = xN / sc; xC = xC / sc; xJ = xJ / sc; xB = xB / sc;
       const float inv = (float) (1.0 / (double) sc);
@@ -360,7 +373,7 @@ __global__ void __launch_bounds__(kWsBlock) bck_kernel(const WaveSeqArgs a)
     if (lane == 0) { float *r = xo + (size_t) L * 6; r[0] = xE; r[1] = xN; r[2] = xJ; r[3] = xB; r[4] = xC; r[5] = sc; }
 
     for (int i = L - 1; i >= 1; --i) {
-      const int x = sq[i];                                  // residue x_{i+1} (0-based index i)
+      const int x = rfl((int) sq[i]);                       // residue x_{i+1} (0-based index i)
       const float *er = em + x * Mpad + lane;
       // mp(k) = M(i+1,k+1) e(x_{i+1},k+1): value of the NEXT node
       float me[C];
@@ -392,7 +405,7 @@ __global__ void __launch_bounds__(kWsBlock) bck_kernel(const WaveSeqArgs a)
         for (int c = C - 1; c >= 0; --c) { mm[c] = mm[c] + dn * tmd[c]; dn = dm[c]; }
       }
       if (xB > 1.0e16f) own_scales = true;
-      sc = own_scales ? ((xB > 1.0e4f) ? xB : 1.0f) : fx[(size_t) i * 6 + 5];
+      sc = own_scales ? ((xB > 1.0e4f) ? xB : 1.0f) : __builtin_bit_cast(float, rfl(__builtin_bit_cast(int, fx[(size_t) i * 6 + 5])));
       if (sc > 1.0f) {
         xE /= sc; xN /= sc; xJ /= sc; xB /= sc; xC /= sc;
         const float inv = (float) (1.0 / (double) sc);
@@ -404,7 +417,7 @@ __global__ void __launch_bounds__(kWsBlock) bck_kernel(const WaveSeqArgs a)
     }
     // row 0
     {
-      const int x = sq[0];
+      const int x = rfl((int) sq[0]);
       const float *er = em + x * Mpad + lane;
       float bsum = 0.0f;
 #pragma unroll

@@ -688,6 +688,11 @@ class Hit:
         return self._rec.name.decode()
 
     @property
+    def seqidx(self) -> int:
+        """Index of the target in the searched block / database."""
+        return self._rec.seqidx
+
+    @property
     def accession(self) -> Optional[str]:
         return _s(self._rec.acc)
 
@@ -848,9 +853,9 @@ class TopHits:
 
     @property
     def timings_ms(self) -> dict:
-        buf = (C.c_double * 7)()
-        _lib.lib().p7x_tophits_get_timings(self._handle, buf, 7)
-        return dict(zip(("msv", "bias", "viterbi", "forward", "fwd_rows", "host_domaindef_or_bck", "total"), buf))
+        buf = (C.c_double * 8)()
+        _lib.lib().p7x_tophits_get_timings(self._handle, buf, 8)
+        return dict(zip(("msv", "bias", "viterbi", "forward", "fwd_rows", "host_domaindef", "total", "msv_kernel"), buf))
 
     @property
     def reported(self):
@@ -871,6 +876,23 @@ class TopHits:
     def copy(self) -> "TopHits":
         h = _lib.lib().p7x_tophits_clone(self._handle)
         return TopHits(self.query, C.c_void_p(h))
+
+    def to_bytes(self) -> bytes:
+        """Flat byte image (``p7x_tophits_serialize``) for shipping results between processes / ranks."""
+        n = _lib.lib().p7x_tophits_serialize(self._handle, None, 0)
+        buf = C.create_string_buffer(int(n))
+        _lib.lib().p7x_tophits_serialize(self._handle, buf, n)
+        return buf.raw
+
+    @classmethod
+    def from_bytes(cls, data: bytes, query=None) -> "TopHits":
+        h = _lib.lib().p7x_tophits_deserialize(data, len(data))
+        if not h:
+            raise ValueError(_lib.last_error() or "cannot deserialise TopHits")
+        return cls(query, C.c_void_p(h))
+
+    def __reduce__(self):
+        return (TopHits.from_bytes, (self.to_bytes(), self.query if isinstance(self.query, str) else None))
 
     def merge(self, *others: "TopHits") -> "TopHits":
         """Reference ``plan7.pyx:9172-9276``: concatenate, sum the accounting, re-threshold with the global Z."""
@@ -974,6 +996,10 @@ class Pipeline:
             sequences = sequences.read_block()
         if isinstance(sequences, SequenceDatabase):
             database, sequences = sequences, sequences.block
+        if database is not None and sequences is None:        # database built by SequenceDatabase.from_packed
+            if database.alphabet != self.alphabet:
+                raise AlphabetMismatch(self.alphabet, database.alphabet)
+            return self._search_database(query, database)
         if not isinstance(sequences, DigitalSequenceBlock):
             raise TypeError(f"Expected DigitalSequenceBlock or SequenceFile, found {type(sequences).__name__}")
         if sequences.alphabet != self.alphabet:
@@ -985,6 +1011,10 @@ class Pipeline:
             if self._db_cache is None or self._db_cache[0] != key:
                 self._db_cache = (key, SequenceDatabase(sequences, device=self.device))
             database = self._db_cache[1]
+        return self._search_database(om, database, query)
+
+    def _search_database(self, query, database: "SequenceDatabase", label=None) -> TopHits:
+        om = self._get_om_from_query(query, self.L_HINT)
         cfg = self._cfg()
         out = C.c_void_p()
         bgf = np.ascontiguousarray(self.background.residue_frequencies, dtype=np.float32)
@@ -994,7 +1024,7 @@ class Pipeline:
             raise MissingCutoffs(om.name, self.bit_cutoffs)       # plan7.pyx:6424-6425
         if st != 0:
             raise status_to_exception(st, "p7x_search_block", _lib.last_error())
-        return TopHits(query, out)
+        return TopHits(label if label is not None else query, out)
 
 
 class SequenceDatabase:
@@ -1019,8 +1049,33 @@ class SequenceDatabase:
         self._accs = (C.c_char_p * max(n, 1))(*[(s.accession or "").encode() for s in block])
         self._descs = (C.c_char_p * max(n, 1))(*[(s.description or "").encode() for s in block])
 
+    @classmethod
+    def from_packed(cls, alphabet: Alphabet, dsq: np.ndarray, offsets: np.ndarray, lengths: np.ndarray,
+                    device: int = 0, names=None) -> "SequenceDatabase":
+        """Build directly from flat arrays (the C-ABI's own input format), skipping per-sequence Python objects.
+        Hits then carry the target index (``Hit.seqidx``) and, if ``names`` is None, an empty name."""
+        self = cls.__new__(cls)
+        self.block, self.device = None, device
+        self._n = int(lengths.shape[0])
+        if self._n and int(lengths.max()) > 100000:
+            raise ValueError("sequence length over comparison pipeline limit (100000)")
+        self._keep = (np.ascontiguousarray(dsq, dtype=np.uint8), np.ascontiguousarray(offsets, dtype=np.int64),
+                      np.ascontiguousarray(lengths, dtype=np.int32))
+        self.alphabet = alphabet
+        self._handle = C.c_void_p()
+        st = _lib.lib().p7x_seqdb_create(device, alphabet.type_code, self._keep[0].ctypes.data, self._keep[1].ctypes.data,
+                                         self._keep[2].ctypes.data, self._n, C.byref(self._handle))
+        if st != 0:
+            raise status_to_exception(st, "p7x_seqdb_create", _lib.last_error())
+        if names is None:
+            self._names = self._accs = self._descs = None
+        else:
+            self._names = (C.c_char_p * max(self._n, 1))(*[n.encode() for n in names])
+            self._accs = self._descs = None
+        return self
+
     def __len__(self) -> int:
-        return len(self.block)
+        return len(self.block) if self.block is not None else self._n
 
     def __del__(self):
         if getattr(self, "_handle", None):
@@ -1032,7 +1087,7 @@ class SequenceDatabase:
 
     def filters(self, om: OptimizedProfile, msv=True, viterbi=False, forward=False, bias=False):
         """Raw per-target filter outputs (``p7x_filters_batch``): dict of numpy arrays in target order."""
-        n = len(self.block)
+        n = len(self)
         out = {}
         xj = np.zeros(n, dtype=np.int32) if msv else None
         xc = np.zeros(n, dtype=np.int32) if viterbi else None

@@ -6,42 +6,11 @@ import numpy as np
 import pytest
 
 from conftest import golden_table, synthetic_block
+from golden_checks import check_domtbl as _check_domtbl, check_tbl as _check_tbl
 from pyhmmer_amd import easel, errors, hmmer, plan7
 from test_oracle_golden import STAGE_COUNTS
 
 pytestmark = pytest.mark.gpu
-
-
-def _check_tbl(hits, rows):
-    reported = [h for h in hits if h.reported]
-    assert len(reported) == len(rows)
-    for row, hit in itertools.zip_longest(rows, reported):
-        assert hit.name == row[0]
-        assert hit.accession is None if row[1] == "-" else hit.accession == row[1]
-        assert hit.score == pytest.approx(float(row[5]), abs=0.1)
-        assert hit.bias == pytest.approx(float(row[6]), abs=0.1)
-        assert f"{hit.evalue:9.2g}" == f"{float(row[4]):9.2g}" or hit.evalue == pytest.approx(float(row[4]), rel=0.12)
-        # best-domain and domain-number-estimation columns
-        assert hit.best_domain.score == pytest.approx(float(row[8]), abs=0.1)
-        assert hit.nexpected == pytest.approx(float(row[10]), abs=0.1)
-        assert (hit.nregions, hit.nclustered, hit.noverlaps, hit.nenvelopes) == tuple(int(v) for v in row[11:15])
-        assert len(hit.domains) == int(row[15])
-        assert len(hit.domains.reported) == int(row[16]) and len(hit.domains.included) == int(row[17])
-
-
-def _check_domtbl(hits, rows):
-    doms = [d for h in hits if h.reported for d in h.domains if d.reported]
-    assert len(doms) == len(rows)
-    for row, d in itertools.zip_longest(rows, doms):
-        assert d.hit.name == row[0]
-        assert d.score == pytest.approx(float(row[13]), abs=0.1)
-        assert d.bias == pytest.approx(float(row[14]), abs=0.1)
-        assert f"{d.c_evalue:9.2g}" == f"{float(row[11]):9.2g}" or d.c_evalue == pytest.approx(float(row[11]), rel=0.12)
-        assert f"{d.i_evalue:9.2g}" == f"{float(row[12]):9.2g}" or d.i_evalue == pytest.approx(float(row[12]), rel=0.12)
-        assert (d.alignment.hmm_from, d.alignment.hmm_to) == (int(row[15]), int(row[16]))
-        assert (d.alignment.target_from, d.alignment.target_to) == (int(row[17]), int(row[18]))
-        assert (d.env_from, d.env_to) == (int(row[19]), int(row[20]))
-        assert d.accuracy == pytest.approx(float(row[21]), abs=0.01)
 
 
 def test_pf02826_hits_and_domains_match_hmmer(models, proteome):
@@ -142,7 +111,7 @@ def test_z_and_bit_cutoffs(models, proteome):
     hits = plan7.Pipeline(hmm.alphabet, Z=25).search_hmm(hmm, proteome)
     assert hits.Z == 25
     ga = plan7.Pipeline(hmm.alphabet, bit_cutoffs="gathering").search_hmm(hmm, proteome)
-    assert all(h.score >= 25.1 for h in ga.reported) and len(ga.reported) == 6
+    assert all(h.score >= 25.1 for h in ga.reported) and len(ga.reported) == 7
     thio = models["Thioesterase"][0]
     with pytest.raises(errors.MissingCutoffs):
         plan7.Pipeline(thio.alphabet, bit_cutoffs="gathering").search_hmm(thio, proteome)
