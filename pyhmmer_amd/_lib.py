@@ -48,10 +48,7 @@ def build(force: bool = False, verbose: bool = False) -> Path:
         objs.append(o)
         if (not force) and o.exists() and o.stat().st_mtime >= max(p.stat().st_mtime for p in deps if p.suffix in (".hpp", ".h") or p == s):
             continue
-        cmd = [hipcc, *common, "-c", str(s), "-o", str(o)]
-        if s.suffix == ".cpp":
-            cmd.insert(1, "-x")
-            cmd.insert(2, "hip")
+        cmd = [hipcc, *common, "-c", str(s), "-o", str(o)]     # hipcc compiles .cpp units as HIP too (host code only)
         if verbose:
             print(" ".join(cmd))
         procs.append((s, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))

@@ -14,13 +14,41 @@
 // traceback) that visiting order is reproduced.  Runs only for ~1e-5 of random targets plus true homologs.
 #include "p7x_host.hpp"
 #include <algorithm>
+#include <atomic>
 #include <cctype>
+#include <chrono>
 #include <cmath>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 
 namespace p7x {
 
+// optional host profile (P7X_HOST_PROF=1): accumulated nanoseconds per phase, printed by host_prof_dump()
+static bool g_prof_on = std::getenv("P7X_HOST_PROF") != nullptr;
+static std::atomic<long long> g_prof_ns[12];
+static const char *g_prof_name[12] = { "domain_decoding", "region_forward", "stochastic_traces", "null2_by_trace", "cluster",
+                                        "env_forward", "env_backward", "env_decoding", "optimal_accuracy", "oa_trace+display",
+                                        "null2_expect", "other" };
+struct ProfScope {
+  int id; std::chrono::steady_clock::time_point t0;
+  explicit ProfScope(int i) : id(i) { if (g_prof_on) t0 = std::chrono::steady_clock::now(); }
+  ~ProfScope() { if (g_prof_on) g_prof_ns[id] += std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count(); }
+};
+void host_prof_dump()
+{
+  if (!g_prof_on) return;
+  for (int i = 0; i < 12; ++i) { std::fprintf(stderr, "[p7x host prof] %-18s %9.3f ms\n", g_prof_name[i], g_prof_ns[i].load() / 1e6); g_prof_ns[i] = 0; }
+}
+
 namespace {
+
+// hot loops are compiled twice (AVX2 and baseline x86-64) and dispatched at load time
+#if defined(__HIP_DEVICE_COMPILE__)
+#define P7X_MULTIVERSION
+#else
+#define P7X_MULTIVERSION __attribute__((target_clones("avx2", "default")))
+#endif
 
 enum { sM = 1, sD = 2, sI = 3, sS = 4, sN = 5, sB = 6, sE = 7, sC = 8, sT = 9, sJ = 10 };   // p7T_* (p7_trace.pxd)
 enum { xE_ = 0, xN_ = 1, xJ_ = 2, xB_ = 3, xC_ = 4, xS_ = 5, NX = 6 };
@@ -64,6 +92,26 @@ struct Model {
   float xf[4][2];                 // [E,N,J,C][MOVE,LOOP] for the current mode / length
   const float *tf(int t) const { return p->tf.data() + (size_t) t * (M + 1); }
   const float *rf(int x) const { return p->rf_.data() + (size_t) x * (M + 1); }
+  // D->D chains are the only serial dependency along k.  They are evaluated as kSeg independent segment chains
+  // (instruction-level parallelism) followed by a vectorisable carry fix-up with these prefix products.
+  static constexpr int kSeg = 8;
+  int seglen = 0;
+  std::vector<float> ddpre_f, ddpre_b, ddpass;      // ddpass[k]: 0 if every tDD from the segment start to k is > 0, else -inf
+  void prepare()
+  {
+    seglen = (M + kSeg - 1) / kSeg;
+    const float *tDD = tf(7);
+    ddpre_f.assign(M + 2, 0.0f); ddpre_b.assign(M + 2, 0.0f); ddpass.assign(M + 2, -INFINITY);
+    for (int s0 = 1; s0 <= M; s0 += seglen) {
+      const int s1 = std::min(M, s0 + seglen - 1);
+      float pr = 1.0f;
+      for (int k = s0; k <= s1; ++k) { pr *= tDD[k - 1]; ddpre_f[k] = pr; }      // product of tDD[s0-1 .. k-1]
+      bool open = true;
+      for (int k = s0; k <= s1; ++k) { open = open && (tDD[k - 1] > 0.0f); ddpass[k] = open ? 0.0f : -INFINITY; }
+      pr = 1.0f;
+      for (int k = s1; k >= s0; --k) { pr *= tDD[k]; ddpre_b[k] = pr; }          // product of tDD[k .. s1]
+    }
+  }
   void configure(bool multihit, int L)
   { // p7_oprofile_ReconfigMultihit / ReconfigUnihit (+ ReconfigLength)
     const float nj = multihit ? 1.0f : 0.0f;
@@ -77,7 +125,7 @@ struct Model {
 // Full DP matrix: rows 0..L, per row three arrays of M+1 floats (M, I, D) plus the specials.
 struct Matrix {
   int M = 0, L = 0;
-  std::vector<float> m, i, d, x;
+  std::vector<float> m, i, d, x, scratch;
   float totscale = 0.0f;
   bool own_scales = false;
   void resize(int M_, int L_)
@@ -86,6 +134,7 @@ struct Matrix {
     const size_t n = (size_t) (L + 1) * (M + 2);
     if (m.size() < n) { m.resize(n); i.resize(n); d.resize(n); }
     if (x.size() < (size_t) (L + 1) * NX) x.resize((size_t) (L + 1) * NX);
+    if (scratch.size() < (size_t) (M + 4) + 4 * (size_t) (L + 1)) scratch.resize((size_t) (M + 4) + 4 * (size_t) (L + 1));
   }
   float *M_(int r) { return m.data() + (size_t) r * (M + 2); }
   float *I_(int r) { return i.data() + (size_t) r * (M + 2); }
@@ -99,21 +148,49 @@ struct Matrix {
 
 // ---------------------------------------------------------------- p7_Forward (full matrix)
 // dsq is 1-indexed over the envelope: residues dsq[1..L].
-int forward_full(const Model &om, const uint8_t *dsq, int L, Matrix &ox, float *ret_sc)
+static inline float hsum8(const float (&acc)[8]) { return ((acc[0] + acc[1]) + (acc[2] + acc[3])) + ((acc[4] + acc[5]) + (acc[6] + acc[7])); }
+
+// D(i,k) = M(i,k-1) tMD(k-1) + D(i,k-1) tDD(k-1), k = 1..M, given the finished M row.
+P7X_MULTIVERSION static void dchain_forward(const Model &om, const float *__restrict mc, float *__restrict dc)
+{
+  const int M = om.M, seglen = om.seglen;
+  const float *__restrict tMD = om.tf(4), *__restrict tDD = om.tf(7);
+  for (int k = 1; k <= M; ++k) dc[k] = mc[k - 1] * tMD[k - 1];              // M->D part (vectorises); mc[0] = 0
+  float cur[Model::kSeg];
+  for (int s = 0; s < Model::kSeg; ++s) cur[s] = 0.0f;
+  for (int j = 0; j < seglen; ++j)                                          // kSeg independent chains, interleaved
+    for (int s = 0; s < Model::kSeg; ++s) {
+      const int k = 1 + s * seglen + j;
+      if (k > M) continue;
+      const float v = (j == 0) ? dc[k] : dc[k] + cur[s] * tDD[k - 1];
+      cur[s] = v; dc[k] = v;
+    }
+  for (int s = 1; s < Model::kSeg; ++s) {                                   // carries, in order
+    const int s0 = 1 + s * seglen;
+    if (s0 > M) break;
+    const int s1 = std::min(M, s0 + seglen - 1);
+    const float carry = dc[s0 - 1];
+    if (carry == 0.0f) continue;
+    const float *__restrict pre = om.ddpre_f.data();
+    for (int k = s0; k <= s1; ++k) dc[k] += carry * pre[k];
+  }
+}
+
+P7X_MULTIVERSION int forward_full(const Model &om, const uint8_t *dsq, int L, Matrix &ox, float *ret_sc)
 {
   const int M = om.M;
   ox.resize(M, L);
-  const float *tMM = om.tf(1), *tIM = om.tf(2), *tDM = om.tf(3), *tMD = om.tf(4), *tMI = om.tf(5), *tII = om.tf(6), *tDD = om.tf(7);
+  const float *__restrict bm = om.tf(0), *__restrict tMM = om.tf(1), *__restrict tIM = om.tf(2), *__restrict tDM = om.tf(3),
+              *__restrict tMI = om.tf(5), *__restrict tII = om.tf(6);
   float *m0 = ox.M_(0), *i0 = ox.I_(0), *d0 = ox.D_(0);
   for (int k = 0; k <= M + 1; ++k) m0[k] = i0[k] = d0[k] = 0.0f;
   float xE = 0.f, xN = 1.f, xJ = 0.f, xB = om.xf[XN][MOVE], xC = 0.f;
   ox.X(0, xE_) = xE; ox.X(0, xN_) = xN; ox.X(0, xJ_) = xJ; ox.X(0, xB_) = xB; ox.X(0, xC_) = xC; ox.X(0, xS_) = 1.0f;
   ox.totscale = 0.0f; ox.own_scales = true;
-  const float *bm = om.tf(0);
   for (int r = 1; r <= L; ++r) {
-    const float *rf = om.rf(dsq[r]);
-    const float *mp = ox.M_(r - 1), *ip = ox.I_(r - 1), *dp = ox.D_(r - 1);
-    float *mc = ox.M_(r), *ic = ox.I_(r), *dc = ox.D_(r);
+    const float *__restrict rf = om.rf(dsq[r]);
+    const float *__restrict mp = ox.M_(r - 1), *__restrict ip = ox.I_(r - 1), *__restrict dp = ox.D_(r - 1);
+    float *__restrict mc = ox.M_(r), *__restrict ic = ox.I_(r), *__restrict dc = ox.D_(r);
     mc[0] = ic[0] = dc[0] = 0.0f;
     for (int k = 1; k <= M; ++k) {
       float sv = xB * bm[k];
@@ -123,13 +200,13 @@ int forward_full(const Model &om, const uint8_t *dsq, int L, Matrix &ox, float *
       mc[k] = sv * rf[k];
       ic[k] = mp[k] * tMI[k] + ip[k] * tII[k];
     }
-    float esum = 0.0f;
-    dc[1] = 0.0f;
-    for (int k = 2; k <= M; ++k) dc[k] = mc[k - 1] * tMD[k - 1] + dc[k - 1] * tDD[k - 1];
-    for (int k = 1; k <= M; ++k) esum += mc[k];
-    for (int k = 1; k <= M; ++k) esum += dc[k];
+    dchain_forward(om, mc, dc);
+    float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    int k = 1;
+    for (; k + 7 <= M; k += 8) for (int z = 0; z < 8; ++z) acc[z] += mc[k + z] + dc[k + z];
+    for (; k <= M; ++k) acc[0] += mc[k] + dc[k];
     mc[M + 1] = ic[M + 1] = dc[M + 1] = 0.0f;
-    xE = esum;
+    xE = hsum8(acc);
     xN = xN * om.xf[XN][LOOP];
     xC = (xC * om.xf[XC][LOOP]) + (xE * om.xf[XE][MOVE]);
     xJ = (xJ * om.xf[XJ][LOOP]) + (xE * om.xf[XE][LOOP]);
@@ -137,7 +214,7 @@ int forward_full(const Model &om, const uint8_t *dsq, int L, Matrix &ox, float *
     if (xE > 1.0e4) {
       xN = xN / xE; xC = xC / xE; xJ = xJ / xE; xB = xB / xE;
       const float inv = 1.0 / xE;
-      for (int k = 1; k <= M; ++k) { mc[k] *= inv; dc[k] *= inv; ic[k] *= inv; }
+      for (int q = 1; q <= M; ++q) { mc[q] *= inv; dc[q] *= inv; ic[q] *= inv; }
       ox.X(r, xS_) = xE;
       ox.totscale += std::log((double) xE);
       xE = 1.0;
@@ -150,23 +227,53 @@ int forward_full(const Model &om, const uint8_t *dsq, int L, Matrix &ox, float *
 }
 
 // ---------------------------------------------------------------- p7_Backward (full matrix)
-int backward_full(const Model &om, const uint8_t *dsq, int L, const Matrix &fwd, Matrix &bck, float *ret_sc)
+// D(i,k) = base(k) + D(i,k+1) tDD(k), k = M..1 (D(i,M+1) = 0); on entry dc[k] = base(k).
+P7X_MULTIVERSION static void dchain_backward(const Model &om, float *__restrict dc)
+{
+  const int M = om.M, seglen = om.seglen;
+  const float *__restrict tDD = om.tf(7);
+  float cur[Model::kSeg];
+  for (int s = 0; s < Model::kSeg; ++s) cur[s] = 0.0f;
+  for (int j = 0; j < seglen; ++j)
+    for (int s = 0; s < Model::kSeg; ++s) {
+      const int s0 = 1 + s * seglen;
+      if (s0 > M) continue;
+      const int s1 = std::min(M, s0 + seglen - 1);
+      const int k = s1 - j;
+      if (k < s0) continue;
+      const float v = (j == 0) ? dc[k] : dc[k] + cur[s] * tDD[k];
+      cur[s] = v; dc[k] = v;
+    }
+  for (int s = Model::kSeg - 2; s >= 0; --s) {
+    const int s0 = 1 + s * seglen;
+    if (s0 > M) continue;
+    const int s1 = std::min(M, s0 + seglen - 1);
+    if (s1 + 1 > M) continue;
+    const float carry = dc[s1 + 1];
+    if (carry == 0.0f) continue;
+    const float *__restrict pre = om.ddpre_b.data();
+    for (int k = s0; k <= s1; ++k) dc[k] += carry * pre[k];
+  }
+}
+
+P7X_MULTIVERSION int backward_full(const Model &om, const uint8_t *dsq, int L, const Matrix &fwd, Matrix &bck, float *ret_sc)
 {
   const int M = om.M;
   bck.resize(M, L);
-  const float *bm = om.tf(0), *tMM = om.tf(1), *tIM = om.tf(2), *tDM = om.tf(3), *tMD = om.tf(4), *tMI = om.tf(5), *tII = om.tf(6), *tDD = om.tf(7);
+  const float *__restrict bm = om.tf(0), *__restrict tMM = om.tf(1), *__restrict tIM = om.tf(2), *__restrict tDM = om.tf(3),
+              *__restrict tMD = om.tf(4), *__restrict tMI = om.tf(5), *__restrict tII = om.tf(6);
   bck.own_scales = false;
   float xJ = 0.f, xB = 0.f, xN = 0.f;
   float xC = om.xf[XC][MOVE];
   float xE = xC * om.xf[XE][MOVE];
+  float *__restrict me = bck.scratch.data();          // [M+3] work row (no allocation inside the multiversioned body)
+  for (int k = 0; k <= M + 2; ++k) me[k] = 0.0f;
   {
-    float *mc = bck.M_(L), *ic = bck.I_(L), *dc = bck.D_(L);
+    float *__restrict mc = bck.M_(L), *__restrict ic = bck.I_(L), *__restrict dc = bck.D_(L);
     mc[M + 1] = ic[M + 1] = dc[M + 1] = 0.0f;
-    for (int k = M; k >= 1; --k) {
-      dc[k] = xE + dc[k + 1] * tDD[k];     // tDD[M] = 0
-      mc[k] = xE + dc[k + 1] * tMD[k];
-      ic[k] = 0.0f;
-    }
+    for (int k = 1; k <= M; ++k) { dc[k] = xE; ic[k] = 0.0f; }
+    dchain_backward(om, dc);
+    for (int k = 1; k <= M; ++k) mc[k] = xE + dc[k + 1] * tMD[k];
     mc[0] = ic[0] = dc[0] = 0.0f;
     float sc = fwd.X(L, xS_);
     if (sc > 1.0f) {
@@ -179,24 +286,31 @@ int backward_full(const Model &om, const uint8_t *dsq, int L, const Matrix &fwd,
     bck.X(L, xE_) = xE; bck.X(L, xN_) = xN; bck.X(L, xJ_) = xJ; bck.X(L, xB_) = xB; bck.X(L, xC_) = xC;
   }
   for (int r = L - 1; r >= 1; --r) {
-    const float *rf = om.rf(dsq[r + 1]);
-    const float *mn = bck.M_(r + 1), *in = bck.I_(r + 1);
-    float *mc = bck.M_(r), *ic = bck.I_(r), *dc = bck.D_(r);
-    float bsum = 0.0f;
-    for (int k = 1; k <= M; ++k) bsum += (mn[k] * rf[k]) * bm[k];
-    xB = bsum;
+    const float *__restrict rf = om.rf(dsq[r + 1]);
+    const float *__restrict mn = bck.M_(r + 1), *__restrict in = bck.I_(r + 1);
+    float *__restrict mc = bck.M_(r), *__restrict ic = bck.I_(r), *__restrict dc = bck.D_(r);
+    float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (int k = 1; k <= M; ++k) me[k] = mn[k] * rf[k];                      // M(i+1,k) e(x_{i+1},k)
+    me[M + 1] = 0.0f;
+    int kk = 1;
+    for (; kk + 7 <= M; kk += 8) for (int z = 0; z < 8; ++z) acc[z] += me[kk + z] * bm[kk + z];
+    for (; kk <= M; ++kk) acc[0] += me[kk] * bm[kk];
+    xB = hsum8(acc);
     xC = xC * om.xf[XC][LOOP];
     xJ = (xB * om.xf[XJ][MOVE]) + (xJ * om.xf[XJ][LOOP]);
     xN = (xB * om.xf[XN][MOVE]) + (xN * om.xf[XN][LOOP]);
     xE = (xC * om.xf[XE][MOVE]) + (xJ * om.xf[XE][LOOP]);
     mc[M + 1] = ic[M + 1] = dc[M + 1] = 0.0f;
-    for (int k = M; k >= 1; --k) {
-      const float me = (k < M) ? mn[k + 1] * rf[k + 1] : 0.0f;     // M(i+1,k+1) e(x_{i+1}, k+1)
-      const float tmm = (k < M) ? tMM[k + 1] : 0.0f, tim = (k < M) ? tIM[k + 1] : 0.0f, tdm = (k < M) ? tDM[k + 1] : 0.0f;
-      ic[k] = in[k] * tII[k] + me * tim;
-      dc[k] = (me * tdm + xE) + dc[k + 1] * tDD[k];
-      mc[k] = ((in[k] * tMI[k] + me * tmm) + xE) + dc[k + 1] * tMD[k];
+    // entering-transitions of node k+1 are stored at index k+1; node M+1 does not exist (me[M+1] = 0)
+    for (int k = 1; k < M; ++k) {
+      const float mek = me[k + 1];
+      ic[k] = in[k] * tII[k] + mek * tIM[k + 1];
+      dc[k] = mek * tDM[k + 1] + xE;
+      mc[k] = (in[k] * tMI[k] + mek * tMM[k + 1]) + xE;
     }
+    ic[M] = in[M] * tII[M]; dc[M] = xE; mc[M] = in[M] * tMI[M] + xE;
+    dchain_backward(om, dc);
+    for (int k = 1; k <= M; ++k) mc[k] += dc[k + 1] * tMD[k];
     mc[0] = ic[0] = dc[0] = 0.0f;
     if (xB > 1.0e16) bck.own_scales = true;
     float sc = bck.own_scales ? ((xB > 1.0e4) ? xB : 1.0f) : fwd.X(r, xS_);
@@ -210,8 +324,8 @@ int backward_full(const Model &om, const uint8_t *dsq, int L, const Matrix &fwd,
     bck.X(r, xE_) = xE; bck.X(r, xN_) = xN; bck.X(r, xJ_) = xJ; bck.X(r, xB_) = xB; bck.X(r, xC_) = xC;
   }
   {
-    const float *rf = om.rf(dsq[1]);
-    const float *mn = bck.M_(1);
+    const float *__restrict rf = om.rf(dsq[1]);
+    const float *__restrict mn = bck.M_(1);
     float bsum = 0.0f;
     for (int k = 1; k <= M; ++k) bsum += (mn[k] * rf[k]) * bm[k];
     xB = bsum;
@@ -226,13 +340,13 @@ int backward_full(const Model &om, const uint8_t *dsq, int L, const Matrix &fwd,
 }
 
 // ---------------------------------------------------------------- p7_Decoding: posteriors into <bck> (in place)
-int decoding(const Model &om, const Matrix &fwd, Matrix &bck)
+P7X_MULTIVERSION int decoding(const Model &om, const Matrix &fwd, Matrix &bck)
 {
   const int M = om.M, L = fwd.L;
   float scaleproduct = 1.0 / bck.X(0, xN_);
   // row 0 is zeroed *after* reading xN(0); upstream writes into a third matrix, we overwrite <bck> row by row,
   // which is safe because row i of the posterior only needs row i of both matrices and specials of row i-1 (fwd).
-  std::vector<float> bN(L + 1), bJ(L + 1), bC(L + 1), bS(L + 1);
+  float *bN = bck.scratch.data() + (M + 4), *bJ = bN + (L + 1), *bC = bJ + (L + 1), *bS = bC + (L + 1);
   for (int r = 0; r <= L; ++r) { bN[r] = bck.X(r, xN_); bJ[r] = bck.X(r, xJ_); bC[r] = bck.X(r, xC_); bS[r] = bck.X(r, xS_); }
   {
     float *mc = bck.M_(0), *ic = bck.I_(0), *dc = bck.D_(0);
@@ -241,8 +355,8 @@ int decoding(const Model &om, const Matrix &fwd, Matrix &bck)
   }
   for (int r = 1; r <= L; ++r) {
     const float totr = scaleproduct * fwd.X(r, xS_);
-    const float *fm = fwd.M_(r), *fi = fwd.I_(r);
-    float *mc = bck.M_(r), *ic = bck.I_(r), *dc = bck.D_(r);
+    const float *__restrict fm = fwd.M_(r), *__restrict fi = fwd.I_(r);
+    float *__restrict mc = bck.M_(r), *__restrict ic = bck.I_(r), *__restrict dc = bck.D_(r);
     for (int k = 1; k <= M; ++k) {
       mc[k] = (fm[k] * mc[k]) * totr;
       dc[k] = 0.0f;
@@ -271,7 +385,7 @@ void finish_null2(const Profile &p, float *null2)
 }
 
 // ---------------------------------------------------------------- p7_Null2_ByExpectation (pp = posterior matrix)
-void null2_by_expectation(const Model &om, Matrix &pp, float *null2)
+P7X_MULTIVERSION void null2_by_expectation(const Model &om, Matrix &pp, float *null2)
 {
   const int M = om.M, Ld = pp.L;
   float *m0 = pp.M_(0), *i0 = pp.I_(0);
@@ -353,8 +467,9 @@ struct Trace {
 
 // ---------------------------------------------------------------- p7_OptimalAccuracy + p7_OATrace
 inline float gate(float t, float v) { return t > 0.0f ? v : 0.0f; }   // upstream: and(cmpgt(t,0), v)
+inline float vmax(float a, float b) { return a > b ? a : b; }
 
-void optimal_accuracy(const Model &om, const Matrix &pp, Matrix &ox, float *ret_e)
+P7X_MULTIVERSION void optimal_accuracy(const Model &om, const Matrix &pp, Matrix &ox, float *ret_e)
 {
   const int M = om.M, L = pp.L;
   ox.resize(M, L);
@@ -365,27 +480,53 @@ void optimal_accuracy(const Model &om, const Matrix &pp, Matrix &ox, float *ret_
   }
   ox.X(0, xE_) = -INFINITY; ox.X(0, xN_) = 0.f; ox.X(0, xJ_) = -INFINITY; ox.X(0, xB_) = 0.f; ox.X(0, xC_) = -INFINITY;
   for (int r = 1; r <= L; ++r) {
-    const float *mp = ox.M_(r - 1), *ip = ox.I_(r - 1), *dp = ox.D_(r - 1);
-    const float *pm = pp.M_(r), *pi = pp.I_(r);
-    float *mc = ox.M_(r), *ic = ox.I_(r), *dc = ox.D_(r);
+    const float *__restrict mp = ox.M_(r - 1), *__restrict ip = ox.I_(r - 1), *__restrict dp = ox.D_(r - 1);
+    const float *__restrict pm = pp.M_(r), *__restrict pi = pp.I_(r);
+    float *__restrict mc = ox.M_(r), *__restrict ic = ox.I_(r), *__restrict dc = ox.D_(r);
     const float xB = ox.X(r - 1, xB_);
     mc[0] = ic[0] = dc[0] = -INFINITY;
-    float xEmax = -INFINITY;
     for (int k = 1; k <= M; ++k) {
       float sv = gate(bm[k], xB);
-      sv = std::fmax(sv, gate(tMM[k], mp[k - 1]));
-      sv = std::fmax(sv, gate(tIM[k], ip[k - 1]));
-      sv = std::fmax(sv, gate(tDM[k], dp[k - 1]));
-      sv = sv + pm[k];
-      mc[k] = sv;
-      xEmax = std::fmax(xEmax, sv);
+      sv = vmax(sv, gate(tMM[k], mp[k - 1]));
+      sv = vmax(sv, gate(tIM[k], ip[k - 1]));
+      sv = vmax(sv, gate(tDM[k], dp[k - 1]));
+      mc[k] = sv + pm[k];
       float iv = gate(tMI[k], mp[k]);
-      iv = std::fmax(iv, gate(tII[k], ip[k]));
+      iv = vmax(iv, gate(tII[k], ip[k]));
       ic[k] = iv + pi[k];
     }
-    dc[1] = -INFINITY;
-    for (int k = 2; k <= M; ++k) dc[k] = std::fmax(gate(tMD[k - 1], mc[k - 1]), gate(tDD[k - 1], dc[k - 1]));
-    for (int k = 1; k <= M; ++k) xEmax = std::fmax(xEmax, dc[k]);
+    // D(i,k) = max( gate(tMD(k-1), M(i,k-1)), gate(tDD(k-1), D(i,k-1)) ): segment chains + carry fix-up
+    {
+      const int seglen = om.seglen;
+      for (int k = 1; k <= M; ++k) dc[k] = vmax(gate(tMD[k - 1], mc[k - 1]), (tDD[k - 1] > 0.0f) ? -INFINITY : 0.0f);
+      dc[1] = -INFINITY;
+      float cur[Model::kSeg];
+      for (int s = 0; s < Model::kSeg; ++s) cur[s] = -INFINITY;
+      for (int j = 0; j < seglen; ++j)
+        for (int s = 0; s < Model::kSeg; ++s) {
+          const int k = 1 + s * seglen + j;
+          if (k > M) continue;
+          const float v = (j == 0) ? dc[k] : vmax(dc[k], (tDD[k - 1] > 0.0f) ? cur[s] : -INFINITY);
+          cur[s] = v; dc[k] = v;
+        }
+      const float *__restrict pass = om.ddpass.data();
+      for (int s = 1; s < Model::kSeg; ++s) {
+        const int s0 = 1 + s * seglen;
+        if (s0 > M) break;
+        const int s1 = (M < s0 + seglen - 1) ? M : s0 + seglen - 1;
+        const float carry = dc[s0 - 1];
+        if (carry == -INFINITY) continue;
+        for (int k = s0; k <= s1; ++k) dc[k] = vmax(dc[k], carry + pass[k]);
+      }
+    }
+    float xEmax = -INFINITY;
+    {
+      float a8[8]; for (int z = 0; z < 8; ++z) a8[z] = -INFINITY;
+      int k = 1;
+      for (; k + 7 <= M; k += 8) for (int z = 0; z < 8; ++z) a8[z] = vmax(a8[z], vmax(mc[k + z], dc[k + z]));
+      for (; k <= M; ++k) a8[0] = vmax(a8[0], vmax(mc[k], dc[k]));
+      for (int z = 0; z < 8; ++z) xEmax = vmax(xEmax, a8[z]);
+    }
     mc[M + 1] = ic[M + 1] = dc[M + 1] = -INFINITY;
     ox.X(r, xE_) = xEmax;
     float t1, t2;
@@ -739,10 +880,11 @@ int rescore_isolated_domain(const Profile &p, Model &om, const uint8_t *dsq, int
 {
   const int Ld = j - i + 1;
   float envsc = 0.0f, oasc = 0.0f;
-  forward_full(om, dsq + i - 1, Ld, ws.fwd, &envsc);
-  backward_full(om, dsq + i - 1, Ld, ws.fwd, ws.bck, nullptr);
-  if (decoding(om, ws.fwd, ws.bck) == P7X_ERANGE) return P7X_ENORESULT;   // repetitive garbage; the envelope is dropped
-  optimal_accuracy(om, ws.bck, ws.fwd, &oasc);                              // <fwd> now holds the OA matrix
+  { ProfScope ps(5); forward_full(om, dsq + i - 1, Ld, ws.fwd, &envsc); }
+  { ProfScope ps(6); backward_full(om, dsq + i - 1, Ld, ws.fwd, ws.bck, nullptr); }
+  { ProfScope ps(7); if (decoding(om, ws.fwd, ws.bck) == P7X_ERANGE) return P7X_ENORESULT; }   // repetitive garbage; the envelope is dropped
+  { ProfScope ps(8); optimal_accuracy(om, ws.bck, ws.fwd, &oasc); }                              // <fwd> now holds the OA matrix
+  ProfScope ps9(9);
   if (oa_trace(om, ws.bck, ws.fwd, ws.tr) != P7X_OK) return P7X_EINVAL;
   for (size_t z = 0; z < ws.tr.st.size(); ++z) if (ws.tr.i[z] > 0) ws.tr.i[z] += i - 1;
   Domain dom;
@@ -750,6 +892,7 @@ int rescore_isolated_domain(const Profile &p, Model &om, const uint8_t *dsq, int
   float domcorrection = 0.0f;
   if (!null2_is_done) {
     float null2[MAXKP];
+    ProfScope psn(10);
     null2_by_expectation(om, ws.bck, null2);
     for (int pos = i; pos <= j; ++pos) dd.n2sc[pos] = logf(null2[dsq[pos]]);
   }
@@ -773,6 +916,7 @@ int domaindef_by_posterior_heuristics(const Profile &p, const uint8_t *dsq, int 
   const bool of_smaller = true; const int max_diagdiff = 4;
 
   Model om{ &p, p.M, {} };
+  om.prepare();
   thread_local Workspace ws;
   dd.dcl.clear(); dd.n2sc.assign(L + 1, 0.0f);
   dd.nregions = dd.nclustered = dd.noverlaps = dd.nenvelopes = 0;
@@ -812,19 +956,19 @@ int domaindef_by_posterior_heuristics(const Profile &p, const uint8_t *dsq, int 
         dd.nclustered++;
         // region_trace_ensemble: sample tracebacks from a multihit Forward matrix of the region, cluster them
         om.configure(true, L);
-        forward_full(om, dsq + i - 1, j - i + 1, ws.fwd, nullptr);
+        { ProfScope ps(1); forward_full(om, dsq + i - 1, j - i + 1, ws.fwd, nullptr); }
         const int Lr = j - i + 1;
         for (int pos = i; pos <= j; ++pos) dd.n2sc[pos] = 0.0f;
         if (do_reseeding) rng.init(seed);
         std::vector<SpCoord> sp;
         float null2[MAXKP];
         for (int t = 0; t < nsamples; ++t) {
-          if (stochastic_trace(rng, om, ws.fwd, Lr, ws.tr) != P7X_OK) return P7X_EINVAL;
+          { ProfScope ps(2); if (stochastic_trace(rng, om, ws.fwd, Lr, ws.tr) != P7X_OK) return P7X_EINVAL; }
           ws.tr.index();
           int pos = 1;
           for (int d = 0; d < ws.tr.ndom; ++d) {
             sp.push_back(SpCoord{ t, ws.tr.sqfrom[d] + i - 1, ws.tr.sqto[d] + i - 1, ws.tr.hmmfrom[d], ws.tr.hmmto[d], 0.0f });
-            null2_by_trace(om, ws.tr, ws.tr.tfrom[d], ws.tr.tto[d], ws.wm, ws.wi, null2);
+            { ProfScope ps(3); null2_by_trace(om, ws.tr, ws.tr.tfrom[d], ws.tr.tto[d], ws.wm, ws.wi, null2); }
             for (; pos <= ws.tr.sqfrom[d]; ++pos) dd.n2sc[i + pos - 1] += 1.0f;   // sic: the first domain residue counts as "outside"
             for (; pos <= ws.tr.sqto[d]; ++pos) dd.n2sc[i + pos - 1] += null2[dsq[i + pos - 1]];
           }
@@ -832,7 +976,7 @@ int domaindef_by_posterior_heuristics(const Profile &p, const uint8_t *dsq, int 
         }
         for (int pos = i; pos <= j; ++pos) dd.n2sc[pos] = logf(dd.n2sc[pos] / (float) nsamples);
         std::vector<SpCoord> sigc;
-        sp_cluster(sp, nsamples, min_overlap, of_smaller, max_diagdiff, min_posterior, min_endpointp, sigc);
+        { ProfScope ps(4); sp_cluster(sp, nsamples, min_overlap, of_smaller, max_diagdiff, min_posterior, min_endpointp, sigc); }
         // remove envelopes dominated (>= 80% overlap of the smaller) by a more probable one
         const int nc0 = (int) sigc.size();
         std::vector<char> dominated(nc0, 0);

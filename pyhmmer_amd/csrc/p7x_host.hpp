@@ -59,6 +59,7 @@ int host_finish_search(const p7x_pipeline_cfg &cfg, const p7x_oprofile *om, cons
                        const uint64_t *counts, const double *ms, p7x_tophits **out);
 void tophits_set_total_ms(p7x_tophits *th, double ms);
 float kahan_fsum(const float *v, int n);
+void host_prof_dump();
 
 } // namespace p7x
 

@@ -396,16 +396,9 @@ static int run_cascade(const p7x_pipeline_cfg &cfg, const p7x_oprofile *om, cons
     out.fwd_xmx.resize(tot); out.bck_xmx.resize(tot);
     P7X_HIP(hipMemcpyAsync(out.fwd_xmx.data(), ws->xmx_f, (size_t) tot * 4, hipMemcpyDeviceToHost, s));
     P7X_HIP(hipMemcpyAsync(out.bck_xmx.data(), ws->xmx_b, (size_t) tot * 4, hipMemcpyDeviceToHost, s));
-    std::vector<float> usc_all, fsc_all, vsc_all, fwd_all;
-    // gather per-survivor scores with small strided copies (nfin is tiny next to the database)
-    std::vector<float> tmp(4);
+    // the rows pass recomputed each survivor's Forward score in list order: one contiguous copy
+    P7X_HIP(hipMemcpyAsync(out.fwdsc.data(), ws->b.fwd_by_item, (size_t) nfin * 4, hipMemcpyDeviceToHost, s));
     P7X_HIP(hipStreamSynchronize(s));
-    for (int i = 0; i < nfin; ++i) {
-      const int sl = out.fin_slots[i];
-      P7X_HIP(hipMemcpy(&out.usc[i], ws->b.usc + sl, 4, hipMemcpyDeviceToHost));
-      P7X_HIP(hipMemcpy(&out.filtersc[i], ws->b.filtersc + sl, 4, hipMemcpyDeviceToHost));
-      P7X_HIP(hipMemcpy(&out.fwdsc[i], ws->b.fwdsc + sl, 4, hipMemcpyDeviceToHost));
-    }
   } else {
     P7X_HIP(hipEventRecord(ws->ev[5], s)); P7X_HIP(hipEventRecord(ws->ev[6], s));
     P7X_HIP(hipStreamSynchronize(s));

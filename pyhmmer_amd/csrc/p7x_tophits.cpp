@@ -8,7 +8,10 @@
 #include <atomic>
 #include <chrono>
 #include <cmath>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
+#include <sched.h>
 #include <thread>
 
 namespace p7x {
@@ -45,6 +48,28 @@ static void apply_bit_cutoffs(p7x_pipeline_cfg &c, const Profile &p)
 }
 
 struct Pending { bool have = false; Hit hit; };
+
+// CPUs this process may actually use: affinity mask, then the cgroup CPU quota (containers on many-core hosts)
+static int usable_cpus()
+{
+  int n = (int) std::thread::hardware_concurrency();
+  cpu_set_t set;
+  if (sched_getaffinity(0, sizeof(set), &set) == 0) { const int c = CPU_COUNT(&set); if (c > 0 && (n <= 0 || c < n)) n = c; }
+  if (FILE *f = std::fopen("/sys/fs/cgroup/cpu.max", "r")) {            // cgroup v2: "<quota|max> <period>"
+    char q[64]; long period = 0;
+    if (std::fscanf(f, "%63s %ld", q, &period) == 2 && std::strcmp(q, "max") != 0 && period > 0) {
+      const long quota = std::atol(q);
+      if (quota > 0) { const int c = (int) ((quota + period - 1) / period); if (c > 0 && c < n) n = c; }
+    }
+    std::fclose(f);
+  } else {
+    long quota = -1, period = -1;                                        // cgroup v1
+    if (FILE *g = std::fopen("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", "r")) { if (std::fscanf(g, "%ld", &quota) != 1) quota = -1; std::fclose(g); }
+    if (FILE *g = std::fopen("/sys/fs/cgroup/cpu/cpu.cfs_period_us", "r")) { if (std::fscanf(g, "%ld", &period) != 1) period = -1; std::fclose(g); }
+    if (quota > 0 && period > 0) { const int c = (int) ((quota + period - 1) / period); if (c > 0 && c < n) n = c; }
+  }
+  return n > 0 ? n : 1;
+}
 
 float kahan_fsum(const float *v, int n)
 { // Easel esl_vec_FSum: Kahan compensated summation
@@ -220,15 +245,17 @@ int host_finish_search(const p7x_pipeline_cfg &cfg_in, const p7x_oprofile *om, c
       if (pend[i].have) pend[i].hit.seqidx = t;
     }
   };
-  int nthreads = cfg.host_threads > 0 ? cfg.host_threads : (int) std::thread::hardware_concurrency();
+  int nthreads = cfg.host_threads > 0 ? cfg.host_threads : usable_cpus();
   if (nthreads < 1) nthreads = 1;
-  if (nthreads > n) nthreads = n > 0 ? n : 1;
+  if (nthreads > (n + 3) / 4) nthreads = (n + 3) / 4;      // at least ~4 targets per worker
+  if (nthreads < 1) nthreads = 1;
   if (nthreads <= 1) worker();
   else {
     std::vector<std::thread> pool;
     for (int i = 0; i < nthreads; ++i) pool.emplace_back(worker);
     for (auto &t : pool) t.join();
   }
+  host_prof_dump();
   if (failed.load() != 0) { set_error("domain definition workflow failure"); return failed.load(); }
   // hits in target order, as the reference's sequential loop would have appended them
   std::vector<int> idx((size_t) n);
