@@ -1,0 +1,84 @@
+"""The N>1 path on CPU: two `gloo` ranks each search their residue-balanced shard of the targets, ship their
+serialised TopHits to rank 0 (all_gather_object -- results only, no data-path collective), rank 0 merges and
+re-thresholds.  The merged list must equal the single-process search field by field
+(reference tests/test_plan7/test_tophits.py:191-224; bench.py uses the same gather + merge for --gpus N).
+
+No GPU here: each rank's device half is stood in for by the oracle (tests/host_pipeline.py); the sharding, the
+serialisation, the gather and p7x_tophits_merge are the product's."""
+import os
+import socket
+import sys
+from pathlib import Path
+
+import pytest
+
+ROOT = Path(__file__).resolve().parent.parent
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank, world, port, out_path):
+    sys.path.insert(0, str(ROOT)); sys.path.insert(0, str(ROOT / "tests"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import pickle
+    import torch.distributed as dist
+    import host_pipeline
+    import oracle_lib
+    from conftest import GOLDEN, load_hmms
+    from pyhmmer_amd import easel, hmmer, plan7
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    with easel.SequenceFile(GOLDEN / "seqs" / "938293.PRJEB85.HG003687.faa", digital=True, alphabet=easel.Alphabet.amino()) as sf:
+        block = sf.read_block()
+    hmm = load_hmms("PF02826")[0]
+    shard = hmmer.make_chunks(block, world)[rank]
+    hits = host_pipeline.host_search(oracle_lib, hmm, shard)
+    blobs = [None] * world
+    dist.all_gather_object(blobs, hits.to_bytes())
+    if rank == 0:
+        merged = plan7.TopHits.from_bytes(blobs[0])
+        for b in blobs[1:]:
+            merged = merged.merge(plan7.TopHits.from_bytes(b))
+        whole = host_pipeline.host_search(oracle_lib, hmm, block)
+        def dump(th):
+            return [(h.name, h.score, h.pre_score, h.sum_score, h.evalue, h.reported, h.included,
+                     [(d.env_from, d.env_to, d.score, d.c_evalue, d.i_evalue, d.reported, d.included,
+                       d.alignment.target_sequence) for d in h.domains]) for h in th]
+        res = dict(merged=dump(merged), whole=dump(whole), Z=(merged.Z, whole.Z), domZ=(merged.domZ, whole.domZ),
+                   counts=(merged.stage_counts, whole.stage_counts),
+                   residues=(merged.searched_residues, whole.searched_residues), shard_sizes=[len(shard)])
+        with open(out_path, "wb") as f:
+            pickle.dump(res, f)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_shard_gather_merge_equals_whole(tmp_path):
+    import pickle
+    import torch.multiprocessing as mp
+    out = tmp_path / "res.pkl"
+    mp.spawn(_worker, args=(2, _free_port(), str(out)), nprocs=2, join=True)
+    res = pickle.load(open(out, "rb"))
+    assert res["Z"] == (2100.0, 2100.0) and res["domZ"][0] == res["domZ"][1]
+    assert res["counts"][0] == res["counts"][1] and res["residues"][0] == res["residues"][1] == 682583
+    assert len(res["merged"]) == len(res["whole"]) == 22
+    assert res["merged"] == res["whole"]
+
+
+def test_tophits_bytes_roundtrip(models, oracle, proteome):
+    import pickle
+    import host_pipeline
+    from pyhmmer_amd import plan7
+    hmm = models["PF02826"][0]
+    hits = host_pipeline.host_search(oracle, hmm, proteome[:700])
+    again = plan7.TopHits.from_bytes(hits.to_bytes())
+    assert [(h.name, h.score, h.evalue, len(h.domains)) for h in again] == [(h.name, h.score, h.evalue, len(h.domains)) for h in hits]
+    assert again.Z == hits.Z and again.stage_counts == hits.stage_counts
+    viap = pickle.loads(pickle.dumps(hits))
+    assert [h.name for h in viap] == [h.name for h in hits]
+    with pytest.raises(ValueError):
+        plan7.TopHits.from_bytes(b"garbage")
