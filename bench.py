@@ -28,8 +28,9 @@ sys.path.insert(0, str(ROOT))
 sys.path.insert(0, str(ROOT / "tests"))
 
 HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
-VALU_LANE_OPS_PER_S = 256 * 4 * 32 * 2.4e9    # 256 CU x 4 SIMD-32 x 2.4 GHz (packed-16 ops issue at the 32-bit rate)
-MSV_OPS_PER_CELL = 1.5           # v_pk_max_i16, v_pk_add_u16, v_pk_max_i16 per two cells (p7x_msv.hip)
+VALU_LANE_OPS_PER_S = 256 * 4 * 16 * 2.4e9    # 256 CU x 4 SIMD x 16 lanes/clk x 2.4 GHz: packed-16 VOP3P ops take 4 cycles per
+                                              # wave64 (PMC: SQ_ACTIVE_INST_VALU == SQ_INSTS_VALU quad-cycles, profiles/r01_bench_pmc.md)
+MSV_OPS_PER_CELL = 1.0           # fast MSV kernel: v_pk_add_i16 clamp + v_pk_max_i16 per two cells (p7x_msv.hip)
 
 
 def emit_from_model(hmm, rng, tabs):

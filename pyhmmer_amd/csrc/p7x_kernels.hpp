@@ -16,6 +16,9 @@ struct MsvArgs {
   int base, bias, tec, tbm;
   int *counter;
   int16_t *out_xJ;          // [ngroups*64] slot order; -1 = overflow
+  // fast variant: groups whose result is ambiguous are appended here and redone by the exact kernel
+  int *amb_count; int *amb_groups; int *counter2;
+  const int *group_list; const int *group_count;   // exact kernel: optional list of groups to process
 };
 int  msv_pick_R(int M);
 int  msv_stride(int R);

@@ -29,6 +29,8 @@ typedef short s2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ s2 as_s2(uint32_t u) { return __builtin_bit_cast(s2, u); }
 __device__ __forceinline__ uint32_t as_u32(s2 v) { return __builtin_bit_cast(uint32_t, v); }
 __device__ __forceinline__ s2 pk_max(s2 a, s2 b) { return __builtin_elementwise_max(a, b); }
+__device__ __forceinline__ s2 pk_adds(s2 a, s2 b) { return __builtin_elementwise_add_sat(a, b); }   // v_pk_add_i16 clamp
+__device__ __forceinline__ s2 pk_subs(s2 a, s2 b) { return __builtin_elementwise_sub_sat(a, b); }   // v_pk_sub_i16 clamp
 __device__ __forceinline__ s2 splat(int v) { s2 r; r.x = (short) v; r.y = (short) v; return r; }
 __device__ __forceinline__ s2 swap_halves(s2 v) { return as_s2(__builtin_amdgcn_alignbit(as_u32(v), as_u32(v), 16)); }
 
@@ -54,7 +56,7 @@ __device__ __forceinline__ void lds_issue4(uint32_t addr, Chunk &c)
                "ds_read_b64 %1, %4 offset:%6\n\t"
                "ds_read_b64 %2, %4 offset:%7\n\t"
                "ds_read_b64 %3, %4 offset:%8"
-               : "=v"(c.e0), "=v"(c.e1), "=v"(c.e2), "=v"(c.e3)
+               : "=&v"(c.e0), "=&v"(c.e1), "=&v"(c.e2), "=&v"(c.e3)   // early-clobber: results may land before the last issue
                : "v"(addr), "i"(OFF), "i"(OFF + 8), "i"(OFF + 16), "i"(OFF + 24));
 }
 template <int PENDING>
@@ -64,7 +66,7 @@ __device__ __forceinline__ void lds_wait(Chunk &c)
 }
 
 // One DP row over the register file, four register pairs (8 registers, 16 cells) per chunk.
-template <int R, bool ODD, int T>   // T = chunk index being computed
+template <int R, bool ODD, int T, bool FAST = false>   // T = chunk index being computed
 struct RowChunks {
   static constexpr int NT = R / 8;
   static constexpr int S = msv_stride_c(R);
@@ -73,7 +75,22 @@ struct RowChunks {
   template <int JJ>
   static __device__ __forceinline__ void pair(s2 (&v)[R], const uint2 e, const s2 xB, s2 &accA, s2 &accB)
   {
-    if constexpr (ODD) {        // register j <- cells (2j-1, 2j), read from register j-1 of the previous (even) row
+    if constexpr (FAST) {       // floored representation: the saturating add *is* max(., xB) (see msv_fast_kernel)
+      if constexpr (ODD) {
+        v[2 * JJ + 1] = pk_adds(v[2 * JJ], as_s2(e.y));
+        s2 pred = xB;           // xB holds splat(-32768) here: the floor itself
+        if constexpr (JJ > 0) pred = v[2 * JJ - 1];
+        v[2 * JJ] = pk_adds(pred, as_s2(e.x));
+      } else {
+        v[2 * JJ] = pk_adds(v[2 * JJ], as_s2(e.x));
+        v[2 * JJ + 1] = pk_adds(v[2 * JJ + 1], as_s2(e.y));
+      }
+      accA = pk_max(accA, v[2 * JJ]);
+      accB = pk_max(accB, v[2 * JJ + 1]);
+      // Pin the two accumulator updates here (empty asm = opaque use).  Otherwise LLVM sinks the whole max chain to
+      // the end of the row, where back-to-back dependent VOP3P ops each need a wait state on gfx950 (s_nop per op).
+      asm volatile("" : "+v"(accA), "+v"(accB));
+    } else if constexpr (ODD) {        // register j <- cells (2j-1, 2j), read from register j-1 of the previous (even) row
       const s2 t1 = pk_max(v[2 * JJ], xB);
       v[2 * JJ + 1] = t1 + as_s2(e.y);
       accA = pk_max(accA, v[2 * JJ + 1]);
@@ -107,7 +124,7 @@ struct RowChunks {
       pair<4 * T + 2>(v, cur.e2, xB, accA, accB);
       pair<4 * T + 3>(v, cur.e3, xB, accA, accB);
     }
-    if constexpr (!last) RowChunks<R, ODD, TN>::run(v, addr, nxt, cur, xB, accA, accB);
+    if constexpr (!last) RowChunks<R, ODD, TN, FAST>::run(v, addr, nxt, cur, xB, accA, accB);
   }
 };
 
@@ -147,11 +164,13 @@ __global__ void __launch_bounds__(kMsvBlock) msv_kernel(const MsvArgs a)
   const int lane = threadIdx.x & 63;
   const s2 basev = splat(a.base), tecv = splat(a.tec), zerov = splat(0);
 
+  const int ngroups = a.group_list ? *a.group_count : a.ngroups;
   for (;;) {
     int g = 0;
     if (lane == 0) g = atomicAdd(a.counter, 1);
     g = __builtin_amdgcn_readfirstlane(g);
-    if (g >= a.ngroups) break;
+    if (g >= ngroups) break;
+    if (a.group_list) g = __builtin_amdgcn_readfirstlane(a.group_list[g]);
 
     const int slot = g * 64 + lane;
     const int L = a.slot_len[slot];
@@ -186,6 +205,100 @@ __global__ void __launch_bounds__(kMsvBlock) msv_kernel(const MsvArgs a)
   }
 }
 
+// ---------------------------------------------------------------------------- the fast variant: 1.0 op per cell
+// Cells are stored relative to the current begin score:  s = v - xB - 32768.  Then the signed saturating add
+// floors at -32768 == xB, i.e. one v_pk_add_i16 clamp computes  max(M[k-1], xB) + e  *and* the next row's floor;
+// with the row-maximum update that is 2 packed ops per two cells.  Differences to the exact kernel:
+//   * xE is seen as max(xE, xB).  This never changes xB (J only matters above base) and changes the final xJ
+//     only if *every* row maximum stayed below its begin score, in which case xJ comes out as the constant
+//     F0 = base - tjb - tbm - tec.  Exactly those targets (xJ == F0 with a floored row) are ambiguous: their
+//     64-target group is appended to a list and recomputed by the exact kernel above.  All other xJ are exact.
+//   * when xJ rises above base the begin score moves: every register is re-biased by the increment
+//     (v_pk_sub_i16 clamp; wave-uniform branch, taken a few times per group at most).
+template <int R>
+__global__ void __launch_bounds__(kMsvBlock) msv_fast_kernel(const MsvArgs a)
+{
+  extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
+  constexpr int S = msv_stride_c(R);
+  {
+    constexpr int n4 = (2 * kTabRows * S) / 4;
+    const uint4 *src = reinterpret_cast<const uint4 *>(a.tab);
+    uint4 *dst = reinterpret_cast<uint4 *>(lds);
+    for (int i = threadIdx.x; i < n4; i += kMsvBlock) dst[i] = src[i];
+  }
+  __syncthreads();
+
+  const int lane = threadIdx.x & 63;
+  const s2 floorv = splat(-32768);
+  constexpr int NT = R / 8;
+
+  for (;;) {
+    int g = 0;
+    if (lane == 0) g = atomicAdd(a.counter, 1);
+    g = __builtin_amdgcn_readfirstlane(g);
+    if (g >= a.ngroups) break;
+
+    const int slot = g * 64 + lane;
+    const int L = a.slot_len[slot];
+    const int nblk = a.grp_nblk[g];
+    const uint4 *tp = a.tiles + a.grp_off[g] + lane;
+    const int tjbm = (int) a.tjb_tab[L] + a.tbm;
+
+    s2 v[R];
+#pragma unroll
+    for (int j = 0; j < R; ++j) v[j] = floorv;
+    int xJ = 0, xEmax = 0;
+    int xB = max(a.base - tjbm, 0);
+    const int F0 = xB - a.tec;
+    bool floored = false;
+
+    uint4 cur = tp[0];
+    for (int b = 0; b < nblk; ++b) {
+      const uint4 nxt = (b + 1 < nblk) ? tp[(size_t) (b + 1) * 64] : cur;
+      uint32_t w0 = cur.x, w1 = cur.y, w2 = cur.z, w3 = cur.w;
+#pragma unroll 1
+      for (int c = 0; c < 8; ++c) {
+        const uint32_t x0 = w0 & 0xffu, x1 = (w0 >> 8) & 0xffu;
+        w0 = __builtin_amdgcn_alignbit(w1, w0, 16); w1 = __builtin_amdgcn_alignbit(w2, w1, 16);
+        w2 = __builtin_amdgcn_alignbit(w3, w2, 16); w3 >>= 16;
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+          Chunk ca, cb;
+          s2 accA = floorv, accB = floorv;
+          if (half == 0) {        // odd row
+            const uint32_t addr = x0 * (uint32_t) (S * 4);
+            lds_issue4<(NT - 1) * 32>(addr, ca);
+            RowChunks<R, true, NT - 1, true>::run(v, addr, ca, cb, floorv, accA, accB);
+          } else {                // even row
+            const uint32_t addr = x1 * (uint32_t) (S * 4);
+            lds_issue4<kTabRows * S * 4>(addr, ca);
+            RowChunks<R, false, 0, true>::run(v, addr, ca, cb, floorv, accA, accB);
+          }
+          const s2 m2 = pk_max(accA, accB);
+          const int m = max((int) m2.x, (int) m2.y);
+          floored |= (m == -32768);
+          const int xE = m + 32768 + xB;
+          xEmax = max(xEmax, xE);
+          xJ = max(xJ, xE - a.tec);
+          const int xBn = max(max(a.base, xJ) - tjbm, 0);
+          const int delta = xBn - xB;
+          if (__builtin_expect(__any(delta > 0), 0)) {
+            asm volatile("; re-bias: the begin score moved" ::: "memory");   // keeps this a real (rare) branch: no if-conversion
+            const s2 dv = splat(delta);
+#pragma unroll
+            for (int j = 0; j < R; ++j) v[j] = pk_subs(v[j], dv);
+            xB = xBn;
+          }
+        }
+      }
+      cur = nxt;
+    }
+    const bool ambiguous = (L > 0) && floored && (xJ == F0) && !(xEmax >= 255 - a.bias);
+    if (L > 0) a.out_xJ[slot] = (xEmax >= 255 - a.bias) ? (int16_t) -1 : (int16_t) xJ;
+    if (__any(ambiguous) && lane == 0) { const int idx = atomicAdd(a.amb_count, 1); a.amb_groups[idx] = g; }
+  }
+}
+
 // ---------------------------------------------------------------------------- host side
 
 static const int kRList[] = { 8, 16, 24, 32, 40, 48, 56, 64, 72, 80, 88, 96, 104, 112, 120, 128, 136, 144, 152, 160,
@@ -193,7 +306,7 @@ static const int kRList[] = { 8, 16, 24, 32, 40, 48, 56, 64, 72, 80, 88, 96, 104
 
 int msv_pick_R(int M)
 {
-  const int need = M / 2 + 1;
+  const int need = (M + 1) / 2 + 1;   // odd rows hold cells (2j-1, 2j): node M needs register (M+1)/2
   for (int r : kRList) if (r >= need) return r;
   return -1;
 }
@@ -233,7 +346,25 @@ static int launch_R(const MsvArgs &a, int num_cu, hipStream_t st)
   long grid = (long) num_cu * per_cu;
   if (grid > want) grid = want;
   if (grid < 1) grid = 1;
-  hipLaunchKernelGGL(msv_kernel<R>, dim3((unsigned) grid), dim3(kMsvBlock), lds_bytes, st, a);
+  if (a.amb_groups == nullptr) {           // exact kernel over every group
+    hipLaunchKernelGGL(msv_kernel<R>, dim3((unsigned) grid), dim3(kMsvBlock), lds_bytes, st, a);
+    P7X_HIP(hipGetLastError());
+    return P7X_OK;
+  }
+  // fast kernel over every group, then the exact kernel over the (normally empty) list of ambiguous groups
+  if (lds_bytes > 64 * 1024)
+    P7X_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&msv_fast_kernel<R>), hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds_bytes));
+  int per_cu2 = 0;
+  P7X_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu2, msv_fast_kernel<R>, kMsvBlock, lds_bytes));
+  if (per_cu2 < 1) per_cu2 = 1;
+  long grid2 = (long) num_cu * per_cu2;
+  if (grid2 > want) grid2 = want;
+  if (grid2 < 1) grid2 = 1;
+  hipLaunchKernelGGL(msv_fast_kernel<R>, dim3((unsigned) grid2), dim3(kMsvBlock), lds_bytes, st, a);
+  P7X_HIP(hipGetLastError());
+  MsvArgs b = a;
+  b.group_list = a.amb_groups; b.group_count = a.amb_count; b.counter = a.counter2; b.amb_groups = nullptr;
+  hipLaunchKernelGGL(msv_kernel<R>, dim3(32), dim3(kMsvBlock), lds_bytes, st, b);
   P7X_HIP(hipGetLastError());
   return P7X_OK;
 }

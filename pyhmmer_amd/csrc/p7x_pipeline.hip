@@ -11,6 +11,7 @@
 #include "p7x_host.hpp"
 #include <chrono>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <memory>
 
@@ -294,6 +295,8 @@ static WaveSeqArgs ws_args(const Profile &p, const DevProfile *dp, const p7x_seq
   return a;
 }
 
+static const bool g_msv_exact_only = std::getenv("P7X_MSV_EXACT") != nullptr;   // A/B switch for profiling
+
 // Run MSV over the whole database; leaves xJ (slot order) in ws->b.xJ.
 static int run_msv(const Profile &p, const DevProfile *dp, const p7x_seqdb *db, DeviceCtx *ctx, Workspace *ws)
 {
@@ -303,6 +306,8 @@ static int run_msv(const Profile &p, const DevProfile *dp, const p7x_seqdb *db, 
   a.slot_len = db->d_slot_len; a.tjb_tab = ctx->lt.tjb; a.ngroups = (int) db->ngroups;
   a.base = p.base_b; a.bias = p.bias_b; a.tec = p.tec_b; a.tbm = p.tbm_b;
   a.counter = &ws->b.counters[0]; a.out_xJ = ws->b.xJ;
+  a.amb_count = &ws->b.counters[10]; a.counter2 = &ws->b.counters[11];
+  a.amb_groups = g_msv_exact_only ? nullptr : ws->b.list_fin;     // list_fin is free until the Forward stage
   return msv_launch(dp->msvR, a, ctx->num_cu, ctx->stream);
 }
 

@@ -8,7 +8,7 @@ import math
 import numpy as np
 import pytest
 
-from conftest import synthetic_block
+from conftest import load_hmms, random_hmm, synthetic_block
 from pyhmmer_amd import easel, plan7
 
 pytestmark = pytest.mark.gpu
@@ -145,3 +145,98 @@ def test_msv_bit_exact_on_large_synthetic_block(models, oracle):
     got = plan7.SequenceDatabase(blk).filters(om, msv=True)["xJ"]
     want = oracle.OracleProfile(hmm, bg, 400).msv_block(blk.packed())
     assert np.array_equal(got, want)
+
+
+def test_msv_floor_ambiguous_targets_fall_back_to_exact_kernel(models, oracle):
+    """Targets whose every row maximum stays below the begin score (all-'*', all-X, poly-W ...) are exactly the
+    ones the fast MSV kernel cannot resolve (xJ == F0): their groups must be redone by the exact kernel."""
+    hmm = models["PF02826"][0]
+    abc = hmm.alphabet
+    bg = plan7.Background(abc)
+    rng = np.random.default_rng(5)
+    seqs = []
+    for t, code in enumerate([27, 26, 18, 1, 27, 26]):          # '*', 'X', 'W', 'C'
+        seqs.append(easel.DigitalSequence(abc, name=f"deg{t}", sequence=np.full(40 + 13 * t, code, dtype=np.uint8)))
+    for t in range(70):                                           # normal neighbours in the same 64-target groups
+        seqs.append(easel.DigitalSequence(abc, name=f"n{t}", sequence=rng.integers(0, 20, size=60 + t).astype(np.uint8)))
+    seqs.append(easel.DigitalSequence(abc, name="mix", sequence=np.array([27] * 30 + [0, 5, 9] + [27] * 30, dtype=np.uint8)))
+    blk = easel.DigitalSequenceBlock(abc, seqs)
+    om = plan7.OptimizedProfile(hmm, bg, 400)
+    got = plan7.SequenceDatabase(blk).filters(om, msv=True)["xJ"]
+    want = oracle.OracleProfile(hmm, bg, 400).msv_block(blk.packed())
+    assert np.array_equal(got, want), (got[:8], want[:8])
+
+
+def _model_block(hmm, nrand, nhom, seed):
+    """Random background targets of ragged length plus a few sequences emitted from the model itself."""
+    import bench
+    abc = hmm.alphabet
+    rng = np.random.default_rng(seed)
+    lens = rng.integers(1, 420, size=nrand)
+    blk = synthetic_block(nrand, 0, seed=seed, alphabet=abc, lengths=lens)
+    seqs = list(blk)
+    t = hmm.transition_probabilities.astype(np.float64)
+    mat, ins = hmm.match_emissions.astype(np.float64), hmm.insert_emissions.astype(np.float64)
+    cmat = np.cumsum(mat / np.maximum(mat.sum(axis=1, keepdims=True), 1e-30), axis=1)
+    cins = np.cumsum(ins / np.maximum(ins.sum(axis=1, keepdims=True), 1e-30), axis=1)
+    ct = np.zeros((hmm.M + 1, 4))
+    s3 = np.maximum(t[:, 0:3].sum(axis=1), 1e-30)
+    ct[:, 0], ct[:, 1] = t[:, 0] / s3, (t[:, 0] + t[:, 1]) / s3
+    ct[:, 2] = t[:, 3] / np.maximum(t[:, 3] + t[:, 4], 1e-30)
+    ct[:, 3] = t[:, 5] / np.maximum(t[:, 5] + t[:, 6], 1e-30)
+    for h in range(nhom):
+        dom = bench.emit_from_model(hmm, rng, (cmat, cins, ct))
+        lo = int(rng.integers(0, max(1, len(dom) // 2)))
+        hi = int(rng.integers(lo + 1, len(dom) + 1))
+        flank = rng.integers(0, 20, size=int(rng.integers(0, 50))).astype(np.uint8)
+        seqs.append(easel.DigitalSequence(abc, name=f"hom{h}", sequence=np.concatenate([flank, dom[lo:hi], flank])))
+    return easel.DigitalSequenceBlock(abc, seqs)
+
+
+# one model length per register-count instantiation of the MSV kernels (R = M/2+1 rounded up to the R list) and per
+# nodes-per-lane instantiation C of the wavefront kernels (C = ceil(M/64) rounded up to the C list)
+_R_LIST = [8, 16, 24, 32, 40, 48, 56, 64, 72, 80, 88, 96, 104, 112, 120, 128, 136, 144, 152, 160, 176, 192, 208, 224, 240]
+SWEEP_M = [1, 2, 3] + [m for r in _R_LIST for m in (2 * (r - 1) - 1, 2 * (r - 1))]    # largest odd and even M per R
+
+
+@pytest.mark.parametrize("M", SWEEP_M)
+def test_every_msv_kernel_instantiation_bit_exact(M, oracle):
+    hmm = random_hmm(M, seed=1000 + M)
+    bg = plan7.Background(hmm.alphabet)
+    blk = _model_block(hmm, 400, 12, seed=M)
+    om = plan7.OptimizedProfile(hmm, bg, 400)
+    op = oracle.OracleProfile(hmm, bg, 400)
+    for rep in range(2):          # twice: hazards in hand-scheduled LDS traffic are timing dependent
+        got = plan7.SequenceDatabase(blk).filters(om, msv=True)["xJ"]
+        assert np.array_equal(got, op.msv_block(blk.packed())), f"M={M} rep={rep}"
+
+
+@pytest.mark.parametrize("M", [1, 3, 64, 65, 128, 150, 192, 256, 300, 320, 384, 500, 512, 640, 700, 768, 1000, 1024])
+def test_every_wavefront_kernel_instantiation_vs_oracle(M, oracle):
+    hmm = random_hmm(M, seed=2000 + M)
+    bg = plan7.Background(hmm.alphabet)
+    blk = _model_block(hmm, 120, 6, seed=M)
+    om = plan7.OptimizedProfile(hmm, bg, 400)
+    got = plan7.SequenceDatabase(blk).filters(om, msv=(M <= 478), viterbi=True, forward=True)
+    want = _oracle_scores(oracle.OracleProfile(hmm, bg, 400), blk, want=("vit", "fwd"))
+    assert np.array_equal(got["xC"], want["vit"]), f"M={M}"
+    ok = np.isfinite(want["fwd"])
+    assert np.array_equal(np.isfinite(got["fwd"]), ok)
+    # float32 scores of several hundred nats carry ~1e-4 of representation error on their own
+    assert np.all(np.abs(got["fwd"][ok] - want["fwd"][ok]) < FWD_TOL_NATS + 1e-5 * np.abs(want["fwd"][ok]))
+
+
+def test_msv_baseline_config2_full_size_vs_oracle(oracle):
+    """BASELINE.json configs[1] at full size: 10^6 synthetic 300-residue targets, every xJ against the oracle."""
+    import bench
+    from types import SimpleNamespace
+    hmm = load_hmms("KR")[0]
+    bg = plan7.Background(hmm.alphabet)
+    flat, off, ln, planted = bench.make_workload(hmm, 1_000_000, 300, 42)
+    db = plan7.SequenceDatabase.from_packed(hmm.alphabet, flat, off, ln)
+    om = plan7.OptimizedProfile(hmm, bg, 300)
+    want = oracle.OracleProfile(hmm, bg, 300).msv_block(SimpleNamespace(dsq=flat, offsets=off, lengths=ln, n=len(ln)))
+    for rep in range(2):
+        got = db.filters(om, msv=True)["xJ"]
+        bad = np.nonzero(got != want)[0]
+        assert bad.size == 0, (rep, bad[:10], got[bad[:10]], want[bad[:10]])

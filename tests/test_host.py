@@ -113,3 +113,25 @@ def test_sequence_length_limit(libp7x):
     big = easel.DigitalSequence(abc, name="big", sequence=np.zeros(100001, dtype=np.uint8))
     with pytest.raises(ValueError):
         plan7.SequenceDatabase(easel.DigitalSequenceBlock(abc, [big]))
+
+
+def test_msv_isa_never_touches_a_vgpr_with_an_lds_load_in_flight(tmp_path):
+    """The MSV kernels issue their LDS loads from inline asm and count completions by hand, which the compiler
+    cannot check.  Compile the kernels to ISA and verify statically that no instruction reads or writes a register
+    whose ds_read is still outstanding (a missing early-clobber once let a load's result overwrite the address of
+    the next load: a timing-dependent wrong score in 4e-4 of targets)."""
+    import shutil
+    import subprocess
+    import sys
+    from pathlib import Path
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not Path(hipcc).exists():
+        pytest.skip("hipcc not available")
+    root = Path(__file__).resolve().parents[1]
+    asm = tmp_path / "msv.s"
+    subprocess.run([hipcc, "-O3", "-std=c++17", "-ffp-contract=off", "-fno-fast-math", "--offload-arch=gfx950", "-S",
+                    "--cuda-device-only", "-o", str(asm), str(root / "pyhmmer_amd/csrc/p7x_msv.hip")],
+                   check=True, capture_output=True)
+    r = subprocess.run([sys.executable, str(root / "scripts/check_lds_asm.py"), str(asm)], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout[-2000:]
+    assert "ds_read_b64" in asm.read_text()
