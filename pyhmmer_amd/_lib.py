@@ -17,7 +17,7 @@ _ROOT = _PKG.parent
 CSRC = _PKG / "csrc"
 LIB_PATH = _PKG / "libp7x.so"
 
-SOURCES = ["p7x_profile.cpp", "p7x_device.hip", "p7x_msv.hip", "p7x_vitfwd.hip", "p7x_pipeline.hip",
+SOURCES = ["p7x_profile.cpp", "p7x_device.hip", "p7x_msv.hip", "p7x_vitfwd.hip", "p7x_envelope.hip", "p7x_pipeline.hip",
            "p7x_domaindef.cpp", "p7x_tophits.cpp"]
 
 
@@ -103,7 +103,7 @@ class PipelineCfg(C.Structure):
         ("Z", C.c_double), ("domZ", C.c_double), ("Z_setby", C.c_int32), ("domZ_setby", C.c_int32),
         ("F1", C.c_double), ("F2", C.c_double), ("F3", C.c_double),
         ("do_max", C.c_int32), ("do_biasfilter", C.c_int32), ("do_null2", C.c_int32),
-        ("seed", C.c_uint32), ("mode", C.c_int32), ("host_threads", C.c_int32),
+        ("seed", C.c_uint32), ("mode", C.c_int32), ("host_threads", C.c_int32), ("host_envelopes", C.c_int32),
     ]
 
 
@@ -198,7 +198,7 @@ def lib() -> C.CDLL:
             fn = getattr(l, name)      # AttributeError if the ABI is incomplete
             fn.restype = res
             fn.argtypes = args
-        if l.p7x_abi_version() != 1:
+        if l.p7x_abi_version() != 2:
             raise ImportError("libp7x ABI version mismatch; rebuild")
         _lib = l
     return _lib

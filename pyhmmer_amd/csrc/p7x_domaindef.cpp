@@ -908,7 +908,8 @@ int rescore_isolated_domain(const Profile &p, Model &om, const uint8_t *dsq, int
 
 // ---------------------------------------------------------------- p7_domaindef_ByPosteriorHeuristics
 int domaindef_by_posterior_heuristics(const Profile &p, const uint8_t *dsq, int L, const float *fx, const float *bx,
-                                      uint32_t seed, bool do_reseeding, DomainDefResult &dd)
+                                      uint32_t seed, bool do_reseeding, DomainDefResult &dd,
+                                      std::vector<EnvelopeRequest> *defer, int item)
 {
   const float rt1 = 0.25f, rt2 = 0.10f, rt3 = 0.20f;                         // p7_domaindef.pxd:39-41
   const int nsamples = 200;                                                  // p7_domaindef.pxd:43-48
@@ -998,11 +999,52 @@ int domaindef_by_posterior_heuristics(const Profile &p, const uint8_t *dsq, int 
         }
       } else {
         dd.nenvelopes++;
-        rescore_isolated_domain(p, om, dsq, L, i, j, false, ws, dd);
+        if (defer) {                 // rescored on the device; domaindef_finish_deferred() fills the placeholder
+          Domain ph; ph.ienv = i; ph.jenv = j; ph.deferred = (int) defer->size();
+          defer->push_back(EnvelopeRequest{ item, i, j });
+          dd.dcl.push_back(std::move(ph));
+        } else rescore_isolated_domain(p, om, dsq, L, i, j, false, ws, dd);
       }
       i = -1; triggered = false;
     }
   }
+  return P7X_OK;
+}
+
+// Second half of rescore_isolated_domain() for envelopes rescored by the device kernel: trace -> alignment
+// display, null2 odds -> per-residue corrections.  req_index[n] is the position in <res> of local request n
+// (Domain::deferred of the placeholders of this target).
+int domaindef_finish_deferred(const Profile &p, const uint8_t *dsq, int L, const std::vector<EnvelopeResult> &res,
+                              const std::vector<int> &req_index, DomainDefResult &dd)
+{
+  thread_local Workspace ws;
+  std::vector<Domain> kept;
+  kept.reserve(dd.dcl.size());
+  for (Domain &d : dd.dcl) {
+    if (d.deferred < 0) { kept.push_back(std::move(d)); continue; }
+    const EnvelopeResult &r = res[(size_t) req_index[(size_t) d.deferred]];
+    const int i = (int) d.ienv, j = (int) d.jenv;
+    if (r.status & 2) continue;                      // p7_Decoding range error: the envelope is dropped
+    if (r.status & ~3) continue;                     // traceback failure: upstream's rescore returns without a domain
+    Trace &tr = ws.tr;
+    tr.clear();
+    for (int z = 0; z < r.ntrace; ++z) tr.append((int) (r.ta[z] & 0xffu), (int) ((r.ta[z] >> 8) & 0xffffu), r.ti[z], r.tp[z]);
+    tr.reverse();
+    for (size_t z = 0; z < tr.st.size(); ++z) if (tr.i[z] > 0) tr.i[z] += i - 1;
+    Domain dom;
+    make_alidisplay(p, tr, dsq, L, dom);
+    float null2[MAXKP];
+    for (int x = 0; x < p.K; ++x) null2[x] = r.null2[x];
+    finish_null2(p, null2);
+    float domcorrection = 0.0f;
+    for (int pos = i; pos <= j; ++pos) dd.n2sc[pos] = logf(null2[dsq[pos]]);
+    for (int pos = i; pos <= j; ++pos) domcorrection += dd.n2sc[pos];
+    dom.domcorrection = domcorrection;
+    dom.ienv = i; dom.jenv = j; dom.envsc = r.envsc; dom.oasc = r.oasc;
+    dom.iali = dom.sqfrom; dom.jali = dom.sqto;
+    kept.push_back(std::move(dom));
+  }
+  dd.dcl = std::move(kept);
   return P7X_OK;
 }
 

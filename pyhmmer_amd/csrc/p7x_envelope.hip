@@ -1,0 +1,581 @@
+// p7x_envelope.hip -- rescoring of one domain envelope on CDNA4: one envelope per WAVEFRONT, all four steps of
+// upstream's rescore_isolated_domain() (p7_domaindef.c) fused into one kernel:
+//
+//   1. Forward over the envelope, unihit, full target length model     (impl_sse/fwdback.c  p7_Forward)
+//   2. Backward, re-using Forward's scale factors                       (impl_sse/fwdback.c  p7_Backward)
+//   3. posterior decoding + null2 expectation + optimal-accuracy DP     (decoding.c, null2.c, optacc.c)
+//   4. optimal-accuracy traceback                                       (optacc.c  p7_OATrace)
+//
+// Layout is the one of the parsers in p7x_vitfwd.hip: lane z owns nodes z*C+1 .. z*C+C, device tables are
+// [c*64 + lane].  Steps 1 and 2 park their M and I rows in a per-wavefront HBM workspace (D is not needed:
+// posterior decoding leaves D at zero); step 3 streams both back once, row by row, keeps the OA row in
+// registers and writes one byte of back-pointers per cell; step 4 is a serial walk over those bytes by lane 0,
+// followed by a lane-parallel pass that attaches the posterior probability of every emitted residue.
+// The host (p7x_domaindef.cpp) turns the trace into the alignment display and applies the null2 correction.
+#include "p7x_wave.hpp"
+
+namespace p7x {
+
+namespace {
+
+constexpr float kNegInf = -__builtin_inff();
+
+// p7T_* state codes (p7_trace.pxd), as the host uses them
+enum { tM = 1, tD = 2, tI = 3, tS = 4, tN = 5, tB = 6, tE = 7, tC = 8, tT = 9, tJ = 10 };
+
+__device__ __forceinline__ float gate(float t, float v) { return t > 0.0f ? v : 0.0f; }          // and(cmpgt(t, 0), v)
+__device__ __forceinline__ float block(float t, float v) { return t > 0.0f ? v : kNegInf; }      // traceback: t == 0 ? -inf : v
+__device__ __forceinline__ float vmax(float a, float b) { return a > b ? a : b; }
+__device__ __forceinline__ float rflf(float v) { return __builtin_bit_cast(float, rfl(__builtin_bit_cast(int, v))); }
+
+__device__ __forceinline__ void phase_fence()
+{ // rows written by this wavefront are read back by it (possibly by other lanes, and the workspace is re-used
+  // for the next envelope): make the stores visible and drop stale vector-cache lines.
+  __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "agent");
+}
+
+} // namespace
+
+template <int C>
+__global__ void __launch_bounds__(kWsBlock) env_kernel(const EnvArgs a)
+{
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  constexpr int Mpad = 64 * C;
+  float4 *tr = reinterpret_cast<float4 *>(smem);                         // [2*Mpad]
+  float *em = reinterpret_cast<float *>(smem + (size_t) Mpad * 32);      // [nrows][Mpad]
+  {
+    const float4 *gt = reinterpret_cast<const float4 *>(a.trans);
+    for (int i = threadIdx.x; i < 2 * Mpad; i += kWsBlock) tr[i] = gt[i];
+    const float4 *ge = reinterpret_cast<const float4 *>(a.emis);
+    float4 *le = reinterpret_cast<float4 *>(em);
+    for (int i = threadIdx.x; i < a.nrows * Mpad / 4; i += kWsBlock) le[i] = ge[i];
+  }
+  __syncthreads();
+  const int lane = threadIdx.x & 63;
+  const int nlist = a.nenv;
+  const int wave_id = rfl((int) (blockIdx.x * (kWsBlock / 64) + (threadIdx.x >> 6)));
+
+  // per-wavefront workspace
+  float *wsf = a.work + (size_t) wave_id * (size_t) a.work_stride;
+  const size_t rows = (size_t) a.Lmax + 1;
+  float *fM = wsf, *fI = fM + rows * Mpad, *bM = fI + rows * Mpad, *bI = bM + rows * Mpad;
+  float *fx = bI + rows * Mpad;             // [rows][6]  E N J B C SCALE
+  float *bx = fx + rows * 6;                // [rows][6]
+  float *ox = bx + rows * 6;                // [rows][5]  OA specials E N J B C
+  float *px = ox + rows * 5;                // [rows][3]  posterior N J C
+  float *totr_row = px + rows * 3;          // [rows]
+  unsigned char *bp = reinterpret_cast<unsigned char *>(totr_row + rows);   // [rows][Mpad] back-pointers
+
+  P7X_WAVE_ITEMS(it) {
+    const int Ld = rfl(a.env_len[it]);
+    const int Lfull = rfl(a.env_L[it]);
+    const unsigned long long off = (unsigned long long) a.env_sq[it];
+    const unsigned olo = (unsigned) rfl((int) (unsigned) off), ohi = (unsigned) rfl((int) (unsigned) (off >> 32));
+    const uint8_t *sq = a.dsq + (((unsigned long long) ohi << 32) | olo);      // sq[0] = first residue of the envelope
+    const float pmove = (2.0f + a.nj) / ((float) Lfull + 2.0f + a.nj), ploop = 1.0f - pmove;
+    int status = 0;
+
+    // ------------------------------------------------------------------ 1. Forward
+    float envsc;
+    {
+      float mm[C], im[C], dm[C];
+#pragma unroll
+      for (int c = 0; c < C; ++c) mm[c] = im[c] = dm[c] = 0.0f;
+      float ddprod = 1.0f;
+#pragma unroll
+      for (int c = 0; c < C; ++c) ddprod *= tr[2 * (c * 64 + lane) + 1].w;
+      float xN = 1.0f, xB = pmove, xJ = 0.0f, xC = 0.0f, xE = 0.0f, totscale = 0.0f;
+      if (lane == 0) { fx[0] = 0.0f; fx[1] = 1.0f; fx[2] = 0.0f; fx[3] = xB; fx[4] = 0.0f; fx[5] = 1.0f; }
+      for (int i0 = 0; i0 < Ld; i0 += 64) {
+        const int nrow = min(64, Ld - i0);
+        const uint32_t resid = (lane < nrow) ? sq[i0 + lane] : 0;
+        for (int r = 0; r < nrow; ++r) {
+          const int i = i0 + r;
+          const int x = __builtin_amdgcn_readlane((int) resid, r);
+          const float *er = em + x * Mpad + lane;
+          float mp = dpp_shr1f(mm[C - 1], 0.0f), ip = dpp_shr1f(im[C - 1], 0.0f), dp = dpp_shr1f(dm[C - 1], 0.0f);
+          float esum = 0.0f;
+          float t_dd[C], t_md[C];
+#pragma unroll
+          for (int c = 0; c < C; ++c) {
+            const F8 t = load_f8(tr, c * 64 + lane);
+            float sv = xB * t.bm;
+            sv = sv + mp * t.mm;
+            sv = sv + ip * t.im;
+            sv = sv + dp * t.dm;
+            sv = sv * er[c * 64];
+            esum = esum + sv;
+            mp = mm[c]; ip = im[c]; dp = dm[c];
+            im[c] = mp * t.mi + ip * t.ii;
+            mm[c] = sv;
+            t_dd[c] = t.dd; t_md[c] = t.md;
+          }
+          float A = 0.0f;
+#pragma unroll
+          for (int c = 0; c < C; ++c) { dm[c] = A; A = mm[c] * t_md[c] + A * t_dd[c]; }
+          float sa = A, sp = ddprod;
+#pragma unroll
+          for (int s = 1; s < 64; s <<= 1) {
+            const float pa = __shfl_up(sa, s), pp = __shfl_up(sp, s);
+            if (lane >= s) { sa = sa + pa * sp; sp = sp * pp; }
+          }
+          {
+            float w = dpp_shr1f(sa, 0.0f);
+#pragma unroll
+            for (int c = 0; c < C; ++c) { dm[c] = dm[c] + w; esum = esum + dm[c]; w = w * t_dd[c]; }
+          }
+          xE = wave_sum_f32(esum);
+          xN = xN * ploop;
+          xC = (xC * ploop) + (xE * a.xf_e_move);
+          xJ = (xJ * ploop) + (xE * a.xf_e_loop);
+          xB = (xJ * pmove) + (xN * pmove);
+          float scale = 1.0f;
+          if (xE > 1.0e4f) {
+            xN = xN / xE; xC = xC / xE; xJ = xJ / xE; xB = xB / xE;
+            const float inv = (float) (1.0 / (double) xE);
+#pragma unroll
+            for (int c = 0; c < C; ++c) { mm[c] *= inv; dm[c] *= inv; im[c] *= inv; }
+            scale = xE;
+            totscale += (float) log((double) xE);
+            xE = 1.0f;
+          }
+          float *rm = fM + (size_t) (i + 1) * Mpad + lane, *ri = fI + (size_t) (i + 1) * Mpad + lane;
+#pragma unroll
+          for (int c = 0; c < C; ++c) { rm[c * 64] = mm[c]; ri[c * 64] = im[c]; }
+          if (lane == 0) {
+            float *row = fx + (size_t) (i + 1) * 6;
+            row[0] = xE; row[1] = xN; row[2] = xJ; row[3] = xB; row[4] = xC; row[5] = scale;
+          }
+        }
+      }
+      if (xC != xC || (Ld > 0 && xC == 0.0f) || __builtin_isinf(xC)) { envsc = __builtin_inff(); status |= 1; }
+      else envsc = (float) ((double) totscale + log((double) (xC * pmove)));
+    }
+    phase_fence();
+
+    // ------------------------------------------------------------------ 2. Backward
+    bool own_scales = false;
+    float bck_xN0;
+    {
+      float t_md[C], t_dd[C], t_mi[C], t_ii[C], t_bm[C], n_mm[C], n_im[C], n_dm[C];
+      float ddprod = 1.0f;
+#pragma unroll
+      for (int c = 0; c < C; ++c) {
+        const F8 t = load_f8(tr, c * 64 + lane);
+        t_md[c] = t.md; t_dd[c] = t.dd; t_mi[c] = t.mi; t_ii[c] = t.ii; t_bm[c] = t.bm;
+        ddprod *= t.dd;
+      }
+#pragma unroll
+      for (int c = 0; c < C; ++c) {          // transitions entering the NEXT node
+        float mmn, imn, dmn;
+        if (c + 1 < C) { const F8 t = load_f8(tr, (c + 1) * 64 + lane); mmn = t.mm; imn = t.im; dmn = t.dm; }
+        else { const F8 t = load_f8(tr, lane); mmn = dpp_shl1f(t.mm, 0.0f); imn = dpp_shl1f(t.im, 0.0f); dmn = dpp_shl1f(t.dm, 0.0f); }
+        n_mm[c] = mmn; n_im[c] = imn; n_dm[c] = dmn;
+      }
+      float mm[C], im[C], dm[C];
+      float xJ = 0.0f, xB = 0.0f, xN = 0.0f;
+      float xC = pmove;
+      float xE = xC * a.xf_e_move;
+      auto d_chain = [&](float (&d)[C]) {
+        float A = 0.0f;
+#pragma unroll
+        for (int c = C - 1; c >= 0; --c) { A = d[c] + A * t_dd[c]; }
+        float sa = A, sp = ddprod;
+#pragma unroll
+        for (int s = 1; s < 64; s <<= 1) {
+          const float pa = __shfl_down(sa, s), pp = __shfl_down(sp, s);
+          if (lane + s < 64) { sa = sa + pa * sp; sp = sp * pp; }
+        }
+        float w = dpp_shl1f(sa, 0.0f);
+#pragma unroll
+        for (int c = C - 1; c >= 0; --c) { d[c] = d[c] + w * t_dd[c]; w = d[c]; }
+      };
+      auto store_row = [&](int r) {
+        float *rm = bM + (size_t) r * Mpad + lane, *ri = bI + (size_t) r * Mpad + lane;
+#pragma unroll
+        for (int c = 0; c < C; ++c) { rm[c * 64] = mm[c]; ri[c * 64] = im[c]; }
+      };
+#pragma unroll
+      for (int c = 0; c < C; ++c) { mm[c] = xE; dm[c] = xE; im[c] = 0.0f; }
+      d_chain(dm);
+      {
+        float dn = dpp_shl1f(dm[0], 0.0f);
+#pragma unroll
+        for (int c = C - 1; c >= 0; --c) { mm[c] = mm[c] + dn * t_md[c]; dn = dm[c]; }
+      }
+      float sc = rflf(fx[(size_t) Ld * 6 + 5]);
+      if (sc > 1.0f) {
+        xE = xE / sc; xN = xN / sc; xC = xC / sc; xJ = xJ / sc; xB = xB / sc;
+        const float inv = (float) (1.0 / (double) sc);
+#pragma unroll
+        for (int c = 0; c < C; ++c) { mm[c] *= inv; dm[c] *= inv; im[c] *= inv; }
+      }
+      store_row(Ld);
+      if (lane == 0) { float *r = bx + (size_t) Ld * 6; r[0] = xE; r[1] = xN; r[2] = xJ; r[3] = xB; r[4] = xC; r[5] = sc; }
+
+      for (int i = Ld - 1; i >= 1; --i) {
+        const int x = rfl((int) sq[i]);
+        const float *er = em + x * Mpad + lane;
+        float me[C];
+#pragma unroll
+        for (int c = 0; c < C; ++c) me[c] = mm[c] * er[c * 64];
+        float bsum = 0.0f;
+#pragma unroll
+        for (int c = 0; c < C; ++c) bsum = bsum + me[c] * t_bm[c];
+        const float me_next0 = dpp_shl1f(me[0], 0.0f);
+#pragma unroll
+        for (int c = 0; c < C; ++c) {
+          const float mp = (c + 1 < C) ? me[c + 1] : me_next0;
+          const float ipv = im[c];
+          im[c] = ipv * t_ii[c] + mp * n_im[c];
+          dm[c] = mp * n_dm[c];
+          mm[c] = ipv * t_mi[c] + mp * n_mm[c];
+        }
+        xB = wave_sum_f32(bsum);
+        xC = xC * ploop;
+        xJ = (xB * pmove) + (xJ * ploop);
+        xN = (xB * pmove) + (xN * ploop);
+        xE = (xC * a.xf_e_move) + (xJ * a.xf_e_loop);
+#pragma unroll
+        for (int c = 0; c < C; ++c) { dm[c] = dm[c] + xE; mm[c] = mm[c] + xE; }
+        d_chain(dm);
+        {
+          float dn = dpp_shl1f(dm[0], 0.0f);
+#pragma unroll
+          for (int c = C - 1; c >= 0; --c) { mm[c] = mm[c] + dn * t_md[c]; dn = dm[c]; }
+        }
+        if (xB > 1.0e16f) own_scales = true;
+        sc = own_scales ? ((xB > 1.0e4f) ? xB : 1.0f) : rflf(fx[(size_t) i * 6 + 5]);
+        if (sc > 1.0f) {
+          xE /= sc; xN /= sc; xJ /= sc; xB /= sc; xC /= sc;
+          const float inv = (float) (1.0 / (double) sc);
+#pragma unroll
+          for (int c = 0; c < C; ++c) { mm[c] *= inv; dm[c] *= inv; im[c] *= inv; }
+        }
+        store_row(i);
+        if (lane == 0) { float *r = bx + (size_t) i * 6; r[0] = xE; r[1] = xN; r[2] = xJ; r[3] = xB; r[4] = xC; r[5] = sc; }
+      }
+      {
+        const int x = rfl((int) sq[0]);
+        const float *er = em + x * Mpad + lane;
+        float bsum = 0.0f;
+#pragma unroll
+        for (int c = 0; c < C; ++c) bsum = bsum + (mm[c] * er[c * 64]) * t_bm[c];
+        xB = wave_sum_f32(bsum);
+        xN = (xB * pmove) + (xN * ploop);
+        bck_xN0 = xN;
+      }
+    }
+    phase_fence();
+
+    // ------------------------------------------------------------------ 3. decoding, null2 sums, optimal accuracy
+    float oasc;
+    int e_row = -1, e_k = 0, e_s = 0;
+    {
+      float scaleproduct = (float) (1.0 / (double) bck_xN0);
+      bool ddpass = true;                                            // every D->D transition of this lane is open
+#pragma unroll
+      for (int c = 0; c < C; ++c) ddpass = ddpass && (tr[2 * (c * 64 + lane) + 1].w > 0.0f);
+      float p_md0, p_dd0;                                            // leaving transitions of the previous lane's last node
+      { const F8 t = load_f8(tr, (C - 1) * 64 + lane); p_md0 = dpp_shr1f(t.md, 0.0f); p_dd0 = dpp_shr1f(t.dd, 0.0f); }
+      float om_[C], oi_[C], od_[C], msum[C], isum[C];
+#pragma unroll
+      for (int c = 0; c < C; ++c) { om_[c] = oi_[c] = od_[c] = kNegInf; msum[c] = isum[c] = 0.0f; }
+      float oE = kNegInf, oN = 0.0f, oJ = kNegInf, oB = 0.0f, oC = kNegInf;
+      float eN = 0.0f, eJ = 0.0f, eC = 0.0f;
+      const int Q = max(2, (a.M - 1) / 4 + 1);                         // p7O_NQF(M): the striped visiting order of select_e
+      const bool loopJ = ploop != 0.0f, loopE = a.xf_e_loop != 0.0f, moveE = a.xf_e_move != 0.0f, moveNJ = pmove != 0.0f;
+      for (int r = 1; r <= Ld; ++r) {
+        const float fS = rflf(fx[(size_t) r * 6 + 5]), bS = rflf(bx[(size_t) r * 6 + 5]);
+        const float totr = scaleproduct * fS;
+        const float *rfm = fM + (size_t) r * Mpad + lane, *rfi = fI + (size_t) r * Mpad + lane;
+        const float *rbm = bM + (size_t) r * Mpad + lane, *rbi = bI + (size_t) r * Mpad + lane;
+        float ppm[C], ppi[C];
+#pragma unroll
+        for (int c = 0; c < C; ++c) {
+          ppm[c] = (rfm[c * 64] * rbm[c * 64]) * totr;
+          ppi[c] = (rfi[c * 64] * rbi[c * 64]) * totr;
+          msum[c] = ppm[c] + msum[c];
+          isum[c] = ppi[c] + isum[c];
+        }
+        const float ppN = rflf(fx[(size_t) (r - 1) * 6 + 1]) * rflf(bx[(size_t) r * 6 + 1]) * ploop * scaleproduct;
+        const float ppJ = rflf(fx[(size_t) (r - 1) * 6 + 2]) * rflf(bx[(size_t) r * 6 + 2]) * ploop * scaleproduct;
+        const float ppC = rflf(fx[(size_t) (r - 1) * 6 + 4]) * rflf(bx[(size_t) r * 6 + 4]) * ploop * scaleproduct;
+        eN += ppN; eJ += ppJ; eC += ppC;
+        if (own_scales) scaleproduct *= fS / bS;
+
+        // OA row.  DP values use gate() (0 when a transition is closed); the traceback rule uses -inf (block()).
+        const float xBp = oB;
+        float mp = dpp_shr1f(om_[C - 1], kNegInf), ip = dpp_shr1f(oi_[C - 1], kNegInf), dp = dpp_shr1f(od_[C - 1], kNegInf);
+        unsigned char code[C];
+        float t_md[C], t_dd[C];
+#pragma unroll
+        for (int c = 0; c < C; ++c) {
+          const F8 t = load_f8(tr, c * 64 + lane);
+          t_md[c] = t.md; t_dd[c] = t.dd;
+          float sv = gate(t.bm, xBp);
+          sv = vmax(sv, gate(t.mm, mp));
+          sv = vmax(sv, gate(t.im, ip));
+          sv = vmax(sv, gate(t.dm, dp));
+          int best = 0; float bv = block(t.mm, mp);
+          { const float p1 = block(t.im, ip); if (p1 > bv) { best = 1; bv = p1; } }
+          { const float p2 = block(t.dm, dp); if (p2 > bv) { best = 2; bv = p2; } }
+          { const float p3 = block(t.bm, xBp); if (p3 > bv) { best = 3; } }
+          const float mcur = om_[c], icur = oi_[c];
+          float iv = gate(t.mi, mcur);
+          iv = vmax(iv, gate(t.ii, icur));
+          const int ichoice = (block(t.mi, mcur) >= block(t.ii, icur)) ? 0 : 1;
+          mp = mcur; ip = icur; dp = od_[c];
+          om_[c] = sv + ppm[c];
+          oi_[c] = iv + ppi[c];
+          code[c] = (unsigned char) (best | (ichoice << 2));
+        }
+        // D(r,k) = max(gate(tMD(k-1), M(r,k-1)), tDD(k-1) > 0 ? D(r,k-1) : 0), D(r,1) = -inf: a segmented max-scan
+        {
+          float w = kNegInf;
+#pragma unroll
+          for (int c = 0; c < C; ++c) w = vmax(gate(t_md[c], om_[c]), t_dd[c] > 0.0f ? w : 0.0f);
+          float sa = w; int sp = ddpass ? 1 : 0;
+#pragma unroll
+          for (int s = 1; s < 64; s <<= 1) {
+            const float pa = __shfl_up(sa, s); const int pp = __shfl_up(sp, s);
+            if (lane >= s) { sa = vmax(sa, sp ? pa : kNegInf); sp = sp & pp; }
+          }
+          w = dpp_shr1f(sa, kNegInf);
+#pragma unroll
+          for (int c = 0; c < C; ++c) { od_[c] = w; w = vmax(gate(t_md[c], om_[c]), t_dd[c] > 0.0f ? w : 0.0f); }
+        }
+        {
+          float pm = dpp_shr1f(om_[C - 1], kNegInf), pd = dpp_shr1f(od_[C - 1], kNegInf);
+          float pmd = p_md0, pdd = p_dd0;
+#pragma unroll
+          for (int c = 0; c < C; ++c) {
+            const int dchoice = (block(pmd, pm) >= block(pdd, pd)) ? 0 : 1;
+            code[c] |= (unsigned char) (dchoice << 3);
+            pm = om_[c]; pd = od_[c]; pmd = t_md[c]; pdd = t_dd[c];
+          }
+        }
+        {
+          unsigned char *rb = bp + (size_t) r * Mpad + lane;
+#pragma unroll
+          for (int c = 0; c < C; ++c) rb[c * 64] = code[c];
+        }
+        float rowmax = kNegInf;
+#pragma unroll
+        for (int c = 0; c < C; ++c) if (lane * C + c + 1 <= a.M) rowmax = vmax(rowmax, vmax(om_[c], od_[c]));
+        oE = wave_max_f32(rowmax);
+        float t1, t2;
+        t1 = !loopJ ? 0.0f : oJ + ppJ;
+        t2 = !loopE ? 0.0f : oE;
+        oJ = fmaxf(t1, t2);
+        t1 = !loopJ ? 0.0f : oC + ppC;                 // C, J and N share one loop probability
+        t2 = !moveE ? 0.0f : oE;
+        const int c_from_e = rfl((int) !(t1 > t2));    // what select_c will decide at this row (wave-uniform)
+        oC = fmaxf(t1, t2);
+        oN = !loopJ ? 0.0f : oN + ppN;
+        t1 = !moveNJ ? 0.0f : oN;
+        t2 = !moveNJ ? 0.0f : oJ;
+        oB = fmaxf(t1, t2);
+        if (c_from_e) {
+          // select_e for this row, should the traceback enter E here: upstream scans the striped layout, q outer,
+          // M cells with >=, D cells with >.  Net effect: the LAST M cell (striped order) that equals the row
+          // maximum wins; without one, the FIRST D cell that does.
+          int keyM = 0, keyD = 0;
+#pragma unroll
+          for (int c = 0; c < C; ++c) {
+            const int k = lane * C + c + 1;
+            if (k <= a.M) {
+              const int rank = ((k - 1) % Q) * 4 + (k - 1) / Q;
+              if (om_[c] == oE) keyM = max(keyM, rank + 1);
+              if (od_[c] == oE) keyD = max(keyD, (1 << 24) - rank);
+            }
+          }
+          keyM = wave_max_i32(keyM);
+          if (keyM > 0) { const int rank = keyM - 1; e_k = (rank % 4) * Q + rank / 4 + 1; e_s = tM; }
+          else {
+            keyD = wave_max_i32(keyD);
+            if (keyD > 0) { const int rank = (1 << 24) - keyD; e_k = (rank % 4) * Q + rank / 4 + 1; e_s = tD; }
+            else { e_k = 0; e_s = -1; }
+          }
+          e_row = r;
+        }
+        if (lane == 0) {
+          float *o = ox + (size_t) r * 5; o[0] = oE; o[1] = oN; o[2] = oJ; o[3] = oB; o[4] = oC;
+          float *q = px + (size_t) r * 3; q[0] = ppN; q[1] = ppJ; q[2] = ppC;
+          totr_row[r] = totr;
+        }
+      }
+      if (lane == 0) { float *o = ox; o[0] = kNegInf; o[1] = 0.0f; o[2] = kNegInf; o[3] = 0.0f; o[4] = kNegInf; }
+      oasc = oC;
+      if (__builtin_isinf(scaleproduct)) status |= 2;            // p7_Decoding: eslERANGE, the envelope is dropped
+
+      // null2 by expectation: state occupancies -> residue odds
+      const float norm = (float) (1.0 / (double) (float) Ld);
+      const float xfactor = (eN * norm + eC * norm) + eJ * norm;
+      float *n2 = a.out_null2 + (size_t) it * 32;
+      for (int x = 0; x < a.K; ++x) {
+        const float *er = em + x * Mpad + lane;
+        float s = 0.0f;
+#pragma unroll
+        for (int c = 0; c < C; ++c) { s = s + (msum[c] * norm) * er[c * 64]; s = s + isum[c] * norm; }
+        s = wave_sum_f32(s);
+        if (lane == 0) n2[x] = s + xfactor;
+      }
+    }
+    phase_fence();
+
+    // ------------------------------------------------------------------ 4. traceback (p7_OATrace), lane 0
+    uint32_t *ta = a.tr_a + a.tr_off[it];
+    int32_t *ti = a.tr_i + a.tr_off[it];
+    float *tp = a.tr_pp + a.tr_off[it];
+    int n = 0;
+    if (lane == 0) {
+      const int cap = Ld + a.M + 16;
+      int i = Ld, k = 0, s0 = tC;
+      ta[n] = tT; ti[n] = i; ++n;
+      ta[n] = tC; ti[n] = i; ++n;
+      const float t1c = (ploop == 0.0f) ? 0.0f : 1.0f, t2e_move = (a.xf_e_move == 0.0f) ? 0.0f : 1.0f;
+      const float t2e_loop = (a.xf_e_loop == 0.0f) ? 0.0f : 1.0f, tmove = (pmove == 0.0f) ? 0.0f : 1.0f;
+      while (s0 != tS && n < cap) {
+        int s1 = -1;
+        switch (s0) {
+          case tM: {
+            if (i < 1 || k < 1) { status |= 4; break; }
+            const int code = bp[(size_t) i * Mpad + ((k - 1) % C) * 64 + (k - 1) / C] & 3;
+            s1 = (code == 0) ? tM : (code == 1) ? tI : (code == 2) ? tD : tB;
+            --k; --i;
+            break;
+          }
+          case tD: {
+            if (i < 1 || k < 1) { status |= 4; break; }
+            const int code = (bp[(size_t) i * Mpad + ((k - 1) % C) * 64 + (k - 1) / C] >> 3) & 1;
+            s1 = code ? tD : tM; --k;
+            break;
+          }
+          case tI: {
+            if (i < 1 || k < 1) { status |= 4; break; }
+            const int code = (bp[(size_t) i * Mpad + ((k - 1) % C) * 64 + (k - 1) / C] >> 2) & 1;
+            s1 = code ? tI : tM; --i;
+            break;
+          }
+          case tN: s1 = (i == 0) ? tS : tN; break;
+          case tC: {
+            if (i < 1) { status |= 4; break; }
+            const float p0 = t1c * (ox[(size_t) (i - 1) * 5 + 4] + px[(size_t) i * 3 + 2]), p1 = t2e_move * ox[(size_t) i * 5 + 0];
+            s1 = (p0 > p1) ? tC : tE;
+            break;
+          }
+          case tJ: {
+            if (i < 1) { status |= 4; break; }
+            const float p0 = t1c * (ox[(size_t) (i - 1) * 5 + 2] + px[(size_t) i * 3 + 1]), p1 = t2e_loop * ox[(size_t) i * 5 + 0];
+            s1 = (p0 > p1) ? tJ : tE;
+            break;
+          }
+          case tE:
+            if (i != e_row || e_s < 0) { status |= 8; break; }   // only the last C<-E row was resolved (unihit envelopes)
+            k = e_k; s1 = e_s;
+            break;
+          case tB:
+            s1 = (tmove * ox[(size_t) i * 5 + 1] > tmove * ox[(size_t) i * 5 + 2]) ? tN : tJ;
+            break;
+          default: break;
+        }
+        if (s1 == -1) { status |= 16; break; }
+        ta[n] = (uint32_t) s1 | ((uint32_t) k << 8) | ((s1 == s0) ? 0x80000000u : 0u);
+        ti[n] = i; ++n;
+        if ((s1 == tN || s1 == tJ || s1 == tC) && s1 == s0) --i;
+        s0 = s1;
+      }
+      if (s0 != tS) status |= 32;
+    }
+    n = rfl(n);
+    phase_fence();
+    // posterior probability of each trace step (get_postprob), all lanes
+    for (int z = lane; z < n; z += 64) {
+      const uint32_t w = ta[z];
+      const int s = (int) (w & 0xffu), k = (int) ((w >> 8) & 0xffffu), i = ti[z];
+      const bool same = (w & 0x80000000u) != 0;
+      float pp = 0.0f;
+      if ((s == tM || s == tI) && i >= 1 && k >= 1) {
+        const size_t idx = (size_t) i * Mpad + ((k - 1) % C) * 64 + (k - 1) / C;
+        pp = (s == tM) ? (fM[idx] * bM[idx]) * totr_row[i] : (fI[idx] * bI[idx]) * totr_row[i];
+      } else if (same && i >= 1) {
+        if (s == tN) pp = px[(size_t) i * 3 + 0];
+        else if (s == tJ) pp = px[(size_t) i * 3 + 1];
+        else if (s == tC) pp = px[(size_t) i * 3 + 2];
+      }
+      tp[z] = pp;
+      ta[z] = w & 0x7fffffffu;
+    }
+    if (lane == 0) {
+      a.out_sc[(size_t) it * 2 + 0] = envsc;
+      a.out_sc[(size_t) it * 2 + 1] = oasc;
+      a.out_status[it] = status;
+      a.tr_n[it] = n;
+    }
+    phase_fence();      // the workspace is about to be overwritten by this wavefront's next envelope
+  }
+}
+
+// ---------------------------------------------------------------------------- host side
+size_t env_work_floats(int C, int Lmax)
+{ // floats per wavefront; keep in step with the carving at the top of env_kernel
+  const size_t rows = (size_t) Lmax + 1, Mpad = (size_t) 64 * C;
+  size_t f = 4 * rows * Mpad + rows * (6 + 6 + 5 + 3 + 1);
+  f += (rows * Mpad + 3) / 4;          // back-pointer bytes
+  return (f + 63) & ~(size_t) 63;
+}
+
+template <typename K>
+static int launch_env(K kernel, const EnvArgs &a, size_t lds_bytes, int nblocks, hipStream_t st)
+{
+  if (lds_bytes > 64 * 1024)
+    P7X_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds_bytes));
+  hipLaunchKernelGGL(kernel, dim3((unsigned) nblocks), dim3(kWsBlock), lds_bytes, st, a);
+  P7X_HIP(hipGetLastError());
+  return P7X_OK;
+}
+
+template <typename K>
+static int occupancy_env(K kernel, size_t lds_bytes, int *per_cu)
+{
+  if (lds_bytes > 64 * 1024)
+    P7X_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds_bytes));
+  P7X_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(per_cu, kernel, kWsBlock, lds_bytes));
+  if (*per_cu < 1) *per_cu = 1;
+  return P7X_OK;
+}
+
+#define P7X_ENV_SWITCH(EXPR)                                                                                  \
+  switch (C) {                                                                                                \
+    case 1:  { auto kern = env_kernel<1>;  return EXPR; }                                                     \
+    case 2:  { auto kern = env_kernel<2>;  return EXPR; }                                                     \
+    case 3:  { auto kern = env_kernel<3>;  return EXPR; }                                                     \
+    case 4:  { auto kern = env_kernel<4>;  return EXPR; }                                                     \
+    case 5:  { auto kern = env_kernel<5>;  return EXPR; }                                                     \
+    case 6:  { auto kern = env_kernel<6>;  return EXPR; }                                                     \
+    case 8:  { auto kern = env_kernel<8>;  return EXPR; }                                                     \
+    case 10: { auto kern = env_kernel<10>; return EXPR; }                                                     \
+    case 12: { auto kern = env_kernel<12>; return EXPR; }                                                     \
+    case 16: { auto kern = env_kernel<16>; return EXPR; }                                                     \
+    default: set_error("model too long for the envelope kernel"); return P7X_EINVAL;                         \
+  }
+
+static size_t env_lds_bytes(int C, int nrows) { return (size_t) 64 * C * (32 + (size_t) nrows * 4); }
+
+int env_max_blocks(int C, int nrows, int num_cu, int *nblocks)
+{
+  const size_t lds = env_lds_bytes(C, nrows);
+  int per_cu = 1;
+  auto finish = [&](int st) { if (st == P7X_OK) *nblocks = num_cu * per_cu; return st; };
+  P7X_ENV_SWITCH(finish(occupancy_env(kern, lds, &per_cu)))
+}
+
+int env_launch(const EnvArgs &a, int nblocks, hipStream_t st)
+{
+  const int C = a.C;
+  const size_t lds = env_lds_bytes(C, a.nrows);
+  P7X_ENV_SWITCH(launch_env(kern, a, lds, nblocks, st))
+}
+
+} // namespace p7x

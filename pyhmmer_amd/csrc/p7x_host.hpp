@@ -20,6 +20,7 @@ struct Domain {
   int N = 0, hmmfrom = 0, hmmto = 0, M = 0;
   int64_t sqfrom = 0, sqto = 0, L = 0;
   std::string model, mline, aseq, ppline, rfline, mmline, csline;
+  int deferred = -1;          // >= 0: placeholder, to be filled from envelope request <deferred> (device rescoring)
 };
 
 struct DomainDefResult {      // the P7_DOMAINDEF fields p7_Pipeline reads (p7_domaindef.pxd:23-59)
@@ -29,10 +30,29 @@ struct DomainDefResult {      // the P7_DOMAINDEF fields p7_Pipeline reads (p7_d
   int nregions = 0, nclustered = 0, noverlaps = 0, nenvelopes = 0;
 };
 
+// Rescoring of single-domain envelopes can be handed to the device (p7x_envelope.hip): the first half of domain
+// definition then only queues a request per envelope, the second half turns the device's answer into a Domain.
+struct EnvelopeRequest { int item; int32_t i, j; };          // item: index into the survivor list; envelope i..j (1-based)
+struct EnvelopeResult {
+  float envsc = 0, oasc = 0; int status = 0;
+  float null2[32];                                           // odds of the canonical residues (before esl_abc_FAvgScVec)
+  int ntrace = 0; const uint32_t *ta = nullptr; const int32_t *ti = nullptr; const float *tp = nullptr;   // traceback order
+};
+struct EnvelopeScorer {
+  virtual ~EnvelopeScorer() = default;
+  // targets[item] = caller index of the survivor; fills res[r] for every req[r]; buffers stay valid until the next call
+  virtual int score(const std::vector<EnvelopeRequest> &req, const std::vector<int32_t> &targets, std::vector<EnvelopeResult> &res) = 0;
+};
+
 // p7_domaindef_ByPosteriorHeuristics (p7_domaindef.pxd:69-72).  dsq is 1-indexed (dsq[1..L]);
 // fwd_xmx / bck_xmx are the parsers' special-state rows, (L+1) x [E,N,J,B,C,SCALE].
+// With <defer> the single-domain regions are queued there (tagged <item>) instead of being rescored on the host;
+// domaindef_finish_deferred() completes them from the device results (res[d.deferred] for placeholder d).
 int domaindef_by_posterior_heuristics(const Profile &p, const uint8_t *dsq, int L, const float *fwd_xmx,
-                                      const float *bck_xmx, uint32_t seed, bool do_reseeding, DomainDefResult &out);
+                                      const float *bck_xmx, uint32_t seed, bool do_reseeding, DomainDefResult &out,
+                                      std::vector<EnvelopeRequest> *defer = nullptr, int item = 0);
+int domaindef_finish_deferred(const Profile &p, const uint8_t *dsq, int L, const std::vector<EnvelopeResult> &res,
+                              const std::vector<int> &req_index, DomainDefResult &dd);
 
 struct Hit {                  // P7_HIT, p7_hit.pxd:27-58
   std::string name, acc, desc;
@@ -56,7 +76,7 @@ int host_finish_search(const p7x_pipeline_cfg &cfg, const p7x_oprofile *om, cons
                        const char *const *names, const char *const *accs, const char *const *descs,
                        const std::vector<int32_t> &targets, const float *fwdsc,
                        const float *fwd_xmx, const float *bck_xmx, const int64_t *xmx_off,
-                       const uint64_t *counts, const double *ms, p7x_tophits **out);
+                       const uint64_t *counts, const double *ms, p7x_tophits **out, EnvelopeScorer *scorer = nullptr);
 void tophits_set_total_ms(p7x_tophits *th, double ms);
 float kahan_fsum(const float *v, int n);
 void host_prof_dump();
@@ -71,7 +91,7 @@ struct p7x_tophits {
   std::string qname, qacc, qdesc;     // the query (model) the alignment displays refer to
   bool q_has_acc = false, q_has_desc = false;
   int M = 0;
-  double ms[8]{};
+  double ms[10]{};
   bool sorted_by_key = false;
   int64_t nreported = 0, nincluded = 0;
 };

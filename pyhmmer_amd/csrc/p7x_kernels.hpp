@@ -54,5 +54,30 @@ int vit_launch(const WaveSeqArgs &a, int num_cu, hipStream_t st);
 int fwd_launch(const WaveSeqArgs &a, int num_cu, hipStream_t st);
 int bck_launch(const WaveSeqArgs &a, int num_cu, hipStream_t st);
 
+// ---- envelope rescoring (p7x_envelope.hip): Forward + Backward + decoding/null2/optimal accuracy + traceback,
+// one domain envelope per wavefront.  Trace steps come back in traceback order (T first): tr_a = state | k << 8,
+// tr_i = residue index inside the envelope (1..Ld, as the traceback saw it), tr_pp = posterior of that step.
+struct EnvArgs {
+  int M, C, K, nrows;       // K: canonical residues (null2 vector length); nrows: residue rows of the emission table
+  const void *trans;        // Forward tables of the profile (float4[2*Mpad], float[nrows][Mpad])
+  const void *emis;
+  const uint8_t *dsq;
+  float nj, xf_e_move, xf_e_loop;   // unihit: 0, 1, 0
+  int nenv;
+  const int64_t *env_sq;    // [nenv] offset in dsq of the first residue of the envelope
+  const int32_t *env_len;   // [nenv] envelope length Ld
+  const int32_t *env_L;     // [nenv] full target length (the length model is not re-configured per envelope)
+  float *work; int64_t work_stride; int Lmax;    // per-wavefront workspace (env_work_floats), rows 0..Lmax
+  float *out_sc;            // [nenv][2] envelope Forward score (nats), optimal accuracy score
+  int32_t *out_status;      // [nenv] bit 0 Forward range, 1 decoding range (envelope dropped), >= 2 traceback failures
+  float *out_null2;         // [nenv][32] null2 odds of the canonical residues
+  const int64_t *tr_off;    // [nenv] first trace element; capacity Ld + M + 16 each
+  uint32_t *tr_a; int32_t *tr_i; float *tr_pp;
+  int32_t *tr_n;            // [nenv] trace length
+};
+size_t env_work_floats(int C, int Lmax);
+int env_max_blocks(int C, int nrows, int num_cu, int *nblocks);
+int env_launch(const EnvArgs &a, int nblocks, hipStream_t st);
+
 // ---- thread-per-sequence small stages (p7x_pipeline.hip)
 } // namespace p7x

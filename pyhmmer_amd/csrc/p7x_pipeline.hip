@@ -296,6 +296,7 @@ static WaveSeqArgs ws_args(const Profile &p, const DevProfile *dp, const p7x_seq
 }
 
 static const bool g_msv_exact_only = std::getenv("P7X_MSV_EXACT") != nullptr;   // A/B switch for profiling
+static const bool g_host_envelopes = std::getenv("P7X_HOST_ENVELOPES") != nullptr;   // A/B: rescore envelopes on the host
 
 // Run MSV over the whole database; leaves xJ (slot order) in ws->b.xJ.
 static int run_msv(const Profile &p, const DevProfile *dp, const p7x_seqdb *db, DeviceCtx *ctx, Workspace *ws)
@@ -412,6 +413,135 @@ static int run_cascade(const p7x_pipeline_cfg &cfg, const p7x_oprofile *om, cons
   { float ms = 0; (void) hipEventElapsedTime(&ms, ws->ev[0], ws->ev[7]); out.ms[7] = ms; }
   return P7X_OK;
 }
+
+// ---------------------------------------------------------------------------- envelope rescoring on the device
+// Device and pinned-host buffers live for the thread (grow-only), like the cascade workspace.
+struct EnvBuffers {
+  int device = -1;
+  float *work = nullptr; size_t work_floats = 0;
+  unsigned char *d_in = nullptr; size_t d_in_cap = 0;        // env_sq | tr_off | env_len | env_L
+  unsigned char *d_out = nullptr; size_t d_out_cap = 0;      // out_sc | out_null2 | out_status | tr_n | tr_a | tr_i | tr_pp
+  unsigned char *h_out = nullptr; size_t h_out_cap = 0;      // pinned mirror of d_out
+  ~EnvBuffers() {
+    if (device < 0) return;
+    (void) hipSetDevice(device);
+    (void) hipFree(work); (void) hipFree(d_in); (void) hipFree(d_out);
+    if (h_out) (void) hipHostFree(h_out);
+  }
+};
+static thread_local std::vector<std::unique_ptr<EnvBuffers>> tl_env;
+
+static size_t env_budget_bytes()
+{
+  size_t gb = 24;
+  if (const char *e = std::getenv("P7X_ENV_WORKSPACE_GB")) { const long v = std::atol(e); if (v > 0) gb = (size_t) v; }
+  size_t free_b = 0, total_b = 0;
+  if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && free_b / 2 < gb << 30) return free_b / 2;
+  return gb << 30;
+}
+
+class DeviceEnvelopeScorer final : public EnvelopeScorer {
+public:
+  DeviceEnvelopeScorer(DeviceCtx *ctx, const DevProfile *dp, const p7x_seqdb *db, const Profile &p) : ctx_(ctx), dp_(dp), db_(db), p_(p) {}
+
+  int score(const std::vector<EnvelopeRequest> &req, const std::vector<int32_t> &targets, std::vector<EnvelopeResult> &res) override
+  {
+    const int nenv = (int) req.size();
+    res.assign((size_t) nenv, EnvelopeResult{});
+    if (nenv == 0) return P7X_OK;
+    P7X_HIP(hipSetDevice(db_->device));
+    EnvBuffers *eb = nullptr;
+    for (auto &b : tl_env) if (b->device == db_->device) eb = b.get();
+    if (!eb) { tl_env.push_back(std::make_unique<EnvBuffers>()); eb = tl_env.back().get(); eb->device = db_->device; }
+
+    // inputs
+    const size_t in_bytes = (size_t) nenv * (8 + 8 + 4 + 4);
+    std::vector<unsigned char> h_in(in_bytes);
+    int64_t *env_sq = reinterpret_cast<int64_t *>(h_in.data());
+    int64_t *tr_off = env_sq + nenv;
+    int32_t *env_len = reinterpret_cast<int32_t *>(tr_off + nenv);
+    int32_t *env_L = env_len + nenv;
+    int Lmax = 1; int64_t ntr = 0;
+    for (int r = 0; r < nenv; ++r) {
+      const int t = targets[(size_t) req[r].item];
+      const int Ld = req[r].j - req[r].i + 1;
+      env_sq[r] = db_->h_off[t] + (req[r].i - 1);
+      env_len[r] = Ld; env_L[r] = db_->h_len[t];
+      tr_off[r] = ntr; ntr += (int64_t) Ld + p_.M + 16;
+      Lmax = std::max(Lmax, Ld);
+    }
+    // workspace: one slab per resident wavefront, sized for the longest envelope of the batch
+    const int C = dp_->vitC;
+    const size_t stride = env_work_floats(C, Lmax);
+    int nblocks = 0;
+    int st = env_max_blocks(C, p_.Kp + 1, ctx_->num_cu, &nblocks);
+    if (st != P7X_OK) return st;
+    nblocks = std::min(nblocks, (nenv + 3) / 4);
+    const size_t budget = env_budget_bytes();
+    while (nblocks > 1 && (size_t) nblocks * 4 * stride * 4 > budget) nblocks = (nblocks + 1) / 2;
+    const size_t work_floats = (size_t) nblocks * 4 * stride;
+    if (work_floats * 4 > budget && work_floats > eb->work_floats) {
+      set_error("envelope workspace does not fit in device memory (envelope of " + std::to_string(Lmax) + " residues, M = " + std::to_string(p_.M) + ")");
+      return P7X_EMEM;
+    }
+    if (work_floats > eb->work_floats) {
+      (void) hipFree(eb->work); eb->work = nullptr; eb->work_floats = 0;
+      P7X_HIP(hipMalloc(&eb->work, work_floats * 4)); eb->work_floats = work_floats;
+    }
+    if (in_bytes > eb->d_in_cap) {
+      (void) hipFree(eb->d_in); eb->d_in = nullptr;
+      P7X_HIP(hipMalloc(&eb->d_in, in_bytes * 2)); eb->d_in_cap = in_bytes * 2;
+    }
+    // outputs: [out_sc 2f][null2 32f][status i][tr_n i] per envelope, then the three trace arrays
+    const size_t o_sc = 0, o_n2 = o_sc + (size_t) nenv * 8, o_st = o_n2 + (size_t) nenv * 128, o_n = o_st + (size_t) nenv * 4;
+    const size_t o_ta = o_n + (size_t) nenv * 4, o_ti = o_ta + (size_t) ntr * 4, o_tp = o_ti + (size_t) ntr * 4;
+    const size_t out_bytes = o_tp + (size_t) ntr * 4;
+    if (out_bytes > eb->d_out_cap) {
+      (void) hipFree(eb->d_out); eb->d_out = nullptr;
+      if (eb->h_out) { (void) hipHostFree(eb->h_out); eb->h_out = nullptr; }
+      const size_t cap = out_bytes + out_bytes / 2;
+      P7X_HIP(hipMalloc(&eb->d_out, cap)); eb->d_out_cap = cap;
+      P7X_HIP(hipHostMalloc(reinterpret_cast<void **>(&eb->h_out), cap, hipHostMallocDefault)); eb->h_out_cap = cap;
+    }
+    hipStream_t s = ctx_->stream;
+    P7X_HIP(hipMemcpyAsync(eb->d_in, h_in.data(), in_bytes, hipMemcpyHostToDevice, s));
+    EnvArgs a{};
+    a.M = p_.M; a.C = C; a.K = p_.K; a.nrows = p_.Kp + 1;
+    a.trans = dp_->fwd_trans; a.emis = dp_->fwd_emis; a.dsq = db_->d_dsq;
+    a.nj = 0.0f; a.xf_e_move = 1.0f; a.xf_e_loop = 0.0f;              // p7_oprofile_ReconfigUnihit
+    a.nenv = nenv;
+    a.env_sq = reinterpret_cast<const int64_t *>(eb->d_in);
+    a.tr_off = a.env_sq + nenv;
+    a.env_len = reinterpret_cast<const int32_t *>(a.tr_off + nenv);
+    a.env_L = a.env_len + nenv;
+    a.work = eb->work; a.work_stride = (int64_t) stride; a.Lmax = Lmax;
+    a.out_sc = reinterpret_cast<float *>(eb->d_out + o_sc);
+    a.out_null2 = reinterpret_cast<float *>(eb->d_out + o_n2);
+    a.out_status = reinterpret_cast<int32_t *>(eb->d_out + o_st);
+    a.tr_n = reinterpret_cast<int32_t *>(eb->d_out + o_n);
+    a.tr_a = reinterpret_cast<uint32_t *>(eb->d_out + o_ta);
+    a.tr_i = reinterpret_cast<int32_t *>(eb->d_out + o_ti);
+    a.tr_pp = reinterpret_cast<float *>(eb->d_out + o_tp);
+    if ((st = env_launch(a, nblocks, s)) != P7X_OK) return st;
+    P7X_HIP(hipMemcpyAsync(eb->h_out, eb->d_out, out_bytes, hipMemcpyDeviceToHost, s));
+    P7X_HIP(hipStreamSynchronize(s));
+    const float *h_sc = reinterpret_cast<const float *>(eb->h_out + o_sc), *h_n2 = reinterpret_cast<const float *>(eb->h_out + o_n2);
+    const int32_t *h_st = reinterpret_cast<const int32_t *>(eb->h_out + o_st), *h_n = reinterpret_cast<const int32_t *>(eb->h_out + o_n);
+    const uint32_t *h_ta = reinterpret_cast<const uint32_t *>(eb->h_out + o_ta);
+    const int32_t *h_ti = reinterpret_cast<const int32_t *>(eb->h_out + o_ti);
+    const float *h_tp = reinterpret_cast<const float *>(eb->h_out + o_tp);
+    for (int r = 0; r < nenv; ++r) {
+      EnvelopeResult &e = res[(size_t) r];
+      e.envsc = h_sc[2 * r]; e.oasc = h_sc[2 * r + 1]; e.status = h_st[r];
+      std::memcpy(e.null2, h_n2 + (size_t) r * 32, sizeof(e.null2));
+      e.ntrace = h_n[r]; e.ta = h_ta + tr_off[r]; e.ti = h_ti + tr_off[r]; e.tp = h_tp + tr_off[r];
+    }
+    return P7X_OK;
+  }
+
+private:
+  DeviceCtx *ctx_; const DevProfile *dp_; const p7x_seqdb *db_; const Profile &p_;
+};
 
 } // namespace p7x
 
@@ -587,8 +717,14 @@ int p7x_search_block(const p7x_pipeline_cfg *cfg, const p7x_oprofile *om, const 
   std::vector<int32_t> targets(co.fin_slots.size());
   for (size_t i = 0; i < targets.size(); ++i) targets[i] = db->h_order[co.fin_slots[i]];
   const uint64_t counts[4] = { (uint64_t) co.counts[1], (uint64_t) co.counts[8], (uint64_t) co.counts[3], (uint64_t) co.counts[4] };
+  std::unique_ptr<DeviceEnvelopeScorer> scorer;
+  if (!g_host_envelopes && !cfg->host_envelopes && !targets.empty()) {
+    DeviceCtx *ctx = nullptr; DevProfile *dp = nullptr;
+    if ((st = get_ctx(db->device, &ctx)) != P7X_OK || (st = get_dev_profile(om, ctx, &dp)) != P7X_OK) return st;
+    scorer = std::make_unique<DeviceEnvelopeScorer>(ctx, dp, db, om->p);
+  }
   st = host_finish_search(*cfg, om, tg, names, accs, descs, targets, co.fwdsc.data(), co.fwd_xmx.data(), co.bck_xmx.data(),
-                          co.xmx_off.data(), counts, co.ms, out);
+                          co.xmx_off.data(), counts, co.ms, out, scorer.get());
   if (st == P7X_OK) {
     const double total = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     tophits_set_total_ms(*out, total);

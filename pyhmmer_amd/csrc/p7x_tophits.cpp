@@ -12,6 +12,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <sched.h>
+#include <functional>
 #include <thread>
 
 namespace p7x {
@@ -208,7 +209,7 @@ int host_finish_search(const p7x_pipeline_cfg &cfg_in, const p7x_oprofile *om, c
                        const char *const *names, const char *const *accs, const char *const *descs,
                        const std::vector<int32_t> &tgt, const float *fwdsc,
                        const float *fwd_xmx, const float *bck_xmx, const int64_t *xmx_off,
-                       const uint64_t *counts, const double *ms, p7x_tophits **out)
+                       const uint64_t *counts, const double *ms, p7x_tophits **out, EnvelopeScorer *scorer)
 {
   const Profile &p = om->p;
   auto th = std::make_unique<p7x_tophits>();
@@ -226,34 +227,69 @@ int host_finish_search(const p7x_pipeline_cfg &cfg_in, const p7x_oprofile *om, c
   const auto t0 = std::chrono::steady_clock::now();
   const int n = (int) tgt.size();
   std::vector<Pending> pend((size_t) n);
-  std::atomic<int> next{0};
   std::atomic<int> failed{0};
-  auto worker = [&]() {
-    flogsum_init();
-    for (;;) {
-      const int i = next.fetch_add(1);
-      if (i >= n) break;
-      const int t = tgt[i];
-      const int L = tg.len[t];
-      const uint8_t *dsq = tg.dsq + tg.off[t] - 1;
-      DomainDefResult dd;
-      const int st = domaindef_by_posterior_heuristics(p, dsq, L, fwd_xmx + xmx_off[i], bck_xmx + xmx_off[i],
-                                                       cfg.seed, cfg.seed != 0, dd);
-      if (st != P7X_OK) { failed.store(st); continue; }
-      const double Zrun = (cfg.Z_setby == P7X_ZSETBY_NTARGETS) ? (double) (t + 1) : cfg.Z;
-      finish_one(cfg, p, L, fwdsc[i], Zrun, dd, pend[i]);
-      if (pend[i].have) pend[i].hit.seqidx = t;
-    }
-  };
   int nthreads = cfg.host_threads > 0 ? cfg.host_threads : usable_cpus();
   if (nthreads < 1) nthreads = 1;
   if (nthreads > (n + 3) / 4) nthreads = (n + 3) / 4;      // at least ~4 targets per worker
   if (nthreads < 1) nthreads = 1;
-  if (nthreads <= 1) worker();
-  else {
-    std::vector<std::thread> pool;
-    for (int i = 0; i < nthreads; ++i) pool.emplace_back(worker);
-    for (auto &t : pool) t.join();
+  auto run_pool = [&](const std::function<void(int)> &body) {
+    std::atomic<int> next{0};
+    auto worker = [&](int tid) {
+      flogsum_init();
+      for (;;) { const int i = next.fetch_add(1); if (i >= n) break; body(i); (void) tid; }
+    };
+    if (nthreads <= 1) worker(0);
+    else {
+      std::vector<std::thread> pool;
+      for (int i = 0; i < nthreads; ++i) pool.emplace_back(worker, i);
+      for (auto &t : pool) t.join();
+    }
+  };
+  auto finish = [&](int i, DomainDefResult &dd) {
+    const int t = tgt[i];
+    const double Zrun = (cfg.Z_setby == P7X_ZSETBY_NTARGETS) ? (double) (t + 1) : cfg.Z;
+    finish_one(cfg, p, tg.len[t], fwdsc[i], Zrun, dd, pend[i]);
+    if (pend[i].have) pend[i].hit.seqidx = t;
+  };
+  if (!scorer) {
+    // everything on the host (CPU test seam, and the fallback for models the envelope kernel does not cover)
+    run_pool([&](int i) {
+      const int t = tgt[i];
+      DomainDefResult dd;
+      const int st = domaindef_by_posterior_heuristics(p, tg.dsq + tg.off[t] - 1, tg.len[t], fwd_xmx + xmx_off[i], bck_xmx + xmx_off[i],
+                                                       cfg.seed, cfg.seed != 0, dd);
+      if (st != P7X_OK) { failed.store(st); return; }
+      finish(i, dd);
+    });
+  } else {
+    // 1. regions on the host; single-domain envelopes are queued for the device, multi-domain regions (stochastic
+    //    traceback clustering) are resolved right here
+    std::vector<DomainDefResult> dds((size_t) n);
+    std::vector<std::vector<EnvelopeRequest>> local((size_t) n);
+    run_pool([&](int i) {
+      const int t = tgt[i];
+      const int st = domaindef_by_posterior_heuristics(p, tg.dsq + tg.off[t] - 1, tg.len[t], fwd_xmx + xmx_off[i], bck_xmx + xmx_off[i],
+                                                       cfg.seed, cfg.seed != 0, dds[i], &local[i], i);
+      if (st != P7X_OK) failed.store(st);
+    });
+    th->ms[9] = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    if (failed.load() == 0) {
+      // 2. one batch through the envelope kernel
+      std::vector<EnvelopeRequest> req;
+      std::vector<std::vector<int>> req_index((size_t) n);
+      for (int i = 0; i < n; ++i)
+        for (const EnvelopeRequest &r : local[i]) { req_index[i].push_back((int) req.size()); req.push_back(r); }
+      std::vector<EnvelopeResult> res;
+      const auto t1 = std::chrono::steady_clock::now();
+      if (!req.empty()) { const int st = scorer->score(req, tgt, res); if (st != P7X_OK) return st; }
+      th->ms[8] = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t1).count();
+      // 3. alignment displays, null2 corrections, per-target scores
+      run_pool([&](int i) {
+        const int t = tgt[i];
+        if (!req_index[i].empty()) domaindef_finish_deferred(p, tg.dsq + tg.off[t] - 1, tg.len[t], res, req_index[i], dds[i]);
+        finish(i, dds[i]);
+      });
+    }
   }
   host_prof_dump();
   if (failed.load() != 0) { set_error("domain definition workflow failure"); return failed.load(); }
@@ -385,7 +421,7 @@ int p7x_tophits_merge(p7x_tophits *dst, const p7x_tophits *src)
   dst->ctr.n_past_msv += src->ctr.n_past_msv; dst->ctr.n_past_bias += src->ctr.n_past_bias;
   dst->ctr.n_past_vit += src->ctr.n_past_vit; dst->ctr.n_past_fwd += src->ctr.n_past_fwd;
   if (dst->cfg.Z_setby == P7X_ZSETBY_NTARGETS) dst->cfg.Z += src->cfg.Z;
-  for (int i = 0; i < 8; ++i) dst->ms[i] += src->ms[i];
+  for (int i = 0; i < 10; ++i) dst->ms[i] += src->ms[i];
   if (!dst->cfg.use_bit_cutoffs)
     for (Hit &h : dst->hits) {
       h.flags &= ~(uint32_t) (P7X_IS_REPORTED | P7X_IS_INCLUDED);
@@ -411,7 +447,7 @@ struct Reader {
   template <class T> void pod(T &v) { if (p + sizeof(T) > e) { ok = false; return; } std::memcpy(&v, p, sizeof(T)); p += sizeof(T); }
   void str(std::string &s) { uint32_t n = 0; pod(n); if (!ok || p + n > e) { ok = false; return; } s.assign((const char *) p, n); p += n; }
 };
-constexpr uint32_t kMagic = 0x70377874u;   // "p7xt"
+constexpr uint32_t kMagic = 0x70377875u;   // "p7xu" (format 2: ten timing slots)
 
 template <class IO> void io_domain(IO &io, Domain &d)
 {
@@ -438,7 +474,7 @@ int64_t p7x_tophits_serialize(const p7x_tophits *th, void *buf, size_t cap)
   uint32_t magic = kMagic; w.pod(magic);
   w.pod(th->cfg); w.pod(th->ctr);
   w.str(th->qname); w.str(th->qacc); w.str(th->qdesc); w.pod(th->q_has_acc); w.pod(th->q_has_desc); w.pod(th->M);
-  for (int i = 0; i < 8; ++i) w.pod(th->ms[i]);
+  for (int i = 0; i < 10; ++i) w.pod(th->ms[i]);
   const uint64_t n = th->hits.size(); w.pod(n);
   for (const Hit &hc : th->hits) {
     Hit &h = const_cast<Hit &>(hc);
@@ -458,7 +494,7 @@ p7x_tophits *p7x_tophits_deserialize(const void *buf, size_t n)
   auto th = std::make_unique<p7x_tophits>();
   r.pod(th->cfg); r.pod(th->ctr);
   r.str(th->qname); r.str(th->qacc); r.str(th->qdesc); r.pod(th->q_has_acc); r.pod(th->q_has_desc); r.pod(th->M);
-  for (int i = 0; i < 8; ++i) r.pod(th->ms[i]);
+  for (int i = 0; i < 10; ++i) r.pod(th->ms[i]);
   uint64_t nh = 0; r.pod(nh);
   if (!r.ok) return nullptr;
   th->hits.resize(nh);
@@ -477,7 +513,7 @@ p7x_tophits *p7x_tophits_deserialize(const void *buf, size_t n)
 int p7x_tophits_get_timings(const p7x_tophits *th, double *ms, int n)
 {
   if (!th || !ms) return P7X_EINVAL;
-  for (int i = 0; i < n && i < 8; ++i) ms[i] = th->ms[i];
+  for (int i = 0; i < n && i < 10; ++i) ms[i] = th->ms[i];
   return P7X_OK;
 }
 

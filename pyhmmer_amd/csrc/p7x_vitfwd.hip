@@ -12,70 +12,9 @@
 //     max-plus, hence bit-identical to the serial evaluation; Forward/Backward use a 6-step affine scan.
 // Integer semantics follow upstream impl_sse/vitfilter.c exactly (signed saturating 16-bit adds via
 // v_add_i16 clamp); float semantics follow impl_sse/fwdback.c up to the association order of sums.
-#include "p7x_device.hpp"
-#include "p7x_kernels.hpp"
+#include "p7x_wave.hpp"
 
 namespace p7x {
-
-constexpr int kWsBlock = 256;     // 4 wavefronts per workgroup, each walking its own targets
-
-__device__ __forceinline__ int   dpp_shr1(int v, int fill)   { return __builtin_amdgcn_update_dpp(fill, v, 0x138, 0xf, 0xf, false); }
-__device__ __forceinline__ int   dpp_shl1(int v, int fill)   { return __builtin_amdgcn_update_dpp(fill, v, 0x130, 0xf, 0xf, false); }
-__device__ __forceinline__ float dpp_shr1f(float v, float fill) { return __builtin_bit_cast(float, dpp_shr1(__builtin_bit_cast(int, v), __builtin_bit_cast(int, fill))); }
-__device__ __forceinline__ float dpp_shl1f(float v, float fill) { return __builtin_bit_cast(float, dpp_shl1(__builtin_bit_cast(int, v), __builtin_bit_cast(int, fill))); }
-
-#define P7X_DPP_STEP_I(v, ident, ctrl, rmask) __builtin_amdgcn_update_dpp((ident), (v), (ctrl), (rmask), 0xf, false)
-
-__device__ __forceinline__ int wave_max_i32(int v)
-{
-  const int id = INT_MIN;
-  v = max(v, P7X_DPP_STEP_I(v, id, 0x111, 0xf));
-  v = max(v, P7X_DPP_STEP_I(v, id, 0x112, 0xf));
-  v = max(v, P7X_DPP_STEP_I(v, id, 0x114, 0xf));
-  v = max(v, P7X_DPP_STEP_I(v, id, 0x118, 0xf));
-  v = max(v, P7X_DPP_STEP_I(v, id, 0x142, 0xa));
-  v = max(v, P7X_DPP_STEP_I(v, id, 0x143, 0xc));
-  return __builtin_amdgcn_readlane(v, 63);
-}
-#define P7X_DPP_STEP_F(v, ctrl, rmask) __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, (v)), (ctrl), (rmask), 0xf, false))
-__device__ __forceinline__ float wave_sum_f32(float v)
-{
-  v = v + P7X_DPP_STEP_F(v, 0x111, 0xf);
-  v = v + P7X_DPP_STEP_F(v, 0x112, 0xf);
-  v = v + P7X_DPP_STEP_F(v, 0x114, 0xf);
-  v = v + P7X_DPP_STEP_F(v, 0x118, 0xf);
-  v = v + P7X_DPP_STEP_F(v, 0x142, 0xa);
-  v = v + P7X_DPP_STEP_F(v, 0x143, 0xc);
-  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
-}
-
-__device__ __forceinline__ short adds16(short a, short b) { return __builtin_elementwise_add_sat(a, b); }
-__device__ __forceinline__ short max16(short a, short b) { return a > b ? a : b; }
-__device__ __forceinline__ short lo16(uint32_t w) { return (short) (w & 0xffffu); }
-__device__ __forceinline__ short hi16(uint32_t w) { return (short) (w >> 16); }
-
-// Work distribution: wave w of the grid takes items w, w + nwaves, ...  Everything that steers control flow
-// (item index, slot, length, residue pointer) is forced into SGPRs with readfirstlane so that the row loops are
-// plain scalar loops: the DPP / readlane steps below must never run under a partial EXEC mask.
-struct Item { int slot, L; const uint8_t *sq; };
-
-__device__ __forceinline__ int rfl(int v) { return __builtin_amdgcn_readfirstlane(v); }
-
-__device__ __forceinline__ Item load_item(const WaveSeqArgs &a, int it)
-{
-  Item o;
-  o.slot = rfl(a.list ? a.list[it] : it);
-  o.L = rfl(a.slot_len[o.slot]);
-  const unsigned long long off = (unsigned long long) a.slot_off[o.slot];
-  const unsigned lo = (unsigned) rfl((int) (unsigned) off), hi = (unsigned) rfl((int) (unsigned) (off >> 32));
-  o.sq = a.dsq + (((unsigned long long) hi << 32) | lo);
-  return o;
-}
-
-#define P7X_WAVE_ITEMS(it)                                                                                   \
-  const int wave0_ = rfl((int) (blockIdx.x * (kWsBlock / 64) + (threadIdx.x >> 6)));                        \
-  const int nwaves_ = (int) (gridDim.x * (kWsBlock / 64));                                                  \
-  for (int it = wave0_; it < nlist; it += nwaves_)
 
 // ======================================================================================= Viterbi filter
 template <int C>
@@ -166,13 +105,6 @@ __global__ void __launch_bounds__(kWsBlock) vit_kernel(const WaveSeqArgs a)
 }
 
 // ======================================================================================= Forward parser
-struct F8 { float bm, mm, im, dm, md, mi, ii, dd; };
-__device__ __forceinline__ F8 load_f8(const float4 *t, int idx)
-{
-  const float4 a = t[2 * idx], b = t[2 * idx + 1];
-  return F8{ a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w };
-}
-
 template <int C>
 __global__ void __launch_bounds__(kWsBlock) fwd_kernel(const WaveSeqArgs a)
 {

@@ -853,9 +853,10 @@ class TopHits:
 
     @property
     def timings_ms(self) -> dict:
-        buf = (C.c_double * 8)()
-        _lib.lib().p7x_tophits_get_timings(self._handle, buf, 8)
-        return dict(zip(("msv", "bias", "viterbi", "forward", "fwd_rows", "host_domaindef", "total", "msv_kernel"), buf))
+        buf = (C.c_double * 10)()
+        _lib.lib().p7x_tophits_get_timings(self._handle, buf, 10)
+        return dict(zip(("msv", "bias", "viterbi", "forward", "fwd_rows", "host_domaindef", "total", "msv_kernel",
+                         "envelopes", "host_regions"), buf))
 
     @property
     def reported(self):
@@ -924,7 +925,7 @@ class Pipeline:
                  null2: bool = True, seed: int = 42, Z=None, domZ=None, F1: float = 0.02, F2: float = 1e-3,
                  F3: float = 1e-5, E: float = 10.0, T=None, domE: float = 10.0, domT=None, incE: float = 0.01,
                  incT=None, incdomE: float = 0.01, incdomT=None, bit_cutoffs: Optional[str] = None,
-                 device: int = 0, host_threads: int = 0):
+                 device: int = 0, host_threads: int = 0, host_envelopes: bool = False):
         self.alphabet = alphabet
         if background is None:
             self.background = Background(alphabet)
@@ -948,6 +949,7 @@ class Pipeline:
         self.bit_cutoffs = bit_cutoffs
         self.device = device
         self.host_threads = host_threads
+        self.host_envelopes = bool(host_envelopes)
         self._db_cache = None           # (id(block), packed n, device) -> SequenceDatabase
 
     def clear(self) -> None:
@@ -973,6 +975,7 @@ class Pipeline:
             c.domZ, c.domZ_setby = float(self.domZ), 1
         c.use_bit_cutoffs = 0 if self.bit_cutoffs is None else self._BIT_CUTOFFS[self.bit_cutoffs]
         c.host_threads = int(self.host_threads)
+        c.host_envelopes = int(self.host_envelopes)
         return c
 
     def _get_om_from_query(self, query, L: int = L_HINT) -> OptimizedProfile:
