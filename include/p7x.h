@@ -216,7 +216,7 @@ int      p7x_tophits_threshold(p7x_tophits *th);         /* p7_tophits_Threshold
 /* per-stage device timings of the search that produced th, milliseconds (HIP events):
  * [0] msv + P-value pass [1] bias filter [2] viterbi [3] forward [4] forward rows for survivors [5] backward, then
  * overwritten by host domain definition wall time (including [8]) [6] whole call wall time [7] the MSV kernel alone
- * [8] device rescoring of domain envelopes (wall, with transfers) [9] host: regions + multi-domain regions.  n <= 10. */
+ * [8] device rescoring of domain envelopes (wall, with transfers) [9] host: multi-domain regions (overlaps [8]).  n <= 10. */
 int      p7x_tophits_get_timings(const p7x_tophits *th, double *ms, int n);
 
 const char *p7x_last_error(void);

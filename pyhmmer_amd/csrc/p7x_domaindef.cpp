@@ -68,7 +68,14 @@ struct FastRng {
   double next() { x = x * 69069u + 1u; return (double) x / 4294967296.0; }
 };
 
-float fsum(const float *v, int n) { return kahan_fsum(v, n); }
+// esl_vec_FSum (Kahan).  Same arithmetic as kahan_fsum(); this translation unit is compiled without fast-math and
+// without contraction, so the compensation survives without the volatile round trips through memory.
+static inline float fsum(const float *v, int n)
+{
+  float sum = 0.0f, c = 0.0f;
+  for (int i = 0; i < n; ++i) { const float y = v[i] - c; const float t = sum + y; c = (t - sum) - y; sum = t; }
+  return sum;
+}
 void fnorm(float *v, int n)
 {
   const float s = fsum(v, n);
@@ -97,6 +104,13 @@ struct Model {
   static constexpr int kSeg = 8;
   int seglen = 0;
   std::vector<float> ddpre_f, ddpre_b, ddpass;      // ddpass[k]: 0 if every tDD from the segment start to k is > 0, else -inf
+  std::vector<float> rfT;                           // [M+1][kKpad] match odds, residue-minor (null2_by_trace)
+  static constexpr int kKpad = 24;
+  void prepare_rfT()
+  {
+    rfT.assign((size_t) (M + 1) * kKpad, 0.0f);
+    for (int x = 0; x < p->K && x < kKpad; ++x) { const float *r = rf(x); for (int k = 1; k <= M; ++k) rfT[(size_t) k * kKpad + x] = r[k]; }
+  }
   void prepare()
   {
     seglen = (M + kSeg - 1) / kSeg;
@@ -712,10 +726,13 @@ int stochastic_trace(FastRng &rng, const Model &om, const Matrix &fx, int L, Tra
 }
 
 // ---------------------------------------------------------------- p7_Null2_ByTrace
-void null2_by_trace(const Model &om, const Trace &tr, int zstart, int zend, std::vector<float> &wm, std::vector<float> &wi, float *null2)
-{
-  const int M = om.M, Q = om.p->Q4();
-  wm.assign(M + 2, 0.0f); wi.assign(M + 2, 0.0f);
+P7X_MULTIVERSION void null2_by_trace(const Model &om, const Trace &tr, int zstart, int zend, float *wm, float *wi, float *null2)
+{ // wm / wi: [M+2] scratch.  The sums run in upstream's striped order (4 lanes, q ascending) for every residue at once:
+  // residue-minor odds make the inner loop a plain vector update, and nodes the trace never visited contribute
+  // exact zeros, so they are skipped.
+  const int M = om.M, Q = om.p->Q4(), K = om.p->K;
+  constexpr int KP = Model::kKpad;
+  for (int k = 0; k <= M + 1; ++k) { wm[k] = 0.0f; wi[k] = 0.0f; }
   float eN = 0.0f, eC = 0.0f, eJ = 0.0f;
   int Ld = 0;
   for (int z = zstart; z <= zend; ++z) {
@@ -728,18 +745,20 @@ void null2_by_trace(const Model &om, const Trace &tr, int zstart, int zend, std:
   for (int k = 1; k <= M; ++k) { wm[k] *= norm; wi[k] *= norm; }
   eN *= norm; eC *= norm; eJ *= norm;
   const float xfactor = eN + eC + eJ;
-  for (int x = 0; x < om.p->K; ++x) {
-    const float *rf = om.rf(x);
-    float lane[4] = {0, 0, 0, 0};
-    for (int q = 0; q < Q; ++q)
-      for (int z = 0; z < 4; ++z) {
-        const int k = q + 1 + z * Q;
-        if (k > M) continue;
-        lane[z] = lane[z] + wm[k] * rf[k];
-        lane[z] = lane[z] + wi[k];
-      }
-    null2[x] = ((lane[0] + lane[1]) + (lane[2] + lane[3])) + xfactor;
-  }
+  float acc[4][KP];
+  for (int z = 0; z < 4; ++z) for (int x = 0; x < KP; ++x) acc[z][x] = 0.0f;
+  const float *__restrict rfT = om.rfT.data();
+  for (int q = 0; q < Q; ++q)
+    for (int z = 0; z < 4; ++z) {
+      const int k = q + 1 + z * Q;
+      if (k > M) continue;
+      const float w = wm[k], v = wi[k];
+      if (w == 0.0f && v == 0.0f) continue;
+      const float *__restrict r = rfT + (size_t) k * KP;
+      float *__restrict a = acc[z];
+      for (int x = 0; x < KP; ++x) { a[x] = a[x] + w * r[x]; a[x] = a[x] + v; }
+    }
+  for (int x = 0; x < K; ++x) null2[x] = ((acc[0][x] + acc[1][x]) + (acc[2][x] + acc[3][x])) + xfactor;
   finish_null2(*om.p, null2);
 }
 
@@ -907,24 +926,17 @@ int rescore_isolated_domain(const Profile &p, Model &om, const uint8_t *dsq, int
 } // anonymous namespace
 
 // ---------------------------------------------------------------- p7_domaindef_ByPosteriorHeuristics
-int domaindef_by_posterior_heuristics(const Profile &p, const uint8_t *dsq, int L, const float *fx, const float *bx,
-                                      uint32_t seed, bool do_reseeding, DomainDefResult &dd,
-                                      std::vector<EnvelopeRequest> *defer, int item)
+// Step 1: posterior decoding of the special states (p7_DomainDecoding) and the region scan.
+int domaindef_regions(const Profile &p, int L, const float *fx, const float *bx, DomainDefResult &dd, std::vector<Region> &regs)
 {
   const float rt1 = 0.25f, rt2 = 0.10f, rt3 = 0.20f;                         // p7_domaindef.pxd:39-41
-  const int nsamples = 200;                                                  // p7_domaindef.pxd:43-48
-  const float min_overlap = 0.8f, min_posterior = 0.25f, min_endpointp = 0.02f;
-  const bool of_smaller = true; const int max_diagdiff = 4;
-
   Model om{ &p, p.M, {} };
-  om.prepare();
-  thread_local Workspace ws;
-  dd.dcl.clear(); dd.n2sc.assign(L + 1, 0.0f);
+  dd.dcl.clear(); dd.n2sc.assign(L + 1, 0.0f); dd.multi.clear();
   dd.nregions = dd.nclustered = dd.noverlaps = dd.nenvelopes = 0;
-
-  // p7_DomainDecoding from the parsers' special rows (multihit configuration of the whole target)
+  regs.clear();
   om.configure(true, L);
-  std::vector<float> btot(L + 1), etot(L + 1), mocc(L + 1);
+  thread_local std::vector<float> btot, etot, mocc;
+  btot.resize(L + 1); etot.resize(L + 1); mocc.resize(L + 1);
   {
     float scaleproduct = 1.0 / bx[0 * NX + xN_];
     btot[0] = etot[0] = mocc[0] = 0.0f;
@@ -939,9 +951,6 @@ int domaindef_by_posterior_heuristics(const Profile &p, const uint8_t *dsq, int 
     if (std::isinf(scaleproduct)) return P7X_ERANGE;
   }
   dd.nexpected = btot[L];
-
-  FastRng rng; rng.init(seed);
-  om.configure(false, L);           // every envelope is rescored in unihit mode, with the full-length length model
   int i = -1; bool triggered = false;
   for (int j = 1; j <= L; ++j) {
     if (!triggered) {
@@ -950,63 +959,126 @@ int domaindef_by_posterior_heuristics(const Profile &p, const uint8_t *dsq, int 
       if (mocc[j] >= rt1) triggered = true;
     } else if (mocc[j] - (etot[j] - etot[j - 1]) < rt2) {
       dd.nregions++;
-      // is_multidomain_region
-      float mx = -1.0f;
+      float mx = -1.0f;                                                      // is_multidomain_region
       for (int z = i; z <= j; ++z) mx = std::max(mx, std::min(etot[z] - etot[i - 1], btot[j] - btot[z - 1]));
-      if (mx >= rt3) {
-        dd.nclustered++;
-        // region_trace_ensemble: sample tracebacks from a multihit Forward matrix of the region, cluster them
-        om.configure(true, L);
-        { ProfScope ps(1); forward_full(om, dsq + i - 1, j - i + 1, ws.fwd, nullptr); }
-        const int Lr = j - i + 1;
-        for (int pos = i; pos <= j; ++pos) dd.n2sc[pos] = 0.0f;
-        if (do_reseeding) rng.init(seed);
-        std::vector<SpCoord> sp;
-        float null2[MAXKP];
-        for (int t = 0; t < nsamples; ++t) {
-          { ProfScope ps(2); if (stochastic_trace(rng, om, ws.fwd, Lr, ws.tr) != P7X_OK) return P7X_EINVAL; }
-          ws.tr.index();
-          int pos = 1;
-          for (int d = 0; d < ws.tr.ndom; ++d) {
-            sp.push_back(SpCoord{ t, ws.tr.sqfrom[d] + i - 1, ws.tr.sqto[d] + i - 1, ws.tr.hmmfrom[d], ws.tr.hmmto[d], 0.0f });
-            { ProfScope ps(3); null2_by_trace(om, ws.tr, ws.tr.tfrom[d], ws.tr.tto[d], ws.wm, ws.wi, null2); }
-            for (; pos <= ws.tr.sqfrom[d]; ++pos) dd.n2sc[i + pos - 1] += 1.0f;   // sic: the first domain residue counts as "outside"
-            for (; pos <= ws.tr.sqto[d]; ++pos) dd.n2sc[i + pos - 1] += null2[dsq[i + pos - 1]];
-          }
-          for (; pos <= Lr; ++pos) dd.n2sc[i + pos - 1] += 1.0f;
-        }
-        for (int pos = i; pos <= j; ++pos) dd.n2sc[pos] = logf(dd.n2sc[pos] / (float) nsamples);
-        std::vector<SpCoord> sigc;
-        { ProfScope ps(4); sp_cluster(sp, nsamples, min_overlap, of_smaller, max_diagdiff, min_posterior, min_endpointp, sigc); }
-        // remove envelopes dominated (>= 80% overlap of the smaller) by a more probable one
-        const int nc0 = (int) sigc.size();
-        std::vector<char> dominated(nc0, 0);
-        for (int d = 0; d < nc0; ++d)
-          for (int d2 = d + 1; d2 < nc0; ++d2) {
-            const int nov = std::min(sigc[d].j, sigc[d2].j) - std::max(sigc[d].i, sigc[d2].i) + 1;
-            if (nov == 0) break;
-            const int n = std::min(sigc[d].j - sigc[d].i + 1, sigc[d2].j - sigc[d2].i + 1);
-            if ((float) nov / (float) n >= 0.8f) { if (sigc[d].prob > sigc[d2].prob) dominated[d2] = 1; else dominated[d] = 1; }
-          }
-        om.configure(false, L);
-        int last_j2 = 0;
-        for (int d = 0; d < nc0; ++d) {
-          if (dominated[d]) continue;
-          const int i2 = sigc[d].i, j2 = sigc[d].j;
-          if (i2 <= last_j2) dd.noverlaps++;
-          dd.nenvelopes++;
-          if (rescore_isolated_domain(p, om, dsq, L, i2, j2, true, ws, dd) == P7X_OK) last_j2 = j2;
-        }
-      } else {
-        dd.nenvelopes++;
-        if (defer) {                 // rescored on the device; domaindef_finish_deferred() fills the placeholder
-          Domain ph; ph.ienv = i; ph.jenv = j; ph.deferred = (int) defer->size();
-          defer->push_back(EnvelopeRequest{ item, i, j });
-          dd.dcl.push_back(std::move(ph));
-        } else rescore_isolated_domain(p, om, dsq, L, i, j, false, ws, dd);
-      }
+      regs.push_back(Region{ i, j, mx >= rt3 });
       i = -1; triggered = false;
     }
+  }
+  return P7X_OK;
+}
+
+// Step 2 for a multi-domain region: region_trace_ensemble (sampled tracebacks from a multihit Forward matrix of the
+// region, single-linkage clustering of their domain coordinates), then every surviving envelope is rescored.
+int domaindef_multi_region(const Profile &p, const uint8_t *dsq, int L, int i, int j, uint32_t seed, bool do_reseeding,
+                           MultiRegionState &state, DomainDefResult &dd, std::vector<Domain> &out)
+{
+  const int nsamples = 200;                                                  // p7_domaindef.pxd:43-48
+  const float min_overlap = 0.8f, min_posterior = 0.25f, min_endpointp = 0.02f;
+  const bool of_smaller = true; const int max_diagdiff = 4;
+  thread_local Workspace ws;
+  Model om{ &p, p.M, {} };
+  om.prepare();
+  om.prepare_rfT();
+  ws.wm.resize(p.M + 2); ws.wi.resize(p.M + 2);
+  FastRng rng; rng.seed = state.rng_seed; rng.x = state.rng_x;
+  if (!state.started) { rng.init(seed); state.started = true; }
+  dd.nclustered++;
+  om.configure(true, L);
+  { ProfScope ps(1); forward_full(om, dsq + i - 1, j - i + 1, ws.fwd, nullptr); }
+  const int Lr = j - i + 1;
+  for (int pos = i; pos <= j; ++pos) dd.n2sc[pos] = 0.0f;
+  if (do_reseeding) rng.init(seed);
+  std::vector<SpCoord> sp;
+  float null2[MAXKP];
+  for (int t = 0; t < nsamples; ++t) {
+    { ProfScope ps(2); if (stochastic_trace(rng, om, ws.fwd, Lr, ws.tr) != P7X_OK) return P7X_EINVAL; }
+    ws.tr.index();
+    int pos = 1;
+    for (int d = 0; d < ws.tr.ndom; ++d) {
+      sp.push_back(SpCoord{ t, ws.tr.sqfrom[d] + i - 1, ws.tr.sqto[d] + i - 1, ws.tr.hmmfrom[d], ws.tr.hmmto[d], 0.0f });
+      { ProfScope ps(3); null2_by_trace(om, ws.tr, ws.tr.tfrom[d], ws.tr.tto[d], ws.wm.data(), ws.wi.data(), null2); }
+      for (; pos <= ws.tr.sqfrom[d]; ++pos) dd.n2sc[i + pos - 1] += 1.0f;   // sic: the first domain residue counts as "outside"
+      for (; pos <= ws.tr.sqto[d]; ++pos) dd.n2sc[i + pos - 1] += null2[dsq[i + pos - 1]];
+    }
+    for (; pos <= Lr; ++pos) dd.n2sc[i + pos - 1] += 1.0f;
+  }
+  state.rng_seed = rng.seed; state.rng_x = rng.x;
+  for (int pos = i; pos <= j; ++pos) dd.n2sc[pos] = logf(dd.n2sc[pos] / (float) nsamples);
+  std::vector<SpCoord> sigc;
+  { ProfScope ps(4); sp_cluster(sp, nsamples, min_overlap, of_smaller, max_diagdiff, min_posterior, min_endpointp, sigc); }
+  // remove envelopes dominated (>= 80% overlap of the smaller) by a more probable one
+  const int nc0 = (int) sigc.size();
+  std::vector<char> dominated(nc0, 0);
+  for (int d = 0; d < nc0; ++d)
+    for (int d2 = d + 1; d2 < nc0; ++d2) {
+      const int nov = std::min(sigc[d].j, sigc[d2].j) - std::max(sigc[d].i, sigc[d2].i) + 1;
+      if (nov == 0) break;
+      const int n = std::min(sigc[d].j - sigc[d].i + 1, sigc[d2].j - sigc[d2].i + 1);
+      if ((float) nov / (float) n >= 0.8f) { if (sigc[d].prob > sigc[d2].prob) dominated[d2] = 1; else dominated[d] = 1; }
+    }
+  om.configure(false, L);
+  int last_j2 = 0;
+  std::vector<Domain> keep;
+  keep.swap(dd.dcl);                       // rescore_isolated_domain() appends to dd.dcl: collect this region's domains apart
+  for (int d = 0; d < nc0; ++d) {
+    if (dominated[d]) continue;
+    const int i2 = sigc[d].i, j2 = sigc[d].j;
+    if (i2 <= last_j2) dd.noverlaps++;
+    dd.nenvelopes++;
+    if (rescore_isolated_domain(p, om, dsq, L, i2, j2, true, ws, dd) == P7X_OK) last_j2 = j2;
+  }
+  out = std::move(dd.dcl);
+  dd.dcl.swap(keep);
+  return P7X_OK;
+}
+
+int domaindef_by_posterior_heuristics(const Profile &p, const uint8_t *dsq, int L, const float *fx, const float *bx,
+                                      uint32_t seed, bool do_reseeding, DomainDefResult &dd,
+                                      std::vector<EnvelopeRequest> *defer, int item)
+{
+  thread_local std::vector<Region> regs;
+  const int st = domaindef_regions(p, L, fx, bx, dd, regs);
+  if (st != P7X_OK) return st;
+  Model om{ &p, p.M, {} };
+  thread_local Workspace ws;
+  bool prepared = false;
+  MultiRegionState state;
+  for (const Region &r : regs) {
+    if (r.multi) {
+      if (defer) {                    // resolved later by domaindef_multi_region(): leave a marker in domain order
+        Domain ph; ph.ienv = r.i; ph.jenv = r.j; ph.deferred = -2; ph.multi_slot = (int) dd.multi.size();
+        dd.multi.emplace_back();
+        dd.dcl.push_back(std::move(ph));
+        continue;
+      }
+      std::vector<Domain> doms;
+      const int st2 = domaindef_multi_region(p, dsq, L, r.i, r.j, seed, do_reseeding, state, dd, doms);
+      if (st2 != P7X_OK) return st2;
+      for (Domain &d : doms) dd.dcl.push_back(std::move(d));
+    } else {
+      dd.nenvelopes++;
+      if (defer) {                   // rescored on the device; domaindef_finish_deferred() fills the placeholder
+        Domain ph; ph.ienv = r.i; ph.jenv = r.j; ph.deferred = (int) defer->size();
+        defer->push_back(EnvelopeRequest{ item, r.i, r.j });
+        dd.dcl.push_back(std::move(ph));
+      } else {
+        if (!prepared) { om.prepare(); om.configure(false, L); prepared = true; }
+        rescore_isolated_domain(p, om, dsq, L, r.i, r.j, false, ws, dd);
+      }
+    }
+  }
+  return P7X_OK;
+}
+
+// The multi-domain regions left behind by the deferring call above, in order.
+int domaindef_finish_multi(const Profile &p, const uint8_t *dsq, int L, uint32_t seed, bool do_reseeding, DomainDefResult &dd)
+{
+  MultiRegionState state;
+  for (Domain &d : dd.dcl) {
+    if (d.deferred != -2) continue;
+    const int st = domaindef_multi_region(p, dsq, L, (int) d.ienv, (int) d.jenv, seed, do_reseeding, state, dd, dd.multi[(size_t) d.multi_slot]);
+    if (st != P7X_OK) return st;
   }
   return P7X_OK;
 }
@@ -1021,6 +1093,7 @@ int domaindef_finish_deferred(const Profile &p, const uint8_t *dsq, int L, const
   std::vector<Domain> kept;
   kept.reserve(dd.dcl.size());
   for (Domain &d : dd.dcl) {
+    if (d.deferred == -2) { for (Domain &m : dd.multi[(size_t) d.multi_slot]) kept.push_back(std::move(m)); continue; }
     if (d.deferred < 0) { kept.push_back(std::move(d)); continue; }
     const EnvelopeResult &r = res[(size_t) req_index[(size_t) d.deferred]];
     const int i = (int) d.ienv, j = (int) d.jenv;

@@ -21,11 +21,13 @@ struct Domain {
   int64_t sqfrom = 0, sqto = 0, L = 0;
   std::string model, mline, aseq, ppline, rfline, mmline, csline;
   int deferred = -1;          // >= 0: placeholder, to be filled from envelope request <deferred> (device rescoring)
+  int multi_slot = -1;        // deferred == -2: placeholder of a multi-domain region, domains in DomainDefResult::multi
 };
 
 struct DomainDefResult {      // the P7_DOMAINDEF fields p7_Pipeline reads (p7_domaindef.pxd:23-59)
   std::vector<Domain> dcl;
   std::vector<float> n2sc;    // [L+1]
+  std::vector<std::vector<Domain>> multi;   // domains of deferred multi-domain regions (see Domain::multi_slot)
   float nexpected = 0;
   int nregions = 0, nclustered = 0, noverlaps = 0, nenvelopes = 0;
 };
@@ -40,12 +42,21 @@ struct EnvelopeResult {
 };
 struct EnvelopeScorer {
   virtual ~EnvelopeScorer() = default;
-  // targets[item] = caller index of the survivor; fills res[r] for every req[r]; buffers stay valid until the next call
-  virtual int score(const std::vector<EnvelopeRequest> &req, const std::vector<int32_t> &targets, std::vector<EnvelopeResult> &res) = 0;
+  // begin() enqueues the batch (targets[item] = caller index of the survivor) and returns; wait() blocks until it is
+  // done and fills res[r] for every req[r].  Result buffers stay valid until the next begin().
+  virtual int begin(const std::vector<EnvelopeRequest> &req, const std::vector<int32_t> &targets) = 0;
+  virtual int wait(std::vector<EnvelopeResult> &res) = 0;
 };
 
 // p7_domaindef_ByPosteriorHeuristics (p7_domaindef.pxd:69-72).  dsq is 1-indexed (dsq[1..L]);
 // fwd_xmx / bck_xmx are the parsers' special-state rows, (L+1) x [E,N,J,B,C,SCALE].
+struct Region { int i, j; bool multi; };
+struct MultiRegionState { bool started = false; uint32_t rng_seed = 42, rng_x = 0; };   // RNG carried between the regions of one target
+int domaindef_regions(const Profile &p, int L, const float *fwd_xmx, const float *bck_xmx, DomainDefResult &dd, std::vector<Region> &regs);
+int domaindef_multi_region(const Profile &p, const uint8_t *dsq, int L, int i, int j, uint32_t seed, bool do_reseeding,
+                           MultiRegionState &state, DomainDefResult &dd, std::vector<Domain> &out);
+int domaindef_finish_multi(const Profile &p, const uint8_t *dsq, int L, uint32_t seed, bool do_reseeding, DomainDefResult &dd);
+
 // With <defer> the single-domain regions are queued there (tagged <item>) instead of being rescored on the host;
 // domaindef_finish_deferred() completes them from the device results (res[d.deferred] for placeholder d).
 int domaindef_by_posterior_heuristics(const Profile &p, const uint8_t *dsq, int L, const float *fwd_xmx,

@@ -444,10 +444,10 @@ class DeviceEnvelopeScorer final : public EnvelopeScorer {
 public:
   DeviceEnvelopeScorer(DeviceCtx *ctx, const DevProfile *dp, const p7x_seqdb *db, const Profile &p) : ctx_(ctx), dp_(dp), db_(db), p_(p) {}
 
-  int score(const std::vector<EnvelopeRequest> &req, const std::vector<int32_t> &targets, std::vector<EnvelopeResult> &res) override
+  int begin(const std::vector<EnvelopeRequest> &req, const std::vector<int32_t> &targets) override
   {
     const int nenv = (int) req.size();
-    res.assign((size_t) nenv, EnvelopeResult{});
+    nenv_ = nenv;
     if (nenv == 0) return P7X_OK;
     P7X_HIP(hipSetDevice(db_->device));
     EnvBuffers *eb = nullptr;
@@ -456,7 +456,8 @@ public:
 
     // inputs
     const size_t in_bytes = (size_t) nenv * (8 + 8 + 4 + 4);
-    std::vector<unsigned char> h_in(in_bytes);
+    h_in_.resize(in_bytes);
+    std::vector<unsigned char> &h_in = h_in_;
     int64_t *env_sq = reinterpret_cast<int64_t *>(h_in.data());
     int64_t *tr_off = env_sq + nenv;
     int32_t *env_len = reinterpret_cast<int32_t *>(tr_off + nenv);
@@ -524,7 +525,20 @@ public:
     a.tr_pp = reinterpret_cast<float *>(eb->d_out + o_tp);
     if ((st = env_launch(a, nblocks, s)) != P7X_OK) return st;
     P7X_HIP(hipMemcpyAsync(eb->h_out, eb->d_out, out_bytes, hipMemcpyDeviceToHost, s));
-    P7X_HIP(hipStreamSynchronize(s));
+    eb_ = eb; o_sc_ = o_sc; o_n2_ = o_n2; o_st_ = o_st; o_n_ = o_n; o_ta_ = o_ta; o_ti_ = o_ti; o_tp_ = o_tp;
+    return P7X_OK;
+  }
+
+  int wait(std::vector<EnvelopeResult> &res) override
+  {
+    const int nenv = nenv_;
+    res.assign((size_t) nenv, EnvelopeResult{});
+    if (nenv == 0) return P7X_OK;
+    P7X_HIP(hipSetDevice(db_->device));
+    P7X_HIP(hipStreamSynchronize(ctx_->stream));
+    EnvBuffers *eb = eb_;
+    const size_t o_sc = o_sc_, o_n2 = o_n2_, o_st = o_st_, o_n = o_n_, o_ta = o_ta_, o_ti = o_ti_, o_tp = o_tp_;
+    const int64_t *tr_off = reinterpret_cast<const int64_t *>(h_in_.data()) + nenv;
     const float *h_sc = reinterpret_cast<const float *>(eb->h_out + o_sc), *h_n2 = reinterpret_cast<const float *>(eb->h_out + o_n2);
     const int32_t *h_st = reinterpret_cast<const int32_t *>(eb->h_out + o_st), *h_n = reinterpret_cast<const int32_t *>(eb->h_out + o_n);
     const uint32_t *h_ta = reinterpret_cast<const uint32_t *>(eb->h_out + o_ta);
@@ -541,6 +555,10 @@ public:
 
 private:
   DeviceCtx *ctx_; const DevProfile *dp_; const p7x_seqdb *db_; const Profile &p_;
+  int nenv_ = 0;
+  std::vector<unsigned char> h_in_;
+  EnvBuffers *eb_ = nullptr;
+  size_t o_sc_ = 0, o_n2_ = 0, o_st_ = 0, o_n_ = 0, o_ta_ = 0, o_ti_ = 0, o_tp_ = 0;
 };
 
 } // namespace p7x

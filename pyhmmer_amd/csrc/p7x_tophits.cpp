@@ -12,7 +12,9 @@
 #include <cstdlib>
 #include <cstring>
 #include <sched.h>
+#include <condition_variable>
 #include <functional>
+#include <mutex>
 #include <thread>
 
 namespace p7x {
@@ -71,6 +73,63 @@ static int usable_cpus()
   }
   return n > 0 ? n : 1;
 }
+
+// Persistent workers for the host phases of a search (spawning 16 threads three times per query costs ~1 ms).
+// run(n, nthreads, body) calls body(i) for every i in [0, n), dynamically scheduled; the caller participates.
+class HostPool {
+public:
+  static HostPool &get() { static HostPool pool; return pool; }
+  void run(int n, int nthreads, const std::function<void(int)> &body)
+  {
+    if (n <= 0) return;
+    std::unique_lock<std::mutex> run_lock(run_mu_);                  // one parallel region at a time
+    if (nthreads > n) nthreads = n;
+    if (nthreads <= 1) { flogsum_init(); for (int i = 0; i < n; ++i) body(i); return; }
+    {
+      std::lock_guard<std::mutex> lk(mu_);
+      while ((int) workers_.size() < nthreads - 1) workers_.emplace_back([this, id = (int) workers_.size()] { loop(id); });
+      body_ = &body; n_ = n; next_.store(0); active_ = nthreads - 1; pending_ = nthreads - 1; ++generation_;
+    }
+    cv_.notify_all();
+    flogsum_init();
+    for (;;) { const int i = next_.fetch_add(1); if (i >= n) break; body(i); }
+    std::unique_lock<std::mutex> lk(mu_);
+    done_cv_.wait(lk, [this] { return pending_ == 0; });
+    body_ = nullptr;
+  }
+private:
+  HostPool() = default;
+  ~HostPool()
+  {
+    { std::lock_guard<std::mutex> lk(mu_); stop_ = true; ++generation_; }
+    cv_.notify_all();
+    for (auto &t : workers_) t.join();
+  }
+  void loop(int id)
+  {
+    flogsum_init();
+    uint64_t seen = 0;
+    for (;;) {
+      const std::function<void(int)> *body = nullptr; int n = 0;
+      {
+        std::unique_lock<std::mutex> lk(mu_);
+        cv_.wait(lk, [&] { return stop_ || (generation_ != seen && id < active_); });
+        if (stop_) return;
+        seen = generation_; body = body_; n = n_;
+      }
+      for (;;) { const int i = next_.fetch_add(1); if (i >= n) break; (*body)(i); }
+      { std::lock_guard<std::mutex> lk(mu_); if (--pending_ == 0) done_cv_.notify_one(); }
+    }
+  }
+  std::mutex run_mu_, mu_;
+  std::condition_variable cv_, done_cv_;
+  std::vector<std::thread> workers_;
+  const std::function<void(int)> *body_ = nullptr;
+  int n_ = 0, active_ = 0, pending_ = 0;
+  std::atomic<int> next_{0};
+  uint64_t generation_ = 0;
+  bool stop_ = false;
+};
 
 float kahan_fsum(const float *v, int n)
 { // Easel esl_vec_FSum: Kahan compensated summation
@@ -232,63 +291,62 @@ int host_finish_search(const p7x_pipeline_cfg &cfg_in, const p7x_oprofile *om, c
   if (nthreads < 1) nthreads = 1;
   if (nthreads > (n + 3) / 4) nthreads = (n + 3) / 4;      // at least ~4 targets per worker
   if (nthreads < 1) nthreads = 1;
-  auto run_pool = [&](const std::function<void(int)> &body) {
-    std::atomic<int> next{0};
-    auto worker = [&](int tid) {
-      flogsum_init();
-      for (;;) { const int i = next.fetch_add(1); if (i >= n) break; body(i); (void) tid; }
-    };
-    if (nthreads <= 1) worker(0);
-    else {
-      std::vector<std::thread> pool;
-      for (int i = 0; i < nthreads; ++i) pool.emplace_back(worker, i);
-      for (auto &t : pool) t.join();
-    }
-  };
+  auto run_pool = [&](int count, const std::function<void(int)> &body) { HostPool::get().run(count, nthreads, body); };
   auto finish = [&](int i, DomainDefResult &dd) {
     const int t = tgt[i];
     const double Zrun = (cfg.Z_setby == P7X_ZSETBY_NTARGETS) ? (double) (t + 1) : cfg.Z;
     finish_one(cfg, p, tg.len[t], fwdsc[i], Zrun, dd, pend[i]);
     if (pend[i].have) pend[i].hit.seqidx = t;
   };
+  const bool reseed = cfg.seed != 0;
   if (!scorer) {
     // everything on the host (CPU test seam, and the fallback for models the envelope kernel does not cover)
-    run_pool([&](int i) {
+    run_pool(n, [&](int i) {
       const int t = tgt[i];
       DomainDefResult dd;
       const int st = domaindef_by_posterior_heuristics(p, tg.dsq + tg.off[t] - 1, tg.len[t], fwd_xmx + xmx_off[i], bck_xmx + xmx_off[i],
-                                                       cfg.seed, cfg.seed != 0, dd);
+                                                       cfg.seed, reseed, dd);
       if (st != P7X_OK) { failed.store(st); return; }
       finish(i, dd);
     });
   } else {
-    // 1. regions on the host; single-domain envelopes are queued for the device, multi-domain regions (stochastic
-    //    traceback clustering) are resolved right here
+    // 1. regions (cheap); single-domain envelopes are queued for the device
     std::vector<DomainDefResult> dds((size_t) n);
     std::vector<std::vector<EnvelopeRequest>> local((size_t) n);
-    run_pool([&](int i) {
+    run_pool(n, [&](int i) {
       const int t = tgt[i];
       const int st = domaindef_by_posterior_heuristics(p, tg.dsq + tg.off[t] - 1, tg.len[t], fwd_xmx + xmx_off[i], bck_xmx + xmx_off[i],
-                                                       cfg.seed, cfg.seed != 0, dds[i], &local[i], i);
+                                                       cfg.seed, reseed, dds[i], &local[i], i);
       if (st != P7X_OK) failed.store(st);
     });
-    th->ms[9] = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     if (failed.load() == 0) {
-      // 2. one batch through the envelope kernel
       std::vector<EnvelopeRequest> req;
       std::vector<std::vector<int>> req_index((size_t) n);
-      for (int i = 0; i < n; ++i)
+      std::vector<int> heavy;
+      for (int i = 0; i < n; ++i) {
         for (const EnvelopeRequest &r : local[i]) { req_index[i].push_back((int) req.size()); req.push_back(r); }
-      std::vector<EnvelopeResult> res;
+        if (!dds[i].multi.empty()) heavy.push_back(i);
+      }
+      // 2. the envelope kernel runs while the host resolves the multi-domain regions (stochastic traceback
+      //    ensembles: inherently sequential per region, so they are spread over the workers target by target)
       const auto t1 = std::chrono::steady_clock::now();
-      if (!req.empty()) { const int st = scorer->score(req, tgt, res); if (st != P7X_OK) return st; }
+      if (!req.empty()) { const int st = scorer->begin(req, tgt); if (st != P7X_OK) return st; }
+      run_pool((int) heavy.size(), [&](int h) {
+        const int i = heavy[(size_t) h], t = tgt[i];
+        const int st = domaindef_finish_multi(p, tg.dsq + tg.off[t] - 1, tg.len[t], cfg.seed, reseed, dds[i]);
+        if (st != P7X_OK) failed.store(st);
+      });
+      th->ms[9] = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t1).count();
+      std::vector<EnvelopeResult> res;
+      if (!req.empty()) { const int st = scorer->wait(res); if (st != P7X_OK) return st; }
       th->ms[8] = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t1).count();
       // 3. alignment displays, null2 corrections, per-target scores
-      run_pool([&](int i) {
-        const int t = tgt[i];
-        if (!req_index[i].empty()) domaindef_finish_deferred(p, tg.dsq + tg.off[t] - 1, tg.len[t], res, req_index[i], dds[i]);
-        finish(i, dds[i]);
-      });
+      if (failed.load() == 0)
+        run_pool(n, [&](int i) {
+          const int t = tgt[i];
+          domaindef_finish_deferred(p, tg.dsq + tg.off[t] - 1, tg.len[t], res, req_index[i], dds[i]);
+          finish(i, dds[i]);
+        });
     }
   }
   host_prof_dump();

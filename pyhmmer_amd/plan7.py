@@ -856,7 +856,7 @@ class TopHits:
         buf = (C.c_double * 10)()
         _lib.lib().p7x_tophits_get_timings(self._handle, buf, 10)
         return dict(zip(("msv", "bias", "viterbi", "forward", "fwd_rows", "host_domaindef", "total", "msv_kernel",
-                         "envelopes", "host_regions"), buf))
+                         "envelopes", "host_multi"), buf))
 
     @property
     def reported(self):
