@@ -98,12 +98,13 @@ def make_workload(hmm, nseq, L, seed, planted_frac=0.001):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--nseq", type=int, default=1_000_000, help="targets per GPU")
     ap.add_argument("--seqlen", type=int, default=300)
     ap.add_argument("--hmm", default="KR")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--pipeline-depth", type=int, default=2, help="queries whose device stage may run ahead of the host stage (0: none)")
     ap.add_argument("--cpu-sample", type=int, default=1_000_000, help="targets timed through the CPU oracle (rank 0, N=1)")
     args = ap.parse_args()
 
@@ -136,10 +137,18 @@ def main():
     db = plan7.SequenceDatabase.from_packed(hmm.alphabet, flat, offsets, lengths, device=local_rank)
     torch.cuda.synchronize()
     t_pack = time.perf_counter() - t0
-    pli = plan7.Pipeline(hmm.alphabet, device=local_rank)
 
-    def step():
-        return pli.search_hmm(om, db)
+    from pyhmmer_amd import hmmer
+
+    def run(nsteps):
+        """nsteps searches of the same workload through the public entry point.  hmmsearch overlaps the device
+        stage of query k+1 with the host stage of query k (pipeline_depth), exactly as it does for distinct queries."""
+        last, acc = None, {}
+        for h in hmmer.hmmsearch((om for _ in range(nsteps)), db, pipeline_depth=args.pipeline_depth):
+            last = h
+            for k, v in h.timings_ms.items():
+                acc[k] = acc.get(k, 0.0) + v
+        return last, acc
 
     def barrier():
         if dist is not None:
@@ -147,15 +156,11 @@ def main():
         torch.cuda.synchronize()
 
     hits = None
-    for _ in range(args.warmup):
-        hits = step()
+    if args.warmup > 0:
+        hits, _ = run(args.warmup)
     barrier()
     t0 = time.perf_counter()
-    stage = {}
-    for _ in range(args.steps):
-        hits = step()
-        for k, v in hits.timings_ms.items():
-            stage[k] = stage.get(k, 0.0) + v
+    hits, stage = run(args.steps)
     barrier()
     elapsed = time.perf_counter() - t0
     stage = {k: v / args.steps for k, v in stage.items()}
@@ -204,7 +209,11 @@ def main():
                             f"{args.seqlen}-aa targets per GPU, i.i.d. background + 0.1% planted positives, full pipeline "
                             "MSV->bias->Viterbi->Forward->Backward on device + domain definition/TopHits on host",
                 "targets_per_gpu": args.nseq, "target_len": args.seqlen, "M": hmm.M, "parallelism": f"targets sharded over {world} GPU(s), host merge",
-                "timed_region": "Pipeline.search_hmm per step, targets resident in HBM (pack+upload once: %.2fs, generation %.2fs, not timed)" % (t_pack, t_gen),
+                "timed_region": "hmmer.hmmsearch over `steps` queries (the same profile each time), every query runs the complete "
+                                "search; device stage of query k+1 overlaps the host stage of query k (pipeline_depth=%d); targets "
+                                "resident in HBM (pack+upload once: %.2fs, generation %.2fs, not timed)" % (args.pipeline_depth, t_pack, t_gen),
+                "pipeline_depth": args.pipeline_depth,
+                "latency_ms_per_query": round(stage.get("total", 0.0), 3),
             },
             "stages": {
                 "n_targets": args.nseq, "past_msv": sc["msv"], "past_bias": sc["bias"], "past_vit": sc["vit"], "past_fwd": sc["fwd"],

@@ -186,6 +186,17 @@ int p7x_search_block(const p7x_pipeline_cfg *cfg, const p7x_oprofile *om, const 
                      const p7x_seqdb *db, const char *const *names, const char *const *accs,
                      const char *const *descs, p7x_tophits **out);
 
+/* The same search in two stages, for callers that overlap consecutive queries (the reference runs its queries on
+ * worker threads, _hmmsearch.py:294-436): begin = filters + parsers on the device (blocks until they are done),
+ * finish = domain definition + hit list; finish consumes the handle.  begin/finish of different searches may run
+ * on different host threads at the same time. */
+typedef struct p7x_pending p7x_pending;
+int  p7x_search_block_begin(const p7x_pipeline_cfg *cfg, const p7x_oprofile *om, const float *bg_f,
+                            const p7x_seqdb *db, p7x_pending **out);
+int  p7x_search_block_finish(p7x_pending *pending, const char *const *names, const char *const *accs,
+                             const char *const *descs, p7x_tophits **out);
+void p7x_pending_destroy(p7x_pending *pending);
+
 /* Host half of p7_Pipeline for targets that already passed the Forward filter: Backward-derived domain
  * definition (p7_domaindef_ByPosteriorHeuristics, p7_domaindef.pxd:69-72), per-sequence / per-domain scores,
  * reporting thresholds, sort.  p7x_search_block calls this internally with the device parsers' output; it is

@@ -179,6 +179,9 @@ _SIGNATURES = {
     "p7x_tophits_sort_by_key": (C.c_int, [_VP]),
     "p7x_tophits_threshold": (C.c_int, [_VP]),
     "p7x_tophits_get_timings": (C.c_int, [_VP, C.POINTER(C.c_double), C.c_int]),
+    "p7x_search_block_begin": (C.c_int, [C.POINTER(PipelineCfg), _VP, _VP, _VP, C.POINTER(_VP)]),
+    "p7x_search_block_finish": (C.c_int, [_VP, _VP, _VP, _VP, C.POINTER(_VP)]),
+    "p7x_pending_destroy": (None, [_VP]),
     "p7x_last_error": (C.c_char_p, []),
 }
 

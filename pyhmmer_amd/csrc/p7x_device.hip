@@ -31,6 +31,7 @@ int get_ctx(int device, DeviceCtx **out)
   auto ctx = std::make_unique<DeviceCtx>();
   ctx->device = device;
   P7X_HIP(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
+  P7X_HIP(hipStreamCreateWithFlags(&ctx->stream2, hipStreamNonBlocking));
   hipDeviceProp_t prop;
   P7X_HIP(hipGetDeviceProperties(&prop, device));
   ctx->num_cu = prop.multiProcessorCount;

@@ -27,6 +27,7 @@ struct LengthTables {
 struct DeviceCtx {
   int device = -1;
   hipStream_t stream = nullptr;
+  hipStream_t stream2 = nullptr;     // envelope rescoring (host stage of a search), so it never waits on the next cascade
   LengthTables lt;
   int num_cu = 256;
   std::mutex mu;

@@ -504,7 +504,7 @@ public:
       P7X_HIP(hipMalloc(&eb->d_out, cap)); eb->d_out_cap = cap;
       P7X_HIP(hipHostMalloc(reinterpret_cast<void **>(&eb->h_out), cap, hipHostMallocDefault)); eb->h_out_cap = cap;
     }
-    hipStream_t s = ctx_->stream;
+    hipStream_t s = ctx_->stream2;
     P7X_HIP(hipMemcpyAsync(eb->d_in, h_in.data(), in_bytes, hipMemcpyHostToDevice, s));
     EnvArgs a{};
     a.M = p_.M; a.C = C; a.K = p_.K; a.nrows = p_.Kp + 1;
@@ -535,7 +535,7 @@ public:
     res.assign((size_t) nenv, EnvelopeResult{});
     if (nenv == 0) return P7X_OK;
     P7X_HIP(hipSetDevice(db_->device));
-    P7X_HIP(hipStreamSynchronize(ctx_->stream));
+    P7X_HIP(hipStreamSynchronize(ctx_->stream2));
     EnvBuffers *eb = eb_;
     const size_t o_sc = o_sc_, o_n2 = o_n2_, o_st = o_st_, o_n = o_n_, o_ta = o_ta_, o_ti = o_ti_, o_tp = o_tp_;
     const int64_t *tr_off = reinterpret_cast<const int64_t *>(h_in_.data()) + nenv;
@@ -716,38 +716,78 @@ int p7x_fwd_parser(const p7x_oprofile *om, int device, const uint8_t *dsq, int32
 int p7x_bck_parser(const p7x_oprofile *om, int device, const uint8_t *dsq, int32_t L, float *sc) { return one_seq(om, device, dsq, L, 3, sc); }
 
 // ---------------------------------------------------------------------------- the search
-int p7x_search_block(const p7x_pipeline_cfg *cfg, const p7x_oprofile *om, const float *bg_f, const p7x_seqdb *db,
-                     const char *const *names, const char *const *accs, const char *const *descs, p7x_tophits **out)
+// Two stages, so that a caller with many queries can overlap them (hmmer.hmmsearch does): begin = the filter
+// cascade and the parsers on the device, finish = domain definition on the host (+ the envelope kernel on its own
+// stream).  p7x_search_block is begin followed by finish.
+struct p7x_pending {
+  p7x_pipeline_cfg cfg{};
+  const p7x_oprofile *om = nullptr;
+  const p7x_seqdb *db = nullptr;
+  CascadeOut co;
+  std::chrono::steady_clock::time_point t0;
+};
+
+int p7x_search_block_begin(const p7x_pipeline_cfg *cfg, const p7x_oprofile *om, const float *bg_f, const p7x_seqdb *db,
+                           p7x_pending **out)
 {
-  if (!cfg || !om || !db || !out) { set_error("p7x_search_block: bad arguments"); return P7X_EINVAL; }
+  if (!cfg || !om || !db || !out) { set_error("p7x_search_block_begin: bad arguments"); return P7X_EINVAL; }
   (void) bg_f;
-  const auto t0 = std::chrono::steady_clock::now();
+  *out = nullptr;
+  auto pd = std::make_unique<p7x_pending>();
+  pd->t0 = std::chrono::steady_clock::now();
   if (cfg->use_bit_cutoffs) {   // p7_pli_NewModelThresholds: eslEINVAL when the model lacks the cutoffs
     const Profile &p = om->p;
     const int i = cfg->use_bit_cutoffs == P7X_BITCUT_GA ? P7X_GA1 : (cfg->use_bit_cutoffs == P7X_BITCUT_TC ? P7X_TC1 : P7X_NC1);
     if (p.cutoff[i] == P7X_CUTOFF_UNSET || p.cutoff[i + 1] == P7X_CUTOFF_UNSET) { set_error("model is missing the requested bit score cutoffs"); return P7X_EINVAL; }
   }
-  CascadeOut co;
-  int st = run_cascade(*cfg, om, db, co);
+  pd->cfg = *cfg; pd->om = om; pd->db = db;
+  const int st = run_cascade(*cfg, om, db, pd->co);
   if (st != P7X_OK) return st;
+  pd->co.ms[6] = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - pd->t0).count();   // stage 1 wall
+  *out = pd.release();
+  return P7X_OK;
+}
+
+int p7x_search_block_finish(p7x_pending *pd, const char *const *names, const char *const *accs, const char *const *descs,
+                            p7x_tophits **out)
+{
+  if (!pd || !out) { set_error("p7x_search_block_finish: bad arguments"); return P7X_EINVAL; }
+  std::unique_ptr<p7x_pending> owner(pd);                // consumed, also on failure
+  const auto t1 = std::chrono::steady_clock::now();
+  const p7x_seqdb *db = pd->db; const p7x_oprofile *om = pd->om; CascadeOut &co = pd->co;
   HostTargets tg;
   tg.n = db->n; tg.nres = db->nres; tg.len = db->h_len.data(); tg.off = db->h_off.data(); tg.dsq = db->h_dsq.data();
   std::vector<int32_t> targets(co.fin_slots.size());
   for (size_t i = 0; i < targets.size(); ++i) targets[i] = db->h_order[co.fin_slots[i]];
   const uint64_t counts[4] = { (uint64_t) co.counts[1], (uint64_t) co.counts[8], (uint64_t) co.counts[3], (uint64_t) co.counts[4] };
+  int st = P7X_OK;
   std::unique_ptr<DeviceEnvelopeScorer> scorer;
-  if (!g_host_envelopes && !cfg->host_envelopes && !targets.empty()) {
+  if (!g_host_envelopes && !pd->cfg.host_envelopes && !targets.empty()) {
     DeviceCtx *ctx = nullptr; DevProfile *dp = nullptr;
     if ((st = get_ctx(db->device, &ctx)) != P7X_OK || (st = get_dev_profile(om, ctx, &dp)) != P7X_OK) return st;
     scorer = std::make_unique<DeviceEnvelopeScorer>(ctx, dp, db, om->p);
   }
-  st = host_finish_search(*cfg, om, tg, names, accs, descs, targets, co.fwdsc.data(), co.fwd_xmx.data(), co.bck_xmx.data(),
+  const double stage1 = co.ms[6];
+  st = host_finish_search(pd->cfg, om, tg, names, accs, descs, targets, co.fwdsc.data(), co.fwd_xmx.data(), co.bck_xmx.data(),
                           co.xmx_off.data(), counts, co.ms, out, scorer.get());
   if (st == P7X_OK) {
-    const double total = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
-    tophits_set_total_ms(*out, total);
+    // work time of this search (stage 1 + stage 2), not the time it spent queued between the stages
+    const double stage2 = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t1).count();
+    tophits_set_total_ms(*out, stage1 + stage2);
   }
   return st;
+}
+
+void p7x_pending_destroy(p7x_pending *pd) { delete pd; }
+
+int p7x_search_block(const p7x_pipeline_cfg *cfg, const p7x_oprofile *om, const float *bg_f, const p7x_seqdb *db,
+                     const char *const *names, const char *const *accs, const char *const *descs, p7x_tophits **out)
+{
+  if (!cfg || !om || !db || !out) { set_error("p7x_search_block: bad arguments"); return P7X_EINVAL; }
+  p7x_pending *pd = nullptr;
+  const int st = p7x_search_block_begin(cfg, om, bg_f, db, &pd);
+  if (st != P7X_OK) return st;
+  return p7x_search_block_finish(pd, names, accs, descs, out);
 }
 
 } // extern "C"

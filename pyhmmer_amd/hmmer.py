@@ -10,6 +10,7 @@ re-thresholded on the host.  No collective is involved.
 """
 from __future__ import annotations
 
+import queue
 import threading
 from typing import Callable, Iterable, Iterator, List, Optional, Sequence, Union
 
@@ -51,38 +52,67 @@ class ShardedDatabase:
         self.chunks = make_chunks(block, len(self.devices))
         self.shards = [SequenceDatabase(c, device=d) for c, d in zip(self.chunks, self.devices)]
 
-    def search(self, pipelines: Sequence[Pipeline], query) -> TopHits:
-        results: List[Optional[TopHits]] = [None] * len(self.shards)
+    @classmethod
+    def from_database(cls, database: SequenceDatabase) -> "ShardedDatabase":
+        """One resident shard that was packed by the caller (``SequenceDatabase.from_packed``)."""
+        self = cls.__new__(cls)
+        self.block = database.block
+        self.devices = [database.device]
+        self.chunks = [database.block]
+        self.shards = [database]
+        return self
+
+    def _on_shards(self, fn) -> list:
+        """fn(i) for every shard, concurrently when there are several; the first exception is re-raised."""
+        n = len(self.shards)
+        if n == 1:
+            return [fn(0)]
+        results: list = [None] * n
         errors: List[BaseException] = []
 
         def work(i: int):
             try:
-                results[i] = pipelines[i].search_hmm(query, self.shards[i])
+                results[i] = fn(i)
             except BaseException as e:      # forwarded to the caller like _base.py:305-318
                 errors.append(e)
 
-        if len(self.shards) == 1:
-            work(0)
-        else:
-            threads = [threading.Thread(target=work, args=(i,)) for i in range(len(self.shards))]
-            for t in threads:
-                t.start()
-            for t in threads:
-                t.join()
+        threads = [threading.Thread(target=work, args=(i,)) for i in range(n)]
+        for t in threads:
+            t.start()
+        for t in threads:
+            t.join()
         if errors:
             raise errors[0]
+        return results
+
+    def begin(self, pipelines: Sequence[Pipeline], query) -> list:
+        """Stage 1 (device filters + parsers) of ``query`` on every shard."""
+        return self._on_shards(lambda i: pipelines[i]._search_begin(query, self.shards[i]))
+
+    def finish(self, pendings: list) -> TopHits:
+        """Stage 2 (domain definition, hit lists) on every shard, then the merge."""
+        results = self._on_shards(lambda i: Pipeline._search_finish(pendings[i]))
         hits = results[0]
         return hits if len(results) == 1 else hits.merge(*results[1:])
+
+    def search(self, pipelines: Sequence[Pipeline], query) -> TopHits:
+        return self.finish(self.begin(pipelines, query))
 
 
 def hmmsearch(queries: Union[HMM, Profile, OptimizedProfile, Iterable], sequences, *, cpus: int = 0,
               callback: Optional[Callable] = None, devices: Optional[Sequence[int]] = None,
-              **options) -> Iterator[TopHits]:
+              pipeline_depth: int = 2, **options) -> Iterator[TopHits]:
     """Search HMMs against a sequence database; yields one ``TopHits`` per query, in query order.
 
     ``devices`` lists the HIP devices to shard the targets over (default: device 0).  ``cpus`` is accepted for
     signature compatibility and sets the number of host threads used for domain definition.  All other keyword
     arguments are forwarded to :class:`~pyhmmer_amd.plan7.Pipeline` (reference ``_hmmsearch.py:294-436``).
+
+    Consecutive queries are overlapped the way the reference overlaps them on worker threads
+    (``hmmer/_base.py:416-489``): a feeder thread runs the device stage (filters and parsers) of up to
+    ``pipeline_depth`` queries ahead while the host stage (domain definition) of the current query runs in the
+    caller's thread.  ``pipeline_depth=0`` runs the two stages of every query back to back.
+    ``sequences`` may also be a :class:`~pyhmmer_amd.plan7.SequenceDatabase` already resident on one device.
     """
     if isinstance(queries, (HMM, Profile, OptimizedProfile)):
         queries = (queries,)
@@ -90,23 +120,81 @@ def hmmsearch(queries: Union[HMM, Profile, OptimizedProfile, Iterable], sequence
         if not sequences.digital:
             raise ValueError("target sequences file is not in digital mode")
         sequences = sequences.read_block()
-    if not isinstance(sequences, DigitalSequenceBlock):
+    if not isinstance(sequences, (DigitalSequenceBlock, SequenceDatabase)):
         raise TypeError(f"Expected DigitalSequenceBlock or SequenceFile, found {type(sequences).__name__}")
     alphabet: Alphabet = sequences.alphabet
-    devs = list(devices) if devices else [0]
     ndev = _lib.lib().p7x_device_count()
     if ndev < 1:
         from .errors import DeviceUnavailable
         raise DeviceUnavailable("hmmsearch: no HIP device is usable and there is no CPU fallback")
-    db = ShardedDatabase(sequences, devs)
+    if isinstance(sequences, SequenceDatabase):
+        db = ShardedDatabase.from_database(sequences)
+        devs = db.devices
+    else:
+        devs = list(devices) if devices else [0]
+        db = ShardedDatabase(sequences, devs)
     pipelines = [Pipeline(alphabet, device=d, host_threads=cpus, **options) for d in devs]
     total = None
     try:
         total = len(queries)          # type: ignore[arg-type]
     except TypeError:
         pass
-    for q in queries:
-        hits = db.search(pipelines, q)
-        if callback is not None:
-            callback(q, total)
-        yield hits
+
+    if pipeline_depth <= 0:
+        for q in queries:
+            hits = db.search(pipelines, q)
+            if callback is not None:
+                callback(q, total)
+            yield hits
+        return
+
+    # two-stage software pipeline over the queries
+    staged: "queue.Queue" = queue.Queue(maxsize=pipeline_depth)
+    stop = threading.Event()
+    _END = object()
+
+    def feeder():
+        try:
+            for q in queries:
+                if stop.is_set():
+                    break
+                item = (q, db.begin(pipelines, q), None)
+                while not stop.is_set():
+                    try:
+                        staged.put(item, timeout=0.1)
+                        item = None
+                        break
+                    except queue.Full:
+                        continue
+                if item is not None:            # interrupted: release the device-side results
+                    for pend in item[1]:
+                        _lib.lib().p7x_pending_destroy(pend[0])
+        except BaseException as e:              # forwarded to the caller like _base.py:305-318
+            staged.put((None, None, e))
+        finally:
+            staged.put((None, None, _END))
+
+    thread = threading.Thread(target=feeder, name="p7x-hmmsearch-feeder", daemon=True)
+    thread.start()
+    try:
+        while True:
+            q, pendings, err = staged.get()
+            if err is _END:
+                break
+            if err is not None:
+                raise err
+            hits = db.finish(pendings)
+            if callback is not None:
+                callback(q, total)
+            yield hits
+    finally:
+        stop.set()
+        while thread.is_alive():                # drain so that the feeder can leave, releasing what it staged
+            try:
+                q, pendings, err = staged.get(timeout=0.1)
+                if pendings:
+                    for pend in pendings:
+                        _lib.lib().p7x_pending_destroy(pend[0])
+            except queue.Empty:
+                pass
+        thread.join()

@@ -1016,6 +1016,33 @@ class Pipeline:
             database = self._db_cache[1]
         return self._search_database(om, database, query)
 
+    # -- the two stages of a search (``p7x_search_block_begin`` / ``_finish``).  ``hmmer.hmmsearch`` runs stage 1
+    #    of the next query while stage 2 of the previous one is still busy on the host.
+    def _search_begin(self, query, database: "SequenceDatabase", label=None):
+        if query.alphabet != self.alphabet:
+            raise AlphabetMismatch(self.alphabet, query.alphabet)
+        om = self._get_om_from_query(query, self.L_HINT)
+        cfg = self._cfg()
+        pend = C.c_void_p()
+        bgf = np.ascontiguousarray(self.background.residue_frequencies, dtype=np.float32)
+        st = _lib.lib().p7x_search_block_begin(C.byref(cfg), om._handle, bgf.ctypes.data, database._handle, C.byref(pend))
+        if st == 11 and self.bit_cutoffs is not None:
+            raise MissingCutoffs(om.name, self.bit_cutoffs)       # plan7.pyx:6424-6425
+        if st != 0:
+            raise status_to_exception(st, "p7x_search_block_begin", _lib.last_error())
+        return (pend, om, database, label if label is not None else query)
+
+    @staticmethod
+    def _search_finish(pending) -> TopHits:
+        pend, om, database, label = pending
+        out = C.c_void_p()
+        st = _lib.lib().p7x_search_block_finish(pend, database._names, database._accs, database._descs, C.byref(out))
+        if st != 0:
+            raise status_to_exception(st, "p7x_search_block_finish", _lib.last_error())
+        hits = TopHits(label, out)
+        hits._om = om                   # the alignments refer to the profile: keep it alive with the hits
+        return hits
+
     def _search_database(self, query, database: "SequenceDatabase", label=None) -> TopHits:
         om = self._get_om_from_query(query, self.L_HINT)
         cfg = self._cfg()
@@ -1037,6 +1064,7 @@ class SequenceDatabase:
     def __init__(self, block: DigitalSequenceBlock, device: int = 0):
         self.block = block
         self.device = device
+        self.alphabet = block.alphabet
         limit = 100000                                            # plan7.pyx:5421, 6218-6219
         for s in block:
             if len(s) > limit:

@@ -117,3 +117,29 @@ def test_z_and_bit_cutoffs(models, proteome):
         plan7.Pipeline(thio.alphabet, bit_cutoffs="gathering").search_hmm(thio, proteome)
     with pytest.raises(errors.AlphabetMismatch):
         plan7.Pipeline(easel.Alphabet.dna()).search_hmm(hmm, proteome)
+
+
+def test_hmmsearch_query_pipeline_matches_back_to_back_searches(models, proteome):
+    """hmmsearch overlaps the device stage of the next query with the host stage of the current one; the hits must
+    be those of plain sequential searches, in query order, also across a resident SequenceDatabase."""
+    queries = models["RREFam"] + models["PF02826"] + models["KR"] + models["RREFam"][:3]
+    seq = [h for h in hmmer.hmmsearch(queries, proteome, pipeline_depth=0)]
+    for depth, target in ((2, proteome), (4, plan7.SequenceDatabase(proteome))):
+        got = [h for h in hmmer.hmmsearch(iter(queries), target, pipeline_depth=depth)]
+        assert len(got) == len(seq) == len(queries)
+        for q, a, b in zip(queries, got, seq):
+            assert a.query.name == q.name
+            assert a.to_bytes()[:0] == b""                  # serialisable
+            assert [(h.name, h.score, h.evalue, len(h.domains)) for h in a] == [(h.name, h.score, h.evalue, len(h.domains)) for h in b]
+            assert a.stage_counts == b.stage_counts
+
+
+def test_hmmsearch_pipeline_forwards_errors_and_can_be_abandoned(models, proteome):
+    queries = [models["PF02826"][0], models["KR"][0], models["PF02826"][0]]     # KR.hmm has no GA cutoffs
+    it = hmmer.hmmsearch(queries, proteome, bit_cutoffs="gathering")
+    assert len(next(it)) > 0
+    with pytest.raises(errors.MissingCutoffs):
+        next(it)
+    it = hmmer.hmmsearch(models["RREFam"], proteome)       # closing the generator early must not leak or hang
+    next(it)
+    it.close()
