@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define P7X_ABI_VERSION 2
+#define P7X_ABI_VERSION 3
 
 enum {
   P7X_OK = 0, P7X_EMEM = 5, P7X_EINVAL = 11, P7X_ERANGE = 16, P7X_ENORESULT = 19,
@@ -141,6 +141,7 @@ typedef struct p7x_pipeline_cfg {
   int32_t mode;              /* P7X_SEARCH_SEQS | P7X_SCAN_MODELS */
   int32_t host_threads;      /* workers for host-side domain definition; 0 = hardware_concurrency */
   int32_t host_envelopes;    /* 0 (default): single-domain envelopes are rescored by the device kernel; 1: on the host */
+  int32_t host_regions;      /* 0 (default): posterior decoding of the specials + region scan on the device; 1: on the host */
 } p7x_pipeline_cfg;
 void p7x_pipeline_cfg_default(p7x_pipeline_cfg *cfg);   /* p7_pipeline_Create(NULL,...) defaults, plan7.pyx:5413-5421 */
 
@@ -227,7 +228,8 @@ int      p7x_tophits_threshold(p7x_tophits *th);         /* p7_tophits_Threshold
 /* per-stage device timings of the search that produced th, milliseconds (HIP events):
  * [0] msv + P-value pass [1] bias filter [2] viterbi [3] forward [4] forward rows for survivors [5] backward, then
  * overwritten by host domain definition wall time (including [8]) [6] whole call wall time [7] the MSV kernel alone
- * [8] device rescoring of domain envelopes (wall, with transfers) [9] host: multi-domain regions (overlaps [8]).  n <= 10. */
+ * [8] device rescoring of domain envelopes (wall, with transfers) [9] host: multi-domain regions (overlaps [8])
+ * [10] wall time of stage 1 (p7x_search_block_begin) [11] of stage 2 (_finish); [6] = [10] + [11].  n <= 12. */
 int      p7x_tophits_get_timings(const p7x_tophits *th, double *ms, int n);
 
 const char *p7x_last_error(void);

@@ -103,7 +103,7 @@ class PipelineCfg(C.Structure):
         ("Z", C.c_double), ("domZ", C.c_double), ("Z_setby", C.c_int32), ("domZ_setby", C.c_int32),
         ("F1", C.c_double), ("F2", C.c_double), ("F3", C.c_double),
         ("do_max", C.c_int32), ("do_biasfilter", C.c_int32), ("do_null2", C.c_int32),
-        ("seed", C.c_uint32), ("mode", C.c_int32), ("host_threads", C.c_int32), ("host_envelopes", C.c_int32),
+        ("seed", C.c_uint32), ("mode", C.c_int32), ("host_threads", C.c_int32), ("host_envelopes", C.c_int32), ("host_regions", C.c_int32),
     ]
 
 
@@ -201,7 +201,7 @@ def lib() -> C.CDLL:
             fn = getattr(l, name)      # AttributeError if the ABI is incomplete
             fn.restype = res
             fn.argtypes = args
-        if l.p7x_abi_version() != 2:
+        if l.p7x_abi_version() != 3:
             raise ImportError("libp7x ABI version mismatch; rebuild")
         _lib = l
     return _lib

@@ -1033,6 +1033,9 @@ int domaindef_multi_region(const Profile &p, const uint8_t *dsq, int L, int i, i
   return P7X_OK;
 }
 
+static int dispatch_regions(const Profile &p, const uint8_t *dsq, int L, const Region *regs, int nregs, uint32_t seed,
+                            bool do_reseeding, DomainDefResult &dd, std::vector<EnvelopeRequest> *defer, int item);
+
 int domaindef_by_posterior_heuristics(const Profile &p, const uint8_t *dsq, int L, const float *fx, const float *bx,
                                       uint32_t seed, bool do_reseeding, DomainDefResult &dd,
                                       std::vector<EnvelopeRequest> *defer, int item)
@@ -1040,11 +1043,27 @@ int domaindef_by_posterior_heuristics(const Profile &p, const uint8_t *dsq, int 
   thread_local std::vector<Region> regs;
   const int st = domaindef_regions(p, L, fx, bx, dd, regs);
   if (st != P7X_OK) return st;
+  return dispatch_regions(p, dsq, L, regs.data(), (int) regs.size(), seed, do_reseeding, dd, defer, item);
+}
+
+int domaindef_from_regions(const Profile &p, const uint8_t *dsq, int L, float nexpected, const Region *regs, int nregs,
+                           uint32_t seed, bool do_reseeding, DomainDefResult &dd, std::vector<EnvelopeRequest> *defer, int item)
+{
+  dd.dcl.clear(); dd.n2sc.assign(L + 1, 0.0f); dd.multi.clear();
+  dd.nclustered = dd.noverlaps = dd.nenvelopes = 0;
+  dd.nregions = nregs; dd.nexpected = nexpected;
+  return dispatch_regions(p, dsq, L, regs, nregs, seed, do_reseeding, dd, defer, item);
+}
+
+static int dispatch_regions(const Profile &p, const uint8_t *dsq, int L, const Region *regs, int nregs, uint32_t seed,
+                            bool do_reseeding, DomainDefResult &dd, std::vector<EnvelopeRequest> *defer, int item)
+{
   Model om{ &p, p.M, {} };
   thread_local Workspace ws;
   bool prepared = false;
   MultiRegionState state;
-  for (const Region &r : regs) {
+  for (int ri = 0; ri < nregs; ++ri) {
+    const Region &r = regs[ri];
     if (r.multi) {
       if (defer) {                    // resolved later by domaindef_multi_region(): leave a marker in domain order
         Domain ph; ph.ienv = r.i; ph.jenv = r.j; ph.deferred = -2; ph.multi_slot = (int) dd.multi.size();

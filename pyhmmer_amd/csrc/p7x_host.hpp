@@ -51,6 +51,9 @@ struct EnvelopeScorer {
 // p7_domaindef_ByPosteriorHeuristics (p7_domaindef.pxd:69-72).  dsq is 1-indexed (dsq[1..L]);
 // fwd_xmx / bck_xmx are the parsers' special-state rows, (L+1) x [E,N,J,B,C,SCALE].
 struct Region { int i, j; bool multi; };
+// Region scan done on the device (p7x_pipeline.hip regions_kernel): per survivor n[i] regions (or -1: range error),
+// regs[(i*cap + r)*3 ..] = first residue, last residue, is_multidomain_region; nexpected[i] = expected number of domains.
+struct DeviceRegions { const int32_t *n = nullptr; const int32_t *regs = nullptr; const float *nexpected = nullptr; int cap = 0; };
 struct MultiRegionState { bool started = false; uint32_t rng_seed = 42, rng_x = 0; };   // RNG carried between the regions of one target
 int domaindef_regions(const Profile &p, int L, const float *fwd_xmx, const float *bck_xmx, DomainDefResult &dd, std::vector<Region> &regs);
 int domaindef_multi_region(const Profile &p, const uint8_t *dsq, int L, int i, int j, uint32_t seed, bool do_reseeding,
@@ -62,6 +65,9 @@ int domaindef_finish_multi(const Profile &p, const uint8_t *dsq, int L, uint32_t
 int domaindef_by_posterior_heuristics(const Profile &p, const uint8_t *dsq, int L, const float *fwd_xmx,
                                       const float *bck_xmx, uint32_t seed, bool do_reseeding, DomainDefResult &out,
                                       std::vector<EnvelopeRequest> *defer = nullptr, int item = 0);
+// The same from a region list that was found elsewhere (device scan); n2sc etc. are initialised here.
+int domaindef_from_regions(const Profile &p, const uint8_t *dsq, int L, float nexpected, const Region *regs, int nregs,
+                           uint32_t seed, bool do_reseeding, DomainDefResult &out, std::vector<EnvelopeRequest> *defer, int item);
 int domaindef_finish_deferred(const Profile &p, const uint8_t *dsq, int L, const std::vector<EnvelopeResult> &res,
                               const std::vector<int> &req_index, DomainDefResult &dd);
 
@@ -87,8 +93,9 @@ int host_finish_search(const p7x_pipeline_cfg &cfg, const p7x_oprofile *om, cons
                        const char *const *names, const char *const *accs, const char *const *descs,
                        const std::vector<int32_t> &targets, const float *fwdsc,
                        const float *fwd_xmx, const float *bck_xmx, const int64_t *xmx_off,
-                       const uint64_t *counts, const double *ms, p7x_tophits **out, EnvelopeScorer *scorer = nullptr);
-void tophits_set_total_ms(p7x_tophits *th, double ms);
+                       const uint64_t *counts, const double *ms, p7x_tophits **out, EnvelopeScorer *scorer = nullptr,
+                       const DeviceRegions *regions = nullptr);
+void tophits_set_total_ms(p7x_tophits *th, double stage1_ms, double stage2_ms);
 float kahan_fsum(const float *v, int n);
 void host_prof_dump();
 
@@ -102,7 +109,7 @@ struct p7x_tophits {
   std::string qname, qacc, qdesc;     // the query (model) the alignment displays refer to
   bool q_has_acc = false, q_has_desc = false;
   int M = 0;
-  double ms[10]{};
+  double ms[12]{};
   bool sorted_by_key = false;
   int64_t nreported = 0, nincluded = 0;
 };

@@ -6,8 +6,7 @@
 //   -> Backward -> (host) domain definition -> hit.
 // Every stage is a kernel over a device-resident work list; the lists are built with atomics and their
 // lengths are read by the next stage from device memory, so the cascade runs without host round trips.
-#include "p7x_device.hpp"
-#include "p7x_kernels.hpp"
+#include "p7x_wave.hpp"
 #include "p7x_host.hpp"
 #include <chrono>
 #include <cmath>
@@ -235,11 +234,99 @@ __global__ void decide_fwd_kernel(StageBufs b, StageParams p)
   }
 }
 
+// ---------------------------------------------------------------------------- regions (p7_DomainDecoding + region scan)
+// One wavefront per Forward survivor.  The parsers' special-state rows stay on the device: the posterior
+// begin/end/occupancy terms are formed lane-parallel, their running sums and the trigger scan run in upstream's
+// sequential order (every lane follows the same scalar recurrence; only the prefix arrays needed by the
+// multi-domain test are written out), and is_multidomain_region() is a wave-parallel max.  Same arithmetic as
+// domaindef_regions() in p7x_domaindef.cpp, which remains the reference for it (tests/test_gpu_envelopes.py).
+constexpr int kRegionCap = 128;     // regions kept per target; more than that falls back to the host scan
+
+struct RegionArgs {
+  int nitems;
+  const int32_t *list;        // slot of item
+  const int32_t *slot_len;
+  const float *fx, *bx;       // parser rows, (L+1) x [E,N,J,B,C,SCALE]
+  const int64_t *xmx_off;     // per item
+  float *scratch;             // per item at xmx_off: terms [3][L+1] then prefix sums [2][L+1]  (5 of the 6 row floats)
+  int32_t *out_regs;          // [nitems][kRegionCap][3] = i, j, multi
+  int32_t *out_n;             // [nitems] number of regions, or -1 (range error), or -2 (more than kRegionCap)
+  float *out_nexpected;       // [nitems]
+};
+
+__global__ void __launch_bounds__(256) regions_kernel(const RegionArgs a)
+{
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane((int) (blockIdx.x * 4 + (threadIdx.x >> 6)));
+  const int nwaves = (int) gridDim.x * 4;
+  const float rt1 = 0.25f, rt2 = 0.10f, rt3 = 0.20f;                         // p7_domaindef.pxd:39-41
+  for (int it = wave; it < a.nitems; it += nwaves) {
+    const int L = __builtin_amdgcn_readfirstlane(a.slot_len[a.list[it]]);
+    const long long off = a.xmx_off[it];
+    const float *fx = a.fx + off, *bx = a.bx + off;
+    float *tb = a.scratch + off, *te = tb + (L + 1), *tm = te + (L + 1), *pb = tm + (L + 1), *pe = pb + (L + 1);
+    const float pmove = (2.0f + 1.0f) / ((float) L + 2.0f + 1.0f), ploop = 1.0f - pmove;      // multihit, full length
+    const float scaleproduct = (float) (1.0 / (double) bx[1]);
+    for (int i = 1 + lane; i <= L; i += 64) {
+      const float *f0 = fx + (size_t) (i - 1) * 6, *f1 = fx + (size_t) i * 6, *b0 = bx + (size_t) (i - 1) * 6, *b1 = bx + (size_t) i * 6;
+      tb[i] = (f0[3] * b0[3]) * f0[5] * scaleproduct;
+      te[i] = (f1[0] * b1[0]) * f1[5] * scaleproduct;
+      float njcp = f0[1] * b1[1] * ploop * scaleproduct;
+      njcp += f0[2] * b1[2] * ploop * scaleproduct;
+      njcp += f0[4] * b1[4] * ploop * scaleproduct;
+      tm[i] = (float) (1. - (double) njcp);
+    }
+    if (lane == 0) { pb[0] = 0.0f; pe[0] = 0.0f; }
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "agent");
+    int nreg = 0;
+    int32_t *regs = a.out_regs + (size_t) it * kRegionCap * 3;
+    float b = 0.0f, e = 0.0f;
+    int i = -1; bool triggered = false;
+    for (int j0 = 1; j0 <= L; j0 += 64) {
+      const int nj = min(64, L - j0 + 1);
+      // this block's terms, one per lane; broadcast in order below
+      const float vb = (lane < nj) ? tb[j0 + lane] : 0.0f, ve = (lane < nj) ? te[j0 + lane] : 0.0f, vm = (lane < nj) ? tm[j0 + lane] : 0.0f;
+      float keepb = 0.0f, keepe = 0.0f;
+      for (int r = 0; r < nj; ++r) {
+        const int j = j0 + r;
+        const float dbt = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, vb), r));
+        const float det = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, ve), r));
+        const float mo = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, vm), r));
+        const float bprev = b, eprev = e;
+        b = bprev + dbt; e = eprev + det;
+        if (lane == r) { keepb = b; keepe = e; }
+        if (!triggered) {
+          if (mo - (b - bprev) < rt2) i = j;
+          else if (i == -1) i = j;
+          if (mo >= rt1) triggered = true;
+        } else if (mo - (e - eprev) < rt2) {
+          // region i..j closes here: flush this block's prefix sums, then is_multidomain_region()
+          if (lane <= r) { pb[j0 + lane] = keepb; pe[j0 + lane] = keepe; }
+          __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "agent");
+          const float e0 = pe[i - 1], bj = b;
+          float mx = -1.0f;
+          for (int z = i + lane; z <= j; z += 64) mx = fmaxf(mx, fminf(pe[z] - e0, bj - pb[z - 1]));
+          mx = wave_max_f32(mx);
+          if (nreg < kRegionCap && lane == 0) { regs[nreg * 3 + 0] = i; regs[nreg * 3 + 1] = j; regs[nreg * 3 + 2] = (mx >= rt3) ? 1 : 0; }
+          ++nreg;
+          i = -1; triggered = false;
+        }
+      }
+      if (lane < nj) { pb[j0 + lane] = keepb; pe[j0 + lane] = keepe; }
+    }
+    if (lane == 0) {
+      a.out_nexpected[it] = b;
+      a.out_n[it] = __builtin_isinf(scaleproduct) ? -1 : (nreg > kRegionCap ? -2 : nreg);
+    }
+  }
+}
+
 // ---------------------------------------------------------------------------- workspace
 struct Workspace {
   int device = -1; int64_t cap_slots = 0;
   StageBufs b{};
-  float *xmx_f = nullptr, *xmx_b = nullptr; int64_t xmx_cap = 0; int64_t *xmx_off = nullptr; int64_t xmx_off_cap = 0;
+  float *xmx_f = nullptr, *xmx_b = nullptr, *xmx_s = nullptr; int64_t xmx_cap = 0; int64_t *xmx_off = nullptr; int64_t xmx_off_cap = 0;
+  int32_t *reg_out = nullptr;      // [cap][kRegionCap*3 + 2]: regions | count | nexpected bits, per survivor
   hipEvent_t ev[8]{};
   ~Workspace() {
     if (device < 0) return;
@@ -247,7 +334,7 @@ struct Workspace {
     (void) hipFree(b.xJ); (void) hipFree(b.usc); (void) hipFree(b.filtersc); (void) hipFree(b.vfsc); (void) hipFree(b.fwdsc);
     (void) hipFree(b.xC); (void) hipFree(b.fwd_by_item); (void) hipFree(b.list_bias); (void) hipFree(b.list_vit);
     (void) hipFree(b.list_fwd); (void) hipFree(b.list_fin); (void) hipFree(b.counters);
-    (void) hipFree(xmx_f); (void) hipFree(xmx_b); (void) hipFree(xmx_off);
+    (void) hipFree(xmx_f); (void) hipFree(xmx_b); (void) hipFree(xmx_s); (void) hipFree(xmx_off); (void) hipFree(reg_out);
     for (auto &e : ev) if (e) (void) hipEventDestroy(e);
   }
 };
@@ -297,6 +384,7 @@ static WaveSeqArgs ws_args(const Profile &p, const DevProfile *dp, const p7x_seq
 
 static const bool g_msv_exact_only = std::getenv("P7X_MSV_EXACT") != nullptr;   // A/B switch for profiling
 static const bool g_host_envelopes = std::getenv("P7X_HOST_ENVELOPES") != nullptr;   // A/B: rescore envelopes on the host
+static const bool g_host_regions = std::getenv("P7X_HOST_REGIONS") != nullptr;       // A/B: region scan on the host
 
 // Run MSV over the whole database; leaves xJ (slot order) in ws->b.xJ.
 static int run_msv(const Profile &p, const DevProfile *dp, const p7x_seqdb *db, DeviceCtx *ctx, Workspace *ws)
@@ -315,8 +403,11 @@ static int run_msv(const Profile &p, const DevProfile *dp, const p7x_seqdb *db, 
 struct CascadeOut {
   std::vector<int32_t> fin_slots;         // survivors of the Forward filter (slot ids)
   std::vector<float> usc, filtersc, vfsc, fwdsc;   // per survivor
-  std::vector<float> fwd_xmx, bck_xmx;    // concatenated (L+1)*6 blocks
+  std::vector<float> fwd_xmx, bck_xmx;    // concatenated (L+1)*6 blocks; only fetched when the device region scan overflowed
   std::vector<int64_t> xmx_off;
+  std::vector<int32_t> reg_n, regs;       // device region scan: count per survivor (-1 range error), kRegionCap x (i, j, multi)
+  std::vector<float> nexpected;
+  bool have_xmx = false;
   int counts[16]{};
   double ms[8]{};
 };
@@ -379,13 +470,15 @@ static int run_cascade(const p7x_pipeline_cfg &cfg, const p7x_oprofile *om, cons
       tot += (int64_t) (db->h_len[db->h_order[out.fin_slots[i]]] + 1) * 6;
     }
     if (tot > ws->xmx_cap) {
-      (void) hipFree(ws->xmx_f); (void) hipFree(ws->xmx_b); ws->xmx_f = ws->xmx_b = nullptr;
+      (void) hipFree(ws->xmx_f); (void) hipFree(ws->xmx_b); (void) hipFree(ws->xmx_s); ws->xmx_f = ws->xmx_b = ws->xmx_s = nullptr;
       P7X_HIP(hipMalloc(&ws->xmx_f, (size_t) tot * 4)); P7X_HIP(hipMalloc(&ws->xmx_b, (size_t) tot * 4));
+      P7X_HIP(hipMalloc(&ws->xmx_s, (size_t) tot * 4));
       ws->xmx_cap = tot;
     }
     if (nfin > ws->xmx_off_cap) {
-      (void) hipFree(ws->xmx_off); ws->xmx_off = nullptr;
+      (void) hipFree(ws->xmx_off); (void) hipFree(ws->reg_out); ws->xmx_off = nullptr; ws->reg_out = nullptr;
       P7X_HIP(hipMalloc(&ws->xmx_off, (size_t) nfin * 8)); ws->xmx_off_cap = nfin;
+      P7X_HIP(hipMalloc(&ws->reg_out, (size_t) nfin * (kRegionCap * 3 + 2) * 4));
     }
     P7X_HIP(hipMemcpyAsync(ws->xmx_off, out.xmx_off.data(), (size_t) nfin * 8, hipMemcpyHostToDevice, s));
     P7X_HIP(hipMemsetAsync(&ws->b.counters[5], 0, 3 * 4, s));
@@ -398,13 +491,34 @@ static int run_cascade(const p7x_pipeline_cfg &cfg, const p7x_oprofile *om, cons
     a.out_sc = ws->b.fwd_by_item + nfin; a.xmx = ws->xmx_b; a.fwd_xmx = ws->xmx_f;
     if (2 * (int64_t) nfin <= ws->cap_slots) { if ((st = bck_launch(a, ctx->num_cu, s)) != P7X_OK) return st; }
     else { set_error("workspace too small for Backward scores"); return P7X_EINVAL; }
+    {   // posterior decoding of the special states and the region scan, on the rows where they are
+      RegionArgs ra{};
+      ra.nitems = nfin; ra.list = ws->b.list_fin; ra.slot_len = db->d_slot_len; ra.fx = ws->xmx_f; ra.bx = ws->xmx_b;
+      ra.xmx_off = ws->xmx_off; ra.scratch = ws->xmx_s;
+      ra.out_regs = ws->reg_out; ra.out_n = ws->reg_out + (size_t) nfin * kRegionCap * 3;
+      ra.out_nexpected = reinterpret_cast<float *>(ra.out_n + nfin);
+      const int grid = std::min(ctx->num_cu * 4, (nfin + 3) / 4);
+      hipLaunchKernelGGL(regions_kernel, dim3((unsigned) grid), dim3(256), 0, s, ra);
+      P7X_HIP(hipGetLastError());
+    }
     P7X_HIP(hipEventRecord(ws->ev[6], s));
-    out.fwd_xmx.resize(tot); out.bck_xmx.resize(tot);
-    P7X_HIP(hipMemcpyAsync(out.fwd_xmx.data(), ws->xmx_f, (size_t) tot * 4, hipMemcpyDeviceToHost, s));
-    P7X_HIP(hipMemcpyAsync(out.bck_xmx.data(), ws->xmx_b, (size_t) tot * 4, hipMemcpyDeviceToHost, s));
+    std::vector<int32_t> regbuf((size_t) nfin * (kRegionCap * 3 + 2));
+    P7X_HIP(hipMemcpyAsync(regbuf.data(), ws->reg_out, regbuf.size() * 4, hipMemcpyDeviceToHost, s));
     // the rows pass recomputed each survivor's Forward score in list order: one contiguous copy
     P7X_HIP(hipMemcpyAsync(out.fwdsc.data(), ws->b.fwd_by_item, (size_t) nfin * 4, hipMemcpyDeviceToHost, s));
     P7X_HIP(hipStreamSynchronize(s));
+    out.regs.assign(regbuf.begin(), regbuf.begin() + (size_t) nfin * kRegionCap * 3);
+    out.reg_n.assign(regbuf.begin() + (size_t) nfin * kRegionCap * 3, regbuf.begin() + (size_t) nfin * (kRegionCap * 3 + 1));
+    out.nexpected.resize(nfin);
+    std::memcpy(out.nexpected.data(), regbuf.data() + (size_t) nfin * (kRegionCap * 3 + 1), (size_t) nfin * 4);
+    bool overflow = g_host_regions || cfg.host_regions != 0;
+    for (int i = 0; i < nfin; ++i) if (out.reg_n[i] == -2) overflow = true;
+    if (overflow) {        // a target with more regions than the device keeps (or the A/B switch): the host scans the rows
+      out.fwd_xmx.resize(tot); out.bck_xmx.resize(tot);
+      P7X_HIP(hipMemcpy(out.fwd_xmx.data(), ws->xmx_f, (size_t) tot * 4, hipMemcpyDeviceToHost));
+      P7X_HIP(hipMemcpy(out.bck_xmx.data(), ws->xmx_b, (size_t) tot * 4, hipMemcpyDeviceToHost));
+      out.have_xmx = true;
+    }
   } else {
     P7X_HIP(hipEventRecord(ws->ev[5], s)); P7X_HIP(hipEventRecord(ws->ev[6], s));
     P7X_HIP(hipStreamSynchronize(s));
@@ -694,6 +808,7 @@ static int one_seq(const p7x_oprofile *om, int device, const uint8_t *dsq, int32
     // Backward: run Forward with rows, then Backward
     p7x_pipeline_cfg cfg; p7x_pipeline_cfg_default(&cfg);
     cfg.do_max = 1;
+    cfg.host_regions = 1;                 // fetch the parsers' rows
     CascadeOut out;
     st = run_cascade(cfg, om, db, out);
     if (st == P7X_OK) {
@@ -768,12 +883,14 @@ int p7x_search_block_finish(p7x_pending *pd, const char *const *names, const cha
     scorer = std::make_unique<DeviceEnvelopeScorer>(ctx, dp, db, om->p);
   }
   const double stage1 = co.ms[6];
+  DeviceRegions dr;
+  if (!co.have_xmx && !targets.empty()) { dr.n = co.reg_n.data(); dr.regs = co.regs.data(); dr.nexpected = co.nexpected.data(); dr.cap = kRegionCap; }
   st = host_finish_search(pd->cfg, om, tg, names, accs, descs, targets, co.fwdsc.data(), co.fwd_xmx.data(), co.bck_xmx.data(),
-                          co.xmx_off.data(), counts, co.ms, out, scorer.get());
+                          co.xmx_off.data(), counts, co.ms, out, scorer.get(), dr.n ? &dr : nullptr);
   if (st == P7X_OK) {
     // work time of this search (stage 1 + stage 2), not the time it spent queued between the stages
     const double stage2 = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t1).count();
-    tophits_set_total_ms(*out, stage1 + stage2);
+    tophits_set_total_ms(*out, stage1, stage2);
   }
   return st;
 }

@@ -268,7 +268,8 @@ int host_finish_search(const p7x_pipeline_cfg &cfg_in, const p7x_oprofile *om, c
                        const char *const *names, const char *const *accs, const char *const *descs,
                        const std::vector<int32_t> &tgt, const float *fwdsc,
                        const float *fwd_xmx, const float *bck_xmx, const int64_t *xmx_off,
-                       const uint64_t *counts, const double *ms, p7x_tophits **out, EnvelopeScorer *scorer)
+                       const uint64_t *counts, const double *ms, p7x_tophits **out, EnvelopeScorer *scorer,
+                       const DeviceRegions *dregs)
 {
   const Profile &p = om->p;
   auto th = std::make_unique<p7x_tophits>();
@@ -299,13 +300,24 @@ int host_finish_search(const p7x_pipeline_cfg &cfg_in, const p7x_oprofile *om, c
     if (pend[i].have) pend[i].hit.seqidx = t;
   };
   const bool reseed = cfg.seed != 0;
+  // regions come from the device scan when there is one, else from the parsers' rows
+  auto define = [&](int i, DomainDefResult &dd, std::vector<EnvelopeRequest> *defer) -> int {
+    const int t = tgt[i];
+    const uint8_t *dsq = tg.dsq + tg.off[t] - 1;
+    if (!dregs)
+      return domaindef_by_posterior_heuristics(p, dsq, tg.len[t], fwd_xmx + xmx_off[i], bck_xmx + xmx_off[i], cfg.seed, reseed, dd, defer, i);
+    const int nr = dregs->n[i];
+    if (nr < 0) return P7X_ERANGE;
+    Region regs[256];
+    const int32_t *src = dregs->regs + (size_t) i * dregs->cap * 3;
+    for (int r = 0; r < nr && r < 256; ++r) regs[r] = Region{ src[r * 3], src[r * 3 + 1], src[r * 3 + 2] != 0 };
+    return domaindef_from_regions(p, dsq, tg.len[t], dregs->nexpected[i], regs, nr, cfg.seed, reseed, dd, defer, i);
+  };
   if (!scorer) {
     // everything on the host (CPU test seam, and the fallback for models the envelope kernel does not cover)
     run_pool(n, [&](int i) {
-      const int t = tgt[i];
       DomainDefResult dd;
-      const int st = domaindef_by_posterior_heuristics(p, tg.dsq + tg.off[t] - 1, tg.len[t], fwd_xmx + xmx_off[i], bck_xmx + xmx_off[i],
-                                                       cfg.seed, reseed, dd);
+      const int st = define(i, dd, nullptr);
       if (st != P7X_OK) { failed.store(st); return; }
       finish(i, dd);
     });
@@ -314,9 +326,7 @@ int host_finish_search(const p7x_pipeline_cfg &cfg_in, const p7x_oprofile *om, c
     std::vector<DomainDefResult> dds((size_t) n);
     std::vector<std::vector<EnvelopeRequest>> local((size_t) n);
     run_pool(n, [&](int i) {
-      const int t = tgt[i];
-      const int st = domaindef_by_posterior_heuristics(p, tg.dsq + tg.off[t] - 1, tg.len[t], fwd_xmx + xmx_off[i], bck_xmx + xmx_off[i],
-                                                       cfg.seed, reseed, dds[i], &local[i], i);
+      const int st = define(i, dds[i], &local[i]);
       if (st != P7X_OK) failed.store(st);
     });
     if (failed.load() == 0) {
@@ -373,7 +383,7 @@ int host_finish_search(const p7x_pipeline_cfg &cfg_in, const p7x_oprofile *om, c
   return P7X_OK;
 }
 
-void tophits_set_total_ms(p7x_tophits *th, double ms) { th->ms[6] = ms; }
+void tophits_set_total_ms(p7x_tophits *th, double stage1, double stage2) { th->ms[6] = stage1 + stage2; th->ms[10] = stage1; th->ms[11] = stage2; }
 
 } // namespace p7x
 
@@ -479,7 +489,7 @@ int p7x_tophits_merge(p7x_tophits *dst, const p7x_tophits *src)
   dst->ctr.n_past_msv += src->ctr.n_past_msv; dst->ctr.n_past_bias += src->ctr.n_past_bias;
   dst->ctr.n_past_vit += src->ctr.n_past_vit; dst->ctr.n_past_fwd += src->ctr.n_past_fwd;
   if (dst->cfg.Z_setby == P7X_ZSETBY_NTARGETS) dst->cfg.Z += src->cfg.Z;
-  for (int i = 0; i < 10; ++i) dst->ms[i] += src->ms[i];
+  for (int i = 0; i < 12; ++i) dst->ms[i] += src->ms[i];
   if (!dst->cfg.use_bit_cutoffs)
     for (Hit &h : dst->hits) {
       h.flags &= ~(uint32_t) (P7X_IS_REPORTED | P7X_IS_INCLUDED);
@@ -505,7 +515,7 @@ struct Reader {
   template <class T> void pod(T &v) { if (p + sizeof(T) > e) { ok = false; return; } std::memcpy(&v, p, sizeof(T)); p += sizeof(T); }
   void str(std::string &s) { uint32_t n = 0; pod(n); if (!ok || p + n > e) { ok = false; return; } s.assign((const char *) p, n); p += n; }
 };
-constexpr uint32_t kMagic = 0x70377875u;   // "p7xu" (format 2: ten timing slots)
+constexpr uint32_t kMagic = 0x70377876u;   // "p7xv" (format 3: twelve timing slots)
 
 template <class IO> void io_domain(IO &io, Domain &d)
 {
@@ -532,7 +542,7 @@ int64_t p7x_tophits_serialize(const p7x_tophits *th, void *buf, size_t cap)
   uint32_t magic = kMagic; w.pod(magic);
   w.pod(th->cfg); w.pod(th->ctr);
   w.str(th->qname); w.str(th->qacc); w.str(th->qdesc); w.pod(th->q_has_acc); w.pod(th->q_has_desc); w.pod(th->M);
-  for (int i = 0; i < 10; ++i) w.pod(th->ms[i]);
+  for (int i = 0; i < 12; ++i) w.pod(th->ms[i]);
   const uint64_t n = th->hits.size(); w.pod(n);
   for (const Hit &hc : th->hits) {
     Hit &h = const_cast<Hit &>(hc);
@@ -552,7 +562,7 @@ p7x_tophits *p7x_tophits_deserialize(const void *buf, size_t n)
   auto th = std::make_unique<p7x_tophits>();
   r.pod(th->cfg); r.pod(th->ctr);
   r.str(th->qname); r.str(th->qacc); r.str(th->qdesc); r.pod(th->q_has_acc); r.pod(th->q_has_desc); r.pod(th->M);
-  for (int i = 0; i < 10; ++i) r.pod(th->ms[i]);
+  for (int i = 0; i < 12; ++i) r.pod(th->ms[i]);
   uint64_t nh = 0; r.pod(nh);
   if (!r.ok) return nullptr;
   th->hits.resize(nh);
@@ -571,7 +581,7 @@ p7x_tophits *p7x_tophits_deserialize(const void *buf, size_t n)
 int p7x_tophits_get_timings(const p7x_tophits *th, double *ms, int n)
 {
   if (!th || !ms) return P7X_EINVAL;
-  for (int i = 0; i < n && i < 10; ++i) ms[i] = th->ms[i];
+  for (int i = 0; i < n && i < 12; ++i) ms[i] = th->ms[i];
   return P7X_OK;
 }
 

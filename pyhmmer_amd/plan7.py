@@ -853,10 +853,10 @@ class TopHits:
 
     @property
     def timings_ms(self) -> dict:
-        buf = (C.c_double * 10)()
-        _lib.lib().p7x_tophits_get_timings(self._handle, buf, 10)
+        buf = (C.c_double * 12)()
+        _lib.lib().p7x_tophits_get_timings(self._handle, buf, 12)
         return dict(zip(("msv", "bias", "viterbi", "forward", "fwd_rows", "host_domaindef", "total", "msv_kernel",
-                         "envelopes", "host_multi"), buf))
+                         "envelopes", "host_multi", "stage1", "stage2"), buf))
 
     @property
     def reported(self):
@@ -925,7 +925,7 @@ class Pipeline:
                  null2: bool = True, seed: int = 42, Z=None, domZ=None, F1: float = 0.02, F2: float = 1e-3,
                  F3: float = 1e-5, E: float = 10.0, T=None, domE: float = 10.0, domT=None, incE: float = 0.01,
                  incT=None, incdomE: float = 0.01, incdomT=None, bit_cutoffs: Optional[str] = None,
-                 device: int = 0, host_threads: int = 0, host_envelopes: bool = False):
+                 device: int = 0, host_threads: int = 0, host_envelopes: bool = False, host_regions: bool = False):
         self.alphabet = alphabet
         if background is None:
             self.background = Background(alphabet)
@@ -950,6 +950,7 @@ class Pipeline:
         self.device = device
         self.host_threads = host_threads
         self.host_envelopes = bool(host_envelopes)
+        self.host_regions = bool(host_regions)
         self._db_cache = None           # (id(block), packed n, device) -> SequenceDatabase
 
     def clear(self) -> None:
@@ -976,6 +977,7 @@ class Pipeline:
         c.use_bit_cutoffs = 0 if self.bit_cutoffs is None else self._BIT_CUTOFFS[self.bit_cutoffs]
         c.host_threads = int(self.host_threads)
         c.host_envelopes = int(self.host_envelopes)
+        c.host_regions = int(self.host_regions)
         return c
 
     def _get_om_from_query(self, query, L: int = L_HINT) -> OptimizedProfile:

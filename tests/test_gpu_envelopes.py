@@ -32,7 +32,12 @@ def _records(hits):
 
 def _compare(hmm, db, **opts):
     dev = _records(plan7.Pipeline(hmm.alphabet, **opts).search_hmm(hmm, db))
-    host = _records(plan7.Pipeline(hmm.alphabet, host_envelopes=True, **opts).search_hmm(hmm, db))
+    host = _records(plan7.Pipeline(hmm.alphabet, host_envelopes=True, host_regions=True, **opts).search_hmm(hmm, db))
+    # the region scan alone (same envelope kernel on both sides): everything must be identical, bit for bit
+    a = plan7.Pipeline(hmm.alphabet, host_regions=True, **opts).search_hmm(hmm, db)
+    assert _records(a) == dev
+    assert [(h.nregions, h.nclustered, h.nenvelopes, h.nexpected) for h in a] == \
+           [(h.nregions, h.nclustered, h.nenvelopes, h.nexpected) for h in plan7.Pipeline(hmm.alphabet, **opts).search_hmm(hmm, db)]
     assert [r[0] for r in dev] == [r[0] for r in host]
     ndom, near_ties = 0, 0
     for (name, sa, da), (_, sb, dbb) in zip(dev, host):
