@@ -328,6 +328,7 @@ struct Workspace {
   float *xmx_f = nullptr, *xmx_b = nullptr, *xmx_s = nullptr; int64_t xmx_cap = 0; int64_t *xmx_off = nullptr; int64_t xmx_off_cap = 0;
   int32_t *reg_out = nullptr;      // [cap][kRegionCap*3 + 2]: regions | count | nexpected bits, per survivor
   hipEvent_t ev[8]{};
+  hipEvent_t ev_sync = nullptr;
   ~Workspace() {
     if (device < 0) return;
     (void) hipSetDevice(device);
@@ -336,6 +337,7 @@ struct Workspace {
     (void) hipFree(b.list_fwd); (void) hipFree(b.list_fin); (void) hipFree(b.counters);
     (void) hipFree(xmx_f); (void) hipFree(xmx_b); (void) hipFree(xmx_s); (void) hipFree(xmx_off); (void) hipFree(reg_out);
     for (auto &e : ev) if (e) (void) hipEventDestroy(e);
+    if (ev_sync) (void) hipEventDestroy(ev_sync);
   }
 };
 
@@ -356,6 +358,7 @@ static int get_workspace(int device, int64_t nslots, Workspace **out)
   P7X_HIP(hipMalloc(&w->b.list_fwd, cap * 4)); P7X_HIP(hipMalloc(&w->b.list_fin, cap * 4));
   P7X_HIP(hipMalloc(&w->b.counters, 16 * 4));
   for (auto &e : w->ev) P7X_HIP(hipEventCreate(&e));
+  P7X_HIP(hipEventCreateWithFlags(&w->ev_sync, hipEventDisableTiming));
   *out = w.get();
   tl_ws.push_back(std::move(w));
   return P7X_OK;
@@ -455,15 +458,16 @@ static int run_cascade(const p7x_pipeline_cfg &cfg, const p7x_oprofile *om, cons
   }
   P7X_HIP(hipEventRecord(ws->ev[4], s));
   P7X_HIP(hipMemcpyAsync(out.counts, ws->b.counters, 16 * 4, hipMemcpyDeviceToHost, s));
-  P7X_HIP(hipStreamSynchronize(s));
+  P7X_HIP(hipEventRecord(ws->ev_sync, s)); P7X_HIP(hipEventSynchronize(ws->ev_sync));   // our work only: other host threads share the stream
   // ---- survivors: Forward again with the special-state rows kept, then Backward
   const int nfin = out.counts[4];
   out.fin_slots.resize(nfin);
   out.usc.resize(nfin); out.filtersc.resize(nfin); out.vfsc.resize(nfin); out.fwdsc.resize(nfin); out.xmx_off.resize(nfin);
   if (nfin > 0) {
-    P7X_HIP(hipMemcpy(out.fin_slots.data(), ws->b.list_fin, (size_t) nfin * 4, hipMemcpyDeviceToHost));
+    P7X_HIP(hipMemcpyAsync(out.fin_slots.data(), ws->b.list_fin, (size_t) nfin * 4, hipMemcpyDeviceToHost, s));
+    P7X_HIP(hipEventRecord(ws->ev_sync, s)); P7X_HIP(hipEventSynchronize(ws->ev_sync));
     std::sort(out.fin_slots.begin(), out.fin_slots.end());         // deterministic order
-    P7X_HIP(hipMemcpy(ws->b.list_fin, out.fin_slots.data(), (size_t) nfin * 4, hipMemcpyHostToDevice));
+    P7X_HIP(hipMemcpyAsync(ws->b.list_fin, out.fin_slots.data(), (size_t) nfin * 4, hipMemcpyHostToDevice, s));
     int64_t tot = 0;
     for (int i = 0; i < nfin; ++i) {
       out.xmx_off[i] = tot;
@@ -506,7 +510,7 @@ static int run_cascade(const p7x_pipeline_cfg &cfg, const p7x_oprofile *om, cons
     P7X_HIP(hipMemcpyAsync(regbuf.data(), ws->reg_out, regbuf.size() * 4, hipMemcpyDeviceToHost, s));
     // the rows pass recomputed each survivor's Forward score in list order: one contiguous copy
     P7X_HIP(hipMemcpyAsync(out.fwdsc.data(), ws->b.fwd_by_item, (size_t) nfin * 4, hipMemcpyDeviceToHost, s));
-    P7X_HIP(hipStreamSynchronize(s));
+    P7X_HIP(hipEventRecord(ws->ev_sync, s)); P7X_HIP(hipEventSynchronize(ws->ev_sync));   // our work only: other host threads share the stream
     out.regs.assign(regbuf.begin(), regbuf.begin() + (size_t) nfin * kRegionCap * 3);
     out.reg_n.assign(regbuf.begin() + (size_t) nfin * kRegionCap * 3, regbuf.begin() + (size_t) nfin * (kRegionCap * 3 + 1));
     out.nexpected.resize(nfin);
@@ -521,7 +525,7 @@ static int run_cascade(const p7x_pipeline_cfg &cfg, const p7x_oprofile *om, cons
     }
   } else {
     P7X_HIP(hipEventRecord(ws->ev[5], s)); P7X_HIP(hipEventRecord(ws->ev[6], s));
-    P7X_HIP(hipStreamSynchronize(s));
+    P7X_HIP(hipEventRecord(ws->ev_sync, s)); P7X_HIP(hipEventSynchronize(ws->ev_sync));   // our work only: other host threads share the stream
   }
   for (int i = 0; i < 6; ++i) { float ms = 0; (void) hipEventElapsedTime(&ms, ws->ev[i], ws->ev[i + 1]); out.ms[i] = ms; }
   { float ms = 0; (void) hipEventElapsedTime(&ms, ws->ev[0], ws->ev[7]); out.ms[7] = ms; }
