@@ -104,7 +104,8 @@ def main():
     ap.add_argument("--seqlen", type=int, default=300)
     ap.add_argument("--hmm", default="KR")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--pipeline-depth", type=int, default=2, help="queries whose device stage may run ahead of the host stage (0: none)")
+    ap.add_argument("--pipeline-depth", type=int, default=3, help="queries whose device stage may run ahead of the host stage (0: none)")
+    ap.add_argument("--feeders", type=int, default=2, help="host threads issuing device stages (each on its own stream)")
     ap.add_argument("--cpu-sample", type=int, default=1_000_000, help="targets timed through the CPU oracle (rank 0, N=1)")
     args = ap.parse_args()
 
@@ -144,7 +145,7 @@ def main():
         """nsteps searches of the same workload through the public entry point.  hmmsearch overlaps the device
         stage of query k+1 with the host stage of query k (pipeline_depth), exactly as it does for distinct queries."""
         last, acc = None, {}
-        for h in hmmer.hmmsearch((om for _ in range(nsteps)), db, pipeline_depth=args.pipeline_depth):
+        for h in hmmer.hmmsearch((om for _ in range(nsteps)), db, pipeline_depth=args.pipeline_depth, feeders=args.feeders):
             last = h
             for k, v in h.timings_ms.items():
                 acc[k] = acc.get(k, 0.0) + v
@@ -212,7 +213,7 @@ def main():
                 "timed_region": "hmmer.hmmsearch over `steps` queries (the same profile each time), every query runs the complete "
                                 "search; device stage of query k+1 overlaps the host stage of query k (pipeline_depth=%d); targets "
                                 "resident in HBM (pack+upload once: %.2fs, generation %.2fs, not timed)" % (args.pipeline_depth, t_pack, t_gen),
-                "pipeline_depth": args.pipeline_depth,
+                "pipeline_depth": args.pipeline_depth, "feeders": args.feeders,
                 "latency_ms_per_query": round(stage.get("total", 0.0), 3),
             },
             "stages": {

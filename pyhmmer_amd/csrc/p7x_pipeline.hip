@@ -121,27 +121,48 @@ __device__ __forceinline__ double d_gumbel_surv(double x, double mu, double lamb
 }
 __device__ __forceinline__ double d_exp_surv(double x, double mu, double lambda) { return x < mu ? 1.0 : exp(-lambda * (x - mu)); }
 
+// Append <value> to a device work list for every lane with <take>: one atomic per wavefront instead of one per lane
+// (thousands of lanes finish the same stage at the same moment; same-address atomics serialise in L2).
+// Must be reached by all lanes of the wavefront that are still in the kernel.
+__device__ __forceinline__ void wave_append(int *counter, int32_t *list, bool take, int32_t value)
+{
+  const unsigned long long mask = __ballot(take);
+  if (mask == 0) return;
+  const int lane = (int) (threadIdx.x & 63);
+  const int leader = __ffsll((long long) mask) - 1;
+  int base = 0;
+  if (lane == leader) base = atomicAdd(counter, __popcll(mask));
+  base = __shfl(base, leader);
+  if (take) list[base + __popcll(mask & ((1ull << lane) - 1ull))] = value;
+}
+__device__ __forceinline__ void wave_count(int *counter, bool take)
+{
+  const unsigned long long mask = __ballot(take);
+  if (mask != 0 && (int) (threadIdx.x & 63) == __ffsll((long long) mask) - 1) atomicAdd(counter, __popcll(mask));
+}
+
 // after MSV: usc, P1; survivors -> list_bias
 __global__ void decide_msv_kernel(StageBufs b, StageParams p, const int32_t *slot_len, const uint8_t *tjb_tab,
                                   const float *null1_tab, int64_t nslots)
 {
   const int64_t s = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
-  if (s >= nslots) return;
-  const int L = slot_len[s];
-  const int xJ = b.xJ[s];
-  float usc;
-  if (xJ < 0) usc = __builtin_inff();
-  else {
-    usc = ((float) (xJ - (int) tjb_tab[L]) - (float) p.base_b);
-    usc /= p.scale_b;
-    usc -= 3.0f;
+  bool take = false;
+  if (s < nslots) {
+    const int L = slot_len[s];
+    const int xJ = b.xJ[s];
+    float usc;
+    if (xJ < 0) usc = __builtin_inff();
+    else {
+      usc = ((float) (xJ - (int) tjb_tab[L]) - (float) p.base_b);
+      usc /= p.scale_b;
+      usc -= 3.0f;
+    }
+    b.usc[s] = usc;
+    const float seq_score = (float) ((double) (usc - null1_tab[L]) / kLog2);
+    const double P = d_gumbel_surv((double) seq_score, (double) p.mmu, (double) p.mlambda);
+    take = !(P > p.F1);
   }
-  b.usc[s] = usc;
-  const float seq_score = (float) ((double) (usc - null1_tab[L]) / kLog2);
-  const double P = d_gumbel_surv((double) seq_score, (double) p.mmu, (double) p.mlambda);
-  if (P > p.F1) return;
-  const int idx = atomicAdd(&b.counters[1], 1);
-  b.list_bias[idx] = (int32_t) s;
+  wave_append(&b.counters[1], b.list_bias, take, (int32_t) s);
 }
 
 // bias filter: esl_hmm_Forward on the 2-state composition HMM (p7_bg_FilterScore); survivors -> list_vit / list_fwd
@@ -149,13 +170,18 @@ __global__ void bias_kernel(StageBufs b, StageParams p, const uint8_t *dsq, cons
                             const int32_t *slot_len, const float *null1_tab, const float *eo)
 {
   const int n = b.counters[1];
-  for (int it = blockIdx.x * blockDim.x + threadIdx.x; it < n; it += gridDim.x * blockDim.x) {
-    const int s = b.list_bias[it];
+  for (int it0 = blockIdx.x * blockDim.x; it0 < n; it0 += gridDim.x * blockDim.x) {     // uniform trip count per wavefront
+    const int it = it0 + (int) threadIdx.x;
+    bool to_vit = false, to_fwd = false;
+    int s = 0;
+    if (it < n) {
+    s = b.list_bias[it];
     const int L = slot_len[s];
     const float nullsc = null1_tab[L];
     float filtersc = nullsc;
     const float usc = b.usc[s];
     double P;
+    bool pass = true;
     if (p.do_bias) {
       const uint8_t *sq = dsq + slot_off[s];
       const float p1 = (float) L / (float) (L + 1);
@@ -168,13 +194,35 @@ __global__ void bias_kernel(StageBufs b, StageParams p, const uint8_t *dsq, cons
       dp0 /= mx; dp1 /= mx;
       float logsc = 0.0f;
       logsc += (float) log((double) mx);
-      for (int i = 1; i < L; ++i) {
-        x = sq[i];
-        float n0 = 0.0f; n0 += dp0 * t00; n0 += dp1 * t10; n0 *= eo[x * 2];
-        float n1 = 0.0f; n1 += dp0 * t01; n1 += dp1 * t11; n1 *= eo[x * 2 + 1];
-        mx = 0.0f; mx = n0 > mx ? n0 : mx; mx = n1 > mx ? n1 : mx;
-        dp0 = n0 / mx; dp1 = n1 / mx;
-        logsc += (float) log((double) mx);
+      // The recurrence is a short dependent chain per residue; a byte load per step would put a memory round trip
+      // on it (~1 us x L).  Residues and their emission odds are therefore fetched 16 steps ahead.
+      for (int i0 = 1; i0 < L; i0 += 16) {
+        const int nstep = min(16, L - i0);
+        float e0[16], e1[16];
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+          const int xj = (j < nstep) ? (int) sq[i0 + j] : 0;
+          e0[j] = eo[xj * 2]; e1[j] = eo[xj * 2 + 1];
+        }
+        float mxs[16];
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+          mxs[j] = 1.0f;
+          if (j < nstep) {
+            float n0 = 0.0f; n0 += dp0 * t00; n0 += dp1 * t10; n0 *= e0[j];
+            float n1 = 0.0f; n1 += dp0 * t01; n1 += dp1 * t11; n1 *= e1[j];
+            mx = 0.0f; mx = n0 > mx ? n0 : mx; mx = n1 > mx ? n1 : mx;
+            dp0 = n0 / mx; dp1 = n1 / mx;
+            mxs[j] = mx;
+          }
+        }
+        // the sixteen double-precision logs are independent of each other and of the chain above: the compiler
+        // interleaves them.  They are still added to the score in sequence order.
+        float lg[16];
+#pragma unroll
+        for (int j = 0; j < 16; ++j) lg[j] = (float) log((double) mxs[j]);
+#pragma unroll
+        for (int j = 0; j < 16; ++j) if (j < nstep) logsc += lg[j];
       }
       float last = 0.0f; last += dp0 * 1.0f; last += dp1 * 1.0f;
       logsc += (float) log((double) last);
@@ -182,15 +230,18 @@ __global__ void bias_kernel(StageBufs b, StageParams p, const uint8_t *dsq, cons
       const float seq_score = (float) ((double) (usc - filtersc) / kLog2);
       P = d_gumbel_surv((double) seq_score, (double) p.mmu, (double) p.mlambda);
       b.filtersc[s] = filtersc;
-      if (P > p.F1) continue;
+      if (P > p.F1) pass = false;
     } else {
       const float seq_score = (float) ((double) (usc - nullsc) / kLog2);
       P = d_gumbel_surv((double) seq_score, (double) p.mmu, (double) p.mlambda);
       b.filtersc[s] = filtersc;
     }
-    atomicAdd(&b.counters[8], 1);
-    if (P > p.F2) { const int idx = atomicAdd(&b.counters[2], 1); b.list_vit[idx] = s; }
-    else          { const int idx = atomicAdd(&b.counters[3], 1); b.list_fwd[idx] = s; }
+    to_vit = pass && (P > p.F2);
+    to_fwd = pass && !(P > p.F2);
+    }
+    wave_count(&b.counters[8], to_vit || to_fwd);
+    wave_append(&b.counters[2], b.list_vit, to_vit, s);
+    wave_append(&b.counters[3], b.list_fwd, to_fwd, s);
   }
 }
 
@@ -198,8 +249,11 @@ __global__ void bias_kernel(StageBufs b, StageParams p, const uint8_t *dsq, cons
 __global__ void decide_vit_kernel(StageBufs b, StageParams p, const int32_t *slot_len, const int16_t *xwmove_tab)
 {
   const int n = b.counters[2];
-  for (int it = blockIdx.x * blockDim.x + threadIdx.x; it < n; it += gridDim.x * blockDim.x) {
-    const int s = b.list_vit[it];
+  for (int it0 = blockIdx.x * blockDim.x; it0 < n; it0 += gridDim.x * blockDim.x) {
+    const int it = it0 + (int) threadIdx.x;
+    bool take = false; int s = 0;
+    if (it < n) {
+    s = b.list_vit[it];
     const int L = slot_len[s];
     const int xC = b.xC[it];
     float vfsc;
@@ -212,9 +266,9 @@ __global__ void decide_vit_kernel(StageBufs b, StageParams p, const int32_t *slo
     b.vfsc[s] = vfsc;
     const float seq_score = (float) ((double) (vfsc - b.filtersc[s]) / kLog2);
     const double P = d_gumbel_surv((double) seq_score, (double) p.vmu, (double) p.vlambda);
-    if (P > p.F2) continue;
-    const int idx = atomicAdd(&b.counters[3], 1);
-    b.list_fwd[idx] = s;
+    take = !(P > p.F2);
+    }
+    wave_append(&b.counters[3], b.list_fwd, take, s);
   }
 }
 
@@ -222,15 +276,18 @@ __global__ void decide_vit_kernel(StageBufs b, StageParams p, const int32_t *slo
 __global__ void decide_fwd_kernel(StageBufs b, StageParams p)
 {
   const int n = b.counters[3];
-  for (int it = blockIdx.x * blockDim.x + threadIdx.x; it < n; it += gridDim.x * blockDim.x) {
-    const int s = b.list_fwd[it];
-    const float fwdsc = b.fwd_by_item[it];
-    b.fwdsc[s] = fwdsc;
-    const float seq_score = (float) ((double) (fwdsc - b.filtersc[s]) / kLog2);
-    const double P = d_exp_surv((double) seq_score, (double) p.ftau, (double) p.flambda);
-    if (P > p.F3) continue;
-    const int idx = atomicAdd(&b.counters[4], 1);
-    b.list_fin[idx] = s;
+  for (int it0 = blockIdx.x * blockDim.x; it0 < n; it0 += gridDim.x * blockDim.x) {
+    const int it = it0 + (int) threadIdx.x;
+    bool take = false; int s = 0;
+    if (it < n) {
+      s = b.list_fwd[it];
+      const float fwdsc = b.fwd_by_item[it];
+      b.fwdsc[s] = fwdsc;
+      const float seq_score = (float) ((double) (fwdsc - b.filtersc[s]) / kLog2);
+      const double P = d_exp_surv((double) seq_score, (double) p.ftau, (double) p.flambda);
+      take = !(P > p.F3);
+    }
+    wave_append(&b.counters[4], b.list_fin, take, s);
   }
 }
 
@@ -329,6 +386,7 @@ struct Workspace {
   int32_t *reg_out = nullptr;      // [cap][kRegionCap*3 + 2]: regions | count | nexpected bits, per survivor
   hipEvent_t ev[8]{};
   hipEvent_t ev_sync = nullptr;
+  hipStream_t stream = nullptr;     // one stream per host thread driving cascades: concurrent searches overlap on the device
   ~Workspace() {
     if (device < 0) return;
     (void) hipSetDevice(device);
@@ -338,6 +396,7 @@ struct Workspace {
     (void) hipFree(xmx_f); (void) hipFree(xmx_b); (void) hipFree(xmx_s); (void) hipFree(xmx_off); (void) hipFree(reg_out);
     for (auto &e : ev) if (e) (void) hipEventDestroy(e);
     if (ev_sync) (void) hipEventDestroy(ev_sync);
+    if (stream) (void) hipStreamDestroy(stream);
   }
 };
 
@@ -359,6 +418,7 @@ static int get_workspace(int device, int64_t nslots, Workspace **out)
   P7X_HIP(hipMalloc(&w->b.counters, 16 * 4));
   for (auto &e : w->ev) P7X_HIP(hipEventCreate(&e));
   P7X_HIP(hipEventCreateWithFlags(&w->ev_sync, hipEventDisableTiming));
+  P7X_HIP(hipStreamCreateWithFlags(&w->stream, hipStreamNonBlocking));
   *out = w.get();
   tl_ws.push_back(std::move(w));
   return P7X_OK;
@@ -390,7 +450,7 @@ static const bool g_host_envelopes = std::getenv("P7X_HOST_ENVELOPES") != nullpt
 static const bool g_host_regions = std::getenv("P7X_HOST_REGIONS") != nullptr;       // A/B: region scan on the host
 
 // Run MSV over the whole database; leaves xJ (slot order) in ws->b.xJ.
-static int run_msv(const Profile &p, const DevProfile *dp, const p7x_seqdb *db, DeviceCtx *ctx, Workspace *ws)
+static int run_msv(const Profile &p, const DevProfile *dp, const p7x_seqdb *db, DeviceCtx *ctx, Workspace *ws, hipStream_t stream)
 {
   if (dp->msvR <= 0) { set_error("model too long for the MSV kernel (M > 478 is not supported yet)"); return P7X_EINVAL; }
   MsvArgs a{};
@@ -400,7 +460,7 @@ static int run_msv(const Profile &p, const DevProfile *dp, const p7x_seqdb *db, 
   a.counter = &ws->b.counters[0]; a.out_xJ = ws->b.xJ;
   a.amb_count = &ws->b.counters[10]; a.counter2 = &ws->b.counters[11];
   a.amb_groups = g_msv_exact_only ? nullptr : ws->b.list_fin;     // list_fin is free until the Forward stage
-  return msv_launch(dp->msvR, a, ctx->num_cu, ctx->stream);
+  return msv_launch(dp->msvR, a, ctx->num_cu, stream);
 }
 
 struct CascadeOut {
@@ -427,11 +487,11 @@ static int run_cascade(const p7x_pipeline_cfg &cfg, const p7x_oprofile *om, cons
   if (dp->vitC <= 0 || dp->vitC > 16) { set_error("model too long for the Forward kernel (M > 1024 is not supported yet)"); return P7X_EINVAL; }
   Workspace *ws = nullptr;
   if ((st = get_workspace(db->device, db->nslots, &ws)) != P7X_OK) return st;
-  hipStream_t s = ctx->stream;
+  hipStream_t s = ws->stream;
   const StageParams sp = make_params(p, cfg);
   P7X_HIP(hipMemsetAsync(ws->b.counters, 0, 16 * 4, s));
   P7X_HIP(hipEventRecord(ws->ev[0], s));
-  if ((st = run_msv(p, dp, db, ctx, ws)) != P7X_OK) return st;
+  if ((st = run_msv(p, dp, db, ctx, ws, s)) != P7X_OK) return st;
   P7X_HIP(hipEventRecord(ws->ev[7], s));
   {
     const unsigned grid = (unsigned) ((db->nslots + 255) / 256);
@@ -725,7 +785,7 @@ int p7x_filters_batch(const p7x_oprofile *om, const p7x_seqdb *db, int32_t *xJ, 
   hipStream_t s = ctx->stream;
   P7X_HIP(hipMemsetAsync(ws->b.counters, 0, 16 * 4, s));
   if (xJ) {
-    if ((st = run_msv(p, dp, db, ctx, ws)) != P7X_OK) return st;
+    if ((st = run_msv(p, dp, db, ctx, ws, s)) != P7X_OK) return st;
     std::vector<int16_t> h((size_t) ns);
     P7X_HIP(hipMemcpyAsync(h.data(), ws->b.xJ, (size_t) ns * 2, hipMemcpyDeviceToHost, s));
     P7X_HIP(hipStreamSynchronize(s));

@@ -10,7 +10,6 @@ re-thresholded on the host.  No collective is involved.
 """
 from __future__ import annotations
 
-import queue
 import threading
 from typing import Callable, Iterable, Iterator, List, Optional, Sequence, Union
 
@@ -101,7 +100,7 @@ class ShardedDatabase:
 
 def hmmsearch(queries: Union[HMM, Profile, OptimizedProfile, Iterable], sequences, *, cpus: int = 0,
               callback: Optional[Callable] = None, devices: Optional[Sequence[int]] = None,
-              pipeline_depth: int = 2, **options) -> Iterator[TopHits]:
+              pipeline_depth: int = 3, feeders: int = 2, **options) -> Iterator[TopHits]:
     """Search HMMs against a sequence database; yields one ``TopHits`` per query, in query order.
 
     ``devices`` lists the HIP devices to shard the targets over (default: device 0).  ``cpus`` is accepted for
@@ -109,7 +108,7 @@ def hmmsearch(queries: Union[HMM, Profile, OptimizedProfile, Iterable], sequence
     arguments are forwarded to :class:`~pyhmmer_amd.plan7.Pipeline` (reference ``_hmmsearch.py:294-436``).
 
     Consecutive queries are overlapped the way the reference overlaps them on worker threads
-    (``hmmer/_base.py:416-489``): a feeder thread runs the device stage (filters and parsers) of up to
+    (``hmmer/_base.py:416-489``): ``feeders`` threads run the device stage (filters and parsers) of up to
     ``pipeline_depth`` queries ahead while the host stage (domain definition) of the current query runs in the
     caller's thread.  ``pipeline_depth=0`` runs the two stages of every query back to back.
     ``sequences`` may also be a :class:`~pyhmmer_amd.plan7.SequenceDatabase` already resident on one device.
@@ -148,39 +147,67 @@ def hmmsearch(queries: Union[HMM, Profile, OptimizedProfile, Iterable], sequence
             yield hits
         return
 
-    # two-stage software pipeline over the queries
-    staged: "queue.Queue" = queue.Queue(maxsize=pipeline_depth)
+    # two-stage software pipeline over the queries.  Feeder threads (each with its own device stream) run the
+    # device stage ahead of the host stage; with two of them the latency-bound tail of one query's cascade (parsers,
+    # region scan) overlaps the next query's MSV.  Results are handed over in query order, at most
+    # pipeline_depth of them staged or in flight at any time.
+    nfeed = max(1, min(feeders, pipeline_depth))
+    lock = threading.Lock()
+    ready = threading.Condition(lock)
+    slots = threading.Semaphore(pipeline_depth)
     stop = threading.Event()
-    _END = object()
+    qiter = enumerate(queries)
+    staged: dict = {}                 # index -> (query, pendings, error)
+    state = {"issued": 0, "exhausted": False, "live": nfeed}
 
     def feeder():
         try:
-            for q in queries:
-                if stop.is_set():
-                    break
-                item = (q, db.begin(pipelines, q), None)
-                while not stop.is_set():
+            while not stop.is_set():
+                if not slots.acquire(timeout=0.1):
+                    continue
+                with lock:
+                    if state["exhausted"] or stop.is_set():
+                        slots.release()
+                        return
                     try:
-                        staged.put(item, timeout=0.1)
-                        item = None
-                        break
-                    except queue.Full:
-                        continue
-                if item is not None:            # interrupted: release the device-side results
-                    for pend in item[1]:
-                        _lib.lib().p7x_pending_destroy(pend[0])
-        except BaseException as e:              # forwarded to the caller like _base.py:305-318
-            staged.put((None, None, e))
+                        idx, q = next(qiter)
+                    except StopIteration:
+                        state["exhausted"] = True
+                        slots.release()
+                        return
+                    except BaseException as e:      # the caller's iterable failed: report it in order
+                        state["exhausted"] = True
+                        staged[state["issued"]] = (None, None, e)
+                        state["issued"] += 1
+                        ready.notify_all()
+                        return
+                    state["issued"] = idx + 1
+                try:
+                    item = (q, db.begin(pipelines, q), None)
+                except BaseException as e:          # forwarded to the caller like _base.py:305-318
+                    item = (q, None, e)
+                with lock:
+                    staged[idx] = item
+                    ready.notify_all()
         finally:
-            staged.put((None, None, _END))
+            with lock:
+                state["live"] -= 1
+                ready.notify_all()
 
-    thread = threading.Thread(target=feeder, name="p7x-hmmsearch-feeder", daemon=True)
-    thread.start()
+    threads = [threading.Thread(target=feeder, name=f"p7x-hmmsearch-feeder-{i}", daemon=True) for i in range(nfeed)]
+    for t in threads:
+        t.start()
+    nxt = 0
     try:
         while True:
-            q, pendings, err = staged.get()
-            if err is _END:
-                break
+            with lock:
+                while nxt not in staged and not (state["live"] == 0 and nxt >= state["issued"]):
+                    ready.wait()
+                if nxt not in staged:
+                    break
+                q, pendings, err = staged.pop(nxt)
+            nxt += 1
+            slots.release()
             if err is not None:
                 raise err
             hits = db.finish(pendings)
@@ -189,12 +216,13 @@ def hmmsearch(queries: Union[HMM, Profile, OptimizedProfile, Iterable], sequence
             yield hits
     finally:
         stop.set()
-        while thread.is_alive():                # drain so that the feeder can leave, releasing what it staged
-            try:
-                q, pendings, err = staged.get(timeout=0.1)
-                if pendings:
-                    for pend in pendings:
-                        _lib.lib().p7x_pending_destroy(pend[0])
-            except queue.Empty:
-                pass
-        thread.join()
+        with lock:
+            state["exhausted"] = True
+        for t in threads:
+            slots.release()
+        for t in threads:
+            t.join()
+        for _, pendings, _ in staged.values():
+            if pendings:
+                for pend in pendings:
+                    _lib.lib().p7x_pending_destroy(pend[0])
