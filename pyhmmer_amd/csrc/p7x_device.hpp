@@ -45,6 +45,9 @@ struct DevProfile {
   int vitC = 0, Mpad = 0;
   int16_t *vit_trans = nullptr;
   int16_t *vit_emis = nullptr;
+  // packed Viterbi (p7x_vitpk.hip), when the model is short enough: T lanes per target, P register pairs per lane
+  int vitpkT = 0, vitpkP = 0;
+  uint32_t *vitpk_trans = nullptr, *vitpk_emis = nullptr;
   // Forward/Backward: transitions [Mpad][8] f32, emissions [kTabRows][Mpad] f32
   float *fwd_trans = nullptr;
   float *fwd_emis = nullptr;

@@ -54,6 +54,19 @@ int vit_launch(const WaveSeqArgs &a, int num_cu, hipStream_t st);
 int fwd_launch(const WaveSeqArgs &a, int num_cu, hipStream_t st);
 int bck_launch(const WaveSeqArgs &a, int num_cu, hipStream_t st);
 
+// ---- packed Viterbi filter (p7x_vitpk.hip): T lanes per target, 2P nodes per lane, for M <= 640
+struct VitPkArgs {
+  const void *trans, *emis;     // vitpk_build_tables()
+  const uint8_t *dsq; const int64_t *slot_off; const int32_t *slot_len;
+  const int32_t *list; int nlist; const int *nlist_ptr;     // as WaveSeqArgs
+  int nrows;
+  const int16_t *xwmove_tab; int base_w, xw_e, ddbound;
+  int32_t *out_xC;
+};
+bool vitpk_pick(int M, int *T, int *P);
+void vitpk_build_tables(const Profile &p, int T, int P, std::vector<uint32_t> &trans, std::vector<uint32_t> &emis);
+int  vitpk_launch(int T, int P, const VitPkArgs &a, int num_cu, hipStream_t st);
+
 // ---- envelope rescoring (p7x_envelope.hip): Forward + Backward + decoding/null2/optimal accuracy + traceback,
 // one domain envelope per wavefront.  Trace steps come back in traceback order (T first): tr_a = state | k << 8,
 // tr_i = residue index inside the envelope (1..Ld, as the traceback saw it), tr_pp = posterior of that step.

@@ -28,6 +28,7 @@ static void free_dev_profile(DevProfile *d)
   if (!d) return;
   (void) hipSetDevice(d->device);
   (void) hipFree(d->msv_tab); (void) hipFree(d->vit_trans); (void) hipFree(d->vit_emis);
+  (void) hipFree(d->vitpk_trans); (void) hipFree(d->vitpk_emis);
   (void) hipFree(d->fwd_trans); (void) hipFree(d->fwd_emis); (void) hipFree(d->bias_eo);
   delete d;
 }
@@ -74,6 +75,16 @@ static int get_dev_profile(const p7x_oprofile *om, DeviceCtx *ctx, DevProfile **
     P7X_HIP(hipMalloc(&d->vit_emis, ve.size() * 2));  P7X_HIP(hipMemcpy(d->vit_emis, ve.data(), ve.size() * 2, hipMemcpyHostToDevice));
     P7X_HIP(hipMalloc(&d->fwd_trans, ft.size() * 4)); P7X_HIP(hipMemcpy(d->fwd_trans, ft.data(), ft.size() * 4, hipMemcpyHostToDevice));
     P7X_HIP(hipMalloc(&d->fwd_emis, fe.size() * 4));  P7X_HIP(hipMemcpy(d->fwd_emis, fe.data(), fe.size() * 4, hipMemcpyHostToDevice));
+  }
+  {
+    int T = 0, P = 0;
+    if (vitpk_pick(p.M, &T, &P)) {
+      std::vector<uint32_t> tt, te;
+      vitpk_build_tables(p, T, P, tt, te);
+      d->vitpkT = T; d->vitpkP = P;
+      P7X_HIP(hipMalloc(&d->vitpk_trans, tt.size() * 4)); P7X_HIP(hipMemcpy(d->vitpk_trans, tt.data(), tt.size() * 4, hipMemcpyHostToDevice));
+      P7X_HIP(hipMalloc(&d->vitpk_emis, te.size() * 4));  P7X_HIP(hipMemcpy(d->vitpk_emis, te.data(), te.size() * 4, hipMemcpyHostToDevice));
+    }
   }
   // bias filter emission odds (esl_hmm_Configure on the 2-state filter HMM, p7_bg_SetFilter)
   {
@@ -446,6 +457,7 @@ static WaveSeqArgs ws_args(const Profile &p, const DevProfile *dp, const p7x_seq
 }
 
 static const bool g_msv_exact_only = std::getenv("P7X_MSV_EXACT") != nullptr;   // A/B switch for profiling
+static const bool g_vit_wave = std::getenv("P7X_VIT_WAVE") != nullptr;            // A/B: wave-per-target Viterbi kernel
 static const bool g_host_envelopes = std::getenv("P7X_HOST_ENVELOPES") != nullptr;   // A/B: rescore envelopes on the host
 static const bool g_host_regions = std::getenv("P7X_HOST_REGIONS") != nullptr;       // A/B: region scan on the host
 
@@ -461,6 +473,20 @@ static int run_msv(const Profile &p, const DevProfile *dp, const p7x_seqdb *db, 
   a.amb_count = &ws->b.counters[10]; a.counter2 = &ws->b.counters[11];
   a.amb_groups = g_msv_exact_only ? nullptr : ws->b.list_fin;     // list_fin is free until the Forward stage
   return msv_launch(dp->msvR, a, ctx->num_cu, stream);
+}
+
+// Viterbi filter over a work list: the packed kernel when the model fits it, else one target per wavefront.
+static int run_viterbi(const Profile &p, const DevProfile *dp, const p7x_seqdb *db, DeviceCtx *ctx, const WaveSeqArgs &w, hipStream_t s)
+{
+  if (dp->vitpkT > 0 && !g_vit_wave) {
+    VitPkArgs a{};
+    a.trans = dp->vitpk_trans; a.emis = dp->vitpk_emis; a.dsq = db->d_dsq; a.slot_off = db->d_slot_off; a.slot_len = db->d_slot_len;
+    a.list = w.list; a.nlist = w.nlist; a.nlist_ptr = w.nlist_ptr; a.nrows = p.Kp + 1;
+    a.xwmove_tab = ctx->lt.xwmove; a.base_w = p.base_w; a.xw_e = p.xw[XE][MOVE]; a.ddbound = p.ddbound_w;
+    a.out_xC = w.out_xC;
+    return vitpk_launch(dp->vitpkT, dp->vitpkP, a, ctx->num_cu, s);
+  }
+  return vit_launch(w, ctx->num_cu, s);
 }
 
 struct CascadeOut {
@@ -505,7 +531,7 @@ static int run_cascade(const p7x_pipeline_cfg &cfg, const p7x_oprofile *om, cons
     WaveSeqArgs a = ws_args(p, dp, db, ctx);
     a.trans = dp->vit_trans; a.emis = dp->vit_emis; a.list = ws->b.list_vit; a.nlist_ptr = &ws->b.counters[2];
     a.counter = &ws->b.counters[5]; a.out_xC = ws->b.xC;
-    if ((st = vit_launch(a, ctx->num_cu, s)) != P7X_OK) return st;
+    if ((st = run_viterbi(p, dp, db, ctx, a, s)) != P7X_OK) return st;
     hipLaunchKernelGGL(decide_vit_kernel, dim3(ctx->num_cu), dim3(256), 0, s, ws->b, sp, db->d_slot_len, ctx->lt.xwmove);
   }
   P7X_HIP(hipEventRecord(ws->ev[3], s));
@@ -797,7 +823,7 @@ int p7x_filters_batch(const p7x_oprofile *om, const p7x_seqdb *db, int32_t *xJ, 
     a.list = nullptr; a.nlist = (int) ns; a.nlist_ptr = nullptr;
     if (xC) {
       a.trans = dp->vit_trans; a.emis = dp->vit_emis; a.counter = &ws->b.counters[5]; a.out_xC = ws->b.xC;
-      if ((st = vit_launch(a, ctx->num_cu, s)) != P7X_OK) return st;
+      if ((st = run_viterbi(p, dp, db, ctx, a, s)) != P7X_OK) return st;
       std::vector<int32_t> h((size_t) ns);
       P7X_HIP(hipMemcpyAsync(h.data(), ws->b.xC, (size_t) ns * 4, hipMemcpyDeviceToHost, s));
       P7X_HIP(hipStreamSynchronize(s));

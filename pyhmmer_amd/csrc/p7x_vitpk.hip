@@ -1,0 +1,254 @@
+// p7x_vitpk.hip -- Viterbi filter, packed: T lanes per target (T = 8 or 16), 64/T targets per wavefront.
+//
+// The wave-per-target kernel in p7x_vitfwd.hip spends most of a row on work that does not shrink with the model:
+// wave-wide reductions, the scalar special-state chain, and 16-bit values in 32-bit lanes.  For the common
+// Pfam-sized models (M <= 640) this kernel shares those costs between several targets:
+//   * lane s of a group owns the 2P consecutive nodes s*2P+1 .. s*2P+2P, two per VGPR (v_pk_add_i16 clamp /
+//     v_pk_max_i16 reproduce _mm_adds_epi16 / _mm_max_epi16 of impl_sse/vitfilter.c exactly);
+//   * the k-1 neighbour is one v_alignbit across adjacent registers, one DPP shift at the lane boundary;
+//   * transitions (8 x int16 per node: BM MM IM DM MD MI II DD) and emissions come from LDS as ds_read_b128,
+//     the DP rows (M, I, D) stay in 3P registers;
+//   * xE / Dmax are 3- or 4-step DPP butterflies inside the group, the special states are per-lane integers that
+//     are uniform within a group; targets that have ended are masked, the row loop runs to the longest target of
+//     the wavefront;
+//   * lazy F follows upstream: D gets only M->D unless Dmax + ddbound > xB for that target; then the D->D closure
+//     is evaluated in full (serial inside the lane, carries relaxed across lanes until nothing improves).
+// Results are bit-identical to p7x_vitfwd.hip::vit_kernel and to the oracle (tests/test_gpu_filters.py).
+#include "p7x_wave.hpp"
+
+namespace p7x {
+
+namespace {
+
+typedef short s2v __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ s2v as_s2v(uint32_t u) { return __builtin_bit_cast(s2v, u); }
+__device__ __forceinline__ uint32_t as_u(s2v v) { return __builtin_bit_cast(uint32_t, v); }
+__device__ __forceinline__ uint32_t pk_adds(uint32_t a, uint32_t b) { return as_u(__builtin_elementwise_add_sat(as_s2v(a), as_s2v(b))); }
+__device__ __forceinline__ uint32_t pk_max(uint32_t a, uint32_t b) { return as_u(__builtin_elementwise_max(as_s2v(a), as_s2v(b))); }
+__device__ __forceinline__ uint32_t splat16(int v) { const uint32_t w = (uint32_t) v & 0xffffu; return w | (w << 16); }
+__device__ __forceinline__ int lo_of(uint32_t w) { return (int) (short) (w & 0xffffu); }
+__device__ __forceinline__ int hi_of(uint32_t w) { return (int) (short) (w >> 16); }
+// (prev.hi, cur.lo): the register holding, for every node of <cur>, the value of its predecessor node
+__device__ __forceinline__ uint32_t shift_in(uint32_t cur, uint32_t prev) { return __builtin_amdgcn_alignbit(cur, prev, 16); }
+
+constexpr uint32_t kNeg2 = 0x80008000u;      // (-32768, -32768)
+constexpr int vitpk_rowq(int T, int P) { return (((P + 3) / 4) * T) | 1; }
+
+#define P7X_DPP_U(v, ctrl) ((uint32_t) __builtin_amdgcn_update_dpp((int) kNeg2, (int) (v), (ctrl), 0xf, 0xf, false))
+
+// maximum over the T lanes of a group, every lane receives it.  Packed pairs in, one int out.
+template <int T>
+__device__ __forceinline__ int group_max(uint32_t v)
+{
+  v = pk_max(v, P7X_DPP_U(v, 0xB1));      // quad_perm [1,0,3,2]
+  v = pk_max(v, P7X_DPP_U(v, 0x4E));      // quad_perm [2,3,0,1]
+  v = pk_max(v, P7X_DPP_U(v, 0x141));     // row_half_mirror: 8 lanes
+  if constexpr (T == 16) v = pk_max(v, P7X_DPP_U(v, 0x140));   // row_mirror: 16 lanes
+  return max(lo_of(v), hi_of(v));
+}
+
+} // namespace
+
+template <int T, int P>
+__global__ void __launch_bounds__(256) vitpk_kernel(const VitPkArgs a)
+{
+  constexpr int G = 64 / T;                // targets per wavefront
+  constexpr int PS = (P + 3) & ~3;         // table stride per lane, in pairs
+  constexpr int ROWQ = vitpk_rowq(T, P);   // uint4 per emission row (odd: rows of different residues spread over the banks)
+  // LDS layouts are lane-minor, so that the 16-byte reads of the T lanes of a group (and of the groups of a
+  // ds_read_b128 service group) fall on distinct 4-bank slots:
+  //   tra / trb [P][T] uint4   (BM MM IM DM) / (MD MI II DD) of pair j, lane s
+  //   em        [nrows][ROWQ]  uint4 q*T + s = pairs 4q..4q+3 of lane s
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  uint4 *tra = reinterpret_cast<uint4 *>(smem);
+  uint4 *trb = tra + P * T;
+  uint4 *em = trb + P * T;
+  {
+    const uint4 *gt = reinterpret_cast<const uint4 *>(a.trans);
+    for (int i = threadIdx.x; i < 2 * P * T; i += 256) tra[i] = gt[i];
+    const uint4 *ge = reinterpret_cast<const uint4 *>(a.emis);
+    for (int i = threadIdx.x; i < a.nrows * ROWQ; i += 256) em[i] = ge[i];
+  }
+  __syncthreads();
+  const int lane = threadIdx.x & 63;
+  const int s = lane % T, g = lane / T;
+  const bool first = (s == 0);
+  const int nlist = a.nlist_ptr ? *a.nlist_ptr : a.nlist;
+  const int wave0 = rfl((int) (blockIdx.x * 4 + (threadIdx.x >> 6)));
+  const int nwaves = (int) gridDim.x * 4;
+  const uint4 *tral = tra + s, *trbl = trb + s, *eml = em + s;
+
+  for (int it0 = wave0 * G; it0 < nlist; it0 += nwaves * G) {
+    const int it = it0 + g;
+    const bool have = it < nlist;
+    const int slot = have ? (a.list ? a.list[it] : it) : 0;
+    const int L = have ? a.slot_len[slot] : 0;
+    const uint8_t *sq = a.dsq + (have ? a.slot_off[slot] : 0);
+    const int xwm = (int) a.xwmove_tab[L];
+    const int Lmax = wave_max_i32(L);
+
+    uint32_t mm[P], im[P], dm[P];
+#pragma unroll
+    for (int j = 0; j < P; ++j) mm[j] = im[j] = dm[j] = kNeg2;
+    int xN = a.base_w, xB = xN + xwm, xJ = -32768, xC = -32768;
+    bool overflow = false;
+
+    for (int i0 = 0; i0 < Lmax; i0 += 4 * T) {
+      // residues of the next 4T rows: lane s holds rows i0+4s .. i0+4s+3 of its target (clamped reads; rows past the
+      // end of a target are masked below)
+      uint32_t word = 0;
+#pragma unroll
+      for (int b = 0; b < 4; ++b) {
+        const int r = i0 + 4 * s + b;
+        const uint32_t x = (r < L) ? (uint32_t) sq[r] : 0u;
+        word |= x << (8 * b);
+      }
+      const int nrow = min(4 * T, Lmax - i0);
+      for (int r = 0; r < nrow; ++r) {
+        const int i = i0 + r;
+        const uint32_t w = (uint32_t) __shfl((int) word, g * T + (r >> 2));
+        const uint32_t x = (w >> (8 * (r & 3))) & 0xffu;
+        const bool active = i < L;
+        const uint4 *er = eml + x * ROWQ;
+        const uint32_t xBv = splat16(xB);
+        // values of the previous lane's last register (previous row), -32768 at the start of a group
+        uint32_t mo = P7X_DPP_U(mm[P - 1], 0x138), io = P7X_DPP_U(im[P - 1], 0x138), dob = P7X_DPP_U(dm[P - 1], 0x138);
+        if (first) { mo = kNeg2; io = kNeg2; dob = kNeg2; }
+        uint32_t xEv = kNeg2, dmaxv = kNeg2, dcv_prev = kNeg2, dcv_last = kNeg2;
+#pragma unroll
+        for (int j4 = 0; j4 < PS; j4 += 4) {
+          const uint4 e4 = er[(j4 / 4) * T];
+          const uint32_t ev[4] = { e4.x, e4.y, e4.z, e4.w };
+#pragma unroll
+          for (int jj = 0; jj < 4; ++jj) {
+            const int j = j4 + jj;
+            if (j < P) {
+              const uint4 ta = tral[j * T], tb = trbl[j * T];          // BM MM IM DM | MD MI II DD
+              const uint32_t m_old = mm[j], i_old = im[j], d_old = dm[j];
+              const uint32_t mpv = shift_in(m_old, mo), ipv = shift_in(i_old, io), dpv = shift_in(d_old, dob);
+              uint32_t sv = pk_adds(xBv, ta.x);
+              sv = pk_max(sv, pk_adds(mpv, ta.y));
+              sv = pk_max(sv, pk_adds(ipv, ta.z));
+              sv = pk_max(sv, pk_adds(dpv, ta.w));
+              sv = pk_adds(sv, ev[jj]);
+              xEv = pk_max(xEv, sv);
+              mm[j] = sv;
+              const uint32_t dcv = pk_adds(sv, tb.x);                  // M(i,k) -> D(i,k+1)
+              dmaxv = pk_max(dmaxv, dcv);
+              dm[j] = shift_in(dcv, dcv_prev);                         // register 0 is completed after the loop
+              im[j] = pk_max(pk_adds(m_old, tb.y), pk_adds(i_old, tb.z));
+              mo = m_old; io = i_old; dob = d_old; dcv_prev = dcv;
+              if (j == P - 1) dcv_last = dcv;
+            }
+          }
+          // keep the LDS loads of later pairs behind this point: hoisting all 2P transition loads costs 8 VGPRs per pair
+          asm volatile("" ::: "memory");
+        }
+        {
+          uint32_t c = P7X_DPP_U(dcv_last, 0x138);
+          if (first) c = kNeg2;
+          dm[0] = (dm[0] & 0xffff0000u) | (c >> 16);                   // node s*2P+1 takes M(i, s*2P) + tMD from the lane before
+        }
+        const int xE = group_max<T>(xEv);
+        const int Dmax = group_max<T>(dmaxv);
+        if (active) {
+          if (xE >= 32767) overflow = true;
+          xC = max(xC, xE + a.xw_e);               // xw[C][LOOP] = xw[J][LOOP] = xw[N][LOOP] = 0
+          xJ = max(xJ, xE + a.xw_e);
+          xB = max(xJ + xwm, xN + xwm);
+        }
+        const bool trig = active && (Dmax + a.ddbound > xB);            // lazy F, per target
+        if (__any(trig)) {
+          // D->D transitions of this lane; -32768 for targets that did not ask for the closure: their adds saturate to
+          // -32768 and the maxima below leave D untouched, so the closure runs in place
+          uint32_t tdd[P];
+#pragma unroll
+          for (int j = 0; j < P; ++j) { const uint32_t t = trbl[j * T].w; tdd[j] = trig ? t : kNeg2; }
+          for (int pass = 0; pass < T; ++pass) {
+            // serial closure inside the lane: e(n+1) = max(e(n+1), e(n) + tDD(n)) along the 2P packed elements
+#pragma unroll
+            for (int j = 0; j < P; ++j) {
+              const uint32_t t1 = pk_adds(dm[j], tdd[j]);                                        // lo + tDD(lo)
+              dm[j] = pk_max(dm[j], (t1 << 16) | 0x8000u);                                       // -> hi   (lo half: max(lo, -32768))
+              if (j + 1 < P) {
+                const uint32_t t2 = pk_adds(dm[j], tdd[j]);                                      // hi + tDD(hi)
+                dm[j + 1] = pk_max(dm[j + 1], (t2 >> 16) | 0x80000000u);                         // -> next lo
+              }
+            }
+            // carry into the next lane of the group; stop when nothing improves any more
+            const uint32_t tl = pk_adds(dm[P - 1], tdd[P - 1]);
+            uint32_t c = P7X_DPP_U(tl, 0x138);
+            if (first) c = kNeg2;
+            const int cand = trig ? hi_of(c) : -32768;
+            const bool better = cand > lo_of(dm[0]);
+            if (!__any(better)) break;
+            if (better) dm[0] = (dm[0] & 0xffff0000u) | ((uint32_t) cand & 0xffffu);
+          }
+        }
+      }
+    }
+    if (have && s == 0) a.out_xC[it] = overflow ? 32767 : xC;
+  }
+}
+
+// ---------------------------------------------------------------------------- host side
+bool vitpk_pick(int M, int *T, int *P)
+{
+  static const int p8[] = { 2, 4, 6, 8, 10, 12, 14, 15, 16, 17, 18, 19, 20 };
+  static const int p16[] = { 11, 12, 13, 14, 15, 16, 17, 18, 19, 20 };
+  for (int p : p8) if (M <= 8 * 2 * p) { *T = 8; *P = p; return true; }
+  for (int p : p16) if (M <= 16 * 2 * p) { *T = 16; *P = p; return true; }
+  return false;
+}
+
+// trans: uint4 [2][P][T] = (BM MM IM DM) then (MD MI II DD) of pair j of lane s, each dword (node lo, node hi);
+// emis: uint4 [nrows][ROWQ], q*T + s = pairs 4q .. 4q+3 of lane s.  Nodes beyond M and unused pairs hold -32768.
+void vitpk_build_tables(const Profile &p, int T, int P, std::vector<uint32_t> &trans, std::vector<uint32_t> &emis)
+{
+  const int rowq = vitpk_rowq(T, P), nrows = p.Kp + 1;
+  auto pack = [](int lo, int hi) { return ((uint32_t) lo & 0xffffu) | (((uint32_t) hi & 0xffffu) << 16); };
+  trans.assign((size_t) 2 * P * T * 4, kNeg2);
+  emis.assign((size_t) nrows * rowq * 4, kNeg2);
+  for (int s = 0; s < T; ++s)
+    for (int j = 0; j < P; ++j) {
+      const int k0 = s * 2 * P + 2 * j + 1, k1 = k0 + 1;
+      for (int t = 0; t < NTRANS; ++t) {
+        const int lo = (k0 <= p.M) ? p.tw[(size_t) t * (p.M + 1) + k0] : -32768;
+        const int hi = (k1 <= p.M) ? p.tw[(size_t) t * (p.M + 1) + k1] : -32768;
+        trans[((size_t) (t / 4) * P * T + (size_t) j * T + s) * 4 + (t % 4)] = pack(lo, hi);
+      }
+      for (int x = 0; x < p.Kp; ++x) {
+        const int lo = (k0 <= p.M) ? p.rw[(size_t) x * (p.M + 1) + k0] : -32768;
+        const int hi = (k1 <= p.M) ? p.rw[(size_t) x * (p.M + 1) + k1] : -32768;
+        emis[((size_t) x * rowq + (size_t) (j / 4) * T + s) * 4 + (j % 4)] = pack(lo, hi);
+      }
+    }
+}
+
+template <int T, int P>
+static int launch_pk(const VitPkArgs &a, int num_cu, hipStream_t st)
+{
+  const size_t lds = ((size_t) 2 * P * T + (size_t) a.nrows * vitpk_rowq(T, P)) * 16;
+  auto kern = vitpk_kernel<T, P>;
+  if (lds > 64 * 1024) P7X_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds));
+  int per_cu = 0;
+  P7X_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, 256, lds));
+  if (per_cu < 1) per_cu = 1;
+  hipLaunchKernelGGL(kern, dim3((unsigned) (num_cu * per_cu)), dim3(256), lds, st, a);
+  P7X_HIP(hipGetLastError());
+  return P7X_OK;
+}
+
+int vitpk_launch(int T, int P, const VitPkArgs &a, int num_cu, hipStream_t st)
+{
+#define P7X_PK(TT, PP) if (T == TT && P == PP) return launch_pk<TT, PP>(a, num_cu, st);
+  P7X_PK(8, 2) P7X_PK(8, 4) P7X_PK(8, 6) P7X_PK(8, 8) P7X_PK(8, 10) P7X_PK(8, 12) P7X_PK(8, 14) P7X_PK(8, 15) P7X_PK(8, 16)
+  P7X_PK(8, 17) P7X_PK(8, 18) P7X_PK(8, 19) P7X_PK(8, 20)
+  P7X_PK(16, 11) P7X_PK(16, 12) P7X_PK(16, 13) P7X_PK(16, 14) P7X_PK(16, 15) P7X_PK(16, 16) P7X_PK(16, 17) P7X_PK(16, 18)
+  P7X_PK(16, 19) P7X_PK(16, 20)
+#undef P7X_PK
+  set_error("no packed Viterbi kernel for this model length");
+  return P7X_EINVAL;
+}
+
+} // namespace p7x

@@ -211,11 +211,17 @@ def test_every_msv_kernel_instantiation_bit_exact(M, oracle):
         assert np.array_equal(got, op.msv_block(blk.packed())), f"M={M} rep={rep}"
 
 
-@pytest.mark.parametrize("M", [1, 3, 64, 65, 128, 150, 192, 256, 300, 320, 384, 500, 512, 640, 700, 768, 1000, 1024])
+# wave-per-target kernels: one M per nodes-per-lane count C; packed Viterbi kernel (M <= 640): the largest M of every
+# (lanes per target T, register pairs per lane P) instantiation, i.e. 16 P for T = 8 and 32 P for T = 16, and one below
+_PK_M = sorted({16 * p - d for p in (2, 4, 6, 8, 10, 12, 14, 15, 16, 17, 18, 19, 20) for d in (0, 1)} |
+               {32 * p - d for p in range(11, 21) for d in (0, 1)})
+
+
+@pytest.mark.parametrize("M", sorted(set([1, 3, 64, 65, 128, 150, 192, 256, 300, 320, 384, 500, 512, 640, 641, 700, 768, 1000, 1024] + _PK_M)))
 def test_every_wavefront_kernel_instantiation_vs_oracle(M, oracle):
     hmm = random_hmm(M, seed=2000 + M)
     bg = plan7.Background(hmm.alphabet)
-    blk = _model_block(hmm, 120, 6, seed=M)
+    blk = _model_block(hmm, 90, 6, seed=M)
     om = plan7.OptimizedProfile(hmm, bg, 400)
     got = plan7.SequenceDatabase(blk).filters(om, msv=(M <= 478), viterbi=True, forward=True)
     want = _oracle_scores(oracle.OracleProfile(hmm, bg, 400), blk, want=("vit", "fwd"))
