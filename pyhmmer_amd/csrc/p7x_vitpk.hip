@@ -166,14 +166,29 @@ __global__ void __launch_bounds__(256) vitpk_kernel(const VitPkArgs a)
           for (int j = 0; j < P; ++j) { const uint32_t t = trbl[j * T].w; tdd[j] = trig ? t : kNeg2; }
           for (int pass = 0; pass < T; ++pass) {
             // serial closure inside the lane: e(n+1) = max(e(n+1), e(n) + tDD(n)) along the 2P packed elements
+            // Half-register (op_sel) forms of the 16-bit VOP3 ops walk the chain without unpacking: two instructions per
+            // element.  A partial register write needs one wait state before its result is read (gfx940 dst_sel
+            // forwarding hazard); the compiler does not see inside the asm, so the s_nops are written out.
 #pragma unroll
             for (int j = 0; j < P; ++j) {
-              const uint32_t t1 = pk_adds(dm[j], tdd[j]);                                        // lo + tDD(lo)
-              dm[j] = pk_max(dm[j], (t1 << 16) | 0x8000u);                                       // -> hi   (lo half: max(lo, -32768))
-              if (j + 1 < P) {
-                const uint32_t t2 = pk_adds(dm[j], tdd[j]);                                      // hi + tDD(hi)
-                dm[j + 1] = pk_max(dm[j + 1], (t2 >> 16) | 0x80000000u);                         // -> next lo
-              }
+              uint32_t tmp;
+              if (j + 1 < P)
+                asm volatile("s_nop 0\n\t"
+                             "v_add_i16 %2, %0, %3 clamp\n\t"                    // tmp.lo = d.lo + tDD(lo)
+                             "s_nop 0\n\t"
+                             "v_max3_i16 %0, %0, %2, %2 op_sel:[1,0,0,1]\n\t"    // d.hi   = max(d.hi, tmp.lo)
+                             "s_nop 0\n\t"
+                             "v_add_i16 %2, %0, %3 op_sel:[1,1,0] clamp\n\t"     // tmp.lo = d.hi + tDD(hi)
+                             "s_nop 0\n\t"
+                             "v_max3_i16 %1, %1, %2, %2"                          // next.lo = max(next.lo, tmp.lo), next.hi kept
+                             : "+v"(dm[j]), "+v"(dm[j + 1 < P ? j + 1 : j]), "=&v"(tmp) : "v"(tdd[j]));
+              else
+                asm volatile("s_nop 0\n\t"
+                             "v_add_i16 %1, %0, %2 clamp\n\t"
+                             "s_nop 0\n\t"
+                             "v_max3_i16 %0, %0, %1, %1 op_sel:[1,0,0,1]\n\t"
+                             "s_nop 0"
+                             : "+v"(dm[j]), "=&v"(tmp) : "v"(tdd[j]));
             }
             // carry into the next lane of the group; stop when nothing improves any more
             const uint32_t tl = pk_adds(dm[P - 1], tdd[P - 1]);
