@@ -104,8 +104,8 @@ def main():
     ap.add_argument("--seqlen", type=int, default=300)
     ap.add_argument("--hmm", default="KR")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--pipeline-depth", type=int, default=3, help="queries whose device stage may run ahead of the host stage (0: none)")
-    ap.add_argument("--feeders", type=int, default=2, help="host threads issuing device stages (each on its own stream)")
+    ap.add_argument("--pipeline-depth", type=int, default=2, help="queries whose device stage may run ahead of the host stage (0: none)")
+    ap.add_argument("--feeders", type=int, default=1, help="host threads issuing device stages (each on its own stream)")
     ap.add_argument("--cpu-sample", type=int, default=1_000_000, help="targets timed through the CPU oracle (rank 0, N=1)")
     args = ap.parse_args()
 
