@@ -29,7 +29,7 @@ extern "C" {
 #define P7X_ABI_VERSION 3
 
 enum {
-  P7X_OK = 0, P7X_EMEM = 5, P7X_EINVAL = 11, P7X_ERANGE = 16, P7X_ENORESULT = 19,
+  P7X_OK = 0, P7X_EMEM = 5, P7X_EFORMAT = 7, P7X_EINVAL = 11, P7X_ERANGE = 16, P7X_ENORESULT = 19,
   P7X_ENODEVICE = 100, P7X_EDEVICE = 101
 };
 
@@ -96,6 +96,19 @@ int p7x_oprofile_get_info(const p7x_oprofile *om, p7x_oprofile_info *info);
  * which: 0 rbv u8 [Kp][Q16*16]; 1 sbv i8 [Kp][(Q16+17)*16]; 2 rwv i16 [Kp][Q8*8]; 3 twv i16 [8*Q8*8];
  *        4 rfv f32 [Kp][Q4*4]; 5 tfv f32 [8*Q4*4].  Returns bytes written, or -1. */
 int64_t p7x_oprofile_striped(const p7x_oprofile *om, int which, void *out, size_t out_bytes);
+
+/* Pressed profiles: one record of a `.h3f` (MSV part) and of a `.h3p` (everything else) file, the formats
+ * `hmmpress` writes (reference hmmer/_hmmpress.py:29-66, OptimizedProfile.write plan7.pyx:5078-5105,
+ * HMMPressedFile plan7.pyx:4051-4197).  write: pass NULL buffers to obtain the sizes; offs = byte offsets of this
+ * model in the .h3m/.h3f/.h3p files (NULL: zeros).  read: parses one record from each buffer and returns the bytes
+ * consumed; the log-odds tables come out exactly as stored. */
+int p7x_oprofile_write_pressed(const p7x_oprofile *om, const int64_t offs[3], uint8_t *h3f, size_t cap_f, size_t *len_f,
+                               uint8_t *h3p, size_t cap_p, size_t *len_p);
+/* name (0), accession (1), description (2), consensus line with its leading pad (3): copies at most n-1 characters,
+ * returns the full length, 0 when absent, -1 on bad arguments. */
+int p7x_oprofile_get_string(const p7x_oprofile *om, int which, char *buf, size_t n);
+int p7x_oprofile_read_pressed(const uint8_t *h3f, size_t nf, const uint8_t *h3p, size_t np, const float *bg_f,
+                              p7x_oprofile **out, size_t *used_f, size_t *used_p, int64_t offs[3]);
 
 /* ------------------------------------------------------------------ devices */
 int p7x_device_count(void);                       /* 0 when no HIP device is usable */

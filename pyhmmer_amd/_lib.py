@@ -182,6 +182,11 @@ _SIGNATURES = {
     "p7x_search_block_begin": (C.c_int, [C.POINTER(PipelineCfg), _VP, _VP, _VP, C.POINTER(_VP)]),
     "p7x_search_block_finish": (C.c_int, [_VP, _VP, _VP, _VP, C.POINTER(_VP)]),
     "p7x_pending_destroy": (None, [_VP]),
+    "p7x_oprofile_write_pressed": (C.c_int, [_VP, C.POINTER(C.c_int64), _VP, C.c_size_t, C.POINTER(C.c_size_t), _VP, C.c_size_t,
+                                             C.POINTER(C.c_size_t)]),
+    "p7x_oprofile_read_pressed": (C.c_int, [_VP, C.c_size_t, _VP, C.c_size_t, _VP, C.POINTER(_VP), C.POINTER(C.c_size_t),
+                                            C.POINTER(C.c_size_t), C.POINTER(C.c_int64)]),
+    "p7x_oprofile_get_string": (C.c_int, [_VP, C.c_int, C.c_char_p, C.c_size_t]),
     "p7x_last_error": (C.c_char_p, []),
 }
 

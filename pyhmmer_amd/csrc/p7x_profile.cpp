@@ -8,8 +8,11 @@
 // striping is an SSE artefact; the device kernels build their own layouts from these arrays, and
 // p7x_oprofile_striped() re-creates the impl_sse views on demand for API parity.
 #include "p7x_internal.hpp"
+#include <algorithm>
 #include <cmath>
+#include <cstdio>
 #include <cstring>
+#include <memory>
 #include <mutex>
 
 namespace p7x {
@@ -276,6 +279,7 @@ int p7x_oprofile_create(const p7x_hmm_view *h, const float *bg_f, int32_t L, p7x
   Profile &p = om->p;
   const Alphabet &abc = Alphabet::get(h->abc_type);
   p.M = h->M; p.K = abc.K; p.Kp = abc.Kp; p.abc_type = h->abc_type; p.L = L; p.max_length = h->max_length;
+  p.mode = 1;                                  // p7_LOCAL: multihit local alignment, the only mode the pipeline configures
   p.name = h->name;
   if (h->acc)  { p.acc = h->acc;   p.has_acc = true; }
   if (h->desc) { p.desc = h->desc; p.has_desc = true; }
@@ -397,6 +401,180 @@ int64_t p7x_oprofile_striped(const p7x_oprofile *om, int which, void *out, size_
   }
 }
 
+
+} // extern "C"
+
+// ---------------------------------------------------------------- pressed profiles (.h3f / .h3p)
+// Record layouts of upstream's p7_oprofile_Write (impl_sse/io.c; reference impl_sse/io.pxd:11-16, magics in
+// patches/p7_hmmfile.c.patch:15-20), restated in SURVEY.md section 8(f) and checked byte for byte against the
+// reference's pressed fixtures (tests/test_host.py).  Little-endian, as HMMER writes on x86.
+namespace {
+constexpr uint32_t kMagicF = 0xb3e6e6f3u, kMagicP = 0xb3e6f0f3u;
+
+struct Writer {
+  uint8_t *buf; size_t cap; size_t n = 0;
+  void bytes(const void *p, size_t len) { if (buf && n + len <= cap) std::memcpy(buf + n, p, len); n += len; }
+  template <typename T> void pod(T v) { bytes(&v, sizeof(T)); }
+  void str_f(const std::string &s) { pod<int32_t>((int32_t) s.size()); bytes(s.c_str(), s.size() + 1); }          // .h3f name: always written
+  void str_p(const std::string &s, bool have) { if (!have || s.empty()) { pod<int32_t>(0); return; } str_f(s); }   // .h3p: n == 0 means absent
+  void line(const std::string &s, int M) { std::vector<char> l((size_t) M + 2, 0); std::memcpy(l.data(), s.data(), std::min(s.size(), (size_t) M + 1)); bytes(l.data(), l.size()); }
+};
+struct Rd {
+  const uint8_t *buf; size_t len; size_t n = 0; bool ok = true;
+  void bytes(void *p, size_t k) { if (n + k > len) { ok = false; return; } std::memcpy(p, buf + n, k); n += k; }
+  template <typename T> T pod() { T v{}; bytes(&v, sizeof(T)); return v; }
+  std::string str(int32_t k) { std::string s; if (k < 0 || n + (size_t) k + 1 > len) { ok = false; return s; } s.assign((const char *) buf + n, (size_t) k); n += (size_t) k + 1; return s; }
+  std::string line(int M) { std::string s; if (n + (size_t) M + 2 > len) { ok = false; return s; } s.assign((const char *) buf + n, strnlen((const char *) buf + n, (size_t) M + 2)); n += (size_t) M + 2; return s; }
+};
+
+void write_pressed(const Profile &p, const int64_t offs[3], Writer &f, Writer &q, const p7x_oprofile *om)
+{
+  const int M = p.M, Kp = p.Kp;
+  std::vector<uint8_t> tmp;
+  auto striped = [&](int which, size_t bytes) { tmp.resize(bytes); p7x_oprofile_striped(om, which, tmp.data(), bytes); return tmp.data(); };
+  // ---- MSV part
+  f.pod(kMagicF); f.pod<int32_t>(M); f.pod<int32_t>(p.abc_type);
+  f.str_f(p.name);
+  f.pod<int32_t>(p.max_length);
+  f.pod(p.tbm_b); f.pod(p.tec_b); f.pod(p.tjb_b); f.pod(p.scale_b); f.pod(p.base_b); f.pod(p.bias_b);
+  { const size_t n = (size_t) Kp * (p.Q16() + 17) * 16; f.bytes(striped(1, n), n); }
+  { const size_t n = (size_t) Kp * p.Q16() * 16; f.bytes(striped(0, n), n); }
+  f.bytes(p.evparam, sizeof(p.evparam));
+  f.bytes(offs, 3 * sizeof(int64_t));
+  { float compo[20]; std::memset(compo, 0, sizeof(compo)); std::memcpy(compo, p.compo, sizeof(float) * std::min(20, (int) MAXK)); f.bytes(compo, sizeof(compo)); }
+  f.pod(kMagicF);
+  // ---- the rest
+  q.pod(kMagicP); q.pod<int32_t>(M); q.pod<int32_t>(p.abc_type);
+  q.str_p(p.name, true); q.str_p(p.acc, p.has_acc); q.str_p(p.desc, p.has_desc);
+  q.line(p.rf, M); q.line(p.mm, M); q.line(p.cs, M); q.line(p.consensus, M);
+  { const size_t n = (size_t) 8 * p.Q8() * 8 * 2; q.bytes(striped(3, n), n); }
+  { const size_t n = (size_t) Kp * p.Q8() * 8 * 2; q.bytes(striped(2, n), n); }
+  q.bytes(p.xw, sizeof(p.xw));
+  q.pod(p.scale_w); q.pod(p.base_w); q.pod(p.ddbound_w); q.pod(p.ncj_roundoff);
+  { const size_t n = (size_t) 8 * p.Q4() * 4 * 4; q.bytes(striped(5, n), n); }
+  { const size_t n = (size_t) Kp * p.Q4() * 4 * 4; q.bytes(striped(4, n), n); }
+  q.bytes(p.xf, sizeof(p.xf));
+  q.bytes(p.cutoff, sizeof(p.cutoff));
+  q.pod(p.nj); q.pod<int32_t>(p.mode); q.pod<int32_t>(p.L);
+  q.pod(kMagicP);
+}
+} // namespace
+
+extern "C" {
+
+int p7x_oprofile_get_string(const p7x_oprofile *om, int which, char *buf, size_t n)
+{
+  if (!om || !buf || n == 0) return -1;
+  const Profile &p = om->p;
+  const std::string *s = nullptr;
+  switch (which) {
+    case 0: s = &p.name; break;
+    case 1: if (p.has_acc) s = &p.acc; break;
+    case 2: if (p.has_desc) s = &p.desc; break;
+    case 3: s = &p.consensus; break;
+    default: return -1;
+  }
+  buf[0] = 0;
+  if (!s || s->empty()) return 0;
+  std::snprintf(buf, n, "%s", s->c_str());
+  return (int) s->size();
+}
+
+int p7x_oprofile_write_pressed(const p7x_oprofile *om, const int64_t offs[3], uint8_t *h3f, size_t cap_f, size_t *len_f,
+                               uint8_t *h3p, size_t cap_p, size_t *len_p)
+{
+  if (!om || !len_f || !len_p) { set_error("p7x_oprofile_write_pressed: bad arguments"); return P7X_EINVAL; }
+  const int64_t zero[3] = {0, 0, 0};
+  Writer f{ h3f, h3f ? cap_f : 0 }, q{ h3p, h3p ? cap_p : 0 };
+  write_pressed(om->p, offs ? offs : zero, f, q, om);
+  *len_f = f.n; *len_p = q.n;
+  if ((h3f && f.n > cap_f) || (h3p && q.n > cap_p)) { set_error("p7x_oprofile_write_pressed: buffer too small"); return P7X_EINVAL; }
+  return P7X_OK;
+}
+
+int p7x_oprofile_read_pressed(const uint8_t *h3f, size_t nf, const uint8_t *h3p, size_t np, const float *bg_f,
+                              p7x_oprofile **out, size_t *used_f, size_t *used_p, int64_t offs[3])
+{
+  if (!h3f || !h3p || !bg_f || !out) { set_error("p7x_oprofile_read_pressed: bad arguments"); return P7X_EINVAL; }
+  Rd f{ h3f, nf }, q{ h3p, np };
+  auto om = std::make_unique<p7x_oprofile>();
+  Profile &p = om->p;
+  auto bad = [&](const char *what) { set_error(std::string("pressed profile: ") + what); return P7X_EFORMAT; };
+  // ---- .h3f
+  if (f.pod<uint32_t>() != kMagicF || !f.ok) return bad("bad magic in the MSV filter file (.h3f)");
+  p.M = f.pod<int32_t>(); p.abc_type = f.pod<int32_t>();
+  if (!f.ok || p.M < 1 || p.M > 100000 || (p.abc_type != P7X_AMINO && p.abc_type != P7X_DNA && p.abc_type != P7X_RNA)) return bad("bad model header (.h3f)");
+  const Alphabet &abc = Alphabet::get(p.abc_type);
+  p.K = abc.K; p.Kp = abc.Kp;
+  const int M = p.M, Kp = p.Kp;
+  p.name = f.str(f.pod<int32_t>());
+  p.max_length = f.pod<int32_t>();
+  p.tbm_b = f.pod<uint8_t>(); p.tec_b = f.pod<uint8_t>(); p.tjb_b = f.pod<uint8_t>(); p.scale_b = f.pod<float>();
+  p.base_b = f.pod<uint8_t>(); p.bias_b = f.pod<uint8_t>();
+  const int Q16 = p.Q16(), Q8 = p.Q8(), Q4 = p.Q4();
+  { std::vector<int8_t> sbv((size_t) Kp * (Q16 + 17) * 16); f.bytes(sbv.data(), sbv.size()); }      // derived from rbv: not kept
+  {
+    std::vector<uint8_t> rbv((size_t) Kp * Q16 * 16); f.bytes(rbv.data(), rbv.size());
+    p.rb.assign((size_t) Kp * (M + 1), 255);
+    if (f.ok)
+      for (int x = 0; x < Kp; ++x) for (int q2 = 0; q2 < Q16; ++q2) for (int z = 0; z < 16; ++z) {
+        const int k = q2 + 1 + z * Q16;
+        if (k <= M) p.rb[(size_t) x * (M + 1) + k] = rbv[((size_t) x * Q16 + q2) * 16 + z];
+      }
+  }
+  f.bytes(p.evparam, sizeof(p.evparam));
+  int64_t o3[3] = {0, 0, 0}; f.bytes(o3, sizeof(o3));
+  { float compo[20]; f.bytes(compo, sizeof(compo)); std::memset(p.compo, 0, sizeof(p.compo)); std::memcpy(p.compo, compo, sizeof(float) * std::min(20, (int) MAXK)); }
+  if (f.pod<uint32_t>() != kMagicF || !f.ok) return bad("truncated or corrupt record (.h3f)");
+  // ---- .h3p
+  if (q.pod<uint32_t>() != kMagicP || !q.ok) return bad("bad magic in the profile file (.h3p)");
+  if (q.pod<int32_t>() != M || q.pod<int32_t>() != p.abc_type || !q.ok) return bad(".h3f and .h3p records disagree");
+  { const int32_t n = q.pod<int32_t>(); const std::string nm = n > 0 ? q.str(n) : std::string(); if (nm != p.name) return bad(".h3f and .h3p records carry different names"); }
+  { const int32_t n = q.pod<int32_t>(); if (n > 0) { p.acc = q.str(n); p.has_acc = true; } }
+  { const int32_t n = q.pod<int32_t>(); if (n > 0) { p.desc = q.str(n); p.has_desc = true; } }
+  p.rf = q.line(M); p.mm = q.line(M); p.cs = q.line(M); p.consensus = q.line(M);
+  {
+    std::vector<int16_t> twv((size_t) 8 * Q8 * 8), rwv((size_t) Kp * Q8 * 8);
+    q.bytes(twv.data(), twv.size() * 2); q.bytes(rwv.data(), rwv.size() * 2);
+    p.tw.assign((size_t) NTRANS * (M + 1), -32768); p.rw.assign((size_t) Kp * (M + 1), -32768);
+    if (q.ok)
+      for (int q2 = 0; q2 < Q8; ++q2) for (int z = 0; z < 8; ++z) {
+        const int k = q2 + 1 + z * Q8;
+        if (k > M) continue;
+        for (int t = tBM; t <= tII; ++t) p.tw[(size_t) t * (M + 1) + k] = twv[((size_t) q2 * 7 + t) * 8 + z];
+        p.tw[(size_t) tDD * (M + 1) + k] = twv[((size_t) 7 * Q8 + q2) * 8 + z];
+        for (int x = 0; x < Kp; ++x) p.rw[(size_t) x * (M + 1) + k] = rwv[((size_t) x * Q8 + q2) * 8 + z];
+      }
+  }
+  q.bytes(p.xw, sizeof(p.xw));
+  p.scale_w = q.pod<float>(); p.base_w = q.pod<int16_t>(); p.ddbound_w = q.pod<int16_t>(); p.ncj_roundoff = q.pod<float>();
+  {
+    std::vector<float> tfv((size_t) 8 * Q4 * 4), rfv((size_t) Kp * Q4 * 4);
+    q.bytes(tfv.data(), tfv.size() * 4); q.bytes(rfv.data(), rfv.size() * 4);
+    p.tf.assign((size_t) NTRANS * (M + 1), 0.0f); p.rf_.assign((size_t) Kp * (M + 1), 0.0f);
+    if (q.ok)
+      for (int q2 = 0; q2 < Q4; ++q2) for (int z = 0; z < 4; ++z) {
+        const int k = q2 + 1 + z * Q4;
+        if (k > M) continue;
+        for (int t = tBM; t <= tII; ++t) p.tf[(size_t) t * (M + 1) + k] = tfv[((size_t) q2 * 7 + t) * 4 + z];
+        p.tf[(size_t) tDD * (M + 1) + k] = tfv[((size_t) 7 * Q4 + q2) * 4 + z];
+        for (int x = 0; x < Kp; ++x) p.rf_[(size_t) x * (M + 1) + k] = rfv[((size_t) x * Q4 + q2) * 4 + z];
+      }
+  }
+  q.bytes(p.xf, sizeof(p.xf));
+  q.bytes(p.cutoff, sizeof(p.cutoff));
+  p.nj = q.pod<float>(); p.mode = q.pod<int32_t>(); p.L = q.pod<int32_t>();
+  if (q.pod<uint32_t>() != kMagicP || !q.ok) return bad("truncated or corrupt record (.h3p)");
+  std::memset(p.bgf, 0, sizeof(p.bgf));
+  std::memcpy(p.bgf, bg_f, sizeof(float) * p.K);
+  flogsum_init();
+  attach_dev_cache(om.get());
+  if (used_f) *used_f = f.n;
+  if (used_p) *used_p = q.n;
+  if (offs) std::memcpy(offs, o3, sizeof(o3));
+  *out = om.release();
+  return P7X_OK;
+}
 
 void p7x_pipeline_cfg_default(p7x_pipeline_cfg *c)
 { // p7_pipeline_Create(NULL, ...) defaults; pyhmmer plan7.pyx:5413-5421

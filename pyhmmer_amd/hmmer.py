@@ -10,6 +10,7 @@ re-thresholded on the host.  No collective is involved.
 """
 from __future__ import annotations
 
+import os
 import threading
 from typing import Callable, Iterable, Iterator, List, Optional, Sequence, Union
 
@@ -17,7 +18,7 @@ from . import _lib
 from .easel import Alphabet, DigitalSequenceBlock, SequenceFile
 from .plan7 import HMM, OptimizedProfile, Pipeline, Profile, SequenceDatabase, TopHits
 
-__all__ = ["hmmsearch", "make_chunks", "ShardedDatabase"]
+__all__ = ["hmmsearch", "hmmpress", "make_chunks", "ShardedDatabase"]
 
 
 def make_chunks(block: DigitalSequenceBlock, n: int) -> List[DigitalSequenceBlock]:
@@ -96,6 +97,23 @@ class ShardedDatabase:
 
     def search(self, pipelines: Sequence[Pipeline], query) -> TopHits:
         return self.finish(self.begin(pipelines, query))
+
+
+def hmmpress(hmms: Iterable, output) -> int:
+    """Press HMMs into the optimized-profile database ``<output>.h3f`` + ``<output>.h3p`` (reference
+    ``hmmer/_hmmpress.py:29-66``: every model is configured for L=400, converted and written).  Returns the number of
+    models.  The ``.h3m`` (binary core models) and ``.h3i`` (SSI index) companions of upstream's ``hmmpress`` are not
+    written: searches need only the two profile files (``HMMPressedFile``)."""
+    from .plan7 import Background
+    path = os.fspath(output)
+    n = 0
+    bgs: dict = {}
+    with open(path + ".h3f", "wb") as ff, open(path + ".h3p", "wb") as fp:
+        for hmm in hmms:
+            bg = bgs.setdefault(hmm.alphabet.type_code, Background(hmm.alphabet))
+            OptimizedProfile(hmm, bg, 400).write(ff, fp)
+            n += 1
+    return n
 
 
 def hmmsearch(queries: Union[HMM, Profile, OptimizedProfile, Iterable], sequences, *, cpus: int = 0,

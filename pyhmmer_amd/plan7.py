@@ -385,6 +385,17 @@ class OptimizedProfile:
         self.consensus = hmm.consensus
         self._hmm = hmm
 
+    @classmethod
+    def _from_handle(cls, alphabet: Alphabet, handle) -> "OptimizedProfile":
+        """Wrap a ``p7x_oprofile`` that was built elsewhere (a pressed record)."""
+        self = cls.__new__(cls)
+        self.alphabet = alphabet
+        self._handle = handle
+        self._info = _lib.OprofileInfo()
+        _lib.lib().p7x_oprofile_get_info(self._handle, C.byref(self._info))
+        self._hmm = None
+        return self
+
     def __del__(self):
         h = getattr(self, "_handle", None)
         if h:
@@ -393,6 +404,34 @@ class OptimizedProfile:
             except Exception:
                 pass
             self._handle = None
+
+    def write(self, fh_filter, fh_profile, offsets=None) -> None:
+        """Write the profile in pressed form: the MSV part to ``fh_filter`` (``.h3f``) and the rest to ``fh_profile``
+        (``.h3p``), both binary file objects (reference ``OptimizedProfile.write``, ``plan7.pyx:5078-5105``).
+        ``offsets``: byte offsets of this model in the ``.h3m``, ``.h3f`` and ``.h3p`` files of a pressed
+        database (stored inside the ``.h3f`` record); default: the current positions of the two files and 0."""
+        lf, lp = C.c_size_t(), C.c_size_t()
+        st = _lib.lib().p7x_oprofile_write_pressed(self._handle, None, None, 0, C.byref(lf), None, 0, C.byref(lp))
+        if st != 0:
+            raise status_to_exception(st, "p7x_oprofile_write_pressed", _lib.last_error())
+        if offsets is None:
+            offsets = (0, fh_filter.tell(), fh_profile.tell())
+        offs = (C.c_int64 * 3)(*[int(o) for o in offsets])
+        bf, bp = (C.c_uint8 * lf.value)(), (C.c_uint8 * lp.value)()
+        st = _lib.lib().p7x_oprofile_write_pressed(self._handle, offs, bf, lf.value, C.byref(lf), bp, lp.value, C.byref(lp))
+        if st != 0:
+            raise status_to_exception(st, "p7x_oprofile_write_pressed", _lib.last_error())
+        fh_filter.write(bytes(bf))
+        fh_profile.write(bytes(bp))
+
+    def _fill_names(self) -> None:
+        buf = C.create_string_buffer(1 << 16)
+        vals = []
+        for which in range(4):
+            n = _lib.lib().p7x_oprofile_get_string(self._handle, which, buf, len(buf))
+            vals.append(buf.value.decode() if n > 0 else None)
+        self.name, self.accession, self.description = vals[0], vals[1], vals[2]
+        self.consensus = vals[3][1:] if vals[3] else None
 
     # scalars (reference plan7.pyx:4450-4620, 4726-4764)
     @property
@@ -518,6 +557,75 @@ class OptimizedProfile:
 
     def backward_parser(self, seq: DigitalSequence, device: int = 0) -> float:
         return self._one(_lib.lib().p7x_bck_parser, seq, device)
+
+
+class HMMPressedFile:
+    """Iterator over the optimized profiles of a pressed HMM database: ``<path>.h3f`` + ``<path>.h3p`` as written by
+    ``hmmpress`` (reference ``plan7.pyx:4051-4197``; the ``.h3m`` / ``.h3i`` companions are not needed to search).
+    Yields :class:`OptimizedProfile` objects whose tables are exactly the stored ones."""
+
+    def __init__(self, path, alphabet: Optional[Alphabet] = None):
+        base = os.fspath(path)
+        for ext in (".h3f", ".h3p"):
+            if not os.path.exists(base + ext):
+                raise FileNotFoundError(2, f"no such file or directory: {base + ext!r}")
+        self.name = base
+        self._f = np.fromfile(base + ".h3f", dtype=np.uint8)
+        self._p = np.fromfile(base + ".h3p", dtype=np.uint8)
+        self._pf = self._pp = 0
+        self._alphabet = alphabet
+        self._bg = {}
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+        return False
+
+    def close(self) -> None:
+        self._f = self._p = np.zeros(0, dtype=np.uint8)
+
+    def rewind(self) -> None:
+        self._pf = self._pp = 0
+
+    def __iter__(self):
+        return self
+
+    def __len__(self) -> int:
+        pf, pp = self._pf, self._pp
+        self.rewind()
+        n = sum(1 for _ in self)
+        self._pf, self._pp = pf, pp
+        return n
+
+    def __next__(self) -> "OptimizedProfile":
+        if self._pf >= self._f.shape[0]:
+            raise StopIteration
+        if self._f.shape[0] - self._pf < 12:
+            raise ValueError(f"{self.name}.h3f: truncated record")
+        abc_type = int(self._f[self._pf + 8:self._pf + 12].view(np.int32)[0])
+        abc = {3: Alphabet.amino, 2: Alphabet.dna, 1: Alphabet.rna}.get(abc_type)
+        if abc is None:
+            raise ValueError(f"{self.name}.h3f: unknown alphabet type {abc_type}")
+        alphabet = abc()
+        if self._alphabet is not None and self._alphabet != alphabet:
+            raise AlphabetMismatch(self._alphabet, alphabet)
+        bg = self._bg.setdefault(abc_type, np.ascontiguousarray(Background(alphabet).residue_frequencies, dtype=np.float32))
+        handle, uf, up = C.c_void_p(), C.c_size_t(), C.c_size_t()
+        f, p = self._f[self._pf:], self._p[self._pp:]
+        st = _lib.lib().p7x_oprofile_read_pressed(f.ctypes.data, f.shape[0], p.ctypes.data, p.shape[0], bg.ctypes.data,
+                                                  C.byref(handle), C.byref(uf), C.byref(up), None)
+        if st != 0:
+            raise ValueError(f"{self.name}: {_lib.last_error()}") if st == 7 else \
+                status_to_exception(st, "p7x_oprofile_read_pressed", _lib.last_error())
+        self._pf += uf.value
+        self._pp += up.value
+        om = OptimizedProfile._from_handle(alphabet, handle)
+        om._fill_names()
+        return om
+
+    read = __next__
 
 
 class Profile:

@@ -143,3 +143,17 @@ def test_hmmsearch_pipeline_forwards_errors_and_can_be_abandoned(models, proteom
     it = hmmer.hmmsearch(models["RREFam"], proteome)       # closing the generator early must not leak or hang
     next(it)
     it.close()
+
+
+def test_search_with_pressed_profiles_equals_search_with_text_models(models, proteome):
+    """OptimizedProfile records read from a pressed database (.h3f/.h3p) are complete queries."""
+    from conftest import GOLDEN
+    db = plan7.SequenceDatabase(proteome)
+    pli = plan7.Pipeline(proteome.alphabet)
+    for name in ("PF02826", "RREFam"):
+        with plan7.HMMPressedFile(GOLDEN / "db" / f"{name}.hmm") as pressed:
+            for om, hmm in zip(pressed, models[name]):
+                a, b = pli.search_hmm(om, db), pli.search_hmm(hmm, db)
+                assert a.stage_counts == b.stage_counts
+                assert [(h.name, h.score, h.evalue, [(d.env_from, d.env_to, d.score, d.alignment.hmm_sequence) for d in h.domains]) for h in a] == \
+                       [(h.name, h.score, h.evalue, [(d.env_from, d.env_to, d.score, d.alignment.hmm_sequence) for d in h.domains]) for h in b]

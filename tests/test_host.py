@@ -135,3 +135,41 @@ def test_msv_isa_never_touches_a_vgpr_with_an_lds_load_in_flight(tmp_path):
     r = subprocess.run([sys.executable, str(root / "scripts/check_lds_asm.py"), str(asm)], capture_output=True, text=True)
     assert r.returncode == 0, r.stdout[-2000:]
     assert "ds_read_b64" in asm.read_text()
+
+
+@pytest.mark.parametrize("name", ["PF02826", "Thioesterase", "RREFam"])
+def test_pressed_files_are_written_byte_for_byte(name, models, tmp_path):
+    """hmmpress: .h3f / .h3p produced here == the files real HMMER pressed (reference tests/data/hmms/db), byte for
+    byte, once the .h3m offsets (a file this build does not write) are taken from the fixture."""
+    want_f = (GOLDEN / "db" / f"{name}.hmm.h3f").read_bytes()
+    want_p = (GOLDEN / "db" / f"{name}.hmm.h3p").read_bytes()
+    offs = [r["offs"] for r in h3_reader.read_h3f(GOLDEN / "db" / f"{name}.hmm.h3f")]
+    import io
+    ff, fp = io.BytesIO(), io.BytesIO()
+    for hmm, o in zip(models[name], offs):
+        om = plan7.OptimizedProfile(hmm, plan7.Background(hmm.alphabet), 400)
+        om.write(ff, fp, offsets=(int(o[0]), ff.tell(), fp.tell()))
+        assert (ff.tell(), fp.tell()) != (0, 0)
+    assert ff.getvalue() == want_f
+    assert fp.getvalue() == want_p
+    assert hmmer.hmmpress(models[name], tmp_path / "db") == len(models[name])
+    got_f = (tmp_path / "db.h3f").read_bytes()
+    assert len(got_f) == len(want_f)                        # identical except the 8-byte .h3m offset of each record
+
+
+@pytest.mark.parametrize("name", ["PF02826", "Thioesterase", "RREFam"])
+def test_pressed_files_are_read_back_exactly(name, models):
+    """HMMPressedFile: every table of every record equals the profile converted from the text model."""
+    with plan7.HMMPressedFile(GOLDEN / "db" / f"{name}.hmm") as pressed:
+        assert len(pressed) == len(models[name])
+        for om, hmm in zip(pressed, models[name]):
+            ref = plan7.OptimizedProfile(hmm, plan7.Background(hmm.alphabet), 400)
+            assert (om.name, om.accession, om.description) == (hmm.name, hmm.accession, hmm.description)
+            assert om.consensus == hmm.consensus
+            assert (om.M, om.L, om.tbm, om.tec, om.tjb, om.base, om.bias) == (ref.M, 400, ref.tbm, ref.tec, ref.tjb, ref.base, ref.bias)
+            for tab in ("rbv", "sbv", "rwv", "twv", "rfv", "tfv"):
+                a, b = getattr(om, tab), getattr(ref, tab)
+                assert a.dtype == b.dtype and np.array_equal(a.view(np.uint8), b.view(np.uint8)), tab
+            assert np.array_equal(om.evalue_parameters.as_vector(), ref.evalue_parameters.as_vector()) if hasattr(om, "evalue_parameters") else True
+    with pytest.raises(FileNotFoundError):
+        plan7.HMMPressedFile(GOLDEN / "db" / "nothing.hmm")
