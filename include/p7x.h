@@ -211,6 +211,15 @@ int  p7x_search_block_finish(p7x_pending *pending, const char *const *names, con
                              const char *const *descs, p7x_tophits **out);
 void p7x_pending_destroy(p7x_pending *pending);
 
+/* hmmscan orientation (Pipeline.scan_seq / _scan_loop, plan7.pyx:6534-6677; hmmer/_hmmscan.py): search every model
+ * against the block of query sequences with cfg.mode = P7X_SCAN_MODELS (one device pass per model, nothing pruned), then
+ * transpose: out[s] (caller-provided array of nseqs pointers) receives the hit list of query sequence s, its hits
+ * named after the models, reportability tested with the running Z = models seen so far, E-values with Z = nmodels,
+ * counters per sequence (nmodels, nnodes, n_past_* = models whose filters the sequence passed). */
+int p7x_scan_collect(p7x_tophits *const *per_model, size_t nmodels, const p7x_pipeline_cfg *cfg, size_t nseqs,
+                     const char *const *seq_names, const char *const *seq_accs, const char *const *seq_descs,
+                     const int32_t *seq_lengths, p7x_tophits **out);
+
 /* Host half of p7_Pipeline for targets that already passed the Forward filter: Backward-derived domain
  * definition (p7_domaindef_ByPosteriorHeuristics, p7_domaindef.pxd:69-72), per-sequence / per-domain scores,
  * reporting thresholds, sort.  p7x_search_block calls this internally with the device parsers' output; it is

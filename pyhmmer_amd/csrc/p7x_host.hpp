@@ -96,6 +96,7 @@ int host_finish_search(const p7x_pipeline_cfg &cfg, const p7x_oprofile *om, cons
                        const uint64_t *counts, const double *ms, p7x_tophits **out, EnvelopeScorer *scorer = nullptr,
                        const DeviceRegions *regions = nullptr);
 void tophits_set_total_ms(p7x_tophits *th, double stage1_ms, double stage2_ms);
+void tophits_set_stages(p7x_tophits *th, std::vector<uint8_t> &&stage);
 float kahan_fsum(const float *v, int n);
 void host_prof_dump();
 
@@ -111,5 +112,7 @@ struct p7x_tophits {
   int M = 0;
   double ms[12]{};
   bool sorted_by_key = false;
+  bool scan_collected = false;        // built by p7x_scan_collect(): one query sequence, hits are models
+  std::vector<uint8_t> stage;         // scan mode, per-model result: last filter passed by each target (not serialised)
   int64_t nreported = 0, nincluded = 0;
 };

@@ -112,6 +112,7 @@ struct StageBufs {            // all indexed by slot unless noted
   int32_t *xC;                // [nslots] by Viterbi work-list position
   float *fwd_by_item;         // [nslots] by Forward work-list position
   int32_t *list_bias, *list_vit, *list_fwd, *list_fin;
+  uint8_t *stage;             // [nslots] last filter passed: 1 MSV, 2 bias, 3 Viterbi, 4 Forward (scan mode accounting)
   int *counters;              // [0] msv groups [1] n_bias(list_bias) [2] n_vit [3] n_fwd [4] n_fin [5..7] work counters
                               // [8] n_past_bias [9] n_past_vit(reach Forward)
 };
@@ -172,6 +173,7 @@ __global__ void decide_msv_kernel(StageBufs b, StageParams p, const int32_t *slo
     const float seq_score = (float) ((double) (usc - null1_tab[L]) / kLog2);
     const double P = d_gumbel_surv((double) seq_score, (double) p.mmu, (double) p.mlambda);
     take = !(P > p.F1);
+    b.stage[s] = take ? 1 : 0;
   }
   wave_append(&b.counters[1], b.list_bias, take, (int32_t) s);
 }
@@ -249,6 +251,7 @@ __global__ void bias_kernel(StageBufs b, StageParams p, const uint8_t *dsq, cons
     }
     to_vit = pass && (P > p.F2);
     to_fwd = pass && !(P > p.F2);
+    if (pass) b.stage[s] = to_fwd ? 3 : 2;     // P <= F2 already: the Viterbi filter is skipped and counts as passed
     }
     wave_count(&b.counters[8], to_vit || to_fwd);
     wave_append(&b.counters[2], b.list_vit, to_vit, s);
@@ -278,6 +281,7 @@ __global__ void decide_vit_kernel(StageBufs b, StageParams p, const int32_t *slo
     const float seq_score = (float) ((double) (vfsc - b.filtersc[s]) / kLog2);
     const double P = d_gumbel_surv((double) seq_score, (double) p.vmu, (double) p.vlambda);
     take = !(P > p.F2);
+    if (take) b.stage[s] = 3;
     }
     wave_append(&b.counters[3], b.list_fwd, take, s);
   }
@@ -297,6 +301,7 @@ __global__ void decide_fwd_kernel(StageBufs b, StageParams p)
       const float seq_score = (float) ((double) (fwdsc - b.filtersc[s]) / kLog2);
       const double P = d_exp_surv((double) seq_score, (double) p.ftau, (double) p.flambda);
       take = !(P > p.F3);
+      if (take) b.stage[s] = 4;
     }
     wave_append(&b.counters[4], b.list_fin, take, s);
   }
@@ -403,7 +408,7 @@ struct Workspace {
     (void) hipSetDevice(device);
     (void) hipFree(b.xJ); (void) hipFree(b.usc); (void) hipFree(b.filtersc); (void) hipFree(b.vfsc); (void) hipFree(b.fwdsc);
     (void) hipFree(b.xC); (void) hipFree(b.fwd_by_item); (void) hipFree(b.list_bias); (void) hipFree(b.list_vit);
-    (void) hipFree(b.list_fwd); (void) hipFree(b.list_fin); (void) hipFree(b.counters);
+    (void) hipFree(b.list_fwd); (void) hipFree(b.list_fin); (void) hipFree(b.counters); (void) hipFree(b.stage);
     (void) hipFree(xmx_f); (void) hipFree(xmx_b); (void) hipFree(xmx_s); (void) hipFree(xmx_off); (void) hipFree(reg_out);
     for (auto &e : ev) if (e) (void) hipEventDestroy(e);
     if (ev_sync) (void) hipEventDestroy(ev_sync);
@@ -427,6 +432,7 @@ static int get_workspace(int device, int64_t nslots, Workspace **out)
   P7X_HIP(hipMalloc(&w->b.list_bias, cap * 4)); P7X_HIP(hipMalloc(&w->b.list_vit, cap * 4));
   P7X_HIP(hipMalloc(&w->b.list_fwd, cap * 4)); P7X_HIP(hipMalloc(&w->b.list_fin, cap * 4));
   P7X_HIP(hipMalloc(&w->b.counters, 16 * 4));
+  P7X_HIP(hipMalloc(&w->b.stage, cap));
   for (auto &e : w->ev) P7X_HIP(hipEventCreate(&e));
   P7X_HIP(hipEventCreateWithFlags(&w->ev_sync, hipEventDisableTiming));
   P7X_HIP(hipStreamCreateWithFlags(&w->stream, hipStreamNonBlocking));
@@ -497,6 +503,7 @@ struct CascadeOut {
   std::vector<int32_t> reg_n, regs;       // device region scan: count per survivor (-1 range error), kRegionCap x (i, j, multi)
   std::vector<float> nexpected;
   bool have_xmx = false;
+  std::vector<uint8_t> stage;             // scan mode: last filter passed, per target (caller order)
   int counts[16]{};
   double ms[8]{};
 };
@@ -612,6 +619,13 @@ static int run_cascade(const p7x_pipeline_cfg &cfg, const p7x_oprofile *om, cons
   } else {
     P7X_HIP(hipEventRecord(ws->ev[5], s)); P7X_HIP(hipEventRecord(ws->ev[6], s));
     P7X_HIP(hipEventRecord(ws->ev_sync, s)); P7X_HIP(hipEventSynchronize(ws->ev_sync));   // our work only: other host threads share the stream
+  }
+  if (cfg.mode == P7X_SCAN_MODELS) {        // per-target accounting: which filters every (model, sequence) pair passed
+    std::vector<uint8_t> by_slot((size_t) db->nslots);
+    P7X_HIP(hipMemcpyAsync(by_slot.data(), ws->b.stage, by_slot.size(), hipMemcpyDeviceToHost, s));
+    P7X_HIP(hipEventRecord(ws->ev_sync, s)); P7X_HIP(hipEventSynchronize(ws->ev_sync));
+    out.stage.assign((size_t) db->n, 0);
+    for (int64_t sl = 0; sl < db->nslots; ++sl) out.stage[(size_t) db->h_order[sl]] = by_slot[(size_t) sl];
   }
   for (int i = 0; i < 6; ++i) { float ms = 0; (void) hipEventElapsedTime(&ms, ws->ev[i], ws->ev[i + 1]); out.ms[i] = ms; }
   { float ms = 0; (void) hipEventElapsedTime(&ms, ws->ev[0], ws->ev[7]); out.ms[7] = ms; }
@@ -977,6 +991,7 @@ int p7x_search_block_finish(p7x_pending *pd, const char *const *names, const cha
   if (!co.have_xmx && !targets.empty()) { dr.n = co.reg_n.data(); dr.regs = co.regs.data(); dr.nexpected = co.nexpected.data(); dr.cap = kRegionCap; }
   st = host_finish_search(pd->cfg, om, tg, names, accs, descs, targets, co.fwdsc.data(), co.fwd_xmx.data(), co.bck_xmx.data(),
                           co.xmx_off.data(), counts, co.ms, out, scorer.get(), dr.n ? &dr : nullptr);
+  if (st == P7X_OK && !co.stage.empty()) tophits_set_stages(*out, std::move(co.stage));
   if (st == P7X_OK) {
     // work time of this search (stage 1 + stage 2), not the time it spent queued between the stages
     const double stage2 = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t1).count();

@@ -40,6 +40,14 @@ static bool domain_includable(const p7x_pipeline_cfg &c, double domZ, float scor
   return score >= c.incdomT;
 }
 
+// the same thresholds, taken over from a configuration they were already applied to (scan mode: one model per result)
+static void apply_bit_cutoffs_from(p7x_pipeline_cfg &c, const p7x_pipeline_cfg &model_cfg)
+{
+  if (!c.use_bit_cutoffs) return;
+  c.T = model_cfg.T; c.incT = model_cfg.incT; c.domT = model_cfg.domT; c.incdomT = model_cfg.incdomT;
+  c.by_E = c.dom_by_E = c.inc_by_E = c.incdom_by_E = 0;
+}
+
 // model-specific thresholds (p7_pli_NewModelThresholds): T/domT/incT/incdomT from GA/TC/NC
 static void apply_bit_cutoffs(p7x_pipeline_cfg &c, const Profile &p)
 {
@@ -172,7 +180,8 @@ static void finish_one(const p7x_pipeline_cfg &cfg, const Profile &p, int L, flo
   if (Ld > 0 && sum_score > seq_score) { seq_score = sum_score; pre_score = pre2_score; }
 
   const double lnP = exp_logsurv(seq_score, p.evparam[P7X_FTAU], p.evparam[P7X_FLAMBDA]);
-  if (!target_reportable(cfg, Z_running, seq_score, lnP)) return;
+  // scan mode: the running Z of a query sequence is the number of models seen so far, known only to p7x_scan_collect()
+  if (cfg.mode != P7X_SCAN_MODELS && !target_reportable(cfg, Z_running, seq_score, lnP)) return;
 
   Hit &h = out.hit;
   out.have = true;
@@ -383,6 +392,7 @@ int host_finish_search(const p7x_pipeline_cfg &cfg_in, const p7x_oprofile *om, c
   return P7X_OK;
 }
 
+void tophits_set_stages(p7x_tophits *th, std::vector<uint8_t> &&stage) { th->stage = std::move(stage); }
 void tophits_set_total_ms(p7x_tophits *th, double stage1, double stage2) { th->ms[6] = stage1 + stage2; th->ms[10] = stage1; th->ms[11] = stage2; }
 
 } // namespace p7x
@@ -460,8 +470,66 @@ int p7x_tophits_get_domain(const p7x_tophits *th, int64_t i, int32_t d, p7x_doma
   o->rfline = m.rfline.empty() ? nullptr : m.rfline.c_str();
   o->mmline = m.mmline.empty() ? nullptr : m.mmline.c_str();
   o->csline = m.csline.empty() ? nullptr : m.csline.c_str();
-  o->hmmname = th->qname.c_str(); o->hmmacc = th->q_has_acc ? th->qacc.c_str() : nullptr; o->hmmdesc = th->q_has_desc ? th->qdesc.c_str() : nullptr;
-  o->sqname = h->name.c_str(); o->sqacc = h->has_acc ? h->acc.c_str() : nullptr; o->sqdesc = h->has_desc ? h->desc.c_str() : nullptr;
+  const bool scan = th->cfg.mode == P7X_SCAN_MODELS && th->scan_collected;      // hits are models, the query is the sequence
+  const char *qn = th->qname.c_str(), *qa = th->q_has_acc ? th->qacc.c_str() : nullptr, *qd = th->q_has_desc ? th->qdesc.c_str() : nullptr;
+  const char *hn = h->name.c_str(), *ha = h->has_acc ? h->acc.c_str() : nullptr, *hd = h->has_desc ? h->desc.c_str() : nullptr;
+  o->hmmname = scan ? hn : qn; o->hmmacc = scan ? ha : qa; o->hmmdesc = scan ? hd : qd;
+  o->sqname = scan ? qn : hn; o->sqacc = scan ? qa : ha; o->sqdesc = scan ? qd : hd;
+  return P7X_OK;
+}
+
+// hmmscan orientation (Pipeline._scan_loop, plan7.pyx:6624-6677): per_model[m] is the result of model m against
+// all query sequences (searched with cfg.mode = P7X_SCAN_MODELS: nothing pruned); out[s] becomes the hit list of
+// sequence s, whose hits are the models.  Reportability is applied in model order with the running Z = number of
+// models seen (p7_pli_NewModel), then the usual sort and threshold with Z = nmodels.
+int p7x_scan_collect(p7x_tophits *const *per_model, size_t nmodels, const p7x_pipeline_cfg *cfg_in, size_t nseqs,
+                     const char *const *seq_names, const char *const *seq_accs, const char *const *seq_descs,
+                     const int32_t *seq_lengths, p7x_tophits **out)
+{
+  if (!per_model || !cfg_in || !out || (nseqs && !seq_lengths)) { set_error("p7x_scan_collect: bad arguments"); return P7X_EINVAL; }
+  flogsum_init();
+  std::vector<std::unique_ptr<p7x_tophits>> res(nseqs);
+  for (size_t s = 0; s < nseqs; ++s) {
+    auto th = std::make_unique<p7x_tophits>();
+    th->cfg = *cfg_in; th->cfg.mode = P7X_SCAN_MODELS;
+    th->scan_collected = true;
+    if (seq_names && seq_names[s]) th->qname = seq_names[s];
+    if (seq_accs && seq_accs[s] && seq_accs[s][0]) { th->qacc = seq_accs[s]; th->q_has_acc = true; }
+    if (seq_descs && seq_descs[s] && seq_descs[s][0]) { th->qdesc = seq_descs[s]; th->q_has_desc = true; }
+    th->ctr.nseqs = 1; th->ctr.nres = (uint64_t) seq_lengths[s];
+    res[s] = std::move(th);
+  }
+  for (size_t m = 0; m < nmodels; ++m) {
+    const p7x_tophits *pm = per_model[m];
+    if (!pm) { set_error("p7x_scan_collect: missing per-model result"); return P7X_EINVAL; }
+    if (pm->ctr.nseqs != nseqs) { set_error("p7x_scan_collect: per-model results cover different sequence sets"); return P7X_EINVAL; }
+    for (size_t s = 0; s < nseqs; ++s) {
+      p7x_counters &c = res[s]->ctr;
+      c.nmodels += 1; c.nnodes += (uint64_t) pm->M;
+      const int stg = pm->stage.size() == nseqs ? pm->stage[s] : 0;
+      c.n_past_msv += stg >= 1; c.n_past_bias += stg >= 2; c.n_past_vit += stg >= 3; c.n_past_fwd += stg >= 4;
+    }
+    for (const Hit &h : pm->hits) {
+      if (h.seqidx < 0 || (size_t) h.seqidx >= nseqs) continue;
+      p7x_tophits &th = *res[(size_t) h.seqidx];
+      p7x_pipeline_cfg rc = th.cfg;
+      apply_bit_cutoffs_from(rc, pm->cfg);               // model-specific GA/TC/NC thresholds travel with the per-model result
+      const double Zrun = (rc.Z_setby == P7X_ZSETBY_NTARGETS) ? (double) (m + 1) : rc.Z;
+      if (!target_reportable(rc, Zrun, h.score, h.lnP)) continue;
+      Hit copy = h;
+      copy.name = pm->qname; copy.acc = pm->qacc; copy.desc = pm->qdesc; copy.has_acc = pm->q_has_acc; copy.has_desc = pm->q_has_desc;
+      copy.seqidx = (int64_t) m;
+      th.hits.push_back(std::move(copy));
+    }
+  }
+  for (size_t s = 0; s < nseqs; ++s) {
+    p7x_tophits &th = *res[s];
+    if (th.cfg.Z_setby == P7X_ZSETBY_NTARGETS) th.cfg.Z = (double) nmodels;
+    sort_by_key(th);
+    threshold(th);
+    out[s] = nullptr;
+  }
+  for (size_t s = 0; s < nseqs; ++s) out[s] = res[s].release();
   return P7X_OK;
 }
 
@@ -515,7 +583,7 @@ struct Reader {
   template <class T> void pod(T &v) { if (p + sizeof(T) > e) { ok = false; return; } std::memcpy(&v, p, sizeof(T)); p += sizeof(T); }
   void str(std::string &s) { uint32_t n = 0; pod(n); if (!ok || p + n > e) { ok = false; return; } s.assign((const char *) p, n); p += n; }
 };
-constexpr uint32_t kMagic = 0x70377876u;   // "p7xv" (format 3: twelve timing slots)
+constexpr uint32_t kMagic = 0x70377877u;   // "p7xw" (format 4: twelve timing slots, scan flag)
 
 template <class IO> void io_domain(IO &io, Domain &d)
 {
@@ -541,7 +609,7 @@ int64_t p7x_tophits_serialize(const p7x_tophits *th, void *buf, size_t cap)
   Writer w;
   uint32_t magic = kMagic; w.pod(magic);
   w.pod(th->cfg); w.pod(th->ctr);
-  w.str(th->qname); w.str(th->qacc); w.str(th->qdesc); w.pod(th->q_has_acc); w.pod(th->q_has_desc); w.pod(th->M);
+  w.str(th->qname); w.str(th->qacc); w.str(th->qdesc); w.pod(th->q_has_acc); w.pod(th->q_has_desc); w.pod(th->M); w.pod(th->scan_collected);
   for (int i = 0; i < 12; ++i) w.pod(th->ms[i]);
   const uint64_t n = th->hits.size(); w.pod(n);
   for (const Hit &hc : th->hits) {
@@ -561,7 +629,7 @@ p7x_tophits *p7x_tophits_deserialize(const void *buf, size_t n)
   if (!r.ok || magic != kMagic) { set_error("not a serialised TopHits"); return nullptr; }
   auto th = std::make_unique<p7x_tophits>();
   r.pod(th->cfg); r.pod(th->ctr);
-  r.str(th->qname); r.str(th->qacc); r.str(th->qdesc); r.pod(th->q_has_acc); r.pod(th->q_has_desc); r.pod(th->M);
+  r.str(th->qname); r.str(th->qacc); r.str(th->qdesc); r.pod(th->q_has_acc); r.pod(th->q_has_desc); r.pod(th->M); r.pod(th->scan_collected);
   for (int i = 0; i < 12; ++i) r.pod(th->ms[i]);
   uint64_t nh = 0; r.pod(nh);
   if (!r.ok) return nullptr;

@@ -18,7 +18,7 @@ from . import _lib
 from .easel import Alphabet, DigitalSequenceBlock, SequenceFile
 from .plan7 import HMM, OptimizedProfile, Pipeline, Profile, SequenceDatabase, TopHits
 
-__all__ = ["hmmsearch", "hmmpress", "make_chunks", "ShardedDatabase"]
+__all__ = ["hmmsearch", "hmmscan", "hmmpress", "make_chunks", "ShardedDatabase"]
 
 
 def make_chunks(block: DigitalSequenceBlock, n: int) -> List[DigitalSequenceBlock]:
@@ -156,19 +156,23 @@ def hmmsearch(queries: Union[HMM, Profile, OptimizedProfile, Iterable], sequence
         total = len(queries)          # type: ignore[arg-type]
     except TypeError:
         pass
+    for q, hits in _run_queries(db, pipelines, queries, pipeline_depth, feeders):
+        if callback is not None:
+            callback(q, total)
+        yield hits
 
+
+def _run_queries(db: "ShardedDatabase", pipelines: Sequence[Pipeline], queries: Iterable, pipeline_depth: int,
+                 feeders: int) -> Iterator:
+    """Yield ``(query, TopHits)`` for every query, in order, overlapping the two stages of consecutive queries."""
     if pipeline_depth <= 0:
         for q in queries:
-            hits = db.search(pipelines, q)
-            if callback is not None:
-                callback(q, total)
-            yield hits
+            yield q, db.search(pipelines, q)
         return
 
     # two-stage software pipeline over the queries.  Feeder threads (each with its own device stream) run the
-    # device stage ahead of the host stage; with two of them the latency-bound tail of one query's cascade (parsers,
-    # region scan) overlaps the next query's MSV.  Results are handed over in query order, at most
-    # pipeline_depth of them staged or in flight at any time.
+    # device stage ahead of the host stage; results are handed over in query order, at most pipeline_depth of them
+    # staged or in flight at any time.
     nfeed = max(1, min(feeders, pipeline_depth))
     lock = threading.Lock()
     ready = threading.Condition(lock)
@@ -228,10 +232,7 @@ def hmmsearch(queries: Union[HMM, Profile, OptimizedProfile, Iterable], sequence
             slots.release()
             if err is not None:
                 raise err
-            hits = db.finish(pendings)
-            if callback is not None:
-                callback(q, total)
-            yield hits
+            yield q, db.finish(pendings)
     finally:
         stop.set()
         with lock:
@@ -244,3 +245,61 @@ def hmmsearch(queries: Union[HMM, Profile, OptimizedProfile, Iterable], sequence
             if pendings:
                 for pend in pendings:
                     _lib.lib().p7x_pending_destroy(pend[0])
+
+
+def hmmscan(queries, profiles, *, cpus: int = 0, callback: Optional[Callable] = None, devices: Optional[Sequence[int]] = None,
+            pipeline_depth: int = 2, feeders: int = 1, **options) -> Iterator[TopHits]:
+    """Scan query sequences against a profile database; yields one ``TopHits`` per query sequence, in query order, whose
+    hits are the profiles (reference ``hmmer/_hmmscan.py:90-231``, ``Pipeline.scan_seq`` ``plan7.pyx:6534-6622``).
+
+    ``queries``: a ``DigitalSequence``, an iterable of them, a ``DigitalSequenceBlock`` or a digital ``SequenceFile``;
+    ``profiles``: an iterable of ``HMM`` / ``Profile`` / ``OptimizedProfile`` (``HMMFile``, ``HMMPressedFile`` ...).
+
+    The device-friendly orientation is profile-major: the query sequences are packed into one resident block, every
+    profile makes one pass over all of them (the same two-stage pipeline as ``hmmsearch``), and the per-profile results
+    are transposed into per-sequence hit lists (``p7x_scan_collect``): reportability with the running number of models,
+    E-values with ``Z`` = number of profiles, per-sequence accounting.
+    """
+    from .easel import DigitalSequence
+    from .plan7 import _P7X_SCAN_MODELS
+    import ctypes as C
+    if isinstance(queries, DigitalSequence):
+        queries = (queries,)
+    if isinstance(queries, SequenceFile):
+        if not queries.digital:
+            raise ValueError("query sequences file is not in digital mode")
+        queries = queries.read_block()
+    if not isinstance(queries, DigitalSequenceBlock):
+        seqs = list(queries)
+        if not seqs:
+            return
+        queries = DigitalSequenceBlock(seqs[0].alphabet, seqs)
+    if len(queries) == 0:
+        return
+    alphabet: Alphabet = queries.alphabet
+    if _lib.lib().p7x_device_count() < 1:
+        from .errors import DeviceUnavailable
+        raise DeviceUnavailable("hmmscan: no HIP device is usable and there is no CPU fallback")
+    devs = [devices[0]] if devices else [0]            # the query block is small by construction: one device
+    db = ShardedDatabase(queries, devs)
+    pipelines = [Pipeline(alphabet, device=d, host_threads=cpus, **options) for d in devs]
+    for p in pipelines:
+        p._mode = _P7X_SCAN_MODELS
+    per_model = [hits for _, hits in _run_queries(db, pipelines, profiles, pipeline_depth, feeders)]
+    n = len(queries)
+    out = (C.c_void_p * n)()
+    shard = db.shards[0]
+    lengths = (C.c_int32 * n)(*[len(s) for s in queries])
+    handles = (C.c_void_p * max(len(per_model), 1))(*[h._handle for h in per_model])
+    cfg = pipelines[0]._cfg()
+    st = _lib.lib().p7x_scan_collect(handles, len(per_model), C.byref(cfg), n, shard._names, shard._accs, shard._descs,
+                                     lengths, out)
+    if st != 0:
+        from .errors import status_to_exception
+        raise status_to_exception(st, "p7x_scan_collect", _lib.last_error())
+    results = [TopHits(q, C.c_void_p(out[i])) for i, q in enumerate(queries)]
+    del per_model
+    for q, hits in zip(queries, results):
+        if callback is not None:
+            callback(q, n)
+        yield hits

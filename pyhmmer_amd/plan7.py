@@ -559,6 +559,9 @@ class OptimizedProfile:
         return self._one(_lib.lib().p7x_bck_parser, seq, device)
 
 
+_P7X_SEARCH_SEQS, _P7X_SCAN_MODELS = 0, 1      # p7x.h / p7_pipeline.pxd:26-28
+
+
 class HMMPressedFile:
     """Iterator over the optimized profiles of a pressed HMM database: ``<path>.h3f`` + ``<path>.h3p`` as written by
     ``hmmpress`` (reference ``plan7.pyx:4051-4197``; the ``.h3m`` / ``.h3i`` companions are not needed to search).
@@ -1059,6 +1062,7 @@ class Pipeline:
         self.host_threads = host_threads
         self.host_envelopes = bool(host_envelopes)
         self.host_regions = bool(host_regions)
+        self._mode = _P7X_SEARCH_SEQS
         self._db_cache = None           # (id(block), packed n, device) -> SequenceDatabase
 
     def clear(self) -> None:
@@ -1086,6 +1090,7 @@ class Pipeline:
         c.host_threads = int(self.host_threads)
         c.host_envelopes = int(self.host_envelopes)
         c.host_regions = int(self.host_regions)
+        c.mode = int(self._mode)
         return c
 
     def _get_om_from_query(self, query, L: int = L_HINT) -> OptimizedProfile:
@@ -1125,6 +1130,18 @@ class Pipeline:
                 self._db_cache = (key, SequenceDatabase(sequences, device=self.device))
             database = self._db_cache[1]
         return self._search_database(om, database, query)
+
+    def scan_seq(self, query: DigitalSequence, optimized_profiles) -> TopHits:
+        """Run the pipeline with one query sequence against a collection of profiles (reference
+        ``plan7.pyx:6534-6622``).  See :func:`pyhmmer_amd.hmmer.hmmscan` for the batched form."""
+        from .hmmer import hmmscan
+        if query.alphabet != self.alphabet:
+            raise AlphabetMismatch(self.alphabet, query.alphabet)
+        opts = dict(bias_filter=self.bias_filter, null2=self.null2, seed=self.seed, Z=self.Z, domZ=self.domZ, F1=self.F1,
+                    F2=self.F2, F3=self.F3, E=self.E, T=self.T, domE=self.domE, domT=self.domT, incE=self.incE,
+                    incT=self.incT, incdomE=self.incdomE, incdomT=self.incdomT, bit_cutoffs=self.bit_cutoffs,
+                    background=self.background)
+        return next(iter(hmmscan(query, optimized_profiles, cpus=self.host_threads, devices=[self.device], **opts)))
 
     # -- the two stages of a search (``p7x_search_block_begin`` / ``_finish``).  ``hmmer.hmmsearch`` runs stage 1
     #    of the next query while stage 2 of the previous one is still busy on the host.

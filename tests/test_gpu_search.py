@@ -157,3 +157,55 @@ def test_search_with_pressed_profiles_equals_search_with_text_models(models, pro
                 assert a.stage_counts == b.stage_counts
                 assert [(h.name, h.score, h.evalue, [(d.env_from, d.env_to, d.score, d.alignment.hmm_sequence) for d in h.domains]) for h in a] == \
                        [(h.name, h.score, h.evalue, [(d.env_from, d.env_to, d.score, d.alignment.hmm_sequence) for d in h.domains]) for h in b]
+
+
+def test_hmmscan_rrefam_matches_hmmer_scan_table(models, proteome):
+    """reference test_hmmer.py:836-904 (hmmscan of the RREFam profiles) against tables/RREFam.scan.tbl, which real
+    HMMER produced from the fixture proteome: per query sequence the same models, in the same order, with the table's
+    score / bias / E-value (Z = number of profiles)."""
+    from conftest import GOLDEN
+    expected = {}
+    for row in golden_table("RREFam.scan.tbl"):
+        expected.setdefault(row[2], []).append(row)
+    nq = 0
+    for source in (models["RREFam"], plan7.HMMPressedFile(GOLDEN / "db" / "RREFam.hmm")):
+        seen = set()
+        for seq, hits in zip(proteome, hmmer.hmmscan(proteome, source)):
+            assert hits.query is seq and hits.Z == 10
+            rows = expected.get(seq.name, [])
+            assert [h.name for h in hits.reported] == [r[0] for r in rows], seq.name
+            for h, r in zip(hits.reported, rows):
+                tol = 0.3 if h.nclustered > 0 else 0.1          # stochastic-null2 hits: see DESIGN.md section 4
+                assert h.score == pytest.approx(float(r[5]), abs=tol) and h.bias == pytest.approx(float(r[6]), abs=tol)
+                assert h.evalue == pytest.approx(float(r[4]), rel=0.15 if tol == 0.1 else 0.3)
+                assert h.accession == (None if r[1] == "-" else r[1])
+                assert len(h.domains) == int(r[15]) and h.domains[0].alignment.hmm_name == h.name
+                assert h.domains[0].alignment.target_name == seq.name
+            if rows:
+                seen.add(seq.name)
+            nq += 1
+        assert seen == set(expected)
+    assert nq == 2 * len(proteome)
+
+
+def test_hmmscan_equals_transposed_hmmsearch(models, proteome):
+    """Per (model, sequence) pair scan and search run the same comparison: scores and domains agree, only the roles of
+    query and target (names, Z, E-values, accounting) differ.  Also scan_seq for a single query."""
+    sub = proteome
+    profs = models["RREFam"] + models["PF02826"]
+    by_pair = {}
+    for hmm, hits in zip(profs, hmmer.hmmsearch(profs, sub, E=1e9, domE=1e9)):
+        for h in hits:
+            by_pair[(hmm.name, h.name)] = (h.score, h.bias, [(d.env_from, d.env_to, d.score) for d in h.domains])
+    got = {}
+    all_hits = list(hmmer.hmmscan(sub, profs, E=1e9, domE=1e9))
+    for seq, hits in zip(sub, all_hits):
+        assert hits.searched_models == len(profs) and hits.searched_sequences == 1 and hits.searched_residues == len(seq)
+        assert hits.searched_nodes == sum(p.M for p in profs)
+        for h in hits:
+            got[(h.name, seq.name)] = (h.score, h.bias, [(d.env_from, d.env_to, d.score) for d in h.domains])
+    assert got == by_pair and len(got) > 10
+    q = next(s for s, hits in zip(sub, all_hits) if len(hits))
+    one = plan7.Pipeline(sub.alphabet, E=1e9, domE=1e9).scan_seq(q, profs)
+    ref = next(hits for s, hits in zip(sub, all_hits) if s is q)
+    assert [(h.name, h.score) for h in one] == [(h.name, h.score) for h in ref]
