@@ -41,6 +41,7 @@ struct DevProfile {
   // MSV: two parity tables of packed int16 pairs, [2][kTabRows][S] dwords
   int msvR = 0, msvS = 0;
   uint32_t *msv_tab = nullptr;
+  int16_t *msvw_emis = nullptr;     // msvR <= 0 (M > 478): wave-per-target MSV, [kTabRows][Mpad] bias - cost
   // Viterbi: transitions [Mpad][8] int16 (BM,MM,IM,DM,MD,MI,II,DD), emissions [kTabRows][Mpad] int16
   int vitC = 0, Mpad = 0;
   int16_t *vit_trans = nullptr;

@@ -54,6 +54,16 @@ int vit_launch(const WaveSeqArgs &a, int num_cu, hipStream_t st);
 int fwd_launch(const WaveSeqArgs &a, int num_cu, hipStream_t st);
 int bck_launch(const WaveSeqArgs &a, int num_cu, hipStream_t st);
 
+// ---- MSV for models beyond the register-resident kernels (p7x_vitfwd.hip::msv_wave_kernel), M <= 2048
+struct MsvWaveArgs {
+  int C, nrows;
+  const void *emis;         // int16 [nrows][64*C], (bias - cost) in lane-chunk order, kNegPad outside the model / pad row
+  const uint8_t *dsq; const int64_t *slot_off; const int32_t *slot_len; const uint8_t *tjb_tab;
+  int nslots, base, bias, tec, tbm;
+  int16_t *out_xJ;
+};
+int msv_wave_launch(const MsvWaveArgs &a, int num_cu, hipStream_t st);
+
 // ---- packed Viterbi filter (p7x_vitpk.hip): T lanes per target, 2P nodes per lane, for M <= 640
 struct VitPkArgs {
   const void *trans, *emis;     // vitpk_build_tables()

@@ -27,7 +27,7 @@ static void free_dev_profile(DevProfile *d)
 {
   if (!d) return;
   (void) hipSetDevice(d->device);
-  (void) hipFree(d->msv_tab); (void) hipFree(d->vit_trans); (void) hipFree(d->vit_emis);
+  (void) hipFree(d->msv_tab); (void) hipFree(d->msvw_emis); (void) hipFree(d->vit_trans); (void) hipFree(d->vit_emis);
   (void) hipFree(d->vitpk_trans); (void) hipFree(d->vitpk_emis);
   (void) hipFree(d->fwd_trans); (void) hipFree(d->fwd_emis); (void) hipFree(d->bias_eo);
   delete d;
@@ -70,6 +70,12 @@ static int get_dev_profile(const p7x_oprofile *om, DeviceCtx *ctx, DevProfile **
         ve[(size_t) x * Mpad + pos[k]] = p.rw[(size_t) x * (p.M + 1) + k];
         fe[(size_t) x * Mpad + pos[k]] = p.rf_[(size_t) x * (p.M + 1) + k];
       }
+    }
+    if (d->msvR <= 0) {     // long model: emission table of the wave-per-target MSV kernel, same node order as Viterbi's
+      std::vector<int16_t> me((size_t) kTabRows * Mpad, (int16_t) kNegPad);
+      for (int k = 1; k <= p.M; ++k)
+        for (int x = 0; x < p.Kp; ++x) me[(size_t) x * Mpad + pos[k]] = (int16_t) ((int) p.bias_b - (int) p.rb[(size_t) x * (p.M + 1) + k]);
+      P7X_HIP(hipMalloc(&d->msvw_emis, me.size() * 2)); P7X_HIP(hipMemcpy(d->msvw_emis, me.data(), me.size() * 2, hipMemcpyHostToDevice));
     }
     P7X_HIP(hipMalloc(&d->vit_trans, vt.size() * 2)); P7X_HIP(hipMemcpy(d->vit_trans, vt.data(), vt.size() * 2, hipMemcpyHostToDevice));
     P7X_HIP(hipMalloc(&d->vit_emis, ve.size() * 2));  P7X_HIP(hipMemcpy(d->vit_emis, ve.data(), ve.size() * 2, hipMemcpyHostToDevice));
@@ -470,7 +476,14 @@ static const bool g_host_regions = std::getenv("P7X_HOST_REGIONS") != nullptr;  
 // Run MSV over the whole database; leaves xJ (slot order) in ws->b.xJ.
 static int run_msv(const Profile &p, const DevProfile *dp, const p7x_seqdb *db, DeviceCtx *ctx, Workspace *ws, hipStream_t stream)
 {
-  if (dp->msvR <= 0) { set_error("model too long for the MSV kernel (M > 478 is not supported yet)"); return P7X_EINVAL; }
+  if (dp->msvR <= 0) {      // M > 478: wave-per-target kernel
+    if (!dp->msvw_emis) { set_error("model too long for the MSV kernels (M > 2048)"); return P7X_EINVAL; }
+    MsvWaveArgs w{};
+    w.C = dp->vitC; w.nrows = kTabRows; w.emis = dp->msvw_emis; w.dsq = db->d_dsq; w.slot_off = db->d_slot_off; w.slot_len = db->d_slot_len;
+    w.tjb_tab = ctx->lt.tjb; w.nslots = (int) db->nslots; w.base = p.base_b; w.bias = p.bias_b; w.tec = p.tec_b; w.tbm = p.tbm_b;
+    w.out_xJ = ws->b.xJ;
+    return msv_wave_launch(w, ctx->num_cu, stream);
+  }
   MsvArgs a{};
   a.tab = dp->msv_tab; a.tiles = db->d_tiles; a.grp_off = db->d_grp_off; a.grp_nblk = db->d_grp_nblk;
   a.slot_len = db->d_slot_len; a.tjb_tab = ctx->lt.tjb; a.ngroups = (int) db->ngroups;
@@ -517,7 +530,7 @@ static int run_cascade(const p7x_pipeline_cfg &cfg, const p7x_oprofile *om, cons
   DevProfile *dp = nullptr;
   if ((st = get_dev_profile(om, ctx, &dp)) != P7X_OK) return st;
   if (db->nslots == 0) return P7X_OK;
-  if (dp->vitC <= 0 || dp->vitC > 16) { set_error("model too long for the Forward kernel (M > 1024 is not supported yet)"); return P7X_EINVAL; }
+  if (dp->vitC <= 0 || dp->vitC > 32) { set_error("model too long for the device kernels (M > 2048)"); return P7X_EINVAL; }
   Workspace *ws = nullptr;
   if ((st = get_workspace(db->device, db->nslots, &ws)) != P7X_OK) return st;
   hipStream_t s = ws->stream;
@@ -981,7 +994,8 @@ int p7x_search_block_finish(p7x_pending *pd, const char *const *names, const cha
   const uint64_t counts[4] = { (uint64_t) co.counts[1], (uint64_t) co.counts[8], (uint64_t) co.counts[3], (uint64_t) co.counts[4] };
   int st = P7X_OK;
   std::unique_ptr<DeviceEnvelopeScorer> scorer;
-  if (!g_host_envelopes && !pd->cfg.host_envelopes && !targets.empty()) {
+  const bool env_fits = om->p.M <= 1024;        // env_kernel keeps the emission table in LDS; longer models are rescored on the host
+  if (!g_host_envelopes && !pd->cfg.host_envelopes && !targets.empty() && env_fits) {
     DeviceCtx *ctx = nullptr; DevProfile *dp = nullptr;
     if ((st = get_ctx(db->device, &ctx)) != P7X_OK || (st = get_dev_profile(om, ctx, &dp)) != P7X_OK) return st;
     scorer = std::make_unique<DeviceEnvelopeScorer>(ctx, dp, db, om->p);

@@ -104,20 +104,81 @@ __global__ void __launch_bounds__(kWsBlock) vit_kernel(const WaveSeqArgs a)
   }
 }
 
-// ======================================================================================= Forward parser
+// ======================================================================================= MSV for long models
+// The lane-per-target kernels of p7x_msv.hip keep a whole DP row in registers and stop at M = 478.  Longer models
+// (a few per cent of Pfam) take this wave-per-target form of the same recurrence: lane z owns nodes zC+1..zC+C,
+// int arithmetic with the u8 semantics of impl_sse/msvfilter.c reproduced as in msv_kernel (floor at 0 is implied by
+// the next row's max(., xB); the 255 clip can only follow a row that already reported overflow).  ~4x the
+// instructions per cell of the fast kernel: a functional fallback, bit-exact (tests/test_gpu_filters.py).
 template <int C>
+__global__ void __launch_bounds__(kWsBlock) msv_wave_kernel(const MsvWaveArgs a)
+{
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  constexpr int Mpad = 64 * C;
+  short *em = reinterpret_cast<short *>(smem);                       // [nrows][Mpad] bias - cost, kNegPad outside the model
+  {
+    const uint4 *ge = reinterpret_cast<const uint4 *>(a.emis);
+    uint4 *le = reinterpret_cast<uint4 *>(em);
+    for (int i = threadIdx.x; i < a.nrows * Mpad / 8; i += kWsBlock) le[i] = ge[i];
+  }
+  __syncthreads();
+  const int lane = threadIdx.x & 63;
+  const int nlist = a.nslots;
+  P7X_WAVE_ITEMS(it) {
+    const int slot = it;
+    const int L = rfl(a.slot_len[slot]);
+    const unsigned long long off = (unsigned long long) a.slot_off[slot];
+    const unsigned lo = (unsigned) rfl((int) (unsigned) off), hi = (unsigned) rfl((int) (unsigned) (off >> 32));
+    const uint8_t *sq = a.dsq + (((unsigned long long) hi << 32) | lo);
+    const int tjbm = rfl((int) a.tjb_tab[L]) + a.tbm;
+    int mm[C];
+#pragma unroll
+    for (int c = 0; c < C; ++c) mm[c] = 0;
+    int xJ = 0, xEmax = 0;
+    int xB = max(a.base - tjbm, 0);
+    for (int i0 = 0; i0 < L; i0 += 64) {
+      const int nrow = min(64, L - i0);
+      const uint32_t resid = (lane < nrow) ? sq[i0 + lane] : 0;
+      for (int r = 0; r < nrow; ++r) {
+        const int x = __builtin_amdgcn_readlane((int) resid, r);
+        const short *er = em + x * Mpad + lane;
+        int mp = dpp_shr1(mm[C - 1], 0);
+        int rowmax = kNegPad;
+#pragma unroll
+        for (int c = 0; c < C; ++c) {
+          const int sv = max(mp, xB) + (int) er[c * 64];
+          mp = mm[c];
+          mm[c] = sv;
+          rowmax = max(rowmax, sv);
+        }
+        const int xE = wave_max_i32(rowmax);
+        xEmax = max(xEmax, xE);
+        xJ = max(xJ, xE - a.tec);
+        xB = max(max(a.base, xJ) - tjbm, 0);
+      }
+    }
+    if (lane == 0 && L > 0) a.out_xJ[slot] = (xEmax >= 255 - a.bias) ? (int16_t) -1 : (int16_t) xJ;
+  }
+}
+
+// ======================================================================================= Forward parser
+// EG: the emission table does not fit in LDS next to the transitions (M > 1024) and is read from global memory
+// (it stays L2-resident: 30 rows x Mpad floats).
+template <int C, bool EG = false>
 __global__ void __launch_bounds__(kWsBlock) fwd_kernel(const WaveSeqArgs a)
 {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   constexpr int Mpad = 64 * C;
   float4 *tr = reinterpret_cast<float4 *>(smem);                         // [2*Mpad]
-  float *em = reinterpret_cast<float *>(smem + (size_t) Mpad * 32);      // [kTabRows][Mpad]
+  const float *em = EG ? reinterpret_cast<const float *>(a.emis) : reinterpret_cast<const float *>(smem + (size_t) Mpad * 32);      // [kTabRows][Mpad]
   {
     const float4 *gt = reinterpret_cast<const float4 *>(a.trans);
     for (int i = threadIdx.x; i < 2 * Mpad; i += kWsBlock) tr[i] = gt[i];
-    const float4 *ge = reinterpret_cast<const float4 *>(a.emis);
-    float4 *le = reinterpret_cast<float4 *>(em);
-    for (int i = threadIdx.x; i < a.nrows * Mpad / 4; i += kWsBlock) le[i] = ge[i];
+    if constexpr (!EG) {
+      const float4 *ge = reinterpret_cast<const float4 *>(a.emis);
+      float4 *le = reinterpret_cast<float4 *>(smem + (size_t) Mpad * 32);
+      for (int i = threadIdx.x; i < a.nrows * Mpad / 4; i += kWsBlock) le[i] = ge[i];
+    }
   }
   __syncthreads();
   const int lane = threadIdx.x & 63;
@@ -213,19 +274,21 @@ __global__ void __launch_bounds__(kWsBlock) fwd_kernel(const WaveSeqArgs a)
 
 // ======================================================================================= Backward parser
 // Mirror of the Forward parser, re-using Forward's per-row scale factors (upstream backward_engine).
-template <int C>
+template <int C, bool EG = false>
 __global__ void __launch_bounds__(kWsBlock) bck_kernel(const WaveSeqArgs a)
 {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   constexpr int Mpad = 64 * C;
   float4 *tr = reinterpret_cast<float4 *>(smem);
-  float *em = reinterpret_cast<float *>(smem + (size_t) Mpad * 32);
+  const float *em = EG ? reinterpret_cast<const float *>(a.emis) : reinterpret_cast<const float *>(smem + (size_t) Mpad * 32);
   {
     const float4 *gt = reinterpret_cast<const float4 *>(a.trans);
     for (int i = threadIdx.x; i < 2 * Mpad; i += kWsBlock) tr[i] = gt[i];
-    const float4 *ge = reinterpret_cast<const float4 *>(a.emis);
-    float4 *le = reinterpret_cast<float4 *>(em);
-    for (int i = threadIdx.x; i < a.nrows * Mpad / 4; i += kWsBlock) le[i] = ge[i];
+    if constexpr (!EG) {
+      const float4 *ge = reinterpret_cast<const float4 *>(a.emis);
+      float4 *le = reinterpret_cast<float4 *>(smem + (size_t) Mpad * 32);
+      for (int i = threadIdx.x; i < a.nrows * Mpad / 4; i += kWsBlock) le[i] = ge[i];
+    }
   }
   __syncthreads();
   const int lane = threadIdx.x & 63;
@@ -426,8 +489,37 @@ int vit_launch(const WaveSeqArgs &a, int num_cu, hipStream_t st) { P7X_C_SWITCH(
     case 10: return launch_ws(KERNEL<10>, a, (size_t) 64 * 10 * (32 + a.nrows * 4), num_cu, st);           \
     case 12: return launch_ws(KERNEL<12>, a, (size_t) 64 * 12 * (32 + a.nrows * 4), num_cu, st);           \
     case 16: return launch_ws(KERNEL<16>, a, (size_t) 64 * 16 * (32 + a.nrows * 4), num_cu, st);           \
-    default: set_error("model too long for the Forward/Backward kernels"); return P7X_EINVAL;               \
+    case 20: return launch_ws(KERNEL<20, true>, a, (size_t) 64 * 20 * 32, num_cu, st);                     \
+    case 24: return launch_ws(KERNEL<24, true>, a, (size_t) 64 * 24 * 32, num_cu, st);                     \
+    case 32: return launch_ws(KERNEL<32, true>, a, (size_t) 64 * 32 * 32, num_cu, st);                     \
+    default: set_error("model too long for the Forward/Backward kernels (M > 2048)"); return P7X_EINVAL;   \
   }
+
+int msv_wave_launch(const MsvWaveArgs &a, int num_cu, hipStream_t st)
+{
+  if (a.nslots <= 0) return P7X_OK;
+  auto go = [&](auto kernel) -> int {
+    const size_t lds = (size_t) 64 * a.C * a.nrows * 2;
+    if (lds > 64 * 1024) P7X_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds));
+    int per_cu = 0;
+    P7X_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, kWsBlock, lds));
+    if (per_cu < 1) per_cu = 1;
+    long grid = std::min<long>((long) num_cu * per_cu, ((long) a.nslots + 3) / 4);
+    hipLaunchKernelGGL(kernel, dim3((unsigned) std::max<long>(grid, 1)), dim3(kWsBlock), lds, st, a);
+    P7X_HIP(hipGetLastError());
+    return P7X_OK;
+  };
+  switch (a.C) {
+    case 8:  return go(msv_wave_kernel<8>);
+    case 10: return go(msv_wave_kernel<10>);
+    case 12: return go(msv_wave_kernel<12>);
+    case 16: return go(msv_wave_kernel<16>);
+    case 20: return go(msv_wave_kernel<20>);
+    case 24: return go(msv_wave_kernel<24>);
+    case 32: return go(msv_wave_kernel<32>);
+    default: set_error("no wave-per-target MSV kernel for this model length"); return P7X_EINVAL;
+  }
+}
 
 int fwd_launch(const WaveSeqArgs &a, int num_cu, hipStream_t st) { P7X_CF_SWITCH(fwd_kernel) }
 int bck_launch(const WaveSeqArgs &a, int num_cu, hipStream_t st) { P7X_CF_SWITCH(bck_kernel) }

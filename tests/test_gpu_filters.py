@@ -217,14 +217,16 @@ _PK_M = sorted({16 * p - d for p in (2, 4, 6, 8, 10, 12, 14, 15, 16, 17, 18, 19,
                {32 * p - d for p in range(11, 21) for d in (0, 1)})
 
 
-@pytest.mark.parametrize("M", sorted(set([1, 3, 64, 65, 128, 150, 192, 256, 300, 320, 384, 500, 512, 640, 641, 700, 768, 1000, 1024] + _PK_M)))
+@pytest.mark.parametrize("M", sorted(set([1, 3, 64, 65, 128, 150, 192, 256, 300, 320, 384, 479, 500, 512, 640, 641, 700, 768, 1000, 1024, 1025,
+                                          1280, 1500, 1536, 2000, 2048] + _PK_M)))
 def test_every_wavefront_kernel_instantiation_vs_oracle(M, oracle):
     hmm = random_hmm(M, seed=2000 + M)
     bg = plan7.Background(hmm.alphabet)
     blk = _model_block(hmm, 90, 6, seed=M)
     om = plan7.OptimizedProfile(hmm, bg, 400)
-    got = plan7.SequenceDatabase(blk).filters(om, msv=(M <= 478), viterbi=True, forward=True)
-    want = _oracle_scores(oracle.OracleProfile(hmm, bg, 400), blk, want=("vit", "fwd"))
+    got = plan7.SequenceDatabase(blk).filters(om, msv=True, viterbi=True, forward=True)
+    want = _oracle_scores(oracle.OracleProfile(hmm, bg, 400), blk, want=("msv", "vit", "fwd"))
+    assert np.array_equal(got["xJ"], want["msv"]), f"M={M}"      # M > 478: the wave-per-target MSV kernel
     assert np.array_equal(got["xC"], want["vit"]), f"M={M}"
     ok = np.isfinite(want["fwd"])
     assert np.array_equal(np.isfinite(got["fwd"]), ok)
