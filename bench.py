@@ -95,6 +95,21 @@ def make_workload(hmm, nseq, L, seed, planted_frac=0.001):
     return flat, offsets, lengths, np.sort(planted)
 
 
+MSV_TRAFFIC_BYTES = int((2 * 151_100 + 6_684) * 1024)      # profiles/r01_bench_pmc_traffic.md, msv_fast_kernel<136>
+
+
+def host_cpus():
+    """CPUs this job may use: affinity mask, then the cgroup quota (the GPU boxes are containers on many-core hosts)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, -(-int(quota) // int(period))))
+    except (OSError, ValueError):
+        pass
+    return max(1, n)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -140,12 +155,15 @@ def main():
     t_pack = time.perf_counter() - t0
 
     from pyhmmer_amd import hmmer
+    # the ranks of one node share its CPUs: split them instead of letting every rank start a full-size worker pool
+    local_world = int(os.environ.get("LOCAL_WORLD_SIZE", str(world)))
+    host_threads = max(2, host_cpus() // max(1, local_world))
 
     def run(nsteps):
         """nsteps searches of the same workload through the public entry point.  hmmsearch overlaps the device
         stage of query k+1 with the host stage of query k (pipeline_depth), exactly as it does for distinct queries."""
         last, acc = None, {}
-        for h in hmmer.hmmsearch((om for _ in range(nsteps)), db, pipeline_depth=args.pipeline_depth, feeders=args.feeders):
+        for h in hmmer.hmmsearch((om for _ in range(nsteps)), db, pipeline_depth=args.pipeline_depth, feeders=args.feeders, cpus=host_threads):
             last = h
             for k, v in h.timings_ms.items():
                 acc[k] = acc.get(k, 0.0) + v
@@ -213,7 +231,7 @@ def main():
                 "timed_region": "hmmer.hmmsearch over `steps` queries (the same profile each time), every query runs the complete "
                                 "search; device stage of query k+1 overlaps the host stage of query k (pipeline_depth=%d); targets "
                                 "resident in HBM (pack+upload once: %.2fs, generation %.2fs, not timed)" % (args.pipeline_depth, t_pack, t_gen),
-                "pipeline_depth": args.pipeline_depth, "feeders": args.feeders,
+                "pipeline_depth": args.pipeline_depth, "feeders": args.feeders, "host_threads_per_rank": host_threads,
                 "latency_ms_per_query": round(stage.get("total", 0.0), 3),
             },
             "stages": {
@@ -224,7 +242,11 @@ def main():
             "roofline": {
                 "kernel": "p7x::msv_kernel (lane-per-sequence MSV, p7x_msv.hip)",
                 "bound": "hbm", "achieved": round(achieved_gbs, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(achieved_gbs / HBM_PEAK_GBS, 6), "traffic": None,
+                "frac": round(achieved_gbs / HBM_PEAK_GBS, 6),
+                # HBM bytes per launch from the PMC passes committed in profiles/r01_bench_pmc_traffic.md (same command):
+                # 2 x FETCH_SIZE (gfx950 tallies 16 B/lane streaming reads at half their bytes) + WRITE_SIZE, both in KB.
+                # Only meaningful for the default workload; measured, not re-collected on every run.
+                "traffic": MSV_TRAFFIC_BYTES if (args.nseq == 1_000_000 and args.seqlen == 300 and args.hmm == "KR") else None,
                 "note": "the MSV working set (emission tables) lives in LDS; only residues stream from HBM (~1/M byte per cell), "
                         "so the binding roof is VALU issue, reported below",
                 "valu": {"msv_gcups": round(msv_cups / 1e9, 1), "ops_per_cell": MSV_OPS_PER_CELL,
