@@ -8,7 +8,7 @@ import numpy as np
 import pytest
 
 import bench
-from conftest import load_hmms, random_hmm
+from conftest import load_hmms, random_hmm, synthetic_block
 from pyhmmer_amd import easel, plan7
 from test_gpu_filters import _model_block
 
@@ -95,3 +95,43 @@ def test_long_models_search_end_to_end(M):
     a = _records(plan7.Pipeline(hmm.alphabet, E=1e3, domE=1e3).search_hmm(hmm, db))
     b = _records(plan7.Pipeline(hmm.alphabet, E=1e3, domE=1e3, host_envelopes=True, host_regions=True).search_hmm(hmm, db))
     assert a == b and sum(len(r[2]) for r in a) >= 12
+
+
+def _repeat_protein(hmm, nrep, spacer, seed):
+    """A long target: <nrep> copies of a sequence emitted by the model, separated by random spacers."""
+    rng = np.random.default_rng(seed)
+    t = hmm.transition_probabilities.astype(np.float64)
+    mat, ins = hmm.match_emissions.astype(np.float64), hmm.insert_emissions.astype(np.float64)
+    cmat = np.cumsum(mat / np.maximum(mat.sum(axis=1, keepdims=True), 1e-30), axis=1)
+    cins = np.cumsum(ins / np.maximum(ins.sum(axis=1, keepdims=True), 1e-30), axis=1)
+    ct = np.zeros((hmm.M + 1, 4))
+    s3 = np.maximum(t[:, 0:3].sum(axis=1), 1e-30)
+    ct[:, 0], ct[:, 1] = t[:, 0] / s3, (t[:, 0] + t[:, 1]) / s3
+    ct[:, 2] = t[:, 3] / np.maximum(t[:, 3] + t[:, 4], 1e-30)
+    ct[:, 3] = t[:, 5] / np.maximum(t[:, 5] + t[:, 6], 1e-30)
+    parts = []
+    for _ in range(nrep):
+        parts.append(bench.emit_from_model(hmm, rng, (cmat, cins, ct)))
+        parts.append(rng.integers(0, 20, size=spacer).astype(np.uint8))
+    return np.concatenate(parts)
+
+
+def test_very_long_targets_and_region_overflow():
+    """A 30,000-residue target with 60 domains (envelope slabs sized for long envelopes, many regions) and a target
+    with more regions than the device scan keeps (>128: the whole block falls back to the host scan); both must
+    give the host twin's answer."""
+    hmm = load_hmms("KR")[0]
+    abc = hmm.alphabet
+    seqs = [easel.DigitalSequence(abc, name="long60", sequence=_repeat_protein(hmm, 60, 250, 1)[:30000]),
+            easel.DigitalSequence(abc, name="tight4", sequence=_repeat_protein(hmm, 4, 3, 2))]
+    seqs += list(synthetic_block(200, 300, seed=3, alphabet=abc))
+    db = plan7.SequenceDatabase(easel.DigitalSequenceBlock(abc, seqs))
+    nhits, ndom = _compare(hmm, db)
+    assert nhits >= 2 and ndom >= 60
+    many = easel.DigitalSequence(abc, name="many150", sequence=_repeat_protein(hmm, 150, 120, 4))
+    assert len(many) <= 100000
+    db2 = plan7.SequenceDatabase(easel.DigitalSequenceBlock(abc, [many] + seqs[2:50]))
+    hits = plan7.Pipeline(abc).search_hmm(hmm, db2)
+    assert hits[0].name == "many150" and hits[0].nregions > 128 and len(hits[0].domains) >= 140
+    nhits2, ndom2 = _compare(hmm, db2)
+    assert ndom2 >= 140
