@@ -188,7 +188,7 @@ def _model_block(hmm, nrand, nhom, seed):
         dom = bench.emit_from_model(hmm, rng, (cmat, cins, ct))
         lo = int(rng.integers(0, max(1, len(dom) // 2)))
         hi = int(rng.integers(lo + 1, len(dom) + 1))
-        flank = rng.integers(0, 20, size=int(rng.integers(0, 50))).astype(np.uint8)
+        flank = rng.integers(0, abc.K, size=int(rng.integers(0, 50))).astype(np.uint8)
         seqs.append(easel.DigitalSequence(abc, name=f"hom{h}", sequence=np.concatenate([flank, dom[lo:hi], flank])))
     return easel.DigitalSequenceBlock(abc, seqs)
 
@@ -248,3 +248,21 @@ def test_msv_baseline_config2_full_size_vs_oracle(oracle):
         got = db.filters(om, msv=True)["xJ"]
         bad = np.nonzero(got != want)[0]
         assert bad.size == 0, (rep, bad[:10], got[bad[:10]], want[bad[:10]])
+
+
+@pytest.mark.parametrize("kind", ["dna", "rna"])
+def test_nucleotide_alphabets_through_every_filter(kind, oracle):
+    """The standard pipeline is alphabet-agnostic (Kp = 18 residue rows instead of 29)."""
+    abc = easel.Alphabet.dna() if kind == "dna" else easel.Alphabet.rna()
+    hmm = random_hmm(150, seed=77, alphabet=abc)
+    bg = plan7.Background(abc)
+    blk = _model_block(hmm, 200, 10, seed=5)
+    om = plan7.OptimizedProfile(hmm, bg, 400)
+    got = plan7.SequenceDatabase(blk).filters(om, msv=True, viterbi=True, forward=True, bias=True)
+    want = _oracle_scores(oracle.OracleProfile(hmm, bg, 400), blk)
+    assert np.array_equal(got["xJ"], want["msv"]) and np.array_equal(got["xC"], want["vit"])
+    ok = np.isfinite(want["fwd"])
+    assert np.all(np.abs(got["fwd"][ok] - want["fwd"][ok]) < FWD_TOL_NATS + 1e-5 * np.abs(want["fwd"][ok]))
+    assert np.max(np.abs(got["filtersc"] - want["bias"])) < BIAS_TOL_NATS
+    hits = plan7.Pipeline(abc, E=1e3).search_hmm(hmm, blk)
+    assert len(hits) >= 4 and all(h.domains[0].alignment.target_sequence for h in hits)
