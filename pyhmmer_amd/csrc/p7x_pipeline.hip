@@ -653,9 +653,11 @@ struct EnvBuffers {
   unsigned char *d_in = nullptr; size_t d_in_cap = 0;        // env_sq | tr_off | env_len | env_L
   unsigned char *d_out = nullptr; size_t d_out_cap = 0;      // out_sc | out_null2 | out_status | tr_n | tr_a | tr_i | tr_pp
   unsigned char *h_out = nullptr; size_t h_out_cap = 0;      // pinned mirror of d_out
+  hipStream_t stream = nullptr;                               // per host thread: concurrent host stages do not wait on each other
   ~EnvBuffers() {
     if (device < 0) return;
     (void) hipSetDevice(device);
+    if (stream) (void) hipStreamDestroy(stream);
     (void) hipFree(work); (void) hipFree(d_in); (void) hipFree(d_out);
     if (h_out) (void) hipHostFree(h_out);
   }
@@ -683,7 +685,10 @@ public:
     P7X_HIP(hipSetDevice(db_->device));
     EnvBuffers *eb = nullptr;
     for (auto &b : tl_env) if (b->device == db_->device) eb = b.get();
-    if (!eb) { tl_env.push_back(std::make_unique<EnvBuffers>()); eb = tl_env.back().get(); eb->device = db_->device; }
+    if (!eb) {
+      tl_env.push_back(std::make_unique<EnvBuffers>()); eb = tl_env.back().get(); eb->device = db_->device;
+      P7X_HIP(hipStreamCreateWithFlags(&eb->stream, hipStreamNonBlocking));
+    }
 
     // inputs
     const size_t in_bytes = (size_t) nenv * (8 + 8 + 4 + 4);
@@ -735,7 +740,7 @@ public:
       P7X_HIP(hipMalloc(&eb->d_out, cap)); eb->d_out_cap = cap;
       P7X_HIP(hipHostMalloc(reinterpret_cast<void **>(&eb->h_out), cap, hipHostMallocDefault)); eb->h_out_cap = cap;
     }
-    hipStream_t s = ctx_->stream2;
+    hipStream_t s = eb->stream;
     P7X_HIP(hipMemcpyAsync(eb->d_in, h_in.data(), in_bytes, hipMemcpyHostToDevice, s));
     EnvArgs a{};
     a.M = p_.M; a.C = C; a.K = p_.K; a.nrows = p_.Kp + 1;
@@ -766,8 +771,8 @@ public:
     res.assign((size_t) nenv, EnvelopeResult{});
     if (nenv == 0) return P7X_OK;
     P7X_HIP(hipSetDevice(db_->device));
-    P7X_HIP(hipStreamSynchronize(ctx_->stream2));
     EnvBuffers *eb = eb_;
+    P7X_HIP(hipStreamSynchronize(eb->stream));
     const size_t o_sc = o_sc_, o_n2 = o_n2_, o_st = o_st_, o_n = o_n_, o_ta = o_ta_, o_ti = o_ti_, o_tp = o_tp_;
     const int64_t *tr_off = reinterpret_cast<const int64_t *>(h_in_.data()) + nenv;
     const float *h_sc = reinterpret_cast<const float *>(eb->h_out + o_sc), *h_n2 = reinterpret_cast<const float *>(eb->h_out + o_n2);

@@ -12,6 +12,8 @@ from __future__ import annotations
 
 import os
 import threading
+from collections import deque
+from concurrent.futures import ThreadPoolExecutor
 from typing import Callable, Iterable, Iterator, List, Optional, Sequence, Union
 
 from . import _lib
@@ -220,21 +222,42 @@ def _run_queries(db: "ShardedDatabase", pipelines: Sequence[Pipeline], queries: 
     for t in threads:
         t.start()
     nxt = 0
+    # the host stage of several queries may be in flight as well (each waits for its own envelope kernel): with one
+    # feeder it runs in the caller's thread, with more a small pool finishes queries concurrently, results in order
+    pool = ThreadPoolExecutor(max_workers=nfeed, thread_name_prefix="p7x-hmmsearch-finish") if nfeed > 1 else None
+    inflight: "deque" = deque()
     try:
         while True:
             with lock:
-                while nxt not in staged and not (state["live"] == 0 and nxt >= state["issued"]):
-                    ready.wait()
-                if nxt not in staged:
-                    break
-                q, pendings, err = staged.pop(nxt)
-            nxt += 1
-            slots.release()
-            if err is not None:
-                raise err
-            yield q, db.finish(pendings)
+                while nxt not in staged and not (state["live"] == 0 and nxt >= state["issued"]) and \
+                        not (inflight and inflight[0][1].done()):
+                    ready.wait(timeout=0.002 if inflight else None)
+                item = staged.pop(nxt) if nxt in staged else None
+                drained = item is None and state["live"] == 0 and nxt >= state["issued"]
+            if item is not None:
+                q, pendings, err = item
+                nxt += 1
+                slots.release()
+                if err is not None:
+                    raise err
+                if pool is None:
+                    yield q, db.finish(pendings)
+                    continue
+                inflight.append((q, pool.submit(db.finish, pendings)))
+            while inflight and (inflight[0][1].done() or len(inflight) >= nfeed or drained):
+                q, fut = inflight.popleft()
+                yield q, fut.result()
+            if drained and not inflight:
+                break
     finally:
         stop.set()
+        if pool is not None:
+            for _, fut in inflight:
+                try:
+                    fut.result()            # results own device-side buffers: let them finish and be released
+                except BaseException:
+                    pass
+            pool.shutdown(wait=True)
         with lock:
             state["exhausted"] = True
         for t in threads:
@@ -248,7 +271,7 @@ def _run_queries(db: "ShardedDatabase", pipelines: Sequence[Pipeline], queries: 
 
 
 def hmmscan(queries, profiles, *, cpus: int = 0, callback: Optional[Callable] = None, devices: Optional[Sequence[int]] = None,
-            pipeline_depth: int = 2, feeders: int = 1, **options) -> Iterator[TopHits]:
+            pipeline_depth: int = 16, feeders: int = 8, **options) -> Iterator[TopHits]:
     """Scan query sequences against a profile database; yields one ``TopHits`` per query sequence, in query order, whose
     hits are the profiles (reference ``hmmer/_hmmscan.py:90-231``, ``Pipeline.scan_seq`` ``plan7.pyx:6534-6622``).
 
@@ -258,7 +281,9 @@ def hmmscan(queries, profiles, *, cpus: int = 0, callback: Optional[Callable] = 
     The device-friendly orientation is profile-major: the query sequences are packed into one resident block, every
     profile makes one pass over all of them (the same two-stage pipeline as ``hmmsearch``), and the per-profile results
     are transposed into per-sequence hit lists (``p7x_scan_collect``): reportability with the running number of models,
-    E-values with ``Z`` = number of profiles, per-sequence accounting.
+    E-values with ``Z`` = number of profiles, per-sequence accounting.  A query block is small next to a search
+    database, so one profile's kernels are a few wavefronts running for the length of the longest query: several profiles
+    are kept in flight on separate streams (``feeders``) to fill the device.
     """
     from .easel import DigitalSequence
     from .plan7 import _P7X_SCAN_MODELS
