@@ -441,7 +441,12 @@ static int get_workspace(int device, int64_t nslots, Workspace **out)
   P7X_HIP(hipMalloc(&w->b.stage, cap));
   for (auto &e : w->ev) P7X_HIP(hipEventCreate(&e));
   P7X_HIP(hipEventCreateWithFlags(&w->ev_sync, hipEventDisableTiming));
-  P7X_HIP(hipStreamCreateWithFlags(&w->stream, hipStreamNonBlocking));
+  {   // the cascade is the critical path of a search: its wavefronts go first when the envelope kernel of the previous
+      // query (low priority, latency bound) shares the device
+    int least = 0, greatest = 0;
+    P7X_HIP(hipDeviceGetStreamPriorityRange(&least, &greatest));
+    P7X_HIP(hipStreamCreateWithPriority(&w->stream, hipStreamNonBlocking, greatest));
+  }
   *out = w.get();
   tl_ws.push_back(std::move(w));
   return P7X_OK;
@@ -687,7 +692,9 @@ public:
     for (auto &b : tl_env) if (b->device == db_->device) eb = b.get();
     if (!eb) {
       tl_env.push_back(std::make_unique<EnvBuffers>()); eb = tl_env.back().get(); eb->device = db_->device;
-      P7X_HIP(hipStreamCreateWithFlags(&eb->stream, hipStreamNonBlocking));
+      int least = 0, greatest = 0;
+      P7X_HIP(hipDeviceGetStreamPriorityRange(&least, &greatest));
+      P7X_HIP(hipStreamCreateWithPriority(&eb->stream, hipStreamNonBlocking, least));
     }
 
     // inputs
