@@ -238,6 +238,12 @@ def main():
                 "n_targets": args.nseq, "past_msv": sc["msv"], "past_bias": sc["bias"], "past_vit": sc["vit"], "past_fwd": sc["fwd"],
                 "hits": hits_total, "reported": reported_total, "planted": int(len(planted)),
                 "device_ms": {k: round(v, 4) for k, v in stage.items()},
+                # later-stage work, reported separately from the headline: cells actually run per stage
+                "stage_gcups": {
+                    "msv": round(cells_rank / (stage["msv_kernel"] * 1e-3) / 1e9, 1),
+                    "viterbi": round(sc["bias"] * args.seqlen * hmm.M / (stage["viterbi"] * 1e-3) / 1e9, 1),
+                    "forward": round(sc["vit"] * args.seqlen * hmm.M / (stage["forward"] * 1e-3) / 1e9, 1),
+                },
             },
             "roofline": {
                 "kernel": "p7x::msv_kernel (lane-per-sequence MSV, p7x_msv.hip)",

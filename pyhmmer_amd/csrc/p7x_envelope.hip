@@ -213,8 +213,17 @@ __global__ void __launch_bounds__(kWsBlock) env_kernel(const EnvArgs a)
       store_row(Ld);
       if (lane == 0) { float *r = bx + (size_t) Ld * 6; r[0] = xE; r[1] = xN; r[2] = xJ; r[3] = xB; r[4] = xC; r[5] = sc; }
 
+      // residue x_{i+1} and Forward's scale factor of row i are fetched one row ahead (lane 0 / lane 1 of one VGPR each)
+      auto fetch_bk = [&](int i) -> float {
+        if (i < 1) return 0.0f;
+        return (lane == 0) ? (float) sq[i] : ((lane == 1) ? fx[(size_t) i * 6 + 5] : 0.0f);
+      };
+      float bk_next = fetch_bk(Ld - 1);
       for (int i = Ld - 1; i >= 1; --i) {
-        const int x = rfl((int) sq[i]);
+        const float bk = bk_next;
+        bk_next = fetch_bk(i - 1);
+        const int x = (int) __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, bk), 0));
+        const float fsc = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, bk), 1));
         const float *er = em + x * Mpad + lane;
         float me[C];
 #pragma unroll
@@ -245,7 +254,7 @@ __global__ void __launch_bounds__(kWsBlock) env_kernel(const EnvArgs a)
           for (int c = C - 1; c >= 0; --c) { mm[c] = mm[c] + dn * t_md[c]; dn = dm[c]; }
         }
         if (xB > 1.0e16f) own_scales = true;
-        sc = own_scales ? ((xB > 1.0e4f) ? xB : 1.0f) : rflf(fx[(size_t) i * 6 + 5]);
+        sc = own_scales ? ((xB > 1.0e4f) ? xB : 1.0f) : fsc;
         if (sc > 1.0f) {
           xE /= sc; xN /= sc; xJ /= sc; xB /= sc; xC /= sc;
           const float inv = (float) (1.0 / (double) sc);
@@ -285,22 +294,45 @@ __global__ void __launch_bounds__(kWsBlock) env_kernel(const EnvArgs a)
       float eN = 0.0f, eJ = 0.0f, eC = 0.0f;
       const int Q = max(2, (a.M - 1) / 4 + 1);                         // p7O_NQF(M): the striped visiting order of select_e
       const bool loopJ = ploop != 0.0f, loopE = a.xf_e_loop != 0.0f, moveE = a.xf_e_move != 0.0f, moveNJ = pmove != 0.0f;
-      for (int r = 1; r <= Ld; ++r) {
-        const float fS = rflf(fx[(size_t) r * 6 + 5]), bS = rflf(bx[(size_t) r * 6 + 5]);
-        const float totr = scaleproduct * fS;
+      // Row r+1 is fetched while row r is processed: four vector rows and the twelve special-state values (one load,
+      // lane l < 6 takes Forward's, lane 8 + l Backward's), so that no memory round trip sits on the row's critical path.
+      float nfm[C], nfi[C], nbm[C], nbi[C];
+      auto fetch_row = [&](int r, float (&a)[C], float (&b)[C], float (&c2)[C], float (&d)[C]) {
         const float *rfm = fM + (size_t) r * Mpad + lane, *rfi = fI + (size_t) r * Mpad + lane;
         const float *rbm = bM + (size_t) r * Mpad + lane, *rbi = bI + (size_t) r * Mpad + lane;
+#pragma unroll
+        for (int c = 0; c < C; ++c) { a[c] = rfm[c * 64]; b[c] = rfi[c * 64]; c2[c] = rbm[c * 64]; d[c] = rbi[c * 64]; }
+      };
+      auto fetch_x = [&](int r) -> float {
+        const int l = lane & 7;
+        const float *src = (lane < 8) ? fx + (size_t) r * 6 : bx + (size_t) r * 6;
+        return (l < 6 && lane < 16) ? src[l] : 0.0f;
+      };
+      auto xval = [&](float v, int idx) { return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), idx)); };
+      fetch_row(1, nfm, nfi, nbm, nbi);
+      float xprev = fetch_x(0), xcur = fetch_x(1);
+      for (int r = 1; r <= Ld; ++r) {
+        float cfm[C], cfi[C], cbm[C], cbi[C];
+#pragma unroll
+        for (int c = 0; c < C; ++c) { cfm[c] = nfm[c]; cfi[c] = nfi[c]; cbm[c] = nbm[c]; cbi[c] = nbi[c]; }
+        const float xthis = xcur;
+        const int rn = (r < Ld) ? r + 1 : r;                 // the last iteration re-reads its own row (harmless)
+        fetch_row(rn, nfm, nfi, nbm, nbi);
+        xcur = fetch_x(rn);
+        const float fS = xval(xthis, 5), bS = xval(xthis, 8 + 5);
+        const float totr = scaleproduct * fS;
         float ppm[C], ppi[C];
 #pragma unroll
         for (int c = 0; c < C; ++c) {
-          ppm[c] = (rfm[c * 64] * rbm[c * 64]) * totr;
-          ppi[c] = (rfi[c * 64] * rbi[c * 64]) * totr;
+          ppm[c] = (cfm[c] * cbm[c]) * totr;
+          ppi[c] = (cfi[c] * cbi[c]) * totr;
           msum[c] = ppm[c] + msum[c];
           isum[c] = ppi[c] + isum[c];
         }
-        const float ppN = rflf(fx[(size_t) (r - 1) * 6 + 1]) * rflf(bx[(size_t) r * 6 + 1]) * ploop * scaleproduct;
-        const float ppJ = rflf(fx[(size_t) (r - 1) * 6 + 2]) * rflf(bx[(size_t) r * 6 + 2]) * ploop * scaleproduct;
-        const float ppC = rflf(fx[(size_t) (r - 1) * 6 + 4]) * rflf(bx[(size_t) r * 6 + 4]) * ploop * scaleproduct;
+        const float ppN = xval(xprev, 1) * xval(xthis, 8 + 1) * ploop * scaleproduct;
+        const float ppJ = xval(xprev, 2) * xval(xthis, 8 + 2) * ploop * scaleproduct;
+        const float ppC = xval(xprev, 4) * xval(xthis, 8 + 4) * ploop * scaleproduct;
+        xprev = xthis;
         eN += ppN; eJ += ppJ; eC += ppC;
         if (own_scales) scaleproduct *= fS / bS;
 
