@@ -238,7 +238,10 @@ def _run_queries(db: "ShardedDatabase", pipelines: Sequence[Pipeline], queries: 
                 q, pendings, err = item
                 nxt += 1
                 slots.release()
-                if err is not None:
+                if err is not None:            # surfaces at the failing query's position: first the results before it
+                    while inflight:
+                        q0, fut = inflight.popleft()
+                        yield q0, fut.result()
                     raise err
                 if pool is None:
                     yield q, db.finish(pendings)

@@ -209,3 +209,21 @@ def test_hmmscan_equals_transposed_hmmsearch(models, proteome):
     one = plan7.Pipeline(sub.alphabet, E=1e9, domE=1e9).scan_seq(q, profs)
     ref = next(hits for s, hits in zip(sub, all_hits) if s is q)
     assert [(h.name, h.score) for h in one] == [(h.name, h.score) for h in ref]
+
+
+def test_concurrent_feeders_and_finishers_keep_order_and_forward_errors(models, proteome):
+    """Several searches in flight on separate streams (the hmmscan configuration) must return the results of the
+    sequential loop, in order; an error of one query surfaces at its position; abandoning the generator is clean."""
+    queries = (models["RREFam"] + models["PF02826"] + models["KR"]) * 3
+    want = [[(h.name, h.score) for h in hits] for hits in hmmer.hmmsearch(queries, proteome, pipeline_depth=0)]
+    got = [[(h.name, h.score) for h in hits] for hits in hmmer.hmmsearch(iter(queries), proteome, pipeline_depth=12, feeders=6)]
+    assert got == want
+    bad = [models["PF02826"][0]] * 5 + [models["KR"][0]] + [models["PF02826"][0]] * 5       # KR.hmm has no GA cutoffs
+    it = hmmer.hmmsearch(bad, proteome, bit_cutoffs="gathering", pipeline_depth=8, feeders=4)
+    for _ in range(5):
+        assert len(next(it)) > 0
+    with pytest.raises(errors.MissingCutoffs):
+        next(it)
+    it = hmmer.hmmsearch(queries, proteome, pipeline_depth=8, feeders=4)
+    next(it); next(it)
+    it.close()
