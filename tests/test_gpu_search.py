@@ -227,3 +227,16 @@ def test_concurrent_feeders_and_finishers_keep_order_and_forward_errors(models, 
     it = hmmer.hmmsearch(queries, proteome, pipeline_depth=8, feeders=4)
     next(it); next(it)
     it.close()
+
+
+def test_hmmscan_with_gathering_cutoffs(models, proteome):
+    """Bit-score cutoffs are model specific: in scan orientation they travel with each profile's result."""
+    hmm = models["PF02826"][0]
+    search = hmmer.hmmsearch([hmm], proteome, bit_cutoffs="gathering")
+    want = sorted(h.name for h in next(search).reported)
+    assert len(want) == 7
+    got = sorted(seq.name for seq, hits in zip(proteome, hmmer.hmmscan(proteome, [hmm], bit_cutoffs="gathering"))
+                 if [h for h in hits.reported if h.name == hmm.name])
+    assert got == want
+    with pytest.raises(errors.MissingCutoffs):
+        list(hmmer.hmmscan(proteome, [hmm, models["KR"][0]], bit_cutoffs="gathering"))
