@@ -110,6 +110,15 @@ int p7x_oprofile_get_string(const p7x_oprofile *om, int which, char *buf, size_t
 int p7x_oprofile_read_pressed(const uint8_t *h3f, size_t nf, const uint8_t *h3p, size_t np, const float *bg_f,
                               p7x_oprofile **out, size_t *used_f, size_t *used_p, int64_t offs[3]);
 
+/* FASTA text -> packed block (the input format of p7x_seqdb_create) in one pass; the reference reads sequence files
+ * through Easel's C parser (easel.pyx SequenceFile.read_block, 8168-8192).  lut[256]: digital code per character,
+ * 255 = illegal, 254 = ignored.  First call with dsq == NULL returns the sizes (nseq, nres, bytes of the string
+ * table); second call fills dsq[nres + nseq + 1], offsets/lengths[nseq], strtab (NUL-terminated name then
+ * description per record) and its two index arrays.  P7X_EFORMAT + *bad_pos on an illegal character. */
+int p7x_fasta_parse(const char *text, size_t n, const uint8_t *lut, size_t *nseq, size_t *nres, size_t *strbytes,
+                    uint8_t *dsq, int64_t *offsets, int32_t *lengths, char *strtab, int64_t *name_off, int64_t *desc_off,
+                    size_t *bad_pos);
+
 /* ------------------------------------------------------------------ devices */
 int p7x_device_count(void);                       /* 0 when no HIP device is usable */
 int p7x_device_name(int device, char *buf, size_t n);

@@ -462,6 +462,67 @@ void write_pressed(const Profile &p, const int64_t offs[3], Writer &f, Writer &q
 
 extern "C" {
 
+// FASTA text -> the packed block of the C-ABI (255 x1..xL 255 ...) in one pass over the buffer, at memory speed.
+// lut[c]: digital code of character c, 255 = illegal, 254 = ignored (white space, digits).  Call once with
+// dsq == NULL to size the outputs (nseq, nres, bytes of the string table), then again to fill them.
+// strtab receives, per record, the NUL-terminated name (first word of the header line) followed by the
+// NUL-terminated description (rest of the line, trimmed); name_off / desc_off index it.
+int p7x_fasta_parse(const char *text, size_t n, const uint8_t *lut, size_t *nseq, size_t *nres, size_t *strbytes,
+                    uint8_t *dsq, int64_t *offsets, int32_t *lengths, char *strtab, int64_t *name_off, int64_t *desc_off,
+                    size_t *bad_pos)
+{
+  if (!text || !lut || !nseq || !nres || !strbytes) { set_error("p7x_fasta_parse: bad arguments"); return P7X_EINVAL; }
+  const bool fill = dsq != nullptr;
+  if (fill && (!offsets || !lengths || !strtab || !name_off || !desc_off)) { set_error("p7x_fasta_parse: bad arguments"); return P7X_EINVAL; }
+  size_t ns = 0, nr = 0, sb = 0, pos = 0, w = 0;
+  if (fill) dsq[w] = 255;
+  ++w;
+  while (pos < n && text[pos] != '>') {                       // anything before the first record must be blank
+    const unsigned char c = (unsigned char) text[pos];
+    if (c != ' ' && c != '\t' && c != '\r' && c != '\n') { if (bad_pos) *bad_pos = pos; set_error("FASTA text does not start with '>'"); return P7X_EFORMAT; }
+    ++pos;
+  }
+  while (pos < n) {
+    // header line
+    size_t h0 = pos + 1, h1 = h0;
+    while (h1 < n && text[h1] != '\n') ++h1;
+    size_t he = h1;
+    while (he > h0 && (text[he - 1] == '\r' || text[he - 1] == ' ' || text[he - 1] == '\t')) --he;
+    size_t a = h0;
+    while (a < he && (text[a] == ' ' || text[a] == '\t')) ++a;
+    size_t b = a;
+    while (b < he && text[b] != ' ' && text[b] != '\t') ++b;
+    size_t d = b;
+    while (d < he && (text[d] == ' ' || text[d] == '\t')) ++d;
+    if (fill) {
+      name_off[ns] = (int64_t) sb; std::memcpy(strtab + sb, text + a, b - a); strtab[sb + (b - a)] = 0;
+      desc_off[ns] = (int64_t) (sb + (b - a) + 1); std::memcpy(strtab + sb + (b - a) + 1, text + d, he - d); strtab[sb + (b - a) + 1 + (he - d)] = 0;
+    }
+    sb += (b - a) + 1 + (he - d) + 1;
+    pos = h1 < n ? h1 + 1 : n;
+    // residues up to the next '>' at the start of a line
+    const size_t start = w;
+    bool bol = true;
+    while (pos < n) {
+      const unsigned char c = (unsigned char) text[pos];
+      if (bol && c == '>') break;
+      if (c == '\n') { bol = true; ++pos; continue; }
+      bol = false;
+      const uint8_t code = lut[c];
+      if (code < 254) { if (fill) dsq[w] = code; ++w; }
+      else if (code == 255) { if (bad_pos) *bad_pos = pos; set_error(std::string("invalid symbol '") + (char) c + "' in sequence data"); return P7X_EFORMAT; }
+      ++pos;
+    }
+    const size_t L = w - start;
+    if (L > 0x7fffffff) { set_error("sequence too long"); return P7X_ERANGE; }
+    if (fill) { offsets[ns] = (int64_t) start; lengths[ns] = (int32_t) L; dsq[w] = 255; }
+    ++w;
+    nr += L; ++ns;
+  }
+  *nseq = ns; *nres = nr; *strbytes = sb;
+  return P7X_OK;
+}
+
 int p7x_oprofile_get_string(const p7x_oprofile *om, int which, char *buf, size_t n)
 {
   if (!om || !buf || n == 0) return -1;

@@ -204,6 +204,13 @@ class PackedBlock:
         self.dsq, self.offsets, self.lengths = dsq, offsets, lengths
         self.n, self.total_residues = n, total
 
+    @classmethod
+    def from_arrays(cls, dsq: np.ndarray, offsets: np.ndarray, lengths: np.ndarray) -> "PackedBlock":
+        self = cls.__new__(cls)
+        self.dsq, self.offsets, self.lengths = dsq, offsets, lengths
+        self.n, self.total_residues = int(lengths.shape[0]), int(lengths.sum(dtype=np.int64))
+        return self
+
 
 class _SequenceBlock:
     __slots__ = ("_seqs", "_packed")
@@ -283,6 +290,62 @@ class DigitalSequenceBlock(_SequenceBlock):
         return self._packed
 
 
+class _LazyDigitalSequenceBlock(DigitalSequenceBlock):
+    """A block that exists only as the packed arrays the native FASTA parser produced (``p7x_fasta_parse``): a
+    million-record file becomes a searchable block without a million Python objects.  ``DigitalSequence`` objects are
+    built on demand (indexing) or all at once when the block is iterated or mutated."""
+
+    __slots__ = ("_list", "_pk", "_strtab", "_name_off", "_desc_off")
+
+    def __init__(self, alphabet: Alphabet, pk: PackedBlock, strtab: np.ndarray, name_off: np.ndarray, desc_off: np.ndarray):
+        self._list = None
+        self._pk, self._strtab, self._name_off, self._desc_off = pk, strtab, name_off, desc_off
+        self.alphabet = alphabet
+        self._packed = pk
+
+    def _cstr(self, off: int) -> str:
+        buf = self._strtab
+        end = off
+        n = buf.shape[0]
+        while end < n and buf[end] != 0:
+            end += 1
+        return bytes(buf[off:end]).decode("utf-8", "replace")
+
+    def _make(self, t: int) -> DigitalSequence:
+        pk = self._pk
+        o, L = int(pk.offsets[t]), int(pk.lengths[t])
+        return DigitalSequence(self.alphabet, name=self._cstr(int(self._name_off[t])),
+                               description=self._cstr(int(self._desc_off[t])), sequence=pk.dsq[o:o + L])
+
+    @property
+    def _seqs(self):
+        if self._list is None:
+            self._list = [self._make(t) for t in range(self._pk.n)]
+        return self._list
+
+    @_seqs.setter
+    def _seqs(self, value):
+        self._list = value
+
+    def __len__(self) -> int:
+        return self._pk.n if self._list is None else len(self._list)
+
+    def __getitem__(self, index):
+        if self._list is None and not isinstance(index, slice):
+            n = self._pk.n
+            i = index + n if index < 0 else index
+            if not 0 <= i < n:
+                raise IndexError("block index out of range")
+            return self._make(i)
+        return super().__getitem__(index)
+
+    def total_length(self) -> int:
+        return self._pk.total_residues if self._list is None else super().total_length()
+
+    def packed(self) -> PackedBlock:
+        return self._pk if self._list is None else super().packed()
+
+
 class SequenceFile:
     """FASTA reader with the reference's ``SequenceFile`` surface (``read``, ``read_block``,
     iteration, context manager).  Only the FASTA format is supported here."""
@@ -302,6 +365,7 @@ class SequenceFile:
         self.digital = digital
         self.alphabet = alphabet
         self._pending: Optional[str] = None
+        self._touched = False
         if digital and alphabet is None:
             self.alphabet = self.guess_alphabet()
             if self.alphabet is None:
@@ -321,6 +385,7 @@ class SequenceFile:
     def rewind(self) -> None:
         self._fh.seek(0)
         self._pending = None
+        self._touched = False
 
     def guess_alphabet(self) -> Optional[Alphabet]:
         pos = self._fh.tell()
@@ -341,6 +406,7 @@ class SequenceFile:
         return Alphabet.dna() if nuc >= 0.9 * n else Alphabet.amino()
 
     def _read_text(self) -> Optional[TextSequence]:
+        self._touched = True
         header = self._pending
         self._pending = None
         if header is None:
@@ -378,7 +444,35 @@ class SequenceFile:
             raise StopIteration
         return s
 
+    def _read_block_native(self) -> "DigitalSequenceBlock":
+        """Whole file -> packed block through the C parser (no per-record Python work)."""
+        import ctypes as C
+        from . import _lib
+        data = np.fromfile(self.name, dtype=np.uint8)
+        lut = self.alphabet._lut.copy()
+        for ch in b" \t\r\n0123456789":
+            lut[ch] = 254                                     # ignored inside sequence data, as Easel's sqio does
+        ns, nr, sb, bad = C.c_size_t(), C.c_size_t(), C.c_size_t(), C.c_size_t()
+        fn = _lib.lib().p7x_fasta_parse
+        st = fn(data.ctypes.data, data.shape[0], lut.ctypes.data, C.byref(ns), C.byref(nr), C.byref(sb), None, None, None,
+                None, None, None, C.byref(bad))
+        if st == 0:
+            dsq = np.empty(nr.value + ns.value + 1, dtype=np.uint8)
+            offsets, lengths = np.empty(ns.value, dtype=np.int64), np.empty(ns.value, dtype=np.int32)
+            strtab = np.empty(max(sb.value, 1), dtype=np.uint8)
+            name_off, desc_off = np.empty(ns.value, dtype=np.int64), np.empty(ns.value, dtype=np.int64)
+            st = fn(data.ctypes.data, data.shape[0], lut.ctypes.data, C.byref(ns), C.byref(nr), C.byref(sb), dsq.ctypes.data,
+                    offsets.ctypes.data, lengths.ctypes.data, strtab.ctypes.data, name_off.ctypes.data, desc_off.ctypes.data,
+                    C.byref(bad))
+        if st != 0:
+            raise ValueError(f"{self.name}: {_lib.last_error()} (byte {bad.value})")
+        self._touched = True
+        self._fh.seek(0, 2)                                   # the file is consumed
+        return _LazyDigitalSequenceBlock(self.alphabet, PackedBlock.from_arrays(dsq, offsets, lengths), strtab, name_off, desc_off)
+
     def read_block(self, sequences: Optional[int] = None, residues: Optional[int] = None):
+        if self.digital and self._own and not self._touched and sequences is None and residues is None:
+            return self._read_block_native()
         out = []
         nres = 0
         while True:

@@ -1193,19 +1193,28 @@ class SequenceDatabase:
         self.device = device
         self.alphabet = block.alphabet
         limit = 100000                                            # plan7.pyx:5421, 6218-6219
-        for s in block:
-            if len(s) > limit:
-                raise ValueError(f"sequence length over comparison pipeline limit ({limit})")
         pk = block.packed()
+        if pk.n and int(pk.lengths.max()) > limit:
+            raise ValueError(f"sequence length over comparison pipeline limit ({limit})")
         self._handle = C.c_void_p()
         st = _lib.lib().p7x_seqdb_create(device, block.alphabet.type_code, pk.dsq.ctypes.data, pk.offsets.ctypes.data,
                                          pk.lengths.ctypes.data, pk.n, C.byref(self._handle))
         if st != 0:
             raise status_to_exception(st, "p7x_seqdb_create", _lib.last_error())
         n = pk.n
-        self._names = (C.c_char_p * max(n, 1))(*[s.name.encode() for s in block])
-        self._accs = (C.c_char_p * max(n, 1))(*[(s.accession or "").encode() for s in block])
-        self._descs = (C.c_char_p * max(n, 1))(*[(s.description or "").encode() for s in block])
+        lazy = getattr(block, "_list", 0) is None          # packed-only block from the native FASTA parser
+        if lazy:
+            # name / description tables: arrays of char* into the parser's NUL-terminated string table
+            base = block._strtab.ctypes.data
+            self._name_ptrs = (block._name_off + base).astype(np.uint64)
+            self._desc_ptrs = (block._desc_off + base).astype(np.uint64)
+            self._names = C.c_void_p(self._name_ptrs.ctypes.data)
+            self._descs = C.c_void_p(self._desc_ptrs.ctypes.data)
+            self._accs = None
+        else:
+            self._names = (C.c_char_p * max(n, 1))(*[s.name.encode() for s in block])
+            self._accs = (C.c_char_p * max(n, 1))(*[(s.accession or "").encode() for s in block])
+            self._descs = (C.c_char_p * max(n, 1))(*[(s.description or "").encode() for s in block])
 
     @classmethod
     def from_packed(cls, alphabet: Alphabet, dsq: np.ndarray, offsets: np.ndarray, lengths: np.ndarray,

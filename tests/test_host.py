@@ -173,3 +173,34 @@ def test_pressed_files_are_read_back_exactly(name, models):
             assert np.array_equal(om.evalue_parameters.as_vector(), ref.evalue_parameters.as_vector()) if hasattr(om, "evalue_parameters") else True
     with pytest.raises(FileNotFoundError):
         plan7.HMMPressedFile(GOLDEN / "db" / "nothing.hmm")
+
+
+def test_native_fasta_reader_equals_python_reader(tmp_path):
+    """SequenceFile.read_block() goes through p7x_fasta_parse for digital files; record by record it must give what
+    the per-record Python reader gives (names, descriptions, residues), and reject illegal symbols."""
+    path = GOLDEN / "seqs" / "938293.PRJEB85.HG003687.faa"
+    abc = easel.Alphabet.amino()
+    with easel.SequenceFile(path, digital=True, alphabet=abc) as f:
+        fast = f.read_block()
+        assert f.read() is None                                   # consumed
+    with easel.SequenceFile(path, digital=True, alphabet=abc) as f:
+        slow = easel.DigitalSequenceBlock(abc, list(iter(f.read, None)))
+    assert type(fast).__name__ == "_LazyDigitalSequenceBlock" and len(fast) == len(slow) == 2100
+    assert fast.total_length() == slow.total_length()
+    pk_fast, pk_slow = fast.packed(), slow.packed()
+    assert np.array_equal(pk_fast.dsq, pk_slow.dsq) and np.array_equal(pk_fast.offsets, pk_slow.offsets)
+    assert np.array_equal(pk_fast.lengths, pk_slow.lengths)
+    for t in (0, 1, 17, 2099, -1):
+        a, b = fast[t], slow[t]
+        assert (a.name, a.description) == (b.name, b.description) and np.array_equal(a.sequence, b.sequence)
+    assert [s.name for s in fast[10:13]] == [s.name for s in slow[10:13]]      # slicing materialises the list
+    odd = tmp_path / "odd.fa"
+    odd.write_text("\n>s1  two  words \r\nAC DE\nfg 10\n>s2\n\n>s3 x\nWWW")
+    with easel.SequenceFile(odd, digital=True, alphabet=abc) as f:
+        blk = f.read_block()
+    assert [(s.name, s.description, len(s)) for s in blk] == [("s1", "two  words", 6), ("s2", "", 0), ("s3", "x", 3)]
+    bad = tmp_path / "bad.fa"
+    bad.write_text(">s1\nAC?DE\n")
+    with easel.SequenceFile(bad, digital=True, alphabet=abc) as f:
+        with pytest.raises(ValueError):
+            f.read_block()
