@@ -216,7 +216,7 @@ __global__ void __launch_bounds__(kMsvBlock) msv_kernel(const MsvArgs a)
 //   * when xJ rises above base the begin score moves: every register is re-biased by the increment
 //     (v_pk_sub_i16 clamp; wave-uniform branch, taken a few times per group at most).
 template <int R>
-__global__ void __launch_bounds__(kMsvBlock, (R <= 136 ? 3 : 2)) msv_fast_kernel(const MsvArgs a)
+__global__ void __launch_bounds__(kMsvBlock, (R <= 88 ? 4 : (R <= 136 ? 3 : 2))) msv_fast_kernel(const MsvArgs a)
 {
   extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
   constexpr int S = msv_stride_c(R);
