@@ -106,6 +106,29 @@ def test_no_cpu_fallback_without_a_device(libp7x, models):
         plan7.Pipeline(hmm.alphabet).search_hmm(hmm, blk)
     with pytest.raises(errors.DeviceUnavailable):
         list(hmmer.hmmsearch(hmm, blk))
+    with pytest.raises(errors.DeviceUnavailable):
+        list(hmmer.hmmscan(blk, [hmm]))
+    with pytest.raises(errors.DeviceUnavailable):
+        plan7.Pipeline(hmm.alphabet).scan_seq(blk[0], [hmm])
+
+
+def test_scan_collect_and_pending_argument_checks(libp7x):
+    """Host-only entry points of the scan / two-stage API reject bad arguments instead of crashing."""
+    cfg = _lib.PipelineCfg()
+    libp7x.p7x_pipeline_cfg_default(C.byref(cfg))
+    out = (C.c_void_p * 2)()
+    assert libp7x.p7x_scan_collect(None, 0, C.byref(cfg), 2, None, None, None, None, out) == 11
+    lengths = (C.c_int32 * 2)(5, 7)
+    names = (C.c_char_p * 2)(b"a", b"b")
+    handles = (C.c_void_p * 1)()
+    assert libp7x.p7x_scan_collect(handles, 0, C.byref(cfg), 2, names, None, None, lengths, out) == 0     # no models: empty lists
+    for i in range(2):
+        assert libp7x.p7x_tophits_nhits(out[i]) == 0
+        libp7x.p7x_tophits_destroy(out[i])
+    assert libp7x.p7x_scan_collect(handles, 1, C.byref(cfg), 2, names, None, None, lengths, out) == 11    # NULL per-model result
+    libp7x.p7x_pending_destroy(None)
+    res = C.c_void_p()
+    assert libp7x.p7x_search_block_finish(None, None, None, None, C.byref(res)) == 11
 
 
 def test_sequence_length_limit(libp7x):
