@@ -131,11 +131,20 @@ def main():
     if world != args.gpus and world > 1:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     dist = None
+    # P7X_BENCH_SHARE_DEVICE=1: rehearsal of the N > 1 path on a box with one GPU (all ranks on device 0, gloo for the
+    # few scalars that are exchanged); never used for reported numbers
+    rehearsal = os.environ.get("P7X_BENCH_SHARE_DEVICE") == "1"
+    if rehearsal:
+        local_rank = 0
+    red_dev = "cpu" if rehearsal else "cuda"
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        if rehearsal:
+            dist.init_process_group(backend="gloo")
+        else:
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the product has no CPU path (only the reported cpu_baseline runs on the host)")
 
@@ -188,10 +197,10 @@ def main():
     cells_rank = float(hmm.M) * residues
     t_max, cells_total, seqs_total = elapsed, cells_rank, float(args.nseq)
     if dist is not None:
-        buf = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        buf = torch.tensor([elapsed], dtype=torch.float64, device=red_dev)
         dist.all_reduce(buf, op=dist.ReduceOp.MAX)
         t_max = float(buf.item())
-        tot = torch.tensor([cells_rank, float(args.nseq)], dtype=torch.float64, device="cuda")
+        tot = torch.tensor([cells_rank, float(args.nseq)], dtype=torch.float64, device=red_dev)
         dist.all_reduce(tot, op=dist.ReduceOp.SUM)
         cells_total, seqs_total = float(tot[0].item()), float(tot[1].item())
         # per-GPU TopHits merged on the host of rank 0 (no data-path collective: this only moves the results)
