@@ -37,6 +37,7 @@ struct WaveSeqArgs {
   const int32_t *list;      // slots to process (NULL: 0..nlist-1)
   int nlist;
   const int *nlist_ptr;     // if non-NULL the list length is read from device memory (no host sync between stages)
+  const int *abort_flag;    // optional: non-zero on the device = skip all work (buffers not sized for this list)
   int nrows;                // residue rows in the emission table (Kp + 1)
   int *counter;
   // Viterbi

@@ -313,6 +313,27 @@ __global__ void decide_fwd_kernel(StageBufs b, StageParams p)
   }
 }
 
+// ---------------------------------------------------------------------------- layout of the survivors' row blocks
+// Exclusive scan of (L+1)*6 floats over the Forward survivors, so that the rows pass, Backward and the region scan
+// can follow the filters without the host learning the number of survivors first.  One block; flags[0] is raised
+// when there are more survivors than the workspace was sized for (the host then grows it and repeats the tail).
+__global__ void __launch_bounds__(256) layout_rows_kernel(const int *nfin_ptr, const int32_t *list_fin, const int32_t *slot_len,
+                                                          int64_t *xmx_off, int cap_items, int *flags)
+{
+  __shared__ long long part[256];
+  const int n = *nfin_ptr;
+  if (n > cap_items) { if (threadIdx.x == 0) flags[0] = 1; return; }
+  const int per = (n + 255) / 256, lo = threadIdx.x * per, hi = min(n, lo + per);
+  long long sum = 0;
+  for (int i = lo; i < hi; ++i) sum += (long long) (slot_len[list_fin[i]] + 1) * 6;
+  part[threadIdx.x] = sum;
+  __syncthreads();
+  if (threadIdx.x == 0) { long long run = 0; for (int t = 0; t < 256; ++t) { const long long v = part[t]; part[t] = run; run += v; } }
+  __syncthreads();
+  long long run = part[threadIdx.x];
+  for (int i = lo; i < hi; ++i) { xmx_off[i] = run; run += (long long) (slot_len[list_fin[i]] + 1) * 6; }
+}
+
 // ---------------------------------------------------------------------------- regions (p7_DomainDecoding + region scan)
 // One wavefront per Forward survivor.  The parsers' special-state rows stay on the device: the posterior
 // begin/end/occupancy terms are formed lane-parallel, their running sums and the trigger scan run in upstream's
@@ -322,7 +343,8 @@ __global__ void decide_fwd_kernel(StageBufs b, StageParams p)
 constexpr int kRegionCap = 128;     // regions kept per target; more than that falls back to the host scan
 
 struct RegionArgs {
-  int nitems;
+  const int *nitems_ptr;      // number of Forward survivors, on the device
+  const int *abort_flag;      // raised by layout_rows_kernel when the buffers are too small: do nothing
   const int32_t *list;        // slot of item
   const int32_t *slot_len;
   const float *fx, *bx;       // parser rows, (L+1) x [E,N,J,B,C,SCALE]
@@ -339,7 +361,8 @@ __global__ void __launch_bounds__(256) regions_kernel(const RegionArgs a)
   const int wave = __builtin_amdgcn_readfirstlane((int) (blockIdx.x * 4 + (threadIdx.x >> 6)));
   const int nwaves = (int) gridDim.x * 4;
   const float rt1 = 0.25f, rt2 = 0.10f, rt3 = 0.20f;                         // p7_domaindef.pxd:39-41
-  for (int it = wave; it < a.nitems; it += nwaves) {
+  const int nitems = (a.abort_flag && *a.abort_flag) ? 0 : *a.nitems_ptr;
+  for (int it = wave; it < nitems; it += nwaves) {
     const int L = __builtin_amdgcn_readfirstlane(a.slot_len[a.list[it]]);
     const long long off = a.xmx_off[it];
     const float *fx = a.fx + off, *bx = a.bx + off;
@@ -405,7 +428,9 @@ struct Workspace {
   int device = -1; int64_t cap_slots = 0;
   StageBufs b{};
   float *xmx_f = nullptr, *xmx_b = nullptr, *xmx_s = nullptr; int64_t xmx_cap = 0; int64_t *xmx_off = nullptr; int64_t xmx_off_cap = 0;
-  int32_t *reg_out = nullptr;      // [cap][kRegionCap*3 + 2]: regions | count | nexpected bits, per survivor
+  int32_t *reg_out = nullptr;      // [fin_cap][kRegionCap*3 + 2]: regions | count | nexpected bits, per survivor
+  float *bck_sc = nullptr;         // [fin_cap] Backward scores (not used by the pipeline)
+  int64_t fin_cap = 0;             // Forward survivors the row buffers are sized for
   hipEvent_t ev[8]{};
   hipEvent_t ev_sync = nullptr;
   hipStream_t stream = nullptr;     // one stream per host thread driving cascades: concurrent searches overlap on the device
@@ -415,7 +440,7 @@ struct Workspace {
     (void) hipFree(b.xJ); (void) hipFree(b.usc); (void) hipFree(b.filtersc); (void) hipFree(b.vfsc); (void) hipFree(b.fwdsc);
     (void) hipFree(b.xC); (void) hipFree(b.fwd_by_item); (void) hipFree(b.list_bias); (void) hipFree(b.list_vit);
     (void) hipFree(b.list_fwd); (void) hipFree(b.list_fin); (void) hipFree(b.counters); (void) hipFree(b.stage);
-    (void) hipFree(xmx_f); (void) hipFree(xmx_b); (void) hipFree(xmx_s); (void) hipFree(xmx_off); (void) hipFree(reg_out);
+    (void) hipFree(xmx_f); (void) hipFree(xmx_b); (void) hipFree(xmx_s); (void) hipFree(xmx_off); (void) hipFree(reg_out); (void) hipFree(bck_sc);
     for (auto &e : ev) if (e) (void) hipEventDestroy(e);
     if (ev_sync) (void) hipEventDestroy(ev_sync);
     if (stream) (void) hipStreamDestroy(stream);
@@ -568,64 +593,76 @@ static int run_cascade(const p7x_pipeline_cfg &cfg, const p7x_oprofile *om, cons
     hipLaunchKernelGGL(decide_fwd_kernel, dim3(ctx->num_cu), dim3(256), 0, s, ws->b, sp);
   }
   P7X_HIP(hipEventRecord(ws->ev[4], s));
-  P7X_HIP(hipMemcpyAsync(out.counts, ws->b.counters, 16 * 4, hipMemcpyDeviceToHost, s));
-  P7X_HIP(hipEventRecord(ws->ev_sync, s)); P7X_HIP(hipEventSynchronize(ws->ev_sync));   // our work only: other host threads share the stream
-  // ---- survivors: Forward again with the special-state rows kept, then Backward
-  const int nfin = out.counts[4];
+  // ---- survivors: Forward again with the special-state rows kept, Backward, region scan -- still without the host:
+  //      the buffers are sized for fin_cap survivors (the fin_cap longest targets bound their rows), the kernels read
+  //      the survivor count from device memory, and only then does the host look.
+  int nfin = 0;
+  int64_t tot = 0;
+  for (int attempt = 0; ; ++attempt) {
+    int64_t want_cap = std::min<int64_t>(db->nslots, std::max<int64_t>(4096, db->nslots / 64));
+    if (attempt > 0) want_cap = std::min<int64_t>(db->nslots, std::max<int64_t>(want_cap, (int64_t) nfin));
+    int64_t rows = 0;                                        // slots are sorted by decreasing length
+    for (int64_t sl = 0; sl < want_cap; ++sl) rows += (int64_t) db->h_len[db->h_order[sl]] + 1;
+    const int64_t want_floats = rows * 6;
+    if (want_floats > ws->xmx_cap) {
+      (void) hipFree(ws->xmx_f); (void) hipFree(ws->xmx_b); (void) hipFree(ws->xmx_s); ws->xmx_f = ws->xmx_b = ws->xmx_s = nullptr;
+      P7X_HIP(hipMalloc(&ws->xmx_f, (size_t) want_floats * 4)); P7X_HIP(hipMalloc(&ws->xmx_b, (size_t) want_floats * 4));
+      P7X_HIP(hipMalloc(&ws->xmx_s, (size_t) want_floats * 4));
+      ws->xmx_cap = want_floats;
+    }
+    if (want_cap > ws->fin_cap) {
+      (void) hipFree(ws->xmx_off); (void) hipFree(ws->reg_out); (void) hipFree(ws->bck_sc);
+      ws->xmx_off = nullptr; ws->reg_out = nullptr; ws->bck_sc = nullptr;
+      P7X_HIP(hipMalloc(&ws->xmx_off, (size_t) want_cap * 8));
+      P7X_HIP(hipMalloc(&ws->reg_out, (size_t) want_cap * (kRegionCap * 3 + 2) * 4));
+      P7X_HIP(hipMalloc(&ws->bck_sc, (size_t) want_cap * 4));
+      ws->fin_cap = want_cap;
+    }
+    const int64_t cap = ws->fin_cap;
+    P7X_HIP(hipMemsetAsync(&ws->b.counters[12], 0, 4, s));
+    hipLaunchKernelGGL(layout_rows_kernel, dim3(1), dim3(256), 0, s, &ws->b.counters[4], ws->b.list_fin, db->d_slot_len, ws->xmx_off,
+                       (int) std::min<int64_t>(cap, INT_MAX), &ws->b.counters[12]);
+    P7X_HIP(hipMemsetAsync(&ws->b.counters[5], 0, 3 * 4, s));
+    WaveSeqArgs a = ws_args(p, dp, db, ctx);
+    a.trans = dp->fwd_trans; a.emis = dp->fwd_emis; a.list = ws->b.list_fin; a.nlist_ptr = &ws->b.counters[4];
+    a.nlist = (int) std::min<int64_t>(cap, INT_MAX);          // sizes the grid only
+    a.counter = &ws->b.counters[5]; a.out_sc = ws->b.fwd_by_item; a.xmx = ws->xmx_f; a.xmx_off = ws->xmx_off;
+    a.abort_flag = &ws->b.counters[12];
+    if ((st = fwd_launch(a, ctx->num_cu, s)) != P7X_OK) return st;
+    if (attempt == 0) P7X_HIP(hipEventRecord(ws->ev[5], s));
+    a.counter = &ws->b.counters[6]; a.out_sc = ws->bck_sc; a.xmx = ws->xmx_b; a.fwd_xmx = ws->xmx_f;
+    if ((st = bck_launch(a, ctx->num_cu, s)) != P7X_OK) return st;
+    {   // posterior decoding of the special states and the region scan, on the rows where they are
+      RegionArgs ra{};
+      ra.nitems_ptr = &ws->b.counters[4]; ra.abort_flag = &ws->b.counters[12];
+      ra.list = ws->b.list_fin; ra.slot_len = db->d_slot_len; ra.fx = ws->xmx_f; ra.bx = ws->xmx_b;
+      ra.xmx_off = ws->xmx_off; ra.scratch = ws->xmx_s;
+      ra.out_regs = ws->reg_out; ra.out_n = ws->reg_out + (size_t) cap * kRegionCap * 3;
+      ra.out_nexpected = reinterpret_cast<float *>(ra.out_n + cap);
+      hipLaunchKernelGGL(regions_kernel, dim3((unsigned) (ctx->num_cu * 4)), dim3(256), 0, s, ra);
+      P7X_HIP(hipGetLastError());
+    }
+    if (attempt == 0) P7X_HIP(hipEventRecord(ws->ev[6], s));
+    P7X_HIP(hipMemcpyAsync(out.counts, ws->b.counters, 16 * 4, hipMemcpyDeviceToHost, s));
+    P7X_HIP(hipEventRecord(ws->ev_sync, s)); P7X_HIP(hipEventSynchronize(ws->ev_sync));   // our work only: other host threads share the stream
+    nfin = out.counts[4];
+    if (out.counts[12] == 0) break;                            // everything fitted
+    if (attempt > 0) { set_error("row buffers could not be sized for the Forward survivors"); return P7X_EMEM; }
+  }
   out.fin_slots.resize(nfin);
   out.usc.resize(nfin); out.filtersc.resize(nfin); out.vfsc.resize(nfin); out.fwdsc.resize(nfin); out.xmx_off.resize(nfin);
   if (nfin > 0) {
+    const int64_t cap = ws->fin_cap;
+    out.regs.resize((size_t) nfin * kRegionCap * 3); out.reg_n.resize(nfin); out.nexpected.resize(nfin);
     P7X_HIP(hipMemcpyAsync(out.fin_slots.data(), ws->b.list_fin, (size_t) nfin * 4, hipMemcpyDeviceToHost, s));
-    P7X_HIP(hipEventRecord(ws->ev_sync, s)); P7X_HIP(hipEventSynchronize(ws->ev_sync));
-    std::sort(out.fin_slots.begin(), out.fin_slots.end());         // deterministic order
-    P7X_HIP(hipMemcpyAsync(ws->b.list_fin, out.fin_slots.data(), (size_t) nfin * 4, hipMemcpyHostToDevice, s));
-    int64_t tot = 0;
-    for (int i = 0; i < nfin; ++i) {
-      out.xmx_off[i] = tot;
-      tot += (int64_t) (db->h_len[db->h_order[out.fin_slots[i]]] + 1) * 6;
-    }
-    if (tot > ws->xmx_cap) {
-      (void) hipFree(ws->xmx_f); (void) hipFree(ws->xmx_b); (void) hipFree(ws->xmx_s); ws->xmx_f = ws->xmx_b = ws->xmx_s = nullptr;
-      P7X_HIP(hipMalloc(&ws->xmx_f, (size_t) tot * 4)); P7X_HIP(hipMalloc(&ws->xmx_b, (size_t) tot * 4));
-      P7X_HIP(hipMalloc(&ws->xmx_s, (size_t) tot * 4));
-      ws->xmx_cap = tot;
-    }
-    if (nfin > ws->xmx_off_cap) {
-      (void) hipFree(ws->xmx_off); (void) hipFree(ws->reg_out); ws->xmx_off = nullptr; ws->reg_out = nullptr;
-      P7X_HIP(hipMalloc(&ws->xmx_off, (size_t) nfin * 8)); ws->xmx_off_cap = nfin;
-      P7X_HIP(hipMalloc(&ws->reg_out, (size_t) nfin * (kRegionCap * 3 + 2) * 4));
-    }
-    P7X_HIP(hipMemcpyAsync(ws->xmx_off, out.xmx_off.data(), (size_t) nfin * 8, hipMemcpyHostToDevice, s));
-    P7X_HIP(hipMemsetAsync(&ws->b.counters[5], 0, 3 * 4, s));
-    WaveSeqArgs a = ws_args(p, dp, db, ctx);
-    a.trans = dp->fwd_trans; a.emis = dp->fwd_emis; a.list = ws->b.list_fin; a.nlist = nfin; a.nlist_ptr = nullptr;
-    a.counter = &ws->b.counters[5]; a.out_sc = ws->b.fwd_by_item; a.xmx = ws->xmx_f; a.xmx_off = ws->xmx_off;
-    if ((st = fwd_launch(a, ctx->num_cu, s)) != P7X_OK) return st;
-    P7X_HIP(hipEventRecord(ws->ev[5], s));
-    a.counter = &ws->b.counters[6]; a.out_sc = ws->b.vfsc /* scratch: Backward scores are not used */;
-    a.out_sc = ws->b.fwd_by_item + nfin; a.xmx = ws->xmx_b; a.fwd_xmx = ws->xmx_f;
-    if (2 * (int64_t) nfin <= ws->cap_slots) { if ((st = bck_launch(a, ctx->num_cu, s)) != P7X_OK) return st; }
-    else { set_error("workspace too small for Backward scores"); return P7X_EINVAL; }
-    {   // posterior decoding of the special states and the region scan, on the rows where they are
-      RegionArgs ra{};
-      ra.nitems = nfin; ra.list = ws->b.list_fin; ra.slot_len = db->d_slot_len; ra.fx = ws->xmx_f; ra.bx = ws->xmx_b;
-      ra.xmx_off = ws->xmx_off; ra.scratch = ws->xmx_s;
-      ra.out_regs = ws->reg_out; ra.out_n = ws->reg_out + (size_t) nfin * kRegionCap * 3;
-      ra.out_nexpected = reinterpret_cast<float *>(ra.out_n + nfin);
-      const int grid = std::min(ctx->num_cu * 4, (nfin + 3) / 4);
-      hipLaunchKernelGGL(regions_kernel, dim3((unsigned) grid), dim3(256), 0, s, ra);
-      P7X_HIP(hipGetLastError());
-    }
-    P7X_HIP(hipEventRecord(ws->ev[6], s));
-    std::vector<int32_t> regbuf((size_t) nfin * (kRegionCap * 3 + 2));
-    P7X_HIP(hipMemcpyAsync(regbuf.data(), ws->reg_out, regbuf.size() * 4, hipMemcpyDeviceToHost, s));
+    P7X_HIP(hipMemcpyAsync(out.xmx_off.data(), ws->xmx_off, (size_t) nfin * 8, hipMemcpyDeviceToHost, s));
+    P7X_HIP(hipMemcpyAsync(out.regs.data(), ws->reg_out, out.regs.size() * 4, hipMemcpyDeviceToHost, s));
+    P7X_HIP(hipMemcpyAsync(out.reg_n.data(), ws->reg_out + (size_t) cap * kRegionCap * 3, (size_t) nfin * 4, hipMemcpyDeviceToHost, s));
+    P7X_HIP(hipMemcpyAsync(out.nexpected.data(), ws->reg_out + (size_t) cap * (kRegionCap * 3 + 1), (size_t) nfin * 4, hipMemcpyDeviceToHost, s));
     // the rows pass recomputed each survivor's Forward score in list order: one contiguous copy
     P7X_HIP(hipMemcpyAsync(out.fwdsc.data(), ws->b.fwd_by_item, (size_t) nfin * 4, hipMemcpyDeviceToHost, s));
-    P7X_HIP(hipEventRecord(ws->ev_sync, s)); P7X_HIP(hipEventSynchronize(ws->ev_sync));   // our work only: other host threads share the stream
-    out.regs.assign(regbuf.begin(), regbuf.begin() + (size_t) nfin * kRegionCap * 3);
-    out.reg_n.assign(regbuf.begin() + (size_t) nfin * kRegionCap * 3, regbuf.begin() + (size_t) nfin * (kRegionCap * 3 + 1));
-    out.nexpected.resize(nfin);
-    std::memcpy(out.nexpected.data(), regbuf.data() + (size_t) nfin * (kRegionCap * 3 + 1), (size_t) nfin * 4);
+    P7X_HIP(hipEventRecord(ws->ev_sync, s)); P7X_HIP(hipEventSynchronize(ws->ev_sync));
+    tot = out.xmx_off[(size_t) nfin - 1] + (int64_t) (db->h_len[db->h_order[out.fin_slots[(size_t) nfin - 1]]] + 1) * 6;
     bool overflow = g_host_regions || cfg.host_regions != 0;
     for (int i = 0; i < nfin; ++i) if (out.reg_n[i] == -2) overflow = true;
     if (overflow) {        // a target with more regions than the device keeps (or the A/B switch): the host scans the rows
@@ -634,9 +671,6 @@ static int run_cascade(const p7x_pipeline_cfg &cfg, const p7x_oprofile *om, cons
       P7X_HIP(hipMemcpy(out.bck_xmx.data(), ws->xmx_b, (size_t) tot * 4, hipMemcpyDeviceToHost));
       out.have_xmx = true;
     }
-  } else {
-    P7X_HIP(hipEventRecord(ws->ev[5], s)); P7X_HIP(hipEventRecord(ws->ev[6], s));
-    P7X_HIP(hipEventRecord(ws->ev_sync, s)); P7X_HIP(hipEventSynchronize(ws->ev_sync));   // our work only: other host threads share the stream
   }
   if (cfg.mode == P7X_SCAN_MODELS) {        // per-target accounting: which filters every (model, sequence) pair passed
     std::vector<uint8_t> by_slot((size_t) db->nslots);

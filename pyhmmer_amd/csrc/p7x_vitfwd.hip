@@ -34,7 +34,7 @@ __global__ void __launch_bounds__(kWsBlock) vit_kernel(const WaveSeqArgs a)
   __syncthreads();
   const int lane = threadIdx.x & 63;
   const short NEG = (short) -32768;
-  const int nlist = a.nlist_ptr ? *a.nlist_ptr : a.nlist;
+  const int nlist = (a.abort_flag && *a.abort_flag) ? 0 : (a.nlist_ptr ? *a.nlist_ptr : a.nlist);
 
   P7X_WAVE_ITEMS(it) {
     const Item item = load_item(a, it);
@@ -182,7 +182,7 @@ __global__ void __launch_bounds__(kWsBlock) fwd_kernel(const WaveSeqArgs a)
   }
   __syncthreads();
   const int lane = threadIdx.x & 63;
-  const int nlist = a.nlist_ptr ? *a.nlist_ptr : a.nlist;
+  const int nlist = (a.abort_flag && *a.abort_flag) ? 0 : (a.nlist_ptr ? *a.nlist_ptr : a.nlist);
 
   P7X_WAVE_ITEMS(it) {
     const Item item = load_item(a, it);
@@ -292,7 +292,7 @@ __global__ void __launch_bounds__(kWsBlock) bck_kernel(const WaveSeqArgs a)
   }
   __syncthreads();
   const int lane = threadIdx.x & 63;
-  const int nlist = a.nlist_ptr ? *a.nlist_ptr : a.nlist;
+  const int nlist = (a.abort_flag && *a.abort_flag) ? 0 : (a.nlist_ptr ? *a.nlist_ptr : a.nlist);
 
   P7X_WAVE_ITEMS(it) {
     const Item item = load_item(a, it);
