@@ -32,6 +32,7 @@ int get_ctx(int device, DeviceCtx **out)
   ctx->device = device;
   P7X_HIP(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
   P7X_HIP(hipStreamCreateWithFlags(&ctx->stream2, hipStreamNonBlocking));
+  for (auto &e : ctx->msv_done) P7X_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
   hipDeviceProp_t prop;
   P7X_HIP(hipGetDeviceProperties(&prop, device));
   ctx->num_cu = prop.multiProcessorCount;

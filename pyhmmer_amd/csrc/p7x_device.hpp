@@ -31,6 +31,11 @@ struct DeviceCtx {
   LengthTables lt;
   int num_cu = 256;
   std::mutex mu;
+  // MSV launches of concurrent searches are chained: two of them sharing the device finish no earlier than one after
+  // the other (both are VALU bound), but each would take twice as long and delay its own cascade's tail
+  std::mutex msv_mu;
+  hipEvent_t msv_done[2] = { nullptr, nullptr };
+  int msv_last = -1;
 };
 int get_ctx(int device, DeviceCtx **out);
 

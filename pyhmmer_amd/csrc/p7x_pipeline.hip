@@ -566,9 +566,15 @@ static int run_cascade(const p7x_pipeline_cfg &cfg, const p7x_oprofile *om, cons
   hipStream_t s = ws->stream;
   const StageParams sp = make_params(p, cfg);
   P7X_HIP(hipMemsetAsync(ws->b.counters, 0, 16 * 4, s));
-  P7X_HIP(hipEventRecord(ws->ev[0], s));
-  if ((st = run_msv(p, dp, db, ctx, ws, s)) != P7X_OK) return st;
-  P7X_HIP(hipEventRecord(ws->ev[7], s));
+  {
+    std::lock_guard<std::mutex> lk(ctx->msv_mu);          // enqueue order == chain order
+    if (ctx->msv_last >= 0) P7X_HIP(hipStreamWaitEvent(s, ctx->msv_done[ctx->msv_last], 0));
+    P7X_HIP(hipEventRecord(ws->ev[0], s));
+    if ((st = run_msv(p, dp, db, ctx, ws, s)) != P7X_OK) return st;
+    P7X_HIP(hipEventRecord(ws->ev[7], s));
+    ctx->msv_last = (ctx->msv_last + 1) & 1;
+    P7X_HIP(hipEventRecord(ctx->msv_done[ctx->msv_last], s));
+  }
   {
     const unsigned grid = (unsigned) ((db->nslots + 255) / 256);
     hipLaunchKernelGGL(decide_msv_kernel, dim3(grid), dim3(256), 0, s, ws->b, sp, db->d_slot_len, ctx->lt.tjb, ctx->lt.null1, db->nslots);

@@ -120,7 +120,7 @@ def hmmpress(hmms: Iterable, output) -> int:
 
 def hmmsearch(queries: Union[HMM, Profile, OptimizedProfile, Iterable], sequences, *, cpus: int = 0,
               callback: Optional[Callable] = None, devices: Optional[Sequence[int]] = None,
-              pipeline_depth: int = 2, feeders: int = 1, **options) -> Iterator[TopHits]:
+              pipeline_depth: int = 4, feeders: int = 2, **options) -> Iterator[TopHits]:
     """Search HMMs against a sequence database; yields one ``TopHits`` per query, in query order.
 
     ``devices`` lists the HIP devices to shard the targets over (default: device 0).  ``cpus`` is accepted for
