@@ -9,7 +9,7 @@ import pytest
 
 import bench
 from conftest import load_hmms, random_hmm, synthetic_block
-from pyhmmer_amd import easel, plan7
+from pyhmmer_amd import easel, hmmer, plan7
 from test_gpu_filters import _model_block
 
 pytestmark = pytest.mark.gpu
@@ -38,6 +38,8 @@ def _compare(hmm, db, **opts):
     assert _records(a) == dev
     assert [(h.nregions, h.nclustered, h.nenvelopes, h.nexpected) for h in a] == \
            [(h.nregions, h.nclustered, h.nenvelopes, h.nexpected) for h in plan7.Pipeline(hmm.alphabet, **opts).search_hmm(hmm, db)]
+    # hits whose scores differ by less than the tolerance may swap places in the ranking: compare by name
+    dev, host = sorted(dev, key=lambda r: r[0]), sorted(host, key=lambda r: r[0])
     assert [r[0] for r in dev] == [r[0] for r in host]
     ndom, near_ties = 0, 0
     for (name, sa, da), (_, sb, dbb) in zip(dev, host):
@@ -135,3 +137,35 @@ def test_very_long_targets_and_region_overflow():
     assert hits[0].name == "many150" and hits[0].nregions > 128 and len(hits[0].domains) >= 140
     nhits2, ndom2 = _compare(hmm, db2)
     assert ndom2 >= 140
+
+
+def test_more_survivors_than_the_row_buffers_were_sized_for():
+    """6,000 targets that are all homologs: more Forward survivors than the first sizing of the row buffers
+    (max(4096, N/64)), so the cascade tail is repeated with larger buffers; every target must come back as a hit, and
+    equal to the host twin."""
+    hmm = load_hmms("PF02826")[0]
+    abc = hmm.alphabet
+    rng = np.random.default_rng(11)
+    seqs = []
+    for t in range(6000):
+        dom = _repeat_protein(hmm, 1, int(rng.integers(0, 30)), 100 + t)
+        seqs.append(easel.DigitalSequence(abc, name=f"h{t}", sequence=dom))
+    db = plan7.SequenceDatabase(easel.DigitalSequenceBlock(abc, seqs))
+    hits = plan7.Pipeline(abc).search_hmm(hmm, db)
+    assert hits.stage_counts["fwd"] > 4096 and len(hits) == hits.stage_counts["fwd"]
+    assert sorted(h.name for h in hits)[:3] == ["h0", "h1", "h10"]
+    nhits, ndom = _compare(hmm, db)
+    assert nhits == len(hits)
+
+
+def test_degenerate_databases(models):
+    hmm = models["PF02826"][0]
+    abc = hmm.alphabet
+    pli = plan7.Pipeline(abc)
+    empty = pli.search_hmm(hmm, easel.DigitalSequenceBlock(abc, []))
+    assert len(empty) == 0 and empty.searched_sequences == 0
+    tiny = easel.DigitalSequenceBlock(abc, [easel.DigitalSequence(abc, name=f"s{L}", sequence=np.full(L, L % 20, dtype=np.uint8))
+                                            for L in (1, 2, 3, 5, 8, 0, 1)])
+    res = pli.search_hmm(hmm, tiny)
+    assert len(res) == 0 and res.searched_sequences == 7 and res.searched_residues == 20
+    assert [len(h) for h in hmmer.hmmscan(tiny, [hmm])] == [0] * 7
