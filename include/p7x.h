@@ -256,6 +256,10 @@ int64_t  p7x_tophits_serialize(const p7x_tophits *th, void *buf, size_t cap);
 p7x_tophits *p7x_tophits_deserialize(const void *buf, size_t n);
 int      p7x_tophits_sort_by_key(p7x_tophits *th);       /* p7_tophits_SortBySortkey, plan7.pyx:8820-8824 */
 int      p7x_tophits_threshold(p7x_tophits *th);         /* p7_tophits_Threshold, plan7.pyx:8804-8818 */
+int      p7x_tophits_sort_by_seqidx(p7x_tophits *th);    /* p7_tophits_SortBySeqidxAndAlipos, TopHits.sort(by="seqidx") plan7.pyx:9120-9148 */
+int      p7x_tophits_is_sorted(const p7x_tophits *th, int by_seqidx);   /* TopHits.is_sorted, plan7.pyx:9078-9118; 1 / 0 */
+/* Hit.reported / included / dropped / duplicate setters (plan7.pyx:2125-2235): replace the P7X_IS_* flag word of hit i. */
+int      p7x_tophits_set_hit_flags(p7x_tophits *th, int64_t i, uint32_t flags);
 /* per-stage device timings of the search that produced th, milliseconds (HIP events):
  * [0] msv + P-value pass [1] bias filter [2] viterbi [3] forward [4] forward rows for survivors [5] backward, then
  * overwritten by host domain definition wall time (including [8]) [6] whole call wall time [7] the MSV kernel alone

@@ -536,6 +536,43 @@ int p7x_scan_collect(p7x_tophits *const *per_model, size_t nmodels, const p7x_pi
 int p7x_tophits_sort_by_key(p7x_tophits *th) { if (!th) return P7X_EINVAL; sort_by_key(*th); return P7X_OK; }
 int p7x_tophits_threshold(p7x_tophits *th)   { if (!th) return P7X_EINVAL; threshold(*th); return P7X_OK; }
 
+// p7_tophits_SortBySeqidxAndAlipos: target index, then strand (forward first), then alignment start.
+static bool seqidx_less(const Hit &h1, const Hit &h2)
+{
+  if (h1.seqidx != h2.seqidx) return h1.seqidx < h2.seqidx;
+  const int dir1 = h1.dcl[0].iali < h1.dcl[0].jali ? 1 : -1, dir2 = h2.dcl[0].iali < h2.dcl[0].jali ? 1 : -1;
+  if (dir1 != dir2) return dir2 < 0;
+  return h1.dcl[0].iali < h2.dcl[0].iali;
+}
+int p7x_tophits_sort_by_seqidx(p7x_tophits *th)
+{
+  if (!th) return P7X_EINVAL;
+  th->order.resize(th->hits.size());
+  for (size_t i = 0; i < th->order.size(); ++i) th->order[i] = (int) i;
+  std::stable_sort(th->order.begin(), th->order.end(), [&](int a, int b) { return seqidx_less(th->hits[a], th->hits[b]); });
+  th->sorted_by_key = false;
+  return P7X_OK;
+}
+int p7x_tophits_is_sorted(const p7x_tophits *th, int by_seqidx)
+{
+  if (!th) return 0;
+  const size_t n = th->hits.size();
+  if (th->order.size() != n) return n <= 1;
+  for (size_t i = 1; i < n; ++i) {
+    const Hit &a = th->hits[th->order[i - 1]], &b = th->hits[th->order[i]];
+    if (by_seqidx) { if (seqidx_less(b, a)) return 0; }
+    else if (a.sortkey < b.sortkey || (a.sortkey == b.sortkey && std::strcmp(a.name.c_str(), b.name.c_str()) > 0)) return 0;
+  }
+  return 1;
+}
+int p7x_tophits_set_hit_flags(p7x_tophits *th, int64_t i, uint32_t flags)
+{
+  if (!th || i < 0 || (size_t) i >= th->hits.size()) return P7X_EINVAL;
+  Hit &h = th->order.size() == th->hits.size() ? th->hits[th->order[i]] : th->hits[i];
+  h.flags = flags;
+  return P7X_OK;
+}
+
 // TopHits.merge (plan7.pyx:9172-9276): p7_tophits_Merge (concatenate, re-sort), p7_pipeline_Merge (add the
 // accounting; Z too when it counts targets), clear REPORTED/INCLUDED unless bit cutoffs, re-threshold.
 int p7x_tophits_merge(p7x_tophits *dst, const p7x_tophits *src)

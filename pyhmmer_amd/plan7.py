@@ -843,21 +843,53 @@ class Hit:
     def best_domain(self) -> Domain:
         return Domain(self, self._rec.best_domain)
 
+    # flag word: P7X_IS_INCLUDED = 1, P7X_IS_REPORTED = 2, P7X_IS_NEW = 4, P7X_IS_DROPPED = 8, P7X_IS_DUPLICATE = 16;
+    # the setters restate plan7.pyx:2125-2235 (the reported / included counts are derived from the flags here)
+    def _set_flags(self, flags: int) -> None:
+        st = _lib.lib().p7x_tophits_set_hit_flags(self.hits._handle, self._index, flags)
+        if st != 0:
+            raise IndexError("hit index out of range")
+        self._rec.flags = flags
+
     @property
     def reported(self) -> bool:
         return bool(self._rec.flags & 2)
+
+    @reported.setter
+    def reported(self, reported: bool) -> None:
+        self._set_flags((self._rec.flags | 2) if reported else (self._rec.flags & ~3))
 
     @property
     def included(self) -> bool:
         return bool(self._rec.flags & 1)
 
+    @included.setter
+    def included(self, included: bool) -> None:
+        self._set_flags(((self._rec.flags | 3) & ~24) if included else (self._rec.flags & ~1))
+
+    @property
+    def new(self) -> bool:
+        return bool(self._rec.flags & 4)
+
+    @new.setter
+    def new(self, new: bool) -> None:
+        self._set_flags((self._rec.flags | 4) if new else (self._rec.flags & ~4))
+
     @property
     def dropped(self) -> bool:
         return bool(self._rec.flags & 8)
 
+    @dropped.setter
+    def dropped(self, dropped: bool) -> None:
+        self._set_flags(((self._rec.flags | 8) & ~1) if dropped else (self._rec.flags & ~8))
+
     @property
     def duplicate(self) -> bool:
         return bool(self._rec.flags & 16)
+
+    @duplicate.setter
+    def duplicate(self, duplicate: bool) -> None:
+        self._set_flags(((self._rec.flags | 16) & ~3) if duplicate else (self._rec.flags & ~16))
 
     @property
     def length(self) -> int:
@@ -977,13 +1009,102 @@ class TopHits:
     def included(self):
         return [h for h in self if h.included]
 
+    @property
+    def mode(self) -> str:
+        """``"search"`` or ``"scan"`` (reference ``plan7.pyx:8560-8571``)."""
+        return "scan" if self._cfg().mode == _P7X_SCAN_MODELS else "search"
+
+    @property
+    def strand(self) -> Optional[str]:
+        """Always `None`: only protein-style (single strand) pipelines exist here (``plan7.pyx:8489-8505``)."""
+        return None
+
     def sort(self, by: str = "key") -> None:
-        if by != "key":
-            raise InvalidParameter("by", by, choices=["key"])
-        _lib.lib().p7x_tophits_sort_by_key(self._handle)
+        """``p7_tophits_SortBySortkey`` / ``p7_tophits_SortBySeqidxAndAlipos`` (reference ``plan7.pyx:9120-9148``)."""
+        if by == "key":
+            _lib.lib().p7x_tophits_sort_by_key(self._handle)
+        elif by == "seqidx":
+            _lib.lib().p7x_tophits_sort_by_seqidx(self._handle)
+        else:
+            raise InvalidParameter("by", by, choices=["key", "seqidx"])
 
     def is_sorted(self, by: str = "key") -> bool:
-        return True
+        if by not in ("key", "seqidx"):
+            raise InvalidParameter("by", by, choices=["key", "seqidx"])
+        return bool(_lib.lib().p7x_tophits_is_sorted(self._handle, 1 if by == "seqidx" else 0))
+
+    def threshold(self) -> None:
+        """Re-apply the reporting / inclusion thresholds (``p7_tophits_Threshold``, ``plan7.pyx:8804-8818``)."""
+        _lib.lib().p7x_tophits_threshold(self._handle)
+
+    def write(self, fh, format: str = "targets", header: bool = True) -> None:
+        """Tabular output as ``hmmsearch --tblout`` (``"targets"``) / ``--domtblout`` (``"domains"``) write it:
+        ``p7_tophits_TabularTargets`` / ``p7_tophits_TabularDomains`` behind reference ``plan7.pyx:9071-9118``, pinned by
+        the golden ``.tbl`` / ``.domtbl`` files.  The reference's third format (``"pfam"``) has no fixture to pin it and is
+        not offered.  ``fh`` is a file object opened in binary mode."""
+        if format not in ("targets", "domains"):
+            raise InvalidParameter("format", format, choices=["targets", "domains"])
+        q = self.query
+        qname = getattr(q, "name", None) if q is not None and not isinstance(q, str) else q
+        qacc = getattr(q, "accession", None) if q is not None and not isinstance(q, str) else None
+        qname = qname if qname else "-"
+        qacc = qacc if qacc else "-"
+        hits = [h for h in self if h.reported]
+        tnamew = max([20] + [len(h.name) for h in self])
+        taccw = max([10] + [len(h.accession or "") for h in self])
+        qnamew = max(20, len(qname))
+        qaccw = max(10, len(qacc))
+        Z, domZ = self.Z, self.domZ
+        out = []
+        if format == "targets":
+            if header:
+                out.append("#%*s %22s %22s %33s" % (tnamew + qnamew + taccw + qaccw + 2, "", "--- full sequence ----",
+                                                     "--- best 1 domain ----", "--- domain number estimation ----"))
+                out.append("#%-*s %-*s %-*s %-*s %9s %6s %5s %9s %6s %5s %5s %3s %3s %3s %3s %3s %3s %3s %s" % (
+                    tnamew - 1, " target name", taccw, "accession", qnamew, "query name", qaccw, "accession",
+                    "  E-value", " score", " bias", "  E-value", " score", " bias", "exp", "reg", "clu", " ov", "env",
+                    "dom", "rep", "inc", "description of target"))
+                out.append("#%*s %*s %*s %*s %9s %6s %5s %9s %6s %5s %5s %3s %3s %3s %3s %3s %3s %3s %s" % (
+                    tnamew - 1, "-------------------", taccw, "----------", qnamew, "--------------------", qaccw,
+                    "----------", "---------", "------", "-----", "---------", "------", "-----", "---", "---", "---",
+                    "---", "---", "---", "---", "---", "---------------------"))
+            for h in hits:
+                r, d = h._rec, h.best_domain._rec
+                out.append("%-*s %-*s %-*s %-*s %9.2g %6.1f %5.1f %9.2g %6.1f %5.1f %5.1f %3d %3d %3d %3d %3d %3d %3d %s" % (
+                    tnamew, h.name, taccw, h.accession or "-", qnamew, qname, qaccw, qacc,
+                    math.exp(r.lnP) * Z, r.score, r.pre_score - r.score, math.exp(d.lnP) * Z, d.bitscore,
+                    d.dombias / math.log(2.0), r.nexpected, r.nregions, r.nclustered, r.noverlaps, r.nenvelopes, r.ndom,
+                    r.nreported, r.nincluded, h.description or "-"))
+        else:
+            qlen = getattr(q, "M", None)
+            if qlen is None:
+                qlen = len(q) if q is not None and not isinstance(q, str) else 0
+            if header:
+                out.append("#%*s %22s %40s %11s %11s %11s" % (tnamew + qnamew - 1 + 15 + taccw + qaccw, "",
+                                                               "--- full sequence ---", "-------------- this domain -------------",
+                                                               "hmm coord", "ali coord", "env coord"))
+                out.append("#%-*s %-*s %5s %-*s %-*s %5s %9s %6s %5s %3s %3s %9s %9s %6s %5s %5s %5s %5s %5s %5s %5s %4s %s" % (
+                    tnamew - 1, " target name", taccw, "accession", "tlen", qnamew, "query name", qaccw, "accession", "qlen",
+                    "E-value", "score", "bias", "#", "of", "c-Evalue", "i-Evalue", "score", "bias", "from", "to", "from",
+                    "to", "from", "to", "acc", "description of target"))
+                out.append("#%*s %*s %5s %*s %*s %5s %9s %6s %5s %3s %3s %9s %9s %6s %5s %5s %5s %5s %5s %5s %5s %4s %s" % (
+                    tnamew - 1, "-------------------", taccw, "----------", "-----", qnamew, "--------------------", qaccw,
+                    "----------", "-----", "---------", "------", "-----", "---", "---", "---------", "---------", "------",
+                    "-----", "-----", "-----", "-----", "-----", "-----", "-----", "----", "---------------------"))
+            for h in hits:
+                r = h._rec
+                nd = 0
+                for dom in h.domains:
+                    d = dom._rec
+                    if not d.is_reported:
+                        continue
+                    nd += 1
+                    out.append("%-*s %-*s %5d %-*s %-*s %5d %9.2g %6.1f %5.1f %3d %3d %9.2g %9.2g %6.1f %5.1f %5d %5d %5d %5d %5d %5d %4.2f %s" % (
+                        tnamew, h.name, taccw, h.accession or "-", d.L, qnamew, qname, qaccw, qacc, qlen,
+                        math.exp(r.lnP) * Z, r.score, r.pre_score - r.score, nd, r.nreported, math.exp(d.lnP) * domZ,
+                        math.exp(d.lnP) * Z, d.bitscore, d.dombias / math.log(2.0), d.hmmfrom, d.hmmto, d.sqfrom, d.sqto,
+                        d.ienv, d.jenv, d.oasc / (1.0 + abs(float(d.jenv - d.ienv))), h.description or "-"))
+        fh.write(("\n".join(out) + "\n").encode() if out else b"")
 
     def copy(self) -> "TopHits":
         h = _lib.lib().p7x_tophits_clone(self._handle)

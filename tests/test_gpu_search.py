@@ -240,3 +240,37 @@ def test_hmmscan_with_gathering_cutoffs(models, proteome):
     assert got == want
     with pytest.raises(errors.MissingCutoffs):
         list(hmmer.hmmscan(proteome, [hmm, models["KR"][0]], bit_cutoffs="gathering"))
+
+
+@pytest.mark.parametrize("fmt,table", [("targets", "PF02826.tbl"), ("domains", "PF02826.domtbl")])
+def test_written_tables_equal_hmmer_output_text(models, proteome, fmt, table):
+    """reference tests/test_plan7/test_tophits.py:359-381, through the device path.  Rows of hits whose null2 comes from
+    the stochastic ensemble have their score / E-value columns masked."""
+    import io
+    from conftest import GOLDEN
+    hmm = models["PF02826"][0]
+    hits = plan7.Pipeline(hmm.alphabet).search_hmm(hmm, proteome)
+    buf = io.BytesIO()
+    hits.write(buf, format=fmt)
+    got = buf.getvalue().decode().splitlines()
+    want = open(GOLDEN / "tables" / table).read().splitlines()
+    while want[-1].startswith("#"):
+        want.pop()
+    assert len(got) == len(want)
+    sampled = {h.name for h in hits if h.nclustered > 0}
+    score_cols = (4, 5, 6, 7, 8, 9) if fmt == "targets" else (6, 7, 8, 11, 12, 13, 14)
+    for g, w in zip(got, want):
+        if g.split()[0] in sampled:
+            gf, wf = g.split(), w.split()
+            assert [f for i, f in enumerate(gf) if i not in score_cols] == [f for i, f in enumerate(wf) if i not in score_cols]
+        else:
+            assert g == w
+    # scan mode: the model names are the "targets" and the sequence is the query (RREFam.scan.tbl layout)
+    seq = next(s for s in proteome if s.name == "938293.PRJEB85.HG003691_78")
+    scan = list(hmmer.hmmscan([seq], models["RREFam"]))[0]
+    assert scan.mode == "scan"
+    out = io.BytesIO()
+    scan.write(out, format="targets", header=False)
+    rows = [l.split() for l in out.getvalue().decode().splitlines()]
+    want_rows = [r for r in golden_table("RREFam.scan.tbl") if r[2] == seq.name]
+    assert [(r[0], r[1], r[2]) for r in rows] == [(r[0], r[1], r[2]) for r in want_rows]

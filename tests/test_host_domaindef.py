@@ -1,7 +1,9 @@
 """The product's HOST half (p7_domaindef + p7_tophits restatement in libp7x) against real HMMER output.  No GPU:
 the device half is stood in for by the oracle (tests/host_pipeline.py) and the rows go through the exported
 C-ABI entry point p7x_postprocess_targets."""
+import io
 import itertools
+import pickle
 
 import pytest
 
@@ -83,3 +85,95 @@ def test_host_thresholds_and_z(models, oracle, proteome):
     assert all(d.score >= 10.0 for h in byT.reported for d in h.domains.reported)
     nonull2 = host_pipeline.host_search(oracle, hmm, proteome, pipeline=plan7.Pipeline(hmm.alphabet, null2=False))
     assert all(h.bias == pytest.approx(0.0, abs=1e-4) or h.sum_score >= h.pre_score - 1e-3 for h in nonull2)
+
+
+def _golden_lines(name):
+    lines = open(host_pipeline_golden() / "tables" / name).read().splitlines()
+    while lines[-1].startswith("#"):
+        lines.pop()
+    return lines
+
+
+def host_pipeline_golden():
+    from conftest import GOLDEN
+    return GOLDEN
+
+
+@pytest.mark.parametrize("fmt,table", [("targets", "PF02826.tbl"), ("domains", "PF02826.domtbl")])
+def test_host_write_reproduces_hmmer_tables_byte_for_byte(models, oracle, proteome, fmt, table):
+    """reference tests/test_plan7/test_tophits.py:359-381 (`TopHits.write` against the --tblout / --domtblout text).
+    Header and every row are compared as text; rows of hits whose null2 came from the stochastic ensemble
+    (known deviation) are compared with their score / E-value columns masked."""
+    hmm = models["PF02826"][0]
+    hits = host_pipeline.host_search(oracle, hmm, proteome)
+    buf = io.BytesIO()
+    hits.write(buf, format=fmt)
+    got = buf.getvalue().decode().splitlines()
+    want = _golden_lines(table)
+    assert len(got) == len(want)
+    sampled = {h.name for h in hits if h.nclustered > 0}
+    score_cols = (4, 5, 6, 7, 8, 9) if fmt == "targets" else (6, 7, 8, 11, 12, 13, 14)
+    exact = 0
+    for g, w in zip(got, want):
+        if g.split()[0] in sampled and not g.startswith("#"):
+            gf, wf = g.split(), w.split()
+            assert [f for i, f in enumerate(gf) if i not in score_cols] == [f for i, f in enumerate(wf) if i not in score_cols]
+        else:
+            assert g == w
+            exact += 1
+    assert len(sampled) == 6 and exact == len(got) - sum(1 for g in got if g.split()[0] in sampled)
+    nohdr = io.BytesIO()
+    hits.write(nohdr, format=fmt, header=False)
+    assert nohdr.getvalue().decode().splitlines() == got[3:]
+    with pytest.raises(ValueError):
+        hits.write(io.BytesIO(), format="nonsense")
+
+
+def test_host_tophits_api(models, oracle, proteome):
+    """reference tests/test_plan7/test_tophits.py:112-160, 293-327, 343-357, 383-450 and test_hit.py:94-150."""
+    hmm = models["PF02826"][0]
+    base = host_pipeline.host_search(oracle, hmm, proteome)
+    hits = base.copy()
+    assert hits.mode == "search" and hits.strand is None and bool(hits)
+    assert hits.query is hmm and hits.query.name == hmm.name and hits.query.M == hmm.M
+    with pytest.raises(IndexError):
+        hits[len(hits) + 1]
+    with pytest.raises(IndexError):
+        hits[-len(hits) - 1]
+    assert hits[len(hits) - 1].name == hits[-1].name == "938293.PRJEB85.HG003687_187"
+    assert (len(hits.included), len(hits.reported)) == (15, 22)
+    # sorting
+    assert hits.is_sorted() and not hits.is_sorted(by="seqidx")
+    hits.sort(by="seqidx")
+    assert hits.is_sorted(by="seqidx") and not hits.is_sorted(by="key")
+    assert [h.seqidx for h in hits] == sorted(h.seqidx for h in hits)
+    hits.sort()
+    assert hits.is_sorted() and [h.name for h in hits] == [h.name for h in base]
+    with pytest.raises(ValueError):
+        hits.sort(by="nonsense")
+    with pytest.raises(ValueError):
+        hits.is_sorted(by="nonsense")
+    # pickling round trip
+    again = pickle.loads(pickle.dumps(hits))
+    assert [(h.name, h.score, h.evalue, h.included) for h in again] == [(h.name, h.score, h.evalue, h.included) for h in hits]
+    # manual flags
+    hits[0].reported = False
+    assert len(hits.reported) == 21 and not hits[0].reported and len(hits.included) == 14
+    hits[0].reported = True
+    hits[0].included = True
+    assert (len(hits.included), len(hits.reported)) == (15, 22)
+    hits[0].included = False
+    assert (len(hits.included), len(hits.reported)) == (14, 22) and hits[0].reported
+    hits[0].included = True
+    hits[0].dropped = True
+    assert (len(hits.included), len(hits.reported)) == (14, 22) and hits[0].dropped and not hits[0].included
+    hits[0].dropped = False
+    assert (len(hits.included), len(hits.reported)) == (14, 22) and not hits[0].dropped and not hits[0].included
+    hits[0].included = True
+    hits[0].duplicate = True
+    assert (len(hits.included), len(hits.reported)) == (14, 21) and hits[0].duplicate
+    hits[0].duplicate = False
+    assert (len(hits.included), len(hits.reported)) == (14, 21) and not hits[0].duplicate
+    hits.threshold()
+    assert (len(hits.included), len(hits.reported)) == (15, 22)
+    assert (len(base.included), len(base.reported)) == (15, 22)          # the copy was independent
