@@ -471,8 +471,6 @@ struct Trace {
           if (hmmfrom[ndom] == 0) hmmfrom[ndom] = k[z];
           sqto[ndom] = i[z]; hmmto[ndom] = k[z];
           break;
-        case sI: sqto[ndom] = i[z]; break;
-        case sD: if (hmmfrom[ndom] == 0) hmmfrom[ndom] = k[z]; hmmto[ndom] = k[z]; break;
         case sE: tto[ndom] = z; ndom++; break;
         default: break;
       }
