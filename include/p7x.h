@@ -219,6 +219,13 @@ int  p7x_search_block_begin(const p7x_pipeline_cfg *cfg, const p7x_oprofile *om,
 int  p7x_search_block_finish(p7x_pending *pending, const char *const *names, const char *const *accs,
                              const char *const *descs, p7x_tophits **out);
 void p7x_pending_destroy(p7x_pending *pending);
+/* begin in two halves, for a caller that keeps several searches of one host thread in flight (hmmscan: one per model,
+ * the OptimizedProfileBlock loop of plan7.pyx:6624-6677 turned inside out): enqueue queues stage 1 on its own device
+ * stream and returns at once; wait blocks until that work is done (idempotent; finish calls it when the caller did
+ * not).  Both halves of one search, and destroy of an un-waited handle, belong to the thread that called enqueue. */
+int  p7x_search_block_enqueue(const p7x_pipeline_cfg *cfg, const p7x_oprofile *om, const float *bg_f,
+                              const p7x_seqdb *db, p7x_pending **out);
+int  p7x_search_block_wait(p7x_pending *pending);
 
 /* hmmscan orientation (Pipeline.scan_seq / _scan_loop, plan7.pyx:6534-6677; hmmer/_hmmscan.py): search every model
  * against the block of query sequences with cfg.mode = P7X_SCAN_MODELS (one device pass per model, nothing pruned), then

@@ -183,6 +183,8 @@ _SIGNATURES = {
     "p7x_tophits_set_hit_flags": (C.c_int, [_VP, C.c_int64, C.c_uint32]),
     "p7x_tophits_get_timings": (C.c_int, [_VP, C.POINTER(C.c_double), C.c_int]),
     "p7x_search_block_begin": (C.c_int, [C.POINTER(PipelineCfg), _VP, _VP, _VP, C.POINTER(_VP)]),
+    "p7x_search_block_enqueue": (C.c_int, [C.POINTER(PipelineCfg), _VP, _VP, _VP, C.POINTER(_VP)]),
+    "p7x_search_block_wait": (C.c_int, [_VP]),
     "p7x_search_block_finish": (C.c_int, [_VP, _VP, _VP, _VP, C.POINTER(_VP)]),
     "p7x_pending_destroy": (None, [_VP]),
     "p7x_oprofile_write_pressed": (C.c_int, [_VP, C.POINTER(C.c_int64), _VP, C.c_size_t, C.POINTER(C.c_size_t), _VP, C.c_size_t,

@@ -19,6 +19,7 @@
 //   * emission lookups are per-lane LDS gathers with ds_read_b64; the table row stride S (dwords)
 //     has S/2 odd so the <=32 residue rows fall on distinct bank pairs: conflict-free;
 //   * residues arrive as coalesced 16-byte loads from 64-sequence interleaved tiles (p7x_seqdb).
+#include <cstdlib>
 #include "p7x_device.hpp"
 #include "p7x_kernels.hpp"
 
@@ -357,6 +358,9 @@ static int launch_R(const MsvArgs &a, int num_cu, hipStream_t st)
   int per_cu2 = 0;
   P7X_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu2, msv_fast_kernel<R>, kMsvBlock, lds_bytes));
   if (per_cu2 < 1) per_cu2 = 1;
+  // A/B switch: cap the resident blocks per CU so that other kernels' wavefronts fit beside the MSV row registers
+  static const int cap = std::getenv("P7X_MSV_BLOCKS_PER_CU") ? std::atoi(std::getenv("P7X_MSV_BLOCKS_PER_CU")) : 0;
+  if (cap > 0 && per_cu2 > cap) per_cu2 = cap;
   long grid2 = (long) num_cu * per_cu2;
   if (grid2 > want) grid2 = want;
   if (grid2 < 1) grid2 = 1;

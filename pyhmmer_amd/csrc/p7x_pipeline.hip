@@ -71,7 +71,7 @@ static int get_dev_profile(const p7x_oprofile *om, DeviceCtx *ctx, DevProfile **
         fe[(size_t) x * Mpad + pos[k]] = p.rf_[(size_t) x * (p.M + 1) + k];
       }
     }
-    if (d->msvR <= 0) {     // long model: emission table of the wave-per-target MSV kernel, same node order as Viterbi's
+    {     // emission table of the wave-per-target MSV kernel (long models, small target blocks), same node order as Viterbi's
       std::vector<int16_t> me((size_t) kTabRows * Mpad, (int16_t) kNegPad);
       for (int k = 1; k <= p.M; ++k)
         for (int x = 0; x < p.Kp; ++x) me[(size_t) x * Mpad + pos[k]] = (int16_t) ((int) p.bias_b - (int) p.rb[(size_t) x * (p.M + 1) + k]);
@@ -433,7 +433,9 @@ struct Workspace {
   int64_t fin_cap = 0;             // Forward survivors the row buffers are sized for
   hipEvent_t ev[8]{};
   hipEvent_t ev_sync = nullptr;
-  hipStream_t stream = nullptr;     // one stream per host thread driving cascades: concurrent searches overlap on the device
+  hipStream_t stream = nullptr;     // one stream per cascade in flight: concurrent searches overlap on the device
+  int *h_counts = nullptr;          // pinned mirror of b.counters (the enqueue half must not block on a pageable copy)
+  bool busy = false;                // between the enqueue and the collect half of a cascade
   ~Workspace() {
     if (device < 0) return;
     (void) hipSetDevice(device);
@@ -444,6 +446,7 @@ struct Workspace {
     for (auto &e : ev) if (e) (void) hipEventDestroy(e);
     if (ev_sync) (void) hipEventDestroy(ev_sync);
     if (stream) (void) hipStreamDestroy(stream);
+    if (h_counts) (void) hipHostFree(h_counts);
   }
 };
 
@@ -451,7 +454,7 @@ static thread_local std::vector<std::unique_ptr<Workspace>> tl_ws;
 
 static int get_workspace(int device, int64_t nslots, Workspace **out)
 {
-  for (auto &w : tl_ws) if (w->device == device && w->cap_slots >= nslots) { *out = w.get(); return P7X_OK; }
+  for (auto &w : tl_ws) if (!w->busy && w->device == device && w->cap_slots >= nslots) { *out = w.get(); return P7X_OK; }
   auto w = std::make_unique<Workspace>();
   w->device = device;
   const int64_t cap = std::max<int64_t>(64, ((nslots + 63) / 64) * 64);
@@ -463,6 +466,7 @@ static int get_workspace(int device, int64_t nslots, Workspace **out)
   P7X_HIP(hipMalloc(&w->b.list_bias, cap * 4)); P7X_HIP(hipMalloc(&w->b.list_vit, cap * 4));
   P7X_HIP(hipMalloc(&w->b.list_fwd, cap * 4)); P7X_HIP(hipMalloc(&w->b.list_fin, cap * 4));
   P7X_HIP(hipMalloc(&w->b.counters, 16 * 4));
+  P7X_HIP(hipHostMalloc(reinterpret_cast<void **>(&w->h_counts), 16 * 4, hipHostMallocDefault));
   P7X_HIP(hipMalloc(&w->b.stage, cap));
   for (auto &e : w->ev) P7X_HIP(hipEventCreate(&e));
   P7X_HIP(hipEventCreateWithFlags(&w->ev_sync, hipEventDisableTiming));
@@ -503,10 +507,16 @@ static const bool g_vit_wave = std::getenv("P7X_VIT_WAVE") != nullptr;          
 static const bool g_host_envelopes = std::getenv("P7X_HOST_ENVELOPES") != nullptr;   // A/B: rescore envelopes on the host
 static const bool g_host_regions = std::getenv("P7X_HOST_REGIONS") != nullptr;       // A/B: region scan on the host
 
+// A block with at most one 64-target group per SIMD cannot fill the device with the lane-per-target kernels and would
+// run for as long as its longest sequences take one wavefront: such blocks (hmmscan's queries) go one target per
+// wavefront through the filters instead.  P7X_SMALL_BLOCK=0 disables the switch (A/B).
+static const bool g_small_block = !(std::getenv("P7X_SMALL_BLOCK") && std::atoi(std::getenv("P7X_SMALL_BLOCK")) == 0);
+static bool small_block(const p7x_seqdb *db, const DeviceCtx *ctx) { return g_small_block && db->ngroups <= (int64_t) ctx->num_cu * 4; }
+
 // Run MSV over the whole database; leaves xJ (slot order) in ws->b.xJ.
 static int run_msv(const Profile &p, const DevProfile *dp, const p7x_seqdb *db, DeviceCtx *ctx, Workspace *ws, hipStream_t stream)
 {
-  if (dp->msvR <= 0) {      // M > 478: wave-per-target kernel
+  if (dp->msvR <= 0 || small_block(db, ctx)) {      // M > 478, or too few targets for one per lane: wave-per-target kernel
     if (!dp->msvw_emis) { set_error("model too long for the MSV kernels (M > 2048)"); return P7X_EINVAL; }
     MsvWaveArgs w{};
     w.C = dp->vitC; w.nrows = kTabRows; w.emis = dp->msvw_emis; w.dsq = db->d_dsq; w.slot_off = db->d_slot_off; w.slot_len = db->d_slot_len;
@@ -527,7 +537,7 @@ static int run_msv(const Profile &p, const DevProfile *dp, const p7x_seqdb *db, 
 // Viterbi filter over a work list: the packed kernel when the model fits it, else one target per wavefront.
 static int run_viterbi(const Profile &p, const DevProfile *dp, const p7x_seqdb *db, DeviceCtx *ctx, const WaveSeqArgs &w, hipStream_t s)
 {
-  if (dp->vitpkT > 0 && !g_vit_wave) {
+  if (dp->vitpkT > 0 && !g_vit_wave && !small_block(db, ctx)) {
     VitPkArgs a{};
     a.trans = dp->vitpk_trans; a.emis = dp->vitpk_emis; a.dsq = db->d_dsq; a.slot_off = db->d_slot_off; a.slot_len = db->d_slot_len;
     a.list = w.list; a.nlist = w.nlist; a.nlist_ptr = w.nlist_ptr; a.nrows = p.Kp + 1;
@@ -551,22 +561,99 @@ struct CascadeOut {
   double ms[8]{};
 };
 
-static int run_cascade(const p7x_pipeline_cfg &cfg, const p7x_oprofile *om, const p7x_seqdb *db, CascadeOut &out)
-{
+// One cascade in flight: the enqueue half queues every kernel of stage 1 on the workspace's stream and returns, the
+// collect half waits for them (once), repeats the survivor passes in the rare case that the row buffers were too small,
+// and downloads the small result arrays.  A host thread may keep several cascades in flight (hmmscan does: one per
+// model), each on its own workspace; the halves of one cascade must run on the thread that owns the workspace.
+struct CascadeRun {
+  p7x_pipeline_cfg cfg{};
+  const p7x_oprofile *om = nullptr;
+  const p7x_seqdb *db = nullptr;
   DeviceCtx *ctx = nullptr;
-  int st = get_ctx(db->device, &ctx);
-  if (st != P7X_OK) return st;
-  const Profile &p = om->p;
   DevProfile *dp = nullptr;
-  if ((st = get_dev_profile(om, ctx, &dp)) != P7X_OK) return st;
+  Workspace *ws = nullptr;
+  StageParams sp{};
+  bool queued = false, collected = false;
+  ~CascadeRun() { if (ws && queued && !collected) { (void) hipStreamSynchronize(ws->stream); ws->busy = false; } }
+};
+
+// Forward with the special-state rows kept, Backward, region scan for the survivors, sized for fin_cap of them (the
+// fin_cap longest targets bound their rows); the kernels read the survivor count from device memory.
+static int enqueue_survivor_passes(CascadeRun &r, int attempt, int nfin)
+{
+  const p7x_seqdb *db = r.db; Workspace *ws = r.ws; DeviceCtx *ctx = r.ctx; hipStream_t s = ws->stream;
+  int st = P7X_OK;
+  int64_t want_cap = std::min<int64_t>(db->nslots, std::max<int64_t>(4096, db->nslots / 64));
+  if (attempt > 0) want_cap = std::min<int64_t>(db->nslots, std::max<int64_t>(want_cap, (int64_t) nfin));
+  int64_t rows = 0;                                        // slots are sorted by decreasing length
+  for (int64_t sl = 0; sl < want_cap; ++sl) rows += (int64_t) db->h_len[db->h_order[sl]] + 1;
+  const int64_t want_floats = rows * 6;
+  if (want_floats > ws->xmx_cap) {
+    (void) hipFree(ws->xmx_f); (void) hipFree(ws->xmx_b); (void) hipFree(ws->xmx_s); ws->xmx_f = ws->xmx_b = ws->xmx_s = nullptr;
+    P7X_HIP(hipMalloc(&ws->xmx_f, (size_t) want_floats * 4)); P7X_HIP(hipMalloc(&ws->xmx_b, (size_t) want_floats * 4));
+    P7X_HIP(hipMalloc(&ws->xmx_s, (size_t) want_floats * 4));
+    ws->xmx_cap = want_floats;
+  }
+  if (want_cap > ws->fin_cap) {
+    (void) hipFree(ws->xmx_off); (void) hipFree(ws->reg_out); (void) hipFree(ws->bck_sc);
+    ws->xmx_off = nullptr; ws->reg_out = nullptr; ws->bck_sc = nullptr;
+    P7X_HIP(hipMalloc(&ws->xmx_off, (size_t) want_cap * 8));
+    P7X_HIP(hipMalloc(&ws->reg_out, (size_t) want_cap * (kRegionCap * 3 + 2) * 4));
+    P7X_HIP(hipMalloc(&ws->bck_sc, (size_t) want_cap * 4));
+    ws->fin_cap = want_cap;
+  }
+  const int64_t cap = ws->fin_cap;
+  P7X_HIP(hipMemsetAsync(&ws->b.counters[12], 0, 4, s));
+  hipLaunchKernelGGL(layout_rows_kernel, dim3(1), dim3(256), 0, s, &ws->b.counters[4], ws->b.list_fin, db->d_slot_len, ws->xmx_off,
+                     (int) std::min<int64_t>(cap, INT_MAX), &ws->b.counters[12]);
+  P7X_HIP(hipMemsetAsync(&ws->b.counters[5], 0, 3 * 4, s));
+  WaveSeqArgs a = ws_args(r.om->p, r.dp, db, ctx);
+  a.trans = r.dp->fwd_trans; a.emis = r.dp->fwd_emis; a.list = ws->b.list_fin; a.nlist_ptr = &ws->b.counters[4];
+  a.nlist = (int) std::min<int64_t>(cap, INT_MAX);          // sizes the grid only
+  a.counter = &ws->b.counters[5]; a.out_sc = ws->b.fwd_by_item; a.xmx = ws->xmx_f; a.xmx_off = ws->xmx_off;
+  a.abort_flag = &ws->b.counters[12];
+  if ((st = fwd_launch(a, ctx->num_cu, s)) != P7X_OK) return st;
+  if (attempt == 0) P7X_HIP(hipEventRecord(ws->ev[5], s));
+  a.counter = &ws->b.counters[6]; a.out_sc = ws->bck_sc; a.xmx = ws->xmx_b; a.fwd_xmx = ws->xmx_f;
+  if ((st = bck_launch(a, ctx->num_cu, s)) != P7X_OK) return st;
+  {   // posterior decoding of the special states and the region scan, on the rows where they are
+    RegionArgs ra{};
+    ra.nitems_ptr = &ws->b.counters[4]; ra.abort_flag = &ws->b.counters[12];
+    ra.list = ws->b.list_fin; ra.slot_len = db->d_slot_len; ra.fx = ws->xmx_f; ra.bx = ws->xmx_b;
+    ra.xmx_off = ws->xmx_off; ra.scratch = ws->xmx_s;
+    ra.out_regs = ws->reg_out; ra.out_n = ws->reg_out + (size_t) cap * kRegionCap * 3;
+    ra.out_nexpected = reinterpret_cast<float *>(ra.out_n + cap);
+    hipLaunchKernelGGL(regions_kernel, dim3((unsigned) (ctx->num_cu * 4)), dim3(256), 0, s, ra);
+    P7X_HIP(hipGetLastError());
+  }
+  if (attempt == 0) P7X_HIP(hipEventRecord(ws->ev[6], s));
+  P7X_HIP(hipMemcpyAsync(ws->h_counts, ws->b.counters, 16 * 4, hipMemcpyDeviceToHost, s));
+  P7X_HIP(hipEventRecord(ws->ev_sync, s));
+  return P7X_OK;
+}
+
+static int cascade_enqueue(CascadeRun &r)
+{
+  const p7x_pipeline_cfg &cfg = r.cfg; const p7x_oprofile *om = r.om; const p7x_seqdb *db = r.db;
+  int st = get_ctx(db->device, &r.ctx);
+  if (st != P7X_OK) return st;
+  DeviceCtx *ctx = r.ctx;
+  const Profile &p = om->p;
+  if ((st = get_dev_profile(om, ctx, &r.dp)) != P7X_OK) return st;
+  DevProfile *dp = r.dp;
   if (db->nslots == 0) return P7X_OK;
   if (dp->vitC <= 0 || dp->vitC > 32) { set_error("model too long for the device kernels (M > 2048)"); return P7X_EINVAL; }
-  Workspace *ws = nullptr;
-  if ((st = get_workspace(db->device, db->nslots, &ws)) != P7X_OK) return st;
+  if ((st = get_workspace(db->device, db->nslots, &r.ws)) != P7X_OK) return st;
+  Workspace *ws = r.ws;
   hipStream_t s = ws->stream;
-  const StageParams sp = make_params(p, cfg);
+  r.sp = make_params(p, cfg);
+  const StageParams &sp = r.sp;
+  ws->busy = true; r.queued = true;
   P7X_HIP(hipMemsetAsync(ws->b.counters, 0, 16 * 4, s));
-  {
+  // MSV launches that fill the device on their own are chained (two of them sharing the CUs only slow each other
+  // down); small blocks -- a scan's query sequences -- leave most of the device idle and run side by side instead
+  const bool fills_device = db->nslots / 64 >= (int64_t) ctx->num_cu * 8;
+  if (fills_device) {
     std::lock_guard<std::mutex> lk(ctx->msv_mu);          // enqueue order == chain order
     if (ctx->msv_last >= 0) P7X_HIP(hipStreamWaitEvent(s, ctx->msv_done[ctx->msv_last], 0));
     P7X_HIP(hipEventRecord(ws->ev[0], s));
@@ -574,6 +661,10 @@ static int run_cascade(const p7x_pipeline_cfg &cfg, const p7x_oprofile *om, cons
     P7X_HIP(hipEventRecord(ws->ev[7], s));
     ctx->msv_last = (ctx->msv_last + 1) & 1;
     P7X_HIP(hipEventRecord(ctx->msv_done[ctx->msv_last], s));
+  } else {
+    P7X_HIP(hipEventRecord(ws->ev[0], s));
+    if ((st = run_msv(p, dp, db, ctx, ws, s)) != P7X_OK) return st;
+    P7X_HIP(hipEventRecord(ws->ev[7], s));
   }
   {
     const unsigned grid = (unsigned) ((db->nslots + 255) / 256);
@@ -599,58 +690,22 @@ static int run_cascade(const p7x_pipeline_cfg &cfg, const p7x_oprofile *om, cons
     hipLaunchKernelGGL(decide_fwd_kernel, dim3(ctx->num_cu), dim3(256), 0, s, ws->b, sp);
   }
   P7X_HIP(hipEventRecord(ws->ev[4], s));
-  // ---- survivors: Forward again with the special-state rows kept, Backward, region scan -- still without the host:
-  //      the buffers are sized for fin_cap survivors (the fin_cap longest targets bound their rows), the kernels read
-  //      the survivor count from device memory, and only then does the host look.
+  return enqueue_survivor_passes(r, 0, 0);
+}
+
+static int cascade_collect(CascadeRun &r, CascadeOut &out)
+{
+  if (!r.queued || r.collected) return P7X_OK;
+  const p7x_pipeline_cfg &cfg = r.cfg; const p7x_seqdb *db = r.db; Workspace *ws = r.ws;
+  hipStream_t s = ws->stream;
+  struct Release { CascadeRun &r; ~Release() { (void) hipStreamSynchronize(r.ws->stream); r.ws->busy = false; r.collected = true; } } release{ r };
+  int st = P7X_OK;
   int nfin = 0;
   int64_t tot = 0;
   for (int attempt = 0; ; ++attempt) {
-    int64_t want_cap = std::min<int64_t>(db->nslots, std::max<int64_t>(4096, db->nslots / 64));
-    if (attempt > 0) want_cap = std::min<int64_t>(db->nslots, std::max<int64_t>(want_cap, (int64_t) nfin));
-    int64_t rows = 0;                                        // slots are sorted by decreasing length
-    for (int64_t sl = 0; sl < want_cap; ++sl) rows += (int64_t) db->h_len[db->h_order[sl]] + 1;
-    const int64_t want_floats = rows * 6;
-    if (want_floats > ws->xmx_cap) {
-      (void) hipFree(ws->xmx_f); (void) hipFree(ws->xmx_b); (void) hipFree(ws->xmx_s); ws->xmx_f = ws->xmx_b = ws->xmx_s = nullptr;
-      P7X_HIP(hipMalloc(&ws->xmx_f, (size_t) want_floats * 4)); P7X_HIP(hipMalloc(&ws->xmx_b, (size_t) want_floats * 4));
-      P7X_HIP(hipMalloc(&ws->xmx_s, (size_t) want_floats * 4));
-      ws->xmx_cap = want_floats;
-    }
-    if (want_cap > ws->fin_cap) {
-      (void) hipFree(ws->xmx_off); (void) hipFree(ws->reg_out); (void) hipFree(ws->bck_sc);
-      ws->xmx_off = nullptr; ws->reg_out = nullptr; ws->bck_sc = nullptr;
-      P7X_HIP(hipMalloc(&ws->xmx_off, (size_t) want_cap * 8));
-      P7X_HIP(hipMalloc(&ws->reg_out, (size_t) want_cap * (kRegionCap * 3 + 2) * 4));
-      P7X_HIP(hipMalloc(&ws->bck_sc, (size_t) want_cap * 4));
-      ws->fin_cap = want_cap;
-    }
-    const int64_t cap = ws->fin_cap;
-    P7X_HIP(hipMemsetAsync(&ws->b.counters[12], 0, 4, s));
-    hipLaunchKernelGGL(layout_rows_kernel, dim3(1), dim3(256), 0, s, &ws->b.counters[4], ws->b.list_fin, db->d_slot_len, ws->xmx_off,
-                       (int) std::min<int64_t>(cap, INT_MAX), &ws->b.counters[12]);
-    P7X_HIP(hipMemsetAsync(&ws->b.counters[5], 0, 3 * 4, s));
-    WaveSeqArgs a = ws_args(p, dp, db, ctx);
-    a.trans = dp->fwd_trans; a.emis = dp->fwd_emis; a.list = ws->b.list_fin; a.nlist_ptr = &ws->b.counters[4];
-    a.nlist = (int) std::min<int64_t>(cap, INT_MAX);          // sizes the grid only
-    a.counter = &ws->b.counters[5]; a.out_sc = ws->b.fwd_by_item; a.xmx = ws->xmx_f; a.xmx_off = ws->xmx_off;
-    a.abort_flag = &ws->b.counters[12];
-    if ((st = fwd_launch(a, ctx->num_cu, s)) != P7X_OK) return st;
-    if (attempt == 0) P7X_HIP(hipEventRecord(ws->ev[5], s));
-    a.counter = &ws->b.counters[6]; a.out_sc = ws->bck_sc; a.xmx = ws->xmx_b; a.fwd_xmx = ws->xmx_f;
-    if ((st = bck_launch(a, ctx->num_cu, s)) != P7X_OK) return st;
-    {   // posterior decoding of the special states and the region scan, on the rows where they are
-      RegionArgs ra{};
-      ra.nitems_ptr = &ws->b.counters[4]; ra.abort_flag = &ws->b.counters[12];
-      ra.list = ws->b.list_fin; ra.slot_len = db->d_slot_len; ra.fx = ws->xmx_f; ra.bx = ws->xmx_b;
-      ra.xmx_off = ws->xmx_off; ra.scratch = ws->xmx_s;
-      ra.out_regs = ws->reg_out; ra.out_n = ws->reg_out + (size_t) cap * kRegionCap * 3;
-      ra.out_nexpected = reinterpret_cast<float *>(ra.out_n + cap);
-      hipLaunchKernelGGL(regions_kernel, dim3((unsigned) (ctx->num_cu * 4)), dim3(256), 0, s, ra);
-      P7X_HIP(hipGetLastError());
-    }
-    if (attempt == 0) P7X_HIP(hipEventRecord(ws->ev[6], s));
-    P7X_HIP(hipMemcpyAsync(out.counts, ws->b.counters, 16 * 4, hipMemcpyDeviceToHost, s));
-    P7X_HIP(hipEventRecord(ws->ev_sync, s)); P7X_HIP(hipEventSynchronize(ws->ev_sync));   // our work only: other host threads share the stream
+    if (attempt > 0 && (st = enqueue_survivor_passes(r, attempt, nfin)) != P7X_OK) return st;
+    P7X_HIP(hipEventSynchronize(ws->ev_sync));              // our work only: other cascades run on other streams
+    std::memcpy(out.counts, ws->h_counts, 16 * 4);
     nfin = out.counts[4];
     if (out.counts[12] == 0) break;                            // everything fitted
     if (attempt > 0) { set_error("row buffers could not be sized for the Forward survivors"); return P7X_EMEM; }
@@ -688,6 +743,16 @@ static int run_cascade(const p7x_pipeline_cfg &cfg, const p7x_oprofile *om, cons
   for (int i = 0; i < 6; ++i) { float ms = 0; (void) hipEventElapsedTime(&ms, ws->ev[i], ws->ev[i + 1]); out.ms[i] = ms; }
   { float ms = 0; (void) hipEventElapsedTime(&ms, ws->ev[0], ws->ev[7]); out.ms[7] = ms; }
   return P7X_OK;
+}
+
+
+static int run_cascade(const p7x_pipeline_cfg &cfg, const p7x_oprofile *om, const p7x_seqdb *db, CascadeOut &out)
+{
+  CascadeRun r;
+  r.cfg = cfg; r.om = om; r.db = db;
+  const int st = cascade_enqueue(r);
+  if (st != P7X_OK) return st;
+  return cascade_collect(r, out);
 }
 
 // ---------------------------------------------------------------------------- envelope rescoring on the device
@@ -1007,14 +1072,16 @@ struct p7x_pending {
   p7x_pipeline_cfg cfg{};
   const p7x_oprofile *om = nullptr;
   const p7x_seqdb *db = nullptr;
+  CascadeRun run;
   CascadeOut co;
+  bool waited = false;
   std::chrono::steady_clock::time_point t0;
 };
 
-int p7x_search_block_begin(const p7x_pipeline_cfg *cfg, const p7x_oprofile *om, const float *bg_f, const p7x_seqdb *db,
-                           p7x_pending **out)
+int p7x_search_block_enqueue(const p7x_pipeline_cfg *cfg, const p7x_oprofile *om, const float *bg_f, const p7x_seqdb *db,
+                             p7x_pending **out)
 {
-  if (!cfg || !om || !db || !out) { set_error("p7x_search_block_begin: bad arguments"); return P7X_EINVAL; }
+  if (!cfg || !om || !db || !out) { set_error("p7x_search_block_enqueue: bad arguments"); return P7X_EINVAL; }
   (void) bg_f;
   *out = nullptr;
   auto pd = std::make_unique<p7x_pending>();
@@ -1025,10 +1092,33 @@ int p7x_search_block_begin(const p7x_pipeline_cfg *cfg, const p7x_oprofile *om, 
     if (p.cutoff[i] == P7X_CUTOFF_UNSET || p.cutoff[i + 1] == P7X_CUTOFF_UNSET) { set_error("model is missing the requested bit score cutoffs"); return P7X_EINVAL; }
   }
   pd->cfg = *cfg; pd->om = om; pd->db = db;
-  const int st = run_cascade(*cfg, om, db, pd->co);
+  pd->run.cfg = *cfg; pd->run.om = om; pd->run.db = db;
+  const int st = cascade_enqueue(pd->run);
   if (st != P7X_OK) return st;
-  pd->co.ms[6] = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - pd->t0).count();   // stage 1 wall
   *out = pd.release();
+  return P7X_OK;
+}
+
+int p7x_search_block_wait(p7x_pending *pd)
+{
+  if (!pd) { set_error("p7x_search_block_wait: bad arguments"); return P7X_EINVAL; }
+  if (pd->waited) return P7X_OK;
+  const int st = cascade_collect(pd->run, pd->co);
+  if (st != P7X_OK) return st;
+  pd->waited = true;
+  pd->co.ms[6] = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - pd->t0).count();   // stage 1 wall
+  return P7X_OK;
+}
+
+int p7x_search_block_begin(const p7x_pipeline_cfg *cfg, const p7x_oprofile *om, const float *bg_f, const p7x_seqdb *db,
+                           p7x_pending **out)
+{
+  if (!out) { set_error("p7x_search_block_begin: bad arguments"); return P7X_EINVAL; }
+  p7x_pending *pd = nullptr;
+  int st = p7x_search_block_enqueue(cfg, om, bg_f, db, &pd);
+  if (st != P7X_OK) return st;
+  if ((st = p7x_search_block_wait(pd)) != P7X_OK) { delete pd; *out = nullptr; return st; }
+  *out = pd;
   return P7X_OK;
 }
 
@@ -1037,6 +1127,7 @@ int p7x_search_block_finish(p7x_pending *pd, const char *const *names, const cha
 {
   if (!pd || !out) { set_error("p7x_search_block_finish: bad arguments"); return P7X_EINVAL; }
   std::unique_ptr<p7x_pending> owner(pd);                // consumed, also on failure
+  if (!pd->waited) { const int wst = p7x_search_block_wait(pd); if (wst != P7X_OK) return wst; }
   const auto t1 = std::chrono::steady_clock::now();
   const p7x_seqdb *db = pd->db; const p7x_oprofile *om = pd->om; CascadeOut &co = pd->co;
   HostTargets tg;

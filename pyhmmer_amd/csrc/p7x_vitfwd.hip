@@ -104,9 +104,12 @@ __global__ void __launch_bounds__(kWsBlock) vit_kernel(const WaveSeqArgs a)
   }
 }
 
-// ======================================================================================= MSV for long models
-// The lane-per-target kernels of p7x_msv.hip keep a whole DP row in registers and stop at M = 478.  Longer models
-// (a few per cent of Pfam) take this wave-per-target form of the same recurrence: lane z owns nodes zC+1..zC+C,
+// ======================================================================================= MSV, one target per wavefront
+// The lane-per-target kernels of p7x_msv.hip keep a whole DP row in registers and stop at M = 478, and they need
+// tens of thousands of targets to fill the device (64 per wavefront, a group lasts as long as its longest member).
+// Longer models (a few per cent of Pfam) and small target blocks (hmmscan's query sequences: a few thousand
+// wavefronts of work, where the latency of the longest sequence is what counts) take this wave-per-target form of
+// the same recurrence: lane z owns nodes zC+1..zC+C,
 // int arithmetic with the u8 semantics of impl_sse/msvfilter.c reproduced as in msv_kernel (floor at 0 is implied by
 // the next row's max(., xB); the 255 clip can only follow a row that already reported overflow).  ~4x the
 // instructions per cell of the fast kernel: a functional fallback, bit-exact (tests/test_gpu_filters.py).
@@ -510,6 +513,12 @@ int msv_wave_launch(const MsvWaveArgs &a, int num_cu, hipStream_t st)
     return P7X_OK;
   };
   switch (a.C) {
+    case 1:  return go(msv_wave_kernel<1>);
+    case 2:  return go(msv_wave_kernel<2>);
+    case 3:  return go(msv_wave_kernel<3>);
+    case 4:  return go(msv_wave_kernel<4>);
+    case 5:  return go(msv_wave_kernel<5>);
+    case 6:  return go(msv_wave_kernel<6>);
     case 8:  return go(msv_wave_kernel<8>);
     case 10: return go(msv_wave_kernel<10>);
     case 12: return go(msv_wave_kernel<12>);

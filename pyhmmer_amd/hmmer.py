@@ -91,6 +91,17 @@ class ShardedDatabase:
         """Stage 1 (device filters + parsers) of ``query`` on every shard."""
         return self._on_shards(lambda i: pipelines[i]._search_begin(query, self.shards[i]))
 
+    def enqueue(self, pipelines: Sequence[Pipeline], query) -> list:
+        """Queue stage 1 of ``query`` without waiting for it (one shard: the calling thread keeps several queries in
+        flight and must also call `wait`; several shards: the shards already run side by side, so this is `begin`)."""
+        if len(self.shards) == 1:
+            return [pipelines[0]._search_enqueue(query, self.shards[0])]
+        return self.begin(pipelines, query)
+
+    def wait(self, pendings: list) -> None:
+        if len(self.shards) == 1:
+            Pipeline._search_wait(pendings[0])
+
     def finish(self, pendings: list) -> TopHits:
         """Stage 2 (domain definition, hit lists) on every shard, then the merge."""
         results = self._on_shards(lambda i: Pipeline._search_finish(pendings[i]))
@@ -165,8 +176,9 @@ def hmmsearch(queries: Union[HMM, Profile, OptimizedProfile, Iterable], sequence
 
 
 def _run_queries(db: "ShardedDatabase", pipelines: Sequence[Pipeline], queries: Iterable, pipeline_depth: int,
-                 feeders: int) -> Iterator:
-    """Yield ``(query, TopHits)`` for every query, in order, overlapping the two stages of consecutive queries."""
+                 feeders: int, window: int = 1) -> Iterator:
+    """Yield ``(query, TopHits)`` for every query, in order, overlapping the two stages of consecutive queries.
+    ``window`` > 1: every feeder queues the device stage of that many queries before it waits for the oldest."""
     if pipeline_depth <= 0:
         for q in queries:
             yield q, db.search(pipelines, q)
@@ -185,9 +197,29 @@ def _run_queries(db: "ShardedDatabase", pipelines: Sequence[Pipeline], queries: 
     state = {"issued": 0, "exhausted": False, "live": nfeed}
 
     def feeder():
+        queued: "deque" = deque()         # (idx, query, pendings, error): device work queued by this thread, not yet waited for
+
+        def hand_over_oldest():
+            idx, q, pendings, err = queued.popleft()
+            if err is None:
+                try:
+                    db.wait(pendings)
+                except BaseException as e:          # forwarded to the caller like _base.py:305-318
+                    err = e
+                    for pend in pendings:
+                        _lib.lib().p7x_pending_destroy(pend[0])
+                    pendings = None
+            with lock:
+                staged[idx] = (q, pendings, err)
+                ready.notify_all()
+
         try:
             while not stop.is_set():
-                if not slots.acquire(timeout=0.1):
+                if queued:
+                    if not slots.acquire(blocking=False):   # the depth budget is spent: make room by finishing our oldest
+                        hand_over_oldest()
+                        continue
+                elif not slots.acquire(timeout=0.1):
                     continue
                 with lock:
                     if state["exhausted"] or stop.is_set():
@@ -207,13 +239,19 @@ def _run_queries(db: "ShardedDatabase", pipelines: Sequence[Pipeline], queries: 
                         return
                     state["issued"] = idx + 1
                 try:
-                    item = (q, db.begin(pipelines, q), None)
-                except BaseException as e:          # forwarded to the caller like _base.py:305-318
-                    item = (q, None, e)
-                with lock:
-                    staged[idx] = item
-                    ready.notify_all()
+                    queued.append((idx, q, db.enqueue(pipelines, q), None))
+                except BaseException as e:
+                    queued.append((idx, q, None, e))
+                if len(queued) >= window:
+                    hand_over_oldest()
         finally:
+            while queued:
+                if stop.is_set():                   # abandoned: release what was queued
+                    idx, q, pendings, err = queued.popleft()
+                    for pend in pendings or ():
+                        _lib.lib().p7x_pending_destroy(pend[0])
+                else:
+                    hand_over_oldest()
             with lock:
                 state["live"] -= 1
                 ready.notify_all()
@@ -274,7 +312,7 @@ def _run_queries(db: "ShardedDatabase", pipelines: Sequence[Pipeline], queries: 
 
 
 def hmmscan(queries, profiles, *, cpus: int = 0, callback: Optional[Callable] = None, devices: Optional[Sequence[int]] = None,
-            pipeline_depth: int = 8, feeders: int = 4, **options) -> Iterator[TopHits]:
+            pipeline_depth: int = 32, feeders: int = 2, window: int = 8, **options) -> Iterator[TopHits]:
     """Scan query sequences against a profile database; yields one ``TopHits`` per query sequence, in query order, whose
     hits are the profiles (reference ``hmmer/_hmmscan.py:90-231``, ``Pipeline.scan_seq`` ``plan7.pyx:6534-6622``).
 
@@ -286,7 +324,8 @@ def hmmscan(queries, profiles, *, cpus: int = 0, callback: Optional[Callable] = 
     are transposed into per-sequence hit lists (``p7x_scan_collect``): reportability with the running number of models,
     E-values with ``Z`` = number of profiles, per-sequence accounting.  A query block is small next to a search
     database, so one profile's kernels are a few wavefronts running for the length of the longest query: several profiles
-    are kept in flight on separate streams (``feeders``) to fill the device.
+    are kept in flight on separate device streams to fill the device: each of the ``feeders`` threads queues the
+    device stage of ``window`` profiles before it waits for the oldest one, at most ``pipeline_depth`` in total.
     """
     from .easel import DigitalSequence
     from .plan7 import _P7X_SCAN_MODELS
@@ -313,7 +352,7 @@ def hmmscan(queries, profiles, *, cpus: int = 0, callback: Optional[Callable] = 
     pipelines = [Pipeline(alphabet, device=d, host_threads=cpus, **options) for d in devs]
     for p in pipelines:
         p._mode = _P7X_SCAN_MODELS
-    per_model = [hits for _, hits in _run_queries(db, pipelines, profiles, pipeline_depth, feeders)]
+    per_model = [hits for _, hits in _run_queries(db, pipelines, profiles, pipeline_depth, feeders, window)]
     n = len(queries)
     out = (C.c_void_p * n)()
     shard = db.shards[0]

@@ -1266,19 +1266,31 @@ class Pipeline:
 
     # -- the two stages of a search (``p7x_search_block_begin`` / ``_finish``).  ``hmmer.hmmsearch`` runs stage 1
     #    of the next query while stage 2 of the previous one is still busy on the host.
-    def _search_begin(self, query, database: "SequenceDatabase", label=None):
+    def _search_begin(self, query, database: "SequenceDatabase", label=None, _entry="p7x_search_block_begin"):
         if query.alphabet != self.alphabet:
             raise AlphabetMismatch(self.alphabet, query.alphabet)
         om = self._get_om_from_query(query, self.L_HINT)
         cfg = self._cfg()
         pend = C.c_void_p()
         bgf = np.ascontiguousarray(self.background.residue_frequencies, dtype=np.float32)
-        st = _lib.lib().p7x_search_block_begin(C.byref(cfg), om._handle, bgf.ctypes.data, database._handle, C.byref(pend))
+        st = getattr(_lib.lib(), _entry)(C.byref(cfg), om._handle, bgf.ctypes.data, database._handle, C.byref(pend))
         if st == 11 and self.bit_cutoffs is not None:
             raise MissingCutoffs(om.name, self.bit_cutoffs)       # plan7.pyx:6424-6425
         if st != 0:
-            raise status_to_exception(st, "p7x_search_block_begin", _lib.last_error())
+            raise status_to_exception(st, _entry, _lib.last_error())
         return (pend, om, database, label if label is not None else query)
+
+    # stage 1 in two halves (``p7x_search_block_enqueue`` / ``_wait``): a thread queues the device work of several
+    # queries before it waits for the first (``hmmer.hmmscan`` keeps a window of models in flight this way).  Both
+    # halves of one search must run on the same thread.
+    def _search_enqueue(self, query, database: "SequenceDatabase", label=None):
+        return self._search_begin(query, database, label, _entry="p7x_search_block_enqueue")
+
+    @staticmethod
+    def _search_wait(pending) -> None:
+        st = _lib.lib().p7x_search_block_wait(pending[0])
+        if st != 0:
+            raise status_to_exception(st, "p7x_search_block_wait", _lib.last_error())
 
     @staticmethod
     def _search_finish(pending) -> TopHits:
