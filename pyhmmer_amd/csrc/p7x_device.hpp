@@ -2,6 +2,7 @@
 #pragma once
 #include "p7x_internal.hpp"
 #include <hip/hip_runtime.h>
+#include <map>
 #include <mutex>
 
 namespace p7x {
@@ -36,7 +37,15 @@ struct DeviceCtx {
   std::mutex msv_mu;
   hipEvent_t msv_done[2] = { nullptr, nullptr };
   int msv_last = -1;
+  // Device images of query profiles come and go with every query (a scan walks through thousands of models):
+  // hipMalloc / hipFree per image would serialise the host against the whole device, so freed slabs are kept here,
+  // by size class, and handed out again.
+  std::mutex slab_mu;
+  std::multimap<size_t, void *> slab_free;
+  size_t slab_free_bytes = 0;
 };
+int slab_acquire(DeviceCtx *ctx, size_t bytes, void **out, size_t *got);
+void slab_release(DeviceCtx *ctx, void *p, size_t bytes);
 int get_ctx(int device, DeviceCtx **out);
 
 // Device image of one query profile.
@@ -59,6 +68,8 @@ struct DevProfile {
   float *fwd_emis = nullptr;
   // bias filter: emission odds [kTabRows][2]
   float *bias_eo = nullptr;
+  // all of the tables above live in one device allocation taken from (and returned to) the context's slab pool
+  void *slab = nullptr; size_t slab_bytes = 0;
 };
 
 } // namespace p7x

@@ -23,17 +23,108 @@ static void chunk_transpose_fill(int M, int C, std::vector<int> &pos_of_node)
   for (int k = 1; k <= M; ++k) { const int z = (k - 1) / C, c = (k - 1) % C; pos_of_node[k] = c * 64 + z; }
 }
 
+// Pinned host blocks are recycled through a process-wide pool and never handed back to the runtime: hipHostFree from a
+// thread that is winding down (thread_local workspaces) while other threads drive the device is not something the
+// runtime tolerates reliably, and the blocks are small.
+struct PinnedPool { std::mutex mu; std::multimap<size_t, void *> free; };
+static PinnedPool &pinned_pool() { static PinnedPool *p = new PinnedPool(); return *p; }      // never destroyed
+static int pinned_acquire(size_t bytes, void **out, size_t *got)
+{
+  size_t want = 256;
+  while (want < bytes) want *= 2;
+  {
+    PinnedPool &pp = pinned_pool();
+    std::lock_guard<std::mutex> lk(pp.mu);
+    auto it = pp.free.find(want);
+    if (it != pp.free.end()) { *out = it->second; *got = want; pp.free.erase(it); return P7X_OK; }
+  }
+  P7X_HIP(hipHostMalloc(out, want, hipHostMallocDefault));
+  *got = want;
+  return P7X_OK;
+}
+static void pinned_release(void *p, size_t bytes)
+{
+  if (!p) return;
+  PinnedPool &pp = pinned_pool();
+  std::lock_guard<std::mutex> lk(pp.mu);
+  pp.free.emplace(bytes, p);
+}
+
+int slab_acquire(DeviceCtx *ctx, size_t bytes, void **out, size_t *got)
+{
+  const size_t want = ((bytes + 65535) / 65536) * 65536;
+  {
+    std::lock_guard<std::mutex> lk(ctx->slab_mu);
+    auto it = ctx->slab_free.lower_bound(want);
+    if (it != ctx->slab_free.end() && it->first <= want * 2) {
+      *out = it->second; *got = it->first; ctx->slab_free_bytes -= it->first; ctx->slab_free.erase(it);
+      return P7X_OK;
+    }
+  }
+  P7X_HIP(hipMalloc(out, want));
+  *got = want;
+  return P7X_OK;
+}
+
+void slab_release(DeviceCtx *ctx, void *p, size_t bytes)
+{
+  if (!p) return;
+  std::lock_guard<std::mutex> lk(ctx->slab_mu);
+  if (ctx->slab_free_bytes + bytes > ((size_t) 4 << 30)) { (void) hipFree(p); return; }   // keep at most 4 GiB parked
+  ctx->slab_free.emplace(bytes, p); ctx->slab_free_bytes += bytes;
+}
+
 static void free_dev_profile(DevProfile *d)
 {
   if (!d) return;
-  (void) hipSetDevice(d->device);
-  (void) hipFree(d->msv_tab); (void) hipFree(d->msvw_emis); (void) hipFree(d->vit_trans); (void) hipFree(d->vit_emis);
-  (void) hipFree(d->vitpk_trans); (void) hipFree(d->vitpk_emis);
-  (void) hipFree(d->fwd_trans); (void) hipFree(d->fwd_emis); (void) hipFree(d->bias_eo);
+  DeviceCtx *ctx = nullptr;
+  if (get_ctx(d->device, &ctx) == P7X_OK) slab_release(ctx, d->slab, d->slab_bytes);
   delete d;
 }
 
 struct DevCache { std::mutex mu; std::vector<DevProfile *> per_device; };
+
+// Host-side staging of a device image: the tables are laid out back to back (256-byte aligned) in one pinned buffer
+// and go up with one copy on a stream of the building thread.
+struct ImageStage {
+  char *pinned = nullptr; size_t cap = 0; hipStream_t stream = nullptr; int device = -1;
+  std::vector<std::pair<void **, size_t>> fix;      // pointer field in the DevProfile <- offset in the slab
+  size_t used = 0;
+  ~ImageStage() { pinned_release(pinned, cap); if (stream) (void) hipStreamDestroy(stream); }
+  int reserve(size_t bytes)
+  {
+    if (bytes <= cap) return P7X_OK;
+    pinned_release(pinned, cap);
+    pinned = nullptr; cap = 0;
+    void *p = nullptr; size_t got = 0;
+    const int st = pinned_acquire(std::max<size_t>(bytes, (size_t) 1 << 20), &p, &got);
+    if (st != P7X_OK) return st;
+    pinned = static_cast<char *>(p); cap = got;
+    return P7X_OK;
+  }
+};
+struct StagePool { std::mutex mu; std::vector<ImageStage *> idle; };
+static StagePool &stage_pool() { static StagePool *p = new StagePool(); return *p; }      // never destroyed
+struct StageLease {
+  ImageStage *st = nullptr;
+  StageLease()
+  {
+    StagePool &sp = stage_pool();
+    { std::lock_guard<std::mutex> lk(sp.mu); if (!sp.idle.empty()) { st = sp.idle.back(); sp.idle.pop_back(); } }
+    if (!st) st = new ImageStage();
+  }
+  ~StageLease() { std::lock_guard<std::mutex> lk(stage_pool().mu); stage_pool().idle.push_back(st); }
+};
+
+template <typename T, typename F>
+static int stage_table(ImageStage &st, std::vector<std::vector<char>> &parts, F **field, const std::vector<T> &v)
+{
+  const size_t off = st.used;
+  parts.emplace_back(reinterpret_cast<const char *>(v.data()), reinterpret_cast<const char *>(v.data()) + v.size() * sizeof(T));
+  st.fix.emplace_back(reinterpret_cast<void **>(field), off);
+  st.used = ((off + v.size() * sizeof(T) + 255) / 256) * 256;
+  return P7X_OK;
+}
 
 static int get_dev_profile(const p7x_oprofile *om, DeviceCtx *ctx, DevProfile **out)
 {
@@ -43,14 +134,17 @@ static int get_dev_profile(const p7x_oprofile *om, DeviceCtx *ctx, DevProfile **
   const Profile &p = om->p;
   auto d = std::make_unique<DevProfile>();
   d->device = ctx->device; d->M = p.M; d->Kp = p.Kp;
+  StageLease stage_lease;
+  ImageStage &stg = *stage_lease.st;
+  stg.fix.clear(); stg.used = 0;
+  std::vector<std::vector<char>> parts;
   // MSV parity tables
   d->msvR = msv_pick_R(p.M);
   if (d->msvR > 0) {
     d->msvS = msv_stride(d->msvR);
     std::vector<uint32_t> tab;
     msv_build_tables(p, d->msvR, d->msvS, tab);
-    P7X_HIP(hipMalloc(&d->msv_tab, tab.size() * 4));
-    P7X_HIP(hipMemcpy(d->msv_tab, tab.data(), tab.size() * 4, hipMemcpyHostToDevice));
+    stage_table(stg, parts, &d->msv_tab, tab);
   }
   // wave-per-sequence tables
   d->vitC = vit_pick_C(p.M);
@@ -75,12 +169,12 @@ static int get_dev_profile(const p7x_oprofile *om, DeviceCtx *ctx, DevProfile **
       std::vector<int16_t> me((size_t) kTabRows * Mpad, (int16_t) kNegPad);
       for (int k = 1; k <= p.M; ++k)
         for (int x = 0; x < p.Kp; ++x) me[(size_t) x * Mpad + pos[k]] = (int16_t) ((int) p.bias_b - (int) p.rb[(size_t) x * (p.M + 1) + k]);
-      P7X_HIP(hipMalloc(&d->msvw_emis, me.size() * 2)); P7X_HIP(hipMemcpy(d->msvw_emis, me.data(), me.size() * 2, hipMemcpyHostToDevice));
+      stage_table(stg, parts, &d->msvw_emis, me);
     }
-    P7X_HIP(hipMalloc(&d->vit_trans, vt.size() * 2)); P7X_HIP(hipMemcpy(d->vit_trans, vt.data(), vt.size() * 2, hipMemcpyHostToDevice));
-    P7X_HIP(hipMalloc(&d->vit_emis, ve.size() * 2));  P7X_HIP(hipMemcpy(d->vit_emis, ve.data(), ve.size() * 2, hipMemcpyHostToDevice));
-    P7X_HIP(hipMalloc(&d->fwd_trans, ft.size() * 4)); P7X_HIP(hipMemcpy(d->fwd_trans, ft.data(), ft.size() * 4, hipMemcpyHostToDevice));
-    P7X_HIP(hipMalloc(&d->fwd_emis, fe.size() * 4));  P7X_HIP(hipMemcpy(d->fwd_emis, fe.data(), fe.size() * 4, hipMemcpyHostToDevice));
+    stage_table(stg, parts, &d->vit_trans, vt);
+    stage_table(stg, parts, &d->vit_emis, ve);
+    stage_table(stg, parts, &d->fwd_trans, ft);
+    stage_table(stg, parts, &d->fwd_emis, fe);
   }
   {
     int T = 0, P = 0;
@@ -88,8 +182,8 @@ static int get_dev_profile(const p7x_oprofile *om, DeviceCtx *ctx, DevProfile **
       std::vector<uint32_t> tt, te;
       vitpk_build_tables(p, T, P, tt, te);
       d->vitpkT = T; d->vitpkP = P;
-      P7X_HIP(hipMalloc(&d->vitpk_trans, tt.size() * 4)); P7X_HIP(hipMemcpy(d->vitpk_trans, tt.data(), tt.size() * 4, hipMemcpyHostToDevice));
-      P7X_HIP(hipMalloc(&d->vitpk_emis, te.size() * 4));  P7X_HIP(hipMemcpy(d->vitpk_emis, te.data(), te.size() * 4, hipMemcpyHostToDevice));
+      stage_table(stg, parts, &d->vitpk_trans, tt);
+      stage_table(stg, parts, &d->vitpk_emis, te);
     }
   }
   // bias filter emission odds (esl_hmm_Configure on the 2-state filter HMM, p7_bg_SetFilter)
@@ -103,8 +197,28 @@ static int get_dev_profile(const p7x_oprofile *om, DeviceCtx *ctx, DevProfile **
         for (int y = 0; y < p.K; ++y) if (abc.degen[x][y]) { e += (s == 0 ? p.bgf[y] : p.compo[y]); den += p.bgf[y]; }
         eo[x * 2 + s] = den > 0.0f ? e / den : 0.0f;
       }
-    P7X_HIP(hipMalloc(&d->bias_eo, eo.size() * 4));
-    P7X_HIP(hipMemcpy(d->bias_eo, eo.data(), eo.size() * 4, hipMemcpyHostToDevice));
+    stage_table(stg, parts, &d->bias_eo, eo);
+  }
+  // one slab, one copy
+  {
+    int stq = P7X_OK;
+    if ((stq = stg.reserve(stg.used)) != P7X_OK) return stq;
+    if (stg.stream == nullptr || stg.device != ctx->device) {
+      if (stg.stream) (void) hipStreamDestroy(stg.stream);
+      P7X_HIP(hipStreamCreateWithFlags(&stg.stream, hipStreamNonBlocking));
+      stg.device = ctx->device;
+    }
+    if ((stq = slab_acquire(ctx, stg.used, &d->slab, &d->slab_bytes)) != P7X_OK) return stq;
+    for (size_t i = 0; i < parts.size(); ++i) {
+      std::memcpy(stg.pinned + stg.fix[i].second, parts[i].data(), parts[i].size());
+      *stg.fix[i].first = static_cast<char *>(d->slab) + stg.fix[i].second;
+    }
+    if (hipMemcpyAsync(d->slab, stg.pinned, stg.used, hipMemcpyHostToDevice, stg.stream) != hipSuccess ||
+        hipStreamSynchronize(stg.stream) != hipSuccess) {
+      slab_release(ctx, d->slab, d->slab_bytes);
+      set_error("uploading the profile's device image failed");
+      return P7X_EDEVICE;
+    }
   }
   *out = d.get();
   cache->per_device.push_back(d.release());
@@ -434,7 +548,7 @@ struct Workspace {
   hipEvent_t ev[8]{};
   hipEvent_t ev_sync = nullptr;
   hipStream_t stream = nullptr;     // one stream per cascade in flight: concurrent searches overlap on the device
-  int *h_counts = nullptr;          // pinned mirror of b.counters (the enqueue half must not block on a pageable copy)
+  int *h_counts = nullptr; size_t h_counts_bytes = 0;   // pinned mirror of b.counters (the enqueue half must not block on a pageable copy)
   bool busy = false;                // between the enqueue and the collect half of a cascade
   ~Workspace() {
     if (device < 0) return;
@@ -446,15 +560,31 @@ struct Workspace {
     for (auto &e : ev) if (e) (void) hipEventDestroy(e);
     if (ev_sync) (void) hipEventDestroy(ev_sync);
     if (stream) (void) hipStreamDestroy(stream);
-    if (h_counts) (void) hipHostFree(h_counts);
+    pinned_release(h_counts, h_counts_bytes);
   }
 };
 
-static thread_local std::vector<std::unique_ptr<Workspace>> tl_ws;
+// Workspaces are leased from a process-wide pool and returned to it (release_workspace); the pool is never torn down,
+// so no device memory, stream or event is destroyed from a thread that is exiting or at process exit.
+struct WorkspacePool { std::mutex mu; std::vector<Workspace *> all; };
+static WorkspacePool &ws_pool() { static WorkspacePool *p = new WorkspacePool(); return *p; }
+
+static void release_workspace(Workspace *w)
+{
+  if (!w) return;
+  std::lock_guard<std::mutex> lk(ws_pool().mu);
+  w->busy = false;
+}
 
 static int get_workspace(int device, int64_t nslots, Workspace **out)
 {
-  for (auto &w : tl_ws) if (!w->busy && w->device == device && w->cap_slots >= nslots) { *out = w.get(); return P7X_OK; }
+  {
+    std::lock_guard<std::mutex> lk(ws_pool().mu);
+    Workspace *best = nullptr;
+    for (Workspace *w : ws_pool().all)
+      if (!w->busy && w->device == device && w->cap_slots >= nslots && (!best || w->cap_slots < best->cap_slots)) best = w;
+    if (best) { best->busy = true; *out = best; return P7X_OK; }
+  }
   auto w = std::make_unique<Workspace>();
   w->device = device;
   const int64_t cap = std::max<int64_t>(64, ((nslots + 63) / 64) * 64);
@@ -466,7 +596,7 @@ static int get_workspace(int device, int64_t nslots, Workspace **out)
   P7X_HIP(hipMalloc(&w->b.list_bias, cap * 4)); P7X_HIP(hipMalloc(&w->b.list_vit, cap * 4));
   P7X_HIP(hipMalloc(&w->b.list_fwd, cap * 4)); P7X_HIP(hipMalloc(&w->b.list_fin, cap * 4));
   P7X_HIP(hipMalloc(&w->b.counters, 16 * 4));
-  P7X_HIP(hipHostMalloc(reinterpret_cast<void **>(&w->h_counts), 16 * 4, hipHostMallocDefault));
+  { void *hp = nullptr; const int pst = pinned_acquire(16 * 4, &hp, &w->h_counts_bytes); if (pst != P7X_OK) return pst; w->h_counts = static_cast<int *>(hp); }
   P7X_HIP(hipMalloc(&w->b.stage, cap));
   for (auto &e : w->ev) P7X_HIP(hipEventCreate(&e));
   P7X_HIP(hipEventCreateWithFlags(&w->ev_sync, hipEventDisableTiming));
@@ -476,10 +606,16 @@ static int get_workspace(int device, int64_t nslots, Workspace **out)
     P7X_HIP(hipDeviceGetStreamPriorityRange(&least, &greatest));
     P7X_HIP(hipStreamCreateWithPriority(&w->stream, hipStreamNonBlocking, greatest));
   }
+  w->busy = true;
   *out = w.get();
-  tl_ws.push_back(std::move(w));
+  std::lock_guard<std::mutex> lk(ws_pool().mu);
+  ws_pool().all.push_back(w.release());
   return P7X_OK;
 }
+struct WorkspaceLease {      // for the synchronous entry points
+  Workspace *w = nullptr;
+  ~WorkspaceLease() { release_workspace(w); }
+};
 
 static StageParams make_params(const Profile &p, const p7x_pipeline_cfg &cfg)
 {
@@ -564,7 +700,7 @@ struct CascadeOut {
 // One cascade in flight: the enqueue half queues every kernel of stage 1 on the workspace's stream and returns, the
 // collect half waits for them (once), repeats the survivor passes in the rare case that the row buffers were too small,
 // and downloads the small result arrays.  A host thread may keep several cascades in flight (hmmscan does: one per
-// model), each on its own workspace; the halves of one cascade must run on the thread that owns the workspace.
+// model), each on its own leased workspace.
 struct CascadeRun {
   p7x_pipeline_cfg cfg{};
   const p7x_oprofile *om = nullptr;
@@ -574,7 +710,7 @@ struct CascadeRun {
   Workspace *ws = nullptr;
   StageParams sp{};
   bool queued = false, collected = false;
-  ~CascadeRun() { if (ws && queued && !collected) { (void) hipStreamSynchronize(ws->stream); ws->busy = false; } }
+  ~CascadeRun() { if (ws && queued && !collected) { (void) hipStreamSynchronize(ws->stream); release_workspace(ws); } }
 };
 
 // Forward with the special-state rows kept, Backward, region scan for the survivors, sized for fin_cap of them (the
@@ -648,7 +784,7 @@ static int cascade_enqueue(CascadeRun &r)
   hipStream_t s = ws->stream;
   r.sp = make_params(p, cfg);
   const StageParams &sp = r.sp;
-  ws->busy = true; r.queued = true;
+  r.queued = true;
   P7X_HIP(hipMemsetAsync(ws->b.counters, 0, 16 * 4, s));
   // MSV launches that fill the device on their own are chained (two of them sharing the CUs only slow each other
   // down); small blocks -- a scan's query sequences -- leave most of the device idle and run side by side instead
@@ -698,7 +834,7 @@ static int cascade_collect(CascadeRun &r, CascadeOut &out)
   if (!r.queued || r.collected) return P7X_OK;
   const p7x_pipeline_cfg &cfg = r.cfg; const p7x_seqdb *db = r.db; Workspace *ws = r.ws;
   hipStream_t s = ws->stream;
-  struct Release { CascadeRun &r; ~Release() { (void) hipStreamSynchronize(r.ws->stream); r.ws->busy = false; r.collected = true; } } release{ r };
+  struct Release { CascadeRun &r; ~Release() { (void) hipStreamSynchronize(r.ws->stream); release_workspace(r.ws); r.collected = true; } } release{ r };
   int st = P7X_OK;
   int nfin = 0;
   int64_t tot = 0;
@@ -769,10 +905,19 @@ struct EnvBuffers {
     (void) hipSetDevice(device);
     if (stream) (void) hipStreamDestroy(stream);
     (void) hipFree(work); (void) hipFree(d_in); (void) hipFree(d_out);
-    if (h_out) (void) hipHostFree(h_out);
+    pinned_release(h_out, h_out_cap);
   }
 };
-static thread_local std::vector<std::unique_ptr<EnvBuffers>> tl_env;
+// leased from a process-wide pool like the cascade workspaces (never destroyed: no device teardown from exiting threads)
+struct EnvPool { std::mutex mu; std::vector<EnvBuffers *> all; std::vector<char> busy; };
+static EnvPool &env_pool() { static EnvPool *p = new EnvPool(); return *p; }
+static void release_env_buffers(EnvBuffers *eb)
+{
+  if (!eb) return;
+  EnvPool &ep = env_pool();
+  std::lock_guard<std::mutex> lk(ep.mu);
+  for (size_t i = 0; i < ep.all.size(); ++i) if (ep.all[i] == eb) ep.busy[i] = 0;
+}
 
 static size_t env_budget_bytes()
 {
@@ -786,6 +931,7 @@ static size_t env_budget_bytes()
 class DeviceEnvelopeScorer final : public EnvelopeScorer {
 public:
   DeviceEnvelopeScorer(DeviceCtx *ctx, const DevProfile *dp, const p7x_seqdb *db, const Profile &p) : ctx_(ctx), dp_(dp), db_(db), p_(p) {}
+  ~DeviceEnvelopeScorer() override { if (lease_) { if (lease_->stream) (void) hipStreamSynchronize(lease_->stream); release_env_buffers(lease_); } }
 
   int begin(const std::vector<EnvelopeRequest> &req, const std::vector<int32_t> &targets) override
   {
@@ -794,9 +940,15 @@ public:
     if (nenv == 0) return P7X_OK;
     P7X_HIP(hipSetDevice(db_->device));
     EnvBuffers *eb = nullptr;
-    for (auto &b : tl_env) if (b->device == db_->device) eb = b.get();
-    if (!eb) {
-      tl_env.push_back(std::make_unique<EnvBuffers>()); eb = tl_env.back().get(); eb->device = db_->device;
+    {
+      EnvPool &ep = env_pool();
+      std::lock_guard<std::mutex> lk(ep.mu);
+      for (size_t i = 0; i < ep.all.size() && !eb; ++i)
+        if (!ep.busy[i] && ep.all[i]->device == db_->device) { ep.busy[i] = 1; eb = ep.all[i]; }
+      if (!eb) { eb = new EnvBuffers(); eb->device = db_->device; ep.all.push_back(eb); ep.busy.push_back(1); }
+    }
+    lease_ = eb;
+    if (!eb->stream) {
       int least = 0, greatest = 0;
       P7X_HIP(hipDeviceGetStreamPriorityRange(&least, &greatest));
       P7X_HIP(hipStreamCreateWithPriority(&eb->stream, hipStreamNonBlocking, least));
@@ -847,10 +999,11 @@ public:
     const size_t out_bytes = o_tp + (size_t) ntr * 4;
     if (out_bytes > eb->d_out_cap) {
       (void) hipFree(eb->d_out); eb->d_out = nullptr;
-      if (eb->h_out) { (void) hipHostFree(eb->h_out); eb->h_out = nullptr; }
+      pinned_release(eb->h_out, eb->h_out_cap); eb->h_out = nullptr; eb->h_out_cap = 0;
       const size_t cap = out_bytes + out_bytes / 2;
       P7X_HIP(hipMalloc(&eb->d_out, cap)); eb->d_out_cap = cap;
-      P7X_HIP(hipHostMalloc(reinterpret_cast<void **>(&eb->h_out), cap, hipHostMallocDefault)); eb->h_out_cap = cap;
+      { void *hp = nullptr; size_t got = 0; const int pst = pinned_acquire(cap, &hp, &got); if (pst != P7X_OK) return pst;
+        eb->h_out = static_cast<decltype(eb->h_out)>(hp); eb->h_out_cap = got; }
     }
     hipStream_t s = eb->stream;
     P7X_HIP(hipMemcpyAsync(eb->d_in, h_in.data(), in_bytes, hipMemcpyHostToDevice, s));
@@ -906,6 +1059,7 @@ private:
   int nenv_ = 0;
   std::vector<unsigned char> h_in_;
   EnvBuffers *eb_ = nullptr;
+  EnvBuffers *lease_ = nullptr;
   size_t o_sc_ = 0, o_n2_ = 0, o_st_ = 0, o_n_ = 0, o_ta_ = 0, o_ti_ = 0, o_tp_ = 0;
 };
 
@@ -952,6 +1106,7 @@ int p7x_filters_batch(const p7x_oprofile *om, const p7x_seqdb *db, int32_t *xJ, 
   if (ns == 0) return P7X_OK;
   Workspace *ws = nullptr;
   if ((st = get_workspace(db->device, ns, &ws)) != P7X_OK) return st;
+  WorkspaceLease lease{ ws };
   hipStream_t s = ctx->stream;
   P7X_HIP(hipMemsetAsync(ws->b.counters, 0, 16 * 4, s));
   if (xJ) {
