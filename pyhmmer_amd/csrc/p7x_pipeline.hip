@@ -645,9 +645,12 @@ static const bool g_host_regions = std::getenv("P7X_HOST_REGIONS") != nullptr;  
 
 // A block with at most one 64-target group per SIMD cannot fill the device with the lane-per-target kernels and would
 // run for as long as its longest sequences take one wavefront: such blocks (hmmscan's queries) go one target per
-// wavefront through the filters instead.  P7X_SMALL_BLOCK=0 disables the switch (A/B).
-static const bool g_small_block = !(std::getenv("P7X_SMALL_BLOCK") && std::atoi(std::getenv("P7X_SMALL_BLOCK")) == 0);
-static bool small_block(const p7x_seqdb *db, const DeviceCtx *ctx) { return g_small_block && db->ngroups <= (int64_t) ctx->num_cu * 4; }
+// wavefront through the filters instead.  P7X_SMALL_BLOCK=0 disables the switch (A/B, and the tests' second pass).
+static bool small_block(const p7x_seqdb *db, const DeviceCtx *ctx)
+{ // read per call: the tests run every filter through both families of kernels
+  const char *e = std::getenv("P7X_SMALL_BLOCK");
+  return !(e && std::atoi(e) == 0) && db->ngroups <= (int64_t) ctx->num_cu * 4;
+}
 
 // Run MSV over the whole database; leaves xJ (slot order) in ws->b.xJ.
 static int run_msv(const Profile &p, const DevProfile *dp, const p7x_seqdb *db, DeviceCtx *ctx, Workspace *ws, hipStream_t stream)

@@ -13,6 +13,16 @@ from pyhmmer_amd import easel, plan7
 
 pytestmark = pytest.mark.gpu
 
+
+@pytest.fixture(autouse=True, params=["one-target-per-wavefront kernels for small blocks", "lane-per-target kernels"])
+def kernel_family(request, monkeypatch):
+    """Blocks of up to 65,536 targets normally take the wave-per-target MSV / Viterbi kernels (DESIGN.md section 3.4);
+    the second pass sends the same cases through the lane-per-target MSV and the packed Viterbi kernels."""
+    if request.param.startswith("lane"):
+        monkeypatch.setenv("P7X_SMALL_BLOCK", "0")
+    else:
+        monkeypatch.delenv("P7X_SMALL_BLOCK", raising=False)
+
 FWD_TOL_NATS = 2e-3      # |fwd_gpu - fwd_oracle| in nats (float32 sums in a different association order)
 BIAS_TOL_NATS = 1e-3
 

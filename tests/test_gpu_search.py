@@ -13,6 +13,16 @@ from test_oracle_golden import STAGE_COUNTS
 pytestmark = pytest.mark.gpu
 
 
+@pytest.fixture(autouse=True, params=["one-target-per-wavefront kernels for small blocks", "lane-per-target kernels"])
+def kernel_family(request, monkeypatch):
+    """Blocks of up to 65,536 targets normally take the wave-per-target MSV / Viterbi kernels (DESIGN.md section 3.4);
+    the second pass sends the same cases through the lane-per-target MSV and the packed Viterbi kernels."""
+    if request.param.startswith("lane"):
+        monkeypatch.setenv("P7X_SMALL_BLOCK", "0")
+    else:
+        monkeypatch.delenv("P7X_SMALL_BLOCK", raising=False)
+
+
 def test_pf02826_hits_and_domains_match_hmmer(models, proteome):
     hmm = models["PF02826"][0]
     hits = plan7.Pipeline(hmm.alphabet).search_hmm(hmm, proteome)
@@ -274,3 +284,32 @@ def test_written_tables_equal_hmmer_output_text(models, proteome, fmt, table):
     rows = [l.split() for l in out.getvalue().decode().splitlines()]
     want_rows = [r for r in golden_table("RREFam.scan.tbl") if r[2] == seq.name]
     assert [(r[0], r[1], r[2]) for r in rows] == [(r[0], r[1], r[2]) for r in want_rows]
+
+
+def test_one_thread_keeps_several_searches_in_flight(models, proteome):
+    """p7x_search_block_enqueue / _wait: stage 1 of every RREFam model is queued by this thread before it waits for any
+    of them; finished out of order; the results equal the blocking searches.  An un-waited handle can be dropped."""
+    db = plan7.SequenceDatabase(proteome)
+    pli = plan7.Pipeline(proteome.alphabet)
+    want = [pli.search_hmm(hmm, db) for hmm in models["RREFam"]]
+    pend = [pli._search_enqueue(hmm, db) for hmm in models["RREFam"]]
+    got = [None] * len(pend)
+    for i in reversed(range(len(pend))):
+        if i % 2:
+            plan7.Pipeline._search_wait(pend[i])
+            plan7.Pipeline._search_wait(pend[i])          # idempotent
+        got[i] = plan7.Pipeline._search_finish(pend[i])   # finish waits when the caller did not
+    for a, b in zip(got, want):
+        assert [(h.name, h.score, h.evalue, len(h.domains)) for h in a] == [(h.name, h.score, h.evalue, len(h.domains)) for h in b]
+        assert a.stage_counts == b.stage_counts
+    from pyhmmer_amd import _lib
+    dropped = pli._search_enqueue(models["RREFam"][0], db)
+    _lib.lib().p7x_pending_destroy(dropped[0])
+    again = pli.search_hmm(models["RREFam"][0], db)
+    assert [h.name for h in again] == [h.name for h in want[0]]
+    # hmmscan with a window larger than the number of models, and with one model in flight
+    seqs = [s for s in proteome][:64]
+    ref = [[(h.name, round(h.score, 3)) for h in th] for th in hmmer.hmmscan(seqs, models["RREFam"], feeders=1, pipeline_depth=1, window=1)]
+    for feeders, depth, window in ((1, 64, 64), (3, 5, 2), (2, 2, 8)):
+        res = [[(h.name, round(h.score, 3)) for h in th] for th in hmmer.hmmscan(seqs, models["RREFam"], feeders=feeders, pipeline_depth=depth, window=window)]
+        assert res == ref
