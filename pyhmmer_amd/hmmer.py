@@ -176,7 +176,7 @@ def hmmsearch(queries: Union[HMM, Profile, OptimizedProfile, Iterable], sequence
 
 
 def _run_queries(db: "ShardedDatabase", pipelines: Sequence[Pipeline], queries: Iterable, pipeline_depth: int,
-                 feeders: int, window: int = 1) -> Iterator:
+                 feeders: int, window: int = 1, finishers: int = 0) -> Iterator:
     """Yield ``(query, TopHits)`` for every query, in order, overlapping the two stages of consecutive queries.
     ``window`` > 1: every feeder queues the device stage of that many queries before it waits for the oldest."""
     if pipeline_depth <= 0:
@@ -262,7 +262,8 @@ def _run_queries(db: "ShardedDatabase", pipelines: Sequence[Pipeline], queries: 
     nxt = 0
     # the host stage of several queries may be in flight as well (each waits for its own envelope kernel): with one
     # feeder it runs in the caller's thread, with more a small pool finishes queries concurrently, results in order
-    pool = ThreadPoolExecutor(max_workers=nfeed, thread_name_prefix="p7x-hmmsearch-finish") if nfeed > 1 else None
+    nfin = finishers if finishers > 0 else nfeed
+    pool = ThreadPoolExecutor(max_workers=nfin, thread_name_prefix="p7x-hmmsearch-finish") if nfin > 1 else None
     inflight: "deque" = deque()
     try:
         while True:
@@ -285,7 +286,7 @@ def _run_queries(db: "ShardedDatabase", pipelines: Sequence[Pipeline], queries: 
                     yield q, db.finish(pendings)
                     continue
                 inflight.append((q, pool.submit(db.finish, pendings)))
-            while inflight and (inflight[0][1].done() or len(inflight) >= nfeed or drained):
+            while inflight and (inflight[0][1].done() or len(inflight) >= nfin or drained):
                 q, fut = inflight.popleft()
                 yield q, fut.result()
             if drained and not inflight:
@@ -312,7 +313,7 @@ def _run_queries(db: "ShardedDatabase", pipelines: Sequence[Pipeline], queries: 
 
 
 def hmmscan(queries, profiles, *, cpus: int = 0, callback: Optional[Callable] = None, devices: Optional[Sequence[int]] = None,
-            pipeline_depth: int = 32, feeders: int = 4, window: int = 4, **options) -> Iterator[TopHits]:
+            pipeline_depth: int = 32, feeders: int = 4, window: int = 4, finishers: int = 0, **options) -> Iterator[TopHits]:
     """Scan query sequences against a profile database; yields one ``TopHits`` per query sequence, in query order, whose
     hits are the profiles (reference ``hmmer/_hmmscan.py:90-231``, ``Pipeline.scan_seq`` ``plan7.pyx:6534-6622``).
 
@@ -352,7 +353,7 @@ def hmmscan(queries, profiles, *, cpus: int = 0, callback: Optional[Callable] = 
     pipelines = [Pipeline(alphabet, device=d, host_threads=cpus, **options) for d in devs]
     for p in pipelines:
         p._mode = _P7X_SCAN_MODELS
-    per_model = [hits for _, hits in _run_queries(db, pipelines, profiles, pipeline_depth, feeders, window)]
+    per_model = [hits for _, hits in _run_queries(db, pipelines, profiles, pipeline_depth, feeders, window, finishers)]
     n = len(queries)
     out = (C.c_void_p * n)()
     shard = db.shards[0]
