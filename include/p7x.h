@@ -267,6 +267,9 @@ int      p7x_tophits_sort_by_seqidx(p7x_tophits *th);    /* p7_tophits_SortBySeq
 int      p7x_tophits_is_sorted(const p7x_tophits *th, int by_seqidx);   /* TopHits.is_sorted, plan7.pyx:9078-9118; 1 / 0 */
 /* Hit.reported / included / dropped / duplicate setters (plan7.pyx:2125-2235): replace the P7X_IS_* flag word of hit i. */
 int      p7x_tophits_set_hit_flags(p7x_tophits *th, int64_t i, uint32_t flags);
+/* Hit.name / accession / description setters (plan7.pyx:1960-2050): which = 1 name (not NULL), 2 accession, 4 description
+ * (NULL clears); pointers handed out earlier by p7x_tophits_get_hit for this hit are invalidated. */
+int      p7x_tophits_set_hit_text(p7x_tophits *th, int64_t i, int which, const char *value);
 /* per-stage device timings of the search that produced th, milliseconds (HIP events):
  * [0] msv + P-value pass [1] bias filter [2] viterbi [3] forward [4] forward rows for survivors [5] backward, then
  * overwritten by host domain definition wall time (including [8]) [6] whole call wall time [7] the MSV kernel alone

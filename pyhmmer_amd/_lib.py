@@ -181,6 +181,7 @@ _SIGNATURES = {
     "p7x_tophits_sort_by_seqidx": (C.c_int, [_VP]),
     "p7x_tophits_is_sorted": (C.c_int, [_VP, C.c_int]),
     "p7x_tophits_set_hit_flags": (C.c_int, [_VP, C.c_int64, C.c_uint32]),
+    "p7x_tophits_set_hit_text": (C.c_int, [_VP, C.c_int64, C.c_int, C.c_char_p]),
     "p7x_tophits_get_timings": (C.c_int, [_VP, C.POINTER(C.c_double), C.c_int]),
     "p7x_search_block_begin": (C.c_int, [C.POINTER(PipelineCfg), _VP, _VP, _VP, C.POINTER(_VP)]),
     "p7x_search_block_enqueue": (C.c_int, [C.POINTER(PipelineCfg), _VP, _VP, _VP, C.POINTER(_VP)]),

@@ -565,6 +565,18 @@ int p7x_tophits_is_sorted(const p7x_tophits *th, int by_seqidx)
   }
   return 1;
 }
+int p7x_tophits_set_hit_text(p7x_tophits *th, int64_t i, int which, const char *value)
+{
+  if (!th || i < 0 || (size_t) i >= th->hits.size()) return P7X_EINVAL;
+  Hit &h = th->order.size() == th->hits.size() ? th->hits[th->order[i]] : th->hits[i];
+  switch (which) {
+    case 1: if (!value) return P7X_EINVAL; h.name = value; break;
+    case 2: h.has_acc = value != nullptr; h.acc = value ? value : ""; break;
+    case 4: h.has_desc = value != nullptr; h.desc = value ? value : ""; break;
+    default: return P7X_EINVAL;
+  }
+  return P7X_OK;
+}
 int p7x_tophits_set_hit_flags(p7x_tophits *th, int64_t i, uint32_t flags)
 {
   if (!th || i < 0 || (size_t) i >= th->hits.size()) return P7X_EINVAL;

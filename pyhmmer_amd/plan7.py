@@ -684,13 +684,23 @@ class Alignment:
         return self.domain._rec.N
 
     def __str__(self) -> str:
-        w = max(len(self.hmm_name or ""), len(self.target_name or ""))
-        return "\n".join([
-            f"{self.hmm_name:>{w}} {self.hmm_from:6d} {self.hmm_sequence} {self.hmm_to:<6d}",
-            f"{'':>{w}} {'':6} {self.identity_sequence}",
-            f"{self.target_name:>{w}} {self.target_from:6d} {self.target_sequence} {self.target_to:<6d}",
-            f"{'':>{w}} {'':6} {self.posterior_probabilities} PP",
-        ])
+        """One block, as ``p7_alidisplay_Print(fp, ad, 0, -1, FALSE)`` lays it out (reference ``plan7.pyx:262-281``):
+        optional RF / MM / CS annotation lines, model line, match line, target line, posterior line."""
+        r = self.domain._rec
+        hmm, sq = self.hmm_name or "", self.target_name or ""
+        nw = max(len(hmm), len(sq))
+        cw = max(len(str(v)) for v in (self.hmm_from, self.hmm_to, self.target_from, self.target_to))
+        pad = " " * (nw + cw + 1)
+        lines = []
+        for text, tag in ((_s(r.rfline), "RF"), (_s(r.mmline), "MM"), (_s(r.csline), "CS")):
+            if text:
+                lines.append(f"  {pad} {text} {tag}")
+        lines.append(f"  {hmm:>{nw}} {self.hmm_from:>{cw}d} {self.hmm_sequence} {self.hmm_to:<{cw}d}")
+        lines.append(f"  {pad} {self.identity_sequence}")
+        lines.append(f"  {sq:>{nw}} {self.target_from:>{cw}d} {self.target_sequence} {self.target_to:<{cw}d}")
+        if self.posterior_probabilities:
+            lines.append(f"  {pad} {self.posterior_probabilities} PP")
+        return "\n".join(lines) + "\n"
 
 
 class Domain:
@@ -794,9 +804,29 @@ class Hit:
         if st != 0:
             raise IndexError("list index out of range")
 
+    # name / accession / description are read through a fresh record: a setter on another `Hit` object of the same
+    # hit replaces the strings (reference ``plan7.pyx:1960-2050``; tests/test_plan7/test_hit.py:29-93)
+    def _fresh(self) -> "_lib.HitRec":
+        rec = _lib.HitRec()
+        if _lib.lib().p7x_tophits_get_hit(self.hits._handle, self._index, C.byref(rec)) != 0:
+            raise IndexError("list index out of range")
+        return rec
+
+    def _set_text(self, which: int, value: Optional[str]) -> None:
+        st = _lib.lib().p7x_tophits_set_hit_text(self.hits._handle, self._index, which, None if value is None else value.encode())
+        if st != 0:
+            raise ValueError("cannot set hit text")
+        self._rec = self._fresh()
+
     @property
     def name(self) -> str:
-        return self._rec.name.decode()
+        return self._fresh().name.decode()
+
+    @name.setter
+    def name(self, name: str) -> None:
+        if not isinstance(name, str):
+            raise TypeError(f"expected str, found {type(name).__name__}")
+        self._set_text(1, name)
 
     @property
     def seqidx(self) -> int:
@@ -805,11 +835,19 @@ class Hit:
 
     @property
     def accession(self) -> Optional[str]:
-        return _s(self._rec.acc)
+        return _s(self._fresh().acc)
+
+    @accession.setter
+    def accession(self, accession: Optional[str]) -> None:
+        self._set_text(2, accession)
 
     @property
     def description(self) -> Optional[str]:
-        return _s(self._rec.desc)
+        return _s(self._fresh().desc)
+
+    @description.setter
+    def description(self, description: Optional[str]) -> None:
+        self._set_text(4, description)
 
     @property
     def score(self) -> float:

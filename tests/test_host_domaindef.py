@@ -177,3 +177,36 @@ def test_host_tophits_api(models, oracle, proteome):
     hits.threshold()
     assert (len(hits.included), len(hits.reported)) == (15, 22)
     assert (len(base.included), len(base.reported)) == (15, 22)          # the copy was independent
+
+
+def test_host_hit_text_setters_and_alignment_rendering(models, oracle, proteome):
+    """reference tests/test_plan7/test_hit.py:29-93 and test_alignment.py:33-39."""
+    hmm = models["PF02826"][0]
+    base = host_pipeline.host_search(oracle, hmm, proteome)
+    hits = base.copy()
+    hit = hits[-1]
+    assert hit.name == hits[-1].name == base[-1].name == "938293.PRJEB85.HG003687_187" and hit.length == 281
+    hits[-1].name = "new name"
+    assert hit.name == hits[-1].name == "new name" and base[-1].name == "938293.PRJEB85.HG003687_187"
+    with pytest.raises(TypeError):
+        hit.name = None
+    assert hit.accession is None
+    hits[-1].accession = "NEW"
+    assert hit.accession == hits[-1].accession == "NEW" and base[-1].accession is None
+    hits[-1].accession = None
+    assert hit.accession is None
+    assert hit.description.startswith("# 202177 # 203019 #")
+    hits[-1].description = None
+    assert hit.description is None and base[-1].description.startswith("# 202177 # 203019 #")
+    hits[-1].description = "NEW"
+    assert hit.description == hits[-1].description == "NEW"
+    buf = io.BytesIO()
+    hits.write(buf, format="targets", header=False)
+    last = buf.getvalue().decode().splitlines()[-1]
+    assert last.startswith("new name") and last.endswith(" NEW")
+    ali = base[0].best_domain.alignment
+    lines = str(ali).splitlines()
+    assert len(lines) == 5                                   # CS, model, match, target, PP
+    assert lines[0].rstrip().endswith("CS") and lines[4].rstrip().endswith("PP")
+    assert lines[1].strip().startswith(base.query.name) and lines[3].strip().startswith(base[0].name)
+    assert len({len(l) - len(l.lstrip()) + l.lstrip().find(" ") for l in (lines[1], lines[3])}) == 1   # names right-aligned
