@@ -49,6 +49,108 @@ __device__ __forceinline__ int group_max(uint32_t v)
 
 } // namespace
 
+struct RowState { int xN, xB, xJ, xC; bool overflow; };
+
+// One DP row for the G targets of a wavefront: reads the previous row from (mi, ii, di), writes (mo_, io_, do_).
+template <int T, int P>
+__device__ __forceinline__ void vit_row(const VitPkArgs &a, const uint4 *tral, const uint4 *trbl, const uint4 *er, bool first,
+                                        bool active, int xwm, const uint32_t (&mi)[P], const uint32_t (&ii)[P],
+                                        const uint32_t (&di)[P], uint32_t (&mo_)[P], uint32_t (&io_)[P], uint32_t (&do_)[P],
+                                        RowState &rs)
+{
+  constexpr int PS = (P + 3) & ~3;
+  const uint32_t xBv = splat16(rs.xB);
+  // values of the previous lane's last register (previous row), -32768 at the start of a group
+  uint32_t mo = P7X_DPP_U(mi[P - 1], 0x138), io = P7X_DPP_U(ii[P - 1], 0x138), dob = P7X_DPP_U(di[P - 1], 0x138);
+  if (first) { mo = kNeg2; io = kNeg2; dob = kNeg2; }
+  uint32_t xEv = kNeg2, dmaxv = kNeg2, dcv_prev = kNeg2, dcv_last = kNeg2;
+#pragma unroll
+  for (int j4 = 0; j4 < PS; j4 += 4) {
+    const uint4 e4 = er[(j4 / 4) * T];
+    const uint32_t ev[4] = { e4.x, e4.y, e4.z, e4.w };
+#pragma unroll
+    for (int jj = 0; jj < 4; ++jj) {
+      const int j = j4 + jj;
+      if (j < P) {
+        const uint4 ta = tral[j * T], tb = trbl[j * T];          // BM MM IM DM | MD MI II DD
+        const uint32_t m_old = mi[j], i_old = ii[j], d_old = di[j];
+        const uint32_t mpv = shift_in(m_old, mo), ipv = shift_in(i_old, io), dpv = shift_in(d_old, dob);
+        uint32_t sv = pk_adds(xBv, ta.x);
+        sv = pk_max(sv, pk_adds(mpv, ta.y));
+        sv = pk_max(sv, pk_adds(ipv, ta.z));
+        sv = pk_max(sv, pk_adds(dpv, ta.w));
+        sv = pk_adds(sv, ev[jj]);
+        xEv = pk_max(xEv, sv);
+        mo_[j] = sv;
+        const uint32_t dcv = pk_adds(sv, tb.x);                  // M(i,k) -> D(i,k+1)
+        dmaxv = pk_max(dmaxv, dcv);
+        do_[j] = shift_in(dcv, dcv_prev);                        // register 0 is completed after the loop
+        io_[j] = pk_max(pk_adds(m_old, tb.y), pk_adds(i_old, tb.z));
+        mo = m_old; io = i_old; dob = d_old; dcv_prev = dcv;
+        if (j == P - 1) dcv_last = dcv;
+      }
+    }
+    // keep the LDS loads of later pairs behind this point: hoisting all 2P transition loads costs 8 VGPRs per pair
+    asm volatile("" ::: "memory");
+  }
+  {
+    uint32_t c = P7X_DPP_U(dcv_last, 0x138);
+    if (first) c = kNeg2;
+    do_[0] = (do_[0] & 0xffff0000u) | (c >> 16);                 // node s*2P+1 takes M(i, s*2P) + tMD from the lane before
+  }
+  const int xE = group_max<T>(xEv);
+  const int Dmax = group_max<T>(dmaxv);
+  if (active) {
+    if (xE >= 32767) rs.overflow = true;
+    rs.xC = max(rs.xC, xE + a.xw_e);               // xw[C][LOOP] = xw[J][LOOP] = xw[N][LOOP] = 0
+    rs.xJ = max(rs.xJ, xE + a.xw_e);
+    rs.xB = max(rs.xJ + xwm, rs.xN + xwm);
+  }
+  const bool trig = active && (Dmax + a.ddbound > rs.xB);          // lazy F, per target
+  if (__any(trig)) {
+    // D->D transitions of this lane; -32768 for targets that did not ask for the closure: their adds saturate to
+    // -32768 and the maxima below leave D untouched, so the closure runs in place
+    uint32_t tdd[P];
+#pragma unroll
+    for (int j = 0; j < P; ++j) { const uint32_t t = trbl[j * T].w; tdd[j] = trig ? t : kNeg2; }
+    for (int pass = 0; pass < T; ++pass) {
+      // serial closure inside the lane: e(n+1) = max(e(n+1), e(n) + tDD(n)) along the 2P packed elements
+      // Half-register (op_sel) forms of the 16-bit VOP3 ops walk the chain without unpacking: two instructions per
+      // element.  A partial register write needs one wait state before its result is read (gfx940 dst_sel
+      // forwarding hazard); the compiler does not see inside the asm, so the s_nops are written out.
+#pragma unroll
+      for (int j = 0; j < P; ++j) {
+        uint32_t tmp;
+        if (j + 1 < P)
+          asm volatile("s_nop 0\n\t"
+                       "v_add_i16 %2, %0, %3 clamp\n\t"                    // tmp.lo = d.lo + tDD(lo)
+                       "s_nop 0\n\t"
+                       "v_max3_i16 %0, %0, %2, %2 op_sel:[1,0,0,1]\n\t"    // d.hi   = max(d.hi, tmp.lo)
+                       "s_nop 0\n\t"
+                       "v_add_i16 %2, %0, %3 op_sel:[1,1,0] clamp\n\t"     // tmp.lo = d.hi + tDD(hi)
+                       "s_nop 0\n\t"
+                       "v_max3_i16 %1, %1, %2, %2"                          // next.lo = max(next.lo, tmp.lo), next.hi kept
+                       : "+v"(do_[j]), "+v"(do_[j + 1 < P ? j + 1 : j]), "=&v"(tmp) : "v"(tdd[j]));
+        else
+          asm volatile("s_nop 0\n\t"
+                       "v_add_i16 %1, %0, %2 clamp\n\t"
+                       "s_nop 0\n\t"
+                       "v_max3_i16 %0, %0, %1, %1 op_sel:[1,0,0,1]\n\t"
+                       "s_nop 0"
+                       : "+v"(do_[j]), "=&v"(tmp) : "v"(tdd[j]));
+      }
+      // carry into the next lane of the group; stop when nothing improves any more
+      const uint32_t tl = pk_adds(do_[P - 1], tdd[P - 1]);
+      uint32_t c = P7X_DPP_U(tl, 0x138);
+      if (first) c = kNeg2;
+      const int cand = trig ? hi_of(c) : -32768;
+      const bool better = cand > lo_of(do_[0]);
+      if (!__any(better)) break;
+      if (better) do_[0] = (do_[0] & 0xffff0000u) | ((uint32_t) cand & 0xffffu);
+    }
+  }
+}
+
 template <int T, int P>
 __global__ void __launch_bounds__(256) vitpk_kernel(const VitPkArgs a)
 {
@@ -87,11 +189,13 @@ __global__ void __launch_bounds__(256) vitpk_kernel(const VitPkArgs a)
     const int xwm = (int) a.xwmove_tab[L];
     const int Lmax = wave_max_i32(L);
 
-    uint32_t mm[P], im[P], dm[P];
+    // Two register sets for the rows: a row reads one and writes the other, so the old M / I / D of a pair stay
+    // where they are while the new ones are produced (one set would cost a register copy per pair and array per row)
+    uint32_t mA[P], iA[P], dA[P], mB[P], iB[P], dB[P];
 #pragma unroll
-    for (int j = 0; j < P; ++j) mm[j] = im[j] = dm[j] = kNeg2;
-    int xN = a.base_w, xB = xN + xwm, xJ = -32768, xC = -32768;
-    bool overflow = false;
+    for (int j = 0; j < P; ++j) mA[j] = iA[j] = dA[j] = kNeg2;
+    RowState rs;
+    rs.xN = a.base_w; rs.xB = rs.xN + xwm; rs.xJ = -32768; rs.xC = -32768; rs.overflow = false;
 
     for (int i0 = 0; i0 < Lmax; i0 += 4 * T) {
       // residues of the next 4T rows: lane s holds rows i0+4s .. i0+4s+3 of its target (clamped reads; rows past the
@@ -104,104 +208,22 @@ __global__ void __launch_bounds__(256) vitpk_kernel(const VitPkArgs a)
         word |= x << (8 * b);
       }
       const int nrow = min(4 * T, Lmax - i0);
-      for (int r = 0; r < nrow; ++r) {
-        const int i = i0 + r;
+      auto residue = [&](int r) -> uint32_t {
         const uint32_t w = (uint32_t) __shfl((int) word, g * T + (r >> 2));
-        const uint32_t x = (w >> (8 * (r & 3))) & 0xffu;
-        const bool active = i < L;
-        const uint4 *er = eml + x * ROWQ;
-        const uint32_t xBv = splat16(xB);
-        // values of the previous lane's last register (previous row), -32768 at the start of a group
-        uint32_t mo = P7X_DPP_U(mm[P - 1], 0x138), io = P7X_DPP_U(im[P - 1], 0x138), dob = P7X_DPP_U(dm[P - 1], 0x138);
-        if (first) { mo = kNeg2; io = kNeg2; dob = kNeg2; }
-        uint32_t xEv = kNeg2, dmaxv = kNeg2, dcv_prev = kNeg2, dcv_last = kNeg2;
+        return (w >> (8 * (r & 3))) & 0xffu;
+      };
+      int r = 0;
+      for (; r + 1 < nrow; r += 2) {
+        vit_row<T, P>(a, tral, trbl, eml + residue(r) * ROWQ, first, i0 + r < L, xwm, mA, iA, dA, mB, iB, dB, rs);
+        vit_row<T, P>(a, tral, trbl, eml + residue(r + 1) * ROWQ, first, i0 + r + 1 < L, xwm, mB, iB, dB, mA, iA, dA, rs);
+      }
+      if (r < nrow) {     // odd row count (only the last block of a group): one more row, then back into set A
+        vit_row<T, P>(a, tral, trbl, eml + residue(r) * ROWQ, first, i0 + r < L, xwm, mA, iA, dA, mB, iB, dB, rs);
 #pragma unroll
-        for (int j4 = 0; j4 < PS; j4 += 4) {
-          const uint4 e4 = er[(j4 / 4) * T];
-          const uint32_t ev[4] = { e4.x, e4.y, e4.z, e4.w };
-#pragma unroll
-          for (int jj = 0; jj < 4; ++jj) {
-            const int j = j4 + jj;
-            if (j < P) {
-              const uint4 ta = tral[j * T], tb = trbl[j * T];          // BM MM IM DM | MD MI II DD
-              const uint32_t m_old = mm[j], i_old = im[j], d_old = dm[j];
-              const uint32_t mpv = shift_in(m_old, mo), ipv = shift_in(i_old, io), dpv = shift_in(d_old, dob);
-              uint32_t sv = pk_adds(xBv, ta.x);
-              sv = pk_max(sv, pk_adds(mpv, ta.y));
-              sv = pk_max(sv, pk_adds(ipv, ta.z));
-              sv = pk_max(sv, pk_adds(dpv, ta.w));
-              sv = pk_adds(sv, ev[jj]);
-              xEv = pk_max(xEv, sv);
-              mm[j] = sv;
-              const uint32_t dcv = pk_adds(sv, tb.x);                  // M(i,k) -> D(i,k+1)
-              dmaxv = pk_max(dmaxv, dcv);
-              dm[j] = shift_in(dcv, dcv_prev);                         // register 0 is completed after the loop
-              im[j] = pk_max(pk_adds(m_old, tb.y), pk_adds(i_old, tb.z));
-              mo = m_old; io = i_old; dob = d_old; dcv_prev = dcv;
-              if (j == P - 1) dcv_last = dcv;
-            }
-          }
-          // keep the LDS loads of later pairs behind this point: hoisting all 2P transition loads costs 8 VGPRs per pair
-          asm volatile("" ::: "memory");
-        }
-        {
-          uint32_t c = P7X_DPP_U(dcv_last, 0x138);
-          if (first) c = kNeg2;
-          dm[0] = (dm[0] & 0xffff0000u) | (c >> 16);                   // node s*2P+1 takes M(i, s*2P) + tMD from the lane before
-        }
-        const int xE = group_max<T>(xEv);
-        const int Dmax = group_max<T>(dmaxv);
-        if (active) {
-          if (xE >= 32767) overflow = true;
-          xC = max(xC, xE + a.xw_e);               // xw[C][LOOP] = xw[J][LOOP] = xw[N][LOOP] = 0
-          xJ = max(xJ, xE + a.xw_e);
-          xB = max(xJ + xwm, xN + xwm);
-        }
-        const bool trig = active && (Dmax + a.ddbound > xB);            // lazy F, per target
-        if (__any(trig)) {
-          // D->D transitions of this lane; -32768 for targets that did not ask for the closure: their adds saturate to
-          // -32768 and the maxima below leave D untouched, so the closure runs in place
-          uint32_t tdd[P];
-#pragma unroll
-          for (int j = 0; j < P; ++j) { const uint32_t t = trbl[j * T].w; tdd[j] = trig ? t : kNeg2; }
-          for (int pass = 0; pass < T; ++pass) {
-            // serial closure inside the lane: e(n+1) = max(e(n+1), e(n) + tDD(n)) along the 2P packed elements
-            // Half-register (op_sel) forms of the 16-bit VOP3 ops walk the chain without unpacking: two instructions per
-            // element.  A partial register write needs one wait state before its result is read (gfx940 dst_sel
-            // forwarding hazard); the compiler does not see inside the asm, so the s_nops are written out.
-#pragma unroll
-            for (int j = 0; j < P; ++j) {
-              uint32_t tmp;
-              if (j + 1 < P)
-                asm volatile("s_nop 0\n\t"
-                             "v_add_i16 %2, %0, %3 clamp\n\t"                    // tmp.lo = d.lo + tDD(lo)
-                             "s_nop 0\n\t"
-                             "v_max3_i16 %0, %0, %2, %2 op_sel:[1,0,0,1]\n\t"    // d.hi   = max(d.hi, tmp.lo)
-                             "s_nop 0\n\t"
-                             "v_add_i16 %2, %0, %3 op_sel:[1,1,0] clamp\n\t"     // tmp.lo = d.hi + tDD(hi)
-                             "s_nop 0\n\t"
-                             "v_max3_i16 %1, %1, %2, %2"                          // next.lo = max(next.lo, tmp.lo), next.hi kept
-                             : "+v"(dm[j]), "+v"(dm[j + 1 < P ? j + 1 : j]), "=&v"(tmp) : "v"(tdd[j]));
-              else
-                asm volatile("s_nop 0\n\t"
-                             "v_add_i16 %1, %0, %2 clamp\n\t"
-                             "s_nop 0\n\t"
-                             "v_max3_i16 %0, %0, %1, %1 op_sel:[1,0,0,1]\n\t"
-                             "s_nop 0"
-                             : "+v"(dm[j]), "=&v"(tmp) : "v"(tdd[j]));
-            }
-            // carry into the next lane of the group; stop when nothing improves any more
-            const uint32_t tl = pk_adds(dm[P - 1], tdd[P - 1]);
-            uint32_t c = P7X_DPP_U(tl, 0x138);
-            if (first) c = kNeg2;
-            const int cand = trig ? hi_of(c) : -32768;
-            const bool better = cand > lo_of(dm[0]);
-            if (!__any(better)) break;
-            if (better) dm[0] = (dm[0] & 0xffff0000u) | ((uint32_t) cand & 0xffffu);
-          }
-        }
+        for (int j = 0; j < P; ++j) { mA[j] = mB[j]; iA[j] = iB[j]; dA[j] = dB[j]; }
       }
     }
+    const bool overflow = rs.overflow; const int xC = rs.xC;
     if (have && s == 0) a.out_xC[it] = overflow ? 32767 : xC;
   }
 }
