@@ -113,7 +113,9 @@ __device__ __forceinline__ void vit_row(const VitPkArgs &a, const uint4 *tral, c
     uint32_t tdd[P];
 #pragma unroll
     for (int j = 0; j < P; ++j) { const uint32_t t = trbl[j * T].w; tdd[j] = trig ? t : kNeg2; }
-    for (int pass = 0; pass < T; ++pass) {
+    int pass = 0;
+    bool more;
+    do {
       // serial closure inside the lane: e(n+1) = max(e(n+1), e(n) + tDD(n)) along the 2P packed elements
       // Half-register (op_sel) forms of the 16-bit VOP3 ops walk the chain without unpacking: two instructions per
       // element.  A partial register write needs one wait state before its result is read (gfx940 dst_sel
@@ -145,9 +147,9 @@ __device__ __forceinline__ void vit_row(const VitPkArgs &a, const uint4 *tral, c
       if (first) c = kNeg2;
       const int cand = trig ? hi_of(c) : -32768;
       const bool better = cand > lo_of(do_[0]);
-      if (!__any(better)) break;
       if (better) do_[0] = (do_[0] & 0xffff0000u) | ((uint32_t) cand & 0xffffu);
-    }
+      more = __any(better) && ++pass < T;        // a carry crosses at most T-1 lanes
+    } while (more);
   }
 }
 
