@@ -46,6 +46,9 @@ struct DeviceCtx {
 };
 int slab_acquire(DeviceCtx *ctx, size_t bytes, void **out, size_t *got);
 void slab_release(DeviceCtx *ctx, void *p, size_t bytes);
+// pinned host blocks from a process-wide pool that is never torn down (p7x_devimage.hip)
+int pinned_acquire(size_t bytes, void **out, size_t *got);
+void pinned_release(void *p, size_t bytes);
 int get_ctx(int device, DeviceCtx **out);
 
 // Device image of one query profile.
@@ -71,6 +74,18 @@ struct DevProfile {
   // all of the tables above live in one device allocation taken from (and returned to) the context's slab pool
   void *slab = nullptr; size_t slab_bytes = 0;
 };
+
+// Device image of om for ctx's device, built and uploaded on first use (p7x_devimage.hip); owned by the oprofile.
+int get_dev_profile(const p7x_oprofile *om, DeviceCtx *ctx, DevProfile **out);
+void free_dev_profile(DevProfile *d);
+
+// host driver of the envelope kernel (p7x_envscore.hip), behind the EnvelopeScorer interface of p7x_host.hpp
+struct EnvelopeScorer;
+}
+struct p7x_seqdb;
+#include <memory>
+namespace p7x {
+std::unique_ptr<EnvelopeScorer> make_device_envelope_scorer(DeviceCtx *ctx, const DevProfile *dp, const p7x_seqdb *db, const Profile &p);
 
 } // namespace p7x
 

@@ -1,0 +1,243 @@
+// p7x_devimage.hip -- the device image of a query profile, and the pools it is cut from.
+//
+// A query's tables (MSV parity tables, wave-per-target MSV emissions, Viterbi / packed Viterbi / Forward transitions
+// and emissions, bias-filter odds) are laid out back to back in one device slab and uploaded with one copy.  Slabs,
+// staging buffers and pinned blocks come from process-wide pools that are never handed back to the runtime: a scan
+// walks through thousands of short-lived profiles, and hipMalloc / hipFree / hipHostFree per profile (or from a
+// thread that is winding down) would serialise the host against the whole device.
+#include "p7x_device.hpp"
+#include "p7x_kernels.hpp"
+#include <cstring>
+#include <memory>
+
+namespace p7x {
+
+// ---------------------------------------------------------------------------- device profile image
+static void chunk_transpose_fill(int M, int C, std::vector<int> &pos_of_node)
+{ // node k (1..M) -> table position c*64 + z with k = z*C + c + 1
+  pos_of_node.assign(M + 1, -1);
+  for (int k = 1; k <= M; ++k) { const int z = (k - 1) / C, c = (k - 1) % C; pos_of_node[k] = c * 64 + z; }
+}
+
+// Pinned host blocks are recycled through a process-wide pool and never handed back to the runtime: hipHostFree from a
+// thread that is winding down (thread_local workspaces) while other threads drive the device is not something the
+// runtime tolerates reliably, and the blocks are small.
+struct PinnedPool { std::mutex mu; std::multimap<size_t, void *> free; };
+static PinnedPool &pinned_pool() { static PinnedPool *p = new PinnedPool(); return *p; }      // never destroyed
+int pinned_acquire(size_t bytes, void **out, size_t *got)
+{
+  size_t want = 256;
+  while (want < bytes) want *= 2;
+  {
+    PinnedPool &pp = pinned_pool();
+    std::lock_guard<std::mutex> lk(pp.mu);
+    auto it = pp.free.find(want);
+    if (it != pp.free.end()) { *out = it->second; *got = want; pp.free.erase(it); return P7X_OK; }
+  }
+  P7X_HIP(hipHostMalloc(out, want, hipHostMallocDefault));
+  *got = want;
+  return P7X_OK;
+}
+void pinned_release(void *p, size_t bytes)
+{
+  if (!p) return;
+  PinnedPool &pp = pinned_pool();
+  std::lock_guard<std::mutex> lk(pp.mu);
+  pp.free.emplace(bytes, p);
+}
+
+int slab_acquire(DeviceCtx *ctx, size_t bytes, void **out, size_t *got)
+{
+  const size_t want = ((bytes + 65535) / 65536) * 65536;
+  {
+    std::lock_guard<std::mutex> lk(ctx->slab_mu);
+    auto it = ctx->slab_free.lower_bound(want);
+    if (it != ctx->slab_free.end() && it->first <= want * 2) {
+      *out = it->second; *got = it->first; ctx->slab_free_bytes -= it->first; ctx->slab_free.erase(it);
+      return P7X_OK;
+    }
+  }
+  P7X_HIP(hipMalloc(out, want));
+  *got = want;
+  return P7X_OK;
+}
+
+void slab_release(DeviceCtx *ctx, void *p, size_t bytes)
+{
+  if (!p) return;
+  std::lock_guard<std::mutex> lk(ctx->slab_mu);
+  if (ctx->slab_free_bytes + bytes > ((size_t) 4 << 30)) { (void) hipFree(p); return; }   // keep at most 4 GiB parked
+  ctx->slab_free.emplace(bytes, p); ctx->slab_free_bytes += bytes;
+}
+
+void free_dev_profile(DevProfile *d)
+{
+  if (!d) return;
+  DeviceCtx *ctx = nullptr;
+  if (get_ctx(d->device, &ctx) == P7X_OK) slab_release(ctx, d->slab, d->slab_bytes);
+  delete d;
+}
+
+struct DevCache { std::mutex mu; std::vector<DevProfile *> per_device; };
+
+// Host-side staging of a device image: the tables are laid out back to back (256-byte aligned) in one pinned buffer
+// and go up with one copy on a stream of the building thread.
+struct ImageStage {
+  char *pinned = nullptr; size_t cap = 0; hipStream_t stream = nullptr; int device = -1;
+  std::vector<std::pair<void **, size_t>> fix;      // pointer field in the DevProfile <- offset in the slab
+  size_t used = 0;
+  ~ImageStage() { pinned_release(pinned, cap); if (stream) (void) hipStreamDestroy(stream); }
+  int reserve(size_t bytes)
+  {
+    if (bytes <= cap) return P7X_OK;
+    pinned_release(pinned, cap);
+    pinned = nullptr; cap = 0;
+    void *p = nullptr; size_t got = 0;
+    const int st = pinned_acquire(std::max<size_t>(bytes, (size_t) 1 << 20), &p, &got);
+    if (st != P7X_OK) return st;
+    pinned = static_cast<char *>(p); cap = got;
+    return P7X_OK;
+  }
+};
+struct StagePool { std::mutex mu; std::vector<ImageStage *> idle; };
+static StagePool &stage_pool() { static StagePool *p = new StagePool(); return *p; }      // never destroyed
+struct StageLease {
+  ImageStage *st = nullptr;
+  StageLease()
+  {
+    StagePool &sp = stage_pool();
+    { std::lock_guard<std::mutex> lk(sp.mu); if (!sp.idle.empty()) { st = sp.idle.back(); sp.idle.pop_back(); } }
+    if (!st) st = new ImageStage();
+  }
+  ~StageLease() { std::lock_guard<std::mutex> lk(stage_pool().mu); stage_pool().idle.push_back(st); }
+};
+
+template <typename T, typename F>
+static int stage_table(ImageStage &st, std::vector<std::vector<char>> &parts, F **field, const std::vector<T> &v)
+{
+  const size_t off = st.used;
+  parts.emplace_back(reinterpret_cast<const char *>(v.data()), reinterpret_cast<const char *>(v.data()) + v.size() * sizeof(T));
+  st.fix.emplace_back(reinterpret_cast<void **>(field), off);
+  st.used = ((off + v.size() * sizeof(T) + 255) / 256) * 256;
+  return P7X_OK;
+}
+
+int get_dev_profile(const p7x_oprofile *om, DeviceCtx *ctx, DevProfile **out)
+{
+  auto *cache = static_cast<DevCache *>(om->dev_cache);
+  std::lock_guard<std::mutex> lk(cache->mu);
+  for (DevProfile *d : cache->per_device) if (d->device == ctx->device) { *out = d; return P7X_OK; }
+  const Profile &p = om->p;
+  auto d = std::make_unique<DevProfile>();
+  d->device = ctx->device; d->M = p.M; d->Kp = p.Kp;
+  StageLease stage_lease;
+  ImageStage &stg = *stage_lease.st;
+  stg.fix.clear(); stg.used = 0;
+  std::vector<std::vector<char>> parts;
+  // MSV parity tables
+  d->msvR = msv_pick_R(p.M);
+  if (d->msvR > 0) {
+    d->msvS = msv_stride(d->msvR);
+    std::vector<uint32_t> tab;
+    msv_build_tables(p, d->msvR, d->msvS, tab);
+    stage_table(stg, parts, &d->msv_tab, tab);
+  }
+  // wave-per-sequence tables
+  d->vitC = vit_pick_C(p.M);
+  if (d->vitC > 0) {
+    const int C = d->vitC, Mpad = 64 * C, nrows = p.Kp + 1;
+    d->Mpad = Mpad;
+    std::vector<int> pos;
+    chunk_transpose_fill(p.M, C, pos);
+    std::vector<int16_t> vt((size_t) Mpad * 8, -32768), ve((size_t) nrows * Mpad, -32768);
+    std::vector<float> ft((size_t) Mpad * 8, 0.0f), fe((size_t) nrows * Mpad, 0.0f);
+    for (int k = 1; k <= p.M; ++k) {
+      for (int t = 0; t < NTRANS; ++t) {
+        vt[(size_t) pos[k] * 8 + t] = p.tw[(size_t) t * (p.M + 1) + k];
+        ft[(size_t) pos[k] * 8 + t] = p.tf[(size_t) t * (p.M + 1) + k];
+      }
+      for (int x = 0; x < p.Kp; ++x) {
+        ve[(size_t) x * Mpad + pos[k]] = p.rw[(size_t) x * (p.M + 1) + k];
+        fe[(size_t) x * Mpad + pos[k]] = p.rf_[(size_t) x * (p.M + 1) + k];
+      }
+    }
+    {     // emission table of the wave-per-target MSV kernel (long models, small target blocks), same node order as Viterbi's
+      std::vector<int16_t> me((size_t) kTabRows * Mpad, (int16_t) kNegPad);
+      for (int k = 1; k <= p.M; ++k)
+        for (int x = 0; x < p.Kp; ++x) me[(size_t) x * Mpad + pos[k]] = (int16_t) ((int) p.bias_b - (int) p.rb[(size_t) x * (p.M + 1) + k]);
+      stage_table(stg, parts, &d->msvw_emis, me);
+    }
+    stage_table(stg, parts, &d->vit_trans, vt);
+    stage_table(stg, parts, &d->vit_emis, ve);
+    stage_table(stg, parts, &d->fwd_trans, ft);
+    stage_table(stg, parts, &d->fwd_emis, fe);
+  }
+  {
+    int T = 0, P = 0;
+    if (vitpk_pick(p.M, &T, &P)) {
+      std::vector<uint32_t> tt, te;
+      vitpk_build_tables(p, T, P, tt, te);
+      d->vitpkT = T; d->vitpkP = P;
+      stage_table(stg, parts, &d->vitpk_trans, tt);
+      stage_table(stg, parts, &d->vitpk_emis, te);
+    }
+  }
+  // bias filter emission odds (esl_hmm_Configure on the 2-state filter HMM, p7_bg_SetFilter)
+  {
+    const Alphabet &abc = Alphabet::get(p.abc_type);
+    std::vector<float> eo((size_t) kTabRows * 2, 1.0f);
+    for (int x = 0; x < p.K; ++x) { eo[x * 2 + 0] = p.bgf[x] / p.bgf[x]; eo[x * 2 + 1] = p.compo[x] / p.bgf[x]; }
+    for (int x = p.K + 1; x <= p.Kp - 3; ++x)
+      for (int s = 0; s < 2; ++s) {
+        float e = 0.0f, den = 0.0f;
+        for (int y = 0; y < p.K; ++y) if (abc.degen[x][y]) { e += (s == 0 ? p.bgf[y] : p.compo[y]); den += p.bgf[y]; }
+        eo[x * 2 + s] = den > 0.0f ? e / den : 0.0f;
+      }
+    stage_table(stg, parts, &d->bias_eo, eo);
+  }
+  // one slab, one copy
+  {
+    int stq = P7X_OK;
+    if ((stq = stg.reserve(stg.used)) != P7X_OK) return stq;
+    if (stg.stream == nullptr || stg.device != ctx->device) {
+      if (stg.stream) (void) hipStreamDestroy(stg.stream);
+      P7X_HIP(hipStreamCreateWithFlags(&stg.stream, hipStreamNonBlocking));
+      stg.device = ctx->device;
+    }
+    if ((stq = slab_acquire(ctx, stg.used, &d->slab, &d->slab_bytes)) != P7X_OK) return stq;
+    for (size_t i = 0; i < parts.size(); ++i) {
+      std::memcpy(stg.pinned + stg.fix[i].second, parts[i].data(), parts[i].size());
+      *stg.fix[i].first = static_cast<char *>(d->slab) + stg.fix[i].second;
+    }
+    if (hipMemcpyAsync(d->slab, stg.pinned, stg.used, hipMemcpyHostToDevice, stg.stream) != hipSuccess ||
+        hipStreamSynchronize(stg.stream) != hipSuccess) {
+      slab_release(ctx, d->slab, d->slab_bytes);
+      set_error("uploading the profile's device image failed");
+      return P7X_EDEVICE;
+    }
+  }
+  *out = d.get();
+  cache->per_device.push_back(d.release());
+  return P7X_OK;
+}
+
+} // namespace p7x
+
+using namespace p7x;
+
+extern "C" {
+
+void p7x_oprofile_destroy(p7x_oprofile *om)
+{
+  if (!om) return;
+  if (om->dev_cache) {
+    auto *cache = static_cast<DevCache *>(om->dev_cache);
+    for (DevProfile *d : cache->per_device) free_dev_profile(d);
+    delete cache;
+  }
+  delete om;
+}
+
+} // extern "C"
+
+namespace p7x { void attach_dev_cache(p7x_oprofile *om) { om->dev_cache = new DevCache(); } }

@@ -16,215 +16,6 @@
 
 namespace p7x {
 
-// ---------------------------------------------------------------------------- device profile image
-static void chunk_transpose_fill(int M, int C, std::vector<int> &pos_of_node)
-{ // node k (1..M) -> table position c*64 + z with k = z*C + c + 1
-  pos_of_node.assign(M + 1, -1);
-  for (int k = 1; k <= M; ++k) { const int z = (k - 1) / C, c = (k - 1) % C; pos_of_node[k] = c * 64 + z; }
-}
-
-// Pinned host blocks are recycled through a process-wide pool and never handed back to the runtime: hipHostFree from a
-// thread that is winding down (thread_local workspaces) while other threads drive the device is not something the
-// runtime tolerates reliably, and the blocks are small.
-struct PinnedPool { std::mutex mu; std::multimap<size_t, void *> free; };
-static PinnedPool &pinned_pool() { static PinnedPool *p = new PinnedPool(); return *p; }      // never destroyed
-static int pinned_acquire(size_t bytes, void **out, size_t *got)
-{
-  size_t want = 256;
-  while (want < bytes) want *= 2;
-  {
-    PinnedPool &pp = pinned_pool();
-    std::lock_guard<std::mutex> lk(pp.mu);
-    auto it = pp.free.find(want);
-    if (it != pp.free.end()) { *out = it->second; *got = want; pp.free.erase(it); return P7X_OK; }
-  }
-  P7X_HIP(hipHostMalloc(out, want, hipHostMallocDefault));
-  *got = want;
-  return P7X_OK;
-}
-static void pinned_release(void *p, size_t bytes)
-{
-  if (!p) return;
-  PinnedPool &pp = pinned_pool();
-  std::lock_guard<std::mutex> lk(pp.mu);
-  pp.free.emplace(bytes, p);
-}
-
-int slab_acquire(DeviceCtx *ctx, size_t bytes, void **out, size_t *got)
-{
-  const size_t want = ((bytes + 65535) / 65536) * 65536;
-  {
-    std::lock_guard<std::mutex> lk(ctx->slab_mu);
-    auto it = ctx->slab_free.lower_bound(want);
-    if (it != ctx->slab_free.end() && it->first <= want * 2) {
-      *out = it->second; *got = it->first; ctx->slab_free_bytes -= it->first; ctx->slab_free.erase(it);
-      return P7X_OK;
-    }
-  }
-  P7X_HIP(hipMalloc(out, want));
-  *got = want;
-  return P7X_OK;
-}
-
-void slab_release(DeviceCtx *ctx, void *p, size_t bytes)
-{
-  if (!p) return;
-  std::lock_guard<std::mutex> lk(ctx->slab_mu);
-  if (ctx->slab_free_bytes + bytes > ((size_t) 4 << 30)) { (void) hipFree(p); return; }   // keep at most 4 GiB parked
-  ctx->slab_free.emplace(bytes, p); ctx->slab_free_bytes += bytes;
-}
-
-static void free_dev_profile(DevProfile *d)
-{
-  if (!d) return;
-  DeviceCtx *ctx = nullptr;
-  if (get_ctx(d->device, &ctx) == P7X_OK) slab_release(ctx, d->slab, d->slab_bytes);
-  delete d;
-}
-
-struct DevCache { std::mutex mu; std::vector<DevProfile *> per_device; };
-
-// Host-side staging of a device image: the tables are laid out back to back (256-byte aligned) in one pinned buffer
-// and go up with one copy on a stream of the building thread.
-struct ImageStage {
-  char *pinned = nullptr; size_t cap = 0; hipStream_t stream = nullptr; int device = -1;
-  std::vector<std::pair<void **, size_t>> fix;      // pointer field in the DevProfile <- offset in the slab
-  size_t used = 0;
-  ~ImageStage() { pinned_release(pinned, cap); if (stream) (void) hipStreamDestroy(stream); }
-  int reserve(size_t bytes)
-  {
-    if (bytes <= cap) return P7X_OK;
-    pinned_release(pinned, cap);
-    pinned = nullptr; cap = 0;
-    void *p = nullptr; size_t got = 0;
-    const int st = pinned_acquire(std::max<size_t>(bytes, (size_t) 1 << 20), &p, &got);
-    if (st != P7X_OK) return st;
-    pinned = static_cast<char *>(p); cap = got;
-    return P7X_OK;
-  }
-};
-struct StagePool { std::mutex mu; std::vector<ImageStage *> idle; };
-static StagePool &stage_pool() { static StagePool *p = new StagePool(); return *p; }      // never destroyed
-struct StageLease {
-  ImageStage *st = nullptr;
-  StageLease()
-  {
-    StagePool &sp = stage_pool();
-    { std::lock_guard<std::mutex> lk(sp.mu); if (!sp.idle.empty()) { st = sp.idle.back(); sp.idle.pop_back(); } }
-    if (!st) st = new ImageStage();
-  }
-  ~StageLease() { std::lock_guard<std::mutex> lk(stage_pool().mu); stage_pool().idle.push_back(st); }
-};
-
-template <typename T, typename F>
-static int stage_table(ImageStage &st, std::vector<std::vector<char>> &parts, F **field, const std::vector<T> &v)
-{
-  const size_t off = st.used;
-  parts.emplace_back(reinterpret_cast<const char *>(v.data()), reinterpret_cast<const char *>(v.data()) + v.size() * sizeof(T));
-  st.fix.emplace_back(reinterpret_cast<void **>(field), off);
-  st.used = ((off + v.size() * sizeof(T) + 255) / 256) * 256;
-  return P7X_OK;
-}
-
-static int get_dev_profile(const p7x_oprofile *om, DeviceCtx *ctx, DevProfile **out)
-{
-  auto *cache = static_cast<DevCache *>(om->dev_cache);
-  std::lock_guard<std::mutex> lk(cache->mu);
-  for (DevProfile *d : cache->per_device) if (d->device == ctx->device) { *out = d; return P7X_OK; }
-  const Profile &p = om->p;
-  auto d = std::make_unique<DevProfile>();
-  d->device = ctx->device; d->M = p.M; d->Kp = p.Kp;
-  StageLease stage_lease;
-  ImageStage &stg = *stage_lease.st;
-  stg.fix.clear(); stg.used = 0;
-  std::vector<std::vector<char>> parts;
-  // MSV parity tables
-  d->msvR = msv_pick_R(p.M);
-  if (d->msvR > 0) {
-    d->msvS = msv_stride(d->msvR);
-    std::vector<uint32_t> tab;
-    msv_build_tables(p, d->msvR, d->msvS, tab);
-    stage_table(stg, parts, &d->msv_tab, tab);
-  }
-  // wave-per-sequence tables
-  d->vitC = vit_pick_C(p.M);
-  if (d->vitC > 0) {
-    const int C = d->vitC, Mpad = 64 * C, nrows = p.Kp + 1;
-    d->Mpad = Mpad;
-    std::vector<int> pos;
-    chunk_transpose_fill(p.M, C, pos);
-    std::vector<int16_t> vt((size_t) Mpad * 8, -32768), ve((size_t) nrows * Mpad, -32768);
-    std::vector<float> ft((size_t) Mpad * 8, 0.0f), fe((size_t) nrows * Mpad, 0.0f);
-    for (int k = 1; k <= p.M; ++k) {
-      for (int t = 0; t < NTRANS; ++t) {
-        vt[(size_t) pos[k] * 8 + t] = p.tw[(size_t) t * (p.M + 1) + k];
-        ft[(size_t) pos[k] * 8 + t] = p.tf[(size_t) t * (p.M + 1) + k];
-      }
-      for (int x = 0; x < p.Kp; ++x) {
-        ve[(size_t) x * Mpad + pos[k]] = p.rw[(size_t) x * (p.M + 1) + k];
-        fe[(size_t) x * Mpad + pos[k]] = p.rf_[(size_t) x * (p.M + 1) + k];
-      }
-    }
-    {     // emission table of the wave-per-target MSV kernel (long models, small target blocks), same node order as Viterbi's
-      std::vector<int16_t> me((size_t) kTabRows * Mpad, (int16_t) kNegPad);
-      for (int k = 1; k <= p.M; ++k)
-        for (int x = 0; x < p.Kp; ++x) me[(size_t) x * Mpad + pos[k]] = (int16_t) ((int) p.bias_b - (int) p.rb[(size_t) x * (p.M + 1) + k]);
-      stage_table(stg, parts, &d->msvw_emis, me);
-    }
-    stage_table(stg, parts, &d->vit_trans, vt);
-    stage_table(stg, parts, &d->vit_emis, ve);
-    stage_table(stg, parts, &d->fwd_trans, ft);
-    stage_table(stg, parts, &d->fwd_emis, fe);
-  }
-  {
-    int T = 0, P = 0;
-    if (vitpk_pick(p.M, &T, &P)) {
-      std::vector<uint32_t> tt, te;
-      vitpk_build_tables(p, T, P, tt, te);
-      d->vitpkT = T; d->vitpkP = P;
-      stage_table(stg, parts, &d->vitpk_trans, tt);
-      stage_table(stg, parts, &d->vitpk_emis, te);
-    }
-  }
-  // bias filter emission odds (esl_hmm_Configure on the 2-state filter HMM, p7_bg_SetFilter)
-  {
-    const Alphabet &abc = Alphabet::get(p.abc_type);
-    std::vector<float> eo((size_t) kTabRows * 2, 1.0f);
-    for (int x = 0; x < p.K; ++x) { eo[x * 2 + 0] = p.bgf[x] / p.bgf[x]; eo[x * 2 + 1] = p.compo[x] / p.bgf[x]; }
-    for (int x = p.K + 1; x <= p.Kp - 3; ++x)
-      for (int s = 0; s < 2; ++s) {
-        float e = 0.0f, den = 0.0f;
-        for (int y = 0; y < p.K; ++y) if (abc.degen[x][y]) { e += (s == 0 ? p.bgf[y] : p.compo[y]); den += p.bgf[y]; }
-        eo[x * 2 + s] = den > 0.0f ? e / den : 0.0f;
-      }
-    stage_table(stg, parts, &d->bias_eo, eo);
-  }
-  // one slab, one copy
-  {
-    int stq = P7X_OK;
-    if ((stq = stg.reserve(stg.used)) != P7X_OK) return stq;
-    if (stg.stream == nullptr || stg.device != ctx->device) {
-      if (stg.stream) (void) hipStreamDestroy(stg.stream);
-      P7X_HIP(hipStreamCreateWithFlags(&stg.stream, hipStreamNonBlocking));
-      stg.device = ctx->device;
-    }
-    if ((stq = slab_acquire(ctx, stg.used, &d->slab, &d->slab_bytes)) != P7X_OK) return stq;
-    for (size_t i = 0; i < parts.size(); ++i) {
-      std::memcpy(stg.pinned + stg.fix[i].second, parts[i].data(), parts[i].size());
-      *stg.fix[i].first = static_cast<char *>(d->slab) + stg.fix[i].second;
-    }
-    if (hipMemcpyAsync(d->slab, stg.pinned, stg.used, hipMemcpyHostToDevice, stg.stream) != hipSuccess ||
-        hipStreamSynchronize(stg.stream) != hipSuccess) {
-      slab_release(ctx, d->slab, d->slab_bytes);
-      set_error("uploading the profile's device image failed");
-      return P7X_EDEVICE;
-    }
-  }
-  *out = d.get();
-  cache->per_device.push_back(d.release());
-  return P7X_OK;
-}
-
 // ---------------------------------------------------------------------------- small per-target kernels
 struct StageBufs {            // all indexed by slot unless noted
   int16_t *xJ;                // [ngroups*64]
@@ -894,198 +685,10 @@ static int run_cascade(const p7x_pipeline_cfg &cfg, const p7x_oprofile *om, cons
   return cascade_collect(r, out);
 }
 
-// ---------------------------------------------------------------------------- envelope rescoring on the device
-// Device and pinned-host buffers live for the thread (grow-only), like the cascade workspace.
-struct EnvBuffers {
-  int device = -1;
-  float *work = nullptr; size_t work_floats = 0;
-  unsigned char *d_in = nullptr; size_t d_in_cap = 0;        // env_sq | tr_off | env_len | env_L
-  unsigned char *d_out = nullptr; size_t d_out_cap = 0;      // out_sc | out_null2 | out_status | tr_n | tr_a | tr_i | tr_pp
-  unsigned char *h_out = nullptr; size_t h_out_cap = 0;      // pinned mirror of d_out
-  hipStream_t stream = nullptr;                               // per host thread: concurrent host stages do not wait on each other
-  ~EnvBuffers() {
-    if (device < 0) return;
-    (void) hipSetDevice(device);
-    if (stream) (void) hipStreamDestroy(stream);
-    (void) hipFree(work); (void) hipFree(d_in); (void) hipFree(d_out);
-    pinned_release(h_out, h_out_cap);
-  }
-};
-// leased from a process-wide pool like the cascade workspaces (never destroyed: no device teardown from exiting threads)
-struct EnvPool { std::mutex mu; std::vector<EnvBuffers *> all; std::vector<char> busy; };
-static EnvPool &env_pool() { static EnvPool *p = new EnvPool(); return *p; }
-static void release_env_buffers(EnvBuffers *eb)
-{
-  if (!eb) return;
-  EnvPool &ep = env_pool();
-  std::lock_guard<std::mutex> lk(ep.mu);
-  for (size_t i = 0; i < ep.all.size(); ++i) if (ep.all[i] == eb) ep.busy[i] = 0;
-}
-
-static size_t env_budget_bytes()
-{
-  size_t gb = 24;
-  if (const char *e = std::getenv("P7X_ENV_WORKSPACE_GB")) { const long v = std::atol(e); if (v > 0) gb = (size_t) v; }
-  size_t free_b = 0, total_b = 0;
-  if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && free_b / 2 < gb << 30) return free_b / 2;
-  return gb << 30;
-}
-
-class DeviceEnvelopeScorer final : public EnvelopeScorer {
-public:
-  DeviceEnvelopeScorer(DeviceCtx *ctx, const DevProfile *dp, const p7x_seqdb *db, const Profile &p) : ctx_(ctx), dp_(dp), db_(db), p_(p) {}
-  ~DeviceEnvelopeScorer() override { if (lease_) { if (lease_->stream) (void) hipStreamSynchronize(lease_->stream); release_env_buffers(lease_); } }
-
-  int begin(const std::vector<EnvelopeRequest> &req, const std::vector<int32_t> &targets) override
-  {
-    const int nenv = (int) req.size();
-    nenv_ = nenv;
-    if (nenv == 0) return P7X_OK;
-    P7X_HIP(hipSetDevice(db_->device));
-    EnvBuffers *eb = nullptr;
-    {
-      EnvPool &ep = env_pool();
-      std::lock_guard<std::mutex> lk(ep.mu);
-      for (size_t i = 0; i < ep.all.size() && !eb; ++i)
-        if (!ep.busy[i] && ep.all[i]->device == db_->device) { ep.busy[i] = 1; eb = ep.all[i]; }
-      if (!eb) { eb = new EnvBuffers(); eb->device = db_->device; ep.all.push_back(eb); ep.busy.push_back(1); }
-    }
-    lease_ = eb;
-    if (!eb->stream) {
-      int least = 0, greatest = 0;
-      P7X_HIP(hipDeviceGetStreamPriorityRange(&least, &greatest));
-      P7X_HIP(hipStreamCreateWithPriority(&eb->stream, hipStreamNonBlocking, least));
-    }
-
-    // inputs
-    const size_t in_bytes = (size_t) nenv * (8 + 8 + 4 + 4);
-    h_in_.resize(in_bytes);
-    std::vector<unsigned char> &h_in = h_in_;
-    int64_t *env_sq = reinterpret_cast<int64_t *>(h_in.data());
-    int64_t *tr_off = env_sq + nenv;
-    int32_t *env_len = reinterpret_cast<int32_t *>(tr_off + nenv);
-    int32_t *env_L = env_len + nenv;
-    int Lmax = 1; int64_t ntr = 0;
-    for (int r = 0; r < nenv; ++r) {
-      const int t = targets[(size_t) req[r].item];
-      const int Ld = req[r].j - req[r].i + 1;
-      env_sq[r] = db_->h_off[t] + (req[r].i - 1);
-      env_len[r] = Ld; env_L[r] = db_->h_len[t];
-      tr_off[r] = ntr; ntr += (int64_t) Ld + p_.M + 16;
-      Lmax = std::max(Lmax, Ld);
-    }
-    // workspace: one slab per resident wavefront, sized for the longest envelope of the batch
-    const int C = dp_->vitC;
-    const size_t stride = env_work_floats(C, Lmax);
-    int nblocks = 0;
-    int st = env_max_blocks(C, p_.Kp + 1, ctx_->num_cu, &nblocks);
-    if (st != P7X_OK) return st;
-    nblocks = std::min(nblocks, (nenv + 3) / 4);
-    const size_t budget = env_budget_bytes();
-    while (nblocks > 1 && (size_t) nblocks * 4 * stride * 4 > budget) nblocks = (nblocks + 1) / 2;
-    const size_t work_floats = (size_t) nblocks * 4 * stride;
-    if (work_floats * 4 > budget && work_floats > eb->work_floats) {
-      set_error("envelope workspace does not fit in device memory (envelope of " + std::to_string(Lmax) + " residues, M = " + std::to_string(p_.M) + ")");
-      return P7X_EMEM;
-    }
-    if (work_floats > eb->work_floats) {
-      (void) hipFree(eb->work); eb->work = nullptr; eb->work_floats = 0;
-      P7X_HIP(hipMalloc(&eb->work, work_floats * 4)); eb->work_floats = work_floats;
-    }
-    if (in_bytes > eb->d_in_cap) {
-      (void) hipFree(eb->d_in); eb->d_in = nullptr;
-      P7X_HIP(hipMalloc(&eb->d_in, in_bytes * 2)); eb->d_in_cap = in_bytes * 2;
-    }
-    // outputs: [out_sc 2f][null2 32f][status i][tr_n i] per envelope, then the three trace arrays
-    const size_t o_sc = 0, o_n2 = o_sc + (size_t) nenv * 8, o_st = o_n2 + (size_t) nenv * 128, o_n = o_st + (size_t) nenv * 4;
-    const size_t o_ta = o_n + (size_t) nenv * 4, o_ti = o_ta + (size_t) ntr * 4, o_tp = o_ti + (size_t) ntr * 4;
-    const size_t out_bytes = o_tp + (size_t) ntr * 4;
-    if (out_bytes > eb->d_out_cap) {
-      (void) hipFree(eb->d_out); eb->d_out = nullptr;
-      pinned_release(eb->h_out, eb->h_out_cap); eb->h_out = nullptr; eb->h_out_cap = 0;
-      const size_t cap = out_bytes + out_bytes / 2;
-      P7X_HIP(hipMalloc(&eb->d_out, cap)); eb->d_out_cap = cap;
-      { void *hp = nullptr; size_t got = 0; const int pst = pinned_acquire(cap, &hp, &got); if (pst != P7X_OK) return pst;
-        eb->h_out = static_cast<decltype(eb->h_out)>(hp); eb->h_out_cap = got; }
-    }
-    hipStream_t s = eb->stream;
-    P7X_HIP(hipMemcpyAsync(eb->d_in, h_in.data(), in_bytes, hipMemcpyHostToDevice, s));
-    EnvArgs a{};
-    a.M = p_.M; a.C = C; a.K = p_.K; a.nrows = p_.Kp + 1;
-    a.trans = dp_->fwd_trans; a.emis = dp_->fwd_emis; a.dsq = db_->d_dsq;
-    a.nj = 0.0f; a.xf_e_move = 1.0f; a.xf_e_loop = 0.0f;              // p7_oprofile_ReconfigUnihit
-    a.nenv = nenv;
-    a.env_sq = reinterpret_cast<const int64_t *>(eb->d_in);
-    a.tr_off = a.env_sq + nenv;
-    a.env_len = reinterpret_cast<const int32_t *>(a.tr_off + nenv);
-    a.env_L = a.env_len + nenv;
-    a.work = eb->work; a.work_stride = (int64_t) stride; a.Lmax = Lmax;
-    a.out_sc = reinterpret_cast<float *>(eb->d_out + o_sc);
-    a.out_null2 = reinterpret_cast<float *>(eb->d_out + o_n2);
-    a.out_status = reinterpret_cast<int32_t *>(eb->d_out + o_st);
-    a.tr_n = reinterpret_cast<int32_t *>(eb->d_out + o_n);
-    a.tr_a = reinterpret_cast<uint32_t *>(eb->d_out + o_ta);
-    a.tr_i = reinterpret_cast<int32_t *>(eb->d_out + o_ti);
-    a.tr_pp = reinterpret_cast<float *>(eb->d_out + o_tp);
-    if ((st = env_launch(a, nblocks, s)) != P7X_OK) return st;
-    P7X_HIP(hipMemcpyAsync(eb->h_out, eb->d_out, out_bytes, hipMemcpyDeviceToHost, s));
-    eb_ = eb; o_sc_ = o_sc; o_n2_ = o_n2; o_st_ = o_st; o_n_ = o_n; o_ta_ = o_ta; o_ti_ = o_ti; o_tp_ = o_tp;
-    return P7X_OK;
-  }
-
-  int wait(std::vector<EnvelopeResult> &res) override
-  {
-    const int nenv = nenv_;
-    res.assign((size_t) nenv, EnvelopeResult{});
-    if (nenv == 0) return P7X_OK;
-    P7X_HIP(hipSetDevice(db_->device));
-    EnvBuffers *eb = eb_;
-    P7X_HIP(hipStreamSynchronize(eb->stream));
-    const size_t o_sc = o_sc_, o_n2 = o_n2_, o_st = o_st_, o_n = o_n_, o_ta = o_ta_, o_ti = o_ti_, o_tp = o_tp_;
-    const int64_t *tr_off = reinterpret_cast<const int64_t *>(h_in_.data()) + nenv;
-    const float *h_sc = reinterpret_cast<const float *>(eb->h_out + o_sc), *h_n2 = reinterpret_cast<const float *>(eb->h_out + o_n2);
-    const int32_t *h_st = reinterpret_cast<const int32_t *>(eb->h_out + o_st), *h_n = reinterpret_cast<const int32_t *>(eb->h_out + o_n);
-    const uint32_t *h_ta = reinterpret_cast<const uint32_t *>(eb->h_out + o_ta);
-    const int32_t *h_ti = reinterpret_cast<const int32_t *>(eb->h_out + o_ti);
-    const float *h_tp = reinterpret_cast<const float *>(eb->h_out + o_tp);
-    for (int r = 0; r < nenv; ++r) {
-      EnvelopeResult &e = res[(size_t) r];
-      e.envsc = h_sc[2 * r]; e.oasc = h_sc[2 * r + 1]; e.status = h_st[r];
-      std::memcpy(e.null2, h_n2 + (size_t) r * 32, sizeof(e.null2));
-      e.ntrace = h_n[r]; e.ta = h_ta + tr_off[r]; e.ti = h_ti + tr_off[r]; e.tp = h_tp + tr_off[r];
-    }
-    return P7X_OK;
-  }
-
-private:
-  DeviceCtx *ctx_; const DevProfile *dp_; const p7x_seqdb *db_; const Profile &p_;
-  int nenv_ = 0;
-  std::vector<unsigned char> h_in_;
-  EnvBuffers *eb_ = nullptr;
-  EnvBuffers *lease_ = nullptr;
-  size_t o_sc_ = 0, o_n2_ = 0, o_st_ = 0, o_n_ = 0, o_ta_ = 0, o_ti_ = 0, o_tp_ = 0;
-};
-
 } // namespace p7x
 
 using namespace p7x;
 
-extern "C" {
-
-void p7x_oprofile_destroy(p7x_oprofile *om)
-{
-  if (!om) return;
-  if (om->dev_cache) {
-    auto *cache = static_cast<DevCache *>(om->dev_cache);
-    for (DevProfile *d : cache->per_device) free_dev_profile(d);
-    delete cache;
-  }
-  delete om;
-}
-
-} // extern "C"
-
-namespace p7x { void attach_dev_cache(p7x_oprofile *om) { om->dev_cache = new DevCache(); } }
 
 extern "C" {
 
@@ -1294,12 +897,12 @@ int p7x_search_block_finish(p7x_pending *pd, const char *const *names, const cha
   for (size_t i = 0; i < targets.size(); ++i) targets[i] = db->h_order[co.fin_slots[i]];
   const uint64_t counts[4] = { (uint64_t) co.counts[1], (uint64_t) co.counts[8], (uint64_t) co.counts[3], (uint64_t) co.counts[4] };
   int st = P7X_OK;
-  std::unique_ptr<DeviceEnvelopeScorer> scorer;
+  std::unique_ptr<EnvelopeScorer> scorer;
   const bool env_fits = om->p.M <= 1024;        // env_kernel keeps the emission table in LDS; longer models are rescored on the host
   if (!g_host_envelopes && !pd->cfg.host_envelopes && !targets.empty() && env_fits) {
     DeviceCtx *ctx = nullptr; DevProfile *dp = nullptr;
     if ((st = get_ctx(db->device, &ctx)) != P7X_OK || (st = get_dev_profile(om, ctx, &dp)) != P7X_OK) return st;
-    scorer = std::make_unique<DeviceEnvelopeScorer>(ctx, dp, db, om->p);
+    scorer = make_device_envelope_scorer(ctx, dp, db, om->p);
   }
   const double stage1 = co.ms[6];
   DeviceRegions dr;
