@@ -210,3 +210,29 @@ def test_host_hit_text_setters_and_alignment_rendering(models, oracle, proteome)
     assert lines[0].rstrip().endswith("CS") and lines[4].rstrip().endswith("PP")
     assert lines[1].strip().startswith(base.query.name) and lines[3].strip().startswith(base[0].name)
     assert len({len(l) - len(l.lstrip()) + l.lstrip().find(" ") for l in (lines[1], lines[3])}) == 1   # names right-aligned
+
+
+def test_host_write_rrefam_tables_per_query(models, oracle, proteome):
+    """RREFam.tbl / RREFam.domtbl hold the rows of every query model (one p7_tophits_Tabular* call per query, header
+    once): each model's `TopHits.write(header=False)` must reproduce its rows as text (sampled-null2 rows masked)."""
+    from conftest import GOLDEN
+    for fmt, table, qcol, score_cols in (("targets", "RREFam.tbl", 2, (4, 5, 6, 7, 8, 9)),
+                                         ("domains", "RREFam.domtbl", 3, (6, 7, 8, 11, 12, 13, 14))):
+        golden_rows = [l for l in open(GOLDEN / "tables" / table).read().splitlines() if l and not l.startswith("#")]
+        nrows = 0
+        for hmm in models["RREFam"]:
+            hits = host_pipeline.host_search(oracle, hmm, proteome)
+            buf = io.BytesIO()
+            hits.write(buf, format=fmt, header=False)
+            got = buf.getvalue().decode().splitlines()
+            want = [l for l in golden_rows if l.split()[qcol] == hmm.name]
+            assert len(got) == len(want), hmm.name
+            sampled = {h.name for h in hits if h.nclustered > 0}
+            for g, w in zip(got, want):
+                if g.split()[0] in sampled:
+                    gf, wf = g.split(), w.split()
+                    assert [f for i, f in enumerate(gf) if i not in score_cols] == [f for i, f in enumerate(wf) if i not in score_cols]
+                else:
+                    assert g == w, (hmm.name, g, w)
+                nrows += 1
+        assert nrows == len(golden_rows)
