@@ -174,6 +174,8 @@ def test_hmmscan_rrefam_matches_hmmer_scan_table(models, proteome):
     HMMER produced from the fixture proteome: per query sequence the same models, in the same order, with the table's
     score / bias / E-value (Z = number of profiles)."""
     from conftest import GOLDEN
+    import io
+    text_rows = [l for l in open(GOLDEN / "tables" / "RREFam.scan.tbl").read().splitlines() if l and not l.startswith("#")]
     expected = {}
     for row in golden_table("RREFam.scan.tbl"):
         expected.setdefault(row[2], []).append(row)
@@ -193,6 +195,13 @@ def test_hmmscan_rrefam_matches_hmmer_scan_table(models, proteome):
                 assert h.domains[0].alignment.target_name == seq.name
             if rows:
                 seen.add(seq.name)
+                # the --tblout text itself (one p7_tophits_TabularTargets call per query sequence, header once)
+                out = io.BytesIO()
+                hits.write(out, format="targets", header=False)
+                want = [l for l in text_rows if l.split()[2] == seq.name]
+                for g, w, h in zip(out.getvalue().decode().splitlines(), want, hits.reported):
+                    if h.nclustered == 0:
+                        assert g == w
             nq += 1
         assert seen == set(expected)
     assert nq == 2 * len(proteome)
