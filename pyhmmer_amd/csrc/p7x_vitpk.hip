@@ -3,16 +3,18 @@
 // The wave-per-target kernel in p7x_vitfwd.hip spends most of a row on work that does not shrink with the model:
 // wave-wide reductions, the scalar special-state chain, and 16-bit values in 32-bit lanes.  For the common
 // Pfam-sized models (M <= 640) this kernel shares those costs between several targets:
-//   * lane s of a group owns the 2P consecutive nodes s*2P+1 .. s*2P+2P, two per VGPR (v_pk_add_i16 clamp /
-//     v_pk_max_i16 reproduce _mm_adds_epi16 / _mm_max_epi16 of impl_sse/vitfilter.c exactly);
-//   * the k-1 neighbour is one v_alignbit across adjacent registers, one DPP shift at the lane boundary;
+//   * the nodes are striped over the 2T half-lanes of a group (Farrar): register q of lane s holds node q+1+s*P in
+//     its low half and node q+1+(s+T)*P in its high half, so the k-1 neighbour of a register is the register
+//     before it and only register 0 takes values from another lane (v_pk_add_i16 clamp / v_pk_max_i16 reproduce
+//     _mm_adds_epi16 / _mm_max_epi16 of impl_sse/vitfilter.c exactly);
 //   * transitions (8 x int16 per node: BM MM IM DM MD MI II DD) and emissions come from LDS as ds_read_b128,
-//     the DP rows (M, I, D) stay in 3P registers;
+//     the DP rows (M, I, D) stay in 3P registers, two sets of them (a row reads one and writes the other);
 //   * xE / Dmax are 3- or 4-step DPP butterflies inside the group, the special states are per-lane integers that
 //     are uniform within a group; targets that have ended are masked, the row loop runs to the longest target of
 //     the wavefront;
 //   * lazy F follows upstream: D gets only M->D unless Dmax + ddbound > xB for that target; then the D->D closure
-//     is evaluated in full (serial inside the lane, carries relaxed across lanes until nothing improves).
+//     is evaluated in full: two packed ops per register walk every stripe, the carry into the next stripe is a
+//     stripe shift, passes repeat until nothing improves (two on average).
 // Results are bit-identical to p7x_vitfwd.hip::vit_kernel and to the oracle (tests/test_gpu_filters.py).
 #include "p7x_wave.hpp"
 
@@ -28,8 +30,6 @@ __device__ __forceinline__ uint32_t pk_max(uint32_t a, uint32_t b) { return as_u
 __device__ __forceinline__ uint32_t splat16(int v) { const uint32_t w = (uint32_t) v & 0xffffu; return w | (w << 16); }
 __device__ __forceinline__ int lo_of(uint32_t w) { return (int) (short) (w & 0xffffu); }
 __device__ __forceinline__ int hi_of(uint32_t w) { return (int) (short) (w >> 16); }
-// (prev.hi, cur.lo): the register holding, for every node of <cur>, the value of its predecessor node
-__device__ __forceinline__ uint32_t shift_in(uint32_t cur, uint32_t prev) { return __builtin_amdgcn_alignbit(cur, prev, 16); }
 
 constexpr uint32_t kNeg2 = 0x80008000u;      // (-32768, -32768)
 constexpr int vitpk_rowq(int T, int P) { return (((P + 3) / 4) * T) | 1; }
@@ -51,7 +51,19 @@ __device__ __forceinline__ int group_max(uint32_t v)
 
 struct RowState { int xN, xB, xJ, xC; bool overflow; };
 
+// Value of the previous stripe for every stripe of a register: lane z-1's register for lanes z >= 1; the first lane of a
+// group takes (-32768, lo half of the group's last lane): stripe 0 has no predecessor, stripe T follows stripe T-1.
+template <int T>
+__device__ __forceinline__ uint32_t stripe_shift(uint32_t r, bool first)
+{
+  const uint32_t prev = P7X_DPP_U(r, 0x138);                          // wave_shr:1
+  const uint32_t last = P7X_DPP_U(r, T == 8 ? 0x141 : 0x140);         // row_half_mirror / row_mirror: lane 0 <- lane T-1
+  return first ? ((last << 16) | 0x8000u) : prev;
+}
+
 // One DP row for the G targets of a wavefront: reads the previous row from (mi, ii, di), writes (mo_, io_, do_).
+// Register q of a lane holds the nodes q + 1 + s*P of its two stripes s = lane (low half) and lane + T (high half),
+// so the k-1 neighbour of a register is the register before it and only register 0 needs values from another lane.
 template <int T, int P>
 __device__ __forceinline__ void vit_row(const VitPkArgs &a, const uint4 *tral, const uint4 *trbl, const uint4 *er, bool first,
                                         bool active, int xwm, const uint32_t (&mi)[P], const uint32_t (&ii)[P],
@@ -60,44 +72,35 @@ __device__ __forceinline__ void vit_row(const VitPkArgs &a, const uint4 *tral, c
 {
   constexpr int PS = (P + 3) & ~3;
   const uint32_t xBv = splat16(rs.xB);
-  // values of the previous lane's last register (previous row), -32768 at the start of a group
-  uint32_t mo = P7X_DPP_U(mi[P - 1], 0x138), io = P7X_DPP_U(ii[P - 1], 0x138), dob = P7X_DPP_U(di[P - 1], 0x138);
-  if (first) { mo = kNeg2; io = kNeg2; dob = kNeg2; }
-  uint32_t xEv = kNeg2, dmaxv = kNeg2, dcv_prev = kNeg2, dcv_last = kNeg2;
+  uint32_t mp = stripe_shift<T>(mi[P - 1], first), ip = stripe_shift<T>(ii[P - 1], first), dp = stripe_shift<T>(di[P - 1], first);
+  uint32_t xEv = kNeg2, dmaxv = kNeg2, dcv = kNeg2;
 #pragma unroll
   for (int j4 = 0; j4 < PS; j4 += 4) {
     const uint4 e4 = er[(j4 / 4) * T];
     const uint32_t ev[4] = { e4.x, e4.y, e4.z, e4.w };
 #pragma unroll
     for (int jj = 0; jj < 4; ++jj) {
-      const int j = j4 + jj;
-      if (j < P) {
-        const uint4 ta = tral[j * T], tb = trbl[j * T];          // BM MM IM DM | MD MI II DD
-        const uint32_t m_old = mi[j], i_old = ii[j], d_old = di[j];
-        const uint32_t mpv = shift_in(m_old, mo), ipv = shift_in(i_old, io), dpv = shift_in(d_old, dob);
+      const int q = j4 + jj;
+      if (q < P) {
+        const uint4 ta = tral[q * T], tb = trbl[q * T];          // BM MM IM DM | MD MI II DD
         uint32_t sv = pk_adds(xBv, ta.x);
-        sv = pk_max(sv, pk_adds(mpv, ta.y));
-        sv = pk_max(sv, pk_adds(ipv, ta.z));
-        sv = pk_max(sv, pk_adds(dpv, ta.w));
+        sv = pk_max(sv, pk_adds(mp, ta.y));
+        sv = pk_max(sv, pk_adds(ip, ta.z));
+        sv = pk_max(sv, pk_adds(dp, ta.w));
         sv = pk_adds(sv, ev[jj]);
         xEv = pk_max(xEv, sv);
-        mo_[j] = sv;
-        const uint32_t dcv = pk_adds(sv, tb.x);                  // M(i,k) -> D(i,k+1)
+        mo_[q] = sv;
+        if (q > 0) do_[q] = dcv;                                 // M(i,k-1) -> D(i,k), D->D follows in the closure
+        dcv = pk_adds(sv, tb.x);
         dmaxv = pk_max(dmaxv, dcv);
-        do_[j] = shift_in(dcv, dcv_prev);                        // register 0 is completed after the loop
-        io_[j] = pk_max(pk_adds(m_old, tb.y), pk_adds(i_old, tb.z));
-        mo = m_old; io = i_old; dob = d_old; dcv_prev = dcv;
-        if (j == P - 1) dcv_last = dcv;
+        io_[q] = pk_max(pk_adds(mi[q], tb.y), pk_adds(ii[q], tb.z));
+        mp = mi[q]; ip = ii[q]; dp = di[q];
       }
     }
-    // keep the LDS loads of later pairs behind this point: hoisting all 2P transition loads costs 8 VGPRs per pair
+    // keep the LDS loads of later registers behind this point: hoisting all 2P transition loads costs 8 VGPRs each
     asm volatile("" ::: "memory");
   }
-  {
-    uint32_t c = P7X_DPP_U(dcv_last, 0x138);
-    if (first) c = kNeg2;
-    do_[0] = (do_[0] & 0xffff0000u) | (c >> 16);                 // node s*2P+1 takes M(i, s*2P) + tMD from the lane before
-  }
+  do_[0] = stripe_shift<T>(dcv, first);                          // the first node of a stripe follows the last of the one before
   const int xE = group_max<T>(xEv);
   const int Dmax = group_max<T>(dmaxv);
   if (active) {
@@ -108,47 +111,22 @@ __device__ __forceinline__ void vit_row(const VitPkArgs &a, const uint4 *tral, c
   }
   const bool trig = active && (Dmax + a.ddbound > rs.xB);          // lazy F, per target
   if (__any(trig)) {
-    // D->D transitions of this lane; -32768 for targets that did not ask for the closure: their adds saturate to
-    // -32768 and the maxima below leave D untouched, so the closure runs in place
+    // D->D transitions; -32768 for targets that did not ask for the closure: their adds saturate to -32768 and the
+    // maxima leave D untouched.  One pass walks the registers of every stripe, the carry into the next stripe is the
+    // stripe shift of the last register; passes repeat until no stripe of any target improves (2T stripes at most).
     uint32_t tdd[P];
 #pragma unroll
-    for (int j = 0; j < P; ++j) { const uint32_t t = trbl[j * T].w; tdd[j] = trig ? t : kNeg2; }
+    for (int q = 0; q < P; ++q) { const uint32_t t = trbl[q * T].w; tdd[q] = trig ? t : kNeg2; }
     int pass = 0;
     bool more;
     do {
-      // serial closure inside the lane: e(n+1) = max(e(n+1), e(n) + tDD(n)) along the 2P packed elements
-      // Half-register (op_sel) forms of the 16-bit VOP3 ops walk the chain without unpacking: two instructions per
-      // element.  A partial register write needs one wait state before its result is read (gfx940 dst_sel
-      // forwarding hazard); the compiler does not see inside the asm, so the s_nops are written out.
 #pragma unroll
-      for (int j = 0; j < P; ++j) {
-        uint32_t tmp;
-        if (j + 1 < P)
-          asm volatile("s_nop 0\n\t"
-                       "v_add_i16 %2, %0, %3 clamp\n\t"                    // tmp.lo = d.lo + tDD(lo)
-                       "s_nop 0\n\t"
-                       "v_max3_i16 %0, %0, %2, %2 op_sel:[1,0,0,1]\n\t"    // d.hi   = max(d.hi, tmp.lo)
-                       "s_nop 0\n\t"
-                       "v_add_i16 %2, %0, %3 op_sel:[1,1,0] clamp\n\t"     // tmp.lo = d.hi + tDD(hi)
-                       "s_nop 0\n\t"
-                       "v_max3_i16 %1, %1, %2, %2"                          // next.lo = max(next.lo, tmp.lo), next.hi kept
-                       : "+v"(do_[j]), "+v"(do_[j + 1 < P ? j + 1 : j]), "=&v"(tmp) : "v"(tdd[j]));
-        else
-          asm volatile("s_nop 0\n\t"
-                       "v_add_i16 %1, %0, %2 clamp\n\t"
-                       "s_nop 0\n\t"
-                       "v_max3_i16 %0, %0, %1, %1 op_sel:[1,0,0,1]\n\t"
-                       "s_nop 0"
-                       : "+v"(do_[j]), "=&v"(tmp) : "v"(tdd[j]));
-      }
-      // carry into the next lane of the group; stop when nothing improves any more
-      const uint32_t tl = pk_adds(do_[P - 1], tdd[P - 1]);
-      uint32_t c = P7X_DPP_U(tl, 0x138);
-      if (first) c = kNeg2;
-      const int cand = trig ? hi_of(c) : -32768;
-      const bool better = cand > lo_of(do_[0]);
-      if (better) do_[0] = (do_[0] & 0xffff0000u) | ((uint32_t) cand & 0xffffu);
-      more = __any(better) && ++pass < T;        // a carry crosses at most T-1 lanes
+      for (int q = 1; q < P; ++q) do_[q] = pk_max(do_[q], pk_adds(do_[q - 1], tdd[q - 1]));
+      const uint32_t c = stripe_shift<T>(pk_adds(do_[P - 1], tdd[P - 1]), first);
+      const uint32_t d0 = pk_max(do_[0], c);
+      const bool changed = d0 != do_[0];
+      do_[0] = d0;
+      more = __any(changed) && ++pass < 2 * T;
     } while (more);
   }
 }
@@ -240,7 +218,8 @@ bool vitpk_pick(int M, int *T, int *P)
   return false;
 }
 
-// trans: uint4 [2][P][T] = (BM MM IM DM) then (MD MI II DD) of pair j of lane s, each dword (node lo, node hi);
+// trans: uint4 [2][P][T] = (BM MM IM DM) then (MD MI II DD) of register j of lane s, each dword (node lo, node hi)
+// = nodes j + 1 + s*P and j + 1 + (s+T)*P (Farrar striping over the 2T half-lanes of a group);
 // emis: uint4 [nrows][ROWQ], q*T + s = pairs 4q .. 4q+3 of lane s.  Nodes beyond M and unused pairs hold -32768.
 void vitpk_build_tables(const Profile &p, int T, int P, std::vector<uint32_t> &trans, std::vector<uint32_t> &emis)
 {
@@ -250,7 +229,7 @@ void vitpk_build_tables(const Profile &p, int T, int P, std::vector<uint32_t> &t
   emis.assign((size_t) nrows * rowq * 4, kNeg2);
   for (int s = 0; s < T; ++s)
     for (int j = 0; j < P; ++j) {
-      const int k0 = s * 2 * P + 2 * j + 1, k1 = k0 + 1;
+      const int k0 = s * P + j + 1, k1 = (s + T) * P + j + 1;      // stripes s (low half) and s + T (high half)
       for (int t = 0; t < NTRANS; ++t) {
         const int lo = (k0 <= p.M) ? p.tw[(size_t) t * (p.M + 1) + k0] : -32768;
         const int hi = (k1 <= p.M) ? p.tw[(size_t) t * (p.M + 1) + k1] : -32768;
