@@ -68,7 +68,7 @@ template <int T, int P>
 __device__ __forceinline__ void vit_row(const VitPkArgs &a, const uint4 *tral, const uint4 *trbl, const uint4 *er, bool first,
                                         bool active, int xwm, const uint32_t (&mi)[P], const uint32_t (&ii)[P],
                                         const uint32_t (&di)[P], uint32_t (&mo_)[P], uint32_t (&io_)[P], uint32_t (&do_)[P],
-                                        RowState &rs)
+                                        const uint32_t (&tdd)[P], RowState &rs)
 {
   constexpr int PS = (P + 3) & ~3;
   const uint32_t xBv = splat16(rs.xB);
@@ -83,10 +83,9 @@ __device__ __forceinline__ void vit_row(const VitPkArgs &a, const uint4 *tral, c
       const int q = j4 + jj;
       if (q < P) {
         const uint4 ta = tral[q * T], tb = trbl[q * T];          // BM MM IM DM | MD MI II DD
-        uint32_t sv = pk_adds(xBv, ta.x);
-        sv = pk_max(sv, pk_adds(mp, ta.y));
-        sv = pk_max(sv, pk_adds(ip, ta.z));
-        sv = pk_max(sv, pk_adds(dp, ta.w));
+        // four independent adds, then a max tree: the same values as the serial chain, half its depth
+        const uint32_t a0 = pk_adds(xBv, ta.x), a1 = pk_adds(mp, ta.y), a2 = pk_adds(ip, ta.z), a3 = pk_adds(dp, ta.w);
+        uint32_t sv = pk_max(pk_max(a0, a1), pk_max(a2, a3));
         sv = pk_adds(sv, ev[jj]);
         xEv = pk_max(xEv, sv);
         mo_[q] = sv;
@@ -111,18 +110,17 @@ __device__ __forceinline__ void vit_row(const VitPkArgs &a, const uint4 *tral, c
   }
   const bool trig = active && (Dmax + a.ddbound > rs.xB);          // lazy F, per target
   if (__any(trig)) {
-    // D->D transitions; -32768 for targets that did not ask for the closure: their adds saturate to -32768 and the
-    // maxima leave D untouched.  One pass walks the registers of every stripe, the carry into the next stripe is the
-    // stripe shift of the last register; passes repeat until no stripe of any target improves (2T stripes at most).
-    uint32_t tdd[P];
-#pragma unroll
-    for (int q = 0; q < P; ++q) { const uint32_t t = trbl[q * T].w; tdd[q] = trig ? t : kNeg2; }
+    // The registers of every target of the wavefront are walked, also of those that did not ask for the closure:
+    // relaxing D->D edges of such a target cannot reach the next row's M (that is what the lazy-F bound says), so its
+    // score is the same with or without them.  Only the carry into the next stripe is restricted to the targets that
+    // asked, so that the others cannot prolong the loop.  Passes repeat until no stripe improves (2T at most).
     int pass = 0;
     bool more;
     do {
 #pragma unroll
       for (int q = 1; q < P; ++q) do_[q] = pk_max(do_[q], pk_adds(do_[q - 1], tdd[q - 1]));
-      const uint32_t c = stripe_shift<T>(pk_adds(do_[P - 1], tdd[P - 1]), first);
+      uint32_t c = stripe_shift<T>(pk_adds(do_[P - 1], tdd[P - 1]), first);
+      if (!trig) c = kNeg2;
       const uint32_t d0 = pk_max(do_[0], c);
       const bool changed = d0 != do_[0];
       do_[0] = d0;
@@ -159,6 +157,9 @@ __global__ void __launch_bounds__(256) vitpk_kernel(const VitPkArgs a)
   const int wave0 = rfl((int) (blockIdx.x * 4 + (threadIdx.x >> 6)));
   const int nwaves = (int) gridDim.x * 4;
   const uint4 *tral = tra + s, *trbl = trb + s, *eml = em + s;
+  uint32_t tdd[P];                 // D->D transitions of this lane's nodes: row-invariant, kept in registers for the closure
+#pragma unroll
+  for (int q = 0; q < P; ++q) tdd[q] = trbl[q * T].w;
 
   for (int it0 = wave0 * G; it0 < nlist; it0 += nwaves * G) {
     const int it = it0 + g;
@@ -194,11 +195,11 @@ __global__ void __launch_bounds__(256) vitpk_kernel(const VitPkArgs a)
       };
       int r = 0;
       for (; r + 1 < nrow; r += 2) {
-        vit_row<T, P>(a, tral, trbl, eml + residue(r) * ROWQ, first, i0 + r < L, xwm, mA, iA, dA, mB, iB, dB, rs);
-        vit_row<T, P>(a, tral, trbl, eml + residue(r + 1) * ROWQ, first, i0 + r + 1 < L, xwm, mB, iB, dB, mA, iA, dA, rs);
+        vit_row<T, P>(a, tral, trbl, eml + residue(r) * ROWQ, first, i0 + r < L, xwm, mA, iA, dA, mB, iB, dB, tdd, rs);
+        vit_row<T, P>(a, tral, trbl, eml + residue(r + 1) * ROWQ, first, i0 + r + 1 < L, xwm, mB, iB, dB, mA, iA, dA, tdd, rs);
       }
       if (r < nrow) {     // odd row count (only the last block of a group): one more row, then back into set A
-        vit_row<T, P>(a, tral, trbl, eml + residue(r) * ROWQ, first, i0 + r < L, xwm, mA, iA, dA, mB, iB, dB, rs);
+        vit_row<T, P>(a, tral, trbl, eml + residue(r) * ROWQ, first, i0 + r < L, xwm, mA, iA, dA, mB, iB, dB, tdd, rs);
 #pragma unroll
         for (int j = 0; j < P; ++j) { mA[j] = mB[j]; iA[j] = iB[j]; dA[j] = dB[j]; }
       }
