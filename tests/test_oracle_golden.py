@@ -90,3 +90,21 @@ def test_oracle_null1_doctest_value(oracle):
     for L in (1, 50, 400, 100000):
         ref = L * np.log(L / (L + 1.0)) + np.log(1.0 / (L + 1.0))
         assert abs(oracle.lib().p7o_null1(L) - ref) < 2e-3 * abs(ref)
+
+
+@pytest.mark.parametrize("name,T,P", [("KR", 8, 17), ("PF02826", 8, 12), ("PF02826", 16, 11)])
+def test_striped_packed_viterbi_algorithm_equals_oracle(name, T, P, models, oracle, proteome):
+    """The node order, stripe shift and closure rule of p7x_vitpk.hip, restated in numpy (tests/vit_striped_emu.py),
+    give the oracle's Viterbi xC: the kernel's algorithm is checked here without a GPU, its code on the GPU box."""
+    import numpy as np
+    import vit_striped_emu
+    from pyhmmer_amd import plan7
+    hmm = models[name][0]
+    op = oracle.OracleProfile(hmm, plan7.Background(hmm.alphabet), 400)
+    rng = np.random.default_rng(11)
+    passes = []
+    for si in rng.integers(0, len(proteome), 4):
+        seq = np.array(proteome[int(si)].sequence, dtype=np.uint8)[:120]
+        st, sc, xc = op.vit(seq)
+        assert vit_striped_emu.vit_striped(op, seq, T, P, passes) == xc
+    assert passes and max(passes) <= 2 * T
