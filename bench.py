@@ -113,8 +113,8 @@ def host_cpus():
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
-    ap.add_argument("--warmup", type=int, default=30)
+    ap.add_argument("--steps", type=int, default=600)
+    ap.add_argument("--warmup", type=int, default=100)
     ap.add_argument("--nseq", type=int, default=1_000_000, help="targets per GPU")
     ap.add_argument("--seqlen", type=int, default=300)
     ap.add_argument("--hmm", default="KR")
