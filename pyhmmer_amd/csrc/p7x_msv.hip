@@ -69,6 +69,7 @@ __device__ __forceinline__ void lds_wait(Chunk &c)
 // One DP row over the register file, four register pairs (8 registers, 16 cells) per chunk.
 template <int R, bool ODD, int T, bool FAST = false>   // T = chunk index being computed
 struct RowChunks {
+  static_assert(R % 8 == 0, "a row is walked in chunks of 8 registers: the register count must be a multiple of 8");
   static constexpr int NT = R / 8;
   static constexpr int S = msv_stride_c(R);
   static constexpr int TBASE = ODD ? 0 : kTabRows * S * 4;
