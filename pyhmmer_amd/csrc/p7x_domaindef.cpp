@@ -736,7 +736,9 @@ P7X_MULTIVERSION void null2_by_trace(const Model &om, const Trace &tr, int zstar
   for (int z = zstart; z <= zend; ++z) {
     if (tr.i[z] == 0) continue;
     Ld++;
-    if (tr.k[z] > 0) { if (tr.st[z] == sM) wm[tr.k[z]] += 1.0f; else wi[tr.k[z]] += 1.0f; }
+    // upstream computes a match/insert selector here and then never uses it: the usage count of an insert
+    // emission lands in the MATCH slot of node k as well (the insert slot stays zero)
+    if (tr.k[z] > 0) wm[tr.k[z]] += 1.0f;
     else switch (tr.st[z]) { case sN: eN += 1.0f; break; case sC: eC += 1.0f; break; case sJ: eJ += 1.0f; break; default: break; }
   }
   const float norm = 1.0 / (float) Ld;

@@ -187,9 +187,8 @@ def test_hmmscan_rrefam_matches_hmmer_scan_table(models, proteome):
             rows = expected.get(seq.name, [])
             assert [h.name for h in hits.reported] == [r[0] for r in rows], seq.name
             for h, r in zip(hits.reported, rows):
-                tol = 0.3 if h.nclustered > 0 else 0.1          # stochastic-null2 hits: see DESIGN.md section 4
-                assert h.score == pytest.approx(float(r[5]), abs=tol) and h.bias == pytest.approx(float(r[6]), abs=tol)
-                assert h.evalue == pytest.approx(float(r[4]), rel=0.15 if tol == 0.1 else 0.3)
+                assert h.score == pytest.approx(float(r[5]), abs=0.1) and h.bias == pytest.approx(float(r[6]), abs=0.1)
+                assert h.evalue == pytest.approx(float(r[4]), rel=0.06)
                 assert h.accession == (None if r[1] == "-" else r[1])
                 assert len(h.domains) == int(r[15]) and h.domains[0].alignment.hmm_name == h.name
                 assert h.domains[0].alignment.target_name == seq.name
@@ -199,9 +198,7 @@ def test_hmmscan_rrefam_matches_hmmer_scan_table(models, proteome):
                 out = io.BytesIO()
                 hits.write(out, format="targets", header=False)
                 want = [l for l in text_rows if l.split()[2] == seq.name]
-                for g, w, h in zip(out.getvalue().decode().splitlines(), want, hits.reported):
-                    if h.nclustered == 0:
-                        assert g == w
+                assert out.getvalue().decode().splitlines() == want
             nq += 1
         assert seen == set(expected)
     assert nq == 2 * len(proteome)
@@ -263,8 +260,7 @@ def test_hmmscan_with_gathering_cutoffs(models, proteome):
 
 @pytest.mark.parametrize("fmt,table", [("targets", "PF02826.tbl"), ("domains", "PF02826.domtbl")])
 def test_written_tables_equal_hmmer_output_text(models, proteome, fmt, table):
-    """reference tests/test_plan7/test_tophits.py:359-381, through the device path.  Rows of hits whose null2 comes from
-    the stochastic ensemble have their score / E-value columns masked."""
+    """reference tests/test_plan7/test_tophits.py:359-381, through the device path: every line as text."""
     import io
     from conftest import GOLDEN
     hmm = models["PF02826"][0]
@@ -275,15 +271,7 @@ def test_written_tables_equal_hmmer_output_text(models, proteome, fmt, table):
     want = open(GOLDEN / "tables" / table).read().splitlines()
     while want[-1].startswith("#"):
         want.pop()
-    assert len(got) == len(want)
-    sampled = {h.name for h in hits if h.nclustered > 0}
-    score_cols = (4, 5, 6, 7, 8, 9) if fmt == "targets" else (6, 7, 8, 11, 12, 13, 14)
-    for g, w in zip(got, want):
-        if g.split()[0] in sampled:
-            gf, wf = g.split(), w.split()
-            assert [f for i, f in enumerate(gf) if i not in score_cols] == [f for i, f in enumerate(wf) if i not in score_cols]
-        else:
-            assert g == w
+    assert got == want
     # scan mode: the model names are the "targets" and the sequence is the query (RREFam.scan.tbl layout)
     seq = next(s for s in proteome if s.name == "938293.PRJEB85.HG003691_78")
     scan = list(hmmer.hmmscan([seq], models["RREFam"]))[0]
