@@ -221,11 +221,14 @@ __global__ void decide_fwd_kernel(StageBufs b, StageParams p)
 // ---------------------------------------------------------------------------- layout of the survivors' row blocks
 // Exclusive scan of (L+1)*6 floats over the Forward survivors, so that the rows pass, Backward and the region scan
 // can follow the filters without the host learning the number of survivors first.  One block; flags[0] is raised
-// when there are more survivors than the workspace was sized for (the host then grows it and repeats the tail).
+// when there are more survivors than the per-survivor arrays hold, or when their rows exceed the row buffers (a pooled
+// workspace may have been sized by another database: both limits are checked, not inferred from one another); the
+// host then grows the workspace and repeats the tail.
 __global__ void __launch_bounds__(256) layout_rows_kernel(const int *nfin_ptr, const int32_t *list_fin, const int32_t *slot_len,
-                                                          int64_t *xmx_off, int cap_items, int *flags)
+                                                          int64_t *xmx_off, int cap_items, long long cap_floats, int *flags)
 {
   __shared__ long long part[256];
+  __shared__ int too_big;
   const int n = *nfin_ptr;
   if (n > cap_items) { if (threadIdx.x == 0) flags[0] = 1; return; }
   const int per = (n + 255) / 256, lo = threadIdx.x * per, hi = min(n, lo + per);
@@ -233,8 +236,13 @@ __global__ void __launch_bounds__(256) layout_rows_kernel(const int *nfin_ptr, c
   for (int i = lo; i < hi; ++i) sum += (long long) (slot_len[list_fin[i]] + 1) * 6;
   part[threadIdx.x] = sum;
   __syncthreads();
-  if (threadIdx.x == 0) { long long run = 0; for (int t = 0; t < 256; ++t) { const long long v = part[t]; part[t] = run; run += v; } }
+  if (threadIdx.x == 0) {
+    long long run = 0; for (int t = 0; t < 256; ++t) { const long long v = part[t]; part[t] = run; run += v; }
+    too_big = run > cap_floats;
+    if (too_big) flags[0] = 1;
+  }
   __syncthreads();
+  if (too_big) return;
   long long run = part[threadIdx.x];
   for (int i = lo; i < hi; ++i) { xmx_off[i] = run; run += (long long) (slot_len[list_fin[i]] + 1) * 6; }
 }
@@ -535,7 +543,7 @@ static int enqueue_survivor_passes(CascadeRun &r, int attempt, int nfin)
   const int64_t cap = ws->fin_cap;
   P7X_HIP(hipMemsetAsync(&ws->b.counters[12], 0, 4, s));
   hipLaunchKernelGGL(layout_rows_kernel, dim3(1), dim3(256), 0, s, &ws->b.counters[4], ws->b.list_fin, db->d_slot_len, ws->xmx_off,
-                     (int) std::min<int64_t>(cap, INT_MAX), &ws->b.counters[12]);
+                     (int) std::min<int64_t>(cap, INT_MAX), (long long) ws->xmx_cap, &ws->b.counters[12]);
   P7X_HIP(hipMemsetAsync(&ws->b.counters[5], 0, 3 * 4, s));
   WaveSeqArgs a = ws_args(r.om->p, r.dp, db, ctx);
   a.trans = r.dp->fwd_trans; a.emis = r.dp->fwd_emis; a.list = ws->b.list_fin; a.nlist_ptr = &ws->b.counters[4];
