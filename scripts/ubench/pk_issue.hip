@@ -15,8 +15,11 @@
 
 typedef short s2 __attribute__((ext_vector_type(2)));
 
-enum Op { PK_ADD_SAT = 0, PK_MAX = 1, PK_ADD_MAX_MIX = 2, ADD_U32 = 3, FMA_F32 = 4, PK_ADD_WRAP = 5, NOPS };
-static const char *kOpName[NOPS] = { "v_pk_add_i16 clamp", "v_pk_max_i16", "pk_add clamp + pk_max (MSV mix)", "v_add_u32", "v_fma_f32", "v_pk_add_u16" };
+enum Op { PK_ADD_SAT = 0, PK_MAX = 1, PK_ADD_MAX_MIX = 2, ADD_U32 = 3, FMA_F32 = 4, PK_ADD_WRAP = 5,
+          MAX3_I16 = 6, MAX_I16 = 7, ADD_I16_SAT = 8, MAX3_I32 = 9, MAX_I32 = 10, ADD_I32_SAT = 11, PK_ADD_MAX3_MIX = 12, MED3_I16 = 13, NOPS };
+static const char *kOpName[NOPS] = { "v_pk_add_i16 clamp", "v_pk_max_i16", "pk_add clamp + pk_max (MSV mix)", "v_add_u32", "v_fma_f32", "v_pk_add_u16",
+                                     "v_max3_i16 op_sel (lo,lo,hi)", "v_max_i16 (VOP2)", "v_add_i16 clamp (VOP3)", "v_max3_i32", "v_max_i32 (VOP2)",
+                                     "v_add_i32 clamp (VOP3)", "pk_add clamp + max3_i16 (candidate)", "v_med3_i16" };
 
 // One asm statement holds the whole unrolled body (.rept): between separate asm statements the compiler puts a
 // conservative s_nop, which would be measured too.
@@ -28,7 +31,21 @@ static const char *kOpName[NOPS] = { "v_pk_add_i16 clamp", "v_pk_max_i16", "pk_a
 #define I_PK_MAX(c)      "v_pk_max_i16 %" #c ", %" #c ", %16\n\t"
 #define I_ADD_U32(c)     "v_add_u32 %" #c ", %" #c ", %16\n\t"
 #define I_FMA_F32(c)     "v_fma_f32 %" #c ", %" #c ", %16, %16\n\t"
-#define I_MIX(c)         "v_pk_add_i16 %" #c ", %" #c ", %16 clamp\n\tv_pk_max_i16 %8+" #c ", %8+" #c ", %" #c "\n\t"
+#define I_MAX3_I16(c)    "v_max3_i16 %" #c ", %" #c ", %16, %16 op_sel:[0,0,1,0]\n\t"
+#define I_MED3_I16(c)    "v_med3_i16 %" #c ", %" #c ", %16, %16 op_sel:[0,0,1,0]\n\t"
+#define I_MAX_I16(c)     "v_max_i16 %" #c ", %" #c ", %16\n\t"
+#define I_ADD_I16_SAT(c) "v_add_i16 %" #c ", %" #c ", %16 clamp\n\t"
+#define I_MAX3_I32(c)    "v_max3_i32 %" #c ", %" #c ", %16, %16\n\t"
+#define I_MAX_I32(c)     "v_max_i32 %" #c ", %" #c ", %16\n\t"
+#define I_ADD_I32_SAT(c) "v_add_i32 %" #c ", %" #c ", %16 clamp\n\t"
+#define I_MX0 "v_pk_add_i16 %0, %0, %16 clamp\n\tv_max3_i16 %8, %8, %0, %0 op_sel:[0,0,1,0]\n\t"
+#define I_MX1 "v_pk_add_i16 %1, %1, %16 clamp\n\tv_max3_i16 %9, %9, %1, %1 op_sel:[0,0,1,0]\n\t"
+#define I_MX2 "v_pk_add_i16 %2, %2, %16 clamp\n\tv_max3_i16 %10, %10, %2, %2 op_sel:[0,0,1,0]\n\t"
+#define I_MX3 "v_pk_add_i16 %3, %3, %16 clamp\n\tv_max3_i16 %11, %11, %3, %3 op_sel:[0,0,1,0]\n\t"
+#define I_MX4 "v_pk_add_i16 %4, %4, %16 clamp\n\tv_max3_i16 %12, %12, %4, %4 op_sel:[0,0,1,0]\n\t"
+#define I_MX5 "v_pk_add_i16 %5, %5, %16 clamp\n\tv_max3_i16 %13, %13, %5, %5 op_sel:[0,0,1,0]\n\t"
+#define I_MX6 "v_pk_add_i16 %6, %6, %16 clamp\n\tv_max3_i16 %14, %14, %6, %6 op_sel:[0,0,1,0]\n\t"
+#define I_MX7 "v_pk_add_i16 %7, %7, %16 clamp\n\tv_max3_i16 %15, %15, %7, %7 op_sel:[0,0,1,0]\n\t"
 // the accumulator operands of the mix are %8..%15: spell them out (asm operand numbers cannot be computed)
 #define I_MIX0 "v_pk_add_i16 %0, %0, %16 clamp\n\tv_pk_max_i16 %8, %8, %0\n\t"
 #define I_MIX1 "v_pk_add_i16 %1, %1, %16 clamp\n\tv_pk_max_i16 %9, %9, %1\n\t"
@@ -53,6 +70,18 @@ __device__ __forceinline__ void body(uint32_t (&v)[8], uint32_t (&acc)[8], uint3
   else if constexpr (OP == PK_MAX) { P7X_EMIT(I_PK_MAX) }
   else if constexpr (OP == ADD_U32) { P7X_EMIT(I_ADD_U32) }
   else if constexpr (OP == FMA_F32) { P7X_EMIT(I_FMA_F32) }
+  else if constexpr (OP == MAX3_I16) { P7X_EMIT(I_MAX3_I16) }
+  else if constexpr (OP == MED3_I16) { P7X_EMIT(I_MED3_I16) }
+  else if constexpr (OP == MAX_I16) { P7X_EMIT(I_MAX_I16) }
+  else if constexpr (OP == ADD_I16_SAT) { P7X_EMIT(I_ADD_I16_SAT) }
+  else if constexpr (OP == MAX3_I32) { P7X_EMIT(I_MAX3_I32) }
+  else if constexpr (OP == MAX_I32) { P7X_EMIT(I_MAX_I32) }
+  else if constexpr (OP == ADD_I32_SAT) { P7X_EMIT(I_ADD_I32_SAT) }
+  else if constexpr (OP == PK_ADD_MAX3_MIX) {
+    if constexpr (NCHAIN == 1) asm volatile(".rept 64\n\t" I_MX0 ".endr" P7X_OPERANDS);
+    else if constexpr (NCHAIN == 4) asm volatile(".rept 64\n\t" I_MX0 I_MX1 I_MX2 I_MX3 ".endr" P7X_OPERANDS);
+    else asm volatile(".rept 64\n\t" I_MX0 I_MX1 I_MX2 I_MX3 I_MX4 I_MX5 I_MX6 I_MX7 ".endr" P7X_OPERANDS);
+  }
   else {
     if constexpr (NCHAIN == 1) asm volatile(".rept 64\n\t" I_MIX0 ".endr" P7X_OPERANDS);
     else if constexpr (NCHAIN == 4) asm volatile(".rept 64\n\t" I_MIX0 I_MIX1 I_MIX2 I_MIX3 ".endr" P7X_OPERANDS);
@@ -97,7 +126,7 @@ static void run(int waves_per_simd, int num_cu, double clk_hz, uint32_t *d_out, 
   double mean = 0; unsigned long long mx = 0;
   for (auto c : cyc) { mean += (double) c; if (c > mx) mx = c; }
   mean /= nblocks;
-  const double per_wave_insts = (double) iters * 64 * NCHAIN * (OP == PK_ADD_MAX_MIX ? 2 : 1);
+  const double per_wave_insts = (double) iters * 64 * NCHAIN * ((OP == PK_ADD_MAX_MIX || OP == PK_ADD_MAX3_MIX) ? 2 : 1);
   // every SIMD holds waves_per_simd waves when the dispatcher balances them: instructions issued per SIMD
   const double per_simd_insts = per_wave_insts * waves_per_simd;
   const double cyc_counter = mean / per_simd_insts;                        // s_memtime ticks per wave-instruction per SIMD
@@ -109,7 +138,7 @@ static void run(int waves_per_simd, int num_cu, double clk_hz, uint32_t *d_out, 
 template <int OP>
 static void sweep(int num_cu, double clk_hz, uint32_t *d_out, unsigned long long *d_cyc)
 {
-  for (int w : { 1, 2, 3, 4, 8 }) {
+  for (int w : { 1, 2, 3, 4 }) {
     run<OP, 1>(w, num_cu, clk_hz, d_out, d_cyc);
     run<OP, 4>(w, num_cu, clk_hz, d_out, d_cyc);
     run<OP, 8>(w, num_cu, clk_hz, d_out, d_cyc);
@@ -134,5 +163,13 @@ int main()
   sweep<PK_ADD_WRAP>(num_cu, clk_hz, d_out, d_cyc);
   sweep<PK_MAX>(num_cu, clk_hz, d_out, d_cyc);
   sweep<PK_ADD_MAX_MIX>(num_cu, clk_hz, d_out, d_cyc);
+  sweep<MAX3_I16>(num_cu, clk_hz, d_out, d_cyc);
+  sweep<MED3_I16>(num_cu, clk_hz, d_out, d_cyc);
+  sweep<MAX_I16>(num_cu, clk_hz, d_out, d_cyc);
+  sweep<ADD_I16_SAT>(num_cu, clk_hz, d_out, d_cyc);
+  sweep<MAX3_I32>(num_cu, clk_hz, d_out, d_cyc);
+  sweep<MAX_I32>(num_cu, clk_hz, d_out, d_cyc);
+  sweep<ADD_I32_SAT>(num_cu, clk_hz, d_out, d_cyc);
+  sweep<PK_ADD_MAX3_MIX>(num_cu, clk_hz, d_out, d_cyc);
   return 0;
 }
