@@ -226,6 +226,17 @@ void p7x_pending_destroy(p7x_pending *pending);
 int  p7x_search_block_enqueue(const p7x_pipeline_cfg *cfg, const p7x_oprofile *om, const float *bg_f,
                               const p7x_seqdb *db, p7x_pending **out);
 int  p7x_search_block_wait(p7x_pending *pending);
+/* A batch of query profiles against one resident target block: the many-query loops of the reference -- hmmsearch
+ * over an iterable of HMMs (_hmmsearch.py:294-436, one Pipeline.search_hmm per query) and Pipeline._scan_loop over an
+ * OptimizedProfileBlock (plan7.pyx:5072-5338, 6624-6677) -- as ONE set of device launches: every kernel of the cascade
+ * takes the profile of its work item from the batch (blockIdx.y), so a launch serves all nq profiles.  Results are
+ * those of nq separate searches (tests/test_gpu_search.py).  oms[q] may have any lengths; out of finish is a caller
+ * array of nq hit lists, in the order of oms.  wait is p7x_search_block_wait; the threading rules are the same. */
+int  p7x_search_batch_enqueue(const p7x_pipeline_cfg *cfg, const p7x_oprofile *const *oms, size_t nq, const float *bg_f,
+                              const p7x_seqdb *db, p7x_pending **out);
+int  p7x_search_batch_finish(p7x_pending *pending, const char *const *names, const char *const *accs,
+                             const char *const *descs, p7x_tophits **outs);
+size_t p7x_pending_nqueries(const p7x_pending *pending);
 
 /* hmmscan orientation (Pipeline.scan_seq / _scan_loop, plan7.pyx:6534-6677; hmmer/_hmmscan.py): search every model
  * against the block of query sequences with cfg.mode = P7X_SCAN_MODELS (one device pass per model, nothing pruned), then

@@ -188,6 +188,9 @@ _SIGNATURES = {
     "p7x_search_block_wait": (C.c_int, [_VP]),
     "p7x_search_block_finish": (C.c_int, [_VP, _VP, _VP, _VP, C.POINTER(_VP)]),
     "p7x_pending_destroy": (None, [_VP]),
+    "p7x_search_batch_enqueue": (C.c_int, [C.POINTER(PipelineCfg), C.POINTER(_VP), C.c_size_t, _VP, _VP, C.POINTER(_VP)]),
+    "p7x_search_batch_finish": (C.c_int, [_VP, _VP, _VP, _VP, C.POINTER(_VP)]),
+    "p7x_pending_nqueries": (C.c_size_t, [_VP]),
     "p7x_oprofile_write_pressed": (C.c_int, [_VP, C.POINTER(C.c_int64), _VP, C.c_size_t, C.POINTER(C.c_size_t), _VP, C.c_size_t,
                                              C.POINTER(C.c_size_t)]),
     "p7x_oprofile_read_pressed": (C.c_int, [_VP, C.c_size_t, _VP, C.c_size_t, _VP, C.POINTER(_VP), C.POINTER(C.c_size_t),

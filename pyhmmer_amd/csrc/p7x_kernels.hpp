@@ -4,6 +4,40 @@
 
 namespace p7x {
 
+// ---- batched launches
+// Every kernel of the cascade takes its arguments from DEVICE memory, one record per profile ("lane") of a batch of
+// queries that run against the same resident target block: blockIdx.y selects the record, blockIdx.x walks that lane's
+// work exactly as it did when a launch served one profile.  Records are <stride> bytes apart, so they can be members
+// of a larger per-lane struct (LaneArgs in p7x_pipeline.hip).  One query alone is a batch of one.
+struct ArgRef { const void *base; uint32_t stride; };
+#if defined(__HIPCC__)
+template <class A> __device__ __forceinline__ A load_args(const ArgRef r)
+{ // constant address space: the record is not written while the kernel runs, so it is fetched with scalar loads
+#if defined(__HIP_DEVICE_COMPILE__)
+  typedef const __attribute__((address_space(4))) A *cptr;
+  return *(cptr) (unsigned long long) (static_cast<const char *>(r.base) + (size_t) blockIdx.y * r.stride);
+#else
+  return *reinterpret_cast<const A *>(static_cast<const char *>(r.base) + (size_t) blockIdx.y * r.stride);   // host pass: never run
+#endif
+}
+#endif
+// A run of consecutive lanes that share one kernel instantiation: host copies of the records (for grid sizing) and
+// the device copies the kernel reads.
+template <class A> struct ArgRun {
+  const A *host = nullptr; const void *dev = nullptr; uint32_t stride = 0; int n = 0;
+  const A &at(int i) const { return *reinterpret_cast<const A *>(reinterpret_cast<const char *>(host) + (size_t) i * stride); }
+  ArgRef ref() const { return ArgRef{ dev, stride }; }
+};
+// blocks per lane: <want> of them have work; one lane alone gets what is resident at once, the lanes of a batch share
+// about twice that (their blocks queue up behind each other; every kernel walks its list with a grid-stride loop)
+inline unsigned lane_grid(long want, long resident, int nlanes)
+{
+  long cap = nlanes > 1 ? (2 * resident + nlanes - 1) / nlanes : resident;
+  if (cap < 1) cap = 1;
+  if (want > cap) want = cap;
+  return (unsigned) (want < 1 ? 1 : want);
+}
+
 // ---- MSV (p7x_msv.hip)
 struct MsvArgs {
   const uint32_t *tab;      // [2][kTabRows][S] dwords: parity 0 = "odd" alignment, parity 1 = "even"
@@ -23,7 +57,9 @@ struct MsvArgs {
 int  msv_pick_R(int M);
 int  msv_stride(int R);
 void msv_build_tables(const Profile &p, int R, int S, std::vector<uint32_t> &out);
-int  msv_launch(int R, const MsvArgs &a, int num_cu, hipStream_t st);
+// fast kernel over <main> followed by the exact kernel over each lane's list of ambiguous groups (<amb>: records with
+// group_list / group_count set); amb == nullptr: the exact kernel over every group of <main>
+int  msv_launch(int R, const ArgRun<MsvArgs> &main, const ArgRun<MsvArgs> *amb, int num_cu, hipStream_t st);
 
 // ---- wave-per-sequence stages (p7x_vitfwd.hip): Viterbi filter, Forward / Backward parsers
 // Node k = z*C + c + 1 lives in lane z, chunk position c; device tables are stored [c*64 + z].
@@ -51,9 +87,10 @@ struct WaveSeqArgs {
   const float *fwd_xmx;     // Backward only: Forward's blocks (for the scale factors)
 };
 int vit_pick_C(int M);
-int vit_launch(const WaveSeqArgs &a, int num_cu, hipStream_t st);
-int fwd_launch(const WaveSeqArgs &a, int num_cu, hipStream_t st);
-int bck_launch(const WaveSeqArgs &a, int num_cu, hipStream_t st);
+// every record of a run has the same C (and nrows); nlist of the host copies bounds the lists and sizes the grid
+int vit_launch(const ArgRun<WaveSeqArgs> &a, int num_cu, hipStream_t st);
+int fwd_launch(const ArgRun<WaveSeqArgs> &a, int num_cu, hipStream_t st);
+int bck_launch(const ArgRun<WaveSeqArgs> &a, int num_cu, hipStream_t st);
 
 // ---- MSV for models beyond the register-resident kernels (p7x_vitfwd.hip::msv_wave_kernel), M <= 2048
 struct MsvWaveArgs {
@@ -63,7 +100,7 @@ struct MsvWaveArgs {
   int nslots, base, bias, tec, tbm;
   int16_t *out_xJ;
 };
-int msv_wave_launch(const MsvWaveArgs &a, int num_cu, hipStream_t st);
+int msv_wave_launch(const ArgRun<MsvWaveArgs> &a, int num_cu, hipStream_t st);
 
 // ---- packed Viterbi filter (p7x_vitpk.hip): T lanes per target, 2P nodes per lane, for M <= 640
 struct VitPkArgs {
@@ -76,7 +113,7 @@ struct VitPkArgs {
 };
 bool vitpk_pick(int M, int *T, int *P);
 void vitpk_build_tables(const Profile &p, int T, int P, std::vector<uint32_t> &trans, std::vector<uint32_t> &emis);
-int  vitpk_launch(int T, int P, const VitPkArgs &a, int num_cu, hipStream_t st);
+int  vitpk_launch(int T, int P, const ArgRun<VitPkArgs> &a, int num_cu, hipStream_t st);
 
 // ---- envelope rescoring (p7x_envelope.hip): Forward + Backward + decoding/null2/optimal accuracy + traceback,
 // one domain envelope per wavefront.  Trace steps come back in traceback order (T first): tr_a = state | k << 8,

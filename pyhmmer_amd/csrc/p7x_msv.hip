@@ -20,6 +20,7 @@
 //     has S/2 odd so the <=32 residue rows fall on distinct bank pairs: conflict-free;
 //   * residues arrive as coalesced 16-byte loads from 64-sequence interleaved tiles (p7x_seqdb).
 #include <cstdlib>
+#include <mutex>
 #include "p7x_device.hpp"
 #include "p7x_kernels.hpp"
 
@@ -151,10 +152,13 @@ __device__ __forceinline__ void msv_row(s2 (&v)[R], uint32_t x, s2 &xB, s2 &xJ, 
 }
 
 template <int R>
-__global__ void __launch_bounds__(kMsvBlock) msv_kernel(const MsvArgs a)
+__global__ void __launch_bounds__(kMsvBlock) msv_kernel(const ArgRef ref)
 {
   extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
   constexpr int S = msv_stride_c(R);
+  const MsvArgs a = load_args<MsvArgs>(ref);
+  const int ngroups = a.group_list ? *a.group_count : a.ngroups;
+  if (ngroups == 0 || *a.counter >= ngroups) return;          // nothing (left) for this lane: skip the table load
   {
     constexpr int n4 = (2 * kTabRows * S) / 4;
     const uint4 *src = reinterpret_cast<const uint4 *>(a.tab);
@@ -166,7 +170,6 @@ __global__ void __launch_bounds__(kMsvBlock) msv_kernel(const MsvArgs a)
   const int lane = threadIdx.x & 63;
   const s2 basev = splat(a.base), tecv = splat(a.tec), zerov = splat(0);
 
-  const int ngroups = a.group_list ? *a.group_count : a.ngroups;
   for (;;) {
     int g = 0;
     if (lane == 0) g = atomicAdd(a.counter, 1);
@@ -218,10 +221,12 @@ __global__ void __launch_bounds__(kMsvBlock) msv_kernel(const MsvArgs a)
 //   * when xJ rises above base the begin score moves: every register is re-biased by the increment
 //     (v_pk_sub_i16 clamp; wave-uniform branch, taken a few times per group at most).
 template <int R>
-__global__ void __launch_bounds__(kMsvBlock, (R <= 88 ? 4 : (R <= 136 ? 3 : 2))) msv_fast_kernel(const MsvArgs a)
+__global__ void __launch_bounds__(kMsvBlock, (R <= 88 ? 4 : (R <= 136 ? 3 : 2))) msv_fast_kernel(const ArgRef ref)
 {
   extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
   constexpr int S = msv_stride_c(R);
+  const MsvArgs a = load_args<MsvArgs>(ref);
+  if (*a.counter >= a.ngroups) return;          // this lane's groups are all taken: skip the table load
   {
     constexpr int n4 = (2 * kTabRows * S) / 4;
     const uint4 *src = reinterpret_cast<const uint4 *>(a.tab);
@@ -336,48 +341,53 @@ void msv_build_tables(const Profile &p, int R, int S, std::vector<uint32_t> &out
 }
 
 template <int R>
-static int launch_R(const MsvArgs &a, int num_cu, hipStream_t st)
+static int launch_R(const ArgRun<MsvArgs> &main, const ArgRun<MsvArgs> *amb, int num_cu, hipStream_t st)
 {
   const size_t lds_bytes = (size_t) 2 * kTabRows * msv_stride_c(R) * 4;
-  if (lds_bytes > 64 * 1024)
-    P7X_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&msv_kernel<R>), hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds_bytes));
-  int per_cu = 0;
-  P7X_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, msv_kernel<R>, kMsvBlock, lds_bytes));
-  if (per_cu < 1) per_cu = 1;
-  long want = ((long) a.ngroups + 3) / 4;
-  long grid = (long) num_cu * per_cu;
-  if (grid > want) grid = want;
-  if (grid < 1) grid = 1;
-  if (a.amb_groups == nullptr) {           // exact kernel over every group
-    hipLaunchKernelGGL(msv_kernel<R>, dim3((unsigned) grid), dim3(kMsvBlock), lds_bytes, st, a);
+  // occupancy and the LDS opt-in are per kernel instantiation: looked up once
+  struct Info { int per_cu_exact = 0, per_cu_fast = 0; bool ok = false; };
+  static Info info;
+  static std::mutex mu;
+  {
+    std::lock_guard<std::mutex> lk(mu);
+    if (!info.ok) {
+      if (lds_bytes > 64 * 1024) {
+        P7X_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&msv_kernel<R>), hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds_bytes));
+        P7X_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&msv_fast_kernel<R>), hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds_bytes));
+      }
+      P7X_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&info.per_cu_exact, msv_kernel<R>, kMsvBlock, lds_bytes));
+      P7X_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&info.per_cu_fast, msv_fast_kernel<R>, kMsvBlock, lds_bytes));
+      if (info.per_cu_exact < 1) info.per_cu_exact = 1;
+      if (info.per_cu_fast < 1) info.per_cu_fast = 1;
+      info.ok = true;
+    }
+  }
+  long want = 1;
+  for (int i = 0; i < main.n; ++i) want = std::max<long>(want, ((long) main.at(i).ngroups + 3) / 4);
+  if (amb == nullptr) {           // exact kernel over every group
+    const unsigned gx = lane_grid(want, (long) num_cu * info.per_cu_exact, main.n);
+    hipLaunchKernelGGL(msv_kernel<R>, dim3(gx, (unsigned) main.n), dim3(kMsvBlock), lds_bytes, st, main.ref());
     P7X_HIP(hipGetLastError());
     return P7X_OK;
   }
-  // fast kernel over every group, then the exact kernel over the (normally empty) list of ambiguous groups
-  if (lds_bytes > 64 * 1024)
-    P7X_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&msv_fast_kernel<R>), hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds_bytes));
-  int per_cu2 = 0;
-  P7X_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu2, msv_fast_kernel<R>, kMsvBlock, lds_bytes));
-  if (per_cu2 < 1) per_cu2 = 1;
+  // fast kernel over every group, then the exact kernel over the (normally empty) lists of ambiguous groups
+  int per_cu2 = info.per_cu_fast;
   // A/B switch: cap the resident blocks per CU so that other kernels' wavefronts fit beside the MSV row registers
   static const int cap = std::getenv("P7X_MSV_BLOCKS_PER_CU") ? std::atoi(std::getenv("P7X_MSV_BLOCKS_PER_CU")) : 0;
   if (cap > 0 && per_cu2 > cap) per_cu2 = cap;
-  long grid2 = (long) num_cu * per_cu2;
-  if (grid2 > want) grid2 = want;
-  if (grid2 < 1) grid2 = 1;
-  hipLaunchKernelGGL(msv_fast_kernel<R>, dim3((unsigned) grid2), dim3(kMsvBlock), lds_bytes, st, a);
+  const unsigned gx2 = lane_grid(want, (long) num_cu * per_cu2, main.n);
+  hipLaunchKernelGGL(msv_fast_kernel<R>, dim3(gx2, (unsigned) main.n), dim3(kMsvBlock), lds_bytes, st, main.ref());
   P7X_HIP(hipGetLastError());
-  MsvArgs b = a;
-  b.group_list = a.amb_groups; b.group_count = a.amb_count; b.counter = a.counter2; b.amb_groups = nullptr;
-  hipLaunchKernelGGL(msv_kernel<R>, dim3(32), dim3(kMsvBlock), lds_bytes, st, b);
+  hipLaunchKernelGGL(msv_kernel<R>, dim3(lane_grid(32, 32, amb->n), (unsigned) amb->n), dim3(kMsvBlock), lds_bytes, st, amb->ref());
   P7X_HIP(hipGetLastError());
   return P7X_OK;
 }
 
-int msv_launch(int R, const MsvArgs &a, int num_cu, hipStream_t st)
+int msv_launch(int R, const ArgRun<MsvArgs> &main, const ArgRun<MsvArgs> *amb, int num_cu, hipStream_t st)
 {
+  if (main.n <= 0) return P7X_OK;
   switch (R) {
-#define P7X_CASE(r) case r: return launch_R<r>(a, num_cu, st);
+#define P7X_CASE(r) case r: return launch_R<r>(main, amb, num_cu, st);
     P7X_CASE(8) P7X_CASE(16) P7X_CASE(24) P7X_CASE(32) P7X_CASE(40) P7X_CASE(48) P7X_CASE(56) P7X_CASE(64) P7X_CASE(72)
     P7X_CASE(80) P7X_CASE(88) P7X_CASE(96) P7X_CASE(104) P7X_CASE(112) P7X_CASE(120) P7X_CASE(128) P7X_CASE(136)
     P7X_CASE(144) P7X_CASE(152) P7X_CASE(160) P7X_CASE(176) P7X_CASE(192) P7X_CASE(208) P7X_CASE(224) P7X_CASE(240)

@@ -64,24 +64,33 @@ __device__ __forceinline__ void wave_count(int *counter, bool take)
   if (mask != 0 && (int) (threadIdx.x & 63) == __ffsll((long long) mask) - 1) atomicAdd(counter, __popcll(mask));
 }
 
+// What the per-target decision kernels of one lane read
+struct DecideArgs {
+  StageBufs b; StageParams p;
+  const int32_t *slot_len; const uint8_t *tjb_tab; const float *null1_tab; const int16_t *xwmove_tab;
+  const uint8_t *dsq; const int64_t *slot_off; const float *eo;
+  int64_t nslots;
+};
+
 // after MSV: usc, P1; survivors -> list_bias
-__global__ void decide_msv_kernel(StageBufs b, StageParams p, const int32_t *slot_len, const uint8_t *tjb_tab,
-                                  const float *null1_tab, int64_t nslots)
+__global__ void decide_msv_kernel(const ArgRef ref)
 {
+  const DecideArgs a = load_args<DecideArgs>(ref);
+  const StageBufs &b = a.b; const StageParams &p = a.p;
   const int64_t s = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
   bool take = false;
-  if (s < nslots) {
-    const int L = slot_len[s];
+  if (s < a.nslots) {
+    const int L = a.slot_len[s];
     const int xJ = b.xJ[s];
     float usc;
     if (xJ < 0) usc = __builtin_inff();
     else {
-      usc = ((float) (xJ - (int) tjb_tab[L]) - (float) p.base_b);
+      usc = ((float) (xJ - (int) a.tjb_tab[L]) - (float) p.base_b);
       usc /= p.scale_b;
       usc -= 3.0f;
     }
     b.usc[s] = usc;
-    const float seq_score = (float) ((double) (usc - null1_tab[L]) / kLog2);
+    const float seq_score = (float) ((double) (usc - a.null1_tab[L]) / kLog2);
     const double P = d_gumbel_surv((double) seq_score, (double) p.mmu, (double) p.mlambda);
     take = !(P > p.F1);
     b.stage[s] = take ? 1 : 0;
@@ -90,9 +99,11 @@ __global__ void decide_msv_kernel(StageBufs b, StageParams p, const int32_t *slo
 }
 
 // bias filter: esl_hmm_Forward on the 2-state composition HMM (p7_bg_FilterScore); survivors -> list_vit / list_fwd
-__global__ void bias_kernel(StageBufs b, StageParams p, const uint8_t *dsq, const int64_t *slot_off,
-                            const int32_t *slot_len, const float *null1_tab, const float *eo)
+__global__ void bias_kernel(const ArgRef ref)
 {
+  const DecideArgs a = load_args<DecideArgs>(ref);
+  const StageBufs &b = a.b; const StageParams &p = a.p;
+  const uint8_t *dsq = a.dsq; const float *eo = a.eo;
   const int n = b.counters[1];
   for (int it0 = blockIdx.x * blockDim.x; it0 < n; it0 += gridDim.x * blockDim.x) {     // uniform trip count per wavefront
     const int it = it0 + (int) threadIdx.x;
@@ -100,14 +111,14 @@ __global__ void bias_kernel(StageBufs b, StageParams p, const uint8_t *dsq, cons
     int s = 0;
     if (it < n) {
     s = b.list_bias[it];
-    const int L = slot_len[s];
-    const float nullsc = null1_tab[L];
+    const int L = a.slot_len[s];
+    const float nullsc = a.null1_tab[L];
     float filtersc = nullsc;
     const float usc = b.usc[s];
     double P;
     bool pass = true;
     if (p.do_bias) {
-      const uint8_t *sq = dsq + slot_off[s];
+      const uint8_t *sq = dsq + a.slot_off[s];
       const float p1 = (float) L / (float) (L + 1);
       const float L1 = (float) ((double) (float) p.M / 8.0);
       const float t00 = p1, t01 = 1.0f - p1, t10 = 1.0f / (L1 + 1.0f), t11 = L1 / (L1 + 1.0f);
@@ -171,20 +182,22 @@ __global__ void bias_kernel(StageBufs b, StageParams p, const uint8_t *dsq, cons
 }
 
 // after Viterbi: vfsc, P2; survivors -> list_fwd
-__global__ void decide_vit_kernel(StageBufs b, StageParams p, const int32_t *slot_len, const int16_t *xwmove_tab)
+__global__ void decide_vit_kernel(const ArgRef ref)
 {
+  const DecideArgs a = load_args<DecideArgs>(ref);
+  const StageBufs &b = a.b; const StageParams &p = a.p;
   const int n = b.counters[2];
   for (int it0 = blockIdx.x * blockDim.x; it0 < n; it0 += gridDim.x * blockDim.x) {
     const int it = it0 + (int) threadIdx.x;
     bool take = false; int s = 0;
     if (it < n) {
     s = b.list_vit[it];
-    const int L = slot_len[s];
+    const int L = a.slot_len[s];
     const int xC = b.xC[it];
     float vfsc;
     if (xC >= 32767) vfsc = __builtin_inff();
     else if (xC > -32768) {
-      vfsc = (float) xC + (float) xwmove_tab[L] - (float) p.base_w;
+      vfsc = (float) xC + (float) a.xwmove_tab[L] - (float) p.base_w;
       vfsc /= p.scale_w;
       vfsc -= 3.0f;
     } else vfsc = -__builtin_inff();
@@ -199,8 +212,10 @@ __global__ void decide_vit_kernel(StageBufs b, StageParams p, const int32_t *slo
 }
 
 // after Forward: P3; survivors -> list_fin
-__global__ void decide_fwd_kernel(StageBufs b, StageParams p)
+__global__ void decide_fwd_kernel(const ArgRef ref)
 {
+  const DecideArgs a = load_args<DecideArgs>(ref);
+  const StageBufs &b = a.b; const StageParams &p = a.p;
   const int n = b.counters[3];
   for (int it0 = blockIdx.x * blockDim.x; it0 < n; it0 += gridDim.x * blockDim.x) {
     const int it = it0 + (int) threadIdx.x;
@@ -219,32 +234,38 @@ __global__ void decide_fwd_kernel(StageBufs b, StageParams p)
 }
 
 // ---------------------------------------------------------------------------- layout of the survivors' row blocks
-// Exclusive scan of (L+1)*6 floats over the Forward survivors, so that the rows pass, Backward and the region scan
-// can follow the filters without the host learning the number of survivors first.  One block; flags[0] is raised
-// when there are more survivors than the per-survivor arrays hold, or when their rows exceed the row buffers (a pooled
-// workspace may have been sized by another database: both limits are checked, not inferred from one another); the
-// host then grows the workspace and repeats the tail.
-__global__ void __launch_bounds__(256) layout_rows_kernel(const int *nfin_ptr, const int32_t *list_fin, const int32_t *slot_len,
-                                                          int64_t *xmx_off, int cap_items, long long cap_floats, int *flags)
+// Exclusive scan of (L+1)*6 floats over a lane's Forward survivors, so that the rows pass, Backward and the region
+// scan can follow the filters without the host learning the number of survivors first.  One block per lane; the lanes
+// of a batch share one row arena and take their part of it from a cursor (one 64-bit atomic per lane).  flags[0] of
+// the lane is raised when it has more survivors than its per-survivor arrays hold, or when its rows do not fit in what
+// is left of the arena; the host then repeats the tail for that lane with buffers of the right size.
+struct LayoutArgs {
+  const int *nfin_ptr; const int32_t *list_fin; const int32_t *slot_len;
+  int64_t *xmx_off; int cap_items; long long cap_floats; unsigned long long *cursor; int *flags;
+};
+
+__global__ void __launch_bounds__(256) layout_rows_kernel(const ArgRef ref)
 {
+  const LayoutArgs a = load_args<LayoutArgs>(ref);
   __shared__ long long part[256];
-  __shared__ int too_big;
-  const int n = *nfin_ptr;
-  if (n > cap_items) { if (threadIdx.x == 0) flags[0] = 1; return; }
+  __shared__ long long base_s;
+  const int n = *a.nfin_ptr;
+  if (n == 0) return;
+  if (n > a.cap_items) { if (threadIdx.x == 0) a.flags[0] = 1; return; }
   const int per = (n + 255) / 256, lo = threadIdx.x * per, hi = min(n, lo + per);
   long long sum = 0;
-  for (int i = lo; i < hi; ++i) sum += (long long) (slot_len[list_fin[i]] + 1) * 6;
+  for (int i = lo; i < hi; ++i) sum += (long long) (a.slot_len[a.list_fin[i]] + 1) * 6;
   part[threadIdx.x] = sum;
   __syncthreads();
   if (threadIdx.x == 0) {
     long long run = 0; for (int t = 0; t < 256; ++t) { const long long v = part[t]; part[t] = run; run += v; }
-    too_big = run > cap_floats;
-    if (too_big) flags[0] = 1;
+    const long long base = (long long) atomicAdd(a.cursor, (unsigned long long) run);
+    if (base + run > a.cap_floats) { a.flags[0] = 1; base_s = -1; } else base_s = base;
   }
   __syncthreads();
-  if (too_big) return;
-  long long run = part[threadIdx.x];
-  for (int i = lo; i < hi; ++i) { xmx_off[i] = run; run += (long long) (slot_len[list_fin[i]] + 1) * 6; }
+  if (base_s < 0) return;
+  long long run = base_s + part[threadIdx.x];
+  for (int i = lo; i < hi; ++i) { a.xmx_off[i] = run; run += (long long) (a.slot_len[a.list_fin[i]] + 1) * 6; }
 }
 
 // ---------------------------------------------------------------------------- regions (p7_DomainDecoding + region scan)
@@ -268,8 +289,9 @@ struct RegionArgs {
   float *out_nexpected;       // [nitems]
 };
 
-__global__ void __launch_bounds__(256) regions_kernel(const RegionArgs a)
+__global__ void __launch_bounds__(256) regions_kernel(const ArgRef ref)
 {
+  const RegionArgs a = load_args<RegionArgs>(ref);
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane((int) (blockIdx.x * 4 + (threadIdx.x >> 6)));
   const int nwaves = (int) gridDim.x * 4;
@@ -337,29 +359,67 @@ __global__ void __launch_bounds__(256) regions_kernel(const RegionArgs a)
 }
 
 // ---------------------------------------------------------------------------- workspace
+// Everything the kernels of one lane (one query profile of a batch) read, as one device record.
+struct LaneArgs {
+  DecideArgs dec;
+  MsvArgs msv, msv_amb;       // fast (or exact-over-everything) MSV; exact MSV over the lane's ambiguous groups
+  MsvWaveArgs msvw;
+  VitPkArgs vitpk;
+  WaveSeqArgs vit, fwd, rows, bck;
+  LayoutArgs lay;
+  RegionArgs reg;
+};
+constexpr int kLaneCounters = 16;
+// counters of a lane: [0] msv groups taken [1] n(list_bias) [2] n(list_vit) [3] n(list_fwd) [4] n(list_fin)
+// [8] n_past_bias [10] ambiguous MSV groups [11] exact-MSV groups taken [12] flag: survivor buffers too small
+
+// A workspace serves a batch of up to <nlanes> queries against a block of up to <cap_slots> targets: per-lane
+// score / list arrays, one row arena shared by the lanes, the lanes' argument records, one stream.
 struct Workspace {
-  int device = -1; int64_t cap_slots = 0;
-  StageBufs b{};
-  float *xmx_f = nullptr, *xmx_b = nullptr, *xmx_s = nullptr; int64_t xmx_cap = 0; int64_t *xmx_off = nullptr; int64_t xmx_off_cap = 0;
-  int32_t *reg_out = nullptr;      // [fin_cap][kRegionCap*3 + 2]: regions | count | nexpected bits, per survivor
-  float *bck_sc = nullptr;         // [fin_cap] Backward scores (not used by the pipeline)
-  int64_t fin_cap = 0;             // Forward survivors the row buffers are sized for
+  int device = -1; int64_t cap_slots = 0; int nlanes = 0;
+  // per lane, lane-major: lane l's part starts at l * cap_slots elements
+  int16_t *xJ = nullptr; float *usc = nullptr, *filtersc = nullptr, *vfsc = nullptr, *fwdsc = nullptr;
+  int32_t *xC = nullptr; float *fwd_by_item = nullptr;
+  int32_t *list_bias = nullptr, *list_vit = nullptr, *list_fwd = nullptr, *list_fin = nullptr;
+  uint8_t *stage = nullptr;
+  int *counters = nullptr;                  // [nlanes][kLaneCounters] then the arena cursor (64 bit)
+  LaneArgs *d_args = nullptr, *h_args = nullptr; size_t h_args_bytes = 0;     // [nlanes], device / pinned host
+  // Forward survivors: row arena (Forward rows, Backward rows, region-scan scratch) and per-lane, per-survivor arrays
+  float *xmx_f = nullptr, *xmx_b = nullptr, *xmx_s = nullptr; int64_t xmx_cap = 0;
+  int64_t *xmx_off = nullptr; int32_t *reg_out = nullptr; float *bck_sc = nullptr;   // [nlanes][fin_cap (* kRegionCap*3+2)]
+  int64_t fin_cap = 0;
+  // one lane at a time, when the shared buffers were too small for it (rare)
+  int64_t *rt_xmx_off = nullptr; int32_t *rt_reg_out = nullptr; float *rt_bck_sc = nullptr; int64_t rt_cap = 0;
   hipEvent_t ev[8]{};
   hipEvent_t ev_sync = nullptr;
   hipStream_t stream = nullptr;     // one stream per cascade in flight: concurrent searches overlap on the device
-  int *h_counts = nullptr; size_t h_counts_bytes = 0;   // pinned mirror of b.counters (the enqueue half must not block on a pageable copy)
+  int *h_counts = nullptr; size_t h_counts_bytes = 0;   // pinned mirror of counters
   bool busy = false;                // between the enqueue and the collect half of a cascade
+  size_t counters_bytes() const { return (size_t) nlanes * kLaneCounters * 4 + 8; }
+  unsigned long long *cursor() const { return reinterpret_cast<unsigned long long *>(counters + (size_t) nlanes * kLaneCounters); }
   ~Workspace() {
     if (device < 0) return;
     (void) hipSetDevice(device);
-    (void) hipFree(b.xJ); (void) hipFree(b.usc); (void) hipFree(b.filtersc); (void) hipFree(b.vfsc); (void) hipFree(b.fwdsc);
-    (void) hipFree(b.xC); (void) hipFree(b.fwd_by_item); (void) hipFree(b.list_bias); (void) hipFree(b.list_vit);
-    (void) hipFree(b.list_fwd); (void) hipFree(b.list_fin); (void) hipFree(b.counters); (void) hipFree(b.stage);
+    (void) hipFree(xJ); (void) hipFree(usc); (void) hipFree(filtersc); (void) hipFree(vfsc); (void) hipFree(fwdsc);
+    (void) hipFree(xC); (void) hipFree(fwd_by_item); (void) hipFree(list_bias); (void) hipFree(list_vit);
+    (void) hipFree(list_fwd); (void) hipFree(list_fin); (void) hipFree(counters); (void) hipFree(stage); (void) hipFree(d_args);
     (void) hipFree(xmx_f); (void) hipFree(xmx_b); (void) hipFree(xmx_s); (void) hipFree(xmx_off); (void) hipFree(reg_out); (void) hipFree(bck_sc);
+    (void) hipFree(rt_xmx_off); (void) hipFree(rt_reg_out); (void) hipFree(rt_bck_sc);
     for (auto &e : ev) if (e) (void) hipEventDestroy(e);
     if (ev_sync) (void) hipEventDestroy(ev_sync);
     if (stream) (void) hipStreamDestroy(stream);
     pinned_release(h_counts, h_counts_bytes);
+    pinned_release(h_args, h_args_bytes);
+  }
+  StageBufs lane_bufs(int l) const
+  {
+    const size_t o = (size_t) l * (size_t) cap_slots;
+    StageBufs b{};
+    b.xJ = xJ + o; b.usc = usc + o; b.filtersc = filtersc + o; b.vfsc = vfsc + o; b.fwdsc = fwdsc + o;
+    b.xC = xC + o; b.fwd_by_item = fwd_by_item + o;
+    b.list_bias = list_bias + o; b.list_vit = list_vit + o; b.list_fwd = list_fwd + o; b.list_fin = list_fin + o;
+    b.stage = stage + o; b.counters = counters + (size_t) l * kLaneCounters;
+    return b;
   }
 };
 
@@ -375,28 +435,32 @@ static void release_workspace(Workspace *w)
   w->busy = false;
 }
 
-static int get_workspace(int device, int64_t nslots, Workspace **out)
+static int get_workspace(int device, int64_t nslots, int nlanes, Workspace **out)
 {
   {
     std::lock_guard<std::mutex> lk(ws_pool().mu);
     Workspace *best = nullptr;
     for (Workspace *w : ws_pool().all)
-      if (!w->busy && w->device == device && w->cap_slots >= nslots && (!best || w->cap_slots < best->cap_slots)) best = w;
+      if (!w->busy && w->device == device && w->cap_slots >= nslots && w->nlanes >= nlanes &&
+          (!best || w->cap_slots * w->nlanes < best->cap_slots * best->nlanes)) best = w;
     if (best) { best->busy = true; *out = best; return P7X_OK; }
   }
   auto w = std::make_unique<Workspace>();
   w->device = device;
   const int64_t cap = std::max<int64_t>(64, ((nslots + 63) / 64) * 64);
-  w->cap_slots = cap;
-  P7X_HIP(hipMalloc(&w->b.xJ, cap * 2));
-  P7X_HIP(hipMalloc(&w->b.usc, cap * 4)); P7X_HIP(hipMalloc(&w->b.filtersc, cap * 4));
-  P7X_HIP(hipMalloc(&w->b.vfsc, cap * 4)); P7X_HIP(hipMalloc(&w->b.fwdsc, cap * 4));
-  P7X_HIP(hipMalloc(&w->b.xC, cap * 4)); P7X_HIP(hipMalloc(&w->b.fwd_by_item, cap * 4));
-  P7X_HIP(hipMalloc(&w->b.list_bias, cap * 4)); P7X_HIP(hipMalloc(&w->b.list_vit, cap * 4));
-  P7X_HIP(hipMalloc(&w->b.list_fwd, cap * 4)); P7X_HIP(hipMalloc(&w->b.list_fin, cap * 4));
-  P7X_HIP(hipMalloc(&w->b.counters, 16 * 4));
-  { void *hp = nullptr; const int pst = pinned_acquire(16 * 4, &hp, &w->h_counts_bytes); if (pst != P7X_OK) return pst; w->h_counts = static_cast<int *>(hp); }
-  P7X_HIP(hipMalloc(&w->b.stage, cap));
+  w->cap_slots = cap; w->nlanes = nlanes;
+  const size_t tot = (size_t) cap * (size_t) nlanes;
+  P7X_HIP(hipMalloc(&w->xJ, tot * 2));
+  P7X_HIP(hipMalloc(&w->usc, tot * 4)); P7X_HIP(hipMalloc(&w->filtersc, tot * 4));
+  P7X_HIP(hipMalloc(&w->vfsc, tot * 4)); P7X_HIP(hipMalloc(&w->fwdsc, tot * 4));
+  P7X_HIP(hipMalloc(&w->xC, tot * 4)); P7X_HIP(hipMalloc(&w->fwd_by_item, tot * 4));
+  P7X_HIP(hipMalloc(&w->list_bias, tot * 4)); P7X_HIP(hipMalloc(&w->list_vit, tot * 4));
+  P7X_HIP(hipMalloc(&w->list_fwd, tot * 4)); P7X_HIP(hipMalloc(&w->list_fin, tot * 4));
+  P7X_HIP(hipMalloc(&w->counters, w->counters_bytes()));
+  P7X_HIP(hipMalloc(&w->d_args, (size_t) nlanes * sizeof(LaneArgs)));
+  { void *hp = nullptr; const int pst = pinned_acquire(w->counters_bytes(), &hp, &w->h_counts_bytes); if (pst != P7X_OK) return pst; w->h_counts = static_cast<int *>(hp); }
+  { void *hp = nullptr; const int pst = pinned_acquire((size_t) nlanes * sizeof(LaneArgs), &hp, &w->h_args_bytes); if (pst != P7X_OK) return pst; w->h_args = static_cast<LaneArgs *>(hp); }
+  P7X_HIP(hipMalloc(&w->stage, tot));
   for (auto &e : w->ev) P7X_HIP(hipEventCreate(&e));
   P7X_HIP(hipEventCreateWithFlags(&w->ev_sync, hipEventDisableTiming));
   {   // the cascade is the critical path of a search: its wavefronts go first when the envelope kernel of the previous
@@ -442,53 +506,125 @@ static const bool g_vit_wave = std::getenv("P7X_VIT_WAVE") != nullptr;          
 static const bool g_host_envelopes = std::getenv("P7X_HOST_ENVELOPES") != nullptr;   // A/B: rescore envelopes on the host
 static const bool g_host_regions = std::getenv("P7X_HOST_REGIONS") != nullptr;       // A/B: region scan on the host
 
-// A block with at most one 64-target group per SIMD cannot fill the device with the lane-per-target kernels and would
-// run for as long as its longest sequences take one wavefront: such blocks (hmmscan's queries) go one target per
-// wavefront through the filters instead.  P7X_SMALL_BLOCK=0 disables the switch (A/B, and the tests' second pass).
-static bool small_block(const p7x_seqdb *db, const DeviceCtx *ctx)
+// The lane-per-target MSV and the 8-lanes-per-target Viterbi need many (profile, 64-target group) pairs to fill the
+// device and run for as long as the longest member of a group takes one wavefront.  A batch with at most one such
+// pair per SIMD (one profile against a scan's query sequences, the fixture proteome) goes one target per wavefront
+// through the filters instead.  P7X_SMALL_BLOCK=0 disables the switch (A/B, and the tests' second pass).
+static bool small_block(const p7x_seqdb *db, const DeviceCtx *ctx, int nlanes)
 { // read per call: the tests run every filter through both families of kernels
   const char *e = std::getenv("P7X_SMALL_BLOCK");
-  return !(e && std::atoi(e) == 0) && db->ngroups <= (int64_t) ctx->num_cu * 4;
+  return !(e && std::atoi(e) == 0) && db->ngroups * (int64_t) nlanes <= (int64_t) ctx->num_cu * 4;
 }
 
-// Run MSV over the whole database; leaves xJ (slot order) in ws->b.xJ.
-static int run_msv(const Profile &p, const DevProfile *dp, const p7x_seqdb *db, DeviceCtx *ctx, Workspace *ws, hipStream_t stream)
+// ---- argument records of a lane
+static void fill_msv_args(LaneArgs &la, const Profile &p, const DevProfile *dp, const p7x_seqdb *db, DeviceCtx *ctx, const StageBufs &b)
 {
-  if (dp->msvR <= 0 || small_block(db, ctx)) {      // M > 478, or too few targets for one per lane: wave-per-target kernel
-    if (!dp->msvw_emis) { set_error("model too long for the MSV kernels (M > 2048)"); return P7X_EINVAL; }
-    MsvWaveArgs w{};
-    w.C = dp->vitC; w.nrows = kTabRows; w.emis = dp->msvw_emis; w.dsq = db->d_dsq; w.slot_off = db->d_slot_off; w.slot_len = db->d_slot_len;
-    w.tjb_tab = ctx->lt.tjb; w.nslots = (int) db->nslots; w.base = p.base_b; w.bias = p.bias_b; w.tec = p.tec_b; w.tbm = p.tbm_b;
-    w.out_xJ = ws->b.xJ;
-    return msv_wave_launch(w, ctx->num_cu, stream);
-  }
+  MsvWaveArgs w{};
+  w.C = dp->vitC; w.nrows = kTabRows; w.emis = dp->msvw_emis; w.dsq = db->d_dsq; w.slot_off = db->d_slot_off; w.slot_len = db->d_slot_len;
+  w.tjb_tab = ctx->lt.tjb; w.nslots = (int) db->nslots; w.base = p.base_b; w.bias = p.bias_b; w.tec = p.tec_b; w.tbm = p.tbm_b;
+  w.out_xJ = b.xJ;
+  la.msvw = w;
   MsvArgs a{};
   a.tab = dp->msv_tab; a.tiles = db->d_tiles; a.grp_off = db->d_grp_off; a.grp_nblk = db->d_grp_nblk;
   a.slot_len = db->d_slot_len; a.tjb_tab = ctx->lt.tjb; a.ngroups = (int) db->ngroups;
   a.base = p.base_b; a.bias = p.bias_b; a.tec = p.tec_b; a.tbm = p.tbm_b;
-  a.counter = &ws->b.counters[0]; a.out_xJ = ws->b.xJ;
-  a.amb_count = &ws->b.counters[10]; a.counter2 = &ws->b.counters[11];
-  a.amb_groups = g_msv_exact_only ? nullptr : ws->b.list_fin;     // list_fin is free until the Forward stage
-  return msv_launch(dp->msvR, a, ctx->num_cu, stream);
+  a.counter = &b.counters[0]; a.out_xJ = b.xJ;
+  a.amb_count = &b.counters[10]; a.counter2 = &b.counters[11];
+  a.amb_groups = g_msv_exact_only ? nullptr : b.list_fin;     // list_fin is free until the Forward stage
+  la.msv = a;
+  MsvArgs x = a;
+  x.group_list = a.amb_groups; x.group_count = a.amb_count; x.counter = a.counter2; x.amb_groups = nullptr;
+  la.msv_amb = x;
 }
 
-// Viterbi filter over a work list: the packed kernel when the model fits it, else one target per wavefront.
-static int run_viterbi(const Profile &p, const DevProfile *dp, const p7x_seqdb *db, DeviceCtx *ctx, const WaveSeqArgs &w, hipStream_t s)
+static void fill_vit_args(LaneArgs &la, const Profile &p, const DevProfile *dp, const p7x_seqdb *db, DeviceCtx *ctx,
+                          const int32_t *list, int nlist, const int *nlist_ptr, int32_t *out_xC)
 {
-  if (dp->vitpkT > 0 && !g_vit_wave && !small_block(db, ctx)) {
-    VitPkArgs a{};
-    a.trans = dp->vitpk_trans; a.emis = dp->vitpk_emis; a.dsq = db->d_dsq; a.slot_off = db->d_slot_off; a.slot_len = db->d_slot_len;
-    a.list = w.list; a.nlist = w.nlist; a.nlist_ptr = w.nlist_ptr; a.nrows = p.Kp + 1;
-    a.xwmove_tab = ctx->lt.xwmove; a.base_w = p.base_w; a.xw_e = p.xw[XE][MOVE]; a.ddbound = p.ddbound_w;
-    a.out_xC = w.out_xC;
-    return vitpk_launch(dp->vitpkT, dp->vitpkP, a, ctx->num_cu, s);
+  WaveSeqArgs w = ws_args(p, dp, db, ctx);
+  w.trans = dp->vit_trans; w.emis = dp->vit_emis; w.list = list; w.nlist = nlist; w.nlist_ptr = nlist_ptr; w.out_xC = out_xC;
+  la.vit = w;
+  VitPkArgs a{};
+  a.trans = dp->vitpk_trans; a.emis = dp->vitpk_emis; a.dsq = db->d_dsq; a.slot_off = db->d_slot_off; a.slot_len = db->d_slot_len;
+  a.list = list; a.nlist = nlist; a.nlist_ptr = nlist_ptr; a.nrows = p.Kp + 1;
+  a.xwmove_tab = ctx->lt.xwmove; a.base_w = p.base_w; a.xw_e = p.xw[XE][MOVE]; a.ddbound = p.ddbound_w;
+  a.out_xC = out_xC;
+  la.vitpk = a;
+}
+
+template <class A> static ArgRun<A> lane_run(const Workspace *ws, A LaneArgs::*member, int first, int n)
+{
+  ArgRun<A> r;
+  r.host = &(ws->h_args[first].*member);
+  r.dev = reinterpret_cast<const char *>(ws->d_args + first) + (reinterpret_cast<const char *>(r.host) - reinterpret_cast<const char *>(ws->h_args + first));
+  r.stride = (uint32_t) sizeof(LaneArgs); r.n = n;
+  return r;
+}
+
+// Lanes are sorted by model length, so the lanes that share a kernel instantiation are consecutive: launch run by run.
+template <class KeyFn, class LaunchFn>
+static int for_runs(int nlanes, KeyFn key, LaunchFn launch)
+{
+  for (int first = 0; first < nlanes; ) {
+    int last = first + 1;
+    const long k = key(first);
+    while (last < nlanes && key(last) == k) ++last;
+    const int st = launch(first, last - first);
+    if (st != P7X_OK) return st;
+    first = last;
   }
-  return vit_launch(w, ctx->num_cu, s);
+  return P7X_OK;
+}
+
+struct LaneModel { const p7x_oprofile *om = nullptr; DevProfile *dp = nullptr; };
+
+static int upload_args(Workspace *ws, int first, int n, hipStream_t s)
+{
+  P7X_HIP(hipMemcpyAsync(ws->d_args + first, ws->h_args + first, (size_t) n * sizeof(LaneArgs), hipMemcpyHostToDevice, s));
+  return P7X_OK;
+}
+
+// MSV over the whole database for every lane; leaves xJ (slot order) in the lanes' xJ arrays.
+static int run_msv(const std::vector<LaneModel> &lm, const p7x_seqdb *db, DeviceCtx *ctx, Workspace *ws, hipStream_t stream)
+{
+  const int nl = (int) lm.size();
+  const bool small = small_block(db, ctx, nl);
+  for (int l = 0; l < nl; ++l)
+    if ((lm[l].dp->msvR <= 0 || small) && !lm[l].dp->msvw_emis) { set_error("model too long for the MSV kernels (M > 2048)"); return P7X_EINVAL; }
+  // M > 478, or too few targets for one per lane: wave-per-target kernel (key < 0), else the register tile
+  auto key = [&](int l) -> long { return (lm[l].dp->msvR <= 0 || small) ? -(long) lm[l].dp->vitC : (long) lm[l].dp->msvR; };
+  return for_runs(nl, key, [&](int first, int n) -> int {
+    if (key(first) < 0) return msv_wave_launch(lane_run(ws, &LaneArgs::msvw, first, n), ctx->num_cu, stream);
+    const ArgRun<MsvArgs> amb = lane_run(ws, &LaneArgs::msv_amb, first, n);
+    return msv_launch(lm[first].dp->msvR, lane_run(ws, &LaneArgs::msv, first, n), g_msv_exact_only ? nullptr : &amb, ctx->num_cu, stream);
+  });
+}
+
+// Viterbi filter over the lanes' work lists: the packed kernel when the model fits it, else one target per wavefront.
+static int run_viterbi(const std::vector<LaneModel> &lm, const p7x_seqdb *db, DeviceCtx *ctx, Workspace *ws, hipStream_t s)
+{
+  const int nl = (int) lm.size();
+  const bool small = small_block(db, ctx, nl);
+  auto key = [&](int l) -> long {
+    const DevProfile *dp = lm[l].dp;
+    return (dp->vitpkT > 0 && !g_vit_wave && !small) ? (long) (dp->vitpkT * 256 + dp->vitpkP) : -(long) dp->vitC;
+  };
+  return for_runs(nl, key, [&](int first, int n) -> int {
+    if (key(first) < 0) return vit_launch(lane_run(ws, &LaneArgs::vit, first, n), ctx->num_cu, s);
+    return vitpk_launch(lm[first].dp->vitpkT, lm[first].dp->vitpkP, lane_run(ws, &LaneArgs::vitpk, first, n), ctx->num_cu, s);
+  });
+}
+
+static int run_wave_stage(const std::vector<LaneModel> &lm, Workspace *ws, WaveSeqArgs LaneArgs::*member, bool backward, DeviceCtx *ctx, hipStream_t s)
+{
+  auto key = [&](int l) -> long { return lm[l].dp->vitC; };
+  return for_runs((int) lm.size(), key, [&](int first, int n) -> int {
+    return backward ? bck_launch(lane_run(ws, member, first, n), ctx->num_cu, s) : fwd_launch(lane_run(ws, member, first, n), ctx->num_cu, s);
+  });
 }
 
 struct CascadeOut {
   std::vector<int32_t> fin_slots;         // survivors of the Forward filter (slot ids)
-  std::vector<float> usc, filtersc, vfsc, fwdsc;   // per survivor
+  std::vector<float> fwdsc;               // per survivor
   std::vector<float> fwd_xmx, bck_xmx;    // concatenated (L+1)*6 blocks; only fetched when the device region scan overflowed
   std::vector<int64_t> xmx_off;
   std::vector<int32_t> reg_n, regs;       // device region scan: count per survivor (-1 range error), kRegionCap x (i, j, multi)
@@ -499,198 +635,293 @@ struct CascadeOut {
   double ms[8]{};
 };
 
-// One cascade in flight: the enqueue half queues every kernel of stage 1 on the workspace's stream and returns, the
-// collect half waits for them (once), repeats the survivor passes in the rare case that the row buffers were too small,
-// and downloads the small result arrays.  A host thread may keep several cascades in flight (hmmscan does: one per
-// model), each on its own leased workspace.
+// One batched cascade in flight: the enqueue half queues every kernel of stage 1 for all lanes on the workspace's
+// stream and returns, the collect half waits for them (once), repeats the survivor passes of the lanes whose row
+// buffers were too small (rare), and downloads the small result arrays.  A host thread may keep several cascades
+// in flight, each on its own leased workspace.
 struct CascadeRun {
   p7x_pipeline_cfg cfg{};
-  const p7x_oprofile *om = nullptr;
+  std::vector<const p7x_oprofile *> oms;  // the queries, caller order
+  std::vector<int> lane_of;               // caller index -> lane (lanes are sorted by model length)
+  std::vector<LaneModel> lm;              // per lane
+  std::vector<int> query_of;              // lane -> caller index
   const p7x_seqdb *db = nullptr;
   DeviceCtx *ctx = nullptr;
-  DevProfile *dp = nullptr;
   Workspace *ws = nullptr;
-  StageParams sp{};
   bool queued = false, collected = false;
   ~CascadeRun() { if (ws && queued && !collected) { (void) hipStreamSynchronize(ws->stream); release_workspace(ws); } }
 };
 
-// Forward with the special-state rows kept, Backward, region scan for the survivors, sized for fin_cap of them (the
-// fin_cap longest targets bound their rows); the kernels read the survivor count from device memory.
-static int enqueue_survivor_passes(CascadeRun &r, int attempt, int nfin)
+// rows of the <count> longest targets (slots are sorted by decreasing length): bounds the rows of any <count> survivors
+static int64_t longest_rows(const p7x_seqdb *db, int64_t count)
+{
+  int64_t rows = 0;
+  count = std::min<int64_t>(count, db->nslots);
+  for (int64_t sl = 0; sl < count; ++sl) rows += (int64_t) db->h_len[db->h_order[sl]] + 1;
+  return rows;
+}
+
+// Forward with the special-state rows kept, Backward, region scan for the survivors of lanes [first, first + n); the
+// kernels read the survivor counts from device memory.  <single>: one lane on the retry buffers (sized for its nfin).
+static int enqueue_survivor_passes(CascadeRun &r, int first, int n, bool retry, int nfin)
 {
   const p7x_seqdb *db = r.db; Workspace *ws = r.ws; DeviceCtx *ctx = r.ctx; hipStream_t s = ws->stream;
   int st = P7X_OK;
   int64_t want_cap = std::min<int64_t>(db->nslots, std::max<int64_t>(4096, db->nslots / 64));
-  if (attempt > 0) want_cap = std::min<int64_t>(db->nslots, std::max<int64_t>(want_cap, (int64_t) nfin));
-  int64_t rows = 0;                                        // slots are sorted by decreasing length
-  for (int64_t sl = 0; sl < want_cap; ++sl) rows += (int64_t) db->h_len[db->h_order[sl]] + 1;
-  const int64_t want_floats = rows * 6;
+  if (retry) want_cap = std::min<int64_t>(db->nslots, std::max<int64_t>(want_cap, (int64_t) nfin));
+  const int64_t want_floats = longest_rows(db, want_cap) * 6;
   if (want_floats > ws->xmx_cap) {
-    (void) hipFree(ws->xmx_f); (void) hipFree(ws->xmx_b); (void) hipFree(ws->xmx_s); ws->xmx_f = ws->xmx_b = ws->xmx_s = nullptr;
+    (void) hipFree(ws->xmx_f); (void) hipFree(ws->xmx_b); (void) hipFree(ws->xmx_s); ws->xmx_f = ws->xmx_b = ws->xmx_s = nullptr; ws->xmx_cap = 0;
     P7X_HIP(hipMalloc(&ws->xmx_f, (size_t) want_floats * 4)); P7X_HIP(hipMalloc(&ws->xmx_b, (size_t) want_floats * 4));
     P7X_HIP(hipMalloc(&ws->xmx_s, (size_t) want_floats * 4));
     ws->xmx_cap = want_floats;
   }
-  if (want_cap > ws->fin_cap) {
-    (void) hipFree(ws->xmx_off); (void) hipFree(ws->reg_out); (void) hipFree(ws->bck_sc);
-    ws->xmx_off = nullptr; ws->reg_out = nullptr; ws->bck_sc = nullptr;
-    P7X_HIP(hipMalloc(&ws->xmx_off, (size_t) want_cap * 8));
-    P7X_HIP(hipMalloc(&ws->reg_out, (size_t) want_cap * (kRegionCap * 3 + 2) * 4));
-    P7X_HIP(hipMalloc(&ws->bck_sc, (size_t) want_cap * 4));
-    ws->fin_cap = want_cap;
+  int64_t cap = 0;
+  int64_t *xmx_off = nullptr; int32_t *reg_out = nullptr; float *bck_sc = nullptr;
+  if (!retry) {
+    if (want_cap > ws->fin_cap) {
+      (void) hipFree(ws->xmx_off); (void) hipFree(ws->reg_out); (void) hipFree(ws->bck_sc);
+      ws->xmx_off = nullptr; ws->reg_out = nullptr; ws->bck_sc = nullptr; ws->fin_cap = 0;
+      P7X_HIP(hipMalloc(&ws->xmx_off, (size_t) ws->nlanes * want_cap * 8));
+      P7X_HIP(hipMalloc(&ws->reg_out, (size_t) ws->nlanes * want_cap * (kRegionCap * 3 + 2) * 4));
+      P7X_HIP(hipMalloc(&ws->bck_sc, (size_t) ws->nlanes * want_cap * 4));
+      ws->fin_cap = want_cap;
+    }
+    cap = ws->fin_cap;
+  } else {
+    if (want_cap > ws->rt_cap) {
+      (void) hipFree(ws->rt_xmx_off); (void) hipFree(ws->rt_reg_out); (void) hipFree(ws->rt_bck_sc);
+      ws->rt_xmx_off = nullptr; ws->rt_reg_out = nullptr; ws->rt_bck_sc = nullptr; ws->rt_cap = 0;
+      P7X_HIP(hipMalloc(&ws->rt_xmx_off, (size_t) want_cap * 8));
+      P7X_HIP(hipMalloc(&ws->rt_reg_out, (size_t) want_cap * (kRegionCap * 3 + 2) * 4));
+      P7X_HIP(hipMalloc(&ws->rt_bck_sc, (size_t) want_cap * 4));
+      ws->rt_cap = want_cap;
+    }
+    cap = ws->rt_cap;
   }
-  const int64_t cap = ws->fin_cap;
-  P7X_HIP(hipMemsetAsync(&ws->b.counters[12], 0, 4, s));
-  hipLaunchKernelGGL(layout_rows_kernel, dim3(1), dim3(256), 0, s, &ws->b.counters[4], ws->b.list_fin, db->d_slot_len, ws->xmx_off,
-                     (int) std::min<int64_t>(cap, INT_MAX), (long long) ws->xmx_cap, &ws->b.counters[12]);
-  P7X_HIP(hipMemsetAsync(&ws->b.counters[5], 0, 3 * 4, s));
-  WaveSeqArgs a = ws_args(r.om->p, r.dp, db, ctx);
-  a.trans = r.dp->fwd_trans; a.emis = r.dp->fwd_emis; a.list = ws->b.list_fin; a.nlist_ptr = &ws->b.counters[4];
-  a.nlist = (int) std::min<int64_t>(cap, INT_MAX);          // sizes the grid only
-  a.counter = &ws->b.counters[5]; a.out_sc = ws->b.fwd_by_item; a.xmx = ws->xmx_f; a.xmx_off = ws->xmx_off;
-  a.abort_flag = &ws->b.counters[12];
-  if ((st = fwd_launch(a, ctx->num_cu, s)) != P7X_OK) return st;
-  if (attempt == 0) P7X_HIP(hipEventRecord(ws->ev[5], s));
-  a.counter = &ws->b.counters[6]; a.out_sc = ws->bck_sc; a.xmx = ws->xmx_b; a.fwd_xmx = ws->xmx_f;
-  if ((st = bck_launch(a, ctx->num_cu, s)) != P7X_OK) return st;
-  {   // posterior decoding of the special states and the region scan, on the rows where they are
+  for (int l = first; l < first + n; ++l) {
+    const Profile &p = r.lm[l].om->p; const DevProfile *dp = r.lm[l].dp;
+    LaneArgs &la = ws->h_args[l];
+    const StageBufs b = ws->lane_bufs(l);
+    xmx_off = retry ? ws->rt_xmx_off : ws->xmx_off + (size_t) l * cap;
+    reg_out = retry ? ws->rt_reg_out : ws->reg_out + (size_t) l * cap * (kRegionCap * 3 + 2);
+    bck_sc = retry ? ws->rt_bck_sc : ws->bck_sc + (size_t) l * cap;
+    LayoutArgs lay{};
+    lay.nfin_ptr = &b.counters[4]; lay.list_fin = b.list_fin; lay.slot_len = db->d_slot_len; lay.xmx_off = xmx_off;
+    lay.cap_items = (int) std::min<int64_t>(cap, INT_MAX); lay.cap_floats = (long long) ws->xmx_cap; lay.cursor = ws->cursor();
+    lay.flags = &b.counters[12];
+    la.lay = lay;
+    WaveSeqArgs a = ws_args(p, dp, db, ctx);
+    a.trans = dp->fwd_trans; a.emis = dp->fwd_emis; a.list = b.list_fin; a.nlist_ptr = &b.counters[4];
+    a.nlist = (int) std::min<int64_t>(cap, INT_MAX);          // sizes the grid only
+    a.out_sc = b.fwd_by_item; a.xmx = ws->xmx_f; a.xmx_off = xmx_off;
+    a.abort_flag = &b.counters[12];
+    la.rows = a;
+    a.out_sc = bck_sc; a.xmx = ws->xmx_b; a.fwd_xmx = ws->xmx_f;
+    la.bck = a;
     RegionArgs ra{};
-    ra.nitems_ptr = &ws->b.counters[4]; ra.abort_flag = &ws->b.counters[12];
-    ra.list = ws->b.list_fin; ra.slot_len = db->d_slot_len; ra.fx = ws->xmx_f; ra.bx = ws->xmx_b;
-    ra.xmx_off = ws->xmx_off; ra.scratch = ws->xmx_s;
-    ra.out_regs = ws->reg_out; ra.out_n = ws->reg_out + (size_t) cap * kRegionCap * 3;
+    ra.nitems_ptr = &b.counters[4]; ra.abort_flag = &b.counters[12];
+    ra.list = b.list_fin; ra.slot_len = db->d_slot_len; ra.fx = ws->xmx_f; ra.bx = ws->xmx_b;
+    ra.xmx_off = xmx_off; ra.scratch = ws->xmx_s;
+    ra.out_regs = reg_out; ra.out_n = reg_out + (size_t) cap * kRegionCap * 3;
     ra.out_nexpected = reinterpret_cast<float *>(ra.out_n + cap);
-    hipLaunchKernelGGL(regions_kernel, dim3((unsigned) (ctx->num_cu * 4)), dim3(256), 0, s, ra);
+    la.reg = ra;
+  }
+  if ((st = upload_args(ws, first, n, s)) != P7X_OK) return st;
+  if (retry) P7X_HIP(hipMemsetAsync(&ws->lane_bufs(first).counters[12], 0, 4, s));
+  P7X_HIP(hipMemsetAsync(ws->cursor(), 0, 8, s));
+  hipLaunchKernelGGL(layout_rows_kernel, dim3(1, (unsigned) n), dim3(256), 0, s, lane_run(ws, &LaneArgs::lay, first, n).ref());
+  P7X_HIP(hipGetLastError());
+  std::vector<LaneModel> sub(r.lm.begin() + first, r.lm.begin() + first + n);
+  {
+    auto key = [&](int l) -> long { return sub[l].dp->vitC; };
+    if ((st = for_runs(n, key, [&](int f, int c) { return fwd_launch(lane_run(ws, &LaneArgs::rows, first + f, c), ctx->num_cu, s); })) != P7X_OK) return st;
+    if (!retry) P7X_HIP(hipEventRecord(ws->ev[5], s));
+    if ((st = for_runs(n, key, [&](int f, int c) { return bck_launch(lane_run(ws, &LaneArgs::bck, first + f, c), ctx->num_cu, s); })) != P7X_OK) return st;
+  }
+  {   // posterior decoding of the special states and the region scan, on the rows where they are
+    const unsigned gx = lane_grid(std::min<int64_t>((cap + 3) / 4, ctx->num_cu * 4), ctx->num_cu * 4, n);
+    hipLaunchKernelGGL(regions_kernel, dim3(gx, (unsigned) n), dim3(256), 0, s, lane_run(ws, &LaneArgs::reg, first, n).ref());
     P7X_HIP(hipGetLastError());
   }
-  if (attempt == 0) P7X_HIP(hipEventRecord(ws->ev[6], s));
-  P7X_HIP(hipMemcpyAsync(ws->h_counts, ws->b.counters, 16 * 4, hipMemcpyDeviceToHost, s));
+  if (!retry) P7X_HIP(hipEventRecord(ws->ev[6], s));
+  P7X_HIP(hipMemcpyAsync(ws->h_counts, ws->counters, ws->counters_bytes(), hipMemcpyDeviceToHost, s));
   P7X_HIP(hipEventRecord(ws->ev_sync, s));
   return P7X_OK;
 }
 
 static int cascade_enqueue(CascadeRun &r)
 {
-  const p7x_pipeline_cfg &cfg = r.cfg; const p7x_oprofile *om = r.om; const p7x_seqdb *db = r.db;
+  const p7x_pipeline_cfg &cfg = r.cfg; const p7x_seqdb *db = r.db;
   int st = get_ctx(db->device, &r.ctx);
   if (st != P7X_OK) return st;
   DeviceCtx *ctx = r.ctx;
-  const Profile &p = om->p;
-  if ((st = get_dev_profile(om, ctx, &r.dp)) != P7X_OK) return st;
-  DevProfile *dp = r.dp;
-  if (db->nslots == 0) return P7X_OK;
-  if (dp->vitC <= 0 || dp->vitC > 32) { set_error("model too long for the device kernels (M > 2048)"); return P7X_EINVAL; }
-  if ((st = get_workspace(db->device, db->nslots, &r.ws)) != P7X_OK) return st;
+  const int nq = (int) r.oms.size();
+  // lanes in order of model length: the lanes of one kernel instantiation are then consecutive
+  r.query_of.resize(nq);
+  for (int i = 0; i < nq; ++i) r.query_of[i] = i;
+  std::stable_sort(r.query_of.begin(), r.query_of.end(), [&](int a, int b) { return r.oms[a]->p.M < r.oms[b]->p.M; });
+  r.lane_of.resize(nq); r.lm.resize(nq);
+  for (int l = 0; l < nq; ++l) {
+    r.lane_of[r.query_of[l]] = l;
+    r.lm[l].om = r.oms[r.query_of[l]];
+    if ((st = get_dev_profile(r.lm[l].om, ctx, &r.lm[l].dp)) != P7X_OK) return st;
+  }
+  if (db->nslots == 0 || nq == 0) return P7X_OK;
+  for (int l = 0; l < nq; ++l)
+    if (r.lm[l].dp->vitC <= 0 || r.lm[l].dp->vitC > 32) { set_error("model too long for the device kernels (M > 2048)"); return P7X_EINVAL; }
+  if ((st = get_workspace(db->device, db->nslots, nq, &r.ws)) != P7X_OK) return st;
   Workspace *ws = r.ws;
   hipStream_t s = ws->stream;
-  r.sp = make_params(p, cfg);
-  const StageParams &sp = r.sp;
   r.queued = true;
-  P7X_HIP(hipMemsetAsync(ws->b.counters, 0, 16 * 4, s));
+  const int nbound = (int) std::min<int64_t>(db->nslots, INT_MAX);
+  for (int l = 0; l < nq; ++l) {
+    const Profile &p = r.lm[l].om->p; const DevProfile *dp = r.lm[l].dp;
+    LaneArgs &la = ws->h_args[l];
+    const StageBufs b = ws->lane_bufs(l);
+    DecideArgs d{};
+    d.b = b; d.p = make_params(p, cfg);
+    d.slot_len = db->d_slot_len; d.tjb_tab = ctx->lt.tjb; d.null1_tab = ctx->lt.null1; d.xwmove_tab = ctx->lt.xwmove;
+    d.dsq = db->d_dsq; d.slot_off = db->d_slot_off; d.eo = dp->bias_eo; d.nslots = db->nslots;
+    la.dec = d;
+    fill_msv_args(la, p, dp, db, ctx, b);
+    fill_vit_args(la, p, dp, db, ctx, b.list_vit, nbound, &b.counters[2], b.xC);
+    WaveSeqArgs a = ws_args(p, dp, db, ctx);
+    a.trans = dp->fwd_trans; a.emis = dp->fwd_emis; a.list = b.list_fwd; a.nlist = nbound; a.nlist_ptr = &b.counters[3];
+    a.out_sc = b.fwd_by_item;
+    la.fwd = a;
+  }
+  if ((st = upload_args(ws, 0, nq, s)) != P7X_OK) return st;
+  P7X_HIP(hipMemsetAsync(ws->counters, 0, ws->counters_bytes(), s));
   // MSV launches that fill the device on their own are chained (two of them sharing the CUs only slow each other
   // down); small blocks -- a scan's query sequences -- leave most of the device idle and run side by side instead
-  const bool fills_device = db->nslots / 64 >= (int64_t) ctx->num_cu * 8;
+  const bool fills_device = (db->nslots / 64) * (int64_t) nq >= (int64_t) ctx->num_cu * 8;
   if (fills_device) {
     std::lock_guard<std::mutex> lk(ctx->msv_mu);          // enqueue order == chain order
     if (ctx->msv_last >= 0) P7X_HIP(hipStreamWaitEvent(s, ctx->msv_done[ctx->msv_last], 0));
     P7X_HIP(hipEventRecord(ws->ev[0], s));
-    if ((st = run_msv(p, dp, db, ctx, ws, s)) != P7X_OK) return st;
+    if ((st = run_msv(r.lm, db, ctx, ws, s)) != P7X_OK) return st;
     P7X_HIP(hipEventRecord(ws->ev[7], s));
     ctx->msv_last = (ctx->msv_last + 1) & 1;
     P7X_HIP(hipEventRecord(ctx->msv_done[ctx->msv_last], s));
   } else {
     P7X_HIP(hipEventRecord(ws->ev[0], s));
-    if ((st = run_msv(p, dp, db, ctx, ws, s)) != P7X_OK) return st;
+    if ((st = run_msv(r.lm, db, ctx, ws, s)) != P7X_OK) return st;
     P7X_HIP(hipEventRecord(ws->ev[7], s));
   }
-  {
-    const unsigned grid = (unsigned) ((db->nslots + 255) / 256);
-    hipLaunchKernelGGL(decide_msv_kernel, dim3(grid), dim3(256), 0, s, ws->b, sp, db->d_slot_len, ctx->lt.tjb, ctx->lt.null1, db->nslots);
-  }
+  const ArgRef dec = lane_run(ws, &LaneArgs::dec, 0, nq).ref();
+  hipLaunchKernelGGL(decide_msv_kernel, dim3((unsigned) ((db->nslots + 255) / 256), (unsigned) nq), dim3(256), 0, s, dec);
   P7X_HIP(hipEventRecord(ws->ev[1], s));
-  hipLaunchKernelGGL(bias_kernel, dim3(ctx->num_cu * 4), dim3(64), 0, s, ws->b, sp, db->d_dsq, db->d_slot_off, db->d_slot_len,
-                     ctx->lt.null1, dp->bias_eo);
+  hipLaunchKernelGGL(bias_kernel, dim3(lane_grid((db->nslots + 63) / 64, ctx->num_cu * 4, nq), (unsigned) nq), dim3(64), 0, s, dec);
   P7X_HIP(hipEventRecord(ws->ev[2], s));
-  {
-    WaveSeqArgs a = ws_args(p, dp, db, ctx);
-    a.trans = dp->vit_trans; a.emis = dp->vit_emis; a.list = ws->b.list_vit; a.nlist_ptr = &ws->b.counters[2];
-    a.counter = &ws->b.counters[5]; a.out_xC = ws->b.xC;
-    if ((st = run_viterbi(p, dp, db, ctx, a, s)) != P7X_OK) return st;
-    hipLaunchKernelGGL(decide_vit_kernel, dim3(ctx->num_cu), dim3(256), 0, s, ws->b, sp, db->d_slot_len, ctx->lt.xwmove);
-  }
+  if ((st = run_viterbi(r.lm, db, ctx, ws, s)) != P7X_OK) return st;
+  const unsigned gdec = lane_grid((db->nslots + 255) / 256, ctx->num_cu, nq);
+  hipLaunchKernelGGL(decide_vit_kernel, dim3(gdec, (unsigned) nq), dim3(256), 0, s, dec);
   P7X_HIP(hipEventRecord(ws->ev[3], s));
-  {
-    WaveSeqArgs a = ws_args(p, dp, db, ctx);
-    a.trans = dp->fwd_trans; a.emis = dp->fwd_emis; a.list = ws->b.list_fwd; a.nlist_ptr = &ws->b.counters[3];
-    a.counter = &ws->b.counters[6]; a.out_sc = ws->b.fwd_by_item;
-    if ((st = fwd_launch(a, ctx->num_cu, s)) != P7X_OK) return st;
-    hipLaunchKernelGGL(decide_fwd_kernel, dim3(ctx->num_cu), dim3(256), 0, s, ws->b, sp);
-  }
+  if ((st = run_wave_stage(r.lm, ws, &LaneArgs::fwd, false, ctx, s)) != P7X_OK) return st;
+  hipLaunchKernelGGL(decide_fwd_kernel, dim3(gdec, (unsigned) nq), dim3(256), 0, s, dec);
+  P7X_HIP(hipGetLastError());
   P7X_HIP(hipEventRecord(ws->ev[4], s));
-  return enqueue_survivor_passes(r, 0, 0);
+  return enqueue_survivor_passes(r, 0, nq, false, 0);
 }
 
-static int cascade_collect(CascadeRun &r, CascadeOut &out)
+// download one lane's per-survivor results (queued on the workspace's stream; the caller synchronises)
+static int fetch_lane(CascadeRun &r, int l, bool retry, CascadeOut &out)
 {
+  Workspace *ws = r.ws; hipStream_t s = ws->stream;
+  const int nfin = out.counts[4];
+  out.fin_slots.resize(nfin); out.fwdsc.resize(nfin); out.xmx_off.resize(nfin);
+  if (nfin == 0) return P7X_OK;
+  const StageBufs b = ws->lane_bufs(l);
+  const int64_t cap = retry ? ws->rt_cap : ws->fin_cap;
+  const int64_t *xmx_off = retry ? ws->rt_xmx_off : ws->xmx_off + (size_t) l * cap;
+  const int32_t *reg_out = retry ? ws->rt_reg_out : ws->reg_out + (size_t) l * cap * (kRegionCap * 3 + 2);
+  out.regs.resize((size_t) nfin * kRegionCap * 3); out.reg_n.resize(nfin); out.nexpected.resize(nfin);
+  P7X_HIP(hipMemcpyAsync(out.fin_slots.data(), b.list_fin, (size_t) nfin * 4, hipMemcpyDeviceToHost, s));
+  P7X_HIP(hipMemcpyAsync(out.xmx_off.data(), xmx_off, (size_t) nfin * 8, hipMemcpyDeviceToHost, s));
+  P7X_HIP(hipMemcpyAsync(out.regs.data(), reg_out, out.regs.size() * 4, hipMemcpyDeviceToHost, s));
+  P7X_HIP(hipMemcpyAsync(out.reg_n.data(), reg_out + (size_t) cap * kRegionCap * 3, (size_t) nfin * 4, hipMemcpyDeviceToHost, s));
+  P7X_HIP(hipMemcpyAsync(out.nexpected.data(), reg_out + (size_t) cap * (kRegionCap * 3 + 1), (size_t) nfin * 4, hipMemcpyDeviceToHost, s));
+  // the rows pass recomputed each survivor's Forward score in list order: one contiguous copy
+  P7X_HIP(hipMemcpyAsync(out.fwdsc.data(), b.fwd_by_item, (size_t) nfin * 4, hipMemcpyDeviceToHost, s));
+  return P7X_OK;
+}
+
+// after the lane's results have arrived: the parsers' rows when the host has to scan them itself
+static int fetch_lane_rows(CascadeRun &r, CascadeOut &out)
+{
+  const p7x_seqdb *db = r.db; Workspace *ws = r.ws;
+  const int nfin = out.counts[4];
+  if (nfin == 0) return P7X_OK;
+  bool overflow = g_host_regions || r.cfg.host_regions != 0;
+  for (int i = 0; i < nfin; ++i) if (out.reg_n[i] == -2) overflow = true;
+  if (!overflow) return P7X_OK;     // a target with more regions than the device keeps (or the A/B switch): the host scans the rows
+  // the lane's blocks are contiguous in the arena (one cursor step), in list order
+  const int64_t lo = out.xmx_off[0];
+  const int64_t hi = out.xmx_off[(size_t) nfin - 1] + (int64_t) (db->h_len[db->h_order[out.fin_slots[(size_t) nfin - 1]]] + 1) * 6;
+  out.fwd_xmx.resize((size_t) (hi - lo)); out.bck_xmx.resize((size_t) (hi - lo));
+  P7X_HIP(hipMemcpy(out.fwd_xmx.data(), ws->xmx_f + lo, (size_t) (hi - lo) * 4, hipMemcpyDeviceToHost));
+  P7X_HIP(hipMemcpy(out.bck_xmx.data(), ws->xmx_b + lo, (size_t) (hi - lo) * 4, hipMemcpyDeviceToHost));
+  for (auto &o : out.xmx_off) o -= lo;
+  out.have_xmx = true;
+  return P7X_OK;
+}
+
+static int cascade_collect(CascadeRun &r, std::vector<CascadeOut> &outs)
+{
+  const int nq = (int) r.oms.size();
+  outs.assign((size_t) nq, CascadeOut{});
   if (!r.queued || r.collected) return P7X_OK;
   const p7x_pipeline_cfg &cfg = r.cfg; const p7x_seqdb *db = r.db; Workspace *ws = r.ws;
   hipStream_t s = ws->stream;
   struct Release { CascadeRun &r; ~Release() { (void) hipStreamSynchronize(r.ws->stream); release_workspace(r.ws); r.collected = true; } } release{ r };
   int st = P7X_OK;
-  int nfin = 0;
-  int64_t tot = 0;
-  for (int attempt = 0; ; ++attempt) {
-    if (attempt > 0 && (st = enqueue_survivor_passes(r, attempt, nfin)) != P7X_OK) return st;
-    P7X_HIP(hipEventSynchronize(ws->ev_sync));              // our work only: other cascades run on other streams
-    std::memcpy(out.counts, ws->h_counts, 16 * 4);
-    nfin = out.counts[4];
-    if (out.counts[12] == 0) break;                            // everything fitted
-    if (attempt > 0) { set_error("row buffers could not be sized for the Forward survivors"); return P7X_EMEM; }
+  P7X_HIP(hipSetDevice(db->device));                      // the collecting thread may have driven another device since
+  P7X_HIP(hipEventSynchronize(ws->ev_sync));              // our work only: other cascades run on other streams
+  std::vector<int> flagged;
+  for (int l = 0; l < nq; ++l) {
+    CascadeOut &out = outs[(size_t) r.query_of[l]];
+    std::memcpy(out.counts, ws->h_counts + (size_t) l * kLaneCounters, kLaneCounters * 4);
+    if (out.counts[12] != 0) flagged.push_back(l);
+    else if ((st = fetch_lane(r, l, false, out)) != P7X_OK) return st;
   }
-  out.fin_slots.resize(nfin);
-  out.usc.resize(nfin); out.filtersc.resize(nfin); out.vfsc.resize(nfin); out.fwdsc.resize(nfin); out.xmx_off.resize(nfin);
-  if (nfin > 0) {
-    const int64_t cap = ws->fin_cap;
-    out.regs.resize((size_t) nfin * kRegionCap * 3); out.reg_n.resize(nfin); out.nexpected.resize(nfin);
-    P7X_HIP(hipMemcpyAsync(out.fin_slots.data(), ws->b.list_fin, (size_t) nfin * 4, hipMemcpyDeviceToHost, s));
-    P7X_HIP(hipMemcpyAsync(out.xmx_off.data(), ws->xmx_off, (size_t) nfin * 8, hipMemcpyDeviceToHost, s));
-    P7X_HIP(hipMemcpyAsync(out.regs.data(), ws->reg_out, out.regs.size() * 4, hipMemcpyDeviceToHost, s));
-    P7X_HIP(hipMemcpyAsync(out.reg_n.data(), ws->reg_out + (size_t) cap * kRegionCap * 3, (size_t) nfin * 4, hipMemcpyDeviceToHost, s));
-    P7X_HIP(hipMemcpyAsync(out.nexpected.data(), ws->reg_out + (size_t) cap * (kRegionCap * 3 + 1), (size_t) nfin * 4, hipMemcpyDeviceToHost, s));
-    // the rows pass recomputed each survivor's Forward score in list order: one contiguous copy
-    P7X_HIP(hipMemcpyAsync(out.fwdsc.data(), ws->b.fwd_by_item, (size_t) nfin * 4, hipMemcpyDeviceToHost, s));
-    P7X_HIP(hipEventRecord(ws->ev_sync, s)); P7X_HIP(hipEventSynchronize(ws->ev_sync));
-    tot = out.xmx_off[(size_t) nfin - 1] + (int64_t) (db->h_len[db->h_order[out.fin_slots[(size_t) nfin - 1]]] + 1) * 6;
-    bool overflow = g_host_regions || cfg.host_regions != 0;
-    for (int i = 0; i < nfin; ++i) if (out.reg_n[i] == -2) overflow = true;
-    if (overflow) {        // a target with more regions than the device keeps (or the A/B switch): the host scans the rows
-      out.fwd_xmx.resize(tot); out.bck_xmx.resize(tot);
-      P7X_HIP(hipMemcpy(out.fwd_xmx.data(), ws->xmx_f, (size_t) tot * 4, hipMemcpyDeviceToHost));
-      P7X_HIP(hipMemcpy(out.bck_xmx.data(), ws->xmx_b, (size_t) tot * 4, hipMemcpyDeviceToHost));
-      out.have_xmx = true;
+  std::vector<std::vector<uint8_t>> by_slot;
+  if (cfg.mode == P7X_SCAN_MODELS) {        // per-target accounting: which filters every (model, sequence) pair passed
+    by_slot.resize((size_t) nq);
+    for (int l = 0; l < nq; ++l) {
+      by_slot[l].resize((size_t) db->nslots);
+      P7X_HIP(hipMemcpyAsync(by_slot[l].data(), ws->lane_bufs(l).stage, by_slot[l].size(), hipMemcpyDeviceToHost, s));
     }
   }
-  if (cfg.mode == P7X_SCAN_MODELS) {        // per-target accounting: which filters every (model, sequence) pair passed
-    std::vector<uint8_t> by_slot((size_t) db->nslots);
-    P7X_HIP(hipMemcpyAsync(by_slot.data(), ws->b.stage, by_slot.size(), hipMemcpyDeviceToHost, s));
-    P7X_HIP(hipEventRecord(ws->ev_sync, s)); P7X_HIP(hipEventSynchronize(ws->ev_sync));
-    out.stage.assign((size_t) db->n, 0);
-    for (int64_t sl = 0; sl < db->nslots; ++sl) out.stage[(size_t) db->h_order[sl]] = by_slot[(size_t) sl];
+  P7X_HIP(hipEventRecord(ws->ev_sync, s)); P7X_HIP(hipEventSynchronize(ws->ev_sync));
+  for (int l = 0; l < nq; ++l) {
+    CascadeOut &out = outs[(size_t) r.query_of[l]];
+    if (out.counts[12] == 0 && (st = fetch_lane_rows(r, out)) != P7X_OK) return st;
   }
-  for (int i = 0; i < 6; ++i) { float ms = 0; (void) hipEventElapsedTime(&ms, ws->ev[i], ws->ev[i + 1]); out.ms[i] = ms; }
-  { float ms = 0; (void) hipEventElapsedTime(&ms, ws->ev[0], ws->ev[7]); out.ms[7] = ms; }
+  // lanes whose survivors did not fit (more of them than the shared buffers were sized for): one at a time, with
+  // buffers sized for the lane's own count
+  for (int l : flagged) {
+    CascadeOut &out = outs[(size_t) r.query_of[l]];
+    if ((st = enqueue_survivor_passes(r, l, 1, true, out.counts[4])) != P7X_OK) return st;
+    P7X_HIP(hipEventSynchronize(ws->ev_sync));
+    std::memcpy(out.counts, ws->h_counts + (size_t) l * kLaneCounters, kLaneCounters * 4);
+    if (out.counts[12] != 0) { set_error("row buffers could not be sized for the Forward survivors"); return P7X_EMEM; }
+    if ((st = fetch_lane(r, l, true, out)) != P7X_OK) return st;
+    P7X_HIP(hipEventRecord(ws->ev_sync, s)); P7X_HIP(hipEventSynchronize(ws->ev_sync));
+    if ((st = fetch_lane_rows(r, out)) != P7X_OK) return st;
+  }
+  double ms[8]{};
+  for (int i = 0; i < 6; ++i) { float t = 0; (void) hipEventElapsedTime(&t, ws->ev[i], ws->ev[i + 1]); ms[i] = t; }
+  { float t = 0; (void) hipEventElapsedTime(&t, ws->ev[0], ws->ev[7]); ms[7] = t; }
+  for (int l = 0; l < nq; ++l) {
+    CascadeOut &out = outs[(size_t) r.query_of[l]];
+    std::memcpy(out.ms, ms, sizeof(ms));
+    if (cfg.mode == P7X_SCAN_MODELS) {
+      out.stage.assign((size_t) db->n, 0);
+      for (int64_t sl = 0; sl < db->nslots; ++sl) out.stage[(size_t) db->h_order[sl]] = by_slot[l][(size_t) sl];
+    }
+  }
   return P7X_OK;
-}
-
-
-static int run_cascade(const p7x_pipeline_cfg &cfg, const p7x_oprofile *om, const p7x_seqdb *db, CascadeOut &out)
-{
-  CascadeRun r;
-  r.cfg = cfg; r.om = om; r.db = db;
-  const int st = cascade_enqueue(r);
-  if (st != P7X_OK) return st;
-  return cascade_collect(r, out);
 }
 
 } // namespace p7x
@@ -708,8 +939,10 @@ int p7x_filters_batch(const p7x_oprofile *om, const p7x_seqdb *db, int32_t *xJ, 
   int st = get_ctx(db->device, &ctx);
   if (st != P7X_OK) return st;
   const Profile &p = om->p;
-  DevProfile *dp = nullptr;
-  if ((st = get_dev_profile(om, ctx, &dp)) != P7X_OK) return st;
+  std::vector<LaneModel> lm(1);
+  lm[0].om = om;
+  if ((st = get_dev_profile(om, ctx, &lm[0].dp)) != P7X_OK) return st;
+  DevProfile *dp = lm[0].dp;
   const int64_t ns = db->nslots;
   for (int64_t t = 0; t < db->n; ++t) {
     if (xJ) xJ[t] = 0;
@@ -719,34 +952,49 @@ int p7x_filters_batch(const p7x_oprofile *om, const p7x_seqdb *db, int32_t *xJ, 
   }
   if (ns == 0) return P7X_OK;
   Workspace *ws = nullptr;
-  if ((st = get_workspace(db->device, ns, &ws)) != P7X_OK) return st;
+  if ((st = get_workspace(db->device, ns, 1, &ws)) != P7X_OK) return st;
   WorkspaceLease lease{ ws };
   hipStream_t s = ctx->stream;
-  P7X_HIP(hipMemsetAsync(ws->b.counters, 0, 16 * 4, s));
+  const StageBufs b = ws->lane_bufs(0);
+  LaneArgs &la = ws->h_args[0];
+  p7x_pipeline_cfg cfg; p7x_pipeline_cfg_default(&cfg);
+  {
+    DecideArgs d{};
+    d.b = b; d.p = make_params(p, cfg);
+    d.p.F1 = 2.0; d.p.F2 = 2.0;              // the bias pass below scores every target
+    d.slot_len = db->d_slot_len; d.tjb_tab = ctx->lt.tjb; d.null1_tab = ctx->lt.null1; d.xwmove_tab = ctx->lt.xwmove;
+    d.dsq = db->d_dsq; d.slot_off = db->d_slot_off; d.eo = dp->bias_eo; d.nslots = ns;
+    la.dec = d;
+    fill_msv_args(la, p, dp, db, ctx, b);
+    if (dp->vitC > 0) {
+      fill_vit_args(la, p, dp, db, ctx, nullptr, (int) ns, nullptr, b.xC);
+      WaveSeqArgs a = ws_args(p, dp, db, ctx);
+      a.trans = dp->fwd_trans; a.emis = dp->fwd_emis; a.list = nullptr; a.nlist = (int) ns; a.nlist_ptr = nullptr; a.out_sc = b.fwd_by_item;
+      la.fwd = a;
+    }
+  }
+  if ((st = upload_args(ws, 0, 1, s)) != P7X_OK) return st;
+  P7X_HIP(hipMemsetAsync(ws->counters, 0, ws->counters_bytes(), s));
   if (xJ) {
-    if ((st = run_msv(p, dp, db, ctx, ws, s)) != P7X_OK) return st;
+    if ((st = run_msv(lm, db, ctx, ws, s)) != P7X_OK) return st;
     std::vector<int16_t> h((size_t) ns);
-    P7X_HIP(hipMemcpyAsync(h.data(), ws->b.xJ, (size_t) ns * 2, hipMemcpyDeviceToHost, s));
+    P7X_HIP(hipMemcpyAsync(h.data(), b.xJ, (size_t) ns * 2, hipMemcpyDeviceToHost, s));
     P7X_HIP(hipStreamSynchronize(s));
     for (int64_t sl = 0; sl < ns; ++sl) xJ[db->h_order[sl]] = h[sl];
   }
   if (xC || fwd) {
     if (dp->vitC <= 0) { set_error("model too long for the wave-per-sequence kernels"); return P7X_EINVAL; }
-    WaveSeqArgs a = ws_args(p, dp, db, ctx);
-    a.list = nullptr; a.nlist = (int) ns; a.nlist_ptr = nullptr;
     if (xC) {
-      a.trans = dp->vit_trans; a.emis = dp->vit_emis; a.counter = &ws->b.counters[5]; a.out_xC = ws->b.xC;
-      if ((st = run_viterbi(p, dp, db, ctx, a, s)) != P7X_OK) return st;
+      if ((st = run_viterbi(lm, db, ctx, ws, s)) != P7X_OK) return st;
       std::vector<int32_t> h((size_t) ns);
-      P7X_HIP(hipMemcpyAsync(h.data(), ws->b.xC, (size_t) ns * 4, hipMemcpyDeviceToHost, s));
+      P7X_HIP(hipMemcpyAsync(h.data(), b.xC, (size_t) ns * 4, hipMemcpyDeviceToHost, s));
       P7X_HIP(hipStreamSynchronize(s));
       for (int64_t sl = 0; sl < ns; ++sl) xC[db->h_order[sl]] = h[sl];
     }
     if (fwd) {
-      a.trans = dp->fwd_trans; a.emis = dp->fwd_emis; a.counter = &ws->b.counters[6]; a.out_sc = ws->b.fwd_by_item;
-      if ((st = fwd_launch(a, ctx->num_cu, s)) != P7X_OK) return st;
+      if ((st = run_wave_stage(lm, ws, &LaneArgs::fwd, false, ctx, s)) != P7X_OK) return st;
       std::vector<float> h((size_t) ns);
-      P7X_HIP(hipMemcpyAsync(h.data(), ws->b.fwd_by_item, (size_t) ns * 4, hipMemcpyDeviceToHost, s));
+      P7X_HIP(hipMemcpyAsync(h.data(), b.fwd_by_item, (size_t) ns * 4, hipMemcpyDeviceToHost, s));
       P7X_HIP(hipStreamSynchronize(s));
       for (int64_t sl = 0; sl < ns; ++sl) fwd[db->h_order[sl]] = h[sl];
     }
@@ -755,18 +1003,14 @@ int p7x_filters_batch(const p7x_oprofile *om, const p7x_seqdb *db, int32_t *xJ, 
     // run the bias kernel over every target: list_bias = identity
     std::vector<int32_t> ident((size_t) ns);
     for (int64_t i = 0; i < ns; ++i) ident[i] = (int32_t) i;
-    P7X_HIP(hipMemcpyAsync(ws->b.list_bias, ident.data(), (size_t) ns * 4, hipMemcpyHostToDevice, s));
+    P7X_HIP(hipMemcpyAsync(b.list_bias, ident.data(), (size_t) ns * 4, hipMemcpyHostToDevice, s));
     int cnt = (int) ns;
-    P7X_HIP(hipMemcpyAsync(&ws->b.counters[1], &cnt, 4, hipMemcpyHostToDevice, s));
-    p7x_pipeline_cfg cfg; p7x_pipeline_cfg_default(&cfg);
-    StageParams sp = make_params(p, cfg);
-    sp.F1 = 2.0; sp.F2 = 2.0;
+    P7X_HIP(hipMemcpyAsync(&b.counters[1], &cnt, 4, hipMemcpyHostToDevice, s));
     std::vector<float> zero((size_t) ns, 0.0f);
-    P7X_HIP(hipMemcpyAsync(ws->b.usc, zero.data(), (size_t) ns * 4, hipMemcpyHostToDevice, s));
-    hipLaunchKernelGGL(bias_kernel, dim3(ctx->num_cu * 4), dim3(64), 0, s, ws->b, sp, db->d_dsq, db->d_slot_off, db->d_slot_len,
-                       ctx->lt.null1, dp->bias_eo);
+    P7X_HIP(hipMemcpyAsync(b.usc, zero.data(), (size_t) ns * 4, hipMemcpyHostToDevice, s));
+    hipLaunchKernelGGL(bias_kernel, dim3(ctx->num_cu * 4), dim3(64), 0, s, lane_run(ws, &LaneArgs::dec, 0, 1).ref());
     std::vector<float> h((size_t) ns);
-    P7X_HIP(hipMemcpyAsync(h.data(), ws->b.filtersc, (size_t) ns * 4, hipMemcpyDeviceToHost, s));
+    P7X_HIP(hipMemcpyAsync(h.data(), b.filtersc, (size_t) ns * 4, hipMemcpyDeviceToHost, s));
     P7X_HIP(hipStreamSynchronize(s));
     for (int64_t sl = 0; sl < ns; ++sl) bias_filtersc[db->h_order[sl]] = h[sl];
   }
@@ -774,6 +1018,18 @@ int p7x_filters_batch(const p7x_oprofile *om, const p7x_seqdb *db, int32_t *xJ, 
 }
 
 // ---------------------------------------------------------------------------- single-sequence seam
+static int run_cascade(const p7x_pipeline_cfg &cfg, const p7x_oprofile *om, const p7x_seqdb *db, CascadeOut &out)
+{
+  CascadeRun r;
+  r.cfg = cfg; r.oms.assign(1, om); r.db = db;
+  int st = cascade_enqueue(r);
+  if (st != P7X_OK) return st;
+  std::vector<CascadeOut> outs;
+  if ((st = cascade_collect(r, outs)) != P7X_OK) return st;
+  out = std::move(outs[0]);
+  return P7X_OK;
+}
+
 static int one_seq(const p7x_oprofile *om, int device, const uint8_t *dsq, int32_t L, int which, float *sc)
 {
   if (!om || !dsq || !sc || L < 1) { set_error("bad arguments"); return P7X_EINVAL; }
@@ -834,38 +1090,53 @@ int p7x_fwd_parser(const p7x_oprofile *om, int device, const uint8_t *dsq, int32
 int p7x_bck_parser(const p7x_oprofile *om, int device, const uint8_t *dsq, int32_t L, float *sc) { return one_seq(om, device, dsq, L, 3, sc); }
 
 // ---------------------------------------------------------------------------- the search
-// Two stages, so that a caller with many queries can overlap them (hmmer.hmmsearch does): begin = the filter
-// cascade and the parsers on the device, finish = domain definition on the host (+ the envelope kernel on its own
-// stream).  p7x_search_block is begin followed by finish.
+// Two stages, so that a caller with many queries can overlap them (hmmer.hmmsearch does): enqueue / wait = the filter
+// cascade and the parsers on the device for a batch of query profiles against one resident target block, finish =
+// domain definition on the host (+ the envelope kernel on its own stream), one hit list per query.  One query alone
+// (p7x_search_block_*) is a batch of one.
 struct p7x_pending {
   p7x_pipeline_cfg cfg{};
-  const p7x_oprofile *om = nullptr;
   const p7x_seqdb *db = nullptr;
   CascadeRun run;
-  CascadeOut co;
+  std::vector<CascadeOut> co;             // caller order
   bool waited = false;
   std::chrono::steady_clock::time_point t0;
 };
+
+int p7x_search_batch_enqueue(const p7x_pipeline_cfg *cfg, const p7x_oprofile *const *oms, size_t nq, const float *bg_f,
+                             const p7x_seqdb *db, p7x_pending **out)
+{
+  if (!cfg || !oms || !db || !out || nq == 0 || nq > 4096) { set_error("p7x_search_batch_enqueue: bad arguments"); return P7X_EINVAL; }
+  *out = nullptr;
+  auto pd = std::make_unique<p7x_pending>();
+  pd->t0 = std::chrono::steady_clock::now();
+  for (size_t q = 0; q < nq; ++q) {
+    if (!oms[q]) { set_error("p7x_search_batch_enqueue: null profile"); return P7X_EINVAL; }
+    const Profile &p = oms[q]->p;
+    if (p.abc_type != db->abc_type) { set_error("profile and target block have different alphabets"); return P7X_EINVAL; }
+    // The bias filter's composition odds and the null2 background are baked into the optimized profile when it is
+    // converted (p7_bg_SetFilter / p7_ProfileConfig with the Background given then).  A pipeline whose background
+    // differs from that one would silently score against the wrong null model: refuse it instead.
+    if (bg_f) for (int x = 0; x < p.K; ++x) if (bg_f[x] != p.bgf[x]) {
+      set_error("the pipeline's background differs from the one the optimized profile was configured with"); return P7X_EINVAL; }
+    if (cfg->use_bit_cutoffs) {   // p7_pli_NewModelThresholds: eslEINVAL when the model lacks the cutoffs
+      const int i = cfg->use_bit_cutoffs == P7X_BITCUT_GA ? P7X_GA1 : (cfg->use_bit_cutoffs == P7X_BITCUT_TC ? P7X_TC1 : P7X_NC1);
+      if (p.cutoff[i] == P7X_CUTOFF_UNSET || p.cutoff[i + 1] == P7X_CUTOFF_UNSET) { set_error("model is missing the requested bit score cutoffs"); return P7X_EINVAL; }
+    }
+  }
+  pd->cfg = *cfg; pd->db = db;
+  pd->run.cfg = *cfg; pd->run.oms.assign(oms, oms + nq); pd->run.db = db;
+  const int st = cascade_enqueue(pd->run);
+  if (st != P7X_OK) return st;
+  *out = pd.release();
+  return P7X_OK;
+}
 
 int p7x_search_block_enqueue(const p7x_pipeline_cfg *cfg, const p7x_oprofile *om, const float *bg_f, const p7x_seqdb *db,
                              p7x_pending **out)
 {
   if (!cfg || !om || !db || !out) { set_error("p7x_search_block_enqueue: bad arguments"); return P7X_EINVAL; }
-  (void) bg_f;
-  *out = nullptr;
-  auto pd = std::make_unique<p7x_pending>();
-  pd->t0 = std::chrono::steady_clock::now();
-  if (cfg->use_bit_cutoffs) {   // p7_pli_NewModelThresholds: eslEINVAL when the model lacks the cutoffs
-    const Profile &p = om->p;
-    const int i = cfg->use_bit_cutoffs == P7X_BITCUT_GA ? P7X_GA1 : (cfg->use_bit_cutoffs == P7X_BITCUT_TC ? P7X_TC1 : P7X_NC1);
-    if (p.cutoff[i] == P7X_CUTOFF_UNSET || p.cutoff[i + 1] == P7X_CUTOFF_UNSET) { set_error("model is missing the requested bit score cutoffs"); return P7X_EINVAL; }
-  }
-  pd->cfg = *cfg; pd->om = om; pd->db = db;
-  pd->run.cfg = *cfg; pd->run.om = om; pd->run.db = db;
-  const int st = cascade_enqueue(pd->run);
-  if (st != P7X_OK) return st;
-  *out = pd.release();
-  return P7X_OK;
+  return p7x_search_batch_enqueue(cfg, &om, 1, bg_f, db, out);
 }
 
 int p7x_search_block_wait(p7x_pending *pd)
@@ -875,9 +1146,12 @@ int p7x_search_block_wait(p7x_pending *pd)
   const int st = cascade_collect(pd->run, pd->co);
   if (st != P7X_OK) return st;
   pd->waited = true;
-  pd->co.ms[6] = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - pd->t0).count();   // stage 1 wall
+  const double wall = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - pd->t0).count();   // stage 1 wall
+  for (auto &c : pd->co) c.ms[6] = wall;
   return P7X_OK;
 }
+
+size_t p7x_pending_nqueries(const p7x_pending *pd) { return pd ? pd->run.oms.size() : 0; }
 
 int p7x_search_block_begin(const p7x_pipeline_cfg *cfg, const p7x_oprofile *om, const float *bg_f, const p7x_seqdb *db,
                            p7x_pending **out)
@@ -891,39 +1165,52 @@ int p7x_search_block_begin(const p7x_pipeline_cfg *cfg, const p7x_oprofile *om, 
   return P7X_OK;
 }
 
+int p7x_search_batch_finish(p7x_pending *pd, const char *const *names, const char *const *accs, const char *const *descs,
+                            p7x_tophits **outs)
+{
+  if (!pd || !outs) { set_error("p7x_search_batch_finish: bad arguments"); return P7X_EINVAL; }
+  std::unique_ptr<p7x_pending> owner(pd);                // consumed, also on failure
+  const size_t nq = pd->run.oms.size();
+  for (size_t q = 0; q < nq; ++q) outs[q] = nullptr;
+  if (!pd->waited) { const int wst = p7x_search_block_wait(pd); if (wst != P7X_OK) return wst; }
+  const p7x_seqdb *db = pd->db;
+  HostTargets tg;
+  tg.n = db->n; tg.nres = db->nres; tg.len = db->h_len.data(); tg.off = db->h_off.data(); tg.dsq = db->h_dsq.data();
+  auto fail = [&](int st) { for (size_t q = 0; q < nq; ++q) { delete outs[q]; outs[q] = nullptr; } return st; };
+  for (size_t q = 0; q < nq; ++q) {
+    const auto t1 = std::chrono::steady_clock::now();
+    const p7x_oprofile *om = pd->run.oms[q]; CascadeOut &co = pd->co[q];
+    std::vector<int32_t> targets(co.fin_slots.size());
+    for (size_t i = 0; i < targets.size(); ++i) targets[i] = db->h_order[co.fin_slots[i]];
+    const uint64_t counts[4] = { (uint64_t) co.counts[1], (uint64_t) co.counts[8], (uint64_t) co.counts[3], (uint64_t) co.counts[4] };
+    int st = P7X_OK;
+    std::unique_ptr<EnvelopeScorer> scorer;
+    const bool env_fits = om->p.M <= 1024;        // env_kernel keeps the emission table in LDS; longer models are rescored on the host
+    if (!g_host_envelopes && !pd->cfg.host_envelopes && !targets.empty() && env_fits) {
+      DeviceCtx *ctx = nullptr; DevProfile *dp = nullptr;
+      if ((st = get_ctx(db->device, &ctx)) != P7X_OK || (st = get_dev_profile(om, ctx, &dp)) != P7X_OK) return fail(st);
+      scorer = make_device_envelope_scorer(ctx, dp, db, om->p);
+    }
+    const double stage1 = co.ms[6];
+    DeviceRegions dr;
+    if (!co.have_xmx && !targets.empty()) { dr.n = co.reg_n.data(); dr.regs = co.regs.data(); dr.nexpected = co.nexpected.data(); dr.cap = kRegionCap; }
+    st = host_finish_search(pd->cfg, om, tg, names, accs, descs, targets, co.fwdsc.data(), co.fwd_xmx.data(), co.bck_xmx.data(),
+                            co.xmx_off.data(), counts, co.ms, &outs[q], scorer.get(), dr.n ? &dr : nullptr);
+    if (st != P7X_OK) return fail(st);
+    if (!co.stage.empty()) tophits_set_stages(outs[q], std::move(co.stage));
+    // work time of this search (stage 1 + stage 2), not the time it spent queued between the stages
+    const double stage2 = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t1).count();
+    tophits_set_total_ms(outs[q], stage1, stage2);
+  }
+  return P7X_OK;
+}
+
 int p7x_search_block_finish(p7x_pending *pd, const char *const *names, const char *const *accs, const char *const *descs,
                             p7x_tophits **out)
 {
   if (!pd || !out) { set_error("p7x_search_block_finish: bad arguments"); return P7X_EINVAL; }
-  std::unique_ptr<p7x_pending> owner(pd);                // consumed, also on failure
-  if (!pd->waited) { const int wst = p7x_search_block_wait(pd); if (wst != P7X_OK) return wst; }
-  const auto t1 = std::chrono::steady_clock::now();
-  const p7x_seqdb *db = pd->db; const p7x_oprofile *om = pd->om; CascadeOut &co = pd->co;
-  HostTargets tg;
-  tg.n = db->n; tg.nres = db->nres; tg.len = db->h_len.data(); tg.off = db->h_off.data(); tg.dsq = db->h_dsq.data();
-  std::vector<int32_t> targets(co.fin_slots.size());
-  for (size_t i = 0; i < targets.size(); ++i) targets[i] = db->h_order[co.fin_slots[i]];
-  const uint64_t counts[4] = { (uint64_t) co.counts[1], (uint64_t) co.counts[8], (uint64_t) co.counts[3], (uint64_t) co.counts[4] };
-  int st = P7X_OK;
-  std::unique_ptr<EnvelopeScorer> scorer;
-  const bool env_fits = om->p.M <= 1024;        // env_kernel keeps the emission table in LDS; longer models are rescored on the host
-  if (!g_host_envelopes && !pd->cfg.host_envelopes && !targets.empty() && env_fits) {
-    DeviceCtx *ctx = nullptr; DevProfile *dp = nullptr;
-    if ((st = get_ctx(db->device, &ctx)) != P7X_OK || (st = get_dev_profile(om, ctx, &dp)) != P7X_OK) return st;
-    scorer = make_device_envelope_scorer(ctx, dp, db, om->p);
-  }
-  const double stage1 = co.ms[6];
-  DeviceRegions dr;
-  if (!co.have_xmx && !targets.empty()) { dr.n = co.reg_n.data(); dr.regs = co.regs.data(); dr.nexpected = co.nexpected.data(); dr.cap = kRegionCap; }
-  st = host_finish_search(pd->cfg, om, tg, names, accs, descs, targets, co.fwdsc.data(), co.fwd_xmx.data(), co.bck_xmx.data(),
-                          co.xmx_off.data(), counts, co.ms, out, scorer.get(), dr.n ? &dr : nullptr);
-  if (st == P7X_OK && !co.stage.empty()) tophits_set_stages(*out, std::move(co.stage));
-  if (st == P7X_OK) {
-    // work time of this search (stage 1 + stage 2), not the time it spent queued between the stages
-    const double stage2 = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t1).count();
-    tophits_set_total_ms(*out, stage1, stage2);
-  }
-  return st;
+  if (pd->run.oms.size() != 1) { delete pd; set_error("p7x_search_block_finish: the handle holds a batch (use p7x_search_batch_finish)"); return P7X_EINVAL; }
+  return p7x_search_batch_finish(pd, names, accs, descs, out);
 }
 
 void p7x_pending_destroy(p7x_pending *pd) { delete pd; }

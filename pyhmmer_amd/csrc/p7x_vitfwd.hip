@@ -18,10 +18,13 @@ namespace p7x {
 
 // ======================================================================================= Viterbi filter
 template <int C>
-__global__ void __launch_bounds__(kWsBlock) vit_kernel(const WaveSeqArgs a)
+__global__ void __launch_bounds__(kWsBlock) vit_kernel(const ArgRef ref)
 {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   constexpr int Mpad = 64 * C;
+  const WaveSeqArgs a = load_args<WaveSeqArgs>(ref);
+  const int nlist = (a.abort_flag && *a.abort_flag) ? 0 : (a.nlist_ptr ? *a.nlist_ptr : a.nlist);
+  if ((int) (blockIdx.x * (kWsBlock / 64)) >= nlist) return;         // no item for this block: skip the table load
   uint4 *tr = reinterpret_cast<uint4 *>(smem);                       // [Mpad]
   short *em = reinterpret_cast<short *>(smem + (size_t) Mpad * 16);  // [kTabRows][Mpad]
   {
@@ -34,7 +37,6 @@ __global__ void __launch_bounds__(kWsBlock) vit_kernel(const WaveSeqArgs a)
   __syncthreads();
   const int lane = threadIdx.x & 63;
   const short NEG = (short) -32768;
-  const int nlist = (a.abort_flag && *a.abort_flag) ? 0 : (a.nlist_ptr ? *a.nlist_ptr : a.nlist);
 
   P7X_WAVE_ITEMS(it) {
     const Item item = load_item(a, it);
@@ -114,10 +116,13 @@ __global__ void __launch_bounds__(kWsBlock) vit_kernel(const WaveSeqArgs a)
 // the next row's max(., xB); the 255 clip can only follow a row that already reported overflow).  ~4x the
 // instructions per cell of the fast kernel: a functional fallback, bit-exact (tests/test_gpu_filters.py).
 template <int C>
-__global__ void __launch_bounds__(kWsBlock) msv_wave_kernel(const MsvWaveArgs a)
+__global__ void __launch_bounds__(kWsBlock) msv_wave_kernel(const ArgRef ref)
 {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   constexpr int Mpad = 64 * C;
+  const MsvWaveArgs a = load_args<MsvWaveArgs>(ref);
+  const int nlist = a.nslots;
+  if ((int) (blockIdx.x * (kWsBlock / 64)) >= nlist) return;
   short *em = reinterpret_cast<short *>(smem);                       // [nrows][Mpad] bias - cost, kNegPad outside the model
   {
     const uint4 *ge = reinterpret_cast<const uint4 *>(a.emis);
@@ -126,7 +131,6 @@ __global__ void __launch_bounds__(kWsBlock) msv_wave_kernel(const MsvWaveArgs a)
   }
   __syncthreads();
   const int lane = threadIdx.x & 63;
-  const int nlist = a.nslots;
   P7X_WAVE_ITEMS(it) {
     const int slot = it;
     const int L = rfl(a.slot_len[slot]);
@@ -168,10 +172,13 @@ __global__ void __launch_bounds__(kWsBlock) msv_wave_kernel(const MsvWaveArgs a)
 // EG: the emission table does not fit in LDS next to the transitions (M > 1024) and is read from global memory
 // (it stays L2-resident: 30 rows x Mpad floats).
 template <int C, bool EG = false>
-__global__ void __launch_bounds__(kWsBlock) fwd_kernel(const WaveSeqArgs a)
+__global__ void __launch_bounds__(kWsBlock) fwd_kernel(const ArgRef ref)
 {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   constexpr int Mpad = 64 * C;
+  const WaveSeqArgs a = load_args<WaveSeqArgs>(ref);
+  const int nlist = (a.abort_flag && *a.abort_flag) ? 0 : (a.nlist_ptr ? *a.nlist_ptr : a.nlist);
+  if ((int) (blockIdx.x * (kWsBlock / 64)) >= nlist) return;         // no item for this block: skip the table load
   float4 *tr = reinterpret_cast<float4 *>(smem);                         // [2*Mpad]
   const float *em = EG ? reinterpret_cast<const float *>(a.emis) : reinterpret_cast<const float *>(smem + (size_t) Mpad * 32);      // [kTabRows][Mpad]
   {
@@ -185,7 +192,6 @@ __global__ void __launch_bounds__(kWsBlock) fwd_kernel(const WaveSeqArgs a)
   }
   __syncthreads();
   const int lane = threadIdx.x & 63;
-  const int nlist = (a.abort_flag && *a.abort_flag) ? 0 : (a.nlist_ptr ? *a.nlist_ptr : a.nlist);
 
   P7X_WAVE_ITEMS(it) {
     const Item item = load_item(a, it);
@@ -278,10 +284,13 @@ __global__ void __launch_bounds__(kWsBlock) fwd_kernel(const WaveSeqArgs a)
 // ======================================================================================= Backward parser
 // Mirror of the Forward parser, re-using Forward's per-row scale factors (upstream backward_engine).
 template <int C, bool EG = false>
-__global__ void __launch_bounds__(kWsBlock) bck_kernel(const WaveSeqArgs a)
+__global__ void __launch_bounds__(kWsBlock) bck_kernel(const ArgRef ref)
 {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   constexpr int Mpad = 64 * C;
+  const WaveSeqArgs a = load_args<WaveSeqArgs>(ref);
+  const int nlist = (a.abort_flag && *a.abort_flag) ? 0 : (a.nlist_ptr ? *a.nlist_ptr : a.nlist);
+  if ((int) (blockIdx.x * (kWsBlock / 64)) >= nlist) return;         // no item for this block: skip the table load
   float4 *tr = reinterpret_cast<float4 *>(smem);
   const float *em = EG ? reinterpret_cast<const float *>(a.emis) : reinterpret_cast<const float *>(smem + (size_t) Mpad * 32);
   {
@@ -295,7 +304,6 @@ __global__ void __launch_bounds__(kWsBlock) bck_kernel(const WaveSeqArgs a)
   }
   __syncthreads();
   const int lane = threadIdx.x & 63;
-  const int nlist = (a.abort_flag && *a.abort_flag) ? 0 : (a.nlist_ptr ? *a.nlist_ptr : a.nlist);
 
   P7X_WAVE_ITEMS(it) {
     const Item item = load_item(a, it);
@@ -443,76 +451,100 @@ int vit_pick_C(int M)
   return -1;
 }
 
+// occupancy and the LDS opt-in of one kernel instantiation, looked up once
+struct KernelInfo { std::mutex mu; std::map<const void *, int> per_cu; };
+static KernelInfo &kernel_info() { static KernelInfo *k = new KernelInfo(); return *k; }
 template <typename K>
-static int launch_ws(K kernel, const WaveSeqArgs &a, size_t lds_bytes, int num_cu, hipStream_t st)
+static int blocks_per_cu(K kernel, size_t lds_bytes, int *out)
 {
-  if (!a.nlist_ptr && a.nlist <= 0) return P7X_OK;
+  KernelInfo &ki = kernel_info();
+  std::lock_guard<std::mutex> lk(ki.mu);
+  const void *key = reinterpret_cast<const void *>(kernel);
+  auto it = ki.per_cu.find(key);
+  if (it != ki.per_cu.end()) { *out = it->second; return P7X_OK; }
   if (lds_bytes > 64 * 1024)
-    P7X_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds_bytes));
+    P7X_HIP(hipFuncSetAttribute(key, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds_bytes));
   int per_cu = 0;
   P7X_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, kWsBlock, lds_bytes));
   if (per_cu < 1) per_cu = 1;
-  long grid = (long) num_cu * per_cu, want = ((long) a.nlist + 3) / 4;
-  if (!a.nlist_ptr && grid > want) grid = want;
-  if (grid < 1) grid = 1;
-  hipLaunchKernelGGL(kernel, dim3((unsigned) grid), dim3(kWsBlock), lds_bytes, st, a);
+  ki.per_cu[key] = per_cu;
+  *out = per_cu;
+  return P7X_OK;
+}
+
+template <typename K>
+static int launch_ws(K kernel, const ArgRun<WaveSeqArgs> &a, size_t lds_bytes, int num_cu, hipStream_t st)
+{
+  long want = 0;
+  for (int i = 0; i < a.n; ++i) want = std::max<long>(want, ((long) a.at(i).nlist + 3) / 4);      // nlist bounds the device-side count
+  if (want <= 0) return P7X_OK;
+  int per_cu = 0;
+  const int pst = blocks_per_cu(kernel, lds_bytes, &per_cu);
+  if (pst != P7X_OK) return pst;
+  hipLaunchKernelGGL(kernel, dim3(lane_grid(want, (long) num_cu * per_cu, a.n), (unsigned) a.n), dim3(kWsBlock), lds_bytes, st, a.ref());
   P7X_HIP(hipGetLastError());
   return P7X_OK;
 }
 
 #define P7X_C_SWITCH(KERNEL, BYTES_PER_NODE, EBYTES)                                                        \
-  switch (a.C) {                                                                                            \
-    case 1:  return launch_ws(KERNEL<1>,  a, (size_t) 64 * 1  * (BYTES_PER_NODE + a.nrows * EBYTES), num_cu, st); \
-    case 2:  return launch_ws(KERNEL<2>,  a, (size_t) 64 * 2  * (BYTES_PER_NODE + a.nrows * EBYTES), num_cu, st); \
-    case 3:  return launch_ws(KERNEL<3>,  a, (size_t) 64 * 3  * (BYTES_PER_NODE + a.nrows * EBYTES), num_cu, st); \
-    case 4:  return launch_ws(KERNEL<4>,  a, (size_t) 64 * 4  * (BYTES_PER_NODE + a.nrows * EBYTES), num_cu, st); \
-    case 5:  return launch_ws(KERNEL<5>,  a, (size_t) 64 * 5  * (BYTES_PER_NODE + a.nrows * EBYTES), num_cu, st); \
-    case 6:  return launch_ws(KERNEL<6>,  a, (size_t) 64 * 6  * (BYTES_PER_NODE + a.nrows * EBYTES), num_cu, st); \
-    case 8:  return launch_ws(KERNEL<8>,  a, (size_t) 64 * 8  * (BYTES_PER_NODE + a.nrows * EBYTES), num_cu, st); \
-    case 10: return launch_ws(KERNEL<10>, a, (size_t) 64 * 10 * (BYTES_PER_NODE + a.nrows * EBYTES), num_cu, st); \
-    case 12: return launch_ws(KERNEL<12>, a, (size_t) 64 * 12 * (BYTES_PER_NODE + a.nrows * EBYTES), num_cu, st); \
-    case 16: return launch_ws(KERNEL<16>, a, (size_t) 64 * 16 * (BYTES_PER_NODE + a.nrows * EBYTES), num_cu, st); \
-    case 20: return launch_ws(KERNEL<20>, a, (size_t) 64 * 20 * (BYTES_PER_NODE + a.nrows * EBYTES), num_cu, st); \
-    case 24: return launch_ws(KERNEL<24>, a, (size_t) 64 * 24 * (BYTES_PER_NODE + a.nrows * EBYTES), num_cu, st); \
-    case 32: return launch_ws(KERNEL<32>, a, (size_t) 64 * 32 * (BYTES_PER_NODE + a.nrows * EBYTES), num_cu, st); \
+  switch (C) {                                                                                              \
+    case 1:  return launch_ws(KERNEL<1>,  a, (size_t) 64 * 1  * (BYTES_PER_NODE + nrows * EBYTES), num_cu, st); \
+    case 2:  return launch_ws(KERNEL<2>,  a, (size_t) 64 * 2  * (BYTES_PER_NODE + nrows * EBYTES), num_cu, st); \
+    case 3:  return launch_ws(KERNEL<3>,  a, (size_t) 64 * 3  * (BYTES_PER_NODE + nrows * EBYTES), num_cu, st); \
+    case 4:  return launch_ws(KERNEL<4>,  a, (size_t) 64 * 4  * (BYTES_PER_NODE + nrows * EBYTES), num_cu, st); \
+    case 5:  return launch_ws(KERNEL<5>,  a, (size_t) 64 * 5  * (BYTES_PER_NODE + nrows * EBYTES), num_cu, st); \
+    case 6:  return launch_ws(KERNEL<6>,  a, (size_t) 64 * 6  * (BYTES_PER_NODE + nrows * EBYTES), num_cu, st); \
+    case 8:  return launch_ws(KERNEL<8>,  a, (size_t) 64 * 8  * (BYTES_PER_NODE + nrows * EBYTES), num_cu, st); \
+    case 10: return launch_ws(KERNEL<10>, a, (size_t) 64 * 10 * (BYTES_PER_NODE + nrows * EBYTES), num_cu, st); \
+    case 12: return launch_ws(KERNEL<12>, a, (size_t) 64 * 12 * (BYTES_PER_NODE + nrows * EBYTES), num_cu, st); \
+    case 16: return launch_ws(KERNEL<16>, a, (size_t) 64 * 16 * (BYTES_PER_NODE + nrows * EBYTES), num_cu, st); \
+    case 20: return launch_ws(KERNEL<20>, a, (size_t) 64 * 20 * (BYTES_PER_NODE + nrows * EBYTES), num_cu, st); \
+    case 24: return launch_ws(KERNEL<24>, a, (size_t) 64 * 24 * (BYTES_PER_NODE + nrows * EBYTES), num_cu, st); \
+    case 32: return launch_ws(KERNEL<32>, a, (size_t) 64 * 32 * (BYTES_PER_NODE + nrows * EBYTES), num_cu, st); \
     default: set_error("model too long for the wave-per-sequence kernels"); return P7X_EINVAL;             \
   }
 
-int vit_launch(const WaveSeqArgs &a, int num_cu, hipStream_t st) { P7X_C_SWITCH(vit_kernel, 16, 2) }
+int vit_launch(const ArgRun<WaveSeqArgs> &a, int num_cu, hipStream_t st)
+{
+  if (a.n <= 0) return P7X_OK;
+  const int C = a.at(0).C, nrows = a.at(0).nrows;
+  P7X_C_SWITCH(vit_kernel, 16, 2)
+}
 
 #define P7X_CF_SWITCH(KERNEL)                                                                               \
-  switch (a.C) {                                                                                            \
-    case 1:  return launch_ws(KERNEL<1>,  a, (size_t) 64 * 1  * (32 + a.nrows * 4), num_cu, st);           \
-    case 2:  return launch_ws(KERNEL<2>,  a, (size_t) 64 * 2  * (32 + a.nrows * 4), num_cu, st);           \
-    case 3:  return launch_ws(KERNEL<3>,  a, (size_t) 64 * 3  * (32 + a.nrows * 4), num_cu, st);           \
-    case 4:  return launch_ws(KERNEL<4>,  a, (size_t) 64 * 4  * (32 + a.nrows * 4), num_cu, st);           \
-    case 5:  return launch_ws(KERNEL<5>,  a, (size_t) 64 * 5  * (32 + a.nrows * 4), num_cu, st);           \
-    case 6:  return launch_ws(KERNEL<6>,  a, (size_t) 64 * 6  * (32 + a.nrows * 4), num_cu, st);           \
-    case 8:  return launch_ws(KERNEL<8>,  a, (size_t) 64 * 8  * (32 + a.nrows * 4), num_cu, st);           \
-    case 10: return launch_ws(KERNEL<10>, a, (size_t) 64 * 10 * (32 + a.nrows * 4), num_cu, st);           \
-    case 12: return launch_ws(KERNEL<12>, a, (size_t) 64 * 12 * (32 + a.nrows * 4), num_cu, st);           \
-    case 16: return launch_ws(KERNEL<16>, a, (size_t) 64 * 16 * (32 + a.nrows * 4), num_cu, st);           \
+  switch (C) {                                                                                              \
+    case 1:  return launch_ws(KERNEL<1>,  a, (size_t) 64 * 1  * (32 + nrows * 4), num_cu, st);           \
+    case 2:  return launch_ws(KERNEL<2>,  a, (size_t) 64 * 2  * (32 + nrows * 4), num_cu, st);           \
+    case 3:  return launch_ws(KERNEL<3>,  a, (size_t) 64 * 3  * (32 + nrows * 4), num_cu, st);           \
+    case 4:  return launch_ws(KERNEL<4>,  a, (size_t) 64 * 4  * (32 + nrows * 4), num_cu, st);           \
+    case 5:  return launch_ws(KERNEL<5>,  a, (size_t) 64 * 5  * (32 + nrows * 4), num_cu, st);           \
+    case 6:  return launch_ws(KERNEL<6>,  a, (size_t) 64 * 6  * (32 + nrows * 4), num_cu, st);           \
+    case 8:  return launch_ws(KERNEL<8>,  a, (size_t) 64 * 8  * (32 + nrows * 4), num_cu, st);           \
+    case 10: return launch_ws(KERNEL<10>, a, (size_t) 64 * 10 * (32 + nrows * 4), num_cu, st);           \
+    case 12: return launch_ws(KERNEL<12>, a, (size_t) 64 * 12 * (32 + nrows * 4), num_cu, st);           \
+    case 16: return launch_ws(KERNEL<16>, a, (size_t) 64 * 16 * (32 + nrows * 4), num_cu, st);           \
     case 20: return launch_ws(KERNEL<20, true>, a, (size_t) 64 * 20 * 32, num_cu, st);                     \
     case 24: return launch_ws(KERNEL<24, true>, a, (size_t) 64 * 24 * 32, num_cu, st);                     \
     case 32: return launch_ws(KERNEL<32, true>, a, (size_t) 64 * 32 * 32, num_cu, st);                     \
     default: set_error("model too long for the Forward/Backward kernels (M > 2048)"); return P7X_EINVAL;   \
   }
 
-int msv_wave_launch(const MsvWaveArgs &a, int num_cu, hipStream_t st)
+int msv_wave_launch(const ArgRun<MsvWaveArgs> &a, int num_cu, hipStream_t st)
 {
-  if (a.nslots <= 0) return P7X_OK;
+  long want = 0;
+  for (int i = 0; i < a.n; ++i) want = std::max<long>(want, ((long) a.at(i).nslots + 3) / 4);
+  if (want <= 0) return P7X_OK;
+  const int C = a.at(0).C, nrows = a.at(0).nrows;
   auto go = [&](auto kernel) -> int {
-    const size_t lds = (size_t) 64 * a.C * a.nrows * 2;
-    if (lds > 64 * 1024) P7X_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds));
+    const size_t lds = (size_t) 64 * C * nrows * 2;
     int per_cu = 0;
-    P7X_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, kWsBlock, lds));
-    if (per_cu < 1) per_cu = 1;
-    long grid = std::min<long>((long) num_cu * per_cu, ((long) a.nslots + 3) / 4);
-    hipLaunchKernelGGL(kernel, dim3((unsigned) std::max<long>(grid, 1)), dim3(kWsBlock), lds, st, a);
+    const int pst = blocks_per_cu(kernel, lds, &per_cu);
+    if (pst != P7X_OK) return pst;
+    hipLaunchKernelGGL(kernel, dim3(lane_grid(want, (long) num_cu * per_cu, a.n), (unsigned) a.n), dim3(kWsBlock), lds, st, a.ref());
     P7X_HIP(hipGetLastError());
     return P7X_OK;
   };
-  switch (a.C) {
+  switch (C) {
     case 1:  return go(msv_wave_kernel<1>);
     case 2:  return go(msv_wave_kernel<2>);
     case 3:  return go(msv_wave_kernel<3>);
@@ -530,7 +562,17 @@ int msv_wave_launch(const MsvWaveArgs &a, int num_cu, hipStream_t st)
   }
 }
 
-int fwd_launch(const WaveSeqArgs &a, int num_cu, hipStream_t st) { P7X_CF_SWITCH(fwd_kernel) }
-int bck_launch(const WaveSeqArgs &a, int num_cu, hipStream_t st) { P7X_CF_SWITCH(bck_kernel) }
+int fwd_launch(const ArgRun<WaveSeqArgs> &a, int num_cu, hipStream_t st)
+{
+  if (a.n <= 0) return P7X_OK;
+  const int C = a.at(0).C, nrows = a.at(0).nrows;
+  P7X_CF_SWITCH(fwd_kernel)
+}
+int bck_launch(const ArgRun<WaveSeqArgs> &a, int num_cu, hipStream_t st)
+{
+  if (a.n <= 0) return P7X_OK;
+  const int C = a.at(0).C, nrows = a.at(0).nrows;
+  P7X_CF_SWITCH(bck_kernel)
+}
 
 } // namespace p7x

@@ -17,6 +17,7 @@
 //     stripe shift, passes repeat until nothing improves (two on average).
 // Results are bit-identical to p7x_vitfwd.hip::vit_kernel and to the oracle (tests/test_gpu_filters.py).
 #include "p7x_wave.hpp"
+#include <mutex>
 
 namespace p7x {
 
@@ -130,9 +131,12 @@ __device__ __forceinline__ void vit_row(const VitPkArgs &a, const uint4 *tral, c
 }
 
 template <int T, int P>
-__global__ void __launch_bounds__(256) vitpk_kernel(const VitPkArgs a)
+__global__ void __launch_bounds__(256) vitpk_kernel(const ArgRef ref)
 {
   constexpr int G = 64 / T;                // targets per wavefront
+  const VitPkArgs a = load_args<VitPkArgs>(ref);
+  const int nlist = a.nlist_ptr ? *a.nlist_ptr : a.nlist;
+  if ((int) (blockIdx.x * 4 * G) >= nlist) return;          // no target for this block: skip the table load
   constexpr int PS = (P + 3) & ~3;         // table stride per lane, in pairs
   constexpr int ROWQ = vitpk_rowq(T, P);   // uint4 per emission row (odd: rows of different residues spread over the banks)
   // LDS layouts are lane-minor, so that the 16-byte reads of the T lanes of a group (and of the groups of a
@@ -153,7 +157,6 @@ __global__ void __launch_bounds__(256) vitpk_kernel(const VitPkArgs a)
   const int lane = threadIdx.x & 63;
   const int s = lane % T, g = lane / T;
   const bool first = (s == 0);
-  const int nlist = a.nlist_ptr ? *a.nlist_ptr : a.nlist;
   const int wave0 = rfl((int) (blockIdx.x * 4 + (threadIdx.x >> 6)));
   const int nwaves = (int) gridDim.x * 4;
   const uint4 *tral = tra + s, *trbl = trb + s, *eml = em + s;
@@ -245,21 +248,33 @@ void vitpk_build_tables(const Profile &p, int T, int P, std::vector<uint32_t> &t
 }
 
 template <int T, int P>
-static int launch_pk(const VitPkArgs &a, int num_cu, hipStream_t st)
+static int launch_pk(const ArgRun<VitPkArgs> &a, int num_cu, hipStream_t st)
 {
-  const size_t lds = ((size_t) 2 * P * T + (size_t) a.nrows * vitpk_rowq(T, P)) * 16;
+  const size_t lds = ((size_t) 2 * P * T + (size_t) a.at(0).nrows * vitpk_rowq(T, P)) * 16;
   auto kern = vitpk_kernel<T, P>;
-  if (lds > 64 * 1024) P7X_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds));
+  static int per_cu_cached = 0;
+  static std::mutex mu;
   int per_cu = 0;
-  P7X_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, 256, lds));
-  if (per_cu < 1) per_cu = 1;
-  hipLaunchKernelGGL(kern, dim3((unsigned) (num_cu * per_cu)), dim3(256), lds, st, a);
+  {
+    std::lock_guard<std::mutex> lk(mu);
+    if (per_cu_cached == 0) {
+      if (lds > 64 * 1024) P7X_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds));
+      P7X_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu_cached, kern, 256, lds));
+      if (per_cu_cached < 1) per_cu_cached = 1;
+    }
+    per_cu = per_cu_cached;
+  }
+  long want = 0;
+  for (int i = 0; i < a.n; ++i) want = std::max<long>(want, ((long) a.at(i).nlist + 4 * (64 / T) - 1) / (4 * (64 / T)));   // nlist bounds the list
+  if (want <= 0) return P7X_OK;
+  hipLaunchKernelGGL(kern, dim3(lane_grid(want, (long) num_cu * per_cu, a.n), (unsigned) a.n), dim3(256), lds, st, a.ref());
   P7X_HIP(hipGetLastError());
   return P7X_OK;
 }
 
-int vitpk_launch(int T, int P, const VitPkArgs &a, int num_cu, hipStream_t st)
+int vitpk_launch(int T, int P, const ArgRun<VitPkArgs> &a, int num_cu, hipStream_t st)
 {
+  if (a.n <= 0) return P7X_OK;
 #define P7X_PK(TT, PP) if (T == TT && P == PP) return launch_pk<TT, PP>(a, num_cu, st);
   P7X_PK(8, 2) P7X_PK(8, 4) P7X_PK(8, 6) P7X_PK(8, 8) P7X_PK(8, 10) P7X_PK(8, 12) P7X_PK(8, 14) P7X_PK(8, 15) P7X_PK(8, 16)
   P7X_PK(8, 17) P7X_PK(8, 18) P7X_PK(8, 19) P7X_PK(8, 20)

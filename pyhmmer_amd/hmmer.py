@@ -64,52 +64,56 @@ class ShardedDatabase:
         self.shards = [database]
         return self
 
-    def _on_shards(self, fn) -> list:
-        """fn(i) for every shard, concurrently when there are several; the first exception is re-raised."""
-        n = len(self.shards)
-        if n == 1:
-            return [fn(0)]
-        results: list = [None] * n
-        errors: List[BaseException] = []
-
-        def work(i: int):
-            try:
-                results[i] = fn(i)
-            except BaseException as e:      # forwarded to the caller like _base.py:305-318
-                errors.append(e)
-
-        threads = [threading.Thread(target=work, args=(i,)) for i in range(n)]
-        for t in threads:
-            t.start()
-        for t in threads:
-            t.join()
-        if errors:
-            raise errors[0]
-        return results
-
-    def begin(self, pipelines: Sequence[Pipeline], query) -> list:
-        """Stage 1 (device filters + parsers) of ``query`` on every shard."""
-        return self._on_shards(lambda i: pipelines[i]._search_begin(query, self.shards[i]))
-
-    def enqueue(self, pipelines: Sequence[Pipeline], query) -> list:
-        """Queue stage 1 of ``query`` without waiting for it (one shard: the calling thread keeps several queries in
-        flight and must also call `wait`; several shards: the shards already run side by side, so this is `begin`)."""
-        if len(self.shards) == 1:
-            return [pipelines[0]._search_enqueue(query, self.shards[0])]
-        return self.begin(pipelines, query)
+    # A "pending" search is a list with one entry per shard: the (handle, profiles, database, labels) tuple of
+    # Pipeline._search_enqueue_batch.  Stage 1 is asynchronous on every device (own stream per search), so one host
+    # thread queues a batch of queries on all shards before it waits for any of them: the shards run side by side
+    # without per-query threads, and the query pipeline of hmmsearch keeps its depth with any number of shards.
+    def enqueue(self, pipelines: Sequence[Pipeline], queries) -> list:
+        """Queue stage 1 (device filters + parsers) of a batch of queries on every shard, without waiting."""
+        pendings: list = []
+        try:
+            for i, shard in enumerate(self.shards):
+                pendings.append(pipelines[i]._search_enqueue_batch(queries, shard))
+        except BaseException:
+            self.abandon(pendings)
+            raise
+        return pendings
 
     def wait(self, pendings: list) -> None:
-        if len(self.shards) == 1:
-            Pipeline._search_wait(pendings[0])
+        for pend in pendings:
+            Pipeline._search_wait(pend)
 
-    def finish(self, pendings: list) -> TopHits:
-        """Stage 2 (domain definition, hit lists) on every shard, then the merge."""
-        results = self._on_shards(lambda i: Pipeline._search_finish(pendings[i]))
-        hits = results[0]
-        return hits if len(results) == 1 else hits.merge(*results[1:])
+    @staticmethod
+    def abandon(pendings) -> None:
+        """Release the device side of searches that will not be finished (a failure on another shard, an abandoned
+        iterator): every handle is destroyed exactly once."""
+        for pend in pendings or ():
+            _lib.lib().p7x_pending_destroy(pend[0])
 
-    def search(self, pipelines: Sequence[Pipeline], query) -> TopHits:
-        return self.finish(self.begin(pipelines, query))
+    def finish(self, pendings: list) -> List[TopHits]:
+        """Stage 2 (domain definition, hit lists) on every shard, then the per-query merge (``TopHits.merge``:
+        concatenate, sum the counters and ``Z``, re-threshold, re-sort -- reference ``_hmmsearch.py:259-263``)."""
+        per_shard: list = []
+        todo = list(pendings)
+        try:
+            while todo:
+                pend = todo.pop(0)                      # finish consumes the handle, also when it fails
+                per_shard.append(Pipeline._search_finish_batch(pend))
+        except BaseException:
+            self.abandon(todo)
+            raise
+        if len(per_shard) == 1:
+            return per_shard[0]
+        return [hits[0].merge(*hits[1:]) for hits in zip(*per_shard)]
+
+    def search(self, pipelines: Sequence[Pipeline], queries) -> List[TopHits]:
+        pendings = self.enqueue(pipelines, queries)
+        try:
+            self.wait(pendings)
+        except BaseException:
+            self.abandon(pendings)
+            raise
+        return self.finish(pendings)
 
 
 def hmmpress(hmms: Iterable, output) -> int:
@@ -131,8 +135,18 @@ def hmmpress(hmms: Iterable, output) -> int:
 
 def hmmsearch(queries: Union[HMM, Profile, OptimizedProfile, Iterable], sequences, *, cpus: int = 0,
               callback: Optional[Callable] = None, devices: Optional[Sequence[int]] = None,
-              pipeline_depth: int = 4, feeders: int = 2, **options) -> Iterator[TopHits]:
+              pipeline_depth: int = 4, feeders: int = 2, batch: int = 0,
+              backend: Optional[str] = None, parallel: Optional[str] = None, builder=None, timeout: Optional[float] = None,
+              **options) -> Iterator[TopHits]:
     """Search HMMs against a sequence database; yields one ``TopHits`` per query, in query order.
+
+    ``batch`` queries share one set of device launches (``p7x_search_batch_enqueue``: every kernel of the cascade
+    serves all of them); 0 picks a size from the amount of work one query is (a query that fills the device for
+    milliseconds runs alone, Pfam-sized models against a proteome run 64 at a time).  The reference's ``backend``,
+    ``parallel`` ("queries" / "targets"), ``builder`` and ``timeout`` keywords (``_hmmsearch.py:294-436``) are accepted:
+    the first two choose between host worker models that have no counterpart here (the device path always shards
+    targets), ``builder`` only applies to sequence / MSA queries, which this path does not build HMMs from, and a
+    search cannot time out waiting for workers.
 
     ``devices`` lists the HIP devices to shard the targets over (default: device 0).  ``cpus`` is accepted for
     signature compatibility and sets the number of host threads used for domain definition.  All other keyword
@@ -144,6 +158,10 @@ def hmmsearch(queries: Union[HMM, Profile, OptimizedProfile, Iterable], sequence
     caller's thread.  ``pipeline_depth=0`` runs the two stages of every query back to back.
     ``sequences`` may also be a :class:`~pyhmmer_amd.plan7.SequenceDatabase` already resident on one device.
     """
+    if backend not in (None, "threading", "multiprocessing"):
+        raise ValueError(f"invalid value for `backend`: {backend!r}")           # _base.py: the reference's own check
+    if parallel not in (None, "queries", "targets"):
+        raise ValueError(f"invalid value for `parallel`: {parallel!r}")
     if isinstance(queries, (HMM, Profile, OptimizedProfile)):
         queries = (queries,)
     if isinstance(sequences, SequenceFile):
@@ -169,23 +187,52 @@ def hmmsearch(queries: Union[HMM, Profile, OptimizedProfile, Iterable], sequence
         total = len(queries)          # type: ignore[arg-type]
     except TypeError:
         pass
-    for q, hits in _run_queries(db, pipelines, queries, pipeline_depth, feeders):
+    for q, hits in _run_queries(db, pipelines, queries, pipeline_depth, feeders, batch=batch):
         if callback is not None:
             callback(q, total)
         yield hits
 
 
+def _auto_batch(db: "ShardedDatabase", M_hint: int = 150) -> int:
+    """Queries per device batch: enough (profile, target) cells per launch set to amortise its fixed cost (a dozen
+    launches, one event wait), few enough that a batch stays a few milliseconds of device time."""
+    res = max(1, max(int(_lib.lib().p7x_seqdb_nresidues(sh._handle)) for sh in db.shards))
+    cells = float(res) * M_hint                       # one query, one shard
+    return int(max(1, min(64, 6e10 // cells)))        # ~2-3 ms of MSV per batch
+
+
+def _batches(queries: Iterable, size: int) -> Iterator[list]:
+    cur: list = []
+    for q in queries:
+        cur.append(q)
+        if len(cur) >= size:
+            yield cur
+            cur = []
+    if cur:
+        yield cur
+
+
 def _run_queries(db: "ShardedDatabase", pipelines: Sequence[Pipeline], queries: Iterable, pipeline_depth: int,
+                 feeders: int, window: int = 1, finishers: int = 0, batch: int = 1) -> Iterator:
+    """Yield ``(query, TopHits)`` for every query, in order.  Queries travel in batches of ``batch`` (one set of
+    device launches each); the two stages of consecutive batches overlap.  ``window`` > 1: every feeder queues the
+    device stage of that many batches before it waits for the oldest."""
+    if batch <= 0:
+        batch = _auto_batch(db)
+    for qs, hits in _run_batches(db, pipelines, _batches(queries, batch), pipeline_depth, feeders, window, finishers):
+        yield from zip(qs, hits)
+
+
+def _run_batches(db: "ShardedDatabase", pipelines: Sequence[Pipeline], queries: Iterable, pipeline_depth: int,
                  feeders: int, window: int = 1, finishers: int = 0) -> Iterator:
-    """Yield ``(query, TopHits)`` for every query, in order, overlapping the two stages of consecutive queries.
-    ``window`` > 1: every feeder queues the device stage of that many queries before it waits for the oldest."""
+    """``queries`` yields lists of queries; yields ``(list, [TopHits])`` in order."""
     if pipeline_depth <= 0:
         for q in queries:
             yield q, db.search(pipelines, q)
         return
 
-    # two-stage software pipeline over the queries.  Feeder threads (each with its own device stream) run the
-    # device stage ahead of the host stage; results are handed over in query order, at most pipeline_depth of them
+    # two-stage software pipeline over the batches.  Feeder threads (each with its own device stream) run the
+    # device stage ahead of the host stage; results are handed over in order, at most pipeline_depth of them
     # staged or in flight at any time.
     nfeed = max(1, min(feeders, pipeline_depth))
     lock = threading.Lock()
@@ -193,11 +240,11 @@ def _run_queries(db: "ShardedDatabase", pipelines: Sequence[Pipeline], queries: 
     slots = threading.Semaphore(pipeline_depth)
     stop = threading.Event()
     qiter = enumerate(queries)
-    staged: dict = {}                 # index -> (query, pendings, error)
+    staged: dict = {}                 # index -> (batch, pendings, error)
     state = {"issued": 0, "exhausted": False, "live": nfeed}
 
     def feeder():
-        queued: "deque" = deque()         # (idx, query, pendings, error): device work queued by this thread, not yet waited for
+        queued: "deque" = deque()         # (idx, batch, pendings, error): device work queued by this thread, not yet waited for
 
         def hand_over_oldest():
             idx, q, pendings, err = queued.popleft()
@@ -206,8 +253,7 @@ def _run_queries(db: "ShardedDatabase", pipelines: Sequence[Pipeline], queries: 
                     db.wait(pendings)
                 except BaseException as e:          # forwarded to the caller like _base.py:305-318
                     err = e
-                    for pend in pendings:
-                        _lib.lib().p7x_pending_destroy(pend[0])
+                    db.abandon(pendings)
                     pendings = None
             with lock:
                 staged[idx] = (q, pendings, err)
@@ -248,8 +294,7 @@ def _run_queries(db: "ShardedDatabase", pipelines: Sequence[Pipeline], queries: 
             while queued:
                 if stop.is_set():                   # abandoned: release what was queued
                     idx, q, pendings, err = queued.popleft()
-                    for pend in pendings or ():
-                        _lib.lib().p7x_pending_destroy(pend[0])
+                    db.abandon(pendings)
                 else:
                     hand_over_oldest()
             with lock:
@@ -260,8 +305,8 @@ def _run_queries(db: "ShardedDatabase", pipelines: Sequence[Pipeline], queries: 
     for t in threads:
         t.start()
     nxt = 0
-    # the host stage of several queries may be in flight as well (each waits for its own envelope kernel): with one
-    # feeder it runs in the caller's thread, with more a small pool finishes queries concurrently, results in order
+    # the host stage of several batches may be in flight as well (each waits for its own envelope kernel): with one
+    # feeder it runs in the caller's thread, with more a small pool finishes batches concurrently, results in order
     nfin = finishers if finishers > 0 else nfeed
     pool = ThreadPoolExecutor(max_workers=nfin, thread_name_prefix="p7x-hmmsearch-finish") if nfin > 1 else None
     inflight: "deque" = deque()
@@ -277,7 +322,7 @@ def _run_queries(db: "ShardedDatabase", pipelines: Sequence[Pipeline], queries: 
                 q, pendings, err = item
                 nxt += 1
                 slots.release()
-                if err is not None:            # surfaces at the failing query's position: first the results before it
+                if err is not None:            # surfaces at the failing batch's position: first the results before it
                     while inflight:
                         q0, fut = inflight.popleft()
                         yield q0, fut.result()
@@ -307,13 +352,12 @@ def _run_queries(db: "ShardedDatabase", pipelines: Sequence[Pipeline], queries: 
         for t in threads:
             t.join()
         for _, pendings, _ in staged.values():
-            if pendings:
-                for pend in pendings:
-                    _lib.lib().p7x_pending_destroy(pend[0])
+            db.abandon(pendings)
 
 
 def hmmscan(queries, profiles, *, cpus: int = 0, callback: Optional[Callable] = None, devices: Optional[Sequence[int]] = None,
-            pipeline_depth: int = 32, feeders: int = 4, window: int = 4, finishers: int = 0, **options) -> Iterator[TopHits]:
+            pipeline_depth: int = 6, feeders: int = 2, window: int = 2, finishers: int = 0, batch: int = 64,
+            backend: Optional[str] = None, **options) -> Iterator[TopHits]:
     """Scan query sequences against a profile database; yields one ``TopHits`` per query sequence, in query order, whose
     hits are the profiles (reference ``hmmer/_hmmscan.py:90-231``, ``Pipeline.scan_seq`` ``plan7.pyx:6534-6622``).
 
@@ -353,7 +397,7 @@ def hmmscan(queries, profiles, *, cpus: int = 0, callback: Optional[Callable] = 
     pipelines = [Pipeline(alphabet, device=d, host_threads=cpus, **options) for d in devs]
     for p in pipelines:
         p._mode = _P7X_SCAN_MODELS
-    per_model = [hits for _, hits in _run_queries(db, pipelines, profiles, pipeline_depth, feeders, window, finishers)]
+    per_model = [hits for _, hits in _run_queries(db, pipelines, profiles, pipeline_depth, feeders, window, finishers, batch=batch)]
     n = len(queries)
     out = (C.c_void_p * n)()
     shard = db.shards[0]

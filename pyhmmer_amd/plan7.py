@@ -10,6 +10,7 @@ from __future__ import annotations
 import ctypes as C
 import math
 import os
+import sys
 from typing import Iterable, Iterator, List, Optional, Union
 
 import numpy as np
@@ -21,7 +22,7 @@ from .errors import (AlphabetMismatch, AllocationError, InvalidParameter, Missin
                      UnexpectedError, status_to_exception)
 
 __all__ = [
-    "HMM", "HMMFile", "Background", "Profile", "OptimizedProfile", "EvalueParameters", "Cutoffs",
+    "HMM", "HMMFile", "HMMPressedFile", "Background", "Profile", "OptimizedProfile", "OptimizedProfileBlock", "EvalueParameters", "Cutoffs",
     "Pipeline", "SequenceDatabase", "TopHits", "Hit", "Domain", "Domains", "Alignment",
 ]
 
@@ -560,6 +561,89 @@ class OptimizedProfile:
 
 
 _P7X_SEARCH_SEQS, _P7X_SCAN_MODELS = 0, 1      # p7x.h / p7_pipeline.pxd:26-28
+
+
+class OptimizedProfileBlock:
+    """A container of `OptimizedProfile` objects for the scan loop (reference ``plan7.pyx:5072-5338``: a Python list
+    kept in step with a C array of ``P7_OPROFILE*`` plus one lock per profile, because ``_scan_loop`` mutates the
+    length model of every profile it visits).  Here the profiles are never mutated by a search -- the length model
+    is a per-target table lookup on the device -- so the block is a typed list; ``Pipeline.scan_seq`` and
+    ``hmmer.hmmscan`` hand its members to the device in batches (``p7x_search_batch_enqueue``) and a block whose
+    profiles have been searched once keeps their device images resident in HBM."""
+
+    def __init__(self, alphabet: Alphabet, iterable=()):
+        self.alphabet = alphabet
+        self._storage: List[OptimizedProfile] = []
+        self.extend(iterable)
+
+    def _check(self, om) -> "OptimizedProfile":
+        if not isinstance(om, OptimizedProfile):
+            raise TypeError(f"Expected OptimizedProfile, found {type(om).__name__}")
+        if om.alphabet != self.alphabet:
+            raise AlphabetMismatch(self.alphabet, om.alphabet)
+        return om
+
+    def __len__(self) -> int:
+        return len(self._storage)
+
+    def __contains__(self, item) -> bool:
+        return isinstance(item, OptimizedProfile) and any(item is om for om in self._storage)
+
+    def __getitem__(self, index):
+        if isinstance(index, slice):
+            return OptimizedProfileBlock(self.alphabet, self._storage[index])
+        return self._storage[index]
+
+    def __setitem__(self, index, value) -> None:
+        if isinstance(index, slice):
+            self._storage[index] = [self._check(om) for om in value]
+        else:
+            self._storage[index] = self._check(value)
+
+    def __delitem__(self, index) -> None:
+        del self._storage[index]
+
+    def __iter__(self):
+        return iter(self._storage)
+
+    def __eq__(self, other) -> bool:
+        if not isinstance(other, OptimizedProfileBlock):
+            return NotImplemented
+        return self.alphabet == other.alphabet and len(self) == len(other) and all(a is b for a, b in zip(self, other))
+
+    def __repr__(self) -> str:
+        return f"{type(self).__name__}({self.alphabet!r}, {self._storage!r})"
+
+    def __copy__(self) -> "OptimizedProfileBlock":
+        return self.copy()
+
+    def append(self, optimized_profile) -> None:
+        self._storage.append(self._check(optimized_profile))
+
+    def clear(self) -> None:
+        self._storage.clear()
+
+    def extend(self, iterable) -> None:
+        for om in iterable:
+            self.append(om)
+
+    def index(self, optimized_profile, start: int = 0, stop: int = sys.maxsize) -> int:
+        for i in range(*slice(start, stop).indices(len(self._storage))):
+            if self._storage[i] is optimized_profile:
+                return i
+        raise ValueError(f"{optimized_profile!r} is not in block")
+
+    def insert(self, index: int, optimized_profile) -> None:
+        self._storage.insert(index, self._check(optimized_profile))
+
+    def pop(self, index: int = -1) -> "OptimizedProfile":
+        return self._storage.pop(index)
+
+    def remove(self, optimized_profile) -> None:
+        del self._storage[self.index(optimized_profile)]
+
+    def copy(self) -> "OptimizedProfileBlock":
+        return OptimizedProfileBlock(self.alphabet, self._storage)
 
 
 class HMMPressedFile:
@@ -1302,27 +1386,40 @@ class Pipeline:
                     background=self.background)
         return next(iter(hmmscan(query, optimized_profiles, cpus=self.host_threads, devices=[self.device], **opts)))
 
-    # -- the two stages of a search (``p7x_search_block_begin`` / ``_finish``).  ``hmmer.hmmsearch`` runs stage 1
-    #    of the next query while stage 2 of the previous one is still busy on the host.
-    def _search_begin(self, query, database: "SequenceDatabase", label=None, _entry="p7x_search_block_begin"):
-        if query.alphabet != self.alphabet:
-            raise AlphabetMismatch(self.alphabet, query.alphabet)
-        om = self._get_om_from_query(query, self.L_HINT)
+    # -- the two stages of a search.  ``hmmer.hmmsearch`` runs stage 1 (device filters + parsers, ``p7x_search_batch_enqueue``
+    #    / ``p7x_search_block_wait``) of the next queries while stage 2 (domain definition, ``p7x_search_batch_finish``) of the
+    #    previous ones is still busy on the host.  A pending search is the tuple (handle, profiles, database, labels) of a
+    #    BATCH of queries that share one set of device launches; a single query is a batch of one.  Both halves of
+    #    stage 1 must run on the same thread.
+    def _search_enqueue_batch(self, queries, database: "SequenceDatabase", labels=None):
+        oms = []
+        for q in queries:
+            if q.alphabet != self.alphabet:
+                raise AlphabetMismatch(self.alphabet, q.alphabet)
+            oms.append(self._get_om_from_query(q, self.L_HINT))
         cfg = self._cfg()
         pend = C.c_void_p()
         bgf = np.ascontiguousarray(self.background.residue_frequencies, dtype=np.float32)
-        st = getattr(_lib.lib(), _entry)(C.byref(cfg), om._handle, bgf.ctypes.data, database._handle, C.byref(pend))
-        if st == 11 and self.bit_cutoffs is not None:
-            raise MissingCutoffs(om.name, self.bit_cutoffs)       # plan7.pyx:6424-6425
+        handles = (C.c_void_p * len(oms))(*[om._handle for om in oms])
+        st = _lib.lib().p7x_search_batch_enqueue(C.byref(cfg), handles, len(oms), bgf.ctypes.data, database._handle, C.byref(pend))
+        if st == 11 and self.bit_cutoffs is not None and "cutoffs" in _lib.last_error():
+            missing = next((om for om in oms if not getattr(om.cutoffs, self.bit_cutoffs + "_available")()), oms[0])
+            raise MissingCutoffs(missing.name, self.bit_cutoffs)       # plan7.pyx:6424-6425
         if st != 0:
-            raise status_to_exception(st, _entry, _lib.last_error())
-        return (pend, om, database, label if label is not None else query)
+            raise status_to_exception(st, "p7x_search_batch_enqueue", _lib.last_error())
+        return (pend, oms, database, list(labels) if labels is not None else list(queries))
 
-    # stage 1 in two halves (``p7x_search_block_enqueue`` / ``_wait``): a thread queues the device work of several
-    # queries before it waits for the first (``hmmer.hmmscan`` keeps a window of models in flight this way).  Both
-    # halves of one search must run on the same thread.
     def _search_enqueue(self, query, database: "SequenceDatabase", label=None):
-        return self._search_begin(query, database, label, _entry="p7x_search_block_enqueue")
+        return self._search_enqueue_batch([query], database, None if label is None else [label])
+
+    def _search_begin(self, query, database: "SequenceDatabase", label=None):
+        pending = self._search_enqueue(query, database, label)
+        try:
+            self._search_wait(pending)
+        except BaseException:
+            _lib.lib().p7x_pending_destroy(pending[0])
+            raise
+        return pending
 
     @staticmethod
     def _search_wait(pending) -> None:
@@ -1331,15 +1428,22 @@ class Pipeline:
             raise status_to_exception(st, "p7x_search_block_wait", _lib.last_error())
 
     @staticmethod
-    def _search_finish(pending) -> TopHits:
-        pend, om, database, label = pending
-        out = C.c_void_p()
-        st = _lib.lib().p7x_search_block_finish(pend, database._names, database._accs, database._descs, C.byref(out))
+    def _search_finish_batch(pending) -> List["TopHits"]:
+        pend, oms, database, labels = pending
+        outs = (C.c_void_p * len(oms))()
+        st = _lib.lib().p7x_search_batch_finish(pend, database._names, database._accs, database._descs, outs)
         if st != 0:
-            raise status_to_exception(st, "p7x_search_block_finish", _lib.last_error())
-        hits = TopHits(label, out)
-        hits._om = om                   # the alignments refer to the profile: keep it alive with the hits
-        return hits
+            raise status_to_exception(st, "p7x_search_batch_finish", _lib.last_error())
+        res = []
+        for om, label, h in zip(oms, labels, outs):
+            hits = TopHits(label, C.c_void_p(h))
+            hits._om = om                   # the alignments refer to the profile: keep it alive with the hits
+            res.append(hits)
+        return res
+
+    @staticmethod
+    def _search_finish(pending) -> TopHits:
+        return Pipeline._search_finish_batch(pending)[0]
 
     def _search_database(self, query, database: "SequenceDatabase", label=None) -> TopHits:
         om = self._get_om_from_query(query, self.L_HINT)

@@ -310,3 +310,73 @@ def test_one_thread_keeps_several_searches_in_flight(models, proteome):
     for feeders, depth, window in ((1, 64, 64), (3, 5, 2), (2, 2, 8)):
         res = [[(h.name, round(h.score, 3)) for h in th] for th in hmmer.hmmscan(seqs, models["RREFam"], feeders=feeders, pipeline_depth=depth, window=window)]
         assert res == ref
+
+
+def _hit_fields(hits):
+    return [(h.name, h.score, h.pre_score, h.sum_score, h.evalue, h.reported, h.included, len(h.domains),
+             [(d.env_from, d.env_to, d.score, d.alignment.hmm_from, d.alignment.hmm_to, d.alignment.target_from, d.alignment.target_to)
+              for d in h.domains]) for h in hits]
+
+
+def test_batched_search_equals_single_searches(models, proteome):
+    """p7x_search_batch_enqueue / _finish: 16 fixture models of 27 ... 430 nodes (several instantiations of every
+    kernel family in one launch set, lanes sorted by length inside the library) give the hit lists, domains, stage
+    counts and accounting of 16 separate searches (both kernel families: the autouse fixture above)."""
+    db = plan7.SequenceDatabase(proteome)
+    pli = plan7.Pipeline(proteome.alphabet)
+    qs = models["KR"] + models["RREFam"] + models["PF02826"] + models["Thioesterase"] + models["LuxC"] + models["RREFam"][:2]
+    want = [pli.search_hmm(q, db) for q in qs]
+    pend = pli._search_enqueue_batch(qs, db)
+    plan7.Pipeline._search_wait(pend)
+    got = plan7.Pipeline._search_finish_batch(pend)
+    assert len(got) == len(qs)
+    for q, a, b in zip(qs, got, want):
+        assert a.query is q
+        assert a.stage_counts == b.stage_counts, q.name
+        assert (a.Z, a.domZ, a.searched_sequences, a.searched_residues, a.searched_nodes) == \
+               (b.Z, b.domZ, b.searched_sequences, b.searched_residues, b.searched_nodes)
+        assert _hit_fields(a) == _hit_fields(b), q.name
+    assert sum(len(h) for h in got) > 30
+    # through the public entry point, every batch size from "one at a time" to "all in one"
+    for batch in (1, 3, 64):
+        res = list(hmmer.hmmsearch(qs, db, batch=batch))
+        assert [_hit_fields(a) for a in res] == [_hit_fields(b) for b in want], batch
+    # an un-waited batch can be dropped; a failing member (no gathering cutoffs) fails the batch before anything is queued
+    from pyhmmer_amd import _lib
+    _lib.lib().p7x_pending_destroy(pli._search_enqueue_batch(qs[:3], db)[0])
+    with pytest.raises(errors.MissingCutoffs):
+        plan7.Pipeline(proteome.alphabet, bit_cutoffs="gathering")._search_enqueue_batch(qs, db)
+
+
+def test_batched_search_more_survivors_than_the_shared_buffers(models, proteome):
+    """With the filters switched off (F1 = F2 = F3 = 1) every target of every lane reaches Backward: the lanes' rows
+    do not fit the shared arena and the per-lane retry path has to produce the same lists as separate searches."""
+    db = plan7.SequenceDatabase(proteome)
+    pli = plan7.Pipeline(proteome.alphabet, F1=1.0, F2=1.0, F3=1.0, bias_filter=False)
+    qs = models["RREFam"][:3] + models["PF02826"]
+    want = [pli.search_hmm(q, db) for q in qs]
+    pend = pli._search_enqueue_batch(qs, db)
+    got = plan7.Pipeline._search_finish_batch(pend)           # finish waits when the caller did not
+    for q, a, b in zip(qs, got, want):
+        assert a.stage_counts == b.stage_counts and a.stage_counts["fwd"] == len(proteome), q.name
+        assert _hit_fields(a) == _hit_fields(b), q.name
+
+
+def test_optimized_profile_block_scan(models, proteome):
+    """reference tests/test_plan7/test_pipeline.py:229-240 (scan_seq over an OptimizedProfileBlock) and the container
+    protocol of plan7.pyx:5121-5338."""
+    bg = plan7.Background(proteome.alphabet)
+    oms = [plan7.OptimizedProfile(h, bg) for h in models["RREFam"]]
+    block = plan7.OptimizedProfileBlock(proteome.alphabet, oms)
+    assert len(block) == 10 and block[3] is oms[3] and oms[4] in block and block.index(oms[4]) == 4
+    assert len(block[2:5]) == 3 and block.copy() == block
+    block.append(block.pop())
+    with pytest.raises(TypeError):
+        block.append(models["RREFam"][0])
+    with pytest.raises(errors.AlphabetMismatch):
+        plan7.OptimizedProfileBlock(easel.Alphabet.dna(), oms)
+    seq = next(s for s in proteome if s.name == "938293.PRJEB85.HG003691_78")
+    pli = plan7.Pipeline(proteome.alphabet)
+    hits = pli.scan_seq(seq, block)
+    ref = list(hmmer.hmmscan([seq], models["RREFam"], batch=1))[0]
+    assert len(hits) >= 1 and _hit_fields(hits) == _hit_fields(ref) and hits.mode == "scan"

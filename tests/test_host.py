@@ -230,42 +230,45 @@ def test_native_fasta_reader_equals_python_reader(tmp_path):
 
 
 class _FakeShards:
-    """Stands in for hmmer.ShardedDatabase in the query pipeline: stage 1 'runs' for a random time after enqueue."""
+    """Stands in for hmmer.ShardedDatabase in the query pipeline: stage 1 of a batch of queries 'runs' for a random time
+    after enqueue.  A batch fails when it contains a failing query."""
 
     def __init__(self, seed, fail_at=(), fail_in="enqueue"):
         import random
         self.rnd = random.Random(seed)
         self.fail_at, self.fail_in = set(fail_at), fail_in
-        self.destroyed = []
+        self.abandoned = []
 
-    def enqueue(self, pipelines, q):
-        if q in self.fail_at and self.fail_in == "enqueue":
-            raise ValueError(f"query {q}")
+    def _check(self, qs, where):
+        bad = [q for q in qs if q in self.fail_at]
+        if bad and self.fail_in == where:
+            raise ValueError(f"query {bad[0]}")
+
+    def enqueue(self, pipelines, qs):
+        self._check(qs, "enqueue")
         import time
-        return [("pend", q, time.perf_counter() + self.rnd.random() * 0.004)]
+        return [("pend", list(qs), time.perf_counter() + self.rnd.random() * 0.004)]
 
     def wait(self, pendings):
         import time
-        _, q, due = pendings[0]
+        _, qs, due = pendings[0]
         while time.perf_counter() < due:
             time.sleep(0.0002)
-        if q in self.fail_at and self.fail_in == "wait":
-            raise ValueError(f"query {q}")
+        self._check(qs, "wait")
 
-    def begin(self, pipelines, q):
-        p = self.enqueue(pipelines, q)
-        self.wait(p)
-        return p
+    def abandon(self, pendings):
+        self.abandoned.extend(pendings or ())
 
     def finish(self, pendings):
         import time
         time.sleep(self.rnd.random() * 0.002)
-        if pendings[0][1] in self.fail_at and self.fail_in == "finish":
-            raise ValueError(f"query {pendings[0][1]}")
-        return ("hits", pendings[0][1])
+        self._check(pendings[0][1], "finish")
+        return [("hits", q) for q in pendings[0][1]]
 
-    def search(self, pipelines, q):
-        return self.finish(self.begin(pipelines, q))
+    def search(self, pipelines, qs):
+        p = self.enqueue(pipelines, qs)
+        self.wait(p)
+        return self.finish(p)
 
 
 @pytest.mark.timeout(120)
@@ -274,25 +277,24 @@ def test_query_pipeline_orders_results_and_errors_for_every_shape(libp7x, monkey
     device: results in query order, an error surfaces at its query's position after the results before it, an
     abandoned generator leaves no thread behind -- for many feeder / depth / window / finisher combinations."""
     import threading
-    from pyhmmer_amd import hmmer, _lib
-    monkeypatch.setattr(_lib.lib(), "p7x_pending_destroy", lambda *_: None, raising=False)
+    from pyhmmer_amd import hmmer
     before = threading.active_count()
     shapes = [(0, 1, 1, 0), (1, 1, 1, 0), (2, 1, 1, 0), (4, 2, 1, 0), (8, 4, 1, 0), (8, 1, 8, 0), (32, 2, 8, 0), (5, 3, 2, 0),
               (2, 2, 8, 4), (64, 4, 4, 8), (3, 8, 64, 2)]
     for seed, (depth, feeders, window, fin) in enumerate(shapes):
+        batch = (1, 3, 8)[seed % 3]             # queries per device batch
         for n in (0, 1, 7, 40):
             db = _FakeShards(seed)
-            out = list(hmmer._run_queries(db, [None], iter(range(n)), depth, feeders, window, fin))
+            out = list(hmmer._run_queries(db, [None], iter(range(n)), depth, feeders, window, fin, batch=batch))
             assert out == [(q, ("hits", q)) for q in range(n)], (depth, feeders, window, fin, n)
         for where in ("enqueue", "wait", "finish"):
-            if depth == 0 and where == "wait":
-                continue
             db = _FakeShards(seed, fail_at={11}, fail_in=where)
             got = []
             with pytest.raises(ValueError, match="query 11"):
-                for q, h in hmmer._run_queries(db, [None], iter(range(30)), depth, feeders, window, fin):
+                for q, h in hmmer._run_queries(db, [None], iter(range(30)), depth, feeders, window, fin, batch=batch):
                     got.append(q)
-            assert got == list(range(11)), (depth, feeders, window, fin, where, got)
+            # the error surfaces at the failing query's batch, after every result of the batches before it
+            assert got == list(range(11 - 11 % batch)), (depth, feeders, window, fin, where, got)
         gen = hmmer._run_queries(_FakeShards(seed), [None], iter(range(1000)), depth, feeders, window, fin)
         assert [next(gen)[0] for _ in range(3)] == [0, 1, 2]
         gen.close()                                        # abandoned: feeders stop, queued work is released
