@@ -219,16 +219,32 @@ def _run_queries(db: "ShardedDatabase", pipelines: Sequence[Pipeline], queries: 
     device stage of that many batches before it waits for the oldest."""
     if batch <= 0:
         batch = _auto_batch(db)
-    for qs, hits in _run_batches(db, pipelines, _batches(queries, batch), pipeline_depth, feeders, window, finishers):
-        yield from zip(qs, hits)
+    for qs, hits, err in _run_batches(db, pipelines, _batches(queries, batch), pipeline_depth, feeders, window, finishers):
+        if err is None:
+            yield from zip(qs, hits)
+        elif len(qs) == 1:
+            raise err
+        else:
+            # a member of the batch failed (missing cutoffs, a device error ...): the reference would have yielded the
+            # results of the queries before it first (_base.py:305-318).  Run the batch again one query at a time; the
+            # error then surfaces at its own position.
+            for q in qs:
+                yield q, db.search(pipelines, [q])[0]
+            raise err           # not reproducible query by query: report it after the batch
 
 
 def _run_batches(db: "ShardedDatabase", pipelines: Sequence[Pipeline], queries: Iterable, pipeline_depth: int,
                  feeders: int, window: int = 1, finishers: int = 0) -> Iterator:
-    """``queries`` yields lists of queries; yields ``(list, [TopHits])`` in order."""
+    """``queries`` yields lists of queries; yields ``(list, [TopHits], None)`` in order, or ``(list, None, error)`` for
+    the first batch that failed (nothing follows it)."""
     if pipeline_depth <= 0:
         for q in queries:
-            yield q, db.search(pipelines, q)
+            try:
+                res = db.search(pipelines, q)
+            except BaseException as e:
+                yield q, None, e
+                return
+            yield q, res, None
         return
 
     # two-stage software pipeline over the batches.  Feeder threads (each with its own device stream) run the
@@ -310,6 +326,13 @@ def _run_batches(db: "ShardedDatabase", pipelines: Sequence[Pipeline], queries: 
     nfin = finishers if finishers > 0 else nfeed
     pool = ThreadPoolExecutor(max_workers=nfin, thread_name_prefix="p7x-hmmsearch-finish") if nfin > 1 else None
     inflight: "deque" = deque()
+
+    def result_of(q, fut):
+        try:
+            return q, fut.result(), None
+        except BaseException as e:
+            return q, None, e
+
     try:
         while True:
             with lock:
@@ -325,15 +348,29 @@ def _run_batches(db: "ShardedDatabase", pipelines: Sequence[Pipeline], queries: 
                 if err is not None:            # surfaces at the failing batch's position: first the results before it
                     while inflight:
                         q0, fut = inflight.popleft()
-                        yield q0, fut.result()
-                    raise err
+                        item0 = result_of(q0, fut)
+                        yield item0
+                        if item0[2] is not None:
+                            return
+                    if q is None:
+                        raise err              # the caller's iterable failed
+                    yield q, None, err
+                    return
                 if pool is None:
-                    yield q, db.finish(pendings)
+                    try:
+                        res = db.finish(pendings)
+                    except BaseException as e:
+                        yield q, None, e
+                        return
+                    yield q, res, None
                     continue
                 inflight.append((q, pool.submit(db.finish, pendings)))
             while inflight and (inflight[0][1].done() or len(inflight) >= nfin or drained):
                 q, fut = inflight.popleft()
-                yield q, fut.result()
+                item0 = result_of(q, fut)
+                yield item0
+                if item0[2] is not None:
+                    return
             if drained and not inflight:
                 break
     finally:
