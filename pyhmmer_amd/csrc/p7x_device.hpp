@@ -85,7 +85,7 @@ struct EnvelopeScorer;
 struct p7x_seqdb;
 #include <memory>
 namespace p7x {
-std::unique_ptr<EnvelopeScorer> make_device_envelope_scorer(DeviceCtx *ctx, const DevProfile *dp, const p7x_seqdb *db, const Profile &p);
+std::unique_ptr<EnvelopeScorer> make_device_envelope_scorer(DeviceCtx *ctx, const p7x_seqdb *db);
 
 } // namespace p7x
 

@@ -37,10 +37,12 @@ __device__ __forceinline__ void phase_fence()
 } // namespace
 
 template <int C>
-__global__ void __launch_bounds__(kWsBlock) env_kernel(const EnvArgs a)
+__global__ void __launch_bounds__(kWsBlock) env_kernel(const ArgRef ref)
 {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   constexpr int Mpad = 64 * C;
+  const EnvArgs a = load_args<EnvArgs>(ref);
+  if ((int) blockIdx.x >= a.nblocks) return;        // this job has fewer blocks than the widest job of the launch
   float4 *tr = reinterpret_cast<float4 *>(smem);                         // [2*Mpad]
   float *em = reinterpret_cast<float *>(smem + (size_t) Mpad * 32);      // [nrows][Mpad]
   {
@@ -53,7 +55,8 @@ __global__ void __launch_bounds__(kWsBlock) env_kernel(const EnvArgs a)
   __syncthreads();
   const int lane = threadIdx.x & 63;
   const int nlist = a.nenv;
-  const int wave_id = rfl((int) (blockIdx.x * (kWsBlock / 64) + (threadIdx.x >> 6)));
+  const int wave_in_job = rfl((int) (blockIdx.x * (kWsBlock / 64) + (threadIdx.x >> 6)));
+  const int wave_id = a.slab_base + wave_in_job;     // per-wavefront workspace slabs are numbered across the jobs of a launch
 
   // per-wavefront workspace
   float *wsf = a.work + (size_t) wave_id * (size_t) a.work_stride;
@@ -66,7 +69,7 @@ __global__ void __launch_bounds__(kWsBlock) env_kernel(const EnvArgs a)
   float *totr_row = px + rows * 3;          // [rows]
   unsigned char *bp = reinterpret_cast<unsigned char *>(totr_row + rows);   // [rows][Mpad] back-pointers
 
-  P7X_WAVE_ITEMS(it) {
+  for (int it = wave_in_job; it < nlist; it += a.nblocks * (kWsBlock / 64)) {
     const int Ld = rfl(a.env_len[it]);
     const int Lfull = rfl(a.env_L[it]);
     const unsigned long long off = (unsigned long long) a.env_sq[it];
@@ -559,11 +562,13 @@ size_t env_work_floats(int C, int Lmax)
 }
 
 template <typename K>
-static int launch_env(K kernel, const EnvArgs &a, size_t lds_bytes, int nblocks, hipStream_t st)
+static int launch_env(K kernel, const ArgRun<EnvArgs> &a, size_t lds_bytes, hipStream_t st)
 {
   if (lds_bytes > 64 * 1024)
     P7X_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds_bytes));
-  hipLaunchKernelGGL(kernel, dim3((unsigned) nblocks), dim3(kWsBlock), lds_bytes, st, a);
+  int gx = 1;
+  for (int i = 0; i < a.n; ++i) gx = std::max(gx, a.at(i).nblocks);
+  hipLaunchKernelGGL(kernel, dim3((unsigned) gx, (unsigned) a.n), dim3(kWsBlock), lds_bytes, st, a.ref());
   P7X_HIP(hipGetLastError());
   return P7X_OK;
 }
@@ -603,11 +608,12 @@ int env_max_blocks(int C, int nrows, int num_cu, int *nblocks)
   P7X_ENV_SWITCH(finish(occupancy_env(kern, lds, &per_cu)))
 }
 
-int env_launch(const EnvArgs &a, int nblocks, hipStream_t st)
+int env_launch(const ArgRun<EnvArgs> &a, hipStream_t st)
 {
-  const int C = a.C;
-  const size_t lds = env_lds_bytes(C, a.nrows);
-  P7X_ENV_SWITCH(launch_env(kern, a, lds, nblocks, st))
+  if (a.n <= 0) return P7X_OK;
+  const int C = a.at(0).C;
+  const size_t lds = env_lds_bytes(C, a.at(0).nrows);
+  P7X_ENV_SWITCH(launch_env(kern, a, lds, st))
 }
 
 } // namespace p7x

@@ -5,6 +5,7 @@
 #include "p7x_host.hpp"
 #include <cstdlib>
 #include <cstring>
+#include <map>
 #include <memory>
 
 namespace p7x {
@@ -14,7 +15,8 @@ namespace p7x {
 struct EnvBuffers {
   int device = -1;
   float *work = nullptr; size_t work_floats = 0;
-  unsigned char *d_in = nullptr; size_t d_in_cap = 0;        // env_sq | tr_off | env_len | env_L
+  unsigned char *d_in = nullptr; size_t d_in_cap = 0;        // env_sq | tr_off | env_len | env_L | EnvArgs records
+  unsigned char *h_in = nullptr; size_t h_in_cap = 0;        // pinned mirror of d_in
   unsigned char *d_out = nullptr; size_t d_out_cap = 0;      // out_sc | out_null2 | out_status | tr_n | tr_a | tr_i | tr_pp
   unsigned char *h_out = nullptr; size_t h_out_cap = 0;      // pinned mirror of d_out
   hipStream_t stream = nullptr;                               // per host thread: concurrent host stages do not wait on each other
@@ -24,6 +26,7 @@ struct EnvBuffers {
     if (stream) (void) hipStreamDestroy(stream);
     (void) hipFree(work); (void) hipFree(d_in); (void) hipFree(d_out);
     pinned_release(h_out, h_out_cap);
+    pinned_release(h_in, h_in_cap);
   }
 };
 // leased from a process-wide pool like the cascade workspaces (never destroyed: no device teardown from exiting threads)
@@ -48,14 +51,17 @@ static size_t env_budget_bytes()
 
 class DeviceEnvelopeScorer final : public EnvelopeScorer {
 public:
-  DeviceEnvelopeScorer(DeviceCtx *ctx, const DevProfile *dp, const p7x_seqdb *db, const Profile &p) : ctx_(ctx), dp_(dp), db_(db), p_(p) {}
+  DeviceEnvelopeScorer(DeviceCtx *ctx, const p7x_seqdb *db) : ctx_(ctx), db_(db) {}
   ~DeviceEnvelopeScorer() override { if (lease_) { if (lease_->stream) (void) hipStreamSynchronize(lease_->stream); release_env_buffers(lease_); } }
 
-  int begin(const std::vector<EnvelopeRequest> &req, const std::vector<int32_t> &targets) override
+  int begin(const std::vector<EnvelopeJob> &jobs) override
   {
-    const int nenv = (int) req.size();
-    nenv_ = nenv;
-    if (nenv == 0) return P7X_OK;
+    jobs_ = jobs;
+    meta_.assign(jobs.size(), JobMeta{});
+    int64_t nenv_tot = 0;
+    for (size_t j = 0; j < jobs.size(); ++j) { meta_[j].first = nenv_tot; meta_[j].nenv = (int) jobs[j].req->size(); nenv_tot += meta_[j].nenv; }
+    nenv_ = nenv_tot;
+    if (nenv_tot == 0) return P7X_OK;
     P7X_HIP(hipSetDevice(db_->device));
     EnvBuffers *eb = nullptr;
     {
@@ -71,49 +77,77 @@ public:
       P7X_HIP(hipDeviceGetStreamPriorityRange(&least, &greatest));
       P7X_HIP(hipStreamCreateWithPriority(&eb->stream, hipStreamNonBlocking, least));
     }
-
-    // inputs
-    const size_t in_bytes = (size_t) nenv * (8 + 8 + 4 + 4);
-    h_in_.resize(in_bytes);
-    std::vector<unsigned char> &h_in = h_in_;
-    int64_t *env_sq = reinterpret_cast<int64_t *>(h_in.data());
-    int64_t *tr_off = env_sq + nenv;
-    int32_t *env_len = reinterpret_cast<int32_t *>(tr_off + nenv);
-    int32_t *env_L = env_len + nenv;
-    int Lmax = 1; int64_t ntr = 0;
-    for (int r = 0; r < nenv; ++r) {
-      const int t = targets[(size_t) req[r].item];
-      const int Ld = req[r].j - req[r].i + 1;
-      env_sq[r] = db_->h_off[t] + (req[r].i - 1);
-      env_len[r] = Ld; env_L[r] = db_->h_len[t];
-      tr_off[r] = ntr; ntr += (int64_t) Ld + p_.M + 16;
-      Lmax = std::max(Lmax, Ld);
+    // inputs: [env_sq i64][tr_off i64][env_len i32][env_L i32] over all envelopes, then one EnvArgs record per job
+    const size_t nj = jobs.size();
+    const size_t o_args = ((size_t) nenv_tot * (8 + 8 + 4 + 4) + 255) & ~(size_t) 255;
+    const size_t in_bytes = o_args + nj * sizeof(EnvArgs);
+    if (in_bytes > eb->h_in_cap) {
+      pinned_release(eb->h_in, eb->h_in_cap); eb->h_in = nullptr; eb->h_in_cap = 0;
+      void *hp = nullptr; size_t got = 0; const int pst = pinned_acquire(in_bytes * 2, &hp, &got); if (pst != P7X_OK) return pst;
+      eb->h_in = static_cast<unsigned char *>(hp); eb->h_in_cap = got;
     }
-    // workspace: one slab per resident wavefront, sized for the longest envelope of the batch
-    const int C = dp_->vitC;
-    const size_t stride = env_work_floats(C, Lmax);
-    int nblocks = 0;
-    int st = env_max_blocks(C, p_.Kp + 1, ctx_->num_cu, &nblocks);
-    if (st != P7X_OK) return st;
-    nblocks = std::min(nblocks, (nenv + 3) / 4);
+    if (in_bytes > eb->d_in_cap) {
+      (void) hipFree(eb->d_in); eb->d_in = nullptr; eb->d_in_cap = 0;
+      P7X_HIP(hipMalloc(&eb->d_in, in_bytes * 2)); eb->d_in_cap = in_bytes * 2;
+    }
+    int64_t *env_sq = reinterpret_cast<int64_t *>(eb->h_in);
+    int64_t *tr_off = env_sq + nenv_tot;
+    int32_t *env_len = reinterpret_cast<int32_t *>(tr_off + nenv_tot);
+    int32_t *env_L = env_len + nenv_tot;
+    EnvArgs *h_args = reinterpret_cast<EnvArgs *>(eb->h_in + o_args);
+    int64_t ntr = 0;
+    // jobs of one model-length class (nodes per lane C) go into one launch: order them by class
+    order_.resize(nj);
+    for (size_t j = 0; j < nj; ++j) order_[j] = (int) j;
+    int st = P7X_OK;
+    for (size_t j = 0; j < nj; ++j) {
+      JobMeta &m = meta_[j];
+      if (m.nenv == 0) continue;
+      const Profile &p = jobs[j].om->p;
+      if ((st = get_dev_profile(jobs[j].om, ctx_, &m.dp)) != P7X_OK) return st;
+      m.C = m.dp->vitC; m.Lmax = 1;
+      for (int r = 0; r < m.nenv; ++r) {
+        const EnvelopeRequest &rq = (*jobs[j].req)[(size_t) r];
+        const int t = (*jobs[j].targets)[(size_t) rq.item];
+        const int Ld = rq.j - rq.i + 1;
+        const int64_t e = m.first + r;
+        env_sq[e] = db_->h_off[t] + (rq.i - 1);
+        env_len[e] = Ld; env_L[e] = db_->h_len[t];
+        tr_off[e] = ntr; ntr += (int64_t) Ld + p.M + 16;
+        m.Lmax = std::max(m.Lmax, Ld);
+      }
+    }
+    std::stable_sort(order_.begin(), order_.end(), [&](int x, int y) { return meta_[x].C < meta_[y].C; });
+    // workspace: one slab per wavefront of every job, sized for the longest envelope of the job's class
+    std::map<int, int> class_Lmax;
+    for (size_t j = 0; j < nj; ++j) if (meta_[j].nenv) { int &v = class_Lmax[meta_[j].C]; v = std::max(v, meta_[j].Lmax); }
     const size_t budget = env_budget_bytes();
-    while (nblocks > 1 && (size_t) nblocks * 4 * stride * 4 > budget) nblocks = (nblocks + 1) / 2;
-    const size_t work_floats = (size_t) nblocks * 4 * stride;
-    if (work_floats * 4 > budget && work_floats > eb->work_floats) {
-      set_error("envelope workspace does not fit in device memory (envelope of " + std::to_string(Lmax) + " residues, M = " + std::to_string(p_.M) + ")");
-      return P7X_EMEM;
+    int shrink = 1;
+    size_t work_floats = 0;
+    for (;; shrink *= 2) {
+      work_floats = 0;
+      for (size_t j = 0; j < nj; ++j) {
+        JobMeta &m = meta_[j];
+        if (m.nenv == 0) continue;
+        int cap_blocks = 0;
+        if ((st = env_max_blocks(m.C, jobs[j].om->p.Kp + 1, ctx_->num_cu, &cap_blocks)) != P7X_OK) return st;
+        m.nblocks = std::max(1, std::min(cap_blocks, (m.nenv + 3) / 4) / shrink);
+        m.stride = env_work_floats(m.C, class_Lmax[m.C]);
+        work_floats += (size_t) m.nblocks * 4 * m.stride;
+      }
+      if (work_floats * 4 <= budget || work_floats <= eb->work_floats) break;
+      bool all_one = true;
+      for (size_t j = 0; j < nj; ++j) if (meta_[j].nenv && meta_[j].nblocks > 1) all_one = false;
+      if (all_one) { set_error("envelope workspace does not fit in device memory"); return P7X_EMEM; }
     }
     if (work_floats > eb->work_floats) {
       (void) hipFree(eb->work); eb->work = nullptr; eb->work_floats = 0;
       P7X_HIP(hipMalloc(&eb->work, work_floats * 4)); eb->work_floats = work_floats;
     }
-    if (in_bytes > eb->d_in_cap) {
-      (void) hipFree(eb->d_in); eb->d_in = nullptr;
-      P7X_HIP(hipMalloc(&eb->d_in, in_bytes * 2)); eb->d_in_cap = in_bytes * 2;
-    }
     // outputs: [out_sc 2f][null2 32f][status i][tr_n i] per envelope, then the three trace arrays
-    const size_t o_sc = 0, o_n2 = o_sc + (size_t) nenv * 8, o_st = o_n2 + (size_t) nenv * 128, o_n = o_st + (size_t) nenv * 4;
-    const size_t o_ta = o_n + (size_t) nenv * 4, o_ti = o_ta + (size_t) ntr * 4, o_tp = o_ti + (size_t) ntr * 4;
+    const size_t n = (size_t) nenv_tot;
+    const size_t o_sc = 0, o_n2 = o_sc + n * 8, o_st = o_n2 + n * 128, o_n = o_st + n * 4;
+    const size_t o_ta = o_n + n * 4, o_ti = o_ta + (size_t) ntr * 4, o_tp = o_ti + (size_t) ntr * 4;
     const size_t out_bytes = o_tp + (size_t) ntr * 4;
     if (out_bytes > eb->d_out_cap) {
       (void) hipFree(eb->d_out); eb->d_out = nullptr;
@@ -124,66 +158,95 @@ public:
         eb->h_out = static_cast<decltype(eb->h_out)>(hp); eb->h_out_cap = got; }
     }
     hipStream_t s = eb->stream;
-    P7X_HIP(hipMemcpyAsync(eb->d_in, h_in.data(), in_bytes, hipMemcpyHostToDevice, s));
-    EnvArgs a{};
-    a.M = p_.M; a.C = C; a.K = p_.K; a.nrows = p_.Kp + 1;
-    a.trans = dp_->fwd_trans; a.emis = dp_->fwd_emis; a.dsq = db_->d_dsq;
-    a.nj = 0.0f; a.xf_e_move = 1.0f; a.xf_e_loop = 0.0f;              // p7_oprofile_ReconfigUnihit
-    a.nenv = nenv;
-    a.env_sq = reinterpret_cast<const int64_t *>(eb->d_in);
-    a.tr_off = a.env_sq + nenv;
-    a.env_len = reinterpret_cast<const int32_t *>(a.tr_off + nenv);
-    a.env_L = a.env_len + nenv;
-    a.work = eb->work; a.work_stride = (int64_t) stride; a.Lmax = Lmax;
-    a.out_sc = reinterpret_cast<float *>(eb->d_out + o_sc);
-    a.out_null2 = reinterpret_cast<float *>(eb->d_out + o_n2);
-    a.out_status = reinterpret_cast<int32_t *>(eb->d_out + o_st);
-    a.tr_n = reinterpret_cast<int32_t *>(eb->d_out + o_n);
-    a.tr_a = reinterpret_cast<uint32_t *>(eb->d_out + o_ta);
-    a.tr_i = reinterpret_cast<int32_t *>(eb->d_out + o_ti);
-    a.tr_pp = reinterpret_cast<float *>(eb->d_out + o_tp);
-    if ((st = env_launch(a, nblocks, s)) != P7X_OK) return st;
+    const int64_t *d_env_sq = reinterpret_cast<const int64_t *>(eb->d_in);
+    const int64_t *d_tr_off = d_env_sq + nenv_tot;
+    const int32_t *d_env_len = reinterpret_cast<const int32_t *>(d_tr_off + nenv_tot);
+    const int32_t *d_env_L = d_env_len + nenv_tot;
+    // argument records in launch order (class by class)
+    size_t slab_floats = 0;
+    std::vector<std::pair<int, int>> runs;        // first record, count
+    int nrec = 0;
+    for (size_t k = 0; k < nj; ++k) {
+      const int j = order_[k];
+      const JobMeta &m = meta_[(size_t) j];
+      if (m.nenv == 0) continue;
+      const Profile &p = jobs[(size_t) j].om->p;
+      EnvArgs a{};
+      a.M = p.M; a.C = m.C; a.K = p.K; a.nrows = p.Kp + 1;
+      a.trans = m.dp->fwd_trans; a.emis = m.dp->fwd_emis; a.dsq = db_->d_dsq;
+      a.nj = 0.0f; a.xf_e_move = 1.0f; a.xf_e_loop = 0.0f;              // p7_oprofile_ReconfigUnihit
+      a.nenv = m.nenv;
+      a.env_sq = d_env_sq + m.first; a.tr_off = d_tr_off + m.first; a.env_len = d_env_len + m.first; a.env_L = d_env_L + m.first;
+      // slab_base counts slabs of THIS job's stride from the start of its own region of the workspace
+      a.work = eb->work + slab_floats; a.work_stride = (int64_t) m.stride; a.Lmax = class_Lmax[m.C];
+      a.nblocks = m.nblocks; a.slab_base = 0;
+      slab_floats += (size_t) m.nblocks * 4 * m.stride;
+      a.out_sc = reinterpret_cast<float *>(eb->d_out + o_sc) + 2 * m.first;
+      a.out_null2 = reinterpret_cast<float *>(eb->d_out + o_n2) + 32 * m.first;
+      a.out_status = reinterpret_cast<int32_t *>(eb->d_out + o_st) + m.first;
+      a.tr_n = reinterpret_cast<int32_t *>(eb->d_out + o_n) + m.first;
+      a.tr_a = reinterpret_cast<uint32_t *>(eb->d_out + o_ta);
+      a.tr_i = reinterpret_cast<int32_t *>(eb->d_out + o_ti);
+      a.tr_pp = reinterpret_cast<float *>(eb->d_out + o_tp);
+      if (!runs.empty() && h_args[runs.back().first].C == a.C && h_args[runs.back().first].nrows == a.nrows) runs.back().second++;
+      else runs.emplace_back(nrec, 1);
+      h_args[nrec++] = a;
+    }
+    P7X_HIP(hipMemcpyAsync(eb->d_in, eb->h_in, in_bytes, hipMemcpyHostToDevice, s));
+    for (const auto &run : runs) {
+      ArgRun<EnvArgs> ar;
+      ar.host = h_args + run.first; ar.dev = eb->d_in + o_args + (size_t) run.first * sizeof(EnvArgs);
+      ar.stride = (uint32_t) sizeof(EnvArgs); ar.n = run.second;
+      if ((st = env_launch(ar, s)) != P7X_OK) return st;
+    }
     P7X_HIP(hipMemcpyAsync(eb->h_out, eb->d_out, out_bytes, hipMemcpyDeviceToHost, s));
     eb_ = eb; o_sc_ = o_sc; o_n2_ = o_n2; o_st_ = o_st; o_n_ = o_n; o_ta_ = o_ta; o_ti_ = o_ti; o_tp_ = o_tp;
+    tr_off_.assign(tr_off, tr_off + nenv_tot);
     return P7X_OK;
   }
 
-  int wait(std::vector<EnvelopeResult> &res) override
+  int wait(std::vector<std::vector<EnvelopeResult>> &res) override
   {
-    const int nenv = nenv_;
-    res.assign((size_t) nenv, EnvelopeResult{});
-    if (nenv == 0) return P7X_OK;
+    res.assign(jobs_.size(), {});
+    if (nenv_ == 0) return P7X_OK;
     P7X_HIP(hipSetDevice(db_->device));
     EnvBuffers *eb = eb_;
     P7X_HIP(hipStreamSynchronize(eb->stream));
-    const size_t o_sc = o_sc_, o_n2 = o_n2_, o_st = o_st_, o_n = o_n_, o_ta = o_ta_, o_ti = o_ti_, o_tp = o_tp_;
-    const int64_t *tr_off = reinterpret_cast<const int64_t *>(h_in_.data()) + nenv;
-    const float *h_sc = reinterpret_cast<const float *>(eb->h_out + o_sc), *h_n2 = reinterpret_cast<const float *>(eb->h_out + o_n2);
-    const int32_t *h_st = reinterpret_cast<const int32_t *>(eb->h_out + o_st), *h_n = reinterpret_cast<const int32_t *>(eb->h_out + o_n);
-    const uint32_t *h_ta = reinterpret_cast<const uint32_t *>(eb->h_out + o_ta);
-    const int32_t *h_ti = reinterpret_cast<const int32_t *>(eb->h_out + o_ti);
-    const float *h_tp = reinterpret_cast<const float *>(eb->h_out + o_tp);
-    for (int r = 0; r < nenv; ++r) {
-      EnvelopeResult &e = res[(size_t) r];
-      e.envsc = h_sc[2 * r]; e.oasc = h_sc[2 * r + 1]; e.status = h_st[r];
-      std::memcpy(e.null2, h_n2 + (size_t) r * 32, sizeof(e.null2));
-      e.ntrace = h_n[r]; e.ta = h_ta + tr_off[r]; e.ti = h_ti + tr_off[r]; e.tp = h_tp + tr_off[r];
+    const float *h_sc = reinterpret_cast<const float *>(eb->h_out + o_sc_), *h_n2 = reinterpret_cast<const float *>(eb->h_out + o_n2_);
+    const int32_t *h_st = reinterpret_cast<const int32_t *>(eb->h_out + o_st_), *h_n = reinterpret_cast<const int32_t *>(eb->h_out + o_n_);
+    const uint32_t *h_ta = reinterpret_cast<const uint32_t *>(eb->h_out + o_ta_);
+    const int32_t *h_ti = reinterpret_cast<const int32_t *>(eb->h_out + o_ti_);
+    const float *h_tp = reinterpret_cast<const float *>(eb->h_out + o_tp_);
+    for (size_t j = 0; j < jobs_.size(); ++j) {
+      const JobMeta &m = meta_[j];
+      res[j].assign((size_t) m.nenv, EnvelopeResult{});
+      for (int r = 0; r < m.nenv; ++r) {
+        const int64_t g = m.first + r;
+        EnvelopeResult &e = res[j][(size_t) r];
+        e.envsc = h_sc[2 * g]; e.oasc = h_sc[2 * g + 1]; e.status = h_st[g];
+        std::memcpy(e.null2, h_n2 + (size_t) g * 32, sizeof(e.null2));
+        e.ntrace = h_n[g]; e.ta = h_ta + tr_off_[(size_t) g]; e.ti = h_ti + tr_off_[(size_t) g]; e.tp = h_tp + tr_off_[(size_t) g];
+      }
     }
     return P7X_OK;
   }
 
 private:
-  DeviceCtx *ctx_; const DevProfile *dp_; const p7x_seqdb *db_; const Profile &p_;
-  int nenv_ = 0;
-  std::vector<unsigned char> h_in_;
+  struct JobMeta { int64_t first = 0; int nenv = 0, C = 0, Lmax = 1, nblocks = 1; size_t stride = 0; DevProfile *dp = nullptr; };
+  DeviceCtx *ctx_; const p7x_seqdb *db_;
+  std::vector<EnvelopeJob> jobs_;
+  std::vector<JobMeta> meta_;
+  std::vector<int> order_;
+  std::vector<int64_t> tr_off_;
+  int64_t nenv_ = 0;
   EnvBuffers *eb_ = nullptr;
   EnvBuffers *lease_ = nullptr;
   size_t o_sc_ = 0, o_n2_ = 0, o_st_ = 0, o_n_ = 0, o_ta_ = 0, o_ti_ = 0, o_tp_ = 0;
 };
 
-std::unique_ptr<EnvelopeScorer> make_device_envelope_scorer(DeviceCtx *ctx, const DevProfile *dp, const p7x_seqdb *db, const Profile &p)
+std::unique_ptr<EnvelopeScorer> make_device_envelope_scorer(DeviceCtx *ctx, const p7x_seqdb *db)
 {
-  return std::make_unique<DeviceEnvelopeScorer>(ctx, dp, db, p);
+  return std::make_unique<DeviceEnvelopeScorer>(ctx, db);
 }
 
 } // namespace p7x

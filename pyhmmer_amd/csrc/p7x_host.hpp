@@ -40,12 +40,15 @@ struct EnvelopeResult {
   float null2[32];                                           // odds of the canonical residues (before esl_abc_FAvgScVec)
   int ntrace = 0; const uint32_t *ta = nullptr; const int32_t *ti = nullptr; const float *tp = nullptr;   // traceback order
 };
+// One job = the envelopes of one query profile (targets[item] = caller index of the survivor a request belongs to).
+struct EnvelopeJob { const p7x_oprofile *om = nullptr; const std::vector<EnvelopeRequest> *req = nullptr; const std::vector<int32_t> *targets = nullptr; };
 struct EnvelopeScorer {
   virtual ~EnvelopeScorer() = default;
-  // begin() enqueues the batch (targets[item] = caller index of the survivor) and returns; wait() blocks until it is
-  // done and fills res[r] for every req[r].  Result buffers stay valid until the next begin().
-  virtual int begin(const std::vector<EnvelopeRequest> &req, const std::vector<int32_t> &targets) = 0;
-  virtual int wait(std::vector<EnvelopeResult> &res) = 0;
+  // begin() enqueues the jobs of a batch of queries (one launch per model-length class, all profiles of a class in
+  // it) and returns; wait() blocks until they are done and fills res[j][r] for every request r of job j.  Result
+  // buffers stay valid until the next begin().
+  virtual int begin(const std::vector<EnvelopeJob> &jobs) = 0;
+  virtual int wait(std::vector<std::vector<EnvelopeResult>> &res) = 0;
 };
 
 // p7_domaindef_ByPosteriorHeuristics (p7_domaindef.pxd:69-72).  dsq is 1-indexed (dsq[1..L]);
@@ -95,6 +98,20 @@ int host_finish_search(const p7x_pipeline_cfg &cfg, const p7x_oprofile *om, cons
                        const float *fwd_xmx, const float *bck_xmx, const int64_t *xmx_off,
                        const uint64_t *counts, const double *ms, p7x_tophits **out, EnvelopeScorer *scorer = nullptr,
                        const DeviceRegions *regions = nullptr);
+// One query of a batch as the host stage receives it from the device stage.
+struct FinishItem {
+  const p7x_oprofile *om = nullptr;
+  const std::vector<int32_t> *targets = nullptr;      // caller indices of the Forward survivors
+  const float *fwdsc = nullptr;                       // per survivor
+  const float *fwd_xmx = nullptr, *bck_xmx = nullptr; const int64_t *xmx_off = nullptr;   // parser rows (when regions == nullptr)
+  uint64_t counts[4] = { 0, 0, 0, 0 };                // n_past_{msv,bias,vit,fwd}
+  const double *ms = nullptr;
+  const DeviceRegions *regions = nullptr;             // region lists found on the device
+  bool device_envelopes = false;                      // single-domain envelopes go to the scorer
+};
+int host_finish_batch(const p7x_pipeline_cfg &cfg, const std::vector<FinishItem> &items, const HostTargets &tg,
+                      const char *const *names, const char *const *accs, const char *const *descs,
+                      p7x_tophits **outs, EnvelopeScorer *scorer = nullptr);
 void tophits_set_total_ms(p7x_tophits *th, double stage1_ms, double stage2_ms);
 void tophits_set_stages(p7x_tophits *th, std::vector<uint8_t> &&stage);
 float kahan_fsum(const float *v, int n);

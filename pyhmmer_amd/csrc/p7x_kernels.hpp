@@ -129,6 +129,7 @@ struct EnvArgs {
   const int32_t *env_len;   // [nenv] envelope length Ld
   const int32_t *env_L;     // [nenv] full target length (the length model is not re-configured per envelope)
   float *work; int64_t work_stride; int Lmax;    // per-wavefront workspace (env_work_floats), rows 0..Lmax
+  int nblocks, slab_base;   // blocks of this job (blockIdx.x beyond them exit); first workspace slab of the job
   float *out_sc;            // [nenv][2] envelope Forward score (nats), optimal accuracy score
   int32_t *out_status;      // [nenv] bit 0 Forward range, 1 decoding range (envelope dropped), >= 2 traceback failures
   float *out_null2;         // [nenv][32] null2 odds of the canonical residues
@@ -138,7 +139,8 @@ struct EnvArgs {
 };
 size_t env_work_floats(int C, int Lmax);
 int env_max_blocks(int C, int nrows, int num_cu, int *nblocks);
-int env_launch(const EnvArgs &a, int nblocks, hipStream_t st);
+// every record of the run has the same C and nrows; grid.x = the widest job's nblocks
+int env_launch(const ArgRun<EnvArgs> &a, hipStream_t st);
 
 // ---- thread-per-sequence small stages (p7x_pipeline.hip)
 } // namespace p7x

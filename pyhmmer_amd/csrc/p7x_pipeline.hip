@@ -393,6 +393,11 @@ struct Workspace {
   hipEvent_t ev[8]{};
   hipEvent_t ev_sync = nullptr;
   hipStream_t stream = nullptr;     // one stream per cascade in flight: concurrent searches overlap on the device
+  // The lanes of a batch fall into classes that share every kernel instantiation; each class runs its cascade on its
+  // own stream (forked from / joined into <stream>), so that the classes' latency-bound launches overlap
+  static constexpr int kSide = 7;
+  hipStream_t side[kSide]{};
+  hipEvent_t ev_fork = nullptr, ev_join[kSide]{};
   int *h_counts = nullptr; size_t h_counts_bytes = 0;   // pinned mirror of counters
   bool busy = false;                // between the enqueue and the collect half of a cascade
   size_t counters_bytes() const { return (size_t) nlanes * kLaneCounters * 4 + 8; }
@@ -407,7 +412,10 @@ struct Workspace {
     (void) hipFree(rt_xmx_off); (void) hipFree(rt_reg_out); (void) hipFree(rt_bck_sc);
     for (auto &e : ev) if (e) (void) hipEventDestroy(e);
     if (ev_sync) (void) hipEventDestroy(ev_sync);
+    if (ev_fork) (void) hipEventDestroy(ev_fork);
+    for (auto &e : ev_join) if (e) (void) hipEventDestroy(e);
     if (stream) (void) hipStreamDestroy(stream);
+    for (auto &q : side) if (q) (void) hipStreamDestroy(q);
     pinned_release(h_counts, h_counts_bytes);
     pinned_release(h_args, h_args_bytes);
   }
@@ -468,6 +476,11 @@ static int get_workspace(int device, int64_t nslots, int nlanes, Workspace **out
     int least = 0, greatest = 0;
     P7X_HIP(hipDeviceGetStreamPriorityRange(&least, &greatest));
     P7X_HIP(hipStreamCreateWithPriority(&w->stream, hipStreamNonBlocking, greatest));
+    if (nlanes > 1) {
+      for (auto &q : w->side) P7X_HIP(hipStreamCreateWithPriority(&q, hipStreamNonBlocking, greatest));
+      P7X_HIP(hipEventCreateWithFlags(&w->ev_fork, hipEventDisableTiming));
+      for (auto &e : w->ev_join) P7X_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    }
   }
   w->busy = true;
   *out = w.get();
@@ -560,21 +573,6 @@ template <class A> static ArgRun<A> lane_run(const Workspace *ws, A LaneArgs::*m
   return r;
 }
 
-// Lanes are sorted by model length, so the lanes that share a kernel instantiation are consecutive: launch run by run.
-template <class KeyFn, class LaunchFn>
-static int for_runs(int nlanes, KeyFn key, LaunchFn launch)
-{
-  for (int first = 0; first < nlanes; ) {
-    int last = first + 1;
-    const long k = key(first);
-    while (last < nlanes && key(last) == k) ++last;
-    const int st = launch(first, last - first);
-    if (st != P7X_OK) return st;
-    first = last;
-  }
-  return P7X_OK;
-}
-
 struct LaneModel { const p7x_oprofile *om = nullptr; DevProfile *dp = nullptr; };
 
 static int upload_args(Workspace *ws, int first, int n, hipStream_t s)
@@ -583,43 +581,52 @@ static int upload_args(Workspace *ws, int first, int n, hipStream_t s)
   return P7X_OK;
 }
 
-// MSV over the whole database for every lane; leaves xJ (slot order) in the lanes' xJ arrays.
-static int run_msv(const std::vector<LaneModel> &lm, const p7x_seqdb *db, DeviceCtx *ctx, Workspace *ws, hipStream_t stream)
+// Lanes are sorted by model length, so the lanes that share the instantiation of every kernel family (MSV register
+// tile or wave kernel, packed or wave Viterbi, nodes per lane of the parsers) are consecutive: a class.
+struct LaneClass { int first = 0, n = 0; long msv_key = 0, vit_key = 0; int C = 0; };
+
+static long msv_key_of(const DevProfile *dp, bool small)
+{ // M > 478, or too few targets for one per lane: wave-per-target kernel (key < 0), else the register tile
+  return (dp->msvR <= 0 || small) ? -(long) dp->vitC : (long) dp->msvR;
+}
+static long vit_key_of(const DevProfile *dp, bool small)
+{
+  return (dp->vitpkT > 0 && !g_vit_wave && !small) ? (long) (dp->vitpkT * 256 + dp->vitpkP) : -(long) dp->vitC;
+}
+
+static int lane_classes(const std::vector<LaneModel> &lm, const p7x_seqdb *db, const DeviceCtx *ctx, std::vector<LaneClass> &out)
 {
   const int nl = (int) lm.size();
   const bool small = small_block(db, ctx, nl);
-  for (int l = 0; l < nl; ++l)
-    if ((lm[l].dp->msvR <= 0 || small) && !lm[l].dp->msvw_emis) { set_error("model too long for the MSV kernels (M > 2048)"); return P7X_EINVAL; }
-  // M > 478, or too few targets for one per lane: wave-per-target kernel (key < 0), else the register tile
-  auto key = [&](int l) -> long { return (lm[l].dp->msvR <= 0 || small) ? -(long) lm[l].dp->vitC : (long) lm[l].dp->msvR; };
-  return for_runs(nl, key, [&](int first, int n) -> int {
-    if (key(first) < 0) return msv_wave_launch(lane_run(ws, &LaneArgs::msvw, first, n), ctx->num_cu, stream);
-    const ArgRun<MsvArgs> amb = lane_run(ws, &LaneArgs::msv_amb, first, n);
-    return msv_launch(lm[first].dp->msvR, lane_run(ws, &LaneArgs::msv, first, n), g_msv_exact_only ? nullptr : &amb, ctx->num_cu, stream);
-  });
+  out.clear();
+  for (int l = 0; l < nl; ++l) {
+    const DevProfile *dp = lm[l].dp;
+    if ((dp->msvR <= 0 || small) && !dp->msvw_emis) { set_error("model too long for the MSV kernels (M > 2048)"); return P7X_EINVAL; }
+    LaneClass c; c.first = l; c.n = 1; c.msv_key = msv_key_of(dp, small); c.vit_key = vit_key_of(dp, small); c.C = dp->vitC;
+    if (!out.empty() && out.back().msv_key == c.msv_key && out.back().vit_key == c.vit_key && out.back().C == c.C) out.back().n++;
+    else out.push_back(c);
+  }
+  return P7X_OK;
+}
+
+// MSV over the whole database for the lanes of a class; leaves xJ (slot order) in the lanes' xJ arrays.
+static int class_msv(const LaneClass &c, const std::vector<LaneModel> &lm, DeviceCtx *ctx, Workspace *ws, hipStream_t stream)
+{
+  if (c.msv_key < 0) return msv_wave_launch(lane_run(ws, &LaneArgs::msvw, c.first, c.n), ctx->num_cu, stream);
+  const ArgRun<MsvArgs> amb = lane_run(ws, &LaneArgs::msv_amb, c.first, c.n);
+  return msv_launch(lm[c.first].dp->msvR, lane_run(ws, &LaneArgs::msv, c.first, c.n), g_msv_exact_only ? nullptr : &amb, ctx->num_cu, stream);
 }
 
 // Viterbi filter over the lanes' work lists: the packed kernel when the model fits it, else one target per wavefront.
-static int run_viterbi(const std::vector<LaneModel> &lm, const p7x_seqdb *db, DeviceCtx *ctx, Workspace *ws, hipStream_t s)
+static int class_viterbi(const LaneClass &c, const std::vector<LaneModel> &lm, DeviceCtx *ctx, Workspace *ws, hipStream_t s)
 {
-  const int nl = (int) lm.size();
-  const bool small = small_block(db, ctx, nl);
-  auto key = [&](int l) -> long {
-    const DevProfile *dp = lm[l].dp;
-    return (dp->vitpkT > 0 && !g_vit_wave && !small) ? (long) (dp->vitpkT * 256 + dp->vitpkP) : -(long) dp->vitC;
-  };
-  return for_runs(nl, key, [&](int first, int n) -> int {
-    if (key(first) < 0) return vit_launch(lane_run(ws, &LaneArgs::vit, first, n), ctx->num_cu, s);
-    return vitpk_launch(lm[first].dp->vitpkT, lm[first].dp->vitpkP, lane_run(ws, &LaneArgs::vitpk, first, n), ctx->num_cu, s);
-  });
+  if (c.vit_key < 0) return vit_launch(lane_run(ws, &LaneArgs::vit, c.first, c.n), ctx->num_cu, s);
+  return vitpk_launch(lm[c.first].dp->vitpkT, lm[c.first].dp->vitpkP, lane_run(ws, &LaneArgs::vitpk, c.first, c.n), ctx->num_cu, s);
 }
 
-static int run_wave_stage(const std::vector<LaneModel> &lm, Workspace *ws, WaveSeqArgs LaneArgs::*member, bool backward, DeviceCtx *ctx, hipStream_t s)
+static int class_wave(const LaneClass &c, Workspace *ws, WaveSeqArgs LaneArgs::*member, bool backward, DeviceCtx *ctx, hipStream_t s)
 {
-  auto key = [&](int l) -> long { return lm[l].dp->vitC; };
-  return for_runs((int) lm.size(), key, [&](int first, int n) -> int {
-    return backward ? bck_launch(lane_run(ws, member, first, n), ctx->num_cu, s) : fwd_launch(lane_run(ws, member, first, n), ctx->num_cu, s);
-  });
+  return backward ? bck_launch(lane_run(ws, member, c.first, c.n), ctx->num_cu, s) : fwd_launch(lane_run(ws, member, c.first, c.n), ctx->num_cu, s);
 }
 
 struct CascadeOut {
@@ -661,12 +668,11 @@ static int64_t longest_rows(const p7x_seqdb *db, int64_t count)
   return rows;
 }
 
-// Forward with the special-state rows kept, Backward, region scan for the survivors of lanes [first, first + n); the
-// kernels read the survivor counts from device memory.  <single>: one lane on the retry buffers (sized for its nfin).
-static int enqueue_survivor_passes(CascadeRun &r, int first, int n, bool retry, int nfin)
+// Argument records of the survivor passes (Forward with the special-state rows kept, Backward, region scan) of lanes
+// [first, first + n), and the buffers behind them.  <retry>: one lane on the retry buffers, sized for its own nfin.
+static int fill_survivor_args(CascadeRun &r, int first, int n, bool retry, int nfin)
 {
-  const p7x_seqdb *db = r.db; Workspace *ws = r.ws; DeviceCtx *ctx = r.ctx; hipStream_t s = ws->stream;
-  int st = P7X_OK;
+  const p7x_seqdb *db = r.db; Workspace *ws = r.ws; DeviceCtx *ctx = r.ctx;
   int64_t want_cap = std::min<int64_t>(db->nslots, std::max<int64_t>(4096, db->nslots / 64));
   if (retry) want_cap = std::min<int64_t>(db->nslots, std::max<int64_t>(want_cap, (int64_t) nfin));
   const int64_t want_floats = longest_rows(db, want_cap) * 6;
@@ -677,7 +683,6 @@ static int enqueue_survivor_passes(CascadeRun &r, int first, int n, bool retry, 
     ws->xmx_cap = want_floats;
   }
   int64_t cap = 0;
-  int64_t *xmx_off = nullptr; int32_t *reg_out = nullptr; float *bck_sc = nullptr;
   if (!retry) {
     if (want_cap > ws->fin_cap) {
       (void) hipFree(ws->xmx_off); (void) hipFree(ws->reg_out); (void) hipFree(ws->bck_sc);
@@ -703,9 +708,9 @@ static int enqueue_survivor_passes(CascadeRun &r, int first, int n, bool retry, 
     const Profile &p = r.lm[l].om->p; const DevProfile *dp = r.lm[l].dp;
     LaneArgs &la = ws->h_args[l];
     const StageBufs b = ws->lane_bufs(l);
-    xmx_off = retry ? ws->rt_xmx_off : ws->xmx_off + (size_t) l * cap;
-    reg_out = retry ? ws->rt_reg_out : ws->reg_out + (size_t) l * cap * (kRegionCap * 3 + 2);
-    bck_sc = retry ? ws->rt_bck_sc : ws->bck_sc + (size_t) l * cap;
+    int64_t *xmx_off = retry ? ws->rt_xmx_off : ws->xmx_off + (size_t) l * cap;
+    int32_t *reg_out = retry ? ws->rt_reg_out : ws->reg_out + (size_t) l * cap * (kRegionCap * 3 + 2);
+    float *bck_sc = retry ? ws->rt_bck_sc : ws->bck_sc + (size_t) l * cap;
     LayoutArgs lay{};
     lay.nfin_ptr = &b.counters[4]; lay.list_fin = b.list_fin; lay.slot_len = db->d_slot_len; lay.xmx_off = xmx_off;
     lay.cap_items = (int) std::min<int64_t>(cap, INT_MAX); lay.cap_floats = (long long) ws->xmx_cap; lay.cursor = ws->cursor();
@@ -727,27 +732,63 @@ static int enqueue_survivor_passes(CascadeRun &r, int first, int n, bool retry, 
     ra.out_nexpected = reinterpret_cast<float *>(ra.out_n + cap);
     la.reg = ra;
   }
-  if ((st = upload_args(ws, first, n, s)) != P7X_OK) return st;
-  if (retry) P7X_HIP(hipMemsetAsync(&ws->lane_bufs(first).counters[12], 0, 4, s));
-  P7X_HIP(hipMemsetAsync(ws->cursor(), 0, 8, s));
-  hipLaunchKernelGGL(layout_rows_kernel, dim3(1, (unsigned) n), dim3(256), 0, s, lane_run(ws, &LaneArgs::lay, first, n).ref());
+  return P7X_OK;
+}
+
+// the survivor passes of one class on stream <s>; the kernels read the survivor counts from device memory
+static int launch_survivor_passes(CascadeRun &r, const LaneClass &c, hipStream_t s, bool retry, bool record_events)
+{
+  Workspace *ws = r.ws; DeviceCtx *ctx = r.ctx;
+  const int64_t cap = retry ? ws->rt_cap : ws->fin_cap;
+  int st = P7X_OK;
+  hipLaunchKernelGGL(layout_rows_kernel, dim3(1, (unsigned) c.n), dim3(256), 0, s, lane_run(ws, &LaneArgs::lay, c.first, c.n).ref());
   P7X_HIP(hipGetLastError());
-  std::vector<LaneModel> sub(r.lm.begin() + first, r.lm.begin() + first + n);
-  {
-    auto key = [&](int l) -> long { return sub[l].dp->vitC; };
-    if ((st = for_runs(n, key, [&](int f, int c) { return fwd_launch(lane_run(ws, &LaneArgs::rows, first + f, c), ctx->num_cu, s); })) != P7X_OK) return st;
-    if (!retry) P7X_HIP(hipEventRecord(ws->ev[5], s));
-    if ((st = for_runs(n, key, [&](int f, int c) { return bck_launch(lane_run(ws, &LaneArgs::bck, first + f, c), ctx->num_cu, s); })) != P7X_OK) return st;
-  }
+  if ((st = class_wave(c, ws, &LaneArgs::rows, false, ctx, s)) != P7X_OK) return st;
+  if (record_events) P7X_HIP(hipEventRecord(ws->ev[5], s));
+  if ((st = class_wave(c, ws, &LaneArgs::bck, true, ctx, s)) != P7X_OK) return st;
   {   // posterior decoding of the special states and the region scan, on the rows where they are
-    const unsigned gx = lane_grid(std::min<int64_t>((cap + 3) / 4, ctx->num_cu * 4), ctx->num_cu * 4, n);
-    hipLaunchKernelGGL(regions_kernel, dim3(gx, (unsigned) n), dim3(256), 0, s, lane_run(ws, &LaneArgs::reg, first, n).ref());
+    const unsigned gx = lane_grid(std::min<int64_t>((cap + 3) / 4, ctx->num_cu * 4), ctx->num_cu * 4, c.n);
+    hipLaunchKernelGGL(regions_kernel, dim3(gx, (unsigned) c.n), dim3(256), 0, s, lane_run(ws, &LaneArgs::reg, c.first, c.n).ref());
     P7X_HIP(hipGetLastError());
   }
-  if (!retry) P7X_HIP(hipEventRecord(ws->ev[6], s));
-  P7X_HIP(hipMemcpyAsync(ws->h_counts, ws->counters, ws->counters_bytes(), hipMemcpyDeviceToHost, s));
-  P7X_HIP(hipEventRecord(ws->ev_sync, s));
+  if (record_events) P7X_HIP(hipEventRecord(ws->ev[6], s));
   return P7X_OK;
+}
+
+// every kernel of stage 1 for the lanes of one class, on stream <s>
+static int class_cascade(CascadeRun &r, const LaneClass &c, hipStream_t s, bool record_events, bool chain_msv)
+{
+  const p7x_seqdb *db = r.db; Workspace *ws = r.ws; DeviceCtx *ctx = r.ctx;
+  int st = P7X_OK;
+  if (chain_msv) {
+    // MSV launches that fill the device on their own are chained (two of them sharing the CUs only slow each other
+    // down); small blocks -- a scan's query sequences -- leave most of the device idle and run side by side instead
+    std::lock_guard<std::mutex> lk(ctx->msv_mu);          // enqueue order == chain order
+    if (ctx->msv_last >= 0) P7X_HIP(hipStreamWaitEvent(s, ctx->msv_done[ctx->msv_last], 0));
+    if (record_events) P7X_HIP(hipEventRecord(ws->ev[0], s));
+    if ((st = class_msv(c, r.lm, ctx, ws, s)) != P7X_OK) return st;
+    if (record_events) P7X_HIP(hipEventRecord(ws->ev[7], s));
+    ctx->msv_last = (ctx->msv_last + 1) & 1;
+    P7X_HIP(hipEventRecord(ctx->msv_done[ctx->msv_last], s));
+  } else {
+    if (record_events) P7X_HIP(hipEventRecord(ws->ev[0], s));
+    if ((st = class_msv(c, r.lm, ctx, ws, s)) != P7X_OK) return st;
+    if (record_events) P7X_HIP(hipEventRecord(ws->ev[7], s));
+  }
+  const ArgRef dec = lane_run(ws, &LaneArgs::dec, c.first, c.n).ref();
+  hipLaunchKernelGGL(decide_msv_kernel, dim3((unsigned) ((db->nslots + 255) / 256), (unsigned) c.n), dim3(256), 0, s, dec);
+  if (record_events) P7X_HIP(hipEventRecord(ws->ev[1], s));
+  hipLaunchKernelGGL(bias_kernel, dim3(lane_grid((db->nslots + 63) / 64, ctx->num_cu * 4, c.n), (unsigned) c.n), dim3(64), 0, s, dec);
+  if (record_events) P7X_HIP(hipEventRecord(ws->ev[2], s));
+  if ((st = class_viterbi(c, r.lm, ctx, ws, s)) != P7X_OK) return st;
+  const unsigned gdec = lane_grid((db->nslots + 255) / 256, ctx->num_cu, c.n);
+  hipLaunchKernelGGL(decide_vit_kernel, dim3(gdec, (unsigned) c.n), dim3(256), 0, s, dec);
+  if (record_events) P7X_HIP(hipEventRecord(ws->ev[3], s));
+  if ((st = class_wave(c, ws, &LaneArgs::fwd, false, ctx, s)) != P7X_OK) return st;
+  hipLaunchKernelGGL(decide_fwd_kernel, dim3(gdec, (unsigned) c.n), dim3(256), 0, s, dec);
+  P7X_HIP(hipGetLastError());
+  if (record_events) P7X_HIP(hipEventRecord(ws->ev[4], s));
+  return launch_survivor_passes(r, c, s, false, record_events);
 }
 
 static int cascade_enqueue(CascadeRun &r)
@@ -770,6 +811,8 @@ static int cascade_enqueue(CascadeRun &r)
   if (db->nslots == 0 || nq == 0) return P7X_OK;
   for (int l = 0; l < nq; ++l)
     if (r.lm[l].dp->vitC <= 0 || r.lm[l].dp->vitC > 32) { set_error("model too long for the device kernels (M > 2048)"); return P7X_EINVAL; }
+  std::vector<LaneClass> classes;
+  if ((st = lane_classes(r.lm, db, ctx, classes)) != P7X_OK) return st;
   if ((st = get_workspace(db->device, db->nslots, nq, &r.ws)) != P7X_OK) return st;
   Workspace *ws = r.ws;
   hipStream_t s = ws->stream;
@@ -791,38 +834,45 @@ static int cascade_enqueue(CascadeRun &r)
     a.out_sc = b.fwd_by_item;
     la.fwd = a;
   }
+  if ((st = fill_survivor_args(r, 0, nq, false, 0)) != P7X_OK) return st;
   if ((st = upload_args(ws, 0, nq, s)) != P7X_OK) return st;
-  P7X_HIP(hipMemsetAsync(ws->counters, 0, ws->counters_bytes(), s));
-  // MSV launches that fill the device on their own are chained (two of them sharing the CUs only slow each other
-  // down); small blocks -- a scan's query sequences -- leave most of the device idle and run side by side instead
-  const bool fills_device = (db->nslots / 64) * (int64_t) nq >= (int64_t) ctx->num_cu * 8;
-  if (fills_device) {
-    std::lock_guard<std::mutex> lk(ctx->msv_mu);          // enqueue order == chain order
-    if (ctx->msv_last >= 0) P7X_HIP(hipStreamWaitEvent(s, ctx->msv_done[ctx->msv_last], 0));
-    P7X_HIP(hipEventRecord(ws->ev[0], s));
-    if ((st = run_msv(r.lm, db, ctx, ws, s)) != P7X_OK) return st;
-    P7X_HIP(hipEventRecord(ws->ev[7], s));
-    ctx->msv_last = (ctx->msv_last + 1) & 1;
-    P7X_HIP(hipEventRecord(ctx->msv_done[ctx->msv_last], s));
+  P7X_HIP(hipMemsetAsync(ws->counters, 0, ws->counters_bytes(), s));      // lane counters and the arena cursor
+  if (classes.size() == 1) {
+    const bool fills_device = (db->nslots / 64) * (int64_t) nq >= (int64_t) ctx->num_cu * 8;
+    if ((st = class_cascade(r, classes[0], s, true, fills_device)) != P7X_OK) return st;
   } else {
-    P7X_HIP(hipEventRecord(ws->ev[0], s));
-    if ((st = run_msv(r.lm, db, ctx, ws, s)) != P7X_OK) return st;
-    P7X_HIP(hipEventRecord(ws->ev[7], s));
+    // every class on its own stream, forked from and joined into the workspace's stream
+    P7X_HIP(hipEventRecord(ws->ev_fork, s));
+    const int nside = std::min<int>((int) classes.size() - 1, Workspace::kSide);
+    for (int k = 0; k < nside; ++k) P7X_HIP(hipStreamWaitEvent(ws->side[k], ws->ev_fork, 0));
+    for (size_t c = 0; c < classes.size(); ++c) {
+      hipStream_t cs = c == 0 ? s : ws->side[(c - 1) % Workspace::kSide];
+      if ((st = class_cascade(r, classes[c], cs, c == 0, false)) != P7X_OK) return st;
+    }
+    for (int k = 0; k < nside; ++k) {
+      P7X_HIP(hipEventRecord(ws->ev_join[k], ws->side[k]));
+      P7X_HIP(hipStreamWaitEvent(s, ws->ev_join[k], 0));
+    }
   }
-  const ArgRef dec = lane_run(ws, &LaneArgs::dec, 0, nq).ref();
-  hipLaunchKernelGGL(decide_msv_kernel, dim3((unsigned) ((db->nslots + 255) / 256), (unsigned) nq), dim3(256), 0, s, dec);
-  P7X_HIP(hipEventRecord(ws->ev[1], s));
-  hipLaunchKernelGGL(bias_kernel, dim3(lane_grid((db->nslots + 63) / 64, ctx->num_cu * 4, nq), (unsigned) nq), dim3(64), 0, s, dec);
-  P7X_HIP(hipEventRecord(ws->ev[2], s));
-  if ((st = run_viterbi(r.lm, db, ctx, ws, s)) != P7X_OK) return st;
-  const unsigned gdec = lane_grid((db->nslots + 255) / 256, ctx->num_cu, nq);
-  hipLaunchKernelGGL(decide_vit_kernel, dim3(gdec, (unsigned) nq), dim3(256), 0, s, dec);
-  P7X_HIP(hipEventRecord(ws->ev[3], s));
-  if ((st = run_wave_stage(r.lm, ws, &LaneArgs::fwd, false, ctx, s)) != P7X_OK) return st;
-  hipLaunchKernelGGL(decide_fwd_kernel, dim3(gdec, (unsigned) nq), dim3(256), 0, s, dec);
-  P7X_HIP(hipGetLastError());
-  P7X_HIP(hipEventRecord(ws->ev[4], s));
-  return enqueue_survivor_passes(r, 0, nq, false, 0);
+  P7X_HIP(hipMemcpyAsync(ws->h_counts, ws->counters, ws->counters_bytes(), hipMemcpyDeviceToHost, s));
+  P7X_HIP(hipEventRecord(ws->ev_sync, s));
+  return P7X_OK;
+}
+
+// one lane again, after its survivors did not fit the shared buffers
+static int retry_survivor_passes(CascadeRun &r, int l, int nfin)
+{
+  Workspace *ws = r.ws; hipStream_t s = ws->stream;
+  int st = fill_survivor_args(r, l, 1, true, nfin);
+  if (st != P7X_OK) return st;
+  if ((st = upload_args(ws, l, 1, s)) != P7X_OK) return st;
+  P7X_HIP(hipMemsetAsync(&ws->lane_bufs(l).counters[12], 0, 4, s));
+  P7X_HIP(hipMemsetAsync(ws->cursor(), 0, 8, s));
+  LaneClass c; c.first = l; c.n = 1; c.C = r.lm[l].dp->vitC;
+  if ((st = launch_survivor_passes(r, c, s, true, false)) != P7X_OK) return st;
+  P7X_HIP(hipMemcpyAsync(ws->h_counts, ws->counters, ws->counters_bytes(), hipMemcpyDeviceToHost, s));
+  P7X_HIP(hipEventRecord(ws->ev_sync, s));
+  return P7X_OK;
 }
 
 // download one lane's per-survivor results (queued on the workspace's stream; the caller synchronises)
@@ -878,22 +928,52 @@ static int cascade_collect(CascadeRun &r, std::vector<CascadeOut> &outs)
   int st = P7X_OK;
   P7X_HIP(hipSetDevice(db->device));                      // the collecting thread may have driven another device since
   P7X_HIP(hipEventSynchronize(ws->ev_sync));              // our work only: other cascades run on other streams
-  std::vector<int> flagged;
+  std::vector<int> flagged, few;
+  constexpr int kFew = 64;            // lanes with at most this many survivors are fetched together, one 2-D copy per array
+  int few_w = 0;
   for (int l = 0; l < nq; ++l) {
     CascadeOut &out = outs[(size_t) r.query_of[l]];
     std::memcpy(out.counts, ws->h_counts + (size_t) l * kLaneCounters, kLaneCounters * 4);
+    const int nfin = out.counts[4];
     if (out.counts[12] != 0) flagged.push_back(l);
+    else if (nfin > 0 && nfin <= kFew && nq > 1) { few.push_back(l); few_w = std::max(few_w, nfin); }
     else if ((st = fetch_lane(r, l, false, out)) != P7X_OK) return st;
   }
-  std::vector<std::vector<uint8_t>> by_slot;
+  // staging of the lanes with few survivors: rows = lanes few.front() .. few.back(), few_w survivors wide
+  const int few_lo = few.empty() ? 0 : few.front(), few_h = few.empty() ? 0 : few.back() - few.front() + 1;
+  std::vector<int32_t> st_fin, st_regn, st_regs; std::vector<int64_t> st_off; std::vector<float> st_nexp, st_fwd;
+  if (!few.empty()) {
+    const size_t cells = (size_t) few_h * few_w;
+    const int64_t cap = ws->fin_cap;
+    st_fin.resize(cells); st_regn.resize(cells); st_off.resize(cells); st_nexp.resize(cells); st_fwd.resize(cells);
+    st_regs.resize(cells * kRegionCap * 3);
+    const StageBufs b0 = ws->lane_bufs(few_lo);
+    const int32_t *reg0 = ws->reg_out + (size_t) few_lo * cap * (kRegionCap * 3 + 2);
+    const size_t reg_pitch = (size_t) cap * (kRegionCap * 3 + 2) * 4;
+    P7X_HIP(hipMemcpy2DAsync(st_fin.data(), (size_t) few_w * 4, b0.list_fin, (size_t) ws->cap_slots * 4, (size_t) few_w * 4, few_h, hipMemcpyDeviceToHost, s));
+    P7X_HIP(hipMemcpy2DAsync(st_fwd.data(), (size_t) few_w * 4, b0.fwd_by_item, (size_t) ws->cap_slots * 4, (size_t) few_w * 4, few_h, hipMemcpyDeviceToHost, s));
+    P7X_HIP(hipMemcpy2DAsync(st_off.data(), (size_t) few_w * 8, ws->xmx_off + (size_t) few_lo * cap, (size_t) cap * 8, (size_t) few_w * 8, few_h, hipMemcpyDeviceToHost, s));
+    P7X_HIP(hipMemcpy2DAsync(st_regs.data(), (size_t) few_w * kRegionCap * 3 * 4, reg0, reg_pitch, (size_t) few_w * kRegionCap * 3 * 4, few_h, hipMemcpyDeviceToHost, s));
+    P7X_HIP(hipMemcpy2DAsync(st_regn.data(), (size_t) few_w * 4, reg0 + (size_t) cap * kRegionCap * 3, reg_pitch, (size_t) few_w * 4, few_h, hipMemcpyDeviceToHost, s));
+    P7X_HIP(hipMemcpy2DAsync(st_nexp.data(), (size_t) few_w * 4, reg0 + (size_t) cap * (kRegionCap * 3 + 1), reg_pitch, (size_t) few_w * 4, few_h, hipMemcpyDeviceToHost, s));
+  }
+  std::vector<uint8_t> by_slot;
   if (cfg.mode == P7X_SCAN_MODELS) {        // per-target accounting: which filters every (model, sequence) pair passed
-    by_slot.resize((size_t) nq);
-    for (int l = 0; l < nq; ++l) {
-      by_slot[l].resize((size_t) db->nslots);
-      P7X_HIP(hipMemcpyAsync(by_slot[l].data(), ws->lane_bufs(l).stage, by_slot[l].size(), hipMemcpyDeviceToHost, s));
-    }
+    by_slot.resize((size_t) nq * (size_t) db->nslots);
+    P7X_HIP(hipMemcpy2DAsync(by_slot.data(), (size_t) db->nslots, ws->stage, (size_t) ws->cap_slots, (size_t) db->nslots, nq, hipMemcpyDeviceToHost, s));
   }
   P7X_HIP(hipEventRecord(ws->ev_sync, s)); P7X_HIP(hipEventSynchronize(ws->ev_sync));
+  for (int l : few) {
+    CascadeOut &out = outs[(size_t) r.query_of[l]];
+    const int nfin = out.counts[4];
+    const size_t row = (size_t) (l - few_lo) * few_w;
+    out.fin_slots.assign(st_fin.begin() + row, st_fin.begin() + row + nfin);
+    out.fwdsc.assign(st_fwd.begin() + row, st_fwd.begin() + row + nfin);
+    out.xmx_off.assign(st_off.begin() + row, st_off.begin() + row + nfin);
+    out.reg_n.assign(st_regn.begin() + row, st_regn.begin() + row + nfin);
+    out.nexpected.assign(st_nexp.begin() + row, st_nexp.begin() + row + nfin);
+    out.regs.assign(st_regs.begin() + row * kRegionCap * 3, st_regs.begin() + (row + nfin) * kRegionCap * 3);
+  }
   for (int l = 0; l < nq; ++l) {
     CascadeOut &out = outs[(size_t) r.query_of[l]];
     if (out.counts[12] == 0 && (st = fetch_lane_rows(r, out)) != P7X_OK) return st;
@@ -902,7 +982,7 @@ static int cascade_collect(CascadeRun &r, std::vector<CascadeOut> &outs)
   // buffers sized for the lane's own count
   for (int l : flagged) {
     CascadeOut &out = outs[(size_t) r.query_of[l]];
-    if ((st = enqueue_survivor_passes(r, l, 1, true, out.counts[4])) != P7X_OK) return st;
+    if ((st = retry_survivor_passes(r, l, out.counts[4])) != P7X_OK) return st;
     P7X_HIP(hipEventSynchronize(ws->ev_sync));
     std::memcpy(out.counts, ws->h_counts + (size_t) l * kLaneCounters, kLaneCounters * 4);
     if (out.counts[12] != 0) { set_error("row buffers could not be sized for the Forward survivors"); return P7X_EMEM; }
@@ -918,7 +998,8 @@ static int cascade_collect(CascadeRun &r, std::vector<CascadeOut> &outs)
     std::memcpy(out.ms, ms, sizeof(ms));
     if (cfg.mode == P7X_SCAN_MODELS) {
       out.stage.assign((size_t) db->n, 0);
-      for (int64_t sl = 0; sl < db->nslots; ++sl) out.stage[(size_t) db->h_order[sl]] = by_slot[l][(size_t) sl];
+      const uint8_t *row = by_slot.data() + (size_t) l * (size_t) db->nslots;
+      for (int64_t sl = 0; sl < db->nslots; ++sl) out.stage[(size_t) db->h_order[sl]] = row[(size_t) sl];
     }
   }
   return P7X_OK;
@@ -944,6 +1025,12 @@ int p7x_filters_batch(const p7x_oprofile *om, const p7x_seqdb *db, int32_t *xJ, 
   if ((st = get_dev_profile(om, ctx, &lm[0].dp)) != P7X_OK) return st;
   DevProfile *dp = lm[0].dp;
   const int64_t ns = db->nslots;
+  LaneClass cls;
+  {
+    const bool small = small_block(db, ctx, 1);
+    cls.first = 0; cls.n = 1; cls.msv_key = msv_key_of(dp, small); cls.vit_key = vit_key_of(dp, small); cls.C = dp->vitC;
+    if (xJ && cls.msv_key < 0 && !dp->msvw_emis) { set_error("model too long for the MSV kernels (M > 2048)"); return P7X_EINVAL; }
+  }
   for (int64_t t = 0; t < db->n; ++t) {
     if (xJ) xJ[t] = 0;
     if (xC) xC[t] = -32768;
@@ -976,7 +1063,7 @@ int p7x_filters_batch(const p7x_oprofile *om, const p7x_seqdb *db, int32_t *xJ, 
   if ((st = upload_args(ws, 0, 1, s)) != P7X_OK) return st;
   P7X_HIP(hipMemsetAsync(ws->counters, 0, ws->counters_bytes(), s));
   if (xJ) {
-    if ((st = run_msv(lm, db, ctx, ws, s)) != P7X_OK) return st;
+    if ((st = class_msv(cls, lm, ctx, ws, s)) != P7X_OK) return st;
     std::vector<int16_t> h((size_t) ns);
     P7X_HIP(hipMemcpyAsync(h.data(), b.xJ, (size_t) ns * 2, hipMemcpyDeviceToHost, s));
     P7X_HIP(hipStreamSynchronize(s));
@@ -985,14 +1072,14 @@ int p7x_filters_batch(const p7x_oprofile *om, const p7x_seqdb *db, int32_t *xJ, 
   if (xC || fwd) {
     if (dp->vitC <= 0) { set_error("model too long for the wave-per-sequence kernels"); return P7X_EINVAL; }
     if (xC) {
-      if ((st = run_viterbi(lm, db, ctx, ws, s)) != P7X_OK) return st;
+      if ((st = class_viterbi(cls, lm, ctx, ws, s)) != P7X_OK) return st;
       std::vector<int32_t> h((size_t) ns);
       P7X_HIP(hipMemcpyAsync(h.data(), b.xC, (size_t) ns * 4, hipMemcpyDeviceToHost, s));
       P7X_HIP(hipStreamSynchronize(s));
       for (int64_t sl = 0; sl < ns; ++sl) xC[db->h_order[sl]] = h[sl];
     }
     if (fwd) {
-      if ((st = run_wave_stage(lm, ws, &LaneArgs::fwd, false, ctx, s)) != P7X_OK) return st;
+      if ((st = class_wave(cls, ws, &LaneArgs::fwd, false, ctx, s)) != P7X_OK) return st;
       std::vector<float> h((size_t) ns);
       P7X_HIP(hipMemcpyAsync(h.data(), b.fwd_by_item, (size_t) ns * 4, hipMemcpyDeviceToHost, s));
       P7X_HIP(hipStreamSynchronize(s));
@@ -1176,31 +1263,39 @@ int p7x_search_batch_finish(p7x_pending *pd, const char *const *names, const cha
   const p7x_seqdb *db = pd->db;
   HostTargets tg;
   tg.n = db->n; tg.nres = db->nres; tg.len = db->h_len.data(); tg.off = db->h_off.data(); tg.dsq = db->h_dsq.data();
-  auto fail = [&](int st) { for (size_t q = 0; q < nq; ++q) { delete outs[q]; outs[q] = nullptr; } return st; };
+  const auto t1 = std::chrono::steady_clock::now();
+  std::vector<std::vector<int32_t>> targets(nq);
+  std::vector<DeviceRegions> dr(nq);
+  std::vector<FinishItem> items(nq);
+  bool any_device = false;
   for (size_t q = 0; q < nq; ++q) {
-    const auto t1 = std::chrono::steady_clock::now();
     const p7x_oprofile *om = pd->run.oms[q]; CascadeOut &co = pd->co[q];
-    std::vector<int32_t> targets(co.fin_slots.size());
-    for (size_t i = 0; i < targets.size(); ++i) targets[i] = db->h_order[co.fin_slots[i]];
-    const uint64_t counts[4] = { (uint64_t) co.counts[1], (uint64_t) co.counts[8], (uint64_t) co.counts[3], (uint64_t) co.counts[4] };
-    int st = P7X_OK;
-    std::unique_ptr<EnvelopeScorer> scorer;
-    const bool env_fits = om->p.M <= 1024;        // env_kernel keeps the emission table in LDS; longer models are rescored on the host
-    if (!g_host_envelopes && !pd->cfg.host_envelopes && !targets.empty() && env_fits) {
-      DeviceCtx *ctx = nullptr; DevProfile *dp = nullptr;
-      if ((st = get_ctx(db->device, &ctx)) != P7X_OK || (st = get_dev_profile(om, ctx, &dp)) != P7X_OK) return fail(st);
-      scorer = make_device_envelope_scorer(ctx, dp, db, om->p);
-    }
-    const double stage1 = co.ms[6];
-    DeviceRegions dr;
-    if (!co.have_xmx && !targets.empty()) { dr.n = co.reg_n.data(); dr.regs = co.regs.data(); dr.nexpected = co.nexpected.data(); dr.cap = kRegionCap; }
-    st = host_finish_search(pd->cfg, om, tg, names, accs, descs, targets, co.fwdsc.data(), co.fwd_xmx.data(), co.bck_xmx.data(),
-                            co.xmx_off.data(), counts, co.ms, &outs[q], scorer.get(), dr.n ? &dr : nullptr);
-    if (st != P7X_OK) return fail(st);
+    targets[q].resize(co.fin_slots.size());
+    for (size_t i = 0; i < targets[q].size(); ++i) targets[q][i] = db->h_order[co.fin_slots[i]];
+    FinishItem &it = items[q];
+    it.om = om; it.targets = &targets[q]; it.fwdsc = co.fwdsc.data();
+    it.fwd_xmx = co.fwd_xmx.data(); it.bck_xmx = co.bck_xmx.data(); it.xmx_off = co.xmx_off.data();
+    it.counts[0] = (uint64_t) co.counts[1]; it.counts[1] = (uint64_t) co.counts[8]; it.counts[2] = (uint64_t) co.counts[3]; it.counts[3] = (uint64_t) co.counts[4];
+    it.ms = co.ms;
+    if (!co.have_xmx && !targets[q].empty()) { dr[q].n = co.reg_n.data(); dr[q].regs = co.regs.data(); dr[q].nexpected = co.nexpected.data(); dr[q].cap = kRegionCap; it.regions = &dr[q]; }
+    // env_kernel keeps the emission table in LDS; longer models are rescored on the host
+    it.device_envelopes = !g_host_envelopes && !pd->cfg.host_envelopes && !targets[q].empty() && om->p.M <= 1024;
+    any_device = any_device || it.device_envelopes;
+  }
+  int st = P7X_OK;
+  std::unique_ptr<EnvelopeScorer> scorer;
+  if (any_device) {
+    DeviceCtx *ctx = nullptr;
+    if ((st = get_ctx(db->device, &ctx)) != P7X_OK) return st;
+    scorer = make_device_envelope_scorer(ctx, db);
+  }
+  if ((st = host_finish_batch(pd->cfg, items, tg, names, accs, descs, outs, scorer.get())) != P7X_OK) return st;
+  // work time of this batch (stage 1 + stage 2), not the time it spent queued between the stages
+  const double stage2 = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t1).count();
+  for (size_t q = 0; q < nq; ++q) {
+    CascadeOut &co = pd->co[q];
     if (!co.stage.empty()) tophits_set_stages(outs[q], std::move(co.stage));
-    // work time of this search (stage 1 + stage 2), not the time it spent queued between the stages
-    const double stage2 = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t1).count();
-    tophits_set_total_ms(outs[q], stage1, stage2);
+    tophits_set_total_ms(outs[q], co.ms[6], stage2);
   }
   return P7X_OK;
 }

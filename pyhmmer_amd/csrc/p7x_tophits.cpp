@@ -273,6 +273,151 @@ static void threshold(p7x_tophits &th)
           }
 }
 
+// The host stage of a batch of queries against one target block.  The per-survivor phases run over the survivors of
+// ALL queries at once (one parallel region per phase, not per query), and the single-domain envelopes of all queries
+// go to the device in one submission (one launch per model-length class).
+int host_finish_batch(const p7x_pipeline_cfg &cfg_in, const std::vector<FinishItem> &items, const HostTargets &tg,
+                      const char *const *names, const char *const *accs, const char *const *descs,
+                      p7x_tophits **outs, EnvelopeScorer *scorer)
+{
+  const int nq = (int) items.size();
+  std::vector<std::unique_ptr<p7x_tophits>> ths((size_t) nq);
+  std::vector<int> first((size_t) nq + 1, 0);            // flattened survivor index of every query's first survivor
+  for (int q = 0; q < nq; ++q) {
+    const FinishItem &it = items[(size_t) q];
+    const Profile &p = it.om->p;
+    auto th = std::make_unique<p7x_tophits>();
+    th->cfg = cfg_in;
+    apply_bit_cutoffs(th->cfg, p);
+    th->qname = p.name; th->qacc = p.acc; th->qdesc = p.desc; th->q_has_acc = p.has_acc; th->q_has_desc = p.has_desc;
+    th->M = p.M;
+    th->ctr.nmodels = 1; th->ctr.nnodes = (uint64_t) p.M;
+    th->ctr.nseqs = (uint64_t) tg.n; th->ctr.nres = (uint64_t) tg.nres;
+    th->ctr.n_past_msv = it.counts[0]; th->ctr.n_past_bias = it.counts[1];
+    th->ctr.n_past_vit = it.counts[2]; th->ctr.n_past_fwd = it.counts[3];
+    if (it.ms) for (int i = 0; i < 8; ++i) th->ms[i] = it.ms[i];
+    ths[(size_t) q] = std::move(th);
+    first[(size_t) q + 1] = first[(size_t) q] + (int) it.targets->size();
+  }
+  const int S = first[(size_t) nq];
+  const auto t0 = std::chrono::steady_clock::now();
+  std::vector<Pending> pend((size_t) S);
+  std::atomic<int> failed{0};
+  int nthreads = cfg_in.host_threads > 0 ? cfg_in.host_threads : usable_cpus();
+  if (nthreads < 1) nthreads = 1;
+  if (nthreads > (S + 3) / 4) nthreads = (S + 3) / 4;      // at least ~4 targets per worker
+  if (nthreads < 1) nthreads = 1;
+  auto run_pool = [&](int count, const std::function<void(int)> &body) { HostPool::get().run(count, nthreads, body); };
+  // flattened survivor f -> (query q, survivor i of q)
+  std::vector<int> q_of((size_t) S);
+  for (int q = 0; q < nq; ++q) for (int f = first[(size_t) q]; f < first[(size_t) q + 1]; ++f) q_of[(size_t) f] = q;
+  const bool reseed = cfg_in.seed != 0;
+  auto finish = [&](int f, DomainDefResult &dd) {
+    const int q = q_of[(size_t) f], i = f - first[(size_t) q];
+    const FinishItem &it = items[(size_t) q];
+    const p7x_pipeline_cfg &cfg = ths[(size_t) q]->cfg;
+    const int t = (*it.targets)[(size_t) i];
+    const double Zrun = (cfg.Z_setby == P7X_ZSETBY_NTARGETS) ? (double) (t + 1) : cfg.Z;
+    finish_one(cfg, it.om->p, tg.len[t], it.fwdsc[i], Zrun, dd, pend[(size_t) f]);
+    if (pend[(size_t) f].have) pend[(size_t) f].hit.seqidx = t;
+  };
+  // regions come from the device scan when there is one, else from the parsers' rows
+  auto define = [&](int f, DomainDefResult &dd, std::vector<EnvelopeRequest> *defer) -> int {
+    const int q = q_of[(size_t) f], i = f - first[(size_t) q];
+    const FinishItem &it = items[(size_t) q];
+    const Profile &p = it.om->p;
+    const int t = (*it.targets)[(size_t) i];
+    const uint8_t *dsq = tg.dsq + tg.off[t] - 1;
+    if (!it.regions)
+      return domaindef_by_posterior_heuristics(p, dsq, tg.len[t], it.fwd_xmx + it.xmx_off[i], it.bck_xmx + it.xmx_off[i], cfg_in.seed, reseed, dd, defer, i);
+    const DeviceRegions *dregs = it.regions;
+    const int nr = dregs->n[i];
+    if (nr < 0) return P7X_ERANGE;
+    Region regs[256];
+    const int32_t *src = dregs->regs + (size_t) i * dregs->cap * 3;
+    for (int r = 0; r < nr && r < 256; ++r) regs[r] = Region{ src[r * 3], src[r * 3 + 1], src[r * 3 + 2] != 0 };
+    return domaindef_from_regions(p, dsq, tg.len[t], dregs->nexpected[i], regs, nr, cfg_in.seed, reseed, dd, defer, i);
+  };
+  auto on_device = [&](int q) { return scorer != nullptr && items[(size_t) q].device_envelopes; };
+  // 1. regions (cheap); single-domain envelopes of the queries that use the device are queued for it, the others
+  //    (the CPU test seam, models the envelope kernel does not cover) are rescored right here
+  std::vector<DomainDefResult> dds((size_t) S);
+  std::vector<std::vector<EnvelopeRequest>> local((size_t) S);
+  run_pool(S, [&](int f) {
+    const bool dev = on_device(q_of[(size_t) f]);
+    const int st = define(f, dds[(size_t) f], dev ? &local[(size_t) f] : nullptr);
+    if (st != P7X_OK) { failed.store(st); return; }
+    if (!dev) finish(f, dds[(size_t) f]);
+  });
+  double ms_multi = 0.0, ms_env = 0.0;
+  if (failed.load() == 0 && scorer) {
+    std::vector<std::vector<EnvelopeRequest>> req((size_t) nq);
+    std::vector<std::vector<int>> req_index((size_t) S);
+    std::vector<int> heavy;
+    for (int f = 0; f < S; ++f) {
+      const int q = q_of[(size_t) f];
+      if (!on_device(q)) continue;
+      for (const EnvelopeRequest &r : local[(size_t) f]) { req_index[(size_t) f].push_back((int) req[(size_t) q].size()); req[(size_t) q].push_back(r); }
+      if (!dds[(size_t) f].multi.empty()) heavy.push_back(f);
+    }
+    // 2. the envelope kernels run while the host resolves the multi-domain regions (stochastic traceback
+    //    ensembles: inherently sequential per region, so they are spread over the workers target by target)
+    const auto t1 = std::chrono::steady_clock::now();
+    std::vector<EnvelopeJob> jobs((size_t) nq);
+    bool any = false;
+    for (int q = 0; q < nq; ++q) { jobs[(size_t) q] = EnvelopeJob{ items[(size_t) q].om, &req[(size_t) q], items[(size_t) q].targets }; any = any || !req[(size_t) q].empty(); }
+    if (any) { const int st = scorer->begin(jobs); if (st != P7X_OK) return st; }
+    run_pool((int) heavy.size(), [&](int h) {
+      const int f = heavy[(size_t) h], q = q_of[(size_t) f], i = f - first[(size_t) q];
+      const int t = (*items[(size_t) q].targets)[(size_t) i];
+      const int st = domaindef_finish_multi(items[(size_t) q].om->p, tg.dsq + tg.off[t] - 1, tg.len[t], cfg_in.seed, reseed, dds[(size_t) f]);
+      if (st != P7X_OK) failed.store(st);
+    });
+    ms_multi = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t1).count();
+    std::vector<std::vector<EnvelopeResult>> res((size_t) nq);
+    if (any) { const int st = scorer->wait(res); if (st != P7X_OK) return st; }
+    ms_env = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t1).count();
+    // 3. alignment displays, null2 corrections, per-target scores
+    if (failed.load() == 0)
+      run_pool(S, [&](int f) {
+        const int q = q_of[(size_t) f];
+        if (!on_device(q)) return;
+        const int i = f - first[(size_t) q];
+        const int t = (*items[(size_t) q].targets)[(size_t) i];
+        domaindef_finish_deferred(items[(size_t) q].om->p, tg.dsq + tg.off[t] - 1, tg.len[t], res[(size_t) q], req_index[(size_t) f], dds[(size_t) f]);
+        finish(f, dds[(size_t) f]);
+      });
+  }
+  host_prof_dump();
+  if (failed.load() != 0) { set_error("domain definition workflow failure"); return failed.load(); }
+  const double ms_host = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+  // 4. one hit list per query: hits in target order, as the reference's sequential loop would have appended them
+  run_pool(nq, [&](int q) {
+    const FinishItem &it = items[(size_t) q];
+    p7x_tophits &th = *ths[(size_t) q];
+    const int n = (int) it.targets->size(), f0 = first[(size_t) q];
+    std::vector<int> idx((size_t) n);
+    for (int i = 0; i < n; ++i) idx[(size_t) i] = i;
+    std::sort(idx.begin(), idx.end(), [&](int a, int b) { return (*it.targets)[(size_t) a] < (*it.targets)[(size_t) b]; });
+    for (int i : idx) {
+      if (!pend[(size_t) (f0 + i)].have) continue;
+      Hit &h = pend[(size_t) (f0 + i)].hit;
+      const int t = (*it.targets)[(size_t) i];
+      if (names && names[t]) h.name = names[t];
+      if (accs && accs[t] && accs[t][0]) { h.acc = accs[t]; h.has_acc = true; }
+      if (descs && descs[t] && descs[t][0]) { h.desc = descs[t]; h.has_desc = true; }
+      th.hits.push_back(std::move(h));
+    }
+    th.ms[5] = ms_host; th.ms[8] = ms_env; th.ms[9] = ms_multi;
+    // Z for E-values: number of targets seen (p7_pli_NewSeq), unless set by the caller
+    if (th.cfg.Z_setby == P7X_ZSETBY_NTARGETS) th.cfg.Z = (double) tg.n;
+    sort_by_key(th);
+    threshold(th);
+  });
+  for (int q = 0; q < nq; ++q) outs[q] = ths[(size_t) q].release();
+  return P7X_OK;
+}
+
 int host_finish_search(const p7x_pipeline_cfg &cfg_in, const p7x_oprofile *om, const HostTargets &tg,
                        const char *const *names, const char *const *accs, const char *const *descs,
                        const std::vector<int32_t> &tgt, const float *fwdsc,
@@ -280,116 +425,12 @@ int host_finish_search(const p7x_pipeline_cfg &cfg_in, const p7x_oprofile *om, c
                        const uint64_t *counts, const double *ms, p7x_tophits **out, EnvelopeScorer *scorer,
                        const DeviceRegions *dregs)
 {
-  const Profile &p = om->p;
-  auto th = std::make_unique<p7x_tophits>();
-  th->cfg = cfg_in;
-  p7x_pipeline_cfg &cfg = th->cfg;
-  apply_bit_cutoffs(cfg, p);
-  th->qname = p.name; th->qacc = p.acc; th->qdesc = p.desc; th->q_has_acc = p.has_acc; th->q_has_desc = p.has_desc;
-  th->M = p.M;
-  th->ctr.nmodels = 1; th->ctr.nnodes = (uint64_t) p.M;
-  th->ctr.nseqs = (uint64_t) tg.n; th->ctr.nres = (uint64_t) tg.nres;
-  th->ctr.n_past_msv = counts[0]; th->ctr.n_past_bias = counts[1];
-  th->ctr.n_past_vit = counts[2]; th->ctr.n_past_fwd = counts[3];
-  if (ms) for (int i = 0; i < 8; ++i) th->ms[i] = ms[i];
-
-  const auto t0 = std::chrono::steady_clock::now();
-  const int n = (int) tgt.size();
-  std::vector<Pending> pend((size_t) n);
-  std::atomic<int> failed{0};
-  int nthreads = cfg.host_threads > 0 ? cfg.host_threads : usable_cpus();
-  if (nthreads < 1) nthreads = 1;
-  if (nthreads > (n + 3) / 4) nthreads = (n + 3) / 4;      // at least ~4 targets per worker
-  if (nthreads < 1) nthreads = 1;
-  auto run_pool = [&](int count, const std::function<void(int)> &body) { HostPool::get().run(count, nthreads, body); };
-  auto finish = [&](int i, DomainDefResult &dd) {
-    const int t = tgt[i];
-    const double Zrun = (cfg.Z_setby == P7X_ZSETBY_NTARGETS) ? (double) (t + 1) : cfg.Z;
-    finish_one(cfg, p, tg.len[t], fwdsc[i], Zrun, dd, pend[i]);
-    if (pend[i].have) pend[i].hit.seqidx = t;
-  };
-  const bool reseed = cfg.seed != 0;
-  // regions come from the device scan when there is one, else from the parsers' rows
-  auto define = [&](int i, DomainDefResult &dd, std::vector<EnvelopeRequest> *defer) -> int {
-    const int t = tgt[i];
-    const uint8_t *dsq = tg.dsq + tg.off[t] - 1;
-    if (!dregs)
-      return domaindef_by_posterior_heuristics(p, dsq, tg.len[t], fwd_xmx + xmx_off[i], bck_xmx + xmx_off[i], cfg.seed, reseed, dd, defer, i);
-    const int nr = dregs->n[i];
-    if (nr < 0) return P7X_ERANGE;
-    Region regs[256];
-    const int32_t *src = dregs->regs + (size_t) i * dregs->cap * 3;
-    for (int r = 0; r < nr && r < 256; ++r) regs[r] = Region{ src[r * 3], src[r * 3 + 1], src[r * 3 + 2] != 0 };
-    return domaindef_from_regions(p, dsq, tg.len[t], dregs->nexpected[i], regs, nr, cfg.seed, reseed, dd, defer, i);
-  };
-  if (!scorer) {
-    // everything on the host (CPU test seam, and the fallback for models the envelope kernel does not cover)
-    run_pool(n, [&](int i) {
-      DomainDefResult dd;
-      const int st = define(i, dd, nullptr);
-      if (st != P7X_OK) { failed.store(st); return; }
-      finish(i, dd);
-    });
-  } else {
-    // 1. regions (cheap); single-domain envelopes are queued for the device
-    std::vector<DomainDefResult> dds((size_t) n);
-    std::vector<std::vector<EnvelopeRequest>> local((size_t) n);
-    run_pool(n, [&](int i) {
-      const int st = define(i, dds[i], &local[i]);
-      if (st != P7X_OK) failed.store(st);
-    });
-    if (failed.load() == 0) {
-      std::vector<EnvelopeRequest> req;
-      std::vector<std::vector<int>> req_index((size_t) n);
-      std::vector<int> heavy;
-      for (int i = 0; i < n; ++i) {
-        for (const EnvelopeRequest &r : local[i]) { req_index[i].push_back((int) req.size()); req.push_back(r); }
-        if (!dds[i].multi.empty()) heavy.push_back(i);
-      }
-      // 2. the envelope kernel runs while the host resolves the multi-domain regions (stochastic traceback
-      //    ensembles: inherently sequential per region, so they are spread over the workers target by target)
-      const auto t1 = std::chrono::steady_clock::now();
-      if (!req.empty()) { const int st = scorer->begin(req, tgt); if (st != P7X_OK) return st; }
-      run_pool((int) heavy.size(), [&](int h) {
-        const int i = heavy[(size_t) h], t = tgt[i];
-        const int st = domaindef_finish_multi(p, tg.dsq + tg.off[t] - 1, tg.len[t], cfg.seed, reseed, dds[i]);
-        if (st != P7X_OK) failed.store(st);
-      });
-      th->ms[9] = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t1).count();
-      std::vector<EnvelopeResult> res;
-      if (!req.empty()) { const int st = scorer->wait(res); if (st != P7X_OK) return st; }
-      th->ms[8] = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t1).count();
-      // 3. alignment displays, null2 corrections, per-target scores
-      if (failed.load() == 0)
-        run_pool(n, [&](int i) {
-          const int t = tgt[i];
-          domaindef_finish_deferred(p, tg.dsq + tg.off[t] - 1, tg.len[t], res, req_index[i], dds[i]);
-          finish(i, dds[i]);
-        });
-    }
-  }
-  host_prof_dump();
-  if (failed.load() != 0) { set_error("domain definition workflow failure"); return failed.load(); }
-  // hits in target order, as the reference's sequential loop would have appended them
-  std::vector<int> idx((size_t) n);
-  for (int i = 0; i < n; ++i) idx[i] = i;
-  std::sort(idx.begin(), idx.end(), [&](int a, int b) { return tgt[a] < tgt[b]; });
-  for (int i : idx) {
-    if (!pend[i].have) continue;
-    Hit &h = pend[i].hit;
-    const int t = tgt[i];
-    if (names && names[t]) h.name = names[t];
-    if (accs && accs[t] && accs[t][0]) { h.acc = accs[t]; h.has_acc = true; }
-    if (descs && descs[t] && descs[t][0]) { h.desc = descs[t]; h.has_desc = true; }
-    th->hits.push_back(std::move(h));
-  }
-  th->ms[5] = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
-  // Z for E-values: number of targets seen (p7_pli_NewSeq), unless set by the caller
-  if (cfg.Z_setby == P7X_ZSETBY_NTARGETS) cfg.Z = (double) tg.n;
-  sort_by_key(*th);
-  threshold(*th);
-  *out = th.release();
-  return P7X_OK;
+  std::vector<FinishItem> items(1);
+  FinishItem &it = items[0];
+  it.om = om; it.targets = &tgt; it.fwdsc = fwdsc; it.fwd_xmx = fwd_xmx; it.bck_xmx = bck_xmx; it.xmx_off = xmx_off;
+  for (int i = 0; i < 4; ++i) it.counts[i] = counts[i];
+  it.ms = ms; it.regions = dregs; it.device_envelopes = scorer != nullptr;
+  return host_finish_batch(cfg_in, items, tg, names, accs, descs, out, scorer);
 }
 
 void tophits_set_stages(p7x_tophits *th, std::vector<uint8_t> &&stage) { th->stage = std::move(stage); }

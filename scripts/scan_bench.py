@@ -1,5 +1,6 @@
 """hmmscan orientation timing: the fixture proteome (2,100 sequences) against N x 14 profiles (every profile its own
-OptimizedProfile object, so each one pays for its device image), for several feeder / window settings."""
+OptimizedProfile object, so each one pays for its device image), for several batch / feeder / window settings, and the
+host time of the three phases of one batch (enqueue / wait / finish) on a single thread."""
 import sys, time
 sys.path.insert(0, "."); sys.path.insert(0, "tests")
 from conftest import load_hmms, GOLDEN
@@ -22,21 +23,30 @@ def fresh():
 oms, tb = fresh()
 print(f"{len(oms)} profiles built on the host in {1e3 * tb / len(oms):.3f} ms/profile")
 cells = sum(om.M for om in oms) * block.total_length()
-list(hmmer.hmmscan(block, oms[:14]))          # warm-up: kernels, workspaces
-for feeders, depth, window in ((1, 2, 1), (4, 8, 1), (1, 8, 8), (2, 32, 8), (2, 64, 16), (4, 64, 8), (1, 32, 32)):
+list(hmmer.hmmscan(block, oms[:28]))          # warm-up: kernels, workspaces
+for batch, feeders, depth, window in ((1, 4, 32, 4), (8, 2, 6, 2), (32, 2, 6, 2), (64, 2, 6, 2), (64, 1, 2, 1), (128, 2, 4, 1), (256, 2, 4, 1)):
     oms, _ = fresh()
     t0 = time.perf_counter()
-    res = list(hmmer.hmmscan(block, oms, feeders=feeders, pipeline_depth=depth, window=window))
+    res = list(hmmer.hmmscan(block, oms, feeders=feeders, pipeline_depth=depth, window=window, batch=batch))
     dt = time.perf_counter() - t0
-    print(f"feeders {feeders:2d} depth {depth:2d} window {window:2d}: {len(oms)} profiles x {len(block)} seqs in {dt:6.3f} s = "
+    print(f"batch {batch:3d} feeders {feeders:2d} depth {depth:2d} window {window:2d}: {len(oms)} profiles x {len(block)} seqs in {dt:6.3f} s = "
           f"{1e3 * dt / len(oms):6.3f} ms/profile, {cells / dt / 1e9:8.1f} GCUPS, hits {sum(len(r) for r in res)}", flush=True)
-acc = {}
-n = 0
-oms, _ = fresh()
+# resident images (second pass over the same OptimizedProfile objects)
 t0 = time.perf_counter()
-for h in hmmer.hmmsearch(oms, block, feeders=1, pipeline_depth=2):
-    n += 1
-    for k, v in h.timings_ms.items():
-        acc[k] = acc.get(k, 0.0) + v
+res = list(hmmer.hmmscan(block, oms, batch=64))
 dt = time.perf_counter() - t0
-print(f"hmmsearch (one feeder): {1e3 * dt / n:.3f} ms/profile;", {k: round(v / n, 3) for k, v in acc.items()})
+print(f"batch 64, device images already resident: {1e3 * dt / len(oms):6.3f} ms/profile, {cells / dt / 1e9:8.1f} GCUPS")
+# phases of one batch on one thread
+db = plan7.SequenceDatabase(block)
+pli = plan7.Pipeline(block.alphabet)
+for B in (1, 16, 64):
+    acc = [0.0, 0.0, 0.0]
+    nb = 0
+    for lo in range(0, min(len(oms), 8 * B), B):
+        qs = oms[lo:lo + B]
+        t0 = time.perf_counter(); pend = pli._search_enqueue_batch(qs, db)
+        t1 = time.perf_counter(); plan7.Pipeline._search_wait(pend)
+        t2 = time.perf_counter(); plan7.Pipeline._search_finish_batch(pend)
+        t3 = time.perf_counter()
+        acc[0] += t1 - t0; acc[1] += t2 - t1; acc[2] += t3 - t2; nb += len(qs)
+    print(f"one thread, batch {B:3d}: enqueue {1e3 * acc[0] / nb:.3f}  wait {1e3 * acc[1] / nb:.3f}  finish {1e3 * acc[2] / nb:.3f} ms per profile")
