@@ -185,6 +185,90 @@ def cpu_baseline(hmm, bg, flat, offsets, lengths, n, L_hint):
     }
 
 
+def shard_bounds(lengths, world):
+    """Residue-balanced contiguous target shards (hmmer.make_chunks / _hmmsearch.py:153-171 on the packed arrays)."""
+    csum = np.cumsum(lengths.astype(np.int64))
+    total = int(csum[-1])
+    cuts = [0]
+    for r in range(1, world):
+        cuts.append(int(np.searchsorted(csum, total * r / world, side="left")) + 1)
+    cuts.append(len(lengths))
+    return cuts
+
+
+def run_pfam(args, rank, world, local_rank, dist, red_dev, torch, host_threads):
+    """the first `--pfam-profiles` entries of the synthetic 20k-profile library against
+    `--pfam-targets` Swiss-Prot-shaped targets, STRONG scaling: the targets are sharded by residues over the ranks,
+    every rank searches every profile against its shard, rank 0 gathers the per-rank hit lists and merges them per
+    query (TopHits.merge) -- all inside the timed region.  Profiles (device images) and targets are resident in HBM
+    before the clock starts, like a pressed database and a loaded proteome."""
+    import bench_workloads as bw
+    from pyhmmer_amd import hmmer, plan7
+    t0 = time.perf_counter()
+    hmms, lib_lengths, templates = bw.make_library(args.pfam_library, device=local_rank, count=args.pfam_profiles)
+    bg = plan7.Background(hmms[0].alphabet)
+    oms = [plan7.OptimizedProfile(h, bg, 400) for h in hmms]
+    t_lib = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    frac = min(0.5, 12.5 * len(hmms) / args.pfam_targets)
+    flat, offsets, lengths, nplanted = bw.make_targets(args.pfam_targets, len(hmms), templates, lib_lengths, planted_frac=frac)
+    cuts = shard_bounds(lengths, world)
+    lo, hi = cuts[rank], cuts[rank + 1]
+    db = plan7.SequenceDatabase.from_packed(hmms[0].alphabet, flat, offsets[lo:hi], lengths[lo:hi], device=local_rank)
+    t_tgt = time.perf_counter() - t0
+
+    def search(qs):
+        return list(hmmer.hmmsearch(qs, db, cpus=host_threads, batch=args.pfam_batch, pipeline_depth=args.pfam_depth, feeders=args.feeders))
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    nwarm = min(len(oms), 4 * max(1, args.pfam_batch or 64))
+    search(oms)                     # device images of every profile become resident; pools, clocks and workers settle
+    search(oms[:nwarm])
+    barrier()
+    t0 = time.perf_counter()
+    hits = search(oms)
+    t_search = time.perf_counter() - t0
+    merged = hits
+    if dist is not None:
+        blobs = [None] * world if rank == 0 else None
+        dist.gather_object([h.to_bytes() for h in hits], blobs, dst=0)
+        if rank == 0:
+            merged = []
+            for q in range(len(oms)):
+                th = plan7.TopHits.from_bytes(blobs[0][q])
+                merged.append(th.merge(*[plan7.TopHits.from_bytes(blobs[r][q]) for r in range(1, world)]))
+    barrier()
+    elapsed = time.perf_counter() - t0
+    t_max = elapsed
+    if dist is not None:
+        b = torch.tensor([elapsed], dtype=torch.float64, device=red_dev)
+        dist.all_reduce(b, op=dist.ReduceOp.MAX)
+        t_max = float(b.item())
+    if rank != 0:
+        return None
+    nodes = float(sum(h.M for h in hmms))
+    residues = float(lengths.sum())
+    nhits = sum(len(h) for h in merged)
+    nrep = sum(len(h.reported) for h in merged)
+    sc = {k: sum(h.stage_counts[k] for h in hits) for k in ("msv", "bias", "vit", "fwd")}
+    return {
+        "workload": f"configs[3]-shaped: the first {len(hmms)} profiles of the synthetic {args.pfam_library}-entry library (14 fixture "
+                    f"models resampled to M ~ lognormal(median 120), calibrated on the device) x {args.pfam_targets} targets "
+                    f"(L ~ lognormal(5.65, 0.65) in [30, 5000], {nplanted} with a planted domain), sharded by residues over {world} GPU(s), "
+                    "per-query TopHits gathered and merged on rank 0 inside the timed region",
+        "value": round(nodes * residues / t_max / 1e9, 2), "unit": "GCUPS", "scaling": "strong",
+        "profiles": len(hmms), "targets": int(args.pfam_targets), "mean_M": round(nodes / len(hmms), 1), "mean_L": round(residues / len(lengths), 1),
+        "seconds": round(t_max, 4), "ms_per_profile": round(1e3 * t_max / len(hmms), 4), "profiles_per_s": round(len(hmms) / t_max, 1),
+        "search_seconds_rank0": round(t_search, 4), "batch": args.pfam_batch, "pipeline_depth": args.pfam_depth,
+        "hits": nhits, "reported": nrep, "stage_counts_rank0": sc,
+        "setup_seconds": {"library": round(t_lib, 2), "targets": round(t_tgt, 2)},
+    }
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -198,7 +282,17 @@ def main():
     ap.add_argument("--feeders", type=int, default=2, help="host threads issuing device stages (each on its own stream)")
     ap.add_argument("--cpu-sample", type=int, default=1_000_000, help="targets timed through the CPU oracle (rank 0, N=1)")
     ap.add_argument("--spinup-max", type=int, default=15, help="at most this many untimed 20-query windows before the warm-up")
+    ap.add_argument("--workload", choices=("both", "config1", "pfam"), default="both",
+                    help="config1: the headline (one profile x 1M targets per GPU); pfam: the many-query workload; both: headline + a `pfam` field")
+    ap.add_argument("--pfam-profiles", type=int, default=2048, help="library entries searched (the first ones of the 20k-entry library)")
+    ap.add_argument("--pfam-library", type=int, default=20000)
+    ap.add_argument("--pfam-targets", type=int, default=500_000, help="targets in total (sharded over the GPUs)")
+    ap.add_argument("--pfam-batch", type=int, default=0, help="queries per device batch (0: the library's choice)")
+    ap.add_argument("--pfam-depth", type=int, default=4)
     args = ap.parse_args()
+
+    if args.workload == "pfam":          # development switch: the headline part shrinks to a token run
+        args.steps, args.warmup, args.spinup_max, args.no_cpu_baseline = min(args.steps, 5), 0, 1, True
 
     import torch
     rank = int(os.environ.get("RANK", "0"))
@@ -315,6 +409,11 @@ def main():
     if dist is None:
         hits_total, reported_total = len(hits), len(hits.reported)
 
+    pfam = None
+    if args.workload in ("both", "pfam"):
+        del db                       # the headline's target block leaves HBM first
+        pfam = run_pfam(args, rank, world, local_rank, dist, red_dev, torch, host_threads)
+
     if rank == 0:
         ms_per_step = 1e3 * t_max / args.steps
         gcups = cells_total * args.steps / t_max / 1e9
@@ -378,6 +477,8 @@ def main():
                 "kernel_ms": round(msv_ms, 4), "algorithmic_bytes": int(alg_bytes),
             },
         }
+        if pfam is not None:
+            out["pfam"] = pfam
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(hmm, bg, flat, offsets, lengths, min(args.cpu_sample, args.nseq), args.seqlen)
         print(json.dumps(out))

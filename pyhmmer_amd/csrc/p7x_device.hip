@@ -1,5 +1,6 @@
 // p7x_device.hip -- device contexts, the device-resident sequence database and profile images.
 #include "p7x_device.hpp"
+#include <cstdlib>
 #include "p7x_kernels.hpp"
 #include <algorithm>
 #include <cmath>
@@ -19,6 +20,11 @@ static int device_count_checked()
   if (hipGetDeviceCount(&n) != hipSuccess) { (void) hipGetLastError(); return 0; }
   return n;
 }
+
+// The classes of a batch run on up to eight streams of one workspace, and several workspaces are in flight: ask the
+// runtime for more hardware queues than its default of four before it initialises (no effect if the process already
+// made a HIP call, or if the user set the variable).
+static const int g_hw_queues_set = setenv("GPU_MAX_HW_QUEUES", "8", 0);
 
 int get_ctx(int device, DeviceCtx **out)
 {
@@ -164,6 +170,8 @@ int p7x_seqdb_create(int device, int32_t abc_type, const uint8_t *dsq, const int
     u4 += (int64_t) grp_nblk[g] * 64;
   }
   db->tile_u4 = u4;
+  db->h_grp_len.resize((size_t) G); db->h_grp_suffix.assign((size_t) G + 1, 0);
+  for (int64_t g = G - 1; g >= 0; --g) { db->h_grp_len[g] = slot_len[g * 64]; db->h_grp_suffix[g] = db->h_grp_suffix[g + 1] + slot_len[g * 64]; }
   P7X_HIP(hipMalloc(&db->d_dsq, db->h_dsq.size()));
   P7X_HIP(hipMalloc(&db->d_slot_off, slot_off.size() * 8));
   P7X_HIP(hipMalloc(&db->d_slot_len, slot_len.size() * 4));

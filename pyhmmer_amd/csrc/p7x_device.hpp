@@ -101,6 +101,8 @@ struct p7x_seqdb {
   std::vector<int32_t> h_order;    // [nslots] slot -> caller index
   std::vector<int64_t> h_off;      // [n] offsets into h_dsq (sentinel-framed copy)
   std::vector<uint8_t> h_dsq;      // 255 x1..xL 255 x1..xL 255 ...
+  std::vector<int32_t> h_grp_len;  // [ngroups] length of the longest (= first) target of a 64-target group, decreasing
+  std::vector<int64_t> h_grp_suffix;   // [ngroups + 1] sum of h_grp_len[g ..]: DP rows the lane-per-target MSV walks from group g on
   // device
   uint8_t *d_dsq = nullptr;        // same framing as h_dsq
   int64_t *d_slot_off = nullptr;   // [nslots] offset of x1 in d_dsq

@@ -47,6 +47,7 @@ struct MsvArgs {
   const int32_t *slot_len;
   const uint8_t *tjb_tab;
   int ngroups;
+  int group_first;          // groups below this one are left to the wave-per-target kernel (the longest targets)
   int base, bias, tec, tbm;
   int *counter;
   int16_t *out_xJ;          // [ngroups*64] slot order; -1 = overflow

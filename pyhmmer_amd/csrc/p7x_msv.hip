@@ -157,8 +157,8 @@ __global__ void __launch_bounds__(kMsvBlock) msv_kernel(const ArgRef ref)
   extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
   constexpr int S = msv_stride_c(R);
   const MsvArgs a = load_args<MsvArgs>(ref);
-  const int ngroups = a.group_list ? *a.group_count : a.ngroups;
-  if (ngroups == 0 || *a.counter >= ngroups) return;          // nothing (left) for this lane: skip the table load
+  const int ngroups = a.group_list ? *a.group_count : a.ngroups - a.group_first;
+  if (ngroups <= 0 || *a.counter >= ngroups) return;          // nothing (left) for this lane: skip the table load
   {
     constexpr int n4 = (2 * kTabRows * S) / 4;
     const uint4 *src = reinterpret_cast<const uint4 *>(a.tab);
@@ -175,7 +175,7 @@ __global__ void __launch_bounds__(kMsvBlock) msv_kernel(const ArgRef ref)
     if (lane == 0) g = atomicAdd(a.counter, 1);
     g = __builtin_amdgcn_readfirstlane(g);
     if (g >= ngroups) break;
-    if (a.group_list) g = __builtin_amdgcn_readfirstlane(a.group_list[g]);
+    g = a.group_list ? __builtin_amdgcn_readfirstlane(a.group_list[g]) : g + a.group_first;
 
     const int slot = g * 64 + lane;
     const int L = a.slot_len[slot];
@@ -226,7 +226,8 @@ __global__ void __launch_bounds__(kMsvBlock, (R <= 88 ? 4 : (R <= 136 ? 3 : 2)))
   extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
   constexpr int S = msv_stride_c(R);
   const MsvArgs a = load_args<MsvArgs>(ref);
-  if (*a.counter >= a.ngroups) return;          // this lane's groups are all taken: skip the table load
+  const int ngroups = a.ngroups - a.group_first;
+  if (*a.counter >= ngroups) return;            // this lane's groups are all taken: skip the table load
   {
     constexpr int n4 = (2 * kTabRows * S) / 4;
     const uint4 *src = reinterpret_cast<const uint4 *>(a.tab);
@@ -243,7 +244,8 @@ __global__ void __launch_bounds__(kMsvBlock, (R <= 88 ? 4 : (R <= 136 ? 3 : 2)))
     int g = 0;
     if (lane == 0) g = atomicAdd(a.counter, 1);
     g = __builtin_amdgcn_readfirstlane(g);
-    if (g >= a.ngroups) break;
+    if (g >= ngroups) break;
+    g += a.group_first;
 
     const int slot = g * 64 + lane;
     const int L = a.slot_len[slot];
@@ -363,7 +365,7 @@ static int launch_R(const ArgRun<MsvArgs> &main, const ArgRun<MsvArgs> *amb, int
     }
   }
   long want = 1;
-  for (int i = 0; i < main.n; ++i) want = std::max<long>(want, ((long) main.at(i).ngroups + 3) / 4);
+  for (int i = 0; i < main.n; ++i) want = std::max<long>(want, ((long) (main.at(i).ngroups - main.at(i).group_first) + 3) / 4);
   if (amb == nullptr) {           // exact kernel over every group
     const unsigned gx = lane_grid(want, (long) num_cu * info.per_cu_exact, main.n);
     hipLaunchKernelGGL(msv_kernel<R>, dim3(gx, (unsigned) main.n), dim3(kMsvBlock), lds_bytes, st, main.ref());

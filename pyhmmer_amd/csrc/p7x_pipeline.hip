@@ -529,15 +529,34 @@ static bool small_block(const p7x_seqdb *db, const DeviceCtx *ctx, int nlanes)
   return !(e && std::atoi(e) == 0) && db->ngroups * (int64_t) nlanes <= (int64_t) ctx->num_cu * 4;
 }
 
+// The lane-per-target MSV kernel walks a 64-target group for as long as its longest member: one 8000-residue protein
+// keeps a wavefront busy for milliseconds while the other groups of the launch finished long ago.  The leading
+// (longest) groups are therefore left to the wave-per-target kernel: as many as it takes for the lane kernel's
+// longest remaining group to be no longer than its average work per resident wavefront (its makespan is then set by
+// throughput, not by the tail).  With many lanes (profiles) per launch the average grows and fewer groups qualify.
+static int long_groups(const p7x_seqdb *db, const DeviceCtx *ctx, int nlanes)
+{
+  static const bool off = std::getenv("P7X_MSV_LONG_GROUPS") && std::atoi(std::getenv("P7X_MSV_LONG_GROUPS")) == 0;
+  if (off || db->ngroups < 2) return 0;
+  const int64_t resident = (int64_t) ctx->num_cu * 4 * 3;           // wavefronts the lane kernel keeps in flight
+  const int64_t G = db->ngroups;
+  int64_t g = 0;
+  while (g < G / 2 && (int64_t) db->h_grp_len[(size_t) g] * resident > (int64_t) nlanes * db->h_grp_suffix[(size_t) g]) ++g;
+  return (int) g;
+}
+
 // ---- argument records of a lane
-static void fill_msv_args(LaneArgs &la, const Profile &p, const DevProfile *dp, const p7x_seqdb *db, DeviceCtx *ctx, const StageBufs &b)
+static void fill_msv_args(LaneArgs &la, const Profile &p, const DevProfile *dp, const p7x_seqdb *db, DeviceCtx *ctx, const StageBufs &b,
+                          int nlong = 0)
 {
   MsvWaveArgs w{};
   w.C = dp->vitC; w.nrows = kTabRows; w.emis = dp->msvw_emis; w.dsq = db->d_dsq; w.slot_off = db->d_slot_off; w.slot_len = db->d_slot_len;
   w.tjb_tab = ctx->lt.tjb; w.nslots = (int) db->nslots; w.base = p.base_b; w.bias = p.bias_b; w.tec = p.tec_b; w.tbm = p.tbm_b;
   w.out_xJ = b.xJ;
+  if (nlong > 0) w.nslots = (int) std::min<int64_t>((int64_t) nlong * 64, db->nslots);   // only the long groups (with the lane kernel)
   la.msvw = w;
   MsvArgs a{};
+  a.group_first = nlong;
   a.tab = dp->msv_tab; a.tiles = db->d_tiles; a.grp_off = db->d_grp_off; a.grp_nblk = db->d_grp_nblk;
   a.slot_len = db->d_slot_len; a.tjb_tab = ctx->lt.tjb; a.ngroups = (int) db->ngroups;
   a.base = p.base_b; a.bias = p.bias_b; a.tec = p.tec_b; a.tbm = p.tbm_b;
@@ -583,7 +602,7 @@ static int upload_args(Workspace *ws, int first, int n, hipStream_t s)
 
 // Lanes are sorted by model length, so the lanes that share the instantiation of every kernel family (MSV register
 // tile or wave kernel, packed or wave Viterbi, nodes per lane of the parsers) are consecutive: a class.
-struct LaneClass { int first = 0, n = 0; long msv_key = 0, vit_key = 0; int C = 0; };
+struct LaneClass { int first = 0, n = 0; long msv_key = 0, vit_key = 0; int C = 0; int nlong = 0; };
 
 static long msv_key_of(const DevProfile *dp, bool small)
 { // M > 478, or too few targets for one per lane: wave-per-target kernel (key < 0), else the register tile
@@ -598,11 +617,13 @@ static int lane_classes(const std::vector<LaneModel> &lm, const p7x_seqdb *db, c
 {
   const int nl = (int) lm.size();
   const bool small = small_block(db, ctx, nl);
+  const int nlong = small ? 0 : long_groups(db, ctx, nl);
   out.clear();
   for (int l = 0; l < nl; ++l) {
     const DevProfile *dp = lm[l].dp;
     if ((dp->msvR <= 0 || small) && !dp->msvw_emis) { set_error("model too long for the MSV kernels (M > 2048)"); return P7X_EINVAL; }
     LaneClass c; c.first = l; c.n = 1; c.msv_key = msv_key_of(dp, small); c.vit_key = vit_key_of(dp, small); c.C = dp->vitC;
+    c.nlong = (c.msv_key >= 0 && dp->msvw_emis) ? nlong : 0;
     if (!out.empty() && out.back().msv_key == c.msv_key && out.back().vit_key == c.vit_key && out.back().C == c.C) out.back().n++;
     else out.push_back(c);
   }
@@ -613,6 +634,10 @@ static int lane_classes(const std::vector<LaneModel> &lm, const p7x_seqdb *db, c
 static int class_msv(const LaneClass &c, const std::vector<LaneModel> &lm, DeviceCtx *ctx, Workspace *ws, hipStream_t stream)
 {
   if (c.msv_key < 0) return msv_wave_launch(lane_run(ws, &LaneArgs::msvw, c.first, c.n), ctx->num_cu, stream);
+  if (c.nlong > 0) {      // the longest targets first, one per wavefront
+    const int st = msv_wave_launch(lane_run(ws, &LaneArgs::msvw, c.first, c.n), ctx->num_cu, stream);
+    if (st != P7X_OK) return st;
+  }
   const ArgRun<MsvArgs> amb = lane_run(ws, &LaneArgs::msv_amb, c.first, c.n);
   return msv_launch(lm[c.first].dp->msvR, lane_run(ws, &LaneArgs::msv, c.first, c.n), g_msv_exact_only ? nullptr : &amb, ctx->num_cu, stream);
 }
@@ -818,6 +843,8 @@ static int cascade_enqueue(CascadeRun &r)
   hipStream_t s = ws->stream;
   r.queued = true;
   const int nbound = (int) std::min<int64_t>(db->nslots, INT_MAX);
+  std::vector<int> nlong_of((size_t) nq, 0);
+  for (const LaneClass &c : classes) for (int l = c.first; l < c.first + c.n; ++l) nlong_of[(size_t) l] = c.nlong;
   for (int l = 0; l < nq; ++l) {
     const Profile &p = r.lm[l].om->p; const DevProfile *dp = r.lm[l].dp;
     LaneArgs &la = ws->h_args[l];
@@ -827,7 +854,7 @@ static int cascade_enqueue(CascadeRun &r)
     d.slot_len = db->d_slot_len; d.tjb_tab = ctx->lt.tjb; d.null1_tab = ctx->lt.null1; d.xwmove_tab = ctx->lt.xwmove;
     d.dsq = db->d_dsq; d.slot_off = db->d_slot_off; d.eo = dp->bias_eo; d.nslots = db->nslots;
     la.dec = d;
-    fill_msv_args(la, p, dp, db, ctx, b);
+    fill_msv_args(la, p, dp, db, ctx, b, nlong_of[(size_t) l]);
     fill_vit_args(la, p, dp, db, ctx, b.list_vit, nbound, &b.counters[2], b.xC);
     WaveSeqArgs a = ws_args(p, dp, db, ctx);
     a.trans = dp->fwd_trans; a.emis = dp->fwd_emis; a.list = b.list_fwd; a.nlist = nbound; a.nlist_ptr = &b.counters[3];
@@ -1029,6 +1056,7 @@ int p7x_filters_batch(const p7x_oprofile *om, const p7x_seqdb *db, int32_t *xJ, 
   {
     const bool small = small_block(db, ctx, 1);
     cls.first = 0; cls.n = 1; cls.msv_key = msv_key_of(dp, small); cls.vit_key = vit_key_of(dp, small); cls.C = dp->vitC;
+    cls.nlong = (!small && cls.msv_key >= 0 && dp->msvw_emis) ? long_groups(db, ctx, 1) : 0;
     if (xJ && cls.msv_key < 0 && !dp->msvw_emis) { set_error("model too long for the MSV kernels (M > 2048)"); return P7X_EINVAL; }
   }
   for (int64_t t = 0; t < db->n; ++t) {
@@ -1052,7 +1080,7 @@ int p7x_filters_batch(const p7x_oprofile *om, const p7x_seqdb *db, int32_t *xJ, 
     d.slot_len = db->d_slot_len; d.tjb_tab = ctx->lt.tjb; d.null1_tab = ctx->lt.null1; d.xwmove_tab = ctx->lt.xwmove;
     d.dsq = db->d_dsq; d.slot_off = db->d_slot_off; d.eo = dp->bias_eo; d.nslots = ns;
     la.dec = d;
-    fill_msv_args(la, p, dp, db, ctx, b);
+    fill_msv_args(la, p, dp, db, ctx, b, cls.nlong);
     if (dp->vitC > 0) {
       fill_vit_args(la, p, dp, db, ctx, nullptr, (int) ns, nullptr, b.xC);
       WaveSeqArgs a = ws_args(p, dp, db, ctx);

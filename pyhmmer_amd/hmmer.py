@@ -198,7 +198,7 @@ def _auto_batch(db: "ShardedDatabase", M_hint: int = 150) -> int:
     launches, one event wait), few enough that a batch stays a few milliseconds of device time."""
     res = max(1, max(int(_lib.lib().p7x_seqdb_nresidues(sh._handle)) for sh in db.shards))
     cells = float(res) * M_hint                       # one query, one shard
-    return int(max(1, min(64, 6e10 // cells)))        # ~2-3 ms of MSV per batch
+    return int(max(1, min(64, 2e11 // cells)))        # ~8 ms of MSV per batch
 
 
 def _batches(queries: Iterable, size: int) -> Iterator[list]:

@@ -1,7 +1,9 @@
 """One thread, batches of B fixture profiles against the fixture proteome: host time of enqueue / wait / finish per
 batch after a warm-up, for profiling (rocprofv3 --kernel-trace) the batched cascade.  usage: batch_phases.py B nbatches [scan]"""
 import sys, time
-sys.path.insert(0, "."); sys.path.insert(0, "tests")
+import os
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 from conftest import load_hmms, GOLDEN
 from pyhmmer_amd import easel, plan7
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 64

@@ -2,7 +2,9 @@
 OptimizedProfile object, so each one pays for its device image), for several batch / feeder / window settings, and the
 host time of the three phases of one batch (enqueue / wait / finish) on a single thread."""
 import sys, time
-sys.path.insert(0, "."); sys.path.insert(0, "tests")
+import os
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 from conftest import load_hmms, GOLDEN
 from pyhmmer_amd import easel, plan7, hmmer
 with easel.SequenceFile(GOLDEN / "seqs" / "938293.PRJEB85.HG003687.faa", digital=True, alphabet=easel.Alphabet.amino()) as sf:
