@@ -265,6 +265,8 @@ def run_pfam(args, rank, world, local_rank, dist, red_dev, torch, host_threads):
         "seconds": round(t_max, 4), "ms_per_profile": round(1e3 * t_max / len(hmms), 4), "profiles_per_s": round(len(hmms) / t_max, 1),
         "search_seconds_rank0": round(t_search, 4), "batch": args.pfam_batch, "pipeline_depth": args.pfam_depth,
         "hits": nhits, "reported": nrep, "stage_counts_rank0": sc,
+        # per-BATCH times (every query of a batch reports its batch's): device stages by HIP events of the first class
+        "batch_ms_mean_rank0": {k: round(sum(h.timings_ms[k] for h in hits) / len(hits), 3) for k in hits[0].timings_ms},
         "setup_seconds": {"library": round(t_lib, 2), "targets": round(t_tgt, 2)},
     }
 

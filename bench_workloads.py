@@ -3,8 +3,10 @@ Swiss-Prot-shaped target database of SURVEY.md 8(d), configs 3 and 4.
 
 Pfam-A is not available offline, so the library is derived from the 14 calibrated fixture protein models
 (tests/golden/hmms: PF02826, Thioesterase, KR, LuxC, 10 x RREFam): entry e stretches or shrinks a template to a length
-M ~ lognormal(median 120, sigma 0.8) clipped to [20, 2000] (node k of the new model is the template's node
-round(k * Mt / M)), mixes a little Dirichlet noise into every emission row, and is then calibrated the way hmmbuild
+M ~ lognormal(median 120, sigma 0.8) clipped to [20, 2000] (the new model's nodes are the template's nodes
+round(k * Mt / M), k = 1..M, in a per-entry random ORDER: entries that share a template keep its emission and
+transition statistics but are not homologous to one another, as Pfam families are not), mixes a little Dirichlet
+noise into every emission row, and is then calibrated the way hmmbuild
 calibrates (p7_Calibrate: Gumbel location of the MSV / Viterbi scores and the exponential tail of the Forward scores
 of 200 random 100-residue sequences), the scores coming from the device filters.  Targets: L ~ lognormal(mu 5.65,
 sigma 0.65) clipped to [30, 5000], residues i.i.d. from the background, and every second target carries one domain
@@ -41,6 +43,7 @@ def make_entry(templates, e, M, seed=43):
     rng = np.random.default_rng([seed, e])
     K = tpl.alphabet.K
     src = np.clip(np.rint(np.arange(M + 1) * (tpl.M / M)), 1, tpl.M).astype(np.int64)
+    src[1:] = src[1:][rng.permutation(M)]              # a family of its own: same node statistics, different order
     src[0] = 0
     hmm = plan7.HMM(tpl.alphabet, M, f"syn{e:05d}_{tpl.name}")
     t = tpl.transition_probabilities[src].astype(np.float64)

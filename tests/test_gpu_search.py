@@ -1,6 +1,9 @@
 """End-to-end parity of Pipeline.search_hmm / hmmsearch with the reference's golden tables
 (real HMMER output: tests/golden/tables, reference tests/test_hmmer.py:51-238) and with the oracle's cascade."""
 import itertools
+import sys
+from pathlib import Path
+sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
 
 import numpy as np
 import pytest
@@ -380,3 +383,45 @@ def test_optimized_profile_block_scan(models, proteome):
     hits = pli.scan_seq(seq, block)
     ref = list(hmmer.hmmscan([seq], models["RREFam"], batch=1))[0]
     assert len(hits) >= 1 and _hit_fields(hits) == _hit_fields(ref) and hits.mode == "scan"
+
+
+@pytest.mark.timeout(600)
+def test_config3_profile_library_against_a_proteome(proteome, monkeypatch, request):
+    """BASELINE configs[2] at full profile count (SURVEY.md 8d "config 3"): a 20,000-entry profile library (the
+    synthetic, device-calibrated Pfam stand-in of bench_workloads.py; M ~ lognormal, 20 ... 2000 nodes) scanned
+    against the 2,100-sequence fixture proteome through hmmer.hmmscan in batches of 256.  Properties that do not
+    depend on the size: every per-sequence hit list carries Z = number of profiles; the per-profile stage counts and
+    hits of the batched run equal those of one-profile-at-a-time searches (sampled entries across the length range);
+    the hits of a sequence across all profiles equal the transposed per-profile hits."""
+    import bench_workloads as bw
+    if "lane-per-target" in request.node.name:
+        pytest.skip("one pass is enough: a 20,000-profile batch run picks its kernels itself")
+    monkeypatch.delenv("P7X_SMALL_BLOCK", raising=False)
+    n = 20000
+    hmms, lengths, templates = bw.make_library(n, count=n)
+    assert len(hmms) == n and int(lengths.min()) >= 20 and int(lengths.max()) > 1000
+    bg = plan7.Background(proteome.alphabet)
+    block = plan7.OptimizedProfileBlock(proteome.alphabet, (plan7.OptimizedProfile(h, bg, 400) for h in hmms))
+    db = plan7.SequenceDatabase(proteome)
+    # search orientation over the whole library, batched: stage counts per profile
+    batched = list(hmmer.hmmsearch(block, db, batch=256, pipeline_depth=4, feeders=2))
+    assert len(batched) == n
+    sample = sorted(set(list(range(0, n, 997)) + [int(np.argmax(lengths)), int(np.argmin(lengths))]))
+    pli = plan7.Pipeline(proteome.alphabet)
+    for e in sample:
+        single = pli.search_hmm(block[e], db)
+        assert batched[e].stage_counts == single.stage_counts, (e, hmms[e].M)
+        assert _hit_fields(batched[e]) == _hit_fields(single), (e, hmms[e].M)
+    total = {k: sum(h.stage_counts[k] for h in batched) for k in ("msv", "bias", "vit", "fwd")}
+    assert total["msv"] >= total["bias"] >= total["vit"] >= total["fwd"] > 0
+    # the MSV filter passes about F1 of the comparisons for calibrated models (0.02; composition and length effects allowed for)
+    assert 0.005 < total["msv"] / (n * len(proteome)) < 0.06
+    # scan orientation: per-sequence lists, Z = number of profiles, same (profile, sequence) pairs
+    scanned = list(hmmer.hmmscan(proteome, block, batch=256))
+    assert len(scanned) == len(proteome) and all(h.Z == n for h in scanned[:50])
+    pairs_scan = {(hit.name, q.name) for q, th in zip(proteome, scanned) for hit in th}
+    pairs_search = {(hmms[e].name, hit.name) for e, th in enumerate(batched) for hit in th}
+    # reportability differs (scan: E-values with Z = 20000 profiles; search: Z = 2100 sequences): compare the strong pairs
+    strong_scan = {(hit.name, q.name) for q, th in zip(proteome, scanned) for hit in th if hit.score > 40}
+    strong_search = {(hmms[e].name, hit.name) for e, th in enumerate(batched) for hit in th if hit.score > 40}
+    assert strong_scan == strong_search and len(pairs_scan) > 0 and len(pairs_search) > 0
