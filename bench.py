@@ -23,6 +23,8 @@ from pathlib import Path
 
 import numpy as np
 
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")      # before torch initialises HIP (see pyhmmer_amd/__init__.py)
+
 ROOT = Path(__file__).resolve().parent
 sys.path.insert(0, str(ROOT))
 sys.path.insert(0, str(ROOT / "tests"))

@@ -170,6 +170,14 @@ int p7x_seqdb_create(int device, int32_t abc_type, const uint8_t *dsq, const int
     u4 += (int64_t) grp_nblk[g] * 64;
   }
   db->tile_u4 = u4;
+  {   // targets more than three times as long as the median (and longer than 768) are "long" for the packed Viterbi
+      // kernel, whose wavefronts run to their longest target: a few per cent of the residues of a proteome
+    const int median = nslots > 0 ? slot_len[nslots / 2] : 0;
+    const int cut = std::max(768, 3 * median);
+    int64_t k = 0;
+    while (k < nslots && slot_len[k] > cut) ++k;
+    db->vit_long_slots = k;
+  }
   db->h_grp_len.resize((size_t) G); db->h_grp_suffix.assign((size_t) G + 1, 0);
   for (int64_t g = G - 1; g >= 0; --g) { db->h_grp_len[g] = slot_len[g * 64]; db->h_grp_suffix[g] = db->h_grp_suffix[g + 1] + slot_len[g * 64]; }
   P7X_HIP(hipMalloc(&db->d_dsq, db->h_dsq.size()));

@@ -101,6 +101,7 @@ struct p7x_seqdb {
   std::vector<int32_t> h_order;    // [nslots] slot -> caller index
   std::vector<int64_t> h_off;      // [n] offsets into h_dsq (sentinel-framed copy)
   std::vector<uint8_t> h_dsq;      // 255 x1..xL 255 x1..xL 255 ...
+  int64_t vit_long_slots = 0;      // leading slots (longest targets) the packed Viterbi kernel leaves to the wave kernel
   std::vector<int32_t> h_grp_len;  // [ngroups] length of the longest (= first) target of a 64-target group, decreasing
   std::vector<int64_t> h_grp_suffix;   // [ngroups + 1] sum of h_grp_len[g ..]: DP rows the lane-per-target MSV walks from group g on
   // device

@@ -108,6 +108,7 @@ struct VitPkArgs {
   const void *trans, *emis;     // vitpk_build_tables()
   const uint8_t *dsq; const int64_t *slot_off; const int32_t *slot_len;
   const int32_t *list; int nlist; const int *nlist_ptr;     // as WaveSeqArgs
+  const int *nskip_ptr;     // optional: the first *nskip_ptr list items are left to the wave-per-target kernel
   int nrows;
   const int16_t *xwmove_tab; int base_w, xw_e, ddbound;
   int32_t *out_xC;

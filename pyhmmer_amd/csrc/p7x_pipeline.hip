@@ -176,7 +176,8 @@ __global__ void bias_kernel(const ArgRef ref)
     if (pass) b.stage[s] = to_fwd ? 3 : 2;     // P <= F2 already: the Viterbi filter is skipped and counts as passed
     }
     wave_count(&b.counters[8], to_vit || to_fwd);
-    wave_append(&b.counters[2], b.list_vit, to_vit, s);
+    // targets for the Viterbi filter are marked stage == 2; their work list is built by vit_compact_* below, in slot
+    // order (= by decreasing length), instead of in the order in which the threads here happen to finish
     wave_append(&b.counters[3], b.list_fwd, to_fwd, s);
   }
 }
@@ -230,6 +231,87 @@ __global__ void decide_fwd_kernel(const ArgRef ref)
       if (take) b.stage[s] = 4;
     }
     wave_append(&b.counters[4], b.list_fin, take, s);
+  }
+}
+
+// ---------------------------------------------------------------------------- Viterbi work list, sorted by length
+// Slots are sorted by decreasing target length, so the list of slots with stage == 2 in slot order is the Viterbi
+// work list sorted by decreasing length: the 8 (or 4) targets that share a wavefront of the packed kernel then have
+// about the same length (a wavefront runs to its longest target), and the longest targets -- the first <long_slots>
+// slots -- form a prefix of the list that goes to the wave-per-target kernel instead (counters[13] = its length).
+constexpr int kCompactChunk = 4096;       // slots per block
+struct CompactArgs {
+  const uint8_t *stage; int32_t *list; int *chunk_cnt; int *counters;
+  int64_t nslots; int64_t long_slots;
+};
+
+__device__ __forceinline__ int count_marked(const uint8_t *stage, int64_t lo, int64_t hi, uint32_t &mask)
+{ // this thread's 16 slots lo .. lo+15 (clipped to hi): bit j of mask = slot lo + j is marked
+  mask = 0;
+  if (lo + 16 <= hi) {
+    const uint4 v = *reinterpret_cast<const uint4 *>(stage + lo);
+    const uint32_t w[4] = { v.x, v.y, v.z, v.w };
+#pragma unroll
+    for (int j = 0; j < 16; ++j) if (((w[j >> 2] >> (8 * (j & 3))) & 0xffu) == 2u) mask |= 1u << j;
+  } else {
+    for (int j = 0; j < 16 && lo + j < hi; ++j) if (stage[lo + j] == 2) mask |= 1u << j;
+  }
+  return __popc(mask);
+}
+
+__global__ void __launch_bounds__(256) vit_compact_count_kernel(const ArgRef ref)
+{
+  const CompactArgs a = load_args<CompactArgs>(ref);
+  const int64_t lo = (int64_t) blockIdx.x * kCompactChunk + (int64_t) threadIdx.x * 16;
+  if ((int64_t) blockIdx.x * kCompactChunk >= a.nslots) return;
+  uint32_t mask;
+  int c = count_marked(a.stage, lo, a.nslots, mask);
+  c = (int) wave_sum_i32(c);
+  __shared__ int part[4];
+  if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = c;
+  __syncthreads();
+  if (threadIdx.x == 0) a.chunk_cnt[blockIdx.x] = part[0] + part[1] + part[2] + part[3];
+}
+
+__global__ void __launch_bounds__(256) vit_compact_write_kernel(const ArgRef ref)
+{
+  const CompactArgs a = load_args<CompactArgs>(ref);
+  const int64_t chunk_lo = (int64_t) blockIdx.x * kCompactChunk;
+  if (chunk_lo >= a.nslots) return;
+  __shared__ int scan[256];
+  __shared__ int base_s;
+  // list position of this chunk's first marked slot: the marked slots of the chunks before it
+  if (threadIdx.x < 64) {
+    int acc = 0;
+    for (int c = (int) threadIdx.x; c < (int) blockIdx.x; c += 64) acc += a.chunk_cnt[c];
+    acc = (int) wave_sum_i32(acc);
+    if (threadIdx.x == 0) base_s = acc;
+  }
+  const int64_t lo = chunk_lo + (int64_t) threadIdx.x * 16;
+  uint32_t mask;
+  const int c = count_marked(a.stage, lo, a.nslots, mask);
+  scan[threadIdx.x] = c;
+  __syncthreads();
+  for (int d = 1; d < 256; d <<= 1) {         // inclusive Hillis-Steele scan over the 256 thread counts
+    const int v = (int) threadIdx.x >= d ? scan[threadIdx.x - d] : 0;
+    __syncthreads();
+    scan[threadIdx.x] += v;
+    __syncthreads();
+  }
+  int pos = base_s + scan[threadIdx.x] - c;
+  for (int j = 0; j < 16; ++j) if (mask & (1u << j)) a.list[pos++] = (int32_t) (lo + j);
+  // the long prefix ends inside the chunk that holds slot long_slots (or is the whole list)
+  if (a.long_slots > chunk_lo && a.long_slots <= chunk_lo + kCompactChunk && a.long_slots < a.nslots) {
+    const int64_t cut = a.long_slots - lo;             // slots of this thread below the cut
+    int below = cut >= 16 ? c : (cut <= 0 ? 0 : __popc(mask & ((1u << cut) - 1u)));
+    below = (int) wave_sum_i32(below);
+    if ((threadIdx.x & 63) == 0) atomicAdd(&a.counters[13], below);
+    if (threadIdx.x == 0) atomicAdd(&a.counters[13], base_s);
+  }
+  if (chunk_lo + kCompactChunk >= a.nslots && threadIdx.x == 255) {      // last chunk: the list's length
+    const int total = base_s + scan[255];
+    a.counters[2] = total;
+    if (a.long_slots >= a.nslots) a.counters[13] = total;
   }
 }
 
@@ -365,6 +447,7 @@ struct LaneArgs {
   MsvArgs msv, msv_amb;       // fast (or exact-over-everything) MSV; exact MSV over the lane's ambiguous groups
   MsvWaveArgs msvw;
   VitPkArgs vitpk;
+  CompactArgs cmp;
   WaveSeqArgs vit, fwd, rows, bck;
   LayoutArgs lay;
   RegionArgs reg;
@@ -372,6 +455,7 @@ struct LaneArgs {
 constexpr int kLaneCounters = 16;
 // counters of a lane: [0] msv groups taken [1] n(list_bias) [2] n(list_vit) [3] n(list_fwd) [4] n(list_fin)
 // [8] n_past_bias [10] ambiguous MSV groups [11] exact-MSV groups taken [12] flag: survivor buffers too small
+// [13] length of the prefix of list_vit that holds the longest targets (wave-per-target Viterbi)
 
 // A workspace serves a batch of up to <nlanes> queries against a block of up to <cap_slots> targets: per-lane
 // score / list arrays, one row arena shared by the lanes, the lanes' argument records, one stream.
@@ -382,6 +466,7 @@ struct Workspace {
   int32_t *xC = nullptr; float *fwd_by_item = nullptr;
   int32_t *list_bias = nullptr, *list_vit = nullptr, *list_fwd = nullptr, *list_fin = nullptr;
   uint8_t *stage = nullptr;
+  int *chunk_cnt = nullptr; int64_t chunks_per_lane = 0;      // [nlanes][chunks_per_lane] marked slots per compaction chunk
   int *counters = nullptr;                  // [nlanes][kLaneCounters] then the arena cursor (64 bit)
   LaneArgs *d_args = nullptr, *h_args = nullptr; size_t h_args_bytes = 0;     // [nlanes], device / pinned host
   // Forward survivors: row arena (Forward rows, Backward rows, region-scan scratch) and per-lane, per-survivor arrays
@@ -408,6 +493,7 @@ struct Workspace {
     (void) hipFree(xJ); (void) hipFree(usc); (void) hipFree(filtersc); (void) hipFree(vfsc); (void) hipFree(fwdsc);
     (void) hipFree(xC); (void) hipFree(fwd_by_item); (void) hipFree(list_bias); (void) hipFree(list_vit);
     (void) hipFree(list_fwd); (void) hipFree(list_fin); (void) hipFree(counters); (void) hipFree(stage); (void) hipFree(d_args);
+    (void) hipFree(chunk_cnt);
     (void) hipFree(xmx_f); (void) hipFree(xmx_b); (void) hipFree(xmx_s); (void) hipFree(xmx_off); (void) hipFree(reg_out); (void) hipFree(bck_sc);
     (void) hipFree(rt_xmx_off); (void) hipFree(rt_reg_out); (void) hipFree(rt_bck_sc);
     for (auto &e : ev) if (e) (void) hipEventDestroy(e);
@@ -469,6 +555,8 @@ static int get_workspace(int device, int64_t nslots, int nlanes, Workspace **out
   { void *hp = nullptr; const int pst = pinned_acquire(w->counters_bytes(), &hp, &w->h_counts_bytes); if (pst != P7X_OK) return pst; w->h_counts = static_cast<int *>(hp); }
   { void *hp = nullptr; const int pst = pinned_acquire((size_t) nlanes * sizeof(LaneArgs), &hp, &w->h_args_bytes); if (pst != P7X_OK) return pst; w->h_args = static_cast<LaneArgs *>(hp); }
   P7X_HIP(hipMalloc(&w->stage, tot));
+  w->chunks_per_lane = (cap + kCompactChunk - 1) / kCompactChunk;
+  P7X_HIP(hipMalloc(&w->chunk_cnt, (size_t) nlanes * (size_t) w->chunks_per_lane * 4));
   for (auto &e : w->ev) P7X_HIP(hipEventCreate(&e));
   P7X_HIP(hipEventCreateWithFlags(&w->ev_sync, hipEventDisableTiming));
   {   // the cascade is the critical path of a search: its wavefronts go first when the envelope kernel of the previous
@@ -569,15 +657,19 @@ static void fill_msv_args(LaneArgs &la, const Profile &p, const DevProfile *dp, 
   la.msv_amb = x;
 }
 
+// <nlong_ptr> (packed kernel only): the first *nlong_ptr items of the list are the longest targets; the wave-per-target
+// kernel takes them (<nlong_bound> of them at most), the packed kernel the rest.
 static void fill_vit_args(LaneArgs &la, const Profile &p, const DevProfile *dp, const p7x_seqdb *db, DeviceCtx *ctx,
-                          const int32_t *list, int nlist, const int *nlist_ptr, int32_t *out_xC)
+                          const int32_t *list, int nlist, const int *nlist_ptr, int32_t *out_xC,
+                          const int *nlong_ptr = nullptr, int nlong_bound = 0)
 {
   WaveSeqArgs w = ws_args(p, dp, db, ctx);
   w.trans = dp->vit_trans; w.emis = dp->vit_emis; w.list = list; w.nlist = nlist; w.nlist_ptr = nlist_ptr; w.out_xC = out_xC;
+  if (nlong_ptr) { w.nlist_ptr = nlong_ptr; w.nlist = nlong_bound; }
   la.vit = w;
   VitPkArgs a{};
   a.trans = dp->vitpk_trans; a.emis = dp->vitpk_emis; a.dsq = db->d_dsq; a.slot_off = db->d_slot_off; a.slot_len = db->d_slot_len;
-  a.list = list; a.nlist = nlist; a.nlist_ptr = nlist_ptr; a.nrows = p.Kp + 1;
+  a.list = list; a.nlist = nlist; a.nlist_ptr = nlist_ptr; a.nskip_ptr = nlong_ptr; a.nrows = p.Kp + 1;
   a.xwmove_tab = ctx->lt.xwmove; a.base_w = p.base_w; a.xw_e = p.xw[XE][MOVE]; a.ddbound = p.ddbound_w;
   a.out_xC = out_xC;
   la.vitpk = a;
@@ -602,7 +694,7 @@ static int upload_args(Workspace *ws, int first, int n, hipStream_t s)
 
 // Lanes are sorted by model length, so the lanes that share the instantiation of every kernel family (MSV register
 // tile or wave kernel, packed or wave Viterbi, nodes per lane of the parsers) are consecutive: a class.
-struct LaneClass { int first = 0, n = 0; long msv_key = 0, vit_key = 0; int C = 0; int nlong = 0; };
+struct LaneClass { int first = 0, n = 0; long msv_key = 0, vit_key = 0; int C = 0; int nlong = 0; int64_t vit_long = 0; };
 
 static long msv_key_of(const DevProfile *dp, bool small)
 { // M > 478, or too few targets for one per lane: wave-per-target kernel (key < 0), else the register tile
@@ -624,6 +716,7 @@ static int lane_classes(const std::vector<LaneModel> &lm, const p7x_seqdb *db, c
     if ((dp->msvR <= 0 || small) && !dp->msvw_emis) { set_error("model too long for the MSV kernels (M > 2048)"); return P7X_EINVAL; }
     LaneClass c; c.first = l; c.n = 1; c.msv_key = msv_key_of(dp, small); c.vit_key = vit_key_of(dp, small); c.C = dp->vitC;
     c.nlong = (c.msv_key >= 0 && dp->msvw_emis) ? nlong : 0;
+    c.vit_long = c.vit_key >= 0 ? db->vit_long_slots : 0;
     if (!out.empty() && out.back().msv_key == c.msv_key && out.back().vit_key == c.vit_key && out.back().C == c.C) out.back().n++;
     else out.push_back(c);
   }
@@ -646,6 +739,10 @@ static int class_msv(const LaneClass &c, const std::vector<LaneModel> &lm, Devic
 static int class_viterbi(const LaneClass &c, const std::vector<LaneModel> &lm, DeviceCtx *ctx, Workspace *ws, hipStream_t s)
 {
   if (c.vit_key < 0) return vit_launch(lane_run(ws, &LaneArgs::vit, c.first, c.n), ctx->num_cu, s);
+  if (c.vit_long > 0) {       // the longest targets (the head of the sorted list) one per wavefront
+    const int st = vit_launch(lane_run(ws, &LaneArgs::vit, c.first, c.n), ctx->num_cu, s);
+    if (st != P7X_OK) return st;
+  }
   return vitpk_launch(lm[c.first].dp->vitpkT, lm[c.first].dp->vitpkP, lane_run(ws, &LaneArgs::vitpk, c.first, c.n), ctx->num_cu, s);
 }
 
@@ -804,6 +901,12 @@ static int class_cascade(CascadeRun &r, const LaneClass &c, hipStream_t s, bool 
   hipLaunchKernelGGL(decide_msv_kernel, dim3((unsigned) ((db->nslots + 255) / 256), (unsigned) c.n), dim3(256), 0, s, dec);
   if (record_events) P7X_HIP(hipEventRecord(ws->ev[1], s));
   hipLaunchKernelGGL(bias_kernel, dim3(lane_grid((db->nslots + 63) / 64, ctx->num_cu * 4, c.n), (unsigned) c.n), dim3(64), 0, s, dec);
+  {   // the Viterbi work list, in slot order
+    const unsigned nchunks = (unsigned) ((db->nslots + kCompactChunk - 1) / kCompactChunk);
+    const ArgRef cmp = lane_run(ws, &LaneArgs::cmp, c.first, c.n).ref();
+    hipLaunchKernelGGL(vit_compact_count_kernel, dim3(nchunks, (unsigned) c.n), dim3(256), 0, s, cmp);
+    hipLaunchKernelGGL(vit_compact_write_kernel, dim3(nchunks, (unsigned) c.n), dim3(256), 0, s, cmp);
+  }
   if (record_events) P7X_HIP(hipEventRecord(ws->ev[2], s));
   if ((st = class_viterbi(c, r.lm, ctx, ws, s)) != P7X_OK) return st;
   const unsigned gdec = lane_grid((db->nslots + 255) / 256, ctx->num_cu, c.n);
@@ -844,7 +947,8 @@ static int cascade_enqueue(CascadeRun &r)
   r.queued = true;
   const int nbound = (int) std::min<int64_t>(db->nslots, INT_MAX);
   std::vector<int> nlong_of((size_t) nq, 0);
-  for (const LaneClass &c : classes) for (int l = c.first; l < c.first + c.n; ++l) nlong_of[(size_t) l] = c.nlong;
+  std::vector<int64_t> vit_long_of((size_t) nq, 0);
+  for (const LaneClass &c : classes) for (int l = c.first; l < c.first + c.n; ++l) { nlong_of[(size_t) l] = c.nlong; vit_long_of[(size_t) l] = c.vit_long; }
   for (int l = 0; l < nq; ++l) {
     const Profile &p = r.lm[l].om->p; const DevProfile *dp = r.lm[l].dp;
     LaneArgs &la = ws->h_args[l];
@@ -855,7 +959,13 @@ static int cascade_enqueue(CascadeRun &r)
     d.dsq = db->d_dsq; d.slot_off = db->d_slot_off; d.eo = dp->bias_eo; d.nslots = db->nslots;
     la.dec = d;
     fill_msv_args(la, p, dp, db, ctx, b, nlong_of[(size_t) l]);
-    fill_vit_args(la, p, dp, db, ctx, b.list_vit, nbound, &b.counters[2], b.xC);
+    const int64_t vit_long = vit_long_of[(size_t) l];
+    fill_vit_args(la, p, dp, db, ctx, b.list_vit, nbound, &b.counters[2], b.xC,
+                  vit_long > 0 ? &b.counters[13] : nullptr, (int) std::min<int64_t>(vit_long, INT_MAX));
+    CompactArgs ca{};
+    ca.stage = b.stage; ca.list = b.list_vit; ca.chunk_cnt = ws->chunk_cnt + (size_t) l * (size_t) ws->chunks_per_lane; ca.counters = b.counters;
+    ca.nslots = db->nslots; ca.long_slots = vit_long;
+    la.cmp = ca;
     WaveSeqArgs a = ws_args(p, dp, db, ctx);
     a.trans = dp->fwd_trans; a.emis = dp->fwd_emis; a.list = b.list_fwd; a.nlist = nbound; a.nlist_ptr = &b.counters[3];
     a.out_sc = b.fwd_by_item;

@@ -136,7 +136,8 @@ __global__ void __launch_bounds__(256) vitpk_kernel(const ArgRef ref)
   constexpr int G = 64 / T;                // targets per wavefront
   const VitPkArgs a = load_args<VitPkArgs>(ref);
   const int nlist = a.nlist_ptr ? *a.nlist_ptr : a.nlist;
-  if ((int) (blockIdx.x * 4 * G) >= nlist) return;          // no target for this block: skip the table load
+  const int nskip = a.nskip_ptr ? *a.nskip_ptr : 0;         // the longest targets (a prefix of the list) go elsewhere
+  if (nskip + (int) (blockIdx.x * 4 * G) >= nlist) return;  // no target for this block: skip the table load
   constexpr int PS = (P + 3) & ~3;         // table stride per lane, in pairs
   constexpr int ROWQ = vitpk_rowq(T, P);   // uint4 per emission row (odd: rows of different residues spread over the banks)
   // LDS layouts are lane-minor, so that the 16-byte reads of the T lanes of a group (and of the groups of a
@@ -164,7 +165,7 @@ __global__ void __launch_bounds__(256) vitpk_kernel(const ArgRef ref)
 #pragma unroll
   for (int q = 0; q < P; ++q) tdd[q] = trbl[q * T].w;
 
-  for (int it0 = wave0 * G; it0 < nlist; it0 += nwaves * G) {
+  for (int it0 = nskip + wave0 * G; it0 < nlist; it0 += nwaves * G) {
     const int it = it0 + g;
     const bool have = it < nlist;
     const int slot = have ? (a.list ? a.list[it] : it) : 0;

@@ -26,6 +26,16 @@ __device__ __forceinline__ int wave_max_i32(int v)
   v = max(v, P7X_DPP_STEP_I(v, id, 0x143, 0xc));
   return __builtin_amdgcn_readlane(v, 63);
 }
+__device__ __forceinline__ int wave_sum_i32(int v)
+{
+  v = v + P7X_DPP_STEP_I(v, 0, 0x111, 0xf);
+  v = v + P7X_DPP_STEP_I(v, 0, 0x112, 0xf);
+  v = v + P7X_DPP_STEP_I(v, 0, 0x114, 0xf);
+  v = v + P7X_DPP_STEP_I(v, 0, 0x118, 0xf);
+  v = v + P7X_DPP_STEP_I(v, 0, 0x142, 0xa);
+  v = v + P7X_DPP_STEP_I(v, 0, 0x143, 0xc);
+  return __builtin_amdgcn_readlane(v, 63);
+}
 #define P7X_DPP_STEP_F(v, ctrl, rmask) __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, (v)), (ctrl), (rmask), 0xf, false))
 __device__ __forceinline__ float wave_sum_f32(float v)
 {

@@ -212,25 +212,92 @@ def _batches(queries: Iterable, size: int) -> Iterator[list]:
         yield cur
 
 
+def _query_length(q) -> int:
+    try:
+        return int(q.M)
+    except Exception:
+        return 0
+
+
 def _run_queries(db: "ShardedDatabase", pipelines: Sequence[Pipeline], queries: Iterable, pipeline_depth: int,
-                 feeders: int, window: int = 1, finishers: int = 0, batch: int = 1) -> Iterator:
-    """Yield ``(query, TopHits)`` for every query, in order.  Queries travel in batches of ``batch`` (one set of
+                 feeders: int, window: int = 1, finishers: int = 0, batch: int = 1, reorder: int = 32) -> Iterator:
+    """Yield ``(query, TopHits)`` for every query, in input order.  Queries travel in batches of ``batch`` (one set of
     device launches each); the two stages of consecutive batches overlap.  ``window`` > 1: every feeder queues the
-    device stage of that many batches before it waits for the oldest."""
+    device stage of that many batches before it waits for the oldest.
+
+    Inside a span of ``reorder`` batches the queries are sorted by model length before they are cut into batches:
+    profiles of similar length share every kernel instantiation, so a batch is a few launches with many profiles each
+    instead of one launch per profile.  Results are held back until every earlier query of the input has been yielded."""
     if batch <= 0:
         batch = _auto_batch(db)
-    for qs, hits, err in _run_batches(db, pipelines, _batches(queries, batch), pipeline_depth, feeders, window, finishers):
-        if err is None:
-            yield from zip(qs, hits)
-        elif len(qs) == 1:
-            raise err
-        else:
-            # a member of the batch failed (missing cutoffs, a device error ...): the reference would have yielded the
-            # results of the queries before it first (_base.py:305-318).  Run the batch again one query at a time; the
-            # error then surfaces at its own position.
-            for q in qs:
-                yield q, db.search(pipelines, [q])[0]
-            raise err           # not reproducible query by query: report it after the batch
+    span = batch * max(1, reorder) if batch > 1 else 1
+    order: list = []                      # input index of every query handed to the device, in hand-over order
+    inputs: list = []                     # the queries, by input index (dropped once yielded)
+    it = iter(queries)
+    src_error: list = []
+
+    def sorted_batches():
+        base = 0
+        while True:
+            chunk = []
+            try:
+                for q in it:
+                    chunk.append(q)
+                    if len(chunk) >= span:
+                        break
+            except BaseException as e:        # the caller's iterable failed: deliver what it produced, then the error
+                src_error.append(e)
+            if not chunk:
+                return
+            inputs.extend(chunk)
+            idx = sorted(range(len(chunk)), key=lambda i: _query_length(chunk[i])) if span > 1 else list(range(len(chunk)))
+            for lo in range(0, len(idx), batch):
+                part = idx[lo:lo + batch]
+                order.extend(base + i for i in part)
+                yield [chunk[i] for i in part]
+            base += len(chunk)
+            if src_error:
+                return
+
+    done: dict = {}
+    nxt = 0
+    pos = 0                               # batches' members consumed from `order`
+    failure = None
+    runner = _run_batches(db, pipelines, sorted_batches(), pipeline_depth, feeders, window, finishers)
+    for qs, hits, err in runner:
+        members = order[pos:pos + len(qs)]
+        pos += len(qs)
+        if err is not None:
+            failure = (members, err)
+            break
+        for i, h in zip(members, hits):
+            done[i] = h
+        while nxt in done:
+            q, inputs[nxt] = inputs[nxt], None
+            yield q, done.pop(nxt)
+            nxt += 1
+    runner.close()                        # feeders stop, queued device work is released
+    if failure is not None:
+        # A member of a batch failed (missing cutoffs, a device error ...).  The reference would have yielded the results
+        # of every query before it first (_base.py:305-318): finish the input order one query at a time up to the failing
+        # batch's last member; the error then surfaces at its own position.
+        members, err = failure
+        last = max(members)
+        while nxt <= last:
+            if nxt in done:
+                res = done.pop(nxt)
+            else:
+                res = db.search(pipelines, [inputs[nxt]])[0]
+            q, inputs[nxt] = inputs[nxt], None
+            yield q, res
+            nxt += 1
+        raise err           # not reproducible query by query: report it after the batch
+    while nxt in done:
+        q, inputs[nxt] = inputs[nxt], None
+        yield q, done.pop(nxt)
+        nxt += 1
+    if src_error:
+        raise src_error[0]
 
 
 def _run_batches(db: "ShardedDatabase", pipelines: Sequence[Pipeline], queries: Iterable, pipeline_depth: int,
