@@ -285,6 +285,10 @@ def main():
     ap.add_argument("--pipeline-depth", type=int, default=4, help="queries whose device stage may run ahead of the host stage (0: none)")
     ap.add_argument("--feeders", type=int, default=2, help="host threads issuing device stages (each on its own stream)")
     ap.add_argument("--cpu-sample", type=int, default=1_000_000, help="targets timed through the CPU oracle (rank 0, N=1)")
+    ap.add_argument("--queries-per-step", type=int, default=8,
+                    help="a step is this many consecutive queries, each a complete search of the resident target block: the "
+                         "pipeline's fill and drain (about two query times) then weigh as little in a 20-step run as in a long one")
+    ap.add_argument("--batch", type=int, default=0, help="headline workload: queries per device batch (0: the library's own choice)")
     ap.add_argument("--spinup-max", type=int, default=15, help="at most this many untimed 20-query windows before the warm-up")
     ap.add_argument("--workload", choices=("both", "config1", "pfam"), default="both",
                     help="config1: the headline (one profile x 1M targets per GPU); pfam: the many-query workload; both: headline + a `pfam` field")
@@ -342,11 +346,15 @@ def main():
     local_world = int(os.environ.get("LOCAL_WORLD_SIZE", str(world)))
     host_threads = max(2, host_cpus() // max(1, local_world))
 
+    qps = max(1, args.queries_per_step)
+    lanes_per_launch = args.batch or hmmer._auto_batch(hmmer.ShardedDatabase.from_database(db))
+
     def run(nsteps):
-        """nsteps searches of the same workload through the public entry point.  hmmsearch overlaps the device
-        stage of query k+1 with the host stage of query k (pipeline_depth), exactly as it does for distinct queries."""
+        """nsteps x queries_per_step searches of the same workload through the public entry point.  hmmsearch overlaps
+        the device stage of later queries with the host stage of earlier ones (pipeline_depth), exactly as it does for
+        distinct queries."""
         last, acc = None, {}
-        for h in hmmer.hmmsearch((om for _ in range(nsteps)), db, pipeline_depth=args.pipeline_depth, feeders=args.feeders, cpus=host_threads):
+        for h in hmmer.hmmsearch((om for _ in range(nsteps * qps)), db, pipeline_depth=args.pipeline_depth, feeders=args.feeders, cpus=host_threads, batch=args.batch):
             last = h
             for k, v in h.timings_ms.items():
                 acc[k] = acc.get(k, 0.0) + v
@@ -363,7 +371,7 @@ def main():
     spin = []
     for _ in range(args.spinup_max):
         t0 = time.perf_counter()
-        run(20)
+        run(max(1, 20 // qps))
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
         if dist is not None:
@@ -381,14 +389,15 @@ def main():
     hits, stage = run(args.steps)
     barrier()
     elapsed = time.perf_counter() - t0
-    stage = {k: v / args.steps for k, v in stage.items()}
+    nqueries = args.steps * qps
+    stage = {k: v / nqueries for k, v in stage.items()}          # per query (a batch's times are reported by each of its queries)
     # Outside the timed region: the same kernels without a second search in flight.  With several feeders the device
     # stages of two queries share the device, which raises throughput and stretches every single launch; the
     # stand-alone duration is what the kernel itself achieves.
     solo = {}
     if args.pipeline_depth > 0 and rank == 0:
         n_solo = 3
-        for h in hmmer.hmmsearch((om for _ in range(n_solo)), db, pipeline_depth=0, cpus=host_threads):
+        for h in hmmer.hmmsearch((om for _ in range(n_solo)), db, pipeline_depth=0, cpus=host_threads, batch=1):
             for k, v in h.timings_ms.items():
                 solo[k] = solo.get(k, 0.0) + v / n_solo
 
@@ -420,14 +429,17 @@ def main():
 
     if rank == 0:
         ms_per_step = 1e3 * t_max / args.steps
-        gcups = cells_total * args.steps / t_max / 1e9
+        gcups = cells_total * nqueries / t_max / 1e9
         sc = hits.stage_counts
         # ---- roofline of the dominant kernel (MSV), from HIP events recorded on the library's stream
+        # one MSV launch serves the B queries of a device batch (each reads the residue tiles): per launch B x the
+        # per-comparison bytes of SURVEY.md 8(d); every query of a batch reports its batch's launch duration
+        B = lanes_per_launch
         msv_ms = stage["msv_kernel"]
         table_bytes = 29 * 16 * max(2, (hmm.M - 1) // 16 + 1)
-        alg_bytes = float(residues + 2 * args.nseq) + 16.0 * args.nseq + table_bytes
+        alg_bytes = B * (float(residues + 2 * args.nseq) + 16.0 * args.nseq + table_bytes)
         achieved_gbs = alg_bytes / (msv_ms * 1e-3) / 1e9
-        msv_cups = cells_rank / (msv_ms * 1e-3)
+        msv_cups = B * cells_rank / (msv_ms * 1e-3)
         om_R = (hmm.M + 1) // 2 + 1
         om_R = ((om_R + 7) // 8) * 8 if om_R <= 160 else ((om_R + 15) // 16) * 16
         out = {
@@ -437,15 +449,18 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "u8/i16 filters (MSV, Viterbi), f32 Forward/Backward",
             "data": "synthetic",
-            "seqs_per_s": round(seqs_total * args.steps / t_max, 1),
+            "seqs_per_s": round(seqs_total * nqueries / t_max, 1),
+            "ms_per_query": round(1e3 * t_max / nqueries, 3),
             "config": {
                 "workload": f"configs[1]: single profile {hmm.name} (M={hmm.M}, fixture {args.hmm}.hmm) vs {args.nseq} synthetic "
                             f"{args.seqlen}-aa targets per GPU, i.i.d. background + 0.1% planted positives, full pipeline "
                             "MSV->bias->Viterbi->Forward->Backward on device + domain definition/TopHits on host",
                 "targets_per_gpu": args.nseq, "target_len": args.seqlen, "M": hmm.M, "parallelism": f"targets sharded over {world} GPU(s), host merge",
-                "timed_region": "hmmer.hmmsearch over `steps` queries (the same profile each time), every query runs the complete "
-                                "search; device stage of query k+1 overlaps the host stage of query k (pipeline_depth=%d); targets "
-                                "resident in HBM (pack+upload once: %.2fs, generation %.2fs, not timed)" % (args.pipeline_depth, t_pack, t_gen),
+                "timed_region": "hmmer.hmmsearch over steps x queries_per_step queries (the same profile each time), every query runs "
+                                "the complete search; device stage of later queries overlaps the host stage of earlier ones "
+                                "(pipeline_depth=%d batches); targets resident in HBM (pack+upload once: %.2fs, generation %.2fs, "
+                                "not timed)" % (args.pipeline_depth, t_pack, t_gen),
+                "queries_per_step": qps, "queries_per_device_batch": lanes_per_launch,
                 "pipeline_depth": args.pipeline_depth, "feeders": args.feeders, "host_threads_per_rank": host_threads,
                 "spinup_windows_s": [round(x, 4) for x in spin],
                 "latency_ms_per_query": round(stage.get("total", 0.0), 3),
@@ -456,9 +471,9 @@ def main():
                 "device_ms": {k: round(v, 4) for k, v in stage.items()},
                 # later-stage work, reported separately from the headline: cells actually run per stage
                 "stage_gcups": {
-                    "msv": round(cells_rank / (stage["msv_kernel"] * 1e-3) / 1e9, 1),
-                    "viterbi": round(sc["bias"] * args.seqlen * hmm.M / (stage["viterbi"] * 1e-3) / 1e9, 1),
-                    "forward": round(sc["vit"] * args.seqlen * hmm.M / (stage["forward"] * 1e-3) / 1e9, 1),
+                    "msv": round(B * cells_rank / (stage["msv_kernel"] * 1e-3) / 1e9, 1),
+                    "viterbi": round(B * sc["bias"] * args.seqlen * hmm.M / (stage["viterbi"] * 1e-3) / 1e9, 1),
+                    "forward": round(B * sc["vit"] * args.seqlen * hmm.M / (stage["forward"] * 1e-3) / 1e9, 1),
                 },
             },
             "roofline": {
@@ -467,7 +482,7 @@ def main():
                 "frac": round(achieved_gbs / HBM_PEAK_GBS, 6),
                 # HBM bytes per launch from the PMC passes of the same command (profiles/msv_traffic.json names the runs);
                 # None when this workload has no committed measurement.
-                "traffic": msv_traffic_bytes(f"{args.hmm}:{args.nseq}x{args.seqlen}"),
+                "traffic": msv_traffic_bytes(f"{args.hmm}:{args.nseq}x{args.seqlen}:b{B}"),
                 "note": "the MSV working set (emission tables) lives in LDS; only residues stream from HBM (~1/M byte per cell), "
                         "so the binding roof is VALU issue, reported below",
                 "valu": {"msv_gcups": round(msv_cups / 1e9, 1), "ops_per_cell": MSV_OPS_PER_CELL,
@@ -478,7 +493,7 @@ def main():
                                          "msv_gcups": round(cells_rank / (solo["msv_kernel"] * 1e-3) / 1e9, 1),
                                          "frac": round(cells_rank / (solo["msv_kernel"] * 1e-3) * MSV_OPS_PER_CELL / VALU_LANE_OPS_PER_S, 4)}
                                         if solo else None)},
-                "kernel_ms": round(msv_ms, 4), "algorithmic_bytes": int(alg_bytes),
+                "kernel_ms": round(msv_ms, 4), "algorithmic_bytes": int(alg_bytes), "queries_per_launch": B,
             },
         }
         if pfam is not None:

@@ -28,13 +28,13 @@ template <class A> struct ArgRun {
   const A &at(int i) const { return *reinterpret_cast<const A *>(reinterpret_cast<const char *>(host) + (size_t) i * stride); }
   ArgRef ref() const { return ArgRef{ dev, stride }; }
 };
-// blocks per lane: <want> of them have work; one lane alone gets what is resident at once, the lanes of a batch share
-// about twice that (their blocks queue up behind each other; every kernel walks its list with a grid-stride loop)
+// blocks per lane: <want> of them are expected to have work (every kernel walks its list with a grid-stride loop, so
+// an estimate that is too low only costs balance, and blocks without work leave before they load their tables); at
+// most what is resident at once per lane -- the lanes' blocks queue up behind each other
 inline unsigned lane_grid(long want, long resident, int nlanes)
 {
-  long cap = nlanes > 1 ? (2 * resident + nlanes - 1) / nlanes : resident;
-  if (cap < 1) cap = 1;
-  if (want > cap) want = cap;
+  (void) nlanes;
+  if (want > resident) want = resident;
   return (unsigned) (want < 1 ? 1 : want);
 }
 

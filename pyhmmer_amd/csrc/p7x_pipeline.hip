@@ -592,6 +592,22 @@ static StageParams make_params(const Profile &p, const p7x_pipeline_cfg &cfg)
   return s;
 }
 
+// Expected lengths of the work lists (grid sizing only; the kernels read the true lengths on the device): the filters
+// pass about F1 / F2 / F3 of the comparisons of unrelated sequences, a few times that on homolog-rich databases.
+struct ListEstimates { int bias, vit, fwd, fin; };
+static ListEstimates estimate_lists(const p7x_pipeline_cfg &cfg, int64_t nslots)
+{
+  auto est = [&](double f, double slack, int floor_) {
+    const double v = cfg.do_max ? (double) nslots : std::min<double>((double) nslots, (double) nslots * f * slack + floor_);
+    return (int) std::min<double>(v, (double) INT_MAX);
+  };
+  ListEstimates e;
+  e.bias = est(cfg.F1, 2.0, 1024); e.vit = e.bias;
+  e.fwd = est(cfg.F2, 8.0, 512);
+  e.fin = est(cfg.F3, 50.0, 1024);
+  return e;
+}
+
 static WaveSeqArgs ws_args(const Profile &p, const DevProfile *dp, const p7x_seqdb *db, DeviceCtx *ctx)
 {
   WaveSeqArgs a{};
@@ -777,6 +793,7 @@ struct CascadeRun {
   const p7x_seqdb *db = nullptr;
   DeviceCtx *ctx = nullptr;
   Workspace *ws = nullptr;
+  int est_bias = 0, est_vit = 0, est_fwd = 0, est_fin = 0;      // expected list lengths (grid sizing)
   bool queued = false, collected = false;
   ~CascadeRun() { if (ws && queued && !collected) { (void) hipStreamSynchronize(ws->stream); release_workspace(ws); } }
 };
@@ -840,7 +857,7 @@ static int fill_survivor_args(CascadeRun &r, int first, int n, bool retry, int n
     la.lay = lay;
     WaveSeqArgs a = ws_args(p, dp, db, ctx);
     a.trans = dp->fwd_trans; a.emis = dp->fwd_emis; a.list = b.list_fin; a.nlist_ptr = &b.counters[4];
-    a.nlist = (int) std::min<int64_t>(cap, INT_MAX);          // sizes the grid only
+    a.nlist = (int) std::min<int64_t>(cap, retry ? std::max(nfin, 1) : std::max(r.est_fin, 1));          // sizes the grid only
     a.out_sc = b.fwd_by_item; a.xmx = ws->xmx_f; a.xmx_off = xmx_off;
     a.abort_flag = &b.counters[12];
     la.rows = a;
@@ -869,7 +886,8 @@ static int launch_survivor_passes(CascadeRun &r, const LaneClass &c, hipStream_t
   if (record_events) P7X_HIP(hipEventRecord(ws->ev[5], s));
   if ((st = class_wave(c, ws, &LaneArgs::bck, true, ctx, s)) != P7X_OK) return st;
   {   // posterior decoding of the special states and the region scan, on the rows where they are
-    const unsigned gx = lane_grid(std::min<int64_t>((cap + 3) / 4, ctx->num_cu * 4), ctx->num_cu * 4, c.n);
+    const int64_t items = std::min<int64_t>(cap, retry ? cap : std::max(r.est_fin, 1));
+    const unsigned gx = lane_grid((items + 3) / 4, ctx->num_cu * 4, c.n);
     hipLaunchKernelGGL(regions_kernel, dim3(gx, (unsigned) c.n), dim3(256), 0, s, lane_run(ws, &LaneArgs::reg, c.first, c.n).ref());
     P7X_HIP(hipGetLastError());
   }
@@ -900,7 +918,7 @@ static int class_cascade(CascadeRun &r, const LaneClass &c, hipStream_t s, bool 
   const ArgRef dec = lane_run(ws, &LaneArgs::dec, c.first, c.n).ref();
   hipLaunchKernelGGL(decide_msv_kernel, dim3((unsigned) ((db->nslots + 255) / 256), (unsigned) c.n), dim3(256), 0, s, dec);
   if (record_events) P7X_HIP(hipEventRecord(ws->ev[1], s));
-  hipLaunchKernelGGL(bias_kernel, dim3(lane_grid((db->nslots + 63) / 64, ctx->num_cu * 4, c.n), (unsigned) c.n), dim3(64), 0, s, dec);
+  hipLaunchKernelGGL(bias_kernel, dim3(lane_grid((r.est_bias + 63) / 64, ctx->num_cu * 4, c.n), (unsigned) c.n), dim3(64), 0, s, dec);
   {   // the Viterbi work list, in slot order
     const unsigned nchunks = (unsigned) ((db->nslots + kCompactChunk - 1) / kCompactChunk);
     const ArgRef cmp = lane_run(ws, &LaneArgs::cmp, c.first, c.n).ref();
@@ -909,11 +927,10 @@ static int class_cascade(CascadeRun &r, const LaneClass &c, hipStream_t s, bool 
   }
   if (record_events) P7X_HIP(hipEventRecord(ws->ev[2], s));
   if ((st = class_viterbi(c, r.lm, ctx, ws, s)) != P7X_OK) return st;
-  const unsigned gdec = lane_grid((db->nslots + 255) / 256, ctx->num_cu, c.n);
-  hipLaunchKernelGGL(decide_vit_kernel, dim3(gdec, (unsigned) c.n), dim3(256), 0, s, dec);
+  hipLaunchKernelGGL(decide_vit_kernel, dim3(lane_grid((r.est_vit + 255) / 256, ctx->num_cu, c.n), (unsigned) c.n), dim3(256), 0, s, dec);
   if (record_events) P7X_HIP(hipEventRecord(ws->ev[3], s));
   if ((st = class_wave(c, ws, &LaneArgs::fwd, false, ctx, s)) != P7X_OK) return st;
-  hipLaunchKernelGGL(decide_fwd_kernel, dim3(gdec, (unsigned) c.n), dim3(256), 0, s, dec);
+  hipLaunchKernelGGL(decide_fwd_kernel, dim3(lane_grid((r.est_fwd + 255) / 256, ctx->num_cu, c.n), (unsigned) c.n), dim3(256), 0, s, dec);
   P7X_HIP(hipGetLastError());
   if (record_events) P7X_HIP(hipEventRecord(ws->ev[4], s));
   return launch_survivor_passes(r, c, s, false, record_events);
@@ -945,7 +962,8 @@ static int cascade_enqueue(CascadeRun &r)
   Workspace *ws = r.ws;
   hipStream_t s = ws->stream;
   r.queued = true;
-  const int nbound = (int) std::min<int64_t>(db->nslots, INT_MAX);
+  const ListEstimates est = estimate_lists(cfg, db->nslots);
+  r.est_bias = est.bias; r.est_vit = est.vit; r.est_fwd = est.fwd; r.est_fin = est.fin;
   std::vector<int> nlong_of((size_t) nq, 0);
   std::vector<int64_t> vit_long_of((size_t) nq, 0);
   for (const LaneClass &c : classes) for (int l = c.first; l < c.first + c.n; ++l) { nlong_of[(size_t) l] = c.nlong; vit_long_of[(size_t) l] = c.vit_long; }
@@ -960,14 +978,14 @@ static int cascade_enqueue(CascadeRun &r)
     la.dec = d;
     fill_msv_args(la, p, dp, db, ctx, b, nlong_of[(size_t) l]);
     const int64_t vit_long = vit_long_of[(size_t) l];
-    fill_vit_args(la, p, dp, db, ctx, b.list_vit, nbound, &b.counters[2], b.xC,
-                  vit_long > 0 ? &b.counters[13] : nullptr, (int) std::min<int64_t>(vit_long, INT_MAX));
+    fill_vit_args(la, p, dp, db, ctx, b.list_vit, est.vit, &b.counters[2], b.xC,
+                  vit_long > 0 ? &b.counters[13] : nullptr, (int) std::min<int64_t>(vit_long, (int64_t) est.vit));
     CompactArgs ca{};
     ca.stage = b.stage; ca.list = b.list_vit; ca.chunk_cnt = ws->chunk_cnt + (size_t) l * (size_t) ws->chunks_per_lane; ca.counters = b.counters;
     ca.nslots = db->nslots; ca.long_slots = vit_long;
     la.cmp = ca;
     WaveSeqArgs a = ws_args(p, dp, db, ctx);
-    a.trans = dp->fwd_trans; a.emis = dp->fwd_emis; a.list = b.list_fwd; a.nlist = nbound; a.nlist_ptr = &b.counters[3];
+    a.trans = dp->fwd_trans; a.emis = dp->fwd_emis; a.list = b.list_fwd; a.nlist = est.fwd; a.nlist_ptr = &b.counters[3];
     a.out_sc = b.fwd_by_item;
     la.fwd = a;
   }
