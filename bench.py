@@ -366,12 +366,12 @@ def main():
         torch.cuda.synchronize()
 
     # Untimed spin-up (independent of --warmup): a fresh process needs a few dozen queries before the host worker pool,
-    # the pooled device workspaces and the clocks settle (first windows measure 10-25 % low).  Windows of 20 queries are
+    # the pooled device workspaces and the clocks settle (first windows measure 10-25 % low).  Windows of 40 queries are
     # run until three consecutive ones agree to 2 % (at most `--spinup-max` windows); all ranks run the same number.
     spin = []
     for _ in range(args.spinup_max):
         t0 = time.perf_counter()
-        run(max(1, 20 // qps))
+        run(max(1, 40 // qps))
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
         if dist is not None:
