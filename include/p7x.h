@@ -164,7 +164,18 @@ typedef struct p7x_pipeline_cfg {
   int32_t host_threads;      /* workers for host-side domain definition; 0 = hardware_concurrency */
   int32_t host_envelopes;    /* 0 (default): single-domain envelopes are rescored by the device kernel; 1: on the host */
   int32_t host_regions;      /* 0 (default): posterior decoding of the specials + region scan on the device; 1: on the host */
+  /* long targets (nhmmer): p7_pipeline.pxd:80-87, 103-107; LongTargetsPipeline.__init__ plan7.pyx:6957-7060 */
+  int32_t long_targets;      /* p7_Pipeline_LongTarget semantics: every domain is a hit, E-values from residues searched */
+  int32_t strands;           /* P7X_STRAND_BOTH | _TOPONLY | _BOTTOMONLY */
+  int32_t B1, B2, B3;        /* window lengths of the biased-composition modifier for the MSV / Viterbi / Forward filters */
+  int32_t block_length;      /* residues per block read from a long target (W); consecutive blocks overlap by max_length */
+  int32_t window_length;     /* > 0: overrides the model's max_length (nhmmer --w_length) */
+  int32_t lt_bias_mode;      /* how a long-target envelope's bias is formed (rescore_isolated_domain in p7x_domaindef.cpp); default 20:
+                              * alignment against emissions re-derived for a background mixed with the envelope's composition,
+                              * score from the unmodified model, bias = the score lost to the adjustment */
+  float   lt_bg_mix;         /* weight of the envelope's composition in that background; default 0.75 */
 } p7x_pipeline_cfg;
+enum { P7X_STRAND_BOTH = 0, P7X_STRAND_TOPONLY = 1, P7X_STRAND_BOTTOMONLY = 2 };
 void p7x_pipeline_cfg_default(p7x_pipeline_cfg *cfg);   /* p7_pipeline_Create(NULL,...) defaults, plan7.pyx:5413-5421 */
 
 typedef struct p7x_counters {   /* accounting, p7_pipeline.pxd:88-101 */
@@ -237,6 +248,29 @@ int  p7x_search_batch_enqueue(const p7x_pipeline_cfg *cfg, const p7x_oprofile *c
 int  p7x_search_batch_finish(p7x_pending *pending, const char *const *names, const char *const *accs,
                              const char *const *descs, p7x_tophits **outs);
 size_t p7x_pending_nqueries(const p7x_pending *pending);
+
+/* nhmmer: LongTargetsPipeline.search_hmm / _search_loop_longtargets (plan7.pyx:7272-7418, 7541-7664) for a block of
+ * long DNA / RNA targets.  Per target and strand: the SSV scan of p7_Pipeline_LongTarget (p7_pipeline.pxd:131-143) runs
+ * on the device over the whole strand (reverse complement formed on the fly); the windows it seeds go through
+ * p7_Pipeline_LongTarget's tail on the host (window MSV + bias, long-target Viterbi, Forward / Backward, domain
+ * definition with long_target = TRUE, one hit per domain), followed by p7_tophits_ComputeNhmmerEvalues, target lengths,
+ * p7_tophits_RemoveDuplicates, sort and threshold (plan7.pyx:7390-7412).  Targets: residues dsq[offsets[t] ..
+ * offsets[t] + lengths[t] - 1] (64-bit lengths: chromosomes); cfg.long_targets must be set. */
+int p7x_search_longtargets(const p7x_pipeline_cfg *cfg, const p7x_oprofile *om, int device,
+                           const uint8_t *dsq, const int64_t *offsets, const int64_t *lengths, size_t n,
+                           const char *const *names, const char *const *accs, const char *const *descs, p7x_tophits **out);
+/* SSV window seeds of one strand of one target block as p7_SSVFilter_longtarget emits them (position of the diagonal's
+ * first residue, model node of its last cell, diagonal length), for tests against the oracle: the device scan followed
+ * by upstream's sequential bookkeeping.  seeds: caller array of cap x 3 int64; returns the number found (may exceed cap)
+ * or a negative status. */
+int64_t p7x_ssv_longtarget_seeds(const p7x_pipeline_cfg *cfg, const p7x_oprofile *om, int device, const uint8_t *dsq, int64_t L,
+                                 int complement, int64_t *seeds, size_t cap);
+/* CPU test seam: the host tail of the long-target pipeline for seeds found elsewhere (the oracle's scan); no device. */
+int p7x_longtarget_from_seeds(const p7x_pipeline_cfg *cfg, const p7x_oprofile *om,
+                              const uint8_t *dsq, const int64_t *offsets, const int64_t *lengths, size_t n,
+                              const char *const *names, const char *const *accs, const char *const *descs,
+                              const int64_t *seed_target, const int64_t *seed_block, const int32_t *seed_strand,
+                              const int64_t *seeds, size_t nseeds, p7x_tophits **out);
 
 /* hmmscan orientation (Pipeline.scan_seq / _scan_loop, plan7.pyx:6534-6677; hmmer/_hmmscan.py): search every model
  * against the block of query sequences with cfg.mode = P7X_SCAN_MODELS (one device pass per model, nothing pruned), then

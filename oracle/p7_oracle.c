@@ -993,3 +993,68 @@ int p7o_msv_block(P7O_PROFILE *p, const uint8_t *dsq_concat, const int64_t *offs
   }
   return 0;
 }
+
+/* ---------------------------------------------------------------- long targets (nhmmer)
+ * upstream impl_sse/msvfilter.c p7_SSVFilter_longtarget (reference include/libhmmer/p7_pipeline.pxd:131-143, called by
+ * p7_Pipeline_LongTarget from plan7.pyx:7628/7645): the sequential SSV scan of one strand block.  Un-striped u8
+ * arithmetic; the choice among several cells at or above the threshold follows the order in which upstream unstripes
+ * the row (vector q outer, byte z inner).  Emits (first residue of the diagonal, model node of its last cell, length)
+ * per window seed.  Parity: restated from memory of upstream; pinned end to end by tests/golden/tables/bmyD{1,2}.tbl.
+ */
+static float p7o_null1_len(int L) { float p1 = (float) L / (float) (L + 1); return (float) L * logf(p1) + logf(1.0f - p1); }
+
+int64_t p7o_ssv_longtarget(P7O_PROFILE *p, const uint8_t *dsq, int64_t L, int max_length, double F1, int64_t *seeds, int64_t cap)
+{
+  int M = p->M, Q = p->Q16;
+  /* score threshold for P = F1 under the length model of max_length (upstream's comment block in p7_SSVFilter_longtarget) */
+  double invP = p->evparam[p7_MMU] - log(-1.0 * log(1.0 - F1)) / p->evparam[p7_MLAMBDA];      /* esl_gumbel_invsurv */
+  float nullsc = p7o_null1_len(max_length);
+  int tjb = unbiased_byteify(p, logf(3.0f / (float) (max_length + 3)));
+  int sc_thresh = (int) ceil(((nullsc + (invP * 0.69314718055994529) + 3.0) * p->scale_b) + p->base_b + p->tec_b + tjb);
+  int bias = p->bias_b, xB = p->base_b - tjb - p->tbm_b; if (xB < 0) xB = 0;
+  int *row = (int *) calloc(M + 1, sizeof(int)), *nxt = (int *) calloc(M + 1, sizeof(int));
+  int64_t nseeds = 0;
+  for (int64_t i = 1; i <= L; i++) {
+    int x = dsq[i], hit = 0;
+    for (int k = 1; k <= M; k++) {
+      int sv = row[k-1] > xB ? row[k-1] : xB;
+      sv += bias; if (sv > 255) sv = 255;
+      sv -= rb_unstriped(p, x, k); if (sv < 0) sv = 0;
+      nxt[k] = sv;
+      if (sv >= sc_thresh) hit = 1;
+    }
+    { int *t = row; row = nxt; nxt = t; }
+    if (!hit) continue;
+    /* which model state hit the threshold: the best one, the first such in unstriping order */
+    int end = -1, rem_sc = -1;
+    for (int q = 0; q < Q; q++)
+      for (int z = 0; z < 16; z++) {
+        int k = q + Q * z + 1;
+        if (k <= M && row[k] >= sc_thresh && row[k] > rem_sc) { end = k; rem_sc = row[k]; }
+      }
+    for (int k = 0; k <= M; k++) row[k] = 0;        /* values restart from xB in the next row */
+    /* recover the diagonal that hit the threshold */
+    int start = end, sc = rem_sc;
+    int64_t target_end = i, target_start = i;
+    while (rem_sc > p->base_b - tjb - p->tbm_b && start >= 1 && target_start >= 1) {
+      rem_sc -= bias - rb_unstriped(p, dsq[target_start], start);
+      --start; --target_start;
+    }
+    start++; target_start++;
+    /* extend it forward while it keeps (nearly) rising */
+    int k = end + 1; int64_t n = target_end + 1, max_end = target_end; int max_sc = sc, pos_since_max = 0;
+    while (k < M && n <= L) {
+      sc += bias - rb_unstriped(p, dsq[n], k);
+      if (sc >= max_sc) { max_sc = sc; max_end = n; pos_since_max = 0; }
+      else if (++pos_since_max == 5) break;
+      k++; n++;
+    }
+    end += (int) (max_end - target_end);
+    target_end = max_end;
+    if (nseeds < cap) { seeds[3*nseeds] = target_start; seeds[3*nseeds+1] = end; seeds[3*nseeds+2] = end - start + 1; }
+    nseeds++;
+    i = target_end;                                 /* skip forward */
+  }
+  free(row); free(nxt);
+  return nseeds;
+}

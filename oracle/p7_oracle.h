@@ -116,6 +116,9 @@ int   p7o_msv_block(P7O_PROFILE *p, const uint8_t *dsq_concat, const int64_t *of
 void  p7o_expf_neg(const double *in, float *out, size_t n);   /* expf(-1.0*v), '*' encoded as +inf */
 float p7o_sse_expf_scalar(float x);
 
+/* long targets: upstream p7_SSVFilter_longtarget for one strand block; seeds = cap x (first residue, last node, length) */
+int64_t p7o_ssv_longtarget(P7O_PROFILE *p, const uint8_t *dsq, int64_t L, int max_length, double F1, int64_t *seeds, int64_t cap);
+
 #ifdef __cplusplus
 }
 #endif

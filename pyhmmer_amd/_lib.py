@@ -17,7 +17,7 @@ _ROOT = _PKG.parent
 CSRC = _PKG / "csrc"
 LIB_PATH = _PKG / "libp7x.so"
 
-SOURCES = ["p7x_profile.cpp", "p7x_device.hip", "p7x_devimage.hip", "p7x_msv.hip", "p7x_vitfwd.hip", "p7x_vitpk.hip", "p7x_envelope.hip",
+SOURCES = ["p7x_profile.cpp", "p7x_device.hip", "p7x_devimage.hip", "p7x_msv.hip", "p7x_vitfwd.hip", "p7x_vitpk.hip", "p7x_envelope.hip", "p7x_ssvlong.hip", "p7x_longtarget.hip",
            "p7x_envscore.hip", "p7x_pipeline.hip", "p7x_domaindef.cpp", "p7x_tophits.cpp"]
 
 
@@ -104,6 +104,8 @@ class PipelineCfg(C.Structure):
         ("F1", C.c_double), ("F2", C.c_double), ("F3", C.c_double),
         ("do_max", C.c_int32), ("do_biasfilter", C.c_int32), ("do_null2", C.c_int32),
         ("seed", C.c_uint32), ("mode", C.c_int32), ("host_threads", C.c_int32), ("host_envelopes", C.c_int32), ("host_regions", C.c_int32),
+        ("long_targets", C.c_int32), ("strands", C.c_int32), ("B1", C.c_int32), ("B2", C.c_int32), ("B3", C.c_int32),
+        ("block_length", C.c_int32), ("window_length", C.c_int32), ("lt_bias_mode", C.c_int32), ("lt_bg_mix", C.c_float),
     ]
 
 
@@ -191,6 +193,10 @@ _SIGNATURES = {
     "p7x_search_batch_enqueue": (C.c_int, [C.POINTER(PipelineCfg), C.POINTER(_VP), C.c_size_t, _VP, _VP, C.POINTER(_VP)]),
     "p7x_search_batch_finish": (C.c_int, [_VP, _VP, _VP, _VP, C.POINTER(_VP)]),
     "p7x_pending_nqueries": (C.c_size_t, [_VP]),
+    "p7x_search_longtargets": (C.c_int, [C.POINTER(PipelineCfg), _VP, C.c_int, _VP, _VP, _VP, C.c_size_t, _VP, _VP, _VP, C.POINTER(_VP)]),
+    "p7x_ssv_longtarget_seeds": (C.c_int64, [C.POINTER(PipelineCfg), _VP, C.c_int, _VP, C.c_int64, C.c_int, _VP, C.c_size_t]),
+    "p7x_longtarget_from_seeds": (C.c_int, [C.POINTER(PipelineCfg), _VP, _VP, _VP, _VP, C.c_size_t, _VP, _VP, _VP, _VP, _VP, _VP, _VP,
+                                            C.c_size_t, C.POINTER(_VP)]),
     "p7x_oprofile_write_pressed": (C.c_int, [_VP, C.POINTER(C.c_int64), _VP, C.c_size_t, C.POINTER(C.c_size_t), _VP, C.c_size_t,
                                              C.POINTER(C.c_size_t)]),
     "p7x_oprofile_read_pressed": (C.c_int, [_VP, C.c_size_t, _VP, C.c_size_t, _VP, C.POINTER(_VP), C.POINTER(C.c_size_t),

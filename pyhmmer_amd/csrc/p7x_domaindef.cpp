@@ -93,12 +93,25 @@ int fchoose(FastRng &r, const float *p, int n)
 }
 
 // ---------------------------------------------------------------- the query in a given configuration
+// Long-target (nhmmer) variant of envelope rescoring, upstream rescore_isolated_domain(..., long_target = TRUE, ...)
+struct LongTargetOpts {
+  bool do_null2 = true;
+  const float *match_prob = nullptr;   // [M+1][K] match emission probabilities of the core model (fwd_emissions_arr)
+  int bias_mode = 0;                   // how the envelope's bias correction is formed, see rescore_isolated_domain()
+  float bg_mix = 0.25f;                // weight of the envelope's own composition in the re-parameterised background
+  int max_env_extra = 20;
+  bool retrim_bg = false;              // recompute the background from the trimmed envelope before aligning it again
+  bool bg_from_ali = false, bg_from_window = false;
+};
+
 struct Model {
   const Profile *p;
   int M;
   float xf[4][2];                 // [E,N,J,C][MOVE,LOOP] for the current mode / length
+  const float *rf_over = nullptr; // [Kp][M+1] replacement match odds (long targets: composition-adjusted background)
+  const LongTargetOpts *lt = nullptr;
   const float *tf(int t) const { return p->tf.data() + (size_t) t * (M + 1); }
-  const float *rf(int x) const { return p->rf_.data() + (size_t) x * (M + 1); }
+  const float *rf(int x) const { return (rf_over ? rf_over : p->rf_.data()) + (size_t) x * (M + 1); }
   // D->D chains are the only serial dependency along k.  They are evaluated as kSeg independent segment chains
   // (instruction-level parallelism) followed by a vectorisable carry fix-up with these prefix products.
   static constexpr int kSeg = 8;
@@ -894,28 +907,110 @@ void make_alidisplay(const Profile &p, const Trace &tr, const uint8_t *dsq, int 
 struct Workspace { Matrix fwd, bck; Trace tr; std::vector<float> wm, wi; };
 
 // ---------------------------------------------------------------- rescore_isolated_domain
+// Match odds against a background that is mixed with the composition of the envelope (upstream reparameterize_model +
+// p7_oprofile_UpdateFwdEmissionScores): rf'[x][k] = match_prob[k][x] / bg'[x], degenerate codes by expectation.
+static void reparameterize(const Profile &p, const LongTargetOpts &lt, const uint8_t *dsq, int i, int j, std::vector<float> &rf)
+{
+  const int M = p.M, K = p.K, Kp = p.Kp;
+  const Alphabet &abc = Alphabet::get(p.abc_type);
+  float cnt[MAXK];
+  for (int x = 0; x < K; ++x) cnt[x] = 0.0f;
+  for (int pos = i; pos <= j; ++pos) {           // esl_sq_CountResidues: degenerate residues count fractionally
+    const int x = dsq[pos];
+    if (x < K) cnt[x] += 1.0f;
+    else if (x > K && x <= Kp - 3) {
+      int nd = 0; for (int y = 0; y < K; ++y) nd += abc.degen[x][y] ? 1 : 0;
+      for (int y = 0; y < K; ++y) if (abc.degen[x][y]) cnt[y] += 1.0f / (float) nd;
+    }
+  }
+  float tot = 0.0f; for (int x = 0; x < K; ++x) tot += cnt[x];
+  float bgn[MAXK];
+  for (int x = 0; x < K; ++x) bgn[x] = lt.bg_mix * (tot > 0 ? cnt[x] / tot : p.bgf[x]) + (1.0f - lt.bg_mix) * p.bgf[x];
+  rf.assign((size_t) Kp * (M + 1), 0.0f);
+  for (int k = 1; k <= M; ++k) {
+    float sc[MAXKP];
+    for (int x = 0; x < K; ++x) sc[x] = logf(lt.match_prob[(size_t) k * K + x] / bgn[x]);
+    sc[K] = sc[Kp - 2] = sc[Kp - 1] = -INFINITY;
+    for (int x = K + 1; x <= Kp - 3; ++x) {      // esl_abc_FExpectScVec with the new background
+      float num = 0.f, den = 0.f;
+      for (int y = 0; y < K; ++y) if (abc.degen[x][y]) { num += sc[y] * bgn[y]; den += bgn[y]; }
+      sc[x] = num / den;
+    }
+    for (int x = 0; x < Kp; ++x) rf[(size_t) x * (M + 1) + k] = expf(sc[x]);
+  }
+}
+
 int rescore_isolated_domain(const Profile &p, Model &om, const uint8_t *dsq, int L, int i, int j, bool null2_is_done,
                             Workspace &ws, DomainDefResult &dd)
 {
-  const int Ld = j - i + 1;
+  const LongTargetOpts *lt = om.lt;
+  int Ld = j - i + 1;
   float envsc = 0.0f, oasc = 0.0f;
-  { ProfScope ps(5); forward_full(om, dsq + i - 1, Ld, ws.fwd, &envsc); }
-  { ProfScope ps(6); backward_full(om, dsq + i - 1, Ld, ws.fwd, ws.bck, nullptr); }
-  { ProfScope ps(7); if (decoding(om, ws.fwd, ws.bck) == P7X_ERANGE) return P7X_ENORESULT; }   // repetitive garbage; the envelope is dropped
-  { ProfScope ps(8); optimal_accuracy(om, ws.bck, ws.fwd, &oasc); }                              // <fwd> now holds the OA matrix
-  ProfScope ps9(9);
-  if (oa_trace(om, ws.bck, ws.fwd, ws.tr) != P7X_OK) return P7X_EINVAL;
-  for (size_t z = 0; z < ws.tr.st.size(); ++z) if (ws.tr.i[z] > 0) ws.tr.i[z] += i - 1;
+  float save_xf[4][2];
+  thread_local std::vector<float> rf_lt;
+  if (lt) {   // the envelope keeps the window's length model (the pipeline re-expresses the score for max_length afterwards)
+    std::memcpy(save_xf, om.xf, sizeof(save_xf));
+    if (lt->do_null2 && lt->bias_mode != 0) {
+      if (lt->bg_from_window) reparameterize(p, *lt, dsq, 1, L, rf_lt); else reparameterize(p, *lt, dsq, i, j, rf_lt);
+      om.rf_over = rf_lt.data();
+    }
+  }
+  struct Restore { Model &om; const LongTargetOpts *lt; float (*xf)[2];
+                   ~Restore() { if (lt) { om.rf_over = nullptr; std::memcpy(om.xf, xf, sizeof(float) * 8); } } } restore{ om, lt, save_xf };
+  auto align = [&]() -> int {
+    { ProfScope ps(5); forward_full(om, dsq + i - 1, Ld, ws.fwd, &envsc); }
+    { ProfScope ps(6); backward_full(om, dsq + i - 1, Ld, ws.fwd, ws.bck, nullptr); }
+    { ProfScope ps(7); if (decoding(om, ws.fwd, ws.bck) == P7X_ERANGE) return P7X_ENORESULT; }   // repetitive garbage; the envelope is dropped
+    { ProfScope ps(8); optimal_accuracy(om, ws.bck, ws.fwd, &oasc); }                              // <fwd> now holds the OA matrix
+    ProfScope ps9(9);
+    if (oa_trace(om, ws.bck, ws.fwd, ws.tr) != P7X_OK) return P7X_EINVAL;
+    for (size_t z = 0; z < ws.tr.st.size(); ++z) if (ws.tr.i[z] > 0) ws.tr.i[z] += i - 1;
+    return P7X_OK;
+  };
+  int st = align();
+  if (st != P7X_OK) return st;
   Domain dom;
   make_alidisplay(p, ws.tr, dsq, L, dom);
-  float domcorrection = 0.0f;
-  if (!null2_is_done) {
-    float null2[MAXKP];
-    ProfScope psn(10);
-    null2_by_expectation(om, ws.bck, null2);
-    for (int pos = i; pos <= j; ++pos) dd.n2sc[pos] = logf(null2[dsq[pos]]);
+  if (lt && (i < dom.sqfrom - lt->max_env_extra || j > dom.sqto + lt->max_env_extra)) {
+    // long targets often give envelopes far wider than the alignment (a repetitive stretch of the model collecting
+    // weak matches): trim the envelope to the alignment +- max_env_extra and align again
+    i = std::max<int>(i, (int) dom.sqfrom - lt->max_env_extra);
+    j = std::min<int>(j, (int) dom.sqto + lt->max_env_extra);
+    Ld = j - i + 1;
+    if (om.rf_over && lt->retrim_bg && !lt->bg_from_window) {
+      if (lt->bg_from_ali) reparameterize(p, *lt, dsq, (int) dom.sqfrom, (int) dom.sqto, rf_lt); else reparameterize(p, *lt, dsq, i, j, rf_lt);
+      om.rf_over = rf_lt.data();
+    }
+    if ((st = align()) != P7X_OK) return st;
+    dom = Domain();
+    make_alidisplay(p, ws.tr, dsq, L, dom);
   }
-  for (int pos = i; pos <= j; ++pos) domcorrection += dd.n2sc[pos];
+  float domcorrection = 0.0f;
+  if (lt) {
+    if (lt->do_null2) {
+      if (lt->bias_mode == 0) {        // null2 by expectation over the envelope, as for protein targets
+        float null2[MAXKP];
+        null2_by_expectation(om, ws.bck, null2);
+        for (int pos = i; pos <= j; ++pos) domcorrection += logf(null2[dsq[pos]]);
+      } else {                         // the score lost against the composition-adjusted background is the bias
+        float orig = 0.0f;
+        om.rf_over = nullptr;
+        forward_full(om, dsq + i - 1, Ld, ws.fwd, &orig);
+        if (lt->bias_mode == 1) { domcorrection = std::max(0.0f, orig - envsc); envsc = orig; }
+        else if (lt->bias_mode == 3) { domcorrection = (orig - envsc) + 5.545177444f; envsc = orig; }   // bias = logsum(0, orig - adjusted)
+        else if (lt->bias_mode == 4) { domcorrection = std::max(0.0f, orig - envsc); envsc = orig; }     // bias = the loss itself
+        else domcorrection = std::max(0.0f, orig - envsc);      // mode 2: envsc stays the adjusted score
+      }
+    }
+  } else {
+    if (!null2_is_done) {
+      float null2[MAXKP];
+      ProfScope psn(10);
+      null2_by_expectation(om, ws.bck, null2);
+      for (int pos = i; pos <= j; ++pos) dd.n2sc[pos] = logf(null2[dsq[pos]]);
+    }
+    for (int pos = i; pos <= j; ++pos) domcorrection += dd.n2sc[pos];
+  }
   dom.domcorrection = domcorrection;
   dom.ienv = i; dom.jenv = j; dom.envsc = envsc; dom.oasc = oasc;
   dom.iali = dom.sqfrom; dom.jali = dom.sqto;
@@ -970,6 +1065,8 @@ int domaindef_regions(const Profile &p, int L, const float *fx, const float *bx,
 
 // Step 2 for a multi-domain region: region_trace_ensemble (sampled tracebacks from a multihit Forward matrix of the
 // region, single-linkage clustering of their domain coordinates), then every surviving envelope is rescored.
+static thread_local const LongTargetOpts *t_long_target = nullptr;     // set by the long-target pipeline around its calls
+
 int domaindef_multi_region(const Profile &p, const uint8_t *dsq, int L, int i, int j, uint32_t seed, bool do_reseeding,
                            MultiRegionState &state, DomainDefResult &dd, std::vector<Domain> &out)
 {
@@ -978,6 +1075,7 @@ int domaindef_multi_region(const Profile &p, const uint8_t *dsq, int L, int i, i
   const bool of_smaller = true; const int max_diagdiff = 4;
   thread_local Workspace ws;
   Model om{ &p, p.M, {} };
+  om.lt = t_long_target;
   om.prepare();
   om.prepare_rfT();
   ws.wm.resize(p.M + 2); ws.wi.resize(p.M + 2);
@@ -1059,6 +1157,7 @@ static int dispatch_regions(const Profile &p, const uint8_t *dsq, int L, const R
                             bool do_reseeding, DomainDefResult &dd, std::vector<EnvelopeRequest> *defer, int item)
 {
   Model om{ &p, p.M, {} };
+  om.lt = t_long_target;
   thread_local Workspace ws;
   bool prepared = false;
   MultiRegionState state;
@@ -1141,3 +1240,5 @@ int domaindef_finish_deferred(const Profile &p, const uint8_t *dsq, int L, const
 }
 
 } // namespace p7x
+
+#include "p7x_longtarget.inc.hpp"

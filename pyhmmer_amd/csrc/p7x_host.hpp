@@ -78,6 +78,7 @@ struct Hit {                  // P7_HIT, p7_hit.pxd:27-58
   std::string name, acc, desc;
   bool has_acc = false, has_desc = false;
   int64_t seqidx = 0;
+  int32_t window_length = 0;  // long targets: the model's max_length the E-value refers to
   double sortkey = 0;
   float score = 0, pre_score = 0, sum_score = 0;
   double lnP = 0, pre_lnP = 0, sum_lnP = 0;
@@ -113,8 +114,23 @@ int host_finish_batch(const p7x_pipeline_cfg &cfg, const std::vector<FinishItem>
                       const char *const *names, const char *const *accs, const char *const *descs,
                       p7x_tophits **outs, EnvelopeScorer *scorer = nullptr);
 void tophits_set_total_ms(p7x_tophits *th, double stage1_ms, double stage2_ms);
+void tophits_sort_by_key(p7x_tophits &th);
+void tophits_threshold(p7x_tophits &th);
+bool tophits_target_reportable(const p7x_pipeline_cfg &c, float score, double lnP);
+int tophits_usable_cpus();
 void tophits_set_stages(p7x_tophits *th, std::vector<uint8_t> &&stage);
 float kahan_fsum(const float *v, int n);
+
+// ---- long targets (p7x_longtarget.inc.hpp <-> p7x_longtarget.hip)
+struct LongTargetRow { int64_t pos; int k, sc; };            // a row of a strand block that reached the SSV threshold, and the cell upstream picks
+struct LongTargetSeed { int64_t target, block_start; int strand; int64_t n; int k; int64_t length; };   // an SSV window seed of one block
+int longtarget_setup(const p7x_pipeline_cfg &cfg, const Profile &p, int *max_length, int *sc_thresh, int *xB);
+const uint8_t *longtarget_complement(int abc_type);
+void longtarget_seeds_from_rows(const Profile &p, const uint8_t *block_dsq, int64_t L, const LongTargetRow *rows, size_t nrows,
+                                int sc_thresh, int xB, std::vector<int64_t> &seeds3);
+int longtarget_run_host(const p7x_pipeline_cfg &cfg, const p7x_oprofile *om, const uint8_t *dsq, const int64_t *offsets, const int64_t *lengths,
+                        size_t n, const char *const *names, const char *const *accs, const char *const *descs,
+                        const std::vector<LongTargetSeed> &seeds, p7x_tophits **out);
 void host_prof_dump();
 
 } // namespace p7x

@@ -144,5 +144,25 @@ int env_max_blocks(int C, int nrows, int num_cu, int *nblocks);
 // every record of the run has the same C and nrows; grid.x = the widest job's nblocks
 int env_launch(const ArgRun<EnvArgs> &a, hipStream_t st);
 
+// ---- long-target SSV scan (p7x_ssvlong.hip): one chunk of one strand per wavefront, model split across the lanes
+struct SsvLongArgs {
+  const uint32_t *tab4;       // [2 parities][4][R][64] packed emission pairs of A, C, G, T (staged in LDS)
+  const uint32_t *tab_full;   // [2][Kp][R][64] the same for every residue code (degenerate residues, read from global memory)
+  const uint8_t *dsq;         // the target, 1-based (dsq[0] is a sentinel)
+  const uint8_t *comp;        // [Kp] complement of every residue code
+  long long L;                // target length
+  int M, Kp;
+  int chunk_len;              // rows per chunk
+  long long chunks_per_strand, nchunks;     // nchunks = strands x chunks_per_strand; chunk c of strand strand0 + c / chunks_per_strand
+  int strand0;                // 1: only the reverse-complement strand is scanned
+  int thresh_s;               // score threshold, relative to the begin score and offset by -32768 (the cells' representation)
+  int xB, Q16;                // the begin score in byte units; vectors per row of the reference's striped layout (tie-breaks)
+  // rows that reach the threshold: position on the strand, strand, and the cell upstream would pick (node, byte score)
+  int *nrec; long long *rec_pos; uint8_t *rec_strand; int *rec_k; int *rec_sc; int rec_cap;
+};
+int  ssvlong_pick_R(int M);
+void ssvlong_build_tables(const Profile &p, int R, std::vector<uint32_t> &tab4, std::vector<uint32_t> &tab_full);
+int  ssvlong_launch(int R, const SsvLongArgs &a, int num_cu, hipStream_t st);
+
 // ---- thread-per-sequence small stages (p7x_pipeline.hip)
 } // namespace p7x

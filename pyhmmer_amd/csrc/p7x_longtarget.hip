@@ -1,0 +1,180 @@
+// p7x_longtarget.hip -- device half of the long-target (nhmmer) search: the SSV scan of every target strand
+// (p7x_ssvlong.hip) and the hand-over of the rows it reports to the host tail (p7x_longtarget.inc.hpp).
+// Reference: LongTargetsPipeline._search_loop_longtargets, plan7.pyx:7541-7664; p7_Pipeline_LongTarget,
+// p7_pipeline.pxd:131-143.
+#include "p7x_device.hpp"
+#include "p7x_kernels.hpp"
+#include "p7x_host.hpp"
+#include <algorithm>
+#include <chrono>
+#include <cstring>
+#include <memory>
+
+namespace p7x {
+
+namespace {
+
+struct DevBuf {
+  void *p = nullptr;
+  ~DevBuf() { if (p) (void) hipFree(p); }
+  int alloc(size_t bytes) { if (p) (void) hipFree(p); p = nullptr; P7X_HIP(hipMalloc(&p, std::max<size_t>(bytes, 16))); return P7X_OK; }
+};
+
+struct ScanRow { int64_t pos; int strand, k, sc; };
+
+// The reset-free SSV scan of one target (both strands, or one): every row whose best diagonal reaches the threshold.
+// <ms>: kernel time by HIP events.
+static int scan_target(const p7x_pipeline_cfg &cfg, const Profile &p, DeviceCtx *ctx, const uint8_t *seq1 /* 1-based */, int64_t L,
+                       int sc_thresh, int xB, int strands_mask, std::vector<ScanRow> &rows, double *ms)
+{
+  const int R = ssvlong_pick_R(p.M);
+  if (R < 0) { set_error("model too long for the long-target SSV kernel (M > 6141)"); return P7X_EINVAL; }
+  std::vector<uint32_t> tab4, tab_full;
+  ssvlong_build_tables(p, R, tab4, tab_full);
+  DevBuf d_tab4, d_full, d_seq, d_comp, d_nrec, d_pos, d_strand, d_k, d_sc;
+  int st;
+  if ((st = d_tab4.alloc(tab4.size() * 4)) || (st = d_full.alloc(tab_full.size() * 4)) || (st = d_seq.alloc((size_t) L + 2)) ||
+      (st = d_comp.alloc(32)) || (st = d_nrec.alloc(4))) return st;
+  hipStream_t s = ctx->stream;
+  P7X_HIP(hipMemcpyAsync(d_tab4.p, tab4.data(), tab4.size() * 4, hipMemcpyHostToDevice, s));
+  P7X_HIP(hipMemcpyAsync(d_full.p, tab_full.data(), tab_full.size() * 4, hipMemcpyHostToDevice, s));
+  P7X_HIP(hipMemcpyAsync(static_cast<uint8_t *>(d_seq.p) + 1, seq1 + 1, (size_t) L, hipMemcpyHostToDevice, s));
+  P7X_HIP(hipMemcpyAsync(d_comp.p, longtarget_complement(p.abc_type), 18, hipMemcpyHostToDevice, s));
+  // chunks: long enough that the M warm-up rows are a small overhead, short enough that every SIMD gets several
+  const int64_t want_chunks = (int64_t) ctx->num_cu * 4 * 8;
+  int chunk_len = (int) std::max<int64_t>(8 * (int64_t) p.M, std::min<int64_t>(1 << 16, (L + want_chunks - 1) / want_chunks));
+  chunk_len = ((chunk_len + 63) / 64) * 64;
+  const int nstrands = strands_mask == 3 ? 2 : 1;
+  SsvLongArgs a{};
+  a.tab4 = static_cast<const uint32_t *>(d_tab4.p); a.tab_full = static_cast<const uint32_t *>(d_full.p);
+  a.dsq = static_cast<const uint8_t *>(d_seq.p); a.comp = static_cast<const uint8_t *>(d_comp.p);
+  a.L = L; a.M = p.M; a.Kp = p.Kp; a.chunk_len = chunk_len;
+  a.chunks_per_strand = (L + chunk_len - 1) / chunk_len; a.nchunks = a.chunks_per_strand * nstrands;
+  a.thresh_s = sc_thresh - xB - 32768; a.xB = xB; a.Q16 = p.Q16();
+  a.nrec = static_cast<int *>(d_nrec.p);
+  a.strand0 = strands_mask == 2 ? 1 : 0;
+  hipEvent_t e0, e1;
+  P7X_HIP(hipEventCreate(&e0)); P7X_HIP(hipEventCreate(&e1));
+  int cap = (int) std::min<int64_t>(std::max<int64_t>(1 << 16, L / 64), 1 << 28);
+  for (int attempt = 0; attempt < 2; ++attempt) {
+    if ((st = d_pos.alloc((size_t) cap * 8)) || (st = d_strand.alloc((size_t) cap)) || (st = d_k.alloc((size_t) cap * 4)) || (st = d_sc.alloc((size_t) cap * 4))) return st;
+    a.rec_pos = static_cast<long long *>(d_pos.p); a.rec_strand = static_cast<uint8_t *>(d_strand.p);
+    a.rec_k = static_cast<int *>(d_k.p); a.rec_sc = static_cast<int *>(d_sc.p); a.rec_cap = cap;
+    P7X_HIP(hipMemsetAsync(d_nrec.p, 0, 4, s));
+    P7X_HIP(hipEventRecord(e0, s));
+    if ((st = ssvlong_launch(R, a, ctx->num_cu, s)) != P7X_OK) return st;
+    P7X_HIP(hipEventRecord(e1, s));
+    int nrec = 0;
+    P7X_HIP(hipMemcpyAsync(&nrec, d_nrec.p, 4, hipMemcpyDeviceToHost, s));
+    P7X_HIP(hipStreamSynchronize(s));
+    float t = 0; (void) hipEventElapsedTime(&t, e0, e1);
+    if (ms) *ms = t;
+    if (nrec <= cap) {
+      std::vector<long long> pos((size_t) nrec); std::vector<uint8_t> strand((size_t) nrec); std::vector<int> k((size_t) nrec), sc((size_t) nrec);
+      if (nrec) {
+        P7X_HIP(hipMemcpy(pos.data(), d_pos.p, (size_t) nrec * 8, hipMemcpyDeviceToHost));
+        P7X_HIP(hipMemcpy(strand.data(), d_strand.p, (size_t) nrec, hipMemcpyDeviceToHost));
+        P7X_HIP(hipMemcpy(k.data(), d_k.p, (size_t) nrec * 4, hipMemcpyDeviceToHost));
+        P7X_HIP(hipMemcpy(sc.data(), d_sc.p, (size_t) nrec * 4, hipMemcpyDeviceToHost));
+      }
+      rows.resize((size_t) nrec);
+      for (int i = 0; i < nrec; ++i) rows[(size_t) i] = ScanRow{ pos[(size_t) i], strand[(size_t) i], k[(size_t) i], sc[(size_t) i] };
+      std::sort(rows.begin(), rows.end(), [](const ScanRow &x, const ScanRow &y) { return x.strand != y.strand ? x.strand < y.strand : x.pos < y.pos; });
+      (void) hipEventDestroy(e0); (void) hipEventDestroy(e1);
+      return P7X_OK;
+    }
+    cap = nrec + 1024;              // more rows than the buffer holds: once more with room for all of them
+  }
+  (void) hipEventDestroy(e0); (void) hipEventDestroy(e1);
+  set_error("long-target SSV scan: record buffer could not be sized");
+  return P7X_EMEM;
+}
+
+// seeds of one block of one strand from the rows of the whole-strand scan
+static void block_seeds(const Profile &p, const uint8_t *seq1, int64_t Lt, int64_t i, int64_t bn, int strand, const std::vector<ScanRow> &rows,
+                        int sc_thresh, int xB, std::vector<int64_t> &seeds3)
+{
+  // block rows 1..bn: strand 0: original positions i+1 .. i+bn; strand 1: reverse-strand positions (Lt-i-bn)+1 .. (Lt-i-bn)+bn
+  const int64_t base = strand == 0 ? i : Lt - i - bn;
+  std::vector<LongTargetRow> br;
+  auto lo = std::lower_bound(rows.begin(), rows.end(), ScanRow{ base + 1, strand, 0, 0 },
+                             [](const ScanRow &x, const ScanRow &y) { return x.strand != y.strand ? x.strand < y.strand : x.pos < y.pos; });
+  for (auto it = lo; it != rows.end() && it->strand == strand && it->pos <= base + bn; ++it) br.push_back(LongTargetRow{ it->pos - base, it->k, it->sc });
+  if (br.empty()) return;
+  const uint8_t *comp = longtarget_complement(p.abc_type);
+  std::vector<uint8_t> buf((size_t) bn + 2, 255);
+  if (strand == 0) std::memcpy(buf.data() + 1, seq1 + i + 1, (size_t) bn);
+  else for (int64_t q = 1; q <= bn; ++q) buf[(size_t) q] = comp[seq1[i + bn - q + 1]];
+  longtarget_seeds_from_rows(p, buf.data(), bn, br.data(), br.size(), sc_thresh, xB, seeds3);
+}
+
+} // namespace
+} // namespace p7x
+
+using namespace p7x;
+
+extern "C" {
+
+int p7x_search_longtargets(const p7x_pipeline_cfg *cfg, const p7x_oprofile *om, int device,
+                           const uint8_t *dsq, const int64_t *offsets, const int64_t *lengths, size_t n,
+                           const char *const *names, const char *const *accs, const char *const *descs, p7x_tophits **out)
+{
+  if (!cfg || !om || !out || (n && (!dsq || !offsets || !lengths))) { set_error("p7x_search_longtargets: bad arguments"); return P7X_EINVAL; }
+  if (!cfg->long_targets) { set_error("p7x_search_longtargets: cfg.long_targets is not set"); return P7X_EINVAL; }
+  const Profile &p = om->p;
+  int max_length = 0, sc_thresh = 0, xB = 0;
+  int st = longtarget_setup(*cfg, p, &max_length, &sc_thresh, &xB);
+  if (st != P7X_OK) return st;
+  DeviceCtx *ctx = nullptr;
+  if ((st = get_ctx(device, &ctx)) != P7X_OK) return st;
+  const int mask = cfg->strands == P7X_STRAND_TOPONLY ? 1 : (cfg->strands == P7X_STRAND_BOTTOMONLY ? 2 : 3);
+  const int64_t W = cfg->block_length, C = max_length;
+  std::vector<LongTargetSeed> seeds;
+  double scan_ms = 0.0;
+  for (size_t t = 0; t < n; ++t) {
+    const int64_t Lt = lengths[t];
+    if (Lt <= 0) continue;
+    const uint8_t *seq1 = dsq + offsets[t] - 1;
+    std::vector<ScanRow> rows;
+    double ms = 0.0;
+    if ((st = scan_target(*cfg, p, ctx, seq1, Lt, sc_thresh, xB, mask, rows, &ms)) != P7X_OK) return st;
+    scan_ms += ms;
+    for (int64_t i = 0; i < Lt; i += W - C) {
+      const int64_t bc = i == 0 ? 0 : std::min<int64_t>(C, Lt - i);
+      const int64_t bw = std::min<int64_t>(W, Lt - i - bc);
+      const int64_t bn = bc + bw;
+      if (bn <= 0) break;
+      for (int strand = 0; strand < 2; ++strand) {
+        if (!(mask & (1 << strand))) continue;
+        std::vector<int64_t> s3;
+        block_seeds(p, seq1, Lt, i, bn, strand, rows, sc_thresh, xB, s3);
+        for (size_t q = 0; q + 2 < s3.size(); q += 3) seeds.push_back(LongTargetSeed{ (int64_t) t, i, strand, s3[q], (int) s3[q + 1], s3[q + 2] });
+      }
+      if (i + bn >= Lt) break;
+    }
+  }
+  st = longtarget_run_host(*cfg, om, dsq, offsets, lengths, n, names, accs, descs, seeds, out);
+  if (st == P7X_OK && *out) (*out)->ms[7] = scan_ms;          // the SSV scan kernels (HIP events)
+  return st;
+}
+
+int64_t p7x_ssv_longtarget_seeds(const p7x_pipeline_cfg *cfg, const p7x_oprofile *om, int device, const uint8_t *dsq, int64_t L,
+                                 int complement, int64_t *seeds, size_t cap)
+{
+  if (!cfg || !om || !dsq || L <= 0 || (cap && !seeds)) { set_error("p7x_ssv_longtarget_seeds: bad arguments"); return -P7X_EINVAL; }
+  const Profile &p = om->p;
+  int max_length = 0, sc_thresh = 0, xB = 0;
+  int st = longtarget_setup(*cfg, p, &max_length, &sc_thresh, &xB);
+  if (st != P7X_OK) return -st;
+  DeviceCtx *ctx = nullptr;
+  if ((st = get_ctx(device, &ctx)) != P7X_OK) return -st;
+  std::vector<ScanRow> rows;
+  if ((st = scan_target(*cfg, p, ctx, dsq - 1, L, sc_thresh, xB, complement ? 2 : 1, rows, nullptr)) != P7X_OK) return -st;
+  std::vector<int64_t> s3;
+  block_seeds(p, dsq - 1, L, 0, L, complement ? 1 : 0, rows, sc_thresh, xB, s3);
+  const size_t ns = s3.size() / 3;
+  for (size_t q = 0; q < ns && q < cap; ++q) { seeds[3 * q] = s3[3 * q]; seeds[3 * q + 1] = s3[3 * q + 1]; seeds[3 * q + 2] = s3[3 * q + 2]; }
+  return (int64_t) ns;
+}
+
+} // extern "C"

@@ -1,0 +1,671 @@
+// p7x_longtarget.inc.hpp -- host tail of p7_Pipeline_LongTarget (nhmmer), included at the end of p7x_domaindef.cpp
+// (it drives that file's envelope machinery).
+//
+// Restates, from upstream HMMER 3.3/3.4 (absent from the reference checkout; entry points and structs in
+// include/libhmmer/p7_pipeline.pxd:131-143, p7_scoredata.pxd:16-30, called from plan7.pyx:7541-7664):
+//   p7_pipeline.c   p7_Pipeline_LongTarget, p7_pli_ExtendAndMergeWindows, p7_pli_postSSV_LongTarget,
+//                   p7_pli_postViterbi_LongTarget and the per-domain hit construction
+//   impl_sse/msvfilter.c  the bookkeeping of p7_SSVFilter_longtarget around a row that reaches the threshold
+//   impl_sse/vitfilter.c  p7_ViterbiFilter_longtarget
+//   p7_scoredata.c  p7_hmm_ScoreDataComputeRest (prefix / suffix lengths)
+//   p7_tophits.c    p7_tophits_ComputeNhmmerEvalues, p7_tophits_RemoveDuplicates
+// The SSV scan itself runs on the device (p7x_ssvlong.hip); everything here sees only the few windows it seeds.
+// Parity status: restated from memory of upstream and pinned only by the reference's nhmmer fixtures
+// (tests/golden/tables/bmyD{1,2}.tbl, the RF00001 known answers); see DESIGN.md.
+#include <mutex>
+
+namespace p7x {
+
+namespace {
+
+struct LtWindow { int64_t n = 0; int k = 0; int64_t length = 0; };     // first residue (1-based in the block), model node of the last cell, length
+
+// ---------------------------------------------------------------- scalar filters on one window
+struct LtLengthModel { uint8_t tjb_b; int16_t xw_move; float nullsc; };
+
+static float lt_null1(int64_t L)
+{
+  const float p1 = (float) L / (float) (L + 1);
+  return (float) L * logf(p1) + logf(1.0f - p1);
+}
+
+// p7_MSVFilter on dsq[1..L] with the length model of L (u8 arithmetic of impl_sse/msvfilter.c)
+static float lt_msv(const Profile &p, const uint8_t *dsq, int64_t L)
+{
+  const int M = p.M;
+  const int tjb = unbiased_byteify(p.scale_b, logf(3.0f / (float) (L + 3)));
+  const int bias = p.bias_b, base = p.base_b, tjbm = tjb + p.tbm_b, tec = p.tec_b;
+  std::vector<int> row(M + 1, 0), nxt(M + 1, 0);
+  int xJ = 0, xB = std::max(base - tjbm, 0);
+  for (int64_t i = 1; i <= L; ++i) {
+    const uint8_t *rb = p.rb.data() + (size_t) dsq[i] * (M + 1);
+    int xE = 0;
+    for (int k = 1; k <= M; ++k) {
+      int sv = std::max(row[k - 1], xB);
+      sv = std::min(sv + bias, 255);
+      sv = std::max(sv - (int) rb[k], 0);
+      xE = std::max(xE, sv);
+      nxt[k] = sv;
+    }
+    if (xE + bias >= 255) return INFINITY;
+    xE = std::max(xE - tec, 0);
+    xJ = std::max(xJ, xE);
+    xB = std::max(std::max(base, xJ) - tjbm, 0);
+    row.swap(nxt);
+  }
+  float sc = ((float) (xJ - tjb) - (float) p.base_b);
+  sc /= p.scale_b;
+  sc -= 3.0f;
+  return sc;
+}
+
+// p7_bg_FilterScore: Forward score of the two-state composition HMM (esl_hmm_Forward), float arithmetic as upstream
+static float lt_bias_filter(const Profile &p, const uint8_t *dsq, int64_t L)
+{
+  const Alphabet &abc = Alphabet::get(p.abc_type);
+  float eo[MAXKP][2];
+  for (int x = 0; x < p.Kp; ++x) { eo[x][0] = 1.0f; eo[x][1] = 1.0f; }
+  for (int x = 0; x < p.K; ++x) { eo[x][0] = p.bgf[x] / p.bgf[x]; eo[x][1] = p.compo[x] / p.bgf[x]; }
+  for (int x = p.K + 1; x <= p.Kp - 3; ++x)
+    for (int s = 0; s < 2; ++s) {
+      float e = 0.0f, den = 0.0f;
+      for (int y = 0; y < p.K; ++y) if (abc.degen[x][y]) { e += (s == 0 ? p.bgf[y] : p.compo[y]); den += p.bgf[y]; }
+      eo[x][s] = den > 0.0f ? e / den : 0.0f;
+    }
+  const float p1 = (float) L / (float) (L + 1);
+  const float L1 = (float) ((double) (float) p.M / 8.0);
+  const float t00 = p1, t01 = 1.0f - p1, t10 = 1.0f / (L1 + 1.0f), t11 = L1 / (L1 + 1.0f);
+  float dp0 = eo[dsq[1]][0] * 0.999f, dp1 = eo[dsq[1]][1] * 0.001f;
+  float mx = std::max(0.0f, std::max(dp0, dp1));
+  dp0 /= mx; dp1 /= mx;
+  float logsc = 0.0f;
+  logsc += (float) std::log((double) mx);
+  for (int64_t i = 2; i <= L; ++i) {
+    const int x = dsq[i];
+    float n0 = 0.0f; n0 += dp0 * t00; n0 += dp1 * t10; n0 *= eo[x][0];
+    float n1 = 0.0f; n1 += dp0 * t01; n1 += dp1 * t11; n1 *= eo[x][1];
+    mx = std::max(0.0f, std::max(n0, n1));
+    dp0 = n0 / mx; dp1 = n1 / mx;
+    logsc += (float) std::log((double) mx);
+  }
+  float last = 0.0f; last += dp0 * 1.0f; last += dp1 * 1.0f;
+  logsc += (float) std::log((double) last);
+  return logsc + (float) L * logf(p1) + logf((float) (1. - (double) p1));
+}
+
+static inline int16_t sat16(int v) { return (int16_t) std::max(-32768, std::min(32767, v)); }
+
+// p7_ViterbiFilter_longtarget: every row whose best match cell reaches the score that corresponds to P = F2 seeds a
+// window (one per cell that holds that score) and clears the row.  Un-striped; the D->D path is evaluated in full,
+// which gives the same M cells as upstream's lazy-F evaluation.
+static void lt_viterbi_longtarget(const Profile &p, const uint8_t *dsq, int64_t L, float filtersc, double F2, std::vector<LtWindow> &out)
+{
+  const int M = p.M;
+  const int16_t xw_move = wordify(p.scale_w, logf(3.0f / (float) (L + 3)));
+  const int16_t xw_e_move = p.xw[XE][MOVE], xw_e_loop = p.xw[XE][LOOP];
+  const double invP = p.evparam[P7X_VMU] - std::log(-1.0 * std::log(1.0 - F2)) / p.evparam[P7X_VLAMBDA];     // esl_gumbel_invsurv
+  const int sc_thresh = (int) std::ceil(((filtersc + (float) (kLog2 * invP) + 3.0) * p.scale_w)
+                                        - (float) xw_e_move - (float) xw_move + (float) p.base_w);
+  auto tw = [&](int t, int k) -> int { return p.tw[(size_t) t * (M + 1) + k]; };
+  std::vector<int16_t> mm(M + 2, -32768), im(M + 2, -32768), dm(M + 2, -32768), mn(M + 2), in_(M + 2), dn(M + 2);
+  const int xN = p.base_w;
+  int xB = sat16(xN + xw_move), xJ = -32768, xC = -32768;
+  for (int64_t i = 1; i <= L; ++i) {
+    const int16_t *rw = p.rw.data() + (size_t) dsq[i] * (M + 1);
+    int xE = -32768;
+    mn[0] = in_[0] = dn[0] = -32768;
+    for (int k = 1; k <= M; ++k) {
+      int sv = sat16(xB + tw(0, k));
+      sv = std::max(sv, (int) sat16(mm[k - 1] + tw(1, k)));
+      sv = std::max(sv, (int) sat16(im[k - 1] + tw(2, k)));
+      sv = std::max(sv, (int) sat16(dm[k - 1] + tw(3, k)));
+      sv = sat16(sv + rw[k]);
+      mn[k] = (int16_t) sv;
+      xE = std::max(xE, sv);
+      in_[k] = (int16_t) std::max((int) sat16(mm[k] + tw(5, k)), (int) sat16(im[k] + tw(6, k)));
+    }
+    if (xE >= sc_thresh) {
+      for (int k = 1; k <= M; ++k) if (mn[k] == xE) out.push_back(LtWindow{ i, k, 1 });
+      std::fill(mm.begin(), mm.end(), (int16_t) -32768); std::fill(im.begin(), im.end(), (int16_t) -32768); std::fill(dm.begin(), dm.end(), (int16_t) -32768);
+      continue;
+    }
+    xC = std::max(xC, xE + xw_e_move);
+    xJ = std::max(xJ, xE + xw_e_loop);
+    xB = std::max(xJ + xw_move, xN + xw_move);
+    dn[1] = -32768;
+    for (int k = 2; k <= M; ++k) dn[k] = (int16_t) std::max((int) sat16(mn[k - 1] + tw(4, k - 1)), (int) sat16(dn[k - 1] + tw(7, k - 1)));
+    mm.swap(mn); im.swap(in_); dm.swap(dn);
+  }
+}
+
+// Forward / Backward parsers on a window (multihit, length model of the window): special-state rows only, two rolling
+// DP rows.  Same arithmetic and scaling as forward_full / backward_full above; rows are (L+1) x [E,N,J,B,C,SCALE].
+static int lt_forward_parser(Model &om, const uint8_t *dsq, int L, std::vector<float> &xmx, float *ret_sc)
+{
+  const int M = om.M;
+  const float *__restrict bm = om.tf(0), *__restrict tMM = om.tf(1), *__restrict tIM = om.tf(2), *__restrict tDM = om.tf(3),
+              *__restrict tMI = om.tf(5), *__restrict tII = om.tf(6);
+  std::vector<float> buf((size_t) 6 * (M + 2), 0.0f);
+  float *mp = buf.data(), *ip = mp + (M + 2), *dp = ip + (M + 2), *mc = dp + (M + 2), *ic = mc + (M + 2), *dc = ic + (M + 2);
+  xmx.assign((size_t) (L + 1) * NX, 0.0f);
+  float xE = 0.f, xN = 1.f, xJ = 0.f, xB = om.xf[XN][MOVE], xC = 0.f, totscale = 0.0f;
+  xmx[xN_] = xN; xmx[xB_] = xB; xmx[xS_] = 1.0f;
+  for (int r = 1; r <= L; ++r) {
+    const float *__restrict rf = om.rf(dsq[r]);
+    mc[0] = ic[0] = dc[0] = 0.0f;
+    for (int k = 1; k <= M; ++k) {
+      float sv = xB * bm[k];
+      sv = sv + mp[k - 1] * tMM[k];
+      sv = sv + ip[k - 1] * tIM[k];
+      sv = sv + dp[k - 1] * tDM[k];
+      mc[k] = sv * rf[k];
+      ic[k] = mp[k] * tMI[k] + ip[k] * tII[k];
+    }
+    dchain_forward(om, mc, dc);
+    float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    int k = 1;
+    for (; k + 7 <= M; k += 8) for (int z = 0; z < 8; ++z) acc[z] += mc[k + z] + dc[k + z];
+    for (; k <= M; ++k) acc[0] += mc[k] + dc[k];
+    mc[M + 1] = ic[M + 1] = dc[M + 1] = 0.0f;
+    xE = hsum8(acc);
+    xN = xN * om.xf[XN][LOOP];
+    xC = (xC * om.xf[XC][LOOP]) + (xE * om.xf[XE][MOVE]);
+    xJ = (xJ * om.xf[XJ][LOOP]) + (xE * om.xf[XE][LOOP]);
+    xB = (xJ * om.xf[XJ][MOVE]) + (xN * om.xf[XN][MOVE]);
+    float *row = xmx.data() + (size_t) r * NX;
+    if (xE > 1.0e4) {
+      xN = xN / xE; xC = xC / xE; xJ = xJ / xE; xB = xB / xE;
+      const float inv = 1.0 / xE;
+      for (int q = 1; q <= M; ++q) { mc[q] *= inv; dc[q] *= inv; ic[q] *= inv; }
+      row[xS_] = xE;
+      totscale += std::log((double) xE);
+      xE = 1.0;
+    } else row[xS_] = 1.0f;
+    row[xE_] = xE; row[xN_] = xN; row[xJ_] = xJ; row[xB_] = xB; row[xC_] = xC;
+    std::swap(mp, mc); std::swap(ip, ic); std::swap(dp, dc);
+  }
+  if (std::isnan(xC) || (L > 0 && xC == 0.0f) || std::isinf(xC)) { if (ret_sc) *ret_sc = INFINITY; return P7X_ERANGE; }
+  if (ret_sc) *ret_sc = totscale + std::log((double) (xC * om.xf[XC][MOVE]));
+  return P7X_OK;
+}
+
+// ---------------------------------------------------------------- windows
+struct LtScoreData { std::vector<float> prefix, suffix; };       // [M+1] fractions of the model's maximal length up to / from node k
+
+// p7_hmm_ScoreDataComputeRest: per node the longest insert that still carries a tail mass of 1e-7, cumulated and
+// normalised to fractions of the whole model
+static void lt_scoredata(const Profile &p, LtScoreData &sd)
+{
+  const int M = p.M;
+  const double beta = 1e-7;                                   // p7_DEFAULT_WINDOW_BETA
+  sd.prefix.assign(M + 2, 0.0f); sd.suffix.assign(M + 2, 0.0f);
+  float sum = 0.0f;
+  for (int k = 1; k < M; ++k) {
+    const float tmi = p.tf[(size_t) tMI * (M + 1) + k], tii = p.tf[(size_t) tII * (M + 1) + k];
+    float len = 2.0f;
+    if (tmi > 0.0f && tii > 0.0f && tii < 1.0f) len = 2.0f + (float) (int) (std::log(beta / tmi) / std::log(tii));
+    if (len < 2.0f) len = 2.0f;
+    sd.prefix[k] = len;
+    sum += len;
+  }
+  sd.prefix[M] = 1.0f; sum += 1.0f;
+  for (int k = 1; k <= M; ++k) sd.prefix[k] /= sum;
+  sd.suffix[M] = sd.prefix[M];
+  for (int k = M - 1; k >= 1; --k) sd.suffix[k] = sd.suffix[k + 1] + sd.prefix[k];
+  for (int k = 2; k <= M; ++k) sd.prefix[k] += sd.prefix[k - 1];
+}
+
+// p7_pli_ExtendAndMergeWindows (one strand, positions on that strand)
+static void lt_extend_and_merge(const LtScoreData &sd, int max_length, int64_t target_len, float pct_overlap, std::vector<LtWindow> &w)
+{
+  if (w.empty()) return;
+  for (LtWindow &c : w) {
+    const int kfirst = std::max<int64_t>(1, (int64_t) c.k - c.length + 1);
+    const int64_t ws = std::max<int64_t>(1, c.n - (int64_t) (max_length * (0.1 + sd.prefix[(size_t) kfirst])));
+    const int64_t we = std::min<int64_t>(target_len, c.n + c.length + (int64_t) (max_length * (0.1 + sd.suffix[(size_t) c.k])));
+    c.length = we - ws + 1; c.n = ws;
+  }
+  size_t cnt = 0;
+  for (size_t i = 1; i < w.size(); ++i) {
+    LtWindow &prev = w[cnt]; const LtWindow &cur = w[i];
+    const int64_t os = std::max(prev.n, cur.n), oe = std::min(prev.n + prev.length - 1, cur.n + cur.length - 1);
+    if ((float) (oe - os + 1) / (float) std::min(prev.length, cur.length) > pct_overlap) {
+      const int64_t ms = std::min(prev.n, cur.n), me = std::max(prev.n + prev.length - 1, cur.n + cur.length - 1);
+      prev.n = ms; prev.length = me - ms + 1;
+    } else { ++cnt; w[cnt] = w[i]; }
+  }
+  w.resize(cnt + 1);
+}
+
+static double lt_gumbel_invsurv(double P, double mu, double lambda) { return mu - std::log(-1.0 * std::log(1.0 - P)) / lambda; }
+
+// the score threshold of p7_SSVFilter_longtarget (byte units) and the constant begin score
+static void lt_ssv_threshold(const Profile &p, int max_length, double F1, int *sc_thresh, int *xB, int *tjb)
+{
+  const double invP = lt_gumbel_invsurv(F1, p.evparam[P7X_MMU], p.evparam[P7X_MLAMBDA]);
+  const float nullsc = lt_null1(max_length);
+  const int tjb_b = unbiased_byteify(p.scale_b, logf(3.0f / (float) (max_length + 3)));
+  *sc_thresh = (int) std::ceil(((nullsc + (invP * kLog2) + 3.0) * p.scale_b) + p.base_b + p.tec_b + tjb_b);
+  *xB = std::max((int) p.base_b - tjb_b - (int) p.tbm_b, 0);
+  *tjb = tjb_b;
+}
+
+// What p7_SSVFilter_longtarget does with a row i whose cell (k, sc) reached the threshold: recover the diagonal back
+// to where it left the begin score, extend it forward while it keeps (nearly) rising, emit the window.  Returns the
+// last row of the extended diagonal (upstream resumes scanning behind it).
+static int64_t lt_seed_from_cell(const Profile &p, const uint8_t *dsq, int64_t L, int64_t i, int k, int sc, int xB, LtWindow *out)
+{
+  const int M = p.M, bias = p.bias_b;
+  auto cost = [&](int kk, int64_t pos) -> int { return (int) p.rb[(size_t) dsq[pos] * (M + 1) + kk]; };
+  int start = k; int64_t tstart = i; int rem = sc;
+  while (rem > xB && start >= 1 && tstart >= 1) { rem -= bias - cost(start, tstart); --start; --tstart; }
+  ++start; ++tstart;
+  int kk = k + 1; int64_t n = i + 1, max_end = i; int max_sc = sc, cur = sc, since = 0;
+  while (kk < M && n <= L) {
+    cur += bias - cost(kk, n);
+    if (cur >= max_sc) { max_sc = cur; max_end = n; since = 0; }
+    else if (++since == 5) break;
+    ++kk; ++n;
+  }
+  const int end = k + (int) (max_end - i);
+  out->n = tstart; out->k = end; out->length = end - start + 1;
+  return max_end;
+}
+
+// A short exact replay of the scan from row <from> (all cells at the begin score) to <to>: the first row whose best
+// cell reaches the threshold, with upstream's choice of cell.  Used in the shadow of a previous seed, where the
+// reset-free device scan over-reports.
+static bool lt_replay(const Profile &p, const uint8_t *dsq, int64_t from, int64_t to, int sc_thresh, int xB, int64_t *row_out, int *k_out, int *sc_out)
+{
+  const int M = p.M, bias = p.bias_b, Q = p.Q16();
+  std::vector<int> row(M + 1, 0), nxt(M + 1, 0);
+  for (int64_t i = from; i <= to; ++i) {
+    const uint8_t *rb = p.rb.data() + (size_t) dsq[i] * (M + 1);
+    int best = -1, bestkey = INT_MAX;
+    for (int k = 1; k <= M; ++k) {
+      int sv = std::max(row[k - 1], xB);
+      sv = std::min(sv + bias, 255);
+      sv = std::max(sv - (int) rb[k], 0);
+      nxt[k] = sv;
+      if (sv >= sc_thresh) {
+        const int key = ((k - 1) % Q) * 16 + (k - 1) / Q;
+        if (sv > best || (sv == best && key < bestkey)) { best = sv; bestkey = key; }
+      }
+    }
+    if (best >= 0) { *row_out = i; *k_out = (bestkey / 16) + Q * (bestkey % 16) + 1; *sc_out = best; return true; }
+    row.swap(nxt);
+  }
+  return false;
+}
+
+struct LtRow { int64_t pos; int k, sc; };       // a row the device scan reported: position on the strand, upstream's cell
+
+// Upstream's sequential bookkeeping over the rows the reset-free scan reported for one block of one strand.  Rows are
+// positions inside the block (1..L), ascending.
+static void lt_seeds_from_rows(const Profile &p, const uint8_t *dsq, int64_t L, const std::vector<LtRow> &rows, int sc_thresh, int xB,
+                               std::vector<LtWindow> &seeds)
+{
+  const int M = p.M;
+  int64_t prev_end = 0;          // last row of the previous seed's diagonal (the scan restarted behind it); 0: block start
+  size_t idx = 0;
+  while (idx < rows.size()) {
+    const LtRow &r = rows[idx];
+    if (r.pos <= prev_end) { ++idx; continue; }                 // skipped by upstream's jump behind the previous seed
+    int64_t row = r.pos; int k = r.k, sc = r.sc;
+    if (r.pos - prev_end <= M) {
+      // diagonals of this row may have started before the restart: replay the scan from there to the first true crossing
+      const int64_t to = std::min<int64_t>(L, prev_end + M);
+      if (!lt_replay(p, dsq, prev_end + 1, to, sc_thresh, xB, &row, &k, &sc)) {
+        while (idx < rows.size() && rows[idx].pos <= to) ++idx;
+        prev_end = to;              // beyond the shadow the reported rows are exact again
+        // (rows after <to> no longer depend on the restart: treat <to> as a restart that changed nothing)
+        continue;
+      }
+    }
+    LtWindow w;
+    prev_end = lt_seed_from_cell(p, dsq, L, row, k, sc, xB, &w);
+    seeds.push_back(w);
+    while (idx < rows.size() && rows[idx].pos <= prev_end) ++idx;
+  }
+}
+
+// ---------------------------------------------------------------- one window past the SSV filter
+struct LtTarget { int64_t idx; const char *name, *acc, *desc; int64_t length; };
+
+struct LtBlock {                 // one block of one strand, as p7_Pipeline_LongTarget receives it
+  const uint8_t *dsq;            // 1-based residues of the block on this strand (dsq[0] and dsq[n+1] are sentinels)
+  int64_t n;                     // residues in the block
+  int64_t start;                 // sq->start: original coordinate of dsq[1] (for the complement strand: the block's last residue)
+  bool complement;
+};
+
+struct LtCounters { uint64_t n_past_msv = 0, n_past_bias = 0, n_past_vit = 0, n_past_fwd = 0, pos_past_msv = 0, pos_past_bias = 0, pos_past_vit = 0, pos_past_fwd = 0; };
+
+static int lt_post_viterbi(const p7x_pipeline_cfg &cfg, const Profile &p, const LongTargetOpts &lto, int max_length, uint64_t nres_so_far,
+                           const LtBlock &blk, const LtTarget &tg, int64_t window_start, int64_t window_len,
+                           std::vector<Hit> &hits, LtCounters &ctr)
+{
+  const uint8_t *subseq = blk.dsq + window_start - 1;         // subseq[1..window_len]
+  const int64_t F3_L = std::min<int64_t>(window_len, cfg.B3);
+  const float nullsc = lt_null1(window_len);
+  float filtersc = nullsc;
+  if (cfg.do_biasfilter) {
+    float bias_filtersc = lt_bias_filter(p, subseq, window_len);
+    bias_filtersc -= nullsc;
+    filtersc = nullsc + (bias_filtersc * (F3_L > window_len ? 1.0f : (float) F3_L / (float) window_len));
+  }
+  Model om{ &p, p.M, {} };
+  om.prepare();
+  om.configure(true, (int) window_len);
+  std::vector<float> fx, bx;
+  float fwdsc = 0.0f;
+  lt_forward_parser(om, subseq, (int) window_len, fx, &fwdsc);
+  const float seq_score = (fwdsc - filtersc) / (float) kLog2;
+  const double P = exp_surv(seq_score, p.evparam[P7X_FTAU], p.evparam[P7X_FLAMBDA]);
+  if (P > cfg.F3) return P7X_OK;
+  ctr.n_past_fwd++; ctr.pos_past_fwd += (uint64_t) window_len;
+  // Backward parser rows: the full-matrix routine on the window would need L x M floats; the region scan only needs the
+  // special states, which the generic Backward delivers row by row.  Windows are a few max_length long.
+  {
+    Matrix fm, bm;
+    float sc2 = 0.0f;
+    forward_full(om, subseq, (int) window_len, fm, &sc2);
+    backward_full(om, subseq, (int) window_len, fm, bm, nullptr);
+    fx.assign(fm.x.begin(), fm.x.begin() + (size_t) (window_len + 1) * NX);
+    bx.assign(bm.x.begin(), bm.x.begin() + (size_t) (window_len + 1) * NX);
+  }
+  DomainDefResult dd;
+  t_long_target = &lto;
+  const int st = domaindef_by_posterior_heuristics(p, subseq, (int) window_len, fx.data(), bx.data(), cfg.seed, cfg.seed != 0, dd, nullptr, 0);
+  t_long_target = nullptr;
+  if (st != P7X_OK) return st == P7X_ERANGE ? P7X_OK : st;
+  if (std::getenv("P7X_LT_DEBUG")) {
+    std::fprintf(stderr, "[lt] window start %lld len %lld compl %d fwd %.3f P %.3g: nregions %d nclustered %d nenvelopes %d ndom %zu\n",
+                 (long long) window_start, (long long) window_len, (int) blk.complement, fwdsc, P, dd.nregions, dd.nclustered, dd.nenvelopes, dd.dcl.size());
+    for (const Domain &d : dd.dcl) std::fprintf(stderr, "[lt]   env %lld-%lld ali %lld-%lld hmm %d-%d envsc %.3f domcorr %.3f\n", (long long) d.ienv, (long long) d.jenv,
+                                                 (long long) d.iali, (long long) d.jali, d.hmmfrom, d.hmmto, d.envsc, d.domcorrection);
+  }
+  if (dd.nregions == 0 || dd.nenvelopes == 0) return P7X_OK;
+  const float omega = 1.0f / 256.0f;
+  for (Domain &dom : dd.dcl) {
+    const int64_t env_len = dom.jenv - dom.ienv + 1, ali_len = dom.jali - dom.iali + 1;
+    float bitscore = dom.envsc;
+    // the envelope was scored with its own length model; charge the window and then re-express the score as if every
+    // window had the length max_length, so that scores do not depend on how the windows happened to merge
+    bitscore -= 2 * log(2. / (window_len + 2));
+    bitscore += 2 * log(2. / (max_length + 2));
+    bitscore += (std::max<int64_t>(max_length, env_len) - ali_len) * log((float) max_length / (float) (max_length + 2));
+    const float dom_nullsc = lt_null1(std::max<int64_t>(max_length, env_len));
+    const float dom_bias = !cfg.do_null2 ? 0.0f : (lto.bias_mode == 4 ? dom.domcorrection : flogsum(0.0f, std::log((double) omega) + dom.domcorrection));
+    const float dom_score = (bitscore - (dom_nullsc + dom_bias)) / (float) kLog2;
+    const double dom_lnP = exp_logsurv(dom_score, p.evparam[P7X_FTAU], p.evparam[P7X_FLAMBDA]);
+    // conservative test with the residues seen so far; the final E-values use the whole search (ComputeNhmmerEvalues)
+    const double lnP_test = dom_lnP + std::log((double) std::max<uint64_t>(nres_so_far, 1) / (double) max_length);
+    if (!tophits_target_reportable(cfg, dom_score, lnP_test)) continue;
+    Hit h;
+    h.ndom = 1; h.best_domain = 0; h.window_length = max_length; h.seqidx = tg.idx;
+    if (tg.name) h.name = tg.name;
+    if (tg.acc && tg.acc[0]) { h.acc = tg.acc; h.has_acc = true; }
+    if (tg.desc && tg.desc[0]) { h.desc = tg.desc; h.has_desc = true; }
+    // positions in the original target: blk.start is the original coordinate of the block's first residue on this strand
+    auto map_pos = [&](int64_t x) -> int64_t {
+      return blk.complement ? blk.start - (window_start + x) + 2 : (blk.start - 1) + (window_start - 1) + x;
+    };
+    dom.ienv = map_pos(dom.ienv); dom.jenv = map_pos(dom.jenv);
+    dom.iali = map_pos(dom.iali); dom.jali = map_pos(dom.jali);
+    dom.sqfrom = map_pos(dom.sqfrom); dom.sqto = map_pos(dom.sqto);
+    dom.L = tg.length;
+    dom.dombias = dom_bias; dom.bitscore = dom_score; dom.lnP = dom_lnP;
+    h.pre_score = bitscore / (float) kLog2;
+    h.pre_lnP = exp_logsurv(h.pre_score, p.evparam[P7X_FTAU], p.evparam[P7X_FLAMBDA]);
+    h.sum_score = h.score = dom_score;
+    h.sum_lnP = h.lnP = dom_lnP;
+    h.sortkey = cfg.inc_by_E ? -dom_lnP : dom_score;
+    h.nexpected = dd.nexpected; h.nregions = dd.nregions; h.nclustered = dd.nclustered; h.noverlaps = dd.noverlaps; h.nenvelopes = dd.nenvelopes;
+    h.dcl.push_back(std::move(dom));
+    hits.push_back(std::move(h));
+  }
+  return P7X_OK;
+}
+
+static int lt_post_ssv(const p7x_pipeline_cfg &cfg, const Profile &p, const LongTargetOpts &lto, const LtScoreData &sd, int max_length,
+                       uint64_t nres_so_far, const LtBlock &blk, const LtTarget &tg, int64_t window_start, int64_t window_len,
+                       std::vector<Hit> &hits, LtCounters &ctr)
+{
+  const uint8_t *subseq = blk.dsq + window_start - 1;
+  const int64_t F1_L = std::min<int64_t>(window_len, cfg.B1), F2_L = std::min<int64_t>(window_len, cfg.B2);
+  const float nullsc = lt_null1(window_len);
+  // the full MSV score of the window (SSV only seeded it)
+  const float usc = lt_msv(p, subseq, window_len);
+  double P = gumbel_surv((usc - nullsc) / kLog2, p.evparam[P7X_MMU], p.evparam[P7X_MLAMBDA]);
+  if (P > cfg.F1) return P7X_OK;
+  ctr.n_past_msv++; ctr.pos_past_msv += (uint64_t) window_len;
+  float bias_filtersc = 0.0f, filtersc = nullsc;
+  if (cfg.do_biasfilter) {
+    bias_filtersc = lt_bias_filter(p, subseq, window_len) - nullsc;
+    filtersc = nullsc + (bias_filtersc * (F1_L > window_len ? 1.0f : (float) F1_L / (float) window_len));
+    P = gumbel_surv((usc - filtersc) / kLog2, p.evparam[P7X_MMU], p.evparam[P7X_MLAMBDA]);
+    if (P > cfg.F1) return P7X_OK;
+  }
+  ctr.n_past_bias++; ctr.pos_past_bias += (uint64_t) window_len;
+  std::vector<LtWindow> vit;
+  if (P > cfg.F2) {
+    if (cfg.do_biasfilter) filtersc = nullsc + (bias_filtersc * (F2_L > window_len ? 1.0f : (float) F2_L / (float) window_len));
+    lt_viterbi_longtarget(p, subseq, window_len, filtersc, cfg.F2, vit);
+    lt_extend_and_merge(sd, max_length, window_len, 0.5f, vit);
+  } else vit.push_back(LtWindow{ 1, 0, window_len });
+  for (const LtWindow &w : vit) {
+    ctr.n_past_vit++; ctr.pos_past_vit += (uint64_t) w.length;
+    const int st = lt_post_viterbi(cfg, p, lto, max_length, nres_so_far, blk, tg, window_start + w.n - 1, w.length, hits, ctr);
+    if (st != P7X_OK) return st;
+  }
+  return P7X_OK;
+}
+
+// p7_Pipeline_LongTarget behind the SSV scan: seeds -> windows -> the rest, for one block of one strand
+static int lt_block_tail(const p7x_pipeline_cfg &cfg, const Profile &p, const LongTargetOpts &lto, const LtScoreData &sd, int max_length,
+                         uint64_t nres_so_far, const LtBlock &blk, const LtTarget &tg, std::vector<LtWindow> seeds,
+                         std::vector<Hit> &hits, LtCounters &ctr)
+{
+  if (seeds.empty()) return P7X_OK;
+  lt_extend_and_merge(sd, max_length, blk.n, 0.0f, seeds);
+  // very long merged windows are cut into overlapping pieces (upstream: longer than 80 kb -> 40 kb pieces)
+  std::vector<LtWindow> windows;
+  const int64_t max_window = 80000, piece = 40000;
+  for (const LtWindow &w : seeds) {
+    if (w.length <= max_window) { windows.push_back(w); continue; }
+    for (int64_t off = 0; off < w.length; off += piece - max_length) {
+      const int64_t len = std::min<int64_t>(piece, w.length - off);
+      windows.push_back(LtWindow{ w.n + off, 0, len });
+      if (off + len >= w.length) break;
+    }
+  }
+  for (const LtWindow &w : windows) {
+    const int st = lt_post_ssv(cfg, p, lto, sd, max_length, nres_so_far, blk, tg, w.n, w.length, hits, ctr);
+    if (st != P7X_OK) return st;
+  }
+  return P7X_OK;
+}
+
+// ---------------------------------------------------------------- hit list: E-values, duplicates
+static void lt_finish_tophits(const p7x_pipeline_cfg &cfg_in, const Profile &p, int max_length, uint64_t nres, uint64_t nseqs,
+                              const LtCounters &ctr, std::vector<Hit> &hits, p7x_tophits **out)
+{
+  auto th = std::make_unique<p7x_tophits>();
+  th->cfg = cfg_in;
+  th->qname = p.name; th->qacc = p.acc; th->qdesc = p.desc; th->q_has_acc = p.has_acc; th->q_has_desc = p.has_desc;
+  th->M = p.M;
+  th->ctr.nmodels = 1; th->ctr.nnodes = (uint64_t) p.M; th->ctr.nseqs = nseqs; th->ctr.nres = nres;
+  th->ctr.n_past_msv = ctr.n_past_msv; th->ctr.n_past_bias = ctr.n_past_bias; th->ctr.n_past_vit = ctr.n_past_vit; th->ctr.n_past_fwd = ctr.n_past_fwd;
+  th->ctr.pos_past_msv = ctr.pos_past_msv; th->ctr.pos_past_bias = ctr.pos_past_bias; th->ctr.pos_past_vit = ctr.pos_past_vit; th->ctr.pos_past_fwd = ctr.pos_past_fwd;
+  // p7_tophits_ComputeNhmmerEvalues: the P-value of a hit refers to one window of max_length; scale by the windows searched
+  double res_count = (double) nres;
+  if (cfg_in.Z_setby != P7X_ZSETBY_NTARGETS) { res_count = 1000000.0 * cfg_in.Z; if (cfg_in.strands == P7X_STRAND_BOTH) res_count *= 2; }
+  for (Hit &h : hits) {
+    h.lnP += std::log((float) res_count / (float) max_length);
+    h.dcl[0].lnP = h.lnP;
+    h.sortkey = -1.0 * h.lnP;
+  }
+  // p7_tophits_SortBySeqidxAndAlipos + p7_tophits_RemoveDuplicates: the same region found in two overlapping blocks or
+  // windows; the hit with the better E-value stays
+  std::vector<size_t> ord(hits.size());
+  for (size_t i = 0; i < ord.size(); ++i) ord[i] = i;
+  auto lo = [&](const Hit &h) { return std::min(h.dcl[0].iali, h.dcl[0].jali); };
+  std::sort(ord.begin(), ord.end(), [&](size_t a, size_t b) {
+    if (hits[a].seqidx != hits[b].seqidx) return hits[a].seqidx < hits[b].seqidx;
+    const bool ca = hits[a].dcl[0].iali > hits[a].dcl[0].jali, cb = hits[b].dcl[0].iali > hits[b].dcl[0].jali;
+    if (ca != cb) return !ca;
+    if (lo(hits[a]) != lo(hits[b])) return lo(hits[a]) < lo(hits[b]);
+    return a < b;
+  });
+  size_t j = 0;
+  for (size_t q = 1; q < ord.size(); ++q) {
+    Hit &hj = hits[ord[j]], &hi = hits[ord[q]];
+    const bool cj = hj.dcl[0].iali > hj.dcl[0].jali, ci = hi.dcl[0].iali > hi.dcl[0].jali;
+    bool dup = false;
+    if (hj.seqidx == hi.seqidx && cj == ci) {
+      const int64_t sj = std::min(hj.dcl[0].iali, hj.dcl[0].jali), ej = std::max(hj.dcl[0].iali, hj.dcl[0].jali);
+      const int64_t si = std::min(hi.dcl[0].iali, hi.dcl[0].jali), ei = std::max(hi.dcl[0].iali, hi.dcl[0].jali);
+      const int64_t inter = std::min(ei, ej) - std::max(si, sj) + 1;
+      const int64_t li = ei - si + 1, lj = ej - sj + 1;
+      if (inter > 0 && ((std::llabs(si - sj) <= 3) || (std::llabs(ei - ej) <= 3) || inter >= 0.95 * (double) li || inter >= 0.95 * (double) lj)) dup = true;
+    }
+    if (dup) {
+      const size_t remove = hi.lnP < hj.lnP ? j : q;
+      hits[ord[remove]].flags |= P7X_IS_DUPLICATE;
+      if (remove == j) j = q;
+    } else j = q;
+  }
+  th->hits = std::move(hits);
+  tophits_sort_by_key(*th);
+  tophits_threshold(*th);
+  th->ctr.n_output = th->ctr.pos_output = 0;
+  for (const Hit &h : th->hits)
+    if (h.flags & (P7X_IS_REPORTED | P7X_IS_INCLUDED)) { th->ctr.n_output++; th->ctr.pos_output += 1 + (uint64_t) std::llabs(h.dcl[0].jali - h.dcl[0].iali); }
+  *out = th.release();
+}
+
+static void lt_match_probabilities(const Profile &p, std::vector<float> &mp)
+{ // p7_oprofile_GetFwdEmissionArray: match emission probabilities back from the odds ratios
+  mp.assign((size_t) (p.M + 1) * p.K, 0.0f);
+  for (int k = 1; k <= p.M; ++k)
+    for (int x = 0; x < p.K; ++x) mp[(size_t) k * p.K + x] = p.rf_[(size_t) x * (p.M + 1) + k] * p.bgf[x];
+}
+
+static const uint8_t *lt_complement_table(int abc_type)
+{ // Easel's complement of every DNA / RNA residue code: ACGT-RYMKSWHBVDN*~
+  static const uint8_t comp[18] = { 3, 2, 1, 0, 4, 6, 5, 8, 7, 9, 10, 14, 13, 12, 11, 15, 16, 17 };
+  (void) abc_type;
+  return comp;
+}
+
+struct LtSeedIn { int64_t target, block_start; int strand; LtWindow w; };
+
+// The whole host side for a set of targets, given the SSV seeds of every (target, block, strand).
+static int lt_run_host(const p7x_pipeline_cfg &cfg, const p7x_oprofile *om, const uint8_t *dsq, const int64_t *offsets, const int64_t *lengths, size_t n,
+                       const char *const *names, const char *const *accs, const char *const *descs,
+                       const std::vector<LtSeedIn> &seeds_in, p7x_tophits **out)
+{
+  const Profile &p = om->p;
+  if (p.abc_type != P7X_DNA && p.abc_type != P7X_RNA) { set_error("long-target pipeline needs a nucleotide model"); return P7X_EINVAL; }
+  const int max_length = cfg.window_length > 0 ? cfg.window_length : p.max_length;
+  if (max_length <= 0) { set_error("model has no max_length (MAXL) and no window_length was given"); return P7X_EINVAL; }
+  const int64_t W = cfg.block_length, C = max_length;
+  if (W <= C) { set_error("block_length must exceed the model's max_length"); return P7X_EINVAL; }
+  flogsum_init();
+  LtScoreData sd; lt_scoredata(p, sd);
+  std::vector<float> mp; lt_match_probabilities(p, mp);
+  LongTargetOpts lto; lto.do_null2 = cfg.do_null2 != 0; lto.match_prob = mp.data(); lto.bias_mode = cfg.lt_bias_mode & 15; lto.bg_mix = cfg.lt_bg_mix; lto.retrim_bg = (cfg.lt_bias_mode & 16) != 0; lto.bg_from_ali = (cfg.lt_bias_mode & 32) != 0; lto.bg_from_window = (cfg.lt_bias_mode & 64) != 0;
+  const uint8_t *comp = lt_complement_table(p.abc_type);
+  std::vector<Hit> hits;
+  LtCounters ctr;
+  uint64_t nres = 0;
+  std::vector<uint8_t> buf;
+  size_t sidx = 0;
+  for (size_t t = 0; t < n; ++t) {
+    const int64_t Lt = lengths[t];
+    LtTarget tg{ (int64_t) t, names ? names[t] : nullptr, accs ? accs[t] : nullptr, descs ? descs[t] : nullptr, Lt };
+    const uint8_t *seq = dsq + offsets[t] - 1;              // seq[1..Lt]
+    for (int64_t i = 0; i < Lt; i += W - C) {
+      const int64_t bc = i == 0 ? 0 : std::min<int64_t>(C, Lt - i);
+      const int64_t bw = std::min<int64_t>(W, Lt - i - bc);
+      const int64_t bn = bc + bw;
+      if (bn <= 0) break;
+      nres += (uint64_t) bn;                                 // p7_pli_NewSeq
+      for (int strand = 0; strand < 2; ++strand) {
+        if (strand == 0 && cfg.strands == P7X_STRAND_BOTTOMONLY) { nres -= (uint64_t) bn; continue; }
+        if (strand == 0) nres -= (uint64_t) bc;              // the overlap with the previous block was counted there
+        if (strand == 1 && cfg.strands == P7X_STRAND_TOPONLY) continue;
+        buf.assign((size_t) bn + 2, 255);
+        if (strand == 0) std::memcpy(buf.data() + 1, seq + i + 1, (size_t) bn);
+        else for (int64_t q = 1; q <= bn; ++q) buf[(size_t) q] = comp[seq[i + bn - q + 1]];
+        LtBlock blk{ buf.data(), bn, strand == 0 ? i + 1 : i + bn, strand == 1 };
+        std::vector<LtWindow> seeds;
+        while (sidx < seeds_in.size() && seeds_in[sidx].target == (int64_t) t && seeds_in[sidx].block_start == i && seeds_in[sidx].strand == strand)
+          seeds.push_back(seeds_in[sidx++].w);
+        const int st = lt_block_tail(cfg, p, lto, sd, max_length, nres, blk, tg, std::move(seeds), hits, ctr);
+        if (st != P7X_OK) return st;
+        if (strand == 1) nres += (uint64_t) bw;
+      }
+      if (i + bn >= Lt) break;
+    }
+  }
+  lt_finish_tophits(cfg, p, max_length, nres, (uint64_t) n, ctr, hits, out);
+  return P7X_OK;
+}
+
+} // namespace
+
+// ---- what the device half (p7x_longtarget.hip) needs from here
+int longtarget_setup(const p7x_pipeline_cfg &cfg, const Profile &p, int *max_length, int *sc_thresh, int *xB)
+{
+  if (p.abc_type != P7X_DNA && p.abc_type != P7X_RNA) { set_error("long-target pipeline needs a nucleotide model"); return P7X_EINVAL; }
+  *max_length = cfg.window_length > 0 ? cfg.window_length : p.max_length;
+  if (*max_length <= 0) { set_error("model has no max_length (MAXL) and no window_length was given"); return P7X_EINVAL; }
+  if (cfg.block_length <= *max_length) { set_error("block_length must exceed the model's max_length"); return P7X_EINVAL; }
+  int tjb = 0;
+  lt_ssv_threshold(p, *max_length, cfg.F1, sc_thresh, xB, &tjb);
+  return P7X_OK;
+}
+
+const uint8_t *longtarget_complement(int abc_type) { return lt_complement_table(abc_type); }
+
+void longtarget_seeds_from_rows(const Profile &p, const uint8_t *block_dsq, int64_t L, const LongTargetRow *rows, size_t nrows,
+                                int sc_thresh, int xB, std::vector<int64_t> &seeds3)
+{
+  std::vector<LtRow> r(nrows);
+  for (size_t i = 0; i < nrows; ++i) r[i] = LtRow{ rows[i].pos, rows[i].k, rows[i].sc };
+  std::vector<LtWindow> w;
+  lt_seeds_from_rows(p, block_dsq, L, r, sc_thresh, xB, w);
+  for (const LtWindow &x : w) { seeds3.push_back(x.n); seeds3.push_back(x.k); seeds3.push_back(x.length); }
+}
+
+int longtarget_run_host(const p7x_pipeline_cfg &cfg, const p7x_oprofile *om, const uint8_t *dsq, const int64_t *offsets, const int64_t *lengths,
+                        size_t n, const char *const *names, const char *const *accs, const char *const *descs,
+                        const std::vector<LongTargetSeed> &seeds, p7x_tophits **out)
+{
+  std::vector<LtSeedIn> in(seeds.size());
+  for (size_t s = 0; s < seeds.size(); ++s) in[s] = LtSeedIn{ seeds[s].target, seeds[s].block_start, seeds[s].strand, LtWindow{ seeds[s].n, seeds[s].k, seeds[s].length } };
+  return lt_run_host(cfg, om, dsq, offsets, lengths, n, names, accs, descs, in, out);
+}
+
+} // namespace p7x
+
+using namespace p7x;
+
+extern "C" {
+
+int p7x_longtarget_from_seeds(const p7x_pipeline_cfg *cfg, const p7x_oprofile *om,
+                              const uint8_t *dsq, const int64_t *offsets, const int64_t *lengths, size_t n,
+                              const char *const *names, const char *const *accs, const char *const *descs,
+                              const int64_t *seed_target, const int64_t *seed_block, const int32_t *seed_strand,
+                              const int64_t *seeds, size_t nseeds, p7x_tophits **out)
+{
+  if (!cfg || !om || !out || (n && (!dsq || !offsets || !lengths))) { set_error("p7x_longtarget_from_seeds: bad arguments"); return P7X_EINVAL; }
+  std::vector<LtSeedIn> in(nseeds);
+  for (size_t s = 0; s < nseeds; ++s)
+    in[s] = LtSeedIn{ seed_target[s], seed_block[s], seed_strand[s], LtWindow{ seeds[3 * s], (int) seeds[3 * s + 1], seeds[3 * s + 2] } };
+  return lt_run_host(*cfg, om, dsq, offsets, lengths, n, names, accs, descs, in, out);
+}
+
+} // extern "C"

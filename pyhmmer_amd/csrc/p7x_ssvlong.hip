@@ -1,0 +1,204 @@
+// p7x_ssvlong.hip -- p7_SSVFilter_longtarget on CDNA4: the SSV scan of nhmmer over a chromosome, both strands.
+//
+// Upstream (impl_sse/msvfilter.c: p7_SSVFilter_longtarget; reference p7_pipeline.pxd:131-143, called from
+// p7_Pipeline_LongTarget) walks the target once with the single-segment recurrence
+//     M_i[k] = sat( max(M_{i-1}[k-1], xB) + bias - rbv[x_i][k] ),    xB = base - tjb - tbm  (constant: no J state),
+// and whenever a cell reaches the score threshold that corresponds to P = F1 it emits the diagonal through that cell as
+// a window seed, zeroes the row and skips ahead.  The scan is >99 % of nhmmer's work: L x M cells per strand.
+//
+// Here the scan is RESET-FREE and parallel: the strand is cut into chunks, one wavefront per chunk, each with M rows
+// of warm-up so that every diagonal that can reach a row of the chunk is complete.  A reset can only lower scores, so
+// the rows that reach the threshold upstream are a subset of the rows reported here; the host replays upstream's
+// sequential bookkeeping (choice of the seed cell, diagonal recovery and extension, skip-ahead) on the reported rows
+// (p7x_longtarget.inc.hpp).
+//
+// Layout: the model is split across the 64 lanes, R packed int16 pairs per lane.  Global register g = lane*R + j holds
+// cells (2g-1, 2g) on odd rows and (2g, 2g+1) on even rows (the MSV kernel's parity trick: the diagonal move costs
+// nothing inside a lane, and one DPP move per odd row carries the last register of a lane to the next lane).  Cells
+// are stored relative to the constant begin score, s = v - xB - 32768, so v_pk_add_i16 clamp computes
+// max(M[k-1], xB) + e in one instruction; with the row-maximum update that is 2 packed ops per 2 cells.  The emission
+// scores of A, C, G, T for both parities sit in LDS ([parity][x][j][lane], one conflict-free ds_read_b32 per register);
+// degenerate residues (rare in chromosomes) take a slow path through the full table in global memory.  u8 saturation at
+// 255 is not reproduced: it can only keep a cell at or above a threshold it has already reached.
+#include "p7x_wave.hpp"
+#include <mutex>
+
+namespace p7x {
+
+namespace {
+
+typedef short s2w __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t pk_adds_u(uint32_t a, uint32_t b) { return __builtin_bit_cast(uint32_t, __builtin_elementwise_add_sat(__builtin_bit_cast(s2w, a), __builtin_bit_cast(s2w, b))); }
+__device__ __forceinline__ uint32_t pk_max_u(uint32_t a, uint32_t b) { return __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(s2w, a), __builtin_bit_cast(s2w, b))); }
+constexpr uint32_t kFloor2 = 0x80008000u;
+
+}  // namespace
+
+// one chunk of one strand per wavefront
+template <int R>
+__global__ void __launch_bounds__(256) ssvlong_kernel(const SsvLongArgs a)
+{
+  // LDS: emission pairs of the four canonical residues, [parity][x][j][lane]
+  extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
+  for (int i = threadIdx.x; i < 2 * 4 * R * 64; i += 256) lds[i] = a.tab4[i];
+  __syncthreads();
+  const int lane = threadIdx.x & 63;
+  const int wave = rfl((int) (blockIdx.x * 4 + (threadIdx.x >> 6)));
+  const int nwaves = (int) gridDim.x * 4;
+
+  for (long long ch = wave; ch < a.nchunks; ch += nwaves) {
+    // chunk ch of strand s: rows first .. last (1-based positions on that strand), preceded by up to M warm-up rows
+    const int strand = a.strand0 + (int) (ch / a.chunks_per_strand);  // 0: as given, 1: reverse complement
+    const long long c0 = (ch % a.chunks_per_strand) * (long long) a.chunk_len;
+    const long long first = c0 + 1, last = min(a.L, c0 + a.chunk_len);
+    const long long warm = max(1LL, first - a.M);
+    uint32_t v[R];
+#pragma unroll
+    for (int j = 0; j < R; ++j) v[j] = kFloor2;
+    for (long long i0 = warm; i0 <= last; i0 += 64) {
+      const int nrow = (int) min(64LL, last - i0 + 1);
+      // residues of the next 64 rows, one per lane: strand 1 reads the target backwards and complements
+      uint32_t res = 0;
+      if (lane < nrow) {
+        const long long pos = i0 + lane;                              // position on this strand
+        const long long src = strand == 0 ? pos : a.L - pos + 1;      // position in the stored sequence
+        const uint32_t x = a.dsq[src];
+        res = strand == 0 ? x : (uint32_t) a.comp[x];
+      }
+      for (int r = 0; r < nrow; ++r) {
+        const long long i = i0 + r;
+        const int x = __builtin_amdgcn_readlane((int) res, r);
+        const bool odd = ((i - warm) & 1) == 0;                       // the first row of a chunk is an "odd" row
+        uint32_t acc = kFloor2;
+        if (x < 4) {
+          const uint32_t *e = lds + ((size_t) ((odd ? 0 : 4) + x) * R) * 64 + lane;
+          if (odd) {       // register g <- f(register g-1): walk downwards, the lane's first register comes from the lane before
+            const uint32_t carry = (uint32_t) dpp_shr1((int) v[R - 1], (int) kFloor2);
+#pragma unroll
+            for (int j = R - 1; j >= 1; --j) { v[j] = pk_adds_u(v[j - 1], e[j * 64]); acc = pk_max_u(acc, v[j]); }
+            v[0] = pk_adds_u(carry, e[0]); acc = pk_max_u(acc, v[0]);
+          } else {
+#pragma unroll
+            for (int j = 0; j < R; ++j) { v[j] = pk_adds_u(v[j], e[j * 64]); acc = pk_max_u(acc, v[j]); }
+          }
+        } else {           // degenerate residue: emissions from the full table in global memory [parity][Kp][R][64]
+          const uint32_t *e = a.tab_full + ((size_t) ((odd ? 0 : a.Kp) + x) * R) * 64 + lane;
+          if (odd) {
+            const uint32_t carry = (uint32_t) dpp_shr1((int) v[R - 1], (int) kFloor2);
+#pragma unroll
+            for (int j = R - 1; j >= 1; --j) { v[j] = pk_adds_u(v[j - 1], e[j * 64]); acc = pk_max_u(acc, v[j]); }
+            v[0] = pk_adds_u(carry, e[0]); acc = pk_max_u(acc, v[0]);
+          } else {
+#pragma unroll
+            for (int j = 0; j < R; ++j) { v[j] = pk_adds_u(v[j], e[j * 64]); acc = pk_max_u(acc, v[j]); }
+          }
+        }
+        // any cell of this row at or above the threshold?  (rare: the wavefront leaves the fast path together)
+        const int hi = (int) (short) (acc >> 16), lo = (int) (short) (acc & 0xffffu);
+        const bool hit = max(hi, lo) >= a.thresh_s;
+        if (i >= first && __any(hit)) {
+          // the cell upstream would pick: the highest byte score (scores saturate at 255), the first such cell in the
+          // order in which p7_SSVFilter_longtarget unstripes the row (vector q outer, byte z inner; k = q + Q z + 1)
+          int best = INT_MIN, bestkey = INT_MAX;
+#pragma unroll
+          for (int j = 0; j < R; ++j) {
+            const int g = lane * R + j, c0 = odd ? 2 * g - 1 : 2 * g;
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+              const int k = c0 + h;
+              const int sv = (int) (short) (h ? (v[j] >> 16) : (v[j] & 0xffffu));
+              if (k >= 1 && k <= a.M) {
+                const int val = min(255, sv + 32768 + a.xB);
+                const int key = ((k - 1) % a.Q16) * 16 + (k - 1) / a.Q16;
+                if (val > best || (val == best && key < bestkey)) { best = val; bestkey = key; }
+              }
+            }
+          }
+          const int smax = wave_max_i32(best);
+          const int kmin = -wave_max_i32(best == smax ? -bestkey : INT_MIN);
+          if (lane == 0) {
+            const int slot = atomicAdd(a.nrec, 1);
+            if (slot < a.rec_cap) {
+              a.rec_pos[slot] = i; a.rec_strand[slot] = (uint8_t) strand;
+              a.rec_k[slot] = (kmin / 16) + a.Q16 * (kmin % 16) + 1; a.rec_sc[slot] = smax;
+            }
+          }
+        }
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------- host side
+static const int kSsvR[] = { 2, 4, 6, 8, 12, 16, 24, 32, 48 };
+
+int ssvlong_pick_R(int M)
+{
+  const int need = (M + 1) / 2 + 1;                 // global registers: cells up to M in both parities
+  for (int r : kSsvR) if (r * 64 >= need) return r;
+  return -1;
+}
+
+// tables: pairs (lo, hi) of signed emission scores s[x][k] = bias - rb[x][k] in byte units, kNegPad outside 1..M.
+// odd rows: register g = cells (2g-1, 2g); even rows: (2g, 2g+1); g = lane*R + j, stored [parity][x][j][lane].
+void ssvlong_build_tables(const Profile &p, int R, std::vector<uint32_t> &tab4, std::vector<uint32_t> &tab_full)
+{
+  auto sval = [&](int x, int k) -> int {
+    if (x >= p.Kp || k < 1 || k > p.M) return kNegPad;
+    return (int) p.bias_b - (int) p.rb[(size_t) x * (p.M + 1) + k];
+  };
+  auto pack = [](int lo, int hi) -> uint32_t { return ((uint32_t) (uint16_t) (int16_t) lo) | ((uint32_t) (uint16_t) (int16_t) hi << 16); };
+  tab4.assign((size_t) 2 * 4 * R * 64, 0);
+  tab_full.assign((size_t) 2 * p.Kp * R * 64, 0);
+  for (int par = 0; par < 2; ++par)
+    for (int x = 0; x < p.Kp; ++x)
+      for (int j = 0; j < R; ++j)
+        for (int lane = 0; lane < 64; ++lane) {
+          const int g = lane * R + j;
+          const uint32_t w = par == 0 ? pack(sval(x, 2 * g - 1), sval(x, 2 * g)) : pack(sval(x, 2 * g), sval(x, 2 * g + 1));
+          tab_full[(((size_t) par * p.Kp + x) * R + j) * 64 + lane] = w;
+          if (x < 4) tab4[(((size_t) par * 4 + x) * R + j) * 64 + lane] = w;
+        }
+}
+
+template <int R>
+static int launch_ssv(const SsvLongArgs &a, int num_cu, hipStream_t st)
+{
+  const size_t lds = (size_t) 2 * 4 * R * 64 * 4;
+  auto kern = ssvlong_kernel<R>;
+  static int per_cu_cached = 0;
+  static std::mutex mu;
+  int per_cu = 0;
+  {
+    std::lock_guard<std::mutex> lk(mu);
+    if (per_cu_cached == 0) {
+      if (lds > 64 * 1024) P7X_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds));
+      P7X_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu_cached, kern, 256, lds));
+      if (per_cu_cached < 1) per_cu_cached = 1;
+    }
+    per_cu = per_cu_cached;
+  }
+  long long grid = std::min<long long>((a.nchunks + 3) / 4, (long long) num_cu * per_cu);
+  if (grid < 1) grid = 1;
+  hipLaunchKernelGGL(kern, dim3((unsigned) grid), dim3(256), lds, st, a);
+  P7X_HIP(hipGetLastError());
+  return P7X_OK;
+}
+
+int ssvlong_launch(int R, const SsvLongArgs &a, int num_cu, hipStream_t st)
+{
+  switch (R) {
+    case 2: return launch_ssv<2>(a, num_cu, st);
+    case 4: return launch_ssv<4>(a, num_cu, st);
+    case 6: return launch_ssv<6>(a, num_cu, st);
+    case 8: return launch_ssv<8>(a, num_cu, st);
+    case 12: return launch_ssv<12>(a, num_cu, st);
+    case 16: return launch_ssv<16>(a, num_cu, st);
+    case 24: return launch_ssv<24>(a, num_cu, st);
+    case 32: return launch_ssv<32>(a, num_cu, st);
+    case 48: return launch_ssv<48>(a, num_cu, st);
+    default: set_error("model too long for the long-target SSV kernel (M > 6141)"); return P7X_EINVAL;
+  }
+}
+
+} // namespace p7x

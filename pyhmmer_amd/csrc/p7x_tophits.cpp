@@ -21,22 +21,22 @@ namespace p7x {
 
 static bool target_reportable(const p7x_pipeline_cfg &c, double Z, float score, double lnP)
 {
-  if (c.by_E) return std::exp(lnP) * Z <= c.E;
+  if (c.by_E) return std::exp(lnP) * (c.long_targets ? 1.0 : Z) <= c.E;     // long targets: the database size is in the P-value
   return score >= c.T;
 }
 static bool target_includable(const p7x_pipeline_cfg &c, double Z, float score, double lnP)
 {
-  if (c.inc_by_E) return std::exp(lnP) * Z <= c.incE;
+  if (c.inc_by_E) return std::exp(lnP) * (c.long_targets ? 1.0 : Z) <= c.incE;
   return score >= c.incT;
 }
 static bool domain_reportable(const p7x_pipeline_cfg &c, double domZ, float score, double lnP)
 {
-  if (c.dom_by_E) return std::exp(lnP) * domZ <= c.domE;
+  if (c.dom_by_E) return std::exp(lnP) * (c.long_targets ? 1.0 : domZ) <= c.domE;
   return score >= c.domT;
 }
 static bool domain_includable(const p7x_pipeline_cfg &c, double domZ, float score, double lnP)
 {
-  if (c.incdom_by_E) return std::exp(lnP) * domZ <= c.incdomE;
+  if (c.incdom_by_E) return std::exp(lnP) * (c.long_targets ? 1.0 : domZ) <= c.incdomE;
   return score >= c.incdomT;
 }
 
@@ -433,6 +433,11 @@ int host_finish_search(const p7x_pipeline_cfg &cfg_in, const p7x_oprofile *om, c
   return host_finish_batch(cfg_in, items, tg, names, accs, descs, out, scorer);
 }
 
+void tophits_sort_by_key(p7x_tophits &th) { sort_by_key(th); }
+void tophits_threshold(p7x_tophits &th) { threshold(th); }
+bool tophits_target_reportable(const p7x_pipeline_cfg &c, float score, double lnP) { return target_reportable(c, c.Z, score, lnP); }
+int tophits_usable_cpus() { return usable_cpus(); }
+
 void tophits_set_stages(p7x_tophits *th, std::vector<uint8_t> &&stage) { th->stage = std::move(stage); }
 void tophits_set_total_ms(p7x_tophits *th, double stage1, double stage2) { th->ms[6] = stage1 + stage2; th->ms[10] = stage1; th->ms[11] = stage2; }
 
@@ -490,7 +495,7 @@ int p7x_tophits_get_hit(const p7x_tophits *th, int64_t i, p7x_hit *o)
   if (!h || !o) return P7X_EINVAL;
   std::memset(o, 0, sizeof(*o));
   o->name = h->name.c_str(); o->acc = h->has_acc ? h->acc.c_str() : nullptr; o->desc = h->has_desc ? h->desc.c_str() : nullptr;
-  o->seqidx = h->seqidx; o->sortkey = h->sortkey; o->score = h->score; o->pre_score = h->pre_score; o->sum_score = h->sum_score;
+  o->seqidx = h->seqidx; o->window_length = h->window_length; o->sortkey = h->sortkey; o->score = h->score; o->pre_score = h->pre_score; o->sum_score = h->sum_score;
   o->lnP = h->lnP; o->pre_lnP = h->pre_lnP; o->sum_lnP = h->sum_lnP; o->nexpected = h->nexpected;
   o->nregions = h->nregions; o->nclustered = h->nclustered; o->noverlaps = h->noverlaps; o->nenvelopes = h->nenvelopes;
   o->ndom = h->ndom; o->flags = h->flags; o->nreported = h->nreported; o->nincluded = h->nincluded; o->best_domain = h->best_domain;
@@ -684,7 +689,7 @@ template <class IO> void io_domain(IO &io, Domain &d)
 }
 template <class IO> void io_hit(IO &io, Hit &h)
 {
-  io.str(h.name); io.str(h.acc); io.str(h.desc); io.pod(h.has_acc); io.pod(h.has_desc); io.pod(h.seqidx); io.pod(h.sortkey);
+  io.str(h.name); io.str(h.acc); io.str(h.desc); io.pod(h.has_acc); io.pod(h.has_desc); io.pod(h.seqidx); io.pod(h.window_length); io.pod(h.sortkey);
   io.pod(h.score); io.pod(h.pre_score); io.pod(h.sum_score); io.pod(h.lnP); io.pod(h.pre_lnP); io.pod(h.sum_lnP);
   io.pod(h.nexpected); io.pod(h.nregions); io.pod(h.nclustered); io.pod(h.noverlaps); io.pod(h.nenvelopes); io.pod(h.ndom);
   io.pod(h.flags); io.pod(h.nreported); io.pod(h.nincluded); io.pod(h.best_domain);

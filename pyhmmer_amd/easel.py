@@ -347,12 +347,13 @@ class _LazyDigitalSequenceBlock(DigitalSequenceBlock):
 
 
 class SequenceFile:
-    """FASTA reader with the reference's ``SequenceFile`` surface (``read``, ``read_block``,
-    iteration, context manager).  Only the FASTA format is supported here."""
+    """Sequence reader with the reference's ``SequenceFile`` surface (``read``, ``read_block``, iteration, context
+    manager).  FASTA, and the sequence records of GenBank flat files (LOCUS / DEFINITION / VERSION / ORIGIN: what the
+    reference's nhmmer fixtures need); the format is recognised from the first line when it is not given."""
 
     def __init__(self, file, format: Optional[str] = None, *, digital: bool = False,
                  alphabet: Optional[Alphabet] = None):
-        if format not in (None, "fasta", "afa"):
+        if format not in (None, "fasta", "afa", "genbank"):
             raise ValueError(f"unsupported sequence format: {format!r}")
         if isinstance(file, (str, bytes, os.PathLike)):
             self._fh = open(file, "r")
@@ -366,6 +367,15 @@ class SequenceFile:
         self.alphabet = alphabet
         self._pending: Optional[str] = None
         self._touched = False
+        if format is None:
+            try:
+                pos = self._fh.tell()
+                first = self._fh.readline()
+                self._fh.seek(pos)
+                format = "genbank" if first.startswith("LOCUS") else "fasta"
+            except (OSError, ValueError):
+                format = "fasta"
+        self.format = format
         if digital and alphabet is None:
             self.alphabet = self.guess_alphabet()
             if self.alphabet is None:
@@ -391,9 +401,19 @@ class SequenceFile:
         pos = self._fh.tell()
         counts = np.zeros(256, dtype=np.int64)
         n = 0
+        in_origin = self.format != "genbank"
         for line in self._fh:
             if line.startswith(">"):
                 continue
+            if self.format == "genbank":
+                if line.startswith("ORIGIN"):
+                    in_origin = True
+                    continue
+                if line.startswith("//"):
+                    in_origin = False
+                if not in_origin:
+                    continue
+                line = "".join(c for c in line if c.isalpha())
             raw = np.frombuffer(line.strip().upper().encode("ascii", "ignore"), dtype=np.uint8)
             counts += np.bincount(raw, minlength=256)
             n += raw.size
@@ -405,8 +425,51 @@ class SequenceFile:
         nuc = sum(int(counts[ord(c)]) for c in "ACGTUN")
         return Alphabet.dna() if nuc >= 0.9 * n else Alphabet.amino()
 
+    def _read_genbank(self) -> Optional[TextSequence]:
+        """One record of a GenBank flat file: name from LOCUS, accession from VERSION (else ACCESSION), description from
+        DEFINITION (continuation lines joined), residues from ORIGIN .. //."""
+        name = acc = ""
+        desc: list = []
+        chunks: list = []
+        state = None
+        seen = False
+        for line in self._fh:
+            if line.startswith("//"):
+                if seen:
+                    break
+                continue
+            key = line[:12].strip()
+            if key == "LOCUS":
+                name = line.split()[1]
+                seen = True
+                state = None
+            elif key == "DEFINITION":
+                desc = [line[12:].strip()]
+                state = "def"
+            elif key == "VERSION":
+                parts = line.split()
+                acc = parts[1] if len(parts) > 1 else acc
+                state = None
+            elif key == "ACCESSION":
+                parts = line.split()
+                acc = acc or (parts[1] if len(parts) > 1 else "")
+                state = None
+            elif key == "ORIGIN":
+                state = "seq"
+            elif state == "seq":
+                chunks.append("".join(c for c in line if c.isalpha()))
+            elif state == "def" and line.startswith(" "):
+                desc.append(line.strip())
+            elif key:
+                state = None
+        if not seen:
+            return None
+        return TextSequence(name=name, description=" ".join(desc), accession=acc, sequence="".join(chunks))
+
     def _read_text(self) -> Optional[TextSequence]:
         self._touched = True
+        if self.format == "genbank":
+            return self._read_genbank()
         header = self._pending
         self._pending = None
         if header is None:
@@ -471,7 +534,7 @@ class SequenceFile:
         return _LazyDigitalSequenceBlock(self.alphabet, PackedBlock.from_arrays(dsq, offsets, lengths), strtab, name_off, desc_off)
 
     def read_block(self, sequences: Optional[int] = None, residues: Optional[int] = None):
-        if self.digital and self._own and not self._touched and sequences is None and residues is None:
+        if self.digital and self._own and not self._touched and sequences is None and residues is None and self.format != "genbank":
             return self._read_block_native()
         out = []
         nres = 0

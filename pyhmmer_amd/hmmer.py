@@ -18,9 +18,9 @@ from typing import Callable, Iterable, Iterator, List, Optional, Sequence, Union
 
 from . import _lib
 from .easel import Alphabet, DigitalSequenceBlock, SequenceFile
-from .plan7 import HMM, OptimizedProfile, Pipeline, Profile, SequenceDatabase, TopHits
+from .plan7 import HMM, LongTargetsPipeline, OptimizedProfile, Pipeline, Profile, SequenceDatabase, TopHits
 
-__all__ = ["hmmsearch", "hmmscan", "hmmpress", "make_chunks", "ShardedDatabase"]
+__all__ = ["hmmsearch", "hmmscan", "nhmmer", "hmmpress", "make_chunks", "ShardedDatabase"]
 
 
 def make_chunks(block: DigitalSequenceBlock, n: int) -> List[DigitalSequenceBlock]:
@@ -518,4 +518,39 @@ def hmmscan(queries, profiles, *, cpus: int = 0, callback: Optional[Callable] = 
     for q, hits in zip(queries, results):
         if callback is not None:
             callback(q, n)
+        yield hits
+
+
+def nhmmer(queries, sequences, *, cpus: int = 0, callback: Optional[Callable] = None, devices: Optional[Sequence[int]] = None,
+           backend: Optional[str] = None, builder=None, timeout: Optional[float] = None, **options) -> Iterator[TopHits]:
+    """Search nucleotide HMMs against long nucleotide targets; yields one ``TopHits`` per query, in query order
+    (reference ``hmmer/_nhmmer.py:24-56``: one ``LongTargetsPipeline.search_hmm`` per query).
+
+    ``queries``: ``HMM`` / ``Profile`` / ``OptimizedProfile`` objects (one or an iterable).  Sequence and alignment
+    queries of the reference go through the HMM builder first, which is outside this path: build the HMM and pass it.
+    ``sequences``: a ``DigitalSequenceBlock`` or a digital ``SequenceFile`` (FASTA or GenBank).  Keyword arguments are
+    those of :class:`~pyhmmer_amd.plan7.LongTargetsPipeline`."""
+    if isinstance(queries, (HMM, Profile, OptimizedProfile)):
+        queries = (queries,)
+    if isinstance(sequences, SequenceFile):
+        if not sequences.digital:
+            raise ValueError("target sequences file is not in digital mode")
+        sequences = sequences.read_block()
+    if not isinstance(sequences, DigitalSequenceBlock):
+        raise TypeError(f"Expected DigitalSequenceBlock or SequenceFile, found {type(sequences).__name__}")
+    if _lib.lib().p7x_device_count() < 1:
+        from .errors import DeviceUnavailable
+        raise DeviceUnavailable("nhmmer: no HIP device is usable and there is no CPU fallback")
+    pipeline = LongTargetsPipeline(sequences.alphabet, device=(devices[0] if devices else 0), host_threads=cpus, **options)
+    total = None
+    try:
+        total = len(queries)          # type: ignore[arg-type]
+    except TypeError:
+        pass
+    for q in queries:
+        if not isinstance(q, (HMM, Profile, OptimizedProfile)):
+            raise TypeError(f"Unsupported query type for `nhmmer`: {type(q).__name__} (build an HMM from it first)")
+        hits = pipeline.search_hmm(q, sequences)
+        if callback is not None:
+            callback(q, total)
         yield hits

@@ -23,7 +23,7 @@ from .errors import (AlphabetMismatch, AllocationError, InvalidParameter, Missin
 
 __all__ = [
     "HMM", "HMMFile", "HMMPressedFile", "Background", "Profile", "OptimizedProfile", "OptimizedProfileBlock", "EvalueParameters", "Cutoffs",
-    "Pipeline", "SequenceDatabase", "TopHits", "Hit", "Domain", "Domains", "Alignment",
+    "Pipeline", "LongTargetsPipeline", "SequenceDatabase", "TopHits", "Hit", "Domain", "Domains", "Alignment",
 ]
 
 CUTOFF_UNSET = -99999.0
@@ -829,11 +829,22 @@ class Domain:
 
     @property
     def c_evalue(self) -> float:
+        if self.hit.hits.long_targets:
+            return math.exp(self._rec.lnP)
         return math.exp(self._rec.lnP) * self.hit.hits.domZ      # plan7.pyx:1557-1574
 
     @property
     def i_evalue(self) -> float:
+        if self.hit.hits.long_targets:
+            return math.exp(self._rec.lnP)
         return math.exp(self._rec.lnP) * self.hit.hits.Z
+
+    @property
+    def strand(self) -> Optional[str]:
+        """"+" / "-" for hits of a `LongTargetsPipeline`, else `None` (reference ``plan7.pyx:1511-1526``)."""
+        if not self.hit.hits.long_targets:
+            return None
+        return "+" if self._rec.iali < self._rec.jali else "-"
 
     @property
     def reported(self) -> bool:
@@ -955,6 +966,8 @@ class Hit:
 
     @property
     def evalue(self) -> float:
+        if self.hits.long_targets:
+            return math.exp(self._rec.lnP)                         # the database size is part of a long-target P-value
         return math.exp(self._rec.lnP) * self.hits.Z              # plan7.pyx:2104-2111
 
     @property
@@ -1137,9 +1150,22 @@ class TopHits:
         return "scan" if self._cfg().mode == _P7X_SCAN_MODELS else "search"
 
     @property
+    def long_targets(self) -> bool:
+        """Whether these hits come from a `LongTargetsPipeline` (reference ``plan7.pyx:8739-8746``)."""
+        return bool(self._cfg().long_targets)
+
+    @property
     def strand(self) -> Optional[str]:
-        """Always `None`: only protein-style (single strand) pipelines exist here (``plan7.pyx:8489-8505``)."""
+        """The strand a `LongTargetsPipeline` was restricted to, or `None` (reference ``plan7.pyx:8748-8764``)."""
+        c = self._cfg()
+        if c.long_targets:
+            return {1: "watson", 2: "crick"}.get(c.strands)
         return None
+
+    @property
+    def block_length(self) -> Optional[int]:
+        c = self._cfg()
+        return int(c.block_length) if c.long_targets else None
 
     def sort(self, by: str = "key") -> None:
         """``p7_tophits_SortBySortkey`` / ``p7_tophits_SortBySeqidxAndAlipos`` (reference ``plan7.pyx:9120-9148``)."""
@@ -1457,6 +1483,102 @@ class Pipeline:
         if st != 0:
             raise status_to_exception(st, "p7x_search_block", _lib.last_error())
         return TopHits(label if label is not None else query, out)
+
+
+class LongTargetsPipeline(Pipeline):
+    """An HMMER3 pipeline tuned for long (nucleotide) targets: ``nhmmer`` (reference ``plan7.pyx:6917-7763``).
+
+    Same constructor as the reference (``plan7.pyx:6957-7060``: ``F1=0.02, F2=3e-3, F3=3e-5, strand, B1=100, B2=240,
+    B3=1000, block_length=0x40000, window_length, window_beta``).  ``search_hmm`` runs
+    ``_search_loop_longtargets`` + the E-value / duplicate / threshold tail (``plan7.pyx:7272-7418``): the SSV scan of
+    every target strand on the device, the windows it seeds on the host (``p7x_search_longtargets``).
+    ``window_beta`` (recomputing ``max_length`` from the core model, ``p7_Builder_MaxLength``) belongs to the HMM
+    builder, which is out of scope: the model's own ``MAXL`` is used unless ``window_length`` is given."""
+
+    _STRANDS = {None: 0, "watson": 1, "crick": 2}
+
+    def __init__(self, alphabet: Alphabet, background: Optional[Background] = None, *, F1: float = 0.02, F2: float = 3e-3,
+                 F3: float = 3e-5, strand: Optional[str] = None, B1: int = 100, B2: int = 240, B3: int = 1000,
+                 block_length: int = 0x40000, window_length: Optional[int] = None, window_beta: Optional[float] = None,
+                 **kwargs):
+        if not (alphabet.is_dna() or alphabet.is_rna()):
+            raise ValueError(f"Expected nucleotide alphabet, found {alphabet!r}")          # plan7.pyx:7062-7064
+        if strand not in self._STRANDS:
+            raise InvalidParameter("strand", strand, choices=["watson", "crick", None])
+        for name, v in (("B1", B1), ("B2", B2), ("B3", B3)):
+            if v < 0:
+                raise InvalidParameter(name, v, hint="positive integer")
+        if block_length <= 0:
+            raise InvalidParameter("block_length", block_length, hint="strictly positive integer")
+        if window_length is not None and window_length < 4:
+            raise InvalidParameter("window_length", window_length, hint="integer greater than or equal to 4")
+        if window_beta is not None and not (0 < window_beta <= 1):
+            raise InvalidParameter("window_beta", window_beta, hint="real number between 0 and 1")
+        super().__init__(alphabet, background, F1=F1, F2=F2, F3=F3, **kwargs)
+        self.strand = strand
+        self.B1, self.B2, self.B3 = int(B1), int(B2), int(B3)
+        self.block_length = int(block_length)
+        self.window_length = window_length
+        self.window_beta = window_beta
+        # debugging switches of the long-target bias correction (see p7x_domaindef.cpp)
+        self._lt_bias_mode = int(os.environ.get("P7X_LT_BIAS_MODE", "20"))
+        self._lt_bg_mix = float(os.environ.get("P7X_LT_BG_MIX", "0.75"))
+
+    def _cfg(self) -> "_lib.PipelineCfg":
+        c = super()._cfg()
+        c.long_targets = 1
+        c.strands = self._STRANDS[self.strand]
+        c.B1, c.B2, c.B3 = self.B1, self.B2, self.B3
+        c.block_length = self.block_length
+        c.window_length = -1 if self.window_length is None else int(self.window_length)
+        c.lt_bias_mode, c.lt_bg_mix = self._lt_bias_mode, self._lt_bg_mix
+        return c
+
+    @staticmethod
+    def _pack(sequences):
+        """Flat arrays of the C-ABI (255 x1..xL 255 ...) with 64-bit lengths, and the name tables."""
+        n = len(sequences)
+        lengths = np.array([len(s) for s in sequences], dtype=np.int64)
+        offsets = np.empty(n, dtype=np.int64)
+        dsq = np.full(int(lengths.sum()) + n + 1, 255, dtype=np.uint8)
+        pos = 1
+        for i, s in enumerate(sequences):
+            offsets[i] = pos
+            dsq[pos:pos + len(s)] = s.sequence
+            pos += len(s) + 1
+        names = (C.c_char_p * max(n, 1))(*[s.name.encode() for s in sequences])
+        accs = (C.c_char_p * max(n, 1))(*[(s.accession or "").encode() for s in sequences])
+        descs = (C.c_char_p * max(n, 1))(*[(s.description or "").encode() for s in sequences])
+        return dsq, offsets, lengths, names, accs, descs
+
+    def search_hmm(self, query, sequences) -> "TopHits":
+        """``nhmmer`` with ``query`` against the long targets of ``sequences`` (reference ``plan7.pyx:7272-7418``)."""
+        if isinstance(sequences, SequenceFile):
+            if sequences.name is None:
+                raise ValueError("can only use a `SequenceFile` backed by a file for reading targets")
+            if not sequences.digital:
+                raise ValueError("target sequences file is not in digital mode")
+            sequences = sequences.read_block()
+        if query.alphabet != self.alphabet:
+            raise AlphabetMismatch(self.alphabet, query.alphabet)
+        if sequences.alphabet != self.alphabet:
+            raise AlphabetMismatch(self.alphabet, sequences.alphabet)
+        if isinstance(query, (Profile, OptimizedProfile)) and self.window_length is None and (getattr(query, "max_length", None) or -1) <= 0:
+            raise TypeError("Cannot use `Profile` or `OptimizedProfile` query without `max_length` set")     # plan7.pyx:7354
+        L = len(sequences[0]) if len(sequences) else self.L_HINT
+        om = self._get_om_from_query(query, min(L, 100000))
+        cfg = self._cfg()
+        if self.bit_cutoffs is not None and not getattr(om.cutoffs, self.bit_cutoffs + "_available")():
+            raise MissingCutoffs(om.name, self.bit_cutoffs)
+        dsq, offsets, lengths, names, accs, descs = self._pack(sequences)
+        out = C.c_void_p()
+        st = _lib.lib().p7x_search_longtargets(C.byref(cfg), om._handle, self.device, dsq.ctypes.data, offsets.ctypes.data,
+                                               lengths.ctypes.data, len(sequences), names, accs, descs, C.byref(out))
+        if st != 0:
+            raise status_to_exception(st, "p7x_search_longtargets", _lib.last_error())
+        hits = TopHits(query, out)
+        hits._om = om
+        return hits
 
 
 class SequenceDatabase:

@@ -47,3 +47,58 @@ def host_search(oracle, hmm, block, pipeline=None, F=(0.02, 1e-3, 1e-5)):
     hits = plan7.TopHits(hmm, out)
     hits._keep = (om, names, accs, descs)
     return hits
+
+
+DNA_COMP = np.array([3, 2, 1, 0, 4, 6, 5, 8, 7, 9, 10, 14, 13, 12, 11, 15, 16, 17], dtype=np.uint8)
+
+
+def blocks_of(L, W, Cov):
+    """(start i, residues n) of the blocks LongTargetsPipeline._search_loop_longtargets cuts a target into (plan7.pyx:7604-7610)."""
+    out = []
+    i = 0
+    while i < L:
+        c = 0 if i == 0 else min(Cov, L - i)
+        w = min(W, L - i - c)
+        n = c + w
+        if n <= 0:
+            break
+        out.append((i, n))
+        if i + n >= L:
+            break
+        i += W - Cov
+    return out
+
+
+def host_nhmmer(oracle, hmm, sequences, pipeline=None):
+    """CPU harness of the long-target path: the oracle's sequential SSV scan seeds the windows of every (target, block,
+    strand); the product's host tail (p7x_longtarget_from_seeds) does the rest."""
+    pipeline = pipeline or plan7.LongTargetsPipeline(hmm.alphabet)
+    bg = pipeline.background
+    op = oracle.OracleProfile(hmm, bg, 400)
+    om = plan7.OptimizedProfile(hmm, bg, 400)
+    cfg = pipeline._cfg()
+    max_length = pipeline.window_length or hmm.max_length
+    dsq, offsets, lengths, names, accs, descs = plan7.LongTargetsPipeline._pack(sequences)
+    st_t, st_b, st_s, seeds = [], [], [], []
+    for t, s in enumerate(sequences):
+        seq = np.asarray(s.sequence, dtype=np.uint8)
+        for (i, n) in blocks_of(len(seq), pipeline.block_length, max_length):
+            for strand in (0, 1):
+                if (strand == 0 and pipeline.strand == "crick") or (strand == 1 and pipeline.strand == "watson"):
+                    continue
+                blk = seq[i:i + n] if strand == 0 else DNA_COMP[seq[i:i + n][::-1]]
+                for sd in oracle.ssv_longtarget(op, blk, max_length, pipeline.F1):
+                    st_t.append(t); st_b.append(i); st_s.append(strand); seeds.append(sd)
+    ns = len(seeds)
+    a_t = np.array(st_t or [0], dtype=np.int64); a_b = np.array(st_b or [0], dtype=np.int64); a_s = np.array(st_s or [0], dtype=np.int32)
+    a_seeds = np.array(seeds if seeds else [[0, 0, 0]], dtype=np.int64).reshape(-1, 3)
+    out = C.c_void_p()
+    st = _lib.lib().p7x_longtarget_from_seeds(C.byref(cfg), om._handle, dsq.ctypes.data, offsets.ctypes.data, lengths.ctypes.data,
+                                              len(sequences), names, accs, descs, a_t.ctypes.data, a_b.ctypes.data, a_s.ctypes.data,
+                                              np.ascontiguousarray(a_seeds).ctypes.data, ns, C.byref(out))
+    if st != 0:
+        raise RuntimeError(f"p7x_longtarget_from_seeds failed: {st} {_lib.last_error()}")
+    hits = plan7.TopHits(hmm, out)
+    hits._keep = (om, names, accs, descs, dsq)
+    hits._nseeds = ns
+    return hits

@@ -157,3 +157,17 @@ class OracleProfile:
         lib().p7o_msv_block(self.ptr, packed.dsq.ctypes.data, packed.offsets.ctypes.data, packed.lengths.ctypes.data,
                             packed.n, out.ctypes.data)
         return out
+
+
+def ssv_longtarget(op, block_dsq, max_length, F1=0.02, cap=1 << 16):
+    """Oracle's exact sequential p7_SSVFilter_longtarget over one strand block (block_dsq: residues, 0-based numpy)."""
+    l = lib()
+    l.p7o_ssv_longtarget.restype = C.c_int64
+    l.p7o_ssv_longtarget.argtypes = [C.POINTER(Profile), C.c_void_p, C.c_int64, C.c_int, C.c_double, C.c_void_p, C.c_int64]
+    d = np.empty(len(block_dsq) + 2, dtype=np.uint8)
+    d[0] = d[-1] = 255
+    d[1:-1] = block_dsq
+    seeds = np.zeros((cap, 3), dtype=np.int64)
+    n = l.p7o_ssv_longtarget(op.ptr, d.ctypes.data, len(block_dsq), int(max_length), float(F1), seeds.ctypes.data, cap)
+    assert n <= cap
+    return seeds[:n].copy()
