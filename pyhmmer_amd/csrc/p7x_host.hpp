@@ -1,6 +1,7 @@
 // p7x_host.hpp -- host-side post-processing of Forward survivors: domain definition and hit lists.
 #pragma once
 #include "p7x_internal.hpp"
+#include <functional>
 #include <memory>
 #include <string>
 #include <vector>
@@ -118,6 +119,8 @@ void tophits_sort_by_key(p7x_tophits &th);
 void tophits_threshold(p7x_tophits &th);
 bool tophits_target_reportable(const p7x_pipeline_cfg &c, float score, double lnP);
 int tophits_usable_cpus();
+// body(i) for i in [0, n) on the persistent host workers (dynamic schedule; nthreads <= 0: every usable CPU)
+void host_parallel_for(int n, int nthreads, const std::function<void(int)> &body);
 void tophits_set_stages(p7x_tophits *th, std::vector<uint8_t> &&stage);
 float kahan_fsum(const float *v, int n);
 
@@ -128,9 +131,20 @@ int longtarget_setup(const p7x_pipeline_cfg &cfg, const Profile &p, int *max_len
 const uint8_t *longtarget_complement(int abc_type);
 void longtarget_seeds_from_rows(const Profile &p, const uint8_t *block_dsq, int64_t L, const LongTargetRow *rows, size_t nrows,
                                 int sc_thresh, int xB, std::vector<int64_t> &seeds3);
+// The filter scores of a target's windows from one device batch (p7x_longtarget.hip): a window = <length> residues of
+// <strand> starting at original position <start> (strand 1: running towards lower positions, complemented).
+struct LongTargetWindowRef { int64_t start, length; int strand; };
+struct LongTargetWindowScore { float usc, bias_filtersc, vfsc; int have_vit; };
+struct LongTargetWindowScorer {
+  virtual ~LongTargetWindowScorer() = default;
+  // seq1: the target, 1-based; sc[w]: MSV score (nats), bias filter score, and for windows that pass both P <= F1 tests
+  // but not P <= F2 the standard Viterbi filter score
+  virtual int score(const uint8_t *seq1, int64_t L, const uint8_t *comp, const LongTargetWindowRef *w, size_t nw, double F1, bool do_bias,
+                    LongTargetWindowScore *sc) = 0;
+};
 int longtarget_run_host(const p7x_pipeline_cfg &cfg, const p7x_oprofile *om, const uint8_t *dsq, const int64_t *offsets, const int64_t *lengths,
                         size_t n, const char *const *names, const char *const *accs, const char *const *descs,
-                        const std::vector<LongTargetSeed> &seeds, p7x_tophits **out);
+                        const std::vector<LongTargetSeed> &seeds, p7x_tophits **out, LongTargetWindowScorer *filters = nullptr);
 void host_prof_dump();
 
 } // namespace p7x

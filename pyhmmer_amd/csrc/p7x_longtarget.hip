@@ -108,6 +108,54 @@ static void block_seeds(const Profile &p, const uint8_t *seq1, int64_t Lt, int64
   longtarget_seeds_from_rows(p, buf.data(), bn, br.data(), br.size(), sc_thresh, xB, seeds3);
 }
 
+// The windows of a target as one block of "targets" through the batch filter kernels: exact MSV scores (u8), the bias
+// filter score and the standard Viterbi filter score (an upper bound for every row of the long-target Viterbi scan).
+struct DeviceWindowScorer final : LongTargetWindowScorer {
+  const p7x_oprofile *om; int device;
+  double ms = 0.0; size_t nwindows = 0;
+  DeviceWindowScorer(const p7x_oprofile *o, int d) : om(o), device(d) {}
+  int score(const uint8_t *seq1, int64_t L, const uint8_t *comp, const LongTargetWindowRef *w, size_t nw, double F1, bool do_bias,
+            LongTargetWindowScore *sc) override
+  {
+    (void) L; (void) F1;
+    const auto t0 = std::chrono::steady_clock::now();
+    const Profile &p = om->p;
+    size_t tot = 1;
+    for (size_t q = 0; q < nw; ++q) tot += (size_t) w[q].length + 1;
+    std::vector<uint8_t> dsq(tot, 255);
+    std::vector<int64_t> off(nw); std::vector<int32_t> len(nw);
+    size_t pos = 1;
+    for (size_t q = 0; q < nw; ++q) {
+      off[q] = (int64_t) pos; len[q] = (int32_t) w[q].length;
+      if (w[q].strand == 0) std::memcpy(dsq.data() + pos, seq1 + w[q].start, (size_t) w[q].length);
+      else for (int64_t r = 0; r < w[q].length; ++r) dsq[pos + (size_t) r] = comp[seq1[w[q].start - r]];
+      pos += (size_t) w[q].length + 1;
+    }
+    p7x_seqdb *db = nullptr;
+    int st = p7x_seqdb_create(device, p.abc_type, dsq.data(), off.data(), len.data(), nw, &db);
+    if (st != P7X_OK) return st;
+    std::vector<int32_t> xJ(nw), xC(nw); std::vector<float> bias(nw);
+    st = p7x_filters_batch(om, db, xJ.data(), xC.data(), nullptr, do_bias ? bias.data() : nullptr);
+    p7x_seqdb_destroy(db);
+    if (st != P7X_OK) return st;
+    for (size_t q = 0; q < nw; ++q) {
+      const int Lw = len[q];
+      const float pm = logf(3.0f / (float) (Lw + 3));
+      float usc;
+      if (xJ[q] < 0) usc = INFINITY;
+      else { const uint8_t tjb = unbiased_byteify(p.scale_b, pm); usc = ((float) (xJ[q] - tjb) - (float) p.base_b); usc /= p.scale_b; usc -= 3.0f; }
+      float vf;
+      if (xC[q] >= 32767) vf = INFINITY;
+      else if (xC[q] > -32768) { vf = (float) xC[q] + (float) wordify(p.scale_w, pm) - (float) p.base_w; vf /= p.scale_w; vf -= 3.0f; }
+      else vf = -INFINITY;
+      sc[q].usc = usc; sc[q].bias_filtersc = do_bias ? bias[q] : 0.0f; sc[q].vfsc = vf; sc[q].have_vit = 1;
+    }
+    ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    nwindows += nw;
+    return P7X_OK;
+  }
+};
+
 } // namespace
 } // namespace p7x
 
@@ -129,6 +177,7 @@ int p7x_search_longtargets(const p7x_pipeline_cfg *cfg, const p7x_oprofile *om, 
   if ((st = get_ctx(device, &ctx)) != P7X_OK) return st;
   const int mask = cfg->strands == P7X_STRAND_TOPONLY ? 1 : (cfg->strands == P7X_STRAND_BOTTOMONLY ? 2 : 3);
   const int64_t W = cfg->block_length, C = max_length;
+  const auto t_begin = std::chrono::steady_clock::now();
   std::vector<LongTargetSeed> seeds;
   double scan_ms = 0.0;
   for (size_t t = 0; t < n; ++t) {
@@ -153,8 +202,15 @@ int p7x_search_longtargets(const p7x_pipeline_cfg *cfg, const p7x_oprofile *om, 
       if (i + bn >= Lt) break;
     }
   }
-  st = longtarget_run_host(*cfg, om, dsq, offsets, lengths, n, names, accs, descs, seeds, out);
-  if (st == P7X_OK && *out) (*out)->ms[7] = scan_ms;          // the SSV scan kernels (HIP events)
+  const auto t_host = std::chrono::steady_clock::now();
+  DeviceWindowScorer scorer(om, device);
+  st = longtarget_run_host(*cfg, om, dsq, offsets, lengths, n, names, accs, descs, seeds, out, &scorer);
+  if (st == P7X_OK && *out) {
+    (*out)->ms[7] = scan_ms;                                   // the SSV scan kernels (HIP events)
+    (*out)->ms[0] = std::chrono::duration<double, std::milli>(t_host - t_begin).count();      // scan + seeds, wall
+    (*out)->ms[1] = scorer.ms;                                 // window MSV / bias / Viterbi batch on the device, wall
+    (*out)->ms[5] = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_host).count();   // host tail incl. [1]
+  }
   return st;
 }
 

@@ -428,21 +428,25 @@ static int lt_post_viterbi(const p7x_pipeline_cfg &cfg, const Profile &p, const 
   return P7X_OK;
 }
 
+// Filter scores of a window computed elsewhere (the device batch of p7x_longtarget.hip): MSV score, bias filter score,
+// and the standard Viterbi filter score, which bounds every row of the long-target Viterbi scan from above.
+struct LtWindowFilters { bool have = false; float usc = 0.0f, bias_filtersc = 0.0f; bool have_vit = false; float vfsc = 0.0f; };
+
 static int lt_post_ssv(const p7x_pipeline_cfg &cfg, const Profile &p, const LongTargetOpts &lto, const LtScoreData &sd, int max_length,
                        uint64_t nres_so_far, const LtBlock &blk, const LtTarget &tg, int64_t window_start, int64_t window_len,
-                       std::vector<Hit> &hits, LtCounters &ctr)
+                       std::vector<Hit> &hits, LtCounters &ctr, const LtWindowFilters *wf = nullptr)
 {
   const uint8_t *subseq = blk.dsq + window_start - 1;
   const int64_t F1_L = std::min<int64_t>(window_len, cfg.B1), F2_L = std::min<int64_t>(window_len, cfg.B2);
   const float nullsc = lt_null1(window_len);
   // the full MSV score of the window (SSV only seeded it)
-  const float usc = lt_msv(p, subseq, window_len);
+  const float usc = (wf && wf->have) ? wf->usc : lt_msv(p, subseq, window_len);
   double P = gumbel_surv((usc - nullsc) / kLog2, p.evparam[P7X_MMU], p.evparam[P7X_MLAMBDA]);
   if (P > cfg.F1) return P7X_OK;
   ctr.n_past_msv++; ctr.pos_past_msv += (uint64_t) window_len;
   float bias_filtersc = 0.0f, filtersc = nullsc;
   if (cfg.do_biasfilter) {
-    bias_filtersc = lt_bias_filter(p, subseq, window_len) - nullsc;
+    bias_filtersc = ((wf && wf->have) ? wf->bias_filtersc : lt_bias_filter(p, subseq, window_len)) - nullsc;
     filtersc = nullsc + (bias_filtersc * (F1_L > window_len ? 1.0f : (float) F1_L / (float) window_len));
     P = gumbel_surv((usc - filtersc) / kLog2, p.evparam[P7X_MMU], p.evparam[P7X_MLAMBDA]);
     if (P > cfg.F1) return P7X_OK;
@@ -451,6 +455,10 @@ static int lt_post_ssv(const p7x_pipeline_cfg &cfg, const Profile &p, const Long
   std::vector<LtWindow> vit;
   if (P > cfg.F2) {
     if (cfg.do_biasfilter) filtersc = nullsc + (bias_filtersc * (F2_L > window_len ? 1.0f : (float) F2_L / (float) window_len));
+    // The standard Viterbi filter score of the window is at least the score any single row reaches in the long-target
+    // scan (its C state collects every row's E; clearing rows can only lower later ones): a window that fails P <= F2
+    // with it cannot seed a Viterbi window, and the scan is skipped.
+    if (wf && wf->have_vit && gumbel_surv((wf->vfsc - filtersc) / kLog2, p.evparam[P7X_VMU], p.evparam[P7X_VLAMBDA]) > cfg.F2) return P7X_OK;
     lt_viterbi_longtarget(p, subseq, window_len, filtersc, cfg.F2, vit);
     lt_extend_and_merge(sd, max_length, window_len, 0.5f, vit);
   } else vit.push_back(LtWindow{ 1, 0, window_len });
@@ -462,15 +470,13 @@ static int lt_post_ssv(const p7x_pipeline_cfg &cfg, const Profile &p, const Long
   return P7X_OK;
 }
 
-// p7_Pipeline_LongTarget behind the SSV scan: seeds -> windows -> the rest, for one block of one strand
-static int lt_block_tail(const p7x_pipeline_cfg &cfg, const Profile &p, const LongTargetOpts &lto, const LtScoreData &sd, int max_length,
-                         uint64_t nres_so_far, const LtBlock &blk, const LtTarget &tg, std::vector<LtWindow> seeds,
-                         std::vector<Hit> &hits, LtCounters &ctr)
+// p7_Pipeline_LongTarget behind the SSV scan, first half: the seeds of one block of one strand become its windows
+static void lt_block_windows(const LtScoreData &sd, int max_length, int64_t block_len, std::vector<LtWindow> seeds, std::vector<LtWindow> &windows)
 {
-  if (seeds.empty()) return P7X_OK;
-  lt_extend_and_merge(sd, max_length, blk.n, 0.0f, seeds);
+  windows.clear();
+  if (seeds.empty()) return;
+  lt_extend_and_merge(sd, max_length, block_len, 0.0f, seeds);
   // very long merged windows are cut into overlapping pieces (upstream: longer than 80 kb -> 40 kb pieces)
-  std::vector<LtWindow> windows;
   const int64_t max_window = 80000, piece = 40000;
   for (const LtWindow &w : seeds) {
     if (w.length <= max_window) { windows.push_back(w); continue; }
@@ -480,9 +486,27 @@ static int lt_block_tail(const p7x_pipeline_cfg &cfg, const Profile &p, const Lo
       if (off + len >= w.length) break;
     }
   }
-  for (const LtWindow &w : windows) {
-    const int st = lt_post_ssv(cfg, p, lto, sd, max_length, nres_so_far, blk, tg, w.n, w.length, hits, ctr);
-    if (st != P7X_OK) return st;
+}
+
+// second half: every window through the rest of the pipeline (the windows are independent: spread over the host workers,
+// hits kept in window order)
+static int lt_block_run(const p7x_pipeline_cfg &cfg, const Profile &p, const LongTargetOpts &lto, const LtScoreData &sd, int max_length,
+                        uint64_t nres_so_far, const LtBlock &blk, const LtTarget &tg, const std::vector<LtWindow> &windows,
+                        const LtWindowFilters *wf, std::vector<Hit> &hits, LtCounters &ctr)
+{
+  std::vector<std::vector<Hit>> wh(windows.size());
+  std::vector<LtCounters> wc(windows.size());
+  std::vector<int> wst(windows.size(), P7X_OK);
+  host_parallel_for((int) windows.size(), cfg.host_threads, [&](int i) {
+    flogsum_init();
+    wst[(size_t) i] = lt_post_ssv(cfg, p, lto, sd, max_length, nres_so_far, blk, tg, windows[(size_t) i].n, windows[(size_t) i].length,
+                                  wh[(size_t) i], wc[(size_t) i], wf ? wf + i : nullptr);
+  });
+  for (size_t i = 0; i < windows.size(); ++i) {
+    if (wst[i] != P7X_OK) return wst[i];
+    for (Hit &h : wh[i]) hits.push_back(std::move(h));
+    ctr.n_past_msv += wc[i].n_past_msv; ctr.n_past_bias += wc[i].n_past_bias; ctr.n_past_vit += wc[i].n_past_vit; ctr.n_past_fwd += wc[i].n_past_fwd;
+    ctr.pos_past_msv += wc[i].pos_past_msv; ctr.pos_past_bias += wc[i].pos_past_bias; ctr.pos_past_vit += wc[i].pos_past_vit; ctr.pos_past_fwd += wc[i].pos_past_fwd;
   }
   return P7X_OK;
 }
@@ -561,10 +585,11 @@ static const uint8_t *lt_complement_table(int abc_type)
 
 struct LtSeedIn { int64_t target, block_start; int strand; LtWindow w; };
 
-// The whole host side for a set of targets, given the SSV seeds of every (target, block, strand).
+// The whole host side for a set of targets, given the SSV seeds of every (target, block, strand).  <filters>, when
+// given, scores all windows of a target in one device batch before the host sees them.
 static int lt_run_host(const p7x_pipeline_cfg &cfg, const p7x_oprofile *om, const uint8_t *dsq, const int64_t *offsets, const int64_t *lengths, size_t n,
                        const char *const *names, const char *const *accs, const char *const *descs,
-                       const std::vector<LtSeedIn> &seeds_in, p7x_tophits **out)
+                       const std::vector<LtSeedIn> &seeds_in, p7x_tophits **out, LongTargetWindowScorer *filters)
 {
   const Profile &p = om->p;
   if (p.abc_type != P7X_DNA && p.abc_type != P7X_RNA) { set_error("long-target pipeline needs a nucleotide model"); return P7X_EINVAL; }
@@ -575,17 +600,21 @@ static int lt_run_host(const p7x_pipeline_cfg &cfg, const p7x_oprofile *om, cons
   flogsum_init();
   LtScoreData sd; lt_scoredata(p, sd);
   std::vector<float> mp; lt_match_probabilities(p, mp);
-  LongTargetOpts lto; lto.do_null2 = cfg.do_null2 != 0; lto.match_prob = mp.data(); lto.bias_mode = cfg.lt_bias_mode & 15; lto.bg_mix = cfg.lt_bg_mix; lto.retrim_bg = (cfg.lt_bias_mode & 16) != 0; lto.bg_from_ali = (cfg.lt_bias_mode & 32) != 0; lto.bg_from_window = (cfg.lt_bias_mode & 64) != 0;
+  LongTargetOpts lto; lto.do_null2 = cfg.do_null2 != 0; lto.match_prob = mp.data();
+  lto.bias_mode = cfg.lt_bias_mode & 15; lto.bg_mix = cfg.lt_bg_mix; lto.retrim_bg = (cfg.lt_bias_mode & 16) != 0; lto.bg_from_ali = (cfg.lt_bias_mode & 32) != 0; lto.bg_from_window = (cfg.lt_bias_mode & 64) != 0;
   const uint8_t *comp = lt_complement_table(p.abc_type);
   std::vector<Hit> hits;
   LtCounters ctr;
   uint64_t nres = 0;
-  std::vector<uint8_t> buf;
   size_t sidx = 0;
+  struct BlockJob { int64_t i, bn, bc, bw; int strand; uint64_t nres_at; std::vector<LtWindow> windows; size_t first_window; };
   for (size_t t = 0; t < n; ++t) {
     const int64_t Lt = lengths[t];
     LtTarget tg{ (int64_t) t, names ? names[t] : nullptr, accs ? accs[t] : nullptr, descs ? descs[t] : nullptr, Lt };
     const uint8_t *seq = dsq + offsets[t] - 1;              // seq[1..Lt]
+    // pass 1: the windows of every block and strand of this target (and the residue accounting of the block loop)
+    std::vector<BlockJob> jobs;
+    size_t nwin = 0;
     for (int64_t i = 0; i < Lt; i += W - C) {
       const int64_t bc = i == 0 ? 0 : std::min<int64_t>(C, Lt - i);
       const int64_t bw = std::min<int64_t>(W, Lt - i - bc);
@@ -596,18 +625,43 @@ static int lt_run_host(const p7x_pipeline_cfg &cfg, const p7x_oprofile *om, cons
         if (strand == 0 && cfg.strands == P7X_STRAND_BOTTOMONLY) { nres -= (uint64_t) bn; continue; }
         if (strand == 0) nres -= (uint64_t) bc;              // the overlap with the previous block was counted there
         if (strand == 1 && cfg.strands == P7X_STRAND_TOPONLY) continue;
-        buf.assign((size_t) bn + 2, 255);
-        if (strand == 0) std::memcpy(buf.data() + 1, seq + i + 1, (size_t) bn);
-        else for (int64_t q = 1; q <= bn; ++q) buf[(size_t) q] = comp[seq[i + bn - q + 1]];
-        LtBlock blk{ buf.data(), bn, strand == 0 ? i + 1 : i + bn, strand == 1 };
         std::vector<LtWindow> seeds;
         while (sidx < seeds_in.size() && seeds_in[sidx].target == (int64_t) t && seeds_in[sidx].block_start == i && seeds_in[sidx].strand == strand)
           seeds.push_back(seeds_in[sidx++].w);
-        const int st = lt_block_tail(cfg, p, lto, sd, max_length, nres, blk, tg, std::move(seeds), hits, ctr);
-        if (st != P7X_OK) return st;
+        BlockJob job{ i, bn, bc, bw, strand, nres, {}, nwin };
+        lt_block_windows(sd, max_length, bn, std::move(seeds), job.windows);
+        nwin += job.windows.size();
+        if (!job.windows.empty()) jobs.push_back(std::move(job));
         if (strand == 1) nres += (uint64_t) bw;
       }
       if (i + bn >= Lt) break;
+    }
+    // the windows' filter scores, one device batch per target
+    std::vector<LtWindowFilters> wf;
+    if (filters && nwin > 0) {
+      std::vector<LongTargetWindowRef> refs; refs.reserve(nwin);
+      for (const BlockJob &job : jobs)
+        for (const LtWindow &w : job.windows) {
+          // original coordinates of the window's first residue on its strand and its length
+          LongTargetWindowRef r; r.strand = job.strand; r.length = w.length;
+          r.start = job.strand == 0 ? job.i + w.n : job.i + job.bn - w.n + 1;       // strand 1: original position of the window's first (revcomp) residue
+          refs.push_back(r);
+        }
+      std::vector<LongTargetWindowScore> sc(nwin);
+      const int st = filters->score(seq, Lt, comp, refs.data(), nwin, cfg.F1, cfg.do_biasfilter != 0, sc.data());
+      if (st != P7X_OK) return st;
+      wf.resize(nwin);
+      for (size_t q = 0; q < nwin; ++q) { wf[q].have = true; wf[q].usc = sc[q].usc; wf[q].bias_filtersc = sc[q].bias_filtersc; wf[q].have_vit = sc[q].have_vit != 0; wf[q].vfsc = sc[q].vfsc; }
+    }
+    // pass 2: the rest of the pipeline, block by block
+    std::vector<uint8_t> buf;
+    for (const BlockJob &job : jobs) {
+      buf.assign((size_t) job.bn + 2, 255);
+      if (job.strand == 0) std::memcpy(buf.data() + 1, seq + job.i + 1, (size_t) job.bn);
+      else for (int64_t q = 1; q <= job.bn; ++q) buf[(size_t) q] = comp[seq[job.i + job.bn - q + 1]];
+      LtBlock blk{ buf.data(), job.bn, job.strand == 0 ? job.i + 1 : job.i + job.bn, job.strand == 1 };
+      const int st = lt_block_run(cfg, p, lto, sd, max_length, job.nres_at, blk, tg, job.windows, wf.empty() ? nullptr : wf.data() + job.first_window, hits, ctr);
+      if (st != P7X_OK) return st;
     }
   }
   lt_finish_tophits(cfg, p, max_length, nres, (uint64_t) n, ctr, hits, out);
@@ -642,11 +696,11 @@ void longtarget_seeds_from_rows(const Profile &p, const uint8_t *block_dsq, int6
 
 int longtarget_run_host(const p7x_pipeline_cfg &cfg, const p7x_oprofile *om, const uint8_t *dsq, const int64_t *offsets, const int64_t *lengths,
                         size_t n, const char *const *names, const char *const *accs, const char *const *descs,
-                        const std::vector<LongTargetSeed> &seeds, p7x_tophits **out)
+                        const std::vector<LongTargetSeed> &seeds, p7x_tophits **out, LongTargetWindowScorer *filters)
 {
   std::vector<LtSeedIn> in(seeds.size());
   for (size_t s = 0; s < seeds.size(); ++s) in[s] = LtSeedIn{ seeds[s].target, seeds[s].block_start, seeds[s].strand, LtWindow{ seeds[s].n, seeds[s].k, seeds[s].length } };
-  return lt_run_host(cfg, om, dsq, offsets, lengths, n, names, accs, descs, in, out);
+  return lt_run_host(cfg, om, dsq, offsets, lengths, n, names, accs, descs, in, out, filters);
 }
 
 } // namespace p7x
@@ -665,7 +719,7 @@ int p7x_longtarget_from_seeds(const p7x_pipeline_cfg *cfg, const p7x_oprofile *o
   std::vector<LtSeedIn> in(nseeds);
   for (size_t s = 0; s < nseeds; ++s)
     in[s] = LtSeedIn{ seed_target[s], seed_block[s], seed_strand[s], LtWindow{ seeds[3 * s], (int) seeds[3 * s + 1], seeds[3 * s + 2] } };
-  return lt_run_host(*cfg, om, dsq, offsets, lengths, n, names, accs, descs, in, out);
+  return lt_run_host(*cfg, om, dsq, offsets, lengths, n, names, accs, descs, in, out, nullptr);
 }
 
 } // extern "C"

@@ -437,6 +437,11 @@ void tophits_sort_by_key(p7x_tophits &th) { sort_by_key(th); }
 void tophits_threshold(p7x_tophits &th) { threshold(th); }
 bool tophits_target_reportable(const p7x_pipeline_cfg &c, float score, double lnP) { return target_reportable(c, c.Z, score, lnP); }
 int tophits_usable_cpus() { return usable_cpus(); }
+void host_parallel_for(int n, int nthreads, const std::function<void(int)> &body)
+{
+  if (nthreads <= 0) nthreads = usable_cpus();
+  HostPool::get().run(n, nthreads, body);
+}
 
 void tophits_set_stages(p7x_tophits *th, std::vector<uint8_t> &&stage) { th->stage = std::move(stage); }
 void tophits_set_total_ms(p7x_tophits *th, double stage1, double stage2) { th->ms[6] = stage1 + stage2; th->ms[10] = stage1; th->ms[11] = stage2; }

@@ -1,0 +1,35 @@
+"""BASELINE configs[4]: nhmmer long-target, one DNA HMM (fixture bmyD, M = 1203) against a synthetic chromosome (i.i.d.
+ACGT 0.25, seed 45; SURVEY.md 8d "config 5"), both strands, block_length 262144.  Reports the SSV scan kernel (HIP
+events) as GCUPS = 2 strands x L x M / time, and the whole search.  usage: nhmmer_bench.py [Mbp] [planted]"""
+import os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+import numpy as np
+from pyhmmer_amd import easel, plan7
+mbp = float(sys.argv[1]) if len(sys.argv) > 1 else 250.0
+planted = int(sys.argv[2]) if len(sys.argv) > 2 else 50
+with plan7.HMMFile(os.path.join(ROOT, "tests", "golden", "hmms", "bmyD.hmm")) as f:
+    hmm = next(iter(f))
+L = int(mbp * 1e6)
+rng = np.random.default_rng(45)
+seq = rng.integers(0, 4, size=L, dtype=np.uint8)
+cons = np.argmax(hmm.match_emissions[1:], axis=1).astype(np.uint8)
+comp = np.array([3, 2, 1, 0], dtype=np.uint8)
+for c in range(planted):          # a few homologous segments so that the later stages have work
+    a = int(rng.integers(0, hmm.M - 200)); n = min(int(rng.integers(150, 1200)), hmm.M - a)
+    pos = int(rng.integers(0, L - n))
+    seg = cons[a:a + n].copy()
+    mut = rng.random(n) < 0.2
+    seg[mut] = rng.integers(0, 4, size=int(mut.sum()))
+    seq[pos:pos + n] = seg if c % 2 == 0 else comp[seg[::-1]]
+block = easel.DigitalSequenceBlock(hmm.alphabet, [easel.DigitalSequence(hmm.alphabet, name="chrSyn", sequence=seq)])
+pli = plan7.LongTargetsPipeline(hmm.alphabet)
+for it in range(2):
+    t0 = time.perf_counter()
+    hits = pli.search_hmm(hmm, block)
+    dt = time.perf_counter() - t0
+    scan_ms = hits.timings_ms["msv_kernel"]
+    cells = 2.0 * L * hmm.M
+    print(f"run {it}: {mbp:g} Mbp x 2 strands x M={hmm.M}: SSV scan kernels {scan_ms:.2f} ms = {cells / scan_ms / 1e6:.0f} GCUPS; "
+          f"whole search {dt:.2f} s = {cells / dt / 1e9:.0f} GCUPS; windows past msv/bias/vit/fwd {hits.stage_counts}, "
+          f"hits {len(hits)} reported {len(hits.reported)} (planted {planted})", flush=True)
