@@ -80,6 +80,10 @@ struct WaveSeqArgs {
   // Viterbi
   const int16_t *xwmove_tab; int base_w, xw_e, ddbound;
   int32_t *out_xC;          // [nlist]
+  // Viterbi, long-target variant (p7_ViterbiFilter_longtarget): a row whose best match cell reaches the item's score
+  // threshold is recorded (item, row, node: one record per cell holding that score) and the DP rows are cleared
+  const int *lt_thresh;     // [nlist] per item; NULL: the standard filter
+  int *lt_nrec; int *lt_rec; int lt_cap;      // records [cap][3]
   // Forward / Backward
   float xf_e_move, xf_e_loop;
   float *out_sc;            // [nlist] nats

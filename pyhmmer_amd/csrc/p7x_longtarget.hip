@@ -109,11 +109,14 @@ static void block_seeds(const Profile &p, const uint8_t *seq1, int64_t Lt, int64
 }
 
 // The windows of a target as one block of "targets" through the batch filter kernels: exact MSV scores (u8), the bias
-// filter score and the standard Viterbi filter score (an upper bound for every row of the long-target Viterbi scan).
+// filter score, the standard Viterbi filter score (an upper bound for every row of the long-target Viterbi scan), and
+// then the long-target Viterbi scan itself (vit_kernel with per-window row thresholds) for the windows that need it.
 struct DeviceWindowScorer final : LongTargetWindowScorer {
   const p7x_oprofile *om; int device;
+  p7x_seqdb *db = nullptr;
   double ms = 0.0; size_t nwindows = 0;
   DeviceWindowScorer(const p7x_oprofile *o, int d) : om(o), device(d) {}
+  ~DeviceWindowScorer() override { if (db) p7x_seqdb_destroy(db); }
   int score(const uint8_t *seq1, int64_t L, const uint8_t *comp, const LongTargetWindowRef *w, size_t nw, double F1, bool do_bias,
             LongTargetWindowScore *sc) override
   {
@@ -131,12 +134,11 @@ struct DeviceWindowScorer final : LongTargetWindowScorer {
       else for (int64_t r = 0; r < w[q].length; ++r) dsq[pos + (size_t) r] = comp[seq1[w[q].start - r]];
       pos += (size_t) w[q].length + 1;
     }
-    p7x_seqdb *db = nullptr;
+    if (db) { p7x_seqdb_destroy(db); db = nullptr; }
     int st = p7x_seqdb_create(device, p.abc_type, dsq.data(), off.data(), len.data(), nw, &db);
     if (st != P7X_OK) return st;
     std::vector<int32_t> xJ(nw), xC(nw); std::vector<float> bias(nw);
     st = p7x_filters_batch(om, db, xJ.data(), xC.data(), nullptr, do_bias ? bias.data() : nullptr);
-    p7x_seqdb_destroy(db);
     if (st != P7X_OK) return st;
     for (size_t q = 0; q < nw; ++q) {
       const int Lw = len[q];
@@ -153,6 +155,66 @@ struct DeviceWindowScorer final : LongTargetWindowScorer {
     ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     nwindows += nw;
     return P7X_OK;
+  }
+
+  int viterbi(const int *which, const int *thresh, size_t n, std::vector<int> &rec) override
+  {
+    rec.clear();
+    if (n == 0 || !db) return P7X_OK;
+    const auto t0 = std::chrono::steady_clock::now();
+    const Profile &p = om->p;
+    DeviceCtx *ctx = nullptr; DevProfile *dp = nullptr;
+    int st;
+    if ((st = get_ctx(device, &ctx)) != P7X_OK || (st = get_dev_profile(om, ctx, &dp)) != P7X_OK) return st;
+    if (dp->vitC <= 0) { set_error("model too long for the wave-per-target Viterbi kernel"); return P7X_EINVAL; }
+    // caller index -> slot of the window block (slots are sorted by decreasing length)
+    std::vector<int32_t> slot_of((size_t) db->n, -1);
+    for (int64_t sl = 0; sl < db->nslots; ++sl) slot_of[(size_t) db->h_order[(size_t) sl]] = (int32_t) sl;
+    std::vector<int32_t> list(n);
+    for (size_t i = 0; i < n; ++i) list[i] = slot_of[(size_t) which[i]];
+    hipStream_t s = ctx->stream;
+    DevBuf d_list, d_thr, d_xc, d_nrec, d_rec, d_args;
+    if ((st = d_list.alloc(n * 4)) || (st = d_thr.alloc(n * 4)) || (st = d_xc.alloc(n * 4)) || (st = d_nrec.alloc(4)) || (st = d_args.alloc(sizeof(WaveSeqArgs)))) return st;
+    P7X_HIP(hipMemcpyAsync(d_list.p, list.data(), n * 4, hipMemcpyHostToDevice, s));
+    P7X_HIP(hipMemcpyAsync(d_thr.p, thresh, n * 4, hipMemcpyHostToDevice, s));
+    int cap = (int) std::max<size_t>(1 << 16, 64 * n);
+    for (int attempt = 0; attempt < 2; ++attempt) {
+      if ((st = d_rec.alloc((size_t) cap * 12)) != P7X_OK) return st;
+      WaveSeqArgs a{};
+      a.M = p.M; a.C = dp->vitC; a.nrows = p.Kp + 1;
+      a.trans = dp->vit_trans; a.emis = dp->vit_emis;
+      a.dsq = db->d_dsq; a.slot_off = db->d_slot_off; a.slot_len = db->d_slot_len;
+      a.list = static_cast<const int32_t *>(d_list.p); a.nlist = (int) n;
+      a.xwmove_tab = ctx->lt.xwmove; a.base_w = p.base_w; a.xw_e = p.xw[XE][MOVE]; a.ddbound = p.ddbound_w;
+      a.out_xC = static_cast<int32_t *>(d_xc.p);
+      a.lt_thresh = static_cast<const int *>(d_thr.p); a.lt_nrec = static_cast<int *>(d_nrec.p); a.lt_rec = static_cast<int *>(d_rec.p); a.lt_cap = cap;
+      P7X_HIP(hipMemcpyAsync(d_args.p, &a, sizeof(a), hipMemcpyHostToDevice, s));
+      P7X_HIP(hipMemsetAsync(d_nrec.p, 0, 4, s));
+      ArgRun<WaveSeqArgs> run; run.host = &a; run.dev = d_args.p; run.stride = (uint32_t) sizeof(WaveSeqArgs); run.n = 1;
+      if ((st = vit_launch(run, ctx->num_cu, s)) != P7X_OK) return st;
+      int nrec = 0;
+      P7X_HIP(hipMemcpyAsync(&nrec, d_nrec.p, 4, hipMemcpyDeviceToHost, s));
+      P7X_HIP(hipStreamSynchronize(s));
+      if (nrec <= cap) {
+        rec.resize((size_t) nrec * 3);
+        if (nrec) P7X_HIP(hipMemcpy(rec.data(), d_rec.p, (size_t) nrec * 12, hipMemcpyDeviceToHost));
+        // (item, row, node) ascending, as the host scan emits them
+        std::vector<int> ord((size_t) nrec);
+        for (int i = 0; i < nrec; ++i) ord[(size_t) i] = i;
+        std::sort(ord.begin(), ord.end(), [&](int x, int y) {
+          for (int f = 0; f < 3; ++f) if (rec[(size_t) x * 3 + f] != rec[(size_t) y * 3 + f]) return rec[(size_t) x * 3 + f] < rec[(size_t) y * 3 + f];
+          return false;
+        });
+        std::vector<int> sorted((size_t) nrec * 3);
+        for (int i = 0; i < nrec; ++i) for (int f = 0; f < 3; ++f) sorted[(size_t) i * 3 + f] = rec[(size_t) ord[(size_t) i] * 3 + f];
+        rec.swap(sorted);
+        ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+        return P7X_OK;
+      }
+      cap = nrec + 1024;
+    }
+    set_error("long-target Viterbi scan: record buffer could not be sized");
+    return P7X_EMEM;
   }
 };
 

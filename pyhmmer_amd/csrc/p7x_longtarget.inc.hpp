@@ -95,6 +95,14 @@ static float lt_bias_filter(const Profile &p, const uint8_t *dsq, int64_t L)
 
 static inline int16_t sat16(int v) { return (int16_t) std::max(-32768, std::min(32767, v)); }
 
+// the row score that corresponds to P = F2 for a window of length L with bias-adjusted null score <filtersc>
+static int lt_viterbi_threshold(const Profile &p, int64_t L, float filtersc, double F2)
+{
+  const int16_t xw_move = wordify(p.scale_w, logf(3.0f / (float) (L + 3)));
+  const double invP = p.evparam[P7X_VMU] - std::log(-1.0 * std::log(1.0 - F2)) / p.evparam[P7X_VLAMBDA];     // esl_gumbel_invsurv
+  return (int) std::ceil(((filtersc + (float) (kLog2 * invP) + 3.0) * p.scale_w) - (float) p.xw[XE][MOVE] - (float) xw_move + (float) p.base_w);
+}
+
 // p7_ViterbiFilter_longtarget: every row whose best match cell reaches the score that corresponds to P = F2 seeds a
 // window (one per cell that holds that score) and clears the row.  Un-striped; the D->D path is evaluated in full,
 // which gives the same M cells as upstream's lazy-F evaluation.
@@ -103,9 +111,7 @@ static void lt_viterbi_longtarget(const Profile &p, const uint8_t *dsq, int64_t 
   const int M = p.M;
   const int16_t xw_move = wordify(p.scale_w, logf(3.0f / (float) (L + 3)));
   const int16_t xw_e_move = p.xw[XE][MOVE], xw_e_loop = p.xw[XE][LOOP];
-  const double invP = p.evparam[P7X_VMU] - std::log(-1.0 * std::log(1.0 - F2)) / p.evparam[P7X_VLAMBDA];     // esl_gumbel_invsurv
-  const int sc_thresh = (int) std::ceil(((filtersc + (float) (kLog2 * invP) + 3.0) * p.scale_w)
-                                        - (float) xw_e_move - (float) xw_move + (float) p.base_w);
+  const int sc_thresh = lt_viterbi_threshold(p, L, filtersc, F2);
   auto tw = [&](int t, int k) -> int { return p.tw[(size_t) t * (M + 1) + k]; };
   std::vector<int16_t> mm(M + 2, -32768), im(M + 2, -32768), dm(M + 2, -32768), mn(M + 2), in_(M + 2), dn(M + 2);
   const int xN = p.base_w;
@@ -432,34 +438,49 @@ static int lt_post_viterbi(const p7x_pipeline_cfg &cfg, const Profile &p, const 
 // and the standard Viterbi filter score, which bounds every row of the long-target Viterbi scan from above.
 struct LtWindowFilters { bool have = false; float usc = 0.0f, bias_filtersc = 0.0f; bool have_vit = false; float vfsc = 0.0f; };
 
-static int lt_post_ssv(const p7x_pipeline_cfg &cfg, const Profile &p, const LongTargetOpts &lto, const LtScoreData &sd, int max_length,
-                       uint64_t nres_so_far, const LtBlock &blk, const LtTarget &tg, int64_t window_start, int64_t window_len,
-                       std::vector<Hit> &hits, LtCounters &ctr, const LtWindowFilters *wf = nullptr)
+// p7_pli_postSSV_LongTarget up to the Viterbi step: MSV and bias tests of one window.  state: 0 dropped, 1 passes P <= F2
+// already (the whole window goes on), 2 needs the long-target Viterbi scan with score threshold <vit_thresh>.
+struct LtPrefilter { int state = 0; int vit_thresh = 0; float filtersc_f2 = 0.0f; };
+
+static LtPrefilter lt_window_prefilter(const p7x_pipeline_cfg &cfg, const Profile &p, const uint8_t *subseq, int64_t window_len,
+                                       const LtWindowFilters *wf, LtCounters &ctr)
 {
-  const uint8_t *subseq = blk.dsq + window_start - 1;
+  LtPrefilter out;
   const int64_t F1_L = std::min<int64_t>(window_len, cfg.B1), F2_L = std::min<int64_t>(window_len, cfg.B2);
   const float nullsc = lt_null1(window_len);
   // the full MSV score of the window (SSV only seeded it)
   const float usc = (wf && wf->have) ? wf->usc : lt_msv(p, subseq, window_len);
   double P = gumbel_surv((usc - nullsc) / kLog2, p.evparam[P7X_MMU], p.evparam[P7X_MLAMBDA]);
-  if (P > cfg.F1) return P7X_OK;
+  if (P > cfg.F1) return out;
   ctr.n_past_msv++; ctr.pos_past_msv += (uint64_t) window_len;
   float bias_filtersc = 0.0f, filtersc = nullsc;
   if (cfg.do_biasfilter) {
     bias_filtersc = ((wf && wf->have) ? wf->bias_filtersc : lt_bias_filter(p, subseq, window_len)) - nullsc;
     filtersc = nullsc + (bias_filtersc * (F1_L > window_len ? 1.0f : (float) F1_L / (float) window_len));
     P = gumbel_surv((usc - filtersc) / kLog2, p.evparam[P7X_MMU], p.evparam[P7X_MLAMBDA]);
-    if (P > cfg.F1) return P7X_OK;
+    if (P > cfg.F1) return out;
   }
   ctr.n_past_bias++; ctr.pos_past_bias += (uint64_t) window_len;
+  if (!(P > cfg.F2)) { out.state = 1; return out; }
+  if (cfg.do_biasfilter) filtersc = nullsc + (bias_filtersc * (F2_L > window_len ? 1.0f : (float) F2_L / (float) window_len));
+  // The standard Viterbi filter score of the window is at least the score any single row reaches in the long-target
+  // scan (its C state collects every row's E; clearing rows can only lower later ones): a window that fails P <= F2
+  // with it cannot seed a Viterbi window.
+  if (wf && wf->have_vit && gumbel_surv((wf->vfsc - filtersc) / kLog2, p.evparam[P7X_VMU], p.evparam[P7X_VLAMBDA]) > cfg.F2) return out;
+  out.state = 2; out.filtersc_f2 = filtersc; out.vit_thresh = lt_viterbi_threshold(p, window_len, filtersc, cfg.F2);
+  return out;
+}
+
+// the rest of p7_pli_postSSV_LongTarget for a window that passed: its Viterbi windows (given, or scanned here) through
+// Forward, Backward, domain definition
+static int lt_window_finish(const p7x_pipeline_cfg &cfg, const Profile &p, const LongTargetOpts &lto, const LtScoreData &sd, int max_length,
+                            uint64_t nres_so_far, const LtBlock &blk, const LtTarget &tg, int64_t window_start, int64_t window_len,
+                            const LtPrefilter &pf, const std::vector<LtWindow> *vit_seeds, std::vector<Hit> &hits, LtCounters &ctr)
+{
+  const uint8_t *subseq = blk.dsq + window_start - 1;
   std::vector<LtWindow> vit;
-  if (P > cfg.F2) {
-    if (cfg.do_biasfilter) filtersc = nullsc + (bias_filtersc * (F2_L > window_len ? 1.0f : (float) F2_L / (float) window_len));
-    // The standard Viterbi filter score of the window is at least the score any single row reaches in the long-target
-    // scan (its C state collects every row's E; clearing rows can only lower later ones): a window that fails P <= F2
-    // with it cannot seed a Viterbi window, and the scan is skipped.
-    if (wf && wf->have_vit && gumbel_surv((wf->vfsc - filtersc) / kLog2, p.evparam[P7X_VMU], p.evparam[P7X_VLAMBDA]) > cfg.F2) return P7X_OK;
-    lt_viterbi_longtarget(p, subseq, window_len, filtersc, cfg.F2, vit);
+  if (pf.state == 2) {
+    if (vit_seeds) vit = *vit_seeds; else lt_viterbi_longtarget(p, subseq, window_len, pf.filtersc_f2, cfg.F2, vit);
     lt_extend_and_merge(sd, max_length, window_len, 0.5f, vit);
   } else vit.push_back(LtWindow{ 1, 0, window_len });
   for (const LtWindow &w : vit) {
@@ -488,25 +509,27 @@ static void lt_block_windows(const LtScoreData &sd, int max_length, int64_t bloc
   }
 }
 
-// second half: every window through the rest of the pipeline (the windows are independent: spread over the host workers,
-// hits kept in window order)
+// second half: every window that passed the prefilter through the rest of the pipeline (the windows are independent:
+// spread over the host workers, hits kept in window order).  vit_seeds[w]: the window's long-target Viterbi records when
+// they were found on the device.
 static int lt_block_run(const p7x_pipeline_cfg &cfg, const Profile &p, const LongTargetOpts &lto, const LtScoreData &sd, int max_length,
                         uint64_t nres_so_far, const LtBlock &blk, const LtTarget &tg, const std::vector<LtWindow> &windows,
-                        const LtWindowFilters *wf, std::vector<Hit> &hits, LtCounters &ctr)
+                        const LtPrefilter *pf, const std::vector<LtWindow> *vit_seeds, std::vector<Hit> &hits, LtCounters &ctr)
 {
   std::vector<std::vector<Hit>> wh(windows.size());
   std::vector<LtCounters> wc(windows.size());
   std::vector<int> wst(windows.size(), P7X_OK);
   host_parallel_for((int) windows.size(), cfg.host_threads, [&](int i) {
+    if (pf[i].state == 0) return;
     flogsum_init();
-    wst[(size_t) i] = lt_post_ssv(cfg, p, lto, sd, max_length, nres_so_far, blk, tg, windows[(size_t) i].n, windows[(size_t) i].length,
-                                  wh[(size_t) i], wc[(size_t) i], wf ? wf + i : nullptr);
+    wst[(size_t) i] = lt_window_finish(cfg, p, lto, sd, max_length, nres_so_far, blk, tg, windows[(size_t) i].n, windows[(size_t) i].length,
+                                       pf[i], vit_seeds ? vit_seeds + i : nullptr, wh[(size_t) i], wc[(size_t) i]);
   });
   for (size_t i = 0; i < windows.size(); ++i) {
     if (wst[i] != P7X_OK) return wst[i];
     for (Hit &h : wh[i]) hits.push_back(std::move(h));
-    ctr.n_past_msv += wc[i].n_past_msv; ctr.n_past_bias += wc[i].n_past_bias; ctr.n_past_vit += wc[i].n_past_vit; ctr.n_past_fwd += wc[i].n_past_fwd;
-    ctr.pos_past_msv += wc[i].pos_past_msv; ctr.pos_past_bias += wc[i].pos_past_bias; ctr.pos_past_vit += wc[i].pos_past_vit; ctr.pos_past_fwd += wc[i].pos_past_fwd;
+    ctr.n_past_vit += wc[i].n_past_vit; ctr.n_past_fwd += wc[i].n_past_fwd;
+    ctr.pos_past_vit += wc[i].pos_past_vit; ctr.pos_past_fwd += wc[i].pos_past_fwd;
   }
   return P7X_OK;
 }
@@ -638,8 +661,9 @@ static int lt_run_host(const p7x_pipeline_cfg &cfg, const p7x_oprofile *om, cons
     }
     // the windows' filter scores, one device batch per target
     std::vector<LtWindowFilters> wf;
+    std::vector<LongTargetWindowRef> refs;
     if (filters && nwin > 0) {
-      std::vector<LongTargetWindowRef> refs; refs.reserve(nwin);
+      refs.reserve(nwin);
       for (const BlockJob &job : jobs)
         for (const LtWindow &w : job.windows) {
           // original coordinates of the window's first residue on its strand and its length
@@ -653,14 +677,54 @@ static int lt_run_host(const p7x_pipeline_cfg &cfg, const p7x_oprofile *om, cons
       wf.resize(nwin);
       for (size_t q = 0; q < nwin; ++q) { wf[q].have = true; wf[q].usc = sc[q].usc; wf[q].bias_filtersc = sc[q].bias_filtersc; wf[q].have_vit = sc[q].have_vit != 0; wf[q].vfsc = sc[q].vfsc; }
     }
+    // MSV / bias tests of every window (with the device's scores these are a few flops each; without, the host filters
+    // run here, in parallel)
+    std::vector<LtPrefilter> pf(nwin);
+    {
+      std::vector<std::pair<const BlockJob *, size_t>> flat; flat.reserve(nwin);
+      for (const BlockJob &job : jobs) for (size_t w = 0; w < job.windows.size(); ++w) flat.emplace_back(&job, w);
+      std::vector<LtCounters> pc(nwin);
+      host_parallel_for((int) nwin, wf.empty() ? cfg.host_threads : 1, [&](int q) {
+        const BlockJob &job = *flat[(size_t) q].first; const LtWindow &w = job.windows[flat[(size_t) q].second];
+        std::vector<uint8_t> sub;
+        const uint8_t *subseq = nullptr;
+        if (wf.empty()) {            // host filters need the residues
+          sub.assign((size_t) w.length + 2, 255);
+          for (int64_t r = 1; r <= w.length; ++r) {
+            const int64_t bp = w.n + r - 1;        // block position
+            sub[(size_t) r] = job.strand == 0 ? seq[job.i + bp] : comp[seq[job.i + job.bn - bp + 1]];
+          }
+          subseq = sub.data();
+        }
+        pf[(size_t) q] = lt_window_prefilter(cfg, p, subseq, w.length, wf.empty() ? nullptr : &wf[(size_t) q], pc[(size_t) q]);
+      });
+      for (const LtCounters &c : pc) { ctr.n_past_msv += c.n_past_msv; ctr.n_past_bias += c.n_past_bias; ctr.pos_past_msv += c.pos_past_msv; ctr.pos_past_bias += c.pos_past_bias; }
+    }
+    // long-target Viterbi scan of the windows that need it, on the device when there is one
+    std::vector<std::vector<LtWindow>> vit_seeds;
+    if (filters && nwin > 0) {
+      std::vector<int> need; std::vector<int> thr;
+      for (size_t q = 0; q < nwin; ++q) if (pf[q].state == 2) { need.push_back((int) q); thr.push_back(pf[q].vit_thresh); }
+      vit_seeds.resize(nwin);
+      if (!need.empty()) {
+        std::vector<int> rec;            // (index into need, row, node) triples, sorted
+        const int st = filters->viterbi(need.data(), thr.data(), need.size(), rec);
+        if (st != P7X_OK) return st;
+        for (size_t r = 0; r + 2 < rec.size(); r += 3) vit_seeds[(size_t) need[(size_t) rec[r]]].push_back(LtWindow{ rec[r + 1], rec[r + 2], 1 });
+      }
+    }
     // pass 2: the rest of the pipeline, block by block
     std::vector<uint8_t> buf;
     for (const BlockJob &job : jobs) {
+      bool any = false;
+      for (size_t w = 0; w < job.windows.size(); ++w) any = any || pf[job.first_window + w].state != 0;
+      if (!any) continue;
       buf.assign((size_t) job.bn + 2, 255);
       if (job.strand == 0) std::memcpy(buf.data() + 1, seq + job.i + 1, (size_t) job.bn);
       else for (int64_t q = 1; q <= job.bn; ++q) buf[(size_t) q] = comp[seq[job.i + job.bn - q + 1]];
       LtBlock blk{ buf.data(), job.bn, job.strand == 0 ? job.i + 1 : job.i + job.bn, job.strand == 1 };
-      const int st = lt_block_run(cfg, p, lto, sd, max_length, job.nres_at, blk, tg, job.windows, wf.empty() ? nullptr : wf.data() + job.first_window, hits, ctr);
+      const int st = lt_block_run(cfg, p, lto, sd, max_length, job.nres_at, blk, tg, job.windows, pf.data() + job.first_window,
+                                  vit_seeds.empty() ? nullptr : vit_seeds.data() + job.first_window, hits, ctr);
       if (st != P7X_OK) return st;
     }
   }

@@ -49,6 +49,7 @@ __global__ void __launch_bounds__(kWsBlock) vit_kernel(const ArgRef ref)
     for (int c = 0; c < C; ++c) { mm[c] = im[c] = dm[c] = NEG; tdd[c] = NEG; }
     int xN = a.base_w, xB = xN + xwm, xJ = -32768, xC = -32768;
     bool overflow = false;
+    const int lt_thr = a.lt_thresh ? rfl(a.lt_thresh[it]) : INT_MAX;
 
     for (int i0 = 0; i0 < L && !overflow; i0 += 64) {
       const int nrow = min(64, L - i0);
@@ -81,6 +82,20 @@ __global__ void __launch_bounds__(kWsBlock) vit_kernel(const ArgRef ref)
         dm[0] = (short) dpp_shr1(dcarry, NEG);
 
         const int xE = wave_max_i32((int) rowmax);
+        if (xE >= lt_thr) {
+          // long-target scan: every match cell that holds the row maximum seeds a window; the rows start afresh and the
+          // special states keep their values (upstream p7_ViterbiFilter_longtarget)
+#pragma unroll
+          for (int c = 0; c < C; ++c) {
+            const int k = lane * C + c + 1;
+            if ((int) mm[c] == xE && k <= a.M) {
+              const int slot = atomicAdd(a.lt_nrec, 1);
+              if (slot < a.lt_cap) { a.lt_rec[3 * slot] = it; a.lt_rec[3 * slot + 1] = i0 + r + 1; a.lt_rec[3 * slot + 2] = k; }
+            }
+            mm[c] = im[c] = dm[c] = NEG;
+          }
+          continue;
+        }
         if (xE >= 32767) overflow = true;
         xC = max(xC, xE + a.xw_e);              // xw[C][LOOP] = xw[J][LOOP] = xw[N][LOOP] = 0
         xJ = max(xJ, xE + a.xw_e);

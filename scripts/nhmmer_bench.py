@@ -32,4 +32,4 @@ for it in range(2):
     cells = 2.0 * L * hmm.M
     print(f"run {it}: {mbp:g} Mbp x 2 strands x M={hmm.M}: SSV scan kernels {scan_ms:.2f} ms = {cells / scan_ms / 1e6:.0f} GCUPS; "
           f"whole search {dt:.2f} s = {cells / dt / 1e9:.0f} GCUPS; windows past msv/bias/vit/fwd {hits.stage_counts}, "
-          f"hits {len(hits)} reported {len(hits.reported)} (planted {planted})", flush=True)
+          f"hits {len(hits)} reported {len(hits.reported)} (planted {planted}); ms: scan+seeds wall {hits.timings_ms['msv']:.0f}, window batch on device {hits.timings_ms['bias']:.0f}, host tail {hits.timings_ms['host_domaindef']:.0f}", flush=True)
