@@ -144,6 +144,8 @@ struct LongTargetWindowScorer {
   // p7_ViterbiFilter_longtarget over windows which[0..n) of the last score() call, window i with row-score threshold
   // thresh[i]: rec receives (i, row, node) for every seeding cell, sorted by (i, row, node)
   virtual int viterbi(const int *which, const int *thresh, size_t n, std::vector<int> &rec) = 0;
+  // p7_ForwardParser scores (nats) of another set of windows of the same target (the Viterbi windows)
+  virtual int forward(const uint8_t *seq1, const uint8_t *comp, const LongTargetWindowRef *w, size_t nw, float *fwdsc) = 0;
 };
 int longtarget_run_host(const p7x_pipeline_cfg &cfg, const p7x_oprofile *om, const uint8_t *dsq, const int64_t *offsets, const int64_t *lengths,
                         size_t n, const char *const *names, const char *const *accs, const char *const *descs,

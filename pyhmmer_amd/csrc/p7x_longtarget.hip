@@ -7,6 +7,8 @@
 #include "p7x_host.hpp"
 #include <algorithm>
 #include <chrono>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <memory>
 
@@ -157,6 +159,36 @@ struct DeviceWindowScorer final : LongTargetWindowScorer {
     return P7X_OK;
   }
 
+  static void pack_windows(const uint8_t *seq1, const uint8_t *comp, const LongTargetWindowRef *w, size_t nw, std::vector<uint8_t> &dsq,
+                           std::vector<int64_t> &off, std::vector<int32_t> &len)
+  {
+    size_t tot = 1;
+    for (size_t q = 0; q < nw; ++q) tot += (size_t) w[q].length + 1;
+    dsq.assign(tot, 255); off.resize(nw); len.resize(nw);
+    size_t pos = 1;
+    for (size_t q = 0; q < nw; ++q) {
+      off[q] = (int64_t) pos; len[q] = (int32_t) w[q].length;
+      if (w[q].strand == 0) std::memcpy(dsq.data() + pos, seq1 + w[q].start, (size_t) w[q].length);
+      else for (int64_t r = 0; r < w[q].length; ++r) dsq[pos + (size_t) r] = comp[seq1[w[q].start - r]];
+      pos += (size_t) w[q].length + 1;
+    }
+  }
+
+  int forward(const uint8_t *seq1, const uint8_t *comp, const LongTargetWindowRef *w, size_t nw, float *fwdsc) override
+  {
+    if (nw == 0) return P7X_OK;
+    const auto t0 = std::chrono::steady_clock::now();
+    std::vector<uint8_t> dsq; std::vector<int64_t> off; std::vector<int32_t> len;
+    pack_windows(seq1, comp, w, nw, dsq, off, len);
+    p7x_seqdb *fdb = nullptr;
+    int st = p7x_seqdb_create(device, om->p.abc_type, dsq.data(), off.data(), len.data(), nw, &fdb);
+    if (st != P7X_OK) return st;
+    st = p7x_filters_batch(om, fdb, nullptr, nullptr, fwdsc, nullptr);
+    p7x_seqdb_destroy(fdb);
+    ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    return st;
+  }
+
   int viterbi(const int *which, const int *thresh, size_t n, std::vector<int> &rec) override
   {
     rec.clear();
@@ -248,8 +280,10 @@ int p7x_search_longtargets(const p7x_pipeline_cfg *cfg, const p7x_oprofile *om, 
     const uint8_t *seq1 = dsq + offsets[t] - 1;
     std::vector<ScanRow> rows;
     double ms = 0.0;
+    const auto ts0 = std::chrono::steady_clock::now();
     if ((st = scan_target(*cfg, p, ctx, seq1, Lt, sc_thresh, xB, mask, rows, &ms)) != P7X_OK) return st;
     scan_ms += ms;
+    const auto ts1 = std::chrono::steady_clock::now();
     for (int64_t i = 0; i < Lt; i += W - C) {
       const int64_t bc = i == 0 ? 0 : std::min<int64_t>(C, Lt - i);
       const int64_t bw = std::min<int64_t>(W, Lt - i - bc);
@@ -263,6 +297,10 @@ int p7x_search_longtargets(const p7x_pipeline_cfg *cfg, const p7x_oprofile *om, 
       }
       if (i + bn >= Lt) break;
     }
+    if (std::getenv("P7X_LT_DEBUG"))
+      std::fprintf(stderr, "[lt] target %zu: scan call %.1f ms (kernel %.1f), %zu rows, seeds so far %zu, seed bookkeeping %.1f ms\n", t,
+                   std::chrono::duration<double, std::milli>(ts1 - ts0).count(), ms, rows.size(), seeds.size(),
+                   std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - ts1).count());
   }
   const auto t_host = std::chrono::steady_clock::now();
   DeviceWindowScorer scorer(om, device);

@@ -312,26 +312,29 @@ static void lt_seeds_from_rows(const Profile &p, const uint8_t *dsq, int64_t L, 
                                std::vector<LtWindow> &seeds)
 {
   const int M = p.M;
-  int64_t prev_end = 0;          // last row of the previous seed's diagonal (the scan restarted behind it); 0: block start
+  // The scan restarts (all cells at the begin score) behind every seed and at the block start; rows up to M behind a
+  // restart are its "shadow": a diagonal through them may have begun before the restart, so the reset-free scores of the
+  // device do not apply there.  Outside shadows they are upstream's.
+  int64_t restart = 0;             // the scan restarted at row restart + 1
+  bool shadow = true;              // rows restart + 1 .. restart + M still have to be looked at
+  int64_t skip_to = 0;             // rows up to here are behind us (consumed by a seed's diagonal, or replayed)
   size_t idx = 0;
   while (idx < rows.size()) {
     const LtRow &r = rows[idx];
-    if (r.pos <= prev_end) { ++idx; continue; }                 // skipped by upstream's jump behind the previous seed
+    if (r.pos <= skip_to) { ++idx; continue; }
     int64_t row = r.pos; int k = r.k, sc = r.sc;
-    if (r.pos - prev_end <= M) {
-      // diagonals of this row may have started before the restart: replay the scan from there to the first true crossing
-      const int64_t to = std::min<int64_t>(L, prev_end + M);
-      if (!lt_replay(p, dsq, prev_end + 1, to, sc_thresh, xB, &row, &k, &sc)) {
-        while (idx < rows.size() && rows[idx].pos <= to) ++idx;
-        prev_end = to;              // beyond the shadow the reported rows are exact again
-        // (rows after <to> no longer depend on the restart: treat <to> as a restart that changed nothing)
-        continue;
-      }
+    if (shadow && r.pos <= restart + M) {
+      // replay the scan from the restart; a true crossing can only be at a row the device reported, so the replay ends at
+      // the last reported row inside the shadow
+      int64_t to = r.pos;
+      for (size_t j = idx; j < rows.size() && rows[j].pos <= restart + M; ++j) to = rows[j].pos;
+      to = std::min(to, L);
+      if (!lt_replay(p, dsq, restart + 1, to, sc_thresh, xB, &row, &k, &sc)) { skip_to = to; shadow = false; continue; }
     }
     LtWindow w;
-    prev_end = lt_seed_from_cell(p, dsq, L, row, k, sc, xB, &w);
+    const int64_t end = lt_seed_from_cell(p, dsq, L, row, k, sc, xB, &w);
     seeds.push_back(w);
-    while (idx < rows.size() && rows[idx].pos <= prev_end) ++idx;
+    restart = end; shadow = true; skip_to = end;
   }
 }
 
@@ -347,11 +350,13 @@ struct LtBlock {                 // one block of one strand, as p7_Pipeline_Long
 
 struct LtCounters { uint64_t n_past_msv = 0, n_past_bias = 0, n_past_vit = 0, n_past_fwd = 0, pos_past_msv = 0, pos_past_bias = 0, pos_past_vit = 0, pos_past_fwd = 0; };
 
+// blk.dsq is not used here: <subseq>[1..window_len] are the window's residues; blk.start / blk.complement and
+// window_start (the window's first residue in the block) map coordinates back to the target.  fwd_given: the window's
+// Forward parser score when it was computed elsewhere (the device batch).
 static int lt_post_viterbi(const p7x_pipeline_cfg &cfg, const Profile &p, const LongTargetOpts &lto, int max_length, uint64_t nres_so_far,
-                           const LtBlock &blk, const LtTarget &tg, int64_t window_start, int64_t window_len,
-                           std::vector<Hit> &hits, LtCounters &ctr)
+                           const LtBlock &blk, const LtTarget &tg, int64_t window_start, int64_t window_len, const uint8_t *subseq,
+                           const float *fwd_given, std::vector<Hit> &hits, LtCounters &ctr)
 {
-  const uint8_t *subseq = blk.dsq + window_start - 1;         // subseq[1..window_len]
   const int64_t F3_L = std::min<int64_t>(window_len, cfg.B3);
   const float nullsc = lt_null1(window_len);
   float filtersc = nullsc;
@@ -365,7 +370,7 @@ static int lt_post_viterbi(const p7x_pipeline_cfg &cfg, const Profile &p, const 
   om.configure(true, (int) window_len);
   std::vector<float> fx, bx;
   float fwdsc = 0.0f;
-  lt_forward_parser(om, subseq, (int) window_len, fx, &fwdsc);
+  if (fwd_given) fwdsc = *fwd_given; else lt_forward_parser(om, subseq, (int) window_len, fx, &fwdsc);
   const float seq_score = (fwdsc - filtersc) / (float) kLog2;
   const double P = exp_surv(seq_score, p.evparam[P7X_FTAU], p.evparam[P7X_FLAMBDA]);
   if (P > cfg.F3) return P7X_OK;
@@ -471,26 +476,6 @@ static LtPrefilter lt_window_prefilter(const p7x_pipeline_cfg &cfg, const Profil
   return out;
 }
 
-// the rest of p7_pli_postSSV_LongTarget for a window that passed: its Viterbi windows (given, or scanned here) through
-// Forward, Backward, domain definition
-static int lt_window_finish(const p7x_pipeline_cfg &cfg, const Profile &p, const LongTargetOpts &lto, const LtScoreData &sd, int max_length,
-                            uint64_t nres_so_far, const LtBlock &blk, const LtTarget &tg, int64_t window_start, int64_t window_len,
-                            const LtPrefilter &pf, const std::vector<LtWindow> *vit_seeds, std::vector<Hit> &hits, LtCounters &ctr)
-{
-  const uint8_t *subseq = blk.dsq + window_start - 1;
-  std::vector<LtWindow> vit;
-  if (pf.state == 2) {
-    if (vit_seeds) vit = *vit_seeds; else lt_viterbi_longtarget(p, subseq, window_len, pf.filtersc_f2, cfg.F2, vit);
-    lt_extend_and_merge(sd, max_length, window_len, 0.5f, vit);
-  } else vit.push_back(LtWindow{ 1, 0, window_len });
-  for (const LtWindow &w : vit) {
-    ctr.n_past_vit++; ctr.pos_past_vit += (uint64_t) w.length;
-    const int st = lt_post_viterbi(cfg, p, lto, max_length, nres_so_far, blk, tg, window_start + w.n - 1, w.length, hits, ctr);
-    if (st != P7X_OK) return st;
-  }
-  return P7X_OK;
-}
-
 // p7_Pipeline_LongTarget behind the SSV scan, first half: the seeds of one block of one strand become its windows
 static void lt_block_windows(const LtScoreData &sd, int max_length, int64_t block_len, std::vector<LtWindow> seeds, std::vector<LtWindow> &windows)
 {
@@ -507,31 +492,6 @@ static void lt_block_windows(const LtScoreData &sd, int max_length, int64_t bloc
       if (off + len >= w.length) break;
     }
   }
-}
-
-// second half: every window that passed the prefilter through the rest of the pipeline (the windows are independent:
-// spread over the host workers, hits kept in window order).  vit_seeds[w]: the window's long-target Viterbi records when
-// they were found on the device.
-static int lt_block_run(const p7x_pipeline_cfg &cfg, const Profile &p, const LongTargetOpts &lto, const LtScoreData &sd, int max_length,
-                        uint64_t nres_so_far, const LtBlock &blk, const LtTarget &tg, const std::vector<LtWindow> &windows,
-                        const LtPrefilter *pf, const std::vector<LtWindow> *vit_seeds, std::vector<Hit> &hits, LtCounters &ctr)
-{
-  std::vector<std::vector<Hit>> wh(windows.size());
-  std::vector<LtCounters> wc(windows.size());
-  std::vector<int> wst(windows.size(), P7X_OK);
-  host_parallel_for((int) windows.size(), cfg.host_threads, [&](int i) {
-    if (pf[i].state == 0) return;
-    flogsum_init();
-    wst[(size_t) i] = lt_window_finish(cfg, p, lto, sd, max_length, nres_so_far, blk, tg, windows[(size_t) i].n, windows[(size_t) i].length,
-                                       pf[i], vit_seeds ? vit_seeds + i : nullptr, wh[(size_t) i], wc[(size_t) i]);
-  });
-  for (size_t i = 0; i < windows.size(); ++i) {
-    if (wst[i] != P7X_OK) return wst[i];
-    for (Hit &h : wh[i]) hits.push_back(std::move(h));
-    ctr.n_past_vit += wc[i].n_past_vit; ctr.n_past_fwd += wc[i].n_past_fwd;
-    ctr.pos_past_vit += wc[i].pos_past_vit; ctr.pos_past_fwd += wc[i].pos_past_fwd;
-  }
-  return P7X_OK;
 }
 
 // ---------------------------------------------------------------- hit list: E-values, duplicates
@@ -681,11 +641,11 @@ static int lt_run_host(const p7x_pipeline_cfg &cfg, const p7x_oprofile *om, cons
     // run here, in parallel)
     std::vector<LtPrefilter> pf(nwin);
     {
-      std::vector<std::pair<const BlockJob *, size_t>> flat; flat.reserve(nwin);
-      for (const BlockJob &job : jobs) for (size_t w = 0; w < job.windows.size(); ++w) flat.emplace_back(&job, w);
+      std::vector<std::pair<const BlockJob *, size_t>> flat0; flat0.reserve(nwin);
+      for (const BlockJob &job : jobs) for (size_t w = 0; w < job.windows.size(); ++w) flat0.emplace_back(&job, w);
       std::vector<LtCounters> pc(nwin);
       host_parallel_for((int) nwin, wf.empty() ? cfg.host_threads : 1, [&](int q) {
-        const BlockJob &job = *flat[(size_t) q].first; const LtWindow &w = job.windows[flat[(size_t) q].second];
+        const BlockJob &job = *flat0[(size_t) q].first; const LtWindow &w = job.windows[flat0[(size_t) q].second];
         std::vector<uint8_t> sub;
         const uint8_t *subseq = nullptr;
         if (wf.empty()) {            // host filters need the residues
@@ -700,32 +660,77 @@ static int lt_run_host(const p7x_pipeline_cfg &cfg, const p7x_oprofile *om, cons
       });
       for (const LtCounters &c : pc) { ctr.n_past_msv += c.n_past_msv; ctr.n_past_bias += c.n_past_bias; ctr.pos_past_msv += c.pos_past_msv; ctr.pos_past_bias += c.pos_past_bias; }
     }
-    // long-target Viterbi scan of the windows that need it, on the device when there is one
-    std::vector<std::vector<LtWindow>> vit_seeds;
-    if (filters && nwin > 0) {
+    // residues of a stretch of a block on its strand: out[1..len], sentinels around
+    auto fetch = [&](const BlockJob &job, int64_t first_block_pos, int64_t len, std::vector<uint8_t> &outv) {
+      outv.assign((size_t) len + 2, 255);
+      if (job.strand == 0) std::memcpy(outv.data() + 1, seq + job.i + first_block_pos, (size_t) len);
+      else for (int64_t r = 0; r < len; ++r) outv[(size_t) r + 1] = comp[seq[job.i + job.bn - (first_block_pos + r) + 1]];
+    };
+    std::vector<std::pair<const BlockJob *, size_t>> flat; flat.reserve(nwin);
+    for (const BlockJob &job : jobs) for (size_t w = 0; w < job.windows.size(); ++w) flat.emplace_back(&job, w);
+    // long-target Viterbi scan of the windows that need it: on the device when there is one, else on the host workers
+    std::vector<std::vector<LtWindow>> vit_of(nwin);
+    {
       std::vector<int> need; std::vector<int> thr;
       for (size_t q = 0; q < nwin; ++q) if (pf[q].state == 2) { need.push_back((int) q); thr.push_back(pf[q].vit_thresh); }
-      vit_seeds.resize(nwin);
-      if (!need.empty()) {
+      if (filters && !need.empty()) {
         std::vector<int> rec;            // (index into need, row, node) triples, sorted
         const int st = filters->viterbi(need.data(), thr.data(), need.size(), rec);
         if (st != P7X_OK) return st;
-        for (size_t r = 0; r + 2 < rec.size(); r += 3) vit_seeds[(size_t) need[(size_t) rec[r]]].push_back(LtWindow{ rec[r + 1], rec[r + 2], 1 });
+        for (size_t r = 0; r + 2 < rec.size(); r += 3) vit_of[(size_t) need[(size_t) rec[r]]].push_back(LtWindow{ rec[r + 1], rec[r + 2], 1 });
+      } else if (!need.empty()) {
+        host_parallel_for((int) need.size(), cfg.host_threads, [&](int z) {
+          const size_t q = (size_t) need[(size_t) z];
+          const BlockJob &job = *flat[q].first; const LtWindow &w = job.windows[flat[q].second];
+          std::vector<uint8_t> sub;
+          fetch(job, w.n, w.length, sub);
+          lt_viterbi_longtarget(p, sub.data(), w.length, pf[q].filtersc_f2, cfg.F2, vit_of[q]);
+        });
+      }
+      for (size_t q = 0; q < nwin; ++q) {
+        const LtWindow &w = flat[q].first->windows[flat[q].second];
+        if (pf[q].state == 2) lt_extend_and_merge(sd, max_length, w.length, 0.5f, vit_of[q]);
+        else if (pf[q].state == 1) vit_of[q].assign(1, LtWindow{ 1, 0, w.length });
       }
     }
-    // pass 2: the rest of the pipeline, block by block
-    std::vector<uint8_t> buf;
-    for (const BlockJob &job : jobs) {
-      bool any = false;
-      for (size_t w = 0; w < job.windows.size(); ++w) any = any || pf[job.first_window + w].state != 0;
-      if (!any) continue;
-      buf.assign((size_t) job.bn + 2, 255);
-      if (job.strand == 0) std::memcpy(buf.data() + 1, seq + job.i + 1, (size_t) job.bn);
-      else for (int64_t q = 1; q <= job.bn; ++q) buf[(size_t) q] = comp[seq[job.i + job.bn - q + 1]];
-      LtBlock blk{ buf.data(), job.bn, job.strand == 0 ? job.i + 1 : job.i + job.bn, job.strand == 1 };
-      const int st = lt_block_run(cfg, p, lto, sd, max_length, job.nres_at, blk, tg, job.windows, pf.data() + job.first_window,
-                                  vit_seeds.empty() ? nullptr : vit_seeds.data() + job.first_window, hits, ctr);
+    // every Viterbi window: Forward (one device batch when there is a device), then Backward / domain definition for
+    // the few that pass, on the host workers; hits stay in window order
+    struct VitJob { size_t q; LtWindow vw; };
+    std::vector<VitJob> vj;
+    for (size_t q = 0; q < nwin; ++q) for (const LtWindow &vw : vit_of[q]) vj.push_back(VitJob{ q, vw });
+    std::vector<float> fwd_dev;
+    if (filters && !vj.empty()) {
+      std::vector<LongTargetWindowRef> vrefs(vj.size());
+      for (size_t z = 0; z < vj.size(); ++z) {
+        const BlockJob &job = *flat[vj[z].q].first; const LtWindow &w = job.windows[flat[vj[z].q].second];
+        const int64_t bp = w.n + vj[z].vw.n - 1;                // block position of the Viterbi window's first residue
+        vrefs[z].strand = job.strand; vrefs[z].length = vj[z].vw.length;
+        vrefs[z].start = job.strand == 0 ? job.i + bp : job.i + job.bn - bp + 1;
+      }
+      fwd_dev.resize(vj.size());
+      const int st = filters->forward(seq, comp, vrefs.data(), vrefs.size(), fwd_dev.data());
       if (st != P7X_OK) return st;
+    }
+    std::vector<std::vector<Hit>> jh(vj.size());
+    std::vector<LtCounters> jc(vj.size());
+    std::vector<int> jst(vj.size(), P7X_OK);
+    host_parallel_for((int) vj.size(), cfg.host_threads, [&](int z) {
+      flogsum_init();
+      const BlockJob &job = *flat[vj[(size_t) z].q].first; const LtWindow &w = job.windows[flat[vj[(size_t) z].q].second];
+      const LtWindow &vw = vj[(size_t) z].vw;
+      const int64_t bp = w.n + vw.n - 1;
+      std::vector<uint8_t> sub;
+      fetch(job, bp, vw.length, sub);
+      LtBlock blk{ nullptr, job.bn, job.strand == 0 ? job.i + 1 : job.i + job.bn, job.strand == 1 };
+      jc[(size_t) z].n_past_vit++; jc[(size_t) z].pos_past_vit += (uint64_t) vw.length;
+      jst[(size_t) z] = lt_post_viterbi(cfg, p, lto, max_length, job.nres_at, blk, tg, bp, vw.length, sub.data(),
+                                        fwd_dev.empty() ? nullptr : &fwd_dev[(size_t) z], jh[(size_t) z], jc[(size_t) z]);
+    });
+    for (size_t z = 0; z < vj.size(); ++z) {
+      if (jst[z] != P7X_OK) return jst[z];
+      for (Hit &h : jh[z]) hits.push_back(std::move(h));
+      ctr.n_past_vit += jc[z].n_past_vit; ctr.n_past_fwd += jc[z].n_past_fwd;
+      ctr.pos_past_vit += jc[z].pos_past_vit; ctr.pos_past_fwd += jc[z].pos_past_fwd;
     }
   }
   lt_finish_tophits(cfg, p, max_length, nres, (uint64_t) n, ctr, hits, out);
