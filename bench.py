@@ -273,6 +273,58 @@ def run_pfam(args, rank, world, local_rank, dist, red_dev, torch, host_threads):
     }
 
 
+def run_nhmmer(args, rank, world, local_rank, dist, red_dev, torch):
+    """BASELINE configs[4]: nhmmer long-target, one DNA profile (fixture bmyD, M = 1203) against a synthetic chromosome
+    per GPU (weak scaling: every rank searches a chromosome of its own, both strands), the whole search timed:
+    SSV scan + window filters + Viterbi scan + Forward on the device, seed bookkeeping / Backward / domain definition
+    on the host."""
+    import bench_workloads as bw
+    from pyhmmer_amd import easel, plan7
+    with plan7.HMMFile(ROOT / "tests" / "golden" / "hmms" / "bmyD.hmm") as hf:
+        hmm = next(iter(hf))
+    L = int(args.nhmmer_mbp * 1e6)
+    seq = bw.make_chromosome(hmm, L, planted=50, seed=45 + rank)
+    block = easel.DigitalSequenceBlock(hmm.alphabet, [easel.DigitalSequence(hmm.alphabet, name=f"chrSyn{rank}", sequence=seq)])
+    pli = plan7.LongTargetsPipeline(hmm.alphabet, device=local_rank)
+    pli.search_hmm(hmm, block)                                   # warm-up: tables, workspaces
+    n = max(1, args.nhmmer_searches)
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    scan_ms = 0.0
+    for _ in range(n):
+        hits = pli.search_hmm(hmm, block)
+        scan_ms += hits.timings_ms["msv_kernel"]
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    cells = 2.0 * L * hmm.M
+    tot = cells
+    if dist is not None:
+        b = torch.tensor([dt], dtype=torch.float64, device=red_dev)
+        dist.all_reduce(b, op=dist.ReduceOp.MAX)
+        dt = float(b.item())
+        c = torch.tensor([cells], dtype=torch.float64, device=red_dev)
+        dist.all_reduce(c, op=dist.ReduceOp.SUM)
+        tot = float(c.item())
+    if rank != 0:
+        return None
+    sc = hits.stage_counts
+    return {
+        "workload": f"configs[4]: nhmmer, profile {hmm.name} (M={hmm.M}) vs one synthetic {args.nhmmer_mbp:g} Mbp chromosome per GPU "
+                    "(i.i.d. ACGT + 50 planted mutated consensus stretches), both strands, block_length 262144",
+        "value": round(tot * n / dt / 1e9, 1), "unit": "GCUPS", "searches": n, "s_per_search": round(dt / n, 4),
+        "mbp_per_s": round(2.0 * L * world * n / dt / 1e6, 1),
+        "ssv_scan_kernel_ms": round(scan_ms / n, 3), "ssv_scan_gcups": round(cells / (scan_ms / n * 1e-3) / 1e9, 1),
+        "windows": {"past_ssv": sc["msv"], "past_bias": sc["bias"], "past_vit": sc["vit"], "past_fwd": sc["fwd"]},
+        "hits": len(hits), "reported": len(hits.reported),
+        "ms": {"scan_and_seeds": round(hits.timings_ms["msv"], 1), "window_batches_device": round(hits.timings_ms["bias"], 1),
+               "host_tail": round(hits.timings_ms["host_domaindef"], 1)},
+    }
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -290,8 +342,11 @@ def main():
                          "pipeline's fill and drain (about two query times) then weigh as little in a 20-step run as in a long one")
     ap.add_argument("--batch", type=int, default=0, help="headline workload: queries per device batch (0: the library's own choice)")
     ap.add_argument("--spinup-max", type=int, default=15, help="at most this many untimed 20-query windows before the warm-up")
-    ap.add_argument("--workload", choices=("both", "config1", "pfam"), default="both",
-                    help="config1: the headline (one profile x 1M targets per GPU); pfam: the many-query workload; both: headline + a `pfam` field")
+    ap.add_argument("--workload", choices=("both", "config1", "pfam", "nhmmer"), default="both",
+                    help="config1: the headline (one profile x 1M targets per GPU); pfam / nhmmer: (a token headline and) that "
+                         "workload's field; both: headline + the `pfam` and `nhmmer` fields")
+    ap.add_argument("--nhmmer-mbp", type=float, default=250.0, help="chromosome length per GPU")
+    ap.add_argument("--nhmmer-searches", type=int, default=3)
     ap.add_argument("--pfam-profiles", type=int, default=2048, help="library entries searched (the first ones of the 20k-entry library)")
     ap.add_argument("--pfam-library", type=int, default=20000)
     ap.add_argument("--pfam-targets", type=int, default=500_000, help="targets in total (sharded over the GPUs)")
@@ -299,7 +354,7 @@ def main():
     ap.add_argument("--pfam-depth", type=int, default=4)
     args = ap.parse_args()
 
-    if args.workload == "pfam":          # development switch: the headline part shrinks to a token run
+    if args.workload in ("pfam", "nhmmer"):          # development switch: the headline part shrinks to a token run
         args.steps, args.warmup, args.spinup_max, args.no_cpu_baseline = min(args.steps, 5), 0, 1, True
 
     import torch
@@ -426,6 +481,11 @@ def main():
     if args.workload in ("both", "pfam"):
         del db                       # the headline's target block leaves HBM first
         pfam = run_pfam(args, rank, world, local_rank, dist, red_dev, torch, host_threads)
+    nh = None
+    if args.workload in ("both", "nhmmer"):
+        if args.workload == "nhmmer":
+            del db
+        nh = run_nhmmer(args, rank, world, local_rank, dist, red_dev, torch)
 
     if rank == 0:
         ms_per_step = 1e3 * t_max / args.steps
@@ -498,6 +558,8 @@ def main():
         }
         if pfam is not None:
             out["pfam"] = pfam
+        if nh is not None:
+            out["nhmmer"] = nh
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(hmm, bg, flat, offsets, lengths, min(args.cpu_sample, args.nseq), args.seqlen)
         print(json.dumps(out))

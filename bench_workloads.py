@@ -178,3 +178,21 @@ def make_targets(nseq, library_size, templates, lib_lengths, seed=44, planted_fr
             flat[o:o + dom_len] = np.minimum(dom, K - 1)
             nplanted += 1
     return flat, offsets.astype(np.int64), lens.astype(np.int32), nplanted
+
+
+def make_chromosome(hmm, L, planted=50, seed=45):
+    """configs[4]: an i.i.d. ACGT (0.25 each) chromosome of L residues with `planted` mutated (20 %) stretches of the
+    model's consensus, every second one on the reverse strand, so that the stages behind the SSV scan have work."""
+    rng = np.random.default_rng(seed)
+    seq = rng.integers(0, 4, size=L, dtype=np.uint8)
+    cons = np.argmax(hmm.match_emissions[1:], axis=1).astype(np.uint8)
+    comp = np.array([3, 2, 1, 0], dtype=np.uint8)
+    for c in range(planted):
+        a = int(rng.integers(0, max(1, hmm.M - 200)))
+        n = min(int(rng.integers(150, 1200)), hmm.M - a)
+        pos = int(rng.integers(0, L - n))
+        seg = cons[a:a + n].copy()
+        mut = rng.random(n) < 0.2
+        seg[mut] = rng.integers(0, 4, size=int(mut.sum()))
+        seq[pos:pos + n] = seg if c % 2 == 0 else comp[seg[::-1]]
+    return seq

@@ -11,17 +11,8 @@ planted = int(sys.argv[2]) if len(sys.argv) > 2 else 50
 with plan7.HMMFile(os.path.join(ROOT, "tests", "golden", "hmms", "bmyD.hmm")) as f:
     hmm = next(iter(f))
 L = int(mbp * 1e6)
-rng = np.random.default_rng(45)
-seq = rng.integers(0, 4, size=L, dtype=np.uint8)
-cons = np.argmax(hmm.match_emissions[1:], axis=1).astype(np.uint8)
-comp = np.array([3, 2, 1, 0], dtype=np.uint8)
-for c in range(planted):          # a few homologous segments so that the later stages have work
-    a = int(rng.integers(0, hmm.M - 200)); n = min(int(rng.integers(150, 1200)), hmm.M - a)
-    pos = int(rng.integers(0, L - n))
-    seg = cons[a:a + n].copy()
-    mut = rng.random(n) < 0.2
-    seg[mut] = rng.integers(0, 4, size=int(mut.sum()))
-    seq[pos:pos + n] = seg if c % 2 == 0 else comp[seg[::-1]]
+import bench_workloads as bw
+seq = bw.make_chromosome(hmm, L, planted)
 block = easel.DigitalSequenceBlock(hmm.alphabet, [easel.DigitalSequence(hmm.alphabet, name="chrSyn", sequence=seq)])
 pli = plan7.LongTargetsPipeline(hmm.alphabet)
 for it in range(2):
