@@ -501,7 +501,7 @@ def main():
         achieved_gbs = alg_bytes / (msv_ms * 1e-3) / 1e9
         msv_cups = B * cells_rank / (msv_ms * 1e-3)
         om_R = (hmm.M + 1) // 2 + 1
-        om_R = ((om_R + 7) // 8) * 8 if om_R <= 160 else ((om_R + 15) // 16) * 16
+        om_R = ((om_R + 3) // 4) * 4 if om_R <= 160 else ((om_R + 15) // 16) * 16
         out = {
             "metric": "GCUPS (DP cells/s) + seqs/s for hmmsearch, Pfam-A vs proteome, 1/2/4/8 GPUs",
             "value": round(gcups, 2), "unit": "GCUPS",

@@ -61,19 +61,40 @@ __device__ __forceinline__ void lds_issue4(uint32_t addr, Chunk &c)
                : "=&v"(c.e0), "=&v"(c.e1), "=&v"(c.e2), "=&v"(c.e3)   // early-clobber: results may land before the last issue
                : "v"(addr), "i"(OFF), "i"(OFF + 8), "i"(OFF + 16), "i"(OFF + 24));
 }
+template <int OFF>
+__device__ __forceinline__ void lds_issue2(uint32_t addr, Chunk &c)
+{
+  asm volatile("ds_read_b64 %0, %2 offset:%3\n\t"
+               "ds_read_b64 %1, %2 offset:%4"
+               : "=&v"(c.e0), "=&v"(c.e1)
+               : "v"(addr), "i"(OFF), "i"(OFF + 8));
+}
 template <int PENDING>
-__device__ __forceinline__ void lds_wait(Chunk &c)
+__device__ __forceinline__ void lds_wait4(Chunk &c)
 {
   asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(c.e0), "+v"(c.e1), "+v"(c.e2), "+v"(c.e3) : "i"(PENDING));
 }
+template <int PENDING>
+__device__ __forceinline__ void lds_wait2(Chunk &c)
+{
+  asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(c.e0), "+v"(c.e1) : "i"(PENDING));
+}
 
-// One DP row over the register file, four register pairs (8 registers, 16 cells) per chunk.
+// One DP row over the register file: chunks of four register pairs (8 registers, 16 cells); when R is not a multiple
+// of 8 the top chunk holds two pairs.
 template <int R, bool ODD, int T, bool FAST = false>   // T = chunk index being computed
 struct RowChunks {
-  static_assert(R % 8 == 0, "a row is walked in chunks of 8 registers: the register count must be a multiple of 8");
-  static constexpr int NT = R / 8;
+  static_assert(R % 4 == 0, "a row is walked in chunks of 8 registers and a last one of 4: the register count must be a multiple of 4");
+  static constexpr int NT = (R + 7) / 8;
   static constexpr int S = msv_stride_c(R);
   static constexpr int TBASE = ODD ? 0 : kTabRows * S * 4;
+  static constexpr int pairs(int t) { return (t == NT - 1 && (R % 8) != 0) ? 2 : 4; }
+
+  template <int TT>
+  static __device__ __forceinline__ void issue(uint32_t addr, Chunk &c)
+  {
+    if constexpr (pairs(TT) == 4) lds_issue4<TBASE + TT * 32>(addr, c); else lds_issue2<TBASE + TT * 32>(addr, c);
+  }
 
   template <int JJ>
   static __device__ __forceinline__ void pair(s2 (&v)[R], const uint2 e, const s2 xB, s2 &accA, s2 &accB)
@@ -114,18 +135,27 @@ struct RowChunks {
   {
     constexpr bool last = ODD ? (T == 0) : (T == NT - 1);
     constexpr int TN = ODD ? T - 1 : T + 1;
-    if constexpr (!last) lds_issue4<TBASE + TN * 32>(addr, nxt);
-    lds_wait<last ? 0 : 4>(cur);
+    constexpr int np = pairs(T);
+    if constexpr (!last) {
+      issue<TN>(addr, nxt);
+      if constexpr (np == 4) lds_wait4<pairs(TN)>(cur); else lds_wait2<pairs(TN)>(cur);
+    } else {
+      if constexpr (np == 4) lds_wait4<0>(cur); else lds_wait2<0>(cur);
+    }
     if constexpr (ODD) {
-      pair<4 * T + 3>(v, cur.e3, xB, accA, accB);
-      pair<4 * T + 2>(v, cur.e2, xB, accA, accB);
+      if constexpr (np == 4) {
+        pair<4 * T + 3>(v, cur.e3, xB, accA, accB);
+        pair<4 * T + 2>(v, cur.e2, xB, accA, accB);
+      }
       pair<4 * T + 1>(v, cur.e1, xB, accA, accB);
       pair<4 * T + 0>(v, cur.e0, xB, accA, accB);
     } else {
       pair<4 * T + 0>(v, cur.e0, xB, accA, accB);
       pair<4 * T + 1>(v, cur.e1, xB, accA, accB);
-      pair<4 * T + 2>(v, cur.e2, xB, accA, accB);
-      pair<4 * T + 3>(v, cur.e3, xB, accA, accB);
+      if constexpr (np == 4) {
+        pair<4 * T + 2>(v, cur.e2, xB, accA, accB);
+        pair<4 * T + 3>(v, cur.e3, xB, accA, accB);
+      }
     }
     if constexpr (!last) RowChunks<R, ODD, TN, FAST>::run(v, addr, nxt, cur, xB, accA, accB);
   }
@@ -135,12 +165,11 @@ template <int R, bool ODD>
 __device__ __forceinline__ void msv_row(s2 (&v)[R], uint32_t x, s2 &xB, s2 &xJ, s2 &xEmax,
                                         const s2 basev, const s2 tecv, const s2 tjbmv, const s2 zerov)
 {
-  constexpr int S = msv_stride_c(R), NT = R / 8;
+  constexpr int S = msv_stride_c(R), NT = (R + 7) / 8;
   constexpr int T0 = ODD ? NT - 1 : 0;
-  constexpr int TBASE = ODD ? 0 : kTabRows * S * 4;
   const uint32_t addr = x * (uint32_t) (S * 4);
   Chunk ca, cb;
-  lds_issue4<TBASE + T0 * 32>(addr, ca);
+  RowChunks<R, ODD, T0>::template issue<T0>(addr, ca);
   s2 accA = splat(kNegPad), accB = accA;
   RowChunks<R, ODD, T0>::run(v, addr, ca, cb, xB, accA, accB);
   s2 m = pk_max(accA, accB);
@@ -216,12 +245,16 @@ __global__ void __launch_bounds__(kMsvBlock) msv_kernel(const ArgRef ref)
 // with the row-maximum update that is 2 packed ops per two cells.  Differences to the exact kernel:
 //   * xE is seen as max(xE, xB).  This never changes xB (J only matters above base) and changes the final xJ
 //     only if *every* row maximum stayed below its begin score, in which case xJ comes out as the constant
-//     F0 = base - tjb - tbm - tec.  Exactly those targets (xJ == F0 with a floored row) are ambiguous: their
-//     64-target group is appended to a list and recomputed by the exact kernel above.  All other xJ are exact.
-//   * when xJ rises above base the begin score moves: every register is re-biased by the increment
-//     (v_pk_sub_i16 clamp; wave-uniform branch, taken a few times per group at most).
+//     F0 = base - tjb - tbm - tec.  Exactly those targets (xJ == F0) are ambiguous: their 64-target group is
+//     appended to a list and recomputed by the exact kernel above.  All other xJ are exact.
+//   * the begin score moves when xJ rises above base: with xB = max(max(base, xJ) - tjbm, 0) as the invariant, a
+//     row moves it iff its (relative) maximum m exceeds the per-target constant T = tjbm + tec - 32768.  The
+//     maximum is therefore accumulated over an EPOCH of rows (the accumulators are not reset per row), a row costs
+//     three ops beyond its cells (merge, max with T, compare), and xJ / the overflow watermark are folded from the
+//     epoch maximum when an epoch ends: at the (rare, wave-uniform branch) row that moves some lane's begin score
+//     -- every register is then re-biased by the increment (v_pk_sub_i16 clamp) -- and after the last row.
 template <int R>
-__global__ void __launch_bounds__(kMsvBlock, (R <= 88 ? 4 : (R <= 136 ? 3 : 2))) msv_fast_kernel(const ArgRef ref)
+__global__ void __launch_bounds__(kMsvBlock, (R <= 92 ? 4 : (R <= 136 ? 3 : 2))) msv_fast_kernel(const ArgRef ref)
 {
   extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
   constexpr int S = msv_stride_c(R);
@@ -238,7 +271,7 @@ __global__ void __launch_bounds__(kMsvBlock, (R <= 88 ? 4 : (R <= 136 ? 3 : 2)))
 
   const int lane = threadIdx.x & 63;
   const s2 floorv = splat(-32768);
-  constexpr int NT = R / 8;
+  constexpr int NT = (R + 7) / 8;
 
   for (;;) {
     int g = 0;
@@ -250,7 +283,7 @@ __global__ void __launch_bounds__(kMsvBlock, (R <= 88 ? 4 : (R <= 136 ? 3 : 2)))
     const int slot = g * 64 + lane;
     const int L = a.slot_len[slot];
     const int nblk = a.grp_nblk[g];
-    const uint4 *tp = a.tiles + a.grp_off[g] + lane;
+    const uint2 *tp = reinterpret_cast<const uint2 *>(a.tiles + a.grp_off[g] + lane);   // this lane's 16 residues of a tile: tp[0], tp[1]
     const int tjbm = (int) a.tjb_tab[L] + a.tbm;
 
     s2 v[R];
@@ -259,50 +292,52 @@ __global__ void __launch_bounds__(kMsvBlock, (R <= 88 ? 4 : (R <= 136 ? 3 : 2)))
     int xJ = 0, xEmax = 0;
     int xB = max(a.base - tjbm, 0);
     const int F0 = xB - a.tec;
-    bool floored = false;
+    const s2 Tv = splat(tjbm + a.tec - 32768);
+    s2 accA = floorv, accB = floorv;             // the epoch's running maximum
+    // fold the epoch maximum into xJ / the overflow watermark; returns the begin score that follows
+    auto fold = [&](const s2 m2) -> int {
+      const int xE = max((int) m2.x, (int) m2.y) + 32768 + xB;
+      xEmax = max(xEmax, xE);
+      xJ = max(xJ, xE - a.tec);
+      return max(max(a.base, xJ) - tjbm, 0);
+    };
 
-    uint4 cur = tp[0];
-    for (int b = 0; b < nblk; ++b) {
-      const uint4 nxt = (b + 1 < nblk) ? tp[(size_t) (b + 1) * 64] : cur;
-      uint32_t w0 = cur.x, w1 = cur.y, w2 = cur.z, w3 = cur.w;
+    uint2 cur = tp[0];
+    for (int h = 0; h < 2 * nblk; ++h) {          // 8 residues at a time
+      const uint2 nxt = (h + 1 < 2 * nblk) ? tp[(size_t) ((h + 1) >> 1) * 128 + ((h + 1) & 1)] : cur;
+      uint32_t w0 = cur.x, w1 = cur.y;
 #pragma unroll 1
-      for (int c = 0; c < 8; ++c) {
+      for (int c = 0; c < 4; ++c) {
         const uint32_t x0 = w0 & 0xffu, x1 = (w0 >> 8) & 0xffu;
-        w0 = __builtin_amdgcn_alignbit(w1, w0, 16); w1 = __builtin_amdgcn_alignbit(w2, w1, 16);
-        w2 = __builtin_amdgcn_alignbit(w3, w2, 16); w3 >>= 16;
+        w0 = __builtin_amdgcn_alignbit(w1, w0, 16); w1 >>= 16;
 #pragma unroll
         for (int half = 0; half < 2; ++half) {
           Chunk ca, cb;
-          s2 accA = floorv, accB = floorv;
           if (half == 0) {        // odd row
             const uint32_t addr = x0 * (uint32_t) (S * 4);
-            lds_issue4<(NT - 1) * 32>(addr, ca);
+            RowChunks<R, true, NT - 1, true>::template issue<NT - 1>(addr, ca);
             RowChunks<R, true, NT - 1, true>::run(v, addr, ca, cb, floorv, accA, accB);
           } else {                // even row
             const uint32_t addr = x1 * (uint32_t) (S * 4);
-            lds_issue4<kTabRows * S * 4>(addr, ca);
+            RowChunks<R, false, 0, true>::template issue<0>(addr, ca);
             RowChunks<R, false, 0, true>::run(v, addr, ca, cb, floorv, accA, accB);
           }
           const s2 m2 = pk_max(accA, accB);
-          const int m = max((int) m2.x, (int) m2.y);
-          floored |= (m == -32768);
-          const int xE = m + 32768 + xB;
-          xEmax = max(xEmax, xE);
-          xJ = max(xJ, xE - a.tec);
-          const int xBn = max(max(a.base, xJ) - tjbm, 0);
-          const int delta = xBn - xB;
-          if (__builtin_expect(__any(delta > 0), 0)) {
+          if (__builtin_expect(__any(as_u32(pk_max(m2, Tv)) != as_u32(Tv)), 0)) {
             asm volatile("; re-bias: the begin score moved" ::: "memory");   // keeps this a real (rare) branch: no if-conversion
-            const s2 dv = splat(delta);
+            const int xBn = fold(m2);
+            const s2 dv = splat(xBn - xB);        // zero in the lanes whose own maximum stayed at or below T
 #pragma unroll
             for (int j = 0; j < R; ++j) v[j] = pk_subs(v[j], dv);
             xB = xBn;
+            accA = floorv; accB = floorv;
           }
         }
       }
       cur = nxt;
     }
-    const bool ambiguous = (L > 0) && floored && (xJ == F0) && !(xEmax >= 255 - a.bias);
+    fold(pk_max(accA, accB));
+    const bool ambiguous = (L > 0) && (xJ == F0) && !(xEmax >= 255 - a.bias);
     if (L > 0) a.out_xJ[slot] = (xEmax >= 255 - a.bias) ? (int16_t) -1 : (int16_t) xJ;
     if (__any(ambiguous) && lane == 0) { const int idx = atomicAdd(a.amb_count, 1); a.amb_groups[idx] = g; }
   }
@@ -310,8 +345,8 @@ __global__ void __launch_bounds__(kMsvBlock, (R <= 88 ? 4 : (R <= 136 ? 3 : 2)))
 
 // ---------------------------------------------------------------------------- host side
 
-static const int kRList[] = { 8, 16, 24, 32, 40, 48, 56, 64, 72, 80, 88, 96, 104, 112, 120, 128, 136, 144, 152, 160,
-                              176, 192, 208, 224, 240 };
+static const int kRList[] = { 8, 12, 16, 20, 24, 28, 32, 36, 40, 44, 48, 52, 56, 60, 64, 68, 72, 76, 80, 84, 88, 92, 96, 100, 104, 108,
+                              112, 116, 120, 124, 128, 132, 136, 140, 144, 148, 152, 156, 160, 176, 192, 208, 224, 240 };
 
 int msv_pick_R(int M)
 {
@@ -390,9 +425,11 @@ int msv_launch(int R, const ArgRun<MsvArgs> &main, const ArgRun<MsvArgs> *amb, i
   if (main.n <= 0) return P7X_OK;
   switch (R) {
 #define P7X_CASE(r) case r: return launch_R<r>(main, amb, num_cu, st);
-    P7X_CASE(8) P7X_CASE(16) P7X_CASE(24) P7X_CASE(32) P7X_CASE(40) P7X_CASE(48) P7X_CASE(56) P7X_CASE(64) P7X_CASE(72)
-    P7X_CASE(80) P7X_CASE(88) P7X_CASE(96) P7X_CASE(104) P7X_CASE(112) P7X_CASE(120) P7X_CASE(128) P7X_CASE(136)
-    P7X_CASE(144) P7X_CASE(152) P7X_CASE(160) P7X_CASE(176) P7X_CASE(192) P7X_CASE(208) P7X_CASE(224) P7X_CASE(240)
+    P7X_CASE(8) P7X_CASE(12) P7X_CASE(16) P7X_CASE(20) P7X_CASE(24) P7X_CASE(28) P7X_CASE(32) P7X_CASE(36) P7X_CASE(40)
+    P7X_CASE(44) P7X_CASE(48) P7X_CASE(52) P7X_CASE(56) P7X_CASE(60) P7X_CASE(64) P7X_CASE(68) P7X_CASE(72) P7X_CASE(76)
+    P7X_CASE(80) P7X_CASE(84) P7X_CASE(88) P7X_CASE(92) P7X_CASE(96) P7X_CASE(100) P7X_CASE(104) P7X_CASE(108) P7X_CASE(112)
+    P7X_CASE(116) P7X_CASE(120) P7X_CASE(124) P7X_CASE(128) P7X_CASE(132) P7X_CASE(136) P7X_CASE(140) P7X_CASE(144)
+    P7X_CASE(148) P7X_CASE(152) P7X_CASE(156) P7X_CASE(160) P7X_CASE(176) P7X_CASE(192) P7X_CASE(208) P7X_CASE(224) P7X_CASE(240)
 #undef P7X_CASE
     default: set_error("msv_launch: unsupported register tile"); return P7X_EINVAL;
   }
