@@ -32,6 +32,8 @@ sys.path.insert(0, str(ROOT / "tests"))
 HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 VALU_LANE_OPS_PER_S = 256 * 4 * 16 * 2.4e9    # 256 CU x 4 SIMD x 16 lanes/clk x 2.4 GHz: packed-16 VOP3P ops take 4 cycles per
                                               # wave64 (PMC: SQ_ACTIVE_INST_VALU == SQ_INSTS_VALU quad-cycles, profiles/r01_bench_pmc.md)
+VALU_SUSTAINED_GCUPS = 35600.0   # the same two packed ops held for 30-140 ms with every SIMD busy (scripts/ubench/sustained,
+                                 # profiles/r02_sustained_ubench.md): the packed-op roof in wall-clock terms (2.17 GHz-equivalent)
 MSV_OPS_PER_CELL = 1.0           # fast MSV kernel: v_pk_add_i16 clamp + v_pk_max_i16 per two cells (p7x_msv.hip)
 
 
@@ -548,10 +550,14 @@ def main():
                 "valu": {"msv_gcups": round(msv_cups / 1e9, 1), "ops_per_cell": MSV_OPS_PER_CELL,
                          "peak_gcups": round(VALU_LANE_OPS_PER_S / MSV_OPS_PER_CELL / 1e9, 1),
                          "frac": round(msv_cups * MSV_OPS_PER_CELL / VALU_LANE_OPS_PER_S, 4),
+                         # against what the chip sustains for the two packed ops alone / with the kernel's LDS reads
+                         "sustained_peak_gcups": VALU_SUSTAINED_GCUPS, "frac_sustained": round(msv_cups / 1e9 / VALU_SUSTAINED_GCUPS, 4),
+                         "sustained_mix_gcups": 30900.0,
                          # the same launch when no other search shares the device (measured after the timed region)
                          "standalone": ({"kernel_ms": round(solo["msv_kernel"], 4),
                                          "msv_gcups": round(cells_rank / (solo["msv_kernel"] * 1e-3) / 1e9, 1),
-                                         "frac": round(cells_rank / (solo["msv_kernel"] * 1e-3) * MSV_OPS_PER_CELL / VALU_LANE_OPS_PER_S, 4)}
+                                         "frac": round(cells_rank / (solo["msv_kernel"] * 1e-3) * MSV_OPS_PER_CELL / VALU_LANE_OPS_PER_S, 4),
+                                         "frac_sustained": round(cells_rank / (solo["msv_kernel"] * 1e-3) / 1e9 / VALU_SUSTAINED_GCUPS, 4)}
                                         if solo else None)},
                 "kernel_ms": round(msv_ms, 4), "algorithmic_bytes": int(alg_bytes), "queries_per_launch": B,
             },
