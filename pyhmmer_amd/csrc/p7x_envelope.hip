@@ -12,11 +12,16 @@
 // registers and writes one byte of back-pointers per cell; step 4 is a serial walk over those bytes by lane 0,
 // followed by a lane-parallel pass that attaches the posterior probability of every emitted residue.
 // The host (p7x_domaindef.cpp) turns the trace into the alignment display and applies the null2 correction.
+#include <cstdlib>
+#include <cstdio>
+#include <cstdlib>
 #include "p7x_wave.hpp"
 
 namespace p7x {
 
 namespace {
+
+
 
 constexpr float kNegInf = -__builtin_inff();
 
@@ -36,9 +41,12 @@ __device__ __forceinline__ void phase_fence()
 
 } // namespace
 
+// One block per CU: its wavefronts (env_waves(C): 12 where the row registers allow three per SIMD, else 8) share one
+// copy of the profile tables in LDS and each walks its own envelopes.
 template <int C>
-__global__ void __launch_bounds__(kWsBlock) env_kernel(const ArgRef ref)
+__global__ void __launch_bounds__(env_waves(C) * 64, env_waves(C) / 4) env_kernel(const ArgRef ref)
 {
+  constexpr int kEnvBlock = env_waves(C) * 64;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   constexpr int Mpad = 64 * C;
   const EnvArgs a = load_args<EnvArgs>(ref);
@@ -47,15 +55,15 @@ __global__ void __launch_bounds__(kWsBlock) env_kernel(const ArgRef ref)
   float *em = reinterpret_cast<float *>(smem + (size_t) Mpad * 32);      // [nrows][Mpad]
   {
     const float4 *gt = reinterpret_cast<const float4 *>(a.trans);
-    for (int i = threadIdx.x; i < 2 * Mpad; i += kWsBlock) tr[i] = gt[i];
+    for (int i = threadIdx.x; i < 2 * Mpad; i += kEnvBlock) tr[i] = gt[i];
     const float4 *ge = reinterpret_cast<const float4 *>(a.emis);
     float4 *le = reinterpret_cast<float4 *>(em);
-    for (int i = threadIdx.x; i < a.nrows * Mpad / 4; i += kWsBlock) le[i] = ge[i];
+    for (int i = threadIdx.x; i < a.nrows * Mpad / 4; i += kEnvBlock) le[i] = ge[i];
   }
   __syncthreads();
   const int lane = threadIdx.x & 63;
   const int nlist = a.nenv;
-  const int wave_in_job = rfl((int) (blockIdx.x * (kWsBlock / 64) + (threadIdx.x >> 6)));
+  const int wave_in_job = rfl((int) (blockIdx.x * (kEnvBlock / 64) + (threadIdx.x >> 6)));
   const int wave_id = a.slab_base + wave_in_job;     // per-wavefront workspace slabs are numbered across the jobs of a launch
 
   // per-wavefront workspace
@@ -69,7 +77,13 @@ __global__ void __launch_bounds__(kWsBlock) env_kernel(const ArgRef ref)
   float *totr_row = px + rows * 3;          // [rows]
   unsigned char *bp = reinterpret_cast<unsigned char *>(totr_row + rows);   // [rows][Mpad] back-pointers
 
-  for (int it = wave_in_job; it < nlist; it += a.nblocks * (kWsBlock / 64)) {
+  for (;;) {
+    // envelopes are taken longest first from the job's queue: a wavefront that drew a short one comes back for more
+    int q = 0;
+    if (lane == 0) q = atomicAdd(a.cursor, 1);
+    q = rfl(q);
+    if (q >= nlist) break;
+    const int it = rfl(a.order[q]);
     const int Ld = rfl(a.env_len[it]);
     const int Lfull = rfl(a.env_L[it]);
     const unsigned long long off = (unsigned long long) a.env_sq[it];
@@ -117,11 +131,7 @@ __global__ void __launch_bounds__(kWsBlock) env_kernel(const ArgRef ref)
 #pragma unroll
           for (int c = 0; c < C; ++c) { dm[c] = A; A = mm[c] * t_md[c] + A * t_dd[c]; }
           float sa = A, sp = ddprod;
-#pragma unroll
-          for (int s = 1; s < 64; s <<= 1) {
-            const float pa = __shfl_up(sa, s), pp = __shfl_up(sp, s);
-            if (lane >= s) { sa = sa + pa * sp; sp = sp * pp; }
-          }
+          affine_scan_up(sa, sp);
           {
             float w = dpp_shr1f(sa, 0.0f);
 #pragma unroll
@@ -184,11 +194,7 @@ __global__ void __launch_bounds__(kWsBlock) env_kernel(const ArgRef ref)
 #pragma unroll
         for (int c = C - 1; c >= 0; --c) { A = d[c] + A * t_dd[c]; }
         float sa = A, sp = ddprod;
-#pragma unroll
-        for (int s = 1; s < 64; s <<= 1) {
-          const float pa = __shfl_down(sa, s), pp = __shfl_down(sp, s);
-          if (lane + s < 64) { sa = sa + pa * sp; sp = sp * pp; }
-        }
+        affine_scan_down(sa, sp, lane);
         float w = dpp_shl1f(sa, 0.0f);
 #pragma unroll
         for (int c = C - 1; c >= 0; --c) { d[c] = d[c] + w * t_dd[c]; w = d[c]; }
@@ -371,11 +377,7 @@ __global__ void __launch_bounds__(kWsBlock) env_kernel(const ArgRef ref)
 #pragma unroll
           for (int c = 0; c < C; ++c) w = vmax(gate(t_md[c], om_[c]), t_dd[c] > 0.0f ? w : 0.0f);
           float sa = w; int sp = ddpass ? 1 : 0;
-#pragma unroll
-          for (int s = 1; s < 64; s <<= 1) {
-            const float pa = __shfl_up(sa, s); const int pp = __shfl_up(sp, s);
-            if (lane >= s) { sa = vmax(sa, sp ? pa : kNegInf); sp = sp & pp; }
-          }
+          gated_max_scan_up(sa, sp);
           w = dpp_shr1f(sa, kNegInf);
 #pragma unroll
           for (int c = 0; c < C; ++c) { od_[c] = w; w = vmax(gate(t_md[c], om_[c]), t_dd[c] > 0.0f ? w : 0.0f); }
@@ -568,17 +570,22 @@ static int launch_env(K kernel, const ArgRun<EnvArgs> &a, size_t lds_bytes, hipS
     P7X_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds_bytes));
   int gx = 1;
   for (int i = 0; i < a.n; ++i) gx = std::max(gx, a.at(i).nblocks);
-  hipLaunchKernelGGL(kernel, dim3((unsigned) gx, (unsigned) a.n), dim3(kWsBlock), lds_bytes, st, a.ref());
+  hipLaunchKernelGGL(kernel, dim3((unsigned) gx, (unsigned) a.n), dim3((unsigned) env_waves(a.at(0).C) * 64), lds_bytes, st, a.ref());
   P7X_HIP(hipGetLastError());
   return P7X_OK;
 }
 
 template <typename K>
-static int occupancy_env(K kernel, size_t lds_bytes, int *per_cu)
+static int occupancy_env(K kernel, int kEnvBlock, size_t lds_bytes, int *per_cu)
 {
   if (lds_bytes > 64 * 1024)
     P7X_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds_bytes));
-  P7X_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(per_cu, kernel, kWsBlock, lds_bytes));
+  P7X_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(per_cu, kernel, kEnvBlock, lds_bytes));
+  if (std::getenv("P7X_ENV_DEBUG")) {
+    hipFuncAttributes fa; (void) hipFuncGetAttributes(&fa, reinterpret_cast<const void *>(kernel));
+    std::fprintf(stderr, "[env] occupancy %d blocks/CU of %d threads, lds %zu, regs %d, static lds %zu, maxthreads %d\n", *per_cu, kEnvBlock, lds_bytes,
+                 fa.numRegs, fa.sharedSizeBytes, fa.maxThreadsPerBlock);
+  }
   if (*per_cu < 1) *per_cu = 1;
   return P7X_OK;
 }
@@ -605,7 +612,7 @@ int env_max_blocks(int C, int nrows, int num_cu, int *nblocks)
   const size_t lds = env_lds_bytes(C, nrows);
   int per_cu = 1;
   auto finish = [&](int st) { if (st == P7X_OK) *nblocks = num_cu * per_cu; return st; };
-  P7X_ENV_SWITCH(finish(occupancy_env(kern, lds, &per_cu)))
+  P7X_ENV_SWITCH(finish(occupancy_env(kern, env_waves(C) * 64, lds, &per_cu)))
 }
 
 int env_launch(const ArgRun<EnvArgs> &a, hipStream_t st)

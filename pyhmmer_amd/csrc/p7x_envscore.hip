@@ -3,6 +3,7 @@
 // host stage (p7x_domaindef.cpp / p7x_tophits.cpp) through the EnvelopeScorer interface.
 #include "p7x_wave.hpp"
 #include "p7x_host.hpp"
+#include <algorithm>
 #include <cstdlib>
 #include <cstring>
 #include <map>
@@ -77,9 +78,11 @@ public:
       P7X_HIP(hipDeviceGetStreamPriorityRange(&least, &greatest));
       P7X_HIP(hipStreamCreateWithPriority(&eb->stream, hipStreamNonBlocking, least));
     }
-    // inputs: [env_sq i64][tr_off i64][env_len i32][env_L i32] over all envelopes, then one EnvArgs record per job
+    // inputs: [env_sq i64][tr_off i64][env_len i32][env_L i32][order i32] over all envelopes, one queue cursor per job,
+    // then one EnvArgs record per job
     const size_t nj = jobs.size();
-    const size_t o_args = ((size_t) nenv_tot * (8 + 8 + 4 + 4) + 255) & ~(size_t) 255;
+    const size_t o_cursor = (size_t) nenv_tot * (8 + 8 + 4 + 4 + 4);
+    const size_t o_args = (o_cursor + nj * 4 + 255) & ~(size_t) 255;
     const size_t in_bytes = o_args + nj * sizeof(EnvArgs);
     if (in_bytes > eb->h_in_cap) {
       pinned_release(eb->h_in, eb->h_in_cap); eb->h_in = nullptr; eb->h_in_cap = 0;
@@ -94,6 +97,9 @@ public:
     int64_t *tr_off = env_sq + nenv_tot;
     int32_t *env_len = reinterpret_cast<int32_t *>(tr_off + nenv_tot);
     int32_t *env_L = env_len + nenv_tot;
+    int32_t *env_order = env_L + nenv_tot;
+    int32_t *h_cursor = reinterpret_cast<int32_t *>(eb->h_in + o_cursor);
+    for (size_t j = 0; j < nj; ++j) h_cursor[j] = 0;
     EnvArgs *h_args = reinterpret_cast<EnvArgs *>(eb->h_in + o_args);
     int64_t ntr = 0;
     // jobs of one model-length class (nodes per lane C) go into one launch: order them by class
@@ -116,6 +122,11 @@ public:
         tr_off[e] = ntr; ntr += (int64_t) Ld + p.M + 16;
         m.Lmax = std::max(m.Lmax, Ld);
       }
+      // longest first (job-relative indices)
+      int32_t *ord = env_order + m.first;
+      for (int r = 0; r < m.nenv; ++r) ord[r] = r;
+      const int32_t *len = env_len + m.first;
+      std::stable_sort(ord, ord + m.nenv, [len](int32_t x, int32_t y) { return len[x] > len[y]; });
     }
     std::stable_sort(order_.begin(), order_.end(), [&](int x, int y) { return meta_[x].C < meta_[y].C; });
     // workspace: one slab per wavefront of every job, sized for the longest envelope of the job's class
@@ -131,9 +142,12 @@ public:
         if (m.nenv == 0) continue;
         int cap_blocks = 0;
         if ((st = env_max_blocks(m.C, jobs[j].om->p.Kp + 1, ctx_->num_cu, &cap_blocks)) != P7X_OK) return st;
-        m.nblocks = std::max(1, std::min(cap_blocks, (m.nenv + 3) / 4) / shrink);
+        // the jobs share the resident blocks in proportion to their envelopes; a job with more envelopes than wavefronts
+        // hands them out longest first (EnvArgs::order / cursor)
+        const int share = (int) std::max<int64_t>(1, (int64_t) cap_blocks * m.nenv / nenv_tot);
+        m.nblocks = std::max(1, std::min(share, (m.nenv + env_waves(m.C) - 1) / env_waves(m.C)) / shrink);
         m.stride = env_work_floats(m.C, class_Lmax[m.C]);
-        work_floats += (size_t) m.nblocks * 4 * m.stride;
+        work_floats += (size_t) m.nblocks * env_waves(m.C) * m.stride;
       }
       if (work_floats * 4 <= budget || work_floats <= eb->work_floats) break;
       bool all_one = true;
@@ -162,6 +176,8 @@ public:
     const int64_t *d_tr_off = d_env_sq + nenv_tot;
     const int32_t *d_env_len = reinterpret_cast<const int32_t *>(d_tr_off + nenv_tot);
     const int32_t *d_env_L = d_env_len + nenv_tot;
+    const int32_t *d_env_order = d_env_L + nenv_tot;
+    int *d_cursor = reinterpret_cast<int *>(eb->d_in + o_cursor);
     // argument records in launch order (class by class)
     size_t slab_floats = 0;
     std::vector<std::pair<int, int>> runs;        // first record, count
@@ -177,10 +193,11 @@ public:
       a.nj = 0.0f; a.xf_e_move = 1.0f; a.xf_e_loop = 0.0f;              // p7_oprofile_ReconfigUnihit
       a.nenv = m.nenv;
       a.env_sq = d_env_sq + m.first; a.tr_off = d_tr_off + m.first; a.env_len = d_env_len + m.first; a.env_L = d_env_L + m.first;
+      a.order = d_env_order + m.first; a.cursor = d_cursor + j;
       // slab_base counts slabs of THIS job's stride from the start of its own region of the workspace
       a.work = eb->work + slab_floats; a.work_stride = (int64_t) m.stride; a.Lmax = class_Lmax[m.C];
       a.nblocks = m.nblocks; a.slab_base = 0;
-      slab_floats += (size_t) m.nblocks * 4 * m.stride;
+      slab_floats += (size_t) m.nblocks * env_waves(m.C) * m.stride;
       a.out_sc = reinterpret_cast<float *>(eb->d_out + o_sc) + 2 * m.first;
       a.out_null2 = reinterpret_cast<float *>(eb->d_out + o_n2) + 32 * m.first;
       a.out_status = reinterpret_cast<int32_t *>(eb->d_out + o_st) + m.first;

@@ -134,6 +134,8 @@ struct EnvArgs {
   const int64_t *env_sq;    // [nenv] offset in dsq of the first residue of the envelope
   const int32_t *env_len;   // [nenv] envelope length Ld
   const int32_t *env_L;     // [nenv] full target length (the length model is not re-configured per envelope)
+  const int32_t *order;     // [nenv] envelopes by decreasing length: the order in which wavefronts draw them
+  int *cursor;              // the job's queue position (zero at launch)
   float *work; int64_t work_stride; int Lmax;    // per-wavefront workspace (env_work_floats), rows 0..Lmax
   int nblocks, slab_base;   // blocks of this job (blockIdx.x beyond them exit); first workspace slab of the job
   float *out_sc;            // [nenv][2] envelope Forward score (nats), optimal accuracy score
@@ -143,6 +145,7 @@ struct EnvArgs {
   uint32_t *tr_a; int32_t *tr_i; float *tr_pp;
   int32_t *tr_n;            // [nenv] trace length
 };
+constexpr int env_waves(int C) { (void) C; return 8; }   // wavefronts (= envelopes in flight) per block of env_kernel
 size_t env_work_floats(int C, int Lmax);
 int env_max_blocks(int C, int nrows, int num_cu, int *nblocks);
 // every record of the run has the same C and nrows; grid.x = the widest job's nblocks

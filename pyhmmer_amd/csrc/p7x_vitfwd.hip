@@ -254,11 +254,7 @@ __global__ void __launch_bounds__(kWsBlock) fwd_kernel(const ArgRef ref)
 #pragma unroll
       for (int c = 0; c < C; ++c) { dm[c] = A; A = mm[c] * tmd[c] + A * tdd[c]; }
       float sa = A, sp = ddprod;                        // inclusive scan of (carry, multiplier)
-#pragma unroll
-      for (int s = 1; s < 64; s <<= 1) {
-        const float pa = __shfl_up(sa, s), pp = __shfl_up(sp, s);
-        if (lane >= s) { sa = sa + pa * sp; sp = sp * pp; }
-      }
+      affine_scan_up(sa, sp);
       dcarry = dpp_shr1f(sa, 0.0f);                     // exclusive: the carry entering this lane
       {
         float w = dcarry;
@@ -364,11 +360,7 @@ __global__ void __launch_bounds__(kWsBlock) bck_kernel(const ArgRef ref)
 #pragma unroll
       for (int c = C - 1; c >= 0; --c) { A = d[c] + A * tdd[c]; }
       float sa = A, sp = ddprod;
-#pragma unroll
-      for (int s = 1; s < 64; s <<= 1) {
-        const float pa = __shfl_down(sa, s), pp = __shfl_down(sp, s);
-        if (lane + s < 64) { sa = sa + pa * sp; sp = sp * pp; }
-      }
+      affine_scan_down(sa, sp, lane);
       float w = dpp_shl1f(sa, 0.0f);                    // D of the first node of the next lane
 #pragma unroll
       for (int c = C - 1; c >= 0; --c) { d[c] = d[c] + w * tdd[c]; w = d[c]; }

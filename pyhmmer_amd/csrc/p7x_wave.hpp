@@ -48,6 +48,47 @@ __device__ __forceinline__ float wave_sum_f32(float v)
   return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
 }
 
+// ---- scans of the delete-state chain across the 64 lanes.  Lane l holds the affine map x -> a_l + p_l * x of its own
+// nodes; the inclusive scan composes the maps of lanes 0..l (up) or l..63 (down).  DPP moves inside the four 16-lane
+// rows (Kogge-Stone with row_shr / row_shl: a lane whose source falls outside its row keeps the identity), then the
+// row totals: row_bcast:15 / row_bcast:31 upwards; v_readlane of the first lane of the next row(s) downwards.  A DPP
+// step is one VALU issue; the ds_bpermute it replaces (__shfl_up) is an LDS round trip on the row's critical path.
+#define P7X_DPPF(v, old, ctrl, rmask) __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, (float) (old)), __builtin_bit_cast(int, (v)), (ctrl), (rmask), 0xf, false))
+#define P7X_AFFINE_STEP(ctrl, rmask) { const float pa_ = P7X_DPPF(sa, 0.0f, ctrl, rmask), pp_ = P7X_DPPF(sp, 1.0f, ctrl, rmask); sa = sa + pa_ * sp; sp = sp * pp_; }
+__device__ __forceinline__ float readlane_f(float v, int l) { return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), l)); }
+
+__device__ __forceinline__ void affine_scan_up(float &sa, float &sp)
+{
+  P7X_AFFINE_STEP(0x111, 0xf) P7X_AFFINE_STEP(0x112, 0xf) P7X_AFFINE_STEP(0x114, 0xf) P7X_AFFINE_STEP(0x118, 0xf)
+  P7X_AFFINE_STEP(0x142, 0xa) P7X_AFFINE_STEP(0x143, 0xc)
+}
+__device__ __forceinline__ void affine_scan_down(float &sa, float &sp, int lane)
+{
+  P7X_AFFINE_STEP(0x101, 0xf) P7X_AFFINE_STEP(0x102, 0xf) P7X_AFFINE_STEP(0x104, 0xf) P7X_AFFINE_STEP(0x108, 0xf)
+  const int row = lane >> 4;
+  {   // rows 2 <- 3 and 0 <- 1
+    const float a48 = readlane_f(sa, 48), p48 = readlane_f(sp, 48), a16 = readlane_f(sa, 16), p16 = readlane_f(sp, 16);
+    const float pa_ = (row == 2) ? a48 : ((row == 0) ? a16 : 0.0f), pp_ = (row == 2) ? p48 : ((row == 0) ? p16 : 1.0f);
+    sa = sa + pa_ * sp; sp = sp * pp_;
+  }
+  {   // rows 0, 1 <- rows 2-3
+    const float a32 = readlane_f(sa, 32), p32 = readlane_f(sp, 32);
+    const float pa_ = (row < 2) ? a32 : 0.0f, pp_ = (row < 2) ? p32 : 1.0f;
+    sa = sa + pa_ * sp; sp = sp * pp_;
+  }
+}
+#undef P7X_AFFINE_STEP
+// the same upwards for the optimal-accuracy delete chain: x -> max(a, open ? x : -inf), open = every D->D of the lane is open
+__device__ __forceinline__ void gated_max_scan_up(float &sa, int &sp)
+{
+#define P7X_GMAX_STEP(ctrl, rmask) { const float pa_ = P7X_DPPF(sa, -__builtin_inff(), ctrl, rmask);                                  \
+    const int pp_ = __builtin_amdgcn_update_dpp(1, sp, (ctrl), (rmask), 0xf, false);                                                  \
+    const float cand_ = sp ? pa_ : -__builtin_inff(); sa = sa > cand_ ? sa : cand_; sp = sp & pp_; }
+  P7X_GMAX_STEP(0x111, 0xf) P7X_GMAX_STEP(0x112, 0xf) P7X_GMAX_STEP(0x114, 0xf) P7X_GMAX_STEP(0x118, 0xf)
+  P7X_GMAX_STEP(0x142, 0xa) P7X_GMAX_STEP(0x143, 0xc)
+#undef P7X_GMAX_STEP
+}
+
 __device__ __forceinline__ short adds16(short a, short b) { return __builtin_elementwise_add_sat(a, b); }
 __device__ __forceinline__ short max16(short a, short b) { return a > b ? a : b; }
 __device__ __forceinline__ short lo16(uint32_t w) { return (short) (w & 0xffffu); }
