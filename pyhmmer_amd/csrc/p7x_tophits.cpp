@@ -683,7 +683,7 @@ struct Reader {
   template <class T> void pod(T &v) { if (p + sizeof(T) > e) { ok = false; return; } std::memcpy(&v, p, sizeof(T)); p += sizeof(T); }
   void str(std::string &s) { uint32_t n = 0; pod(n); if (!ok || p + n > e) { ok = false; return; } s.assign((const char *) p, n); p += n; }
 };
-constexpr uint32_t kMagic = 0x70377877u;   // "p7xw" (format 4: twelve timing slots, scan flag)
+constexpr uint32_t kMagic = 0x70377878u;   // "p7xx" (format 5: presentation order, sort state and flags travel as they are)
 
 template <class IO> void io_domain(IO &io, Domain &d)
 {
@@ -717,6 +717,10 @@ int64_t p7x_tophits_serialize(const p7x_tophits *th, void *buf, size_t cap)
     io_hit(w, h);
     for (Domain &d : h.dcl) io_domain(w, d);
   }
+  // presentation state: the order (key or seqidx sort), the counts, and the flags inside the hits are kept as they are
+  w.pod(th->sorted_by_key); w.pod(th->nreported); w.pod(th->nincluded);
+  const uint64_t no = th->order.size(); w.pod(no);
+  for (int o : th->order) w.pod(o);
   if (buf && cap >= w.b.size()) std::memcpy(buf, w.b.data(), w.b.size());
   return (int64_t) w.b.size();
 }
@@ -732,17 +736,28 @@ p7x_tophits *p7x_tophits_deserialize(const void *buf, size_t n)
   r.str(th->qname); r.str(th->qacc); r.str(th->qdesc); r.pod(th->q_has_acc); r.pod(th->q_has_desc); r.pod(th->M); r.pod(th->scan_collected);
   for (int i = 0; i < 12; ++i) r.pod(th->ms[i]);
   uint64_t nh = 0; r.pod(nh);
-  if (!r.ok) return nullptr;
-  th->hits.resize(nh);
-  for (Hit &h : th->hits) {
-    io_hit(r, h);
-    if (!r.ok || h.ndom < 0 || h.ndom > 100000) { set_error("corrupt serialised TopHits"); return nullptr; }
-    h.dcl.resize(h.ndom);
-    for (Domain &d : h.dcl) io_domain(r, d);
+  if (!r.ok) { set_error("truncated serialised TopHits"); return nullptr; }
+  // a hit takes at least its fixed fields (three length words, the scores and counts): a count the buffer cannot hold
+  // is corruption, not an allocation request
+  constexpr size_t kMinHit = 3 * 4 + 2 + 8 + 4 + 8 + 3 * 4 + 3 * 8 + 4 + 5 * 4 + 4 + 3 * 4;
+  if (nh > (uint64_t) (r.e - r.p) / kMinHit) { set_error("corrupt serialised TopHits"); return nullptr; }
+  try {
+    th->hits.resize(nh);
+    for (Hit &h : th->hits) {
+      io_hit(r, h);
+      if (!r.ok || h.ndom < 0 || (uint64_t) h.ndom > (uint64_t) (r.e - r.p) / 64) { set_error("corrupt serialised TopHits"); return nullptr; }
+      h.dcl.resize(h.ndom);
+      for (Domain &d : h.dcl) io_domain(r, d);
+    }
+    uint64_t no = 0;
+    r.pod(th->sorted_by_key); r.pod(th->nreported); r.pod(th->nincluded); r.pod(no);
+    if (!r.ok || (no != 0 && no != nh)) { set_error("truncated serialised TopHits"); return nullptr; }
+    th->order.resize(no);
+    for (int &o : th->order) { r.pod(o); if (!r.ok || o < 0 || (uint64_t) o >= nh) { set_error("corrupt serialised TopHits"); return nullptr; } }
+  } catch (const std::exception &) {
+    set_error("corrupt serialised TopHits"); return nullptr;
   }
   if (!r.ok) { set_error("truncated serialised TopHits"); return nullptr; }
-  sort_by_key(*th);
-  threshold(*th);
   return th.release();
 }
 

@@ -213,11 +213,16 @@ class PackedBlock:
 
 
 class _SequenceBlock:
-    __slots__ = ("_seqs", "_packed")
+    __slots__ = ("_seqs", "_packed", "_version")
 
     def __init__(self, iterable: Iterable = ()):
         self._seqs: List = list(iterable)
         self._packed = None
+        self._version = 0           # bumped by every mutation: caches of the packed / resident copy key on it
+
+    def _touch(self) -> None:
+        self._packed = None
+        self._version += 1
 
     def __len__(self) -> int:
         return len(self._seqs)
@@ -230,17 +235,44 @@ class _SequenceBlock:
             return type(self)._from_list(self, self._seqs[index])
         return self._seqs[index]
 
+    def __setitem__(self, index, value) -> None:
+        self._seqs[index] = value
+        self._touch()
+
+    def __delitem__(self, index) -> None:
+        del self._seqs[index]
+        self._touch()
+
+    def __contains__(self, item) -> bool:
+        return item in self._seqs
+
     def append(self, seq) -> None:
         self._seqs.append(seq)
-        self._packed = None
+        self._touch()
 
     def extend(self, iterable) -> None:
         self._seqs.extend(iterable)
-        self._packed = None
+        self._touch()
+
+    def insert(self, index: int, seq) -> None:
+        self._seqs.insert(index, seq)
+        self._touch()
+
+    def pop(self, index: int = -1):
+        seq = self._seqs.pop(index)
+        self._touch()
+        return seq
+
+    def remove(self, seq) -> None:
+        self._seqs.remove(seq)
+        self._touch()
+
+    def index(self, seq, start: int = 0, stop: Optional[int] = None) -> int:
+        return self._seqs.index(seq, start, len(self._seqs) if stop is None else stop)
 
     def clear(self) -> None:
         self._seqs.clear()
-        self._packed = None
+        self._touch()
 
     def largest(self):
         if not self._seqs:
@@ -302,6 +334,7 @@ class _LazyDigitalSequenceBlock(DigitalSequenceBlock):
         self._pk, self._strtab, self._name_off, self._desc_off = pk, strtab, name_off, desc_off
         self.alphabet = alphabet
         self._packed = pk
+        self._version = 0
 
     def _cstr(self, off: int) -> str:
         buf = self._strtab

@@ -1332,7 +1332,7 @@ class Pipeline:
         self.host_envelopes = bool(host_envelopes)
         self.host_regions = bool(host_regions)
         self._mode = _P7X_SEARCH_SEQS
-        self._db_cache = None           # (id(block), packed n, device) -> SequenceDatabase
+        self._db_cache = None           # (id(block), block version, n, device) -> SequenceDatabase
 
     def clear(self) -> None:
         """Reference ``plan7.pyx:6113-6154``: reset accounting between queries (stateless here)."""
@@ -1394,7 +1394,7 @@ class Pipeline:
         L = len(sequences[0]) if len(sequences) else self.L_HINT
         om = self._get_om_from_query(query, L)
         if database is None:
-            key = (id(sequences), len(sequences), self.device)
+            key = (id(sequences), getattr(sequences, "_version", 0), len(sequences), self.device)
             if self._db_cache is None or self._db_cache[0] != key:
                 self._db_cache = (key, SequenceDatabase(sequences, device=self.device))
             database = self._db_cache[1]

@@ -82,3 +82,47 @@ def test_tophits_bytes_roundtrip(models, oracle, proteome):
     assert [h.name for h in viap] == [h.name for h in hits]
     with pytest.raises(ValueError):
         plan7.TopHits.from_bytes(b"garbage")
+
+
+def test_tophits_bytes_keep_order_and_flags(models, oracle, proteome):
+    """Pickling keeps what the user did to the list (reference plan7.pyx:8394-8572): the seqidx sort order and the
+    reported / included / dropped flags are not recomputed on load; a corrupt hit count is an error, not an abort."""
+    import struct
+    import host_pipeline
+    from pyhmmer_amd import plan7
+    hmm = models["PF02826"][0]
+    hits = host_pipeline.host_search(oracle, hmm, proteome[:700])
+    assert len(hits) >= 3
+    hits.sort(by="seqidx")
+    hits[0].dropped = True
+    hits[1].included = False
+    blob = hits.to_bytes()
+    again = plan7.TopHits.from_bytes(blob)
+    assert again.is_sorted(by="seqidx") and [h.name for h in again] == [h.name for h in hits]
+    assert again[0].dropped and not again[0].included and not again[1].included
+    assert [(h.reported, h.included) for h in again] == [(h.reported, h.included) for h in hits]
+    assert len(again.reported) == len(hits.reported) and len(again.included) == len(hits.included)
+    # the 64-bit hit count sits right before the first hit's name: find it and overwrite it with an absurd value
+    name = hits[0].name if isinstance(hits[0].name, bytes) else hits[0].name.encode()
+    key = struct.pack("<Q", len(hits))
+    at = blob.rfind(key, 0, blob.find(name))
+    assert at > 0
+    with pytest.raises(ValueError):
+        plan7.TopHits.from_bytes(blob[:at] + struct.pack("<Q", 1 << 60) + blob[at + 8:])
+    with pytest.raises(ValueError):
+        plan7.TopHits.from_bytes(blob[:len(blob) // 2])
+
+
+def test_block_mutation_invalidates_the_packed_copy():
+    from pyhmmer_amd import easel
+    abc = easel.Alphabet.amino()
+    mk = lambda name, text: easel.TextSequence(name=name, sequence=text).digitize(abc)
+    block = easel.DigitalSequenceBlock(abc, [mk("a", "ACDEFG"), mk("b", "HIKLMN")])
+    v0, pk0 = block._version, block.packed()
+    block[1] = mk("c", "PQRSTV")                       # same length, different residues
+    assert block._version != v0
+    pk1 = block.packed()
+    assert pk1 is not pk0 and bytes(pk1.dsq) != bytes(pk0.dsq)
+    block.insert(0, mk("d", "WY"))
+    assert block.packed().n == 3 and block.pop().name in (b"c", "c")
+    assert block.packed().n == 2
