@@ -174,6 +174,9 @@ typedef struct p7x_pipeline_cfg {
                               * alignment against emissions re-derived for a background mixed with the envelope's composition,
                               * score from the unmodified model, bias = the score lost to the adjustment */
   float   lt_bg_mix;         /* weight of the envelope's composition in that background; default 0.75 */
+  float   f3_guard;          /* relative half-width of the band around F3 inside which a target's Forward P-value is not trusted to the
+                              * device's summation order: the device passes P <= F3 (1 + g), the host stage re-scores the targets with
+                              * P > F3 (1 - g) with p7x_forward_parser_exact and applies F3 to that.  Default 1e-3; 0: no guard */
 } p7x_pipeline_cfg;
 enum { P7X_STRAND_BOTH = 0, P7X_STRAND_TOPONLY = 1, P7X_STRAND_BOTTOMONLY = 2 };
 void p7x_pipeline_cfg_default(p7x_pipeline_cfg *cfg);   /* p7_pipeline_Create(NULL,...) defaults, plan7.pyx:5413-5421 */
@@ -271,6 +274,11 @@ int p7x_longtarget_from_seeds(const p7x_pipeline_cfg *cfg, const p7x_oprofile *o
                               const char *const *names, const char *const *accs, const char *const *descs,
                               const int64_t *seed_target, const int64_t *seed_block, const int32_t *seed_strand,
                               const int64_t *seeds, size_t nseeds, p7x_tophits **out);
+
+/* The Forward parser score (nats) of residues dsq[1..L] in the summation order of the reference's striped vectors
+ * (impl_sse/fwdback.c forward_engine, do_full = FALSE; multihit, length model of L): what the host stage uses to decide
+ * targets whose Forward P-value falls within the guard band around F3 (cfg.f3_guard).  Host code; no device. */
+int p7x_forward_parser_exact(const p7x_oprofile *om, const uint8_t *dsq, int32_t L, float *sc);
 
 /* hmmscan orientation (Pipeline.scan_seq / _scan_loop, plan7.pyx:6534-6677; hmmer/_hmmscan.py): search every model
  * against the block of query sequences with cfg.mode = P7X_SCAN_MODELS (one device pass per model, nothing pruned), then

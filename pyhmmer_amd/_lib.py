@@ -106,6 +106,7 @@ class PipelineCfg(C.Structure):
         ("seed", C.c_uint32), ("mode", C.c_int32), ("host_threads", C.c_int32), ("host_envelopes", C.c_int32), ("host_regions", C.c_int32),
         ("long_targets", C.c_int32), ("strands", C.c_int32), ("B1", C.c_int32), ("B2", C.c_int32), ("B3", C.c_int32),
         ("block_length", C.c_int32), ("window_length", C.c_int32), ("lt_bias_mode", C.c_int32), ("lt_bg_mix", C.c_float),
+        ("f3_guard", C.c_float),
     ]
 
 
@@ -195,6 +196,7 @@ _SIGNATURES = {
     "p7x_pending_nqueries": (C.c_size_t, [_VP]),
     "p7x_search_longtargets": (C.c_int, [C.POINTER(PipelineCfg), _VP, C.c_int, _VP, _VP, _VP, C.c_size_t, _VP, _VP, _VP, C.POINTER(_VP)]),
     "p7x_ssv_longtarget_seeds": (C.c_int64, [C.POINTER(PipelineCfg), _VP, C.c_int, _VP, C.c_int64, C.c_int, _VP, C.c_size_t]),
+    "p7x_forward_parser_exact": (C.c_int, [_VP, _VP, C.c_int32, C.POINTER(C.c_float)]),
     "p7x_longtarget_from_seeds": (C.c_int, [C.POINTER(PipelineCfg), _VP, _VP, _VP, _VP, C.c_size_t, _VP, _VP, _VP, _VP, _VP, _VP, _VP,
                                             C.c_size_t, C.POINTER(_VP)]),
     "p7x_oprofile_write_pressed": (C.c_int, [_VP, C.POINTER(C.c_int64), _VP, C.c_size_t, C.POINTER(C.c_size_t), _VP, C.c_size_t,

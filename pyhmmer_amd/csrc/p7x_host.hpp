@@ -150,6 +150,8 @@ struct LongTargetWindowScorer {
 int longtarget_run_host(const p7x_pipeline_cfg &cfg, const p7x_oprofile *om, const uint8_t *dsq, const int64_t *offsets, const int64_t *lengths,
                         size_t n, const char *const *names, const char *const *accs, const char *const *descs,
                         const std::vector<LongTargetSeed> &seeds, p7x_tophits **out, LongTargetWindowScorer *filters = nullptr);
+int host_forward_parser_exact(const Profile &p, const uint8_t *dsq1, int L, float *sc);     // dsq1[1..L]
+float host_filter_null_score(const Profile &p, const uint8_t *dsq1, int L, bool do_bias);
 void host_prof_dump();
 
 } // namespace p7x
@@ -166,5 +168,6 @@ struct p7x_tophits {
   bool sorted_by_key = false;
   bool scan_collected = false;        // built by p7x_scan_collect(): one query sequence, hits are models
   std::vector<uint8_t> stage;         // scan mode, per-model result: last filter passed by each target (not serialised)
+  std::vector<int32_t> guard_dropped; // targets the F3 guard took out of the device's survivor list (not serialised)
   int64_t nreported = 0, nincluded = 0;
 };

@@ -195,6 +195,107 @@ static int lt_forward_parser(Model &om, const uint8_t *dsq, int L, std::vector<f
   return P7X_OK;
 }
 
+// ---------------------------------------------------------------- Forward parser in upstream's summation order
+// impl_sse/fwdback.c forward_engine() adds its floats in the order the striped 4-lane vectors impose: node k lives in
+// lane z = (k-1) / Q of vector q = (k-1) % Q; xE is four per-lane sums over q (match cells first, delete cells after
+// the delete chain) folded as (l0 + l1) + (l2 + l3); the D->D chain is one serial sweep per lane and then up to three
+// carry sweeps from lane to lane (always three when M < 100, else until no cell grows).  The device kernels and
+// forward_full() above use other (faster) association orders, a few ulps apart -- which only matters for a target
+// whose P-value sits on the F3 threshold.  This routine is the tie-breaker for exactly those targets (the guard in
+// p7x_tophits.cpp): plain scalar code, lane by lane, same operations in the same order.
+// dsq[1..L]; multihit, length model of L as the pipeline configures the parser.
+static int forward_parser_striped(const Profile &p, const uint8_t *dsq, int L, float *ret_sc)
+{
+  const int M = p.M, Q = p.Q4();
+  Model om{ &p, M, {} };
+  om.configure(true, L);
+  const float *bm = om.tf(0), *tMM = om.tf(1), *tIM = om.tf(2), *tDM = om.tf(3), *tMD = om.tf(4), *tMI = om.tf(5), *tII = om.tf(6), *tDD = om.tf(7);
+  struct V { float v[4]; };
+  std::vector<V> mmo((size_t) Q, V{{0, 0, 0, 0}}), dmo = mmo, imo = mmo;
+  // transitions of vector q, lane z (node k = q + 1 + z Q); padding nodes, and the transitions that would leave node M, are zero
+  std::vector<V> vBM((size_t) Q), vMM = vBM, vIM = vBM, vDM = vBM, vMD = vBM, vMI = vBM, vII = vBM, vDD = vBM;
+  for (int q = 0; q < Q; ++q)
+    for (int z = 0; z < 4; ++z) {
+      const int k = q + 1 + z * Q;
+      const bool in = k <= M;
+      vBM[q].v[z] = in ? bm[k] : 0.0f; vMM[q].v[z] = in ? tMM[k] : 0.0f; vIM[q].v[z] = in ? tIM[k] : 0.0f; vDM[q].v[z] = in ? tDM[k] : 0.0f;
+      vMI[q].v[z] = in ? tMI[k] : 0.0f; vII[q].v[z] = in ? tII[k] : 0.0f;
+      vMD[q].v[z] = (k < M) ? tMD[k] : 0.0f; vDD[q].v[z] = (k < M) ? tDD[k] : 0.0f;
+    }
+  auto rightshift = [](const V &a) { return V{{ 0.0f, a.v[0], a.v[1], a.v[2] }}; };
+  float xE = 0.f, xN = 1.f, xJ = 0.f, xB = om.xf[XN][MOVE], xC = 0.f, totscale = 0.0f;
+  std::vector<V> rv((size_t) Q);
+  for (int i = 1; i <= L; ++i) {
+    const float *rf = om.rf(dsq[i]);
+    for (int q = 0; q < Q; ++q) for (int z = 0; z < 4; ++z) { const int k = q + 1 + z * Q; rv[q].v[z] = k <= M ? rf[k] : 0.0f; }
+    V dcv{{0, 0, 0, 0}}, xEv{{0, 0, 0, 0}};
+    V mpv = rightshift(mmo[Q - 1]), dpv = rightshift(dmo[Q - 1]), ipv = rightshift(imo[Q - 1]);
+    for (int q = 0; q < Q; ++q) {
+      V sv;
+      for (int z = 0; z < 4; ++z) {
+        float s = xB * vBM[q].v[z];
+        s = s + mpv.v[z] * vMM[q].v[z];
+        s = s + ipv.v[z] * vIM[q].v[z];
+        s = s + dpv.v[z] * vDM[q].v[z];
+        s = s * rv[q].v[z];
+        sv.v[z] = s;
+        xEv.v[z] = xEv.v[z] + s;
+      }
+      mpv = mmo[q]; dpv = dmo[q]; ipv = imo[q];
+      mmo[q] = sv;
+      dmo[q] = dcv;
+      for (int z = 0; z < 4; ++z) {
+        dcv.v[z] = sv.v[z] * vMD[q].v[z];
+        const float t = mpv.v[z] * vMI[q].v[z];
+        imo[q].v[z] = t + ipv.v[z] * vII[q].v[z];
+      }
+    }
+    dcv = rightshift(dcv);
+    dmo[0] = V{{0, 0, 0, 0}};
+    for (int q = 0; q < Q; ++q)
+      for (int z = 0; z < 4; ++z) { dmo[q].v[z] = dcv.v[z] + dmo[q].v[z]; dcv.v[z] = dmo[q].v[z] * vDD[q].v[z]; }
+    if (M < 100) {
+      for (int j = 1; j < 4; ++j) {
+        dcv = rightshift(dcv);
+        for (int q = 0; q < Q; ++q)
+          for (int z = 0; z < 4; ++z) { dmo[q].v[z] = dcv.v[z] + dmo[q].v[z]; dcv.v[z] = dcv.v[z] * vDD[q].v[z]; }
+      }
+    } else {
+      for (int j = 1; j < 4; ++j) {
+        bool grew = false;
+        dcv = rightshift(dcv);
+        for (int q = 0; q < Q; ++q)
+          for (int z = 0; z < 4; ++z) {
+            const float s = dcv.v[z] + dmo[q].v[z];
+            if (s > dmo[q].v[z]) grew = true;
+            dmo[q].v[z] = s;
+            dcv.v[z] = dcv.v[z] * vDD[q].v[z];
+          }
+        if (!grew) break;
+      }
+    }
+    for (int q = 0; q < Q; ++q) for (int z = 0; z < 4; ++z) xEv.v[z] = dmo[q].v[z] + xEv.v[z];
+    {
+      const float a0 = xEv.v[0] + xEv.v[1], a2 = xEv.v[2] + xEv.v[3];
+      xE = a0 + a2;
+    }
+    xN = xN * om.xf[XN][LOOP];
+    xC = (xC * om.xf[XC][LOOP]) + (xE * om.xf[XE][MOVE]);
+    xJ = (xJ * om.xf[XJ][LOOP]) + (xE * om.xf[XE][LOOP]);
+    xB = (xJ * om.xf[XJ][MOVE]) + (xN * om.xf[XN][MOVE]);
+    if (xE > 1.0e4) {
+      xN = xN / xE; xC = xC / xE; xJ = xJ / xE; xB = xB / xE;
+      const float inv = 1.0 / xE;
+      for (int q = 0; q < Q; ++q) for (int z = 0; z < 4; ++z) { mmo[q].v[z] = mmo[q].v[z] * inv; dmo[q].v[z] = dmo[q].v[z] * inv; imo[q].v[z] = imo[q].v[z] * inv; }
+      totscale += std::log((double) xE);
+      xE = 1.0;
+    }
+  }
+  if (std::isnan(xC) || (L > 0 && xC == 0.0f) || std::isinf(xC)) { *ret_sc = INFINITY; return P7X_ERANGE; }
+  *ret_sc = totscale + std::log((double) (xC * om.xf[XC][MOVE]));
+  return P7X_OK;
+}
+
 // ---------------------------------------------------------------- windows
 struct LtScoreData { std::vector<float> prefix, suffix; };       // [M+1] fractions of the model's maximal length up to / from node k
 
@@ -740,6 +841,10 @@ static int lt_run_host(const p7x_pipeline_cfg &cfg, const p7x_oprofile *om, cons
 } // namespace
 
 // ---- what the device half (p7x_longtarget.hip) needs from here
+// the F3 tie-breaker of p7x_tophits.cpp: Forward parser score in upstream's summation order, and the filter's null score
+int host_forward_parser_exact(const Profile &p, const uint8_t *dsq1, int L, float *sc) { return forward_parser_striped(p, dsq1, L, sc); }
+float host_filter_null_score(const Profile &p, const uint8_t *dsq1, int L, bool do_bias) { return do_bias ? lt_bias_filter(p, dsq1, L) : lt_null1(L); }
+
 int longtarget_setup(const p7x_pipeline_cfg &cfg, const Profile &p, int *max_length, int *sc_thresh, int *xB)
 {
   if (p.abc_type != P7X_DNA && p.abc_type != P7X_RNA) { set_error("long-target pipeline needs a nucleotide model"); return P7X_EINVAL; }
@@ -777,6 +882,12 @@ int longtarget_run_host(const p7x_pipeline_cfg &cfg, const p7x_oprofile *om, con
 using namespace p7x;
 
 extern "C" {
+
+int p7x_forward_parser_exact(const p7x_oprofile *om, const uint8_t *dsq, int32_t L, float *sc)
+{
+  if (!om || !sc || L < 0 || (L > 0 && !dsq)) { set_error("p7x_forward_parser_exact: bad arguments"); return P7X_EINVAL; }
+  return forward_parser_striped(om->p, dsq, L, sc);
+}
 
 int p7x_longtarget_from_seeds(const p7x_pipeline_cfg *cfg, const p7x_oprofile *om,
                               const uint8_t *dsq, const int64_t *offsets, const int64_t *lengths, size_t n,

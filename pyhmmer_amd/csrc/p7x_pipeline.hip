@@ -585,6 +585,8 @@ static StageParams make_params(const Profile &p, const p7x_pipeline_cfg &cfg)
 {
   StageParams s{};
   s.F1 = cfg.do_max ? 1.0 : cfg.F1; s.F2 = cfg.do_max ? 1.0 : cfg.F2; s.F3 = cfg.do_max ? 1.0 : cfg.F3;
+  // the host stage has the last word on targets within the guard band of F3 (p7x_tophits.cpp): let all of them through
+  if (!cfg.do_max && !cfg.long_targets && cfg.f3_guard > 0.0f) s.F3 = cfg.F3 * (1.0 + (double) cfg.f3_guard);
   s.mmu = p.evparam[P7X_MMU]; s.mlambda = p.evparam[P7X_MLAMBDA]; s.vmu = p.evparam[P7X_VMU];
   s.vlambda = p.evparam[P7X_VLAMBDA]; s.ftau = p.evparam[P7X_FTAU]; s.flambda = p.evparam[P7X_FLAMBDA];
   s.do_bias = cfg.do_max ? 0 : cfg.do_biasfilter;

@@ -312,13 +312,43 @@ int host_finish_batch(const p7x_pipeline_cfg &cfg_in, const std::vector<FinishIt
   std::vector<int> q_of((size_t) S);
   for (int q = 0; q < nq; ++q) for (int f = first[(size_t) q]; f < first[(size_t) q + 1]; ++f) q_of[(size_t) f] = q;
   const bool reseed = cfg_in.seed != 0;
+  // F3 guard: the device let every target with P <= F3 (1 + g) through.  Those whose P-value (device Forward score) lies
+  // above F3 (1 - g) are re-scored in the reference's summation order and F3 is applied to that score; the rest keep
+  // the device's score.  <dropped> targets leave the survivor list (and the n_past_fwd count).
+  std::vector<float> fwd_use((size_t) S);
+  std::vector<char> dropped((size_t) S, 0);
+  for (int f = 0; f < S; ++f) { const int q = q_of[(size_t) f]; fwd_use[(size_t) f] = items[(size_t) q].fwdsc[f - first[(size_t) q]]; }
+  if (cfg_in.f3_guard > 0.0f && !cfg_in.do_max && !cfg_in.long_targets) {
+    const double lo = cfg_in.F3 * (1.0 - (double) cfg_in.f3_guard);
+    run_pool(S, [&](int f) {
+      const int q = q_of[(size_t) f], i = f - first[(size_t) q];
+      const FinishItem &it = items[(size_t) q];
+      const Profile &p = it.om->p;
+      const int t = (*it.targets)[(size_t) i];
+      const uint8_t *dsq1 = tg.dsq + tg.off[t] - 1;
+      const float filtersc = host_filter_null_score(p, dsq1, tg.len[t], cfg_in.do_biasfilter != 0);
+      const float s_dev = (float) ((double) (fwd_use[(size_t) f] - filtersc) / kLog2);
+      if (!(exp_surv(s_dev, p.evparam[P7X_FTAU], p.evparam[P7X_FLAMBDA]) > lo)) return;          // clearly inside
+      float exact = 0.0f;
+      if (host_forward_parser_exact(p, dsq1, tg.len[t], &exact) != P7X_OK) return;              // range error: the device's call stands
+      const float s_ex = (float) ((double) (exact - filtersc) / kLog2);
+      if (exp_surv(s_ex, p.evparam[P7X_FTAU], p.evparam[P7X_FLAMBDA]) > cfg_in.F3) dropped[(size_t) f] = 1;
+      else fwd_use[(size_t) f] = exact;
+    });
+    for (int f = 0; f < S; ++f)
+      if (dropped[(size_t) f]) {
+        const int q = q_of[(size_t) f];
+        ths[(size_t) q]->ctr.n_past_fwd--;
+        ths[(size_t) q]->guard_dropped.push_back((*items[(size_t) q].targets)[(size_t) (f - first[(size_t) q])]);
+      }
+  }
   auto finish = [&](int f, DomainDefResult &dd) {
     const int q = q_of[(size_t) f], i = f - first[(size_t) q];
     const FinishItem &it = items[(size_t) q];
     const p7x_pipeline_cfg &cfg = ths[(size_t) q]->cfg;
     const int t = (*it.targets)[(size_t) i];
     const double Zrun = (cfg.Z_setby == P7X_ZSETBY_NTARGETS) ? (double) (t + 1) : cfg.Z;
-    finish_one(cfg, it.om->p, tg.len[t], it.fwdsc[i], Zrun, dd, pend[(size_t) f]);
+    finish_one(cfg, it.om->p, tg.len[t], fwd_use[(size_t) f], Zrun, dd, pend[(size_t) f]);
     if (pend[(size_t) f].have) pend[(size_t) f].hit.seqidx = t;
   };
   // regions come from the device scan when there is one, else from the parsers' rows
@@ -344,6 +374,7 @@ int host_finish_batch(const p7x_pipeline_cfg &cfg_in, const std::vector<FinishIt
   std::vector<DomainDefResult> dds((size_t) S);
   std::vector<std::vector<EnvelopeRequest>> local((size_t) S);
   run_pool(S, [&](int f) {
+    if (dropped[(size_t) f]) return;
     const bool dev = on_device(q_of[(size_t) f]);
     const int st = define(f, dds[(size_t) f], dev ? &local[(size_t) f] : nullptr);
     if (st != P7X_OK) { failed.store(st); return; }
@@ -381,7 +412,7 @@ int host_finish_batch(const p7x_pipeline_cfg &cfg_in, const std::vector<FinishIt
     if (failed.load() == 0)
       run_pool(S, [&](int f) {
         const int q = q_of[(size_t) f];
-        if (!on_device(q)) return;
+        if (!on_device(q) || dropped[(size_t) f]) return;
         const int i = f - first[(size_t) q];
         const int t = (*items[(size_t) q].targets)[(size_t) i];
         domaindef_finish_deferred(items[(size_t) q].om->p, tg.dsq + tg.off[t] - 1, tg.len[t], res[(size_t) q], req_index[(size_t) f], dds[(size_t) f]);
@@ -443,7 +474,11 @@ void host_parallel_for(int n, int nthreads, const std::function<void(int)> &body
   HostPool::get().run(n, nthreads, body);
 }
 
-void tophits_set_stages(p7x_tophits *th, std::vector<uint8_t> &&stage) { th->stage = std::move(stage); }
+void tophits_set_stages(p7x_tophits *th, std::vector<uint8_t> &&stage)
+{
+  th->stage = std::move(stage);
+  for (int32_t t : th->guard_dropped) if ((size_t) t < th->stage.size() && th->stage[(size_t) t] == 4) th->stage[(size_t) t] = 3;
+}
 void tophits_set_total_ms(p7x_tophits *th, double stage1, double stage2) { th->ms[6] = stage1 + stage2; th->ms[10] = stage1; th->ms[11] = stage2; }
 
 } // namespace p7x

@@ -12,14 +12,16 @@ import numpy as np
 from pyhmmer_amd import _lib, plan7
 
 
-def host_search(oracle, hmm, block, pipeline=None, F=(0.02, 1e-3, 1e-5)):
+def host_search(oracle, hmm, block, pipeline=None, F=(0.02, 1e-3, 1e-5), perturb_fwd=None):
+    """The oracle's filter cascade (thresholds F: what the first stage applies) followed by the product's host stage
+    (thresholds of <pipeline>).  perturb_fwd: {target: Forward score handed to the host stage instead of the oracle's}."""
     pipeline = pipeline or plan7.Pipeline(hmm.alphabet)
     bg = pipeline.background
     op = oracle.OracleProfile(hmm, bg, 400)
     pk = block.packed()
     recs, ctr = op.cascade_block(pk, F1=F[0], F2=F[1], F3=F[2], do_bias=pipeline.bias_filter)
     surv = [t for t in range(len(block)) if recs[t].stage == 4]
-    fwdsc = np.array([recs[t].fwdsc for t in surv], dtype=np.float32)
+    fwdsc = np.array([(perturb_fwd or {}).get(t, recs[t].fwdsc) for t in surv], dtype=np.float32)
     fx, bx, off = [], [], []
     pos = 0
     for t in surv:

@@ -425,3 +425,28 @@ def test_config3_profile_library_against_a_proteome(proteome, monkeypatch, reque
     strong_scan = {(hit.name, q.name) for q, th in zip(proteome, scanned) for hit in th if hit.score > 40}
     strong_search = {(hmms[e].name, hit.name) for e, th in enumerate(batched) for hit in th if hit.score > 40}
     assert strong_scan == strong_search and len(pairs_scan) > 0 and len(pairs_search) > 0
+
+
+def test_forward_threshold_ties_are_decided_in_the_reference_order(models, oracle, proteome):
+    """F3 placed exactly on the (reference-order) Forward P-value of a target, and one ulp below it: the number of targets
+    past the Forward filter is what the oracle's arithmetic gives, although the device sums Forward in another order
+    (cfg.f3_guard: the device passes the band around F3, the host stage re-scores it)."""
+    import math
+    hmm = models["PF02826"][0]
+    bg = plan7.Background(hmm.alphabet)
+    op = oracle.OracleProfile(hmm, bg, 400)
+    recs, _ = op.cascade_block(proteome.packed(), F3=1.0)
+    ftau, flam = float(hmm.evalue_parameters.f_tau), float(hmm.evalue_parameters.f_lambda)
+
+    def pval(rec):
+        sc = np.float32((np.float64(np.float32(rec.fwdsc) - np.float32(rec.filtersc))) / 0.69314718055994529)
+        return math.exp(-flam * (float(sc) - ftau)) if float(sc) >= ftau else 1.0
+
+    cand = sorted((t for t in range(len(proteome)) if recs[t].stage >= 4 and 1e-9 < pval(recs[t]) < 1e-2), key=lambda t: pval(recs[t]))
+    assert len(cand) >= 4
+    for t in cand[:: max(1, len(cand) // 4)]:
+        P = pval(recs[t])
+        for F3 in (P, float(np.nextafter(P, 0.0))):
+            want = sum(1 for u in range(len(proteome)) if recs[u].stage >= 4 and not (pval(recs[u]) > F3))
+            hits = plan7.Pipeline(hmm.alphabet, F3=F3).search_hmm(hmm, proteome)
+            assert hits.stage_counts["fwd"] == want, (proteome[t].name, F3)

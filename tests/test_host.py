@@ -310,3 +310,63 @@ def test_query_pipeline_orders_results_and_errors_for_every_shape(libp7x, monkey
     while threading.active_count() > before and __import__("time").time() < deadline:
         __import__("time").sleep(0.05)
     assert threading.active_count() <= before
+
+
+def test_forward_parser_in_reference_summation_order_is_bit_identical_to_the_oracle(models, oracle, proteome):
+    """The F3 tie-breaker (p7x_forward_parser_exact) must be the reference's Forward parser bit for bit: it is
+    compared with the SSE2 restatement of impl_sse/fwdback.c in oracle/ on short (M < 100: three fixed carry sweeps) and
+    long (conditional sweeps) models, including targets long enough to rescale."""
+    import ctypes as C
+    import numpy as np
+    from pyhmmer_amd import _lib, plan7
+    lib = _lib.lib()
+    rng = np.random.default_rng(7)
+    for name, idx in (("RREFam", 0), ("PF02826", 0), ("LuxC", 0)):
+        hmm = models[name][idx]
+        bg = plan7.Background(hmm.alphabet)
+        op = oracle.OracleProfile(hmm, bg, 400)
+        om = plan7.OptimizedProfile(hmm, bg, 400)
+        seqs = [proteome[i] for i in rng.choice(len(proteome), size=25, replace=False)]
+        seqs.sort(key=len)
+        for s in seqs[:12] + seqs[-3:]:
+            st, want = op.fwd(s.sequence)
+            d = np.concatenate([[255], np.asarray(s.sequence, dtype=np.uint8), [255]]).astype(np.uint8)
+            got = C.c_float()
+            st2 = lib.p7x_forward_parser_exact(om._handle, d.ctypes.data, len(s), C.byref(got))
+            assert (st == 0) == (st2 == 0)
+            if st == 0:
+                assert np.float32(got.value).tobytes() == np.float32(want).tobytes(), (name, s.name, got.value, want)
+
+
+def test_f3_guard_follows_the_reference_order_on_the_threshold(models, oracle, proteome):
+    """A target whose Forward P-value is put exactly on F3 (and one ulp beside it) is kept / dropped as the reference's
+    arithmetic says, whatever score the first stage handed over: the first stage lets the guard band through, the host
+    stage re-scores the targets inside it in the reference's summation order."""
+    import math
+    import numpy as np
+    import host_pipeline
+    from pyhmmer_amd import plan7
+    hmm = models["PF02826"][0]
+    bg = plan7.Background(hmm.alphabet)
+    block = proteome[:700]
+    op = oracle.OracleProfile(hmm, bg, 400)
+    recs, _ = op.cascade_block(block.packed(), F3=1.0)             # every Viterbi survivor gets a Forward score
+    ftau, flam = float(hmm.evalue_parameters.f_tau), float(hmm.evalue_parameters.f_lambda)
+
+    def pval(rec):
+        sc = np.float32((np.float64(np.float32(rec.fwdsc) - np.float32(rec.filtersc))) / 0.69314718055994529)
+        return math.exp(-flam * (float(sc) - ftau)) if float(sc) >= ftau else 1.0
+
+    cand = sorted((t for t in range(len(block)) if recs[t].stage >= 4 and 1e-9 < pval(recs[t]) < 1e-2), key=lambda t: pval(recs[t]))
+    assert cand
+    t = cand[len(cand) // 2]
+    P = pval(recs[t])
+    for F3, kept in ((P, True), (float(np.nextafter(P, 0.0)), False)):
+        want = sum(1 for u in range(len(block)) if recs[u].stage >= 4 and not (pval(recs[u]) > F3))
+        for ulps in (-3, 3):                                       # the first stage's score is a few ulps off either way
+            off = np.float32(recs[t].fwdsc)
+            for _ in range(abs(ulps)):
+                off = np.nextafter(off, np.float32(1e30 if ulps > 0 else -1e30))
+            pli = plan7.Pipeline(hmm.alphabet, F3=F3)
+            hits = host_pipeline.host_search(oracle, hmm, block, pipeline=pli, F=(0.02, 1e-3, F3 * (1.0 + 1e-3)), perturb_fwd={t: float(off)})
+            assert hits.stage_counts["fwd"] == want, (F3, kept, ulps)
