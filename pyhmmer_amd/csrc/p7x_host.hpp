@@ -105,6 +105,8 @@ struct FinishItem {
   const p7x_oprofile *om = nullptr;
   const std::vector<int32_t> *targets = nullptr;      // caller indices of the Forward survivors
   const float *fwdsc = nullptr;                       // per survivor
+  const std::vector<char> *near = nullptr;            // which survivors the first stage saw inside the F3 guard band (empty: none;
+                                                      // nullptr: not known, the host stage checks every survivor itself)
   const float *fwd_xmx = nullptr, *bck_xmx = nullptr; const int64_t *xmx_off = nullptr;   // parser rows (when regions == nullptr)
   uint64_t counts[4] = { 0, 0, 0, 0 };                // n_past_{msv,bias,vit,fwd}
   const double *ms = nullptr;

@@ -25,11 +25,12 @@ struct StageBufs {            // all indexed by slot unless noted
   int32_t *list_bias, *list_vit, *list_fwd, *list_fin;
   uint8_t *stage;             // [nslots] last filter passed: 1 MSV, 2 bias, 3 Viterbi, 4 Forward (scan mode accounting)
   int *counters;              // [0] msv groups [1] n_bias(list_bias) [2] n_vit [3] n_fwd [4] n_fin [5..7] work counters
-                              // [8] n_past_bias [9] n_past_vit(reach Forward)
+                              // [8] n_past_bias [9] n_past_vit(reach Forward) [14] Forward survivors inside the F3 guard band
 };
 
 struct StageParams {
   double F1, F2, F3;
+  double F3_near;             // Forward survivors with P above this are listed for the host stage's F3 guard (list_bias is free by then)
   float mmu, mlambda, vmu, vlambda, ftau, flambda;
   int do_bias;
   int base_b, tjb_unused; float scale_b;
@@ -220,7 +221,7 @@ __global__ void decide_fwd_kernel(const ArgRef ref)
   const int n = b.counters[3];
   for (int it0 = blockIdx.x * blockDim.x; it0 < n; it0 += gridDim.x * blockDim.x) {
     const int it = it0 + (int) threadIdx.x;
-    bool take = false; int s = 0;
+    bool take = false, near = false; int s = 0;
     if (it < n) {
       s = b.list_fwd[it];
       const float fwdsc = b.fwd_by_item[it];
@@ -228,9 +229,11 @@ __global__ void decide_fwd_kernel(const ArgRef ref)
       const float seq_score = (float) ((double) (fwdsc - b.filtersc[s]) / kLog2);
       const double P = d_exp_surv((double) seq_score, (double) p.ftau, (double) p.flambda);
       take = !(P > p.F3);
+      near = take && (P > p.F3_near);
       if (take) b.stage[s] = 4;
     }
     wave_append(&b.counters[4], b.list_fin, take, s);
+    wave_append(&b.counters[14], b.list_bias, near, s);
   }
 }
 
@@ -586,7 +589,8 @@ static StageParams make_params(const Profile &p, const p7x_pipeline_cfg &cfg)
   StageParams s{};
   s.F1 = cfg.do_max ? 1.0 : cfg.F1; s.F2 = cfg.do_max ? 1.0 : cfg.F2; s.F3 = cfg.do_max ? 1.0 : cfg.F3;
   // the host stage has the last word on targets within the guard band of F3 (p7x_tophits.cpp): let all of them through
-  if (!cfg.do_max && !cfg.long_targets && cfg.f3_guard > 0.0f) s.F3 = cfg.F3 * (1.0 + (double) cfg.f3_guard);
+  s.F3_near = 2.0;
+  if (!cfg.do_max && !cfg.long_targets && cfg.f3_guard > 0.0f) { s.F3 = cfg.F3 * (1.0 + (double) cfg.f3_guard); s.F3_near = cfg.F3 * (1.0 - (double) cfg.f3_guard); }
   s.mmu = p.evparam[P7X_MMU]; s.mlambda = p.evparam[P7X_MLAMBDA]; s.vmu = p.evparam[P7X_VMU];
   s.vlambda = p.evparam[P7X_VLAMBDA]; s.ftau = p.evparam[P7X_FTAU]; s.flambda = p.evparam[P7X_FLAMBDA];
   s.do_bias = cfg.do_max ? 0 : cfg.do_biasfilter;
@@ -776,6 +780,7 @@ struct CascadeOut {
   std::vector<int64_t> xmx_off;
   std::vector<int32_t> reg_n, regs;       // device region scan: count per survivor (-1 range error), kRegionCap x (i, j, multi)
   std::vector<float> nexpected;
+  std::vector<char> near;                 // per survivor: inside the F3 guard band (empty: none)
   bool have_xmx = false;
   std::vector<uint8_t> stage;             // scan mode: last filter passed, per target (caller order)
   int counts[16]{};
@@ -1147,6 +1152,17 @@ static int cascade_collect(CascadeRun &r, std::vector<CascadeOut> &outs)
     P7X_HIP(hipEventRecord(ws->ev_sync, s)); P7X_HIP(hipEventSynchronize(ws->ev_sync));
     if ((st = fetch_lane_rows(r, out)) != P7X_OK) return st;
   }
+  // Forward survivors inside the F3 guard band (normally none): their slots, matched against the survivor list
+  for (int l = 0; l < nq; ++l) {
+    CascadeOut &out = outs[(size_t) r.query_of[l]];
+    const int nnear = out.counts[14];
+    if (nnear <= 0 || out.fin_slots.empty()) continue;
+    std::vector<int32_t> slots((size_t) nnear);
+    P7X_HIP(hipMemcpy(slots.data(), ws->lane_bufs(l).list_bias, (size_t) nnear * 4, hipMemcpyDeviceToHost));
+    std::sort(slots.begin(), slots.end());
+    out.near.assign(out.fin_slots.size(), 0);
+    for (size_t i = 0; i < out.fin_slots.size(); ++i) out.near[i] = std::binary_search(slots.begin(), slots.end(), out.fin_slots[i]) ? 1 : 0;
+  }
   double ms[8]{};
   for (int i = 0; i < 6; ++i) { float t = 0; (void) hipEventElapsedTime(&t, ws->ev[i], ws->ev[i + 1]); ms[i] = t; }
   { float t = 0; (void) hipEventElapsedTime(&t, ws->ev[0], ws->ev[7]); ms[7] = t; }
@@ -1432,6 +1448,7 @@ int p7x_search_batch_finish(p7x_pending *pd, const char *const *names, const cha
     for (size_t i = 0; i < targets[q].size(); ++i) targets[q][i] = db->h_order[co.fin_slots[i]];
     FinishItem &it = items[q];
     it.om = om; it.targets = &targets[q]; it.fwdsc = co.fwdsc.data();
+    it.near = &co.near;
     it.fwd_xmx = co.fwd_xmx.data(); it.bck_xmx = co.bck_xmx.data(); it.xmx_off = co.xmx_off.data();
     it.counts[0] = (uint64_t) co.counts[1]; it.counts[1] = (uint64_t) co.counts[8]; it.counts[2] = (uint64_t) co.counts[3]; it.counts[3] = (uint64_t) co.counts[4];
     it.ms = co.ms;

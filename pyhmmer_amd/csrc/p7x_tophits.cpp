@@ -323,6 +323,7 @@ int host_finish_batch(const p7x_pipeline_cfg &cfg_in, const std::vector<FinishIt
     run_pool(S, [&](int f) {
       const int q = q_of[(size_t) f], i = f - first[(size_t) q];
       const FinishItem &it = items[(size_t) q];
+      if (it.near && (it.near->empty() || !(*it.near)[(size_t) i])) return;
       const Profile &p = it.om->p;
       const int t = (*it.targets)[(size_t) i];
       const uint8_t *dsq1 = tg.dsq + tg.off[t] - 1;
