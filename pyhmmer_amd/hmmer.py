@@ -460,7 +460,7 @@ def _run_batches(db: "ShardedDatabase", pipelines: Sequence[Pipeline], queries: 
 
 
 def hmmscan(queries, profiles, *, cpus: int = 0, callback: Optional[Callable] = None, devices: Optional[Sequence[int]] = None,
-            pipeline_depth: int = 6, feeders: int = 2, window: int = 2, finishers: int = 0, batch: int = 64,
+            pipeline_depth: int = 3, feeders: int = 3, window: int = 1, finishers: int = 0, batch: int = 64,
             backend: Optional[str] = None, **options) -> Iterator[TopHits]:
     """Scan query sequences against a profile database; yields one ``TopHits`` per query sequence, in query order, whose
     hits are the profiles (reference ``hmmer/_hmmscan.py:90-231``, ``Pipeline.scan_seq`` ``plan7.pyx:6534-6622``).
@@ -474,7 +474,10 @@ def hmmscan(queries, profiles, *, cpus: int = 0, callback: Optional[Callable] = 
     E-values with ``Z`` = number of profiles, per-sequence accounting.  A query block is small next to a search
     database, so one profile's kernels are a few wavefronts running for the length of the longest query: several profiles
     are kept in flight on separate device streams to fill the device: each of the ``feeders`` threads queues the
-    device stage of ``window`` profiles before it waits for the oldest one, at most ``pipeline_depth`` in total.
+    device stage of ``window`` batches of ``batch`` profiles before it waits for the oldest one, at most
+    ``pipeline_depth`` in total.  The defaults are the measured optimum of the 700-profile x 2,100-sequence case
+    (``scripts/scan_bench.py``): a batch of 64 profiles already spreads its length classes over the device's hardware
+    queues, so more than one batch per feeder only makes the batches wait for one another.
     """
     from .easel import DigitalSequence
     from .plan7 import _P7X_SCAN_MODELS

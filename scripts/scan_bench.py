@@ -26,7 +26,7 @@ oms, tb = fresh()
 print(f"{len(oms)} profiles built on the host in {1e3 * tb / len(oms):.3f} ms/profile")
 cells = sum(om.M for om in oms) * block.total_length()
 list(hmmer.hmmscan(block, oms[:28]))          # warm-up: kernels, workspaces
-for batch, feeders, depth, window in ((1, 4, 32, 4), (8, 2, 6, 2), (32, 2, 6, 2), (64, 2, 6, 2), (64, 1, 2, 1), (128, 2, 4, 1), (256, 2, 4, 1)):
+for batch, feeders, depth, window in ((1, 4, 32, 4), (64, 2, 6, 2), (64, 1, 2, 1), (64, 2, 2, 1), (64, 3, 3, 1), (64, 4, 4, 1), (32, 4, 4, 1), (32, 2, 2, 1)):
     oms, _ = fresh()
     t0 = time.perf_counter()
     res = list(hmmer.hmmscan(block, oms, feeders=feeders, pipeline_depth=depth, window=window, batch=batch))
