@@ -404,7 +404,7 @@ def main():
     host_threads = max(2, host_cpus() // max(1, local_world))
 
     qps = max(1, args.queries_per_step)
-    lanes_per_launch = args.batch or hmmer._auto_batch(hmmer.ShardedDatabase.from_database(db))
+    lanes_per_launch = args.batch or hmmer._auto_batch(hmmer.ShardedDatabase.from_database(db), hmm.M)
 
     def run(nsteps):
         """nsteps x queries_per_step searches of the same workload through the public entry point.  hmmsearch overlaps

@@ -193,12 +193,21 @@ def hmmsearch(queries: Union[HMM, Profile, OptimizedProfile, Iterable], sequence
         yield hits
 
 
+_BATCH_CELLS = 6e11        # (profile, target) cells per device batch when the caller leaves the batch size open: ~25 ms of MSV
+_BATCH_MAX = 64
+
+
+def _shard_residues(db: "ShardedDatabase") -> int:
+    return max(1, max(int(_lib.lib().p7x_seqdb_nresidues(sh._handle)) for sh in db.shards))
+
+
 def _auto_batch(db: "ShardedDatabase", M_hint: int = 150) -> int:
-    """Queries per device batch: enough (profile, target) cells per launch set to amortise its fixed cost (a dozen
-    launches, one event wait), few enough that a batch stays a few milliseconds of device time."""
-    res = max(1, max(int(_lib.lib().p7x_seqdb_nresidues(sh._handle)) for sh in db.shards))
-    cells = float(res) * M_hint                       # one query, one shard
-    return int(max(1, min(64, 2e11 // cells)))        # ~8 ms of MSV per batch
+    """Queries of length ``M_hint`` per device batch: enough (profile, target) cells per launch set to amortise its
+    fixed cost (a few dozen launches, one event wait, one pass of the host stage), few enough that the host stage of one
+    batch does not outlast the device stage of the next.  Measured on the MI355X: 4-8 for M = 262 against 3e8 residues,
+    ~32 for the Pfam-shaped library (median M 120) against 1.75e8."""
+    cells = float(_shard_residues(db)) * max(1, M_hint)          # one query, one shard
+    return int(max(1, min(_BATCH_MAX, _BATCH_CELLS // cells)))
 
 
 def _batches(queries: Iterable, size: int) -> Iterator[list]:
@@ -228,9 +237,13 @@ def _run_queries(db: "ShardedDatabase", pipelines: Sequence[Pipeline], queries: 
     Inside a span of ``reorder`` batches the queries are sorted by model length before they are cut into batches:
     profiles of similar length share every kernel instantiation, so a batch is a few launches with many profiles each
     instead of one launch per profile.  Results are held back until every earlier query of the input has been yielded."""
-    if batch <= 0:
-        batch = _auto_batch(db)
+    auto = batch <= 0
+    res = _shard_residues(db) if auto else 0
+    if auto:
+        batch = _BATCH_MAX                # upper bound; the cut below follows the cell budget
     span = batch * max(1, reorder) if batch > 1 else 1
+    if auto:
+        span = 8 * _BATCH_MAX
     order: list = []                      # input index of every query handed to the device, in hand-over order
     inputs: list = []                     # the queries, by input index (dropped once yielded)
     it = iter(queries)
@@ -251,8 +264,19 @@ def _run_queries(db: "ShardedDatabase", pipelines: Sequence[Pipeline], queries: 
                 return
             inputs.extend(chunk)
             idx = sorted(range(len(chunk)), key=lambda i: _query_length(chunk[i])) if span > 1 else list(range(len(chunk)))
-            for lo in range(0, len(idx), batch):
-                part = idx[lo:lo + batch]
+            lo = 0
+            while lo < len(idx):
+                if auto:                      # as many queries as the cell budget holds (short models: many, long ones: few)
+                    hi, cells = lo, 0.0
+                    while hi < len(idx) and hi - lo < _BATCH_MAX:
+                        cells += float(res) * max(1, _query_length(chunk[idx[hi]]) or 150)
+                        if hi > lo and cells > _BATCH_CELLS:
+                            break
+                        hi += 1
+                else:
+                    hi = min(len(idx), lo + batch)
+                part = idx[lo:hi]
+                lo = hi
                 order.extend(base + i for i in part)
                 yield [chunk[i] for i in part]
             base += len(chunk)
