@@ -56,7 +56,7 @@ struct DevProfile {
   int device = -1;
   int M = 0, Kp = 0;
   // MSV: two parity tables of packed int16 pairs, [2][kTabRows][S] dwords
-  int msvR = 0, msvS = 0;
+  int msvR = 0, msvK = 0, msvS = 0;     // lane kernels: row registers per lane, lanes per target, dwords per table row
   uint32_t *msv_tab = nullptr;
   int16_t *msvw_emis = nullptr;     // msvR <= 0 (M > 478): wave-per-target MSV, [kTabRows][Mpad] bias - cost
   // Viterbi: transitions [Mpad][8] int16 (BM,MM,IM,DM,MD,MI,II,DD), emissions [kTabRows][Mpad] int16

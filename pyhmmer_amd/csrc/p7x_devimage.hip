@@ -135,11 +135,11 @@ int get_dev_profile(const p7x_oprofile *om, DeviceCtx *ctx, DevProfile **out)
   stg.fix.clear(); stg.used = 0;
   std::vector<std::vector<char>> parts;
   // MSV parity tables
-  d->msvR = msv_pick_R(p.M);
+  d->msvR = msv_pick(p.M, &d->msvK);
   if (d->msvR > 0) {
-    d->msvS = msv_stride(d->msvR);
+    d->msvS = msv_stride(d->msvR, d->msvK);
     std::vector<uint32_t> tab;
-    msv_build_tables(p, d->msvR, d->msvS, tab);
+    msv_build_tables(p, d->msvR, d->msvK, tab);
     stage_table(stg, parts, &d->msv_tab, tab);
   }
   // wave-per-sequence tables

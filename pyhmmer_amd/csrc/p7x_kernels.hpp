@@ -55,12 +55,12 @@ struct MsvArgs {
   int *amb_count; int *amb_groups; int *counter2;
   const int *group_list; const int *group_count;   // exact kernel: optional list of groups to process
 };
-int  msv_pick_R(int M);
-int  msv_stride(int R);
-void msv_build_tables(const Profile &p, int R, int S, std::vector<uint32_t> &out);
+int  msv_pick(int M, int *K);       // row registers per lane and lanes per target (K = 1, 2, 4) of the lane kernels; -1: none fits
+int  msv_stride(int R, int K);     // dwords per table row
+void msv_build_tables(const Profile &p, int R, int K, std::vector<uint32_t> &out);
 // fast kernel over <main> followed by the exact kernel over each lane's list of ambiguous groups (<amb>: records with
 // group_list / group_count set); amb == nullptr: the exact kernel over every group of <main>
-int  msv_launch(int R, const ArgRun<MsvArgs> &main, const ArgRun<MsvArgs> *amb, int num_cu, hipStream_t st);
+int  msv_launch(int R, int K, const ArgRun<MsvArgs> &main, const ArgRun<MsvArgs> *amb, int num_cu, hipStream_t st);
 
 // ---- wave-per-sequence stages (p7x_vitfwd.hip): Viterbi filter, Forward / Backward parsers
 // Node k = z*C + c + 1 lives in lane z, chunk position c; device tables are stored [c*64 + z].

@@ -37,13 +37,43 @@ __device__ __forceinline__ s2 splat(int v) { s2 r; r.x = (short) v; r.y = (short
 __device__ __forceinline__ s2 swap_halves(s2 v) { return as_s2(__builtin_amdgcn_alignbit(as_u32(v), as_u32(v), 16)); }
 
 
-constexpr int kMsvBlock = 256;
-
 constexpr int msv_stride_c(int R)
 { // smallest S >= R with S/2 odd: the row -> bank-pair map 2*(x*(S/2) mod 32) is then injective for x < 32
   int S = R + (R & 1);
   if (((S / 2) & 1) == 0) S += 2;
   return S;
+}
+// K > 1 lanes per target (models whose row does not fit one lane's registers): lane h of a target holds registers
+// h*R .. h*R + R - 1 of the row and reads them at column h*Rs of the table row.  With Rs = 2 (mod 64) a lane's bank pair is
+// (x*K + h + j/2) mod 32: the K lanes of a target never collide, and two targets only when their residues agree mod 32/K.
+constexpr int msv_lane_stride_c(int R, int K)
+{
+  if (K == 1) return msv_stride_c(R);
+  int s = R + (R & 1);
+  while (s % 64 != 2) s += 2;
+  return s;
+}
+constexpr int msv_row_stride_c(int R, int K) { return K * msv_lane_stride_c(R, K); }      // dwords per table row
+// the even-parity table starts kTabRows rows behind the odd one: as an instruction immediate while that fits 16 bits (K = 1),
+// else as part of the lane's address
+constexpr int msv_even_imm_c(int R, int K) { return K == 1 ? kTabRows * msv_row_stride_c(R, K) * 4 : 0; }
+constexpr int msv_even_add_c(int R, int K) { return K == 1 ? 0 : kTabRows * msv_row_stride_c(R, K) * 4; }
+constexpr int msv_block_c(int K) { return K == 1 ? 256 : 512; }                            // threads per block: K > 1 tables are big, more
+                                                                                           // wavefronts share one copy
+// maximum over the K lanes of a target (K = 1, 2, 4, 8; lanes of a target are consecutive)
+template <int K> __device__ __forceinline__ s2 target_max(s2 m)
+{
+  if constexpr (K >= 2) m = pk_max(m, as_s2((uint32_t) __builtin_amdgcn_update_dpp(0, (int) as_u32(m), 0xB1, 0xf, 0xf, false)));   // quad_perm [1,0,3,2]
+  if constexpr (K >= 4) m = pk_max(m, as_s2((uint32_t) __builtin_amdgcn_update_dpp(0, (int) as_u32(m), 0x4E, 0xf, 0xf, false)));   // quad_perm [2,3,0,1]
+  if constexpr (K >= 8) m = pk_max(m, as_s2((uint32_t) __builtin_amdgcn_update_dpp(0, (int) as_u32(m), 0x141, 0xf, 0xf, false)));  // row_half_mirror
+  return m;
+}
+// the register below a lane's first one: the last register of the lane before it (same target), or <edge> in a target's first lane
+template <int K> __device__ __forceinline__ s2 carry_in(s2 last, s2 edge, int h)
+{
+  if constexpr (K == 1) return edge;
+  const s2 up = as_s2((uint32_t) __builtin_amdgcn_update_dpp(0, (int) as_u32(last), 0x111, 0xf, 0xf, false));      // row_shr:1
+  return h == 0 ? edge : up;
 }
 
 // LDS emission fetch.  hipcc fuses adjacent 8-byte LDS loads into ds_read2_b64, which is serviced in
@@ -82,12 +112,11 @@ __device__ __forceinline__ void lds_wait2(Chunk &c)
 
 // One DP row over the register file: chunks of four register pairs (8 registers, 16 cells); when R is not a multiple
 // of 8 the top chunk holds two pairs.
-template <int R, bool ODD, int T, bool FAST = false>   // T = chunk index being computed
-struct RowChunks {
+template <int R, int TB, bool ODD, int T, bool FAST = false>   // TB = byte offset of the row's parity table that goes into the
+struct RowChunks {                                            // instructions' immediate; T = chunk index being computed
   static_assert(R % 4 == 0, "a row is walked in chunks of 8 registers and a last one of 4: the register count must be a multiple of 4");
   static constexpr int NT = (R + 7) / 8;
-  static constexpr int S = msv_stride_c(R);
-  static constexpr int TBASE = ODD ? 0 : kTabRows * S * 4;
+  static constexpr int TBASE = TB;
   static constexpr int pairs(int t) { return (t == NT - 1 && (R % 8) != 0) ? 2 : 4; }
 
   template <int TT>
@@ -96,13 +125,14 @@ struct RowChunks {
     if constexpr (pairs(TT) == 4) lds_issue4<TBASE + TT * 32>(addr, c); else lds_issue2<TBASE + TT * 32>(addr, c);
   }
 
+  // <carry>: what sits below register 0 (odd rows): the begin score / floor, or the neighbour lane's last register
   template <int JJ>
-  static __device__ __forceinline__ void pair(s2 (&v)[R], const uint2 e, const s2 xB, s2 &accA, s2 &accB)
+  static __device__ __forceinline__ void pair(s2 (&v)[R], const uint2 e, const s2 xB, const s2 carry, s2 &accA, s2 &accB)
   {
     if constexpr (FAST) {       // floored representation: the saturating add *is* max(., xB) (see msv_fast_kernel)
       if constexpr (ODD) {
         v[2 * JJ + 1] = pk_adds(v[2 * JJ], as_s2(e.y));
-        s2 pred = xB;           // xB holds splat(-32768) here: the floor itself
+        s2 pred = carry;
         if constexpr (JJ > 0) pred = v[2 * JJ - 1];
         v[2 * JJ] = pk_adds(pred, as_s2(e.x));
       } else {
@@ -118,7 +148,7 @@ struct RowChunks {
       const s2 t1 = pk_max(v[2 * JJ], xB);
       v[2 * JJ + 1] = t1 + as_s2(e.y);
       accA = pk_max(accA, v[2 * JJ + 1]);
-      s2 t0 = xB;
+      s2 t0 = pk_max(carry, xB);
       if constexpr (JJ > 0) t0 = pk_max(v[2 * JJ - 1], xB);
       v[2 * JJ] = t0 + as_s2(e.x);
       accB = pk_max(accB, v[2 * JJ]);
@@ -131,7 +161,7 @@ struct RowChunks {
   }
 
   // cur holds chunk T (already issued); nxt is free.  ODD rows walk chunks downwards, EVEN rows upwards.
-  static __device__ __forceinline__ void run(s2 (&v)[R], uint32_t addr, Chunk &cur, Chunk &nxt, const s2 xB, s2 &accA, s2 &accB)
+  static __device__ __forceinline__ void run(s2 (&v)[R], uint32_t addr, Chunk &cur, Chunk &nxt, const s2 xB, const s2 carry, s2 &accA, s2 &accB)
   {
     constexpr bool last = ODD ? (T == 0) : (T == NT - 1);
     constexpr int TN = ODD ? T - 1 : T + 1;
@@ -144,55 +174,64 @@ struct RowChunks {
     }
     if constexpr (ODD) {
       if constexpr (np == 4) {
-        pair<4 * T + 3>(v, cur.e3, xB, accA, accB);
-        pair<4 * T + 2>(v, cur.e2, xB, accA, accB);
+        pair<4 * T + 3>(v, cur.e3, xB, carry, accA, accB);
+        pair<4 * T + 2>(v, cur.e2, xB, carry, accA, accB);
       }
-      pair<4 * T + 1>(v, cur.e1, xB, accA, accB);
-      pair<4 * T + 0>(v, cur.e0, xB, accA, accB);
+      pair<4 * T + 1>(v, cur.e1, xB, carry, accA, accB);
+      pair<4 * T + 0>(v, cur.e0, xB, carry, accA, accB);
     } else {
-      pair<4 * T + 0>(v, cur.e0, xB, accA, accB);
-      pair<4 * T + 1>(v, cur.e1, xB, accA, accB);
+      pair<4 * T + 0>(v, cur.e0, xB, carry, accA, accB);
+      pair<4 * T + 1>(v, cur.e1, xB, carry, accA, accB);
       if constexpr (np == 4) {
-        pair<4 * T + 2>(v, cur.e2, xB, accA, accB);
-        pair<4 * T + 3>(v, cur.e3, xB, accA, accB);
+        pair<4 * T + 2>(v, cur.e2, xB, carry, accA, accB);
+        pair<4 * T + 3>(v, cur.e3, xB, carry, accA, accB);
       }
     }
-    if constexpr (!last) RowChunks<R, ODD, TN, FAST>::run(v, addr, nxt, cur, xB, accA, accB);
+    if constexpr (!last) RowChunks<R, TB, ODD, TN, FAST>::run(v, addr, nxt, cur, xB, carry, accA, accB);
   }
 };
 
-template <int R, bool ODD>
-__device__ __forceinline__ void msv_row(s2 (&v)[R], uint32_t x, s2 &xB, s2 &xJ, s2 &xEmax,
+template <int R, int K, bool ODD>
+__device__ __forceinline__ void msv_row(s2 (&v)[R], uint32_t addr, int h, s2 &xB, s2 &xJ, s2 &xEmax,
                                         const s2 basev, const s2 tecv, const s2 tjbmv, const s2 zerov)
 {
-  constexpr int S = msv_stride_c(R), NT = (R + 7) / 8;
+  constexpr int NT = (R + 7) / 8;
   constexpr int T0 = ODD ? NT - 1 : 0;
-  const uint32_t addr = x * (uint32_t) (S * 4);
+  constexpr int TB = ODD ? 0 : msv_even_imm_c(R, K);
+  const s2 carry = ODD ? carry_in<K>(v[R - 1], xB, h) : xB;
   Chunk ca, cb;
-  RowChunks<R, ODD, T0>::template issue<T0>(addr, ca);
+  RowChunks<R, TB, ODD, T0>::template issue<T0>(addr, ca);
   s2 accA = splat(kNegPad), accB = accA;
-  RowChunks<R, ODD, T0>::run(v, addr, ca, cb, xB, accA, accB);
+  RowChunks<R, TB, ODD, T0>::run(v, addr, ca, cb, xB, carry, accA, accB);
   s2 m = pk_max(accA, accB);
   m = pk_max(m, swap_halves(m));
+  m = target_max<K>(m);
   xEmax = pk_max(xEmax, m);          // running row maximum: overflow <=> some xE >= 255 - bias
   m = m - tecv;
   xJ = pk_max(xJ, m);
   xB = pk_max(pk_max(basev, xJ) - tjbmv, zerov);
 }
 
-template <int R>
-__global__ void __launch_bounds__(kMsvBlock) msv_kernel(const ArgRef ref)
+// A work item is a (64-target group, part) pair: with K lanes per target a wavefront holds 64 / K targets, part p of a
+// group are its targets p * 64 / K ...; lane l of the wavefront is lane h = l % K of target l / K of the part.
+template <int K> struct MsvItem {
+  int g, t, h;
+  __device__ __forceinline__ MsvItem(int group, int part, int lane) : g(group), t(part * (64 / K) + lane / K), h(lane % K) {}
+};
+
+template <int R, int K>
+__global__ void __launch_bounds__(msv_block_c(K)) msv_kernel(const ArgRef ref)
 {
   extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
-  constexpr int S = msv_stride_c(R);
+  constexpr int S = msv_row_stride_c(R, K), Rs = msv_lane_stride_c(R, K), BLK = msv_block_c(K);
   const MsvArgs a = load_args<MsvArgs>(ref);
-  const int ngroups = a.group_list ? *a.group_count : a.ngroups - a.group_first;
-  if (ngroups <= 0 || *a.counter >= ngroups) return;          // nothing (left) for this lane: skip the table load
+  const int nitems = (a.group_list ? *a.group_count : a.ngroups - a.group_first) * K;
+  if (nitems <= 0 || *a.counter >= nitems) return;          // nothing (left) for this lane: skip the table load
   {
     constexpr int n4 = (2 * kTabRows * S) / 4;
     const uint4 *src = reinterpret_cast<const uint4 *>(a.tab);
     uint4 *dst = reinterpret_cast<uint4 *>(lds);
-    for (int i = threadIdx.x; i < n4; i += kMsvBlock) dst[i] = src[i];
+    for (int i = threadIdx.x; i < n4; i += BLK) dst[i] = src[i];
   }
   __syncthreads();
 
@@ -200,17 +239,19 @@ __global__ void __launch_bounds__(kMsvBlock) msv_kernel(const ArgRef ref)
   const s2 basev = splat(a.base), tecv = splat(a.tec), zerov = splat(0);
 
   for (;;) {
-    int g = 0;
-    if (lane == 0) g = atomicAdd(a.counter, 1);
-    g = __builtin_amdgcn_readfirstlane(g);
-    if (g >= ngroups) break;
-    g = a.group_list ? __builtin_amdgcn_readfirstlane(a.group_list[g]) : g + a.group_first;
+    int item = 0;
+    if (lane == 0) item = atomicAdd(a.counter, 1);
+    item = __builtin_amdgcn_readfirstlane(item);
+    if (item >= nitems) break;
+    const int gi = item / K;
+    const MsvItem<K> it(a.group_list ? __builtin_amdgcn_readfirstlane(a.group_list[gi]) : gi + a.group_first, item % K, lane);
 
-    const int slot = g * 64 + lane;
+    const int slot = it.g * 64 + it.t;
     const int L = a.slot_len[slot];
-    const int nblk = a.grp_nblk[g];
-    const uint4 *tp = a.tiles + a.grp_off[g] + lane;
+    const int nblk = a.grp_nblk[it.g];
+    const uint4 *tp = a.tiles + a.grp_off[it.g] + it.t;
     const s2 tjbmv = splat((int) a.tjb_tab[L] + a.tbm);
+    const uint32_t lane_col = (uint32_t) it.h * (uint32_t) (Rs * 4);
 
     s2 v[R];
 #pragma unroll
@@ -227,12 +268,12 @@ __global__ void __launch_bounds__(kMsvBlock) msv_kernel(const ArgRef ref)
         const uint32_t x0 = w0 & 0xffu, x1 = (w0 >> 8) & 0xffu;
         w0 = __builtin_amdgcn_alignbit(w1, w0, 16); w1 = __builtin_amdgcn_alignbit(w2, w1, 16);
         w2 = __builtin_amdgcn_alignbit(w3, w2, 16); w3 >>= 16;
-        msv_row<R, true >(v, x0, xB, xJ, xEmax, basev, tecv, tjbmv, zerov);
-        msv_row<R, false>(v, x1, xB, xJ, xEmax, basev, tecv, tjbmv, zerov);
+        msv_row<R, K, true >(v, x0 * (uint32_t) (S * 4) + lane_col, it.h, xB, xJ, xEmax, basev, tecv, tjbmv, zerov);
+        msv_row<R, K, false>(v, x1 * (uint32_t) (S * 4) + lane_col + (uint32_t) msv_even_add_c(R, K), it.h, xB, xJ, xEmax, basev, tecv, tjbmv, zerov);
       }
       cur = nxt;
     }
-    if (L > 0) {
+    if (L > 0 && it.h == 0) {
       const int xe = xEmax.x;
       a.out_xJ[slot] = (xe >= 255 - a.bias) ? (int16_t) -1 : (int16_t) xJ.x;
     }
@@ -253,19 +294,22 @@ __global__ void __launch_bounds__(kMsvBlock) msv_kernel(const ArgRef ref)
 //     three ops beyond its cells (merge, max with T, compare), and xJ / the overflow watermark are folded from the
 //     epoch maximum when an epoch ends: at the (rare, wave-uniform branch) row that moves some lane's begin score
 //     -- every register is then re-biased by the increment (v_pk_sub_i16 clamp) -- and after the last row.
-template <int R>
-__global__ void __launch_bounds__(kMsvBlock, (R <= 92 ? 4 : (R <= 136 ? 3 : 2))) msv_fast_kernel(const ArgRef ref)
+// K > 1: the row of a long model is spread over K consecutive lanes (blocks of R registers).  Per row that adds the
+// neighbour's last register as the carry into an odd row (one DPP move) and the maximum over the K lanes (log2 K DPP
+// steps); everything else, including the begin-score bookkeeping, runs identically in the K lanes.
+template <int R, int K>
+__global__ void __launch_bounds__(msv_block_c(K), (K > 1 ? 2 : (R <= 92 ? 4 : (R <= 136 ? 3 : 2)))) msv_fast_kernel(const ArgRef ref)
 {
   extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
-  constexpr int S = msv_stride_c(R);
+  constexpr int S = msv_row_stride_c(R, K), Rs = msv_lane_stride_c(R, K), BLK = msv_block_c(K);
   const MsvArgs a = load_args<MsvArgs>(ref);
-  const int ngroups = a.ngroups - a.group_first;
-  if (*a.counter >= ngroups) return;            // this lane's groups are all taken: skip the table load
+  const int nitems = (a.ngroups - a.group_first) * K;
+  if (*a.counter >= nitems) return;            // this lane's groups are all taken: skip the table load
   {
     constexpr int n4 = (2 * kTabRows * S) / 4;
     const uint4 *src = reinterpret_cast<const uint4 *>(a.tab);
     uint4 *dst = reinterpret_cast<uint4 *>(lds);
-    for (int i = threadIdx.x; i < n4; i += kMsvBlock) dst[i] = src[i];
+    for (int i = threadIdx.x; i < n4; i += BLK) dst[i] = src[i];
   }
   __syncthreads();
 
@@ -274,17 +318,18 @@ __global__ void __launch_bounds__(kMsvBlock, (R <= 92 ? 4 : (R <= 136 ? 3 : 2)))
   constexpr int NT = (R + 7) / 8;
 
   for (;;) {
-    int g = 0;
-    if (lane == 0) g = atomicAdd(a.counter, 1);
-    g = __builtin_amdgcn_readfirstlane(g);
-    if (g >= ngroups) break;
-    g += a.group_first;
+    int item = 0;
+    if (lane == 0) item = atomicAdd(a.counter, 1);
+    item = __builtin_amdgcn_readfirstlane(item);
+    if (item >= nitems) break;
+    const MsvItem<K> it(item / K + a.group_first, item % K, lane);
 
-    const int slot = g * 64 + lane;
+    const int slot = it.g * 64 + it.t;
     const int L = a.slot_len[slot];
-    const int nblk = a.grp_nblk[g];
-    const uint2 *tp = reinterpret_cast<const uint2 *>(a.tiles + a.grp_off[g] + lane);   // this lane's 16 residues of a tile: tp[0], tp[1]
+    const int nblk = a.grp_nblk[it.g];
+    const uint2 *tp = reinterpret_cast<const uint2 *>(a.tiles + a.grp_off[it.g] + it.t);   // this target's 16 residues of a tile: tp[0], tp[1]
     const int tjbm = (int) a.tjb_tab[L] + a.tbm;
+    const uint32_t lane_col = (uint32_t) it.h * (uint32_t) (Rs * 4);
 
     s2 v[R];
 #pragma unroll
@@ -303,8 +348,8 @@ __global__ void __launch_bounds__(kMsvBlock, (R <= 92 ? 4 : (R <= 136 ? 3 : 2)))
     };
 
     uint2 cur = tp[0];
-    for (int h = 0; h < 2 * nblk; ++h) {          // 8 residues at a time
-      const uint2 nxt = (h + 1 < 2 * nblk) ? tp[(size_t) ((h + 1) >> 1) * 128 + ((h + 1) & 1)] : cur;
+    for (int hb = 0; hb < 2 * nblk; ++hb) {          // 8 residues at a time
+      const uint2 nxt = (hb + 1 < 2 * nblk) ? tp[(size_t) ((hb + 1) >> 1) * 128 + ((hb + 1) & 1)] : cur;
       uint32_t w0 = cur.x, w1 = cur.y;
 #pragma unroll 1
       for (int c = 0; c < 4; ++c) {
@@ -314,15 +359,16 @@ __global__ void __launch_bounds__(kMsvBlock, (R <= 92 ? 4 : (R <= 136 ? 3 : 2)))
         for (int half = 0; half < 2; ++half) {
           Chunk ca, cb;
           if (half == 0) {        // odd row
-            const uint32_t addr = x0 * (uint32_t) (S * 4);
-            RowChunks<R, true, NT - 1, true>::template issue<NT - 1>(addr, ca);
-            RowChunks<R, true, NT - 1, true>::run(v, addr, ca, cb, floorv, accA, accB);
+            const uint32_t addr = x0 * (uint32_t) (S * 4) + lane_col;
+            const s2 carry = carry_in<K>(v[R - 1], floorv, it.h);
+            RowChunks<R, 0, true, NT - 1, true>::template issue<NT - 1>(addr, ca);
+            RowChunks<R, 0, true, NT - 1, true>::run(v, addr, ca, cb, floorv, carry, accA, accB);
           } else {                // even row
-            const uint32_t addr = x1 * (uint32_t) (S * 4);
-            RowChunks<R, false, 0, true>::template issue<0>(addr, ca);
-            RowChunks<R, false, 0, true>::run(v, addr, ca, cb, floorv, accA, accB);
+            const uint32_t addr = x1 * (uint32_t) (S * 4) + lane_col + (uint32_t) msv_even_add_c(R, K);
+            RowChunks<R, msv_even_imm_c(R, K), false, 0, true>::template issue<0>(addr, ca);
+            RowChunks<R, msv_even_imm_c(R, K), false, 0, true>::run(v, addr, ca, cb, floorv, floorv, accA, accB);
           }
-          const s2 m2 = pk_max(accA, accB);
+          const s2 m2 = target_max<K>(pk_max(accA, accB));
           if (__builtin_expect(__any(as_u32(pk_max(m2, Tv)) != as_u32(Tv)), 0)) {
             asm volatile("; re-bias: the begin score moved" ::: "memory");   // keeps this a real (rare) branch: no if-conversion
             const int xBn = fold(m2);
@@ -336,33 +382,52 @@ __global__ void __launch_bounds__(kMsvBlock, (R <= 92 ? 4 : (R <= 136 ? 3 : 2)))
       }
       cur = nxt;
     }
-    fold(pk_max(accA, accB));
+    fold(target_max<K>(pk_max(accA, accB)));
     const bool ambiguous = (L > 0) && (xJ == F0) && !(xEmax >= 255 - a.bias);
-    if (L > 0) a.out_xJ[slot] = (xEmax >= 255 - a.bias) ? (int16_t) -1 : (int16_t) xJ;
-    if (__any(ambiguous) && lane == 0) { const int idx = atomicAdd(a.amb_count, 1); a.amb_groups[idx] = g; }
+    if (L > 0 && it.h == 0) a.out_xJ[slot] = (xEmax >= 255 - a.bias) ? (int16_t) -1 : (int16_t) xJ;
+    if (__any(ambiguous) && lane == 0) { const int idx = atomicAdd(a.amb_count, 1); a.amb_groups[idx] = it.g; }
   }
 }
 
 // ---------------------------------------------------------------------------- host side
 
+// One lane per target up to 224 row registers (M <= 445); two lanes (M <= 893) and four lanes (M <= 1021) beyond, while
+// the parity tables of the K lanes (256 * K * Rs bytes) fit the CU's LDS.  Longer models: wave-per-target kernel.
 static const int kRList[] = { 8, 12, 16, 20, 24, 28, 32, 36, 40, 44, 48, 52, 56, 60, 64, 68, 72, 76, 80, 84, 88, 92, 96, 100, 104, 108,
-                              112, 116, 120, 124, 128, 132, 136, 140, 144, 148, 152, 156, 160, 176, 192, 208, 224, 240 };
+                              112, 116, 120, 124, 128, 132, 136, 140, 144, 148, 152, 156, 160, 176, 192, 208, 224 };
+static const int kRList2[] = { 120, 128, 136, 144, 152, 160, 168, 176, 184, 192, 200, 208, 216, 224 };
+static const int kRList4[] = { 120, 128 };
 
-int msv_pick_R(int M)
+int msv_pick(int M, int *K)
 {
   const int need = (M + 1) / 2 + 1;   // odd rows hold cells (2j-1, 2j): node M needs register (M+1)/2
+  *K = 1;
   for (int r : kRList) if (r >= need) return r;
+  *K = 2;
+  for (int r : kRList2) if (2 * r >= need) return r;
+  *K = 4;
+  for (int r : kRList4) if (4 * r >= need) return r;
+  *K = 0;
   return -1;
 }
 
-int msv_stride(int R) { return msv_stride_c(R); }
+static int row_stride(int R, int K)
+{
+  int rs = R + (R & 1);
+  if (K == 1) { if (((rs / 2) & 1) == 0) rs += 2; return rs; }
+  while (rs % 64 != 2) rs += 2;
+  return K * rs;
+}
+int msv_stride(int R, int K) { return row_stride(R, K); }
 
 // Build the two parity tables from un-striped biased costs rb[x][k] (k = 1..M):
 //   signed emission s[x][k] = bias - rb[x][k]  (the value sbv holds, impl_sse/p7_oprofile.pxd: sbv)
 //   odd  table, register j: (s[2j-1], s[2j]);  even table, register j: (s[2j], s[2j+1])
-// nodes < 1 or > M, and the pad residue row, get kNegPad.
-void msv_build_tables(const Profile &p, int R, int S, std::vector<uint32_t> &out)
+// nodes < 1 or > M, and the pad residue row, get kNegPad.  K lanes per target: register j = h * R + r of the row is
+// register r of lane h and sits at column h * (S / K) + r of the table row.
+void msv_build_tables(const Profile &p, int R, int K, std::vector<uint32_t> &out)
 {
+  const int S = row_stride(R, K), Rs = S / K;
   out.assign((size_t) 2 * kTabRows * S, 0);
   auto sval = [&](int x, int k) -> int {
     if (x >= p.Kp || k < 1 || k > p.M) return kNegPad;
@@ -370,17 +435,20 @@ void msv_build_tables(const Profile &p, int R, int S, std::vector<uint32_t> &out
   };
   auto pack = [](int lo, int hi) -> uint32_t { return ((uint32_t) (uint16_t) (int16_t) lo) | ((uint32_t) (uint16_t) (int16_t) hi << 16); };
   for (int x = 0; x < kTabRows; ++x)
-    for (int j = 0; j < S; ++j) {
-      const bool live = j < R;
-      out[((size_t) 0 * kTabRows + x) * S + j] = live ? pack(sval(x, 2 * j - 1), sval(x, 2 * j)) : pack(kNegPad, kNegPad);
-      out[((size_t) 1 * kTabRows + x) * S + j] = live ? pack(sval(x, 2 * j), sval(x, 2 * j + 1)) : pack(kNegPad, kNegPad);
-    }
+    for (int h = 0; h < K; ++h)
+      for (int r = 0; r < Rs; ++r) {
+        const bool live = r < R;
+        const int j = h * R + r;
+        out[((size_t) 0 * kTabRows + x) * S + (size_t) h * Rs + r] = live ? pack(sval(x, 2 * j - 1), sval(x, 2 * j)) : pack(kNegPad, kNegPad);
+        out[((size_t) 1 * kTabRows + x) * S + (size_t) h * Rs + r] = live ? pack(sval(x, 2 * j), sval(x, 2 * j + 1)) : pack(kNegPad, kNegPad);
+      }
 }
 
-template <int R>
-static int launch_R(const ArgRun<MsvArgs> &main, const ArgRun<MsvArgs> *amb, int num_cu, hipStream_t st)
+template <int R, int K>
+static int launch_RK(const ArgRun<MsvArgs> &main, const ArgRun<MsvArgs> *amb, int num_cu, hipStream_t st)
 {
-  const size_t lds_bytes = (size_t) 2 * kTabRows * msv_stride_c(R) * 4;
+  constexpr int BLK = msv_block_c(K);
+  const size_t lds_bytes = (size_t) 2 * kTabRows * msv_row_stride_c(R, K) * 4;
   // occupancy and the LDS opt-in are per kernel instantiation: looked up once
   struct Info { int per_cu_exact = 0, per_cu_fast = 0; bool ok = false; };
   static Info info;
@@ -389,21 +457,22 @@ static int launch_R(const ArgRun<MsvArgs> &main, const ArgRun<MsvArgs> *amb, int
     std::lock_guard<std::mutex> lk(mu);
     if (!info.ok) {
       if (lds_bytes > 64 * 1024) {
-        P7X_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&msv_kernel<R>), hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds_bytes));
-        P7X_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&msv_fast_kernel<R>), hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds_bytes));
+        P7X_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&msv_kernel<R, K>), hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds_bytes));
+        P7X_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&msv_fast_kernel<R, K>), hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds_bytes));
       }
-      P7X_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&info.per_cu_exact, msv_kernel<R>, kMsvBlock, lds_bytes));
-      P7X_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&info.per_cu_fast, msv_fast_kernel<R>, kMsvBlock, lds_bytes));
+      P7X_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&info.per_cu_exact, msv_kernel<R, K>, BLK, lds_bytes));
+      P7X_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&info.per_cu_fast, msv_fast_kernel<R, K>, BLK, lds_bytes));
       if (info.per_cu_exact < 1) info.per_cu_exact = 1;
       if (info.per_cu_fast < 1) info.per_cu_fast = 1;
       info.ok = true;
     }
   }
+  constexpr int wpb = BLK / 64;          // wavefronts (work items in flight) per block
   long want = 1;
-  for (int i = 0; i < main.n; ++i) want = std::max<long>(want, ((long) (main.at(i).ngroups - main.at(i).group_first) + 3) / 4);
+  for (int i = 0; i < main.n; ++i) want = std::max<long>(want, ((long) (main.at(i).ngroups - main.at(i).group_first) * K + wpb - 1) / wpb);
   if (amb == nullptr) {           // exact kernel over every group
     const unsigned gx = lane_grid(want, (long) num_cu * info.per_cu_exact, main.n);
-    hipLaunchKernelGGL(msv_kernel<R>, dim3(gx, (unsigned) main.n), dim3(kMsvBlock), lds_bytes, st, main.ref());
+    hipLaunchKernelGGL((msv_kernel<R, K>), dim3(gx, (unsigned) main.n), dim3(BLK), lds_bytes, st, main.ref());
     P7X_HIP(hipGetLastError());
     return P7X_OK;
   }
@@ -413,23 +482,30 @@ static int launch_R(const ArgRun<MsvArgs> &main, const ArgRun<MsvArgs> *amb, int
   static const int cap = std::getenv("P7X_MSV_BLOCKS_PER_CU") ? std::atoi(std::getenv("P7X_MSV_BLOCKS_PER_CU")) : 0;
   if (cap > 0 && per_cu2 > cap) per_cu2 = cap;
   const unsigned gx2 = lane_grid(want, (long) num_cu * per_cu2, main.n);
-  hipLaunchKernelGGL(msv_fast_kernel<R>, dim3(gx2, (unsigned) main.n), dim3(kMsvBlock), lds_bytes, st, main.ref());
+  hipLaunchKernelGGL((msv_fast_kernel<R, K>), dim3(gx2, (unsigned) main.n), dim3(BLK), lds_bytes, st, main.ref());
   P7X_HIP(hipGetLastError());
-  hipLaunchKernelGGL(msv_kernel<R>, dim3(lane_grid(32, 32, amb->n), (unsigned) amb->n), dim3(kMsvBlock), lds_bytes, st, amb->ref());
+  hipLaunchKernelGGL((msv_kernel<R, K>), dim3(lane_grid(32, 32, amb->n), (unsigned) amb->n), dim3(BLK), lds_bytes, st, amb->ref());
   P7X_HIP(hipGetLastError());
   return P7X_OK;
 }
 
-int msv_launch(int R, const ArgRun<MsvArgs> &main, const ArgRun<MsvArgs> *amb, int num_cu, hipStream_t st)
+int msv_launch(int R, int K, const ArgRun<MsvArgs> &main, const ArgRun<MsvArgs> *amb, int num_cu, hipStream_t st)
 {
   if (main.n <= 0) return P7X_OK;
-  switch (R) {
-#define P7X_CASE(r) case r: return launch_R<r>(main, amb, num_cu, st);
+  switch (K * 1000 + R) {
+#define P7X_CASE(r) case 1000 + r: return launch_RK<r, 1>(main, amb, num_cu, st);
     P7X_CASE(8) P7X_CASE(12) P7X_CASE(16) P7X_CASE(20) P7X_CASE(24) P7X_CASE(28) P7X_CASE(32) P7X_CASE(36) P7X_CASE(40)
     P7X_CASE(44) P7X_CASE(48) P7X_CASE(52) P7X_CASE(56) P7X_CASE(60) P7X_CASE(64) P7X_CASE(68) P7X_CASE(72) P7X_CASE(76)
     P7X_CASE(80) P7X_CASE(84) P7X_CASE(88) P7X_CASE(92) P7X_CASE(96) P7X_CASE(100) P7X_CASE(104) P7X_CASE(108) P7X_CASE(112)
     P7X_CASE(116) P7X_CASE(120) P7X_CASE(124) P7X_CASE(128) P7X_CASE(132) P7X_CASE(136) P7X_CASE(140) P7X_CASE(144)
-    P7X_CASE(148) P7X_CASE(152) P7X_CASE(156) P7X_CASE(160) P7X_CASE(176) P7X_CASE(192) P7X_CASE(208) P7X_CASE(224) P7X_CASE(240)
+    P7X_CASE(148) P7X_CASE(152) P7X_CASE(156) P7X_CASE(160) P7X_CASE(176) P7X_CASE(192) P7X_CASE(208) P7X_CASE(224)
+#undef P7X_CASE
+#define P7X_CASE(r) case 2000 + r: return launch_RK<r, 2>(main, amb, num_cu, st);
+    P7X_CASE(120) P7X_CASE(128) P7X_CASE(136) P7X_CASE(144) P7X_CASE(152) P7X_CASE(160) P7X_CASE(168) P7X_CASE(176)
+    P7X_CASE(184) P7X_CASE(192) P7X_CASE(200) P7X_CASE(208) P7X_CASE(216) P7X_CASE(224)
+#undef P7X_CASE
+#define P7X_CASE(r) case 4000 + r: return launch_RK<r, 4>(main, amb, num_cu, st);
+    P7X_CASE(120) P7X_CASE(128)
 #undef P7X_CASE
     default: set_error("msv_launch: unsupported register tile"); return P7X_EINVAL;
   }

@@ -720,7 +720,7 @@ struct LaneClass { int first = 0, n = 0; long msv_key = 0, vit_key = 0; int C = 
 
 static long msv_key_of(const DevProfile *dp, bool small)
 { // M > 478, or too few targets for one per lane: wave-per-target kernel (key < 0), else the register tile
-  return (dp->msvR <= 0 || small) ? -(long) dp->vitC : (long) dp->msvR;
+  return (dp->msvR <= 0 || small) ? -(long) dp->vitC : (long) (dp->msvK * 1000 + dp->msvR);
 }
 static long vit_key_of(const DevProfile *dp, bool small)
 {
@@ -754,7 +754,7 @@ static int class_msv(const LaneClass &c, const std::vector<LaneModel> &lm, Devic
     if (st != P7X_OK) return st;
   }
   const ArgRun<MsvArgs> amb = lane_run(ws, &LaneArgs::msv_amb, c.first, c.n);
-  return msv_launch(lm[c.first].dp->msvR, lane_run(ws, &LaneArgs::msv, c.first, c.n), g_msv_exact_only ? nullptr : &amb, ctx->num_cu, stream);
+  return msv_launch(lm[c.first].dp->msvR, lm[c.first].dp->msvK, lane_run(ws, &LaneArgs::msv, c.first, c.n), g_msv_exact_only ? nullptr : &amb, ctx->num_cu, stream);
 }
 
 // Viterbi filter over the lanes' work lists: the packed kernel when the model fits it, else one target per wavefront.

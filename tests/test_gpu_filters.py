@@ -205,8 +205,14 @@ def _model_block(hmm, nrand, nhom, seed):
 
 # one model length per register-count instantiation of the MSV kernels (R = M/2+1 rounded up to the R list) and per
 # nodes-per-lane instantiation C of the wavefront kernels (C = ceil(M/64) rounded up to the C list)
-_R_LIST = [8, 16, 24, 32, 40, 48, 56, 64, 72, 80, 88, 96, 104, 112, 120, 128, 136, 144, 152, 160, 176, 192, 208, 224, 240]
-SWEEP_M = [1, 2, 3] + [m for r in _R_LIST for m in (2 * (r - 1) - 1, 2 * (r - 1))]    # largest odd and even M per R
+# K lanes per target: one lane up to 224 registers, two lanes (8-register steps) and four lanes beyond (p7x_msv.hip: msv_pick)
+_R_LIST = list(range(8, 161, 4)) + [176, 192, 208, 224]
+_R_LIST2 = list(range(120, 225, 8))
+_R_LIST4 = [120, 128]
+SWEEP_M = ([1, 2, 3] + [m for r in _R_LIST for m in (2 * (r - 1) - 1, 2 * (r - 1))]       # largest odd and even M per R
+           + [m for r in _R_LIST2 for m in (2 * (2 * r - 1) - 1, 2 * (2 * r - 1))]
+           + [m for r in _R_LIST4 for m in (2 * (4 * r - 1) - 1, 2 * (4 * r - 1))]
+           + [447, 448, 449, 894, 895, 1022, 1023])                                         # the seams between the families
 
 
 @pytest.mark.parametrize("M", SWEEP_M)
