@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define P7X_ABI_VERSION 3
+#define P7X_ABI_VERSION 4
 
 enum {
   P7X_OK = 0, P7X_EMEM = 5, P7X_EFORMAT = 7, P7X_EINVAL = 11, P7X_ERANGE = 16, P7X_ENORESULT = 19,

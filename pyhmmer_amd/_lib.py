@@ -226,7 +226,7 @@ def lib() -> C.CDLL:
             fn = getattr(l, name)      # AttributeError if the ABI is incomplete
             fn.restype = res
             fn.argtypes = args
-        if l.p7x_abi_version() != 3:
+        if l.p7x_abi_version() != 4:
             raise ImportError("libp7x ABI version mismatch; rebuild")
         _lib = l
     return _lib
