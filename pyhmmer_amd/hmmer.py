@@ -198,6 +198,10 @@ _BATCH_MAX = 64
 
 
 def _shard_residues(db: "ShardedDatabase") -> int:
+    """Residues of the largest shard (what one device sees of a query)."""
+    known = getattr(db, "shard_residues", None)
+    if known is not None:
+        return max(1, int(known))
     return max(1, max(int(_lib.lib().p7x_seqdb_nresidues(sh._handle)) for sh in db.shards))
 
 

@@ -312,6 +312,41 @@ def test_query_pipeline_orders_results_and_errors_for_every_shape(libp7x, monkey
     assert threading.active_count() <= before
 
 
+def test_automatic_batches_follow_the_cell_budget():
+    """batch=0: queries are sorted by model length inside a span and cut so that a batch holds at most the cell budget
+    (short models: up to 64 per batch, long ones: few), results still come back in input order."""
+    import random
+    from pyhmmer_amd import hmmer
+
+    class Q:
+        def __init__(self, i, M):
+            self.i, self.M = i, M
+
+    class Recorder(_FakeShards):
+        shard_residues = 100_000_000
+
+        def __init__(self):
+            super().__init__(3)
+            self.batches = []
+
+        def enqueue(self, pipelines, qs):
+            self.batches.append([q.M for q in qs])
+            return super().enqueue(pipelines, qs)
+
+    rnd = random.Random(5)
+    qs = [Q(i, rnd.choice((40, 90, 150, 400, 1200, 3000))) for i in range(700)]
+    db = Recorder()
+    out = list(hmmer._run_queries(db, [None], iter(qs), 3, 2, 1, 0, batch=0))
+    assert [q.i for q, _ in out] == list(range(700))
+    assert sum(len(b) for b in db.batches) == 700
+    budget = hmmer._BATCH_CELLS
+    for b in db.batches:
+        assert 1 <= len(b) <= hmmer._BATCH_MAX and b == sorted(b)
+        assert len(b) == 1 or sum(b) * Recorder.shard_residues <= budget * (1 + 1e-9)
+    assert max(len(b) for b in db.batches) == hmmer._BATCH_MAX          # 40-node models: the cap, not the budget
+    assert any(b == [3000, 3000] for b in db.batches)                    # 3e11 cells each: two per batch
+
+
 def test_forward_parser_in_reference_summation_order_is_bit_identical_to_the_oracle(models, oracle, proteome):
     """The F3 tie-breaker (p7x_forward_parser_exact) must be the reference's Forward parser bit for bit: it is
     compared with the SSE2 restatement of impl_sse/fwdback.c in oracle/ on short (M < 100: three fixed carry sweeps) and
