@@ -20,7 +20,7 @@ from . import _lib
 from .easel import Alphabet, DigitalSequenceBlock, SequenceFile
 from .plan7 import HMM, LongTargetsPipeline, OptimizedProfile, Pipeline, Profile, SequenceDatabase, TopHits
 
-__all__ = ["hmmsearch", "hmmscan", "nhmmer", "hmmpress", "make_chunks", "ShardedDatabase"]
+__all__ = ["hmmsearch", "hmmscan", "nhmmer", "hmmpress", "make_chunks", "ShardedDatabase", "ReplicatedDatabase"]
 
 
 def make_chunks(block: DigitalSequenceBlock, n: int) -> List[DigitalSequenceBlock]:
@@ -114,6 +114,29 @@ class ShardedDatabase:
             self.abandon(pendings)
             raise
         return self.finish(pendings)
+
+
+class ReplicatedDatabase(ShardedDatabase):
+    """The whole block resident on every device; a batch of queries runs on ONE of them, dealt round robin.  This is the
+    multi-device mode of the scan orientation (few sequences, many profiles: SURVEY.md 8e "for config 3 shard profiles
+    instead"): nothing has to be merged, every profile's result comes from a single device."""
+
+    def __init__(self, block: DigitalSequenceBlock, devices: Sequence[int]):
+        self.block = block
+        self.devices = list(devices)
+        self.chunks = [block] * len(self.devices)
+        self.shards = [SequenceDatabase(block, device=d) for d in self.devices]
+        self._next = 0
+        self._deal = threading.Lock()
+
+    def enqueue(self, pipelines: Sequence[Pipeline], queries) -> list:
+        with self._deal:
+            i = self._next
+            self._next = (i + 1) % len(self.shards)
+        return [pipelines[i]._search_enqueue_batch(queries, self.shards[i])]
+
+    def finish(self, pendings: list) -> List[TopHits]:
+        return Pipeline._search_finish_batch(pendings[0])
 
 
 def hmmpress(hmms: Iterable, output) -> int:
@@ -527,8 +550,9 @@ def hmmscan(queries, profiles, *, cpus: int = 0, callback: Optional[Callable] = 
     if _lib.lib().p7x_device_count() < 1:
         from .errors import DeviceUnavailable
         raise DeviceUnavailable("hmmscan: no HIP device is usable and there is no CPU fallback")
-    devs = [devices[0]] if devices else [0]            # the query block is small by construction: one device
-    db = ShardedDatabase(queries, devs)
+    devs = list(devices) if devices else [0]
+    # the query block is small by construction: every device holds all of it and takes its share of the profiles
+    db = ReplicatedDatabase(queries, devs) if len(devs) > 1 else ShardedDatabase(queries, devs)
     pipelines = [Pipeline(alphabet, device=d, host_threads=cpus, **options) for d in devs]
     for p in pipelines:
         p._mode = _P7X_SCAN_MODELS

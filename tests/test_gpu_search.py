@@ -450,3 +450,19 @@ def test_forward_threshold_ties_are_decided_in_the_reference_order(models, oracl
             want = sum(1 for u in range(len(proteome)) if recs[u].stage >= 4 and not (pval(recs[u]) > F3))
             hits = plan7.Pipeline(hmm.alphabet, F3=F3).search_hmm(hmm, proteome)
             assert hits.stage_counts["fwd"] == want, (proteome[t].name, F3)
+
+
+def test_hmmscan_deals_profile_batches_over_devices(models, proteome):
+    """Multi-device scan orientation (few sequences, many profiles -> shard the profiles): every device holds
+    the whole query block and takes batches of profiles in turn.  With the one device of the test box listed twice the
+    dealing, the ordering and the transposition are exercised; results must equal the single-device scan."""
+    profs = (models["RREFam"] + models["PF02826"] + models["Thioesterase"]) * 3
+    sub = proteome[:600]
+    one = list(hmmer.hmmscan(sub, profs, batch=4))
+    two = list(hmmer.hmmscan(sub, profs, devices=[0, 0], batch=4))
+    assert len(one) == len(two) == len(sub)
+    for a, b in zip(one, two):
+        assert a.searched_models == b.searched_models == len(profs)
+        assert [(h.name, h.score, h.evalue, len(h.domains)) for h in a] == [(h.name, h.score, h.evalue, len(h.domains)) for h in b]
+    db = hmmer.ReplicatedDatabase(sub, [0, 0])
+    assert [sh.device for sh in db.shards] == [0, 0] and all(len(sh.block) == len(sub) for sh in db.shards)
