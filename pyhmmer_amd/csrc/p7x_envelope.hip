@@ -7,10 +7,13 @@
 //   4. optimal-accuracy traceback                                       (optacc.c  p7_OATrace)
 //
 // Layout is the one of the parsers in p7x_vitfwd.hip: lane z owns nodes z*C+1 .. z*C+C, device tables are
-// [c*64 + lane].  Steps 1 and 2 park their M and I rows in a per-wavefront HBM workspace (D is not needed:
-// posterior decoding leaves D at zero); step 3 streams both back once, row by row, keeps the OA row in
-// registers and writes one byte of back-pointers per cell; step 4 is a serial walk over those bytes by lane 0,
-// followed by a lane-parallel pass that attaches the posterior probability of every emitted residue.
+// [c*64 + lane].  Step 1 keeps only the envelope score and the per-row scale factors; step 2 parks Backward's M and I
+// rows in a per-wavefront HBM workspace (D is not needed: posterior decoding leaves D at zero); step 3 streams them back
+// once, row by row, while it runs Forward AGAIN next to them (same code as step 1: bit-identical values), keeps the OA
+// row in registers and writes 16 bits per cell: the back-pointers and the posterior digits of the M and I cell (all the
+// alignment display needs of the posteriors); step 4 is a serial walk over those by lane 0, followed by a lane-parallel
+// pass that attaches the posterior digit of every emitted residue.  8 + 8 + 2 bytes of HBM traffic per cell (round 1:
+// 16 + 16 + 1); lanes whose nodes are all padding move nothing.
 // The host (p7x_domaindef.cpp) turns the trace into the alignment display and applies the null2 correction.
 #include <cstdlib>
 #include <cstdio>
@@ -43,6 +46,82 @@ __device__ __forceinline__ void phase_fence()
 
 // One block per CU: its wavefronts (env_waves(C): 12 where the row registers allow three per SIMD, else 8) share one
 // copy of the profile tables in LDS and each walks its own envelopes.
+// One row of the unihit Forward recurrence on the envelope, state in registers.  Phase 1 runs it for the envelope score
+// and the per-row scale factors; phase 3 runs it AGAIN next to the decoding (same code, same operations in the same order:
+// bit-identical values), which is what lets the kernel park only Backward's rows in HBM.
+template <int C>
+struct EnvForward {
+  float mm[C], im[C], dm[C];
+  float ddprod;
+  float xN, xB, xJ, xC, xE, scale, totscale;
+  __device__ __forceinline__ void init(const float4 *tr, int lane, float pmove)
+  {
+#pragma unroll
+    for (int c = 0; c < C; ++c) mm[c] = im[c] = dm[c] = 0.0f;
+    ddprod = 1.0f;
+#pragma unroll
+    for (int c = 0; c < C; ++c) ddprod *= tr[2 * (c * 64 + lane) + 1].w;
+    xN = 1.0f; xB = pmove; xJ = 0.0f; xC = 0.0f; xE = 0.0f; scale = 1.0f; totscale = 0.0f;
+  }
+  __device__ __forceinline__ void row(const float4 *tr, const float *em, int Mpad, int lane, int x, float pmove, float ploop,
+                                      float xf_e_move, float xf_e_loop)
+  {
+    const float *er = em + x * Mpad + lane;
+    float mp = dpp_shr1f(mm[C - 1], 0.0f), ip = dpp_shr1f(im[C - 1], 0.0f), dp = dpp_shr1f(dm[C - 1], 0.0f);
+    float esum = 0.0f;
+    float t_dd[C], t_md[C];
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+      const F8 t = load_f8(tr, c * 64 + lane);
+      float sv = xB * t.bm;
+      sv = sv + mp * t.mm;
+      sv = sv + ip * t.im;
+      sv = sv + dp * t.dm;
+      sv = sv * er[c * 64];
+      esum = esum + sv;
+      mp = mm[c]; ip = im[c]; dp = dm[c];
+      im[c] = mp * t.mi + ip * t.ii;
+      mm[c] = sv;
+      t_dd[c] = t.dd; t_md[c] = t.md;
+    }
+    float A = 0.0f;
+#pragma unroll
+    for (int c = 0; c < C; ++c) { dm[c] = A; A = mm[c] * t_md[c] + A * t_dd[c]; }
+    float sa = A, sp = ddprod;
+    affine_scan_up(sa, sp);
+    {
+      float w = dpp_shr1f(sa, 0.0f);
+#pragma unroll
+      for (int c = 0; c < C; ++c) { dm[c] = dm[c] + w; esum = esum + dm[c]; w = w * t_dd[c]; }
+    }
+    xE = wave_sum_f32(esum);
+    xN = xN * ploop;
+    xC = (xC * ploop) + (xE * xf_e_move);
+    xJ = (xJ * ploop) + (xE * xf_e_loop);
+    xB = (xJ * pmove) + (xN * pmove);
+    scale = 1.0f;
+    if (xE > 1.0e4f) {
+      xN = xN / xE; xC = xC / xE; xJ = xJ / xE; xB = xB / xE;
+      const float inv = (float) (1.0 / (double) xE);
+#pragma unroll
+      for (int c = 0; c < C; ++c) { mm[c] *= inv; dm[c] *= inv; im[c] *= inv; }
+      scale = xE;
+      totscale += (float) log((double) xE);
+      xE = 1.0f;
+    }
+  }
+};
+
+// posterior probability -> the digit of the alignment's posterior line, exactly as the host prints it
+// (p7_alidisplay: (p + 0.05 >= 1.0) ? '*' : '0' + (int) ((p + 0.05) * 10.0), in double): 0..9, 10 = '*'
+__device__ __forceinline__ unsigned pp_code(float p)
+{
+  const double v = (double) p + 0.05;
+  return v >= 1.0 ? 10u : (unsigned) (int) (v * 10.0);
+}
+// and back to a float that prints as that digit (the host stage formats the line from floats)
+__device__ __forceinline__ float pp_from_code(unsigned code) { return code >= 10u ? 1.0f : (float) (((double) code + 0.5) / 10.0 - 0.05); }
+
 template <int C>
 __global__ void __launch_bounds__(env_waves(C) * 64, env_waves(C) / 4) env_kernel(const ArgRef ref)
 {
@@ -69,13 +148,15 @@ __global__ void __launch_bounds__(env_waves(C) * 64, env_waves(C) / 4) env_kerne
   // per-wavefront workspace
   float *wsf = a.work + (size_t) wave_id * (size_t) a.work_stride;
   const size_t rows = (size_t) a.Lmax + 1;
-  float *fM = wsf, *fI = fM + rows * Mpad, *bM = fI + rows * Mpad, *bI = bM + rows * Mpad;
+  float *bM = wsf, *bI = bM + rows * Mpad;  // Backward's M and I rows (Forward's are recomputed in phase 3)
   float *fx = bI + rows * Mpad;             // [rows][6]  E N J B C SCALE
   float *bx = fx + rows * 6;                // [rows][6]
   float *ox = bx + rows * 6;                // [rows][5]  OA specials E N J B C
   float *px = ox + rows * 5;                // [rows][3]  posterior N J C
   float *totr_row = px + rows * 3;          // [rows]
-  unsigned char *bp = reinterpret_cast<unsigned char *>(totr_row + rows);   // [rows][Mpad] back-pointers
+  unsigned short *bp = reinterpret_cast<unsigned short *>(totr_row + rows); // [rows][Mpad] back-pointers (bits 0-3) and the posterior
+                                                                            // digits of the M (4-7) and I (8-11) cells
+  const bool lane_live = lane * C < a.M;    // lanes whose nodes are all padding neither store nor load rows
 
   for (;;) {
     // envelopes are taken longest first from the job's queue: a wavefront that drew a short one comes back for more
@@ -92,77 +173,26 @@ __global__ void __launch_bounds__(env_waves(C) * 64, env_waves(C) / 4) env_kerne
     const float pmove = (2.0f + a.nj) / ((float) Lfull + 2.0f + a.nj), ploop = 1.0f - pmove;
     int status = 0;
 
-    // ------------------------------------------------------------------ 1. Forward
+    // ------------------------------------------------------------------ 1. Forward (score and scale factors)
     float envsc;
     {
-      float mm[C], im[C], dm[C];
-#pragma unroll
-      for (int c = 0; c < C; ++c) mm[c] = im[c] = dm[c] = 0.0f;
-      float ddprod = 1.0f;
-#pragma unroll
-      for (int c = 0; c < C; ++c) ddprod *= tr[2 * (c * 64 + lane) + 1].w;
-      float xN = 1.0f, xB = pmove, xJ = 0.0f, xC = 0.0f, xE = 0.0f, totscale = 0.0f;
-      if (lane == 0) { fx[0] = 0.0f; fx[1] = 1.0f; fx[2] = 0.0f; fx[3] = xB; fx[4] = 0.0f; fx[5] = 1.0f; }
+      EnvForward<C> f;
+      f.init(tr, lane, pmove);
+      if (lane == 0) { fx[0] = 0.0f; fx[1] = 1.0f; fx[2] = 0.0f; fx[3] = f.xB; fx[4] = 0.0f; fx[5] = 1.0f; }
       for (int i0 = 0; i0 < Ld; i0 += 64) {
         const int nrow = min(64, Ld - i0);
         const uint32_t resid = (lane < nrow) ? sq[i0 + lane] : 0;
         for (int r = 0; r < nrow; ++r) {
           const int i = i0 + r;
-          const int x = __builtin_amdgcn_readlane((int) resid, r);
-          const float *er = em + x * Mpad + lane;
-          float mp = dpp_shr1f(mm[C - 1], 0.0f), ip = dpp_shr1f(im[C - 1], 0.0f), dp = dpp_shr1f(dm[C - 1], 0.0f);
-          float esum = 0.0f;
-          float t_dd[C], t_md[C];
-#pragma unroll
-          for (int c = 0; c < C; ++c) {
-            const F8 t = load_f8(tr, c * 64 + lane);
-            float sv = xB * t.bm;
-            sv = sv + mp * t.mm;
-            sv = sv + ip * t.im;
-            sv = sv + dp * t.dm;
-            sv = sv * er[c * 64];
-            esum = esum + sv;
-            mp = mm[c]; ip = im[c]; dp = dm[c];
-            im[c] = mp * t.mi + ip * t.ii;
-            mm[c] = sv;
-            t_dd[c] = t.dd; t_md[c] = t.md;
-          }
-          float A = 0.0f;
-#pragma unroll
-          for (int c = 0; c < C; ++c) { dm[c] = A; A = mm[c] * t_md[c] + A * t_dd[c]; }
-          float sa = A, sp = ddprod;
-          affine_scan_up(sa, sp);
-          {
-            float w = dpp_shr1f(sa, 0.0f);
-#pragma unroll
-            for (int c = 0; c < C; ++c) { dm[c] = dm[c] + w; esum = esum + dm[c]; w = w * t_dd[c]; }
-          }
-          xE = wave_sum_f32(esum);
-          xN = xN * ploop;
-          xC = (xC * ploop) + (xE * a.xf_e_move);
-          xJ = (xJ * ploop) + (xE * a.xf_e_loop);
-          xB = (xJ * pmove) + (xN * pmove);
-          float scale = 1.0f;
-          if (xE > 1.0e4f) {
-            xN = xN / xE; xC = xC / xE; xJ = xJ / xE; xB = xB / xE;
-            const float inv = (float) (1.0 / (double) xE);
-#pragma unroll
-            for (int c = 0; c < C; ++c) { mm[c] *= inv; dm[c] *= inv; im[c] *= inv; }
-            scale = xE;
-            totscale += (float) log((double) xE);
-            xE = 1.0f;
-          }
-          float *rm = fM + (size_t) (i + 1) * Mpad + lane, *ri = fI + (size_t) (i + 1) * Mpad + lane;
-#pragma unroll
-          for (int c = 0; c < C; ++c) { rm[c * 64] = mm[c]; ri[c * 64] = im[c]; }
+          f.row(tr, em, Mpad, lane, __builtin_amdgcn_readlane((int) resid, r), pmove, ploop, a.xf_e_move, a.xf_e_loop);
           if (lane == 0) {
             float *row = fx + (size_t) (i + 1) * 6;
-            row[0] = xE; row[1] = xN; row[2] = xJ; row[3] = xB; row[4] = xC; row[5] = scale;
+            row[0] = f.xE; row[1] = f.xN; row[2] = f.xJ; row[3] = f.xB; row[4] = f.xC; row[5] = f.scale;
           }
         }
       }
-      if (xC != xC || (Ld > 0 && xC == 0.0f) || __builtin_isinf(xC)) { envsc = __builtin_inff(); status |= 1; }
-      else envsc = (float) ((double) totscale + log((double) (xC * pmove)));
+      if (f.xC != f.xC || (Ld > 0 && f.xC == 0.0f) || __builtin_isinf(f.xC)) { envsc = __builtin_inff(); status |= 1; }
+      else envsc = (float) ((double) f.totscale + log((double) (f.xC * pmove)));
     }
     phase_fence();
 
@@ -201,8 +231,10 @@ __global__ void __launch_bounds__(env_waves(C) * 64, env_waves(C) / 4) env_kerne
       };
       auto store_row = [&](int r) {
         float *rm = bM + (size_t) r * Mpad + lane, *ri = bI + (size_t) r * Mpad + lane;
+        if (lane_live) {
 #pragma unroll
-        for (int c = 0; c < C; ++c) { rm[c * 64] = mm[c]; ri[c * 64] = im[c]; }
+          for (int c = 0; c < C; ++c) { rm[c * 64] = mm[c]; ri[c * 64] = im[c]; }
+        }
       };
 #pragma unroll
       for (int c = 0; c < C; ++c) { mm[c] = xE; dm[c] = xE; im[c] = 0.0f; }
@@ -305,29 +337,35 @@ __global__ void __launch_bounds__(env_waves(C) * 64, env_waves(C) / 4) env_kerne
       const bool loopJ = ploop != 0.0f, loopE = a.xf_e_loop != 0.0f, moveE = a.xf_e_move != 0.0f, moveNJ = pmove != 0.0f;
       // Row r+1 is fetched while row r is processed: four vector rows and the twelve special-state values (one load,
       // lane l < 6 takes Forward's, lane 8 + l Backward's), so that no memory round trip sits on the row's critical path.
-      float nfm[C], nfi[C], nbm[C], nbi[C];
-      auto fetch_row = [&](int r, float (&a)[C], float (&b)[C], float (&c2)[C], float (&d)[C]) {
-        const float *rfm = fM + (size_t) r * Mpad + lane, *rfi = fI + (size_t) r * Mpad + lane;
+      float nbm[C], nbi[C];
+      auto fetch_row = [&](int r, float (&c2)[C], float (&d)[C]) {
         const float *rbm = bM + (size_t) r * Mpad + lane, *rbi = bI + (size_t) r * Mpad + lane;
 #pragma unroll
-        for (int c = 0; c < C; ++c) { a[c] = rfm[c * 64]; b[c] = rfi[c * 64]; c2[c] = rbm[c * 64]; d[c] = rbi[c * 64]; }
+        for (int c = 0; c < C; ++c) { c2[c] = lane_live ? rbm[c * 64] : 0.0f; d[c] = lane_live ? rbi[c * 64] : 0.0f; }
       };
+      EnvForward<C> f;                 // Forward again, row by row, next to the decoding
+      f.init(tr, lane, pmove);
+      uint32_t resid3 = (lane < min(64, Ld)) ? sq[lane] : 0;
       auto fetch_x = [&](int r) -> float {
         const int l = lane & 7;
         const float *src = (lane < 8) ? fx + (size_t) r * 6 : bx + (size_t) r * 6;
         return (l < 6 && lane < 16) ? src[l] : 0.0f;
       };
       auto xval = [&](float v, int idx) { return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), idx)); };
-      fetch_row(1, nfm, nfi, nbm, nbi);
+      fetch_row(1, nbm, nbi);
       float xprev = fetch_x(0), xcur = fetch_x(1);
       for (int r = 1; r <= Ld; ++r) {
-        float cfm[C], cfi[C], cbm[C], cbi[C];
+        float cbm[C], cbi[C];
 #pragma unroll
-        for (int c = 0; c < C; ++c) { cfm[c] = nfm[c]; cfi[c] = nfi[c]; cbm[c] = nbm[c]; cbi[c] = nbi[c]; }
+        for (int c = 0; c < C; ++c) { cbm[c] = nbm[c]; cbi[c] = nbi[c]; }
         const float xthis = xcur;
         const int rn = (r < Ld) ? r + 1 : r;                 // the last iteration re-reads its own row (harmless)
-        fetch_row(rn, nfm, nfi, nbm, nbi);
+        fetch_row(rn, nbm, nbi);
         xcur = fetch_x(rn);
+        if (((r - 1) & 63) == 0 && r > 1) resid3 = (lane < min(64, Ld - (r - 1))) ? sq[(r - 1) + lane] : 0;
+        f.row(tr, em, Mpad, lane, __builtin_amdgcn_readlane((int) resid3, (r - 1) & 63), pmove, ploop, a.xf_e_move, a.xf_e_loop);
+        const float (&cfm)[C] = f.mm;
+        const float (&cfi)[C] = f.im;
         const float fS = xval(xthis, 5), bS = xval(xthis, 8 + 5);
         const float totr = scaleproduct * fS;
         float ppm[C], ppi[C];
@@ -348,7 +386,7 @@ __global__ void __launch_bounds__(env_waves(C) * 64, env_waves(C) / 4) env_kerne
         // OA row.  DP values use gate() (0 when a transition is closed); the traceback rule uses -inf (block()).
         const float xBp = oB;
         float mp = dpp_shr1f(om_[C - 1], kNegInf), ip = dpp_shr1f(oi_[C - 1], kNegInf), dp = dpp_shr1f(od_[C - 1], kNegInf);
-        unsigned char code[C];
+        unsigned short code[C];
         float t_md[C], t_dd[C];
 #pragma unroll
         for (int c = 0; c < C; ++c) {
@@ -369,7 +407,7 @@ __global__ void __launch_bounds__(env_waves(C) * 64, env_waves(C) / 4) env_kerne
           mp = mcur; ip = icur; dp = od_[c];
           om_[c] = sv + ppm[c];
           oi_[c] = iv + ppi[c];
-          code[c] = (unsigned char) (best | (ichoice << 2));
+          code[c] = (unsigned short) (best | (ichoice << 2) | (pp_code(ppm[c]) << 4) | (pp_code(ppi[c]) << 8));
         }
         // D(r,k) = max(gate(tMD(k-1), M(r,k-1)), tDD(k-1) > 0 ? D(r,k-1) : 0), D(r,1) = -inf: a segmented max-scan
         {
@@ -388,14 +426,16 @@ __global__ void __launch_bounds__(env_waves(C) * 64, env_waves(C) / 4) env_kerne
 #pragma unroll
           for (int c = 0; c < C; ++c) {
             const int dchoice = (block(pmd, pm) >= block(pdd, pd)) ? 0 : 1;
-            code[c] |= (unsigned char) (dchoice << 3);
+            code[c] |= (unsigned short) (dchoice << 3);
             pm = om_[c]; pd = od_[c]; pmd = t_md[c]; pdd = t_dd[c];
           }
         }
         {
-          unsigned char *rb = bp + (size_t) r * Mpad + lane;
+          unsigned short *rb = bp + (size_t) r * Mpad + lane;
+          if (lane_live) {
 #pragma unroll
-          for (int c = 0; c < C; ++c) rb[c * 64] = code[c];
+            for (int c = 0; c < C; ++c) rb[c * 64] = code[c];
+          }
         }
         float rowmax = kNegInf;
 #pragma unroll
@@ -439,7 +479,6 @@ __global__ void __launch_bounds__(env_waves(C) * 64, env_waves(C) / 4) env_kerne
         if (lane == 0) {
           float *o = ox + (size_t) r * 5; o[0] = oE; o[1] = oN; o[2] = oJ; o[3] = oB; o[4] = oC;
           float *q = px + (size_t) r * 3; q[0] = ppN; q[1] = ppJ; q[2] = ppC;
-          totr_row[r] = totr;
         }
       }
       if (lane == 0) { float *o = ox; o[0] = kNegInf; o[1] = 0.0f; o[2] = kNegInf; o[3] = 0.0f; o[4] = kNegInf; }
@@ -534,8 +573,8 @@ __global__ void __launch_bounds__(env_waves(C) * 64, env_waves(C) / 4) env_kerne
       const bool same = (w & 0x80000000u) != 0;
       float pp = 0.0f;
       if ((s == tM || s == tI) && i >= 1 && k >= 1) {
-        const size_t idx = (size_t) i * Mpad + ((k - 1) % C) * 64 + (k - 1) / C;
-        pp = (s == tM) ? (fM[idx] * bM[idx]) * totr_row[i] : (fI[idx] * bI[idx]) * totr_row[i];
+        const unsigned w16 = bp[(size_t) i * Mpad + ((k - 1) % C) * 64 + (k - 1) / C];
+        pp = pp_from_code((s == tM) ? ((w16 >> 4) & 15u) : ((w16 >> 8) & 15u));
       } else if (same && i >= 1) {
         if (s == tN) pp = px[(size_t) i * 3 + 0];
         else if (s == tJ) pp = px[(size_t) i * 3 + 1];
@@ -558,8 +597,8 @@ __global__ void __launch_bounds__(env_waves(C) * 64, env_waves(C) / 4) env_kerne
 size_t env_work_floats(int C, int Lmax)
 { // floats per wavefront; keep in step with the carving at the top of env_kernel
   const size_t rows = (size_t) Lmax + 1, Mpad = (size_t) 64 * C;
-  size_t f = 4 * rows * Mpad + rows * (6 + 6 + 5 + 3 + 1);
-  f += (rows * Mpad + 3) / 4;          // back-pointer bytes
+  size_t f = 2 * rows * Mpad + rows * (6 + 6 + 5 + 3 + 1);
+  f += (rows * Mpad + 1) / 2;          // back-pointers + posterior digits, 16 bits per cell
   return (f + 63) & ~(size_t) 63;
 }
 
