@@ -131,13 +131,18 @@ __global__ void __launch_bounds__(env_waves(C) * 64, env_waves(C) / 4) env_kerne
   const EnvArgs a = load_args<EnvArgs>(ref);
   if ((int) blockIdx.x >= a.nblocks) return;        // this job has fewer blocks than the widest job of the launch
   float4 *tr = reinterpret_cast<float4 *>(smem);                         // [2*Mpad]
-  float *em = reinterpret_cast<float *>(smem + (size_t) Mpad * 32);      // [nrows][Mpad]
+  // emission odds [nrows][Mpad]: staged in LDS while they fit beside the transitions (M <= 1024), else read where they
+  // lie (one coalesced 256-byte row segment per chunk and row: L2-resident, like the parsers' long-model variant)
+  constexpr bool kEmisInLds = C <= 16;
+  const float *em = kEmisInLds ? reinterpret_cast<const float *>(smem + (size_t) Mpad * 32) : reinterpret_cast<const float *>(a.emis);
   {
     const float4 *gt = reinterpret_cast<const float4 *>(a.trans);
     for (int i = threadIdx.x; i < 2 * Mpad; i += kEnvBlock) tr[i] = gt[i];
-    const float4 *ge = reinterpret_cast<const float4 *>(a.emis);
-    float4 *le = reinterpret_cast<float4 *>(em);
-    for (int i = threadIdx.x; i < a.nrows * Mpad / 4; i += kEnvBlock) le[i] = ge[i];
+    if constexpr (kEmisInLds) {
+      const float4 *ge = reinterpret_cast<const float4 *>(a.emis);
+      float4 *le = reinterpret_cast<float4 *>(smem + (size_t) Mpad * 32);
+      for (int i = threadIdx.x; i < a.nrows * Mpad / 4; i += kEnvBlock) le[i] = ge[i];
+    }
   }
   __syncthreads();
   const int lane = threadIdx.x & 63;
@@ -641,10 +646,13 @@ static int occupancy_env(K kernel, int kEnvBlock, size_t lds_bytes, int *per_cu)
     case 10: { auto kern = env_kernel<10>; return EXPR; }                                                     \
     case 12: { auto kern = env_kernel<12>; return EXPR; }                                                     \
     case 16: { auto kern = env_kernel<16>; return EXPR; }                                                     \
+    case 20: { auto kern = env_kernel<20>; return EXPR; }                                                     \
+    case 24: { auto kern = env_kernel<24>; return EXPR; }                                                     \
+    case 32: { auto kern = env_kernel<32>; return EXPR; }                                                     \
     default: set_error("model too long for the envelope kernel"); return P7X_EINVAL;                         \
   }
 
-static size_t env_lds_bytes(int C, int nrows) { return (size_t) 64 * C * (32 + (size_t) nrows * 4); }
+static size_t env_lds_bytes(int C, int nrows) { return (size_t) 64 * C * (32 + (C <= 16 ? (size_t) nrows * 4 : 0)); }
 
 int env_max_blocks(int C, int nrows, int num_cu, int *nblocks)
 {

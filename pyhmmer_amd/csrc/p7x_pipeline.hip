@@ -1453,8 +1453,7 @@ int p7x_search_batch_finish(p7x_pending *pd, const char *const *names, const cha
     it.counts[0] = (uint64_t) co.counts[1]; it.counts[1] = (uint64_t) co.counts[8]; it.counts[2] = (uint64_t) co.counts[3]; it.counts[3] = (uint64_t) co.counts[4];
     it.ms = co.ms;
     if (!co.have_xmx && !targets[q].empty()) { dr[q].n = co.reg_n.data(); dr[q].regs = co.regs.data(); dr[q].nexpected = co.nexpected.data(); dr[q].cap = kRegionCap; it.regions = &dr[q]; }
-    // env_kernel keeps the emission table in LDS; longer models are rescored on the host
-    it.device_envelopes = !g_host_envelopes && !pd->cfg.host_envelopes && !targets[q].empty() && om->p.M <= 1024;
+    it.device_envelopes = !g_host_envelopes && !pd->cfg.host_envelopes && !targets[q].empty();
     any_device = any_device || it.device_envelopes;
   }
   int st = P7X_OK;
