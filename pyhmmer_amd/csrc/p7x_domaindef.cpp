@@ -743,7 +743,8 @@ P7X_MULTIVERSION void null2_by_trace(const Model &om, const Trace &tr, int zstar
   // exact zeros, so they are skipped.
   const int M = om.M, Q = om.p->Q4(), K = om.p->K;
   constexpr int KP = Model::kKpad;
-  for (int k = 0; k <= M + 1; ++k) { wm[k] = 0.0f; wi[k] = 0.0f; }
+  (void) wi;          // the insert slots stay zero (see below): adding them is adding 0.0f, which is exact, so they are left out
+  for (int k = 0; k <= M + 1; ++k) wm[k] = 0.0f;
   float eN = 0.0f, eC = 0.0f, eJ = 0.0f;
   int Ld = 0;
   for (int z = zstart; z <= zend; ++z) {
@@ -755,7 +756,7 @@ P7X_MULTIVERSION void null2_by_trace(const Model &om, const Trace &tr, int zstar
     else switch (tr.st[z]) { case sN: eN += 1.0f; break; case sC: eC += 1.0f; break; case sJ: eJ += 1.0f; break; default: break; }
   }
   const float norm = 1.0 / (float) Ld;
-  for (int k = 1; k <= M; ++k) { wm[k] *= norm; wi[k] *= norm; }
+  for (int k = 1; k <= M; ++k) wm[k] *= norm;
   eN *= norm; eC *= norm; eJ *= norm;
   const float xfactor = eN + eC + eJ;
   float acc[4][KP];
@@ -765,11 +766,11 @@ P7X_MULTIVERSION void null2_by_trace(const Model &om, const Trace &tr, int zstar
     for (int z = 0; z < 4; ++z) {
       const int k = q + 1 + z * Q;
       if (k > M) continue;
-      const float w = wm[k], v = wi[k];
-      if (w == 0.0f && v == 0.0f) continue;
+      const float w = wm[k];
+      if (w == 0.0f) continue;
       const float *__restrict r = rfT + (size_t) k * KP;
       float *__restrict a = acc[z];
-      for (int x = 0; x < KP; ++x) { a[x] = a[x] + w * r[x]; a[x] = a[x] + v; }
+      for (int x = 0; x < KP; ++x) a[x] = a[x] + w * r[x];
     }
   for (int x = 0; x < K; ++x) null2[x] = ((acc[0][x] + acc[1][x]) + (acc[2][x] + acc[3][x])) + xfactor;
   finish_null2(*om.p, null2);
