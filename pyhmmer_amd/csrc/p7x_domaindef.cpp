@@ -1069,7 +1069,8 @@ int domaindef_regions(const Profile &p, int L, const float *fx, const float *bx,
 static thread_local const LongTargetOpts *t_long_target = nullptr;     // set by the long-target pipeline around its calls
 
 int domaindef_multi_region(const Profile &p, const uint8_t *dsq, int L, int i, int j, uint32_t seed, bool do_reseeding,
-                           MultiRegionState &state, DomainDefResult &dd, std::vector<Domain> &out)
+                           MultiRegionState &state, DomainDefResult &dd, std::vector<Domain> &out,
+                           std::vector<EnvelopeRequest> *defer2, int item)
 {
   const int nsamples = 200;                                                  // p7_domaindef.pxd:43-48
   const float min_overlap = 0.8f, min_posterior = 0.25f, min_endpointp = 0.02f;
@@ -1117,6 +1118,17 @@ int domaindef_multi_region(const Profile &p, const uint8_t *dsq, int L, int i, i
       if ((float) nov / (float) n >= 0.8f) { if (sigc[d].prob > sigc[d2].prob) dominated[d2] = 1; else dominated[d] = 1; }
     }
   om.configure(false, L);
+  if (defer2 && !om.lt) {                  // the device rescores the clustered envelopes; overlaps are counted when its answers are in
+    out.clear();
+    for (int d = 0; d < nc0; ++d) {
+      if (dominated[d]) continue;
+      dd.nenvelopes++;
+      Domain ph; ph.ienv = sigc[d].i; ph.jenv = sigc[d].j; ph.deferred2 = (int) defer2->size();
+      defer2->push_back(EnvelopeRequest{ item, (int32_t) sigc[d].i, (int32_t) sigc[d].j });
+      out.push_back(std::move(ph));
+    }
+    return P7X_OK;
+  }
   int last_j2 = 0;
   std::vector<Domain> keep;
   keep.swap(dd.dcl);                       // rescore_isolated_domain() appends to dd.dcl: collect this region's domains apart
@@ -1191,12 +1203,14 @@ static int dispatch_regions(const Profile &p, const uint8_t *dsq, int L, const R
 }
 
 // The multi-domain regions left behind by the deferring call above, in order.
-int domaindef_finish_multi(const Profile &p, const uint8_t *dsq, int L, uint32_t seed, bool do_reseeding, DomainDefResult &dd)
+int domaindef_finish_multi(const Profile &p, const uint8_t *dsq, int L, uint32_t seed, bool do_reseeding, DomainDefResult &dd,
+                           std::vector<EnvelopeRequest> *defer2, int item)
 {
   MultiRegionState state;
   for (Domain &d : dd.dcl) {
     if (d.deferred != -2) continue;
-    const int st = domaindef_multi_region(p, dsq, L, (int) d.ienv, (int) d.jenv, seed, do_reseeding, state, dd, dd.multi[(size_t) d.multi_slot]);
+    const int st = domaindef_multi_region(p, dsq, L, (int) d.ienv, (int) d.jenv, seed, do_reseeding, state, dd, dd.multi[(size_t) d.multi_slot],
+                                          defer2, item);
     if (st != P7X_OK) return st;
   }
   return P7X_OK;
@@ -1206,35 +1220,50 @@ int domaindef_finish_multi(const Profile &p, const uint8_t *dsq, int L, uint32_t
 // display, null2 odds -> per-residue corrections.  req_index[n] is the position in <res> of local request n
 // (Domain::deferred of the placeholders of this target).
 int domaindef_finish_deferred(const Profile &p, const uint8_t *dsq, int L, const std::vector<EnvelopeResult> &res,
-                              const std::vector<int> &req_index, DomainDefResult &dd)
+                              const std::vector<int> &req_index, DomainDefResult &dd,
+                              const std::vector<EnvelopeResult> *res2, const std::vector<int> *req_index2)
 {
   thread_local Workspace ws;
   std::vector<Domain> kept;
   kept.reserve(dd.dcl.size());
-  for (Domain &d : dd.dcl) {
-    if (d.deferred == -2) { for (Domain &m : dd.multi[(size_t) d.multi_slot]) kept.push_back(std::move(m)); continue; }
-    if (d.deferred < 0) { kept.push_back(std::move(d)); continue; }
-    const EnvelopeResult &r = res[(size_t) req_index[(size_t) d.deferred]];
-    const int i = (int) d.ienv, j = (int) d.jenv;
-    if (r.status & 2) continue;                      // p7_Decoding range error: the envelope is dropped
-    if (r.status & ~3) continue;                     // traceback failure: upstream's rescore returns without a domain
+  // the device's answer for envelope i..j -> a Domain; null2_done: the region's ensemble already set dd.n2sc on i..j
+  auto from_result = [&](const EnvelopeResult &r, int i, int j, bool null2_done, Domain &dom) -> bool {
+    if (r.status & 2) return false;                  // p7_Decoding range error: the envelope is dropped
+    if (r.status & ~3) return false;                 // traceback failure: upstream's rescore returns without a domain
     Trace &tr = ws.tr;
     tr.clear();
     for (int z = 0; z < r.ntrace; ++z) tr.append((int) (r.ta[z] & 0xffu), (int) ((r.ta[z] >> 8) & 0xffffu), r.ti[z], r.tp[z]);
     tr.reverse();
     for (size_t z = 0; z < tr.st.size(); ++z) if (tr.i[z] > 0) tr.i[z] += i - 1;
-    Domain dom;
     make_alidisplay(p, tr, dsq, L, dom);
-    float null2[MAXKP];
-    for (int x = 0; x < p.K; ++x) null2[x] = r.null2[x];
-    finish_null2(p, null2);
+    if (!null2_done) {
+      float null2[MAXKP];
+      for (int x = 0; x < p.K; ++x) null2[x] = r.null2[x];
+      finish_null2(p, null2);
+      for (int pos = i; pos <= j; ++pos) dd.n2sc[pos] = logf(null2[dsq[pos]]);
+    }
     float domcorrection = 0.0f;
-    for (int pos = i; pos <= j; ++pos) dd.n2sc[pos] = logf(null2[dsq[pos]]);
     for (int pos = i; pos <= j; ++pos) domcorrection += dd.n2sc[pos];
     dom.domcorrection = domcorrection;
     dom.ienv = i; dom.jenv = j; dom.envsc = r.envsc; dom.oasc = r.oasc;
     dom.iali = dom.sqfrom; dom.jali = dom.sqto;
-    kept.push_back(std::move(dom));
+    return true;
+  };
+  for (Domain &d : dd.dcl) {
+    if (d.deferred == -2) {
+      int last_j2 = 0;
+      for (Domain &m : dd.multi[(size_t) d.multi_slot]) {
+        if (m.deferred2 < 0 || !res2 || !req_index2) { kept.push_back(std::move(m)); continue; }
+        const int i2 = (int) m.ienv, j2 = (int) m.jenv;
+        if (i2 <= last_j2) dd.noverlaps++;
+        Domain dom;
+        if (from_result((*res2)[(size_t) (*req_index2)[(size_t) m.deferred2]], i2, j2, true, dom)) { last_j2 = j2; kept.push_back(std::move(dom)); }
+      }
+      continue;
+    }
+    if (d.deferred < 0) { kept.push_back(std::move(d)); continue; }
+    Domain dom;
+    if (from_result(res[(size_t) req_index[(size_t) d.deferred]], (int) d.ienv, (int) d.jenv, false, dom)) kept.push_back(std::move(dom));
   }
   dd.dcl = std::move(kept);
   return P7X_OK;

@@ -23,6 +23,7 @@ struct Domain {
   std::string model, mline, aseq, ppline, rfline, mmline, csline;
   int deferred = -1;          // >= 0: placeholder, to be filled from envelope request <deferred> (device rescoring)
   int multi_slot = -1;        // deferred == -2: placeholder of a multi-domain region, domains in DomainDefResult::multi
+  int deferred2 = -1;         // >= 0 (inside DomainDefResult::multi): clustered envelope rescored by the device in a second round
 };
 
 struct DomainDefResult {      // the P7_DOMAINDEF fields p7_Pipeline reads (p7_domaindef.pxd:23-59)
@@ -60,9 +61,13 @@ struct Region { int i, j; bool multi; };
 struct DeviceRegions { const int32_t *n = nullptr; const int32_t *regs = nullptr; const float *nexpected = nullptr; int cap = 0; };
 struct MultiRegionState { bool started = false; uint32_t rng_seed = 42, rng_x = 0; };   // RNG carried between the regions of one target
 int domaindef_regions(const Profile &p, int L, const float *fwd_xmx, const float *bck_xmx, DomainDefResult &dd, std::vector<Region> &regs);
+// <defer2>: the clustered envelopes are queued there (tagged <item>) for a second round of device rescoring instead of being
+// rescored on the host; their placeholders carry Domain::deferred2 and are completed by domaindef_finish_deferred().
 int domaindef_multi_region(const Profile &p, const uint8_t *dsq, int L, int i, int j, uint32_t seed, bool do_reseeding,
-                           MultiRegionState &state, DomainDefResult &dd, std::vector<Domain> &out);
-int domaindef_finish_multi(const Profile &p, const uint8_t *dsq, int L, uint32_t seed, bool do_reseeding, DomainDefResult &dd);
+                           MultiRegionState &state, DomainDefResult &dd, std::vector<Domain> &out,
+                           std::vector<EnvelopeRequest> *defer2 = nullptr, int item = 0);
+int domaindef_finish_multi(const Profile &p, const uint8_t *dsq, int L, uint32_t seed, bool do_reseeding, DomainDefResult &dd,
+                           std::vector<EnvelopeRequest> *defer2 = nullptr, int item = 0);
 
 // With <defer> the single-domain regions are queued there (tagged <item>) instead of being rescored on the host;
 // domaindef_finish_deferred() completes them from the device results (res[d.deferred] for placeholder d).
@@ -73,7 +78,8 @@ int domaindef_by_posterior_heuristics(const Profile &p, const uint8_t *dsq, int 
 int domaindef_from_regions(const Profile &p, const uint8_t *dsq, int L, float nexpected, const Region *regs, int nregs,
                            uint32_t seed, bool do_reseeding, DomainDefResult &out, std::vector<EnvelopeRequest> *defer, int item);
 int domaindef_finish_deferred(const Profile &p, const uint8_t *dsq, int L, const std::vector<EnvelopeResult> &res,
-                              const std::vector<int> &req_index, DomainDefResult &dd);
+                              const std::vector<int> &req_index, DomainDefResult &dd,
+                              const std::vector<EnvelopeResult> *res2 = nullptr, const std::vector<int> *req_index2 = nullptr);
 
 struct Hit {                  // P7_HIT, p7_hit.pxd:27-58
   std::string name, acc, desc;
@@ -115,7 +121,7 @@ struct FinishItem {
 };
 int host_finish_batch(const p7x_pipeline_cfg &cfg, const std::vector<FinishItem> &items, const HostTargets &tg,
                       const char *const *names, const char *const *accs, const char *const *descs,
-                      p7x_tophits **outs, EnvelopeScorer *scorer = nullptr);
+                      p7x_tophits **outs, EnvelopeScorer *scorer = nullptr, EnvelopeScorer *scorer2 = nullptr);
 void tophits_set_total_ms(p7x_tophits *th, double stage1_ms, double stage2_ms);
 void tophits_sort_by_key(p7x_tophits &th);
 void tophits_threshold(p7x_tophits &th);

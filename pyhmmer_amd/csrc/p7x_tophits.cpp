@@ -278,7 +278,7 @@ static void threshold(p7x_tophits &th)
 // go to the device in one submission (one launch per model-length class).
 int host_finish_batch(const p7x_pipeline_cfg &cfg_in, const std::vector<FinishItem> &items, const HostTargets &tg,
                       const char *const *names, const char *const *accs, const char *const *descs,
-                      p7x_tophits **outs, EnvelopeScorer *scorer)
+                      p7x_tophits **outs, EnvelopeScorer *scorer, EnvelopeScorer *scorer2)
 {
   const int nq = (int) items.size();
   std::vector<std::unique_ptr<p7x_tophits>> ths((size_t) nq);
@@ -399,15 +399,32 @@ int host_finish_batch(const p7x_pipeline_cfg &cfg_in, const std::vector<FinishIt
     bool any = false;
     for (int q = 0; q < nq; ++q) { jobs[(size_t) q] = EnvelopeJob{ items[(size_t) q].om, &req[(size_t) q], items[(size_t) q].targets }; any = any || !req[(size_t) q].empty(); }
     if (any) { const int st = scorer->begin(jobs); if (st != P7X_OK) return st; }
+    // the ensembles' clustered envelopes go to the device as a second round (scorer2) instead of being rescored here
+    std::vector<std::vector<EnvelopeRequest>> local2((size_t) S);
     run_pool((int) heavy.size(), [&](int h) {
       const int f = heavy[(size_t) h], q = q_of[(size_t) f], i = f - first[(size_t) q];
       const int t = (*items[(size_t) q].targets)[(size_t) i];
-      const int st = domaindef_finish_multi(items[(size_t) q].om->p, tg.dsq + tg.off[t] - 1, tg.len[t], cfg_in.seed, reseed, dds[(size_t) f]);
+      const int st = domaindef_finish_multi(items[(size_t) q].om->p, tg.dsq + tg.off[t] - 1, tg.len[t], cfg_in.seed, reseed, dds[(size_t) f],
+                                            scorer2 ? &local2[(size_t) f] : nullptr, i);
       if (st != P7X_OK) failed.store(st);
     });
     ms_multi = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t1).count();
-    std::vector<std::vector<EnvelopeResult>> res((size_t) nq);
+    std::vector<std::vector<EnvelopeRequest>> req2((size_t) nq);
+    std::vector<std::vector<int>> req_index2((size_t) S);
+    std::vector<EnvelopeJob> jobs2((size_t) nq);
+    bool any2 = false;
+    if (scorer2 && failed.load() == 0) {
+      for (int f : heavy) {
+        const int q = q_of[(size_t) f];
+        for (const EnvelopeRequest &r : local2[(size_t) f]) { req_index2[(size_t) f].push_back((int) req2[(size_t) q].size()); req2[(size_t) q].push_back(r); }
+      }
+      for (int q = 0; q < nq; ++q) { jobs2[(size_t) q] = EnvelopeJob{ items[(size_t) q].om, &req2[(size_t) q], items[(size_t) q].targets }; any2 = any2 || !req2[(size_t) q].empty(); }
+      if (any2) { const int st = scorer2->begin(jobs2); if (st != P7X_OK) return st; }
+    }
+    std::vector<std::vector<EnvelopeResult>> res((size_t) nq), res2((size_t) nq);
     if (any) { const int st = scorer->wait(res); if (st != P7X_OK) return st; }
+    if (any2) { const int st = scorer2->wait(res2); if (st != P7X_OK) return st; }
+    if (!any2) res2.assign((size_t) nq, {});
     ms_env = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t1).count();
     // 3. alignment displays, null2 corrections, per-target scores
     if (failed.load() == 0)
@@ -416,7 +433,8 @@ int host_finish_batch(const p7x_pipeline_cfg &cfg_in, const std::vector<FinishIt
         if (!on_device(q) || dropped[(size_t) f]) return;
         const int i = f - first[(size_t) q];
         const int t = (*items[(size_t) q].targets)[(size_t) i];
-        domaindef_finish_deferred(items[(size_t) q].om->p, tg.dsq + tg.off[t] - 1, tg.len[t], res[(size_t) q], req_index[(size_t) f], dds[(size_t) f]);
+        domaindef_finish_deferred(items[(size_t) q].om->p, tg.dsq + tg.off[t] - 1, tg.len[t], res[(size_t) q], req_index[(size_t) f], dds[(size_t) f],
+                                  &res2[(size_t) q], &req_index2[(size_t) f]);
         finish(f, dds[(size_t) f]);
       });
   }

@@ -466,3 +466,22 @@ def test_hmmscan_deals_profile_batches_over_devices(models, proteome):
         assert [(h.name, h.score, h.evalue, len(h.domains)) for h in a] == [(h.name, h.score, h.evalue, len(h.domains)) for h in b]
     db = hmmer.ReplicatedDatabase(sub, [0, 0])
     assert [sh.device for sh in db.shards] == [0, 0] and all(len(sh.block) == len(sub) for sh in db.shards)
+
+
+def test_clustered_envelopes_on_the_device_give_the_same_tables(models, proteome, monkeypatch):
+    """P7X_DEVICE_CLUSTERED=1: the envelopes that the stochastic ensembles of multi-domain regions produce are rescored by
+    the envelope kernel in a second round instead of by the host workers.  Hits, domains and the written tables are the
+    same (the golden tables contain nine such hits)."""
+    import io
+    hmm = models["PF02826"][0]
+    base = plan7.Pipeline(hmm.alphabet).search_hmm(hmm, proteome)
+    monkeypatch.setenv("P7X_DEVICE_CLUSTERED", "1")
+    dev = plan7.Pipeline(hmm.alphabet).search_hmm(hmm, proteome)
+    assert sum(h.nclustered for h in dev) == sum(h.nclustered for h in base) > 0
+    _check_tbl(dev, golden_table("PF02826.tbl"))
+    _check_domtbl(dev, golden_table("PF02826.domtbl", kind="domtbl"))
+    assert [(h.name, len(h.domains), h.nenvelopes, h.noverlaps) for h in dev] == [(h.name, len(h.domains), h.nenvelopes, h.noverlaps) for h in base]
+    for fmt in ("targets", "domains"):
+        a, b = io.BytesIO(), io.BytesIO()
+        base.write(a, format=fmt); dev.write(b, format=fmt)
+        assert a.getvalue() == b.getvalue()
