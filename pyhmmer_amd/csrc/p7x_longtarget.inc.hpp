@@ -195,6 +195,85 @@ static int lt_forward_parser(Model &om, const uint8_t *dsq, int L, std::vector<f
   return P7X_OK;
 }
 
+// Backward parser on a window: the special-state rows only, two rolling DP rows.  Operation for operation backward_full()
+// (same D chains, same sums), without its (L+1) x M matrices -- a 2,400-residue window of a 1,200-node model would
+// stream 70 MB through the host caches for rows the region scan never reads.  fx: Forward's rows (scale factors).
+static int lt_backward_parser(const Model &om, const uint8_t *dsq, int L, const std::vector<float> &fx, std::vector<float> &bx)
+{
+  const int M = om.M;
+  const float *__restrict bm = om.tf(0), *__restrict tMM = om.tf(1), *__restrict tIM = om.tf(2), *__restrict tDM = om.tf(3),
+              *__restrict tMD = om.tf(4), *__restrict tMI = om.tf(5), *__restrict tII = om.tf(6);
+  std::vector<float> buf((size_t) 7 * (M + 3), 0.0f);
+  float *mc = buf.data(), *ic = mc + (M + 3), *dc = ic + (M + 3), *mn = dc + (M + 3), *in = mn + (M + 3), *dn = in + (M + 3), *me = dn + (M + 3);
+  bx.assign((size_t) (L + 1) * NX, 0.0f);
+  auto X = [&](int r, int s) -> float & { return bx[(size_t) r * NX + s]; };
+  auto FS = [&](int r) { return fx[(size_t) r * NX + xS_]; };
+  bool own_scales = false;
+  float xJ = 0.f, xB = 0.f, xN = 0.f;
+  float xC = om.xf[XC][MOVE];
+  float xE = xC * om.xf[XE][MOVE];
+  {
+    mc[M + 1] = ic[M + 1] = dc[M + 1] = 0.0f;
+    for (int k = 1; k <= M; ++k) { dc[k] = xE; ic[k] = 0.0f; }
+    dchain_backward(om, dc);
+    for (int k = 1; k <= M; ++k) mc[k] = xE + dc[k + 1] * tMD[k];
+    mc[0] = ic[0] = dc[0] = 0.0f;
+    const float sc = FS(L);
+    if (sc > 1.0f) {
+      xE = xE / sc; xN = xN / sc; xC = xC / sc; xJ = xJ / sc; xB = xB / sc;
+      const float inv = 1.0 / sc;
+      for (int k = 1; k <= M; ++k) { mc[k] *= inv; dc[k] *= inv; ic[k] *= inv; }
+    }
+    X(L, xS_) = sc;
+    X(L, xE_) = xE; X(L, xN_) = xN; X(L, xJ_) = xJ; X(L, xB_) = xB; X(L, xC_) = xC;
+  }
+  for (int r = L - 1; r >= 1; --r) {
+    std::swap(mc, mn); std::swap(ic, in); std::swap(dc, dn);           // row r+1 becomes "next"
+    const float *__restrict rf = om.rf(dsq[r + 1]);
+    float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (int k = 1; k <= M; ++k) me[k] = mn[k] * rf[k];
+    me[M + 1] = 0.0f;
+    int kk = 1;
+    for (; kk + 7 <= M; kk += 8) for (int z = 0; z < 8; ++z) acc[z] += me[kk + z] * bm[kk + z];
+    for (; kk <= M; ++kk) acc[0] += me[kk] * bm[kk];
+    xB = hsum8(acc);
+    xC = xC * om.xf[XC][LOOP];
+    xJ = (xB * om.xf[XJ][MOVE]) + (xJ * om.xf[XJ][LOOP]);
+    xN = (xB * om.xf[XN][MOVE]) + (xN * om.xf[XN][LOOP]);
+    xE = (xC * om.xf[XE][MOVE]) + (xJ * om.xf[XE][LOOP]);
+    mc[M + 1] = ic[M + 1] = dc[M + 1] = 0.0f;
+    for (int k = 1; k < M; ++k) {
+      const float mek = me[k + 1];
+      ic[k] = in[k] * tII[k] + mek * tIM[k + 1];
+      dc[k] = mek * tDM[k + 1] + xE;
+      mc[k] = (in[k] * tMI[k] + mek * tMM[k + 1]) + xE;
+    }
+    ic[M] = in[M] * tII[M]; dc[M] = xE; mc[M] = in[M] * tMI[M] + xE;
+    dchain_backward(om, dc);
+    for (int k = 1; k <= M; ++k) mc[k] += dc[k + 1] * tMD[k];
+    mc[0] = ic[0] = dc[0] = 0.0f;
+    if (xB > 1.0e16) own_scales = true;
+    const float sc = own_scales ? ((xB > 1.0e4) ? xB : 1.0f) : FS(r);
+    X(r, xS_) = sc;
+    if (sc > 1.0f) {
+      xE /= sc; xN /= sc; xJ /= sc; xB /= sc; xC /= sc;
+      const float inv = 1.0 / sc;
+      for (int k = 1; k <= M; ++k) { mc[k] *= inv; dc[k] *= inv; ic[k] *= inv; }
+    }
+    X(r, xE_) = xE; X(r, xN_) = xN; X(r, xJ_) = xJ; X(r, xB_) = xB; X(r, xC_) = xC;
+  }
+  {
+    const float *__restrict rf = om.rf(dsq[1]);
+    float bsum = 0.0f;
+    for (int k = 1; k <= M; ++k) bsum += (mc[k] * rf[k]) * bm[k];
+    xB = bsum;
+    xN = (xB * om.xf[XN][MOVE]) + (xN * om.xf[XN][LOOP]);
+    X(0, xB_) = xB; X(0, xC_) = 0.0f; X(0, xJ_) = 0.0f; X(0, xN_) = xN; X(0, xE_) = 0.0f; X(0, xS_) = 1.0f;
+  }
+  if (std::isnan(xN) || (L > 0 && xN == 0.0f) || std::isinf(xN)) return P7X_ERANGE;
+  return P7X_OK;
+}
+
 // ---------------------------------------------------------------- Forward parser in upstream's summation order
 // impl_sse/fwdback.c forward_engine() adds its floats in the order the striped 4-lane vectors impose: node k lives in
 // lane z = (k-1) / Q of vector q = (k-1) % Q; xE is four per-lane sums over q (match cells first, delete cells after
@@ -479,12 +558,9 @@ static int lt_post_viterbi(const p7x_pipeline_cfg &cfg, const Profile &p, const 
   // Backward parser rows: the full-matrix routine on the window would need L x M floats; the region scan only needs the
   // special states, which the generic Backward delivers row by row.  Windows are a few max_length long.
   {
-    Matrix fm, bm;
     float sc2 = 0.0f;
-    forward_full(om, subseq, (int) window_len, fm, &sc2);
-    backward_full(om, subseq, (int) window_len, fm, bm, nullptr);
-    fx.assign(fm.x.begin(), fm.x.begin() + (size_t) (window_len + 1) * NX);
-    bx.assign(bm.x.begin(), bm.x.begin() + (size_t) (window_len + 1) * NX);
+    if (fwd_given || fx.size() != (size_t) (window_len + 1) * NX) lt_forward_parser(om, subseq, (int) window_len, fx, &sc2);
+    lt_backward_parser(om, subseq, (int) window_len, fx, bx);
   }
   DomainDefResult dd;
   t_long_target = &lto;
