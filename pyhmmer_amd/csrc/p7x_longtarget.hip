@@ -284,19 +284,23 @@ int p7x_search_longtargets(const p7x_pipeline_cfg *cfg, const p7x_oprofile *om, 
     if ((st = scan_target(*cfg, p, ctx, seq1, Lt, sc_thresh, xB, mask, rows, &ms)) != P7X_OK) return st;
     scan_ms += ms;
     const auto ts1 = std::chrono::steady_clock::now();
+    // upstream's bookkeeping per (block, strand): the units are independent, the host workers take them side by side
+    struct Unit { int64_t i, bn; int strand; std::vector<int64_t> s3; };
+    std::vector<Unit> units;
     for (int64_t i = 0; i < Lt; i += W - C) {
       const int64_t bc = i == 0 ? 0 : std::min<int64_t>(C, Lt - i);
       const int64_t bw = std::min<int64_t>(W, Lt - i - bc);
       const int64_t bn = bc + bw;
       if (bn <= 0) break;
-      for (int strand = 0; strand < 2; ++strand) {
-        if (!(mask & (1 << strand))) continue;
-        std::vector<int64_t> s3;
-        block_seeds(p, seq1, Lt, i, bn, strand, rows, sc_thresh, xB, s3);
-        for (size_t q = 0; q + 2 < s3.size(); q += 3) seeds.push_back(LongTargetSeed{ (int64_t) t, i, strand, s3[q], (int) s3[q + 1], s3[q + 2] });
-      }
+      for (int strand = 0; strand < 2; ++strand) if (mask & (1 << strand)) units.push_back(Unit{ i, bn, strand, {} });
       if (i + bn >= Lt) break;
     }
+    host_parallel_for((int) units.size(), cfg->host_threads, [&](int u) {
+      Unit &un = units[(size_t) u];
+      block_seeds(p, seq1, Lt, un.i, un.bn, un.strand, rows, sc_thresh, xB, un.s3);
+    });
+    for (const Unit &un : units)
+      for (size_t q = 0; q + 2 < un.s3.size(); q += 3) seeds.push_back(LongTargetSeed{ (int64_t) t, un.i, un.strand, un.s3[q], (int) un.s3[q + 1], un.s3[q + 2] });
     if (std::getenv("P7X_LT_DEBUG"))
       std::fprintf(stderr, "[lt] target %zu: scan call %.1f ms (kernel %.1f), %zu rows, seeds so far %zu, seed bookkeeping %.1f ms\n", t,
                    std::chrono::duration<double, std::milli>(ts1 - ts0).count(), ms, rows.size(), seeds.size(),
