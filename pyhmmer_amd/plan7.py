@@ -1570,7 +1570,16 @@ class LongTargetsPipeline(Pipeline):
         cfg = self._cfg()
         if self.bit_cutoffs is not None and not getattr(om.cutoffs, self.bit_cutoffs + "_available")():
             raise MissingCutoffs(om.name, self.bit_cutoffs)
-        dsq, offsets, lengths, names, accs, descs = self._pack(sequences)
+        if isinstance(sequences, DigitalSequenceBlock) and all(len(s) < 2 ** 31 for s in sequences):
+            # the block's cached flat image (the same "255 x1..xL 255 ..." layout): a chromosome is not copied per query
+            pk = sequences.packed()
+            n = len(sequences)
+            dsq, offsets, lengths = pk.dsq, pk.offsets, pk.lengths.astype(np.int64)
+            names = (C.c_char_p * max(n, 1))(*[s.name.encode() for s in sequences])
+            accs = (C.c_char_p * max(n, 1))(*[(s.accession or "").encode() for s in sequences])
+            descs = (C.c_char_p * max(n, 1))(*[(s.description or "").encode() for s in sequences])
+        else:
+            dsq, offsets, lengths, names, accs, descs = self._pack(sequences)
         out = C.c_void_p()
         st = _lib.lib().p7x_search_longtargets(C.byref(cfg), om._handle, self.device, dsq.ctypes.data, offsets.ctypes.data,
                                                lengths.ctypes.data, len(sequences), names, accs, descs, C.byref(out))
