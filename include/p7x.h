@@ -176,7 +176,7 @@ typedef struct p7x_pipeline_cfg {
   float   lt_bg_mix;         /* weight of the envelope's composition in that background; default 0.75 */
   float   f3_guard;          /* relative half-width of the band around F3 inside which a target's Forward P-value is not trusted to the
                               * device's summation order: the device passes P <= F3 (1 + g), the host stage re-scores the targets with
-                              * P > F3 (1 - g) with p7x_forward_parser_exact and applies F3 to that.  Default 1e-3; 0: no guard */
+                              * P > F3 (1 - g) with p7x_forward_parser_exact and applies F3 to that.  Default 4e-3 (a band of about 6e-3 bit, three times the stated tolerance of the device Forward score); 0: no guard */
 } p7x_pipeline_cfg;
 enum { P7X_STRAND_BOTH = 0, P7X_STRAND_TOPONLY = 1, P7X_STRAND_BOTTOMONLY = 2 };
 void p7x_pipeline_cfg_default(p7x_pipeline_cfg *cfg);   /* p7_pipeline_Create(NULL,...) defaults, plan7.pyx:5413-5421 */
