@@ -993,6 +993,10 @@ int rescore_isolated_domain(const Profile &p, Model &om, const uint8_t *dsq, int
         float null2[MAXKP];
         null2_by_expectation(om, ws.bck, null2);
         for (int pos = i; pos <= j; ++pos) domcorrection += logf(null2[dsq[pos]]);
+      } else if (lt->bias_mode == 5) { // null2 by expectation under the composition-adjusted model; envsc stays the adjusted score
+        float null2[MAXKP];
+        null2_by_expectation(om, ws.bck, null2);
+        for (int pos = i; pos <= j; ++pos) domcorrection += logf(null2[dsq[pos]]);
       } else {                         // the score lost against the composition-adjusted background is the bias
         float orig = 0.0f;
         om.rf_over = nullptr;

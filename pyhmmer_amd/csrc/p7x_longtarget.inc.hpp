@@ -620,8 +620,11 @@ static int lt_post_viterbi(const p7x_pipeline_cfg &cfg, const Profile &p, const 
 // and the standard Viterbi filter score, which bounds every row of the long-target Viterbi scan from above.
 struct LtWindowFilters { bool have = false; float usc = 0.0f, bias_filtersc = 0.0f; bool have_vit = false; float vfsc = 0.0f; };
 
-// p7_pli_postSSV_LongTarget up to the Viterbi step: MSV and bias tests of one window.  state: 0 dropped, 1 passes P <= F2
-// already (the whole window goes on), 2 needs the long-target Viterbi scan with score threshold <vit_thresh>.
+// p7_pli_postSSV_LongTarget up to the Viterbi step: MSV and bias tests of one window.  state: 0 dropped, 2 goes through the
+// long-target Viterbi scan with score threshold <vit_thresh>.  (Every surviving window does, also one whose MSV P-value is
+// already below F2: the scan is what cuts a merged SSV window into the Viterbi windows Forward is run on.  Passing such
+// windows on whole -- the protein pipeline's shortcut -- made bmyD2.tbl's third row come out of a 4.6 kb window together
+// with a weak envelope nhmmer never sees.)
 struct LtPrefilter { int state = 0; int vit_thresh = 0; float filtersc_f2 = 0.0f; };
 
 static LtPrefilter lt_window_prefilter(const p7x_pipeline_cfg &cfg, const Profile &p, const uint8_t *subseq, int64_t window_len,
@@ -643,7 +646,6 @@ static LtPrefilter lt_window_prefilter(const p7x_pipeline_cfg &cfg, const Profil
     if (P > cfg.F1) return out;
   }
   ctr.n_past_bias++; ctr.pos_past_bias += (uint64_t) window_len;
-  if (!(P > cfg.F2)) { out.state = 1; return out; }
   if (cfg.do_biasfilter) filtersc = nullsc + (bias_filtersc * (F2_L > window_len ? 1.0f : (float) F2_L / (float) window_len));
   // The standard Viterbi filter score of the window is at least the score any single row reaches in the long-target
   // scan (its C state collects every row's E; clearing rows can only lower later ones): a window that fails P <= F2
