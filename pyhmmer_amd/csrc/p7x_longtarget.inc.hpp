@@ -770,6 +770,15 @@ static int lt_run_host(const p7x_pipeline_cfg &cfg, const p7x_oprofile *om, cons
   uint64_t nres = 0;
   size_t sidx = 0;
   struct BlockJob { int64_t i, bn, bc, bw; int strand; uint64_t nres_at; std::vector<LtWindow> windows; size_t first_window; };
+  // P7X_LT_DEBUG: wall time of the phases of this function
+  const bool dbg = std::getenv("P7X_LT_DEBUG") != nullptr;
+  auto t_last = std::chrono::steady_clock::now();
+  auto tick = [&](const char *what) {
+    if (!dbg) return;
+    const auto now = std::chrono::steady_clock::now();
+    std::fprintf(stderr, "[lt] host phase %-28s %8.2f ms\n", what, std::chrono::duration<double, std::milli>(now - t_last).count());
+    t_last = now;
+  };
   for (size_t t = 0; t < n; ++t) {
     const int64_t Lt = lengths[t];
     LtTarget tg{ (int64_t) t, names ? names[t] : nullptr, accs ? accs[t] : nullptr, descs ? descs[t] : nullptr, Lt };
@@ -798,6 +807,7 @@ static int lt_run_host(const p7x_pipeline_cfg &cfg, const p7x_oprofile *om, cons
       }
       if (i + bn >= Lt) break;
     }
+    tick("windows of the blocks");
     // the windows' filter scores, one device batch per target
     std::vector<LtWindowFilters> wf;
     std::vector<LongTargetWindowRef> refs;
@@ -839,6 +849,7 @@ static int lt_run_host(const p7x_pipeline_cfg &cfg, const p7x_oprofile *om, cons
       });
       for (const LtCounters &c : pc) { ctr.n_past_msv += c.n_past_msv; ctr.n_past_bias += c.n_past_bias; ctr.pos_past_msv += c.pos_past_msv; ctr.pos_past_bias += c.pos_past_bias; }
     }
+    tick("window scores + prefilter");
     // residues of a stretch of a block on its strand: out[1..len], sentinels around
     auto fetch = [&](const BlockJob &job, int64_t first_block_pos, int64_t len, std::vector<uint8_t> &outv) {
       outv.assign((size_t) len + 2, 255);
@@ -872,6 +883,7 @@ static int lt_run_host(const p7x_pipeline_cfg &cfg, const p7x_oprofile *om, cons
         else if (pf[q].state == 1) vit_of[q].assign(1, LtWindow{ 1, 0, w.length });
       }
     }
+    tick("long-target Viterbi scan");
     // every Viterbi window: Forward (one device batch when there is a device), then Backward / domain definition for
     // the few that pass, on the host workers; hits stay in window order
     struct VitJob { size_t q; LtWindow vw; };
@@ -890,6 +902,7 @@ static int lt_run_host(const p7x_pipeline_cfg &cfg, const p7x_oprofile *om, cons
       const int st = filters->forward(seq, comp, vrefs.data(), vrefs.size(), fwd_dev.data());
       if (st != P7X_OK) return st;
     }
+    tick("Forward of the Viterbi windows");
     std::vector<std::vector<Hit>> jh(vj.size());
     std::vector<LtCounters> jc(vj.size());
     std::vector<int> jst(vj.size(), P7X_OK);
@@ -912,7 +925,9 @@ static int lt_run_host(const p7x_pipeline_cfg &cfg, const p7x_oprofile *om, cons
       ctr.pos_past_vit += jc[z].pos_past_vit; ctr.pos_past_fwd += jc[z].pos_past_fwd;
     }
   }
+  tick("Backward + domain definition");
   lt_finish_tophits(cfg, p, max_length, nres, (uint64_t) n, ctr, hits, out);
+  tick("hit list");
   return P7X_OK;
 }
 
