@@ -578,9 +578,10 @@ static int lt_post_viterbi(const p7x_pipeline_cfg &cfg, const Profile &p, const 
   for (Domain &dom : dd.dcl) {
     const int64_t env_len = dom.jenv - dom.ienv + 1, ali_len = dom.jali - dom.iali + 1;
     float bitscore = dom.envsc;
-    // the envelope was scored with its own length model; charge the window and then re-express the score as if every
-    // window had the length max_length, so that scores do not depend on how the windows happened to merge
-    bitscore -= 2 * log(2. / (window_len + 2));
+    // the envelope was scored (unihit) under the window's length model: take out what that model charged for entering,
+    // leaving and the envelope's flanks, then re-express the score as if every window had the length max_length, so
+    // that scores do not depend on how the windows happened to merge
+    bitscore -= 2 * log(2. / (window_len + 2)) + (env_len - ali_len) * log((float) window_len / (float) (window_len + 2));
     bitscore += 2 * log(2. / (max_length + 2));
     bitscore += (std::max<int64_t>(max_length, env_len) - ali_len) * log((float) max_length / (float) (max_length + 2));
     const float dom_nullsc = lt_null1(std::max<int64_t>(max_length, env_len));

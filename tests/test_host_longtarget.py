@@ -68,9 +68,9 @@ def test_bmyd_hmm_vs_genome_matches_nhmmer_table(libp7x, oracle):
     """reference test_bmyd_hmm_genome_block / _file (test_hmmer.py:755-775) against tables/bmyD2.tbl (391 kb contig, two
     blocks of 0x40000 with max_length overlap): three reported hits, two of them included, in the table's order.  Rows 1
     and 2: every coordinate exact; row 3 (a 65-column alignment scoring 1.1 bits): envelope exact, alignment ends within
-    one residue.  Scores and biases agree to 0.12 bit (the reference's assertion allows 0.1: row 2 is 8.79 / 1.10
-    against 8.9 / 1.2), E-values to the reference's tolerance: see DESIGN.md on what is pinned of the long-target
-    domain definition."""
+    one residue.  Scores, biases and E-values agree to the reference's own tolerance, 0.1 (assertTableEqual,
+    test_hmmer.py:675-692; the closest call is row 2, 8.83 / 1.10 against 8.9 / 1.2): see DESIGN.md on what is pinned of
+    the long-target domain definition."""
     hmm = load_hmms("bmyD")[0]
     seqs = _read("1390.SAMEA104415756.OFHT01000022.fna", hmm.alphabet)
     hits = host_pipeline.host_nhmmer(oracle, hmm, seqs)
@@ -79,13 +79,13 @@ def test_bmyd_hmm_vs_genome_matches_nhmmer_table(libp7x, oracle):
 
 def check_bmyd2_table(hits, rows):
     assert len(hits.reported) == 3 and len(hits.included) == 2
-    check_nhmmer_table(hits, rows, exact_rows=1)
+    check_nhmmer_table(hits, rows, exact_rows=2)
     for row, hit in zip(rows, hits.reported):
         d = hit.best_domain
         assert (d.env_from, d.env_to) == (int(row[8]), int(row[9])) and d.strand == row[11]
         assert abs(d.alignment.target_from - int(row[6])) <= 1 and abs(d.alignment.target_to - int(row[7])) <= 1
         assert abs(d.alignment.hmm_from - int(row[4])) <= 1 and d.alignment.hmm_to == int(row[5])
-        assert d.score == pytest.approx(float(row[13]), abs=0.12) and d.bias == pytest.approx(float(row[14]), abs=0.12)
+        assert d.score == pytest.approx(float(row[13]), abs=0.1) and d.bias == pytest.approx(float(row[14]), abs=0.1)
         assert d.i_evalue == pytest.approx(float(row[12]), abs=0.1) and d.i_evalue == pytest.approx(float(row[12]), rel=0.12)
     assert [(h.best_domain.alignment.target_from, h.best_domain.alignment.target_to) for h in hits.reported[:2]] == [(int(r[6]), int(r[7])) for r in rows[:2]]
 
