@@ -3,6 +3,7 @@
 #include "p7x_internal.hpp"
 #include <hip/hip_runtime.h>
 #include <map>
+#include <memory>
 #include <mutex>
 
 namespace p7x {
@@ -51,6 +52,9 @@ int pinned_acquire(size_t bytes, void **out, size_t *got);
 void pinned_release(void *p, size_t bytes);
 int get_ctx(int device, DeviceCtx **out);
 
+// A slab of the context's pool that goes back to it when the last owner lets go.
+struct SlabRef { DeviceCtx *ctx = nullptr; void *p = nullptr; size_t bytes = 0; ~SlabRef(); };
+
 // Device image of one query profile.
 struct DevProfile {
   int device = -1;
@@ -71,12 +75,15 @@ struct DevProfile {
   float *fwd_emis = nullptr;
   // bias filter: emission odds [kTabRows][2]
   float *bias_eo = nullptr;
-  // all of the tables above live in one device allocation taken from (and returned to) the context's slab pool
-  void *slab = nullptr; size_t slab_bytes = 0;
+  // all of the tables above live in one device allocation taken from (and returned to) the context's slab pool, shared
+  // by the images that were built in one call (get_dev_profiles)
+  std::shared_ptr<SlabRef> shared;
 };
 
 // Device image of om for ctx's device, built and uploaded on first use (p7x_devimage.hip); owned by the oprofile.
 int get_dev_profile(const p7x_oprofile *om, DeviceCtx *ctx, DevProfile **out);
+// the same for the profiles of a batch: tables laid out by <nthreads> host workers, one slab, one copy
+int get_dev_profiles(const p7x_oprofile *const *oms, int n, DeviceCtx *ctx, DevProfile **out, int nthreads);
 void free_dev_profile(DevProfile *d);
 
 // host driver of the envelope kernel (p7x_envscore.hip), behind the EnvelopeScorer interface of p7x_host.hpp

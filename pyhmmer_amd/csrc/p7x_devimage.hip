@@ -7,6 +7,7 @@
 // thread that is winding down) would serialise the host against the whole device.
 #include "p7x_device.hpp"
 #include "p7x_kernels.hpp"
+#include "p7x_host.hpp"
 #include <cstring>
 #include <memory>
 
@@ -66,16 +67,15 @@ void slab_release(DeviceCtx *ctx, void *p, size_t bytes)
 {
   if (!p) return;
   std::lock_guard<std::mutex> lk(ctx->slab_mu);
-  if (ctx->slab_free_bytes + bytes > ((size_t) 4 << 30)) { (void) hipFree(p); return; }   // keep at most 4 GiB parked
+  if (ctx->slab_free_bytes + bytes > ((size_t) 32 << 30)) { (void) hipFree(p); return; }   // keep at most 32 GiB parked (of 288)
   ctx->slab_free.emplace(bytes, p); ctx->slab_free_bytes += bytes;
 }
 
+SlabRef::~SlabRef() { if (ctx && p) slab_release(ctx, p, bytes); }
+
 void free_dev_profile(DevProfile *d)
 {
-  if (!d) return;
-  DeviceCtx *ctx = nullptr;
-  if (get_ctx(d->device, &ctx) == P7X_OK) slab_release(ctx, d->slab, d->slab_bytes);
-  delete d;
+  delete d;          // the slab goes back to the pool with the last image cut from it (SlabRef)
 }
 
 struct DevCache { std::mutex mu; std::vector<DevProfile *> per_device; };
@@ -84,8 +84,6 @@ struct DevCache { std::mutex mu; std::vector<DevProfile *> per_device; };
 // and go up with one copy on a stream of the building thread.
 struct ImageStage {
   char *pinned = nullptr; size_t cap = 0; hipStream_t stream = nullptr; int device = -1;
-  std::vector<std::pair<void **, size_t>> fix;      // pointer field in the DevProfile <- offset in the slab
-  size_t used = 0;
   ~ImageStage() { pinned_release(pinned, cap); if (stream) (void) hipStreamDestroy(stream); }
   int reserve(size_t bytes)
   {
@@ -112,35 +110,31 @@ struct StageLease {
   ~StageLease() { std::lock_guard<std::mutex> lk(stage_pool().mu); stage_pool().idle.push_back(st); }
 };
 
-template <typename T, typename F>
-static int stage_table(ImageStage &st, std::vector<std::vector<char>> &parts, F **field, const std::vector<T> &v)
-{
-  const size_t off = st.used;
-  parts.emplace_back(reinterpret_cast<const char *>(v.data()), reinterpret_cast<const char *>(v.data()) + v.size() * sizeof(T));
-  st.fix.emplace_back(reinterpret_cast<void **>(field), off);
-  st.used = ((off + v.size() * sizeof(T) + 255) / 256) * 256;
-  return P7X_OK;
-}
+// Host side of one image: the tables back to back (256-byte aligned) and, for every table, the DevProfile field that
+// will point at it.
+struct HostImage {
+  std::vector<char> bytes;
+  std::vector<std::pair<void **, size_t>> fix;      // pointer field in the DevProfile <- offset in <bytes>
+  template <typename T, typename F>
+  void add(F **field, const std::vector<T> &v)
+  {
+    const size_t off = bytes.size(), n = v.size() * sizeof(T);
+    bytes.resize(((off + n + 255) / 256) * 256);
+    std::memcpy(bytes.data() + off, v.data(), n);
+    fix.emplace_back(reinterpret_cast<void **>(field), off);
+  }
+};
 
-int get_dev_profile(const p7x_oprofile *om, DeviceCtx *ctx, DevProfile **out)
+// All the tables of one profile, laid out on the host (pure CPU work: the batch entry point runs it on the workers).
+static void build_host_image(const Profile &p, DevProfile *d, HostImage &img)
 {
-  auto *cache = static_cast<DevCache *>(om->dev_cache);
-  std::lock_guard<std::mutex> lk(cache->mu);
-  for (DevProfile *d : cache->per_device) if (d->device == ctx->device) { *out = d; return P7X_OK; }
-  const Profile &p = om->p;
-  auto d = std::make_unique<DevProfile>();
-  d->device = ctx->device; d->M = p.M; d->Kp = p.Kp;
-  StageLease stage_lease;
-  ImageStage &stg = *stage_lease.st;
-  stg.fix.clear(); stg.used = 0;
-  std::vector<std::vector<char>> parts;
   // MSV parity tables
   d->msvR = msv_pick(p.M, &d->msvK);
   if (d->msvR > 0) {
     d->msvS = msv_stride(d->msvR, d->msvK);
     std::vector<uint32_t> tab;
     msv_build_tables(p, d->msvR, d->msvK, tab);
-    stage_table(stg, parts, &d->msv_tab, tab);
+    img.add(&d->msv_tab, tab);
   }
   // wave-per-sequence tables
   d->vitC = vit_pick_C(p.M);
@@ -165,12 +159,12 @@ int get_dev_profile(const p7x_oprofile *om, DeviceCtx *ctx, DevProfile **out)
       std::vector<int16_t> me((size_t) kTabRows * Mpad, (int16_t) kNegPad);
       for (int k = 1; k <= p.M; ++k)
         for (int x = 0; x < p.Kp; ++x) me[(size_t) x * Mpad + pos[k]] = (int16_t) ((int) p.bias_b - (int) p.rb[(size_t) x * (p.M + 1) + k]);
-      stage_table(stg, parts, &d->msvw_emis, me);
+      img.add(&d->msvw_emis, me);
     }
-    stage_table(stg, parts, &d->vit_trans, vt);
-    stage_table(stg, parts, &d->vit_emis, ve);
-    stage_table(stg, parts, &d->fwd_trans, ft);
-    stage_table(stg, parts, &d->fwd_emis, fe);
+    img.add(&d->vit_trans, vt);
+    img.add(&d->vit_emis, ve);
+    img.add(&d->fwd_trans, ft);
+    img.add(&d->fwd_emis, fe);
   }
   {
     int T = 0, P = 0;
@@ -178,8 +172,8 @@ int get_dev_profile(const p7x_oprofile *om, DeviceCtx *ctx, DevProfile **out)
       std::vector<uint32_t> tt, te;
       vitpk_build_tables(p, T, P, tt, te);
       d->vitpkT = T; d->vitpkP = P;
-      stage_table(stg, parts, &d->vitpk_trans, tt);
-      stage_table(stg, parts, &d->vitpk_emis, te);
+      img.add(&d->vitpk_trans, tt);
+      img.add(&d->vitpk_emis, te);
     }
   }
   // bias filter emission odds (esl_hmm_Configure on the 2-state filter HMM, p7_bg_SetFilter)
@@ -193,33 +187,74 @@ int get_dev_profile(const p7x_oprofile *om, DeviceCtx *ctx, DevProfile **out)
         for (int y = 0; y < p.K; ++y) if (abc.degen[x][y]) { e += (s == 0 ? p.bgf[y] : p.compo[y]); den += p.bgf[y]; }
         eo[x * 2 + s] = den > 0.0f ? e / den : 0.0f;
       }
-    stage_table(stg, parts, &d->bias_eo, eo);
+    img.add(&d->bias_eo, eo);
   }
-  // one slab, one copy
-  {
-    int stq = P7X_OK;
-    if ((stq = stg.reserve(stg.used)) != P7X_OK) return stq;
-    if (stg.stream == nullptr || stg.device != ctx->device) {
-      if (stg.stream) (void) hipStreamDestroy(stg.stream);
-      P7X_HIP(hipStreamCreateWithFlags(&stg.stream, hipStreamNonBlocking));
-      stg.device = ctx->device;
-    }
-    if ((stq = slab_acquire(ctx, stg.used, &d->slab, &d->slab_bytes)) != P7X_OK) return stq;
-    for (size_t i = 0; i < parts.size(); ++i) {
-      std::memcpy(stg.pinned + stg.fix[i].second, parts[i].data(), parts[i].size());
-      *stg.fix[i].first = static_cast<char *>(d->slab) + stg.fix[i].second;
-    }
-    if (hipMemcpyAsync(d->slab, stg.pinned, stg.used, hipMemcpyHostToDevice, stg.stream) != hipSuccess ||
-        hipStreamSynchronize(stg.stream) != hipSuccess) {
-      slab_release(ctx, d->slab, d->slab_bytes);
-      set_error("uploading the profile's device image failed");
-      return P7X_EDEVICE;
-    }
+}
+
+// Images of the profiles of a batch that have none on ctx's device yet (a scan: all of them): the tables are laid out
+// by the host workers, then ONE slab holds them all and ONE copy takes them up -- a device allocation and a stream
+// synchronisation per profile cost more than the tables themselves once several batches are in flight.  The images of
+// one call share their slab (DevProfile::shared); it goes back to the pool with the last of them.
+int get_dev_profiles(const p7x_oprofile *const *oms, int n, DeviceCtx *ctx, DevProfile **out, int nthreads)
+{
+  std::vector<int> missing;
+  for (int i = 0; i < n; ++i) {
+    out[i] = nullptr;
+    auto *cache = static_cast<DevCache *>(oms[i]->dev_cache);
+    std::lock_guard<std::mutex> lk(cache->mu);
+    for (DevProfile *d : cache->per_device) if (d->device == ctx->device) { out[i] = d; break; }
+    if (!out[i]) missing.push_back(i);
   }
-  *out = d.get();
-  cache->per_device.push_back(d.release());
+  if (missing.empty()) return P7X_OK;
+  const int nm = (int) missing.size();
+  std::vector<std::unique_ptr<DevProfile>> fresh((size_t) nm);
+  std::vector<HostImage> imgs((size_t) nm);
+  auto build = [&](int z) {
+    const Profile &p = oms[missing[(size_t) z]]->p;
+    auto d = std::make_unique<DevProfile>();
+    d->device = ctx->device; d->M = p.M; d->Kp = p.Kp;
+    build_host_image(p, d.get(), imgs[(size_t) z]);
+    fresh[(size_t) z] = std::move(d);
+  };
+  if (nm >= 4) host_parallel_for(nm, nthreads, build); else for (int z = 0; z < nm; ++z) build(z);
+  std::vector<size_t> off((size_t) nm + 1, 0);
+  for (int z = 0; z < nm; ++z) off[(size_t) z + 1] = off[(size_t) z] + imgs[(size_t) z].bytes.size();
+  const size_t total = off[(size_t) nm];
+  StageLease stage_lease;
+  ImageStage &stg = *stage_lease.st;
+  int st = P7X_OK;
+  if ((st = stg.reserve(total)) != P7X_OK) return st;
+  if (stg.stream == nullptr || stg.device != ctx->device) {
+    if (stg.stream) (void) hipStreamDestroy(stg.stream);
+    P7X_HIP(hipStreamCreateWithFlags(&stg.stream, hipStreamNonBlocking));
+    stg.device = ctx->device;
+  }
+  auto shared = std::make_shared<SlabRef>();
+  shared->ctx = ctx;
+  if ((st = slab_acquire(ctx, total, &shared->p, &shared->bytes)) != P7X_OK) return st;
+  auto place = [&](int z) {
+    const HostImage &img = imgs[(size_t) z];
+    std::memcpy(stg.pinned + off[(size_t) z], img.bytes.data(), img.bytes.size());
+    for (const auto &f : img.fix) *f.first = static_cast<char *>(shared->p) + off[(size_t) z] + f.second;
+    fresh[(size_t) z]->shared = shared;
+  };
+  if (nm >= 4) host_parallel_for(nm, nthreads, place); else for (int z = 0; z < nm; ++z) place(z);
+  if (hipMemcpyAsync(shared->p, stg.pinned, total, hipMemcpyHostToDevice, stg.stream) != hipSuccess ||
+      hipStreamSynchronize(stg.stream) != hipSuccess) {
+    set_error("uploading the profiles' device images failed");
+    return P7X_EDEVICE;
+  }
+  for (int z = 0; z < nm; ++z) {
+    const int i = missing[(size_t) z];
+    auto *cache = static_cast<DevCache *>(oms[i]->dev_cache);
+    std::lock_guard<std::mutex> lk(cache->mu);
+    for (DevProfile *d : cache->per_device) if (d->device == ctx->device) { out[i] = d; break; }   // a duplicate in this batch, or another thread
+    if (!out[i]) { out[i] = fresh[(size_t) z].get(); cache->per_device.push_back(fresh[(size_t) z].release()); }
+  }
   return P7X_OK;
 }
+
+int get_dev_profile(const p7x_oprofile *om, DeviceCtx *ctx, DevProfile **out) { return get_dev_profiles(&om, 1, ctx, out, 1); }
 
 } // namespace p7x
 

@@ -4,18 +4,23 @@
 #include "p7x_wave.hpp"
 #include "p7x_host.hpp"
 #include <algorithm>
+#include <chrono>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <map>
 #include <memory>
+#include <string>
 
 namespace p7x {
 
 // ---------------------------------------------------------------------------- envelope rescoring on the device
-// Device and pinned-host buffers live for the thread (grow-only), like the cascade workspace.
+// Device and pinned-host buffers are grow-only, like the cascade workspace; a buffer that has to grow goes back to the
+// context's slab pool and the larger one comes from there (hipFree would wait for every stream of the device, i.e. for
+// the cascades of the other searches in flight).
 struct EnvBuffers {
   int device = -1;
-  float *work = nullptr; size_t work_floats = 0;
+  float *work = nullptr; size_t work_floats = 0, work_bytes = 0;
   unsigned char *d_in = nullptr; size_t d_in_cap = 0;        // env_sq | tr_off | env_len | env_L | EnvArgs records
   unsigned char *h_in = nullptr; size_t h_in_cap = 0;        // pinned mirror of d_in
   unsigned char *d_out = nullptr; size_t d_out_cap = 0;      // out_sc | out_null2 | out_status | tr_n | tr_a | tr_i | tr_pp
@@ -25,7 +30,8 @@ struct EnvBuffers {
     if (device < 0) return;
     (void) hipSetDevice(device);
     if (stream) (void) hipStreamDestroy(stream);
-    (void) hipFree(work); (void) hipFree(d_in); (void) hipFree(d_out);
+    DeviceCtx *ctx = nullptr;
+    if (get_ctx(device, &ctx) == P7X_OK) { slab_release(ctx, work, work_bytes); slab_release(ctx, d_in, d_in_cap); slab_release(ctx, d_out, d_out_cap); }
     pinned_release(h_out, h_out_cap);
     pinned_release(h_in, h_in_cap);
   }
@@ -57,6 +63,15 @@ public:
 
   int begin(const std::vector<EnvelopeJob> &jobs) override
   {
+    static const bool debug = std::getenv("P7X_FINISH_DEBUG") != nullptr;
+    auto tlast = std::chrono::steady_clock::now();
+    std::string dbg;
+    auto tick = [&](const char *what) {
+      if (!debug) return;
+      const auto now = std::chrono::steady_clock::now();
+      char buf[64]; std::snprintf(buf, sizeof buf, " %s %.2f", what, std::chrono::duration<double, std::milli>(now - tlast).count());
+      dbg += buf; tlast = now;
+    };
     jobs_ = jobs;
     meta_.assign(jobs.size(), JobMeta{});
     int64_t nenv_tot = 0;
@@ -68,11 +83,14 @@ public:
     {
       EnvPool &ep = env_pool();
       std::lock_guard<std::mutex> lk(ep.mu);
-      for (size_t i = 0; i < ep.all.size() && !eb; ++i)
-        if (!ep.busy[i] && ep.all[i]->device == db_->device) { ep.busy[i] = 1; eb = ep.all[i]; }
+      size_t pick = ep.all.size();       // the idle set with the largest workspace: fewer buffers have to grow
+      for (size_t i = 0; i < ep.all.size(); ++i)
+        if (!ep.busy[i] && ep.all[i]->device == db_->device && (pick == ep.all.size() || ep.all[i]->work_bytes > ep.all[pick]->work_bytes)) pick = i;
+      if (pick < ep.all.size()) { ep.busy[pick] = 1; eb = ep.all[pick]; }
       if (!eb) { eb = new EnvBuffers(); eb->device = db_->device; ep.all.push_back(eb); ep.busy.push_back(1); }
     }
     lease_ = eb;
+    tick("lease");
     if (!eb->stream) {
       int least = 0, greatest = 0;
       P7X_HIP(hipDeviceGetStreamPriorityRange(&least, &greatest));
@@ -86,13 +104,15 @@ public:
     const size_t in_bytes = o_args + nj * sizeof(EnvArgs);
     if (in_bytes > eb->h_in_cap) {
       pinned_release(eb->h_in, eb->h_in_cap); eb->h_in = nullptr; eb->h_in_cap = 0;
-      void *hp = nullptr; size_t got = 0; const int pst = pinned_acquire(in_bytes * 2, &hp, &got); if (pst != P7X_OK) return pst;
+      void *hp = nullptr; size_t got = 0; const int pst = pinned_acquire(std::max<size_t>(in_bytes * 2, (size_t) 1 << 20), &hp, &got); if (pst != P7X_OK) return pst;
       eb->h_in = static_cast<unsigned char *>(hp); eb->h_in_cap = got;
     }
     if (in_bytes > eb->d_in_cap) {
-      (void) hipFree(eb->d_in); eb->d_in = nullptr; eb->d_in_cap = 0;
-      P7X_HIP(hipMalloc(&eb->d_in, in_bytes * 2)); eb->d_in_cap = in_bytes * 2;
+      slab_release(ctx_, eb->d_in, eb->d_in_cap); eb->d_in = nullptr; eb->d_in_cap = 0;
+      void *dp = nullptr; size_t got = 0; const int sst = slab_acquire(ctx_, std::max<size_t>(in_bytes * 2, (size_t) 1 << 20), &dp, &got); if (sst != P7X_OK) return sst;
+      eb->d_in = static_cast<unsigned char *>(dp); eb->d_in_cap = got;
     }
+    tick("in_bufs");
     int64_t *env_sq = reinterpret_cast<int64_t *>(eb->h_in);
     int64_t *tr_off = env_sq + nenv_tot;
     int32_t *env_len = reinterpret_cast<int32_t *>(tr_off + nenv_tot);
@@ -129,6 +149,7 @@ public:
       std::stable_sort(ord, ord + m.nenv, [len](int32_t x, int32_t y) { return len[x] > len[y]; });
     }
     std::stable_sort(order_.begin(), order_.end(), [&](int x, int y) { return meta_[x].C < meta_[y].C; });
+    tick("requests");
     // workspace: one slab per wavefront of every job, sized for the longest envelope of the job's class
     std::map<int, int> class_Lmax;
     for (size_t j = 0; j < nj; ++j) if (meta_[j].nenv) { int &v = class_Lmax[meta_[j].C]; v = std::max(v, meta_[j].Lmax); }
@@ -155,22 +176,26 @@ public:
       if (all_one) { set_error("envelope workspace does not fit in device memory"); return P7X_EMEM; }
     }
     if (work_floats > eb->work_floats) {
-      (void) hipFree(eb->work); eb->work = nullptr; eb->work_floats = 0;
-      P7X_HIP(hipMalloc(&eb->work, work_floats * 4)); eb->work_floats = work_floats;
+      slab_release(ctx_, eb->work, eb->work_bytes); eb->work = nullptr; eb->work_floats = 0; eb->work_bytes = 0;
+      void *dp = nullptr; size_t got = 0; const int sst = slab_acquire(ctx_, work_floats * 4 + work_floats, &dp, &got); if (sst != P7X_OK) return sst;   // 25 % headroom
+      eb->work = static_cast<float *>(dp); eb->work_bytes = got; eb->work_floats = got / 4;
     }
+    tick("work");
     // outputs: [out_sc 2f][null2 32f][status i][tr_n i] per envelope, then the three trace arrays
     const size_t n = (size_t) nenv_tot;
     const size_t o_sc = 0, o_n2 = o_sc + n * 8, o_st = o_n2 + n * 128, o_n = o_st + n * 4;
     const size_t o_ta = o_n + n * 4, o_ti = o_ta + (size_t) ntr * 4, o_tp = o_ti + (size_t) ntr * 4;
     const size_t out_bytes = o_tp + (size_t) ntr * 4;
     if (out_bytes > eb->d_out_cap) {
-      (void) hipFree(eb->d_out); eb->d_out = nullptr;
+      slab_release(ctx_, eb->d_out, eb->d_out_cap); eb->d_out = nullptr; eb->d_out_cap = 0;
       pinned_release(eb->h_out, eb->h_out_cap); eb->h_out = nullptr; eb->h_out_cap = 0;
-      const size_t cap = out_bytes + out_bytes / 2;
-      P7X_HIP(hipMalloc(&eb->d_out, cap)); eb->d_out_cap = cap;
+      size_t cap = std::max<size_t>(out_bytes + out_bytes / 2, (size_t) 16 << 20);     // growing is a stall (pinned allocation): start generous
+      { void *dp = nullptr; size_t got = 0; const int sst = slab_acquire(ctx_, cap, &dp, &got); if (sst != P7X_OK) return sst;
+        eb->d_out = static_cast<unsigned char *>(dp); eb->d_out_cap = cap = got; }
       { void *hp = nullptr; size_t got = 0; const int pst = pinned_acquire(cap, &hp, &got); if (pst != P7X_OK) return pst;
         eb->h_out = static_cast<decltype(eb->h_out)>(hp); eb->h_out_cap = got; }
     }
+    tick("out_bufs");
     hipStream_t s = eb->stream;
     const int64_t *d_env_sq = reinterpret_cast<const int64_t *>(eb->d_in);
     const int64_t *d_tr_off = d_env_sq + nenv_tot;
@@ -209,14 +234,20 @@ public:
       else runs.emplace_back(nrec, 1);
       h_args[nrec++] = a;
     }
+    tick("args");
     P7X_HIP(hipMemcpyAsync(eb->d_in, eb->h_in, in_bytes, hipMemcpyHostToDevice, s));
+    tick("h2d");
     for (const auto &run : runs) {
       ArgRun<EnvArgs> ar;
       ar.host = h_args + run.first; ar.dev = eb->d_in + o_args + (size_t) run.first * sizeof(EnvArgs);
       ar.stride = (uint32_t) sizeof(EnvArgs); ar.n = run.second;
       if ((st = env_launch(ar, s)) != P7X_OK) return st;
     }
+    tick("launches");
     P7X_HIP(hipMemcpyAsync(eb->h_out, eb->d_out, out_bytes, hipMemcpyDeviceToHost, s));
+    tick("d2h");
+    if (debug) std::fprintf(stderr, "[env begin] jobs %zu envelopes %lld runs %zu work %.1f MB out %.1f MB:%s ms\n", nj, (long long) nenv_tot, runs.size(),
+                            work_floats * 4 / 1e6, out_bytes / 1e6, dbg.c_str());
     eb_ = eb; o_sc_ = o_sc; o_n2_ = o_n2; o_st_ = o_st; o_n_ = o_n; o_ta_ = o_ta; o_ti_ = o_ti; o_tp_ = o_tp;
     tr_off_.assign(tr_off, tr_off + nenv_tot);
     return P7X_OK;

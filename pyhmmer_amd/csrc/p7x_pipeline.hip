@@ -8,11 +8,13 @@
 // lengths are read by the next stage from device memory, so the cascade runs without host round trips.
 #include "p7x_wave.hpp"
 #include "p7x_host.hpp"
+#include <atomic>
 #include <chrono>
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
 #include <memory>
+#include <string>
 
 namespace p7x {
 
@@ -473,7 +475,7 @@ struct Workspace {
   int *counters = nullptr;                  // [nlanes][kLaneCounters] then the arena cursor (64 bit)
   LaneArgs *d_args = nullptr, *h_args = nullptr; size_t h_args_bytes = 0;     // [nlanes], device / pinned host
   // Forward survivors: row arena (Forward rows, Backward rows, region-scan scratch) and per-lane, per-survivor arrays
-  float *xmx_f = nullptr, *xmx_b = nullptr, *xmx_s = nullptr; int64_t xmx_cap = 0;
+  float *xmx_f = nullptr, *xmx_b = nullptr, *xmx_s = nullptr; int64_t xmx_cap = 0; size_t xmx_bytes[3] = { 0, 0, 0 };   // slabs of the context's pool
   int64_t *xmx_off = nullptr; int32_t *reg_out = nullptr; float *bck_sc = nullptr;   // [nlanes][fin_cap (* kRegionCap*3+2)]
   int64_t fin_cap = 0;
   // one lane at a time, when the shared buffers were too small for it (rare)
@@ -826,11 +828,21 @@ static int fill_survivor_args(CascadeRun &r, int first, int n, bool retry, int n
   const p7x_seqdb *db = r.db; Workspace *ws = r.ws; DeviceCtx *ctx = r.ctx;
   int64_t want_cap = std::min<int64_t>(db->nslots, std::max<int64_t>(4096, db->nslots / 64));
   if (retry) want_cap = std::min<int64_t>(db->nslots, std::max<int64_t>(want_cap, (int64_t) nfin));
-  const int64_t want_floats = longest_rows(db, want_cap) * 6;
+  // The lanes of a batch share the row arena (one cursor).  A batch of many profiles against a small block (the scan
+  // orientation) can hold families with a dozen hits per profile: give it room for up to eight times the block's
+  // longest <want_cap> targets, so that such a batch does not fall back to the one-lane-at-a-time retry below.
+  const int64_t share = retry ? 1 : std::max<int64_t>(1, std::min<int64_t>(8, n / 32));
+  const int64_t want_floats = longest_rows(db, want_cap) * 6 * share;
   if (want_floats > ws->xmx_cap) {
-    (void) hipFree(ws->xmx_f); (void) hipFree(ws->xmx_b); (void) hipFree(ws->xmx_s); ws->xmx_f = ws->xmx_b = ws->xmx_s = nullptr; ws->xmx_cap = 0;
-    P7X_HIP(hipMalloc(&ws->xmx_f, (size_t) want_floats * 4)); P7X_HIP(hipMalloc(&ws->xmx_b, (size_t) want_floats * 4));
-    P7X_HIP(hipMalloc(&ws->xmx_s, (size_t) want_floats * 4));
+    // through the slab pool: hipFree would wait for the cascades of the other searches in flight
+    slab_release(ctx, ws->xmx_f, ws->xmx_bytes[0]); slab_release(ctx, ws->xmx_b, ws->xmx_bytes[1]); slab_release(ctx, ws->xmx_s, ws->xmx_bytes[2]);
+    ws->xmx_f = ws->xmx_b = ws->xmx_s = nullptr; ws->xmx_cap = 0;
+    float **dst[3] = { &ws->xmx_f, &ws->xmx_b, &ws->xmx_s };
+    for (int z = 0; z < 3; ++z) {
+      void *dp = nullptr;
+      const int sst = slab_acquire(ctx, (size_t) want_floats * 4, &dp, &ws->xmx_bytes[z]); if (sst != P7X_OK) return sst;
+      *dst[z] = static_cast<float *>(dp);
+    }
     ws->xmx_cap = want_floats;
   }
   int64_t cap = 0;
@@ -960,17 +972,33 @@ static int cascade_enqueue(CascadeRun &r)
   for (int i = 0; i < nq; ++i) r.query_of[i] = i;
   std::stable_sort(r.query_of.begin(), r.query_of.end(), [&](int a, int b) { return r.oms[a]->p.M < r.oms[b]->p.M; });
   r.lane_of.resize(nq); r.lm.resize(nq);
-  for (int l = 0; l < nq; ++l) {
-    r.lane_of[r.query_of[l]] = l;
-    r.lm[l].om = r.oms[r.query_of[l]];
-    if ((st = get_dev_profile(r.lm[l].om, ctx, &r.lm[l].dp)) != P7X_OK) return st;
+  for (int l = 0; l < nq; ++l) { r.lane_of[r.query_of[l]] = l; r.lm[l].om = r.oms[r.query_of[l]]; }
+  static const bool debug = std::getenv("P7X_FINISH_DEBUG") != nullptr;
+  auto tlast = std::chrono::steady_clock::now();
+  std::string dbg;
+  auto tick = [&](const char *what) {
+    if (!debug) return;
+    const auto now = std::chrono::steady_clock::now();
+    char buf[64]; std::snprintf(buf, sizeof buf, " %s %.2f", what, std::chrono::duration<double, std::milli>(now - tlast).count());
+    dbg += buf; tlast = now;
+  };
+  // device images of profiles seen for the first time (a scan: all of them): laid out by the host workers, one slab
+  // and one copy for the batch
+  {
+    std::vector<const p7x_oprofile *> lane_oms((size_t) nq);
+    std::vector<DevProfile *> dps((size_t) nq, nullptr);
+    for (int l = 0; l < nq; ++l) lane_oms[(size_t) l] = r.lm[l].om;
+    if ((st = get_dev_profiles(lane_oms.data(), nq, ctx, dps.data(), cfg.host_threads)) != P7X_OK) return st;
+    for (int l = 0; l < nq; ++l) r.lm[l].dp = dps[(size_t) l];
   }
+  tick("images");
   if (db->nslots == 0 || nq == 0) return P7X_OK;
   for (int l = 0; l < nq; ++l)
     if (r.lm[l].dp->vitC <= 0 || r.lm[l].dp->vitC > 32) { set_error("model too long for the device kernels (M > 2048)"); return P7X_EINVAL; }
   std::vector<LaneClass> classes;
   if ((st = lane_classes(r.lm, db, ctx, classes)) != P7X_OK) return st;
   if ((st = get_workspace(db->device, db->nslots, nq, &r.ws)) != P7X_OK) return st;
+  tick("classes+workspace");
   Workspace *ws = r.ws;
   hipStream_t s = ws->stream;
   r.queued = true;
@@ -1001,8 +1029,11 @@ static int cascade_enqueue(CascadeRun &r)
     a.out_sc = b.fwd_by_item;
     la.fwd = a;
   }
+  tick("args");
   if ((st = fill_survivor_args(r, 0, nq, false, 0)) != P7X_OK) return st;
+  tick("survivor_args");
   if ((st = upload_args(ws, 0, nq, s)) != P7X_OK) return st;
+  tick("upload");
   P7X_HIP(hipMemsetAsync(ws->counters, 0, ws->counters_bytes(), s));      // lane counters and the arena cursor
   if (classes.size() == 1) {
     const bool fills_device = (db->nslots / 64) * (int64_t) nq >= (int64_t) ctx->num_cu * 8;
@@ -1023,6 +1054,8 @@ static int cascade_enqueue(CascadeRun &r)
   }
   P7X_HIP(hipMemcpyAsync(ws->h_counts, ws->counters, ws->counters_bytes(), hipMemcpyDeviceToHost, s));
   P7X_HIP(hipEventRecord(ws->ev_sync, s));
+  tick("launches");
+  if (debug) std::fprintf(stderr, "[enqueue] nq %d classes %zu:%s ms\n", nq, classes.size(), dbg.c_str());
   return P7X_OK;
 }
 
@@ -1094,7 +1127,10 @@ static int cascade_collect(CascadeRun &r, std::vector<CascadeOut> &outs)
   struct Release { CascadeRun &r; ~Release() { (void) hipStreamSynchronize(r.ws->stream); release_workspace(r.ws); r.collected = true; } } release{ r };
   int st = P7X_OK;
   P7X_HIP(hipSetDevice(db->device));                      // the collecting thread may have driven another device since
+  static const bool debug = std::getenv("P7X_FINISH_DEBUG") != nullptr;
+  const auto tc0 = std::chrono::steady_clock::now();
   P7X_HIP(hipEventSynchronize(ws->ev_sync));              // our work only: other cascades run on other streams
+  const auto tc1 = std::chrono::steady_clock::now();
   std::vector<int> flagged, few;
   constexpr int kFew = 64;            // lanes with at most this many survivors are fetched together, one 2-D copy per array
   int few_w = 0;
@@ -1171,6 +1207,13 @@ static int cascade_collect(CascadeRun &r, std::vector<CascadeOut> &outs)
   double ms[8]{};
   for (int i = 0; i < 6; ++i) { float t = 0; (void) hipEventElapsedTime(&t, ws->ev[i], ws->ev[i + 1]); ms[i] = t; }
   { float t = 0; (void) hipEventElapsedTime(&t, ws->ev[0], ws->ev[7]); ms[7] = t; }
+  if (debug) {
+    const auto tc2 = std::chrono::steady_clock::now();
+    long long nfin_tot = 0; for (const CascadeOut &o : outs) nfin_tot += o.counts[4];
+    std::fprintf(stderr, "[collect] nq %d survivors %lld few %zu flagged %zu: device wait %.2f fetch %.2f ms; events msv %.2f bias %.2f vit %.2f fwd %.2f rows %.2f bck+regions %.2f (msv kernel %.2f)\n",
+                 nq, nfin_tot, few.size(), flagged.size(), std::chrono::duration<double, std::milli>(tc1 - tc0).count(),
+                 std::chrono::duration<double, std::milli>(tc2 - tc1).count(), ms[0], ms[1], ms[2], ms[3], ms[4], ms[5], ms[7]);
+  }
   for (int l = 0; l < nq; ++l) {
     CascadeOut &out = outs[(size_t) r.query_of[l]];
     std::memcpy(out.ms, ms, sizeof(ms));

@@ -83,60 +83,59 @@ static int usable_cpus()
 }
 
 // Persistent workers for the host phases of a search (spawning 16 threads three times per query costs ~1 ms).
-// run(n, nthreads, body) calls body(i) for every i in [0, n), dynamically scheduled; the caller participates.
+// run(n, nthreads, body) calls body(i) for every i in [0, n), dynamically scheduled; the caller participates and at most
+// nthreads - 1 workers join it.  Several callers may be inside run() at once (the host stages of the batches in flight):
+// their regions share the workers, oldest region first, so a region that is down to one long item (a stochastic
+// traceback ensemble is a serial walk) does not hold up the short phases of the next batch.
 class HostPool {
 public:
-  static HostPool &get() { static HostPool pool; return pool; }
+  static HostPool &get() { static HostPool *pool = new HostPool(); return *pool; }      // never torn down (no joins at process exit)
   void run(int n, int nthreads, const std::function<void(int)> &body)
   {
     if (n <= 0) return;
-    std::unique_lock<std::mutex> run_lock(run_mu_);                  // one parallel region at a time
     if (nthreads > n) nthreads = n;
-    if (nthreads <= 1) { flogsum_init(); for (int i = 0; i < n; ++i) body(i); return; }
+    flogsum_init();
+    if (nthreads <= 1) { for (int i = 0; i < n; ++i) body(i); return; }
+    Region rg;
+    rg.body = &body; rg.n = n; rg.max_workers = nthreads - 1;
     {
       std::lock_guard<std::mutex> lk(mu_);
-      while ((int) workers_.size() < nthreads - 1) workers_.emplace_back([this, id = (int) workers_.size()] { loop(id); });
-      body_ = &body; n_ = n; next_.store(0); active_ = nthreads - 1; pending_ = nthreads - 1; ++generation_;
+      while ((int) workers_.size() < nthreads - 1) workers_.emplace_back([this] { loop(); });
+      regions_.push_back(&rg);
     }
     cv_.notify_all();
-    flogsum_init();
-    for (;;) { const int i = next_.fetch_add(1); if (i >= n) break; body(i); }
+    for (;;) { const int i = rg.next.fetch_add(1); if (i >= n) break; body(i); }
     std::unique_lock<std::mutex> lk(mu_);
-    done_cv_.wait(lk, [this] { return pending_ == 0; });
-    body_ = nullptr;
+    for (size_t z = 0; z < regions_.size(); ++z) if (regions_[z] == &rg) { regions_.erase(regions_.begin() + (long) z); break; }   // no new workers
+    rg.done_cv.wait(lk, [&] { return rg.active == 0; });
   }
 private:
+  struct Region {
+    const std::function<void(int)> *body = nullptr;
+    int n = 0, max_workers = 0, active = 0;         // active: workers inside this region (under mu_)
+    std::atomic<int> next{0};
+    std::condition_variable done_cv;
+  };
   HostPool() = default;
-  ~HostPool()
-  {
-    { std::lock_guard<std::mutex> lk(mu_); stop_ = true; ++generation_; }
-    cv_.notify_all();
-    for (auto &t : workers_) t.join();
-  }
-  void loop(int id)
+  void loop()
   {
     flogsum_init();
-    uint64_t seen = 0;
+    std::unique_lock<std::mutex> lk(mu_);
     for (;;) {
-      const std::function<void(int)> *body = nullptr; int n = 0;
-      {
-        std::unique_lock<std::mutex> lk(mu_);
-        cv_.wait(lk, [&] { return stop_ || (generation_ != seen && id < active_); });
-        if (stop_) return;
-        seen = generation_; body = body_; n = n_;
-      }
-      for (;;) { const int i = next_.fetch_add(1); if (i >= n) break; (*body)(i); }
-      { std::lock_guard<std::mutex> lk(mu_); if (--pending_ == 0) done_cv_.notify_one(); }
+      Region *rg = nullptr;
+      for (Region *r : regions_) if (r->active < r->max_workers && r->next.load(std::memory_order_relaxed) < r->n) { rg = r; break; }
+      if (!rg) { cv_.wait(lk); continue; }
+      rg->active++;
+      lk.unlock();
+      for (;;) { const int i = rg->next.fetch_add(1); if (i >= rg->n) break; (*rg->body)(i); }
+      lk.lock();
+      if (--rg->active == 0) rg->done_cv.notify_all();
     }
   }
-  std::mutex run_mu_, mu_;
-  std::condition_variable cv_, done_cv_;
+  std::mutex mu_;
+  std::condition_variable cv_;
   std::vector<std::thread> workers_;
-  const std::function<void(int)> *body_ = nullptr;
-  int n_ = 0, active_ = 0, pending_ = 0;
-  std::atomic<int> next_{0};
-  uint64_t generation_ = 0;
-  bool stop_ = false;
+  std::vector<Region *> regions_;
 };
 
 float kahan_fsum(const float *v, int n)
@@ -301,6 +300,16 @@ int host_finish_batch(const p7x_pipeline_cfg &cfg_in, const std::vector<FinishIt
   }
   const int S = first[(size_t) nq];
   const auto t0 = std::chrono::steady_clock::now();
+  // P7X_FINISH_DEBUG: wall time of the phases of this call on stderr
+  static const bool debug = std::getenv("P7X_FINISH_DEBUG") != nullptr;
+  auto tlast = t0;
+  std::string dbg;
+  auto tick = [&](const char *what) {
+    if (!debug) return;
+    const auto now = std::chrono::steady_clock::now();
+    char buf[64]; std::snprintf(buf, sizeof buf, " %s %.2f", what, std::chrono::duration<double, std::milli>(now - tlast).count());
+    dbg += buf; tlast = now;
+  };
   std::vector<Pending> pend((size_t) S);
   std::atomic<int> failed{0};
   int nthreads = cfg_in.host_threads > 0 ? cfg_in.host_threads : usable_cpus();
@@ -343,6 +352,7 @@ int host_finish_batch(const p7x_pipeline_cfg &cfg_in, const std::vector<FinishIt
         ths[(size_t) q]->guard_dropped.push_back((*items[(size_t) q].targets)[(size_t) (f - first[(size_t) q])]);
       }
   }
+  tick("guard");
   auto finish = [&](int f, DomainDefResult &dd) {
     const int q = q_of[(size_t) f], i = f - first[(size_t) q];
     const FinishItem &it = items[(size_t) q];
@@ -381,6 +391,7 @@ int host_finish_batch(const p7x_pipeline_cfg &cfg_in, const std::vector<FinishIt
     if (st != P7X_OK) { failed.store(st); return; }
     if (!dev) finish(f, dds[(size_t) f]);
   });
+  tick("regions");
   double ms_multi = 0.0, ms_env = 0.0;
   if (failed.load() == 0 && scorer) {
     std::vector<std::vector<EnvelopeRequest>> req((size_t) nq);
@@ -399,6 +410,7 @@ int host_finish_batch(const p7x_pipeline_cfg &cfg_in, const std::vector<FinishIt
     bool any = false;
     for (int q = 0; q < nq; ++q) { jobs[(size_t) q] = EnvelopeJob{ items[(size_t) q].om, &req[(size_t) q], items[(size_t) q].targets }; any = any || !req[(size_t) q].empty(); }
     if (any) { const int st = scorer->begin(jobs); if (st != P7X_OK) return st; }
+    tick("env_begin");
     // the ensembles' clustered envelopes go to the device as a second round (scorer2) instead of being rescored here
     std::vector<std::vector<EnvelopeRequest>> local2((size_t) S);
     run_pool((int) heavy.size(), [&](int h) {
@@ -409,6 +421,7 @@ int host_finish_batch(const p7x_pipeline_cfg &cfg_in, const std::vector<FinishIt
       if (st != P7X_OK) failed.store(st);
     });
     ms_multi = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t1).count();
+    tick("multi");
     std::vector<std::vector<EnvelopeRequest>> req2((size_t) nq);
     std::vector<std::vector<int>> req_index2((size_t) S);
     std::vector<EnvelopeJob> jobs2((size_t) nq);
@@ -426,6 +439,7 @@ int host_finish_batch(const p7x_pipeline_cfg &cfg_in, const std::vector<FinishIt
     if (any2) { const int st = scorer2->wait(res2); if (st != P7X_OK) return st; }
     if (!any2) res2.assign((size_t) nq, {});
     ms_env = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t1).count();
+    tick("env_wait");
     // 3. alignment displays, null2 corrections, per-target scores
     if (failed.load() == 0)
       run_pool(S, [&](int f) {
@@ -438,6 +452,7 @@ int host_finish_batch(const p7x_pipeline_cfg &cfg_in, const std::vector<FinishIt
         finish(f, dds[(size_t) f]);
       });
   }
+  tick("deferred");
   host_prof_dump();
   if (failed.load() != 0) { set_error("domain definition workflow failure"); return failed.load(); }
   const double ms_host = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
@@ -464,6 +479,8 @@ int host_finish_batch(const p7x_pipeline_cfg &cfg_in, const std::vector<FinishIt
     sort_by_key(th);
     threshold(th);
   });
+  tick("hitlists");
+  if (debug) std::fprintf(stderr, "[finish] nq %d survivors %d threads %d:%s ms\n", nq, S, nthreads, dbg.c_str());
   for (int q = 0; q < nq; ++q) outs[q] = ths[(size_t) q].release();
   return P7X_OK;
 }

@@ -11,6 +11,8 @@ re-thresholded on the host.  No collective is involved.
 from __future__ import annotations
 
 import os
+import sys
+import time
 import threading
 from collections import deque
 from concurrent.futures import ThreadPoolExecutor
@@ -351,6 +353,22 @@ def _run_queries(db: "ShardedDatabase", pipelines: Sequence[Pipeline], queries: 
         raise src_error[0]
 
 
+_T0 = time.perf_counter()
+
+
+def _pipe_trace(what, idx, n=None):
+    # P7X_PIPE_DEBUG=1: timeline of the batches (ms since import, thread, event, batch index) on stderr
+    sys.stderr.write(f"[pipe] {1e3 * (time.perf_counter() - _T0):9.2f} {threading.current_thread().name[-10:]:>10} {what:9} {idx}{'' if n is None else f' ({n})'}\n")
+
+
+def _traced_finish(db, pendings, trace, idx):
+    trace("finish", idx)
+    try:
+        return db.finish(pendings)
+    finally:
+        trace("finished", idx)
+
+
 def _run_batches(db: "ShardedDatabase", pipelines: Sequence[Pipeline], queries: Iterable, pipeline_depth: int,
                  feeders: int, window: int = 1, finishers: int = 0) -> Iterator:
     """``queries`` yields lists of queries; yields ``(list, [TopHits], None)`` in order, or ``(list, None, error)`` for
@@ -369,6 +387,7 @@ def _run_batches(db: "ShardedDatabase", pipelines: Sequence[Pipeline], queries: 
     # device stage ahead of the host stage; results are handed over in order, at most pipeline_depth of them
     # staged or in flight at any time.
     nfeed = max(1, min(feeders, pipeline_depth))
+    trace = _pipe_trace if os.environ.get("P7X_PIPE_DEBUG") else (lambda *a: None)
     lock = threading.Lock()
     ready = threading.Condition(lock)
     slots = threading.Semaphore(pipeline_depth)
@@ -384,7 +403,9 @@ def _run_batches(db: "ShardedDatabase", pipelines: Sequence[Pipeline], queries: 
             idx, q, pendings, err = queued.popleft()
             if err is None:
                 try:
+                    trace("wait", idx)
                     db.wait(pendings)
+                    trace("waited", idx)
                 except BaseException as e:          # forwarded to the caller like _base.py:305-318
                     err = e
                     db.abandon(pendings)
@@ -419,7 +440,9 @@ def _run_batches(db: "ShardedDatabase", pipelines: Sequence[Pipeline], queries: 
                         return
                     state["issued"] = idx + 1
                 try:
+                    trace("enqueue", idx, len(q))
                     queued.append((idx, q, db.enqueue(pipelines, q), None))
+                    trace("enqueued", idx)
                 except BaseException as e:
                     queued.append((idx, q, None, e))
                 if len(queued) >= window:
@@ -482,7 +505,7 @@ def _run_batches(db: "ShardedDatabase", pipelines: Sequence[Pipeline], queries: 
                         return
                     yield q, res, None
                     continue
-                inflight.append((q, pool.submit(db.finish, pendings)))
+                inflight.append((q, pool.submit(_traced_finish, db, pendings, trace, nxt - 1)))
             while inflight and (inflight[0][1].done() or len(inflight) >= nfin or drained):
                 q, fut = inflight.popleft()
                 item0 = result_of(q, fut)
@@ -511,7 +534,7 @@ def _run_batches(db: "ShardedDatabase", pipelines: Sequence[Pipeline], queries: 
 
 
 def hmmscan(queries, profiles, *, cpus: int = 0, callback: Optional[Callable] = None, devices: Optional[Sequence[int]] = None,
-            pipeline_depth: int = 3, feeders: int = 3, window: int = 1, finishers: int = 0, batch: int = 64,
+            pipeline_depth: int = 3, feeders: int = 3, window: int = 1, finishers: int = 0, batch: int = 256,
             backend: Optional[str] = None, **options) -> Iterator[TopHits]:
     """Scan query sequences against a profile database; yields one ``TopHits`` per query sequence, in query order, whose
     hits are the profiles (reference ``hmmer/_hmmscan.py:90-231``, ``Pipeline.scan_seq`` ``plan7.pyx:6534-6622``).
@@ -526,9 +549,10 @@ def hmmscan(queries, profiles, *, cpus: int = 0, callback: Optional[Callable] = 
     database, so one profile's kernels are a few wavefronts running for the length of the longest query: several profiles
     are kept in flight on separate device streams to fill the device: each of the ``feeders`` threads queues the
     device stage of ``window`` batches of ``batch`` profiles before it waits for the oldest one, at most
-    ``pipeline_depth`` in total.  The defaults are the measured optimum of the 700-profile x 2,100-sequence case
-    (``scripts/scan_bench.py``): a batch of 64 profiles already spreads its length classes over the device's hardware
-    queues, so more than one batch per feeder only makes the batches wait for one another.
+    ``pipeline_depth`` in total.  The defaults are the measured optimum of the 2,800-profile x 2,100-sequence case
+    (``scripts/scan_bench.py``): a batch of 256 profiles fills the device with (profile, target group) work items, its
+    device images are laid out by the host workers and go up in one copy, and one batch per feeder keeps the batches
+    from waiting for one another.
     """
     from .easel import DigitalSequence
     from .plan7 import _P7X_SCAN_MODELS

@@ -26,13 +26,20 @@ oms, tb = fresh()
 print(f"{len(oms)} profiles built on the host in {1e3 * tb / len(oms):.3f} ms/profile")
 cells = sum(om.M for om in oms) * block.total_length()
 list(hmmer.hmmscan(block, oms[:28]))          # warm-up: kernels, workspaces
-for batch, feeders, depth, window in ((1, 4, 32, 4), (64, 2, 6, 2), (64, 1, 2, 1), (64, 2, 2, 1), (64, 3, 3, 1), (64, 4, 4, 1), (32, 4, 4, 1), (32, 2, 2, 1)):
-    oms, _ = fresh()
-    t0 = time.perf_counter()
-    res = list(hmmer.hmmscan(block, oms, feeders=feeders, pipeline_depth=depth, window=window, batch=batch))
-    dt = time.perf_counter() - t0
-    print(f"batch {batch:3d} feeders {feeders:2d} depth {depth:2d} window {window:2d}: {len(oms)} profiles x {len(block)} seqs in {dt:6.3f} s = "
-          f"{1e3 * dt / len(oms):6.3f} ms/profile, {cells / dt / 1e9:8.1f} GCUPS, hits {sum(len(r) for r in res)}", flush=True)
+configs = ((1, 4, 32, 4), (64, 1, 2, 1), (64, 2, 2, 1), (64, 3, 3, 1), (128, 2, 2, 1), (128, 3, 3, 1), (256, 1, 2, 1), (256, 2, 2, 1), (256, 3, 3, 1),
+           (256, 4, 4, 1), (512, 2, 2, 1), (512, 3, 3, 1))
+if len(sys.argv) > 2:
+    configs = tuple(tuple(int(x) for x in c.split(",")) for c in sys.argv[2:])
+for batch, feeders, depth, window in configs:
+    # first pass: workspaces, envelope buffers and pinned blocks of this (batch, feeders) shape are created on the way
+    # (cold); second pass: the same shape with fresh profiles (every profile still pays for its device image)
+    for label in ("cold", "warm"):
+        oms, _ = fresh()
+        t0 = time.perf_counter()
+        res = list(hmmer.hmmscan(block, oms, feeders=feeders, pipeline_depth=depth, window=window, batch=batch))
+        dt = time.perf_counter() - t0
+        print(f"batch {batch:3d} feeders {feeders:2d} depth {depth:2d} window {window:2d} {label}: {len(oms)} profiles x {len(block)} seqs in {dt:6.3f} s = "
+              f"{1e3 * dt / len(oms):6.3f} ms/profile, {cells / dt / 1e9:8.1f} GCUPS, hits {sum(len(r) for r in res)}", flush=True)
 # resident images (second pass over the same OptimizedProfile objects)
 t0 = time.perf_counter()
 res = list(hmmer.hmmscan(block, oms, batch=64))
@@ -41,10 +48,10 @@ print(f"batch 64, device images already resident: {1e3 * dt / len(oms):6.3f} ms/
 # phases of one batch on one thread
 db = plan7.SequenceDatabase(block)
 pli = plan7.Pipeline(block.alphabet)
-for B in (1, 16, 64):
+for B in (1, 16, 64, 256):
     acc = [0.0, 0.0, 0.0]
     nb = 0
-    for lo in range(0, min(len(oms), 8 * B), B):
+    for lo in range(0, min(len(oms), max(8 * B, 512)), B):
         qs = oms[lo:lo + B]
         t0 = time.perf_counter(); pend = pli._search_enqueue_batch(qs, db)
         t1 = time.perf_counter(); plan7.Pipeline._search_wait(pend)
