@@ -177,7 +177,8 @@ public:
     }
     if (work_floats > eb->work_floats) {
       slab_release(ctx_, eb->work, eb->work_bytes); eb->work = nullptr; eb->work_floats = 0; eb->work_bytes = 0;
-      void *dp = nullptr; size_t got = 0; const int sst = slab_acquire(ctx_, work_floats * 4 + work_floats, &dp, &got); if (sst != P7X_OK) return sst;   // 25 % headroom
+      void *dp = nullptr; size_t got = 0; // 25 % headroom and never less than 1 GiB: a large device allocation stalls this host stage for tens of ms
+      const int sst = slab_acquire(ctx_, std::max<size_t>(work_floats * 4 + work_floats, (size_t) 1 << 30), &dp, &got); if (sst != P7X_OK) return sst;
       eb->work = static_cast<float *>(dp); eb->work_bytes = got; eb->work_floats = got / 4;
     }
     tick("work");

@@ -57,8 +57,9 @@ struct EnvelopeScorer {
 // fwd_xmx / bck_xmx are the parsers' special-state rows, (L+1) x [E,N,J,B,C,SCALE].
 struct Region { int i, j; bool multi; };
 // Region scan done on the device (p7x_pipeline.hip regions_kernel): per survivor n[i] regions (or -1: range error),
-// regs[(i*cap + r)*3 ..] = first residue, last residue, is_multidomain_region; nexpected[i] = expected number of domains.
-struct DeviceRegions { const int32_t *n = nullptr; const int32_t *regs = nullptr; const float *nexpected = nullptr; int cap = 0; };
+// regs[(first(i) + r)*3 ..] = first residue, last residue, is_multidomain_region, with first(i) = start[i] (packed), or
+// i*cap when <start> is null; nexpected[i] = expected number of domains.
+struct DeviceRegions { const int32_t *n = nullptr; const int32_t *regs = nullptr; const float *nexpected = nullptr; int cap = 0; const int32_t *start = nullptr; };
 struct MultiRegionState { bool started = false; uint32_t rng_seed = 42, rng_x = 0; };   // RNG carried between the regions of one target
 int domaindef_regions(const Profile &p, int L, const float *fwd_xmx, const float *bck_xmx, DomainDefResult &dd, std::vector<Region> &regs);
 // <defer2>: the clustered envelopes are queued there (tagged <item>) for a second round of device rescoring instead of being

@@ -489,6 +489,9 @@ struct Workspace {
   hipStream_t side[kSide]{};
   hipEvent_t ev_fork = nullptr, ev_join[kSide]{};
   int *h_counts = nullptr; size_t h_counts_bytes = 0;   // pinned mirror of counters
+  // results of the Forward survivors of all lanes, packed by pack_survivors_kernel for one copy to the host
+  unsigned char *pack_dev = nullptr; size_t pack_dev_bytes = 0;      // slab of the context's pool
+  unsigned char *pack_host = nullptr; size_t pack_host_bytes = 0;    // pinned
   bool busy = false;                // between the enqueue and the collect half of a cascade
   size_t counters_bytes() const { return (size_t) nlanes * kLaneCounters * 4 + 8; }
   unsigned long long *cursor() const { return reinterpret_cast<unsigned long long *>(counters + (size_t) nlanes * kLaneCounters); }
@@ -508,6 +511,7 @@ struct Workspace {
     if (stream) (void) hipStreamDestroy(stream);
     for (auto &q : side) if (q) (void) hipStreamDestroy(q);
     pinned_release(h_counts, h_counts_bytes);
+    pinned_release(pack_host, pack_host_bytes); (void) hipFree(pack_dev);
     pinned_release(h_args, h_args_bytes);
   }
   StageBufs lane_bufs(int l) const
@@ -785,7 +789,8 @@ struct CascadeOut {
   std::vector<float> fwdsc;               // per survivor
   std::vector<float> fwd_xmx, bck_xmx;    // concatenated (L+1)*6 blocks; only fetched when the device region scan overflowed
   std::vector<int64_t> xmx_off;
-  std::vector<int32_t> reg_n, regs;       // device region scan: count per survivor (-1 range error), kRegionCap x (i, j, multi)
+  std::vector<int32_t> reg_n, regs;       // device region scan: count per survivor (-1 range error), regions (i, j, multi)
+  std::vector<int32_t> reg_start;         // first region of every survivor in <regs>; empty: kRegionCap slots per survivor
   std::vector<float> nexpected;
   std::vector<char> near;                 // per survivor: inside the F3 guard band (empty: none)
   bool have_xmx = false;
@@ -811,6 +816,46 @@ struct CascadeRun {
   bool queued = false, collected = false;
   ~CascadeRun() { if (ws && queued && !collected) { (void) hipStreamSynchronize(ws->stream); release_workspace(ws); } }
 };
+
+// The Forward survivors of every lane of a batch, gathered for ONE copy to the host: slot, Forward score, row offset,
+// region count, expected number of domains and the regions themselves (the region scan keeps kRegionCap slots per
+// survivor, 1.5 KB, of which a handful are used).  Survivor i of lane l goes to position lane_base[l] + i; its regions to
+// reg_start (a cursor: any order), -1 when the packed region array is full (the host then reads that survivor's
+// regions from the lane's own array).
+struct PackArgs {
+  const int32_t *list_fin; const float *fwd_by_item; int64_t slot_pitch;         // [lane][slot_pitch]
+  const int64_t *xmx_off; const int32_t *reg_out; int64_t cap;                    // [lane][cap], [lane][cap * (kRegionCap*3 + 2)]
+  const int *counters;                                                            // [lane][kLaneCounters]
+  const int32_t *lane_base;                                                       // [nlanes]
+  int32_t *fin; float *fwd; int64_t *off; int32_t *regn; float *nexp; int32_t *reg_start; int32_t *regs; int32_t regs_cap;
+  int *cursor;
+};
+__global__ void pack_survivors_kernel(const PackArgs a)
+{
+  const int l = (int) blockIdx.y;
+  const int nfin = a.counters[(size_t) l * kLaneCounters + 4];
+  if (a.counters[(size_t) l * kLaneCounters + 12] != 0) return;          // flagged lane: redone on its own
+  const int32_t *reg_l = a.reg_out + (size_t) l * (size_t) a.cap * (kRegionCap * 3 + 2);
+  for (int i = (int) (blockIdx.x * blockDim.x + threadIdx.x); i < nfin; i += (int) (gridDim.x * blockDim.x)) {
+    const int64_t t = (int64_t) a.lane_base[l] + i;
+    a.fin[t] = a.list_fin[(size_t) l * a.slot_pitch + i];
+    a.fwd[t] = a.fwd_by_item[(size_t) l * a.slot_pitch + i];
+    a.off[t] = a.xmx_off[(size_t) l * a.cap + i];
+    const int n = reg_l[(size_t) a.cap * kRegionCap * 3 + i];
+    a.regn[t] = n;
+    a.nexp[t] = reinterpret_cast<const float *>(reg_l)[(size_t) a.cap * (kRegionCap * 3 + 1) + i];
+    int start = -1;
+    if (n > 0) {
+      const int r0 = atomicAdd(a.cursor, n);
+      if (r0 + n <= a.regs_cap) {
+        start = r0;
+        const int32_t *src = reg_l + (size_t) i * kRegionCap * 3;
+        for (int z = 0; z < n * 3; ++z) a.regs[(size_t) r0 * 3 + z] = src[z];
+      }
+    }
+    a.reg_start[t] = start;
+  }
+}
 
 // rows of the <count> longest targets (slots are sorted by decreasing length): bounds the rows of any <count> survivors
 static int64_t longest_rows(const p7x_seqdb *db, int64_t count)
@@ -1131,51 +1176,91 @@ static int cascade_collect(CascadeRun &r, std::vector<CascadeOut> &outs)
   const auto tc0 = std::chrono::steady_clock::now();
   P7X_HIP(hipEventSynchronize(ws->ev_sync));              // our work only: other cascades run on other streams
   const auto tc1 = std::chrono::steady_clock::now();
-  std::vector<int> flagged, few;
-  constexpr int kFew = 64;            // lanes with at most this many survivors are fetched together, one 2-D copy per array
-  int few_w = 0;
+  std::vector<int> flagged;
+  std::vector<int32_t> lane_base((size_t) nq, 0);
+  int64_t T = 0; int max_nfin = 0;
   for (int l = 0; l < nq; ++l) {
     CascadeOut &out = outs[(size_t) r.query_of[l]];
     std::memcpy(out.counts, ws->h_counts + (size_t) l * kLaneCounters, kLaneCounters * 4);
-    const int nfin = out.counts[4];
+    lane_base[(size_t) l] = (int32_t) T;
     if (out.counts[12] != 0) flagged.push_back(l);
-    else if (nfin > 0 && nfin <= kFew && nq > 1) { few.push_back(l); few_w = std::max(few_w, nfin); }
-    else if ((st = fetch_lane(r, l, false, out)) != P7X_OK) return st;
+    else { T += out.counts[4]; max_nfin = std::max(max_nfin, out.counts[4]); }
   }
-  // staging of the lanes with few survivors: rows = lanes few.front() .. few.back(), few_w survivors wide
-  const int few_lo = few.empty() ? 0 : few.front(), few_h = few.empty() ? 0 : few.back() - few.front() + 1;
-  std::vector<int32_t> st_fin, st_regn, st_regs; std::vector<int64_t> st_off; std::vector<float> st_nexp, st_fwd;
-  if (!few.empty()) {
-    const size_t cells = (size_t) few_h * few_w;
-    const int64_t cap = ws->fin_cap;
-    st_fin.resize(cells); st_regn.resize(cells); st_off.resize(cells); st_nexp.resize(cells); st_fwd.resize(cells);
-    st_regs.resize(cells * kRegionCap * 3);
-    const StageBufs b0 = ws->lane_bufs(few_lo);
-    const int32_t *reg0 = ws->reg_out + (size_t) few_lo * cap * (kRegionCap * 3 + 2);
-    const size_t reg_pitch = (size_t) cap * (kRegionCap * 3 + 2) * 4;
-    P7X_HIP(hipMemcpy2DAsync(st_fin.data(), (size_t) few_w * 4, b0.list_fin, (size_t) ws->cap_slots * 4, (size_t) few_w * 4, few_h, hipMemcpyDeviceToHost, s));
-    P7X_HIP(hipMemcpy2DAsync(st_fwd.data(), (size_t) few_w * 4, b0.fwd_by_item, (size_t) ws->cap_slots * 4, (size_t) few_w * 4, few_h, hipMemcpyDeviceToHost, s));
-    P7X_HIP(hipMemcpy2DAsync(st_off.data(), (size_t) few_w * 8, ws->xmx_off + (size_t) few_lo * cap, (size_t) cap * 8, (size_t) few_w * 8, few_h, hipMemcpyDeviceToHost, s));
-    P7X_HIP(hipMemcpy2DAsync(st_regs.data(), (size_t) few_w * kRegionCap * 3 * 4, reg0, reg_pitch, (size_t) few_w * kRegionCap * 3 * 4, few_h, hipMemcpyDeviceToHost, s));
-    P7X_HIP(hipMemcpy2DAsync(st_regn.data(), (size_t) few_w * 4, reg0 + (size_t) cap * kRegionCap * 3, reg_pitch, (size_t) few_w * 4, few_h, hipMemcpyDeviceToHost, s));
-    P7X_HIP(hipMemcpy2DAsync(st_nexp.data(), (size_t) few_w * 4, reg0 + (size_t) cap * (kRegionCap * 3 + 1), reg_pitch, (size_t) few_w * 4, few_h, hipMemcpyDeviceToHost, s));
+  // One gather kernel and one copy bring the survivors' results of all lanes to the host (pinned): the region scan's
+  // own array has kRegionCap slots per survivor, and lane-by-lane or strided copies of it were most of this call.
+  const bool scan_mode = cfg.mode == P7X_SCAN_MODELS;
+  const int64_t regs_cap = std::max<int64_t>(8 * T, 4096);
+  const size_t o_base = 0, o_cursor = (size_t) nq * 4, o_off = (o_cursor + 4 + 7) & ~(size_t) 7;
+  const size_t o_fin = o_off + (size_t) T * 8, o_fwd = o_fin + (size_t) T * 4, o_regn = o_fwd + (size_t) T * 4, o_nexp = o_regn + (size_t) T * 4;
+  const size_t o_start = o_nexp + (size_t) T * 4, o_regs = o_start + (size_t) T * 4, o_stage = o_regs + (size_t) regs_cap * 12;
+  const size_t pack_bytes = o_stage + (scan_mode ? (size_t) nq * (size_t) db->nslots : 0);
+  if (pack_bytes > ws->pack_dev_bytes) {
+    slab_release(r.ctx, ws->pack_dev, ws->pack_dev_bytes); ws->pack_dev = nullptr; ws->pack_dev_bytes = 0;
+    void *dp = nullptr; size_t got = 0;
+    if ((st = slab_acquire(r.ctx, pack_bytes + pack_bytes / 2, &dp, &got)) != P7X_OK) return st;
+    ws->pack_dev = static_cast<unsigned char *>(dp); ws->pack_dev_bytes = got;
   }
-  std::vector<uint8_t> by_slot;
-  if (cfg.mode == P7X_SCAN_MODELS) {        // per-target accounting: which filters every (model, sequence) pair passed
-    by_slot.resize((size_t) nq * (size_t) db->nslots);
-    P7X_HIP(hipMemcpy2DAsync(by_slot.data(), (size_t) db->nslots, ws->stage, (size_t) ws->cap_slots, (size_t) db->nslots, nq, hipMemcpyDeviceToHost, s));
+  if (pack_bytes > ws->pack_host_bytes) {
+    pinned_release(ws->pack_host, ws->pack_host_bytes); ws->pack_host = nullptr; ws->pack_host_bytes = 0;
+    void *hp = nullptr; size_t got = 0;
+    if ((st = pinned_acquire(pack_bytes + pack_bytes / 2, &hp, &got)) != P7X_OK) return st;
+    ws->pack_host = static_cast<unsigned char *>(hp); ws->pack_host_bytes = got;
   }
+  unsigned char *ph = ws->pack_host, *pdv = ws->pack_dev;
+  if (T > 0) {
+    std::memcpy(ph + o_base, lane_base.data(), (size_t) nq * 4);
+    *reinterpret_cast<int32_t *>(ph + o_cursor) = 0;
+    P7X_HIP(hipMemcpyAsync(pdv, ph, o_cursor + 4, hipMemcpyHostToDevice, s));
+    PackArgs pa{};
+    pa.list_fin = ws->list_fin; pa.fwd_by_item = ws->fwd_by_item; pa.slot_pitch = ws->cap_slots;
+    pa.xmx_off = ws->xmx_off; pa.reg_out = ws->reg_out; pa.cap = ws->fin_cap;
+    pa.counters = ws->counters; pa.lane_base = reinterpret_cast<const int32_t *>(pdv + o_base);
+    pa.fin = reinterpret_cast<int32_t *>(pdv + o_fin); pa.fwd = reinterpret_cast<float *>(pdv + o_fwd);
+    pa.off = reinterpret_cast<int64_t *>(pdv + o_off); pa.regn = reinterpret_cast<int32_t *>(pdv + o_regn);
+    pa.nexp = reinterpret_cast<float *>(pdv + o_nexp); pa.reg_start = reinterpret_cast<int32_t *>(pdv + o_start);
+    pa.regs = reinterpret_cast<int32_t *>(pdv + o_regs); pa.regs_cap = (int32_t) std::min<int64_t>(regs_cap, INT32_MAX);
+    pa.cursor = reinterpret_cast<int *>(pdv + o_cursor);
+    const unsigned gx = (unsigned) std::max(1, std::min(64, (max_nfin + 255) / 256));
+    hipLaunchKernelGGL(pack_survivors_kernel, dim3(gx, (unsigned) nq), dim3(256), 0, s, pa);
+    P7X_HIP(hipMemcpyAsync(ph + o_cursor, pdv + o_cursor, o_regs - o_cursor, hipMemcpyDeviceToHost, s));
+    // regions: the cursor tells how many there are, but waiting for it costs a round trip; the array is small
+    P7X_HIP(hipMemcpyAsync(ph + o_regs, pdv + o_regs, (size_t) regs_cap * 12, hipMemcpyDeviceToHost, s));
+  }
+  if (scan_mode)           // per-target accounting: which filters every (model, sequence) pair passed
+    P7X_HIP(hipMemcpy2DAsync(ph + o_stage, (size_t) db->nslots, ws->stage, (size_t) ws->cap_slots, (size_t) db->nslots, nq, hipMemcpyDeviceToHost, s));
   P7X_HIP(hipEventRecord(ws->ev_sync, s)); P7X_HIP(hipEventSynchronize(ws->ev_sync));
-  for (int l : few) {
-    CascadeOut &out = outs[(size_t) r.query_of[l]];
-    const int nfin = out.counts[4];
-    const size_t row = (size_t) (l - few_lo) * few_w;
-    out.fin_slots.assign(st_fin.begin() + row, st_fin.begin() + row + nfin);
-    out.fwdsc.assign(st_fwd.begin() + row, st_fwd.begin() + row + nfin);
-    out.xmx_off.assign(st_off.begin() + row, st_off.begin() + row + nfin);
-    out.reg_n.assign(st_regn.begin() + row, st_regn.begin() + row + nfin);
-    out.nexpected.assign(st_nexp.begin() + row, st_nexp.begin() + row + nfin);
-    out.regs.assign(st_regs.begin() + row * kRegionCap * 3, st_regs.begin() + (row + nfin) * kRegionCap * 3);
+  const uint8_t *by_slot = ph + o_stage;
+  if (T > 0) {
+    const int32_t *h_fin = reinterpret_cast<const int32_t *>(ph + o_fin), *h_regn = reinterpret_cast<const int32_t *>(ph + o_regn);
+    const int32_t *h_start = reinterpret_cast<const int32_t *>(ph + o_start), *h_regs = reinterpret_cast<const int32_t *>(ph + o_regs);
+    const float *h_fwd = reinterpret_cast<const float *>(ph + o_fwd), *h_nexp = reinterpret_cast<const float *>(ph + o_nexp);
+    const int64_t *h_off = reinterpret_cast<const int64_t *>(ph + o_off);
+    for (int l = 0; l < nq; ++l) {
+      CascadeOut &out = outs[(size_t) r.query_of[l]];
+      const int nfin = out.counts[4];
+      if (out.counts[12] != 0 || nfin == 0) continue;
+      const size_t base = (size_t) lane_base[(size_t) l];
+      out.fin_slots.assign(h_fin + base, h_fin + base + nfin);
+      out.fwdsc.assign(h_fwd + base, h_fwd + base + nfin);
+      out.xmx_off.assign(h_off + base, h_off + base + nfin);
+      out.reg_n.assign(h_regn + base, h_regn + base + nfin);
+      out.nexpected.assign(h_nexp + base, h_nexp + base + nfin);
+      out.reg_start.assign((size_t) nfin, 0);
+      out.regs.clear();
+      for (int i = 0; i < nfin; ++i) {
+        const int n = out.reg_n[(size_t) i];
+        if (n <= 0) continue;
+        out.reg_start[(size_t) i] = (int32_t) (out.regs.size() / 3);
+        const int32_t rs = h_start[base + (size_t) i];
+        if (rs >= 0) out.regs.insert(out.regs.end(), h_regs + (size_t) rs * 3, h_regs + (size_t) (rs + n) * 3);
+        else {        // the packed array was full: this survivor's regions from the lane's own array
+          const size_t at = out.regs.size();
+          out.regs.resize(at + (size_t) n * 3);
+          const int32_t *src = ws->reg_out + (size_t) l * (size_t) ws->fin_cap * (kRegionCap * 3 + 2) + (size_t) i * kRegionCap * 3;
+          P7X_HIP(hipMemcpy(out.regs.data() + at, src, (size_t) n * 12, hipMemcpyDeviceToHost));
+        }
+      }
+    }
   }
   for (int l = 0; l < nq; ++l) {
     CascadeOut &out = outs[(size_t) r.query_of[l]];
@@ -1210,8 +1295,8 @@ static int cascade_collect(CascadeRun &r, std::vector<CascadeOut> &outs)
   if (debug) {
     const auto tc2 = std::chrono::steady_clock::now();
     long long nfin_tot = 0; for (const CascadeOut &o : outs) nfin_tot += o.counts[4];
-    std::fprintf(stderr, "[collect] nq %d survivors %lld few %zu flagged %zu: device wait %.2f fetch %.2f ms; events msv %.2f bias %.2f vit %.2f fwd %.2f rows %.2f bck+regions %.2f (msv kernel %.2f)\n",
-                 nq, nfin_tot, few.size(), flagged.size(), std::chrono::duration<double, std::milli>(tc1 - tc0).count(),
+    std::fprintf(stderr, "[collect] nq %d survivors %lld flagged %zu: device wait %.2f fetch %.2f ms; events msv %.2f bias %.2f vit %.2f fwd %.2f rows %.2f bck+regions %.2f (msv kernel %.2f)\n",
+                 nq, nfin_tot, flagged.size(), std::chrono::duration<double, std::milli>(tc1 - tc0).count(),
                  std::chrono::duration<double, std::milli>(tc2 - tc1).count(), ms[0], ms[1], ms[2], ms[3], ms[4], ms[5], ms[7]);
   }
   for (int l = 0; l < nq; ++l) {
@@ -1219,7 +1304,7 @@ static int cascade_collect(CascadeRun &r, std::vector<CascadeOut> &outs)
     std::memcpy(out.ms, ms, sizeof(ms));
     if (cfg.mode == P7X_SCAN_MODELS) {
       out.stage.assign((size_t) db->n, 0);
-      const uint8_t *row = by_slot.data() + (size_t) l * (size_t) db->nslots;
+      const uint8_t *row = by_slot + (size_t) l * (size_t) db->nslots;
       for (int64_t sl = 0; sl < db->nslots; ++sl) out.stage[(size_t) db->h_order[sl]] = row[(size_t) sl];
     }
   }
@@ -1500,7 +1585,8 @@ int p7x_search_batch_finish(p7x_pending *pd, const char *const *names, const cha
     it.fwd_xmx = co.fwd_xmx.data(); it.bck_xmx = co.bck_xmx.data(); it.xmx_off = co.xmx_off.data();
     it.counts[0] = (uint64_t) co.counts[1]; it.counts[1] = (uint64_t) co.counts[8]; it.counts[2] = (uint64_t) co.counts[3]; it.counts[3] = (uint64_t) co.counts[4];
     it.ms = co.ms;
-    if (!co.have_xmx && !targets[q].empty()) { dr[q].n = co.reg_n.data(); dr[q].regs = co.regs.data(); dr[q].nexpected = co.nexpected.data(); dr[q].cap = kRegionCap; it.regions = &dr[q]; }
+    if (!co.have_xmx && !targets[q].empty()) { dr[q].n = co.reg_n.data(); dr[q].regs = co.regs.data(); dr[q].nexpected = co.nexpected.data(); dr[q].cap = kRegionCap;
+      dr[q].start = co.reg_start.empty() ? nullptr : co.reg_start.data(); it.regions = &dr[q]; }
     it.device_envelopes = !g_host_envelopes && !pd->cfg.host_envelopes && !targets[q].empty();
     any_device = any_device || it.device_envelopes;
   }

@@ -375,7 +375,7 @@ int host_finish_batch(const p7x_pipeline_cfg &cfg_in, const std::vector<FinishIt
     const int nr = dregs->n[i];
     if (nr < 0) return P7X_ERANGE;
     Region regs[256];
-    const int32_t *src = dregs->regs + (size_t) i * dregs->cap * 3;
+    const int32_t *src = dregs->regs + (dregs->start ? (size_t) dregs->start[i] : (size_t) i * dregs->cap) * 3;
     for (int r = 0; r < nr && r < 256; ++r) regs[r] = Region{ src[r * 3], src[r * 3 + 1], src[r * 3 + 2] != 0 };
     return domaindef_from_regions(p, dsq, tg.len[t], dregs->nexpected[i], regs, nr, cfg_in.seed, reseed, dd, defer, i);
   };

@@ -15,11 +15,11 @@ bg = plan7.Background(models[0].alphabet)
 reps = int(sys.argv[1]) if len(sys.argv) > 1 else 50
 batch = int(sys.argv[2]) if len(sys.argv) > 2 else 256
 feeders = int(sys.argv[3]) if len(sys.argv) > 3 else 3
-oms = [plan7.OptimizedProfile(h, bg, 400) for _ in range(reps) for h in models]
-list(hmmer.hmmscan(block, oms[:28]))
-t0 = time.perf_counter()
-res = list(hmmer.hmmscan(block, oms, feeders=feeders, pipeline_depth=feeders, window=1, batch=batch))
-dt = time.perf_counter() - t0
-print(f"batch {batch} feeders {feeders}: {1e3 * dt / len(oms):.3f} ms/profile")
-for i in range(0, len(res), batch):
-    print(i, {k: round(v, 2) for k, v in res[i].timings_ms.items()})
+list(hmmer.hmmscan(block, [plan7.OptimizedProfile(h, bg, 400) for h in models]))
+for label in ("cold", "warm"):
+    oms = [plan7.OptimizedProfile(h, bg, 400) for _ in range(reps) for h in models]
+    sys.stderr.write(f"==== {label}\n"); sys.stderr.flush()
+    t0 = time.perf_counter()
+    res = list(hmmer.hmmscan(block, oms, feeders=feeders, pipeline_depth=feeders, window=1, batch=batch))
+    dt = time.perf_counter() - t0
+    print(f"batch {batch} feeders {feeders} {label}: {1e3 * dt / len(oms):.3f} ms/profile", flush=True)
