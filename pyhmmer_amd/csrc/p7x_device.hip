@@ -59,6 +59,12 @@ int get_ctx(int device, DeviceCtx **out)
   P7X_HIP(hipMemcpy(ctx->lt.tjb, tjb.data(), tjb.size(), hipMemcpyHostToDevice));
   P7X_HIP(hipMemcpy(ctx->lt.xwmove, xwm.data(), xwm.size() * 2, hipMemcpyHostToDevice));
   P7X_HIP(hipMemcpy(ctx->lt.null1, n1.data(), n1.size() * 4, hipMemcpyHostToDevice));
+  {
+    std::vector<double> lt(256);
+    for (int i = 0; i < 128; ++i) { const double c = 1.0 + ((double) i + 0.5) / 128.0; lt[2 * i] = 1.0 / c; lt[2 * i + 1] = std::log(c); }
+    P7X_HIP(hipMalloc(&ctx->lt.logtab, lt.size() * 8));
+    P7X_HIP(hipMemcpy(ctx->lt.logtab, lt.data(), lt.size() * 8, hipMemcpyHostToDevice));
+  }
   *out = ctx.get();
   g_ctx[device] = std::move(ctx);
   return P7X_OK;

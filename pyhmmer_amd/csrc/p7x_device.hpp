@@ -24,6 +24,7 @@ struct LengthTables {
   uint8_t *tjb = nullptr;
   int16_t *xwmove = nullptr;
   float   *null1 = nullptr;
+  double  *logtab = nullptr;   // [128][2]: 1/c and log(c) for c = 1 + (i + 1/2)/128 (bias filter's log of a float, p7x_pipeline.hip)
 };
 
 struct DeviceCtx {

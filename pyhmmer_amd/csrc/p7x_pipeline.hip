@@ -70,7 +70,7 @@ __device__ __forceinline__ void wave_count(int *counter, bool take)
 // What the per-target decision kernels of one lane read
 struct DecideArgs {
   StageBufs b; StageParams p;
-  const int32_t *slot_len; const uint8_t *tjb_tab; const float *null1_tab; const int16_t *xwmove_tab;
+  const int32_t *slot_len; const uint8_t *tjb_tab; const float *null1_tab; const int16_t *xwmove_tab; const double *logtab;
   const uint8_t *dsq; const int64_t *slot_off; const float *eo;
   int64_t nslots;
 };
@@ -101,12 +101,34 @@ __global__ void decide_msv_kernel(const ArgRef ref)
   wave_append(&b.counters[1], b.list_bias, take, (int32_t) s);
 }
 
+// (float) log((double) x) of a positive normal float, as the reference's scaled Forward takes it at every residue:
+// x = 2^e m, m = c (1 + r) with c the centre of m's 1/128 interval, log x = e ln 2 + log c + log(1 + r), |r| <= 2^-8,
+// five terms of the series in double precision (absolute error 4e-15: rounds to the same float as the library's double
+// logarithm -- 0 differences in 4e6 random arguments -- at a tenth of its instructions).  tab: [128][2] = 1/c, log c.
+__device__ __forceinline__ float log_of_float(float x, const double *tab)
+{
+  const uint32_t u = __float_as_uint(x);
+  if (u - 0x00800000u >= 0x7f000000u) return (float) log((double) x);       // zero, denormal, inf, nan, negative: the library's answer
+  const int e = (int) (u >> 23) - 127;
+  const uint32_t mant = u & 0x7fffffu;
+  const int i = (int) (mant >> 16);
+  const double m = (double) __uint_as_float(mant | 0x3f800000u);
+  const double r = fma(m, tab[2 * i], -1.0);
+  const double q = r * fma(r, fma(r, fma(r, fma(r, 0.2, -0.25), 1.0 / 3.0), -0.5), 1.0);
+  return (float) fma((double) e, 0.693147180559945309417232121458, tab[2 * i + 1] + q);
+}
+
 // bias filter: esl_hmm_Forward on the 2-state composition HMM (p7_bg_FilterScore); survivors -> list_vit / list_fwd
 __global__ void bias_kernel(const ArgRef ref)
 {
   const DecideArgs a = load_args<DecideArgs>(ref);
   const StageBufs &b = a.b; const StageParams &p = a.p;
   const uint8_t *dsq = a.dsq; const float *eo = a.eo;
+  __shared__ double s_logtab[256];
+  __shared__ float s_eo[kTabRows * 2];
+  for (int z = (int) threadIdx.x; z < 256; z += (int) blockDim.x) s_logtab[z] = a.logtab[z];
+  for (int z = (int) threadIdx.x; z < kTabRows * 2; z += (int) blockDim.x) s_eo[z] = eo[z];
+  __syncthreads();
   const int n = b.counters[1];
   for (int it0 = blockIdx.x * blockDim.x; it0 < n; it0 += gridDim.x * blockDim.x) {     // uniform trip count per wavefront
     const int it = it0 + (int) threadIdx.x;
@@ -127,21 +149,25 @@ __global__ void bias_kernel(const ArgRef ref)
       const float t00 = p1, t01 = 1.0f - p1, t10 = 1.0f / (L1 + 1.0f), t11 = L1 / (L1 + 1.0f);
       const float pi0 = (float) 0.999, pi1 = (float) 0.001;
       int x = sq[0];
-      float dp0 = eo[x * 2] * pi0, dp1 = eo[x * 2 + 1] * pi1;
+      float dp0 = s_eo[x * 2] * pi0, dp1 = s_eo[x * 2 + 1] * pi1;
       float mx = 0.0f; mx = dp0 > mx ? dp0 : mx; mx = dp1 > mx ? dp1 : mx;
       dp0 /= mx; dp1 /= mx;
       float logsc = 0.0f;
-      logsc += (float) log((double) mx);
+      logsc += log_of_float(mx, s_logtab);
       // The recurrence is a short dependent chain per residue; a byte load per step would put a memory round trip
-      // on it (~1 us x L).  Residues and their emission odds are therefore fetched 16 steps ahead.
+      // on it (~1 us x L).  Residues are fetched a block of sixteen steps ahead of the block being computed (the loads
+      // of block b + 1 are in flight during the chain and the logs of block b); emission odds come from LDS.
+      int xcur[16];
+#pragma unroll
+      for (int j = 0; j < 16; ++j) xcur[j] = (1 + j < L) ? (int) sq[1 + j] : 0;
       for (int i0 = 1; i0 < L; i0 += 16) {
         const int nstep = min(16, L - i0);
+        int xnext[16];
+#pragma unroll
+        for (int j = 0; j < 16; ++j) xnext[j] = (i0 + 16 + j < L) ? (int) sq[i0 + 16 + j] : 0;
         float e0[16], e1[16];
 #pragma unroll
-        for (int j = 0; j < 16; ++j) {
-          const int xj = (j < nstep) ? (int) sq[i0 + j] : 0;
-          e0[j] = eo[xj * 2]; e1[j] = eo[xj * 2 + 1];
-        }
+        for (int j = 0; j < 16; ++j) { e0[j] = s_eo[xcur[j] * 2]; e1[j] = s_eo[xcur[j] * 2 + 1]; }
         float mxs[16];
 #pragma unroll
         for (int j = 0; j < 16; ++j) {
@@ -154,16 +180,18 @@ __global__ void bias_kernel(const ArgRef ref)
             mxs[j] = mx;
           }
         }
-        // the sixteen double-precision logs are independent of each other and of the chain above: the compiler
-        // interleaves them.  They are still added to the score in sequence order.
+        // the sixteen logs are independent of each other and of the chain above: the compiler interleaves them.  They
+        // are still added to the score in sequence order.
         float lg[16];
 #pragma unroll
-        for (int j = 0; j < 16; ++j) lg[j] = (float) log((double) mxs[j]);
+        for (int j = 0; j < 16; ++j) lg[j] = log_of_float(mxs[j], s_logtab);
 #pragma unroll
         for (int j = 0; j < 16; ++j) if (j < nstep) logsc += lg[j];
+#pragma unroll
+        for (int j = 0; j < 16; ++j) xcur[j] = xnext[j];
       }
       float last = 0.0f; last += dp0 * 1.0f; last += dp1 * 1.0f;
-      logsc += (float) log((double) last);
+      logsc += log_of_float(last, s_logtab);
       filtersc = logsc + (float) L * logf(p1) + logf((float) (1. - (double) p1));
       const float seq_score = (float) ((double) (usc - filtersc) / kLog2);
       P = d_gumbel_surv((double) seq_score, (double) p.mmu, (double) p.mlambda);
@@ -1058,7 +1086,7 @@ static int cascade_enqueue(CascadeRun &r)
     const StageBufs b = ws->lane_bufs(l);
     DecideArgs d{};
     d.b = b; d.p = make_params(p, cfg);
-    d.slot_len = db->d_slot_len; d.tjb_tab = ctx->lt.tjb; d.null1_tab = ctx->lt.null1; d.xwmove_tab = ctx->lt.xwmove;
+    d.slot_len = db->d_slot_len; d.tjb_tab = ctx->lt.tjb; d.null1_tab = ctx->lt.null1; d.xwmove_tab = ctx->lt.xwmove; d.logtab = ctx->lt.logtab;
     d.dsq = db->d_dsq; d.slot_off = db->d_slot_off; d.eo = dp->bias_eo; d.nslots = db->nslots;
     la.dec = d;
     fill_msv_args(la, p, dp, db, ctx, b, nlong_of[(size_t) l]);
@@ -1356,7 +1384,7 @@ int p7x_filters_batch(const p7x_oprofile *om, const p7x_seqdb *db, int32_t *xJ, 
     DecideArgs d{};
     d.b = b; d.p = make_params(p, cfg);
     d.p.F1 = 2.0; d.p.F2 = 2.0;              // the bias pass below scores every target
-    d.slot_len = db->d_slot_len; d.tjb_tab = ctx->lt.tjb; d.null1_tab = ctx->lt.null1; d.xwmove_tab = ctx->lt.xwmove;
+    d.slot_len = db->d_slot_len; d.tjb_tab = ctx->lt.tjb; d.null1_tab = ctx->lt.null1; d.xwmove_tab = ctx->lt.xwmove; d.logtab = ctx->lt.logtab;
     d.dsq = db->d_dsq; d.slot_off = db->d_slot_off; d.eo = dp->bias_eo; d.nslots = ns;
     la.dec = d;
     fill_msv_args(la, p, dp, db, ctx, b, cls.nlong);
