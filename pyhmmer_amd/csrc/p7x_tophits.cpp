@@ -403,6 +403,17 @@ int host_finish_batch(const p7x_pipeline_cfg &cfg_in, const std::vector<FinishIt
       for (const EnvelopeRequest &r : local[(size_t) f]) { req_index[(size_t) f].push_back((int) req[(size_t) q].size()); req[(size_t) q].push_back(r); }
       if (!dds[(size_t) f].multi.empty()) heavy.push_back(f);
     }
+    // an ensemble is a serial walk (one RNG stream per target): hand the targets out longest first, so that the
+    // parallel region does not end on one long target that was started last
+    {
+      std::vector<double> cost((size_t) S, 0.0);
+      for (int f : heavy) {
+        double c = 0.0;
+        for (const Domain &d : dds[(size_t) f].dcl) if (d.deferred == -2) c += (double) (d.jenv - d.ienv + 1);
+        cost[(size_t) f] = c * (double) items[(size_t) q_of[(size_t) f]].om->p.M;
+      }
+      std::stable_sort(heavy.begin(), heavy.end(), [&](int a, int b) { return cost[(size_t) a] > cost[(size_t) b]; });
+    }
     // 2. the envelope kernels run while the host resolves the multi-domain regions (stochastic traceback
     //    ensembles: inherently sequential per region, so they are spread over the workers target by target)
     const auto t1 = std::chrono::steady_clock::now();
