@@ -158,25 +158,65 @@ __global__ void __launch_bounds__(kWsBlock) msv_wave_kernel(const ArgRef ref)
     for (int c = 0; c < C; ++c) mm[c] = 0;
     int xJ = 0, xEmax = 0;
     int xB = max(a.base - tjbm, 0);
+    // The begin score xB moves only when a row's maximum lifts xJ above the base, i.e. on a real hit.  Rows are therefore
+    // run in blocks of kBlk with xB held: no wavefront reduction (and nothing else across the lanes but the one-lane
+    // shift) sits on the row-to-row chain, and one reduction of the block's maximum tells whether the assumption held.
+    // Where it did not (xE - tec above max(base, xJ) somewhere in the block), the block is repeated from its saved
+    // first row with the reduction in every row, as the recurrence is written.  Same integers either way.
+    constexpr int kBlk = 16;
     for (int i0 = 0; i0 < L; i0 += 64) {
       const int nrow = min(64, L - i0);
       const uint32_t resid = (lane < nrow) ? sq[i0 + lane] : 0;
-      for (int r = 0; r < nrow; ++r) {
-        const int x = __builtin_amdgcn_readlane((int) resid, r);
-        const short *er = em + x * Mpad + lane;
-        int mp = dpp_shr1(mm[C - 1], 0);
-        int rowmax = kNegPad;
+      for (int r0 = 0; r0 < nrow; r0 += kBlk) {
+        const int nb = min(kBlk, nrow - r0);
+        int saved[C];
 #pragma unroll
-        for (int c = 0; c < C; ++c) {
-          const int sv = max(mp, xB) + (int) er[c * 64];
-          mp = mm[c];
-          mm[c] = sv;
-          rowmax = max(rowmax, sv);
+        for (int c = 0; c < C; ++c) saved[c] = mm[c];
+        int blkmax = kNegPad;
+        auto row_held = [&](int r) {
+          const int x = __builtin_amdgcn_readlane((int) resid, r);
+          const short *er = em + x * Mpad + lane;
+          int mp = dpp_shr1(mm[C - 1], 0);
+#pragma unroll
+          for (int c = 0; c < C; ++c) {
+            const int sv = max(mp, xB) + (int) er[c * 64];
+            mp = mm[c];
+            mm[c] = sv;
+            blkmax = max(blkmax, sv);
+          }
+        };
+        if (C <= 4 && nb == kBlk) {                    // short models: the rows unrolled (their LDS reads issue ahead of the chain)
+#pragma unroll
+          for (int rr = 0; rr < kBlk; ++rr) row_held(r0 + rr);
+        } else {
+#pragma unroll 1
+          for (int rr = 0; rr < nb; ++rr) row_held(r0 + rr);
         }
-        const int xE = wave_max_i32(rowmax);
-        xEmax = max(xEmax, xE);
-        xJ = max(xJ, xE - a.tec);
-        xB = max(max(a.base, xJ) - tjbm, 0);
+        const int xEb = wave_max_i32(blkmax);
+        if (xEb - a.tec <= max(a.base, xJ)) {          // xB was right for every row of the block
+          xEmax = max(xEmax, xEb);
+          xJ = max(xJ, xEb - a.tec);
+          continue;
+        }
+#pragma unroll
+        for (int c = 0; c < C; ++c) mm[c] = saved[c];
+        for (int r = r0; r < r0 + nb; ++r) {
+          const int x = __builtin_amdgcn_readlane((int) resid, r);
+          const short *er = em + x * Mpad + lane;
+          int mp = dpp_shr1(mm[C - 1], 0);
+          int rowmax = kNegPad;
+#pragma unroll
+          for (int c = 0; c < C; ++c) {
+            const int sv = max(mp, xB) + (int) er[c * 64];
+            mp = mm[c];
+            mm[c] = sv;
+            rowmax = max(rowmax, sv);
+          }
+          const int xE = wave_max_i32(rowmax);
+          xEmax = max(xEmax, xE);
+          xJ = max(xJ, xE - a.tec);
+          xB = max(max(a.base, xJ) - tjbm, 0);
+        }
       }
     }
     if (lane == 0 && L > 0) a.out_xJ[slot] = (xEmax >= 255 - a.bias) ? (int16_t) -1 : (int16_t) xJ;
