@@ -163,11 +163,29 @@ __global__ void __launch_bounds__(kWsBlock) msv_wave_kernel(const ArgRef ref)
     // shift) sits on the row-to-row chain, and one reduction of the block's maximum tells whether the assumption held.
     // Where it did not (xE - tec above max(base, xJ) somewhere in the block), the block is repeated from its saved
     // first row with the reduction in every row, as the recurrence is written.  Same integers either way.
-    constexpr int kBlk = 16;
+    constexpr int kBlk = C <= 8 ? 16 : 1;              // long models: a row is dozens of cells per lane, the reduction a small part of it
     for (int i0 = 0; i0 < L; i0 += 64) {
       const int nrow = min(64, L - i0);
       const uint32_t resid = (lane < nrow) ? sq[i0 + lane] : 0;
       for (int r0 = 0; r0 < nrow; r0 += kBlk) {
+        if (kBlk == 1) {                               // the recurrence as written, one reduction per row
+          const int x = __builtin_amdgcn_readlane((int) resid, r0);
+          const short *er = em + x * Mpad + lane;
+          int mp = dpp_shr1(mm[C - 1], 0);
+          int rowmax = kNegPad;
+#pragma unroll
+          for (int c = 0; c < C; ++c) {
+            const int sv = max(mp, xB) + (int) er[c * 64];
+            mp = mm[c];
+            mm[c] = sv;
+            rowmax = max(rowmax, sv);
+          }
+          const int xE = wave_max_i32(rowmax);
+          xEmax = max(xEmax, xE);
+          xJ = max(xJ, xE - a.tec);
+          xB = max(max(a.base, xJ) - tjbm, 0);
+          continue;
+        }
         const int nb = min(kBlk, nrow - r0);
         int saved[C];
 #pragma unroll
@@ -188,8 +206,11 @@ __global__ void __launch_bounds__(kWsBlock) msv_wave_kernel(const ArgRef ref)
         if (C <= 4 && nb == kBlk) {                    // short models: the rows unrolled (their LDS reads issue ahead of the chain)
 #pragma unroll
           for (int rr = 0; rr < kBlk; ++rr) row_held(r0 + rr);
+        } else if (C <= 12) {
+#pragma unroll 4
+          for (int rr = 0; rr < nb; ++rr) row_held(r0 + rr);
         } else {
-#pragma unroll 1
+#pragma unroll 2
           for (int rr = 0; rr < nb; ++rr) row_held(r0 + rr);
         }
         const int xEb = wave_max_i32(blkmax);
