@@ -63,7 +63,8 @@ struct DevProfile {
   // MSV: two parity tables of packed int16 pairs, [2][kTabRows][S] dwords
   int msvR = 0, msvK = 0, msvS = 0;     // lane kernels: row registers per lane, lanes per target, dwords per table row
   uint32_t *msv_tab = nullptr;
-  int16_t *msvw_emis = nullptr;     // msvR <= 0 (M > 478): wave-per-target MSV, [kTabRows][Mpad] bias - cost
+  int16_t *msvw_emis = nullptr;     // wave-per-target MSV, [kTabRows][Mpad] bias - cost
+  uint32_t *msvw_pk = nullptr;      // models without a lane kernel (M > 1021): the same as packed pairs, [kTabRows][C/4][64][2]
   // Viterbi: transitions [Mpad][8] int16 (BM,MM,IM,DM,MD,MI,II,DD), emissions [kTabRows][Mpad] int16
   int vitC = 0, Mpad = 0;
   int16_t *vit_trans = nullptr;

@@ -101,6 +101,7 @@ int bck_launch(const ArgRun<WaveSeqArgs> &a, int num_cu, hipStream_t st);
 struct MsvWaveArgs {
   int C, nrows;
   const void *emis;         // int16 [nrows][64*C], (bias - cost) in lane-chunk order, kNegPad outside the model / pad row
+  const void *emis_pk;      // long models (C >= 20): the same as packed pairs, [nrows][C/4][64] x (pair, pair) for msv_wavepk_kernel
   const uint8_t *dsq; const int64_t *slot_off; const int32_t *slot_len; const uint8_t *tjb_tab;
   int nslots, base, bias, tec, tbm;
   int16_t *out_xJ;

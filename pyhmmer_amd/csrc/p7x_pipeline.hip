@@ -699,7 +699,7 @@ static void fill_msv_args(LaneArgs &la, const Profile &p, const DevProfile *dp, 
                           int nlong = 0)
 {
   MsvWaveArgs w{};
-  w.C = dp->vitC; w.nrows = kTabRows; w.emis = dp->msvw_emis; w.dsq = db->d_dsq; w.slot_off = db->d_slot_off; w.slot_len = db->d_slot_len;
+  w.C = dp->vitC; w.nrows = kTabRows; w.emis = dp->msvw_emis; w.emis_pk = dp->msvw_pk; w.dsq = db->d_dsq; w.slot_off = db->d_slot_off; w.slot_len = db->d_slot_len;
   w.tjb_tab = ctx->lt.tjb; w.nslots = (int) db->nslots; w.base = p.base_b; w.bias = p.bias_b; w.tec = p.tec_b; w.tbm = p.tbm_b;
   w.out_xJ = b.xJ;
   if (nlong > 0) w.nslots = (int) std::min<int64_t>((int64_t) nlong * 64, db->nslots);   // only the long groups (with the lane kernel)

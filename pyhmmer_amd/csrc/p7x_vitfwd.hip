@@ -244,6 +244,123 @@ __global__ void __launch_bounds__(kWsBlock) msv_wave_kernel(const ArgRef ref)
   }
 }
 
+// ---------------------------------------------------------------------------------------- packed form, long models
+// Models beyond the register-resident lane kernels (M > 1021; a few per cent of Pfam, a fifth of its MSV cells) went
+// through msv_wave_kernel at five instructions per cell and one wavefront per SIMD (the emission table of such a model
+// fills most of the LDS, and a block was four wavefronts).  Here the same recurrence runs on packed 16-bit pairs --
+// two cells per register, values offset by -32768 so that the saturating add is the floor at zero, the one-node shift
+// of a row done with v_alignbit across the pair boundary (and one DPP move across the lane boundary): alignbit, max
+// with the begin score, saturating add of the emission pair, max into the row maximum = four operations per two cells
+// -- and sixteen wavefronts share one copy of the table.  Emission pairs come with one ds_read_b64 per four cells from
+// a table laid out [residue][pair of pairs][lane].  Bit-identical to msv_wave_kernel (tests/test_gpu_filters.py).
+typedef short s2v __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ s2v u2s(uint32_t u) { return __builtin_bit_cast(s2v, u); }
+__device__ __forceinline__ uint32_t s2u(s2v v) { return __builtin_bit_cast(uint32_t, v); }
+constexpr int kPkWaves = 16;
+template <int C>
+__global__ void __launch_bounds__(kPkWaves * 64) msv_wavepk_kernel(const ArgRef ref)
+{
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  static_assert(C % 4 == 0, "pairs of pairs");
+  constexpr int P = C / 2, P2 = C / 4;
+  constexpr uint32_t kFloor = 0x80008000u;
+  const MsvWaveArgs a = load_args<MsvWaveArgs>(ref);
+  const int nlist = a.nslots;
+  if ((int) (blockIdx.x * kPkWaves) >= nlist) return;
+  {
+    const uint4 *g = reinterpret_cast<const uint4 *>(a.emis_pk);
+    uint4 *l = reinterpret_cast<uint4 *>(smem);
+    for (int i = threadIdx.x; i < a.nrows * P * 64 / 4; i += kPkWaves * 64) l[i] = g[i];
+  }
+  __syncthreads();
+  const int lane = threadIdx.x & 63;
+  const uint2 *tab = reinterpret_cast<const uint2 *>(smem) + lane;          // [residue][P2][64] b64
+  const int wave0 = rfl((int) (blockIdx.x * kPkWaves + (threadIdx.x >> 6)));
+  const int nwaves = (int) (gridDim.x * kPkWaves);
+  for (int it = wave0; it < nlist; it += nwaves) {
+    const int slot = it;
+    const int L = rfl(a.slot_len[slot]);
+    const unsigned long long off = (unsigned long long) a.slot_off[slot];
+    const unsigned lo = (unsigned) rfl((int) (unsigned) off), hi = (unsigned) rfl((int) (unsigned) (off >> 32));
+    const uint8_t *sq = a.dsq + (((unsigned long long) hi << 32) | lo);
+    const int tjbm = rfl((int) a.tjb_tab[L]) + a.tbm;
+    uint32_t mm[P];
+#pragma unroll
+    for (int j = 0; j < P; ++j) mm[j] = kFloor;
+    int xJ = 0, xEmax = 0;
+    int xB = max(a.base - tjbm, 0);
+    // one row: every cell's predecessor is the node before it in the previous row (alignbit across the pair boundary,
+    // <left> across the register and the lane boundary)
+    auto row = [&](const uint2 (&ee)[P2], const s2v xBs, s2v &acc) {
+      uint32_t left = (uint32_t) dpp_shr1((int) mm[P - 1], (int) kFloor);
+#pragma unroll
+      for (int j2 = 0; j2 < P2; ++j2) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          const int j = 2 * j2 + h;
+          const uint32_t cur = mm[j];
+          const uint32_t mp = __builtin_amdgcn_alignbit(cur, left, 16);      // (node before the pair's first, the pair's first)
+          const s2v sv = __builtin_elementwise_add_sat(__builtin_elementwise_max(u2s(mp), xBs), u2s(h == 0 ? ee[j2].x : ee[j2].y));
+          mm[j] = s2u(sv);
+          acc = __builtin_elementwise_max(acc, sv);
+          left = cur;
+        }
+      }
+    };
+    constexpr int kBlk = 8;
+    for (int i0 = 0; i0 < L; i0 += 64) {
+      const int nrow = min(64, L - i0);
+      const uint32_t resid = (lane < nrow) ? sq[i0 + lane] : 0;
+      auto load_e = [&](uint2 (&dst)[P2], int r) {
+        const int x = __builtin_amdgcn_readlane((int) resid, r);
+#pragma unroll
+        for (int j2 = 0; j2 < P2; ++j2) dst[j2] = tab[(x * P2 + j2) * 64];
+      };
+      for (int r0 = 0; r0 < nrow; r0 += kBlk) {
+        const int nb = min(kBlk, nrow - r0);
+        const s2v xBs = u2s((uint32_t) ((xB - 32768) & 0xffff) * 0x00010001u);
+        if (nb == kBlk) {
+          // The begin score moves only when a row's maximum lifts xJ above the base (a real hit): eight rows with xB held,
+          // their emissions fetched a row ahead, one reduction of their common maximum.  If it shows that xB would have
+          // moved, the rows are repeated from the saved first one with the reduction in every row.
+          uint32_t saved[P];
+#pragma unroll
+          for (int j = 0; j < P; ++j) saved[j] = mm[j];
+          s2v acc = u2s(kFloor);
+          uint2 ea[P2], eb[P2];
+          load_e(ea, r0);
+#pragma unroll
+          for (int rr = 0; rr < kBlk; rr += 2) {
+            load_e(eb, r0 + rr + 1);
+            row(ea, xBs, acc);
+            if (rr + 2 < kBlk) load_e(ea, r0 + rr + 2);
+            row(eb, xBs, acc);
+          }
+          const int xEb = wave_max_i32(max((int) acc.x, (int) acc.y)) + 32768;
+          if (xEb - a.tec <= max(a.base, xJ)) {
+            xEmax = max(xEmax, xEb);
+            xJ = max(xJ, xEb - a.tec);
+            continue;
+          }
+#pragma unroll
+          for (int j = 0; j < P; ++j) mm[j] = saved[j];
+        }
+        for (int r = r0; r < r0 + nb; ++r) {
+          uint2 e1[P2];
+          load_e(e1, r);
+          s2v rowmax = u2s(kFloor);
+          row(e1, u2s((uint32_t) ((xB - 32768) & 0xffff) * 0x00010001u), rowmax);
+          const int xE = wave_max_i32(max((int) rowmax.x, (int) rowmax.y)) + 32768;
+          xEmax = max(xEmax, xE);
+          xJ = max(xJ, xE - a.tec);
+          xB = max(max(a.base, xJ) - tjbm, 0);
+        }
+      }
+    }
+    if (lane == 0 && L > 0) a.out_xJ[slot] = (xEmax >= 255 - a.bias) ? (int16_t) -1 : (int16_t) xJ;
+  }
+}
+
 // ======================================================================================= Forward parser
 // EG: the emission table does not fit in LDS next to the transitions (M > 1024) and is read from global memory
 // (it stays L2-resident: 30 rows x Mpad floats).
@@ -603,6 +720,23 @@ int msv_wave_launch(const ArgRun<MsvWaveArgs> &a, int num_cu, hipStream_t st)
   for (int i = 0; i < a.n; ++i) want = std::max<long>(want, ((long) a.at(i).nslots + 3) / 4);
   if (want <= 0) return P7X_OK;
   const int C = a.at(0).C, nrows = a.at(0).nrows;
+  if (a.at(0).emis_pk && C >= 20) {          // long models: packed pairs, sixteen wavefronts per copy of the table
+    long wantpk = 0;
+    for (int i = 0; i < a.n; ++i) wantpk = std::max<long>(wantpk, ((long) a.at(i).nslots + kPkWaves - 1) / kPkWaves);
+    auto gopk = [&](auto kernel) -> int {
+      const size_t lds = (size_t) 64 * C * nrows * 2;
+      P7X_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds));
+      hipLaunchKernelGGL(kernel, dim3(lane_grid(wantpk, (long) num_cu, a.n), (unsigned) a.n), dim3(kPkWaves * 64), lds, st, a.ref());
+      P7X_HIP(hipGetLastError());
+      return P7X_OK;
+    };
+    switch (C) {
+      case 20: return gopk(msv_wavepk_kernel<20>);
+      case 24: return gopk(msv_wavepk_kernel<24>);
+      case 32: return gopk(msv_wavepk_kernel<32>);
+      default: break;
+    }
+  }
   auto go = [&](auto kernel) -> int {
     const size_t lds = (size_t) 64 * C * nrows * 2;
     int per_cu = 0;
