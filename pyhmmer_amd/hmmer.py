@@ -219,7 +219,7 @@ def hmmsearch(queries: Union[HMM, Profile, OptimizedProfile, Iterable], sequence
 
 
 _BATCH_CELLS = 6e11        # (profile, target) cells per device batch when the caller leaves the batch size open: ~25 ms of MSV
-_BATCH_MAX = 64
+_BATCH_MAX = 256         # small blocks (a proteome, a query block): the measured optimum of the scan orientation
 
 
 def _shard_residues(db: "ShardedDatabase") -> int:
