@@ -250,6 +250,24 @@ def test_every_wavefront_kernel_instantiation_vs_oracle(M, oracle):
     assert np.all(np.abs(got["fwd"][ok] - want["fwd"][ok]) < FWD_TOL_NATS + 1e-5 * np.abs(want["fwd"][ok]))
 
 
+@pytest.mark.parametrize("M", [1022, 1281, 1537, 2047])
+def test_packed_wave_msv_for_long_models_on_a_ragged_block(M, oracle):
+    """Models beyond the lane kernels (M > 1021) run msv_wavepk_kernel: packed pairs, sixteen wavefronts per block, eight
+    rows per reduction with the begin score held and the block repeated row by row where a hit moved it.  1,500 random
+    targets of 1 ... 420 residues (row tails of every length, several blocks per launch) plus 40 fragments emitted
+    from the model (begin score moves), every xJ against the oracle, twice."""
+    hmm = random_hmm(M, seed=3000 + M)
+    bg = plan7.Background(hmm.alphabet)
+    blk = _model_block(hmm, 1500, 40, seed=M)
+    om = plan7.OptimizedProfile(hmm, bg, 400)
+    want = oracle.OracleProfile(hmm, bg, 400).msv_block(blk.packed())
+    assert int((want > 0).sum()) > 40                      # -1 marks overflow (an infinite score): the fragments do overflow
+    db = plan7.SequenceDatabase(blk)
+    for rep in range(2):
+        got = db.filters(om, msv=True)["xJ"]
+        assert np.array_equal(got, want), f"M={M} rep={rep}"
+
+
 def test_msv_baseline_config2_full_size_vs_oracle(oracle):
     """BASELINE.json configs[1] at full size: 10^6 synthetic 300-residue targets, every xJ against the oracle."""
     import bench

@@ -351,6 +351,34 @@ def test_batched_search_equals_single_searches(models, proteome):
         plan7.Pipeline(proteome.alphabet, bit_cutoffs="gathering")._search_enqueue_batch(qs, db)
 
 
+def test_batch_with_repeated_and_fresh_profile_objects(models, proteome):
+    """The device images of a batch's new profiles are laid out together, share one slab and go up in one copy
+    (get_dev_profiles).  The same OptimizedProfile object several times in one batch gets one image; dropping most of
+    the profiles of a batch leaves the survivor's image intact, also after the pool has handed memory to new images."""
+    import gc
+    bg = plan7.Background(proteome.alphabet)
+    db = plan7.SequenceDatabase(proteome)
+    pli = plan7.Pipeline(proteome.alphabet)
+    base = models["PF02826"] + models["RREFam"][:6] + models["KR"] + models["LuxC"]
+    oms = [plan7.OptimizedProfile(h, bg, 400) for h in base]                  # no device image yet
+    qs = oms + [oms[0], oms[3], oms[0]]                                       # the same objects again inside the batch
+    got = plan7.Pipeline._search_finish_batch(pli._search_enqueue_batch(qs, db))
+    want = [pli.search_hmm(h, db) for h in base]
+    want += [want[0], want[3], want[0]]
+    assert [_hit_fields(a) for a in got] == [_hit_fields(b) for b in want]
+    assert sum(len(a) for a in got) > 20
+    keep, ref = oms[1], _hit_fields(want[1])
+    del oms, qs, got
+    gc.collect()
+    for _ in range(3):                                                        # new batches: their slabs come from the pool
+        fresh = [plan7.OptimizedProfile(h, bg, 400) for h in base]
+        again = plan7.Pipeline._search_finish_batch(pli._search_enqueue_batch(fresh, db))
+        assert [_hit_fields(a) for a in again] == [_hit_fields(b) for b in want[:len(base)]]
+        del fresh, again
+        gc.collect()
+        assert _hit_fields(pli.search_hmm(keep, db)) == ref
+
+
 def test_batched_search_more_survivors_than_the_shared_buffers(models, proteome):
     """With the filters switched off (F1 = F2 = F3 = 1) every target of every lane reaches Backward: the lanes' rows
     do not fit the shared arena and the per-lane retry path has to produce the same lists as separate searches."""
