@@ -44,8 +44,8 @@ __device__ __forceinline__ void phase_fence()
 
 } // namespace
 
-// One block per CU: its wavefronts (env_waves(C): 12 where the row registers allow three per SIMD, else 8) share one
-// copy of the profile tables in LDS and each walks its own envelopes.
+// One block per CU: its wavefronts (env_waves(C): 8, or 4 for models of more than 448 nodes) share one copy of the
+// profile tables in LDS and each walks its own envelopes.
 // One row of the unihit Forward recurrence on the envelope, state in registers.  Phase 1 runs it for the envelope score
 // and the per-row scale factors; phase 3 runs it AGAIN next to the decoding (same code, same operations in the same order:
 // bit-identical values), which is what lets the kernel park only Backward's rows in HBM.

@@ -146,7 +146,10 @@ struct EnvArgs {
   uint32_t *tr_a; int32_t *tr_i; float *tr_pp;
   int32_t *tr_n;            // [nenv] trace length
 };
-constexpr int env_waves(int C) { (void) C; return 8; }   // wavefronts (= envelopes in flight) per block of env_kernel
+// wavefronts (= envelopes in flight) per block of env_kernel: eight (two per SIMD, 256 registers each); from eight
+// nodes per lane on, four (one per SIMD, 512 registers): the row state of two would spill to scratch, which made the
+// envelopes of long models 1.4-3.6x slower than half the occupancy does (scripts/env_by_length.py)
+constexpr int env_waves(int C) { return C >= 8 ? 4 : 8; }
 size_t env_work_floats(int C, int Lmax);
 int env_max_blocks(int C, int nrows, int num_cu, int *nblocks);
 // every record of the run has the same C and nrows; grid.x = the widest job's nblocks
