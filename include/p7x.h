@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define P7X_ABI_VERSION 4
+#define P7X_ABI_VERSION 5
 
 enum {
   P7X_OK = 0, P7X_EMEM = 5, P7X_EFORMAT = 7, P7X_EINVAL = 11, P7X_ERANGE = 16, P7X_ENORESULT = 19,
@@ -76,6 +76,11 @@ typedef struct p7x_oprofile p7x_oprofile;   /* opaque: replaces P7_PROFILE + P7_
  * (impl_sse/p7_oprofile.pxd:121; plan7.pyx:4961), local multihit mode, length model L.
  * bg_f is P7_BG.f (p7_bg.pxd:10-30); K floats. */
 int  p7x_oprofile_create(const p7x_hmm_view *hmm, const float *bg_f, int32_t L, p7x_oprofile **out);
+/* p7_Builder_MaxLength(hmm, emit_thresh) (include/libhmmer/p7_builder.pxd; called by LongTargetsPipeline.search_hmm,
+ * plan7.pyx:7346-7354 with window_beta): the smallest length W such that the core model, entered at its first match
+ * state, emits a W-th residue with probability below <beta>.  Reproduces the MAXL lines hmmbuild wrote into the
+ * nucleotide fixtures (beta = 1e-7: RF00001 305, bmyD 1736).  P7X_ERANGE if no such length below 200,000. */
+int  p7x_hmm_max_length(const p7x_hmm_view *hmm, double beta, int32_t *out);
 void p7x_oprofile_destroy(p7x_oprofile *om);
 
 typedef struct p7x_oprofile_info {          /* scalars of P7_OPROFILE (impl_sse/p7_oprofile.pxd:52-108) */
@@ -170,10 +175,9 @@ typedef struct p7x_pipeline_cfg {
   int32_t B1, B2, B3;        /* window lengths of the biased-composition modifier for the MSV / Viterbi / Forward filters */
   int32_t block_length;      /* residues per block read from a long target (W); consecutive blocks overlap by max_length */
   int32_t window_length;     /* > 0: overrides the model's max_length (nhmmer --w_length) */
-  int32_t lt_bias_mode;      /* how a long-target envelope's bias is formed (rescore_isolated_domain in p7x_domaindef.cpp); default 20:
-                              * alignment against emissions re-derived for a background mixed with the envelope's composition,
-                              * score from the unmodified model, bias = the score lost to the adjustment */
-  float   lt_bg_mix;         /* weight of the envelope's composition in that background; default 0.75 */
+  int32_t evalue_window_length; /* > 0: the window length p7_tophits_ComputeNhmmerEvalues is given when it differs from the scan's
+                              * (an HMM query without window_length: p7_Builder_MaxLength(hmm, window_beta), plan7.pyx:7346-7354,
+                              * while the scan keeps the max_length the optimized profile was built with); <= 0: the scan's */
   float   f3_guard;          /* relative half-width of the band around F3 inside which a target's Forward P-value is not trusted to the
                               * device's summation order: the device passes P <= F3 (1 + g), the host stage re-scores the targets with
                               * P > F3 (1 - g) with p7x_forward_parser_exact and applies F3 to that.  Default 4e-3 (a band of about 6e-3 bit, three times the stated tolerance of the device Forward score); 0: no guard */

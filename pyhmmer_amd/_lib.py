@@ -105,7 +105,7 @@ class PipelineCfg(C.Structure):
         ("do_max", C.c_int32), ("do_biasfilter", C.c_int32), ("do_null2", C.c_int32),
         ("seed", C.c_uint32), ("mode", C.c_int32), ("host_threads", C.c_int32), ("host_envelopes", C.c_int32), ("host_regions", C.c_int32),
         ("long_targets", C.c_int32), ("strands", C.c_int32), ("B1", C.c_int32), ("B2", C.c_int32), ("B3", C.c_int32),
-        ("block_length", C.c_int32), ("window_length", C.c_int32), ("lt_bias_mode", C.c_int32), ("lt_bg_mix", C.c_float),
+        ("block_length", C.c_int32), ("window_length", C.c_int32), ("evalue_window_length", C.c_int32),
         ("f3_guard", C.c_float),
     ]
 
@@ -149,6 +149,7 @@ class HitRec(C.Structure):
 _VP = C.c_void_p
 _SIGNATURES = {
     "p7x_abi_version": (C.c_int, []),
+    "p7x_hmm_max_length": (C.c_int, [C.POINTER(HmmView), C.c_double, C.POINTER(C.c_int32)]),
     "p7x_expf_neg": (None, [_VP, _VP, C.c_size_t]),
     "p7x_oprofile_create": (C.c_int, [C.POINTER(HmmView), _VP, C.c_int32, C.POINTER(_VP)]),
     "p7x_oprofile_destroy": (None, [_VP]),
@@ -226,7 +227,7 @@ def lib() -> C.CDLL:
             fn = getattr(l, name)      # AttributeError if the ABI is incomplete
             fn.restype = res
             fn.argtypes = args
-        if l.p7x_abi_version() != 4:
+        if l.p7x_abi_version() != 5:
             raise ImportError("libp7x ABI version mismatch; rebuild")
         _lib = l
     return _lib

@@ -95,13 +95,9 @@ int fchoose(FastRng &r, const float *p, int n)
 // ---------------------------------------------------------------- the query in a given configuration
 // Long-target (nhmmer) variant of envelope rescoring, upstream rescore_isolated_domain(..., long_target = TRUE, ...)
 struct LongTargetOpts {
-  bool do_null2 = true;
+  bool do_null2 = true;                // false: upstream passes scores_arr == NULL and the model is not re-parameterised
   const float *match_prob = nullptr;   // [M+1][K] match emission probabilities of the core model (fwd_emissions_arr)
-  int bias_mode = 0;                   // how the envelope's bias correction is formed, see rescore_isolated_domain()
-  float bg_mix = 0.25f;                // weight of the envelope's own composition in the re-parameterised background
-  int max_env_extra = 20;
-  bool retrim_bg = false;              // recompute the background from the trimmed envelope before aligning it again
-  bool bg_from_ali = false, bg_from_window = false;
+  int max_env_extra = 20;              // an envelope is trimmed to its alignment +- this many residues
 };
 
 struct Model {
@@ -908,12 +904,16 @@ void make_alidisplay(const Profile &p, const Trace &tr, const uint8_t *dsq, int 
 struct Workspace { Matrix fwd, bck; Trace tr; std::vector<float> wm, wi; };
 
 // ---------------------------------------------------------------- rescore_isolated_domain
-// Match odds against a background that is mixed with the composition of the envelope (upstream reparameterize_model +
-// p7_oprofile_UpdateFwdEmissionScores): rf'[x][k] = match_prob[k][x] / bg'[x], degenerate codes by expectation.
-static void reparameterize(const Profile &p, const LongTargetOpts &lt, const uint8_t *dsq, int i, int j, std::vector<float> &rf)
+// upstream reparameterize_model + p7_oprofile_UpdateFwdEmissionScores: the background becomes
+//   bg'[x] = (1 - s) * composition(dsq[i..j])[x] + s * bg->f[x],   s = 25 / min(100, max(50, n)),  n = window length
+// (0.25 for every window of 100 residues or more), and the match odds rf'[x][k] = match_prob[k][x] / bg'[x], degenerate
+// codes by expectation under bg'.  Pinned by bmyD1/bmyD2.tbl and the RF00001 answers (all windows there are > 100 nt; the
+// short-window branch of s is restated from upstream and not pinned by any fixture).
+static void reparameterize(const Profile &p, const LongTargetOpts &lt, const uint8_t *dsq, int n, int i, int j, std::vector<float> &rf)
 {
   const int M = p.M, K = p.K, Kp = p.Kp;
   const Alphabet &abc = Alphabet::get(p.abc_type);
+  const float bg_smooth = 25.0f / (float) std::min(100, std::max(50, n));
   float cnt[MAXK];
   for (int x = 0; x < K; ++x) cnt[x] = 0.0f;
   for (int pos = i; pos <= j; ++pos) {           // esl_sq_CountResidues: degenerate residues count fractionally
@@ -926,7 +926,7 @@ static void reparameterize(const Profile &p, const LongTargetOpts &lt, const uin
   }
   float tot = 0.0f; for (int x = 0; x < K; ++x) tot += cnt[x];
   float bgn[MAXK];
-  for (int x = 0; x < K; ++x) bgn[x] = lt.bg_mix * (tot > 0 ? cnt[x] / tot : p.bgf[x]) + (1.0f - lt.bg_mix) * p.bgf[x];
+  for (int x = 0; x < K; ++x) bgn[x] = (1.0f - bg_smooth) * (tot > 0 ? cnt[x] / tot : p.bgf[x]) + bg_smooth * p.bgf[x];
   rf.assign((size_t) Kp * (M + 1), 0.0f);
   for (int k = 1; k <= M; ++k) {
     float sc[MAXKP];
@@ -949,15 +949,16 @@ int rescore_isolated_domain(const Profile &p, Model &om, const uint8_t *dsq, int
   float envsc = 0.0f, oasc = 0.0f;
   float save_xf[4][2];
   thread_local std::vector<float> rf_lt;
-  if (lt) {   // the envelope keeps the window's length model (the pipeline re-expresses the score for max_length afterwards)
-    std::memcpy(save_xf, om.xf, sizeof(save_xf));
-    if (lt->do_null2 && lt->bias_mode != 0) {
-      if (lt->bg_from_window) reparameterize(p, *lt, dsq, 1, L, rf_lt); else reparameterize(p, *lt, dsq, i, j, rf_lt);
-      om.rf_over = rf_lt.data();
-    }
-  }
+  if (lt) std::memcpy(save_xf, om.xf, sizeof(save_xf));
   struct Restore { Model &om; const LongTargetOpts *lt; float (*xf)[2];
                    ~Restore() { if (lt) { om.rf_over = nullptr; std::memcpy(om.xf, xf, sizeof(float) * 8); } } } restore{ om, lt, save_xf };
+  // Long targets (upstream rescore_isolated_domain with long_target = TRUE): the envelope is scored unihit under a length
+  // model of its OWN length (p7_oprofile_ReconfigRestLength(om, j-i+1); the pipeline re-expresses the score for max_length
+  // afterwards) and, with null2 on, against emissions re-derived for a background mixed with the envelope's composition.
+  auto lt_setup = [&]() {
+    om.configure(false, Ld);
+    if (lt->do_null2) { reparameterize(p, *lt, dsq, L, i, j, rf_lt); om.rf_over = rf_lt.data(); }
+  };
   auto align = [&]() -> int {
     { ProfScope ps(5); forward_full(om, dsq + i - 1, Ld, ws.fwd, &envsc); }
     { ProfScope ps(6); backward_full(om, dsq + i - 1, Ld, ws.fwd, ws.bck, nullptr); }
@@ -968,20 +969,18 @@ int rescore_isolated_domain(const Profile &p, Model &om, const uint8_t *dsq, int
     for (size_t z = 0; z < ws.tr.st.size(); ++z) if (ws.tr.i[z] > 0) ws.tr.i[z] += i - 1;
     return P7X_OK;
   };
+  if (lt) lt_setup();
   int st = align();
   if (st != P7X_OK) return st;
   Domain dom;
   make_alidisplay(p, ws.tr, dsq, L, dom);
   if (lt && (i < dom.sqfrom - lt->max_env_extra || j > dom.sqto + lt->max_env_extra)) {
     // long targets often give envelopes far wider than the alignment (a repetitive stretch of the model collecting
-    // weak matches): trim the envelope to the alignment +- max_env_extra and align again
+    // weak matches): trim the envelope to the alignment +- max_env_extra and do it again
     i = std::max<int>(i, (int) dom.sqfrom - lt->max_env_extra);
     j = std::min<int>(j, (int) dom.sqto + lt->max_env_extra);
     Ld = j - i + 1;
-    if (om.rf_over && lt->retrim_bg && !lt->bg_from_window) {
-      if (lt->bg_from_ali) reparameterize(p, *lt, dsq, (int) dom.sqfrom, (int) dom.sqto, rf_lt); else reparameterize(p, *lt, dsq, i, j, rf_lt);
-      om.rf_over = rf_lt.data();
-    }
+    lt_setup();
     if ((st = align()) != P7X_OK) return st;
     dom = Domain();
     make_alidisplay(p, ws.tr, dsq, L, dom);
@@ -989,23 +988,13 @@ int rescore_isolated_domain(const Profile &p, Model &om, const uint8_t *dsq, int
   float domcorrection = 0.0f;
   if (lt) {
     if (lt->do_null2) {
-      if (lt->bias_mode == 0) {        // null2 by expectation over the envelope, as for protein targets
-        float null2[MAXKP];
-        null2_by_expectation(om, ws.bck, null2);
-        for (int pos = i; pos <= j; ++pos) domcorrection += logf(null2[dsq[pos]]);
-      } else if (lt->bias_mode == 5) { // null2 by expectation under the composition-adjusted model; envsc stays the adjusted score
-        float null2[MAXKP];
-        null2_by_expectation(om, ws.bck, null2);
-        for (int pos = i; pos <= j; ++pos) domcorrection += logf(null2[dsq[pos]]);
-      } else {                         // the score lost against the composition-adjusted background is the bias
-        float orig = 0.0f;
-        om.rf_over = nullptr;
-        forward_full(om, dsq + i - 1, Ld, ws.fwd, &orig);
-        if (lt->bias_mode == 1) { domcorrection = std::max(0.0f, orig - envsc); envsc = orig; }
-        else if (lt->bias_mode == 3) { domcorrection = (orig - envsc) + 5.545177444f; envsc = orig; }   // bias = logsum(0, orig - adjusted)
-        else if (lt->bias_mode == 4) { domcorrection = std::max(0.0f, orig - envsc); envsc = orig; }     // bias = the loss itself
-        else domcorrection = std::max(0.0f, orig - envsc);      // mode 2: envsc stays the adjusted score
-      }
+      // the bias of a long-target envelope is the score it loses against the composition-adjusted background; the
+      // envelope score itself is the unmodified model's (Forward again with the original emissions)
+      float orig = 0.0f;
+      om.rf_over = nullptr;
+      forward_full(om, dsq + i - 1, Ld, ws.fwd, &orig);
+      domcorrection = std::max(0.0f, orig - envsc);
+      envsc = orig;
     }
   } else {
     if (!null2_is_done) {

@@ -293,7 +293,6 @@ int p7x_search_longtargets(const p7x_pipeline_cfg *cfg, const p7x_oprofile *om, 
       const int64_t bn = bc + bw;
       if (bn <= 0) break;
       for (int strand = 0; strand < 2; ++strand) if (mask & (1 << strand)) units.push_back(Unit{ i, bn, strand, {} });
-      if (i + bn >= Lt) break;
     }
     host_parallel_for((int) units.size(), cfg->host_threads, [&](int u) {
       Unit &un = units[(size_t) u];

@@ -574,18 +574,17 @@ static int lt_post_viterbi(const p7x_pipeline_cfg &cfg, const Profile &p, const 
                                                  (long long) d.iali, (long long) d.jali, d.hmmfrom, d.hmmto, d.envsc, d.domcorrection);
   }
   if (dd.nregions == 0 || dd.nenvelopes == 0) return P7X_OK;
-  const float omega = 1.0f / 256.0f;
   for (Domain &dom : dd.dcl) {
     const int64_t env_len = dom.jenv - dom.ienv + 1, ali_len = dom.jali - dom.iali + 1;
     float bitscore = dom.envsc;
-    // the envelope was scored (unihit) under the window's length model: take out what that model charged for entering,
-    // leaving and the envelope's flanks, then re-express the score as if every window had the length max_length, so
-    // that scores do not depend on how the windows happened to merge
-    bitscore -= 2 * log(2. / (window_len + 2)) + (env_len - ali_len) * log((float) window_len / (float) (window_len + 2));
+    // the envelope was scored (unihit) under a length model of its own length: take out what that model charged for
+    // entering, leaving and the envelope's flanks, then re-express the score as if every window had the length
+    // max_length, so that scores do not depend on how the windows happened to merge
+    bitscore -= 2 * log(2. / (env_len + 2)) + (env_len - ali_len) * log((float) env_len / (float) (env_len + 2));
     bitscore += 2 * log(2. / (max_length + 2));
     bitscore += (std::max<int64_t>(max_length, env_len) - ali_len) * log((float) max_length / (float) (max_length + 2));
     const float dom_nullsc = lt_null1(std::max<int64_t>(max_length, env_len));
-    const float dom_bias = !cfg.do_null2 ? 0.0f : (lto.bias_mode == 4 ? dom.domcorrection : flogsum(0.0f, std::log((double) omega) + dom.domcorrection));
+    const float dom_bias = cfg.do_null2 ? dom.domcorrection : 0.0f;      // long targets: the correction is the bias (no omega prior)
     const float dom_score = (bitscore - (dom_nullsc + dom_bias)) / (float) kLog2;
     const double dom_lnP = exp_logsurv(dom_score, p.evparam[P7X_FTAU], p.evparam[P7X_FLAMBDA]);
     // conservative test with the residues seen so far; the final E-values use the whole search (ComputeNhmmerEvalues)
@@ -715,7 +714,10 @@ static void lt_finish_tophits(const p7x_pipeline_cfg &cfg_in, const Profile &p, 
       const int64_t si = std::min(hi.dcl[0].iali, hi.dcl[0].jali), ei = std::max(hi.dcl[0].iali, hi.dcl[0].jali);
       const int64_t inter = std::min(ei, ej) - std::max(si, sj) + 1;
       const int64_t li = ei - si + 1, lj = ej - sj + 1;
-      if (inter > 0 && ((std::llabs(si - sj) <= 3) || (std::llabs(ei - ej) <= 3) || inter >= 0.95 * (double) li || inter >= 0.95 * (double) lj)) dup = true;
+      // upstream: only hits on similar parts of the model (their model ranges intersect) can be duplicates of each
+      // other -- tandem or partial repeat copies with flush ends but different model ranges are both kept
+      const int hmm_inter = std::min(hi.dcl[0].hmmto, hj.dcl[0].hmmto) - std::max(hi.dcl[0].hmmfrom, hj.dcl[0].hmmfrom) + 1;
+      if (hmm_inter > 0 && ((std::llabs(si - sj) <= 3) || (std::llabs(ei - ej) <= 3) || inter >= 0.95 * (double) li || inter >= 0.95 * (double) lj)) dup = true;
     }
     if (dup) {
       const size_t remove = hi.lnP < hj.lnP ? j : q;
@@ -764,7 +766,6 @@ static int lt_run_host(const p7x_pipeline_cfg &cfg, const p7x_oprofile *om, cons
   LtScoreData sd; lt_scoredata(p, sd);
   std::vector<float> mp; lt_match_probabilities(p, mp);
   LongTargetOpts lto; lto.do_null2 = cfg.do_null2 != 0; lto.match_prob = mp.data();
-  lto.bias_mode = cfg.lt_bias_mode & 15; lto.bg_mix = cfg.lt_bg_mix; lto.retrim_bg = (cfg.lt_bias_mode & 16) != 0; lto.bg_from_ali = (cfg.lt_bias_mode & 32) != 0; lto.bg_from_window = (cfg.lt_bias_mode & 64) != 0;
   const uint8_t *comp = lt_complement_table(p.abc_type);
   std::vector<Hit> hits;
   LtCounters ctr;
@@ -806,7 +807,8 @@ static int lt_run_host(const p7x_pipeline_cfg &cfg, const p7x_oprofile *om, cons
         if (!job.windows.empty()) jobs.push_back(std::move(job));
         if (strand == 1) nres += (uint64_t) bw;
       }
-      if (i + bn >= Lt) break;
+      // no early exit: the reference loop (plan7.pyx:7604 `for i from 0 <= i < sq[t].n by W - C`) visits every start
+      // below the target length, also a trailing block that only repeats residues the previous block has seen
     }
     tick("windows of the blocks");
     // the windows' filter scores, one device batch per target
@@ -927,7 +929,7 @@ static int lt_run_host(const p7x_pipeline_cfg &cfg, const p7x_oprofile *om, cons
     }
   }
   tick("Backward + domain definition");
-  lt_finish_tophits(cfg, p, max_length, nres, (uint64_t) n, ctr, hits, out);
+  lt_finish_tophits(cfg, p, cfg.evalue_window_length > 0 ? cfg.evalue_window_length : max_length, nres, (uint64_t) n, ctr, hits, out);
   tick("hit list");
   return P7X_OK;
 }

@@ -270,6 +270,40 @@ void p7x_expf_neg(const double *in, float *out, size_t n)
   for (size_t i = 0; i < n; ++i) out[i] = std::isinf(in[i]) ? 0.0f : expf((float) (-1.0 * in[i]));
 }
 
+int p7x_hmm_max_length(const p7x_hmm_view *h, double beta, int32_t *out)
+{
+  if (!h || !out || h->M < 1 || !h->t || !(beta > 0.0)) { set_error("p7x_hmm_max_length: bad arguments"); return P7X_EINVAL; }
+  const int M = h->M;
+  if (M == 1) { *out = 1; return P7X_OK; }
+  // column L of a table T[state][L] = P(the model, entered at M1, is in <state> having emitted exactly L residues);
+  // two columns are kept.  The model emits an L-th residue with probability sum_k M[k][L] + I[k][L]: the first L for which
+  // that falls below beta is the bound.  (Measuring what is still inside the model -- rather than one minus what has
+  // left it -- keeps the bound right for transition rows that sum to 1 only to the five decimals of an HMM file.)
+  const float *t = h->t;                       // [M+1][7]: MM MI MD IM II DM DD
+  auto T = [&](int k, int x) -> double { return (double) t[(size_t) k * 7 + x]; };
+  std::vector<double> Mm(2 * (size_t) (M + 1), 0.0), I(2 * (size_t) (M + 1), 0.0), D(2 * (size_t) (M + 1), 0.0);
+  auto at = [&](std::vector<double> &v, int k, int c) -> double & { return v[(size_t) c * (M + 1) + k]; };
+  at(Mm, 1, 0) = 1.0;
+  for (int k = 2; k <= M; ++k) at(D, k, 0) = T(k - 1, 2) * at(Mm, k - 1, 0) + T(k - 1, 6) * at(D, k - 1, 0);
+  const int length_bound = 200000;
+  for (int L = 2; L <= length_bound; ++L) {
+    const int c = (L - 1) & 1, pc = L & 1;
+    at(Mm, 1, c) = 0.0; at(D, 1, c) = 0.0;
+    at(I, 1, c) = T(1, 1) * at(Mm, 1, pc) + T(1, 4) * at(I, 1, pc);
+    double alive = at(I, 1, c);
+    for (int k = 2; k <= M; ++k) {
+      const double m = T(k - 1, 0) * at(Mm, k - 1, pc) + T(k - 1, 3) * at(I, k - 1, pc) + T(k - 1, 5) * at(D, k - 1, pc);
+      const double i = k < M ? T(k, 1) * at(Mm, k, pc) + T(k, 4) * at(I, k, pc) : 0.0;      // no insert state after the last node
+      at(Mm, k, c) = m; at(I, k, c) = i;
+      at(D, k, c) = T(k - 1, 2) * at(Mm, k - 1, c) + T(k - 1, 6) * at(D, k - 1, c);
+      alive += m + i;
+    }
+    if (alive < beta) { *out = L; return P7X_OK; }
+  }
+  set_error("p7x_hmm_max_length: no bound below 200000 residues");
+  return P7X_ERANGE;
+}
+
 int p7x_oprofile_create(const p7x_hmm_view *h, const float *bg_f, int32_t L, p7x_oprofile **out)
 {
   if (!h || !bg_f || !out || h->M < 1 || !h->t || !h->mat || !h->name) { set_error("p7x_oprofile_create: bad arguments"); return P7X_EINVAL; }
@@ -647,7 +681,7 @@ void p7x_pipeline_cfg_default(p7x_pipeline_cfg *c)
   c->do_max = 0; c->do_biasfilter = 1; c->do_null2 = 1;
   c->seed = 42; c->mode = P7X_SEARCH_SEQS; c->host_threads = 0; c->host_envelopes = 0; c->host_regions = 0;
   c->long_targets = 0; c->strands = P7X_STRAND_BOTH; c->B1 = 100; c->B2 = 240; c->B3 = 1000;      // p7_pipeline_Create
-  c->block_length = 0x40000; c->window_length = -1; c->lt_bias_mode = 20; c->lt_bg_mix = 0.75f;
+  c->block_length = 0x40000; c->window_length = -1; c->evalue_window_length = -1;
   c->f3_guard = 4e-3f;
 }
 

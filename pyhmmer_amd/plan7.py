@@ -1520,9 +1520,6 @@ class LongTargetsPipeline(Pipeline):
         self.block_length = int(block_length)
         self.window_length = window_length
         self.window_beta = window_beta
-        # debugging switches of the long-target bias correction (see p7x_domaindef.cpp)
-        self._lt_bias_mode = int(os.environ.get("P7X_LT_BIAS_MODE", "20"))
-        self._lt_bg_mix = float(os.environ.get("P7X_LT_BG_MIX", "0.75"))
 
     def _cfg(self) -> "_lib.PipelineCfg":
         c = super()._cfg()
@@ -1531,8 +1528,27 @@ class LongTargetsPipeline(Pipeline):
         c.B1, c.B2, c.B3 = self.B1, self.B2, self.B3
         c.block_length = self.block_length
         c.window_length = -1 if self.window_length is None else int(self.window_length)
-        c.lt_bias_mode, c.lt_bg_mix = self._lt_bias_mode, self._lt_bg_mix
         return c
+
+    def _windowed_om(self, query, L: int, cfg) -> "OptimizedProfile":
+        """The optimized profile of ``query`` and the two window lengths of the search (reference ``plan7.pyx:7336-7354``):
+        ``window_length`` overrides everything; otherwise the scan uses the ``max_length`` the profile was built with (the
+        file's ``MAXL``) while the E-values use ``p7_Builder_MaxLength(hmm, window_beta)``, which -- as in the reference --
+        also replaces ``hmm.max_length`` for later searches.  An HMM without ``MAXL`` gets the computed bound for both."""
+        if self.window_length is None and isinstance(query, HMM):
+            view, keep = query._view()
+            w = C.c_int32(0)
+            beta = 1e-7 if self.window_beta is None else float(self.window_beta)     # p7_DEFAULT_WINDOW_BETA, plan7.pyx:6993
+            st = _lib.lib().p7x_hmm_max_length(C.byref(view), beta, C.byref(w))
+            if st != 0:
+                raise status_to_exception(st, "p7x_hmm_max_length", _lib.last_error())
+            if (query.max_length or -1) <= 0:
+                query.max_length = int(w.value)
+            om = self._get_om_from_query(query, L)
+            query.max_length = int(w.value)
+            cfg.evalue_window_length = int(w.value)
+            return om
+        return self._get_om_from_query(query, L)
 
     @staticmethod
     def _pack(sequences):
@@ -1566,8 +1582,8 @@ class LongTargetsPipeline(Pipeline):
         if isinstance(query, (Profile, OptimizedProfile)) and self.window_length is None and (getattr(query, "max_length", None) or -1) <= 0:
             raise TypeError("Cannot use `Profile` or `OptimizedProfile` query without `max_length` set")     # plan7.pyx:7354
         L = len(sequences[0]) if len(sequences) else self.L_HINT
-        om = self._get_om_from_query(query, min(L, 100000))
         cfg = self._cfg()
+        om = self._windowed_om(query, min(L, 100000), cfg)
         if self.bit_cutoffs is not None and not getattr(om.cutoffs, self.bit_cutoffs + "_available")():
             raise MissingCutoffs(om.name, self.bit_cutoffs)
         if isinstance(sequences, DigitalSequenceBlock) and all(len(s) < 2 ** 31 for s in sequences):

@@ -65,8 +65,6 @@ def blocks_of(L, W, Cov):
         if n <= 0:
             break
         out.append((i, n))
-        if i + n >= L:
-            break
         i += W - Cov
     return out
 

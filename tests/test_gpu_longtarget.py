@@ -78,7 +78,7 @@ def test_device_ssv_on_a_synthetic_chromosome(oracle):
 def test_nhmmer_bmyd_tables_through_the_device(oracle):
     """hmmer.nhmmer == the CPU harness (oracle scan + host tail) on the bmyD fixtures, and the golden tables."""
     hmm = load_hmms("bmyD")[0]
-    for target, table, nexact in (("BGC0001090.gbk", "bmyD1.tbl", 2), ("1390.SAMEA104415756.OFHT01000022.fna", "bmyD2.tbl", 2)):
+    for target, table in (("BGC0001090.gbk", "bmyD1.tbl"), ("1390.SAMEA104415756.OFHT01000022.fna", "bmyD2.tbl")):
         seqs = _read(target, hmm.alphabet)
         hits = next(hmmer.nhmmer(hmm, seqs))
         ref = host_pipeline.host_nhmmer(oracle, hmm, seqs)
@@ -86,7 +86,7 @@ def test_nhmmer_bmyd_tables_through_the_device(oracle):
         if table == "bmyD2.tbl":
             check_bmyd2_table(hits, golden_table(table))
         else:
-            check_nhmmer_table(hits, golden_table(table), exact_rows=nexact)
+            check_nhmmer_table(hits, golden_table(table))
         assert hits.searched_residues == 2 * len(seqs[0]) and hits.searched_sequences == 1
     # from a file object, one strand
     with easel.SequenceFile(GOLDEN / "seqs" / "BGC0001090.gbk", digital=True, alphabet=hmm.alphabet) as f:
@@ -100,7 +100,7 @@ def test_nhmmer_rf00001_known_answers():
     hmm = load_hmms("RF00001")[0]
     with easel.SequenceFile(GOLDEN / "seqs" / "1390.SAMEA104415756.OFHT01000024.fna", digital=True, alphabet=hmm.alphabet) as f:
         hits = list(hmmer.nhmmer(hmm, f))[0]
-    assert len(hits) == 1 and hits[0].evalue == pytest.approx(2.5e-17, rel=0.05) and hits[0].best_domain.strand == "-"
+    assert len(hits) == 1 and float("%.2g" % hits[0].evalue) == pytest.approx(2.5e-17, rel=1e-6) and hits[0].best_domain.strand == "-"
     seqs = _read("1390.SAMEA104415756.OFHT01000024.fna", hmm.alphabet)
     hits = list(hmmer.nhmmer(hmm, seqs, window_length=3878))[0]
-    assert len(hits) == 2 and hits[0].evalue == pytest.approx(5.4e-17, rel=0.05) and hits[1].evalue == pytest.approx(0.3, abs=0.005)
+    assert len(hits) == 2 and float("%.2g" % hits[0].evalue) == pytest.approx(5.4e-17, rel=1e-6) and hits[1].evalue == pytest.approx(0.3, abs=0.005)

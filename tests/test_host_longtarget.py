@@ -20,11 +20,20 @@ def _rows(hits):
              d.strand, h.evalue, h.score, d.bias, h.reported, h.included) for h in hits for d in [h.domains[0]]]
 
 
-def check_nhmmer_table(hits, rows, exact_rows):
-    """reference TestNhmmer.assertTableEqual (test_hmmer.py:673-690: best-domain bias / score to 0.1 bit, i_evalue to
-    0.1) plus the coordinate and strand columns of the table, for the first `exact_rows` rows."""
+def rounds_to(value, text):
+    """<value> printed with as many decimals as the table column <text> gives the table's number (half a unit of the last
+    printed digit plus float noise)."""
+    decimals = len(text.split(".")[1]) if "." in text else 0
+    return abs(value - float(text)) <= 0.5 * 10.0 ** -decimals + 1e-4
+
+
+def check_nhmmer_table(hits, rows):
+    """reference TestNhmmer.assertTableEqual (test_hmmer.py:673-690 compares best-domain bias, score and i_evalue to
+    0.1) tightened to the table's own print precision -- score and bias to the printed decimal, E-value to its two
+    significant digits -- plus every coordinate and strand column, exactly, for every row."""
     reported = [h for h in hits if h.reported]
-    for row, hit in list(zip(rows, reported))[:exact_rows]:
+    assert len(reported) == len(rows)
+    for row, hit in zip(rows, reported):
         d = hit.best_domain
         assert hit.name == row[0]
         assert (hit.accession or "-") == row[1]
@@ -32,11 +41,11 @@ def check_nhmmer_table(hits, rows, exact_rows):
         assert (d.alignment.target_from, d.alignment.target_to) == (int(row[6]), int(row[7]))
         assert (d.env_from, d.env_to) == (int(row[8]), int(row[9]))
         assert hit.length == int(row[10]) and d.strand == row[11]
-        assert d.bias == pytest.approx(float(row[14]), abs=0.1)
-        assert d.score == pytest.approx(float(row[13]), abs=0.1)
+        assert rounds_to(d.bias, row[14]), (d.bias, row[14])
+        assert rounds_to(d.score, row[13]), (d.score, row[13])
         assert d.i_evalue == pytest.approx(float(row[12]), abs=0.1)
         if float(row[12]) > 0:
-            assert d.i_evalue == pytest.approx(float(row[12]), rel=0.12)
+            assert float("%.2g" % d.i_evalue) == pytest.approx(float(row[12]), rel=0.045), (d.i_evalue, row[12])   # one unit of the second digit
 
 
 def test_genbank_targets_are_read(libp7x):
@@ -53,7 +62,7 @@ def test_bmyd_hmm_vs_bgc_matches_nhmmer_table(libp7x, oracle):
     hits = host_pipeline.host_nhmmer(oracle, hmm, seqs)
     assert hits.long_targets and hits.strand is None and hits.block_length == 0x40000
     assert len(hits.reported) == 2
-    check_nhmmer_table(hits, golden_table("bmyD1.tbl"), exact_rows=2)
+    check_nhmmer_table(hits, golden_table("bmyD1.tbl"))
     assert [h.domains[0].strand for h in hits.reported] == ["+", "-"]
     # one strand at a time
     for strand, want in (("watson", "+"), ("crick", "-")):
@@ -66,11 +75,10 @@ def test_bmyd_hmm_vs_bgc_matches_nhmmer_table(libp7x, oracle):
 
 def test_bmyd_hmm_vs_genome_matches_nhmmer_table(libp7x, oracle):
     """reference test_bmyd_hmm_genome_block / _file (test_hmmer.py:755-775) against tables/bmyD2.tbl (391 kb contig, two
-    blocks of 0x40000 with max_length overlap): three reported hits, two of them included, in the table's order.  Rows 1
-    and 2: every coordinate exact; row 3 (a 65-column alignment scoring 1.1 bits): envelope exact, alignment ends within
-    one residue.  Scores, biases and E-values agree to the reference's own tolerance, 0.1 (assertTableEqual,
-    test_hmmer.py:675-692; the closest call is row 2, 8.83 / 1.10 against 8.9 / 1.2): see DESIGN.md on what is pinned of
-    the long-target domain definition."""
+    blocks of 0x40000 with max_length overlap): three reported hits, two of them included, in the table's order, every
+    coordinate of every row exact, scores / biases / E-values to the table's print precision (the long-target envelope
+    scoring is derived, DESIGN.md section 3.8: length model of the envelope's own length, composition-adjusted background,
+    bias = the score lost to the adjustment)."""
     hmm = load_hmms("bmyD")[0]
     seqs = _read("1390.SAMEA104415756.OFHT01000022.fna", hmm.alphabet)
     hits = host_pipeline.host_nhmmer(oracle, hmm, seqs)
@@ -79,15 +87,7 @@ def test_bmyd_hmm_vs_genome_matches_nhmmer_table(libp7x, oracle):
 
 def check_bmyd2_table(hits, rows):
     assert len(hits.reported) == 3 and len(hits.included) == 2
-    check_nhmmer_table(hits, rows, exact_rows=2)
-    for row, hit in zip(rows, hits.reported):
-        d = hit.best_domain
-        assert (d.env_from, d.env_to) == (int(row[8]), int(row[9])) and d.strand == row[11]
-        assert abs(d.alignment.target_from - int(row[6])) <= 1 and abs(d.alignment.target_to - int(row[7])) <= 1
-        assert abs(d.alignment.hmm_from - int(row[4])) <= 1 and d.alignment.hmm_to == int(row[5])
-        assert d.score == pytest.approx(float(row[13]), abs=0.1) and d.bias == pytest.approx(float(row[14]), abs=0.1)
-        assert d.i_evalue == pytest.approx(float(row[12]), abs=0.1) and d.i_evalue == pytest.approx(float(row[12]), rel=0.12)
-    assert [(h.best_domain.alignment.target_from, h.best_domain.alignment.target_to) for h in hits.reported[:2]] == [(int(r[6]), int(r[7])) for r in rows[:2]]
+    check_nhmmer_table(hits, rows)
 
 
 def test_rf00001_known_answers(libp7x, oracle):
@@ -96,10 +96,10 @@ def test_rf00001_known_answers(libp7x, oracle):
     seqs = _read("1390.SAMEA104415756.OFHT01000024.fna", hmm.alphabet)
     hits = host_pipeline.host_nhmmer(oracle, hmm, seqs)
     assert len(hits) == 1
-    assert hits[0].evalue == pytest.approx(2.5e-17, rel=0.05) and hits[0].best_domain.strand == "-"
+    assert float("%.2g" % hits[0].evalue) == pytest.approx(2.5e-17, rel=1e-6) and hits[0].best_domain.strand == "-"
     hits = host_pipeline.host_nhmmer(oracle, hmm, seqs, plan7.LongTargetsPipeline(hmm.alphabet, window_length=3878))
     assert len(hits) == 2
-    assert hits[0].evalue == pytest.approx(5.4e-17, rel=0.05) and hits[1].evalue == pytest.approx(0.3, abs=0.005)
+    assert float("%.2g" % hits[0].evalue) == pytest.approx(5.4e-17, rel=1e-6) and hits[1].evalue == pytest.approx(0.3, abs=0.005)
     assert hits[0].best_domain.strand == "-" and hits[1].best_domain.strand == "-"
 
 
@@ -115,3 +115,42 @@ def test_long_targets_pipeline_arguments(libp7x):
     pli = plan7.LongTargetsPipeline(dna, strand="crick", B1=110, block_length=4096)
     c = pli._cfg()
     assert (c.long_targets, c.strands, c.B1, c.B2, c.B3, c.block_length, c.F2, c.F3) == (1, 2, 110, 240, 1000, 4096, 3e-3, 3e-5)
+
+
+def test_builder_max_length_reproduces_the_fixtures_maxl(libp7x):
+    """p7_Builder_MaxLength (reference plan7.pyx:7346-7354 calls it with window_beta): with hmmbuild's default
+    beta = 1e-7 the restatement gives the MAXL line hmmbuild wrote into both nucleotide fixtures; a looser beta gives a
+    shorter window, a tighter one a longer."""
+    import ctypes as C
+    from pyhmmer_amd import _lib
+    got = {}
+    for name, want in (("RF00001", 305), ("bmyD", 1736)):
+        hmm = load_hmms(name)[0]
+        assert hmm.max_length == want
+        view, keep = hmm._view()
+        for beta in (1e-7, 1e-3, 1e-9):
+            w = C.c_int32()
+            assert _lib.lib().p7x_hmm_max_length(C.byref(view), beta, C.byref(w)) == 0
+            got[(name, beta)] = w.value
+        assert got[(name, 1e-7)] == want
+        assert got[(name, 1e-3)] < want < got[(name, 1e-9)]
+    w = C.c_int32()
+    assert _lib.lib().p7x_hmm_max_length(C.byref(view), 0.0, C.byref(w)) != 0
+
+
+def test_window_beta_sets_the_evalue_window(libp7x):
+    """LongTargetsPipeline(window_beta=...) with an HMM query (plan7.pyx:7346-7354): the E-values are computed for
+    p7_Builder_MaxLength(hmm, window_beta), the scan keeps the profile's own max_length, and -- as in the reference -- the
+    HMM's max_length is replaced; window_length overrides both."""
+    hmm = load_hmms("bmyD")[0]
+    cfg = plan7.LongTargetsPipeline(hmm.alphabet, window_beta=1e-3)._cfg()
+    pli = plan7.LongTargetsPipeline(hmm.alphabet, window_beta=1e-3)
+    om = pli._windowed_om(hmm, 400, cfg)
+    assert om._info.max_length == 1736 and 1203 < cfg.evalue_window_length < 1736 and hmm.max_length == cfg.evalue_window_length
+    hmm = load_hmms("bmyD")[0]
+    hmm.max_length = None                                     # no MAXL line: the computed bound serves the scan as well
+    cfg = pli._cfg()
+    om = pli._windowed_om(hmm, 400, cfg)
+    assert om._info.max_length == cfg.evalue_window_length == hmm.max_length
+    cfg = plan7.LongTargetsPipeline(hmm.alphabet, window_length=3878)._cfg()
+    assert cfg.window_length == 3878 and cfg.evalue_window_length == -1
