@@ -178,6 +178,10 @@ typedef struct p7x_pipeline_cfg {
   int32_t evalue_window_length; /* > 0: the window length p7_tophits_ComputeNhmmerEvalues is given when it differs from the scan's
                               * (an HMM query without window_length: p7_Builder_MaxLength(hmm, window_beta), plan7.pyx:7346-7354,
                               * while the scan keeps the max_length the optimized profile was built with); <= 0: the scan's */
+  float   oa_guard;          /* near-tie guard of the device's optimal-accuracy traceback: a choice on the trace between candidates
+                              * within |v| * g + g of each other (or a posterior that close to the next printed digit) sends the
+                              * envelope to the host twin, which repeats it in the reference's order of operations.  Default 2e-6
+                              * (about 16 units in the last place); 0: no guard */
   float   f3_guard;          /* relative half-width of the band around F3 inside which a target's Forward P-value is not trusted to the
                               * device's summation order: the device passes P <= F3 (1 + g), the host stage re-scores the targets with
                               * P > F3 (1 - g) with p7x_forward_parser_exact and applies F3 to that.  Default 4e-3 (a band of about 6e-3 bit, three times the stated tolerance of the device Forward score); 0: no guard */
@@ -255,6 +259,13 @@ int  p7x_search_batch_enqueue(const p7x_pipeline_cfg *cfg, const p7x_oprofile *c
 int  p7x_search_batch_finish(p7x_pending *pending, const char *const *names, const char *const *accs,
                              const char *const *descs, p7x_tophits **outs);
 size_t p7x_pending_nqueries(const p7x_pending *pending);
+/* Parity seam of the batched cascade (the multi-profile twin of p7x_filters_batch): runs stage 1 exactly as
+ * p7x_search_batch_enqueue queues it -- profiles grouped into kernel classes, the hybrid lane / wave MSV split, the work
+ * lists -- and returns what the stages left behind, [nq][ntargets] in caller order of both: xJ (every target; -1
+ * overflow), xC of the targets that reached the Viterbi filter (INT32_MIN elsewhere; 32767 overflow) and the last
+ * stage each target passed (0 none, 1 MSV, 2 bias, 3 Viterbi, 4 Forward).  Any output may be NULL. */
+int  p7x_search_batch_raw(const p7x_pipeline_cfg *cfg, const p7x_oprofile *const *oms, size_t nq, const float *bg_f,
+                          const p7x_seqdb *db, int32_t *xJ, int32_t *xC, uint8_t *stage);
 
 /* nhmmer: LongTargetsPipeline.search_hmm / _search_loop_longtargets (plan7.pyx:7272-7418, 7541-7664) for a block of
  * long DNA / RNA targets.  Per target and strand: the SSV scan of p7_Pipeline_LongTarget (p7_pipeline.pxd:131-143) runs
@@ -333,6 +344,9 @@ int      p7x_tophits_set_hit_text(p7x_tophits *th, int64_t i, int which, const c
  * [8] device rescoring of domain envelopes (wall, with transfers) [9] host: multi-domain regions (overlaps [8])
  * [10] wall time of stage 1 (p7x_search_block_begin) [11] of stage 2 (_finish); [6] = [10] + [11].  n <= 12. */
 int      p7x_tophits_get_timings(const p7x_tophits *th, double *ms, int n);
+/* how often the two guards acted in the search that produced <th>: targets the F3 guard took back out of the device's
+ * survivor list, device envelopes the optimal-accuracy near-tie guard repeated on the host (0 after a merge / deserialisation) */
+int      p7x_tophits_get_guard_counts(const p7x_tophits *th, int64_t *f3_dropped, int64_t *oa_redone);
 
 const char *p7x_last_error(void);
 

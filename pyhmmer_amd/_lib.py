@@ -105,7 +105,7 @@ class PipelineCfg(C.Structure):
         ("do_max", C.c_int32), ("do_biasfilter", C.c_int32), ("do_null2", C.c_int32),
         ("seed", C.c_uint32), ("mode", C.c_int32), ("host_threads", C.c_int32), ("host_envelopes", C.c_int32), ("host_regions", C.c_int32),
         ("long_targets", C.c_int32), ("strands", C.c_int32), ("B1", C.c_int32), ("B2", C.c_int32), ("B3", C.c_int32),
-        ("block_length", C.c_int32), ("window_length", C.c_int32), ("evalue_window_length", C.c_int32),
+        ("block_length", C.c_int32), ("window_length", C.c_int32), ("evalue_window_length", C.c_int32), ("oa_guard", C.c_float),
         ("f3_guard", C.c_float),
     ]
 
@@ -149,6 +149,7 @@ class HitRec(C.Structure):
 _VP = C.c_void_p
 _SIGNATURES = {
     "p7x_abi_version": (C.c_int, []),
+    "p7x_tophits_get_guard_counts": (C.c_int, [_VP, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
     "p7x_hmm_max_length": (C.c_int, [C.POINTER(HmmView), C.c_double, C.POINTER(C.c_int32)]),
     "p7x_expf_neg": (None, [_VP, _VP, C.c_size_t]),
     "p7x_oprofile_create": (C.c_int, [C.POINTER(HmmView), _VP, C.c_int32, C.POINTER(_VP)]),
@@ -195,6 +196,7 @@ _SIGNATURES = {
     "p7x_search_batch_enqueue": (C.c_int, [C.POINTER(PipelineCfg), C.POINTER(_VP), C.c_size_t, _VP, _VP, C.POINTER(_VP)]),
     "p7x_search_batch_finish": (C.c_int, [_VP, _VP, _VP, _VP, C.POINTER(_VP)]),
     "p7x_pending_nqueries": (C.c_size_t, [_VP]),
+    "p7x_search_batch_raw": (C.c_int, [C.POINTER(PipelineCfg), C.POINTER(_VP), C.c_size_t, _VP, _VP, _VP, _VP, _VP]),
     "p7x_search_longtargets": (C.c_int, [C.POINTER(PipelineCfg), _VP, C.c_int, _VP, _VP, _VP, C.c_size_t, _VP, _VP, _VP, C.POINTER(_VP)]),
     "p7x_ssv_longtarget_seeds": (C.c_int64, [C.POINTER(PipelineCfg), _VP, C.c_int, _VP, C.c_int64, C.c_int, _VP, C.c_size_t]),
     "p7x_forward_parser_exact": (C.c_int, [_VP, _VP, C.c_int32, C.POINTER(C.c_float)]),

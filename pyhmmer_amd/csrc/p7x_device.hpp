@@ -94,7 +94,7 @@ struct EnvelopeScorer;
 struct p7x_seqdb;
 #include <memory>
 namespace p7x {
-std::unique_ptr<EnvelopeScorer> make_device_envelope_scorer(DeviceCtx *ctx, const p7x_seqdb *db);
+std::unique_ptr<EnvelopeScorer> make_device_envelope_scorer(DeviceCtx *ctx, const p7x_seqdb *db, float oa_guard);
 
 } // namespace p7x
 

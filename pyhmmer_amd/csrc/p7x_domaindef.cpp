@@ -1220,9 +1220,24 @@ int domaindef_finish_deferred(const Profile &p, const uint8_t *dsq, int L, const
   std::vector<Domain> kept;
   kept.reserve(dd.dcl.size());
   // the device's answer for envelope i..j -> a Domain; null2_done: the region's ensemble already set dd.n2sc on i..j
+  Model om_exact{ &p, p.M, {} };
+  bool om_exact_ready = false;
   auto from_result = [&](const EnvelopeResult &r, int i, int j, bool null2_done, Domain &dom) -> bool {
     if (r.status & 2) return false;                  // p7_Decoding range error: the envelope is dropped
-    if (r.status & ~3) return false;                 // traceback failure: upstream's rescore returns without a domain
+    if (r.status & ~(3 | 64)) return false;          // traceback failure: upstream's rescore returns without a domain
+    if (r.status & 64) {
+      // a near-tie on the device's optimal-accuracy trace (p7x_envelope.hip, cfg.oa_guard): this envelope again with
+      // the host twin, which performs the reference's operations in the reference's order
+      if (!om_exact_ready) { om_exact.prepare(); om_exact.configure(false, L); om_exact_ready = true; }
+      DomainDefResult one;
+      one.n2sc.swap(dd.n2sc);
+      const int st = rescore_isolated_domain(p, om_exact, dsq, L, i, j, null2_done, ws, one);
+      dd.n2sc.swap(one.n2sc);
+      dd.nneartie++;
+      if (st != P7X_OK || one.dcl.empty()) return false;
+      dom = std::move(one.dcl[0]);
+      return true;
+    }
     Trace &tr = ws.tr;
     tr.clear();
     for (int z = 0; z < r.ntrace; ++z) tr.append((int) (r.ta[z] & 0xffu), (int) ((r.ta[z] >> 8) & 0xffffu), r.ti[z], r.tp[z]);

@@ -119,6 +119,25 @@ __device__ __forceinline__ unsigned pp_code(float p)
   const double v = (double) p + 0.05;
   return v >= 1.0 ? 10u : (unsigned) (int) (v * 10.0);
 }
+// Near-tie guard (status bit 6).  The optimal-accuracy recursion sums posteriors that differ from the host twin's by a
+// few units in the last place (another summation order in Forward / Backward), so a traceback choice between two
+// candidates that lie within a few ulps of each other -- or a posterior within that distance of the next printed digit
+// -- can fall the other way than in the reference's order of operations.  Every such choice ON THE TRACE flags the
+// envelope, and the host stage repeats flagged envelopes with the host twin (domaindef_finish_deferred), which performs
+// the reference's operations in the reference's order.  guard: relative half-width (cfg.oa_guard); 0 switches it off.
+__device__ __forceinline__ float guard_band(float v, float guard) { return __builtin_fabsf(v) * guard + guard; }
+__device__ __forceinline__ int near_tie(float x, float y, float guard)
+{ // both -inf: the difference is NaN and the test is false (such a cell is unreachable anyway)
+  return (guard > 0.0f && __builtin_fabsf(x - y) <= guard_band(vmax(__builtin_fabsf(x), __builtin_fabsf(y)), guard)) ? 1 : 0;
+}
+__device__ __forceinline__ int pp_near(float p, float guard)
+{
+  // float is enough here: the band is an order of magnitude wider than the rounding of this expression
+  const float v = (p + 0.05f) * 10.0f;
+  const float fr = v - __builtin_floorf(v);
+  const float g = 16.0f * guard;
+  return (guard > 0.0f && (fr < g || fr > 1.0f - g) && v > 0.5f) ? 1 : 0;
+}
 // and back to a float that prints as that digit (the host stage formats the line from floats)
 __device__ __forceinline__ float pp_from_code(unsigned code) { return code >= 10u ? 1.0f : (float) (((double) code + 0.5) / 10.0 - 0.05); }
 
@@ -325,7 +344,7 @@ __global__ void __launch_bounds__(env_waves(C) * 64, env_waves(C) / 4) env_kerne
 
     // ------------------------------------------------------------------ 3. decoding, null2 sums, optimal accuracy
     float oasc;
-    int e_row = -1, e_k = 0, e_s = 0;
+    int e_row = -1, e_k = 0, e_s = 0, e_near = 0;
     {
       float scaleproduct = (float) (1.0 / (double) bck_xN0);
       bool ddpass = true;                                            // every D->D transition of this lane is open
@@ -401,18 +420,23 @@ __global__ void __launch_bounds__(env_waves(C) * 64, env_waves(C) / 4) env_kerne
           sv = vmax(sv, gate(t.mm, mp));
           sv = vmax(sv, gate(t.im, ip));
           sv = vmax(sv, gate(t.dm, dp));
-          int best = 0; float bv = block(t.mm, mp);
-          { const float p1 = block(t.im, ip); if (p1 > bv) { best = 1; bv = p1; } }
-          { const float p2 = block(t.dm, dp); if (p2 > bv) { best = 2; bv = p2; } }
-          { const float p3 = block(t.bm, xBp); if (p3 > bv) { best = 3; } }
+          // winner by upstream's rule (strict >, in this order) and the runner-up for the near-tie guard (near_tie() above)
+          int best = 0; float bv = block(t.mm, mp), second = kNegInf;
+          { const float p1 = block(t.im, ip); if (p1 > bv) { best = 1; second = bv; bv = p1; } else second = vmax(second, p1); }
+          { const float p2 = block(t.dm, dp); if (p2 > bv) { best = 2; second = bv; bv = p2; } else second = vmax(second, p2); }
+          { const float p3 = block(t.bm, xBp); if (p3 > bv) { best = 3; second = bv; bv = p3; } else second = vmax(second, p3); }
+          const int near_m = near_tie(bv, second, a.oa_guard);
           const float mcur = om_[c], icur = oi_[c];
           float iv = gate(t.mi, mcur);
           iv = vmax(iv, gate(t.ii, icur));
-          const int ichoice = (block(t.mi, mcur) >= block(t.ii, icur)) ? 0 : 1;
+          const float q0 = block(t.mi, mcur), q1 = block(t.ii, icur);
+          const int ichoice = (q0 >= q1) ? 0 : 1;
+          const int near_i = near_tie(q0, q1, a.oa_guard);
           mp = mcur; ip = icur; dp = od_[c];
           om_[c] = sv + ppm[c];
           oi_[c] = iv + ppi[c];
-          code[c] = (unsigned short) (best | (ichoice << 2) | (pp_code(ppm[c]) << 4) | (pp_code(ppi[c]) << 8));
+          const int near_pp = pp_near(ppm[c], a.oa_guard) | pp_near(ppi[c], a.oa_guard);
+          code[c] = (unsigned short) (best | (ichoice << 2) | (pp_code(ppm[c]) << 4) | (pp_code(ppi[c]) << 8) | (near_m << 12) | (near_i << 13) | (near_pp << 15));
         }
         // D(r,k) = max(gate(tMD(k-1), M(r,k-1)), tDD(k-1) > 0 ? D(r,k-1) : 0), D(r,1) = -inf: a segmented max-scan
         {
@@ -430,8 +454,9 @@ __global__ void __launch_bounds__(env_waves(C) * 64, env_waves(C) / 4) env_kerne
           float pmd = p_md0, pdd = p_dd0;
 #pragma unroll
           for (int c = 0; c < C; ++c) {
-            const int dchoice = (block(pmd, pm) >= block(pdd, pd)) ? 0 : 1;
-            code[c] |= (unsigned short) (dchoice << 3);
+            const float d0 = block(pmd, pm), d1 = block(pdd, pd);
+            const int dchoice = (d0 >= d1) ? 0 : 1;
+            code[c] |= (unsigned short) ((dchoice << 3) | (near_tie(d0, d1, a.oa_guard) << 14));
             pm = om_[c]; pd = od_[c]; pmd = t_md[c]; pdd = t_dd[c];
           }
         }
@@ -462,7 +487,8 @@ __global__ void __launch_bounds__(env_waves(C) * 64, env_waves(C) / 4) env_kerne
           // select_e for this row, should the traceback enter E here: upstream scans the striped layout, q outer,
           // M cells with >=, D cells with >.  Net effect: the LAST M cell (striped order) that equals the row
           // maximum wins; without one, the FIRST D cell that does.
-          int keyM = 0, keyD = 0;
+          int keyM = 0, keyD = 0, nearM = 0;
+          const float ethr = oE - guard_band(oE, a.oa_guard);
 #pragma unroll
           for (int c = 0; c < C; ++c) {
             const int k = lane * C + c + 1;
@@ -470,9 +496,13 @@ __global__ void __launch_bounds__(env_waves(C) * 64, env_waves(C) / 4) env_kerne
               const int rank = ((k - 1) % Q) * 4 + (k - 1) / Q;
               if (om_[c] == oE) keyM = max(keyM, rank + 1);
               if (od_[c] == oE) keyD = max(keyD, (1 << 24) - rank);
+              nearM += om_[c] >= ethr;
             }
           }
           keyM = wave_max_i32(keyM);
+          // D cells copy the M cell they derive from (a structural tie, the same on any device): only a second MATCH cell
+          // inside the guard band -- or an end in a delete state -- makes the choice of the end cell a near-tie
+          e_near = (a.oa_guard > 0.0f && (wave_max_i32(nearM) > 1 || __builtin_popcountll(__ballot(nearM > 0)) > 1 || keyM == 0)) ? 1 : 0;
           if (keyM > 0) { const int rank = keyM - 1; e_k = (rank % 4) * Q + rank / 4 + 1; e_s = tM; }
           else {
             keyD = wave_max_i32(keyD);
@@ -522,20 +552,26 @@ __global__ void __launch_bounds__(env_waves(C) * 64, env_waves(C) / 4) env_kerne
         switch (s0) {
           case tM: {
             if (i < 1 || k < 1) { status |= 4; break; }
-            const int code = bp[(size_t) i * Mpad + ((k - 1) % C) * 64 + (k - 1) / C] & 3;
+            const unsigned w16 = bp[(size_t) i * Mpad + ((k - 1) % C) * 64 + (k - 1) / C];
+            const int code = w16 & 3;
+            if (w16 & (1u << 12)) status |= 64;
             s1 = (code == 0) ? tM : (code == 1) ? tI : (code == 2) ? tD : tB;
             --k; --i;
             break;
           }
           case tD: {
             if (i < 1 || k < 1) { status |= 4; break; }
-            const int code = (bp[(size_t) i * Mpad + ((k - 1) % C) * 64 + (k - 1) / C] >> 3) & 1;
+            const unsigned w16 = bp[(size_t) i * Mpad + ((k - 1) % C) * 64 + (k - 1) / C];
+            const int code = (w16 >> 3) & 1;
+            if (w16 & (1u << 14)) status |= 64;
             s1 = code ? tD : tM; --k;
             break;
           }
           case tI: {
             if (i < 1 || k < 1) { status |= 4; break; }
-            const int code = (bp[(size_t) i * Mpad + ((k - 1) % C) * 64 + (k - 1) / C] >> 2) & 1;
+            const unsigned w16 = bp[(size_t) i * Mpad + ((k - 1) % C) * 64 + (k - 1) / C];
+            const int code = (w16 >> 2) & 1;
+            if (w16 & (1u << 13)) status |= 64;
             s1 = code ? tI : tM; --i;
             break;
           }
@@ -543,20 +579,24 @@ __global__ void __launch_bounds__(env_waves(C) * 64, env_waves(C) / 4) env_kerne
           case tC: {
             if (i < 1) { status |= 4; break; }
             const float p0 = t1c * (ox[(size_t) (i - 1) * 5 + 4] + px[(size_t) i * 3 + 2]), p1 = t2e_move * ox[(size_t) i * 5 + 0];
+            if (near_tie(p0, p1, a.oa_guard)) status |= 64;
             s1 = (p0 > p1) ? tC : tE;
             break;
           }
           case tJ: {
             if (i < 1) { status |= 4; break; }
             const float p0 = t1c * (ox[(size_t) (i - 1) * 5 + 2] + px[(size_t) i * 3 + 1]), p1 = t2e_loop * ox[(size_t) i * 5 + 0];
+            if (near_tie(p0, p1, a.oa_guard)) status |= 64;
             s1 = (p0 > p1) ? tJ : tE;
             break;
           }
           case tE:
             if (i != e_row || e_s < 0) { status |= 8; break; }   // only the last C<-E row was resolved (unihit envelopes)
+            if (e_near) status |= 64;
             k = e_k; s1 = e_s;
             break;
           case tB:
+            if (near_tie(tmove * ox[(size_t) i * 5 + 1], tmove * ox[(size_t) i * 5 + 2], a.oa_guard)) status |= 64;
             s1 = (tmove * ox[(size_t) i * 5 + 1] > tmove * ox[(size_t) i * 5 + 2]) ? tN : tJ;
             break;
           default: break;
@@ -572,6 +612,7 @@ __global__ void __launch_bounds__(env_waves(C) * 64, env_waves(C) / 4) env_kerne
     n = rfl(n);
     phase_fence();
     // posterior probability of each trace step (get_postprob), all lanes
+    int pp_flag = 0;
     for (int z = lane; z < n; z += 64) {
       const uint32_t w = ta[z];
       const int s = (int) (w & 0xffu), k = (int) ((w >> 8) & 0xffffu), i = ti[z];
@@ -580,6 +621,7 @@ __global__ void __launch_bounds__(env_waves(C) * 64, env_waves(C) / 4) env_kerne
       if ((s == tM || s == tI) && i >= 1 && k >= 1) {
         const unsigned w16 = bp[(size_t) i * Mpad + ((k - 1) % C) * 64 + (k - 1) / C];
         pp = pp_from_code((s == tM) ? ((w16 >> 4) & 15u) : ((w16 >> 8) & 15u));
+        pp_flag |= (int) ((w16 >> 15) & 1u);
       } else if (same && i >= 1) {
         if (s == tN) pp = px[(size_t) i * 3 + 0];
         else if (s == tJ) pp = px[(size_t) i * 3 + 1];
@@ -588,6 +630,7 @@ __global__ void __launch_bounds__(env_waves(C) * 64, env_waves(C) / 4) env_kerne
       tp[z] = pp;
       ta[z] = w & 0x7fffffffu;
     }
+    if (__ballot(pp_flag != 0) != 0ull) status |= 64;        // a printed posterior digit within the guard band of the next one
     if (lane == 0) {
       a.out_sc[(size_t) it * 2 + 0] = envsc;
       a.out_sc[(size_t) it * 2 + 1] = oasc;

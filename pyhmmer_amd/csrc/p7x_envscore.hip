@@ -227,6 +227,7 @@ public:
       a.out_sc = reinterpret_cast<float *>(eb->d_out + o_sc) + 2 * m.first;
       a.out_null2 = reinterpret_cast<float *>(eb->d_out + o_n2) + 32 * m.first;
       a.out_status = reinterpret_cast<int32_t *>(eb->d_out + o_st) + m.first;
+      a.oa_guard = oa_guard_;
       a.tr_n = reinterpret_cast<int32_t *>(eb->d_out + o_n) + m.first;
       a.tr_a = reinterpret_cast<uint32_t *>(eb->d_out + o_ta);
       a.tr_i = reinterpret_cast<int32_t *>(eb->d_out + o_ti);
@@ -280,7 +281,10 @@ public:
     return P7X_OK;
   }
 
+  void set_oa_guard(float g) { oa_guard_ = g > 0.0f ? g : 0.0f; }
+
 private:
+  float oa_guard_ = 0.0f;
   struct JobMeta { int64_t first = 0; int nenv = 0, C = 0, Lmax = 1, nblocks = 1; size_t stride = 0; DevProfile *dp = nullptr; };
   DeviceCtx *ctx_; const p7x_seqdb *db_;
   std::vector<EnvelopeJob> jobs_;
@@ -293,9 +297,11 @@ private:
   size_t o_sc_ = 0, o_n2_ = 0, o_st_ = 0, o_n_ = 0, o_ta_ = 0, o_ti_ = 0, o_tp_ = 0;
 };
 
-std::unique_ptr<EnvelopeScorer> make_device_envelope_scorer(DeviceCtx *ctx, const p7x_seqdb *db)
+std::unique_ptr<EnvelopeScorer> make_device_envelope_scorer(DeviceCtx *ctx, const p7x_seqdb *db, float oa_guard)
 {
-  return std::make_unique<DeviceEnvelopeScorer>(ctx, db);
+  auto s = std::make_unique<DeviceEnvelopeScorer>(ctx, db);
+  s->set_oa_guard(oa_guard);
+  return s;
 }
 
 } // namespace p7x

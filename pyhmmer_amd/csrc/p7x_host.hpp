@@ -32,6 +32,7 @@ struct DomainDefResult {      // the P7_DOMAINDEF fields p7_Pipeline reads (p7_d
   std::vector<std::vector<Domain>> multi;   // domains of deferred multi-domain regions (see Domain::multi_slot)
   float nexpected = 0;
   int nregions = 0, nclustered = 0, noverlaps = 0, nenvelopes = 0;
+  int nneartie = 0;           // device envelopes repeated by the host twin (optimal-accuracy near-tie guard)
 };
 
 // Rescoring of single-domain envelopes can be handed to the device (p7x_envelope.hip): the first half of domain
@@ -178,5 +179,6 @@ struct p7x_tophits {
   bool scan_collected = false;        // built by p7x_scan_collect(): one query sequence, hits are models
   std::vector<uint8_t> stage;         // scan mode, per-model result: last filter passed by each target (not serialised)
   std::vector<int32_t> guard_dropped; // targets the F3 guard took out of the device's survivor list (not serialised)
+  int64_t oa_redone = 0;              // device envelopes the near-tie guard sent to the host twin (not serialised)
   int64_t nreported = 0, nincluded = 0;
 };

@@ -140,7 +140,9 @@ struct EnvArgs {
   float *work; int64_t work_stride; int Lmax;    // per-wavefront workspace (env_work_floats), rows 0..Lmax
   int nblocks, slab_base;   // blocks of this job (blockIdx.x beyond them exit); first workspace slab of the job
   float *out_sc;            // [nenv][2] envelope Forward score (nats), optimal accuracy score
-  int32_t *out_status;      // [nenv] bit 0 Forward range, 1 decoding range (envelope dropped), >= 2 traceback failures
+  float oa_guard;           // near-tie guard of the optimal-accuracy traceback (p7x_pipeline_cfg.oa_guard)
+  int32_t *out_status;      // [nenv] bit 0 Forward range, 1 decoding range (envelope dropped), 2-5 traceback failures,
+                            // 6 a near-tie on the trace: the host stage repeats the envelope in the reference's order
   float *out_null2;         // [nenv][32] null2 odds of the canonical residues
   const int64_t *tr_off;    // [nenv] first trace element; capacity Ld + M + 16 each
   uint32_t *tr_a; int32_t *tr_i; float *tr_pp;

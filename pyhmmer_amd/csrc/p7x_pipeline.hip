@@ -1554,6 +1554,45 @@ int p7x_search_batch_enqueue(const p7x_pipeline_cfg *cfg, const p7x_oprofile *co
   return P7X_OK;
 }
 
+int p7x_search_batch_raw(const p7x_pipeline_cfg *cfg, const p7x_oprofile *const *oms, size_t nq, const float *bg_f,
+                         const p7x_seqdb *db, int32_t *xJ, int32_t *xC, uint8_t *stage)
+{
+  p7x_pending *pd = nullptr;
+  int st = p7x_search_batch_enqueue(cfg, oms, nq, bg_f, db, &pd);
+  if (st != P7X_OK) return st;
+  std::unique_ptr<p7x_pending> owner(pd);
+  CascadeRun &r = pd->run;
+  const int64_t n = db->n, ns = db->nslots;
+  if (xJ) std::fill(xJ, xJ + nq * (size_t) n, 0);
+  if (xC) std::fill(xC, xC + nq * (size_t) n, INT32_MIN);
+  if (stage) std::fill(stage, stage + nq * (size_t) n, (uint8_t) 0);
+  if (!r.queued || ns == 0) return P7X_OK;
+  Workspace *ws = r.ws;
+  P7X_HIP(hipStreamSynchronize(ws->stream));          // the batch as the search runs it, kernels chosen per class
+  std::vector<int16_t> hj((size_t) ns); std::vector<int32_t> hl((size_t) ns), hc((size_t) ns); std::vector<uint8_t> hs((size_t) ns);
+  for (size_t q = 0; q < nq; ++q) {
+    const int l = r.lane_of[q];
+    const StageBufs b = ws->lane_bufs(l);
+    int counters[kLaneCounters];
+    P7X_HIP(hipMemcpy(counters, b.counters, sizeof(counters), hipMemcpyDeviceToHost));
+    if (xJ) {
+      P7X_HIP(hipMemcpy(hj.data(), b.xJ, (size_t) ns * 2, hipMemcpyDeviceToHost));
+      for (int64_t sl = 0; sl < ns; ++sl) xJ[q * (size_t) n + (size_t) db->h_order[sl]] = hj[(size_t) sl];
+    }
+    if (xC) {
+      const int nv = counters[2];
+      P7X_HIP(hipMemcpy(hl.data(), b.list_vit, (size_t) nv * 4, hipMemcpyDeviceToHost));
+      P7X_HIP(hipMemcpy(hc.data(), b.xC, (size_t) nv * 4, hipMemcpyDeviceToHost));
+      for (int it = 0; it < nv; ++it) xC[q * (size_t) n + (size_t) db->h_order[hl[(size_t) it]]] = hc[(size_t) it];
+    }
+    if (stage) {
+      P7X_HIP(hipMemcpy(hs.data(), b.stage, (size_t) ns, hipMemcpyDeviceToHost));
+      for (int64_t sl = 0; sl < ns; ++sl) stage[q * (size_t) n + (size_t) db->h_order[sl]] = hs[(size_t) sl];
+    }
+  }
+  return p7x_search_block_wait(pd);                   // collect (and release the workspace) as a search would
+}
+
 int p7x_search_block_enqueue(const p7x_pipeline_cfg *cfg, const p7x_oprofile *om, const float *bg_f, const p7x_seqdb *db,
                              p7x_pending **out)
 {
@@ -1623,8 +1662,8 @@ int p7x_search_batch_finish(p7x_pending *pd, const char *const *names, const cha
   if (any_device) {
     DeviceCtx *ctx = nullptr;
     if ((st = get_ctx(db->device, &ctx)) != P7X_OK) return st;
-    scorer = make_device_envelope_scorer(ctx, db);
-    if (device_clustered()) scorer2 = make_device_envelope_scorer(ctx, db);
+    scorer = make_device_envelope_scorer(ctx, db, pd->cfg.oa_guard);
+    if (device_clustered()) scorer2 = make_device_envelope_scorer(ctx, db, pd->cfg.oa_guard);
   }
   if ((st = host_finish_batch(pd->cfg, items, tg, names, accs, descs, outs, scorer.get(), scorer2.get())) != P7X_OK) return st;
   // work time of this batch (stage 1 + stage 2), not the time it spent queued between the stages

@@ -463,6 +463,7 @@ int host_finish_batch(const p7x_pipeline_cfg &cfg_in, const std::vector<FinishIt
         finish(f, dds[(size_t) f]);
       });
   }
+  for (int f = 0; f < S; ++f) ths[(size_t) q_of[(size_t) f]]->oa_redone += dds[(size_t) f].nneartie;
   tick("deferred");
   host_prof_dump();
   if (failed.load() != 0) { set_error("domain definition workflow failure"); return failed.load(); }
@@ -841,6 +842,14 @@ p7x_tophits *p7x_tophits_deserialize(const void *buf, size_t n)
   }
   if (!r.ok) { set_error("truncated serialised TopHits"); return nullptr; }
   return th.release();
+}
+
+int p7x_tophits_get_guard_counts(const p7x_tophits *th, int64_t *f3_dropped, int64_t *oa_redone)
+{
+  if (!th) return P7X_EINVAL;
+  if (f3_dropped) *f3_dropped = (int64_t) th->guard_dropped.size();
+  if (oa_redone) *oa_redone = th->oa_redone;
+  return P7X_OK;
 }
 
 int p7x_tophits_get_timings(const p7x_tophits *th, double *ms, int n)

@@ -1130,6 +1130,14 @@ class TopHits:
         return dict(msv=c.n_past_msv, bias=c.n_past_bias, vit=c.n_past_vit, fwd=c.n_past_fwd)
 
     @property
+    def guard_counts(self) -> dict:
+        """How often the two guards acted in this search: targets the F3 guard took back out of the device's survivor
+        list, device envelopes the optimal-accuracy near-tie guard had the host twin repeat."""
+        a, b = C.c_int64(0), C.c_int64(0)
+        _lib.lib().p7x_tophits_get_guard_counts(self._handle, C.byref(a), C.byref(b))
+        return {"f3_dropped": int(a.value), "oa_redone": int(b.value)}
+
+    @property
     def timings_ms(self) -> dict:
         buf = (C.c_double * 12)()
         _lib.lib().p7x_tophits_get_timings(self._handle, buf, 12)
@@ -1305,7 +1313,8 @@ class Pipeline:
                  null2: bool = True, seed: int = 42, Z=None, domZ=None, F1: float = 0.02, F2: float = 1e-3,
                  F3: float = 1e-5, E: float = 10.0, T=None, domE: float = 10.0, domT=None, incE: float = 0.01,
                  incT=None, incdomE: float = 0.01, incdomT=None, bit_cutoffs: Optional[str] = None,
-                 device: int = 0, host_threads: int = 0, host_envelopes: bool = False, host_regions: bool = False):
+                 device: int = 0, host_threads: int = 0, host_envelopes: bool = False, host_regions: bool = False,
+                 oa_guard: Optional[float] = None):
         self.alphabet = alphabet
         if background is None:
             self.background = Background(alphabet)
@@ -1331,6 +1340,7 @@ class Pipeline:
         self.host_threads = host_threads
         self.host_envelopes = bool(host_envelopes)
         self.host_regions = bool(host_regions)
+        self.oa_guard = oa_guard          # None: the library's default (p7x_pipeline_cfg.oa_guard)
         self._mode = _P7X_SEARCH_SEQS
         self._db_cache = None           # (id(block), block version, n, device) -> SequenceDatabase
 
@@ -1359,6 +1369,8 @@ class Pipeline:
         c.host_threads = int(self.host_threads)
         c.host_envelopes = int(self.host_envelopes)
         c.host_regions = int(self.host_regions)
+        if self.oa_guard is not None:
+            c.oa_guard = float(self.oa_guard)
         c.mode = int(self._mode)
         return c
 
