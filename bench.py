@@ -343,6 +343,7 @@ def main():
                     help="a step is this many consecutive queries, each a complete search of the resident target block: the "
                          "pipeline's fill and drain (about two query times) then weigh as little in a 20-step run as in a long one")
     ap.add_argument("--batch", type=int, default=0, help="headline workload: queries per device batch (0: the library's own choice)")
+    ap.add_argument("--oa-guard", type=float, default=None, help="A/B: the optimal-accuracy near-tie guard (default: the library's; 0 switches it off)")
     ap.add_argument("--spinup-max", type=int, default=15, help="at most this many untimed 20-query windows before the warm-up")
     ap.add_argument("--workload", choices=("both", "config1", "pfam", "nhmmer"), default="both",
                     help="config1: the headline (one profile x 1M targets per GPU); pfam / nhmmer: (a token headline and) that "
@@ -404,6 +405,7 @@ def main():
     host_threads = max(2, host_cpus() // max(1, local_world))
 
     qps = max(1, args.queries_per_step)
+    pli_opts = {} if args.oa_guard is None else {"oa_guard": args.oa_guard}
     lanes_per_launch = args.batch or hmmer._auto_batch(hmmer.ShardedDatabase.from_database(db), hmm.M)
 
     def run(nsteps):
@@ -411,7 +413,7 @@ def main():
         the device stage of later queries with the host stage of earlier ones (pipeline_depth), exactly as it does for
         distinct queries."""
         last, acc = None, {}
-        for h in hmmer.hmmsearch((om for _ in range(nsteps * qps)), db, pipeline_depth=args.pipeline_depth, feeders=args.feeders, cpus=host_threads, batch=args.batch):
+        for h in hmmer.hmmsearch((om for _ in range(nsteps * qps)), db, pipeline_depth=args.pipeline_depth, feeders=args.feeders, cpus=host_threads, batch=args.batch, **pli_opts):
             last = h
             for k, v in h.timings_ms.items():
                 acc[k] = acc.get(k, 0.0) + v

@@ -180,8 +180,11 @@ typedef struct p7x_pipeline_cfg {
                               * while the scan keeps the max_length the optimized profile was built with); <= 0: the scan's */
   float   oa_guard;          /* near-tie guard of the device's optimal-accuracy traceback: a choice on the trace between candidates
                               * within |v| * g + g of each other (or a posterior that close to the next printed digit) sends the
-                              * envelope to the host twin, which repeats it in the reference's order of operations.  Default 2e-6
-                              * (about 16 units in the last place); 0: no guard */
+                              * envelope to the host twin, which repeats it in the reference's order of operations.  Default 4e-6
+                              * (about 34 units in the last place).  Measured on 26,394 domains (scripts/oa_guard_sweep2.py,
+                              * profiles/r03_oa_guard_sweep.txt): without the guard 9 domains differ from the host twin, with 1e-6 three,
+                              * with 2e-6 one, from 3e-6 on none; 3e-6 repeats 1.5 % of the envelopes.  0: no guard (and a kernel
+                              * without the guard's arithmetic) */
   float   f3_guard;          /* relative half-width of the band around F3 inside which a target's Forward P-value is not trusted to the
                               * device's summation order: the device passes P <= F3 (1 + g), the host stage re-scores the targets with
                               * P > F3 (1 - g) with p7x_forward_parser_exact and applies F3 to that.  Default 4e-3 (a band of about 6e-3 bit, three times the stated tolerance of the device Forward score); 0: no guard */
@@ -325,6 +328,10 @@ int      p7x_tophits_get_hit(const p7x_tophits *th, int64_t i, p7x_hit *hit);
 int      p7x_tophits_get_domain(const p7x_tophits *th, int64_t i, int32_t d, p7x_domain *dom);
 /* p7_tophits_Merge + p7_pipeline_Merge + re-threshold (plan7.pyx:9172-9276): merges src into dst. */
 int      p7x_tophits_merge(p7x_tophits *dst, const p7x_tophits *src);
+/* Many queries x many shards in one call, threaded over the queries: blobs[q * nparts + r] / sizes[...] = the
+ * p7x_tophits_serialize image of query q on shard r (NULL / 0: that shard had nothing to say, e.g. an empty shard that
+ * was never searched).  outs[q] = what TopHits.merge gives for the same lists in shard order.  threads <= 0: every usable CPU. */
+int      p7x_tophits_merge_many(const void *const *blobs, const size_t *sizes, size_t nq, size_t nparts, int threads, p7x_tophits **outs);
 /* Flat byte image of a hit list (the reference pickles TopHits through p7_hit_Serialize, plan7.pyx:8394-8572);
  * used to move per-device / per-process results to the merging host.  serialize returns the size needed. */
 int64_t  p7x_tophits_serialize(const p7x_tophits *th, void *buf, size_t cap);
@@ -345,8 +352,10 @@ int      p7x_tophits_set_hit_text(p7x_tophits *th, int64_t i, int which, const c
  * [10] wall time of stage 1 (p7x_search_block_begin) [11] of stage 2 (_finish); [6] = [10] + [11].  n <= 12. */
 int      p7x_tophits_get_timings(const p7x_tophits *th, double *ms, int n);
 /* how often the two guards acted in the search that produced <th>: targets the F3 guard took back out of the device's
- * survivor list, device envelopes the optimal-accuracy near-tie guard repeated on the host (0 after a merge / deserialisation) */
-int      p7x_tophits_get_guard_counts(const p7x_tophits *th, int64_t *f3_dropped, int64_t *oa_redone);
+ * survivor list, device envelopes the optimal-accuracy near-tie guard repeated on the host (0 after a merge /
+ * deserialisation), and the latter by the kind of choice that was close: the predecessor of a match / insert / delete
+ * cell, C<-E, J<-E, the end cell, B<-N/J, a printed posterior digit (an envelope can count under several) */
+int      p7x_tophits_get_guard_counts(const p7x_tophits *th, int64_t *f3_dropped, int64_t *oa_redone, int64_t oa_why[8]);
 
 const char *p7x_last_error(void);
 

@@ -1224,7 +1224,7 @@ int domaindef_finish_deferred(const Profile &p, const uint8_t *dsq, int L, const
   bool om_exact_ready = false;
   auto from_result = [&](const EnvelopeResult &r, int i, int j, bool null2_done, Domain &dom) -> bool {
     if (r.status & 2) return false;                  // p7_Decoding range error: the envelope is dropped
-    if (r.status & ~(3 | 64)) return false;          // traceback failure: upstream's rescore returns without a domain
+    if (r.status & 0xff & ~(3 | 64)) return false;   // traceback failure: upstream's rescore returns without a domain
     if (r.status & 64) {
       // a near-tie on the device's optimal-accuracy trace (p7x_envelope.hip, cfg.oa_guard): this envelope again with
       // the host twin, which performs the reference's operations in the reference's order
@@ -1234,6 +1234,7 @@ int domaindef_finish_deferred(const Profile &p, const uint8_t *dsq, int L, const
       const int st = rescore_isolated_domain(p, om_exact, dsq, L, i, j, null2_done, ws, one);
       dd.n2sc.swap(one.n2sc);
       dd.nneartie++;
+      for (int b = 0; b < 8; ++b) if (r.status & (1 << (8 + b))) dd.neartie_why[b]++;
       if (st != P7X_OK || one.dcl.empty()) return false;
       dom = std::move(one.dcl[0]);
       return true;

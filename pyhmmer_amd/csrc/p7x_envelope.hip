@@ -127,21 +127,21 @@ __device__ __forceinline__ unsigned pp_code(float p)
 // the reference's operations in the reference's order.  guard: relative half-width (cfg.oa_guard); 0 switches it off.
 __device__ __forceinline__ float guard_band(float v, float guard) { return __builtin_fabsf(v) * guard + guard; }
 __device__ __forceinline__ int near_tie(float x, float y, float guard)
-{ // both -inf: the difference is NaN and the test is false (such a cell is unreachable anyway)
-  return (guard > 0.0f && __builtin_fabsf(x - y) <= guard_band(vmax(__builtin_fabsf(x), __builtin_fabsf(y)), guard)) ? 1 : 0;
+{ // the band is the winner's: one candidate at -inf (a closed transition, the first row) is an infinite distance away;
+  // both at -inf: the difference is NaN and the test is false (such a cell is unreachable anyway)
+  return (__builtin_fabsf(x - y) <= guard_band(vmax(x, y), guard)) ? 1 : 0;
 }
 __device__ __forceinline__ int pp_near(float p, float guard)
 {
   // float is enough here: the band is an order of magnitude wider than the rounding of this expression
   const float v = (p + 0.05f) * 10.0f;
-  const float fr = v - __builtin_floorf(v);
-  const float g = 16.0f * guard;
-  return (guard > 0.0f && (fr < g || fr > 1.0f - g) && v > 0.5f) ? 1 : 0;
+  return (__builtin_fabsf(v - __builtin_rintf(v)) < 4.0f * guard && v > 0.75f) ? 1 : 0;
 }
 // and back to a float that prints as that digit (the host stage formats the line from floats)
 __device__ __forceinline__ float pp_from_code(unsigned code) { return code >= 10u ? 1.0f : (float) (((double) code + 0.5) / 10.0 - 0.05); }
 
-template <int C>
+// G: with the near-tie guard (a.oa_guard > 0).  Without it the kernel carries none of the guard's arithmetic.
+template <int C, bool G>
 __global__ void __launch_bounds__(env_waves(C) * 64, env_waves(C) / 4) env_kernel(const ArgRef ref)
 {
   constexpr int kEnvBlock = env_waves(C) * 64;
@@ -425,17 +425,20 @@ __global__ void __launch_bounds__(env_waves(C) * 64, env_waves(C) / 4) env_kerne
           { const float p1 = block(t.im, ip); if (p1 > bv) { best = 1; second = bv; bv = p1; } else second = vmax(second, p1); }
           { const float p2 = block(t.dm, dp); if (p2 > bv) { best = 2; second = bv; bv = p2; } else second = vmax(second, p2); }
           { const float p3 = block(t.bm, xBp); if (p3 > bv) { best = 3; second = bv; bv = p3; } else second = vmax(second, p3); }
-          const int near_m = near_tie(bv, second, a.oa_guard);
+          int near_m = 0;
+          if constexpr (G) near_m = near_tie(bv, second, a.oa_guard);
           const float mcur = om_[c], icur = oi_[c];
           float iv = gate(t.mi, mcur);
           iv = vmax(iv, gate(t.ii, icur));
           const float q0 = block(t.mi, mcur), q1 = block(t.ii, icur);
           const int ichoice = (q0 >= q1) ? 0 : 1;
-          const int near_i = near_tie(q0, q1, a.oa_guard);
+          int near_i = 0;
+          if constexpr (G) near_i = near_tie(q0, q1, a.oa_guard);
           mp = mcur; ip = icur; dp = od_[c];
           om_[c] = sv + ppm[c];
           oi_[c] = iv + ppi[c];
-          const int near_pp = pp_near(ppm[c], a.oa_guard) | pp_near(ppi[c], a.oa_guard);
+          int near_pp = 0;
+          if constexpr (G) near_pp = pp_near(ppm[c], a.oa_guard) | pp_near(ppi[c], a.oa_guard);
           code[c] = (unsigned short) (best | (ichoice << 2) | (pp_code(ppm[c]) << 4) | (pp_code(ppi[c]) << 8) | (near_m << 12) | (near_i << 13) | (near_pp << 15));
         }
         // D(r,k) = max(gate(tMD(k-1), M(r,k-1)), tDD(k-1) > 0 ? D(r,k-1) : 0), D(r,1) = -inf: a segmented max-scan
@@ -456,7 +459,9 @@ __global__ void __launch_bounds__(env_waves(C) * 64, env_waves(C) / 4) env_kerne
           for (int c = 0; c < C; ++c) {
             const float d0 = block(pmd, pm), d1 = block(pdd, pd);
             const int dchoice = (d0 >= d1) ? 0 : 1;
-            code[c] |= (unsigned short) ((dchoice << 3) | (near_tie(d0, d1, a.oa_guard) << 14));
+            int near_d = 0;
+            if constexpr (G) near_d = near_tie(d0, d1, a.oa_guard);
+            code[c] |= (unsigned short) ((dchoice << 3) | (near_d << 14));
             pm = om_[c]; pd = od_[c]; pmd = t_md[c]; pdd = t_dd[c];
           }
         }
@@ -496,13 +501,13 @@ __global__ void __launch_bounds__(env_waves(C) * 64, env_waves(C) / 4) env_kerne
               const int rank = ((k - 1) % Q) * 4 + (k - 1) / Q;
               if (om_[c] == oE) keyM = max(keyM, rank + 1);
               if (od_[c] == oE) keyD = max(keyD, (1 << 24) - rank);
-              nearM += om_[c] >= ethr;
+              if constexpr (G) nearM += om_[c] >= ethr;
             }
           }
           keyM = wave_max_i32(keyM);
           // D cells copy the M cell they derive from (a structural tie, the same on any device): only a second MATCH cell
           // inside the guard band -- or an end in a delete state -- makes the choice of the end cell a near-tie
-          e_near = (a.oa_guard > 0.0f && (wave_max_i32(nearM) > 1 || __builtin_popcountll(__ballot(nearM > 0)) > 1 || keyM == 0)) ? 1 : 0;
+          if constexpr (G) e_near = (wave_max_i32(nearM) > 1 || __builtin_popcountll(__ballot(nearM > 0)) > 1 || keyM == 0) ? 1 : 0;
           if (keyM > 0) { const int rank = keyM - 1; e_k = (rank % 4) * Q + rank / 4 + 1; e_s = tM; }
           else {
             keyD = wave_max_i32(keyD);
@@ -554,7 +559,7 @@ __global__ void __launch_bounds__(env_waves(C) * 64, env_waves(C) / 4) env_kerne
             if (i < 1 || k < 1) { status |= 4; break; }
             const unsigned w16 = bp[(size_t) i * Mpad + ((k - 1) % C) * 64 + (k - 1) / C];
             const int code = w16 & 3;
-            if (w16 & (1u << 12)) status |= 64;
+            if (w16 & (1u << 12)) status |= 64 | (1 << 8);
             s1 = (code == 0) ? tM : (code == 1) ? tI : (code == 2) ? tD : tB;
             --k; --i;
             break;
@@ -563,7 +568,7 @@ __global__ void __launch_bounds__(env_waves(C) * 64, env_waves(C) / 4) env_kerne
             if (i < 1 || k < 1) { status |= 4; break; }
             const unsigned w16 = bp[(size_t) i * Mpad + ((k - 1) % C) * 64 + (k - 1) / C];
             const int code = (w16 >> 3) & 1;
-            if (w16 & (1u << 14)) status |= 64;
+            if (w16 & (1u << 14)) status |= 64 | (1 << 10);
             s1 = code ? tD : tM; --k;
             break;
           }
@@ -571,7 +576,7 @@ __global__ void __launch_bounds__(env_waves(C) * 64, env_waves(C) / 4) env_kerne
             if (i < 1 || k < 1) { status |= 4; break; }
             const unsigned w16 = bp[(size_t) i * Mpad + ((k - 1) % C) * 64 + (k - 1) / C];
             const int code = (w16 >> 2) & 1;
-            if (w16 & (1u << 13)) status |= 64;
+            if (w16 & (1u << 13)) status |= 64 | (1 << 9);
             s1 = code ? tI : tM; --i;
             break;
           }
@@ -579,24 +584,24 @@ __global__ void __launch_bounds__(env_waves(C) * 64, env_waves(C) / 4) env_kerne
           case tC: {
             if (i < 1) { status |= 4; break; }
             const float p0 = t1c * (ox[(size_t) (i - 1) * 5 + 4] + px[(size_t) i * 3 + 2]), p1 = t2e_move * ox[(size_t) i * 5 + 0];
-            if (near_tie(p0, p1, a.oa_guard)) status |= 64;
+            if (G && near_tie(p0, p1, a.oa_guard)) status |= 64 | (1 << 11);
             s1 = (p0 > p1) ? tC : tE;
             break;
           }
           case tJ: {
             if (i < 1) { status |= 4; break; }
             const float p0 = t1c * (ox[(size_t) (i - 1) * 5 + 2] + px[(size_t) i * 3 + 1]), p1 = t2e_loop * ox[(size_t) i * 5 + 0];
-            if (near_tie(p0, p1, a.oa_guard)) status |= 64;
+            if (G && near_tie(p0, p1, a.oa_guard)) status |= 64 | (1 << 12);
             s1 = (p0 > p1) ? tJ : tE;
             break;
           }
           case tE:
             if (i != e_row || e_s < 0) { status |= 8; break; }   // only the last C<-E row was resolved (unihit envelopes)
-            if (e_near) status |= 64;
+            if (e_near) status |= 64 | (1 << 13);
             k = e_k; s1 = e_s;
             break;
           case tB:
-            if (near_tie(tmove * ox[(size_t) i * 5 + 1], tmove * ox[(size_t) i * 5 + 2], a.oa_guard)) status |= 64;
+            if (G && near_tie(tmove * ox[(size_t) i * 5 + 1], tmove * ox[(size_t) i * 5 + 2], a.oa_guard)) status |= 64 | (1 << 14);
             s1 = (tmove * ox[(size_t) i * 5 + 1] > tmove * ox[(size_t) i * 5 + 2]) ? tN : tJ;
             break;
           default: break;
@@ -630,7 +635,7 @@ __global__ void __launch_bounds__(env_waves(C) * 64, env_waves(C) / 4) env_kerne
       tp[z] = pp;
       ta[z] = w & 0x7fffffffu;
     }
-    if (__ballot(pp_flag != 0) != 0ull) status |= 64;        // a printed posterior digit within the guard band of the next one
+    if (G && __ballot(pp_flag != 0) != 0ull) status |= 64 | (1 << 15);        // a printed posterior digit within the guard band of the next one
     if (lane == 0) {
       a.out_sc[(size_t) it * 2 + 0] = envsc;
       a.out_sc[(size_t) it * 2 + 1] = oasc;
@@ -679,19 +684,19 @@ static int occupancy_env(K kernel, int kEnvBlock, size_t lds_bytes, int *per_cu)
 
 #define P7X_ENV_SWITCH(EXPR)                                                                                  \
   switch (C) {                                                                                                \
-    case 1:  { auto kern = env_kernel<1>;  return EXPR; }                                                     \
-    case 2:  { auto kern = env_kernel<2>;  return EXPR; }                                                     \
-    case 3:  { auto kern = env_kernel<3>;  return EXPR; }                                                     \
-    case 4:  { auto kern = env_kernel<4>;  return EXPR; }                                                     \
-    case 5:  { auto kern = env_kernel<5>;  return EXPR; }                                                     \
-    case 6:  { auto kern = env_kernel<6>;  return EXPR; }                                                     \
-    case 8:  { auto kern = env_kernel<8>;  return EXPR; }                                                     \
-    case 10: { auto kern = env_kernel<10>; return EXPR; }                                                     \
-    case 12: { auto kern = env_kernel<12>; return EXPR; }                                                     \
-    case 16: { auto kern = env_kernel<16>; return EXPR; }                                                     \
-    case 20: { auto kern = env_kernel<20>; return EXPR; }                                                     \
-    case 24: { auto kern = env_kernel<24>; return EXPR; }                                                     \
-    case 32: { auto kern = env_kernel<32>; return EXPR; }                                                     \
+    case 1: { if (G_) { auto kern = env_kernel<1, true>; return EXPR; } else { auto kern = env_kernel<1, false>; return EXPR; } }                                                     \
+    case 2: { if (G_) { auto kern = env_kernel<2, true>; return EXPR; } else { auto kern = env_kernel<2, false>; return EXPR; } }                                                     \
+    case 3: { if (G_) { auto kern = env_kernel<3, true>; return EXPR; } else { auto kern = env_kernel<3, false>; return EXPR; } }                                                     \
+    case 4: { if (G_) { auto kern = env_kernel<4, true>; return EXPR; } else { auto kern = env_kernel<4, false>; return EXPR; } }                                                     \
+    case 5: { if (G_) { auto kern = env_kernel<5, true>; return EXPR; } else { auto kern = env_kernel<5, false>; return EXPR; } }                                                     \
+    case 6: { if (G_) { auto kern = env_kernel<6, true>; return EXPR; } else { auto kern = env_kernel<6, false>; return EXPR; } }                                                     \
+    case 8: { if (G_) { auto kern = env_kernel<8, true>; return EXPR; } else { auto kern = env_kernel<8, false>; return EXPR; } }                                                     \
+    case 10: { if (G_) { auto kern = env_kernel<10, true>; return EXPR; } else { auto kern = env_kernel<10, false>; return EXPR; } }                                                     \
+    case 12: { if (G_) { auto kern = env_kernel<12, true>; return EXPR; } else { auto kern = env_kernel<12, false>; return EXPR; } }                                                     \
+    case 16: { if (G_) { auto kern = env_kernel<16, true>; return EXPR; } else { auto kern = env_kernel<16, false>; return EXPR; } }                                                     \
+    case 20: { if (G_) { auto kern = env_kernel<20, true>; return EXPR; } else { auto kern = env_kernel<20, false>; return EXPR; } }                                                     \
+    case 24: { if (G_) { auto kern = env_kernel<24, true>; return EXPR; } else { auto kern = env_kernel<24, false>; return EXPR; } }                                                     \
+    case 32: { if (G_) { auto kern = env_kernel<32, true>; return EXPR; } else { auto kern = env_kernel<32, false>; return EXPR; } }                                                     \
     default: set_error("model too long for the envelope kernel"); return P7X_EINVAL;                         \
   }
 
@@ -702,6 +707,7 @@ int env_max_blocks(int C, int nrows, int num_cu, int *nblocks)
   const size_t lds = env_lds_bytes(C, nrows);
   int per_cu = 1;
   auto finish = [&](int st) { if (st == P7X_OK) *nblocks = num_cu * per_cu; return st; };
+  const bool G_ = true;            // the guarded kernel is never the smaller one
   P7X_ENV_SWITCH(finish(occupancy_env(kern, env_waves(C) * 64, lds, &per_cu)))
 }
 
@@ -710,6 +716,7 @@ int env_launch(const ArgRun<EnvArgs> &a, hipStream_t st)
   if (a.n <= 0) return P7X_OK;
   const int C = a.at(0).C;
   const size_t lds = env_lds_bytes(C, a.at(0).nrows);
+  const bool G_ = a.at(0).oa_guard > 0.0f;
   P7X_ENV_SWITCH(launch_env(kern, a, lds, st))
 }
 

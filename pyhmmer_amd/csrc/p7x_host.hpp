@@ -33,6 +33,7 @@ struct DomainDefResult {      // the P7_DOMAINDEF fields p7_Pipeline reads (p7_d
   float nexpected = 0;
   int nregions = 0, nclustered = 0, noverlaps = 0, nenvelopes = 0;
   int nneartie = 0;           // device envelopes repeated by the host twin (optimal-accuracy near-tie guard)
+  int neartie_why[8]{};       // ... by the kind of choice that was close (EnvArgs::out_status bits 8-15)
 };
 
 // Rescoring of single-domain envelopes can be handed to the device (p7x_envelope.hip): the first half of domain
@@ -180,5 +181,6 @@ struct p7x_tophits {
   std::vector<uint8_t> stage;         // scan mode, per-model result: last filter passed by each target (not serialised)
   std::vector<int32_t> guard_dropped; // targets the F3 guard took out of the device's survivor list (not serialised)
   int64_t oa_redone = 0;              // device envelopes the near-tie guard sent to the host twin (not serialised)
+  int64_t oa_why[8]{};                // ... by kind of choice: M, I, D cell, C<-E, J<-E, end cell, B<-N/J, posterior digit
   int64_t nreported = 0, nincluded = 0;
 };

@@ -143,6 +143,7 @@ struct EnvArgs {
   float oa_guard;           // near-tie guard of the optimal-accuracy traceback (p7x_pipeline_cfg.oa_guard)
   int32_t *out_status;      // [nenv] bit 0 Forward range, 1 decoding range (envelope dropped), 2-5 traceback failures,
                             // 6 a near-tie on the trace: the host stage repeats the envelope in the reference's order
+                            // (bits 8-15 say where: M / I / D cell choice, C<-E, J<-E, end cell, B<-N/J, posterior digit)
   float *out_null2;         // [nenv][32] null2 odds of the canonical residues
   const int64_t *tr_off;    // [nenv] first trace element; capacity Ld + M + 16 each
   uint32_t *tr_a; int32_t *tr_i; float *tr_pp;

@@ -463,7 +463,11 @@ int host_finish_batch(const p7x_pipeline_cfg &cfg_in, const std::vector<FinishIt
         finish(f, dds[(size_t) f]);
       });
   }
-  for (int f = 0; f < S; ++f) ths[(size_t) q_of[(size_t) f]]->oa_redone += dds[(size_t) f].nneartie;
+  for (int f = 0; f < S; ++f) {
+    p7x_tophits &th = *ths[(size_t) q_of[(size_t) f]];
+    th.oa_redone += dds[(size_t) f].nneartie;
+    for (int b = 0; b < 8; ++b) th.oa_why[b] += dds[(size_t) f].neartie_why[b];
+  }
   tick("deferred");
   host_prof_dump();
   if (failed.load() != 0) { set_error("domain definition workflow failure"); return failed.load(); }
@@ -721,9 +725,9 @@ int p7x_tophits_set_hit_flags(p7x_tophits *th, int64_t i, uint32_t flags)
 
 // TopHits.merge (plan7.pyx:9172-9276): p7_tophits_Merge (concatenate, re-sort), p7_pipeline_Merge (add the
 // accounting; Z too when it counts targets), clear REPORTED/INCLUDED unless bit cutoffs, re-threshold.
-int p7x_tophits_merge(p7x_tophits *dst, const p7x_tophits *src)
+p7x_tophits *p7x_tophits_deserialize(const void *buf, size_t n);
+static int merge_check(const p7x_tophits *dst, const p7x_tophits *src)
 {
-  if (!dst || !src) return P7X_EINVAL;
   if (dst->qname != src->qname) { set_error("Trying to merge `TopHits` obtained from different queries"); return P7X_EINVAL; }
   const p7x_pipeline_cfg &a = dst->cfg, &b = src->cfg;
   if (a.by_E != b.by_E || a.dom_by_E != b.dom_by_E || a.inc_by_E != b.inc_by_E || a.incdom_by_E != b.incdom_by_E ||
@@ -734,13 +738,23 @@ int p7x_tophits_merge(p7x_tophits *dst, const p7x_tophits *src)
     set_error("Trying to merge `TopHits` obtained from pipelines configured with different parameters");
     return P7X_EINVAL;
   }
-  for (const Hit &h : src->hits) dst->hits.push_back(h);
+  return P7X_OK;
+}
+// concatenation and accounting; <src>'s hits are moved when it is not needed afterwards
+static void merge_append(p7x_tophits *dst, p7x_tophits *src, bool move_hits)
+{
+  dst->hits.reserve(dst->hits.size() + src->hits.size());
+  if (move_hits) for (Hit &h : src->hits) dst->hits.push_back(std::move(h));
+  else for (const Hit &h : src->hits) dst->hits.push_back(h);
   dst->ctr.nseqs += src->ctr.nseqs; dst->ctr.nres += src->ctr.nres;
   dst->ctr.nmodels = std::max(dst->ctr.nmodels, src->ctr.nmodels); dst->ctr.nnodes = std::max(dst->ctr.nnodes, src->ctr.nnodes);
   dst->ctr.n_past_msv += src->ctr.n_past_msv; dst->ctr.n_past_bias += src->ctr.n_past_bias;
   dst->ctr.n_past_vit += src->ctr.n_past_vit; dst->ctr.n_past_fwd += src->ctr.n_past_fwd;
   if (dst->cfg.Z_setby == P7X_ZSETBY_NTARGETS) dst->cfg.Z += src->cfg.Z;
   for (int i = 0; i < 12; ++i) dst->ms[i] += src->ms[i];
+}
+static void merge_finalize(p7x_tophits *dst)
+{
   if (!dst->cfg.use_bit_cutoffs)
     for (Hit &h : dst->hits) {
       h.flags &= ~(uint32_t) (P7X_IS_REPORTED | P7X_IS_INCLUDED);
@@ -749,6 +763,52 @@ int p7x_tophits_merge(p7x_tophits *dst, const p7x_tophits *src)
     }
   sort_by_key(*dst);
   threshold(*dst);
+}
+
+int p7x_tophits_merge(p7x_tophits *dst, const p7x_tophits *src)
+{
+  if (!dst || !src) return P7X_EINVAL;
+  const int st = merge_check(dst, src);
+  if (st != P7X_OK) return st;
+  merge_append(dst, const_cast<p7x_tophits *>(src), false);
+  merge_finalize(dst);
+  return P7X_OK;
+}
+
+// The merging side of a sharded many-query search (rank 0 of `bench.py --gpus N`, the reference's
+// _ReverseSEARCHDispatcher collecting its chunks, _hmmsearch.py:259-263): blobs[q * nparts + r] is the serialised hit
+// list of query q on shard r.  Per query: deserialise, concatenate in shard order, ONE sort and ONE threshold (the result
+// of TopHits.merge over the same lists: sort and threshold depend only on the concatenation), the queries spread over the
+// host workers.  Empty shards (size 0 / NULL) are skipped; a query whose shards are all empty is an error.
+int p7x_tophits_merge_many(const void *const *blobs, const size_t *sizes, size_t nq, size_t nparts, int threads, p7x_tophits **outs)
+{
+  if (!blobs || !sizes || !outs || nparts == 0) { set_error("p7x_tophits_merge_many: bad arguments"); return P7X_EINVAL; }
+  for (size_t q = 0; q < nq; ++q) outs[q] = nullptr;
+  std::atomic<int> failed{ P7X_OK };
+  std::mutex err_mu; std::string err;
+  host_parallel_for((int) nq, threads, [&](int qi) {
+    const size_t q = (size_t) qi;
+    std::unique_ptr<p7x_tophits> dst;
+    auto fail = [&](int st) { int expect = P7X_OK; if (failed.compare_exchange_strong(expect, st)) { std::lock_guard<std::mutex> lk(err_mu); err = p7x_last_error(); } };
+    for (size_t r = 0; r < nparts; ++r) {
+      const void *b = blobs[q * nparts + r]; const size_t n = sizes[q * nparts + r];
+      if (!b || n == 0) continue;
+      std::unique_ptr<p7x_tophits> part(p7x_tophits_deserialize(b, n));
+      if (!part) { fail(P7X_EINVAL); return; }
+      if (!dst) { dst = std::move(part); continue; }
+      const int st = merge_check(dst.get(), part.get());
+      if (st != P7X_OK) { fail(st); return; }
+      merge_append(dst.get(), part.get(), true);
+    }
+    if (!dst) { set_error("p7x_tophits_merge_many: a query without any shard result"); fail(P7X_EINVAL); return; }
+    merge_finalize(dst.get());
+    outs[q] = dst.release();
+  });
+  if (failed.load() != P7X_OK) {
+    for (size_t q = 0; q < nq; ++q) { delete outs[q]; outs[q] = nullptr; }
+    set_error(err.c_str());
+    return failed.load();
+  }
   return P7X_OK;
 }
 
@@ -844,11 +904,12 @@ p7x_tophits *p7x_tophits_deserialize(const void *buf, size_t n)
   return th.release();
 }
 
-int p7x_tophits_get_guard_counts(const p7x_tophits *th, int64_t *f3_dropped, int64_t *oa_redone)
+int p7x_tophits_get_guard_counts(const p7x_tophits *th, int64_t *f3_dropped, int64_t *oa_redone, int64_t *oa_why)
 {
   if (!th) return P7X_EINVAL;
   if (f3_dropped) *f3_dropped = (int64_t) th->guard_dropped.size();
   if (oa_redone) *oa_redone = th->oa_redone;
+  if (oa_why) for (int b = 0; b < 8; ++b) oa_why[b] = th->oa_why[b];
   return P7X_OK;
 }
 

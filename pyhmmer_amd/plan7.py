@@ -1133,9 +1133,10 @@ class TopHits:
     def guard_counts(self) -> dict:
         """How often the two guards acted in this search: targets the F3 guard took back out of the device's survivor
         list, device envelopes the optimal-accuracy near-tie guard had the host twin repeat."""
-        a, b = C.c_int64(0), C.c_int64(0)
-        _lib.lib().p7x_tophits_get_guard_counts(self._handle, C.byref(a), C.byref(b))
-        return {"f3_dropped": int(a.value), "oa_redone": int(b.value)}
+        a, b, why = C.c_int64(0), C.c_int64(0), (C.c_int64 * 8)()
+        _lib.lib().p7x_tophits_get_guard_counts(self._handle, C.byref(a), C.byref(b), why)
+        return {"f3_dropped": int(a.value), "oa_redone": int(b.value),
+                "oa_why": dict(zip(("match", "insert", "delete", "c_from_e", "j_from_e", "end_cell", "begin", "pp_digit"), map(int, why)))}
 
     @property
     def timings_ms(self) -> dict:
@@ -1294,6 +1295,29 @@ class TopHits:
 
     def __add__(self, other: "TopHits") -> "TopHits":
         return self.merge(other)
+
+    @staticmethod
+    def merge_many(blobs, queries=None, threads: int = 0) -> List["TopHits"]:
+        """The merging side of a sharded many-query search: ``blobs[r][q]`` is ``to_bytes()`` of query ``q`` on shard
+        ``r`` (``None`` / ``b""`` for a shard with nothing to report).  One native call (``p7x_tophits_merge_many``),
+        threaded over the queries; the result for query ``q`` equals ``shard0[q].merge(shard1[q], ...)``."""
+        nparts = len(blobs)
+        nq = len(blobs[0]) if nparts else 0
+        if any(len(b) != nq for b in blobs):
+            raise ValueError("every shard must report the same number of queries")
+        if nq == 0:
+            return []
+        flat = (C.c_char_p * (nq * nparts))()
+        sizes = (C.c_size_t * (nq * nparts))()
+        for r, shard in enumerate(blobs):
+            for q, b in enumerate(shard):
+                flat[q * nparts + r] = b if b else None
+                sizes[q * nparts + r] = len(b) if b else 0
+        outs = (C.c_void_p * nq)()
+        st = _lib.lib().p7x_tophits_merge_many(flat, sizes, nq, nparts, int(threads), outs)
+        if st != 0:
+            raise ValueError(_lib.last_error())
+        return [TopHits(None if queries is None else queries[q], C.c_void_p(outs[q])) for q in range(nq)]
 
 
 # --------------------------------------------------------------------------- Pipeline
