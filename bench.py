@@ -27,7 +27,7 @@ os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")      # before torch initialises 
 
 ROOT = Path(__file__).resolve().parent
 sys.path.insert(0, str(ROOT))
-sys.path.insert(0, str(ROOT / "tests"))
+sys.path.insert(0, str(ROOT / "oracle"))     # oracle_lib, for the cpu_baseline legs only (after the timed regions)
 
 HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 VALU_LANE_OPS_PER_S = 256 * 4 * 16 * 2.4e9    # 256 CU x 4 SIMD x 16 lanes/clk x 2.4 GHz: packed-16 VOP3P ops take 4 cycles per
@@ -200,19 +200,41 @@ def shard_bounds(lengths, world):
     return cuts
 
 
-def run_pfam(args, rank, world, local_rank, dist, red_dev, torch, host_threads):
-    """the first `--pfam-profiles` entries of the synthetic 20k-profile library against
-    `--pfam-targets` Swiss-Prot-shaped targets, STRONG scaling: the targets are sharded by residues over the ranks,
-    every rank searches every profile against its shard, rank 0 gathers the per-rank hit lists and merges them per
-    query (TopHits.merge) -- all inside the timed region.  Profiles (device images) and targets are resident in HBM
-    before the clock starts, like a pressed database and a loaded proteome."""
+def cpu_baseline_many(hmms, bg, flat, offsets, lengths, profile_idx, ntargets):
+    """cpu_baseline() (the whole search through oracle/ + the product's host twin, all usable cores) for a SAMPLE of a
+    many-profile workload: the profiles `profile_idx` against the first `ntargets` targets, one after the other."""
+    t = cells = 0.0
+    hits = 0
+    cores = 0
+    for e in profile_idx:
+        r = cpu_baseline(hmms[e], bg, flat, offsets, lengths, ntargets, 400)
+        c = float(hmms[e].M) * float(lengths[:ntargets].sum())
+        t += c / (r["value"] * 1e9); cells += c; hits += max(0, r["hits"]); cores = r["cores"]
+    return {"value": round(cells / t / 1e9, 3), "unit": "GCUPS", "cores": cores, "kind": "port",
+            "sample": f"{len(profile_idx)} profiles (every {profile_idx[1] - profile_idx[0] if len(profile_idx) > 1 else 1}th of the {len(hmms)} searched) "
+                      f"x the first {ntargets} targets of the same workload, whole search per profile (oracle/ filter cascade + parsers, "
+                      f"product host twin for domain definition), {t:.2f} s of wall time", "hits": hits}
+
+
+def build_library(args, local_rank):
     import bench_workloads as bw
-    from pyhmmer_amd import hmmer, plan7
+    from pyhmmer_amd import plan7
     t0 = time.perf_counter()
     hmms, lib_lengths, templates = bw.make_library(args.pfam_library, device=local_rank, count=args.pfam_profiles)
     bg = plan7.Background(hmms[0].alphabet)
     oms = [plan7.OptimizedProfile(h, bg, 400) for h in hmms]
-    t_lib = time.perf_counter() - t0
+    return {"hmms": hmms, "lengths": lib_lengths, "templates": templates, "bg": bg, "oms": oms, "seconds": time.perf_counter() - t0}
+
+
+def run_pfam(args, rank, world, local_rank, dist, red_dev, torch, host_threads, lib):
+    """the first `--pfam-profiles` entries (default: all) of the synthetic 20k-profile library
+    against `--pfam-targets` Swiss-Prot-shaped targets, STRONG scaling: the targets are sharded by residues over the
+    ranks, every rank searches every profile against its shard, rank 0 gathers the per-rank hit lists and merges them per
+    query (one native call, p7x_tophits_merge_many) -- all inside the timed region.  Profiles (device images) and targets
+    are resident in HBM before the clock starts, like a pressed database and a loaded proteome."""
+    import bench_workloads as bw
+    from pyhmmer_amd import hmmer, plan7
+    hmms, lib_lengths, templates, bg, oms = lib["hmms"], lib["lengths"], lib["templates"], lib["bg"], lib["oms"]
     t0 = time.perf_counter()
     frac = min(0.5, 12.5 * len(hmms) / args.pfam_targets)
     flat, offsets, lengths, nplanted = bw.make_targets(args.pfam_targets, len(hmms), templates, lib_lengths, planted_frac=frac)
@@ -237,14 +259,19 @@ def run_pfam(args, rank, world, local_rank, dist, red_dev, torch, host_threads):
     hits = search(oms)
     t_search = time.perf_counter() - t0
     merged = hits
+    t_ser = t_gather = t_merge = 0.0
     if dist is not None:
+        t1 = time.perf_counter()
+        mine = [h.to_bytes() for h in hits]
+        t_ser = time.perf_counter() - t1
+        t1 = time.perf_counter()
         blobs = [None] * world if rank == 0 else None
-        dist.gather_object([h.to_bytes() for h in hits], blobs, dst=0)
+        dist.gather_object(mine, blobs, dst=0)
+        t_gather = time.perf_counter() - t1
         if rank == 0:
-            merged = []
-            for q in range(len(oms)):
-                th = plan7.TopHits.from_bytes(blobs[0][q])
-                merged.append(th.merge(*[plan7.TopHits.from_bytes(blobs[r][q]) for r in range(1, world)]))
+            t1 = time.perf_counter()
+            merged = plan7.TopHits.merge_many(blobs, threads=host_threads)
+            t_merge = time.perf_counter() - t1
     barrier()
     elapsed = time.perf_counter() - t0
     t_max = elapsed
@@ -259,20 +286,76 @@ def run_pfam(args, rank, world, local_rank, dist, red_dev, torch, host_threads):
     nhits = sum(len(h) for h in merged)
     nrep = sum(len(h.reported) for h in merged)
     sc = {k: sum(h.stage_counts[k] for h in hits) for k in ("msv", "bias", "vit", "fwd")}
-    return {
+    out = {
         "workload": f"configs[3]-shaped: the first {len(hmms)} profiles of the synthetic {args.pfam_library}-entry library (14 fixture "
                     f"models resampled to M ~ lognormal(median 120), calibrated on the device) x {args.pfam_targets} targets "
                     f"(L ~ lognormal(5.65, 0.65) in [30, 5000], {nplanted} with a planted domain), sharded by residues over {world} GPU(s), "
-                    "per-query TopHits gathered and merged on rank 0 inside the timed region",
+                    "per-query TopHits gathered and merged on rank 0 (p7x_tophits_merge_many) inside the timed region",
         "value": round(nodes * residues / t_max / 1e9, 2), "unit": "GCUPS", "scaling": "strong",
         "profiles": len(hmms), "targets": int(args.pfam_targets), "mean_M": round(nodes / len(hmms), 1), "mean_L": round(residues / len(lengths), 1),
         "seconds": round(t_max, 4), "ms_per_profile": round(1e3 * t_max / len(hmms), 4), "profiles_per_s": round(len(hmms) / t_max, 1),
-        "search_seconds_rank0": round(t_search, 4), "batch": args.pfam_batch, "pipeline_depth": args.pfam_depth,
+        "search_seconds_rank0": round(t_search, 4),
+        "merge_seconds_rank0": {"serialise": round(t_ser, 4), "gather": round(t_gather, 4), "merge_many": round(t_merge, 4)},
+        "batch": args.pfam_batch, "pipeline_depth": args.pfam_depth,
         "hits": nhits, "reported": nrep, "stage_counts_rank0": sc,
+        "guards_rank0": {"f3_dropped": sum(h.guard_counts["f3_dropped"] for h in hits), "oa_redone": sum(h.guard_counts["oa_redone"] for h in hits)},
         # per-BATCH times (every query of a batch reports its batch's): device stages by HIP events of the first class
         "batch_ms_mean_rank0": {k: round(sum(h.timings_ms[k] for h in hits) / len(hits), 3) for k in hits[0].timings_ms},
-        "setup_seconds": {"library": round(t_lib, 2), "targets": round(t_tgt, 2)},
+        "setup_seconds": {"library": round(lib["seconds"], 2), "targets": round(t_tgt, 2)},
     }
+    del db
+    if world == 1 and not args.no_cpu_baseline:
+        step = max(1, len(hmms) // max(1, args.pfam_cpu_profiles))
+        out["cpu_baseline"] = cpu_baseline_many(hmms, bg, flat, offsets, lengths, list(range(0, len(hmms), step))[:args.pfam_cpu_profiles],
+                                                min(args.pfam_cpu_targets, len(lengths)))
+    return out
+
+
+def run_scan(args, rank, world, local_rank, dist, red_dev, torch, host_threads, lib):
+    """BASELINE configs[2], the hmmscan orientation: the same profile library (device images resident, like a pressed
+    database loaded into an OptimizedProfileBlock) against the 2,100-protein fixture proteome through hmmer.hmmscan
+    (one hit list per query SEQUENCE, Z = number of profiles).  N > 1: the profiles are dealt over the ranks
+    (shard the profiles when the targets are few), every rank scans the whole proteome with its share."""
+    from pyhmmer_amd import easel, hmmer, plan7
+    hmms, bg, oms = lib["hmms"], lib["bg"], lib["oms"]
+    with easel.SequenceFile(ROOT / "tests" / "golden" / "seqs" / "938293.PRJEB85.HG003687.faa", digital=True, alphabet=hmms[0].alphabet) as sf:
+        proteome = sf.read_block()
+    mine = oms[rank::world]
+    block = plan7.OptimizedProfileBlock(hmms[0].alphabet, mine)
+
+    def scan():
+        return list(hmmer.hmmscan(proteome, block, cpus=host_threads, devices=[local_rank]))
+
+    scan()                                  # images of this rank's profiles resident on this device, pools warm
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    res = scan()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    t_max = dt
+    if dist is not None:
+        b = torch.tensor([dt], dtype=torch.float64, device=red_dev)
+        dist.all_reduce(b, op=dist.ReduceOp.MAX)
+        t_max = float(b.item())
+    if rank != 0:
+        return None
+    nodes = float(sum(h.M for h in hmms))
+    residues = float(proteome.total_length())
+    out = {
+        "workload": f"configs[2]: hmmscan orientation, {len(hmms)} library profiles (device images resident) x the {len(proteome)}-protein "
+                    f"fixture proteome ({int(residues)} residues), hmmer.hmmscan defaults, profiles dealt over {world} GPU(s)",
+        "value": round(nodes * residues / t_max / 1e9, 2), "unit": "GCUPS", "scaling": "strong",
+        "profiles": len(hmms), "query_sequences": len(proteome), "seconds": round(t_max, 4),
+        "ms_per_profile": round(1e3 * t_max / len(hmms), 5), "query_sequences_per_s": round(len(proteome) / t_max, 1),
+        "hits_rank0": sum(len(r) for r in res),
+    }
+    if world == 1 and not args.no_cpu_baseline:
+        pk = proteome.packed()
+        step = max(1, len(hmms) // max(1, args.pfam_cpu_profiles))
+        out["cpu_baseline"] = cpu_baseline_many(hmms, bg, pk.dsq, pk.offsets, pk.lengths, list(range(0, len(hmms), step))[:args.pfam_cpu_profiles], pk.n)
+    return out
 
 
 def run_nhmmer(args, rank, world, local_rank, dist, red_dev, torch):
@@ -345,12 +428,14 @@ def main():
     ap.add_argument("--batch", type=int, default=0, help="headline workload: queries per device batch (0: the library's own choice)")
     ap.add_argument("--oa-guard", type=float, default=None, help="A/B: the optimal-accuracy near-tie guard (default: the library's; 0 switches it off)")
     ap.add_argument("--spinup-max", type=int, default=15, help="at most this many untimed 20-query windows before the warm-up")
-    ap.add_argument("--workload", choices=("both", "config1", "pfam", "nhmmer"), default="both",
+    ap.add_argument("--workload", choices=("both", "config1", "pfam", "scan", "nhmmer"), default="both",
                     help="config1: the headline (one profile x 1M targets per GPU); pfam / nhmmer: (a token headline and) that "
                          "workload's field; both: headline + the `pfam` and `nhmmer` fields")
     ap.add_argument("--nhmmer-mbp", type=float, default=250.0, help="chromosome length per GPU")
     ap.add_argument("--nhmmer-searches", type=int, default=3)
-    ap.add_argument("--pfam-profiles", type=int, default=2048, help="library entries searched (the first ones of the 20k-entry library)")
+    ap.add_argument("--pfam-profiles", type=int, default=20000, help="library entries searched (the first ones of the 20k-entry library; default: all)")
+    ap.add_argument("--pfam-cpu-profiles", type=int, default=40, help="cpu_baseline of the many-profile workloads: this many profiles, evenly spaced")
+    ap.add_argument("--pfam-cpu-targets", type=int, default=25_000, help="... against the first this many targets")
     ap.add_argument("--pfam-library", type=int, default=20000)
     ap.add_argument("--pfam-targets", type=int, default=500_000, help="targets in total (sharded over the GPUs)")
     ap.add_argument("--pfam-batch", type=int, default=0, help="queries per device batch (0: the library's choice)")
@@ -481,10 +566,15 @@ def main():
     if dist is None:
         hits_total, reported_total = len(hits), len(hits.reported)
 
-    pfam = None
-    if args.workload in ("both", "pfam"):
+    pfam = scan = None
+    if args.workload in ("both", "pfam", "scan"):
         del db                       # the headline's target block leaves HBM first
-        pfam = run_pfam(args, rank, world, local_rank, dist, red_dev, torch, host_threads)
+        lib = build_library(args, local_rank)
+        if args.workload in ("both", "pfam"):
+            pfam = run_pfam(args, rank, world, local_rank, dist, red_dev, torch, host_threads, lib)
+        if args.workload in ("both", "scan"):
+            scan = run_scan(args, rank, world, local_rank, dist, red_dev, torch, host_threads, lib)
+        del lib
     nh = None
     if args.workload in ("both", "nhmmer"):
         if args.workload == "nhmmer":
@@ -566,6 +656,8 @@ def main():
         }
         if pfam is not None:
             out["pfam"] = pfam
+        if scan is not None:
+            out["scan"] = scan
         if nh is not None:
             out["nhmmer"] = nh
         if world == 1 and not args.no_cpu_baseline:

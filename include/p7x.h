@@ -178,6 +178,10 @@ typedef struct p7x_pipeline_cfg {
   int32_t evalue_window_length; /* > 0: the window length p7_tophits_ComputeNhmmerEvalues is given when it differs from the scan's
                               * (an HMM query without window_length: p7_Builder_MaxLength(hmm, window_beta), plan7.pyx:7346-7354,
                               * while the scan keeps the max_length the optimized profile was built with); <= 0: the scan's */
+  int32_t lt_part, lt_nparts; /* nhmmer over several devices: this call takes part lt_part of lt_nparts of the (target, block, strand)
+                              * units of the search -- consecutive units, units counted in the order of the reference's loop
+                              * (plan7.pyx:7582-7655) -- and returns an unfinished hit list; p7x_tophits_merge_longtargets finishes the
+                              * parts together (E-values for all residues searched, duplicates, thresholds).  Default 0 of 1 */
   float   oa_guard;          /* near-tie guard of the device's optimal-accuracy traceback: a choice on the trace between candidates
                               * within |v| * g + g of each other (or a posterior that close to the next printed digit) sends the
                               * envelope to the host twin, which repeats it in the reference's order of operations.  Default 4e-6
@@ -328,6 +332,10 @@ int      p7x_tophits_get_hit(const p7x_tophits *th, int64_t i, p7x_hit *hit);
 int      p7x_tophits_get_domain(const p7x_tophits *th, int64_t i, int32_t d, p7x_domain *dom);
 /* p7_tophits_Merge + p7_pipeline_Merge + re-threshold (plan7.pyx:9172-9276): merges src into dst. */
 int      p7x_tophits_merge(p7x_tophits *dst, const p7x_tophits *src);
+/* The parts of one long-target search (cfg.lt_nparts > 1, one p7x_search_longtargets call per part, typically one per
+ * device) -> the hit list of the whole search: p7_tophits_ComputeNhmmerEvalues with the residues of all parts,
+ * p7_tophits_RemoveDuplicates across them, sort, threshold (plan7.pyx:7390-7412).  The parts are consumed. */
+int      p7x_tophits_merge_longtargets(p7x_tophits **parts, size_t nparts, p7x_tophits **out);
 /* Many queries x many shards in one call, threaded over the queries: blobs[q * nparts + r] / sizes[...] = the
  * p7x_tophits_serialize image of query q on shard r (NULL / 0: that shard had nothing to say, e.g. an empty shard that
  * was never searched).  outs[q] = what TopHits.merge gives for the same lists in shard order.  threads <= 0: every usable CPU. */

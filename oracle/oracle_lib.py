@@ -6,8 +6,8 @@ from pathlib import Path
 
 import numpy as np
 
-ROOT = Path(__file__).resolve().parent.parent
-ORACLE_DIR = ROOT / "oracle"
+ORACLE_DIR = Path(__file__).resolve().parent
+ROOT = ORACLE_DIR.parent
 LIB = ORACLE_DIR / "_build" / "libp7oracle.so"
 
 

@@ -105,7 +105,7 @@ class PipelineCfg(C.Structure):
         ("do_max", C.c_int32), ("do_biasfilter", C.c_int32), ("do_null2", C.c_int32),
         ("seed", C.c_uint32), ("mode", C.c_int32), ("host_threads", C.c_int32), ("host_envelopes", C.c_int32), ("host_regions", C.c_int32),
         ("long_targets", C.c_int32), ("strands", C.c_int32), ("B1", C.c_int32), ("B2", C.c_int32), ("B3", C.c_int32),
-        ("block_length", C.c_int32), ("window_length", C.c_int32), ("evalue_window_length", C.c_int32), ("oa_guard", C.c_float),
+        ("block_length", C.c_int32), ("window_length", C.c_int32), ("evalue_window_length", C.c_int32), ("lt_part", C.c_int32), ("lt_nparts", C.c_int32), ("oa_guard", C.c_float),
         ("f3_guard", C.c_float),
     ]
 
@@ -149,6 +149,7 @@ class HitRec(C.Structure):
 _VP = C.c_void_p
 _SIGNATURES = {
     "p7x_abi_version": (C.c_int, []),
+    "p7x_tophits_merge_longtargets": (C.c_int, [C.POINTER(_VP), C.c_size_t, C.POINTER(_VP)]),
     "p7x_tophits_merge_many": (C.c_int, [C.POINTER(C.c_char_p), C.POINTER(C.c_size_t), C.c_size_t, C.c_size_t, C.c_int, C.POINTER(_VP)]),
     "p7x_tophits_get_guard_counts": (C.c_int, [_VP, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
     "p7x_hmm_max_length": (C.c_int, [C.POINTER(HmmView), C.c_double, C.POINTER(C.c_int32)]),

@@ -138,6 +138,14 @@ float kahan_fsum(const float *v, int n);
 // ---- long targets (p7x_longtarget.inc.hpp <-> p7x_longtarget.hip)
 struct LongTargetRow { int64_t pos; int k, sc; };            // a row of a strand block that reached the SSV threshold, and the cell upstream picks
 struct LongTargetSeed { int64_t target, block_start; int strand; int64_t n; int k; int64_t length; };   // an SSV window seed of one block
+// (target, block, strand) units of a long-target search in the order of the reference's loop, and the part that owns one
+struct LongTargetUnits {
+  int64_t W = 0, C = 0; int strands = 0; uint64_t total = 0; int part = 0, nparts = 1;
+  void count(const p7x_pipeline_cfg &cfg, int max_length, const int64_t *lengths, size_t n);
+  bool mine(uint64_t u) const { return nparts <= 1 || (int) ((u * (uint64_t) nparts) / (total ? total : 1)) == part; }
+};
+void longtarget_finalize(p7x_tophits *th, int evalue_window, double res_count);
+double longtarget_res_count(const p7x_pipeline_cfg &cfg, uint64_t nres);
 int longtarget_setup(const p7x_pipeline_cfg &cfg, const Profile &p, int *max_length, int *sc_thresh, int *xB);
 const uint8_t *longtarget_complement(int abc_type);
 void longtarget_seeds_from_rows(const Profile &p, const uint8_t *block_dsq, int64_t L, const LongTargetRow *rows, size_t nrows,
@@ -180,6 +188,8 @@ struct p7x_tophits {
   bool scan_collected = false;        // built by p7x_scan_collect(): one query sequence, hits are models
   std::vector<uint8_t> stage;         // scan mode, per-model result: last filter passed by each target (not serialised)
   std::vector<int32_t> guard_dropped; // targets the F3 guard took out of the device's survivor list (not serialised)
+  bool lt_unfinished = false;         // one part of a long-target search (cfg.lt_nparts > 1): E-values, duplicates, thresholds still to do
+  int lt_evalue_window = 0;           // ... and the window length its E-values refer to
   int64_t oa_redone = 0;              // device envelopes the near-tie guard sent to the host twin (not serialised)
   int64_t oa_why[8]{};                // ... by kind of choice: M, I, D cell, C<-E, J<-E, end cell, B<-N/J, posterior digit
   int64_t nreported = 0, nincluded = 0;

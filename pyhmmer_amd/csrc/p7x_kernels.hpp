@@ -164,6 +164,7 @@ struct SsvLongArgs {
   const uint32_t *tab_full;   // [2][Kp][R][64] the same for every residue code (degenerate residues, read from global memory)
   const uint8_t *dsq;         // the target, 1-based (dsq[0] is a sentinel)
   const uint8_t *comp;        // [Kp] complement of every residue code
+  const long long *chunk_list;  // NULL: every chunk; else the nchunks chunk numbers to scan (a part of a search dealt over devices)
   long long L;                // target length
   int M, Kp;
   int chunk_len;              // rows per chunk

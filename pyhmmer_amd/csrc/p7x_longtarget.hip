@@ -26,8 +26,11 @@ struct ScanRow { int64_t pos; int strand, k, sc; };
 
 // The reset-free SSV scan of one target (both strands, or one): every row whose best diagonal reaches the threshold.
 // <ms>: kernel time by HIP events.
+// <ranges>, when given: only the chunks that touch one of these (strand, first, last) position ranges are scanned
+// (a search dealt over several devices: every device scans the blocks of its own units).
+struct ScanRange { int strand; int64_t first, last; };
 static int scan_target(const p7x_pipeline_cfg &cfg, const Profile &p, DeviceCtx *ctx, const uint8_t *seq1 /* 1-based */, int64_t L,
-                       int sc_thresh, int xB, int strands_mask, std::vector<ScanRow> &rows, double *ms)
+                       int sc_thresh, int xB, int strands_mask, std::vector<ScanRow> &rows, double *ms, const std::vector<ScanRange> *ranges = nullptr)
 {
   const int R = ssvlong_pick_R(p.M);
   if (R < 0) { set_error("model too long for the long-target SSV kernel (M > 6141)"); return P7X_EINVAL; }
@@ -55,6 +58,22 @@ static int scan_target(const p7x_pipeline_cfg &cfg, const Profile &p, DeviceCtx 
   a.thresh_s = sc_thresh - xB - 32768; a.xB = xB; a.Q16 = p.Q16();
   a.nrec = static_cast<int *>(d_nrec.p);
   a.strand0 = strands_mask == 2 ? 1 : 0;
+  DevBuf d_chunks;
+  if (ranges) {
+    std::vector<long long> list;
+    for (const ScanRange &r : *ranges) {
+      const long long s_off = (long long) (r.strand - a.strand0) * a.chunks_per_strand;
+      for (long long c = (r.first - 1) / chunk_len; c <= (r.last - 1) / chunk_len && c < a.chunks_per_strand; ++c) list.push_back(s_off + c);
+    }
+    std::sort(list.begin(), list.end());
+    list.erase(std::unique(list.begin(), list.end()), list.end());
+    rows.clear();
+    if (list.empty()) { if (ms) *ms = 0.0; return P7X_OK; }
+    if ((st = d_chunks.alloc(list.size() * 8)) != P7X_OK) return st;
+    P7X_HIP(hipMemcpyAsync(d_chunks.p, list.data(), list.size() * 8, hipMemcpyHostToDevice, s));
+    P7X_HIP(hipStreamSynchronize(s));                       // <list> leaves scope
+    a.chunk_list = static_cast<const long long *>(d_chunks.p); a.nchunks = (long long) list.size();
+  }
   hipEvent_t e0, e1;
   P7X_HIP(hipEventCreate(&e0)); P7X_HIP(hipEventCreate(&e1));
   int cap = (int) std::min<int64_t>(std::max<int64_t>(1 << 16, L / 64), 1 << 28);
@@ -274,26 +293,36 @@ int p7x_search_longtargets(const p7x_pipeline_cfg *cfg, const p7x_oprofile *om, 
   const auto t_begin = std::chrono::steady_clock::now();
   std::vector<LongTargetSeed> seeds;
   double scan_ms = 0.0;
+  LongTargetUnits all_units; all_units.count(*cfg, max_length, lengths, n);
+  uint64_t unit = 0;
   for (size_t t = 0; t < n; ++t) {
     const int64_t Lt = lengths[t];
     if (Lt <= 0) continue;
     const uint8_t *seq1 = dsq + offsets[t] - 1;
-    std::vector<ScanRow> rows;
-    double ms = 0.0;
-    const auto ts0 = std::chrono::steady_clock::now();
-    if ((st = scan_target(*cfg, p, ctx, seq1, Lt, sc_thresh, xB, mask, rows, &ms)) != P7X_OK) return st;
-    scan_ms += ms;
-    const auto ts1 = std::chrono::steady_clock::now();
-    // upstream's bookkeeping per (block, strand): the units are independent, the host workers take them side by side
+    // upstream's bookkeeping per (block, strand): the units are independent, the host workers take them side by side;
+    // with the search dealt over several devices (cfg.lt_nparts) this call only has the units of its part
     struct Unit { int64_t i, bn; int strand; std::vector<int64_t> s3; };
     std::vector<Unit> units;
+    std::vector<ScanRange> ranges;
     for (int64_t i = 0; i < Lt; i += W - C) {
       const int64_t bc = i == 0 ? 0 : std::min<int64_t>(C, Lt - i);
       const int64_t bw = std::min<int64_t>(W, Lt - i - bc);
       const int64_t bn = bc + bw;
       if (bn <= 0) break;
-      for (int strand = 0; strand < 2; ++strand) if (mask & (1 << strand)) units.push_back(Unit{ i, bn, strand, {} });
+      for (int strand = 0; strand < 2; ++strand) if (mask & (1 << strand)) {
+        if (!all_units.mine(unit++)) continue;
+        units.push_back(Unit{ i, bn, strand, {} });
+        const int64_t base = strand == 0 ? i : Lt - i - bn;          // the block's rows in strand coordinates: base + 1 .. base + bn
+        ranges.push_back(ScanRange{ strand, base + 1, base + bn });
+      }
     }
+    if (units.empty()) continue;
+    std::vector<ScanRow> rows;
+    double ms = 0.0;
+    const auto ts0 = std::chrono::steady_clock::now();
+    if ((st = scan_target(*cfg, p, ctx, seq1, Lt, sc_thresh, xB, mask, rows, &ms, all_units.nparts > 1 ? &ranges : nullptr)) != P7X_OK) return st;
+    scan_ms += ms;
+    const auto ts1 = std::chrono::steady_clock::now();
     host_parallel_for((int) units.size(), cfg->host_threads, [&](int u) {
       Unit &un = units[(size_t) u];
       block_seeds(p, seq1, Lt, un.i, un.bn, un.strand, rows, sc_thresh, xB, un.s3);

@@ -674,19 +674,11 @@ static void lt_block_windows(const LtScoreData &sd, int max_length, int64_t bloc
 }
 
 // ---------------------------------------------------------------- hit list: E-values, duplicates
-static void lt_finish_tophits(const p7x_pipeline_cfg &cfg_in, const Profile &p, int max_length, uint64_t nres, uint64_t nseqs,
-                              const LtCounters &ctr, std::vector<Hit> &hits, p7x_tophits **out)
+// E-values, duplicates, order and thresholds of a long-target hit list whose hits still carry per-window P-values
+static void lt_finalize(p7x_tophits *th, int max_length, double res_count)
 {
-  auto th = std::make_unique<p7x_tophits>();
-  th->cfg = cfg_in;
-  th->qname = p.name; th->qacc = p.acc; th->qdesc = p.desc; th->q_has_acc = p.has_acc; th->q_has_desc = p.has_desc;
-  th->M = p.M;
-  th->ctr.nmodels = 1; th->ctr.nnodes = (uint64_t) p.M; th->ctr.nseqs = nseqs; th->ctr.nres = nres;
-  th->ctr.n_past_msv = ctr.n_past_msv; th->ctr.n_past_bias = ctr.n_past_bias; th->ctr.n_past_vit = ctr.n_past_vit; th->ctr.n_past_fwd = ctr.n_past_fwd;
-  th->ctr.pos_past_msv = ctr.pos_past_msv; th->ctr.pos_past_bias = ctr.pos_past_bias; th->ctr.pos_past_vit = ctr.pos_past_vit; th->ctr.pos_past_fwd = ctr.pos_past_fwd;
+  std::vector<Hit> &hits = th->hits;
   // p7_tophits_ComputeNhmmerEvalues: the P-value of a hit refers to one window of max_length; scale by the windows searched
-  double res_count = (double) nres;
-  if (cfg_in.Z_setby != P7X_ZSETBY_NTARGETS) { res_count = 1000000.0 * cfg_in.Z; if (cfg_in.strands == P7X_STRAND_BOTH) res_count *= 2; }
   for (Hit &h : hits) {
     h.lnP += std::log((float) res_count / (float) max_length);
     h.dcl[0].lnP = h.lnP;
@@ -725,12 +717,37 @@ static void lt_finish_tophits(const p7x_pipeline_cfg &cfg_in, const Profile &p, 
       if (remove == j) j = q;
     } else j = q;
   }
-  th->hits = std::move(hits);
+  th->order.clear(); th->sorted_by_key = false;
   tophits_sort_by_key(*th);
   tophits_threshold(*th);
   th->ctr.n_output = th->ctr.pos_output = 0;
   for (const Hit &h : th->hits)
     if (h.flags & (P7X_IS_REPORTED | P7X_IS_INCLUDED)) { th->ctr.n_output++; th->ctr.pos_output += 1 + (uint64_t) std::llabs(h.dcl[0].jali - h.dcl[0].iali); }
+  th->lt_unfinished = false;
+}
+
+static double lt_res_count(const p7x_pipeline_cfg &cfg, uint64_t nres)
+{
+  double res_count = (double) nres;
+  if (cfg.Z_setby != P7X_ZSETBY_NTARGETS) { res_count = 1000000.0 * cfg.Z; if (cfg.strands == P7X_STRAND_BOTH) res_count *= 2; }
+  return res_count;
+}
+
+static void lt_finish_tophits(const p7x_pipeline_cfg &cfg_in, const Profile &p, int max_length, uint64_t nres, uint64_t nseqs,
+                              const LtCounters &ctr, std::vector<Hit> &hits, p7x_tophits **out)
+{
+  auto th = std::make_unique<p7x_tophits>();
+  th->cfg = cfg_in;
+  th->qname = p.name; th->qacc = p.acc; th->qdesc = p.desc; th->q_has_acc = p.has_acc; th->q_has_desc = p.has_desc;
+  th->M = p.M;
+  th->ctr.nmodels = 1; th->ctr.nnodes = (uint64_t) p.M; th->ctr.nseqs = nseqs; th->ctr.nres = nres;
+  th->ctr.n_past_msv = ctr.n_past_msv; th->ctr.n_past_bias = ctr.n_past_bias; th->ctr.n_past_vit = ctr.n_past_vit; th->ctr.n_past_fwd = ctr.n_past_fwd;
+  th->ctr.pos_past_msv = ctr.pos_past_msv; th->ctr.pos_past_bias = ctr.pos_past_bias; th->ctr.pos_past_vit = ctr.pos_past_vit; th->ctr.pos_past_fwd = ctr.pos_past_fwd;
+  th->hits = std::move(hits);
+  th->lt_evalue_window = max_length;
+  th->lt_unfinished = true;
+  // one part of several: the parts are finished together (p7x_tophits_merge_longtargets)
+  if (cfg_in.lt_nparts <= 1) lt_finalize(th.get(), max_length, lt_res_count(cfg_in, nres));
   *out = th.release();
 }
 
@@ -771,6 +788,8 @@ static int lt_run_host(const p7x_pipeline_cfg &cfg, const p7x_oprofile *om, cons
   LtCounters ctr;
   uint64_t nres = 0;
   size_t sidx = 0;
+  LongTargetUnits units; units.count(cfg, max_length, lengths, n);
+  uint64_t unit = 0;
   struct BlockJob { int64_t i, bn, bc, bw; int strand; uint64_t nres_at; std::vector<LtWindow> windows; size_t first_window; };
   // P7X_LT_DEBUG: wall time of the phases of this function
   const bool dbg = std::getenv("P7X_LT_DEBUG") != nullptr;
@@ -798,11 +817,12 @@ static int lt_run_host(const p7x_pipeline_cfg &cfg, const p7x_oprofile *om, cons
         if (strand == 0 && cfg.strands == P7X_STRAND_BOTTOMONLY) { nres -= (uint64_t) bn; continue; }
         if (strand == 0) nres -= (uint64_t) bc;              // the overlap with the previous block was counted there
         if (strand == 1 && cfg.strands == P7X_STRAND_TOPONLY) continue;
+        const bool mine = units.mine(unit++);                // another part's unit: only its residues are counted here
         std::vector<LtWindow> seeds;
         while (sidx < seeds_in.size() && seeds_in[sidx].target == (int64_t) t && seeds_in[sidx].block_start == i && seeds_in[sidx].strand == strand)
           seeds.push_back(seeds_in[sidx++].w);
         BlockJob job{ i, bn, bc, bw, strand, nres, {}, nwin };
-        lt_block_windows(sd, max_length, bn, std::move(seeds), job.windows);
+        if (mine) lt_block_windows(sd, max_length, bn, std::move(seeds), job.windows);
         nwin += job.windows.size();
         if (!job.windows.empty()) jobs.push_back(std::move(job));
         if (strand == 1) nres += (uint64_t) bw;
@@ -953,6 +973,17 @@ int longtarget_setup(const p7x_pipeline_cfg &cfg, const Profile &p, int *max_len
 }
 
 const uint8_t *longtarget_complement(int abc_type) { return lt_complement_table(abc_type); }
+
+void LongTargetUnits::count(const p7x_pipeline_cfg &cfg, int max_length, const int64_t *lengths, size_t n)
+{
+  W = cfg.block_length; C = max_length; strands = cfg.strands == P7X_STRAND_BOTH ? 2 : 1;
+  part = cfg.lt_part; nparts = std::max(1, cfg.lt_nparts);
+  total = 0;
+  for (size_t t = 0; t < n; ++t) for (int64_t i = 0; i < lengths[t]; i += W - C) total += (uint64_t) strands;
+}
+
+void longtarget_finalize(p7x_tophits *th, int evalue_window, double res_count) { lt_finalize(th, evalue_window, res_count); }
+double longtarget_res_count(const p7x_pipeline_cfg &cfg, uint64_t nres) { return lt_res_count(cfg, nres); }
 
 void longtarget_seeds_from_rows(const Profile &p, const uint8_t *block_dsq, int64_t L, const LongTargetRow *rows, size_t nrows,
                                 int sc_thresh, int xB, std::vector<int64_t> &seeds3)

@@ -46,7 +46,8 @@ __global__ void __launch_bounds__(256) ssvlong_kernel(const SsvLongArgs a)
   const int wave = rfl((int) (blockIdx.x * 4 + (threadIdx.x >> 6)));
   const int nwaves = (int) gridDim.x * 4;
 
-  for (long long ch = wave; ch < a.nchunks; ch += nwaves) {
+  for (long long chi = wave; chi < a.nchunks; chi += nwaves) {
+    const long long ch = a.chunk_list ? a.chunk_list[chi] : chi;
     // chunk ch of strand s: rows first .. last (1-based positions on that strand), preceded by up to M warm-up rows
     const int strand = a.strand0 + (int) (ch / a.chunks_per_strand);  // 0: as given, 1: reverse complement
     const long long c0 = (ch % a.chunks_per_strand) * (long long) a.chunk_len;

@@ -775,6 +775,39 @@ int p7x_tophits_merge(p7x_tophits *dst, const p7x_tophits *src)
   return P7X_OK;
 }
 
+int p7x_tophits_merge_longtargets(p7x_tophits **parts, size_t nparts, p7x_tophits **out)
+{
+  if (!parts || !out || nparts == 0) { set_error("p7x_tophits_merge_longtargets: bad arguments"); return P7X_EINVAL; }
+  *out = nullptr;
+  std::vector<std::unique_ptr<p7x_tophits>> own;
+  for (size_t r = 0; r < nparts; ++r) { own.emplace_back(parts[r]); parts[r] = nullptr; }      // consumed, also on failure
+  for (size_t r = 0; r < nparts; ++r) {
+    if (!own[r] || !own[r]->lt_unfinished || !own[r]->cfg.long_targets) { set_error("p7x_tophits_merge_longtargets: not an unfinished part of a long-target search"); return P7X_EINVAL; }
+    if (own[r]->qname != own[0]->qname || own[r]->cfg.lt_nparts != (int) nparts || own[r]->ctr.nres != own[0]->ctr.nres ||
+        own[r]->lt_evalue_window != own[0]->lt_evalue_window) { set_error("p7x_tophits_merge_longtargets: the parts belong to different searches"); return P7X_EINVAL; }
+  }
+  std::vector<size_t> by_part(nparts);
+  for (size_t r = 0; r < nparts; ++r) by_part[r] = r;
+  std::sort(by_part.begin(), by_part.end(), [&](size_t a, size_t b) { return own[a]->cfg.lt_part < own[b]->cfg.lt_part; });
+  for (size_t r = 0; r < nparts; ++r) if (own[by_part[r]]->cfg.lt_part != (int) r) { set_error("p7x_tophits_merge_longtargets: a part is missing or given twice"); return P7X_EINVAL; }
+  std::unique_ptr<p7x_tophits> dst = std::move(own[by_part[0]]);
+  for (size_t r = 1; r < nparts; ++r) {
+    p7x_tophits *src = own[by_part[r]].get();
+    // every part kept the residue accounting of the WHOLE search (the reference's pli.nres, which the reportability test
+    // of a window reads as it goes), so nres / nseqs are not added; the window counters are per part
+    for (Hit &h : src->hits) dst->hits.push_back(std::move(h));
+    dst->ctr.n_past_msv += src->ctr.n_past_msv; dst->ctr.n_past_bias += src->ctr.n_past_bias;
+    dst->ctr.n_past_vit += src->ctr.n_past_vit; dst->ctr.n_past_fwd += src->ctr.n_past_fwd;
+    dst->ctr.pos_past_msv += src->ctr.pos_past_msv; dst->ctr.pos_past_bias += src->ctr.pos_past_bias;
+    dst->ctr.pos_past_vit += src->ctr.pos_past_vit; dst->ctr.pos_past_fwd += src->ctr.pos_past_fwd;
+    for (int i = 0; i < 12; ++i) dst->ms[i] = std::max(dst->ms[i], src->ms[i]);      // the parts ran side by side
+  }
+  dst->cfg.lt_part = 0; dst->cfg.lt_nparts = 1;
+  longtarget_finalize(dst.get(), dst->lt_evalue_window, longtarget_res_count(dst->cfg, dst->ctr.nres));
+  *out = dst.release();
+  return P7X_OK;
+}
+
 // The merging side of a sharded many-query search (rank 0 of `bench.py --gpus N`, the reference's
 // _ReverseSEARCHDispatcher collecting its chunks, _hmmsearch.py:259-263): blobs[q * nparts + r] is the serialised hit
 // list of query q on shard r.  Per query: deserialise, concatenate in shard order, ONE sort and ONE threshold (the result

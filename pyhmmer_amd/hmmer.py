@@ -620,6 +620,8 @@ def nhmmer(queries, sequences, *, cpus: int = 0, callback: Optional[Callable] = 
     if _lib.lib().p7x_device_count() < 1:
         from .errors import DeviceUnavailable
         raise DeviceUnavailable("nhmmer: no HIP device is usable and there is no CPU fallback")
+    if devices is not None and len(devices) == 0:
+        raise ValueError("devices must name at least one device")
     pipeline = LongTargetsPipeline(sequences.alphabet, device=(devices[0] if devices else 0), host_threads=cpus, **options)
     total = None
     try:
@@ -629,7 +631,7 @@ def nhmmer(queries, sequences, *, cpus: int = 0, callback: Optional[Callable] = 
     for q in queries:
         if not isinstance(q, (HMM, Profile, OptimizedProfile)):
             raise TypeError(f"Unsupported query type for `nhmmer`: {type(q).__name__} (build an HMM from it first)")
-        hits = pipeline.search_hmm(q, sequences)
+        hits = pipeline.search_hmm(q, sequences, devices=devices)      # the units of one search dealt over the devices
         if callback is not None:
             callback(q, total)
         yield hits

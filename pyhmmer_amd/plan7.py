@@ -11,7 +11,7 @@ import ctypes as C
 import math
 import os
 import sys
-from typing import Iterable, Iterator, List, Optional, Union
+from typing import Iterable, Iterator, List, Optional, Sequence, Union
 
 import numpy as np
 
@@ -1603,8 +1603,13 @@ class LongTargetsPipeline(Pipeline):
         descs = (C.c_char_p * max(n, 1))(*[(s.description or "").encode() for s in sequences])
         return dsq, offsets, lengths, names, accs, descs
 
-    def search_hmm(self, query, sequences) -> "TopHits":
-        """``nhmmer`` with ``query`` against the long targets of ``sequences`` (reference ``plan7.pyx:7272-7418``)."""
+    def search_hmm(self, query, sequences, devices: Optional[Sequence[int]] = None) -> "TopHits":
+        """``nhmmer`` with ``query`` against the long targets of ``sequences`` (reference ``plan7.pyx:7272-7418``).
+
+        ``devices``: deal the (target, block, strand) units of the search -- the iterations of the reference's loop
+        (``plan7.pyx:7582-7655``), which are independent of one another -- over these devices, consecutive units per
+        device, one host thread each; the parts are finished together (E-values for all residues searched, duplicate
+        removal across block boundaries, thresholds), so the result is the one-device result."""
         if isinstance(sequences, SequenceFile):
             if sequences.name is None:
                 raise ValueError("can only use a `SequenceFile` backed by a file for reading targets")
@@ -1632,11 +1637,39 @@ class LongTargetsPipeline(Pipeline):
             descs = (C.c_char_p * max(n, 1))(*[(s.description or "").encode() for s in sequences])
         else:
             dsq, offsets, lengths, names, accs, descs = self._pack(sequences)
-        out = C.c_void_p()
-        st = _lib.lib().p7x_search_longtargets(C.byref(cfg), om._handle, self.device, dsq.ctypes.data, offsets.ctypes.data,
-                                               lengths.ctypes.data, len(sequences), names, accs, descs, C.byref(out))
-        if st != 0:
-            raise status_to_exception(st, "p7x_search_longtargets", _lib.last_error())
+
+        def part(device: int, k: int, nparts: int) -> C.c_void_p:
+            c = _lib.PipelineCfg.from_buffer_copy(cfg)
+            c.lt_part, c.lt_nparts = k, nparts
+            out = C.c_void_p()
+            st = _lib.lib().p7x_search_longtargets(C.byref(c), om._handle, device, dsq.ctypes.data, offsets.ctypes.data,
+                                                   lengths.ctypes.data, len(sequences), names, accs, descs, C.byref(out))
+            if st != 0:
+                raise status_to_exception(st, "p7x_search_longtargets", _lib.last_error())
+            return out
+
+        devices = list(devices) if devices else [self.device]
+        if len(devices) == 1:
+            out = part(devices[0], 0, 1)
+        else:
+            from concurrent.futures import ThreadPoolExecutor
+            with ThreadPoolExecutor(max_workers=len(devices)) as ex:
+                futs = [ex.submit(part, d, k, len(devices)) for k, d in enumerate(devices)]
+                handles, err = [], None
+                for f in futs:
+                    try:
+                        handles.append(f.result())
+                    except BaseException as e:          # noqa: BLE001 - the other parts are still released below
+                        err = err or e
+            if err is not None:
+                for h in handles:
+                    _lib.lib().p7x_tophits_destroy(h)
+                raise err
+            arr = (C.c_void_p * len(handles))(*[h.value for h in handles])
+            out = C.c_void_p()
+            st = _lib.lib().p7x_tophits_merge_longtargets(arr, len(handles), C.byref(out))      # consumes the parts
+            if st != 0:
+                raise status_to_exception(st, "p7x_tophits_merge_longtargets", _lib.last_error())
         hits = TopHits(query, out)
         hits._om = om
         return hits

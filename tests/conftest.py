@@ -7,6 +7,7 @@ import pytest
 ROOT = Path(__file__).resolve().parent.parent
 sys.path.insert(0, str(ROOT))
 sys.path.insert(0, str(ROOT / "tests"))
+sys.path.insert(0, str(ROOT / "oracle"))          # oracle_lib: the checker's ctypes binding lives with the checker
 GOLDEN = ROOT / "tests" / "golden"
 
 

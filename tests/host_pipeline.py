@@ -69,17 +69,18 @@ def blocks_of(L, W, Cov):
     return out
 
 
-def host_nhmmer(oracle, hmm, sequences, pipeline=None):
+def host_nhmmer(oracle, hmm, sequences, pipeline=None, nparts=1):
     """CPU harness of the long-target path: the oracle's sequential SSV scan seeds the windows of every (target, block,
-    strand); the product's host tail (p7x_longtarget_from_seeds) does the rest."""
+    strand); the product's host tail (p7x_longtarget_from_seeds) does the rest.  nparts > 1: the units are dealt over
+    that many parts as a multi-device search deals them (cfg.lt_part / lt_nparts: consecutive units per part, each part
+    sees only the seeds of its own units) and the parts are finished together by p7x_tophits_merge_longtargets."""
     pipeline = pipeline or plan7.LongTargetsPipeline(hmm.alphabet)
     bg = pipeline.background
     op = oracle.OracleProfile(hmm, bg, 400)
     om = plan7.OptimizedProfile(hmm, bg, 400)
-    cfg = pipeline._cfg()
     max_length = pipeline.window_length or hmm.max_length
     dsq, offsets, lengths, names, accs, descs = plan7.LongTargetsPipeline._pack(sequences)
-    st_t, st_b, st_s, seeds = [], [], [], []
+    units = []                                    # (target, block start, strand, seeds) in the order of the reference's loop
     for t, s in enumerate(sequences):
         seq = np.asarray(s.sequence, dtype=np.uint8)
         for (i, n) in blocks_of(len(seq), pipeline.block_length, max_length):
@@ -87,18 +88,36 @@ def host_nhmmer(oracle, hmm, sequences, pipeline=None):
                 if (strand == 0 and pipeline.strand == "crick") or (strand == 1 and pipeline.strand == "watson"):
                     continue
                 blk = seq[i:i + n] if strand == 0 else DNA_COMP[seq[i:i + n][::-1]]
-                for sd in oracle.ssv_longtarget(op, blk, max_length, pipeline.F1):
-                    st_t.append(t); st_b.append(i); st_s.append(strand); seeds.append(sd)
-    ns = len(seeds)
-    a_t = np.array(st_t or [0], dtype=np.int64); a_b = np.array(st_b or [0], dtype=np.int64); a_s = np.array(st_s or [0], dtype=np.int32)
-    a_seeds = np.array(seeds if seeds else [[0, 0, 0]], dtype=np.int64).reshape(-1, 3)
-    out = C.c_void_p()
-    st = _lib.lib().p7x_longtarget_from_seeds(C.byref(cfg), om._handle, dsq.ctypes.data, offsets.ctypes.data, lengths.ctypes.data,
-                                              len(sequences), names, accs, descs, a_t.ctypes.data, a_b.ctypes.data, a_s.ctypes.data,
-                                              np.ascontiguousarray(a_seeds).ctypes.data, ns, C.byref(out))
-    if st != 0:
-        raise RuntimeError(f"p7x_longtarget_from_seeds failed: {st} {_lib.last_error()}")
+                units.append((t, i, strand, list(oracle.ssv_longtarget(op, blk, max_length, pipeline.F1))))
+    handles, nseeds = [], 0
+    for part in range(nparts):
+        cfg = pipeline._cfg()
+        cfg.lt_part, cfg.lt_nparts = part, nparts
+        st_t, st_b, st_s, seeds = [], [], [], []
+        for u, (t, i, strand, sds) in enumerate(units):
+            if nparts > 1 and (u * nparts) // len(units) != part:
+                continue
+            for sd in sds:
+                st_t.append(t); st_b.append(i); st_s.append(strand); seeds.append(sd)
+        ns = len(seeds)
+        nseeds += ns
+        a_t = np.array(st_t or [0], dtype=np.int64); a_b = np.array(st_b or [0], dtype=np.int64); a_s = np.array(st_s or [0], dtype=np.int32)
+        a_seeds = np.array(seeds if seeds else [[0, 0, 0]], dtype=np.int64).reshape(-1, 3)
+        out = C.c_void_p()
+        st = _lib.lib().p7x_longtarget_from_seeds(C.byref(cfg), om._handle, dsq.ctypes.data, offsets.ctypes.data, lengths.ctypes.data,
+                                                  len(sequences), names, accs, descs, a_t.ctypes.data, a_b.ctypes.data, a_s.ctypes.data,
+                                                  np.ascontiguousarray(a_seeds).ctypes.data, ns, C.byref(out))
+        if st != 0:
+            raise RuntimeError(f"p7x_longtarget_from_seeds failed: {st} {_lib.last_error()}")
+        handles.append(out)
+    if nparts > 1:
+        arr = (C.c_void_p * nparts)(*[h.value for h in handles])
+        out = C.c_void_p()
+        st = _lib.lib().p7x_tophits_merge_longtargets(arr, nparts, C.byref(out))
+        if st != 0:
+            raise RuntimeError(f"p7x_tophits_merge_longtargets failed: {st} {_lib.last_error()}")
     hits = plan7.TopHits(hmm, out)
     hits._keep = (om, names, accs, descs, dsq)
-    hits._nseeds = ns
+    hits._nseeds = nseeds
+    hits._nunits = len(units)
     return hits

@@ -104,3 +104,31 @@ def test_nhmmer_rf00001_known_answers():
     seqs = _read("1390.SAMEA104415756.OFHT01000024.fna", hmm.alphabet)
     hits = list(hmmer.nhmmer(hmm, seqs, window_length=3878))[0]
     assert len(hits) == 2 and float("%.2g" % hits[0].evalue) == pytest.approx(5.4e-17, rel=1e-6) and hits[1].evalue == pytest.approx(0.3, abs=0.005)
+
+
+def test_nhmmer_dealt_over_devices_equals_one_device():
+    """hmmer.nhmmer(devices=[...]): the (target, block, strand) units of one search dealt over several devices (here the
+    same device three and five times: every part scans only the chunks of its own blocks, cfg.lt_part / lt_nparts) and
+    finished together == the one-device search, on a 6 Mbp synthetic chromosome (24 blocks x 2 strands, planted hits
+    next to block boundaries) plus a short second target, and on the golden bmyD2 table."""
+    import bench_workloads as bw
+    hmm = load_hmms("bmyD")[0]
+    abc = hmm.alphabet
+    big = bw.make_chromosome(hmm, 6_000_000, planted=60, seed=11)
+    W, Cv = 0x40000, hmm.max_length
+    cons = np.argmax(hmm.match_emissions[1:], axis=1).astype(np.uint8)
+    for b in (3, 7, 11):                     # a copy of the model's first 900 nodes across the seam of blocks b-1 / b
+        at = b * (W - Cv) + Cv // 2 - 450
+        big[at:at + 900] = cons[:900]
+    small = bw.make_chromosome(hmm, 150_000, planted=3, seed=12)
+    block = easel.DigitalSequenceBlock(abc, [easel.DigitalSequence(abc, name="chrA", sequence=big),
+                                             easel.DigitalSequence(abc, name="ctgB", sequence=small)])
+    one = next(hmmer.nhmmer(hmm, block))
+    assert len(one) > 40 and any(h.duplicate for h in one)
+    for devs in ([0, 0, 0], [0] * 5):
+        many = next(hmmer.nhmmer(hmm, block, devices=devs))
+        assert _rows(many) == _rows(one), devs
+        assert [(h.evalue, h.reported, h.included, h.duplicate) for h in many] == [(h.evalue, h.reported, h.included, h.duplicate) for h in one]
+        assert many.stage_counts == one.stage_counts and many.searched_residues == one.searched_residues
+    seqs = _read("1390.SAMEA104415756.OFHT01000022.fna", abc)
+    check_bmyd2_table(next(hmmer.nhmmer(hmm, seqs, devices=[0, 0])), golden_table("bmyD2.tbl"))

@@ -154,3 +154,29 @@ def test_window_beta_sets_the_evalue_window(libp7x):
     assert om._info.max_length == cfg.evalue_window_length == hmm.max_length
     cfg = plan7.LongTargetsPipeline(hmm.alphabet, window_length=3878)._cfg()
     assert cfg.window_length == 3878 and cfg.evalue_window_length == -1
+
+
+def test_search_dealt_over_parts_equals_the_whole(libp7x, oracle):
+    """nhmmer over several devices (cfg.lt_part / lt_nparts + p7x_tophits_merge_longtargets): the (target, block, strand)
+    units are independent, so a search dealt over 2, 3 or 4 parts -- E-values for all residues, duplicates across block
+    boundaries and thresholds done once for the merged list -- equals the one-part search, field by field."""
+    hmm = load_hmms("bmyD")[0]
+    seqs = _read("1390.SAMEA104415756.OFHT01000022.fna", hmm.alphabet)          # 391 kb: two blocks x two strands
+    # a short block length gives the parts more units and puts hits next to block boundaries
+    for block_length in (0x40000, 60000):
+        mk = lambda: plan7.LongTargetsPipeline(hmm.alphabet, block_length=block_length)
+        whole = host_pipeline.host_nhmmer(oracle, hmm, seqs, mk())
+        assert whole._nunits == 2 * len(host_pipeline.blocks_of(len(seqs[0]), block_length, hmm.max_length))
+        for nparts in (2, 3, 4, whole._nunits):
+            parts = host_pipeline.host_nhmmer(oracle, hmm, seqs, mk(), nparts=nparts)
+            assert _rows(parts) == _rows(whole), (block_length, nparts)
+            assert parts.stage_counts == whole.stage_counts and parts.searched_residues == whole.searched_residues
+            assert [(h.evalue, h.score, h.reported, h.included, h.duplicate) for h in parts] == \
+                   [(h.evalue, h.score, h.reported, h.included, h.duplicate) for h in whole]
+    check_bmyd2_table(host_pipeline.host_nhmmer(oracle, hmm, seqs, nparts=3), golden_table("bmyD2.tbl"))
+    # a part cannot pass for a finished hit list, and parts of different searches do not merge
+    import ctypes as C
+    from pyhmmer_amd import _lib
+    bad = (C.c_void_p * 1)(None)
+    out = C.c_void_p()
+    assert _lib.lib().p7x_tophits_merge_longtargets(bad, 1, C.byref(out)) != 0
