@@ -400,6 +400,7 @@ class SequenceFile:
         self.alphabet = alphabet
         self._pending: Optional[str] = None
         self._touched = False
+        self._chunk_pos = 0
         if format is None:
             try:
                 pos = self._fh.tell()
@@ -429,6 +430,8 @@ class SequenceFile:
         self._fh.seek(0)
         self._pending = None
         self._touched = False
+        self._chunk_pos = 0
+        self._chunk_pos = 0
 
     def guess_alphabet(self) -> Optional[Alphabet]:
         pos = self._fh.tell()
@@ -542,9 +545,44 @@ class SequenceFile:
 
     def _read_block_native(self) -> "DigitalSequenceBlock":
         """Whole file -> packed block through the C parser (no per-record Python work)."""
+        block = self._parse_native(np.fromfile(self.name, dtype=np.uint8))
+        self._touched = True
+        self._fh.seek(0, 2)                                   # the file is consumed
+        return block
+
+    def read_chunk(self, max_bytes: int = 1 << 28) -> "DigitalSequenceBlock":
+        """The next whole records of a digital FASTA file, about ``max_bytes`` of text at a time, through the C parser:
+        how ``hmmsearch`` walks a target database that is larger than memory (the reference iterates the file, one
+        sequence at a time: ``plan7.pyx:6244-6252``, ``_search_loop_file`` ``:6456``).  An empty block at the end of the
+        file; ``rewind()`` starts over.  Other formats and text mode fall back to ``read_block(residues=max_bytes)``."""
+        if not (self.digital and self._own and self.format != "genbank"):
+            return self.read_block(residues=max_bytes)
+        if self._touched and self._chunk_pos == 0:
+            raise ValueError("read_chunk() cannot continue a file that was partly read record by record; rewind() first")
+        with open(self.name, "rb") as f:
+            f.seek(self._chunk_pos)
+            data = f.read(max_bytes)
+            if len(data) == max_bytes:                        # most likely inside a record: take the rest of it
+                tail = data[-1:]
+                while True:
+                    more = f.read(1 << 20)
+                    if not more:
+                        break
+                    k = (tail + more).find(b"\n>")
+                    if k >= 0:
+                        data += more[:k]                      # up to and including the newline before the next header
+                        break
+                    data += more
+                    tail = more[-1:]
+        self._chunk_pos += len(data)
+        self._touched = True
+        if not data.strip():
+            return DigitalSequenceBlock(self.alphabet, [])
+        return self._parse_native(np.frombuffer(data, dtype=np.uint8))
+
+    def _parse_native(self, data: np.ndarray) -> "DigitalSequenceBlock":
         import ctypes as C
         from . import _lib
-        data = np.fromfile(self.name, dtype=np.uint8)
         lut = self.alphabet._lut.copy()
         for ch in b" \t\r\n0123456789":
             lut[ch] = 254                                     # ignored inside sequence data, as Easel's sqio does
@@ -562,8 +600,6 @@ class SequenceFile:
                     C.byref(bad))
         if st != 0:
             raise ValueError(f"{self.name}: {_lib.last_error()} (byte {bad.value})")
-        self._touched = True
-        self._fh.seek(0, 2)                                   # the file is consumed
         return _LazyDigitalSequenceBlock(self.alphabet, PackedBlock.from_arrays(dsq, offsets, lengths), strtab, name_off, desc_off)
 
     def read_block(self, sequences: Optional[int] = None, residues: Optional[int] = None):

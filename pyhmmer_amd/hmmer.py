@@ -162,8 +162,15 @@ def hmmsearch(queries: Union[HMM, Profile, OptimizedProfile, Iterable], sequence
               callback: Optional[Callable] = None, devices: Optional[Sequence[int]] = None,
               pipeline_depth: int = 4, feeders: int = 2, batch: int = 0,
               backend: Optional[str] = None, parallel: Optional[str] = None, builder=None, timeout: Optional[float] = None,
-              **options) -> Iterator[TopHits]:
+              chunk_bytes: Optional[int] = None, **options) -> Iterator[TopHits]:
     """Search HMMs against a sequence database; yields one ``TopHits`` per query, in query order.
+
+    A ``SequenceFile`` of targets is walked in chunks, as the reference walks it sequence by sequence
+    (``plan7.pyx:6244-6252``, ``_search_loop_file`` ``:6456``): ``chunk_bytes`` of FASTA text (default 1 GiB; a file that
+    fits is one chunk) are parsed, made resident and searched by every query of a span of up to 2,048 queries, then the
+    next chunk replaces them; the per-chunk hit lists of a query are merged as the reference merges target chunks
+    (``TopHits.merge``: counters and ``Z`` summed, thresholds re-applied).  Neither host memory nor HBM ever hold more
+    than one chunk, so the database may be larger than both.
 
     ``batch`` queries share one set of device launches (``p7x_search_batch_enqueue``: every kernel of the cascade
     serves all of them); 0 picks a size from the amount of work one query is (a query that fills the device for
@@ -189,14 +196,25 @@ def hmmsearch(queries: Union[HMM, Profile, OptimizedProfile, Iterable], sequence
         raise ValueError(f"invalid value for `parallel`: {parallel!r}")
     if isinstance(queries, (HMM, Profile, OptimizedProfile)):
         queries = (queries,)
+    if builder is not None or timeout is not None:
+        import warnings
+        warnings.warn("hmmsearch: `builder` only applies to sequence / MSA queries (not built on this path) and `timeout` "
+                      "to worker processes (there are none); both are ignored", RuntimeWarning, stacklevel=2)
+    ndev = _lib.lib().p7x_device_count()
     if isinstance(sequences, SequenceFile):
+        if sequences.name is None:
+            raise ValueError("expected named `SequenceFile` for targets")               # _hmmsearch.py:392-393
         if not sequences.digital:
             raise ValueError("target sequences file is not in digital mode")
-        sequences = sequences.read_block()
+        if ndev < 1:
+            from .errors import DeviceUnavailable
+            raise DeviceUnavailable("hmmsearch: no HIP device is usable and there is no CPU fallback")
+        yield from _search_file(queries, sequences, chunk_bytes or (1 << 30), list(devices) if devices else [0], cpus, callback,
+                                pipeline_depth, feeders, batch, options)
+        return
     if not isinstance(sequences, (DigitalSequenceBlock, SequenceDatabase)):
         raise TypeError(f"Expected DigitalSequenceBlock or SequenceFile, found {type(sequences).__name__}")
     alphabet: Alphabet = sequences.alphabet
-    ndev = _lib.lib().p7x_device_count()
     if ndev < 1:
         from .errors import DeviceUnavailable
         raise DeviceUnavailable("hmmsearch: no HIP device is usable and there is no CPU fallback")
@@ -216,6 +234,50 @@ def hmmsearch(queries: Union[HMM, Profile, OptimizedProfile, Iterable], sequence
         if callback is not None:
             callback(q, total)
         yield hits
+
+
+_FILE_SPAN = 2048          # queries that share one pass over a target file
+
+
+def _search_file(queries: Iterable, file: SequenceFile, chunk_bytes: int, devs: List[int], cpus: int, callback, pipeline_depth: int,
+                 feeders: int, batch: int, options: dict) -> Iterator[TopHits]:
+    """hmmsearch against a target FILE: chunk after chunk resident, every query of a span over every chunk, the chunks'
+    hit lists of a query merged (see hmmsearch)."""
+    alphabet: Alphabet = file.alphabet
+    total = None
+    try:
+        total = len(queries)          # type: ignore[arg-type]
+    except TypeError:
+        pass
+    it = iter(queries)
+    while True:
+        span: list = []
+        for q in it:
+            span.append(q)
+            if len(span) >= _FILE_SPAN:
+                break
+        if not span:
+            return
+        file.rewind()
+        parts: List[List[TopHits]] = [[] for _ in span]
+        nchunks = 0
+        while True:
+            block = file.read_chunk(chunk_bytes)
+            if len(block) == 0 and nchunks > 0:
+                break
+            nchunks += 1
+            db = ShardedDatabase(block, devs)           # an empty file: one empty chunk, so that every query still reports
+            pipelines = [Pipeline(alphabet, device=d, host_threads=cpus, **options) for d in devs]
+            for i, (_, hits) in enumerate(_run_queries(db, pipelines, span, pipeline_depth, feeders, batch=batch)):
+                parts[i].append(hits)
+            del db, pipelines                            # the chunk leaves HBM before the next one is read
+            if len(block) == 0:
+                break
+        for q, hs in zip(span, parts):
+            hits = hs[0] if len(hs) == 1 else hs[0].merge(*hs[1:])
+            if callback is not None:
+                callback(q, total)
+            yield hits
 
 
 _BATCH_CELLS = 6e11        # (profile, target) cells per device batch when the caller leaves the batch size open: ~25 ms of MSV
@@ -272,9 +334,12 @@ def _run_queries(db: "ShardedDatabase", pipelines: Sequence[Pipeline], queries: 
         batch = _BATCH_MAX                # upper bound; the cut below follows the cell budget
     span = batch * max(1, reorder) if batch > 1 else 1
     if auto:
-        span = 8 * _BATCH_MAX
+        # a query source of unknown length (a generator, a file being parsed) is read a shorter way ahead: the first
+        # result of a span waits for the whole span to be read
+        import operator
+        span = (8 if operator.length_hint(queries) > 0 else 2) * _BATCH_MAX
     order: list = []                      # input index of every query handed to the device, in hand-over order
-    inputs: list = []                     # the queries, by input index (dropped once yielded)
+    inputs: dict = {}                     # the queries that have not been yielded yet, by input index
     it = iter(queries)
     src_error: list = []
 
@@ -291,7 +356,7 @@ def _run_queries(db: "ShardedDatabase", pipelines: Sequence[Pipeline], queries: 
                 src_error.append(e)
             if not chunk:
                 return
-            inputs.extend(chunk)
+            inputs.update((base + i, q) for i, q in enumerate(chunk))
             idx = sorted(range(len(chunk)), key=lambda i: _query_length(chunk[i])) if span > 1 else list(range(len(chunk)))
             lo = 0
             while lo < len(idx):
@@ -326,8 +391,7 @@ def _run_queries(db: "ShardedDatabase", pipelines: Sequence[Pipeline], queries: 
         for i, h in zip(members, hits):
             done[i] = h
         while nxt in done:
-            q, inputs[nxt] = inputs[nxt], None
-            yield q, done.pop(nxt)
+            yield inputs.pop(nxt), done.pop(nxt)
             nxt += 1
     runner.close()                        # feeders stop, queued device work is released
     if failure is not None:
@@ -337,17 +401,12 @@ def _run_queries(db: "ShardedDatabase", pipelines: Sequence[Pipeline], queries: 
         members, err = failure
         last = max(members)
         while nxt <= last:
-            if nxt in done:
-                res = done.pop(nxt)
-            else:
-                res = db.search(pipelines, [inputs[nxt]])[0]
-            q, inputs[nxt] = inputs[nxt], None
-            yield q, res
+            one = done.pop(nxt) if nxt in done else db.search(pipelines, [inputs[nxt]])[0]
+            yield inputs.pop(nxt), one
             nxt += 1
         raise err           # not reproducible query by query: report it after the batch
     while nxt in done:
-        q, inputs[nxt] = inputs[nxt], None
-        yield q, done.pop(nxt)
+        yield inputs.pop(nxt), done.pop(nxt)
         nxt += 1
     if src_error:
         raise src_error[0]

@@ -513,3 +513,32 @@ def test_clustered_envelopes_on_the_device_give_the_same_tables(models, proteome
         a, b = io.BytesIO(), io.BytesIO()
         base.write(a, format=fmt); dev.write(b, format=fmt)
         assert a.getvalue() == b.getvalue()
+
+
+def test_target_file_is_searched_in_chunks(models, proteome, golden):
+    """hmmsearch(queries, SequenceFile): the file is walked in chunks (here 100 kB of text: ten chunks for the fixture
+    proteome), one chunk resident at a time; the merged hit lists equal the search of the whole block -- scores, E-values
+    with the global Z, flags, domains -- and reproduce the golden table (reference plan7.pyx:6244-6252, :6456;
+    test_hmmer.py:109-198 runs the same comparison in "file" mode)."""
+    queries = [models["PF02826"][0], models["Thioesterase"][0]] + models["RREFam"][:3]
+    whole = list(hmmer.hmmsearch(queries, proteome))
+    with easel.SequenceFile(golden / "seqs" / "938293.PRJEB85.HG003687.faa", digital=True, alphabet=proteome.alphabet) as sf:
+        seen = []
+        chunked = list(hmmer.hmmsearch(queries, sf, chunk_bytes=100_000, callback=lambda q, n: seen.append(q.name)))
+        one_chunk = list(hmmer.hmmsearch(queries, sf))
+    assert seen == [q.name for q in queries]
+    for a, b, c in zip(chunked, whole, one_chunk):
+        assert a.Z == b.Z == c.Z == 2100 and a.domZ == b.domZ
+        assert a.stage_counts == b.stage_counts and a.searched_residues == b.searched_residues == 682583
+        for x in (a, c):
+            assert [(h.name, h.score, h.evalue, h.reported, h.included) for h in x.reported] == \
+                   [(h.name, h.score, h.evalue, h.reported, h.included) for h in b.reported]
+            assert [[(d.env_from, d.env_to, d.score, d.i_evalue, d.alignment.target_sequence) for d in h.domains] for h in x.reported] == \
+                   [[(d.env_from, d.env_to, d.score, d.i_evalue, d.alignment.target_sequence) for d in h.domains] for h in b.reported]
+    _check_tbl(chunked[0], golden_table("PF02826.tbl"))
+    # an empty target file still answers every query
+    import tempfile
+    with tempfile.NamedTemporaryFile(suffix=".faa") as tmp:
+        with easel.SequenceFile(tmp.name, digital=True, alphabet=proteome.alphabet) as sf:
+            empty = list(hmmer.hmmsearch(queries[:2], sf))
+    assert [len(h) for h in empty] == [0, 0] and empty[0].Z == 0
