@@ -56,10 +56,10 @@ struct EnvForward {
   float xN, xB, xJ, xC, xE, scale, totscale;
   __device__ __forceinline__ void init(const float4 *tr, int lane, float pmove)
   {
-#pragma unroll
+#pragma unroll unroll_c(C)
     for (int c = 0; c < C; ++c) mm[c] = im[c] = dm[c] = 0.0f;
     ddprod = 1.0f;
-#pragma unroll
+#pragma unroll unroll_c(C)
     for (int c = 0; c < C; ++c) ddprod *= tr[2 * (c * 64 + lane) + 1].w;
     xN = 1.0f; xB = pmove; xJ = 0.0f; xC = 0.0f; xE = 0.0f; scale = 1.0f; totscale = 0.0f;
   }
@@ -70,7 +70,7 @@ struct EnvForward {
     float mp = dpp_shr1f(mm[C - 1], 0.0f), ip = dpp_shr1f(im[C - 1], 0.0f), dp = dpp_shr1f(dm[C - 1], 0.0f);
     float esum = 0.0f;
     float t_dd[C], t_md[C];
-#pragma unroll
+#pragma unroll unroll_c(C)
     for (int c = 0; c < C; ++c) {
       const F8 t = load_f8(tr, c * 64 + lane);
       float sv = xB * t.bm;
@@ -85,13 +85,13 @@ struct EnvForward {
       t_dd[c] = t.dd; t_md[c] = t.md;
     }
     float A = 0.0f;
-#pragma unroll
+#pragma unroll unroll_c(C)
     for (int c = 0; c < C; ++c) { dm[c] = A; A = mm[c] * t_md[c] + A * t_dd[c]; }
     float sa = A, sp = ddprod;
     affine_scan_up(sa, sp);
     {
       float w = dpp_shr1f(sa, 0.0f);
-#pragma unroll
+#pragma unroll unroll_c(C)
       for (int c = 0; c < C; ++c) { dm[c] = dm[c] + w; esum = esum + dm[c]; w = w * t_dd[c]; }
     }
     xE = wave_sum_f32(esum);
@@ -103,7 +103,7 @@ struct EnvForward {
     if (xE > 1.0e4f) {
       xN = xN / xE; xC = xC / xE; xJ = xJ / xE; xB = xB / xE;
       const float inv = (float) (1.0 / (double) xE);
-#pragma unroll
+#pragma unroll unroll_c(C)
       for (int c = 0; c < C; ++c) { mm[c] *= inv; dm[c] *= inv; im[c] *= inv; }
       scale = xE;
       totscale += (float) log((double) xE);
@@ -149,14 +149,18 @@ __global__ void __launch_bounds__(env_waves(C) * 64, env_waves(C) / 4) env_kerne
   constexpr int Mpad = 64 * C;
   const EnvArgs a = load_args<EnvArgs>(ref);
   if ((int) blockIdx.x >= a.nblocks) return;        // this job has fewer blocks than the widest job of the launch
-  float4 *tr = reinterpret_cast<float4 *>(smem);                         // [2*Mpad]
+  constexpr bool TG = C > 64;         // M > 4096: the transitions are read through L2 as well
+  const float4 *tr = TG ? reinterpret_cast<const float4 *>(a.trans) : reinterpret_cast<const float4 *>(smem);      // [2*Mpad]
   // emission odds [nrows][Mpad]: staged in LDS while they fit beside the transitions (M <= 1024), else read where they
   // lie (one coalesced 256-byte row segment per chunk and row: L2-resident, like the parsers' long-model variant)
   constexpr bool kEmisInLds = C <= 16;
   const float *em = kEmisInLds ? reinterpret_cast<const float *>(smem + (size_t) Mpad * 32) : reinterpret_cast<const float *>(a.emis);
   {
-    const float4 *gt = reinterpret_cast<const float4 *>(a.trans);
-    for (int i = threadIdx.x; i < 2 * Mpad; i += kEnvBlock) tr[i] = gt[i];
+    if constexpr (!TG) {
+      const float4 *gt = reinterpret_cast<const float4 *>(a.trans);
+      float4 *lt = reinterpret_cast<float4 *>(smem);
+      for (int i = threadIdx.x; i < 2 * Mpad; i += kEnvBlock) lt[i] = gt[i];
+    }
     if constexpr (kEmisInLds) {
       const float4 *ge = reinterpret_cast<const float4 *>(a.emis);
       float4 *le = reinterpret_cast<float4 *>(smem + (size_t) Mpad * 32);
@@ -226,13 +230,13 @@ __global__ void __launch_bounds__(env_waves(C) * 64, env_waves(C) / 4) env_kerne
     {
       float t_md[C], t_dd[C], t_mi[C], t_ii[C], t_bm[C], n_mm[C], n_im[C], n_dm[C];
       float ddprod = 1.0f;
-#pragma unroll
+#pragma unroll unroll_c(C)
       for (int c = 0; c < C; ++c) {
         const F8 t = load_f8(tr, c * 64 + lane);
         t_md[c] = t.md; t_dd[c] = t.dd; t_mi[c] = t.mi; t_ii[c] = t.ii; t_bm[c] = t.bm;
         ddprod *= t.dd;
       }
-#pragma unroll
+#pragma unroll unroll_c(C)
       for (int c = 0; c < C; ++c) {          // transitions entering the NEXT node
         float mmn, imn, dmn;
         if (c + 1 < C) { const F8 t = load_f8(tr, (c + 1) * 64 + lane); mmn = t.mm; imn = t.im; dmn = t.dm; }
@@ -245,34 +249,34 @@ __global__ void __launch_bounds__(env_waves(C) * 64, env_waves(C) / 4) env_kerne
       float xE = xC * a.xf_e_move;
       auto d_chain = [&](float (&d)[C]) {
         float A = 0.0f;
-#pragma unroll
+#pragma unroll unroll_c(C)
         for (int c = C - 1; c >= 0; --c) { A = d[c] + A * t_dd[c]; }
         float sa = A, sp = ddprod;
         affine_scan_down(sa, sp, lane);
         float w = dpp_shl1f(sa, 0.0f);
-#pragma unroll
+#pragma unroll unroll_c(C)
         for (int c = C - 1; c >= 0; --c) { d[c] = d[c] + w * t_dd[c]; w = d[c]; }
       };
       auto store_row = [&](int r) {
         float *rm = bM + (size_t) r * Mpad + lane, *ri = bI + (size_t) r * Mpad + lane;
         if (lane_live) {
-#pragma unroll
+#pragma unroll unroll_c(C)
           for (int c = 0; c < C; ++c) { rm[c * 64] = mm[c]; ri[c * 64] = im[c]; }
         }
       };
-#pragma unroll
+#pragma unroll unroll_c(C)
       for (int c = 0; c < C; ++c) { mm[c] = xE; dm[c] = xE; im[c] = 0.0f; }
       d_chain(dm);
       {
         float dn = dpp_shl1f(dm[0], 0.0f);
-#pragma unroll
+#pragma unroll unroll_c(C)
         for (int c = C - 1; c >= 0; --c) { mm[c] = mm[c] + dn * t_md[c]; dn = dm[c]; }
       }
       float sc = rflf(fx[(size_t) Ld * 6 + 5]);
       if (sc > 1.0f) {
         xE = xE / sc; xN = xN / sc; xC = xC / sc; xJ = xJ / sc; xB = xB / sc;
         const float inv = (float) (1.0 / (double) sc);
-#pragma unroll
+#pragma unroll unroll_c(C)
         for (int c = 0; c < C; ++c) { mm[c] *= inv; dm[c] *= inv; im[c] *= inv; }
       }
       store_row(Ld);
@@ -291,13 +295,13 @@ __global__ void __launch_bounds__(env_waves(C) * 64, env_waves(C) / 4) env_kerne
         const float fsc = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, bk), 1));
         const float *er = em + x * Mpad + lane;
         float me[C];
-#pragma unroll
+#pragma unroll unroll_c(C)
         for (int c = 0; c < C; ++c) me[c] = mm[c] * er[c * 64];
         float bsum = 0.0f;
-#pragma unroll
+#pragma unroll unroll_c(C)
         for (int c = 0; c < C; ++c) bsum = bsum + me[c] * t_bm[c];
         const float me_next0 = dpp_shl1f(me[0], 0.0f);
-#pragma unroll
+#pragma unroll unroll_c(C)
         for (int c = 0; c < C; ++c) {
           const float mp = (c + 1 < C) ? me[c + 1] : me_next0;
           const float ipv = im[c];
@@ -310,12 +314,12 @@ __global__ void __launch_bounds__(env_waves(C) * 64, env_waves(C) / 4) env_kerne
         xJ = (xB * pmove) + (xJ * ploop);
         xN = (xB * pmove) + (xN * ploop);
         xE = (xC * a.xf_e_move) + (xJ * a.xf_e_loop);
-#pragma unroll
+#pragma unroll unroll_c(C)
         for (int c = 0; c < C; ++c) { dm[c] = dm[c] + xE; mm[c] = mm[c] + xE; }
         d_chain(dm);
         {
           float dn = dpp_shl1f(dm[0], 0.0f);
-#pragma unroll
+#pragma unroll unroll_c(C)
           for (int c = C - 1; c >= 0; --c) { mm[c] = mm[c] + dn * t_md[c]; dn = dm[c]; }
         }
         if (xB > 1.0e16f) own_scales = true;
@@ -323,7 +327,7 @@ __global__ void __launch_bounds__(env_waves(C) * 64, env_waves(C) / 4) env_kerne
         if (sc > 1.0f) {
           xE /= sc; xN /= sc; xJ /= sc; xB /= sc; xC /= sc;
           const float inv = (float) (1.0 / (double) sc);
-#pragma unroll
+#pragma unroll unroll_c(C)
           for (int c = 0; c < C; ++c) { mm[c] *= inv; dm[c] *= inv; im[c] *= inv; }
         }
         store_row(i);
@@ -333,7 +337,7 @@ __global__ void __launch_bounds__(env_waves(C) * 64, env_waves(C) / 4) env_kerne
         const int x = rfl((int) sq[0]);
         const float *er = em + x * Mpad + lane;
         float bsum = 0.0f;
-#pragma unroll
+#pragma unroll unroll_c(C)
         for (int c = 0; c < C; ++c) bsum = bsum + (mm[c] * er[c * 64]) * t_bm[c];
         xB = wave_sum_f32(bsum);
         xN = (xB * pmove) + (xN * ploop);
@@ -348,12 +352,12 @@ __global__ void __launch_bounds__(env_waves(C) * 64, env_waves(C) / 4) env_kerne
     {
       float scaleproduct = (float) (1.0 / (double) bck_xN0);
       bool ddpass = true;                                            // every D->D transition of this lane is open
-#pragma unroll
+#pragma unroll unroll_c(C)
       for (int c = 0; c < C; ++c) ddpass = ddpass && (tr[2 * (c * 64 + lane) + 1].w > 0.0f);
       float p_md0, p_dd0;                                            // leaving transitions of the previous lane's last node
       { const F8 t = load_f8(tr, (C - 1) * 64 + lane); p_md0 = dpp_shr1f(t.md, 0.0f); p_dd0 = dpp_shr1f(t.dd, 0.0f); }
       float om_[C], oi_[C], od_[C], msum[C], isum[C];
-#pragma unroll
+#pragma unroll unroll_c(C)
       for (int c = 0; c < C; ++c) { om_[c] = oi_[c] = od_[c] = kNegInf; msum[c] = isum[c] = 0.0f; }
       float oE = kNegInf, oN = 0.0f, oJ = kNegInf, oB = 0.0f, oC = kNegInf;
       float eN = 0.0f, eJ = 0.0f, eC = 0.0f;
@@ -364,7 +368,7 @@ __global__ void __launch_bounds__(env_waves(C) * 64, env_waves(C) / 4) env_kerne
       float nbm[C], nbi[C];
       auto fetch_row = [&](int r, float (&c2)[C], float (&d)[C]) {
         const float *rbm = bM + (size_t) r * Mpad + lane, *rbi = bI + (size_t) r * Mpad + lane;
-#pragma unroll
+#pragma unroll unroll_c(C)
         for (int c = 0; c < C; ++c) { c2[c] = lane_live ? rbm[c * 64] : 0.0f; d[c] = lane_live ? rbi[c * 64] : 0.0f; }
       };
       EnvForward<C> f;                 // Forward again, row by row, next to the decoding
@@ -380,7 +384,7 @@ __global__ void __launch_bounds__(env_waves(C) * 64, env_waves(C) / 4) env_kerne
       float xprev = fetch_x(0), xcur = fetch_x(1);
       for (int r = 1; r <= Ld; ++r) {
         float cbm[C], cbi[C];
-#pragma unroll
+#pragma unroll unroll_c(C)
         for (int c = 0; c < C; ++c) { cbm[c] = nbm[c]; cbi[c] = nbi[c]; }
         const float xthis = xcur;
         const int rn = (r < Ld) ? r + 1 : r;                 // the last iteration re-reads its own row (harmless)
@@ -393,7 +397,7 @@ __global__ void __launch_bounds__(env_waves(C) * 64, env_waves(C) / 4) env_kerne
         const float fS = xval(xthis, 5), bS = xval(xthis, 8 + 5);
         const float totr = scaleproduct * fS;
         float ppm[C], ppi[C];
-#pragma unroll
+#pragma unroll unroll_c(C)
         for (int c = 0; c < C; ++c) {
           ppm[c] = (cfm[c] * cbm[c]) * totr;
           ppi[c] = (cfi[c] * cbi[c]) * totr;
@@ -412,7 +416,7 @@ __global__ void __launch_bounds__(env_waves(C) * 64, env_waves(C) / 4) env_kerne
         float mp = dpp_shr1f(om_[C - 1], kNegInf), ip = dpp_shr1f(oi_[C - 1], kNegInf), dp = dpp_shr1f(od_[C - 1], kNegInf);
         unsigned short code[C];
         float t_md[C], t_dd[C];
-#pragma unroll
+#pragma unroll unroll_c(C)
         for (int c = 0; c < C; ++c) {
           const F8 t = load_f8(tr, c * 64 + lane);
           t_md[c] = t.md; t_dd[c] = t.dd;
@@ -444,18 +448,18 @@ __global__ void __launch_bounds__(env_waves(C) * 64, env_waves(C) / 4) env_kerne
         // D(r,k) = max(gate(tMD(k-1), M(r,k-1)), tDD(k-1) > 0 ? D(r,k-1) : 0), D(r,1) = -inf: a segmented max-scan
         {
           float w = kNegInf;
-#pragma unroll
+#pragma unroll unroll_c(C)
           for (int c = 0; c < C; ++c) w = vmax(gate(t_md[c], om_[c]), t_dd[c] > 0.0f ? w : 0.0f);
           float sa = w; int sp = ddpass ? 1 : 0;
           gated_max_scan_up(sa, sp);
           w = dpp_shr1f(sa, kNegInf);
-#pragma unroll
+#pragma unroll unroll_c(C)
           for (int c = 0; c < C; ++c) { od_[c] = w; w = vmax(gate(t_md[c], om_[c]), t_dd[c] > 0.0f ? w : 0.0f); }
         }
         {
           float pm = dpp_shr1f(om_[C - 1], kNegInf), pd = dpp_shr1f(od_[C - 1], kNegInf);
           float pmd = p_md0, pdd = p_dd0;
-#pragma unroll
+#pragma unroll unroll_c(C)
           for (int c = 0; c < C; ++c) {
             const float d0 = block(pmd, pm), d1 = block(pdd, pd);
             const int dchoice = (d0 >= d1) ? 0 : 1;
@@ -468,12 +472,12 @@ __global__ void __launch_bounds__(env_waves(C) * 64, env_waves(C) / 4) env_kerne
         {
           unsigned short *rb = bp + (size_t) r * Mpad + lane;
           if (lane_live) {
-#pragma unroll
+#pragma unroll unroll_c(C)
             for (int c = 0; c < C; ++c) rb[c * 64] = code[c];
           }
         }
         float rowmax = kNegInf;
-#pragma unroll
+#pragma unroll unroll_c(C)
         for (int c = 0; c < C; ++c) if (lane * C + c + 1 <= a.M) rowmax = vmax(rowmax, vmax(om_[c], od_[c]));
         oE = wave_max_f32(rowmax);
         float t1, t2;
@@ -494,7 +498,7 @@ __global__ void __launch_bounds__(env_waves(C) * 64, env_waves(C) / 4) env_kerne
           // maximum wins; without one, the FIRST D cell that does.
           int keyM = 0, keyD = 0, nearM = 0;
           const float ethr = oE - guard_band(oE, a.oa_guard);
-#pragma unroll
+#pragma unroll unroll_c(C)
           for (int c = 0; c < C; ++c) {
             const int k = lane * C + c + 1;
             if (k <= a.M) {
@@ -532,7 +536,7 @@ __global__ void __launch_bounds__(env_waves(C) * 64, env_waves(C) / 4) env_kerne
       for (int x = 0; x < a.K; ++x) {
         const float *er = em + x * Mpad + lane;
         float s = 0.0f;
-#pragma unroll
+#pragma unroll unroll_c(C)
         for (int c = 0; c < C; ++c) { s = s + (msum[c] * norm) * er[c * 64]; s = s + isum[c] * norm; }
         s = wave_sum_f32(s);
         if (lane == 0) n2[x] = s + xfactor;
@@ -696,11 +700,15 @@ static int occupancy_env(K kernel, int kEnvBlock, size_t lds_bytes, int *per_cu)
     case 16: { if (G_) { auto kern = env_kernel<16, true>; return EXPR; } else { auto kern = env_kernel<16, false>; return EXPR; } }                                                     \
     case 20: { if (G_) { auto kern = env_kernel<20, true>; return EXPR; } else { auto kern = env_kernel<20, false>; return EXPR; } }                                                     \
     case 24: { if (G_) { auto kern = env_kernel<24, true>; return EXPR; } else { auto kern = env_kernel<24, false>; return EXPR; } }                                                     \
-    case 32: { if (G_) { auto kern = env_kernel<32, true>; return EXPR; } else { auto kern = env_kernel<32, false>; return EXPR; } }                                                     \
+    case 32: { if (G_) { auto kern = env_kernel<32, true>; return EXPR; } else { auto kern = env_kernel<32, false>; return EXPR; } } \
+    case 48: { if (G_) { auto kern = env_kernel<48, true>; return EXPR; } else { auto kern = env_kernel<48, false>; return EXPR; } } \
+    case 64: { if (G_) { auto kern = env_kernel<64, true>; return EXPR; } else { auto kern = env_kernel<64, false>; return EXPR; } } \
+    case 96: { if (G_) { auto kern = env_kernel<96, true>; return EXPR; } else { auto kern = env_kernel<96, false>; return EXPR; } } \
+    case 128: { if (G_) { auto kern = env_kernel<128, true>; return EXPR; } else { auto kern = env_kernel<128, false>; return EXPR; } }                                                     \
     default: set_error("model too long for the envelope kernel"); return P7X_EINVAL;                         \
   }
 
-static size_t env_lds_bytes(int C, int nrows) { return (size_t) 64 * C * (32 + (C <= 16 ? (size_t) nrows * 4 : 0)); }
+static size_t env_lds_bytes(int C, int nrows) { return C > 64 ? (size_t) 256 : (size_t) 64 * C * (32 + (C <= 16 ? (size_t) nrows * 4 : 0)); }
 
 int env_max_blocks(int C, int nrows, int num_cu, int *nblocks)
 {

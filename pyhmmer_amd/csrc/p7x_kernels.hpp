@@ -97,7 +97,7 @@ int vit_launch(const ArgRun<WaveSeqArgs> &a, int num_cu, hipStream_t st);
 int fwd_launch(const ArgRun<WaveSeqArgs> &a, int num_cu, hipStream_t st);
 int bck_launch(const ArgRun<WaveSeqArgs> &a, int num_cu, hipStream_t st);
 
-// ---- MSV for models beyond the register-resident kernels (p7x_vitfwd.hip::msv_wave_kernel), M <= 2048
+// ---- MSV for models beyond the register-resident kernels (p7x_vitfwd.hip::msv_wave_kernel), M <= 8192
 struct MsvWaveArgs {
   int C, nrows;
   const void *emis;         // int16 [nrows][64*C], (bias - cost) in lane-chunk order, kNegPad outside the model / pad row

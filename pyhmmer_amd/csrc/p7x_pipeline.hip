@@ -774,7 +774,7 @@ static int lane_classes(const std::vector<LaneModel> &lm, const p7x_seqdb *db, c
   out.clear();
   for (int l = 0; l < nl; ++l) {
     const DevProfile *dp = lm[l].dp;
-    if ((dp->msvR <= 0 || small) && !dp->msvw_emis) { set_error("model too long for the MSV kernels (M > 2048)"); return P7X_EINVAL; }
+    if ((dp->msvR <= 0 || small) && !dp->msvw_emis) { set_error("model too long for the MSV kernels (M > 8192)"); return P7X_EINVAL; }
     LaneClass c; c.first = l; c.n = 1; c.msv_key = msv_key_of(dp, small); c.vit_key = vit_key_of(dp, small); c.C = dp->vitC;
     c.nlong = (c.msv_key >= 0 && dp->msvw_emis) ? nlong : 0;
     c.vit_long = c.vit_key >= 0 ? db->vit_long_slots : 0;
@@ -1067,7 +1067,7 @@ static int cascade_enqueue(CascadeRun &r)
   tick("images");
   if (db->nslots == 0 || nq == 0) return P7X_OK;
   for (int l = 0; l < nq; ++l)
-    if (r.lm[l].dp->vitC <= 0 || r.lm[l].dp->vitC > 32) { set_error("model too long for the device kernels (M > 2048)"); return P7X_EINVAL; }
+    if (r.lm[l].dp->vitC <= 0) { set_error("model too long for the device kernels (M > 8192)"); return P7X_EINVAL; }
   std::vector<LaneClass> classes;
   if ((st = lane_classes(r.lm, db, ctx, classes)) != P7X_OK) return st;
   if ((st = get_workspace(db->device, db->nslots, nq, &r.ws)) != P7X_OK) return st;
@@ -1364,7 +1364,7 @@ int p7x_filters_batch(const p7x_oprofile *om, const p7x_seqdb *db, int32_t *xJ, 
     const bool small = small_block(db, ctx, 1);
     cls.first = 0; cls.n = 1; cls.msv_key = msv_key_of(dp, small); cls.vit_key = vit_key_of(dp, small); cls.C = dp->vitC;
     cls.nlong = (!small && cls.msv_key >= 0 && dp->msvw_emis) ? long_groups(db, ctx, 1) : 0;
-    if (xJ && cls.msv_key < 0 && !dp->msvw_emis) { set_error("model too long for the MSV kernels (M > 2048)"); return P7X_EINVAL; }
+    if (xJ && cls.msv_key < 0 && !dp->msvw_emis) { set_error("model too long for the MSV kernels (M > 8192)"); return P7X_EINVAL; }
   }
   for (int64_t t = 0; t < db->n; ++t) {
     if (xJ) xJ[t] = 0;

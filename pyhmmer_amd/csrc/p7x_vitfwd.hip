@@ -25,14 +25,17 @@ __global__ void __launch_bounds__(kWsBlock) vit_kernel(const ArgRef ref)
   const WaveSeqArgs a = load_args<WaveSeqArgs>(ref);
   const int nlist = (a.abort_flag && *a.abort_flag) ? 0 : (a.nlist_ptr ? *a.nlist_ptr : a.nlist);
   if ((int) (blockIdx.x * (kWsBlock / 64)) >= nlist) return;         // no item for this block: skip the table load
+  constexpr bool EG = C > 32;         // long models (M > 2048): the emission table is read where it lies (L2), only the transitions are staged
   uint4 *tr = reinterpret_cast<uint4 *>(smem);                       // [Mpad]
-  short *em = reinterpret_cast<short *>(smem + (size_t) Mpad * 16);  // [kTabRows][Mpad]
+  const short *em = EG ? reinterpret_cast<const short *>(a.emis) : reinterpret_cast<const short *>(smem + (size_t) Mpad * 16);  // [kTabRows][Mpad]
   {
     const uint4 *gt = reinterpret_cast<const uint4 *>(a.trans);
     for (int i = threadIdx.x; i < Mpad; i += kWsBlock) tr[i] = gt[i];
-    const uint4 *ge = reinterpret_cast<const uint4 *>(a.emis);
-    uint4 *le = reinterpret_cast<uint4 *>(em);
-    for (int i = threadIdx.x; i < a.nrows * Mpad / 8; i += kWsBlock) le[i] = ge[i];
+    if constexpr (!EG) {
+      const uint4 *ge = reinterpret_cast<const uint4 *>(a.emis);
+      uint4 *le = reinterpret_cast<uint4 *>(smem + (size_t) Mpad * 16);
+      for (int i = threadIdx.x; i < a.nrows * Mpad / 8; i += kWsBlock) le[i] = ge[i];
+    }
   }
   __syncthreads();
   const int lane = threadIdx.x & 63;
@@ -45,7 +48,7 @@ __global__ void __launch_bounds__(kWsBlock) vit_kernel(const ArgRef ref)
     const int xwm = rfl((int) a.xwmove_tab[L]);
 
     short mm[C], im[C], dm[C], tdd[C];
-#pragma unroll
+#pragma unroll unroll_c(C)
     for (int c = 0; c < C; ++c) { mm[c] = im[c] = dm[c] = NEG; tdd[c] = NEG; }
     int xN = a.base_w, xB = xN + xwm, xJ = -32768, xC = -32768;
     bool overflow = false;
@@ -62,7 +65,7 @@ __global__ void __launch_bounds__(kWsBlock) vit_kernel(const ArgRef ref)
         short ip = (short) dpp_shr1(im[C - 1], NEG);
         short dp = (short) dpp_shr1(dm[C - 1], NEG);
         short rowmax = NEG, dmax = NEG, dcarry = NEG;
-#pragma unroll
+#pragma unroll unroll_c(C)
         for (int c = 0; c < C; ++c) {
           const uint4 t = tr[c * 64 + lane];
           short sv = adds16(xBs, lo16(t.x));
@@ -85,7 +88,7 @@ __global__ void __launch_bounds__(kWsBlock) vit_kernel(const ArgRef ref)
         if (xE >= lt_thr) {
           // long-target scan: every match cell that holds the row maximum seeds a window; the rows start afresh and the
           // special states keep their values (upstream p7_ViterbiFilter_longtarget)
-#pragma unroll
+#pragma unroll unroll_c(C)
           for (int c = 0; c < C; ++c) {
             const int k = lane * C + c + 1;
             if ((int) mm[c] == xE && k <= a.M) {
@@ -103,7 +106,7 @@ __global__ void __launch_bounds__(kWsBlock) vit_kernel(const ArgRef ref)
 
         const int Dmax = wave_max_i32((int) dmax);
         if (Dmax + a.ddbound > xB) {            // lazy F: only now can a D->D path beat B->M on the next row
-#pragma unroll
+#pragma unroll unroll_c(C)
           for (int c = 1; c < C; ++c) dm[c] = max16(dm[c], adds16(dm[c - 1], tdd[c - 1]));
           for (int pass = 0; pass < 64; ++pass) { // a carry can cross at most 63 lane boundaries
             const short ddout = adds16(dm[C - 1], tdd[C - 1]);
@@ -111,7 +114,7 @@ __global__ void __launch_bounds__(kWsBlock) vit_kernel(const ArgRef ref)
             const int improved = wave_max_i32((cand > dm[0]) ? 1 : 0);
             if (improved == 0) break;
             dm[0] = max16(dm[0], cand);
-#pragma unroll
+#pragma unroll unroll_c(C)
             for (int c = 1; c < C; ++c) dm[c] = max16(dm[c], adds16(dm[c - 1], tdd[c - 1]));
           }
         }
@@ -138,10 +141,11 @@ __global__ void __launch_bounds__(kWsBlock) msv_wave_kernel(const ArgRef ref)
   const MsvWaveArgs a = load_args<MsvWaveArgs>(ref);
   const int nlist = a.nslots;
   if ((int) (blockIdx.x * (kWsBlock / 64)) >= nlist) return;
-  short *em = reinterpret_cast<short *>(smem);                       // [nrows][Mpad] bias - cost, kNegPad outside the model
-  {
+  constexpr bool EG = C > 32;         // long models (M > 2048): the table is read where it lies (L2)
+  const short *em = EG ? reinterpret_cast<const short *>(a.emis) : reinterpret_cast<const short *>(smem);      // [nrows][Mpad] bias - cost, kNegPad outside the model
+  if constexpr (!EG) {
     const uint4 *ge = reinterpret_cast<const uint4 *>(a.emis);
-    uint4 *le = reinterpret_cast<uint4 *>(em);
+    uint4 *le = reinterpret_cast<uint4 *>(smem);
     for (int i = threadIdx.x; i < a.nrows * Mpad / 8; i += kWsBlock) le[i] = ge[i];
   }
   __syncthreads();
@@ -154,7 +158,7 @@ __global__ void __launch_bounds__(kWsBlock) msv_wave_kernel(const ArgRef ref)
     const uint8_t *sq = a.dsq + (((unsigned long long) hi << 32) | lo);
     const int tjbm = rfl((int) a.tjb_tab[L]) + a.tbm;
     int mm[C];
-#pragma unroll
+#pragma unroll unroll_c(C)
     for (int c = 0; c < C; ++c) mm[c] = 0;
     int xJ = 0, xEmax = 0;
     int xB = max(a.base - tjbm, 0);
@@ -173,7 +177,7 @@ __global__ void __launch_bounds__(kWsBlock) msv_wave_kernel(const ArgRef ref)
           const short *er = em + x * Mpad + lane;
           int mp = dpp_shr1(mm[C - 1], 0);
           int rowmax = kNegPad;
-#pragma unroll
+#pragma unroll unroll_c(C)
           for (int c = 0; c < C; ++c) {
             const int sv = max(mp, xB) + (int) er[c * 64];
             mp = mm[c];
@@ -188,14 +192,14 @@ __global__ void __launch_bounds__(kWsBlock) msv_wave_kernel(const ArgRef ref)
         }
         const int nb = min(kBlk, nrow - r0);
         int saved[C];
-#pragma unroll
+#pragma unroll unroll_c(C)
         for (int c = 0; c < C; ++c) saved[c] = mm[c];
         int blkmax = kNegPad;
         auto row_held = [&](int r) {
           const int x = __builtin_amdgcn_readlane((int) resid, r);
           const short *er = em + x * Mpad + lane;
           int mp = dpp_shr1(mm[C - 1], 0);
-#pragma unroll
+#pragma unroll unroll_c(C)
           for (int c = 0; c < C; ++c) {
             const int sv = max(mp, xB) + (int) er[c * 64];
             mp = mm[c];
@@ -219,14 +223,14 @@ __global__ void __launch_bounds__(kWsBlock) msv_wave_kernel(const ArgRef ref)
           xJ = max(xJ, xEb - a.tec);
           continue;
         }
-#pragma unroll
+#pragma unroll unroll_c(C)
         for (int c = 0; c < C; ++c) mm[c] = saved[c];
         for (int r = r0; r < r0 + nb; ++r) {
           const int x = __builtin_amdgcn_readlane((int) resid, r);
           const short *er = em + x * Mpad + lane;
           int mp = dpp_shr1(mm[C - 1], 0);
           int rowmax = kNegPad;
-#pragma unroll
+#pragma unroll unroll_c(C)
           for (int c = 0; c < C; ++c) {
             const int sv = max(mp, xB) + (int) er[c * 64];
             mp = mm[c];
@@ -372,11 +376,15 @@ __global__ void __launch_bounds__(kWsBlock) fwd_kernel(const ArgRef ref)
   const WaveSeqArgs a = load_args<WaveSeqArgs>(ref);
   const int nlist = (a.abort_flag && *a.abort_flag) ? 0 : (a.nlist_ptr ? *a.nlist_ptr : a.nlist);
   if ((int) (blockIdx.x * (kWsBlock / 64)) >= nlist) return;         // no item for this block: skip the table load
-  float4 *tr = reinterpret_cast<float4 *>(smem);                         // [2*Mpad]
+  constexpr bool TG = C > 64;         // M > 4096: the transitions no longer fit the LDS either and are read through L2
+  const float4 *tr = TG ? reinterpret_cast<const float4 *>(a.trans) : reinterpret_cast<const float4 *>(smem);      // [2*Mpad]
   const float *em = EG ? reinterpret_cast<const float *>(a.emis) : reinterpret_cast<const float *>(smem + (size_t) Mpad * 32);      // [kTabRows][Mpad]
   {
-    const float4 *gt = reinterpret_cast<const float4 *>(a.trans);
-    for (int i = threadIdx.x; i < 2 * Mpad; i += kWsBlock) tr[i] = gt[i];
+    if constexpr (!TG) {
+      const float4 *gt = reinterpret_cast<const float4 *>(a.trans);
+      float4 *lt = reinterpret_cast<float4 *>(smem);
+      for (int i = threadIdx.x; i < 2 * Mpad; i += kWsBlock) lt[i] = gt[i];
+    }
     if constexpr (!EG) {
       const float4 *ge = reinterpret_cast<const float4 *>(a.emis);
       float4 *le = reinterpret_cast<float4 *>(smem + (size_t) Mpad * 32);
@@ -394,11 +402,11 @@ __global__ void __launch_bounds__(kWsBlock) fwd_kernel(const ArgRef ref)
     const float pmove = (2.0f + 1.0f) / ((float) L + 2.0f + 1.0f), ploop = 1.0f - pmove;
 
     float mm[C], im[C], dm[C];
-#pragma unroll
+#pragma unroll unroll_c(C)
     for (int c = 0; c < C; ++c) mm[c] = im[c] = dm[c] = 0.0f;
     // product of this lane's D->D probabilities: the multiplier of an incoming D carry
     float ddprod = 1.0f;
-#pragma unroll
+#pragma unroll unroll_c(C)
     for (int c = 0; c < C; ++c) ddprod *= tr[2 * (c * 64 + lane) + 1].w;
 
     float xN = 1.0f, xB = pmove, xJ = 0.0f, xC = 0.0f, xE = 0.0f, totscale = 0.0f;
@@ -413,7 +421,7 @@ __global__ void __launch_bounds__(kWsBlock) fwd_kernel(const ArgRef ref)
       float mp = dpp_shr1f(mm[C - 1], 0.0f), ip = dpp_shr1f(im[C - 1], 0.0f), dp = dpp_shr1f(dm[C - 1], 0.0f);
       float esum = 0.0f, dcarry = 0.0f;
       float tdd[C], tmd[C];
-#pragma unroll
+#pragma unroll unroll_c(C)
       for (int c = 0; c < C; ++c) {
         const F8 t = load_f8(tr, c * 64 + lane);
         float sv = xB * t.bm;
@@ -429,14 +437,14 @@ __global__ void __launch_bounds__(kWsBlock) fwd_kernel(const ArgRef ref)
       }
       // D(i,k) = M(i,k-1) tMD(k-1) + D(i,k-1) tDD(k-1): serial inside the lane, affine scan across lanes
       float A = 0.0f;                                   // this lane's outgoing carry for a zero incoming carry
-#pragma unroll
+#pragma unroll unroll_c(C)
       for (int c = 0; c < C; ++c) { dm[c] = A; A = mm[c] * tmd[c] + A * tdd[c]; }
       float sa = A, sp = ddprod;                        // inclusive scan of (carry, multiplier)
       affine_scan_up(sa, sp);
       dcarry = dpp_shr1f(sa, 0.0f);                     // exclusive: the carry entering this lane
       {
         float w = dcarry;
-#pragma unroll
+#pragma unroll unroll_c(C)
         for (int c = 0; c < C; ++c) { dm[c] = dm[c] + w; esum = esum + dm[c]; w = w * tdd[c]; }
       }
       xE = wave_sum_f32(esum);
@@ -448,7 +456,7 @@ __global__ void __launch_bounds__(kWsBlock) fwd_kernel(const ArgRef ref)
       if (xE > 1.0e4f) {
         xN = xN / xE; xC = xC / xE; xJ = xJ / xE; xB = xB / xE;
         const float inv = (float) (1.0 / (double) xE);
-#pragma unroll
+#pragma unroll unroll_c(C)
         for (int c = 0; c < C; ++c) { mm[c] *= inv; dm[c] *= inv; im[c] *= inv; }
         scale = xE;
         totscale += (float) log((double) xE);
@@ -480,11 +488,15 @@ __global__ void __launch_bounds__(kWsBlock) bck_kernel(const ArgRef ref)
   const WaveSeqArgs a = load_args<WaveSeqArgs>(ref);
   const int nlist = (a.abort_flag && *a.abort_flag) ? 0 : (a.nlist_ptr ? *a.nlist_ptr : a.nlist);
   if ((int) (blockIdx.x * (kWsBlock / 64)) >= nlist) return;         // no item for this block: skip the table load
-  float4 *tr = reinterpret_cast<float4 *>(smem);
-  const float *em = EG ? reinterpret_cast<const float *>(a.emis) : reinterpret_cast<const float *>(smem + (size_t) Mpad * 32);
+  constexpr bool TG = C > 64;         // M > 4096: the transitions no longer fit the LDS either and are read through L2
+  const float4 *tr = TG ? reinterpret_cast<const float4 *>(a.trans) : reinterpret_cast<const float4 *>(smem);      // [2*Mpad]
+  const float *em = EG ? reinterpret_cast<const float *>(a.emis) : reinterpret_cast<const float *>(smem + (size_t) Mpad * 32);      // [kTabRows][Mpad]
   {
-    const float4 *gt = reinterpret_cast<const float4 *>(a.trans);
-    for (int i = threadIdx.x; i < 2 * Mpad; i += kWsBlock) tr[i] = gt[i];
+    if constexpr (!TG) {
+      const float4 *gt = reinterpret_cast<const float4 *>(a.trans);
+      float4 *lt = reinterpret_cast<float4 *>(smem);
+      for (int i = threadIdx.x; i < 2 * Mpad; i += kWsBlock) lt[i] = gt[i];
+    }
     if constexpr (!EG) {
       const float4 *ge = reinterpret_cast<const float4 *>(a.emis);
       float4 *le = reinterpret_cast<float4 *>(smem + (size_t) Mpad * 32);
@@ -507,13 +519,13 @@ __global__ void __launch_bounds__(kWsBlock) bck_kernel(const ArgRef ref)
     float nmm[C], nim[C], ndm[C];               // entering node k+1 (B->M uses node k itself: bm[c])
     float bm[C];
     float ddprod = 1.0f;
-#pragma unroll
+#pragma unroll unroll_c(C)
     for (int c = 0; c < C; ++c) {
       const F8 t = load_f8(tr, c * 64 + lane);
       tmd[c] = t.md; tdd[c] = t.dd; tmi[c] = t.mi; tii[c] = t.ii; bm[c] = t.bm;
       ddprod *= t.dd;
     }
-#pragma unroll
+#pragma unroll unroll_c(C)
     for (int c = 0; c < C; ++c) {
       float mmn, imn, dmn;
       if (c + 1 < C) { const F8 t = load_f8(tr, (c + 1) * 64 + lane); mmn = t.mm; imn = t.im; dmn = t.dm; }
@@ -535,29 +547,29 @@ __global__ void __launch_bounds__(kWsBlock) bck_kernel(const ArgRef ref)
     // across lanes in reverse lane order.  On entry dm[c] holds base(k); on exit the full D(i,k).
     auto d_chain = [&](float (&d)[C]) {
       float A = 0.0f;                                   // outgoing carry (towards lower k) for zero incoming
-#pragma unroll
+#pragma unroll unroll_c(C)
       for (int c = C - 1; c >= 0; --c) { A = d[c] + A * tdd[c]; }
       float sa = A, sp = ddprod;
       affine_scan_down(sa, sp, lane);
       float w = dpp_shl1f(sa, 0.0f);                    // D of the first node of the next lane
-#pragma unroll
+#pragma unroll unroll_c(C)
       for (int c = C - 1; c >= 0; --c) { d[c] = d[c] + w * tdd[c]; w = d[c]; }
     };
 
     // row L
-#pragma unroll
+#pragma unroll unroll_c(C)
     for (int c = 0; c < C; ++c) { mm[c] = xE; dm[c] = xE; im[c] = 0.0f; }
     d_chain(dm);
     {
       float dn = dpp_shl1f(dm[0], 0.0f);
-#pragma unroll
+#pragma unroll unroll_c(C)
       for (int c = C - 1; c >= 0; --c) { mm[c] = mm[c] + dn * tmd[c]; dn = dm[c]; }
     }
     float sc = __builtin_bit_cast(float, rfl(__builtin_bit_cast(int, fx[(size_t) L * 6 + 5])));
     if (sc > 1.0f) {
       xE = xE / sc; xN = xN / sc; xC = xC / sc; xJ = xJ / sc; xB = xB / sc;
       const float inv = (float) (1.0 / (double) sc);
-#pragma unroll
+#pragma unroll unroll_c(C)
       for (int c = 0; c < C; ++c) { mm[c] *= inv; dm[c] *= inv; im[c] *= inv; }
     }
     totscale = (float) log((double) sc);
@@ -568,13 +580,13 @@ __global__ void __launch_bounds__(kWsBlock) bck_kernel(const ArgRef ref)
       const float *er = em + x * Mpad + lane;
       // mp(k) = M(i+1,k+1) e(x_{i+1},k+1): value of the NEXT node
       float me[C];
-#pragma unroll
+#pragma unroll unroll_c(C)
       for (int c = 0; c < C; ++c) me[c] = mm[c] * er[c * 64];
       float bsum = 0.0f;
-#pragma unroll
+#pragma unroll unroll_c(C)
       for (int c = 0; c < C; ++c) bsum = bsum + me[c] * bm[c];
       const float me_next0 = dpp_shl1f(me[0], 0.0f);
-#pragma unroll
+#pragma unroll unroll_c(C)
       for (int c = 0; c < C; ++c) {
         const float mp = (c + 1 < C) ? me[c + 1] : me_next0;
         const float ipv = im[c];
@@ -587,12 +599,12 @@ __global__ void __launch_bounds__(kWsBlock) bck_kernel(const ArgRef ref)
       xJ = (xB * pmove) + (xJ * ploop);
       xN = (xB * pmove) + (xN * ploop);
       xE = (xC * a.xf_e_move) + (xJ * a.xf_e_loop);
-#pragma unroll
+#pragma unroll unroll_c(C)
       for (int c = 0; c < C; ++c) { dm[c] = dm[c] + xE; mm[c] = mm[c] + xE; }
       d_chain(dm);
       {
         float dn = dpp_shl1f(dm[0], 0.0f);
-#pragma unroll
+#pragma unroll unroll_c(C)
         for (int c = C - 1; c >= 0; --c) { mm[c] = mm[c] + dn * tmd[c]; dn = dm[c]; }
       }
       if (xB > 1.0e16f) own_scales = true;
@@ -600,7 +612,7 @@ __global__ void __launch_bounds__(kWsBlock) bck_kernel(const ArgRef ref)
       if (sc > 1.0f) {
         xE /= sc; xN /= sc; xJ /= sc; xB /= sc; xC /= sc;
         const float inv = (float) (1.0 / (double) sc);
-#pragma unroll
+#pragma unroll unroll_c(C)
         for (int c = 0; c < C; ++c) { mm[c] *= inv; dm[c] *= inv; im[c] *= inv; }
         totscale += (float) log((double) sc);
       }
@@ -611,7 +623,7 @@ __global__ void __launch_bounds__(kWsBlock) bck_kernel(const ArgRef ref)
       const int x = rfl((int) sq[0]);
       const float *er = em + x * Mpad + lane;
       float bsum = 0.0f;
-#pragma unroll
+#pragma unroll unroll_c(C)
       for (int c = 0; c < C; ++c) bsum = bsum + (mm[c] * er[c * 64]) * bm[c];
       xB = wave_sum_f32(bsum);
       xN = (xB * pmove) + (xN * ploop);
@@ -627,7 +639,7 @@ __global__ void __launch_bounds__(kWsBlock) bck_kernel(const ArgRef ref)
 }
 
 // ---------------------------------------------------------------------------- host side
-static const int kCList[] = { 1, 2, 3, 4, 5, 6, 8, 10, 12, 16, 20, 24, 32, 40 };
+static const int kCList[] = { 1, 2, 3, 4, 5, 6, 8, 10, 12, 16, 20, 24, 32, 48, 64, 96, 128 };      // M <= 8192
 
 int vit_pick_C(int M)
 {
@@ -686,7 +698,11 @@ static int launch_ws(K kernel, const ArgRun<WaveSeqArgs> &a, size_t lds_bytes, i
     case 20: return launch_ws(KERNEL<20>, a, (size_t) 64 * 20 * (BYTES_PER_NODE + nrows * EBYTES), num_cu, st); \
     case 24: return launch_ws(KERNEL<24>, a, (size_t) 64 * 24 * (BYTES_PER_NODE + nrows * EBYTES), num_cu, st); \
     case 32: return launch_ws(KERNEL<32>, a, (size_t) 64 * 32 * (BYTES_PER_NODE + nrows * EBYTES), num_cu, st); \
-    default: set_error("model too long for the wave-per-sequence kernels"); return P7X_EINVAL;             \
+    case 48: return launch_ws(KERNEL<48>, a, (size_t) 64 * 48 * BYTES_PER_NODE, num_cu, st);                \
+    case 64: return launch_ws(KERNEL<64>, a, (size_t) 64 * 64 * BYTES_PER_NODE, num_cu, st);                \
+    case 96: return launch_ws(KERNEL<96>, a, (size_t) 64 * 96 * BYTES_PER_NODE, num_cu, st);                \
+    case 128: return launch_ws(KERNEL<128>, a, (size_t) 64 * 128 * BYTES_PER_NODE, num_cu, st);             \
+    default: set_error("model too long for the wave-per-sequence kernels (M > 8192)"); return P7X_EINVAL;  \
   }
 
 int vit_launch(const ArgRun<WaveSeqArgs> &a, int num_cu, hipStream_t st)
@@ -711,7 +727,11 @@ int vit_launch(const ArgRun<WaveSeqArgs> &a, int num_cu, hipStream_t st)
     case 20: return launch_ws(KERNEL<20, true>, a, (size_t) 64 * 20 * 32, num_cu, st);                     \
     case 24: return launch_ws(KERNEL<24, true>, a, (size_t) 64 * 24 * 32, num_cu, st);                     \
     case 32: return launch_ws(KERNEL<32, true>, a, (size_t) 64 * 32 * 32, num_cu, st);                     \
-    default: set_error("model too long for the Forward/Backward kernels (M > 2048)"); return P7X_EINVAL;   \
+    case 48: return launch_ws(KERNEL<48, true>, a, (size_t) 64 * 48 * 32, num_cu, st);                     \
+    case 64: return launch_ws(KERNEL<64, true>, a, (size_t) 64 * 64 * 32, num_cu, st);                     \
+    case 96: return launch_ws(KERNEL<96, true>, a, (size_t) 256, num_cu, st);                              \
+    case 128: return launch_ws(KERNEL<128, true>, a, (size_t) 256, num_cu, st);                            \
+    default: set_error("model too long for the Forward/Backward kernels (M > 8192)"); return P7X_EINVAL;   \
   }
 
 int msv_wave_launch(const ArgRun<MsvWaveArgs> &a, int num_cu, hipStream_t st)
@@ -738,7 +758,7 @@ int msv_wave_launch(const ArgRun<MsvWaveArgs> &a, int num_cu, hipStream_t st)
     }
   }
   auto go = [&](auto kernel) -> int {
-    const size_t lds = (size_t) 64 * C * nrows * 2;
+    const size_t lds = C > 32 ? (size_t) 256 : (size_t) 64 * C * nrows * 2;
     int per_cu = 0;
     const int pst = blocks_per_cu(kernel, lds, &per_cu);
     if (pst != P7X_OK) return pst;
@@ -760,6 +780,10 @@ int msv_wave_launch(const ArgRun<MsvWaveArgs> &a, int num_cu, hipStream_t st)
     case 20: return go(msv_wave_kernel<20>);
     case 24: return go(msv_wave_kernel<24>);
     case 32: return go(msv_wave_kernel<32>);
+    case 48: return go(msv_wave_kernel<48>);
+    case 64: return go(msv_wave_kernel<64>);
+    case 96: return go(msv_wave_kernel<96>);
+    case 128: return go(msv_wave_kernel<128>);
     default: set_error("no wave-per-target MSV kernel for this model length"); return P7X_EINVAL;
   }
 }

@@ -117,6 +117,11 @@ __device__ __forceinline__ Item load_item(const WaveSeqArgs &a, int it)
   const int nwaves_ = (int) (gridDim.x * (kWsBlock / 64));                                                  \
   for (int it = wave0_; it < nlist; it += nwaves_)
 
+// Loops over the C nodes of a lane are unrolled (the row state then lives in registers) up to 32 nodes per lane; the
+// long-model instantiations beyond that (M > 2048) keep them rolled: the row state goes to scratch memory, the code
+// stays small, and such models -- a handful in any profile library -- run at a fraction of the speed, but they run.
+constexpr int unroll_c(int C) { return C <= 32 ? C : 1; }
+
 struct F8 { float bm, mm, im, dm, md, mi, ii, dd; };
 __device__ __forceinline__ F8 load_f8(const float4 *t, int idx)
 {

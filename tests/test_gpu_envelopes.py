@@ -16,6 +16,8 @@ from test_gpu_filters import _model_block
 pytestmark = pytest.mark.gpu
 
 ENV_TOL_BITS = 5e-3
+ENV_TOL_REL_LONG = 5e-5  # models of thousands of nodes (scores and null2 corrections of thousands / hundreds of bits, each a float32
+                         # sum over thousands of terms): relative, on top of ENV_TOL_BITS
 
 
 def _records(hits):
@@ -31,7 +33,7 @@ def _records(hits):
     return out
 
 
-def _compare(hmm, db, **opts):
+def _compare(hmm, db, rtol=1e-5, **opts):
     dev = _records(plan7.Pipeline(hmm.alphabet, **opts).search_hmm(hmm, db))
     host = _records(plan7.Pipeline(hmm.alphabet, host_envelopes=True, host_regions=True, **opts).search_hmm(hmm, db))
     # the region scan alone (same envelope kernel on both sides): everything must be identical, bit for bit
@@ -44,10 +46,10 @@ def _compare(hmm, db, **opts):
     assert [r[0] for r in dev] == [r[0] for r in host]
     ndom = 0
     for (name, sa, da), (_, sb, dbb) in zip(dev, host):
-        assert np.allclose(sa, sb, atol=ENV_TOL_BITS), name
+        assert np.allclose(sa, sb, atol=ENV_TOL_BITS, rtol=rtol), name
         assert len(da) == len(dbb), name
         for (ia, fa), (ib, fb) in zip(da, dbb):
-            assert np.allclose(fa, fb, atol=ENV_TOL_BITS), (name, fa, fb)
+            assert np.allclose(fa, fb, atol=ENV_TOL_BITS, rtol=rtol), (name, fa, fb)
             ndom += 1
             # The optimal-accuracy alignment is an argmax over float32 sums.  The device kernel flags every choice on its
             # trace that lies within the guard band of the runner-up (cfg.oa_guard) and the host twin repeats those
@@ -80,23 +82,25 @@ def test_device_envelopes_on_planted_workload():
     assert plan7.Pipeline(hmm.alphabet, oa_guard=0.0).search_hmm(hmm, db).guard_counts["oa_redone"] == 0
 
 
-@pytest.mark.parametrize("M", [5, 64, 65, 150, 256, 300, 384, 478, 500, 640, 768, 1000, 1024, 1100, 1500, 2048])
+@pytest.mark.parametrize("M", [5, 64, 65, 150, 256, 300, 384, 478, 500, 640, 768, 1000, 1024, 1100, 1500, 2048, 2049, 3000, 5000, 8192])
 def test_device_envelopes_for_every_kernel_instantiation(M):
     """Random models, one per nodes-per-lane instantiation of the envelope kernel."""
     hmm = random_hmm(M, seed=3000 + M)
     blk = _model_block(hmm, 300, 40, seed=M)
     db = plan7.SequenceDatabase(blk)
-    nhits, ndom = _compare(hmm, db, E=1e3, domE=1e3)
+    nhits, ndom = _compare(hmm, db, E=1e3, domE=1e3, rtol=ENV_TOL_REL_LONG if M > 2048 else 1e-5)
     assert ndom > 0 or M < 64
 
 
-@pytest.mark.parametrize("M", [1100, 2048])
+@pytest.mark.parametrize("M", [1100, 2048, 2049, 3000, 5000])
 def test_long_models_search_end_to_end(M):
-    """M > 1024: every stage on the device, the emission tables of the parsers and the envelope kernel read through L2."""
+    """M > 1024: every stage on the device, the emission tables of the parsers and the envelope kernel read through L2;
+    M > 2048 (the reference has no model-length limit, plan7.pyx:6156-6262): the long-model instantiations with the
+    lane's row state in scratch memory, M > 4096 with the transition tables through L2 as well."""
     hmm = random_hmm(M, seed=4000 + M)
     blk = _model_block(hmm, 150, 12, seed=M)
     db = plan7.SequenceDatabase(blk)
-    nhits, ndom = _compare(hmm, db, E=1e3, domE=1e3)
+    nhits, ndom = _compare(hmm, db, E=1e3, domE=1e3, rtol=ENV_TOL_REL_LONG if M > 2048 else 1e-5)
     assert ndom >= 12
 
 

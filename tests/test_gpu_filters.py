@@ -234,7 +234,8 @@ _PK_M = sorted({16 * p - d for p in (2, 4, 6, 8, 10, 12, 14, 15, 16, 17, 18, 19,
 
 
 @pytest.mark.parametrize("M", sorted(set([1, 3, 64, 65, 128, 150, 192, 256, 300, 320, 384, 479, 500, 512, 640, 641, 700, 768, 1000, 1024, 1025,
-                                          1280, 1500, 1536, 2000, 2048] + _PK_M)))
+                                          1280, 1500, 1536, 2000, 2048,
+                                          2049, 3000, 3072, 4096, 4097, 5000, 6144, 8192] + _PK_M)))   # M > 2048: rolled loops, tables through L2
 def test_every_wavefront_kernel_instantiation_vs_oracle(M, oracle):
     hmm = random_hmm(M, seed=2000 + M)
     bg = plan7.Background(hmm.alphabet)
