@@ -41,6 +41,7 @@ def build(force: bool = False, verbose: bool = False) -> Path:
     hipcc = _hipcc()
     common = ["-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math",
               "--offload-arch=gfx950", "-I", str(_ROOT / "include"), "-Wno-unused-result"]
+    common += os.environ.get("P7X_CXXFLAGS", "").split()        # build-time experiments (e.g. -DP7X_ENV_UNROLL_MAX=16)
     objs = []
     procs = []
     for s in srcs:

@@ -94,6 +94,8 @@ struct EnvelopeScorer;
 struct p7x_seqdb;
 #include <memory>
 namespace p7x {
+struct LongTargetWindowRegions;
+int device_regions_of_all(const p7x_oprofile *om, const p7x_seqdb *db, std::vector<LongTargetWindowRegions> &out);
 std::unique_ptr<EnvelopeScorer> make_device_envelope_scorer(DeviceCtx *ctx, const p7x_seqdb *db, float oa_guard);
 
 } // namespace p7x

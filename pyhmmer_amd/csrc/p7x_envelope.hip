@@ -28,6 +28,12 @@ namespace {
 
 constexpr float kNegInf = -__builtin_inff();
 
+// node loops of the envelope kernel: unrolled (row state in registers) up to this many nodes per lane, rolled beyond
+#ifndef P7X_ENV_UNROLL_MAX
+#define P7X_ENV_UNROLL_MAX 32
+#endif
+constexpr int unroll_env(int C) { return C <= P7X_ENV_UNROLL_MAX ? C : 1; }
+
 // p7T_* state codes (p7_trace.pxd), as the host uses them
 enum { tM = 1, tD = 2, tI = 3, tS = 4, tN = 5, tB = 6, tE = 7, tC = 8, tT = 9, tJ = 10 };
 
@@ -56,10 +62,10 @@ struct EnvForward {
   float xN, xB, xJ, xC, xE, scale, totscale;
   __device__ __forceinline__ void init(const float4 *tr, int lane, float pmove)
   {
-#pragma unroll unroll_c(C)
+#pragma unroll unroll_env(C)
     for (int c = 0; c < C; ++c) mm[c] = im[c] = dm[c] = 0.0f;
     ddprod = 1.0f;
-#pragma unroll unroll_c(C)
+#pragma unroll unroll_env(C)
     for (int c = 0; c < C; ++c) ddprod *= tr[2 * (c * 64 + lane) + 1].w;
     xN = 1.0f; xB = pmove; xJ = 0.0f; xC = 0.0f; xE = 0.0f; scale = 1.0f; totscale = 0.0f;
   }
@@ -70,7 +76,7 @@ struct EnvForward {
     float mp = dpp_shr1f(mm[C - 1], 0.0f), ip = dpp_shr1f(im[C - 1], 0.0f), dp = dpp_shr1f(dm[C - 1], 0.0f);
     float esum = 0.0f;
     float t_dd[C], t_md[C];
-#pragma unroll unroll_c(C)
+#pragma unroll unroll_env(C)
     for (int c = 0; c < C; ++c) {
       const F8 t = load_f8(tr, c * 64 + lane);
       float sv = xB * t.bm;
@@ -85,13 +91,13 @@ struct EnvForward {
       t_dd[c] = t.dd; t_md[c] = t.md;
     }
     float A = 0.0f;
-#pragma unroll unroll_c(C)
+#pragma unroll unroll_env(C)
     for (int c = 0; c < C; ++c) { dm[c] = A; A = mm[c] * t_md[c] + A * t_dd[c]; }
     float sa = A, sp = ddprod;
     affine_scan_up(sa, sp);
     {
       float w = dpp_shr1f(sa, 0.0f);
-#pragma unroll unroll_c(C)
+#pragma unroll unroll_env(C)
       for (int c = 0; c < C; ++c) { dm[c] = dm[c] + w; esum = esum + dm[c]; w = w * t_dd[c]; }
     }
     xE = wave_sum_f32(esum);
@@ -103,7 +109,7 @@ struct EnvForward {
     if (xE > 1.0e4f) {
       xN = xN / xE; xC = xC / xE; xJ = xJ / xE; xB = xB / xE;
       const float inv = (float) (1.0 / (double) xE);
-#pragma unroll unroll_c(C)
+#pragma unroll unroll_env(C)
       for (int c = 0; c < C; ++c) { mm[c] *= inv; dm[c] *= inv; im[c] *= inv; }
       scale = xE;
       totscale += (float) log((double) xE);
@@ -230,13 +236,13 @@ __global__ void __launch_bounds__(env_waves(C) * 64, env_waves(C) / 4) env_kerne
     {
       float t_md[C], t_dd[C], t_mi[C], t_ii[C], t_bm[C], n_mm[C], n_im[C], n_dm[C];
       float ddprod = 1.0f;
-#pragma unroll unroll_c(C)
+#pragma unroll unroll_env(C)
       for (int c = 0; c < C; ++c) {
         const F8 t = load_f8(tr, c * 64 + lane);
         t_md[c] = t.md; t_dd[c] = t.dd; t_mi[c] = t.mi; t_ii[c] = t.ii; t_bm[c] = t.bm;
         ddprod *= t.dd;
       }
-#pragma unroll unroll_c(C)
+#pragma unroll unroll_env(C)
       for (int c = 0; c < C; ++c) {          // transitions entering the NEXT node
         float mmn, imn, dmn;
         if (c + 1 < C) { const F8 t = load_f8(tr, (c + 1) * 64 + lane); mmn = t.mm; imn = t.im; dmn = t.dm; }
@@ -249,34 +255,34 @@ __global__ void __launch_bounds__(env_waves(C) * 64, env_waves(C) / 4) env_kerne
       float xE = xC * a.xf_e_move;
       auto d_chain = [&](float (&d)[C]) {
         float A = 0.0f;
-#pragma unroll unroll_c(C)
+#pragma unroll unroll_env(C)
         for (int c = C - 1; c >= 0; --c) { A = d[c] + A * t_dd[c]; }
         float sa = A, sp = ddprod;
         affine_scan_down(sa, sp, lane);
         float w = dpp_shl1f(sa, 0.0f);
-#pragma unroll unroll_c(C)
+#pragma unroll unroll_env(C)
         for (int c = C - 1; c >= 0; --c) { d[c] = d[c] + w * t_dd[c]; w = d[c]; }
       };
       auto store_row = [&](int r) {
         float *rm = bM + (size_t) r * Mpad + lane, *ri = bI + (size_t) r * Mpad + lane;
         if (lane_live) {
-#pragma unroll unroll_c(C)
+#pragma unroll unroll_env(C)
           for (int c = 0; c < C; ++c) { rm[c * 64] = mm[c]; ri[c * 64] = im[c]; }
         }
       };
-#pragma unroll unroll_c(C)
+#pragma unroll unroll_env(C)
       for (int c = 0; c < C; ++c) { mm[c] = xE; dm[c] = xE; im[c] = 0.0f; }
       d_chain(dm);
       {
         float dn = dpp_shl1f(dm[0], 0.0f);
-#pragma unroll unroll_c(C)
+#pragma unroll unroll_env(C)
         for (int c = C - 1; c >= 0; --c) { mm[c] = mm[c] + dn * t_md[c]; dn = dm[c]; }
       }
       float sc = rflf(fx[(size_t) Ld * 6 + 5]);
       if (sc > 1.0f) {
         xE = xE / sc; xN = xN / sc; xC = xC / sc; xJ = xJ / sc; xB = xB / sc;
         const float inv = (float) (1.0 / (double) sc);
-#pragma unroll unroll_c(C)
+#pragma unroll unroll_env(C)
         for (int c = 0; c < C; ++c) { mm[c] *= inv; dm[c] *= inv; im[c] *= inv; }
       }
       store_row(Ld);
@@ -295,13 +301,13 @@ __global__ void __launch_bounds__(env_waves(C) * 64, env_waves(C) / 4) env_kerne
         const float fsc = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, bk), 1));
         const float *er = em + x * Mpad + lane;
         float me[C];
-#pragma unroll unroll_c(C)
+#pragma unroll unroll_env(C)
         for (int c = 0; c < C; ++c) me[c] = mm[c] * er[c * 64];
         float bsum = 0.0f;
-#pragma unroll unroll_c(C)
+#pragma unroll unroll_env(C)
         for (int c = 0; c < C; ++c) bsum = bsum + me[c] * t_bm[c];
         const float me_next0 = dpp_shl1f(me[0], 0.0f);
-#pragma unroll unroll_c(C)
+#pragma unroll unroll_env(C)
         for (int c = 0; c < C; ++c) {
           const float mp = (c + 1 < C) ? me[c + 1] : me_next0;
           const float ipv = im[c];
@@ -314,12 +320,12 @@ __global__ void __launch_bounds__(env_waves(C) * 64, env_waves(C) / 4) env_kerne
         xJ = (xB * pmove) + (xJ * ploop);
         xN = (xB * pmove) + (xN * ploop);
         xE = (xC * a.xf_e_move) + (xJ * a.xf_e_loop);
-#pragma unroll unroll_c(C)
+#pragma unroll unroll_env(C)
         for (int c = 0; c < C; ++c) { dm[c] = dm[c] + xE; mm[c] = mm[c] + xE; }
         d_chain(dm);
         {
           float dn = dpp_shl1f(dm[0], 0.0f);
-#pragma unroll unroll_c(C)
+#pragma unroll unroll_env(C)
           for (int c = C - 1; c >= 0; --c) { mm[c] = mm[c] + dn * t_md[c]; dn = dm[c]; }
         }
         if (xB > 1.0e16f) own_scales = true;
@@ -327,7 +333,7 @@ __global__ void __launch_bounds__(env_waves(C) * 64, env_waves(C) / 4) env_kerne
         if (sc > 1.0f) {
           xE /= sc; xN /= sc; xJ /= sc; xB /= sc; xC /= sc;
           const float inv = (float) (1.0 / (double) sc);
-#pragma unroll unroll_c(C)
+#pragma unroll unroll_env(C)
           for (int c = 0; c < C; ++c) { mm[c] *= inv; dm[c] *= inv; im[c] *= inv; }
         }
         store_row(i);
@@ -337,7 +343,7 @@ __global__ void __launch_bounds__(env_waves(C) * 64, env_waves(C) / 4) env_kerne
         const int x = rfl((int) sq[0]);
         const float *er = em + x * Mpad + lane;
         float bsum = 0.0f;
-#pragma unroll unroll_c(C)
+#pragma unroll unroll_env(C)
         for (int c = 0; c < C; ++c) bsum = bsum + (mm[c] * er[c * 64]) * t_bm[c];
         xB = wave_sum_f32(bsum);
         xN = (xB * pmove) + (xN * ploop);
@@ -348,16 +354,16 @@ __global__ void __launch_bounds__(env_waves(C) * 64, env_waves(C) / 4) env_kerne
 
     // ------------------------------------------------------------------ 3. decoding, null2 sums, optimal accuracy
     float oasc;
-    int e_row = -1, e_k = 0, e_s = 0, e_near = 0;
+    int e_row = -1, e_k = 0, e_s = 0, e_near = 0, c_near_row = -1;
     {
       float scaleproduct = (float) (1.0 / (double) bck_xN0);
       bool ddpass = true;                                            // every D->D transition of this lane is open
-#pragma unroll unroll_c(C)
+#pragma unroll unroll_env(C)
       for (int c = 0; c < C; ++c) ddpass = ddpass && (tr[2 * (c * 64 + lane) + 1].w > 0.0f);
       float p_md0, p_dd0;                                            // leaving transitions of the previous lane's last node
       { const F8 t = load_f8(tr, (C - 1) * 64 + lane); p_md0 = dpp_shr1f(t.md, 0.0f); p_dd0 = dpp_shr1f(t.dd, 0.0f); }
       float om_[C], oi_[C], od_[C], msum[C], isum[C];
-#pragma unroll unroll_c(C)
+#pragma unroll unroll_env(C)
       for (int c = 0; c < C; ++c) { om_[c] = oi_[c] = od_[c] = kNegInf; msum[c] = isum[c] = 0.0f; }
       float oE = kNegInf, oN = 0.0f, oJ = kNegInf, oB = 0.0f, oC = kNegInf;
       float eN = 0.0f, eJ = 0.0f, eC = 0.0f;
@@ -368,7 +374,7 @@ __global__ void __launch_bounds__(env_waves(C) * 64, env_waves(C) / 4) env_kerne
       float nbm[C], nbi[C];
       auto fetch_row = [&](int r, float (&c2)[C], float (&d)[C]) {
         const float *rbm = bM + (size_t) r * Mpad + lane, *rbi = bI + (size_t) r * Mpad + lane;
-#pragma unroll unroll_c(C)
+#pragma unroll unroll_env(C)
         for (int c = 0; c < C; ++c) { c2[c] = lane_live ? rbm[c * 64] : 0.0f; d[c] = lane_live ? rbi[c * 64] : 0.0f; }
       };
       EnvForward<C> f;                 // Forward again, row by row, next to the decoding
@@ -384,7 +390,7 @@ __global__ void __launch_bounds__(env_waves(C) * 64, env_waves(C) / 4) env_kerne
       float xprev = fetch_x(0), xcur = fetch_x(1);
       for (int r = 1; r <= Ld; ++r) {
         float cbm[C], cbi[C];
-#pragma unroll unroll_c(C)
+#pragma unroll unroll_env(C)
         for (int c = 0; c < C; ++c) { cbm[c] = nbm[c]; cbi[c] = nbi[c]; }
         const float xthis = xcur;
         const int rn = (r < Ld) ? r + 1 : r;                 // the last iteration re-reads its own row (harmless)
@@ -397,7 +403,7 @@ __global__ void __launch_bounds__(env_waves(C) * 64, env_waves(C) / 4) env_kerne
         const float fS = xval(xthis, 5), bS = xval(xthis, 8 + 5);
         const float totr = scaleproduct * fS;
         float ppm[C], ppi[C];
-#pragma unroll unroll_c(C)
+#pragma unroll unroll_env(C)
         for (int c = 0; c < C; ++c) {
           ppm[c] = (cfm[c] * cbm[c]) * totr;
           ppi[c] = (cfi[c] * cbi[c]) * totr;
@@ -416,7 +422,7 @@ __global__ void __launch_bounds__(env_waves(C) * 64, env_waves(C) / 4) env_kerne
         float mp = dpp_shr1f(om_[C - 1], kNegInf), ip = dpp_shr1f(oi_[C - 1], kNegInf), dp = dpp_shr1f(od_[C - 1], kNegInf);
         unsigned short code[C];
         float t_md[C], t_dd[C];
-#pragma unroll unroll_c(C)
+#pragma unroll unroll_env(C)
         for (int c = 0; c < C; ++c) {
           const F8 t = load_f8(tr, c * 64 + lane);
           t_md[c] = t.md; t_dd[c] = t.dd;
@@ -448,18 +454,18 @@ __global__ void __launch_bounds__(env_waves(C) * 64, env_waves(C) / 4) env_kerne
         // D(r,k) = max(gate(tMD(k-1), M(r,k-1)), tDD(k-1) > 0 ? D(r,k-1) : 0), D(r,1) = -inf: a segmented max-scan
         {
           float w = kNegInf;
-#pragma unroll unroll_c(C)
+#pragma unroll unroll_env(C)
           for (int c = 0; c < C; ++c) w = vmax(gate(t_md[c], om_[c]), t_dd[c] > 0.0f ? w : 0.0f);
           float sa = w; int sp = ddpass ? 1 : 0;
           gated_max_scan_up(sa, sp);
           w = dpp_shr1f(sa, kNegInf);
-#pragma unroll unroll_c(C)
+#pragma unroll unroll_env(C)
           for (int c = 0; c < C; ++c) { od_[c] = w; w = vmax(gate(t_md[c], om_[c]), t_dd[c] > 0.0f ? w : 0.0f); }
         }
         {
           float pm = dpp_shr1f(om_[C - 1], kNegInf), pd = dpp_shr1f(od_[C - 1], kNegInf);
           float pmd = p_md0, pdd = p_dd0;
-#pragma unroll unroll_c(C)
+#pragma unroll unroll_env(C)
           for (int c = 0; c < C; ++c) {
             const float d0 = block(pmd, pm), d1 = block(pdd, pd);
             const int dchoice = (d0 >= d1) ? 0 : 1;
@@ -472,12 +478,12 @@ __global__ void __launch_bounds__(env_waves(C) * 64, env_waves(C) / 4) env_kerne
         {
           unsigned short *rb = bp + (size_t) r * Mpad + lane;
           if (lane_live) {
-#pragma unroll unroll_c(C)
+#pragma unroll unroll_env(C)
             for (int c = 0; c < C; ++c) rb[c * 64] = code[c];
           }
         }
         float rowmax = kNegInf;
-#pragma unroll unroll_c(C)
+#pragma unroll unroll_env(C)
         for (int c = 0; c < C; ++c) if (lane * C + c + 1 <= a.M) rowmax = vmax(rowmax, vmax(om_[c], od_[c]));
         oE = wave_max_f32(rowmax);
         float t1, t2;
@@ -487,6 +493,7 @@ __global__ void __launch_bounds__(env_waves(C) * 64, env_waves(C) / 4) env_kerne
         t1 = !loopJ ? 0.0f : oC + ppC;                 // C, J and N share one loop probability
         t2 = !moveE ? 0.0f : oE;
         const int c_from_e = rfl((int) !(t1 > t2));    // what select_c will decide at this row (wave-uniform)
+        if constexpr (G) { if (near_tie(t1, t2, a.oa_guard)) c_near_row = r; }     // ... and whether that decision was a close one
         oC = fmaxf(t1, t2);
         oN = !loopJ ? 0.0f : oN + ppN;
         t1 = !moveNJ ? 0.0f : oN;
@@ -498,7 +505,7 @@ __global__ void __launch_bounds__(env_waves(C) * 64, env_waves(C) / 4) env_kerne
           // maximum wins; without one, the FIRST D cell that does.
           int keyM = 0, keyD = 0, nearM = 0;
           const float ethr = oE - guard_band(oE, a.oa_guard);
-#pragma unroll unroll_c(C)
+#pragma unroll unroll_env(C)
           for (int c = 0; c < C; ++c) {
             const int k = lane * C + c + 1;
             if (k <= a.M) {
@@ -536,7 +543,7 @@ __global__ void __launch_bounds__(env_waves(C) * 64, env_waves(C) / 4) env_kerne
       for (int x = 0; x < a.K; ++x) {
         const float *er = em + x * Mpad + lane;
         float s = 0.0f;
-#pragma unroll unroll_c(C)
+#pragma unroll unroll_env(C)
         for (int c = 0; c < C; ++c) { s = s + (msum[c] * norm) * er[c * 64]; s = s + isum[c] * norm; }
         s = wave_sum_f32(s);
         if (lane == 0) n2[x] = s + xfactor;
@@ -544,24 +551,52 @@ __global__ void __launch_bounds__(env_waves(C) * 64, env_waves(C) / 4) env_kerne
     }
     phase_fence();
 
-    // ------------------------------------------------------------------ 4. traceback (p7_OATrace), lane 0
+    // ------------------------------------------------------------------ 4. traceback (p7_OATrace)
+    // The walk is serial, but most of it needs no decision at all: the C states from the last row down to the row where
+    // C took E (known from phase 3) and the N states from the first aligned row up are runs that all lanes write side by
+    // side; in between, the M / I / D steps read one 16-bit code each -- a dependent memory access per step when done
+    // naively.  Here all lanes walk together (the state is wave-uniform) and fetch the codes of the 64 cells DOWN THE
+    // DIAGONAL from the current one in one go: a match-to-match step finds its code in a register, only an insert or a
+    // delete (or 64 matches) makes a new fetch.
     uint32_t *ta = a.tr_a + a.tr_off[it];
     int32_t *ti = a.tr_i + a.tr_off[it];
     float *tp = a.tr_pp + a.tr_off[it];
     int n = 0;
-    if (lane == 0) {
+    {
       const int cap = Ld + a.M + 16;
       int i = Ld, k = 0, s0 = tC;
-      ta[n] = tT; ti[n] = i; ++n;
-      ta[n] = tC; ti[n] = i; ++n;
+      if (lane == 0) { ta[0] = tT; ti[0] = i; ta[1] = tC; ti[1] = i; }
+      n = 2;
       const float t1c = (ploop == 0.0f) ? 0.0f : 1.0f, t2e_move = (a.xf_e_move == 0.0f) ? 0.0f : 1.0f;
       const float t2e_loop = (a.xf_e_loop == 0.0f) ? 0.0f : 1.0f, tmove = (pmove == 0.0f) ? 0.0f : 1.0f;
+      if (e_row >= 1 && e_s >= 0 && t1c != 0.0f && t2e_move != 0.0f) {
+        // C <- C at rows Ld .. e_row + 1 (phase 3 saw C take E for the last time at e_row), then C <- E at e_row
+        const int nc = Ld - e_row;
+        for (int z = lane; z < nc; z += 64) { ta[2 + z] = (uint32_t) tC | 0x80000000u; ti[2 + z] = Ld - z; }
+        n += nc;
+        if (G && c_near_row >= e_row) status |= 64 | (1 << 11);
+        i = e_row;
+        if (lane == 0) { ta[n] = (uint32_t) tE; ti[n] = i; }
+        ++n;
+        s0 = tE;
+      }
+      int di = -1, dk = -1;                  // <diag> of lane l holds the code of cell (di - l, dk - l)
+      uint32_t diag = 0;
+      auto code_at = [&](int ci, int ck) -> unsigned {
+        int l = di - ci;
+        if (!(l >= 0 && l < 64 && dk - ck == l)) {
+          di = ci; dk = ck; l = 0;
+          const int ii = ci - lane, kk = ck - lane;
+          diag = (ii >= 1 && kk >= 1) ? (uint32_t) bp[(size_t) ii * Mpad + ((kk - 1) % C) * 64 + (kk - 1) / C] : 0u;
+        }
+        return (unsigned) __builtin_amdgcn_readlane((int) diag, l);
+      };
       while (s0 != tS && n < cap) {
         int s1 = -1;
         switch (s0) {
           case tM: {
             if (i < 1 || k < 1) { status |= 4; break; }
-            const unsigned w16 = bp[(size_t) i * Mpad + ((k - 1) % C) * 64 + (k - 1) / C];
+            const unsigned w16 = code_at(i, k);
             const int code = w16 & 3;
             if (w16 & (1u << 12)) status |= 64 | (1 << 8);
             s1 = (code == 0) ? tM : (code == 1) ? tI : (code == 2) ? tD : tB;
@@ -570,7 +605,7 @@ __global__ void __launch_bounds__(env_waves(C) * 64, env_waves(C) / 4) env_kerne
           }
           case tD: {
             if (i < 1 || k < 1) { status |= 4; break; }
-            const unsigned w16 = bp[(size_t) i * Mpad + ((k - 1) % C) * 64 + (k - 1) / C];
+            const unsigned w16 = code_at(i, k);
             const int code = (w16 >> 3) & 1;
             if (w16 & (1u << 14)) status |= 64 | (1 << 10);
             s1 = code ? tD : tM; --k;
@@ -578,13 +613,25 @@ __global__ void __launch_bounds__(env_waves(C) * 64, env_waves(C) / 4) env_kerne
           }
           case tI: {
             if (i < 1 || k < 1) { status |= 4; break; }
-            const unsigned w16 = bp[(size_t) i * Mpad + ((k - 1) % C) * 64 + (k - 1) / C];
+            const unsigned w16 = code_at(i, k);
             const int code = (w16 >> 2) & 1;
             if (w16 & (1u << 13)) status |= 64 | (1 << 9);
             s1 = code ? tI : tM; --i;
             break;
           }
-          case tN: s1 = (i == 0) ? tS : tN; break;
+          case tN: {
+            // N <- N at rows i .. 1, then S at row 0: i + 1 entries, written side by side
+            const int room = cap - n, want = i + 1, cnt = want < room ? want : room;
+            for (int z = lane; z < cnt; z += 64) {
+              const bool last = z == i;
+              ta[n + z] = (uint32_t) (last ? tS : tN) | ((uint32_t) k << 8) | (last ? 0u : 0x80000000u);
+              ti[n + z] = last ? 0 : i - z;
+            }
+            n += cnt;
+            s0 = cnt == want ? tS : tN;
+            i = 0;
+            continue;
+          }
           case tC: {
             if (i < 1) { status |= 4; break; }
             const float p0 = t1c * (ox[(size_t) (i - 1) * 5 + 4] + px[(size_t) i * 3 + 2]), p1 = t2e_move * ox[(size_t) i * 5 + 0];
@@ -611,8 +658,8 @@ __global__ void __launch_bounds__(env_waves(C) * 64, env_waves(C) / 4) env_kerne
           default: break;
         }
         if (s1 == -1) { status |= 16; break; }
-        ta[n] = (uint32_t) s1 | ((uint32_t) k << 8) | ((s1 == s0) ? 0x80000000u : 0u);
-        ti[n] = i; ++n;
+        if (lane == 0) { ta[n] = (uint32_t) s1 | ((uint32_t) k << 8) | ((s1 == s0) ? 0x80000000u : 0u); ti[n] = i; }
+        ++n;
         if ((s1 == tN || s1 == tJ || s1 == tC) && s1 == s0) --i;
         s0 = s1;
       }

@@ -154,6 +154,7 @@ void longtarget_seeds_from_rows(const Profile &p, const uint8_t *block_dsq, int6
 // <strand> starting at original position <start> (strand 1: running towards lower positions, complemented).
 struct LongTargetWindowRef { int64_t start, length; int strand; };
 struct LongTargetWindowScore { float usc, bias_filtersc, vfsc; int have_vit; };
+struct LongTargetWindowRegions { int n = -2; float nexpected = 0.0f; std::vector<Region> regs; };
 struct LongTargetWindowScorer {
   virtual ~LongTargetWindowScorer() = default;
   // seq1: the target, 1-based; sc[w]: MSV score (nats), bias filter score, and for windows that pass both P <= F1 tests
@@ -165,6 +166,10 @@ struct LongTargetWindowScorer {
   virtual int viterbi(const int *which, const int *thresh, size_t n, std::vector<int> &rec) = 0;
   // p7_ForwardParser scores (nats) of another set of windows of the same target (the Viterbi windows)
   virtual int forward(const uint8_t *seq1, const uint8_t *comp, const LongTargetWindowRef *w, size_t nw, float *fwdsc) = 0;
+  // Forward + Backward parsers, posterior decoding of the special states and the region scan (the first step of
+  // p7_domaindef_ByPosteriorHeuristics) of the windows that passed the Forward filter, in one device batch:
+  // out[w].n regions (-1: p7_DomainDecoding range error, the window is dropped; -2: not available, the host scans)
+  virtual int regions(const uint8_t *seq1, const uint8_t *comp, const LongTargetWindowRef *w, size_t nw, std::vector<LongTargetWindowRegions> &out) = 0;
 };
 int longtarget_run_host(const p7x_pipeline_cfg &cfg, const p7x_oprofile *om, const uint8_t *dsq, const int64_t *offsets, const int64_t *lengths,
                         size_t n, const char *const *names, const char *const *accs, const char *const *descs,

@@ -164,6 +164,8 @@ struct SsvLongArgs {
   const uint32_t *tab_full;   // [2][Kp][R][64] the same for every residue code (degenerate residues, read from global memory)
   const uint8_t *dsq;         // the target, 1-based (dsq[0] is a sentinel)
   const uint8_t *comp;        // [Kp] complement of every residue code
+  int pair_slack;             // register kernel: the most a cell can lose in one row with a canonical residue (byte units)
+  int use_lds;                // 1: the LDS kernel also where the register kernel exists (A/B, tests)
   const long long *chunk_list;  // NULL: every chunk; else the nchunks chunk numbers to scan (a part of a search dealt over devices)
   long long L;                // target length
   int M, Kp;
@@ -176,7 +178,8 @@ struct SsvLongArgs {
   int *nrec; long long *rec_pos; uint8_t *rec_strand; int *rec_k; int *rec_sc; int rec_cap;
 };
 int  ssvlong_pick_R(int M);
-void ssvlong_build_tables(const Profile &p, int R, std::vector<uint32_t> &tab4, std::vector<uint32_t> &tab_full);
+void ssvlong_build_tables(const Profile &p, int R, bool virtual_node, std::vector<uint32_t> &tab4, std::vector<uint32_t> &tab_full, int *pair_slack);
+constexpr int kSsvRegMaxR = 24;     // up to this many packed registers per lane the emission pairs live in registers (ssvlong_reg_kernel)
 int  ssvlong_launch(int R, const SsvLongArgs &a, int num_cu, hipStream_t st);
 
 // ---- thread-per-sequence small stages (p7x_pipeline.hip)

@@ -35,7 +35,8 @@ static int scan_target(const p7x_pipeline_cfg &cfg, const Profile &p, DeviceCtx 
   const int R = ssvlong_pick_R(p.M);
   if (R < 0) { set_error("model too long for the long-target SSV kernel (M > 6141)"); return P7X_EINVAL; }
   std::vector<uint32_t> tab4, tab_full;
-  ssvlong_build_tables(p, R, tab4, tab_full);
+  int pair_slack = 0;
+  ssvlong_build_tables(p, R, false, tab4, tab_full, &pair_slack);
   DevBuf d_tab4, d_full, d_seq, d_comp, d_nrec, d_pos, d_strand, d_k, d_sc;
   int st;
   if ((st = d_tab4.alloc(tab4.size() * 4)) || (st = d_full.alloc(tab_full.size() * 4)) || (st = d_seq.alloc((size_t) L + 2)) ||
@@ -58,6 +59,7 @@ static int scan_target(const p7x_pipeline_cfg &cfg, const Profile &p, DeviceCtx 
   a.thresh_s = sc_thresh - xB - 32768; a.xB = xB; a.Q16 = p.Q16();
   a.nrec = static_cast<int *>(d_nrec.p);
   a.strand0 = strands_mask == 2 ? 1 : 0;
+  a.pair_slack = pair_slack; a.use_lds = R > kSsvRegMaxR ? 1 : 0;
   DevBuf d_chunks;
   if (ranges) {
     std::vector<long long> list;
@@ -204,6 +206,22 @@ struct DeviceWindowScorer final : LongTargetWindowScorer {
     if (st != P7X_OK) return st;
     st = p7x_filters_batch(om, fdb, nullptr, nullptr, fwdsc, nullptr);
     p7x_seqdb_destroy(fdb);
+    ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    return st;
+  }
+
+  int regions(const uint8_t *seq1, const uint8_t *comp, const LongTargetWindowRef *w, size_t nw, std::vector<LongTargetWindowRegions> &out) override
+  {
+    out.assign(nw, LongTargetWindowRegions{});
+    if (nw == 0) return P7X_OK;
+    const auto t0 = std::chrono::steady_clock::now();
+    std::vector<uint8_t> dsq; std::vector<int64_t> off; std::vector<int32_t> len;
+    pack_windows(seq1, comp, w, nw, dsq, off, len);
+    p7x_seqdb *rdb = nullptr;
+    int st = p7x_seqdb_create(device, om->p.abc_type, dsq.data(), off.data(), len.data(), nw, &rdb);
+    if (st != P7X_OK) return st;
+    st = device_regions_of_all(om, rdb, out);
+    p7x_seqdb_destroy(rdb);
     ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     return st;
   }

@@ -533,9 +533,8 @@ struct LtCounters { uint64_t n_past_msv = 0, n_past_bias = 0, n_past_vit = 0, n_
 // blk.dsq is not used here: <subseq>[1..window_len] are the window's residues; blk.start / blk.complement and
 // window_start (the window's first residue in the block) map coordinates back to the target.  fwd_given: the window's
 // Forward parser score when it was computed elsewhere (the device batch).
-static int lt_post_viterbi(const p7x_pipeline_cfg &cfg, const Profile &p, const LongTargetOpts &lto, int max_length, uint64_t nres_so_far,
-                           const LtBlock &blk, const LtTarget &tg, int64_t window_start, int64_t window_len, const uint8_t *subseq,
-                           const float *fwd_given, std::vector<Hit> &hits, LtCounters &ctr)
+// The Forward filter of one Viterbi window (p7_pli_postViterbi_LongTarget up to the F3 test): true when it passes.
+static bool lt_forward_test(const p7x_pipeline_cfg &cfg, const Profile &p, int64_t window_len, const uint8_t *subseq, float fwdsc)
 {
   const int64_t F3_L = std::min<int64_t>(window_len, cfg.B3);
   const float nullsc = lt_null1(window_len);
@@ -545,31 +544,41 @@ static int lt_post_viterbi(const p7x_pipeline_cfg &cfg, const Profile &p, const 
     bias_filtersc -= nullsc;
     filtersc = nullsc + (bias_filtersc * (F3_L > window_len ? 1.0f : (float) F3_L / (float) window_len));
   }
-  Model om{ &p, p.M, {} };
-  om.prepare();
-  om.configure(true, (int) window_len);
-  std::vector<float> fx, bx;
-  float fwdsc = 0.0f;
-  if (fwd_given) fwdsc = *fwd_given; else lt_forward_parser(om, subseq, (int) window_len, fx, &fwdsc);
   const float seq_score = (fwdsc - filtersc) / (float) kLog2;
-  const double P = exp_surv(seq_score, p.evparam[P7X_FTAU], p.evparam[P7X_FLAMBDA]);
-  if (P > cfg.F3) return P7X_OK;
+  return !(exp_surv(seq_score, p.evparam[P7X_FTAU], p.evparam[P7X_FLAMBDA]) > cfg.F3);
+}
+
+// The rest of p7_pli_postViterbi_LongTarget for a window that passed the Forward filter: Backward, domain definition
+// with long_target = TRUE, one hit per domain.  <dev>: the device's region scan of this window (n >= 0), else the host
+// runs the parsers itself.
+static int lt_post_viterbi(const p7x_pipeline_cfg &cfg, const Profile &p, const LongTargetOpts &lto, int max_length, uint64_t nres_so_far,
+                           const LtBlock &blk, const LtTarget &tg, int64_t window_start, int64_t window_len, const uint8_t *subseq,
+                           float fwdsc, const LongTargetWindowRegions *dev, std::vector<Hit> &hits, LtCounters &ctr)
+{
   ctr.n_past_fwd++; ctr.pos_past_fwd += (uint64_t) window_len;
-  // Backward parser rows: the full-matrix routine on the window would need L x M floats; the region scan only needs the
-  // special states, which the generic Backward delivers row by row.  Windows are a few max_length long.
-  {
-    float sc2 = 0.0f;
-    if (fwd_given || fx.size() != (size_t) (window_len + 1) * NX) lt_forward_parser(om, subseq, (int) window_len, fx, &sc2);
-    lt_backward_parser(om, subseq, (int) window_len, fx, bx);
-  }
   DomainDefResult dd;
+  int st = P7X_OK;
+  if (dev && dev->n == -1) return P7X_OK;                      // p7_DomainDecoding: eslERANGE, nothing comes of this window
   t_long_target = &lto;
-  const int st = domaindef_by_posterior_heuristics(p, subseq, (int) window_len, fx.data(), bx.data(), cfg.seed, cfg.seed != 0, dd, nullptr, 0);
+  if (dev && dev->n >= 0) {
+    st = domaindef_from_regions(p, subseq, (int) window_len, dev->nexpected, dev->regs.data(), dev->n, cfg.seed, cfg.seed != 0, dd, nullptr, 0);
+  } else {
+    // Backward parser rows: the full-matrix routine on the window would need L x M floats; the region scan only needs the
+    // special states, which the generic Backward delivers row by row.  Windows are a few max_length long.
+    Model om{ &p, p.M, {} };
+    om.prepare();
+    om.configure(true, (int) window_len);
+    std::vector<float> fx, bx;
+    float sc2 = 0.0f;
+    lt_forward_parser(om, subseq, (int) window_len, fx, &sc2);
+    lt_backward_parser(om, subseq, (int) window_len, fx, bx);
+    st = domaindef_by_posterior_heuristics(p, subseq, (int) window_len, fx.data(), bx.data(), cfg.seed, cfg.seed != 0, dd, nullptr, 0);
+  }
   t_long_target = nullptr;
   if (st != P7X_OK) return st == P7X_ERANGE ? P7X_OK : st;
   if (std::getenv("P7X_LT_DEBUG")) {
-    std::fprintf(stderr, "[lt] window start %lld len %lld compl %d fwd %.3f P %.3g: nregions %d nclustered %d nenvelopes %d ndom %zu\n",
-                 (long long) window_start, (long long) window_len, (int) blk.complement, fwdsc, P, dd.nregions, dd.nclustered, dd.nenvelopes, dd.dcl.size());
+    std::fprintf(stderr, "[lt] window start %lld len %lld compl %d fwd %.3f: nregions %d nclustered %d nenvelopes %d ndom %zu\n",
+                 (long long) window_start, (long long) window_len, (int) blk.complement, fwdsc, dd.nregions, dd.nclustered, dd.nenvelopes, dd.dcl.size());
     for (const Domain &d : dd.dcl) std::fprintf(stderr, "[lt]   env %lld-%lld ali %lld-%lld hmm %d-%d envsc %.3f domcorr %.3f\n", (long long) d.ienv, (long long) d.jenv,
                                                  (long long) d.iali, (long long) d.jali, d.hmmfrom, d.hmmto, d.envsc, d.domcorrection);
   }
@@ -926,20 +935,63 @@ static int lt_run_host(const p7x_pipeline_cfg &cfg, const p7x_oprofile *om, cons
       if (st != P7X_OK) return st;
     }
     tick("Forward of the Viterbi windows");
+    // the Forward filter of every Viterbi window (with the device's scores a bias-filter pass over the window and a few
+    // flops; without a device the Forward parser itself runs here), then -- one device batch again -- the parsers' rows
+    // and the region scan of the windows that passed, so that the host starts at the envelopes
+    std::vector<std::vector<uint8_t>> subs(vj.size());
+    std::vector<float> fwd_of(vj.size(), 0.0f);
+    std::vector<char> pass(vj.size(), 0);
+    auto geometry = [&](size_t z, const BlockJob *&job, int64_t &bp) {
+      job = flat[vj[z].q].first; const LtWindow &w = job->windows[flat[vj[z].q].second];
+      bp = w.n + vj[z].vw.n - 1;
+    };
+    host_parallel_for((int) vj.size(), cfg.host_threads, [&](int zi) {
+      const size_t z = (size_t) zi;
+      flogsum_init();
+      const BlockJob *job; int64_t bp; geometry(z, job, bp);
+      fetch(*job, bp, vj[z].vw.length, subs[z]);
+      if (!fwd_dev.empty()) fwd_of[z] = fwd_dev[z];
+      else {
+        Model om{ &p, p.M, {} };
+        om.prepare(); om.configure(true, (int) vj[z].vw.length);
+        std::vector<float> fx;
+        lt_forward_parser(om, subs[z].data(), (int) vj[z].vw.length, fx, &fwd_of[z]);
+      }
+      pass[z] = lt_forward_test(cfg, p, vj[z].vw.length, subs[z].data(), fwd_of[z]) ? 1 : 0;
+      if (!pass[z]) std::vector<uint8_t>().swap(subs[z]);
+    });
+    tick("Forward filter of the Viterbi windows");
+    std::vector<LongTargetWindowRegions> dev_regions;
+    std::vector<int> dev_of(vj.size(), -1);
+    if (filters) {
+      std::vector<LongTargetWindowRef> prefs;
+      for (size_t z = 0; z < vj.size(); ++z) if (pass[z]) {
+        const BlockJob *job; int64_t bp; geometry(z, job, bp);
+        LongTargetWindowRef r; r.strand = job->strand; r.length = vj[z].vw.length;
+        r.start = job->strand == 0 ? job->i + bp : job->i + job->bn - bp + 1;
+        dev_of[z] = (int) prefs.size();
+        prefs.push_back(r);
+      }
+      if (!prefs.empty()) {
+        const int st = filters->regions(seq, comp, prefs.data(), prefs.size(), dev_regions);
+        if (st != P7X_OK) return st;
+      }
+    }
+    tick("parsers + region scan of the survivors");
     std::vector<std::vector<Hit>> jh(vj.size());
     std::vector<LtCounters> jc(vj.size());
     std::vector<int> jst(vj.size(), P7X_OK);
-    host_parallel_for((int) vj.size(), cfg.host_threads, [&](int z) {
+    host_parallel_for((int) vj.size(), cfg.host_threads, [&](int zi) {
+      const size_t z = (size_t) zi;
       flogsum_init();
-      const BlockJob &job = *flat[vj[(size_t) z].q].first; const LtWindow &w = job.windows[flat[vj[(size_t) z].q].second];
-      const LtWindow &vw = vj[(size_t) z].vw;
-      const int64_t bp = w.n + vw.n - 1;
-      std::vector<uint8_t> sub;
-      fetch(job, bp, vw.length, sub);
-      LtBlock blk{ nullptr, job.bn, job.strand == 0 ? job.i + 1 : job.i + job.bn, job.strand == 1 };
-      jc[(size_t) z].n_past_vit++; jc[(size_t) z].pos_past_vit += (uint64_t) vw.length;
-      jst[(size_t) z] = lt_post_viterbi(cfg, p, lto, max_length, job.nres_at, blk, tg, bp, vw.length, sub.data(),
-                                        fwd_dev.empty() ? nullptr : &fwd_dev[(size_t) z], jh[(size_t) z], jc[(size_t) z]);
+      const BlockJob *job; int64_t bp; geometry(z, job, bp);
+      const LtWindow &vw = vj[z].vw;
+      LtBlock blk{ nullptr, job->bn, job->strand == 0 ? job->i + 1 : job->i + job->bn, job->strand == 1 };
+      jc[z].n_past_vit++; jc[z].pos_past_vit += (uint64_t) vw.length;
+      if (!pass[z]) return;
+      const LtTarget &tgr = tg;
+      jst[z] = lt_post_viterbi(cfg, p, lto, max_length, job->nres_at, blk, tgr, bp, vw.length, subs[z].data(), fwd_of[z],
+                               dev_of[z] >= 0 && (size_t) dev_of[z] < dev_regions.size() ? &dev_regions[(size_t) dev_of[z]] : nullptr, jh[z], jc[z]);
     });
     for (size_t z = 0; z < vj.size(); ++z) {
       if (jst[z] != P7X_OK) return jst[z];

@@ -1697,3 +1697,30 @@ int p7x_search_block(const p7x_pipeline_cfg *cfg, const p7x_oprofile *om, const 
 }
 
 } // extern "C"
+
+namespace p7x {
+// Forward / Backward parsers + region scan of EVERY target of <db> (the long-target pipeline's Forward survivors, packed
+// as a block of windows): the survivor passes of the cascade with all filters open.  out[t] in the caller's order.
+int device_regions_of_all(const p7x_oprofile *om, const p7x_seqdb *db, std::vector<LongTargetWindowRegions> &out)
+{
+  out.assign((size_t) db->n, LongTargetWindowRegions{});
+  if (db->n == 0) return P7X_OK;
+  p7x_pipeline_cfg cfg; p7x_pipeline_cfg_default(&cfg);
+  cfg.do_max = 1;
+  CascadeOut co;
+  const int st = run_cascade(cfg, om, db, co);
+  if (st != P7X_OK) return st;
+  if (co.have_xmx) return P7X_OK;                      // a window with more regions than the device keeps: the host scans (n stays -2)
+  for (size_t i = 0; i < co.fin_slots.size(); ++i) {
+    LongTargetWindowRegions &w = out[(size_t) db->h_order[(size_t) co.fin_slots[i]]];
+    const int n = co.reg_n[i];
+    w.n = n < 0 ? (n == -1 ? -1 : -2) : n;
+    w.nexpected = co.nexpected[i];
+    if (n <= 0) continue;
+    const size_t start = co.reg_start.empty() ? i * (size_t) kRegionCap : (size_t) co.reg_start[i];
+    w.regs.resize((size_t) n);
+    for (int z = 0; z < n; ++z) w.regs[(size_t) z] = Region{ co.regs[(start + (size_t) z) * 3], co.regs[(start + (size_t) z) * 3 + 1], co.regs[(start + (size_t) z) * 3 + 2] != 0 };
+  }
+  return P7X_OK;
+}
+}

@@ -130,8 +130,147 @@ __global__ void __launch_bounds__(256) ssvlong_kernel(const SsvLongArgs a)
   }
 }
 
+// ---------------------------------------------------------------------------------------- emission pairs in registers
+// Every lane of a wavefront works on the same residue, so a row needs the emission pairs of ONE residue: with the pairs
+// of A, C, G, T for both parities held in registers (8 R of them) a row is R saturating adds and R maxima and no LDS
+// traffic at all (the LDS kernel above issues one ds_read_b32 per register and row, which at 64 lanes x 4 bytes occupies
+// the LDS pipe for as long as the two packed operations occupy the SIMD).  The residue selects the register set through
+// a wave-uniform branch; rows run in (odd, even) pairs so that the parity is static.  The threshold test is deferred: the
+// row maxima of eight rows are folded into one register and compared once; only a block in which some row reached the
+// threshold (rare) is run again from its saved first row with the test in every row.  The residues of the next 64 rows
+// are fetched while the current ones are processed.  Models up to 3,069 nodes (R <= 24: 192 table registers); longer
+// ones keep the LDS kernel.  250 Mbp x 2 strands x M = 1203: 37.7 ms against 44.1 ms (profiles/r03_ssv_kernels.txt lists
+// the variants that were measured, among them two that halve the maxima and were no faster: the compiler's handling of
+// the wave-uniform branches, not the arithmetic, sets the pace).
+template <int R>
+__global__ void __launch_bounds__(256) ssvlong_reg_kernel(const SsvLongArgs a)
+{
+  const int lane = threadIdx.x & 63;
+  const int wave = rfl((int) (blockIdx.x * 4 + (threadIdx.x >> 6)));
+  const int nwaves = (int) gridDim.x * 4;
+  uint32_t T[2][4][R];
+#pragma unroll
+  for (int par = 0; par < 2; ++par)
+#pragma unroll
+    for (int x = 0; x < 4; ++x)
+#pragma unroll
+      for (int j = 0; j < R; ++j) T[par][x][j] = a.tab4[((size_t) (par * 4 + x) * R + j) * 64 + lane];
+
+  // one row with the emission pairs <e>; ODD: register g <- f(register g-1), the lane's first register from the lane before
+  auto row = [&](uint32_t (&v)[R], const uint32_t (&e)[R], bool odd) -> uint32_t {
+    uint32_t acc0 = kFloor2, acc1 = kFloor2;
+    if (odd) {
+      const uint32_t carry = (uint32_t) dpp_shr1((int) v[R - 1], (int) kFloor2);
+#pragma unroll
+      for (int j = R - 1; j >= 1; --j) { v[j] = pk_adds_u(v[j - 1], e[j]); if (j & 1) acc1 = pk_max_u(acc1, v[j]); else acc0 = pk_max_u(acc0, v[j]); }
+      v[0] = pk_adds_u(carry, e[0]); acc0 = pk_max_u(acc0, v[0]);
+    } else {
+#pragma unroll
+      for (int j = 0; j < R; ++j) { v[j] = pk_adds_u(v[j], e[j]); if (j & 1) acc1 = pk_max_u(acc1, v[j]); else acc0 = pk_max_u(acc0, v[j]); }
+    }
+    return pk_max_u(acc0, acc1);
+  };
+  auto row_any = [&](uint32_t (&v)[R], int x, bool odd) -> uint32_t {
+    if (x < 4) {
+      const int par = odd ? 0 : 1;
+      switch (x) {                                  // wave-uniform: one of four register sets
+        case 0: return row(v, T[par][0], odd);
+        case 1: return row(v, T[par][1], odd);
+        case 2: return row(v, T[par][2], odd);
+        default: return row(v, T[par][3], odd);
+      }
+    }
+    // degenerate residue: emissions from the full table in global memory [parity][Kp][R][64]
+    const uint32_t *eg = a.tab_full + ((size_t) ((odd ? 0 : a.Kp) + x) * R) * 64 + lane;
+    uint32_t e[R];
+#pragma unroll
+    for (int j = 0; j < R; ++j) e[j] = eg[j * 64];
+    return row(v, e, odd);
+  };
+  // the report of a row that reached the threshold, exactly as the LDS kernel makes it
+  auto report = [&](const uint32_t (&v)[R], bool odd, long long i, int strand) {
+    int best = INT_MIN, bestkey = INT_MAX;
+#pragma unroll
+    for (int j = 0; j < R; ++j) {
+      const int g = lane * R + j, c0 = odd ? 2 * g - 1 : 2 * g;
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const int k = c0 + h;
+        const int sv = (int) (short) (h ? (v[j] >> 16) : (v[j] & 0xffffu));
+        if (k >= 1 && k <= a.M) {
+          const int val = min(255, sv + 32768 + a.xB);
+          const int key = ((k - 1) % a.Q16) * 16 + (k - 1) / a.Q16;
+          if (val > best || (val == best && key < bestkey)) { best = val; bestkey = key; }
+        }
+      }
+    }
+    const int smax = wave_max_i32(best);
+    const int kmin = -wave_max_i32(best == smax ? -bestkey : INT_MIN);
+    if (lane == 0) {
+      const int slot = atomicAdd(a.nrec, 1);
+      if (slot < a.rec_cap) {
+        a.rec_pos[slot] = i; a.rec_strand[slot] = (uint8_t) strand;
+        a.rec_k[slot] = (kmin / 16) + a.Q16 * (kmin % 16) + 1; a.rec_sc[slot] = smax;
+      }
+    }
+  };
+  auto reached = [&](uint32_t acc) -> bool {
+    const int hi = (int) (short) (acc >> 16), lo = (int) (short) (acc & 0xffffu);
+    return __any(max(hi, lo) >= a.thresh_s) != 0;
+  };
+
+  for (long long chi = wave; chi < a.nchunks; chi += nwaves) {
+    const long long ch = a.chunk_list ? a.chunk_list[chi] : chi;
+    const int strand = a.strand0 + (int) (ch / a.chunks_per_strand);
+    const long long c0 = (ch % a.chunks_per_strand) * (long long) a.chunk_len;
+    const long long first = c0 + 1, last = min(a.L, c0 + a.chunk_len);
+    const long long warm = max(1LL, first - a.M);
+    uint32_t v[R];
+#pragma unroll
+    for (int j = 0; j < R; ++j) v[j] = kFloor2;
+    // residues of 64 rows, one per lane: strand 1 reads the target backwards and complements (canonical residues by
+    // arithmetic: the table lookup would be a second dependent load); fetched one block ahead of its use
+    auto fetch = [&](long long i0) -> uint32_t {
+      const long long pos = i0 + lane;
+      if (pos > last) return 0u;
+      const long long src = strand == 0 ? pos : a.L - pos + 1;
+      const uint32_t x = a.dsq[src];
+      return strand == 0 ? x : (x < 4 ? 3u - x : (uint32_t) a.comp[x]);
+    };
+    uint32_t res_next = fetch(warm);
+    for (long long i0 = warm; i0 <= last; i0 += 64) {     // i0 - warm is a multiple of 64: row r of a block is odd iff r is even
+      const int nrow = (int) min(64LL, last - i0 + 1);
+      const uint32_t res = res_next;
+      res_next = fetch(i0 + 64);
+      for (int r0 = 0; r0 < nrow; r0 += 8) {
+        const int nb = min(8, nrow - r0);
+        uint32_t saved[R];
+#pragma unroll
+        for (int j = 0; j < R; ++j) saved[j] = v[j];
+        uint32_t blk = kFloor2;
+        if (nb == 8) {
+#pragma unroll
+          for (int rr = 0; rr < 8; ++rr) blk = pk_max_u(blk, row_any(v, __builtin_amdgcn_readlane((int) res, r0 + rr), (rr & 1) == 0));
+        } else {
+          for (int rr = 0; rr < nb; ++rr) blk = pk_max_u(blk, row_any(v, __builtin_amdgcn_readlane((int) res, r0 + rr), (rr & 1) == 0));
+        }
+        if (i0 + r0 + nb - 1 < first || !reached(blk)) continue;       // warm-up rows report nothing
+        // some row of the block reached the threshold: the block again, row by row (same arithmetic, same values)
+#pragma unroll
+        for (int j = 0; j < R; ++j) v[j] = saved[j];
+        for (int rr = 0; rr < nb; ++rr) {
+          const bool odd = (rr & 1) == 0;
+          const uint32_t acc = row_any(v, __builtin_amdgcn_readlane((int) res, r0 + rr), odd);
+          const long long i = i0 + r0 + rr;
+          if (i >= first && reached(acc)) report(v, odd, i, strand);
+        }
+      }
+    }
+  }
+}
+
 // ---------------------------------------------------------------------------- host side
-static const int kSsvR[] = { 2, 4, 6, 8, 12, 16, 24, 32, 48 };
+static const int kSsvR[] = { 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 14, 16, 20, 24, 32, 48 };      // <= 24: emission pairs in registers
 
 int ssvlong_pick_R(int M)
 {
@@ -142,9 +281,12 @@ int ssvlong_pick_R(int M)
 
 // tables: pairs (lo, hi) of signed emission scores s[x][k] = bias - rb[x][k] in byte units, kNegPad outside 1..M.
 // odd rows: register g = cells (2g-1, 2g); even rows: (2g, 2g+1); g = lane*R + j, stored [parity][x][j][lane].
-void ssvlong_build_tables(const Profile &p, int R, std::vector<uint32_t> &tab4, std::vector<uint32_t> &tab_full)
+// <virtual_node> (register kernel): node M+1 exists with emission 0 for every residue, so that a score that reached the
+// last node is still there one row later (ssvlong_reg_kernel tests once per pair of rows); it never counts as a cell.
+void ssvlong_build_tables(const Profile &p, int R, bool virtual_node, std::vector<uint32_t> &tab4, std::vector<uint32_t> &tab_full, int *pair_slack)
 {
   auto sval = [&](int x, int k) -> int {
+    if (virtual_node && k == p.M + 1 && x < p.Kp) return 0;
     if (x >= p.Kp || k < 1 || k > p.M) return kNegPad;
     return (int) p.bias_b - (int) p.rb[(size_t) x * (p.M + 1) + k];
   };
@@ -160,6 +302,11 @@ void ssvlong_build_tables(const Profile &p, int R, std::vector<uint32_t> &tab4, 
           tab_full[(((size_t) par * p.Kp + x) * R + j) * 64 + lane] = w;
           if (x < 4) tab4[(((size_t) par * 4 + x) * R + j) * 64 + lane] = w;
         }
+  if (pair_slack) {
+    int worst = 0;
+    for (int x = 0; x < 4 && x < p.Kp; ++x) for (int k = 1; k <= p.M; ++k) worst = std::max(worst, -sval(x, k));
+    *pair_slack = worst;
+  }
 }
 
 template <int R>
@@ -186,16 +333,46 @@ static int launch_ssv(const SsvLongArgs &a, int num_cu, hipStream_t st)
   return P7X_OK;
 }
 
+template <int R>
+static int launch_ssv_reg(const SsvLongArgs &a, int num_cu, hipStream_t st)
+{
+  auto kern = ssvlong_reg_kernel<R>;
+  static int per_cu_cached = 0;
+  static std::mutex mu;
+  int per_cu = 0;
+  {
+    std::lock_guard<std::mutex> lk(mu);
+    if (per_cu_cached == 0) {
+      P7X_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu_cached, kern, 256, 0));
+      if (per_cu_cached < 1) per_cu_cached = 1;
+    }
+    per_cu = per_cu_cached;
+  }
+  long long grid = std::min<long long>((a.nchunks + 3) / 4, (long long) num_cu * per_cu);
+  if (grid < 1) grid = 1;
+  hipLaunchKernelGGL(kern, dim3((unsigned) grid), dim3(256), 0, st, a);
+  P7X_HIP(hipGetLastError());
+  return P7X_OK;
+}
+
 int ssvlong_launch(int R, const SsvLongArgs &a, int num_cu, hipStream_t st)
 {
   switch (R) {
-    case 2: return launch_ssv<2>(a, num_cu, st);
-    case 4: return launch_ssv<4>(a, num_cu, st);
-    case 6: return launch_ssv<6>(a, num_cu, st);
-    case 8: return launch_ssv<8>(a, num_cu, st);
-    case 12: return launch_ssv<12>(a, num_cu, st);
-    case 16: return launch_ssv<16>(a, num_cu, st);
-    case 24: return launch_ssv<24>(a, num_cu, st);
+    case 3: return launch_ssv_reg<3>(a, num_cu, st);
+    case 5: return launch_ssv_reg<5>(a, num_cu, st);
+    case 7: return launch_ssv_reg<7>(a, num_cu, st);
+    case 9: return launch_ssv_reg<9>(a, num_cu, st);
+    case 10: return launch_ssv_reg<10>(a, num_cu, st);
+    case 11: return launch_ssv_reg<11>(a, num_cu, st);
+    case 14: return launch_ssv_reg<14>(a, num_cu, st);
+    case 20: return launch_ssv_reg<20>(a, num_cu, st);
+    case 2: return a.use_lds ? launch_ssv<2>(a, num_cu, st) : launch_ssv_reg<2>(a, num_cu, st);
+    case 4: return a.use_lds ? launch_ssv<4>(a, num_cu, st) : launch_ssv_reg<4>(a, num_cu, st);
+    case 6: return a.use_lds ? launch_ssv<6>(a, num_cu, st) : launch_ssv_reg<6>(a, num_cu, st);
+    case 8: return a.use_lds ? launch_ssv<8>(a, num_cu, st) : launch_ssv_reg<8>(a, num_cu, st);
+    case 12: return a.use_lds ? launch_ssv<12>(a, num_cu, st) : launch_ssv_reg<12>(a, num_cu, st);
+    case 16: return a.use_lds ? launch_ssv<16>(a, num_cu, st) : launch_ssv_reg<16>(a, num_cu, st);
+    case 24: return a.use_lds ? launch_ssv<24>(a, num_cu, st) : launch_ssv_reg<24>(a, num_cu, st);
     case 32: return launch_ssv<32>(a, num_cu, st);
     case 48: return launch_ssv<48>(a, num_cu, st);
     default: set_error("model too long for the long-target SSV kernel (M > 6141)"); return P7X_EINVAL;

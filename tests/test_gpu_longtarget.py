@@ -132,3 +132,37 @@ def test_nhmmer_dealt_over_devices_equals_one_device():
         assert many.stage_counts == one.stage_counts and many.searched_residues == one.searched_residues
     seqs = _read("1390.SAMEA104415756.OFHT01000022.fna", abc)
     check_bmyd2_table(next(hmmer.nhmmer(hmm, seqs, devices=[0, 0])), golden_table("bmyD2.tbl"))
+
+
+@pytest.mark.parametrize("M", [60, 150, 250, 330, 380, 440, 500, 560, 630, 700, 760, 880, 1000, 1270, 1500, 2040, 2500, 3060, 3500, 5000])
+def test_device_ssv_every_register_count(M, oracle):
+    """One model length per instantiation of the long-target SSV kernels -- emission pairs in registers for R <= 24
+    packed registers per lane (M <= 3069), the LDS kernel beyond -- on a 400 kb random sequence with planted stretches of
+    the model's consensus: window seeds equal the oracle's sequential p7_SSVFilter_longtarget, both strands."""
+    abc = easel.Alphabet.dna()
+    from conftest import random_hmm
+    hmm = random_hmm(M, seed=9000 + M, alphabet=abc)
+    rng = np.random.default_rng(M)
+    L = 400_000
+    seq = rng.integers(0, 4, size=L).astype(np.uint8)
+    cons = np.argmax(hmm.match_emissions[1:], axis=1).astype(np.uint8)
+    for c in range(30):
+        a = int(rng.integers(0, max(1, M - 40)))
+        n = min(int(rng.integers(30, 400)), M - a)
+        pos = int(rng.integers(0, L - n))
+        seg = cons[a:a + n].copy()
+        mut = rng.random(n) < 0.1
+        seg[mut] = rng.integers(0, 4, size=int(mut.sum()))
+        seq[pos:pos + n] = seg if c % 2 == 0 else host_pipeline.DNA_COMP[seg[::-1]]
+    seq[5000:5030] = 15                                   # a run of N: the degenerate-residue path
+    pli = plan7.LongTargetsPipeline(abc, block_length=1 << 30)
+    om = plan7.OptimizedProfile(hmm, pli.background, 400)
+    op = oracle.OracleProfile(hmm, pli.background, 400)
+    total = 0
+    for strand in (0, 1):
+        blk = seq if strand == 0 else host_pipeline.DNA_COMP[seq[::-1]]
+        want = oracle.ssv_longtarget(op, blk, hmm.max_length, pli.F1)
+        got = device_seeds(om, pli._cfg(), seq, strand)
+        assert got.tolist() == want.tolist(), (M, strand)
+        total += len(want)
+    assert total >= 10, total
