@@ -281,7 +281,19 @@ def _search_file(queries: Iterable, file: SequenceFile, chunk_bytes: int, devs: 
 
 
 _BATCH_CELLS = 6e11        # (profile, target) cells per device batch when the caller leaves the batch size open: ~25 ms of MSV
-_BATCH_MAX = 256         # small blocks (a proteome, a query block): the measured optimum of the scan orientation
+_BATCH_MAX = 256         # queries per batch against a large block (the cell budget usually cuts far below this)
+_BATCH_LIMIT = 4096      # p7x_search_batch_enqueue takes at most this many profiles
+_BATCH_SLOTS = 1 << 23   # (profile, target) score slots of one batch's workspace (~30 bytes each)
+
+
+def _batch_cap(db: "ShardedDatabase") -> int:
+    """Most queries a batch may hold.  Against a small block (a proteome, hmmscan's query sequences) the kernels of a
+    batch are latency bound -- a few dozen launches, each as long as its longest target takes one wavefront -- so the more
+    profiles share a launch set the better: round 3 measured 3.4 TCUPS with batches of 256, 4.5 with 1,024, 5.2 with 2,048
+    and 5.6 with 4,096 profiles on the 20,000-profile x 2,100-sequence scan (profiles/r03_scan_sweep.txt).  The cap falls
+    with the number of targets, because the batch's workspace is (profiles x targets) slots."""
+    ntargets = max(1, max(int(_lib.lib().p7x_seqdb_ntargets(sh._handle)) for sh in db.shards))
+    return int(min(_BATCH_LIMIT, max(_BATCH_MAX, _BATCH_SLOTS // ntargets)))
 
 
 def _shard_residues(db: "ShardedDatabase") -> int:
@@ -298,7 +310,7 @@ def _auto_batch(db: "ShardedDatabase", M_hint: int = 150) -> int:
     batch does not outlast the device stage of the next.  Measured on the MI355X: 4-8 for M = 262 against 3e8 residues,
     ~32 for the Pfam-shaped library (median M 120) against 1.75e8."""
     cells = float(_shard_residues(db)) * max(1, M_hint)          # one query, one shard
-    return int(max(1, min(_BATCH_MAX, _BATCH_CELLS // cells)))
+    return int(max(1, min(_batch_cap(db), _BATCH_CELLS // cells)))
 
 
 def _batches(queries: Iterable, size: int) -> Iterator[list]:
@@ -330,14 +342,16 @@ def _run_queries(db: "ShardedDatabase", pipelines: Sequence[Pipeline], queries: 
     instead of one launch per profile.  Results are held back until every earlier query of the input has been yielded."""
     auto = batch <= 0
     res = _shard_residues(db) if auto else 0
+    cap = _batch_cap(db) if auto else batch
     if auto:
-        batch = _BATCH_MAX                # upper bound; the cut below follows the cell budget
+        batch = cap                       # upper bound; the cut below follows the cell budget
     span = batch * max(1, reorder) if batch > 1 else 1
     if auto:
         # a query source of unknown length (a generator, a file being parsed) is read a shorter way ahead: the first
         # result of a span waits for the whole span to be read
         import operator
-        span = (8 if operator.length_hint(queries) > 0 else 2) * _BATCH_MAX
+        hint = operator.length_hint(queries)
+        span = min(max(hint, 8 * _BATCH_MAX), 1 << 16) if hint > 0 else 2 * _BATCH_MAX      # a sized source is sorted as a whole (up to 65,536)
     order: list = []                      # input index of every query handed to the device, in hand-over order
     inputs: dict = {}                     # the queries that have not been yielded yet, by input index
     it = iter(queries)
@@ -362,7 +376,7 @@ def _run_queries(db: "ShardedDatabase", pipelines: Sequence[Pipeline], queries: 
             while lo < len(idx):
                 if auto:                      # as many queries as the cell budget holds (short models: many, long ones: few)
                     hi, cells = lo, 0.0
-                    while hi < len(idx) and hi - lo < _BATCH_MAX:
+                    while hi < len(idx) and hi - lo < cap:
                         cells += float(res) * max(1, _query_length(chunk[idx[hi]]) or 150)
                         if hi > lo and cells > _BATCH_CELLS:
                             break
@@ -593,7 +607,7 @@ def _run_batches(db: "ShardedDatabase", pipelines: Sequence[Pipeline], queries: 
 
 
 def hmmscan(queries, profiles, *, cpus: int = 0, callback: Optional[Callable] = None, devices: Optional[Sequence[int]] = None,
-            pipeline_depth: int = 3, feeders: int = 3, window: int = 1, finishers: int = 0, batch: int = 256,
+            pipeline_depth: int = 4, feeders: int = 3, window: int = 1, finishers: int = 0, batch: int = 0,
             backend: Optional[str] = None, **options) -> Iterator[TopHits]:
     """Scan query sequences against a profile database; yields one ``TopHits`` per query sequence, in query order, whose
     hits are the profiles (reference ``hmmer/_hmmscan.py:90-231``, ``Pipeline.scan_seq`` ``plan7.pyx:6534-6622``).
@@ -608,10 +622,11 @@ def hmmscan(queries, profiles, *, cpus: int = 0, callback: Optional[Callable] = 
     database, so one profile's kernels are a few wavefronts running for the length of the longest query: several profiles
     are kept in flight on separate device streams to fill the device: each of the ``feeders`` threads queues the
     device stage of ``window`` batches of ``batch`` profiles before it waits for the oldest one, at most
-    ``pipeline_depth`` in total.  The defaults are the measured optimum of the 2,800-profile x 2,100-sequence case
-    (``scripts/scan_bench.py``): a batch of 256 profiles fills the device with (profile, target group) work items, its
-    device images are laid out by the host workers and go up in one copy, and one batch per feeder keeps the batches
-    from waiting for one another.
+    ``pipeline_depth`` in total.  ``batch=0`` (default) takes as many profiles per batch as the workspace allows for this
+    query block (``_batch_cap``: 4,096 for a proteome-sized block): the kernels of a batch are latency bound, and the
+    20,000-profile x 2,100-sequence scan went from 3.4 TCUPS with batches of 256 to 5.6 with 4,096, three feeders and a
+    depth of four (``scripts/scan_sweep.py``, ``profiles/r03_scan_sweep.txt``).  The device images of a batch are laid
+    out by the host workers and go up in one copy.
     """
     from .easel import DigitalSequence
     from .plan7 import _P7X_SCAN_MODELS

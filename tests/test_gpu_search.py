@@ -445,7 +445,7 @@ def test_config3_profile_library_against_a_proteome(proteome, monkeypatch, reque
     # the MSV filter passes about F1 of the comparisons for calibrated models (0.02; composition and length effects allowed for)
     assert 0.005 < total["msv"] / (n * len(proteome)) < 0.06
     # scan orientation: per-sequence lists, Z = number of profiles, same (profile, sequence) pairs
-    scanned = list(hmmer.hmmscan(proteome, block, batch=256))
+    scanned = list(hmmer.hmmscan(proteome, block))          # default: as many profiles per batch as the workspace allows (4,096 here)
     assert len(scanned) == len(proteome) and all(h.Z == n for h in scanned[:50])
     pairs_scan = {(hit.name, q.name) for q, th in zip(proteome, scanned) for hit in th}
     pairs_search = {(hmms[e].name, hit.name) for e, th in enumerate(batched) for hit in th}
