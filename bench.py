@@ -23,7 +23,9 @@ from pathlib import Path
 
 import numpy as np
 
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")      # before torch initialises HIP (see pyhmmer_amd/__init__.py)
+# before torch initialises HIP (see pyhmmer_amd/__init__.py).  A rehearsal with many ranks on ONE device (P7X_BENCH_SHARE_DEVICE)
+# must not ask for 8 hardware queues per process: 8 ranks x 8 queues crashed the runtime on the shared device.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "2" if (os.environ.get("P7X_BENCH_SHARE_DEVICE") == "1" and int(os.environ.get("WORLD_SIZE", "1")) > 4) else "8")
 
 ROOT = Path(__file__).resolve().parent
 sys.path.insert(0, str(ROOT))
