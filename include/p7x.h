@@ -167,7 +167,9 @@ typedef struct p7x_pipeline_cfg {
   uint32_t seed;             /* do_reseeding = (seed != 0), plan7.pyx:5684-5688 */
   int32_t mode;              /* P7X_SEARCH_SEQS | P7X_SCAN_MODELS */
   int32_t host_threads;      /* workers for host-side domain definition; 0 = hardware_concurrency */
-  int32_t host_envelopes;    /* 0 (default): single-domain envelopes are rescored by the device kernel; 1: on the host */
+  int32_t host_envelopes;    /* 0 (default): single-domain envelopes are rescored by the device kernel; 1: on the host.  Long targets:
+                              * 0 the device when the number of envelopes makes it pay (a few long envelopes are faster on the host
+                              * workers), 1 always the host, 2 always the device */
   int32_t host_regions;      /* 0 (default): posterior decoding of the specials + region scan on the device; 1: on the host */
   /* long targets (nhmmer): p7_pipeline.pxd:80-87, 103-107; LongTargetsPipeline.__init__ plan7.pyx:6957-7060 */
   int32_t long_targets;      /* p7_Pipeline_LongTarget semantics: every domain is a hit, E-values from residues searched */

@@ -147,7 +147,11 @@ __device__ __forceinline__ int pp_near(float p, float guard)
 __device__ __forceinline__ float pp_from_code(unsigned code) { return code >= 10u ? 1.0f : (float) (((double) code + 0.5) / 10.0 - 0.05); }
 
 // G: with the near-tie guard (a.oa_guard > 0).  Without it the kernel carries none of the guard's arithmetic.
-template <int C, bool G>
+// LT: a long-target (nhmmer) envelope -- upstream rescore_isolated_domain(long_target = TRUE): the match odds come from a
+// table of the ENVELOPE's own (re-derived by the host for the background mixed with the envelope's composition,
+// a.env_emis; the length model is the envelope's own length through env_L), and Forward runs once more with the profile's
+// unmodified odds: that score is the envelope's, the difference the bias (a.out_orig).
+template <int C, bool G, bool LT = false>
 __global__ void __launch_bounds__(env_waves(C) * 64, env_waves(C) / 4) env_kernel(const ArgRef ref)
 {
   constexpr int kEnvBlock = env_waves(C) * 64;
@@ -159,8 +163,8 @@ __global__ void __launch_bounds__(env_waves(C) * 64, env_waves(C) / 4) env_kerne
   const float4 *tr = TG ? reinterpret_cast<const float4 *>(a.trans) : reinterpret_cast<const float4 *>(smem);      // [2*Mpad]
   // emission odds [nrows][Mpad]: staged in LDS while they fit beside the transitions (M <= 1024), else read where they
   // lie (one coalesced 256-byte row segment per chunk and row: L2-resident, like the parsers' long-model variant)
-  constexpr bool kEmisInLds = C <= 16;
-  const float *em = kEmisInLds ? reinterpret_cast<const float *>(smem + (size_t) Mpad * 32) : reinterpret_cast<const float *>(a.emis);
+  constexpr bool kEmisInLds = C <= 16 && !LT;
+  const float *em_profile = kEmisInLds ? reinterpret_cast<const float *>(smem + (size_t) Mpad * 32) : reinterpret_cast<const float *>(a.emis);
   {
     if constexpr (!TG) {
       const float4 *gt = reinterpret_cast<const float4 *>(a.trans);
@@ -206,6 +210,7 @@ __global__ void __launch_bounds__(env_waves(C) * 64, env_waves(C) / 4) env_kerne
     const uint8_t *sq = a.dsq + (((unsigned long long) ohi << 32) | olo);      // sq[0] = first residue of the envelope
     const float pmove = (2.0f + a.nj) / ((float) Lfull + 2.0f + a.nj), ploop = 1.0f - pmove;
     int status = 0;
+    const float *em = LT ? a.env_emis + (size_t) it * (size_t) a.env_emis_stride : em_profile;      // [nrows][Mpad]
 
     // ------------------------------------------------------------------ 1. Forward (score and scale factors)
     float envsc;
@@ -227,6 +232,21 @@ __global__ void __launch_bounds__(env_waves(C) * 64, env_waves(C) / 4) env_kerne
       }
       if (f.xC != f.xC || (Ld > 0 && f.xC == 0.0f) || __builtin_isinf(f.xC)) { envsc = __builtin_inff(); status |= 1; }
       else envsc = (float) ((double) f.totscale + log((double) (f.xC * pmove)));
+    }
+    if constexpr (LT) {            // Forward with the profile's own odds: the envelope's score proper.  (Run row by row next to
+                                   // the first recurrence it was slower: 66 against 58 ms for the benchmark's two rounds.)
+      EnvForward<C> g;
+      g.init(tr, lane, pmove);
+      for (int i0 = 0; i0 < Ld; i0 += 64) {
+        const int nrow = min(64, Ld - i0);
+        const uint32_t resid = (lane < nrow) ? sq[i0 + lane] : 0;
+        for (int r = 0; r < nrow; ++r)
+          g.row(tr, em_profile, Mpad, lane, __builtin_amdgcn_readlane((int) resid, r), pmove, ploop, a.xf_e_move, a.xf_e_loop);
+      }
+      float orig;
+      if (g.xC != g.xC || (Ld > 0 && g.xC == 0.0f) || __builtin_isinf(g.xC)) { orig = __builtin_inff(); status |= 1; }
+      else orig = (float) ((double) g.totscale + log((double) (g.xC * pmove)));
+      if (lane == 0) a.out_orig[it] = orig;
     }
     phase_fence();
 
@@ -735,23 +755,23 @@ static int occupancy_env(K kernel, int kEnvBlock, size_t lds_bytes, int *per_cu)
 
 #define P7X_ENV_SWITCH(EXPR)                                                                                  \
   switch (C) {                                                                                                \
-    case 1: { if (G_) { auto kern = env_kernel<1, true>; return EXPR; } else { auto kern = env_kernel<1, false>; return EXPR; } }                                                     \
-    case 2: { if (G_) { auto kern = env_kernel<2, true>; return EXPR; } else { auto kern = env_kernel<2, false>; return EXPR; } }                                                     \
-    case 3: { if (G_) { auto kern = env_kernel<3, true>; return EXPR; } else { auto kern = env_kernel<3, false>; return EXPR; } }                                                     \
-    case 4: { if (G_) { auto kern = env_kernel<4, true>; return EXPR; } else { auto kern = env_kernel<4, false>; return EXPR; } }                                                     \
-    case 5: { if (G_) { auto kern = env_kernel<5, true>; return EXPR; } else { auto kern = env_kernel<5, false>; return EXPR; } }                                                     \
-    case 6: { if (G_) { auto kern = env_kernel<6, true>; return EXPR; } else { auto kern = env_kernel<6, false>; return EXPR; } }                                                     \
-    case 8: { if (G_) { auto kern = env_kernel<8, true>; return EXPR; } else { auto kern = env_kernel<8, false>; return EXPR; } }                                                     \
-    case 10: { if (G_) { auto kern = env_kernel<10, true>; return EXPR; } else { auto kern = env_kernel<10, false>; return EXPR; } }                                                     \
-    case 12: { if (G_) { auto kern = env_kernel<12, true>; return EXPR; } else { auto kern = env_kernel<12, false>; return EXPR; } }                                                     \
-    case 16: { if (G_) { auto kern = env_kernel<16, true>; return EXPR; } else { auto kern = env_kernel<16, false>; return EXPR; } }                                                     \
-    case 20: { if (G_) { auto kern = env_kernel<20, true>; return EXPR; } else { auto kern = env_kernel<20, false>; return EXPR; } }                                                     \
-    case 24: { if (G_) { auto kern = env_kernel<24, true>; return EXPR; } else { auto kern = env_kernel<24, false>; return EXPR; } }                                                     \
-    case 32: { if (G_) { auto kern = env_kernel<32, true>; return EXPR; } else { auto kern = env_kernel<32, false>; return EXPR; } } \
-    case 48: { if (G_) { auto kern = env_kernel<48, true>; return EXPR; } else { auto kern = env_kernel<48, false>; return EXPR; } } \
-    case 64: { if (G_) { auto kern = env_kernel<64, true>; return EXPR; } else { auto kern = env_kernel<64, false>; return EXPR; } } \
-    case 96: { if (G_) { auto kern = env_kernel<96, true>; return EXPR; } else { auto kern = env_kernel<96, false>; return EXPR; } } \
-    case 128: { if (G_) { auto kern = env_kernel<128, true>; return EXPR; } else { auto kern = env_kernel<128, false>; return EXPR; } }                                                     \
+    case 1: { if (LT_) { auto kern = env_kernel<1, true, true>; return EXPR; } else if (G_) { auto kern = env_kernel<1, true>; return EXPR; } else { auto kern = env_kernel<1, false>; return EXPR; } }                                                     \
+    case 2: { if (LT_) { auto kern = env_kernel<2, true, true>; return EXPR; } else if (G_) { auto kern = env_kernel<2, true>; return EXPR; } else { auto kern = env_kernel<2, false>; return EXPR; } }                                                     \
+    case 3: { if (LT_) { auto kern = env_kernel<3, true, true>; return EXPR; } else if (G_) { auto kern = env_kernel<3, true>; return EXPR; } else { auto kern = env_kernel<3, false>; return EXPR; } }                                                     \
+    case 4: { if (LT_) { auto kern = env_kernel<4, true, true>; return EXPR; } else if (G_) { auto kern = env_kernel<4, true>; return EXPR; } else { auto kern = env_kernel<4, false>; return EXPR; } }                                                     \
+    case 5: { if (LT_) { auto kern = env_kernel<5, true, true>; return EXPR; } else if (G_) { auto kern = env_kernel<5, true>; return EXPR; } else { auto kern = env_kernel<5, false>; return EXPR; } }                                                     \
+    case 6: { if (LT_) { auto kern = env_kernel<6, true, true>; return EXPR; } else if (G_) { auto kern = env_kernel<6, true>; return EXPR; } else { auto kern = env_kernel<6, false>; return EXPR; } }                                                     \
+    case 8: { if (LT_) { auto kern = env_kernel<8, true, true>; return EXPR; } else if (G_) { auto kern = env_kernel<8, true>; return EXPR; } else { auto kern = env_kernel<8, false>; return EXPR; } }                                                     \
+    case 10: { if (LT_) { auto kern = env_kernel<10, true, true>; return EXPR; } else if (G_) { auto kern = env_kernel<10, true>; return EXPR; } else { auto kern = env_kernel<10, false>; return EXPR; } }                                                     \
+    case 12: { if (LT_) { auto kern = env_kernel<12, true, true>; return EXPR; } else if (G_) { auto kern = env_kernel<12, true>; return EXPR; } else { auto kern = env_kernel<12, false>; return EXPR; } }                                                     \
+    case 16: { if (LT_) { auto kern = env_kernel<16, true, true>; return EXPR; } else if (G_) { auto kern = env_kernel<16, true>; return EXPR; } else { auto kern = env_kernel<16, false>; return EXPR; } }                                                     \
+    case 20: { if (LT_) { auto kern = env_kernel<20, true, true>; return EXPR; } else if (G_) { auto kern = env_kernel<20, true>; return EXPR; } else { auto kern = env_kernel<20, false>; return EXPR; } }                                                     \
+    case 24: { if (LT_) { auto kern = env_kernel<24, true, true>; return EXPR; } else if (G_) { auto kern = env_kernel<24, true>; return EXPR; } else { auto kern = env_kernel<24, false>; return EXPR; } }                                                     \
+    case 32: { if (LT_) { auto kern = env_kernel<32, true, true>; return EXPR; } else if (G_) { auto kern = env_kernel<32, true>; return EXPR; } else { auto kern = env_kernel<32, false>; return EXPR; } } \
+    case 48: { if (LT_) { auto kern = env_kernel<48, true, true>; return EXPR; } else if (G_) { auto kern = env_kernel<48, true>; return EXPR; } else { auto kern = env_kernel<48, false>; return EXPR; } } \
+    case 64: { if (LT_) { auto kern = env_kernel<64, true, true>; return EXPR; } else if (G_) { auto kern = env_kernel<64, true>; return EXPR; } else { auto kern = env_kernel<64, false>; return EXPR; } } \
+    case 96: { if (LT_) { auto kern = env_kernel<96, true, true>; return EXPR; } else if (G_) { auto kern = env_kernel<96, true>; return EXPR; } else { auto kern = env_kernel<96, false>; return EXPR; } } \
+    case 128: { if (LT_) { auto kern = env_kernel<128, true, true>; return EXPR; } else if (G_) { auto kern = env_kernel<128, true>; return EXPR; } else { auto kern = env_kernel<128, false>; return EXPR; } }                                                     \
     default: set_error("model too long for the envelope kernel"); return P7X_EINVAL;                         \
   }
 
@@ -762,7 +782,7 @@ int env_max_blocks(int C, int nrows, int num_cu, int *nblocks)
   const size_t lds = env_lds_bytes(C, nrows);
   int per_cu = 1;
   auto finish = [&](int st) { if (st == P7X_OK) *nblocks = num_cu * per_cu; return st; };
-  const bool G_ = true;            // the guarded kernel is never the smaller one
+  const bool G_ = true, LT_ = false;            // the guarded kernel is never the smaller one
   P7X_ENV_SWITCH(finish(occupancy_env(kern, env_waves(C) * 64, lds, &per_cu)))
 }
 
@@ -770,7 +790,8 @@ int env_launch(const ArgRun<EnvArgs> &a, hipStream_t st)
 {
   if (a.n <= 0) return P7X_OK;
   const int C = a.at(0).C;
-  const size_t lds = env_lds_bytes(C, a.at(0).nrows);
+  const bool LT_ = a.at(0).env_emis != nullptr;
+  const size_t lds = LT_ ? (C > 64 ? (size_t) 256 : (size_t) 64 * C * 32) : env_lds_bytes(C, a.at(0).nrows);
   const bool G_ = a.at(0).oa_guard > 0.0f;
   P7X_ENV_SWITCH(launch_env(kern, a, lds, st))
 }

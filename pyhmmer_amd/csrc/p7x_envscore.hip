@@ -25,13 +25,14 @@ struct EnvBuffers {
   unsigned char *h_in = nullptr; size_t h_in_cap = 0;        // pinned mirror of d_in
   unsigned char *d_out = nullptr; size_t d_out_cap = 0;      // out_sc | out_null2 | out_status | tr_n | tr_a | tr_i | tr_pp
   unsigned char *h_out = nullptr; size_t h_out_cap = 0;      // pinned mirror of d_out
+  float *lt_dev = nullptr; size_t lt_bytes = 0;              // long-target envelopes: their emission tables
   hipStream_t stream = nullptr;                               // per host thread: concurrent host stages do not wait on each other
   ~EnvBuffers() {
     if (device < 0) return;
     (void) hipSetDevice(device);
     if (stream) (void) hipStreamDestroy(stream);
     DeviceCtx *ctx = nullptr;
-    if (get_ctx(device, &ctx) == P7X_OK) { slab_release(ctx, work, work_bytes); slab_release(ctx, d_in, d_in_cap); slab_release(ctx, d_out, d_out_cap); }
+    if (get_ctx(device, &ctx) == P7X_OK) { slab_release(ctx, work, work_bytes); slab_release(ctx, d_in, d_in_cap); slab_release(ctx, d_out, d_out_cap); slab_release(ctx, lt_dev, lt_bytes); }
     pinned_release(h_out, h_out_cap);
     pinned_release(h_in, h_in_cap);
   }
@@ -138,7 +139,7 @@ public:
         const int Ld = rq.j - rq.i + 1;
         const int64_t e = m.first + r;
         env_sq[e] = db_->h_off[t] + (rq.i - 1);
-        env_len[e] = Ld; env_L[e] = db_->h_len[t];
+        env_len[e] = Ld; env_L[e] = jobs[j].lt_tables ? Ld : db_->h_len[t];      // long targets: the envelope's own length model
         tr_off[e] = ntr; ntr += (int64_t) Ld + p.M + 16;
         m.Lmax = std::max(m.Lmax, Ld);
       }
@@ -182,11 +183,19 @@ public:
       eb->work = static_cast<float *>(dp); eb->work_bytes = got; eb->work_floats = got / 4;
     }
     tick("work");
-    // outputs: [out_sc 2f][null2 32f][status i][tr_n i] per envelope, then the three trace arrays
+    // outputs: [out_sc 2f][null2 32f][status i][tr_n i][orig f] per envelope, then the three trace arrays
     const size_t n = (size_t) nenv_tot;
-    const size_t o_sc = 0, o_n2 = o_sc + n * 8, o_st = o_n2 + n * 128, o_n = o_st + n * 4;
-    const size_t o_ta = o_n + n * 4, o_ti = o_ta + (size_t) ntr * 4, o_tp = o_ti + (size_t) ntr * 4;
+    const size_t o_sc = 0, o_n2 = o_sc + n * 8, o_st = o_n2 + n * 128, o_n = o_st + n * 4, o_orig = o_n + n * 4;
+    const size_t o_ta = o_orig + n * 4, o_ti = o_ta + (size_t) ntr * 4, o_tp = o_ti + (size_t) ntr * 4;
     const size_t out_bytes = o_tp + (size_t) ntr * 4;
+    // long-target jobs: the envelopes' own emission tables go up next to the requests
+    size_t lt_floats = 0;
+    for (size_t j = 0; j < nj; ++j) if (jobs[j].lt_tables) lt_floats += (size_t) meta_[j].nenv * jobs[j].lt_stride;
+    if (lt_floats * 4 > eb->lt_bytes) {
+      slab_release(ctx_, eb->lt_dev, eb->lt_bytes); eb->lt_dev = nullptr; eb->lt_bytes = 0;
+      void *dp = nullptr; size_t got = 0; const int sst = slab_acquire(ctx_, lt_floats * 4 + lt_floats, &dp, &got); if (sst != P7X_OK) return sst;
+      eb->lt_dev = static_cast<float *>(dp); eb->lt_bytes = got;
+    }
     if (out_bytes > eb->d_out_cap) {
       slab_release(ctx_, eb->d_out, eb->d_out_cap); eb->d_out = nullptr; eb->d_out_cap = 0;
       pinned_release(eb->h_out, eb->h_out_cap); eb->h_out = nullptr; eb->h_out_cap = 0;
@@ -205,7 +214,7 @@ public:
     const int32_t *d_env_order = d_env_L + nenv_tot;
     int *d_cursor = reinterpret_cast<int *>(eb->d_in + o_cursor);
     // argument records in launch order (class by class)
-    size_t slab_floats = 0;
+    size_t slab_floats = 0, lt_at = 0;
     std::vector<std::pair<int, int>> runs;        // first record, count
     int nrec = 0;
     for (size_t k = 0; k < nj; ++k) {
@@ -227,12 +236,20 @@ public:
       a.out_sc = reinterpret_cast<float *>(eb->d_out + o_sc) + 2 * m.first;
       a.out_null2 = reinterpret_cast<float *>(eb->d_out + o_n2) + 32 * m.first;
       a.out_status = reinterpret_cast<int32_t *>(eb->d_out + o_st) + m.first;
+      a.out_orig = reinterpret_cast<float *>(eb->d_out + o_orig) + m.first;
+      if (jobs[(size_t) j].lt_tables) {
+        const size_t cnt = (size_t) m.nenv * jobs[(size_t) j].lt_stride;
+        P7X_HIP(hipMemcpyAsync(eb->lt_dev + lt_at, jobs[(size_t) j].lt_tables, cnt * 4, hipMemcpyHostToDevice, s));
+        a.env_emis = eb->lt_dev + lt_at; a.env_emis_stride = (long long) jobs[(size_t) j].lt_stride;
+        lt_at += cnt;
+      }
       a.oa_guard = oa_guard_;
       a.tr_n = reinterpret_cast<int32_t *>(eb->d_out + o_n) + m.first;
       a.tr_a = reinterpret_cast<uint32_t *>(eb->d_out + o_ta);
       a.tr_i = reinterpret_cast<int32_t *>(eb->d_out + o_ti);
       a.tr_pp = reinterpret_cast<float *>(eb->d_out + o_tp);
-      if (!runs.empty() && h_args[runs.back().first].C == a.C && h_args[runs.back().first].nrows == a.nrows) runs.back().second++;
+      if (!runs.empty() && h_args[runs.back().first].C == a.C && h_args[runs.back().first].nrows == a.nrows &&
+          (h_args[runs.back().first].env_emis != nullptr) == (a.env_emis != nullptr)) runs.back().second++;
       else runs.emplace_back(nrec, 1);
       h_args[nrec++] = a;
     }
@@ -250,7 +267,7 @@ public:
     tick("d2h");
     if (debug) std::fprintf(stderr, "[env begin] jobs %zu envelopes %lld runs %zu work %.1f MB out %.1f MB:%s ms\n", nj, (long long) nenv_tot, runs.size(),
                             work_floats * 4 / 1e6, out_bytes / 1e6, dbg.c_str());
-    eb_ = eb; o_sc_ = o_sc; o_n2_ = o_n2; o_st_ = o_st; o_n_ = o_n; o_ta_ = o_ta; o_ti_ = o_ti; o_tp_ = o_tp;
+    eb_ = eb; o_sc_ = o_sc; o_n2_ = o_n2; o_st_ = o_st; o_n_ = o_n; o_orig_ = o_orig; o_ta_ = o_ta; o_ti_ = o_ti; o_tp_ = o_tp;
     tr_off_.assign(tr_off, tr_off + nenv_tot);
     return P7X_OK;
   }
@@ -274,6 +291,7 @@ public:
         const int64_t g = m.first + r;
         EnvelopeResult &e = res[j][(size_t) r];
         e.envsc = h_sc[2 * g]; e.oasc = h_sc[2 * g + 1]; e.status = h_st[g];
+        e.orig = reinterpret_cast<const float *>(eb->h_out + o_orig_)[g];
         std::memcpy(e.null2, h_n2 + (size_t) g * 32, sizeof(e.null2));
         e.ntrace = h_n[g]; e.ta = h_ta + tr_off_[(size_t) g]; e.ti = h_ti + tr_off_[(size_t) g]; e.tp = h_tp + tr_off_[(size_t) g];
       }
@@ -294,7 +312,7 @@ private:
   int64_t nenv_ = 0;
   EnvBuffers *eb_ = nullptr;
   EnvBuffers *lease_ = nullptr;
-  size_t o_sc_ = 0, o_n2_ = 0, o_st_ = 0, o_n_ = 0, o_ta_ = 0, o_ti_ = 0, o_tp_ = 0;
+  size_t o_sc_ = 0, o_n2_ = 0, o_st_ = 0, o_n_ = 0, o_orig_ = 0, o_ta_ = 0, o_ti_ = 0, o_tp_ = 0;
 };
 
 std::unique_ptr<EnvelopeScorer> make_device_envelope_scorer(DeviceCtx *ctx, const p7x_seqdb *db, float oa_guard)

@@ -41,11 +41,15 @@ struct DomainDefResult {      // the P7_DOMAINDEF fields p7_Pipeline reads (p7_d
 struct EnvelopeRequest { int item; int32_t i, j; };          // item: index into the survivor list; envelope i..j (1-based)
 struct EnvelopeResult {
   float envsc = 0, oasc = 0; int status = 0;
+  float orig = 0;                                            // long-target envelopes: Forward with the unmodified odds
   float null2[32];                                           // odds of the canonical residues (before esl_abc_FAvgScVec)
   int ntrace = 0; const uint32_t *ta = nullptr; const int32_t *ti = nullptr; const float *tp = nullptr;   // traceback order
 };
 // One job = the envelopes of one query profile (targets[item] = caller index of the survivor a request belongs to).
-struct EnvelopeJob { const p7x_oprofile *om = nullptr; const std::vector<EnvelopeRequest> *req = nullptr; const std::vector<int32_t> *targets = nullptr; };
+struct EnvelopeJob { const p7x_oprofile *om = nullptr; const std::vector<EnvelopeRequest> *req = nullptr; const std::vector<int32_t> *targets = nullptr;
+                     // long-target envelopes: match odds of every request in the device's table layout ([nrows][Mpad] each,
+                     // lt_stride floats apart); the length model is then the envelope's own length
+                     const float *lt_tables = nullptr; size_t lt_stride = 0; };
 struct EnvelopeScorer {
   virtual ~EnvelopeScorer() = default;
   // begin() enqueues the jobs of a batch of queries (one launch per model-length class, all profiles of a class in
@@ -155,6 +159,10 @@ void longtarget_seeds_from_rows(const Profile &p, const uint8_t *block_dsq, int6
 struct LongTargetWindowRef { int64_t start, length; int strand; };
 struct LongTargetWindowScore { float usc, bias_filtersc, vfsc; int have_vit; };
 struct LongTargetWindowRegions { int n = -2; float nexpected = 0.0f; std::vector<Region> regs; };
+// one long-target envelope for the device: window (index into the last regions() call), envelope i..j in the window,
+// and its adjusted match odds rf[x * (M + 1) + k] (x < Kp), as reparameterize() makes them
+struct LongTargetEnvRequest { int window = 0; int i = 0, j = 0; const float *rf = nullptr; };
+struct LongTargetEnvResult { float envsc = 0, oasc = 0, orig = 0; int status = 0; std::vector<uint32_t> ta; std::vector<int32_t> ti; std::vector<float> tp; };
 struct LongTargetWindowScorer {
   virtual ~LongTargetWindowScorer() = default;
   // seq1: the target, 1-based; sc[w]: MSV score (nats), bias filter score, and for windows that pass both P <= F1 tests
@@ -170,6 +178,9 @@ struct LongTargetWindowScorer {
   // p7_domaindef_ByPosteriorHeuristics) of the windows that passed the Forward filter, in one device batch:
   // out[w].n regions (-1: p7_DomainDecoding range error, the window is dropped; -2: not available, the host scans)
   virtual int regions(const uint8_t *seq1, const uint8_t *comp, const LongTargetWindowRef *w, size_t nw, std::vector<LongTargetWindowRegions> &out) = 0;
+  // rescore_isolated_domain(long_target = TRUE) of envelopes of those windows, one device batch (the envelope kernel's
+  // LT instantiation): adjusted and unmodified Forward scores, optimal-accuracy score and trace
+  virtual int envelopes(const LongTargetEnvRequest *req, size_t n, std::vector<LongTargetEnvResult> &out) = 0;
 };
 int longtarget_run_host(const p7x_pipeline_cfg &cfg, const p7x_oprofile *om, const uint8_t *dsq, const int64_t *offsets, const int64_t *lengths,
                         size_t n, const char *const *names, const char *const *accs, const char *const *descs,

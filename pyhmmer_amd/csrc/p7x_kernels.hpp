@@ -140,6 +140,9 @@ struct EnvArgs {
   float *work; int64_t work_stride; int Lmax;    // per-wavefront workspace (env_work_floats), rows 0..Lmax
   int nblocks, slab_base;   // blocks of this job (blockIdx.x beyond them exit); first workspace slab of the job
   float *out_sc;            // [nenv][2] envelope Forward score (nats), optimal accuracy score
+  const float *env_emis;    // long-target envelopes: per-envelope match odds [nenv][nrows][Mpad] (NULL: the profile's own table)
+  long long env_emis_stride;  // floats per envelope table
+  float *out_orig;          // long-target envelopes: [nenv] Forward score with the profile's unmodified odds
   float oa_guard;           // near-tie guard of the optimal-accuracy traceback (p7x_pipeline_cfg.oa_guard)
   int32_t *out_status;      // [nenv] bit 0 Forward range, 1 decoding range (envelope dropped), 2-5 traceback failures,
                             // 6 a near-tie on the trace: the host stage repeats the envelope in the reference's order

@@ -137,9 +137,11 @@ static void block_seeds(const Profile &p, const uint8_t *seq1, int64_t Lt, int64
 struct DeviceWindowScorer final : LongTargetWindowScorer {
   const p7x_oprofile *om; int device;
   p7x_seqdb *db = nullptr;
+  p7x_seqdb *rdb = nullptr;             // the windows of the last regions() call: envelopes() refers to them
+  float oa_guard = 0.0f;
   double ms = 0.0; size_t nwindows = 0;
-  DeviceWindowScorer(const p7x_oprofile *o, int d) : om(o), device(d) {}
-  ~DeviceWindowScorer() override { if (db) p7x_seqdb_destroy(db); }
+  DeviceWindowScorer(const p7x_oprofile *o, int d, float guard) : om(o), device(d), oa_guard(guard) {}
+  ~DeviceWindowScorer() override { if (db) p7x_seqdb_destroy(db); if (rdb) p7x_seqdb_destroy(rdb); }
   int score(const uint8_t *seq1, int64_t L, const uint8_t *comp, const LongTargetWindowRef *w, size_t nw, double F1, bool do_bias,
             LongTargetWindowScore *sc) override
   {
@@ -217,13 +219,53 @@ struct DeviceWindowScorer final : LongTargetWindowScorer {
     const auto t0 = std::chrono::steady_clock::now();
     std::vector<uint8_t> dsq; std::vector<int64_t> off; std::vector<int32_t> len;
     pack_windows(seq1, comp, w, nw, dsq, off, len);
-    p7x_seqdb *rdb = nullptr;
+    if (rdb) { p7x_seqdb_destroy(rdb); rdb = nullptr; }
     int st = p7x_seqdb_create(device, om->p.abc_type, dsq.data(), off.data(), len.data(), nw, &rdb);
     if (st != P7X_OK) return st;
     st = device_regions_of_all(om, rdb, out);
-    p7x_seqdb_destroy(rdb);
     ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     return st;
+  }
+
+  int envelopes(const LongTargetEnvRequest *req, size_t n, std::vector<LongTargetEnvResult> &out) override
+  {
+    out.assign(n, LongTargetEnvResult{});
+    if (n == 0) return P7X_OK;
+    if (!rdb) { set_error("long-target envelopes before the windows' region scan"); return P7X_EINVAL; }
+    const auto t0 = std::chrono::steady_clock::now();
+    const Profile &p = om->p;
+    DeviceCtx *ctx = nullptr; DevProfile *dp = nullptr;
+    int st;
+    if ((st = get_ctx(device, &ctx)) != P7X_OK || (st = get_dev_profile(om, ctx, &dp)) != P7X_OK) return st;
+    const int C = dp->vitC, Mpad = 64 * C, nrows = p.Kp + 1;
+    if (C <= 0) { set_error("model too long for the envelope kernel"); return P7X_EINVAL; }
+    // the envelopes' match odds in the kernel's table layout: [row x][position of node k], node k of lane z, slot c at c * 64 + z
+    const size_t stride = (size_t) nrows * Mpad;
+    std::vector<float> tables(n * stride, 0.0f);
+    host_parallel_for((int) n, 0, [&](int e) {
+      float *t = tables.data() + (size_t) e * stride;
+      const float *rf = req[(size_t) e].rf;
+      for (int x = 0; x < p.Kp; ++x)
+        for (int k = 1; k <= p.M; ++k) t[(size_t) x * Mpad + ((k - 1) % C) * 64 + (k - 1) / C] = rf[(size_t) x * (p.M + 1) + k];
+    });
+    std::vector<EnvelopeRequest> rq(n);
+    std::vector<int32_t> targets((size_t) rdb->n);
+    for (int64_t t = 0; t < rdb->n; ++t) targets[(size_t) t] = (int32_t) t;
+    for (size_t e = 0; e < n; ++e) rq[e] = EnvelopeRequest{ req[e].window, req[e].i, req[e].j };
+    std::unique_ptr<EnvelopeScorer> scorer = make_device_envelope_scorer(ctx, rdb, oa_guard);
+    std::vector<EnvelopeJob> jobs(1);
+    jobs[0].om = om; jobs[0].req = &rq; jobs[0].targets = &targets; jobs[0].lt_tables = tables.data(); jobs[0].lt_stride = stride;
+    if ((st = scorer->begin(jobs)) != P7X_OK) return st;
+    std::vector<std::vector<EnvelopeResult>> res;
+    if ((st = scorer->wait(res)) != P7X_OK) return st;
+    for (size_t e = 0; e < n; ++e) {
+      const EnvelopeResult &r = res[0][e];
+      LongTargetEnvResult &o = out[e];
+      o.envsc = r.envsc; o.oasc = r.oasc; o.orig = r.orig; o.status = r.status;
+      if (r.ntrace > 0) { o.ta.assign(r.ta, r.ta + r.ntrace); o.ti.assign(r.ti, r.ti + r.ntrace); o.tp.assign(r.tp, r.tp + r.ntrace); }
+    }
+    ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    return P7X_OK;
   }
 
   int viterbi(const int *which, const int *thresh, size_t n, std::vector<int> &rec) override
@@ -353,7 +395,7 @@ int p7x_search_longtargets(const p7x_pipeline_cfg *cfg, const p7x_oprofile *om, 
                    std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - ts1).count());
   }
   const auto t_host = std::chrono::steady_clock::now();
-  DeviceWindowScorer scorer(om, device);
+  DeviceWindowScorer scorer(om, device, cfg->oa_guard);
   st = longtarget_run_host(*cfg, om, dsq, offsets, lengths, n, names, accs, descs, seeds, out, &scorer);
   if (st == P7X_OK && *out) {
     (*out)->ms[7] = scan_ms;                                   // the SSV scan kernels (HIP events)

@@ -548,6 +548,9 @@ static bool lt_forward_test(const p7x_pipeline_cfg &cfg, const Profile &p, int64
   return !(exp_surv(seq_score, p.evparam[P7X_FTAU], p.evparam[P7X_FLAMBDA]) > cfg.F3);
 }
 
+static int lt_window_hits(const p7x_pipeline_cfg &cfg, const Profile &p, int max_length, uint64_t nres_so_far, const LtBlock &blk, const LtTarget &tg,
+                          int64_t window_start, DomainDefResult &dd, std::vector<Hit> &hits);
+
 // The rest of p7_pli_postViterbi_LongTarget for a window that passed the Forward filter: Backward, domain definition
 // with long_target = TRUE, one hit per domain.  <dev>: the device's region scan of this window (n >= 0), else the host
 // runs the parsers itself.
@@ -582,6 +585,13 @@ static int lt_post_viterbi(const p7x_pipeline_cfg &cfg, const Profile &p, const 
     for (const Domain &d : dd.dcl) std::fprintf(stderr, "[lt]   env %lld-%lld ali %lld-%lld hmm %d-%d envsc %.3f domcorr %.3f\n", (long long) d.ienv, (long long) d.jenv,
                                                  (long long) d.iali, (long long) d.jali, d.hmmfrom, d.hmmto, d.envsc, d.domcorrection);
   }
+  return lt_window_hits(cfg, p, max_length, nres_so_far, blk, tg, window_start, dd, hits);
+}
+
+// The domains of one window (coordinates relative to the window) -> hits: p7_pli_postDomainDef of the long-target pipeline
+static int lt_window_hits(const p7x_pipeline_cfg &cfg, const Profile &p, int max_length, uint64_t nres_so_far, const LtBlock &blk, const LtTarget &tg,
+                          int64_t window_start, DomainDefResult &dd, std::vector<Hit> &hits)
+{
   if (dd.nregions == 0 || dd.nenvelopes == 0) return P7X_OK;
   for (Domain &dom : dd.dcl) {
     const int64_t env_len = dom.jenv - dom.ienv + 1, ali_len = dom.jali - dom.iali + 1;
@@ -981,6 +991,25 @@ static int lt_run_host(const p7x_pipeline_cfg &cfg, const p7x_oprofile *om, cons
     std::vector<std::vector<Hit>> jh(vj.size());
     std::vector<LtCounters> jc(vj.size());
     std::vector<int> jst(vj.size(), P7X_OK);
+    // With a device and null2 on, the single-domain envelopes of all windows are rescored by the envelope kernel's
+    // long-target instantiation in two batches (the second for the envelopes that are trimmed to their alignment):
+    // phase A queues them, phase B builds their composition-adjusted odds and runs them, phase C makes the hits.
+    // Whether that pays is a matter of numbers: the kernel's time is the latency of its longest envelope (two rounds of
+    // ~27 ms for envelopes of a 1,203-node model, 1,024 of them at a time), the host workers need ~8.4 ms of one thread
+    // for such an envelope (measured on the benchmark, profiles/r03_bench.json: 110 envelopes, 16 threads: 58 ms either
+    // way).  A handful of hits stays with the host workers; a repeat family with thousands of copies goes to the device.
+    // cfg.host_envelopes: 1 always the host, 2 always the device (tests), 0 by that estimate.
+    bool dev_env = filters != nullptr && lto.do_null2 && !dev_regions.empty() && cfg.host_envelopes != 1;
+    if (dev_env && cfg.host_envelopes != 2) {
+      size_t nsingle = 0;
+      for (const LongTargetWindowRegions &w : dev_regions) for (const Region &r : w.regs) nsingle += r.multi ? 0 : 1;
+      const int threads = cfg.host_threads > 0 ? cfg.host_threads : tophits_usable_cpus();
+      const double host_ms = (double) nsingle * 8.4 * ((double) p.M / 1203.0) / (double) std::max(1, threads);
+      const double dev_ms = 67.0 * (double) ((nsingle + 1023) / 1024);
+      dev_env = nsingle > 0 && host_ms > dev_ms;
+    }
+    struct WinDD { DomainDefResult dd; std::vector<EnvelopeRequest> defer; bool active = false; };
+    std::vector<WinDD> wdd(dev_env ? vj.size() : 0);
     host_parallel_for((int) vj.size(), cfg.host_threads, [&](int zi) {
       const size_t z = (size_t) zi;
       flogsum_init();
@@ -989,10 +1018,111 @@ static int lt_run_host(const p7x_pipeline_cfg &cfg, const p7x_oprofile *om, cons
       LtBlock blk{ nullptr, job->bn, job->strand == 0 ? job->i + 1 : job->i + job->bn, job->strand == 1 };
       jc[z].n_past_vit++; jc[z].pos_past_vit += (uint64_t) vw.length;
       if (!pass[z]) return;
-      const LtTarget &tgr = tg;
-      jst[z] = lt_post_viterbi(cfg, p, lto, max_length, job->nres_at, blk, tgr, bp, vw.length, subs[z].data(), fwd_of[z],
-                               dev_of[z] >= 0 && (size_t) dev_of[z] < dev_regions.size() ? &dev_regions[(size_t) dev_of[z]] : nullptr, jh[z], jc[z]);
+      const LongTargetWindowRegions *dr = dev_of[z] >= 0 && (size_t) dev_of[z] < dev_regions.size() ? &dev_regions[(size_t) dev_of[z]] : nullptr;
+      if (dev_env && dr && dr->n >= 0) {           // phase A: regions -> queued envelopes; multi-domain regions resolved here, on the host
+        jc[z].n_past_fwd++; jc[z].pos_past_fwd += (uint64_t) vw.length;
+        WinDD &w = wdd[z];
+        t_long_target = &lto;
+        int st = domaindef_from_regions(p, subs[z].data(), (int) vw.length, dr->nexpected, dr->regs.data(), dr->n, cfg.seed, cfg.seed != 0, w.dd, &w.defer, (int) z);
+        if (st == P7X_OK) st = domaindef_finish_multi(p, subs[z].data(), (int) vw.length, cfg.seed, cfg.seed != 0, w.dd, nullptr, (int) z);
+        t_long_target = nullptr;
+        if (st != P7X_OK && st != P7X_ERANGE) jst[z] = st;
+        w.active = st == P7X_OK;
+        return;
+      }
+      jst[z] = lt_post_viterbi(cfg, p, lto, max_length, job->nres_at, blk, tg, bp, vw.length, subs[z].data(), fwd_of[z], dr, jh[z], jc[z]);
     });
+    if (dev_env) {
+      for (size_t z = 0; z < vj.size(); ++z) if (jst[z] != P7X_OK) return jst[z];
+      // phase B: every queued envelope, two rounds
+      struct EnvState { size_t z; int slot; int i, j; std::vector<float> rf; LongTargetEnvResult res; bool host = false, done = false; };
+      std::vector<EnvState> es;
+      for (size_t z = 0; z < vj.size(); ++z) if (wdd[z].active)
+        for (size_t q = 0; q < wdd[z].defer.size(); ++q) { EnvState e; e.z = z; e.slot = (int) q; e.i = wdd[z].defer[q].i; e.j = wdd[z].defer[q].j; es.push_back(std::move(e)); }
+      auto trace_of = [&](const LongTargetEnvResult &r, int i, Trace &tr) {
+        tr.clear();
+        for (size_t q = 0; q < r.ta.size(); ++q) tr.append((int) (r.ta[q] & 0xffu), (int) ((r.ta[q] >> 8) & 0xffffu), r.ti[q], r.tp[q]);
+        tr.reverse();
+        for (size_t q = 0; q < tr.st.size(); ++q) if (tr.i[q] > 0) tr.i[q] += i - 1;
+      };
+      std::vector<size_t> todo(es.size());
+      for (size_t e = 0; e < es.size(); ++e) todo[e] = e;
+      for (int round = 0; round < 2 && !todo.empty(); ++round) {
+        host_parallel_for((int) todo.size(), cfg.host_threads, [&](int q) {
+          EnvState &e = es[todo[(size_t) q]];
+          reparameterize(p, lto, subs[e.z].data(), (int) vj[e.z].vw.length, e.i, e.j, e.rf);
+        });
+        std::vector<LongTargetEnvRequest> rq(todo.size());
+        for (size_t q = 0; q < todo.size(); ++q) { const EnvState &e = es[todo[q]]; rq[q] = LongTargetEnvRequest{ dev_of[e.z], e.i, e.j, e.rf.data() }; }
+        std::vector<LongTargetEnvResult> rs;
+        const int st = filters->envelopes(rq.data(), rq.size(), rs);
+        if (st != P7X_OK) return st;
+        std::vector<size_t> next;
+        std::vector<char> again(todo.size(), 0);
+        host_parallel_for((int) todo.size(), cfg.host_threads, [&](int q) {
+          EnvState &e = es[todo[(size_t) q]];
+          e.res = std::move(rs[(size_t) q]);
+          const int stt = e.res.status;
+          if ((stt & 2) || (stt & 0xff & ~(3 | 64))) { e.done = true; return; }      // dropped (range error / traceback failure), as the host would
+          if (stt & 64) { e.host = true; e.done = true; return; }                   // a near-tie: the host twin repeats this envelope from the start
+          if (round == 0) {
+            thread_local Trace tr;
+            trace_of(e.res, e.i, tr);
+            Domain d;
+            make_alidisplay(p, tr, subs[e.z].data(), (int) vj[e.z].vw.length, d);
+            if (e.i < d.sqfrom - lto.max_env_extra || e.j > d.sqto + lto.max_env_extra) {
+              e.i = std::max<int>(e.i, (int) d.sqfrom - lto.max_env_extra);
+              e.j = std::min<int>(e.j, (int) d.sqto + lto.max_env_extra);
+              again[(size_t) q] = 1;
+              return;
+            }
+          }
+          e.done = true;
+        });
+        for (size_t q = 0; q < todo.size(); ++q) if (again[q]) next.push_back(todo[q]);
+        todo.swap(next);
+      }
+      tick("envelopes on the device");
+      // phase C: the windows' domains in order, then their hits
+      std::vector<std::vector<size_t>> of_win(vj.size());
+      for (size_t e = 0; e < es.size(); ++e) of_win[es[e].z].push_back(e);
+      host_parallel_for((int) vj.size(), cfg.host_threads, [&](int zi) {
+        const size_t z = (size_t) zi;
+        if (!wdd[z].active) return;
+        flogsum_init();
+        WinDD &w = wdd[z];
+        const BlockJob *job; int64_t bp; geometry(z, job, bp);
+        const int L = (int) vj[z].vw.length;
+        const uint8_t *dsq = subs[z].data();
+        std::vector<Domain> kept;
+        thread_local Workspace hws;
+        thread_local Trace tr;
+        for (Domain &d : w.dd.dcl) {
+          if (d.deferred == -2) { for (Domain &m : w.dd.multi[(size_t) d.multi_slot]) kept.push_back(std::move(m)); continue; }
+          if (d.deferred < 0) { kept.push_back(std::move(d)); continue; }
+          EnvState &e = es[of_win[z][(size_t) d.deferred]];
+          if (e.host) {                 // the reference's order of operations, from the untrimmed envelope
+            Model om{ &p, p.M, {} };
+            om.lt = &lto; om.prepare(); om.configure(false, L);
+            DomainDefResult one; one.n2sc.assign((size_t) L + 1, 0.0f);
+            if (rescore_isolated_domain(p, om, dsq, L, (int) d.ienv, (int) d.jenv, false, hws, one) == P7X_OK && !one.dcl.empty()) kept.push_back(std::move(one.dcl[0]));
+            continue;
+          }
+          const int stt = e.res.status;
+          if ((stt & 2) || (stt & 0xff & ~(3 | 64)) || e.res.ta.empty()) continue;
+          trace_of(e.res, e.i, tr);
+          Domain dom;
+          make_alidisplay(p, tr, dsq, L, dom);
+          dom.domcorrection = std::max(0.0f, e.res.orig - e.res.envsc);      // the score lost to the composition-adjusted background
+          dom.ienv = e.i; dom.jenv = e.j; dom.envsc = e.res.orig; dom.oasc = e.res.oasc;
+          dom.iali = dom.sqfrom; dom.jali = dom.sqto;
+          kept.push_back(std::move(dom));
+        }
+        w.dd.dcl = std::move(kept);
+        LtBlock blk{ nullptr, job->bn, job->strand == 0 ? job->i + 1 : job->i + job->bn, job->strand == 1 };
+        jst[z] = lt_window_hits(cfg, p, max_length, job->nres_at, blk, tg, bp, w.dd, jh[z]);
+      });
+    }
     for (size_t z = 0; z < vj.size(); ++z) {
       if (jst[z] != P7X_OK) return jst[z];
       for (Hit &h : jh[z]) hits.push_back(std::move(h));

@@ -1362,7 +1362,7 @@ class Pipeline:
         self.bit_cutoffs = bit_cutoffs
         self.device = device
         self.host_threads = host_threads
-        self.host_envelopes = bool(host_envelopes)
+        self.host_envelopes = int(host_envelopes)       # bool for the protein pipeline; long targets: 0 auto, 1 host, 2 device
         self.host_regions = bool(host_regions)
         self.oa_guard = oa_guard          # None: the library's default (p7x_pipeline_cfg.oa_guard)
         self._mode = _P7X_SEARCH_SEQS
@@ -1391,7 +1391,7 @@ class Pipeline:
             c.domZ, c.domZ_setby = float(self.domZ), 1
         c.use_bit_cutoffs = 0 if self.bit_cutoffs is None else self._BIT_CUTOFFS[self.bit_cutoffs]
         c.host_threads = int(self.host_threads)
-        c.host_envelopes = int(self.host_envelopes)
+        c.host_envelopes = int(self.host_envelopes)      # long targets also take 2: always the device (see p7x.h)
         c.host_regions = int(self.host_regions)
         if self.oa_guard is not None:
             c.oa_guard = float(self.oa_guard)

@@ -14,6 +14,17 @@ from test_host_longtarget import _read, _rows, check_bmyd2_table, check_nhmmer_t
 pytestmark = pytest.mark.gpu
 
 
+def rows_agree(dev, ref):
+    """Device search against the CPU harness: names, coordinates, strands and flags identical; scores, biases and E-values
+    to float32 summation-order noise (the device rescoring the envelopes sums Forward / Backward in another order)."""
+    assert len(dev) == len(ref), (len(dev), len(ref))
+    for a, b in zip(dev, ref):
+        assert a[:8] == b[:8], (a, b)                        # name, model and target coordinates, envelope, strand
+        assert a[11:] == b[11:], (a, b)                      # reported / included
+        assert a[8] == pytest.approx(b[8], rel=2e-3, abs=1e-300), (a, b)
+        assert a[9] == pytest.approx(b[9], abs=3e-3) and a[10] == pytest.approx(b[10], abs=3e-3), (a, b)
+
+
 def device_seeds(om, cfg, residues, complement):
     cap = 1 << 16
     seeds = np.zeros((cap, 3), dtype=np.int64)
@@ -82,7 +93,13 @@ def test_nhmmer_bmyd_tables_through_the_device(oracle):
         seqs = _read(target, hmm.alphabet)
         hits = next(hmmer.nhmmer(hmm, seqs))
         ref = host_pipeline.host_nhmmer(oracle, hmm, seqs)
-        assert _rows(hits) == _rows(ref)
+        rows_agree(_rows(hits), _rows(ref))
+        # the envelopes through the envelope kernel's long-target instantiation (host_envelopes=2: always; by default a
+        # handful of envelopes stays with the host workers) and through the host workers: the same rows, the same table
+        for where in (1, 2):
+            forced = next(hmmer.nhmmer(hmm, seqs, host_envelopes=where))
+            rows_agree(_rows(forced), _rows(ref))
+            (check_bmyd2_table if table == "bmyD2.tbl" else check_nhmmer_table)(forced, golden_table(table))
         if table == "bmyD2.tbl":
             check_bmyd2_table(hits, golden_table(table))
         else:
@@ -123,10 +140,13 @@ def test_nhmmer_dealt_over_devices_equals_one_device():
     small = bw.make_chromosome(hmm, 150_000, planted=3, seed=12)
     block = easel.DigitalSequenceBlock(abc, [easel.DigitalSequence(abc, name="chrA", sequence=big),
                                              easel.DigitalSequence(abc, name="ctgB", sequence=small)])
-    one = next(hmmer.nhmmer(hmm, block))
+    # host_envelopes=1: where the envelopes are rescored (host workers or envelope kernel) is decided by their number, which a
+    # part sees less of than the whole; pinned to the host workers the dealt search equals the whole one bit for bit
+    one = next(hmmer.nhmmer(hmm, block, host_envelopes=1))
     assert len(one) > 40 and any(h.duplicate for h in one)
+    rows_agree(_rows(next(hmmer.nhmmer(hmm, block, devices=[0, 0]))), _rows(one))
     for devs in ([0, 0, 0], [0] * 5):
-        many = next(hmmer.nhmmer(hmm, block, devices=devs))
+        many = next(hmmer.nhmmer(hmm, block, devices=devs, host_envelopes=1))
         assert _rows(many) == _rows(one), devs
         assert [(h.evalue, h.reported, h.included, h.duplicate) for h in many] == [(h.evalue, h.reported, h.included, h.duplicate) for h in one]
         assert many.stage_counts == one.stage_counts and many.searched_residues == one.searched_residues
@@ -166,3 +186,23 @@ def test_device_ssv_every_register_count(M, oracle):
         assert got.tolist() == want.tolist(), (M, strand)
         total += len(want)
     assert total >= 10, total
+
+
+def test_long_target_envelopes_on_the_device_equal_the_host_workers():
+    """A hit-rich search (250 planted copies on 3 Mbp: the case the device path is for): the envelope kernel's long-target
+    instantiation (two rounds: the envelope, then the envelope trimmed to its alignment; composition-adjusted odds per
+    envelope; Forward with the unmodified odds for the bias) against the host workers' rescore_isolated_domain: the same
+    hits, coordinates and flags, scores to float32 noise."""
+    import bench_workloads as bw
+    hmm = load_hmms("bmyD")[0]
+    abc = hmm.alphabet
+    seq = bw.make_chromosome(hmm, 3_000_000, planted=250, seed=21)
+    seq[1_000_000:1_000_040] = 15                                   # N inside a window
+    block = easel.DigitalSequenceBlock(abc, [easel.DigitalSequence(abc, name="chrC", sequence=seq)])
+    host = next(hmmer.nhmmer(hmm, block, host_envelopes=1))
+    dev = next(hmmer.nhmmer(hmm, block, host_envelopes=2))
+    assert len(host) > 200
+    rows_agree(_rows(dev), _rows(host))
+    assert dev.stage_counts == host.stage_counts
+    auto = next(hmmer.nhmmer(hmm, block))                          # the default picks one of the two
+    rows_agree(_rows(auto), _rows(host))
