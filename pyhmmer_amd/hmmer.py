@@ -292,7 +292,8 @@ def _batch_cap(db: "ShardedDatabase") -> int:
     profiles share a launch set the better: round 3 measured 3.4 TCUPS with batches of 256, 4.5 with 1,024, 5.2 with 2,048
     and 5.6 with 4,096 profiles on the 20,000-profile x 2,100-sequence scan (profiles/r03_scan_sweep.txt).  The cap falls
     with the number of targets, because the batch's workspace is (profiles x targets) slots."""
-    ntargets = max(1, max(int(_lib.lib().p7x_seqdb_ntargets(sh._handle)) for sh in db.shards))
+    known = getattr(db, "shard_targets", None)
+    ntargets = max(1, int(known)) if known is not None else max(1, max(int(_lib.lib().p7x_seqdb_ntargets(sh._handle)) for sh in db.shards))
     return int(min(_BATCH_LIMIT, max(_BATCH_MAX, _BATCH_SLOTS // ntargets)))
 
 

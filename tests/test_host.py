@@ -324,6 +324,7 @@ def test_automatic_batches_follow_the_cell_budget():
 
     class Recorder(_FakeShards):
         shard_residues = 100_000_000
+        shard_targets = 300_000
 
         def __init__(self):
             super().__init__(3)
@@ -345,6 +346,12 @@ def test_automatic_batches_follow_the_cell_budget():
         assert len(b) == 1 or sum(b) * Recorder.shard_residues <= budget * (1 + 1e-9)
     assert 64 < max(len(b) for b in db.batches) <= int(budget // (40 * Recorder.shard_residues))    # 40-node models: the budget holds 150 of them
     assert any(b == [3000, 3000] for b in db.batches)                    # 3e11 cells each: two per batch
+    # a small block (hmmscan's query sequences, a proteome): the cap grows to what the workspace allows
+    small = Recorder()
+    small.shard_residues, small.shard_targets = 700_000, 2_100
+    assert hmmer._batch_cap(small) == 3994 and hmmer._batch_cap(db) == hmmer._BATCH_MAX
+    out = list(hmmer._run_queries(small, [None], qs, 3, 2, 1, 0, batch=0))          # a sized source: sorted as a whole
+    assert [q.i for q, _ in out] == list(range(700)) and len(small.batches) == 1 and small.batches[0] == sorted(q.M for q in qs)
 
 
 def test_forward_parser_in_reference_summation_order_is_bit_identical_to_the_oracle(models, oracle, proteome):
