@@ -268,6 +268,10 @@ int  p7x_search_batch_enqueue(const p7x_pipeline_cfg *cfg, const p7x_oprofile *c
 int  p7x_search_batch_finish(p7x_pending *pending, const char *const *names, const char *const *accs,
                              const char *const *descs, p7x_tophits **outs);
 size_t p7x_pending_nqueries(const p7x_pending *pending);
+/* Test seam of the bias filter's logarithm: out[i] = the device's (float) log((double) in[i]) as bias_kernel takes it at every
+ * residue (a table + series evaluation in double; claimed to round to the same float as the C library's logarithm, which
+ * is what the reference's esl_hmm_Forward calls: tests/test_gpu_filters.py checks every float of [2^-7, 2^7)). */
+int  p7x_debug_log_of_float(int device, const float *in, float *out, size_t n);
 /* Parity seam of the batched cascade (the multi-profile twin of p7x_filters_batch): runs stage 1 exactly as
  * p7x_search_batch_enqueue queues it -- profiles grouped into kernel classes, the hybrid lane / wave MSV split, the work
  * lists -- and returns what the stages left behind, [nq][ntargets] in caller order of both: xJ (every target; -1

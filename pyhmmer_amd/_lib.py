@@ -199,6 +199,7 @@ _SIGNATURES = {
     "p7x_search_batch_enqueue": (C.c_int, [C.POINTER(PipelineCfg), C.POINTER(_VP), C.c_size_t, _VP, _VP, C.POINTER(_VP)]),
     "p7x_search_batch_finish": (C.c_int, [_VP, _VP, _VP, _VP, C.POINTER(_VP)]),
     "p7x_pending_nqueries": (C.c_size_t, [_VP]),
+    "p7x_debug_log_of_float": (C.c_int, [C.c_int, _VP, _VP, C.c_size_t]),
     "p7x_search_batch_raw": (C.c_int, [C.POINTER(PipelineCfg), C.POINTER(_VP), C.c_size_t, _VP, _VP, _VP, _VP, _VP]),
     "p7x_search_longtargets": (C.c_int, [C.POINTER(PipelineCfg), _VP, C.c_int, _VP, _VP, _VP, C.c_size_t, _VP, _VP, _VP, C.POINTER(_VP)]),
     "p7x_ssv_longtarget_seeds": (C.c_int64, [C.POINTER(PipelineCfg), _VP, C.c_int, _VP, C.c_int64, C.c_int, _VP, C.c_size_t]),

@@ -16,10 +16,12 @@
 typedef short s2 __attribute__((ext_vector_type(2)));
 
 enum Op { PK_ADD_SAT = 0, PK_MAX = 1, PK_ADD_MAX_MIX = 2, ADD_U32 = 3, FMA_F32 = 4, PK_ADD_WRAP = 5,
-          MAX3_I16 = 6, MAX_I16 = 7, ADD_I16_SAT = 8, MAX3_I32 = 9, MAX_I32 = 10, ADD_I32_SAT = 11, PK_ADD_MAX3_MIX = 12, MED3_I16 = 13, NOPS };
+          MAX3_I16 = 6, MAX_I16 = 7, ADD_I16_SAT = 8, MAX3_I32 = 9, MAX_I32 = 10, ADD_I32_SAT = 11, PK_ADD_MAX3_MIX = 12, MED3_I16 = 13,
+          FMA_F32_2V = 14, FMA_F32_K = 15, NOPS };
 static const char *kOpName[NOPS] = { "v_pk_add_i16 clamp", "v_pk_max_i16", "pk_add clamp + pk_max (MSV mix)", "v_add_u32", "v_fma_f32", "v_pk_add_u16",
                                      "v_max3_i16 op_sel (lo,lo,hi)", "v_max_i16 (VOP2)", "v_add_i16 clamp (VOP3)", "v_max3_i32", "v_max_i32 (VOP2)",
-                                     "v_add_i32 clamp (VOP3)", "pk_add clamp + max3_i16 (candidate)", "v_med3_i16" };
+                                     "v_add_i32 clamp (VOP3)", "pk_add clamp + max3_i16 (candidate)", "v_med3_i16",
+                                     "v_fma_f32 c, c, e, c (2 VGPRs read)", "v_fma_f32 c, c, 1.0, e (2 VGPRs read)" };
 
 // One asm statement holds the whole unrolled body (.rept): between separate asm statements the compiler puts a
 // conservative s_nop, which would be measured too.
@@ -31,6 +33,9 @@ static const char *kOpName[NOPS] = { "v_pk_add_i16 clamp", "v_pk_max_i16", "pk_a
 #define I_PK_MAX(c)      "v_pk_max_i16 %" #c ", %" #c ", %16\n\t"
 #define I_ADD_U32(c)     "v_add_u32 %" #c ", %" #c ", %16\n\t"
 #define I_FMA_F32(c)     "v_fma_f32 %" #c ", %" #c ", %16, %16\n\t"
+// the control above reads three VGPR operands (c, e, e); these two read two: is the 4-cycle figure the operand fetch?
+#define I_FMA_F32_2V(c)  "v_fma_f32 %" #c ", %" #c ", %16, %" #c "\n\t"
+#define I_FMA_F32_K(c)   "v_fma_f32 %" #c ", %" #c ", 1.0, %16\n\t"
 #define I_MAX3_I16(c)    "v_max3_i16 %" #c ", %" #c ", %16, %16 op_sel:[0,0,1,0]\n\t"
 #define I_MED3_I16(c)    "v_med3_i16 %" #c ", %" #c ", %16, %16 op_sel:[0,0,1,0]\n\t"
 #define I_MAX_I16(c)     "v_max_i16 %" #c ", %" #c ", %16\n\t"
@@ -70,6 +75,8 @@ __device__ __forceinline__ void body(uint32_t (&v)[8], uint32_t (&acc)[8], uint3
   else if constexpr (OP == PK_MAX) { P7X_EMIT(I_PK_MAX) }
   else if constexpr (OP == ADD_U32) { P7X_EMIT(I_ADD_U32) }
   else if constexpr (OP == FMA_F32) { P7X_EMIT(I_FMA_F32) }
+  else if constexpr (OP == FMA_F32_2V) { P7X_EMIT(I_FMA_F32_2V) }
+  else if constexpr (OP == FMA_F32_K) { P7X_EMIT(I_FMA_F32_K) }
   else if constexpr (OP == MAX3_I16) { P7X_EMIT(I_MAX3_I16) }
   else if constexpr (OP == MED3_I16) { P7X_EMIT(I_MED3_I16) }
   else if constexpr (OP == MAX_I16) { P7X_EMIT(I_MAX_I16) }
@@ -145,7 +152,7 @@ static void sweep(int num_cu, double clk_hz, uint32_t *d_out, unsigned long long
   }
 }
 
-int main()
+int main(int argc, char **argv)
 {
   hipDeviceProp_t prop; CK(hipGetDeviceProperties(&prop, 0));
   const int num_cu = prop.multiProcessorCount;
@@ -159,6 +166,9 @@ int main()
   CK(hipMalloc(&d_out, (size_t) num_cu * 4 * 8 * 64 * 4)); CK(hipMalloc(&d_cyc, (size_t) num_cu * 4 * 8 * 8));
   sweep<ADD_U32>(num_cu, clk_hz, d_out, d_cyc);
   sweep<FMA_F32>(num_cu, clk_hz, d_out, d_cyc);
+  sweep<FMA_F32_2V>(num_cu, clk_hz, d_out, d_cyc);
+  sweep<FMA_F32_K>(num_cu, clk_hz, d_out, d_cyc);
+  if (argc > 1 && argv[1][0] == 'f') return 0;          // "f": the f32 controls only
   sweep<PK_ADD_SAT>(num_cu, clk_hz, d_out, d_cyc);
   sweep<PK_ADD_WRAP>(num_cu, clk_hz, d_out, d_cyc);
   sweep<PK_MAX>(num_cu, clk_hz, d_out, d_cyc);

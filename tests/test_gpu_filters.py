@@ -301,3 +301,25 @@ def test_nucleotide_alphabets_through_every_filter(kind, oracle):
     assert np.max(np.abs(got["filtersc"] - want["bias"])) < BIAS_TOL_NATS
     hits = plan7.Pipeline(abc, E=1e3).search_hmm(hmm, blk)
     assert len(hits) >= 4 and all(h.domains[0].alignment.target_sequence for h in hits)
+
+
+def test_bias_filter_logarithm_equals_the_library_logarithm_for_every_float():
+    """bias_kernel takes (float) log((double) x) at every residue through log_of_float (a 128-entry table and five series
+    terms in double) instead of the library call the reference makes in esl_hmm_Forward.  The arguments are sums of two
+    probability x odds products, of order one: EVERY float of [2^-7, 2^7) -- 14 binades, 117,440,512 values -- must give
+    the same float as the host's log(); zero, denormals, infinity and NaN take the library path."""
+    import ctypes as C
+    from pyhmmer_amd import _lib
+    bad = 0
+    for e in range(-7, 7):
+        bits = np.arange(1 << 23, dtype=np.uint32) | np.uint32((127 + e) << 23)
+        x = bits.view(np.float32)
+        out = np.empty_like(x)
+        assert _lib.lib().p7x_debug_log_of_float(0, x.ctypes.data, out.ctypes.data, x.size) == 0, _lib.last_error()
+        want = np.log(x.astype(np.float64)).astype(np.float32)
+        bad += int(np.count_nonzero(out != want))
+    assert bad == 0, bad
+    x = np.array([0.0, 1e-42, np.inf, 1.0, 2.0], dtype=np.float32)
+    out = np.empty_like(x)
+    assert _lib.lib().p7x_debug_log_of_float(0, x.ctypes.data, out.ctypes.data, x.size) == 0
+    assert out[0] == -np.inf and out[2] == np.inf and out[3] == 0.0 and out[4] == np.float32(np.log(2.0)) and abs(out[1] - np.log(1e-42)) < 1e-3
