@@ -76,8 +76,12 @@ static int scan_target(const p7x_pipeline_cfg &cfg, const Profile &p, DeviceCtx 
     P7X_HIP(hipStreamSynchronize(s));                       // <list> leaves scope
     a.chunk_list = static_cast<const long long *>(d_chunks.p); a.nchunks = (long long) list.size();
   }
-  hipEvent_t e0, e1;
-  P7X_HIP(hipEventCreate(&e0)); P7X_HIP(hipEventCreate(&e1));
+  struct Events {                     // destroyed on every way out
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    ~Events() { if (e0) (void) hipEventDestroy(e0); if (e1) (void) hipEventDestroy(e1); }
+  } ev;
+  P7X_HIP(hipEventCreate(&ev.e0)); P7X_HIP(hipEventCreate(&ev.e1));
+  hipEvent_t e0 = ev.e0, e1 = ev.e1;
   int cap = (int) std::min<int64_t>(std::max<int64_t>(1 << 16, L / 64), 1 << 28);
   for (int attempt = 0; attempt < 2; ++attempt) {
     if ((st = d_pos.alloc((size_t) cap * 8)) || (st = d_strand.alloc((size_t) cap)) || (st = d_k.alloc((size_t) cap * 4)) || (st = d_sc.alloc((size_t) cap * 4))) return st;
@@ -103,22 +107,22 @@ static int scan_target(const p7x_pipeline_cfg &cfg, const Profile &p, DeviceCtx 
       rows.resize((size_t) nrec);
       for (int i = 0; i < nrec; ++i) rows[(size_t) i] = ScanRow{ pos[(size_t) i], strand[(size_t) i], k[(size_t) i], sc[(size_t) i] };
       std::sort(rows.begin(), rows.end(), [](const ScanRow &x, const ScanRow &y) { return x.strand != y.strand ? x.strand < y.strand : x.pos < y.pos; });
-      (void) hipEventDestroy(e0); (void) hipEventDestroy(e1);
       return P7X_OK;
     }
     cap = nrec + 1024;              // more rows than the buffer holds: once more with room for all of them
   }
-  (void) hipEventDestroy(e0); (void) hipEventDestroy(e1);
   set_error("long-target SSV scan: record buffer could not be sized");
   return P7X_EMEM;
 }
 
 // seeds of one block of one strand from the rows of the whole-strand scan
+// <shift>: what the scan's row positions are ahead of the target's own strand positions (a scan over several targets
+// laid end to end)
 static void block_seeds(const Profile &p, const uint8_t *seq1, int64_t Lt, int64_t i, int64_t bn, int strand, const std::vector<ScanRow> &rows,
-                        int sc_thresh, int xB, std::vector<int64_t> &seeds3)
+                        int sc_thresh, int xB, std::vector<int64_t> &seeds3, int64_t shift = 0)
 {
   // block rows 1..bn: strand 0: original positions i+1 .. i+bn; strand 1: reverse-strand positions (Lt-i-bn)+1 .. (Lt-i-bn)+bn
-  const int64_t base = strand == 0 ? i : Lt - i - bn;
+  const int64_t base = (strand == 0 ? i : Lt - i - bn) + shift;
   std::vector<LongTargetRow> br;
   auto lo = std::lower_bound(rows.begin(), rows.end(), ScanRow{ base + 1, strand, 0, 0 },
                              [](const ScanRow &x, const ScanRow &y) { return x.strand != y.strand ? x.strand < y.strand : x.pos < y.pos; });
@@ -353,17 +357,41 @@ int p7x_search_longtargets(const p7x_pipeline_cfg *cfg, const p7x_oprofile *om, 
   const auto t_begin = std::chrono::steady_clock::now();
   std::vector<LongTargetSeed> seeds;
   double scan_ms = 0.0;
+  // One scan for the whole target set: the records lie end to end in <dsq> with a sentinel between them, which the scan
+  // kernels take as the end of every diagonal, so a file of 1e5 contigs costs one launch, one upload and one set of
+  // buffers like a single chromosome does.  Scan position q of strand 0 is dsq[q]; of strand 1 it is dsq[Ltot - q + 1]
+  // (the whole buffer read backwards: the last target's reverse strand comes first).
+  std::vector<uint8_t> packed;                    // only when the caller's records do not lie end to end
+  std::vector<int64_t> poff;
+  const int64_t *off = offsets;
+  const uint8_t *base = dsq;
+  {
+    bool contiguous = n == 0 || offsets[0] >= 1;
+    for (size_t t = 0; contiguous && t + 1 < n; ++t) contiguous = offsets[t + 1] == offsets[t] + lengths[t] + 1;
+    for (size_t t = 0; contiguous && t + 1 < n; ++t) contiguous = dsq[offsets[t] + lengths[t]] >= (uint8_t) p.Kp;
+    if (!contiguous) {
+      poff.resize(n);
+      int64_t at = 1;
+      for (size_t t = 0; t < n; ++t) { poff[t] = at; at += std::max<int64_t>(lengths[t], 0) + 1; }
+      packed.assign((size_t) at + 1, 255);
+      for (size_t t = 0; t < n; ++t) if (lengths[t] > 0) std::memcpy(packed.data() + poff[t], dsq + offsets[t], (size_t) lengths[t]);
+      off = poff.data(); base = packed.data();
+    }
+  }
+  const int64_t first_at = n ? off[0] : 1;                                  // the scan starts at the first record
+  const int64_t Ltot = n ? off[n - 1] + std::max<int64_t>(lengths[n - 1], 0) - first_at : 0;   // scan positions 1..Ltot
+  const uint8_t *scan1 = base + first_at - 1;                               // scan1[q] = position q of strand 0
   LongTargetUnits all_units; all_units.count(*cfg, max_length, lengths, n);
   uint64_t unit = 0;
+  // upstream's bookkeeping per (target, block, strand): the units are independent, the host workers take them side by
+  // side; with the search dealt over several devices (cfg.lt_nparts) this call only has the units of its part
+  struct Unit { size_t t; int64_t i, bn; int strand; int64_t shift; std::vector<int64_t> s3; };
+  std::vector<Unit> units;
+  std::vector<ScanRange> ranges;
   for (size_t t = 0; t < n; ++t) {
     const int64_t Lt = lengths[t];
     if (Lt <= 0) continue;
-    const uint8_t *seq1 = dsq + offsets[t] - 1;
-    // upstream's bookkeeping per (block, strand): the units are independent, the host workers take them side by side;
-    // with the search dealt over several devices (cfg.lt_nparts) this call only has the units of its part
-    struct Unit { int64_t i, bn; int strand; std::vector<int64_t> s3; };
-    std::vector<Unit> units;
-    std::vector<ScanRange> ranges;
+    const int64_t at = off[t] - first_at + 1;                 // scan position of the target's first residue on strand 0
     for (int64_t i = 0; i < Lt; i += W - C) {
       const int64_t bc = i == 0 ? 0 : std::min<int64_t>(C, Lt - i);
       const int64_t bw = std::min<int64_t>(W, Lt - i - bc);
@@ -371,27 +399,30 @@ int p7x_search_longtargets(const p7x_pipeline_cfg *cfg, const p7x_oprofile *om, 
       if (bn <= 0) break;
       for (int strand = 0; strand < 2; ++strand) if (mask & (1 << strand)) {
         if (!all_units.mine(unit++)) continue;
-        units.push_back(Unit{ i, bn, strand, {} });
-        const int64_t base = strand == 0 ? i : Lt - i - bn;          // the block's rows in strand coordinates: base + 1 .. base + bn
-        ranges.push_back(ScanRange{ strand, base + 1, base + bn });
+        // the target's strand position ps is scan position ps + shift
+        const int64_t shift = strand == 0 ? at - 1 : Ltot - (at + Lt - 1);
+        units.push_back(Unit{ t, i, bn, strand, shift, {} });
+        const int64_t b0 = (strand == 0 ? i : Lt - i - bn) + shift;  // the block's rows in scan coordinates: b0 + 1 .. b0 + bn
+        ranges.push_back(ScanRange{ strand, b0 + 1, b0 + bn });
       }
     }
-    if (units.empty()) continue;
+  }
+  if (!units.empty() && Ltot > 0) {
     std::vector<ScanRow> rows;
     double ms = 0.0;
     const auto ts0 = std::chrono::steady_clock::now();
-    if ((st = scan_target(*cfg, p, ctx, seq1, Lt, sc_thresh, xB, mask, rows, &ms, all_units.nparts > 1 ? &ranges : nullptr)) != P7X_OK) return st;
+    if ((st = scan_target(*cfg, p, ctx, scan1, Ltot, sc_thresh, xB, mask, rows, &ms, all_units.nparts > 1 ? &ranges : nullptr)) != P7X_OK) return st;
     scan_ms += ms;
     const auto ts1 = std::chrono::steady_clock::now();
     host_parallel_for((int) units.size(), cfg->host_threads, [&](int u) {
       Unit &un = units[(size_t) u];
-      block_seeds(p, seq1, Lt, un.i, un.bn, un.strand, rows, sc_thresh, xB, un.s3);
+      block_seeds(p, base + off[un.t] - 1, lengths[un.t], un.i, un.bn, un.strand, rows, sc_thresh, xB, un.s3, un.shift);
     });
     for (const Unit &un : units)
-      for (size_t q = 0; q + 2 < un.s3.size(); q += 3) seeds.push_back(LongTargetSeed{ (int64_t) t, un.i, un.strand, un.s3[q], (int) un.s3[q + 1], un.s3[q + 2] });
+      for (size_t q = 0; q + 2 < un.s3.size(); q += 3) seeds.push_back(LongTargetSeed{ (int64_t) un.t, un.i, un.strand, un.s3[q], (int) un.s3[q + 1], un.s3[q + 2] });
     if (std::getenv("P7X_LT_DEBUG"))
-      std::fprintf(stderr, "[lt] target %zu: scan call %.1f ms (kernel %.1f), %zu rows, seeds so far %zu, seed bookkeeping %.1f ms\n", t,
-                   std::chrono::duration<double, std::milli>(ts1 - ts0).count(), ms, rows.size(), seeds.size(),
+      std::fprintf(stderr, "[lt] %zu targets, %lld positions: scan call %.1f ms (kernel %.1f), %zu rows, %zu seeds, seed bookkeeping %.1f ms\n", n,
+                   (long long) Ltot, std::chrono::duration<double, std::milli>(ts1 - ts0).count(), ms, rows.size(), seeds.size(),
                    std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - ts1).count());
   }
   const auto t_host = std::chrono::steady_clock::now();

@@ -809,7 +809,15 @@ static int lt_run_host(const p7x_pipeline_cfg &cfg, const p7x_oprofile *om, cons
   size_t sidx = 0;
   LongTargetUnits units; units.count(cfg, max_length, lengths, n);
   uint64_t unit = 0;
-  struct BlockJob { int64_t i, bn, bc, bw; int strand; uint64_t nres_at; std::vector<LtWindow> windows; size_t first_window; };
+  struct BlockJob { size_t t; int64_t i, bn, bc, bw; int strand; uint64_t nres_at; std::vector<LtWindow> windows; size_t first_window; };
+  // One pass over the targets collects the windows of every (target, block, strand); everything after that runs once
+  // over all of them -- one device batch per stage for the whole search, however many records the target file has
+  // (an assembly of 1e5 contigs costs the same number of launches as one chromosome).  Window references handed to
+  // the device stages are positions in `dsq` itself (offsets[t] - 1 + position in the target).
+  std::vector<BlockJob> jobs;
+  size_t nwin = 0;
+  auto seq_of = [&](const BlockJob &job) { return dsq + offsets[job.t] - 1; };      // seq[1..Lt] of the job's target
+  auto target_of = [&](const BlockJob &job) { const size_t t = job.t; return LtTarget{ (int64_t) t, names ? names[t] : nullptr, accs ? accs[t] : nullptr, descs ? descs[t] : nullptr, lengths[t] }; };
   // P7X_LT_DEBUG: wall time of the phases of this function
   const bool dbg = std::getenv("P7X_LT_DEBUG") != nullptr;
   auto t_last = std::chrono::steady_clock::now();
@@ -821,11 +829,7 @@ static int lt_run_host(const p7x_pipeline_cfg &cfg, const p7x_oprofile *om, cons
   };
   for (size_t t = 0; t < n; ++t) {
     const int64_t Lt = lengths[t];
-    LtTarget tg{ (int64_t) t, names ? names[t] : nullptr, accs ? accs[t] : nullptr, descs ? descs[t] : nullptr, Lt };
-    const uint8_t *seq = dsq + offsets[t] - 1;              // seq[1..Lt]
-    // pass 1: the windows of every block and strand of this target (and the residue accounting of the block loop)
-    std::vector<BlockJob> jobs;
-    size_t nwin = 0;
+    // the windows of every block and strand of this target (and the residue accounting of the block loop)
     for (int64_t i = 0; i < Lt; i += W - C) {
       const int64_t bc = i == 0 ? 0 : std::min<int64_t>(C, Lt - i);
       const int64_t bw = std::min<int64_t>(W, Lt - i - bc);
@@ -840,7 +844,7 @@ static int lt_run_host(const p7x_pipeline_cfg &cfg, const p7x_oprofile *om, cons
         std::vector<LtWindow> seeds;
         while (sidx < seeds_in.size() && seeds_in[sidx].target == (int64_t) t && seeds_in[sidx].block_start == i && seeds_in[sidx].strand == strand)
           seeds.push_back(seeds_in[sidx++].w);
-        BlockJob job{ i, bn, bc, bw, strand, nres, {}, nwin };
+        BlockJob job{ t, i, bn, bc, bw, strand, nres, {}, nwin };
         if (mine) lt_block_windows(sd, max_length, bn, std::move(seeds), job.windows);
         nwin += job.windows.size();
         if (!job.windows.empty()) jobs.push_back(std::move(job));
@@ -849,8 +853,10 @@ static int lt_run_host(const p7x_pipeline_cfg &cfg, const p7x_oprofile *om, cons
       // no early exit: the reference loop (plan7.pyx:7604 `for i from 0 <= i < sq[t].n by W - C`) visits every start
       // below the target length, also a trailing block that only repeats residues the previous block has seen
     }
+  }
+  {
     tick("windows of the blocks");
-    // the windows' filter scores, one device batch per target
+    // the windows' filter scores, one device batch
     std::vector<LtWindowFilters> wf;
     std::vector<LongTargetWindowRef> refs;
     if (filters && nwin > 0) {
@@ -860,10 +866,11 @@ static int lt_run_host(const p7x_pipeline_cfg &cfg, const p7x_oprofile *om, cons
           // original coordinates of the window's first residue on its strand and its length
           LongTargetWindowRef r; r.strand = job.strand; r.length = w.length;
           r.start = job.strand == 0 ? job.i + w.n : job.i + job.bn - w.n + 1;       // strand 1: original position of the window's first (revcomp) residue
+          r.start += offsets[job.t] - 1;
           refs.push_back(r);
         }
       std::vector<LongTargetWindowScore> sc(nwin);
-      const int st = filters->score(seq, Lt, comp, refs.data(), nwin, cfg.F1, cfg.do_biasfilter != 0, sc.data());
+      const int st = filters->score(dsq, 0, comp, refs.data(), nwin, cfg.F1, cfg.do_biasfilter != 0, sc.data());
       if (st != P7X_OK) return st;
       wf.resize(nwin);
       for (size_t q = 0; q < nwin; ++q) { wf[q].have = true; wf[q].usc = sc[q].usc; wf[q].bias_filtersc = sc[q].bias_filtersc; wf[q].have_vit = sc[q].have_vit != 0; wf[q].vfsc = sc[q].vfsc; }
@@ -881,6 +888,7 @@ static int lt_run_host(const p7x_pipeline_cfg &cfg, const p7x_oprofile *om, cons
         const uint8_t *subseq = nullptr;
         if (wf.empty()) {            // host filters need the residues
           sub.assign((size_t) w.length + 2, 255);
+          const uint8_t *seq = seq_of(job);
           for (int64_t r = 1; r <= w.length; ++r) {
             const int64_t bp = w.n + r - 1;        // block position
             sub[(size_t) r] = job.strand == 0 ? seq[job.i + bp] : comp[seq[job.i + job.bn - bp + 1]];
@@ -895,6 +903,7 @@ static int lt_run_host(const p7x_pipeline_cfg &cfg, const p7x_oprofile *om, cons
     // residues of a stretch of a block on its strand: out[1..len], sentinels around
     auto fetch = [&](const BlockJob &job, int64_t first_block_pos, int64_t len, std::vector<uint8_t> &outv) {
       outv.assign((size_t) len + 2, 255);
+      const uint8_t *seq = seq_of(job);
       if (job.strand == 0) std::memcpy(outv.data() + 1, seq + job.i + first_block_pos, (size_t) len);
       else for (int64_t r = 0; r < len; ++r) outv[(size_t) r + 1] = comp[seq[job.i + job.bn - (first_block_pos + r) + 1]];
     };
@@ -938,10 +947,10 @@ static int lt_run_host(const p7x_pipeline_cfg &cfg, const p7x_oprofile *om, cons
         const BlockJob &job = *flat[vj[z].q].first; const LtWindow &w = job.windows[flat[vj[z].q].second];
         const int64_t bp = w.n + vj[z].vw.n - 1;                // block position of the Viterbi window's first residue
         vrefs[z].strand = job.strand; vrefs[z].length = vj[z].vw.length;
-        vrefs[z].start = job.strand == 0 ? job.i + bp : job.i + job.bn - bp + 1;
+        vrefs[z].start = (job.strand == 0 ? job.i + bp : job.i + job.bn - bp + 1) + offsets[job.t] - 1;
       }
       fwd_dev.resize(vj.size());
-      const int st = filters->forward(seq, comp, vrefs.data(), vrefs.size(), fwd_dev.data());
+      const int st = filters->forward(dsq, comp, vrefs.data(), vrefs.size(), fwd_dev.data());
       if (st != P7X_OK) return st;
     }
     tick("Forward of the Viterbi windows");
@@ -978,12 +987,12 @@ static int lt_run_host(const p7x_pipeline_cfg &cfg, const p7x_oprofile *om, cons
       for (size_t z = 0; z < vj.size(); ++z) if (pass[z]) {
         const BlockJob *job; int64_t bp; geometry(z, job, bp);
         LongTargetWindowRef r; r.strand = job->strand; r.length = vj[z].vw.length;
-        r.start = job->strand == 0 ? job->i + bp : job->i + job->bn - bp + 1;
+        r.start = (job->strand == 0 ? job->i + bp : job->i + job->bn - bp + 1) + offsets[job->t] - 1;
         dev_of[z] = (int) prefs.size();
         prefs.push_back(r);
       }
       if (!prefs.empty()) {
-        const int st = filters->regions(seq, comp, prefs.data(), prefs.size(), dev_regions);
+        const int st = filters->regions(dsq, comp, prefs.data(), prefs.size(), dev_regions);
         if (st != P7X_OK) return st;
       }
     }
@@ -1030,7 +1039,7 @@ static int lt_run_host(const p7x_pipeline_cfg &cfg, const p7x_oprofile *om, cons
         w.active = st == P7X_OK;
         return;
       }
-      jst[z] = lt_post_viterbi(cfg, p, lto, max_length, job->nres_at, blk, tg, bp, vw.length, subs[z].data(), fwd_of[z], dr, jh[z], jc[z]);
+      jst[z] = lt_post_viterbi(cfg, p, lto, max_length, job->nres_at, blk, target_of(*job), bp, vw.length, subs[z].data(), fwd_of[z], dr, jh[z], jc[z]);
     });
     if (dev_env) {
       for (size_t z = 0; z < vj.size(); ++z) if (jst[z] != P7X_OK) return jst[z];
@@ -1120,7 +1129,7 @@ static int lt_run_host(const p7x_pipeline_cfg &cfg, const p7x_oprofile *om, cons
         }
         w.dd.dcl = std::move(kept);
         LtBlock blk{ nullptr, job->bn, job->strand == 0 ? job->i + 1 : job->i + job->bn, job->strand == 1 };
-        jst[z] = lt_window_hits(cfg, p, max_length, job->nres_at, blk, tg, bp, w.dd, jh[z]);
+        jst[z] = lt_window_hits(cfg, p, max_length, job->nres_at, blk, target_of(*job), bp, w.dd, jh[z]);
       });
     }
     for (size_t z = 0; z < vj.size(); ++z) {

@@ -64,7 +64,7 @@ __global__ void __launch_bounds__(256) ssvlong_kernel(const SsvLongArgs a)
         const long long pos = i0 + lane;                              // position on this strand
         const long long src = strand == 0 ? pos : a.L - pos + 1;      // position in the stored sequence
         const uint32_t x = a.dsq[src];
-        res = strand == 0 ? x : (uint32_t) a.comp[x];
+        res = strand == 0 || x >= (uint32_t) a.Kp ? x : (uint32_t) a.comp[x];       // codes outside the alphabet separate targets
       }
       for (int r = 0; r < nrow; ++r) {
         const long long i = i0 + r;
@@ -82,6 +82,9 @@ __global__ void __launch_bounds__(256) ssvlong_kernel(const SsvLongArgs a)
 #pragma unroll
             for (int j = 0; j < R; ++j) { v[j] = pk_adds_u(v[j], e[j * 64]); acc = pk_max_u(acc, v[j]); }
           }
+        } else if (x >= a.Kp) {     // between two targets of a concatenated scan: every diagonal ends here
+#pragma unroll
+          for (int j = 0; j < R; ++j) v[j] = kFloor2;
         } else {           // degenerate residue: emissions from the full table in global memory [parity][Kp][R][64]
           const uint32_t *e = a.tab_full + ((size_t) ((odd ? 0 : a.Kp) + x) * R) * 64 + lane;
           if (odd) {
@@ -180,6 +183,11 @@ __global__ void __launch_bounds__(256) ssvlong_reg_kernel(const SsvLongArgs a)
         default: return row(v, T[par][3], odd);
       }
     }
+    if (x >= a.Kp) {              // between two targets of a concatenated scan: every diagonal ends here
+#pragma unroll
+      for (int j = 0; j < R; ++j) v[j] = kFloor2;
+      return kFloor2;
+    }
     // degenerate residue: emissions from the full table in global memory [parity][Kp][R][64]
     const uint32_t *eg = a.tab_full + ((size_t) ((odd ? 0 : a.Kp) + x) * R) * 64 + lane;
     uint32_t e[R];
@@ -235,7 +243,7 @@ __global__ void __launch_bounds__(256) ssvlong_reg_kernel(const SsvLongArgs a)
       if (pos > last) return 0u;
       const long long src = strand == 0 ? pos : a.L - pos + 1;
       const uint32_t x = a.dsq[src];
-      return strand == 0 ? x : (x < 4 ? 3u - x : (uint32_t) a.comp[x]);
+      return strand == 0 ? x : (x < 4 ? 3u - x : (x >= (uint32_t) a.Kp ? x : (uint32_t) a.comp[x]));
     };
     uint32_t res_next = fetch(warm);
     for (long long i0 = warm; i0 <= last; i0 += 64) {     // i0 - warm is a multiple of 64: row r of a block is odd iff r is even

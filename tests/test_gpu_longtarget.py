@@ -206,3 +206,43 @@ def test_long_target_envelopes_on_the_device_equal_the_host_workers():
     assert dev.stage_counts == host.stage_counts
     auto = next(hmmer.nhmmer(hmm, block))                          # the default picks one of the two
     rows_agree(_rows(auto), _rows(host))
+
+
+def test_contig_rich_target_set_is_one_scan(oracle):
+    """An assembly-shaped target set -- 2 Mbp with 150 planted copies cut into ~500 contigs of 1 .. 12,000 residues, some
+    shorter than the model, runs of N, a contig of N only -- goes through the device as ONE scan over the records laid end
+    to end (the sentinel between two records ends every diagonal) and one device batch per stage; the hits equal the CPU
+    harness that scans contig by contig with the oracle's sequential SSV filter."""
+    import time
+    import bench_workloads as bw
+    hmm = load_hmms("bmyD")[0]
+    abc = hmm.alphabet
+    seq = bw.make_chromosome(hmm, 2_000_000, planted=150, seed=33)
+    rng = np.random.default_rng(5)
+    cuts, at = [], 0
+    while at < len(seq):
+        n = int(rng.choice([1, 40, 300, 900, 2500, 6000, 12000], p=[0.02, 0.05, 0.13, 0.2, 0.25, 0.2, 0.15]))
+        cuts.append((at, min(len(seq), at + n)))
+        at += n
+    seqs = []
+    for q, (a, b) in enumerate(cuts):
+        s = seq[a:b].copy()
+        if q % 37 == 5:
+            s[len(s) // 3: len(s) // 3 + 25] = 15            # a run of N
+        if q == 11:
+            s[:] = 15
+        seqs.append(easel.DigitalSequence(abc, name=f"ctg{q:05d}", sequence=s))
+    assert len(seqs) > 400
+    block = easel.DigitalSequenceBlock(abc, seqs)
+    next(hmmer.nhmmer(hmm, block, host_envelopes=1))          # warm
+    t0 = time.perf_counter()
+    dev = next(hmmer.nhmmer(hmm, block, host_envelopes=1))
+    dt = time.perf_counter() - t0
+    ref = host_pipeline.host_nhmmer(oracle, hmm, seqs)
+    assert len(ref) > 60
+    rows_agree(_rows(dev), _rows(ref))
+    assert dev.stage_counts == ref.stage_counts and dev.searched_residues == ref.searched_residues
+    print(f"\n{len(seqs)} contigs, {len(seq)} residues: {dt * 1e3:.1f} ms per search, {len(dev)} hits")
+    # the same search dealt over three parts
+    many = next(hmmer.nhmmer(hmm, block, devices=[0, 0, 0], host_envelopes=1))
+    assert _rows(many) == _rows(dev)
