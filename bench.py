@@ -246,7 +246,7 @@ def run_pfam(args, rank, world, local_rank, dist, red_dev, torch, host_threads, 
     t_tgt = time.perf_counter() - t0
 
     def search(qs):
-        return list(hmmer.hmmsearch(qs, db, cpus=host_threads, batch=args.pfam_batch, pipeline_depth=args.pfam_depth, feeders=args.feeders))
+        return list(hmmer.hmmsearch(qs, db, cpus=host_threads, batch=args.pfam_batch, pipeline_depth=args.pfam_depth, feeders=args.feeders, finishers=args.finishers))
 
     def barrier():
         if dist is not None:
@@ -423,6 +423,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--pipeline-depth", type=int, default=4, help="queries whose device stage may run ahead of the host stage (0: none)")
     ap.add_argument("--feeders", type=int, default=2, help="host threads issuing device stages (each on its own stream)")
+    ap.add_argument("--finishers", type=int, default=0, help="host threads running host stages (0: the library's default, feeders + 2)")
     ap.add_argument("--cpu-sample", type=int, default=1_000_000, help="targets timed through the CPU oracle (rank 0, N=1)")
     ap.add_argument("--queries-per-step", type=int, default=8,
                     help="a step is this many consecutive queries, each a complete search of the resident target block: the "
@@ -500,7 +501,7 @@ def main():
         the device stage of later queries with the host stage of earlier ones (pipeline_depth), exactly as it does for
         distinct queries."""
         last, acc = None, {}
-        for h in hmmer.hmmsearch((om for _ in range(nsteps * qps)), db, pipeline_depth=args.pipeline_depth, feeders=args.feeders, cpus=host_threads, batch=args.batch, **pli_opts):
+        for h in hmmer.hmmsearch((om for _ in range(nsteps * qps)), db, pipeline_depth=args.pipeline_depth, feeders=args.feeders, finishers=args.finishers, cpus=host_threads, batch=args.batch, **pli_opts):
             last = h
             for k, v in h.timings_ms.items():
                 acc[k] = acc.get(k, 0.0) + v
@@ -617,7 +618,7 @@ def main():
                                 "(pipeline_depth=%d batches); targets resident in HBM (pack+upload once: %.2fs, generation %.2fs, "
                                 "not timed)" % (args.pipeline_depth, t_pack, t_gen),
                 "queries_per_step": qps, "queries_per_device_batch": lanes_per_launch,
-                "pipeline_depth": args.pipeline_depth, "feeders": args.feeders, "host_threads_per_rank": host_threads,
+                "pipeline_depth": args.pipeline_depth, "feeders": args.feeders, "finishers": args.finishers or args.feeders + 2, "host_threads_per_rank": host_threads,
                 "spinup_windows_s": [round(x, 4) for x in spin],
                 "latency_ms_per_query": round(stage.get("total", 0.0), 3),
             },

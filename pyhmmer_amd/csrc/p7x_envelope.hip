@@ -43,12 +43,24 @@ __device__ __forceinline__ float vmax(float a, float b) { return a > b ? a : b; 
 __device__ __forceinline__ float rflf(float v) { return __builtin_bit_cast(float, rfl(__builtin_bit_cast(int, v))); }
 
 __device__ __forceinline__ void phase_fence()
-{ // rows written by this wavefront are read back by it (possibly by other lanes, and the workspace is re-used
-  // for the next envelope): make the stores visible and drop stale vector-cache lines.
-  __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "agent");
+{ // Rows written by this wavefront are read back by it (possibly by other lanes, and the workspace is re-used for the
+  // next envelope).  Producer and consumer are the same wavefront, so work-group scope is all that is needed: the
+  // stores have left the wavefront (vmcnt(0)) and the CU's vector cache is coherent for its own stores.  Agent scope
+  // would write back and invalidate the XCD's whole L2 (buffer_wbl2 / buffer_inv sc1) four times per envelope and
+  // wavefront -- taking the lines of every other wavefront and of the filter kernels running beside this one with it.
+  __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
 }
 
 } // namespace
+
+#ifdef P7X_ENV_PROFILE
+// build-time experiment (-DP7X_ENV_PROFILE): core-clock cycles every wavefront spent in the phases of env_kernel, summed
+// over the wavefronts of all launches since the last read: [0..3] phases 1-4, [4] rows, [5] envelopes
+__device__ unsigned long long g_env_prof[8];
+#define P7X_ENV_STAMP(slot) do { const unsigned long long now_ = __builtin_readcyclecounter(); if (lane == 0) atomicAdd(&g_env_prof[slot], now_ - stamp_); stamp_ = now_; } while (0)
+#else
+#define P7X_ENV_STAMP(slot) do { } while (0)
+#endif
 
 // One block per CU: its wavefronts (env_waves(C): 8, or 4 for models of more than 448 nodes) share one copy of the
 // profile tables in LDS and each walks its own envelopes.
@@ -212,6 +224,10 @@ __global__ void __launch_bounds__(env_waves(C) * 64, env_waves(C) / 4) env_kerne
     int status = 0;
     const float *em = LT ? a.env_emis + (size_t) it * (size_t) a.env_emis_stride : em_profile;      // [nrows][Mpad]
 
+#ifdef P7X_ENV_PROFILE
+    unsigned long long stamp_ = __builtin_readcyclecounter();
+    if (lane == 0) { atomicAdd(&g_env_prof[4], (unsigned long long) Ld); atomicAdd(&g_env_prof[5], 1ull); }
+#endif
     // ------------------------------------------------------------------ 1. Forward (score and scale factors)
     float envsc;
     {
@@ -249,6 +265,7 @@ __global__ void __launch_bounds__(env_waves(C) * 64, env_waves(C) / 4) env_kerne
       if (lane == 0) a.out_orig[it] = orig;
     }
     phase_fence();
+    P7X_ENV_STAMP(0);
 
     // ------------------------------------------------------------------ 2. Backward
     bool own_scales = false;
@@ -308,17 +325,17 @@ __global__ void __launch_bounds__(env_waves(C) * 64, env_waves(C) / 4) env_kerne
       store_row(Ld);
       if (lane == 0) { float *r = bx + (size_t) Ld * 6; r[0] = xE; r[1] = xN; r[2] = xJ; r[3] = xB; r[4] = xC; r[5] = sc; }
 
-      // residue x_{i+1} and Forward's scale factor of row i are fetched one row ahead (lane 0 / lane 1 of one VGPR each)
-      auto fetch_bk = [&](int i) -> float {
-        if (i < 1) return 0.0f;
-        return (lane == 0) ? (float) sq[i] : ((lane == 1) ? fx[(size_t) i * 6 + 5] : 0.0f);
-      };
-      float bk_next = fetch_bk(Ld - 1);
-      for (int i = Ld - 1; i >= 1; --i) {
-        const float bk = bk_next;
-        bk_next = fetch_bk(i - 1);
-        const int x = (int) __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, bk), 0));
-        const float fsc = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, bk), 1));
+      // Residue x_{i+1} and Forward's scale factor of row i: 64 rows at a time, one per lane, so that the row loop itself
+      // has stores only.  (A load inside the row loop is waited for with vmcnt(0) -- the counter retires in order -- and
+      // that wait also covers every row store issued before it: one HBM round trip per row.)
+      for (int ib = Ld - 1; ib >= 1; ib -= 64) {
+      const int nblk = min(64, ib);
+      uint32_t res_b = 0; float fsc_b = 0.0f;
+      if (lane < nblk) { res_b = sq[ib - lane]; fsc_b = fx[(size_t) (ib - lane) * 6 + 5]; }
+      for (int l = 0; l < nblk; ++l) {
+        const int i = ib - l;
+        const int x = __builtin_amdgcn_readlane((int) res_b, l);
+        const float fsc = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, fsc_b), l));
         const float *er = em + x * Mpad + lane;
         float me[C];
 #pragma unroll unroll_env(C)
@@ -359,6 +376,7 @@ __global__ void __launch_bounds__(env_waves(C) * 64, env_waves(C) / 4) env_kerne
         store_row(i);
         if (lane == 0) { float *r = bx + (size_t) i * 6; r[0] = xE; r[1] = xN; r[2] = xJ; r[3] = xB; r[4] = xC; r[5] = sc; }
       }
+      }
       {
         const int x = rfl((int) sq[0]);
         const float *er = em + x * Mpad + lane;
@@ -371,6 +389,7 @@ __global__ void __launch_bounds__(env_waves(C) * 64, env_waves(C) / 4) env_kerne
       }
     }
     phase_fence();
+    P7X_ENV_STAMP(1);
 
     // ------------------------------------------------------------------ 3. decoding, null2 sums, optimal accuracy
     float oasc;
@@ -395,29 +414,34 @@ __global__ void __launch_bounds__(env_waves(C) * 64, env_waves(C) / 4) env_kerne
       auto fetch_row = [&](int r, float (&c2)[C], float (&d)[C]) {
         const float *rbm = bM + (size_t) r * Mpad + lane, *rbi = bI + (size_t) r * Mpad + lane;
 #pragma unroll unroll_env(C)
-        for (int c = 0; c < C; ++c) { c2[c] = lane_live ? rbm[c * 64] : 0.0f; d[c] = lane_live ? rbi[c * 64] : 0.0f; }
-      };
+        for (int c = 0; c < C; ++c) { c2[c] = rbm[c * 64]; d[c] = rbi[c * 64]; }      // every lane loads (its own columns: valid
+      };                                                                                 // memory); dead lanes are zeroed at the use
       EnvForward<C> f;                 // Forward again, row by row, next to the decoding
       f.init(tr, lane, pmove);
-      uint32_t resid3 = (lane < min(64, Ld)) ? sq[lane] : 0;
-      auto fetch_x = [&](int r) -> float {
-        const int l = lane & 7;
-        const float *src = (lane < 8) ? fx + (size_t) r * 6 : bx + (size_t) r * 6;
-        return (l < 6 && lane < 16) ? src[l] : 0.0f;
+      auto fetch_x = [&](int r) -> float {       // unconditional: lanes past 16 repeat the pattern, nobody reads them
+        const int l = min(lane & 7, 5);
+        const float *src = (lane & 8) ? bx + (size_t) r * 6 : fx + (size_t) r * 6;
+        return src[l];
       };
       auto xval = [&](float v, int idx) { return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), idx)); };
       fetch_row(1, nbm, nbi);
       float xprev = fetch_x(0), xcur = fetch_x(1);
-      for (int r = 1; r <= Ld; ++r) {
+      // The row loop has no conditional load and none that is consumed in the iteration that issues it: the in-order
+      // vmcnt counter then lets the wait for row r's values leave the loads of row r + 1 and the stores in flight.  The
+      // residues come 64 rows at a time in the outer loop.
+      for (int r0 = 1; r0 <= Ld; r0 += 64) {
+      const int nblk = min(64, Ld - r0 + 1);
+      const uint32_t resid3 = (lane < nblk) ? sq[(r0 - 1) + lane] : 0;
+      for (int l = 0; l < nblk; ++l) {
+        const int r = r0 + l;
         float cbm[C], cbi[C];
 #pragma unroll unroll_env(C)
-        for (int c = 0; c < C; ++c) { cbm[c] = nbm[c]; cbi[c] = nbi[c]; }
+        for (int c = 0; c < C; ++c) { cbm[c] = lane_live ? nbm[c] : 0.0f; cbi[c] = lane_live ? nbi[c] : 0.0f; }
         const float xthis = xcur;
         const int rn = (r < Ld) ? r + 1 : r;                 // the last iteration re-reads its own row (harmless)
         fetch_row(rn, nbm, nbi);
         xcur = fetch_x(rn);
-        if (((r - 1) & 63) == 0 && r > 1) resid3 = (lane < min(64, Ld - (r - 1))) ? sq[(r - 1) + lane] : 0;
-        f.row(tr, em, Mpad, lane, __builtin_amdgcn_readlane((int) resid3, (r - 1) & 63), pmove, ploop, a.xf_e_move, a.xf_e_loop);
+        f.row(tr, em, Mpad, lane, __builtin_amdgcn_readlane((int) resid3, l), pmove, ploop, a.xf_e_move, a.xf_e_loop);
         const float (&cfm)[C] = f.mm;
         const float (&cfi)[C] = f.im;
         const float fS = xval(xthis, 5), bS = xval(xthis, 8 + 5);
@@ -495,6 +519,10 @@ __global__ void __launch_bounds__(env_waves(C) * 64, env_waves(C) / 4) env_kerne
             pm = om_[c]; pd = od_[c]; pmd = t_md[c]; pdd = t_dd[c];
           }
         }
+        // Row r + 1's loads have had this row's arithmetic to arrive; waiting for them HERE, before this row's stores are
+        // issued, keeps those stores out of the wait (vmcnt retires in order: a wait placed after the stores -- at the
+        // next row's first use, where the compiler would put it -- covers the stores' round trip as well).
+        __builtin_amdgcn_s_waitcnt(0x0f70);            // vmcnt(0), expcnt and lgkmcnt unconstrained
         {
           unsigned short *rb = bp + (size_t) r * Mpad + lane;
           if (lane_live) {
@@ -552,6 +580,7 @@ __global__ void __launch_bounds__(env_waves(C) * 64, env_waves(C) / 4) env_kerne
           float *q = px + (size_t) r * 3; q[0] = ppN; q[1] = ppJ; q[2] = ppC;
         }
       }
+      }
       if (lane == 0) { float *o = ox; o[0] = kNegInf; o[1] = 0.0f; o[2] = kNegInf; o[3] = 0.0f; o[4] = kNegInf; }
       oasc = oC;
       if (__builtin_isinf(scaleproduct)) status |= 2;            // p7_Decoding: eslERANGE, the envelope is dropped
@@ -570,6 +599,7 @@ __global__ void __launch_bounds__(env_waves(C) * 64, env_waves(C) / 4) env_kerne
       }
     }
     phase_fence();
+    P7X_ENV_STAMP(2);
 
     // ------------------------------------------------------------------ 4. traceback (p7_OATrace)
     // The walk is serial, but most of it needs no decision at all: the C states from the last row down to the row where
@@ -714,6 +744,7 @@ __global__ void __launch_bounds__(env_waves(C) * 64, env_waves(C) / 4) env_kerne
       a.tr_n[it] = n;
     }
     phase_fence();      // the workspace is about to be overwritten by this wavefront's next envelope
+    P7X_ENV_STAMP(3);
   }
 }
 
@@ -797,3 +828,12 @@ int env_launch(const ArgRun<EnvArgs> &a, hipStream_t st)
 }
 
 } // namespace p7x
+
+#ifdef P7X_ENV_PROFILE
+extern "C" int p7x_debug_env_profile(unsigned long long *out8)
+{
+  unsigned long long zero[8] = { 0 };
+  if (hipMemcpyFromSymbol(out8, HIP_SYMBOL(p7x::g_env_prof), sizeof zero) != hipSuccess) return 1;
+  return hipMemcpyToSymbol(HIP_SYMBOL(p7x::g_env_prof), zero, sizeof zero) != hipSuccess;
+}
+#endif

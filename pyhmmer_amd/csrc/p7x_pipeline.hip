@@ -448,7 +448,7 @@ __global__ void __launch_bounds__(256) regions_kernel(const ArgRef ref)
       tm[i] = (float) (1. - (double) njcp);
     }
     if (lane == 0) { pb[0] = 0.0f; pe[0] = 0.0f; }
-    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "agent");
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");      // producer and consumer are this wavefront
     int nreg = 0;
     int32_t *regs = a.out_regs + (size_t) it * kRegionCap * 3;
     float b = 0.0f, e = 0.0f;
@@ -473,7 +473,7 @@ __global__ void __launch_bounds__(256) regions_kernel(const ArgRef ref)
         } else if (mo - (e - eprev) < rt2) {
           // region i..j closes here: flush this block's prefix sums, then is_multidomain_region()
           if (lane <= r) { pb[j0 + lane] = keepb; pe[j0 + lane] = keepe; }
-          __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "agent");
+          __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");      // producer and consumer are this wavefront
           const float e0 = pe[i - 1], bj = b;
           float mx = -1.0f;
           for (int z = i + lane; z <= j; z += 64) mx = fmaxf(mx, fminf(pe[z] - e0, bj - pb[z - 1]));
