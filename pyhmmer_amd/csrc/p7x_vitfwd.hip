@@ -575,8 +575,16 @@ __global__ void __launch_bounds__(kWsBlock) bck_kernel(const ArgRef ref)
     totscale = (float) log((double) sc);
     if (lane == 0) { float *r = xo + (size_t) L * 6; r[0] = xE; r[1] = xN; r[2] = xJ; r[3] = xB; r[4] = xC; r[5] = sc; }
 
-    for (int i = L - 1; i >= 1; --i) {
-      const int x = rfl((int) sq[i]);                       // residue x_{i+1} (0-based index i)
+    // Residue x_{i+1} (0-based index i) and Forward's scale factor of row i come 64 rows at a time, one per lane: a load
+    // inside the row loop is waited for with vmcnt(0), which also covers the row stores issued before it (the counter
+    // retires in order) -- two memory round trips per row.
+    for (int ib = L - 1; ib >= 1; ib -= 64) {
+    const int nblk = min(64, ib);
+    uint32_t res_b = 0; float fsc_b = 0.0f;
+    if (lane < nblk) { res_b = sq[ib - lane]; fsc_b = fx[(size_t) (ib - lane) * 6 + 5]; }
+    for (int l = 0; l < nblk; ++l) {
+      const int i = ib - l;
+      const int x = __builtin_amdgcn_readlane((int) res_b, l);
       const float *er = em + x * Mpad + lane;
       // mp(k) = M(i+1,k+1) e(x_{i+1},k+1): value of the NEXT node
       float me[C];
@@ -608,7 +616,7 @@ __global__ void __launch_bounds__(kWsBlock) bck_kernel(const ArgRef ref)
         for (int c = C - 1; c >= 0; --c) { mm[c] = mm[c] + dn * tmd[c]; dn = dm[c]; }
       }
       if (xB > 1.0e16f) own_scales = true;
-      sc = own_scales ? ((xB > 1.0e4f) ? xB : 1.0f) : __builtin_bit_cast(float, rfl(__builtin_bit_cast(int, fx[(size_t) i * 6 + 5])));
+      sc = own_scales ? ((xB > 1.0e4f) ? xB : 1.0f) : __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, fsc_b), l));
       if (sc > 1.0f) {
         xE /= sc; xN /= sc; xJ /= sc; xB /= sc; xC /= sc;
         const float inv = (float) (1.0 / (double) sc);
@@ -617,6 +625,7 @@ __global__ void __launch_bounds__(kWsBlock) bck_kernel(const ArgRef ref)
         totscale += (float) log((double) sc);
       }
       if (lane == 0) { float *r = xo + (size_t) i * 6; r[0] = xE; r[1] = xN; r[2] = xJ; r[3] = xB; r[4] = xC; r[5] = sc; }
+    }
     }
     // row 0
     {

@@ -16,4 +16,5 @@ depth = int(os.environ.get("DEPTH", "0"))
 out = []
 for h in hmmer.hmmsearch((om for _ in range(42)), db, pipeline_depth=depth, batch=7):
     out.append(h.timings_ms["envelopes"])
+print({k: round(v, 2) for k, v in h.timings_ms.items()})
 print(sys.argv[1] if len(sys.argv) > 1 else "", "envelope stage per batch of 7 (ms):", " ".join(f"{x:.1f}" for x in out[::7]))
