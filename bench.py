@@ -415,8 +415,8 @@ def run_nhmmer(args, rank, world, local_rank, dist, red_dev, torch):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
-    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--nseq", type=int, default=1_000_000, help="targets per GPU")
     ap.add_argument("--seqlen", type=int, default=300)
     ap.add_argument("--hmm", default="KR")
@@ -425,7 +425,7 @@ def main():
     ap.add_argument("--feeders", type=int, default=2, help="host threads issuing device stages (each on its own stream)")
     ap.add_argument("--finishers", type=int, default=0, help="host threads running host stages (0: the library's default, feeders + 2)")
     ap.add_argument("--cpu-sample", type=int, default=1_000_000, help="targets timed through the CPU oracle (rank 0, N=1)")
-    ap.add_argument("--queries-per-step", type=int, default=8,
+    ap.add_argument("--queries-per-step", type=int, default=32,
                     help="a step is this many consecutive queries, each a complete search of the resident target block: the "
                          "pipeline's fill and drain (about two query times) then weigh as little in a 20-step run as in a long one")
     ap.add_argument("--batch", type=int, default=0, help="headline workload: queries per device batch (0: the library's own choice)")
