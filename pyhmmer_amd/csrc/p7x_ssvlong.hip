@@ -238,18 +238,25 @@ __global__ void __launch_bounds__(256) ssvlong_reg_kernel(const SsvLongArgs a)
     for (int j = 0; j < R; ++j) v[j] = kFloor2;
     // residues of 64 rows, one per lane: strand 1 reads the target backwards and complements (canonical residues by
     // arithmetic: the table lookup would be a second dependent load); fetched one block ahead of its use
+    // The fetch is the byte load and nothing else: whatever consumes the byte (the complement) would make the compiler
+    // wait for it on the spot, and the prefetch would be a synchronous load.
     auto fetch = [&](long long i0) -> uint32_t {
       const long long pos = i0 + lane;
       if (pos > last) return 0u;
-      const long long src = strand == 0 ? pos : a.L - pos + 1;
-      const uint32_t x = a.dsq[src];
+      return a.dsq[strand == 0 ? pos : a.L - pos + 1];
+    };
+    auto on_strand = [&](uint32_t x) -> uint32_t {
       return strand == 0 ? x : (x < 4 ? 3u - x : (x >= (uint32_t) a.Kp ? x : (uint32_t) a.comp[x]));
     };
-    uint32_t res_next = fetch(warm);
+    uint32_t raw_next = fetch(warm);
     for (long long i0 = warm; i0 <= last; i0 += 64) {     // i0 - warm is a multiple of 64: row r of a block is odd iff r is even
       const int nrow = (int) min(64LL, last - i0 + 1);
-      const uint32_t res = res_next;
-      res_next = fetch(i0 + 64);
+      // The bytes fetched during the previous 64 rows are waited for HERE, before the next fetch is issued: left to the
+      // compiler the wait lands at the top of the 8-row loop as vmcnt(0) (the counter retires in order), where it also
+      // waits for the fetch just issued -- one exposed memory round trip per 64 rows.
+      __builtin_amdgcn_s_waitcnt(0x0f70);            // vmcnt(0); expcnt and lgkmcnt unconstrained
+      const uint32_t res = on_strand(raw_next);
+      raw_next = fetch(i0 + 64);
       for (int r0 = 0; r0 < nrow; r0 += 8) {
         const int nb = min(8, nrow - r0);
         uint32_t saved[R];
