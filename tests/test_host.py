@@ -160,6 +160,39 @@ def test_msv_isa_never_touches_a_vgpr_with_an_lds_load_in_flight(tmp_path):
     assert "ds_read_b64" in asm.read_text()
 
 
+def test_envelope_kernel_isa_keeps_memory_round_trips_out_of_its_row_loops(tmp_path):
+    """Two properties of the envelope kernel that only show in the ISA and were worth 18 % of its time:
+    its phase fences are work-group scope (agent scope is `buffer_wbl2` / `buffer_inv sc1` on gfx950: the whole L2 written
+    back and invalidated per phase and wavefront), and no row loop waits for a load behind a store of the same iteration
+    (`vmcnt` retires in order): Forward's and Backward's loops have no load at all, the decoding loop waits once, ahead of
+    its stores.  scripts/isa_inner_loops.py reads the loop bodies from the compiler's block annotations."""
+    import shutil
+    import subprocess
+    import sys
+    from pathlib import Path
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not Path(hipcc).exists():
+        pytest.skip("hipcc not available")
+    root = Path(__file__).resolve().parents[1]
+    asm = tmp_path / "env.s"
+    subprocess.run([hipcc, "-O3", "-std=c++17", "-ffp-contract=off", "-fno-fast-math", "--offload-arch=gfx950", "-S",
+                    "--cuda-device-only", "-I", str(root / "include"), "-o", str(asm), str(root / "pyhmmer_amd/csrc/p7x_envelope.hip")],
+                   check=True, capture_output=True)
+    text = asm.read_text()
+    assert "buffer_wbl2" not in text and "buffer_inv" not in text
+    sys.path.insert(0, str(root / "scripts"))
+    try:
+        import isa_inner_loops
+    finally:
+        sys.path.pop(0)
+    for inst in ("ILi5ELb1ELb0E", "ILi3ELb1ELb0E", "ILi12ELb1ELb0E"):          # the benchmark's class, a short and a long one
+        loops = isa_inner_loops.loops(asm, "env_kernel" + inst)
+        rows = [l for l in loops if l[4] >= 2 and l[2] > 200]           # row loops (the traceback walk, a pointer chase, is shorter)
+        assert len(rows) >= 3, loops
+        assert not any(serial for *_, serial in rows), rows
+        assert sum(1 for l in rows if l[3] == 0) >= 2, rows            # Forward and Backward: stores only
+
+
 @pytest.mark.parametrize("name", ["PF02826", "Thioesterase", "RREFam"])
 def test_pressed_files_are_written_byte_for_byte(name, models, tmp_path):
     """hmmpress: .h3f / .h3p produced here == the files real HMMER pressed (reference tests/data/hmms/db), byte for
@@ -280,7 +313,7 @@ def test_query_pipeline_orders_results_and_errors_for_every_shape(libp7x, monkey
     from pyhmmer_amd import hmmer
     before = threading.active_count()
     shapes = [(0, 1, 1, 0), (1, 1, 1, 0), (2, 1, 1, 0), (4, 2, 1, 0), (8, 4, 1, 0), (8, 1, 8, 0), (32, 2, 8, 0), (5, 3, 2, 0),
-              (2, 2, 8, 4), (64, 4, 4, 8), (3, 8, 64, 2)]
+              (2, 2, 8, 4), (64, 4, 4, 8), (3, 8, 64, 2), (4, 2, 1, 4)]      # the last one: hmmsearch's defaults
     for seed, (depth, feeders, window, fin) in enumerate(shapes):
         batch = (1, 3, 8)[seed % 3]             # queries per device batch
         for n in (0, 1, 7, 40):
