@@ -286,7 +286,10 @@ int  p7x_search_batch_raw(const p7x_pipeline_cfg *cfg, const p7x_oprofile *const
  * p7_Pipeline_LongTarget's tail on the host (window MSV + bias, long-target Viterbi, Forward / Backward, domain
  * definition with long_target = TRUE, one hit per domain), followed by p7_tophits_ComputeNhmmerEvalues, target lengths,
  * p7_tophits_RemoveDuplicates, sort and threshold (plan7.pyx:7390-7412).  Targets: residues dsq[offsets[t] ..
- * offsets[t] + lengths[t] - 1] (64-bit lengths: chromosomes); cfg.long_targets must be set. */
+ * offsets[t] + lengths[t] - 1] (64-bit lengths: chromosomes); cfg.long_targets must be set.
+ * Records that lie end to end in dsq with one sentinel (a code outside the alphabet) between them -- the layout of
+ * p7x_seqdb_create -- are scanned where they are, all of them with one launch (the sentinel ends every diagonal); any
+ * other layout is packed that way first.  The window stages run one device batch per stage for the whole target set. */
 int p7x_search_longtargets(const p7x_pipeline_cfg *cfg, const p7x_oprofile *om, int device,
                            const uint8_t *dsq, const int64_t *offsets, const int64_t *lengths, size_t n,
                            const char *const *names, const char *const *accs, const char *const *descs, p7x_tophits **out);
