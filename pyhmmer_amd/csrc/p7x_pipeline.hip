@@ -685,7 +685,17 @@ static const bool g_host_regions = std::getenv("P7X_HOST_REGIONS") != nullptr;  
 // workers: 20 % less host thread time per query, but the second launch sits on the host stage's critical path.  On a
 // box with enough CPUs per device the host is not the bottleneck and the round trip only costs (config 2, 16 CPUs:
 // 16.7 vs 17.1 TCUPS), so it is opt-in -- meant for nodes where many ranks share few cores.
-static bool device_clustered() { const char *e = std::getenv("P7X_DEVICE_CLUSTERED"); return e && std::atoi(e) != 0; }   // read per call (tests)
+// The clustered envelopes of the stochastic ensembles (about two per multi-domain region, a third of the host stage's
+// thread time) can be rescored by the envelope kernel as a second round instead of by the host workers: identical
+// results either way.  P7X_DEVICE_CLUSTERED=0/1 decides; unset, the host workers do it where there are many of them and the
+// device where there are few (measured on the benchmark: 16 threads 19.1 vs 18.7-19.2 TCUPS, 8 threads 10.0 vs 11.1).
+static bool device_clustered(int host_threads)
+{
+  const char *e = std::getenv("P7X_DEVICE_CLUSTERED");                     // read per call (tests)
+  if (e && *e) return std::atoi(e) != 0;
+  const int threads = host_threads > 0 ? std::min(host_threads, tophits_usable_cpus()) : tophits_usable_cpus();
+  return threads < 12;
+}
 
 // The lane-per-target MSV and the 8-lanes-per-target Viterbi need many (profile, 64-target group) pairs to fill the
 // device and run for as long as the longest member of a group takes one wavefront.  A batch with at most one such
@@ -1700,7 +1710,7 @@ int p7x_search_batch_finish(p7x_pending *pd, const char *const *names, const cha
     DeviceCtx *ctx = nullptr;
     if ((st = get_ctx(db->device, &ctx)) != P7X_OK) return st;
     scorer = make_device_envelope_scorer(ctx, db, pd->cfg.oa_guard);
-    if (device_clustered()) scorer2 = make_device_envelope_scorer(ctx, db, pd->cfg.oa_guard);
+    if (device_clustered(pd->cfg.host_threads)) scorer2 = make_device_envelope_scorer(ctx, db, pd->cfg.oa_guard);
   }
   if ((st = host_finish_batch(pd->cfg, items, tg, names, accs, descs, outs, scorer.get(), scorer2.get())) != P7X_OK) return st;
   // work time of this batch (stage 1 + stage 2), not the time it spent queued between the stages

@@ -502,6 +502,7 @@ def test_clustered_envelopes_on_the_device_give_the_same_tables(models, proteome
     same (the golden tables contain nine such hits)."""
     import io
     hmm = models["PF02826"][0]
+    monkeypatch.setenv("P7X_DEVICE_CLUSTERED", "0")          # unset, the library decides by the number of host threads
     base = plan7.Pipeline(hmm.alphabet).search_hmm(hmm, proteome)
     monkeypatch.setenv("P7X_DEVICE_CLUSTERED", "1")
     dev = plan7.Pipeline(hmm.alphabet).search_hmm(hmm, proteome)
@@ -513,6 +514,11 @@ def test_clustered_envelopes_on_the_device_give_the_same_tables(models, proteome
         a, b = io.BytesIO(), io.BytesIO()
         base.write(a, format=fmt); dev.write(b, format=fmt)
         assert a.getvalue() == b.getvalue()
+    monkeypatch.delenv("P7X_DEVICE_CLUSTERED")
+    few = plan7.Pipeline(hmm.alphabet, host_threads=4).search_hmm(hmm, proteome)        # few host threads: the device's turn
+    a, b = io.BytesIO(), io.BytesIO()
+    base.write(a, format="domains"); few.write(b, format="domains")
+    assert a.getvalue() == b.getvalue()
 
 
 def test_target_file_is_searched_in_chunks(models, proteome, golden):
