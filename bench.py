@@ -372,7 +372,7 @@ def run_nhmmer(args, rank, world, local_rank, dist, red_dev, torch):
     L = int(args.nhmmer_mbp * 1e6)
     seq = bw.make_chromosome(hmm, L, planted=50, seed=45 + rank)
     block = easel.DigitalSequenceBlock(hmm.alphabet, [easel.DigitalSequence(hmm.alphabet, name=f"chrSyn{rank}", sequence=seq)])
-    pli = plan7.LongTargetsPipeline(hmm.alphabet, device=local_rank)
+    pli = plan7.LongTargetsPipeline(hmm.alphabet, device=local_rank, host_envelopes=args.nhmmer_envelopes)
     pli.search_hmm(hmm, block)                                   # warm-up: tables, workspaces
     n = max(1, args.nhmmer_searches)
     if dist is not None:
@@ -436,6 +436,7 @@ def main():
                          "workload's field; both: headline + the `pfam` and `nhmmer` fields")
     ap.add_argument("--nhmmer-mbp", type=float, default=250.0, help="chromosome length per GPU")
     ap.add_argument("--nhmmer-searches", type=int, default=3)
+    ap.add_argument("--nhmmer-envelopes", type=int, default=0, help="A/B: 0 the library decides where envelopes are rescored, 1 host workers, 2 envelope kernel")
     ap.add_argument("--pfam-profiles", type=int, default=20000, help="library entries searched (the first ones of the 20k-entry library; default: all)")
     ap.add_argument("--pfam-cpu-profiles", type=int, default=40, help="cpu_baseline of the many-profile workloads: this many profiles, evenly spaced")
     ap.add_argument("--pfam-cpu-targets", type=int, default=25_000, help="... against the first this many targets")

@@ -1004,17 +1004,19 @@ static int lt_run_host(const p7x_pipeline_cfg &cfg, const p7x_oprofile *om, cons
     // long-target instantiation in two batches (the second for the envelopes that are trimmed to their alignment):
     // phase A queues them, phase B builds their composition-adjusted odds and runs them, phase C makes the hits.
     // Whether that pays is a matter of numbers: the kernel's time is the latency of its longest envelope (two rounds of
-    // ~27 ms for envelopes of a 1,203-node model, 1,024 of them at a time), the host workers need ~8.4 ms of one thread
-    // for such an envelope (measured on the benchmark, profiles/r03_bench.json: 110 envelopes, 16 threads: 58 ms either
-    // way).  A handful of hits stays with the host workers; a repeat family with thousands of copies goes to the device.
+    // ~19 ms for envelopes of a 1,203-node model, 1,024 of them at a time, plus ~10 ms of host work around them), the
+    // host workers need ~7.5 ms of one thread for such an envelope (measured on the benchmark: 110 envelopes, 16
+    // threads: 51.6 ms on the host, 49.8 ms through the device; before the envelope kernel's fences and waits were fixed
+    // the two rounds took 53 ms).  A handful of hits stays with the host workers; more than a hundred per 16 threads, or
+    // a repeat family with thousands of copies, go to the device.
     // cfg.host_envelopes: 1 always the host, 2 always the device (tests), 0 by that estimate.
     bool dev_env = filters != nullptr && lto.do_null2 && !dev_regions.empty() && cfg.host_envelopes != 1;
     if (dev_env && cfg.host_envelopes != 2) {
       size_t nsingle = 0;
       for (const LongTargetWindowRegions &w : dev_regions) for (const Region &r : w.regs) nsingle += r.multi ? 0 : 1;
       const int threads = cfg.host_threads > 0 ? cfg.host_threads : tophits_usable_cpus();
-      const double host_ms = (double) nsingle * 8.4 * ((double) p.M / 1203.0) / (double) std::max(1, threads);
-      const double dev_ms = 67.0 * (double) ((nsingle + 1023) / 1024);
+      const double host_ms = (double) nsingle * 7.5 * ((double) p.M / 1203.0) / (double) std::max(1, threads);
+      const double dev_ms = 48.0 * (double) ((nsingle + 1023) / 1024);
       dev_env = nsingle > 0 && host_ms > dev_ms;
     }
     struct WinDD { DomainDefResult dd; std::vector<EnvelopeRequest> defer; bool active = false; };
