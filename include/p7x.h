@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define P7X_ABI_VERSION 5
+#define P7X_ABI_VERSION 6
 
 enum {
   P7X_OK = 0, P7X_EMEM = 5, P7X_EFORMAT = 7, P7X_EINVAL = 11, P7X_ERANGE = 16, P7X_ENORESULT = 19,
@@ -194,6 +194,10 @@ typedef struct p7x_pipeline_cfg {
   float   f3_guard;          /* relative half-width of the band around F3 inside which a target's Forward P-value is not trusted to the
                               * device's summation order: the device passes P <= F3 (1 + g), the host stage re-scores the targets with
                               * P > F3 (1 - g) with p7x_forward_parser_exact and applies F3 to that.  Default 4e-3 (a band of about 6e-3 bit, three times the stated tolerance of the device Forward score); 0: no guard */
+  uint64_t lt_resident_key;  /* p7x_search_longtargets: nonzero = the caller's promise that a target buffer passed with this key always
+                              * has the same contents (a token of the packed image, not of its address).  The device copy is then kept
+                              * after the call and a later search with the same key and size does not upload the targets again (one
+                              * copy per device; a new key replaces it).  0 (default): upload per call, nothing kept */
 } p7x_pipeline_cfg;
 enum { P7X_STRAND_BOTH = 0, P7X_STRAND_TOPONLY = 1, P7X_STRAND_BOTTOMONLY = 2 };
 void p7x_pipeline_cfg_default(p7x_pipeline_cfg *cfg);   /* p7_pipeline_Create(NULL,...) defaults, plan7.pyx:5413-5421 */

@@ -108,6 +108,7 @@ class PipelineCfg(C.Structure):
         ("long_targets", C.c_int32), ("strands", C.c_int32), ("B1", C.c_int32), ("B2", C.c_int32), ("B3", C.c_int32),
         ("block_length", C.c_int32), ("window_length", C.c_int32), ("evalue_window_length", C.c_int32), ("lt_part", C.c_int32), ("lt_nparts", C.c_int32), ("oa_guard", C.c_float),
         ("f3_guard", C.c_float),
+        ("lt_resident_key", C.c_uint64),
     ]
 
 
@@ -233,7 +234,7 @@ def lib() -> C.CDLL:
             fn = getattr(l, name)      # AttributeError if the ABI is incomplete
             fn.restype = res
             fn.argtypes = args
-        if l.p7x_abi_version() != 5:
+        if l.p7x_abi_version() != 6:
             raise ImportError("libp7x ABI version mismatch; rebuild")
         _lib = l
     return _lib

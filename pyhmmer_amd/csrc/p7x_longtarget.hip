@@ -10,7 +10,9 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <map>
 #include <memory>
+#include <mutex>
 
 namespace p7x {
 
@@ -24,27 +26,69 @@ struct DevBuf {
 
 struct ScanRow { int64_t pos; int strand, k, sc; };
 
+// The device copy of a target set that its owner promised not to change (cfg.lt_resident_key): one per device, kept
+// until a set with another key arrives.  Searches hold a reference while they run, so replacing the copy never pulls it
+// from under a search still scanning it.
+struct ResidentTargets {
+  uint64_t key = 0; int device = -1; void *p = nullptr; size_t bytes = 0;
+  ~ResidentTargets() { if (p) { (void) hipSetDevice(device); (void) hipFree(p); } }
+};
+static std::mutex g_resident_mu;
+static std::map<int, std::shared_ptr<ResidentTargets>> &resident_by_device()
+{ // never destroyed: at process exit the HIP runtime may be gone before a static destructor could free device memory
+  static auto *m = new std::map<int, std::shared_ptr<ResidentTargets>>();
+  return *m;
+}
+
+// <seq1> (1-based, L residues) on the device: the kept copy when the key and the size match, else a fresh upload --
+// kept in its place when there is a key.  *uploaded tells which it was (timing, tests).
+static int resident_targets(DeviceCtx *ctx, int device, uint64_t key, const uint8_t *seq1, int64_t L, std::shared_ptr<ResidentTargets> &out, bool *uploaded)
+{
+  const size_t bytes = (size_t) L + 2;
+  if (key != 0) {
+    std::lock_guard<std::mutex> lk(g_resident_mu);
+    auto it = resident_by_device().find(device);
+    if (it != resident_by_device().end() && it->second->key == key && it->second->bytes == bytes) { out = it->second; *uploaded = false; return P7X_OK; }
+  }
+  auto r = std::make_shared<ResidentTargets>();
+  r->key = key; r->device = device; r->bytes = bytes;
+  P7X_HIP(hipMalloc(&r->p, std::max<size_t>(bytes, 16)));
+  P7X_HIP(hipMemcpyAsync(static_cast<uint8_t *>(r->p) + 1, seq1 + 1, (size_t) L, hipMemcpyHostToDevice, ctx->stream));
+  P7X_HIP(hipStreamSynchronize(ctx->stream));            // another search may pick the copy up as soon as it is published
+  *uploaded = true;
+  if (key != 0) {
+    std::lock_guard<std::mutex> lk(g_resident_mu);
+    resident_by_device()[device] = r;                      // the previous copy goes when its last search is done
+  }
+  out = std::move(r);
+  return P7X_OK;
+}
+
 // The reset-free SSV scan of one target (both strands, or one): every row whose best diagonal reaches the threshold.
 // <ms>: kernel time by HIP events.
 // <ranges>, when given: only the chunks that touch one of these (strand, first, last) position ranges are scanned
 // (a search dealt over several devices: every device scans the blocks of its own units).
 struct ScanRange { int strand; int64_t first, last; };
 static int scan_target(const p7x_pipeline_cfg &cfg, const Profile &p, DeviceCtx *ctx, const uint8_t *seq1 /* 1-based */, int64_t L,
-                       int sc_thresh, int xB, int strands_mask, std::vector<ScanRow> &rows, double *ms, const std::vector<ScanRange> *ranges = nullptr)
+                       int sc_thresh, int xB, int strands_mask, std::vector<ScanRow> &rows, double *ms, const std::vector<ScanRange> *ranges = nullptr,
+                       int device = 0, uint64_t resident_key = 0)
 {
   const int R = ssvlong_pick_R(p.M);
   if (R < 0) { set_error("model too long for the long-target SSV kernel (M > 6141)"); return P7X_EINVAL; }
   std::vector<uint32_t> tab4, tab_full;
   int pair_slack = 0;
   ssvlong_build_tables(p, R, false, tab4, tab_full, &pair_slack);
-  DevBuf d_tab4, d_full, d_seq, d_comp, d_nrec, d_pos, d_strand, d_k, d_sc;
+  DevBuf d_tab4, d_full, d_comp, d_nrec, d_pos, d_strand, d_k, d_sc;
   int st;
-  if ((st = d_tab4.alloc(tab4.size() * 4)) || (st = d_full.alloc(tab_full.size() * 4)) || (st = d_seq.alloc((size_t) L + 2)) ||
+  if ((st = d_tab4.alloc(tab4.size() * 4)) || (st = d_full.alloc(tab_full.size() * 4)) ||
       (st = d_comp.alloc(32)) || (st = d_nrec.alloc(4))) return st;
   hipStream_t s = ctx->stream;
+  std::shared_ptr<ResidentTargets> d_seq;
+  bool uploaded = false;
+  if ((st = resident_targets(ctx, device, resident_key, seq1, L, d_seq, &uploaded)) != P7X_OK) return st;
+  if (std::getenv("P7X_LT_DEBUG")) std::fprintf(stderr, "[lt] targets on the device: %s (%lld bytes, key %llu)\n", uploaded ? "uploaded" : "resident", (long long) L, (unsigned long long) resident_key);
   P7X_HIP(hipMemcpyAsync(d_tab4.p, tab4.data(), tab4.size() * 4, hipMemcpyHostToDevice, s));
   P7X_HIP(hipMemcpyAsync(d_full.p, tab_full.data(), tab_full.size() * 4, hipMemcpyHostToDevice, s));
-  P7X_HIP(hipMemcpyAsync(static_cast<uint8_t *>(d_seq.p) + 1, seq1 + 1, (size_t) L, hipMemcpyHostToDevice, s));
   P7X_HIP(hipMemcpyAsync(d_comp.p, longtarget_complement(p.abc_type), 18, hipMemcpyHostToDevice, s));
   // chunks: long enough that the M warm-up rows are a small overhead, short enough that every SIMD gets several
   const int64_t want_chunks = (int64_t) ctx->num_cu * 4 * 8;
@@ -53,7 +97,7 @@ static int scan_target(const p7x_pipeline_cfg &cfg, const Profile &p, DeviceCtx 
   const int nstrands = strands_mask == 3 ? 2 : 1;
   SsvLongArgs a{};
   a.tab4 = static_cast<const uint32_t *>(d_tab4.p); a.tab_full = static_cast<const uint32_t *>(d_full.p);
-  a.dsq = static_cast<const uint8_t *>(d_seq.p); a.comp = static_cast<const uint8_t *>(d_comp.p);
+  a.dsq = static_cast<const uint8_t *>(d_seq->p); a.comp = static_cast<const uint8_t *>(d_comp.p);
   a.L = L; a.M = p.M; a.Kp = p.Kp; a.chunk_len = chunk_len;
   a.chunks_per_strand = (L + chunk_len - 1) / chunk_len; a.nchunks = a.chunks_per_strand * nstrands;
   a.thresh_s = sc_thresh - xB - 32768; a.xB = xB; a.Q16 = p.Q16();
@@ -411,7 +455,9 @@ int p7x_search_longtargets(const p7x_pipeline_cfg *cfg, const p7x_oprofile *om, 
     std::vector<ScanRow> rows;
     double ms = 0.0;
     const auto ts0 = std::chrono::steady_clock::now();
-    if ((st = scan_target(*cfg, p, ctx, scan1, Ltot, sc_thresh, xB, mask, rows, &ms, all_units.nparts > 1 ? &ranges : nullptr)) != P7X_OK) return st;
+    // the kept copy is of the caller's buffer as it lies: a set that had to be packed first is uploaded per call
+    const uint64_t rkey = packed.empty() ? cfg->lt_resident_key : 0;
+    if ((st = scan_target(*cfg, p, ctx, scan1, Ltot, sc_thresh, xB, mask, rows, &ms, all_units.nparts > 1 ? &ranges : nullptr, device, rkey)) != P7X_OK) return st;
     scan_ms += ms;
     const auto ts1 = std::chrono::steady_clock::now();
     host_parallel_for((int) units.size(), cfg->host_threads, [&](int u) {

@@ -187,7 +187,7 @@ class PackedBlock:
     ``offsets[t]`` indexes ``x1`` of target ``t``; ``lengths[t]`` is ``L_t``.
     """
 
-    __slots__ = ("dsq", "offsets", "lengths", "n", "total_residues")
+    __slots__ = ("dsq", "offsets", "lengths", "n", "total_residues", "_resident_token")
 
     def __init__(self, seqs: _Seq[DigitalSequence]):
         n = len(seqs)

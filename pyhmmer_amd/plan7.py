@@ -13,6 +13,8 @@ import os
 import sys
 from typing import Iterable, Iterator, List, Optional, Sequence, Union
 
+import itertools
+
 import numpy as np
 
 from . import _lib
@@ -1632,6 +1634,16 @@ class LongTargetsPipeline(Pipeline):
             pk = sequences.packed()
             n = len(sequences)
             dsq, offsets, lengths = pk.dsq, pk.offsets, pk.lengths.astype(np.int64)
+            # ... nor uploaded per query: the image is immutable (a mutated block gets a new one), its token lets the device
+            # keep its copy between searches (cfg.lt_resident_key; one copy per device)
+            tok = getattr(pk, "_resident_token", None)
+            if tok is None:
+                tok = next(_RESIDENT_TOKENS)
+                try:
+                    pk._resident_token = tok
+                except AttributeError:
+                    tok = 0
+            cfg.lt_resident_key = tok
             names = (C.c_char_p * max(n, 1))(*[s.name.encode() for s in sequences])
             accs = (C.c_char_p * max(n, 1))(*[(s.accession or "").encode() for s in sequences])
             descs = (C.c_char_p * max(n, 1))(*[(s.description or "").encode() for s in sequences])
@@ -1673,6 +1685,9 @@ class LongTargetsPipeline(Pipeline):
         hits = TopHits(query, out)
         hits._om = om
         return hits
+
+
+_RESIDENT_TOKENS = itertools.count(1)          # one per packed image whose device copy may be kept (cfg.lt_resident_key)
 
 
 class SequenceDatabase:

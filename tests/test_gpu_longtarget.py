@@ -246,3 +246,31 @@ def test_contig_rich_target_set_is_one_scan(oracle):
     # the same search dealt over three parts
     many = next(hmmer.nhmmer(hmm, block, devices=[0, 0, 0], host_envelopes=1))
     assert _rows(many) == _rows(dev)
+
+
+def test_targets_stay_on_the_device_between_searches(capfd, monkeypatch):
+    """cfg.lt_resident_key: the packed image of a block carries a token, and a later search of the same image -- by any
+    query -- finds the targets on the device instead of uploading them again; a block that was changed has a new image,
+    a new token and is uploaded; the results are those of a fresh block either way."""
+    import bench_workloads as bw
+    monkeypatch.setenv("P7X_LT_DEBUG", "1")
+    hmm = load_hmms("bmyD")[0]
+    abc = hmm.alphabet
+    seqs = [easel.DigitalSequence(abc, name=f"chr{i}", sequence=bw.make_chromosome(hmm, 400_000, planted=6, seed=70 + i)) for i in range(2)]
+    block = easel.DigitalSequenceBlock(abc, seqs)
+    pli = plan7.LongTargetsPipeline(abc)
+    first = pli.search_hmm(hmm, block)
+    e1 = capfd.readouterr().err
+    second = plan7.LongTargetsPipeline(abc).search_hmm(hmm, block)           # another pipeline object, the same image
+    e2 = capfd.readouterr().err
+    assert "targets on the device: uploaded" in e1 and "targets on the device: resident" in e2
+    assert _rows(first) == _rows(second) and len(first) >= 10
+    extra = easel.DigitalSequence(abc, name="chr2", sequence=bw.make_chromosome(hmm, 300_000, planted=4, seed=90))
+    block.append(extra)
+    third = pli.search_hmm(hmm, block)
+    e3 = capfd.readouterr().err
+    assert "targets on the device: uploaded" in e3
+    fresh = plan7.LongTargetsPipeline(abc).search_hmm(hmm, easel.DigitalSequenceBlock(abc, seqs + [extra]))
+    assert _rows(third) == _rows(fresh) and len(third) > len(first)
+    two = pli.search_hmm(hmm, block, devices=[0, 0])                        # parts of one search share the device's copy
+    assert _rows(two) == _rows(third)
