@@ -494,7 +494,7 @@ int64_t p7x_ssv_longtarget_seeds(const p7x_pipeline_cfg *cfg, const p7x_oprofile
   DeviceCtx *ctx = nullptr;
   if ((st = get_ctx(device, &ctx)) != P7X_OK) return -st;
   std::vector<ScanRow> rows;
-  if ((st = scan_target(*cfg, p, ctx, dsq - 1, L, sc_thresh, xB, complement ? 2 : 1, rows, nullptr)) != P7X_OK) return -st;
+  if ((st = scan_target(*cfg, p, ctx, dsq - 1, L, sc_thresh, xB, complement ? 2 : 1, rows, nullptr, nullptr, device, 0)) != P7X_OK) return -st;
   std::vector<int64_t> s3;
   block_seeds(p, dsq - 1, L, 0, L, complement ? 1 : 0, rows, sc_thresh, xB, s3);
   const size_t ns = s3.size() / 3;
