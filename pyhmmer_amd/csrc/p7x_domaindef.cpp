@@ -875,7 +875,12 @@ void make_alidisplay(const Profile &p, const Trace &tr, const uint8_t *dsq, int 
   if (has_rf) dom.rfline.assign(dom.N, ' ');
   if (has_mm) dom.mmline.assign(dom.N, ' ');
   if (has_cs) dom.csline.assign(dom.N, ' ');
-  auto digitize = [&](char c) -> int { const char *q = std::strchr(abc.sym, std::toupper((unsigned char) c)); return q ? (int) (q - abc.sym) : -1; };
+  // residue code of a consensus character (strchr over the alphabet's symbols, upper-cased): tabulated per call instead
+  // of searched per aligned column -- most of this function's time was the search
+  signed char code_of[256];
+  std::memset(code_of, -1, sizeof code_of);
+  for (int x = (int) std::strlen(abc.sym) - 1; x >= 0; --x) code_of[(unsigned char) abc.sym[x]] = (signed char) x;     // first occurrence wins, as strchr
+  auto digitize = [&](char c) -> int { return code_of[(unsigned char) std::toupper((unsigned char) c)]; };
   for (int z = z1; z <= z2; ++z) {
     const int k = tr.k[z], i = tr.i[z], s = tr.st[z], o = z - z1;
     const char cons = (k >= 1 && (int) p.consensus.size() > k) ? p.consensus[k] : 'x';
@@ -1001,7 +1006,9 @@ int rescore_isolated_domain(const Profile &p, Model &om, const uint8_t *dsq, int
       float null2[MAXKP];
       ProfScope psn(10);
       null2_by_expectation(om, ws.bck, null2);
-      for (int pos = i; pos <= j; ++pos) dd.n2sc[pos] = logf(null2[dsq[pos]]);
+      float ln2[MAXKP];                                   // one logarithm per residue code, not per residue
+      for (int x = 0; x < p.Kp; ++x) ln2[x] = logf(null2[x]);
+      for (int pos = i; pos <= j; ++pos) dd.n2sc[pos] = ln2[dsq[pos]];
     }
     for (int pos = i; pos <= j; ++pos) domcorrection += dd.n2sc[pos];
   }
@@ -1249,7 +1256,9 @@ int domaindef_finish_deferred(const Profile &p, const uint8_t *dsq, int L, const
       float null2[MAXKP];
       for (int x = 0; x < p.K; ++x) null2[x] = r.null2[x];
       finish_null2(p, null2);
-      for (int pos = i; pos <= j; ++pos) dd.n2sc[pos] = logf(null2[dsq[pos]]);
+      float ln2[MAXKP];                                   // one logarithm per residue code, not per residue
+      for (int x = 0; x < p.Kp; ++x) ln2[x] = logf(null2[x]);
+      for (int pos = i; pos <= j; ++pos) dd.n2sc[pos] = ln2[dsq[pos]];
     }
     float domcorrection = 0.0f;
     for (int pos = i; pos <= j; ++pos) domcorrection += dd.n2sc[pos];
