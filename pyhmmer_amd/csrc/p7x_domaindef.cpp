@@ -380,9 +380,10 @@ P7X_MULTIVERSION int decoding(const Model &om, const Matrix &fwd, Matrix &bck)
     const float totr = scaleproduct * fwd.X(r, xS_);
     const float *__restrict fm = fwd.M_(r), *__restrict fi = fwd.I_(r);
     float *__restrict mc = bck.M_(r), *__restrict ic = bck.I_(r), *__restrict dc = bck.D_(r);
+    (void) dc;                 // upstream zeroes the delete posteriors; nothing downstream reads them (optimal accuracy, null2 and the
+                               // trace take M and I), so the row is left as Backward wrote it and a store stream is saved
     for (int k = 1; k <= M; ++k) {
       mc[k] = (fm[k] * mc[k]) * totr;
-      dc[k] = 0.0f;
       ic[k] = (fi[k] * ic[k]) * totr;
     }
     bck.X(r, xE_) = 0.0f;
