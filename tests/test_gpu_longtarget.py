@@ -274,3 +274,38 @@ def test_targets_stay_on_the_device_between_searches(capfd, monkeypatch):
     assert _rows(third) == _rows(fresh) and len(third) > len(first)
     two = pli.search_hmm(hmm, block, devices=[0, 0])                        # parts of one search share the device's copy
     assert _rows(two) == _rows(third)
+
+
+def test_a_target_buffer_with_gaps_is_packed_and_gives_the_same_hits():
+    """The C-ABI takes any (dsq, offsets, lengths); only records that lie end to end with one sentinel between them are
+    scanned where they are.  Here the records are laid out with gaps of ordinary residues between them and in a buffer
+    that starts with junk: the library packs them first, and the hits are those of the contiguous layout."""
+    import bench_workloads as bw
+    hmm = load_hmms("bmyD")[0]
+    abc = hmm.alphabet
+    seqs = [easel.DigitalSequence(abc, name=f"c{i}", sequence=bw.make_chromosome(hmm, n, planted=p, seed=40 + i))
+            for i, (n, p) in enumerate([(200_000, 3), (1_500, 0), (90_000, 2)])]
+    block = easel.DigitalSequenceBlock(abc, seqs)
+    pli = plan7.LongTargetsPipeline(abc)
+    want = pli.search_hmm(hmm, block)
+    assert len(want) >= 4
+    cfg = pli._cfg()
+    om = pli._windowed_om(hmm, 100000, cfg)
+    gap = 1000
+    total = sum(len(s) for s in seqs) + gap * (len(seqs) + 1)
+    rng = np.random.default_rng(1)
+    dsq = rng.integers(0, 4, size=total + 2, dtype=np.uint8)            # the gaps are residues, not sentinels
+    offsets, lengths, pos = [], [], gap
+    for s in seqs:
+        dsq[pos:pos + len(s)] = s.sequence
+        offsets.append(pos); lengths.append(len(s))
+        pos += len(s) + gap
+    offsets = np.array(offsets, dtype=np.int64); lengths = np.array(lengths, dtype=np.int64)
+    names = (C.c_char_p * 3)(*[s.name.encode() for s in seqs])
+    empty = (C.c_char_p * 3)(b"", b"", b"")
+    out = C.c_void_p()
+    st = _lib.lib().p7x_search_longtargets(C.byref(cfg), om._handle, 0, dsq.ctypes.data, offsets.ctypes.data, lengths.ctypes.data, 3,
+                                           names, empty, empty, C.byref(out))
+    assert st == 0, _lib.last_error()
+    got = plan7.TopHits(hmm, out)
+    assert _rows(got) == _rows(want)
