@@ -326,7 +326,7 @@ def run_scan(args, rank, world, local_rank, dist, red_dev, torch, host_threads, 
     block = plan7.OptimizedProfileBlock(hmms[0].alphabet, mine)
 
     def scan():
-        return list(hmmer.hmmscan(proteome, block, cpus=host_threads, devices=[local_rank], finishers=args.finishers))
+        return list(hmmer.hmmscan(proteome, block, cpus=host_threads, devices=[local_rank]))
 
     scan()                                  # images of this rank's profiles resident on this device, pools warm
     if dist is not None:
@@ -423,7 +423,10 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--pipeline-depth", type=int, default=4, help="queries whose device stage may run ahead of the host stage (0: none)")
     ap.add_argument("--feeders", type=int, default=2, help="host threads issuing device stages (each on its own stream)")
-    ap.add_argument("--finishers", type=int, default=0, help="host threads running host stages (0: the library's default, feeders + 2)")
+    ap.add_argument("--finishers", type=int, default=4,
+                    help="host-stage threads of the headline workload (and of `scan` when given): 4 = two more than feeders, which takes a "
+                         "run-to-run slow mode out of a single-profile query stream (14.4-18.0 -> 19.0-19.3 TCUPS); the library's own default "
+                         "(0 = as many as feeders) suits many-profile streams, see --pfam-finishers and DESIGN.md 4")
     ap.add_argument("--cpu-sample", type=int, default=1_000_000, help="targets timed through the CPU oracle (rank 0, N=1)")
     ap.add_argument("--queries-per-step", type=int, default=32,
                     help="a step is this many consecutive queries, each a complete search of the resident target block: the "
@@ -622,7 +625,7 @@ def main():
                                 "(pipeline_depth=%d batches); targets resident in HBM (pack+upload once: %.2fs, generation %.2fs, "
                                 "not timed)" % (args.pipeline_depth, t_pack, t_gen),
                 "queries_per_step": qps, "queries_per_device_batch": lanes_per_launch,
-                "pipeline_depth": args.pipeline_depth, "feeders": args.feeders, "finishers": args.finishers or args.feeders + 2, "host_threads_per_rank": host_threads,
+                "pipeline_depth": args.pipeline_depth, "feeders": args.feeders, "finishers": args.finishers or args.feeders, "host_threads_per_rank": host_threads,
                 "spinup_windows_s": [round(x, 4) for x in spin],
                 "latency_ms_per_query": round(stage.get("total", 0.0), 3),
             },

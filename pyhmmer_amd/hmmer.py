@@ -186,11 +186,14 @@ def hmmsearch(queries: Union[HMM, Profile, OptimizedProfile, Iterable], sequence
 
     Consecutive queries are overlapped the way the reference overlaps them on worker threads
     (``hmmer/_base.py:416-489``): ``feeders`` threads run the device stage (filters and parsers) of up to
-    ``pipeline_depth`` batches of queries ahead while ``finishers`` threads (default: two more than feeders) run the host
+    ``pipeline_depth`` batches of queries ahead while ``finishers`` threads (default: as many as feeders) run the host
     stage (envelope kernel, domain definition, hit list) of the batches before them; results come back in query order.
-    A finished device stage spends most of its host stage waiting for its own envelope kernel, so with only as many
-    finishers as feeders the host stage paces the search (measured on the benchmark: 14.4-18.0 TCUPS from run to run
-    with two finishers, 19.0-19.3 with four).  ``pipeline_depth=0`` runs the two stages of every query back to back.
+    How many host stages should be in flight depends on the query stream, and both ways were measured: a stream of one
+    260-node profile against a million targets (the benchmark's headline) wanders between 14.4 and 18.0 TCUPS from run
+    to run with two finishers and holds 19.0-19.3 with four, a Pfam-shaped stream of 20,000 different profiles takes
+    29.0 s with two and 34.5 s with three or four.  The default suits the second, which is what the
+    reference is used for; ``bench.py`` passes four for the first.  ``pipeline_depth=0`` runs the two stages of every
+    query back to back.
     ``sequences`` may also be a :class:`~pyhmmer_amd.plan7.SequenceDatabase` already resident on one device.
     """
     if backend not in (None, "threading", "multiprocessing"):
@@ -213,7 +216,7 @@ def hmmsearch(queries: Union[HMM, Profile, OptimizedProfile, Iterable], sequence
             from .errors import DeviceUnavailable
             raise DeviceUnavailable("hmmsearch: no HIP device is usable and there is no CPU fallback")
         yield from _search_file(queries, sequences, chunk_bytes or (1 << 30), list(devices) if devices else [0], cpus, callback,
-                                pipeline_depth, feeders, batch, options, finishers=finishers or feeders + 2)
+                                pipeline_depth, feeders, batch, options, finishers=finishers)
         return
     if not isinstance(sequences, (DigitalSequenceBlock, SequenceDatabase)):
         raise TypeError(f"Expected DigitalSequenceBlock or SequenceFile, found {type(sequences).__name__}")
@@ -233,7 +236,7 @@ def hmmsearch(queries: Union[HMM, Profile, OptimizedProfile, Iterable], sequence
         total = len(queries)          # type: ignore[arg-type]
     except TypeError:
         pass
-    for q, hits in _run_queries(db, pipelines, queries, pipeline_depth, feeders, finishers=finishers or feeders + 2, batch=batch):
+    for q, hits in _run_queries(db, pipelines, queries, pipeline_depth, feeders, finishers=finishers, batch=batch):
         if callback is not None:
             callback(q, total)
         yield hits

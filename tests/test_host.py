@@ -313,7 +313,7 @@ def test_query_pipeline_orders_results_and_errors_for_every_shape(libp7x, monkey
     from pyhmmer_amd import hmmer
     before = threading.active_count()
     shapes = [(0, 1, 1, 0), (1, 1, 1, 0), (2, 1, 1, 0), (4, 2, 1, 0), (8, 4, 1, 0), (8, 1, 8, 0), (32, 2, 8, 0), (5, 3, 2, 0),
-              (2, 2, 8, 4), (64, 4, 4, 8), (3, 8, 64, 2), (4, 2, 1, 4)]      # the last one: hmmsearch's defaults
+              (2, 2, 8, 4), (64, 4, 4, 8), (3, 8, 64, 2), (4, 2, 1, 4)]      # the last one: the shape bench.py runs the headline with
     for seed, (depth, feeders, window, fin) in enumerate(shapes):
         batch = (1, 3, 8)[seed % 3]             # queries per device batch
         for n in (0, 1, 7, 40):
