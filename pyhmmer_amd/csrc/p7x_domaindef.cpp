@@ -24,6 +24,8 @@
 
 namespace p7x {
 
+int vit_pick_C(int M);          // p7x_vitfwd.hip: nodes per lane of the wave-per-target kernels, a function of M alone
+
 // optional host profile (P7X_HOST_PROF=1): accumulated nanoseconds per phase, printed by host_prof_dump()
 static bool g_prof_on = std::getenv("P7X_HOST_PROF") != nullptr;
 static std::atomic<long long> g_prof_ns[12];
@@ -92,6 +94,69 @@ int fchoose(FastRng &r, const float *p, int n)
   return 0;
 }
 
+// ---------------------------------------------------------------- the wavefront's combining trees, lane by lane
+// Host restatement of p7x_wave.hpp (affine_scan_up / affine_scan_down / wave_sum_f32): the same operations on the same
+// operands in the same order, so that a sum formed here and on the device is the same float.  A DPP step whose source
+// lane lies outside the 16-lane row (or whose row is masked) leaves the identity (a = 0, p = 1) in place of the operand.
+static inline void lanes_scan_up(float *sa, float *sp)
+{ // inclusive scan of the affine maps x -> a_l + p_l x over lanes 0..l: Kogge-Stone inside the rows, then row_bcast:15 / :31
+  float a[64], q[64];
+  for (int s = 1; s <= 8; s <<= 1) {
+    for (int l = 0; l < 64; ++l) {
+      const bool src = (l & 15) >= s;
+      const float pa = src ? sa[l - s] : 0.0f, pp = src ? sp[l - s] : 1.0f;
+      a[l] = sa[l] + pa * sp[l]; q[l] = sp[l] * pp;
+    }
+    for (int l = 0; l < 64; ++l) { sa[l] = a[l]; sp[l] = q[l]; }
+  }
+  for (int row = 1; row < 4; row += 2) {            // rows 1 and 3 take the last lane of the row before them
+    const float pa = sa[16 * row - 1], pp = sp[16 * row - 1];
+    for (int l = 16 * row; l < 16 * row + 16; ++l) { sa[l] = sa[l] + pa * sp[l]; sp[l] = sp[l] * pp; }
+  }
+  {                                                 // rows 2 and 3 take lane 31
+    const float pa = sa[31], pp = sp[31];
+    for (int l = 32; l < 64; ++l) { sa[l] = sa[l] + pa * sp[l]; sp[l] = sp[l] * pp; }
+  }
+}
+static inline void lanes_scan_down(float *sa, float *sp)
+{ // the same over lanes l..63
+  float a[64], q[64];
+  for (int s = 1; s <= 8; s <<= 1) {
+    for (int l = 0; l < 64; ++l) {
+      const bool src = (l & 15) + s <= 15;
+      const float pa = src ? sa[l + s] : 0.0f, pp = src ? sp[l + s] : 1.0f;
+      a[l] = sa[l] + pa * sp[l]; q[l] = sp[l] * pp;
+    }
+    for (int l = 0; l < 64; ++l) { sa[l] = a[l]; sp[l] = q[l]; }
+  }
+  {
+    const float a48 = sa[48], p48 = sp[48], a16 = sa[16], p16 = sp[16];
+    for (int l = 0; l < 64; ++l) {
+      const int row = l >> 4;
+      const float pa = (row == 2) ? a48 : ((row == 0) ? a16 : 0.0f), pp = (row == 2) ? p48 : ((row == 0) ? p16 : 1.0f);
+      sa[l] = sa[l] + pa * sp[l]; sp[l] = sp[l] * pp;
+    }
+  }
+  {
+    const float a32 = sa[32], p32 = sp[32];
+    for (int l = 0; l < 64; ++l) {
+      const float pa = (l < 32) ? a32 : 0.0f, pp = (l < 32) ? p32 : 1.0f;
+      sa[l] = sa[l] + pa * sp[l]; sp[l] = sp[l] * pp;
+    }
+  }
+}
+static inline float lanes_sum(float *v)
+{ // wave_sum_f32: the value lane 63 ends up with
+  float t[64];
+  for (int s = 1; s <= 8; s <<= 1) {
+    for (int l = 0; l < 64; ++l) t[l] = v[l] + (((l & 15) >= s) ? v[l - s] : 0.0f);
+    for (int l = 0; l < 64; ++l) v[l] = t[l];
+  }
+  for (int row = 1; row < 4; row += 2) { const float b = v[16 * row - 1]; for (int l = 16 * row; l < 16 * row + 16; ++l) v[l] = v[l] + b; }
+  { const float b = v[31]; for (int l = 32; l < 64; ++l) v[l] = v[l] + b; }
+  return v[63];
+}
+
 // ---------------------------------------------------------------- the query in a given configuration
 // Long-target (nhmmer) variant of envelope rescoring, upstream rescore_isolated_domain(..., long_target = TRUE, ...)
 struct LongTargetOpts {
@@ -108,11 +173,15 @@ struct Model {
   const LongTargetOpts *lt = nullptr;
   const float *tf(int t) const { return p->tf.data() + (size_t) t * (M + 1); }
   const float *rf(int x) const { return (rf_over ? rf_over : p->rf_.data()) + (size_t) x * (M + 1); }
-  // D->D chains are the only serial dependency along k.  They are evaluated as kSeg independent segment chains
-  // (instruction-level parallelism) followed by a vectorisable carry fix-up with these prefix products.
-  static constexpr int kSeg = 8;
-  int seglen = 0;
-  std::vector<float> ddpre_f, ddpre_b, ddpass;      // ddpass[k]: 0 if every tDD from the segment start to k is > 0, else -inf
+  // Order of operations.  The sums whose result depends on the order of the float additions -- the D->D chains, the row
+  // sums xE / xB, the null2 expectation -- run in the order of the device kernels (p7x_envelope.hip, p7x_wave.hpp): lane z
+  // of a 64-lane wavefront owns the C consecutive nodes zC+1 .. zC+C, walks them in order, and the lanes are combined by
+  // the wavefront's scan / reduction trees (lanes_scan_up / lanes_scan_down / lanes_sum below).  Host twin and device
+  // therefore produce the same bits, and every discrete decision taken from them (optimal-accuracy traceback, the
+  // stochastic tracebacks' choices) is the same decision.  Upstream's own order (four striped lanes, serial D->D sweeps)
+  // is a third one; what the fixtures pin is reproduced by all of them.
+  int C = 1;                                        // nodes per lane: vit_pick_C(M), the device image's choice
+  float ddprod[64];                                 // product of the D->D transitions of a lane's nodes, in node order
   std::vector<float> rfT;                           // [M+1][kKpad] match odds, residue-minor (null2_by_trace)
   static constexpr int kKpad = 24;
   void prepare_rfT()
@@ -122,17 +191,13 @@ struct Model {
   }
   void prepare()
   {
-    seglen = (M + kSeg - 1) / kSeg;
+    C = vit_pick_C(M);
+    if (C <= 0) C = (M + 63) / 64;                  // beyond the device kernels' reach: the same rule, continued
     const float *tDD = tf(7);
-    ddpre_f.assign(M + 2, 0.0f); ddpre_b.assign(M + 2, 0.0f); ddpass.assign(M + 2, -INFINITY);
-    for (int s0 = 1; s0 <= M; s0 += seglen) {
-      const int s1 = std::min(M, s0 + seglen - 1);
+    for (int z = 0; z < 64; ++z) {
       float pr = 1.0f;
-      for (int k = s0; k <= s1; ++k) { pr *= tDD[k - 1]; ddpre_f[k] = pr; }      // product of tDD[s0-1 .. k-1]
-      bool open = true;
-      for (int k = s0; k <= s1; ++k) { open = open && (tDD[k - 1] > 0.0f); ddpass[k] = open ? 0.0f : -INFINITY; }
-      pr = 1.0f;
-      for (int k = s1; k >= s0; --k) { pr *= tDD[k]; ddpre_b[k] = pr; }          // product of tDD[k .. s1]
+      for (int c = 0; c < C; ++c) { const int k = z * C + c + 1; pr *= (k <= M ? tDD[k] : 0.0f); }
+      ddprod[z] = pr;
     }
   }
   void configure(bool multihit, int L)
@@ -171,32 +236,31 @@ struct Matrix {
 
 // ---------------------------------------------------------------- p7_Forward (full matrix)
 // dsq is 1-indexed over the envelope: residues dsq[1..L].
-static inline float hsum8(const float (&acc)[8]) { return ((acc[0] + acc[1]) + (acc[2] + acc[3])) + ((acc[4] + acc[5]) + (acc[6] + acc[7])); }
-
-// D(i,k) = M(i,k-1) tMD(k-1) + D(i,k-1) tDD(k-1), k = 1..M, given the finished M row.
-P7X_MULTIVERSION static void dchain_forward(const Model &om, const float *__restrict mc, float *__restrict dc)
+// D(i,k) = M(i,k-1) tMD(k-1) + D(i,k-1) tDD(k-1), k = 1..M, given the finished M row; returns xE = sum_k M(i,k) + D(i,k).
+// EnvForward<C>::row (p7x_envelope.hip) operation for operation: every lane runs its own chain from a zero carry, the
+// lanes' affine maps are composed by the scan, the carry enters a lane's nodes through successive products, and the row
+// sum takes a lane's match cells, then its delete cells, then the reduction tree.
+static float dchain_forward(const Model &om, const float *__restrict mc, float *__restrict dc)
 {
-  const int M = om.M, seglen = om.seglen;
+  const int M = om.M, C = om.C;
   const float *__restrict tMD = om.tf(4), *__restrict tDD = om.tf(7);
-  for (int k = 1; k <= M; ++k) dc[k] = mc[k - 1] * tMD[k - 1];              // M->D part (vectorises); mc[0] = 0
-  float cur[Model::kSeg];
-  for (int s = 0; s < Model::kSeg; ++s) cur[s] = 0.0f;
-  for (int j = 0; j < seglen; ++j)                                          // kSeg independent chains, interleaved
-    for (int s = 0; s < Model::kSeg; ++s) {
-      const int k = 1 + s * seglen + j;
-      if (k > M) continue;
-      const float v = (j == 0) ? dc[k] : dc[k] + cur[s] * tDD[k - 1];
-      cur[s] = v; dc[k] = v;
-    }
-  for (int s = 1; s < Model::kSeg; ++s) {                                   // carries, in order
-    const int s0 = 1 + s * seglen;
-    if (s0 > M) break;
-    const int s1 = std::min(M, s0 + seglen - 1);
-    const float carry = dc[s0 - 1];
-    if (carry == 0.0f) continue;
-    const float *__restrict pre = om.ddpre_f.data();
-    for (int k = s0; k <= s1; ++k) dc[k] += carry * pre[k];
+  float sa[64], sp[64], es[64];
+  for (int z = 0; z < 64; ++z) {
+    const int k0 = z * C + 1;
+    float A = 0.0f, e = 0.0f;
+    const int k1 = std::min(M, k0 + C - 1);
+    for (int k = k0; k <= k1; ++k) { e = e + mc[k]; dc[k] = A; A = mc[k] * tMD[k] + A * tDD[k]; }
+    if (k0 + C - 1 > M) A = 0.0f;                   // a padding node closes the chain (its transitions are zero)
+    sa[z] = A; sp[z] = om.ddprod[z]; es[z] = e;
   }
+  lanes_scan_up(sa, sp);
+  for (int z = 0; z < 64; ++z) {
+    const int k0 = z * C + 1, k1 = std::min(M, k0 + C - 1);
+    float w = z ? sa[z - 1] : 0.0f, e = es[z];
+    for (int k = k0; k <= k1; ++k) { dc[k] = dc[k] + w; e = e + dc[k]; w = w * tDD[k]; }
+    es[z] = e;
+  }
+  return lanes_sum(es);
 }
 
 P7X_MULTIVERSION int forward_full(const Model &om, const uint8_t *dsq, int L, Matrix &ox, float *ret_sc)
@@ -223,13 +287,8 @@ P7X_MULTIVERSION int forward_full(const Model &om, const uint8_t *dsq, int L, Ma
       mc[k] = sv * rf[k];
       ic[k] = mp[k] * tMI[k] + ip[k] * tII[k];
     }
-    dchain_forward(om, mc, dc);
-    float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    int k = 1;
-    for (; k + 7 <= M; k += 8) for (int z = 0; z < 8; ++z) acc[z] += mc[k + z] + dc[k + z];
-    for (; k <= M; ++k) acc[0] += mc[k] + dc[k];
+    xE = dchain_forward(om, mc, dc);
     mc[M + 1] = ic[M + 1] = dc[M + 1] = 0.0f;
-    xE = hsum8(acc);
     xN = xN * om.xf[XN][LOOP];
     xC = (xC * om.xf[XC][LOOP]) + (xE * om.xf[XE][MOVE]);
     xJ = (xJ * om.xf[XJ][LOOP]) + (xE * om.xf[XE][LOOP]);
@@ -250,33 +309,39 @@ P7X_MULTIVERSION int forward_full(const Model &om, const uint8_t *dsq, int L, Ma
 }
 
 // ---------------------------------------------------------------- p7_Backward (full matrix)
-// D(i,k) = base(k) + D(i,k+1) tDD(k), k = M..1 (D(i,M+1) = 0); on entry dc[k] = base(k).
-P7X_MULTIVERSION static void dchain_backward(const Model &om, float *__restrict dc)
+// D(i,k) = base(k) + D(i,k+1) tDD(k), k = M..1 (D(i,M+1) = 0); on entry dc[k] = base(k).  The envelope kernel's d_chain:
+// every lane folds its nodes from the last to the first, the scan composes the lanes from 63 downwards, and each lane
+// then recomputes its chain from the carry it was handed.
+static void dchain_backward(const Model &om, float *__restrict dc)
 {
-  const int M = om.M, seglen = om.seglen;
+  const int M = om.M, C = om.C;
   const float *__restrict tDD = om.tf(7);
-  float cur[Model::kSeg];
-  for (int s = 0; s < Model::kSeg; ++s) cur[s] = 0.0f;
-  for (int j = 0; j < seglen; ++j)
-    for (int s = 0; s < Model::kSeg; ++s) {
-      const int s0 = 1 + s * seglen;
-      if (s0 > M) continue;
-      const int s1 = std::min(M, s0 + seglen - 1);
-      const int k = s1 - j;
-      if (k < s0) continue;
-      const float v = (j == 0) ? dc[k] : dc[k] + cur[s] * tDD[k];
-      cur[s] = v; dc[k] = v;
-    }
-  for (int s = Model::kSeg - 2; s >= 0; --s) {
-    const int s0 = 1 + s * seglen;
-    if (s0 > M) continue;
-    const int s1 = std::min(M, s0 + seglen - 1);
-    if (s1 + 1 > M) continue;
-    const float carry = dc[s1 + 1];
-    if (carry == 0.0f) continue;
-    const float *__restrict pre = om.ddpre_b.data();
-    for (int k = s0; k <= s1; ++k) dc[k] += carry * pre[k];
+  float sa[64], sp[64];
+  for (int z = 0; z < 64; ++z) {
+    const int k0 = z * C + 1, k1 = std::min(M, k0 + C - 1);
+    float A = 0.0f;
+    for (int k = k1; k >= k0; --k) A = dc[k] + A * tDD[k];
+    sa[z] = A; sp[z] = om.ddprod[z];
   }
+  lanes_scan_down(sa, sp);
+  for (int z = 0; z < 64; ++z) {
+    const int k0 = z * C + 1, k1 = std::min(M, k0 + C - 1);
+    float w = (z < 63) ? sa[z + 1] : 0.0f;
+    for (int k = k1; k >= k0; --k) { dc[k] = dc[k] + w * tDD[k]; w = dc[k]; }
+  }
+}
+// sum_k v(k) w(k) as the kernels form it: a lane's nodes in order, then the reduction tree (v = nullptr: sum of w)
+static float lanes_dot(const Model &om, const float *__restrict v, const float *__restrict w)
+{
+  const int M = om.M, C = om.C;
+  float es[64];
+  for (int z = 0; z < 64; ++z) {
+    const int k0 = z * C + 1, k1 = std::min(M, k0 + C - 1);
+    float e = 0.0f;
+    for (int k = k0; k <= k1; ++k) e = e + v[k] * w[k];
+    es[z] = e;
+  }
+  return lanes_sum(es);
 }
 
 P7X_MULTIVERSION int backward_full(const Model &om, const uint8_t *dsq, int L, const Matrix &fwd, Matrix &bck, float *ret_sc)
@@ -312,13 +377,9 @@ P7X_MULTIVERSION int backward_full(const Model &om, const uint8_t *dsq, int L, c
     const float *__restrict rf = om.rf(dsq[r + 1]);
     const float *__restrict mn = bck.M_(r + 1), *__restrict in = bck.I_(r + 1);
     float *__restrict mc = bck.M_(r), *__restrict ic = bck.I_(r), *__restrict dc = bck.D_(r);
-    float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     for (int k = 1; k <= M; ++k) me[k] = mn[k] * rf[k];                      // M(i+1,k) e(x_{i+1},k)
     me[M + 1] = 0.0f;
-    int kk = 1;
-    for (; kk + 7 <= M; kk += 8) for (int z = 0; z < 8; ++z) acc[z] += me[kk + z] * bm[kk + z];
-    for (; kk <= M; ++kk) acc[0] += me[kk] * bm[kk];
-    xB = hsum8(acc);
+    xB = lanes_dot(om, me, bm);
     xC = xC * om.xf[XC][LOOP];
     xJ = (xB * om.xf[XJ][MOVE]) + (xJ * om.xf[XJ][LOOP]);
     xN = (xB * om.xf[XN][MOVE]) + (xN * om.xf[XN][LOOP]);
@@ -349,9 +410,8 @@ P7X_MULTIVERSION int backward_full(const Model &om, const uint8_t *dsq, int L, c
   {
     const float *__restrict rf = om.rf(dsq[1]);
     const float *__restrict mn = bck.M_(1);
-    float bsum = 0.0f;
-    for (int k = 1; k <= M; ++k) bsum += (mn[k] * rf[k]) * bm[k];
-    xB = bsum;
+    for (int k = 1; k <= M; ++k) me[k] = mn[k] * rf[k];
+    xB = lanes_dot(om, me, bm);
     xN = (xB * om.xf[XN][MOVE]) + (xN * om.xf[XN][LOOP]);
     bck.X(0, xB_) = xB; bck.X(0, xC_) = 0.0f; bck.X(0, xJ_) = 0.0f; bck.X(0, xN_) = xN; bck.X(0, xE_) = 0.0f; bck.X(0, xS_) = 1.0f;
     float *mc = bck.M_(0), *ic = bck.I_(0), *dc = bck.D_(0);
@@ -425,18 +485,17 @@ P7X_MULTIVERSION void null2_by_expectation(const Model &om, Matrix &pp, float *n
   for (int k = 1; k <= M; ++k) { m0[k] *= norm; i0[k] *= norm; }
   eN *= norm; eC *= norm; eJ *= norm;
   const float xfactor = eN + eC + eJ;
-  const int Q = om.p->Q4();
+  const int C = om.C;
   for (int x = 0; x < om.p->K; ++x) {
     const float *rf = om.rf(x);
-    float lane[4] = {0, 0, 0, 0};                       // upstream's 4-lane striped accumulation order
-    for (int q = 0; q < Q; ++q)
-      for (int z = 0; z < 4; ++z) {
-        const int k = q + 1 + z * Q;
-        if (k > M) continue;
-        lane[z] = lane[z] + m0[k] * rf[k];
-        lane[z] = lane[z] + i0[k];
-      }
-    null2[x] = ((lane[0] + lane[1]) + (lane[2] + lane[3])) + xfactor;
+    float es[64];                                       // the envelope kernel's order: a lane's nodes, match then insert, then the tree
+    for (int z = 0; z < 64; ++z) {
+      const int k0 = z * C + 1, k1 = std::min(M, k0 + C - 1);
+      float e = 0.0f;
+      for (int k = k0; k <= k1; ++k) { e = e + m0[k] * rf[k]; e = e + i0[k]; }
+      es[z] = e;
+    }
+    null2[x] = lanes_sum(es) + xfactor;
   }
   finish_null2(*om.p, null2);
 }
@@ -517,30 +576,10 @@ P7X_MULTIVERSION void optimal_accuracy(const Model &om, const Matrix &pp, Matrix
       iv = vmax(iv, gate(tII[k], ip[k]));
       ic[k] = iv + pi[k];
     }
-    // D(i,k) = max( gate(tMD(k-1), M(i,k-1)), gate(tDD(k-1), D(i,k-1)) ): segment chains + carry fix-up
-    {
-      const int seglen = om.seglen;
-      for (int k = 1; k <= M; ++k) dc[k] = vmax(gate(tMD[k - 1], mc[k - 1]), (tDD[k - 1] > 0.0f) ? -INFINITY : 0.0f);
-      dc[1] = -INFINITY;
-      float cur[Model::kSeg];
-      for (int s = 0; s < Model::kSeg; ++s) cur[s] = -INFINITY;
-      for (int j = 0; j < seglen; ++j)
-        for (int s = 0; s < Model::kSeg; ++s) {
-          const int k = 1 + s * seglen + j;
-          if (k > M) continue;
-          const float v = (j == 0) ? dc[k] : vmax(dc[k], (tDD[k - 1] > 0.0f) ? cur[s] : -INFINITY);
-          cur[s] = v; dc[k] = v;
-        }
-      const float *__restrict pass = om.ddpass.data();
-      for (int s = 1; s < Model::kSeg; ++s) {
-        const int s0 = 1 + s * seglen;
-        if (s0 > M) break;
-        const int s1 = (M < s0 + seglen - 1) ? M : s0 + seglen - 1;
-        const float carry = dc[s0 - 1];
-        if (carry == -INFINITY) continue;
-        for (int k = s0; k <= s1; ++k) dc[k] = vmax(dc[k], carry + pass[k]);
-      }
-    }
+    // D(i,k) = max( gate(tMD(k-1), M(i,k-1)), gate(tDD(k-1), D(i,k-1)) ), D(i,1) = -inf.  Maxima are exact: any order of
+    // evaluation (the device's gated max-scan included) gives these values.
+    dc[1] = -INFINITY;
+    for (int k = 2; k <= M; ++k) dc[k] = vmax(gate(tMD[k - 1], mc[k - 1]), (tDD[k - 1] > 0.0f) ? dc[k - 1] : 0.0f);
     float xEmax = -INFINITY;
     {
       float a8[8]; for (int z = 0; z < 8; ++z) a8[z] = -INFINITY;

@@ -124,7 +124,7 @@ struct EnvForward {
 #pragma unroll unroll_env(C)
       for (int c = 0; c < C; ++c) { mm[c] *= inv; dm[c] *= inv; im[c] *= inv; }
       scale = xE;
-      totscale += (float) log((double) xE);
+      totscale = (float) ((double) totscale + log((double) xE));        // float += double, as upstream (and the host twin) has it
       xE = 1.0f;
     }
   }

@@ -167,13 +167,8 @@ static int lt_forward_parser(Model &om, const uint8_t *dsq, int L, std::vector<f
       mc[k] = sv * rf[k];
       ic[k] = mp[k] * tMI[k] + ip[k] * tII[k];
     }
-    dchain_forward(om, mc, dc);
-    float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    int k = 1;
-    for (; k + 7 <= M; k += 8) for (int z = 0; z < 8; ++z) acc[z] += mc[k + z] + dc[k + z];
-    for (; k <= M; ++k) acc[0] += mc[k] + dc[k];
+    xE = dchain_forward(om, mc, dc);
     mc[M + 1] = ic[M + 1] = dc[M + 1] = 0.0f;
-    xE = hsum8(acc);
     xN = xN * om.xf[XN][LOOP];
     xC = (xC * om.xf[XC][LOOP]) + (xE * om.xf[XE][MOVE]);
     xJ = (xJ * om.xf[XJ][LOOP]) + (xE * om.xf[XE][LOOP]);
@@ -230,13 +225,9 @@ static int lt_backward_parser(const Model &om, const uint8_t *dsq, int L, const 
   for (int r = L - 1; r >= 1; --r) {
     std::swap(mc, mn); std::swap(ic, in); std::swap(dc, dn);           // row r+1 becomes "next"
     const float *__restrict rf = om.rf(dsq[r + 1]);
-    float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     for (int k = 1; k <= M; ++k) me[k] = mn[k] * rf[k];
     me[M + 1] = 0.0f;
-    int kk = 1;
-    for (; kk + 7 <= M; kk += 8) for (int z = 0; z < 8; ++z) acc[z] += me[kk + z] * bm[kk + z];
-    for (; kk <= M; ++kk) acc[0] += me[kk] * bm[kk];
-    xB = hsum8(acc);
+    xB = lanes_dot(om, me, bm);
     xC = xC * om.xf[XC][LOOP];
     xJ = (xB * om.xf[XJ][MOVE]) + (xJ * om.xf[XJ][LOOP]);
     xN = (xB * om.xf[XN][MOVE]) + (xN * om.xf[XN][LOOP]);
@@ -264,9 +255,8 @@ static int lt_backward_parser(const Model &om, const uint8_t *dsq, int L, const 
   }
   {
     const float *__restrict rf = om.rf(dsq[1]);
-    float bsum = 0.0f;
-    for (int k = 1; k <= M; ++k) bsum += (mc[k] * rf[k]) * bm[k];
-    xB = bsum;
+    for (int k = 1; k <= M; ++k) me[k] = mc[k] * rf[k];
+    xB = lanes_dot(om, me, bm);
     xN = (xB * om.xf[XN][MOVE]) + (xN * om.xf[XN][LOOP]);
     X(0, xB_) = xB; X(0, xC_) = 0.0f; X(0, xJ_) = 0.0f; X(0, xN_) = xN; X(0, xE_) = 0.0f; X(0, xS_) = 1.0f;
   }

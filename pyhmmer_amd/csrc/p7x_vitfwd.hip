@@ -459,7 +459,7 @@ __global__ void __launch_bounds__(kWsBlock) fwd_kernel(const ArgRef ref)
 #pragma unroll unroll_c(C)
         for (int c = 0; c < C; ++c) { mm[c] *= inv; dm[c] *= inv; im[c] *= inv; }
         scale = xE;
-        totscale += (float) log((double) xE);
+        totscale = (float) ((double) totscale + log((double) xE));
         xE = 1.0f;
       }
       if (xo && lane == 0) {
@@ -622,7 +622,7 @@ __global__ void __launch_bounds__(kWsBlock) bck_kernel(const ArgRef ref)
         const float inv = (float) (1.0 / (double) sc);
 #pragma unroll unroll_c(C)
         for (int c = 0; c < C; ++c) { mm[c] *= inv; dm[c] *= inv; im[c] *= inv; }
-        totscale += (float) log((double) sc);
+        totscale = (float) ((double) totscale + log((double) sc));
       }
       if (lane == 0) { float *r = xo + (size_t) i * 6; r[0] = xE; r[1] = xN; r[2] = xJ; r[3] = xB; r[4] = xC; r[5] = sc; }
     }
