@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define P7X_ABI_VERSION 6
+#define P7X_ABI_VERSION 7
 
 enum {
   P7X_OK = 0, P7X_EMEM = 5, P7X_EFORMAT = 7, P7X_EINVAL = 11, P7X_ERANGE = 16, P7X_ENORESULT = 19,
@@ -198,6 +198,11 @@ typedef struct p7x_pipeline_cfg {
                               * has the same contents (a token of the packed image, not of its address).  The device copy is then kept
                               * after the call and a later search with the same key and size does not upload the targets again (one
                               * copy per device; a new key replaces it).  0 (default): upload per call, nothing kept */
+  int32_t host_ensembles;    /* 0 (default): the stochastic traceback ensembles of multi-domain regions (p7_domaindef.c
+                              * region_trace_ensemble: 200 sampled tracebacks per region, p7_Null2_ByTrace of every sampled domain) run
+                              * on the device and the clustered envelopes are rescored there in a second round; 1: on the host
+                              * workers.  Identical results (one generator stream per region, the same choices: p7x_choice.hpp).
+                              * Without re-seeding (seed 0) the regions of a search share one stream and the host samples them. */
 } p7x_pipeline_cfg;
 enum { P7X_STRAND_BOTH = 0, P7X_STRAND_TOPONLY = 1, P7X_STRAND_BOTTOMONLY = 2 };
 void p7x_pipeline_cfg_default(p7x_pipeline_cfg *cfg);   /* p7_pipeline_Create(NULL,...) defaults, plan7.pyx:5413-5421 */
@@ -276,6 +281,17 @@ size_t p7x_pending_nqueries(const p7x_pending *pending);
  * residue (a table + series evaluation in double; claimed to round to the same float as the C library's logarithm, which
  * is what the reference's esl_hmm_Forward calls: tests/test_gpu_filters.py checks every float of [2^-7, 2^7)). */
 int  p7x_debug_log_of_float(int device, const float *in, float *out, size_t n);
+/* Test seams of the stochastic traceback ensembles (p7_domaindef.c region_trace_ensemble; p7_domaindef.pxd:23-59).
+ * p7x_debug_choice: one choice point of p7_StochasticTrace with n paths of weights p[], for the generator state x after the
+ *   draw: the path taken through the integer thresholds the product uses and through esl_rnd_FChoose as the reference
+ *   writes it (they must agree for every p and x).
+ * p7x_debug_ensemble: the 200 sampled tracebacks of region i..j (1-based) of one target of a resident block, on the device
+ *   (use_device != 0) or by the host twin: dom[ndom][5] = sample, first / last residue inside the region, first / last
+ *   node, a sample's domains first to last; n2[pos], pos = 1..j-i+1: the summed null2 odds ratios of the residue;
+ *   status 0 = sampled. */
+int  p7x_debug_choice(const float *p, int n, uint32_t x, int *via_thresholds, int *via_fchoose);
+int  p7x_debug_ensemble(const p7x_oprofile *om, const p7x_seqdb *db, int64_t target, int32_t i, int32_t j, uint32_t seed,
+                        int use_device, int32_t *ndom, int32_t *dom, int32_t dom_cap, float *n2, int32_t *status);
 /* Parity seam of the batched cascade (the multi-profile twin of p7x_filters_batch): runs stage 1 exactly as
  * p7x_search_batch_enqueue queues it -- profiles grouped into kernel classes, the hybrid lane / wave MSV split, the work
  * lists -- and returns what the stages left behind, [nq][ntargets] in caller order of both: xJ (every target; -1

@@ -17,7 +17,7 @@ _ROOT = _PKG.parent
 CSRC = _PKG / "csrc"
 LIB_PATH = _PKG / "libp7x.so"
 
-SOURCES = ["p7x_profile.cpp", "p7x_device.hip", "p7x_devimage.hip", "p7x_msv.hip", "p7x_vitfwd.hip", "p7x_vitpk.hip", "p7x_envelope.hip", "p7x_ssvlong.hip", "p7x_longtarget.hip",
+SOURCES = ["p7x_profile.cpp", "p7x_device.hip", "p7x_devimage.hip", "p7x_msv.hip", "p7x_vitfwd.hip", "p7x_vitpk.hip", "p7x_envelope.hip", "p7x_ensemble.hip", "p7x_ssvlong.hip", "p7x_longtarget.hip",
            "p7x_envscore.hip", "p7x_pipeline.hip", "p7x_domaindef.cpp", "p7x_tophits.cpp"]
 
 
@@ -109,6 +109,7 @@ class PipelineCfg(C.Structure):
         ("block_length", C.c_int32), ("window_length", C.c_int32), ("evalue_window_length", C.c_int32), ("lt_part", C.c_int32), ("lt_nparts", C.c_int32), ("oa_guard", C.c_float),
         ("f3_guard", C.c_float),
         ("lt_resident_key", C.c_uint64),
+        ("host_ensembles", C.c_int32),
     ]
 
 
@@ -201,6 +202,8 @@ _SIGNATURES = {
     "p7x_search_batch_finish": (C.c_int, [_VP, _VP, _VP, _VP, C.POINTER(_VP)]),
     "p7x_pending_nqueries": (C.c_size_t, [_VP]),
     "p7x_debug_log_of_float": (C.c_int, [C.c_int, _VP, _VP, C.c_size_t]),
+    "p7x_debug_choice": (C.c_int, [_VP, C.c_int, C.c_uint32, _VP, _VP]),
+    "p7x_debug_ensemble": (C.c_int, [_VP, _VP, C.c_int64, C.c_int32, C.c_int32, C.c_uint32, C.c_int, _VP, _VP, C.c_int32, _VP, _VP]),
     "p7x_search_batch_raw": (C.c_int, [C.POINTER(PipelineCfg), C.POINTER(_VP), C.c_size_t, _VP, _VP, _VP, _VP, _VP]),
     "p7x_search_longtargets": (C.c_int, [C.POINTER(PipelineCfg), _VP, C.c_int, _VP, _VP, _VP, C.c_size_t, _VP, _VP, _VP, C.POINTER(_VP)]),
     "p7x_ssv_longtarget_seeds": (C.c_int64, [C.POINTER(PipelineCfg), _VP, C.c_int, _VP, C.c_int64, C.c_int, _VP, C.c_size_t]),
@@ -234,7 +237,7 @@ def lib() -> C.CDLL:
             fn = getattr(l, name)      # AttributeError if the ABI is incomplete
             fn.restype = res
             fn.argtypes = args
-        if l.p7x_abi_version() != 6:
+        if l.p7x_abi_version() != 7:
             raise ImportError("libp7x ABI version mismatch; rebuild")
         _lib = l
     return _lib

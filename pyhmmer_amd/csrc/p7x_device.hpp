@@ -90,6 +90,7 @@ void free_dev_profile(DevProfile *d);
 
 // host driver of the envelope kernel (p7x_envscore.hip), behind the EnvelopeScorer interface of p7x_host.hpp
 struct EnvelopeScorer;
+struct EnsembleRunner;
 }
 struct p7x_seqdb;
 #include <memory>
@@ -97,6 +98,7 @@ namespace p7x {
 struct LongTargetWindowRegions;
 int device_regions_of_all(const p7x_oprofile *om, const p7x_seqdb *db, std::vector<LongTargetWindowRegions> &out);
 std::unique_ptr<EnvelopeScorer> make_device_envelope_scorer(DeviceCtx *ctx, const p7x_seqdb *db, float oa_guard);
+std::unique_ptr<EnsembleRunner> make_device_ensemble_runner(DeviceCtx *ctx, const p7x_seqdb *db);
 
 } // namespace p7x
 

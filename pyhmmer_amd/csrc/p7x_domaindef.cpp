@@ -13,6 +13,7 @@
 // the striped SSE code visits cells (tie-breaks in the OA traceback, cumulative sums in the stochastic
 // traceback) that visiting order is reproduced.  Runs only for ~1e-5 of random targets plus true homologs.
 #include "p7x_host.hpp"
+#include "p7x_choice.hpp"
 #include <algorithm>
 #include <atomic>
 #include <cctype>
@@ -67,7 +68,8 @@ struct FastRng {
   }
   // esl_randomness_Init for the LCG type: the seed is dispersed with Jenkins' mix3, never zero
   void init(uint32_t s) { seed = s; x = mix3(s, 87654321u, 12345678u); if (x == 0) x = 42; }
-  double next() { x = x * 69069u + 1u; return (double) x / 4294967296.0; }
+  uint32_t next_u32() { x = lcg_next(x); return x; }
+  double next() { return (double) next_u32() / 4294967296.0; }
 };
 
 // esl_vec_FSum (Kahan).  Same arithmetic as kahan_fsum(); this translation unit is compiled without fast-math and
@@ -84,16 +86,6 @@ void fnorm(float *v, int n)
   if (s != 0.0f) for (int i = 0; i < n; ++i) v[i] /= s;
   else           for (int i = 0; i < n; ++i) v[i] = 1. / (float) n;
 }
-int fchoose(FastRng &r, const float *p, int n)
-{ // esl_rnd_FChoose: cumulative sum in double against one uniform deviate
-  const double roll = r.next();
-  const double norm = fsum(p, n);
-  double sum = 0.0;
-  for (int i = 0; i < n; ++i) { sum += p[i]; if (roll < sum / norm) return i; }
-  for (int i = n - 1; i >= 0; --i) if (p[i] > 0.0f) return i;
-  return 0;
-}
-
 // ---------------------------------------------------------------- the wavefront's combining trees, lane by lane
 // Host restatement of p7x_wave.hpp (affine_scan_up / affine_scan_down / wave_sum_f32): the same operations on the same
 // operands in the same order, so that a sum formed here and on the device is the same float.  A DPP step whose source
@@ -691,6 +683,8 @@ int oa_trace(const Model &om, const Matrix &pp, const Matrix &ox, Trace &tr)
 }
 
 // ---------------------------------------------------------------- p7_StochasticTrace
+// The choices are made through p7x_choice.hpp (integer thresholds against the generator's 32-bit state -- the reference's
+// floating-point test restated exactly, see there): the same functions the device fills its choice records with.
 int stochastic_trace(FastRng &rng, const Model &om, const Matrix &fx, int L, Trace &tr)
 {
   const int M = om.M, Q = om.p->Q4();
@@ -700,43 +694,41 @@ int stochastic_trace(FastRng &rng, const Model &om, const Matrix &fx, int L, Tra
   tr.append(sT, k, i, 0.0f);
   tr.append(sC, k, i, 0.0f);
   int s0 = sC;
+  auto pair = [&](float a, float b) -> int {
+    uint32_t T, bits;
+    choice_pair(a, b, &T, &bits);
+    return choice_pick_pair(T, bits, rng.next_u32());
+  };
   while (s0 != sS) {
     int s1 = -1;
     switch (s0) {
       case sM: {
-        float path[4];
-        path[0] = fx.X(i - 1, xB_) * bm[k];
-        path[1] = fx.M_(i - 1)[k - 1] * tMM[k];
-        path[2] = fx.I_(i - 1)[k - 1] * tIM[k];
-        path[3] = fx.D_(i - 1)[k - 1] * tDM[k];
-        fnorm(path, 4);
+        if (i < 1 || k < 1) return P7X_EINVAL;
+        uint32_t c4[4];
+        choice_cell_m(fx.X(i - 1, xB_) * bm[k], fx.M_(i - 1)[k - 1] * tMM[k], fx.I_(i - 1)[k - 1] * tIM[k], fx.D_(i - 1)[k - 1] * tDM[k], c4);
         static const int state[4] = { sB, sM, sI, sD };
-        s1 = state[fchoose(rng, path, 4)]; k--; i--;
+        s1 = state[choice_pick_m(c4, rng.next_u32())]; k--; i--;
         break;
       }
       case sD: {
-        float path[2] = { fx.M_(i)[k - 1] * tMD[k - 1], fx.D_(i)[k - 1] * tDD[k - 1] };
-        fnorm(path, 2);
-        s1 = fchoose(rng, path, 2) == 0 ? sM : sD; k--;
+        if (i < 1 || k < 1) return P7X_EINVAL;
+        s1 = pair(fx.M_(i)[k - 1] * tMD[k - 1], fx.D_(i)[k - 1] * tDD[k - 1]) == 0 ? sM : sD; k--;
         break;
       }
       case sI: {
-        float path[2] = { fx.M_(i - 1)[k] * tMI[k], fx.I_(i - 1)[k] * tII[k] };
-        fnorm(path, 2);
-        s1 = fchoose(rng, path, 2) == 0 ? sM : sI; i--;
+        if (i < 1 || k < 1) return P7X_EINVAL;
+        s1 = pair(fx.M_(i - 1)[k] * tMI[k], fx.I_(i - 1)[k] * tII[k]) == 0 ? sM : sI; i--;
         break;
       }
       case sN: s1 = (i == 0) ? sS : sN; break;
       case sC: {
-        float path[2] = { fx.X(i - 1, xC_) * om.xf[XC][LOOP], fx.X(i, xE_) * om.xf[XE][MOVE] * fx.X(i, xS_) };
-        fnorm(path, 2);
-        s1 = fchoose(rng, path, 2) == 0 ? sC : sE;
+        if (i < 1) return P7X_EINVAL;
+        s1 = pair(fx.X(i - 1, xC_) * om.xf[XC][LOOP], fx.X(i, xE_) * om.xf[XE][MOVE] * fx.X(i, xS_)) == 0 ? sC : sE;
         break;
       }
       case sJ: {
-        float path[2] = { fx.X(i - 1, xJ_) * om.xf[XJ][LOOP], fx.X(i, xE_) * om.xf[XE][LOOP] * fx.X(i, xS_) };
-        fnorm(path, 2);
-        s1 = fchoose(rng, path, 2) == 0 ? sJ : sE;
+        if (i < 1) return P7X_EINVAL;
+        s1 = pair(fx.X(i - 1, xJ_) * om.xf[XJ][LOOP], fx.X(i, xE_) * om.xf[XE][LOOP] * fx.X(i, xS_)) == 0 ? sJ : sE;
         break;
       }
       case sE: {
@@ -756,9 +748,7 @@ int stochastic_trace(FastRng &rng, const Model &om, const Matrix &fx, int L, Tra
         break;
       }
       case sB: {
-        float path[2] = { fx.X(i, xN_) * om.xf[XN][MOVE], fx.X(i, xJ_) * om.xf[XJ][MOVE] };
-        fnorm(path, 2);
-        s1 = fchoose(rng, path, 2) == 0 ? sN : sJ;
+        s1 = pair(fx.X(i, xN_) * om.xf[XN][MOVE], fx.X(i, xJ_) * om.xf[XJ][MOVE]) == 0 ? sN : sJ;
         break;
       }
       default: return P7X_EINVAL;
@@ -1110,7 +1100,7 @@ static thread_local const LongTargetOpts *t_long_target = nullptr;     // set by
 
 int domaindef_multi_region(const Profile &p, const uint8_t *dsq, int L, int i, int j, uint32_t seed, bool do_reseeding,
                            MultiRegionState &state, DomainDefResult &dd, std::vector<Domain> &out,
-                           std::vector<EnvelopeRequest> *defer2, int item)
+                           std::vector<EnvelopeRequest> *defer2, int item, const EnsembleResult *ens)
 {
   const int nsamples = 200;                                                  // p7_domaindef.pxd:43-48
   const float min_overlap = 0.8f, min_posterior = 0.25f, min_endpointp = 0.02f;
@@ -1119,32 +1109,54 @@ int domaindef_multi_region(const Profile &p, const uint8_t *dsq, int L, int i, i
   Model om{ &p, p.M, {} };
   om.lt = t_long_target;
   om.prepare();
-  om.prepare_rfT();
-  ws.wm.resize(p.M + 2); ws.wi.resize(p.M + 2);
-  FastRng rng; rng.seed = state.rng_seed; rng.x = state.rng_x;
-  if (!state.started) { rng.init(seed); state.started = true; }
-  dd.nclustered++;
-  om.configure(true, L);
-  { ProfScope ps(1); forward_full(om, dsq + i - 1, j - i + 1, ws.fwd, nullptr); }
   const int Lr = j - i + 1;
-  for (int pos = i; pos <= j; ++pos) dd.n2sc[pos] = 0.0f;
-  if (do_reseeding) rng.init(seed);
   std::vector<SpCoord> sp;
-  float null2[MAXKP];
-  for (int t = 0; t < nsamples; ++t) {
-    { ProfScope ps(2); if (stochastic_trace(rng, om, ws.fwd, Lr, ws.tr) != P7X_OK) return P7X_EINVAL; }
-    ws.tr.index();
-    int pos = 1;
-    for (int d = 0; d < ws.tr.ndom; ++d) {
-      sp.push_back(SpCoord{ t, ws.tr.sqfrom[d] + i - 1, ws.tr.sqto[d] + i - 1, ws.tr.hmmfrom[d], ws.tr.hmmto[d], 0.0f });
-      { ProfScope ps(3); null2_by_trace(om, ws.tr, ws.tr.tfrom[d], ws.tr.tto[d], ws.wm.data(), ws.wi.data(), null2); }
-      for (; pos <= ws.tr.sqfrom[d]; ++pos) dd.n2sc[i + pos - 1] += 1.0f;   // sic: the first domain residue counts as "outside"
-      for (; pos <= ws.tr.sqto[d]; ++pos) dd.n2sc[i + pos - 1] += null2[dsq[i + pos - 1]];
+  dd.nclustered++;
+  if (ens && ens->status == 0 && do_reseeding && !om.lt) {
+    // the ensemble was sampled on the device (p7x_ensemble.hip): end points and null2 sums are in; a sample's domains come
+    // in traceback order and go into the list first domain first, as p7_trace_Index numbers them
+    sp.reserve((size_t) ens->ndom);
+    for (int a = 0; a < ens->ndom; ) {
+      int b = a;
+      while (b < ens->ndom && ens->dom[(size_t) b * 5] == ens->dom[(size_t) a * 5]) ++b;
+      for (int d = b - 1; d >= a; --d) {
+        const int32_t *o = ens->dom + (size_t) d * 5;
+        sp.push_back(SpCoord{ o[0], o[1] + i - 1, o[2] + i - 1, o[3], o[4], 0.0f });
+      }
+      a = b;
     }
-    for (; pos <= Lr; ++pos) dd.n2sc[i + pos - 1] += 1.0f;
+    for (int pos = 1; pos <= Lr; ++pos) dd.n2sc[i + pos - 1] = logf(ens->n2[pos] / (float) nsamples);
+  } else {
+    om.prepare_rfT();
+    ws.wm.resize(p.M + 2); ws.wi.resize(p.M + 2);
+    FastRng rng; rng.seed = state.rng_seed; rng.x = state.rng_x;
+    if (!state.started) { rng.init(seed); state.started = true; }
+    om.configure(true, L);
+    { ProfScope ps(1); forward_full(om, dsq + i - 1, j - i + 1, ws.fwd, nullptr); }
+    for (int pos = i; pos <= j; ++pos) dd.n2sc[pos] = 0.0f;
+    if (do_reseeding) rng.init(seed);
+    float null2[MAXKP];
+    for (int t = 0; t < nsamples; ++t) {
+      { ProfScope ps(2); if (stochastic_trace(rng, om, ws.fwd, Lr, ws.tr) != P7X_OK) return P7X_EINVAL; }
+      ws.tr.index();
+      int pos = 1;
+      for (int d = 0; d < ws.tr.ndom; ++d) {
+        sp.push_back(SpCoord{ t, ws.tr.sqfrom[d] + i - 1, ws.tr.sqto[d] + i - 1, ws.tr.hmmfrom[d], ws.tr.hmmto[d], 0.0f });
+        { ProfScope ps(3); null2_by_trace(om, ws.tr, ws.tr.tfrom[d], ws.tr.tto[d], ws.wm.data(), ws.wi.data(), null2); }
+        for (; pos <= ws.tr.sqfrom[d]; ++pos) dd.n2sc[i + pos - 1] += 1.0f;   // sic: the first domain residue counts as "outside"
+        for (; pos <= ws.tr.sqto[d]; ++pos) dd.n2sc[i + pos - 1] += null2[dsq[i + pos - 1]];
+      }
+      for (; pos <= Lr; ++pos) dd.n2sc[i + pos - 1] += 1.0f;
+    }
+    state.rng_seed = rng.seed; state.rng_x = rng.x;
+    if (ens && ens->raw_out) {            // test seam: the ensemble as sampled, before the logarithm and the clustering
+      ens->raw_out->dom.clear();
+      for (const SpCoord &c : sp) { ens->raw_out->dom.push_back(c.idx); ens->raw_out->dom.push_back(c.i - i + 1); ens->raw_out->dom.push_back(c.j - i + 1); ens->raw_out->dom.push_back(c.k); ens->raw_out->dom.push_back(c.m); }
+      ens->raw_out->n2.assign((size_t) Lr + 1, 0.0f);
+      for (int pos = 1; pos <= Lr; ++pos) ens->raw_out->n2[(size_t) pos] = dd.n2sc[i + pos - 1];
+    }
+    for (int pos = i; pos <= j; ++pos) dd.n2sc[pos] = logf(dd.n2sc[pos] / (float) nsamples);
   }
-  state.rng_seed = rng.seed; state.rng_x = rng.x;
-  for (int pos = i; pos <= j; ++pos) dd.n2sc[pos] = logf(dd.n2sc[pos] / (float) nsamples);
   std::vector<SpCoord> sigc;
   { ProfScope ps(4); sp_cluster(sp, nsamples, min_overlap, of_smaller, max_diagdiff, min_posterior, min_endpointp, sigc); }
   // remove envelopes dominated (>= 80% overlap of the smaller) by a more probable one
@@ -1244,17 +1256,21 @@ static int dispatch_regions(const Profile &p, const uint8_t *dsq, int L, const R
 
 // The multi-domain regions left behind by the deferring call above, in order.
 int domaindef_finish_multi(const Profile &p, const uint8_t *dsq, int L, uint32_t seed, bool do_reseeding, DomainDefResult &dd,
-                           std::vector<EnvelopeRequest> *defer2, int item)
+                           std::vector<EnvelopeRequest> *defer2, int item, const EnsembleResult *const *ens)
 {
   MultiRegionState state;
+  int nth = 0;
   for (Domain &d : dd.dcl) {
     if (d.deferred != -2) continue;
     const int st = domaindef_multi_region(p, dsq, L, (int) d.ienv, (int) d.jenv, seed, do_reseeding, state, dd, dd.multi[(size_t) d.multi_slot],
-                                          defer2, item);
+                                          defer2, item, ens ? ens[nth] : nullptr);
+    ++nth;
     if (st != P7X_OK) return st;
   }
   return P7X_OK;
 }
+
+uint32_t fast_rng_state(uint32_t seed) { FastRng r; r.init(seed); return r.x; }
 
 // Second half of rescore_isolated_domain() for envelopes rescored by the device kernel: trace -> alignment
 // display, null2 odds -> per-residue corrections.  req_index[n] is the position in <res> of local request n
@@ -1328,5 +1344,28 @@ int domaindef_finish_deferred(const Profile &p, const uint8_t *dsq, int L, const
 }
 
 } // namespace p7x
+
+// Test seam: one choice point through the integer thresholds of p7x_choice.hpp and through esl_rnd_FChoose as the
+// reference writes it (floating-point test against roll = x / 2^32); x is the generator's state AFTER the draw.
+extern "C" int p7x_debug_choice(const float *p, int n, uint32_t x, int *via_thresholds, int *via_fchoose)
+{
+  using namespace p7x;
+  if (!p || n < 2 || n > 4 || !via_thresholds || !via_fchoose) return P7X_EINVAL;
+  float a[4], b[4];
+  for (int i = 0; i < n; ++i) a[i] = b[i] = p[i];
+  uint32_t T[3] = { 0, 0, 0 }, sat = 0, fb = 0;
+  choice_thresholds(a, n, T, &sat, &fb);
+  *via_thresholds = choice_pick(T, sat, fb, n, x);
+  fnorm(b, n);
+  FastRng r; r.x = x;
+  const double roll = (double) x / 4294967296.0;
+  const double norm = fsum(b, n);
+  double sum = 0.0;
+  int pick = -1;
+  for (int i = 0; i < n && pick < 0; ++i) { sum += b[i]; if (roll < sum / norm) pick = i; }
+  if (pick < 0) { pick = 0; for (int i = n - 1; i >= 0; --i) if (b[i] > 0.0f) { pick = i; break; } }
+  *via_fchoose = pick;
+  return P7X_OK;
+}
 
 #include "p7x_longtarget.inc.hpp"

@@ -19,6 +19,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include "p7x_wave.hpp"
+#include "p7x_envfwd.hpp"
 
 namespace p7x {
 
@@ -27,12 +28,6 @@ namespace {
 
 
 constexpr float kNegInf = -__builtin_inff();
-
-// node loops of the envelope kernel: unrolled (row state in registers) up to this many nodes per lane, rolled beyond
-#ifndef P7X_ENV_UNROLL_MAX
-#define P7X_ENV_UNROLL_MAX 32
-#endif
-constexpr int unroll_env(int C) { return C <= P7X_ENV_UNROLL_MAX ? C : 1; }
 
 // p7T_* state codes (p7_trace.pxd), as the host uses them
 enum { tM = 1, tD = 2, tI = 3, tS = 4, tN = 5, tB = 6, tE = 7, tC = 8, tT = 9, tJ = 10 };
@@ -64,72 +59,6 @@ __device__ unsigned long long g_env_prof[8];
 
 // One block per CU: its wavefronts (env_waves(C): 8, or 4 for models of more than 448 nodes) share one copy of the
 // profile tables in LDS and each walks its own envelopes.
-// One row of the unihit Forward recurrence on the envelope, state in registers.  Phase 1 runs it for the envelope score
-// and the per-row scale factors; phase 3 runs it AGAIN next to the decoding (same code, same operations in the same order:
-// bit-identical values), which is what lets the kernel park only Backward's rows in HBM.
-template <int C>
-struct EnvForward {
-  float mm[C], im[C], dm[C];
-  float ddprod;
-  float xN, xB, xJ, xC, xE, scale, totscale;
-  __device__ __forceinline__ void init(const float4 *tr, int lane, float pmove)
-  {
-#pragma unroll unroll_env(C)
-    for (int c = 0; c < C; ++c) mm[c] = im[c] = dm[c] = 0.0f;
-    ddprod = 1.0f;
-#pragma unroll unroll_env(C)
-    for (int c = 0; c < C; ++c) ddprod *= tr[2 * (c * 64 + lane) + 1].w;
-    xN = 1.0f; xB = pmove; xJ = 0.0f; xC = 0.0f; xE = 0.0f; scale = 1.0f; totscale = 0.0f;
-  }
-  __device__ __forceinline__ void row(const float4 *tr, const float *em, int Mpad, int lane, int x, float pmove, float ploop,
-                                      float xf_e_move, float xf_e_loop)
-  {
-    const float *er = em + x * Mpad + lane;
-    float mp = dpp_shr1f(mm[C - 1], 0.0f), ip = dpp_shr1f(im[C - 1], 0.0f), dp = dpp_shr1f(dm[C - 1], 0.0f);
-    float esum = 0.0f;
-    float t_dd[C], t_md[C];
-#pragma unroll unroll_env(C)
-    for (int c = 0; c < C; ++c) {
-      const F8 t = load_f8(tr, c * 64 + lane);
-      float sv = xB * t.bm;
-      sv = sv + mp * t.mm;
-      sv = sv + ip * t.im;
-      sv = sv + dp * t.dm;
-      sv = sv * er[c * 64];
-      esum = esum + sv;
-      mp = mm[c]; ip = im[c]; dp = dm[c];
-      im[c] = mp * t.mi + ip * t.ii;
-      mm[c] = sv;
-      t_dd[c] = t.dd; t_md[c] = t.md;
-    }
-    float A = 0.0f;
-#pragma unroll unroll_env(C)
-    for (int c = 0; c < C; ++c) { dm[c] = A; A = mm[c] * t_md[c] + A * t_dd[c]; }
-    float sa = A, sp = ddprod;
-    affine_scan_up(sa, sp);
-    {
-      float w = dpp_shr1f(sa, 0.0f);
-#pragma unroll unroll_env(C)
-      for (int c = 0; c < C; ++c) { dm[c] = dm[c] + w; esum = esum + dm[c]; w = w * t_dd[c]; }
-    }
-    xE = wave_sum_f32(esum);
-    xN = xN * ploop;
-    xC = (xC * ploop) + (xE * xf_e_move);
-    xJ = (xJ * ploop) + (xE * xf_e_loop);
-    xB = (xJ * pmove) + (xN * pmove);
-    scale = 1.0f;
-    if (xE > 1.0e4f) {
-      xN = xN / xE; xC = xC / xE; xJ = xJ / xE; xB = xB / xE;
-      const float inv = (float) (1.0 / (double) xE);
-#pragma unroll unroll_env(C)
-      for (int c = 0; c < C; ++c) { mm[c] *= inv; dm[c] *= inv; im[c] *= inv; }
-      scale = xE;
-      totscale = (float) ((double) totscale + log((double) xE));        // float += double, as upstream (and the host twin) has it
-      xE = 1.0f;
-    }
-  }
-};
-
 // posterior probability -> the digit of the alignment's posterior line, exactly as the host prints it
 // (p7_alidisplay: (p + 0.05 >= 1.0) ? '*' : '0' + (int) ((p + 0.05) * 10.0), in double): 0..9, 10 = '*'
 __device__ __forceinline__ unsigned pp_code(float p)

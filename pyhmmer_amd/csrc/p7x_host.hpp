@@ -59,6 +59,26 @@ struct EnvelopeScorer {
   virtual int wait(std::vector<std::vector<EnvelopeResult>> &res) = 0;
 };
 
+// The stochastic traceback ensembles of multi-domain regions can be handed to the device as well (p7x_ensemble.hip): a
+// request is region i..j of survivor <item> (EnvelopeRequest), the answer the sampled domains' end points and the
+// per-residue sums of their null2 odds; clustering and everything after it stays with the host stage.
+struct EnsembleRaw { std::vector<int32_t> dom; std::vector<float> n2; };      // test seam: a host-sampled ensemble in the device's format
+struct EnsembleResult {
+  int status = -1;                      // 0: done; anything else: the host resolves the region itself
+  int ndom = 0;                         // sampled domains, all samples together
+  const int32_t *dom = nullptr;         // [ndom][5] sample, sqfrom, sqto (1-based inside the region), hmmfrom, hmmto; the domains
+                                        // of a sample in traceback order (last domain first)
+  const float *n2 = nullptr;            // [Lr + 1] n2[pos]: sum over the samples of the odds ratio of region residue pos
+  EnsembleRaw *raw_out = nullptr;       // test seam (status != 0): the host's own ensemble of the region is written here, domains first to last
+};
+struct EnsembleRunner {
+  virtual ~EnsembleRunner() = default;
+  // seed_state: the generator's state after esl_randomness_Init (every region starts there: do_reseeding)
+  virtual int begin(const std::vector<EnvelopeJob> &jobs, uint32_t seed_state, int nsamples) = 0;
+  virtual int wait(std::vector<std::vector<EnsembleResult>> &res) = 0;
+};
+uint32_t fast_rng_state(uint32_t seed);          // esl_randomness_Init for the LCG
+
 // p7_domaindef_ByPosteriorHeuristics (p7_domaindef.pxd:69-72).  dsq is 1-indexed (dsq[1..L]);
 // fwd_xmx / bck_xmx are the parsers' special-state rows, (L+1) x [E,N,J,B,C,SCALE].
 struct Region { int i, j; bool multi; };
@@ -72,9 +92,11 @@ int domaindef_regions(const Profile &p, int L, const float *fwd_xmx, const float
 // rescored on the host; their placeholders carry Domain::deferred2 and are completed by domaindef_finish_deferred().
 int domaindef_multi_region(const Profile &p, const uint8_t *dsq, int L, int i, int j, uint32_t seed, bool do_reseeding,
                            MultiRegionState &state, DomainDefResult &dd, std::vector<Domain> &out,
-                           std::vector<EnvelopeRequest> *defer2 = nullptr, int item = 0);
+                           std::vector<EnvelopeRequest> *defer2 = nullptr, int item = 0, const EnsembleResult *ens = nullptr);
+// <ens>: the device's ensembles of this target's multi-domain regions, in order (nullptr, or an entry with status != 0: the
+// host samples the region itself)
 int domaindef_finish_multi(const Profile &p, const uint8_t *dsq, int L, uint32_t seed, bool do_reseeding, DomainDefResult &dd,
-                           std::vector<EnvelopeRequest> *defer2 = nullptr, int item = 0);
+                           std::vector<EnvelopeRequest> *defer2 = nullptr, int item = 0, const EnsembleResult *const *ens = nullptr);
 
 // With <defer> the single-domain regions are queued there (tagged <item>) instead of being rescored on the host;
 // domaindef_finish_deferred() completes them from the device results (res[d.deferred] for placeholder d).
@@ -128,7 +150,8 @@ struct FinishItem {
 };
 int host_finish_batch(const p7x_pipeline_cfg &cfg, const std::vector<FinishItem> &items, const HostTargets &tg,
                       const char *const *names, const char *const *accs, const char *const *descs,
-                      p7x_tophits **outs, EnvelopeScorer *scorer = nullptr, EnvelopeScorer *scorer2 = nullptr);
+                      p7x_tophits **outs, EnvelopeScorer *scorer = nullptr, EnvelopeScorer *scorer2 = nullptr,
+                      EnsembleRunner *ensembles = nullptr);
 void tophits_set_total_ms(p7x_tophits *th, double stage1_ms, double stage2_ms);
 void tophits_sort_by_key(p7x_tophits &th);
 void tophits_threshold(p7x_tophits &th);

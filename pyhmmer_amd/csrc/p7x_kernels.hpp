@@ -161,6 +161,38 @@ int env_max_blocks(int C, int nrows, int num_cu, int *nblocks);
 // every record of the run has the same C and nrows; grid.x = the widest job's nblocks
 int env_launch(const ArgRun<EnvArgs> &a, hipStream_t st);
 
+// ---- stochastic traceback ensembles of multi-domain regions (p7x_ensemble.hip; upstream p7_domaindef.c
+// region_trace_ensemble): a multihit Forward fill of the region that leaves, per cell and per row, the integer
+// thresholds of every choice a stochastic traceback can face there (p7x_choice.hpp), then one wavefront per region that
+// walks the region's tracebacks through those records, consuming the region's single generator stream.
+struct ChoiceCell; struct ChoiceRow;
+struct EnsRegion {          // one multi-domain region, as both kernels see it
+  int64_t sq;               // offset in dsq of the region's first residue
+  int64_t cell0;            // first cell record: (Lr + 1) rows of M + 1 cells, row-major, node-minor (node 0 unused)
+  int64_t row0;             // first row record; rows 0 .. Lr.  The null2 accumulators use the same offsets
+  int64_t dom0;             // first domain record of the region's output
+  int32_t Lr, L;            // region length; full target length (the length model)
+  int32_t job, pad;
+};
+struct EnsJob {             // per query profile
+  int M, C, K, Kp, nrows, Q;          // Q = p7O_NQF(M): select_e walks the reference's striped order
+  const void *trans, *emis;           // Forward tables of the device image
+  const float *rft;                   // [M + 1][32] match odds, residue-minor (p7_Null2_ByTrace)
+  const uint8_t *degen;               // [32][32] degeneracy matrix of the alphabet (esl_abc_FAvgScVec)
+  int reg_first, nreg;                // the job's regions in EnsArgs::regions
+};
+struct EnsArgs {
+  const EnsJob *jobs; const EnsRegion *regions; int nregions;
+  const uint8_t *dsq;
+  ChoiceCell *cells; float2 *md; ChoiceRow *rows;      // md: Forward's M and D cell (select_e)
+  uint32_t seed_x;          // the generator's state after esl_randomness_Init(seed): every region starts there
+  int nsamples;
+  float *n2acc;             // [rows] per residue: sum over the samples of the null2 odds ratio (1 outside domains)
+  int32_t *dom; int dom_cap;   // [5] per domain: sample, sqfrom, sqto (1-based inside the region), hmmfrom, hmmto; dom_cap per region
+  int32_t *out_ndom; int32_t *out_status;               // per region
+  int n2_lds_cap;           // regions up to this length keep their accumulators in LDS
+};
+
 // ---- long-target SSV scan (p7x_ssvlong.hip): one chunk of one strand per wavefront, model split across the lanes
 struct SsvLongArgs {
   const uint32_t *tab4;       // [2 parities][4][R][64] packed emission pairs of A, C, G, T (staged in LDS)

@@ -1706,13 +1706,17 @@ int p7x_search_batch_finish(p7x_pending *pd, const char *const *names, const cha
   }
   int st = P7X_OK;
   std::unique_ptr<EnvelopeScorer> scorer, scorer2;      // single-domain envelopes; second round: the ensembles' clustered envelopes
+  std::unique_ptr<EnsembleRunner> ensembles;
   if (any_device) {
     DeviceCtx *ctx = nullptr;
     if ((st = get_ctx(db->device, &ctx)) != P7X_OK) return st;
     scorer = make_device_envelope_scorer(ctx, db, pd->cfg.oa_guard);
-    if (device_clustered(pd->cfg.host_threads)) scorer2 = make_device_envelope_scorer(ctx, db, pd->cfg.oa_guard);
+    if (!pd->cfg.host_ensembles) {          // the multi-domain regions' ensembles and their clustered envelopes on the device as well
+      ensembles = make_device_ensemble_runner(ctx, db);
+      scorer2 = make_device_envelope_scorer(ctx, db, pd->cfg.oa_guard);
+    } else if (device_clustered(pd->cfg.host_threads)) scorer2 = make_device_envelope_scorer(ctx, db, pd->cfg.oa_guard);
   }
-  if ((st = host_finish_batch(pd->cfg, items, tg, names, accs, descs, outs, scorer.get(), scorer2.get())) != P7X_OK) return st;
+  if ((st = host_finish_batch(pd->cfg, items, tg, names, accs, descs, outs, scorer.get(), scorer2.get(), ensembles.get())) != P7X_OK) return st;
   // work time of this batch (stage 1 + stage 2), not the time it spent queued between the stages
   const double stage2 = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t1).count();
   for (size_t q = 0; q < nq; ++q) {

@@ -277,7 +277,7 @@ static void threshold(p7x_tophits &th)
 // go to the device in one submission (one launch per model-length class).
 int host_finish_batch(const p7x_pipeline_cfg &cfg_in, const std::vector<FinishItem> &items, const HostTargets &tg,
                       const char *const *names, const char *const *accs, const char *const *descs,
-                      p7x_tophits **outs, EnvelopeScorer *scorer, EnvelopeScorer *scorer2)
+                      p7x_tophits **outs, EnvelopeScorer *scorer, EnvelopeScorer *scorer2, EnsembleRunner *ensembles)
 {
   const int nq = (int) items.size();
   std::vector<std::unique_ptr<p7x_tophits>> ths((size_t) nq);
@@ -422,13 +422,36 @@ int host_finish_batch(const p7x_pipeline_cfg &cfg_in, const std::vector<FinishIt
     for (int q = 0; q < nq; ++q) { jobs[(size_t) q] = EnvelopeJob{ items[(size_t) q].om, &req[(size_t) q], items[(size_t) q].targets }; any = any || !req[(size_t) q].empty(); }
     if (any) { const int st = scorer->begin(jobs); if (st != P7X_OK) return st; }
     tick("env_begin");
+    // The stochastic traceback ensembles of the multi-domain regions: sampled on the device when there is a runner (every
+    // region starts from the re-seeded generator, so regions are independent of each other); what remains here is the
+    // clustering of the sampled end points.  Without a runner -- or for a region it hands back -- the host samples.
+    std::vector<std::vector<EnvelopeRequest>> ereq((size_t) nq);
+    std::vector<std::vector<EnsembleResult>> eres;
+    std::vector<std::vector<int>> ereq_index((size_t) S);
+    const bool dev_ens = ensembles != nullptr && reseed && !cfg_in.long_targets;
+    if (dev_ens) {
+      for (int f : heavy) {
+        const int q = q_of[(size_t) f], i = f - first[(size_t) q];
+        for (const Domain &d : dds[(size_t) f].dcl)
+          if (d.deferred == -2) { ereq_index[(size_t) f].push_back((int) ereq[(size_t) q].size()); ereq[(size_t) q].push_back(EnvelopeRequest{ i, (int32_t) d.ienv, (int32_t) d.jenv }); }
+      }
+      std::vector<EnvelopeJob> ejobs((size_t) nq);
+      for (int q = 0; q < nq; ++q) ejobs[(size_t) q] = EnvelopeJob{ items[(size_t) q].om, &ereq[(size_t) q], items[(size_t) q].targets };
+      int st = ensembles->begin(ejobs, fast_rng_state(cfg_in.seed), 200);
+      if (st != P7X_OK) return st;
+      tick("ens_begin");
+      if ((st = ensembles->wait(eres)) != P7X_OK) return st;
+      tick("ens_wait");
+    }
     // the ensembles' clustered envelopes go to the device as a second round (scorer2) instead of being rescored here
     std::vector<std::vector<EnvelopeRequest>> local2((size_t) S);
     run_pool((int) heavy.size(), [&](int h) {
       const int f = heavy[(size_t) h], q = q_of[(size_t) f], i = f - first[(size_t) q];
       const int t = (*items[(size_t) q].targets)[(size_t) i];
+      std::vector<const EnsembleResult *> mine;
+      if (dev_ens) for (int e : ereq_index[(size_t) f]) mine.push_back(&eres[(size_t) q][(size_t) e]);
       const int st = domaindef_finish_multi(items[(size_t) q].om->p, tg.dsq + tg.off[t] - 1, tg.len[t], cfg_in.seed, reseed, dds[(size_t) f],
-                                            scorer2 ? &local2[(size_t) f] : nullptr, i);
+                                            scorer2 ? &local2[(size_t) f] : nullptr, i, dev_ens ? mine.data() : nullptr);
       if (st != P7X_OK) failed.store(st);
     });
     ms_multi = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t1).count();

@@ -1340,7 +1340,7 @@ class Pipeline:
                  F3: float = 1e-5, E: float = 10.0, T=None, domE: float = 10.0, domT=None, incE: float = 0.01,
                  incT=None, incdomE: float = 0.01, incdomT=None, bit_cutoffs: Optional[str] = None,
                  device: int = 0, host_threads: int = 0, host_envelopes: bool = False, host_regions: bool = False,
-                 oa_guard: Optional[float] = None):
+                 oa_guard: Optional[float] = None, host_ensembles: bool = False):
         self.alphabet = alphabet
         if background is None:
             self.background = Background(alphabet)
@@ -1366,6 +1366,7 @@ class Pipeline:
         self.host_threads = host_threads
         self.host_envelopes = int(host_envelopes)       # bool for the protein pipeline; long targets: 0 auto, 1 host, 2 device
         self.host_regions = bool(host_regions)
+        self.host_ensembles = bool(host_ensembles)      # True: the stochastic traceback ensembles stay on the host workers
         self.oa_guard = oa_guard          # None: the library's default (p7x_pipeline_cfg.oa_guard)
         self._mode = _P7X_SEARCH_SEQS
         self._db_cache = None           # (id(block), block version, n, device) -> SequenceDatabase
@@ -1395,6 +1396,7 @@ class Pipeline:
         c.host_threads = int(self.host_threads)
         c.host_envelopes = int(self.host_envelopes)      # long targets also take 2: always the device (see p7x.h)
         c.host_regions = int(self.host_regions)
+        c.host_ensembles = int(self.host_ensembles)
         if self.oa_guard is not None:
             c.oa_guard = float(self.oa_guard)
         c.mode = int(self._mode)
@@ -1757,6 +1759,21 @@ class SequenceDatabase:
             except Exception:
                 pass
             self._handle = None
+
+    def ensemble(self, om: OptimizedProfile, target: int, start: int, end: int, *, seed: int = 42, device: bool = True):
+        """Test seam (``p7x_debug_ensemble``): the 200 stochastic tracebacks of region ``start..end`` (1-based) of one
+        target, sampled by the device kernels or by the host twin.  Returns ``(status, domains[n, 5], null2_sums[Lr + 1])``:
+        ``domains`` rows are (sample, first residue, last residue, first node, last node), residues counted inside the region."""
+        Lr = end - start + 1
+        cap = 200 * 16
+        ndom, status = C.c_int32(0), C.c_int32(0)
+        dom = np.zeros((cap, 5), dtype=np.int32)
+        n2 = np.zeros(Lr + 1, dtype=np.float32)
+        st = _lib.lib().p7x_debug_ensemble(om._handle, self._handle, int(target), int(start), int(end), int(seed), int(bool(device)),
+                                           C.byref(ndom), dom.ctypes.data, cap, n2.ctypes.data, C.byref(status))
+        if st != 0:
+            raise status_to_exception(st, "p7x_debug_ensemble", _lib.last_error())
+        return status.value, dom[:min(ndom.value, cap)].copy(), n2
 
     def filters(self, om: OptimizedProfile, msv=True, viterbi=False, forward=False, bias=False):
         """Raw per-target filter outputs (``p7x_filters_batch``): dict of numpy arrays in target order."""

@@ -18,7 +18,7 @@ def test_abi_exports_every_declared_symbol(libp7x):
     for name in sorted(declared):
         assert hasattr(raw, name), f"libp7x.so does not export {name}"
     assert declared == set(_lib.declared_symbols()), declared ^ set(_lib.declared_symbols())
-    assert libp7x.p7x_abi_version() == 6
+    assert libp7x.p7x_abi_version() == 7
 
 
 @pytest.mark.parametrize("name", ["PF02826", "Thioesterase", "RREFam"])
@@ -445,3 +445,39 @@ def test_f3_guard_follows_the_reference_order_on_the_threshold(models, oracle, p
             pli = plan7.Pipeline(hmm.alphabet, F3=F3)
             hits = host_pipeline.host_search(oracle, hmm, block, pipeline=pli, F=(0.02, 1e-3, F3 * (1.0 + 4e-3)), perturb_fwd={t: float(off)})
             assert hits.stage_counts["fwd"] == want, (F3, kept, ulps)
+
+
+def test_integer_thresholds_of_a_traceback_choice_are_the_reference_test(libp7x):
+    """p7x_choice.hpp restates esl_rnd_FChoose's floating-point test (roll < cumulative / norm, roll = x / 2^32) as integer
+    thresholds on the generator's state: the same path for every weight vector and every state, also next to a threshold."""
+    import ctypes as C
+    rng = np.random.default_rng(5)
+    a, b = C.c_int(0), C.c_int(0)
+    nchecked = 0
+    for trial in range(3000):
+        n = int(rng.choice([2, 4]))
+        kind = trial % 6
+        if kind == 0:
+            p = rng.random(n)
+        elif kind == 1:
+            p = rng.random(n) * 10.0 ** rng.integers(-30, 5, size=n)
+        elif kind == 2:
+            p = rng.random(n); p[rng.integers(0, n)] = 0.0
+        elif kind == 3:
+            p = np.zeros(n); p[rng.integers(0, n)] = rng.random()
+        elif kind == 4:
+            p = np.zeros(n)                                   # esl_vec_FNorm's uniform fallback
+        else:
+            p = rng.random(n); p[-1] = 0.0; p[0] = 1e-30
+        p32 = np.ascontiguousarray(p, dtype=np.float32)
+        s = float(p32.sum()) or 1.0
+        cum = np.cumsum(p32.astype(np.float64)) / s
+        xs = [0, 1, 2**32 - 1, 2**32 - 2, 2**31] + [int(v) for v in rng.integers(0, 2**32, size=6)]
+        for c in cum:                                         # states around every threshold
+            t = int(min(max(np.ceil(c * 2.0**32), 0), 2**32 - 1))
+            xs += [min(max(t + d, 0), 2**32 - 1) for d in (-3, -2, -1, 0, 1, 2, 3, 300, -300)]
+        for x in xs:
+            assert libp7x.p7x_debug_choice(p32.ctypes.data, n, C.c_uint32(x), C.byref(a), C.byref(b)) == 0
+            assert a.value == b.value, (p32, x, a.value, b.value)
+            nchecked += 1
+    assert nchecked > 50000
