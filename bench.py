@@ -433,6 +433,7 @@ def main():
                          "pipeline's fill and drain (about two query times) then weigh as little in a 20-step run as in a long one")
     ap.add_argument("--batch", type=int, default=0, help="headline workload: queries per device batch (0: the library's own choice)")
     ap.add_argument("--oa-guard", type=float, default=None, help="A/B: the optimal-accuracy near-tie guard (default: the library's; 0 switches it off)")
+    ap.add_argument("--host-ensembles", action="store_true", help="A/B: the stochastic traceback ensembles on the host workers instead of the device")
     ap.add_argument("--spinup-max", type=int, default=15, help="at most this many untimed 20-query windows before the warm-up")
     ap.add_argument("--workload", choices=("both", "config1", "pfam", "scan", "nhmmer"), default="both",
                     help="config1: the headline (one profile x 1M targets per GPU); pfam / nhmmer: (a token headline and) that "
@@ -501,6 +502,8 @@ def main():
 
     qps = max(1, args.queries_per_step)
     pli_opts = {} if args.oa_guard is None else {"oa_guard": args.oa_guard}
+    if args.host_ensembles:
+        pli_opts["host_ensembles"] = True
     lanes_per_launch = args.batch or hmmer._auto_batch(hmmer.ShardedDatabase.from_database(db), hmm.M)
 
     def run(nsteps):

@@ -184,13 +184,14 @@ typedef struct p7x_pipeline_cfg {
                               * units of the search -- consecutive units, units counted in the order of the reference's loop
                               * (plan7.pyx:7582-7655) -- and returns an unfinished hit list; p7x_tophits_merge_longtargets finishes the
                               * parts together (E-values for all residues searched, duplicates, thresholds).  Default 0 of 1 */
-  float   oa_guard;          /* near-tie guard of the device's optimal-accuracy traceback: a choice on the trace between candidates
-                              * within |v| * g + g of each other (or a posterior that close to the next printed digit) sends the
-                              * envelope to the host twin, which repeats it in the reference's order of operations.  Default 4e-6
-                              * (about 34 units in the last place).  Measured on 26,394 domains (scripts/oa_guard_sweep2.py,
-                              * profiles/r03_oa_guard_sweep.txt): without the guard 9 domains differ from the host twin, with 1e-6 three,
-                              * with 2e-6 one, from 3e-6 on none; 3e-6 repeats 1.5 % of the envelopes.  0: no guard (and a kernel
-                              * without the guard's arithmetic) */
+  float   oa_guard;          /* near-tie guard of the device's optimal-accuracy traceback: with g > 0 a choice on the trace between
+                              * candidates within |v| * g + g of each other (or a posterior that close to the next printed digit) sends
+                              * the envelope to the host twin, which repeats it.  Default 0 (off, and a kernel without the guard's
+                              * arithmetic): since ABI 7 the host twin forms every order-sensitive sum of Forward, Backward and the
+                              * null2 expectation in the device's order (lane chunks, the wavefront's scan / reduction trees), so both
+                              * compute the same posteriors and take the same decisions (tests/test_gpu_envelopes.py compares every
+                              * integer field of every domain; scripts/oa_guard_sweep2.py counts differences over 26,000 domains).
+                              * The guard remains as a diagnostic: with 4e-6 it flags about 3 % of the envelopes */
   float   f3_guard;          /* relative half-width of the band around F3 inside which a target's Forward P-value is not trusted to the
                               * device's summation order: the device passes P <= F3 (1 + g), the host stage re-scores the targets with
                               * P > F3 (1 - g) with p7x_forward_parser_exact and applies F3 to that.  Default 4e-3 (a band of about 6e-3 bit, three times the stated tolerance of the device Forward score); 0: no guard */

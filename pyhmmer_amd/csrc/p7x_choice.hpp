@@ -31,40 +31,43 @@ P7X_HD float choice_fsum(const float *v, int n)
 }
 
 // Thresholds of one choice point with n <= 4 paths.  p[]: the raw path weights (normalised in place, as esl_vec_FNorm
-// does).  T[i], i < n - 1: path i is taken when x < T[i] -- or always, when bit i of *sat is set (T would be 2^32) -- and
-// no earlier path was; *fallback is the path taken when none of those is.
-P7X_HD void choice_thresholds(float *p, int n, uint32_t *T, uint32_t *sat, uint32_t *fallback)
+// does).  Path i < n - 1 is taken when x < T[i] and no earlier path was; *fallback is the path taken when none of those
+// is.  A cumulative ratio that reaches 1 (its threshold would be 2^32: always taken) ends the list there: that path
+// becomes the fallback and the thresholds from it on are 0 (never) -- the ratios only grow, so nothing behind it could be
+// reached anyway, and no threshold needs a 33rd bit.
+P7X_HD void choice_thresholds(float *p, int n, uint32_t *T, uint32_t *fallback)
 {
   const float s = choice_fsum(p, n);
   if (s != 0.0f) { for (int i = 0; i < n; ++i) p[i] /= s; }
   else           { for (int i = 0; i < n; ++i) p[i] = (float) (1. / (double) (float) n); }
   const double norm = (double) choice_fsum(p, n);
   double sum = 0.0;
-  uint32_t sbits = 0, fb = 0;
+  uint32_t fb = 0;
+  int always = -1;                                                        // first path whose cumulative ratio is >= 1
   for (int i = 0; i < n; ++i) {
     sum += (double) p[i];
     if (p[i] > 0.0f) fb = (uint32_t) i;
     if (i < n - 1) {
       const double t = __builtin_ceil((sum / norm) * 4294967296.0);
       uint32_t ti = 0;
-      if (t >= 4294967296.0) { ti = 0xffffffffu; sbits |= 1u << i; }
-      else if (t > 0.0) ti = (uint32_t) t;                              // NaN or zero: never taken
+      if (t >= 4294967296.0) { if (always < 0) always = i; }
+      else if (t > 0.0 && always < 0) ti = (uint32_t) t;                  // NaN or zero: never taken
       T[i] = ti;
     }
   }
-  *sat = sbits; *fallback = fb;
+  *fallback = always >= 0 ? (uint32_t) always : fb;
 }
-P7X_HD int choice_pick(const uint32_t *T, uint32_t sat, uint32_t fallback, int n, uint32_t x)
+P7X_HD int choice_pick(const uint32_t *T, uint32_t fallback, int n, uint32_t x)
 {
-  for (int i = 0; i < n - 1; ++i) if (x < T[i] || ((sat >> i) & 1u)) return i;
+  for (int i = 0; i < n - 1; ++i) if (x < T[i]) return i;
   return (int) fallback;
 }
 
 // ---- what the device stores per Forward cell (i, k) and per row i (p7x_ensemble.hip); the host twin fills the same
 // records from its own matrix where its walk passes, and the debug seams compare them word for word.
-// cell, first 16 bytes -- the match cell's choice among B, M, I, D of (i-1, k-1):  T0 T1 T2 | fallback (bits 0-1), sat (2-4)
-// cell, second 16 bytes -- insert: M or I of (i-1, k); delete: M or D of (i, k-1):  TI TD | fI (bit 0) satI (1) fD (2) satD (3) | 0
-// row, first 16 bytes -- C: C(i-1) or E(i); J: J(i-1) or E(i); B: N(i) or J(i):     TC TJ TB | fC (0) satC (1) fJ (2) satJ (3) fB (4) satB (5)
+// cell, first 16 bytes -- the match cell's choice among B, M, I, D of (i-1, k-1):  T0 T1 T2 | fallback (bits 0-1)
+// cell, second 16 bytes -- insert: M or I of (i-1, k); delete: M or D of (i, k-1):  TI TD | fI (bit 0) fD (bit 2) | 0
+// row, first 16 bytes -- C: C(i-1) or E(i); J: J(i-1) or E(i); B: N(i) or J(i):     TC TJ TB | fC (bit 0) fJ (bit 2) fB (bit 4)
 // row, second 16 bytes -- (float) (1 / xE(i)), the factor of select_e's cumulative sum; three spare words
 struct ChoiceCell { uint32_t m[4]; uint32_t id[4]; };
 struct ChoiceRow  { uint32_t x[4]; uint32_t e[4]; };
@@ -72,18 +75,16 @@ struct ChoiceRow  { uint32_t x[4]; uint32_t e[4]; };
 P7X_HD void choice_cell_m(float b, float m, float i, float d, uint32_t *out4)
 { // path[0..3] = B(i-1) bm(k), M(i-1,k-1) tMM(k), I(i-1,k-1) tIM(k), D(i-1,k-1) tDM(k): the products, formed by the caller
   float p[4] = { b, m, i, d };
-  uint32_t sat, fb;
-  choice_thresholds(p, 4, out4, &sat, &fb);
-  out4[3] = fb | (sat << 2);
+  uint32_t fb;
+  choice_thresholds(p, 4, out4, &fb);
+  out4[3] = fb;
 }
-P7X_HD void choice_pair(float a, float b, uint32_t *T, uint32_t *bits2)
-{ // a two-way choice: *bits2 = fallback (bit 0) | sat (bit 1)
+P7X_HD void choice_pair(float a, float b, uint32_t *T, uint32_t *fallback)
+{
   float p[2] = { a, b };
-  uint32_t sat, fb;
-  choice_thresholds(p, 2, T, &sat, &fb);
-  *bits2 = fb | (sat << 1);
+  choice_thresholds(p, 2, T, fallback);
 }
-P7X_HD int choice_pick_m(const uint32_t *c4, uint32_t x) { return choice_pick(c4, c4[3] >> 2, c4[3] & 3u, 4, x); }
-P7X_HD int choice_pick_pair(uint32_t T, uint32_t bits2, uint32_t x) { return (x < T || (bits2 & 2u)) ? 0 : (int) (bits2 & 1u); }
+P7X_HD int choice_pick_m(const uint32_t *c4, uint32_t x) { return x < c4[0] ? 0 : (x < c4[1] ? 1 : (x < c4[2] ? 2 : (int) (c4[3] & 3u))); }
+P7X_HD int choice_pick_pair(uint32_t T, uint32_t fallback, uint32_t x) { return x < T ? 0 : (int) (fallback & 1u); }
 
 } // namespace p7x

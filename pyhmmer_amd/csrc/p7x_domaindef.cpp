@@ -1353,9 +1353,9 @@ extern "C" int p7x_debug_choice(const float *p, int n, uint32_t x, int *via_thre
   if (!p || n < 2 || n > 4 || !via_thresholds || !via_fchoose) return P7X_EINVAL;
   float a[4], b[4];
   for (int i = 0; i < n; ++i) a[i] = b[i] = p[i];
-  uint32_t T[3] = { 0, 0, 0 }, sat = 0, fb = 0;
-  choice_thresholds(a, n, T, &sat, &fb);
-  *via_thresholds = choice_pick(T, sat, fb, n, x);
+  uint32_t T[3] = { 0, 0, 0 }, fb = 0;
+  choice_thresholds(a, n, T, &fb);
+  *via_thresholds = choice_pick(T, fb, n, x);
   fnorm(b, n);
   FastRng r; r.x = x;
   const double roll = (double) x / 4294967296.0;

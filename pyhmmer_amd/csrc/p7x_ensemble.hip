@@ -125,11 +125,78 @@ __global__ void __launch_bounds__(64) ens_forward_kernel(const EnsArgs a, const 
 }
 
 // ---------------------------------------------------------------------------- the walks
+#ifdef P7X_ENS_PROFILE
+// build-time experiment (-DP7X_ENS_PROFILE): core-clock cycles the walk kernel's wavefronts spent in [0] C / J runs, [1] select_e,
+// [2] the core walk, [3] finishing domains; [4] core steps, [5] samples, [6] record-cache misses, [7] regions
+__device__ unsigned long long g_ens_prof[8];
+#define P7X_ENS_STAMP(slot) do { const unsigned long long now_ = __builtin_readcyclecounter(); if (lane == 0) atomicAdd(&g_ens_prof[slot], now_ - stamp_); stamp_ = now_; } while (0)
+#define P7X_ENS_COUNT(slot, n) do { if (lane == 0) atomicAdd(&g_ens_prof[slot], (unsigned long long) (n)); } while (0)
+#else
+#define P7X_ENS_STAMP(slot) do { } while (0)
+#define P7X_ENS_COUNT(slot, n) do { } while (0)
+#endif
+namespace {
+// inclusive prefix sum over the wavefront, in double (two 32-bit DPP moves per step; the scan tree of wave_sum_f32)
+__device__ __forceinline__ double dpp_f64(double v, const int ctrl_sel)
+{
+  const unsigned long long u = __builtin_bit_cast(unsigned long long, v);
+  int lo = (int) (unsigned) u, hi = (int) (unsigned) (u >> 32);
+  switch (ctrl_sel) {
+    case 0: lo = __builtin_amdgcn_update_dpp(0, lo, 0x111, 0xf, 0xf, false); hi = __builtin_amdgcn_update_dpp(0, hi, 0x111, 0xf, 0xf, false); break;
+    case 1: lo = __builtin_amdgcn_update_dpp(0, lo, 0x112, 0xf, 0xf, false); hi = __builtin_amdgcn_update_dpp(0, hi, 0x112, 0xf, 0xf, false); break;
+    case 2: lo = __builtin_amdgcn_update_dpp(0, lo, 0x114, 0xf, 0xf, false); hi = __builtin_amdgcn_update_dpp(0, hi, 0x114, 0xf, 0xf, false); break;
+    case 3: lo = __builtin_amdgcn_update_dpp(0, lo, 0x118, 0xf, 0xf, false); hi = __builtin_amdgcn_update_dpp(0, hi, 0x118, 0xf, 0xf, false); break;
+    case 4: lo = __builtin_amdgcn_update_dpp(0, lo, 0x142, 0xa, 0xf, false); hi = __builtin_amdgcn_update_dpp(0, hi, 0x142, 0xa, 0xf, false); break;
+    default: lo = __builtin_amdgcn_update_dpp(0, lo, 0x143, 0xc, 0xf, false); hi = __builtin_amdgcn_update_dpp(0, hi, 0x143, 0xc, 0xf, false); break;
+  }
+  return __builtin_bit_cast(double, ((unsigned long long) (unsigned) hi << 32) | (unsigned long long) (unsigned) lo);
+}
+__device__ __forceinline__ double wave_scan_f64(double v)
+{
+  v = v + dpp_f64(v, 0); v = v + dpp_f64(v, 1); v = v + dpp_f64(v, 2); v = v + dpp_f64(v, 3);
+  v = v + dpp_f64(v, 4); v = v + dpp_f64(v, 5);
+  return v;
+}
+__device__ __forceinline__ double readlane_f64(double v, int l)
+{
+  const unsigned long long u = __builtin_bit_cast(unsigned long long, v);
+  const unsigned lo = (unsigned) __builtin_amdgcn_readlane((int) (unsigned) u, l), hi = (unsigned) __builtin_amdgcn_readlane((int) (unsigned) (u >> 32), l);
+  return __builtin_bit_cast(double, ((unsigned long long) hi << 32) | lo);
+}
+// a 16-byte record through the vector memory path (in-order returns: a load issued a step ahead stays in flight while the
+// current one is consumed; scalar loads return out of order and would be waited for together)
+__device__ __forceinline__ uint4 vload16(const void *base, unsigned byte_off)
+{
+  asm volatile("" : "+v"(byte_off));
+  return *reinterpret_cast<const uint4 *>(static_cast<const unsigned char *>(base) + byte_off);
+}
+
+// select_e exactly as the reference sums it: one double accumulator, the cells in the striped visiting order (q outer; four
+// match cells, then four delete cells).  Only the rare draw that the lane-parallel version below cannot decide comes here.
+__device__ __noinline__ int select_e_serial(const float2 *mdr, int M, int Q, float norm, double roll)
+{ // returns node | delete << 30, or -1
+  double sum = 0.0;
+  for (int pass = 0; pass < 2; ++pass) {
+    for (int q = 0; q < Q; ++q) {
+      for (int z = 0; z < 4; ++z) { const int kk = z * Q + q + 1; sum += (double) (kk <= M ? mdr[kk].x * norm : 0.0f); if (roll < sum) return kk; }
+      for (int z = 0; z < 4; ++z) { const int kk = z * Q + q + 1; sum += (double) (kk <= M ? mdr[kk].y * norm : 0.0f); if (roll < sum) return kk | (1 << 30); }
+    }
+    if (sum < 0.99) return -1;
+  }
+  return -1;
+}
+} // namespace
+
 // LDS: visit counts per node (p7_Null2_ByTrace's usage counts of one domain), the null2 vector of the domain just
-// finished, its four per-stripe partial sums, and -- for regions that fit -- the per-residue accumulators.
+// finished and its four per-stripe partial sums; then, as far as they fit, the rows' choice records, the region's residues,
+// the per-residue accumulators (regions of up to 512 residues keep them in registers), the profile's residue-minor match
+// odds, a few Forward rows for select_e, and the record caches of the core walk.
 __global__ void __launch_bounds__(64) ens_walk_kernel(const EnsArgs a)
 {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  // One wavefront walks a region's 200 samples, a serial chain from the first deviate to the last: whenever it can issue
+  // it should, ahead of the throughput kernels' wavefronts it shares a SIMD with.
+  __builtin_amdgcn_s_setprio(3);
   const int lane = threadIdx.x;
   const int r = blockIdx.x;
   const EnsRegion reg = a.regions[r];
@@ -138,174 +205,320 @@ __global__ void __launch_bounds__(64) ens_walk_kernel(const EnsArgs a)
   uint32_t *cnt = reinterpret_cast<uint32_t *>(smem);                          // [M + 2]
   float *n2v = reinterpret_cast<float *>(cnt + ((M + 2 + 31) & ~31));          // [32]
   float *accz = n2v + 32;                                                      // [4][32]
-  float *n2lds = accz + 128;                                                   // [Lr + 1] when it fits
-  const bool n2_in_lds = Lr <= a.n2_lds_cap;
-  float *n2g = a.n2acc + reg.row0;
-  float *n2 = n2_in_lds ? n2lds : n2g;
-  for (int k = lane; k < M + 2; k += 64) cnt[k] = 0;
-  for (int pos = lane; pos <= Lr; pos += 64) n2[pos] = 0.0f;
-  if (!n2_in_lds) own_stores_visible();
-  __syncthreads();
-  const ChoiceCell *__restrict__ cells = a.cells + reg.cell0;
-  const float2 *__restrict__ md = a.md + reg.cell0;
+  int *mdtag = reinterpret_cast<int *>(accz + 128);                            // [8]
+  size_t used = (size_t) (((M + 2 + 31) & ~31) + 32 + 128 + 8) * 4;
+  const size_t cap = (size_t) a.lds_bytes - 4096;               // the record caches' minimum stays free
   const ChoiceRow *__restrict__ rows = a.rows + reg.row0;
-  const uint8_t *__restrict__ sq = a.dsq + reg.sq;
-  const float *__restrict__ rft = job.rft;
+  // rows' records C / J / B (16 bytes each) and select_e's factor 1 / xE(i)
+  const bool rows_in_lds = used + (size_t) (Lr + 1) * 20 + 16 <= cap;
+  uint4 *rowl = reinterpret_cast<uint4 *>(smem + used);
+  float *norml = reinterpret_cast<float *>(rowl + (Lr + 1));
+  if (rows_in_lds) used += ((size_t) (Lr + 1) * 20 + 15) & ~(size_t) 15;
+  // the region's residues (the finished domains look their odds up by residue)
+  const uint8_t *__restrict__ sqg = a.dsq + reg.sq;
+  const bool sq_in_lds = used + (size_t) Lr + 16 <= cap;
+  uint8_t *sql = smem + used;
+  if (sq_in_lds) { for (int q = lane; q < Lr; q += 64) sql[q] = sqg[q]; used += ((size_t) Lr + 15) & ~(size_t) 15; }
+  // accumulators: lane l keeps residues l + 1 + 64 j, j < 8, in registers when the region is short enough
+  constexpr int NR = 8;
+  const bool n2_in_regs = Lr <= 64 * NR && sq_in_lds;
+  const bool n2_in_lds = !n2_in_regs && used + (size_t) (Lr + 1) * 4 + 16 <= cap;
+  float *n2g = a.n2acc + reg.row0;
+  float *n2 = n2_in_lds ? reinterpret_cast<float *>(smem + used) : n2g;
+  if (n2_in_lds) used += (size_t) (((Lr + 1) + 3) & ~3) * 4;
+  // match odds
+  const bool rft_in_lds = used + (size_t) (M + 1) * 128 <= cap;
+  const float *rft = rft_in_lds ? reinterpret_cast<const float *>(smem + used) : job.rft;
+  if (rft_in_lds) {
+    float4 *dst = reinterpret_cast<float4 *>(smem + used);
+    const float4 *src = reinterpret_cast<const float4 *>(job.rft);
+    for (int q = lane; q < (M + 1) * 8; q += 64) dst[q] = src[q];
+    used += (size_t) (M + 1) * 128;
+  }
+  // eight Forward rows (M and D cells) for select_e: a sample's domains end where the last sample's did, give or take
+  const bool md_in_lds = used + (size_t) 8 * Mrow * 8 + 16 <= cap;
+  float2 *mdl = reinterpret_cast<float2 *>(smem + used);
+  if (md_in_lds) used += ((size_t) 8 * Mrow * 8 + 15) & ~(size_t) 15;
+  // the record caches of the core walk (see there): 16-byte entries, powers of two; the match cells' gets about three
+  // quarters of what is left (at most 4096 entries), the insert / delete cells' the rest (at most 1024)
+  used = (used + 15) & ~(size_t) 15;
+  const size_t left = (size_t) a.lds_bytes - used;
+  int mbits = 7, idbits = 6;
+  while (mbits < 12 && ((size_t) 32 << mbits) <= left - left / 4) ++mbits;
+  while (idbits < 10 && ((size_t) 16 << mbits) + ((size_t) 32 << idbits) <= left) ++idbits;
+  uint4 *mcache = reinterpret_cast<uint4 *>(smem + used);
+  const unsigned idbase = 1u << mbits;                                                 // the insert / delete cache follows the match cache
+  for (int q = lane; q < (1 << mbits) + (1 << idbits); q += 64) mcache[q] = make_uint4(0u, 0u, 0u, 0u);
+  const bool cache_ok = (size_t) (Lr + 1) * (size_t) Mrow < ((size_t) 1 << 27) - 2;      // cell numbers fit the 27-bit tags
+  const bool by_row = Lr < (1 << (mbits - 2));                                         // every row has its own four entries
+  if (rows_in_lds) for (int q = lane; q <= Lr; q += 64) { rowl[q] = *reinterpret_cast<const uint4 *>(rows[q].x); norml[q] = bitsf(rows[q].e[0]); }
+  for (int k = lane; k < M + 2; k += 64) cnt[k] = 0;
+  if (lane < 8) mdtag[lane] = -1;
+  if (!n2_in_regs) { for (int pos = lane; pos <= Lr; pos += 64) n2[pos] = 0.0f; if (!n2_in_lds) own_stores_visible(); }
+  float acc[NR];
+#pragma unroll
+  for (int j = 0; j < NR; ++j) acc[j] = 0.0f;
+  // esl_abc_FAvgScVec: which canonical residues residue code <lane> stands for
+  uint32_t degen_mask = 0;
+  if (lane > K && lane <= Kp - 3) for (int y = 0; y < K; ++y) if (job.degen[lane * 32 + y]) degen_mask |= 1u << y;
+  __syncthreads();
+  const ChoiceCell *cells = a.cells + reg.cell0;
+  const float2 *__restrict__ md = a.md + reg.cell0;
   int32_t *dom = a.dom + reg.dom0 * 5;
+  const int dom_cap = reg.dom_cap;
   uint32_t x = a.seed_x;
   int ndom = 0, status = 0;
   const int step_cap = 4 * (Lr + M) + 64;
+  uint32_t jumpA = 1u, jumpC = 0u;                                 // lane + 1 draws of x <- 69069 x + 1 in one step
+  for (int l = 0; l <= lane; ++l) { jumpA *= 69069u; jumpC = jumpC * 69069u + 1u; }
+  auto row_rec = [&](int i) -> uint4 { return rows_in_lds ? rowl[i] : *reinterpret_cast<const uint4 *>(rows[i].x); };
+  const unsigned rmask = (1u << (mbits - 2)) - 1u, mshift = 32u - (unsigned) mbits, idshift = 32u - (unsigned) idbits;
 
+#ifdef P7X_ENS_PROFILE
+  unsigned long long stamp_ = __builtin_readcyclecounter();
+  P7X_ENS_COUNT(7, 1);
+#endif
   for (int t = 0; t < a.nsamples && status == 0; ++t) {
+    P7X_ENS_COUNT(5, 1);
     int i = Lr, k = 0, st = tC;
     int hi = Lr;                        // residues hi+1 .. Lr have received this sample's contribution
-    int dj = 0, dm_ = 0, di = 0, dk = 0, Ld = 0, klo = 0, khi = 0;
     int steps = 0;
     bool running = true;
     while (running) {
       if (++steps > step_cap) { status |= 1; break; }
       // the walk's state is the same in every lane: keep it in scalar registers (scalar branches, one address per load)
       st = rfl(st); i = rfl(i); k = rfl(k); x = (uint32_t) rfl((int) x);
-      switch (st) {
-        case tC: {
-          if (i < 1) { status |= 2; running = false; break; }
-          x = lcg_next(x);
-          const uint4 rw = *reinterpret_cast<const uint4 *>(rows[i].x);
-          if (choice_pick_pair(rw.x, rw.w & 3u, x) == 0) --i; else st = tE;
-          break;
+      if (st == tC || st == tJ) {
+        // A run of C (or J) states: row i-l decides with the l-th deviate from here, every choice of the run is independent
+        // of the others, so 64 rows are looked at together -- lane l jumps the generator l draws ahead (x -> A_l x + C_l)
+        // and the first lane that leaves for E ends the run.
+        if (i < 1) { status |= 2; break; }
+        const int row = i - lane;
+        const uint32_t xl = jumpA * x + jumpC;                        // the state after lane + 1 draws
+        bool leave = false;
+        if (row >= 1) {
+          const uint4 rw = row_rec(row);
+          const int c = (st == tC) ? choice_pick_pair(rw.x, rw.w & 3u, xl) : choice_pick_pair(rw.y, (rw.w >> 2) & 3u, xl);
+          leave = c != 0;
         }
-        case tJ: {
-          if (i < 1) { status |= 2; running = false; break; }
-          x = lcg_next(x);
-          const uint4 rw = *reinterpret_cast<const uint4 *>(rows[i].x);
-          if (choice_pick_pair(rw.y, (rw.w >> 2) & 3u, x) == 0) --i; else st = tE;
-          break;
+        const unsigned long long lv = __ballot(leave);
+        const int nrows = min(64, i);                                 // rows this look covers
+        if (lv != 0ull) {
+          const int l = (int) __builtin_ctzll(lv);
+          x = (uint32_t) __builtin_amdgcn_readlane((int) xl, l);
+          i -= l; st = tE;
+        } else {
+          x = (uint32_t) __builtin_amdgcn_readlane((int) xl, nrows - 1);
+          i -= nrows;
+          if (i < 1) { status |= 2; break; }                          // the run reached row 0 without an E: no such trace
         }
-        case tE: {
-          // select_e: the first cell, in the striped visiting order (q outer; four match cells, then four delete cells),
-          // whose cumulative share of xE(i) exceeds the deviate; the sum runs in double, as upstream's does
-          x = lcg_next(x);
-          const double roll = (double) x / 4294967296.0;
-          const float norm = bitsf(rows[i].e[0]);
-          const float2 *mdr = md + (size_t) i * Mrow;
-          double sum = 0.0;
-          int found = 0;
-          for (int pass = 0; pass < 2 && !found; ++pass) {
-            for (int q = 0; q < Q && !found; ++q) {
-              float mv[4], dv[4];
-#pragma unroll
-              for (int z = 0; z < 4; ++z) {
-                const int kk = z * Q + q + 1;
-                float2 v = make_float2(0.0f, 0.0f);
-                if (kk <= M) v = mdr[kk];
-                mv[z] = (kk <= M) ? v.x * norm : 0.0f;
-                dv[z] = (kk <= M) ? v.y * norm : 0.0f;
-              }
-#pragma unroll
-              for (int z = 0; z < 4; ++z) { sum += (double) mv[z]; if (!found && roll < sum) { found = 1; k = z * Q + q + 1; st = tM; } }
-#pragma unroll
-              for (int z = 0; z < 4; ++z) { sum += (double) dv[z]; if (!found && roll < sum) { found = 1; k = z * Q + q + 1; st = tD; } }
-            }
-            if (!found && sum < 0.99) break;
-          }
-          if (!found) { status |= 4; running = false; break; }
-          dj = 0; Ld = 0; khi = k; klo = k;
-          break;
-        }
-        case tM: {
-          if (i < 1 || k < 1) { status |= 2; running = false; break; }
-          if (lane == 0) cnt[k] += 1;
-          ++Ld; klo = k;
-          if (dj == 0) { dj = i; dm_ = k; }
-          di = i; dk = k;
-          x = lcg_next(x);
-          const uint4 c4 = *reinterpret_cast<const uint4 *>(cells[(size_t) i * Mrow + k].m);
-          const uint32_t cw[4] = { c4.x, c4.y, c4.z, c4.w };
-          const int c = choice_pick_m(cw, x);
-          --i; --k;
-          st = (c == 0) ? tB : (c == 1) ? tM : (c == 2) ? tI : tD;
-          break;
-        }
-        case tI: {
-          if (i < 1 || k < 1) { status |= 2; running = false; break; }
-          if (lane == 0) cnt[k] += 1;
-          ++Ld; klo = k;
-          x = lcg_next(x);
-          const uint4 c4 = *reinterpret_cast<const uint4 *>(cells[(size_t) i * Mrow + k].id);
-          st = (choice_pick_pair(c4.x, c4.z & 3u, x) == 0) ? tM : tI;
-          --i;
-          break;
-        }
-        case tD: {
-          if (i < 1 || k < 1) { status |= 2; running = false; break; }
-          klo = k;
-          x = lcg_next(x);
-          const uint4 c4 = *reinterpret_cast<const uint4 *>(cells[(size_t) i * Mrow + k].id);
-          st = (choice_pick_pair(c4.y, (c4.z >> 2) & 3u, x) == 0) ? tM : tD;
-          --k;
-          break;
-        }
-        case tB: {
-          // a domain is complete: residues di .. dj of the region, nodes dk .. dm_ (p7_trace_Index); its end points go out for
-          // clustering, its null2 odds (p7_Null2_ByTrace over the visit counts) onto the residues di+1 .. dj
-          if (dj == 0 || Ld < 1) { status |= 8; running = false; break; }
-          if (ndom < a.dom_cap) {
-            if (lane == 0) { int32_t *o = dom + (size_t) ndom * 5; o[0] = t; o[1] = di; o[2] = dj; o[3] = dk; o[4] = dm_; }
-          } else status |= 16;                                            // more domains than the record holds: the host repeats the region
-          ++ndom;
-          __syncthreads();                                                // the counts are in
-          {
-            const float nrm = (float) (1.0 / (double) (float) Ld);
-            const int z = lane >> 4, xs = lane & 15;
-            float acc0 = 0.0f, acc1 = 0.0f;
-            const int q0 = max(0, klo - 1 - z * Q), q1 = min(Q - 1, khi - 1 - z * Q);
-            for (int q = q0; q <= q1; ++q) {
-              const int kk = q + 1 + z * Q;
-              const uint32_t cv = cnt[kk];
-              if (cv != 0 && kk <= M) {
-                const float w = (float) cv * nrm;
-                acc0 = acc0 + w * rft[(size_t) kk * 32 + xs];
-                acc1 = acc1 + w * rft[(size_t) kk * 32 + 16 + xs];
-              }
-            }
-            accz[z * 32 + xs] = acc0; accz[z * 32 + 16 + xs] = acc1;
-          }
-          __syncthreads();
-          if (lane < 32) n2v[lane] = ((accz[lane] + accz[32 + lane]) + (accz[64 + lane] + accz[96 + lane])) + 0.0f;      // + xfactor: no N, C, J inside a domain
-          __syncthreads();
-          {   // esl_abc_FAvgScVec over the degenerate codes; gap, nonresidue and missing-data codes score 1
-            float v = 0.0f; bool set = false;
-            if (lane > K && lane <= Kp - 3) {
-              float res = 0.0f; int n = 0;
-              for (int y = 0; y < K; ++y) if (job.degen[lane * 32 + y]) { res += n2v[y]; ++n; }
-              v = res / (float) n; set = true;
-            } else if (lane == K || lane == Kp - 2 || lane == Kp - 1) { v = 1.0f; set = true; }
-            __syncthreads();
-            if (set) n2v[lane] = v;
-          }
-          __syncthreads();
-          for (int pos = dj + 1 + lane; pos <= hi; pos += 64) n2[pos] += 1.0f;
-          for (int pos = di + 1 + lane; pos <= dj; pos += 64) n2[pos] += n2v[sq[pos - 1]];
-          hi = di;
-          for (int kk = klo + lane; kk <= khi; kk += 64) cnt[kk] = 0;
-          if (!n2_in_lds) own_stores_visible();
-          __syncthreads();
-          x = lcg_next(x);
-          const uint4 rw = *reinterpret_cast<const uint4 *>(rows[i].x);
-          if (choice_pick_pair(rw.z, (rw.w >> 4) & 3u, x) == 0) running = false;     // N: the rest of the trace is N ... N S
-          else st = tJ;
-          break;
-        }
-        default: status |= 32; running = false; break;
+        P7X_ENS_STAMP(0);
+        continue;
       }
+      if (st != tE) { status |= 32; break; }
+      // ---- E(i): select_e, then the domain's core walk back to its B state
+      {
+        x = lcg_next(x);
+        const double roll = (double) x / 4294967296.0;
+        const float norm = rows_in_lds ? norml[i] : bitsf(rows[i].e[0]);
+        const float2 *mdg = md + (size_t) i * Mrow;
+        const int ms = i & 7;
+        if (md_in_lds && rfl(mdtag[ms]) != i) {                     // this row's cells into one of the eight LDS rows
+          for (int q = lane; q < Mrow; q += 64) mdl[ms * Mrow + q] = mdg[q];
+          if (lane == 0) mdtag[ms] = i;
+          __syncthreads();
+        }
+        // Lane l of block b holds the cell of rank 64 b + l in the visiting order: rank = 8 q + 4 [delete] + z, node z Q + q + 1.
+        // Cumulative shares by a wavefront scan per block; the first rank whose cumulative share exceeds the deviate wins.  A
+        // scan adds in another order than the reference's single accumulator (differences ~1e-13): a deviate closer than
+        // 1e-9 to any cumulative share it was compared with is decided by select_e_serial instead.
+        const int nblk = (8 * Q + 63) >> 6;
+        double base = 0.0;
+        int found = -1, ambiguous = 0;
+        for (int b0 = 0; b0 < nblk && found < 0 && !ambiguous; b0 += 8) {
+          float v[8];
+#pragma unroll
+          for (int u = 0; u < 8; ++u) {
+            const int rank = ((b0 + u) << 6) + lane, q = rank >> 3, z = rank & 3, kk = z * Q + q + 1;
+            float2 c = make_float2(0.0f, 0.0f);
+            if (b0 + u < nblk && q < Q && kk <= M) { if (md_in_lds) c = mdl[ms * Mrow + kk]; else c = mdg[kk]; }
+            v[u] = ((rank & 4) ? c.y : c.x) * norm;
+          }
+#pragma unroll
+          for (int u = 0; u < 8; ++u) {
+            if (b0 + u < nblk && found < 0 && !ambiguous) {
+              const double cum = base + wave_scan_f64((double) v[u]);
+              const double dist = __builtin_fabs(cum - roll);
+              if (__ballot(dist < 1.0e-9) != 0ull) ambiguous = 1;
+              else {
+                const unsigned long long hit = __ballot(roll < cum);
+                if (hit != 0ull) found = ((b0 + u) << 6) + (int) __builtin_ctzll(hit);
+                else base = readlane_f64(cum, 63);
+              }
+            }
+          }
+        }
+        if (found >= 0 && !ambiguous) { const int q = found >> 3, z = found & 3; k = z * Q + q + 1; st = (found & 4) ? tD : tM; }
+        else {                                                            // also the second pass of a first pass that ended short
+          const int code = select_e_serial(mdg, M, Q, norm, roll);
+          if (code < 0) { status |= 4; break; }
+          k = code & 0x3fffffff; st = (code >> 30) ? tD : tM;
+        }
+      }
+      k = rfl(k); st = rfl(st);
+      P7X_ENS_STAMP(1);
+      int dj = 0, dm_ = 0, di = 0, dk = 0;
+      const int khi = k;
+      // The core walk, a RUN at a time.  While the walk stays in one state it moves along a line -- M down the diagonal
+      // (i-l, k-l), I up the column (i-l, k), D along the row (i, k-l) -- and the choice at the l-th cell of the line uses the
+      // l-th deviate from here: lane l looks at that cell with the generator jumped l draws ahead, and the first lane whose
+      // choice leaves the state ends the run.  A domain of a few hundred residues is a dozen runs instead of a few hundred
+      // dependent steps.
+      // The cells a region's samples visit are a narrow band around its alignments, visited again and again -- but between
+      // two visits the filter kernels running beside this one have streamed gigabytes through L2, and a round trip to HBM
+      // (and through the TLB: every cell of a line is another row, kilobytes away) is what a record then costs.  So the
+      // records are cached in LDS, 16 bytes per entry: the match cells' in a cache indexed by row and node -- row i owns
+      // entries 4 (i mod R) .. + 3, node k goes to k mod 4, so a walk that keeps to a band of four diagonals never evicts
+      // its own cells (regions longer than R rows: hashed by cell number instead) -- and the insert / delete cells' in a
+      // smaller one hashed by cell number.  The first sample fetches its cells from memory (all lanes of a run at once),
+      // the other 199 mostly find them here.
+      while (st != tB) {
+        if (++steps > step_cap) { status |= 1; break; }
+        if (i < 1 || k < 1) { status |= 2; break; }
+        const bool isM = st == tM, isI = st == tI;
+        const int ii = i - (isM || isI ? lane : 0), kk = k - (isI ? 0 : lane);
+        const bool inside = ii >= 1 && kk >= 1;
+        const unsigned tg = (unsigned) ii * (unsigned) Mrow + (unsigned) kk + 1u;         // cell number + 1
+        const uint32_t xl = jumpA * x + jumpC;                                            // the state after lane + 1 draws
+        const unsigned hsh = tg * 2654435761u;
+        const unsigned slot = isM ? (by_row ? ((((unsigned) ii & rmask) << 2) | ((unsigned) kk & 3u)) : (hsh >> mshift)) : idbase + (hsh >> idshift);
+        uint4 rec = mcache[slot];                                                         // (any lane: the index is in range)
+        asm volatile("" : "+v"(rec.x), "+v"(rec.y), "+v"(rec.z), "+v"(rec.w));            // the whole entry, one read
+        const bool missed = inside && (!cache_ok || (isM ? (rec.w >> 5) : rec.w) != tg);
+        if (missed) {                                                                     // from memory (all missing lanes at once)
+          const unsigned char *src = reinterpret_cast<const unsigned char *>(cells) + ((size_t) ii * Mrow + kk) * 32 + (isM ? 0 : 16);
+          rec = *reinterpret_cast<const uint4 *>(src);
+          rec.w = isM ? ((rec.w & 31u) | (tg << 5)) : tg;
+        }
+        int s1;
+        if (isM) {
+          const int fstate = (int) ((0x2316u >> ((rec.w & 3u) * 4u)) & 15u);              // fallback path 0..3 -> B, M, I, D
+          s1 = xl < rec.x ? tB : (xl < rec.y ? tM : (xl < rec.z ? tI : fstate));
+        } else {
+          const uint32_t thr = isI ? rec.x : rec.y;
+          const bool stay = isI ? (rec.z & 1u) != 0u : (rec.z & 4u) != 0u;
+          s1 = xl < thr ? tM : (stay ? st : tM);
+        }
+        if (!inside) s1 = 0;                                                              // off the matrix: leaves, and is an error if reached
+        const unsigned long long leave = __ballot(s1 != st);
+        const int l = leave ? (int) __builtin_ctzll(leave) : 63;                          // the run's last cell is lane l's
+        if (cache_ok && missed && lane <= l) mcache[slot] = rec;                          // only cells the walk really visited
+        P7X_ENS_COUNT(6, __builtin_popcountll(__ballot(missed && lane <= l)));
+        if (st != tD && lane <= l && inside) atomicAdd(&cnt[kk], 1u);                     // emitting states: one visit each
+        const int sl = __builtin_amdgcn_readlane(s1, l);
+        if (leave && sl == 0) { status |= 2; break; }                                     // the walk ran off the matrix
+        if (isM) {
+          if (dj == 0) { dj = i; dm_ = k; }
+          di = i - l; dk = k - l;
+        }
+        x = (uint32_t) __builtin_amdgcn_readlane((int) xl, l);
+        const int adv = l + 1;
+        if (st != tD) i -= adv;
+        if (st != tI) k -= adv;
+        if (leave) st = sl;
+        i = rfl(i); k = rfl(k); st = rfl(st);
+      }
+      if (status) break;
+      const int Ld = dj - di + 1;             // every residue di .. dj was emitted by exactly one M or I state of the domain
+      P7X_ENS_STAMP(2);
+      P7X_ENS_COUNT(4, Ld);
+      const int klo = k + 1;                // the lowest node the domain touched: its first match state's
+      // ---- B(i): the domain is complete -- residues di .. dj of the region, nodes dk .. dm_ (p7_trace_Index); its end points go
+      // out for clustering, its null2 odds (p7_Null2_ByTrace over the visit counts) onto the residues di+1 .. dj
+      if (dj == 0 || Ld < 1) { status |= 8; break; }
+      if (ndom < dom_cap) {
+        if (lane == 0) { int32_t *o = dom + (size_t) ndom * 5; o[0] = t; o[1] = di; o[2] = dj; o[3] = dk; o[4] = dm_; }
+      } else status |= 16;                                              // more domains than the record holds: the host repeats the region
+      ++ndom;
+      __syncthreads();                                                  // the counts are in
+      {
+        const float nrm = (float) (1.0 / (double) (float) Ld);
+        const int z = lane >> 4, xs = lane & 15;
+        float acc0 = 0.0f, acc1 = 0.0f;
+        const int lo = max(klo, 1);
+        const int q0 = max(0, lo - 1 - z * Q), q1 = min(min(Q - 1, khi - 1 - z * Q), M - 1 - z * Q);
+        int q = q0;
+        for (; q + 3 <= q1; q += 4) {                                   // four nodes' loads in flight, then the chain
+          const int kk = q + 1 + z * Q;
+          const float w0 = (float) cnt[kk] * nrm, w1 = (float) cnt[kk + 1] * nrm, w2 = (float) cnt[kk + 2] * nrm, w3 = (float) cnt[kk + 3] * nrm;
+          const float a0 = rft[(size_t) kk * 32 + xs], a1 = rft[(size_t) (kk + 1) * 32 + xs], a2 = rft[(size_t) (kk + 2) * 32 + xs], a3 = rft[(size_t) (kk + 3) * 32 + xs];
+          const float b0 = rft[(size_t) kk * 32 + 16 + xs], b1 = rft[(size_t) (kk + 1) * 32 + 16 + xs], b2 = rft[(size_t) (kk + 2) * 32 + 16 + xs], b3 = rft[(size_t) (kk + 3) * 32 + 16 + xs];
+          acc0 = acc0 + w0 * a0; acc1 = acc1 + w0 * b0;                 // an unvisited node adds w = 0: an exact no-op, as skipping it is
+          acc0 = acc0 + w1 * a1; acc1 = acc1 + w1 * b1;
+          acc0 = acc0 + w2 * a2; acc1 = acc1 + w2 * b2;
+          acc0 = acc0 + w3 * a3; acc1 = acc1 + w3 * b3;
+        }
+        for (; q <= q1; ++q) {
+          const int kk = q + 1 + z * Q;
+          const float w = (float) cnt[kk] * nrm;
+          acc0 = acc0 + w * rft[(size_t) kk * 32 + xs];
+          acc1 = acc1 + w * rft[(size_t) kk * 32 + 16 + xs];
+        }
+        accz[z * 32 + xs] = acc0; accz[z * 32 + 16 + xs] = acc1;
+      }
+      __syncthreads();
+      if (lane < 32) n2v[lane] = ((accz[lane] + accz[32 + lane]) + (accz[64 + lane] + accz[96 + lane])) + 0.0f;      // + xfactor: no N, C, J inside a domain
+      __syncthreads();
+      {   // esl_abc_FAvgScVec over the degenerate codes; gap, nonresidue and missing-data codes score 1
+        float v = 0.0f; bool set = false;
+        if (lane > K && lane <= Kp - 3) {
+          float res = 0.0f; int n = 0;
+          for (int y = 0; y < K; ++y) if ((degen_mask >> y) & 1u) { res += n2v[y]; ++n; }
+          v = res / (float) n; set = true;
+        } else if (lane == K || lane == Kp - 2 || lane == Kp - 1) { v = 1.0f; set = true; }
+        __syncthreads();
+        if (set) n2v[lane] = v;
+      }
+      __syncthreads();
+      if (n2_in_regs) {
+#pragma unroll
+        for (int j = 0; j < NR; ++j) {
+          const int pos = 1 + lane + 64 * j;
+          if (pos > dj && pos <= hi) acc[j] += 1.0f;
+          else if (pos > di && pos <= dj) acc[j] += n2v[sql[pos - 1]];
+        }
+      } else {
+        for (int pos = dj + 1 + lane; pos <= hi; pos += 64) n2[pos] += 1.0f;
+        for (int pos = di + 1 + lane; pos <= dj; pos += 64) n2[pos] += n2v[sq_in_lds ? sql[pos - 1] : sqg[pos - 1]];
+        if (!n2_in_lds) own_stores_visible();
+      }
+      hi = di;
+      for (int kk = max(klo, 0) + lane; kk <= khi; kk += 64) cnt[kk] = 0;
+      __syncthreads();
+      {
+        x = lcg_next(x);
+        const uint4 rw = row_rec(i);
+        if (choice_pick_pair(rw.z, (rw.w >> 4) & 3u, x) == 0) running = false;       // N: the rest of the trace is N ... N S
+        else st = tJ;
+      }
+      P7X_ENS_STAMP(3);
     }
     if (status == 0) {
-      for (int pos = 1 + lane; pos <= hi; pos += 64) n2[pos] += 1.0f;
-      if (!n2_in_lds) own_stores_visible();
-      __syncthreads();
+      if (n2_in_regs) {
+#pragma unroll
+        for (int j = 0; j < NR; ++j) if (1 + lane + 64 * j <= hi) acc[j] += 1.0f;
+      } else {
+        for (int pos = 1 + lane; pos <= hi; pos += 64) n2[pos] += 1.0f;
+        if (!n2_in_lds) own_stores_visible();
+        __syncthreads();
+      }
     }
   }
-  if (n2_in_lds) for (int pos = lane; pos <= Lr; pos += 64) n2g[pos] = n2[pos];
+  if (n2_in_regs) {
+#pragma unroll
+    for (int j = 0; j < NR; ++j) { const int pos = 1 + lane + 64 * j; if (pos <= Lr) n2g[pos] = acc[j]; }
+    if (lane == 0) n2g[0] = 0.0f;
+  } else if (n2_in_lds) for (int pos = lane; pos <= Lr; pos += 64) n2g[pos] = n2[pos];
   if (lane == 0) { a.out_ndom[r] = ndom; a.out_status[r] = status; }
 }
 
@@ -325,17 +538,15 @@ static int ens_forward_launch(int C, const EnsArgs &a, const int *d_reg_list, in
   return P7X_OK;
 }
 
-static size_t ens_walk_lds_bytes(int maxM, int n2_cap)
-{
-  return (size_t) (((maxM + 2 + 31) & ~31) + 32 + 128 + (n2_cap + 1) + 15) * 4;
-}
-
-static int ens_walk_launch(const EnsArgs &a, int maxM, hipStream_t st)
+static int ens_walk_launch(const EnsArgs &a, hipStream_t st)
 {
   if (a.nregions <= 0) return P7X_OK;
-  const size_t lds = ens_walk_lds_bytes(maxM, a.n2_lds_cap);
-  if (lds > 64 * 1024)
-    P7X_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(ens_walk_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds));
+  const size_t lds = (size_t) a.lds_bytes;
+  if (lds > 64 * 1024) {
+    static std::mutex mu; static size_t granted = 0;
+    std::lock_guard<std::mutex> lk(mu);
+    if (lds > granted) { P7X_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(ens_walk_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int) (128 * 1024))); granted = 128 * 1024; }
+  }
   hipLaunchKernelGGL(ens_walk_kernel, dim3((unsigned) a.nregions), dim3(64), lds, st, a);
   P7X_HIP(hipGetLastError());
   return P7X_OK;
@@ -412,7 +623,8 @@ public:
     if (!eb->stream) {
       int least = 0, greatest = 0;
       P7X_HIP(hipDeviceGetStreamPriorityRange(&least, &greatest));
-      P7X_HIP(hipStreamCreateWithPriority(&eb->stream, hipStreamNonBlocking, least));
+      // a few wavefronts, each a long serial chain, and the host stage waits for them: ahead of the filter kernels' queues
+      P7X_HIP(hipStreamCreateWithPriority(&eb->stream, hipStreamNonBlocking, greatest));
     }
     // which regions the device takes: every one whose records fit the workspace budget, and whose model the kernels cover
     size_t free_b = 0, total_b = 0;
@@ -423,11 +635,10 @@ public:
     std::vector<int64_t> reg_global;          // launched region -> global request number
     std::vector<EnsJob> ejobs(nj);
     std::map<int, std::vector<int>> by_class;
-    int64_t ncells = 0, nrows = 0;
-    int maxM = 1;
+    int64_t ncells = 0, nrows = 0, ndomrec = 0;
+    int maxM = 1, maxLr = 1;
     size_t rft_floats = 0;
     std::vector<size_t> rft_at(nj, 0);
-    const int dom_cap = nsamples * 4;
     for (size_t j = 0; j < nj; ++j) {
       EnsJob &ej = ejobs[j];
       std::memset(&ej, 0, sizeof ej);
@@ -446,8 +657,11 @@ public:
         const int64_t cells = (int64_t) (Lr + 1) * (p.M + 1);
         if ((size_t) (ncells + cells) * 40 + (size_t) (nrows + Lr + 1) * 32 > budget) continue;
         EnsRegion er;
-        er.sq = db_->h_off[t] + (rq.i - 1); er.cell0 = ncells; er.row0 = nrows; er.dom0 = (int64_t) regs.size() * dom_cap;
-        er.Lr = Lr; er.L = db_->h_len[t]; er.job = (int) j; er.pad = 0;
+        er.sq = db_->h_off[t] + (rq.i - 1); er.cell0 = ncells; er.row0 = nrows; er.dom0 = ndomrec;
+        er.Lr = Lr; er.L = db_->h_len[t]; er.job = (int) j;
+        er.dom_cap = nsamples * std::min(64, 4 + 4 * Lr / (p.M + 16));   // a region whose samples average more domains than that goes back to the host
+        ndomrec += er.dom_cap;
+        maxLr = std::max(maxLr, Lr);
         ncells += cells; nrows += Lr + 1;
         by_class[ej.C].push_back((int) regs.size());
         launched_[(size_t) (first_[j] + (int64_t) r)] = 1;
@@ -473,7 +687,7 @@ public:
     if ((st = grow_device(ctx_, eb->d_in, eb->d_in_cap, in_bytes, (size_t) 1 << 20)) != P7X_OK) return st;
     // outputs: ndom | status | dom records | null2 accumulators
     o_ndom_ = 0; o_status_ = align256((size_t) nl * 4); o_dom_ = align256(o_status_ + (size_t) nl * 4);
-    o_n2_ = align256(o_dom_ + (size_t) nl * dom_cap * 5 * 4);
+    o_n2_ = align256(o_dom_ + (size_t) ndomrec * 5 * 4);
     const size_t out_bytes = align256(o_n2_ + (size_t) nrows * 4);
     if ((st = grow_device(ctx_, eb->d_out, eb->d_out_cap, out_bytes, (size_t) 4 << 20)) != P7X_OK) return st;
     if ((st = grow_pinned(eb->h_out, eb->h_out_cap, out_bytes, (size_t) 4 << 20)) != P7X_OK) return st;
@@ -508,18 +722,22 @@ public:
     a.rows = reinterpret_cast<ChoiceRow *>(eb->work + o_rows);
     a.seed_x = seed_state; a.nsamples = nsamples;
     a.n2acc = reinterpret_cast<float *>(eb->d_out + o_n2_);
-    a.dom = reinterpret_cast<int32_t *>(eb->d_out + o_dom_); a.dom_cap = dom_cap;
+    a.dom = reinterpret_cast<int32_t *>(eb->d_out + o_dom_);
     a.out_ndom = reinterpret_cast<int32_t *>(eb->d_out + o_ndom_); a.out_status = reinterpret_cast<int32_t *>(eb->d_out + o_status_);
-    {   // accumulators in LDS for regions that fit beside the node counts in 60 KiB
-      const long words = 60 * 256 - (((maxM + 2 + 31) & ~31) + 32 + 128 + 1 + 15);
-      a.n2_lds_cap = (int) std::max(0L, words);
+    {   // LDS of the walk kernel: node counts and the null2 scratch always; then, as far as 128 KiB go, the largest region's row
+        // records, residues and accumulators, the longest model's odds table and eight of its Forward rows (each region
+        // takes what fits, in that order), and the record caches of the core walk in the rest (48 KiB when there is room,
+        // never less than 4 KiB)
+      const size_t least = (size_t) (((maxM + 2 + 31) & ~31) + 32 + 128 + 8) * 4 + 64 + 4096;
+      const size_t want = least + (size_t) (maxLr + 1) * 25 + 128 + (size_t) (maxM + 1) * (128 + 64) + 44 * 1024;
+      a.lds_bytes = (int) std::max(least, std::min(want, (size_t) 128 * 1024));
     }
     const int32_t *d_lists = reinterpret_cast<const int32_t *>(eb->d_in + o_lists);
     for (const auto &run : runs)
       if ((st = ens_forward_launch(run.first, a, d_lists + run.second.first, run.second.second, s)) != P7X_OK) return st;
-    if ((st = ens_walk_launch(a, maxM, s)) != P7X_OK) return st;
+    if ((st = ens_walk_launch(a, s)) != P7X_OK) return st;
     P7X_HIP(hipMemcpyAsync(eb->h_out, eb->d_out, out_bytes, hipMemcpyDeviceToHost, s));
-    regs_ = std::move(regs); dom_cap_ = dom_cap;
+    regs_ = std::move(regs);
     return P7X_OK;
   }
 
@@ -551,7 +769,7 @@ private:
   std::vector<int64_t> first_, reg_global_;
   std::vector<char> launched_;
   std::vector<EnsRegion> regs_;
-  int64_t nreg_ = 0; int nlaunched_ = 0, dom_cap_ = 0;
+  int64_t nreg_ = 0; int nlaunched_ = 0;
   EnsBuffers *lease_ = nullptr;
   size_t o_ndom_ = 0, o_status_ = 0, o_dom_ = 0, o_n2_ = 0;
 };
@@ -615,3 +833,12 @@ extern "C" int p7x_debug_ensemble(const p7x_oprofile *om, const p7x_seqdb *db, i
   std::memcpy(n2, raw.n2.data(), (size_t) (Lr + 1) * 4);
   return P7X_OK;
 }
+
+#ifdef P7X_ENS_PROFILE
+extern "C" int p7x_debug_ens_profile(unsigned long long *out8)
+{
+  unsigned long long zero[8] = { 0 };
+  if (hipMemcpyFromSymbol(out8, HIP_SYMBOL(p7x::g_ens_prof), sizeof zero) != hipSuccess) return 1;
+  return hipMemcpyToSymbol(HIP_SYMBOL(p7x::g_ens_prof), zero, sizeof zero) != hipSuccess;
+}
+#endif

@@ -172,7 +172,7 @@ struct EnsRegion {          // one multi-domain region, as both kernels see it
   int64_t row0;             // first row record; rows 0 .. Lr.  The null2 accumulators use the same offsets
   int64_t dom0;             // first domain record of the region's output
   int32_t Lr, L;            // region length; full target length (the length model)
-  int32_t job, pad;
+  int32_t job, dom_cap;     // the profile; room for this many domain records at dom0
 };
 struct EnsJob {             // per query profile
   int M, C, K, Kp, nrows, Q;          // Q = p7O_NQF(M): select_e walks the reference's striped order
@@ -188,9 +188,9 @@ struct EnsArgs {
   uint32_t seed_x;          // the generator's state after esl_randomness_Init(seed): every region starts there
   int nsamples;
   float *n2acc;             // [rows] per residue: sum over the samples of the null2 odds ratio (1 outside domains)
-  int32_t *dom; int dom_cap;   // [5] per domain: sample, sqfrom, sqto (1-based inside the region), hmmfrom, hmmto; dom_cap per region
+  int32_t *dom;             // [5] per domain: sample, sqfrom, sqto (1-based inside the region), hmmfrom, hmmto
   int32_t *out_ndom; int32_t *out_status;               // per region
-  int n2_lds_cap;           // regions up to this length keep their accumulators in LDS
+  int lds_bytes;            // dynamic LDS of the walk kernel: what fits of a region's row records, accumulators and odds table lives there
 };
 
 // ---- long-target SSV scan (p7x_ssvlong.hip): one chunk of one strand per wavefront, model split across the lanes

@@ -681,7 +681,7 @@ void p7x_pipeline_cfg_default(p7x_pipeline_cfg *c)
   c->do_max = 0; c->do_biasfilter = 1; c->do_null2 = 1;
   c->seed = 42; c->mode = P7X_SEARCH_SEQS; c->host_threads = 0; c->host_envelopes = 0; c->host_regions = 0; c->host_ensembles = 0;
   c->long_targets = 0; c->strands = P7X_STRAND_BOTH; c->B1 = 100; c->B2 = 240; c->B3 = 1000;      // p7_pipeline_Create
-  c->block_length = 0x40000; c->window_length = -1; c->evalue_window_length = -1; c->oa_guard = 4e-6f; c->lt_part = 0; c->lt_nparts = 1;
+  c->block_length = 0x40000; c->window_length = -1; c->evalue_window_length = -1; c->oa_guard = 0.0f; c->lt_part = 0; c->lt_nparts = 1;
   c->f3_guard = 4e-3f;
   c->lt_resident_key = 0;
 }

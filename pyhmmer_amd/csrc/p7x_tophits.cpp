@@ -414,17 +414,11 @@ int host_finish_batch(const p7x_pipeline_cfg &cfg_in, const std::vector<FinishIt
       }
       std::stable_sort(heavy.begin(), heavy.end(), [&](int a, int b) { return cost[(size_t) a] > cost[(size_t) b]; });
     }
-    // 2. the envelope kernels run while the host resolves the multi-domain regions (stochastic traceback
-    //    ensembles: inherently sequential per region, so they are spread over the workers target by target)
+    // 2. The stochastic traceback ensembles of the multi-domain regions are the longest chain of this stage: sampled on the
+    //    device when there is a runner (every region starts from the re-seeded generator, so regions are independent of each
+    //    other), they are queued first; the single-domain envelopes' kernel follows on its own stream.  Without a runner --
+    //    or for a region it hands back -- the host workers sample (one serial walk per region, spread target by target).
     const auto t1 = std::chrono::steady_clock::now();
-    std::vector<EnvelopeJob> jobs((size_t) nq);
-    bool any = false;
-    for (int q = 0; q < nq; ++q) { jobs[(size_t) q] = EnvelopeJob{ items[(size_t) q].om, &req[(size_t) q], items[(size_t) q].targets }; any = any || !req[(size_t) q].empty(); }
-    if (any) { const int st = scorer->begin(jobs); if (st != P7X_OK) return st; }
-    tick("env_begin");
-    // The stochastic traceback ensembles of the multi-domain regions: sampled on the device when there is a runner (every
-    // region starts from the re-seeded generator, so regions are independent of each other); what remains here is the
-    // clustering of the sampled end points.  Without a runner -- or for a region it hands back -- the host samples.
     std::vector<std::vector<EnvelopeRequest>> ereq((size_t) nq);
     std::vector<std::vector<EnsembleResult>> eres;
     std::vector<std::vector<int>> ereq_index((size_t) S);
@@ -437,13 +431,22 @@ int host_finish_batch(const p7x_pipeline_cfg &cfg_in, const std::vector<FinishIt
       }
       std::vector<EnvelopeJob> ejobs((size_t) nq);
       for (int q = 0; q < nq; ++q) ejobs[(size_t) q] = EnvelopeJob{ items[(size_t) q].om, &ereq[(size_t) q], items[(size_t) q].targets };
-      int st = ensembles->begin(ejobs, fast_rng_state(cfg_in.seed), 200);
+      const int st = ensembles->begin(ejobs, fast_rng_state(cfg_in.seed), 200);
       if (st != P7X_OK) return st;
       tick("ens_begin");
-      if ((st = ensembles->wait(eres)) != P7X_OK) return st;
+    }
+    std::vector<EnvelopeJob> jobs((size_t) nq);
+    bool any = false;
+    for (int q = 0; q < nq; ++q) { jobs[(size_t) q] = EnvelopeJob{ items[(size_t) q].om, &req[(size_t) q], items[(size_t) q].targets }; any = any || !req[(size_t) q].empty(); }
+    if (any) { const int st = scorer->begin(jobs); if (st != P7X_OK) return st; }
+    tick("env_begin");
+    if (dev_ens) {
+      const int st = ensembles->wait(eres);
+      if (st != P7X_OK) return st;
       tick("ens_wait");
     }
-    // the ensembles' clustered envelopes go to the device as a second round (scorer2) instead of being rescored here
+    // what remains of a region's resolution here is the clustering of the sampled end points; the clustered envelopes go
+    // to the device as a second round (scorer2) instead of being rescored here
     std::vector<std::vector<EnvelopeRequest>> local2((size_t) S);
     run_pool((int) heavy.size(), [&](int h) {
       const int f = heavy[(size_t) h], q = q_of[(size_t) f], i = f - first[(size_t) q];
@@ -470,28 +473,36 @@ int host_finish_batch(const p7x_pipeline_cfg &cfg_in, const std::vector<FinishIt
     }
     std::vector<std::vector<EnvelopeResult>> res((size_t) nq), res2((size_t) nq);
     if (any) { const int st = scorer->wait(res); if (st != P7X_OK) return st; }
-    if (any2) { const int st = scorer2->wait(res2); if (st != P7X_OK) return st; }
-    if (!any2) res2.assign((size_t) nq, {});
-    ms_env = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t1).count();
     tick("env_wait");
-    // 3. alignment displays, null2 corrections, per-target scores
-    if (failed.load() == 0)
-      run_pool(S, [&](int f) {
-        const int q = q_of[(size_t) f];
-        if (!on_device(q) || dropped[(size_t) f]) return;
-        const int i = f - first[(size_t) q];
-        const int t = (*items[(size_t) q].targets)[(size_t) i];
-        domaindef_finish_deferred(items[(size_t) q].om->p, tg.dsq + tg.off[t] - 1, tg.len[t], res[(size_t) q], req_index[(size_t) f], dds[(size_t) f],
-                                  &res2[(size_t) q], &req_index2[(size_t) f]);
-        finish(f, dds[(size_t) f]);
-      });
+    // 3. alignment displays, null2 corrections, per-target scores: the targets without a second-round envelope while that
+    //    round runs, the others when it is in
+    std::vector<char> second((size_t) S, 0);
+    if (any2) for (int f : heavy) if (!local2[(size_t) f].empty()) second[(size_t) f] = 1;
+    auto complete = [&](int f) {
+      const int q = q_of[(size_t) f];
+      if (!on_device(q) || dropped[(size_t) f]) return;
+      const int i = f - first[(size_t) q];
+      const int t = (*items[(size_t) q].targets)[(size_t) i];
+      domaindef_finish_deferred(items[(size_t) q].om->p, tg.dsq + tg.off[t] - 1, tg.len[t], res[(size_t) q], req_index[(size_t) f], dds[(size_t) f],
+                                &res2[(size_t) q], &req_index2[(size_t) f]);
+      finish(f, dds[(size_t) f]);
+    };
+    if (!any2) res2.assign((size_t) nq, {});
+    if (failed.load() == 0) run_pool(S, [&](int f) { if (!second[(size_t) f]) complete(f); });
+    tick("deferred");
+    if (any2) {
+      const int st = scorer2->wait(res2); if (st != P7X_OK) return st;
+      tick("env2_wait");
+      if (failed.load() == 0) run_pool((int) heavy.size(), [&](int h) { const int f = heavy[(size_t) h]; if (second[(size_t) f]) complete(f); });
+      tick("deferred2");
+    }
+    ms_env = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t1).count();
   }
   for (int f = 0; f < S; ++f) {
     p7x_tophits &th = *ths[(size_t) q_of[(size_t) f]];
     th.oa_redone += dds[(size_t) f].nneartie;
     for (int b = 0; b < 8; ++b) th.oa_why[b] += dds[(size_t) f].neartie_why[b];
   }
-  tick("deferred");
   host_prof_dump();
   if (failed.load() != 0) { set_error("domain definition workflow failure"); return failed.load(); }
   const double ms_host = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();

@@ -74,12 +74,15 @@ def test_device_envelopes_on_planted_workload():
     db = plan7.SequenceDatabase.from_packed(hmm.alphabet, flat, off, ln)
     nhits, ndom = _compare(hmm, db)
     assert nhits >= 900 and ndom >= nhits
-    # the guard is what makes the comparison above exact: it acts on a small fraction of the envelopes ...
+    # the comparison above ran without the near-tie guard (the default since the host twin sums in the device's order) ...
     hits = plan7.Pipeline(hmm.alphabet).search_hmm(hmm, db)
-    redone = hits.guard_counts["oa_redone"]
+    assert hits.guard_counts["oa_redone"] == 0
+    # ... which still exists as a diagnostic: it flags a small fraction of the envelopes and has the host twin repeat them,
+    # to the same result
+    guarded = plan7.Pipeline(hmm.alphabet, oa_guard=4e-6).search_hmm(hmm, db)
+    redone = guarded.guard_counts["oa_redone"]
     assert 0 < redone <= ndom // 20, (redone, ndom)
-    # ... and can be switched off (every envelope then keeps the device's own trace)
-    assert plan7.Pipeline(hmm.alphabet, oa_guard=0.0).search_hmm(hmm, db).guard_counts["oa_redone"] == 0
+    assert _records(guarded) == _records(hits)
 
 
 @pytest.mark.parametrize("M", [5, 64, 65, 150, 256, 300, 384, 478, 500, 640, 768, 1000, 1024, 1100, 1500, 2048, 2049, 3000, 5000, 8192])
