@@ -66,6 +66,30 @@ def emit_from_model(hmm, rng, tabs):
     return np.minimum(np.array(out, dtype=np.uint8), hmm.alphabet.K - 1)
 
 
+def pipe_opts(depth, feeders, finishers):
+    """Keyword arguments for hmmer.hmmsearch: only what a command line flag set; everything else is the library's default."""
+    o = {}
+    if depth is not None:
+        o["pipeline_depth"] = depth
+    if feeders is not None:
+        o["feeders"] = feeders
+    if finishers is not None:
+        o["finishers"] = finishers
+    return o
+
+
+def pipe_effective(depth, feeders, finishers):
+    """What the search runs with (the library's defaults where no flag was given), for the report."""
+    import inspect
+    from pyhmmer_amd import hmmer
+    d = {k: v.default for k, v in inspect.signature(hmmer.hmmsearch).parameters.items() if k in ("pipeline_depth", "feeders", "finishers")}
+    d.update(pipe_opts(depth, feeders, finishers))
+    if not d["finishers"]:
+        d["finishers"] = max(d["feeders"], d["pipeline_depth"])
+    d["library_defaults"] = not pipe_opts(depth, feeders, finishers)
+    return d
+
+
 def make_workload(hmm, nseq, L, seed, planted_frac=0.001):
     """Flat arrays in the C-ABI's input format: 255 x1..xL 255 x1..xL 255 ..."""
     from pyhmmer_amd import plan7
@@ -246,7 +270,7 @@ def run_pfam(args, rank, world, local_rank, dist, red_dev, torch, host_threads, 
     t_tgt = time.perf_counter() - t0
 
     def search(qs):
-        return list(hmmer.hmmsearch(qs, db, cpus=host_threads, batch=args.pfam_batch, pipeline_depth=args.pfam_depth, feeders=args.feeders, finishers=args.pfam_finishers))
+        return list(hmmer.hmmsearch(qs, db, cpus=host_threads, batch=args.pfam_batch, **pipe_opts(args.pfam_depth, args.feeders, args.pfam_finishers)))
 
     def barrier():
         if dist is not None:
@@ -298,7 +322,7 @@ def run_pfam(args, rank, world, local_rank, dist, red_dev, torch, host_threads, 
         "seconds": round(t_max, 4), "ms_per_profile": round(1e3 * t_max / len(hmms), 4), "profiles_per_s": round(len(hmms) / t_max, 1),
         "search_seconds_rank0": round(t_search, 4),
         "merge_seconds_rank0": {"serialise": round(t_ser, 4), "gather": round(t_gather, 4), "merge_many": round(t_merge, 4)},
-        "batch": args.pfam_batch, "pipeline_depth": args.pfam_depth, "finishers": args.pfam_finishers,
+        "batch": args.pfam_batch, **pipe_effective(args.pfam_depth, args.feeders, args.pfam_finishers),
         "hits": nhits, "reported": nrep, "stage_counts_rank0": sc,
         "guards_rank0": {"f3_dropped": sum(h.guard_counts["f3_dropped"] for h in hits), "oa_redone": sum(h.guard_counts["oa_redone"] for h in hits)},
         # per-BATCH times (every query of a batch reports its batch's): device stages by HIP events of the first class
@@ -421,12 +445,9 @@ def main():
     ap.add_argument("--seqlen", type=int, default=300)
     ap.add_argument("--hmm", default="KR")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--pipeline-depth", type=int, default=4, help="queries whose device stage may run ahead of the host stage (0: none)")
-    ap.add_argument("--feeders", type=int, default=2, help="host threads issuing device stages (each on its own stream)")
-    ap.add_argument("--finishers", type=int, default=4,
-                    help="host-stage threads of the headline workload (and of `scan` when given): 4 = two more than feeders, which takes a "
-                         "run-to-run slow mode out of a single-profile query stream (14.4-18.0 -> 19.0-19.3 TCUPS); the library's own default "
-                         "(0 = as many as feeders) suits many-profile streams, see --pfam-finishers and DESIGN.md 4")
+    ap.add_argument("--pipeline-depth", type=int, default=None, help="A/B: batches of queries in flight (default: the library's own, hmmer.hmmsearch)")
+    ap.add_argument("--feeders", type=int, default=None, help="A/B: host threads issuing device stages (default: the library's own)")
+    ap.add_argument("--finishers", type=int, default=None, help="A/B: host-stage threads (default: the library's own, one per batch in flight)")
     ap.add_argument("--cpu-sample", type=int, default=1_000_000, help="targets timed through the CPU oracle (rank 0, N=1)")
     ap.add_argument("--queries-per-step", type=int, default=32,
                     help="a step is this many consecutive queries, each a complete search of the resident target block: the "
@@ -447,10 +468,8 @@ def main():
     ap.add_argument("--pfam-library", type=int, default=20000)
     ap.add_argument("--pfam-targets", type=int, default=500_000, help="targets in total (sharded over the GPUs)")
     ap.add_argument("--pfam-batch", type=int, default=0, help="queries per device batch (0: the library's choice)")
-    ap.add_argument("--pfam-depth", type=int, default=4)
-    ap.add_argument("--pfam-finishers", type=int, default=2,
-                    help="host-stage threads of the many-profile workload (measured: 29.0 s with 2, 34.5 s with 3 or 4 over the 20,000 profiles; "
-                         "the headline workload is the other way round, see DESIGN.md 5)")
+    ap.add_argument("--pfam-depth", type=int, default=None, help="A/B, many-profile workload (default: the library's own)")
+    ap.add_argument("--pfam-finishers", type=int, default=None, help="A/B, many-profile workload (default: the library's own)")
     args = ap.parse_args()
 
     if args.workload in ("pfam", "nhmmer"):          # development switch: the headline part shrinks to a token run
@@ -511,7 +530,7 @@ def main():
         the device stage of later queries with the host stage of earlier ones (pipeline_depth), exactly as it does for
         distinct queries."""
         last, acc = None, {}
-        for h in hmmer.hmmsearch((om for _ in range(nsteps * qps)), db, pipeline_depth=args.pipeline_depth, feeders=args.feeders, finishers=args.finishers, cpus=host_threads, batch=args.batch, **pli_opts):
+        for h in hmmer.hmmsearch((om for _ in range(nsteps * qps)), db, cpus=host_threads, batch=args.batch, **pipe_opts(args.pipeline_depth, args.feeders, args.finishers), **pli_opts):
             last = h
             for k, v in h.timings_ms.items():
                 acc[k] = acc.get(k, 0.0) + v
@@ -552,7 +571,7 @@ def main():
     # stages of two queries share the device, which raises throughput and stretches every single launch; the
     # stand-alone duration is what the kernel itself achieves.
     solo = {}
-    if args.pipeline_depth > 0 and rank == 0:
+    if pipe_effective(args.pipeline_depth, args.feeders, args.finishers)["pipeline_depth"] > 0 and rank == 0:
         n_solo = 3
         for h in hmmer.hmmsearch((om for _ in range(n_solo)), db, pipeline_depth=0, cpus=host_threads, batch=1):
             for k, v in h.timings_ms.items():
@@ -626,9 +645,9 @@ def main():
                 "timed_region": "hmmer.hmmsearch over steps x queries_per_step queries (the same profile each time), every query runs "
                                 "the complete search; device stage of later queries overlaps the host stage of earlier ones "
                                 "(pipeline_depth=%d batches); targets resident in HBM (pack+upload once: %.2fs, generation %.2fs, "
-                                "not timed)" % (args.pipeline_depth, t_pack, t_gen),
+                                "not timed)" % (pipe_effective(args.pipeline_depth, args.feeders, args.finishers)["pipeline_depth"], t_pack, t_gen),
                 "queries_per_step": qps, "queries_per_device_batch": lanes_per_launch,
-                "pipeline_depth": args.pipeline_depth, "feeders": args.feeders, "finishers": args.finishers or args.feeders, "host_threads_per_rank": host_threads,
+                **pipe_effective(args.pipeline_depth, args.feeders, args.finishers), "host_threads_per_rank": host_threads,
                 "spinup_windows_s": [round(x, 4) for x in spin],
                 "latency_ms_per_query": round(stage.get("total", 0.0), 3),
             },

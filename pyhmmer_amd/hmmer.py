@@ -160,7 +160,7 @@ def hmmpress(hmms: Iterable, output) -> int:
 
 def hmmsearch(queries: Union[HMM, Profile, OptimizedProfile, Iterable], sequences, *, cpus: int = 0,
               callback: Optional[Callable] = None, devices: Optional[Sequence[int]] = None,
-              pipeline_depth: int = 4, feeders: int = 2, finishers: int = 0, batch: int = 0,
+              pipeline_depth: int = 8, feeders: int = 2, finishers: int = 0, batch: int = 0,
               backend: Optional[str] = None, parallel: Optional[str] = None, builder=None, timeout: Optional[float] = None,
               chunk_bytes: Optional[int] = None, **options) -> Iterator[TopHits]:
     """Search HMMs against a sequence database; yields one ``TopHits`` per query, in query order.
@@ -186,14 +186,15 @@ def hmmsearch(queries: Union[HMM, Profile, OptimizedProfile, Iterable], sequence
 
     Consecutive queries are overlapped the way the reference overlaps them on worker threads
     (``hmmer/_base.py:416-489``): ``feeders`` threads run the device stage (filters and parsers) of up to
-    ``pipeline_depth`` batches of queries ahead while ``finishers`` threads (default: as many as feeders) run the host
-    stage (envelope kernel, domain definition, hit list) of the batches before them; results come back in query order.
-    How many host stages should be in flight depends on the query stream, and both ways were measured: a stream of one
-    260-node profile against a million targets (the benchmark's headline) wanders between 14.4 and 18.0 TCUPS from run
-    to run with two finishers and holds 19.0-19.3 with four, a Pfam-shaped stream of 20,000 different profiles takes
-    29.0 s with two and 34.5 s with three or four.  The default suits the second, which is what the
-    reference is used for; ``bench.py`` passes four for the first.  ``pipeline_depth=0`` runs the two stages of every
-    query back to back.
+    ``pipeline_depth`` batches of queries ahead while ``finishers`` threads (default: one per batch in flight, i.e.
+    ``pipeline_depth``) run the host stage of the batches before them; results come back in query order.  Since round 4
+    the host stage is mostly a wait for the device -- the envelope kernel, the stochastic traceback ensembles of the
+    multi-domain regions and a second envelope round for their clustered envelopes all run there, a chain of small
+    launches that takes 60-100 ms while the filter kernels of the following batches saturate the device -- so enough
+    batches must be in flight to cover that latency: the headline stream (one 262-node profile, a million targets)
+    measured 14.8-15.4 TCUPS at depth 4, 16.0 at 6 and 17.6 at 8; the many-profile stream does not depend on it
+    (34.8 s with 2, 4 or 6 host stages in flight).  One default serves both.  ``pipeline_depth=0`` runs the two stages of
+    every query back to back.
     ``sequences`` may also be a :class:`~pyhmmer_amd.plan7.SequenceDatabase` already resident on one device.
     """
     if backend not in (None, "threading", "multiprocessing"):
@@ -544,7 +545,7 @@ def _run_batches(db: "ShardedDatabase", pipelines: Sequence[Pipeline], queries: 
     nxt = 0
     # the host stage of several batches may be in flight as well (each waits for its own envelope kernel): with one
     # feeder it runs in the caller's thread, with more a small pool finishes batches concurrently, results in order
-    nfin = finishers if finishers > 0 else nfeed
+    nfin = finishers if finishers > 0 else max(nfeed, pipeline_depth)
     pool = ThreadPoolExecutor(max_workers=nfin, thread_name_prefix="p7x-hmmsearch-finish") if nfin > 1 else None
     inflight: "deque" = deque()
 
