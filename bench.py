@@ -454,6 +454,8 @@ def main():
                          "pipeline's fill and drain (about two query times) then weigh as little in a 20-step run as in a long one")
     ap.add_argument("--batch", type=int, default=0, help="headline workload: queries per device batch (0: the library's own choice)")
     ap.add_argument("--oa-guard", type=float, default=None, help="A/B: the optimal-accuracy near-tie guard (default: the library's; 0 switches it off)")
+    ap.add_argument("--debug-option", action="append", default=[], metavar="NAME=VALUE",
+                    help="diagnostics: set a knob of the library's test seam (p7x_debug_set_option), e.g. trace_finish=1")
     ap.add_argument("--host-ensembles", action="store_true", help="A/B: the stochastic traceback ensembles on the host workers instead of the device")
     ap.add_argument("--spinup-max", type=int, default=15, help="at most this many untimed 20-query windows before the warm-up")
     ap.add_argument("--workload", choices=("both", "config1", "pfam", "scan", "nhmmer"), default="both",
@@ -471,6 +473,10 @@ def main():
     ap.add_argument("--pfam-depth", type=int, default=None, help="A/B, many-profile workload (default: the library's own)")
     ap.add_argument("--pfam-finishers", type=int, default=None, help="A/B, many-profile workload (default: the library's own)")
     args = ap.parse_args()
+    for item in args.debug_option:
+        from pyhmmer_amd import _lib as _p7lib
+        name, _, value = item.partition("=")
+        _p7lib.set_debug_option(name, int(value or 1))
 
     if args.workload in ("pfam", "nhmmer"):          # development switch: the headline part shrinks to a token run
         args.steps, args.warmup, args.spinup_max, args.no_cpu_baseline = min(args.steps, 5), 0, 1, True

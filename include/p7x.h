@@ -291,6 +291,13 @@ int  p7x_debug_log_of_float(int device, const float *in, float *out, size_t n);
  *   node, a sample's domains first to last; n2[pos], pos = 1..j-i+1: the summed null2 odds ratios of the residue;
  *   status 0 = sampled. */
 int  p7x_debug_choice(const float *p, int n, uint32_t x, int *via_thresholds, int *via_fchoose);
+/* Test / diagnostic seam: process-wide knobs, by name; value -1 = not set (the library decides).  The library itself reads no
+ * environment variables.  Kernel families for parity tests: "small_block" (0: never the wave-per-target filters for small
+ * blocks), "vit_wave" (1: the wave-per-target Viterbi kernel for every model), "msv_exact" (1: no fast MSV pass),
+ * "msv_long_groups" (0: the longest groups stay with the lane kernel), "msv_blocks_per_cu" (cap), "device_clustered" (0 / 1:
+ * with host ensembles, where their clustered envelopes are rescored), "env_workspace_gb" (cap of the envelope kernel's
+ * workspace).  Traces on stderr: "trace_finish", "trace_longtarget", "trace_envelope", "host_profile" (1: on). */
+int  p7x_debug_set_option(const char *name, int value);
 int  p7x_debug_ensemble(const p7x_oprofile *om, const p7x_seqdb *db, int64_t target, int32_t i, int32_t j, uint32_t seed,
                         int use_device, int32_t *ndom, int32_t *dom, int32_t dom_cap, float *n2, int32_t *status);
 /* Parity seam of the batched cascade (the multi-profile twin of p7x_filters_batch): runs stage 1 exactly as
@@ -314,6 +321,11 @@ int  p7x_search_batch_raw(const p7x_pipeline_cfg *cfg, const p7x_oprofile *const
 int p7x_search_longtargets(const p7x_pipeline_cfg *cfg, const p7x_oprofile *om, int device,
                            const uint8_t *dsq, const int64_t *offsets, const int64_t *lengths, size_t n,
                            const char *const *names, const char *const *accs, const char *const *descs, p7x_tophits **out);
+/* The device copy that cfg.lt_resident_key keeps between searches is dropped: on <device> (-1: every device), if it carries
+ * <key> (0: whatever it carries).  The reference has no counterpart (its targets live in host memory); here the owner of a
+ * target image calls this when the image goes (pyhmmer_amd does, from a finalizer of the packed block), so that a genome
+ * does not stay pinned in HBM for the life of the process.  A search still scanning the copy keeps it until it is done. */
+int p7x_longtargets_release_resident(int device, uint64_t key);
 /* SSV window seeds of one strand of one target block as p7_SSVFilter_longtarget emits them (position of the diagonal's
  * first residue, model node of its last cell, diagonal length), for tests against the oracle: the device scan followed
  * by upstream's sequential bookkeeping.  seeds: caller array of cap x 3 int64; returns the number found (may exceed cap)

@@ -203,6 +203,8 @@ _SIGNATURES = {
     "p7x_pending_nqueries": (C.c_size_t, [_VP]),
     "p7x_debug_log_of_float": (C.c_int, [C.c_int, _VP, _VP, C.c_size_t]),
     "p7x_debug_choice": (C.c_int, [_VP, C.c_int, C.c_uint32, _VP, _VP]),
+    "p7x_debug_set_option": (C.c_int, [C.c_char_p, C.c_int]),
+    "p7x_longtargets_release_resident": (C.c_int, [C.c_int, C.c_uint64]),
     "p7x_debug_ensemble": (C.c_int, [_VP, _VP, C.c_int64, C.c_int32, C.c_int32, C.c_uint32, C.c_int, _VP, _VP, C.c_int32, _VP, _VP]),
     "p7x_search_batch_raw": (C.c_int, [C.POINTER(PipelineCfg), C.POINTER(_VP), C.c_size_t, _VP, _VP, _VP, _VP, _VP]),
     "p7x_search_longtargets": (C.c_int, [C.POINTER(PipelineCfg), _VP, C.c_int, _VP, _VP, _VP, C.c_size_t, _VP, _VP, _VP, C.POINTER(_VP)]),
@@ -250,3 +252,9 @@ def declared_symbols():
 def last_error() -> str:
     e = lib().p7x_last_error()
     return e.decode() if e else ""
+
+
+def set_debug_option(name: str, value: int) -> None:
+    """Test / diagnostic seam (``p7x_debug_set_option``): kernel-family choices for parity tests, traces.  -1 unsets."""
+    if lib().p7x_debug_set_option(name.encode(), int(value)) != 0:
+        raise ValueError(last_error())

@@ -27,8 +27,8 @@ namespace p7x {
 
 int vit_pick_C(int M);          // p7x_vitfwd.hip: nodes per lane of the wave-per-target kernels, a function of M alone
 
-// optional host profile (P7X_HOST_PROF=1): accumulated nanoseconds per phase, printed by host_prof_dump()
-static bool g_prof_on = std::getenv("P7X_HOST_PROF") != nullptr;
+// optional host profile (option "host_profile"): accumulated nanoseconds per phase, printed by host_prof_dump()
+#define g_prof_on (debug_opt(OPT_HOST_PROFILE) > 0)
 static std::atomic<long long> g_prof_ns[12];
 static const char *g_prof_name[12] = { "domain_decoding", "region_forward", "stochastic_traces", "null2_by_trace", "cluster",
                                         "env_forward", "env_backward", "env_decoding", "optimal_accuracy", "oa_trace+display",
@@ -415,6 +415,8 @@ P7X_MULTIVERSION int backward_full(const Model &om, const uint8_t *dsq, int L, c
 }
 
 // ---------------------------------------------------------------- p7_Decoding: posteriors into <bck> (in place)
+// NOTE: only the M and I posteriors are formed.  bck.D_ keeps Backward's delete values afterwards (upstream zeroes them): a
+// future reader of the delete "posteriors" must not take them from here.
 P7X_MULTIVERSION int decoding(const Model &om, const Matrix &fwd, Matrix &bck)
 {
   const int M = om.M, L = fwd.L;

@@ -43,6 +43,8 @@ __device__ __forceinline__ void phase_fence()
   // stores have left the wavefront (vmcnt(0)) and the CU's vector cache is coherent for its own stores.  Agent scope
   // would write back and invalidate the XCD's whole L2 (buffer_wbl2 / buffer_inv sc1) four times per envelope and
   // wavefront -- taking the lines of every other wavefront and of the filter kernels running beside this one with it.
+  // (This relies on the wavefront's producer and consumer lanes sharing one CU's vector cache: the kernels of this file must
+  // not be built for tgsplit mode, where a work-group may straddle CUs.)
   __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
 }
 
@@ -704,7 +706,7 @@ static int occupancy_env(K kernel, int kEnvBlock, size_t lds_bytes, int *per_cu)
   if (lds_bytes > 64 * 1024)
     P7X_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds_bytes));
   P7X_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(per_cu, kernel, kEnvBlock, lds_bytes));
-  if (std::getenv("P7X_ENV_DEBUG")) {
+  if (debug_opt(OPT_TRACE_ENVELOPE) > 0) {
     hipFuncAttributes fa; (void) hipFuncGetAttributes(&fa, reinterpret_cast<const void *>(kernel));
     std::fprintf(stderr, "[env] occupancy %d blocks/CU of %d threads, lds %zu, regs %d, static lds %zu, maxthreads %d\n", *per_cu, kEnvBlock, lds_bytes,
                  fa.numRegs, fa.sharedSizeBytes, fa.maxThreadsPerBlock);

@@ -51,7 +51,7 @@ static void release_env_buffers(EnvBuffers *eb)
 static size_t env_budget_bytes()
 {
   size_t gb = 24;
-  if (const char *e = std::getenv("P7X_ENV_WORKSPACE_GB")) { const long v = std::atol(e); if (v > 0) gb = (size_t) v; }
+  if (debug_opt(OPT_ENV_WORKSPACE_GB) > 0) gb = (size_t) debug_opt(OPT_ENV_WORKSPACE_GB);      // tests: a workspace too small for every envelope at once
   size_t free_b = 0, total_b = 0;
   if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && free_b / 2 < gb << 30) return free_b / 2;
   return gb << 30;
@@ -64,7 +64,7 @@ public:
 
   int begin(const std::vector<EnvelopeJob> &jobs) override
   {
-    static const bool debug = std::getenv("P7X_FINISH_DEBUG") != nullptr;
+    const bool debug = debug_opt(OPT_TRACE_FINISH) > 0;
     auto tlast = std::chrono::steady_clock::now();
     std::string dbg;
     auto tick = [&](const char *what) {

@@ -40,6 +40,19 @@ static std::map<int, std::shared_ptr<ResidentTargets>> &resident_by_device()
   return *m;
 }
 
+// Lets go of the kept copy of <device> (-1: every device) if it carries <key> (0: whatever it carries).  A search still
+// scanning it holds its own reference: the memory goes when that search is done.
+extern "C" int p7x_longtargets_release_resident(int device, uint64_t key)
+{
+  std::lock_guard<std::mutex> lk(g_resident_mu);
+  auto &m = resident_by_device();
+  for (auto it = m.begin(); it != m.end(); ) {
+    if ((device < 0 || it->first == device) && (key == 0 || it->second->key == key)) it = m.erase(it);
+    else ++it;
+  }
+  return P7X_OK;
+}
+
 // <seq1> (1-based, L residues) on the device: the kept copy when the key and the size match, else a fresh upload --
 // kept in its place when there is a key.  *uploaded tells which it was (timing, tests).
 static int resident_targets(DeviceCtx *ctx, int device, uint64_t key, const uint8_t *seq1, int64_t L, std::shared_ptr<ResidentTargets> &out, bool *uploaded)
@@ -86,7 +99,7 @@ static int scan_target(const p7x_pipeline_cfg &cfg, const Profile &p, DeviceCtx 
   std::shared_ptr<ResidentTargets> d_seq;
   bool uploaded = false;
   if ((st = resident_targets(ctx, device, resident_key, seq1, L, d_seq, &uploaded)) != P7X_OK) return st;
-  if (std::getenv("P7X_LT_DEBUG")) std::fprintf(stderr, "[lt] targets on the device: %s (%lld bytes, key %llu)\n", uploaded ? "uploaded" : "resident", (long long) L, (unsigned long long) resident_key);
+  if ((debug_opt(OPT_TRACE_LONGTARGET) > 0)) std::fprintf(stderr, "[lt] targets on the device: %s (%lld bytes, key %llu)\n", uploaded ? "uploaded" : "resident", (long long) L, (unsigned long long) resident_key);
   P7X_HIP(hipMemcpyAsync(d_tab4.p, tab4.data(), tab4.size() * 4, hipMemcpyHostToDevice, s));
   P7X_HIP(hipMemcpyAsync(d_full.p, tab_full.data(), tab_full.size() * 4, hipMemcpyHostToDevice, s));
   P7X_HIP(hipMemcpyAsync(d_comp.p, longtarget_complement(p.abc_type), 18, hipMemcpyHostToDevice, s));
@@ -390,6 +403,7 @@ int p7x_search_longtargets(const p7x_pipeline_cfg *cfg, const p7x_oprofile *om, 
 {
   if (!cfg || !om || !out || (n && (!dsq || !offsets || !lengths))) { set_error("p7x_search_longtargets: bad arguments"); return P7X_EINVAL; }
   if (!cfg->long_targets) { set_error("p7x_search_longtargets: cfg.long_targets is not set"); return P7X_EINVAL; }
+  if (cfg->lt_nparts > 1 && (cfg->lt_part < 0 || cfg->lt_part >= cfg->lt_nparts)) { set_error("p7x_search_longtargets: cfg.lt_part is not one of the cfg.lt_nparts parts"); return P7X_EINVAL; }
   const Profile &p = om->p;
   int max_length = 0, sc_thresh = 0, xB = 0;
   int st = longtarget_setup(*cfg, p, &max_length, &sc_thresh, &xB);
@@ -466,7 +480,7 @@ int p7x_search_longtargets(const p7x_pipeline_cfg *cfg, const p7x_oprofile *om, 
     });
     for (const Unit &un : units)
       for (size_t q = 0; q + 2 < un.s3.size(); q += 3) seeds.push_back(LongTargetSeed{ (int64_t) un.t, un.i, un.strand, un.s3[q], (int) un.s3[q + 1], un.s3[q + 2] });
-    if (std::getenv("P7X_LT_DEBUG"))
+    if ((debug_opt(OPT_TRACE_LONGTARGET) > 0))
       std::fprintf(stderr, "[lt] %zu targets, %lld positions: scan call %.1f ms (kernel %.1f), %zu rows, %zu seeds, seed bookkeeping %.1f ms\n", n,
                    (long long) Ltot, std::chrono::duration<double, std::milli>(ts1 - ts0).count(), ms, rows.size(), seeds.size(),
                    std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - ts1).count());

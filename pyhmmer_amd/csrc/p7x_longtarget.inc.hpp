@@ -569,7 +569,7 @@ static int lt_post_viterbi(const p7x_pipeline_cfg &cfg, const Profile &p, const 
   }
   t_long_target = nullptr;
   if (st != P7X_OK) return st == P7X_ERANGE ? P7X_OK : st;
-  if (std::getenv("P7X_LT_DEBUG")) {
+  if ((debug_opt(OPT_TRACE_LONGTARGET) > 0)) {
     std::fprintf(stderr, "[lt] window start %lld len %lld compl %d fwd %.3f: nregions %d nclustered %d nenvelopes %d ndom %zu\n",
                  (long long) window_start, (long long) window_len, (int) blk.complement, fwdsc, dd.nregions, dd.nclustered, dd.nenvelopes, dd.dcl.size());
     for (const Domain &d : dd.dcl) std::fprintf(stderr, "[lt]   env %lld-%lld ali %lld-%lld hmm %d-%d envsc %.3f domcorr %.3f\n", (long long) d.ienv, (long long) d.jenv,
@@ -809,7 +809,7 @@ static int lt_run_host(const p7x_pipeline_cfg &cfg, const p7x_oprofile *om, cons
   auto seq_of = [&](const BlockJob &job) { return dsq + offsets[job.t] - 1; };      // seq[1..Lt] of the job's target
   auto target_of = [&](const BlockJob &job) { const size_t t = job.t; return LtTarget{ (int64_t) t, names ? names[t] : nullptr, accs ? accs[t] : nullptr, descs ? descs[t] : nullptr, lengths[t] }; };
   // P7X_LT_DEBUG: wall time of the phases of this function
-  const bool dbg = std::getenv("P7X_LT_DEBUG") != nullptr;
+  const bool dbg = debug_opt(OPT_TRACE_LONGTARGET) > 0;
   auto t_last = std::chrono::steady_clock::now();
   auto tick = [&](const char *what) {
     if (!dbg) return;

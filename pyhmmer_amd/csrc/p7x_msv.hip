@@ -479,7 +479,7 @@ static int launch_RK(const ArgRun<MsvArgs> &main, const ArgRun<MsvArgs> *amb, in
   // fast kernel over every group, then the exact kernel over the (normally empty) lists of ambiguous groups
   int per_cu2 = info.per_cu_fast;
   // A/B switch: cap the resident blocks per CU so that other kernels' wavefronts fit beside the MSV row registers
-  static const int cap = std::getenv("P7X_MSV_BLOCKS_PER_CU") ? std::atoi(std::getenv("P7X_MSV_BLOCKS_PER_CU")) : 0;
+  const int cap = debug_opt(OPT_MSV_BLOCKS_PER_CU);
   if (cap > 0 && per_cu2 > cap) per_cu2 = cap;
   const unsigned gx2 = lane_grid(want, (long) num_cu * per_cu2, main.n);
   hipLaunchKernelGGL((msv_fast_kernel<R, K>), dim3(gx2, (unsigned) main.n), dim3(BLK), lds_bytes, st, main.ref());

@@ -677,22 +677,17 @@ static WaveSeqArgs ws_args(const Profile &p, const DevProfile *dp, const p7x_seq
   return a;
 }
 
-static const bool g_msv_exact_only = std::getenv("P7X_MSV_EXACT") != nullptr;   // A/B switch for profiling
-static const bool g_vit_wave = std::getenv("P7X_VIT_WAVE") != nullptr;            // A/B: wave-per-target Viterbi kernel
-static const bool g_host_envelopes = std::getenv("P7X_HOST_ENVELOPES") != nullptr;   // A/B: rescore envelopes on the host
-static const bool g_host_regions = std::getenv("P7X_HOST_REGIONS") != nullptr;       // A/B: region scan on the host
-// The ensembles' clustered envelopes can go to the envelope kernel as a second round instead of being rescored by the host
-// workers: 20 % less host thread time per query, but the second launch sits on the host stage's critical path.  On a
-// box with enough CPUs per device the host is not the bottleneck and the round trip only costs (config 2, 16 CPUs:
-// 16.7 vs 17.1 TCUPS), so it is opt-in -- meant for nodes where many ranks share few cores.
-// The clustered envelopes of the stochastic ensembles (about two per multi-domain region, a third of the host stage's
-// thread time) can be rescored by the envelope kernel as a second round instead of by the host workers: identical
-// results either way.  P7X_DEVICE_CLUSTERED=0/1 decides; unset, the host workers do it where there are many of them and the
-// device where there are few (measured on the benchmark: 16 threads 19.1 vs 18.7-19.2 TCUPS, 8 threads 10.0 vs 11.1).
+// kernel families and placements a parity test or an A/B run can force through the test seam p7x_debug_set_option (p7x.h)
+static bool msv_exact_only() { return debug_opt(OPT_MSV_EXACT) > 0; }      // only the exact MSV kernel (no fast pass)
+static bool vit_wave_only() { return debug_opt(OPT_VIT_WAVE) > 0; }        // the wave-per-target Viterbi kernel for every model
+// With host_ensembles set (the stochastic ensembles stay on the host workers) their clustered envelopes -- about two per
+// multi-domain region -- can still be rescored by the envelope kernel as a second round: identical results either way.
+// The host workers do it where there are many of them and the device where there are few (round 3, 16 threads 19.1 vs
+// 18.7-19.2 TCUPS, 8 threads 10.0 vs 11.1); option "device_clustered" forces either.
 static bool device_clustered(int host_threads)
 {
-  const char *e = std::getenv("P7X_DEVICE_CLUSTERED");                     // read per call (tests)
-  if (e && *e) return std::atoi(e) != 0;
+  const int forced = debug_opt(OPT_DEVICE_CLUSTERED);
+  if (forced >= 0) return forced != 0;
   const int threads = host_threads > 0 ? std::min(host_threads, tophits_usable_cpus()) : tophits_usable_cpus();
   return threads < 12;
 }
@@ -700,11 +695,11 @@ static bool device_clustered(int host_threads)
 // The lane-per-target MSV and the 8-lanes-per-target Viterbi need many (profile, 64-target group) pairs to fill the
 // device and run for as long as the longest member of a group takes one wavefront.  A batch with at most one such
 // pair per SIMD (one profile against a scan's query sequences, the fixture proteome) goes one target per wavefront
-// through the filters instead.  P7X_SMALL_BLOCK=0 disables the switch (A/B, and the tests' second pass).
+// through the filters instead.  Option "small_block" = 0 disables the switch (the tests run every filter through both
+// families of kernels).
 static bool small_block(const p7x_seqdb *db, const DeviceCtx *ctx, int nlanes)
-{ // read per call: the tests run every filter through both families of kernels
-  const char *e = std::getenv("P7X_SMALL_BLOCK");
-  return !(e && std::atoi(e) == 0) && db->ngroups * (int64_t) nlanes <= (int64_t) ctx->num_cu * 4;
+{
+  return debug_opt(OPT_SMALL_BLOCK) != 0 && db->ngroups * (int64_t) nlanes <= (int64_t) ctx->num_cu * 4;
 }
 
 // The lane-per-target MSV kernel walks a 64-target group for as long as its longest member: one 8000-residue protein
@@ -714,8 +709,7 @@ static bool small_block(const p7x_seqdb *db, const DeviceCtx *ctx, int nlanes)
 // throughput, not by the tail).  With many lanes (profiles) per launch the average grows and fewer groups qualify.
 static int long_groups(const p7x_seqdb *db, const DeviceCtx *ctx, int nlanes)
 {
-  static const bool off = std::getenv("P7X_MSV_LONG_GROUPS") && std::atoi(std::getenv("P7X_MSV_LONG_GROUPS")) == 0;
-  if (off || db->ngroups < 2) return 0;
+  if (debug_opt(OPT_MSV_LONG_GROUPS) == 0 || db->ngroups < 2) return 0;
   const int64_t resident = (int64_t) ctx->num_cu * 4 * 3;           // wavefronts the lane kernel keeps in flight
   const int64_t G = db->ngroups;
   int64_t g = 0;
@@ -740,7 +734,7 @@ static void fill_msv_args(LaneArgs &la, const Profile &p, const DevProfile *dp, 
   a.base = p.base_b; a.bias = p.bias_b; a.tec = p.tec_b; a.tbm = p.tbm_b;
   a.counter = &b.counters[0]; a.out_xJ = b.xJ;
   a.amb_count = &b.counters[10]; a.counter2 = &b.counters[11];
-  a.amb_groups = g_msv_exact_only ? nullptr : b.list_fin;     // list_fin is free until the Forward stage
+  a.amb_groups = msv_exact_only() ? nullptr : b.list_fin;     // list_fin is free until the Forward stage
   la.msv = a;
   MsvArgs x = a;
   x.group_list = a.amb_groups; x.group_count = a.amb_count; x.counter = a.counter2; x.amb_groups = nullptr;
@@ -792,7 +786,7 @@ static long msv_key_of(const DevProfile *dp, bool small)
 }
 static long vit_key_of(const DevProfile *dp, bool small)
 {
-  return (dp->vitpkT > 0 && !g_vit_wave && !small) ? (long) (dp->vitpkT * 256 + dp->vitpkP) : -(long) dp->vitC;
+  return (dp->vitpkT > 0 && !vit_wave_only() && !small) ? (long) (dp->vitpkT * 256 + dp->vitpkP) : -(long) dp->vitC;
 }
 
 static int lane_classes(const std::vector<LaneModel> &lm, const p7x_seqdb *db, const DeviceCtx *ctx, std::vector<LaneClass> &out)
@@ -822,7 +816,7 @@ static int class_msv(const LaneClass &c, const std::vector<LaneModel> &lm, Devic
     if (st != P7X_OK) return st;
   }
   const ArgRun<MsvArgs> amb = lane_run(ws, &LaneArgs::msv_amb, c.first, c.n);
-  return msv_launch(lm[c.first].dp->msvR, lm[c.first].dp->msvK, lane_run(ws, &LaneArgs::msv, c.first, c.n), g_msv_exact_only ? nullptr : &amb, ctx->num_cu, stream);
+  return msv_launch(lm[c.first].dp->msvR, lm[c.first].dp->msvK, lane_run(ws, &LaneArgs::msv, c.first, c.n), msv_exact_only() ? nullptr : &amb, ctx->num_cu, stream);
 }
 
 // Viterbi filter over the lanes' work lists: the packed kernel when the model fits it, else one target per wavefront.
@@ -1075,7 +1069,7 @@ static int cascade_enqueue(CascadeRun &r)
   std::stable_sort(r.query_of.begin(), r.query_of.end(), [&](int a, int b) { return r.oms[a]->p.M < r.oms[b]->p.M; });
   r.lane_of.resize(nq); r.lm.resize(nq);
   for (int l = 0; l < nq; ++l) { r.lane_of[r.query_of[l]] = l; r.lm[l].om = r.oms[r.query_of[l]]; }
-  static const bool debug = std::getenv("P7X_FINISH_DEBUG") != nullptr;
+  const bool debug = debug_opt(OPT_TRACE_FINISH) > 0;
   auto tlast = std::chrono::steady_clock::now();
   std::string dbg;
   auto tick = [&](const char *what) {
@@ -1096,7 +1090,7 @@ static int cascade_enqueue(CascadeRun &r)
   tick("images");
   if (db->nslots == 0 || nq == 0) return P7X_OK;
   for (int l = 0; l < nq; ++l)
-    if (r.lm[l].dp->vitC <= 0) { set_error("model too long for the device kernels (M > 8192)"); return P7X_EINVAL; }
+    if (r.lm[l].dp->vitC <= 0) { set_error("model too long for the device kernels: M > 8192 nodes (the reference has no limit, plan7.pyx:6156-6262; the lane-chunk layout of the wave-per-target kernels ends at 128 nodes per lane -- no Pfam-A model comes near it)"); return P7X_EINVAL; }
   std::vector<LaneClass> classes;
   if ((st = lane_classes(r.lm, db, ctx, classes)) != P7X_OK) return st;
   if ((st = get_workspace(db->device, db->nslots, nq, &r.ws)) != P7X_OK) return st;
@@ -1205,7 +1199,7 @@ static int fetch_lane_rows(CascadeRun &r, CascadeOut &out)
   const p7x_seqdb *db = r.db; Workspace *ws = r.ws;
   const int nfin = out.counts[4];
   if (nfin == 0) return P7X_OK;
-  bool overflow = g_host_regions || r.cfg.host_regions != 0;
+  bool overflow = r.cfg.host_regions != 0;
   for (int i = 0; i < nfin; ++i) if (out.reg_n[i] == -2) overflow = true;
   if (!overflow) return P7X_OK;     // a target with more regions than the device keeps (or the A/B switch): the host scans the rows
   // the lane's blocks are contiguous in the arena (one cursor step), in list order
@@ -1229,7 +1223,7 @@ static int cascade_collect(CascadeRun &r, std::vector<CascadeOut> &outs)
   struct Release { CascadeRun &r; ~Release() { (void) hipStreamSynchronize(r.ws->stream); release_workspace(r.ws); r.collected = true; } } release{ r };
   int st = P7X_OK;
   P7X_HIP(hipSetDevice(db->device));                      // the collecting thread may have driven another device since
-  static const bool debug = std::getenv("P7X_FINISH_DEBUG") != nullptr;
+  const bool debug = debug_opt(OPT_TRACE_FINISH) > 0;
   const auto tc0 = std::chrono::steady_clock::now();
   P7X_HIP(hipEventSynchronize(ws->ev_sync));              // our work only: other cascades run on other streams
   const auto tc1 = std::chrono::steady_clock::now();
@@ -1590,14 +1584,14 @@ int p7x_debug_log_of_float(int device, const float *in, float *out, size_t n)
   DeviceCtx *ctx = nullptr;
   const int st = get_ctx(device, &ctx);
   if (st != P7X_OK) return st;
-  float *d_in = nullptr, *d_out = nullptr;
-  P7X_HIP(hipMalloc(&d_in, n * 4)); P7X_HIP(hipMalloc(&d_out, n * 4));
+  struct Dev { void *p = nullptr; ~Dev() { if (p) (void) hipFree(p); } } b_in, b_out;       // released on every return path
+  P7X_HIP(hipMalloc(&b_in.p, n * 4)); P7X_HIP(hipMalloc(&b_out.p, n * 4));
+  float *d_in = static_cast<float *>(b_in.p), *d_out = static_cast<float *>(b_out.p);
   P7X_HIP(hipMemcpy(d_in, in, n * 4, hipMemcpyHostToDevice));
   hipLaunchKernelGGL(log_of_float_kernel, dim3(1024), dim3(256), 0, ctx->stream, d_in, d_out, n, ctx->lt.logtab);
   P7X_HIP(hipGetLastError());
   P7X_HIP(hipStreamSynchronize(ctx->stream));
   P7X_HIP(hipMemcpy(out, d_out, n * 4, hipMemcpyDeviceToHost));
-  (void) hipFree(d_in); (void) hipFree(d_out);
   return P7X_OK;
 }
 
@@ -1701,7 +1695,7 @@ int p7x_search_batch_finish(p7x_pending *pd, const char *const *names, const cha
     it.ms = co.ms;
     if (!co.have_xmx && !targets[q].empty()) { dr[q].n = co.reg_n.data(); dr[q].regs = co.regs.data(); dr[q].nexpected = co.nexpected.data(); dr[q].cap = kRegionCap;
       dr[q].start = co.reg_start.empty() ? nullptr : co.reg_start.data(); it.regions = &dr[q]; }
-    it.device_envelopes = !g_host_envelopes && !pd->cfg.host_envelopes && !targets[q].empty();
+    it.device_envelopes = !pd->cfg.host_envelopes && !targets[q].empty();
     any_device = any_device || it.device_envelopes;
   }
   int st = P7X_OK;

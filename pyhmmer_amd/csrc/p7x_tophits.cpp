@@ -300,8 +300,8 @@ int host_finish_batch(const p7x_pipeline_cfg &cfg_in, const std::vector<FinishIt
   }
   const int S = first[(size_t) nq];
   const auto t0 = std::chrono::steady_clock::now();
-  // P7X_FINISH_DEBUG: wall time of the phases of this call on stderr
-  static const bool debug = std::getenv("P7X_FINISH_DEBUG") != nullptr;
+  // option "trace_finish": wall time of the phases of this call on stderr
+  const bool debug = debug_opt(OPT_TRACE_FINISH) > 0;
   auto tlast = t0;
   std::string dbg;
   auto tick = [&](const char *what) {

@@ -187,7 +187,7 @@ class PackedBlock:
     ``offsets[t]`` indexes ``x1`` of target ``t``; ``lengths[t]`` is ``L_t``.
     """
 
-    __slots__ = ("dsq", "offsets", "lengths", "n", "total_residues", "_resident_token")
+    __slots__ = ("dsq", "offsets", "lengths", "n", "total_residues", "_resident_token", "__weakref__")
 
     def __init__(self, seqs: _Seq[DigitalSequence]):
         n = len(seqs)
@@ -401,6 +401,7 @@ class SequenceFile:
         self._pending: Optional[str] = None
         self._touched = False
         self._chunk_pos = 0
+        self._chunking = False                                # read_chunk() is walking the file
         if format is None:
             try:
                 pos = self._fh.tell()
@@ -431,7 +432,7 @@ class SequenceFile:
         self._pending = None
         self._touched = False
         self._chunk_pos = 0
-        self._chunk_pos = 0
+        self._chunking = False
 
     def guess_alphabet(self) -> Optional[Alphabet]:
         pos = self._fh.tell()
@@ -557,7 +558,7 @@ class SequenceFile:
         file; ``rewind()`` starts over.  Other formats and text mode fall back to ``read_block(residues=max_bytes)``."""
         if not (self.digital and self._own and self.format != "genbank"):
             return self.read_block(residues=max_bytes)
-        if self._touched and self._chunk_pos == 0:
+        if self._touched and not self._chunking:
             raise ValueError("read_chunk() cannot continue a file that was partly read record by record; rewind() first")
         with open(self.name, "rb") as f:
             f.seek(self._chunk_pos)
@@ -576,6 +577,9 @@ class SequenceFile:
                     tail = more[-1:]
         self._chunk_pos += len(data)
         self._touched = True
+        self._chunking = True
+        self._fh.seek(self._chunk_pos)                        # record-by-record reads continue where the chunks ended
+        self._pending = None
         if not data.strip():
             return DigitalSequenceBlock(self.alphabet, [])
         return self._parse_native(np.frombuffer(data, dtype=np.uint8))

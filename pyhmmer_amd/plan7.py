@@ -11,6 +11,7 @@ import ctypes as C
 import math
 import os
 import sys
+import weakref
 from typing import Iterable, Iterator, List, Optional, Sequence, Union
 
 import itertools
@@ -1643,7 +1644,9 @@ class LongTargetsPipeline(Pipeline):
                 tok = next(_RESIDENT_TOKENS)
                 try:
                     pk._resident_token = tok
-                except AttributeError:
+                    # the device copies go when the image does (p7x_longtargets_release_resident: every device, this key)
+                    weakref.finalize(pk, _release_resident, tok)
+                except (AttributeError, TypeError):
                     tok = 0
             cfg.lt_resident_key = tok
             names = (C.c_char_p * max(n, 1))(*[s.name.encode() for s in sequences])
@@ -1655,6 +1658,9 @@ class LongTargetsPipeline(Pipeline):
         def part(device: int, k: int, nparts: int) -> C.c_void_p:
             c = _lib.PipelineCfg.from_buffer_copy(cfg)
             c.lt_part, c.lt_nparts = k, nparts
+            if nparts > 1:                              # the parts run side by side: each gets its share of the host workers
+                usable = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+                c.host_threads = max(1, (c.host_threads if c.host_threads > 0 else usable) // nparts)
             out = C.c_void_p()
             st = _lib.lib().p7x_search_longtargets(C.byref(c), om._handle, device, dsq.ctypes.data, offsets.ctypes.data,
                                                    lengths.ctypes.data, len(sequences), names, accs, descs, C.byref(out))
@@ -1690,6 +1696,13 @@ class LongTargetsPipeline(Pipeline):
 
 
 _RESIDENT_TOKENS = itertools.count(1)          # one per packed image whose device copy may be kept (cfg.lt_resident_key)
+
+
+def _release_resident(token: int) -> None:
+    try:
+        _lib.lib().p7x_longtargets_release_resident(-1, token)
+    except Exception:                           # noqa: BLE001 - interpreter shutdown: the library may be gone
+        pass
 
 
 class SequenceDatabase:

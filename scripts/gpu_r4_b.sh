@@ -5,7 +5,7 @@ cd "$R"
 mkdir -p gpurun_out/r4b
 timeout 900 python -m pytest tests/test_gpu_ensembles.py -q -x 2>&1 | tail -25 > gpurun_out/r4b/ens.txt
 tail -3 gpurun_out/r4b/ens.txt
-P7X_FINISH_DEBUG=1 timeout 600 python bench.py --workload config1 --steps 6 --warmup 2 --no-cpu-baseline > gpurun_out/r4b/bench_config1.txt 2> gpurun_out/r4b/bench_config1.err
+timeout 600 python bench.py --debug-option trace_finish=1 --workload config1 --steps 6 --warmup 2 --no-cpu-baseline > gpurun_out/r4b/bench_config1.txt 2> gpurun_out/r4b/bench_config1.err
 tail -c 600 gpurun_out/r4b/bench_config1.txt
 grep "finish\]" gpurun_out/r4b/bench_config1.err | tail -5
 cd /tmp && export TMPDIR=/tmp

@@ -15,13 +15,14 @@ pytestmark = pytest.mark.gpu
 
 
 @pytest.fixture(autouse=True, params=["one-target-per-wavefront kernels for small blocks", "lane-per-target kernels"])
-def kernel_family(request, monkeypatch):
+def kernel_family(request):
     """Blocks of up to 65,536 targets normally take the wave-per-target MSV / Viterbi kernels (DESIGN.md section 3.4);
-    the second pass sends the same cases through the lane-per-target MSV and the packed Viterbi kernels."""
-    if request.param.startswith("lane"):
-        monkeypatch.setenv("P7X_SMALL_BLOCK", "0")
-    else:
-        monkeypatch.delenv("P7X_SMALL_BLOCK", raising=False)
+    the second pass sends the same cases through the lane-per-target MSV and the packed Viterbi kernels (test seam
+    p7x_debug_set_option "small_block")."""
+    from pyhmmer_amd import _lib
+    _lib.set_debug_option("small_block", 0 if request.param.startswith("lane") else -1)
+    yield
+    _lib.set_debug_option("small_block", -1)
 
 FWD_TOL_NATS = 2e-3      # |fwd_gpu - fwd_oracle| in nats (float32 sums in a different association order)
 BIAS_TOL_NATS = 1e-3

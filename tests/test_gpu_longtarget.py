@@ -248,12 +248,13 @@ def test_contig_rich_target_set_is_one_scan(oracle):
     assert _rows(many) == _rows(dev)
 
 
-def test_targets_stay_on_the_device_between_searches(capfd, monkeypatch):
+def test_targets_stay_on_the_device_between_searches(capfd):
     """cfg.lt_resident_key: the packed image of a block carries a token, and a later search of the same image -- by any
     query -- finds the targets on the device instead of uploading them again; a block that was changed has a new image,
     a new token and is uploaded; the results are those of a fresh block either way."""
     import bench_workloads as bw
-    monkeypatch.setenv("P7X_LT_DEBUG", "1")
+    from pyhmmer_amd import _lib
+    _lib.set_debug_option("trace_longtarget", 1)
     hmm = load_hmms("bmyD")[0]
     abc = hmm.alphabet
     seqs = [easel.DigitalSequence(abc, name=f"chr{i}", sequence=bw.make_chromosome(hmm, 400_000, planted=6, seed=70 + i)) for i in range(2)]
@@ -274,6 +275,7 @@ def test_targets_stay_on_the_device_between_searches(capfd, monkeypatch):
     assert _rows(third) == _rows(fresh) and len(third) > len(first)
     two = pli.search_hmm(hmm, block, devices=[0, 0])                        # parts of one search share the device's copy
     assert _rows(two) == _rows(third)
+    _lib.set_debug_option("trace_longtarget", -1)
 
 
 def test_a_target_buffer_with_gaps_is_packed_and_gives_the_same_hits():

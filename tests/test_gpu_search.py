@@ -17,13 +17,14 @@ pytestmark = pytest.mark.gpu
 
 
 @pytest.fixture(autouse=True, params=["one-target-per-wavefront kernels for small blocks", "lane-per-target kernels"])
-def kernel_family(request, monkeypatch):
+def kernel_family(request):
     """Blocks of up to 65,536 targets normally take the wave-per-target MSV / Viterbi kernels (DESIGN.md section 3.4);
-    the second pass sends the same cases through the lane-per-target MSV and the packed Viterbi kernels."""
-    if request.param.startswith("lane"):
-        monkeypatch.setenv("P7X_SMALL_BLOCK", "0")
-    else:
-        monkeypatch.delenv("P7X_SMALL_BLOCK", raising=False)
+    the second pass sends the same cases through the lane-per-target MSV and the packed Viterbi kernels (test seam
+    p7x_debug_set_option "small_block")."""
+    from pyhmmer_amd import _lib
+    _lib.set_debug_option("small_block", 0 if request.param.startswith("lane") else -1)
+    yield
+    _lib.set_debug_option("small_block", -1)
 
 
 def test_pf02826_hits_and_domains_match_hmmer(models, proteome):
@@ -414,7 +415,7 @@ def test_optimized_profile_block_scan(models, proteome):
 
 
 @pytest.mark.timeout(600)
-def test_config3_profile_library_against_a_proteome(proteome, monkeypatch, request):
+def test_config3_profile_library_against_a_proteome(proteome, request):
     """BASELINE configs[2] at full profile count (SURVEY.md 8d "config 3"): a 20,000-entry profile library (the
     synthetic, device-calibrated Pfam stand-in of bench_workloads.py; M ~ lognormal, 20 ... 2000 nodes) scanned
     against the 2,100-sequence fixture proteome through hmmer.hmmscan in batches of 256.  Properties that do not
@@ -424,7 +425,6 @@ def test_config3_profile_library_against_a_proteome(proteome, monkeypatch, reque
     import bench_workloads as bw
     if "lane-per-target" in request.node.name:
         pytest.skip("one pass is enough: a 20,000-profile batch run picks its kernels itself")
-    monkeypatch.delenv("P7X_SMALL_BLOCK", raising=False)
     n = 20000
     hmms, lengths, templates = bw.make_library(n, count=n)
     assert len(hmms) == n and int(lengths.min()) >= 20 and int(lengths.max()) > 1000
@@ -496,26 +496,32 @@ def test_hmmscan_deals_profile_batches_over_devices(models, proteome):
     assert [sh.device for sh in db.shards] == [0, 0] and all(len(sh.block) == len(sub) for sh in db.shards)
 
 
-def test_clustered_envelopes_on_the_device_give_the_same_tables(models, proteome, monkeypatch):
-    """P7X_DEVICE_CLUSTERED=1: the envelopes that the stochastic ensembles of multi-domain regions produce are rescored by
-    the envelope kernel in a second round instead of by the host workers.  Hits, domains and the written tables are the
-    same (the golden tables contain nine such hits)."""
+def test_clustered_envelopes_on_the_device_give_the_same_tables(models, proteome):
+    """With the stochastic ensembles on the host workers (host_ensembles) their clustered envelopes can be rescored by the
+    envelope kernel in a second round or by the host workers (option "device_clustered"); with the ensembles on the device
+    (the default) the second round always runs there.  Hits, domains and the written tables are the same every way (the
+    golden tables contain nine such hits)."""
     import io
+    from pyhmmer_amd import _lib
     hmm = models["PF02826"][0]
-    monkeypatch.setenv("P7X_DEVICE_CLUSTERED", "0")          # unset, the library decides by the number of host threads
-    base = plan7.Pipeline(hmm.alphabet).search_hmm(hmm, proteome)
-    monkeypatch.setenv("P7X_DEVICE_CLUSTERED", "1")
-    dev = plan7.Pipeline(hmm.alphabet).search_hmm(hmm, proteome)
-    assert sum(h.nclustered for h in dev) == sum(h.nclustered for h in base) > 0
-    _check_tbl(dev, golden_table("PF02826.tbl"))
-    _check_domtbl(dev, golden_table("PF02826.domtbl", kind="domtbl"))
-    assert [(h.name, len(h.domains), h.nenvelopes, h.noverlaps) for h in dev] == [(h.name, len(h.domains), h.nenvelopes, h.noverlaps) for h in base]
-    for fmt in ("targets", "domains"):
-        a, b = io.BytesIO(), io.BytesIO()
-        base.write(a, format=fmt); dev.write(b, format=fmt)
-        assert a.getvalue() == b.getvalue()
-    monkeypatch.delenv("P7X_DEVICE_CLUSTERED")
-    few = plan7.Pipeline(hmm.alphabet, host_threads=4).search_hmm(hmm, proteome)        # few host threads: the device's turn
+    try:
+        _lib.set_debug_option("device_clustered", 0)
+        base = plan7.Pipeline(hmm.alphabet, host_ensembles=True).search_hmm(hmm, proteome)
+        _lib.set_debug_option("device_clustered", 1)
+        dev = plan7.Pipeline(hmm.alphabet, host_ensembles=True).search_hmm(hmm, proteome)
+    finally:
+        _lib.set_debug_option("device_clustered", -1)
+    alldev = plan7.Pipeline(hmm.alphabet).search_hmm(hmm, proteome)          # ensembles and clustered envelopes on the device
+    assert sum(h.nclustered for h in dev) == sum(h.nclustered for h in base) == sum(h.nclustered for h in alldev) > 0
+    for res in (dev, alldev):
+        _check_tbl(res, golden_table("PF02826.tbl"))
+        _check_domtbl(res, golden_table("PF02826.domtbl", kind="domtbl"))
+        assert [(h.name, len(h.domains), h.nenvelopes, h.noverlaps) for h in res] == [(h.name, len(h.domains), h.nenvelopes, h.noverlaps) for h in base]
+        for fmt in ("targets", "domains"):
+            a, b = io.BytesIO(), io.BytesIO()
+            base.write(a, format=fmt); res.write(b, format=fmt)
+            assert a.getvalue() == b.getvalue()
+    few = plan7.Pipeline(hmm.alphabet, host_threads=4, host_ensembles=True).search_hmm(hmm, proteome)        # few host threads: the device's turn
     a, b = io.BytesIO(), io.BytesIO()
     base.write(a, format="domains"); few.write(b, format="domains")
     assert a.getvalue() == b.getvalue()
