@@ -569,6 +569,7 @@ def main():
     barrier()
     t0 = time.perf_counter()
     hits, stage = run(args.steps)
+    pstats = hmmer.pipeline_stats()           # this rank's query pipeline over the timed region (before the barrier: its own clock)
     barrier()
     elapsed = time.perf_counter() - t0
     nqueries = args.steps * qps
@@ -586,6 +587,20 @@ def main():
     residues = int(lengths.sum())
     cells_rank = float(hmm.M) * residues
     t_max, cells_total, seqs_total = elapsed, cells_rank, float(args.nseq)
+    # What makes a scaling run diagnosable: per rank, how its threads spent the timed region.  A rank whose
+    # feeders mostly waited for a free slot is bound by its host stages (too few CPUs or too little depth), one whose feeders
+    # mostly waited for the device is device bound (the intended state); rank 0 adds the time it took to merge the ranks' hits.
+    wall = max(pstats.get("wall", 0.0), 1e-9)
+    nfeed_eff = max(1, pstats.get("feeders", 1))
+    rank_diag = {"rank": rank, "host_threads": host_threads, "elapsed_s": round(elapsed, 4),
+                 "feeder_device_wait_frac": round(pstats.get("feeder_device_wait", 0.0) / (wall * nfeed_eff), 4),
+                 "feeder_slot_wait_frac": round(pstats.get("feeder_slot_wait", 0.0) / (wall * nfeed_eff), 4),
+                 "feeder_enqueue_frac": round(pstats.get("feeder_enqueue", 0.0) / (wall * nfeed_eff), 4),
+                 "host_stage_s_per_batch": round(pstats.get("finish", 0.0) / max(1, pstats.get("batches", 1)), 4),
+                 "consumer_finish_wait_frac": round(pstats.get("consumer_finish_wait", 0.0) / wall, 4),
+                 "host_stages_in_flight": pstats.get("finishers"), "batches": pstats.get("batches")}
+    merge_s = 0.0
+    diags = [rank_diag]
     if dist is not None:
         buf = torch.tensor([elapsed], dtype=torch.float64, device=red_dev)
         dist.all_reduce(buf, op=dist.ReduceOp.MAX)
@@ -596,10 +611,14 @@ def main():
         # per-GPU TopHits merged on the host of rank 0 (no data-path collective: this only moves the results)
         blobs = [None] * world
         dist.all_gather_object(blobs, hits.to_bytes())
+        diags = [None] * world
+        dist.all_gather_object(diags, rank_diag)
         if rank == 0:
+            tm = time.perf_counter()
             merged = plan7.TopHits.from_bytes(blobs[0])
             for b in blobs[1:]:
                 merged = merged.merge(plan7.TopHits.from_bytes(b))
+            merge_s = time.perf_counter() - tm
             hits_total, reported_total = len(merged), len(merged.reported)
     if dist is None:
         hits_total, reported_total = len(hits), len(hits.reported)
@@ -657,6 +676,9 @@ def main():
                 "spinup_windows_s": [round(x, 4) for x in spin],
                 "latency_ms_per_query": round(stage.get("total", 0.0), 3),
             },
+            "ranks": {"per_rank": diags, "merge_seconds_rank0": round(merge_s, 5),
+                      "note": "fractions of the timed region, per feeder thread; slot wait = every batch slot was taken and the feeders "
+                              "waited for a host stage (host bound), device wait = waiting for the cascade (device bound)"},
             "stages": {
                 "n_targets": args.nseq, "past_msv": sc["msv"], "past_bias": sc["bias"], "past_vit": sc["vit"], "past_fwd": sc["fwd"],
                 "hits": hits_total, "reported": reported_total, "planted": int(len(planted)),

@@ -437,17 +437,35 @@ def _run_queries(db: "ShardedDatabase", pipelines: Sequence[Pipeline], queries: 
 _T0 = time.perf_counter()
 
 
+PIPE_TRACE = False       # diagnostics: set to True for a timeline of the batches on stderr (the library reads no environment)
+_LAST_STATS: dict = {}
+
+
+def pipeline_stats() -> dict:
+    """Where the threads of the last (finished) query pipeline of this process spent their time, in seconds summed over the
+    threads of a kind: ``feeder_enqueue`` / ``feeder_device_wait`` (issuing a batch's device stage, waiting for it),
+    ``feeder_slot_wait`` (all ``pipeline_depth`` batches were in flight: the feeders waited for a host stage to finish --
+    the search is host-stage bound when this dominates), ``finish`` (host stages, most of it waits for the envelope and
+    ensemble kernels), ``consumer_finish_wait`` (the consumer waited for the oldest host stage), ``wall``; plus the thread
+    counts.  What a scaling run needs to tell a device-bound rank from a host-bound one."""
+    return dict(_LAST_STATS)
+
+
 def _pipe_trace(what, idx, n=None):
-    # P7X_PIPE_DEBUG=1: timeline of the batches (ms since import, thread, event, batch index) on stderr
+    # PIPE_TRACE: timeline of the batches (ms since import, thread, event, batch index) on stderr
     sys.stderr.write(f"[pipe] {1e3 * (time.perf_counter() - _T0):9.2f} {threading.current_thread().name[-10:]:>10} {what:9} {idx}{'' if n is None else f' ({n})'}\n")
 
 
-def _traced_finish(db, pendings, trace, idx):
+def _traced_finish(db, pendings, trace, idx, stats=None, lock=None):
     trace("finish", idx)
+    t0 = time.perf_counter()
     try:
         return db.finish(pendings)
     finally:
         trace("finished", idx)
+        if stats is not None:
+            with lock:
+                stats["finish"] += time.perf_counter() - t0
 
 
 def _run_batches(db: "ShardedDatabase", pipelines: Sequence[Pipeline], queries: Iterable, pipeline_depth: int,
@@ -468,7 +486,10 @@ def _run_batches(db: "ShardedDatabase", pipelines: Sequence[Pipeline], queries: 
     # device stage ahead of the host stage; results are handed over in order, at most pipeline_depth of them
     # staged or in flight at any time.
     nfeed = max(1, min(feeders, pipeline_depth))
-    trace = _pipe_trace if os.environ.get("P7X_PIPE_DEBUG") else (lambda *a: None)
+    trace = _pipe_trace if PIPE_TRACE else (lambda *a: None)
+    stats = {"feeder_enqueue": 0.0, "feeder_device_wait": 0.0, "feeder_slot_wait": 0.0, "finish": 0.0, "consumer_finish_wait": 0.0,
+             "batches": 0}
+    t_start = time.perf_counter()
     lock = threading.Lock()
     ready = threading.Condition(lock)
     slots = threading.Semaphore(pipeline_depth)
@@ -485,7 +506,10 @@ def _run_batches(db: "ShardedDatabase", pipelines: Sequence[Pipeline], queries: 
             if err is None:
                 try:
                     trace("wait", idx)
+                    t0 = time.perf_counter()
                     db.wait(pendings)
+                    with lock:
+                        stats["feeder_device_wait"] += time.perf_counter() - t0
                     trace("waited", idx)
                 except BaseException as e:          # forwarded to the caller like _base.py:305-318
                     err = e
@@ -501,8 +525,13 @@ def _run_batches(db: "ShardedDatabase", pipelines: Sequence[Pipeline], queries: 
                     if not slots.acquire(blocking=False):   # the depth budget is spent: make room by finishing our oldest
                         hand_over_oldest()
                         continue
-                elif not slots.acquire(timeout=0.1):
-                    continue
+                else:
+                    t0 = time.perf_counter()
+                    got = slots.acquire(timeout=0.1)
+                    with lock:
+                        stats["feeder_slot_wait"] += time.perf_counter() - t0
+                    if not got:
+                        continue
                 with lock:
                     if state["exhausted"] or stop.is_set():
                         slots.release()
@@ -522,7 +551,11 @@ def _run_batches(db: "ShardedDatabase", pipelines: Sequence[Pipeline], queries: 
                     state["issued"] = idx + 1
                 try:
                     trace("enqueue", idx, len(q))
+                    t0 = time.perf_counter()
                     queued.append((idx, q, db.enqueue(pipelines, q), None))
+                    with lock:
+                        stats["feeder_enqueue"] += time.perf_counter() - t0
+                        stats["batches"] += 1
                     trace("enqueued", idx)
                 except BaseException as e:
                     queued.append((idx, q, None, e))
@@ -580,16 +613,18 @@ def _run_batches(db: "ShardedDatabase", pipelines: Sequence[Pipeline], queries: 
                     return
                 if pool is None:
                     try:
-                        res = db.finish(pendings)
+                        res = _traced_finish(db, pendings, trace, nxt - 1, stats, lock)
                     except BaseException as e:
                         yield q, None, e
                         return
                     yield q, res, None
                     continue
-                inflight.append((q, pool.submit(_traced_finish, db, pendings, trace, nxt - 1)))
+                inflight.append((q, pool.submit(_traced_finish, db, pendings, trace, nxt - 1, stats, lock)))
             while inflight and (inflight[0][1].done() or len(inflight) >= nfin or drained):
                 q, fut = inflight.popleft()
+                t0 = time.perf_counter()
                 item0 = result_of(q, fut)
+                stats["consumer_finish_wait"] += time.perf_counter() - t0
                 yield item0
                 if item0[2] is not None:
                     return
@@ -610,6 +645,9 @@ def _run_batches(db: "ShardedDatabase", pipelines: Sequence[Pipeline], queries: 
             slots.release()
         for t in threads:
             t.join()
+        stats.update(wall=time.perf_counter() - t_start, feeders=nfeed, finishers=nfin, pipeline_depth=pipeline_depth)
+        _LAST_STATS.clear()
+        _LAST_STATS.update(stats)
         for _, pendings, _ in staged.values():
             db.abandon(pendings)
 
