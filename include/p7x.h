@@ -352,6 +352,16 @@ int p7x_forward_parser_exact(const p7x_oprofile *om, const uint8_t *dsq, int32_t
 int p7x_scan_collect(p7x_tophits *const *per_model, size_t nmodels, const p7x_pipeline_cfg *cfg, size_t nseqs,
                      const char *const *seq_names, const char *const *seq_accs, const char *const *seq_descs,
                      const int32_t *seq_lengths, p7x_tophits **out);
+/* The same, incrementally: the per-model results are folded in as the device batches of a scan come back (in model order;
+ * the running Z of p7_pli_NewModel is the model's number) and can be destroyed right after, so a scan over a library of
+ * any size holds one batch of per-model results at a time, as the reference's loop over the pressed file holds one
+ * profile (plan7.pyx:6680-6737).  p7x_scan_accum_finish consumes the accumulator. */
+typedef struct p7x_scan_accum p7x_scan_accum;
+int  p7x_scan_accum_create(const p7x_pipeline_cfg *cfg, size_t nseqs, const char *const *seq_names, const char *const *seq_accs,
+                           const char *const *seq_descs, const int32_t *seq_lengths, p7x_scan_accum **out);
+int  p7x_scan_accum_add(p7x_scan_accum *acc, p7x_tophits *const *per_model, size_t nmodels);
+int  p7x_scan_accum_finish(p7x_scan_accum *acc, p7x_tophits **out);
+void p7x_scan_accum_destroy(p7x_scan_accum *acc);
 
 /* Host half of p7_Pipeline for targets that already passed the Forward filter: Backward-derived domain
  * definition (p7_domaindef_ByPosteriorHeuristics, p7_domaindef.pxd:69-72), per-sequence / per-domain scores,

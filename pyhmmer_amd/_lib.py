@@ -218,6 +218,10 @@ _SIGNATURES = {
                                             C.POINTER(C.c_size_t), C.POINTER(C.c_int64)]),
     "p7x_oprofile_get_string": (C.c_int, [_VP, C.c_int, C.c_char_p, C.c_size_t]),
     "p7x_scan_collect": (C.c_int, [C.POINTER(_VP), C.c_size_t, C.POINTER(PipelineCfg), C.c_size_t, _VP, _VP, _VP, _VP, C.POINTER(_VP)]),
+    "p7x_scan_accum_create": (C.c_int, [C.POINTER(PipelineCfg), C.c_size_t, _VP, _VP, _VP, _VP, C.POINTER(_VP)]),
+    "p7x_scan_accum_add": (C.c_int, [_VP, C.POINTER(_VP), C.c_size_t]),
+    "p7x_scan_accum_finish": (C.c_int, [_VP, C.POINTER(_VP)]),
+    "p7x_scan_accum_destroy": (None, [_VP]),
     "p7x_fasta_parse": (C.c_int, [_VP, C.c_size_t, _VP, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t), C.POINTER(C.c_size_t),
                                   _VP, _VP, _VP, _VP, _VP, _VP, C.POINTER(C.c_size_t)]),
     "p7x_last_error": (C.c_char_p, []),

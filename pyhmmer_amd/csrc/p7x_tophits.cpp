@@ -654,13 +654,20 @@ int p7x_tophits_get_domain(const p7x_tophits *th, int64_t i, int32_t d, p7x_doma
 // all query sequences (searched with cfg.mode = P7X_SCAN_MODELS: nothing pruned); out[s] becomes the hit list of
 // sequence s, whose hits are the models.  Reportability is applied in model order with the running Z = number of
 // models seen (p7_pli_NewModel), then the usual sort and threshold with Z = nmodels.
-int p7x_scan_collect(p7x_tophits *const *per_model, size_t nmodels, const p7x_pipeline_cfg *cfg_in, size_t nseqs,
-                     const char *const *seq_names, const char *const *seq_accs, const char *const *seq_descs,
-                     const int32_t *seq_lengths, p7x_tophits **out)
+// The collection is incremental: the per-model results of one device batch are folded in (in model order) and can be
+// released before the next batch is in, so a scan never holds more than a batch of them.
+struct p7x_scan_accum {
+  std::vector<std::unique_ptr<p7x_tophits>> res;
+  size_t nmodels = 0;
+};
+
+int p7x_scan_accum_create(const p7x_pipeline_cfg *cfg_in, size_t nseqs, const char *const *seq_names, const char *const *seq_accs,
+                          const char *const *seq_descs, const int32_t *seq_lengths, p7x_scan_accum **out)
 {
-  if (!per_model || !cfg_in || !out || (nseqs && !seq_lengths)) { set_error("p7x_scan_collect: bad arguments"); return P7X_EINVAL; }
+  if (!cfg_in || !out || (nseqs && !seq_lengths)) { set_error("p7x_scan_accum_create: bad arguments"); return P7X_EINVAL; }
   flogsum_init();
-  std::vector<std::unique_ptr<p7x_tophits>> res(nseqs);
+  auto acc = std::make_unique<p7x_scan_accum>();
+  acc->res.resize(nseqs);
   for (size_t s = 0; s < nseqs; ++s) {
     auto th = std::make_unique<p7x_tophits>();
     th->cfg = *cfg_in; th->cfg.mode = P7X_SCAN_MODELS;
@@ -669,21 +676,30 @@ int p7x_scan_collect(p7x_tophits *const *per_model, size_t nmodels, const p7x_pi
     if (seq_accs && seq_accs[s] && seq_accs[s][0]) { th->qacc = seq_accs[s]; th->q_has_acc = true; }
     if (seq_descs && seq_descs[s] && seq_descs[s][0]) { th->qdesc = seq_descs[s]; th->q_has_desc = true; }
     th->ctr.nseqs = 1; th->ctr.nres = (uint64_t) seq_lengths[s];
-    res[s] = std::move(th);
+    acc->res[s] = std::move(th);
   }
-  for (size_t m = 0; m < nmodels; ++m) {
-    const p7x_tophits *pm = per_model[m];
-    if (!pm) { set_error("p7x_scan_collect: missing per-model result"); return P7X_EINVAL; }
-    if (pm->ctr.nseqs != nseqs) { set_error("p7x_scan_collect: per-model results cover different sequence sets"); return P7X_EINVAL; }
+  *out = acc.release();
+  return P7X_OK;
+}
+
+int p7x_scan_accum_add(p7x_scan_accum *acc, p7x_tophits *const *per_model, size_t nmodels)
+{
+  if (!acc || (nmodels && !per_model)) { set_error("p7x_scan_accum_add: bad arguments"); return P7X_EINVAL; }
+  const size_t nseqs = acc->res.size();
+  for (size_t mm = 0; mm < nmodels; ++mm) {
+    const p7x_tophits *pm = per_model[mm];
+    const size_t m = acc->nmodels + mm;                      // the model's number in the scan
+    if (!pm) { set_error("p7x_scan_accum_add: missing per-model result"); return P7X_EINVAL; }
+    if (pm->ctr.nseqs != nseqs) { set_error("p7x_scan_accum_add: per-model results cover different sequence sets"); return P7X_EINVAL; }
     for (size_t s = 0; s < nseqs; ++s) {
-      p7x_counters &c = res[s]->ctr;
+      p7x_counters &c = acc->res[s]->ctr;
       c.nmodels += 1; c.nnodes += (uint64_t) pm->M;
       const int stg = pm->stage.size() == nseqs ? pm->stage[s] : 0;
       c.n_past_msv += stg >= 1; c.n_past_bias += stg >= 2; c.n_past_vit += stg >= 3; c.n_past_fwd += stg >= 4;
     }
     for (const Hit &h : pm->hits) {
       if (h.seqidx < 0 || (size_t) h.seqidx >= nseqs) continue;
-      p7x_tophits &th = *res[(size_t) h.seqidx];
+      p7x_tophits &th = *acc->res[(size_t) h.seqidx];
       p7x_pipeline_cfg rc = th.cfg;
       apply_bit_cutoffs_from(rc, pm->cfg);               // model-specific GA/TC/NC thresholds travel with the per-model result
       const double Zrun = (rc.Z_setby == P7X_ZSETBY_NTARGETS) ? (double) (m + 1) : rc.Z;
@@ -694,15 +710,36 @@ int p7x_scan_collect(p7x_tophits *const *per_model, size_t nmodels, const p7x_pi
       th.hits.push_back(std::move(copy));
     }
   }
-  for (size_t s = 0; s < nseqs; ++s) {
-    p7x_tophits &th = *res[s];
-    if (th.cfg.Z_setby == P7X_ZSETBY_NTARGETS) th.cfg.Z = (double) nmodels;
+  acc->nmodels += nmodels;
+  return P7X_OK;
+}
+
+int p7x_scan_accum_finish(p7x_scan_accum *acc, p7x_tophits **out)
+{ // consumes the accumulator
+  if (!acc || !out) { set_error("p7x_scan_accum_finish: bad arguments"); delete acc; return P7X_EINVAL; }
+  std::unique_ptr<p7x_scan_accum> owner(acc);
+  for (size_t s = 0; s < acc->res.size(); ++s) {
+    p7x_tophits &th = *acc->res[s];
+    if (th.cfg.Z_setby == P7X_ZSETBY_NTARGETS) th.cfg.Z = (double) acc->nmodels;
     sort_by_key(th);
     threshold(th);
-    out[s] = nullptr;
   }
-  for (size_t s = 0; s < nseqs; ++s) out[s] = res[s].release();
+  for (size_t s = 0; s < acc->res.size(); ++s) out[s] = acc->res[s].release();
   return P7X_OK;
+}
+
+void p7x_scan_accum_destroy(p7x_scan_accum *acc) { delete acc; }
+
+int p7x_scan_collect(p7x_tophits *const *per_model, size_t nmodels, const p7x_pipeline_cfg *cfg_in, size_t nseqs,
+                     const char *const *seq_names, const char *const *seq_accs, const char *const *seq_descs,
+                     const int32_t *seq_lengths, p7x_tophits **out)
+{
+  if (!per_model || !cfg_in || !out || (nseqs && !seq_lengths)) { set_error("p7x_scan_collect: bad arguments"); return P7X_EINVAL; }
+  p7x_scan_accum *acc = nullptr;
+  int st = p7x_scan_accum_create(cfg_in, nseqs, seq_names, seq_accs, seq_descs, seq_lengths, &acc);
+  if (st != P7X_OK) return st;
+  if ((st = p7x_scan_accum_add(acc, per_model, nmodels)) != P7X_OK) { delete acc; return st; }
+  return p7x_scan_accum_finish(acc, out);
 }
 
 int p7x_tophits_sort_by_key(p7x_tophits *th) { if (!th) return P7X_EINVAL; sort_by_key(*th); return P7X_OK; }

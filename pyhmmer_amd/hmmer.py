@@ -654,7 +654,8 @@ def _run_batches(db: "ShardedDatabase", pipelines: Sequence[Pipeline], queries: 
 
 def hmmscan(queries, profiles, *, cpus: int = 0, callback: Optional[Callable] = None, devices: Optional[Sequence[int]] = None,
             pipeline_depth: int = 4, feeders: int = 3, window: int = 1, finishers: int = 0, batch: int = 0,
-            backend: Optional[str] = None, **options) -> Iterator[TopHits]:
+            backend: Optional[str] = None, query_block_sequences: int = 16384, query_block_residues: int = 1 << 23,
+            **options) -> Iterator[TopHits]:
     """Scan query sequences against a profile database; yields one ``TopHits`` per query sequence, in query order, whose
     hits are the profiles (reference ``hmmer/_hmmscan.py:90-231``, ``Pipeline.scan_seq`` ``plan7.pyx:6534-6622``).
 
@@ -677,53 +678,115 @@ def hmmscan(queries, profiles, *, cpus: int = 0, callback: Optional[Callable] = 
     from .easel import DigitalSequence
     from .plan7 import _P7X_SCAN_MODELS
     import ctypes as C
-    if isinstance(queries, DigitalSequence):
-        queries = (queries,)
-    if isinstance(queries, SequenceFile):
-        if not queries.digital:
-            raise ValueError("query sequences file is not in digital mode")
-        queries = queries.read_block()
-    if not isinstance(queries, DigitalSequenceBlock):
-        seqs = list(queries)
-        if not seqs:
-            return
-        queries = DigitalSequenceBlock(seqs[0].alphabet, seqs)
-    if len(queries) == 0:
-        return
-    alphabet: Alphabet = queries.alphabet
     if _lib.lib().p7x_device_count() < 1:
         from .errors import DeviceUnavailable
         raise DeviceUnavailable("hmmscan: no HIP device is usable and there is no CPU fallback")
+    if isinstance(queries, DigitalSequence):
+        queries = (queries,)
+    if isinstance(queries, SequenceFile) and not queries.digital:
+        raise ValueError("query sequences file is not in digital mode")
+    # The queries are taken a block at a time (the reference takes them one at a time, plan7.pyx:6680-6737): a block is
+    # scanned against the whole profile database and its results are handed out before the next block is read, so a query
+    # file of any size streams through, and the first results arrive after one pass over the profiles, not after all of them.
+    if not hasattr(profiles, "rewind") and not isinstance(profiles, (list, tuple)):
+        profiles = list(profiles)                  # a one-shot iterable is walked once per query block
     devs = list(devices) if devices else [0]
-    # the query block is small by construction: every device holds all of it and takes its share of the profiles
-    db = ReplicatedDatabase(queries, devs) if len(devs) > 1 else ShardedDatabase(queries, devs)
-    pipelines = [Pipeline(alphabet, device=d, host_threads=cpus, **options) for d in devs]
-    for p in pipelines:
-        p._mode = _P7X_SCAN_MODELS
-    per_model = [hits for _, hits in _run_queries(db, pipelines, profiles, pipeline_depth, feeders, window, finishers, batch=batch)]
-    n = len(queries)
-    out = (C.c_void_p * n)()
-    shard = db.shards[0]
-    lengths = (C.c_int32 * n)(*[len(s) for s in queries])
-    handles = (C.c_void_p * max(len(per_model), 1))(*[h._handle for h in per_model])
-    cfg = pipelines[0]._cfg()
-    st = _lib.lib().p7x_scan_collect(handles, len(per_model), C.byref(cfg), n, shard._names, shard._accs, shard._descs,
-                                     lengths, out)
-    if st != 0:
-        from .errors import status_to_exception
-        raise status_to_exception(st, "p7x_scan_collect", _lib.last_error())
-    results = [TopHits(q, C.c_void_p(out[i])) for i, q in enumerate(queries)]
-    del per_model
-    for q, hits in zip(queries, results):
-        if callback is not None:
-            callback(q, n)
-        yield hits
+    seen = 0
+    for block in _query_blocks(queries, query_block_sequences, query_block_residues):
+        if len(block) == 0:
+            continue
+        if seen and hasattr(profiles, "rewind"):
+            profiles.rewind()
+        seen += 1
+        alphabet: Alphabet = block.alphabet
+        # the query block is small by construction: every device holds all of it and takes its share of the profiles
+        db = ReplicatedDatabase(block, devs) if len(devs) > 1 else ShardedDatabase(block, devs)
+        pipelines = [Pipeline(alphabet, device=d, host_threads=cpus, **options) for d in devs]
+        for pl in pipelines:
+            pl._mode = _P7X_SCAN_MODELS
+        n = len(block)
+        shard = db.shards[0]
+        lengths = (C.c_int32 * n)(*[len(s) for s in block])
+        cfg = pipelines[0]._cfg()
+        acc = C.c_void_p()
+        st = _lib.lib().p7x_scan_accum_create(C.byref(cfg), n, shard._names, shard._accs, shard._descs, lengths, C.byref(acc))
+        if st != 0:
+            from .errors import status_to_exception
+            raise status_to_exception(st, "p7x_scan_accum_create", _lib.last_error())
+        try:
+            # per-model results are folded into the per-sequence lists as they come back, a few hundred at a time, and
+            # released: the scan holds a batch of them, not the library's worth
+            held: list = []
+
+            def fold():
+                if held:
+                    handles = (C.c_void_p * len(held))(*[h._handle for h in held])
+                    st2 = _lib.lib().p7x_scan_accum_add(acc, handles, len(held))
+                    if st2 != 0:
+                        from .errors import status_to_exception
+                        raise status_to_exception(st2, "p7x_scan_accum_add", _lib.last_error())
+                    held.clear()
+
+            for _, hits in _run_queries(db, pipelines, profiles, pipeline_depth, feeders, window, finishers, batch=batch):
+                held.append(hits)
+                if len(held) >= 256:
+                    fold()
+            fold()
+            out = (C.c_void_p * n)()
+            st = _lib.lib().p7x_scan_accum_finish(acc, out)          # consumes the accumulator
+            acc = C.c_void_p()
+            if st != 0:
+                from .errors import status_to_exception
+                raise status_to_exception(st, "p7x_scan_accum_finish", _lib.last_error())
+        finally:
+            if acc:
+                _lib.lib().p7x_scan_accum_destroy(acc)
+        results = [TopHits(q, C.c_void_p(out[i])) for i, q in enumerate(block)]
+        del db, pipelines                                            # the block leaves HBM before the next one is read
+        for q, hits in zip(block, results):
+            if callback is not None:
+                callback(q, n)
+            yield hits
+
+
+def _query_blocks(queries, max_sequences: int, max_residues: int):
+    """Blocks of query sequences for hmmscan: from a block as it is, from a file or an iterable a bounded number at a time."""
+    from .easel import DigitalSequence
+    if isinstance(queries, DigitalSequenceBlock):
+        yield queries
+        return
+    if isinstance(queries, SequenceFile):
+        while True:
+            if max_sequences >= 16384:             # the native chunked parser (FASTA), about max_residues bytes of text at a time
+                block = queries.read_chunk(max_residues)
+            else:
+                block = queries.read_block(sequences=max_sequences, residues=max_residues)
+            if len(block) == 0:
+                return
+            yield block
+    cur, nres = [], 0
+    for s in queries:
+        cur.append(s)
+        nres += len(s)
+        if len(cur) >= max_sequences or nres >= max_residues:
+            yield DigitalSequenceBlock(cur[0].alphabet, cur)
+            cur, nres = [], 0
+    if cur:
+        yield DigitalSequenceBlock(cur[0].alphabet, cur)
 
 
 def nhmmer(queries, sequences, *, cpus: int = 0, callback: Optional[Callable] = None, devices: Optional[Sequence[int]] = None,
-           backend: Optional[str] = None, builder=None, timeout: Optional[float] = None, **options) -> Iterator[TopHits]:
+           backend: Optional[str] = None, builder=None, timeout: Optional[float] = None, searches_in_flight: int = 2,
+           **options) -> Iterator[TopHits]:
     """Search nucleotide HMMs against long nucleotide targets; yields one ``TopHits`` per query, in query order
-    (reference ``hmmer/_nhmmer.py:24-56``: one ``LongTargetsPipeline.search_hmm`` per query).
+    (reference ``hmmer/_nhmmer.py:24-56``: one ``LongTargetsPipeline.search_hmm`` per query, the queries spread over
+    worker threads, ``hmmer/_base.py:416-489``).
+
+    A search is a device phase (the SSV scan of both strands: the whole device for tens of milliseconds) followed by a
+    tail that is mostly host work (seed bookkeeping, window merging, domain definition of the surviving windows, with a
+    few small device batches in between).  ``searches_in_flight`` consecutive queries run at the same time on their own
+    threads, so that the scan of the next query fills the device while the tail of the previous one runs; results are
+    handed back in query order.  1 runs the queries one after the other.
 
     ``queries``: ``HMM`` / ``Profile`` / ``OptimizedProfile`` objects (one or an iterable).  Sequence and alignment
     queries of the reference go through the HMM builder first, which is outside this path: build the HMM and pass it.
@@ -748,10 +811,40 @@ def nhmmer(queries, sequences, *, cpus: int = 0, callback: Optional[Callable] = 
         total = len(queries)          # type: ignore[arg-type]
     except TypeError:
         pass
-    for q in queries:
+    def search(q):
         if not isinstance(q, (HMM, Profile, OptimizedProfile)):
             raise TypeError(f"Unsupported query type for `nhmmer`: {type(q).__name__} (build an HMM from it first)")
-        hits = pipeline.search_hmm(q, sequences, devices=devices)      # the units of one search dealt over the devices
-        if callback is not None:
-            callback(q, total)
-        yield hits
+        return pipeline.search_hmm(q, sequences, devices=devices)      # the units of one search dealt over the devices
+
+    if searches_in_flight <= 1:
+        for q in queries:
+            hits = search(q)
+            if callback is not None:
+                callback(q, total)
+            yield hits
+        return
+    if isinstance(sequences, DigitalSequenceBlock):
+        sequences.packed()                      # the flat image (and its residency token) once, before the threads race for it
+    inflight: "deque" = deque()
+    with ThreadPoolExecutor(max_workers=searches_in_flight, thread_name_prefix="p7x-nhmmer") as pool:
+        try:
+            for q in queries:
+                inflight.append((q, pool.submit(search, q)))
+                while len(inflight) >= searches_in_flight:
+                    q0, fut = inflight.popleft()
+                    hits = fut.result()
+                    if callback is not None:
+                        callback(q0, total)
+                    yield hits
+            while inflight:
+                q0, fut = inflight.popleft()
+                hits = fut.result()
+                if callback is not None:
+                    callback(q0, total)
+                yield hits
+        finally:
+            for _, fut in inflight:             # abandoned or failed: let what was started finish (it owns device buffers)
+                try:
+                    fut.result()
+                except BaseException:           # noqa: BLE001
+                    pass

@@ -311,3 +311,40 @@ def test_a_target_buffer_with_gaps_is_packed_and_gives_the_same_hits():
     assert st == 0, _lib.last_error()
     got = plan7.TopHits(hmm, out)
     assert _rows(got) == _rows(want)
+
+
+def test_a_stream_of_queries_overlaps_searches_and_gives_the_same_hits():
+    """hmmer.nhmmer keeps two searches in flight (the scan of one under the host tail of the other; the reference's
+    hmmer/_nhmmer.py:24-56 runs its queries on worker threads): every query's hits equal those of the same search run alone,
+    in query order, also when the queries differ (here: the fixture model and two sub-models cut out of it)."""
+    import bench_workloads as bw
+    full = load_hmms("bmyD")[0]
+    abc = full.alphabet
+
+    def cut(lo, hi, name):
+        h = plan7.HMM(abc, hi - lo, name)
+        h.transition_probabilities[1:] = full.transition_probabilities[lo + 1:hi + 1]
+        h.transition_probabilities[0] = full.transition_probabilities[0]
+        h.match_emissions[1:] = full.match_emissions[lo + 1:hi + 1]
+        h.insert_emissions[:] = full.insert_emissions[lo:hi + 1]
+        t = np.array(h.transition_probabilities[hi - lo])
+        t[0], t[2] = t[0] + t[2], 0.0
+        t[5], t[6] = 1.0, 0.0
+        h.transition_probabilities[hi - lo] = t
+        h.composition = full.composition
+        h.consensus = full.consensus[lo:hi]
+        h._evparam[:] = full._evparam
+        h.max_length = 4 * (hi - lo)
+        return h
+
+    hmms = [full, cut(100, 500, "bmyD_a"), cut(600, 1100, "bmyD_b")]
+    seqs = [easel.DigitalSequence(abc, name=f"chr{i}", sequence=bw.make_chromosome(full, 600_000, planted=8, seed=170 + i)) for i in range(2)]
+    block = easel.DigitalSequenceBlock(abc, seqs)
+    order = [0, 1, 0, 2, 1, 0]
+    alone = [_rows(plan7.LongTargetsPipeline(abc).search_hmm(q, block)) for q in hmms]
+    want = [alone[i] for i in order]
+    queries = [hmms[i] for i in order]
+    assert len(alone[0]) >= 10 and len(alone[1]) >= 1 and len(alone[2]) >= 1
+    assert [_rows(h) for h in hmmer.nhmmer(queries, block)] == want
+    assert [_rows(h) for h in hmmer.nhmmer(queries, block, searches_in_flight=1)] == want
+    assert [_rows(h) for h in hmmer.nhmmer(queries, block, searches_in_flight=3)] == want

@@ -554,3 +554,33 @@ def test_target_file_is_searched_in_chunks(models, proteome, golden):
         with easel.SequenceFile(tmp.name, digital=True, alphabet=proteome.alphabet) as sf:
             empty = list(hmmer.hmmsearch(queries[:2], sf))
     assert [len(h) for h in empty] == [0, 0] and empty[0].Z == 0
+
+
+def test_hmmscan_streams_a_query_file_in_blocks(models, golden):
+    """A query FILE is walked a block at a time (the reference takes its queries one at a time, plan7.pyx:6680-6737): every
+    block is scanned against the whole profile database and its results are out before the next block is read; the
+    per-sequence hit lists are those of a scan of the whole file as one block, in file order, whatever the block size --
+    from a profile file that is rewound per block, and from a one-shot iterator of profiles."""
+    import io
+    path = golden / "seqs" / "938293.PRJEB85.HG003687.faa"
+    abc = easel.Alphabet.amino()
+
+    def table(results):
+        out = []
+        for hits in results:
+            b = io.BytesIO()
+            hits.write(b, format="targets", header=False)
+            out.append(b.getvalue())
+        return out
+
+    with easel.SequenceFile(path, digital=True, alphabet=abc) as sf:
+        whole = sf.read_block()
+    profs = models["RREFam"] + models["PF02826"]
+    want = table(hmmer.hmmscan(whole, profs))
+    assert sum(len(t) > 0 for t in want) >= 20
+    for per_block in (500, 64):
+        with easel.SequenceFile(path, digital=True, alphabet=abc) as sf:
+            assert table(hmmer.hmmscan(sf, iter(profs), query_block_sequences=per_block)) == want
+    with easel.SequenceFile(path, digital=True, alphabet=abc) as sf, plan7.HMMFile(golden / "hmms" / "RREFam.hmm") as hf:
+        got = table(hmmer.hmmscan(sf, hf, query_block_residues=200_000))           # native chunk reads, the profile file rewound per block
+    assert got == table(hmmer.hmmscan(whole, models["RREFam"]))
