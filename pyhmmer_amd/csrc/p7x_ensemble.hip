@@ -196,7 +196,9 @@ __global__ void __launch_bounds__(64) ens_walk_kernel(const EnsArgs a)
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   // One wavefront walks a region's 200 samples, a serial chain from the first deviate to the last: whenever it can issue
   // it should, ahead of the throughput kernels' wavefronts it shares a SIMD with.
+#ifndef P7X_ENS_NO_SETPRIO
   __builtin_amdgcn_s_setprio(3);
+#endif
   const int lane = threadIdx.x;
   const int r = blockIdx.x;
   const EnsRegion reg = a.regions[r];
@@ -624,7 +626,11 @@ public:
       int least = 0, greatest = 0;
       P7X_HIP(hipDeviceGetStreamPriorityRange(&least, &greatest));
       // a few wavefronts, each a long serial chain, and the host stage waits for them: ahead of the filter kernels' queues
+#ifdef P7X_ENS_STREAM_LOW
+      P7X_HIP(hipStreamCreateWithPriority(&eb->stream, hipStreamNonBlocking, least));
+#else
       P7X_HIP(hipStreamCreateWithPriority(&eb->stream, hipStreamNonBlocking, greatest));
+#endif
     }
     // which regions the device takes: every one whose records fit the workspace budget, and whose model the kernels cover
     size_t free_b = 0, total_b = 0;

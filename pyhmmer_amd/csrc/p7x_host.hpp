@@ -222,7 +222,7 @@ struct p7x_tophits {
   std::string qname, qacc, qdesc;     // the query (model) the alignment displays refer to
   bool q_has_acc = false, q_has_desc = false;
   int M = 0;
-  double ms[12]{};
+  double ms[16]{};            // see TopHits.timings_ms (plan7.py) for the slots
   bool sorted_by_key = false;
   bool scan_collected = false;        // built by p7x_scan_collect(): one query sequence, hits are models
   std::vector<uint8_t> stage;         // scan mode, per-model result: last filter passed by each target (not serialised)

@@ -392,7 +392,8 @@ int host_finish_batch(const p7x_pipeline_cfg &cfg_in, const std::vector<FinishIt
     if (!dev) finish(f, dds[(size_t) f]);
   });
   tick("regions");
-  double ms_multi = 0.0, ms_env = 0.0;
+  double ms_multi = 0.0, ms_env = 0.0, ms_ens_wait = 0.0, ms_env_wait = 0.0;
+  auto since = [](std::chrono::steady_clock::time_point a) { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - a).count(); };
   if (failed.load() == 0 && scorer) {
     std::vector<std::vector<EnvelopeRequest>> req((size_t) nq);
     std::vector<std::vector<int>> req_index((size_t) S);
@@ -441,10 +442,13 @@ int host_finish_batch(const p7x_pipeline_cfg &cfg_in, const std::vector<FinishIt
     if (any) { const int st = scorer->begin(jobs); if (st != P7X_OK) return st; }
     tick("env_begin");
     if (dev_ens) {
+      const auto tw = std::chrono::steady_clock::now();
       const int st = ensembles->wait(eres);
       if (st != P7X_OK) return st;
+      ms_ens_wait = since(tw);
       tick("ens_wait");
     }
+    const auto t_multi = std::chrono::steady_clock::now();
     // what remains of a region's resolution here is the clustering of the sampled end points; the clustered envelopes go
     // to the device as a second round (scorer2) instead of being rescored here
     std::vector<std::vector<EnvelopeRequest>> local2((size_t) S);
@@ -457,7 +461,7 @@ int host_finish_batch(const p7x_pipeline_cfg &cfg_in, const std::vector<FinishIt
                                             scorer2 ? &local2[(size_t) f] : nullptr, i, dev_ens ? mine.data() : nullptr);
       if (st != P7X_OK) failed.store(st);
     });
-    ms_multi = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t1).count();
+    ms_multi = since(t_multi);                  // the host's own share of the multi-domain regions: clustering, or sampling as well
     tick("multi");
     std::vector<std::vector<EnvelopeRequest>> req2((size_t) nq);
     std::vector<std::vector<int>> req_index2((size_t) S);
@@ -472,7 +476,7 @@ int host_finish_batch(const p7x_pipeline_cfg &cfg_in, const std::vector<FinishIt
       if (any2) { const int st = scorer2->begin(jobs2); if (st != P7X_OK) return st; }
     }
     std::vector<std::vector<EnvelopeResult>> res((size_t) nq), res2((size_t) nq);
-    if (any) { const int st = scorer->wait(res); if (st != P7X_OK) return st; }
+    if (any) { const auto tw = std::chrono::steady_clock::now(); const int st = scorer->wait(res); if (st != P7X_OK) return st; ms_env_wait += since(tw); }
     tick("env_wait");
     // 3. alignment displays, null2 corrections, per-target scores: the targets without a second-round envelope while that
     //    round runs, the others when it is in
@@ -491,7 +495,9 @@ int host_finish_batch(const p7x_pipeline_cfg &cfg_in, const std::vector<FinishIt
     if (failed.load() == 0) run_pool(S, [&](int f) { if (!second[(size_t) f]) complete(f); });
     tick("deferred");
     if (any2) {
+      const auto tw = std::chrono::steady_clock::now();
       const int st = scorer2->wait(res2); if (st != P7X_OK) return st;
+      ms_env_wait += since(tw);
       tick("env2_wait");
       if (failed.load() == 0) run_pool((int) heavy.size(), [&](int h) { const int f = heavy[(size_t) h]; if (second[(size_t) f]) complete(f); });
       tick("deferred2");
@@ -524,6 +530,8 @@ int host_finish_batch(const p7x_pipeline_cfg &cfg_in, const std::vector<FinishIt
       th.hits.push_back(std::move(h));
     }
     th.ms[5] = ms_host; th.ms[8] = ms_env; th.ms[9] = ms_multi;
+    th.ms[13] = ms_ens_wait; th.ms[14] = ms_env_wait;
+    th.ms[12] = std::max(0.0, ms_host - ms_ens_wait - ms_env_wait);       // the host stage without its waits for the device
     // Z for E-values: number of targets seen (p7_pli_NewSeq), unless set by the caller
     if (th.cfg.Z_setby == P7X_ZSETBY_NTARGETS) th.cfg.Z = (double) tg.n;
     sort_by_key(th);
@@ -822,7 +830,7 @@ static void merge_append(p7x_tophits *dst, p7x_tophits *src, bool move_hits)
   dst->ctr.n_past_msv += src->ctr.n_past_msv; dst->ctr.n_past_bias += src->ctr.n_past_bias;
   dst->ctr.n_past_vit += src->ctr.n_past_vit; dst->ctr.n_past_fwd += src->ctr.n_past_fwd;
   if (dst->cfg.Z_setby == P7X_ZSETBY_NTARGETS) dst->cfg.Z += src->cfg.Z;
-  for (int i = 0; i < 12; ++i) dst->ms[i] += src->ms[i];
+  for (int i = 0; i < 16; ++i) dst->ms[i] += src->ms[i];
 }
 static void merge_finalize(p7x_tophits *dst)
 {
@@ -871,7 +879,7 @@ int p7x_tophits_merge_longtargets(p7x_tophits **parts, size_t nparts, p7x_tophit
     dst->ctr.n_past_vit += src->ctr.n_past_vit; dst->ctr.n_past_fwd += src->ctr.n_past_fwd;
     dst->ctr.pos_past_msv += src->ctr.pos_past_msv; dst->ctr.pos_past_bias += src->ctr.pos_past_bias;
     dst->ctr.pos_past_vit += src->ctr.pos_past_vit; dst->ctr.pos_past_fwd += src->ctr.pos_past_fwd;
-    for (int i = 0; i < 12; ++i) dst->ms[i] = std::max(dst->ms[i], src->ms[i]);      // the parts ran side by side
+    for (int i = 0; i < 16; ++i) dst->ms[i] = std::max(dst->ms[i], src->ms[i]);      // the parts ran side by side
   }
   dst->cfg.lt_part = 0; dst->cfg.lt_nparts = 1;
   longtarget_finalize(dst.get(), dst->lt_evalue_window, longtarget_res_count(dst->cfg, dst->ctr.nres));
@@ -957,7 +965,7 @@ int64_t p7x_tophits_serialize(const p7x_tophits *th, void *buf, size_t cap)
   uint32_t magic = kMagic; w.pod(magic);
   w.pod(th->cfg); w.pod(th->ctr);
   w.str(th->qname); w.str(th->qacc); w.str(th->qdesc); w.pod(th->q_has_acc); w.pod(th->q_has_desc); w.pod(th->M); w.pod(th->scan_collected);
-  for (int i = 0; i < 12; ++i) w.pod(th->ms[i]);
+  for (int i = 0; i < 16; ++i) w.pod(th->ms[i]);
   const uint64_t n = th->hits.size(); w.pod(n);
   for (const Hit &hc : th->hits) {
     Hit &h = const_cast<Hit &>(hc);
@@ -981,7 +989,7 @@ p7x_tophits *p7x_tophits_deserialize(const void *buf, size_t n)
   auto th = std::make_unique<p7x_tophits>();
   r.pod(th->cfg); r.pod(th->ctr);
   r.str(th->qname); r.str(th->qacc); r.str(th->qdesc); r.pod(th->q_has_acc); r.pod(th->q_has_desc); r.pod(th->M); r.pod(th->scan_collected);
-  for (int i = 0; i < 12; ++i) r.pod(th->ms[i]);
+  for (int i = 0; i < 16; ++i) r.pod(th->ms[i]);
   uint64_t nh = 0; r.pod(nh);
   if (!r.ok) { set_error("truncated serialised TopHits"); return nullptr; }
   // a hit takes at least its fixed fields (three length words, the scores and counts): a count the buffer cannot hold
@@ -1020,7 +1028,7 @@ int p7x_tophits_get_guard_counts(const p7x_tophits *th, int64_t *f3_dropped, int
 int p7x_tophits_get_timings(const p7x_tophits *th, double *ms, int n)
 {
   if (!th || !ms) return P7X_EINVAL;
-  for (int i = 0; i < n && i < 12; ++i) ms[i] = th->ms[i];
+  for (int i = 0; i < n && i < 16; ++i) ms[i] = th->ms[i];
   return P7X_OK;
 }
 

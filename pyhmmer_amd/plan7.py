@@ -1143,10 +1143,15 @@ class TopHits:
 
     @property
     def timings_ms(self) -> dict:
-        buf = (C.c_double * 12)()
-        _lib.lib().p7x_tophits_get_timings(self._handle, buf, 12)
+        """Milliseconds of the batch this query travelled in.  ``host_domaindef``: the host stage, wall; of that
+        ``ensemble_wait`` and ``envelope_wait`` were spent waiting for the device (ensemble kernels; the two envelope rounds)
+        and ``host_stage_busy`` is the rest -- what the host itself did (region bookkeeping, clustering, alignments, hit
+        lists).  ``host_multi``: the host's own share of the multi-domain regions (clustering; sampling too when the ensembles
+        stay on the host).  ``envelopes``: wall from the first launch of the stage to the last result."""
+        buf = (C.c_double * 16)()
+        _lib.lib().p7x_tophits_get_timings(self._handle, buf, 16)
         return dict(zip(("msv", "bias", "viterbi", "forward", "fwd_rows", "host_domaindef", "total", "msv_kernel",
-                         "envelopes", "host_multi", "stage1", "stage2"), buf))
+                         "envelopes", "host_multi", "stage1", "stage2", "host_stage_busy", "ensemble_wait", "envelope_wait"), buf))
 
     @property
     def reported(self):
