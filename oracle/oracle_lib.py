@@ -171,3 +171,50 @@ def ssv_longtarget(op, block_dsq, max_length, F1=0.02, cap=1 << 16):
     n = l.p7o_ssv_longtarget(op.ptr, d.ctypes.data, len(block_dsq), int(max_length), float(F1), seeds.ctypes.data, cap)
     assert n <= cap
     return seeds[:n].copy()
+
+
+def lt_block(op, block_dsq, max_length, F1=0.02, F2=3e-3, F3=3e-5, B1=110, B2=240, B3=1000, do_bias=True, cap=1 << 14):
+    """The tail of p7_Pipeline_LongTarget for one strand block (p7_oracle_lt.c).  Returns (windows[n, 5], counts[8]): the windows
+    that pass Forward as (first residue, length, fwdsc, nullsc, filtersc at F3) in block coordinates; counts = windows past
+    MSV, bias, Viterbi, Forward, then residues past each."""
+    l = lib()
+    l.p7o_lt_block.restype = C.c_int64
+    l.p7o_lt_block.argtypes = [C.POINTER(Profile), C.c_void_p, C.c_int64, C.c_int, C.c_double, C.c_double, C.c_double,
+                               C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int64, C.c_void_p]
+    d = np.empty(len(block_dsq) + 2, dtype=np.uint8)
+    d[0] = d[-1] = 255
+    d[1:-1] = block_dsq
+    out = np.zeros((cap, 6), dtype=np.float64)
+    counts = np.zeros(8, dtype=np.uint64)
+    n = l.p7o_lt_block(op.ptr, d.ctypes.data, len(block_dsq), int(max_length), F1, F2, F3, B1, B2, B3, int(do_bias),
+                       out.ctypes.data, cap, counts.ctypes.data)
+    assert n <= cap
+    return out[:n, :5].copy(), counts
+
+
+def lt_domain_score(op, max_length, env_len, ali_len, envsc, domcorrection, do_null2=True):
+    l = lib()
+    l.p7o_lt_domain_score.restype = C.c_float
+    l.p7o_lt_domain_score.argtypes = [C.POINTER(Profile), C.c_int, C.c_int64, C.c_int64, C.c_float, C.c_float, C.c_int, C.c_void_p, C.c_void_p]
+    bias, lnp = C.c_float(0), C.c_double(0)
+    sc = l.p7o_lt_domain_score(op.ptr, int(max_length), int(env_len), int(ali_len), float(envsc), float(domcorrection), int(do_null2),
+                               C.byref(bias), C.byref(lnp))
+    return float(sc), float(bias.value), float(lnp.value)
+
+
+def lt_envelope_scores(op, env_residues, window_len):
+    """Forward of one envelope under its own length model, unihit: (orig, adjusted) in nats -- with the profile's odds and with
+    odds re-derived for the background mixed with the envelope's composition (reparameterize_model)."""
+    l = lib()
+    l.p7o_lt_envelope_scores.restype = C.c_int
+    l.p7o_lt_envelope_scores.argtypes = [C.POINTER(Profile), C.c_void_p, C.c_int, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]
+    d = np.empty(len(env_residues) + 2, dtype=np.uint8)
+    d[0] = d[-1] = 255
+    d[1:-1] = env_residues
+    K = op.ptr.contents.K
+    degen = np.zeros((32, K), dtype=np.uint8)
+    degen[:K, :K] = np.eye(K, dtype=np.uint8)
+    orig, adj = C.c_float(0), C.c_float(0)
+    st = l.p7o_lt_envelope_scores(op.ptr, d.ctypes.data, len(env_residues), int(window_len), degen.ctypes.data, C.byref(orig), C.byref(adj))
+    assert st == 0
+    return float(orig.value), float(adj.value)

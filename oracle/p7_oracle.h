@@ -119,6 +119,17 @@ float p7o_sse_expf_scalar(float x);
 /* long targets: upstream p7_SSVFilter_longtarget for one strand block; seeds = cap x (first residue, last node, length) */
 int64_t p7o_ssv_longtarget(P7O_PROFILE *p, const uint8_t *dsq, int64_t L, int max_length, double F1, int64_t *seeds, int64_t cap);
 
+/* long targets, behind the SSV scan (p7_oracle_lt.c): one strand block through window merging, the MSV / bias tests, the
+ * long-target Viterbi scan and the Forward test; the scoring of an envelope; the background an envelope is rescored against */
+int64_t p7o_lt_block(P7O_PROFILE *p, const uint8_t *dsq, int64_t L, int max_length, double F1, double F2, double F3,
+                     int B1, int B2, int B3, int do_bias, double *out, int64_t cap, uint64_t *counts);
+float p7o_lt_domain_score(const P7O_PROFILE *p, int max_length, int64_t env_len, int64_t ali_len,
+                          float envsc, float domcorrection, int do_null2, float *ret_bias_bits, double *ret_lnP);
+int   p7o_lt_envelope_scores(const P7O_PROFILE *p, const uint8_t *env, int n, int64_t window_len, const uint8_t *degen,
+                             float *orig, float *adj);
+void  p7o_lt_envelope_background(const P7O_PROFILE *p, const uint8_t *env, int64_t n_env, int64_t window_len,
+                                 const uint8_t *degen, float *bg_out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -348,3 +348,26 @@ def test_a_stream_of_queries_overlaps_searches_and_gives_the_same_hits():
     assert [_rows(h) for h in hmmer.nhmmer(queries, block)] == want
     assert [_rows(h) for h in hmmer.nhmmer(queries, block, searches_in_flight=1)] == want
     assert [_rows(h) for h in hmmer.nhmmer(queries, block, searches_in_flight=3)] == want
+
+
+def test_device_long_target_search_against_the_oracle_restatement():
+    """hmmer.nhmmer (SSV scan, window filters, long-target Viterbi scan, Forward, Backward and region scan on the device,
+    envelope kernel or host workers for the envelopes) on a 2 Mbp synthetic chromosome with more than a thousand SSV
+    windows -- copies of the model on both strands, copies laid across the seams between blocks, hundreds of fragments
+    shorter than 100 residues, low-complexity stretches -- against oracle/p7_oracle_lt.c, which restates the tail of
+    p7_Pipeline_LongTarget apart from the product (plan7.pyx:7541-7664, p7_pipeline.pxd:131-143): the windows past every
+    filter are counted alike, every hit lies inside a window the oracle lets through Forward, and its score and bias follow
+    from its own envelope and alignment coordinates by the oracle's rule (1e-3 bit), the envelope's two Forward scores from
+    its residues (5e-3 nat)."""
+    import lt_oracle_check as lc
+    hmm = load_hmms("bmyD")[0]
+    pli = plan7.LongTargetsPipeline(hmm.alphabet)
+    seq = lc.synthetic_chromosome(hmm, 2_000_000, seed=23, block_length=pli.block_length, max_length=hmm.max_length)
+    block = easel.DigitalSequenceBlock(hmm.alphabet, [easel.DigitalSequence(hmm.alphabet, name="chr2M", sequence=seq)])
+    hits = next(iter(hmmer.nhmmer([hmm], block)))
+    nwin, nshort = lc.check_hits_against_oracle(pli, hmm, seq, hits, min_windows=1000, min_short=30)
+    assert len(hits) >= 150
+    # the same with the envelopes forced onto the envelope kernel, and onto the host workers
+    for where in (1, 2):
+        other = next(iter(hmmer.nhmmer([hmm], block, host_envelopes=where)))
+        lc.check_hits_against_oracle(pli, hmm, seq, other, min_windows=1000, min_short=30)

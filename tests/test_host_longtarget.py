@@ -3,6 +3,7 @@ tail (p7x_longtarget_from_seeds: window filters, long-target Viterbi, parsers, d
 hit construction, p7_tophits_ComputeNhmmerEvalues / RemoveDuplicates) does the rest.  Pinned by the reference's own
 nhmmer fixtures (reference tests/test_hmmer.py:631-795): tables/bmyD1.tbl and bmyD2.tbl (real nhmmer 3.3 / 3.4 output)
 and the RF00001 known answers."""
+import numpy as np
 import pytest
 
 import host_pipeline
@@ -180,3 +181,51 @@ def test_search_dealt_over_parts_equals_the_whole(libp7x, oracle):
     bad = (C.c_void_p * 1)(None)
     out = C.c_void_p()
     assert _lib.lib().p7x_tophits_merge_longtargets(bad, 1, C.byref(out)) != 0
+
+
+def test_long_target_tail_against_the_oracle_restatement(oracle):
+    """The product's host tail (fed with the oracle's SSV seeds) against oracle/p7_oracle_lt.c on a 300 kbp synthetic chromosome with
+    copies across block seams, short fragments and low-complexity stretches: the numbers of windows past every filter are equal,
+    every hit lies inside a window the oracle lets through Forward, and every score follows from the hit's own coordinates by
+    the oracle's scoring rule (1e-3 bit).  The 2 Mbp version of this test runs the device path (tests/test_gpu_longtarget.py)."""
+    import lt_oracle_check as lc
+    hmm = load_hmms("bmyD")[0]
+    pli = plan7.LongTargetsPipeline(hmm.alphabet, block_length=65536)
+    seq = lc.synthetic_chromosome(hmm, 300_000, seed=11, block_length=pli.block_length, max_length=hmm.max_length)
+    block = easel.DigitalSequenceBlock(hmm.alphabet, [easel.DigitalSequence(hmm.alphabet, name="chrT", sequence=seq)])
+    hits = host_pipeline.host_nhmmer(oracle, hmm, block, pipeline=pli)
+    nwin, nshort = lc.check_hits_against_oracle(pli, hmm, seq, hits, min_windows=100, min_short=3)
+    assert len(hits) >= 20
+
+
+def _cut_model(full, lo, hi, name):
+    """Nodes lo+1 .. hi of <full> as a model of their own (test input: a short nucleotide model, short windows)."""
+    abc = full.alphabet
+    h = plan7.HMM(abc, hi - lo, name)
+    h.transition_probabilities[1:] = full.transition_probabilities[lo + 1:hi + 1]
+    h.transition_probabilities[0] = full.transition_probabilities[0]
+    h.match_emissions[1:] = full.match_emissions[lo + 1:hi + 1]
+    h.insert_emissions[:] = full.insert_emissions[lo:hi + 1]
+    t = np.array(h.transition_probabilities[hi - lo])
+    t[0], t[2] = t[0] + t[2], 0.0
+    t[5], t[6] = 1.0, 0.0
+    h.transition_probabilities[hi - lo] = t
+    h.composition = full.composition
+    h.consensus = full.consensus[lo:hi]
+    h._evparam[:] = full._evparam
+    return h
+
+
+def test_short_windows_against_the_oracle_restatement(oracle):
+    """A 40-node model: its windows are a few dozen residues long, so the background an envelope is rescored against is mixed
+    with smoothing 25 / max(50, n) > 0.25 -- the branch of upstream's reparameterize_model that no fixture of the reference
+    reaches (all its windows are longer than 100 residues)."""
+    import lt_oracle_check as lc
+    full = load_hmms("bmyD")[0]
+    hmm = _cut_model(full, 400, 440, "bmyD_40")
+    pli = plan7.LongTargetsPipeline(hmm.alphabet, block_length=32768, E=100.0, window_length=70)     # nhmmer --w_length 70
+    seq = lc.synthetic_chromosome(hmm, 120_000, seed=5, block_length=pli.block_length, max_length=70, long_copies=False)
+    block = easel.DigitalSequenceBlock(hmm.alphabet, [easel.DigitalSequence(hmm.alphabet, name="chrS", sequence=seq)])
+    hits = host_pipeline.host_nhmmer(oracle, hmm, block, pipeline=pli)
+    nwin, nshort, nshortwin = lc.check_hits_against_oracle(pli, hmm, seq, hits, min_windows=20, min_short=5, want_short_windows=True)
+    assert nshortwin >= 3 and len(hits) >= 5
