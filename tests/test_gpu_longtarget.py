@@ -364,10 +364,11 @@ def test_device_long_target_search_against_the_oracle_restatement():
     pli = plan7.LongTargetsPipeline(hmm.alphabet)
     seq = lc.synthetic_chromosome(hmm, 2_000_000, seed=23, block_length=pli.block_length, max_length=hmm.max_length)
     block = easel.DigitalSequenceBlock(hmm.alphabet, [easel.DigitalSequence(hmm.alphabet, name="chr2M", sequence=seq)])
+    want = lc.oracle_windows(pli, hmm, seq)                     # once: a minute of scalar C
     hits = next(iter(hmmer.nhmmer([hmm], block)))
-    nwin, nshort = lc.check_hits_against_oracle(pli, hmm, seq, hits, min_windows=1000, min_short=30)
+    nwin, nshort = lc.check_hits_against_oracle(pli, hmm, seq, hits, min_windows=1000, min_short=30, oracle=want)
     assert len(hits) >= 150
     # the same with the envelopes forced onto the envelope kernel, and onto the host workers
     for where in (1, 2):
         other = next(iter(hmmer.nhmmer([hmm], block, host_envelopes=where)))
-        lc.check_hits_against_oracle(pli, hmm, seq, other, min_windows=1000, min_short=30)
+        lc.check_hits_against_oracle(pli, hmm, seq, other, min_windows=1000, min_short=30, oracle=want)
