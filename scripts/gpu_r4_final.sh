@@ -19,11 +19,12 @@ for f in sorted(glob.glob("gpurun_out/r04/bench_*.json")):
                   "scan", (j.get('scan') or {}).get('value'), (j.get('scan') or {}).get('seconds'), "nhmmer", (j.get('nhmmer') or {}).get('s_per_search'), "cpu", (j.get('cpu_baseline') or {}).get('value'))
 PY
 cd /tmp && export TMPDIR=/tmp
-timeout 900 rocprofv3 --kernel-trace --stats -d $R/$OUT/trace -o bench -- python $R/bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline > $R/$OUT/bench_traced.json 2> $R/$OUT/bench_traced.err
+# (the full command -- with the pfam / scan / nhmmer fields -- dies inside rocprofv3's own interception layer once a few dozen
+# streams are live; the headline workload alone, same flags, is what is traced)
+timeout 900 rocprofv3 --kernel-trace --stats -d $R/$OUT/trace -o bench -- python $R/bench.py --gpus 1 --steps 20 --warmup 5 --workload config1 --no-cpu-baseline > $R/$OUT/bench_traced.json 2> $R/$OUT/bench_traced.err
 cd $R
-python scripts/rocprof_summary.py $(find $OUT/trace -name "*.db" | head -1) $OUT/kernel_stats.md "python bench.py --gpus 1 --steps 20 --warmup 5 under rocprofv3 --kernel-trace --stats" > /dev/null
+python scripts/rocprof_summary.py $(find $OUT/trace -name "*.db" | head -1) $OUT/kernel_stats.md "python bench.py --gpus 1 --steps 20 --warmup 5 --workload config1 --no-cpu-baseline under rocprofv3 --kernel-trace --stats" > /dev/null
 head -30 $OUT/kernel_stats.md | cut -c1-160
-bash scripts/pmc_msv.sh $OUT/pmc 7 > $OUT/pmc.log 2>&1
 find $OUT -name "*.db" -delete
 find $OUT -name "*.csv" -size +2M -delete
 du -sh $OUT
