@@ -195,12 +195,11 @@ struct EnsArgs {
 
 // ---- long-target SSV scan (p7x_ssvlong.hip): one chunk of one strand per wavefront, model split across the lanes
 struct SsvLongArgs {
-  const uint32_t *tab4;       // [2 parities][4][R][64] packed emission pairs of A, C, G, T (staged in LDS)
-  const uint32_t *tab_full;   // [2][Kp][R][64] the same for every residue code (degenerate residues, read from global memory)
+  const uint32_t *tab4q;      // [2 parities][4][(R+3)/4][64] uint4: quads of packed emission pairs of A, C, G, T (staged in LDS)
+  const uint32_t *tab_full;   // [2][Kp][R][64] the pairs of every residue code (degenerate residues, read from global memory)
   const uint8_t *dsq;         // the target, 1-based (dsq[0] is a sentinel)
   const uint8_t *comp;        // [Kp] complement of every residue code
-  int pair_slack;             // register kernel: the most a cell can lose in one row with a canonical residue (byte units)
-  int use_lds;                // 1: the LDS kernel also where the register kernel exists (A/B, tests)
+  int pair_slack;             // the most a cell can lose in one row with a canonical residue (byte units)
   const long long *chunk_list;  // NULL: every chunk; else the nchunks chunk numbers to scan (a part of a search dealt over devices)
   long long L;                // target length
   int M, Kp;
@@ -212,10 +211,11 @@ struct SsvLongArgs {
   // rows that reach the threshold: position on the strand, strand, and the cell upstream would pick (node, byte score)
   int *nrec; long long *rec_pos; uint8_t *rec_strand; int *rec_k; int *rec_sc; int rec_cap;
 };
-int  ssvlong_pick_R(int M);
-void ssvlong_build_tables(const Profile &p, int R, bool virtual_node, std::vector<uint32_t> &tab4, std::vector<uint32_t> &tab_full, int *pair_slack);
-constexpr int kSsvRegMaxR = 24;     // up to this many packed registers per lane the emission pairs live in registers (ssvlong_reg_kernel)
-int  ssvlong_launch(int R, const SsvLongArgs &a, int num_cu, hipStream_t st);
+// <pair>: the row maximum only on every second row, against a threshold lowered by pair_slack, tables with the virtual node
+int  ssvlong_pick_R(int M, bool pair);
+void ssvlong_build_tables(const Profile &p, int R, bool pair, std::vector<uint32_t> &tab4q, std::vector<uint32_t> &tab_full, int *pair_slack);
+int  ssvlong_capacity(int R, bool pair, int num_cu, long long *waves);
+int  ssvlong_launch(int R, bool pair, const SsvLongArgs &a, int num_cu, hipStream_t st);
 
 // ---- thread-per-sequence small stages (p7x_pipeline.hip)
 } // namespace p7x

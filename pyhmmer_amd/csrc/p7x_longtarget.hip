@@ -86,37 +86,44 @@ static int scan_target(const p7x_pipeline_cfg &cfg, const Profile &p, DeviceCtx 
                        int sc_thresh, int xB, int strands_mask, std::vector<ScanRow> &rows, double *ms, const std::vector<ScanRange> *ranges = nullptr,
                        int device = 0, uint64_t resident_key = 0)
 {
-  const int R = ssvlong_pick_R(p.M);
+  // option ssv_kernel = 3 (tests, A/B): the row maximum in every row instead of every second one
+  const bool pair = debug_opt(OPT_SSV_KERNEL) != 3;
+  const int R = ssvlong_pick_R(p.M, pair);
   if (R < 0) { set_error("model too long for the long-target SSV kernel (M > 6141)"); return P7X_EINVAL; }
-  std::vector<uint32_t> tab4, tab_full;
+  std::vector<uint32_t> tab4q, tab_full;
   int pair_slack = 0;
-  ssvlong_build_tables(p, R, false, tab4, tab_full, &pair_slack);
-  DevBuf d_tab4, d_full, d_comp, d_nrec, d_pos, d_strand, d_k, d_sc;
+  ssvlong_build_tables(p, R, pair, tab4q, tab_full, &pair_slack);
+  DevBuf d_tab4q, d_full, d_comp, d_nrec, d_pos, d_strand, d_k, d_sc;
   int st;
-  if ((st = d_tab4.alloc(tab4.size() * 4)) || (st = d_full.alloc(tab_full.size() * 4)) ||
-      (st = d_comp.alloc(32)) || (st = d_nrec.alloc(4))) return st;
+  if ((st = d_tab4q.alloc(tab4q.size() * 4)) || (st = d_full.alloc(tab_full.size() * 4)) || (st = d_comp.alloc(32)) || (st = d_nrec.alloc(4))) return st;
   hipStream_t s = ctx->stream;
   std::shared_ptr<ResidentTargets> d_seq;
   bool uploaded = false;
   if ((st = resident_targets(ctx, device, resident_key, seq1, L, d_seq, &uploaded)) != P7X_OK) return st;
   if ((debug_opt(OPT_TRACE_LONGTARGET) > 0)) std::fprintf(stderr, "[lt] targets on the device: %s (%lld bytes, key %llu)\n", uploaded ? "uploaded" : "resident", (long long) L, (unsigned long long) resident_key);
-  P7X_HIP(hipMemcpyAsync(d_tab4.p, tab4.data(), tab4.size() * 4, hipMemcpyHostToDevice, s));
+  P7X_HIP(hipMemcpyAsync(d_tab4q.p, tab4q.data(), tab4q.size() * 4, hipMemcpyHostToDevice, s));
   P7X_HIP(hipMemcpyAsync(d_full.p, tab_full.data(), tab_full.size() * 4, hipMemcpyHostToDevice, s));
   P7X_HIP(hipMemcpyAsync(d_comp.p, longtarget_complement(p.abc_type), 18, hipMemcpyHostToDevice, s));
-  // chunks: long enough that the M warm-up rows are a small overhead, short enough that every SIMD gets several
-  const int64_t want_chunks = (int64_t) ctx->num_cu * 4 * 8;
+  // chunks: long enough that the M warm-up rows are a small overhead.  The kernel's wavefronts all stay on the device and
+  // take the chunks in turn, so the number of chunks is made a multiple of the wavefronts (a last round that only some
+  // of them take is paid in full: 16,384 chunks on 3,072 wavefronts were six rounds, the last a third full)
+  const int nstrands_plan = strands_mask == 3 ? 2 : 1;
+  long long waves = 0;
+  if ((st = ssvlong_capacity(R, pair, ctx->num_cu, &waves)) != P7X_OK) return st;
+  const int64_t rounds = std::max<int64_t>(1, (L * nstrands_plan + waves * 49152 - 1) / (waves * 49152));
+  const int64_t want_chunks = (waves * rounds + nstrands_plan - 1) / nstrands_plan;             // per strand
   int chunk_len = (int) std::max<int64_t>(8 * (int64_t) p.M, std::min<int64_t>(1 << 16, (L + want_chunks - 1) / want_chunks));
   chunk_len = ((chunk_len + 63) / 64) * 64;
   const int nstrands = strands_mask == 3 ? 2 : 1;
   SsvLongArgs a{};
-  a.tab4 = static_cast<const uint32_t *>(d_tab4.p); a.tab_full = static_cast<const uint32_t *>(d_full.p);
+  a.tab4q = static_cast<const uint32_t *>(d_tab4q.p); a.tab_full = static_cast<const uint32_t *>(d_full.p);
   a.dsq = static_cast<const uint8_t *>(d_seq->p); a.comp = static_cast<const uint8_t *>(d_comp.p);
   a.L = L; a.M = p.M; a.Kp = p.Kp; a.chunk_len = chunk_len;
   a.chunks_per_strand = (L + chunk_len - 1) / chunk_len; a.nchunks = a.chunks_per_strand * nstrands;
   a.thresh_s = sc_thresh - xB - 32768; a.xB = xB; a.Q16 = p.Q16();
   a.nrec = static_cast<int *>(d_nrec.p);
   a.strand0 = strands_mask == 2 ? 1 : 0;
-  a.pair_slack = pair_slack; a.use_lds = R > kSsvRegMaxR ? 1 : 0;
+  a.pair_slack = pair_slack;
   DevBuf d_chunks;
   if (ranges) {
     std::vector<long long> list;
@@ -146,7 +153,7 @@ static int scan_target(const p7x_pipeline_cfg &cfg, const Profile &p, DeviceCtx 
     a.rec_k = static_cast<int *>(d_k.p); a.rec_sc = static_cast<int *>(d_sc.p); a.rec_cap = cap;
     P7X_HIP(hipMemsetAsync(d_nrec.p, 0, 4, s));
     P7X_HIP(hipEventRecord(e0, s));
-    if ((st = ssvlong_launch(R, a, ctx->num_cu, s)) != P7X_OK) return st;
+    if ((st = ssvlong_launch(R, pair, a, ctx->num_cu, s)) != P7X_OK) return st;
     P7X_HIP(hipEventRecord(e1, s));
     int nrec = 0;
     P7X_HIP(hipMemcpyAsync(&nrec, d_nrec.p, 4, hipMemcpyDeviceToHost, s));

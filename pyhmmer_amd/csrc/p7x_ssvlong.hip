@@ -17,9 +17,9 @@
 // nothing inside a lane, and one DPP move per odd row carries the last register of a lane to the next lane).  Cells
 // are stored relative to the constant begin score, s = v - xB - 32768, so v_pk_add_i16 clamp computes
 // max(M[k-1], xB) + e in one instruction; with the row-maximum update that is 2 packed ops per 2 cells.  The emission
-// scores of A, C, G, T for both parities sit in LDS ([parity][x][j][lane], one conflict-free ds_read_b32 per register);
-// degenerate residues (rare in chromosomes) take a slow path through the full table in global memory.  u8 saturation at
-// 255 is not reproduced: it can only keep a cell at or above a threshold it has already reached.
+// scores of A, C, G, T for both parities sit in LDS as quads of registers; degenerate residues (rare in chromosomes)
+// take a slow path through the full table in global memory.  u8 saturation at 255 is not reproduced: it can only keep a
+// cell at or above a threshold it has already reached.
 #include "p7x_wave.hpp"
 #include <mutex>
 
@@ -34,168 +34,87 @@ constexpr uint32_t kFloor2 = 0x80008000u;
 
 }  // namespace
 
-// one chunk of one strand per wavefront
-template <int R>
-__global__ void __launch_bounds__(256) ssvlong_kernel(const SsvLongArgs a)
+// ---------------------------------------------------------------------------------------- emission quads from LDS
+// The row loop has no branch on the residue.  Its predecessors did: rounds 2-3 kept the emission pairs of A, C, G, T in
+// 8 R registers and selected the set through a four-way wave-uniform branch per row -- 15.9 TCUPS = 0.40 of the
+// packed-op roof, held there not by arithmetic but by the code around it (5-8 scalar branches and mask moves per row as
+// the compiler lowers the switch, 136 VGPRs = three wavefronts per SIMD, a vmcnt(0) at every join that also waits for the
+// residues fetched ahead); round 2 read them from LDS one ds_read_b32 per register, which occupies the LDS pipe for as
+// long as the two packed operations occupy the SIMD (13.6 TCUPS).  Here the table is [parity][x][q][lane] uint4 (quad
+// q = registers 4q .. 4q+3 of the lane), one ds_read_b128 per quad whose address is the lane's slot plus a wave-uniform
+// offset x * R4 * 1 KiB.  A ds_read_b128 moves 256 B per LDS clock (a ds_read_b32 128 B), so a register costs the LDS
+// one clock per wavefront against eight SIMD clocks of packed arithmetic: with four SIMDs per CU the LDS pipe is half
+// used.  The 16-byte slots of consecutive lanes are consecutive, which is conflict-free for the b128 service groups.
+// 77-80 VGPRs at R = 10: six wavefronts per SIMD.  Measured, bmyD (M = 1203) x 250 Mbp x 2 strands: 25.6 ms = 23.5 TCUPS
+// with the maximum in every row, 21.7 ms = 27.7 TCUPS = 0.70 of the roof with PAIR (round 3: 37.7 ms).
+//   * 64 rows at a time.  A block whose residues are all canonical (ballot, once per block) runs as straight-line
+//     code, 16 rows per loop trip, the quads of row r+1 in flight while row r is computed (two register sets), the
+//     row maxima folded into two accumulators that are compared with the threshold once per 16 rows.  If a group
+//     reaches it (rare) -- or the block holds a degenerate residue, a separator, or is the ragged end of a chunk -- the
+//     block is run again from its saved first row by the row-by-row loop, which tests every row and reports.
+//   * PAIR: the maximum is only taken on every second row (the second, fourth, ... of a block, so that the successor of
+//     every skipped row lies in the same block), against a threshold lowered by the most a cell can lose in one row
+//     (pair_slack): a cell at or above the threshold on a skipped row is at or above the lowered one a row later, one
+//     node further -- for the last node that is the virtual node M + 1 of the tables, whose emission is 0.  The exact
+//     test of the repeat decides; the virtual node never counts as a cell there.
+//   * chunks are sized by the caller so that their number is a multiple of the resident wavefronts (ssvlong_capacity).
+__device__ __forceinline__ bool ssv_reached(uint32_t acc, int thr)
 {
-  // LDS: emission pairs of the four canonical residues, [parity][x][j][lane]
-  extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
-  for (int i = threadIdx.x; i < 2 * 4 * R * 64; i += 256) lds[i] = a.tab4[i];
-  __syncthreads();
-  const int lane = threadIdx.x & 63;
-  const int wave = rfl((int) (blockIdx.x * 4 + (threadIdx.x >> 6)));
-  const int nwaves = (int) gridDim.x * 4;
+  const int hi = (int) (short) (acc >> 16), lo = (int) (short) (acc & 0xffffu);
+  return __any(max(hi, lo) >= thr) != 0;
+}
 
-  for (long long chi = wave; chi < a.nchunks; chi += nwaves) {
-    const long long ch = a.chunk_list ? a.chunk_list[chi] : chi;
-    // chunk ch of strand s: rows first .. last (1-based positions on that strand), preceded by up to M warm-up rows
-    const int strand = a.strand0 + (int) (ch / a.chunks_per_strand);  // 0: as given, 1: reverse complement
-    const long long c0 = (ch % a.chunks_per_strand) * (long long) a.chunk_len;
-    const long long first = c0 + 1, last = min(a.L, c0 + a.chunk_len);
-    const long long warm = max(1LL, first - a.M);
-    uint32_t v[R];
+// one row; ODD: register g <- f(register g-1), the lane's first register from the lane before.  DOMAX: fold into acc0 / acc1
+template <int R, bool ODD, bool DOMAX, int RE>
+__device__ __forceinline__ void ssv_row(uint32_t (&v)[R], const uint32_t (&e)[RE], uint32_t &acc0, uint32_t &acc1)
+{
+  static_assert(RE >= R, "emission registers");
+  if constexpr (ODD) {
+    const uint32_t carry = (uint32_t) dpp_shr1((int) v[R - 1], (int) kFloor2);
 #pragma unroll
-    for (int j = 0; j < R; ++j) v[j] = kFloor2;
-    for (long long i0 = warm; i0 <= last; i0 += 64) {
-      const int nrow = (int) min(64LL, last - i0 + 1);
-      // residues of the next 64 rows, one per lane: strand 1 reads the target backwards and complements
-      uint32_t res = 0;
-      if (lane < nrow) {
-        const long long pos = i0 + lane;                              // position on this strand
-        const long long src = strand == 0 ? pos : a.L - pos + 1;      // position in the stored sequence
-        const uint32_t x = a.dsq[src];
-        res = strand == 0 || x >= (uint32_t) a.Kp ? x : (uint32_t) a.comp[x];       // codes outside the alphabet separate targets
-      }
-      for (int r = 0; r < nrow; ++r) {
-        const long long i = i0 + r;
-        const int x = __builtin_amdgcn_readlane((int) res, r);
-        const bool odd = ((i - warm) & 1) == 0;                       // the first row of a chunk is an "odd" row
-        uint32_t acc = kFloor2;
-        if (x < 4) {
-          const uint32_t *e = lds + ((size_t) ((odd ? 0 : 4) + x) * R) * 64 + lane;
-          if (odd) {       // register g <- f(register g-1): walk downwards, the lane's first register comes from the lane before
-            const uint32_t carry = (uint32_t) dpp_shr1((int) v[R - 1], (int) kFloor2);
+    for (int j = R - 1; j >= 1; --j) {
+      v[j] = pk_adds_u(v[j - 1], e[j]);
+      if constexpr (DOMAX) { if (j & 1) acc1 = pk_max_u(acc1, v[j]); else acc0 = pk_max_u(acc0, v[j]); }
+    }
+    v[0] = pk_adds_u(carry, e[0]);
+    if constexpr (DOMAX) acc0 = pk_max_u(acc0, v[0]);
+  } else {
 #pragma unroll
-            for (int j = R - 1; j >= 1; --j) { v[j] = pk_adds_u(v[j - 1], e[j * 64]); acc = pk_max_u(acc, v[j]); }
-            v[0] = pk_adds_u(carry, e[0]); acc = pk_max_u(acc, v[0]);
-          } else {
-#pragma unroll
-            for (int j = 0; j < R; ++j) { v[j] = pk_adds_u(v[j], e[j * 64]); acc = pk_max_u(acc, v[j]); }
-          }
-        } else if (x >= a.Kp) {     // between two targets of a concatenated scan: every diagonal ends here
-#pragma unroll
-          for (int j = 0; j < R; ++j) v[j] = kFloor2;
-        } else {           // degenerate residue: emissions from the full table in global memory [parity][Kp][R][64]
-          const uint32_t *e = a.tab_full + ((size_t) ((odd ? 0 : a.Kp) + x) * R) * 64 + lane;
-          if (odd) {
-            const uint32_t carry = (uint32_t) dpp_shr1((int) v[R - 1], (int) kFloor2);
-#pragma unroll
-            for (int j = R - 1; j >= 1; --j) { v[j] = pk_adds_u(v[j - 1], e[j * 64]); acc = pk_max_u(acc, v[j]); }
-            v[0] = pk_adds_u(carry, e[0]); acc = pk_max_u(acc, v[0]);
-          } else {
-#pragma unroll
-            for (int j = 0; j < R; ++j) { v[j] = pk_adds_u(v[j], e[j * 64]); acc = pk_max_u(acc, v[j]); }
-          }
-        }
-        // any cell of this row at or above the threshold?  (rare: the wavefront leaves the fast path together)
-        const int hi = (int) (short) (acc >> 16), lo = (int) (short) (acc & 0xffffu);
-        const bool hit = max(hi, lo) >= a.thresh_s;
-        if (i >= first && __any(hit)) {
-          // the cell upstream would pick: the highest byte score (scores saturate at 255), the first such cell in the
-          // order in which p7_SSVFilter_longtarget unstripes the row (vector q outer, byte z inner; k = q + Q z + 1)
-          int best = INT_MIN, bestkey = INT_MAX;
-#pragma unroll
-          for (int j = 0; j < R; ++j) {
-            const int g = lane * R + j, c0 = odd ? 2 * g - 1 : 2 * g;
-#pragma unroll
-            for (int h = 0; h < 2; ++h) {
-              const int k = c0 + h;
-              const int sv = (int) (short) (h ? (v[j] >> 16) : (v[j] & 0xffffu));
-              if (k >= 1 && k <= a.M) {
-                const int val = min(255, sv + 32768 + a.xB);
-                const int key = ((k - 1) % a.Q16) * 16 + (k - 1) / a.Q16;
-                if (val > best || (val == best && key < bestkey)) { best = val; bestkey = key; }
-              }
-            }
-          }
-          const int smax = wave_max_i32(best);
-          const int kmin = -wave_max_i32(best == smax ? -bestkey : INT_MIN);
-          if (lane == 0) {
-            const int slot = atomicAdd(a.nrec, 1);
-            if (slot < a.rec_cap) {
-              a.rec_pos[slot] = i; a.rec_strand[slot] = (uint8_t) strand;
-              a.rec_k[slot] = (kmin / 16) + a.Q16 * (kmin % 16) + 1; a.rec_sc[slot] = smax;
-            }
-          }
-        }
-      }
+    for (int j = 0; j < R; ++j) {
+      v[j] = pk_adds_u(v[j], e[j]);
+      if constexpr (DOMAX) { if (j & 1) acc1 = pk_max_u(acc1, v[j]); else acc0 = pk_max_u(acc0, v[j]); }
     }
   }
 }
 
-// ---------------------------------------------------------------------------------------- emission pairs in registers
-// Every lane of a wavefront works on the same residue, so a row needs the emission pairs of ONE residue: with the pairs
-// of A, C, G, T for both parities held in registers (8 R of them) a row is R saturating adds and R maxima and no LDS
-// traffic at all (the LDS kernel above issues one ds_read_b32 per register and row, which at 64 lanes x 4 bytes occupies
-// the LDS pipe for as long as the two packed operations occupy the SIMD).  The residue selects the register set through
-// a wave-uniform branch; rows run in (odd, even) pairs so that the parity is static.  The threshold test is deferred: the
-// row maxima of eight rows are folded into one register and compared once; only a block in which some row reached the
-// threshold (rare) is run again from its saved first row with the test in every row.  The residues of the next 64 rows
-// are fetched while the current ones are processed.  Models up to 3,069 nodes (R <= 24: 192 table registers); longer
-// ones keep the LDS kernel.  250 Mbp x 2 strands x M = 1203: 37.7 ms against 44.1 ms (profiles/r03_ssv_kernels.txt lists
-// the variants that were measured, among them two that halve the maxima and were no faster: the compiler's handling of
-// the wave-uniform branches, not the arithmetic, sets the pace).
-template <int R>
-__global__ void __launch_bounds__(256) ssvlong_reg_kernel(const SsvLongArgs a)
+template <int R, bool PAIR>
+__global__ void __launch_bounds__(256) ssvlong_quad_kernel(const SsvLongArgs a)
 {
+  constexpr int R4 = (R + 3) / 4;
+  constexpr int RE = 4 * R4;                       // emission registers of a row (the last quad may be partly unused)
+  constexpr int XS = R4 * 64;                      // uint4 per (parity, residue)
+  extern __shared__ __attribute__((aligned(16))) uint4 ldsq[];
+  {
+    const uint4 *g = reinterpret_cast<const uint4 *>(a.tab4q);
+    for (int i = threadIdx.x; i < 8 * XS; i += 256) ldsq[i] = g[i];
+  }
+  __syncthreads();
   const int lane = threadIdx.x & 63;
   const int wave = rfl((int) (blockIdx.x * 4 + (threadIdx.x >> 6)));
   const int nwaves = (int) gridDim.x * 4;
-  uint32_t T[2][4][R];
-#pragma unroll
-  for (int par = 0; par < 2; ++par)
-#pragma unroll
-    for (int x = 0; x < 4; ++x)
-#pragma unroll
-      for (int j = 0; j < R; ++j) T[par][x][j] = a.tab4[((size_t) (par * 4 + x) * R + j) * 64 + lane];
+  const uint4 *lq = ldsq + lane;
+  const int thr_fast = PAIR ? a.thresh_s - a.pair_slack : a.thresh_s;
+  const int sc_thresh = a.thresh_s + a.xB + 32768;          // the threshold in byte units
 
-  // one row with the emission pairs <e>; ODD: register g <- f(register g-1), the lane's first register from the lane before
-  auto row = [&](uint32_t (&v)[R], const uint32_t (&e)[R], bool odd) -> uint32_t {
-    uint32_t acc0 = kFloor2, acc1 = kFloor2;
-    if (odd) {
-      const uint32_t carry = (uint32_t) dpp_shr1((int) v[R - 1], (int) kFloor2);
+  // the quads of residue x (xs = x * XS, wave-uniform) and parity <par> (0: odd rows)
+  auto load_quads = [&](uint32_t (&e)[RE], uint32_t xs, int par) {
+    const uint4 *p = lq + xs + par * 4 * XS;
 #pragma unroll
-      for (int j = R - 1; j >= 1; --j) { v[j] = pk_adds_u(v[j - 1], e[j]); if (j & 1) acc1 = pk_max_u(acc1, v[j]); else acc0 = pk_max_u(acc0, v[j]); }
-      v[0] = pk_adds_u(carry, e[0]); acc0 = pk_max_u(acc0, v[0]);
-    } else {
-#pragma unroll
-      for (int j = 0; j < R; ++j) { v[j] = pk_adds_u(v[j], e[j]); if (j & 1) acc1 = pk_max_u(acc1, v[j]); else acc0 = pk_max_u(acc0, v[j]); }
-    }
-    return pk_max_u(acc0, acc1);
+    for (int q = 0; q < R4; ++q) { const uint4 t = p[q * 64]; e[4 * q] = t.x; e[4 * q + 1] = t.y; e[4 * q + 2] = t.z; e[4 * q + 3] = t.w; }
   };
-  auto row_any = [&](uint32_t (&v)[R], int x, bool odd) -> uint32_t {
-    if (x < 4) {
-      const int par = odd ? 0 : 1;
-      switch (x) {                                  // wave-uniform: one of four register sets
-        case 0: return row(v, T[par][0], odd);
-        case 1: return row(v, T[par][1], odd);
-        case 2: return row(v, T[par][2], odd);
-        default: return row(v, T[par][3], odd);
-      }
-    }
-    if (x >= a.Kp) {              // between two targets of a concatenated scan: every diagonal ends here
-#pragma unroll
-      for (int j = 0; j < R; ++j) v[j] = kFloor2;
-      return kFloor2;
-    }
-    // degenerate residue: emissions from the full table in global memory [parity][Kp][R][64]
-    const uint32_t *eg = a.tab_full + ((size_t) ((odd ? 0 : a.Kp) + x) * R) * 64 + lane;
-    uint32_t e[R];
-#pragma unroll
-    for (int j = 0; j < R; ++j) e[j] = eg[j * 64];
-    return row(v, e, odd);
-  };
-  // the report of a row that reached the threshold, exactly as the LDS kernel makes it
+  // the report of a row whose best cell reaches the threshold: the cell upstream would pick -- the highest byte score
+  // (scores saturate at 255), the first such cell in the order in which p7_SSVFilter_longtarget unstripes the row
+  // (vector q outer, byte z inner; k = q + Q z + 1).  Cells outside 1..M (padding, the virtual node) do not count.
   auto report = [&](const uint32_t (&v)[R], bool odd, long long i, int strand) {
     int best = INT_MIN, bestkey = INT_MAX;
 #pragma unroll
@@ -213,6 +132,7 @@ __global__ void __launch_bounds__(256) ssvlong_reg_kernel(const SsvLongArgs a)
       }
     }
     const int smax = wave_max_i32(best);
+    if (smax < sc_thresh) return;
     const int kmin = -wave_max_i32(best == smax ? -bestkey : INT_MIN);
     if (lane == 0) {
       const int slot = atomicAdd(a.nrec, 1);
@@ -222,9 +142,26 @@ __global__ void __launch_bounds__(256) ssvlong_reg_kernel(const SsvLongArgs a)
       }
     }
   };
-  auto reached = [&](uint32_t acc) -> bool {
-    const int hi = (int) (short) (acc >> 16), lo = (int) (short) (acc & 0xffffu);
-    return __any(max(hi, lo) >= a.thresh_s) != 0;
+  // 64 canonical rows; xsv = the lanes' residues times XS.  false: some group of 16 rows may have reached the threshold
+  auto fast_block = [&](uint32_t (&v)[R], uint32_t xsv) -> bool {
+    uint32_t eA[RE], eB[RE];
+    load_quads(eA, (uint32_t) __builtin_amdgcn_readlane((int) xsv, 0), 0);
+    for (int r0 = 0; r0 < 64; r0 += 16) {
+      uint32_t acc0 = kFloor2, acc1 = kFloor2;
+#pragma unroll
+      for (int rr = 0; rr < 16; rr += 2) {
+        // the scheduler stays inside a row: left alone it gathers the quads of many rows at the top of the loop and
+        // pays for them with half the wavefronts per SIMD (136 VGPRs instead of 77 at R = 10)
+        load_quads(eB, (uint32_t) __builtin_amdgcn_readlane((int) xsv, r0 + rr + 1), 1);
+        ssv_row<R, true, !PAIR>(v, eA, acc0, acc1);
+        __builtin_amdgcn_sched_barrier(0);
+        load_quads(eA, (uint32_t) __builtin_amdgcn_readlane((int) xsv, (r0 + rr + 2) & 63), 0);      // the last one of a block is not used
+        ssv_row<R, false, true>(v, eB, acc0, acc1);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      if (ssv_reached(pk_max_u(acc0, acc1), thr_fast)) return false;
+    }
+    return true;
   };
 
   for (long long chi = wave; chi < a.nchunks; chi += nwaves) {
@@ -237,9 +174,8 @@ __global__ void __launch_bounds__(256) ssvlong_reg_kernel(const SsvLongArgs a)
 #pragma unroll
     for (int j = 0; j < R; ++j) v[j] = kFloor2;
     // residues of 64 rows, one per lane: strand 1 reads the target backwards and complements (canonical residues by
-    // arithmetic: the table lookup would be a second dependent load); fetched one block ahead of its use
-    // The fetch is the byte load and nothing else: whatever consumes the byte (the complement) would make the compiler
-    // wait for it on the spot, and the prefetch would be a synchronous load.
+    // arithmetic: the table lookup would be a second dependent load); fetched one block ahead of its use.  The fetch is
+    // the byte load and nothing else: whatever consumes the byte would make the compiler wait for it on the spot.
     auto fetch = [&](long long i0) -> uint32_t {
       const long long pos = i0 + lane;
       if (pos > last) return 0u;
@@ -251,33 +187,42 @@ __global__ void __launch_bounds__(256) ssvlong_reg_kernel(const SsvLongArgs a)
     uint32_t raw_next = fetch(warm);
     for (long long i0 = warm; i0 <= last; i0 += 64) {     // i0 - warm is a multiple of 64: row r of a block is odd iff r is even
       const int nrow = (int) min(64LL, last - i0 + 1);
-      // The bytes fetched during the previous 64 rows are waited for HERE, before the next fetch is issued: left to the
-      // compiler the wait lands at the top of the 8-row loop as vmcnt(0) (the counter retires in order), where it also
-      // waits for the fetch just issued -- one exposed memory round trip per 64 rows.
+      // the bytes fetched during the previous block are waited for HERE, before the next fetch is issued: left to the
+      // compiler the wait would also cover the fetch just issued -- one exposed memory round trip per 64 rows
       __builtin_amdgcn_s_waitcnt(0x0f70);            // vmcnt(0); expcnt and lgkmcnt unconstrained
       const uint32_t res = on_strand(raw_next);
       raw_next = fetch(i0 + 64);
-      for (int r0 = 0; r0 < nrow; r0 += 8) {
-        const int nb = min(8, nrow - r0);
+      if (nrow == 64 && __all(res < 4u)) {
         uint32_t saved[R];
 #pragma unroll
         for (int j = 0; j < R; ++j) saved[j] = v[j];
-        uint32_t blk = kFloor2;
-        if (nb == 8) {
-#pragma unroll
-          for (int rr = 0; rr < 8; ++rr) blk = pk_max_u(blk, row_any(v, __builtin_amdgcn_readlane((int) res, r0 + rr), (rr & 1) == 0));
-        } else {
-          for (int rr = 0; rr < nb; ++rr) blk = pk_max_u(blk, row_any(v, __builtin_amdgcn_readlane((int) res, r0 + rr), (rr & 1) == 0));
-        }
-        if (i0 + r0 + nb - 1 < first || !reached(blk)) continue;       // warm-up rows report nothing
-        // some row of the block reached the threshold: the block again, row by row (same arithmetic, same values)
+        if (fast_block(v, res * (uint32_t) XS)) continue;
 #pragma unroll
         for (int j = 0; j < R; ++j) v[j] = saved[j];
-        for (int rr = 0; rr < nb; ++rr) {
-          const bool odd = (rr & 1) == 0;
-          const uint32_t acc = row_any(v, __builtin_amdgcn_readlane((int) res, r0 + rr), odd);
-          const long long i = i0 + r0 + rr;
-          if (i >= first && reached(acc)) report(v, odd, i, strand);
+      }
+      // row by row: every kind of residue, the exact test in every row
+      for (int r = 0; r < nrow; r += 2) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          if (r + h >= nrow) break;
+          const int x = __builtin_amdgcn_readlane((int) res, r + h);
+          uint32_t acc0 = kFloor2, acc1 = kFloor2;
+          if (x < 4) {
+            uint32_t e[RE];
+            load_quads(e, (uint32_t) x * XS, h);
+            if (h == 0) ssv_row<R, true, true>(v, e, acc0, acc1); else ssv_row<R, false, true>(v, e, acc0, acc1);
+          } else if (x >= a.Kp) {     // between two targets of a concatenated scan: every diagonal ends here
+#pragma unroll
+            for (int j = 0; j < R; ++j) v[j] = kFloor2;
+          } else {                    // degenerate residue: emissions from the full table in global memory [parity][Kp][R][64]
+            const uint32_t *eg = a.tab_full + ((size_t) ((h == 0 ? 0 : a.Kp) + x) * R) * 64 + lane;
+            uint32_t e[R];
+#pragma unroll
+            for (int j = 0; j < R; ++j) e[j] = eg[j * 64];
+            if (h == 0) ssv_row<R, true, true>(v, e, acc0, acc1); else ssv_row<R, false, true>(v, e, acc0, acc1);
+          }
+          const long long i = i0 + r + h;
+          if (i >= first && ssv_reached(pk_max_u(acc0, acc1), a.thresh_s)) report(v, h == 0, i, strand);
         }
       }
     }
@@ -285,20 +230,23 @@ __global__ void __launch_bounds__(256) ssvlong_reg_kernel(const SsvLongArgs a)
 }
 
 // ---------------------------------------------------------------------------- host side
-static const int kSsvR[] = { 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 14, 16, 20, 24, 32, 48 };      // <= 24: emission pairs in registers
+static const int kSsvR[] = { 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 14, 16, 20, 24, 32, 48 };      // packed registers per lane
 
-int ssvlong_pick_R(int M)
+int ssvlong_pick_R(int M, bool virtual_node)
 {
-  const int need = (M + 1) / 2 + 1;                 // global registers: cells up to M in both parities
+  const int top = M + (virtual_node ? 1 : 0);
+  const int need = (top + 1) / 2 + 1;               // global registers: cells up to <top> in both parities
   for (int r : kSsvR) if (r * 64 >= need) return r;
   return -1;
 }
 
 // tables: pairs (lo, hi) of signed emission scores s[x][k] = bias - rb[x][k] in byte units, kNegPad outside 1..M.
-// odd rows: register g = cells (2g-1, 2g); even rows: (2g, 2g+1); g = lane*R + j, stored [parity][x][j][lane].
-// <virtual_node> (register kernel): node M+1 exists with emission 0 for every residue, so that a score that reached the
-// last node is still there one row later (ssvlong_reg_kernel tests once per pair of rows); it never counts as a cell.
-void ssvlong_build_tables(const Profile &p, int R, bool virtual_node, std::vector<uint32_t> &tab4, std::vector<uint32_t> &tab_full, int *pair_slack)
+// odd rows: register g = cells (2g-1, 2g); even rows: (2g, 2g+1); g = lane*R + j.
+//   tab4q    [parity][x < 4][q][lane] uint4: registers 4q .. 4q+3 of the lane for A, C, G, T (0 beyond R)
+//   tab_full [parity][Kp][R][64] uint32: every residue code (degenerate residues, read from global memory)
+// <virtual_node> (PAIR): node M+1 exists with emission 0 for every residue, so that a score that reached the last node
+// is still there one row later; it never counts as a cell.  pair_slack: the most a cell can lose in one canonical row.
+void ssvlong_build_tables(const Profile &p, int R, bool virtual_node, std::vector<uint32_t> &tab4q, std::vector<uint32_t> &tab_full, int *pair_slack)
 {
   auto sval = [&](int x, int k) -> int {
     if (virtual_node && k == p.M + 1 && x < p.Kp) return 0;
@@ -306,7 +254,8 @@ void ssvlong_build_tables(const Profile &p, int R, bool virtual_node, std::vecto
     return (int) p.bias_b - (int) p.rb[(size_t) x * (p.M + 1) + k];
   };
   auto pack = [](int lo, int hi) -> uint32_t { return ((uint32_t) (uint16_t) (int16_t) lo) | ((uint32_t) (uint16_t) (int16_t) hi << 16); };
-  tab4.assign((size_t) 2 * 4 * R * 64, 0);
+  const int R4 = (R + 3) / 4;
+  tab4q.assign((size_t) 2 * 4 * R4 * 64 * 4, 0);
   tab_full.assign((size_t) 2 * p.Kp * R * 64, 0);
   for (int par = 0; par < 2; ++par)
     for (int x = 0; x < p.Kp; ++x)
@@ -315,7 +264,7 @@ void ssvlong_build_tables(const Profile &p, int R, bool virtual_node, std::vecto
           const int g = lane * R + j;
           const uint32_t w = par == 0 ? pack(sval(x, 2 * g - 1), sval(x, 2 * g)) : pack(sval(x, 2 * g), sval(x, 2 * g + 1));
           tab_full[(((size_t) par * p.Kp + x) * R + j) * 64 + lane] = w;
-          if (x < 4) tab4[(((size_t) par * 4 + x) * R + j) * 64 + lane] = w;
+          if (x < 4) tab4q[((((size_t) par * 4 + x) * R4 + j / 4) * 64 + lane) * 4 + j % 4] = w;
         }
   if (pair_slack) {
     int worst = 0;
@@ -324,11 +273,12 @@ void ssvlong_build_tables(const Profile &p, int R, bool virtual_node, std::vecto
   }
 }
 
-template <int R>
-static int launch_ssv(const SsvLongArgs &a, int num_cu, hipStream_t st)
+// cap_waves != NULL: no launch, only the number of wavefronts the device holds at once
+template <int R, bool PAIR>
+static int launch_ssv_quad(const SsvLongArgs &a, int num_cu, hipStream_t st, long long *cap_waves)
 {
-  const size_t lds = (size_t) 2 * 4 * R * 64 * 4;
-  auto kern = ssvlong_kernel<R>;
+  const size_t lds = (size_t) 2 * 4 * ((R + 3) / 4) * 64 * 16;
+  auto kern = ssvlong_quad_kernel<R, PAIR>;
   static int per_cu_cached = 0;
   static std::mutex mu;
   int per_cu = 0;
@@ -341,6 +291,7 @@ static int launch_ssv(const SsvLongArgs &a, int num_cu, hipStream_t st)
     }
     per_cu = per_cu_cached;
   }
+  if (cap_waves) { *cap_waves = (long long) num_cu * per_cu * 4; return P7X_OK; }
   long long grid = std::min<long long>((a.nchunks + 3) / 4, (long long) num_cu * per_cu);
   if (grid < 1) grid = 1;
   hipLaunchKernelGGL(kern, dim3((unsigned) grid), dim3(256), lds, st, a);
@@ -348,50 +299,27 @@ static int launch_ssv(const SsvLongArgs &a, int num_cu, hipStream_t st)
   return P7X_OK;
 }
 
-template <int R>
-static int launch_ssv_reg(const SsvLongArgs &a, int num_cu, hipStream_t st)
+static int ssvlong_quad_dispatch(int R, bool pair, const SsvLongArgs &a, int num_cu, hipStream_t st, long long *cap_waves)
 {
-  auto kern = ssvlong_reg_kernel<R>;
-  static int per_cu_cached = 0;
-  static std::mutex mu;
-  int per_cu = 0;
-  {
-    std::lock_guard<std::mutex> lk(mu);
-    if (per_cu_cached == 0) {
-      P7X_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu_cached, kern, 256, 0));
-      if (per_cu_cached < 1) per_cu_cached = 1;
-    }
-    per_cu = per_cu_cached;
-  }
-  long long grid = std::min<long long>((a.nchunks + 3) / 4, (long long) num_cu * per_cu);
-  if (grid < 1) grid = 1;
-  hipLaunchKernelGGL(kern, dim3((unsigned) grid), dim3(256), 0, st, a);
-  P7X_HIP(hipGetLastError());
-  return P7X_OK;
-}
-
-int ssvlong_launch(int R, const SsvLongArgs &a, int num_cu, hipStream_t st)
-{
+#define P7X_SQ(RR) case RR: return pair ? launch_ssv_quad<RR, true>(a, num_cu, st, cap_waves) : launch_ssv_quad<RR, false>(a, num_cu, st, cap_waves);
   switch (R) {
-    case 3: return launch_ssv_reg<3>(a, num_cu, st);
-    case 5: return launch_ssv_reg<5>(a, num_cu, st);
-    case 7: return launch_ssv_reg<7>(a, num_cu, st);
-    case 9: return launch_ssv_reg<9>(a, num_cu, st);
-    case 10: return launch_ssv_reg<10>(a, num_cu, st);
-    case 11: return launch_ssv_reg<11>(a, num_cu, st);
-    case 14: return launch_ssv_reg<14>(a, num_cu, st);
-    case 20: return launch_ssv_reg<20>(a, num_cu, st);
-    case 2: return a.use_lds ? launch_ssv<2>(a, num_cu, st) : launch_ssv_reg<2>(a, num_cu, st);
-    case 4: return a.use_lds ? launch_ssv<4>(a, num_cu, st) : launch_ssv_reg<4>(a, num_cu, st);
-    case 6: return a.use_lds ? launch_ssv<6>(a, num_cu, st) : launch_ssv_reg<6>(a, num_cu, st);
-    case 8: return a.use_lds ? launch_ssv<8>(a, num_cu, st) : launch_ssv_reg<8>(a, num_cu, st);
-    case 12: return a.use_lds ? launch_ssv<12>(a, num_cu, st) : launch_ssv_reg<12>(a, num_cu, st);
-    case 16: return a.use_lds ? launch_ssv<16>(a, num_cu, st) : launch_ssv_reg<16>(a, num_cu, st);
-    case 24: return a.use_lds ? launch_ssv<24>(a, num_cu, st) : launch_ssv_reg<24>(a, num_cu, st);
-    case 32: return launch_ssv<32>(a, num_cu, st);
-    case 48: return launch_ssv<48>(a, num_cu, st);
+    P7X_SQ(2) P7X_SQ(3) P7X_SQ(4) P7X_SQ(5) P7X_SQ(6) P7X_SQ(7) P7X_SQ(8) P7X_SQ(9) P7X_SQ(10) P7X_SQ(11) P7X_SQ(12) P7X_SQ(14) P7X_SQ(16)
+    P7X_SQ(20) P7X_SQ(24) P7X_SQ(32) P7X_SQ(48)
     default: set_error("model too long for the long-target SSV kernel (M > 6141)"); return P7X_EINVAL;
   }
+#undef P7X_SQ
+}
+
+// wavefronts of the quad kernel the device holds at once: the caller cuts the strands into a multiple of that many chunks
+int ssvlong_capacity(int R, bool pair, int num_cu, long long *waves)
+{
+  SsvLongArgs none{};
+  return ssvlong_quad_dispatch(R, pair, none, num_cu, nullptr, waves);
+}
+
+int ssvlong_launch(int R, bool pair, const SsvLongArgs &a, int num_cu, hipStream_t st)
+{
+  return ssvlong_quad_dispatch(R, pair, a, num_cu, st, nullptr);
 }
 
 } // namespace p7x

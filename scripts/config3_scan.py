@@ -22,3 +22,12 @@ for label in ("device images built on the way", "device images resident"):
     res = list(hmmer.hmmscan(proteome, block))
     dt = time.perf_counter() - t0
     print(f"hmmscan, {label}: {dt:.3f} s = {1e3 * dt / n:.4f} ms per profile, {cells / dt / 1e9:.0f} GCUPS, {len(proteome) / dt:.0f} query sequences/s, hits {sum(len(r) for r in res)}", flush=True)
+if len(sys.argv) > 2 and sys.argv[2] == "trace":          # where a resident pass spends its time
+    import json
+    print("pipeline_stats of the last pass:", json.dumps({k: (round(v, 4) if isinstance(v, float) else v) for k, v in hmmer.pipeline_stats().items()}), flush=True)
+    from pyhmmer_amd import _lib
+    _lib.set_debug_option("trace_finish", 1)
+    hmmer.PIPE_TRACE = True
+    t0 = time.perf_counter()
+    res = list(hmmer.hmmscan(proteome, block))
+    print(f"traced pass: {time.perf_counter() - t0:.3f} s", flush=True)

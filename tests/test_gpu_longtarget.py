@@ -25,6 +25,16 @@ def rows_agree(dev, ref):
         assert a[9] == pytest.approx(b[9], abs=3e-3) and a[10] == pytest.approx(b[10], abs=3e-3), (a, b)
 
 
+SSV_KERNELS = {"row maximum every second row (the default)": -1, "row maximum in every row": 3}
+
+
+@pytest.fixture
+def ssv_kernel():
+    """Selects the long-target SSV kernel through the test seam; the library's own choice again afterwards."""
+    yield lambda variant: _lib.set_debug_option("ssv_kernel", variant)
+    _lib.set_debug_option("ssv_kernel", -1)
+
+
 def device_seeds(om, cfg, residues, complement):
     cap = 1 << 16
     seeds = np.zeros((cap, 3), dtype=np.int64)
@@ -36,10 +46,10 @@ def device_seeds(om, cfg, residues, complement):
 
 @pytest.mark.parametrize("model,target", [("bmyD", "BGC0001090.gbk"), ("bmyD", "1390.SAMEA104415756.OFHT01000022.fna"),
                                           ("RF00001", "1390.SAMEA104415756.OFHT01000024.fna")])
-def test_device_ssv_seeds_equal_the_sequential_scan(oracle, model, target):
+def test_device_ssv_seeds_equal_the_sequential_scan(oracle, model, target, ssv_kernel):
     """The window seeds (first residue, last model node, diagonal length) that come out of the device scan + the host's
     sequential bookkeeping equal those of the oracle's p7_SSVFilter_longtarget, on both strands of every fixture target
-    (whole target as one block)."""
+    (whole target as one block), with every kernel."""
     hmm = load_hmms(model)[0]
     seqs = _read(target, hmm.alphabet)
     pli = plan7.LongTargetsPipeline(hmm.alphabet, block_length=1 << 30)
@@ -52,13 +62,15 @@ def test_device_ssv_seeds_equal_the_sequential_scan(oracle, model, target):
     for strand in (0, 1):
         blk = seq if strand == 0 else host_pipeline.DNA_COMP[seq[::-1]]
         want = oracle.ssv_longtarget(op, blk, hmm.max_length, pli.F1)
-        got = device_seeds(om, cfg, seq, strand)
-        assert got.tolist() == want.tolist(), (model, target, strand)
+        for what, variant in SSV_KERNELS.items():
+            ssv_kernel(variant)
+            got = device_seeds(om, cfg, seq, strand)
+            assert got.tolist() == want.tolist(), (model, target, strand, what)
         total += len(want)
     assert total > 0
 
 
-def test_device_ssv_on_a_synthetic_chromosome(oracle):
+def test_device_ssv_on_a_synthetic_chromosome(oracle, ssv_kernel):
     """2 Mbp of i.i.d. ACGT with 40 planted copies of model segments (some adjacent, some overlapping a chunk boundary of
     the device scan): seeds equal the sequential scan; a few N runs exercise the degenerate-residue path."""
     hmm = load_hmms("bmyD")[0]
@@ -81,9 +93,11 @@ def test_device_ssv_on_a_synthetic_chromosome(oracle):
     for strand in (0, 1):
         blk = seq if strand == 0 else host_pipeline.DNA_COMP[seq[::-1]]
         want = oracle.ssv_longtarget(op, blk, hmm.max_length, pli.F1)
-        got = device_seeds(om, pli._cfg(), seq, strand)
         assert len(want) > 20
-        assert got.tolist() == want.tolist(), strand
+        for what, variant in SSV_KERNELS.items():
+            ssv_kernel(variant)
+            got = device_seeds(om, pli._cfg(), seq, strand)
+            assert got.tolist() == want.tolist(), (strand, what)
 
 
 def test_nhmmer_bmyd_tables_through_the_device(oracle):
@@ -155,10 +169,11 @@ def test_nhmmer_dealt_over_devices_equals_one_device():
 
 
 @pytest.mark.parametrize("M", [60, 150, 250, 330, 380, 440, 500, 560, 630, 700, 760, 880, 1000, 1270, 1500, 2040, 2500, 3060, 3500, 5000])
-def test_device_ssv_every_register_count(M, oracle):
-    """One model length per instantiation of the long-target SSV kernels -- emission pairs in registers for R <= 24
-    packed registers per lane (M <= 3069), the LDS kernel beyond -- on a 400 kb random sequence with planted stretches of
-    the model's consensus: window seeds equal the oracle's sequential p7_SSVFilter_longtarget, both strands."""
+def test_device_ssv_every_register_count(M, oracle, ssv_kernel):
+    """One model length per instantiation (registers per lane) of the long-target SSV kernel, with the row maximum in every
+    second row (the default: lowered threshold, virtual node M + 1, exact repeat) and in every row, on a 400 kb random
+    sequence with planted stretches of the model's consensus and a run of N: window seeds equal the oracle's sequential
+    p7_SSVFilter_longtarget, both strands."""
     abc = easel.Alphabet.dna()
     from conftest import random_hmm
     hmm = random_hmm(M, seed=9000 + M, alphabet=abc)
@@ -182,8 +197,10 @@ def test_device_ssv_every_register_count(M, oracle):
     for strand in (0, 1):
         blk = seq if strand == 0 else host_pipeline.DNA_COMP[seq[::-1]]
         want = oracle.ssv_longtarget(op, blk, hmm.max_length, pli.F1)
-        got = device_seeds(om, pli._cfg(), seq, strand)
-        assert got.tolist() == want.tolist(), (M, strand)
+        for what, variant in SSV_KERNELS.items():
+            ssv_kernel(variant)
+            got = device_seeds(om, pli._cfg(), seq, strand)
+            assert got.tolist() == want.tolist(), (M, strand, what)
         total += len(want)
     assert total >= 10, total
 
