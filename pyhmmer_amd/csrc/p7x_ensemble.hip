@@ -54,7 +54,7 @@ __global__ void __launch_bounds__(64) ens_forward_kernel(const EnsArgs a, const 
   const EnsRegion reg = a.regions[reg_list[blockIdx.x]];
   const EnsJob job = a.jobs[reg.job];
   const int M = job.M, Mrow = M + 1, Lr = reg.Lr;
-  const float4 *tr = reinterpret_cast<const float4 *>(job.trans);
+  const TransView<false> tr{ reinterpret_cast<const float4 *>(job.trans), 0 };     // read where they lie (L2)
   const float *em = reinterpret_cast<const float *>(job.emis);
   const uint8_t *sq = a.dsq + reg.sq;                              // sq[0] = first residue of the region
   ChoiceCell *cells = a.cells + reg.cell0;
@@ -68,7 +68,7 @@ __global__ void __launch_bounds__(64) ens_forward_kernel(const EnsArgs a, const 
   f.init(tr, lane, pmove);
   // leaving transitions of the node before this lane's first one (the delete cell's choice looks one node back)
   float p_md0, p_dd0;
-  { const F8 t = load_f8(tr, (C - 1) * 64 + lane); p_md0 = dpp_shr1f(t.md, 0.0f); p_dd0 = dpp_shr1f(t.dd, 0.0f); }
+  { const F8 t = tr.at((C - 1) * 64 + lane); p_md0 = dpp_shr1f(t.md, 0.0f); p_dd0 = dpp_shr1f(t.dd, 0.0f); }
   if (lane == 0) {
     ChoiceRow r0{};
     uint32_t T, b;
@@ -93,7 +93,7 @@ __global__ void __launch_bounds__(64) ens_forward_kernel(const EnsArgs a, const 
 #pragma unroll unroll_env(C)
       for (int c = 0; c < C; ++c) {
         const int k = lane * C + c + 1;
-        const F8 t = load_f8(tr, c * 64 + lane);
+        const F8 t = tr.at(c * 64 + lane);
         if (k <= M) {
           ChoiceCell cell;
           choice_cell_m(pB * t.bm, mp * t.mm, ip * t.im, dp * t.dm, cell.m);

@@ -103,7 +103,8 @@ __global__ void __launch_bounds__(env_waves(C) * 64, env_waves(C) / 4) env_kerne
   const EnvArgs a = load_args<EnvArgs>(ref);
   if ((int) blockIdx.x >= a.nblocks) return;        // this job has fewer blocks than the widest job of the launch
   constexpr bool TG = C > 64;         // M > 4096: the transitions are read through L2 as well
-  const float4 *tr = TG ? reinterpret_cast<const float4 *>(a.trans) : reinterpret_cast<const float4 *>(smem);      // [2*Mpad]
+  // transitions: from LDS in two planes (see TransView), or where they lie
+  const TransView<!TG> tr{ TG ? reinterpret_cast<const float4 *>(a.trans) : reinterpret_cast<const float4 *>(smem), Mpad };
   // emission odds [nrows][Mpad]: staged in LDS while they fit beside the transitions (M <= 1024), else read where they
   // lie (one coalesced 256-byte row segment per chunk and row: L2-resident, like the parsers' long-model variant)
   constexpr bool kEmisInLds = C <= 16 && !LT;
@@ -112,7 +113,7 @@ __global__ void __launch_bounds__(env_waves(C) * 64, env_waves(C) / 4) env_kerne
     if constexpr (!TG) {
       const float4 *gt = reinterpret_cast<const float4 *>(a.trans);
       float4 *lt = reinterpret_cast<float4 *>(smem);
-      for (int i = threadIdx.x; i < 2 * Mpad; i += kEnvBlock) lt[i] = gt[i];
+      for (int i = threadIdx.x; i < 2 * Mpad; i += kEnvBlock) lt[(i & 1) * Mpad + (i >> 1)] = gt[i];
     }
     if constexpr (kEmisInLds) {
       const float4 *ge = reinterpret_cast<const float4 *>(a.emis);
@@ -206,15 +207,15 @@ __global__ void __launch_bounds__(env_waves(C) * 64, env_waves(C) / 4) env_kerne
       float ddprod = 1.0f;
 #pragma unroll unroll_env(C)
       for (int c = 0; c < C; ++c) {
-        const F8 t = load_f8(tr, c * 64 + lane);
+        const F8 t = tr.at(c * 64 + lane);
         t_md[c] = t.md; t_dd[c] = t.dd; t_mi[c] = t.mi; t_ii[c] = t.ii; t_bm[c] = t.bm;
         ddprod *= t.dd;
       }
 #pragma unroll unroll_env(C)
       for (int c = 0; c < C; ++c) {          // transitions entering the NEXT node
         float mmn, imn, dmn;
-        if (c + 1 < C) { const F8 t = load_f8(tr, (c + 1) * 64 + lane); mmn = t.mm; imn = t.im; dmn = t.dm; }
-        else { const F8 t = load_f8(tr, lane); mmn = dpp_shl1f(t.mm, 0.0f); imn = dpp_shl1f(t.im, 0.0f); dmn = dpp_shl1f(t.dm, 0.0f); }
+        if (c + 1 < C) { const F8 t = tr.at((c + 1) * 64 + lane); mmn = t.mm; imn = t.im; dmn = t.dm; }
+        else { const F8 t = tr.at(lane); mmn = dpp_shl1f(t.mm, 0.0f); imn = dpp_shl1f(t.im, 0.0f); dmn = dpp_shl1f(t.dm, 0.0f); }
         n_mm[c] = mmn; n_im[c] = imn; n_dm[c] = dmn;
       }
       float mm[C], im[C], dm[C];
@@ -329,9 +330,9 @@ __global__ void __launch_bounds__(env_waves(C) * 64, env_waves(C) / 4) env_kerne
       float scaleproduct = (float) (1.0 / (double) bck_xN0);
       bool ddpass = true;                                            // every D->D transition of this lane is open
 #pragma unroll unroll_env(C)
-      for (int c = 0; c < C; ++c) ddpass = ddpass && (tr[2 * (c * 64 + lane) + 1].w > 0.0f);
+      for (int c = 0; c < C; ++c) ddpass = ddpass && (tr.dd(c * 64 + lane) > 0.0f);
       float p_md0, p_dd0;                                            // leaving transitions of the previous lane's last node
-      { const F8 t = load_f8(tr, (C - 1) * 64 + lane); p_md0 = dpp_shr1f(t.md, 0.0f); p_dd0 = dpp_shr1f(t.dd, 0.0f); }
+      { const F8 t = tr.at((C - 1) * 64 + lane); p_md0 = dpp_shr1f(t.md, 0.0f); p_dd0 = dpp_shr1f(t.dd, 0.0f); }
       float om_[C], oi_[C], od_[C], msum[C], isum[C];
 #pragma unroll unroll_env(C)
       for (int c = 0; c < C; ++c) { om_[c] = oi_[c] = od_[c] = kNegInf; msum[c] = isum[c] = 0.0f; }
@@ -399,7 +400,7 @@ __global__ void __launch_bounds__(env_waves(C) * 64, env_waves(C) / 4) env_kerne
         float t_md[C], t_dd[C];
 #pragma unroll unroll_env(C)
         for (int c = 0; c < C; ++c) {
-          const F8 t = load_f8(tr, c * 64 + lane);
+          const F8 t = tr.at(c * 64 + lane);
           t_md[c] = t.md; t_dd[c] = t.dd;
           float sv = gate(t.bm, xBp);
           sv = vmax(sv, gate(t.mm, mp));

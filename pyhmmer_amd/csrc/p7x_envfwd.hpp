@@ -22,16 +22,18 @@ struct EnvForward {
   float mm[C], im[C], dm[C];
   float ddprod;
   float xN, xB, xJ, xC, xE, scale, totscale;
-  __device__ __forceinline__ void init(const float4 *tr, int lane, float pmove)
+  template <class TV>
+  __device__ __forceinline__ void init(const TV &tr, int lane, float pmove)
   {
 #pragma unroll unroll_env(C)
     for (int c = 0; c < C; ++c) mm[c] = im[c] = dm[c] = 0.0f;
     ddprod = 1.0f;
 #pragma unroll unroll_env(C)
-    for (int c = 0; c < C; ++c) ddprod *= tr[2 * (c * 64 + lane) + 1].w;
+    for (int c = 0; c < C; ++c) ddprod *= tr.dd(c * 64 + lane);
     xN = 1.0f; xB = pmove; xJ = 0.0f; xC = 0.0f; xE = 0.0f; scale = 1.0f; totscale = 0.0f;
   }
-  __device__ __forceinline__ void row(const float4 *tr, const float *em, int Mpad, int lane, int x, float pmove, float ploop,
+  template <class TV>
+  __device__ __forceinline__ void row(const TV &tr, const float *em, int Mpad, int lane, int x, float pmove, float ploop,
                                       float xf_e_move, float xf_e_loop)
   {
     const float *er = em + x * Mpad + lane;
@@ -40,7 +42,7 @@ struct EnvForward {
     float t_dd[C], t_md[C];
 #pragma unroll unroll_env(C)
     for (int c = 0; c < C; ++c) {
-      const F8 t = load_f8(tr, c * 64 + lane);
+      const F8 t = tr.at(c * 64 + lane);
       float sv = xB * t.bm;
       sv = sv + mp * t.mm;
       sv = sv + ip * t.im;

