@@ -1134,12 +1134,20 @@ static int cascade_enqueue(CascadeRun &r)
     const bool fills_device = (db->nslots / 64) * (int64_t) nq >= (int64_t) ctx->num_cu * 8;
     if ((st = class_cascade(r, classes[0], s, true, fills_device)) != P7X_OK) return st;
   } else {
-    // every class on its own stream, forked from and joined into the workspace's stream
+    // the classes in turn over the workspace's stream and its side streams (eight streams = the eight hardware queues:
+    // with the workspace's stream taking only the first class its queue idled through most of a 28-class batch of the
+    // scan orientation, whose device phase is the longest queue's sum of kernel latencies), forked from and joined into
+    // the workspace's stream
     P7X_HIP(hipEventRecord(ws->ev_fork, s));
     const int nside = std::min<int>((int) classes.size() - 1, Workspace::kSide);
     for (int k = 0; k < nside; ++k) P7X_HIP(hipStreamWaitEvent(ws->side[k], ws->ev_fork, 0));
     for (size_t c = 0; c < classes.size(); ++c) {
-      hipStream_t cs = c == 0 ? s : ws->side[(c - 1) % Workspace::kSide];
+      // back and forth (the classes come in the order of the batch's models, shortest first: dealt in one direction the
+      // last stream would get the heaviest class of every round)
+      constexpr int kStreams = Workspace::kSide + 1;
+      int turn = (int) (c % (size_t) kStreams);
+      if ((c / (size_t) kStreams) & 1) turn = kStreams - 1 - turn;
+      hipStream_t cs = turn == 0 ? s : ws->side[turn - 1];
       if ((st = class_cascade(r, classes[c], cs, c == 0, false)) != P7X_OK) return st;
     }
     for (int k = 0; k < nside; ++k) {
