@@ -86,13 +86,24 @@ static int scan_target(const p7x_pipeline_cfg &cfg, const Profile &p, DeviceCtx 
                        int sc_thresh, int xB, int strands_mask, std::vector<ScanRow> &rows, double *ms, const std::vector<ScanRange> *ranges = nullptr,
                        int device = 0, uint64_t resident_key = 0)
 {
-  // option ssv_kernel = 3 (tests, A/B): the row maximum in every row instead of every second one
-  const bool pair = debug_opt(OPT_SSV_KERNEL) != 3;
-  const int R = ssvlong_pick_R(p.M, pair);
+  // The row maximum in every second row only (PAIR) tests against a threshold lowered by the most a cell can lose in one
+  // row, and every group of rows that reaches the lowered threshold is run again: it pays while that loss is a few score
+  // units (9 for bmyD, 12 for RF00001: 2^(loss/3) times as many groups are repeated as reach the threshold itself) and is
+  // a loss for models with near-impossible emissions (60-110 units for the tests' Dirichlet models: every block would be
+  // repeated).  Option ssv_kernel (tests, A/B): 3 = every row, 4 = every second row whatever the loss.
+  constexpr int kMaxPairSlack = 16;
+  const int opt = debug_opt(OPT_SSV_KERNEL);
+  bool pair = opt != 3;
+  int R = ssvlong_pick_R(p.M, pair);
   if (R < 0) { set_error("model too long for the long-target SSV kernel (M > 6141)"); return P7X_EINVAL; }
   std::vector<uint32_t> tab4q, tab_full;
   int pair_slack = 0;
   ssvlong_build_tables(p, R, pair, tab4q, tab_full, &pair_slack);
+  if (pair && opt != 4 && pair_slack > kMaxPairSlack) {
+    pair = false;
+    R = ssvlong_pick_R(p.M, false);
+    ssvlong_build_tables(p, R, false, tab4q, tab_full, &pair_slack);
+  }
   DevBuf d_tab4q, d_full, d_comp, d_nrec, d_pos, d_strand, d_k, d_sc;
   int st;
   if ((st = d_tab4q.alloc(tab4q.size() * 4)) || (st = d_full.alloc(tab_full.size() * 4)) || (st = d_comp.alloc(32)) || (st = d_nrec.alloc(4))) return st;

@@ -1,6 +1,6 @@
 """BASELINE configs[4]: nhmmer long-target, one DNA HMM (fixture bmyD, M = 1203) against a synthetic chromosome (i.i.d.
 ACGT 0.25, seed 45; SURVEY.md 8d "config 5"), both strands, block_length 262144.  Reports the SSV scan kernel (HIP
-events) as GCUPS = 2 strands x L x M / time, and the whole search.  usage: nhmmer_bench.py [Mbp] [planted] [ssv_kernel option: 3 = row maximum in every row]"""
+events) as GCUPS = 2 strands x L x M / time, and the whole search.  usage: nhmmer_bench.py [Mbp] [planted] [ssv_kernel option: 3 = row maximum in every row, 4 = in every second row | trace]"""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
