@@ -291,12 +291,20 @@ int  p7x_debug_log_of_float(int device, const float *in, float *out, size_t n);
  *   node, a sample's domains first to last; n2[pos], pos = 1..j-i+1: the summed null2 odds ratios of the residue;
  *   status 0 = sampled. */
 int  p7x_debug_choice(const float *p, int n, uint32_t x, int *via_thresholds, int *via_fchoose);
+/* Test seam of the long-target SSV scan's tables (host code, no device): the registers per lane R the kernel takes for this
+ * model, the most a cell can lose in one row with a canonical residue (byte units), and the table it stages in LDS --
+ * [parity][x < 4][q][lane][c] packed pairs (lo, hi) of bias - rb[x][k], register j = 4q + c of the lane holding nodes
+ * (2g - 1, 2g) on odd rows (parity 0) and (2g, 2g + 1) on even rows, g = lane * R + j; <pair> != 0: with the virtual node
+ * M + 1 (emission 0) of the every-second-row flavour.  Returns the number of 32-bit words of the table (written when
+ * cap_words is large enough), or a negative status. */
+int64_t p7x_debug_ssv_tables(const p7x_oprofile *om, int pair, int32_t *R, int32_t *pair_slack, uint32_t *tab4q, size_t cap_words);
 /* Test / diagnostic seam: process-wide knobs, by name; value -1 = not set (the library decides).  The library itself reads no
  * environment variables.  Kernel families for parity tests: "small_block" (0: never the wave-per-target filters for small
  * blocks), "vit_wave" (1: the wave-per-target Viterbi kernel for every model), "msv_exact" (1: no fast MSV pass),
  * "msv_long_groups" (0: the longest groups stay with the lane kernel), "msv_blocks_per_cu" (cap), "device_clustered" (0 / 1:
  * with host ensembles, where their clustered envelopes are rescored), "env_workspace_gb" (cap of the envelope kernel's
- * workspace).  Traces on stderr: "trace_finish", "trace_longtarget", "trace_envelope", "host_profile" (1: on). */
+ * workspace), "ssv_kernel" (long-target SSV scan: 3 = the row maximum in every row, 4 = in every second row whatever the
+ * model).  Traces on stderr: "trace_finish", "trace_longtarget", "trace_envelope", "host_profile" (1: on). */
 int  p7x_debug_set_option(const char *name, int value);
 int  p7x_debug_ensemble(const p7x_oprofile *om, const p7x_seqdb *db, int64_t target, int32_t i, int32_t j, uint32_t seed,
                         int use_device, int32_t *ndom, int32_t *dom, int32_t dom_cap, float *n2, int32_t *status);

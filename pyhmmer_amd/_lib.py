@@ -203,6 +203,7 @@ _SIGNATURES = {
     "p7x_pending_nqueries": (C.c_size_t, [_VP]),
     "p7x_debug_log_of_float": (C.c_int, [C.c_int, _VP, _VP, C.c_size_t]),
     "p7x_debug_choice": (C.c_int, [_VP, C.c_int, C.c_uint32, _VP, _VP]),
+    "p7x_debug_ssv_tables": (C.c_int64, [_VP, C.c_int, _VP, _VP, _VP, C.c_size_t]),
     "p7x_debug_set_option": (C.c_int, [C.c_char_p, C.c_int]),
     "p7x_longtargets_release_resident": (C.c_int, [C.c_int, C.c_uint64]),
     "p7x_debug_ensemble": (C.c_int, [_VP, _VP, C.c_int64, C.c_int32, C.c_int32, C.c_uint32, C.c_int, _VP, _VP, C.c_int32, _VP, _VP]),

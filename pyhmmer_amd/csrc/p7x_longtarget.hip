@@ -534,4 +534,19 @@ int64_t p7x_ssv_longtarget_seeds(const p7x_pipeline_cfg *cfg, const p7x_oprofile
   return (int64_t) ns;
 }
 
+int64_t p7x_debug_ssv_tables(const p7x_oprofile *om, int pair, int32_t *R, int32_t *pair_slack, uint32_t *tab4q, size_t cap_words)
+{
+  if (!om) { set_error("p7x_debug_ssv_tables: no profile"); return -P7X_EINVAL; }
+  const Profile &p = om->p;
+  const int r = ssvlong_pick_R(p.M, pair != 0);
+  if (r < 0) { set_error("model too long for the long-target SSV kernel (M > 6141)"); return -P7X_EINVAL; }
+  std::vector<uint32_t> quads, full;
+  int slack = 0;
+  ssvlong_build_tables(p, r, pair != 0, quads, full, &slack);
+  if (R) *R = r;
+  if (pair_slack) *pair_slack = slack;
+  if (tab4q && cap_words >= quads.size()) std::copy(quads.begin(), quads.end(), tab4q);
+  return (int64_t) quads.size();
+}
+
 } // extern "C"

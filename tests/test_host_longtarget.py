@@ -229,3 +229,57 @@ def test_short_windows_against_the_oracle_restatement(oracle):
     hits = host_pipeline.host_nhmmer(oracle, hmm, block, pipeline=pli)
     nwin, nshort, nshortwin = lc.check_hits_against_oracle(pli, hmm, seq, hits, min_windows=20, min_short=5, want_short_windows=True)
     assert nshortwin >= 3 and len(hits) >= 5
+
+
+@pytest.mark.parametrize("name,M", [("bmyD", None), ("RF00001", None), (None, 60), (None, 638), (None, 1278), (None, 2047)])
+def test_ssv_scan_tables_against_the_oracle_profile(libp7x, oracle, name, M):
+    """The table the long-target SSV kernel stages in LDS (test seam p7x_debug_ssv_tables; host code): every packed pair is
+    bias - rb[x][k] of the oracle's pressed-format byte costs at the documented place ([parity][x][quad][lane][c], register
+    j = 4 quad + c of the lane = nodes (2g - 1, 2g) / (2g, 2g + 1), g = lane R + j), padding is -512, the virtual node M + 1
+    of the every-second-row flavour has emission 0, R is the smallest register count that holds the model, and the reported
+    one-row loss is the largest canonical cost above the bias."""
+    import ctypes as C
+    from conftest import random_hmm
+    from pyhmmer_amd import _lib
+    hmm = load_hmms(name)[0] if name else random_hmm(M, seed=4000 + M, alphabet=easel.Alphabet.dna())
+    bg = plan7.Background(hmm.alphabet)
+    om = plan7.OptimizedProfile(hmm, bg, 400)
+    op = oracle.OracleProfile(hmm, bg, 400)
+    M, Q, bias = hmm.M, int(op.p.Q16), int(op.p.bias_b)
+    rbv = np.asarray(op.arr("rbv")).astype(np.int64)
+    cost = np.zeros((4, M + 3), dtype=np.int64)                     # un-striped: node k sits at vector (k-1) % Q, byte (k-1) // Q
+    for k in range(1, M + 1):
+        cost[:, k] = rbv[:4, ((k - 1) % Q) * 16 + (k - 1) // Q]
+    sval = bias - cost                                               # the signed emission the kernel adds
+    for pair in (0, 1):
+        R, slack = C.c_int32(), C.c_int32()
+        n = _lib.lib().p7x_debug_ssv_tables(om._handle, pair, C.byref(R), C.byref(slack), None, 0)
+        assert n > 0, _lib.last_error()
+        tab = np.zeros(n, dtype=np.uint32)
+        assert _lib.lib().p7x_debug_ssv_tables(om._handle, pair, C.byref(R), C.byref(slack), tab.ctypes.data, n) == n
+        R = R.value
+        top = M + pair
+        need = (top + 1) // 2 + 1
+        assert R * 64 >= need and (R == 2 or [r for r in (2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 14, 16, 20, 24, 32, 48) if r * 64 >= need][0] == R)
+        assert slack.value == int((cost[:, 1:M + 1] - bias).max())
+        R4 = (R + 3) // 4
+        assert n == 2 * 4 * R4 * 64 * 4
+        t = tab.reshape(2, 4, R4, 64, 4)
+        lo = (t & 0xffff).astype(np.int64); lo[lo >= 32768] -= 65536
+        hi = (t >> 16).astype(np.int64); hi[hi >= 32768] -= 65536
+
+        def want(x, k):
+            if pair and k == M + 1:
+                return 0
+            return int(sval[x, k]) if 1 <= k <= M else -512
+        rng = np.random.default_rng(M)
+        lanes = np.unique(np.concatenate([[0, 1, 63], rng.integers(0, 64, size=12)]))
+        for par in (0, 1):
+            for x in range(4):
+                for lane in lanes:
+                    for j in range(R):
+                        g = int(lane) * R + j
+                        k0 = 2 * g - 1 if par == 0 else 2 * g
+                        assert (int(lo[par, x, j // 4, lane, j % 4]), int(hi[par, x, j // 4, lane, j % 4])) == (want(x, k0), want(x, k0 + 1)), (pair, par, x, lane, j)
+                    for j in range(R, 4 * R4):                       # the unused registers of the last quad
+                        assert t[par, x, j // 4, lane, j % 4] == 0
