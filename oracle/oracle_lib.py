@@ -218,3 +218,40 @@ def lt_envelope_scores(op, env_residues, window_len):
     st = l.p7o_lt_envelope_scores(op.ptr, d.ctypes.data, len(env_residues), int(window_len), degen.ctypes.data, C.byref(orig), C.byref(adj))
     assert st == 0
     return float(orig.value), float(adj.value)
+
+
+# Easel's standard residue-code sets (esl_alphabet.c: B = ND, J = IL, Z = QE, O = K, U = C, X = any; R = AG, Y = CT, ...)
+_DEGEN_AMINO = {21: "ND", 22: "IL", 23: "QE", 24: "K", 25: "C", 26: "ACDEFGHIKLMNPQRSTVWY"}
+_DEGEN_NUCLEIC = {5: "AG", 6: "CT", 7: "AC", 8: "GT", 9: "CG", 10: "AT", 11: "ACT", 12: "CGT", 13: "ACG", 14: "AGT", 15: "ACGT"}
+
+
+def degeneracy_sets(K):
+    """[Kp][K] matrix: which canonical residues a residue code stands for."""
+    Kp = 29 if K == 20 else 18
+    canon = "ACDEFGHIKLMNPQRSTVWY" if K == 20 else "ACGT"
+    d = np.zeros((Kp, K), dtype=np.uint8)
+    d[:K, :K] = np.eye(K, dtype=np.uint8)
+    for x, members in (_DEGEN_AMINO if K == 20 else _DEGEN_NUCLEIC).items():
+        for c in members:
+            d[x, canon.index(c)] = 1
+    return d
+
+
+def domains_single(op, seq, do_null2=True):
+    """p7_oracle_dd.c on one target: (envelopes, counts).  envelopes: rows of ienv jenv iali jali hmmfrom hmmto envsc(nats)
+    domcorrection(nats) oasc bitscore(bits) dombias(bits) lnP for every region that holds one domain; counts = (regions,
+    single-domain envelopes, regions left to the traceback ensemble)."""
+    l = lib()
+    l.p7o_domains_single.restype = C.c_int64
+    l.p7o_domains_single.argtypes = [C.POINTER(Profile), C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p,
+                                     C.c_int64, C.c_void_p]
+    st, bsc, fx, bx = op.bck(seq)                          # configures the profile for len(seq)
+    d = op._dsq(seq)
+    degen = degeneracy_sets(op.ptr.contents.K)
+    cap = 64
+    out = np.zeros((cap, 12), dtype=np.float64)
+    counts = np.zeros(3, dtype=np.int64)
+    n = l.p7o_domains_single(op.ptr, d.ctypes.data, len(seq), fx.ctypes.data, bx.ctypes.data, degen.ctypes.data, int(do_null2),
+                             out.ctypes.data, cap, counts.ctypes.data)
+    assert n >= 0
+    return out[:n].copy(), tuple(int(c) for c in counts)

@@ -1,0 +1,482 @@
+/* p7_oracle_dd.c -- TEST INFRASTRUCTURE ONLY (see p7_oracle.h).
+ *
+ * CPU restatement of HMMER 3.4's domain definition for the regions that hold ONE domain -- the part of
+ * p7_domaindef_ByPosteriorHeuristics (reference include/libhmmer/p7_domaindef.pxd:69-72, reached from
+ * Pipeline._search_loop, src/pyhmmer/plan7.pyx:6393-6453, through p7_Pipeline) that every hit goes through:
+ *
+ *   p7_DomainDecoding          posterior begin / end / occupancy totals from the parsers' special-state rows
+ *   the region scan            rt1 = 0.25, rt2 = 0.10: where the occupancy rises and falls
+ *   is_multidomain_region      rt3 = 0.20: regions that need the stochastic traceback ensemble are only REPORTED here
+ *                              (their envelopes come out of a clustering of 200 sampled tracebacks; not restated)
+ *   rescore_isolated_domain    unihit Forward / Backward over the envelope (upstream impl_sse/fwdback.c, odds space with
+ *                              sparse rescaling), p7_Decoding, p7_Null2_ByExpectation, p7_OptimalAccuracy, p7_OATrace
+ *   the scoring of a domain    p7_pipeline.c: envelope score + length correction - null1 - null2, in bits; exponential tail
+ *
+ * Plain scalar C over un-striped tables, every sum taken in the order of the nodes: neither upstream's striped vector
+ * order nor the product's lane-chunk order.  Posteriors therefore differ from either in the last bits, and a comparison
+ * with the product is exact only away from ties (tests/test_oracle_domains.py states the rates it accepts).  What this
+ * file is for: a second, independently structured implementation of the logic -- thresholds, recursions, tie-break
+ * orders, coordinate conventions -- pinned by the reference's own domain tables (tests/golden/tables/ *.domtbl: envelope
+ * and alignment coordinates exactly, scores and biases at print precision) and compared with the product on thousands of
+ * synthetic targets.  It shares no code with pyhmmer_amd/csrc/p7x_domaindef.cpp.
+ */
+#include "p7_oracle.h"
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+#include <float.h>
+
+/* ---------------------------------------------------------------------------------------------------------------------
+ * un-striped model: odds (probability / background), nodes 1..M
+ * tfv holds, per striped position, (BM MM IM DM MD MI II) and then the DD's: the first four ENTER node k, the last four
+ * LEAVE node k (impl_sse/p7_oprofile.pxd:41-49; p7_oprofile.c: fb_conversion). */
+typedef struct {
+  int M, K, Kp;
+  float *bm, *mm, *im, *dm;        /* [M+2] into M_k from B, M_{k-1}, I_{k-1}, D_{k-1} */
+  float *md, *mi, *ii, *dd;        /* [M+2] M_k->D_{k+1}, M_k->I_k, I_k->I_k, D_k->D_{k+1} */
+  float *em;                       /* [Kp][M+1] match emission odds (insert odds are 1) */
+  float nloop, nmove, cloop, cmove, jloop, jmove, eloop, emove;
+} DDModel;
+
+static void ddmodel_free(DDModel *m)
+{
+  free(m->bm); free(m->mm); free(m->im); free(m->dm); free(m->md); free(m->mi); free(m->ii); free(m->dd); free(m->em);
+}
+
+static int ddmodel_build(const P7O_PROFILE *p, int L, int multihit, DDModel *m)
+{
+  const int M = p->M, Q = p->Q4;
+  memset(m, 0, sizeof(*m));
+  m->M = M; m->K = p->K; m->Kp = p->Kp;
+  float **t[8] = { &m->bm, &m->mm, &m->im, &m->dm, &m->md, &m->mi, &m->ii, &m->dd };
+  for (int s = 0; s < 8; s++) { *t[s] = (float *) calloc((size_t) M + 2, sizeof(float)); if (!*t[s]) return -1; }
+  m->em = (float *) calloc((size_t) p->Kp * (M + 1), sizeof(float));
+  if (!m->em) return -1;
+  for (int k = 1; k <= M; k++) {
+    const int q = (k - 1) % Q, z = (k - 1) / Q;
+    for (int s = 0; s < 7; s++) (*t[s])[k] = p->tfv[(size_t) (7 * q + s) * 4 + z];
+    m->dd[k] = p->tfv[(size_t) (7 * Q + q) * 4 + z];
+    for (int x = 0; x < p->Kp; x++) m->em[(size_t) x * (M + 1) + k] = p->rfv[(size_t) x * Q * 4 + (size_t) q * 4 + z];
+  }
+  /* p7_oprofile_ReconfigLength + ReconfigMultihit / ReconfigUnihit (impl_sse/p7_oprofile.c) */
+  const float nj = multihit ? 1.0f : 0.0f;
+  const float pmove = (2.0f + nj) / ((float) L + 2.0f + nj);
+  const float ploop = 1.0f - pmove;
+  m->nloop = m->cloop = m->jloop = ploop;
+  m->nmove = m->cmove = m->jmove = pmove;
+  m->eloop = multihit ? 0.5f : 0.0f;
+  m->emove = multihit ? 0.5f : 1.0f;
+  return 0;
+}
+
+/* full matrices of an envelope: rows 0..L, nodes 0..M (node 0 unused, kept at 0) */
+typedef struct {
+  int L, M;
+  float *mx, *ix, *dx;      /* [(L+1)*(M+1)] */
+  float *xE, *xN, *xJ, *xB, *xC, *scale;   /* [L+1] */
+} DDMatrix;
+
+static int ddmx_alloc(DDMatrix *x, int L, int M)
+{
+  memset(x, 0, sizeof(*x));
+  x->L = L; x->M = M;
+  const size_t n = (size_t) (L + 1) * (M + 1);
+  x->mx = (float *) calloc(n, sizeof(float)); x->ix = (float *) calloc(n, sizeof(float)); x->dx = (float *) calloc(n, sizeof(float));
+  float **s[6] = { &x->xE, &x->xN, &x->xJ, &x->xB, &x->xC, &x->scale };
+  for (int i = 0; i < 6; i++) { *s[i] = (float *) calloc((size_t) L + 1, sizeof(float)); if (!*s[i]) return -1; }
+  return (x->mx && x->ix && x->dx) ? 0 : -1;
+}
+static void ddmx_free(DDMatrix *x)
+{
+  free(x->mx); free(x->ix); free(x->dx); free(x->xE); free(x->xN); free(x->xJ); free(x->xB); free(x->xC); free(x->scale);
+}
+#define MX(x, i, k) ((x)->mx[(size_t) (i) * ((x)->M + 1) + (k)])
+#define IX(x, i, k) ((x)->ix[(size_t) (i) * ((x)->M + 1) + (k)])
+#define DX(x, i, k) ((x)->dx[(size_t) (i) * ((x)->M + 1) + (k)])
+
+/* p7_Forward (impl_sse/fwdback.c forward_engine with a full matrix): odds space; a row whose xE exceeds 1e4 is divided by it
+ * and the logarithm of the divisor kept.  dsq[1..L].  Returns 0, or 1 when the score is not a finite number. */
+static int dd_forward(const DDModel *m, const uint8_t *dsq, int L, DDMatrix *f, float *ret_sc)
+{
+  const int M = m->M;
+  float xN = 1.0f, xB = m->nmove, xJ = 0.0f, xC = 0.0f, xE = 0.0f, totscale = 0.0f;
+  f->xE[0] = 0.0f; f->xN[0] = xN; f->xJ[0] = xJ; f->xB[0] = xB; f->xC[0] = xC; f->scale[0] = 1.0f;
+  for (int i = 1; i <= L; i++) {
+    const float *e = m->em + (size_t) dsq[i] * (M + 1);
+    xE = 0.0f;
+    float dprev = 0.0f;                       /* D(i, k-1) */
+    for (int k = 1; k <= M; k++) {
+      float sv = xB * m->bm[k];
+      sv += MX(f, i - 1, k - 1) * m->mm[k];
+      sv += IX(f, i - 1, k - 1) * m->im[k];
+      sv += DX(f, i - 1, k - 1) * m->dm[k];
+      sv *= e[k];
+      const float dv = (k > 1) ? MX(f, i, k - 1) * m->md[k - 1] + dprev * m->dd[k - 1] : 0.0f;
+      MX(f, i, k) = sv;
+      DX(f, i, k) = dv;
+      IX(f, i, k) = MX(f, i - 1, k) * m->mi[k] + IX(f, i - 1, k) * m->ii[k];
+      xE += sv;
+      xE += dv;
+      dprev = dv;
+    }
+    xN = xN * m->nloop;
+    xC = xC * m->cloop + xE * m->emove;
+    xJ = xJ * m->jloop + xE * m->eloop;
+    xB = xJ * m->jmove + xN * m->nmove;
+    float scale = 1.0f;
+    if (xE > 1.0e4f) {
+      xN /= xE; xC /= xE; xJ /= xE; xB /= xE;
+      const float inv = 1.0f / xE;
+      for (int k = 1; k <= M; k++) { MX(f, i, k) *= inv; DX(f, i, k) *= inv; IX(f, i, k) *= inv; }
+      scale = xE;
+      totscale += logf(xE);
+      xE = 1.0f;
+    }
+    f->xE[i] = xE; f->xN[i] = xN; f->xJ[i] = xJ; f->xB[i] = xB; f->xC[i] = xC; f->scale[i] = scale;
+  }
+  if (isnan(xC) || (L > 0 && xC == 0.0f) || isinf(xC)) { *ret_sc = -INFINITY; return 1; }
+  *ret_sc = totscale + logf(xC * m->cmove);
+  return 0;
+}
+
+/* p7_Backward (impl_sse/fwdback.c backward_engine): row i is divided by Forward's scale factor of row i. */
+static void dd_backward(const DDModel *m, const uint8_t *dsq, int L, const DDMatrix *f, DDMatrix *b)
+{
+  const int M = m->M;
+  /* row L: everything that can still reach the end exits through E -> C -> T */
+  float xC = m->cmove, xE = xC * m->emove, xJ = 0.0f, xB = 0.0f, xN = 0.0f;
+  {
+    float dnext = 0.0f;
+    for (int k = M; k >= 1; k--) {
+      const float dv = xE + dnext * m->dd[k];                 /* D_k -> E, or on to D_{k+1} */
+      MX(b, L, k) = xE + dnext * m->md[k];                    /* M_k -> E, or M_k -> D_{k+1} */
+      DX(b, L, k) = dv;
+      IX(b, L, k) = 0.0f;
+      dnext = dv;
+    }
+  }
+  if (L > 0) {
+    const float s = f->scale[L];
+    if (s != 1.0f) { xC /= s; xE /= s; for (int k = 1; k <= M; k++) { MX(b, L, k) /= s; DX(b, L, k) /= s; } }
+  }
+  b->xE[L] = xE; b->xN[L] = xN; b->xJ[L] = xJ; b->xB[L] = xB; b->xC[L] = xC; b->scale[L] = f->scale[L];
+  for (int i = L - 1; i >= 0; i--) {
+    const float *e = m->em + (size_t) dsq[i + 1] * (M + 1);
+    /* B(i): into any M_k of the next row */
+    xB = 0.0f;
+    for (int k = 1; k <= M; k++) xB += MX(b, i + 1, k) * e[k] * m->bm[k];
+    xJ = b->xJ[i + 1] * m->jloop + xB * m->jmove;
+    xC = b->xC[i + 1] * m->cloop;
+    xE = xC * m->emove + xJ * m->eloop;
+    xN = b->xN[i + 1] * m->nloop + xB * m->nmove;
+    if (i > 0) {
+      float dnext = 0.0f;
+      for (int k = M; k >= 1; k--) {
+        const float mnext = (k < M) ? MX(b, i + 1, k + 1) * e[k + 1] : 0.0f;      /* M_{k+1} of the next row, emission included */
+        const float dv = xE + mnext * ((k < M) ? m->dm[k + 1] : 0.0f) + dnext * m->dd[k];
+        const float iv = mnext * ((k < M) ? m->im[k + 1] : 0.0f) + IX(b, i + 1, k) * m->ii[k];
+        const float mv = xE + mnext * ((k < M) ? m->mm[k + 1] : 0.0f) + IX(b, i + 1, k) * m->mi[k] + dnext * m->md[k];
+        MX(b, i, k) = mv; IX(b, i, k) = iv; DX(b, i, k) = dv;
+        dnext = dv;
+      }
+      const float s = f->scale[i];
+      if (s != 1.0f) {
+        xB /= s; xJ /= s; xC /= s; xE /= s; xN /= s;
+        for (int k = 1; k <= M; k++) { MX(b, i, k) /= s; IX(b, i, k) /= s; DX(b, i, k) /= s; }
+      }
+    }
+    b->xE[i] = xE; b->xN[i] = xN; b->xJ[i] = xJ; b->xB[i] = xB; b->xC[i] = xC; b->scale[i] = f->scale[i];
+  }
+}
+
+/* p7_Decoding (impl_sse/decoding.c): posterior probabilities of the emitting states, written over <b>; delete states are
+ * not decoded (0).  Returns 1 when the scale product is not finite (upstream: eslERANGE, the domain is dropped). */
+static int dd_decoding(const DDModel *m, int L, const DDMatrix *f, DDMatrix *b)
+{
+  const int M = m->M;
+  const float scaleproduct = 1.0f / b->xN[0];
+  float pN_prev = 0.0f, pJ_prev = 0.0f, pC_prev = 0.0f;
+  (void) pN_prev; (void) pJ_prev; (void) pC_prev;
+  /* the specials need Backward's row i and Forward's row i-1: walk upwards keeping Backward's values before overwriting */
+  float *bN = (float *) malloc(sizeof(float) * (size_t) (L + 1)), *bJ = (float *) malloc(sizeof(float) * (size_t) (L + 1)),
+        *bC = (float *) malloc(sizeof(float) * (size_t) (L + 1));
+  if (!bN || !bJ || !bC) { free(bN); free(bJ); free(bC); return 1; }
+  memcpy(bN, b->xN, sizeof(float) * (size_t) (L + 1)); memcpy(bJ, b->xJ, sizeof(float) * (size_t) (L + 1)); memcpy(bC, b->xC, sizeof(float) * (size_t) (L + 1));
+  b->xE[0] = b->xN[0] = b->xJ[0] = b->xB[0] = b->xC[0] = 0.0f;
+  for (int k = 0; k <= M; k++) { MX(b, 0, k) = IX(b, 0, k) = DX(b, 0, k) = 0.0f; }
+  for (int i = 1; i <= L; i++) {
+    const float totr = scaleproduct * f->scale[i];
+    for (int k = 1; k <= M; k++) {
+      MX(b, i, k) = MX(f, i, k) * MX(b, i, k) * totr;
+      IX(b, i, k) = IX(f, i, k) * IX(b, i, k) * totr;
+      DX(b, i, k) = 0.0f;
+    }
+    b->xE[i] = 0.0f; b->xB[i] = 0.0f;
+    b->xN[i] = f->xN[i - 1] * bN[i] * m->nloop * scaleproduct;
+    b->xJ[i] = f->xJ[i - 1] * bJ[i] * m->jloop * scaleproduct;
+    b->xC[i] = f->xC[i - 1] * bC[i] * m->cloop * scaleproduct;
+  }
+  free(bN); free(bJ); free(bC);
+  return (isinf(scaleproduct) || isnan(scaleproduct)) ? 1 : 0;
+}
+
+/* p7_Null2_ByExpectation (impl_sse/null2.c): the envelope's own residue composition as the posterior-weighted mean of the
+ * emission odds of the states that explain it; null2[x], x < Kp, odds ratios.  degen[x*K + y] != 0: residue code x stands
+ * for canonical residue y (esl_abc_FAvgScVec: a degenerate code gets the plain mean of its residues' ratios). */
+static void dd_null2_by_expectation(const DDModel *m, int L, const DDMatrix *pp, const uint8_t *degen, float *null2)
+{
+  const int M = m->M, K = m->K, Kp = m->Kp;
+  float *wm = (float *) calloc((size_t) M + 1, sizeof(float)), *wi = (float *) calloc((size_t) M + 1, sizeof(float));
+  float xN = 0.0f, xC = 0.0f, xJ = 0.0f;
+  for (int i = 1; i <= L; i++) {
+    for (int k = 1; k <= M; k++) { wm[k] += MX(pp, i, k); wi[k] += IX(pp, i, k); }
+    xN += pp->xN[i]; xC += pp->xC[i]; xJ += pp->xJ[i];
+  }
+  const float norm = 1.0f / (float) L;
+  for (int k = 1; k <= M; k++) { wm[k] *= norm; wi[k] *= norm; }
+  xN *= norm; xC *= norm; xJ *= norm;
+  const float xfactor = xN + xC + xJ;
+  for (int x = 0; x < K; x++) {
+    const float *e = m->em + (size_t) x * (M + 1);
+    float sv = 0.0f;
+    for (int k = 1; k <= M; k++) { sv += wm[k] * e[k]; sv += wi[k]; }
+    null2[x] = sv + xfactor;
+  }
+  for (int x = K; x < Kp; x++) null2[x] = 1.0f;                 /* gap, *, ~ */
+  for (int x = K + 1; x < Kp - 2; x++) {                         /* the degenerate codes */
+    float sum = 0.0f; int n = 0;
+    for (int y = 0; y < K; y++) if (degen[(size_t) x * K + y]) { sum += null2[y]; n++; }
+    null2[x] = n ? sum / (float) n : 1.0f;
+  }
+  free(wm); free(wi);
+}
+
+/* p7_OptimalAccuracy (impl_sse/optacc.c): the alignment that maximises the expected number of correctly aligned
+ * residues; a transition that the model does not have contributes 0 (the vector code masks it), impossible cells of row 0
+ * are -infinity.  Written over <f>.  */
+static float dd_optimal_accuracy(const DDModel *m, int L, const DDMatrix *pp, DDMatrix *ox)
+{
+  const int M = m->M;
+  ox->xE[0] = -INFINITY; ox->xN[0] = 0.0f; ox->xJ[0] = -INFINITY; ox->xB[0] = 0.0f; ox->xC[0] = -INFINITY;
+  for (int k = 0; k <= M; k++) { MX(ox, 0, k) = IX(ox, 0, k) = DX(ox, 0, k) = -INFINITY; }
+  for (int i = 1; i <= L; i++) {
+    float xE = -INFINITY;
+    MX(ox, i, 0) = IX(ox, i, 0) = DX(ox, i, 0) = -INFINITY;
+    for (int k = 1; k <= M; k++) {
+      float sv = (m->bm[k] > 0.0f) ? ox->xB[i - 1] : 0.0f;
+      if (k > 1) {
+        sv = fmaxf(sv, (m->mm[k] > 0.0f) ? MX(ox, i - 1, k - 1) : 0.0f);
+        sv = fmaxf(sv, (m->im[k] > 0.0f) ? IX(ox, i - 1, k - 1) : 0.0f);
+        sv = fmaxf(sv, (m->dm[k] > 0.0f) ? DX(ox, i - 1, k - 1) : 0.0f);
+      } else {                                    /* node 0 does not exist: the vector code shifts zeros in */
+        sv = fmaxf(sv, 0.0f);
+      }
+      sv += MX(pp, i, k);
+      MX(ox, i, k) = sv;
+      xE = fmaxf(xE, sv);
+      float iv = (m->mi[k] > 0.0f) ? MX(ox, i - 1, k) : 0.0f;
+      iv = fmaxf(iv, (m->ii[k] > 0.0f) ? IX(ox, i - 1, k) : 0.0f);
+      IX(ox, i, k) = iv + IX(pp, i, k);
+      float dv = 0.0f;
+      if (k > 1) {
+        dv = (m->md[k - 1] > 0.0f) ? MX(ox, i, k - 1) : 0.0f;
+        dv = fmaxf(dv, (m->dd[k - 1] > 0.0f) ? DX(ox, i, k - 1) : 0.0f);
+      }
+      DX(ox, i, k) = dv;
+      xE = fmaxf(xE, dv);
+    }
+    ox->xE[i] = xE;
+    float t1 = (m->jloop == 0.0f) ? 0.0f : ox->xJ[i - 1] + pp->xJ[i];
+    float t2 = (m->eloop == 0.0f) ? 0.0f : xE;
+    ox->xJ[i] = fmaxf(t1, t2);
+    t1 = (m->cloop == 0.0f) ? 0.0f : ox->xC[i - 1] + pp->xC[i];
+    t2 = (m->emove == 0.0f) ? 0.0f : xE;
+    ox->xC[i] = fmaxf(t1, t2);
+    ox->xN[i] = (m->nloop == 0.0f) ? 0.0f : ox->xN[i - 1] + pp->xN[i];
+    t1 = (m->nmove == 0.0f) ? 0.0f : ox->xN[i];
+    t2 = (m->jmove == 0.0f) ? 0.0f : ox->xJ[i];
+    ox->xB[i] = fmaxf(t1, t2);
+  }
+  return (m->cmove == 0.0f) ? 0.0f : ox->xC[L];
+}
+
+/* p7_OATrace (impl_sse/optacc.c): back from C(L); a state's predecessor is the FIRST of its candidates, in upstream's
+ * order, that holds the maximum (esl_vec_FArgMax); E looks for the best M or D cell of its row in the order in which the
+ * striped vectors are scanned (vector q outer, then the four M's, then the four D's: node k = z Q + q + 1, strictly greater).
+ * Only the unihit configuration is traced here (one domain).  Returns 0 and the first / last match state's residue and
+ * node, or 1 when the trace holds no match state. */
+enum { ST_M = 1, ST_I, ST_D, ST_B, ST_N, ST_C, ST_E, ST_S };
+static int dd_oa_trace(const DDModel *m, int L, const DDMatrix *pp, const DDMatrix *ox, int Q,
+                       int *ia, int *ja, int *ka, int *kb)
+{
+  const int M = m->M;
+  int i = L, k = 0, st = ST_C;
+  *ia = *ja = *ka = *kb = 0;
+  long guard = 4L * (L + 2) * (M + 2) + 16;
+  while (st != ST_S && guard-- > 0) {
+    switch (st) {
+    case ST_C: {
+      const float t1 = (m->cloop == 0.0f) ? -INFINITY : ox->xC[i - 1] + pp->xC[i];
+      const float t2 = (m->emove == 0.0f) ? -INFINITY : ox->xE[i];
+      if (i < 1) return 1;
+      if (t1 >= t2) { st = ST_C; i--; } else st = ST_E;      /* argmax over (C, E): C first */
+      if (i == 0 && st == ST_C) return 1;                     /* C cannot begin a path */
+      break;
+    }
+    case ST_E: {
+      float best = -INFINITY; int bk = 0, bs = 0;
+      for (int q = 0; q < Q; q++) {
+        for (int z = 0; z < 4; z++) { const int kk = z * Q + q + 1; if (kk <= M && MX(ox, i, kk) > best) { best = MX(ox, i, kk); bk = kk; bs = ST_M; } }
+        for (int z = 0; z < 4; z++) { const int kk = z * Q + q + 1; if (kk <= M && DX(ox, i, kk) > best) { best = DX(ox, i, kk); bk = kk; bs = ST_D; } }
+      }
+      if (!bs) return 1;
+      st = bs; k = bk;
+      break;
+    }
+    case ST_M: {
+      if (*ja == 0) { *ja = i; *kb = k; }
+      *ia = i; *ka = k;
+      float path[4];
+      path[0] = (k > 1 && m->mm[k] != 0.0f) ? MX(ox, i - 1, k - 1) : -INFINITY;
+      path[1] = (k > 1 && m->im[k] != 0.0f) ? IX(ox, i - 1, k - 1) : -INFINITY;
+      path[2] = (k > 1 && m->dm[k] != 0.0f) ? DX(ox, i - 1, k - 1) : -INFINITY;
+      path[3] = (m->bm[k] != 0.0f) ? ox->xB[i - 1] : -INFINITY;
+      if (k == 1) { path[0] = (m->mm[k] != 0.0f) ? 0.0f : -INFINITY; path[1] = (m->im[k] != 0.0f) ? 0.0f : -INFINITY; path[2] = (m->dm[k] != 0.0f) ? 0.0f : -INFINITY; }
+      int arg = 0;
+      for (int s = 1; s < 4; s++) if (path[s] > path[arg]) arg = s;
+      i--;
+      if (arg == 0) { st = ST_M; k--; } else if (arg == 1) { st = ST_I; k--; } else if (arg == 2) { st = ST_D; k--; } else st = ST_B;
+      if (st != ST_B && k < 1) return 1;
+      break;
+    }
+    case ST_D: {
+      const float p0 = (k > 1 && m->md[k - 1] != 0.0f) ? MX(ox, i, k - 1) : -INFINITY;
+      const float p1 = (k > 1 && m->dd[k - 1] != 0.0f) ? DX(ox, i, k - 1) : -INFINITY;
+      if (k <= 1) return 1;
+      st = (p1 > p0) ? ST_D : ST_M; k--;
+      break;
+    }
+    case ST_I: {
+      const float p0 = (m->mi[k] != 0.0f) ? MX(ox, i - 1, k) : -INFINITY;
+      const float p1 = (m->ii[k] != 0.0f) ? IX(ox, i - 1, k) : -INFINITY;
+      st = (p1 > p0) ? ST_I : ST_M; i--;
+      break;
+    }
+    case ST_B: st = ST_N; break;       /* unihit: J is not reachable */
+    case ST_N: st = ST_S; break;       /* the N run back to row 0 emits nothing that is recorded here */
+    default: return 1;
+    }
+  }
+  return (*ia > 0 && guard > 0) ? 0 : 1;
+}
+
+/* ---------------------------------------------------------------------------------------------------------------------
+ * the heuristics on the parsers' rows (p7_domaindef.c) */
+
+/* p7_DomainDecoding (impl_sse/decoding.c): fx / bx are the parsers' rows, (L+1) x [E N J B C SCALE] */
+static void dd_domain_decoding(const P7O_PROFILE *p, int L, const float *fx, const float *bx, float *btot, float *etot, float *mocc)
+{
+  enum { E = 0, N = 1, J = 2, B = 3, C = 4, S = 5 };
+  const float scaleproduct = 1.0f / bx[N];
+  btot[0] = etot[0] = mocc[0] = 0.0f;
+  for (int i = 1; i <= L; i++) {
+    const float *f1 = fx + (size_t) (i - 1) * 6, *f = fx + (size_t) i * 6, *b1 = bx + (size_t) (i - 1) * 6, *b = bx + (size_t) i * 6;
+    btot[i] = btot[i - 1] + f1[B] * b1[B] * f1[S] * scaleproduct;
+    etot[i] = etot[i - 1] + f[E] * b[E] * f[S] * scaleproduct;
+    float njcp = f1[N] * b[N] * p->xf[p7O_N][p7O_LOOP] * scaleproduct;
+    njcp += f1[J] * b[J] * p->xf[p7O_J][p7O_LOOP] * scaleproduct;
+    njcp += f1[C] * b[C] * p->xf[p7O_C][p7O_LOOP] * scaleproduct;
+    mocc[i] = 1.0f - njcp;
+  }
+}
+
+static int dd_is_multidomain(const float *btot, const float *etot, int i, int j, float rt3)
+{
+  float max = -1.0f;
+  for (int z = i; z <= j; z++) {
+    const float a = etot[z] - etot[i - 1], b = btot[j] - btot[z - 1];
+    const float expected_n = a < b ? a : b;
+    if (expected_n > max) max = expected_n;
+  }
+  return max >= rt3;
+}
+
+/* p7_FLogsum (logsum.c): log(e^a + e^b) through a table of log(1 + e^-x) at steps of 1/1000 nat, as upstream evaluates it */
+static float dd_flogsum(float a, float b)
+{
+  static float table[16000];
+  static int ready = 0;
+  if (!ready) { for (int i = 0; i < 16000; i++) table[i] = (float) log(1.0 + exp((double) -i / 1000.0)); ready = 1; }
+  const float hi = a > b ? a : b, lo = a > b ? b : a;
+  return (lo == -INFINITY || (hi - lo) >= 15.7f) ? hi : hi + table[(int) ((hi - lo) * 1000.0f)];
+}
+
+/* One target: dsq[1..L]; fx / bx: Forward / Backward parser rows of the whole target in the multihit configuration of
+ * length L ((L+1) x 6 floats each, p7o_fwd / p7o_bck).  The profile <p> must be configured for L (p7o_reconfig_length).
+ * out: cap x 12 doubles per single-domain envelope, in order:
+ *   ienv jenv iali jali hmmfrom hmmto  envsc domcorrection oasc (nats / residues)  bitscore(bits) dombias(bits) lnP
+ * counts[0..2] = regions, single-domain envelopes, regions that need the ensemble (not resolved here).
+ * Returns the number of envelopes written, or -1. */
+int64_t p7o_domains_single(P7O_PROFILE *p, const uint8_t *dsq, int L, const float *fx, const float *bx, const uint8_t *degen,
+                           int do_null2, double *out, int64_t cap, int64_t *counts)
+{
+  const float rt1 = 0.25f, rt2 = 0.10f, rt3 = 0.20f;
+  int64_t nout = 0;
+  counts[0] = counts[1] = counts[2] = 0;
+  float *btot = (float *) calloc((size_t) L + 1, sizeof(float)), *etot = (float *) calloc((size_t) L + 1, sizeof(float)),
+        *mocc = (float *) calloc((size_t) L + 1, sizeof(float));
+  if (!btot || !etot || !mocc) { free(btot); free(etot); free(mocc); return -1; }
+  dd_domain_decoding(p, L, fx, bx, btot, etot, mocc);
+  DDModel m;
+  if (ddmodel_build(p, L, 0, &m) != 0) { free(btot); free(etot); free(mocc); return -1; }
+  const float nullsc = p7o_null1(L);
+  const float omega = 1.0f / 256.0f;
+  int i = -1, triggered = 0;
+  for (int j = 1; j <= L; j++) {
+    if (!triggered) {
+      if (mocc[j] - (btot[j] - btot[j - 1]) < rt2) i = j;
+      else if (i == -1) i = j;
+      if (mocc[j] >= rt1) triggered = 1;
+    } else if (mocc[j] - (etot[j] - etot[j - 1]) < rt2) {
+      counts[0]++;
+      if (dd_is_multidomain(btot, etot, i, j, rt3)) counts[2]++;
+      else {
+        counts[1]++;
+        const int Ld = j - i + 1;
+        DDMatrix f, b;
+        if (ddmx_alloc(&f, Ld, m.M) != 0 || ddmx_alloc(&b, Ld, m.M) != 0) { ddmx_free(&f); ddmx_free(&b); nout = -1; break; }
+        float envsc = 0.0f;
+        const uint8_t *sub = dsq + i - 1;                       /* sub[1..Ld] */
+        const int bad = dd_forward(&m, sub, Ld, &f, &envsc);
+        dd_backward(&m, sub, Ld, &f, &b);
+        const int range = dd_decoding(&m, Ld, &f, &b);           /* b holds the posteriors now */
+        if (!bad && !range) {
+          float null2[P7O_MAXKP];
+          float domcorrection = 0.0f;
+          if (do_null2) {
+            dd_null2_by_expectation(&m, Ld, &b, degen, null2);
+            for (int pos = i; pos <= j; pos++) domcorrection += logf(null2[dsq[pos]]);
+          }
+          const float oasc = dd_optimal_accuracy(&m, Ld, &b, &f);     /* f holds the optimal-accuracy matrix now */
+          int ia, ja, ka, kb;
+          if (dd_oa_trace(&m, Ld, &b, &f, p->Q4, &ia, &ja, &ka, &kb) == 0 && nout < cap) {
+            double *o = out + nout * 12;
+            /* p7_pipeline.c: the domain's bit score */
+            float bitscore = envsc + (float) (L - Ld) * logf((float) L / (float) (L + 3));
+            const float dombias = do_null2 ? dd_flogsum(0.0f, logf(omega) + domcorrection) : 0.0f;
+            bitscore = (bitscore - (nullsc + dombias)) / 0.69314718055994529f;
+            o[0] = i; o[1] = j; o[2] = ia + i - 1; o[3] = ja + i - 1; o[4] = ka; o[5] = kb;
+            o[6] = envsc; o[7] = domcorrection; o[8] = oasc; o[9] = bitscore; o[10] = dombias / 0.69314718055994529f;
+            o[11] = p7o_exp_logsurv((double) bitscore, (double) p->evparam[p7_FTAU], (double) p->evparam[p7_FLAMBDA]);
+            nout++;
+          }
+        }
+        ddmx_free(&f); ddmx_free(&b);
+      }
+      i = -1; triggered = 0;
+    }
+  }
+  ddmodel_free(&m);
+  free(btot); free(etot); free(mocc);
+  return nout;
+}
