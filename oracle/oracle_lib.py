@@ -237,21 +237,29 @@ def degeneracy_sets(K):
     return d
 
 
-def domains_single(op, seq, do_null2=True):
+def domains(op, seq, do_null2=True, seed=42, ensembles=True):
     """p7_oracle_dd.c on one target: (envelopes, counts).  envelopes: rows of ienv jenv iali jali hmmfrom hmmto envsc(nats)
-    domcorrection(nats) oasc bitscore(bits) dombias(bits) lnP for every region that holds one domain; counts = (regions,
-    single-domain envelopes, regions left to the traceback ensemble)."""
+    domcorrection(nats) oasc bitscore(bits) dombias(bits) lnP kind (0: a region that holds one domain, 1: a cluster of an
+    ensemble region), in the reference's order; counts = (regions, envelopes, ensemble regions, clusters, overlapping
+    clusters) -- the reference's (nregions, nclustered, noverlaps, nenvelopes) are counts[0], [2], [4], [1].
+    ensembles=False: regions that need the traceback ensemble are counted and left out."""
     l = lib()
-    l.p7o_domains_single.restype = C.c_int64
-    l.p7o_domains_single.argtypes = [C.POINTER(Profile), C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p,
-                                     C.c_int64, C.c_void_p]
+    l.p7o_domains.restype = C.c_int64
+    l.p7o_domains.argtypes = [C.POINTER(Profile), C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_uint32, C.c_int,
+                              C.c_void_p, C.c_int64, C.c_void_p]
     st, bsc, fx, bx = op.bck(seq)                          # configures the profile for len(seq)
     d = op._dsq(seq)
     degen = degeneracy_sets(op.ptr.contents.K)
-    cap = 64
-    out = np.zeros((cap, 12), dtype=np.float64)
-    counts = np.zeros(3, dtype=np.int64)
-    n = l.p7o_domains_single(op.ptr, d.ctypes.data, len(seq), fx.ctypes.data, bx.ctypes.data, degen.ctypes.data, int(do_null2),
-                             out.ctypes.data, cap, counts.ctypes.data)
-    assert n >= 0
+    cap = 256
+    out = np.zeros((cap, 13), dtype=np.float64)
+    counts = np.zeros(5, dtype=np.int64)
+    n = l.p7o_domains(op.ptr, d.ctypes.data, len(seq), fx.ctypes.data, bx.ctypes.data, degen.ctypes.data, int(do_null2), int(seed),
+                      int(bool(ensembles)), out.ctypes.data, cap, counts.ctypes.data)
+    assert 0 <= n <= cap, n
     return out[:n].copy(), tuple(int(c) for c in counts)
+
+
+def domains_single(op, seq, do_null2=True):
+    """The regions that hold one domain only: (envelopes, (regions, single-domain envelopes, ensemble regions))."""
+    envs, counts = domains(op, seq, do_null2=do_null2, ensembles=False)
+    return envs, (counts[0], counts[1], counts[2])

@@ -130,12 +130,13 @@ int   p7o_lt_envelope_scores(const P7O_PROFILE *p, const uint8_t *env, int n, in
 void  p7o_lt_envelope_background(const P7O_PROFILE *p, const uint8_t *env, int64_t n_env, int64_t window_len,
                                  const uint8_t *degen, float *bg_out);
 
-/* domain definition of the regions that hold one domain (p7_oracle_dd.c): regions from the parsers' rows, then per region
- * the envelope's Forward / Backward / decoding / null2 / optimal-accuracy alignment and its score.  out: 12 doubles per
- * envelope (ienv jenv iali jali hmmfrom hmmto envsc domcorrection oasc bitscore dombias lnP); counts: regions,
- * single-domain envelopes, regions that need the traceback ensemble (not resolved).  degen: [Kp][K] residue-code sets. */
-int64_t p7o_domains_single(P7O_PROFILE *p, const uint8_t *dsq, int L, const float *fx, const float *bx, const uint8_t *degen,
-                           int do_null2, double *out, int64_t cap, int64_t *counts);
+/* domain definition (p7_oracle_dd.c): regions from the parsers' rows; a region that holds one domain is rescored as it is,
+ * a region that holds several through the ensemble of 200 sampled tracebacks, their clustering and the null2 scores by
+ * trace (seed != 0 and ensembles != 0; else such regions are only counted).  out: 13 doubles per envelope (ienv jenv iali
+ * jali hmmfrom hmmto envsc domcorrection oasc bitscore dombias lnP kind); counts: regions, envelopes, ensemble regions,
+ * clusters, overlapping clusters.  degen: [Kp][K] residue-code sets. */
+int64_t p7o_domains(P7O_PROFILE *p, const uint8_t *dsq, int L, const float *fx, const float *bx, const uint8_t *degen,
+                    int do_null2, uint32_t seed, int ensembles, double *out, int64_t cap, int64_t *counts);
 
 #ifdef __cplusplus
 }

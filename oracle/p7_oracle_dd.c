@@ -1,24 +1,33 @@
 /* p7_oracle_dd.c -- TEST INFRASTRUCTURE ONLY (see p7_oracle.h).
  *
- * CPU restatement of HMMER 3.4's domain definition for the regions that hold ONE domain -- the part of
- * p7_domaindef_ByPosteriorHeuristics (reference include/libhmmer/p7_domaindef.pxd:69-72, reached from
- * Pipeline._search_loop, src/pyhmmer/plan7.pyx:6393-6453, through p7_Pipeline) that every hit goes through:
+ * CPU restatement of HMMER 3.4's domain definition, p7_domaindef_ByPosteriorHeuristics (reference
+ * include/libhmmer/p7_domaindef.pxd:23-72, p7_spensemble.pxd:3-39; reached from Pipeline._search_loop,
+ * src/pyhmmer/plan7.pyx:6393-6453, through p7_Pipeline; the generator is re-seeded per region, plan7.pyx:5684-5688):
  *
  *   p7_DomainDecoding          posterior begin / end / occupancy totals from the parsers' special-state rows
  *   the region scan            rt1 = 0.25, rt2 = 0.10: where the occupancy rises and falls
- *   is_multidomain_region      rt3 = 0.20: regions that need the stochastic traceback ensemble are only REPORTED here
- *                              (their envelopes come out of a clustering of 200 sampled tracebacks; not restated)
+ *   is_multidomain_region      rt3 = 0.20
  *   rescore_isolated_domain    unihit Forward / Backward over the envelope (upstream impl_sse/fwdback.c, odds space with
  *                              sparse rescaling), p7_Decoding, p7_Null2_ByExpectation, p7_OptimalAccuracy, p7_OATrace
+ *   region_trace_ensemble      multihit Forward of the region, 200 x p7_StochasticTrace from Easel's fast generator
+ *                              (esl_random.c: LCG, Jenkins-mixed seed; esl_rnd_FChoose on Kahan-normalised weights),
+ *                              p7_trace_Index, p7_Null2_ByTrace per sampled domain, the per-residue null2 scores
+ *   p7_spensemble_Cluster      single linkage (link_spsamples), clusters with posterior >= 0.25, consensus end points
  *   the scoring of a domain    p7_pipeline.c: envelope score + length correction - null1 - null2, in bits; exponential tail
  *
  * Plain scalar C over un-striped tables, every sum taken in the order of the nodes: neither upstream's striped vector
- * order nor the product's lane-chunk order.  Posteriors therefore differ from either in the last bits, and a comparison
- * with the product is exact only away from ties (tests/test_oracle_domains.py states the rates it accepts).  What this
- * file is for: a second, independently structured implementation of the logic -- thresholds, recursions, tie-break
- * orders, coordinate conventions -- pinned by the reference's own domain tables (tests/golden/tables/ *.domtbl: envelope
- * and alignment coordinates exactly, scores and biases at print precision) and compared with the product on thousands of
- * synthetic targets.  It shares no code with pyhmmer_amd/csrc/p7x_domaindef.cpp.
+ * order nor the product's lane-chunk order.  Posteriors therefore differ from either in the last bits; a comparison with
+ * the product is exact away from ties, and a sampled traceback that meets a tie takes another path and with it every
+ * later sample of its region (tests/test_oracle_domains.py states the rates it accepts and observes).  What this file is
+ * for: a second, independently structured implementation of the logic -- thresholds, recursions, tie-break orders,
+ * coordinate conventions, the order and number of the generator's draws -- pinned by the reference's own domain tables
+ * (tests/golden/tables/ *.domtbl: all 53 rows, envelope / alignment / model coordinates exactly, scores and biases at print
+ * precision) and compared with the product on thousands of synthetic targets.  It shares no code with
+ * pyhmmer_amd/csrc/p7x_domaindef.cpp.  Four of upstream's peculiarities that the tables pin were written wrongly at first
+ * from memory and corrected after the tables (and the product, which reproduces them) disagreed: two sampled domains link
+ * when their START points OR their END points lie on nearby diagonals; p7_Null2_ByTrace counts an insert state's residue
+ * in the match slot of its node; region_trace_ensemble counts a sampled domain's first residue as outside the domain; the
+ * E state's draw multiplies the cells by a single-precision reciprocal.
  */
 #include "p7_oracle.h"
 #include <math.h>
@@ -411,72 +420,383 @@ static float dd_flogsum(float a, float b)
   return (lo == -INFINITY || (hi - lo) >= 15.7f) ? hi : hi + table[(int) ((hi - lo) * 1000.0f)];
 }
 
+/* ---------------------------------------------------------------------------------------------------------------------
+ * regions that hold more than one domain: p7_domaindef.c region_trace_ensemble (reference p7_domaindef.pxd:23-59) */
+
+/* Easel's fast generator (esl_random.c, eslRND_FAST): x <- 69069 x + 1, a draw is x / 2^32; esl_randomness_Init disperses the
+ * seed with Jenkins' mix3 */
+typedef struct { uint32_t x; } DDRng;
+static uint32_t dd_mix3(uint32_t a, uint32_t b, uint32_t c)
+{
+  a -= b; a -= c; a ^= (c >> 13);  b -= c; b -= a; b ^= (a << 8);   c -= a; c -= b; c ^= (b >> 13);
+  a -= b; a -= c; a ^= (c >> 12);  b -= c; b -= a; b ^= (a << 16);  c -= a; c -= b; c ^= (b >> 5);
+  a -= b; a -= c; a ^= (c >> 3);   b -= c; b -= a; b ^= (a << 10);  c -= a; c -= b; c ^= (b >> 15);
+  return c;
+}
+static void dd_rng_init(DDRng *r, uint32_t seed) { r->x = dd_mix3(seed, 87654321u, 12345678u); if (r->x == 0) r->x = 42; }
+static double dd_random(DDRng *r) { r->x = r->x * 69069u + 1u; return (double) r->x / 4294967296.0; }
+
+/* esl_vec_FNorm (its sum is Kahan-compensated, esl_vectorops.c) + esl_rnd_FChoose (esl_random.c: roll and running sum in
+ * double -- a float roll could be 1.0 --, and when rounding leaves the roll above the last sum, uniform draws until one hits
+ * a path of nonzero weight) */
+static int dd_fchoose(DDRng *r, float *p, int n)
+{
+  float sum = 0.0f, c = 0.0f;
+  for (int i = 0; i < n; i++) { const float y = p[i] - c, t = sum + y; c = (t - sum) - y; sum = t; }
+  if (sum != 0.0f) for (int i = 0; i < n; i++) p[i] /= sum; else for (int i = 0; i < n; i++) p[i] = 1.0f / (float) n;
+  const double roll = dd_random(r);
+  double acc = 0.0;
+  for (int i = 0; i < n; i++) { acc += p[i]; if (roll < acc) return i; }
+  int i;
+  do { i = (int) (dd_random(r) * n); } while (p[i] == 0.0f);
+  return i;
+}
+
+/* one sampled domain of a traceback: residues ia..ja of the region, nodes ka..kb, and the states that emitted inside it */
+typedef struct { int ia, ja, ka, kb; } DDSeg;
+
+/* p7_StochasticTrace (impl_sse/stotrace.c) on the region's multihit Forward matrix, p7_trace_Index, and for every domain
+ * of the trace p7_Null2_ByTrace (impl_sse/null2.c): cnt_m / cnt_i count the match / insert states the domain used.
+ * segs: the trace's domains in sequence order.  n2acc[1..Lr] is bumped as region_trace_ensemble bumps ddef->n2sc. */
+static int dd_sample_trace(const DDModel *m, const uint8_t *dsq /* region, 1..Lr */, int Lr, const DDMatrix *f, int Q, DDRng *r,
+                           const uint8_t *degen, DDSeg *segs, int segcap, float *n2acc, float *cnt_m, float *cnt_i)
+{
+  const int M = m->M, K = m->K, Kp = m->Kp;
+  /* the walk, from C at row Lr back to S; domains are met last to first */
+  enum { tS, tN, tB, tM, tD, tI, tE, tJ, tC };
+  int i = Lr, k = 0, sprv = tC, nseg = 0;
+  /* the emitting states of the domain being walked: list of (state, k, i) is not needed, only the counts per domain, so the
+   * counts are collected per domain on the way and committed when its B is reached */
+  int cur_ja = 0, cur_kb = 0, cur_ia = 0, cur_ka = 0, in_dom = 0;
+  /* per-domain emitting states: stored so that null2 can be applied after the whole trace is known (domains come out last
+   * first, the accumulation into n2acc runs first to last over positions) */
+  int *dom_state_k = (int *) malloc(sizeof(int) * (size_t) (2 * (Lr + M) + 8));       /* +k for M, -k for I */
+  int *dom_first = (int *) malloc(sizeof(int) * (size_t) (segcap + 1));
+  int nstates = 0;
+  if (!dom_state_k || !dom_first) { free(dom_state_k); free(dom_first); return -1; }
+  long guard = 8L * (Lr + 2) * (M + 2) + 64;
+  while (sprv != tS && guard-- > 0) {
+    int scur = -1;
+    float path[4];
+    switch (sprv) {
+    case tM:
+      path[0] = f->xB[i - 1] * m->bm[k];
+      path[1] = (k > 1) ? MX(f, i - 1, k - 1) * m->mm[k] : 0.0f;
+      path[2] = (k > 1) ? IX(f, i - 1, k - 1) * m->im[k] : 0.0f;
+      path[3] = (k > 1) ? DX(f, i - 1, k - 1) * m->dm[k] : 0.0f;
+      { static const int st[4] = { tB, tM, tI, tD }; scur = st[dd_fchoose(r, path, 4)]; }
+      k--; i--;
+      break;
+    case tD:
+      path[0] = MX(f, i, k - 1) * m->md[k - 1];
+      path[1] = DX(f, i, k - 1) * m->dd[k - 1];
+      scur = dd_fchoose(r, path, 2) == 0 ? tM : tD;
+      k--;
+      break;
+    case tI:
+      path[0] = MX(f, i - 1, k) * m->mi[k];
+      path[1] = IX(f, i - 1, k) * m->ii[k];
+      scur = dd_fchoose(r, path, 2) == 0 ? tM : tI;
+      i--;
+      break;
+    case tN: scur = (i == 0) ? tS : tN; break;
+    case tC:
+      path[0] = f->xC[i - 1] * m->cloop;
+      path[1] = f->xE[i] * m->emove * f->scale[i];
+      scur = dd_fchoose(r, path, 2) == 0 ? tC : tE;
+      break;
+    case tJ:
+      path[0] = f->xJ[i - 1] * m->jloop;
+      path[1] = f->xE[i] * m->eloop * f->scale[i];
+      scur = dd_fchoose(r, path, 2) == 0 ? tJ : tE;
+      break;
+    case tE: {
+      /* E(i) from M(i,k) or D(i,k): one draw against the running sum, cells in the order of the striped vectors */
+      const double roll = dd_random(r);
+      const float norm = (float) (1.0 / f->xE[i]);
+      double sum = 0.0;
+      int tries = 0;
+      while (scur < 0 && tries++ < 4) {
+        for (int q = 0; q < Q && scur < 0; q++) {
+          for (int z = 0; z < 4 && scur < 0; z++) { const int kk = z * Q + q + 1; if (kk <= M) { sum += MX(f, i, kk) * norm; if (roll < sum) { scur = tM; k = kk; } } }
+          for (int z = 0; z < 4 && scur < 0; z++) { const int kk = z * Q + q + 1; if (kk <= M) { sum += DX(f, i, kk) * norm; if (roll < sum) { scur = tD; k = kk; } } }
+        }
+      }
+      if (scur < 0) { free(dom_state_k); free(dom_first); return -1; }
+      in_dom = 1; cur_ja = cur_kb = cur_ia = cur_ka = 0;
+      if (nseg < segcap) dom_first[nseg] = nstates;
+      break;
+    }
+    case tB:
+      path[0] = f->xN[i] * m->nmove;
+      path[1] = f->xJ[i] * m->jmove;
+      scur = dd_fchoose(r, path, 2) == 0 ? tN : tJ;
+      break;
+    default: break;
+    }
+    if (scur < 0) { free(dom_state_k); free(dom_first); return -1; }
+    /* the state just chosen sits at (k, i) */
+    if (scur == tM) {
+      if (cur_ja == 0) { cur_ja = i; cur_kb = k; }
+      cur_ia = i; cur_ka = k;
+      dom_state_k[nstates++] = k;
+    } else if (scur == tI) {
+      dom_state_k[nstates++] = -k;
+    } else if (scur == tB && in_dom) {
+      if (nseg < segcap) { segs[nseg].ia = cur_ia; segs[nseg].ja = cur_ja; segs[nseg].ka = cur_ka; segs[nseg].kb = cur_kb; }
+      nseg++;
+      in_dom = 0;
+    }
+    if ((scur == tN || scur == tJ || scur == tC) && scur == sprv) i--;
+    sprv = scur;
+  }
+  if (guard <= 0 || nseg > segcap) { free(dom_state_k); free(dom_first); return -1; }
+  dom_first[nseg] = nstates;
+  /* first to last */
+  for (int a = 0, b = nseg - 1; a < b; a++, b--) { DDSeg t = segs[a]; segs[a] = segs[b]; segs[b] = t; }
+  int pos = 1;
+  for (int d = 0; d < nseg; d++) {
+    const int w = nseg - 1 - d;                                /* where this domain's states were stored */
+    /* p7_Null2_ByTrace */
+    for (int kk = 0; kk <= M; kk++) cnt_m[kk] = cnt_i[kk] = 0.0f;
+    int Ld = 0;
+    /* upstream works out whether the emitting state is a match or an insert state and then does not use it: an insert
+     * state's residue is counted in the MATCH slot of its node, and the insert slots stay zero */
+    for (int z = dom_first[w]; z < dom_first[w + 1]; z++) { const int v = dom_state_k[z]; cnt_m[v > 0 ? v : -v] += 1.0f; Ld++; }
+    float null2[P7O_MAXKP];
+    const float norm = 1.0f / (float) Ld;
+    for (int kk = 1; kk <= M; kk++) { cnt_m[kk] *= norm; cnt_i[kk] *= norm; }
+    for (int x = 0; x < K; x++) {
+      const float *e = m->em + (size_t) x * (M + 1);
+      float sv = 0.0f;
+      for (int kk = 1; kk <= M; kk++) { sv += cnt_m[kk] * e[kk]; sv += cnt_i[kk]; }
+      null2[x] = sv;                                          /* no N / C / J residue inside a domain: xfactor = 0 */
+    }
+    for (int x = K; x < Kp; x++) null2[x] = 1.0f;
+    for (int x = K + 1; x < Kp - 2; x++) {
+      float sum = 0.0f; int n = 0;
+      for (int y = 0; y < K; y++) if (degen[(size_t) x * K + y]) { sum += null2[y]; n++; }
+      null2[x] = n ? sum / (float) n : 1.0f;
+    }
+    /* residues outside the domains count 1, residues inside their null2 ratio (upstream's loop bounds: the domain's
+     * first residue is still counted as outside) */
+    for (; pos <= segs[d].ia; pos++) n2acc[pos] += 1.0f;
+    for (; pos <= segs[d].ja; pos++) n2acc[pos] += null2[dsq[pos]];
+  }
+  for (; pos <= Lr; pos++) n2acc[pos] += 1.0f;
+  free(dom_state_k); free(dom_first);
+  return nseg;
+}
+
+/* p7_spensemble_Cluster (p7_spensemble.c): single-linkage clustering of the sampled domains (esl_cluster_SingleLinkage with
+ * link_spsamples: overlap of at least min_overlap of the smaller one in the sequence AND in the model, and the start points
+ * or the end points on nearby diagonals), then for every cluster that at least min_posterior of the samples take part in, consensus end points: the
+ * leftmost start and the rightmost end that at least min_endpointp of its samples use. */
+typedef struct { int i, j, k, m, idx; } DDCoord;
+static int dd_linked(const DDCoord *a, const DDCoord *b)
+{
+  const float min_overlap = 0.8f; const int max_diagdiff = 4;
+  int nov = (a->j < b->j ? a->j : b->j) - (a->i > b->i ? a->i : b->i) + 1;
+  int la = a->j - a->i + 1, lb = b->j - b->i + 1;
+  int n = la < lb ? la : lb;
+  if ((float) nov / (float) n < min_overlap) return 0;
+  nov = (a->m < b->m ? a->m : b->m) - (a->k > b->k ? a->k : b->k) + 1;
+  la = a->m - a->k + 1; lb = b->m - b->k + 1;
+  n = la < lb ? la : lb;
+  if ((float) nov / (float) n < min_overlap) return 0;
+  if (abs((a->i - a->k) - (b->i - b->k)) <= max_diagdiff) return 1;      /* the start points on nearby diagonals, */
+  if (abs((a->j - a->m) - (b->j - b->m)) <= max_diagdiff) return 1;      /* or the end points */
+  return 0;
+}
+static int dd_coord_by_start(const void *x, const void *y)
+{
+  const DDCoord *a = (const DDCoord *) x, *b = (const DDCoord *) y;
+  return (a->i > b->i) - (a->i < b->i);
+}
+static int dd_cluster(const DDCoord *seg, int n, int nsamples, DDCoord *out, int outcap)
+{
+  const float min_posterior = 0.25f, min_endpointp = 0.02f;
+  int *assign = (int *) malloc(sizeof(int) * (size_t) (n + 1)), *stack = (int *) malloc(sizeof(int) * (size_t) (n + 1));
+  char *seen = (char *) calloc((size_t) nsamples + 1, 1);
+  if (!assign || !stack || !seen) { free(assign); free(stack); free(seen); return -1; }
+  for (int h = 0; h < n; h++) assign[h] = -1;
+  int nc = 0;
+  for (int h = 0; h < n; h++) {                 /* connected components */
+    if (assign[h] >= 0) continue;
+    int ns = 0; stack[ns++] = h; assign[h] = nc;
+    while (ns > 0) {
+      const int v = stack[--ns];
+      for (int w = 0; w < n; w++) if (assign[w] < 0 && dd_linked(seg + v, seg + w)) { assign[w] = nc; stack[ns++] = w; }
+    }
+    nc++;
+  }
+  int nout = 0;
+  for (int c = 0; c < nc; c++) {
+    memset(seen, 0, (size_t) nsamples + 1);
+    int ninc = 0, imin = 1 << 30, imax = 0, jmin = 1 << 30, jmax = 0, kmin = 1 << 30, kmax = 0, mmin = 1 << 30, mmax = 0;
+    for (int h = 0; h < n; h++) if (assign[h] == c) {
+      if (!seen[seg[h].idx]) { seen[seg[h].idx] = 1; ninc++; }
+      if (seg[h].i < imin) imin = seg[h].i;
+      if (seg[h].i > imax) imax = seg[h].i;
+      if (seg[h].j < jmin) jmin = seg[h].j;
+      if (seg[h].j > jmax) jmax = seg[h].j;
+      if (seg[h].k < kmin) kmin = seg[h].k;
+      if (seg[h].k > kmax) kmax = seg[h].k;
+      if (seg[h].m < mmin) mmin = seg[h].m;
+      if (seg[h].m > mmax) mmax = seg[h].m;
+    }
+    if ((float) ninc / (float) nsamples < min_posterior) continue;
+    /* end points: histogram over the cluster's members, threshold in members-per-sample units */
+    int span = imax - imin; if (jmax - jmin > span) span = jmax - jmin; if (kmax - kmin > span) span = kmax - kmin; if (mmax - mmin > span) span = mmax - mmin;
+    int *epc = (int *) calloc((size_t) span + 2, sizeof(int));
+    if (!epc) { free(assign); free(stack); free(seen); return -1; }
+    int best[4];
+    for (int which = 0; which < 4; which++) {
+      const int lo = which == 0 ? imin : which == 1 ? jmin : which == 2 ? kmin : mmin;
+      const int hi = which == 0 ? imax : which == 1 ? jmax : which == 2 ? kmax : mmax;
+      memset(epc, 0, sizeof(int) * (size_t) (span + 2));
+      for (int h = 0; h < n; h++) if (assign[h] == c) epc[(which == 0 ? seg[h].i : which == 1 ? seg[h].j : which == 2 ? seg[h].k : seg[h].m) - lo]++;
+      int b = -1;
+      if (which == 0 || which == 2) { for (int v = lo; v <= hi; v++) if ((float) epc[v - lo] / (float) ninc >= min_endpointp) { b = v; break; } }
+      else                          { for (int v = hi; v >= lo; v--) if ((float) epc[v - lo] / (float) ninc >= min_endpointp) { b = v; break; } }
+      if (b < 0) { int arg = 0; for (int v = 1; v <= hi - lo; v++) if (epc[v] > epc[arg]) arg = v; b = lo + arg; }
+      best[which] = b;
+    }
+    free(epc);
+    if (nout < outcap) { out[nout].i = best[0]; out[nout].j = best[1]; out[nout].k = best[2]; out[nout].m = best[3]; out[nout].idx = c; }
+    nout++;
+  }
+  free(assign); free(stack); free(seen);
+  if (nout > outcap) return -1;
+  qsort(out, (size_t) nout, sizeof(DDCoord), dd_coord_by_start);
+  return nout;
+}
+
+/* rescore_isolated_domain: the envelope i..j of the target; n2sc != NULL: the null2 log ratios of the target's residues are
+ * already there (an ensemble region), else they come from the envelope's own posterior expectation.  Appends one row. */
+static int dd_rescore(const P7O_PROFILE *p, const DDModel *uni, const uint8_t *dsq, int L, int i, int j, const uint8_t *degen, int do_null2,
+                      const float *n2sc, double *out, int64_t *nout, int64_t cap, double kind)
+{
+  const int Ld = j - i + 1;
+  DDMatrix f, b;
+  if (ddmx_alloc(&f, Ld, uni->M) != 0 || ddmx_alloc(&b, Ld, uni->M) != 0) { ddmx_free(&f); ddmx_free(&b); return -1; }
+  float envsc = 0.0f;
+  const uint8_t *sub = dsq + i - 1;                       /* sub[1..Ld] */
+  const int bad = dd_forward(uni, sub, Ld, &f, &envsc);
+  dd_backward(uni, sub, Ld, &f, &b);
+  const int range = dd_decoding(uni, Ld, &f, &b);          /* b holds the posteriors now */
+  int ok = 0;
+  if (!bad && !range) {
+    float null2[P7O_MAXKP];
+    float domcorrection = 0.0f;
+    if (do_null2) {
+      if (n2sc) { for (int pos = i; pos <= j; pos++) domcorrection += n2sc[pos]; }
+      else {
+        dd_null2_by_expectation(uni, Ld, &b, degen, null2);
+        for (int pos = i; pos <= j; pos++) domcorrection += logf(null2[dsq[pos]]);
+      }
+    }
+    const float oasc = dd_optimal_accuracy(uni, Ld, &b, &f);     /* f holds the optimal-accuracy matrix now */
+    int ia, ja, ka, kb;
+    if (dd_oa_trace(uni, Ld, &b, &f, p->Q4, &ia, &ja, &ka, &kb) == 0) {
+      ok = 1;
+      if (*nout < cap) {
+        double *o = out + *nout * 13;
+        const float nullsc = p7o_null1(L), omega = 1.0f / 256.0f;
+        /* p7_pipeline.c: the domain's bit score */
+        float bitscore = envsc + (float) (L - Ld) * logf((float) L / (float) (L + 3));
+        const float dombias = do_null2 ? dd_flogsum(0.0f, logf(omega) + domcorrection) : 0.0f;
+        bitscore = (bitscore - (nullsc + dombias)) / 0.69314718055994529f;
+        o[0] = i; o[1] = j; o[2] = ia + i - 1; o[3] = ja + i - 1; o[4] = ka; o[5] = kb;
+        o[6] = envsc; o[7] = domcorrection; o[8] = oasc; o[9] = bitscore; o[10] = dombias / 0.69314718055994529f;
+        o[11] = p7o_exp_logsurv((double) bitscore, (double) p->evparam[p7_FTAU], (double) p->evparam[p7_FLAMBDA]);
+        o[12] = kind;
+      }
+      (*nout)++;
+    }
+  }
+  ddmx_free(&f); ddmx_free(&b);
+  return ok;
+}
+
 /* One target: dsq[1..L]; fx / bx: Forward / Backward parser rows of the whole target in the multihit configuration of
  * length L ((L+1) x 6 floats each, p7o_fwd / p7o_bck).  The profile <p> must be configured for L (p7o_reconfig_length).
- * out: cap x 12 doubles per single-domain envelope, in order:
+ * seed: the pipeline's seed (the generator is re-seeded for every ensemble region, plan7.pyx:5684-5688); seed 0 or
+ * ensembles == 0: regions that need the ensemble are counted and left out.
+ * out: cap x 13 doubles per envelope, in the order the reference defines them:
  *   ienv jenv iali jali hmmfrom hmmto  envsc domcorrection oasc (nats / residues)  bitscore(bits) dombias(bits) lnP
- * counts[0..2] = regions, single-domain envelopes, regions that need the ensemble (not resolved here).
- * Returns the number of envelopes written, or -1. */
-int64_t p7o_domains_single(P7O_PROFILE *p, const uint8_t *dsq, int L, const float *fx, const float *bx, const uint8_t *degen,
-                           int do_null2, double *out, int64_t cap, int64_t *counts)
+ *   kind (0: a region that holds one domain, 1: a cluster of an ensemble region)
+ * counts[0..4] = regions, envelopes, ensemble regions, clusters, overlapping clusters.
+ * Returns the number of envelopes (may exceed cap: only cap are written), or -1. */
+int64_t p7o_domains(P7O_PROFILE *p, const uint8_t *dsq, int L, const float *fx, const float *bx, const uint8_t *degen,
+                    int do_null2, uint32_t seed, int ensembles, double *out, int64_t cap, int64_t *counts)
 {
   const float rt1 = 0.25f, rt2 = 0.10f, rt3 = 0.20f;
+  const int nsamples = 200;
   int64_t nout = 0;
-  counts[0] = counts[1] = counts[2] = 0;
+  for (int c = 0; c < 5; c++) counts[c] = 0;
   float *btot = (float *) calloc((size_t) L + 1, sizeof(float)), *etot = (float *) calloc((size_t) L + 1, sizeof(float)),
-        *mocc = (float *) calloc((size_t) L + 1, sizeof(float));
-  if (!btot || !etot || !mocc) { free(btot); free(etot); free(mocc); return -1; }
+        *mocc = (float *) calloc((size_t) L + 1, sizeof(float)), *n2sc = (float *) calloc((size_t) L + 2, sizeof(float));
+  if (!btot || !etot || !mocc || !n2sc) { free(btot); free(etot); free(mocc); free(n2sc); return -1; }
   dd_domain_decoding(p, L, fx, bx, btot, etot, mocc);
-  DDModel m;
-  if (ddmodel_build(p, L, 0, &m) != 0) { free(btot); free(etot); free(mocc); return -1; }
-  const float nullsc = p7o_null1(L);
-  const float omega = 1.0f / 256.0f;
-  int i = -1, triggered = 0;
-  for (int j = 1; j <= L; j++) {
+  DDModel uni, multi;
+  if (ddmodel_build(p, L, 0, &uni) != 0 || ddmodel_build(p, L, 1, &multi) != 0) { free(btot); free(etot); free(mocc); free(n2sc); return -1; }
+  int i = -1, triggered = 0, failed = 0;
+  for (int j = 1; j <= L && !failed; j++) {
     if (!triggered) {
       if (mocc[j] - (btot[j] - btot[j - 1]) < rt2) i = j;
       else if (i == -1) i = j;
       if (mocc[j] >= rt1) triggered = 1;
     } else if (mocc[j] - (etot[j] - etot[j - 1]) < rt2) {
       counts[0]++;
-      if (dd_is_multidomain(btot, etot, i, j, rt3)) counts[2]++;
-      else {
-        counts[1]++;
-        const int Ld = j - i + 1;
-        DDMatrix f, b;
-        if (ddmx_alloc(&f, Ld, m.M) != 0 || ddmx_alloc(&b, Ld, m.M) != 0) { ddmx_free(&f); ddmx_free(&b); nout = -1; break; }
-        float envsc = 0.0f;
-        const uint8_t *sub = dsq + i - 1;                       /* sub[1..Ld] */
-        const int bad = dd_forward(&m, sub, Ld, &f, &envsc);
-        dd_backward(&m, sub, Ld, &f, &b);
-        const int range = dd_decoding(&m, Ld, &f, &b);           /* b holds the posteriors now */
-        if (!bad && !range) {
-          float null2[P7O_MAXKP];
-          float domcorrection = 0.0f;
-          if (do_null2) {
-            dd_null2_by_expectation(&m, Ld, &b, degen, null2);
-            for (int pos = i; pos <= j; pos++) domcorrection += logf(null2[dsq[pos]]);
+      if (dd_is_multidomain(btot, etot, i, j, rt3)) {
+        counts[2]++;
+        if (ensembles && seed != 0) {
+          const int Lr = j - i + 1, M = multi.M;
+          const uint8_t *sub = dsq + i - 1;
+          DDMatrix f;
+          float fsc;
+          const int segcap = 4 + Lr;
+          DDSeg *segs = (DDSeg *) malloc(sizeof(DDSeg) * (size_t) segcap);
+          DDCoord *all = (DDCoord *) malloc(sizeof(DDCoord) * (size_t) nsamples * (size_t) segcap);
+          DDCoord *cl = (DDCoord *) malloc(sizeof(DDCoord) * (size_t) (nsamples * 4 + 16));
+          float *n2acc = (float *) calloc((size_t) Lr + 2, sizeof(float));
+          float *cm = (float *) calloc((size_t) M + 1, sizeof(float)), *ci = (float *) calloc((size_t) M + 1, sizeof(float));
+          if (ddmx_alloc(&f, Lr, M) != 0 || !segs || !all || !cl || !n2acc || !cm || !ci) failed = 1;
+          int nall = 0;
+          if (!failed) {
+            dd_forward(&multi, sub, Lr, &f, &fsc);
+            DDRng rng;
+            dd_rng_init(&rng, seed);
+            for (int t = 0; t < nsamples && !failed; t++) {
+              const int ns = dd_sample_trace(&multi, sub, Lr, &f, p->Q4, &rng, degen, segs, segcap, n2acc, cm, ci);
+              if (ns < 0) { failed = 1; break; }
+              for (int d = 0; d < ns; d++) { all[nall].i = segs[d].ia + i - 1; all[nall].j = segs[d].ja + i - 1; all[nall].k = segs[d].ka; all[nall].m = segs[d].kb; all[nall].idx = t; nall++; }
+            }
           }
-          const float oasc = dd_optimal_accuracy(&m, Ld, &b, &f);     /* f holds the optimal-accuracy matrix now */
-          int ia, ja, ka, kb;
-          if (dd_oa_trace(&m, Ld, &b, &f, p->Q4, &ia, &ja, &ka, &kb) == 0 && nout < cap) {
-            double *o = out + nout * 12;
-            /* p7_pipeline.c: the domain's bit score */
-            float bitscore = envsc + (float) (L - Ld) * logf((float) L / (float) (L + 3));
-            const float dombias = do_null2 ? dd_flogsum(0.0f, logf(omega) + domcorrection) : 0.0f;
-            bitscore = (bitscore - (nullsc + dombias)) / 0.69314718055994529f;
-            o[0] = i; o[1] = j; o[2] = ia + i - 1; o[3] = ja + i - 1; o[4] = ka; o[5] = kb;
-            o[6] = envsc; o[7] = domcorrection; o[8] = oasc; o[9] = bitscore; o[10] = dombias / 0.69314718055994529f;
-            o[11] = p7o_exp_logsurv((double) bitscore, (double) p->evparam[p7_FTAU], (double) p->evparam[p7_FLAMBDA]);
-            nout++;
+          if (!failed) {
+            for (int pos = 1; pos <= Lr; pos++) n2sc[i + pos - 1] = logf(n2acc[pos] / (float) nsamples);
+            const int nc = dd_cluster(all, nall, nsamples, cl, nsamples * 4 + 16);
+            if (nc < 0) failed = 1;
+            int last_j2 = 0;
+            for (int d = 0; d < nc && !failed; d++) {
+              counts[3]++;
+              if (cl[d].i <= last_j2) counts[4]++;
+              const int st = dd_rescore(p, &uni, dsq, L, cl[d].i, cl[d].j, degen, do_null2, n2sc, out, &nout, cap, 1.0);
+              if (st < 0) failed = 1; else if (st > 0) { last_j2 = cl[d].j; counts[1]++; }
+            }
           }
+          ddmx_free(&f);
+          free(segs); free(all); free(cl); free(n2acc); free(cm); free(ci);
         }
-        ddmx_free(&f); ddmx_free(&b);
+      } else {
+        const int st = dd_rescore(p, &uni, dsq, L, i, j, degen, do_null2, NULL, out, &nout, cap, 0.0);
+        if (st < 0) failed = 1; else counts[1]++;
       }
       i = -1; triggered = 0;
     }
   }
-  ddmodel_free(&m);
-  free(btot); free(etot); free(mocc);
-  return nout;
+  ddmodel_free(&uni); ddmodel_free(&multi);
+  free(btot); free(etot); free(mocc); free(n2sc);
+  return failed ? -1 : nout;
 }
