@@ -16,6 +16,7 @@ divided by the max-over-ranks wall time per step (all-pairs M*L denominator, as 
 """
 import argparse
 import json
+import math
 import os
 import sys
 import time
@@ -206,12 +207,24 @@ def cpu_baseline(hmm, bg, flat, offsets, lengths, n, L_hint):
     t_dd = time.perf_counter() - t0
     nhits = len(plan7.TopHits(hmm, outp)) if st == 0 else -1
     dt = t_filters + t_dd
+    # The same survivors once more through the oracle's OWN domain definition and sequence scoring (oracle/p7_oracle_dd.c:
+    # no product code past the filters), not timed: how many targets it reports at the pipeline's thresholds (E <= 10 over
+    # these n targets).  The host twin's count above and this one agree unless a target sits on the threshold.
+    oracle_hits = None
+    try:
+        oracle_hits = 0
+        for t in surv:
+            envs, cnt, sq = oracle_lib.domains(ops[0], flat[offsets[t]: offsets[t] + lengths[t]], seed=42, want_sequence=True)
+            if sq["ndom"] > 0 and math.exp(sq["lnP"]) * n <= 10.0:
+                oracle_hits += 1
+    except Exception:                                   # the check must never cost the bench its line
+        oracle_hits = None
     return {
         "value": round(float(hmm.M) * float(lengths[:n].sum()) / dt / 1e9, 3), "unit": "GCUPS", "cores": cores, "kind": "port",
         "sample": f"the first {n} targets of the same workload, whole search: oracle/ filter cascade + parsers (SSE2 restatement of "
                   f"impl_sse) on {cores} threads {t_filters:.2f} s, Backward rows + domain definition / hit list (product host twin) "
                   f"{t_dd:.2f} s",
-        "past_msv": int(counts[0]), "past_fwd": int(counts[3]), "hits": nhits,
+        "past_msv": int(counts[0]), "past_fwd": int(counts[3]), "hits": nhits, "hits_by_the_oracles_own_domain_definition": oracle_hits,
     }
 
 

@@ -237,25 +237,30 @@ def degeneracy_sets(K):
     return d
 
 
-def domains(op, seq, do_null2=True, seed=42, ensembles=True):
+def domains(op, seq, do_null2=True, seed=42, ensembles=True, want_sequence=False):
     """p7_oracle_dd.c on one target: (envelopes, counts).  envelopes: rows of ienv jenv iali jali hmmfrom hmmto envsc(nats)
     domcorrection(nats) oasc bitscore(bits) dombias(bits) lnP kind (0: a region that holds one domain, 1: a cluster of an
     ensemble region), in the reference's order; counts = (regions, envelopes, ensemble regions, clusters, overlapping
     clusters) -- the reference's (nregions, nclustered, noverlaps, nenvelopes) are counts[0], [2], [4], [1].
-    ensembles=False: regions that need the traceback ensemble are counted and left out."""
+    ensembles=False: regions that need the traceback ensemble are counted and left out.  want_sequence: also the
+    sequence's scores as p7_pipeline.c derives them (bit score, pre-score, sum-of-domains score, ln P, domains, their length)."""
     l = lib()
     l.p7o_domains.restype = C.c_int64
     l.p7o_domains.argtypes = [C.POINTER(Profile), C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_uint32, C.c_int,
-                              C.c_void_p, C.c_int64, C.c_void_p]
+                              C.c_void_p, C.c_int64, C.c_void_p, C.c_float, C.c_void_p]
     st, bsc, fx, bx = op.bck(seq)                          # configures the profile for len(seq)
+    fst, fwdsc = op.fwd(seq)
     d = op._dsq(seq)
     degen = degeneracy_sets(op.ptr.contents.K)
     cap = 256
     out = np.zeros((cap, 13), dtype=np.float64)
     counts = np.zeros(5, dtype=np.int64)
+    seqout = np.zeros(6, dtype=np.float64)
     n = l.p7o_domains(op.ptr, d.ctypes.data, len(seq), fx.ctypes.data, bx.ctypes.data, degen.ctypes.data, int(do_null2), int(seed),
-                      int(bool(ensembles)), out.ctypes.data, cap, counts.ctypes.data)
+                      int(bool(ensembles)), out.ctypes.data, cap, counts.ctypes.data, float(fwdsc), seqout.ctypes.data)
     assert 0 <= n <= cap, n
+    if want_sequence:
+        return out[:n].copy(), tuple(int(c) for c in counts), dict(zip(("score", "pre_score", "sum_score", "lnP", "ndom", "domain_residues"), seqout.tolist()))
     return out[:n].copy(), tuple(int(c) for c in counts)
 
 

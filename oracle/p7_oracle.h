@@ -134,9 +134,10 @@ void  p7o_lt_envelope_background(const P7O_PROFILE *p, const uint8_t *env, int64
  * a region that holds several through the ensemble of 200 sampled tracebacks, their clustering and the null2 scores by
  * trace (seed != 0 and ensembles != 0; else such regions are only counted).  out: 13 doubles per envelope (ienv jenv iali
  * jali hmmfrom hmmto envsc domcorrection oasc bitscore dombias lnP kind); counts: regions, envelopes, ensemble regions,
- * clusters, overlapping clusters.  degen: [Kp][K] residue-code sets. */
+ * clusters, overlapping clusters.  seqout (or NULL), given the parser's Forward score: the sequence's bit score, pre-score,
+ * sum-of-domains score, ln P, number of domains, their length (p7_pipeline.c).  degen: [Kp][K] residue-code sets. */
 int64_t p7o_domains(P7O_PROFILE *p, const uint8_t *dsq, int L, const float *fx, const float *bx, const uint8_t *degen,
-                    int do_null2, uint32_t seed, int ensembles, double *out, int64_t cap, int64_t *counts);
+                    int do_null2, uint32_t seed, int ensembles, double *out, int64_t cap, int64_t *counts, float fwdsc, double *seqout);
 
 #ifdef __cplusplus
 }

@@ -673,9 +673,10 @@ static int dd_cluster(const DDCoord *seg, int n, int nsamples, DDCoord *out, int
 }
 
 /* rescore_isolated_domain: the envelope i..j of the target; n2sc != NULL: the null2 log ratios of the target's residues are
- * already there (an ensemble region), else they come from the envelope's own posterior expectation.  Appends one row. */
+ * already there (null2_is_done: an ensemble region), else they come from the envelope's own posterior expectation and are
+ * left there.  Appends one row. */
 static int dd_rescore(const P7O_PROFILE *p, const DDModel *uni, const uint8_t *dsq, int L, int i, int j, const uint8_t *degen, int do_null2,
-                      const float *n2sc, double *out, int64_t *nout, int64_t cap, double kind)
+                      float *n2sc, int null2_is_done, double *out, int64_t *nout, int64_t cap, double kind)
 {
   const int Ld = j - i + 1;
   DDMatrix f, b;
@@ -690,11 +691,11 @@ static int dd_rescore(const P7O_PROFILE *p, const DDModel *uni, const uint8_t *d
     float null2[P7O_MAXKP];
     float domcorrection = 0.0f;
     if (do_null2) {
-      if (n2sc) { for (int pos = i; pos <= j; pos++) domcorrection += n2sc[pos]; }
-      else {
+      if (!null2_is_done) {
         dd_null2_by_expectation(uni, Ld, &b, degen, null2);
-        for (int pos = i; pos <= j; pos++) domcorrection += logf(null2[dsq[pos]]);
+        for (int pos = i; pos <= j; pos++) n2sc[pos] = logf(null2[dsq[pos]]);
       }
+      for (int pos = i; pos <= j; pos++) domcorrection += n2sc[pos];
     }
     const float oasc = dd_optimal_accuracy(uni, Ld, &b, &f);     /* f holds the optimal-accuracy matrix now */
     int ia, ja, ka, kb;
@@ -727,9 +728,11 @@ static int dd_rescore(const P7O_PROFILE *p, const DDModel *uni, const uint8_t *d
  *   ienv jenv iali jali hmmfrom hmmto  envsc domcorrection oasc (nats / residues)  bitscore(bits) dombias(bits) lnP
  *   kind (0: a region that holds one domain, 1: a cluster of an ensemble region)
  * counts[0..4] = regions, envelopes, ensemble regions, clusters, overlapping clusters.
+ * seqout (may be NULL), given the parser's Forward score fwdsc (nats): the sequence's bit score, its score before the null2
+ * correction, the sum-of-domains score, ln P, the number of domains, their total length.
  * Returns the number of envelopes (may exceed cap: only cap are written), or -1. */
 int64_t p7o_domains(P7O_PROFILE *p, const uint8_t *dsq, int L, const float *fx, const float *bx, const uint8_t *degen,
-                    int do_null2, uint32_t seed, int ensembles, double *out, int64_t cap, int64_t *counts)
+                    int do_null2, uint32_t seed, int ensembles, double *out, int64_t cap, int64_t *counts, float fwdsc, double *seqout)
 {
   const float rt1 = 0.25f, rt2 = 0.10f, rt3 = 0.20f;
   const int nsamples = 200;
@@ -782,7 +785,7 @@ int64_t p7o_domains(P7O_PROFILE *p, const uint8_t *dsq, int L, const float *fx, 
             for (int d = 0; d < nc && !failed; d++) {
               counts[3]++;
               if (cl[d].i <= last_j2) counts[4]++;
-              const int st = dd_rescore(p, &uni, dsq, L, cl[d].i, cl[d].j, degen, do_null2, n2sc, out, &nout, cap, 1.0);
+              const int st = dd_rescore(p, &uni, dsq, L, cl[d].i, cl[d].j, degen, do_null2, n2sc, 1, out, &nout, cap, 1.0);
               if (st < 0) failed = 1; else if (st > 0) { last_j2 = cl[d].j; counts[1]++; }
             }
           }
@@ -790,11 +793,38 @@ int64_t p7o_domains(P7O_PROFILE *p, const uint8_t *dsq, int L, const float *fx, 
           free(segs); free(all); free(cl); free(n2acc); free(cm); free(ci);
         }
       } else {
-        const int st = dd_rescore(p, &uni, dsq, L, i, j, degen, do_null2, NULL, out, &nout, cap, 0.0);
+        const int st = dd_rescore(p, &uni, dsq, L, i, j, degen, do_null2, n2sc, 0, out, &nout, cap, 0.0);
         if (st < 0) failed = 1; else counts[1]++;
       }
       i = -1; triggered = 0;
     }
+  }
+  if (seqout && !failed) {
+    /* p7_pipeline.c, after domain definition: the sequence's score with the null2 correction of all its residues, or, if
+     * that is higher, the sum of its domains that are worth more than their correction */
+    const float nullsc = p7o_null1(L), omega = 1.0f / 256.0f;
+    float seqbias = 0.0f;
+    if (do_null2) {
+      float sum = 0.0f, c = 0.0f;                                  /* esl_vec_FSum */
+      for (int pos = 0; pos <= L; pos++) { const float y = n2sc[pos] - c, t = sum + y; c = (t - sum) - y; sum = t; }
+      seqbias = dd_flogsum(0.0f, logf(omega) + sum);
+    }
+    float pre_score = (fwdsc - nullsc) / 0.69314718055994529f;
+    float seq_score = (fwdsc - (nullsc + seqbias)) / 0.69314718055994529f;
+    float sum_score = 0.0f; int Ld = 0; seqbias = 0.0f;
+    const int64_t nd = nout < cap ? nout : cap;
+    for (int64_t d = 0; d < nd; d++) {
+      const double *o = out + d * 13;
+      if (!do_null2 || o[6] - o[7] > 0.0) { sum_score += (float) o[6]; Ld += (int) (o[1] - o[0] + 1); seqbias += (float) o[7]; }
+    }
+    seqbias = do_null2 ? dd_flogsum(0.0f, logf(omega) + seqbias) : 0.0f;
+    sum_score += (float) (L - Ld) * logf((float) L / (float) (L + 3));
+    const float pre2_score = (sum_score - nullsc) / 0.69314718055994529f;
+    sum_score = (sum_score - (nullsc + seqbias)) / 0.69314718055994529f;
+    if (Ld > 0 && sum_score > seq_score) { seq_score = sum_score; pre_score = pre2_score; }
+    seqout[0] = seq_score; seqout[1] = pre_score; seqout[2] = sum_score;
+    seqout[3] = p7o_exp_logsurv((double) seq_score, (double) p->evparam[p7_FTAU], (double) p->evparam[p7_FLAMBDA]);
+    seqout[4] = (double) nout; seqout[5] = (double) Ld;
   }
   ddmodel_free(&uni); ddmodel_free(&multi);
   free(btot); free(etot); free(mocc); free(n2sc);

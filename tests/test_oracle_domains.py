@@ -140,3 +140,24 @@ def test_host_stage_agrees_with_the_oracle_on_ensemble_regions(oracle, model):
             for e, d in zip(envs, h.domains):
                 assert abs(d.score - e[9]) <= 2e-3 and abs(d.bias - e[10]) <= 2e-3, (h.name, d.score, e[9], d.bias, e[10])
     assert with_ensembles >= 10 and same >= 0.9 * with_ensembles, (same, with_ensembles)
+
+
+def test_oracle_sequence_scores_reproduce_the_reference_target_tables(oracle, proteome):
+    """PF02826.tbl and RREFam.tbl: the full-sequence score, bias and E-value of every reported target from the oracle's own
+    domain definition (null2 correction over all residues, or the sum of the domains when that is higher: p7_pipeline.c)."""
+    by_name = {s.name: s for s in proteome}
+    checked = 0
+    for hmm in load_hmms("PF02826") + load_hmms("RREFam"):
+        rows = golden_table("PF02826.tbl" if hmm.name == "2-Hacid_dh_C" else "RREFam.tbl", hmm.name)
+        if not rows:
+            continue
+        op = oracle.OracleProfile(hmm, plan7.Background(hmm.alphabet), 400)
+        for r in rows:
+            envs, counts, sq = oracle.domains(op, np.asarray(by_name[r[0]].sequence, dtype=np.uint8), want_sequence=True)
+            assert abs(sq["score"] - float(r[5])) <= 0.051, (hmm.name, r[0], r[5], sq)
+            assert abs((sq["pre_score"] - sq["score"]) - float(r[6])) <= 0.051, (hmm.name, r[0], r[6], sq)
+            evalue = float(np.exp(sq["lnP"])) * len(proteome)
+            assert abs(evalue - float(r[4])) <= 0.06 * float(r[4]), (hmm.name, r[0], r[4], evalue)
+            assert int(sq["ndom"]) >= int(r[17])                      # the table's "dom" column counts the domains it reports
+            checked += 1
+    assert checked >= 30
