@@ -161,3 +161,33 @@ def test_oracle_sequence_scores_reproduce_the_reference_target_tables(oracle, pr
             assert int(sq["ndom"]) >= int(r[17])                      # the table's "dom" column counts the domains it reports
             checked += 1
     assert checked >= 30
+
+
+def test_degenerate_residues_inside_envelopes(oracle):
+    """Targets whose homologous fragments carry X, B and Z residues (the null2 odds of a degenerate code are the plain mean
+    over its residues, esl_abc_FAvgScVec; its emission odds come from the profile's own rows): host stage == oracle."""
+    hmm = load_hmms("PF02826")[0]
+    block = _homolog_block(hmm, 20, 120, seed=31)
+    rng = np.random.default_rng(5)
+    seqs = []
+    for s in block:
+        a = np.asarray(s.sequence, dtype=np.uint8).copy()
+        hit = rng.random(len(a)) < 0.03
+        a[hit] = rng.choice([26, 21, 23], size=int(hit.sum()))            # X, B, Z
+        seqs.append(easel.DigitalSequence(hmm.alphabet, name=s.name, sequence=a))
+    block = easel.DigitalSequenceBlock(hmm.alphabet, seqs)
+    pli = plan7.Pipeline(hmm.alphabet, E=1e9, domE=1e9, incE=1e9, incdomE=1e9)
+    hits = host_pipeline.host_search(oracle, hmm, block, pipeline=pli)
+    op = oracle.OracleProfile(hmm, pli.background, 400)
+    by_name = {s.name: s for s in block}
+    compared = 0
+    for h in hits:
+        envs, counts = oracle.domains(op, np.asarray(by_name[h.name].sequence, dtype=np.uint8))
+        if counts[2]:
+            continue                                                     # ensemble regions: see the test above
+        ours = [(d.env_from, d.env_to, d.alignment.target_from, d.alignment.target_to, d.alignment.hmm_from, d.alignment.hmm_to) for d in h.domains]
+        assert ours == [tuple(int(v) for v in e[:6]) for e in envs], h.name
+        for e, d in zip(envs, h.domains):
+            assert abs(d.score - e[9]) <= 2e-3 and abs(d.bias - e[10]) <= 2e-3, (h.name, d.score, e[9], d.bias, e[10])
+            compared += 1
+    assert compared >= 80
