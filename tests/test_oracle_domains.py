@@ -79,13 +79,16 @@ def _homolog_block(hmm, nbg, nhom, seed):
     return easel.DigitalSequenceBlock(abc, seqs)
 
 
-@pytest.mark.parametrize("model", ["PF02826", "KR", "Thioesterase", "LuxC", 30, 150, 400])
+@pytest.mark.parametrize("model", ["PF02826", "KR", "Thioesterase", "LuxC", 30, 150, 400, "dna 120", "RF00001"])
 def test_host_stage_agrees_with_the_oracle_on_single_domain_regions(oracle, model):
     """The product's host stage and the oracle get the same parser rows (the oracle's) for 100 background + 200 homolog
     targets; for every region the oracle resolves: the product defines a domain with the same envelope, the same alignment
     and model coordinates, and score and bias within 2e-3 bit (the table of p7_FLogsum has steps of 1e-3 nat, so two
     summation orders can land on neighbouring entries).  Observed: no differing coordinate in 1,900 envelopes."""
-    hmm = load_hmms(model)[0] if isinstance(model, str) else random_hmm(model, seed=500 + model)
+    if model == "dna 120":
+        hmm = random_hmm(120, seed=620, alphabet=easel.Alphabet.dna(), conserved=0.3)
+    else:
+        hmm = load_hmms(model)[0] if isinstance(model, str) else random_hmm(model, seed=500 + model)
     block = _homolog_block(hmm, 100, 200, seed=11)
     pli = plan7.Pipeline(hmm.alphabet, E=1e9, domE=1e9, incE=1e9, incdomE=1e9)
     hits = host_pipeline.host_search(oracle, hmm, block, pipeline=pli)
