@@ -109,6 +109,7 @@ def test_host_stage_agrees_with_the_oracle_on_single_domain_regions(oracle, mode
             else:
                 assert abs(d.score - e[9]) <= 2e-3 and abs(d.bias - e[10]) <= 2e-3, (h.name, d.score, e[9], d.bias, e[10])
                 assert abs(d.envelope_score * np.log(2.0) - e[6]) <= 2e-3 * max(1.0, abs(e[6]) / 100.0)
+                assert abs(d.accuracy - e[8] / (1.0 + e[1] - e[0])) <= 1e-4                    # the optimal-accuracy score per envelope residue
     assert envelopes >= 150
     assert differing <= envelopes // 200, (differing, envelopes)            # near-ties of two summation orders: at most 0.5 %
 
