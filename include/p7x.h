@@ -368,6 +368,10 @@ typedef struct p7x_scan_accum p7x_scan_accum;
 int  p7x_scan_accum_create(const p7x_pipeline_cfg *cfg, size_t nseqs, const char *const *seq_names, const char *const *seq_accs,
                            const char *const *seq_descs, const int32_t *seq_lengths, p7x_scan_accum **out);
 int  p7x_scan_accum_add(p7x_scan_accum *acc, p7x_tophits *const *per_model, size_t nmodels);
+/* the same for results that come back in any order (batches of a length-sorted profile database): model_index[i] is the
+ * number of per_model[i]'s profile in the database (0-based, each exactly once over the scan); callable from several threads.
+ * The running Z of a model is its number + 1 either way, and p7x_scan_accum_finish restores the database's order. */
+int  p7x_scan_accum_add_indexed(p7x_scan_accum *acc, p7x_tophits *const *per_model, const int64_t *model_index, size_t nmodels);
 int  p7x_scan_accum_finish(p7x_scan_accum *acc, p7x_tophits **out);
 void p7x_scan_accum_destroy(p7x_scan_accum *acc);
 

@@ -667,6 +667,8 @@ int p7x_tophits_get_domain(const p7x_tophits *th, int64_t i, int32_t d, p7x_doma
 struct p7x_scan_accum {
   std::vector<std::unique_ptr<p7x_tophits>> res;
   size_t nmodels = 0;
+  bool in_order = true;            // every model so far was added with the next number: the hit lists are in model order
+  std::mutex mu;                   // p7x_scan_accum_add_indexed may be called from several threads
 };
 
 int p7x_scan_accum_create(const p7x_pipeline_cfg *cfg_in, size_t nseqs, const char *const *seq_names, const char *const *seq_accs,
@@ -690,15 +692,22 @@ int p7x_scan_accum_create(const p7x_pipeline_cfg *cfg_in, size_t nseqs, const ch
   return P7X_OK;
 }
 
-int p7x_scan_accum_add(p7x_scan_accum *acc, p7x_tophits *const *per_model, size_t nmodels)
+// model_index: the models' numbers in the scan (0-based: the order of the profile database), each exactly once over the
+// calls of a scan, in any order and from any thread; NULL: the next nmodels numbers
+static int scan_accum_add(p7x_scan_accum *acc, p7x_tophits *const *per_model, const int64_t *model_index, size_t nmodels, const char *who)
 {
-  if (!acc || (nmodels && !per_model)) { set_error("p7x_scan_accum_add: bad arguments"); return P7X_EINVAL; }
+  if (!acc || (nmodels && !per_model)) { set_error(std::string(who) + ": bad arguments"); return P7X_EINVAL; }
+  std::lock_guard<std::mutex> lk(acc->mu);
   const size_t nseqs = acc->res.size();
   for (size_t mm = 0; mm < nmodels; ++mm) {
+    if (!per_model[mm]) { set_error(std::string(who) + ": missing per-model result"); return P7X_EINVAL; }
+    if (per_model[mm]->ctr.nseqs != nseqs) { set_error(std::string(who) + ": per-model results cover different sequence sets"); return P7X_EINVAL; }
+    if (model_index && model_index[mm] < 0) { set_error(std::string(who) + ": negative model number"); return P7X_EINVAL; }
+  }
+  for (size_t mm = 0; mm < nmodels; ++mm) {
     const p7x_tophits *pm = per_model[mm];
-    const size_t m = acc->nmodels + mm;                      // the model's number in the scan
-    if (!pm) { set_error("p7x_scan_accum_add: missing per-model result"); return P7X_EINVAL; }
-    if (pm->ctr.nseqs != nseqs) { set_error("p7x_scan_accum_add: per-model results cover different sequence sets"); return P7X_EINVAL; }
+    const size_t m = model_index ? (size_t) model_index[mm] : acc->nmodels + mm;       // the model's number in the scan
+    if (m != acc->nmodels + mm) acc->in_order = false;
     for (size_t s = 0; s < nseqs; ++s) {
       p7x_counters &c = acc->res[s]->ctr;
       c.nmodels += 1; c.nnodes += (uint64_t) pm->M;
@@ -710,7 +719,7 @@ int p7x_scan_accum_add(p7x_scan_accum *acc, p7x_tophits *const *per_model, size_
       p7x_tophits &th = *acc->res[(size_t) h.seqidx];
       p7x_pipeline_cfg rc = th.cfg;
       apply_bit_cutoffs_from(rc, pm->cfg);               // model-specific GA/TC/NC thresholds travel with the per-model result
-      const double Zrun = (rc.Z_setby == P7X_ZSETBY_NTARGETS) ? (double) (m + 1) : rc.Z;
+      const double Zrun = (rc.Z_setby == P7X_ZSETBY_NTARGETS) ? (double) (m + 1) : rc.Z;      // p7_pli_NewModel's running count
       if (!target_reportable(rc, Zrun, h.score, h.lnP)) continue;
       Hit copy = h;
       copy.name = pm->qname; copy.acc = pm->qacc; copy.desc = pm->qdesc; copy.has_acc = pm->q_has_acc; copy.has_desc = pm->q_has_desc;
@@ -722,6 +731,17 @@ int p7x_scan_accum_add(p7x_scan_accum *acc, p7x_tophits *const *per_model, size_
   return P7X_OK;
 }
 
+int p7x_scan_accum_add(p7x_scan_accum *acc, p7x_tophits *const *per_model, size_t nmodels)
+{
+  return scan_accum_add(acc, per_model, nullptr, nmodels, "p7x_scan_accum_add");
+}
+
+int p7x_scan_accum_add_indexed(p7x_scan_accum *acc, p7x_tophits *const *per_model, const int64_t *model_index, size_t nmodels)
+{
+  if (nmodels && !model_index) { set_error("p7x_scan_accum_add_indexed: no model numbers"); return P7X_EINVAL; }
+  return scan_accum_add(acc, per_model, model_index, nmodels, "p7x_scan_accum_add_indexed");
+}
+
 int p7x_scan_accum_finish(p7x_scan_accum *acc, p7x_tophits **out)
 { // consumes the accumulator
   if (!acc || !out) { set_error("p7x_scan_accum_finish: bad arguments"); delete acc; return P7X_EINVAL; }
@@ -729,6 +749,9 @@ int p7x_scan_accum_finish(p7x_scan_accum *acc, p7x_tophits **out)
   for (size_t s = 0; s < acc->res.size(); ++s) {
     p7x_tophits &th = *acc->res[s];
     if (th.cfg.Z_setby == P7X_ZSETBY_NTARGETS) th.cfg.Z = (double) acc->nmodels;
+    // results that arrived out of order: back into the order of the models first, which is the order the reference's loop
+    // over the profile database appends them in (ties of the key sort keep it)
+    if (!acc->in_order) std::stable_sort(th.hits.begin(), th.hits.end(), [](const Hit &a, const Hit &b) { return a.seqidx < b.seqidx; });
     sort_by_key(th);
     threshold(th);
   }

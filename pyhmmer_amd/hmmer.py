@@ -340,8 +340,10 @@ def _query_length(q) -> int:
 
 
 def _run_queries(db: "ShardedDatabase", pipelines: Sequence[Pipeline], queries: Iterable, pipeline_depth: int,
-                 feeders: int, window: int = 1, finishers: int = 0, batch: int = 1, reorder: int = 32) -> Iterator:
-    """Yield ``(query, TopHits)`` for every query, in input order.  Queries travel in batches of ``batch`` (one set of
+                 feeders: int, window: int = 1, finishers: int = 0, batch: int = 1, reorder: int = 32, by_batch: bool = False) -> Iterator:
+    """Yield ``(query, TopHits)`` for every query, in input order -- or, with ``by_batch``, ``(input indices, queries, [TopHits])``
+    for every batch as soon as it is finished (the scan orientation folds a batch's results into per-sequence lists while
+    the next batches are still on the device; their order is restored from the indices).  Queries travel in batches of ``batch`` (one set of
     device launches each); the two stages of consecutive batches overlap.  ``window`` > 1: every feeder queues the
     device stage of that many batches before it waits for the oldest.
 
@@ -410,12 +412,19 @@ def _run_queries(db: "ShardedDatabase", pipelines: Sequence[Pipeline], queries: 
         if err is not None:
             failure = (members, err)
             break
+        if by_batch:
+            for i in members:
+                inputs.pop(i, None)
+            yield members, qs, hits
+            continue
         for i, h in zip(members, hits):
             done[i] = h
         while nxt in done:
             yield inputs.pop(nxt), done.pop(nxt)
             nxt += 1
     runner.close()                        # feeders stop, queued device work is released
+    if failure is not None and by_batch:
+        raise failure[1]                  # the results so far were handed out batch by batch; nothing to finish in order
     if failure is not None:
         # A member of a batch failed (missing cutoffs, a device error ...).  The reference would have yielded the results
         # of every query before it first (_base.py:305-318): finish the input order one query at a time up to the failing
@@ -714,24 +723,20 @@ def hmmscan(queries, profiles, *, cpus: int = 0, callback: Optional[Callable] = 
             from .errors import status_to_exception
             raise status_to_exception(st, "p7x_scan_accum_create", _lib.last_error())
         try:
-            # per-model results are folded into the per-sequence lists as they come back, a few hundred at a time, and
-            # released: the scan holds a batch of them, not the library's worth
-            held: list = []
-
-            def fold():
-                if held:
-                    handles = (C.c_void_p * len(held))(*[h._handle for h in held])
-                    st2 = _lib.lib().p7x_scan_accum_add(acc, handles, len(held))
-                    if st2 != 0:
-                        from .errors import status_to_exception
-                        raise status_to_exception(st2, "p7x_scan_accum_add", _lib.last_error())
-                    held.clear()
-
-            for _, hits in _run_queries(db, pipelines, profiles, pipeline_depth, feeders, window, finishers, batch=batch):
-                held.append(hits)
-                if len(held) >= 256:
-                    fold()
-            fold()
+            # per-model results are folded into the per-sequence lists batch by batch, as the batches are finished, and
+            # released: the scan holds a batch of them, not the library's worth, and only the last batch's fold is left
+            # when the device is done.  Batches hold the profiles in order of length, not of the database: every result
+            # goes in with its profile's number (the running Z of the reference's loop, plan7.pyx:6680-6737), and the
+            # accumulator restores the database's order at the end.
+            for members, _, per_model in _run_queries(db, pipelines, profiles, pipeline_depth, feeders, window, finishers, batch=batch,
+                                                      by_batch=True):
+                handles = (C.c_void_p * len(per_model))(*[h._handle for h in per_model])
+                numbers = (C.c_int64 * len(members))(*members)
+                st2 = _lib.lib().p7x_scan_accum_add_indexed(acc, handles, numbers, len(per_model))
+                if st2 != 0:
+                    from .errors import status_to_exception
+                    raise status_to_exception(st2, "p7x_scan_accum_add_indexed", _lib.last_error())
+                del per_model, handles
             out = (C.c_void_p * n)()
             st = _lib.lib().p7x_scan_accum_finish(acc, out)          # consumes the accumulator
             acc = C.c_void_p()
