@@ -2,14 +2,12 @@
 (p7x_scan_accum_add_indexed) equal the in-order fold (p7x_scan_collect), and hmmer.hmmscan end to end over a stand-in for the
 device whose two stages are the oracle's filters and the product's host stage -- against RREFam.scan.tbl."""
 import ctypes as C
-import io
 
 import numpy as np
-import pytest
 
 import host_pipeline
 from conftest import golden_table, load_hmms
-from pyhmmer_amd import _lib, easel, hmmer, plan7
+from pyhmmer_amd import _lib, hmmer, plan7
 
 
 def _scan_pipeline(abc, **kw):

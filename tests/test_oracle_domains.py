@@ -7,7 +7,7 @@ import numpy as np
 import pytest
 
 import host_pipeline
-from conftest import GOLDEN, golden_table, load_hmms, random_hmm
+from conftest import golden_table, load_hmms, random_hmm
 from pyhmmer_amd import easel, plan7
 
 
