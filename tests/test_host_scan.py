@@ -79,6 +79,10 @@ def test_results_folded_in_any_order_equal_the_fold_in_database_order(libp7x, or
     handles = (C.c_void_p * 1)(per_model[0]._handle)
     assert libp7x.p7x_scan_accum_add_indexed(acc, handles, None, 1) == 11
     assert libp7x.p7x_scan_accum_add_indexed(acc, handles, (C.c_int64 * 1)(-1), 1) == 11
+    assert libp7x.p7x_scan_accum_add_indexed(acc, handles, (C.c_int64 * 1)(5), 1) == 0
+    assert libp7x.p7x_scan_accum_add_indexed(acc, handles, (C.c_int64 * 1)(5), 1) == 11          # a model number twice
+    two = (C.c_void_p * 2)(per_model[0]._handle, per_model[1]._handle)
+    assert libp7x.p7x_scan_accum_add_indexed(acc, two, (C.c_int64 * 2)(9, 9), 2) == 11
     libp7x.p7x_scan_accum_destroy(acc)
 
 
