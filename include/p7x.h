@@ -372,6 +372,10 @@ int  p7x_scan_accum_add(p7x_scan_accum *acc, p7x_tophits *const *per_model, size
  * number of per_model[i]'s profile in the database (0-based, each exactly once over the scan); callable from several threads.
  * The running Z of a model is its number + 1 either way, and p7x_scan_accum_finish restores the database's order. */
 int  p7x_scan_accum_add_indexed(p7x_scan_accum *acc, p7x_tophits *const *per_model, const int64_t *model_index, size_t nmodels);
+/* Test seam: the last filter every target passed (0 none, 1 MSV, 2 bias, 3 Viterbi, 4 Forward), as the device path records it
+ * in a scan's per-model results and p7x_scan_accum_* turn into per-sequence accounting; lets the CPU tests attach the
+ * oracle's stages to results of p7x_postprocess_targets. */
+int  p7x_debug_tophits_set_stages(p7x_tophits *th, const uint8_t *stage, size_t n);
 int  p7x_scan_accum_finish(p7x_scan_accum *acc, p7x_tophits **out);
 void p7x_scan_accum_destroy(p7x_scan_accum *acc);
 

@@ -222,6 +222,7 @@ _SIGNATURES = {
     "p7x_scan_accum_create": (C.c_int, [C.POINTER(PipelineCfg), C.c_size_t, _VP, _VP, _VP, _VP, C.POINTER(_VP)]),
     "p7x_scan_accum_add": (C.c_int, [_VP, C.POINTER(_VP), C.c_size_t]),
     "p7x_scan_accum_add_indexed": (C.c_int, [_VP, C.POINTER(_VP), C.POINTER(C.c_int64), C.c_size_t]),
+    "p7x_debug_tophits_set_stages": (C.c_int, [_VP, _VP, C.c_size_t]),
     "p7x_scan_accum_finish": (C.c_int, [_VP, C.POINTER(_VP)]),
     "p7x_scan_accum_destroy": (None, [_VP]),
     "p7x_fasta_parse": (C.c_int, [_VP, C.c_size_t, _VP, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t), C.POINTER(C.c_size_t),

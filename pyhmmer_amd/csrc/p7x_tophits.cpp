@@ -785,6 +785,13 @@ int p7x_scan_accum_finish(p7x_scan_accum *acc, p7x_tophits **out)
 
 void p7x_scan_accum_destroy(p7x_scan_accum *acc) { delete acc; }
 
+int p7x_debug_tophits_set_stages(p7x_tophits *th, const uint8_t *stage, size_t n)
+{
+  if (!th || (n && !stage)) { set_error("p7x_debug_tophits_set_stages: bad arguments"); return P7X_EINVAL; }
+  th->stage.assign(stage, stage + n);
+  return P7X_OK;
+}
+
 int p7x_scan_collect(p7x_tophits *const *per_model, size_t nmodels, const p7x_pipeline_cfg *cfg_in, size_t nseqs,
                      const char *const *seq_names, const char *const *seq_accs, const char *const *seq_descs,
                      const int32_t *seq_lengths, p7x_tophits **out)

@@ -48,6 +48,11 @@ def host_search(oracle, hmm, block, pipeline=None, F=(0.02, 1e-3, 1e-5), perturb
         raise RuntimeError(f"p7x_postprocess_targets failed: {st} {_lib.last_error()}")
     hits = plan7.TopHits(hmm, out)
     hits._keep = (om, names, accs, descs)
+    if getattr(pipeline, "_mode", 0) == plan7._P7X_SCAN_MODELS:
+        # a scan's per-model results carry the last filter every target passed (the device path records it); here it is
+        # the oracle's, attached through the test seam
+        stages = np.array([recs[t].stage for t in range(n)], dtype=np.uint8)
+        assert _lib.lib().p7x_debug_tophits_set_stages(out, stages.ctypes.data, n) == 0
     return hits
 
 

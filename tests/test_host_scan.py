@@ -62,7 +62,12 @@ def test_results_folded_in_any_order_equal_the_fold_in_database_order(libp7x, or
     for E in (200.0, 2e-5):            # the second: weak hits pass at the running Z of an early model and not at the final Z
         per_model = _per_model(oracle, hmms, block, E=E)
         pli = _scan_pipeline(hmms[0].alphabet, E=E)
-        want = _rows(_accumulate(block, pli, per_model))
+        in_order = _accumulate(block, pli, per_model)
+        want = _rows(in_order)
+        # per-sequence accounting: how many models' filters every sequence passed, and the models' nodes
+        passed = [sum(tuple(pm.stage_counts.values())[f] for pm in per_model) for f in range(4)]
+        assert [sum(tuple(th.stage_counts.values())[f] for th in in_order) for f in range(4)] == passed and passed[0] > 100
+        assert all(th.searched_models == len(hmms) and th.searched_nodes == sum(h.M for h in hmms) for th in in_order)
         total += sum(len(r) - 3 for r in want)
         if E < 1.0:
             assert any(not h[3] for r in want for h in r[:-3])
