@@ -268,3 +268,20 @@ def domains_single(op, seq, do_null2=True):
     """The regions that hold one domain only: (envelopes, (regions, single-domain envelopes, ensemble regions))."""
     envs, counts = domains(op, seq, do_null2=do_null2, ensembles=False)
     return envs, (counts[0], counts[1], counts[2])
+
+
+def domain_alignment(op, seq, ienv, jenv):
+    """p7_alidisplay_Create of the envelope's optimal-accuracy alignment: (model, match, sequence, posterior) lines."""
+    l = lib()
+    l.p7o_domain_alignment.restype = C.c_int
+    l.p7o_domain_alignment.argtypes = [C.POINTER(Profile), C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_char_p, C.c_char_p,
+                                       C.c_char_p, C.c_char_p, C.c_char_p, C.c_char_p, C.c_int]
+    l.p7o_reconfig_length(op.ptr, len(seq))
+    d = op._dsq(seq)
+    hmm = op.hmm
+    cap = 2 * (len(seq) + hmm.M) + 16
+    bufs = [C.create_string_buffer(cap) for _ in range(4)]
+    n = l.p7o_domain_alignment(op.ptr, d.ctypes.data, len(seq), int(ienv), int(jenv), (" " + hmm.consensus).encode(),
+                               hmm.alphabet.symbols.encode(), bufs[0], bufs[1], bufs[2], bufs[3], cap)
+    assert 0 <= n < cap, n
+    return tuple(b.value.decode() for b in bufs)

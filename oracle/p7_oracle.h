@@ -139,6 +139,11 @@ void  p7o_lt_envelope_background(const P7O_PROFILE *p, const uint8_t *env, int64
 int64_t p7o_domains(P7O_PROFILE *p, const uint8_t *dsq, int L, const float *fx, const float *bx, const uint8_t *degen,
                     int do_null2, uint32_t seed, int ensembles, double *out, int64_t cap, int64_t *counts, float fwdsc, double *seqout);
 
+/* the alignment display of an envelope's optimal-accuracy alignment (p7_alidisplay_Create): model / match / sequence /
+ * posterior lines, one column per state between B and E.  consensus[1..M], sym = the alphabet's symbols. */
+int p7o_domain_alignment(P7O_PROFILE *p, const uint8_t *dsq, int L, int ienv, int jenv, const char *consensus, const char *sym,
+                         char *model, char *mline, char *aseq, char *ppline, int cap);
+
 #ifdef __cplusplus
 }
 #endif

@@ -315,8 +315,21 @@ static float dd_optimal_accuracy(const DDModel *m, int L, const DDMatrix *pp, DD
  * Only the unihit configuration is traced here (one domain).  Returns 0 and the first / last match state's residue and
  * node, or 1 when the trace holds no match state. */
 enum { ST_M = 1, ST_I, ST_D, ST_B, ST_N, ST_C, ST_E, ST_S };
+typedef struct { int n, cap; int *st, *k, *i; float *pp; } DDPath;     /* the states between B and E, last first */
+static void dd_path_push(DDPath *p, int st, int k, int i, float pp)
+{
+  if (p && p->n < p->cap) { p->st[p->n] = st; p->k[p->n] = k; p->i[p->n] = i; p->pp[p->n] = pp; p->n++; }
+  else if (p) p->n++;
+}
+static int dd_oa_trace_path(const DDModel *m, int L, const DDMatrix *pp, const DDMatrix *ox, int Q,
+                            int *ia, int *ja, int *ka, int *kb, DDPath *path);
 static int dd_oa_trace(const DDModel *m, int L, const DDMatrix *pp, const DDMatrix *ox, int Q,
                        int *ia, int *ja, int *ka, int *kb)
+{
+  return dd_oa_trace_path(m, L, pp, ox, Q, ia, ja, ka, kb, NULL);
+}
+static int dd_oa_trace_path(const DDModel *m, int L, const DDMatrix *pp, const DDMatrix *ox, int Q,
+                            int *ia, int *ja, int *ka, int *kb, DDPath *path)
 {
   const int M = m->M;
   int i = L, k = 0, st = ST_C;
@@ -345,6 +358,7 @@ static int dd_oa_trace(const DDModel *m, int L, const DDMatrix *pp, const DDMatr
     case ST_M: {
       if (*ja == 0) { *ja = i; *kb = k; }
       *ia = i; *ka = k;
+      dd_path_push(path, ST_M, k, i, MX(pp, i, k));
       float path[4];
       path[0] = (k > 1 && m->mm[k] != 0.0f) ? MX(ox, i - 1, k - 1) : -INFINITY;
       path[1] = (k > 1 && m->im[k] != 0.0f) ? IX(ox, i - 1, k - 1) : -INFINITY;
@@ -359,6 +373,7 @@ static int dd_oa_trace(const DDModel *m, int L, const DDMatrix *pp, const DDMatr
       break;
     }
     case ST_D: {
+      dd_path_push(path, ST_D, k, 0, 0.0f);
       const float p0 = (k > 1 && m->md[k - 1] != 0.0f) ? MX(ox, i, k - 1) : -INFINITY;
       const float p1 = (k > 1 && m->dd[k - 1] != 0.0f) ? DX(ox, i, k - 1) : -INFINITY;
       if (k <= 1) return 1;
@@ -366,6 +381,7 @@ static int dd_oa_trace(const DDModel *m, int L, const DDMatrix *pp, const DDMatr
       break;
     }
     case ST_I: {
+      dd_path_push(path, ST_I, k, i, IX(pp, i, k));
       const float p0 = (m->mi[k] != 0.0f) ? MX(ox, i - 1, k) : -INFINITY;
       const float p1 = (m->ii[k] != 0.0f) ? IX(ox, i - 1, k) : -INFINITY;
       st = (p1 > p0) ? ST_I : ST_M; i--;
@@ -829,4 +845,69 @@ int64_t p7o_domains(P7O_PROFILE *p, const uint8_t *dsq, int L, const float *fx, 
   ddmodel_free(&uni); ddmodel_free(&multi);
   free(btot); free(etot); free(mocc); free(n2sc);
   return failed ? -1 : nout;
+}
+
+/* p7_alidisplay_Create (p7_alidisplay.c) for the one domain of an envelope's optimal-accuracy trace: the states between B
+ * and E from the first to the last match state, one column each.  model: the consensus letter of the node for match and delete states, '.' for inserts; mline: the
+ * model's letter when the residue is the consensus residue, '+' when its emission odds exceed 1, else a blank; aseq: the
+ * residue, upper case in match columns, lower case in insert columns, '-' in delete columns; ppline: the posterior
+ * probability of the state in tenths, '*' from 0.95, '.' for deletes.  consensus[1..M]; sym: the alphabet's symbols.
+ * Returns the number of columns (the strings are terminated when they fit cap), or -1. */
+int p7o_domain_alignment(P7O_PROFILE *p, const uint8_t *dsq, int L, int ienv, int jenv, const char *consensus, const char *sym,
+                         char *model, char *mline, char *aseq, char *ppline, int cap)
+{
+  DDModel uni;
+  if (ddmodel_build(p, L, 0, &uni) != 0) return -1;
+  const int Ld = jenv - ienv + 1, M = uni.M;
+  DDMatrix f, b;
+  int ncol = -1;
+  if (ddmx_alloc(&f, Ld, M) == 0 && ddmx_alloc(&b, Ld, M) == 0) {
+    float envsc;
+    const uint8_t *sub = dsq + ienv - 1;
+    const int bad = dd_forward(&uni, sub, Ld, &f, &envsc);
+    dd_backward(&uni, sub, Ld, &f, &b);
+    const int range = dd_decoding(&uni, Ld, &f, &b);
+    if (!bad && !range) {
+      dd_optimal_accuracy(&uni, Ld, &b, &f);
+      DDPath path;
+      path.n = 0; path.cap = 2 * (Ld + M) + 8;
+      path.st = (int *) malloc(sizeof(int) * (size_t) path.cap); path.k = (int *) malloc(sizeof(int) * (size_t) path.cap);
+      path.i = (int *) malloc(sizeof(int) * (size_t) path.cap); path.pp = (float *) malloc(sizeof(float) * (size_t) path.cap);
+      int ia, ja, ka, kb;
+      if (path.st && path.k && path.i && path.pp && dd_oa_trace_path(&uni, Ld, &b, &f, p->Q4, &ia, &ja, &ka, &kb, &path) == 0 && path.n <= path.cap) {
+        /* the display runs from the first to the last match state: an optimal-accuracy trace may leave through a run of
+         * delete states (they cost nothing, and E takes the first best cell of its row) */
+        int zlast = 0, zfirst = path.n - 1;
+        while (zlast < path.n && path.st[zlast] != ST_M) zlast++;
+        while (zfirst >= 0 && path.st[zfirst] != ST_M) zfirst--;
+        ncol = zfirst - zlast + 1;
+        for (int c = 0; c < ncol && c < cap - 1; c++) {
+          const int z = zfirst - c;                         /* the path was recorded last state first */
+          const int st = path.st[z], k = path.k[z];
+          if (st == ST_M) {
+            const int x = sub[path.i[z]];
+            const char cons = consensus[k];
+            const char up = (cons >= 'a' && cons <= 'z') ? (char) (cons - 'a' + 'A') : cons;
+            model[c] = cons;
+            mline[c] = (sym[x] == up) ? cons : (uni.em[(size_t) x * (M + 1) + k] > 1.0f ? '+' : ' ');
+            aseq[c] = sym[x];
+          } else if (st == ST_I) {
+            const int x = sub[path.i[z]];
+            const char lo = (sym[x] >= 'A' && sym[x] <= 'Z') ? (char) (sym[x] - 'A' + 'a') : sym[x];
+            model[c] = '.'; mline[c] = ' '; aseq[c] = lo;
+          } else {
+            model[c] = consensus[k]; mline[c] = ' '; aseq[c] = '-';
+          }
+          const float pr = path.pp[z];
+          ppline[c] = (st == ST_D) ? '.' : ((pr + 0.05f >= 1.0f) ? '*' : (char) ((int) ((pr + 0.05f) * 10.0f) + '0'));
+        }
+        const int end = ncol < cap - 1 ? ncol : cap - 1;
+        model[end] = mline[end] = aseq[end] = ppline[end] = 0;
+      }
+      free(path.st); free(path.k); free(path.i); free(path.pp);
+    }
+  }
+  ddmx_free(&f); ddmx_free(&b);
+  ddmodel_free(&uni);
+  return ncol;
 }

@@ -195,3 +195,32 @@ def test_degenerate_residues_inside_envelopes(oracle):
             assert abs(d.score - e[9]) <= 2e-3 and abs(d.bias - e[10]) <= 2e-3, (h.name, d.score, e[9], d.bias, e[10])
             compared += 1
     assert compared >= 80
+
+
+def test_alignment_display_lines(oracle, proteome):
+    """p7_alidisplay_Create restated in the oracle: the model, match, sequence and posterior lines of the reference's own
+    Thioesterase answer (reference tests/test_hmmer.py:51-106), and the product's host stage against it on every domain of
+    170 synthetic targets of two models (trailing delete states of an optimal-accuracy trace are not displayed; inserts are
+    lower case; '+' marks emission odds above 1)."""
+    hmm = load_hmms("Thioesterase")[0]
+    op = oracle.OracleProfile(hmm, plan7.Background(hmm.alphabet), 400)
+    seq = np.asarray([s for s in proteome if s.name == "938293.PRJEB85.HG003687_113"][0].sequence, dtype=np.uint8)
+    assert oracle.domain_alignment(op, seq, 115, 129) == ("GWSfGGvlAyEmArq", "G+S+GG +A ++A++", "GHSMGGSVAVAIAHE", "9************96")
+    compared = with_inserts = with_deletes = 0
+    for name in ("PF02826", "KR"):
+        hmm = load_hmms(name)[0]
+        block = _homolog_block(hmm, 20, 150, seed=41)
+        pli = plan7.Pipeline(hmm.alphabet, E=1e9, domE=1e9, incE=1e9, incdomE=1e9)
+        hits = host_pipeline.host_search(oracle, hmm, block, pipeline=pli)
+        op = oracle.OracleProfile(hmm, pli.background, 400)
+        by_name = {s.name: s for s in block}
+        for h in hits:
+            seq = np.asarray(by_name[h.name].sequence, dtype=np.uint8)
+            for d in h.domains:
+                a = d.alignment
+                lines = oracle.domain_alignment(op, seq, d.env_from, d.env_to)
+                assert lines == (a.hmm_sequence, a.identity_sequence, a.target_sequence, a.posterior_probabilities), (name, h.name, d.env_from)
+                compared += 1
+                with_inserts += "." in lines[0]
+                with_deletes += "-" in lines[2]
+    assert compared >= 300 and with_inserts >= 20 and with_deletes >= 20
