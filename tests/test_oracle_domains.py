@@ -224,3 +224,53 @@ def test_alignment_display_lines(oracle, proteome):
                 with_inserts += "." in lines[0]
                 with_deletes += "-" in lines[2]
     assert compared >= 300 and with_inserts >= 20 and with_deletes >= 20
+
+
+def _oracle_search(oracle, hmm, block, E=10.0, domE=10.0, incE=0.01, incdomE=0.01):
+    """A whole hmmsearch through the oracle alone: filter cascade, domain definition, sequence scores, then the reference's
+    reporting logic restated here -- p7_pli_TargetReportable per target as it is found, sort by E-value (ties by name),
+    p7_tophits_Threshold: targets reported / included by E-value over Z = number of targets, domains by E-value over domZ =
+    number of reported targets, a domain included only if its target is."""
+    bg = plan7.Background(hmm.alphabet)
+    op = oracle.OracleProfile(hmm, bg, 400)
+    recs, ctr = op.cascade_block(block.packed())
+    Z = len(block)
+    found = []
+    for t in range(Z):
+        if recs[t].stage != 4:
+            continue
+        envs, counts, sq = oracle.domains(op, np.asarray(block[t].sequence, dtype=np.uint8), want_sequence=True)
+        if counts[0] == 0 or len(envs) == 0:
+            continue
+        if np.exp(sq["lnP"]) * Z <= E:
+            found.append((block[t].name, sq, envs))
+    found.sort(key=lambda h: (h[1]["lnP"], h[0]))
+    reported = [np.exp(sq["lnP"]) * Z <= E for _, sq, _ in found]
+    domZ = sum(reported)
+    out = []
+    for (name, sq, envs), rep in zip(found, reported):
+        inc = rep and np.exp(sq["lnP"]) * Z <= incE
+        doms = [(bool(rep and np.exp(e[11]) * domZ <= domE), bool(inc and np.exp(e[11]) * domZ <= incdomE), float(np.exp(e[11]) * domZ), float(np.exp(e[11]) * Z))
+                for e in envs]
+        out.append((name, bool(rep), bool(inc), float(sq["score"]), float(np.exp(sq["lnP"]) * Z), doms))
+    return out
+
+
+@pytest.mark.parametrize("model", ["PF02826", "RREFam", "KR", "LuxC", "Thioesterase"])
+def test_whole_search_through_the_oracle_alone_equals_the_host_pipeline(oracle, proteome, model):
+    """Hit lists of the fixture models against the proteome: the oracle's own search (no product code) and the product's
+    host pipeline (oracle filters + product host stage and hit list) name the same targets in the same order with the same
+    reported / included flags for targets and domains, scores to 2e-3 bit and E-values to 0.2 %."""
+    compared = 0
+    for hmm in load_hmms(model):
+        want = _oracle_search(oracle, hmm, proteome)
+        hits = host_pipeline.host_search(oracle, hmm, proteome)
+        got = [(h.name, h.reported, h.included, h.score, h.evalue, [(d.reported, d.included, d.c_evalue, d.i_evalue) for d in h.domains]) for h in hits]
+        assert [g[:3] for g in got] == [w[:3] for w in want], hmm.name
+        for g, w in zip(got, want):
+            assert abs(g[3] - w[3]) <= 2e-3 and abs(g[4] - w[4]) <= 2e-3 * w[4] + 1e-300, (hmm.name, g[0], g[3:5], w[3:5])
+            assert [d[:2] for d in g[5]] == [d[:2] for d in w[5]], (hmm.name, g[0])
+            for dg, dw in zip(g[5], w[5]):
+                assert abs(dg[2] - dw[2]) <= 3e-3 * dw[2] + 1e-300 and abs(dg[3] - dw[3]) <= 3e-3 * dw[3] + 1e-300, (hmm.name, g[0], dg, dw)
+            compared += 1
+    assert compared >= 1
