@@ -285,3 +285,22 @@ def domain_alignment(op, seq, ienv, jenv):
                                hmm.alphabet.symbols.encode(), bufs[0], bufs[1], bufs[2], bufs[3], cap)
     assert 0 <= n < cap, n
     return tuple(b.value.decode() for b in bufs)
+
+
+def lt_domains(op, window, do_null2=True, seed=42, max_env_extra=20):
+    """Domain definition of one Forward-passing window of a long target (p7o_lt_domains): rows of ienv jenv iali jali hmmfrom
+    hmmto envsc domcorrection oasc ... kind in window coordinates, and the counters."""
+    l = lib()
+    l.p7o_lt_domains.restype = C.c_int64
+    l.p7o_lt_domains.argtypes = [C.POINTER(Profile), C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_uint32, C.c_int,
+                                 C.c_void_p, C.c_int64, C.c_void_p]
+    st, bsc, fx, bx = op.bck(window)                       # configures the profile for the window's length
+    d = op._dsq(window)
+    degen = degeneracy_sets(op.ptr.contents.K)
+    cap = 256
+    out = np.zeros((cap, 13), dtype=np.float64)
+    counts = np.zeros(5, dtype=np.int64)
+    n = l.p7o_lt_domains(op.ptr, d.ctypes.data, len(window), fx.ctypes.data, bx.ctypes.data, degen.ctypes.data, int(do_null2), int(seed),
+                         int(max_env_extra), out.ctypes.data, cap, counts.ctypes.data)
+    assert 0 <= n <= cap, n
+    return out[:n].copy(), tuple(int(c) for c in counts)

@@ -139,6 +139,12 @@ void  p7o_lt_envelope_background(const P7O_PROFILE *p, const uint8_t *env, int64
 int64_t p7o_domains(P7O_PROFILE *p, const uint8_t *dsq, int L, const float *fx, const float *bx, const uint8_t *degen,
                     int do_null2, uint32_t seed, int ensembles, double *out, int64_t cap, int64_t *counts, float fwdsc, double *seqout);
 
+/* domain definition of one Forward-passing window of a long target (rescore_isolated_domain with long_target = TRUE: own
+ * length model, composition-adjusted emissions, the envelope cut back to its alignment + max_env_extra): rows as p7o_domains,
+ * columns 0-8 and 12, window coordinates. */
+int64_t p7o_lt_domains(P7O_PROFILE *p, const uint8_t *win, int W, const float *fx, const float *bx, const uint8_t *degen,
+                       int do_null2, uint32_t seed, int max_env_extra, double *out, int64_t cap, int64_t *counts);
+
 /* the alignment display of an envelope's optimal-accuracy alignment (p7_alidisplay_Create): model / match / sequence /
  * posterior lines, one column per state between B and E.  consensus[1..M], sym = the alphabet's symbols. */
 int p7o_domain_alignment(P7O_PROFILE *p, const uint8_t *dsq, int L, int ienv, int jenv, const char *consensus, const char *sym,

@@ -14,6 +14,8 @@
  *                              p7_trace_Index, p7_Null2_ByTrace per sampled domain, the per-residue null2 scores
  *   p7_spensemble_Cluster      single linkage (link_spsamples), clusters with posterior >= 0.25, consensus end points
  *   the scoring of a domain    p7_pipeline.c: envelope score + length correction - null1 - null2, in bits; exponential tail
+ *   long targets               rescore_isolated_domain with long_target = TRUE (p7o_lt_domains), the alignment display's lines
+ *                              (p7o_domain_alignment), the sequence's scores (seqout)
  *
  * Plain scalar C over un-striped tables, every sum taken in the order of the nodes: neither upstream's striped vector
  * order nor the product's lane-chunk order.  Posteriors therefore differ from either in the last bits; a comparison with
@@ -734,6 +736,163 @@ static int dd_rescore(const P7O_PROFILE *p, const DDModel *uni, const uint8_t *d
   }
   ddmx_free(&f); ddmx_free(&b);
   return ok;
+}
+
+/* ---------------------------------------------------------------------------------------------------------------------
+ * long targets: rescore_isolated_domain with long_target = TRUE (p7_domaindef.c; reference p7_domaindef.pxd:69-72 as called by
+ * p7_Pipeline_LongTarget, p7_pipeline.pxd:131-143).  An envelope is scored unihit under a length model of its OWN length, with
+ * null2 on against match emissions re-derived for a background mixed with the envelope's composition (reparameterize_model:
+ * p7o_lt_envelope_background, p7_oracle_lt.c); when the envelope reaches further than max_env_extra residues beyond its
+ * optimal-accuracy alignment it is cut back to that and aligned again; its score is then Forward's with the profile's own
+ * odds, and its bias what the adjusted odds take from that. */
+static int dd_lt_adjust(const P7O_PROFILE *p, DDModel *m, const uint8_t *first, int Ld, int64_t window_len, const uint8_t *degen)
+{
+  const int M = m->M, K = m->K, Kp = m->Kp;
+  float bg[P7O_MAXK];
+  p7o_lt_envelope_background(p, first, Ld, window_len, degen, bg);
+  for (int k = 1; k <= M; k++) {
+    float sc[P7O_MAXKP];
+    for (int x = 0; x < K; x++) {
+      const float prob = expf(p->msc[(size_t) x * (M + 1) + k]) * p->bgf[x];      /* the core model's match emission */
+      sc[x] = logf(prob / bg[x]);
+    }
+    sc[K] = sc[Kp - 2] = sc[Kp - 1] = -INFINITY;
+    for (int x = K + 1; x <= Kp - 3; x++) {                                        /* esl_abc_FExpectScVec under the new background */
+      float num = 0.0f, den = 0.0f;
+      for (int y = 0; y < K; y++) if (degen[(size_t) x * K + y]) { num += sc[y] * bg[y]; den += bg[y]; }
+      sc[x] = num / den;
+    }
+    for (int x = 0; x < Kp; x++) m->em[(size_t) x * (M + 1) + k] = expf(sc[x]);
+  }
+  return 0;
+}
+
+static int dd_lt_rescore(const P7O_PROFILE *p, const uint8_t *win, int W, int i, int j, const uint8_t *degen, int do_null2, int max_env_extra,
+                         double *out, int64_t *nout, int64_t cap, double kind)
+{
+  int ia = 0, ja = 0, ka = 0, kb = 0, ok = 0;
+  float envsc = 0.0f, oasc = 0.0f;
+  for (int pass = 0; pass < 2; pass++) {
+    const int Ld = j - i + 1;
+    DDModel m;
+    DDMatrix f, b;
+    if (ddmodel_build(p, Ld, 0, &m) != 0) return -1;
+    if (do_null2) dd_lt_adjust(p, &m, win + i, Ld, W, degen);
+    if (ddmx_alloc(&f, Ld, m.M) != 0 || ddmx_alloc(&b, Ld, m.M) != 0) { ddmx_free(&f); ddmx_free(&b); ddmodel_free(&m); return -1; }
+    const uint8_t *sub = win + i - 1;
+    const int bad = dd_forward(&m, sub, Ld, &f, &envsc);
+    dd_backward(&m, sub, Ld, &f, &b);
+    const int range = dd_decoding(&m, Ld, &f, &b);
+    ok = 0;
+    if (!bad && !range) {
+      oasc = dd_optimal_accuracy(&m, Ld, &b, &f);
+      int a1, a2;
+      if (dd_oa_trace(&m, Ld, &b, &f, p->Q4, &a1, &a2, &ka, &kb) == 0) { ok = 1; ia = a1 + i - 1; ja = a2 + i - 1; }
+    }
+    ddmx_free(&f); ddmx_free(&b); ddmodel_free(&m);
+    if (!ok) return 0;
+    if (pass == 0 && (i < ia - max_env_extra || j > ja + max_env_extra)) {
+      if (i < ia - max_env_extra) i = ia - max_env_extra;
+      if (j > ja + max_env_extra) j = ja + max_env_extra;
+      continue;
+    }
+    break;
+  }
+  float domcorrection = 0.0f;
+  if (do_null2) {
+    const int Ld = j - i + 1;
+    DDModel m;
+    DDMatrix f;
+    float orig = 0.0f;
+    if (ddmodel_build(p, Ld, 0, &m) != 0) return -1;
+    if (ddmx_alloc(&f, Ld, m.M) != 0) { ddmx_free(&f); ddmodel_free(&m); return -1; }
+    dd_forward(&m, win + i - 1, Ld, &f, &orig);
+    ddmx_free(&f); ddmodel_free(&m);
+    domcorrection = orig - envsc > 0.0f ? orig - envsc : 0.0f;
+    envsc = orig;
+  }
+  if (*nout < cap) {
+    double *o = out + *nout * 13;
+    o[0] = i; o[1] = j; o[2] = ia; o[3] = ja; o[4] = ka; o[5] = kb; o[6] = envsc; o[7] = domcorrection; o[8] = oasc;
+    o[9] = o[10] = o[11] = 0.0; o[12] = kind;
+  }
+  (*nout)++;
+  return 1;
+}
+
+/* One window of a long target that passed the Forward test: win[1..W] on its strand; fx / bx: the parsers' rows of the window in
+ * the multihit configuration of length W.  out: as p7o_domains, columns 0-8 and 12 (window coordinates; the scoring of a
+ * long-target domain is p7o_lt_domain_score's).  counts as p7o_domains. */
+int64_t p7o_lt_domains(P7O_PROFILE *p, const uint8_t *win, int W, const float *fx, const float *bx, const uint8_t *degen,
+                       int do_null2, uint32_t seed, int max_env_extra, double *out, int64_t cap, int64_t *counts)
+{
+  const float rt1 = 0.25f, rt2 = 0.10f, rt3 = 0.20f;
+  const int nsamples = 200;
+  int64_t nout = 0;
+  for (int c = 0; c < 5; c++) counts[c] = 0;
+  float *btot = (float *) calloc((size_t) W + 1, sizeof(float)), *etot = (float *) calloc((size_t) W + 1, sizeof(float)),
+        *mocc = (float *) calloc((size_t) W + 1, sizeof(float));
+  if (!btot || !etot || !mocc) { free(btot); free(etot); free(mocc); return -1; }
+  dd_domain_decoding(p, W, fx, bx, btot, etot, mocc);
+  DDModel multi;
+  if (ddmodel_build(p, W, 1, &multi) != 0) { free(btot); free(etot); free(mocc); return -1; }
+  int i = -1, triggered = 0, failed = 0;
+  for (int j = 1; j <= W && !failed; j++) {
+    if (!triggered) {
+      if (mocc[j] - (btot[j] - btot[j - 1]) < rt2) i = j;
+      else if (i == -1) i = j;
+      if (mocc[j] >= rt1) triggered = 1;
+    } else if (mocc[j] - (etot[j] - etot[j - 1]) < rt2) {
+      counts[0]++;
+      if (dd_is_multidomain(btot, etot, i, j, rt3)) {
+        counts[2]++;
+        if (seed != 0) {
+          const int Lr = j - i + 1, M = multi.M;
+          const uint8_t *sub = win + i - 1;
+          DDMatrix f;
+          float fsc;
+          const int segcap = 4 + Lr;
+          DDSeg *segs = (DDSeg *) malloc(sizeof(DDSeg) * (size_t) segcap);
+          DDCoord *all = (DDCoord *) malloc(sizeof(DDCoord) * (size_t) nsamples * (size_t) segcap);
+          DDCoord *cl = (DDCoord *) malloc(sizeof(DDCoord) * (size_t) (nsamples * 4 + 16));
+          float *n2acc = (float *) calloc((size_t) Lr + 2, sizeof(float));
+          float *cm = (float *) calloc((size_t) M + 1, sizeof(float)), *ci = (float *) calloc((size_t) M + 1, sizeof(float));
+          if (ddmx_alloc(&f, Lr, M) != 0 || !segs || !all || !cl || !n2acc || !cm || !ci) failed = 1;
+          int nall = 0;
+          if (!failed) {
+            dd_forward(&multi, sub, Lr, &f, &fsc);
+            DDRng rng;
+            dd_rng_init(&rng, seed);
+            for (int t = 0; t < nsamples && !failed; t++) {
+              const int ns = dd_sample_trace(&multi, sub, Lr, &f, p->Q4, &rng, degen, segs, segcap, n2acc, cm, ci);
+              if (ns < 0) { failed = 1; break; }
+              for (int d = 0; d < ns; d++) { all[nall].i = segs[d].ia + i - 1; all[nall].j = segs[d].ja + i - 1; all[nall].k = segs[d].ka; all[nall].m = segs[d].kb; all[nall].idx = t; nall++; }
+            }
+          }
+          if (!failed) {
+            const int nc = dd_cluster(all, nall, nsamples, cl, nsamples * 4 + 16);
+            if (nc < 0) failed = 1;
+            int last_j2 = 0;
+            for (int d = 0; d < nc && !failed; d++) {
+              counts[3]++;
+              if (cl[d].i <= last_j2) counts[4]++;
+              const int st = dd_lt_rescore(p, win, W, cl[d].i, cl[d].j, degen, do_null2, max_env_extra, out, &nout, cap, 1.0);
+              if (st < 0) failed = 1; else if (st > 0) { last_j2 = cl[d].j; counts[1]++; }
+            }
+          }
+          ddmx_free(&f);
+          free(segs); free(all); free(cl); free(n2acc); free(cm); free(ci);
+        }
+      } else {
+        const int st = dd_lt_rescore(p, win, W, i, j, degen, do_null2, max_env_extra, out, &nout, cap, 0.0);
+        if (st < 0) failed = 1; else if (st > 0) counts[1]++;
+      }
+      i = -1; triggered = 0;
+    }
+  }
+  ddmodel_free(&multi);
+  free(btot); free(etot); free(mocc);
+  return failed ? -1 : nout;
 }
 
 /* One target: dsq[1..L]; fx / bx: Forward / Backward parser rows of the whole target in the multihit configuration of

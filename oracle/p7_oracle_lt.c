@@ -19,6 +19,8 @@
  *   the residues of the window outside the envelope, the exponential tail
  *   reparameterize_model          the background mixed with the envelope's composition, smoothing 25 / min(100, max(50, n))
  *
+ * The domains inside a Forward-passing window are defined by p7o_lt_domains (p7_oracle_dd.c).
+ *
  * Pinned by: the reference's nhmmer tables through the product (tests/test_host_longtarget.py), and against the product's
  * device path on a 2 Mbp synthetic chromosome (tests/test_gpu_longtarget.py): stage counts equal, every hit inside a
  * window this file lets through Forward, scores re-derived from the hit's envelope / alignment coordinates to 1e-3 bit.

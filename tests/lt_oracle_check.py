@@ -113,3 +113,47 @@ def check_hits_against_oracle(pipeline, hmm, seq, hits, min_windows=0, min_short
         assert ok, (h.name, d.env_from, d.env_to, orig, adj, d.envelope_score * ln2, d.correction * ln2, wlens)
     assert nshort >= min_short, nshort
     return (int(total[0]), nshort, nshortwin) if want_short_windows else (int(total[0]), nshort)
+
+
+def check_hit_coordinates_against_oracle(pipeline, hmm, seq, hits, oracle=None, min_hits=1):
+    """Every hit's envelope, alignment and model coordinates from the oracle's OWN long-target domain definition
+    (oracle/p7_oracle_dd.c p7o_lt_domains) of a Forward-passing window that holds it: exact -- except that a window with a
+    region resolved by sampled tracebacks may come out differently when a sampled choice falls on a tie of the two
+    implementations' summation orders (every later sample of the region then differs): at most 5 % of the hits, all of them
+    in such windows.  Returns (hits reproduced, of those in ensemble regions)."""
+    op, max_length, units, total = oracle or oracle_windows(pipeline, hmm, seq)
+    cache = {}
+    checked = clustered = tolerated = 0
+    for h in hits:
+        d = h.domains[0]
+        a = d.alignment
+        rev = d.strand == "-"
+        lo, hi = min(d.env_from, d.env_to), max(d.env_from, d.env_to)
+        want = (d.env_from, d.env_to, a.target_from, a.target_to, a.hmm_from, a.hmm_to)
+        found = sampled = False
+        for (i, n, strand), win in units.items():
+            if strand != int(rev) or len(win) == 0 or found:
+                continue
+            b_lo, b_hi = (lo - i, hi - i) if not rev else (i + n - hi + 1, i + n - lo + 1)
+            if b_lo < 1 or b_hi > n:
+                continue
+            blk = seq[i:i + n] if strand == 0 else DNA_COMP[seq[i:i + n][::-1]]
+            for w in np.nonzero((win[:, 0] <= b_lo) & (win[:, 0] + win[:, 1] - 1 >= b_hi))[0]:
+                ws, wl = int(win[w, 0]), int(win[w, 1])
+                key = (i, n, strand, ws, wl)
+                if key not in cache:
+                    cache[key] = oracle_lib.lt_domains(op, blk[ws - 1:ws - 1 + wl], do_null2=pipeline.null2, seed=pipeline.seed)
+                sampled = sampled or cache[key][1][2] > 0
+                for e in cache[key][0]:
+                    def pos(x):                                # window coordinate -> target coordinate on the hit's strand
+                        b = ws - 1 + int(x)                    # block coordinate, 1-based
+                        return i + b if not rev else i + n - b + 1
+                    got = (pos(e[0]), pos(e[1]), pos(e[2]), pos(e[3]), int(e[4]), int(e[5]))
+                    if got == want:
+                        found = True
+                        clustered += int(e[12] == 1)
+        assert found or sampled, (h.name, want)
+        checked += int(found)
+        tolerated += int(not found)
+    assert checked >= min_hits and tolerated <= max(2, len(hits) // 20), (checked, tolerated)
+    return checked, clustered

@@ -186,16 +186,22 @@ def test_search_dealt_over_parts_equals_the_whole(libp7x, oracle):
 def test_long_target_tail_against_the_oracle_restatement(oracle):
     """The product's host tail (fed with the oracle's SSV seeds) against oracle/p7_oracle_lt.c on a 300 kbp synthetic chromosome with
     copies across block seams, short fragments and low-complexity stretches: the numbers of windows past every filter are equal,
-    every hit lies inside a window the oracle lets through Forward, and every score follows from the hit's own coordinates by
-    the oracle's scoring rule (1e-3 bit).  The 2 Mbp version of this test runs the device path (tests/test_gpu_longtarget.py)."""
+    every hit lies inside a window the oracle lets through Forward, every score follows from the hit's own coordinates by
+    the oracle's scoring rule (1e-3 bit), and the coordinates are those of the oracle's own domain definition.  The 2 Mbp version of this test runs the device path (tests/test_gpu_longtarget.py)."""
     import lt_oracle_check as lc
     hmm = load_hmms("bmyD")[0]
     pli = plan7.LongTargetsPipeline(hmm.alphabet, block_length=65536)
     seq = lc.synthetic_chromosome(hmm, 300_000, seed=11, block_length=pli.block_length, max_length=hmm.max_length)
     block = easel.DigitalSequenceBlock(hmm.alphabet, [easel.DigitalSequence(hmm.alphabet, name="chrT", sequence=seq)])
     hits = host_pipeline.host_nhmmer(oracle, hmm, block, pipeline=pli)
-    nwin, nshort = lc.check_hits_against_oracle(pli, hmm, seq, hits, min_windows=100, min_short=3)
+    windows = lc.oracle_windows(pli, hmm, seq)
+    nwin, nshort = lc.check_hits_against_oracle(pli, hmm, seq, hits, min_windows=100, min_short=3, oracle=windows)
     assert len(hits) >= 20
+    # ... and the coordinates themselves from the oracle's own long-target domain definition (p7o_lt_domains: regions,
+    # ensembles, the envelope under its own length model with composition-adjusted emissions, cut back to its alignment):
+    # every hit's envelope, alignment and model coordinates, exactly
+    checked, clustered = lc.check_hit_coordinates_against_oracle(pli, hmm, seq, hits, oracle=windows)
+    assert checked == len(hits) and clustered >= 20
 
 
 def _cut_model(full, lo, hi, name):
@@ -227,8 +233,10 @@ def test_short_windows_against_the_oracle_restatement(oracle):
     seq = lc.synthetic_chromosome(hmm, 120_000, seed=5, block_length=pli.block_length, max_length=70, long_copies=False)
     block = easel.DigitalSequenceBlock(hmm.alphabet, [easel.DigitalSequence(hmm.alphabet, name="chrS", sequence=seq)])
     hits = host_pipeline.host_nhmmer(oracle, hmm, block, pipeline=pli)
-    nwin, nshort, nshortwin = lc.check_hits_against_oracle(pli, hmm, seq, hits, min_windows=20, min_short=5, want_short_windows=True)
+    windows = lc.oracle_windows(pli, hmm, seq)
+    nwin, nshort, nshortwin = lc.check_hits_against_oracle(pli, hmm, seq, hits, min_windows=20, min_short=5, want_short_windows=True, oracle=windows)
     assert nshortwin >= 3 and len(hits) >= 5
+    assert lc.check_hit_coordinates_against_oracle(pli, hmm, seq, hits, oracle=windows)[0] >= len(hits) - 2
 
 
 @pytest.mark.parametrize("name,M", [("bmyD", None), ("RF00001", None), (None, 60), (None, 638), (None, 1278), (None, 2047)])
@@ -283,3 +291,43 @@ def test_ssv_scan_tables_against_the_oracle_profile(libp7x, oracle, name, M):
                         assert (int(lo[par, x, j // 4, lane, j % 4]), int(hi[par, x, j // 4, lane, j % 4])) == (want(x, k0), want(x, k0 + 1)), (pair, par, x, lane, j)
                     for j in range(R, 4 * R4):                       # the unused registers of the last quad
                         assert t[par, x, j // 4, lane, j % 4] == 0
+
+
+@pytest.mark.parametrize("model,target,table", [("bmyD", "BGC0001090.gbk", "bmyD1.tbl"), ("bmyD", "1390.SAMEA104415756.OFHT01000022.fna", "bmyD2.tbl"),
+                                                ("RF00001", "1390.SAMEA104415756.OFHT01000024.fna", None)])
+def test_oracle_long_target_domains_reproduce_the_nhmmer_fixtures(oracle, model, target, table):
+    """The reference's nhmmer answers from the oracle alone: its windows (p7_oracle_lt.c), its own long-target domain
+    definition inside them (p7_oracle_dd.c: p7o_lt_domains) and its scoring rule give every row of bmyD1.tbl / bmyD2.tbl --
+    hmm, alignment and envelope coordinates exactly, score and bias at print precision -- and the RF00001 hit."""
+    import lt_oracle_check as lc
+    hmm = load_hmms(model)[0]
+    seqs = _read(target, hmm.alphabet)
+    pli = plan7.LongTargetsPipeline(hmm.alphabet)
+    rows = golden_table(table) if table else None
+    found = 0
+    for s in seqs:
+        seq = np.asarray(s.sequence, dtype=np.uint8)
+        op, max_length, units, total = lc.oracle_windows(pli, hmm, seq)
+        doms = []
+        for (i, n, strand), win in units.items():
+            blk = seq[i:i + n] if strand == 0 else host_pipeline.DNA_COMP[seq[i:i + n][::-1]]
+            for ws, wl in [(int(w[0]), int(w[1])) for w in win]:
+                envs, counts = oracle.lt_domains(op, blk[ws - 1:ws - 1 + wl], seed=pli.seed)
+                for e in envs:
+                    pos = (lambda x: i + ws - 1 + int(x)) if strand == 0 else (lambda x: i + n - (ws - 1 + int(x)) + 1)
+                    score, bias, lnp = oracle.lt_domain_score(op, max_length, int(e[1] - e[0] + 1), int(e[3] - e[2] + 1), e[6], e[7], pli.null2)
+                    doms.append((s.name, int(e[4]), int(e[5]), pos(e[2]), pos(e[3]), pos(e[0]), pos(e[1]), "+" if strand == 0 else "-", score, bias))
+        if rows:
+            for r in rows:
+                if r[0] != s.name:
+                    continue
+                want = (r[0], int(r[4]), int(r[5]), int(r[6]), int(r[7]), int(r[8]), int(r[9]), r[11])
+                match = [d for d in doms if d[:8] == want]
+                assert match, (want, doms)
+                assert abs(match[0][8] - float(r[13])) <= 0.051 and abs(match[0][9] - float(r[14])) <= 0.051, (want, match[0], r[13], r[14])
+                found += 1
+        else:
+            best = max(doms, key=lambda d: d[8])
+            assert best[7] == "-" and best[8] > 50.0
+            found += 1
+    assert found >= (len(rows) if rows else 1)
