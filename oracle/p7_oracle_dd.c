@@ -25,11 +25,14 @@
  * coordinate conventions, the order and number of the generator's draws -- pinned by the reference's own domain tables
  * (tests/golden/tables/ *.domtbl: all 53 rows, envelope / alignment / model coordinates exactly, scores and biases at print
  * precision) and compared with the product on thousands of synthetic targets.  It shares no code with
- * pyhmmer_amd/csrc/p7x_domaindef.cpp.  Four of upstream's peculiarities that the tables pin were written wrongly at first
- * from memory and corrected after the tables (and the product, which reproduces them) disagreed: two sampled domains link
+ * pyhmmer_amd/csrc/p7x_domaindef.cpp.  Some of upstream's peculiarities were written wrongly at first from memory and
+ * corrected after the tables (and the product, which reproduces them) disagreed -- four that the tables pin: two sampled domains link
  * when their START points OR their END points lie on nearby diagonals; p7_Null2_ByTrace counts an insert state's residue
  * in the match slot of its node; region_trace_ensemble counts a sampled domain's first residue as outside the domain; the
- * E state's draw multiplies the cells by a single-precision reciprocal.
+ * E state's draw multiplies the cells by a single-precision reciprocal -- and two that only models of a few nodes show (a
+ * soak with 3-node models): link_spsamples' overlap on the model side is counted without the + 1 of the sequence side, so
+ * sampled domains of fewer than five nodes never link and their regions yield no envelope; and of two clusters that
+ * overlap by 80 % of the shorter one only the more probable is rescored.
  */
 #include "p7_oracle.h"
 #include <math.h>
@@ -610,7 +613,7 @@ static int dd_sample_trace(const DDModel *m, const uint8_t *dsq /* region, 1..Lr
  * link_spsamples: overlap of at least min_overlap of the smaller one in the sequence AND in the model, and the start points
  * or the end points on nearby diagonals), then for every cluster that at least min_posterior of the samples take part in, consensus end points: the
  * leftmost start and the rightmost end that at least min_endpointp of its samples use. */
-typedef struct { int i, j, k, m, idx; } DDCoord;
+typedef struct { int i, j, k, m, idx; float prob; } DDCoord;
 static int dd_linked(const DDCoord *a, const DDCoord *b)
 {
   const float min_overlap = 0.8f; const int max_diagdiff = 4;
@@ -618,7 +621,7 @@ static int dd_linked(const DDCoord *a, const DDCoord *b)
   int la = a->j - a->i + 1, lb = b->j - b->i + 1;
   int n = la < lb ? la : lb;
   if ((float) nov / (float) n < min_overlap) return 0;
-  nov = (a->m < b->m ? a->m : b->m) - (a->k > b->k ? a->k : b->k) + 1;
+  nov = (a->m < b->m ? a->m : b->m) - (a->k > b->k ? a->k : b->k);        /* sic: no + 1 on the model side */
   la = a->m - a->k + 1; lb = b->m - b->k + 1;
   n = la < lb ? la : lb;
   if ((float) nov / (float) n < min_overlap) return 0;
@@ -681,13 +684,25 @@ static int dd_cluster(const DDCoord *seg, int n, int nsamples, DDCoord *out, int
       best[which] = b;
     }
     free(epc);
-    if (nout < outcap) { out[nout].i = best[0]; out[nout].j = best[1]; out[nout].k = best[2]; out[nout].m = best[3]; out[nout].idx = c; }
+    if (best[0] > best[1] || best[2] > best[3]) continue;
+    if (nout < outcap) { out[nout].i = best[0]; out[nout].j = best[1]; out[nout].k = best[2]; out[nout].m = best[3]; out[nout].idx = c; out[nout].prob = (float) ninc / (float) nsamples; }
     nout++;
   }
   free(assign); free(stack); free(seen);
   if (nout > outcap) return -1;
   qsort(out, (size_t) nout, sizeof(DDCoord), dd_coord_by_start);
-  return nout;
+  /* p7_domaindef.c: of two clusters that overlap by at least 80 % of the shorter one only the more probable is kept */
+  for (int d = 0; d < nout; d++) out[d].idx = 1;
+  for (int d = 0; d < nout; d++)
+    for (int d2 = d + 1; d2 < nout; d2++) {
+      const int nov = (out[d].j < out[d2].j ? out[d].j : out[d2].j) - (out[d].i > out[d2].i ? out[d].i : out[d2].i) + 1;
+      if (nov == 0) break;
+      const int la = out[d].j - out[d].i + 1, lb = out[d2].j - out[d2].i + 1, n = la < lb ? la : lb;
+      if ((float) nov / (float) n >= 0.8f) { if (out[d].prob > out[d2].prob) out[d2].idx = 0; else out[d].idx = 0; }
+    }
+  int kept = 0;
+  for (int d = 0; d < nout; d++) if (out[d].idx) out[kept++] = out[d];
+  return kept;
 }
 
 /* rescore_isolated_domain: the envelope i..j of the target; n2sc != NULL: the null2 log ratios of the target's residues are

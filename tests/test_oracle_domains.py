@@ -274,3 +274,40 @@ def test_whole_search_through_the_oracle_alone_equals_the_host_pipeline(oracle, 
                 assert abs(dg[2] - dw[2]) <= 3e-3 * dw[2] + 1e-300 and abs(dg[3] - dw[3]) <= 3e-3 * dw[3] + 1e-300, (hmm.name, g[0], dg, dw)
             compared += 1
     assert compared >= 1
+
+
+@pytest.mark.parametrize("M", [1, 2, 3, 4, 7, 13])
+def test_models_of_a_few_nodes_against_targets_of_a_few_residues(oracle, M):
+    """300 targets of 1 - 59 residues, a third of them with tandem copies of the model's consensus, some all X: the same hits
+    and the same domain lists from the host pipeline and from the oracle alone.  (With three nodes the regions of tandem
+    copies are resolved by sampled tracebacks whose domains are too short ever to link -- upstream counts the overlap on
+    the model without the + 1 -- so they yield no envelope at all: both sides agree on that, too.)"""
+    abc = easel.Alphabet.amino()
+    rng = np.random.default_rng(9 + M)
+    hmm = random_hmm(M, seed=100 + M, conserved=0.9)
+    cons = np.argmax(hmm.match_emissions[1:], axis=1).astype(np.uint8)
+    seqs = []
+    for t in range(300):
+        L = int(rng.integers(1, 60))
+        a = rng.integers(0, 20, size=L).astype(np.uint8)
+        if t % 3 == 0:
+            rep = np.tile(cons, int(rng.integers(1, 6)))[:L]
+            p0 = int(rng.integers(0, max(1, L - len(rep) + 1)))
+            a[p0:p0 + len(rep)] = rep[:L - p0]
+        if t % 17 == 0:
+            a[:] = 26
+        seqs.append(easel.DigitalSequence(abc, name=f"t{t}", sequence=a))
+    block = easel.DigitalSequenceBlock(abc, seqs)
+    loose = dict(E=1e9, domE=1e9, incE=1e9, incdomE=1e9)
+    want = _oracle_search(oracle, hmm, block, **loose)
+    hits = host_pipeline.host_search(oracle, hmm, block, pipeline=plan7.Pipeline(abc, **loose))
+    assert [h.name for h in hits] == [w[0] for w in want]
+    op = oracle.OracleProfile(hmm, plan7.Background(abc), 400)
+    by_name = {s.name: s for s in block}
+    for h in hits:
+        envs, counts = oracle.domains(op, np.asarray(by_name[h.name].sequence, dtype=np.uint8))
+        ours = [(d.env_from, d.env_to, d.alignment.target_from, d.alignment.target_to, d.alignment.hmm_from, d.alignment.hmm_to) for d in h.domains]
+        assert ours == [tuple(int(v) for v in e[:6]) for e in envs], (M, h.name)
+        assert (h.nregions, h.nclustered, h.noverlaps, h.nenvelopes) == (counts[0], counts[2], counts[4], counts[1]), (M, h.name)
+    if M >= 3:
+        assert len(hits) >= 20
