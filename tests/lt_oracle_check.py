@@ -78,7 +78,9 @@ def check_hits_against_oracle(pipeline, hmm, seq, hits, min_windows=0, min_short
     for h in hits:
         d = h.domains[0]
         a = d.alignment
-        rev = d.strand == "-"
+        # the strand column compares the alignment's ends and reads "-" when they are one residue (as upstream prints it):
+        # the envelope's ends tell
+        rev = d.env_from > d.env_to if d.env_from != d.env_to else d.strand == "-"
         lo, hi = min(d.env_from, d.env_to), max(d.env_from, d.env_to)
         inside, wlens = False, []
         for (i, n, strand), win in units.items():
@@ -127,7 +129,9 @@ def check_hit_coordinates_against_oracle(pipeline, hmm, seq, hits, oracle=None, 
     for h in hits:
         d = h.domains[0]
         a = d.alignment
-        rev = d.strand == "-"
+        # the strand column compares the alignment's ends and reads "-" when they are one residue (as upstream prints it):
+        # the envelope's ends tell
+        rev = d.env_from > d.env_to if d.env_from != d.env_to else d.strand == "-"
         lo, hi = min(d.env_from, d.env_to), max(d.env_from, d.env_to)
         want = (d.env_from, d.env_to, a.target_from, a.target_to, a.hmm_from, a.hmm_to)
         found = sampled = False

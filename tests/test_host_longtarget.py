@@ -331,3 +331,17 @@ def test_oracle_long_target_domains_reproduce_the_nhmmer_fixtures(oracle, model,
             assert best[7] == "-" and best[8] > 50.0
             found += 1
     assert found >= (len(rows) if rows else 1)
+
+
+def test_a_dozen_nodes_against_the_oracle_restatement(oracle):
+    """A 12-node nucleotide model with 40-residue windows (one-residue alignments, envelopes at the target's first residues,
+    windows of the minimum length): stage counts, windows, scores and coordinates as in the tests above."""
+    import lt_oracle_check as lc
+    hmm = _cut_model(load_hmms("bmyD")[0], 100, 112, "bmyD_12")
+    pli = plan7.LongTargetsPipeline(hmm.alphabet, block_length=16384, E=1000.0, window_length=40)
+    seq = lc.synthetic_chromosome(hmm, 40_000, seed=100, block_length=pli.block_length, max_length=40, long_copies=False)
+    block = easel.DigitalSequenceBlock(hmm.alphabet, [easel.DigitalSequence(hmm.alphabet, name="chrD", sequence=seq)])
+    hits = host_pipeline.host_nhmmer(oracle, hmm, block, pipeline=pli)
+    windows = lc.oracle_windows(pli, hmm, seq)
+    lc.check_hits_against_oracle(pli, hmm, seq, hits, oracle=windows)
+    assert lc.check_hit_coordinates_against_oracle(pli, hmm, seq, hits, oracle=windows)[0] >= len(hits) - 2 and len(hits) >= 10
