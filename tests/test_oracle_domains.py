@@ -226,11 +226,16 @@ def test_alignment_display_lines(oracle, proteome):
     assert compared >= 300 and with_inserts >= 20 and with_deletes >= 20
 
 
-def _oracle_search(oracle, hmm, block, E=10.0, domE=10.0, incE=0.01, incdomE=0.01):
+def _oracle_search(oracle, hmm, block, E=10.0, domE=10.0, incE=0.01, incdomE=0.01, T=None, domT=None, incT=None, incdomT=None, cutoffs=None):
     """A whole hmmsearch through the oracle alone: filter cascade, domain definition, sequence scores, then the reference's
     reporting logic restated here -- p7_pli_TargetReportable per target as it is found, sort by E-value (ties by name),
     p7_tophits_Threshold: targets reported / included by E-value over Z = number of targets, domains by E-value over domZ =
-    number of reported targets, a domain included only if its target is."""
+    number of reported targets, a domain included only if its target is.  T / domT / incT / incdomT: score thresholds
+    instead of E-values; cutoffs = (sequence, domain): the model's bit cutoffs for reporting and inclusion alike
+    (p7_pli_NewModelThresholds)."""
+    if cutoffs is not None:
+        T = incT = cutoffs[0]
+        domT = incdomT = cutoffs[1]
     bg = plan7.Background(hmm.alphabet)
     op = oracle.OracleProfile(hmm, bg, 400)
     recs, ctr = op.cascade_block(block.packed())
@@ -242,16 +247,18 @@ def _oracle_search(oracle, hmm, block, E=10.0, domE=10.0, incE=0.01, incdomE=0.0
         envs, counts, sq = oracle.domains(op, np.asarray(block[t].sequence, dtype=np.uint8), want_sequence=True)
         if counts[0] == 0 or len(envs) == 0:
             continue
-        if np.exp(sq["lnP"]) * Z <= E:
+        if (sq["score"] >= T) if T is not None else (np.exp(sq["lnP"]) * Z <= E):
             found.append((block[t].name, sq, envs))
-    found.sort(key=lambda h: (h[1]["lnP"], h[0]))
-    reported = [np.exp(sq["lnP"]) * Z <= E for _, sq, _ in found]
+    by_score = incT is not None                   # the sort key is the score when inclusion goes by score (p7_pipeline.c)
+    found.sort(key=(lambda h: (-h[1]["score"], h[0])) if by_score else (lambda h: (h[1]["lnP"], h[0])))
+    reported = [(sq["score"] >= T) if T is not None else (np.exp(sq["lnP"]) * Z <= E) for _, sq, _ in found]
     domZ = sum(reported)
     out = []
     for (name, sq, envs), rep in zip(found, reported):
-        inc = rep and np.exp(sq["lnP"]) * Z <= incE
-        doms = [(bool(rep and np.exp(e[11]) * domZ <= domE), bool(inc and np.exp(e[11]) * domZ <= incdomE), float(np.exp(e[11]) * domZ), float(np.exp(e[11]) * Z))
-                for e in envs]
+        inc = rep and ((sq["score"] >= incT) if incT is not None else (np.exp(sq["lnP"]) * Z <= incE))
+        doms = [(bool(rep and ((e[9] >= domT) if domT is not None else (np.exp(e[11]) * domZ <= domE))),
+                 bool(inc and ((e[9] >= incdomT) if incdomT is not None else (np.exp(e[11]) * domZ <= incdomE))),
+                 float(np.exp(e[11]) * domZ), float(np.exp(e[11]) * Z)) for e in envs]
         out.append((name, bool(rep), bool(inc), float(sq["score"]), float(np.exp(sq["lnP"]) * Z), doms))
     return out
 
@@ -311,3 +318,20 @@ def test_models_of_a_few_nodes_against_targets_of_a_few_residues(oracle, M):
         assert (h.nregions, h.nclustered, h.noverlaps, h.nenvelopes) == (counts[0], counts[2], counts[4], counts[1]), (M, h.name)
     if M >= 3:
         assert len(hits) >= 20
+
+
+def test_score_thresholds_and_bit_cutoffs_through_the_oracle_alone(oracle, proteome):
+    """The same whole-search comparison with score thresholds (T, domT, incT, incdomT) and with the model's gathering and
+    trusted cutoffs: targets, order and every reported / included flag."""
+    def flags(hits):
+        return [(h.name, h.reported, h.included, [(d.reported, d.included) for d in h.domains]) for h in hits]
+    hmm = load_hmms("PF02826")[0]
+    for kw in (dict(T=20.0, domT=10.0, incT=50.0, incdomT=30.0), dict(T=-5.0), dict(incT=100.0, incdomT=100.0)):
+        want = _oracle_search(oracle, hmm, proteome, **kw)
+        got = host_pipeline.host_search(oracle, hmm, proteome, pipeline=plan7.Pipeline(hmm.alphabet, **kw))
+        assert flags(got) == [(w[0], w[1], w[2], [d[:2] for d in w[5]]) for w in want], kw
+    for which, pair in (("gathering", hmm.cutoffs.gathering), ("trusted", hmm.cutoffs.trusted)):
+        want = _oracle_search(oracle, hmm, proteome, cutoffs=pair)
+        got = host_pipeline.host_search(oracle, hmm, proteome, pipeline=plan7.Pipeline(hmm.alphabet, bit_cutoffs=which))
+        assert flags(got) == [(w[0], w[1], w[2], [d[:2] for d in w[5]]) for w in want], which
+        assert len(got) >= 5
