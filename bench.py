@@ -493,11 +493,6 @@ def main():
     ap.add_argument("--pfam-depth", type=int, default=None, help="A/B, many-profile workload (default: the library's own)")
     ap.add_argument("--pfam-finishers", type=int, default=None, help="A/B, many-profile workload (default: the library's own)")
     args = ap.parse_args()
-    for item in args.debug_option:
-        from pyhmmer_amd import _lib as _p7lib
-        name, _, value = item.partition("=")
-        _p7lib.set_debug_option(name, int(value or 1))
-
     if args.workload in ("pfam", "nhmmer"):          # development switch: the headline part shrinks to a token run
         args.steps, args.warmup, args.spinup_max, args.no_cpu_baseline = min(args.steps, 5), 0, 1, True
 
@@ -527,6 +522,9 @@ def main():
 
     from pyhmmer_amd import _lib, plan7
     lib = _lib.lib()
+    for item in args.debug_option:          # after torch: the library must bind to the HIP runtime torch has loaded
+        name, _, value = item.partition("=")
+        _lib.set_debug_option(name, int(value or 1))
     with plan7.HMMFile(ROOT / "tests" / "golden" / "hmms" / f"{args.hmm}.hmm") as hf:      # fixture data, not test code
         hmm = next(iter(hf))
     bg = plan7.Background(hmm.alphabet)

@@ -36,6 +36,35 @@ __device__ __forceinline__ s2 pk_subs(s2 a, s2 b) { return __builtin_elementwise
 __device__ __forceinline__ s2 splat(int v) { s2 r; r.x = (short) v; r.y = (short) v; return r; }
 __device__ __forceinline__ s2 swap_halves(s2 v) { return as_s2(__builtin_amdgcn_alignbit(as_u32(v), as_u32(v), 16)); }
 
+// The same two cells per register as IEEE half floats (the fast kernel's second flavour, see msv_fast_kernel): a cell holds
+// (v - xB) / 256, a multiple of 2^-8 in [0, 1] -- every sum of a cell and an emission is exact in binary16 -- and the packed
+// add's clamp modifier ([0, 1]) is the floor at the begin score.  What the flavour buys is v_pk_maximum3_f16 (new on gfx950):
+// ONE instruction folds two registers into the running maximum, where the integer flavour needs two v_pk_max_i16.
+typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ h2 as_h2(s2 v) { return __builtin_bit_cast(h2, v); }
+__device__ __forceinline__ s2 as_s2(h2 v) { return __builtin_bit_cast(s2, v); }
+__device__ __forceinline__ s2 h_adds(s2 a, s2 b)            // v_pk_add_f16 clamp
+{
+  const h2 z = { (_Float16) 0.0f, (_Float16) 0.0f }, o = { (_Float16) 1.0f, (_Float16) 1.0f };
+  return as_s2(__builtin_elementwise_min(__builtin_elementwise_max(as_h2(a) + as_h2(b), z), o));
+}
+__device__ __forceinline__ s2 h_subs(s2 a, s2 b)            // v_pk_add_f16 neg clamp
+{
+  const h2 z = { (_Float16) 0.0f, (_Float16) 0.0f }, o = { (_Float16) 1.0f, (_Float16) 1.0f };
+  return as_s2(__builtin_elementwise_min(__builtin_elementwise_max(as_h2(a) - as_h2(b), z), o));
+}
+__device__ __forceinline__ s2 h_max(s2 a, s2 b) { return as_s2(__builtin_elementwise_maximum(as_h2(a), as_h2(b))); }
+__device__ __forceinline__ s2 h_max3(s2 a, s2 b, s2 c)      // v_pk_maximum3_f16
+{ return as_s2(__builtin_elementwise_maximum(__builtin_elementwise_maximum(as_h2(a), as_h2(b)), as_h2(c))); }
+__device__ __forceinline__ s2 h_splat(int units)            // <units> / 256 in both halves; exact for |units| <= 2048
+{ const _Float16 x = (_Float16) ((float) units * (1.0f / 256.0f)); h2 r; r.x = x; r.y = x; return as_s2(r); }
+// a dword of the integer parity tables (two emissions, int16) as two halves: e / 256, pad entries (kNegPad and below) -> -2.0
+__device__ __forceinline__ uint32_t h_of_i16_pair(uint32_t w)
+{
+  const int lo = max((int) (short) (w & 0xffffu), -512), hi = max((int) (short) (w >> 16), -512);
+  return __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pkrtz((float) lo * (1.0f / 256.0f), (float) hi * (1.0f / 256.0f)));
+}
+
 
 constexpr int msv_stride_c(int R)
 { // smallest S >= R with S/2 odd: the row -> bank-pair map 2*(x*(S/2) mod 32) is then injective for x < 32
@@ -61,11 +90,12 @@ constexpr int msv_even_add_c(int R, int K) { return K == 1 ? 0 : kTabRows * msv_
 constexpr int msv_block_c(int K) { return K == 1 ? 256 : 512; }                            // threads per block: K > 1 tables are big, more
                                                                                            // wavefronts share one copy
 // maximum over the K lanes of a target (K = 1, 2, 4, 8; lanes of a target are consecutive)
-template <int K> __device__ __forceinline__ s2 target_max(s2 m)
+template <int K, bool H = false> __device__ __forceinline__ s2 target_max(s2 m)
 {
-  if constexpr (K >= 2) m = pk_max(m, as_s2((uint32_t) __builtin_amdgcn_update_dpp(0, (int) as_u32(m), 0xB1, 0xf, 0xf, false)));   // quad_perm [1,0,3,2]
-  if constexpr (K >= 4) m = pk_max(m, as_s2((uint32_t) __builtin_amdgcn_update_dpp(0, (int) as_u32(m), 0x4E, 0xf, 0xf, false)));   // quad_perm [2,3,0,1]
-  if constexpr (K >= 8) m = pk_max(m, as_s2((uint32_t) __builtin_amdgcn_update_dpp(0, (int) as_u32(m), 0x141, 0xf, 0xf, false)));  // row_half_mirror
+  auto mx = [](s2 a, s2 b) { if constexpr (H) return h_max(a, b); else return pk_max(a, b); };
+  if constexpr (K >= 2) m = mx(m, as_s2((uint32_t) __builtin_amdgcn_update_dpp(0, (int) as_u32(m), 0xB1, 0xf, 0xf, false)));   // quad_perm [1,0,3,2]
+  if constexpr (K >= 4) m = mx(m, as_s2((uint32_t) __builtin_amdgcn_update_dpp(0, (int) as_u32(m), 0x4E, 0xf, 0xf, false)));   // quad_perm [2,3,0,1]
+  if constexpr (K >= 8) m = mx(m, as_s2((uint32_t) __builtin_amdgcn_update_dpp(0, (int) as_u32(m), 0x141, 0xf, 0xf, false)));  // row_half_mirror
   return m;
 }
 // the register below a lane's first one: the last register of the lane before it (same target), or <edge> in a target's first lane
@@ -112,8 +142,9 @@ __device__ __forceinline__ void lds_wait2(Chunk &c)
 
 // One DP row over the register file: chunks of four register pairs (8 registers, 16 cells); when R is not a multiple
 // of 8 the top chunk holds two pairs.
-template <int R, int TB, bool ODD, int T, bool FAST = false>   // TB = byte offset of the row's parity table that goes into the
-struct RowChunks {                                            // instructions' immediate; T = chunk index being computed
+template <int R, int TB, bool ODD, int T, int FAST = 0>   // TB = byte offset of the row's parity table that goes into the
+struct RowChunks {                                        // instructions' immediate; T = chunk index being computed;
+                                                          // FAST: 0 = the recurrence as written, 1 = floored int16, 2 = floored half
   static_assert(R % 4 == 0, "a row is walked in chunks of 8 registers and a last one of 4: the register count must be a multiple of 4");
   static constexpr int NT = (R + 7) / 8;
   static constexpr int TBASE = TB;
@@ -129,7 +160,19 @@ struct RowChunks {                                            // instructions' i
   template <int JJ>
   static __device__ __forceinline__ void pair(s2 (&v)[R], const uint2 e, const s2 xB, const s2 carry, s2 &accA, s2 &accB)
   {
-    if constexpr (FAST) {       // floored representation: the saturating add *is* max(., xB) (see msv_fast_kernel)
+    if constexpr (FAST == 2) {  // floored halves: as below, and one maximum3 takes both registers of the pair
+      if constexpr (ODD) {
+        v[2 * JJ + 1] = h_adds(v[2 * JJ], as_s2(e.y));
+        s2 pred = carry;
+        if constexpr (JJ > 0) pred = v[2 * JJ - 1];
+        v[2 * JJ] = h_adds(pred, as_s2(e.x));
+      } else {
+        v[2 * JJ] = h_adds(v[2 * JJ], as_s2(e.x));
+        v[2 * JJ + 1] = h_adds(v[2 * JJ + 1], as_s2(e.y));
+      }
+      if constexpr (JJ & 1) { accB = h_max3(accB, v[2 * JJ], v[2 * JJ + 1]); asm volatile("" : "+v"(accB)); }
+      else { accA = h_max3(accA, v[2 * JJ], v[2 * JJ + 1]); asm volatile("" : "+v"(accA)); }
+    } else if constexpr (FAST == 1) {       // floored representation: the saturating add *is* max(., xB) (see msv_fast_kernel)
       if constexpr (ODD) {
         v[2 * JJ + 1] = pk_adds(v[2 * JJ], as_s2(e.y));
         s2 pred = carry;
@@ -297,11 +340,18 @@ __global__ void __launch_bounds__(msv_block_c(K)) msv_kernel(const ArgRef ref)
 // K > 1: the row of a long model is spread over K consecutive lanes (blocks of R registers).  Per row that adds the
 // neighbour's last register as the carry into an odd row (one DPP move) and the maximum over the K lanes (log2 K DPP
 // steps); everything else, including the begin-score bookkeeping, runs identically in the K lanes.
-template <int R, int K>
+// H: the half-float flavour (default).  Cells hold (v - xB) / 256 as binary16, the emission tables are converted while they
+// are staged into LDS, v_pk_add_f16 clamp is the add with its floor (0 == xB; the ceiling 1.0 == xB + 256 lies above the
+// overflow watermark 255 - bias, so a clamped cell belongs to a target that is reported as overflow either way), and
+// v_pk_maximum3_f16 takes two registers into the epoch's maximum at once: 1.5 packed ops per cell pair instead of 2.
+// Every value is a multiple of 2^-8 below 4: binary16 arithmetic on them is exact, the integers that leave the kernel
+// are the same as the integer flavour's (option msv_f16 = 0 selects that one; tests compare both with the oracle).
+template <int R, int K, bool H>
 __global__ void __launch_bounds__(msv_block_c(K), (K > 1 ? 2 : (R <= 92 ? 4 : (R <= 136 ? 3 : 2)))) msv_fast_kernel(const ArgRef ref)
 {
   extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
   constexpr int S = msv_row_stride_c(R, K), Rs = msv_lane_stride_c(R, K), BLK = msv_block_c(K);
+  constexpr int MODE = H ? 2 : 1;
   const MsvArgs a = load_args<MsvArgs>(ref);
   const int nitems = (a.ngroups - a.group_first) * K;
   if (*a.counter >= nitems) return;            // this lane's groups are all taken: skip the table load
@@ -309,13 +359,18 @@ __global__ void __launch_bounds__(msv_block_c(K), (K > 1 ? 2 : (R <= 92 ? 4 : (R
     constexpr int n4 = (2 * kTabRows * S) / 4;
     const uint4 *src = reinterpret_cast<const uint4 *>(a.tab);
     uint4 *dst = reinterpret_cast<uint4 *>(lds);
-    for (int i = threadIdx.x; i < n4; i += BLK) dst[i] = src[i];
+    for (int i = threadIdx.x; i < n4; i += BLK) {
+      uint4 w = src[i];
+      if constexpr (H) { w.x = h_of_i16_pair(w.x); w.y = h_of_i16_pair(w.y); w.z = h_of_i16_pair(w.z); w.w = h_of_i16_pair(w.w); }
+      dst[i] = w;
+    }
   }
   __syncthreads();
 
   const int lane = threadIdx.x & 63;
-  const s2 floorv = splat(-32768);
+  const s2 floorv = H ? as_s2(0u) : splat(-32768);
   constexpr int NT = (R + 7) / 8;
+  auto mx = [](s2 x, s2 y) { if constexpr (H) return h_max(x, y); else return pk_max(x, y); };
 
   for (;;) {
     int item = 0;
@@ -337,11 +392,14 @@ __global__ void __launch_bounds__(msv_block_c(K), (K > 1 ? 2 : (R <= 92 ? 4 : (R
     int xJ = 0, xEmax = 0;
     int xB = max(a.base - tjbm, 0);
     const int F0 = xB - a.tec;
-    const s2 Tv = splat(tjbm + a.tec - 32768);
+    const s2 Tv = H ? h_splat(tjbm + a.tec) : splat(tjbm + a.tec - 32768);
     s2 accA = floorv, accB = floorv;             // the epoch's running maximum
     // fold the epoch maximum into xJ / the overflow watermark; returns the begin score that follows
     auto fold = [&](const s2 m2) -> int {
-      const int xE = max((int) m2.x, (int) m2.y) + 32768 + xB;
+      int rel;
+      if constexpr (H) { const h2 m = as_h2(m2); rel = (int) (256.0f * fmaxf((float) m.x, (float) m.y)); }
+      else rel = max((int) m2.x, (int) m2.y) + 32768;
+      const int xE = rel + xB;
       xEmax = max(xEmax, xE);
       xJ = max(xJ, xE - a.tec);
       return max(max(a.base, xJ) - tjbm, 0);
@@ -361,20 +419,20 @@ __global__ void __launch_bounds__(msv_block_c(K), (K > 1 ? 2 : (R <= 92 ? 4 : (R
           if (half == 0) {        // odd row
             const uint32_t addr = x0 * (uint32_t) (S * 4) + lane_col;
             const s2 carry = carry_in<K>(v[R - 1], floorv, it.h);
-            RowChunks<R, 0, true, NT - 1, true>::template issue<NT - 1>(addr, ca);
-            RowChunks<R, 0, true, NT - 1, true>::run(v, addr, ca, cb, floorv, carry, accA, accB);
+            RowChunks<R, 0, true, NT - 1, MODE>::template issue<NT - 1>(addr, ca);
+            RowChunks<R, 0, true, NT - 1, MODE>::run(v, addr, ca, cb, floorv, carry, accA, accB);
           } else {                // even row
             const uint32_t addr = x1 * (uint32_t) (S * 4) + lane_col + (uint32_t) msv_even_add_c(R, K);
-            RowChunks<R, msv_even_imm_c(R, K), false, 0, true>::template issue<0>(addr, ca);
-            RowChunks<R, msv_even_imm_c(R, K), false, 0, true>::run(v, addr, ca, cb, floorv, floorv, accA, accB);
+            RowChunks<R, msv_even_imm_c(R, K), false, 0, MODE>::template issue<0>(addr, ca);
+            RowChunks<R, msv_even_imm_c(R, K), false, 0, MODE>::run(v, addr, ca, cb, floorv, floorv, accA, accB);
           }
-          const s2 m2 = target_max<K>(pk_max(accA, accB));
-          if (__builtin_expect(__any(as_u32(pk_max(m2, Tv)) != as_u32(Tv)), 0)) {
+          const s2 m2 = target_max<K, H>(mx(accA, accB));
+          if (__builtin_expect(__any(as_u32(mx(m2, Tv)) != as_u32(Tv)), 0)) {
             asm volatile("; re-bias: the begin score moved" ::: "memory");   // keeps this a real (rare) branch: no if-conversion
             const int xBn = fold(m2);
-            const s2 dv = splat(xBn - xB);        // zero in the lanes whose own maximum stayed at or below T
+            const s2 dv = H ? h_splat(xBn - xB) : splat(xBn - xB);        // zero in the lanes whose own maximum stayed at or below T
 #pragma unroll
-            for (int j = 0; j < R; ++j) v[j] = pk_subs(v[j], dv);
+            for (int j = 0; j < R; ++j) v[j] = H ? h_subs(v[j], dv) : pk_subs(v[j], dv);
             xB = xBn;
             accA = floorv; accB = floorv;
           }
@@ -382,7 +440,7 @@ __global__ void __launch_bounds__(msv_block_c(K), (K > 1 ? 2 : (R <= 92 ? 4 : (R
       }
       cur = nxt;
     }
-    fold(target_max<K>(pk_max(accA, accB)));
+    fold(target_max<K, H>(mx(accA, accB)));
     const bool ambiguous = (L > 0) && (xJ == F0) && !(xEmax >= 255 - a.bias);
     if (L > 0 && it.h == 0) a.out_xJ[slot] = (xEmax >= 255 - a.bias) ? (int16_t) -1 : (int16_t) xJ;
     if (__any(ambiguous) && lane == 0) { const int idx = atomicAdd(a.amb_count, 1); a.amb_groups[idx] = it.g; }
@@ -450,7 +508,7 @@ static int launch_RK(const ArgRun<MsvArgs> &main, const ArgRun<MsvArgs> *amb, in
   constexpr int BLK = msv_block_c(K);
   const size_t lds_bytes = (size_t) 2 * kTabRows * msv_row_stride_c(R, K) * 4;
   // occupancy and the LDS opt-in are per kernel instantiation: looked up once
-  struct Info { int per_cu_exact = 0, per_cu_fast = 0; bool ok = false; };
+  struct Info { int per_cu_exact = 0, per_cu_fast = 0, per_cu_half = 0; bool ok = false; };
   static Info info;
   static std::mutex mu;
   {
@@ -458,12 +516,15 @@ static int launch_RK(const ArgRun<MsvArgs> &main, const ArgRun<MsvArgs> *amb, in
     if (!info.ok) {
       if (lds_bytes > 64 * 1024) {
         P7X_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&msv_kernel<R, K>), hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds_bytes));
-        P7X_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&msv_fast_kernel<R, K>), hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds_bytes));
+        P7X_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&msv_fast_kernel<R, K, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds_bytes));
+        P7X_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&msv_fast_kernel<R, K, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds_bytes));
       }
       P7X_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&info.per_cu_exact, msv_kernel<R, K>, BLK, lds_bytes));
-      P7X_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&info.per_cu_fast, msv_fast_kernel<R, K>, BLK, lds_bytes));
+      P7X_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&info.per_cu_fast, msv_fast_kernel<R, K, false>, BLK, lds_bytes));
+      P7X_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&info.per_cu_half, msv_fast_kernel<R, K, true>, BLK, lds_bytes));
       if (info.per_cu_exact < 1) info.per_cu_exact = 1;
       if (info.per_cu_fast < 1) info.per_cu_fast = 1;
+      if (info.per_cu_half < 1) info.per_cu_half = 1;
       info.ok = true;
     }
   }
@@ -477,12 +538,14 @@ static int launch_RK(const ArgRun<MsvArgs> &main, const ArgRun<MsvArgs> *amb, in
     return P7X_OK;
   }
   // fast kernel over every group, then the exact kernel over the (normally empty) lists of ambiguous groups
-  int per_cu2 = info.per_cu_fast;
+  const bool half = debug_opt(OPT_MSV_F16) != 0;          // the half-float flavour unless a test asks for the integer one
+  int per_cu2 = half ? info.per_cu_half : info.per_cu_fast;
   // A/B switch: cap the resident blocks per CU so that other kernels' wavefronts fit beside the MSV row registers
   const int cap = debug_opt(OPT_MSV_BLOCKS_PER_CU);
   if (cap > 0 && per_cu2 > cap) per_cu2 = cap;
   const unsigned gx2 = lane_grid(want, (long) num_cu * per_cu2, main.n);
-  hipLaunchKernelGGL((msv_fast_kernel<R, K>), dim3(gx2, (unsigned) main.n), dim3(BLK), lds_bytes, st, main.ref());
+  if (half) hipLaunchKernelGGL((msv_fast_kernel<R, K, true>), dim3(gx2, (unsigned) main.n), dim3(BLK), lds_bytes, st, main.ref());
+  else hipLaunchKernelGGL((msv_fast_kernel<R, K, false>), dim3(gx2, (unsigned) main.n), dim3(BLK), lds_bytes, st, main.ref());
   P7X_HIP(hipGetLastError());
   hipLaunchKernelGGL((msv_kernel<R, K>), dim3(lane_grid(32, 32, amb->n), (unsigned) amb->n), dim3(BLK), lds_bytes, st, amb->ref());
   P7X_HIP(hipGetLastError());

@@ -17,11 +17,13 @@ typedef short s2 __attribute__((ext_vector_type(2)));
 
 enum Op { PK_ADD_SAT = 0, PK_MAX = 1, PK_ADD_MAX_MIX = 2, ADD_U32 = 3, FMA_F32 = 4, PK_ADD_WRAP = 5,
           MAX3_I16 = 6, MAX_I16 = 7, ADD_I16_SAT = 8, MAX3_I32 = 9, MAX_I32 = 10, ADD_I32_SAT = 11, PK_ADD_MAX3_MIX = 12, MED3_I16 = 13,
-          FMA_F32_2V = 14, FMA_F32_K = 15, NOPS };
+          FMA_F32_2V = 14, FMA_F32_K = 15, PK_ADD_F16 = 16, PK_MAX_F16 = 17, PK_MAX3_F16 = 18, PK_F16_MIX = 19, OR_B32 = 20, NOPS };
 static const char *kOpName[NOPS] = { "v_pk_add_i16 clamp", "v_pk_max_i16", "pk_add clamp + pk_max (MSV mix)", "v_add_u32", "v_fma_f32", "v_pk_add_u16",
                                      "v_max3_i16 op_sel (lo,lo,hi)", "v_max_i16 (VOP2)", "v_add_i16 clamp (VOP3)", "v_max3_i32", "v_max_i32 (VOP2)",
                                      "v_add_i32 clamp (VOP3)", "pk_add clamp + max3_i16 (candidate)", "v_med3_i16",
-                                     "v_fma_f32 c, c, e, c (2 VGPRs read)", "v_fma_f32 c, c, 1.0, e (2 VGPRs read)" };
+                                     "v_fma_f32 c, c, e, c (2 VGPRs read)", "v_fma_f32 c, c, 1.0, e (2 VGPRs read)",
+                                     "v_pk_add_f16 clamp", "v_pk_max_f16", "v_pk_maximum3_f16 (3 VGPRs read)", "2 pk_add_f16 clamp + pk_maximum3_f16 (round-5 MSV mix)",
+                                     "v_or_b32" };
 
 // One asm statement holds the whole unrolled body (.rept): between separate asm statements the compiler puts a
 // conservative s_nop, which would be measured too.
@@ -43,6 +45,23 @@ static const char *kOpName[NOPS] = { "v_pk_add_i16 clamp", "v_pk_max_i16", "pk_a
 #define I_MAX3_I32(c)    "v_max3_i32 %" #c ", %" #c ", %16, %16\n\t"
 #define I_MAX_I32(c)     "v_max_i32 %" #c ", %" #c ", %16\n\t"
 #define I_ADD_I32_SAT(c) "v_add_i32 %" #c ", %" #c ", %16 clamp\n\t"
+#define I_PK_ADD_F16(c)  "v_pk_add_f16 %" #c ", %" #c ", %16 clamp\n\t"
+#define I_PK_MAX_F16(c)  "v_pk_max_f16 %" #c ", %" #c ", %16\n\t"
+#define I_OR_B32(c)      "v_or_b32 %" #c ", %" #c ", %16\n\t"
+// the accumulator %8+c takes its own chain's register and the seed: three distinct VGPRs per instruction
+#define I_PK_MAX3_F16_0 "v_pk_maximum3_f16 %8, %8, %0, %16\n\t"
+#define I_PK_MAX3_F16_1 "v_pk_maximum3_f16 %9, %9, %1, %16\n\t"
+#define I_PK_MAX3_F16_2 "v_pk_maximum3_f16 %10, %10, %2, %16\n\t"
+#define I_PK_MAX3_F16_3 "v_pk_maximum3_f16 %11, %11, %3, %16\n\t"
+#define I_PK_MAX3_F16_4 "v_pk_maximum3_f16 %12, %12, %4, %16\n\t"
+#define I_PK_MAX3_F16_5 "v_pk_maximum3_f16 %13, %13, %5, %16\n\t"
+#define I_PK_MAX3_F16_6 "v_pk_maximum3_f16 %14, %14, %6, %16\n\t"
+#define I_PK_MAX3_F16_7 "v_pk_maximum3_f16 %15, %15, %7, %16\n\t"
+// the half-float MSV mix: two adds, one maximum3 over both results (three instructions per two registers)
+#define I_HMIX01 "v_pk_add_f16 %0, %0, %16 clamp\n\tv_pk_add_f16 %1, %1, %16 clamp\n\tv_pk_maximum3_f16 %8, %8, %0, %1\n\t"
+#define I_HMIX23 "v_pk_add_f16 %2, %2, %16 clamp\n\tv_pk_add_f16 %3, %3, %16 clamp\n\tv_pk_maximum3_f16 %9, %9, %2, %3\n\t"
+#define I_HMIX45 "v_pk_add_f16 %4, %4, %16 clamp\n\tv_pk_add_f16 %5, %5, %16 clamp\n\tv_pk_maximum3_f16 %10, %10, %4, %5\n\t"
+#define I_HMIX67 "v_pk_add_f16 %6, %6, %16 clamp\n\tv_pk_add_f16 %7, %7, %16 clamp\n\tv_pk_maximum3_f16 %11, %11, %6, %7\n\t"
 #define I_MX0 "v_pk_add_i16 %0, %0, %16 clamp\n\tv_max3_i16 %8, %8, %0, %0 op_sel:[0,0,1,0]\n\t"
 #define I_MX1 "v_pk_add_i16 %1, %1, %16 clamp\n\tv_max3_i16 %9, %9, %1, %1 op_sel:[0,0,1,0]\n\t"
 #define I_MX2 "v_pk_add_i16 %2, %2, %16 clamp\n\tv_max3_i16 %10, %10, %2, %2 op_sel:[0,0,1,0]\n\t"
@@ -84,6 +103,19 @@ __device__ __forceinline__ void body(uint32_t (&v)[8], uint32_t (&acc)[8], uint3
   else if constexpr (OP == MAX3_I32) { P7X_EMIT(I_MAX3_I32) }
   else if constexpr (OP == MAX_I32) { P7X_EMIT(I_MAX_I32) }
   else if constexpr (OP == ADD_I32_SAT) { P7X_EMIT(I_ADD_I32_SAT) }
+  else if constexpr (OP == PK_ADD_F16) { P7X_EMIT(I_PK_ADD_F16) }
+  else if constexpr (OP == PK_MAX_F16) { P7X_EMIT(I_PK_MAX_F16) }
+  else if constexpr (OP == OR_B32) { P7X_EMIT(I_OR_B32) }
+  else if constexpr (OP == PK_MAX3_F16) {
+    if constexpr (NCHAIN == 1) asm volatile(".rept 64\n\t" I_PK_MAX3_F16_0 ".endr" P7X_OPERANDS);
+    else if constexpr (NCHAIN == 4) asm volatile(".rept 64\n\t" I_PK_MAX3_F16_0 I_PK_MAX3_F16_1 I_PK_MAX3_F16_2 I_PK_MAX3_F16_3 ".endr" P7X_OPERANDS);
+    else asm volatile(".rept 64\n\t" I_PK_MAX3_F16_0 I_PK_MAX3_F16_1 I_PK_MAX3_F16_2 I_PK_MAX3_F16_3 I_PK_MAX3_F16_4 I_PK_MAX3_F16_5 I_PK_MAX3_F16_6 I_PK_MAX3_F16_7 ".endr" P7X_OPERANDS);
+  }
+  else if constexpr (OP == PK_F16_MIX) {        // NCHAIN counts registers: 1 -> one pair, 4 -> two pairs, 8 -> four pairs
+    if constexpr (NCHAIN == 1) asm volatile(".rept 64\n\t" I_HMIX01 ".endr" P7X_OPERANDS);
+    else if constexpr (NCHAIN == 4) asm volatile(".rept 64\n\t" I_HMIX01 I_HMIX23 ".endr" P7X_OPERANDS);
+    else asm volatile(".rept 64\n\t" I_HMIX01 I_HMIX23 I_HMIX45 I_HMIX67 ".endr" P7X_OPERANDS);
+  }
   else if constexpr (OP == PK_ADD_MAX3_MIX) {
     if constexpr (NCHAIN == 1) asm volatile(".rept 64\n\t" I_MX0 ".endr" P7X_OPERANDS);
     else if constexpr (NCHAIN == 4) asm volatile(".rept 64\n\t" I_MX0 I_MX1 I_MX2 I_MX3 ".endr" P7X_OPERANDS);
@@ -133,7 +165,8 @@ static void run(int waves_per_simd, int num_cu, double clk_hz, uint32_t *d_out, 
   double mean = 0; unsigned long long mx = 0;
   for (auto c : cyc) { mean += (double) c; if (c > mx) mx = c; }
   mean /= nblocks;
-  const double per_wave_insts = (double) iters * 64 * NCHAIN * ((OP == PK_ADD_MAX_MIX || OP == PK_ADD_MAX3_MIX) ? 2 : 1);
+  const double per_wave_insts = OP == PK_F16_MIX ? (double) iters * 64 * 3 * (NCHAIN == 1 ? 1 : NCHAIN / 2)
+                                                 : (double) iters * 64 * NCHAIN * ((OP == PK_ADD_MAX_MIX || OP == PK_ADD_MAX3_MIX) ? 2 : 1);
   // every SIMD holds waves_per_simd waves when the dispatcher balances them: instructions issued per SIMD
   const double per_simd_insts = per_wave_insts * waves_per_simd;
   const double cyc_counter = mean / per_simd_insts;                        // s_memtime ticks per wave-instruction per SIMD
@@ -164,6 +197,17 @@ int main(int argc, char **argv)
   printf("| op | chains | waves/SIMD | ms | cyc/inst (counter) | cyc/inst (events) | lanes/clk/SIMD |\n|---|---|---|---|---|---|---|\n");
   uint32_t *d_out; unsigned long long *d_cyc;
   CK(hipMalloc(&d_out, (size_t) num_cu * 4 * 8 * 64 * 4)); CK(hipMalloc(&d_cyc, (size_t) num_cu * 4 * 8 * 8));
+  if (argc > 1 && argv[1][0] == 'h') {                 // "h": round 5, the half-float MSV flavour's instructions
+    sweep<ADD_U32>(num_cu, clk_hz, d_out, d_cyc);
+    sweep<OR_B32>(num_cu, clk_hz, d_out, d_cyc);
+    sweep<PK_ADD_SAT>(num_cu, clk_hz, d_out, d_cyc);
+    sweep<PK_ADD_F16>(num_cu, clk_hz, d_out, d_cyc);
+    sweep<PK_MAX_F16>(num_cu, clk_hz, d_out, d_cyc);
+    sweep<PK_MAX3_F16>(num_cu, clk_hz, d_out, d_cyc);
+    sweep<PK_ADD_MAX_MIX>(num_cu, clk_hz, d_out, d_cyc);
+    sweep<PK_F16_MIX>(num_cu, clk_hz, d_out, d_cyc);
+    return 0;
+  }
   sweep<ADD_U32>(num_cu, clk_hz, d_out, d_cyc);
   sweep<FMA_F32>(num_cu, clk_hz, d_out, d_cyc);
   sweep<FMA_F32_2V>(num_cu, clk_hz, d_out, d_cyc);

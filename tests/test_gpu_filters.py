@@ -228,6 +228,27 @@ def test_every_msv_kernel_instantiation_bit_exact(M, oracle):
         assert np.array_equal(got, op.msv_block(blk.packed())), f"M={M} rep={rep}"
 
 
+@pytest.mark.parametrize("M", [5, 60, 262, 263, 445, 446, 700, 893, 1000, 1021])
+def test_integer_flavour_of_the_fast_msv_kernel_bit_exact(M, oracle):
+    """The lane-per-target MSV kernel has two flavours of its floored representation: binary16 cells (the default since
+    round 5: v_pk_add_f16 clamp + v_pk_maximum3_f16) and int16 cells (v_pk_add_i16 clamp + v_pk_max_i16).  Everything else
+    in this file runs the first; this sends one model per lanes-per-target family through the second (seam "msv_f16")."""
+    from pyhmmer_amd import _lib
+    hmm = random_hmm(M, seed=1000 + M)
+    bg = plan7.Background(hmm.alphabet)
+    blk = _model_block(hmm, 400, 12, seed=M)
+    om = plan7.OptimizedProfile(hmm, bg, 400)
+    want = oracle.OracleProfile(hmm, bg, 400).msv_block(blk.packed())
+    _lib.set_debug_option("small_block", 0)
+    try:
+        for flavour in (0, 1):
+            _lib.set_debug_option("msv_f16", flavour)
+            got = plan7.SequenceDatabase(blk).filters(om, msv=True)["xJ"]
+            assert np.array_equal(got, want), f"M={M} flavour={'half' if flavour else 'int16'}"
+    finally:
+        _lib.set_debug_option("msv_f16", -1)
+
+
 # wave-per-target kernels: one M per nodes-per-lane count C; packed Viterbi kernel (M <= 640): the largest M of every
 # (lanes per target T, register pairs per lane P) instantiation, i.e. 16 P for T = 8 and 32 P for T = 16, and one below
 _PK_M = sorted({16 * p - d for p in (2, 4, 6, 8, 10, 12, 14, 15, 16, 17, 18, 19, 20) for d in (0, 1)} |
