@@ -26,6 +26,16 @@ static int device_count_checked()
 // made a HIP call, or if the user set the variable).
 static const int g_hw_queues_set = setenv("GPU_MAX_HW_QUEUES", "8", 0);
 
+int create_tail_stream(DeviceCtx *ctx, bool high_priority, hipStream_t *out)
+{ // (Round 5 tried these streams on a subset of the CUs, hipExtStreamCreateWithCUMask with 64 or 128 of 256: the headline fell
+  // from 20.0 to 16.5 TCUPS -- such streams lose their priority, and every MSV launch stretched from 17.5 to 22 ms.)
+  (void) ctx;
+  int least = 0, greatest = 0;
+  P7X_HIP(hipDeviceGetStreamPriorityRange(&least, &greatest));
+  P7X_HIP(hipStreamCreateWithPriority(out, hipStreamNonBlocking, high_priority ? greatest : least));
+  return P7X_OK;
+}
+
 int get_ctx(int device, DeviceCtx **out)
 {
   std::lock_guard<std::mutex> lk(g_ctx_mu);

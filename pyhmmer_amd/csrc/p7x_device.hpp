@@ -65,6 +65,8 @@ void slab_release(DeviceCtx *ctx, void *p, size_t bytes);
 int pinned_acquire(size_t bytes, void **out, size_t *got);
 void pinned_release(void *p, size_t bytes);
 int get_ctx(int device, DeviceCtx **out);
+// a stream for the kernels of a search's host stage (envelopes: low priority; ensembles: high)
+int create_tail_stream(DeviceCtx *ctx, bool high_priority, hipStream_t *out);
 
 // A slab of the context's pool that goes back to it when the last owner lets go.
 struct SlabRef { DeviceCtx *ctx = nullptr; void *p = nullptr; size_t bytes = 0; ~SlabRef(); };

@@ -623,14 +623,8 @@ public:
     }
     lease_ = eb;
     if (!eb->stream) {
-      int least = 0, greatest = 0;
-      P7X_HIP(hipDeviceGetStreamPriorityRange(&least, &greatest));
       // a few wavefronts, each a long serial chain, and the host stage waits for them: ahead of the filter kernels' queues
-#ifdef P7X_ENS_STREAM_LOW
-      P7X_HIP(hipStreamCreateWithPriority(&eb->stream, hipStreamNonBlocking, least));
-#else
-      P7X_HIP(hipStreamCreateWithPriority(&eb->stream, hipStreamNonBlocking, greatest));
-#endif
+      const int cst = create_tail_stream(ctx_, true, &eb->stream); if (cst != P7X_OK) return cst;
     }
     // which regions the device takes: every one whose records fit the workspace budget, and whose model the kernels cover
     size_t free_b = 0, total_b = 0;
@@ -736,7 +730,14 @@ public:
         // never less than 4 KiB)
       const size_t least = (size_t) (((maxM + 2 + 31) & ~31) + 32 + 128 + 8) * 4 + 64 + 4096;
       const size_t want = least + (size_t) (maxLr + 1) * 25 + 128 + (size_t) (maxM + 1) * (128 + 64) + 44 * 1024;
-      a.lds_bytes = (int) std::max(least, std::min(want, (size_t) 128 * 1024));
+      // ... but no more than 32 KiB by default (option ens_lds_kb): a walk is one wavefront per workgroup, a latency chain that
+      // needs no throughput, and what it holds is missing for the filter kernels' blocks -- three MSV blocks of a Pfam-sized
+      // model take 100 of a CU's 160 KiB, and with 109 KiB gone to a walk only one of them fits.  Round 5, headline workload:
+      // 19.0-20.0 TCUPS with the full 128 KiB, 20.3-21.0 with 16-40 KiB (profiles/r05_ens_lds.txt); the host stage even waits less
+      // for the ensembles (23-30 ms instead of 30-36), because more walks are resident at once.
+      size_t most = (size_t) 32 * 1024;
+      if (debug_opt(OPT_ENS_LDS_KB) > 0) most = (size_t) debug_opt(OPT_ENS_LDS_KB) * 1024;
+      a.lds_bytes = (int) std::max(least, std::min(want, most));
     }
     const int32_t *d_lists = reinterpret_cast<const int32_t *>(eb->d_in + o_lists);
     for (const auto &run : runs)

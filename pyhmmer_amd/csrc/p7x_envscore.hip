@@ -93,9 +93,7 @@ public:
     lease_ = eb;
     tick("lease");
     if (!eb->stream) {
-      int least = 0, greatest = 0;
-      P7X_HIP(hipDeviceGetStreamPriorityRange(&least, &greatest));
-      P7X_HIP(hipStreamCreateWithPriority(&eb->stream, hipStreamNonBlocking, least));
+      const int cst = create_tail_stream(ctx_, false, &eb->stream); if (cst != P7X_OK) return cst;
     }
     // inputs: [env_sq i64][tr_off i64][env_len i32][env_L i32][order i32] over all envelopes, one queue cursor per job,
     // then one EnvArgs record per job
