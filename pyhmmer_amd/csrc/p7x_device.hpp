@@ -37,6 +37,11 @@ struct DeviceCtx {
   // MSV launches of concurrent searches are chained: two of them sharing the device finish no earlier than one after
   // the other (both are VALU bound), but each would take twice as long and delay its own cascade's tail
   std::mutex msv_mu;
+  // The long-target SSV scan takes the whole device for tens of milliseconds and runs on <stream>: searches that overlap
+  // (hmmer.nhmmer keeps two in flight) take turns at it -- the second one's scan then fills the device while the first
+  // one's tail runs, its stream synchronisation waits for its own work only, its events time its own kernel, and the
+  // first search's upload of a keyed target set is found, not repeated, by the second.
+  std::mutex lt_scan_mu;
   hipEvent_t msv_done[2] = { nullptr, nullptr };
   int msv_last = -1;
   // Device images of query profiles come and go with every query (a scan walks through thousands of models):
@@ -57,7 +62,7 @@ struct DeviceCtx {
   hipStream_t ws_main[kWsSets]{};
   hipStream_t ws_side[kWsSets][kWsSide]{};
   std::vector<hipStream_t> ws_spacers;
-  int ws_next = 0;                      // guarded by mu
+  int ws_set_users[kWsSets]{};          // cascades running on every set right now (guarded by mu): a lease takes the least used one
 };
 int slab_acquire(DeviceCtx *ctx, size_t bytes, void **out, size_t *got);
 void slab_release(DeviceCtx *ctx, void *p, size_t bytes);

@@ -545,8 +545,10 @@ static int ens_walk_launch(const EnsArgs &a, hipStream_t st)
   if (a.nregions <= 0) return P7X_OK;
   const size_t lds = (size_t) a.lds_bytes;
   if (lds > 64 * 1024) {
-    static std::mutex mu; static size_t granted = 0;
+    static std::mutex mu; static std::map<int, size_t> granted_by_device;       // a per-device attribute of the kernel
+    int dev = 0; P7X_HIP(hipGetDevice(&dev));
     std::lock_guard<std::mutex> lk(mu);
+    size_t &granted = granted_by_device[dev];
     if (lds > granted) { P7X_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(ens_walk_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int) (128 * 1024))); granted = 128 * 1024; }
   }
   hipLaunchKernelGGL(ens_walk_kernel, dim3((unsigned) a.nregions), dim3(64), lds, st, a);
@@ -603,7 +605,44 @@ public:
   DeviceEnsembleRunner(DeviceCtx *ctx, const p7x_seqdb *db) : ctx_(ctx), db_(db) {}
   ~DeviceEnsembleRunner() override { if (lease_) { if (lease_->stream) (void) hipStreamSynchronize(lease_->stream); release_ens_buffers(lease_); } }
 
+  // Any region may be sampled by the host workers instead (EnsembleResult::status != 0): a device-side failure here --
+  // the workspace cannot grow because other host stages hold the memory, a launch is refused -- sends every region of
+  // this call there instead of failing the batch and with it the whole search.
   int begin(const std::vector<EnvelopeJob> &jobs, uint32_t seed_state, int nsamples) override
+  {
+    const int st = begin_on_device(jobs, seed_state, nsamples);
+    if (st == P7X_OK) return st;
+    if (lease_ && lease_->stream) (void) hipStreamSynchronize(lease_->stream);      // whatever was queued before the failure
+    (void) hipGetLastError();
+    std::fill(launched_.begin(), launched_.end(), (char) 0);
+    nlaunched_ = 0;
+    return P7X_OK;
+  }
+
+  int wait(std::vector<std::vector<EnsembleResult>> &res) override
+  {
+    res.assign(jobs_.size(), {});
+    for (size_t j = 0; j < jobs_.size(); ++j) res[j].assign(jobs_[j].req->size(), EnsembleResult{});
+    if (nlaunched_ == 0) return P7X_OK;
+    P7X_HIP(hipSetDevice(db_->device));
+    P7X_HIP(hipStreamSynchronize(lease_->stream));
+    const unsigned char *h = lease_->h_out;
+    const int32_t *ndom = reinterpret_cast<const int32_t *>(h + o_ndom_), *status = reinterpret_cast<const int32_t *>(h + o_status_);
+    const int32_t *dom = reinterpret_cast<const int32_t *>(h + o_dom_);
+    const float *n2 = reinterpret_cast<const float *>(h + o_n2_);
+    for (int l = 0; l < nlaunched_; ++l) {
+      const int64_t g = reg_global_[(size_t) l];
+      const size_t j = (size_t) (std::upper_bound(first_.begin(), first_.end(), g) - first_.begin()) - 1;
+      EnsembleResult &e = res[j][(size_t) (g - first_[j])];
+      e.status = status[l]; e.ndom = ndom[l];
+      e.dom = dom + (size_t) regs_[(size_t) l].dom0 * 5;
+      e.n2 = n2 + regs_[(size_t) l].row0;
+    }
+    return P7X_OK;
+  }
+
+private:
+  int begin_on_device(const std::vector<EnvelopeJob> &jobs, uint32_t seed_state, int nsamples)
   {
     jobs_ = jobs;
     const size_t nj = jobs.size();
@@ -627,9 +666,23 @@ public:
       const int cst = create_tail_stream(ctx_, true, &eb->stream); if (cst != P7X_OK) return cst;
     }
     // which regions the device takes: every one whose records fit the workspace budget, and whose model the kernels cover
+    // (a quarter of what is free -- up to eight host stages lease a workspace each, next to two envelope scorers apiece --
+    // and all leases of the device together at most a quarter of its memory: a lease that would have to grow beyond that
+    // keeps its size, and the regions that do not fit sample on the host)
     size_t free_b = 0, total_b = 0;
     size_t budget = (size_t) 16 << 30;
-    if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && free_b / 4 < budget) budget = std::max(free_b / 4, eb->work_bytes);
+    if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
+      if (free_b / 4 < budget) budget = std::max(free_b / 4, eb->work_bytes);
+      size_t pooled = 0;
+      {
+        EnsPool &ep = ens_pool();
+        std::lock_guard<std::mutex> lk(ep.mu);
+        for (const EnsBuffers *o : ep.all) if (o != eb && o->device == db_->device) pooled += o->work_bytes;
+      }
+      const size_t cap = total_b / 4;
+      const size_t room = pooled < cap ? cap - pooled : 0;
+      if (budget > std::max(room, eb->work_bytes)) budget = std::max(room, eb->work_bytes);
+    }
     std::vector<DevProfile *> dps(nj, nullptr);
     std::vector<EnsRegion> regs;
     std::vector<int64_t> reg_global;          // launched region -> global request number
@@ -674,6 +727,7 @@ public:
     const int nl = (int) regs.size();
     nlaunched_ = nl; reg_global_ = reg_global;
     if (nl == 0) return P7X_OK;
+    if (debug_opt(OPT_ENS_FAIL) > 0) { set_error("ensemble workspace: failure requested by the test seam ens_fail"); return P7X_EMEM; }
     // workspace
     const size_t o_cells = 0, o_md = align256(o_cells + (size_t) ncells * 32), o_rows = align256(o_md + (size_t) ncells * 8);
     const size_t work_bytes = align256(o_rows + (size_t) nrows * 32);
@@ -748,29 +802,6 @@ public:
     return P7X_OK;
   }
 
-  int wait(std::vector<std::vector<EnsembleResult>> &res) override
-  {
-    res.assign(jobs_.size(), {});
-    for (size_t j = 0; j < jobs_.size(); ++j) res[j].assign(jobs_[j].req->size(), EnsembleResult{});
-    if (nlaunched_ == 0) return P7X_OK;
-    P7X_HIP(hipSetDevice(db_->device));
-    P7X_HIP(hipStreamSynchronize(lease_->stream));
-    const unsigned char *h = lease_->h_out;
-    const int32_t *ndom = reinterpret_cast<const int32_t *>(h + o_ndom_), *status = reinterpret_cast<const int32_t *>(h + o_status_);
-    const int32_t *dom = reinterpret_cast<const int32_t *>(h + o_dom_);
-    const float *n2 = reinterpret_cast<const float *>(h + o_n2_);
-    for (int l = 0; l < nlaunched_; ++l) {
-      const int64_t g = reg_global_[(size_t) l];
-      const size_t j = (size_t) (std::upper_bound(first_.begin(), first_.end(), g) - first_.begin()) - 1;
-      EnsembleResult &e = res[j][(size_t) (g - first_[j])];
-      e.status = status[l]; e.ndom = ndom[l];
-      e.dom = dom + (size_t) regs_[(size_t) l].dom0 * 5;
-      e.n2 = n2 + regs_[(size_t) l].row0;
-    }
-    return P7X_OK;
-  }
-
-private:
   DeviceCtx *ctx_; const p7x_seqdb *db_;
   std::vector<EnvelopeJob> jobs_;
   std::vector<int64_t> first_, reg_global_;

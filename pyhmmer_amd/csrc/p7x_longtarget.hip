@@ -104,6 +104,7 @@ static int scan_target(const p7x_pipeline_cfg &cfg, const Profile &p, DeviceCtx 
     R = ssvlong_pick_R(p.M, false);
     ssvlong_build_tables(p, R, false, tab4q, tab_full, &pair_slack);
   }
+  std::lock_guard<std::mutex> scan_turn(ctx->lt_scan_mu);      // one scan at a time per device (see DeviceCtx)
   DevBuf d_tab4q, d_full, d_comp, d_nrec, d_pos, d_strand, d_k, d_sc;
   int st;
   if ((st = d_tab4q.alloc(tab4q.size() * 4)) || (st = d_full.alloc(tab_full.size() * 4)) || (st = d_comp.alloc(32)) || (st = d_nrec.alloc(4))) return st;

@@ -20,6 +20,7 @@
 //     has S/2 odd so the <=32 residue rows fall on distinct bank pairs: conflict-free;
 //   * residues arrive as coalesced 16-byte loads from 64-sequence interleaved tiles (p7x_seqdb).
 #include <cstdlib>
+#include <map>
 #include <mutex>
 #include "p7x_device.hpp"
 #include "p7x_kernels.hpp"
@@ -509,11 +510,15 @@ static int launch_RK(const ArgRun<MsvArgs> &main, const ArgRun<MsvArgs> *amb, in
   const size_t lds_bytes = (size_t) 2 * kTabRows * msv_row_stride_c(R, K) * 4;
   // occupancy and the LDS opt-in are per kernel instantiation: looked up once
   struct Info { int per_cu_exact = 0, per_cu_fast = 0, per_cu_half = 0; bool ok = false; };
-  static Info info;
+  static std::map<int, Info> info_by_device;       // ... and per device (the opt-in is an attribute of the kernel ON a device)
   static std::mutex mu;
+  Info info;
   {
+    int dev = 0; P7X_HIP(hipGetDevice(&dev));
     std::lock_guard<std::mutex> lk(mu);
-    if (!info.ok) {
+    Info &slot = info_by_device[dev];
+    if (!slot.ok) {
+      Info &info = slot;
       if (lds_bytes > 64 * 1024) {
         P7X_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&msv_kernel<R, K>), hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds_bytes));
         P7X_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&msv_fast_kernel<R, K, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds_bytes));
@@ -527,6 +532,7 @@ static int launch_RK(const ArgRun<MsvArgs> &main, const ArgRun<MsvArgs> *amb, in
       if (info.per_cu_half < 1) info.per_cu_half = 1;
       info.ok = true;
     }
+    info = slot;
   }
   constexpr int wpb = BLK / 64;          // wavefronts (work items in flight) per block
   long want = 1;

@@ -540,6 +540,7 @@ struct Workspace {
   unsigned char *pack_dev = nullptr; size_t pack_dev_bytes = 0;      // slab of the context's pool
   unsigned char *pack_host = nullptr; size_t pack_host_bytes = 0;    // pinned
   bool busy = false;                // between the enqueue and the collect half of a cascade
+  int set = -1;                     // the context's stream set this lease runs on (taken when leased, given back on release)
   size_t counters_bytes() const { return (size_t) nlanes * kLaneCounters * 4 + 8; }
   unsigned long long *cursor() const { return reinterpret_cast<unsigned long long *>(counters + (size_t) nlanes * kLaneCounters); }
   ~Workspace() {
@@ -576,23 +577,49 @@ struct Workspace {
 struct WorkspacePool { std::mutex mu; std::vector<Workspace *> all; };
 static WorkspacePool &ws_pool() { static WorkspacePool *p = new WorkspacePool(); return *p; }
 
+// The stream sets are the context's (created once, placed apart on the hardware queues); a lease runs on the set that the
+// fewest cascades are using right now.  (Until round 5 a workspace kept the set it was created with, handed out by a
+// creation counter: a workspace that was replaced by a larger one, or more than four live workspaces, could put two
+// running cascades on the same eight streams while another set sat idle.)
+static int lease_stream_set(Workspace *w)
+{
+  DeviceCtx *ctx = nullptr;
+  const int cst = get_ctx(w->device, &ctx);
+  if (cst != P7X_OK) return cst;
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  int set = 0;
+  for (int k = 1; k < DeviceCtx::kWsSets; ++k) if (ctx->ws_set_users[k] < ctx->ws_set_users[set]) set = k;
+  ctx->ws_set_users[set]++;
+  w->set = set;
+  w->stream = ctx->ws_main[set];
+  for (int k = 0; k < Workspace::kSide; ++k) w->side[k] = ctx->ws_side[set][k];
+  return P7X_OK;
+}
+
 static void release_workspace(Workspace *w)
 {
   if (!w) return;
+  if (w->set >= 0) {
+    DeviceCtx *ctx = nullptr;
+    if (get_ctx(w->device, &ctx) == P7X_OK) { std::lock_guard<std::mutex> lk(ctx->mu); if (ctx->ws_set_users[w->set] > 0) ctx->ws_set_users[w->set]--; }
+    w->set = -1;
+  }
   std::lock_guard<std::mutex> lk(ws_pool().mu);
   w->busy = false;
 }
 
 static int get_workspace(int device, int64_t nslots, int nlanes, Workspace **out)
 {
+  Workspace *found = nullptr;
   {
     std::lock_guard<std::mutex> lk(ws_pool().mu);
     Workspace *best = nullptr;
     for (Workspace *w : ws_pool().all)
       if (!w->busy && w->device == device && w->cap_slots >= nslots && w->nlanes >= nlanes &&
           (!best || w->cap_slots * w->nlanes < best->cap_slots * best->nlanes)) best = w;
-    if (best) { best->busy = true; *out = best; return P7X_OK; }
+    if (best) { best->busy = true; found = best; }
   }
+  if (found) { *out = found; return lease_stream_set(found); }
   auto w = std::make_unique<Workspace>();
   w->device = device;
   const int64_t cap = std::max<int64_t>(64, ((nslots + 63) / 64) * 64);
@@ -615,13 +642,8 @@ static int get_workspace(int device, int64_t nslots, int nlanes, Workspace **out
   P7X_HIP(hipEventCreateWithFlags(&w->ev_sync, hipEventDisableTiming));
   {   // the cascade is the critical path of a search (its streams have the highest priority: its wavefronts go first when
       // the envelope kernel of the previous query shares the device); the streams are the context's, dealt out in turn
-    DeviceCtx *ctx = nullptr;
-    const int cst = get_ctx(device, &ctx);
+    const int cst = lease_stream_set(w.get());
     if (cst != P7X_OK) return cst;
-    int set;
-    { std::lock_guard<std::mutex> lk(ctx->mu); set = ctx->ws_next; ctx->ws_next = (ctx->ws_next + 1) % DeviceCtx::kWsSets; }
-    w->stream = ctx->ws_main[set];
-    for (int k = 0; k < Workspace::kSide; ++k) w->side[k] = ctx->ws_side[set][k];
     P7X_HIP(hipEventCreateWithFlags(&w->ev_fork, hipEventDisableTiming));
     for (auto &e : w->ev_join) P7X_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
   }

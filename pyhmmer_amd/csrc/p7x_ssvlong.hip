@@ -20,6 +20,7 @@
 // scores of A, C, G, T for both parities sit in LDS as quads of registers; degenerate residues (rare in chromosomes)
 // take a slow path through the full table in global memory.  u8 saturation at 255 is not reproduced: it can only keep a
 // cell at or above a threshold it has already reached.
+#include <map>
 #include "p7x_wave.hpp"
 #include <mutex>
 
@@ -279,17 +280,19 @@ static int launch_ssv_quad(const SsvLongArgs &a, int num_cu, hipStream_t st, lon
 {
   const size_t lds = (size_t) 2 * 4 * ((R + 3) / 4) * 64 * 16;
   auto kern = ssvlong_quad_kernel<R, PAIR>;
-  static int per_cu_cached = 0;
+  static std::map<int, int> per_cu_by_device;       // the LDS opt-in is a per-device attribute of the kernel: looked up once per device
   static std::mutex mu;
   int per_cu = 0;
   {
+    int dev = 0; P7X_HIP(hipGetDevice(&dev));
     std::lock_guard<std::mutex> lk(mu);
-    if (per_cu_cached == 0) {
+    int &cached = per_cu_by_device[dev];
+    if (cached == 0) {
       if (lds > 64 * 1024) P7X_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds));
-      P7X_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu_cached, kern, 256, lds));
-      if (per_cu_cached < 1) per_cu_cached = 1;
+      P7X_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&cached, kern, 256, lds));
+      if (cached < 1) cached = 1;
     }
-    per_cu = per_cu_cached;
+    per_cu = cached;
   }
   if (cap_waves) { *cap_waves = (long long) num_cu * per_cu * 4; return P7X_OK; }
   long long grid = std::min<long long>((a.nchunks + 3) / 4, (long long) num_cu * per_cu);

@@ -708,6 +708,8 @@ static int scan_accum_add(p7x_scan_accum *acc, p7x_tophits *const *per_model, co
     if (!per_model[mm]) { set_error(std::string(who) + ": missing per-model result"); return P7X_EINVAL; }
     if (per_model[mm]->ctr.nseqs != nseqs) { set_error(std::string(who) + ": per-model results cover different sequence sets"); return P7X_EINVAL; }
     if (model_index && model_index[mm] < 0) { set_error(std::string(who) + ": negative model number"); return P7X_EINVAL; }
+    // model numbers index a bitmap: one that cannot be a position in any profile database is a caller's error, not an allocation
+    if (model_index && model_index[mm] >= ((int64_t) 1 << 31)) { set_error(std::string(who) + ": model number out of range"); return P7X_EINVAL; }
   }
   {
     size_t top = 0;
@@ -992,7 +994,7 @@ struct Reader {
   template <class T> void pod(T &v) { if (p + sizeof(T) > e) { ok = false; return; } std::memcpy(&v, p, sizeof(T)); p += sizeof(T); }
   void str(std::string &s) { uint32_t n = 0; pod(n); if (!ok || p + n > e) { ok = false; return; } s.assign((const char *) p, n); p += n; }
 };
-constexpr uint32_t kMagic = 0x70377878u;   // "p7xx" (format 5: presentation order, sort state and flags travel as they are)
+constexpr uint32_t kMagic = 0x70377879u;   // "p7xy" (format 6: the ABI version and the size of the configuration record follow the magic)
 
 template <class IO> void io_domain(IO &io, Domain &d)
 {
@@ -1017,6 +1019,9 @@ int64_t p7x_tophits_serialize(const p7x_tophits *th, void *buf, size_t cap)
   if (!th) return -1;
   Writer w;
   uint32_t magic = kMagic; w.pod(magic);
+  // the layout follows the configuration record and the timing array, i.e. the ABI: a blob of another ABI version (a pickled
+  // TopHits, a rank running an older library) is rejected, not mis-parsed
+  uint32_t abi = (uint32_t) P7X_ABI_VERSION, cfg_bytes = (uint32_t) sizeof(p7x_pipeline_cfg); w.pod(abi); w.pod(cfg_bytes);
   w.pod(th->cfg); w.pod(th->ctr);
   w.str(th->qname); w.str(th->qacc); w.str(th->qdesc); w.pod(th->q_has_acc); w.pod(th->q_has_desc); w.pod(th->M); w.pod(th->scan_collected);
   for (int i = 0; i < 16; ++i) w.pod(th->ms[i]);
@@ -1040,6 +1045,11 @@ p7x_tophits *p7x_tophits_deserialize(const void *buf, size_t n)
   Reader r{ (const uint8_t *) buf, (const uint8_t *) buf + n };
   uint32_t magic = 0; r.pod(magic);
   if (!r.ok || magic != kMagic) { set_error("not a serialised TopHits"); return nullptr; }
+  uint32_t abi = 0, cfg_bytes = 0; r.pod(abi); r.pod(cfg_bytes);
+  if (!r.ok || abi != (uint32_t) P7X_ABI_VERSION || cfg_bytes != (uint32_t) sizeof(p7x_pipeline_cfg)) {
+    set_error("serialised TopHits of another library version (ABI " + std::to_string(abi) + ", this library " + std::to_string(P7X_ABI_VERSION) + ")");
+    return nullptr;
+  }
   auto th = std::make_unique<p7x_tophits>();
   r.pod(th->cfg); r.pod(th->ctr);
   r.str(th->qname); r.str(th->qacc); r.str(th->qdesc); r.pod(th->q_has_acc); r.pod(th->q_has_desc); r.pod(th->M); r.pod(th->scan_collected);

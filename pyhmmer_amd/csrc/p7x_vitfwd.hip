@@ -658,18 +658,20 @@ int vit_pick_C(int M)
 }
 
 // occupancy and the LDS opt-in of one kernel instantiation, looked up once
-struct KernelInfo { std::mutex mu; std::map<const void *, int> per_cu; };
+struct KernelInfo { std::mutex mu; std::map<std::pair<int, const void *>, int> per_cu; };      // by (device, kernel): the opt-in is per device
 static KernelInfo &kernel_info() { static KernelInfo *k = new KernelInfo(); return *k; }
 template <typename K>
 static int blocks_per_cu(K kernel, size_t lds_bytes, int *out)
 {
   KernelInfo &ki = kernel_info();
   std::lock_guard<std::mutex> lk(ki.mu);
-  const void *key = reinterpret_cast<const void *>(kernel);
+  int dev = 0; P7X_HIP(hipGetDevice(&dev));
+  const void *fn = reinterpret_cast<const void *>(kernel);
+  const std::pair<int, const void *> key(dev, fn);
   auto it = ki.per_cu.find(key);
   if (it != ki.per_cu.end()) { *out = it->second; return P7X_OK; }
   if (lds_bytes > 64 * 1024)
-    P7X_HIP(hipFuncSetAttribute(key, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds_bytes));
+    P7X_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds_bytes));
   int per_cu = 0;
   P7X_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, kWsBlock, lds_bytes));
   if (per_cu < 1) per_cu = 1;

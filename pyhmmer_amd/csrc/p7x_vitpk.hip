@@ -16,6 +16,7 @@
 //     is evaluated in full: two packed ops per register walk every stripe, the carry into the next stripe is a
 //     stripe shift, passes repeat until nothing improves (two on average).
 // Results are bit-identical to p7x_vitfwd.hip::vit_kernel and to the oracle (tests/test_gpu_filters.py).
+#include <map>
 #include "p7x_wave.hpp"
 #include <mutex>
 
@@ -271,17 +272,19 @@ static int launch_pk(const ArgRun<VitPkArgs> &a, int num_cu, hipStream_t st)
 {
   const size_t lds = ((size_t) 2 * P * T + (size_t) a.at(0).nrows * vitpk_rowq(T, P)) * 16;
   auto kern = vitpk_kernel<T, P>;
-  static int per_cu_cached = 0;
+  static std::map<int, int> per_cu_by_device;       // the LDS opt-in is a per-device attribute of the kernel: looked up once per device
   static std::mutex mu;
   int per_cu = 0;
   {
+    int dev = 0; P7X_HIP(hipGetDevice(&dev));
     std::lock_guard<std::mutex> lk(mu);
-    if (per_cu_cached == 0) {
+    int &cached = per_cu_by_device[dev];
+    if (cached == 0) {
       if (lds > 64 * 1024) P7X_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds));
-      P7X_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu_cached, kern, 256, lds));
-      if (per_cu_cached < 1) per_cu_cached = 1;
+      P7X_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&cached, kern, 256, lds));
+      if (cached < 1) cached = 1;
     }
-    per_cu = per_cu_cached;
+    per_cu = cached;
   }
   long want = 0;
   for (int i = 0; i < a.n; ++i) want = std::max<long>(want, ((long) a.at(i).nlist + 4 * (64 / T) - 1) / (4 * (64 / T)));   // nlist bounds the list

@@ -47,6 +47,15 @@ def make_chunks(block: DigitalSequenceBlock, n: int) -> List[DigitalSequenceBloc
     return chunks
 
 
+def default_devices() -> List[int]:
+    """Every HIP device the process can see: what a search uses when the caller names none -- the reference's default is
+    the whole machine as well (``cpus=0``: every physical core, ``_hmmsearch.py:384``).  ``HIP_VISIBLE_DEVICES`` /
+    ``ROCR_VISIBLE_DEVICES`` narrow it, as ``cpus=`` or ``taskset`` narrow the reference's; a process that drives one GPU
+    of a node (one rank per GPU under ``torch.distributed``) passes ``devices=[local_rank]`` or a resident
+    ``SequenceDatabase``."""
+    return list(range(max(1, int(_lib.lib().p7x_device_count()))))
+
+
 class ShardedDatabase:
     """Target block sharded by residues over several devices; each shard is a :class:`SequenceDatabase`."""
 
@@ -64,6 +73,17 @@ class ShardedDatabase:
         self.devices = [database.device]
         self.chunks = [database.block]
         self.shards = [database]
+        return self
+
+    @classmethod
+    def from_databases(cls, databases: Sequence[SequenceDatabase]) -> "ShardedDatabase":
+        """Shards that the caller packed and made resident itself, one per device (``SequenceDatabase.from_packed``): the
+        targets of shard k follow those of shard k - 1 in the merged hit lists' accounting, as chunks of one block would."""
+        self = cls.__new__(cls)
+        self.block = None
+        self.devices = [d.device for d in databases]
+        self.chunks = [d.block for d in databases]
+        self.shards = list(databases)
         return self
 
     # A "pending" search is a list with one entry per shard: the (handle, profiles, database, labels) tuple of
@@ -97,6 +117,23 @@ class ShardedDatabase:
         concatenate, sum the counters and ``Z``, re-threshold, re-sort -- reference ``_hmmsearch.py:259-263``)."""
         per_shard: list = []
         todo = list(pendings)
+        if len(todo) > 1:
+            # the host stage of a shard is mostly a wait for its own device (envelope kernel, ensembles: tens of milliseconds):
+            # the shards' stages run side by side, one thread each -- one after the other they would add up to a host stage
+            # of N x that per batch and starve N devices (the C call releases the GIL)
+            pool = getattr(self, "_finish_pool", None)
+            if pool is None:
+                pool = self._finish_pool = ThreadPoolExecutor(max_workers=len(self.shards), thread_name_prefix="p7x-shard-finish")
+            futs = [pool.submit(Pipeline._search_finish_batch, pend) for pend in todo]      # every handle is consumed, also on failure
+            err = None
+            for f in futs:
+                try:
+                    per_shard.append(f.result())
+                except BaseException as e:          # noqa: BLE001 - the other shards finish (they own device buffers), then it surfaces
+                    err = err or e
+            if err is not None:
+                raise err
+            return [hits[0].merge(*hits[1:]) for hits in zip(*per_shard)]
         try:
             while todo:
                 pend = todo.pop(0)                      # finish consumes the handle, also when it fails
@@ -104,9 +141,7 @@ class ShardedDatabase:
         except BaseException:
             self.abandon(todo)
             raise
-        if len(per_shard) == 1:
-            return per_shard[0]
-        return [hits[0].merge(*hits[1:]) for hits in zip(*per_shard)]
+        return per_shard[0]
 
     def search(self, pipelines: Sequence[Pipeline], queries) -> List[TopHits]:
         pendings = self.enqueue(pipelines, queries)
@@ -180,7 +215,8 @@ def hmmsearch(queries: Union[HMM, Profile, OptimizedProfile, Iterable], sequence
     targets), ``builder`` only applies to sequence / MSA queries, which this path does not build HMMs from, and a
     search cannot time out waiting for workers.
 
-    ``devices`` lists the HIP devices to shard the targets over (default: device 0).  ``cpus`` is accepted for
+    ``devices`` lists the HIP devices to shard the targets over; by default every device the process sees
+    (:func:`default_devices`: the reference's default is the whole machine too, ``cpus=0``, ``_hmmsearch.py:384``).  ``cpus`` is accepted for
     signature compatibility and sets the number of host threads used for domain definition.  All other keyword
     arguments are forwarded to :class:`~pyhmmer_amd.plan7.Pipeline` (reference ``_hmmsearch.py:294-436``).
 
@@ -216,20 +252,23 @@ def hmmsearch(queries: Union[HMM, Profile, OptimizedProfile, Iterable], sequence
         if ndev < 1:
             from .errors import DeviceUnavailable
             raise DeviceUnavailable("hmmsearch: no HIP device is usable and there is no CPU fallback")
-        yield from _search_file(queries, sequences, chunk_bytes or (1 << 30), list(devices) if devices else [0], cpus, callback,
+        yield from _search_file(queries, sequences, chunk_bytes or (1 << 30), list(devices) if devices else default_devices(), cpus, callback,
                                 pipeline_depth, feeders, batch, options, finishers=finishers)
         return
-    if not isinstance(sequences, (DigitalSequenceBlock, SequenceDatabase)):
+    if not isinstance(sequences, (DigitalSequenceBlock, SequenceDatabase, ShardedDatabase)):
         raise TypeError(f"Expected DigitalSequenceBlock or SequenceFile, found {type(sequences).__name__}")
-    alphabet: Alphabet = sequences.alphabet
+    alphabet: Alphabet = sequences.shards[0].alphabet if isinstance(sequences, ShardedDatabase) else sequences.alphabet
     if ndev < 1:
         from .errors import DeviceUnavailable
         raise DeviceUnavailable("hmmsearch: no HIP device is usable and there is no CPU fallback")
     if isinstance(sequences, SequenceDatabase):
         db = ShardedDatabase.from_database(sequences)
         devs = db.devices
+    elif isinstance(sequences, ShardedDatabase):
+        db = sequences                              # shards resident on their devices already
+        devs = db.devices
     else:
-        devs = list(devices) if devices else [0]
+        devs = list(devices) if devices else default_devices()
         db = ShardedDatabase(sequences, devs)
     pipelines = [Pipeline(alphabet, device=d, host_threads=cpus, **options) for d in devs]
     total = None
@@ -697,13 +736,22 @@ def hmmscan(queries, profiles, *, cpus: int = 0, callback: Optional[Callable] = 
     # The queries are taken a block at a time (the reference takes them one at a time, plan7.pyx:6680-6737): a block is
     # scanned against the whole profile database and its results are handed out before the next block is read, so a query
     # file of any size streams through, and the first results arrive after one pass over the profiles, not after all of them.
-    if not hasattr(profiles, "rewind") and not isinstance(profiles, (list, tuple)):
-        profiles = list(profiles)                  # a one-shot iterable is walked once per query block
-    devs = list(devices) if devices else [0]
+    devs = list(devices) if devices else default_devices()
     seen = 0
-    for block in _query_blocks(queries, query_block_sequences, query_block_residues):
-        if len(block) == 0:
-            continue
+    # A one-shot iterable of profiles (a generator streaming a library) is walked once per query block: it is held in
+    # memory only if a second block of queries really arrives -- with one block (the usual case: a proteome is a fraction of
+    # a block) the profiles stream through batch by batch, as they do in the reference.
+    blocks = (b for b in _query_blocks(queries, query_block_sequences, query_block_residues) if len(b) > 0)
+    one_shot = not hasattr(profiles, "rewind") and not isinstance(profiles, (list, tuple))
+    ahead = []
+    if one_shot:
+        for b in blocks:
+            ahead.append(b)
+            if len(ahead) == 2:
+                profiles = list(profiles)
+                break
+    import itertools as _it
+    for block in _it.chain(ahead, blocks):
         if seen and hasattr(profiles, "rewind"):
             profiles.rewind()
         seen += 1
@@ -810,16 +858,31 @@ def nhmmer(queries, sequences, *, cpus: int = 0, callback: Optional[Callable] = 
         raise DeviceUnavailable("nhmmer: no HIP device is usable and there is no CPU fallback")
     if devices is not None and len(devices) == 0:
         raise ValueError("devices must name at least one device")
-    pipeline = LongTargetsPipeline(sequences.alphabet, device=(devices[0] if devices else 0), host_threads=cpus, **options)
+    if devices is None:
+        devices = default_devices()                 # the units of a search are dealt over every device the process sees
+    pipeline = LongTargetsPipeline(sequences.alphabet, device=devices[0], host_threads=cpus, **options)
     total = None
     try:
         total = len(queries)          # type: ignore[arg-type]
     except TypeError:
         pass
-    def search(q):
+    def prepare(q):
+        # what a search reads from and writes to the query object (the profile it scans with, hmm.max_length's replacement) is
+        # settled here, on the caller's thread and in query order: the searches themselves overlap, and the same HMM object may
+        # be in flight twice
         if not isinstance(q, (HMM, Profile, OptimizedProfile)):
             raise TypeError(f"Unsupported query type for `nhmmer`: {type(q).__name__} (build an HMM from it first)")
-        return pipeline.search_hmm(q, sequences, devices=devices)      # the units of one search dealt over the devices
+        if q.alphabet != pipeline.alphabet:
+            from .errors import AlphabetMismatch
+            raise AlphabetMismatch(pipeline.alphabet, q.alphabet)
+        if isinstance(q, (Profile, OptimizedProfile)) and pipeline.window_length is None and (getattr(q, "max_length", None) or -1) <= 0:
+            raise TypeError("Cannot use `Profile` or `OptimizedProfile` query without `max_length` set")     # plan7.pyx:7354
+        return pipeline._prepare_query(q, sequences)
+
+    def search(q, prepared=None):
+        if prepared is None:
+            prepared = prepare(q)
+        return pipeline.search_hmm(q, sequences, devices=devices, _prepared=prepared)      # the units of one search dealt over the devices
 
     if searches_in_flight <= 1:
         for q in queries:
@@ -834,7 +897,13 @@ def nhmmer(queries, sequences, *, cpus: int = 0, callback: Optional[Callable] = 
     with ThreadPoolExecutor(max_workers=searches_in_flight, thread_name_prefix="p7x-nhmmer") as pool:
         try:
             for q in queries:
-                inflight.append((q, pool.submit(search, q)))
+                try:
+                    fut = pool.submit(search, q, prepare(q))
+                except Exception as e:              # noqa: BLE001 - surfaces at this query's position, after the results before it
+                    from concurrent.futures import Future
+                    fut = Future()
+                    fut.set_exception(e)
+                inflight.append((q, fut))
                 while len(inflight) >= searches_in_flight:
                     q0, fut = inflight.popleft()
                     hits = fut.result()

@@ -15,6 +15,7 @@ import weakref
 from typing import Iterable, Iterator, List, Optional, Sequence, Union
 
 import itertools
+import threading
 
 import numpy as np
 
@@ -1613,7 +1614,19 @@ class LongTargetsPipeline(Pipeline):
         descs = (C.c_char_p * max(n, 1))(*[(s.description or "").encode() for s in sequences])
         return dsq, offsets, lengths, names, accs, descs
 
-    def search_hmm(self, query, sequences, devices: Optional[Sequence[int]] = None) -> "TopHits":
+    def _prepare_query(self, query, sequences):
+        """The per-query state of a search -- the optimized profile, the configuration record with the two window lengths,
+        and the replacement of ``hmm.max_length`` (reference ``plan7.pyx:7336-7354``).  It reads and writes the query object,
+        so it runs on the caller's thread, in query order, before a search is handed to a worker: ``hmmer.nhmmer`` keeps
+        several searches in flight, and two of them may hold the same HMM object."""
+        L = len(sequences[0]) if len(sequences) else self.L_HINT
+        cfg = self._cfg()
+        om = self._windowed_om(query, min(L, 100000), cfg)
+        if self.bit_cutoffs is not None and not getattr(om.cutoffs, self.bit_cutoffs + "_available")():
+            raise MissingCutoffs(om.name, self.bit_cutoffs)
+        return om, cfg
+
+    def search_hmm(self, query, sequences, devices: Optional[Sequence[int]] = None, _prepared=None) -> "TopHits":
         """``nhmmer`` with ``query`` against the long targets of ``sequences`` (reference ``plan7.pyx:7272-7418``).
 
         ``devices``: deal the (target, block, strand) units of the search -- the iterations of the reference's loop
@@ -1632,11 +1645,9 @@ class LongTargetsPipeline(Pipeline):
             raise AlphabetMismatch(self.alphabet, sequences.alphabet)
         if isinstance(query, (Profile, OptimizedProfile)) and self.window_length is None and (getattr(query, "max_length", None) or -1) <= 0:
             raise TypeError("Cannot use `Profile` or `OptimizedProfile` query without `max_length` set")     # plan7.pyx:7354
-        L = len(sequences[0]) if len(sequences) else self.L_HINT
-        cfg = self._cfg()
-        om = self._windowed_om(query, min(L, 100000), cfg)
-        if self.bit_cutoffs is not None and not getattr(om.cutoffs, self.bit_cutoffs + "_available")():
-            raise MissingCutoffs(om.name, self.bit_cutoffs)
+        if _prepared is None:
+            _prepared = self._prepare_query(query, sequences)
+        om, cfg = _prepared
         if isinstance(sequences, DigitalSequenceBlock) and all(len(s) < 2 ** 31 for s in sequences):
             # the block's cached flat image (the same "255 x1..xL 255 ..." layout): a chromosome is not copied per query
             pk = sequences.packed()
@@ -1644,15 +1655,16 @@ class LongTargetsPipeline(Pipeline):
             dsq, offsets, lengths = pk.dsq, pk.offsets, pk.lengths.astype(np.int64)
             # ... nor uploaded per query: the image is immutable (a mutated block gets a new one), its token lets the device
             # keep its copy between searches (cfg.lt_resident_key; one copy per device)
-            tok = getattr(pk, "_resident_token", None)
-            if tok is None:
-                tok = next(_RESIDENT_TOKENS)
-                try:
-                    pk._resident_token = tok
-                    # the device copies go when the image does (p7x_longtargets_release_resident: every device, this key)
-                    weakref.finalize(pk, _release_resident, tok)
-                except (AttributeError, TypeError):
-                    tok = 0
+            with _RESIDENT_LOCK:                # one token and one finalizer per image, whoever asks first
+                tok = getattr(pk, "_resident_token", None)
+                if tok is None:
+                    tok = next(_RESIDENT_TOKENS)
+                    try:
+                        pk._resident_token = tok
+                        # the device copies go when the image does (p7x_longtargets_release_resident: every device, this key)
+                        weakref.finalize(pk, _release_resident, tok)
+                    except (AttributeError, TypeError):
+                        tok = 0
             cfg.lt_resident_key = tok
             names = (C.c_char_p * max(n, 1))(*[s.name.encode() for s in sequences])
             accs = (C.c_char_p * max(n, 1))(*[(s.accession or "").encode() for s in sequences])
@@ -1701,6 +1713,7 @@ class LongTargetsPipeline(Pipeline):
 
 
 _RESIDENT_TOKENS = itertools.count(1)          # one per packed image whose device copy may be kept (cfg.lt_resident_key)
+_RESIDENT_LOCK = threading.Lock()
 
 
 def _release_resident(token: int) -> None:

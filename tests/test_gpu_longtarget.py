@@ -390,3 +390,20 @@ def test_device_long_target_search_against_the_oracle_restatement():
     for where in (1, 2):
         other = next(iter(hmmer.nhmmer([hmm], block, host_envelopes=where)))
         lc.check_hits_against_oracle(pli, hmm, seq, other, min_windows=1000, min_short=30, oracle=want)
+
+
+def test_overlapping_searches_of_one_hmm_object_equal_the_sequential_ones():
+    """hmmer.nhmmer overlaps consecutive searches (searches_in_flight = 2) on one shared pipeline; with [hmm] * n the same HMM
+    object is in flight twice.  ADVICE r04: the per-query state is prepared in query order on the caller's thread, the scans
+    of overlapping searches take turns at the device, the target set is uploaded once: every result equals the result of
+    the queries run one after the other."""
+    import bench_workloads as bw
+    abc = load_hmms("bmyD")[0].alphabet
+    chrom = bw.make_chromosome(load_hmms("bmyD")[0], 3_000_000, planted=25, seed=5)
+    block = easel.DigitalSequenceBlock(abc, [easel.DigitalSequence(abc, name="chr", sequence=chrom)])
+    hmm = load_hmms("bmyD")[0]
+    seq = [_rows(h) for h in hmmer.nhmmer([hmm] * 5, block, searches_in_flight=1, window_beta=1e-3)]
+    hmm = load_hmms("bmyD")[0]
+    par = [_rows(h) for h in hmmer.nhmmer([hmm] * 5, block, searches_in_flight=3, window_beta=1e-3)]
+    assert len(seq[0]) > 10 and seq == par
+    assert seq[1] == seq[2] == seq[4]                      # from the second search on the replaced max_length is in force

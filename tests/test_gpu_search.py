@@ -10,7 +10,7 @@ import pytest
 
 from conftest import golden_table, synthetic_block
 from golden_checks import check_domtbl as _check_domtbl, check_tbl as _check_tbl
-from pyhmmer_amd import easel, errors, hmmer, plan7
+from pyhmmer_amd import _lib, easel, errors, hmmer, plan7
 from test_oracle_golden import STAGE_COUNTS
 
 pytestmark = pytest.mark.gpu
@@ -584,3 +584,43 @@ def test_hmmscan_streams_a_query_file_in_blocks(models, golden):
     with easel.SequenceFile(path, digital=True, alphabet=abc) as sf, plan7.HMMFile(golden / "hmms" / "RREFam.hmm") as hf:
         got = table(hmmer.hmmscan(sf, hf, query_block_residues=200_000))           # native chunk reads, the profile file rewound per block
     assert got == table(hmmer.hmmscan(whole, models["RREFam"]))
+
+
+def test_in_process_search_over_four_devices_equals_one(models, proteome):
+    """hmmer.hmmsearch / hmmscan default to every visible device, one process driving all of them (round 5; the reference's
+    default is the whole machine, _hmmsearch.py:384).  The one device of the test box listed four times exercises the in-process
+    N-device path -- four shards enqueued by one feeder, their host stages finished side by side on the shard pool, the per-query
+    merge -- for both orientations; merged == whole."""
+    assert hmmer.default_devices() == list(range(max(1, _lib.lib().p7x_device_count())))
+    queries = models["PF02826"] + models["RREFam"][:4] + models["Thioesterase"]
+    whole = list(hmmer.hmmsearch(queries, proteome, devices=[0]))
+    four = list(hmmer.hmmsearch(queries, proteome, devices=[0, 0, 0, 0]))
+    assert len(whole) == len(four) == len(queries)
+    for a, b in zip(four, whole):
+        assert a.Z == b.Z == len(proteome) and a.domZ == b.domZ and a.stage_counts == b.stage_counts
+        assert [(h.name, h.score, h.evalue, h.reported, h.included, [(d.env_from, d.env_to, d.score, d.alignment.target_sequence) for d in h.domains]) for h in a] == \
+               [(h.name, h.score, h.evalue, h.reported, h.included, [(d.env_from, d.env_to, d.score, d.alignment.target_sequence) for d in h.domains]) for h in b]
+    # resident shards handed in by the caller (what bench.py --inproc-devices does)
+    shards = hmmer.ShardedDatabase(proteome, [0, 0, 0])
+    again = list(hmmer.hmmsearch(queries, shards))
+    assert [[h.name for h in t] for t in again] == [[h.name for h in t] for t in whole]
+    sub = proteome[:500]
+    profs = (models["RREFam"] + models["PF02826"]) * 2
+    one = list(hmmer.hmmscan(sub, profs, devices=[0], batch=3))
+    many = list(hmmer.hmmscan(sub, profs, devices=[0, 0, 0, 0], batch=3))
+    assert [[(h.name, h.score, h.evalue) for h in t] for t in one] == [[(h.name, h.score, h.evalue) for h in t] for t in many]
+
+
+def test_a_failing_ensemble_workspace_sends_the_regions_to_the_host(models, proteome):
+    """an allocation or launch failure of the device ensembles must not fail the search -- every region can be
+    sampled by the host workers, with the same result (seam ens_fail makes DeviceEnsembleRunner::begin fail)."""
+    hmm = models["PF02826"][0]
+    want = plan7.Pipeline(hmm.alphabet).search_hmm(hmm, proteome)
+    assert sum(h.nclustered for h in want) > 0           # the fixture has multi-domain regions: the ensembles do run
+    _lib.set_debug_option("ens_fail", 1)
+    try:
+        got = plan7.Pipeline(hmm.alphabet).search_hmm(hmm, proteome)
+    finally:
+        _lib.set_debug_option("ens_fail", -1)
+    assert [(h.name, h.score, h.nregions, h.nclustered, h.nenvelopes, [(d.env_from, d.env_to, d.score) for d in h.domains]) for h in got] == \
+           [(h.name, h.score, h.nregions, h.nclustered, h.nenvelopes, [(d.env_from, d.env_to, d.score) for d in h.domains]) for h in want]

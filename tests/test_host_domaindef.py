@@ -145,6 +145,16 @@ def test_host_tophits_api(models, oracle, proteome):
     # pickling round trip
     again = pickle.loads(pickle.dumps(hits))
     assert [(h.name, h.score, h.evalue, h.included) for h in again] == [(h.name, h.score, h.evalue, h.included) for h in hits]
+    # ... and a blob written by another version of the library is rejected, not mis-parsed (the layout follows the ABI's
+    # configuration record: the ABI version and the record's size travel behind the magic)
+    blob = bytearray(hits.to_bytes())
+    assert int.from_bytes(blob[4:8], "little") == 7
+    blob[4:8] = (6).to_bytes(4, "little")
+    with pytest.raises(ValueError, match="another library version"):
+        plan7.TopHits.from_bytes(bytes(blob), None)
+    blob[0:4] = b"nope"
+    with pytest.raises(ValueError):
+        plan7.TopHits.from_bytes(bytes(blob), None)
     # manual flags
     hits[0].reported = False
     assert len(hits.reported) == 21 and not hits[0].reported and len(hits.included) == 14

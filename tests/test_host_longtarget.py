@@ -345,3 +345,30 @@ def test_a_dozen_nodes_against_the_oracle_restatement(oracle):
     windows = lc.oracle_windows(pli, hmm, seq)
     lc.check_hits_against_oracle(pli, hmm, seq, hits, oracle=windows)
     assert lc.check_hit_coordinates_against_oracle(pli, hmm, seq, hits, oracle=windows)[0] >= len(hits) - 2 and len(hits) >= 10
+
+
+def test_per_query_state_is_settled_before_a_search_is_handed_to_a_worker(libp7x):
+    """hmmer.nhmmer keeps two searches in flight, and [hmm] * n puts the SAME object into both.  What a search
+    reads from and writes to its query (the profile it scans with, the replacement of hmm.max_length, plan7.pyx:7336-7354)
+    is settled by LongTargetsPipeline._prepare_query on the caller's thread, in query order: the first preparation scans with
+    the file's MAXL, every later one with the replaced value, whatever the timing of the searches themselves."""
+    hmm = load_hmms("bmyD")[0]
+    block = easel.DigitalSequenceBlock(hmm.alphabet, [easel.DigitalSequence(hmm.alphabet, name="t", sequence=np.zeros(5000, dtype=np.uint8))])
+    pli = plan7.LongTargetsPipeline(hmm.alphabet, window_beta=1e-3)
+    om1, cfg1 = pli._prepare_query(hmm, block)
+    om2, cfg2 = pli._prepare_query(hmm, block)
+    assert om1._info.max_length == 1736 and om2._info.max_length == cfg1.evalue_window_length == cfg2.evalue_window_length == hmm.max_length
+    assert 1203 < hmm.max_length < 1736
+    # the residency token of a packed image is minted once, under a lock
+    import threading
+    pk = block.packed()
+    toks = []
+    def grab():
+        with plan7._RESIDENT_LOCK:
+            tok = getattr(pk, "_resident_token", None)
+            if tok is None:
+                tok = next(plan7._RESIDENT_TOKENS); pk._resident_token = tok
+        toks.append(tok)
+    ts = [threading.Thread(target=grab) for _ in range(8)]
+    [t.start() for t in ts]; [t.join() for t in ts]
+    assert len(set(toks)) == 1
