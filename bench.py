@@ -37,12 +37,10 @@ VALU_LANE_OPS_PER_S = 256 * 4 * 16 * 2.4e9    # 256 CU x 4 SIMD x 16 lanes/clk x
                                               # wave64 (PMC: SQ_ACTIVE_INST_VALU == SQ_INSTS_VALU quad-cycles, profiles/r01_bench_pmc.md)
 MSV_OPS_PER_CELL = 0.75          # fast MSV kernel since round 5: two v_pk_add_f16 clamp + ONE v_pk_maximum3_f16 per two registers,
                                  # i.e. three packed instructions per four cells (p7x_msv.hip; 1.0 with the int16 flavour of rounds 1-4)
-VALU_SUSTAINED_LANE_OPS_PER_S = 35600.0e9 * 1.0   # packed ops held for 30-140 ms with every SIMD busy (scripts/ubench/sustained,
-                                 # profiles/r02_sustained_ubench.md, r05_sustained_ubench.md): 2.17 GHz-equivalent, as cells/s of a
-                                 # 1.0-op-per-cell kernel
-VALU_SUSTAINED_GCUPS = VALU_SUSTAINED_LANE_OPS_PER_S / MSV_OPS_PER_CELL / 1e9     # ... of the MSV kernel's own op count
-MSV_SUSTAINED_MIX_GCUPS = 41800.0     # the kernel's mix with its LDS reads (one conflict-free ds_read_b64 per three packed ops), held
-                                      # 30-140 ms: profiles/r05_sustained_ubench.md
+VALU_SUSTAINED_GCUPS = 49500.0   # the kernel's three packed ops per four cells and nothing else, held for 20-100 ms with every SIMD
+                                 # busy in the MSV launch shape (scripts/ubench/sustained, profiles/r05_sustained_ubench.md): the
+                                 # packed-op roof in wall-clock terms (2.27 GHz-equivalent; 35,600 with the int16 flavour's four ops)
+MSV_SUSTAINED_MIX_GCUPS = 41000.0     # ... with the kernel's LDS reads (one conflict-free ds_read_b64 per three packed ops): same file
 F32_LANE_OPS_PER_S = 256 * 4 * 32 * 2.4e9     # two-source f32 VOP2 ops issue in 2 cycles per wave64 (profiles/r03_pk_issue_fma.md)
 # Static instruction counts per DP row of the kernels behind the headline's tail, from the ISA of the instantiations that
 # serve M = 262 (KR: 5 nodes per lane; scripts/isa_inner_loops.py): wave64 instructions per row of one

@@ -207,12 +207,23 @@ int p7x_seqdb_create(int device, int32_t abc_type, const uint8_t *dsq, const int
   }
   db->h_grp_len.resize((size_t) G); db->h_grp_suffix.assign((size_t) G + 1, 0);
   for (int64_t g = G - 1; g >= 0; --g) { db->h_grp_len[g] = slot_len[g * 64]; db->h_grp_suffix[g] = db->h_grp_suffix[g + 1] + slot_len[g * 64]; }
-  P7X_HIP(hipMalloc(&db->d_dsq, db->h_dsq.size()));
-  P7X_HIP(hipMalloc(&db->d_slot_off, slot_off.size() * 8));
-  P7X_HIP(hipMalloc(&db->d_slot_len, slot_len.size() * 4));
-  P7X_HIP(hipMalloc(&db->d_grp_off, grp_off.size() * 8));
-  P7X_HIP(hipMalloc(&db->d_grp_nblk, grp_nblk.size() * 4));
-  P7X_HIP(hipMalloc(&db->d_tiles, (size_t) std::max<int64_t>(u4, 1) * 16));
+  {   // one slab of the context's pool for the six arrays: a block of long-target windows comes and goes with every stage of
+      // every nhmmer search, and hipMalloc / hipFree wait for ALL work queued on the device -- the scan and the envelope
+      // kernels of the other searches in flight (round 5: with them, searches in flight did not overlap at all)
+    auto up = [](size_t v) { return (v + 255) & ~(size_t) 255; };
+    const size_t b_dsq = up(db->h_dsq.size()), b_off = up(slot_off.size() * 8), b_len = up(slot_len.size() * 4), b_goff = up(grp_off.size() * 8),
+                 b_nblk = up(grp_nblk.size() * 4), b_tiles = up((size_t) std::max<int64_t>(u4, 1) * 16);
+    void *base = nullptr;
+    if ((st = slab_acquire(ctx, b_dsq + b_off + b_len + b_goff + b_nblk + b_tiles, &base, &db->slab_bytes)) != P7X_OK) return st;
+    db->slab = base;
+    unsigned char *q = static_cast<unsigned char *>(base);
+    db->d_tiles = reinterpret_cast<uint4 *>(q); q += b_tiles;            // 16-byte elements first
+    db->d_slot_off = reinterpret_cast<int64_t *>(q); q += b_off;
+    db->d_grp_off = reinterpret_cast<int64_t *>(q); q += b_goff;
+    db->d_slot_len = reinterpret_cast<int32_t *>(q); q += b_len;
+    db->d_grp_nblk = reinterpret_cast<int32_t *>(q); q += b_nblk;
+    db->d_dsq = q;
+  }
   P7X_HIP(hipMemcpy(db->d_dsq, db->h_dsq.data(), db->h_dsq.size(), hipMemcpyHostToDevice));
   P7X_HIP(hipMemcpy(db->d_slot_off, slot_off.data(), slot_off.size() * 8, hipMemcpyHostToDevice));
   P7X_HIP(hipMemcpy(db->d_slot_len, slot_len.data(), slot_len.size() * 4, hipMemcpyHostToDevice));
@@ -232,8 +243,8 @@ void p7x_seqdb_destroy(p7x_seqdb *db)
 {
   if (!db) return;
   (void) hipSetDevice(db->device);
-  (void) hipFree(db->d_dsq); (void) hipFree(db->d_slot_off); (void) hipFree(db->d_slot_len);
-  (void) hipFree(db->d_grp_off); (void) hipFree(db->d_grp_nblk); (void) hipFree(db->d_tiles);
+  DeviceCtx *ctx = nullptr;
+  if (db->slab && get_ctx(db->device, &ctx) == P7X_OK) slab_release(ctx, db->slab, db->slab_bytes);      // back to the pool: no device-wide wait
   delete db;
 }
 

@@ -42,6 +42,11 @@ struct DeviceCtx {
   // one's tail runs, its stream synchronisation waits for its own work only, its events time its own kernel, and the
   // first search's upload of a keyed target set is found, not repeated, by the second.
   std::mutex lt_scan_mu;
+  // streams of the long-target window stages, one per search in flight (taken in turn): on the context's one stream the
+  // window kernels of one search queued behind the other search's 20 ms scan
+  static constexpr int kLtStreams = 4;
+  hipStream_t lt_stream[kLtStreams]{};
+  int lt_next = 0;                      // guarded by mu
   hipEvent_t msv_done[2] = { nullptr, nullptr };
   int msv_last = -1;
   // Device images of query profiles come and go with every query (a scan walks through thousands of models):
@@ -145,4 +150,5 @@ struct p7x_seqdb {
   int64_t *d_grp_off = nullptr;    // [ngroups] first uint4 of the group
   int32_t *d_grp_nblk = nullptr;   // [ngroups] number of 16-residue blocks
   int64_t tile_u4 = 0;
+  void *slab = nullptr; size_t slab_bytes = 0;      // the six device arrays are cut from one slab of the context's pool
 };

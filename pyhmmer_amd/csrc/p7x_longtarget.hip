@@ -18,11 +18,21 @@ namespace p7x {
 
 namespace {
 
+// a device buffer from the context's slab pool (hipMalloc / hipFree wait for every stream of the device: see p7x_seqdb_create)
 struct DevBuf {
-  void *p = nullptr;
-  ~DevBuf() { if (p) (void) hipFree(p); }
-  int alloc(size_t bytes) { if (p) (void) hipFree(p); p = nullptr; P7X_HIP(hipMalloc(&p, std::max<size_t>(bytes, 16))); return P7X_OK; }
+  DeviceCtx *ctx = nullptr; void *p = nullptr; size_t bytes = 0;
+  explicit DevBuf(DeviceCtx *c) : ctx(c) {}
+  DevBuf(const DevBuf &) = delete; DevBuf &operator=(const DevBuf &) = delete;
+  ~DevBuf() { if (p) slab_release(ctx, p, bytes); }
+  int alloc(size_t want) { if (p) { slab_release(ctx, p, bytes); p = nullptr; bytes = 0; } return slab_acquire(ctx, std::max<size_t>(want, 16), &p, &bytes); }
 };
+static hipStream_t lt_window_stream(DeviceCtx *ctx)
+{
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  const int k = ctx->lt_next; ctx->lt_next = (k + 1) % DeviceCtx::kLtStreams;
+  if (!ctx->lt_stream[k] && hipStreamCreateWithFlags(&ctx->lt_stream[k], hipStreamNonBlocking) != hipSuccess) { (void) hipGetLastError(); return ctx->stream; }
+  return ctx->lt_stream[k];
+}
 
 struct ScanRow { int64_t pos; int strand, k, sc; };
 
@@ -105,7 +115,7 @@ static int scan_target(const p7x_pipeline_cfg &cfg, const Profile &p, DeviceCtx 
     ssvlong_build_tables(p, R, false, tab4q, tab_full, &pair_slack);
   }
   std::lock_guard<std::mutex> scan_turn(ctx->lt_scan_mu);      // one scan at a time per device (see DeviceCtx)
-  DevBuf d_tab4q, d_full, d_comp, d_nrec, d_pos, d_strand, d_k, d_sc;
+  DevBuf d_tab4q{ctx}, d_full{ctx}, d_comp{ctx}, d_nrec{ctx}, d_pos{ctx}, d_strand{ctx}, d_k{ctx}, d_sc{ctx};
   int st;
   if ((st = d_tab4q.alloc(tab4q.size() * 4)) || (st = d_full.alloc(tab_full.size() * 4)) || (st = d_comp.alloc(32)) || (st = d_nrec.alloc(4))) return st;
   hipStream_t s = ctx->stream;
@@ -136,7 +146,7 @@ static int scan_target(const p7x_pipeline_cfg &cfg, const Profile &p, DeviceCtx 
   a.nrec = static_cast<int *>(d_nrec.p);
   a.strand0 = strands_mask == 2 ? 1 : 0;
   a.pair_slack = pair_slack;
-  DevBuf d_chunks;
+  DevBuf d_chunks{ctx};
   if (ranges) {
     std::vector<long long> list;
     for (const ScanRange &r : *ranges) {
@@ -220,6 +230,7 @@ struct DeviceWindowScorer final : LongTargetWindowScorer {
   p7x_seqdb *rdb = nullptr;             // the windows of the last regions() call: envelopes() refers to them
   float oa_guard = 0.0f;
   double ms = 0.0; size_t nwindows = 0;
+  hipStream_t stream = nullptr;         // this search's own, for the long-target Viterbi scan of its windows
   DeviceWindowScorer(const p7x_oprofile *o, int d, float guard) : om(o), device(d), oa_guard(guard) {}
   ~DeviceWindowScorer() override { if (db) p7x_seqdb_destroy(db); if (rdb) p7x_seqdb_destroy(rdb); }
   int score(const uint8_t *seq1, int64_t L, const uint8_t *comp, const LongTargetWindowRef *w, size_t nw, double F1, bool do_bias,
@@ -363,8 +374,8 @@ struct DeviceWindowScorer final : LongTargetWindowScorer {
     for (int64_t sl = 0; sl < db->nslots; ++sl) slot_of[(size_t) db->h_order[(size_t) sl]] = (int32_t) sl;
     std::vector<int32_t> list(n);
     for (size_t i = 0; i < n; ++i) list[i] = slot_of[(size_t) which[i]];
-    hipStream_t s = ctx->stream;
-    DevBuf d_list, d_thr, d_xc, d_nrec, d_rec, d_args;
+    hipStream_t s = stream ? stream : (stream = lt_window_stream(ctx));
+    DevBuf d_list{ctx}, d_thr{ctx}, d_xc{ctx}, d_nrec{ctx}, d_rec{ctx}, d_args{ctx};
     if ((st = d_list.alloc(n * 4)) || (st = d_thr.alloc(n * 4)) || (st = d_xc.alloc(n * 4)) || (st = d_nrec.alloc(4)) || (st = d_args.alloc(sizeof(WaveSeqArgs)))) return st;
     P7X_HIP(hipMemcpyAsync(d_list.p, list.data(), n * 4, hipMemcpyHostToDevice, s));
     P7X_HIP(hipMemcpyAsync(d_thr.p, thresh, n * 4, hipMemcpyHostToDevice, s));

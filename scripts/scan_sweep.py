@@ -14,9 +14,10 @@ block = plan7.OptimizedProfileBlock(proteome.alphabet, (plan7.OptimizedProfile(h
 cells = float(lengths.sum()) * proteome.total_length()
 list(hmmer.hmmscan(proteome, block))
 for batch, feeders, depth, window in [tuple(int(v) for v in a.split(',')) for a in sys.argv[2:]] or [(256, 3, 3, 1), (1024, 3, 3, 1), (2048, 2, 3, 1)]:
-    best = 1e9
-    for rep in range(2):
+    runs = []
+    for rep in range(4):
         t0 = time.perf_counter()
         res = list(hmmer.hmmscan(proteome, block, batch=batch, feeders=feeders, pipeline_depth=depth, window=window))
-        best = min(best, time.perf_counter() - t0)
-    print(f"batch {batch:5d} feeders {feeders} depth {depth} window {window}: {best:.3f} s = {cells / best / 1e9:.0f} GCUPS", flush=True)
+        runs.append(time.perf_counter() - t0)
+    best = min(runs)
+    print(f"batch {batch:5d} feeders {feeders} depth {depth} window {window}: {best:.3f} s = {cells / best / 1e9:.0f} GCUPS (runs {' '.join(f'{r:.3f}' for r in runs)})", flush=True)

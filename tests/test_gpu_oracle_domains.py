@@ -1,0 +1,79 @@
+"""The device's domain definition against the ORACLE's own (oracle/p7_oracle_dd.c), on the GPU box, through hmmer.hmmsearch
+with its defaults -- not against the product's host twin (tests/test_gpu_envelopes.py, test_gpu_ensembles.py do that; VERDICT
+r04 item 3).  Reference: p7_domaindef_ByPosteriorHeuristics (include/libhmmer/p7_domaindef.pxd:23-72), SURVEY.md row a13.
+
+The oracle sums in node order, the device in its lane chunks: a decision that falls on a tie of the two orders may differ
+(an alignment end moved by one residue; in an ensemble region a sampled traceback that takes the other branch, after which
+the region's later samples differ).  Stated tolerances: coordinates of single-domain regions identical in >= 99.5 % of the
+envelopes; ensemble regions identical in >= 90 % of the targets that have one; scores and biases within 2e-3 bit where the
+coordinates agree (p7_FLogsum's table has steps of 1e-3 nat)."""
+import numpy as np
+import pytest
+
+from conftest import load_hmms
+from test_oracle_domains import _homolog_block
+from pyhmmer_amd import easel, hmmer, plan7
+
+pytestmark = pytest.mark.gpu
+
+
+def _compare(oracle, hmm, hits, sequence_of, bg):
+    op = oracle.OracleProfile(hmm, bg, 400)
+    stats = {"hits": 0, "single_env": 0, "single_diff": 0, "ens_targets": 0, "ens_same": 0, "domains": 0}
+    for h in hits:
+        envs, counts = oracle.domains(op, sequence_of(h))
+        ours = [(d.env_from, d.env_to, d.alignment.target_from, d.alignment.target_to, d.alignment.hmm_from, d.alignment.hmm_to) for d in h.domains]
+        theirs = [tuple(int(v) for v in e[:6]) for e in envs]
+        stats["hits"] += 1
+        assert h.nregions == counts[0], (h.name, h.nregions, counts)
+        if counts[2] == 0:                                   # every region holds one domain
+            assert [o[:2] for o in ours] == [t[:2] for t in theirs], (h.name, ours, theirs)          # envelopes: always
+            for o, t, e, d in zip(ours, theirs, envs, h.domains):
+                stats["single_env"] += 1
+                if o != t:
+                    stats["single_diff"] += 1
+                    continue
+                assert abs(d.score - e[9]) <= 2e-3 and abs(d.bias - e[10]) <= 2e-3, (h.name, d.score, e[9], d.bias, e[10])
+                assert abs(d.envelope_score * np.log(2.0) - e[6]) <= 2e-3 * max(1.0, abs(e[6]) / 100.0)
+                stats["domains"] += 1
+            assert (h.nclustered, h.noverlaps, h.nenvelopes) == (0, 0, counts[1]), h.name
+        else:
+            stats["ens_targets"] += 1
+            if ours == theirs:
+                stats["ens_same"] += 1
+                assert (h.nregions, h.nclustered, h.noverlaps, h.nenvelopes) == (counts[0], counts[2], counts[4], counts[1]), h.name
+                for e, d in zip(envs, h.domains):
+                    assert abs(d.score - e[9]) <= 2e-3 and abs(d.bias - e[10]) <= 2e-3, (h.name, d.score, e[9], d.bias, e[10])
+                    stats["domains"] += 1
+    return stats
+
+
+def test_headline_workload_domains_against_the_oracle(oracle):
+    """BASELINE configs[1] at full size (KR x 1,000,000 x 300 aa, 1,000 planted): every domain of every hit of
+    hmmer.hmmsearch (defaults: device cascade, envelope kernel, device ensembles) against oracle.domains of that target."""
+    import bench
+    hmm = load_hmms("KR")[0]
+    bg = plan7.Background(hmm.alphabet)
+    flat, off, ln, planted = bench.make_workload(hmm, 1_000_000, 300, 42)
+    db = plan7.SequenceDatabase.from_packed(hmm.alphabet, flat, off, ln)
+    hits = next(iter(hmmer.hmmsearch(hmm, db)))
+    assert len(hits) >= 1000
+    st = _compare(oracle, hmm, hits, lambda h: np.asarray(flat[off[h.seqidx]:off[h.seqidx] + ln[h.seqidx]], dtype=np.uint8), bg)
+    assert st["hits"] >= 1000 and st["single_env"] >= 900, st
+    assert st["single_diff"] <= max(1, st["single_env"] // 200), st
+    assert st["ens_targets"] == 0 or st["ens_same"] >= 0.9 * st["ens_targets"], st
+
+
+@pytest.mark.parametrize("model", ["PF02826", "KR", "LuxC"])
+def test_multi_domain_targets_against_the_oracle(oracle, model):
+    """Targets with one to three homologous fragments (a third of them multi-domain): regions that hold several domains go
+    through the ensembles on the device and in the oracle."""
+    hmm = load_hmms(model)[0]
+    bg = plan7.Background(hmm.alphabet)
+    block = _homolog_block(hmm, 50, 200, seed=21)
+    hits = next(iter(hmmer.hmmsearch(hmm, block, E=1e9, domE=1e9, incE=1e9, incdomE=1e9)))
+    by_name = {s.name: s for s in block}
+    st = _compare(oracle, hmm, hits, lambda h: np.asarray(by_name[h.name].sequence, dtype=np.uint8), bg)
+    assert st["hits"] >= 150 and st["ens_targets"] >= 10, st
+    assert st["single_diff"] <= max(1, st["single_env"] // 200), st
+    assert st["ens_same"] >= 0.9 * st["ens_targets"], st
