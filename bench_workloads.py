@@ -180,10 +180,12 @@ def make_targets(nseq, library_size, templates, lib_lengths, seed=44, planted_fr
     return flat, offsets.astype(np.int64), lens.astype(np.int32), nplanted
 
 
-def make_chromosome(hmm, L, planted=50, seed=45):
+def make_chromosome(hmm, L, planted=50, seed=45, return_planted=False):
     """configs[4]: an i.i.d. ACGT (0.25 each) chromosome of L residues with `planted` mutated (20 %) stretches of the
-    model's consensus, every second one on the reverse strand, so that the stages behind the SSV scan have work."""
+    model's consensus, every second one on the reverse strand, so that the stages behind the SSV scan have work.
+    return_planted: also the stretches as (position, length, strand, first model node), 0-based."""
     rng = np.random.default_rng(seed)
+    where = []
     seq = rng.integers(0, 4, size=L, dtype=np.uint8)
     cons = np.argmax(hmm.match_emissions[1:], axis=1).astype(np.uint8)
     comp = np.array([3, 2, 1, 0], dtype=np.uint8)
@@ -195,4 +197,5 @@ def make_chromosome(hmm, L, planted=50, seed=45):
         mut = rng.random(n) < 0.2
         seg[mut] = rng.integers(0, 4, size=int(mut.sum()))
         seq[pos:pos + n] = seg if c % 2 == 0 else comp[seg[::-1]]
-    return seq
+        where.append((pos, n, c % 2, a))
+    return (seq, where) if return_planted else seq

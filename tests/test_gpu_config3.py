@@ -127,3 +127,40 @@ def test_sharded_search_merged_equals_whole(workload):
     # Z-dependent thresholds with model cutoffs left alone (use_bit_cutoffs is per hit; nothing to re-threshold)
     shards = hmmer.make_chunks(block, 2)
     assert abs(sum(len(s) for s in shards[0]) - sum(len(s) for s in shards[1])) < 6000
+
+
+def test_config3_at_full_size_stage_counts_against_the_oracle(oracle):
+    """BASELINE configs[3] at its own size: the bench's 500,000-target block (lognormal lengths up to 5,000,
+    every second target with a planted domain of one of the 20,000 library entries) searched by 40 profiles spread evenly
+    over the library through hmmer.hmmsearch with its defaults -- the batches, kernel classes and hybrid splits of the `pfam`
+    workload.  Per profile the number of targets past the MSV, bias, Viterbi and Forward filters equals the oracle's
+    p7_Pipeline restatement over the same 1.75e8 residues (the integer filters are exact, and targets within the F3 guard band are re-decided by the host in the
+    reference's summation order), and every hit is a target the oracle lets through Forward."""
+    import bench_workloads as bw
+    templates = bw.load_templates()
+    lengths = bw.library_lengths(LIBRARY)
+    cal = bw.Calibrator(templates[0].alphabet)
+    entries = list(range(0, LIBRARY, LIBRARY // 40))[:40]
+    hmms = [cal.calibrate(bw.make_entry(templates, e, int(lengths[e]))) for e in entries]
+    flat, offsets, lens, nplanted = bw.make_targets(500_000, LIBRARY, templates, lengths, planted_frac=0.5)
+    abc = hmms[0].alphabet
+    bg = plan7.Background(abc)
+    db = plan7.SequenceDatabase.from_packed(abc, flat, offsets, lens)
+    hits = list(hmmer.hmmsearch(hmms, db))
+    pk = easel.PackedBlock.from_arrays(flat, offsets, lens)
+
+    def reference(q):
+        op = oracle.OracleProfile(hmms[q], bg, 400)
+        recs, ctr = op.cascade_block(pk, want_records=True)
+        r = np.frombuffer(recs, dtype=RECORD)
+        return (ctr.n_past_msv, ctr.n_past_bias, ctr.n_past_vit, ctr.n_past_fwd), set(np.nonzero(r["stage"] == 4)[0].tolist())
+
+    with ThreadPoolExecutor(max_workers=16) as ex:
+        refs = list(ex.map(reference, range(len(hmms))))
+    nhits = 0
+    for q, (counts, survivors) in enumerate(refs):
+        got = tuple(hits[q].stage_counts.values())
+        assert got == counts, (entries[q], hmms[q].M, got, counts)
+        assert {h.seqidx for h in hits[q]} <= survivors, entries[q]
+        nhits += len(hits[q])
+    assert nhits > 200

@@ -35,8 +35,7 @@ def ssv_kernel():
     _lib.set_debug_option("ssv_kernel", -1)
 
 
-def device_seeds(om, cfg, residues, complement):
-    cap = 1 << 16
+def device_seeds(om, cfg, residues, complement, cap=1 << 16):
     seeds = np.zeros((cap, 3), dtype=np.int64)
     d = np.ascontiguousarray(residues, dtype=np.uint8)
     n = _lib.lib().p7x_ssv_longtarget_seeds(C.byref(cfg), om._handle, 0, d.ctypes.data, len(d), int(complement), seeds.ctypes.data, cap)
@@ -407,3 +406,58 @@ def test_overlapping_searches_of_one_hmm_object_equal_the_sequential_ones():
     par = [_rows(h) for h in hmmer.nhmmer([hmm] * 5, block, searches_in_flight=3, window_beta=1e-3)]
     assert len(seq[0]) > 10 and seq == par
     assert seq[1] == seq[2] == seq[4]                      # from the second search on the replaced max_length is in force
+
+
+def test_config4_at_full_size_seeds_against_the_oracle_and_the_hits_explained(oracle):
+    """BASELINE configs[4] at its own size: bmyD against the bench's 250 Mbp chromosome.
+    (1) The device's SSV seeds of the whole forward strand against the oracle's sequential p7_SSVFilter_longtarget on a
+    sample of 262,144-residue blocks -- half of them around planted stretches, half background: every seed whose diagonal
+    lies at least max_length inside a block must be in both lists (SSV has no J state: what a scan reports away from the
+    ends of what it was given does not depend on where it was started).
+    (2) The bench prints 110 hits for 50 planted stretches: the bmyD model scores its own reverse complement highly (a stretch
+    planted on one strand is found on the other as well, E-values of 1e-30 ... 1e-150 next to 1e-50 ... 1e-270 on its own),
+    so a stretch gives two hits, one per strand, now and then a third where the alignment breaks; half a dozen marginal
+    hits (E > 0.1) lie on background.  Asserted: every hit with E < 1e-3 lies on a planted stretch, every stretch is found
+    on its own strand, and nothing else explains a hit."""
+    import bench_workloads as bw
+    hmm = load_hmms("bmyD")[0]
+    abc = hmm.alphabet
+    seq, planted = bw.make_chromosome(hmm, 250_000_000, 50, return_planted=True)
+    pli = plan7.LongTargetsPipeline(abc, block_length=1 << 30)
+    om = plan7.OptimizedProfile(hmm, pli.background, 400)
+    op = oracle.OracleProfile(hmm, pli.background, 400)
+    got = device_seeds(om, pli._cfg(), seq, 0, cap=1 << 20)
+    assert len(got) > 1000
+    C_, W = int(hmm.max_length), 0x40000
+    fwd = [p for p in planted if p[2] == 0]
+    starts = [max(0, p[0] - W // 2) for p in fwd[:5]] + [10_000_000, 77_777_777, 123_456_789, 200_000_000, 249_000_000 - W]
+    compared = 0
+    for a in starts:
+        blk = seq[a:a + W]
+        want = oracle.ssv_longtarget(op, blk, hmm.max_length, pli.F1)
+        inner = lambda s0, ln: s0 >= a + C_ and s0 + ln <= a + len(blk) - C_
+        w = sorted((int(s[0]) + a, int(s[1]), int(s[2])) for s in want if inner(int(s[0]) + a, int(s[2])))
+        g = sorted((int(s[0]), int(s[1]), int(s[2])) for s in got if inner(int(s[0]), int(s[2])))
+        assert g == w, (a, len(g), len(w), [x for x in g if x not in w][:3], [x for x in w if x not in g][:3])
+        compared += len(w)
+    assert compared > 50
+    block = easel.DigitalSequenceBlock(abc, [easel.DigitalSequence(abc, name="chrSyn", sequence=seq)])
+    hits = next(hmmer.nhmmer(hmm, block))
+    own = [0] * len(planted); other = [0] * len(planted); background = []
+    for h in hits:
+        dom = h.best_domain
+        al = dom.alignment
+        lo, hi = sorted((int(al.target_from), int(al.target_to)))
+        strand = 0 if dom.strand == "+" else 1
+        on = [i for i, (pos, n, st, a0) in enumerate(planted) if lo >= pos + 1 - 50 and hi <= pos + n + 50]
+        if not on:
+            background.append(h.evalue)
+        elif planted[on[0]][2] == strand:
+            own[on[0]] += 1
+        else:
+            other[on[0]] += 1
+    assert all(e > 1e-3 for e in background) and len(background) <= 12, background
+    assert all(c >= 1 for c in own), [(p, c) for p, c in zip(planted, own) if c == 0]                # every stretch, on its own strand
+    assert sum(1 for c in other if c >= 1) >= 40                                                      # ... and nearly all on the other one
+    assert max(own) <= 3 and max(other) <= 3
+    assert len(hits) == sum(own) + sum(other) + len(background) and 95 <= len(hits) <= 125, (len(hits), sum(own), sum(other), len(background))
