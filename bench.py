@@ -209,6 +209,16 @@ def host_cpus():
     return max(1, n)
 
 
+def pyhmmer_probe():
+    """"probe `import pyhmmer` on the GPU box at run time".  Only /root/repo travels there, so the import is
+    expected to fail; the line's cpu_baseline then says so and times the in-repo restatement (kind "port")."""
+    try:
+        import pyhmmer  # noqa: F401
+        return True
+    except Exception:       # noqa: BLE001
+        return False
+
+
 def cpu_baseline(hmm, bg, flat, offsets, lengths, n, L_hint):
     """The whole search on the host cores, C threads: filter cascade + parsers through oracle/ (the SSE2 restatement
     of impl_sse; ctypes releases the GIL, one oracle profile per thread because the length model is configured per
@@ -283,7 +293,8 @@ def cpu_baseline(hmm, bg, flat, offsets, lengths, n, L_hint):
         "value": round(float(hmm.M) * float(lengths[:n].sum()) / dt / 1e9, 3), "unit": "GCUPS", "cores": cores, "kind": "port",
         "sample": f"the first {n} targets of the same workload, whole search: oracle/ filter cascade + parsers (SSE2 restatement of "
                   f"impl_sse) on {cores} threads {t_filters:.2f} s, Backward rows + domain definition / hit list (product host twin) "
-                  f"{t_dd:.2f} s",
+                  f"{t_dd:.2f} s; pyhmmer itself is {'importable here but not used (kind stays port)' if pyhmmer_probe() else 'not installed on this box (import pyhmmer fails: only the repo travels)'}",
+        "pyhmmer_importable": pyhmmer_probe(),
         "past_msv": int(counts[0]), "past_fwd": int(counts[3]), "hits": nhits, "hits_by_the_oracles_own_domain_definition": oracle_hits,
     }
 
@@ -431,13 +442,18 @@ def run_scan(args, rank, world, local_rank, dist, red_dev, torch, host_threads, 
         return list(hmmer.hmmscan(proteome, block, cpus=host_threads, devices=[local_rank]))
 
     scan()                                  # images of this rank's profiles resident on this device, pools warm
-    if dist is not None:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    res = scan()
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
+    # a pass is a third of a second and varies by +-15 % from pass to pass (which hardware queues the host stage's kernels
+    # share with the class chains is a matter of timing: DESIGN.md 8): three timed passes, the MEDIAN is reported, all three listed
+    passes = []
+    for _ in range(3):
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        res = scan()
+        torch.cuda.synchronize()
+        passes.append(time.perf_counter() - t0)
+    dt = sorted(passes)[1]
     t_max = dt
     if dist is not None:
         b = torch.tensor([dt], dtype=torch.float64, device=red_dev)
@@ -453,6 +469,7 @@ def run_scan(args, rank, world, local_rank, dist, red_dev, torch, host_threads, 
         "value": round(nodes * residues / t_max / 1e9, 2), "unit": "GCUPS", "scaling": "strong",
         "profiles": len(hmms), "query_sequences": len(proteome), "seconds": round(t_max, 4),
         "ms_per_profile": round(1e3 * t_max / len(hmms), 5), "query_sequences_per_s": round(len(proteome) / t_max, 1),
+        "passes_seconds_rank0": [round(x, 4) for x in passes], "seconds_is": "the median of three timed passes (max over ranks)",
         "hits_rank0": sum(len(r) for r in res),
     }
     out["roofline"] = valu_roofline(nodes * residues, t_max, MSV_OPS_PER_CELL, "p7x::msv_fast_kernel<R, K, half> (latency bound on this block: DESIGN.md 8)")
