@@ -89,6 +89,32 @@ def tail_kernels(hmm, args, sc, solo, cells_rank):
     return out
 
 
+def pipeline_valu_budget(hmm, args, sc, B, ms_per_batch):
+    """roofline.pipeline: the WHOLE cascade of one device batch against VALU issue, from static instruction counts (the ISA of
+    the M = 262 instantiations) x the units every stage actually processed: wave64 instructions per batch, the cycles they
+    need at their class's best issue rate (packed 16-bit: 4 cycles, f32: 2), and that lower bound in ms on all 1,024 SIMDs
+    at the nominal 2.4 GHz next to the measured time per batch.  MSV's count is the PMC's (SQ_INSTS_VALU per cell,
+    profiles/r05_bench_pmc.md); an envelope is counted as long as its target (an upper bound)."""
+    if hmm.M != 262:
+        return None
+    L = float(args.seqlen)
+    rows = lambda n: float(n) * L * B
+    instr = {
+        "msv (packed)": 6.837e9 / 5.502e11 * float(args.nseq) * L * hmm.M * B,        # 0.795 lane-ops per cell / 64 lanes
+        "viterbi (packed)": rows(sc["bias"]) / 8.0 * 483.0,
+        "forward parser (f32)": rows(sc["vit"]) * 330.0,
+        "forward rows + backward (f32)": rows(sc["fwd"]) * (330.0 + 260.0),
+        "envelopes (f32)": rows(sc["fwd"]) * (330.0 + 260.0 + 1124.0),
+    }
+    cycles = sum(v * (4.0 if "packed" in k else 2.0) for k, v in instr.items())
+    bound_ms = cycles / (256 * 4 * 2.4e9) * 1e3
+    return {"wave_instructions_per_batch": {k: float(f"{v:.4g}") for k, v in instr.items()}, "total": float(f"{sum(instr.values()):.4g}"),
+            "issue_cycles_lower_bound": float(f"{cycles:.4g}"), "issue_bound_ms_per_batch": round(bound_ms, 2),
+            "measured_ms_per_batch": round(ms_per_batch, 2), "frac": round(bound_ms / ms_per_batch, 4),
+            "note": "the pipeline as a whole is VALU-issue bound: every kernel of the cascade is arithmetic on registers, and the tail "
+                    "kernels run in what the MSV launch of the next batch leaves; bias filter, decisions and ensembles (~5 %) not counted"}
+
+
 def valu_roofline(cells, seconds, ops_per_cell, what):
     """A whole workload's cell rate against the packed-op issue roof of its scan kernel (upper bound: the later stages are
     not in the denominator)."""
@@ -839,6 +865,7 @@ def main():
                                         if solo else None)},
                 "kernel_ms": round(msv_ms, 4), "algorithmic_bytes": int(alg_bytes), "queries_per_launch": B,
                 "kernels": tail_kernels(hmm, args, sc, solo, cells_rank),
+                "pipeline": pipeline_valu_budget(hmm, args, sc, B, 1e3 * t_max / nqueries * B),
             },
         }
         if pfam is not None:

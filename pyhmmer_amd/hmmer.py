@@ -177,18 +177,21 @@ class ReplicatedDatabase(ShardedDatabase):
 
 
 def hmmpress(hmms: Iterable, output) -> int:
-    """Press HMMs into the optimized-profile database ``<output>.h3f`` + ``<output>.h3p`` (reference
-    ``hmmer/_hmmpress.py:29-66``: every model is configured for L=400, converted and written).  Returns the number of
-    models.  The ``.h3m`` (binary core models) and ``.h3i`` (SSI index) companions of upstream's ``hmmpress`` are not
-    written: searches need only the two profile files (``HMMPressedFile``)."""
+    """Press HMMs into ``<output>.h3m`` (the core models, binary), ``<output>.h3f`` and ``<output>.h3p`` (the optimized
+    profiles: MSV filter part and the rest), as the reference does (``hmmer/_hmmpress.py:29-66``: every model is
+    configured for L=400, converted and written, each profile record carrying the offsets of its three parts).  Returns
+    the number of models.  The ``.h3i`` SSI index of upstream's ``hmmpress`` is not written: nothing on the search path
+    reads it (``HMMPressedFile`` walks the profile files in order)."""
     from .plan7 import Background
     path = os.fspath(output)
     n = 0
     bgs: dict = {}
-    with open(path + ".h3f", "wb") as ff, open(path + ".h3p", "wb") as fp:
+    with open(path + ".h3m", "wb") as fm, open(path + ".h3f", "wb") as ff, open(path + ".h3p", "wb") as fp:
         for hmm in hmms:
             bg = bgs.setdefault(hmm.alphabet.type_code, Background(hmm.alphabet))
-            OptimizedProfile(hmm, bg, 400).write(ff, fp)
+            at = (fm.tell(), ff.tell(), fp.tell())
+            hmm.write(fm, binary=True)
+            OptimizedProfile(hmm, bg, 400).write(ff, fp, offsets=at)
             n += 1
     return n
 

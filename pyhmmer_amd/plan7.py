@@ -184,6 +184,117 @@ class HMM:
     def __repr__(self):
         return f"<HMM name={self.name!r} M={self.M} alphabet={self.alphabet!r}>"
 
+    def _flags(self) -> int:
+        """The P7_HMM flag word a save file carries: which optional fields this model holds."""
+        F = HMMFile._F
+        unset = lambda x: float(x) == CUTOFF_UNSET
+        have = dict(DESC=self.description is not None, RF=self.reference is not None, CS=self.consensus_structure is not None,
+                    STATS=float(self._evparam[0]) != EVPARAM_UNSET, MAP=self.map is not None, ACC=self.accession is not None,
+                    GA=not unset(self._cutoffs[0]), TC=not unset(self._cutoffs[2]), NC=not unset(self._cutoffs[4]),
+                    COMPO=self.composition is not None, CHKSUM=self.checksum is not None, CONS=self.consensus is not None,
+                    MMASK=self.model_mask is not None)
+        return sum(F[k] for k, v in have.items() if v)
+
+    def write(self, fh, binary: bool = False) -> None:
+        """Write the model to a file object (reference ``plan7.pyx:3403-3436``, upstream ``p7_hmmfile_WriteASCII`` /
+        ``p7_hmmfile_WriteBinary``): the HMMER3/f text format to a text or a binary handle, or the 3/f binary format
+        (``binary=True``, what ``hmmpress`` keeps in ``.h3m``) to a binary handle."""
+        if binary:
+            fh.write(self._to_binary())
+            return
+        text = self._to_text()
+        try:
+            fh.write(text)
+        except TypeError:
+            fh.write(text.encode())
+
+    def _to_binary(self) -> bytes:
+        import struct
+        M, K = self.M, self.alphabet.K
+        f32 = lambda a: np.ascontiguousarray(a, dtype=np.float32).tobytes()
+
+        def string(s):
+            if s is None:
+                return struct.pack("=i", 0)
+            b = s.encode() + b"\0"
+            return struct.pack("=i", len(b)) + b
+
+        def line(s):
+            return (" " + s).encode()[:M + 1].ljust(M + 1, b" ") + b"\0"
+
+        flags = self._flags()
+        F = HMMFile._F
+        out = [struct.pack("=Iiii", HMMFile._MAGIC_3F, flags, M, self.alphabet.type_code),
+               f32(self.match_emissions[1:]), f32(self.insert_emissions), f32(self.transition_probabilities), string(self.name)]
+        if flags & F["ACC"]:
+            out.append(string(self.accession))
+        if flags & F["DESC"]:
+            out.append(string(self.description))
+        for key, s in (("RF", self.reference), ("MMASK", self.model_mask), ("CONS", self.consensus), ("CS", self.consensus_structure)):
+            if flags & F[key]:
+                out.append(line(s))
+        out.append(string(self.command_line))
+        out.append(struct.pack("=ifi", -1 if self.nseq is None else int(self.nseq), -1.0 if self.nseq_effective is None else float(self.nseq_effective),
+                               -1 if self.max_length is None else int(self.max_length)))
+        out.append(string(self.creation_time))
+        if flags & F["MAP"]:
+            out.append(np.ascontiguousarray(self.map, dtype=np.int32).tobytes())
+        out.append(struct.pack("=I", int(self.checksum or 0)))
+        out.append(f32(self._evparam) + f32(self._cutoffs))
+        if flags & F["COMPO"]:
+            out.append(f32(self.composition))
+        return b"".join(out)
+
+    def _to_text(self) -> str:
+        M, abc = self.M, self.alphabet
+
+        def probs(p):
+            p = np.asarray(p, dtype=np.float32)
+            with np.errstate(divide="ignore"):
+                nl = -np.log(p)
+            return "".join("        *" if x == 0.0 else (" %8.5f" % (0.0 if x == 1.0 else v)) for x, v in zip(p.tolist(), nl.tolist()))
+
+        yn = lambda x: "yes" if x is not None else "no"
+        o = ["HMMER3/f [pyhmmer_amd | 3.4 layout]\n", f"NAME  {self.name}\n"]
+        if self.accession is not None:
+            o.append(f"ACC   {self.accession}\n")
+        if self.description is not None:
+            o.append(f"DESC  {self.description}\n")
+        o.append(f"LENG  {M}\n")
+        if self.max_length is not None and self.max_length > 0:
+            o.append(f"MAXL  {self.max_length}\n")
+        o.append("ALPH  %s\n" % {eslAMINO: "amino", eslDNA: "DNA", eslRNA: "RNA"}[abc.type_code])
+        o.append(f"RF    {yn(self.reference)}\nMM    {yn(self.model_mask)}\nCONS  {yn(self.consensus)}\nCS    {yn(self.consensus_structure)}\nMAP   {yn(self.map)}\n")
+        if self.creation_time is not None:
+            o.append(f"DATE  {self.creation_time}\n")
+        if self.command_line is not None:
+            o.extend(f"COM   [{i}] {c}\n" for i, c in enumerate(self.command_line.split("\n"), 1))
+        if self.nseq is not None and self.nseq > 0:
+            o.append(f"NSEQ  {self.nseq}\n")
+        if self.nseq_effective is not None and self.nseq_effective >= 0:
+            o.append("EFFN  %f\n" % self.nseq_effective)
+        if self.checksum is not None:
+            o.append(f"CKSUM {self.checksum}\n")
+        for key, idx in (("GA", 0), ("TC", 2), ("NC", 4)):
+            if float(self._cutoffs[idx]) != CUTOFF_UNSET:
+                o.append("%-5s %.2f %.2f\n" % (key, self._cutoffs[idx], self._cutoffs[idx + 1]))
+        if float(self._evparam[0]) != EVPARAM_UNSET:
+            for label, idx in (("MSV", 0), ("VITERBI", 2), ("FORWARD", 4)):
+                o.append("STATS LOCAL %-8s %8.4f %8.5f\n" % (label, self._evparam[idx], self._evparam[idx + 1]))
+        o.append("HMM     " + "".join(f"     {c}   " for c in abc.symbols[:abc.K]) + "\n")
+        o.append("       " + "".join(" %8s" % s for s in ("m->m", "m->i", "m->d", "i->m", "i->i", "d->m", "d->d")) + "\n")
+        if self.composition is not None:
+            o.append("  COMPO " + probs(self.composition) + "\n")
+        for k in range(M + 1):
+            if k > 0:
+                ann = lambda s: "-" if s is None else s[k - 1]
+                o.append(" %6d " % k + probs(self.match_emissions[k]) + (" %6d" % self.map[k] if self.map is not None else " %6s" % "-")
+                         + f" {ann(self.consensus)} {ann(self.reference)} {ann(self.model_mask)} {ann(self.consensus_structure)}\n")
+            o.append("        " + probs(self.insert_emissions[k]) + "\n")
+            o.append("        " + probs(self.transition_probabilities[k]) + "\n")
+        o.append("//\n")
+        return "".join(o)
+
     def _view(self):
         """Build the ``p7x_hmm_view`` (keeps the numpy buffers alive on the returned tuple)."""
         t = np.ascontiguousarray(self.transition_probabilities, dtype=np.float32)
@@ -210,20 +321,130 @@ class HMM:
 
 
 class HMMFile:
-    """Reader for HMMER3 ASCII save files (reference ``plan7.pyx:3656-4050``; upstream
-    ``p7_hmmfile.c:read_asc30hmm``).  Binary ``.h3m`` and pressed databases are not read here;
-    the pressed ``.h3f/.h3p`` fixtures are parsed only by the tests (``tests/h3_reader.py``)."""
+    """Reader for HMMER3 save files (reference ``plan7.pyx:3656-4050``): the ASCII format (upstream
+    ``p7_hmmfile.c:read_asc30hmm``) and the binary ``.h3m`` format 3/f (``read_bin30hmm``; the reference tells them apart by the
+    four magic bytes, ``plan7.pyx:3712-3760``).  Pressed ``.h3f/.h3p`` databases: ``HMMPressedFile``."""
+
+    _MAGIC_3F = 0xe8ededba            # "hmma" + 0x80808080 (patches/p7_hmmfile.c.patch:15-20); older binary versions are not read
+    _MAGIC_OLD = (0xe8ededb6, 0xe8ededb7, 0xe8ededb8, 0xe8ededb9, 0xe8ededb0)
+    # P7_HMM flags (upstream p7_hmm.h) that say which optional fields a binary record holds
+    _F = dict(DESC=1 << 1, RF=1 << 2, CS=1 << 3, STATS=1 << 7, MAP=1 << 8, ACC=1 << 9, GA=1 << 10, TC=1 << 11, NC=1 << 12, CA=1 << 13,
+              COMPO=1 << 14, CHKSUM=1 << 15, CONS=1 << 16, MMASK=1 << 17)
 
     def __init__(self, file, db: bool = False, *, alphabet: Optional[Alphabet] = None):
+        self._binary = False
         if isinstance(file, (str, bytes, os.PathLike)):
-            self._fh = open(file, "r")
+            with open(file, "rb") as probe:
+                head = probe.read(4)
+            magic = int.from_bytes(head, sys.byteorder) if len(head) == 4 else 0
+            self._binary = magic == self._MAGIC_3F
+            if magic in self._MAGIC_OLD:
+                raise ValueError(f"{os.fspath(file)!r}: binary HMM file of an older format (HMMER 3/a-3/e); only 3/f is read")
+            self._fh = open(file, "rb" if self._binary else "r")
             self._own = True
             self.name = os.fspath(file)
         else:
             self._fh = file
             self._own = False
             self.name = getattr(file, "name", None)
+            head = None
+            if hasattr(file, "peek"):
+                head = file.peek(4)[:4]
+            elif hasattr(file, "seek") and hasattr(file, "tell"):
+                at = file.tell(); head = file.read(4); file.seek(at)
+            if isinstance(head, (bytes, bytearray)) and len(head) == 4:
+                self._binary = int.from_bytes(head, sys.byteorder) == self._MAGIC_3F
         self._alphabet = alphabet
+
+    def _read_binary(self) -> Optional[HMM]:
+        """One record of the 3/f binary format, as upstream's write_bin_hmm lays it out: magic, flags, M, alphabet type; the
+        match emissions of nodes 1..M, the insert emissions and the transitions of nodes 0..M (float32 PROBABILITIES, not the
+        text format's negative logarithms); name [accession] [description] as length-prefixed strings; the annotation lines
+        (M + 2 bytes each: a blank, the M characters, NUL) that the flags announce; command line, nseq, effective nseq,
+        max_length, date, [map], checksum, E-value parameters, cutoffs, [composition]."""
+        import struct
+        fh = self._fh
+        head = fh.read(4)
+        if len(head) == 0:
+            return None
+        if len(head) < 4 or int.from_bytes(head, sys.byteorder) != self._MAGIC_3F:
+            raise ValueError(f"Invalid format in file: {self.name!r} (bad magic in a binary HMM record)")
+
+        def take(n):
+            b = fh.read(n)
+            if len(b) != n:
+                raise ValueError(f"premature end of binary HMM file {self.name!r}")
+            return b
+
+        def word(fmt):
+            return struct.unpack("=" + fmt, take(struct.calcsize("=" + fmt)))
+
+        def string():
+            n, = word("i")
+            if n < 0 or n > (1 << 24):
+                raise ValueError(f"corrupt string length in binary HMM file {self.name!r}")
+            return None if n == 0 else take(n)[:-1].decode()
+
+        flags, M, abc_type = word("iii")
+        alphabet = {eslAMINO: Alphabet.amino, eslDNA: Alphabet.dna, eslRNA: Alphabet.rna}.get(abc_type)
+        if alphabet is None or M < 1 or M > 100000:
+            raise ValueError(f"corrupt header in binary HMM file {self.name!r}")
+        alphabet = alphabet()
+        if self._alphabet is not None and self._alphabet != alphabet:
+            raise AlphabetMismatch(self._alphabet, alphabet)
+        K, F = alphabet.K, self._F
+        mat = np.frombuffer(take(4 * M * K), dtype=np.float32).reshape(M, K)
+        ins = np.frombuffer(take(4 * (M + 1) * K), dtype=np.float32).reshape(M + 1, K)
+        t = np.frombuffer(take(4 * (M + 1) * 7), dtype=np.float32).reshape(M + 1, 7)
+        hmm = HMM(alphabet, M, string() or "")
+        hmm.match_emissions[1:] = mat
+        hmm.match_emissions[0, 0] = 1.0
+        hmm.insert_emissions[:] = ins
+        hmm.transition_probabilities[:] = t
+        if flags & F["ACC"]:
+            hmm.accession = string()
+        if flags & F["DESC"]:
+            hmm.description = string()
+        line = lambda: take(M + 2)[1:M + 1].decode()
+        if flags & F["RF"]:
+            hmm.reference = line()
+        if flags & F["MMASK"]:
+            hmm.model_mask = line()
+        if flags & F["CONS"]:
+            hmm.consensus = line()
+        if flags & F["CS"]:
+            hmm.consensus_structure = line()
+        if flags & F["CA"]:
+            line()                                   # surface accessibility: not kept by the text reader either
+        hmm.command_line = string()
+        hmm.nseq, = word("i")
+        eff, = word("f")
+        hmm.nseq_effective = float(eff)
+        maxl, = word("i")
+        if maxl > 0:
+            hmm.max_length = int(maxl)
+        hmm.creation_time = string()
+        if flags & F["MAP"]:
+            hmm.map = np.array(word(f"{M + 1}i"), dtype=np.int64)
+        cks, = word("I")
+        if flags & F["CHKSUM"]:
+            hmm.checksum = int(cks)
+        ev = word("6f")
+        if flags & F["STATS"]:
+            hmm._evparam[:] = ev
+        cut = word("6f")
+        for key, idx in (("GA", 0), ("TC", 2), ("NC", 4)):
+            if flags & F[key]:
+                hmm._cutoffs[idx], hmm._cutoffs[idx + 1] = cut[idx], cut[idx + 1]
+        if flags & F["COMPO"]:
+            hmm.composition = np.array(word(f"{K}f"), dtype=np.float32)
+        if hmm.nseq is not None and hmm.nseq < 0:
+            hmm.nseq = None
+        if hmm.nseq_effective is not None and hmm.nseq_effective < 0:
+            hmm.nseq_effective = None
+        if hmm.consensus is None:
+            hmm.consensus = _set_consensus(hmm)
+        return hmm
 
     def __enter__(self):
         return self
@@ -256,6 +477,8 @@ class HMMFile:
         return out
 
     def read(self) -> Optional[HMM]:
+        if self._binary:
+            return self._read_binary()
         fh = self._fh
         line = fh.readline()
         while line and not line.strip():
@@ -279,6 +502,11 @@ class HMMFile:
             if tag == "STATS":
                 f = val.split()
                 stats[f[1]] = (float(f[2]), float(f[3]))
+            elif tag == "COM":            # "COM   [n] command": upstream drops the counter and joins the lines with newlines
+                cmd = val
+                if cmd.startswith("[") and "]" in cmd:
+                    cmd = cmd[cmd.index("]") + 1:].strip()
+                hdr["COM"] = (hdr["COM"] + "\n" + cmd) if "COM" in hdr else cmd
             else:
                 hdr[tag] = val
         abc_name = hdr.get("ALPH", "amino").lower()

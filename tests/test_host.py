@@ -1,6 +1,7 @@
 """Host logic of the product (no GPU): file parsing, profile conversion, packing, ABI surface, error behaviour."""
 import ctypes as C
 import re
+import sys
 
 import numpy as np
 import pytest
@@ -196,7 +197,7 @@ def test_envelope_kernel_isa_keeps_memory_round_trips_out_of_its_row_loops(tmp_p
 @pytest.mark.parametrize("name", ["PF02826", "Thioesterase", "RREFam"])
 def test_pressed_files_are_written_byte_for_byte(name, models, tmp_path):
     """hmmpress: .h3f / .h3p produced here == the files real HMMER pressed (reference tests/data/hmms/db), byte for
-    byte, once the .h3m offsets (a file this build does not write) are taken from the fixture."""
+    byte; hmmpress as a whole (which also writes the .h3m the offsets point into) reproduces them too."""
     want_f = (GOLDEN / "db" / f"{name}.hmm.h3f").read_bytes()
     want_p = (GOLDEN / "db" / f"{name}.hmm.h3p").read_bytes()
     offs = [r["offs"] for r in h3_reader.read_h3f(GOLDEN / "db" / f"{name}.hmm.h3f")]
@@ -209,8 +210,8 @@ def test_pressed_files_are_written_byte_for_byte(name, models, tmp_path):
     assert ff.getvalue() == want_f
     assert fp.getvalue() == want_p
     assert hmmer.hmmpress(models[name], tmp_path / "db") == len(models[name])
-    got_f = (tmp_path / "db.h3f").read_bytes()
-    assert len(got_f) == len(want_f)                        # identical except the 8-byte .h3m offset of each record
+    assert (tmp_path / "db.h3f").read_bytes() == want_f and (tmp_path / "db.h3p").read_bytes() == want_p
+    assert (tmp_path / "db.h3m").read_bytes() == (GOLDEN / "hmms" / f"{name}.h3m").read_bytes()
 
 
 @pytest.mark.parametrize("name", ["PF02826", "Thioesterase", "RREFam"])
@@ -481,3 +482,73 @@ def test_integer_thresholds_of_a_traceback_choice_are_the_reference_test(libp7x)
             assert a.value == b.value, (p32, x, a.value, b.value)
             nchecked += 1
     assert nchecked > 50000
+
+
+@pytest.mark.parametrize("name", ["Thioesterase", "PF02826", "RREFam", "RF00001"])
+def test_binary_hmm_files_read_like_their_text_twins(libp7x, name, tmp_path):
+    """HMMFile reads the binary 3/f format (.h3m; reference plan7.pyx:3656-3760, HMMFile's own docstring example:
+    tests/data/hmms/bin/RREFam.h3m holds 10 HMMs, the first one RREFam002.1).  The reference's four binary fixtures against
+    the text files of the same models: every field equal, the probabilities bit for bit (the binary format stores the float
+    the text parser computes)."""
+    import io
+    with plan7.HMMFile(GOLDEN / "hmms" / f"{name}.h3m") as f:
+        binary = list(f)
+    with plan7.HMMFile(GOLDEN / "hmms" / f"{name}.hmm") as f:
+        text = list(f)
+    assert len(binary) == len(text) == (10 if name == "RREFam" else 1)
+    if name == "RREFam":
+        assert binary[0].accession == "RREFam002.1"
+    for b, t in zip(binary, text):
+        for attr in ("M", "name", "accession", "description", "consensus", "reference", "model_mask", "consensus_structure", "max_length",
+                     "nseq", "checksum", "command_line", "creation_time"):
+            assert getattr(b, attr) == getattr(t, attr), (name, attr)
+        assert b.alphabet == t.alphabet
+        assert np.array_equal(b.transition_probabilities, t.transition_probabilities)
+        assert np.array_equal(b.match_emissions, t.match_emissions) and np.array_equal(b.insert_emissions, t.insert_emissions)
+        assert np.array_equal(b._evparam, t._evparam) and np.array_equal(b._cutoffs, t._cutoffs)
+        assert (b.composition is None) == (t.composition is None) and (b.composition is None or np.array_equal(b.composition, t.composition))
+        assert (b.map is None) == (t.map is None) and (b.map is None or np.array_equal(b.map, t.map))
+        assert b.nseq_effective == pytest.approx(t.nseq_effective, abs=1e-5)
+    # a file object, rewinding, a truncated file, an older binary version
+    raw = (GOLDEN / "hmms" / f"{name}.h3m").read_bytes()
+    with plan7.HMMFile(io.BytesIO(raw)) as f:
+        again = list(f)
+        f.rewind()
+        assert [h.name for h in f] == [h.name for h in binary] == [h.name for h in again]
+    (tmp_path / "cut.h3m").write_bytes(raw[:len(raw) // 2])
+    with pytest.raises(ValueError, match="premature end"):
+        list(plan7.HMMFile(tmp_path / "cut.h3m"))
+    (tmp_path / "old.h3m").write_bytes((0xe8ededb8).to_bytes(4, sys.byteorder) + raw[4:])
+    with pytest.raises(ValueError, match="older format"):
+        plan7.HMMFile(tmp_path / "old.h3m")
+
+
+@pytest.mark.parametrize("name", ["PF02826", "RF00001", "RREFam", "Thioesterase", "KR", "LuxC", "bmyD"])
+def test_hmm_write_reproduces_the_save_files(libp7x, name):
+    """HMM.write (reference plan7.pyx:3403-3436): the text form of a parsed model is the fixture it was parsed from, line for
+    line behind the version banner, and reading the binary form back gives the same model; the binary form of the four models
+    that have a .h3m fixture is that fixture, byte for byte."""
+    import io
+    path = GOLDEN / "hmms" / f"{name}.hmm"
+    with plan7.HMMFile(path) as f:
+        hmms = list(f)
+    out = io.StringIO()
+    for h in hmms:
+        h.write(out)
+    got, want = out.getvalue().splitlines(), path.read_text().splitlines()      # (one fixture ends without a newline)
+    assert len(got) == len(want) and out.getvalue().endswith("//\n")
+    assert [g for g, w in zip(got, want) if g != w and not w.startswith("HMMER3/f")] == []
+    raw = io.BytesIO()
+    for h in hmms:
+        h.write(raw, binary=True)
+    if (GOLDEN / "hmms" / f"{name}.h3m").exists():
+        assert raw.getvalue() == (GOLDEN / "hmms" / f"{name}.h3m").read_bytes()
+    raw.seek(0)
+    back = list(plan7.HMMFile(raw))
+    assert [b.name for b in back] == [h.name for h in hmms]
+    for b, h in zip(back, hmms):
+        assert np.array_equal(b.match_emissions, h.match_emissions) and np.array_equal(b.transition_probabilities, h.transition_probabilities)
+        assert np.array_equal(b._evparam, h._evparam) and b.consensus == h.consensus and b.checksum == h.checksum
+    tb = io.BytesIO()
+    hmms[0].write(tb)                                  # a binary handle takes the text form as bytes
+    assert tb.getvalue().decode() == hmms[0]._to_text()
