@@ -1434,10 +1434,15 @@ class TopHits:
     def write(self, fh, format: str = "targets", header: bool = True) -> None:
         """Tabular output as ``hmmsearch --tblout`` (``"targets"``) / ``--domtblout`` (``"domains"``) write it:
         ``p7_tophits_TabularTargets`` / ``p7_tophits_TabularDomains`` behind reference ``plan7.pyx:9071-9118``, pinned by
-        the golden ``.tbl`` / ``.domtbl`` files.  The reference's third format (``"pfam"``) has no fixture to pin it and is
-        not offered.  ``fh`` is a file object opened in binary mode."""
-        if format not in ("targets", "domains"):
-            raise InvalidParameter("format", format, choices=["targets", "domains"])
+        the golden ``.tbl`` / ``.domtbl`` files.  ``"pfam"`` (``plan7.pyx:9155-9164``) is ``p7_tophits_TabularXfam``: the
+        reported hits, a blank line, then every reported domain as a row of its own, best first (by bit score, or by E-value if
+        inclusion is by E-value); it ignores ``header``.  No file in the reference pins that third layout, so it is restated from
+        upstream's format strings and NOT verified byte for byte.  ``fh`` is a file object opened in binary mode."""
+        if format not in ("targets", "domains", "pfam"):
+            raise InvalidParameter("format", format, choices=["targets", "domains", "pfam"])
+        if format == "pfam":
+            fh.write(self._xfam().encode())
+            return
         q = self.query
         qname = getattr(q, "name", None) if q is not None and not isinstance(q, str) else q
         qacc = getattr(q, "accession", None) if q is not None and not isinstance(q, str) else None
@@ -1499,6 +1504,63 @@ class TopHits:
                         math.exp(d.lnP) * Z, d.bitscore, d.dombias / math.log(2.0), d.hmmfrom, d.hmmto, d.sqfrom, d.sqto,
                         d.ienv, d.jenv, d.oasc / (1.0 + abs(float(d.jenv - d.ienv))), h.description or "-"))
         fh.write(("\n".join(out) + "\n").encode() if out else b"")
+
+    def _xfam(self) -> str:
+        q = self.query
+        qname = (getattr(q, "name", None) if q is not None and not isinstance(q, str) else q) or "-"
+        hits = [h for h in self if h.reported]
+        tnamew = max([20] + [len(h.name) for h in self])
+        taccw = max([10] + [len(h.accession or "") for h in self])
+        qnamew = max(20, len(qname))
+        Z = self.Z
+        ln2 = math.log(2.0)
+        o = []
+        if self.long_targets:
+            posw = max([7] + [len(str(max(d._rec.iali, d._rec.jali, d._rec.ienv, d._rec.jenv, d._rec.L))) for h in self for d in h.domains])
+            o.append("# hit scores\n# ----------\n#\n")
+            o.append("# %-*s %-*s %-*s %6s %9s %5s  %s  %s %6s %*s %*s %*s %*s %*s   %s\n" % (
+                tnamew - 1, "name", taccw, "acc", qnamew, "query", "bits", "  e-value", " bias", "hmm-st", "hmm-en", "strand",
+                posw, "ali-st", posw, "ali-en", posw, "env-st", posw, "env-en", posw, "sq-len", "description of target"))
+            o.append("# %*s %*s %*s %6s %9s %5s %s %s %6s %*s %*s %*s %*s %*s   %s\n" % (
+                tnamew - 1, "-------------------", taccw, "----------", qnamew, "--------------------", "------", "---------", "-----",
+                "-------", "-------", "------", posw, "-------", posw, "-------", posw, "-------", posw, "-------", posw, "-------",
+                "---------------------"))
+            for h in hits:
+                r, d = h._rec, h.best_domain._rec
+                o.append("%-*s  %-*s %-*s %6.1f %9.2g %5.1f %7d %7d %s %*d %*d %*d %*d %*d   %s\n" % (
+                    tnamew, h.name, taccw, h.accession or "-", qnamew, qname, r.score, math.exp(r.lnP), d.dombias / ln2, d.hmmfrom, d.hmmto,
+                    "   +  " if d.iali < d.jali else "   -  ", posw, d.iali, posw, d.jali, posw, d.ienv, posw, d.jenv, posw, d.L,
+                    h.description or "-"))
+            return "".join(o)
+        o.append("# Sequence scores\n# ---------------\n#\n")
+        o.append("# %-*s %6s %9s %3s %5s %5s    %s\n" % (tnamew - 1, "name", " bits", "  E-value", "n", "exp", " bias", "description"))
+        o.append("# %*s %6s %9s %3s %5s %5s    %s\n" % (tnamew - 1, "-------------------", "------", "---------", "---", "-----", "-----",
+                                                        "---------------------"))
+        rows = []
+        for h in hits:
+            r = h._rec
+            o.append("%-*s  %6.1f %9.2g %3d %5.1f %5.1f    %s\n" % (tnamew, h.name, r.score, math.exp(r.lnP) * Z, r.ndom, r.nexpected, 0.0,
+                                                                  h.description or "-"))
+            nrep = 0
+            for dom in h.domains:
+                if dom._rec.is_reported:
+                    nrep += 1
+                    rows.append((h, dom._rec, nrep))
+        o.append("\n")
+        by_E = bool(self._cfg().inc_by_E)
+        order = sorted(range(len(rows)), key=lambda i: (-(-rows[i][1].lnP if by_E else rows[i][1].bitscore), rows[i][0].name, i))
+        o.append("# Domain scores\n# -------------\n#\n")
+        o.append("# %-*s %6s %9s %5s %5s %6s %6s %6s %6s %6s %6s     %s\n" % (tnamew - 1, " name", "bits", "E-value", "hit", "bias", "env-st", "env-en",
+                                                                            "ali-st", "ali-en", "hmm-st", "hmm-en", "description"))
+        o.append("# %*s %6s %9s %5s %5s %6s %6s %6s %6s %6s %6s      %s\n" % (tnamew - 1, "-------------------", "------", "---------", "-----", "-----",
+                                                                           "------", "------", "------", "------", "------", "------",
+                                                                           "---------------------"))
+        for i in order:
+            h, d, nth = rows[i]
+            o.append("%-*s  %6.1f %9.2g %5d %5.1f %6d %6d %6d %6d %6d %6d     %s\n" % (
+                tnamew, h.name, d.bitscore, math.exp(d.lnP) * Z, nth, d.dombias / ln2, d.ienv, d.jenv, d.sqfrom, d.sqto, d.hmmfrom, d.hmmto,
+                h.description or "-"))
+        return "".join(o)
 
     def copy(self) -> "TopHits":
         h = _lib.lib().p7x_tophits_clone(self._handle)

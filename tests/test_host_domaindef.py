@@ -118,6 +118,34 @@ def test_host_write_reproduces_hmmer_tables_byte_for_byte(models, oracle, proteo
         hits.write(io.BytesIO(), format="nonsense")
 
 
+def test_host_write_pfam_format_holds_the_domain_table_rows(models, oracle, proteome):
+    """reference plan7.pyx:9155-9164 (`format="pfam"`, p7_tophits_TabularXfam).  No fixture pins the layout; what is checked is
+    its content against the pinned tables: one row per reported hit in hit order, a blank line, one row per reported domain
+    carrying the --domtblout numbers, best bit score first, each with the ordinal of the domain inside its hit."""
+    hmm = models["PF02826"][0]
+    hits = host_pipeline.host_search(oracle, hmm, proteome)
+    buf = io.BytesIO()
+    hits.write(buf, format="pfam", header=False)
+    text = buf.getvalue().decode()
+    seqpart, dompart = text.split("\n\n", 1)
+    seqrows = [l.split() for l in seqpart.splitlines() if not l.startswith("#")]
+    domrows = [l.split() for l in dompart.splitlines() if not l.startswith("#")]
+    assert seqpart.startswith("# Sequence scores\n# ---------------\n#\n") and dompart.startswith("# Domain scores\n# -------------\n#\n")
+    want_hits = [l.split() for l in _golden_lines("PF02826.tbl") if not l.startswith("#")]
+    want_doms = [l.split() for l in _golden_lines("PF02826.domtbl") if not l.startswith("#")]
+    assert [r[0] for r in seqrows] == [w[0] for w in want_hits]
+    assert [(r[1], r[2], r[3], r[4]) for r in seqrows] == [(w[5], w[4], w[15], w[10]) for w in want_hits]      # bits, E-value, ndom (dom), exp
+    assert len(domrows) == len(want_doms)
+    scores = [float(r[1]) for r in domrows]
+    assert scores == sorted(scores, reverse=True)
+    key = lambda name, envst, envto: (name, envst, envto)
+    table = {key(w[0], w[19], w[20]): w for w in want_doms}
+    for r in domrows:
+        w = table[key(r[0], r[5], r[6])]
+        # bits, i-Evalue, ordinal, bias, ali from/to, hmm from/to
+        assert (r[1], r[2], r[3], r[4], r[7], r[8], r[9], r[10]) == (w[13], w[12], w[9], w[14], w[17], w[18], w[15], w[16])
+
+
 def test_host_tophits_api(models, oracle, proteome):
     """reference tests/test_plan7/test_tophits.py:112-160, 293-327, 343-357, 383-450 and test_hit.py:94-150."""
     hmm = models["PF02826"][0]
