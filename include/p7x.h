@@ -392,6 +392,8 @@ int p7x_postprocess_targets(const p7x_pipeline_cfg *cfg, const p7x_oprofile *om,
                             const char *const *accs, const char *const *descs, p7x_tophits **out);
 
 void     p7x_tophits_destroy(p7x_tophits *th);
+/* n results at once (a scan batch is thousands of per-model lists that only pass through the caller); the slots are zeroed */
+void     p7x_tophits_destroy_many(p7x_tophits **th, size_t n);
 p7x_tophits *p7x_tophits_clone(const p7x_tophits *th);   /* TopHits.copy, plan7.pyx:9150-9170 */
 int64_t  p7x_tophits_nhits(const p7x_tophits *th);
 int      p7x_tophits_get_counters(const p7x_tophits *th, p7x_counters *c);

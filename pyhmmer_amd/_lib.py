@@ -177,6 +177,7 @@ _SIGNATURES = {
     "p7x_postprocess_targets": (C.c_int, [C.POINTER(PipelineCfg), _VP, _VP, _VP, _VP, C.c_size_t, _VP, C.c_size_t, _VP, _VP, _VP,
                                           _VP, _VP, _VP, _VP, _VP, C.POINTER(_VP)]),
     "p7x_tophits_destroy": (None, [_VP]),
+    "p7x_tophits_destroy_many": (None, [_VP, C.c_size_t]),
     "p7x_tophits_clone": (_VP, [_VP]),
     "p7x_tophits_nhits": (C.c_int64, [_VP]),
     "p7x_tophits_get_counters": (C.c_int, [_VP, C.POINTER(Counters)]),

@@ -54,6 +54,7 @@ struct MsvArgs {
   // fast variant: groups whose result is ambiguous are appended here and redone by the exact kernel
   int *amb_count; int *amb_groups; int *counter2;
   const int *group_list; const int *group_count;   // exact kernel: optional list of groups to process
+  int R;                    // the lane's register tile (read by the tier kernels, which serve several tiles in one launch)
 };
 int  msv_pick(int M, int *K);       // row registers per lane and lanes per target (K = 1, 2, 4) of the lane kernels; -1: none fits
 int  msv_stride(int R, int K);     // dwords per table row
@@ -61,6 +62,13 @@ void msv_build_tables(const Profile &p, int R, int K, std::vector<uint32_t> &out
 // fast kernel over <main> followed by the exact kernel over each lane's list of ambiguous groups (<amb>: records with
 // group_list / group_count set); amb == nullptr: the exact kernel over every group of <main>
 int  msv_launch(int R, int K, const ArgRun<MsvArgs> &main, const ArgRun<MsvArgs> *amb, int num_cu, hipStream_t st);
+// The fast kernel for the lanes of several register tiles in one launch (half-float flavour), and the exact kernel over the
+// ambiguous groups of one tile's lanes afterwards.  msv_tier: the tier a tile belongs to (0..kMsvTiers-1); lanes of a
+// launch must share it.
+constexpr int kMsvTiers = 5;
+int  msv_tier(int R, int K);
+int  msv_tier_launch(int tier, const ArgRun<MsvArgs> &main, int num_cu, hipStream_t st);
+int  msv_exact_launch(int R, int K, const ArgRun<MsvArgs> &amb, int num_cu, hipStream_t st);
 
 // ---- wave-per-sequence stages (p7x_vitfwd.hip): Viterbi filter, Forward / Backward parsers
 // Node k = z*C + c + 1 lives in lane z, chunk position c; device tables are stored [c*64 + z].

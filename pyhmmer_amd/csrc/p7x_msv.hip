@@ -348,12 +348,10 @@ __global__ void __launch_bounds__(msv_block_c(K)) msv_kernel(const ArgRef ref)
 // Every value is a multiple of 2^-8 below 4: binary16 arithmetic on them is exact, the integers that leave the kernel
 // are the same as the integer flavour's (option msv_f16 = 0 selects that one; tests compare both with the oracle).
 template <int R, int K, bool H>
-__global__ void __launch_bounds__(msv_block_c(K), (K > 1 ? 2 : (R <= 92 ? 4 : (R <= 136 ? 3 : 2)))) msv_fast_kernel(const ArgRef ref)
+__device__ __forceinline__ void msv_fast_body(const MsvArgs &a, uint32_t *lds)
 {
-  extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
   constexpr int S = msv_row_stride_c(R, K), Rs = msv_lane_stride_c(R, K), BLK = msv_block_c(K);
   constexpr int MODE = H ? 2 : 1;
-  const MsvArgs a = load_args<MsvArgs>(ref);
   const int nitems = (a.ngroups - a.group_first) * K;
   if (*a.counter >= nitems) return;            // this lane's groups are all taken: skip the table load
   {
@@ -448,6 +446,68 @@ __global__ void __launch_bounds__(msv_block_c(K), (K > 1 ? 2 : (R <= 92 ? 4 : (R
   }
 }
 
+constexpr int msv_min_blocks_c(int R, int K) { return K > 1 ? 2 : (R <= 92 ? 4 : (R <= 136 ? 3 : 2)); }
+
+template <int R, int K, bool H>
+__global__ void __launch_bounds__(msv_block_c(K), msv_min_blocks_c(R, K)) msv_fast_kernel(const ArgRef ref)
+{
+  extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
+  const MsvArgs a = load_args<MsvArgs>(ref);
+  msv_fast_body<R, K, H>(a, lds);
+}
+
+// One launch for the lanes of SEVERAL register tiles (half-float flavour): a workgroup serves one lane (blockIdx.y) and
+// branches, uniformly, to that lane's instantiation of the row loop.  A batch of the scan orientation holds up to 28 tiles
+// with 1-900 profiles each against a block of a few dozen 64-target groups: one launch per tile is a few hundred to a
+// few thousand wavefronts that last as long as the block's longest group, eight of them in flight on the hardware
+// queues beside the other stages' kernels -- the device ran the MSV stage at a quarter of its rate.  A tier -- the tiles
+// that share a block size and an occupancy -- is one launch that fills the device.  The dynamic LDS of the launch is that
+// of its largest tile; the occupancy that the tier promises (4 / 3 / 2 blocks per CU) holds for it.
+//   tier 0: K = 1, R <= 92;  1: K = 1, R <= 136;  2: K = 1, R <= 224;  3: K = 2;  4: K = 4
+constexpr int msv_tier_block_c(int T) { return T <= 2 ? 256 : 512; }
+constexpr int msv_tier_min_blocks_c(int T) { return T == 0 ? 4 : (T == 1 ? 3 : 2); }
+
+template <int TIER>
+__global__ void __launch_bounds__(msv_tier_block_c(TIER), msv_tier_min_blocks_c(TIER)) msv_tier_kernel(const ArgRef ref)
+{
+  extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
+  const MsvArgs a = load_args<MsvArgs>(ref);
+  const int R = __builtin_amdgcn_readfirstlane(a.R);
+#define P7X_TILE(r, k) case r: msv_fast_body<r, k, true>(a, lds); break;
+  if constexpr (TIER == 0) {
+    switch (R) {
+      P7X_TILE(8, 1) P7X_TILE(12, 1) P7X_TILE(16, 1) P7X_TILE(20, 1) P7X_TILE(24, 1) P7X_TILE(28, 1) P7X_TILE(32, 1) P7X_TILE(36, 1)
+      P7X_TILE(40, 1) P7X_TILE(44, 1) P7X_TILE(48, 1) P7X_TILE(52, 1) P7X_TILE(56, 1) P7X_TILE(60, 1) P7X_TILE(64, 1) P7X_TILE(68, 1)
+      P7X_TILE(72, 1) P7X_TILE(76, 1) P7X_TILE(80, 1) P7X_TILE(84, 1) P7X_TILE(88, 1) P7X_TILE(92, 1)
+      default: break;
+    }
+  } else if constexpr (TIER == 1) {
+    switch (R) {
+      P7X_TILE(96, 1) P7X_TILE(100, 1) P7X_TILE(104, 1) P7X_TILE(108, 1) P7X_TILE(112, 1) P7X_TILE(116, 1) P7X_TILE(120, 1)
+      P7X_TILE(124, 1) P7X_TILE(128, 1) P7X_TILE(132, 1) P7X_TILE(136, 1)
+      default: break;
+    }
+  } else if constexpr (TIER == 2) {
+    switch (R) {
+      P7X_TILE(140, 1) P7X_TILE(144, 1) P7X_TILE(148, 1) P7X_TILE(152, 1) P7X_TILE(156, 1) P7X_TILE(160, 1) P7X_TILE(176, 1)
+      P7X_TILE(192, 1) P7X_TILE(208, 1) P7X_TILE(224, 1)
+      default: break;
+    }
+  } else if constexpr (TIER == 3) {
+    switch (R) {
+      P7X_TILE(120, 2) P7X_TILE(128, 2) P7X_TILE(136, 2) P7X_TILE(144, 2) P7X_TILE(152, 2) P7X_TILE(160, 2) P7X_TILE(168, 2)
+      P7X_TILE(176, 2) P7X_TILE(184, 2) P7X_TILE(192, 2) P7X_TILE(200, 2) P7X_TILE(208, 2) P7X_TILE(216, 2) P7X_TILE(224, 2)
+      default: break;
+    }
+  } else {
+    switch (R) {
+      P7X_TILE(120, 4) P7X_TILE(128, 4)
+      default: break;
+    }
+  }
+#undef P7X_TILE
+}
+
 // ---------------------------------------------------------------------------- host side
 
 // One lane per target up to 224 row registers (M <= 445); two lanes (M <= 893) and four lanes (M <= 1021) beyond, while
@@ -504,7 +564,7 @@ void msv_build_tables(const Profile &p, int R, int K, std::vector<uint32_t> &out
 }
 
 template <int R, int K>
-static int launch_RK(const ArgRun<MsvArgs> &main, const ArgRun<MsvArgs> *amb, int num_cu, hipStream_t st)
+static int launch_RK(const ArgRun<MsvArgs> &main, const ArgRun<MsvArgs> *amb, int num_cu, hipStream_t st, bool amb_only = false)
 {
   constexpr int BLK = msv_block_c(K);
   const size_t lds_bytes = (size_t) 2 * kTabRows * msv_row_stride_c(R, K) * 4;
@@ -534,6 +594,11 @@ static int launch_RK(const ArgRun<MsvArgs> &main, const ArgRun<MsvArgs> *amb, in
     }
     info = slot;
   }
+  if (amb_only) {                        // the fast kernel ran as part of a tier launch: only the lists of ambiguous groups are left
+    hipLaunchKernelGGL((msv_kernel<R, K>), dim3(lane_grid(32, 32, amb->n), (unsigned) amb->n), dim3(BLK), lds_bytes, st, amb->ref());
+    P7X_HIP(hipGetLastError());
+    return P7X_OK;
+  }
   constexpr int wpb = BLK / 64;          // wavefronts (work items in flight) per block
   long want = 1;
   for (int i = 0; i < main.n; ++i) want = std::max<long>(want, ((long) (main.at(i).ngroups - main.at(i).group_first) * K + wpb - 1) / wpb);
@@ -558,22 +623,92 @@ static int launch_RK(const ArgRun<MsvArgs> &main, const ArgRun<MsvArgs> *amb, in
   return P7X_OK;
 }
 
+static int msv_launch_impl(int R, int K, const ArgRun<MsvArgs> &main, const ArgRun<MsvArgs> *amb, int num_cu, hipStream_t st, bool amb_only);
+
 int msv_launch(int R, int K, const ArgRun<MsvArgs> &main, const ArgRun<MsvArgs> *amb, int num_cu, hipStream_t st)
+{ return msv_launch_impl(R, K, main, amb, num_cu, st, false); }
+
+int msv_exact_launch(int R, int K, const ArgRun<MsvArgs> &amb, int num_cu, hipStream_t st)
+{ return msv_launch_impl(R, K, amb, &amb, num_cu, st, true); }
+
+int msv_tier(int R, int K)
+{
+  if (K == 1) return R <= 92 ? 0 : (R <= 136 ? 1 : 2);
+  return K == 2 ? 3 : 4;
+}
+
+template <int TIER>
+static int launch_tier(const ArgRun<MsvArgs> &main, int num_cu, hipStream_t st)
+{
+  constexpr int BLK = msv_tier_block_c(TIER), K = TIER <= 2 ? 1 : (TIER == 3 ? 2 : 4);
+  int Rmax = 0;
+  long want = 1;
+  constexpr int wpb = BLK / 64;
+  for (int i = 0; i < main.n; ++i) {
+    const MsvArgs &a = main.at(i);
+    if (msv_tier(a.R, K) != TIER) { set_error("msv_tier_launch: a lane of another tier"); return P7X_EINVAL; }
+    Rmax = std::max(Rmax, a.R);
+    want = std::max<long>(want, ((long) (a.ngroups - a.group_first) * K + wpb - 1) / wpb);
+  }
+  const size_t lds_bytes = (size_t) 2 * kTabRows * row_stride(Rmax, K) * 4;
+  // occupancy by (device, LDS bytes); the LDS opt-in once per device, for the tier's largest tile
+  static std::map<std::pair<int, size_t>, int> per_cu_of;
+  static std::map<int, bool> opted;
+  static std::mutex mu;
+  int per_cu = 0;
+  {
+    int dev = 0; P7X_HIP(hipGetDevice(&dev));
+    std::lock_guard<std::mutex> lk(mu);
+    if (!opted[dev]) {
+      constexpr int Rtop = TIER == 0 ? 92 : (TIER == 1 ? 136 : (TIER == 4 ? 128 : 224));
+      const size_t most = (size_t) 2 * kTabRows * row_stride(Rtop, K) * 4;
+      if (most > 64 * 1024)
+        P7X_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&msv_tier_kernel<TIER>), hipFuncAttributeMaxDynamicSharedMemorySize, (int) most));
+      opted[dev] = true;
+    }
+    auto it = per_cu_of.find({ dev, lds_bytes });
+    if (it == per_cu_of.end()) {
+      int v = 0;
+      P7X_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&v, msv_tier_kernel<TIER>, BLK, lds_bytes));
+      it = per_cu_of.emplace(std::make_pair(dev, lds_bytes), std::max(v, 1)).first;
+    }
+    per_cu = it->second;
+  }
+  const unsigned gx = lane_grid(want, (long) num_cu * per_cu, main.n);
+  hipLaunchKernelGGL((msv_tier_kernel<TIER>), dim3(gx, (unsigned) main.n), dim3(BLK), lds_bytes, st, main.ref());
+  P7X_HIP(hipGetLastError());
+  return P7X_OK;
+}
+
+int msv_tier_launch(int tier, const ArgRun<MsvArgs> &main, int num_cu, hipStream_t st)
+{
+  if (main.n <= 0) return P7X_OK;
+  switch (tier) {
+    case 0: return launch_tier<0>(main, num_cu, st);
+    case 1: return launch_tier<1>(main, num_cu, st);
+    case 2: return launch_tier<2>(main, num_cu, st);
+    case 3: return launch_tier<3>(main, num_cu, st);
+    case 4: return launch_tier<4>(main, num_cu, st);
+    default: set_error("msv_tier_launch: no such tier"); return P7X_EINVAL;
+  }
+}
+
+static int msv_launch_impl(int R, int K, const ArgRun<MsvArgs> &main, const ArgRun<MsvArgs> *amb, int num_cu, hipStream_t st, bool amb_only)
 {
   if (main.n <= 0) return P7X_OK;
   switch (K * 1000 + R) {
-#define P7X_CASE(r) case 1000 + r: return launch_RK<r, 1>(main, amb, num_cu, st);
+#define P7X_CASE(r) case 1000 + r: return launch_RK<r, 1>(main, amb, num_cu, st, amb_only);
     P7X_CASE(8) P7X_CASE(12) P7X_CASE(16) P7X_CASE(20) P7X_CASE(24) P7X_CASE(28) P7X_CASE(32) P7X_CASE(36) P7X_CASE(40)
     P7X_CASE(44) P7X_CASE(48) P7X_CASE(52) P7X_CASE(56) P7X_CASE(60) P7X_CASE(64) P7X_CASE(68) P7X_CASE(72) P7X_CASE(76)
     P7X_CASE(80) P7X_CASE(84) P7X_CASE(88) P7X_CASE(92) P7X_CASE(96) P7X_CASE(100) P7X_CASE(104) P7X_CASE(108) P7X_CASE(112)
     P7X_CASE(116) P7X_CASE(120) P7X_CASE(124) P7X_CASE(128) P7X_CASE(132) P7X_CASE(136) P7X_CASE(140) P7X_CASE(144)
     P7X_CASE(148) P7X_CASE(152) P7X_CASE(156) P7X_CASE(160) P7X_CASE(176) P7X_CASE(192) P7X_CASE(208) P7X_CASE(224)
 #undef P7X_CASE
-#define P7X_CASE(r) case 2000 + r: return launch_RK<r, 2>(main, amb, num_cu, st);
+#define P7X_CASE(r) case 2000 + r: return launch_RK<r, 2>(main, amb, num_cu, st, amb_only);
     P7X_CASE(120) P7X_CASE(128) P7X_CASE(136) P7X_CASE(144) P7X_CASE(152) P7X_CASE(160) P7X_CASE(168) P7X_CASE(176)
     P7X_CASE(184) P7X_CASE(192) P7X_CASE(200) P7X_CASE(208) P7X_CASE(216) P7X_CASE(224)
 #undef P7X_CASE
-#define P7X_CASE(r) case 4000 + r: return launch_RK<r, 4>(main, amb, num_cu, st);
+#define P7X_CASE(r) case 4000 + r: return launch_RK<r, 4>(main, amb, num_cu, st, amb_only);
     P7X_CASE(120) P7X_CASE(128)
 #undef P7X_CASE
     default: set_error("msv_launch: unsupported register tile"); return P7X_EINVAL;

@@ -541,10 +541,13 @@ struct Workspace {
   static constexpr int kSide = DeviceCtx::kWsSide;        // the streams belong to the device context (queue placement, see there)
   hipStream_t side[kSide]{};
   hipEvent_t ev_fork = nullptr, ev_join[kSide]{};
+  static constexpr int kTierRuns = 8;      // MSV tier launches of a batch (p7x_msv.hip: five tiers; runs of lanes that share one)
+  hipEvent_t ev_tier[kTierRuns]{};
   int *h_counts = nullptr; size_t h_counts_bytes = 0;   // pinned mirror of counters
   // results of the Forward survivors of all lanes, packed by pack_survivors_kernel for one copy to the host
   unsigned char *pack_dev = nullptr; size_t pack_dev_bytes = 0;      // slab of the context's pool
   unsigned char *pack_host = nullptr; size_t pack_host_bytes = 0;    // pinned
+  int64_t early_T_cap = 0;          // > 0: the enqueue half packed and copied the survivors' results itself, for up to this many
   bool busy = false;                // between the enqueue and the collect half of a cascade
   int set = -1;                     // the context's stream set this lease runs on (taken when leased, given back on release)
   size_t counters_bytes() const { return (size_t) nlanes * kLaneCounters * 4 + 8; }
@@ -562,6 +565,7 @@ struct Workspace {
     if (ev_sync) (void) hipEventDestroy(ev_sync);
     if (ev_fork) (void) hipEventDestroy(ev_fork);
     for (auto &e : ev_join) if (e) (void) hipEventDestroy(e);
+    for (auto &e : ev_tier) if (e) (void) hipEventDestroy(e);
     pinned_release(h_counts, h_counts_bytes);
     pinned_release(pack_host, pack_host_bytes); (void) hipFree(pack_dev);
     pinned_release(h_args, h_args_bytes);
@@ -652,6 +656,7 @@ static int get_workspace(int device, int64_t nslots, int nlanes, Workspace **out
     if (cst != P7X_OK) return cst;
     P7X_HIP(hipEventCreateWithFlags(&w->ev_fork, hipEventDisableTiming));
     for (auto &e : w->ev_join) P7X_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    for (auto &e : w->ev_tier) P7X_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
   }
   w->busy = true;
   *out = w.get();
@@ -768,6 +773,7 @@ static void fill_msv_args(LaneArgs &la, const Profile &p, const DevProfile *dp, 
   a.counter = &b.counters[0]; a.out_xJ = b.xJ;
   a.amb_count = &b.counters[10]; a.counter2 = &b.counters[11];
   a.amb_groups = msv_exact_only() ? nullptr : b.list_fin;     // list_fin is free until the Forward stage
+  a.R = dp->msvR;
   la.msv = a;
   MsvArgs x = a;
   x.group_list = a.amb_groups; x.group_count = a.amb_count; x.counter = a.counter2; x.amb_groups = nullptr;
@@ -852,6 +858,18 @@ static int class_msv(const LaneClass &c, const std::vector<LaneModel> &lm, Devic
   return msv_launch(lm[c.first].dp->msvR, lm[c.first].dp->msvK, lane_run(ws, &LaneArgs::msv, c.first, c.n), msv_exact_only() ? nullptr : &amb, ctx->num_cu, stream);
 }
 
+// What is left of class_msv for a class whose fast kernel ran inside a tier launch (msv_tier_launch): the longest targets'
+// wave-per-target pass, and the exact kernel over the groups the fast kernel reported as ambiguous.
+static int class_msv_rest(const LaneClass &c, const std::vector<LaneModel> &lm, DeviceCtx *ctx, Workspace *ws, hipStream_t stream)
+{
+  if (c.nlong > 0) {
+    const int st = msv_wave_launch(lane_run(ws, &LaneArgs::msvw, c.first, c.n), ctx->num_cu, stream);
+    if (st != P7X_OK) return st;
+  }
+  return msv_exact_launch(lm[c.first].dp->msvR, lm[c.first].dp->msvK, lane_run(ws, &LaneArgs::msv_amb, c.first, c.n), ctx->num_cu, stream);
+}
+static bool msv_tiers_enabled() { return !msv_exact_only() && debug_opt(OPT_MSV_F16) != 0 && debug_opt(OPT_MSV_TIERS) != 0; }
+
 // Viterbi filter over the lanes' work lists: the packed kernel when the model fits it, else one target per wavefront.
 static int class_viterbi(const LaneClass &c, const std::vector<LaneModel> &lm, DeviceCtx *ctx, Workspace *ws, hipStream_t s)
 {
@@ -913,6 +931,7 @@ struct PackArgs {
   const int32_t *lane_base;                                                       // [nlanes]
   int32_t *fin; float *fwd; int64_t *off; int32_t *regn; float *nexp; int32_t *reg_start; int32_t *regs; int32_t regs_cap;
   int *cursor;
+  int64_t tcap;             // survivors the packed arrays hold (a batch with more is packed again, to measure, by the collect half)
 };
 __global__ void pack_survivors_kernel(const PackArgs a)
 {
@@ -922,6 +941,7 @@ __global__ void pack_survivors_kernel(const PackArgs a)
   const int32_t *reg_l = a.reg_out + (size_t) l * (size_t) a.cap * (kRegionCap * 3 + 2);
   for (int i = (int) (blockIdx.x * blockDim.x + threadIdx.x); i < nfin; i += (int) (gridDim.x * blockDim.x)) {
     const int64_t t = (int64_t) a.lane_base[l] + i;
+    if (t >= a.tcap) return;
     a.fin[t] = a.list_fin[(size_t) l * a.slot_pitch + i];
     a.fwd[t] = a.fwd_by_item[(size_t) l * a.slot_pitch + i];
     a.off[t] = a.xmx_off[(size_t) l * a.cap + i];
@@ -939,6 +959,40 @@ __global__ void pack_survivors_kernel(const PackArgs a)
     }
     a.reg_start[t] = start;
   }
+}
+
+// first survivor of every lane in the packed arrays (exclusive prefix sum of the lanes' survivor counts, flagged lanes
+// counting nothing -- what the collect half computes on the host from the counters), and the region cursor's reset
+__global__ void __launch_bounds__(1024) lane_base_kernel(const int *counters, int nq, int32_t *lane_base, int *cursor)
+{
+  __shared__ int part[1024];
+  const int t = (int) threadIdx.x, per = (nq + 1023) / 1024;
+  auto count_of = [&](int l) { return counters[(size_t) l * kLaneCounters + 12] != 0 ? 0 : counters[(size_t) l * kLaneCounters + 4]; };
+  int sum = 0;
+  for (int i = 0; i < per; ++i) { const int l = t * per + i; if (l < nq) sum += count_of(l); }
+  part[t] = sum;
+  __syncthreads();
+  if (t == 0) {
+    int run = 0;
+    for (int i = 0; i < 1024; ++i) { const int v = part[i]; part[i] = run; run += v; }
+    *cursor = 0;
+  }
+  __syncthreads();
+  int run = part[t];
+  for (int i = 0; i < per; ++i) { const int l = t * per + i; if (l < nq) { lane_base[l] = run; run += count_of(l); } }
+}
+
+// where the packed results of <T> survivors of <nq> lanes lie (device slab and its pinned mirror)
+struct PackLayout { size_t o_base, o_cursor, o_off, o_fin, o_fwd, o_regn, o_nexp, o_start, o_regs, o_stage, bytes; int64_t regs_cap; };
+static PackLayout pack_layout(int nq, int64_t T, bool scan_mode, int64_t nslots)
+{
+  PackLayout p{};
+  p.regs_cap = std::max<int64_t>(8 * T, 4096);
+  p.o_base = 0; p.o_cursor = (size_t) nq * 4; p.o_off = (p.o_cursor + 4 + 7) & ~(size_t) 7;
+  p.o_fin = p.o_off + (size_t) T * 8; p.o_fwd = p.o_fin + (size_t) T * 4; p.o_regn = p.o_fwd + (size_t) T * 4; p.o_nexp = p.o_regn + (size_t) T * 4;
+  p.o_start = p.o_nexp + (size_t) T * 4; p.o_regs = p.o_start + (size_t) T * 4; p.o_stage = p.o_regs + (size_t) p.regs_cap * 12;
+  p.bytes = p.o_stage + (scan_mode ? (size_t) nq * (size_t) nslots : 0);
+  return p;
 }
 
 // rows of the <count> longest targets (slots are sorted by decreasing length): bounds the rows of any <count> survivors
@@ -1049,7 +1103,7 @@ static int launch_survivor_passes(CascadeRun &r, const LaneClass &c, hipStream_t
 }
 
 // every kernel of stage 1 for the lanes of one class, on stream <s>
-static int class_cascade(CascadeRun &r, const LaneClass &c, hipStream_t s, bool record_events, bool chain_msv)
+static int class_cascade(CascadeRun &r, const LaneClass &c, hipStream_t s, bool record_events, bool chain_msv, bool msv_by_tier = false)
 {
   const p7x_seqdb *db = r.db; Workspace *ws = r.ws; DeviceCtx *ctx = r.ctx;
   int st = P7X_OK;
@@ -1065,7 +1119,7 @@ static int class_cascade(CascadeRun &r, const LaneClass &c, hipStream_t s, bool 
     P7X_HIP(hipEventRecord(ctx->msv_done[ctx->msv_last], s));
   } else {
     if (record_events) P7X_HIP(hipEventRecord(ws->ev[0], s));
-    if ((st = class_msv(c, r.lm, ctx, ws, s)) != P7X_OK) return st;
+    if ((st = msv_by_tier ? class_msv_rest(c, r.lm, ctx, ws, s) : class_msv(c, r.lm, ctx, ws, s)) != P7X_OK) return st;
     if (record_events) P7X_HIP(hipEventRecord(ws->ev[7], s));
   }
   const ArgRef dec = lane_run(ws, &LaneArgs::dec, c.first, c.n).ref();
@@ -1087,6 +1141,114 @@ static int class_cascade(CascadeRun &r, const LaneClass &c, hipStream_t s, bool 
   P7X_HIP(hipGetLastError());
   if (record_events) P7X_HIP(hipEventRecord(ws->ev[4], s));
   return launch_survivor_passes(r, c, s, false, record_events);
+}
+
+struct CascadeRun;
+struct PackLayout;
+static int queue_pack(CascadeRun &r, const PackLayout &lay, int64_t T, const int32_t *lane_base, int max_nfin);
+
+// The batch stage by stage instead of class by class (multi-class batches against a small block: the scan orientation).
+// The kernels that are the same for every lane -- the MSV decision, the bias filter, the compaction of the Viterbi work
+// list, the Viterbi and Forward decisions, the row layout, the region scan -- run ONCE over all lanes of the batch on the
+// workspace's stream; only the stages whose kernels are instantiated per model size fan out over the side streams (MSV
+// by tier, Viterbi by (kernel, nodes per lane), the parsers by nodes per lane) and join again.  Against a block of a few
+// dozen 64-target groups every launch is latency bound (it lasts as long as the longest target takes one wavefront or,
+// for the bias filter, one lane), the hardware runs eight launches at a time, and a class-by-class batch of 28 classes is
+// 28 x 16 of them; stage by stage it is about 28 + 28 + 12 + 24 + 9.
+static int staged_cascade(CascadeRun &r, const std::vector<LaneClass> &classes, hipStream_t s, int nside, const std::vector<int> &run_of)
+{
+  const p7x_seqdb *db = r.db; Workspace *ws = r.ws; DeviceCtx *ctx = r.ctx;
+  const int nq = (int) r.lm.size();
+  constexpr int kStreams = Workspace::kSide + 1;
+  int st = P7X_OK;
+  auto stream_of = [&](size_t n) -> hipStream_t {
+    int turn = (int) (n % (size_t) kStreams);
+    if ((n / (size_t) kStreams) & 1) turn = kStreams - 1 - turn;
+    turn = std::min(turn, nside);
+    return turn == 0 ? s : ws->side[turn - 1];
+  };
+  auto fork = [&]() -> int {
+    P7X_HIP(hipEventRecord(ws->ev_fork, s));
+    for (int k = 0; k < nside; ++k) P7X_HIP(hipStreamWaitEvent(ws->side[k], ws->ev_fork, 0));
+    return P7X_OK;
+  };
+  auto join = [&]() -> int {
+    for (int k = 0; k < nside; ++k) {
+      P7X_HIP(hipEventRecord(ws->ev_join[k], ws->side[k]));
+      P7X_HIP(hipStreamWaitEvent(s, ws->ev_join[k], 0));
+    }
+    return P7X_OK;
+  };
+  // runs of adjacent classes that agree in <same>, as classes of their own (longest models first)
+  auto runs_by = [&](auto same) {
+    std::vector<LaneClass> out;
+    for (const LaneClass &c : classes) {
+      if (!out.empty() && same(out.back(), c)) out.back().n += c.n;
+      else out.push_back(c);
+    }
+    std::reverse(out.begin(), out.end());
+    return out;
+  };
+  // stage A: MSV.  The tier launches are already queued (run_of); what is left per class is the exact kernel over the
+  // ambiguous groups, or the whole MSV stage of the classes outside the tiers (wave-per-target kernels).
+  P7X_HIP(hipEventRecord(ws->ev[0], s));
+  for (size_t n = 0; n < classes.size(); ++n) {
+    const size_t c = classes.size() - 1 - n;
+    hipStream_t cs = stream_of(n);
+    if (run_of[c] >= 0) P7X_HIP(hipStreamWaitEvent(cs, ws->ev_tier[run_of[c]], 0));
+    if ((st = run_of[c] >= 0 ? class_msv_rest(classes[c], r.lm, ctx, ws, cs) : class_msv(classes[c], r.lm, ctx, ws, cs)) != P7X_OK) return st;
+  }
+  if ((st = join()) != P7X_OK) return st;
+  P7X_HIP(hipEventRecord(ws->ev[7], s));
+  const ArgRef dec = lane_run(ws, &LaneArgs::dec, 0, nq).ref();
+  hipLaunchKernelGGL(decide_msv_kernel, dim3((unsigned) ((db->nslots + 255) / 256), (unsigned) nq), dim3(256), 0, s, dec);
+  P7X_HIP(hipEventRecord(ws->ev[1], s));
+  hipLaunchKernelGGL(bias_kernel, dim3(lane_grid((r.est_bias + 63) / 64, ctx->num_cu * 4, nq), (unsigned) nq), dim3(64), 0, s, dec);
+  {
+    const unsigned nchunks = (unsigned) ((db->nslots + kCompactChunk - 1) / kCompactChunk);
+    const ArgRef cmp = lane_run(ws, &LaneArgs::cmp, 0, nq).ref();
+    hipLaunchKernelGGL(vit_compact_count_kernel, dim3(nchunks, (unsigned) nq), dim3(256), 0, s, cmp);
+    hipLaunchKernelGGL(vit_compact_write_kernel, dim3(nchunks, (unsigned) nq), dim3(256), 0, s, cmp);
+  }
+  P7X_HIP(hipGetLastError());
+  P7X_HIP(hipEventRecord(ws->ev[2], s));
+  // stage B: Viterbi, by (kernel instantiation, nodes per lane)
+  if ((st = fork()) != P7X_OK) return st;
+  {
+    const std::vector<LaneClass> runs = runs_by([](const LaneClass &a, const LaneClass &b) { return a.vit_key == b.vit_key && a.C == b.C && a.vit_long == b.vit_long; });
+    for (size_t n = 0; n < runs.size(); ++n)
+      if ((st = class_viterbi(runs[n], r.lm, ctx, ws, stream_of(n))) != P7X_OK) return st;
+  }
+  if ((st = join()) != P7X_OK) return st;
+  hipLaunchKernelGGL(decide_vit_kernel, dim3(lane_grid((r.est_vit + 255) / 256, ctx->num_cu, nq), (unsigned) nq), dim3(256), 0, s, dec);
+  P7X_HIP(hipEventRecord(ws->ev[3], s));
+  // stage C: the Forward parser, by nodes per lane
+  const std::vector<LaneClass> by_C = runs_by([](const LaneClass &a, const LaneClass &b) { return a.C == b.C; });
+  if ((st = fork()) != P7X_OK) return st;
+  for (size_t n = 0; n < by_C.size(); ++n)
+    if ((st = class_wave(by_C[n], ws, &LaneArgs::fwd, false, ctx, stream_of(n))) != P7X_OK) return st;
+  if ((st = join()) != P7X_OK) return st;
+  hipLaunchKernelGGL(decide_fwd_kernel, dim3(lane_grid((r.est_fwd + 255) / 256, ctx->num_cu, nq), (unsigned) nq), dim3(256), 0, s, dec);
+  P7X_HIP(hipEventRecord(ws->ev[4], s));
+  hipLaunchKernelGGL(layout_rows_kernel, dim3(1, (unsigned) nq), dim3(256), 0, s, lane_run(ws, &LaneArgs::lay, 0, nq).ref());
+  P7X_HIP(hipGetLastError());
+  P7X_HIP(hipEventRecord(ws->ev[5], s));
+  // stage D: Forward rows and Backward of the survivors, by nodes per lane; then the region scan of all lanes
+  if ((st = fork()) != P7X_OK) return st;
+  for (size_t n = 0; n < by_C.size(); ++n) {
+    hipStream_t cs = stream_of(n);
+    if ((st = class_wave(by_C[n], ws, &LaneArgs::rows, false, ctx, cs)) != P7X_OK) return st;
+    if ((st = class_wave(by_C[n], ws, &LaneArgs::bck, true, ctx, cs)) != P7X_OK) return st;
+  }
+  if ((st = join()) != P7X_OK) return st;
+  {
+    const int64_t items = std::min<int64_t>(ws->fin_cap, std::max(r.est_fin, 1));
+    const unsigned gx = lane_grid((items + 3) / 4, ctx->num_cu * 4, nq);
+    hipLaunchKernelGGL(regions_kernel, dim3(gx, (unsigned) nq), dim3(256), 0, s, lane_run(ws, &LaneArgs::reg, 0, nq).ref());
+    P7X_HIP(hipGetLastError());
+  }
+  P7X_HIP(hipEventRecord(ws->ev[6], s));
+  return P7X_OK;
 }
 
 static int cascade_enqueue(CascadeRun &r)
@@ -1175,19 +1337,61 @@ static int cascade_enqueue(CascadeRun &r)
     P7X_HIP(hipEventRecord(ws->ev_fork, s));
     const int nside = std::min<int>((int) classes.size() - 1, Workspace::kSide);
     for (int k = 0; k < nside; ++k) P7X_HIP(hipStreamWaitEvent(ws->side[k], ws->ev_fork, 0));
-    for (size_t c = 0; c < classes.size(); ++c) {
-      // back and forth (the classes come in the order of the batch's models, shortest first: dealt in one direction the
-      // last stream would get the heaviest class of every round)
+    // The fast MSV kernel of the whole batch first, as one launch per tier of register tiles (p7x_msv.hip); the classes'
+    // chains then wait for their tier and start at the exact kernel over the ambiguous groups.
+    constexpr int kStreamsAll = Workspace::kSide + 1;
+    std::vector<int> run_of(classes.size(), -1);
+    if (msv_tiers_enabled()) {
+      int nruns = 0, last_tier = -1;
+      for (size_t c = 0; c < classes.size(); ++c) {
+        const LaneClass &k = classes[c];
+        if (k.msv_key < 0) { last_tier = -1; continue; }
+        const int tier = msv_tier(r.lm[k.first].dp->msvR, r.lm[k.first].dp->msvK);
+        if (tier != last_tier) { if (nruns == Workspace::kTierRuns) break; ++nruns; last_tier = tier; }
+        run_of[c] = nruns - 1;
+      }
+      for (int run = nruns - 1; run >= 0; --run) {
+        size_t a = 0; while (run_of[a] != run) ++a;
+        size_t b = a; while (b + 1 < classes.size() && run_of[b + 1] == run) ++b;
+        const int first = classes[a].first, n = classes[b].first + classes[b].n - first;
+        const int turn = (kStreamsAll - 1 - run) % kStreamsAll;       // from the far end: the longest classes' chains are dealt from stream 0
+        hipStream_t ts = turn == 0 ? s : ws->side[std::min(turn, nside) - 1];
+        const LaneClass &k = classes[a];
+        if ((st = msv_tier_launch(msv_tier(r.lm[k.first].dp->msvR, r.lm[k.first].dp->msvK), lane_run(ws, &LaneArgs::msv, first, n), ctx->num_cu, ts)) != P7X_OK) return st;
+        P7X_HIP(hipEventRecord(ws->ev_tier[run], ts));
+      }
+    }
+    // a small block: stage by stage (option stage_merge: 0 never, 1 always, unset: blocks of up to 256 groups)
+    const int sm = debug_opt(OPT_STAGE_MERGE);
+    const bool staged = sm >= 0 ? sm != 0 : db->ngroups <= 256;
+    if (staged) {
+      if ((st = staged_cascade(r, classes, s, nside, run_of)) != P7X_OK) return st;
+    } else
+    for (size_t n = 0; n < classes.size(); ++n) {
+      // the classes of the longest models first (their chains are the longest: started last they would end the batch alone),
+      // dealt back and forth (in one direction the first stream would get the heaviest class of every round)
+      const size_t c = classes.size() - 1 - n;
       constexpr int kStreams = Workspace::kSide + 1;
-      int turn = (int) (c % (size_t) kStreams);
-      if ((c / (size_t) kStreams) & 1) turn = kStreams - 1 - turn;
+      int turn = (int) (n % (size_t) kStreams);
+      if ((n / (size_t) kStreams) & 1) turn = kStreams - 1 - turn;
       hipStream_t cs = turn == 0 ? s : ws->side[turn - 1];
-      if ((st = class_cascade(r, classes[c], cs, c == 0, false)) != P7X_OK) return st;
+      if (run_of[c] >= 0) P7X_HIP(hipStreamWaitEvent(cs, ws->ev_tier[run_of[c]], 0));
+      if ((st = class_cascade(r, classes[c], cs, n == 0, false, run_of[c] >= 0)) != P7X_OK) return st;
     }
     for (int k = 0; k < nside; ++k) {
       P7X_HIP(hipEventRecord(ws->ev_join[k], ws->side[k]));
       P7X_HIP(hipStreamWaitEvent(s, ws->ev_join[k], 0));
     }
+  }
+  // The survivors' results travel with the cascade: gathered and copied behind its last kernel for up to kEarlyPack of them
+  // (the collect half used to queue this after it had read the counts: a second round trip on a stream that shares its
+  // hardware queue with other batches' launches -- 20-90 ms of a scan batch's feeder thread, for a 10 us kernel).
+  ws->early_T_cap = 0;
+  if (debug_opt(OPT_EARLY_PACK) != 0) {
+    constexpr int64_t kEarlyPack = 16384;
+    const PackLayout lay = pack_layout(nq, kEarlyPack, cfg.mode == P7X_SCAN_MODELS, db->nslots);
+    if ((st = queue_pack(r, lay, kEarlyPack, nullptr, 2048)) != P7X_OK) return st;
+    ws->early_T_cap = kEarlyPack;
   }
   P7X_HIP(hipMemcpyAsync(ws->h_counts, ws->counters, ws->counters_bytes(), hipMemcpyDeviceToHost, s));
   P7X_HIP(hipEventRecord(ws->ev_sync, s));
@@ -1254,6 +1458,59 @@ static int fetch_lane_rows(CascadeRun &r, CascadeOut &out)
   return P7X_OK;
 }
 
+// Queue, on the workspace's stream: the gather of the survivors' results into the packed arrays of <lay> and their copy
+// to the pinned mirror (scan orientation: with the per-target stage bytes).  <lane_base> == nullptr: the lanes' first
+// positions are computed on the device (the enqueue half, which does not know the counts yet), else they are the host's.
+static int queue_pack(CascadeRun &r, const PackLayout &lay, int64_t T, const int32_t *lane_base, int max_nfin)
+{
+  Workspace *ws = r.ws; const p7x_seqdb *db = r.db; hipStream_t s = ws->stream;
+  const int nq = (int) r.oms.size();
+  const bool scan_mode = r.cfg.mode == P7X_SCAN_MODELS;
+  int st = P7X_OK;
+  if (lay.bytes > ws->pack_dev_bytes) {
+    slab_release(r.ctx, ws->pack_dev, ws->pack_dev_bytes); ws->pack_dev = nullptr; ws->pack_dev_bytes = 0;
+    void *dp = nullptr; size_t got = 0;
+    if ((st = slab_acquire(r.ctx, lay.bytes + lay.bytes / 2, &dp, &got)) != P7X_OK) return st;
+    ws->pack_dev = static_cast<unsigned char *>(dp); ws->pack_dev_bytes = got;
+  }
+  if (lay.bytes > ws->pack_host_bytes) {
+    pinned_release(ws->pack_host, ws->pack_host_bytes); ws->pack_host = nullptr; ws->pack_host_bytes = 0;
+    void *hp = nullptr; size_t got = 0;
+    if ((st = pinned_acquire(lay.bytes + lay.bytes / 2, &hp, &got)) != P7X_OK) return st;
+    ws->pack_host = static_cast<unsigned char *>(hp); ws->pack_host_bytes = got;
+  }
+  unsigned char *ph = ws->pack_host, *pdv = ws->pack_dev;
+  if (T > 0) {
+    if (lane_base) {
+      std::memcpy(ph + lay.o_base, lane_base, (size_t) nq * 4);
+      *reinterpret_cast<int32_t *>(ph + lay.o_cursor) = 0;
+      P7X_HIP(hipMemcpyAsync(pdv, ph, lay.o_cursor + 4, hipMemcpyHostToDevice, s));
+    } else {
+      hipLaunchKernelGGL(lane_base_kernel, dim3(1), dim3(1024), 0, s, ws->counters, nq, reinterpret_cast<int32_t *>(pdv + lay.o_base),
+                         reinterpret_cast<int *>(pdv + lay.o_cursor));
+    }
+    PackArgs pa{};
+    pa.list_fin = ws->list_fin; pa.fwd_by_item = ws->fwd_by_item; pa.slot_pitch = ws->cap_slots;
+    pa.xmx_off = ws->xmx_off; pa.reg_out = ws->reg_out; pa.cap = ws->fin_cap;
+    pa.counters = ws->counters; pa.lane_base = reinterpret_cast<const int32_t *>(pdv + lay.o_base);
+    pa.fin = reinterpret_cast<int32_t *>(pdv + lay.o_fin); pa.fwd = reinterpret_cast<float *>(pdv + lay.o_fwd);
+    pa.off = reinterpret_cast<int64_t *>(pdv + lay.o_off); pa.regn = reinterpret_cast<int32_t *>(pdv + lay.o_regn);
+    pa.nexp = reinterpret_cast<float *>(pdv + lay.o_nexp); pa.reg_start = reinterpret_cast<int32_t *>(pdv + lay.o_start);
+    pa.regs = reinterpret_cast<int32_t *>(pdv + lay.o_regs); pa.regs_cap = (int32_t) std::min<int64_t>(lay.regs_cap, INT32_MAX);
+    pa.cursor = reinterpret_cast<int *>(pdv + lay.o_cursor);
+    pa.tcap = T;
+    const unsigned gx = (unsigned) std::max(1, std::min(64, (max_nfin + 255) / 256));
+    hipLaunchKernelGGL(pack_survivors_kernel, dim3(gx, (unsigned) nq), dim3(256), 0, s, pa);
+    P7X_HIP(hipGetLastError());
+    P7X_HIP(hipMemcpyAsync(ph + lay.o_cursor, pdv + lay.o_cursor, lay.o_regs - lay.o_cursor, hipMemcpyDeviceToHost, s));
+    // regions: the cursor tells how many there are, but waiting for it costs a round trip; the array is small
+    P7X_HIP(hipMemcpyAsync(ph + lay.o_regs, pdv + lay.o_regs, (size_t) lay.regs_cap * 12, hipMemcpyDeviceToHost, s));
+  }
+  if (scan_mode)           // per-target accounting: which filters every (model, sequence) pair passed
+    P7X_HIP(hipMemcpy2DAsync(ph + lay.o_stage, (size_t) db->nslots, ws->stage, (size_t) ws->cap_slots, (size_t) db->nslots, nq, hipMemcpyDeviceToHost, s));
+  return P7X_OK;
+}
+
 static int cascade_collect(CascadeRun &r, std::vector<CascadeOut> &outs)
 {
   const int nq = (int) r.oms.size();
@@ -1280,47 +1537,19 @@ static int cascade_collect(CascadeRun &r, std::vector<CascadeOut> &outs)
   }
   // One gather kernel and one copy bring the survivors' results of all lanes to the host (pinned): the region scan's
   // own array has kRegionCap slots per survivor, and lane-by-lane or strided copies of it were most of this call.
+  // Normally the enqueue half queued both behind the cascade (queue_pack) and they are here already; a batch with more
+  // survivors than it made room for is packed again, to measure.
   const bool scan_mode = cfg.mode == P7X_SCAN_MODELS;
-  const int64_t regs_cap = std::max<int64_t>(8 * T, 4096);
-  const size_t o_base = 0, o_cursor = (size_t) nq * 4, o_off = (o_cursor + 4 + 7) & ~(size_t) 7;
-  const size_t o_fin = o_off + (size_t) T * 8, o_fwd = o_fin + (size_t) T * 4, o_regn = o_fwd + (size_t) T * 4, o_nexp = o_regn + (size_t) T * 4;
-  const size_t o_start = o_nexp + (size_t) T * 4, o_regs = o_start + (size_t) T * 4, o_stage = o_regs + (size_t) regs_cap * 12;
-  const size_t pack_bytes = o_stage + (scan_mode ? (size_t) nq * (size_t) db->nslots : 0);
-  if (pack_bytes > ws->pack_dev_bytes) {
-    slab_release(r.ctx, ws->pack_dev, ws->pack_dev_bytes); ws->pack_dev = nullptr; ws->pack_dev_bytes = 0;
-    void *dp = nullptr; size_t got = 0;
-    if ((st = slab_acquire(r.ctx, pack_bytes + pack_bytes / 2, &dp, &got)) != P7X_OK) return st;
-    ws->pack_dev = static_cast<unsigned char *>(dp); ws->pack_dev_bytes = got;
+  const bool early = ws->early_T_cap > 0 && T <= ws->early_T_cap;
+  const PackLayout lay = pack_layout(nq, early ? ws->early_T_cap : T, scan_mode, db->nslots);
+  ws->early_T_cap = 0;
+  const size_t o_fin = lay.o_fin, o_fwd = lay.o_fwd, o_regn = lay.o_regn, o_nexp = lay.o_nexp, o_start = lay.o_start, o_regs = lay.o_regs;
+  const size_t o_off = lay.o_off, o_stage = lay.o_stage;
+  if (!early) {
+    if ((st = queue_pack(r, lay, T, lane_base.data(), max_nfin)) != P7X_OK) return st;
+    P7X_HIP(hipEventRecord(ws->ev_sync, s)); P7X_HIP(hipEventSynchronize(ws->ev_sync));
   }
-  if (pack_bytes > ws->pack_host_bytes) {
-    pinned_release(ws->pack_host, ws->pack_host_bytes); ws->pack_host = nullptr; ws->pack_host_bytes = 0;
-    void *hp = nullptr; size_t got = 0;
-    if ((st = pinned_acquire(pack_bytes + pack_bytes / 2, &hp, &got)) != P7X_OK) return st;
-    ws->pack_host = static_cast<unsigned char *>(hp); ws->pack_host_bytes = got;
-  }
-  unsigned char *ph = ws->pack_host, *pdv = ws->pack_dev;
-  if (T > 0) {
-    std::memcpy(ph + o_base, lane_base.data(), (size_t) nq * 4);
-    *reinterpret_cast<int32_t *>(ph + o_cursor) = 0;
-    P7X_HIP(hipMemcpyAsync(pdv, ph, o_cursor + 4, hipMemcpyHostToDevice, s));
-    PackArgs pa{};
-    pa.list_fin = ws->list_fin; pa.fwd_by_item = ws->fwd_by_item; pa.slot_pitch = ws->cap_slots;
-    pa.xmx_off = ws->xmx_off; pa.reg_out = ws->reg_out; pa.cap = ws->fin_cap;
-    pa.counters = ws->counters; pa.lane_base = reinterpret_cast<const int32_t *>(pdv + o_base);
-    pa.fin = reinterpret_cast<int32_t *>(pdv + o_fin); pa.fwd = reinterpret_cast<float *>(pdv + o_fwd);
-    pa.off = reinterpret_cast<int64_t *>(pdv + o_off); pa.regn = reinterpret_cast<int32_t *>(pdv + o_regn);
-    pa.nexp = reinterpret_cast<float *>(pdv + o_nexp); pa.reg_start = reinterpret_cast<int32_t *>(pdv + o_start);
-    pa.regs = reinterpret_cast<int32_t *>(pdv + o_regs); pa.regs_cap = (int32_t) std::min<int64_t>(regs_cap, INT32_MAX);
-    pa.cursor = reinterpret_cast<int *>(pdv + o_cursor);
-    const unsigned gx = (unsigned) std::max(1, std::min(64, (max_nfin + 255) / 256));
-    hipLaunchKernelGGL(pack_survivors_kernel, dim3(gx, (unsigned) nq), dim3(256), 0, s, pa);
-    P7X_HIP(hipMemcpyAsync(ph + o_cursor, pdv + o_cursor, o_regs - o_cursor, hipMemcpyDeviceToHost, s));
-    // regions: the cursor tells how many there are, but waiting for it costs a round trip; the array is small
-    P7X_HIP(hipMemcpyAsync(ph + o_regs, pdv + o_regs, (size_t) regs_cap * 12, hipMemcpyDeviceToHost, s));
-  }
-  if (scan_mode)           // per-target accounting: which filters every (model, sequence) pair passed
-    P7X_HIP(hipMemcpy2DAsync(ph + o_stage, (size_t) db->nslots, ws->stage, (size_t) ws->cap_slots, (size_t) db->nslots, nq, hipMemcpyDeviceToHost, s));
-  P7X_HIP(hipEventRecord(ws->ev_sync, s)); P7X_HIP(hipEventSynchronize(ws->ev_sync));
+  unsigned char *ph = ws->pack_host;
   const uint8_t *by_slot = ph + o_stage;
   if (T > 0) {
     const int32_t *h_fin = reinterpret_cast<const int32_t *>(ph + o_fin), *h_regn = reinterpret_cast<const int32_t *>(ph + o_regn);
@@ -1751,13 +1980,25 @@ int p7x_search_batch_finish(p7x_pending *pd, const char *const *names, const cha
       scorer2 = make_device_envelope_scorer(ctx, db, pd->cfg.oa_guard);
     } else if (device_clustered(pd->cfg.host_threads)) scorer2 = make_device_envelope_scorer(ctx, db, pd->cfg.oa_guard);
   }
+  const auto t2 = std::chrono::steady_clock::now();
   if ((st = host_finish_batch(pd->cfg, items, tg, names, accs, descs, outs, scorer.get(), scorer2.get(), ensembles.get())) != P7X_OK) return st;
   // work time of this batch (stage 1 + stage 2), not the time it spent queued between the stages
-  const double stage2 = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t1).count();
+  const auto t3 = std::chrono::steady_clock::now();
+  const double stage2 = std::chrono::duration<double, std::milli>(t3 - t1).count();
   for (size_t q = 0; q < nq; ++q) {
     CascadeOut &co = pd->co[q];
     if (!co.stage.empty()) tophits_set_stages(outs[q], std::move(co.stage));
     tophits_set_total_ms(outs[q], co.ms[6], stage2);
+  }
+  if (debug_opt(OPT_TRACE_FINISH) > 0) {       // where the call spends its time, the teardown of its helpers included
+    auto ms = [](auto a, auto b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
+    const auto t4 = std::chrono::steady_clock::now();
+    ensembles.reset(); scorer2.reset(); scorer.reset();
+    const auto t5 = std::chrono::steady_clock::now();
+    owner.reset();
+    const auto t6 = std::chrono::steady_clock::now();
+    std::fprintf(stderr, "[batch_finish] nq %zu: items %.2f helpers %.2f host_finish_batch %.2f stages %.2f helpers' teardown %.2f pending's teardown %.2f ms\n",
+                 nq, ms(t1, t2) - 0.0, 0.0, ms(t2, t3), ms(t3, t4), ms(t4, t5), ms(t5, t6));
   }
   return P7X_OK;
 }

@@ -600,6 +600,7 @@ int p7x_postprocess_targets(const p7x_pipeline_cfg *cfg, const p7x_oprofile *om,
 }
 
 void p7x_tophits_destroy(p7x_tophits *th) { delete th; }
+void p7x_tophits_destroy_many(p7x_tophits **th, size_t n) { if (th) for (size_t i = 0; i < n; ++i) { delete th[i]; th[i] = nullptr; } }
 p7x_tophits *p7x_tophits_clone(const p7x_tophits *th) { return th ? new p7x_tophits(*th) : nullptr; }
 int64_t p7x_tophits_nhits(const p7x_tophits *th) { return th ? (int64_t) th->hits.size() : -1; }
 

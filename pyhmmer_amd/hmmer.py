@@ -112,11 +112,17 @@ class ShardedDatabase:
         for pend in pendings or ():
             _lib.lib().p7x_pending_destroy(pend[0])
 
-    def finish(self, pendings: list) -> List[TopHits]:
+    def finish(self, pendings: list, raw: bool = False) -> List[TopHits]:
         """Stage 2 (domain definition, hit lists) on every shard, then the per-query merge (``TopHits.merge``:
-        concatenate, sum the counters and ``Z``, re-threshold, re-sort -- reference ``_hmmsearch.py:259-263``)."""
+        concatenate, sum the counters and ``Z``, re-threshold, re-sort -- reference ``_hmmsearch.py:259-263``).
+        ``raw`` (one shard only: the scan orientation): the results as ``plan7.HitHandles`` instead of ``TopHits`` objects."""
         per_shard: list = []
         todo = list(pendings)
+        if raw:
+            if len(todo) != 1:
+                self.abandon(todo)
+                raise ValueError("raw results come from one shard")
+            return Pipeline._search_finish_batch(todo[0], raw=True)
         if len(todo) > 1:
             # the host stage of a shard is mostly a wait for its own device (envelope kernel, ensembles: tens of milliseconds):
             # the shards' stages run side by side, one thread each -- one after the other they would add up to a host stage
@@ -172,8 +178,8 @@ class ReplicatedDatabase(ShardedDatabase):
             self._next = (i + 1) % len(self.shards)
         return [pipelines[i]._search_enqueue_batch(queries, self.shards[i])]
 
-    def finish(self, pendings: list) -> List[TopHits]:
-        return Pipeline._search_finish_batch(pendings[0])
+    def finish(self, pendings: list, raw: bool = False) -> List[TopHits]:
+        return Pipeline._search_finish_batch(pendings[0], raw=raw)
 
 
 def hmmpress(hmms: Iterable, output) -> int:
@@ -382,7 +388,8 @@ def _query_length(q) -> int:
 
 
 def _run_queries(db: "ShardedDatabase", pipelines: Sequence[Pipeline], queries: Iterable, pipeline_depth: int,
-                 feeders: int, window: int = 1, finishers: int = 0, batch: int = 1, reorder: int = 32, by_batch: bool = False) -> Iterator:
+                 feeders: int, window: int = 1, finishers: int = 0, batch: int = 1, reorder: int = 32, by_batch: bool = False,
+                 raw: bool = False) -> Iterator:
     """Yield ``(query, TopHits)`` for every query, in input order -- or, with ``by_batch``, ``(input indices, queries, [TopHits])``
     for every batch as soon as it is finished (the scan orientation folds a batch's results into per-sequence lists while
     the next batches are still on the device; their order is restored from the indices).  Queries travel in batches of ``batch`` (one set of
@@ -423,7 +430,10 @@ def _run_queries(db: "ShardedDatabase", pipelines: Sequence[Pipeline], queries: 
             if not chunk:
                 return
             inputs.update((base + i, q) for i, q in enumerate(chunk))
-            idx = sorted(range(len(chunk)), key=lambda i: _query_length(chunk[i])) if span > 1 else list(range(len(chunk)))
+            # by_batch (the scan orientation, whose results are re-ordered by index anyway): the longest models first, so that
+            # the batches with the most class chains and the longest host stage run while the others are still to come and the
+            # pass ends on the cheapest batch's host stage, not the dearest's
+            idx = sorted(range(len(chunk)), key=lambda i: _query_length(chunk[i]), reverse=by_batch) if span > 1 else list(range(len(chunk)))
             lo = 0
             while lo < len(idx):
                 if auto:                      # as many queries as the cell budget holds (short models: many, long ones: few)
@@ -447,7 +457,7 @@ def _run_queries(db: "ShardedDatabase", pipelines: Sequence[Pipeline], queries: 
     nxt = 0
     pos = 0                               # batches' members consumed from `order`
     failure = None
-    runner = _run_batches(db, pipelines, sorted_batches(), pipeline_depth, feeders, window, finishers)
+    runner = _run_batches(db, pipelines, sorted_batches(), pipeline_depth, feeders, window, finishers, raw=raw)
     for qs, hits, err in runner:
         members = order[pos:pos + len(qs)]
         pos += len(qs)
@@ -507,11 +517,11 @@ def _pipe_trace(what, idx, n=None):
     sys.stderr.write(f"[pipe] {1e3 * (time.perf_counter() - _T0):9.2f} {threading.current_thread().name[-10:]:>10} {what:9} {idx}{'' if n is None else f' ({n})'}\n")
 
 
-def _traced_finish(db, pendings, trace, idx, stats=None, lock=None):
+def _traced_finish(db, pendings, trace, idx, stats=None, lock=None, raw=False):
     trace("finish", idx)
     t0 = time.perf_counter()
     try:
-        return db.finish(pendings)
+        return db.finish(pendings, raw=True) if raw else db.finish(pendings)
     finally:
         trace("finished", idx)
         if stats is not None:
@@ -520,13 +530,22 @@ def _traced_finish(db, pendings, trace, idx, stats=None, lock=None):
 
 
 def _run_batches(db: "ShardedDatabase", pipelines: Sequence[Pipeline], queries: Iterable, pipeline_depth: int,
-                 feeders: int, window: int = 1, finishers: int = 0) -> Iterator:
+                 feeders: int, window: int = 1, finishers: int = 0, raw: bool = False) -> Iterator:
     """``queries`` yields lists of queries; yields ``(list, [TopHits], None)`` in order, or ``(list, None, error)`` for
     the first batch that failed (nothing follows it)."""
     if pipeline_depth <= 0:
         for q in queries:
             try:
-                res = db.search(pipelines, q)
+                if raw:
+                    pendings = db.enqueue(pipelines, q)
+                    try:
+                        db.wait(pendings)
+                    except BaseException:
+                        db.abandon(pendings)
+                        raise
+                    res = db.finish(pendings, raw=True)
+                else:
+                    res = db.search(pipelines, q)
             except BaseException as e:
                 yield q, None, e
                 return
@@ -664,13 +683,13 @@ def _run_batches(db: "ShardedDatabase", pipelines: Sequence[Pipeline], queries: 
                     return
                 if pool is None:
                     try:
-                        res = _traced_finish(db, pendings, trace, nxt - 1, stats, lock)
+                        res = _traced_finish(db, pendings, trace, nxt - 1, stats, lock, raw)
                     except BaseException as e:
                         yield q, None, e
                         return
                     yield q, res, None
                     continue
-                inflight.append((q, pool.submit(_traced_finish, db, pendings, trace, nxt - 1, stats, lock)))
+                inflight.append((q, pool.submit(_traced_finish, db, pendings, trace, nxt - 1, stats, lock, raw)))
             while inflight and (inflight[0][1].done() or len(inflight) >= nfin or drained):
                 q, fut = inflight.popleft()
                 t0 = time.perf_counter()
@@ -780,14 +799,13 @@ def hmmscan(queries, profiles, *, cpus: int = 0, callback: Optional[Callable] = 
             # goes in with its profile's number (the running Z of the reference's loop, plan7.pyx:6680-6737), and the
             # accumulator restores the database's order at the end.
             for members, _, per_model in _run_queries(db, pipelines, profiles, pipeline_depth, feeders, window, finishers, batch=batch,
-                                                      by_batch=True):
-                handles = (C.c_void_p * len(per_model))(*[h._handle for h in per_model])
+                                                      by_batch=True, raw=True):
                 numbers = (C.c_int64 * len(members))(*members)
-                st2 = _lib.lib().p7x_scan_accum_add_indexed(acc, handles, numbers, len(per_model))
+                st2 = _lib.lib().p7x_scan_accum_add_indexed(acc, per_model.array, numbers, len(per_model))       # plan7.HitHandles
                 if st2 != 0:
                     from .errors import status_to_exception
                     raise status_to_exception(st2, "p7x_scan_accum_add_indexed", _lib.last_error())
-                del per_model, handles
+                del per_model
             out = (C.c_void_p * n)()
             st = _lib.lib().p7x_scan_accum_finish(acc, out)          # consumes the accumulator
             acc = C.c_void_p()

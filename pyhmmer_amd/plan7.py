@@ -1284,6 +1284,29 @@ class Hit:
         return self._rec.nenvelopes
 
 
+class HitHandles:
+    """The results of a batch of queries as bare library handles (``p7x_tophits *``), owned by this object: what
+    ``Pipeline._search_finish_batch(raw=True)`` returns.  ``array`` goes to the C entry points that take ``p7x_tophits **``;
+    the handles are destroyed together when the object goes."""
+
+    __slots__ = ("array", "n")
+
+    def __init__(self, array, n: int):
+        self.array = array
+        self.n = int(n)
+
+    def __len__(self) -> int:
+        return self.n
+
+    def __del__(self):
+        array, self.array = getattr(self, "array", None), None
+        if array is not None:
+            try:
+                _lib.lib().p7x_tophits_destroy_many(array, self.n)
+            except Exception:
+                pass
+
+
 class TopHits:
     """An ordered list of hits with the pipeline accounting that produced it
     (reference ``plan7.pyx:8312-9276``; ``P7_TOPHITS`` + copied ``P7_PIPELINE``)."""
@@ -1791,12 +1814,17 @@ class Pipeline:
             raise status_to_exception(st, "p7x_search_block_wait", _lib.last_error())
 
     @staticmethod
-    def _search_finish_batch(pending) -> List["TopHits"]:
+    def _search_finish_batch(pending, raw: bool = False):
+        """Stage 2 of a batch: one ``TopHits`` per query -- or, with ``raw``, the library's handles as they are
+        (``HitHandles``): the scan orientation only passes the per-model lists on to ``p7x_scan_accum_add_indexed``, and
+        20,000 Python objects per pass, each destroyed through its own foreign call, were a fifth of a resident pass."""
         pend, oms, database, labels = pending
         outs = (C.c_void_p * len(oms))()
         st = _lib.lib().p7x_search_batch_finish(pend, database._names, database._accs, database._descs, outs)
         if st != 0:
             raise status_to_exception(st, "p7x_search_batch_finish", _lib.last_error())
+        if raw:
+            return HitHandles(outs, len(oms))
         res = []
         for om, label, h in zip(oms, labels, outs):
             hits = TopHits(label, C.c_void_p(h))

@@ -26,6 +26,16 @@ if len(sys.argv) > 2 and sys.argv[2] == "trace":          # where a resident pas
     import json
     print("pipeline_stats of the last pass:", json.dumps({k: (round(v, 4) if isinstance(v, float) else v) for k, v in hmmer.pipeline_stats().items()}), flush=True)
     from pyhmmer_amd import _lib
+    L = _lib.lib()
+    def timed(name):            # wall time of a C entry point, on stderr (the CDLL instance caches its functions as attributes)
+        fn = getattr(L, name)
+        def call(*a):
+            t = time.perf_counter(); r = fn(*a)
+            print(f"[py] {name} {1e3 * (time.perf_counter() - t):.2f} ms", file=sys.stderr, flush=True)
+            return r
+        setattr(L, name, call)
+    for name in ("p7x_search_batch_finish", "p7x_scan_accum_add_indexed", "p7x_scan_accum_finish", "p7x_search_batch_enqueue"):
+        timed(name)
     _lib.set_debug_option("trace_finish", 1)
     hmmer.PIPE_TRACE = True
     t0 = time.perf_counter()

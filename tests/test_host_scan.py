@@ -119,9 +119,16 @@ class _OracleBackedDatabase:
     def abandon(self, pendings):
         pass
 
-    def finish(self, pendings):
+    def finish(self, pendings, raw=False):
         pli, queries = pendings[0]
-        return [host_pipeline.host_search(self.oracle, self.hmm_of[id(q)], self.block, pipeline=pli) for q in queries]
+        hits = [host_pipeline.host_search(self.oracle, self.hmm_of[id(q)], self.block, pipeline=pli) for q in queries]
+        if not raw:
+            return hits
+        # the scan orientation asks for the bare handles (plan7.HitHandles): hand them over, the TopHits objects let go of them
+        handles = (C.c_void_p * len(hits))(*[h._handle.value for h in hits])
+        for h in hits:
+            h._handle = None
+        return plan7.HitHandles(handles, len(hits))
 
 
 def test_hmmscan_over_a_stand_in_device_reproduces_the_scan_table(libp7x, oracle, proteome, monkeypatch):
