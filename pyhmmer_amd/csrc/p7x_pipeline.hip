@@ -1387,8 +1387,8 @@ static int cascade_enqueue(CascadeRun &r)
   // (the collect half used to queue this after it had read the counts: a second round trip on a stream that shares its
   // hardware queue with other batches' launches -- 20-90 ms of a scan batch's feeder thread, for a 10 us kernel).
   ws->early_T_cap = 0;
-  if (debug_opt(OPT_EARLY_PACK) != 0) {
-    constexpr int64_t kEarlyPack = 16384;
+  if (debug_opt(OPT_EARLY_PACK) != 0) {       // option early_pack: 0 off, n > 0 room for n survivors (tests: a batch that does not fit)
+    const int64_t kEarlyPack = debug_opt(OPT_EARLY_PACK) > 0 ? debug_opt(OPT_EARLY_PACK) : 16384;
     const PackLayout lay = pack_layout(nq, kEarlyPack, cfg.mode == P7X_SCAN_MODELS, db->nslots);
     if ((st = queue_pack(r, lay, kEarlyPack, nullptr, 2048)) != P7X_OK) return st;
     ws->early_T_cap = kEarlyPack;

@@ -624,3 +624,31 @@ def test_a_failing_ensemble_workspace_sends_the_regions_to_the_host(models, prot
         _lib.set_debug_option("ens_fail", -1)
     assert [(h.name, h.score, h.nregions, h.nclustered, h.nenvelopes, [(d.env_from, d.env_to, d.score) for d in h.domains]) for h in got] == \
            [(h.name, h.score, h.nregions, h.nclustered, h.nenvelopes, [(d.env_from, d.env_to, d.score) for d in h.domains]) for h in want]
+
+
+def test_the_shape_of_a_multi_class_batch_does_not_change_its_results(models, proteome):
+    """One launch per tier of MSV register tiles or one per tile (msv_tiers), the batch stage by stage or class by class
+    (stage_merge), the survivors' results gathered behind the cascade, by the collect half, or by both because the batch
+    has more survivors than the first made room for (early_pack = 0 / 3): a batch of fourteen profiles of seven lengths --
+    several kernel classes -- gives the same hit lists, alignments and accounting every way, in both orientations."""
+    queries = models["RREFam"] + models["PF02826"] + models["Thioesterase"] + models["KR"] + models["LuxC"]
+    assert len({q.M for q in queries}) >= 7
+
+    def search():
+        res = list(hmmer.hmmsearch(queries, proteome, devices=[0], batch=len(queries)))
+        return [(t.stage_counts, t.Z, [(h.name, h.score, h.evalue, h.nregions, h.nclustered,
+                                       [(d.env_from, d.env_to, d.score, d.alignment.hmm_from, d.alignment.target_sequence) for d in h.domains]) for h in t])
+                for t in res]
+
+    def scan():
+        return [[(h.name, h.score, h.evalue, len(h.domains)) for h in t] for t in hmmer.hmmscan(proteome[:700], queries, devices=[0])]
+
+    want, want_scan = search(), scan()
+    assert sum(len(t[2]) for t in want) > 50
+    for name, value in (("msv_tiers", 0), ("stage_merge", 0), ("stage_merge", 1), ("early_pack", 0), ("early_pack", 3)):
+        _lib.set_debug_option(name, value)
+        try:
+            assert search() == want, (name, value)
+            assert scan() == want_scan, (name, value)
+        finally:
+            _lib.set_debug_option(name, -1)
