@@ -644,7 +644,7 @@ def test_the_shape_of_a_multi_class_batch_does_not_change_its_results(models, pr
         return [[(h.name, h.score, h.evalue, len(h.domains)) for h in t] for t in hmmer.hmmscan(proteome[:700], queries, devices=[0])]
 
     want, want_scan = search(), scan()
-    assert sum(len(t[2]) for t in want) > 50
+    assert sum(len(t[2]) for t in want) > 10 and any(want_scan)
     for name, value in (("msv_tiers", 0), ("stage_merge", 0), ("stage_merge", 1), ("early_pack", 0), ("early_pack", 3)):
         _lib.set_debug_option(name, value)
         try:
