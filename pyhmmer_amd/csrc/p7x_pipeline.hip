@@ -548,6 +548,7 @@ struct Workspace {
   unsigned char *pack_dev = nullptr; size_t pack_dev_bytes = 0;      // slab of the context's pool
   unsigned char *pack_host = nullptr; size_t pack_host_bytes = 0;    // pinned
   int64_t early_T_cap = 0;          // > 0: the enqueue half packed and copied the survivors' results itself, for up to this many
+  int64_t last_T = 2048;            // survivors of the last batch collected on this workspace (sizes the next early pack)
   bool busy = false;                // between the enqueue and the collect half of a cascade
   int set = -1;                     // the context's stream set this lease runs on (taken when leased, given back on release)
   size_t counters_bytes() const { return (size_t) nlanes * kLaneCounters * 4 + 8; }
@@ -1387,8 +1388,15 @@ static int cascade_enqueue(CascadeRun &r)
   // (the collect half used to queue this after it had read the counts: a second round trip on a stream that shares its
   // hardware queue with other batches' launches -- 20-90 ms of a scan batch's feeder thread, for a 10 us kernel).
   ws->early_T_cap = 0;
-  if (debug_opt(OPT_EARLY_PACK) != 0) {       // option early_pack: 0 off, n > 0 room for n survivors (tests: a batch that does not fit)
-    const int64_t kEarlyPack = debug_opt(OPT_EARLY_PACK) > 0 ? debug_opt(OPT_EARLY_PACK) : 16384;
+  // Against small blocks only (up to 256 groups: the scan orientation, the long-target pipeline's windows), where the second
+  // round trip waited behind other batches' launches; the many-profile search of a 500,000-target block LOST 2.7 % with it
+  // (22.1 instead of 22.7 TCUPS, whatever the size of the copy), the headline neither gained nor lost.
+  // Option early_pack: 0 off, n > 0 always, with room for n survivors (tests: a batch that does not fit).
+  if (debug_opt(OPT_EARLY_PACK) > 0 || (debug_opt(OPT_EARLY_PACK) < 0 && db->ngroups <= 256)) {
+    // room for twice the survivors of this workspace's last batch (1,024 ... 16,384): the arrays are copied whole
+    int64_t room = 1024;
+    while (room < 16384 && room < 2 * ws->last_T) room *= 2;
+    const int64_t kEarlyPack = debug_opt(OPT_EARLY_PACK) > 0 ? debug_opt(OPT_EARLY_PACK) : room;
     const PackLayout lay = pack_layout(nq, kEarlyPack, cfg.mode == P7X_SCAN_MODELS, db->nslots);
     if ((st = queue_pack(r, lay, kEarlyPack, nullptr, 2048)) != P7X_OK) return st;
     ws->early_T_cap = kEarlyPack;
@@ -1543,6 +1551,7 @@ static int cascade_collect(CascadeRun &r, std::vector<CascadeOut> &outs)
   const bool early = ws->early_T_cap > 0 && T <= ws->early_T_cap;
   const PackLayout lay = pack_layout(nq, early ? ws->early_T_cap : T, scan_mode, db->nslots);
   ws->early_T_cap = 0;
+  ws->last_T = T;
   const size_t o_fin = lay.o_fin, o_fwd = lay.o_fwd, o_regn = lay.o_regn, o_nexp = lay.o_nexp, o_start = lay.o_start, o_regs = lay.o_regs;
   const size_t o_off = lay.o_off, o_stage = lay.o_stage;
   if (!early) {
