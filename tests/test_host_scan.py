@@ -170,3 +170,21 @@ def test_hmmscan_over_a_stand_in_device_reproduces_the_scan_table(libp7x, oracle
     per_model = _per_model(oracle, hmms, proteome)
     want = _rows(_accumulate(proteome, _scan_pipeline(hmms[0].alphabet), per_model))
     assert _rows(got) == want
+
+
+def test_hit_handles_own_their_results_until_they_go(libp7x, oracle, proteome):
+    """plan7.HitHandles: the per-model results of a scan batch as the library's bare handles (what
+    Pipeline._search_finish_batch(raw=True) returns); p7x_tophits_destroy_many releases them together and zeroes the slots."""
+    hmms = load_hmms("RREFam")[:3]
+    hits = [host_pipeline.host_search(oracle, h, proteome[:300]) for h in hmms]
+    n_before = [len(h) for h in hits]
+    handles = (C.c_void_p * len(hits))(*[h._handle.value for h in hits])
+    for h in hits:
+        h._handle = None                                   # handed over
+    batch = plan7.HitHandles(handles, len(hits))
+    assert len(batch) == 3 and all(handles[i] for i in range(3))
+    assert [int(libp7x.p7x_tophits_nhits(C.c_void_p(handles[i]))) for i in range(3)] == n_before
+    del batch
+    assert [handles[i] for i in range(3)] == [None, None, None]
+    libp7x.p7x_tophits_destroy_many(handles, 3)            # empty slots are fine
+    libp7x.p7x_tophits_destroy_many(None, 0)
