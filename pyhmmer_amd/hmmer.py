@@ -389,8 +389,12 @@ def _query_length(q) -> int:
 
 def _run_queries(db: "ShardedDatabase", pipelines: Sequence[Pipeline], queries: Iterable, pipeline_depth: int,
                  feeders: int, window: int = 1, finishers: int = 0, batch: int = 1, reorder: int = 32, by_batch: bool = False,
-                 raw: bool = False) -> Iterator:
-    """Yield ``(query, TopHits)`` for every query, in input order -- or, with ``by_batch``, ``(input indices, queries, [TopHits])``
+                 raw: bool = False, fold: Optional[Callable] = None) -> Iterator:
+    """``fold(input indices, results)``, if given, runs on the thread that finished a batch, straight after its host stage, and
+    what it returns takes the results' place (the scan orientation folds a batch into the per-sequence lists there: six folds of
+    4 ms on the consumer's thread, behind one another at the end of a pass, were 20 ms of 300).
+
+    Yield ``(query, TopHits)`` for every query, in input order -- or, with ``by_batch``, ``(input indices, queries, [TopHits])``
     for every batch as soon as it is finished (the scan orientation folds a batch's results into per-sequence lists while
     the next batches are still on the device; their order is restored from the indices).  Queries travel in batches of ``batch`` (one set of
     device launches each); the two stages of consecutive batches overlap.  ``window`` > 1: every feeder queues the
@@ -412,6 +416,7 @@ def _run_queries(db: "ShardedDatabase", pipelines: Sequence[Pipeline], queries: 
         hint = operator.length_hint(queries)
         span = min(max(hint, 8 * _BATCH_MAX), 1 << 16) if hint > 0 else 2 * _BATCH_MAX      # a sized source is sorted as a whole (up to 65,536)
     order: list = []                      # input index of every query handed to the device, in hand-over order
+    batch_members: list = []              # ... batch by batch (batch number -> input indices)
     inputs: dict = {}                     # the queries that have not been yielded yet, by input index
     it = iter(queries)
     src_error: list = []
@@ -433,13 +438,14 @@ def _run_queries(db: "ShardedDatabase", pipelines: Sequence[Pipeline], queries: 
             # by_batch (the scan orientation, whose results are re-ordered by index anyway): the longest models first, so that
             # the batches with the most class chains and the longest host stage run while the others are still to come and the
             # pass ends on the cheapest batch's host stage, not the dearest's
-            idx = sorted(range(len(chunk)), key=lambda i: _query_length(chunk[i]), reverse=by_batch) if span > 1 else list(range(len(chunk)))
+            lens = [_query_length(q) for q in chunk]          # once: a library of 20,000 profiles is sorted and cut in 5 ms, not 35
+            idx = sorted(range(len(chunk)), key=lens.__getitem__, reverse=by_batch) if span > 1 else list(range(len(chunk)))
             lo = 0
             while lo < len(idx):
                 if auto:                      # as many queries as the cell budget holds (short models: many, long ones: few)
                     hi, cells = lo, 0.0
                     while hi < len(idx) and hi - lo < cap:
-                        cells += float(res) * max(1, _query_length(chunk[idx[hi]]) or 150)
+                        cells += float(res) * max(1, lens[idx[hi]] or 150)
                         if hi > lo and cells > _BATCH_CELLS:
                             break
                         hi += 1
@@ -448,6 +454,7 @@ def _run_queries(db: "ShardedDatabase", pipelines: Sequence[Pipeline], queries: 
                 part = idx[lo:hi]
                 lo = hi
                 order.extend(base + i for i in part)
+                batch_members.append([base + i for i in part])
                 yield [chunk[i] for i in part]
             base += len(chunk)
             if src_error:
@@ -457,7 +464,8 @@ def _run_queries(db: "ShardedDatabase", pipelines: Sequence[Pipeline], queries: 
     nxt = 0
     pos = 0                               # batches' members consumed from `order`
     failure = None
-    runner = _run_batches(db, pipelines, sorted_batches(), pipeline_depth, feeders, window, finishers, raw=raw)
+    post = (lambda b, res: fold(batch_members[b], res)) if fold is not None else None
+    runner = _run_batches(db, pipelines, sorted_batches(), pipeline_depth, feeders, window, finishers, raw=raw, post=post)
     for qs, hits, err in runner:
         members = order[pos:pos + len(qs)]
         pos += len(qs)
@@ -517,11 +525,12 @@ def _pipe_trace(what, idx, n=None):
     sys.stderr.write(f"[pipe] {1e3 * (time.perf_counter() - _T0):9.2f} {threading.current_thread().name[-10:]:>10} {what:9} {idx}{'' if n is None else f' ({n})'}\n")
 
 
-def _traced_finish(db, pendings, trace, idx, stats=None, lock=None, raw=False):
+def _traced_finish(db, pendings, trace, idx, stats=None, lock=None, raw=False, post=None):
     trace("finish", idx)
     t0 = time.perf_counter()
     try:
-        return db.finish(pendings, raw=True) if raw else db.finish(pendings)
+        res = db.finish(pendings, raw=True) if raw else db.finish(pendings)
+        return post(idx, res) if post is not None else res
     finally:
         trace("finished", idx)
         if stats is not None:
@@ -530,11 +539,11 @@ def _traced_finish(db, pendings, trace, idx, stats=None, lock=None, raw=False):
 
 
 def _run_batches(db: "ShardedDatabase", pipelines: Sequence[Pipeline], queries: Iterable, pipeline_depth: int,
-                 feeders: int, window: int = 1, finishers: int = 0, raw: bool = False) -> Iterator:
+                 feeders: int, window: int = 1, finishers: int = 0, raw: bool = False, post: Optional[Callable] = None) -> Iterator:
     """``queries`` yields lists of queries; yields ``(list, [TopHits], None)`` in order, or ``(list, None, error)`` for
     the first batch that failed (nothing follows it)."""
     if pipeline_depth <= 0:
-        for q in queries:
+        for nb, q in enumerate(queries):
             try:
                 if raw:
                     pendings = db.enqueue(pipelines, q)
@@ -546,6 +555,8 @@ def _run_batches(db: "ShardedDatabase", pipelines: Sequence[Pipeline], queries: 
                     res = db.finish(pendings, raw=True)
                 else:
                     res = db.search(pipelines, q)
+                if post is not None:
+                    res = post(nb, res)
             except BaseException as e:
                 yield q, None, e
                 return
@@ -683,13 +694,13 @@ def _run_batches(db: "ShardedDatabase", pipelines: Sequence[Pipeline], queries: 
                     return
                 if pool is None:
                     try:
-                        res = _traced_finish(db, pendings, trace, nxt - 1, stats, lock, raw)
+                        res = _traced_finish(db, pendings, trace, nxt - 1, stats, lock, raw, post)
                     except BaseException as e:
                         yield q, None, e
                         return
                     yield q, res, None
                     continue
-                inflight.append((q, pool.submit(_traced_finish, db, pendings, trace, nxt - 1, stats, lock, raw)))
+                inflight.append((q, pool.submit(_traced_finish, db, pendings, trace, nxt - 1, stats, lock, raw, post)))
             while inflight and (inflight[0][1].done() or len(inflight) >= nfin or drained):
                 q, fut = inflight.popleft()
                 t0 = time.perf_counter()
@@ -778,8 +789,10 @@ def hmmscan(queries, profiles, *, cpus: int = 0, callback: Optional[Callable] = 
             profiles.rewind()
         seen += 1
         alphabet: Alphabet = block.alphabet
+        stamps = [("start", time.perf_counter())] if PIPE_TRACE else None
         # the query block is small by construction: every device holds all of it and takes its share of the profiles
         db = ReplicatedDatabase(block, devs) if len(devs) > 1 else ShardedDatabase(block, devs)
+        if stamps: stamps.append(("block resident", time.perf_counter()))
         pipelines = [Pipeline(alphabet, device=d, host_threads=cpus, **options) for d in devs]
         for pl in pipelines:
             pl._mode = _P7X_SCAN_MODELS
@@ -798,14 +811,18 @@ def hmmscan(queries, profiles, *, cpus: int = 0, callback: Optional[Callable] = 
             # when the device is done.  Batches hold the profiles in order of length, not of the database: every result
             # goes in with its profile's number (the running Z of the reference's loop, plan7.pyx:6680-6737), and the
             # accumulator restores the database's order at the end.
-            for members, _, per_model in _run_queries(db, pipelines, profiles, pipeline_depth, feeders, window, finishers, batch=batch,
-                                                      by_batch=True, raw=True):
+            def fold(members, per_model):          # on the thread that finished the batch (the accumulator takes results from any thread)
                 numbers = (C.c_int64 * len(members))(*members)
                 st2 = _lib.lib().p7x_scan_accum_add_indexed(acc, per_model.array, numbers, len(per_model))       # plan7.HitHandles
                 if st2 != 0:
                     from .errors import status_to_exception
                     raise status_to_exception(st2, "p7x_scan_accum_add_indexed", _lib.last_error())
-                del per_model
+                return len(per_model)               # the handles go with per_model, here
+
+            for members, _, folded in _run_queries(db, pipelines, profiles, pipeline_depth, feeders, window, finishers, batch=batch,
+                                                   by_batch=True, raw=True, fold=fold):
+                if stamps: stamps.append((f"batch of {folded} folded", time.perf_counter()))
+            if stamps: stamps.append(("pipeline closed", time.perf_counter()))
             out = (C.c_void_p * n)()
             st = _lib.lib().p7x_scan_accum_finish(acc, out)          # consumes the accumulator
             acc = C.c_void_p()
@@ -817,6 +834,9 @@ def hmmscan(queries, profiles, *, cpus: int = 0, callback: Optional[Callable] = 
                 _lib.lib().p7x_scan_accum_destroy(acc)
         results = [TopHits(q, C.c_void_p(out[i])) for i, q in enumerate(block)]
         del db, pipelines                                            # the block leaves HBM before the next one is read
+        if stamps:
+            stamps.append(("results", time.perf_counter()))
+            print("[scan] " + ", ".join(f"{what} +{1e3 * (t - stamps[0][1]):.1f}" for what, t in stamps[1:]) + " ms", file=sys.stderr, flush=True)
         for q, hits in zip(block, results):
             if callback is not None:
                 callback(q, n)
