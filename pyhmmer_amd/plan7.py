@@ -331,18 +331,36 @@ class HMMFile:
     _F = dict(DESC=1 << 1, RF=1 << 2, CS=1 << 3, STATS=1 << 7, MAP=1 << 8, ACC=1 << 9, GA=1 << 10, TC=1 << 11, NC=1 << 12, CA=1 << 13,
               COMPO=1 << 14, CHKSUM=1 << 15, CONS=1 << 16, MMASK=1 << 17)
 
-    def __init__(self, file, db: bool = False, *, alphabet: Optional[Alphabet] = None):
+    def __init__(self, file, db: bool = True, *, alphabet: Optional[Alphabet] = None):
+        """``file``: a path or a file object.  ``db`` (reference ``plan7.pyx:3697-3706``, ``p7_hmmfile_Open`` / ``_OpenNoDB``):
+        with a path, a pressed database beside it is used if there is one -- the models are then read from ``<path>.h3m`` and
+        ``optimized_profiles()`` walks ``<path>.h3f`` / ``<path>.h3p``; ``db=False`` ignores it."""
         self._binary = False
+        self._closed = False
+        self._pressed = None
         if isinstance(file, (str, bytes, os.PathLike)):
+            base = os.fsdecode(os.fspath(file))
+            if db and os.path.isfile(base + ".h3m"):           # upstream looks for the pressed database first
+                self._pressed = base if os.path.isfile(base + ".h3f") and os.path.isfile(base + ".h3p") else None
+                file = base + ".h3m"
+            if os.path.isdir(file):
+                raise IsADirectoryError(21, f"Is a directory: {base!r}")
+            if not os.path.exists(file):
+                raise FileNotFoundError(2, f"No such file or directory: {base!r}")
+            if os.stat(file).st_size == 0:
+                raise EOFError("HMM file is empty")
             with open(file, "rb") as probe:
-                head = probe.read(4)
+                first = probe.read(256)
+            head = first[:4]
+            if not first.lstrip().startswith(b"HMMER") and (len(head) < 4 or int.from_bytes(head, sys.byteorder) not in (self._MAGIC_3F,) + self._MAGIC_OLD):
+                raise ValueError("format not recognized by HMMER")
             magic = int.from_bytes(head, sys.byteorder) if len(head) == 4 else 0
             self._binary = magic == self._MAGIC_3F
             if magic in self._MAGIC_OLD:
                 raise ValueError(f"{os.fspath(file)!r}: binary HMM file of an older format (HMMER 3/a-3/e); only 3/f is read")
             self._fh = open(file, "rb" if self._binary else "r")
             self._own = True
-            self.name = os.fspath(file)
+            self.name = base
         else:
             self._fh = file
             self._own = False
@@ -454,8 +472,32 @@ class HMMFile:
         return False
 
     def close(self):
-        if self._own:
+        if self._own and not self._closed:
             self._fh.close()
+        self._closed = True
+
+    @property
+    def closed(self) -> bool:
+        """Whether the file is closed (reference ``plan7.pyx:3903-3907``)."""
+        return self._closed
+
+    def __repr__(self):
+        return f"{type(self).__name__}({self.name!r})" if self.name is not None else f"<{type(self).__name__} file={self._fh!r}>"
+
+    def is_pressed(self) -> bool:
+        """Whether the file is a pressed HMM database (reference ``plan7.pyx:4009-4029``): ``<path>.h3m``, ``.h3f`` and ``.h3p``
+        are there (the ``.h3i`` index of upstream's ``hmmpress`` is not needed by anything on this path)."""
+        if self._closed:
+            raise ValueError("I/O operation on closed file.")
+        return self._pressed is not None
+
+    def optimized_profiles(self) -> "HMMPressedFile":
+        """An iterator over the optimized profiles of the pressed database (reference ``plan7.pyx:4031-4048``)."""
+        if self._closed:
+            raise ValueError("I/O operation on closed file.")
+        if self._pressed is None:
+            raise ValueError("HMM file does not contain optimized profiles.")
+        return HMMPressedFile(self._pressed, alphabet=self._alphabet)
 
     def __iter__(self) -> Iterator[HMM]:
         return self
@@ -477,6 +519,8 @@ class HMMFile:
         return out
 
     def read(self) -> Optional[HMM]:
+        if self._closed:
+            raise ValueError("I/O operation on closed file.")
         if self._binary:
             return self._read_binary()
         fh = self._fh

@@ -552,3 +552,44 @@ def test_hmm_write_reproduces_the_save_files(libp7x, name):
     tb = io.BytesIO()
     hmms[0].write(tb)                                  # a binary handle takes the text form as bytes
     assert tb.getvalue().decode() == hmms[0]._to_text()
+
+
+def test_hmmfile_finds_the_pressed_database_beside_a_path(libp7x, models, tmp_path):
+    """HMMFile(path, db=True) (reference plan7.pyx:3684-3760, 4009-4048): a pressed database beside the path is used -- models from
+    <path>.h3m, optimized_profiles() over <path>.h3f / .h3p -- and db=False ignores it; `closed`, repr, and the errors of opening
+    what is not an HMM file.  (The reference's doctest: bin/Thioesterase.h3m is not pressed, db/Thioesterase.hmm is.)"""
+    assert plan7.HMMFile(GOLDEN / "hmms" / "Thioesterase.h3m").is_pressed() is False
+    base = tmp_path / "RREFam.hmm"
+    assert hmmer.hmmpress(models["RREFam"], base) == 10
+    (tmp_path / "RREFam.hmm").write_text((GOLDEN / "hmms" / "RREFam.hmm").read_text())
+    with plan7.HMMFile(base) as f:
+        assert f.is_pressed() and not f.closed and repr(f) == f"HMMFile({str(base)!r})"
+        from_h3m = list(f)                                  # read from the binary file of the database
+        oms = list(f.optimized_profiles())
+    assert f.closed
+    with pytest.raises(ValueError, match="closed file"):
+        f.read()
+    with pytest.raises(ValueError, match="closed file"):
+        f.is_pressed()
+    assert [h.name for h in from_h3m] == [h.name for h in models["RREFam"]] == [om.name for om in oms]
+    assert all(np.array_equal(a.match_emissions, b.match_emissions) for a, b in zip(from_h3m, models["RREFam"]))
+    with plan7.HMMPressedFile(base) as direct:
+        assert [om.name for om in direct] == [om.name for om in oms]
+    with plan7.HMMFile(base, db=False) as f:                # the text file itself
+        assert not f.is_pressed() and len(list(f)) == 10
+        with pytest.raises(ValueError, match="does not contain optimized profiles"):
+            f.optimized_profiles()
+    # only the pressed files, no text file of that name: still a database (upstream opens <name>.h3m first)
+    (tmp_path / "RREFam.hmm").unlink()
+    with plan7.HMMFile(base) as f:
+        assert f.is_pressed() and len(list(f)) == 10
+    with pytest.raises(FileNotFoundError):
+        plan7.HMMFile(tmp_path / "nothing.hmm")
+    with pytest.raises(IsADirectoryError):
+        plan7.HMMFile(tmp_path)
+    (tmp_path / "empty.hmm").write_bytes(b"")
+    with pytest.raises(EOFError):
+        plan7.HMMFile(tmp_path / "empty.hmm")
+    (tmp_path / "junk.hmm").write_text(">seq1\nACGT\n")
+    with pytest.raises(ValueError, match="not recognized"):
+        plan7.HMMFile(tmp_path / "junk.hmm")
