@@ -184,6 +184,207 @@ class HMM:
     def __repr__(self):
         return f"<HMM name={self.name!r} M={self.M} alphabet={self.alphabet!r}>"
 
+    # ---- copies, comparison, pickling (reference plan7.pyx:2418-2560, 3124-3140)
+    _STATE = ("accession", "description", "composition", "consensus", "consensus_structure", "reference", "model_mask", "map", "nseq",
+              "nseq_effective", "max_length", "checksum", "command_line", "creation_time")
+
+    def copy(self) -> "HMM":
+        new = HMM(self.alphabet, self.M, self.name)
+        new.transition_probabilities[:] = self.transition_probabilities
+        new.match_emissions[:] = self.match_emissions
+        new.insert_emissions[:] = self.insert_emissions
+        new._evparam[:] = self._evparam
+        new._cutoffs[:] = self._cutoffs
+        for attr in self._STATE:
+            v = getattr(self, attr)
+            setattr(new, attr, v.copy() if isinstance(v, np.ndarray) else v)
+        return new
+
+    def __copy__(self) -> "HMM":
+        return self.copy()
+
+    def __deepcopy__(self, memo) -> "HMM":
+        if id(self) not in memo:
+            memo[id(self)] = self.copy()
+        return memo[id(self)]
+
+    def __eq__(self, other):
+        """``p7_hmm_Compare`` with a tolerance of zero: alphabet, size, every parameter, every annotation."""
+        if not isinstance(other, HMM):
+            return NotImplemented
+        if self is other:
+            return True
+        if self.alphabet != other.alphabet or self.M != other.M or self.name != other.name:
+            return False
+        for a, b in ((self.transition_probabilities, other.transition_probabilities), (self.match_emissions, other.match_emissions),
+                     (self.insert_emissions, other.insert_emissions), (self._evparam, other._evparam), (self._cutoffs, other._cutoffs)):
+            if not np.array_equal(a, b):
+                return False
+        for attr in self._STATE:
+            a, b = getattr(self, attr), getattr(other, attr)
+            if isinstance(a, np.ndarray) or isinstance(b, np.ndarray):
+                if a is None or b is None or not np.array_equal(a, b):
+                    return False
+            elif a != b:
+                return False
+        return True
+
+    __hash__ = None
+
+    def __reduce__(self):
+        return HMM, (self.alphabet, self.M, self.name), self.__getstate__()
+
+    def __getstate__(self) -> dict:
+        state = {attr: getattr(self, attr) for attr in self._STATE}
+        state.update(t=self.transition_probabilities, mat=self.match_emissions, ins=self.insert_emissions, evparam=self._evparam,
+                     cutoff=self._cutoffs)
+        return state
+
+    def __setstate__(self, state: dict) -> None:
+        self.transition_probabilities[:] = state["t"]
+        self.match_emissions[:] = state["mat"]
+        self.insert_emissions[:] = state["ins"]
+        self._evparam[:] = state["evparam"]
+        self._cutoffs[:] = state["cutoff"]
+        for attr in self._STATE:
+            setattr(self, attr, state.get(attr))
+
+    # ---- model statistics and edits (reference plan7.pyx:3335-3402, 3459-3520, 3591-3655; upstream p7_hmm.c, modelstats.c)
+    def _occupancy(self):
+        """``p7_hmm_CalculateOccupancy``: the probability that a glocal path uses match state k, and insert state k."""
+        t = self.transition_probabilities.astype(np.float32)
+        M = self.M
+        mocc = np.zeros(M + 1, dtype=np.float32)
+        iocc = np.zeros(M + 1, dtype=np.float32)
+        if M >= 1:
+            mocc[1] = t[0, 1] + t[0, 0]
+            for k in range(2, M + 1):
+                mocc[k] = mocc[k - 1] * (t[k - 1, 0] + t[k - 1, 1]) + (np.float32(1.0) - mocc[k - 1]) * t[k - 1, 5]
+        with np.errstate(divide="ignore", invalid="ignore"):
+            iocc[0] = t[0, 1] / t[0, 3]
+            iocc[1:] = mocc[1:] * t[1:, 1] / t[1:, 3]
+        return mocc, iocc
+
+    def match_occupancy(self) -> np.ndarray:
+        return self._occupancy()[0]
+
+    def mean_match_entropy(self) -> float:
+        """Mean entropy of the match emission distributions, in bits (``p7_MeanMatchEntropy``)."""
+        p = self.match_emissions[1:].astype(np.float64)
+        with np.errstate(divide="ignore", invalid="ignore"):
+            h = -np.where(p > 0, p * np.log2(p), 0.0).sum(axis=1)
+        return float(h.mean())
+
+    def mean_match_information(self, background: "Background") -> float:
+        """Mean information content of the match states against the null model, in bits (``p7_MeanMatchInfo``)."""
+        f = background.residue_frequencies.astype(np.float64)
+        hbg = -float(np.where(f > 0, f * np.log2(f), 0.0).sum())
+        return hbg - self.mean_match_entropy()
+
+    def mean_match_relative_entropy(self, background: "Background") -> float:
+        """Mean relative entropy of the match states against the null model, in bits (``p7_MeanMatchRelativeEntropy``)."""
+        p = self.match_emissions[1:].astype(np.float64)
+        f = background.residue_frequencies.astype(np.float64)
+        with np.errstate(divide="ignore", invalid="ignore"):
+            d = np.where(p > 0, p * np.log2(p / f), 0.0).sum(axis=1)
+        return float(d.mean())
+
+    def renormalize(self) -> None:
+        """``p7_hmm_Renormalize``: every emission row and the three transition distributions of every node sum to one; node M keeps
+        its conventions (D -> M_end is 1, no M -> D)."""
+        def norm(a):
+            tot = a.sum(axis=1, keepdims=True)
+            n = a.shape[1]
+            a[:] = np.where(tot > 0, a / np.where(tot > 0, tot, 1), np.float32(1.0 / n))       # esl_vec_FNorm: a zero vector becomes uniform
+        norm(self.match_emissions)
+        norm(self.insert_emissions)
+        t = self.transition_probabilities
+        norm(t[:, 0:3]); norm(t[:, 3:5]); norm(t[:, 5:7])
+        M = self.M
+        t[M, 5], t[M, 6] = 1.0, 0.0
+        if t[M, 2] > 0.0:
+            t[M, 2] = 0.0; t[M, 0] = 0.5; t[M, 1] = 0.5
+
+    def scale(self, scale: float, exponential: bool = False) -> None:
+        """Rescale a model that holds counts (``p7_hmm_Scale`` / ``p7_hmm_ScaleExponential``: there the factor of node k is
+        count_k ** scale / count_k, count_k the node's match emission counts)."""
+        if not exponential:
+            for a in (self.transition_probabilities, self.match_emissions, self.insert_emissions):
+                a *= np.float32(scale)
+            return
+        for k in range(1, self.M + 1):
+            count = float(self.match_emissions[k].sum())
+            f = np.float32((count ** scale) / count) if count > 0 else np.float32(1.0)
+            self.transition_probabilities[k] *= f
+            self.match_emissions[k] *= f
+            self.insert_emissions[k] *= f
+
+    def zero(self) -> None:
+        """Set every parameter to zero, the composition included (``p7_hmm_Zero``); annotation stays."""
+        self.transition_probabilities[:] = 0
+        self.match_emissions[:] = 0
+        self.insert_emissions[:] = 0
+        if self.composition is not None:
+            self.composition[:] = 0
+
+    def set_composition(self) -> None:
+        """``p7_hmm_SetComposition``: the expected residue composition of a sequence emitted by the model -- the emissions of its
+        match and insert states weighted by their occupancies."""
+        mocc, iocc = self._occupancy()
+        with np.errstate(invalid="ignore"):
+            compo = np.nan_to_num(iocc[0]) * self.insert_emissions[0].astype(np.float32)
+            for k in range(1, self.M + 1):
+                compo = compo + mocc[k] * self.match_emissions[k] + np.nan_to_num(iocc[k]) * self.insert_emissions[k]
+        tot = float(compo.sum())
+        self.composition = (compo / tot if tot > 0 else np.full(self.alphabet.K, 1.0 / self.alphabet.K)).astype(np.float32)
+
+    def set_consensus(self, sequence=None) -> None:
+        """``p7_hmm_SetConsensus``: the residue of highest emission probability at every node, upper case when that probability
+        reaches 0.5 (amino) / 0.9 (nucleic); with a digital ``sequence`` of M residues (a single-sequence model), that sequence."""
+        if sequence is None:
+            self.consensus = _set_consensus(self)
+            return
+        if sequence.alphabet != self.alphabet:
+            raise AlphabetMismatch(self.alphabet, sequence.alphabet)
+        dsq = np.asarray(sequence.sequence)
+        if dsq.shape[0] < self.M:
+            raise ValueError(f"Expected `DigitalSequence` of length {self.M!r}, found {dsq.shape[0]!r}")
+        thresh = 0.5 if self.alphabet.is_amino() else 0.9
+        out = []
+        for k in range(1, self.M + 1):
+            x = int(dsq[k - 1])
+            c = self.alphabet.symbols[x]
+            out.append(c.upper() if x < self.alphabet.K and self.match_emissions[k, x] >= thresh else c.lower())
+        self.consensus = "".join(out)
+
+    def to_profile(self, background: Optional["Background"] = None, L: int = 400, multihit: bool = True, local: bool = True) -> "Profile":
+        profile = Profile(self.M, self.alphabet)
+        profile.configure(self, Background(self.alphabet) if background is None else background, L=L, multihit=multihit, local=local)
+        return profile
+
+    def validate(self, tolerance: float = 1e-4) -> None:
+        """``p7_hmm_Validate``: the structural constraints of a Plan7 model; ``ValueError`` names the first that fails."""
+        t, M = self.transition_probabilities, self.M
+        if M < 1:
+            raise ValueError("HMM has M < 1")
+        def check(a, what, first=0):
+            bad = np.nonzero(np.abs(a.sum(axis=1) - 1.0) > tolerance)[0]
+            if bad.size:
+                raise ValueError(f"Invalid HMM: {what} of node {int(bad[0]) + first} does not sum to 1")
+        if abs(float(self.match_emissions[0, 0]) - 1.0) > tolerance and float(self.match_emissions[0].sum()) != 0.0:
+            raise ValueError("Invalid HMM: mat[0] is not the unused-node convention (1, 0, ...)")
+        check(self.match_emissions[1:], "match emissions", 1)
+        check(self.insert_emissions, "insert emissions")
+        check(t[:, 0:3], "match transitions")
+        check(t[:, 3:5], "insert transitions")
+        check(t[1:, 5:7], "delete transitions", 1)
+        if t[M, 2] != 0.0 or t[M, 6] != 0.0:
+            raise ValueError("Invalid HMM: node M must not enter a delete state")
+        for attr in ("consensus", "consensus_structure", "reference", "model_mask"):
+            v = getattr(self, attr)
+            if v is not None and len(v) != M:
+                raise ValueError(f"Invalid HMM: {attr} annotation has {len(v)} characters for {M} nodes")
+
     def _flags(self) -> int:
         """The P7_HMM flag word a save file carries: which optional fields this model holds."""
         F = HMMFile._F

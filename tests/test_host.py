@@ -593,3 +593,72 @@ def test_hmmfile_finds_the_pressed_database_beside_a_path(libp7x, models, tmp_pa
     (tmp_path / "junk.hmm").write_text(">seq1\nACGT\n")
     with pytest.raises(ValueError, match="not recognized"):
         plan7.HMMFile(tmp_path / "junk.hmm")
+
+
+def test_hmm_statistics_and_edits(libp7x, models):
+    """The HMM's own methods beside the save formats (reference plan7.pyx:2418-2560, 3124-3140, 3335-3655 and
+    tests/test_plan7/test_hmm.py:48-252).  Known answers: the three doctest values of the reference for the Thioesterase model
+    (`mean_match_entropy` 3.0425, `mean_match_information` 1.1330, `mean_match_relative_entropy` 1.1201); `set_composition` and
+    `set_consensus` against the COMPO and consensus lines that real hmmbuild wrote into the fixtures."""
+    import copy
+    import pickle
+    th = models["Thioesterase"][0]
+    bg = plan7.Background(th.alphabet)
+    assert th.mean_match_entropy() == pytest.approx(3.0425, abs=5e-5)
+    assert th.mean_match_information(bg) == pytest.approx(1.1330, abs=5e-5)
+    assert th.mean_match_relative_entropy(bg) == pytest.approx(1.1201, abs=1e-4)
+    for name in ("LuxC", "RREFam"):
+        for hmm in models[name]:
+            again = hmm.copy()
+            again.composition, again.consensus = None, None
+            again.set_composition()
+            again.set_consensus()
+            assert np.allclose(again.composition, hmm.composition, atol=1e-5)        # the COMPO line prints five decimals of -log p
+            assert again.consensus == hmm.consensus
+            occ = hmm.match_occupancy()
+            assert occ.shape == (hmm.M + 1,) and occ[0] == 0.0 and np.all((occ[1:] > 0) & (occ[1:] <= 1.0 + 1e-6))
+            hmm.validate()
+    # copies, equality, pickling (test_hmm.py:48-61, 223-252)
+    luxc = models["LuxC"][0]
+    for other in (luxc.copy(), copy.copy(luxc), copy.deepcopy(luxc), pickle.loads(pickle.dumps(luxc))):
+        assert other == luxc and other is not luxc and other.match_emissions is not luxc.match_emissions
+        assert (other.name, other.accession, other.description, other.consensus, other.checksum) == \
+               (luxc.name, luxc.accession, luxc.description, luxc.consensus, luxc.checksum)
+        assert other.cutoffs.gathering == luxc.cutoffs.gathering and np.array_equal(other._evparam, luxc._evparam)
+    assert luxc != models["KR"][0] and luxc != 1 and luxc != plan7.HMM(luxc.alphabet, luxc.M, luxc.name)
+    edited = luxc.copy()
+    edited.match_emissions[3, 0] += 1e-3
+    assert edited != luxc
+    with pytest.raises(ValueError, match="match emissions of node 3"):
+        edited.validate()
+    # counts -> probabilities (test_hmm.py:186-221)
+    dna = easel.Alphabet.dna()
+    hmm = plan7.HMM(dna, 10, "custom")
+    hmm.match_emissions[1:] = 25.0
+    hmm.scale(2.0)
+    assert np.all(hmm.match_emissions[1:] == 50.0)
+    hmm.scale(0.5, exponential=True)                        # node counts 200 -> sqrt(200)
+    assert np.allclose(hmm.match_emissions[1:].sum(axis=1), np.sqrt(200.0), rtol=1e-5)
+    hmm.renormalize()
+    assert np.allclose(hmm.match_emissions.sum(axis=1), 1.0, atol=1e-5) and np.allclose(hmm.insert_emissions.sum(axis=1), 1.0, atol=1e-5)
+    t = hmm.transition_probabilities
+    assert np.allclose(t[:, 0:3].sum(axis=1), 1.0, atol=1e-5) and t[10, 2] == 0.0 and t[10, 5] == 1.0 and t[10, 6] == 0.0
+    assert hmm.composition is None and hmm.consensus is None
+    hmm.set_composition()
+    assert hmm.composition.shape == (4,) and hmm.composition.sum() == pytest.approx(1.0, abs=1e-5)
+    hmm.set_consensus()
+    assert len(hmm.consensus) == hmm.M
+    seq = easel.TextSequence(sequence="A" * hmm.M).digitize(dna)
+    hmm.set_consensus(seq)
+    assert hmm.consensus.upper() == "A" * hmm.M
+    with pytest.raises(errors.AlphabetMismatch):
+        hmm.set_consensus(easel.TextSequence(sequence="Y" * hmm.M).digitize(easel.Alphabet.amino()))
+    with pytest.raises(ValueError):
+        hmm.set_consensus(easel.TextSequence(sequence="A" * (hmm.M - 1)).digitize(dna))
+    hmm.zero()
+    assert not hmm.match_emissions.any() and not hmm.transition_probabilities.any() and not hmm.composition.any() and hmm.name == "custom"
+    buf = __import__("io").BytesIO()
+    plan7.HMM(easel.Alphabet.amino(), 10, "test").write(buf)             # test_hmm.py:170-176: an empty model can be written
+    assert len(buf.getvalue()) > 0
+    prof = luxc.to_profile(L=200)
+    assert prof.M == luxc.M
