@@ -62,8 +62,22 @@ class EvalueParameters:
             raise AttributeError(name)
         return None if v == EVPARAM_UNSET else v
 
+    def __setattr__(self, name, value):
+        """The parameters can be set (``None`` clears one), as in the reference (``plan7.pyx:1760-1849``); they are the HMM's own."""
+        if name in self._names:
+            self._v[self._names.index(name)] = EVPARAM_UNSET if value is None else value
+        else:
+            object.__setattr__(self, name, value)
+
     def as_vector(self) -> np.ndarray:
         return self._v.copy()
+
+    def __eq__(self, other):
+        if isinstance(other, EvalueParameters):
+            return bool(np.array_equal(self._v, other._v))
+        return NotImplemented
+
+    __hash__ = None
 
     def __repr__(self):
         return "<EvalueParameters " + " ".join(f"{n}={getattr(self, n)!r}" for n in self._names) + ">"
@@ -80,17 +94,34 @@ class Cutoffs:
         a, b = float(self._v[i]), float(self._v[i + 1])
         return None if a == CUTOFF_UNSET or b == CUTOFF_UNSET else (a, b)
 
-    @property
-    def gathering(self):
-        return self._pair(0)
+    def _set_pair(self, i, pair):
+        if pair is None:
+            self._v[i] = self._v[i + 1] = CUTOFF_UNSET
+        else:
+            a, b = pair
+            self._v[i], self._v[i + 1] = a, b
 
-    @property
-    def trusted(self):
-        return self._pair(2)
+    # each pair can be read, set from two floats, and cleared with None or ``del`` (reference ``plan7.pyx:1204-1420``); the values
+    # are the owner's (``HMM.cutoffs`` / ``OptimizedProfile.cutoffs`` hand out a view)
+    gathering = property(lambda self: self._pair(0), lambda self, v: self._set_pair(0, v), lambda self: self._set_pair(0, None))
+    trusted = property(lambda self: self._pair(2), lambda self, v: self._set_pair(2, v), lambda self: self._set_pair(2, None))
+    noise = property(lambda self: self._pair(4), lambda self, v: self._set_pair(4, v), lambda self: self._set_pair(4, None))
+    gathering1 = property(lambda self: None if self._pair(0) is None else self._pair(0)[0])
+    gathering2 = property(lambda self: None if self._pair(0) is None else self._pair(0)[1])
+    trusted1 = property(lambda self: None if self._pair(2) is None else self._pair(2)[0])
+    trusted2 = property(lambda self: None if self._pair(2) is None else self._pair(2)[1])
+    noise1 = property(lambda self: None if self._pair(4) is None else self._pair(4)[0])
+    noise2 = property(lambda self: None if self._pair(4) is None else self._pair(4)[1])
 
-    @property
-    def noise(self):
-        return self._pair(4)
+    def __eq__(self, other):
+        if isinstance(other, Cutoffs):
+            return bool(np.array_equal(self._v, other._v))
+        return NotImplemented
+
+    __hash__ = None
+
+    def __repr__(self):
+        return f"<Cutoffs gathering={self.gathering!r} trusted={self.trusted!r} noise={self.noise!r}>"
 
     def gathering_available(self) -> bool:
         return self.gathering is not None
@@ -1606,6 +1637,17 @@ class TopHits:
     @property
     def E(self) -> float:
         return self._cfg().E
+
+    # the thresholds the hits were reported / included with (reference plan7.pyx:8600-8690): a bit-score threshold is None
+    # while its E-value twin is the one in force
+    T = property(lambda self: None if self._cfg().by_E else self._cfg().T)
+    domE = property(lambda self: self._cfg().domE)
+    domT = property(lambda self: None if self._cfg().dom_by_E else self._cfg().domT)
+    incE = property(lambda self: self._cfg().incE)
+    incT = property(lambda self: None if self._cfg().inc_by_E else self._cfg().incT)
+    incdomE = property(lambda self: self._cfg().incdomE)
+    incdomT = property(lambda self: None if self._cfg().incdom_by_E else self._cfg().incdomT)
+    bit_cutoffs = property(lambda self: {1: "gathering", 2: "noise", 3: "trusted"}.get(int(self._cfg().use_bit_cutoffs)))
 
     @property
     def searched_models(self) -> int:

@@ -662,3 +662,37 @@ def test_hmm_statistics_and_edits(libp7x, models):
     assert len(buf.getvalue()) > 0
     prof = luxc.to_profile(L=200)
     assert prof.M == luxc.M
+
+
+def test_cutoffs_and_evalue_parameters_are_the_models_own(libp7x, models):
+    """reference tests/test_plan7/test_hmm.py:254-340: cutoff pairs read, set, cleared with None or del -- through the view that
+    HMM.cutoffs hands out, into the model (a Pipeline with bit_cutoffs sees them) -- and equal after pickling."""
+    import pickle
+    hmm = models["Thioesterase"][0].copy()
+    c = hmm.cutoffs
+    for pair in ("gathering", "noise", "trusted"):
+        assert getattr(c, pair) is None and getattr(c, pair + "1") is None and getattr(c, pair + "2") is None
+        assert not getattr(c, pair + "_available")()
+    hmm.cutoffs.gathering = (10.0, 12.0)
+    assert hmm.cutoffs.gathering == (10.0, 12.0) and hmm.cutoffs.gathering1 == 10.0 and hmm.cutoffs.gathering2 == 12.0
+    assert hmm.cutoffs.gathering_available() and not hmm.cutoffs.noise_available() and not hmm.cutoffs.trusted_available()
+    hmm.cutoffs.noise = (8.0, 5.0)
+    hmm.cutoffs.trusted = (15.0, 14.0)
+    assert (hmm.cutoffs.noise, hmm.cutoffs.noise1, hmm.cutoffs.noise2) == ((8.0, 5.0), 8.0, 5.0)
+    assert (hmm.cutoffs.trusted, hmm.cutoffs.trusted1, hmm.cutoffs.trusted2) == ((15.0, 14.0), 15.0, 14.0)
+    assert hmm != models["Thioesterase"][0] and "GA    10.00 12.00" in hmm._to_text()
+    pf = models["PF02826"][0].copy()
+    assert pf.cutoffs.gathering_available() and pf.cutoffs.noise_available() and pf.cutoffs.trusted_available()
+    assert pickle.loads(pickle.dumps(pf)).cutoffs == pf.cutoffs and pf.cutoffs != hmm.cutoffs and pf.cutoffs != 3
+    pf.cutoffs.gathering = None
+    assert pf.cutoffs.gathering is None and pf.cutoffs.gathering1 is None and pf.cutoffs.noise_available()
+    del pf.cutoffs.noise
+    assert pf.cutoffs.noise is None and pf.cutoffs.noise2 is None and pf.cutoffs.trusted_available()
+    pf.cutoffs.trusted = None
+    assert not pf.cutoffs.trusted_available() and "Cutoffs gathering=None" in repr(pf.cutoffs)
+    ev = hmm.evalue_parameters
+    assert ev == models["Thioesterase"][0].evalue_parameters and ev.m_mu == pytest.approx(-10.1820, abs=1e-4)
+    hmm.evalue_parameters.m_mu = -9.5
+    assert hmm.evalue_parameters.m_mu == -9.5 and hmm.evalue_parameters != models["Thioesterase"][0].evalue_parameters
+    hmm.evalue_parameters.f_tau = None
+    assert hmm.evalue_parameters.f_tau is None

@@ -146,6 +146,19 @@ def test_host_write_pfam_format_holds_the_domain_table_rows(models, oracle, prot
         assert (r[1], r[2], r[3], r[4], r[7], r[8], r[9], r[10]) == (w[13], w[12], w[9], w[14], w[17], w[18], w[15], w[16])
 
 
+def test_host_tophits_thresholds(models, oracle, proteome):
+    """reference plan7.pyx:8600-8690: the thresholds a hit list was made with; a bit-score threshold is None while its E-value twin
+    is in force."""
+    hmm = models["PF02826"][0]
+    base = host_pipeline.host_search(oracle, hmm, proteome[:400])
+    assert (base.E, base.T, base.domE, base.domT, base.incE, base.incT, base.incdomE, base.incdomT, base.bit_cutoffs) == \
+           (10.0, None, 10.0, None, 0.01, None, 0.01, None, None)
+    byT = host_pipeline.host_search(oracle, hmm, proteome[:400], pipeline=plan7.Pipeline(hmm.alphabet, T=20.0, domT=10.0, incT=25.0, incdomT=12.0))
+    assert (byT.T, byT.domT, byT.incT, byT.incdomT) == (20.0, 10.0, 25.0, 12.0)
+    ga = host_pipeline.host_search(oracle, hmm, proteome[:400], pipeline=plan7.Pipeline(hmm.alphabet, bit_cutoffs="gathering"))
+    assert ga.bit_cutoffs == "gathering"
+
+
 def test_host_tophits_api(models, oracle, proteome):
     """reference tests/test_plan7/test_tophits.py:112-160, 293-327, 343-357, 383-450 and test_hit.py:94-150."""
     hmm = models["PF02826"][0]
