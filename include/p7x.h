@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define P7X_ABI_VERSION 7
+#define P7X_ABI_VERSION 8
 
 enum {
   P7X_OK = 0, P7X_EMEM = 5, P7X_EFORMAT = 7, P7X_EINVAL = 11, P7X_ERANGE = 16, P7X_ENORESULT = 19,
@@ -186,12 +186,12 @@ typedef struct p7x_pipeline_cfg {
                               * parts together (E-values for all residues searched, duplicates, thresholds).  Default 0 of 1 */
   float   oa_guard;          /* near-tie guard of the device's optimal-accuracy traceback: with g > 0 a choice on the trace between
                               * candidates within |v| * g + g of each other (or a posterior that close to the next printed digit) sends
-                              * the envelope to the host twin, which repeats it.  Default 0 (off, and a kernel without the guard's
-                              * arithmetic): since ABI 7 the host twin forms every order-sensitive sum of Forward, Backward and the
-                              * null2 expectation in the device's order (lane chunks, the wavefront's scan / reduction trees), so both
-                              * compute the same posteriors and take the same decisions (tests/test_gpu_envelopes.py compares every
-                              * integer field of every domain; scripts/oa_guard_sweep2.py counts differences over 26,000 domains).
-                              * The guard remains as a diagnostic: with 4e-6 it flags about 3 % of the envelopes */
+                              * the envelope to the host stage, which repeats it with Forward / Backward / null2 summed in UPSTREAM's
+                              * order (impl_sse's four stripes: forward_full_upstream, p7x_domaindef.cpp), so that a decision the
+                              * device's summation order cannot be trusted with is the reference's.  Default 4e-6 since ABI 8 (about
+                              * 2 % of the envelopes; scripts/oa_guard_sweep2.py: no differing domain left at 3e-6 over 26,000); 0:
+                              * off, and a kernel without the guard's arithmetic (the device is then compared with its own host twin,
+                              * option "host_order" = 1, which sums in the device's order) */
   float   f3_guard;          /* relative half-width of the band around F3 inside which a target's Forward P-value is not trusted to the
                               * device's summation order: the device passes P <= F3 (1 + g), the host stage re-scores the targets with
                               * P > F3 (1 - g) with p7x_forward_parser_exact and applies F3 to that.  Default 4e-3 (a band of about 6e-3 bit, three times the stated tolerance of the device Forward score); 0: no guard */
@@ -204,6 +204,13 @@ typedef struct p7x_pipeline_cfg {
                               * on the device and the clustered envelopes are rescored there in a second round; 1: on the host
                               * workers.  Identical results (one generator stream per region, the same choices: p7x_choice.hpp).
                               * Without re-seeding (seed 0) the regions of a search share one stream and the host samples them. */
+  float   ens_guard;         /* ABI 8.  Near-threshold guard of the device's stochastic tracebacks: a choice of a sampled traceback
+                              * whose deviate lies within g (as a fraction of the deviate's range) of one of its thresholds -- they
+                              * come from a Forward matrix summed in the device's order -- flags the region, and the host stage
+                              * samples flagged regions itself from a Forward matrix in upstream's order (status bit 6 of
+                              * EnsembleResult).  Default 2.5e-7 = 2^-22: between the two orders no threshold of a reachable cell was seen
+                              * further apart than 2^-21, and 5 in a million further than 2^-22 (scripts/order_spread.py, 3.6e8
+                              * thresholds, profiles/r06_order_spread.txt); 0: off */
 } p7x_pipeline_cfg;
 enum { P7X_STRAND_BOTH = 0, P7X_STRAND_TOPONLY = 1, P7X_STRAND_BOTTOMONLY = 2 };
 void p7x_pipeline_cfg_default(p7x_pipeline_cfg *cfg);   /* p7_pipeline_Create(NULL,...) defaults, plan7.pyx:5413-5421 */
@@ -291,6 +298,10 @@ int  p7x_debug_log_of_float(int device, const float *in, float *out, size_t n);
  *   node, a sample's domains first to last; n2[pos], pos = 1..j-i+1: the summed null2 odds ratios of the residue;
  *   status 0 = sampled. */
 int  p7x_debug_choice(const float *p, int n, uint32_t x, int *via_thresholds, int *via_fchoose);
+/* Calibration seam of the ensemble walk's near-threshold guard: the Forward matrix of region i..j of dsq1[1..L] in the device's
+ * summation order and in upstream's, and for every cell the integer thresholds of its choice points in both: out12[0] =
+ * thresholds compared, [1] = largest difference / 2^32, [2 + b] = how many differ by more than 2^-(24 - b), b = 0..9. */
+int  p7x_debug_order_spread(const p7x_oprofile *om, const uint8_t *dsq1, int32_t L, int32_t i, int32_t j, int multihit, double *out12);
 /* Test seam of the long-target SSV scan's tables (host code, no device): the registers per lane R the kernel takes for this
  * model, the most a cell can lose in one row with a canonical residue (byte units), and the table it stages in LDS --
  * [parity][x < 4][q][lane][c] packed pairs (lo, hi) of bias - rb[x][k], register j = 4q + c of the lane holding nodes
@@ -434,6 +445,9 @@ int      p7x_tophits_get_timings(const p7x_tophits *th, double *ms, int n);
  * deserialisation), and the latter by the kind of choice that was close: the predecessor of a match / insert / delete
  * cell, C<-E, J<-E, the end cell, B<-N/J, a printed posterior digit (an envelope can count under several) */
 int      p7x_tophits_get_guard_counts(const p7x_tophits *th, int64_t *f3_dropped, int64_t *oa_redone, int64_t oa_why[8]);
+/* ABI 8: multi-domain regions whose traceback ensemble the device sampled, and regions its near-threshold guard
+ * (p7x_pipeline_cfg.ens_guard) flagged and the host stage sampled again in upstream's summation order */
+int      p7x_tophits_get_ensemble_counts(const p7x_tophits *th, int64_t *sampled_on_device, int64_t *redone_by_host);
 
 const char *p7x_last_error(void);
 

@@ -35,7 +35,7 @@
 typedef struct { int64_t n; int k; int64_t length; } LTW;            /* first residue, last node (seeds), residues */
 
 static inline int sat16i(int v) { return v > 32767 ? 32767 : (v < -32768 ? -32768 : v); }
-static float lt_null1(int64_t L) { float p1 = (float) L / (float) (L + 1); return (float) L * logf(p1) + logf(1.0f - p1); }
+static float lt_null1(int64_t L) { float p1 = (float) L / (float) (L + 1); return (float) L * log(p1) + log(1. - p1); }   /* p7_bg_NullOne: C's double log() */
 
 /* node k of the striped 4-lane float tables: vector q = (k-1) % Q, lane z = (k-1) / Q */
 static float tf_at(const P7O_PROFILE *p, int t, int k)

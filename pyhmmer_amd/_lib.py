@@ -110,6 +110,7 @@ class PipelineCfg(C.Structure):
         ("f3_guard", C.c_float),
         ("lt_resident_key", C.c_uint64),
         ("host_ensembles", C.c_int32),
+        ("ens_guard", C.c_float),
     ]
 
 
@@ -155,6 +156,7 @@ _SIGNATURES = {
     "p7x_tophits_merge_longtargets": (C.c_int, [C.POINTER(_VP), C.c_size_t, C.POINTER(_VP)]),
     "p7x_tophits_merge_many": (C.c_int, [C.POINTER(C.c_char_p), C.POINTER(C.c_size_t), C.c_size_t, C.c_size_t, C.c_int, C.POINTER(_VP)]),
     "p7x_tophits_get_guard_counts": (C.c_int, [_VP, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
+    "p7x_tophits_get_ensemble_counts": (C.c_int, [_VP, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
     "p7x_hmm_max_length": (C.c_int, [C.POINTER(HmmView), C.c_double, C.POINTER(C.c_int32)]),
     "p7x_expf_neg": (None, [_VP, _VP, C.c_size_t]),
     "p7x_oprofile_create": (C.c_int, [C.POINTER(HmmView), _VP, C.c_int32, C.POINTER(_VP)]),
@@ -204,6 +206,7 @@ _SIGNATURES = {
     "p7x_pending_nqueries": (C.c_size_t, [_VP]),
     "p7x_debug_log_of_float": (C.c_int, [C.c_int, _VP, _VP, C.c_size_t]),
     "p7x_debug_choice": (C.c_int, [_VP, C.c_int, C.c_uint32, _VP, _VP]),
+    "p7x_debug_order_spread": (C.c_int, [_VP, _VP, C.c_int32, C.c_int32, C.c_int32, C.c_int, _VP]),
     "p7x_debug_ssv_tables": (C.c_int64, [_VP, C.c_int, _VP, _VP, _VP, C.c_size_t]),
     "p7x_debug_set_option": (C.c_int, [C.c_char_p, C.c_int]),
     "p7x_longtargets_release_resident": (C.c_int, [C.c_int, C.c_uint64]),
@@ -247,7 +250,7 @@ def lib() -> C.CDLL:
             fn = getattr(l, name)      # AttributeError if the ABI is incomplete
             fn.restype = res
             fn.argtypes = args
-        if l.p7x_abi_version() != 7:
+        if l.p7x_abi_version() != 8:
             raise ImportError("libp7x ABI version mismatch; rebuild")
         _lib = l
     return _lib

@@ -123,7 +123,7 @@ namespace p7x {
 struct LongTargetWindowRegions;
 int device_regions_of_all(const p7x_oprofile *om, const p7x_seqdb *db, std::vector<LongTargetWindowRegions> &out);
 std::unique_ptr<EnvelopeScorer> make_device_envelope_scorer(DeviceCtx *ctx, const p7x_seqdb *db, float oa_guard);
-std::unique_ptr<EnsembleRunner> make_device_ensemble_runner(DeviceCtx *ctx, const p7x_seqdb *db);
+std::unique_ptr<EnsembleRunner> make_device_ensemble_runner(DeviceCtx *ctx, const p7x_seqdb *db, float guard);
 
 } // namespace p7x
 

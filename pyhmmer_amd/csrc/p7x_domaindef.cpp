@@ -174,6 +174,15 @@ struct Model {
   // is a third one; what the fixtures pin is reproduced by all of them.
   int C = 1;                                        // nodes per lane: vit_pick_C(M), the device image's choice
   float ddprod[64];                                 // product of the D->D transitions of a lane's nodes, in node order
+  // upstream = true (the default; option "host_order" = 1 selects the device's order instead): those sums run as
+  // impl_sse runs them -- four stripes, node k in stripe (k-1)/Q at position (k-1)%Q, serial D->D sweeps, row sums
+  // stripe by stripe and then (s0+s1)+(s2+s3) -- so that every float, and with it every decision, is the reference's.
+  // The host stage uses it for whatever it computes itself, in particular for the envelopes and regions the device
+  // flags as too close to call (near-tie guards of p7x_envelope.hip / p7x_ensemble.hip).
+  bool upstream = true;
+  int Q = 0;
+  std::vector<float> st;                            // [8][Q][4] transitions in the striped layout (padding: 0)
+  const float *sT(int t) const { return st.data() + (size_t) t * Q * 4; }
   std::vector<float> rfT;                           // [M+1][kKpad] match odds, residue-minor (null2_by_trace)
   static constexpr int kKpad = 24;
   void prepare_rfT()
@@ -181,8 +190,16 @@ struct Model {
     rfT.assign((size_t) (M + 1) * kKpad, 0.0f);
     for (int x = 0; x < p->K && x < kKpad; ++x) { const float *r = rf(x); for (int k = 1; k <= M; ++k) rfT[(size_t) k * kKpad + x] = r[k]; }
   }
-  void prepare()
+  void prepare(int order = -1)
   {
+    upstream = order >= 0 ? order == 0 : debug_opt(OPT_HOST_ORDER) <= 0;
+    Q = p->Q4();
+    st.assign((size_t) 8 * Q * 4, 0.0f);
+    for (int t = 0; t < 8; ++t) {
+      const float *src = tf(t);
+      const int last = (t == 4 || t == 7) ? M - 1 : M;        // M -> D and D -> D do not leave node M
+      for (int q = 0; q < Q; ++q) for (int z = 0; z < 4; ++z) { const int k = q + 1 + z * Q; if (k <= last) st[((size_t) t * Q + q) * 4 + z] = src[k]; }
+    }
     C = vit_pick_C(M);
     if (C <= 0) C = (M + 63) / 64;                  // beyond the device kernels' reach: the same rule, continued
     const float *tDD = tf(7);
@@ -255,7 +272,7 @@ static float dchain_forward(const Model &om, const float *__restrict mc, float *
   return lanes_sum(es);
 }
 
-P7X_MULTIVERSION int forward_full(const Model &om, const uint8_t *dsq, int L, Matrix &ox, float *ret_sc)
+P7X_MULTIVERSION int forward_full_lanes(const Model &om, const uint8_t *dsq, int L, Matrix &ox, float *ret_sc)
 {
   const int M = om.M;
   ox.resize(M, L);
@@ -336,7 +353,7 @@ static float lanes_dot(const Model &om, const float *__restrict v, const float *
   return lanes_sum(es);
 }
 
-P7X_MULTIVERSION int backward_full(const Model &om, const uint8_t *dsq, int L, const Matrix &fwd, Matrix &bck, float *ret_sc)
+P7X_MULTIVERSION int backward_full_lanes(const Model &om, const uint8_t *dsq, int L, const Matrix &fwd, Matrix &bck, float *ret_sc)
 {
   const int M = om.M;
   bck.resize(M, L);
@@ -414,6 +431,214 @@ P7X_MULTIVERSION int backward_full(const Model &om, const uint8_t *dsq, int L, c
   return P7X_OK;
 }
 
+
+// ---------------------------------------------------------------- p7_Forward / p7_Backward in upstream's order
+// impl_sse/fwdback.c forward_engine / backward_engine with do_full = TRUE, restated on four-float vectors: vector q of a row
+// holds nodes q+1, q+1+Q, q+1+2Q, q+1+3Q (padding nodes carry zero transitions and emissions, as p7_oprofile_Convert pads
+// them).  Every multiplication and addition of the vector code is performed on the same operands in the same order; the
+// rows go to the un-striped Matrix afterwards.  forward_parser_striped() (p7x_longtarget.inc.hpp) is the do_full = FALSE
+// sibling.
+struct V4 { float v[4]; };
+static inline V4 v4_set(float a) { return V4{{ a, a, a, a }}; }
+static inline V4 v4_add(const V4 &a, const V4 &b) { V4 r; for (int z = 0; z < 4; ++z) r.v[z] = a.v[z] + b.v[z]; return r; }
+static inline V4 v4_mul(const V4 &a, const V4 &b) { V4 r; for (int z = 0; z < 4; ++z) r.v[z] = a.v[z] * b.v[z]; return r; }
+static inline V4 v4_shr(const V4 &a) { return V4{{ 0.0f, a.v[0], a.v[1], a.v[2] }}; }        // esl_sse_rightshift_ps(a, 0)
+static inline V4 v4_shl(const V4 &a) { return V4{{ a.v[1], a.v[2], a.v[3], 0.0f }}; }        // esl_sse_leftshift_ps(a, 0)
+static inline float v4_hsum(const V4 &a) { return (a.v[0] + a.v[1]) + (a.v[2] + a.v[3]); }   // esl_sse_hsum_ps
+struct StripedRow { std::vector<V4> m, d, i; void resize(int Q) { m.resize((size_t) Q); d.resize((size_t) Q); i.resize((size_t) Q); } };
+static inline void unstripe(const StripedRow &r, int Q, int M, float *mc, float *ic, float *dc)
+{
+  for (int q = 0; q < Q; ++q)
+    for (int z = 0; z < 4; ++z) { const int k = q + 1 + z * Q; if (k <= M) { mc[k] = r.m[q].v[z]; ic[k] = r.i[q].v[z]; dc[k] = r.d[q].v[z]; } }
+  mc[0] = ic[0] = dc[0] = 0.0f; mc[M + 1] = ic[M + 1] = dc[M + 1] = 0.0f;
+}
+static inline void stripe_emissions(const float *rf, int Q, int M, std::vector<V4> &rv)
+{
+  for (int q = 0; q < Q; ++q) for (int z = 0; z < 4; ++z) { const int k = q + 1 + z * Q; rv[(size_t) q].v[z] = k <= M ? rf[k] : 0.0f; }
+}
+
+struct StripedScratch { StripedRow a, b; std::vector<V4> rv; };     // per thread, owned by the dispatchers below (no thread_local inside a cloned function)
+P7X_MULTIVERSION int forward_full_upstream(const Model &om, const uint8_t *dsq, int L, Matrix &ox, float *ret_sc, StripedScratch &ss)
+{
+  const int M = om.M, Q = om.Q;
+  ox.resize(M, L);
+  const V4 *tBM = reinterpret_cast<const V4 *>(om.sT(0)), *tMM = reinterpret_cast<const V4 *>(om.sT(1)), *tIM = reinterpret_cast<const V4 *>(om.sT(2)),
+           *tDM = reinterpret_cast<const V4 *>(om.sT(3)), *tMD = reinterpret_cast<const V4 *>(om.sT(4)), *tMI = reinterpret_cast<const V4 *>(om.sT(5)),
+           *tII = reinterpret_cast<const V4 *>(om.sT(6)), *tDD = reinterpret_cast<const V4 *>(om.sT(7));
+  StripedRow &row = ss.a;
+  std::vector<V4> &rv = ss.rv;
+  row.resize(Q); rv.resize((size_t) Q);
+  const V4 zero = v4_set(0.0f);
+  for (int q = 0; q < Q; ++q) row.m[q] = row.d[q] = row.i[q] = zero;
+  { float *m0 = ox.M_(0), *i0 = ox.I_(0), *d0 = ox.D_(0); for (int k = 0; k <= M + 1; ++k) m0[k] = i0[k] = d0[k] = 0.0f; }
+  float xE = 0.f, xN = 1.f, xJ = 0.f, xB = om.xf[XN][MOVE], xC = 0.f;
+  ox.X(0, xE_) = xE; ox.X(0, xN_) = xN; ox.X(0, xJ_) = xJ; ox.X(0, xB_) = xB; ox.X(0, xC_) = xC; ox.X(0, xS_) = 1.0f;
+  ox.totscale = 0.0f; ox.own_scales = true;
+  for (int r = 1; r <= L; ++r) {
+    stripe_emissions(om.rf(dsq[r]), Q, M, rv);
+    V4 dcv = zero, xEv = zero;
+    const V4 xBv = v4_set(xB);
+    V4 mpv = v4_shr(row.m[Q - 1]), dpv = v4_shr(row.d[Q - 1]), ipv = v4_shr(row.i[Q - 1]);
+    for (int q = 0; q < Q; ++q) {
+      V4 sv = v4_mul(xBv, tBM[q]);
+      sv = v4_add(sv, v4_mul(mpv, tMM[q]));
+      sv = v4_add(sv, v4_mul(ipv, tIM[q]));
+      sv = v4_add(sv, v4_mul(dpv, tDM[q]));
+      sv = v4_mul(sv, rv[(size_t) q]);
+      xEv = v4_add(xEv, sv);
+      mpv = row.m[q]; dpv = row.d[q]; ipv = row.i[q];
+      row.m[q] = sv;
+      row.d[q] = dcv;
+      dcv = v4_mul(sv, tMD[q]);
+      sv = v4_mul(mpv, tMI[q]);
+      row.i[q] = v4_add(sv, v4_mul(ipv, tII[q]));
+    }
+    dcv = v4_shr(dcv);
+    row.d[0] = zero;
+    for (int q = 0; q < Q; ++q) { row.d[q] = v4_add(dcv, row.d[q]); dcv = v4_mul(row.d[q], tDD[q]); }
+    if (M < 100) {
+      for (int j = 1; j < 4; ++j) {
+        dcv = v4_shr(dcv);
+        for (int q = 0; q < Q; ++q) { row.d[q] = v4_add(dcv, row.d[q]); dcv = v4_mul(dcv, tDD[q]); }
+      }
+    } else {
+      for (int j = 1; j < 4; ++j) {
+        bool grew = false;
+        dcv = v4_shr(dcv);
+        for (int q = 0; q < Q; ++q) {
+          const V4 sv = v4_add(dcv, row.d[q]);
+          for (int z = 0; z < 4; ++z) grew |= sv.v[z] > row.d[q].v[z];
+          row.d[q] = sv;
+          dcv = v4_mul(dcv, tDD[q]);
+        }
+        if (!grew) break;
+      }
+    }
+    for (int q = 0; q < Q; ++q) xEv = v4_add(row.d[q], xEv);
+    xE = v4_hsum(xEv);
+    xN = xN * om.xf[XN][LOOP];
+    xC = (xC * om.xf[XC][LOOP]) + (xE * om.xf[XE][MOVE]);
+    xJ = (xJ * om.xf[XJ][LOOP]) + (xE * om.xf[XE][LOOP]);
+    xB = (xJ * om.xf[XJ][MOVE]) + (xN * om.xf[XN][MOVE]);
+    if (xE > 1.0e4) {
+      xN = xN / xE; xC = xC / xE; xJ = xJ / xE; xB = xB / xE;
+      const V4 inv = v4_set((float) (1.0 / xE));
+      for (int q = 0; q < Q; ++q) { row.m[q] = v4_mul(row.m[q], inv); row.d[q] = v4_mul(row.d[q], inv); row.i[q] = v4_mul(row.i[q], inv); }
+      ox.X(r, xS_) = xE;
+      ox.totscale += std::log((double) xE);
+      xE = 1.0;
+    } else ox.X(r, xS_) = 1.0f;
+    ox.X(r, xE_) = xE; ox.X(r, xN_) = xN; ox.X(r, xJ_) = xJ; ox.X(r, xB_) = xB; ox.X(r, xC_) = xC;
+    unstripe(row, Q, M, ox.M_(r), ox.I_(r), ox.D_(r));
+  }
+  if (std::isnan(xC) || (L > 0 && xC == 0.0f) || std::isinf(xC)) { if (ret_sc) *ret_sc = INFINITY; return P7X_ERANGE; }
+  if (ret_sc) *ret_sc = ox.totscale + std::log((double) (xC * om.xf[XC][MOVE]));
+  return P7X_OK;
+}
+
+P7X_MULTIVERSION int backward_full_upstream(const Model &om, const uint8_t *dsq, int L, const Matrix &fwd, Matrix &bck, float *ret_sc, StripedScratch &ss)
+{
+  const int M = om.M, Q = om.Q;
+  bck.resize(M, L);
+  const V4 *tBM = reinterpret_cast<const V4 *>(om.sT(0)), *tMM = reinterpret_cast<const V4 *>(om.sT(1)), *tIM = reinterpret_cast<const V4 *>(om.sT(2)),
+           *tDM = reinterpret_cast<const V4 *>(om.sT(3)), *tMD = reinterpret_cast<const V4 *>(om.sT(4)), *tMI = reinterpret_cast<const V4 *>(om.sT(5)),
+           *tII = reinterpret_cast<const V4 *>(om.sT(6)), *tDD = reinterpret_cast<const V4 *>(om.sT(7));
+  StripedRow &rowa = ss.a, &rowb = ss.b;
+  std::vector<V4> &rv = ss.rv;
+  rowa.resize(Q); rowb.resize(Q); rv.resize((size_t) Q);
+  StripedRow *cur = &rowa, *nxt = &rowb;          // row i being built, row i + 1
+  const V4 zero = v4_set(0.0f);
+  bck.own_scales = false;
+  float xJ = 0.f, xB = 0.f, xN = 0.f;
+  float xC = om.xf[XC][MOVE];
+  float xE = xC * om.xf[XE][MOVE];
+  // the D -> D paths of a row: one sweep down every stripe from what the stripe after it holds so far, then three sweeps that
+  // hand the remainder from stripe to stripe; then the M -> D paths.  first: the operand the first sweep starts from.
+  auto close_row = [&](StripedRow &r, const V4 &first, const V4 &xEv, bool add_e) {
+    V4 dpv = v4_shl(first), dcv = zero;
+    for (int q = Q - 1; q >= 0; --q) {
+      dcv = v4_mul(dpv, tDD[q]);
+      if (add_e) { r.d[q] = v4_add(r.d[q], v4_add(dcv, xEv)); r.m[q] = v4_add(r.m[q], xEv); }
+      else       r.d[q] = v4_add(r.d[q], dcv);
+      dpv = r.d[q];
+    }
+    for (int j = 1; j < 4; ++j) {
+      dcv = v4_shl(dcv);
+      for (int q = Q - 1; q >= 0; --q) { dcv = v4_mul(dcv, tDD[q]); r.d[q] = v4_add(r.d[q], dcv); }
+    }
+    dcv = v4_shl(r.d[0]);
+    for (int q = Q - 1; q >= 0; --q) { r.m[q] = v4_add(r.m[q], v4_mul(dcv, tMD[q])); dcv = r.d[q]; }
+  };
+  auto rescale = [&](StripedRow &r, float sc) {
+    const V4 inv = v4_set((float) (1.0 / sc));
+    for (int q = 0; q < Q; ++q) { r.m[q] = v4_mul(r.m[q], inv); r.d[q] = v4_mul(r.d[q], inv); r.i[q] = v4_mul(r.i[q], inv); }
+  };
+  {
+    const V4 xEv = v4_set(xE);
+    for (int q = 0; q < Q; ++q) { cur->m[q] = cur->d[q] = xEv; cur->i[q] = zero; }
+    close_row(*cur, cur->d[Q - 1], xEv, false);
+    const float sc = fwd.X(L, xS_);
+    if (sc > 1.0f) { xE = xE / sc; xN = xN / sc; xC = xC / sc; xJ = xJ / sc; xB = xB / sc; rescale(*cur, sc); }
+    bck.X(L, xS_) = sc;
+    bck.totscale = std::log((double) sc);
+    bck.X(L, xE_) = xE; bck.X(L, xN_) = xN; bck.X(L, xJ_) = xJ; bck.X(L, xB_) = xB; bck.X(L, xC_) = xC;
+    unstripe(*cur, Q, M, bck.M_(L), bck.I_(L), bck.D_(L));
+  }
+  for (int r = L - 1; r >= 1; --r) {
+    std::swap(cur, nxt);
+    stripe_emissions(om.rf(dsq[r + 1]), Q, M, rv);
+    V4 tmmv = v4_shl(tMM[0]), timv = v4_shl(tIM[0]), tdmv = v4_shl(tDM[0]);      // the transitions INTO the node after the stripe's last
+    V4 mpv = v4_shl(v4_mul(nxt->m[0], rv[0]));                                   // M(i+1, k+1) e(x_{i+1}, k+1)
+    V4 xBv = zero;
+    for (int q = Q - 1; q >= 0; --q) {
+      const V4 ipv = nxt->i[q];
+      cur->i[q] = v4_add(v4_mul(ipv, tII[q]), v4_mul(mpv, timv));
+      cur->d[q] = v4_mul(mpv, tdmv);
+      const V4 mcv = v4_add(v4_mul(ipv, tMI[q]), v4_mul(mpv, tmmv));
+      mpv = v4_mul(nxt->m[q], rv[(size_t) q]);
+      cur->m[q] = mcv;
+      tdmv = tDM[q]; timv = tIM[q]; tmmv = tMM[q];
+      xBv = v4_add(xBv, v4_mul(mpv, tBM[q]));
+    }
+    xB = v4_hsum(xBv);
+    xC = xC * om.xf[XC][LOOP];
+    xJ = (xB * om.xf[XJ][MOVE]) + (xJ * om.xf[XJ][LOOP]);
+    xN = (xB * om.xf[XN][MOVE]) + (xN * om.xf[XN][LOOP]);
+    xE = (xC * om.xf[XE][MOVE]) + (xJ * om.xf[XE][LOOP]);
+    const V4 xEv = v4_set(xE);
+    close_row(*cur, v4_add(cur->d[0], xEv), xEv, true);
+    if (xB > 1.0e16) bck.own_scales = true;
+    const float sc = bck.own_scales ? ((xB > 1.0e4) ? xB : 1.0f) : fwd.X(r, xS_);
+    bck.X(r, xS_) = sc;
+    if (sc > 1.0f) {
+      xE /= sc; xN /= sc; xJ /= sc; xB /= sc; xC /= sc;
+      rescale(*cur, sc);
+      bck.totscale += std::log((double) sc);
+    }
+    bck.X(r, xE_) = xE; bck.X(r, xN_) = xN; bck.X(r, xJ_) = xJ; bck.X(r, xB_) = xB; bck.X(r, xC_) = xC;
+    unstripe(*cur, Q, M, bck.M_(r), bck.I_(r), bck.D_(r));
+  }
+  {
+    stripe_emissions(om.rf(dsq[1]), Q, M, rv);
+    V4 xBv = zero;
+    for (int q = Q - 1; q >= 0; --q) xBv = v4_add(xBv, v4_mul(v4_mul(cur->m[q], rv[(size_t) q]), tBM[q]));
+    xB = v4_hsum(xBv);
+    xN = (xB * om.xf[XN][MOVE]) + (xN * om.xf[XN][LOOP]);
+    bck.X(0, xB_) = xB; bck.X(0, xC_) = 0.0f; bck.X(0, xJ_) = 0.0f; bck.X(0, xN_) = xN; bck.X(0, xE_) = 0.0f; bck.X(0, xS_) = 1.0f;
+    float *mc = bck.M_(0), *ic = bck.I_(0), *dc = bck.D_(0);
+    for (int k = 0; k <= M + 1; ++k) mc[k] = ic[k] = dc[k] = 0.0f;
+  }
+  if (std::isnan(xN) || (L > 0 && xN == 0.0f) || std::isinf(xN)) { if (ret_sc) *ret_sc = INFINITY; return P7X_ERANGE; }
+  if (ret_sc) *ret_sc = bck.totscale + std::log((double) xN);
+  return P7X_OK;
+}
+
+static StripedScratch &striped_scratch() { thread_local StripedScratch *ss = new StripedScratch(); return *ss; }     // (leaked with its thread: a few KB)
+static inline int forward_full(const Model &om, const uint8_t *dsq, int L, Matrix &ox, float *ret_sc)
+{ return om.upstream ? forward_full_upstream(om, dsq, L, ox, ret_sc, striped_scratch()) : forward_full_lanes(om, dsq, L, ox, ret_sc); }
+static inline int backward_full(const Model &om, const uint8_t *dsq, int L, const Matrix &fwd, Matrix &bck, float *ret_sc)
+{ return om.upstream ? backward_full_upstream(om, dsq, L, fwd, bck, ret_sc, striped_scratch()) : backward_full_lanes(om, dsq, L, fwd, bck, ret_sc); }
+
 // ---------------------------------------------------------------- p7_Decoding: posteriors into <bck> (in place)
 // NOTE: only the M and I posteriors are formed.  bck.D_ keeps Backward's delete values afterwards (upstream zeroes them): a
 // future reader of the delete "posteriors" must not take them from here.
@@ -480,6 +705,18 @@ P7X_MULTIVERSION void null2_by_expectation(const Model &om, Matrix &pp, float *n
   eN *= norm; eC *= norm; eJ *= norm;
   const float xfactor = eN + eC + eJ;
   const int C = om.C;
+  if (om.upstream) {                                    // impl_sse/null2.c: four stripes, a stripe's nodes in order (match term, insert term), then hsum
+    const int Q = om.Q;
+    for (int x = 0; x < om.p->K; ++x) {
+      const float *rf = om.rf(x);
+      float sv[4] = { 0.0f, 0.0f, 0.0f, 0.0f };
+      for (int q = 0; q < Q; ++q)
+        for (int z = 0; z < 4; ++z) { const int k = q + 1 + z * Q; if (k <= M) { sv[z] = sv[z] + m0[k] * rf[k]; sv[z] = sv[z] + i0[k]; } }
+      null2[x] = ((sv[0] + sv[1]) + (sv[2] + sv[3])) + xfactor;
+    }
+    finish_null2(*om.p, null2);
+    return;
+  }
   for (int x = 0; x < om.p->K; ++x) {
     const float *rf = om.rf(x);
     float es[64];                                       // the envelope kernel's order: a lane's nodes, match then insert, then the tree
@@ -1114,7 +1351,9 @@ int domaindef_multi_region(const Profile &p, const uint8_t *dsq, int L, int i, i
   const int Lr = j - i + 1;
   std::vector<SpCoord> sp;
   dd.nclustered++;
+  if (ens && ens->status >= 0 && (ens->status & 64) && ens->status < 128) dd.nens_redone++;
   if (ens && ens->status == 0 && do_reseeding && !om.lt) {
+    dd.nens_device++;
     // the ensemble was sampled on the device (p7x_ensemble.hip): end points and null2 sums are in; a sample's domains come
     // in traceback order and go into the list first domain first, as p7_trace_Index numbers them
     sp.reserve((size_t) ens->ndom);
@@ -1293,7 +1532,7 @@ int domaindef_finish_deferred(const Profile &p, const uint8_t *dsq, int L, const
     if (r.status & 64) {
       // a near-tie on the device's optimal-accuracy trace (p7x_envelope.hip, cfg.oa_guard): this envelope again with
       // the host twin, which performs the reference's operations in the reference's order
-      if (!om_exact_ready) { om_exact.prepare(); om_exact.configure(false, L); om_exact_ready = true; }
+      if (!om_exact_ready) { om_exact.prepare(); om_exact.configure(false, L); om_exact_ready = true; }      // upstream's order (unless the test seam "host_order" asks for the device's)
       DomainDefResult one;
       one.n2sc.swap(dd.n2sc);
       const int st = rescore_isolated_domain(p, om_exact, dsq, L, i, j, null2_done, ws, one);
@@ -1367,6 +1606,48 @@ extern "C" int p7x_debug_choice(const float *p, int n, uint32_t x, int *via_thre
   for (int i = 0; i < n && pick < 0; ++i) { sum += b[i]; if (roll < sum / norm) pick = i; }
   if (pick < 0) { pick = 0; for (int i = n - 1; i >= 0; --i) if (b[i] > 0.0f) { pick = i; break; } }
   *via_fchoose = pick;
+  return P7X_OK;
+}
+
+// Calibration seam of the ensemble walk's near-threshold guard (p7x_ensemble.hip): the Forward matrix of region i..j of
+// dsq1[1..L] in both summation orders -- the device's lane chunks and upstream's stripes -- and, for every cell, the integer
+// thresholds of the three choice points a traceback can meet there (p7x_choice.hpp).  out[0] = thresholds compared,
+// out[1] = the largest |T_lanes - T_upstream| / 2^32, out[2 + b] = how many differ by more than 2^-(24 - b), b = 0..9.
+extern "C" int p7x_debug_order_spread(const p7x_oprofile *om, const uint8_t *dsq1, int32_t L, int32_t i, int32_t j, int multihit, double *out12)
+{
+  using namespace p7x;
+  if (!om || !dsq1 || !out12 || i < 1 || j < i || j > L) { set_error("p7x_debug_order_spread: bad arguments"); return P7X_EINVAL; }
+  const Profile &p = om->p;
+  Model a{ &p, p.M, {} }, b{ &p, p.M, {} };
+  a.prepare(1); b.prepare(0);
+  a.configure(multihit != 0, L); b.configure(multihit != 0, L);
+  Matrix fa, fb;
+  const int Lr = j - i + 1, M = p.M;
+  forward_full(a, dsq1 + i - 1, Lr, fa, nullptr);
+  forward_full(b, dsq1 + i - 1, Lr, fb, nullptr);
+  for (int q = 0; q < 12; ++q) out12[q] = 0.0;
+  auto note = [&](uint32_t ta, uint32_t tb) {
+    const double d = std::fabs((double) ta - (double) tb) / 4294967296.0;
+    out12[0] += 1.0;
+    if (d > out12[1]) out12[1] = d;
+    for (int q = 0; q < 10; ++q) if (d > std::ldexp(1.0, -(24 - q))) out12[2 + q] += 1.0;
+  };
+  const float *bm = a.tf(0), *tMM = a.tf(1), *tIM = a.tf(2), *tDM = a.tf(3), *tMD = a.tf(4), *tMI = a.tf(5), *tII = a.tf(6), *tDD = a.tf(7);
+  for (int r = 1; r <= Lr; ++r)
+    for (int k = 1; k <= M; ++k) {
+      uint32_t ca[4], cb[4], ta, tb, fa_, fb_;
+      choice_cell_m(fa.X(r - 1, xB_) * bm[k], fa.M_(r - 1)[k - 1] * tMM[k], fa.I_(r - 1)[k - 1] * tIM[k], fa.D_(r - 1)[k - 1] * tDM[k], ca);
+      choice_cell_m(fb.X(r - 1, xB_) * bm[k], fb.M_(r - 1)[k - 1] * tMM[k], fb.I_(r - 1)[k - 1] * tIM[k], fb.D_(r - 1)[k - 1] * tDM[k], cb);
+      for (int q = 0; q < 3; ++q) note(ca[q], cb[q]);
+      choice_pair(fa.M_(r - 1)[k] * tMI[k], fa.I_(r - 1)[k] * tII[k], &ta, &fa_);
+      choice_pair(fb.M_(r - 1)[k] * tMI[k], fb.I_(r - 1)[k] * tII[k], &tb, &fb_);
+      note(ta, tb);
+      if (k > 1) {
+        choice_pair(fa.M_(r)[k - 1] * tMD[k - 1], fa.D_(r)[k - 1] * tDD[k - 1], &ta, &fa_);
+        choice_pair(fb.M_(r)[k - 1] * tMD[k - 1], fb.D_(r)[k - 1] * tDD[k - 1], &tb, &fb_);
+        note(ta, tb);
+      }
+    }
   return P7X_OK;
 }
 

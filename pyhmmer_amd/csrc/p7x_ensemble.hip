@@ -163,6 +163,17 @@ __device__ __forceinline__ double readlane_f64(double v, int l)
   const unsigned lo = (unsigned) __builtin_amdgcn_readlane((int) (unsigned) u, l), hi = (unsigned) __builtin_amdgcn_readlane((int) (unsigned) (u >> 32), l);
   return __builtin_bit_cast(double, ((unsigned long long) hi << 32) | lo);
 }
+// Near-threshold guard (status bit 6).  The thresholds come from a Forward matrix summed in the device's lane-chunk order;
+// upstream sums in its four stripes, so a threshold may lie a few units of 2^-24 (relative) elsewhere there, and a deviate
+// that falls between the two takes another path -- and with it every later sample of the region.  Every comparison the walk
+// actually takes that is closer than the guard flags the region, and the host stage samples flagged regions itself from a
+// Forward matrix in upstream's order (domaindef_multi_region).  T == 0 stands for "never" or, as a fallback, "always": the
+// other order may hold a threshold just inside either end of the deviate's range there.
+__device__ __forceinline__ bool near_thr(uint32_t x, uint32_t T, uint32_t G)
+{
+  if (T == 0u) return x <= G || x >= ~G;
+  return (x > T ? x - T : T - x) <= G;
+}
 // a 16-byte record through the vector memory path (in-order returns: a load issued a step ahead stays in flight while the
 // current one is consumed; scalar loads return out of order and would be waited for together)
 __device__ __forceinline__ uint4 vload16(const void *base, unsigned byte_off)
@@ -270,6 +281,9 @@ __global__ void __launch_bounds__(64) ens_walk_kernel(const EnsArgs a)
   const int dom_cap = reg.dom_cap;
   uint32_t x = a.seed_x;
   int ndom = 0, status = 0;
+  const uint32_t G = a.guard;
+  const double Ge = (double) G / 4294967296.0;
+  bool near_any = false;
   const int step_cap = 4 * (Lr + M) + 64;
   uint32_t jumpA = 1u, jumpC = 0u;                                 // lane + 1 draws of x <- 69069 x + 1 in one step
   for (int l = 0; l <= lane; ++l) { jumpA *= 69069u; jumpC = jumpC * 69069u + 1u; }
@@ -280,7 +294,7 @@ __global__ void __launch_bounds__(64) ens_walk_kernel(const EnsArgs a)
   unsigned long long stamp_ = __builtin_readcyclecounter();
   P7X_ENS_COUNT(7, 1);
 #endif
-  for (int t = 0; t < a.nsamples && status == 0; ++t) {
+  for (int t = 0; t < a.nsamples && status == 0 && !near_any; ++t) {
     P7X_ENS_COUNT(5, 1);
     int i = Lr, k = 0, st = tC;
     int hi = Lr;                        // residues hi+1 .. Lr have received this sample's contribution
@@ -297,14 +311,19 @@ __global__ void __launch_bounds__(64) ens_walk_kernel(const EnsArgs a)
         if (i < 1) { status |= 2; break; }
         const int row = i - lane;
         const uint32_t xl = jumpA * x + jumpC;                        // the state after lane + 1 draws
-        bool leave = false;
+        bool leave = false, nearv = false;
         if (row >= 1) {
           const uint4 rw = row_rec(row);
           const int c = (st == tC) ? choice_pick_pair(rw.x, rw.w & 3u, xl) : choice_pick_pair(rw.y, (rw.w >> 2) & 3u, xl);
           leave = c != 0;
+          nearv = G != 0u && near_thr(xl, (st == tC) ? rw.x : rw.y, G);
         }
         const unsigned long long lv = __ballot(leave);
         const int nrows = min(64, i);                                 // rows this look covers
+        {   // the rows the run really decides: up to and including the first that leaves
+          const int lastl = lv != 0ull ? (int) __builtin_ctzll(lv) : nrows - 1;
+          if (__ballot(nearv && lane <= lastl) != 0ull) near_any = true;
+        }
         if (lv != 0ull) {
           const int l = (int) __builtin_ctzll(lv);
           x = (uint32_t) __builtin_amdgcn_readlane((int) xl, l);
@@ -351,6 +370,7 @@ __global__ void __launch_bounds__(64) ens_walk_kernel(const EnsArgs a)
             if (b0 + u < nblk && found < 0 && !ambiguous) {
               const double cum = base + wave_scan_f64((double) v[u]);
               const double dist = __builtin_fabs(cum - roll);
+              if (G != 0u && __ballot(dist <= Ge) != 0ull) near_any = true;          // (cells behind the winner lie further above the deviate than it does)
               if (__ballot(dist < 1.0e-9) != 0ull) ambiguous = 1;
               else {
                 const unsigned long long hit = __ballot(roll < cum);
@@ -364,6 +384,7 @@ __global__ void __launch_bounds__(64) ens_walk_kernel(const EnsArgs a)
         else {                                                            // also the second pass of a first pass that ended short
           const int code = select_e_serial(mdg, M, Q, norm, roll);
           if (code < 0) { status |= 4; break; }
+          if (G != 0u && !ambiguous) near_any = true;                      // a first pass that ended short of the deviate: the sums' last bits decide
           k = code & 0x3fffffff; st = (code >> 30) ? tD : tM;
         }
       }
@@ -403,17 +424,21 @@ __global__ void __launch_bounds__(64) ens_walk_kernel(const EnsArgs a)
           rec.w = isM ? ((rec.w & 31u) | (tg << 5)) : tg;
         }
         int s1;
+        bool nearv = false;
         if (isM) {
           const int fstate = (int) ((0x2316u >> ((rec.w & 3u) * 4u)) & 15u);              // fallback path 0..3 -> B, M, I, D
           s1 = xl < rec.x ? tB : (xl < rec.y ? tM : (xl < rec.z ? tI : fstate));
+          nearv = G != 0u && (near_thr(xl, rec.x, G) || near_thr(xl, rec.y, G) || near_thr(xl, rec.z, G));
         } else {
           const uint32_t thr = isI ? rec.x : rec.y;
           const bool stay = isI ? (rec.z & 1u) != 0u : (rec.z & 4u) != 0u;
           s1 = xl < thr ? tM : (stay ? st : tM);
+          nearv = G != 0u && near_thr(xl, thr, G);
         }
         if (!inside) s1 = 0;                                                              // off the matrix: leaves, and is an error if reached
         const unsigned long long leave = __ballot(s1 != st);
         const int l = leave ? (int) __builtin_ctzll(leave) : 63;                          // the run's last cell is lane l's
+        if (__ballot(nearv && inside && lane <= l) != 0ull) near_any = true;
         if (cache_ok && missed && lane <= l) mcache[slot] = rec;                          // only cells the walk really visited
         P7X_ENS_COUNT(6, __builtin_popcountll(__ballot(missed && lane <= l)));
         if (st != tD && lane <= l && inside) atomicAdd(&cnt[kk], 1u);                     // emitting states: one visit each
@@ -500,6 +525,7 @@ __global__ void __launch_bounds__(64) ens_walk_kernel(const EnsArgs a)
       {
         x = lcg_next(x);
         const uint4 rw = row_rec(i);
+        if (G != 0u && near_thr(x, rw.z, G)) near_any = true;
         if (choice_pick_pair(rw.z, (rw.w >> 4) & 3u, x) == 0) running = false;       // N: the rest of the trace is N ... N S
         else st = tJ;
       }
@@ -521,6 +547,7 @@ __global__ void __launch_bounds__(64) ens_walk_kernel(const EnsArgs a)
     for (int j = 0; j < NR; ++j) { const int pos = 1 + lane + 64 * j; if (pos <= Lr) n2g[pos] = acc[j]; }
     if (lane == 0) n2g[0] = 0.0f;
   } else if (n2_in_lds) for (int pos = lane; pos <= Lr; pos += 64) n2g[pos] = n2[pos];
+  if (near_any) status |= 64;                    // too close to call: the host stage samples this region in upstream's order
   if (lane == 0) { a.out_ndom[r] = ndom; a.out_status[r] = status; }
 }
 
@@ -602,7 +629,11 @@ size_t align256(size_t v) { return (v + 255) & ~(size_t) 255; }
 
 class DeviceEnsembleRunner final : public EnsembleRunner {
 public:
-  DeviceEnsembleRunner(DeviceCtx *ctx, const p7x_seqdb *db) : ctx_(ctx), db_(db) {}
+  DeviceEnsembleRunner(DeviceCtx *ctx, const p7x_seqdb *db, float guard) : ctx_(ctx), db_(db)
+  {
+    const double g = (double) guard * 4294967296.0;
+    guard_ = g <= 0.0 ? 0u : (g >= 1.0e9 ? 1000000000u : (uint32_t) g);
+  }
   ~DeviceEnsembleRunner() override { if (lease_) { if (lease_->stream) (void) hipStreamSynchronize(lease_->stream); release_ens_buffers(lease_); } }
 
   // Any region may be sampled by the host workers instead (EnsembleResult::status != 0): a device-side failure here --
@@ -774,7 +805,7 @@ private:
     a.cells = reinterpret_cast<ChoiceCell *>(eb->work + o_cells);
     a.md = reinterpret_cast<float2 *>(eb->work + o_md);
     a.rows = reinterpret_cast<ChoiceRow *>(eb->work + o_rows);
-    a.seed_x = seed_state; a.nsamples = nsamples;
+    a.seed_x = seed_state; a.nsamples = nsamples; a.guard = guard_;
     a.n2acc = reinterpret_cast<float *>(eb->d_out + o_n2_);
     a.dom = reinterpret_cast<int32_t *>(eb->d_out + o_dom_);
     a.out_ndom = reinterpret_cast<int32_t *>(eb->d_out + o_ndom_); a.out_status = reinterpret_cast<int32_t *>(eb->d_out + o_status_);
@@ -803,6 +834,7 @@ private:
   }
 
   DeviceCtx *ctx_; const p7x_seqdb *db_;
+  uint32_t guard_ = 0;
   std::vector<EnvelopeJob> jobs_;
   std::vector<int64_t> first_, reg_global_;
   std::vector<char> launched_;
@@ -812,9 +844,9 @@ private:
   size_t o_ndom_ = 0, o_status_ = 0, o_dom_ = 0, o_n2_ = 0;
 };
 
-std::unique_ptr<EnsembleRunner> make_device_ensemble_runner(DeviceCtx *ctx, const p7x_seqdb *db)
+std::unique_ptr<EnsembleRunner> make_device_ensemble_runner(DeviceCtx *ctx, const p7x_seqdb *db, float guard)
 {
-  return std::make_unique<DeviceEnsembleRunner>(ctx, db);
+  return std::make_unique<DeviceEnsembleRunner>(ctx, db, guard);
 }
 
 } // namespace p7x
@@ -837,7 +869,7 @@ extern "C" int p7x_debug_ensemble(const p7x_oprofile *om, const p7x_seqdb *db, i
     DeviceCtx *ctx = nullptr;
     int st = get_ctx(db->device, &ctx);
     if (st != P7X_OK) return st;
-    auto runner = make_device_ensemble_runner(ctx, db);
+    auto runner = make_device_ensemble_runner(ctx, db, 0.0f);        // the seam compares the device's samples with the host twin's in the device's order
     std::vector<EnvelopeJob> jobs{ EnvelopeJob{ om, &req, &targets } };
     if ((st = runner->begin(jobs, fast_rng_state(seed), 200)) != P7X_OK) return st;
     std::vector<std::vector<EnsembleResult>> res;

@@ -34,6 +34,8 @@ struct DomainDefResult {      // the P7_DOMAINDEF fields p7_Pipeline reads (p7_d
   int nregions = 0, nclustered = 0, noverlaps = 0, nenvelopes = 0;
   int nneartie = 0;           // device envelopes repeated by the host twin (optimal-accuracy near-tie guard)
   int neartie_why[8]{};       // ... by the kind of choice that was close (EnvArgs::out_status bits 8-15)
+  int nens_device = 0;        // multi-domain regions whose ensemble the device sampled
+  int nens_redone = 0;        // ... and those it flagged as too close to call (near-threshold guard): sampled again here, in upstream's order
 };
 
 // Rescoring of single-domain envelopes can be handed to the device (p7x_envelope.hip): the first half of domain
@@ -231,5 +233,6 @@ struct p7x_tophits {
   int lt_evalue_window = 0;           // ... and the window length its E-values refer to
   int64_t oa_redone = 0;              // device envelopes the near-tie guard sent to the host twin (not serialised)
   int64_t oa_why[8]{};                // ... by kind of choice: M, I, D cell, C<-E, J<-E, end cell, B<-N/J, posterior digit
+  int64_t ens_device = 0, ens_redone = 0;   // regions sampled on the device / flagged by its near-threshold guard and sampled again by the host stage (not serialised)
   int64_t nreported = 0, nincluded = 0;
 };

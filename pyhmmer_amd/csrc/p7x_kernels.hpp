@@ -199,6 +199,7 @@ struct EnsArgs {
   int32_t *dom;             // [5] per domain: sample, sqfrom, sqto (1-based inside the region), hmmfrom, hmmto
   int32_t *out_ndom; int32_t *out_status;               // per region
   int lds_bytes;            // dynamic LDS of the walk kernel: what fits of a region's row records, accumulators and odds table lives there
+  uint32_t guard;           // near-threshold guard of the walk, in units of the generator's 2^-32 (p7x_pipeline_cfg.ens_guard x 2^32); 0: off
 };
 
 // ---- long-target SSV scan (p7x_ssvlong.hip): one chunk of one strand per wavefront, model split across the lanes

@@ -26,7 +26,7 @@ struct LtLengthModel { uint8_t tjb_b; int16_t xw_move; float nullsc; };
 static float lt_null1(int64_t L)
 {
   const float p1 = (float) L / (float) (L + 1);
-  return (float) L * logf(p1) + logf(1.0f - p1);
+  return (float) L * std::log((double) p1) + std::log(1. - p1);        // p7_bg_NullOne
 }
 
 // p7_MSVFilter on dsq[1..L] with the length model of L (u8 arithmetic of impl_sse/msvfilter.c)
@@ -689,7 +689,7 @@ static void lt_finalize(p7x_tophits *th, int max_length, double res_count)
   std::vector<Hit> &hits = th->hits;
   // p7_tophits_ComputeNhmmerEvalues: the P-value of a hit refers to one window of max_length; scale by the windows searched
   for (Hit &h : hits) {
-    h.lnP += std::log((float) res_count / (float) max_length);
+    h.lnP += std::log((double) ((float) res_count / (float) max_length));
     h.dcl[0].lnP = h.lnP;
     h.sortkey = -1.0 * h.lnP;
   }

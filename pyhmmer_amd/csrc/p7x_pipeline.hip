@@ -1985,7 +1985,7 @@ int p7x_search_batch_finish(p7x_pending *pd, const char *const *names, const cha
     if ((st = get_ctx(db->device, &ctx)) != P7X_OK) return st;
     scorer = make_device_envelope_scorer(ctx, db, pd->cfg.oa_guard);
     if (!pd->cfg.host_ensembles) {          // the multi-domain regions' ensembles and their clustered envelopes on the device as well
-      ensembles = make_device_ensemble_runner(ctx, db);
+      ensembles = make_device_ensemble_runner(ctx, db, pd->cfg.ens_guard);
       scorer2 = make_device_envelope_scorer(ctx, db, pd->cfg.oa_guard);
     } else if (device_clustered(pd->cfg.host_threads)) scorer2 = make_device_envelope_scorer(ctx, db, pd->cfg.oa_guard);
   }

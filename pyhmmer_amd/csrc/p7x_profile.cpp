@@ -118,7 +118,7 @@ double exp_logsurv(double x, double mu, double lambda) { return x < mu ? 0.0 : -
 float null1_score(int L)
 { // p7_bg_SetLength + p7_bg_NullOne (p7_bg.pxd:10-30; plan7.pyx:6435)
   const float p1 = (float) L / (float) (L + 1);
-  return (float) L * std::log(p1) + std::log(1. - p1);
+  return (float) L * std::log((double) p1) + std::log(1. - p1);     // C's log(): double, whatever the argument
 }
 
 static float g_flogsum[16000];
@@ -151,7 +151,7 @@ static void configure_generic(Profile &p, const p7x_hmm_view &h)
     occ[k] = occ[k - 1] * (t[(k - 1) * 7 + 0] + t[(k - 1) * 7 + 1]) + (1.0 - occ[k - 1]) * t[(k - 1) * 7 + 5];
   float Z = 0.f;
   for (int k = 1; k <= M; ++k) Z += occ[k] * (float) (M - k + 1);
-  for (int k = 1; k <= M; ++k) p.tsc[(size_t) (k - 1) * 8 + gBM] = std::log(occ[k] / Z);
+  for (int k = 1; k <= M; ++k) p.tsc[(size_t) (k - 1) * 8 + gBM] = std::log((double) (occ[k] / Z));
   // multihit: E->J = E->C = 1/2
   p.xsc[XE][MOVE] = -kLog2;
   p.xsc[XE][LOOP] = -kLog2;
@@ -159,9 +159,10 @@ static void configure_generic(Profile &p, const p7x_hmm_view &h)
   for (int k = 1; k < M; ++k) {
     float *g = &p.tsc[(size_t) k * 8];
     const float *tk = t + (size_t) k * 7;   // MM,MI,MD,IM,II,DM,DD
-    g[gMM] = std::log(tk[0]); g[gMI] = std::log(tk[1]); g[gMD] = std::log(tk[2]);
-    g[gIM] = std::log(tk[3]); g[gII] = std::log(tk[4]);
-    g[gDM] = std::log(tk[5]); g[gDD] = std::log(tk[6]);
+    // (upstream is C: log() takes and returns double; std::log(float) would be logf)
+    g[gMM] = std::log((double) tk[0]); g[gMI] = std::log((double) tk[1]); g[gMD] = std::log((double) tk[2]);
+    g[gIM] = std::log((double) tk[3]); g[gII] = std::log((double) tk[4]);
+    g[gDM] = std::log((double) tk[5]); g[gDD] = std::log((double) tk[6]);
   }
   for (int k = 1; k <= M; ++k) {
     float sc[MAXKP];
@@ -176,8 +177,8 @@ static void configure_generic(Profile &p, const p7x_hmm_view &h)
   }
   // length model (p7_ReconfigLength)
   const float pmove = (2.0f + p.nj) / ((float) p.L + 2.0f + p.nj), ploop = 1.0f - pmove;
-  p.xsc[XN][LOOP] = p.xsc[XC][LOOP] = p.xsc[XJ][LOOP] = std::log(ploop);
-  p.xsc[XN][MOVE] = p.xsc[XC][MOVE] = p.xsc[XJ][MOVE] = std::log(pmove);
+  p.xsc[XN][LOOP] = p.xsc[XC][LOOP] = p.xsc[XJ][LOOP] = std::log((double) ploop);
+  p.xsc[XN][MOVE] = p.xsc[XC][MOVE] = p.xsc[XJ][MOVE] = std::log((double) pmove);
 }
 
 static void convert_msv(Profile &p)
@@ -270,7 +271,7 @@ int p7x_abi_version(void) { return P7X_ABI_VERSION; }
 int p7x_debug_set_option(const char *name, int value)
 {
   static const char *const names[p7x::OPT_COUNT] = { "small_block", "vit_wave", "msv_exact", "msv_long_groups", "msv_blocks_per_cu", "env_workspace_gb",
-                                                     "device_clustered", "trace_finish", "trace_longtarget", "trace_envelope", "host_profile", "ssv_kernel", "msv_f16", "ens_lds_kb", "ens_fail", "msv_tiers", "stage_merge", "early_pack" };
+                                                     "device_clustered", "trace_finish", "trace_longtarget", "trace_envelope", "host_profile", "ssv_kernel", "msv_f16", "ens_lds_kb", "ens_fail", "msv_tiers", "stage_merge", "early_pack", "host_order" };
   if (!name) { p7x::set_error("p7x_debug_set_option: no name"); return P7X_EINVAL; }
   for (int i = 0; i < p7x::OPT_COUNT; ++i)
     if (std::strcmp(name, names[i]) == 0) { p7x::g_debug_opt[i].store(value); return P7X_OK; }
@@ -696,7 +697,7 @@ void p7x_pipeline_cfg_default(p7x_pipeline_cfg *c)
   c->do_max = 0; c->do_biasfilter = 1; c->do_null2 = 1;
   c->seed = 42; c->mode = P7X_SEARCH_SEQS; c->host_threads = 0; c->host_envelopes = 0; c->host_regions = 0; c->host_ensembles = 0;
   c->long_targets = 0; c->strands = P7X_STRAND_BOTH; c->B1 = 100; c->B2 = 240; c->B3 = 1000;      // p7_pipeline_Create
-  c->block_length = 0x40000; c->window_length = -1; c->evalue_window_length = -1; c->oa_guard = 0.0f; c->lt_part = 0; c->lt_nparts = 1;
+  c->block_length = 0x40000; c->window_length = -1; c->evalue_window_length = -1; c->oa_guard = 4e-6f; c->ens_guard = 2.5e-7f; c->lt_part = 0; c->lt_nparts = 1;
   c->f3_guard = 4e-3f;
   c->lt_resident_key = 0;
 }

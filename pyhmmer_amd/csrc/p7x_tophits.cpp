@@ -508,6 +508,7 @@ int host_finish_batch(const p7x_pipeline_cfg &cfg_in, const std::vector<FinishIt
     p7x_tophits &th = *ths[(size_t) q_of[(size_t) f]];
     th.oa_redone += dds[(size_t) f].nneartie;
     for (int b = 0; b < 8; ++b) th.oa_why[b] += dds[(size_t) f].neartie_why[b];
+    th.ens_device += dds[(size_t) f].nens_device; th.ens_redone += dds[(size_t) f].nens_redone;
   }
   host_prof_dump();
   if (failed.load() != 0) { set_error("domain definition workflow failure"); return failed.load(); }
@@ -1087,6 +1088,14 @@ int p7x_tophits_get_guard_counts(const p7x_tophits *th, int64_t *f3_dropped, int
   if (f3_dropped) *f3_dropped = (int64_t) th->guard_dropped.size();
   if (oa_redone) *oa_redone = th->oa_redone;
   if (oa_why) for (int b = 0; b < 8; ++b) oa_why[b] = th->oa_why[b];
+  return P7X_OK;
+}
+
+int p7x_tophits_get_ensemble_counts(const p7x_tophits *th, int64_t *sampled_on_device, int64_t *redone_by_host)
+{
+  if (!th) return P7X_EINVAL;
+  if (sampled_on_device) *sampled_on_device = th->ens_device;
+  if (redone_by_host) *redone_by_host = th->ens_redone;
   return P7X_OK;
 }
 

@@ -1677,7 +1677,9 @@ class TopHits:
         list, device envelopes the optimal-accuracy near-tie guard had the host twin repeat."""
         a, b, why = C.c_int64(0), C.c_int64(0), (C.c_int64 * 8)()
         _lib.lib().p7x_tophits_get_guard_counts(self._handle, C.byref(a), C.byref(b), why)
-        return {"f3_dropped": int(a.value), "oa_redone": int(b.value),
+        e0, e1 = C.c_int64(0), C.c_int64(0)
+        _lib.lib().p7x_tophits_get_ensemble_counts(self._handle, C.byref(e0), C.byref(e1))
+        return {"f3_dropped": int(a.value), "oa_redone": int(b.value), "ens_device": int(e0.value), "ens_redone": int(e1.value),
                 "oa_why": dict(zip(("match", "insert", "delete", "c_from_e", "j_from_e", "end_cell", "begin", "pp_digit"), map(int, why)))}
 
     @property
@@ -1947,7 +1949,7 @@ class Pipeline:
                  F3: float = 1e-5, E: float = 10.0, T=None, domE: float = 10.0, domT=None, incE: float = 0.01,
                  incT=None, incdomE: float = 0.01, incdomT=None, bit_cutoffs: Optional[str] = None,
                  device: int = 0, host_threads: int = 0, host_envelopes: bool = False, host_regions: bool = False,
-                 oa_guard: Optional[float] = None, host_ensembles: bool = False):
+                 oa_guard: Optional[float] = None, host_ensembles: bool = False, ens_guard: Optional[float] = None):
         self.alphabet = alphabet
         if background is None:
             self.background = Background(alphabet)
@@ -1975,6 +1977,7 @@ class Pipeline:
         self.host_regions = bool(host_regions)
         self.host_ensembles = bool(host_ensembles)      # True: the stochastic traceback ensembles stay on the host workers
         self.oa_guard = oa_guard          # None: the library's default (p7x_pipeline_cfg.oa_guard)
+        self.ens_guard = ens_guard        # None: the library's default (p7x_pipeline_cfg.ens_guard)
         self._mode = _P7X_SEARCH_SEQS
         self._db_cache = None           # (id(block), block version, n, device) -> SequenceDatabase
 
@@ -2006,6 +2009,8 @@ class Pipeline:
         c.host_ensembles = int(self.host_ensembles)
         if self.oa_guard is not None:
             c.oa_guard = float(self.oa_guard)
+        if getattr(self, "ens_guard", None) is not None:
+            c.ens_guard = float(self.ens_guard)
         c.mode = int(self._mode)
         return c
 

@@ -19,6 +19,17 @@ from pyhmmer_amd import easel
 pytestmark = pytest.mark.gpu
 
 
+@pytest.fixture(autouse=True, scope="module")
+def _host_twin_in_the_device_order():
+    """This module validates the KERNELS against the host twin of the same arithmetic: option "host_order" = 1 makes the host
+    code sum in the device's lane-chunk order (the product's default is upstream's striped order, which the device reaches
+    through its near-tie guards: tests/test_gpu_oracle_domains.py)."""
+    from pyhmmer_amd import _lib
+    _lib.set_debug_option("host_order", 1)
+    yield
+    _lib.set_debug_option("host_order", -1)
+
+
 def _same_ensemble(db, om, target, start, end, seed=42):
     sd, dd, nd = db.ensemble(om, target, start, end, seed=seed, device=True)
     sh, dh, nh = db.ensemble(om, target, start, end, seed=seed, device=False)

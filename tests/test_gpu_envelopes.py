@@ -15,6 +15,17 @@ from test_gpu_filters import _model_block
 
 pytestmark = pytest.mark.gpu
 
+
+@pytest.fixture(autouse=True, scope="module")
+def _host_twin_in_the_device_order():
+    """This module validates the KERNELS against the host twin of the same arithmetic: option "host_order" = 1 makes the host
+    code sum in the device's lane-chunk order (the product's default is upstream's striped order, which the device reaches
+    through its near-tie guards: tests/test_gpu_oracle_domains.py)."""
+    from pyhmmer_amd import _lib
+    _lib.set_debug_option("host_order", 1)
+    yield
+    _lib.set_debug_option("host_order", -1)
+
 ENV_TOL_BITS = 5e-3
 ENV_TOL_REL_LONG = 5e-5  # models of thousands of nodes (scores and null2 corrections of thousands / hundreds of bits, each a float32
                          # sum over thousands of terms): relative, on top of ENV_TOL_BITS
@@ -74,12 +85,12 @@ def test_device_envelopes_on_planted_workload():
     db = plan7.SequenceDatabase.from_packed(hmm.alphabet, flat, off, ln)
     nhits, ndom = _compare(hmm, db)
     assert nhits >= 900 and ndom >= nhits
-    # the comparison above ran without the near-tie guard (the default since the host twin sums in the device's order) ...
-    hits = plan7.Pipeline(hmm.alphabet).search_hmm(hmm, db)
+    # without the near-tie guard nothing is repeated ...
+    hits = plan7.Pipeline(hmm.alphabet, oa_guard=0.0).search_hmm(hmm, db)
     assert hits.guard_counts["oa_redone"] == 0
-    # ... which still exists as a diagnostic: it flags a small fraction of the envelopes and has the host twin repeat them,
-    # to the same result
-    guarded = plan7.Pipeline(hmm.alphabet, oa_guard=4e-6).search_hmm(hmm, db)
+    # ... with it (the default: 4e-6) a small fraction of the envelopes is flagged and repeated by the host code -- here, with
+    # the twin in the device's order, to the same result
+    guarded = plan7.Pipeline(hmm.alphabet).search_hmm(hmm, db)
     redone = guarded.guard_counts["oa_redone"]
     assert 0 < redone <= ndom // 20, (redone, ndom)
     assert _records(guarded) == _records(hits)

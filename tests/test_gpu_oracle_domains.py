@@ -2,11 +2,13 @@
 with its defaults -- not against the product's host twin (tests/test_gpu_envelopes.py, test_gpu_ensembles.py do that; VERDICT
 r04 item 3).  Reference: p7_domaindef_ByPosteriorHeuristics (include/libhmmer/p7_domaindef.pxd:23-72), SURVEY.md row a13.
 
-The oracle sums in node order, the device in its lane chunks: a decision that falls on a tie of the two orders may differ
-(an alignment end moved by one residue; in an ensemble region a sampled traceback that takes the other branch, after which
-the region's later samples differ).  Stated tolerances: coordinates of single-domain regions identical in >= 99.5 % of the
-envelopes; ensemble regions identical in >= 90 % of the targets that have one; scores and biases within 2e-3 bit where the
-coordinates agree (p7_FLogsum's table has steps of 1e-3 nat)."""
+The oracle sums every Forward / Backward / null2 float in upstream's striped order (oracle/p7_oracle_dd.c).  The device sums in
+its lane chunks and FLAGS what that order cannot be trusted with -- an optimal-accuracy choice on the trace within
+cfg.oa_guard of its runner-up, a sampled traceback whose deviate lies within cfg.ens_guard of a threshold -- and the host
+stage repeats exactly those envelopes and regions with the same sums in upstream's order (p7x_domaindef.cpp,
+forward_full_upstream).  Required: EVERY coordinate of EVERY domain identical (envelope, alignment, model), the same
+(nregions, nclustered, noverlaps, nenvelopes), scores and biases within 2e-3 bit (the unflagged envelopes keep the device's
+sums; p7_FLogsum's table has steps of 1e-3 nat)."""
 import numpy as np
 import pytest
 
@@ -32,6 +34,7 @@ def _compare(oracle, hmm, hits, sequence_of, bg):
                 stats["single_env"] += 1
                 if o != t:
                     stats["single_diff"] += 1
+                    stats.setdefault("diffs", []).append((h.name, o, t))
                     continue
                 assert abs(d.score - e[9]) <= 2e-3 and abs(d.bias - e[10]) <= 2e-3, (h.name, d.score, e[9], d.bias, e[10])
                 assert abs(d.envelope_score * np.log(2.0) - e[6]) <= 2e-3 * max(1.0, abs(e[6]) / 100.0)
@@ -39,6 +42,8 @@ def _compare(oracle, hmm, hits, sequence_of, bg):
             assert (h.nclustered, h.noverlaps, h.nenvelopes) == (0, 0, counts[1]), h.name
         else:
             stats["ens_targets"] += 1
+            if ours != theirs:
+                stats.setdefault("diffs", []).append((h.name, ours, theirs))
             if ours == theirs:
                 stats["ens_same"] += 1
                 assert (h.nregions, h.nclustered, h.noverlaps, h.nenvelopes) == (counts[0], counts[2], counts[4], counts[1]), h.name
@@ -60,8 +65,9 @@ def test_headline_workload_domains_against_the_oracle(oracle):
     assert len(hits) >= 1000
     st = _compare(oracle, hmm, hits, lambda h: np.asarray(flat[off[h.seqidx]:off[h.seqidx] + ln[h.seqidx]], dtype=np.uint8), bg)
     assert st["hits"] >= 1000 and st["single_env"] >= 900, st
-    assert st["single_diff"] <= max(1, st["single_env"] // 200), st
-    assert st["ens_targets"] == 0 or st["ens_same"] >= 0.9 * st["ens_targets"], st
+    assert st["single_diff"] == 0 and st["ens_same"] == st["ens_targets"], st
+    g = hits.guard_counts
+    assert 0 < g["oa_redone"] <= st["single_env"] // 10, g          # the guard works, and on a small fraction
 
 
 @pytest.mark.parametrize("model", ["PF02826", "KR", "LuxC"])
@@ -75,5 +81,6 @@ def test_multi_domain_targets_against_the_oracle(oracle, model):
     by_name = {s.name: s for s in block}
     st = _compare(oracle, hmm, hits, lambda h: np.asarray(by_name[h.name].sequence, dtype=np.uint8), bg)
     assert st["hits"] >= 150 and st["ens_targets"] >= 10, st
-    assert st["single_diff"] <= max(1, st["single_env"] // 200), st
-    assert st["ens_same"] >= 0.9 * st["ens_targets"], st
+    assert st["single_diff"] == 0 and st["ens_same"] == st["ens_targets"], st
+    g = hits.guard_counts
+    assert g["ens_device"] >= 5 and g["ens_redone"] <= max(3, (g["ens_device"] + g["ens_redone"]) // 2), g

@@ -19,7 +19,7 @@ def test_abi_exports_every_declared_symbol(libp7x):
     for name in sorted(declared):
         assert hasattr(raw, name), f"libp7x.so does not export {name}"
     assert declared == set(_lib.declared_symbols()), declared ^ set(_lib.declared_symbols())
-    assert libp7x.p7x_abi_version() == 7
+    assert libp7x.p7x_abi_version() == 8
 
 
 @pytest.mark.parametrize("name", ["PF02826", "Thioesterase", "RREFam"])

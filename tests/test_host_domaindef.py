@@ -189,7 +189,7 @@ def test_host_tophits_api(models, oracle, proteome):
     # ... and a blob written by another version of the library is rejected, not mis-parsed (the layout follows the ABI's
     # configuration record: the ABI version and the record's size travel behind the magic)
     blob = bytearray(hits.to_bytes())
-    assert int.from_bytes(blob[4:8], "little") == 7
+    assert int.from_bytes(blob[4:8], "little") == 8
     blob[4:8] = (6).to_bytes(4, "little")
     with pytest.raises(ValueError, match="another library version"):
         plan7.TopHits.from_bytes(bytes(blob), None)
