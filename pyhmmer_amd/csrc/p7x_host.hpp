@@ -146,7 +146,7 @@ struct FinishItem {
                                                       // nullptr: not known, the host stage checks every survivor itself)
   const float *fwd_xmx = nullptr, *bck_xmx = nullptr; const int64_t *xmx_off = nullptr;   // parser rows (when regions == nullptr)
   uint64_t counts[4] = { 0, 0, 0, 0 };                // n_past_{msv,bias,vit,fwd}
-  const double *ms = nullptr;
+  const double *ms = nullptr; int nms = 8;            // 0-7 as TopHits.timings_ms; 8-10 (nms >= 11): queries of the batch, lanes and nodes of its largest MSV launch
   const DeviceRegions *regions = nullptr;             // region lists found on the device
   bool device_envelopes = false;                      // single-domain envelopes go to the scorer
 };
@@ -224,7 +224,8 @@ struct p7x_tophits {
   std::string qname, qacc, qdesc;     // the query (model) the alignment displays refer to
   bool q_has_acc = false, q_has_desc = false;
   int M = 0;
-  double ms[16]{};            // see TopHits.timings_ms (plan7.py) for the slots
+  static constexpr int kMs = 20;
+  double ms[kMs]{};           // see TopHits.timings_ms (plan7.py) for the slots
   bool sorted_by_key = false;
   bool scan_collected = false;        // built by p7x_scan_collect(): one query sequence, hits are models
   std::vector<uint8_t> stage;         // scan mode, per-model result: last filter passed by each target (not serialised)

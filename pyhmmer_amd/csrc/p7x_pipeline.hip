@@ -542,7 +542,8 @@ struct Workspace {
   hipStream_t side[kSide]{};
   hipEvent_t ev_fork = nullptr, ev_join[kSide]{};
   static constexpr int kTierRuns = 8;      // MSV tier launches of a batch (p7x_msv.hip: five tiers; runs of lanes that share one)
-  hipEvent_t ev_tier[kTierRuns]{};
+  hipEvent_t ev_tier[kTierRuns]{}, ev_tier0[kTierRuns]{};     // end / begin of every tier launch (timed: the bench's roofline is the largest one's)
+  int ntier_runs = 0, tier_lanes[kTierRuns]{}; int64_t tier_nodes[kTierRuns]{};     // of the cascade in flight
   int *h_counts = nullptr; size_t h_counts_bytes = 0;   // pinned mirror of counters
   // results of the Forward survivors of all lanes, packed by pack_survivors_kernel for one copy to the host
   unsigned char *pack_dev = nullptr; size_t pack_dev_bytes = 0;      // slab of the context's pool
@@ -567,6 +568,7 @@ struct Workspace {
     if (ev_fork) (void) hipEventDestroy(ev_fork);
     for (auto &e : ev_join) if (e) (void) hipEventDestroy(e);
     for (auto &e : ev_tier) if (e) (void) hipEventDestroy(e);
+    for (auto &e : ev_tier0) if (e) (void) hipEventDestroy(e);
     pinned_release(h_counts, h_counts_bytes);
     pinned_release(pack_host, pack_host_bytes); (void) hipFree(pack_dev);
     pinned_release(h_args, h_args_bytes);
@@ -657,7 +659,8 @@ static int get_workspace(int device, int64_t nslots, int nlanes, Workspace **out
     if (cst != P7X_OK) return cst;
     P7X_HIP(hipEventCreateWithFlags(&w->ev_fork, hipEventDisableTiming));
     for (auto &e : w->ev_join) P7X_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-    for (auto &e : w->ev_tier) P7X_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    for (auto &e : w->ev_tier) P7X_HIP(hipEventCreate(&e));
+    for (auto &e : w->ev_tier0) P7X_HIP(hipEventCreate(&e));
   }
   w->busy = true;
   *out = w.get();
@@ -899,7 +902,7 @@ struct CascadeOut {
   bool have_xmx = false;
   std::vector<uint8_t> stage;             // scan mode: last filter passed, per target (caller order)
   int counts[16]{};
-  double ms[8]{};
+  double ms[12]{};                        // 0-5 stage events, 6 wall, 7 the MSV launch, 8 queries of the batch, 9 / 10 lanes and nodes of that launch
 };
 
 // One batched cascade in flight: the enqueue half queues every kernel of stage 1 for all lanes on the workspace's
@@ -1327,6 +1330,7 @@ static int cascade_enqueue(CascadeRun &r)
   if ((st = upload_args(ws, 0, nq, s)) != P7X_OK) return st;
   tick("upload");
   P7X_HIP(hipMemsetAsync(ws->counters, 0, ws->counters_bytes(), s));      // lane counters and the arena cursor
+  ws->ntier_runs = 0;
   if (classes.size() == 1) {
     const bool fills_device = (db->nslots / 64) * (int64_t) nq >= (int64_t) ctx->num_cu * 8;
     if ((st = class_cascade(r, classes[0], s, true, fills_device)) != P7X_OK) return st;
@@ -1358,9 +1362,13 @@ static int cascade_enqueue(CascadeRun &r)
         const int turn = (kStreamsAll - 1 - run) % kStreamsAll;       // from the far end: the longest classes' chains are dealt from stream 0
         hipStream_t ts = turn == 0 ? s : ws->side[std::min(turn, nside) - 1];
         const LaneClass &k = classes[a];
+        P7X_HIP(hipEventRecord(ws->ev_tier0[run], ts));
         if ((st = msv_tier_launch(msv_tier(r.lm[k.first].dp->msvR, r.lm[k.first].dp->msvK), lane_run(ws, &LaneArgs::msv, first, n), ctx->num_cu, ts)) != P7X_OK) return st;
         P7X_HIP(hipEventRecord(ws->ev_tier[run], ts));
+        ws->tier_lanes[run] = n; ws->tier_nodes[run] = 0;
+        for (int l = first; l < first + n; ++l) ws->tier_nodes[run] += r.lm[l].om->p.M;
       }
+      ws->ntier_runs = nruns;
     }
     // a small block: stage by stage (option stage_merge: 0 never, 1 always, unset: blocks of up to 256 groups)
     const int sm = debug_opt(OPT_STAGE_MERGE);
@@ -1619,9 +1627,18 @@ static int cascade_collect(CascadeRun &r, std::vector<CascadeOut> &outs)
     out.near.assign(out.fin_slots.size(), 0);
     for (size_t i = 0; i < out.fin_slots.size(); ++i) out.near[i] = std::binary_search(slots.begin(), slots.end(), out.fin_slots[i]) ? 1 : 0;
   }
-  double ms[8]{};
+  double ms[12]{};
   for (int i = 0; i < 6; ++i) { float t = 0; (void) hipEventElapsedTime(&t, ws->ev[i], ws->ev[i + 1]); ms[i] = t; }
   { float t = 0; (void) hipEventElapsedTime(&t, ws->ev[0], ws->ev[7]); ms[7] = t; }
+  ms[8] = nq; ms[9] = nq; ms[10] = 0.0;
+  for (int l = 0; l < nq; ++l) ms[10] += r.lm[l].om->p.M;
+  if (ws->ntier_runs > 0) {
+    // a batch of several classes: slot 7 is the batch's LARGEST fast-MSV launch (a tier of register tiles, p7x_msv.hip), by its own events
+    int big = 0;
+    for (int k = 1; k < ws->ntier_runs; ++k) if (ws->tier_nodes[k] > ws->tier_nodes[big]) big = k;
+    float t = 0;
+    if (hipEventElapsedTime(&t, ws->ev_tier0[big], ws->ev_tier[big]) == hipSuccess) { ms[7] = t; ms[9] = ws->tier_lanes[big]; ms[10] = (double) ws->tier_nodes[big]; }
+  }
   if (debug) {
     const auto tc2 = std::chrono::steady_clock::now();
     long long nfin_tot = 0; for (const CascadeOut &o : outs) nfin_tot += o.counts[4];
@@ -1971,7 +1988,7 @@ int p7x_search_batch_finish(p7x_pending *pd, const char *const *names, const cha
     it.near = &co.near;
     it.fwd_xmx = co.fwd_xmx.data(); it.bck_xmx = co.bck_xmx.data(); it.xmx_off = co.xmx_off.data();
     it.counts[0] = (uint64_t) co.counts[1]; it.counts[1] = (uint64_t) co.counts[8]; it.counts[2] = (uint64_t) co.counts[3]; it.counts[3] = (uint64_t) co.counts[4];
-    it.ms = co.ms;
+    it.ms = co.ms; it.nms = 12;
     if (!co.have_xmx && !targets[q].empty()) { dr[q].n = co.reg_n.data(); dr[q].regs = co.regs.data(); dr[q].nexpected = co.nexpected.data(); dr[q].cap = kRegionCap;
       dr[q].start = co.reg_start.empty() ? nullptr : co.reg_start.data(); it.regions = &dr[q]; }
     it.device_envelopes = !pd->cfg.host_envelopes && !targets[q].empty();

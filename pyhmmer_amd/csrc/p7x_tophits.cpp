@@ -295,6 +295,7 @@ int host_finish_batch(const p7x_pipeline_cfg &cfg_in, const std::vector<FinishIt
     th->ctr.n_past_msv = it.counts[0]; th->ctr.n_past_bias = it.counts[1];
     th->ctr.n_past_vit = it.counts[2]; th->ctr.n_past_fwd = it.counts[3];
     if (it.ms) for (int i = 0; i < 8; ++i) th->ms[i] = it.ms[i];
+    if (it.ms && it.nms >= 11) { th->ms[15] = it.ms[8]; th->ms[16] = it.ms[9]; th->ms[17] = it.ms[10]; }
     ths[(size_t) q] = std::move(th);
     first[(size_t) q + 1] = first[(size_t) q] + (int) it.targets->size();
   }
@@ -888,7 +889,7 @@ static void merge_append(p7x_tophits *dst, p7x_tophits *src, bool move_hits)
   dst->ctr.n_past_msv += src->ctr.n_past_msv; dst->ctr.n_past_bias += src->ctr.n_past_bias;
   dst->ctr.n_past_vit += src->ctr.n_past_vit; dst->ctr.n_past_fwd += src->ctr.n_past_fwd;
   if (dst->cfg.Z_setby == P7X_ZSETBY_NTARGETS) dst->cfg.Z += src->cfg.Z;
-  for (int i = 0; i < 16; ++i) dst->ms[i] += src->ms[i];
+  for (int i = 0; i < p7x_tophits::kMs; ++i) dst->ms[i] += src->ms[i];
 }
 static void merge_finalize(p7x_tophits *dst)
 {
@@ -937,7 +938,7 @@ int p7x_tophits_merge_longtargets(p7x_tophits **parts, size_t nparts, p7x_tophit
     dst->ctr.n_past_vit += src->ctr.n_past_vit; dst->ctr.n_past_fwd += src->ctr.n_past_fwd;
     dst->ctr.pos_past_msv += src->ctr.pos_past_msv; dst->ctr.pos_past_bias += src->ctr.pos_past_bias;
     dst->ctr.pos_past_vit += src->ctr.pos_past_vit; dst->ctr.pos_past_fwd += src->ctr.pos_past_fwd;
-    for (int i = 0; i < 16; ++i) dst->ms[i] = std::max(dst->ms[i], src->ms[i]);      // the parts ran side by side
+    for (int i = 0; i < p7x_tophits::kMs; ++i) dst->ms[i] = std::max(dst->ms[i], src->ms[i]);      // the parts ran side by side
   }
   dst->cfg.lt_part = 0; dst->cfg.lt_nparts = 1;
   longtarget_finalize(dst.get(), dst->lt_evalue_window, longtarget_res_count(dst->cfg, dst->ctr.nres));
@@ -1026,7 +1027,7 @@ int64_t p7x_tophits_serialize(const p7x_tophits *th, void *buf, size_t cap)
   uint32_t abi = (uint32_t) P7X_ABI_VERSION, cfg_bytes = (uint32_t) sizeof(p7x_pipeline_cfg); w.pod(abi); w.pod(cfg_bytes);
   w.pod(th->cfg); w.pod(th->ctr);
   w.str(th->qname); w.str(th->qacc); w.str(th->qdesc); w.pod(th->q_has_acc); w.pod(th->q_has_desc); w.pod(th->M); w.pod(th->scan_collected);
-  for (int i = 0; i < 16; ++i) w.pod(th->ms[i]);
+  for (int i = 0; i < p7x_tophits::kMs; ++i) w.pod(th->ms[i]);
   const uint64_t n = th->hits.size(); w.pod(n);
   for (const Hit &hc : th->hits) {
     Hit &h = const_cast<Hit &>(hc);
@@ -1055,7 +1056,7 @@ p7x_tophits *p7x_tophits_deserialize(const void *buf, size_t n)
   auto th = std::make_unique<p7x_tophits>();
   r.pod(th->cfg); r.pod(th->ctr);
   r.str(th->qname); r.str(th->qacc); r.str(th->qdesc); r.pod(th->q_has_acc); r.pod(th->q_has_desc); r.pod(th->M); r.pod(th->scan_collected);
-  for (int i = 0; i < 16; ++i) r.pod(th->ms[i]);
+  for (int i = 0; i < p7x_tophits::kMs; ++i) r.pod(th->ms[i]);
   uint64_t nh = 0; r.pod(nh);
   if (!r.ok) { set_error("truncated serialised TopHits"); return nullptr; }
   // a hit takes at least its fixed fields (three length words, the scores and counts): a count the buffer cannot hold
@@ -1102,7 +1103,7 @@ int p7x_tophits_get_ensemble_counts(const p7x_tophits *th, int64_t *sampled_on_d
 int p7x_tophits_get_timings(const p7x_tophits *th, double *ms, int n)
 {
   if (!th || !ms) return P7X_EINVAL;
-  for (int i = 0; i < n && i < 16; ++i) ms[i] = th->ms[i];
+  for (int i = 0; i < n && i < p7x_tophits::kMs; ++i) ms[i] = th->ms[i];
   return P7X_OK;
 }
 

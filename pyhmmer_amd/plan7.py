@@ -1689,10 +1689,12 @@ class TopHits:
         and ``host_stage_busy`` is the rest -- what the host itself did (region bookkeeping, clustering, alignments, hit
         lists).  ``host_multi``: the host's own share of the multi-domain regions (clustering; sampling too when the ensembles
         stay on the host).  ``envelopes``: wall from the first launch of the stage to the last result."""
-        buf = (C.c_double * 16)()
-        _lib.lib().p7x_tophits_get_timings(self._handle, buf, 16)
+        buf = (C.c_double * 20)()
+        _lib.lib().p7x_tophits_get_timings(self._handle, buf, 20)
         return dict(zip(("msv", "bias", "viterbi", "forward", "fwd_rows", "host_domaindef", "total", "msv_kernel",
-                         "envelopes", "host_multi", "stage1", "stage2", "host_stage_busy", "ensemble_wait", "envelope_wait"), buf))
+                         "envelopes", "host_multi", "stage1", "stage2", "host_stage_busy", "ensemble_wait", "envelope_wait",
+                         # msv_kernel is the batch's largest fast-MSV launch by its own HIP events; what it covered:
+                         "batch_queries", "msv_launch_lanes", "msv_launch_nodes"), buf))
 
     @property
     def reported(self):
