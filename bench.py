@@ -1,18 +1,23 @@
 #!/usr/bin/env python
 """bench.py -- hmmsearch throughput of the MI355X-native p7_Pipeline path.
 
-Workload (BASELINE.json configs[1], SURVEY.md 8d "config 2"): ONE calibrated profile (fixture KR.hmm, M=262)
-against 1,000,000 synthetic 300-aa targets per GPU -- residues i.i.d. from the HMMER amino background,
-numpy default_rng(42 + rank), with 0.1 % planted positives emitted from the model -- through the whole
-pipeline: MSV -> bias -> Viterbi -> Forward -> Backward on the device, domain definition + hit list on the host.
-A "step" is one complete search of the (HBM-resident) target database by the profile.
+The line's workload is the one BASELINE.json's metric is quoted on ("hmmsearch, Pfam-A vs proteome": configs[3], SURVEY.md 8d
+"config 4"): a Pfam-shaped library of 20,000 calibrated profiles (bench_workloads.py; Pfam-A itself is not available offline)
+against 500,000 Swiss-Prot-shaped synthetic targets, through hmmer.hmmsearch with the library's defaults: the whole pipeline
+(MSV -> bias -> Viterbi -> Forward -> Backward on the device, domain definition + hit lists on the host), targets sharded by
+residues over the GPUs, per-query TopHits merged on rank 0 inside the timed region.  A "step" is --pfam-profiles-per-step
+(1,000) consecutive library profiles searched against the resident target database; with the driver's --steps 20 the timed
+region is the whole library once.  Profiles' device images and the targets are resident in HBM before the clock starts.
 
-  python bench.py --gpus 1 --steps 5 --warmup 2
+  python bench.py --gpus 1 --steps 20 --warmup 5
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
-         bench.py --gpus N --steps K --warmup W            # one rank per GPU, weak scaling (fixed work per GPU)
+         bench.py --gpus N --steps K --warmup W            # one rank per GPU, strong scaling (the same 500,000 targets sharded)
 
-Rank 0 prints ONE JSON line.  `value` is whole-job GCUPS: sum over ranks of M * residues searched per step,
-divided by the max-over-ranks wall time per step (all-pairs M*L denominator, as the HMMER literature does).
+Rank 0 prints ONE JSON line.  `value` is whole-job GCUPS: sum over the profiles searched of M x residues of all targets,
+divided by the max-over-ranks wall time (all-pairs M*L denominator, as the HMMER literature does).  The other BASELINE configs
+are fields of the same line: `config1` (one profile x 1,000,000 targets: throughput of a stream of queries, and the latency of
+ONE query on an idle device), `scan` (hmmscan orientation, 4,000-protein block), `nhmmer` (250 Mbp chromosome).
+`--workload config1 | scan | nhmmer` prints that workload as the line instead.
 """
 import argparse
 import json
@@ -363,11 +368,13 @@ def build_library(args, local_rank):
 
 
 def run_pfam(args, rank, world, local_rank, dist, red_dev, torch, host_threads, lib):
-    """the first `--pfam-profiles` entries (default: all) of the synthetic 20k-profile library
-    against `--pfam-targets` Swiss-Prot-shaped targets, STRONG scaling: the targets are sharded by residues over the
-    ranks, every rank searches every profile against its shard, rank 0 gathers the per-rank hit lists and merges them per
-    query (one native call, p7x_tophits_merge_many) -- all inside the timed region.  Profiles (device images) and targets
-    are resident in HBM before the clock starts, like a pressed database and a loaded proteome."""
+    """the synthetic 20k-profile library against `--pfam-targets` Swiss-Prot-shaped targets, STRONG
+    scaling: the targets are sharded by residues over the ranks, every rank searches every profile of a step against its shard,
+    rank 0 gathers the per-rank hit lists and merges them per query (one native call, p7x_tophits_merge_many) -- all inside
+    the timed region.  Profiles (device images) and targets are resident in HBM before the clock starts, like a pressed
+    database and a loaded proteome.  Step s searches profiles [s * pps, (s + 1) * pps) of the library (cyclically); the
+    `--warmup` steps are the ones before step 0, the timed region is ONE hmmer.hmmsearch call over the `--steps` steps'
+    profiles, bracketed by barrier + synchronize."""
     import bench_workloads as bw
     from pyhmmer_amd import hmmer, plan7
     hmms, lib_lengths, templates, bg, oms = lib["hmms"], lib["lengths"], lib["templates"], lib["bg"], lib["oms"]
@@ -387,12 +394,17 @@ def run_pfam(args, rank, world, local_rank, dist, red_dev, torch, host_threads, 
             dist.barrier()
         torch.cuda.synchronize()
 
-    nwarm = min(len(oms), 4 * max(1, args.pfam_batch or 64))
-    search(oms)                     # device images of every profile become resident; pools, clocks and workers settle
-    search(oms[:nwarm])
+    pps = max(1, min(args.pfam_profiles_per_step, len(oms)))
+    step_profiles = lambda first, n: [(first * pps + i) % len(oms) for i in range(n * pps)]
+    timed_idx = step_profiles(0, args.steps)
+    t0 = time.perf_counter()
+    search(oms)                     # untimed: device images of every profile become resident; pools, clocks and workers settle
+    t_resident = time.perf_counter() - t0
+    if args.warmup > 0:
+        search([oms[e] for e in step_profiles(-args.warmup, args.warmup)])
     barrier()
     t0 = time.perf_counter()
-    hits = search(oms)
+    hits = search([oms[e] for e in timed_idx])
     t_search = time.perf_counter() - t0
     merged = hits
     t_ser = t_gather = t_merge = 0.0
@@ -417,33 +429,63 @@ def run_pfam(args, rank, world, local_rank, dist, red_dev, torch, host_threads, 
         t_max = float(b.item())
     if rank != 0:
         return None
-    nodes = float(sum(h.M for h in hmms))
+    nodes = float(sum(hmms[e].M for e in timed_idx))
+    nprof = len(timed_idx)
     residues = float(lengths.sum())
     nhits = sum(len(h) for h in merged)
     nrep = sum(len(h.reported) for h in merged)
     sc = {k: sum(h.stage_counts[k] for h in hits) for k in ("msv", "bias", "vit", "fwd")}
     out = {
-        "workload": f"configs[3]-shaped: the first {len(hmms)} profiles of the synthetic {args.pfam_library}-entry library (14 fixture "
-                    f"models resampled to M ~ lognormal(median 120), calibrated on the device) x {args.pfam_targets} targets "
-                    f"(L ~ lognormal(5.65, 0.65) in [30, 5000], {nplanted} with a planted domain), sharded by residues over {world} GPU(s), "
-                    "per-query TopHits gathered and merged on rank 0 (p7x_tophits_merge_many) inside the timed region",
+        "workload": f"configs[3]: hmmsearch of a Pfam-shaped library ({len(hmms)} calibrated profiles: 14 fixture models resampled to "
+                    f"M ~ lognormal(median 120) in [20, 2000], calibrated on the device; Pfam-A itself is not available offline) vs "
+                    f"{args.pfam_targets} Swiss-Prot-shaped synthetic targets (L ~ lognormal(5.65, 0.65) in [30, 5000], {nplanted} with a "
+                    f"planted domain), sharded by residues over {world} GPU(s), hmmer.hmmsearch defaults, per-query TopHits gathered and "
+                    f"merged on rank 0 (p7x_tophits_merge_many) inside the timed region; a step = {pps} consecutive library profiles "
+                    f"x all targets, {args.steps} steps = {nprof} profiles",
         "value": round(nodes * residues / t_max / 1e9, 2), "unit": "GCUPS", "scaling": "strong",
-        "profiles": len(hmms), "targets": int(args.pfam_targets), "mean_M": round(nodes / len(hmms), 1), "mean_L": round(residues / len(lengths), 1),
-        "seconds": round(t_max, 4), "ms_per_profile": round(1e3 * t_max / len(hmms), 4), "profiles_per_s": round(len(hmms) / t_max, 1),
+        "profiles": nprof, "profiles_per_step": pps, "library": len(hmms), "targets": int(args.pfam_targets),
+        "mean_M": round(nodes / nprof, 1), "mean_L": round(residues / len(lengths), 1),
+        "seconds": round(t_max, 4), "ms_per_profile": round(1e3 * t_max / nprof, 4), "profiles_per_s": round(nprof / t_max, 1),
+        "seqs_per_s": round(float(nprof) * len(lengths) / t_max, 1),
+        "untimed_residency_pass_seconds": round(t_resident, 2),
         "search_seconds_rank0": round(t_search, 4),
         "merge_seconds_rank0": {"serialise": round(t_ser, 4), "gather": round(t_gather, 4), "merge_many": round(t_merge, 4)},
         "batch": args.pfam_batch, **pipe_effective(args.pfam_depth, args.feeders, args.pfam_finishers),
         "hits": nhits, "reported": nrep, "stage_counts_rank0": sc,
-        "guards_rank0": {"f3_dropped": sum(h.guard_counts["f3_dropped"] for h in hits), "oa_redone": sum(h.guard_counts["oa_redone"] for h in hits)},
+        "guards_rank0": {k: sum(h.guard_counts[k] for h in hits) for k in ("f3_dropped", "oa_redone", "ens_device", "ens_redone")},
         # per-BATCH times (every query of a batch reports its batch's): device stages by HIP events of the first class
         "batch_ms_mean_rank0": {k: round(sum(h.timings_ms[k] for h in hits) / len(hits), 3) for k in hits[0].timings_ms},
         "setup_seconds": {"library": round(lib["seconds"], 2), "targets": round(t_tgt, 2)},
     }
-    out["roofline"] = valu_roofline(nodes * residues, t_max, MSV_OPS_PER_CELL, "p7x::msv_fast_kernel<R, K, half> over the library's model lengths")
-    # HBM view: every query streams its shard's residues once per stage-1 launch and writes 16 B per comparison
-    alg_bytes = float(len(hmms)) * (residues + 2.0 * len(lengths) + 16.0 * len(lengths)) + nodes / 16.0 * 29 * 16
-    out["roofline"]["hbm"] = {"algorithmic_bytes": int(alg_bytes), "achieved_gbs": round(alg_bytes / t_max / 1e9, 2), "peak_gbs": HBM_PEAK_GBS,
-                              "frac": round(alg_bytes / t_max / 1e9 / HBM_PEAK_GBS, 6)}
+    # ---- roofline of the dominant kernel: the fast MSV launch (one launch per tier of register tiles and batch, p7x_msv.hip
+    # msv_tier_kernel<T>; a batch's LARGEST launch is timed by HIP events on the stream it runs on and reported by every
+    # query of the batch with the lanes (queries) and nodes it covered).  Algorithmic bytes per launch: every
+    # lane streams this rank's residues (L + 2 bytes per comparison incl. the sentinels) and writes 16 B per comparison,
+    # plus its MSV table once (29 x 16 x Q16 bytes).
+    shard_res, shard_n = float(lengths[lo:hi].sum()), float(hi - lo)
+    w = np.array([1.0 / max(1.0, h.timings_ms["batch_queries"]) for h in hits])
+    t_l = np.array([h.timings_ms["msv_kernel"] for h in hits])
+    lanes = np.array([h.timings_ms["msv_launch_lanes"] for h in hits])
+    lnodes = np.array([h.timings_ms["msv_launch_nodes"] for h in hits])
+    nlaunch = float(w.sum())
+    sum_ms = float((w * t_l).sum())
+    sum_bytes = float((w * (lanes * (shard_res + 2.0 * shard_n + 16.0 * shard_n) + lnodes / 16.0 * 29 * 16)).sum())
+    sum_cells = float((w * lnodes).sum()) * shard_res
+    ach = sum_bytes / max(sum_ms * 1e-3, 1e-12) / 1e9
+    kcups = sum_cells / max(sum_ms * 1e-3, 1e-12)
+    out["roofline"] = {
+        "kernel": "p7x::msv_tier_kernel<T> (the fast lane-per-target MSV kernel of all lanes of a batch that share a tier of register tiles, p7x_msv.hip)",
+        "bound": "hbm", "achieved": round(ach, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 6),
+        "traffic": msv_traffic_bytes(f"pfam:{len(hmms)}x{args.pfam_targets}"),
+        "kernel_ms": round(sum_ms / max(nlaunch, 1e-9), 4), "launches_timed": round(nlaunch, 1),
+        "algorithmic_bytes": int(sum_bytes / max(nlaunch, 1e-9)), "queries_per_launch": round(float((w * lanes).sum()) / max(nlaunch, 1e-9), 2),
+        "note": "average over the timed region's batches of the batch's largest fast-MSV launch (HIP events on its stream); the MSV "
+                "working set (emission tables) lives in LDS, only residues stream from HBM (~1/M byte per cell): the binding roof "
+                "is VALU issue, reported in `valu`",
+        "valu": {"msv_gcups": round(kcups / 1e9, 1), "ops_per_cell": MSV_OPS_PER_CELL, "peak_gcups": round(VALU_LANE_OPS_PER_S / MSV_OPS_PER_CELL / 1e9, 1),
+                 "frac": round(kcups * MSV_OPS_PER_CELL / VALU_LANE_OPS_PER_S, 4),
+                 "whole_job": valu_roofline(nodes * residues, t_max, MSV_OPS_PER_CELL, "whole job against the scan kernel's issue roof")},
+    }
     del db
     if world == 1 and not args.no_cpu_baseline:
         step = max(1, len(hmms) // max(1, args.pfam_cpu_profiles))
@@ -452,15 +494,26 @@ def run_pfam(args, rank, world, local_rank, dist, red_dev, torch, host_threads, 
     return out
 
 
-def run_scan(args, rank, world, local_rank, dist, red_dev, torch, host_threads, lib):
+def run_scan(args, rank, world, local_rank, dist, red_dev, torch, host_threads, lib, which="synthetic"):
     """BASELINE configs[2], the hmmscan orientation: the same profile library (device images resident, like a pressed
-    database loaded into an OptimizedProfileBlock) against the 2,100-protein fixture proteome through hmmer.hmmscan
-    (one hit list per query SEQUENCE, Z = number of profiles).  N > 1: the profiles are dealt over the ranks
-    (shard the profiles when the targets are few), every rank scans the whole proteome with its share."""
+    database loaded into an OptimizedProfileBlock) against a block of query proteins through hmmer.hmmscan (one hit list per
+    query SEQUENCE, Z = number of profiles).  which = "synthetic": BASELINE's 4k-protein block (SURVEY.md 8d config 3:
+    4,000 targets, L ~ lognormal(5.65, 0.65) in [30, 5000], seed 43, half of them with a planted domain of a library
+    entry); "fixture": the 2,100-protein fixture proteome (a real proteome's length distribution; the figure of rounds
+    1-5).  N > 1: the profiles are dealt over the ranks (shard the profiles when the targets are few), every
+    rank scans the whole block with its share."""
+    import bench_workloads as bw
     from pyhmmer_amd import easel, hmmer, plan7
     hmms, bg, oms = lib["hmms"], lib["bg"], lib["oms"]
-    with easel.SequenceFile(ROOT / "tests" / "golden" / "seqs" / "938293.PRJEB85.HG003687.faa", digital=True, alphabet=hmms[0].alphabet) as sf:
-        proteome = sf.read_block()
+    if which == "fixture":
+        with easel.SequenceFile(ROOT / "tests" / "golden" / "seqs" / "938293.PRJEB85.HG003687.faa", digital=True, alphabet=hmms[0].alphabet) as sf:
+            proteome = sf.read_block()
+        what = f"the {len(proteome)}-protein fixture proteome"
+    else:
+        f4, o4, l4, np4 = bw.make_targets(args.scan_targets, len(hmms), lib["templates"], lib["lengths"], seed=43, planted_frac=0.5)
+        abc = hmms[0].alphabet
+        proteome = easel.DigitalSequenceBlock(abc, [easel.DigitalSequence(abc, name=f"syn{t:05d}", sequence=f4[o4[t]:o4[t] + l4[t]]) for t in range(len(l4))])
+        what = f"BASELINE's synthetic {len(proteome)}-protein block (L ~ lognormal(5.65, 0.65) in [30, 5000], seed 43, {np4} with a planted domain)"
     mine = oms[rank::world]
     block = plan7.OptimizedProfileBlock(hmms[0].alphabet, mine)
 
@@ -490,8 +543,8 @@ def run_scan(args, rank, world, local_rank, dist, red_dev, torch, host_threads, 
     nodes = float(sum(h.M for h in hmms))
     residues = float(proteome.total_length())
     out = {
-        "workload": f"configs[2]: hmmscan orientation, {len(hmms)} library profiles (device images resident) x the {len(proteome)}-protein "
-                    f"fixture proteome ({int(residues)} residues), hmmer.hmmscan defaults, profiles dealt over {world} GPU(s)",
+        "workload": f"configs[2]: hmmscan orientation, {len(hmms)} library profiles (device images resident) x {what} "
+                    f"({int(residues)} residues), hmmer.hmmscan defaults, profiles dealt over {world} GPU(s)",
         "value": round(nodes * residues / t_max / 1e9, 2), "unit": "GCUPS", "scaling": "strong",
         "profiles": len(hmms), "query_sequences": len(proteome), "seconds": round(t_max, 4),
         "ms_per_profile": round(1e3 * t_max / len(hmms), 5), "query_sequences_per_s": round(len(proteome) / t_max, 1),
@@ -572,7 +625,7 @@ def run_nhmmer(args, rank, world, local_rank, dist, red_dev, torch):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--nseq", type=int, default=1_000_000, help="targets per GPU")
     ap.add_argument("--seqlen", type=int, default=300)
@@ -595,23 +648,32 @@ def main():
                     help="headline workload through the API's own multi-device path: ONE process, hmmer.hmmsearch over this many devices "
                          "(a block of --nseq targets resident on each; P7X_BENCH_SHARE_DEVICE=1: all on this rank's device, a rehearsal) -- "
                          "next to the process-per-GPU path of --gpus N")
-    ap.add_argument("--workload", choices=("both", "config1", "pfam", "scan", "nhmmer"), default="both",
-                    help="config1: the headline (one profile x 1M targets per GPU); pfam / nhmmer: (a token headline and) that "
-                         "workload's field; both: headline + the `pfam` and `nhmmer` fields")
+    ap.add_argument("--workload", choices=("all", "config1", "pfam", "scan", "nhmmer"), default="all",
+                    help="all (default): the line is the pfam workload (BASELINE's metric config, configs[3]) with --steps / --warmup, "
+                         "and config1 / scan / nhmmer are fields; pfam / scan / nhmmer: only that workload; config1: the line is "
+                         "configs[1] (one profile x 1M targets per GPU, a step = --queries-per-step searches) with --steps / --warmup")
+    ap.add_argument("--pfam-profiles-per-step", type=int, default=1000, help="library profiles of one step of the pfam workload")
+    ap.add_argument("--config1-steps", type=int, default=4, help="steps of the configs[1] FIELD when it is not the line (32 queries each)")
+    ap.add_argument("--scan-targets", type=int, default=4000, help="query proteins of the scan workload's synthetic block (BASELINE: 4k)")
     ap.add_argument("--nhmmer-mbp", type=float, default=250.0, help="chromosome length per GPU")
     ap.add_argument("--nhmmer-searches", type=int, default=10, help="queries of the timed stream (hmmer.nhmmer)")
     ap.add_argument("--nhmmer-envelopes", type=int, default=0, help="A/B: 0 the library decides where envelopes are rescored, 1 host workers, 2 envelope kernel")
     ap.add_argument("--pfam-profiles", type=int, default=20000, help="library entries searched (the first ones of the 20k-entry library; default: all)")
     ap.add_argument("--pfam-cpu-profiles", type=int, default=40, help="cpu_baseline of the many-profile workloads: this many profiles, evenly spaced")
-    ap.add_argument("--pfam-cpu-targets", type=int, default=25_000, help="... against the first this many targets")
+    ap.add_argument("--pfam-cpu-targets", type=int, default=100_000, help="... against the first this many targets")
     ap.add_argument("--pfam-library", type=int, default=20000)
     ap.add_argument("--pfam-targets", type=int, default=500_000, help="targets in total (sharded over the GPUs)")
     ap.add_argument("--pfam-batch", type=int, default=0, help="queries per device batch (0: the library's choice)")
     ap.add_argument("--pfam-depth", type=int, default=None, help="A/B, many-profile workload (default: the library's own)")
     ap.add_argument("--pfam-finishers", type=int, default=None, help="A/B, many-profile workload (default: the library's own)")
     args = ap.parse_args()
-    if args.workload in ("pfam", "nhmmer"):          # development switch: the headline part shrinks to a token run
-        args.steps, args.warmup, args.spinup_max, args.no_cpu_baseline = min(args.steps, 5), 0, 1, True
+    line_steps, line_warmup = args.steps, args.warmup      # the driver's K and W belong to the line's workload
+    c1_cpu = not args.no_cpu_baseline
+    if args.workload != "config1":
+        # configs[1] is a field here: a short stream (its steady state shows within a few dozen queries) and no CPU leg of its own
+        args.steps, args.warmup, args.spinup_max, c1_cpu = max(1, args.config1_steps), 1, min(args.spinup_max, 4), False
+        if args.workload in ("pfam", "scan", "nhmmer"):    # development switch: configs[1] shrinks to a token run
+            args.steps, args.warmup, args.spinup_max = 1, 0, 1
 
     import torch
     rank = int(os.environ.get("RANK", "0"))
@@ -727,9 +789,14 @@ def main():
     # stages of two queries share the device, which raises throughput and stretches every single launch; the
     # stand-alone duration is what the kernel itself achieves.
     solo = {}
+    idle_ms = []
     if pipe_effective(args.pipeline_depth, args.feeders, args.finishers)["pipeline_depth"] > 0 and rank == 0:
-        n_solo = 3
-        for h in hmmer.hmmsearch((om for _ in range(n_solo)), db, pipeline_depth=0, cpus=host_threads, batch=1):
+        n_solo = 5
+        for _ in range(n_solo):          # ONE query at a time, nothing else in flight: the literal "single profile vs 1M sequences"
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            h = next(iter(hmmer.hmmsearch([om], db, pipeline_depth=0, cpus=host_threads, batch=1, **pli_opts)))
+            idle_ms.append(1e3 * (time.perf_counter() - t1))
             for k, v in h.timings_ms.items():
                 solo[k] = solo.get(k, 0.0) + v / n_solo
 
@@ -775,16 +842,22 @@ def main():
         hits_total, reported_total = len(hits), len(hits.reported)
 
     pfam = scan = None
-    if args.workload in ("both", "pfam", "scan"):
-        del db                       # the headline's target block leaves HBM first
+    c1_steps, c1_warmup = args.steps, args.warmup
+    if args.workload in ("all", "pfam", "scan"):
+        del db                       # the configs[1] target block leaves HBM first
         lib = build_library(args, local_rank)
-        if args.workload in ("both", "pfam"):
+        if args.workload in ("all", "pfam"):
+            args.steps, args.warmup = line_steps, line_warmup
             pfam = run_pfam(args, rank, world, local_rank, dist, red_dev, torch, host_threads, lib)
-        if args.workload in ("both", "scan"):
-            scan = run_scan(args, rank, world, local_rank, dist, red_dev, torch, host_threads, lib)
+            args.steps, args.warmup = c1_steps, c1_warmup
+        if args.workload in ("all", "scan"):
+            scan = run_scan(args, rank, world, local_rank, dist, red_dev, torch, host_threads, lib, "synthetic")
+            fx = run_scan(args, rank, world, local_rank, dist, red_dev, torch, host_threads, lib, "fixture")
+            if scan is not None:
+                scan["fixture_proteome"] = {k: fx[k] for k in ("workload", "value", "seconds", "query_sequences", "passes_seconds_rank0", "hits_rank0", "roofline")}
         del lib
     nh = None
-    if args.workload in ("both", "nhmmer"):
+    if args.workload in ("all", "nhmmer"):
         if args.workload == "nhmmer":
             del db
         nh = run_nhmmer(args, rank, world, local_rank, dist, red_dev, torch)
@@ -827,6 +900,13 @@ def main():
                 **pipe_effective(args.pipeline_depth, args.feeders, args.finishers), "host_threads_per_rank": host_threads,
                 "spinup_windows_s": [round(x, 4) for x in spin],
                 "latency_ms_per_query": round(stage.get("total", 0.0), 3),
+                # ONE hmmsearch of the one profile against the resident 1M-target block, nothing else in flight (wall clock of the
+                # call, median of five), and where that time goes (the call's own stage clocks, ms)
+                "latency_ms_one_query_idle_device": round(sorted(idle_ms)[len(idle_ms) // 2], 3) if idle_ms else None,
+                "idle_device_gcups": round(cells_rank / (sorted(idle_ms)[len(idle_ms) // 2] * 1e-3) / 1e9, 1) if idle_ms else None,
+                "idle_device_stage_ms": ({k: round(solo[k], 3) for k in ("msv_kernel", "msv", "bias", "viterbi", "forward", "fwd_rows", "stage1",
+                                                                        "envelopes", "ensemble_wait", "envelope_wait", "host_stage_busy", "stage2", "total") if k in solo}
+                                         if solo else None),
             },
             "ranks": {"per_rank": diags, "merge_seconds_rank0": round(merge_s, 5),
                       "note": "fractions of the timed region, per feeder thread; slot wait = every batch slot was taken and the feeders "
@@ -874,24 +954,44 @@ def main():
             out["scan"] = scan
         if nh is not None:
             out["nhmmer"] = nh
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and c1_cpu:
             out["cpu_baseline"] = cpu_baseline(hmm, bg, flat, offsets, lengths, min(args.cpu_sample, args.nseq), args.seqlen)
-        sub = {"pfam": pfam, "scan": scan, "nhmmer": nh}.get(args.workload)
-        if sub is not None:
-            # --workload pfam / scan / nhmmer: that workload IS the line (value, config, roofline, cpu_baseline); the headline's
-            # token run stays as a field
-            secs = sub.get("seconds", sub.get("s_per_search", 0.0) * sub.get("searches", 1))
-            first = {"metric": out["metric"], "value": sub["value"], "unit": "GCUPS", "n_gpus": world,
-                     "steps": sub.get("searches", 1), "warmup": 1, "ms_per_step": round(1e3 * secs / max(1, sub.get("searches", 1)), 3),
-                     "higher_is_better": True, "scaling": sub.get("scaling", "weak"), "vs_baseline": None,
-                     "dtype": out["dtype"] if args.workload != "nhmmer" else "i16 SSV scan and window filters, f32 Forward/Backward",
-                     "data": "synthetic",
-                     "config": {"workload": sub["workload"], "step": "one pass over the whole workload after one untimed pass"
-                                if args.workload != "nhmmer" else "one complete search of a stream of searches",
-                                "parallelism": f"{world} GPU(s), one process each"},
-                     "roofline": sub.get("roofline"), "cpu_baseline": sub.get("cpu_baseline"),
-                     args.workload: sub, "config1_token_run": {"value": out["value"], "steps": out["steps"]}}
+        if args.workload in ("all", "pfam") and pfam is not None:
+            # the line is BASELINE's metric config (configs[3]); configs[1], the scan orientation and nhmmer are fields
+            first = {"metric": out["metric"], "value": pfam["value"], "unit": "GCUPS", "n_gpus": world,
+                     "steps": line_steps, "warmup": line_warmup, "ms_per_step": round(1e3 * pfam["seconds"] / max(1, line_steps), 3),
+                     "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": out["dtype"], "data": "synthetic",
+                     "seqs_per_s": pfam["seqs_per_s"],
+                     "config": {"workload": pfam["workload"],
+                                "step": f"{pfam['profiles_per_step']} library profiles x all {pfam['targets']} targets (complete searches, hit lists merged)",
+                                "profiles_per_step": pfam["profiles_per_step"], "targets": pfam["targets"], "library": pfam["library"],
+                                "parallelism": f"targets sharded by residues over {world} GPU(s), one process each, host merge of the per-GPU TopHits",
+                                "timed_region": "one hmmer.hmmsearch call over the steps' profiles + gather + merge, barrier and synchronize on both "
+                                                "sides; device images of the profiles and the targets resident in HBM (an untimed pass over the whole "
+                                                "library first); library defaults", **{k: pfam[k] for k in ("batch", "pipeline_depth", "feeders", "finishers", "library_defaults")}},
+                     "roofline": pfam.pop("roofline"), "cpu_baseline": pfam.pop("cpu_baseline", None),
+                     "pfam": pfam}
+            if args.workload == "all":
+                first["config1"] = out
+            if scan is not None:
+                first["scan"] = out.pop("scan", scan)
+            if nh is not None:
+                first["nhmmer"] = out.pop("nhmmer", nh)
+            out.pop("pfam", None)
             out = first
+        elif args.workload in ("scan", "nhmmer"):
+            sub = scan if args.workload == "scan" else nh
+            # --workload scan / nhmmer: that workload IS the line (value, config, roofline, cpu_baseline)
+            secs = sub.get("seconds", sub.get("s_per_search", 0.0) * sub.get("searches", 1))
+            out = {"metric": out["metric"], "value": sub["value"], "unit": "GCUPS", "n_gpus": world,
+                   "steps": sub.get("searches", 1), "warmup": 1, "ms_per_step": round(1e3 * secs / max(1, sub.get("searches", 1)), 3),
+                   "higher_is_better": True, "scaling": sub.get("scaling", "weak"), "vs_baseline": None,
+                   "dtype": out["dtype"] if args.workload != "nhmmer" else "i16 SSV scan and window filters, f32 Forward/Backward",
+                   "data": "synthetic",
+                   "config": {"workload": sub["workload"], "step": "one pass over the whole workload after one untimed pass"
+                              if args.workload != "nhmmer" else "one complete search of a stream of searches",
+                              "parallelism": f"{world} GPU(s), one process each"},
+                   "roofline": sub.get("roofline"), "cpu_baseline": sub.get("cpu_baseline"), args.workload: sub}
         print(json.dumps(out))
     if dist is not None:
         dist.destroy_process_group()

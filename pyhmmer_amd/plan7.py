@@ -63,8 +63,11 @@ class EvalueParameters:
         return None if v == EVPARAM_UNSET else v
 
     def __setattr__(self, name, value):
-        """The parameters can be set (``None`` clears one), as in the reference (``plan7.pyx:1760-1849``); they are the HMM's own."""
+        """The parameters can be set (``None`` clears one), as in the reference (``plan7.pyx:1760-1849``); they are the HMM's own.
+        An `OptimizedProfile` hands out a read-only copy (its values live in the search-ready C object): setting raises."""
         if name in self._names:
+            if not self._v.flags.writeable:
+                raise AttributeError(f"the E-value parameters of an OptimizedProfile are read-only (set them on the HMM): {name}")
             self._v[self._names.index(name)] = EVPARAM_UNSET if value is None else value
         else:
             object.__setattr__(self, name, value)
@@ -95,6 +98,8 @@ class Cutoffs:
         return None if a == CUTOFF_UNSET or b == CUTOFF_UNSET else (a, b)
 
     def _set_pair(self, i, pair):
+        if not self._v.flags.writeable:      # an OptimizedProfile's copy: a write here would be silently dropped
+            raise AttributeError("the cutoffs of an OptimizedProfile are read-only (set them on the HMM before optimizing it)")
         if pair is None:
             self._v[i] = self._v[i + 1] = CUTOFF_UNSET
         else:
@@ -102,7 +107,7 @@ class Cutoffs:
             self._v[i], self._v[i + 1] = a, b
 
     # each pair can be read, set from two floats, and cleared with None or ``del`` (reference ``plan7.pyx:1204-1420``); the values
-    # are the owner's (``HMM.cutoffs`` / ``OptimizedProfile.cutoffs`` hand out a view)
+    # are the owner's (``HMM.cutoffs`` hands out a view; ``OptimizedProfile.cutoffs`` a READ-ONLY copy: setting raises)
     gathering = property(lambda self: self._pair(0), lambda self, v: self._set_pair(0, v), lambda self: self._set_pair(0, None))
     trusted = property(lambda self: self._pair(2), lambda self, v: self._set_pair(2, v), lambda self: self._set_pair(2, None))
     noise = property(lambda self: self._pair(4), lambda self, v: self._set_pair(4, v), lambda self: self._set_pair(4, None))
@@ -995,13 +1000,19 @@ class OptimizedProfile:
     def xf(self) -> np.ndarray:
         return np.array([[self._info.xf[i][j] for j in range(2)] for i in range(4)], dtype=np.float32)
 
+    @staticmethod
+    def _frozen(values) -> np.ndarray:
+        a = np.asarray(values, dtype=np.float32)
+        a.flags.writeable = False
+        return a
+
     @property
     def evalue_parameters(self) -> EvalueParameters:
-        return EvalueParameters([self._info.evparam[i] for i in range(6)])
+        return EvalueParameters(self._frozen([self._info.evparam[i] for i in range(6)]))
 
     @property
     def cutoffs(self) -> Cutoffs:
-        return Cutoffs([self._info.cutoff[i] for i in range(6)])
+        return Cutoffs(self._frozen([self._info.cutoff[i] for i in range(6)]))
 
     @property
     def compositions(self) -> np.ndarray:

@@ -7,7 +7,7 @@ import numpy as np
 import pytest
 
 import h3_reader
-from conftest import GOLDEN, ROOT, synthetic_block
+from conftest import GOLDEN, ROOT, load_hmms, synthetic_block
 from pyhmmer_amd import _lib, easel, errors, hmmer, plan7
 
 
@@ -696,3 +696,19 @@ def test_cutoffs_and_evalue_parameters_are_the_models_own(libp7x, models):
     assert hmm.evalue_parameters.m_mu == -9.5 and hmm.evalue_parameters != models["Thioesterase"][0].evalue_parameters
     hmm.evalue_parameters.f_tau = None
     assert hmm.evalue_parameters.f_tau is None
+
+
+def test_optimized_profile_cutoffs_and_evalue_parameters_are_read_only():
+    """`OptimizedProfile.cutoffs` / `.evalue_parameters` are copies of what the search-ready object holds: a write must not be
+    silently dropped -- it raises; the HMM's own views stay writable (reference plan7.pyx:1204-1420, 1760-1849)."""
+    hmm = load_hmms("PF02826")[0]
+    om = plan7.OptimizedProfile(hmm, plan7.Background(hmm.alphabet), 400)
+    with pytest.raises(AttributeError):
+        om.cutoffs.gathering = (1.0, 2.0)
+    with pytest.raises(AttributeError):
+        del om.cutoffs.noise
+    with pytest.raises(AttributeError):
+        om.evalue_parameters.m_mu = 1.0
+    assert om.cutoffs.gathering == hmm.cutoffs.gathering and om.evalue_parameters == hmm.evalue_parameters
+    hmm.cutoffs.gathering = (1.0, 2.0)
+    assert hmm.cutoffs.gathering == (1.0, 2.0)
