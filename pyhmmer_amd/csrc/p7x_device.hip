@@ -198,9 +198,15 @@ int p7x_seqdb_create(int device, int32_t abc_type, const uint8_t *dsq, const int
   }
   db->tile_u4 = u4;
   {   // targets more than three times as long as the median (and longer than 768) are "long" for the packed Viterbi
-      // kernel, whose wavefronts run to their longest target: a few per cent of the residues of a proteome
+      // kernel, whose wavefronts run to their longest target: a few per cent of the residues of a proteome.  That rule is
+      // for SMALL blocks (the scan orientation, up to 256 groups), whose stages last as long as their longest chain.  Against
+      // a large block the device is busy with other batches' kernels while a long chain runs, what counts is the
+      // instructions issued, and the wave-per-target kernel issues three times as many per row: only targets beyond
+      // 20,000 residues (a 25 ms chain) leave the packed kernel there.  Round 6, 4,000 library profiles x 500,000
+      // targets: Viterbi 12.3 -> 9.9 ms per batch, 21.9 -> 22.9 TCUPS (profiles/r06_vit_long_cut.txt).
     const int median = nslots > 0 ? slot_len[nslots / 2] : 0;
-    const int cut = std::max(768, 3 * median);
+    const int cut = debug_opt(OPT_VIT_LONG_CUT) > 0 ? debug_opt(OPT_VIT_LONG_CUT)
+                  : (G > 256 ? std::max(20000, 3 * median) : std::max(768, 3 * median));
     int64_t k = 0;
     while (k < nslots && slot_len[k] > cut) ++k;
     db->vit_long_slots = k;
