@@ -611,6 +611,34 @@ def test_in_process_search_over_four_devices_equals_one(models, proteome):
     assert [[(h.name, h.score, h.evalue) for h in t] for t in one] == [[(h.name, h.score, h.evalue) for h in t] for t in many]
 
 
+def test_in_process_search_over_eight_devices_equals_one(models, proteome):
+    """SURVEY.md 8(e), the node the metric is quoted on: eight devices driven by ONE process (the API's default path when eight
+    are visible).  The one device of the test box listed eight times, all three orientations: hmmsearch (targets sharded by
+    residues, per-query merge), hmmscan (profiles dealt), nhmmer ((target, block, strand) units dealt); merged == whole."""
+    queries = models["PF02826"] + models["RREFam"][:3] + models["KR"]
+    eight = [0] * 8
+    whole = list(hmmer.hmmsearch(queries, proteome, devices=[0]))
+    many = list(hmmer.hmmsearch(queries, proteome, devices=eight))
+    for a, b in zip(many, whole):
+        assert a.Z == b.Z == len(proteome) and a.domZ == b.domZ and a.stage_counts == b.stage_counts
+        assert [(h.name, h.score, h.evalue, h.reported, h.included, [(d.env_from, d.env_to, d.score, d.alignment.target_sequence) for d in h.domains]) for h in a] == \
+               [(h.name, h.score, h.evalue, h.reported, h.included, [(d.env_from, d.env_to, d.score, d.alignment.target_sequence) for d in h.domains]) for h in b]
+    sub = proteome[:400]
+    profs = (models["RREFam"] + models["PF02826"]) * 2
+    one = list(hmmer.hmmscan(sub, profs, devices=[0], batch=3))
+    sc8 = list(hmmer.hmmscan(sub, profs, devices=eight, batch=3))
+    assert [[(h.name, h.score, h.evalue) for h in t] for t in one] == [[(h.name, h.score, h.evalue) for h in t] for t in sc8]
+    import bench_workloads as bw
+    from conftest import load_hmms
+    dna = load_hmms("bmyD")[0]
+    chrom = bw.make_chromosome(dna, 3_000_000, planted=30, seed=19)
+    blk = easel.DigitalSequenceBlock(dna.alphabet, [easel.DigitalSequence(dna.alphabet, name="chr8", sequence=chrom)])
+    rows = lambda hits: [(h.name, h.score, h.evalue, [(d.env_from, d.env_to, d.alignment.hmm_from, d.alignment.hmm_to) for d in h.domains]) for h in hits]
+    n1 = next(hmmer.nhmmer(dna, blk, devices=[0], host_envelopes=1))
+    n8 = next(hmmer.nhmmer(dna, blk, devices=eight, host_envelopes=1))
+    assert len(n1) >= 20 and rows(n8) == rows(n1) and n8.stage_counts == n1.stage_counts
+
+
 def test_a_failing_ensemble_workspace_sends_the_regions_to_the_host(models, proteome):
     """an allocation or launch failure of the device ensembles must not fail the search -- every region can be
     sampled by the host workers, with the same result (seam ens_fail makes DeviceEnsembleRunner::begin fail)."""
