@@ -17,7 +17,7 @@ _ROOT = _PKG.parent
 CSRC = _PKG / "csrc"
 LIB_PATH = _PKG / "libp7x.so"
 
-SOURCES = ["p7x_profile.cpp", "p7x_device.hip", "p7x_devimage.hip", "p7x_msv.hip", "p7x_vitfwd.hip", "p7x_vitpk.hip", "p7x_envelope.hip", "p7x_ensemble.hip", "p7x_ssvlong.hip", "p7x_longtarget.hip",
+SOURCES = ["p7x_profile.cpp", "p7x_device.hip", "p7x_devimage.hip", "p7x_msv.hip", "p7x_vitfwd.hip", "p7x_vitpk.hip", "p7x_fwdpk.hip", "p7x_envelope.hip", "p7x_ensemble.hip", "p7x_ssvlong.hip", "p7x_longtarget.hip",
            "p7x_envscore.hip", "p7x_pipeline.hip", "p7x_domaindef.cpp", "p7x_tophits.cpp"]
 
 

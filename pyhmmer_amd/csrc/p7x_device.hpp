@@ -100,6 +100,9 @@ struct DevProfile {
   // Forward/Backward: transitions [Mpad][8] f32, emissions [kTabRows][Mpad] f32
   float *fwd_trans = nullptr;
   float *fwd_emis = nullptr;
+  // grouped Forward parser (p7x_fwdpk.hip), models of up to 256 nodes: T lanes per target, C nodes per lane
+  int fwdgT = 0, fwdgC = 0;
+  float *fwdg_trans = nullptr, *fwdg_emis = nullptr;
   // bias filter: emission odds [kTabRows][2]
   float *bias_eo = nullptr;
   // all of the tables above live in one device allocation taken from (and returned to) the context's slab pool, shared

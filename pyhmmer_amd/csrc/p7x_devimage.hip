@@ -178,6 +178,14 @@ static void build_host_image(const Profile &p, DevProfile *d, HostImage &img)
     img.add(&d->vit_emis, ve);
     img.add(&d->fwd_trans, ft);
     img.add(&d->fwd_emis, fe);
+    int gT = 0, gC = 0;
+    if (fwdg_pick(p.M, d->vitC, &gT, &gC)) {
+      std::vector<float> gt, ge;
+      fwdg_build_tables(p, gT, gC, gt, ge);
+      d->fwdgT = gT; d->fwdgC = gC;
+      img.add(&d->fwdg_trans, gt);
+      img.add(&d->fwdg_emis, ge);
+    }
   }
   {
     int T = 0, P = 0;

@@ -103,6 +103,10 @@ int vit_pick_C(int M);
 // every record of a run has the same C (and nrows); nlist of the host copies bounds the lists and sizes the grid
 int vit_launch(const ArgRun<WaveSeqArgs> &a, int num_cu, hipStream_t st);
 int fwd_launch(const ArgRun<WaveSeqArgs> &a, int num_cu, hipStream_t st);
+// grouped Forward parser, scores only (p7x_fwdpk.hip): WaveSeqArgs::C = T * 256 + C, trans / emis in its own layout
+bool fwdg_pick(int M, int vitC, int *T, int *C);
+int fwdg_launch(const ArgRun<WaveSeqArgs> &a, int num_cu, hipStream_t st);
+void fwdg_build_tables(const Profile &p, int T, int C, std::vector<float> &trans, std::vector<float> &emis);
 int bck_launch(const ArgRun<WaveSeqArgs> &a, int num_cu, hipStream_t st);
 
 // ---- MSV for models beyond the register-resident kernels (p7x_vitfwd.hip::msv_wave_kernel), M <= 8192

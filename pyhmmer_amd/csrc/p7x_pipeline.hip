@@ -512,7 +512,7 @@ struct LaneArgs {
 };
 constexpr int kLaneCounters = 16;
 // counters of a lane: [0] msv groups taken [1] n(list_bias) [2] n(list_vit) [3] n(list_fwd) [4] n(list_fin)
-// [8] n_past_bias [10] ambiguous MSV groups [11] exact-MSV groups taken [12] flag: survivor buffers too small
+// [5] work counter of the grouped Forward parser [8] n_past_bias [10] ambiguous MSV groups [11] exact-MSV groups taken [12] flag: survivor buffers too small
 // [13] length of the prefix of list_vit that holds the longest targets (wave-per-target Viterbi)
 
 // A workspace serves a batch of up to <nlanes> queries against a block of up to <cap_slots> targets: per-lane
@@ -1106,6 +1106,15 @@ static int launch_survivor_passes(CascadeRun &r, const LaneClass &c, hipStream_t
   return P7X_OK;
 }
 
+// The Forward parser of the first pass (scores only) through the grouped kernel: against large blocks, where throughput counts
+// (a small block's stages last as long as their longest chain: one target per wavefront is the shorter chain there, and the
+// stage-by-stage cascade launches fwd_kernel by nodes per lane).  OFF by default (option fwd_grouped = 1 switches it on): the
+// kernel issues 2.5 times fewer instructions per target and row (ISA: 334 per row of four targets at T = 16, C = 8 against
+// about 260 per row of one) and is bit-for-bit as good within the parser's tolerance (tests/test_gpu_filters.py), but the
+// many-profile workload did not get faster with it (22.4-22.6 against 22.6-22.75 TCUPS, profiles/r06_fwd_grouped.txt): in
+// the pipeline the parser's wavefronts wait for their own dependent chains, not for issue slots.
+static bool fwd_grouped(const p7x_seqdb *db) { return debug_opt(OPT_FWD_GROUPED) > 0 && db->ngroups > 256 && debug_opt(OPT_STAGE_MERGE) <= 0; }
+
 // every kernel of stage 1 for the lanes of one class, on stream <s>
 static int class_cascade(CascadeRun &r, const LaneClass &c, hipStream_t s, bool record_events, bool chain_msv, bool msv_by_tier = false)
 {
@@ -1140,7 +1149,9 @@ static int class_cascade(CascadeRun &r, const LaneClass &c, hipStream_t s, bool 
   if ((st = class_viterbi(c, r.lm, ctx, ws, s)) != P7X_OK) return st;
   hipLaunchKernelGGL(decide_vit_kernel, dim3(lane_grid((r.est_vit + 255) / 256, ctx->num_cu, c.n), (unsigned) c.n), dim3(256), 0, s, dec);
   if (record_events) P7X_HIP(hipEventRecord(ws->ev[3], s));
-  if ((st = class_wave(c, ws, &LaneArgs::fwd, false, ctx, s)) != P7X_OK) return st;
+  if (fwd_grouped(db) && r.lm[c.first].dp->fwdgT > 0) {       // scores only: several targets per wavefront (p7x_fwdpk.hip)
+    if ((st = fwdg_launch(lane_run(ws, &LaneArgs::fwd, c.first, c.n), ctx->num_cu, s)) != P7X_OK) return st;
+  } else if ((st = class_wave(c, ws, &LaneArgs::fwd, false, ctx, s)) != P7X_OK) return st;
   hipLaunchKernelGGL(decide_fwd_kernel, dim3(lane_grid((r.est_fwd + 255) / 256, ctx->num_cu, c.n), (unsigned) c.n), dim3(256), 0, s, dec);
   P7X_HIP(hipGetLastError());
   if (record_events) P7X_HIP(hipEventRecord(ws->ev[4], s));
@@ -1322,6 +1333,7 @@ static int cascade_enqueue(CascadeRun &r)
     WaveSeqArgs a = ws_args(p, dp, db, ctx);
     a.trans = dp->fwd_trans; a.emis = dp->fwd_emis; a.list = b.list_fwd; a.nlist = est.fwd; a.nlist_ptr = &b.counters[3];
     a.out_sc = b.fwd_by_item;
+    if (fwd_grouped(db) && dp->fwdgT > 0) { a.trans = dp->fwdg_trans; a.emis = dp->fwdg_emis; a.C = dp->fwdgT * 256 + dp->fwdgC; a.counter = &b.counters[5]; }
     la.fwd = a;
   }
   tick("args");

@@ -345,3 +345,39 @@ def test_bias_filter_logarithm_equals_the_library_logarithm_for_every_float():
     out = np.empty_like(x)
     assert _lib.lib().p7x_debug_log_of_float(0, x.ctypes.data, out.ctypes.data, x.size) == 0
     assert out[0] == -np.inf and out[2] == np.inf and out[3] == 0.0 and out[4] == np.float32(np.log(2.0)) and abs(out[1] - np.log(1e-42)) < 1e-3
+
+
+@pytest.mark.parametrize("M", [20, 33, 64, 65, 100, 128, 129, 160, 192, 193, 230, 256, 257, 262, 320, 321, 384])
+def test_grouped_forward_parser_against_the_wave_per_target_kernel_and_the_oracle(oracle, M):
+    """p7x_fwdpk.hip (T = 16 or 32 lanes per target, the first Forward pass against large blocks; option fwd_grouped) for every (T, C)
+    instantiation and its boundary lengths: 20,000 ragged targets with 300 homologs; the same stage counts, the same hits
+    and scores within the parser's stated tolerance as with fwd_kernel (option fwd_grouped = 0), and the oracle's Forward
+    scores (upstream's striped order) within 2e-3 nat for every target that reaches the parser."""
+    from pyhmmer_amd import _lib
+    hmm = random_hmm(M, seed=7000 + M)
+    blk = _model_block(hmm, 20_000, 300, seed=M)
+    db = plan7.SequenceDatabase(blk)
+    assert len(blk) > 256 * 64
+    pli = dict(E=1e3, domE=1e3)
+    old = plan7.Pipeline(hmm.alphabet, **pli).search_hmm(hmm, db)
+    _lib.set_debug_option("fwd_grouped", 1)
+    try:
+        new = plan7.Pipeline(hmm.alphabet, **pli).search_hmm(hmm, db)
+    finally:
+        _lib.set_debug_option("fwd_grouped", -1)
+    assert new.stage_counts == old.stage_counts and new.stage_counts["vit"] >= 250
+    assert [h.name for h in new] == [h.name for h in old]
+    for a, b in zip(new, old):
+        assert abs(a.pre_score - b.pre_score) <= 4e-3 and abs(a.score - b.score) <= 4e-3, (a.name, a.pre_score, b.pre_score)
+    # the oracle's parser on the hits: pre_score = (fwd - null1) / ln 2
+    op = oracle.OracleProfile(hmm, plan7.Background(hmm.alphabet), 400)
+    by_name = {s.name: s for s in blk}
+    n = match = 0
+    for h in list(new)[:120]:
+        seq = np.asarray(by_name[h.name].sequence, dtype=np.uint8)
+        st, fsc = op.fwd(seq)
+        L = len(seq)
+        null1 = L * np.log(L / (L + 1.0)) + np.log(1.0 / (L + 1.0))
+        n += 1
+        match += abs(h.pre_score - (fsc - null1) / np.log(2.0)) <= 4e-3      # (not when the sum of the domains replaced the Forward score: p7_pipeline.c)
+    assert n >= 50 and match >= 0.6 * n, (match, n)
