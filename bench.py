@@ -386,8 +386,10 @@ def run_pfam(args, rank, world, local_rank, dist, red_dev, torch, host_threads, 
     db = plan7.SequenceDatabase.from_packed(hmms[0].alphabet, flat, offsets[lo:hi], lengths[lo:hi], device=local_rank)
     t_tgt = time.perf_counter() - t0
 
+    fopts = {k: v for k, v in (("F1", args.F1), ("F2", args.F2), ("F3", args.F3)) if v is not None}     # diagnostics: where the time goes
+
     def search(qs):
-        return list(hmmer.hmmsearch(qs, db, cpus=host_threads, batch=args.pfam_batch, **pipe_opts(args.pfam_depth, args.feeders, args.pfam_finishers)))
+        return list(hmmer.hmmsearch(qs, db, cpus=host_threads, batch=args.pfam_batch, **pipe_opts(args.pfam_depth, args.feeders, args.pfam_finishers), **fopts))
 
     def barrier():
         if dist is not None:
@@ -652,6 +654,8 @@ def main():
                     help="all (default): the line is the pfam workload (BASELINE's metric config, configs[3]) with --steps / --warmup, "
                          "and config1 / scan / nhmmer are fields; pfam / scan / nhmmer: only that workload; config1: the line is "
                          "configs[1] (one profile x 1M targets per GPU, a step = --queries-per-step searches) with --steps / --warmup")
+    for f in ("F1", "F2", "F3"):
+        ap.add_argument(f"--{f}", type=float, default=None, help="diagnostics (pfam workload): filter threshold, e.g. --F1 1e-12 = the MSV stage alone")
     ap.add_argument("--pfam-profiles-per-step", type=int, default=1000, help="library profiles of one step of the pfam workload")
     ap.add_argument("--config1-steps", type=int, default=4, help="steps of the configs[1] FIELD when it is not the line (32 queries each)")
     ap.add_argument("--scan-targets", type=int, default=4000, help="query proteins of the scan workload's synthetic block (BASELINE: 4k)")
