@@ -129,7 +129,11 @@ __device__ __forceinline__ void vit_row(const VitPkArgs &a, const uint4 *tral, c
     rs.xB = max(rs.xJ + xwm, rs.xN + xwm);
   }
   const bool trig = active && (Dmax + a.ddbound > rs.xB);          // lazy F, per target
+#ifdef P7X_VITPK_NO_CLOSURE      // build-time experiment (timing only, wrong scores): what the D->D closure costs
+  if (false) {
+#else
   if (__any(trig)) {
+#endif
     // The registers of every target of the wavefront are walked, also of those that did not ask for the closure:
     // relaxing D->D edges of such a target cannot reach the next row's M (that is what the lazy-F bound says), so its
     // score is the same with or without them.  Only the carry into the next stripe is restricted to the targets that
