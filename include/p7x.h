@@ -445,9 +445,11 @@ int      p7x_tophits_get_timings(const p7x_tophits *th, double *ms, int n);
  * deserialisation), and the latter by the kind of choice that was close: the predecessor of a match / insert / delete
  * cell, C<-E, J<-E, the end cell, B<-N/J, a printed posterior digit (an envelope can count under several) */
 int      p7x_tophits_get_guard_counts(const p7x_tophits *th, int64_t *f3_dropped, int64_t *oa_redone, int64_t oa_why[8]);
-/* ABI 8: multi-domain regions whose traceback ensemble the device sampled, and regions its near-threshold guard
- * (p7x_pipeline_cfg.ens_guard) flagged and the host stage sampled again in upstream's summation order */
-int      p7x_tophits_get_ensemble_counts(const p7x_tophits *th, int64_t *sampled_on_device, int64_t *redone_by_host);
+/* ABI 8: multi-domain regions whose traceback ensemble the device sampled, regions its near-threshold guard
+ * (p7x_pipeline_cfg.ens_guard) flagged and the host stage sampled again in upstream's summation order, and targets whose
+ * region scan (rt1 / rt2 / rt3 against posteriors from the device parsers' rows) had a comparison within 2e-5 of its
+ * threshold and was repeated by the host stage on parser rows in upstream's order (active with oa_guard > 0) */
+int      p7x_tophits_get_ensemble_counts(const p7x_tophits *th, int64_t *sampled_on_device, int64_t *redone_by_host, int64_t *region_scans_redone);
 
 const char *p7x_last_error(void);
 

@@ -156,7 +156,7 @@ _SIGNATURES = {
     "p7x_tophits_merge_longtargets": (C.c_int, [C.POINTER(_VP), C.c_size_t, C.POINTER(_VP)]),
     "p7x_tophits_merge_many": (C.c_int, [C.POINTER(C.c_char_p), C.POINTER(C.c_size_t), C.c_size_t, C.c_size_t, C.c_int, C.POINTER(_VP)]),
     "p7x_tophits_get_guard_counts": (C.c_int, [_VP, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
-    "p7x_tophits_get_ensemble_counts": (C.c_int, [_VP, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
+    "p7x_tophits_get_ensemble_counts": (C.c_int, [_VP, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
     "p7x_hmm_max_length": (C.c_int, [C.POINTER(HmmView), C.c_double, C.POINTER(C.c_int32)]),
     "p7x_expf_neg": (None, [_VP, _VP, C.c_size_t]),
     "p7x_oprofile_create": (C.c_int, [C.POINTER(HmmView), _VP, C.c_int32, C.POINTER(_VP)]),

@@ -1513,6 +1513,21 @@ int domaindef_finish_multi(const Profile &p, const uint8_t *dsq, int L, uint32_t
 
 uint32_t fast_rng_state(uint32_t seed) { FastRng r; r.init(seed); return r.x; }
 
+int parser_rows_upstream(const Profile &p, const uint8_t *dsq, int L, std::vector<float> &fx, std::vector<float> &bx)
+{
+  thread_local Workspace ws;
+  Model om{ &p, p.M, {} };
+  om.prepare(0);
+  om.configure(true, L);
+  int st = forward_full(om, dsq, L, ws.fwd, nullptr);
+  if (st != P7X_OK) return st;
+  st = backward_full(om, dsq, L, ws.fwd, ws.bck, nullptr);
+  if (st != P7X_OK) return st;
+  fx.assign(ws.fwd.x.begin(), ws.fwd.x.begin() + (size_t) (L + 1) * NX);
+  bx.assign(ws.bck.x.begin(), ws.bck.x.begin() + (size_t) (L + 1) * NX);
+  return P7X_OK;
+}
+
 // Second half of rescore_isolated_domain() for envelopes rescored by the device kernel: trace -> alignment
 // display, null2 odds -> per-residue corrections.  req_index[n] is the position in <res> of local request n
 // (Domain::deferred of the placeholders of this target).

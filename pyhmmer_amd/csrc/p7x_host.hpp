@@ -34,6 +34,7 @@ struct DomainDefResult {      // the P7_DOMAINDEF fields p7_Pipeline reads (p7_d
   int nregions = 0, nclustered = 0, noverlaps = 0, nenvelopes = 0;
   int nneartie = 0;           // device envelopes repeated by the host twin (optimal-accuracy near-tie guard)
   int neartie_why[8]{};       // ... by the kind of choice that was close (EnvArgs::out_status bits 8-15)
+  int nregion_redone = 0;     // 1: the device's region scan was inside its guard band, the regions come from rows in upstream's order
   int nens_device = 0;        // multi-domain regions whose ensemble the device sampled
   int nens_redone = 0;        // ... and those it flagged as too close to call (near-threshold guard): sampled again here, in upstream's order
 };
@@ -80,6 +81,9 @@ struct EnsembleRunner {
   virtual int wait(std::vector<std::vector<EnsembleResult>> &res) = 0;
 };
 uint32_t fast_rng_state(uint32_t seed);          // esl_randomness_Init for the LCG
+// p7_ForwardParser / p7_BackwardParser special-state rows ((L+1) x [E,N,J,B,C,SCALE], multihit, length model of L) in upstream's
+// summation order (the full-matrix engine; the target's DP matrices are scratch): dsq[1..L]
+int parser_rows_upstream(const Profile &p, const uint8_t *dsq, int L, std::vector<float> &fx, std::vector<float> &bx);
 
 // p7_domaindef_ByPosteriorHeuristics (p7_domaindef.pxd:69-72).  dsq is 1-indexed (dsq[1..L]);
 // fwd_xmx / bck_xmx are the parsers' special-state rows, (L+1) x [E,N,J,B,C,SCALE].
@@ -234,6 +238,7 @@ struct p7x_tophits {
   int lt_evalue_window = 0;           // ... and the window length its E-values refer to
   int64_t oa_redone = 0;              // device envelopes the near-tie guard sent to the host twin (not serialised)
   int64_t oa_why[8]{};                // ... by kind of choice: M, I, D cell, C<-E, J<-E, end cell, B<-N/J, posterior digit
+  int64_t region_redone = 0;                // targets whose region scan the host stage repeated on rows in upstream's order (the device scan's guard)
   int64_t ens_device = 0, ens_redone = 0;   // regions sampled on the device / flagged by its near-threshold guard and sampled again by the host stage (not serialised)
   int64_t nreported = 0, nincluded = 0;
 };

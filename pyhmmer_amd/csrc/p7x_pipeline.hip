@@ -425,7 +425,10 @@ struct RegionArgs {
   const int64_t *xmx_off;     // per item
   float *scratch;             // per item at xmx_off: terms [3][L+1] then prefix sums [2][L+1]  (5 of the 6 row floats)
   int32_t *out_regs;          // [nitems][kRegionCap][3] = i, j, multi
-  int32_t *out_n;             // [nitems] number of regions, or -1 (range error), or -2 (more than kRegionCap)
+  int32_t *out_n;             // [nitems] number of regions, or -1 (range error), or -2 (more than kRegionCap), or -3 (a threshold
+                              // comparison of the scan within the guard band: the host stage scans this target itself, from parser rows
+                              // in upstream's summation order)
+  float guard;                // absolute half-width of that band (p7x_pipeline_cfg.oa_guard > 0: 2e-5; else 0 = off)
   float *out_nexpected;       // [nitems]
 };
 
@@ -459,6 +462,10 @@ __global__ void __launch_bounds__(256) regions_kernel(const ArgRef ref)
     int32_t *regs = a.out_regs + (size_t) it * kRegionCap * 3;
     float b = 0.0f, e = 0.0f;
     int i = -1; bool triggered = false;
+    // the rows come from the device parsers (lane-chunk summation order): a comparison closer to its threshold than the guard
+    // may fall the other way in upstream's order
+    bool near = false;
+    const float gd = a.guard;
     for (int j0 = 1; j0 <= L; j0 += 64) {
       const int nj = min(64, L - j0 + 1);
       // this block's terms, one per lane; broadcast in order below
@@ -473,10 +480,11 @@ __global__ void __launch_bounds__(256) regions_kernel(const ArgRef ref)
         b = bprev + dbt; e = eprev + det;
         if (lane == r) { keepb = b; keepe = e; }
         if (!triggered) {
+          near = near || __builtin_fabsf((mo - (b - bprev)) - rt2) <= gd || __builtin_fabsf(mo - rt1) <= gd;
           if (mo - (b - bprev) < rt2) i = j;
           else if (i == -1) i = j;
           if (mo >= rt1) triggered = true;
-        } else if (mo - (e - eprev) < rt2) {
+        } else if ((near = near || __builtin_fabsf((mo - (e - eprev)) - rt2) <= gd), mo - (e - eprev) < rt2) {
           // region i..j closes here: flush this block's prefix sums, then is_multidomain_region()
           if (lane <= r) { pb[j0 + lane] = keepb; pe[j0 + lane] = keepe; }
           __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");      // producer and consumer are this wavefront
@@ -484,6 +492,7 @@ __global__ void __launch_bounds__(256) regions_kernel(const ArgRef ref)
           float mx = -1.0f;
           for (int z = i + lane; z <= j; z += 64) mx = fmaxf(mx, fminf(pe[z] - e0, bj - pb[z - 1]));
           mx = wave_max_f32(mx);
+          near = near || __builtin_fabsf(mx - rt3) <= gd;
           if (nreg < kRegionCap && lane == 0) { regs[nreg * 3 + 0] = i; regs[nreg * 3 + 1] = j; regs[nreg * 3 + 2] = (mx >= rt3) ? 1 : 0; }
           ++nreg;
           i = -1; triggered = false;
@@ -493,7 +502,7 @@ __global__ void __launch_bounds__(256) regions_kernel(const ArgRef ref)
     }
     if (lane == 0) {
       a.out_nexpected[it] = b;
-      a.out_n[it] = __builtin_isinf(scaleproduct) ? -1 : (nreg > kRegionCap ? -2 : nreg);
+      a.out_n[it] = __builtin_isinf(scaleproduct) ? -1 : (nreg > kRegionCap ? -2 : ((near && gd > 0.0f) ? -3 : nreg));
     }
   }
 }
@@ -1080,6 +1089,8 @@ static int fill_survivor_args(CascadeRun &r, int first, int n, bool retry, int n
     ra.xmx_off = xmx_off; ra.scratch = ws->xmx_s;
     ra.out_regs = reg_out; ra.out_n = reg_out + (size_t) cap * kRegionCap * 3;
     ra.out_nexpected = reinterpret_cast<float *>(ra.out_n + cap);
+    ra.guard = (r.cfg.oa_guard > 0.0f && !r.cfg.long_targets) ? 2.0e-5f : 0.0f;
+    if (debug_opt(OPT_REGION_GUARD_PPM) >= 0 && !r.cfg.long_targets) ra.guard = 1.0e-6f * (float) debug_opt(OPT_REGION_GUARD_PPM);      // test seam: widen it (or 0: off)
     la.reg = ra;
   }
   return P7X_OK;

@@ -374,6 +374,15 @@ int host_finish_batch(const p7x_pipeline_cfg &cfg_in, const std::vector<FinishIt
       return domaindef_by_posterior_heuristics(p, dsq, tg.len[t], it.fwd_xmx + it.xmx_off[i], it.bck_xmx + it.xmx_off[i], cfg_in.seed, reseed, dd, defer, i);
     const DeviceRegions *dregs = it.regions;
     const int nr = dregs->n[i];
+    if (nr == -3) {
+      // the device's region scan met a threshold comparison inside its guard band: this target's parser rows again, in
+      // upstream's summation order, and the scan on those (p7x_domaindef.cpp)
+      thread_local std::vector<float> ufx, ubx;
+      const int pst = parser_rows_upstream(p, dsq, tg.len[t], ufx, ubx);
+      if (pst != P7X_OK) return pst;
+      dd.nregion_redone = 1;
+      return domaindef_by_posterior_heuristics(p, dsq, tg.len[t], ufx.data(), ubx.data(), cfg_in.seed, reseed, dd, defer, i);
+    }
     if (nr < 0) return P7X_ERANGE;
     Region regs[256];
     const int32_t *src = dregs->regs + (dregs->start ? (size_t) dregs->start[i] : (size_t) i * dregs->cap) * 3;
@@ -509,7 +518,7 @@ int host_finish_batch(const p7x_pipeline_cfg &cfg_in, const std::vector<FinishIt
     p7x_tophits &th = *ths[(size_t) q_of[(size_t) f]];
     th.oa_redone += dds[(size_t) f].nneartie;
     for (int b = 0; b < 8; ++b) th.oa_why[b] += dds[(size_t) f].neartie_why[b];
-    th.ens_device += dds[(size_t) f].nens_device; th.ens_redone += dds[(size_t) f].nens_redone;
+    th.ens_device += dds[(size_t) f].nens_device; th.ens_redone += dds[(size_t) f].nens_redone; th.region_redone += dds[(size_t) f].nregion_redone;
   }
   host_prof_dump();
   if (failed.load() != 0) { set_error("domain definition workflow failure"); return failed.load(); }
@@ -1092,9 +1101,10 @@ int p7x_tophits_get_guard_counts(const p7x_tophits *th, int64_t *f3_dropped, int
   return P7X_OK;
 }
 
-int p7x_tophits_get_ensemble_counts(const p7x_tophits *th, int64_t *sampled_on_device, int64_t *redone_by_host)
+int p7x_tophits_get_ensemble_counts(const p7x_tophits *th, int64_t *sampled_on_device, int64_t *redone_by_host, int64_t *region_scans_redone)
 {
   if (!th) return P7X_EINVAL;
+  if (region_scans_redone) *region_scans_redone = th->region_redone;
   if (sampled_on_device) *sampled_on_device = th->ens_device;
   if (redone_by_host) *redone_by_host = th->ens_redone;
   return P7X_OK;

@@ -1688,9 +1688,10 @@ class TopHits:
         list, device envelopes the optimal-accuracy near-tie guard had the host twin repeat."""
         a, b, why = C.c_int64(0), C.c_int64(0), (C.c_int64 * 8)()
         _lib.lib().p7x_tophits_get_guard_counts(self._handle, C.byref(a), C.byref(b), why)
-        e0, e1 = C.c_int64(0), C.c_int64(0)
-        _lib.lib().p7x_tophits_get_ensemble_counts(self._handle, C.byref(e0), C.byref(e1))
+        e0, e1, e2 = C.c_int64(0), C.c_int64(0), C.c_int64(0)
+        _lib.lib().p7x_tophits_get_ensemble_counts(self._handle, C.byref(e0), C.byref(e1), C.byref(e2))
         return {"f3_dropped": int(a.value), "oa_redone": int(b.value), "ens_device": int(e0.value), "ens_redone": int(e1.value),
+                "region_redone": int(e2.value),
                 "oa_why": dict(zip(("match", "insert", "delete", "c_from_e", "j_from_e", "end_cell", "begin", "pp_digit"), map(int, why)))}
 
     @property

@@ -84,3 +84,27 @@ def test_multi_domain_targets_against_the_oracle(oracle, model):
     assert st["single_diff"] == 0 and st["ens_same"] == st["ens_targets"], st
     g = hits.guard_counts
     assert g["ens_device"] >= 5 and g["ens_redone"] <= max(3, (g["ens_device"] + g["ens_redone"]) // 2), g
+
+
+def test_region_scan_guard_hands_targets_to_the_host_stage_in_upstream_order(oracle):
+    """The device's region scan compares posteriors from its parsers' rows (lane-chunk order) with rt1 / rt2 / rt3; a
+    comparison within 2e-5 of its threshold sends the target to the host stage, which forms the parser rows again in
+    upstream's order and scans those.  Widened to 0.05 through the test seam the guard takes most targets: the result must
+    still be the oracle's, coordinate for coordinate, and equal to the default run's."""
+    from pyhmmer_amd import _lib
+    hmm = load_hmms("PF02826")[0]
+    bg = plan7.Background(hmm.alphabet)
+    block = _homolog_block(hmm, 50, 200, seed=21)
+    loose = dict(E=1e9, domE=1e9, incE=1e9, incdomE=1e9)
+    base = next(iter(hmmer.hmmsearch(hmm, block, **loose)))
+    _lib.set_debug_option("region_guard_ppm", 50000)
+    try:
+        wide = next(iter(hmmer.hmmsearch(hmm, block, **loose)))
+    finally:
+        _lib.set_debug_option("region_guard_ppm", -1)
+    assert wide.guard_counts["region_redone"] >= 50 > base.guard_counts["region_redone"], (wide.guard_counts, base.guard_counts)
+    rec = lambda hits: [(h.name, h.nregions, h.nenvelopes, [(d.env_from, d.env_to, d.alignment.target_from, d.alignment.target_to, d.alignment.hmm_from, d.alignment.hmm_to) for d in h.domains]) for h in hits]
+    assert rec(wide) == rec(base)
+    by_name = {s.name: s for s in block}
+    st = _compare(oracle, hmm, wide, lambda h: np.asarray(by_name[h.name].sequence, dtype=np.uint8), bg)
+    assert st["single_diff"] == 0 and st["ens_same"] == st["ens_targets"], st
