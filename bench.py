@@ -217,7 +217,7 @@ def make_workload(hmm, nseq, L, seed, planted_frac=0.001):
     return flat, offsets, lengths, np.sort(planted)
 
 
-def msv_traffic_bytes(workload_key):
+def msv_traffic_bytes(workload_key, algorithmic_bytes=None):
     """HBM bytes per launch of the dominant kernel from the PMC passes of the same command (rocprofv3 --pmc FETCH_SIZE /
     WRITE_SIZE in separate runs, corrected as MI355X_MICROARCH.md prescribes), as summarised by
     scripts/rocprof_pmc_summary.py into profiles/msv_traffic.json.  None when no measurement of this workload is committed."""
@@ -225,7 +225,10 @@ def msv_traffic_bytes(workload_key):
         rec = json.load(open(ROOT / "profiles" / "msv_traffic.json"))
     except (OSError, ValueError):
         return None
-    return rec.get(workload_key, {}).get("traffic_bytes_per_launch")
+    e = rec.get(workload_key, {})
+    if "traffic_over_algorithmic" in e and algorithmic_bytes is not None:      # many-profile workload: measured over a run's launches as a ratio
+        return int(e["traffic_over_algorithmic"] * algorithmic_bytes)
+    return e.get("traffic_bytes_per_launch")
 
 
 def host_cpus():
@@ -478,7 +481,7 @@ def run_pfam(args, rank, world, local_rank, dist, red_dev, torch, host_threads, 
     out["roofline"] = {
         "kernel": "p7x::msv_tier_kernel<T> (the fast lane-per-target MSV kernel of all lanes of a batch that share a tier of register tiles, p7x_msv.hip)",
         "bound": "hbm", "achieved": round(ach, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 6),
-        "traffic": msv_traffic_bytes(f"pfam:{len(hmms)}x{args.pfam_targets}"),
+        "traffic": msv_traffic_bytes(f"pfam:{len(hmms)}x{args.pfam_targets}", sum_bytes / max(nlaunch, 1e-9)),
         "kernel_ms": round(sum_ms / max(nlaunch, 1e-9), 4), "launches_timed": round(nlaunch, 1),
         "algorithmic_bytes": int(sum_bytes / max(nlaunch, 1e-9)), "queries_per_launch": round(float((w * lanes).sum()) / max(nlaunch, 1e-9), 2),
         "note": "average over the timed region's batches of the batch's largest fast-MSV launch (HIP events on its stream); the MSV "
