@@ -183,6 +183,23 @@ struct Model {
   int Q = 0;
   std::vector<float> st;                            // [8][Q][4] transitions in the striped layout (padding: 0)
   const float *sT(int t) const { return st.data() + (size_t) t * Q * 4; }
+  // [Kp][Q][4] match odds in the striped layout, of whatever rf() currently stands for (rebuilt when that changes: the
+  // long-target path swaps in composition-adjusted odds per envelope)
+  mutable std::vector<float> sr; mutable const float *sr_of = nullptr;
+  const float *sR(int x) const
+  {
+    const float *base = rf(0);
+    if (sr_of != base || sr.size() != (size_t) p->Kp * Q * 4) {
+      sr.assign((size_t) p->Kp * Q * 4, 0.0f);
+      for (int y = 0; y < p->Kp; ++y) {
+        const float *r = rf(y);
+        float *d = sr.data() + (size_t) y * Q * 4;
+        for (int q = 0; q < Q; ++q) for (int z = 0; z < 4; ++z) { const int k = q + 1 + z * Q; if (k <= M) d[q * 4 + z] = r[k]; }
+      }
+      sr_of = base;
+    }
+    return sr.data() + (size_t) x * Q * 4;
+  }
   std::vector<float> rfT;                           // [M+1][kKpad] match odds, residue-minor (null2_by_trace)
   static constexpr int kKpad = 24;
   void prepare_rfT()
@@ -438,23 +455,23 @@ P7X_MULTIVERSION int backward_full_lanes(const Model &om, const uint8_t *dsq, in
 // them).  Every multiplication and addition of the vector code is performed on the same operands in the same order; the
 // rows go to the un-striped Matrix afterwards.  forward_parser_striped() (p7x_longtarget.inc.hpp) is the do_full = FALSE
 // sibling.
-struct V4 { float v[4]; };
-static inline V4 v4_set(float a) { return V4{{ a, a, a, a }}; }
-static inline V4 v4_add(const V4 &a, const V4 &b) { V4 r; for (int z = 0; z < 4; ++z) r.v[z] = a.v[z] + b.v[z]; return r; }
-static inline V4 v4_mul(const V4 &a, const V4 &b) { V4 r; for (int z = 0; z < 4; ++z) r.v[z] = a.v[z] * b.v[z]; return r; }
-static inline V4 v4_shr(const V4 &a) { return V4{{ 0.0f, a.v[0], a.v[1], a.v[2] }}; }        // esl_sse_rightshift_ps(a, 0)
-static inline V4 v4_shl(const V4 &a) { return V4{{ a.v[1], a.v[2], a.v[3], 0.0f }}; }        // esl_sse_leftshift_ps(a, 0)
-static inline float v4_hsum(const V4 &a) { return (a.v[0] + a.v[1]) + (a.v[2] + a.v[3]); }   // esl_sse_hsum_ps
+typedef float V4 __attribute__((vector_size(16), aligned(4)));      // four stripes side by side (the compiler's own vector type: one SIMD operation per vector operation)
+static inline V4 v4_set(float a) { return V4{ a, a, a, a }; }
+static inline V4 v4_add(const V4 &a, const V4 &b) { return a + b; }
+static inline V4 v4_mul(const V4 &a, const V4 &b) { return a * b; }
+static inline V4 v4_shr(const V4 &a) { const V4 z = { 0.0f, 0.0f, 0.0f, 0.0f }; return __builtin_shufflevector(a, z, 4, 0, 1, 2); }   // esl_sse_rightshift_ps(a, 0)
+static inline V4 v4_shl(const V4 &a) { const V4 z = { 0.0f, 0.0f, 0.0f, 0.0f }; return __builtin_shufflevector(a, z, 1, 2, 3, 4); }   // esl_sse_leftshift_ps(a, 0)
+static inline float v4_hsum(const V4 &a) { return (a[0] + a[1]) + (a[2] + a[3]); }            // esl_sse_hsum_ps
 struct StripedRow { std::vector<V4> m, d, i; void resize(int Q) { m.resize((size_t) Q); d.resize((size_t) Q); i.resize((size_t) Q); } };
 static inline void unstripe(const StripedRow &r, int Q, int M, float *mc, float *ic, float *dc)
 {
   for (int q = 0; q < Q; ++q)
-    for (int z = 0; z < 4; ++z) { const int k = q + 1 + z * Q; if (k <= M) { mc[k] = r.m[q].v[z]; ic[k] = r.i[q].v[z]; dc[k] = r.d[q].v[z]; } }
+    for (int z = 0; z < 4; ++z) { const int k = q + 1 + z * Q; if (k <= M) { mc[k] = r.m[q][z]; ic[k] = r.i[q][z]; dc[k] = r.d[q][z]; } }
   mc[0] = ic[0] = dc[0] = 0.0f; mc[M + 1] = ic[M + 1] = dc[M + 1] = 0.0f;
 }
 static inline void stripe_emissions(const float *rf, int Q, int M, std::vector<V4> &rv)
 {
-  for (int q = 0; q < Q; ++q) for (int z = 0; z < 4; ++z) { const int k = q + 1 + z * Q; rv[(size_t) q].v[z] = k <= M ? rf[k] : 0.0f; }
+  for (int q = 0; q < Q; ++q) for (int z = 0; z < 4; ++z) { const int k = q + 1 + z * Q; rv[(size_t) q][z] = k <= M ? rf[k] : 0.0f; }
 }
 
 struct StripedScratch { StripedRow a, b; std::vector<V4> rv; };     // per thread, owned by the dispatchers below (no thread_local inside a cloned function)
@@ -466,8 +483,7 @@ P7X_MULTIVERSION int forward_full_upstream(const Model &om, const uint8_t *dsq, 
            *tDM = reinterpret_cast<const V4 *>(om.sT(3)), *tMD = reinterpret_cast<const V4 *>(om.sT(4)), *tMI = reinterpret_cast<const V4 *>(om.sT(5)),
            *tII = reinterpret_cast<const V4 *>(om.sT(6)), *tDD = reinterpret_cast<const V4 *>(om.sT(7));
   StripedRow &row = ss.a;
-  std::vector<V4> &rv = ss.rv;
-  row.resize(Q); rv.resize((size_t) Q);
+  row.resize(Q);
   const V4 zero = v4_set(0.0f);
   for (int q = 0; q < Q; ++q) row.m[q] = row.d[q] = row.i[q] = zero;
   { float *m0 = ox.M_(0), *i0 = ox.I_(0), *d0 = ox.D_(0); for (int k = 0; k <= M + 1; ++k) m0[k] = i0[k] = d0[k] = 0.0f; }
@@ -475,7 +491,7 @@ P7X_MULTIVERSION int forward_full_upstream(const Model &om, const uint8_t *dsq, 
   ox.X(0, xE_) = xE; ox.X(0, xN_) = xN; ox.X(0, xJ_) = xJ; ox.X(0, xB_) = xB; ox.X(0, xC_) = xC; ox.X(0, xS_) = 1.0f;
   ox.totscale = 0.0f; ox.own_scales = true;
   for (int r = 1; r <= L; ++r) {
-    stripe_emissions(om.rf(dsq[r]), Q, M, rv);
+    const V4 *rv = reinterpret_cast<const V4 *>(om.sR(dsq[r]));
     V4 dcv = zero, xEv = zero;
     const V4 xBv = v4_set(xB);
     V4 mpv = v4_shr(row.m[Q - 1]), dpv = v4_shr(row.d[Q - 1]), ipv = v4_shr(row.i[Q - 1]);
@@ -507,7 +523,7 @@ P7X_MULTIVERSION int forward_full_upstream(const Model &om, const uint8_t *dsq, 
         dcv = v4_shr(dcv);
         for (int q = 0; q < Q; ++q) {
           const V4 sv = v4_add(dcv, row.d[q]);
-          for (int z = 0; z < 4; ++z) grew |= sv.v[z] > row.d[q].v[z];
+          for (int z = 0; z < 4; ++z) grew |= sv[z] > row.d[q][z];
           row.d[q] = sv;
           dcv = v4_mul(dcv, tDD[q]);
         }
@@ -544,8 +560,7 @@ P7X_MULTIVERSION int backward_full_upstream(const Model &om, const uint8_t *dsq,
            *tDM = reinterpret_cast<const V4 *>(om.sT(3)), *tMD = reinterpret_cast<const V4 *>(om.sT(4)), *tMI = reinterpret_cast<const V4 *>(om.sT(5)),
            *tII = reinterpret_cast<const V4 *>(om.sT(6)), *tDD = reinterpret_cast<const V4 *>(om.sT(7));
   StripedRow &rowa = ss.a, &rowb = ss.b;
-  std::vector<V4> &rv = ss.rv;
-  rowa.resize(Q); rowb.resize(Q); rv.resize((size_t) Q);
+  rowa.resize(Q); rowb.resize(Q);
   StripedRow *cur = &rowa, *nxt = &rowb;          // row i being built, row i + 1
   const V4 zero = v4_set(0.0f);
   bck.own_scales = false;
@@ -586,7 +601,7 @@ P7X_MULTIVERSION int backward_full_upstream(const Model &om, const uint8_t *dsq,
   }
   for (int r = L - 1; r >= 1; --r) {
     std::swap(cur, nxt);
-    stripe_emissions(om.rf(dsq[r + 1]), Q, M, rv);
+    const V4 *rv = reinterpret_cast<const V4 *>(om.sR(dsq[r + 1]));
     V4 tmmv = v4_shl(tMM[0]), timv = v4_shl(tIM[0]), tdmv = v4_shl(tDM[0]);      // the transitions INTO the node after the stripe's last
     V4 mpv = v4_shl(v4_mul(nxt->m[0], rv[0]));                                   // M(i+1, k+1) e(x_{i+1}, k+1)
     V4 xBv = zero;
@@ -619,7 +634,7 @@ P7X_MULTIVERSION int backward_full_upstream(const Model &om, const uint8_t *dsq,
     unstripe(*cur, Q, M, bck.M_(r), bck.I_(r), bck.D_(r));
   }
   {
-    stripe_emissions(om.rf(dsq[1]), Q, M, rv);
+    const V4 *rv = reinterpret_cast<const V4 *>(om.sR(dsq[1]));
     V4 xBv = zero;
     for (int q = Q - 1; q >= 0; --q) xBv = v4_add(xBv, v4_mul(v4_mul(cur->m[q], rv[(size_t) q]), tBM[q]));
     xB = v4_hsum(xBv);
@@ -1231,7 +1246,7 @@ int rescore_isolated_domain(const Profile &p, Model &om, const uint8_t *dsq, int
   // afterwards) and, with null2 on, against emissions re-derived for a background mixed with the envelope's composition.
   auto lt_setup = [&]() {
     om.configure(false, Ld);
-    if (lt->do_null2) { reparameterize(p, *lt, dsq, L, i, j, rf_lt); om.rf_over = rf_lt.data(); }
+    if (lt->do_null2) { reparameterize(p, *lt, dsq, L, i, j, rf_lt); om.rf_over = rf_lt.data(); om.sr_of = nullptr; }     // (same buffer, new odds: the striped copy is stale)
   };
   auto align = [&]() -> int {
     { ProfScope ps(5); forward_full(om, dsq + i - 1, Ld, ws.fwd, &envsc); }

@@ -1089,7 +1089,8 @@ static int fill_survivor_args(CascadeRun &r, int first, int n, bool retry, int n
     ra.xmx_off = xmx_off; ra.scratch = ws->xmx_s;
     ra.out_regs = reg_out; ra.out_n = reg_out + (size_t) cap * kRegionCap * 3;
     ra.out_nexpected = reinterpret_cast<float *>(ra.out_n + cap);
-    ra.guard = (r.cfg.oa_guard > 0.0f && !r.cfg.long_targets) ? 2.0e-5f : 0.0f;
+    ra.guard = (r.cfg.oa_guard > 0.0f && !r.cfg.long_targets && debug_opt(OPT_HOST_ORDER) <= 0) ? 2.0e-5f : 0.0f;      // (not when the host code is
+                                                                          // asked for the device's order: the seam that validates the kernels against their twin)
     if (debug_opt(OPT_REGION_GUARD_PPM) >= 0 && !r.cfg.long_targets) ra.guard = 1.0e-6f * (float) debug_opt(OPT_REGION_GUARD_PPM);      // test seam: widen it (or 0: off)
     la.reg = ra;
   }
