@@ -645,6 +645,7 @@ def main():
                          "pipeline's fill and drain (about two query times) then weigh as little in a 20-step run as in a long one")
     ap.add_argument("--batch", type=int, default=0, help="headline workload: queries per device batch (0: the library's own choice)")
     ap.add_argument("--oa-guard", type=float, default=None, help="A/B: the optimal-accuracy near-tie guard (default: the library's; 0 switches it off)")
+    ap.add_argument("--ens-guard", type=float, default=None, help="A/B: the near-threshold guard of the sampled tracebacks (default: the library's; 0 switches it off)")
     ap.add_argument("--debug-option", action="append", default=[], metavar="NAME=VALUE",
                     help="diagnostics: set a knob of the library's test seam (p7x_debug_set_option), e.g. trace_finish=1")
     ap.add_argument("--host-ensembles", action="store_true", help="A/B: the stochastic traceback ensembles on the host workers instead of the device")
@@ -745,6 +746,8 @@ def main():
 
     qps = max(1, args.queries_per_step)
     pli_opts = {} if args.oa_guard is None else {"oa_guard": args.oa_guard}
+    if args.ens_guard is not None:
+        pli_opts["ens_guard"] = args.ens_guard
     if args.host_ensembles:
         pli_opts["host_ensembles"] = True
     lanes_per_launch = args.batch or hmmer._auto_batch(db if inproc > 1 else hmmer.ShardedDatabase.from_database(db), hmm.M)

@@ -160,7 +160,8 @@ static void build_host_image(const Profile &p, DevProfile *d, HostImage &img)
       for (int k = 1; k <= p.M; ++k)
         for (int x = 0; x < p.Kp; ++x) me[(size_t) x * Mpad + pos[k]] = (int16_t) ((int) p.bias_b - (int) p.rb[(size_t) x * (p.M + 1) + k]);
       img.add(&d->msvw_emis, me);
-      if (d->msvR <= 0 && C % 4 == 0 && C <= 32) {     // no lane kernel for this length: packed pairs for msv_wavepk_kernel, lane z owns nodes zC+1 .. zC+C
+      if ((d->msvR <= 0 || d->msvK >= 8) && C % 4 == 0 && C <= 32) {     // M > 1021 (no lane kernel, or the eight-lane one: small blocks and the longest
+                                                                        // targets of large ones still go one per wavefront): packed pairs for msv_wavepk_kernel, lane z owns nodes zC+1 .. zC+C
         const int P2 = C / 4;
         std::vector<uint32_t> pk((size_t) kTabRows * P2 * 64 * 2);
         auto em = [&](int x, int k) -> uint32_t { return (uint32_t) (uint16_t) (int16_t) ((x < p.Kp && k <= p.M) ? (int) p.bias_b - (int) p.rb[(size_t) x * (p.M + 1) + k] : kNegPad); };

@@ -40,7 +40,7 @@ inline unsigned lane_grid(long want, long resident, int nlanes)
 
 // ---- MSV (p7x_msv.hip)
 struct MsvArgs {
-  const uint32_t *tab;      // [2][kTabRows][S] dwords: parity 0 = "odd" alignment, parity 1 = "even"
+  const uint32_t *tab;      // [2][kTabRows][S] dwords: parity 0 = "odd" alignment, parity 1 = "even"; K = 8: [kTabRows][S], one alignment
   const uint4 *tiles;
   const int64_t *grp_off;
   const int32_t *grp_nblk;
@@ -56,7 +56,7 @@ struct MsvArgs {
   const int *group_list; const int *group_count;   // exact kernel: optional list of groups to process
   int R;                    // the lane's register tile (read by the tier kernels, which serve several tiles in one launch)
 };
-int  msv_pick(int M, int *K);       // row registers per lane and lanes per target (K = 1, 2, 4) of the lane kernels; -1: none fits
+int  msv_pick(int M, int *K);       // row registers per lane and lanes per target (K = 1, 2, 4, 8) of the lane kernels; -1: none fits
 int  msv_stride(int R, int K);     // dwords per table row
 void msv_build_tables(const Profile &p, int R, int K, std::vector<uint32_t> &out);
 // fast kernel over <main> followed by the exact kernel over each lane's list of ambiguous groups (<amb>: records with
@@ -65,7 +65,7 @@ int  msv_launch(int R, int K, const ArgRun<MsvArgs> &main, const ArgRun<MsvArgs>
 // The fast kernel for the lanes of several register tiles in one launch (half-float flavour), and the exact kernel over the
 // ambiguous groups of one tile's lanes afterwards.  msv_tier: the tier a tile belongs to (0..kMsvTiers-1); lanes of a
 // launch must share it.
-constexpr int kMsvTiers = 5;
+constexpr int kMsvTiers = 6;
 int  msv_tier(int R, int K);
 int  msv_tier_launch(int tier, const ArgRun<MsvArgs> &main, int num_cu, hipStream_t st);
 int  msv_exact_launch(int R, int K, const ArgRun<MsvArgs> &amb, int num_cu, hipStream_t st);

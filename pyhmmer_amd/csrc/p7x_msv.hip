@@ -84,10 +84,19 @@ constexpr int msv_lane_stride_c(int R, int K)
   return s;
 }
 constexpr int msv_row_stride_c(int R, int K) { return K * msv_lane_stride_c(R, K); }      // dwords per table row
+// K = 8 (models of 1,022 - 2,048 nodes): two parity tables of such a model do not fit a CU's LDS, so these tiles keep ONE
+// table and ONE register alignment -- register j = cells (2j + 1, 2j + 2) in every row -- and move the row down the
+// diagonal with a v_alignbit_b32 per register instead (the "uniform" row, RowChunks<..., U = true>): 2.5 operations per
+// register where the parity trick spends 1.5, and a 32-bit one among them (issued at twice the packed rate) -- against
+// the four packed operations per register, the wavefront reduction per block of rows and the one target per wavefront
+// of msv_wavepk_kernel, which took these models until round 6 (2.8 % of a Pfam-shaped library's cells, 18 % of its MSV
+// kernel time: profiles/r06_msv_k8.txt).
+constexpr bool msv_uniform_c(int K) { return K >= 8; }
+constexpr int msv_parities_c(int K) { return msv_uniform_c(K) ? 1 : 2; }
 // the even-parity table starts kTabRows rows behind the odd one: as an instruction immediate while that fits 16 bits (K = 1),
 // else as part of the lane's address
 constexpr int msv_even_imm_c(int R, int K) { return K == 1 ? kTabRows * msv_row_stride_c(R, K) * 4 : 0; }
-constexpr int msv_even_add_c(int R, int K) { return K == 1 ? 0 : kTabRows * msv_row_stride_c(R, K) * 4; }
+constexpr int msv_even_add_c(int R, int K) { return (K == 1 || msv_uniform_c(K)) ? 0 : kTabRows * msv_row_stride_c(R, K) * 4; }
 constexpr int msv_block_c(int K) { return K == 1 ? 256 : 512; }                            // threads per block: K > 1 tables are big, more
                                                                                            // wavefronts share one copy
 // maximum over the K lanes of a target (K = 1, 2, 4, 8; lanes of a target are consecutive)
@@ -143,9 +152,11 @@ __device__ __forceinline__ void lds_wait2(Chunk &c)
 
 // One DP row over the register file: chunks of four register pairs (8 registers, 16 cells); when R is not a multiple
 // of 8 the top chunk holds two pairs.
-template <int R, int TB, bool ODD, int T, int FAST = 0>   // TB = byte offset of the row's parity table that goes into the
+template <int R, int TB, bool ODD, int T, int FAST = 0, bool U = false>   // TB = byte offset of the row's parity table that goes into the
 struct RowChunks {                                        // instructions' immediate; T = chunk index being computed;
                                                           // FAST: 0 = the recurrence as written, 1 = floored int16, 2 = floored half
+                                                          // U: the uniform row (one alignment, one table; walked downwards: ODD = true)
+  static_assert(!U || ODD, "the uniform row reads the register below: it is walked from the top register down");
   static_assert(R % 4 == 0, "a row is walked in chunks of 8 registers and a last one of 4: the register count must be a multiple of 4");
   static constexpr int NT = (R + 7) / 8;
   static constexpr int TBASE = TB;
@@ -161,7 +172,29 @@ struct RowChunks {                                        // instructions' immed
   template <int JJ>
   static __device__ __forceinline__ void pair(s2 (&v)[R], const uint2 e, const s2 xB, const s2 carry, s2 &accA, s2 &accB)
   {
-    if constexpr (FAST == 2) {  // floored halves: as below, and one maximum3 takes both registers of the pair
+    if constexpr (U) {          // register j <- (high cell of register j - 1, low cell of register j) of the previous row, + emissions
+      s2 pred = carry;
+      if constexpr (JJ > 0) pred = v[2 * JJ - 1];
+      const s2 d1 = as_s2(__builtin_amdgcn_alignbit(as_u32(v[2 * JJ + 1]), as_u32(v[2 * JJ]), 16));
+      const s2 d0 = as_s2(__builtin_amdgcn_alignbit(as_u32(v[2 * JJ]), as_u32(pred), 16));
+      if constexpr (FAST == 2) {
+        v[2 * JJ + 1] = h_adds(d1, as_s2(e.y));
+        v[2 * JJ] = h_adds(d0, as_s2(e.x));
+        if constexpr (JJ & 1) { accB = h_max3(accB, v[2 * JJ], v[2 * JJ + 1]); asm volatile("" : "+v"(accB)); }
+        else { accA = h_max3(accA, v[2 * JJ], v[2 * JJ + 1]); asm volatile("" : "+v"(accA)); }
+      } else if constexpr (FAST == 1) {
+        v[2 * JJ + 1] = pk_adds(d1, as_s2(e.y));
+        v[2 * JJ] = pk_adds(d0, as_s2(e.x));
+        accA = pk_max(accA, v[2 * JJ]);
+        accB = pk_max(accB, v[2 * JJ + 1]);
+        asm volatile("" : "+v"(accA), "+v"(accB));
+      } else {
+        v[2 * JJ + 1] = pk_max(d1, xB) + as_s2(e.y);
+        accA = pk_max(accA, v[2 * JJ + 1]);
+        v[2 * JJ] = pk_max(d0, xB) + as_s2(e.x);
+        accB = pk_max(accB, v[2 * JJ]);
+      }
+    } else if constexpr (FAST == 2) {  // floored halves: as below, and one maximum3 takes both registers of the pair
       if constexpr (ODD) {
         v[2 * JJ + 1] = h_adds(v[2 * JJ], as_s2(e.y));
         s2 pred = carry;
@@ -231,7 +264,7 @@ struct RowChunks {                                        // instructions' immed
         pair<4 * T + 3>(v, cur.e3, xB, carry, accA, accB);
       }
     }
-    if constexpr (!last) RowChunks<R, TB, ODD, TN, FAST>::run(v, addr, nxt, cur, xB, carry, accA, accB);
+    if constexpr (!last) RowChunks<R, TB, ODD, TN, FAST, U>::run(v, addr, nxt, cur, xB, carry, accA, accB);
   }
 };
 
@@ -240,13 +273,14 @@ __device__ __forceinline__ void msv_row(s2 (&v)[R], uint32_t addr, int h, s2 &xB
                                         const s2 basev, const s2 tecv, const s2 tjbmv, const s2 zerov)
 {
   constexpr int NT = (R + 7) / 8;
-  constexpr int T0 = ODD ? NT - 1 : 0;
-  constexpr int TB = ODD ? 0 : msv_even_imm_c(R, K);
-  const s2 carry = ODD ? carry_in<K>(v[R - 1], xB, h) : xB;
+  constexpr bool U = msv_uniform_c(K), DOWN = ODD || U;
+  constexpr int T0 = DOWN ? NT - 1 : 0;
+  constexpr int TB = DOWN ? 0 : msv_even_imm_c(R, K);
+  const s2 carry = DOWN ? carry_in<K>(v[R - 1], xB, h) : xB;
   Chunk ca, cb;
-  RowChunks<R, TB, ODD, T0>::template issue<T0>(addr, ca);
+  RowChunks<R, TB, DOWN, T0, 0, U>::template issue<T0>(addr, ca);
   s2 accA = splat(kNegPad), accB = accA;
-  RowChunks<R, TB, ODD, T0>::run(v, addr, ca, cb, xB, carry, accA, accB);
+  RowChunks<R, TB, DOWN, T0, 0, U>::run(v, addr, ca, cb, xB, carry, accA, accB);
   s2 m = pk_max(accA, accB);
   m = pk_max(m, swap_halves(m));
   m = target_max<K>(m);
@@ -272,7 +306,7 @@ __global__ void __launch_bounds__(msv_block_c(K)) msv_kernel(const ArgRef ref)
   const int nitems = (a.group_list ? *a.group_count : a.ngroups - a.group_first) * K;
   if (nitems <= 0 || *a.counter >= nitems) return;          // nothing (left) for this lane: skip the table load
   {
-    constexpr int n4 = (2 * kTabRows * S) / 4;
+    constexpr int n4 = (msv_parities_c(K) * kTabRows * S) / 4;
     const uint4 *src = reinterpret_cast<const uint4 *>(a.tab);
     uint4 *dst = reinterpret_cast<uint4 *>(lds);
     for (int i = threadIdx.x; i < n4; i += BLK) dst[i] = src[i];
@@ -355,7 +389,7 @@ __device__ __forceinline__ void msv_fast_body(const MsvArgs &a, uint32_t *lds)
   const int nitems = (a.ngroups - a.group_first) * K;
   if (*a.counter >= nitems) return;            // this lane's groups are all taken: skip the table load
   {
-    constexpr int n4 = (2 * kTabRows * S) / 4;
+    constexpr int n4 = (msv_parities_c(K) * kTabRows * S) / 4;
     const uint4 *src = reinterpret_cast<const uint4 *>(a.tab);
     uint4 *dst = reinterpret_cast<uint4 *>(lds);
     for (int i = threadIdx.x; i < n4; i += BLK) {
@@ -415,7 +449,12 @@ __device__ __forceinline__ void msv_fast_body(const MsvArgs &a, uint32_t *lds)
 #pragma unroll
         for (int half = 0; half < 2; ++half) {
           Chunk ca, cb;
-          if (half == 0) {        // odd row
+          if constexpr (msv_uniform_c(K)) {      // one kind of row
+            const uint32_t addr = (half == 0 ? x0 : x1) * (uint32_t) (S * 4) + lane_col;
+            const s2 carry = carry_in<K>(v[R - 1], floorv, it.h);
+            RowChunks<R, 0, true, NT - 1, MODE, true>::template issue<NT - 1>(addr, ca);
+            RowChunks<R, 0, true, NT - 1, MODE, true>::run(v, addr, ca, cb, floorv, carry, accA, accB);
+          } else if (half == 0) {        // odd row
             const uint32_t addr = x0 * (uint32_t) (S * 4) + lane_col;
             const s2 carry = carry_in<K>(v[R - 1], floorv, it.h);
             RowChunks<R, 0, true, NT - 1, MODE>::template issue<NT - 1>(addr, ca);
@@ -463,9 +502,9 @@ __global__ void __launch_bounds__(msv_block_c(K), msv_min_blocks_c(R, K)) msv_fa
 // queues beside the other stages' kernels -- the device ran the MSV stage at a quarter of its rate.  A tier -- the tiles
 // that share a block size and an occupancy -- is one launch that fills the device.  The dynamic LDS of the launch is that
 // of its largest tile; the occupancy that the tier promises (4 / 3 / 2 blocks per CU) holds for it.
-//   tier 0: K = 1, R <= 92;  1: K = 1, R <= 136;  2: K = 1, R <= 224;  3: K = 2;  4: K = 4
+//   tier 0: K = 1, R <= 92;  1: K = 1, R <= 136;  2: K = 1, R <= 224;  3: K = 2;  4: K = 4;  5: K = 8 (uniform rows)
 constexpr int msv_tier_block_c(int T) { return T <= 2 ? 256 : 512; }
-constexpr int msv_tier_min_blocks_c(int T) { return T == 0 ? 4 : (T == 1 ? 3 : 2); }
+constexpr int msv_tier_min_blocks_c(int T) { return T == 0 ? 4 : (T == 1 ? 3 : 2); }      // (waves per SIMD the register budget must allow)
 
 template <int TIER>
 __global__ void __launch_bounds__(msv_tier_block_c(TIER), msv_tier_min_blocks_c(TIER)) msv_tier_kernel(const ArgRef ref)
@@ -499,9 +538,15 @@ __global__ void __launch_bounds__(msv_tier_block_c(TIER), msv_tier_min_blocks_c(
       P7X_TILE(176, 2) P7X_TILE(184, 2) P7X_TILE(192, 2) P7X_TILE(200, 2) P7X_TILE(208, 2) P7X_TILE(216, 2) P7X_TILE(224, 2)
       default: break;
     }
-  } else {
+  } else if constexpr (TIER == 4) {
     switch (R) {
       P7X_TILE(120, 4) P7X_TILE(128, 4)
+      default: break;
+    }
+  } else {
+    switch (R) {
+      P7X_TILE(64, 8) P7X_TILE(72, 8) P7X_TILE(80, 8) P7X_TILE(88, 8) P7X_TILE(96, 8) P7X_TILE(104, 8) P7X_TILE(112, 8)
+      P7X_TILE(120, 8) P7X_TILE(128, 8)
       default: break;
     }
   }
@@ -516,6 +561,7 @@ static const int kRList[] = { 8, 12, 16, 20, 24, 28, 32, 36, 40, 44, 48, 52, 56,
                               112, 116, 120, 124, 128, 132, 136, 140, 144, 148, 152, 156, 160, 176, 192, 208, 224 };
 static const int kRList2[] = { 120, 128, 136, 144, 152, 160, 168, 176, 184, 192, 200, 208, 216, 224 };
 static const int kRList4[] = { 120, 128 };
+static const int kRList8[] = { 64, 72, 80, 88, 96, 104, 112, 120, 128 };      // uniform rows: register j = cells (2j + 1, 2j + 2)
 
 int msv_pick(int M, int *K)
 {
@@ -526,6 +572,9 @@ int msv_pick(int M, int *K)
   for (int r : kRList2) if (2 * r >= need) return r;
   *K = 4;
   for (int r : kRList4) if (4 * r >= need) return r;
+  *K = 8;
+  if (debug_opt(OPT_MSV_K8) != 0)           // (0: A/B and test seam -- these models one target per wavefront, as until round 6)
+    for (int r : kRList8) if (8 * r >= (M + 1) / 2) return r;
   *K = 0;
   return -1;
 }
@@ -538,6 +587,7 @@ static int row_stride(int R, int K)
   return K * rs;
 }
 int msv_stride(int R, int K) { return row_stride(R, K); }
+int msv_table_dwords(int R, int K) { return msv_parities_c(K) * kTabRows * row_stride(R, K); }
 
 // Build the two parity tables from un-striped biased costs rb[x][k] (k = 1..M):
 //   signed emission s[x][k] = bias - rb[x][k]  (the value sbv holds, impl_sse/p7_oprofile.pxd: sbv)
@@ -547,12 +597,21 @@ int msv_stride(int R, int K) { return row_stride(R, K); }
 void msv_build_tables(const Profile &p, int R, int K, std::vector<uint32_t> &out)
 {
   const int S = row_stride(R, K), Rs = S / K;
-  out.assign((size_t) 2 * kTabRows * S, 0);
+  out.assign((size_t) msv_table_dwords(R, K), 0);
   auto sval = [&](int x, int k) -> int {
     if (x >= p.Kp || k < 1 || k > p.M) return kNegPad;
     return (int) p.bias_b - (int) p.rb[(size_t) x * (p.M + 1) + k];
   };
   auto pack = [](int lo, int hi) -> uint32_t { return ((uint32_t) (uint16_t) (int16_t) lo) | ((uint32_t) (uint16_t) (int16_t) hi << 16); };
+  if (msv_uniform_c(K)) {         // one table, register j: (s[2j+1], s[2j+2])
+    for (int x = 0; x < kTabRows; ++x)
+      for (int h = 0; h < K; ++h)
+        for (int r = 0; r < Rs; ++r) {
+          const int j = h * R + r;
+          out[(size_t) x * S + (size_t) h * Rs + r] = r < R ? pack(sval(x, 2 * j + 1), sval(x, 2 * j + 2)) : pack(kNegPad, kNegPad);
+        }
+    return;
+  }
   for (int x = 0; x < kTabRows; ++x)
     for (int h = 0; h < K; ++h)
       for (int r = 0; r < Rs; ++r) {
@@ -567,7 +626,7 @@ template <int R, int K>
 static int launch_RK(const ArgRun<MsvArgs> &main, const ArgRun<MsvArgs> *amb, int num_cu, hipStream_t st, bool amb_only = false)
 {
   constexpr int BLK = msv_block_c(K);
-  const size_t lds_bytes = (size_t) 2 * kTabRows * msv_row_stride_c(R, K) * 4;
+  const size_t lds_bytes = (size_t) msv_parities_c(K) * kTabRows * msv_row_stride_c(R, K) * 4;
   // occupancy and the LDS opt-in are per kernel instantiation: looked up once
   struct Info { int per_cu_exact = 0, per_cu_fast = 0, per_cu_half = 0; bool ok = false; };
   static std::map<int, Info> info_by_device;       // ... and per device (the opt-in is an attribute of the kernel ON a device)
@@ -634,13 +693,13 @@ int msv_exact_launch(int R, int K, const ArgRun<MsvArgs> &amb, int num_cu, hipSt
 int msv_tier(int R, int K)
 {
   if (K == 1) return R <= 92 ? 0 : (R <= 136 ? 1 : 2);
-  return K == 2 ? 3 : 4;
+  return K == 2 ? 3 : (K == 4 ? 4 : 5);
 }
 
 template <int TIER>
 static int launch_tier(const ArgRun<MsvArgs> &main, int num_cu, hipStream_t st)
 {
-  constexpr int BLK = msv_tier_block_c(TIER), K = TIER <= 2 ? 1 : (TIER == 3 ? 2 : 4);
+  constexpr int BLK = msv_tier_block_c(TIER), K = TIER <= 2 ? 1 : (TIER == 3 ? 2 : (TIER == 4 ? 4 : 8));
   int Rmax = 0;
   long want = 1;
   constexpr int wpb = BLK / 64;
@@ -650,7 +709,7 @@ static int launch_tier(const ArgRun<MsvArgs> &main, int num_cu, hipStream_t st)
     Rmax = std::max(Rmax, a.R);
     want = std::max<long>(want, ((long) (a.ngroups - a.group_first) * K + wpb - 1) / wpb);
   }
-  const size_t lds_bytes = (size_t) 2 * kTabRows * row_stride(Rmax, K) * 4;
+  const size_t lds_bytes = (size_t) msv_table_dwords(Rmax, K) * 4;
   // occupancy by (device, LDS bytes); the LDS opt-in once per device, for the tier's largest tile
   static std::map<std::pair<int, size_t>, int> per_cu_of;
   static std::map<int, bool> opted;
@@ -660,8 +719,8 @@ static int launch_tier(const ArgRun<MsvArgs> &main, int num_cu, hipStream_t st)
     int dev = 0; P7X_HIP(hipGetDevice(&dev));
     std::lock_guard<std::mutex> lk(mu);
     if (!opted[dev]) {
-      constexpr int Rtop = TIER == 0 ? 92 : (TIER == 1 ? 136 : (TIER == 4 ? 128 : 224));
-      const size_t most = (size_t) 2 * kTabRows * row_stride(Rtop, K) * 4;
+      constexpr int Rtop = TIER == 0 ? 92 : (TIER == 1 ? 136 : (TIER >= 4 ? 128 : 224));
+      const size_t most = (size_t) msv_table_dwords(Rtop, K) * 4;
       if (most > 64 * 1024)
         P7X_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&msv_tier_kernel<TIER>), hipFuncAttributeMaxDynamicSharedMemorySize, (int) most));
       opted[dev] = true;
@@ -689,6 +748,7 @@ int msv_tier_launch(int tier, const ArgRun<MsvArgs> &main, int num_cu, hipStream
     case 2: return launch_tier<2>(main, num_cu, st);
     case 3: return launch_tier<3>(main, num_cu, st);
     case 4: return launch_tier<4>(main, num_cu, st);
+    case 5: return launch_tier<5>(main, num_cu, st);
     default: set_error("msv_tier_launch: no such tier"); return P7X_EINVAL;
   }
 }
@@ -710,6 +770,9 @@ static int msv_launch_impl(int R, int K, const ArgRun<MsvArgs> &main, const ArgR
 #undef P7X_CASE
 #define P7X_CASE(r) case 4000 + r: return launch_RK<r, 4>(main, amb, num_cu, st, amb_only);
     P7X_CASE(120) P7X_CASE(128)
+#undef P7X_CASE
+#define P7X_CASE(r) case 8000 + r: return launch_RK<r, 8>(main, amb, num_cu, st, amb_only);
+    P7X_CASE(64) P7X_CASE(72) P7X_CASE(80) P7X_CASE(88) P7X_CASE(96) P7X_CASE(104) P7X_CASE(112) P7X_CASE(120) P7X_CASE(128)
 #undef P7X_CASE
     default: set_error("msv_launch: unsupported register tile"); return P7X_EINVAL;
   }

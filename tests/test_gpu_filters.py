@@ -206,14 +206,17 @@ def _model_block(hmm, nrand, nhom, seed):
 
 # one model length per register-count instantiation of the MSV kernels (R = M/2+1 rounded up to the R list) and per
 # nodes-per-lane instantiation C of the wavefront kernels (C = ceil(M/64) rounded up to the C list)
-# K lanes per target: one lane up to 224 registers, two lanes (8-register steps) and four lanes beyond (p7x_msv.hip: msv_pick)
+# K lanes per target: one lane up to 224 registers, two lanes (8-register steps), four lanes, and eight lanes with uniform
+# rows (one table, one register alignment: register j = cells 2j+1, 2j+2) up to 2,048 nodes (p7x_msv.hip: msv_pick)
 _R_LIST = list(range(8, 161, 4)) + [176, 192, 208, 224]
 _R_LIST2 = list(range(120, 225, 8))
 _R_LIST4 = [120, 128]
+_R_LIST8 = list(range(64, 129, 8))
 SWEEP_M = ([1, 2, 3] + [m for r in _R_LIST for m in (2 * (r - 1) - 1, 2 * (r - 1))]       # largest odd and even M per R
            + [m for r in _R_LIST2 for m in (2 * (2 * r - 1) - 1, 2 * (2 * r - 1))]
            + [m for r in _R_LIST4 for m in (2 * (4 * r - 1) - 1, 2 * (4 * r - 1))]
-           + [447, 448, 449, 894, 895, 1022, 1023])                                         # the seams between the families
+           + [m for r in _R_LIST8 if r > 64 for m in (16 * r - 1, 16 * r)]
+           + [447, 448, 449, 894, 895, 1022, 1023, 1024, 1025, 2049])                       # the seams between the families
 
 
 @pytest.mark.parametrize("M", SWEEP_M)
@@ -228,7 +231,7 @@ def test_every_msv_kernel_instantiation_bit_exact(M, oracle):
         assert np.array_equal(got, op.msv_block(blk.packed())), f"M={M} rep={rep}"
 
 
-@pytest.mark.parametrize("M", [5, 60, 262, 263, 445, 446, 700, 893, 1000, 1021])
+@pytest.mark.parametrize("M", [5, 60, 262, 263, 445, 446, 700, 893, 1000, 1021, 1300, 2048])
 def test_integer_flavour_of_the_fast_msv_kernel_bit_exact(M, oracle):
     """The lane-per-target MSV kernel has two flavours of its floored representation: binary16 cells (the default since
     round 5: v_pk_add_f16 clamp + v_pk_maximum3_f16) and int16 cells (v_pk_add_i16 clamp + v_pk_max_i16).  Everything else
