@@ -80,11 +80,20 @@ __device__ __forceinline__ int near_tie(float x, float y, float guard)
   // both at -inf: the difference is NaN and the test is false (such a cell is unreachable anyway)
   return (__builtin_fabsf(x - y) <= guard_band(vmax(x, y), guard)) ? 1 : 0;
 }
-__device__ __forceinline__ int pp_near(float p, float guard)
+// The same two tests as they run inside the decoding row (every cell of every row): the winner <hi> is known there and
+// optimal-accuracy values are sums of probabilities (>= 0, or -inf where nothing leads), so  hi - lo <= hi g + g  is
+// lo >= fma(hi, 1 - g, -g): one fused multiply-add and one comparison.  (An unreachable cell, hi = -inf, tests true; no
+// trace passes through one.)
+__device__ __forceinline__ int near_below(float hi, float lo, float g1, float g) { return lo >= __builtin_fmaf(hi, g1, -g) ? 1 : 0; }
+// ... and the printed digit with its distance from the next one, in float under the guard: v = 10 p + 0.5 is off by an ulp
+// or two of what the host computes in double, the band of 4 guards on either side of a digit boundary is ten times wider
+__device__ __forceinline__ unsigned pp_code_guarded(float p, float band, int &near)
 {
-  // float is enough here: the band is an order of magnitude wider than the rounding of this expression
-  const float v = (p + 0.05f) * 10.0f;
-  return (__builtin_fabsf(v - __builtin_rintf(v)) < 4.0f * guard && v > 0.75f) ? 1 : 0;
+  const float v = __builtin_fmaf(p, 10.0f, 0.5f);
+  const float f = v - __builtin_floorf(v);
+  near |= (__builtin_fabsf(f - 0.5f) > band) ? 1 : 0;             // band = 0.5 - 4 guard
+  const int d = (int) v;
+  return (unsigned) (d > 10 ? 10 : d);
 }
 // and back to a float that prints as that digit (the host stage formats the line from floats)
 __device__ __forceinline__ float pp_from_code(unsigned code) { return code >= 10u ? 1.0f : (float) (((double) code + 0.5) / 10.0 - 0.05); }
@@ -139,6 +148,12 @@ __global__ void __launch_bounds__(env_waves(C) * 64, env_waves(C) / 4) env_kerne
   unsigned short *bp = reinterpret_cast<unsigned short *>(totr_row + rows); // [rows][Mpad] back-pointers (bits 0-3) and the posterior
                                                                             // digits of the M (4-7) and I (8-11) cells
   const bool lane_live = lane * C < a.M;    // lanes whose nodes are all padding neither store nor load rows
+  int erank[C];                             // rank of this lane's nodes in the striped visiting order of select_e (q outer, stripe inner)
+  {
+    const int Qe = max(2, (a.M - 1) / 4 + 1);
+#pragma unroll unroll_env(C)
+    for (int c = 0; c < C; ++c) { const int k = lane * C + c; erank[c] = (k % Qe) * 4 + k / Qe; }
+  }
 
   for (;;) {
     // envelopes are taken longest first from the job's queue: a wavefront that drew a short one comes back for more
@@ -339,6 +354,7 @@ __global__ void __launch_bounds__(env_waves(C) * 64, env_waves(C) / 4) env_kerne
       float oE = kNegInf, oN = 0.0f, oJ = kNegInf, oB = 0.0f, oC = kNegInf;
       float eN = 0.0f, eJ = 0.0f, eC = 0.0f;
       const int Q = max(2, (a.M - 1) / 4 + 1);                         // p7O_NQF(M): the striped visiting order of select_e
+      const float g1 = 1.0f - a.oa_guard, ppband = 0.5f - __builtin_fmaxf(4.0f * a.oa_guard, 2.0e-6f);     // (2e-6: what float costs the digit)
       const bool loopJ = ploop != 0.0f, loopE = a.xf_e_loop != 0.0f, moveE = a.xf_e_move != 0.0f, moveNJ = pmove != 0.0f;
       // Row r+1 is fetched while row r is processed: four vector rows and the twelve special-state values (one load,
       // lane l < 6 takes Forward's, lane 8 + l Backward's), so that no memory round trip sits on the row's critical path.
@@ -412,20 +428,22 @@ __global__ void __launch_bounds__(env_waves(C) * 64, env_waves(C) / 4) env_kerne
           { const float p2 = block(t.dm, dp); if (p2 > bv) { best = 2; second = bv; bv = p2; } else second = vmax(second, p2); }
           { const float p3 = block(t.bm, xBp); if (p3 > bv) { best = 3; second = bv; bv = p3; } else second = vmax(second, p3); }
           int near_m = 0;
-          if constexpr (G) near_m = near_tie(bv, second, a.oa_guard);
+          if constexpr (G) near_m = near_below(bv, second, g1, a.oa_guard);
           const float mcur = om_[c], icur = oi_[c];
           float iv = gate(t.mi, mcur);
           iv = vmax(iv, gate(t.ii, icur));
           const float q0 = block(t.mi, mcur), q1 = block(t.ii, icur);
           const int ichoice = (q0 >= q1) ? 0 : 1;
           int near_i = 0;
-          if constexpr (G) near_i = near_tie(q0, q1, a.oa_guard);
+          if constexpr (G) near_i = near_below(vmax(q0, q1), __builtin_fminf(q0, q1), g1, a.oa_guard);
           mp = mcur; ip = icur; dp = od_[c];
           om_[c] = sv + ppm[c];
           oi_[c] = iv + ppi[c];
           int near_pp = 0;
-          if constexpr (G) near_pp = pp_near(ppm[c], a.oa_guard) | pp_near(ppi[c], a.oa_guard);
-          code[c] = (unsigned short) (best | (ichoice << 2) | (pp_code(ppm[c]) << 4) | (pp_code(ppi[c]) << 8) | (near_m << 12) | (near_i << 13) | (near_pp << 15));
+          unsigned cm, ci;
+          if constexpr (G) { cm = pp_code_guarded(ppm[c], ppband, near_pp); ci = pp_code_guarded(ppi[c], ppband, near_pp); }
+          else { cm = pp_code(ppm[c]); ci = pp_code(ppi[c]); }
+          code[c] = (unsigned short) (best | (ichoice << 2) | (cm << 4) | (ci << 8) | (near_m << 12) | (near_i << 13) | (near_pp << 15));
         }
         // D(r,k) = max(gate(tMD(k-1), M(r,k-1)), tDD(k-1) > 0 ? D(r,k-1) : 0), D(r,1) = -inf: a segmented max-scan
         {
@@ -446,7 +464,7 @@ __global__ void __launch_bounds__(env_waves(C) * 64, env_waves(C) / 4) env_kerne
             const float d0 = block(pmd, pm), d1 = block(pdd, pd);
             const int dchoice = (d0 >= d1) ? 0 : 1;
             int near_d = 0;
-            if constexpr (G) near_d = near_tie(d0, d1, a.oa_guard);
+            if constexpr (G) near_d = near_below(vmax(d0, d1), __builtin_fminf(d0, d1), g1, a.oa_guard);
             code[c] |= (unsigned short) ((dchoice << 3) | (near_d << 14));
             pm = om_[c]; pd = od_[c]; pmd = t_md[c]; pdd = t_dd[c];
           }
@@ -489,7 +507,7 @@ __global__ void __launch_bounds__(env_waves(C) * 64, env_waves(C) / 4) env_kerne
           for (int c = 0; c < C; ++c) {
             const int k = lane * C + c + 1;
             if (k <= a.M) {
-              const int rank = ((k - 1) % Q) * 4 + (k - 1) / Q;
+              const int rank = erank[c];
               if (om_[c] == oE) keyM = max(keyM, rank + 1);
               if (od_[c] == oE) keyD = max(keyD, (1 << 24) - rank);
               if constexpr (G) nearM += om_[c] >= ethr;
