@@ -170,12 +170,15 @@ def pipe_opts(depth, feeders, finishers):
     return o
 
 
-def pipe_effective(depth, feeders, finishers):
-    """What the search runs with (the library's defaults where no flag was given), for the report."""
+def pipe_effective(depth, feeders, finishers, many=False):
+    """What the search runs with (the library's defaults where no flag was given), for the report.  many: batches of several
+    different profiles (feeders = 0, the default, lets the first batch decide: hmmer.hmmsearch)."""
     import inspect
     from pyhmmer_amd import hmmer
     d = {k: v.default for k, v in inspect.signature(hmmer.hmmsearch).parameters.items() if k in ("pipeline_depth", "feeders", "finishers")}
     d.update(pipe_opts(depth, feeders, finishers))
+    if not d["feeders"]:
+        d["feeders"] = 3 if many else 2
     if not d["finishers"]:
         d["finishers"] = max(d["feeders"], d["pipeline_depth"])
     d["library_defaults"] = not pipe_opts(depth, feeders, finishers)
@@ -455,7 +458,7 @@ def run_pfam(args, rank, world, local_rank, dist, red_dev, torch, host_threads, 
         "untimed_residency_pass_seconds": round(t_resident, 2),
         "search_seconds_rank0": round(t_search, 4),
         "merge_seconds_rank0": {"serialise": round(t_ser, 4), "gather": round(t_gather, 4), "merge_many": round(t_merge, 4)},
-        "batch": args.pfam_batch, **pipe_effective(args.pfam_depth, args.feeders, args.pfam_finishers),
+        "batch": args.pfam_batch, **pipe_effective(args.pfam_depth, args.feeders, args.pfam_finishers, many=True),
         "hits": nhits, "reported": nrep, "stage_counts_rank0": sc,
         "guards_rank0": {k: sum(h.guard_counts[k] for h in hits) for k in ("f3_dropped", "oa_redone", "ens_device", "ens_redone")},
         # per-BATCH times (every query of a batch reports its batch's): device stages by HIP events of the first class

@@ -204,7 +204,7 @@ def hmmpress(hmms: Iterable, output) -> int:
 
 def hmmsearch(queries: Union[HMM, Profile, OptimizedProfile, Iterable], sequences, *, cpus: int = 0,
               callback: Optional[Callable] = None, devices: Optional[Sequence[int]] = None,
-              pipeline_depth: int = 8, feeders: int = 2, finishers: int = 0, batch: int = 0,
+              pipeline_depth: int = 8, feeders: int = 0, finishers: int = 0, batch: int = 0,
               backend: Optional[str] = None, parallel: Optional[str] = None, builder=None, timeout: Optional[float] = None,
               chunk_bytes: Optional[int] = None, **options) -> Iterator[TopHits]:
     """Search HMMs against a sequence database; yields one ``TopHits`` per query, in query order.
@@ -239,7 +239,13 @@ def hmmsearch(queries: Union[HMM, Profile, OptimizedProfile, Iterable], sequence
     batches must be in flight to cover that latency: the headline stream (one 262-node profile, a million targets)
     measured 14.8-15.4 TCUPS at depth 4, 16.0 at 6 and 17.6 at 8; the many-profile stream does not depend on it
     (34.8 s with 2, 4 or 6 host stages in flight).  One default serves both.  ``pipeline_depth=0`` runs the two stages of
-    every query back to back.
+    every query back to back.  ``feeders=0`` (the default) lets the first batch decide: batches of several different profiles
+    (a profile library: their launches are spread over the register tiles' tiers and eight streams, and leave gaps) get
+    three cascades in flight, batches of one profile (a single query, or a stream of the same one: one launch that fills
+    the device, and a heavy host stage) two -- measured on one MI355X, round 6: the 20,000-profile library against 500,000
+    targets 23.5 TCUPS with two feeders, 25.6 with three (and +6 ... +11 % on 1/2, 1/4 and 1/8 of the targets, what a rank
+    of an N-GPU run holds; four feeders: no better, and unstable on small shards); one 262-node profile against a million
+    targets 18.8 with two, 16.5 with three (``profiles/r06_feeders.txt``).
     ``sequences`` may also be a :class:`~pyhmmer_amd.plan7.SequenceDatabase` already resident on one device.
     """
     if backend not in (None, "threading", "multiprocessing"):
@@ -566,6 +572,12 @@ def _run_batches(db: "ShardedDatabase", pipelines: Sequence[Pipeline], queries: 
     # two-stage software pipeline over the batches.  Feeder threads (each with its own device stream) run the
     # device stage ahead of the host stage; results are handed over in order, at most pipeline_depth of them
     # staged or in flight at any time.
+    if feeders <= 0:                  # the first batch decides (see hmmsearch): several different profiles -> three cascades in flight
+        import itertools
+        queries = iter(queries)
+        head = list(itertools.islice(queries, 1))
+        feeders = 3 if head and len({id(q) for q in head[0]}) > 1 else 2
+        queries = itertools.chain(head, queries)
     nfeed = max(1, min(feeders, pipeline_depth))
     trace = _pipe_trace if PIPE_TRACE else (lambda *a: None)
     stats = {"feeder_enqueue": 0.0, "feeder_device_wait": 0.0, "feeder_slot_wait": 0.0, "finish": 0.0, "consumer_finish_wait": 0.0,
