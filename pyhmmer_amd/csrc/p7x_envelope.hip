@@ -80,6 +80,12 @@ __device__ __forceinline__ int near_tie(float x, float y, float guard)
   // both at -inf: the difference is NaN and the test is false (such a cell is unreachable anyway)
   return (__builtin_fabsf(x - y) <= guard_band(vmax(x, y), guard)) ? 1 : 0;
 }
+__device__ __forceinline__ int pp_near(float p, float guard)
+{
+  // float is enough here: the band is an order of magnitude wider than the rounding of this expression
+  const float v = (p + 0.05f) * 10.0f;
+  return (__builtin_fabsf(v - __builtin_rintf(v)) < 4.0f * guard && v > 0.75f) ? 1 : 0;
+}
 // The same two tests as they run inside the decoding row (every cell of every row): the winner <hi> is known there and
 // optimal-accuracy values are sums of probabilities (>= 0, or -inf where nothing leads), so  hi - lo <= hi g + g  is
 // lo >= fma(hi, 1 - g, -g): one fused multiply-add and one comparison.  (An unreachable cell, hi = -inf, tests true; no
@@ -441,8 +447,13 @@ __global__ void __launch_bounds__(env_waves(C) * 64, env_waves(C) / 4) env_kerne
           oi_[c] = iv + ppi[c];
           int near_pp = 0;
           unsigned cm, ci;
-          if constexpr (G) { cm = pp_code_guarded(ppm[c], ppband, near_pp); ci = pp_code_guarded(ppi[c], ppband, near_pp); }
-          else { cm = pp_code(ppm[c]); ci = pp_code(ppi[c]); }
+          // (long-target envelopes keep the digits in double: with the float form the <20, true, true> instantiation -- 256 VGPRs,
+          // 420 spilled SGPRs, scratch -- faulted on the device, round 6; their posterior digits are tested against the band alone)
+          if constexpr (G && !LT) { cm = pp_code_guarded(ppm[c], ppband, near_pp); ci = pp_code_guarded(ppi[c], ppband, near_pp); }
+          else {
+            cm = pp_code(ppm[c]); ci = pp_code(ppi[c]);
+            if constexpr (G) near_pp = pp_near(ppm[c], a.oa_guard) | pp_near(ppi[c], a.oa_guard);
+          }
           code[c] = (unsigned short) (best | (ichoice << 2) | (cm << 4) | (ci << 8) | (near_m << 12) | (near_i << 13) | (near_pp << 15));
         }
         // D(r,k) = max(gate(tMD(k-1), M(r,k-1)), tDD(k-1) > 0 ? D(r,k-1) : 0), D(r,1) = -inf: a segmented max-scan

@@ -227,8 +227,8 @@ struct SsvLongArgs {
 // <pair>: the row maximum only on every second row, against a threshold lowered by pair_slack, tables with the virtual node
 int  ssvlong_pick_R(int M, bool pair);
 void ssvlong_build_tables(const Profile &p, int R, bool pair, std::vector<uint32_t> &tab4q, std::vector<uint32_t> &tab_full, int *pair_slack);
-int  ssvlong_capacity(int R, bool pair, int num_cu, long long *waves);
-int  ssvlong_launch(int R, bool pair, const SsvLongArgs &a, int num_cu, hipStream_t st);
+int  ssvlong_capacity(int R, bool pair, bool half, int num_cu, long long *waves);      // half: binary16 cells (the default), else int16
+int  ssvlong_launch(int R, bool pair, bool half, const SsvLongArgs &a, int num_cu, hipStream_t st);
 
 // ---- thread-per-sequence small stages (p7x_pipeline.hip)
 } // namespace p7x

@@ -102,7 +102,9 @@ static int scan_target(const p7x_pipeline_cfg &cfg, const Profile &p, DeviceCtx 
   // a loss for models with near-impossible emissions (60-110 units for the tests' Dirichlet models: every block would be
   // repeated).  Option ssv_kernel (tests, A/B): 3 = every row, 4 = every second row whatever the loss.
   constexpr int kMaxPairSlack = 16;
-  const int opt = debug_opt(OPT_SSV_KERNEL);
+  int opt = debug_opt(OPT_SSV_KERNEL);
+  const bool half = !(opt >= 5 && opt <= 7);       // 5, 6, 7: the int16 flavour of the kernel with the library's choice of rows / every row / every second row
+  if (!half) opt = opt == 5 ? -1 : (opt == 6 ? 3 : 4);
   bool pair = opt != 3;
   int R = ssvlong_pick_R(p.M, pair);
   if (R < 0) { set_error("model too long for the long-target SSV kernel (M > 6141)"); return P7X_EINVAL; }
@@ -131,7 +133,7 @@ static int scan_target(const p7x_pipeline_cfg &cfg, const Profile &p, DeviceCtx 
   // of them take is paid in full: 16,384 chunks on 3,072 wavefronts were six rounds, the last a third full)
   const int nstrands_plan = strands_mask == 3 ? 2 : 1;
   long long waves = 0;
-  if ((st = ssvlong_capacity(R, pair, ctx->num_cu, &waves)) != P7X_OK) return st;
+  if ((st = ssvlong_capacity(R, pair, half, ctx->num_cu, &waves)) != P7X_OK) return st;
   const int64_t rounds = std::max<int64_t>(1, (L * nstrands_plan + waves * 49152 - 1) / (waves * 49152));
   const int64_t want_chunks = (waves * rounds + nstrands_plan - 1) / nstrands_plan;             // per strand
   int chunk_len = (int) std::max<int64_t>(8 * (int64_t) p.M, std::min<int64_t>(1 << 16, (L + want_chunks - 1) / want_chunks));
@@ -175,7 +177,7 @@ static int scan_target(const p7x_pipeline_cfg &cfg, const Profile &p, DeviceCtx 
     a.rec_k = static_cast<int *>(d_k.p); a.rec_sc = static_cast<int *>(d_sc.p); a.rec_cap = cap;
     P7X_HIP(hipMemsetAsync(d_nrec.p, 0, 4, s));
     P7X_HIP(hipEventRecord(e0, s));
-    if ((st = ssvlong_launch(R, pair, a, ctx->num_cu, s)) != P7X_OK) return st;
+    if ((st = ssvlong_launch(R, pair, half, a, ctx->num_cu, s)) != P7X_OK) return st;
     P7X_HIP(hipEventRecord(e1, s));
     int nrec = 0;
     P7X_HIP(hipMemcpyAsync(&nrec, d_nrec.p, 4, hipMemcpyDeviceToHost, s));

@@ -33,6 +33,39 @@ __device__ __forceinline__ uint32_t pk_adds_u(uint32_t a, uint32_t b) { return _
 __device__ __forceinline__ uint32_t pk_max_u(uint32_t a, uint32_t b) { return __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(s2w, a), __builtin_bit_cast(s2w, b))); }
 constexpr uint32_t kFloor2 = 0x80008000u;
 
+// The binary16 flavour (round 6; what p7x_msv.hip's fast kernel does since round 5): a cell holds (v - xB) / 256, a multiple
+// of 2^-8 in [0, 1] -- every sum of a cell and an emission is exact --, v_pk_add_f16 clamp is the add with its floor at the
+// begin score (the ceiling xB + 256 lies above every byte score: a clamped cell has reached any threshold, as the int16
+// flavour's unsaturated one has), and v_pk_maximum3_f16 folds TWO registers into the running maximum: with the maximum
+// taken on every second row that is 2.5 packed operations per register and row pair instead of 3.
+typedef _Float16 h2w __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t h_adds_u(uint32_t a, uint32_t b)            // v_pk_add_f16 clamp
+{
+  const h2w z = { (_Float16) 0.0f, (_Float16) 0.0f }, o = { (_Float16) 1.0f, (_Float16) 1.0f };
+  return __builtin_bit_cast(uint32_t, __builtin_elementwise_min(__builtin_elementwise_max(__builtin_bit_cast(h2w, a) + __builtin_bit_cast(h2w, b), z), o));
+}
+__device__ __forceinline__ uint32_t h_max_u(uint32_t a, uint32_t b)
+{ return __builtin_bit_cast(uint32_t, __builtin_elementwise_maximum(__builtin_bit_cast(h2w, a), __builtin_bit_cast(h2w, b))); }
+__device__ __forceinline__ uint32_t h_max3_u(uint32_t a, uint32_t b, uint32_t c)  // v_pk_maximum3_f16
+{ return __builtin_bit_cast(uint32_t, __builtin_elementwise_maximum(__builtin_elementwise_maximum(__builtin_bit_cast(h2w, a), __builtin_bit_cast(h2w, b)), __builtin_bit_cast(h2w, c))); }
+// a dword of the integer tables (two emissions, int16) as two halves: e / 256, pad entries (kNegPad) -> -2.0
+__device__ __forceinline__ uint32_t h_of_i16_pair_u(uint32_t w)
+{
+  const int lo = max((int) (short) (w & 0xffffu), -512), hi = max((int) (short) (w >> 16), -512);
+  return __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pkrtz((float) lo * (1.0f / 256.0f), (float) hi * (1.0f / 256.0f)));
+}
+// the larger cell of a register, in score units above the begin score
+template <bool H> __device__ __forceinline__ int rel_max(uint32_t w)
+{
+  if constexpr (H) { const h2w m = __builtin_bit_cast(h2w, w); return (int) (256.0f * fmaxf((float) m.x, (float) m.y)); }
+  else return max((int) (short) (w >> 16), (int) (short) (w & 0xffffu)) + 32768;
+}
+template <bool H> __device__ __forceinline__ int rel_half(uint32_t w, int h)
+{
+  if constexpr (H) { const h2w m = __builtin_bit_cast(h2w, w); return (int) (256.0f * (float) (h ? m.y : m.x)); }
+  else return (int) (short) (h ? (w >> 16) : (w & 0xffffu)) + 32768;
+}
+
 }  // namespace
 
 // ---------------------------------------------------------------------------------------- emission quads from LDS
@@ -59,18 +92,38 @@ constexpr uint32_t kFloor2 = 0x80008000u;
 //     node further -- for the last node that is the virtual node M + 1 of the tables, whose emission is 0.  The exact
 //     test of the repeat decides; the virtual node never counts as a cell there.
 //   * chunks are sized by the caller so that their number is a multiple of the resident wavefronts (ssvlong_capacity).
-__device__ __forceinline__ bool ssv_reached(uint32_t acc, int thr)
+template <bool H> __device__ __forceinline__ bool ssv_reached(uint32_t acc, int thr_rel)        // thr_rel: above the begin score
 {
-  const int hi = (int) (short) (acc >> 16), lo = (int) (short) (acc & 0xffffu);
-  return __any(max(hi, lo) >= thr) != 0;
+  return __any(rel_max<H>(acc) >= thr_rel) != 0;
 }
 
 // one row; ODD: register g <- f(register g-1), the lane's first register from the lane before.  DOMAX: fold into acc0 / acc1
-template <int R, bool ODD, bool DOMAX, int RE>
+template <int R, bool ODD, bool DOMAX, int RE, bool H>
 __device__ __forceinline__ void ssv_row(uint32_t (&v)[R], const uint32_t (&e)[RE], uint32_t &acc0, uint32_t &acc1)
 {
   static_assert(RE >= R, "emission registers");
-  if constexpr (ODD) {
+  if constexpr (H) {          // binary16 cells: one maximum3 per two registers, placed behind the second of them
+    if constexpr (ODD) {
+      const uint32_t carry = (uint32_t) dpp_shr1((int) v[R - 1], 0);
+#pragma unroll
+      for (int j = R - 1; j >= 0; --j) {
+        v[j] = h_adds_u(j >= 1 ? v[j - 1] : carry, e[j]);
+        if constexpr (DOMAX) {
+          if ((j & 1) == 0 && j + 1 < R) { if (j & 2) acc1 = h_max3_u(acc1, v[j], v[j + 1]); else acc0 = h_max3_u(acc0, v[j], v[j + 1]); }
+          else if ((j & 1) == 0) acc0 = h_max_u(acc0, v[j]);      // R odd: the top register has no partner
+        }
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < R; ++j) {
+        v[j] = h_adds_u(v[j], e[j]);
+        if constexpr (DOMAX) {
+          if (j & 1) { if (j & 2) acc1 = h_max3_u(acc1, v[j - 1], v[j]); else acc0 = h_max3_u(acc0, v[j - 1], v[j]); }
+          else if (j + 1 == R) acc0 = h_max_u(acc0, v[j]);
+        }
+      }
+    }
+  } else if constexpr (ODD) {
     const uint32_t carry = (uint32_t) dpp_shr1((int) v[R - 1], (int) kFloor2);
 #pragma unroll
     for (int j = R - 1; j >= 1; --j) {
@@ -88,23 +141,29 @@ __device__ __forceinline__ void ssv_row(uint32_t (&v)[R], const uint32_t (&e)[RE
   }
 }
 
-template <int R, bool PAIR>
+template <int R, bool PAIR, bool H>
 __global__ void __launch_bounds__(256) ssvlong_quad_kernel(const SsvLongArgs a)
 {
+  constexpr uint32_t kFloorV = H ? 0u : kFloor2;
   constexpr int R4 = (R + 3) / 4;
   constexpr int RE = 4 * R4;                       // emission registers of a row (the last quad may be partly unused)
   constexpr int XS = R4 * 64;                      // uint4 per (parity, residue)
   extern __shared__ __attribute__((aligned(16))) uint4 ldsq[];
   {
     const uint4 *g = reinterpret_cast<const uint4 *>(a.tab4q);
-    for (int i = threadIdx.x; i < 8 * XS; i += 256) ldsq[i] = g[i];
+    for (int i = threadIdx.x; i < 8 * XS; i += 256) {
+      uint4 w = g[i];
+      if constexpr (H) { w.x = h_of_i16_pair_u(w.x); w.y = h_of_i16_pair_u(w.y); w.z = h_of_i16_pair_u(w.z); w.w = h_of_i16_pair_u(w.w); }
+      ldsq[i] = w;
+    }
   }
   __syncthreads();
   const int lane = threadIdx.x & 63;
   const int wave = rfl((int) (blockIdx.x * 4 + (threadIdx.x >> 6)));
   const int nwaves = (int) gridDim.x * 4;
   const uint4 *lq = ldsq + lane;
-  const int thr_fast = PAIR ? a.thresh_s - a.pair_slack : a.thresh_s;
+  const int thr_exact = a.thresh_s + 32768;                 // the threshold above the begin score (a.thresh_s: in the int16 flavour's offset)
+  const int thr_fast = PAIR ? thr_exact - a.pair_slack : thr_exact;
   const int sc_thresh = a.thresh_s + a.xB + 32768;          // the threshold in byte units
 
   // the quads of residue x (xs = x * XS, wave-uniform) and parity <par> (0: odd rows)
@@ -124,9 +183,9 @@ __global__ void __launch_bounds__(256) ssvlong_quad_kernel(const SsvLongArgs a)
 #pragma unroll
       for (int h = 0; h < 2; ++h) {
         const int k = c0 + h;
-        const int sv = (int) (short) (h ? (v[j] >> 16) : (v[j] & 0xffffu));
+        const int sv = rel_half<H>(v[j], h);
         if (k >= 1 && k <= a.M) {
-          const int val = min(255, sv + 32768 + a.xB);
+          const int val = min(255, sv + a.xB);
           const int key = ((k - 1) % a.Q16) * 16 + (k - 1) / a.Q16;
           if (val > best || (val == best && key < bestkey)) { best = val; bestkey = key; }
         }
@@ -148,19 +207,19 @@ __global__ void __launch_bounds__(256) ssvlong_quad_kernel(const SsvLongArgs a)
     uint32_t eA[RE], eB[RE];
     load_quads(eA, (uint32_t) __builtin_amdgcn_readlane((int) xsv, 0), 0);
     for (int r0 = 0; r0 < 64; r0 += 16) {
-      uint32_t acc0 = kFloor2, acc1 = kFloor2;
+      uint32_t acc0 = kFloorV, acc1 = kFloorV;
 #pragma unroll
       for (int rr = 0; rr < 16; rr += 2) {
         // the scheduler stays inside a row: left alone it gathers the quads of many rows at the top of the loop and
         // pays for them with half the wavefronts per SIMD (136 VGPRs instead of 77 at R = 10)
         load_quads(eB, (uint32_t) __builtin_amdgcn_readlane((int) xsv, r0 + rr + 1), 1);
-        ssv_row<R, true, !PAIR>(v, eA, acc0, acc1);
+        ssv_row<R, true, !PAIR, RE, H>(v, eA, acc0, acc1);
         __builtin_amdgcn_sched_barrier(0);
         load_quads(eA, (uint32_t) __builtin_amdgcn_readlane((int) xsv, (r0 + rr + 2) & 63), 0);      // the last one of a block is not used
-        ssv_row<R, false, true>(v, eB, acc0, acc1);
+        ssv_row<R, false, true, RE, H>(v, eB, acc0, acc1);
         __builtin_amdgcn_sched_barrier(0);
       }
-      if (ssv_reached(pk_max_u(acc0, acc1), thr_fast)) return false;
+      if (ssv_reached<H>(H ? h_max_u(acc0, acc1) : pk_max_u(acc0, acc1), thr_fast)) return false;
     }
     return true;
   };
@@ -173,7 +232,7 @@ __global__ void __launch_bounds__(256) ssvlong_quad_kernel(const SsvLongArgs a)
     const long long warm = max(1LL, first - a.M);
     uint32_t v[R];
 #pragma unroll
-    for (int j = 0; j < R; ++j) v[j] = kFloor2;
+    for (int j = 0; j < R; ++j) v[j] = kFloorV;
     // residues of 64 rows, one per lane: strand 1 reads the target backwards and complements (canonical residues by
     // arithmetic: the table lookup would be a second dependent load); fetched one block ahead of its use.  The fetch is
     // the byte load and nothing else: whatever consumes the byte would make the compiler wait for it on the spot.
@@ -207,23 +266,23 @@ __global__ void __launch_bounds__(256) ssvlong_quad_kernel(const SsvLongArgs a)
         for (int h = 0; h < 2; ++h) {
           if (r + h >= nrow) break;
           const int x = __builtin_amdgcn_readlane((int) res, r + h);
-          uint32_t acc0 = kFloor2, acc1 = kFloor2;
+          uint32_t acc0 = kFloorV, acc1 = kFloorV;
           if (x < 4) {
             uint32_t e[RE];
             load_quads(e, (uint32_t) x * XS, h);
-            if (h == 0) ssv_row<R, true, true>(v, e, acc0, acc1); else ssv_row<R, false, true>(v, e, acc0, acc1);
+            if (h == 0) ssv_row<R, true, true, RE, H>(v, e, acc0, acc1); else ssv_row<R, false, true, RE, H>(v, e, acc0, acc1);
           } else if (x >= a.Kp) {     // between two targets of a concatenated scan: every diagonal ends here
 #pragma unroll
-            for (int j = 0; j < R; ++j) v[j] = kFloor2;
+            for (int j = 0; j < R; ++j) v[j] = kFloorV;
           } else {                    // degenerate residue: emissions from the full table in global memory [parity][Kp][R][64]
             const uint32_t *eg = a.tab_full + ((size_t) ((h == 0 ? 0 : a.Kp) + x) * R) * 64 + lane;
             uint32_t e[R];
 #pragma unroll
-            for (int j = 0; j < R; ++j) e[j] = eg[j * 64];
-            if (h == 0) ssv_row<R, true, true>(v, e, acc0, acc1); else ssv_row<R, false, true>(v, e, acc0, acc1);
+            for (int j = 0; j < R; ++j) e[j] = H ? h_of_i16_pair_u(eg[j * 64]) : eg[j * 64];
+            if (h == 0) ssv_row<R, true, true, R, H>(v, e, acc0, acc1); else ssv_row<R, false, true, R, H>(v, e, acc0, acc1);
           }
           const long long i = i0 + r + h;
-          if (i >= first && ssv_reached(pk_max_u(acc0, acc1), a.thresh_s)) report(v, h == 0, i, strand);
+          if (i >= first && ssv_reached<H>(H ? h_max_u(acc0, acc1) : pk_max_u(acc0, acc1), thr_exact)) report(v, h == 0, i, strand);
         }
       }
     }
@@ -275,11 +334,11 @@ void ssvlong_build_tables(const Profile &p, int R, bool virtual_node, std::vecto
 }
 
 // cap_waves != NULL: no launch, only the number of wavefronts the device holds at once
-template <int R, bool PAIR>
+template <int R, bool PAIR, bool H>
 static int launch_ssv_quad(const SsvLongArgs &a, int num_cu, hipStream_t st, long long *cap_waves)
 {
   const size_t lds = (size_t) 2 * 4 * ((R + 3) / 4) * 64 * 16;
-  auto kern = ssvlong_quad_kernel<R, PAIR>;
+  auto kern = ssvlong_quad_kernel<R, PAIR, H>;
   static std::map<int, int> per_cu_by_device;       // the LDS opt-in is a per-device attribute of the kernel: looked up once per device
   static std::mutex mu;
   int per_cu = 0;
@@ -302,9 +361,10 @@ static int launch_ssv_quad(const SsvLongArgs &a, int num_cu, hipStream_t st, lon
   return P7X_OK;
 }
 
-static int ssvlong_quad_dispatch(int R, bool pair, const SsvLongArgs &a, int num_cu, hipStream_t st, long long *cap_waves)
+static int ssvlong_quad_dispatch(int R, bool pair, bool half, const SsvLongArgs &a, int num_cu, hipStream_t st, long long *cap_waves)
 {
-#define P7X_SQ(RR) case RR: return pair ? launch_ssv_quad<RR, true>(a, num_cu, st, cap_waves) : launch_ssv_quad<RR, false>(a, num_cu, st, cap_waves);
+#define P7X_SQ(RR) case RR: return half ? (pair ? launch_ssv_quad<RR, true, true>(a, num_cu, st, cap_waves) : launch_ssv_quad<RR, false, true>(a, num_cu, st, cap_waves)) \
+                                       : (pair ? launch_ssv_quad<RR, true, false>(a, num_cu, st, cap_waves) : launch_ssv_quad<RR, false, false>(a, num_cu, st, cap_waves));
   switch (R) {
     P7X_SQ(2) P7X_SQ(3) P7X_SQ(4) P7X_SQ(5) P7X_SQ(6) P7X_SQ(7) P7X_SQ(8) P7X_SQ(9) P7X_SQ(10) P7X_SQ(11) P7X_SQ(12) P7X_SQ(14) P7X_SQ(16)
     P7X_SQ(20) P7X_SQ(24) P7X_SQ(32) P7X_SQ(48)
@@ -314,15 +374,15 @@ static int ssvlong_quad_dispatch(int R, bool pair, const SsvLongArgs &a, int num
 }
 
 // wavefronts of the quad kernel the device holds at once: the caller cuts the strands into a multiple of that many chunks
-int ssvlong_capacity(int R, bool pair, int num_cu, long long *waves)
+int ssvlong_capacity(int R, bool pair, bool half, int num_cu, long long *waves)
 {
   SsvLongArgs none{};
-  return ssvlong_quad_dispatch(R, pair, none, num_cu, nullptr, waves);
+  return ssvlong_quad_dispatch(R, pair, half, none, num_cu, nullptr, waves);
 }
 
-int ssvlong_launch(int R, bool pair, const SsvLongArgs &a, int num_cu, hipStream_t st)
+int ssvlong_launch(int R, bool pair, bool half, const SsvLongArgs &a, int num_cu, hipStream_t st)
 {
-  return ssvlong_quad_dispatch(R, pair, a, num_cu, st, nullptr);
+  return ssvlong_quad_dispatch(R, pair, half, a, num_cu, st, nullptr);
 }
 
 } // namespace p7x

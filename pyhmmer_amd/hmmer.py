@@ -341,7 +341,7 @@ def _search_file(queries: Iterable, file: SequenceFile, chunk_bytes: int, devs: 
             yield hits
 
 
-_BATCH_CELLS = 6e11        # (profile, target) cells per device batch when the caller leaves the batch size open: ~25 ms of MSV
+_BATCH_CELLS = float(os.environ.get("P7X_BATCH_CELLS", 6e11))        # (profile, target) cells per device batch when the caller leaves the batch size open: ~25 ms of MSV (the variable: sweeps)
 _BATCH_MAX = 256         # queries per batch against a large block (the cell budget usually cuts far below this)
 _BATCH_LIMIT = 4096      # p7x_search_batch_enqueue takes at most this many profiles
 _BATCH_SLOTS = 1 << 23   # (profile, target) score slots of one batch's workspace (~30 bytes each)

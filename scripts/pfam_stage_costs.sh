@@ -4,8 +4,8 @@
 # Forward parser; defaults: + Backward, regions, envelopes, ensembles, hit lists).
 R=${GRAFT_REPO_ROOT:-/root/repo}; cd $R
 for v in "--F1 1e-12" "--F2 1e-12" "--F3 1e-12" ""; do
-  for i in 1 2; do
-    python bench.py --gpus 1 --workload pfam --pfam-profiles 4000 --steps 4 --warmup 1 --no-cpu-baseline $v 2>/dev/null | python -c "
+  for i in ${RUNS:-1 2}; do
+    python bench.py --gpus 1 --workload pfam --pfam-profiles ${PROFILES:-4000} --steps ${STEPS:-4} --warmup 1 --no-cpu-baseline $v 2>/dev/null | python -c "
 import sys, json
 for line in sys.stdin:
     if line.startswith('{'):

@@ -25,7 +25,9 @@ def rows_agree(dev, ref):
         assert a[9] == pytest.approx(b[9], abs=3e-3) and a[10] == pytest.approx(b[10], abs=3e-3), (a, b)
 
 
-SSV_KERNELS = {"the library's choice": -1, "row maximum in every row": 3, "row maximum every second row": 4}
+# binary16 cells (the default since round 6: v_pk_add_f16 clamp + v_pk_maximum3_f16) and the int16 flavour behind the seam
+SSV_KERNELS = {"the library's choice": -1, "row maximum in every row": 3, "row maximum every second row": 4,
+               "int16 cells, the library's choice of rows": 5, "int16 cells, row maximum every second row": 7}
 
 
 @pytest.fixture
