@@ -230,6 +230,8 @@ int p7x_seqdb_create(int device, int32_t abc_type, const uint8_t *dsq, const int
     db->d_grp_nblk = reinterpret_cast<int32_t *>(q); q += b_nblk;
     db->d_dsq = q;
   }
+  // an upload that fails hands the slab back with the half-built database (it leaked)
+  struct SlabGuard { DeviceCtx *ctx; p7x_seqdb *db; ~SlabGuard() { if (db && db->slab) { slab_release(ctx, db->slab, db->slab_bytes); db->slab = nullptr; } } } guard{ ctx, db.get() };
   P7X_HIP(hipMemcpy(db->d_dsq, db->h_dsq.data(), db->h_dsq.size(), hipMemcpyHostToDevice));
   P7X_HIP(hipMemcpy(db->d_slot_off, slot_off.data(), slot_off.size() * 8, hipMemcpyHostToDevice));
   P7X_HIP(hipMemcpy(db->d_slot_len, slot_len.data(), slot_len.size() * 4, hipMemcpyHostToDevice));
@@ -241,6 +243,7 @@ int p7x_seqdb_create(int device, int32_t abc_type, const uint8_t *dsq, const int
     P7X_HIP(hipGetLastError());
     P7X_HIP(hipStreamSynchronize(ctx->stream));
   }
+  guard.db = nullptr;
   *out = db.release();
   return P7X_OK;
 }

@@ -14,7 +14,7 @@ constexpr int kNegPad    = -512;     // MSV emission for dummy/pad nodes and pad
 
 #define P7X_HIP(call)                                                                          \
   do { hipError_t e_ = (call); if (e_ != hipSuccess) {                                         \
-    p7x::set_error(std::string(#call) + ": " + hipGetErrorString(e_)); return P7X_EDEVICE; } } while (0)
+    p7x::set_error(std::string(#call) + ": " + hipGetErrorString(e_)); return e_ == hipErrorOutOfMemory ? P7X_EMEM : P7X_EDEVICE; } } while (0)
 
 // Length-model tables, exact host arithmetic, indexed by target length L (0..kMaxL):
 //   tjb[L]   = unbiased_byteify(ln(3/(L+3)))     (p7_oprofile_ReconfigMSVLength)

@@ -58,7 +58,19 @@ int slab_acquire(DeviceCtx *ctx, size_t bytes, void **out, size_t *got)
       return P7X_OK;
     }
   }
-  P7X_HIP(hipMalloc(out, want));
+  if (hipMalloc(out, want) != hipSuccess) {
+    // the device is full while slabs sit parked: hand the parked ones back and try once more (a pool sized for
+    // 288 GiB must not run a smaller device -- or one shared with other processes -- out of memory)
+    (void) hipGetLastError();
+    std::vector<void *> parked;
+    {
+      std::lock_guard<std::mutex> lk(ctx->slab_mu);
+      for (auto &kv : ctx->slab_free) parked.push_back(kv.second);
+      ctx->slab_free.clear(); ctx->slab_free_bytes = 0;
+    }
+    for (void *q : parked) (void) hipFree(q);
+    P7X_HIP(hipMalloc(out, want));
+  }
   *got = want;
   return P7X_OK;
 }
@@ -67,7 +79,10 @@ void slab_release(DeviceCtx *ctx, void *p, size_t bytes)
 {
   if (!p) return;
   std::lock_guard<std::mutex> lk(ctx->slab_mu);
-  if (ctx->slab_free_bytes + bytes > ((size_t) 32 << 30)) { (void) hipFree(p); return; }   // keep at most 32 GiB parked (of 288)
+  // keep at most 32 GiB parked (of 288), and never more than an eighth of the device's memory
+  size_t cap = (size_t) 32 << 30, free_b = 0, total_b = 0;
+  if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && total_b / 8 < cap) cap = total_b / 8;
+  if (ctx->slab_free_bytes + bytes > cap) { (void) hipFree(p); return; }
   ctx->slab_free.emplace(bytes, p); ctx->slab_free_bytes += bytes;
 }
 

@@ -643,6 +643,10 @@ public:
   {
     const int st = begin_on_device(jobs, seed_state, nsamples);
     if (st == P7X_OK) return st;
+    // Only a lack of memory (or the test seam that plays one) is a reason to sample on the host instead: a launch fault
+    // or a sticky device error must surface, not turn into a slower search that looks healthy.
+    if (st != P7X_EMEM && debug_opt(OPT_ENS_FAIL) <= 0) return st;
+    if (debug_opt(OPT_TRACE_FINISH) > 0) std::fprintf(stderr, "[ens] device ensembles unavailable for this call (%s): its regions go to the host workers\n", p7x_last_error());
     if (lease_ && lease_->stream) (void) hipStreamSynchronize(lease_->stream);      // whatever was queued before the failure
     (void) hipGetLastError();
     std::fill(launched_.begin(), launched_.end(), (char) 0);

@@ -20,6 +20,7 @@
 //     has S/2 odd so the <=32 residue rows fall on distinct bank pairs: conflict-free;
 //   * residues arrive as coalesced 16-byte loads from 64-sequence interleaved tiles (p7x_seqdb).
 #include <cstdlib>
+#include <iterator>
 #include <map>
 #include <mutex>
 #include "p7x_device.hpp"
@@ -503,6 +504,16 @@ __global__ void __launch_bounds__(msv_block_c(K), msv_min_blocks_c(R, K)) msv_fa
 // that share a block size and an occupancy -- is one launch that fills the device.  The dynamic LDS of the launch is that
 // of its largest tile; the occupancy that the tier promises (4 / 3 / 2 blocks per CU) holds for it.
 //   tier 0: K = 1, R <= 92;  1: K = 1, R <= 136;  2: K = 1, R <= 224;  3: K = 2;  4: K = 4;  5: K = 8 (uniform rows)
+// The register tiles, tier by tier: ONE list for the tier kernels' dispatch, the per-tile launches and msv_pick (a tile that
+// is in one of them and not in another would leave scores unwritten without an error: ADVICE r05).
+#define P7X_TILES_TIER0(X) X(8, 1) X(12, 1) X(16, 1) X(20, 1) X(24, 1) X(28, 1) X(32, 1) X(36, 1) X(40, 1) X(44, 1) X(48, 1) X(52, 1) \
+                           X(56, 1) X(60, 1) X(64, 1) X(68, 1) X(72, 1) X(76, 1) X(80, 1) X(84, 1) X(88, 1) X(92, 1)
+#define P7X_TILES_TIER1(X) X(96, 1) X(100, 1) X(104, 1) X(108, 1) X(112, 1) X(116, 1) X(120, 1) X(124, 1) X(128, 1) X(132, 1) X(136, 1)
+#define P7X_TILES_TIER2(X) X(140, 1) X(144, 1) X(148, 1) X(152, 1) X(156, 1) X(160, 1) X(176, 1) X(192, 1) X(208, 1) X(224, 1)
+#define P7X_TILES_TIER3(X) X(120, 2) X(128, 2) X(136, 2) X(144, 2) X(152, 2) X(160, 2) X(168, 2) X(176, 2) X(184, 2) X(192, 2) X(200, 2) \
+                           X(208, 2) X(216, 2) X(224, 2)
+#define P7X_TILES_TIER4(X) X(120, 4) X(128, 4)
+#define P7X_TILES_TIER5(X) X(64, 8) X(72, 8) X(80, 8) X(88, 8) X(96, 8) X(104, 8) X(112, 8) X(120, 8) X(128, 8)
 constexpr int msv_tier_block_c(int T) { return T <= 2 ? 256 : 512; }
 constexpr int msv_tier_min_blocks_c(int T) { return T == 0 ? 4 : (T == 1 ? 3 : 2); }      // (waves per SIMD the register budget must allow)
 
@@ -513,43 +524,12 @@ __global__ void __launch_bounds__(msv_tier_block_c(TIER), msv_tier_min_blocks_c(
   const MsvArgs a = load_args<MsvArgs>(ref);
   const int R = __builtin_amdgcn_readfirstlane(a.R);
 #define P7X_TILE(r, k) case r: msv_fast_body<r, k, true>(a, lds); break;
-  if constexpr (TIER == 0) {
-    switch (R) {
-      P7X_TILE(8, 1) P7X_TILE(12, 1) P7X_TILE(16, 1) P7X_TILE(20, 1) P7X_TILE(24, 1) P7X_TILE(28, 1) P7X_TILE(32, 1) P7X_TILE(36, 1)
-      P7X_TILE(40, 1) P7X_TILE(44, 1) P7X_TILE(48, 1) P7X_TILE(52, 1) P7X_TILE(56, 1) P7X_TILE(60, 1) P7X_TILE(64, 1) P7X_TILE(68, 1)
-      P7X_TILE(72, 1) P7X_TILE(76, 1) P7X_TILE(80, 1) P7X_TILE(84, 1) P7X_TILE(88, 1) P7X_TILE(92, 1)
-      default: break;
-    }
-  } else if constexpr (TIER == 1) {
-    switch (R) {
-      P7X_TILE(96, 1) P7X_TILE(100, 1) P7X_TILE(104, 1) P7X_TILE(108, 1) P7X_TILE(112, 1) P7X_TILE(116, 1) P7X_TILE(120, 1)
-      P7X_TILE(124, 1) P7X_TILE(128, 1) P7X_TILE(132, 1) P7X_TILE(136, 1)
-      default: break;
-    }
-  } else if constexpr (TIER == 2) {
-    switch (R) {
-      P7X_TILE(140, 1) P7X_TILE(144, 1) P7X_TILE(148, 1) P7X_TILE(152, 1) P7X_TILE(156, 1) P7X_TILE(160, 1) P7X_TILE(176, 1)
-      P7X_TILE(192, 1) P7X_TILE(208, 1) P7X_TILE(224, 1)
-      default: break;
-    }
-  } else if constexpr (TIER == 3) {
-    switch (R) {
-      P7X_TILE(120, 2) P7X_TILE(128, 2) P7X_TILE(136, 2) P7X_TILE(144, 2) P7X_TILE(152, 2) P7X_TILE(160, 2) P7X_TILE(168, 2)
-      P7X_TILE(176, 2) P7X_TILE(184, 2) P7X_TILE(192, 2) P7X_TILE(200, 2) P7X_TILE(208, 2) P7X_TILE(216, 2) P7X_TILE(224, 2)
-      default: break;
-    }
-  } else if constexpr (TIER == 4) {
-    switch (R) {
-      P7X_TILE(120, 4) P7X_TILE(128, 4)
-      default: break;
-    }
-  } else {
-    switch (R) {
-      P7X_TILE(64, 8) P7X_TILE(72, 8) P7X_TILE(80, 8) P7X_TILE(88, 8) P7X_TILE(96, 8) P7X_TILE(104, 8) P7X_TILE(112, 8)
-      P7X_TILE(120, 8) P7X_TILE(128, 8)
-      default: break;
-    }
-  }
+  if constexpr (TIER == 0) { switch (R) { P7X_TILES_TIER0(P7X_TILE) default: break; } }
+  else if constexpr (TIER == 1) { switch (R) { P7X_TILES_TIER1(P7X_TILE) default: break; } }
+  else if constexpr (TIER == 2) { switch (R) { P7X_TILES_TIER2(P7X_TILE) default: break; } }
+  else if constexpr (TIER == 3) { switch (R) { P7X_TILES_TIER3(P7X_TILE) default: break; } }
+  else if constexpr (TIER == 4) { switch (R) { P7X_TILES_TIER4(P7X_TILE) default: break; } }
+  else { switch (R) { P7X_TILES_TIER5(P7X_TILE) default: break; } }        // (launch_tier refuses a tile that is not in its tier's list)
 #undef P7X_TILE
 }
 
@@ -557,11 +537,23 @@ __global__ void __launch_bounds__(msv_tier_block_c(TIER), msv_tier_min_blocks_c(
 
 // One lane per target up to 224 row registers (M <= 445); two lanes (M <= 893) and four lanes (M <= 1021) beyond, while
 // the parity tables of the K lanes (256 * K * Rs bytes) fit the CU's LDS.  Longer models: wave-per-target kernel.
-static const int kRList[] = { 8, 12, 16, 20, 24, 28, 32, 36, 40, 44, 48, 52, 56, 60, 64, 68, 72, 76, 80, 84, 88, 92, 96, 100, 104, 108,
-                              112, 116, 120, 124, 128, 132, 136, 140, 144, 148, 152, 156, 160, 176, 192, 208, 224 };
-static const int kRList2[] = { 120, 128, 136, 144, 152, 160, 168, 176, 184, 192, 200, 208, 216, 224 };
-static const int kRList4[] = { 120, 128 };
-static const int kRList8[] = { 64, 72, 80, 88, 96, 104, 112, 120, 128 };      // uniform rows: register j = cells (2j + 1, 2j + 2)
+#define P7X_R_ONLY(r, k) r,
+static const int kRList[] = { P7X_TILES_TIER0(P7X_R_ONLY) P7X_TILES_TIER1(P7X_R_ONLY) P7X_TILES_TIER2(P7X_R_ONLY) };
+static const int kRList2[] = { P7X_TILES_TIER3(P7X_R_ONLY) };
+static const int kRList4[] = { P7X_TILES_TIER4(P7X_R_ONLY) };
+static const int kRList8[] = { P7X_TILES_TIER5(P7X_R_ONLY) };      // uniform rows: register j = cells (2j + 1, 2j + 2)
+#undef P7X_R_ONLY
+static bool msv_tile_exists(int R, int K)
+{
+  auto in = [R](const int *b, const int *e) { for (; b != e; ++b) if (*b == R) return true; return false; };
+  switch (K) {
+    case 1: return in(std::begin(kRList), std::end(kRList));
+    case 2: return in(std::begin(kRList2), std::end(kRList2));
+    case 4: return in(std::begin(kRList4), std::end(kRList4));
+    case 8: return in(std::begin(kRList8), std::end(kRList8));
+    default: return false;
+  }
+}
 
 int msv_pick(int M, int *K)
 {
@@ -705,7 +697,7 @@ static int launch_tier(const ArgRun<MsvArgs> &main, int num_cu, hipStream_t st)
   constexpr int wpb = BLK / 64;
   for (int i = 0; i < main.n; ++i) {
     const MsvArgs &a = main.at(i);
-    if (msv_tier(a.R, K) != TIER) { set_error("msv_tier_launch: a lane of another tier"); return P7X_EINVAL; }
+    if (msv_tier(a.R, K) != TIER || !msv_tile_exists(a.R, K)) { set_error("msv_tier_launch: a lane of another tier, or a register tile without a kernel"); return P7X_EINVAL; }
     Rmax = std::max(Rmax, a.R);
     want = std::max<long>(want, ((long) (a.ngroups - a.group_first) * K + wpb - 1) / wpb);
   }
@@ -757,22 +749,8 @@ static int msv_launch_impl(int R, int K, const ArgRun<MsvArgs> &main, const ArgR
 {
   if (main.n <= 0) return P7X_OK;
   switch (K * 1000 + R) {
-#define P7X_CASE(r) case 1000 + r: return launch_RK<r, 1>(main, amb, num_cu, st, amb_only);
-    P7X_CASE(8) P7X_CASE(12) P7X_CASE(16) P7X_CASE(20) P7X_CASE(24) P7X_CASE(28) P7X_CASE(32) P7X_CASE(36) P7X_CASE(40)
-    P7X_CASE(44) P7X_CASE(48) P7X_CASE(52) P7X_CASE(56) P7X_CASE(60) P7X_CASE(64) P7X_CASE(68) P7X_CASE(72) P7X_CASE(76)
-    P7X_CASE(80) P7X_CASE(84) P7X_CASE(88) P7X_CASE(92) P7X_CASE(96) P7X_CASE(100) P7X_CASE(104) P7X_CASE(108) P7X_CASE(112)
-    P7X_CASE(116) P7X_CASE(120) P7X_CASE(124) P7X_CASE(128) P7X_CASE(132) P7X_CASE(136) P7X_CASE(140) P7X_CASE(144)
-    P7X_CASE(148) P7X_CASE(152) P7X_CASE(156) P7X_CASE(160) P7X_CASE(176) P7X_CASE(192) P7X_CASE(208) P7X_CASE(224)
-#undef P7X_CASE
-#define P7X_CASE(r) case 2000 + r: return launch_RK<r, 2>(main, amb, num_cu, st, amb_only);
-    P7X_CASE(120) P7X_CASE(128) P7X_CASE(136) P7X_CASE(144) P7X_CASE(152) P7X_CASE(160) P7X_CASE(168) P7X_CASE(176)
-    P7X_CASE(184) P7X_CASE(192) P7X_CASE(200) P7X_CASE(208) P7X_CASE(216) P7X_CASE(224)
-#undef P7X_CASE
-#define P7X_CASE(r) case 4000 + r: return launch_RK<r, 4>(main, amb, num_cu, st, amb_only);
-    P7X_CASE(120) P7X_CASE(128)
-#undef P7X_CASE
-#define P7X_CASE(r) case 8000 + r: return launch_RK<r, 8>(main, amb, num_cu, st, amb_only);
-    P7X_CASE(64) P7X_CASE(72) P7X_CASE(80) P7X_CASE(88) P7X_CASE(96) P7X_CASE(104) P7X_CASE(112) P7X_CASE(120) P7X_CASE(128)
+#define P7X_CASE(r, k) case k * 1000 + r: return launch_RK<r, k>(main, amb, num_cu, st, amb_only);
+    P7X_TILES_TIER0(P7X_CASE) P7X_TILES_TIER1(P7X_CASE) P7X_TILES_TIER2(P7X_CASE) P7X_TILES_TIER3(P7X_CASE) P7X_TILES_TIER4(P7X_CASE) P7X_TILES_TIER5(P7X_CASE)
 #undef P7X_CASE
     default: set_error("msv_launch: unsupported register tile"); return P7X_EINVAL;
   }

@@ -608,7 +608,15 @@ class HMMFile:
             elif hasattr(file, "seek") and hasattr(file, "tell"):
                 at = file.tell(); head = file.read(4); file.seek(at)
             if isinstance(head, (bytes, bytearray)) and len(head) == 4:
-                self._binary = int.from_bytes(head, sys.byteorder) == self._MAGIC_3F
+                magic = int.from_bytes(head, sys.byteorder)
+                self._binary = magic == self._MAGIC_3F
+                if magic in self._MAGIC_OLD:
+                    raise ValueError(f"{self.name!r}: binary HMM file of an older format (HMMER 3/a-3/e); only 3/f is read")
+            if not self._binary and (isinstance(head, (bytes, bytearray)) or isinstance(getattr(file, "read", lambda n: "")(0), (bytes, bytearray))):
+                # a text-format HMM behind a BINARY handle (open(p, "rb"), BytesIO: what the reference's HMMFile takes): the
+                # text parser reads str lines
+                import io
+                self._fh = io.TextIOWrapper(file, encoding="ascii", errors="replace", newline=None)
         self._alphabet = alphabet
 
     def _read_binary(self) -> Optional[HMM]:
@@ -804,7 +812,7 @@ class HMMFile:
         if "NSEQ" in hdr:
             hmm.nseq = int(hdr["NSEQ"])
         if "EFFN" in hdr:
-            hmm.nseq_effective = float(hdr["EFFN"])
+            hmm.nseq_effective = float(np.float32(hdr["EFFN"]))      # upstream holds a float: the text and the binary form of a model then agree
         if "CKSUM" in hdr:
             hmm.checksum = int(hdr["CKSUM"])
         hmm.command_line = hdr.get("COM")

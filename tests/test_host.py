@@ -508,7 +508,15 @@ def test_binary_hmm_files_read_like_their_text_twins(libp7x, name, tmp_path):
         assert np.array_equal(b._evparam, t._evparam) and np.array_equal(b._cutoffs, t._cutoffs)
         assert (b.composition is None) == (t.composition is None) and (b.composition is None or np.array_equal(b.composition, t.composition))
         assert (b.map is None) == (t.map is None) and (b.map is None or np.array_equal(b.map, t.map))
-        assert b.nseq_effective == pytest.approx(t.nseq_effective, abs=1e-5)
+        assert b.nseq_effective == t.nseq_effective          # both hold upstream's float: text and binary forms compare equal
+        assert b == t
+    # a text-format file behind a BINARY handle (what the reference's HMMFile takes), an older magic behind a handle
+    text_path = GOLDEN / "hmms" / f"{name}.hmm"
+    with open(text_path, "rb") as fh:
+        assert [h.name for h in plan7.HMMFile(fh)] == [h.name for h in text]
+    assert [h.name for h in plan7.HMMFile(io.BytesIO(text_path.read_bytes()))] == [h.name for h in text]
+    with pytest.raises(ValueError, match="older format"):
+        plan7.HMMFile(io.BytesIO((0xe8ededb8).to_bytes(4, sys.byteorder) + b"\0" * 64))
     # a file object, rewinding, a truncated file, an older binary version
     raw = (GOLDEN / "hmms" / f"{name}.h3m").read_bytes()
     with plan7.HMMFile(io.BytesIO(raw)) as f:
