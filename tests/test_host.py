@@ -314,7 +314,8 @@ def test_query_pipeline_orders_results_and_errors_for_every_shape(libp7x, monkey
     from pyhmmer_amd import hmmer
     before = threading.active_count()
     shapes = [(0, 1, 1, 0), (1, 1, 1, 0), (2, 1, 1, 0), (4, 2, 1, 0), (8, 4, 1, 0), (8, 1, 8, 0), (32, 2, 8, 0), (5, 3, 2, 0),
-              (2, 2, 8, 4), (64, 4, 4, 8), (3, 8, 64, 2), (4, 2, 1, 4)]      # the last one: the shape bench.py runs the headline with
+              (2, 2, 8, 4), (64, 4, 4, 8), (3, 8, 64, 2), (4, 2, 1, 4),      # ... the shape bench.py ran the headline with until round 5
+              (8, 0, 1, 0)]                                                   # feeders = 0: the first batch decides (hmmsearch's default)
     for seed, (depth, feeders, window, fin) in enumerate(shapes):
         batch = (1, 3, 8)[seed % 3]             # queries per device batch
         for n in (0, 1, 7, 40):
@@ -344,6 +345,27 @@ def test_query_pipeline_orders_results_and_errors_for_every_shape(libp7x, monkey
     while threading.active_count() > before and __import__("time").time() < deadline:
         __import__("time").sleep(0.05)
     assert threading.active_count() <= before
+
+
+def test_the_first_batch_decides_the_feeders(libp7x):
+    """hmmsearch(feeders=0), the default: batches of several different profiles run with three cascades in flight, batches of
+    one profile (a single query, a stream of the same one) with two (hmmer._run_batches; measured: profiles/r06_feeders.txt)."""
+    from pyhmmer_amd import hmmer
+
+    class Q:
+        def __init__(self, M):
+            self.M = M
+
+    def feeders_of(queries, batch):
+        out = list(hmmer._run_queries(_FakeShards(1), [None], iter(queries), 8, 0, 1, 0, batch=batch))
+        assert len(out) == len(queries)
+        return hmmer.pipeline_stats()["feeders"]
+
+    same = Q(262)
+    assert feeders_of([same] * 40, 7) == 2                       # the one-profile stream of configs[1]
+    assert feeders_of([Q(100 + i) for i in range(40)], 8) == 3   # a profile library
+    assert feeders_of([Q(300)], 4) == 2                          # a single query
+    assert feeders_of([], 4) == 2
 
 
 def test_automatic_batches_follow_the_cell_budget():
