@@ -89,7 +89,9 @@ struct DevProfile {
   int msvR = 0, msvK = 0, msvS = 0;     // lane kernels: row registers per lane, lanes per target, dwords per table row
   uint32_t *msv_tab = nullptr;
   int16_t *msvw_emis = nullptr;     // wave-per-target MSV, [kTabRows][Mpad] bias - cost
-  uint32_t *msvw_pk = nullptr;      // models without a lane kernel (M > 1021): the same as packed pairs, [kTabRows][C/4][64][2]
+  uint32_t *msvw_pk = nullptr;      // models beyond the four-lane tiles (M > 1021): the same as packed pairs, [msvw_rows][msvwC/4][64][2]
+  int msvwC = 0, msvw_rows = kTabRows;      // nodes per lane / residue rows of the wave-per-target MSV kernels' tables: vitC and kTabRows, except for
+                                            // 2,048 < M <= 2,560, whose packed table fits the LDS with 36 / 40 nodes per lane and Kp + 1 rows
   // Viterbi: transitions [Mpad][8] int16 (BM,MM,IM,DM,MD,MI,II,DD), emissions [kTabRows][Mpad] int16
   int vitC = 0, Mpad = 0;
   int16_t *vit_trans = nullptr;

@@ -175,16 +175,24 @@ static void build_host_image(const Profile &p, DevProfile *d, HostImage &img)
       for (int k = 1; k <= p.M; ++k)
         for (int x = 0; x < p.Kp; ++x) me[(size_t) x * Mpad + pos[k]] = (int16_t) ((int) p.bias_b - (int) p.rb[(size_t) x * (p.M + 1) + k]);
       img.add(&d->msvw_emis, me);
-      if ((d->msvR <= 0 || d->msvK >= 8) && C % 4 == 0 && C <= 32) {     // M > 1021 (no lane kernel, or the eight-lane one: small blocks and the longest
-                                                                        // targets of large ones still go one per wavefront): packed pairs for msv_wavepk_kernel, lane z owns nodes zC+1 .. zC+C
-        const int P2 = C / 4;
-        std::vector<uint32_t> pk((size_t) kTabRows * P2 * 64 * 2);
+      d->msvwC = C; d->msvw_rows = kTabRows;
+      // packed pairs for msv_wavepk_kernel (lane z owns nodes z Cp + 1 .. z Cp + Cp): M > 1021 (no lane kernel, or the eight-lane
+      // one: small blocks and the longest targets of large ones still go one per wavefront).  Beyond 2,048 nodes the wavefront
+      // kernels' own C (48) would put the table past the LDS; with 36 / 40 nodes per lane and only the rows a target can hold
+      // (Kp + 1) it fits up to 2,560 nodes -- these models ran msv_wave_kernel with its table read through L2 until round 6
+      // (0.5 TCUPS against ~15).
+      int Cp = 0;
+      if ((d->msvR <= 0 || d->msvK >= 8) && C % 4 == 0 && C <= 32) Cp = C;
+      else if (d->msvR <= 0 && C > 32 && p.M <= 2560 && p.Kp + 1 <= 30) { Cp = p.M <= 2304 ? 36 : 40; d->msvwC = Cp; d->msvw_rows = p.Kp + 1; }
+      if (Cp > 0) {
+        const int P2 = Cp / 4, rows = d->msvw_rows;
+        std::vector<uint32_t> pk((size_t) rows * P2 * 64 * 2);
         auto em = [&](int x, int k) -> uint32_t { return (uint32_t) (uint16_t) (int16_t) ((x < p.Kp && k <= p.M) ? (int) p.bias_b - (int) p.rb[(size_t) x * (p.M + 1) + k] : kNegPad); };
-        for (int x = 0; x < kTabRows; ++x)
+        for (int x = 0; x < rows; ++x)
           for (int j2 = 0; j2 < P2; ++j2)
             for (int z = 0; z < 64; ++z)
               for (int h = 0; h < 2; ++h) {
-                const int k = z * C + 2 * (2 * j2 + h) + 1;
+                const int k = z * Cp + 2 * (2 * j2 + h) + 1;
                 pk[(((size_t) x * P2 + j2) * 64 + z) * 2 + h] = em(x, k) | (em(x, k + 1) << 16);
               }
         img.add(&d->msvw_pk, pk);

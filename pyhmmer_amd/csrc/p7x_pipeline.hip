@@ -773,7 +773,7 @@ static void fill_msv_args(LaneArgs &la, const Profile &p, const DevProfile *dp, 
                           int nlong = 0)
 {
   MsvWaveArgs w{};
-  w.C = dp->vitC; w.nrows = kTabRows; w.emis = dp->msvw_emis; w.emis_pk = dp->msvw_pk; w.dsq = db->d_dsq; w.slot_off = db->d_slot_off; w.slot_len = db->d_slot_len;
+  w.C = dp->msvwC; w.nrows = dp->msvw_rows; w.emis = dp->msvw_emis; w.emis_pk = dp->msvw_pk; w.dsq = db->d_dsq; w.slot_off = db->d_slot_off; w.slot_len = db->d_slot_len;
   w.tjb_tab = ctx->lt.tjb; w.nslots = (int) db->nslots; w.base = p.base_b; w.bias = p.bias_b; w.tec = p.tec_b; w.tbm = p.tbm_b;
   w.out_xJ = b.xJ;
   if (nlong > 0) w.nslots = (int) std::min<int64_t>((int64_t) nlong * 64, db->nslots);   // only the long groups (with the lane kernel)
@@ -834,7 +834,7 @@ struct LaneClass { int first = 0, n = 0; long msv_key = 0, vit_key = 0; int C = 
 
 static long msv_key_of(const DevProfile *dp, bool small)
 { // M > 478, or too few targets for one per lane: wave-per-target kernel (key < 0), else the register tile
-  return (dp->msvR <= 0 || small) ? -(long) dp->vitC : (long) (dp->msvK * 1000 + dp->msvR);
+  return (dp->msvR <= 0 || small) ? -(long) dp->msvwC : (long) (dp->msvK * 1000 + dp->msvR);
 }
 static long vit_key_of(const DevProfile *dp, bool small)
 {

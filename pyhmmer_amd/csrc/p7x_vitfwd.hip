@@ -765,6 +765,8 @@ int msv_wave_launch(const ArgRun<MsvWaveArgs> &a, int num_cu, hipStream_t st)
       case 20: return gopk(msv_wavepk_kernel<20>);
       case 24: return gopk(msv_wavepk_kernel<24>);
       case 32: return gopk(msv_wavepk_kernel<32>);
+      case 36: return gopk(msv_wavepk_kernel<36>);      // 2,048 < M <= 2,304 (the other wavefront kernels of such a model: C = 48)
+      case 40: return gopk(msv_wavepk_kernel<40>);      // ... <= 2,560
       default: break;
     }
   }

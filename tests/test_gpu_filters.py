@@ -260,7 +260,7 @@ _PK_M = sorted({16 * p - d for p in (2, 4, 6, 8, 10, 12, 14, 15, 16, 17, 18, 19,
 
 @pytest.mark.parametrize("M", sorted(set([1, 3, 64, 65, 128, 150, 192, 256, 300, 320, 384, 479, 500, 512, 640, 641, 700, 768, 1000, 1024, 1025,
                                           1280, 1500, 1536, 2000, 2048,
-                                          2049, 3000, 3072, 4096, 4097, 5000, 6144, 8192] + _PK_M)))   # M > 2048: rolled loops, tables through L2
+                                          2049, 2304, 2305, 2560, 2561, 3000, 3072, 4096, 4097, 5000, 6144, 8192] + _PK_M)))   # M > 2048: rolled loops, tables through L2
 def test_every_wavefront_kernel_instantiation_vs_oracle(M, oracle):
     hmm = random_hmm(M, seed=2000 + M)
     bg = plan7.Background(hmm.alphabet)
@@ -276,7 +276,7 @@ def test_every_wavefront_kernel_instantiation_vs_oracle(M, oracle):
     assert np.all(np.abs(got["fwd"][ok] - want["fwd"][ok]) < FWD_TOL_NATS + 1e-5 * np.abs(want["fwd"][ok]))
 
 
-@pytest.mark.parametrize("M", [1022, 1281, 1537, 2047])
+@pytest.mark.parametrize("M", [1022, 1281, 1537, 2047, 2100, 2500])      # (beyond 2,048: 36 / 40 nodes per lane, Kp + 1 table rows)
 def test_packed_wave_msv_for_long_models_on_a_ragged_block(M, oracle):
     """Models beyond the lane kernels (M > 1021) run msv_wavepk_kernel: packed pairs, sixteen wavefronts per block, eight
     rows per reduction with the begin score held and the block repeated row by row where a hit moved it.  1,500 random
