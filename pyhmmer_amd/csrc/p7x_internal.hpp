@@ -75,7 +75,7 @@ void set_error(const std::string &msg);
 // Test / diagnostic seam (p7x_debug_set_option, include/p7x.h): process-wide knobs that pick a kernel family for a parity test, bound
 // a workspace, or switch a trace on.  -1 = not set (the library decides).  The library reads no environment variables.
 enum { OPT_SMALL_BLOCK = 0, OPT_VIT_WAVE, OPT_MSV_EXACT, OPT_MSV_LONG_GROUPS, OPT_MSV_BLOCKS_PER_CU, OPT_ENV_WORKSPACE_GB, OPT_DEVICE_CLUSTERED,
-       OPT_TRACE_FINISH, OPT_TRACE_LONGTARGET, OPT_TRACE_ENVELOPE, OPT_HOST_PROFILE, OPT_SSV_KERNEL, OPT_MSV_F16, OPT_ENS_LDS_KB, OPT_ENS_FAIL, OPT_MSV_TIERS, OPT_STAGE_MERGE, OPT_EARLY_PACK, OPT_HOST_ORDER, OPT_VIT_LONG_CUT, OPT_FWD_GROUPED, OPT_REGION_GUARD_PPM, OPT_MSV_K8, OPT_COUNT };
+       OPT_TRACE_FINISH, OPT_TRACE_LONGTARGET, OPT_TRACE_ENVELOPE, OPT_HOST_PROFILE, OPT_SSV_KERNEL, OPT_MSV_F16, OPT_ENS_LDS_KB, OPT_ENS_FAIL, OPT_MSV_TIERS, OPT_STAGE_MERGE, OPT_EARLY_PACK, OPT_HOST_ORDER, OPT_VIT_LONG_CUT, OPT_FWD_GROUPED, OPT_REGION_GUARD_PPM, OPT_MSV_K8, OPT_MSV_LANE_BLOCKS, OPT_COUNT };
 int debug_opt(int which);
 
 }

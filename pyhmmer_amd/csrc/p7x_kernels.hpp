@@ -38,6 +38,20 @@ inline unsigned lane_grid(long want, long resident, int nlanes)
   return (unsigned) (want < 1 ? 1 : want);
 }
 
+// ... for a kernel whose wavefronts PULL their work items (the lane-per-target MSV kernels: an atomic counter per lane, longest
+// groups first): with many lanes in a launch -- a scan's thousands of profiles against a few dozen 64-target groups -- a lane
+// gets only as many blocks as it takes to keep the device twice subscribed, down to ONE: its wavefronts then balance the items
+// among themselves (the longest group beside the sum of the short ones), where nine blocks of four wavefronts for 33 items give
+// every wavefront one item and hold a CU for the longest of them (round 6: profiles/r06_scan_lane_blocks.txt).
+inline unsigned lane_grid_pull(long want, long resident, int nlanes, bool old_rule)
+{
+  if (old_rule || nlanes < 32) return lane_grid(want, resident, nlanes);      // a few lanes with thousands of groups each (a search): as many blocks as are resident
+  long b = (2 * resident + nlanes - 1) / nlanes;
+  if (b > resident) b = resident;
+  if (b > want) b = want;
+  return (unsigned) (b < 1 ? 1 : b);
+}
+
 // ---- MSV (p7x_msv.hip)
 struct MsvArgs {
   const uint32_t *tab;      // [2][kTabRows][S] dwords: parity 0 = "odd" alignment, parity 1 = "even"; K = 8: [kTabRows][S], one alignment

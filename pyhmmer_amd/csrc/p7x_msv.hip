@@ -654,7 +654,7 @@ static int launch_RK(const ArgRun<MsvArgs> &main, const ArgRun<MsvArgs> *amb, in
   long want = 1;
   for (int i = 0; i < main.n; ++i) want = std::max<long>(want, ((long) (main.at(i).ngroups - main.at(i).group_first) * K + wpb - 1) / wpb);
   if (amb == nullptr) {           // exact kernel over every group
-    const unsigned gx = lane_grid(want, (long) num_cu * info.per_cu_exact, main.n);
+    const unsigned gx = lane_grid_pull(want, (long) num_cu * info.per_cu_exact, main.n, debug_opt(OPT_MSV_LANE_BLOCKS) == 0);
     hipLaunchKernelGGL((msv_kernel<R, K>), dim3(gx, (unsigned) main.n), dim3(BLK), lds_bytes, st, main.ref());
     P7X_HIP(hipGetLastError());
     return P7X_OK;
@@ -665,7 +665,7 @@ static int launch_RK(const ArgRun<MsvArgs> &main, const ArgRun<MsvArgs> *amb, in
   // A/B switch: cap the resident blocks per CU so that other kernels' wavefronts fit beside the MSV row registers
   const int cap = debug_opt(OPT_MSV_BLOCKS_PER_CU);
   if (cap > 0 && per_cu2 > cap) per_cu2 = cap;
-  const unsigned gx2 = lane_grid(want, (long) num_cu * per_cu2, main.n);
+  const unsigned gx2 = lane_grid_pull(want, (long) num_cu * per_cu2, main.n, debug_opt(OPT_MSV_LANE_BLOCKS) == 0);
   if (half) hipLaunchKernelGGL((msv_fast_kernel<R, K, true>), dim3(gx2, (unsigned) main.n), dim3(BLK), lds_bytes, st, main.ref());
   else hipLaunchKernelGGL((msv_fast_kernel<R, K, false>), dim3(gx2, (unsigned) main.n), dim3(BLK), lds_bytes, st, main.ref());
   P7X_HIP(hipGetLastError());
@@ -725,7 +725,7 @@ static int launch_tier(const ArgRun<MsvArgs> &main, int num_cu, hipStream_t st)
     }
     per_cu = it->second;
   }
-  const unsigned gx = lane_grid(want, (long) num_cu * per_cu, main.n);
+  const unsigned gx = lane_grid_pull(want, (long) num_cu * per_cu, main.n, debug_opt(OPT_MSV_LANE_BLOCKS) == 0);
   hipLaunchKernelGGL((msv_tier_kernel<TIER>), dim3(gx, (unsigned) main.n), dim3(BLK), lds_bytes, st, main.ref());
   P7X_HIP(hipGetLastError());
   return P7X_OK;

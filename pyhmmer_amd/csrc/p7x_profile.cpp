@@ -272,7 +272,7 @@ int p7x_abi_version(void) { return P7X_ABI_VERSION; }
 int p7x_debug_set_option(const char *name, int value)
 {
   static const char *const names[p7x::OPT_COUNT] = { "small_block", "vit_wave", "msv_exact", "msv_long_groups", "msv_blocks_per_cu", "env_workspace_gb",
-                                                     "device_clustered", "trace_finish", "trace_longtarget", "trace_envelope", "host_profile", "ssv_kernel", "msv_f16", "ens_lds_kb", "ens_fail", "msv_tiers", "stage_merge", "early_pack", "host_order", "vit_long_cut", "fwd_grouped", "region_guard_ppm", "msv_k8" };
+                                                     "device_clustered", "trace_finish", "trace_longtarget", "trace_envelope", "host_profile", "ssv_kernel", "msv_f16", "ens_lds_kb", "ens_fail", "msv_tiers", "stage_merge", "early_pack", "host_order", "vit_long_cut", "fwd_grouped", "region_guard_ppm", "msv_k8", "msv_lane_blocks" };
   if (!name) { p7x::set_error("p7x_debug_set_option: no name"); return P7X_EINVAL; }
   for (int i = 0; i < p7x::OPT_COUNT; ++i)
     if (std::strcmp(name, names[i]) == 0) { p7x::g_debug_opt[i].store(value); return P7X_OK; }
