@@ -593,7 +593,7 @@ def run_nhmmer(args, rank, world, local_rank, dist, red_dev, torch):
     t0 = time.perf_counter()
     scan_ms = 0.0
     # a stream of queries through the public entry point (the reference's own benchmark is 100 genes against one genome,
-    # BASELINE.md 1): hmmer.nhmmer keeps two searches in flight, the scan of one under the host tail of the other
+    # BASELINE.md 1): hmmer.nhmmer keeps several searches in flight (its default), the scan of one under the tails of the others
     for hits in hmmer.nhmmer([hmm] * n, block, devices=[local_rank], host_envelopes=args.nhmmer_envelopes):
         scan_ms += hits.timings_ms["msv_kernel"]
     if dist is not None:
@@ -667,7 +667,7 @@ def main():
     ap.add_argument("--config1-steps", type=int, default=4, help="steps of the configs[1] FIELD when it is not the line (32 queries each)")
     ap.add_argument("--scan-targets", type=int, default=4000, help="query proteins of the scan workload's synthetic block (BASELINE: 4k)")
     ap.add_argument("--nhmmer-mbp", type=float, default=250.0, help="chromosome length per GPU")
-    ap.add_argument("--nhmmer-searches", type=int, default=10, help="queries of the timed stream (hmmer.nhmmer)")
+    ap.add_argument("--nhmmer-searches", type=int, default=24, help="queries of the timed stream (hmmer.nhmmer; the reference's own benchmark is 100 genes against one genome)")
     ap.add_argument("--nhmmer-envelopes", type=int, default=0, help="A/B: 0 the library decides where envelopes are rescored, 1 host workers, 2 envelope kernel")
     ap.add_argument("--pfam-profiles", type=int, default=20000, help="library entries searched (the first ones of the 20k-entry library; default: all)")
     ap.add_argument("--pfam-cpu-profiles", type=int, default=40, help="cpu_baseline of the many-profile workloads: this many profiles, evenly spaced")

@@ -882,7 +882,7 @@ def _query_blocks(queries, max_sequences: int, max_residues: int):
 
 
 def nhmmer(queries, sequences, *, cpus: int = 0, callback: Optional[Callable] = None, devices: Optional[Sequence[int]] = None,
-           backend: Optional[str] = None, builder=None, timeout: Optional[float] = None, searches_in_flight: int = 4,
+           backend: Optional[str] = None, builder=None, timeout: Optional[float] = None, searches_in_flight: int = 8,
            **options) -> Iterator[TopHits]:
     """Search nucleotide HMMs against long nucleotide targets; yields one ``TopHits`` per query, in query order
     (reference ``hmmer/_nhmmer.py:24-56``: one ``LongTargetsPipeline.search_hmm`` per query, the queries spread over
@@ -895,7 +895,9 @@ def nhmmer(queries, sequences, *, cpus: int = 0, callback: Optional[Callable] = 
     themselves take turns at the device); results are handed back in query order.  1 runs the queries one after the other.
     Measured on the 250 Mbp benchmark (round 5, after the window stages stopped calling hipMalloc / hipFree, which wait for
     the whole device): 0.140 s per search alone, 0.088-0.095 with two in flight, 0.078-0.084 with three, 0.074 with four
-    (the default) and no less with six.
+    and no less with six.  Round 6 (the host tail sums in upstream's order and is longer; the scan on binary16 cells): 0.092 /
+    0.065 / 0.059 / 0.057 s per search with 2 / 4 / 6 / 8 in flight over a stream of twelve (`scripts/nh_inflight.py`): the
+    default is eight.
 
     ``queries``: ``HMM`` / ``Profile`` / ``OptimizedProfile`` objects (one or an iterable).  Sequence and alignment
     queries of the reference go through the HMM builder first, which is outside this path: build the HMM and pass it.
