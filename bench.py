@@ -664,7 +664,7 @@ def main():
     for f in ("F1", "F2", "F3"):
         ap.add_argument(f"--{f}", type=float, default=None, help="diagnostics (pfam workload): filter threshold, e.g. --F1 1e-12 = the MSV stage alone")
     ap.add_argument("--pfam-profiles-per-step", type=int, default=1000, help="library profiles of one step of the pfam workload")
-    ap.add_argument("--config1-steps", type=int, default=4, help="steps of the configs[1] FIELD when it is not the line (32 queries each)")
+    ap.add_argument("--config1-steps", type=int, default=12, help="steps of the configs[1] FIELD when it is not the line (32 queries each; round 6: 12 -- over 4 steps the last batches' host stage is a fifth of the region)")
     ap.add_argument("--scan-targets", type=int, default=4000, help="query proteins of the scan workload's synthetic block (BASELINE: 4k)")
     ap.add_argument("--nhmmer-mbp", type=float, default=250.0, help="chromosome length per GPU")
     ap.add_argument("--nhmmer-searches", type=int, default=24, help="queries of the timed stream (hmmer.nhmmer; the reference's own benchmark is 100 genes against one genome)")
