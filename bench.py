@@ -497,8 +497,13 @@ def run_pfam(args, rank, world, local_rank, dist, red_dev, torch, host_threads, 
     del db
     if world == 1 and not args.no_cpu_baseline:
         step = max(1, len(hmms) // max(1, args.pfam_cpu_profiles))
-        out["cpu_baseline"] = cpu_baseline_many(hmms, bg, flat, offsets, lengths, list(range(0, len(hmms), step))[:args.pfam_cpu_profiles],
-                                                min(args.pfam_cpu_targets, len(lengths)))
+        sample = list(range(0, len(hmms), step))[:args.pfam_cpu_profiles]
+        nt = min(args.pfam_cpu_targets, len(lengths))
+        out["cpu_baseline"] = cpu_baseline_many(hmms, bg, flat, offsets, lengths, sample, nt)
+        # the same sample through the device path (outside every timed region): the two legs' hit counts side by side
+        sdb = plan7.SequenceDatabase.from_packed(hmms[0].alphabet, flat, offsets[:nt], lengths[:nt], device=local_rank)
+        out["cpu_baseline"]["gpu_hits_same_sample"] = sum(len(h) for h in hmmer.hmmsearch([oms[e] for e in sample], sdb, cpus=host_threads))
+        del sdb
     return out
 
 
