@@ -342,6 +342,10 @@ def _search_file(queries: Iterable, file: SequenceFile, chunk_bytes: int, devs: 
 
 
 _BATCH_CELLS = float(os.environ.get("P7X_BATCH_CELLS", 6e11))        # (profile, target) cells per device batch when the caller leaves the batch size open: ~25 ms of MSV (the variable: sweeps)
+_BATCH_CELLS_MAX = 4 * _BATCH_CELLS
+_BATCH_MIN = int(os.environ.get("P7X_BATCH_MIN", 64))     # a library search (>= 1,000 queries) against a large block: at least this many profiles per batch
+                         # while the batch stays within _BATCH_CELLS_MAX: 20-profile batches of the line's workload leave ~3 % on the
+                         # table (profiles/r06_feeders.txt: 25.6 TCUPS at one budget, 25.9 at two, 26.35 at four)
 _BATCH_MAX = 256         # queries per batch against a large block (the cell budget usually cuts far below this)
 _BATCH_LIMIT = 4096      # p7x_search_batch_enqueue takes at most this many profiles
 _BATCH_SLOTS = 1 << 23   # (profile, target) score slots of one batch's workspace (~30 bytes each)
@@ -415,12 +419,16 @@ def _run_queries(db: "ShardedDatabase", pipelines: Sequence[Pipeline], queries: 
     if auto:
         batch = cap                       # upper bound; the cut below follows the cell budget
     span = batch * max(1, reorder) if batch > 1 else 1
+    hint = 0
     if auto:
         # a query source of unknown length (a generator, a file being parsed) is read a shorter way ahead: the first
         # result of a span waits for the whole span to be read
         import operator
         hint = operator.length_hint(queries)
         span = min(max(hint, 8 * _BATCH_MAX), 1 << 16) if hint > 0 else 2 * _BATCH_MAX      # a sized source is sorted as a whole (up to 65,536)
+    # a LIBRARY of queries (a sized source of a thousand or more): a batch holds at least _BATCH_MIN profiles while that stays within
+    # four cell budgets -- see _BATCH_MIN
+    nmin = _BATCH_MIN if (auto and not by_batch and hint >= 1000) else 0
     order: list = []                      # input index of every query handed to the device, in hand-over order
     batch_members: list = []              # ... batch by batch (batch number -> input indices)
     inputs: dict = {}                     # the queries that have not been yielded yet, by input index
@@ -452,7 +460,7 @@ def _run_queries(db: "ShardedDatabase", pipelines: Sequence[Pipeline], queries: 
                     hi, cells = lo, 0.0
                     while hi < len(idx) and hi - lo < cap:
                         cells += float(res) * max(1, lens[idx[hi]] or 150)
-                        if hi > lo and cells > _BATCH_CELLS:
+                        if hi > lo and cells > _BATCH_CELLS and (hi - lo >= nmin or cells > _BATCH_CELLS_MAX):
                             break
                         hi += 1
                 else:
