@@ -434,6 +434,12 @@ def test_config3_profile_library_against_a_proteome(proteome, request):
     # search orientation over the whole library, batched: stage counts per profile
     batched = list(hmmer.hmmsearch(block, db, batch=256, pipeline_depth=4, feeders=2))
     assert len(batched) == n
+    # ... and with the library's own choices (round 6: the first batch decides the feeders -- three here --, a sized source of
+    # 1,000 queries or more fills its batches to 64 profiles): the same results, query by query
+    default = list(hmmer.hmmsearch(block, db))
+    assert hmmer.pipeline_stats()["feeders"] == 3
+    assert [h.stage_counts for h in default] == [h.stage_counts for h in batched]
+    assert all(_hit_fields(a) == _hit_fields(b) for a, b in zip(default, batched))
     sample = sorted(set(list(range(0, n, 997)) + [int(np.argmax(lengths)), int(np.argmin(lengths))]))
     pli = plan7.Pipeline(proteome.alphabet)
     for e in sample:
